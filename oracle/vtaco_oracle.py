@@ -1,0 +1,370 @@
+"""CPU oracle for the VTacO occupancy hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``vtaco_amd/`` may import this file;
+it is the checker used by ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py``.
+
+It restates, as plain functions over a ``state_dict`` (same key names as the
+reference checkpoint), the arithmetic of the reference's
+hot path.  All maths is float32 on the CPU (torch CPU tensors), every function
+cites the reference file:line it follows.
+
+Pinning: ``tests/test_oracle_golden.py`` checks every function here against
+golden vectors produced by importing the *real* reference in the build
+container (``tests/golden/make_goldens.py``).  Marching cubes lives in
+``oracle/mc_lewiner.c`` and is pinned against scikit-image 0.18.3 outputs.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------
+# coordinate helpers
+# --------------------------------------------------------------------------
+
+
+def make_3d_grid(bb_min, bb_max, shape):
+    """Query lattice, axis 0 slowest / axis 2 fastest (src/common.py:178-197)."""
+    ax = [torch.linspace(bb_min[k], bb_max[k], shape[k]) for k in range(3)]
+    gx, gy, gz = torch.meshgrid(ax[0], ax[1], ax[2], indexing="ij")
+    return torch.stack([gx.reshape(-1), gy.reshape(-1), gz.reshape(-1)], dim=1)
+
+
+def normalize_3d_coordinate(p, padding=0.1):
+    """[-0.55,0.55] -> [0,1) with clamps (src/common.py:293-309).
+
+    Divisor is 1 + padding + 10e-4 (=1.101); values >= 1 become 1 - 10e-4,
+    values < 0 become 0.  (The reference mutates a clone in place; this is the
+    functional form.)
+    """
+    q = p / (1 + padding + 10e-4) + 0.5
+    q = torch.where(q >= 1, torch.full_like(q, 1 - 10e-4), q)
+    q = torch.where(q < 0, torch.zeros_like(q), q)
+    return q
+
+
+def coordinate2index_3d(x, reso):
+    """Voxel id = ix + R*(iy + R*iz), truncating cast (src/common.py:333-348)."""
+    xi = (x * reso).long()
+    return xi[..., 0] + reso * (xi[..., 1] + reso * xi[..., 2])
+
+
+def voxel_index(p, reso, padding=0.1):
+    """K1: points -> voxel ids (src/encoder/pointnet.py:151-152)."""
+    return coordinate2index_3d(normalize_3d_coordinate(p, padding), reso)
+
+
+# --------------------------------------------------------------------------
+# trilinear gather (K6)
+# --------------------------------------------------------------------------
+
+
+def trilinear_sample(grid, p, padding=0.1):
+    """Trilinear interpolation of ``grid`` [B,C,D,H,W] at points ``p`` [B,N,3].
+
+    Restates ``LocalDecoder.sample_grid_feature`` (decoder.py:62-68), i.e.
+    ``F.grid_sample(c, 2*p_nor-1, padding_mode='border', align_corners=True)``
+    as the explicit 8-corner formula: x <-> W (last dim), y <-> H, z <-> D.
+    Returns [B,N,C].
+    """
+    B, C, D, H, W = grid.shape
+    pn = normalize_3d_coordinate(p.float(), padding)
+    v = 2.0 * pn - 1.0
+
+    def unnorm(coord, size):
+        f = ((coord + 1.0) / 2) * (size - 1)
+        return torch.clamp(f, 0, size - 1)
+
+    fx, fy, fz = unnorm(v[..., 0], W), unnorm(v[..., 1], H), unnorm(v[..., 2], D)
+    x0, y0, z0 = torch.floor(fx), torch.floor(fy), torch.floor(fz)
+    tx, ty, tz = fx - x0, fy - y0, fz - z0          # weight of the +1 corner
+    ux, uy, uz = (x0 + 1) - fx, (y0 + 1) - fy, (z0 + 1) - fz
+    x0, y0, z0 = x0.long(), y0.long(), z0.long()
+    gcl = grid.permute(0, 2, 3, 4, 1).reshape(B, D * H * W, C)
+    out = torch.zeros(B, p.shape[1], C, dtype=grid.dtype)
+    for dz, wz in ((0, uz), (1, tz)):
+        for dy, wy in ((0, uy), (1, ty)):
+            for dx, wx in ((0, ux), (1, tx)):
+                xi, yi, zi = x0 + dx, y0 + dy, z0 + dz
+                inb = (xi <= W - 1) & (yi <= H - 1) & (zi <= D - 1)
+                lin = (zi.clamp(max=D - 1) * H + yi.clamp(max=H - 1)) * W + xi.clamp(max=W - 1)
+                vals = torch.gather(gcl, 1, lin.unsqueeze(-1).expand(-1, -1, C))
+                w = (wx * wy * wz) * inb.to(grid.dtype)
+                out = out + vals * w.unsqueeze(-1)
+    return out
+
+
+# --------------------------------------------------------------------------
+# per-point MLPs
+# --------------------------------------------------------------------------
+
+
+def _lin(sd, name, x, bias=True):
+    y = x @ sd[name + ".weight"].t()
+    if bias and (name + ".bias") in sd:
+        y = y + sd[name + ".bias"]
+    return y
+
+
+def resnet_block_fc(sd, prefix, x):
+    """``ResnetBlockFC.forward`` (src/layers.py:41-50)."""
+    net = _lin(sd, prefix + ".fc_0", F.relu(x))
+    dx = _lin(sd, prefix + ".fc_1", F.relu(net))
+    if (prefix + ".shortcut.weight") in sd:
+        xs = x @ sd[prefix + ".shortcut.weight"].t()
+    else:
+        xs = x
+    return xs + dx
+
+
+def _n_blocks(sd, prefix="blocks."):
+    n = 0
+    while f"{prefix}{n}.fc_0.weight" in sd:
+        n += 1
+    return n
+
+
+def decoder_mlp(sd, net, c):
+    """Conditioned ResNet MLP + head shared by all decoder variants
+    (decoder.py:152-159)."""
+    for i in range(_n_blocks(sd)):
+        net = net + _lin(sd, f"fc_c.{i}", c)
+        net = resnet_block_fc(sd, f"blocks.{i}", net)
+    return net
+
+
+def local_decoder_forward(sd, p, grid, padding=0.1):
+    """``LocalDecoder.forward`` (decoder.py:135-161): logits [B,N]."""
+    c = trilinear_sample(grid, p, padding)
+    net = decoder_mlp(sd, _lin(sd, "fc_p", p.float()), c)
+    return _lin(sd, "fc_out", F.relu(net)).squeeze(-1)
+
+
+def local_decoder_forward_img(sd, p, grid, c_img, padding=0.1):
+    """``LocalDecoder.forward_img`` (decoder.py:71-103): tactile concat."""
+    c = trilinear_sample(grid, p, padding)
+    net = _lin(sd, "fc_p_img", torch.cat((p.float(), c_img), dim=2))
+    net = decoder_mlp(sd, net, c)
+    return _lin(sd, "fc_out", F.relu(net)).squeeze(-1)
+
+
+def local_decoder_forward_contact(sd, p, grid, padding=0.1):
+    """``LocalDecoder.forward_contact`` (decoder.py:105-133)."""
+    c = trilinear_sample(grid, p, padding)
+    net = decoder_mlp(sd, _lin(sd, "fc_p", p.float()), c)
+    a = F.relu(net)
+    return _lin(sd, "fc_out", a).squeeze(-1), _lin(sd, "fc_out_contact", a).squeeze(-1)
+
+
+# --------------------------------------------------------------------------
+# TransformerFusion (K8)
+# --------------------------------------------------------------------------
+
+
+def _relation_unit(sd, pre, q, k, v):
+    """``RelationUnit.forward`` (src/TransformerFusion.py:92-113); tensors are
+    [B,N,C] here (the reference permutes to N,B,C and back)."""
+    wk = F.normalize(k @ sd[pre + ".WK.weight"].t(), p=2, dim=-1)
+    wq = F.normalize(q @ sd[pre + ".WQ.weight"].t(), p=2, dim=-1)
+    dot = torch.bmm(wq, wk.transpose(1, 2))                  # B, Nq, Nk
+    aff = F.softmax(dot, dim=-1)
+    aff = aff / (1e-9 + aff.sum(dim=1, keepdim=True))        # column re-norm (:104)
+    out = torch.bmm(aff, v @ sd[pre + ".WV.weight"].t())
+    return F.relu((q - out) @ sd[pre + ".trans_conv.weight"].t())
+
+
+def _trans_nonlinear(sd, pre, x):
+    """``TransNonlinear.forward`` in eval mode (TransformerFusion.py:21-25)."""
+    y = _lin(sd, pre + ".linear2", F.relu(_lin(sd, pre + ".linear1", x)))
+    x = x + y
+    return F.layer_norm(x, (x.shape[-1],), sd[pre + ".norm2.weight"], sd[pre + ".norm2.bias"], 1e-5)
+
+
+def _mha1(sd, pre, q, k, v):
+    """Single-head ``MultiheadAttention`` (TransformerFusion.py:42-62)."""
+    return _trans_nonlinear(sd, pre + ".extra_nonlinear.0", _relation_unit(sd, pre + ".head.0", q, k, v))
+
+
+def _inorm_relu(x):
+    """InstanceNorm1d over the N axis (no affine, biased var, eps 1e-5) + ReLU
+    (TransformerFusion.py:144-145, 209-210, 216-218)."""
+    m = x.mean(dim=1, keepdim=True)
+    var = x.var(dim=1, unbiased=False, keepdim=True)
+    return F.relu((x - m) / torch.sqrt(var + 1e-5))
+
+
+def transformer_fusion(sd, c_img, c):
+    """``TransformerFusion.forward(search=c_img, template=c)`` with
+    ``num_layers=1, with_pos_embed=False`` in eval mode
+    (TransformerFusion.py:311-333).  ``sd`` keys are relative to ``fuser.``."""
+    sa = "encoder.layers.0.self_attn"                       # shared with decoder's self_attn
+    mem = _inorm_relu(c + _mha1(sd, sa, c, c, c))
+    sa_d = "decoder.layers.0.self_attn"
+    tgt = _inorm_relu(c_img + _mha1(sd, sa_d, c_img, c_img, c_img))
+    ca = "decoder.layers.0.cross_attn"
+    return _inorm_relu(tgt + _mha1(sd, ca, tgt, mem, mem))
+
+
+def attention_decoder_forward_img(sd, p, grid, c_img, padding=0.1):
+    """``AttentionDecoder.forward_img`` (decoder.py:237-271)."""
+    c = trilinear_sample(grid, p, padding)
+    fsd = {k[len("fuser."):]: v for k, v in sd.items() if k.startswith("fuser.")}
+    c = transformer_fusion(fsd, c_img, c)
+    net = decoder_mlp(sd, _lin(sd, "fc_p", p.float()), c)
+    return _lin(sd, "fc_out", F.relu(net)).squeeze(-1)
+
+
+# --------------------------------------------------------------------------
+# PointNet local-pool encoder (K1-K4) and UNet3D (K5)
+# --------------------------------------------------------------------------
+
+
+def segment_pool_max(feat, index):
+    """``pool_local`` for the 'grid' key (pointnet.py:116-132): per-voxel
+    channel-wise max gathered back to the points.  feat [B,T,C], index [B,T]."""
+    out = torch.empty_like(feat)
+    for b in range(feat.shape[0]):
+        uniq, inv = torch.unique(index[b], return_inverse=True)
+        seg = torch.full((uniq.numel(), feat.shape[2]), -float("inf"))
+        seg = seg.scatter_reduce(0, inv.unsqueeze(-1).expand_as(feat[b]), feat[b], "amax", include_self=True)
+        out[b] = seg[inv]
+    return out
+
+
+def scatter_mean_grid(feat, index, reso):
+    """``generate_grid_features`` scatter part (pointnet.py:102-110):
+    per-voxel mean, empty voxels 0; returns [B,C,R,R,R] (dims z,y,x)."""
+    B, T, C = feat.shape
+    grid = torch.zeros(B, reso ** 3, C)
+    cnt = torch.zeros(B, reso ** 3, 1)
+    grid.scatter_add_(1, index.unsqueeze(-1).expand(-1, -1, C), feat)
+    cnt.scatter_add_(1, index.unsqueeze(-1), torch.ones(B, T, 1))
+    grid = grid / cnt.clamp(min=1)
+    return grid.permute(0, 2, 1).reshape(B, C, reso, reso, reso)
+
+
+def pointnet_point_features(sd, p, reso, padding=0.1, return_stages=False):
+    """``LocalPoolPointnet.forward`` up to ``fc_c`` (pointnet.py:135-162)."""
+    idx = voxel_index(p, reso, padding)
+    net = _lin(sd, "fc_pos", p)
+    net = resnet_block_fc(sd, "blocks.0", net)
+    stages = [net]
+    for i in range(1, _n_blocks(sd)):
+        pooled = segment_pool_max(net, idx)
+        net = resnet_block_fc(sd, f"blocks.{i}", torch.cat([net, pooled], dim=2))
+        stages.append(net)
+    c = _lin(sd, "fc_c", net)
+    if return_stages:
+        return c, idx, stages
+    return c, idx
+
+
+def _gcr(sd, pre, x, groups=8):
+    """SingleConv order 'gcr': GroupNorm -> Conv3d(no bias) -> ReLU
+    (unet3d.py:20-72)."""
+    ch = x.shape[1]
+    g = groups if ch >= groups else 1
+    x = F.group_norm(x, g, sd[pre + ".groupnorm.weight"], sd[pre + ".groupnorm.bias"], 1e-5)
+    x = F.conv3d(x, sd[pre + ".conv.weight"], None, padding=1)
+    return F.relu(x)
+
+
+def unet3d_forward(sd, x):
+    """``UNet3D.forward`` (unet3d.py:449-474), DoubleConv blocks, nearest
+    upsample + concat; final sigmoid NOT applied (testing=False)."""
+    n_enc = 0
+    while f"encoders.{n_enc}.basic_module.SingleConv1.conv.weight" in sd:
+        n_enc += 1
+    feats = []
+    for i in range(n_enc):
+        if i > 0:
+            x = F.max_pool3d(x, 2)
+        x = _gcr(sd, f"encoders.{i}.basic_module.SingleConv1", x)
+        x = _gcr(sd, f"encoders.{i}.basic_module.SingleConv2", x)
+        feats.insert(0, x)
+    for i, skip in enumerate(feats[1:]):
+        x = F.interpolate(x, size=skip.shape[2:], mode="nearest")
+        x = torch.cat((skip, x), dim=1)
+        x = _gcr(sd, f"decoders.{i}.basic_module.SingleConv1", x)
+        x = _gcr(sd, f"decoders.{i}.basic_module.SingleConv2", x)
+    return F.conv3d(x, sd["final_conv.weight"], sd["final_conv.bias"])
+
+
+def pointnet_encoder_forward(sd, p, reso, padding=0.1, unet3d=True):
+    """Full ``LocalPoolPointnet.forward`` with plane_type='grid'
+    (pointnet.py:135-166)."""
+    c, idx = pointnet_point_features(sd, p, reso, padding)
+    grid = scatter_mean_grid(c, idx, reso)
+    if unet3d:
+        usd = {k[len("unet3d."):]: v for k, v in sd.items() if k.startswith("unet3d.")}
+        grid = unet3d_forward(usd, grid)
+    return grid
+
+
+# --------------------------------------------------------------------------
+# tactile UNet depth estimator (K9)
+# --------------------------------------------------------------------------
+
+
+def _bn2d(sd, pre, x, training):
+    if training:
+        return F.batch_norm(x, None, None, sd[pre + ".weight"], sd[pre + ".bias"], True, 0.1, 1e-5)
+    return F.batch_norm(x, sd[pre + ".running_mean"], sd[pre + ".running_var"],
+                        sd[pre + ".weight"], sd[pre + ".bias"], False, 0.1, 1e-5)
+
+
+def tactile_unet_forward(sd, x, training=False):
+    """Tactile ``UNet.forward`` (src/layers.py:430-450) with DownConv/UpConv
+    (:246-319): ONE BatchNorm module is applied after both convs of a block."""
+    depth = 0
+    while f"down_convs.{depth}.conv1.weight" in sd:
+        depth += 1
+    skips = []
+    for i in range(depth):
+        pre = f"down_convs.{i}"
+        x = F.relu(_bn2d(sd, pre + ".bn", F.conv2d(x, sd[pre + ".conv1.weight"], sd[pre + ".conv1.bias"], padding=1), training))
+        x = F.relu(_bn2d(sd, pre + ".bn", F.conv2d(x, sd[pre + ".conv2.weight"], sd[pre + ".conv2.bias"], padding=1), training))
+        skips.append(x)
+        if i < depth - 1:
+            x = F.max_pool2d(x, 2, 2)
+    for i in range(depth - 1):
+        pre = f"up_convs.{i}"
+        up = F.conv_transpose2d(x, sd[pre + ".upconv.weight"], sd[pre + ".upconv.bias"], stride=2)
+        x = torch.cat((up, skips[-(i + 2)]), dim=1)
+        x = F.relu(_bn2d(sd, pre + ".bn", F.conv2d(x, sd[pre + ".conv1.weight"], sd[pre + ".conv1.bias"], padding=1), training))
+        x = F.relu(_bn2d(sd, pre + ".bn", F.conv2d(x, sd[pre + ".conv2.weight"], sd[pre + ".conv2.bias"], padding=1), training))
+    x = F.conv2d(x, sd["conv_final.weight"], sd["conv_final.bias"])
+    return torch.sigmoid(x) * 1
+
+
+# --------------------------------------------------------------------------
+# dense evaluation (A11) and mesh post-processing (A12)
+# --------------------------------------------------------------------------
+
+
+def eval_points_dense(sd, grid, nx, padding=0.1, chunk=100000):
+    """``Generator3D.eval_points`` over the ``generate_obj_mesh_wnf`` lattice
+    (generation.py:119-120,155-157,338-383): 100k-point chunks, logits [nx^3]."""
+    pts = (1 + padding) * make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)
+    outs = []
+    for pi in torch.split(pts, chunk):
+        outs.append(local_decoder_forward(sd, pi.unsqueeze(0), grid, padding).squeeze(0))
+    return torch.cat(outs, dim=0)
+
+
+def mesh_rescale(verts, nx, padding=0.1):
+    """``vertices -= nx/2; vertices *= 1.1/nx`` (generation.py:271-272) in f32."""
+    import numpy as np
+    v = verts.astype(np.float32) - np.array([nx / 2] * 3, dtype=np.float32)
+    return v * np.float32(1.1 / nx) if padding == 0.1 else v * np.float32((1 + padding) / nx)
+
+
+def mc_level(vol):
+    """skimage's default iso level ``0.5 * (volume.min() + volume.max())``
+    (skimage/measure/_marching_cubes_lewiner.py, 0.18.3): the sum is rounded
+    in float32 (two np.float32 scalars), the halving is exact."""
+    import numpy as np
+    return 0.5 * float(np.float32(vol.min()) + np.float32(vol.max()))

@@ -1,0 +1,105 @@
+"""CPU: the oracle (oracle/vtaco_oracle.py) against golden vectors produced by
+the real reference (tests/golden/make_goldens.py).  This is what pins it."""
+import numpy as np
+import torch
+
+from conftest import load_golden, sub_sd
+from oracle import vtaco_oracle as orc
+
+T = torch.from_numpy
+
+
+def maxdiff(a, b):
+    return float((torch.as_tensor(a) - torch.as_tensor(b)).abs().max())
+
+
+def test_lattice_matches_reference_points():
+    a, _ = load_golden("g1_decode.npz")
+    pts = 1.1 * orc.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (32,) * 3)
+    assert torch.equal(pts, T(a["pts"])[0])
+
+
+def test_local_decoder_forward_variants():
+    a, sd = load_golden("g1_decode.npz")
+    grid, pts = T(a["grid"]), T(a["pts"])
+    assert maxdiff(orc.local_decoder_forward(sd, pts, grid), a["logits"]) <= 2e-5
+    c_img = T(a["c_img"].astype(np.float32))
+    assert maxdiff(orc.local_decoder_forward_img(sd, pts, grid, c_img), a["logits_img"]) <= 2e-5
+    o, oc = orc.local_decoder_forward_contact(sd, pts, grid)
+    assert maxdiff(o, a["logits_contact"]) <= 2e-5 and maxdiff(oc, a["logits_contact2"]) <= 2e-5
+
+
+def test_trilinear_with_clamped_points():
+    a, sd = load_golden("g1_decode.npz")
+    feat = orc.trilinear_sample(T(a["grid2"]), T(a["prand"]))
+    assert maxdiff(feat.transpose(1, 2), a["feat_rand"]) <= 2e-6
+    assert maxdiff(orc.local_decoder_forward(sd, T(a["prand"]), T(a["grid2"])), a["logits_rand"]) <= 2e-5
+
+
+def test_pointnet_stages_and_grid():
+    a, sd = load_golden("g3_pointnet.npz")
+    p = T(a["p"])
+    c, idx, stages = orc.pointnet_point_features(sd, p, 16, return_stages=True)
+    assert torch.equal(idx, T(a["idx"]))                      # voxel ids bit-exact
+    for i, s in enumerate(stages):
+        assert maxdiff(s, a[f"stage{i}"]) <= 1e-5
+    assert maxdiff(c, a["fc_c"]) <= 1e-5
+    grid = orc.scatter_mean_grid(c, idx, 16)
+    assert maxdiff(grid, a["grid"]) <= 1e-5
+    for b in range(2):                                        # empty voxels exactly zero
+        occ = torch.nonzero(grid[b].abs().sum(0).reshape(-1)).squeeze(1)
+        assert torch.equal(occ, T(a[f"occ{b}"]))
+
+
+def test_unet3d_and_full_encoder():
+    a, sd = load_golden("g4_unet3d.npz")
+    y = orc.unet3d_forward(sub_sd(sd, "unet3d."), T(a["x"]))
+    assert maxdiff(y, a["y"]) <= 1e-4
+    grid = orc.pointnet_encoder_forward(sd, T(a["p"]), 16)
+    assert maxdiff(grid, a["grid"]) <= 1e-4
+
+
+def test_transformer_fusion_and_attention_decoder():
+    a, sd = load_golden("g5_fusion.npz")
+    fsd = sub_sd(sd, "fuser.")
+    for n in (256, 2048):
+        out = orc.transformer_fusion(fsd, T(a[f"c_img{n}"]), T(a[f"c{n}"]))
+        assert maxdiff(out, a[f"fused{n}"]) <= 2e-5
+    lo = orc.attention_decoder_forward_img(sd, T(a["p"]), T(a["grid"]), T(a["c_img256"]))
+    assert maxdiff(lo, a["logits"]) <= 5e-5
+
+
+def test_tactile_unet_eval_and_train_bn():
+    a, sd = load_golden("g6_tactile.npz")
+    x = T(a["x"])
+    assert maxdiff(orc.tactile_unet_forward(sd, x, training=False), a["y_eval"]) <= 1e-5
+    assert maxdiff(orc.tactile_unet_forward(sd, x, training=True), a["y_train"]) <= 1e-5
+
+
+def test_train_step_loss_and_grads_via_autograd_of_oracle():
+    """The oracle is differentiable torch code: its autograd must reproduce the
+    reference's gradients (A14) so it can check the HIP backward kernels."""
+    a, sd = load_golden("g8_trainstep.npz")
+    dsd = {k: v.clone().requires_grad_(True) for k, v in sub_sd(sd, "dec.").items()}
+    esd = {k: v.clone().requires_grad_(True) for k, v in sub_sd(sd, "enc.").items()}
+    c, idx = orc.pointnet_point_features(esd, T(a["p_in"]), 16)
+    grid = orc.scatter_mean_grid(c, idx, 16)
+    grid.retain_grad()
+    c_img = T(a["c_img"]).clone().requires_grad_(True)
+    logits = orc.local_decoder_forward_img(dsd, T(a["pq"]), grid, c_img)
+    loss = torch.nn.functional.l1_loss(logits, T(a["occ"]))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(a["loss"])) <= 1e-6
+    assert maxdiff(logits.detach(), a["logits"]) <= 2e-5
+    for k, v in dsd.items():
+        ref = a["g.dec." + k]
+        got = v.grad if v.grad is not None else torch.zeros_like(v)
+        assert maxdiff(got, ref) <= 1e-6 + 1e-4 * float(np.abs(ref).max()), k
+    for k, v in esd.items():
+        ref = a["g.enc." + k]
+        got = v.grad if v.grad is not None else torch.zeros_like(v)
+        assert maxdiff(got, ref) <= 1e-6 + 1e-4 * float(np.abs(ref).max()), k
+    assert maxdiff(c_img.grad, a["c_img_grad"]) <= 1e-7
+    gi = a["grid_grad_idx"]
+    gg = grid.grad.permute(0, 2, 3, 4, 1).reshape(2, -1, 32)
+    assert maxdiff(gg[gi[:, 0], gi[:, 1]], a["grid_grad_val"]) <= 1e-7
