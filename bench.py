@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""bench.py -- occupancy query-points/s at 128^3 on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the decode hot path (lattice -> logits grid on device:
+in-kernel lattice generation, trilinear gather of the channels-last feature grid,
+per-point conditioned ResNet MLP) over one synthetic scene; weights and feature
+grid are resident in HBM when the timed region starts.
+With --gpus N every rank decodes its own scene (the unit is the query point; no
+data-path collective), so value = N * nx^3 * steps / max-over-ranks time ("weak").
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_POINT = 31488        # 30 976 (16 linear layers) + 512 (8 corners x 32 ch FMA)
+FLOP_PER_POINT_IMG = 33536    # with the tactile concat (forward_img)
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+
+
+def synthetic_scene(seed, device, R=64):
+    """Seeded synthetic inputs: sphere point cloud -> encoder -> grid."""
+    from vtaco_amd.bench_util import build_scene
+    return build_scene(seed, device, R)
+
+
+def cpu_baseline(sd, grid_cpu, nx, budget_s=15.0):
+    """The oracle (a port, not the reference itself) timed on the host cores on a
+    bounded sample: whole 100k-point chunks of the same lattice until ~budget_s."""
+    from oracle import vtaco_oracle as orc
+    torch.set_num_threads(os.cpu_count() or 1)
+    pts = 1.1 * orc.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)
+    chunks = torch.split(pts, 100000)
+    orc.local_decoder_forward(sd, chunks[0][:1000].unsqueeze(0), grid_cpu)   # warm
+    done, t0 = 0, time.perf_counter()
+    for ch in chunks:
+        orc.local_decoder_forward(sd, ch.unsqueeze(0), grid_cpu)
+        done += ch.shape[0]
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "query-points/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} of {nx ** 3} lattice points in 100k-point chunks, oracle/vtaco_oracle.py (torch CPU f32)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--nx", type=int, default=128)
+    ap.add_argument("--mode", choices=["visual", "img"], default="visual")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vtaco_amd import ops
+    scene = synthetic_scene(rank, dev)
+    model, grid = scene["model"], scene["grid"]
+    nx = args.nx
+    npts = nx ** 3
+    dec = model.decoder
+    c_img = scene["c_img"](nx) if args.mode == "img" else None
+    out = torch.empty((1, npts), dtype=torch.float32, device=dev)
+
+    def step():
+        dec.decode_lattice(grid, nx, box=1.1, c_img=c_img, out=out)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fence()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    fence()
+    wall = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps      # HIP events on the launch stream
+    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+
+    if rank == 0:
+        flop_pt = FLOP_PER_POINT_IMG if args.mode == "img" else FLOP_PER_POINT
+        achieved = flop_pt * npts / (kern_ms * 1e-3) / 1e12
+        res = {
+            "metric": "occupancy query-points/sec at 128^3 (decode stage, lattice -> logits on device)",
+            "value": world * npts * args.steps / wall,
+            "unit": "query-points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * wall / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"visual-only PointNet encoder + LocalDecoder, {nx}^3 lattice, 1 scene/GPU, "
+                                   f"R=64 c_dim=32 hidden=32 n_blocks=5, mode={args.mode}, random-init weights "
+                                   "(fc_1 re-randomised), f32 (exact-f32 MFMA; parity bar 1e-4)",
+                       "nx": nx, "points_per_step_per_gpu": npts, "mode": args.mode},
+            "per_gpu": npts * args.steps / wall,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "decode_fwd_kernel", "kernel_ms": kern_ms, "flop_per_point": flop_pt},
+        }
+        extra = scene.get("extra")
+        if extra:
+            res["stages_ms"] = extra(nx)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(scene["sd_decoder_cpu"], scene["grid_cpu"], nx)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+/*
+ * vtaco_hip.h -- C ABI of libvtaco_hip.so, the MI355X (gfx950) implementation
+ * of VTacO's occupancy hot path.
+ *
+ * The reference (jeffsonyu/VTacO) is pure Python: its "plugin API" for this path
+ * is the nn.Module registry (decoder_dict / encoder_dict).  There is no FFI in
+ * the reference, so each entry point below names the reference *call site* whose
+ * third-party native op it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - no allocation, no synchronisation, no host<->device copy inside any call
+ *     (graph-capture safe) unless stated;
+ *   - return value: 0 = ok, >0 = a hipError_t from the runtime, <0 = VT_ERR_*;
+ *     vt_last_error() returns a static, thread-local description;
+ *   - all float data is IEEE float32, all layouts are dense row-major in the
+ *     stated dimension order.
+ */
+#ifndef VTACO_HIP_H
+#define VTACO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VT_ABI_VERSION 1
+
+#define VT_ERR_INVALID      (-1)  /* bad argument (NULL, negative size, ...)        */
+#define VT_ERR_UNSUPPORTED  (-2)  /* shape outside what the gfx950 kernels cover    */
+#define VT_ERR_WORKSPACE    (-3)  /* caller-provided workspace too small            */
+
+#define VT_MAX_BLOCKS 8
+
+int         vt_abi_version(void);
+const char *vt_last_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* Decoder weights.                                                            */
+/* Replaces: nothing in the reference; it is the one-off repack of the          */
+/* nn.Linear parameters of LocalDecoder (src/conv_onet/models/decoder.py:27-44) */
+/* into the MFMA-fragment order vt_decode_fwd reads from LDS.                   */
+/* ------------------------------------------------------------------------- */
+typedef struct vt_decoder_params {
+    int32_t hidden;      /* hidden_size, must be 32                                  */
+    int32_t c_dim;       /* c_dim, must be 32                                        */
+    int32_t n_blocks;    /* n_blocks, must be 5                                      */
+    int32_t p_in;        /* columns of fc_p_w: 3 (fc_p) or 3+c_dim (fc_p_img)        */
+    const float *fc_p_w; /* [hidden, p_in]  fc_p.weight or fc_p_img.weight           */
+    const float *fc_p_b; /* [hidden]                                                 */
+    const float *fc_c_w[VT_MAX_BLOCKS]; /* [hidden, c_dim] fc_c.{i}.weight           */
+    const float *fc_c_b[VT_MAX_BLOCKS]; /* [hidden]                                  */
+    const float *fc0_w[VT_MAX_BLOCKS];  /* [hidden, hidden] blocks.{i}.fc_0.weight   */
+    const float *fc0_b[VT_MAX_BLOCKS];
+    const float *fc1_w[VT_MAX_BLOCKS];  /* [hidden, hidden] blocks.{i}.fc_1.weight   */
+    const float *fc1_b[VT_MAX_BLOCKS];
+    const float *fc_out_w;  /* [1, hidden] fc_out.weight                             */
+    const float *fc_out_b;  /* [1]                                                   */
+    const float *fc_out2_w; /* fc_out_contact.weight or NULL                         */
+    const float *fc_out2_b; /* fc_out_contact.bias   or NULL                         */
+} vt_decoder_params;
+
+/* Size in bytes of the packed blob for a given (hidden, c_dim, n_blocks). */
+size_t vt_decoder_blob_bytes(int hidden, int c_dim, int n_blocks);
+
+/* params_host: HOST pointer to the struct (its members are device pointers). */
+int vt_decoder_pack(const vt_decoder_params *params_host, float *blob, size_t blob_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* Feature grid layout.                                                        */
+/* vt_decode_* read the grid channels-last: grid_cl[b][z][y][x][c].            */
+/* Replaces: the implicit NCDHW read of F.grid_sample (decoder.py:62-68).      */
+/* ------------------------------------------------------------------------- */
+int vt_grid_to_channels_last(const float *grid_ncdhw, float *grid_cl,
+                             int B, int C, int D, int H, int W, void *stream);
+int vt_grid_from_channels_last(const float *grid_cl, float *grid_ncdhw,
+                               int B, int C, int D, int H, int W, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* Fused trilinear gather + conditioned ResNet MLP, forward.                    */
+/* Replaces: LocalDecoder.forward / forward_img / forward_contact               */
+/*   (decoder.py:135-161, 71-103, 105-133) = normalize_3d_coordinate            */
+/*   (src/common.py:293-309) + F.grid_sample (decoder.py:62-68) + fc_p +        */
+/*   5 x (fc_c[i] add, ResnetBlockFC src/layers.py:41-50) + fc_out.             */
+/*                                                                             */
+/*   pts      [B,N,3] query points, or NULL for lattice mode;                   */
+/*   lattice mode: the n-th point of every batch element is the                 */
+/*     (lattice_first + n)-th point of box * make_3d_grid((-.5,)*3,(.5,)*3,     */
+/*     (nx,)*3) (src/common.py:178-197, generation.py:155-157): axis 0 slowest; */
+/*   c_img    [B,N,c_dim] tactile features (forward_img) or NULL;               */
+/*   blob     from vt_decoder_pack (packed with p_in = 3+c_dim iff c_img);      */
+/*   out      [B,N] logits; out2 [B,N] contact logits or NULL.                  */
+/* ------------------------------------------------------------------------- */
+int vt_decode_fwd(const float *grid_cl, int B, int R, int C,
+                  const float *pts, int64_t N,
+                  int lattice_nx, float lattice_box, int64_t lattice_first,
+                  const float *c_img, const float *blob, double padding,
+                  float *out, float *out2, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTACO_HIP_H */

@@ -1,0 +1,95 @@
+"""ctypes binding of libvtaco_hip.so (the C ABI declared in include/vtaco_hip.h).
+
+There is no CPU fallback: if the library is missing, or a tensor is not on a HIP
+device, every op raises.  ``import torch`` must come first so that the library
+resolves libamdhip64.so.7 to the copy torch has already loaded (one HIP runtime
+per process: device pointers are only meaningful inside the runtime that made
+them).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvtaco_hip.so")
+
+VT_MAX_BLOCKS = 8
+c_float_p = ctypes.POINTER(ctypes.c_float)
+
+
+class VtError(RuntimeError):
+    pass
+
+
+class DecoderParams(ctypes.Structure):
+    """Mirror of ``vt_decoder_params`` (include/vtaco_hip.h)."""
+    _fields_ = [
+        ("hidden", ctypes.c_int32), ("c_dim", ctypes.c_int32),
+        ("n_blocks", ctypes.c_int32), ("p_in", ctypes.c_int32),
+        ("fc_p_w", ctypes.c_void_p), ("fc_p_b", ctypes.c_void_p),
+        ("fc_c_w", ctypes.c_void_p * VT_MAX_BLOCKS), ("fc_c_b", ctypes.c_void_p * VT_MAX_BLOCKS),
+        ("fc0_w", ctypes.c_void_p * VT_MAX_BLOCKS), ("fc0_b", ctypes.c_void_p * VT_MAX_BLOCKS),
+        ("fc1_w", ctypes.c_void_p * VT_MAX_BLOCKS), ("fc1_b", ctypes.c_void_p * VT_MAX_BLOCKS),
+        ("fc_out_w", ctypes.c_void_p), ("fc_out_b", ctypes.c_void_p),
+        ("fc_out2_w", ctypes.c_void_p), ("fc_out2_b", ctypes.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); kept in step with include/vtaco_hip.h (tests/test_abi.py
+# parses the header and checks that every declared symbol is exported and listed here)
+_VP, _I, _I64, _F, _D, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_size_t
+SIGNATURES = {
+    "vt_abi_version": (_I, []),
+    "vt_last_error": (ctypes.c_char_p, []),
+    "vt_decoder_blob_bytes": (_SZ, [_I, _I, _I]),
+    "vt_decoder_pack": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
+    "vt_grid_to_channels_last": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP]),
+    "vt_grid_from_channels_last": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP]),
+    "vt_decode_fwd": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _D, _VP, _VP, _VP]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raises VtError with build instructions if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VtError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C vtaco_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().vt_last_error().decode("utf-8", "replace")
+        raise VtError(f"{what} failed (code {rc}): {msg}")
+
+
+def dev_ptr(t, name="tensor", dtype=torch.float32):
+    """Device pointer of a contiguous HIP tensor (raises for CPU tensors)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise VtError(f"{name} must live on a HIP device (got {t.device}); vtaco_amd has no CPU path")
+    if t.dtype != dtype:
+        raise VtError(f"{name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise VtError(f"{name} must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

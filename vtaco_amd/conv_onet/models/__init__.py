@@ -1,0 +1,67 @@
+"""Model container (drop-in for reference src/conv_onet/models/__init__.py:15-197)."""
+from __future__ import annotations
+
+import torch
+from torch import distributions as dist
+from torch import nn
+
+from . import decoder
+
+# same registry names as the reference (models/__init__.py:7-12); the crop / PointConv
+# baselines are out of scope
+decoder_dict = {
+    'simple_local': decoder.LocalDecoder,
+}
+
+
+class ConvolutionalOccupancyNetwork(nn.Module):
+    """Holds decoder / encoder / encoder_hand / encoder_img / encoder_t2d and exposes
+    encode_* / decode* exactly as the reference does."""
+
+    def __init__(self, decoder, encoder=None, encoder_hand=None, encoder_img=None, encoder_t2d=None, device=None):
+        super().__init__()
+        put = lambda m: None if m is None else m.to(device)
+        self.decoder = put(decoder)
+        self.encoder = put(encoder)
+        self.encoder_hand = put(encoder_hand)
+        self.encoder_img = put(encoder_img)
+        self.encoder_t2d = put(encoder_t2d)
+        self._device = device
+
+    def forward(self, p, inputs, imgs=None, sample=True, **kwargs):
+        return self.decode(p, self.encode_inputs(inputs), **kwargs)
+
+    def _encode_with(self, enc, x):
+        return enc(x) if enc is not None else torch.empty(x.size(0), 0)
+
+    def encode_inputs(self, inputs):
+        return self._encode_with(self.encoder, inputs)
+
+    def encode_hand_inputs(self, inputs):
+        return self._encode_with(self.encoder_hand, inputs)
+
+    def encode_img_inputs(self, imgs):
+        """Per-scene loop over the 5 tactile images (models/__init__.py:115-136): keeps
+        train-mode BatchNorm statistics per scene, as the reference does."""
+        if self.encoder_img is None:
+            return torch.empty(imgs.size(0), 0)
+        B, Fn = imgs.shape[:2]
+        return torch.cat([self.encoder_img(imgs[b]).reshape(1, Fn, -1) for b in range(B)], dim=0)
+
+    def encode_t2d(self, inputs, imgs):
+        return self.encoder_t2d.encode_img_inputs(imgs), self.encoder_t2d.encode_hand_inputs(inputs)
+
+    def decode(self, p, c, **kwargs):
+        return dist.Bernoulli(logits=self.decoder(p, c, **kwargs))
+
+    def decode_img(self, p, c, c_img=None, **kwargs):
+        return dist.Bernoulli(logits=self.decoder.forward_img(p, c, c_img, **kwargs))
+
+    def decode_contact(self, p, c, **kwargs):
+        logits, contact = self.decoder.forward_contact(p, c, **kwargs)
+        return dist.Bernoulli(logits=logits), contact
+
+    def to(self, device):
+        model = super().to(device)
+        model._device = device
+        return model

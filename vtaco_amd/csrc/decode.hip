@@ -1,0 +1,413 @@
+// Fused trilinear feature gather + per-point conditioned ResNet MLP (forward),
+// gfx950 only.  Replaces LocalDecoder.forward / forward_img / forward_contact
+// (reference src/conv_onet/models/decoder.py:135-161, 71-103, 105-133).
+//
+// Mapping.  One wave owns a tile of 32 query points.  Every dense layer
+// y = W x (32x32) is computed transposed on the f32 matrix core,
+//     D[out][point] += A[out][k] * B[k][point]      (v_mfma_f32_32x32x2_f32),
+// so the accumulator of one layer (point on the lane, 16 output channels in the
+// 16 accumulator registers) IS the B operand of the next layer with no lane
+// movement: register r of lane-half h holds channel o(r,h) = (r&3)+8(r>>2)+4h,
+// and the weight fragments are pre-permuted into that k order by vt_decoder_pack.
+// Weights live in LDS (one ds_read_b32 per MFMA); biases enter as the initial
+// accumulator; the residual adds are the accumulator chain itself.
+//
+// 242 MFMAs per 32 points (258 with tactile concat): 15 dense 32x32 layers x 16
+// + fc_p (K=3 padded to 4: 2).  The trilinear gather reads the channels-last grid:
+// lane (p,h) loads channels 16h..16h+15 of each of its point's 8 corners.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vt_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// max(x,0) as ONE v_max_f32 (fmaxf on an MFMA result costs a canonicalising second max)
+__device__ __forceinline__ float relu1(float x) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+
+// Force the 16 values to exist in VGPRs here (stops LLVM sinking the FMAs that produce
+// them past later loads, which would keep every load of the gather in flight at once).
+__device__ __forceinline__ void pin16(f32x16 &v) {
+    asm volatile("" : "+v"(v));
+}
+
+// one dense 32x32 layer; x[s] is the B operand of k-step s
+template <bool RELU>
+__device__ __forceinline__ f32x16 dense32(f32x16 acc, const float *wl, const f32x16 &x, int lane) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        float xv = RELU ? relu1(x[s]) : x[s];
+        acc = mfma(wl[s * 64 + lane], xv, acc);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ f32x16 load_frag16(const float *p) {
+    const f32x4 *q = reinterpret_cast<const f32x4 *>(p);
+    f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
+    f32x16 r;
+    r.s0 = a.x; r.s1 = a.y; r.s2 = a.z; r.s3 = a.w;
+    r.s4 = b.x; r.s5 = b.y; r.s6 = b.z; r.s7 = b.w;
+    r.s8 = c.x; r.s9 = c.y; r.sa = c.z; r.sb = c.w;
+    r.sc = d.x; r.sd = d.y; r.se = d.z; r.sf = d.w;
+    return r;
+}
+
+// reference src/common.py:293-309 followed by ATen's align_corners=True
+// un-normalisation and border clip (decoder.py:62-68): returns the continuous
+// grid coordinate in [0, R-1].
+__device__ __forceinline__ float grid_coord(float v, float divisor, int R) {
+    float q = v / divisor + 0.5f;
+    q = (q >= 1.0f) ? 0.999f : q;
+    q = (q < 0.0f) ? 0.0f : q;
+    float g = 2.0f * q - 1.0f;
+    float f = ((g + 1.0f) / 2.0f) * (float)(R - 1);
+    return fminf(fmaxf(f, 0.0f), (float)(R - 1));
+}
+
+struct DecodeArgs {
+    const float *grid;   // [B,R,R,R,32]
+    const float *pts;    // [B,N,3] or null
+    const float *c_img;  // [B,N,32] or null
+    const float *blob;
+    float *out;
+    float *out2;
+    uint32_t N;          // points per batch element
+    uint32_t total;      // B*N   (< 2^31, checked by the entry point)
+    uint32_t lattice_first;
+    int R;
+    int nx;
+    float box;
+    float divisor;       // 1 + padding + 10e-4
+};
+
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS, VT_WAVES_PER_SIMD)
+decode_fwd_kernel(DecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // stage the packed weights (identical for every block) into LDS
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.blob);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
+        for (int i = threadIdx.x; i < VT_BLOB_FLOATS / 4; i += THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int pl = lane & 31;
+    const int h = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    constexpr int WPB = THREADS / 64;
+    const uint32_t ntiles = (a.total + 31u) >> 5;
+    const bool with_img = a.c_img != nullptr;
+    const int R = a.R;
+
+    for (uint32_t tile = blockIdx.x * WPB + wave; tile < ntiles; tile += gridDim.x * WPB) {
+        // Re-derive the LDS base every tile behind an opaque asm so the (loop-invariant)
+        // weight reads are not hoisted out of the tile loop into ~120 extra VGPRs.
+        unsigned lds_off = 0;
+        asm volatile("" : "+v"(lds_off));
+        const float *L = lds + lds_off;
+        uint32_t g = tile * 32u + pl;
+        const bool live = g < a.total;
+        if (!live) g = a.total - 1u;
+        const uint32_t b = g / a.N;
+        const uint32_t n = g - b * a.N;
+
+        float px, py, pz;
+        if (a.pts) {
+            const float *pp = a.pts + (size_t)g * 3;
+            px = pp[0]; py = pp[1]; pz = pp[2];
+        } else {
+            // box * linspace(-0.5, 0.5, nx)[i] (src/common.py:178-197, generation.py:155-157)
+            const uint32_t m = a.lattice_first + n;
+            const uint32_t nx = (uint32_t)a.nx;
+            const uint32_t t = m / nx;
+            const int iz = (int)(m - t * nx);
+            const int ix = (int)(t / nx);
+            const int iy = (int)(t - (uint32_t)ix * nx);
+            const float step = 1.0f / (float)(a.nx - 1);
+            const int half = a.nx / 2;
+            auto lin = [&](int i) {
+                float v = (i < half) ? (-0.5f + step * (float)i) : (0.5f - step * (float)(a.nx - i - 1));
+                return a.box * v;
+            };
+            px = lin(ix); py = lin(iy); pz = lin(iz);
+        }
+
+        // ---- trilinear gather: c[s] = feature channel 16h+s of this lane's point ----
+        f32x16 c;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) c[s] = 0.0f;
+        {
+            const float fx = grid_coord(px, a.divisor, R);
+            const float fy = grid_coord(py, a.divisor, R);
+            const float fz = grid_coord(pz, a.divisor, R);
+            const float x0f = floorf(fx), y0f = floorf(fy), z0f = floorf(fz);
+            const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
+            const float wx1 = fx - x0f, wy1 = fy - y0f, wz1 = fz - z0f;
+            const float wx0 = (x0f + 1.0f) - fx, wy0 = (y0f + 1.0f) - fy, wz0 = (z0f + 1.0f) - fz;
+            const int x1 = min(x0 + 1, R - 1), y1 = min(y0 + 1, R - 1), z1 = min(z0 + 1, R - 1);
+            // a corner beyond the border is skipped by ATen; its weight is 0 there anyway
+            const float mx = (x0 + 1 <= R - 1) ? wx1 : 0.0f;
+            const float my = (y0 + 1 <= R - 1) ? wy1 : 0.0f;
+            const float mz = (z0 + 1 <= R - 1) ? wz1 : 0.0f;
+            const float *gb = a.grid + (size_t)b * R * R * R * 32 + 16 * h;
+            // one z-plane (4 corners, 16 x 16-byte loads per lane) at a time: the scheduling
+            // barrier keeps the second plane's loads from being hoisted above the first
+            // plane's FMAs, which would double the VGPRs held by loads in flight.
+            auto plane = [&](int zz, float wz) {
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    const int yy = dy ? y1 : y0;
+                    const float wyz_a = (dy ? my : wy0);
+                    const size_t row = ((size_t)zz * R + yy) * R;
+                    const f32x16 v0 = load_frag16(gb + (row + x0) * 32);
+                    const f32x16 v1 = load_frag16(gb + (row + x1) * 32);
+                    const float w0 = (wx0 * wyz_a) * wz;
+                    const float w1 = (mx * wyz_a) * wz;
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) c[s] = fmaf(v0[s], w0, c[s]);
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) c[s] = fmaf(v1[s], w1, c[s]);
+                }
+            };
+            plane(z0, wz0);
+            pin16(c);
+            __builtin_amdgcn_sched_barrier(0);
+            plane(z1, mz);
+            pin16(c);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- net = fc_p(p) + fc_c[0](c) (+ fc_p_img's c_img columns) ----
+        f32x16 net = load_frag16(L + VT_OFF_BIAS + 0 * 32 + h * 16);
+        {
+            const float k0 = h ? py : px;          // k = 2s+h : s=0 -> x|y
+            const float k1 = h ? 0.0f : pz;        //            s=1 -> z|pad
+            net = mfma(L[VT_OFF_WP + lane], k0, net);
+            net = mfma(L[VT_OFF_WP + 64 + lane], k1, net);
+        }
+        if (with_img) {
+            const f32x16 ci = load_frag16(a.c_img + (size_t)g * 32 + 16 * h);
+            net = dense32<false>(net, L + VT_OFF_WPI, ci, lane);
+        }
+        net = dense32<false>(net, L + VT_OFF_WL, c, lane);
+
+        // ---- 5 x (ResnetBlockFC + next block's fc_c) ----
+#pragma unroll 1
+        for (int i = 0; i < 5; ++i) {
+            const float *wl = L + VT_OFF_WL + (1 + 3 * i) * 1024;
+            f32x16 hid = load_frag16(L + VT_OFF_BIAS + (1 + 2 * i) * 32 + h * 16);
+            hid = dense32<true>(hid, wl, net, lane);
+            net = dense32<true>(net, wl + 1024, hid, lane);
+            if (i < 4) net = dense32<false>(net, wl + 2048, c, lane);
+            const f32x16 bb = load_frag16(L + VT_OFF_BIAS + (2 + 2 * i) * 32 + h * 16);
+            net = net + bb;
+        }
+
+        // ---- heads: out = fc_out(relu(net)) ----
+        {
+            const f32x16 wo = load_frag16(L + VT_OFF_OUT + h * 16);
+            float acc = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = fmaf(relu1(net[s]), wo[s], acc);
+            acc += __shfl_xor(acc, 32);
+            acc += L[VT_OFF_OUT + 64];
+            if (live && h == 0) a.out[g] = acc;
+            if (a.out2) {
+                const f32x16 wo2 = load_frag16(L + VT_OFF_OUT + 32 + h * 16);
+                float acc2 = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) acc2 = fmaf(relu1(net[s]), wo2[s], acc2);
+                acc2 += __shfl_xor(acc2, 32);
+                acc2 += L[VT_OFF_OUT + 65];
+                if (live && h == 0) a.out2[g] = acc2;
+            }
+        }
+    }
+}
+
+// ---- weight packing -------------------------------------------------------------
+struct PackArgs {
+    vt_decoder_params p;
+    float *blob;
+};
+
+__device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__global__ void decoder_pack_kernel(PackArgs a) {
+    const vt_decoder_params &p = a.p;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < VT_BLOB_FLOATS; e += gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        if (e < VT_OFF_WP) {
+            const int L = e >> 10, s = (e >> 6) & 15, l = e & 63, i = l & 31, h = l >> 5;
+            const float *w;
+            bool gather_fed;
+            if (L == 0) { w = p.fc_c_w[0]; gather_fed = true; }
+            else {
+                const int blk = (L - 1) / 3, kind = (L - 1) % 3;
+                if (kind == 0) { w = p.fc0_w[blk]; gather_fed = false; }
+                else if (kind == 1) { w = p.fc1_w[blk]; gather_fed = false; }
+                else { w = p.fc_c_w[blk + 1]; gather_fed = true; }
+            }
+            const int k = gather_fed ? (16 * h + s) : chan_of(s, h);
+            v = w[i * 32 + k];
+        } else if (e < VT_OFF_WPI) {
+            const int q = e - VT_OFF_WP, s = q >> 6, l = q & 63, i = l & 31, h = l >> 5;
+            const int k = 2 * s + h;
+            v = (k < 3) ? p.fc_p_w[i * p.p_in + k] : 0.0f;
+        } else if (e < VT_OFF_BIAS) {
+            const int q = e - VT_OFF_WPI, s = q >> 6, l = q & 63, i = l & 31, h = l >> 5;
+            v = (p.p_in > 3) ? p.fc_p_w[i * p.p_in + 3 + 16 * h + s] : 0.0f;
+        } else if (e < VT_OFF_OUT) {
+            const int q = e - VT_OFF_BIAS, j = q >> 5, h = (q >> 4) & 1, r = q & 15;
+            const int o = chan_of(r, h);
+            if (j == 0) v = p.fc_p_b[o] + p.fc_c_b[0][o];
+            else if (j & 1) v = p.fc0_b[(j - 1) >> 1][o];
+            else {
+                const int blk = (j - 2) >> 1;
+                v = p.fc1_b[blk][o] + ((blk < 4) ? p.fc_c_b[blk + 1][o] : 0.0f);
+            }
+        } else {
+            const int q = e - VT_OFF_OUT;
+            if (q < 32) v = p.fc_out_w[chan_of(q & 15, q >> 4)];
+            else if (q < 64) v = p.fc_out2_w ? p.fc_out2_w[chan_of(q & 15, (q >> 4) & 1)] : 0.0f;
+            else if (q == 64) v = p.fc_out_b[0];
+            else if (q == 65) v = p.fc_out2_b ? p.fc_out2_b[0] : 0.0f;
+        }
+        a.blob[e] = v;
+    }
+}
+
+// ---- NCDHW <-> NDHWC ---------------------------------------------------------------
+// one block transposes a [C=32] x [64 voxels] tile through LDS
+__global__ void __launch_bounds__(256) grid_to_cl_kernel(const float *src, float *dst, int C, int64_t V) {
+    __shared__ float t[32][65];
+    const int64_t v0 = (int64_t)blockIdx.x * 64;
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * 32;
+    const float *s = src + ((int64_t)b * C + c0) * V;
+    float *d = dst + (int64_t)b * V * C;
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int c = i >> 6, v = i & 63;
+        if (c0 + c < C && v0 + v < V) t[c][v] = s[(int64_t)c * V + v0 + v];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int v = i >> 5, c = i & 31;
+        if (c0 + c < C && v0 + v < V) d[(v0 + v) * C + c0 + c] = t[c][v];
+    }
+}
+
+__global__ void __launch_bounds__(256) grid_from_cl_kernel(const float *src, float *dst, int C, int64_t V) {
+    __shared__ float t[64][33];
+    const int64_t v0 = (int64_t)blockIdx.x * 64;
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * 32;
+    const float *s = src + (int64_t)b * V * C;
+    float *d = dst + ((int64_t)b * C + c0) * V;
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int v = i >> 5, c = i & 31;
+        if (c0 + c < C && v0 + v < V) t[v][c] = s[(v0 + v) * C + c0 + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int c = i >> 6, v = i & 63;
+        if (c0 + c < C && v0 + v < V) d[(int64_t)c * V + v0 + v] = t[v][c];
+    }
+}
+
+}  // namespace
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+extern "C" {
+
+size_t vt_decoder_blob_bytes(int hidden, int c_dim, int n_blocks) {
+    if (hidden != 32 || c_dim != 32 || n_blocks != 5) return 0;
+    return (size_t)VT_BLOB_FLOATS * sizeof(float);
+}
+
+int vt_decoder_pack(const vt_decoder_params *p, float *blob, size_t blob_bytes, void *stream) {
+    if (!p || !blob) return vt_fail(VT_ERR_INVALID, "vt_decoder_pack: null argument");
+    if (p->hidden != 32 || p->c_dim != 32 || p->n_blocks != 5)
+        return vt_fail(VT_ERR_UNSUPPORTED, "vt_decoder_pack: only hidden=32, c_dim=32, n_blocks=5 (the shipped VTacO configs) are built");
+    if (p->p_in != 3 && p->p_in != 3 + p->c_dim) return vt_fail(VT_ERR_INVALID, "vt_decoder_pack: p_in must be 3 or 3+c_dim");
+    if (blob_bytes < (size_t)VT_BLOB_FLOATS * sizeof(float)) return vt_fail(VT_ERR_WORKSPACE, "vt_decoder_pack: blob too small");
+    if (!p->fc_p_w || !p->fc_p_b || !p->fc_out_w || !p->fc_out_b) return vt_fail(VT_ERR_INVALID, "vt_decoder_pack: null weight");
+    for (int i = 0; i < 5; ++i)
+        if (!p->fc_c_w[i] || !p->fc_c_b[i] || !p->fc0_w[i] || !p->fc0_b[i] || !p->fc1_w[i] || !p->fc1_b[i])
+            return vt_fail(VT_ERR_INVALID, "vt_decoder_pack: null block weight");
+    PackArgs a;
+    a.p = *p;
+    a.blob = blob;
+    hipLaunchKernelGGL(decoder_pack_kernel, dim3(17), dim3(1024), 0, (hipStream_t)stream, a);
+    return vt_check(hipGetLastError(), "vt_decoder_pack");
+}
+
+int vt_grid_to_channels_last(const float *src, float *dst, int B, int C, int D, int H, int W, void *stream) {
+    if (!src || !dst || B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return vt_fail(VT_ERR_INVALID, "vt_grid_to_channels_last: bad argument");
+    const int64_t V = (int64_t)D * H * W;
+    dim3 grid((unsigned)((V + 63) / 64), (unsigned)((C + 31) / 32), (unsigned)B);
+    hipLaunchKernelGGL(grid_to_cl_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, V);
+    return vt_check(hipGetLastError(), "vt_grid_to_channels_last");
+}
+
+int vt_grid_from_channels_last(const float *src, float *dst, int B, int C, int D, int H, int W, void *stream) {
+    if (!src || !dst || B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return vt_fail(VT_ERR_INVALID, "vt_grid_from_channels_last: bad argument");
+    const int64_t V = (int64_t)D * H * W;
+    dim3 grid((unsigned)((V + 63) / 64), (unsigned)((C + 31) / 32), (unsigned)B);
+    hipLaunchKernelGGL(grid_from_cl_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, V);
+    return vt_check(hipGetLastError(), "vt_grid_from_channels_last");
+}
+
+int vt_decode_fwd(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                  int lattice_nx, float lattice_box, int64_t lattice_first,
+                  const float *c_img, const float *blob, double padding,
+                  float *out, float *out2, void *stream) {
+    if (!grid_cl || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: null argument");
+    if (B <= 0 || R < 2 || N < 0) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: bad size");
+    if (C != 32) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd: c_dim must be 32");
+    if (!pts) {
+        if (lattice_nx < 2) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: lattice mode needs nx >= 2");
+        const int64_t all = (int64_t)lattice_nx * lattice_nx * lattice_nx;
+        if (lattice_first < 0 || lattice_first + N > all) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: lattice range out of bounds");
+    }
+    if (N == 0) return 0;
+    if ((int64_t)B * N >= (int64_t)1 << 31) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd: B*N must be < 2^31");
+    DecodeArgs a;
+    a.grid = grid_cl; a.pts = pts; a.c_img = c_img; a.blob = blob; a.out = out; a.out2 = out2;
+    a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
+    a.R = R; a.nx = lattice_nx; a.box = lattice_box;
+    a.divisor = (float)(1.0 + padding + 10e-4);   // src/common.py:302, rounded to f32 as torch does
+    constexpr int THREADS = 512;
+    const int64_t ntiles = ((int64_t)a.total + 31) / 32;
+    int64_t blocks = (ntiles + THREADS / 64 - 1) / (THREADS / 64);
+    const int64_t cap = 2 * vt_num_cus();
+    if (blocks > cap) blocks = cap;
+    const size_t lds_bytes = (size_t)VT_BLOB_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(decode_fwd_kernel<THREADS>, dim3((unsigned)blocks), dim3(THREADS), lds_bytes, (hipStream_t)stream, a);
+    return vt_check(hipGetLastError(), "vt_decode_fwd");
+}
+
+}  // extern "C"

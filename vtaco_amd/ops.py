@@ -1,0 +1,138 @@
+"""Host-side launchers for the HIP kernels behind the C ABI (include/vtaco_hip.h).
+
+Thin and allocation-explicit: every function takes torch HIP tensors, hands raw
+device pointers + the current stream to libvtaco_hip.so and returns torch
+tensors.  No function here computes anything with torch ops.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import VtError, check, dev_ptr, stream_ptr
+
+
+def blob_floats(hidden=32, c_dim=32, n_blocks=5):
+    n = _lib.load().vt_decoder_blob_bytes(hidden, c_dim, n_blocks)
+    if n == 0:
+        raise VtError(f"decoder shape hidden={hidden}, c_dim={c_dim}, n_blocks={n_blocks} is not built "
+                      "(gfx950 kernels cover the shipped VTacO shape 32/32/5)")
+    return n // 4
+
+
+def pack_decoder(fc_p_w, fc_p_b, fc_c, blocks, fc_out, fc_out2=None, out=None):
+    """Repack decoder parameters into the MFMA-fragment blob (vt_decoder_pack).
+
+    fc_c: list of (weight, bias); blocks: list of (fc0_w, fc0_b, fc1_w, fc1_b);
+    fc_out / fc_out2: (weight, bias).  ``fc_p_w`` is fc_p.weight [H,3] or
+    fc_p_img.weight [H,3+C].
+    """
+    lib = _lib.load()
+    hidden, p_in = fc_p_w.shape
+    c_dim = fc_c[0][0].shape[1]
+    nb = len(blocks)
+    if nb > _lib.VT_MAX_BLOCKS:
+        raise VtError(f"n_blocks={nb} exceeds VT_MAX_BLOCKS")
+    keep = []
+
+    def ptr(t, name):
+        t = t.detach()
+        if not t.is_contiguous():
+            t = t.contiguous()
+        keep.append(t)
+        return dev_ptr(t, name)
+
+    prm = _lib.DecoderParams()
+    prm.hidden, prm.c_dim, prm.n_blocks, prm.p_in = hidden, c_dim, nb, p_in
+    prm.fc_p_w, prm.fc_p_b = ptr(fc_p_w, "fc_p.weight"), ptr(fc_p_b, "fc_p.bias")
+    for i, (w, b) in enumerate(fc_c):
+        prm.fc_c_w[i], prm.fc_c_b[i] = ptr(w, f"fc_c.{i}.weight").value, ptr(b, f"fc_c.{i}.bias").value
+    for i, (w0, b0, w1, b1) in enumerate(blocks):
+        prm.fc0_w[i], prm.fc0_b[i] = ptr(w0, "fc_0.weight").value, ptr(b0, "fc_0.bias").value
+        prm.fc1_w[i], prm.fc1_b[i] = ptr(w1, "fc_1.weight").value, ptr(b1, "fc_1.bias").value
+    prm.fc_out_w, prm.fc_out_b = ptr(fc_out[0], "fc_out.weight"), ptr(fc_out[1], "fc_out.bias")
+    if fc_out2 is not None:
+        prm.fc_out2_w, prm.fc_out2_b = ptr(fc_out2[0], "fc_out_contact.weight"), ptr(fc_out2[1], "fc_out_contact.bias")
+    n = blob_floats(hidden, c_dim, nb)
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=fc_p_w.device)
+    check(lib.vt_decoder_pack(ctypes.byref(prm), dev_ptr(out, "blob"), n * 4, stream_ptr()), "vt_decoder_pack")
+    return out
+
+
+def is_channels_last_grid(grid):
+    """True if ``grid`` [B,C,D,H,W] is laid out b,z,y,x,c in memory."""
+    B, C, D, H, W = grid.shape
+    return grid.stride() == (D * H * W * C, 1, H * W * C, W * C, C)
+
+
+def grid_to_channels_last(grid):
+    """[B,C,D,H,W] contiguous -> tensor of the SAME shape whose memory is
+    [B,D,H,W,C] (torch.channels_last_3d), via vt_grid_to_channels_last."""
+    if is_channels_last_grid(grid):
+        return grid
+    g = grid.detach()
+    if not g.is_contiguous():
+        g = g.contiguous()
+    B, C, D, H, W = g.shape
+    out = torch.empty((B, D, H, W, C), dtype=torch.float32, device=g.device)
+    check(_lib.load().vt_grid_to_channels_last(dev_ptr(g, "grid"), dev_ptr(out, "grid_cl"), B, C, D, H, W, stream_ptr()),
+          "vt_grid_to_channels_last")
+    return out.permute(0, 4, 1, 2, 3)
+
+
+def grid_from_channels_last(grid_cl):
+    """Inverse of :func:`grid_to_channels_last`: returns a contiguous NCDHW tensor."""
+    B, C, D, H, W = grid_cl.shape
+    if not is_channels_last_grid(grid_cl):
+        raise VtError("grid_from_channels_last: input is not channels-last")
+    out = torch.empty((B, C, D, H, W), dtype=torch.float32, device=grid_cl.device)
+    src = grid_cl.permute(0, 2, 3, 4, 1)
+    check(_lib.load().vt_grid_from_channels_last(dev_ptr(src, "grid_cl"), dev_ptr(out, "grid"), B, C, D, H, W, stream_ptr()),
+          "vt_grid_from_channels_last")
+    return out
+
+
+def _cl_storage(grid):
+    """Device pointer of the channels-last storage of a [B,C,R,R,R] grid."""
+    g = grid_to_channels_last(grid)
+    return g, dev_ptr(g.permute(0, 2, 3, 4, 1), "grid")
+
+
+def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want_contact=False, out=None):
+    """Fused trilinear gather + conditioned MLP (vt_decode_fwd).
+
+    grid  [B,C,R,R,R] (any layout; converted to channels-last if needed)
+    pts   [B,N,3] or None with lattice=(nx, box, first, count)
+    c_img [B,N,C] or None.  Returns logits [B,N] (and contact logits).
+    """
+    lib = _lib.load()
+    B, C, D, H, W = grid.shape
+    if not (D == H == W):
+        raise VtError("feature grid must be cubic")
+    keep, gptr = _cl_storage(grid)
+    if pts is not None:
+        pts = pts.detach().float()
+        if not pts.is_contiguous():
+            pts = pts.contiguous()
+        if pts.shape[0] != B or pts.shape[-1] != 3:
+            raise VtError(f"pts must be [B,N,3] with B={B} (got {tuple(pts.shape)})")
+        N = pts.shape[1]
+        nx, box, first = 0, 0.0, 0
+    else:
+        nx, box, first, N = lattice
+    if c_img is not None:
+        c_img = c_img.detach()
+        if not c_img.is_contiguous():
+            c_img = c_img.contiguous()
+        if tuple(c_img.shape) != (B, N, C):
+            raise VtError(f"c_img must be [B,N,C]=({B},{N},{C}) (got {tuple(c_img.shape)})")
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.float32, device=grid.device)
+    out2 = torch.empty((B, N), dtype=torch.float32, device=grid.device) if want_contact else None
+    check(lib.vt_decode_fwd(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first,
+                            dev_ptr(c_img, "c_img"), dev_ptr(blob, "blob"), float(padding),
+                            dev_ptr(out, "out"), dev_ptr(out2, "out2"), stream_ptr()), "vt_decode_fwd")
+    return (out, out2) if want_contact else out
