@@ -36,7 +36,9 @@ def cpu_baseline(sd, grid_cpu, nx, budget_s=15.0):
     """The oracle (a port, not the reference itself) timed on the host cores on a
     bounded sample: whole 100k-point chunks of the same lattice until ~budget_s."""
     from oracle import vtaco_oracle as orc
-    torch.set_num_threads(os.cpu_count() or 1)
+    # torch's CPU kernels on 100k x 32 operands stop scaling (and then collapse) beyond a few
+    # tens of threads; use what the host has, capped at 32, and report that number as `cores`
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     pts = 1.1 * orc.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)
     chunks = torch.split(pts, 100000)
     orc.local_decoder_forward(sd, chunks[0][:1000].unsqueeze(0), grid_cpu)   # warm

@@ -29,11 +29,12 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// max(x,0) as ONE v_max_f32 (fmaxf on an MFMA result costs a canonicalising second max)
+// max(x,0) as ONE instruction (v_med3_f32 x, 0, +inf).  fmaxf() on an MFMA result costs a
+// second, canonicalising v_max; inline asm is not an option: hipcc inserts the MFMA->VALU
+// wait states only for instructions it can see, and a hand-written v_max read stale
+// accumulators (measured: 6e-2 logit error).
 __device__ __forceinline__ float relu1(float x) {
-    float y;
-    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-    return y;
+    return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff());
 }
 
 // Force the 16 values to exist in VGPRs here (stops LLVM sinking the FMAs that produce

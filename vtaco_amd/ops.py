@@ -132,6 +132,8 @@ def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want
     if out is None:
         out = torch.empty((B, N), dtype=torch.float32, device=grid.device)
     out2 = torch.empty((B, N), dtype=torch.float32, device=grid.device) if want_contact else None
+    if N == 0:                                   # empty query set: nothing to launch
+        return (out, out2) if want_contact else out
     check(lib.vt_decode_fwd(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first,
                             dev_ptr(c_img, "c_img"), dev_ptr(blob, "blob"), float(padding),
                             dev_ptr(out, "out"), dev_ptr(out2, "out2"), stream_ptr()), "vt_decode_fwd")
