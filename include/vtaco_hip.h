@@ -100,6 +100,30 @@ int vt_decode_fwd(const float *grid_cl, int B, int R, int C,
                   const float *c_img, const float *blob, double padding,
                   float *out, float *out2, void *stream);
 
+/* ------------------------------------------------------------------------- */
+/* Marching cubes (Lewiner), vertex numbering identical to scikit-image's.      */
+/* Replaces: skimage.measure.marching_cubes(value_grid,                         */
+/*   gradient_direction='ascent') + the rescale `v -= nx/2; v *= 1.1/nx`        */
+/*   (src/conv_onet/generation.py:268-272; src/conv_onet/inferencing.py:172-179).*/
+/*                                                                             */
+/* Two phases, because the output size is data dependent:                       */
+/*   vt_mc_count  classifies the cells and scans the counts into `workspace`;   */
+/*   vt_mc_read_counts copies {nverts, nfaces, level} to the host (this one      */
+/*                SYNCHRONISES the stream -- skip it when capacities are known); */
+/*   vt_mc_emit   writes verts [nverts,3] f32 (array-axis order, like skimage)   */
+/*                and faces [nfaces,3] i32; entries beyond the capacities are    */
+/*                dropped.  rescale != 0 applies (v - shift) * scale in f32.     */
+/* vol is [n0,n1,n2] f32; auto_level != 0 uses skimage's default                */
+/* 0.5*(min+max) instead of `level`.  workspace: vt_mc_workspace_bytes().       */
+/* ------------------------------------------------------------------------- */
+size_t vt_mc_workspace_bytes(int n0, int n1, int n2);
+int vt_mc_count(const float *vol, int n0, int n1, int n2, double level, int auto_level,
+                void *workspace, size_t workspace_bytes, void *stream);
+int vt_mc_read_counts(const void *workspace, int *nverts_host, int *nfaces_host, double *level_host, void *stream);
+int vt_mc_emit(const float *vol, int n0, int n1, int n2, void *workspace,
+               float *verts, int max_verts, int *faces, int max_faces,
+               int rescale, float shift, float scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

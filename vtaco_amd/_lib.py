@@ -49,6 +49,10 @@ SIGNATURES = {
     "vt_grid_to_channels_last": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "vt_grid_from_channels_last": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "vt_decode_fwd": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _D, _VP, _VP, _VP]),
+    "vt_mc_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "vt_mc_count": (_I, [_VP, _I, _I, _I, _D, _I, _VP, _SZ, _VP]),
+    "vt_mc_read_counts": (_I, [_VP, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_D), _VP]),
+    "vt_mc_emit": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _VP, _I, _I, _F, _F, _VP]),
 }
 
 _lib = None

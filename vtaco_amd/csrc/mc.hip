@@ -1,0 +1,538 @@
+// Marching cubes (Lewiner / "MC33") on gfx950, output identical -- vertex numbering
+// included -- to what the reference gets from
+//     skimage.measure.marching_cubes(value_grid, gradient_direction='ascent')
+// (reference src/conv_onet/generation.py:268-273; scikit-image's Lewiner port).
+//
+// scikit-image sweeps the cells sequentially (array axis 0 outermost, axis 2
+// innermost) and numbers a vertex the first time a triangle refers to it.  Every
+// vertex sits on a grid edge (or is a cell's centre vertex), and every cell that
+// touches a sign-changing edge uses it, so the first user of an edge is its
+// lexicographically smallest adjacent cell: the edge's OWNER.  That turns the
+// sequential numbering into a scan:
+//   vertex id = (# vertices owned by earlier cells) + rank of the edge among the
+//               owner's owned edges in the owner's triangle-list order.
+// Pipeline (all on the caller's stream, no host round trip inside):
+//   minmax    -> iso level 0.5*(min+max) when the caller asks for skimage's default
+//   classify  -> per cell: Lewiner case/sub-case (face + interior tests in f64),
+//                triangle-list offset, #triangles, owned-edge ranks; per-block sums
+//   scan      -> exclusive offsets of the block sums, totals
+//   vertices  -> owners write their vertices (inverse-|value| weighted, f64 -> f32)
+//   faces     -> every triangle corner resolves (owner cell, owner-local edge) -> id
+// HBM-class kernels, latency-dominated at 128^3 (8.4 MB volume).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vt_common.h"
+
+#define MC_TABLE_QUALIFIER __device__ const
+#include "mc_tables.inc"
+
+namespace {
+
+constexpr double MC_EPS = 2.220446049250313e-16;   // skimage's "FLT_EPSILON" = np.spacing(1.0)
+constexpr int CELLS_PER_BLOCK = 256;
+
+struct McHeader {
+    unsigned min_key;      // ordered key of the minimum (atomicMin)
+    unsigned max_key_inv;  // ~ordered key of the maximum (atomicMin)
+    int nverts;
+    int nfaces;
+    double level;
+    int reserved[10];
+};
+static_assert(sizeof(McHeader) == 64, "header is 64 bytes");
+
+struct McDims {
+    int n0, n1, n2;        // volume extents (axis 0,1,2); x runs along axis 2
+    int c1, c2;            // cells along axis 1 and 2
+    unsigned ncells;
+};
+
+struct McWs {
+    McHeader *hdr;
+    uint16_t *cnt;         // ntri | nnew << 8
+    uint32_t *desc;        // offset of the cell's triangle list in MC_LUT (active cells only)
+    uint64_t *rank;        // 13 nibbles: 1 + rank of owned edge e (0 = not owned / unused)
+    uint32_t *vbase;       // first vertex id owned by the cell (active cells only)
+    uint2 *bsum;           // per block (tri, vert) sums
+    uint2 *boff;           // per block exclusive offsets
+};
+
+__device__ __forceinline__ unsigned ordered_key(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(unsigned k) {
+    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+__global__ void __launch_bounds__(256) mc_minmax_kernel(const float *vol, size_t n, McHeader *hdr) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = vol[i];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&hdr->min_key, ordered_key(lo));
+        atomicMin(&hdr->max_key_inv, ~ordered_key(hi));
+    }
+}
+
+__device__ __forceinline__ double iso_level(const McHeader *hdr, double level, int auto_level) {
+    if (!auto_level) return level;
+    // skimage: 0.5 * (volume.min() + volume.max()), the sum rounded in float32
+    const float lo = key_to_float(hdr->min_key), hi = key_to_float(~hdr->max_key_inv);
+    return 0.5 * (double)(lo + hi);
+}
+
+// corner k -> (dx,dy,dz), Lewiner order
+__device__ __forceinline__ int cx(int k) { return (0x66 >> k) & 1; }   // 0,1,1,0,0,1,1,0
+__device__ __forceinline__ int cy(int k) { return (0xCC >> k) & 1; }   // 0,0,1,1,0,0,1,1
+__device__ __forceinline__ int cz(int k) { return k >> 2; }
+
+__device__ __forceinline__ void load_cell(const float *vol, const McDims &d, int x, int y, int z, double level, double v[8]) {
+    const size_t s1 = (size_t)d.n2, s0 = (size_t)d.n1 * d.n2;
+    const float *p = vol + (size_t)z * s0 + (size_t)y * s1 + x;
+    v[0] = (double)p[0] - level;          v[1] = (double)p[1] - level;
+    v[3] = (double)p[s1] - level;         v[2] = (double)p[s1 + 1] - level;
+    v[4] = (double)p[s0] - level;         v[5] = (double)p[s0 + 1] - level;
+    v[7] = (double)p[s0 + s1] - level;    v[6] = (double)p[s0 + s1 + 1] - level;
+}
+
+// select v[k] with a runtime k without sending the array to scratch
+__device__ __forceinline__ double pick(const double v[8], int k) {
+    double r = v[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) r = (k == i) ? v[i] : r;
+    return r;
+}
+
+__device__ bool test_face(const double v[8], int face) {
+    const int f = face < 0 ? -face : face;
+    // corners (A,B,C,D) of faces 1..6, packed 3 bits each
+    const unsigned tab[7] = {0, 0 | 4 << 3 | 5 << 6 | 1 << 9, 1 | 5 << 3 | 6 << 6 | 2 << 9, 2 | 6 << 3 | 7 << 6 | 3 << 9,
+                             3 | 7 << 3 | 4 << 6 | 0 << 9, 0 | 3 << 3 | 2 << 6 | 1 << 9, 4 | 7 << 3 | 6 << 6 | 5 << 9};
+    const unsigned t = tab[f];
+    const double A = pick(v, t & 7), B = pick(v, (t >> 3) & 7), C = pick(v, (t >> 6) & 7), D = pick(v, (t >> 9) & 7);
+    const double acbd = A * C - B * D;
+    if (fabs(acbd) < MC_EPS) return face >= 0;
+    return face * A * acbd >= 0;
+}
+
+__device__ bool test_interior(const double v[8], int mc_case, int edge, int s) {
+    double t, At = 0, Bt = 0, Ct = 0, Dt = 0;
+    if (mc_case == 4 || mc_case == 10) {
+        const double a = (v[4] - v[0]) * (v[6] - v[2]) - (v[7] - v[3]) * (v[5] - v[1]);
+        const double b = v[2] * (v[4] - v[0]) + v[0] * (v[6] - v[2]) - v[1] * (v[7] - v[3]) - v[3] * (v[5] - v[1]);
+        t = -b / (2 * a + MC_EPS);
+        if (t < 0 || t > 1) return s > 0;
+        At = v[0] + (v[4] - v[0]) * t;
+        Bt = v[3] + (v[7] - v[3]) * t;
+        Ct = v[2] + (v[6] - v[2]) * t;
+        Dt = v[1] + (v[5] - v[1]) * t;
+    } else {
+        if (edge < 0 || edge > 11) return s < 0;
+        // reference edge P->Q and the three parallel edges B0->B1, C0->C1, D0->D1 (3 bits each)
+        const unsigned char Pt[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3};
+        const unsigned char Qt[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
+        const unsigned char B0[12] = {3, 0, 1, 2, 7, 4, 5, 6, 3, 0, 1, 2};
+        const unsigned char B1[12] = {2, 3, 0, 1, 6, 7, 4, 5, 7, 4, 5, 6};
+        const unsigned char C0[12] = {7, 4, 5, 6, 3, 0, 1, 2, 2, 3, 0, 1};
+        const unsigned char C1[12] = {6, 7, 4, 5, 2, 3, 0, 1, 6, 7, 4, 5};
+        const unsigned char D0[12] = {4, 5, 6, 7, 0, 1, 2, 3, 1, 2, 3, 0};
+        const unsigned char D1[12] = {5, 6, 7, 4, 1, 2, 3, 0, 5, 6, 7, 4};
+        const double vp = pick(v, Pt[edge]), vq = pick(v, Qt[edge]);
+        t = vp / (vp - vq + MC_EPS);
+        const double b0 = pick(v, B0[edge]), c0 = pick(v, C0[edge]), d0 = pick(v, D0[edge]);
+        Bt = b0 + (pick(v, B1[edge]) - b0) * t;
+        Ct = c0 + (pick(v, C1[edge]) - c0) * t;
+        Dt = d0 + (pick(v, D1[edge]) - d0) * t;
+    }
+    int test = 0;
+    if (At >= 0) test += 1;
+    if (Bt >= 0) test += 2;
+    if (Ct >= 0) test += 4;
+    if (Dt >= 0) test += 8;
+    switch (test) {
+        case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 12: return s > 0;
+        case 5: if (At * Ct - Bt * Dt < MC_EPS) return s > 0; break;
+        case 10: if (At * Ct - Bt * Dt >= MC_EPS) return s > 0; break;
+        case 7: case 11: case 13: case 14: case 15: return s < 0;
+    }
+    return false;   // scikit-image's answer for the two undecided patterns (see oracle/mc_lewiner.c)
+}
+
+#define OFF(name, cfg) (MC_OFF_##name + (cfg) * MC_ROW_##name)
+#define OFF2(name, cfg, sub, len) (MC_OFF_##name + (cfg) * MC_ROW_##name + (sub) * (len))
+#define TST(name, cfg, j) ((int)MC_LUT[MC_OFF_##name + (cfg) * MC_ROW_##name + (j)])
+
+// Lewiner's case analysis: returns the offset of the triangle list in MC_LUT, sets ntri.
+__device__ int classify_cell(const double v[8], int index, int &ntri) {
+    const int cs = MC_LUT[MC_OFF_CASES + 2 * index], cf = MC_LUT[MC_OFF_CASES + 2 * index + 1];
+    int sub = 0;
+    switch (cs) {
+        case 1: ntri = 1; return OFF(TILING1, cf);
+        case 2: ntri = 2; return OFF(TILING2, cf);
+        case 3:
+            if (test_face(v, TST(TEST3, cf, 0))) { ntri = 4; return OFF(TILING3_2, cf); }
+            ntri = 2; return OFF(TILING3_1, cf);
+        case 4:
+            if (test_interior(v, 4, -1, TST(TEST4, cf, 0))) { ntri = 2; return OFF(TILING4_1, cf); }
+            ntri = 6; return OFF(TILING4_2, cf);
+        case 5: ntri = 3; return OFF(TILING5, cf);
+        case 6:
+            if (test_face(v, TST(TEST6, cf, 0))) { ntri = 5; return OFF(TILING6_2, cf); }
+            if (test_interior(v, 6, TST(TEST6, cf, 2), TST(TEST6, cf, 1))) { ntri = 3; return OFF(TILING6_1_1, cf); }
+            ntri = 9; return OFF(TILING6_1_2, cf);
+        case 7:
+            if (test_face(v, TST(TEST7, cf, 0))) sub += 1;
+            if (test_face(v, TST(TEST7, cf, 1))) sub += 2;
+            if (test_face(v, TST(TEST7, cf, 2))) sub += 4;
+            switch (sub) {
+                case 0: ntri = 3; return OFF(TILING7_1, cf);
+                case 1: ntri = 5; return OFF2(TILING7_2, cf, 0, 15);
+                case 2: ntri = 5; return OFF2(TILING7_2, cf, 1, 15);
+                case 3: ntri = 9; return OFF2(TILING7_3, cf, 0, 27);
+                case 4: ntri = 5; return OFF2(TILING7_2, cf, 2, 15);
+                case 5: ntri = 9; return OFF2(TILING7_3, cf, 1, 27);
+                case 6: ntri = 9; return OFF2(TILING7_3, cf, 2, 27);
+                default:
+                    if (test_interior(v, 7, TST(TEST7, cf, 4), TST(TEST7, cf, 3))) { ntri = 9; return OFF(TILING7_4_2, cf); }
+                    ntri = 5; return OFF(TILING7_4_1, cf);
+            }
+        case 8: ntri = 2; return OFF(TILING8, cf);
+        case 9: ntri = 4; return OFF(TILING9, cf);
+        case 10:
+            if (test_face(v, TST(TEST10, cf, 0))) {
+                if (test_face(v, TST(TEST10, cf, 1))) { ntri = 4; return OFF(TILING10_1_1_, cf); }
+                ntri = 8; return OFF(TILING10_2, cf);
+            }
+            if (test_face(v, TST(TEST10, cf, 1))) { ntri = 8; return OFF(TILING10_2_, cf); }
+            if (test_interior(v, 10, -1, TST(TEST10, cf, 2))) { ntri = 4; return OFF(TILING10_1_1, cf); }
+            ntri = 8; return OFF(TILING10_1_2, cf);
+        case 11: ntri = 4; return OFF(TILING11, cf);
+        case 12:
+            if (test_face(v, TST(TEST12, cf, 0))) {
+                if (test_face(v, TST(TEST12, cf, 1))) { ntri = 4; return OFF(TILING12_1_1_, cf); }
+                ntri = 8; return OFF(TILING12_2, cf);
+            }
+            if (test_face(v, TST(TEST12, cf, 1))) { ntri = 8; return OFF(TILING12_2_, cf); }
+            if (test_interior(v, 12, TST(TEST12, cf, 3), TST(TEST12, cf, 2))) { ntri = 4; return OFF(TILING12_1_1, cf); }
+            ntri = 8; return OFF(TILING12_1_2, cf);
+        case 13: {
+            for (int k = 0; k < 6; ++k)
+                if (test_face(v, TST(TEST13, cf, k))) sub += 1 << k;
+            const int sc = MC_LUT[MC_OFF_SUBCONFIG13 + sub];
+            if (sc == 0) { ntri = 4; return OFF(TILING13_1, cf); }
+            if (sc <= 6) { ntri = 6; return OFF2(TILING13_2, cf, sc - 1, 18); }
+            if (sc <= 18) { ntri = 10; return OFF2(TILING13_3, cf, sc - 7, 30); }
+            if (sc <= 22) { ntri = 12; return OFF2(TILING13_4, cf, sc - 19, 36); }
+            if (sc <= 26) {
+                const int e = MC_LUT[OFF2(TILING13_5_1, cf, sc - 23, 18)];
+                if (test_interior(v, 13, e, TST(TEST13, cf, 6))) { ntri = 6; return OFF2(TILING13_5_1, cf, sc - 23, 18); }
+                ntri = 10; return OFF2(TILING13_5_2, cf, sc - 23, 30);
+            }
+            if (sc <= 38) { ntri = 10; return OFF2(TILING13_3_, cf, sc - 27, 30); }
+            if (sc <= 44) { ntri = 6; return OFF2(TILING13_2_, cf, sc - 39, 18); }
+            if (sc == 45) { ntri = 4; return OFF(TILING13_1_, cf); }
+            ntri = 0; return 0;
+        }
+        case 14: ntri = 4; return OFF(TILING14, cf);
+        default: ntri = 0; return 0;
+    }
+}
+
+// which of the 13 vertex slots (12 edges + centre) a cell owns: it is the first cell of the
+// sweep that touches the edge
+__device__ __forceinline__ unsigned own_mask(int x, int y, int z) {
+    const unsigned X = x == 0, Y = y == 0, Z = z == 0;
+    unsigned m = (1u << 6) | (1u << 5) | (1u << 10) | (1u << 12);
+    m |= (Y & Z) << 0; m |= Z << 2; m |= Y << 4;          // x-edges 0,2,4 (6 always)
+    m |= (X & Z) << 3; m |= Z << 1; m |= X << 7;          // y-edges 3,1,7 (5 always)
+    m |= (X & Y) << 8; m |= Y << 9; m |= X << 11;         // z-edges 8,9,11 (10 always)
+    return m;
+}
+
+__device__ __forceinline__ void cell_xyz(unsigned c, const McDims &d, int &x, int &y, int &z) {
+    const unsigned t = c / (unsigned)d.c2;
+    x = (int)(c - t * (unsigned)d.c2);
+    z = (int)(t / (unsigned)d.c1);
+    y = (int)(t - (unsigned)z * (unsigned)d.c1);
+}
+
+// block-wide exclusive scan of (a,b) pairs over 256 threads; returns exclusive prefix, totals in tot
+__device__ __forceinline__ uint2 block_exscan(unsigned a, unsigned b, uint2 *lds /*[4]*/, uint2 &tot) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned ia = a, ib = b;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned ta = __shfl_up(ia, o), tb = __shfl_up(ib, o);
+        if (lane >= o) { ia += ta; ib += tb; }
+    }
+    if (lane == 63) lds[w] = make_uint2(ia, ib);
+    __syncthreads();
+    unsigned oa = 0, ob = 0, sa = 0, sb = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (i < w) { oa += lds[i].x; ob += lds[i].y; }
+        sa += lds[i].x; sb += lds[i].y;
+    }
+    tot = make_uint2(sa, sb);
+    __syncthreads();
+    return make_uint2(oa + ia - a, ob + ib - b);
+}
+
+__global__ void __launch_bounds__(CELLS_PER_BLOCK)
+mc_classify_kernel(const float *vol, McDims d, McWs ws, double level_in, int auto_level) {
+    __shared__ uint2 red[4];
+    const unsigned c = blockIdx.x * CELLS_PER_BLOCK + threadIdx.x;
+    unsigned ntri = 0, nnew = 0;
+    if (c < d.ncells) {
+        const double level = iso_level(ws.hdr, level_in, auto_level);
+        int x, y, z;
+        cell_xyz(c, d, x, y, z);
+        double v[8];
+        load_cell(vol, d, x, y, z, level, v);
+        int index = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) index |= (v[k] > 0.0) << k;
+        if (index != 0 && index != 255) {
+            int nt = 0;
+            const int off = classify_cell(v, index, nt);
+            const unsigned own = own_mask(x, y, z);
+            unsigned seen = 0;
+            uint64_t rk = 0;
+            for (int i = 0; i < 3 * nt; ++i) {
+                const int e = MC_LUT[off + i];
+                if (!((seen >> e) & 1u)) {
+                    seen |= 1u << e;
+                    if ((own >> e) & 1u) { ++nnew; rk |= (uint64_t)nnew << (4 * e); }
+                }
+            }
+            ntri = (unsigned)nt;
+            ws.desc[c] = (uint32_t)off;
+            ws.rank[c] = rk;
+        }
+        ws.cnt[c] = (uint16_t)(ntri | (nnew << 8));
+    }
+    uint2 tot;
+    block_exscan(ntri, nnew, red, tot);
+    if (threadIdx.x == 0) ws.bsum[blockIdx.x] = tot;
+    if (c == 0) ws.hdr->level = iso_level(ws.hdr, level_in, auto_level);
+}
+
+// one block: exclusive scan of the per-block sums
+__global__ void __launch_bounds__(1024) mc_scan_kernel(McWs ws, unsigned nblk) {
+    __shared__ uint2 part[1024];
+    const unsigned per = (nblk + 1023) / 1024;
+    const unsigned lo = threadIdx.x * per, hi = min(lo + per, nblk);
+    unsigned a = 0, b = 0;
+    for (unsigned i = lo; i < hi; ++i) { a += ws.bsum[i].x; b += ws.bsum[i].y; }
+    part[threadIdx.x] = make_uint2(a, b);
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (int o = 1; o < 1024; o <<= 1) {
+        uint2 t = make_uint2(0, 0);
+        if ((int)threadIdx.x >= o) t = part[threadIdx.x - o];
+        __syncthreads();
+        part[threadIdx.x].x += t.x; part[threadIdx.x].y += t.y;
+        __syncthreads();
+    }
+    unsigned ra = part[threadIdx.x].x - a, rb = part[threadIdx.x].y - b;
+    for (unsigned i = lo; i < hi; ++i) {
+        const uint2 s = ws.bsum[i];
+        ws.boff[i] = make_uint2(ra, rb);
+        ra += s.x; rb += s.y;
+    }
+    if (threadIdx.x == 1023) { ws.hdr->nfaces = (int)part[1023].x; ws.hdr->nverts = (int)part[1023].y; }
+}
+
+struct McOut {
+    float *verts; int max_verts;
+    int *faces; int max_faces;
+    int rescale; float shift, scale;
+};
+
+__global__ void __launch_bounds__(CELLS_PER_BLOCK)
+mc_vertices_kernel(const float *vol, McDims d, McWs ws, McOut o) {
+    __shared__ uint2 red[4];
+    const unsigned c = blockIdx.x * CELLS_PER_BLOCK + threadIdx.x;
+    const unsigned cn = (c < d.ncells) ? ws.cnt[c] : 0;
+    uint2 tot;
+    const uint2 pre = block_exscan(cn & 0xff, cn >> 8, red, tot);
+    if (!cn) return;
+    const unsigned vb = ws.boff[blockIdx.x].y + pre.y;
+    ws.vbase[c] = vb;
+    if (!(cn >> 8)) return;
+    const double level = ws.hdr->level;
+    int x, y, z;
+    cell_xyz(c, d, x, y, z);
+    double v[8];
+    load_cell(vol, d, x, y, z, level, v);
+    const uint64_t rk = ws.rank[c];
+    for (int e = 0; e < 13; ++e) {
+        const unsigned nib = (unsigned)(rk >> (4 * e)) & 15u;
+        if (!nib) continue;
+        double fx = 0, fy = 0, fz = 0, ff = 0;
+        if (e == 12) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double w = 1.0 / (MC_EPS + fabs(v[k]));
+                fx += cx(k) * w; fy += cy(k) * w; fz += cz(k) * w; ff += w;
+            }
+        } else {
+            const int a = (e < 8) ? e : e - 8;                       // E0
+            const int b = (e < 8) ? ((e & 4) | ((e + 1) & 3)) : e - 4;  // E1
+            const double wa = 1.0 / (MC_EPS + fabs(pick(v, a)));
+            const double wb = 1.0 / (MC_EPS + fabs(pick(v, b)));
+            fx += cx(a) * wa; fy += cy(a) * wa; fz += cz(a) * wa; ff += wa;
+            fx += cx(b) * wb; fy += cy(b) * wb; fz += cz(b) * wb; ff += wb;
+        }
+        const unsigned vid = vb + nib - 1;
+        if (vid < (unsigned)o.max_verts) {
+            // array-axis order (axis0, axis1, axis2) = (z, y, x), as skimage returns
+            float p0 = (float)((double)z + fz / ff), p1 = (float)((double)y + fy / ff), p2 = (float)((double)x + fx / ff);
+            if (o.rescale) { p0 = (p0 - o.shift) * o.scale; p1 = (p1 - o.shift) * o.scale; p2 = (p2 - o.shift) * o.scale; }
+            float *dst = o.verts + (size_t)vid * 3;
+            dst[0] = p0; dst[1] = p1; dst[2] = p2;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(CELLS_PER_BLOCK)
+mc_faces_kernel(McDims d, McWs ws, McOut o) {
+    __shared__ uint2 red[4];
+    const unsigned c = blockIdx.x * CELLS_PER_BLOCK + threadIdx.x;
+    const unsigned cn = (c < d.ncells) ? ws.cnt[c] : 0;
+    uint2 tot;
+    const uint2 pre = block_exscan(cn & 0xff, cn >> 8, red, tot);
+    const unsigned nt = cn & 0xff;
+    if (!nt) return;
+    const unsigned tb = ws.boff[blockIdx.x].x + pre.x;
+    int x, y, z;
+    cell_xyz(c, d, x, y, z);
+    const unsigned off = ws.desc[c];
+    for (unsigned i = 0; i < 3 * nt; ++i) {
+        const int e = MC_LUT[off + i];
+        int ox = x, oy = y, oz = z, el = 12;
+        if (e < 12) {
+            // edge base point relative to the cell, and direction
+            const int dir = (e >= 8) ? 2 : (e & 1);                 // 0: x, 1: y, 2: z
+            int bx, by, bz;
+            if (e >= 8) { const int k = e - 8; bx = (k == 1) | (k == 2); by = (k >> 1) & 1; bz = 0; }
+            else { const int k = e & 3; bx = (k == 1); by = (k == 2); bz = e >> 2; }
+            const int gx = x + bx, gy = y + by, gz = z + bz;
+            if (dir == 0) {
+                ox = gx; oy = max(gy - 1, 0); oz = max(gz - 1, 0);
+                el = 2 * (gy - oy) + 4 * (gz - oz);                  // 0,2,4,6
+            } else if (dir == 1) {
+                ox = max(gx - 1, 0); oy = gy; oz = max(gz - 1, 0);
+                const int dx = gx - ox, dz = gz - oz;
+                el = (dx ? 1 : 3) + 4 * dz;                          // 3,1,7,5
+            } else {
+                ox = max(gx - 1, 0); oy = max(gy - 1, 0); oz = gz;
+                const int dx = gx - ox, dy = gy - oy;
+                el = 8 + (dy ? (dx ? 2 : 3) : dx);                   // 8,9,11,10
+            }
+        }
+        const unsigned oc = ((unsigned)oz * (unsigned)d.c1 + (unsigned)oy) * (unsigned)d.c2 + (unsigned)ox;
+        const unsigned nib = (unsigned)(ws.rank[oc] >> (4 * el)) & 15u;
+        const unsigned vid = ws.vbase[oc] + nib - 1;
+        const size_t fi = (size_t)tb * 3 + i;
+        if (fi < (size_t)o.max_faces * 3) o.faces[fi] = (int)vid;
+    }
+}
+
+__host__ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+__host__ bool mc_layout(int n0, int n1, int n2, McDims &d, size_t off[8], size_t &total, unsigned &nblk) {
+    if (n0 < 2 || n1 < 2 || n2 < 2) return false;
+    const uint64_t nc = (uint64_t)(n0 - 1) * (n1 - 1) * (n2 - 1);
+    if (nc >= (1ull << 31)) return false;
+    d.n0 = n0; d.n1 = n1; d.n2 = n2; d.c1 = n1 - 1; d.c2 = n2 - 1; d.ncells = (unsigned)nc;
+    nblk = (unsigned)((nc + CELLS_PER_BLOCK - 1) / CELLS_PER_BLOCK);
+    size_t p = 0;
+    off[0] = p; p = align_up(p + sizeof(McHeader), 256);
+    off[1] = p; p = align_up(p + nc * sizeof(uint16_t), 256);
+    off[2] = p; p = align_up(p + nc * sizeof(uint32_t), 256);
+    off[3] = p; p = align_up(p + nc * sizeof(uint64_t), 256);
+    off[4] = p; p = align_up(p + nc * sizeof(uint32_t), 256);
+    off[5] = p; p = align_up(p + (size_t)nblk * sizeof(uint2), 256);
+    off[6] = p; p = align_up(p + (size_t)nblk * sizeof(uint2), 256);
+    total = p;
+    return true;
+}
+
+__host__ McWs mc_ws(void *base, const size_t off[8]) {
+    char *b = (char *)base;
+    McWs w;
+    w.hdr = (McHeader *)(b + off[0]); w.cnt = (uint16_t *)(b + off[1]); w.desc = (uint32_t *)(b + off[2]);
+    w.rank = (uint64_t *)(b + off[3]); w.vbase = (uint32_t *)(b + off[4]);
+    w.bsum = (uint2 *)(b + off[5]); w.boff = (uint2 *)(b + off[6]);
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vt_mc_workspace_bytes(int n0, int n1, int n2) {
+    McDims d; size_t off[8], total; unsigned nblk;
+    if (!mc_layout(n0, n1, n2, d, off, total, nblk)) return 0;
+    return total;
+}
+
+int vt_mc_count(const float *vol, int n0, int n1, int n2, double level, int auto_level,
+                void *workspace, size_t workspace_bytes, void *stream) {
+    if (!vol || !workspace) return vt_fail(VT_ERR_INVALID, "vt_mc_count: null argument");
+    McDims d; size_t off[8], total; unsigned nblk;
+    if (!mc_layout(n0, n1, n2, d, off, total, nblk))
+        return vt_fail(VT_ERR_INVALID, "vt_mc_count: volume must be at least 2x2x2 (and < 2^31 cells)");
+    if (workspace_bytes < total) return vt_fail(VT_ERR_WORKSPACE, "vt_mc_count: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    McWs ws = mc_ws(workspace, off);
+    hipError_t e = hipMemsetAsync(ws.hdr, 0xFF, 8, s);
+    if (e != hipSuccess) return vt_check(e, "vt_mc_count: memset");
+    if (auto_level) {
+        const size_t n = (size_t)n0 * n1 * n2;
+        unsigned g = (unsigned)((n + 256 * 8 - 1) / (256 * 8));
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(mc_minmax_kernel, dim3(g), dim3(256), 0, s, vol, n, ws.hdr);
+    }
+    hipLaunchKernelGGL(mc_classify_kernel, dim3(nblk), dim3(CELLS_PER_BLOCK), 0, s, vol, d, ws, level, auto_level);
+    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, s, ws, nblk);
+    return vt_check(hipGetLastError(), "vt_mc_count");
+}
+
+int vt_mc_read_counts(const void *workspace, int *nverts_host, int *nfaces_host, double *level_host, void *stream) {
+    if (!workspace || !nverts_host || !nfaces_host) return vt_fail(VT_ERR_INVALID, "vt_mc_read_counts: null argument");
+    McHeader h;
+    hipError_t e = hipMemcpyAsync(&h, workspace, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return vt_check(e, "vt_mc_read_counts");
+    *nverts_host = h.nverts; *nfaces_host = h.nfaces;
+    if (level_host) *level_host = h.level;
+    return 0;
+}
+
+int vt_mc_emit(const float *vol, int n0, int n1, int n2, void *workspace,
+               float *verts, int max_verts, int *faces, int max_faces,
+               int rescale, float shift, float scale, void *stream) {
+    if (!vol || !workspace || !verts || !faces) return vt_fail(VT_ERR_INVALID, "vt_mc_emit: null argument");
+    if (max_verts < 0 || max_faces < 0) return vt_fail(VT_ERR_INVALID, "vt_mc_emit: negative capacity");
+    McDims d; size_t off[8], total; unsigned nblk;
+    if (!mc_layout(n0, n1, n2, d, off, total, nblk)) return vt_fail(VT_ERR_INVALID, "vt_mc_emit: bad volume shape");
+    McWs ws = mc_ws(workspace, off);
+    McOut o; o.verts = verts; o.max_verts = max_verts; o.faces = faces; o.max_faces = max_faces;
+    o.rescale = rescale; o.shift = shift; o.scale = scale;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mc_vertices_kernel, dim3(nblk), dim3(CELLS_PER_BLOCK), 0, s, vol, d, ws, o);
+    hipLaunchKernelGGL(mc_faces_kernel, dim3(nblk), dim3(CELLS_PER_BLOCK), 0, s, d, ws, o);
+    return vt_check(hipGetLastError(), "vt_mc_emit");
+}
+
+}  // extern "C"
