@@ -124,6 +124,33 @@ int vt_mc_emit(const float *vol, int n0, int n1, int n2, void *workspace,
                float *verts, int max_verts, int *faces, int max_faces,
                int rescale, float shift, float scale, void *stream);
 
+/* ------------------------------------------------------------------------- */
+/* PointNet local-pool voxeliser.                                              */
+/* Replaces: normalize_3d_coordinate + coordinate2index (src/common.py:293-309, */
+/*   333-348; call site src/encoder/pointnet.py:151-152), torch_scatter          */
+/*   scatter_max + gather in pool_local (pointnet.py:116-132) and scatter_mean   */
+/*   in generate_grid_features (pointnet.py:102-110), and their autograd.        */
+/*                                                                             */
+/* vt_voxel_build runs once per forward: idx[b,t] = ix + R*(iy + R*iz) (bit-exact */
+/* with the reference's f32 maths), order[b,j] = point ids sorted by (voxel,      */
+/* point), seg_lo/seg_hi[b,t] = the sorted range of t's voxel.  T <= 8192.        */
+/* pool_max: out[b,t,c] = max_{t' in voxel(t)} feat[b,t',c], argmax = winning t'.  */
+/* scatter_mean: grid[b,c,z,y,x] (NCDHW, zero-filled inside) = per-voxel mean.     */
+/* All reductions run in ascending point order: bit-reproducible.                 */
+/* ------------------------------------------------------------------------- */
+int vt_voxel_build(const float *pts, int B, int T, int R, double padding,
+                   int *idx, int *order, int *seg_lo, int *seg_hi, void *stream);
+int vt_voxel_pool_max_fwd(const float *feat, const int *order, const int *seg_lo, const int *seg_hi,
+                          int B, int T, int C, float *out, int *argmax, void *stream);
+int vt_voxel_pool_max_bwd(const float *grad_out, const int *argmax, const int *order,
+                          const int *seg_lo, const int *seg_hi,
+                          int B, int T, int C, float *grad_feat, void *stream);
+int vt_voxel_scatter_mean_fwd(const float *feat, const int *idx, const int *order,
+                              const int *seg_lo, const int *seg_hi,
+                              int B, int T, int C, int R, float *grid, void *stream);
+int vt_voxel_scatter_mean_bwd(const float *grad_grid, const int *idx, const int *seg_lo, const int *seg_hi,
+                              int B, int T, int C, int R, float *grad_feat, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

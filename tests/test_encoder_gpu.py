@@ -1,0 +1,115 @@
+"""GPU parity of the encoder side: voxeliser kernels (bit-exact ids, deterministic
+pooling), PointNet + scatter-mean + UNet3D grid, autograd of the HIP Functions, and the
+end-to-end generator against oracle-made meshes."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub_sd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = torch.from_numpy
+
+
+def _encoder(sd, unet3d_kwargs=None, R=16):
+    from vtaco_amd.encoder import encoder_dict
+    enc = encoder_dict['pointnet_local_pool'](c_dim=32, dim=3, hidden_dim=32, unet3d=unet3d_kwargs is not None,
+                                              unet3d_kwargs=unet3d_kwargs, grid_resolution=R, plane_type='grid')
+    enc.load_state_dict(sd, strict=True)
+    return enc.to(DEV)
+
+
+def test_voxel_ids_and_segments_bit_exact():
+    from vtaco_amd import ops
+    a, _ = load_golden("g3_pointnet.npz")
+    p = T(a["p"]).to(DEV)
+    vi = ops.VoxelIndex(p, 16)
+    assert torch.equal(vi.idx.cpu().long(), T(a["idx"]))
+    idx = T(a["idx"])
+    for b in range(2):
+        order = vi.order[b].cpu().long()
+        key = idx[b][order] * 4096 + order
+        assert torch.all(key[1:] > key[:-1])                       # sorted by (voxel, point)
+        lo, hi = vi.seg_lo[b].cpu().long(), vi.seg_hi[b].cpu().long()
+        cnt = torch.bincount(idx[b], minlength=16 ** 3)
+        assert torch.equal(hi - lo, cnt[idx[b]])
+
+
+def test_pointnet_stages_grid_vs_golden_and_determinism():
+    a, sd = load_golden("g3_pointnet.npz")
+    enc = _encoder(sd)
+    p = T(a["p"]).to(DEV)
+    with torch.no_grad():
+        g1 = enc(p)["grid"]
+        g2 = enc(p)["grid"]
+    assert torch.equal(g1, g2)                                      # order-deterministic reductions
+    assert float((g1.cpu() - T(a["grid"])).abs().max()) <= 1e-5
+    for b in range(2):
+        occ = torch.nonzero(g1[b].abs().sum(0).reshape(-1)).squeeze(1).cpu()
+        assert torch.equal(occ, T(a[f"occ{b}"]))                    # empty voxels exactly zero
+
+
+def test_full_encoder_with_unet3d_vs_golden():
+    a, sd = load_golden("g4_unet3d.npz")
+    enc = _encoder(sd, dict(num_levels=3, f_maps=8, in_channels=32, out_channels=32))
+    with torch.no_grad():
+        g = enc(T(a["p"]).to(DEV))["grid"]
+    # MIOpen conv3d / group_norm vs the CPU reference: encoder drift reported separately from
+    # kernel parity; 1e-4 still holds on this small U-Net
+    assert float((g.cpu() - T(a["grid"])).abs().max()) <= 1e-4
+
+
+def test_pool_and_scatter_backward_vs_oracle_autograd():
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd import ops
+    from vtaco_amd.encoder.pointnet import _PoolMax, _ScatterMean
+    a, _ = load_golden("g3_pointnet.npz")
+    p = T(a["p"])
+    g = torch.Generator().manual_seed(3)
+    feat = torch.randn(2, 3000, 32, generator=g)
+    w1 = torch.randn(2, 3000, 32, generator=g)
+    w2 = torch.randn(2, 32, 16, 16, 16, generator=g)
+    idx = orc.voxel_index(p, 16)
+    f0 = feat.clone().requires_grad_(True)
+    (orc.segment_pool_max(f0, idx) * w1).sum().backward()
+    f1 = feat.clone().requires_grad_(True)
+    (orc.scatter_mean_grid(f1, idx, 16) * w2).sum().backward()
+    vi = ops.VoxelIndex(p.to(DEV), 16)
+    d0 = feat.clone().to(DEV).requires_grad_(True)
+    out = _PoolMax.apply(d0, vi)
+    assert torch.equal(out.detach().cpu(), orc.segment_pool_max(feat, idx))
+    (out * w1.to(DEV)).sum().backward()
+    assert float((d0.grad.cpu() - f0.grad).abs().max()) <= 1e-5
+    d1 = feat.clone().to(DEV).requires_grad_(True)
+    grid = _ScatterMean.apply(d1, vi)
+    assert float((grid.detach().cpu() - orc.scatter_mean_grid(feat, idx, 16)).abs().max()) <= 1e-6
+    (grid * w2.to(DEV)).sum().backward()
+    assert float((d1.grad.cpu() - f1.grad).abs().max()) <= 1e-6
+
+
+def test_generator_end_to_end_mesh_vs_oracle():
+    """encode -> 32^3 lattice decode -> marching cubes, against oracle logits + C oracle MC."""
+    from oracle import mc, vtaco_oracle as orc
+    from vtaco_amd.conv_onet.generation import Generator3D
+    from vtaco_amd.conv_onet.models import ConvolutionalOccupancyNetwork, decoder_dict
+    a, sd_e = load_golden("g3_pointnet.npz")
+    _, sd_d = load_golden("g1_decode.npz")
+    dec = decoder_dict['simple_local'](dim=3, c_dim=32, hidden_size=32, with_contact=True)
+    dec.load_state_dict(sd_d, strict=True)
+    model = ConvolutionalOccupancyNetwork(dec, _encoder(sd_e), device=DEV)
+    gen = Generator3D(model, device=DEV, resolution0=8, padding=0.1)
+    p = T(a["p"])[:1]
+    mesh = gen.generate_obj_mesh_wnf({"inputs": p})
+    grid = orc.pointnet_encoder_forward(sd_e, p, 16, unet3d=False)
+    vol = orc.eval_points_dense(sd_d, grid, 32).reshape(32, 32, 32)
+    vol_gpu = gen.eval_lattice(model.encode_inputs(p.to(DEV)), 32).reshape(32, 32, 32).cpu()
+    assert float((vol_gpu - vol).abs().max()) <= 1e-4
+    # eval_points (reference API: explicit points, CPU result) agrees with the lattice path
+    pts = 1.1 * orc.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (32,) * 3)
+    ev = gen.eval_points(pts, model.encode_inputs(p.to(DEV)))
+    assert ev.device.type == "cpu" and float((ev - vol.reshape(-1)).abs().max()) <= 1e-4
+    # marching cubes on the SAME (gpu) volume: numbering bit-exact with the oracle
+    rv, rf, _ = mc.marching_cubes(vol_gpu.numpy())
+    assert np.array_equal(mesh.faces.cpu().numpy(), rf)
+    assert np.abs(mesh.vertices.cpu().numpy() - orc.mesh_rescale(rv, 32)).max() <= 1e-6

@@ -1,0 +1,40 @@
+"""Model / generator factories (drop-in for the hot-path part of reference
+src/conv_onet/config.py:16-143, 215-269): same cfg keys, same registries."""
+from __future__ import annotations
+
+from . import models
+from .generation import Generator3D
+from ..encoder import encoder_dict
+from .._lib import VtError
+
+
+def get_model(cfg, device=None, dataset=None, **kwargs):
+    m = cfg['model']
+    dim, c_dim, padding = cfg['data']['dim'], m['c_dim'], cfg['data']['padding']
+    decoder = None
+    if m['decoder']:
+        decoder = models.decoder_dict[m['decoder']](
+            dim=dim, c_dim=c_dim, padding=padding, with_contact=m.get('with_contact', False), **(m.get('decoder_kwargs') or {}))
+    encoder = None
+    if m['encoder']:
+        encoder = encoder_dict[m['encoder']](dim=dim, c_dim=c_dim, padding=padding, **(m.get('encoder_kwargs') or {}))
+    if m.get('encoder_hand'):
+        raise VtError("get_model: the hand / MANO branch (encoder_hand) is out of scope here; set encoder_hand: False")
+    encoder_img = None
+    if m.get('with_img') and m.get('encoder_img'):
+        encoder_img = encoder_dict[m['encoder_img']](**(m.get('encoder_img_kwargs') or {}))
+    encoder_t2d = None
+    if m.get('encoder_t2d'):
+        kw = m['encoder_t2d_kwargs']
+        img_t2d = encoder_dict[kw['encoder_img']](**kw['encoder_img_kwargs'])
+        encoder_t2d = models.ConvolutionalOccupancyNetwork(None, None, None, img_t2d, None, device=device)
+    return models.ConvolutionalOccupancyNetwork(decoder, encoder, None, encoder_img, encoder_t2d, device=device)
+
+
+def get_generator(model, cfg, device, **kwargs):
+    g = cfg['generation']
+    return Generator3D(model, device=device, threshold=cfg['test']['threshold'], resolution0=g['resolution_0'],
+                       upsampling_steps=g['upsampling_steps'], sample=g.get('use_sampling', False),
+                       refinement_step=g.get('refinement_step', 0), simplify_nfaces=g.get('simplify_nfaces'),
+                       input_type=cfg['data']['input_type'], padding=cfg['data']['padding'],
+                       with_img=cfg['model'].get('with_img', False), encode_t2d=cfg['model'].get('encoder_t2d', False))

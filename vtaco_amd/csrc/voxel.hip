@@ -1,0 +1,230 @@
+// PointNet local-pool voxeliser for gfx950: voxel ids (K1), per-voxel channel-wise max
+// gathered back to the points (K2) and per-voxel mean into the dense feature grid (K3),
+// forward and backward.  Replaces torch_scatter.scatter_max + gather and scatter_mean at
+// reference src/encoder/pointnet.py:116-132 and :102-110, plus the index math of
+// src/common.py:293-309, 333-348.
+//
+// No dense [C, R^3] transient and no float atomics: one workgroup per scene sorts the
+// (voxel id, point id) pairs in LDS once per forward (the ids do not change between the
+// four pooling rounds), which gives every point the contiguous range of its voxel-mates
+// in sorted order.  Reductions then run over those ranges in ascending point order, so
+// max/argmax and the mean are bit-reproducible run to run (the sum order equals the
+// sequential scatter_add order of the CPU path).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vt_common.h"
+
+namespace {
+
+constexpr int SORT_THREADS = 1024;
+constexpr int MAX_T = 8192;          // points per scene the in-LDS sort covers (64 KiB of u64)
+
+// reference src/common.py:293-309 + :333-348 in f32, truncating cast
+__device__ __forceinline__ int voxel_coord(float v, float divisor, int R) {
+    float q = v / divisor + 0.5f;
+    q = (q >= 1.0f) ? 0.999f : q;
+    q = (q < 0.0f) ? 0.0f : q;
+    return (int)(q * (float)R);
+}
+
+__global__ void __launch_bounds__(SORT_THREADS)
+voxel_build_kernel(const float *pts, int T, int Tpad, int R, float divisor,
+                   int *idx, int *order, int *seg_lo, int *seg_hi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const int b = blockIdx.x;
+    const float *p = pts + (size_t)b * T * 3;
+    for (int t = threadIdx.x; t < Tpad; t += SORT_THREADS) {
+        unsigned long long k = ~0ull;
+        if (t < T) {
+            const int ix = voxel_coord(p[3 * t + 0], divisor, R);
+            const int iy = voxel_coord(p[3 * t + 1], divisor, R);
+            const int iz = voxel_coord(p[3 * t + 2], divisor, R);
+            const int id = ix + R * (iy + R * iz);
+            idx[(size_t)b * T + t] = id;
+            k = ((unsigned long long)(unsigned)id << 32) | (unsigned)t;
+        }
+        keys[t] = k;
+    }
+    __syncthreads();
+    // bitonic sort of Tpad (power of two) 64-bit keys: ascending voxel id, then point id
+    for (int k = 2; k <= Tpad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < Tpad; i += SORT_THREADS) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = keys[i], c = keys[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { keys[i] = c; keys[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // segment bounds: every point learns [lo,hi) of its voxel in sorted order
+    for (int j = threadIdx.x; j < T; j += SORT_THREADS) {
+        const unsigned id = (unsigned)(keys[j] >> 32);
+        const int t = (int)(unsigned)keys[j];
+        order[(size_t)b * T + j] = t;
+        const bool first = (j == 0) || ((unsigned)(keys[j - 1] >> 32) != id);
+        if (first) {
+            int e = j + 1;
+            while (e < T && (unsigned)(keys[e] >> 32) == id) ++e;
+            for (int q = j; q < e; ++q) {
+                const int tq = (int)(unsigned)keys[q];
+                seg_lo[(size_t)b * T + tq] = j;
+                seg_hi[(size_t)b * T + tq] = e;
+            }
+        }
+    }
+}
+
+// out[b,t,c] = max over the voxel-mates of t of feat[b,.,c]; argmax = the point that wins
+__global__ void __launch_bounds__(256)
+pool_max_fwd_kernel(const float *feat, const int *order, const int *seg_lo, const int *seg_hi,
+                    float *out, int *argmax, int T, int C, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const size_t bt = e / C;
+        const size_t b = bt / T;
+        const int lo = seg_lo[bt], hi = seg_hi[bt];
+        const int *ord = order + b * T;
+        const float *fb = feat + b * T * C;
+        int best = ord[lo];
+        float m = fb[(size_t)best * C + c];
+        for (int j = lo + 1; j < hi; ++j) {
+            const int t2 = ord[j];
+            const float v = fb[(size_t)t2 * C + c];
+            if (v > m) { m = v; best = t2; }
+        }
+        out[e] = m;
+        if (argmax) argmax[e] = best;
+    }
+}
+
+// grad_feat[b,t,c] = sum over voxel-mates of grad_out[b,.,c] if t is the arg-max, else 0
+__global__ void __launch_bounds__(256)
+pool_max_bwd_kernel(const float *grad_out, const int *argmax, const int *order, const int *seg_lo, const int *seg_hi,
+                    float *grad_feat, int T, int C, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const size_t bt = e / C;
+        const size_t b = bt / T;
+        const int t = (int)(bt - b * T);
+        float g = 0.0f;
+        if (argmax[e] == t) {
+            const int lo = seg_lo[bt], hi = seg_hi[bt];
+            const int *ord = order + b * T;
+            const float *gb = grad_out + b * T * C;
+            for (int j = lo; j < hi; ++j) g += gb[(size_t)ord[j] * C + c];
+        }
+        grad_feat[e] = g;
+    }
+}
+
+// grid[b,c,voxel] = mean of feat over the voxel's points (grid pre-zeroed); NCDHW output
+__global__ void __launch_bounds__(256)
+scatter_mean_fwd_kernel(const float *feat, const int *idx, const int *order, const int *seg_lo, const int *seg_hi,
+                        float *grid, int T, int C, size_t V, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const size_t bt = e / C;
+        const size_t b = bt / T;
+        const int t = (int)(bt - b * T);
+        const int lo = seg_lo[bt], hi = seg_hi[bt];
+        const int *ord = order + b * T;
+        if (ord[lo] != t) continue;               // the voxel's first point writes
+        const float *fb = feat + b * T * C;
+        float s = 0.0f;
+        for (int j = lo; j < hi; ++j) s += fb[(size_t)ord[j] * C + c];
+        grid[(b * C + c) * V + (size_t)idx[bt]] = s / (float)(hi - lo);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+scatter_mean_bwd_kernel(const float *grad_grid, const int *idx, const int *seg_lo, const int *seg_hi,
+                        float *grad_feat, int T, int C, size_t V, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const size_t bt = e / C;
+        const size_t b = bt / T;
+        grad_feat[e] = grad_grid[(b * C + c) * V + (size_t)idx[bt]] / (float)(seg_hi[bt] - seg_lo[bt]);
+    }
+}
+
+inline unsigned blocks_for(size_t total) {
+    size_t g = (total + 255) / 256;
+    const size_t cap = (size_t)vt_num_cus() * 8;
+    return (unsigned)(g < cap ? (g ? g : 1) : cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vt_voxel_build(const float *pts, int B, int T, int R, double padding,
+                   int *idx, int *order, int *seg_lo, int *seg_hi, void *stream) {
+    if (!pts || !idx || !order || !seg_lo || !seg_hi) return vt_fail(VT_ERR_INVALID, "vt_voxel_build: null argument");
+    if (B <= 0 || T <= 0 || R < 1 || R > 1024) return vt_fail(VT_ERR_INVALID, "vt_voxel_build: bad size");
+    if (T > MAX_T) return vt_fail(VT_ERR_UNSUPPORTED, "vt_voxel_build: more than 8192 points per scene");
+    int Tpad = 2;
+    while (Tpad < T) Tpad <<= 1;
+    const size_t lds = (size_t)Tpad * sizeof(unsigned long long);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_build_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MAX_T * sizeof(unsigned long long)));
+        if (e != hipSuccess) return vt_check(e, "vt_voxel_build: hipFuncSetAttribute");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(voxel_build_kernel, dim3(B), dim3(SORT_THREADS), lds, (hipStream_t)stream,
+                       pts, T, Tpad, R, (float)(1.0 + padding + 10e-4), idx, order, seg_lo, seg_hi);
+    return vt_check(hipGetLastError(), "vt_voxel_build");
+}
+
+int vt_voxel_pool_max_fwd(const float *feat, const int *order, const int *seg_lo, const int *seg_hi,
+                          int B, int T, int C, float *out, int *argmax, void *stream) {
+    if (!feat || !order || !seg_lo || !seg_hi || !out) return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_max_fwd: null argument");
+    if (B <= 0 || T <= 0 || C <= 0) return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_max_fwd: bad size");
+    const size_t total = (size_t)B * T * C;
+    hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       feat, order, seg_lo, seg_hi, out, argmax, T, C, total);
+    return vt_check(hipGetLastError(), "vt_voxel_pool_max_fwd");
+}
+
+int vt_voxel_pool_max_bwd(const float *grad_out, const int *argmax, const int *order, const int *seg_lo, const int *seg_hi,
+                          int B, int T, int C, float *grad_feat, void *stream) {
+    if (!grad_out || !argmax || !order || !seg_lo || !seg_hi || !grad_feat)
+        return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_max_bwd: null argument");
+    if (B <= 0 || T <= 0 || C <= 0) return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_max_bwd: bad size");
+    const size_t total = (size_t)B * T * C;
+    hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       grad_out, argmax, order, seg_lo, seg_hi, grad_feat, T, C, total);
+    return vt_check(hipGetLastError(), "vt_voxel_pool_max_bwd");
+}
+
+int vt_voxel_scatter_mean_fwd(const float *feat, const int *idx, const int *order, const int *seg_lo, const int *seg_hi,
+                              int B, int T, int C, int R, float *grid, void *stream) {
+    if (!feat || !idx || !order || !seg_lo || !seg_hi || !grid)
+        return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_fwd: null argument");
+    if (B <= 0 || T <= 0 || C <= 0 || R < 1) return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_fwd: bad size");
+    const size_t V = (size_t)R * R * R, total = (size_t)B * T * C;
+    hipError_t e = hipMemsetAsync(grid, 0, (size_t)B * C * V * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return vt_check(e, "vt_voxel_scatter_mean_fwd: memset");
+    hipLaunchKernelGGL(scatter_mean_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       feat, idx, order, seg_lo, seg_hi, grid, T, C, V, total);
+    return vt_check(hipGetLastError(), "vt_voxel_scatter_mean_fwd");
+}
+
+int vt_voxel_scatter_mean_bwd(const float *grad_grid, const int *idx, const int *seg_lo, const int *seg_hi,
+                              int B, int T, int C, int R, float *grad_feat, void *stream) {
+    if (!grad_grid || !idx || !seg_lo || !seg_hi || !grad_feat)
+        return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_bwd: null argument");
+    if (B <= 0 || T <= 0 || C <= 0 || R < 1) return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_bwd: bad size");
+    const size_t V = (size_t)R * R * R, total = (size_t)B * T * C;
+    hipLaunchKernelGGL(scatter_mean_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       grad_grid, idx, seg_lo, seg_hi, grad_feat, T, C, V, total);
+    return vt_check(hipGetLastError(), "vt_voxel_scatter_mean_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+"""3-D U-Net that refines the scattered feature grid.
+
+Host PyTorch-ROCm (MIOpen conv3d / group_norm): north_star names no HIP kernel for
+it.  Same parameter tree as the reference's ``UNet3D`` (src/encoder/unet3d.py:361-491:
+``encoders.{i}.basic_module.SingleConv{1,2}.{groupnorm,conv}``, ``decoders.{i}...``,
+``final_conv``) so checkpoints load unchanged; only what the shipped configs use is
+built: DoubleConv blocks, layer order 'gcr', max-pool down, nearest-neighbour up +
+concat, 1x1x1 final conv, no final activation (``testing=False``).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+
+def _norm_conv_relu(cin, cout, order, num_groups):
+    """One 'SingleConv': modules named by role, in the order the string gives."""
+    if 'c' not in order or order[0] in 'rle':
+        raise ValueError(f"bad layer order {order!r}")
+    has_norm = ('g' in order) or ('b' in order)
+    mods = OrderedDict()
+    for pos, ch in enumerate(order):
+        if ch == 'c':
+            mods['conv'] = nn.Conv3d(cin, cout, 3, padding=1, bias=not has_norm)
+        elif ch == 'g':
+            n = cin if pos < order.index('c') else cout
+            mods['groupnorm'] = nn.GroupNorm(num_groups if n >= num_groups else 1, n)
+        elif ch == 'b':
+            mods['batchnorm'] = nn.BatchNorm3d(cin if pos < order.index('c') else cout)
+        elif ch == 'r':
+            mods['ReLU'] = nn.ReLU(inplace=True)
+        elif ch == 'l':
+            mods['LeakyReLU'] = nn.LeakyReLU(0.1, inplace=True)
+        elif ch == 'e':
+            mods['ELU'] = nn.ELU(inplace=True)
+        else:
+            raise ValueError(f"unsupported layer type {ch!r}")
+    return nn.Sequential(mods)
+
+
+class _TwoConvs(nn.Sequential):
+    def __init__(self, cin, cout, encoder, order, num_groups):
+        if encoder:
+            mid = max(cout // 2, cin)
+            widths = [(cin, mid), (mid, cout)]
+        else:
+            widths = [(cin, cout), (cout, cout)]
+        super().__init__(OrderedDict(
+            (f'SingleConv{i + 1}', _norm_conv_relu(a, b, order, num_groups)) for i, (a, b) in enumerate(widths)))
+
+
+class _Down(nn.Module):
+    def __init__(self, cin, cout, pool, order, num_groups):
+        super().__init__()
+        self.pooling = nn.MaxPool3d(2) if pool else None
+        self.basic_module = _TwoConvs(cin, cout, True, order, num_groups)
+
+    def forward(self, x):
+        return self.basic_module(x if self.pooling is None else self.pooling(x))
+
+
+class _Up(nn.Module):
+    def __init__(self, cin, cout, order, num_groups):
+        super().__init__()
+        self.basic_module = _TwoConvs(cin, cout, False, order, num_groups)
+
+    def forward(self, skip, x):
+        x = F.interpolate(x, size=skip.shape[2:], mode='nearest')
+        return self.basic_module(torch.cat((skip, x), dim=1))
+
+
+class UNet3D(nn.Module):
+    def __init__(self, in_channels, out_channels, final_sigmoid=True, f_maps=64, layer_order='gcr',
+                 num_groups=8, num_levels=4, is_segmentation=True, testing=False, **kwargs):
+        super().__init__()
+        if isinstance(f_maps, int):
+            f_maps = [f_maps * 2 ** k for k in range(num_levels)]
+        self.encoders = nn.ModuleList(
+            _Down(in_channels if i == 0 else f_maps[i - 1], f, i > 0, layer_order, num_groups)
+            for i, f in enumerate(f_maps))
+        rev = f_maps[::-1]
+        self.decoders = nn.ModuleList(
+            _Up(rev[i] + rev[i + 1], rev[i + 1], layer_order, num_groups) for i in range(len(rev) - 1))
+        self.final_conv = nn.Conv3d(f_maps[0], out_channels, 1)
+        self.testing = testing
+        self.final_activation = (nn.Sigmoid() if final_sigmoid else nn.Softmax(dim=1)) if is_segmentation else None
+
+    def forward(self, x):
+        skips = []
+        for enc in self.encoders:
+            x = enc(x)
+            skips.append(x)
+        for dec, skip in zip(self.decoders, skips[-2::-1]):
+            x = dec(skip, x)
+        x = self.final_conv(x)
+        if self.testing and self.final_activation is not None:
+            x = self.final_activation(x)
+        return x

@@ -33,3 +33,70 @@ class ResnetBlockFC(nn.Module):
     def packed(self):
         """(fc_0.weight, fc_0.bias, fc_1.weight, fc_1.bias) for vt_decoder_pack."""
         return self.fc_0.weight, self.fc_0.bias, self.fc_1.weight, self.fc_1.bias
+
+
+class _ConvPair(nn.Module):
+    """Two 3x3 convs sharing ONE BatchNorm module, ReLU after each (the reference's
+    DownConv / UpConv bodies, src/layers.py:246-319, reuse `self.bn` twice)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.bn = nn.BatchNorm2d(cout)
+
+    def _pair(self, x):
+        x = F.relu(self.bn(self.conv1(x)))
+        return F.relu(self.bn(self.conv2(x)))
+
+
+class DownConv(_ConvPair):
+    def __init__(self, in_channels, out_channels, pooling=True):
+        super().__init__(in_channels, out_channels)
+        self.pooling = pooling
+        if pooling:
+            self.pool = nn.MaxPool2d(2, 2)
+
+    def forward(self, x):
+        skip = self._pair(x)
+        return (self.pool(skip) if self.pooling else skip), skip
+
+
+class UpConv(_ConvPair):
+    def __init__(self, in_channels, out_channels):
+        super().__init__(2 * out_channels, out_channels)
+        self.upconv = nn.ConvTranspose2d(in_channels, out_channels, 2, stride=2)
+
+    def forward(self, from_down, from_up):
+        return self._pair(torch.cat((self.upconv(from_up), from_down), dim=1))
+
+
+class TactileUNet(nn.Module):
+    """Tactile depth estimator (reference ``UNet``, src/layers.py:322-450): `depth`
+    DownConvs (last without pooling), depth-1 UpConvs (transpose-conv up, concat),
+    1x1 conv, sigmoid.  Host PyTorch-ROCm."""
+
+    def __init__(self, num_classes=1, in_channels=3, depth=4, start_filts=32, up_mode='transpose',
+                 merge_mode='concat', **kwargs):
+        super().__init__()
+        if up_mode != 'transpose' or merge_mode != 'concat':
+            raise ValueError("TactileUNet: only up_mode='transpose', merge_mode='concat' (the shipped config) are built")
+        self.num_classes, self.in_channels, self.start_filts, self.depth = num_classes, in_channels, start_filts, depth
+        widths = [start_filts * 2 ** i for i in range(depth)]
+        self.down_convs = nn.ModuleList(
+            DownConv(in_channels if i == 0 else widths[i - 1], w, pooling=i < depth - 1) for i, w in enumerate(widths))
+        self.up_convs = nn.ModuleList(UpConv(widths[i], widths[i - 1]) for i in range(depth - 1, 0, -1))
+        self.conv_final = nn.Conv2d(widths[0], num_classes, 1)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_normal_(m.weight)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        skips = []
+        for down in self.down_convs:
+            x, skip = down(x)
+            skips.append(skip)
+        for i, up in enumerate(self.up_convs):
+            x = up(skips[-(i + 2)], x)
+        return torch.sigmoid(self.conv_final(x)) * 1

@@ -192,3 +192,80 @@ def marching_cubes(vol, level=None, rescale=None, capacity=None):
     if capacity is not None:
         return verts, faces, ws          # counts stay on the device: ws[8:16] = (nverts, nfaces) int32
     return verts, faces, lvl.value
+
+
+# --------------------------------------------------------------------------------------
+# PointNet local-pool voxeliser (vt_voxel_*)
+# --------------------------------------------------------------------------------------
+I32 = torch.int32
+
+
+class VoxelIndex:
+    """Per-forward voxel bookkeeping of a point cloud [B,T,3] (vt_voxel_build)."""
+
+    def __init__(self, pts, reso, padding=0.1):
+        pts = pts.detach().float()
+        if not pts.is_contiguous():
+            pts = pts.contiguous()
+        B, T, _ = pts.shape
+        self.B, self.T, self.R = B, T, reso
+        dev = pts.device
+        self.idx = torch.empty((B, T), dtype=I32, device=dev)
+        self.order = torch.empty((B, T), dtype=I32, device=dev)
+        self.seg_lo = torch.empty((B, T), dtype=I32, device=dev)
+        self.seg_hi = torch.empty((B, T), dtype=I32, device=dev)
+        check(_lib.load().vt_voxel_build(dev_ptr(pts, "pts"), B, T, reso, float(padding),
+                                         dev_ptr(self.idx, "idx", I32), dev_ptr(self.order, "order", I32),
+                                         dev_ptr(self.seg_lo, "seg_lo", I32), dev_ptr(self.seg_hi, "seg_hi", I32),
+                                         stream_ptr()), "vt_voxel_build")
+
+
+def _c(t):
+    t = t.detach()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def voxel_pool_max_fwd(feat, vi, want_argmax=True):
+    feat = _c(feat)
+    B, T, C = feat.shape
+    out = torch.empty_like(feat)
+    arg = torch.empty((B, T, C), dtype=I32, device=feat.device) if want_argmax else None
+    check(_lib.load().vt_voxel_pool_max_fwd(dev_ptr(feat, "feat"), dev_ptr(vi.order, "order", I32),
+                                            dev_ptr(vi.seg_lo, "seg_lo", I32), dev_ptr(vi.seg_hi, "seg_hi", I32),
+                                            B, T, C, dev_ptr(out, "out"), dev_ptr(arg, "argmax", I32), stream_ptr()),
+          "vt_voxel_pool_max_fwd")
+    return out, arg
+
+
+def voxel_pool_max_bwd(grad_out, argmax, vi):
+    grad_out = _c(grad_out)
+    B, T, C = grad_out.shape
+    g = torch.empty_like(grad_out)
+    check(_lib.load().vt_voxel_pool_max_bwd(dev_ptr(grad_out, "grad_out"), dev_ptr(argmax, "argmax", I32),
+                                            dev_ptr(vi.order, "order", I32), dev_ptr(vi.seg_lo, "seg_lo", I32),
+                                            dev_ptr(vi.seg_hi, "seg_hi", I32), B, T, C, dev_ptr(g, "grad_feat"), stream_ptr()),
+          "vt_voxel_pool_max_bwd")
+    return g
+
+
+def voxel_scatter_mean_fwd(feat, vi):
+    feat = _c(feat)
+    B, T, C = feat.shape
+    R = vi.R
+    grid = torch.empty((B, C, R, R, R), dtype=torch.float32, device=feat.device)
+    check(_lib.load().vt_voxel_scatter_mean_fwd(dev_ptr(feat, "feat"), dev_ptr(vi.idx, "idx", I32),
+                                                dev_ptr(vi.order, "order", I32), dev_ptr(vi.seg_lo, "seg_lo", I32),
+                                                dev_ptr(vi.seg_hi, "seg_hi", I32), B, T, C, R, dev_ptr(grid, "grid"),
+                                                stream_ptr()), "vt_voxel_scatter_mean_fwd")
+    return grid
+
+
+def voxel_scatter_mean_bwd(grad_grid, vi, C):
+    grad_grid = _c(grad_grid)
+    B, T = vi.B, vi.T
+    g = torch.empty((B, T, C), dtype=torch.float32, device=grad_grid.device)
+    check(_lib.load().vt_voxel_scatter_mean_bwd(dev_ptr(grad_grid, "grad_grid"), dev_ptr(vi.idx, "idx", I32),
+                                                dev_ptr(vi.seg_lo, "seg_lo", I32), dev_ptr(vi.seg_hi, "seg_hi", I32),
+                                                B, T, C, vi.R, dev_ptr(g, "grad_feat"), stream_ptr()),
+          "vt_voxel_scatter_mean_bwd")
+    return g
