@@ -53,6 +53,51 @@ def cpu_baseline(sd, grid_cpu, nx, budget_s=15.0):
             "sample": f"{done} of {nx ** 3} lattice points in 100k-point chunks, oracle/vtaco_oracle.py (torch CPU f32)"}
 
 
+def mesh_extract_stats(vol, nx, runs=100):
+    """mesh-extract latency (BASELINE.json metric, second half): HIP marching cubes on the
+    device-resident logit grid -> device verts/faces, including the one host read of the
+    counts that sizes the outputs.  p50 over `runs`."""
+    from vtaco_amd import ops
+    lat = []
+    for i in range(runs + 5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        v, f, lvl = ops.marching_cubes(vol, None, rescale=(nx / 2, 1.1 / nx))
+        torch.cuda.synchronize()
+        if i >= 5:
+            lat.append(1e3 * (time.perf_counter() - t0))
+    lat.sort()
+    p50 = lat[len(lat) // 2]
+    nbytes = 4 * nx ** 3 + 12 * v.shape[0] + 12 * f.shape[0]      # SURVEY.md 8d: algorithmic bytes
+    return {"p50_ms": p50, "p90_ms": lat[int(len(lat) * 0.9)], "min_ms": lat[0], "runs": runs, "verts": v.shape[0],
+            "faces": f.shape[0], "level": lvl, "algorithmic_GBps": nbytes / (p50 * 1e-3) / 1e9,
+            "note": "latency-dominated (5 launches + 1 sync readback); 8.4 MB volume = 1.3 us at HBM rate"}
+
+
+def stage_times(scene, dec, grid, nx, out, dev):
+    """End-to-end stages for one scene (reported beside the metric, not part of it)."""
+    def timed(fn, n=5):
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0))
+        return sorted(ts)[len(ts) // 2]
+    res = {}
+    model = scene["model"]
+    if model.encoder is not None:
+        pc = scene["cloud"].to(dev)
+        with torch.no_grad():
+            res["encode_pointnet_unet3d"] = timed(lambda: model.encode_inputs(pc))
+    res["decode_lattice"] = timed(lambda: dec.decode_lattice(grid, nx, box=1.1, out=out))
+    from vtaco_amd import ops
+    res["marching_cubes"] = timed(lambda: ops.marching_cubes(out.view(nx, nx, nx), None, rescale=(nx / 2, 1.1 / nx)))
+    res["end_to_end"] = sum(res.values())
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,9 +174,9 @@ def main():
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                          "kernel": "decode_fwd_kernel", "kernel_ms": kern_ms, "flop_per_point": flop_pt},
         }
-        extra = scene.get("extra")
-        if extra:
-            res["stages_ms"] = extra(nx)
+        if world == 1:
+            res["mesh_extract"] = mesh_extract_stats(out.view(nx, nx, nx), nx)
+            res["stages_ms"] = stage_times(scene, dec, grid, nx, out, dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(scene["sd_decoder_cpu"], scene["grid_cpu"], nx)
         print(json.dumps(res))

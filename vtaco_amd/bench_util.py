@@ -32,6 +32,7 @@ def build_scene(seed, device, R=64):
     except ImportError:
         encoder_dict = None
     g = torch.Generator().manual_seed(1000 + seed)
+    cloud = sphere_cloud(seed)
     if encoder_dict is not None and 'pointnet_local_pool' in encoder_dict:
         torch.manual_seed(0)
         enc = encoder_dict['pointnet_local_pool'](
@@ -40,7 +41,7 @@ def build_scene(seed, device, R=64):
         randomise_fc1(enc, 2)
         model.encoder = enc.to(device)
         with torch.no_grad():
-            grid = model.encode_inputs(sphere_cloud(seed).to(device))['grid']
+            grid = model.encode_inputs(cloud.to(device))['grid']
     else:
         grid = torch.randn(1, 32, R, R, R, generator=g).to(device)
     from . import ops
@@ -54,4 +55,4 @@ def build_scene(seed, device, R=64):
         return (torch.randn(1, 1, 32, generator=gg) * mask).to(device)
 
     return {"model": model, "grid": grid, "grid_cpu": grid.detach().cpu().contiguous(),
-            "sd_decoder_cpu": sd_cpu, "c_img": c_img}
+            "sd_decoder_cpu": sd_cpu, "c_img": c_img, "cloud": cloud}
