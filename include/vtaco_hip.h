@@ -92,13 +92,46 @@ int vt_grid_from_channels_last(const float *grid_cl, float *grid_ncdhw,
 /*     (nx,)*3) (src/common.py:178-197, generation.py:155-157): axis 0 slowest; */
 /*   c_img    [B,N,c_dim] tactile features (forward_img) or NULL;               */
 /*   blob     from vt_decoder_pack (packed with p_in = 3+c_dim iff c_img);      */
-/*   out      [B,N] logits; out2 [B,N] contact logits or NULL.                  */
+/*   out      [B,N] logits; out2 [B,N] contact logits or NULL;                  */
+/*   save     NULL (inference) or vt_decode_save_bytes(B*N) bytes: the training  */
+/*            forward leaves the activations vt_decode_bwd needs there.          */
 /* ------------------------------------------------------------------------- */
 int vt_decode_fwd(const float *grid_cl, int B, int R, int C,
                   const float *pts, int64_t N,
                   int lattice_nx, float lattice_box, int64_t lattice_first,
                   const float *c_img, const float *blob, double padding,
-                  float *out, float *out2, void *stream);
+                  float *out, float *out2, float *save, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* Backward of vt_decode_fwd (training).                                        */
+/* Replaces: PyTorch autograd of LocalDecoder.forward / forward_img, triggered   */
+/*   by loss.backward() at src/conv_onet/training.py:79,89,96 (grid_sampler_3d   */
+/*   backward, addmm backward, relu backward).                                   */
+/*   vt_decoder_pack_t : transposed-weight blob for the data gradient;           */
+/*   vt_decode_bwd     : grad_out [B,N] -> grad_grid_cl [B,R,R,R,C] (ACCUMULATED  */
+/*                       with f32 atomics: zero it first; may be NULL),           */
+/*                       grad_c_img [B,N,C] (or NULL), and per-layer output       */
+/*                       gradients in `gws` (vt_decode_gws_bytes);                */
+/*   vt_decode_wgrad   : all parameter gradients into `grads`                     */
+/*                       (vt_decode_wgrad_floats(p_in) floats, nn.Linear layout): */
+/*                       fc_p.w[32*p_in] fc_p.b[32] fc_c.w[5][32*32] fc_c.b[5][32] */
+/*                       fc_0.w[5][..] fc_0.b[5][32] fc_1.w[5][..] fc_1.b[5][32]   */
+/*                       fc_out.w[32] fc_out.b[1]; p_in = 35 iff c_img != NULL.   */
+/*                       Partials are summed in a fixed order: bit-reproducible.  */
+/* ------------------------------------------------------------------------- */
+size_t vt_decoder_blob_t_bytes(int hidden, int c_dim, int n_blocks);
+int vt_decoder_pack_t(const vt_decoder_params *params_host, float *blob_t, size_t blob_bytes, void *stream);
+size_t vt_decode_save_bytes(int64_t total_points);
+size_t vt_decode_gws_bytes(int64_t total_points);
+int vt_decode_bwd(int B, int R, int C, const float *pts, int64_t N,
+                  int lattice_nx, float lattice_box, int64_t lattice_first, double padding,
+                  const float *blob_t, const float *grad_out, const float *save, float *gws,
+                  float *grad_grid_cl, float *grad_c_img, void *stream);
+size_t vt_decode_wgrad_workspace_bytes(int64_t total_points);
+size_t vt_decode_wgrad_floats(int p_in);
+int vt_decode_wgrad(int B, const float *pts, int64_t N, int lattice_nx, float lattice_box, int64_t lattice_first,
+                    const float *c_img, const float *grad_out, const float *save, const float *gws,
+                    void *workspace, size_t workspace_bytes, float *grads, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* Marching cubes (Lewiner), vertex numbering identical to scikit-image's.      */

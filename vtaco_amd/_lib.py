@@ -48,7 +48,15 @@ SIGNATURES = {
     "vt_decoder_pack": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
     "vt_grid_to_channels_last": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "vt_grid_from_channels_last": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP]),
-    "vt_decode_fwd": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _D, _VP, _VP, _VP]),
+    "vt_decode_fwd": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _D, _VP, _VP, _VP, _VP]),
+    "vt_decoder_blob_t_bytes": (_SZ, [_I, _I, _I]),
+    "vt_decoder_pack_t": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
+    "vt_decode_save_bytes": (_SZ, [_I64]),
+    "vt_decode_gws_bytes": (_SZ, [_I64]),
+    "vt_decode_bwd": (_I, [_I, _I, _I, _VP, _I64, _I, _F, _I64, _D, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "vt_decode_wgrad_workspace_bytes": (_SZ, [_I64]),
+    "vt_decode_wgrad_floats": (_SZ, [_I]),
+    "vt_decode_wgrad": (_I, [_I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP, _VP, _VP, _SZ, _VP, _VP]),
     "vt_mc_workspace_bytes": (_SZ, [_I, _I, _I]),
     "vt_mc_count": (_I, [_VP, _I, _I, _I, _D, _I, _VP, _SZ, _VP]),
     "vt_mc_read_counts": (_I, [_VP, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_D), _VP]),

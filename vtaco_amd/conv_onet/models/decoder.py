@@ -16,6 +16,37 @@ from ..._lib import VtError
 from ...layers import ResnetBlockFC
 
 
+class _DecodeFn(torch.autograd.Function):
+    """Differentiable fused decode: forward = vt_decode_fwd (saving activations), backward =
+    vt_decode_bwd + vt_decode_wgrad.  Gradients flow to the feature grid, c_img and every
+    decoder parameter; not to the query points (the reference never reads p.grad either,
+    SURVEY.md section 8a row A14)."""
+
+    @staticmethod
+    def forward(ctx, dec, p, grid, c_img, *params):
+        img = c_img is not None
+        B, N = p.shape[0], p.shape[1]
+        save = ops.decode_save_buffer(B * N, grid.device)
+        out = ops.decode_fwd(grid, dec._blob(img=img), pts=p, c_img=c_img, padding=dec.padding, save=save)
+        ctx.dec, ctx.img, ctx.save, ctx.grid_shape = dec, img, save, tuple(grid.shape)
+        ctx.p, ctx.c_img = p.detach(), (c_img.detach() if img else None)
+        ctx.need_grid = grid.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        dec, img = ctx.dec, ctx.img
+        ggrid, gimg, flat = ops.decode_bwd(ctx.grid_shape, dec._blob_t(img=img), grad_out, ctx.save, pts=ctx.p,
+                                           with_c_img=img, c_img=ctx.c_img, padding=dec.padding,
+                                           want_grid_grad=ctx.need_grid)
+        g = ops.split_decoder_grads(flat, 3 + dec.c_dim if img else 3)
+        grads = []
+        for name in dec._param_order(img):
+            key, idx = name
+            grads.append(g[key] if idx is None else g[key][idx])
+        return (None, None, ggrid, gimg, *grads)
+
+
 class LocalDecoder(nn.Module):
     """Decoder conditioned on a local 3-D feature grid.
 
@@ -62,6 +93,33 @@ class LocalDecoder(nn.Module):
         self._blobs[(img, contact)] = (stamp, blob)
         return blob
 
+    def _blob_t(self, img=False):
+        first = self.fc_p_img if img else self.fc_p
+        return ops.pack_decoder(first.weight, first.bias, [(l.weight, l.bias) for l in self.fc_c],
+                                [b.packed() for b in self.blocks], (self.fc_out.weight, self.fc_out.bias),
+                                transposed=True)
+
+    def _param_order(self, img):
+        """(gradient key, index) for every tensor passed to _DecodeFn, in order."""
+        order = [("fc_p.weight", None), ("fc_p.bias", None)]
+        for i in range(self.n_blocks):
+            order += [("fc_c.weight", i), ("fc_c.bias", i), ("fc_0.weight", i), ("fc_0.bias", i),
+                      ("fc_1.weight", i), ("fc_1.bias", i)]
+        return order + [("fc_out.weight", None), ("fc_out.bias", None)]
+
+    def _params(self, img):
+        first = self.fc_p_img if img else self.fc_p
+        ps = [first.weight, first.bias]
+        for lin, blk in zip(self.fc_c, self.blocks):
+            ps += [lin.weight, lin.bias, *blk.packed()]
+        return ps + [self.fc_out.weight, self.fc_out.bias]
+
+    def _wants_grad(self, grid, c_img=None):
+        if not torch.is_grad_enabled():
+            return False
+        return grid.requires_grad or (c_img is not None and c_img.requires_grad) or any(
+            p.requires_grad for p in self.parameters())
+
     @staticmethod
     def _grid_of(c_plane):
         if set(c_plane.keys()) != {'grid'}:
@@ -72,16 +130,24 @@ class LocalDecoder(nn.Module):
     # -- reference call signatures ---------------------------------------------
     def forward(self, p, c_plane, **kwargs):
         """logits [B,N] for points p [B,N,3] (decoder.py:135-161)."""
-        return ops.decode_fwd(self._grid_of(c_plane), self._blob(), pts=p, padding=self.padding)
+        grid = self._grid_of(c_plane)
+        if self._wants_grad(grid):
+            return _DecodeFn.apply(self, p, grid, None, *self._params(False))
+        return ops.decode_fwd(grid, self._blob(), pts=p, padding=self.padding)
 
     def forward_img(self, p, c_plane, c_img, **kwargs):
         """Tactile concat variant (decoder.py:71-103): fc_p_img([p; c_img])."""
-        return ops.decode_fwd(self._grid_of(c_plane), self._blob(img=True), pts=p, c_img=c_img, padding=self.padding)
+        grid = self._grid_of(c_plane)
+        if self._wants_grad(grid, c_img):
+            return _DecodeFn.apply(self, p, grid, c_img, *self._params(True))
+        return ops.decode_fwd(grid, self._blob(img=True), pts=p, c_img=c_img, padding=self.padding)
 
     def forward_contact(self, p, c_plane, **kwargs):
         """(occupancy logits, contact logits) (decoder.py:105-133)."""
-        return ops.decode_fwd(self._grid_of(c_plane), self._blob(contact=True), pts=p,
-                              padding=self.padding, want_contact=True)
+        grid = self._grid_of(c_plane)
+        if self._wants_grad(grid):
+            raise VtError("forward_contact: the backward of the contact head is not built (no shipped config trains it)")
+        return ops.decode_fwd(grid, self._blob(contact=True), pts=p, padding=self.padding, want_contact=True)
 
     # -- dense fast path: the lattice is generated in-kernel ---------------------
     def decode_lattice(self, grid, nx, box=1.1, first=0, count=None, c_img=None, out=None):

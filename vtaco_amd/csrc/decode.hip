@@ -18,82 +18,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "vt_common.h"
+#include "decode_common.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// max(x,0) as ONE instruction (v_med3_f32 x, 0, +inf).  fmaxf() on an MFMA result costs a
-// second, canonicalising v_max; inline asm is not an option: hipcc inserts the MFMA->VALU
-// wait states only for instructions it can see, and a hand-written v_max read stale
-// accumulators (measured: 6e-2 logit error).
-__device__ __forceinline__ float relu1(float x) {
-    return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff());
-}
-
-// Force the 16 values to exist in VGPRs here (stops LLVM sinking the FMAs that produce
-// them past later loads, which would keep every load of the gather in flight at once).
-__device__ __forceinline__ void pin16(f32x16 &v) {
-    asm volatile("" : "+v"(v));
-}
-
-// one dense 32x32 layer; x[s] is the B operand of k-step s
-template <bool RELU>
-__device__ __forceinline__ f32x16 dense32(f32x16 acc, const float *wl, const f32x16 &x, int lane) {
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        float xv = RELU ? relu1(x[s]) : x[s];
-        acc = mfma(wl[s * 64 + lane], xv, acc);
-    }
-    return acc;
-}
-
-__device__ __forceinline__ f32x16 load_frag16(const float *p) {
-    const f32x4 *q = reinterpret_cast<const f32x4 *>(p);
-    f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
-    f32x16 r;
-    r.s0 = a.x; r.s1 = a.y; r.s2 = a.z; r.s3 = a.w;
-    r.s4 = b.x; r.s5 = b.y; r.s6 = b.z; r.s7 = b.w;
-    r.s8 = c.x; r.s9 = c.y; r.sa = c.z; r.sb = c.w;
-    r.sc = d.x; r.sd = d.y; r.se = d.z; r.sf = d.w;
-    return r;
-}
-
-// reference src/common.py:293-309 followed by ATen's align_corners=True
-// un-normalisation and border clip (decoder.py:62-68): returns the continuous
-// grid coordinate in [0, R-1].
-__device__ __forceinline__ float grid_coord(float v, float divisor, int R) {
-    float q = v / divisor + 0.5f;
-    q = (q >= 1.0f) ? 0.999f : q;
-    q = (q < 0.0f) ? 0.0f : q;
-    float g = 2.0f * q - 1.0f;
-    float f = ((g + 1.0f) / 2.0f) * (float)(R - 1);
-    return fminf(fmaxf(f, 0.0f), (float)(R - 1));
-}
-
-struct DecodeArgs {
-    const float *grid;   // [B,R,R,R,32]
-    const float *pts;    // [B,N,3] or null
-    const float *c_img;  // [B,N,32] or null
-    const float *blob;
-    float *out;
-    float *out2;
-    uint32_t N;          // points per batch element
-    uint32_t total;      // B*N   (< 2^31, checked by the entry point)
-    uint32_t lattice_first;
-    int R;
-    int nx;
-    float box;
-    float divisor;       // 1 + padding + 10e-4
-};
-
-template <int THREADS>
+template <int THREADS, bool SAVE>
 __global__ void __launch_bounds__(THREADS, VT_WAVES_PER_SIMD)
 decode_fwd_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -127,43 +56,14 @@ decode_fwd_kernel(DecodeArgs a) {
         const uint32_t n = g - b * a.N;
 
         float px, py, pz;
-        if (a.pts) {
-            const float *pp = a.pts + (size_t)g * 3;
-            px = pp[0]; py = pp[1]; pz = pp[2];
-        } else {
-            // box * linspace(-0.5, 0.5, nx)[i] (src/common.py:178-197, generation.py:155-157)
-            const uint32_t m = a.lattice_first + n;
-            const uint32_t nx = (uint32_t)a.nx;
-            const uint32_t t = m / nx;
-            const int iz = (int)(m - t * nx);
-            const int ix = (int)(t / nx);
-            const int iy = (int)(t - (uint32_t)ix * nx);
-            const float step = 1.0f / (float)(a.nx - 1);
-            const int half = a.nx / 2;
-            auto lin = [&](int i) {
-                float v = (i < half) ? (-0.5f + step * (float)i) : (0.5f - step * (float)(a.nx - i - 1));
-                return a.box * v;
-            };
-            px = lin(ix); py = lin(iy); pz = lin(iz);
-        }
+        point_of(a, g, n, px, py, pz);
 
         // ---- trilinear gather: c[s] = feature channel 16h+s of this lane's point ----
         f32x16 c;
 #pragma unroll
         for (int s = 0; s < 16; ++s) c[s] = 0.0f;
         {
-            const float fx = grid_coord(px, a.divisor, R);
-            const float fy = grid_coord(py, a.divisor, R);
-            const float fz = grid_coord(pz, a.divisor, R);
-            const float x0f = floorf(fx), y0f = floorf(fy), z0f = floorf(fz);
-            const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
-            const float wx1 = fx - x0f, wy1 = fy - y0f, wz1 = fz - z0f;
-            const float wx0 = (x0f + 1.0f) - fx, wy0 = (y0f + 1.0f) - fy, wz0 = (z0f + 1.0f) - fz;
-            const int x1 = min(x0 + 1, R - 1), y1 = min(y0 + 1, R - 1), z1 = min(z0 + 1, R - 1);
-            // a corner beyond the border is skipped by ATen; its weight is 0 there anyway
-            const float mx = (x0 + 1 <= R - 1) ? wx1 : 0.0f;
-            const float my = (y0 + 1 <= R - 1) ? wy1 : 0.0f;
-            const float mz = (z0 + 1 <= R - 1) ? wz1 : 0.0f;
+            const Tri t = tri_setup(px, py, pz, a.divisor, R);
             const float *gb = a.grid + (size_t)b * R * R * R * 32 + 16 * h;
             // one z-plane (4 corners, 16 x 16-byte loads per lane) at a time: the scheduling
             // barrier keeps the second plane's loads from being hoisted above the first
@@ -171,26 +71,29 @@ decode_fwd_kernel(DecodeArgs a) {
             auto plane = [&](int zz, float wz) {
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
-                    const int yy = dy ? y1 : y0;
-                    const float wyz_a = (dy ? my : wy0);
+                    const int yy = dy ? t.y1 : t.y0;
+                    const float wy = dy ? t.wy1 : t.wy0;
                     const size_t row = ((size_t)zz * R + yy) * R;
-                    const f32x16 v0 = load_frag16(gb + (row + x0) * 32);
-                    const f32x16 v1 = load_frag16(gb + (row + x1) * 32);
-                    const float w0 = (wx0 * wyz_a) * wz;
-                    const float w1 = (mx * wyz_a) * wz;
+                    const f32x16 v0 = load_frag16(gb + (row + t.x0) * 32);
+                    const f32x16 v1 = load_frag16(gb + (row + t.x1) * 32);
+                    const float w0 = (t.wx0 * wy) * wz;
+                    const float w1 = (t.wx1 * wy) * wz;
 #pragma unroll
                     for (int s = 0; s < 16; ++s) c[s] = fmaf(v0[s], w0, c[s]);
 #pragma unroll
                     for (int s = 0; s < 16; ++s) c[s] = fmaf(v1[s], w1, c[s]);
                 }
             };
-            plane(z0, wz0);
+            plane(t.z0, t.wz0);
             pin16(c);
             __builtin_amdgcn_sched_barrier(0);
-            plane(z1, mz);
+            plane(t.z1, t.wz1);
             pin16(c);
             __builtin_amdgcn_sched_barrier(0);
         }
+        const size_t slot = (size_t)a.total * 32;           // one saved tensor
+        float *srow = SAVE ? a.save + (size_t)g * 32 : nullptr;
+        if (SAVE && live) store_gather16(srow, c, h);        // slot 0: c
 
         // ---- net = fc_p(p) + fc_c[0](c) (+ fc_p_img's c_img columns) ----
         f32x16 net = load_frag16(L + VT_OFF_BIAS + 0 * 32 + h * 16);
@@ -211,13 +114,16 @@ decode_fwd_kernel(DecodeArgs a) {
         for (int i = 0; i < 5; ++i) {
             const float *wl = L + VT_OFF_WL + (1 + 3 * i) * 1024;
             f32x16 hid = load_frag16(L + VT_OFF_BIAS + (1 + 2 * i) * 32 + h * 16);
+            if (SAVE && live) store_acc16(srow + (1 + i) * slot, relu16(net), h);    // slots 1..5: relu(x_i)
             hid = dense32<true>(hid, wl, net, lane);
+            if (SAVE && live) store_acc16(srow + (6 + i) * slot, relu16(hid), h);    // slots 6..10: relu(h_i)
             net = dense32<true>(net, wl + 1024, hid, lane);
             if (i < 4) net = dense32<false>(net, wl + 2048, c, lane);
             const f32x16 bb = load_frag16(L + VT_OFF_BIAS + (2 + 2 * i) * 32 + h * 16);
             net = net + bb;
         }
 
+        if (SAVE && live) store_acc16(srow + 11 * slot, relu16(net), h);            // slot 11: relu(net_5)
         // ---- heads: out = fc_out(relu(net)) ----
         {
             const f32x16 wo = load_frag16(L + VT_OFF_OUT + h * 16);
@@ -245,8 +151,6 @@ struct PackArgs {
     vt_decoder_params p;
     float *blob;
 };
-
-__device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 __global__ void decoder_pack_kernel(PackArgs a) {
     const vt_decoder_params &p = a.p;
@@ -378,7 +282,7 @@ int vt_grid_from_channels_last(const float *src, float *dst, int B, int C, int D
 int vt_decode_fwd(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
                   int lattice_nx, float lattice_box, int64_t lattice_first,
                   const float *c_img, const float *blob, double padding,
-                  float *out, float *out2, void *stream) {
+                  float *out, float *out2, float *save, void *stream) {
     if (!grid_cl || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: null argument");
     if (B <= 0 || R < 2 || N < 0) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: bad size");
     if (C != 32) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd: c_dim must be 32");
@@ -390,7 +294,7 @@ int vt_decode_fwd(const float *grid_cl, int B, int R, int C, const float *pts, i
     if (N == 0) return 0;
     if ((int64_t)B * N >= (int64_t)1 << 31) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd: B*N must be < 2^31");
     DecodeArgs a;
-    a.grid = grid_cl; a.pts = pts; a.c_img = c_img; a.blob = blob; a.out = out; a.out2 = out2;
+    a.grid = grid_cl; a.pts = pts; a.c_img = c_img; a.blob = blob; a.out = out; a.out2 = out2; a.save = save;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box;
     a.divisor = (float)(1.0 + padding + 10e-4);   // src/common.py:302, rounded to f32 as torch does
@@ -402,12 +306,18 @@ int vt_decode_fwd(const float *grid_cl, int B, int R, int C, const float *pts, i
     const size_t lds_bytes = (size_t)VT_BLOB_FLOATS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute");
         attr_set = true;
     }
-    hipLaunchKernelGGL(decode_fwd_kernel<THREADS>, dim3((unsigned)blocks), dim3(THREADS), lds_bytes, (hipStream_t)stream, a);
+    if (save)
+        hipLaunchKernelGGL((decode_fwd_kernel<THREADS, true>), dim3((unsigned)blocks), dim3(THREADS), lds_bytes, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((decode_fwd_kernel<THREADS, false>), dim3((unsigned)blocks), dim3(THREADS), lds_bytes, (hipStream_t)stream, a);
     return vt_check(hipGetLastError(), "vt_decode_fwd");
 }
 

@@ -1,0 +1,162 @@
+// Device helpers shared by the decode forward (decode.hip) and backward (decode_bwd.hip)
+// kernels: MFMA wrappers, fragment loads/stores, the reference's coordinate maths and the
+// trilinear corner set-up.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vt_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// max(x,0) as ONE instruction (v_med3_f32 x, 0, +inf).  fmaxf() on an MFMA result costs a
+// second, canonicalising v_max; inline asm is not an option: hipcc inserts the MFMA->VALU
+// wait states only for instructions it can see, and a hand-written v_max read stale
+// accumulators (measured: 6e-2 logit error).
+__device__ __forceinline__ float relu1(float x) {
+    return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff());
+}
+
+// Force the 16 values to exist in VGPRs here (stops LLVM sinking the FMAs that produce
+// them past later loads, which would keep every load of the gather in flight at once).
+__device__ __forceinline__ void pin16(f32x16 &v) {
+    asm volatile("" : "+v"(v));
+}
+
+// one dense 32x32 layer; x[s] is the B operand of k-step s
+template <bool RELU>
+__device__ __forceinline__ f32x16 dense32(f32x16 acc, const float *wl, const f32x16 &x, int lane) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        float xv = RELU ? relu1(x[s]) : x[s];
+        acc = mfma(wl[s * 64 + lane], xv, acc);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ f32x16 load_frag16(const float *p) {
+    const f32x4 *q = reinterpret_cast<const f32x4 *>(p);
+    f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
+    f32x16 r;
+    r.s0 = a.x; r.s1 = a.y; r.s2 = a.z; r.s3 = a.w;
+    r.s4 = b.x; r.s5 = b.y; r.s6 = b.z; r.s7 = b.w;
+    r.s8 = c.x; r.s9 = c.y; r.sa = c.z; r.sb = c.w;
+    r.sc = d.x; r.sd = d.y; r.se = d.z; r.sf = d.w;
+    return r;
+}
+
+// reference src/common.py:293-309 followed by ATen's align_corners=True
+// un-normalisation and border clip (decoder.py:62-68): returns the continuous
+// grid coordinate in [0, R-1].
+__device__ __forceinline__ float grid_coord(float v, float divisor, int R) {
+    float q = v / divisor + 0.5f;
+    q = (q >= 1.0f) ? 0.999f : q;
+    q = (q < 0.0f) ? 0.0f : q;
+    float g = 2.0f * q - 1.0f;
+    float f = ((g + 1.0f) / 2.0f) * (float)(R - 1);
+    return fminf(fmaxf(f, 0.0f), (float)(R - 1));
+}
+
+struct DecodeArgs {
+    const float *grid;   // [B,R,R,R,32]
+    const float *pts;    // [B,N,3] or null
+    const float *c_img;  // [B,N,32] or null
+    const float *blob;
+    float *out;
+    float *out2;
+    float *save;         // [VT_SAVE_SLOTS][total][32] activations for the backward, or null
+    uint32_t N;          // points per batch element
+    uint32_t total;      // B*N   (< 2^31, checked by the entry point)
+    uint32_t lattice_first;
+    int R;
+    int nx;
+    float box;
+    float divisor;       // 1 + padding + 10e-4
+};
+
+
+// accumulator layout (register r of lane-half h = channel (r&3)+8(r>>2)+4h) <-> a [32]-float row
+__device__ __forceinline__ void store_acc16(float *row, const f32x16 &v, int h) {
+    f32x4 *q = reinterpret_cast<f32x4 *>(row + 4 * h);
+    q[0] = f32x4{v.s0, v.s1, v.s2, v.s3};
+    q[2] = f32x4{v.s4, v.s5, v.s6, v.s7};
+    q[4] = f32x4{v.s8, v.s9, v.sa, v.sb};
+    q[6] = f32x4{v.sc, v.sd, v.se, v.sf};
+}
+__device__ __forceinline__ f32x16 load_acc16(const float *row, int h) {
+    const f32x4 *q = reinterpret_cast<const f32x4 *>(row + 4 * h);
+    const f32x4 a = q[0], b = q[2], c = q[4], d = q[6];
+    f32x16 r;
+    r.s0 = a.x; r.s1 = a.y; r.s2 = a.z; r.s3 = a.w;
+    r.s4 = b.x; r.s5 = b.y; r.s6 = b.z; r.s7 = b.w;
+    r.s8 = c.x; r.s9 = c.y; r.sa = c.z; r.sb = c.w;
+    r.sc = d.x; r.sd = d.y; r.se = d.z; r.sf = d.w;
+    return r;
+}
+// gather layout (register s of lane-half h = channel 16h+s)
+__device__ __forceinline__ void store_gather16(float *row, const f32x16 &v, int h) {
+    f32x4 *q = reinterpret_cast<f32x4 *>(row + 16 * h);
+    q[0] = f32x4{v.s0, v.s1, v.s2, v.s3};
+    q[1] = f32x4{v.s4, v.s5, v.s6, v.s7};
+    q[2] = f32x4{v.s8, v.s9, v.sa, v.sb};
+    q[3] = f32x4{v.sc, v.sd, v.se, v.sf};
+}
+__device__ __forceinline__ f32x16 relu16(const f32x16 &v) {
+    f32x16 r;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) r[s] = relu1(v[s]);
+    return r;
+}
+
+// query point of global index g (points tensor or in-kernel lattice)
+__device__ __forceinline__ void point_of(const DecodeArgs &a, uint32_t g, uint32_t n, float &px, float &py, float &pz) {
+    if (a.pts) {
+        const float *pp = a.pts + (size_t)g * 3;
+        px = pp[0]; py = pp[1]; pz = pp[2];
+    } else {
+        // box * linspace(-0.5, 0.5, nx)[i] (src/common.py:178-197, generation.py:155-157)
+        const uint32_t m = a.lattice_first + n;
+        const uint32_t nx = (uint32_t)a.nx;
+        const uint32_t t = m / nx;
+        const int iz = (int)(m - t * nx);
+        const int ix = (int)(t / nx);
+        const int iy = (int)(t - (uint32_t)ix * nx);
+        const float step = 1.0f / (float)(a.nx - 1);
+        const int half = a.nx / 2;
+        auto lin = [&](int i) {
+            float v = (i < half) ? (-0.5f + step * (float)i) : (0.5f - step * (float)(a.nx - i - 1));
+            return a.box * v;
+        };
+        px = lin(ix); py = lin(iy); pz = lin(iz);
+    }
+}
+
+// the 8 corners and weights of ATen's trilinear grid_sample (align_corners, border)
+struct Tri {
+    int x0, x1, y0, y1, z0, z1;
+    float wx0, wx1, wy0, wy1, wz0, wz1;     // weights; the +1 weight is 0 when the corner is out of bounds
+};
+__device__ __forceinline__ Tri tri_setup(float px, float py, float pz, float divisor, int R) {
+    Tri t;
+    const float fx = grid_coord(px, divisor, R), fy = grid_coord(py, divisor, R), fz = grid_coord(pz, divisor, R);
+    const float x0f = floorf(fx), y0f = floorf(fy), z0f = floorf(fz);
+    t.x0 = (int)x0f; t.y0 = (int)y0f; t.z0 = (int)z0f;
+    t.wx0 = (x0f + 1.0f) - fx; t.wy0 = (y0f + 1.0f) - fy; t.wz0 = (z0f + 1.0f) - fz;
+    t.x1 = min(t.x0 + 1, R - 1); t.y1 = min(t.y0 + 1, R - 1); t.z1 = min(t.z0 + 1, R - 1);
+    // a corner beyond the border is skipped by ATen; its weight is 0 there anyway
+    t.wx1 = (t.x0 + 1 <= R - 1) ? fx - x0f : 0.0f;
+    t.wy1 = (t.y0 + 1 <= R - 1) ? fy - y0f : 0.0f;
+    t.wz1 = (t.z0 + 1 <= R - 1) ? fz - z0f : 0.0f;
+    return t;
+}
+
+__device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+}  // namespace

@@ -21,3 +21,10 @@ static_assert(VT_BLOB_FLOATS % 4 == 0, "blob is copied as float4");
 int vt_fail(int code, const char *msg);
 int vt_check(hipError_t e, const char *where);
 int vt_num_cus();
+
+// ---- activations the training forward saves for the backward: [slot][point][32] ---------
+// 0: c (trilinear features)   1..5: relu(x_i) (block inputs)   6..10: relu(h_i)   11: relu(net_5)
+constexpr int VT_SAVE_SLOTS = 12;
+// ---- output-side gradients vt_decode_bwd leaves for the weight-gradient pass -------------
+// 0: d x_0 (fc_p / fc_c0 output)   1..5: d h_i (fc_0 output)   6..10: d block_i output (fc_1, fc_c{i+1})
+constexpr int VT_GWS_SLOTS = 11;

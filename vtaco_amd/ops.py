@@ -22,8 +22,9 @@ def blob_floats(hidden=32, c_dim=32, n_blocks=5):
     return n // 4
 
 
-def pack_decoder(fc_p_w, fc_p_b, fc_c, blocks, fc_out, fc_out2=None, out=None):
-    """Repack decoder parameters into the MFMA-fragment blob (vt_decoder_pack).
+def pack_decoder(fc_p_w, fc_p_b, fc_c, blocks, fc_out, fc_out2=None, out=None, transposed=False):
+    """Repack decoder parameters into the MFMA-fragment blob (vt_decoder_pack), or with
+    ``transposed=True`` into the transposed-weight blob of the backward (vt_decoder_pack_t).
 
     fc_c: list of (weight, bias); blocks: list of (fc0_w, fc0_b, fc1_w, fc1_b);
     fc_out / fc_out2: (weight, bias).  ``fc_p_w`` is fc_p.weight [H,3] or
@@ -55,6 +56,14 @@ def pack_decoder(fc_p_w, fc_p_b, fc_c, blocks, fc_out, fc_out2=None, out=None):
     prm.fc_out_w, prm.fc_out_b = ptr(fc_out[0], "fc_out.weight"), ptr(fc_out[1], "fc_out.bias")
     if fc_out2 is not None:
         prm.fc_out2_w, prm.fc_out2_b = ptr(fc_out2[0], "fc_out_contact.weight"), ptr(fc_out2[1], "fc_out_contact.bias")
+    if transposed:
+        n = lib.vt_decoder_blob_t_bytes(hidden, c_dim, nb) // 4
+        if n == 0:
+            raise VtError("decoder shape not built (32/32/5 only)")
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=fc_p_w.device)
+        check(lib.vt_decoder_pack_t(ctypes.byref(prm), dev_ptr(out, "blob_t"), n * 4, stream_ptr()), "vt_decoder_pack_t")
+        return out
     n = blob_floats(hidden, c_dim, nb)
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=fc_p_w.device)
@@ -101,7 +110,7 @@ def _cl_storage(grid):
     return g, dev_ptr(g.permute(0, 2, 3, 4, 1), "grid")
 
 
-def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want_contact=False, out=None):
+def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want_contact=False, out=None, save=None):
     """Fused trilinear gather + conditioned MLP (vt_decode_fwd).
 
     grid  [B,C,R,R,R] (any layout; converted to channels-last if needed)
@@ -136,7 +145,7 @@ def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want
         return (out, out2) if want_contact else out
     check(lib.vt_decode_fwd(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first,
                             dev_ptr(c_img, "c_img"), dev_ptr(blob, "blob"), float(padding),
-                            dev_ptr(out, "out"), dev_ptr(out2, "out2"), stream_ptr()), "vt_decode_fwd")
+                            dev_ptr(out, "out"), dev_ptr(out2, "out2"), dev_ptr(save, "save"), stream_ptr()), "vt_decode_fwd")
     return (out, out2) if want_contact else out
 
 
@@ -268,4 +277,66 @@ def voxel_scatter_mean_bwd(grad_grid, vi, C):
                                                 dev_ptr(vi.seg_lo, "seg_lo", I32), dev_ptr(vi.seg_hi, "seg_hi", I32),
                                                 B, T, C, vi.R, dev_ptr(g, "grad_feat"), stream_ptr()),
           "vt_voxel_scatter_mean_bwd")
+    return g
+
+
+# --------------------------------------------------------------------------------------
+# decode backward (training)
+# --------------------------------------------------------------------------------------
+def decode_save_buffer(total_points, device):
+    n = _lib.load().vt_decode_save_bytes(total_points) // 4
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def decode_bwd(grid_shape, blob_t, grad_out, save, pts=None, lattice=None, with_c_img=False, c_img=None,
+               padding=0.1, want_grid_grad=True):
+    """vt_decode_bwd + vt_decode_wgrad.  Returns (grad_grid [B,C,R,R,R] channels-last strided
+    or None, grad_c_img [B,N,C] or None, flat parameter gradients)."""
+    lib = _lib.load()
+    B, C, R = grid_shape[0], grid_shape[1], grid_shape[2]
+    grad_out = _c(grad_out.float())
+    dev = grad_out.device
+    if pts is not None:
+        pts = _c(pts.float())
+        N = pts.shape[1]
+        nx, box, first = 0, 0.0, 0
+    else:
+        nx, box, first, N = lattice
+    total = B * N
+    gws = torch.empty(lib.vt_decode_gws_bytes(total) // 4, dtype=torch.float32, device=dev)
+    ggrid = torch.zeros((B, R, R, R, C), dtype=torch.float32, device=dev) if want_grid_grad else None
+    gimg = torch.empty((B, N, C), dtype=torch.float32, device=dev) if with_c_img else None
+    st = stream_ptr()
+    check(lib.vt_decode_bwd(B, R, C, dev_ptr(pts, "pts"), N, nx, box, first, float(padding),
+                            dev_ptr(blob_t, "blob_t"), dev_ptr(grad_out, "grad_out"), dev_ptr(save, "save"),
+                            dev_ptr(gws, "gws"), dev_ptr(ggrid, "grad_grid"), dev_ptr(gimg, "grad_c_img"), st), "vt_decode_bwd")
+    wsb = lib.vt_decode_wgrad_workspace_bytes(total)
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+    p_in = 3 + C if with_c_img else 3
+    flat = torch.empty(lib.vt_decode_wgrad_floats(p_in), dtype=torch.float32, device=dev)
+    ci = _c(c_img) if with_c_img else None
+    check(lib.vt_decode_wgrad(B, dev_ptr(pts, "pts"), N, nx, box, first, dev_ptr(ci, "c_img"),
+                              dev_ptr(grad_out, "grad_out"), dev_ptr(save, "save"), dev_ptr(gws, "gws"),
+                              ctypes.c_void_p(ws.data_ptr()), wsb, dev_ptr(flat, "grads"), st), "vt_decode_wgrad")
+    return (ggrid.permute(0, 4, 1, 2, 3) if ggrid is not None else None), gimg, flat
+
+
+def split_decoder_grads(flat, p_in, hidden=32, c_dim=32, nb=5):
+    """Views of the flat gradient buffer in the order documented in vtaco_hip.h."""
+    o = 0
+
+    def take(n, shape):
+        nonlocal o
+        v = flat[o:o + n].view(shape)
+        o += n
+        return v
+    g = {"fc_p.weight": take(hidden * p_in, (hidden, p_in)), "fc_p.bias": take(hidden, (hidden,))}
+    g["fc_c.weight"] = take(nb * hidden * c_dim, (nb, hidden, c_dim))
+    g["fc_c.bias"] = take(nb * hidden, (nb, hidden))
+    g["fc_0.weight"] = take(nb * hidden * hidden, (nb, hidden, hidden))
+    g["fc_0.bias"] = take(nb * hidden, (nb, hidden))
+    g["fc_1.weight"] = take(nb * hidden * hidden, (nb, hidden, hidden))
+    g["fc_1.bias"] = take(nb * hidden, (nb, hidden))
+    g["fc_out.weight"] = take(hidden, (1, hidden))
+    g["fc_out.bias"] = take(1, (1,))
     return g
