@@ -102,6 +102,53 @@ int vt_decode_fwd(const float *grid_cl, int B, int R, int C,
                   const float *c_img, const float *blob, double padding,
                   float *out, float *out2, float *save, void *stream);
 
+/* The two halves of vt_decode_fwd on their own, for AttentionDecoder.forward_img      */
+/* (decoder.py:237-271), which transforms the sampled features before the MLP:         */
+/*   vt_sample_grid    feat[B,N,C] = trilinear sample only (decoder.py:62-68);          */
+/*   vt_decode_mlp_fwd the MLP on given features c[B,N,C] (decoder.py:255-269).         */
+int vt_sample_grid(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                   int lattice_nx, float lattice_box, int64_t lattice_first, double padding,
+                   float *feat, void *stream);
+int vt_decode_mlp_fwd(const float *c, int B, int C, const float *pts, int64_t N,
+                      int lattice_nx, float lattice_box, int64_t lattice_first,
+                      const float *blob, float *out, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* TransformerFusion forward (eval mode).                                       */
+/* Replaces: self.fuser(c_img, 1, c, 1) at decoder.py:258, i.e.                  */
+/*   TransformerFusion.forward (src/TransformerFusion.py:311-333) with           */
+/*   num_layers=1, d_model=32, key_feature_dim=64, with_pos_embed=False:          */
+/*   RelationUnit (:92-113, incl. the column re-normalisation :104),              */
+/*   TransNonlinear (:21-25), InstanceNorm1d over the N points of the chunk.       */
+/* self_attn is shared by the encoder layer and the decoder layer's               */
+/* self-attention (the reference builds both from ONE module, :291-309).           */
+/* c_img, c, out: [B,N,32].  Attention couples the N points of a chunk: N is part   */
+/* of the function's definition.                             */
+/* ------------------------------------------------------------------------- */
+typedef struct vt_fusion_unit {
+    const float *WK;         /* [64,32] head.0.WK.weight                              */
+    const float *WQ;         /* [64,32] head.0.WQ.weight                              */
+    const float *WV;         /* [32,32] head.0.WV.weight                              */
+    const float *trans_conv; /* [32,32] head.0.trans_conv.weight                      */
+    const float *linear1_w;  /* [64,32] extra_nonlinear.0.linear1.weight              */
+    const float *linear1_b;  /* [64]                                                  */
+    const float *linear2_w;  /* [32,64] extra_nonlinear.0.linear2.weight              */
+    const float *linear2_b;  /* [32]                                                  */
+    const float *norm2_w;    /* [32] extra_nonlinear.0.norm2.weight                   */
+    const float *norm2_b;    /* [32]                                                  */
+} vt_fusion_unit;
+
+typedef struct vt_fusion_params {
+    int32_t d_model;         /* must be 32 */
+    int32_t key_dim;         /* must be 64 */
+    vt_fusion_unit self_attn;   /* fuser.encoder.layers.0.self_attn (== decoder.layers.0.self_attn) */
+    vt_fusion_unit cross_attn;  /* fuser.decoder.layers.0.cross_attn                                 */
+} vt_fusion_params;
+
+size_t vt_fusion_workspace_bytes(int B, int N);
+int vt_fusion_fwd(const float *c_img, const float *c, int B, int N, const vt_fusion_params *params_host,
+                  void *workspace, size_t workspace_bytes, float *out, void *stream);
+
 /* ------------------------------------------------------------------------- */
 /* Backward of vt_decode_fwd (training).                                        */
 /* Replaces: PyTorch autograd of LocalDecoder.forward / forward_img, triggered   */

@@ -38,6 +38,18 @@ class DecoderParams(ctypes.Structure):
     ]
 
 
+class FusionUnit(ctypes.Structure):
+    """Mirror of ``vt_fusion_unit``."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("WK", "WQ", "WV", "trans_conv", "linear1_w", "linear1_b",
+                                                "linear2_w", "linear2_b", "norm2_w", "norm2_b")]
+
+
+class FusionParams(ctypes.Structure):
+    """Mirror of ``vt_fusion_params``."""
+    _fields_ = [("d_model", ctypes.c_int32), ("key_dim", ctypes.c_int32),
+                ("self_attn", FusionUnit), ("cross_attn", FusionUnit)]
+
+
 # name -> (restype, argtypes); kept in step with include/vtaco_hip.h (tests/test_abi.py
 # parses the header and checks that every declared symbol is exported and listed here)
 _VP, _I, _I64, _F, _D, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_size_t
@@ -49,6 +61,10 @@ SIGNATURES = {
     "vt_grid_to_channels_last": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "vt_grid_from_channels_last": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "vt_decode_fwd": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _D, _VP, _VP, _VP, _VP]),
+    "vt_sample_grid": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _D, _VP, _VP]),
+    "vt_decode_mlp_fwd": (_I, [_VP, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP]),
+    "vt_fusion_workspace_bytes": (_SZ, [_I, _I]),
+    "vt_fusion_fwd": (_I, [_VP, _VP, _I, _I, ctypes.POINTER(FusionParams), _VP, _SZ, _VP, _VP]),
     "vt_decoder_blob_t_bytes": (_SZ, [_I, _I, _I]),
     "vt_decoder_pack_t": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
     "vt_decode_save_bytes": (_SZ, [_I64]),

@@ -11,6 +11,7 @@ from . import decoder
 # baselines are out of scope
 decoder_dict = {
     'simple_local': decoder.LocalDecoder,
+    'attention_local': decoder.AttentionDecoder,
 }
 
 

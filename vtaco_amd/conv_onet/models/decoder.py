@@ -14,6 +14,7 @@ from torch import nn
 from ... import ops
 from ..._lib import VtError
 from ...layers import ResnetBlockFC
+from ...transformer_fusion import TransformerFusion
 
 
 class _DecodeFn(torch.autograd.Function):
@@ -156,3 +157,27 @@ class LocalDecoder(nn.Module):
         count = nx ** 3 - first if count is None else count
         return ops.decode_fwd(grid, self._blob(img=c_img is not None), c_img=c_img, padding=self.padding,
                               lattice=(nx, box, first, count), out=out)
+
+
+class AttentionDecoder(LocalDecoder):
+    """``attention_local`` (reference decoder.py:163-329): ``forward_img`` replaces the sampled
+    grid features by TransformerFusion(c_img, c) -- attention + InstanceNorm across the N query
+    points of the call -- before the same conditioned MLP (with fc_p, not fc_p_img).
+    ``forward`` / ``forward_contact`` are LocalDecoder's."""
+
+    def __init__(self, dim=3, c_dim=128, input_size=2048, hidden_size=256, n_blocks=5, leaky=False,
+                 sample_mode='bilinear', padding=0.1, with_contact=False, **kwargs):
+        super().__init__(dim=dim, c_dim=c_dim, hidden_size=hidden_size, n_blocks=n_blocks, leaky=leaky,
+                         sample_mode=sample_mode, padding=padding, with_contact=with_contact)
+        self.fuser = TransformerFusion(use_xyz=True, input_size=input_size, d_model=c_dim, num_layers=1,
+                                       key_feature_dim=64, with_pos_embed=False,
+                                       encoder_pos_embed_input_dim=3, decoder_pos_embed_input_dim=3)
+        # the reference registers fuser before fc_out_contact; order is irrelevant for load_state_dict
+
+    def forward_img(self, p, c_plane, c_img, **kwargs):
+        grid = self._grid_of(c_plane)
+        if self._wants_grad(grid, c_img) and self.training:
+            raise VtError("AttentionDecoder.forward_img: training through the fuser is not built")
+        c = ops.sample_grid(grid, p, self.padding)
+        c = self.fuser(c_img, 1, c, 1)
+        return ops.decode_mlp_fwd(c, self._blob(), p)

@@ -62,7 +62,9 @@ decode_fwd_kernel(DecodeArgs a) {
         f32x16 c;
 #pragma unroll
         for (int s = 0; s < 16; ++s) c[s] = 0.0f;
-        {
+        if (a.c_direct) {
+            c = load_frag16(a.c_direct + (size_t)g * 32 + 16 * h);
+        } else {
             const Tri t = tri_setup(px, py, pz, a.divisor, R);
             const float *gb = a.grid + (size_t)b * R * R * R * 32 + 16 * h;
             // one z-plane (4 corners, 16 x 16-byte loads per lane) at a time: the scheduling
@@ -143,6 +145,35 @@ decode_fwd_kernel(DecodeArgs a) {
                 if (live && h == 0) a.out2[g] = acc2;
             }
         }
+    }
+}
+
+// ---- trilinear gather only: feat[b,n,:] = grid sampled at the query point -----------------
+__global__ void __launch_bounds__(256) sample_grid_kernel(DecodeArgs a, float *feat) {
+    const int lane = threadIdx.x & 63, pl = lane & 31, h = lane >> 5;
+    const uint32_t ntiles = (a.total + 31u) >> 5;
+    const int R = a.R;
+    for (uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += gridDim.x * 4) {
+        uint32_t g = tile * 32u + pl;
+        const bool live = g < a.total;
+        if (!live) g = a.total - 1u;
+        const uint32_t b = g / a.N, n = g - b * a.N;
+        float px, py, pz;
+        point_of(a, g, n, px, py, pz);
+        const Tri t = tri_setup(px, py, pz, a.divisor, R);
+        const float *gb = a.grid + (size_t)b * R * R * R * 32 + 16 * h;
+        f32x16 c;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) c[s] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int zz = (k & 4) ? t.z1 : t.z0, yy = (k & 2) ? t.y1 : t.y0, xx = (k & 1) ? t.x1 : t.x0;
+            const float w = (((k & 1) ? t.wx1 : t.wx0) * ((k & 2) ? t.wy1 : t.wy0)) * ((k & 4) ? t.wz1 : t.wz0);
+            const f32x16 v = load_frag16(gb + (((size_t)zz * R + yy) * R + xx) * 32);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) c[s] = fmaf(v[s], w, c[s]);
+        }
+        if (live) store_gather16(feat + (size_t)g * 32, c, h);
     }
 }
 
@@ -279,11 +310,11 @@ int vt_grid_from_channels_last(const float *src, float *dst, int B, int C, int D
     return vt_check(hipGetLastError(), "vt_grid_from_channels_last");
 }
 
-int vt_decode_fwd(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
-                  int lattice_nx, float lattice_box, int64_t lattice_first,
-                  const float *c_img, const float *blob, double padding,
-                  float *out, float *out2, float *save, void *stream) {
-    if (!grid_cl || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: null argument");
+static int decode_launch(const float *grid_cl, const float *c_direct, int B, int R, int C, const float *pts, int64_t N,
+                         int lattice_nx, float lattice_box, int64_t lattice_first,
+                         const float *c_img, const float *blob, double padding,
+                         float *out, float *out2, float *save, void *stream) {
+    if ((!grid_cl && !c_direct) || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: null argument");
     if (B <= 0 || R < 2 || N < 0) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: bad size");
     if (C != 32) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd: c_dim must be 32");
     if (!pts) {
@@ -294,7 +325,7 @@ int vt_decode_fwd(const float *grid_cl, int B, int R, int C, const float *pts, i
     if (N == 0) return 0;
     if ((int64_t)B * N >= (int64_t)1 << 31) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd: B*N must be < 2^31");
     DecodeArgs a;
-    a.grid = grid_cl; a.pts = pts; a.c_img = c_img; a.blob = blob; a.out = out; a.out2 = out2; a.save = save;
+    a.c_direct = c_direct; a.grid = grid_cl; a.pts = pts; a.c_img = c_img; a.blob = blob; a.out = out; a.out2 = out2; a.save = save;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box;
     a.divisor = (float)(1.0 + padding + 10e-4);   // src/common.py:302, rounded to f32 as torch does
@@ -319,6 +350,43 @@ int vt_decode_fwd(const float *grid_cl, int B, int R, int C, const float *pts, i
     else
         hipLaunchKernelGGL((decode_fwd_kernel<THREADS, false>), dim3((unsigned)blocks), dim3(THREADS), lds_bytes, (hipStream_t)stream, a);
     return vt_check(hipGetLastError(), "vt_decode_fwd");
+}
+
+int vt_decode_fwd(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                  int lattice_nx, float lattice_box, int64_t lattice_first,
+                  const float *c_img, const float *blob, double padding,
+                  float *out, float *out2, float *save, void *stream) {
+    if (!grid_cl) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: null grid");
+    return decode_launch(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img, blob, padding,
+                         out, out2, save, stream);
+}
+
+int vt_decode_mlp_fwd(const float *c, int B, int C, const float *pts, int64_t N,
+                      int lattice_nx, float lattice_box, int64_t lattice_first,
+                      const float *blob, float *out, void *stream) {
+    if (!c) return vt_fail(VT_ERR_INVALID, "vt_decode_mlp_fwd: null features");
+    return decode_launch(nullptr, c, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, blob, 0.1,
+                         out, nullptr, nullptr, stream);
+}
+
+int vt_sample_grid(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                   int lattice_nx, float lattice_box, int64_t lattice_first, double padding,
+                   float *feat, void *stream) {
+    if (!grid_cl || !feat) return vt_fail(VT_ERR_INVALID, "vt_sample_grid: null argument");
+    if (B <= 0 || R < 2 || N < 0) return vt_fail(VT_ERR_INVALID, "vt_sample_grid: bad size");
+    if (C != 32) return vt_fail(VT_ERR_UNSUPPORTED, "vt_sample_grid: c_dim must be 32");
+    if (!pts && lattice_nx < 2) return vt_fail(VT_ERR_INVALID, "vt_sample_grid: lattice mode needs nx >= 2");
+    if (N == 0) return 0;
+    if ((int64_t)B * N >= (int64_t)1 << 31) return vt_fail(VT_ERR_UNSUPPORTED, "vt_sample_grid: B*N must be < 2^31");
+    DecodeArgs a;
+    a.c_direct = nullptr; a.grid = grid_cl; a.pts = pts; a.c_img = nullptr; a.blob = nullptr; a.out = nullptr; a.out2 = nullptr; a.save = nullptr;
+    a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
+    a.R = R; a.nx = lattice_nx; a.box = lattice_box; a.divisor = (float)(1.0 + padding + 10e-4);
+    int64_t blocks = (((int64_t)a.total + 31) / 32 + 3) / 4;
+    const int64_t cap = 8 * vt_num_cus();
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(sample_grid_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, feat);
+    return vt_check(hipGetLastError(), "vt_sample_grid");
 }
 
 }  // extern "C"

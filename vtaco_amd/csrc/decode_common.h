@@ -72,6 +72,7 @@ struct DecodeArgs {
     float *out;
     float *out2;
     float *save;         // [VT_SAVE_SLOTS][total][32] activations for the backward, or null
+    const float *c_direct;  // [B,N,32] conditioning features given directly (no grid gather), or null
     uint32_t N;          // points per batch element
     uint32_t total;      // B*N   (< 2^31, checked by the entry point)
     uint32_t lattice_first;

@@ -1,0 +1,335 @@
+// TransformerFusion forward (eval mode) for gfx950: the visual-tactile feature fuser of
+// AttentionDecoder.forward_img (reference src/conv_onet/models/decoder.py:237-271 ->
+// src/TransformerFusion.py:311-333; RelationUnit :92-113, TransNonlinear :21-25,
+// encoder/decoder layers :130-146, :191-219), built with num_layers=1, d_model=32,
+// key_feature_dim=64, with_pos_embed=False.
+//
+// One attention unit, X_q (queries) against X_k (keys/values), all [B,N,32]:
+//   Q = l2norm(X_q WQ^T), K = l2norm(X_k WK^T) (64-d), V = X_k WV^T
+//   A = softmax_k(Q K^T);  A <- A / (1e-9 + sum_q A)      (the reference's column re-norm)
+//   r = relu((X_q - A V) Wt^T);  y = LayerNorm(r + W2 relu(W1 r + b1) + b2);  z = X_q + y
+//   out = relu(InstanceNorm_N(z))
+// Q and K are unit vectors, so scores lie in [-1,1] and exp() needs no running max; the
+// column re-normalisation makes the usual one-pass online softmax impossible, so the N x N
+// scores are recomputed three times on the f32 matrix core instead of being stored
+// (3 x 64-deep MFMA passes; N=2048 would need 16 MB per matrix per scene otherwise):
+//   rowsum  l_q = sum_k e^{S_qk}          colsum  s_k = sum_q e^{S_qk} / l_q
+//   attend  O_q = (1/l_q) sum_k e^{S_qk} V_k / (1e-9 + s_k), chained into the epilogue MLP.
+// Score tiles come out of the MFMA with the fixed index on the lane and the streamed index
+// in the 16 registers, which is exactly the B operand the next MFMA (E x V') needs.
+#include "decode_common.h"
+
+namespace {
+
+constexpr int FU_WT = 0, FU_W1A = 1024, FU_W1B = 2048, FU_W2A = 3072, FU_W2B = 4096;
+constexpr int FU_BIAS = 5120;           // b1a, b1b, b2, gamma, beta fragments [2][16] each
+constexpr int FU_BLOB = FU_BIAS + 5 * 32;
+
+struct FusionUnitDev {
+    const float *WK, *WQ, *WV, *Wt, *l1w, *l1b, *l2w, *l2b, *lnw, *lnb;
+};
+
+// epilogue weights -> accumulator-fed fragment order (k = chan_of(s, h))
+__global__ void fusion_pack_kernel(FusionUnitDev u, float *blob) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < FU_BLOB; e += gridDim.x * blockDim.x) {
+        float v;
+        if (e < FU_BIAS) {
+            const int L = e >> 10, s = (e >> 6) & 15, l = e & 63, i = l & 31, h = l >> 5, k = chan_of(s, h);
+            if (L == 0) v = u.Wt[i * 32 + k];
+            else if (L == 1) v = u.l1w[i * 32 + k];               // linear1 rows 0..31
+            else if (L == 2) v = u.l1w[(32 + i) * 32 + k];        // linear1 rows 32..63
+            else if (L == 3) v = u.l2w[i * 64 + k];               // linear2 cols 0..31
+            else v = u.l2w[i * 64 + 32 + k];                      // linear2 cols 32..63
+        } else {
+            const int q = e - FU_BIAS, j = q >> 5, h = (q >> 4) & 1, r = q & 15, o = chan_of(r, h);
+            v = j == 0 ? u.l1b[o] : j == 1 ? u.l1b[32 + o] : j == 2 ? u.l2b[o] : j == 3 ? u.lnw[o] : u.lnb[o];
+        }
+        blob[e] = v;
+    }
+}
+
+// ---- projections: one thread per point ---------------------------------------------------
+// Qd/Kd are stored de-interleaved, [point][kk][32] with column 2s+kk at [kk][s], so that an
+// MFMA lane (row, kk) reads its 32 operands as one contiguous 128-B run.
+template <bool DO_Q, bool DO_KV>
+__global__ void __launch_bounds__(256)
+fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd, float *Kd, float *V, int total) {
+    __shared__ float w[64 * 32 * 2 + 32 * 32];
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+        if (DO_Q) w[i] = u.WQ[i];
+        if (DO_KV) w[2048 + i] = u.WK[i];
+    }
+    if (DO_KV) for (int i = threadIdx.x; i < 32 * 32; i += 256) w[4096 + i] = u.WV[i];
+    __syncthreads();
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    auto project64 = [&](const float *x, const float *W, float *dst) {
+        float out[64];
+        float ss = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            float a = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) a = fmaf(x[k], W[j * 32 + k], a);
+            out[j] = a;
+            ss = fmaf(a, a, ss);
+        }
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);      // F.normalize(p=2, eps=1e-12)
+#pragma unroll
+        for (int j = 0; j < 64; ++j) dst[(j & 1) * 32 + (j >> 1)] = out[j] * inv;
+    };
+    float x[32];
+    if (DO_Q) {
+        const f32x4 *r = reinterpret_cast<const f32x4 *>(Xq + (size_t)p * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const f32x4 t = r[i]; x[4 * i] = t.x; x[4 * i + 1] = t.y; x[4 * i + 2] = t.z; x[4 * i + 3] = t.w; }
+        project64(x, w, Qd + (size_t)p * 64);
+    }
+    if (DO_KV) {
+        const f32x4 *r = reinterpret_cast<const f32x4 *>(Xk + (size_t)p * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const f32x4 t = r[i]; x[4 * i] = t.x; x[4 * i + 1] = t.y; x[4 * i + 2] = t.z; x[4 * i + 3] = t.w; }
+        project64(x, w + 2048, Kd + (size_t)p * 64);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            float a = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) a = fmaf(x[k], w[4096 + j * 32 + k], a);
+            V[(size_t)p * 32 + j] = a;
+        }
+    }
+}
+
+// 32 operands of an MFMA lane: row `row` (clamped), half kk, of a de-interleaved [.,2,32] array
+struct Frag32 { float v[32]; };
+__device__ __forceinline__ void load_frag32(Frag32 &f, const float *base, int row, int kk) {
+    const f32x4 *r = reinterpret_cast<const f32x4 *>(base + (size_t)row * 64 + kk * 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const f32x4 t = r[i]; f.v[4 * i] = t.x; f.v[4 * i + 1] = t.y; f.v[4 * i + 2] = t.z; f.v[4 * i + 3] = t.w; }
+}
+
+// D[i][j] = stream_row_i . fixed_row_j over the 64-d keys: lane (j,h) reg r = score of
+// streamed row chan_of(r,h) against fixed row j
+__device__ __forceinline__ f32x16 score_tile(const Frag32 &stream, const Frag32 &fixed) {
+    f32x16 acc;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = mfma(stream.v[s], fixed.v[s], acc);
+    return acc;
+}
+
+// out[f] = sum over streamed rows i of exp(S_i . F_f) * (w ? w[i] : 1)
+//   rowsum: F = Q, S = K, w = null          colsum: F = K, S = Q, w = 1/l
+__global__ void __launch_bounds__(256)
+fusion_expsum_kernel(const float *Fd, const float *Sd, const float *w, float *out, int N, int recip_out) {
+    __shared__ float part[4][32];
+    const int b = blockIdx.y, f0 = blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    Fd += (size_t)b * N * 64; Sd += (size_t)b * N * 64;
+    if (w) w += (size_t)b * N;
+    Frag32 fixed;
+    load_frag32(fixed, Fd, min(f0 + j, N - 1), h);
+    float sum = 0.0f;
+    for (int s0 = wave * 32; s0 < N; s0 += 128) {
+        Frag32 stream;
+        load_frag32(stream, Sd, min(s0 + j, N - 1), h);
+        const f32x16 sc = score_tile(stream, fixed);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = s0 + chan_of(r, h);
+            if (i < N) sum = fmaf(expf(sc[r]), w ? w[i] : 1.0f, sum);
+        }
+    }
+    sum += __shfl_xor(sum, 32);
+    if (lane < 32) part[wave][lane] = sum;
+    __syncthreads();
+    if (threadIdx.x < 32 && f0 + threadIdx.x < N) {
+        const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        out[(size_t)b * N + f0 + threadIdx.x] = recip_out ? 1.0f / t : t;
+    }
+}
+
+// V'T[b][c][k] = V[b][k][c] / (1e-9 + s[b][k]); columns k >= N (padding to Npad) are zero
+__global__ void __launch_bounds__(256)
+fusion_scalev_kernel(const float *V, const float *s, float *VT, int N, int Npad, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int k = (int)(e % Npad);
+        const size_t bc = e / Npad;
+        const int c = (int)(bc % 32);
+        const size_t b = bc / 32;
+        VT[e] = (k < N) ? V[(b * N + k) * 32 + c] / (1e-9f + s[b * N + k]) : 0.0f;
+    }
+}
+
+// attention output + RelationUnit tail + TransNonlinear + residual: Z = X_q + LN(...)
+__global__ void __launch_bounds__(256)
+fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const float *linv, const float *Xq,
+                     const float *blob, float *Z, int N, int Npad) {
+    __shared__ __attribute__((aligned(16))) float lds[FU_BLOB];
+    __shared__ float opart[3][16][64];
+    for (int i = threadIdx.x; i < FU_BLOB; i += 256) lds[i] = blob[i];
+    const int b = blockIdx.y, q0 = blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    Qd += (size_t)b * N * 64; Kd += (size_t)b * N * 64; VT += (size_t)b * 32 * Npad;
+    Frag32 fixed;
+    load_frag32(fixed, Qd, min(q0 + j, N - 1), h);
+    f32x16 o;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) o[s] = 0.0f;
+    for (int k0 = wave * 32; k0 < N; k0 += 128) {
+        Frag32 stream;
+        load_frag32(stream, Kd, min(k0 + j, N - 1), h);
+        f32x16 e = score_tile(stream, fixed);                    // lane (q,h) reg r: key k0+chan_of(r,h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) e[r] = expf(e[r]);
+        // O^T[c][q] += V'T[c][k] E[k][q]: A operand lane (c,hA), step s = V'T[c][k0 + chan_of(s,hA)]
+        const f32x16 vf = load_acc16(VT + (size_t)j * Npad + k0, h);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) o = mfma(vf[s], e[s], o);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) opart[wave - 1][s][lane] = o[s];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int q = min(q0 + j, N - 1);
+    const float li = linv[(size_t)b * N + q];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) o[s] = (o[s] + opart[0][s][lane] + opart[1][s][lane] + opart[2][s][lane]) * li;
+    // lane (q,h) reg r = channel chan_of(r,h) of the attention output: the accumulator layout
+    const float *xrow = Xq + ((size_t)b * N + q) * 32;
+    const f32x16 x = load_acc16(xrow, h);
+    f32x16 d = x - o;
+    f32x16 r;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) r[s] = 0.0f;
+    r = dense32<false>(r, lds + FU_WT, d, lane);
+    r = relu16(r);                                               // relu(trans_conv(q - out))
+    f32x16 ha = load_frag16(lds + FU_BIAS + 0 * 32 + h * 16), hb = load_frag16(lds + FU_BIAS + 1 * 32 + h * 16);
+    ha = dense32<false>(ha, lds + FU_W1A, r, lane);
+    hb = dense32<false>(hb, lds + FU_W1B, r, lane);
+    f32x16 t = load_frag16(lds + FU_BIAS + 2 * 32 + h * 16);
+    t = dense32<true>(t, lds + FU_W2A, ha, lane);
+    t = dense32<true>(t, lds + FU_W2B, hb, lane);
+    t = t + r;
+    // LayerNorm over the 32 channels of this point (16 registers x 2 lane halves)
+    float m = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) m += t[s];
+    m += __shfl_xor(m, 32);
+    m *= (1.0f / 32.0f);
+    float var = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { const float c = t[s] - m; var = fmaf(c, c, var); }
+    var += __shfl_xor(var, 32);
+    const float rstd = 1.0f / sqrtf(var * (1.0f / 32.0f) + 1e-5f);
+    const f32x16 ga = load_frag16(lds + FU_BIAS + 3 * 32 + h * 16), be = load_frag16(lds + FU_BIAS + 4 * 32 + h * 16);
+    f32x16 z;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) z[s] = x[s] + ((t[s] - m) * rstd * ga[s] + be[s]);
+    if (q0 + j < N) store_acc16(Z + ((size_t)b * N + q0 + j) * 32, z, h);
+}
+
+// out = relu((z - mean_N) / sqrt(var_N + 1e-5)) per (scene, channel); one block per scene
+__global__ void __launch_bounds__(1024)
+fusion_inorm_relu_kernel(const float *Z, float *out, int N) {
+    __shared__ float red[32][33];
+    __shared__ float mean[32], rstd[32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;        // 32 row groups
+    const float *z = Z + (size_t)blockIdx.x * N * 32;
+    float *o = out + (size_t)blockIdx.x * N * 32;
+    float s = 0.0f;
+    for (int n = g; n < N; n += 32) s += z[(size_t)n * 32 + c];
+    red[g][c] = s;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float t = 0.0f;
+        for (int i = 0; i < 32; ++i) t += red[i][threadIdx.x];
+        mean[threadIdx.x] = t / (float)N;
+    }
+    __syncthreads();
+    const float m = mean[c];
+    s = 0.0f;
+    for (int n = g; n < N; n += 32) { const float d = z[(size_t)n * 32 + c] - m; s = fmaf(d, d, s); }
+    __syncthreads();
+    red[g][c] = s;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float t = 0.0f;
+        for (int i = 0; i < 32; ++i) t += red[i][threadIdx.x];
+        rstd[threadIdx.x] = 1.0f / sqrtf(t / (float)N + 1e-5f);
+    }
+    __syncthreads();
+    const float rs = rstd[c];
+    for (int n = g; n < N; n += 32) o[(size_t)n * 32 + c] = fmaxf((z[(size_t)n * 32 + c] - m) * rs, 0.0f);
+}
+
+struct FusionWs {
+    float *Qd, *Kd, *V, *VT, *l, *s, *Z, *M, *T, *blob_s, *blob_x;
+};
+
+size_t fusion_layout(int B, int N, FusionWs *ws, char *base) {
+    const size_t P = (size_t)B * N, Npad = (size_t)(N + 31) / 32 * 32;
+    size_t off = 0;
+    auto take = [&](size_t floats) { float *p = base ? (float *)(base + off) : nullptr; off += (floats * 4 + 255) / 256 * 256; return p; };
+    float *Qd = take(P * 64), *Kd = take(P * 64), *V = take(P * 32), *VT = take((size_t)B * 32 * Npad);
+    float *l = take(P), *s = take(P), *Z = take(P * 32), *M = take(P * 32), *T = take(P * 32);
+    float *bs = take(FU_BLOB), *bx = take(FU_BLOB);
+    if (ws) *ws = FusionWs{Qd, Kd, V, VT, l, s, Z, M, T, bs, bx};
+    return off;
+}
+
+FusionUnitDev unit_of(const vt_fusion_unit &u) {
+    return FusionUnitDev{u.WK, u.WQ, u.WV, u.trans_conv, u.linear1_w, u.linear1_b, u.linear2_w, u.linear2_b, u.norm2_w, u.norm2_b};
+}
+
+// one attention unit: Xq against Xk -> out = relu(IN(Xq + MHA(Xq, Xk, Xk)))
+void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const float *blob, const FusionWs &w,
+              float *out, int B, int N, hipStream_t s) {
+    const int P = B * N, Npad = (N + 31) / 32 * 32;
+    const dim3 pg((P + 255) / 256), tg((N + 31) / 32, B);
+    if (Xq == Xk) {
+        hipLaunchKernelGGL((fusion_proj_kernel<true, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
+    } else {
+        hipLaunchKernelGGL((fusion_proj_kernel<true, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
+        hipLaunchKernelGGL((fusion_proj_kernel<false, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
+    }
+    hipLaunchKernelGGL(fusion_expsum_kernel, tg, dim3(256), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1);   // 1/l_q
+    hipLaunchKernelGGL(fusion_expsum_kernel, tg, dim3(256), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0);         // s_k
+    const size_t tot = (size_t)B * 32 * Npad;
+    size_t g = (tot + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(fusion_scalev_kernel, dim3((unsigned)g), dim3(256), 0, s, w.V, w.s, w.VT, N, Npad, tot);
+    hipLaunchKernelGGL(fusion_attend_kernel, tg, dim3(256), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, Npad);
+    hipLaunchKernelGGL(fusion_inorm_relu_kernel, dim3(B), dim3(1024), 0, s, w.Z, out, N);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vt_fusion_workspace_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return fusion_layout(B, N, nullptr, nullptr);
+}
+
+int vt_fusion_fwd(const float *c_img, const float *c, int B, int N, const vt_fusion_params *p,
+                  void *workspace, size_t workspace_bytes, float *out, void *stream) {
+    if (!c_img || !c || !p || !workspace || !out) return vt_fail(VT_ERR_INVALID, "vt_fusion_fwd: null argument");
+    if (B <= 0 || N <= 0) return vt_fail(VT_ERR_INVALID, "vt_fusion_fwd: bad size");
+    if (p->d_model != 32 || p->key_dim != 64) return vt_fail(VT_ERR_UNSUPPORTED, "vt_fusion_fwd: d_model=32, key_feature_dim=64 only");
+    FusionWs w;
+    if (workspace_bytes < fusion_layout(B, N, &w, (char *)workspace)) return vt_fail(VT_ERR_WORKSPACE, "vt_fusion_fwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const FusionUnitDev us = unit_of(p->self_attn), ux = unit_of(p->cross_attn);
+    hipLaunchKernelGGL(fusion_pack_kernel, dim3(6), dim3(1024), 0, s, us, w.blob_s);
+    hipLaunchKernelGGL(fusion_pack_kernel, dim3(6), dim3(1024), 0, s, ux, w.blob_x);
+    run_unit(c, c, us, w.blob_s, w, w.M, B, N, s);                 // encoder: memory from the grid features
+    run_unit(c_img, c_img, us, w.blob_s, w, w.T, B, N, s);         // decoder self-attention (SAME weights)
+    run_unit(w.T, w.M, ux, w.blob_x, w, out, B, N, s);             // decoder cross-attention
+    return vt_check(hipGetLastError(), "vt_fusion_fwd");
+}
+
+}  // extern "C"

@@ -340,3 +340,59 @@ def split_decoder_grads(flat, p_in, hidden=32, c_dim=32, nb=5):
     g["fc_out.weight"] = take(hidden, (1, hidden))
     g["fc_out.bias"] = take(1, (1,))
     return g
+
+
+# --------------------------------------------------------------------------------------
+# AttentionDecoder pieces: sample-only, MLP-only, TransformerFusion
+# --------------------------------------------------------------------------------------
+def sample_grid(grid, pts, padding=0.1):
+    """Trilinear features [B,N,C] of ``grid`` at ``pts`` (vt_sample_grid)."""
+    B, C, D, H, W = grid.shape
+    keep, gptr = _cl_storage(grid)
+    pts = _c(pts.float())
+    N = pts.shape[1]
+    feat = torch.empty((B, N, C), dtype=torch.float32, device=grid.device)
+    if N:
+        check(_lib.load().vt_sample_grid(gptr, B, D, C, dev_ptr(pts, "pts"), N, 0, 0.0, 0, float(padding),
+                                         dev_ptr(feat, "feat"), stream_ptr()), "vt_sample_grid")
+    return feat
+
+
+def decode_mlp_fwd(c, blob, pts):
+    """The conditioned MLP on given features c [B,N,C] (vt_decode_mlp_fwd)."""
+    c = _c(c)
+    pts = _c(pts.float())
+    B, N, C = c.shape
+    out = torch.empty((B, N), dtype=torch.float32, device=c.device)
+    if N:
+        check(_lib.load().vt_decode_mlp_fwd(dev_ptr(c, "c"), B, C, dev_ptr(pts, "pts"), N, 0, 0.0, 0,
+                                            dev_ptr(blob, "blob"), dev_ptr(out, "out"), stream_ptr()), "vt_decode_mlp_fwd")
+    return out
+
+
+def fusion_fwd(c_img, c, self_attn, cross_attn):
+    """TransformerFusion forward, eval mode (vt_fusion_fwd).  ``self_attn`` / ``cross_attn``:
+    dicts with the ten tensors of a vt_fusion_unit."""
+    lib = _lib.load()
+    c_img, c = _c(c_img.float()), _c(c.float())
+    B, N, C = c.shape
+    if tuple(c_img.shape) != (B, N, C):
+        raise VtError(f"fusion: c_img {tuple(c_img.shape)} and c {tuple(c.shape)} must match")
+    keep = []
+
+    def unit(d):
+        u = _lib.FusionUnit()
+        for name, _t in _lib.FusionUnit._fields_:
+            t = _c(d[name])
+            keep.append(t)
+            setattr(u, name, dev_ptr(t, name).value)
+        return u
+    prm = _lib.FusionParams()
+    prm.d_model, prm.key_dim = C, self_attn["WK"].shape[0]
+    prm.self_attn, prm.cross_attn = unit(self_attn), unit(cross_attn)
+    nbytes = lib.vt_fusion_workspace_bytes(B, N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=c.device)
+    out = torch.empty((B, N, C), dtype=torch.float32, device=c.device)
+    check(lib.vt_fusion_fwd(dev_ptr(c_img, "c_img"), dev_ptr(c, "c"), B, N, ctypes.byref(prm),
+                            ctypes.c_void_p(ws.data_ptr()), nbytes, dev_ptr(out, "out"), stream_ptr()), "vt_fusion_fwd")
+    return out

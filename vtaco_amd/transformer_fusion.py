@@ -1,0 +1,90 @@
+"""TransformerFusion parameter container (reference src/TransformerFusion.py:269-333).
+
+Keeps the reference's parameter tree -- ``encoder.layers.0.self_attn.head.0.{WK,WQ,WV,
+trans_conv,after_norm}``, ``...extra_nonlinear.0.{linear1,linear2,norm2}``,
+``decoder.layers.0.{self_attn,cross_attn}...`` -- including the fact that the encoder
+layer and the decoder layer's self-attention are the SAME module (state_dict lists it
+under both names).  The forward is the HIP pipeline ``vt_fusion_fwd`` (eval mode: the
+reference's dropout layers are identity there; training of the fuser is not built).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import VtError
+
+
+class RelationUnit(nn.Module):
+    def __init__(self, feature_dim=512, key_feature_dim=64):
+        super().__init__()
+        self.temp = 1
+        self.WK = nn.Linear(feature_dim, key_feature_dim, bias=False)
+        self.WQ = nn.Linear(feature_dim, key_feature_dim, bias=False)
+        self.WV = nn.Linear(feature_dim, feature_dim, bias=False)
+        self.after_norm = nn.BatchNorm1d(feature_dim)          # never called by the reference either
+        self.trans_conv = nn.Linear(feature_dim, feature_dim, bias=False)
+        for lin in (self.WK, self.WQ, self.WV):
+            lin.weight.data.normal_(0, math.sqrt(2.0 / lin.out_features))
+
+
+class TransNonlinear(nn.Module):
+    def __init__(self, d_model, dim_feedforward, dropout=0.1):
+        super().__init__()
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+
+class MultiheadAttention(nn.Module):
+    def __init__(self, feature_dim=512, n_head=8, key_feature_dim=64, extra_nonlinear=True):
+        super().__init__()
+        if n_head != 1 or not extra_nonlinear:
+            raise VtError("MultiheadAttention: the fuser is built with n_head=1 and the extra non-linearity")
+        self.Nh = n_head
+        self.head = nn.ModuleList([RelationUnit(feature_dim, key_feature_dim)])
+        self.extra_nonlinear = nn.ModuleList([TransNonlinear(feature_dim, key_feature_dim)])
+
+    def unit_tensors(self):
+        h, e = self.head[0], self.extra_nonlinear[0]
+        return {"WK": h.WK.weight, "WQ": h.WQ.weight, "WV": h.WV.weight, "trans_conv": h.trans_conv.weight,
+                "linear1_w": e.linear1.weight, "linear1_b": e.linear1.bias, "linear2_w": e.linear2.weight,
+                "linear2_b": e.linear2.bias, "norm2_w": e.norm2.weight, "norm2_b": e.norm2.bias}
+
+
+class _Layer(nn.Module):
+    def __init__(self, self_attn, cross_attn=None):
+        super().__init__()
+        self.self_attn = self_attn
+        if cross_attn is not None:
+            self.cross_attn = cross_attn
+
+
+class _Stack(nn.Module):
+    def __init__(self, layer):
+        super().__init__()
+        self.layers = nn.ModuleList([layer])
+
+
+class TransformerFusion(nn.Module):
+    def __init__(self, use_xyz=True, input_size=2048, d_model=32, num_layers=1, key_feature_dim=128,
+                 with_pos_embed=True, encoder_pos_embed_input_dim=3, decoder_pos_embed_input_dim=3):
+        super().__init__()
+        if num_layers != 1 or with_pos_embed:
+            raise VtError("TransformerFusion: only num_layers=1, with_pos_embed=False (what AttentionDecoder builds)")
+        self.d_model, self.input_size = d_model, input_size
+        shared = MultiheadAttention(feature_dim=d_model, n_head=1, key_feature_dim=key_feature_dim)
+        self.encoder = _Stack(_Layer(shared))
+        self.decoder = _Stack(_Layer(shared, MultiheadAttention(feature_dim=d_model, n_head=1,
+                                                                key_feature_dim=key_feature_dim)))
+
+    def forward(self, search_feature, search_coord, template_feature, template_coord):
+        """fuse(search=c_img [B,N,C], template=c [B,N,C]) -> [B,N,C]  (TransformerFusion.py:311-333)."""
+        if self.training and torch.is_grad_enabled():
+            raise VtError("TransformerFusion: only the eval-mode forward is built (train-mode dropout + backward: not yet)")
+        layer = self.decoder.layers[0]
+        return ops.fusion_fwd(search_feature, template_feature, layer.self_attn.unit_tensors(),
+                              layer.cross_attn.unit_tensors())
