@@ -98,6 +98,22 @@ def stage_times(scene, dec, grid, nx, out, dev):
     return res
 
 
+def measured_traffic():
+    """HBM-side bytes per decode launch from the committed PMC passes (profiles/, same command
+    as this bench): (2 x FETCH_SIZE + WRITE_SIZE) KB -- the x2 is the guide's gfx950 correction
+    for 16-B-per-lane reads; None if no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")
+    try:
+        vals = {}
+        for line in open(path).read().splitlines()[1:]:
+            k, c, n, mean = line.split(",")
+            if k == "decode_fwd_kernel":
+                vals[c] = float(mean)
+        return (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +122,7 @@ def main():
     ap.add_argument("--nx", type=int, default=128)
     ap.add_argument("--mode", choices=["visual", "img"], default="visual")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode-only", action="store_true", help="skip the mesh-extract / stage timings (perf experiments)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,10 +188,12 @@ def main():
                        "nx": nx, "points_per_step_per_gpu": npts, "mode": args.mode},
             "per_gpu": npts * args.steps / wall,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": measured_traffic(),
+                         "traffic_note": "bytes/launch at the L2's memory side from rocprofv3 FETCH_SIZE/WRITE_SIZE passes "
+                                         "(profiles/r01_pmc_summary.csv); mostly Infinity-Cache hits: 8 XCD L2s each pull the 33.5 MB grid",
                          "kernel": "decode_fwd_kernel", "kernel_ms": kern_ms, "flop_per_point": flop_pt},
         }
-        if world == 1:
+        if world == 1 and not args.decode_only:
             res["mesh_extract"] = mesh_extract_stats(out.view(nx, nx, nx), nx)
             res["stages_ms"] = stage_times(scene, dec, grid, nx, out, dev)
         if world == 1 and not args.no_cpu_baseline:

@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvtaco_hip.so")
+LIB_PATH = os.environ.get("VTACO_HIP_LIB") or os.path.join(_HERE, "libvtaco_hip.so")   # env: perf-variant builds
 
 VT_MAX_BLOCKS = 8
 c_float_p = ctypes.POINTER(ctypes.c_float)

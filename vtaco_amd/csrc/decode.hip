@@ -26,6 +26,9 @@ template <int THREADS, bool SAVE>
 __global__ void __launch_bounds__(THREADS, VT_WAVES_PER_SIMD)
 decode_fwd_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef VT_DIAG_CLOCK
+    const unsigned long long dc_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     // stage the packed weights (identical for every block) into LDS
     {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(a.blob);
@@ -39,6 +42,10 @@ decode_fwd_kernel(DecodeArgs a) {
     const int h = lane >> 5;
     const int wave = threadIdx.x >> 6;
     constexpr int WPB = THREADS / 64;
+#ifdef VT_DIAG_CLOCK
+    // diagnostic build only: shader-clock vs 100 MHz real-time stamps around the tile loop
+    const unsigned long long dc_t0 = __builtin_amdgcn_s_memtime(), dc_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const uint32_t ntiles = (a.total + 31u) >> 5;
     const bool with_img = a.c_img != nullptr;
     const int R = a.R;
@@ -62,6 +69,12 @@ decode_fwd_kernel(DecodeArgs a) {
         f32x16 c;
 #pragma unroll
         for (int s = 0; s < 16; ++s) c[s] = 0.0f;
+#ifdef VT_DIAG_NOGATHER
+        if (true) {                                   // diagnostic build: no grid traffic at all
+#pragma unroll
+            for (int s = 0; s < 16; ++s) c[s] = px + (float)s;
+        } else
+#endif
         if (a.c_direct) {
             c = load_frag16(a.c_direct + (size_t)g * 32 + 16 * h);
         } else {
@@ -97,6 +110,18 @@ decode_fwd_kernel(DecodeArgs a) {
         float *srow = SAVE ? a.save + (size_t)g * 32 : nullptr;
         if (SAVE && live) store_gather16(srow, c, h);        // slot 0: c
 
+#ifdef VT_DIAG_NOMLP
+        {                                             // diagnostic build: gather only
+            float acc = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc += c[s];
+            if (live && h == 0) a.out[g] = acc;
+            continue;
+        }
+#endif
+#ifdef VT_SETPRIO
+        __builtin_amdgcn_s_setprio(VT_SETPRIO);       // matrix phase outranks the other waves' gather VALU
+#endif
         // ---- net = fc_p(p) + fc_c[0](c) (+ fc_p_img's c_img columns) ----
         f32x16 net = load_frag16(L + VT_OFF_BIAS + 0 * 32 + h * 16);
         {
@@ -125,6 +150,9 @@ decode_fwd_kernel(DecodeArgs a) {
             net = net + bb;
         }
 
+#ifdef VT_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (SAVE && live) store_acc16(srow + 11 * slot, relu16(net), h);            // slot 11: relu(net_5)
         // ---- heads: out = fc_out(relu(net)) ----
         {
@@ -135,6 +163,7 @@ decode_fwd_kernel(DecodeArgs a) {
             acc += __shfl_xor(acc, 32);
             acc += L[VT_OFF_OUT + 64];
             if (live && h == 0) a.out[g] = acc;
+#ifndef VT_DIAG_CLOCK
             if (a.out2) {
                 const f32x16 wo2 = load_frag16(L + VT_OFF_OUT + 32 + h * 16);
                 float acc2 = 0.0f;
@@ -144,8 +173,18 @@ decode_fwd_kernel(DecodeArgs a) {
                 acc2 += L[VT_OFF_OUT + 65];
                 if (live && h == 0) a.out2[g] = acc2;
             }
+#endif
         }
     }
+#ifdef VT_DIAG_CLOCK
+    if (threadIdx.x == 0 && a.out2) {
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(a.out2) + 4 * blockIdx.x;
+        dbg[0] = __builtin_amdgcn_s_memtime() - dc_t0;
+        dbg[1] = __builtin_amdgcn_s_memrealtime() - dc_r0;
+        dbg[2] = dc_r0;
+        dbg[3] = dc_r0 - dc_entry;                    // weight-staging prologue, 10 ns ticks
+    }
+#endif
 }
 
 // ---- trilinear gather only: feat[b,n,:] = grid sampled at the query point -----------------
@@ -329,10 +368,13 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box;
     a.divisor = (float)(1.0 + padding + 10e-4);   // src/common.py:302, rounded to f32 as torch does
-    constexpr int THREADS = 512;
+#ifndef VT_THREADS
+#define VT_THREADS 512
+#endif
+    constexpr int THREADS = VT_THREADS;
     const int64_t ntiles = ((int64_t)a.total + 31) / 32;
     int64_t blocks = (ntiles + THREADS / 64 - 1) / (THREADS / 64);
-    const int64_t cap = 2 * vt_num_cus();
+    const int64_t cap = (int64_t)(1024 / THREADS) * vt_num_cus();
     if (blocks > cap) blocks = cap;
     const size_t lds_bytes = (size_t)VT_BLOB_FLOATS * sizeof(float);
     static bool attr_set = false;

@@ -30,14 +30,21 @@ __device__ __forceinline__ void pin16(f32x16 &v) {
     asm volatile("" : "+v"(v));
 }
 
-// one dense 32x32 layer; x[s] is the B operand of k-step s
+// one dense 32x32 layer; x[s] is the B operand of k-step s.  With RELU the 16 v_max run as
+// one block IN FRONT of the MFMA chain (pinned): VALU instructions interleaved between
+// dependent MFMAs cost ~13 % of the matrix rate (measured, tools/probe/mlp_probe.hip).
 template <bool RELU>
 __device__ __forceinline__ f32x16 dense32(f32x16 acc, const float *wl, const f32x16 &x, int lane) {
+    f32x16 b = x;
+    if (RELU) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        float xv = RELU ? relu1(x[s]) : x[s];
-        acc = mfma(wl[s * 64 + lane], xv, acc);
+        for (int s = 0; s < 16; ++s) b[s] = relu1(x[s]);
+#ifndef VT_RELU_INTERLEAVED
+        asm volatile("" : "+v"(b));
+#endif
     }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = mfma(wl[s * 64 + lane], b[s], acc);
     return acc;
 }
 
