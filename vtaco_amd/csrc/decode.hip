@@ -40,7 +40,8 @@ decode_fwd_kernel(DecodeArgs a) {
     const int lane = threadIdx.x & 63;
     const int pl = lane & 31;
     const int h = lane >> 5;
-    const int wave = threadIdx.x >> 6;
+    // wave-uniform by construction: tell the compiler, so tile/brick index maths runs on the SALU
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int WPB = THREADS / 64;
 #ifdef VT_DIAG_CLOCK
     // diagnostic build only: shader-clock vs 100 MHz real-time stamps around the tile loop
@@ -50,20 +51,46 @@ decode_fwd_kernel(DecodeArgs a) {
     const bool with_img = a.c_img != nullptr;
     const int R = a.R;
 
-    for (uint32_t tile = blockIdx.x * WPB + wave; tile < ntiles; tile += gridDim.x * WPB) {
+    // XCD-aware tile order: workgroups b and b+8 share an XCD (and its 4 MiB L2), so each XCD
+    // gets ONE contiguous eighth of the tiles -- at 128^3 a 16-plane x-slab of the lattice, i.e.
+    // an eighth of every grid row -- instead of every XCD pulling the whole 33.5 MB grid
+    // through its own L2.  Placement only changes speed, never results.
+    uint32_t t_begin = 0, t_end = ntiles, w_idx = blockIdx.x * WPB + wave, w_cnt = gridDim.x * WPB;
+    if ((gridDim.x & 7u) == 0 && ntiles >= 8u * WPB) {
+        const uint32_t chunk = (ntiles + 7u) >> 3, xcd = blockIdx.x & 7u;
+        t_begin = min(xcd * chunk, ntiles);
+        t_end = min(t_begin + chunk, ntiles);
+        w_idx = (blockIdx.x >> 3) * WPB + wave;
+        w_cnt = (gridDim.x >> 3) * WPB;
+    }
+    for (uint32_t tile = t_begin + w_idx; tile < t_end; tile += w_cnt) {
         // Re-derive the LDS base every tile behind an opaque asm so the (loop-invariant)
         // weight reads are not hoisted out of the tile loop into ~120 extra VGPRs.
         unsigned lds_off = 0;
         asm volatile("" : "+v"(lds_off));
         const float *L = lds + lds_off;
-        uint32_t g = tile * 32u + pl;
-        const bool live = g < a.total;
-        if (!live) g = a.total - 1u;
-        const uint32_t b = g / a.N;
-        const uint32_t n = g - b * a.N;
-
+        uint32_t g, b;
+        bool live = true;
         float px, py, pz;
-        point_of(a, g, n, px, py, pz);
+        if (a.brick) {
+            // lattice tile = 2 x 4 x 4 brick of points (x,y,z): 18-27 distinct corner lines per
+            // tile instead of 68 for 32 points along z, and 16-B runs in the output
+            const uint32_t tpb = a.N >> 5, q4 = (uint32_t)a.nx >> 2;
+            b = tile / tpb;
+            const uint32_t t = tile - b * tpb;
+            const uint32_t pp = t / (q4 * q4), rem = t - pp * q4 * q4;
+            const uint32_t by = rem / q4, bz = rem - by * q4;
+            const uint32_t ixl = 2u * pp + (uint32_t)(pl >> 4), iy = 4u * by + (uint32_t)((pl >> 2) & 3), iz = 4u * bz + (uint32_t)(pl & 3);
+            const uint32_t n = (ixl * (uint32_t)a.nx + iy) * (uint32_t)a.nx + iz;
+            g = b * a.N + n;
+            lattice_point(a, a.lattice_first / ((uint32_t)a.nx * (uint32_t)a.nx) + ixl, iy, iz, px, py, pz);
+        } else {
+            g = tile * 32u + pl;
+            live = g < a.total;
+            if (!live) g = a.total - 1u;
+            b = g / a.N;
+            point_of(a, g, g - b * a.N, px, py, pz);
+        }
 
         // ---- trilinear gather: c[s] = feature channel 16h+s of this lane's point ----
         f32x16 c;
@@ -226,8 +253,9 @@ __global__ void decoder_pack_kernel(PackArgs a) {
     const vt_decoder_params &p = a.p;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < VT_BLOB_FLOATS; e += gridDim.x * blockDim.x) {
         float v = 0.0f;
-        if (e < VT_OFF_WP) {
-            const int L = e >> 10, s = (e >> 6) & 15, l = e & 63, i = l & 31, h = l >> 5;
+        if (e >= VT_OFF_WL && e < VT_OFF_WPI) {
+            const int q = e - VT_OFF_WL;
+            const int L = q >> 10, s = (q >> 6) & 15, l = q & 63, i = l & 31, h = l >> 5;
             const float *w;
             bool gather_fed;
             if (L == 0) { w = p.fc_c_w[0]; gather_fed = true; }
@@ -239,11 +267,11 @@ __global__ void decoder_pack_kernel(PackArgs a) {
             }
             const int k = gather_fed ? (16 * h + s) : chan_of(s, h);
             v = w[i * 32 + k];
-        } else if (e < VT_OFF_WPI) {
+        } else if (e >= VT_OFF_WP && e < VT_OFF_WL) {
             const int q = e - VT_OFF_WP, s = q >> 6, l = q & 63, i = l & 31, h = l >> 5;
             const int k = 2 * s + h;
             v = (k < 3) ? p.fc_p_w[i * p.p_in + k] : 0.0f;
-        } else if (e < VT_OFF_BIAS) {
+        } else if (e >= VT_OFF_WPI) {
             const int q = e - VT_OFF_WPI, s = q >> 6, l = q & 63, i = l & 31, h = l >> 5;
             v = (p.p_in > 3) ? p.fc_p_w[i * p.p_in + 3 + 16 * h + s] : 0.0f;
         } else if (e < VT_OFF_OUT) {
@@ -364,18 +392,23 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
     if (N == 0) return 0;
     if ((int64_t)B * N >= (int64_t)1 << 31) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd: B*N must be < 2^31");
     DecodeArgs a;
-    a.c_direct = c_direct; a.grid = grid_cl; a.pts = pts; a.c_img = c_img; a.blob = blob; a.out = out; a.out2 = out2; a.save = save;
+    a.c_direct = c_direct; a.grid = grid_cl; a.pts = pts; a.brick = 0; a.c_img = c_img; a.blob = blob; a.out = out; a.out2 = out2; a.save = save;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box;
     a.divisor = (float)(1.0 + padding + 10e-4);   // src/common.py:302, rounded to f32 as torch does
 #ifndef VT_THREADS
 #define VT_THREADS 512
 #endif
+    if (!pts && !save && (lattice_nx & 3) == 0) {
+        const int64_t pair = 2ll * lattice_nx * lattice_nx;            // two x-planes
+        if (lattice_first % pair == 0 && N % pair == 0) a.brick = 1;
+    }
     constexpr int THREADS = VT_THREADS;
     const int64_t ntiles = ((int64_t)a.total + 31) / 32;
     int64_t blocks = (ntiles + THREADS / 64 - 1) / (THREADS / 64);
     const int64_t cap = (int64_t)(1024 / THREADS) * vt_num_cus();
     if (blocks > cap) blocks = cap;
+    if (blocks > 8) blocks &= ~7ll;                                     // whole workgroups per XCD
     const size_t lds_bytes = (size_t)VT_BLOB_FLOATS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -421,7 +454,7 @@ int vt_sample_grid(const float *grid_cl, int B, int R, int C, const float *pts, 
     if (N == 0) return 0;
     if ((int64_t)B * N >= (int64_t)1 << 31) return vt_fail(VT_ERR_UNSUPPORTED, "vt_sample_grid: B*N must be < 2^31");
     DecodeArgs a;
-    a.c_direct = nullptr; a.grid = grid_cl; a.pts = pts; a.c_img = nullptr; a.blob = nullptr; a.out = nullptr; a.out2 = nullptr; a.save = nullptr;
+    a.c_direct = nullptr; a.brick = 0; a.grid = grid_cl; a.pts = pts; a.c_img = nullptr; a.blob = nullptr; a.out = nullptr; a.out2 = nullptr; a.save = nullptr;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box; a.divisor = (float)(1.0 + padding + 10e-4);
     int64_t blocks = (((int64_t)a.total + 31) / 32 + 3) / 4;

@@ -80,6 +80,7 @@ struct DecodeArgs {
     float *out2;
     float *save;         // [VT_SAVE_SLOTS][total][32] activations for the backward, or null
     const float *c_direct;  // [B,N,32] conditioning features given directly (no grid gather), or null
+    int brick;           // lattice mode with tiles = 2x4x4 bricks (slab aligned to x-plane pairs, nx % 4 == 0)
     uint32_t N;          // points per batch element
     uint32_t total;      // B*N   (< 2^31, checked by the entry point)
     uint32_t lattice_first;
@@ -123,6 +124,18 @@ __device__ __forceinline__ f32x16 relu16(const f32x16 &v) {
     return r;
 }
 
+// box * linspace(-0.5, 0.5, nx)[i] per axis (src/common.py:178-197, generation.py:155-157)
+__device__ __forceinline__ void lattice_point(const DecodeArgs &a, uint32_t ix, uint32_t iy, uint32_t iz,
+                                              float &px, float &py, float &pz) {
+    const float step = 1.0f / (float)(a.nx - 1);
+    const int half = a.nx / 2;
+    auto lin = [&](int i) {
+        float v = (i < half) ? (-0.5f + step * (float)i) : (0.5f - step * (float)(a.nx - i - 1));
+        return a.box * v;
+    };
+    px = lin((int)ix); py = lin((int)iy); pz = lin((int)iz);
+}
+
 // query point of global index g (points tensor or in-kernel lattice)
 __device__ __forceinline__ void point_of(const DecodeArgs &a, uint32_t g, uint32_t n, float &px, float &py, float &pz) {
     if (a.pts) {
@@ -133,16 +146,10 @@ __device__ __forceinline__ void point_of(const DecodeArgs &a, uint32_t g, uint32
         const uint32_t m = a.lattice_first + n;
         const uint32_t nx = (uint32_t)a.nx;
         const uint32_t t = m / nx;
-        const int iz = (int)(m - t * nx);
-        const int ix = (int)(t / nx);
-        const int iy = (int)(t - (uint32_t)ix * nx);
-        const float step = 1.0f / (float)(a.nx - 1);
-        const int half = a.nx / 2;
-        auto lin = [&](int i) {
-            float v = (i < half) ? (-0.5f + step * (float)i) : (0.5f - step * (float)(a.nx - i - 1));
-            return a.box * v;
-        };
-        px = lin(ix); py = lin(iy); pz = lin(iz);
+        const uint32_t iz = m - t * nx;
+        const uint32_t ix = t / nx;
+        const uint32_t iy = t - ix * nx;
+        lattice_point(a, ix, iy, iz, px, py, pz);
     }
 }
 

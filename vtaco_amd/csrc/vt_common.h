@@ -5,18 +5,21 @@
 #include "../../include/vtaco_hip.h"
 
 // ---- packed decoder blob layout (floats); see decode.hip -------------------------
-// 15 dense layers x [16 k-steps][64 lanes]  : fc_c0, then per block fc_0, fc_1, fc_c{i+1}
-constexpr int VT_OFF_WL = 0;
-// fc_p (or fc_p_img columns 0..2), K padded to 4: [2 k-steps][64 lanes]
-constexpr int VT_OFF_WP = 15 * 1024;
-// fc_p_img columns 3..34 (tactile concat): [16][64]
-constexpr int VT_OFF_WPI = VT_OFF_WP + 128;
+// Small fragments first, so that every LDS read of the visual-only path has a byte offset
+// below 64 KiB and fits the ds_read immediate (no address VALU next to the MFMAs).
 // 11 bias fragments [2 halves][16 regs]: 0 = fc_p.b + fc_c0.b, 1+2i = fc_0_i.b, 2+2i = fc_1_i.b + fc_c{i+1}.b
-constexpr int VT_OFF_BIAS = VT_OFF_WPI + 1024;
+constexpr int VT_OFF_BIAS = 0;
 // fc_out fragment [2][16], fc_out_contact fragment [2][16], fc_out.b, fc_out_contact.b, pad
 constexpr int VT_OFF_OUT = VT_OFF_BIAS + 11 * 32;
-constexpr int VT_BLOB_FLOATS = VT_OFF_OUT + 64 + 4;
+// fc_p (or fc_p_img columns 0..2), K padded to 4: [2 k-steps][64 lanes]
+constexpr int VT_OFF_WP = VT_OFF_OUT + 64 + 32;
+// 15 dense layers x [16 k-steps][64 lanes]  : fc_c0, then per block fc_0, fc_1, fc_c{i+1}
+constexpr int VT_OFF_WL = VT_OFF_WP + 128;
+// fc_p_img columns 3..34 (tactile concat): [16][64]
+constexpr int VT_OFF_WPI = VT_OFF_WL + 15 * 1024;
+constexpr int VT_BLOB_FLOATS = VT_OFF_WPI + 1024;
 static_assert(VT_BLOB_FLOATS % 4 == 0, "blob is copied as float4");
+static_assert((VT_OFF_WPI) * 4 <= 65536, "visual-only fragments must sit below the 64 KiB ds_read offset limit");
 
 int vt_fail(int code, const char *msg);
 int vt_check(hipError_t e, const char *where);
