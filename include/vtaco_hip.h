@@ -231,6 +231,37 @@ int vt_voxel_scatter_mean_fwd(const float *feat, const int *idx, const int *orde
 int vt_voxel_scatter_mean_bwd(const float *grad_grid, const int *idx, const int *seg_lo, const int *seg_hi,
                               int B, int T, int C, int R, float *grad_feat, void *stream);
 
+/* ------------------------------------------------------------------------- */
+/* UNet3D forward (inference), channels-last.                                   */
+/* Replaces (SURVEY.md section 8f "next" row 1): the SingleConv 'gcr' blocks     */
+/*   GroupNorm -> Conv3d(3,pad 1,no bias) -> ReLU (src/encoder/unet3d.py:20-72),  */
+/*   MaxPool3d(2) (:219-238), nearest upsample + concat (:283-293, 321-323) and   */
+/*   the final 1x1x1 conv (:440-441) of UNet3D.forward (:449-474).                */
+/* All activations are [B,D,H,W,C] f32; channel counts multiples of 32.           */
+/*   vt_conv3d_pack      Conv3d weight [Cout,Cin,3,3,3] -> MFMA fragment order;    */
+/*   vt_gn_scale_shift   GroupNorm statistics of the (virtually concatenated)      */
+/*                       input -> scale_shift[B][Cin][2];                          */
+/*   vt_conv3d_gcr       out = relu?(conv3x3x3(x * scale + shift)), zero padding   */
+/*                       applied after the normalisation; input = skip [..,C1],    */
+/*                       optionally followed by `low` [B,D/2,H/2,W/2,C2]            */
+/*                       nearest-upsampled (neither is materialised);               */
+/*   vt_maxpool3d_cl, vt_conv1x1_cl: the remaining two layer types;                 */
+/*   vt_voxel_scatter_mean_cl_fwd: scatter-mean writing the channels-last grid.     */
+/* ------------------------------------------------------------------------- */
+size_t vt_conv3d_packed_floats(int Cout, int Cin);
+int vt_conv3d_pack(const float *w, int Cout, int Cin, float *packed, void *stream);
+size_t vt_gn_workspace_bytes(int B, int C);
+int vt_gn_scale_shift(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                      int groups, const float *gamma, const float *beta, double eps,
+                      void *workspace, size_t workspace_bytes, float *scale_shift, void *stream);
+int vt_conv3d_gcr(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                  const float *scale_shift, const float *packed_w, int Cout, int relu, float *out, void *stream);
+int vt_maxpool3d_cl(const float *x, int B, int D, int H, int W, int C, float *out, void *stream);
+int vt_conv1x1_cl(const float *x, int64_t V, int Cin, const float *w, const float *bias, int Cout, float *out, void *stream);
+int vt_voxel_scatter_mean_cl_fwd(const float *feat, const int *idx, const int *order,
+                                 const int *seg_lo, const int *seg_hi,
+                                 int B, int T, int C, int R, float *grid_cl, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

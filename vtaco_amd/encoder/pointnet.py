@@ -85,7 +85,13 @@ class LocalPoolPointnet(nn.Module):
         if not p.is_cuda:
             raise VtError(f"LocalPoolPointnet: inputs must live on a HIP device (got {p.device})")
         vi = ops.VoxelIndex(p, self.reso_grid, self.padding)
-        grid = _ScatterMean.apply(self.point_features(p.float(), vi), vi)
+        feat = self.point_features(p.float(), vi)
+        if self.unet3d is not None and not torch.is_grad_enabled() and self.unet3d.hip_supported():
+            # inference: scatter straight into a channels-last grid, UNet3D on the HIP conv kernels,
+            # and hand the decoder the layout it samples (shape [B,C,R,R,R], channels-last strides)
+            grid = self.unet3d.forward_channels_last(ops.voxel_scatter_mean_cl_fwd(feat, vi))
+            return {'grid': grid.permute(0, 4, 1, 2, 3)}
+        grid = _ScatterMean.apply(feat, vi)
         if self.unet3d is not None:
-            grid = self.unet3d(grid)
+            grid = self.unet3d(grid)                  # training: host PyTorch-ROCm (autograd)
         return {'grid': grid}

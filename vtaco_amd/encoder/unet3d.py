@@ -15,6 +15,8 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from .. import ops
+
 
 def _norm_conv_relu(cin, cout, order, num_groups):
     """One 'SingleConv': modules named by role, in the order the string gives."""
@@ -86,7 +88,53 @@ class UNet3D(nn.Module):
             _Up(rev[i] + rev[i + 1], rev[i + 1], layer_order, num_groups) for i in range(len(rev) - 1))
         self.final_conv = nn.Conv3d(f_maps[0], out_channels, 1)
         self.testing = testing
+        self.layer_order = layer_order
+        self._pack_cache = {}
         self.final_activation = (nn.Sigmoid() if final_sigmoid else nn.Softmax(dim=1)) if is_segmentation else None
+
+    # ---- HIP inference path (channels-last, vt_conv3d_gcr) ------------------------------
+    def hip_supported(self):
+        """The HIP kernels cover the shipped configuration: 'gcr' blocks, max-pool, channel
+        counts that are multiples of 32."""
+        if self.layer_order != 'gcr':
+            return False
+        for m in self.modules():
+            if isinstance(m, nn.Conv3d) and m.kernel_size == (3, 3, 3):
+                if m.in_channels % 32 or m.out_channels % 32 or m.bias is not None:
+                    return False
+        return True
+
+    def _packed(self, conv):
+        key = id(conv)
+        stamp = (conv.weight.data_ptr(), conv.weight._version)
+        hit = self._pack_cache.get(key)
+        if hit is None or hit[0] != stamp:
+            hit = (stamp, ops.conv3d_pack(conv.weight.detach()))
+            self._pack_cache[key] = hit
+        return hit[1]
+
+    def _gcr(self, single, x, low=None):
+        gn, conv = single.groupnorm, single.conv
+        return ops.gn_conv3d_relu(x, low, gn.weight.detach(), gn.bias.detach(), gn.num_groups, self._packed(conv),
+                                  conv.out_channels, eps=gn.eps, relu=True)
+
+    def forward_channels_last(self, x):
+        """x [B,D,H,W,C] channels-last -> [B,D,H,W,out_channels]; inference only (no autograd)."""
+        skips = []
+        for i, enc in enumerate(self.encoders):
+            if i > 0:
+                x = ops.maxpool3d_cl(x)
+            x = self._gcr(enc.basic_module.SingleConv1, x)
+            x = self._gcr(enc.basic_module.SingleConv2, x)
+            skips.append(x)
+        for dec, skip in zip(self.decoders, skips[-2::-1]):
+            x = self._gcr(dec.basic_module.SingleConv1, skip, low=x)
+            x = self._gcr(dec.basic_module.SingleConv2, x)
+        x = ops.conv1x1_cl(x, self.final_conv.weight.detach(), self.final_conv.bias.detach()
+                           if self.final_conv.bias is not None else None)
+        if self.testing and self.final_activation is not None:
+            x = self.final_activation(x) if isinstance(self.final_activation, nn.Sigmoid) else torch.softmax(x, dim=-1)
+        return x
 
     def forward(self, x):
         skips = []

@@ -396,3 +396,69 @@ def fusion_fwd(c_img, c, self_attn, cross_attn):
     check(lib.vt_fusion_fwd(dev_ptr(c_img, "c_img"), dev_ptr(c, "c"), B, N, ctypes.byref(prm),
                             ctypes.c_void_p(ws.data_ptr()), nbytes, dev_ptr(out, "out"), stream_ptr()), "vt_fusion_fwd")
     return out
+
+
+# --------------------------------------------------------------------------------------
+# UNet3D forward, channels-last (vt_conv3d_* / vt_gn_* / vt_maxpool3d_cl / vt_conv1x1_cl)
+# --------------------------------------------------------------------------------------
+def voxel_scatter_mean_cl_fwd(feat, vi):
+    """Scatter-mean into a channels-last grid [B,R,R,R,C]."""
+    feat = _c(feat)
+    B, T, C = feat.shape
+    R = vi.R
+    grid = torch.empty((B, R, R, R, C), dtype=torch.float32, device=feat.device)
+    check(_lib.load().vt_voxel_scatter_mean_cl_fwd(dev_ptr(feat, "feat"), dev_ptr(vi.idx, "idx", I32),
+                                                   dev_ptr(vi.order, "order", I32), dev_ptr(vi.seg_lo, "seg_lo", I32),
+                                                   dev_ptr(vi.seg_hi, "seg_hi", I32), B, T, C, R, dev_ptr(grid, "grid"),
+                                                   stream_ptr()), "vt_voxel_scatter_mean_cl_fwd")
+    return grid
+
+
+def conv3d_pack(weight):
+    lib = _lib.load()
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    n = lib.vt_conv3d_packed_floats(Cout, Cin)
+    if n == 0 or tuple(weight.shape[2:]) != (3, 3, 3):
+        raise VtError(f"conv3d_pack: unsupported weight shape {tuple(weight.shape)}")
+    w = _c(weight)
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(lib.vt_conv3d_pack(dev_ptr(w, "w"), Cout, Cin, dev_ptr(out, "packed"), stream_ptr()), "vt_conv3d_pack")
+    return out
+
+
+def gn_conv3d_relu(x, low, gamma, beta, groups, packed_w, Cout, eps=1e-5, relu=True):
+    """relu(conv3x3x3(GroupNorm([x | upsample(low)]))) on channels-last tensors."""
+    lib = _lib.load()
+    B, D, H, W, C1 = x.shape
+    C2 = low.shape[-1] if low is not None else 0
+    C = C1 + C2
+    dev = x.device
+    wsb = lib.vt_gn_workspace_bytes(B, C)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    ss = torch.empty((B, C, 2), dtype=torch.float32, device=dev)
+    st = stream_ptr()
+    check(lib.vt_gn_scale_shift(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, groups,
+                                dev_ptr(_c(gamma), "gamma"), dev_ptr(_c(beta), "beta"), float(eps),
+                                ctypes.c_void_p(ws.data_ptr()), wsb, dev_ptr(ss, "scale_shift"), st), "vt_gn_scale_shift")
+    out = torch.empty((B, D, H, W, Cout), dtype=torch.float32, device=dev)
+    check(lib.vt_conv3d_gcr(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
+                            dev_ptr(packed_w, "packed_w"), Cout, int(relu), dev_ptr(out, "out"), st), "vt_conv3d_gcr")
+    return out
+
+
+def maxpool3d_cl(x):
+    B, D, H, W, C = x.shape
+    out = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+    check(_lib.load().vt_maxpool3d_cl(dev_ptr(x, "x"), B, D, H, W, C, dev_ptr(out, "out"), stream_ptr()), "vt_maxpool3d_cl")
+    return out
+
+
+def conv1x1_cl(x, weight, bias):
+    B, D, H, W, Cin = x.shape
+    Cout = weight.shape[0]
+    out = torch.empty((B, D, H, W, Cout), dtype=torch.float32, device=x.device)
+    w = _c(weight).reshape(Cout, Cin)
+    check(_lib.load().vt_conv1x1_cl(dev_ptr(x, "x"), B * D * H * W, Cin, dev_ptr(w, "w"),
+                                    dev_ptr(_c(bias) if bias is not None else None, "bias"), Cout,
+                                    dev_ptr(out, "out"), stream_ptr()), "vt_conv1x1_cl")
+    return out
