@@ -250,12 +250,20 @@ int vt_voxel_scatter_mean_bwd(const float *grad_grid, const int *idx, const int 
 /* ------------------------------------------------------------------------- */
 size_t vt_conv3d_packed_floats(int Cout, int Cin);
 int vt_conv3d_pack(const float *w, int Cout, int Cin, float *packed, void *stream);
-size_t vt_gn_workspace_bytes(int B, int C);
-int vt_gn_scale_shift(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
-                      int groups, const float *gamma, const float *beta, double eps,
-                      void *workspace, size_t workspace_bytes, float *scale_shift, void *stream);
+/* GroupNorm statistics travel as per-block partial sums part[B][nblk][C][2] = (sum, sumsq)   */
+/* written by the PRODUCER of a tensor: vt_conv3d_gcr's epilogue (nblk =                       */
+/* vt_conv3d_stat_blocks) or vt_channel_stats (any nblk) for pooled tensors / the input.       */
+/* vt_gn_scale_shift reduces them in a fixed order into scale_shift[B][C1+C2][2]; part2 (may   */
+/* be NULL) is the nearest-upsampled `low` source, whose sums count 8 times.                    */
+size_t vt_stats_floats(int B, int D, int H, int W, int C);
+int vt_conv3d_stat_blocks(int B, int D, int H, int W, int Cout);
+int vt_channel_stats(const float *x, int B, int64_t V, int C, int nblk, float *part, void *stream);
+int vt_gn_scale_shift(const float *part1, int nblk1, int C1, const float *part2, int nblk2, int C2,
+                      int B, int64_t voxels, int groups, const float *gamma, const float *beta, double eps,
+                      float *scale_shift, void *stream);
 int vt_conv3d_gcr(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
-                  const float *scale_shift, const float *packed_w, int Cout, int relu, float *out, void *stream);
+                  const float *scale_shift, const float *packed_w, int Cout, int relu, float *out,
+                  float *out_part, void *stream);
 int vt_maxpool3d_cl(const float *x, int B, int D, int H, int W, int C, float *out, void *stream);
 int vt_conv1x1_cl(const float *x, int64_t V, int Cin, const float *w, const float *bias, int Cout, float *out, void *stream);
 int vt_voxel_scatter_mean_cl_fwd(const float *feat, const int *idx, const int *order,

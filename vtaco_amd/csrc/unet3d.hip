@@ -5,7 +5,7 @@
 //
 // Everything is channels-last [B, D, H, W, C] f32, which is also the layout the decode kernel
 // samples, so the encoder's output needs no transpose.
-//   gn_partial/gn_finalize   GroupNorm statistics -> per (scene, channel) scale/shift
+//   channel_stats/gn_finalize GroupNorm statistics from producer-side partial sums -> scale/shift
 //   conv3d_gcr_kernel        'gcr' SingleConv = GroupNorm -> Conv3d(3x3x3, pad 1, no bias) -> ReLU
 //                            as an implicit GEMM on the f32 matrix core: D[cout][voxel] +=
 //                            W[cout][tap,cin] * Xn[tap,cin][voxel]; the normalised input tile
@@ -35,53 +35,75 @@ __device__ __forceinline__ float src_at(const Src &s, int b, int z, int y, int x
 }
 
 // ---- GroupNorm statistics ---------------------------------------------------------------------
-// partial[chunk][b][c] = (sum, sumsq) over the chunk's voxels, in double
-__global__ void __launch_bounds__(256) gn_partial_kernel(Src s, int nchunks, double *partial) {
-    __shared__ double red[8][32][2];
-    const int b = blockIdx.y, chunk = blockIdx.x;
-    const int C = s.C1 + s.C2;
-    const size_t V = (size_t)s.D * s.H * s.W;
-    const size_t v0 = V * chunk / nchunks, v1 = V * (chunk + 1) / nchunks;
+// Every producer of a tensor leaves per-block partial sums part[b][blk][c] = (sum, sumsq) over its
+// voxels (the conv epilogue for conv outputs, channel_stats_kernel for pooled tensors and the
+// scattered input).  The consumer's GroupNorm reduces them (fixed order: bit-reproducible): the
+// statistics of the virtual concat [skip | upsample(low)] are the per-channel sums of skip plus
+// 8x those of low (nearest upsampling repeats every value 8 times).
+__global__ void __launch_bounds__(256)
+channel_stats_kernel(const float *x, int C, size_t V, int nblk, float *part) {
+    __shared__ float red[8][32][2];
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const size_t v0 = V * blk / nblk, v1 = V * (blk + 1) / nblk;
     const int c = threadIdx.x & 31, vg = threadIdx.x >> 5;
+    const float *xb = x + (size_t)b * V * C;
     for (int cb = 0; cb < C; cb += 32) {
-        double sum = 0.0, sq = 0.0;
+        float sum = 0.0f, sq = 0.0f;
         for (size_t v = v0 + vg; v < v1; v += 8) {
-            const int x = (int)(v % s.W), y = (int)((v / s.W) % s.H), z = (int)(v / ((size_t)s.W * s.H));
-            const double t = (double)src_at(s, b, z, y, x, cb + c);
-            sum += t; sq += t * t;
+            const float t = xb[v * C + cb + c];
+            sum += t; sq = fmaf(t, t, sq);
         }
         red[vg][c][0] = sum; red[vg][c][1] = sq;
         __syncthreads();
         if (threadIdx.x < 32) {
-            double a = 0.0, q = 0.0;
+            float a = 0.0f, q = 0.0f;
             for (int i = 0; i < 8; ++i) { a += red[i][c][0]; q += red[i][c][1]; }
-            double *dst = partial + (((size_t)chunk * gridDim.y + b) * C + cb + c) * 2;
+            float *dst = part + (((size_t)b * nblk + blk) * C + cb + c) * 2;
             dst[0] = a; dst[1] = q;
         }
         __syncthreads();
     }
 }
 
-// scale[b][c] = rstd*gamma, shift[b][c] = beta - mean*rstd*gamma  (biased variance, as torch)
-__global__ void gn_finalize_kernel(const double *partial, int nchunks, int B, int C, int groups, double count,
-                                   const float *gamma, const float *beta, float eps, float *scale_shift) {
-    const int b = blockIdx.x, g = threadIdx.x;
-    if (g >= groups) return;
-    const int cpg = C / groups;
+struct StatSrc { const float *part; int nblk, C; };
+
+// one block per (scene, group): scale[b][c] = rstd*gamma, shift[b][c] = beta - mean*rstd*gamma
+__global__ void __launch_bounds__(256)
+gn_finalize_kernel(StatSrc s1, StatSrc s2, int groups, double count, const float *gamma, const float *beta,
+                   float eps, float *scale_shift) {
+    __shared__ double red[256][2];
+    __shared__ double stat[2];
+    const int b = blockIdx.x, g = blockIdx.y;
+    const int C = s1.C + s2.C, cpg = C / groups;
     double sum = 0.0, sq = 0.0;
-    for (int ch = 0; ch < nchunks; ++ch)
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-            const double *p = partial + (((size_t)ch * B + b) * C + c) * 2;
-            sum += p[0]; sq += p[1];
+    for (int k = 0; k < cpg; ++k) {
+        const int c = g * cpg + k;
+        const StatSrc &s = (c < s1.C) ? s1 : s2;
+        const int cc = (c < s1.C) ? c : c - s1.C;
+        const double mult = (c < s1.C) ? 1.0 : 8.0;
+        for (int blk = threadIdx.x; blk < s.nblk; blk += 256) {
+            const float *p = s.part + (((size_t)b * s.nblk + blk) * s.C + cc) * 2;
+            sum += mult * (double)p[0]; sq += mult * (double)p[1];
         }
-    const double n = count * cpg, mean = sum / n;
-    double var = sq / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const double rstd = 1.0 / sqrt(var + (double)eps);
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-        const double sc = rstd * (double)gamma[c];
+    }
+    red[threadIdx.x][0] = sum; red[threadIdx.x][1] = sq;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[threadIdx.x][0] += red[threadIdx.x + o][0]; red[threadIdx.x][1] += red[threadIdx.x + o][1]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double n = count * cpg, mean = red[0][0] / n;
+        double var = red[0][1] / n - mean * mean;                // biased variance, as torch
+        if (var < 0.0) var = 0.0;
+        stat[0] = mean; stat[1] = 1.0 / sqrt(var + (double)eps);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cpg) {
+        const int c = g * cpg + threadIdx.x;
+        const double sc = stat[1] * (double)gamma[c];
         scale_shift[((size_t)b * C + c) * 2 + 0] = (float)sc;
-        scale_shift[((size_t)b * C + c) * 2 + 1] = (float)((double)beta[c] - mean * sc);
+        scale_shift[((size_t)b * C + c) * 2 + 1] = (float)((double)beta[c] - stat[0] * sc);
     }
 }
 
@@ -104,16 +126,18 @@ struct ConvArgs {
     const float *scale_shift;   // [B][Cin][2] or null (no norm)
     const float *wp;            // packed weights
     float *out;                 // [B,D,H,W,Cout]
+    float *part;                // [B][spatial blocks][Cout][2] partial (sum, sumsq) of the output, or null
     int Cout, relu;
     int TX, TY, TZ;             // block tile of output voxels (TX*TY*TZ = 32 * waves)
     int tiles_x, tiles_y, tiles_z;
 };
 
-// NCO = output-channel blocks (of 32) per workgroup; gridDim.y covers Cout / (32*NCO)
-template <int NCO>
-__global__ void __launch_bounds__(512, 2)
+// WAVES waves per workgroup (each 32 voxels x 32*NCO output channels); gridDim.y covers Cout/(32*NCO)
+template <int NCO, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? 2 : 1)
 conv3d_gcr_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];   // [(TZ+2)(TY+2)(TX+2)][CPAD]
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [(TZ+2)(TY+2)(TX+2)][CPAD], then stats scratch
+    constexpr int THREADS = WAVES * 64;
     const Src &s = a.s;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, kk = lane >> 5;
@@ -127,7 +151,6 @@ conv3d_gcr_kernel(ConvArgs a) {
     const int nvox = PX * PY * PZ;
     const int Cin = s.C1 + s.C2;
     const int co_blk0 = blockIdx.y * NCO, nco_all = a.Cout / 32;
-    // this wave's 32 output voxels: rows of TX within the block tile
     const int rows = 32 / a.TX;                                  // y-rows per wave
     const int wy = wave * rows + j / a.TX;                       // row index inside the block tile (y, then z)
     const int lx = j % a.TX, ly = wy % a.TY, lz = wy / a.TY;
@@ -139,48 +162,101 @@ conv3d_gcr_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
 
+    // staging role of this thread: 4 consecutive channels of every (THREADS/8)-th tile voxel
+    const int sc4 = (threadIdx.x & 7) * 4, sv0 = threadIdx.x >> 3;
     for (int cib = 0; cib < Cin / 32; ++cib) {
         __syncthreads();
-        // stage the normalised input tile for channels [32 cib, 32 cib + 32)
-        for (int e = threadIdx.x; e < nvox * 32; e += blockDim.x) {
-            const int c = e & 31, v = e >> 5;
-            const int px = v % PX, py = (v / PX) % PY, pz = v / (PX * PY);
-            const int gx = x0 + px - 1, gy = y0 + py - 1, gz = z0 + pz - 1;
-            float val = 0.0f;
-            if (gx >= 0 && gx < s.W && gy >= 0 && gy < s.H && gz >= 0 && gz < s.D) {
-                const int ch = cib * 32 + c;
-                val = src_at(s, b, gz, gy, gx, ch);
-                if (a.scale_shift) {
-                    const float *ss = a.scale_shift + ((size_t)b * Cin + ch) * 2;
-                    val = fmaf(val, ss[0], ss[1]);
-                }
+        {
+            const int ch = cib * 32 + sc4;
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (a.scale_shift) {
+                const float *ss = a.scale_shift + ((size_t)b * Cin + ch) * 2;
+                sc = f32x4{ss[0], ss[2], ss[4], ss[6]}; sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
             }
-            tile[v * CPAD + c] = val;
+            const bool from_low = ch >= s.C1;
+            const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
+            for (int v = sv0; v < nvox; v += THREADS / 8) {
+                const int px = v % PX, r2 = v / PX, py = r2 % PY, pz = r2 / PY;
+                const int gx = x0 + px - 1, gy = y0 + py - 1, gz = z0 + pz - 1;
+                f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                if (gx >= 0 && gx < s.W && gy >= 0 && gy < s.H && gz >= 0 && gz < s.D) {
+                    const float *src = from_low
+                        ? s.low + ((((size_t)b * D2 + (gz >> 1)) * H2 + (gy >> 1)) * W2 + (gx >> 1)) * s.C2 + (ch - s.C1)
+                        : s.skip + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * s.C1 + ch;
+                    val = *reinterpret_cast<const f32x4 *>(src);
+                    val.x = fmaf(val.x, sc.x, sh.x); val.y = fmaf(val.y, sc.y, sh.y);
+                    val.z = fmaf(val.z, sc.z, sh.z); val.w = fmaf(val.w, sc.w, sh.w);
+                }
+                float *d = tile + v * CPAD + sc4;
+                d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+            }
         }
         __syncthreads();
-        const float *wc = a.wp + ((size_t)cib * 27 * nco_all) * 1024;
+        const float *wc = a.wp + ((size_t)cib * 27 * nco_all + co_blk0) * 1024 + lane;
+        // weights of tap 0 into registers; each tap prefetches the next one's
+        float wn[NCO][16];
+#pragma unroll
+        for (int n = 0; n < NCO; ++n)
+#pragma unroll
+            for (int st = 0; st < 16; ++st) wn[n][st] = wc[n * 1024 + st * 64];
 #pragma unroll 1
         for (int tap = 0; tap < 27; ++tap) {
+            float wcur[NCO][16];
+#pragma unroll
+            for (int n = 0; n < NCO; ++n)
+#pragma unroll
+                for (int st = 0; st < 16; ++st) wcur[n][st] = wn[n][st];
+            if (tap < 26) {
+                const float *wt = wc + (size_t)(tap + 1) * nco_all * 1024;
+#pragma unroll
+                for (int n = 0; n < NCO; ++n)
+#pragma unroll
+                    for (int st = 0; st < 16; ++st) wn[n][st] = wt[n * 1024 + st * 64];
+            }
             const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
             const float *xin = tile + (center + (dz * PY + dy) * PX + dx) * CPAD + kk;
-            const float *wt = wc + ((size_t)tap * nco_all + co_blk0) * 1024 + lane;
 #pragma unroll
             for (int st = 0; st < 16; ++st) {
                 const float bv = xin[2 * st];
 #pragma unroll
-                for (int n = 0; n < NCO; ++n) acc[n] = mfma(wt[n * 1024 + st * 64], bv, acc[n]);
+                for (int n = 0; n < NCO; ++n) acc[n] = mfma(wcur[n][st], bv, acc[n]);
             }
         }
     }
-    // epilogue: ReLU, channels-last store (lane = voxel, 16 registers = channels chan_of(r,h))
+    // epilogue: ReLU, channels-last store (lane = voxel, 16 registers = channels chan_of(r,h)),
+    // and the per-block (sum, sumsq) of what was stored, for the next layer's GroupNorm
     const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
-    if (gx < s.W && gy < s.H && gz < s.D) {
-        float *orow = a.out + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.Cout;
+    const bool valid = gx < s.W && gy < s.H && gz < s.D;
+    float *orow = a.out + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.Cout;
+    __syncthreads();                                              // tile[] is free: reuse it for the stats
+    float *sred = tile;                                           // [WAVES][NCO*32][2]
 #pragma unroll
-        for (int n = 0; n < NCO; ++n) {
-            f32x16 v = acc[n];
-            if (a.relu) v = relu16(v);
-            store_acc16(orow + (co_blk0 + n) * 32, v, kk);
+    for (int n = 0; n < NCO; ++n) {
+        f32x16 v = acc[n];
+        if (a.relu) v = relu16(v);
+        if (valid) store_acc16(orow + (co_blk0 + n) * 32, v, kk);
+        if (a.part) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sm = valid ? v[r] : 0.0f, sq = sm * sm;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
+                if (j == 0) {
+                    float *d = sred + ((wave * NCO + n) * 32 + chan_of(r, kk)) * 2;
+                    d[0] = sm; d[1] = sq;
+                }
+            }
+        }
+    }
+    if (a.part) {
+        __syncthreads();
+        const int spatial = blockIdx.x % (a.tiles_x * a.tiles_y * a.tiles_z);
+        const int nsp = a.tiles_x * a.tiles_y * a.tiles_z;
+        for (int e = threadIdx.x; e < NCO * 32 * 2; e += THREADS) {
+            float tsum = 0.0f;
+            for (int w = 0; w < WAVES; ++w) tsum += sred[w * NCO * 64 + e];
+            const int n = e >> 6, c2 = e & 63;                    // c2 = channel*2 + {sum,sq}
+            a.part[(((size_t)b * nsp + spatial) * a.Cout + (co_blk0 + n) * 32) * 2 + c2] = tsum;
         }
     }
 }
@@ -247,6 +323,38 @@ bool src_ok(const Src &s, int B) {
     return true;
 }
 
+static int conv_tile(int D, int H, int W, int waves, int &TX, int &TY, int &TZ) {
+    TX = W >= 32 ? 32 : (W >= 16 ? 16 : (W >= 8 ? 8 : 4));
+    const int rows_total = waves * (32 / TX);
+    TY = rows_total < H ? rows_total : H;
+    while (rows_total % TY) --TY;
+    TZ = rows_total / TY;
+    return ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ);
+}
+
+static int conv_waves(int B, int D, int H, int W, int nco) {
+    // fewest blocks-per-launch that still fills the chip: 8 waves per workgroup when the volume is
+    // large, down to 1 for the 8^3 / 16^3 levels
+    for (int waves = 8; waves > 1; waves >>= 1) {
+        int TX, TY, TZ;
+        if ((size_t)conv_tile(D, H, W, waves, TX, TY, TZ) * B * nco >= 512) return waves;
+    }
+    return 1;
+}
+
+template <int NCO, int WAVES>
+static int conv_launch(const ConvArgs &a, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_kernel<NCO, WAVES>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr: hipFuncSetAttribute");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3d_gcr_kernel<NCO, WAVES>), grid, dim3(WAVES * 64), lds, st, a);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -266,60 +374,72 @@ int vt_conv3d_pack(const float *w, int Cout, int Cin, float *packed, void *strea
     return vt_check(hipGetLastError(), "vt_conv3d_pack");
 }
 
-size_t vt_gn_workspace_bytes(int B, int C) { return (size_t)512 * B * C * 2 * sizeof(double); }
-
-int vt_gn_scale_shift(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
-                      int groups, const float *gamma, const float *beta, double eps,
-                      void *workspace, size_t workspace_bytes, float *scale_shift, void *stream) {
-    Src s{skip, low, C1, low ? C2 : 0, D, H, W};
-    if (!src_ok(s, B) || !gamma || !beta || !workspace || !scale_shift) return vt_fail(VT_ERR_INVALID, "vt_gn_scale_shift: bad argument");
-    const int C = s.C1 + s.C2;
-    if (groups <= 0 || groups > 64 || C % groups) return vt_fail(VT_ERR_INVALID, "vt_gn_scale_shift: bad group count");
+// partial-statistics buffers: floats needed for a tensor [B, D,H,W, C]
+size_t vt_stats_floats(int B, int D, int H, int W, int C) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    // generous upper bound on the number of partial blocks a producer uses (conv tiles or stats chunks)
     const size_t V = (size_t)D * H * W;
-    int nchunks = (int)((V + 511) / 512);
-    if (nchunks > 512) nchunks = 512;
-    if (workspace_bytes < (size_t)nchunks * B * C * 2 * sizeof(double)) return vt_fail(VT_ERR_WORKSPACE, "vt_gn_scale_shift: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunks, B), dim3(256), 0, st, s, nchunks, (double *)workspace);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, st, (const double *)workspace, nchunks, B, C, groups,
-                       (double)V, gamma, beta, (float)eps, scale_shift);
+    size_t nblk = (V + 31) / 32;
+    if (nblk < 1024) nblk = 1024;
+    return (size_t)B * nblk * C * 2 + 4;
+}
+
+// number of spatial partial blocks vt_conv3d_gcr writes per scene for this output shape
+int vt_conv3d_stat_blocks(int B, int D, int H, int W, int Cout) {
+    int TX, TY, TZ;
+    return conv_tile(D, H, W, conv_waves(B, D, H, W, Cout / 32), TX, TY, TZ);
+}
+
+int vt_channel_stats(const float *x, int B, int64_t V, int C, int nblk, float *part, void *stream) {
+    if (!x || !part || B <= 0 || V <= 0 || C <= 0 || (C & 31) || nblk <= 0) return vt_fail(VT_ERR_INVALID, "vt_channel_stats: bad argument");
+    hipLaunchKernelGGL(channel_stats_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, x, C, (size_t)V, nblk, part);
+    return vt_check(hipGetLastError(), "vt_channel_stats");
+}
+
+int vt_gn_scale_shift(const float *part1, int nblk1, int C1, const float *part2, int nblk2, int C2,
+                      int B, int64_t voxels, int groups, const float *gamma, const float *beta, double eps,
+                      float *scale_shift, void *stream) {
+    if (!part1 || nblk1 <= 0 || C1 <= 0 || !gamma || !beta || !scale_shift || B <= 0 || voxels <= 0)
+        return vt_fail(VT_ERR_INVALID, "vt_gn_scale_shift: bad argument");
+    if (!part2) { nblk2 = 0; C2 = 0; }
+    const int C = C1 + C2;
+    if (groups <= 0 || C % groups || C / groups > 256) return vt_fail(VT_ERR_INVALID, "vt_gn_scale_shift: bad group count");
+    StatSrc s1{part1, nblk1, C1}, s2{part2, nblk2, C2};
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B, groups), dim3(256), 0, (hipStream_t)stream, s1, s2, groups,
+                       (double)voxels, gamma, beta, (float)eps, scale_shift);
     return vt_check(hipGetLastError(), "vt_gn_scale_shift");
 }
 
 int vt_conv3d_gcr(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
-                  const float *scale_shift, const float *packed_w, int Cout, int relu, float *out, void *stream) {
+                  const float *scale_shift, const float *packed_w, int Cout, int relu, float *out,
+                  float *out_part, void *stream) {
     ConvArgs a;
     a.s = Src{skip, low, C1, low ? C2 : 0, D, H, W};
     if (!src_ok(a.s, B) || !packed_w || !out) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr: bad argument");
     if (Cout <= 0 || (Cout & 31)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr: Cout must be a multiple of 32");
-    a.scale_shift = scale_shift; a.wp = packed_w; a.out = out; a.Cout = Cout; a.relu = relu;
-    // block tile: 8 waves x 32 voxels; a wave covers rows of TX <= 32 voxels along x
-    a.TX = W >= 32 ? 32 : (W >= 16 ? 16 : (W >= 8 ? 8 : 4));
-    const int rows_total = 8 * (32 / a.TX);                       // y-rows (then z) per block
-    a.TY = rows_total < H ? rows_total : H;
-    while (rows_total % a.TY) --a.TY;                              // TY must divide the row count
-    a.TZ = rows_total / a.TY;
-    a.tiles_x = (W + a.TX - 1) / a.TX; a.tiles_y = (H + a.TY - 1) / a.TY; a.tiles_z = (D + a.TZ - 1) / a.TZ;
-    const size_t lds = (size_t)(a.TX + 2) * (a.TY + 2) * (a.TZ + 2) * CPAD * sizeof(float);
-    if (lds > 160 * 1024) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr: tile does not fit LDS");
+    a.scale_shift = scale_shift; a.wp = packed_w; a.out = out; a.part = out_part; a.Cout = Cout; a.relu = relu;
     const int nco = Cout / 32;
-    const size_t spatial_blocks = (size_t)a.tiles_x * a.tiles_y * a.tiles_z * B;
-    int per = nco;                                                 // cout blocks per workgroup: fewer when the volume is small
-    while (per > 1 && (per > 4 || spatial_blocks * (nco / per) < 256)) per >>= 1;
-    if (nco % per) per = 1;
+    const int waves = conv_waves(B, D, H, W, nco);
+    const int nsp = conv_tile(D, H, W, waves, a.TX, a.TY, a.TZ);
+    a.tiles_x = (W + a.TX - 1) / a.TX; a.tiles_y = (H + a.TY - 1) / a.TY; a.tiles_z = (D + a.TZ - 1) / a.TZ;
+    size_t lds = (size_t)(a.TX + 2) * (a.TY + 2) * (a.TZ + 2) * CPAD * sizeof(float);
+    const size_t spatial_blocks = (size_t)nsp * B;
+    int per = 1;                                                   // cout blocks per workgroup: share the staged tile when
+    if (waves == 8) {                                              // the launch has blocks to spare
+        per = nco;
+        while (per > 1 && (per > 4 || spatial_blocks * (nco / per) < 512 || nco % per)) per >>= 1;
+    }
+    const size_t stat_lds = (size_t)waves * per * 64 * sizeof(float);
+    if (stat_lds > lds) lds = stat_lds;
+    if (lds > 160 * 1024) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr: tile does not fit LDS");
     const dim3 grid((unsigned)spatial_blocks, (unsigned)(nco / per));
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr: hipFuncSetAttribute");
-        attr_set = true;
-    }
-    if (per == 1) hipLaunchKernelGGL(conv3d_gcr_kernel<1>, grid, dim3(512), lds, st, a);
-    else if (per == 2) hipLaunchKernelGGL(conv3d_gcr_kernel<2>, grid, dim3(512), lds, st, a);
-    else hipLaunchKernelGGL(conv3d_gcr_kernel<4>, grid, dim3(512), lds, st, a);
+    int rc = 0;
+    if (waves == 8) rc = per == 4 ? conv_launch<4, 8>(a, grid, lds, st) : per == 2 ? conv_launch<2, 8>(a, grid, lds, st) : conv_launch<1, 8>(a, grid, lds, st);
+    else if (waves == 4) rc = conv_launch<1, 4>(a, grid, lds, st);
+    else if (waves == 2) rc = conv_launch<1, 2>(a, grid, lds, st);
+    else rc = conv_launch<1, 1>(a, grid, lds, st);
+    if (rc) return rc;
     return vt_check(hipGetLastError(), "vt_conv3d_gcr");
 }
 

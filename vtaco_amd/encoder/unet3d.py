@@ -113,23 +113,28 @@ class UNet3D(nn.Module):
             self._pack_cache[key] = hit
         return hit[1]
 
-    def _gcr(self, single, x, low=None):
+    def _gcr(self, single, x, x_stats, low=None, low_stats=None):
         gn, conv = single.groupnorm, single.conv
-        return ops.gn_conv3d_relu(x, low, gn.weight.detach(), gn.bias.detach(), gn.num_groups, self._packed(conv),
-                                  conv.out_channels, eps=gn.eps, relu=True)
+        return ops.gn_conv3d_relu(x, x_stats, low, low_stats, gn.weight.detach(), gn.bias.detach(), gn.num_groups,
+                                  self._packed(conv), conv.out_channels, eps=gn.eps, relu=True)
 
     def forward_channels_last(self, x):
-        """x [B,D,H,W,C] channels-last -> [B,D,H,W,out_channels]; inference only (no autograd)."""
+        """x [B,D,H,W,C] channels-last -> [B,D,H,W,out_channels]; inference only (no autograd).
+        GroupNorm statistics are produced by whoever writes a tensor (conv epilogue / a stats pass
+        for the input and the pooled tensors) and consumed by the next conv's prologue."""
         skips = []
+        st = None
         for i, enc in enumerate(self.encoders):
             if i > 0:
                 x = ops.maxpool3d_cl(x)
-            x = self._gcr(enc.basic_module.SingleConv1, x)
-            x = self._gcr(enc.basic_module.SingleConv2, x)
-            skips.append(x)
-        for dec, skip in zip(self.decoders, skips[-2::-1]):
-            x = self._gcr(dec.basic_module.SingleConv1, skip, low=x)
-            x = self._gcr(dec.basic_module.SingleConv2, x)
+            if i > 0 or st is None:
+                st = ops.channel_stats(x)
+            x, st = self._gcr(enc.basic_module.SingleConv1, x, st)
+            x, st = self._gcr(enc.basic_module.SingleConv2, x, st)
+            skips.append((x, st))
+        for dec, (skip, skip_st) in zip(self.decoders, skips[-2::-1]):
+            x, st = self._gcr(dec.basic_module.SingleConv1, skip, skip_st, low=x, low_stats=st)
+            x, st = self._gcr(dec.basic_module.SingleConv2, x, st)
         x = ops.conv1x1_cl(x, self.final_conv.weight.detach(), self.final_conv.bias.detach()
                            if self.final_conv.bias is not None else None)
         if self.testing and self.final_activation is not None:

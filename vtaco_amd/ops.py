@@ -426,24 +426,36 @@ def conv3d_pack(weight):
     return out
 
 
-def gn_conv3d_relu(x, low, gamma, beta, groups, packed_w, Cout, eps=1e-5, relu=True):
-    """relu(conv3x3x3(GroupNorm([x | upsample(low)]))) on channels-last tensors."""
+def channel_stats(x):
+    """Per-block partial (sum, sumsq) of a channels-last tensor: (part, nblk)."""
+    B, D, H, W, C = x.shape
+    V = D * H * W
+    nblk = max(1, min(1024, V // 64))
+    part = torch.empty((B, nblk, C, 2), dtype=torch.float32, device=x.device)
+    check(_lib.load().vt_channel_stats(dev_ptr(x, "x"), B, V, C, nblk, dev_ptr(part, "part"), stream_ptr()), "vt_channel_stats")
+    return part, nblk
+
+
+def gn_conv3d_relu(x, x_stats, low, low_stats, gamma, beta, groups, packed_w, Cout, eps=1e-5, relu=True):
+    """relu(conv3x3x3(GroupNorm([x | upsample(low)]))) on channels-last tensors; the statistics
+    come from the producers' partial sums.  Returns (out, out_stats)."""
     lib = _lib.load()
     B, D, H, W, C1 = x.shape
     C2 = low.shape[-1] if low is not None else 0
-    C = C1 + C2
     dev = x.device
-    wsb = lib.vt_gn_workspace_bytes(B, C)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    ss = torch.empty((B, C, 2), dtype=torch.float32, device=dev)
+    ss = torch.empty((B, C1 + C2, 2), dtype=torch.float32, device=dev)
     st = stream_ptr()
-    check(lib.vt_gn_scale_shift(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, groups,
-                                dev_ptr(_c(gamma), "gamma"), dev_ptr(_c(beta), "beta"), float(eps),
-                                ctypes.c_void_p(ws.data_ptr()), wsb, dev_ptr(ss, "scale_shift"), st), "vt_gn_scale_shift")
+    p2, n2 = low_stats if low is not None else (None, 0)
+    check(lib.vt_gn_scale_shift(dev_ptr(x_stats[0], "part1"), x_stats[1], C1, dev_ptr(p2, "part2"), n2, C2, B, D * H * W,
+                                groups, dev_ptr(_c(gamma), "gamma"), dev_ptr(_c(beta), "beta"), float(eps),
+                                dev_ptr(ss, "scale_shift"), st), "vt_gn_scale_shift")
     out = torch.empty((B, D, H, W, Cout), dtype=torch.float32, device=dev)
+    nblk = lib.vt_conv3d_stat_blocks(B, D, H, W, Cout)
+    part = torch.empty((B, nblk, Cout, 2), dtype=torch.float32, device=dev)
     check(lib.vt_conv3d_gcr(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
-                            dev_ptr(packed_w, "packed_w"), Cout, int(relu), dev_ptr(out, "out"), st), "vt_conv3d_gcr")
-    return out
+                            dev_ptr(packed_w, "packed_w"), Cout, int(relu), dev_ptr(out, "out"), dev_ptr(part, "part"), st),
+          "vt_conv3d_gcr")
+    return out, (part, nblk)
 
 
 def maxpool3d_cl(x):
