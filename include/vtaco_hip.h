@@ -256,7 +256,7 @@ int vt_conv3d_pack(const float *w, int Cout, int Cin, float *packed, void *strea
 /* vt_gn_scale_shift reduces them in a fixed order into scale_shift[B][C1+C2][2]; part2 (may   */
 /* be NULL) is the nearest-upsampled `low` source, whose sums count 8 times.                    */
 size_t vt_stats_floats(int B, int D, int H, int W, int C);
-int vt_conv3d_stat_blocks(int B, int D, int H, int W, int Cout);
+int vt_conv3d_stat_blocks(int B, int D, int H, int W, int Cin, int Cout);
 int vt_channel_stats(const float *x, int B, int64_t V, int C, int nblk, float *part, void *stream);
 int vt_gn_scale_shift(const float *part1, int nblk1, int C1, const float *part2, int nblk2, int C2,
                       int B, int64_t voxels, int groups, const float *gamma, const float *beta, double eps,

@@ -85,7 +85,7 @@ SIGNATURES = {
     "vt_conv3d_packed_floats": (_SZ, [_I, _I]),
     "vt_conv3d_pack": (_I, [_VP, _I, _I, _VP, _VP]),
     "vt_stats_floats": (_SZ, [_I, _I, _I, _I, _I]),
-    "vt_conv3d_stat_blocks": (_I, [_I, _I, _I, _I, _I]),
+    "vt_conv3d_stat_blocks": (_I, [_I, _I, _I, _I, _I, _I]),
     "vt_channel_stats": (_I, [_VP, _I, _I64, _I, _I, _VP, _VP]),
     "vt_gn_scale_shift": (_I, [_VP, _I, _I, _VP, _I, _I, _I, _I64, _I, _VP, _VP, _D, _VP, _VP]),
     "vt_conv3d_gcr": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),

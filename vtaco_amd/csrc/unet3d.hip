@@ -132,6 +132,82 @@ struct ConvArgs {
     int tiles_x, tiles_y, tiles_z;
 };
 
+// stage channels [32 cib, 32 cib+32) of the normalised input tile (origin x0-1,y0-1,z0-1) into LDS;
+// `tid`/`nthr` = this thread's rank among the threads that share the tile
+__device__ __forceinline__ void stage_tile(float *tile, const ConvArgs &a, int b, int cib, int x0, int y0, int z0,
+                                           int PX, int PY, int nvox, int tid, int nthr) {
+    const Src &s = a.s;
+    const int Cin = s.C1 + s.C2;
+    const int sc4 = (tid & 7) * 4, ch = cib * 32 + sc4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (a.scale_shift) {
+        const float *ss = a.scale_shift + ((size_t)b * Cin + ch) * 2;
+        sc = f32x4{ss[0], ss[2], ss[4], ss[6]}; sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
+    }
+    const bool from_low = ch >= s.C1;
+    const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
+    for (int v = tid >> 3; v < nvox; v += nthr >> 3) {
+        const int px = v % PX, r2 = v / PX, py = r2 % PY, pz = r2 / PY;
+        const int gx = x0 + px - 1, gy = y0 + py - 1, gz = z0 + pz - 1;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (gx >= 0 && gx < s.W && gy >= 0 && gy < s.H && gz >= 0 && gz < s.D) {
+            const float *src = from_low
+                ? s.low + ((((size_t)b * D2 + (gz >> 1)) * H2 + (gy >> 1)) * W2 + (gx >> 1)) * s.C2 + (ch - s.C1)
+                : s.skip + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * s.C1 + ch;
+            val = *reinterpret_cast<const f32x4 *>(src);
+            val.x = fmaf(val.x, sc.x, sh.x); val.y = fmaf(val.y, sc.y, sh.y);
+            val.z = fmaf(val.z, sc.z, sh.z); val.w = fmaf(val.w, sc.w, sh.w);
+        }
+        float *d = tile + v * CPAD + sc4;
+        d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+    }
+}
+
+// 27 taps x 16 k-steps of MFMAs for one staged channel block; weight fragments double-buffered in registers
+template <int NCO>
+__device__ __forceinline__ void conv_taps(f32x16 (&acc)[NCO], const float *tile, const float *wc, int nco_all,
+                                          int center, int PX, int PY, int kk) {
+    float wn[NCO][16];
+#pragma unroll
+    for (int n = 0; n < NCO; ++n)
+#pragma unroll
+        for (int st = 0; st < 16; ++st) wn[n][st] = wc[n * 1024 + st * 64];
+#pragma unroll 1
+    for (int tap = 0; tap < 27; ++tap) {
+        float wcur[NCO][16];
+#pragma unroll
+        for (int n = 0; n < NCO; ++n)
+#pragma unroll
+            for (int st = 0; st < 16; ++st) wcur[n][st] = wn[n][st];
+        if (tap < 26) {
+            const float *wt = wc + (size_t)(tap + 1) * nco_all * 1024;
+#pragma unroll
+            for (int n = 0; n < NCO; ++n)
+#pragma unroll
+                for (int st = 0; st < 16; ++st) wn[n][st] = wt[n * 1024 + st * 64];
+        }
+        const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+        const float *xin = tile + (center + (dz * PY + dy) * PX + dx) * CPAD + kk;
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const float bv = xin[2 * st];
+#pragma unroll
+            for (int n = 0; n < NCO; ++n) acc[n] = mfma(wcur[n][st], bv, acc[n]);
+        }
+    }
+}
+
+// per-channel (sum, sumsq) over the wave's 32 voxels of one 32-channel block -> sred[chan][2]
+__device__ __forceinline__ void wave_stats(const f32x16 &v, bool valid, int j, int kk, float *sred) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float sm = valid ? v[r] : 0.0f, sq = sm * sm;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
+        if (j == 0) { sred[chan_of(r, kk) * 2] = sm; sred[chan_of(r, kk) * 2 + 1] = sq; }
+    }
+}
+
 // WAVES waves per workgroup (each 32 voxels x 32*NCO output channels); gridDim.y covers Cout/(32*NCO)
 template <int NCO, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? 2 : 1)
@@ -162,66 +238,11 @@ conv3d_gcr_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
 
-    // staging role of this thread: 4 consecutive channels of every (THREADS/8)-th tile voxel
-    const int sc4 = (threadIdx.x & 7) * 4, sv0 = threadIdx.x >> 3;
     for (int cib = 0; cib < Cin / 32; ++cib) {
         __syncthreads();
-        {
-            const int ch = cib * 32 + sc4;
-            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-            if (a.scale_shift) {
-                const float *ss = a.scale_shift + ((size_t)b * Cin + ch) * 2;
-                sc = f32x4{ss[0], ss[2], ss[4], ss[6]}; sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
-            }
-            const bool from_low = ch >= s.C1;
-            const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
-            for (int v = sv0; v < nvox; v += THREADS / 8) {
-                const int px = v % PX, r2 = v / PX, py = r2 % PY, pz = r2 / PY;
-                const int gx = x0 + px - 1, gy = y0 + py - 1, gz = z0 + pz - 1;
-                f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                if (gx >= 0 && gx < s.W && gy >= 0 && gy < s.H && gz >= 0 && gz < s.D) {
-                    const float *src = from_low
-                        ? s.low + ((((size_t)b * D2 + (gz >> 1)) * H2 + (gy >> 1)) * W2 + (gx >> 1)) * s.C2 + (ch - s.C1)
-                        : s.skip + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * s.C1 + ch;
-                    val = *reinterpret_cast<const f32x4 *>(src);
-                    val.x = fmaf(val.x, sc.x, sh.x); val.y = fmaf(val.y, sc.y, sh.y);
-                    val.z = fmaf(val.z, sc.z, sh.z); val.w = fmaf(val.w, sc.w, sh.w);
-                }
-                float *d = tile + v * CPAD + sc4;
-                d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
-            }
-        }
+        stage_tile(tile, a, b, cib, x0, y0, z0, PX, PY, nvox, threadIdx.x, THREADS);
         __syncthreads();
-        const float *wc = a.wp + ((size_t)cib * 27 * nco_all + co_blk0) * 1024 + lane;
-        // weights of tap 0 into registers; each tap prefetches the next one's
-        float wn[NCO][16];
-#pragma unroll
-        for (int n = 0; n < NCO; ++n)
-#pragma unroll
-            for (int st = 0; st < 16; ++st) wn[n][st] = wc[n * 1024 + st * 64];
-#pragma unroll 1
-        for (int tap = 0; tap < 27; ++tap) {
-            float wcur[NCO][16];
-#pragma unroll
-            for (int n = 0; n < NCO; ++n)
-#pragma unroll
-                for (int st = 0; st < 16; ++st) wcur[n][st] = wn[n][st];
-            if (tap < 26) {
-                const float *wt = wc + (size_t)(tap + 1) * nco_all * 1024;
-#pragma unroll
-                for (int n = 0; n < NCO; ++n)
-#pragma unroll
-                    for (int st = 0; st < 16; ++st) wn[n][st] = wt[n * 1024 + st * 64];
-            }
-            const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
-            const float *xin = tile + (center + (dz * PY + dy) * PX + dx) * CPAD + kk;
-#pragma unroll
-            for (int st = 0; st < 16; ++st) {
-                const float bv = xin[2 * st];
-#pragma unroll
-                for (int n = 0; n < NCO; ++n) acc[n] = mfma(wcur[n][st], bv, acc[n]);
-            }
-        }
+        conv_taps<NCO>(acc, tile, a.wp + ((size_t)cib * 27 * nco_all + co_blk0) * 1024 + lane, nco_all, center, PX, PY, kk);
     }
     // epilogue: ReLU, channels-last store (lane = voxel, 16 registers = channels chan_of(r,h)),
     // and the per-block (sum, sumsq) of what was stored, for the next layer's GroupNorm
@@ -235,29 +256,73 @@ conv3d_gcr_kernel(ConvArgs a) {
         f32x16 v = acc[n];
         if (a.relu) v = relu16(v);
         if (valid) store_acc16(orow + (co_blk0 + n) * 32, v, kk);
-        if (a.part) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float sm = valid ? v[r] : 0.0f, sq = sm * sm;
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
-                if (j == 0) {
-                    float *d = sred + ((wave * NCO + n) * 32 + chan_of(r, kk)) * 2;
-                    d[0] = sm; d[1] = sq;
-                }
-            }
-        }
+        if (a.part) wave_stats(v, valid, j, kk, sred + (wave * NCO + n) * 64);
     }
     if (a.part) {
         __syncthreads();
-        const int spatial = blockIdx.x % (a.tiles_x * a.tiles_y * a.tiles_z);
         const int nsp = a.tiles_x * a.tiles_y * a.tiles_z;
+        const int spatial = blockIdx.x % nsp;
         for (int e = threadIdx.x; e < NCO * 32 * 2; e += THREADS) {
             float tsum = 0.0f;
             for (int w = 0; w < WAVES; ++w) tsum += sred[w * NCO * 64 + e];
             const int n = e >> 6, c2 = e & 63;                    // c2 = channel*2 + {sum,sq}
             a.part[(((size_t)b * nsp + spatial) * a.Cout + (co_blk0 + n) * 32) * 2 + c2] = tsum;
         }
+    }
+}
+
+// Small volumes with many input channels (the 8^3 / 16^3 levels): ONE 32-voxel x 32-channel output
+// tile per workgroup, its WAVES waves split the input-channel blocks (K) between them, each with a
+// private staged tile, and their accumulators are summed through LDS.
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 1)
+conv3d_gcr_ksplit_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // WAVES private tiles
+    const Src &s = a.s;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, kk = lane >> 5;
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y; t /= a.tiles_y;
+    const int tz = t % a.tiles_z;
+    const int b = t / a.tiles_z;
+    const int x0 = tx * a.TX, y0 = ty * a.TY, z0 = tz * a.TZ;
+    const int PX = a.TX + 2, PY = a.TY + 2, PZ = a.TZ + 2;
+    const int nvox = PX * PY * PZ;
+    const int ncib = (s.C1 + s.C2) / 32, nco_all = a.Cout / 32, co_blk = blockIdx.y;
+    const int wy = j / a.TX, lx = j % a.TX, ly = wy % a.TY, lz = wy / a.TY;
+    const int center = ((lz + 1) * PY + (ly + 1)) * PX + (lx + 1);
+    float *tile = lds + (size_t)wave * nvox * CPAD;
+    f32x16 acc[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
+    for (int c0 = 0; c0 < ncib; c0 += WAVES) {
+        const int cib = c0 + wave;
+        __syncthreads();
+        if (cib < ncib) stage_tile(tile, a, b, cib, x0, y0, z0, PX, PY, nvox, lane, 64);
+        __syncthreads();
+        if (cib < ncib)
+            conv_taps<1>(acc, tile, a.wp + ((size_t)cib * 27 * nco_all + co_blk) * 1024 + lane, nco_all, center, PX, PY, kk);
+    }
+    __syncthreads();
+    float *red = lds;                                              // [WAVES-1][16][64]
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[0][r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    f32x16 v = acc[0];
+    for (int w = 0; w < WAVES - 1; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += red[(w * 16 + r) * 64 + lane];
+    if (a.relu) v = relu16(v);
+    const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
+    const bool valid = gx < s.W && gy < s.H && gz < s.D;
+    if (valid) store_acc16(a.out + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.Cout + co_blk * 32, v, kk);
+    if (a.part) {
+        const int nsp = a.tiles_x * a.tiles_y * a.tiles_z;
+        wave_stats(v, valid, j, kk, a.part + (((size_t)b * nsp + blockIdx.x % nsp) * a.Cout + co_blk * 32) * 2);
     }
 }
 
@@ -332,6 +397,12 @@ static int conv_tile(int D, int H, int W, int waves, int &TX, int &TY, int &TZ) 
     return ((W + TX - 1) / TX) * ((H + TY - 1) / TY) * ((D + TZ - 1) / TZ);
 }
 
+// K-split mode: used when even one-wave tiles cannot fill the chip and there are >= 2 input blocks
+static bool conv_use_ksplit(int B, int D, int H, int W, int nco, int ncib) {
+    int TX, TY, TZ;
+    return ncib >= 2 && (size_t)conv_tile(D, H, W, 1, TX, TY, TZ) * B * nco < 1024;
+}
+
 static int conv_waves(int B, int D, int H, int W, int nco) {
     // fewest blocks-per-launch that still fills the chip: 8 waves per workgroup when the volume is
     // large, down to 1 for the 8^3 / 16^3 levels
@@ -385,9 +456,11 @@ size_t vt_stats_floats(int B, int D, int H, int W, int C) {
 }
 
 // number of spatial partial blocks vt_conv3d_gcr writes per scene for this output shape
-int vt_conv3d_stat_blocks(int B, int D, int H, int W, int Cout) {
+int vt_conv3d_stat_blocks(int B, int D, int H, int W, int Cin, int Cout) {
     int TX, TY, TZ;
-    return conv_tile(D, H, W, conv_waves(B, D, H, W, Cout / 32), TX, TY, TZ);
+    const int nco = Cout / 32;
+    if (conv_use_ksplit(B, D, H, W, nco, Cin / 32)) return conv_tile(D, H, W, 1, TX, TY, TZ);
+    return conv_tile(D, H, W, conv_waves(B, D, H, W, nco), TX, TY, TZ);
 }
 
 int vt_channel_stats(const float *x, int B, int64_t V, int C, int nblk, float *part, void *stream) {
@@ -419,6 +492,27 @@ int vt_conv3d_gcr(const float *skip, int C1, const float *low, int C2, int B, in
     if (Cout <= 0 || (Cout & 31)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr: Cout must be a multiple of 32");
     a.scale_shift = scale_shift; a.wp = packed_w; a.out = out; a.part = out_part; a.Cout = Cout; a.relu = relu;
     const int nco = Cout / 32;
+    const int ncib = (a.s.C1 + a.s.C2) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    if (conv_use_ksplit(B, D, H, W, nco, ncib)) {
+        const int nsp1 = conv_tile(D, H, W, 1, a.TX, a.TY, a.TZ);
+        a.tiles_x = (W + a.TX - 1) / a.TX; a.tiles_y = (H + a.TY - 1) / a.TY; a.tiles_z = (D + a.TZ - 1) / a.TZ;
+        const size_t one = (size_t)(a.TX + 2) * (a.TY + 2) * (a.TZ + 2) * CPAD * sizeof(float);
+        const int kw = ncib >= 4 ? 4 : 2;
+        size_t lds = one * kw;
+        if (lds < (size_t)(kw - 1) * 16 * 64 * sizeof(float)) lds = (size_t)(kw - 1) * 16 * 64 * sizeof(float);
+        const dim3 grid((unsigned)((size_t)nsp1 * B), (unsigned)nco);
+        static bool ks_attr = false;
+        if (!ks_attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_ksplit_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_ksplit_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr: hipFuncSetAttribute");
+            ks_attr = true;
+        }
+        if (kw == 4) hipLaunchKernelGGL(conv3d_gcr_ksplit_kernel<4>, grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(conv3d_gcr_ksplit_kernel<2>, grid, dim3(128), lds, st, a);
+        return vt_check(hipGetLastError(), "vt_conv3d_gcr");
+    }
     const int waves = conv_waves(B, D, H, W, nco);
     const int nsp = conv_tile(D, H, W, waves, a.TX, a.TY, a.TZ);
     a.tiles_x = (W + a.TX - 1) / a.TX; a.tiles_y = (H + a.TY - 1) / a.TY; a.tiles_z = (D + a.TZ - 1) / a.TZ;
@@ -433,7 +527,6 @@ int vt_conv3d_gcr(const float *skip, int C1, const float *low, int C2, int B, in
     if (stat_lds > lds) lds = stat_lds;
     if (lds > 160 * 1024) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr: tile does not fit LDS");
     const dim3 grid((unsigned)spatial_blocks, (unsigned)(nco / per));
-    hipStream_t st = (hipStream_t)stream;
     int rc = 0;
     if (waves == 8) rc = per == 4 ? conv_launch<4, 8>(a, grid, lds, st) : per == 2 ? conv_launch<2, 8>(a, grid, lds, st) : conv_launch<1, 8>(a, grid, lds, st);
     else if (waves == 4) rc = conv_launch<1, 4>(a, grid, lds, st);

@@ -450,7 +450,7 @@ def gn_conv3d_relu(x, x_stats, low, low_stats, gamma, beta, groups, packed_w, Co
                                 groups, dev_ptr(_c(gamma), "gamma"), dev_ptr(_c(beta), "beta"), float(eps),
                                 dev_ptr(ss, "scale_shift"), st), "vt_gn_scale_shift")
     out = torch.empty((B, D, H, W, Cout), dtype=torch.float32, device=dev)
-    nblk = lib.vt_conv3d_stat_blocks(B, D, H, W, Cout)
+    nblk = lib.vt_conv3d_stat_blocks(B, D, H, W, C1 + C2, Cout)
     part = torch.empty((B, nblk, Cout, 2), dtype=torch.float32, device=dev)
     check(lib.vt_conv3d_gcr(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
                             dev_ptr(packed_w, "packed_w"), Cout, int(relu), dev_ptr(out, "out"), dev_ptr(part, "part"), st),
