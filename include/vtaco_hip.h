@@ -264,6 +264,29 @@ int vt_gn_scale_shift(const float *part1, int nblk1, int C1, const float *part2,
 int vt_conv3d_gcr(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                   const float *scale_shift, const float *packed_w, int Cout, int relu, float *out,
                   float *out_part, void *stream);
+/* The whole UNet3D.forward (unet3d.py:449-474) in one call: encoder levels (max-pool from level 1  */
+/* on, two gcr convs each), decoder levels (virtual upsample+concat, two gcr convs), final 1x1x1     */
+/* conv.  `packed` = vt_conv3d_pack of the level's Conv3d weight.  x_cl [B,R,R,R,enc[0][0].cin].      */
+#define VT_UNET_MAX_LEVELS 6
+typedef struct vt_unet3d_conv {
+    const float *gn_w;    /* groupnorm.weight [cin] */
+    const float *gn_b;    /* groupnorm.bias   [cin] */
+    const float *packed;  /* vt_conv3d_pack(conv.weight [cout,cin,3,3,3]) */
+    int32_t cin, cout;
+} vt_unet3d_conv;
+typedef struct vt_unet3d_params {
+    int32_t n_levels;     /* len(f_maps) */
+    int32_t groups;       /* num_groups (1 is used when a layer has fewer channels) */
+    double eps;           /* GroupNorm eps */
+    vt_unet3d_conv enc[VT_UNET_MAX_LEVELS][2];   /* encoders.{i}.basic_module.SingleConv{1,2} */
+    vt_unet3d_conv dec[VT_UNET_MAX_LEVELS][2];   /* decoders.{k}.basic_module.SingleConv{1,2} */
+    const float *final_w; /* final_conv.weight [out_channels, f_maps[0]] */
+    const float *final_b; /* final_conv.bias or NULL */
+    int32_t out_channels;
+} vt_unet3d_params;
+size_t vt_unet3d_workspace_bytes(int B, int R, const vt_unet3d_params *params_host);
+int vt_unet3d_fwd(const float *x_cl, int B, int R, const vt_unet3d_params *params_host,
+                  void *workspace, size_t workspace_bytes, float *out, void *stream);
 int vt_maxpool3d_cl(const float *x, int B, int D, int H, int W, int C, float *out, void *stream);
 int vt_conv1x1_cl(const float *x, int64_t V, int Cin, const float *w, const float *bias, int Cout, float *out, void *stream);
 int vt_voxel_scatter_mean_cl_fwd(const float *feat, const int *idx, const int *order,

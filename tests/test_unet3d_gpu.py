@@ -31,7 +31,9 @@ def test_hip_unet3d_vs_oracle_and_torch_path(R, levels, B):
     net = net.to(DEV)
     with torch.no_grad():
         x_cl = x.to(DEV).permute(0, 2, 3, 4, 1).contiguous()
-        got = net.forward_channels_last(x_cl).permute(0, 4, 1, 2, 3)
+        got = net.forward_channels_last(x_cl).permute(0, 4, 1, 2, 3)          # one C-ABI call
+        layered = net.forward_channels_last_layers(x_cl).permute(0, 4, 1, 2, 3)  # same kernels, per layer
+        assert torch.equal(got, layered)
         host = net(x.to(DEV))
     scale = float(ref.abs().max())
     assert float((got.cpu() - ref).abs().max()) <= 1e-4 * max(1.0, scale)

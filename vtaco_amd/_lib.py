@@ -50,6 +50,22 @@ class FusionParams(ctypes.Structure):
                 ("self_attn", FusionUnit), ("cross_attn", FusionUnit)]
 
 
+VT_UNET_MAX_LEVELS = 6
+
+
+class UnetConv(ctypes.Structure):
+    """Mirror of ``vt_unet3d_conv``."""
+    _fields_ = [("gn_w", ctypes.c_void_p), ("gn_b", ctypes.c_void_p), ("packed", ctypes.c_void_p),
+                ("cin", ctypes.c_int32), ("cout", ctypes.c_int32)]
+
+
+class UnetParams(ctypes.Structure):
+    """Mirror of ``vt_unet3d_params``."""
+    _fields_ = [("n_levels", ctypes.c_int32), ("groups", ctypes.c_int32), ("eps", ctypes.c_double),
+                ("enc", (UnetConv * 2) * VT_UNET_MAX_LEVELS), ("dec", (UnetConv * 2) * VT_UNET_MAX_LEVELS),
+                ("final_w", ctypes.c_void_p), ("final_b", ctypes.c_void_p), ("out_channels", ctypes.c_int32)]
+
+
 # name -> (restype, argtypes); kept in step with include/vtaco_hip.h (tests/test_abi.py
 # parses the header and checks that every declared symbol is exported and listed here)
 _VP, _I, _I64, _F, _D, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_size_t
@@ -89,6 +105,8 @@ SIGNATURES = {
     "vt_channel_stats": (_I, [_VP, _I, _I64, _I, _I, _VP, _VP]),
     "vt_gn_scale_shift": (_I, [_VP, _I, _I, _VP, _I, _I, _I, _I64, _I, _VP, _VP, _D, _VP, _VP]),
     "vt_conv3d_gcr": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),
+    "vt_unet3d_workspace_bytes": (_SZ, [_I, _I, ctypes.POINTER(UnetParams)]),
+    "vt_unet3d_fwd": (_I, [_VP, _I, _I, ctypes.POINTER(UnetParams), _VP, _SZ, _VP, _VP]),
     "vt_maxpool3d_cl": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP]),
     "vt_conv1x1_cl": (_I, [_VP, _I64, _I, _VP, _VP, _I, _VP, _VP]),
     "vt_voxel_scatter_mean_cl_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),

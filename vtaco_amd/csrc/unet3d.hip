@@ -569,4 +569,95 @@ int vt_voxel_scatter_mean_cl_fwd(const float *feat, const int *idx, const int *o
     return vt_check(hipGetLastError(), "vt_voxel_scatter_mean_cl_fwd");
 }
 
+// ---- the whole UNet3D.forward in one call (no host round trips between its ~45 launches) ---------
+namespace {
+struct Bump {
+    char *base; size_t off;
+    float *take(size_t floats) { float *p = base ? (float *)(base + off) : nullptr; off += (floats * sizeof(float) + 255) / 256 * 256; return p; }
+};
+struct Tensor { float *x; float *part; int nblk; int C; };
+
+// plan == true only sizes the workspace
+int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char *wsbase, size_t *ws_need, float *out,
+               hipStream_t st) {
+    const int L = p->n_levels;
+    if (L < 1 || L > VT_UNET_MAX_LEVELS) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: bad level count");
+    if (R % (1 << (L - 1))) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: resolution must be divisible by 2^(levels-1)");
+    const bool plan = wsbase == nullptr;
+    Bump ws{wsbase, 0};
+    int maxC = 0;
+    for (int i = 0; i < L; ++i) for (int k = 0; k < 2; ++k) { if (p->enc[i][k].cin > maxC) maxC = p->enc[i][k].cin; }
+    for (int i = 0; i + 1 < L; ++i) for (int k = 0; k < 2; ++k) { if (p->dec[i][k].cin > maxC) maxC = p->dec[i][k].cin; }
+    float *ss = ws.take((size_t)B * maxC * 2);
+    auto stats_of = [&](const float *x, int Ri, int C, Tensor &t) -> int {
+        const int64_t V = (int64_t)Ri * Ri * Ri;
+        t.nblk = (int)(V / 64 < 1 ? 1 : (V / 64 > 1024 ? 1024 : V / 64));
+        t.part = ws.take((size_t)B * t.nblk * C * 2);
+        t.C = C;
+        return plan ? 0 : vt_channel_stats(x, B, V, C, t.nblk, t.part, st);
+    };
+    auto gcr = [&](const vt_unet3d_conv &c, const Tensor &a, const Tensor *low, int Ri, Tensor &o) -> int {
+        const int C2 = low ? low->C : 0;
+        if (a.C + C2 != c.cin) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: channel mismatch between levels");
+        o.C = c.cout;
+        o.x = ws.take((size_t)B * Ri * Ri * Ri * c.cout);
+        o.nblk = vt_conv3d_stat_blocks(B, Ri, Ri, Ri, c.cin, c.cout);
+        o.part = ws.take((size_t)B * o.nblk * c.cout * 2);
+        if (plan) return 0;
+        const int groups = (c.cin >= p->groups) ? p->groups : 1;
+        int rc = vt_gn_scale_shift(a.part, a.nblk, a.C, low ? low->part : nullptr, low ? low->nblk : 0, C2, B,
+                                   (int64_t)Ri * Ri * Ri, groups, c.gn_w, c.gn_b, p->eps, ss, st);
+        if (rc) return rc;
+        return vt_conv3d_gcr(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed, c.cout, 1, o.x, o.part, st);
+    };
+    Tensor skips[VT_UNET_MAX_LEVELS];
+    Tensor cur;
+    cur.x = const_cast<float *>(x_cl); cur.C = p->enc[0][0].cin;
+    int rc = stats_of(x_cl, R, cur.C, cur);
+    if (rc) return rc;
+    for (int i = 0; i < L; ++i) {
+        const int Ri = R >> i;
+        if (i > 0) {
+            Tensor pooled;
+            pooled.C = cur.C;
+            pooled.x = ws.take((size_t)B * Ri * Ri * Ri * cur.C);
+            if (!plan && (rc = vt_maxpool3d_cl(cur.x, B, 2 * Ri, 2 * Ri, 2 * Ri, cur.C, pooled.x, st))) return rc;
+            if ((rc = stats_of(pooled.x, Ri, pooled.C, pooled))) return rc;
+            cur = pooled;
+        }
+        Tensor t1, t2;
+        if ((rc = gcr(p->enc[i][0], cur, nullptr, Ri, t1))) return rc;
+        if ((rc = gcr(p->enc[i][1], t1, nullptr, Ri, t2))) return rc;
+        skips[i] = t2;
+        cur = t2;
+    }
+    for (int k = 0; k + 1 < L; ++k) {
+        const int lvl = L - 2 - k, Ri = R >> lvl;
+        Tensor t1, t2;
+        if ((rc = gcr(p->dec[k][0], skips[lvl], &cur, Ri, t1))) return rc;
+        if ((rc = gcr(p->dec[k][1], t1, nullptr, Ri, t2))) return rc;
+        cur = t2;
+    }
+    if (ws_need) *ws_need = ws.off;
+    if (plan) return 0;
+    return vt_conv1x1_cl(cur.x, (int64_t)B * R * R * R, cur.C, p->final_w, p->final_b, p->out_channels, out, st);
+}
+}  // namespace
+
+size_t vt_unet3d_workspace_bytes(int B, int R, const vt_unet3d_params *params_host) {
+    size_t need = 0;
+    if (!params_host || B <= 0 || R <= 0) return 0;
+    if (unet3d_run(nullptr, B, R, params_host, nullptr, &need, nullptr, nullptr)) return 0;
+    return need;
+}
+
+int vt_unet3d_fwd(const float *x_cl, int B, int R, const vt_unet3d_params *params_host,
+                  void *workspace, size_t workspace_bytes, float *out, void *stream) {
+    if (!x_cl || !params_host || !workspace || !out) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: null argument");
+    const size_t need = vt_unet3d_workspace_bytes(B, R, params_host);
+    if (!need) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: bad configuration");
+    if (workspace_bytes < need) return vt_fail(VT_ERR_WORKSPACE, "vt_unet3d_fwd: workspace too small");
+    return unet3d_run(x_cl, B, R, params_host, (char *)workspace, nullptr, out, (hipStream_t)stream);
+}
+
 }  // extern "C"

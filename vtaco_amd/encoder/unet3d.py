@@ -118,8 +118,50 @@ class UNet3D(nn.Module):
         return ops.gn_conv3d_relu(x, x_stats, low, low_stats, gn.weight.detach(), gn.bias.detach(), gn.num_groups,
                                   self._packed(conv), conv.out_channels, eps=gn.eps, relu=True)
 
+    def _hip_params(self):
+        """vt_unet3d_params for the current weights (re-packed only when a conv weight changed)."""
+        from .. import _lib
+        prm = _lib.UnetParams()
+        keep = []
+
+        def fill(dst, single):
+            gn, conv = single.groupnorm, single.conv
+            tensors = (gn.weight.detach().contiguous(), gn.bias.detach().contiguous(), self._packed(conv))
+            keep.extend(tensors)
+            dst.gn_w, dst.gn_b, dst.packed = (t.data_ptr() for t in tensors)
+            dst.cin, dst.cout = conv.in_channels, conv.out_channels
+        prm.n_levels = len(self.encoders)
+        first_gn = self.encoders[-1].basic_module.SingleConv1.groupnorm
+        prm.groups, prm.eps = first_gn.num_groups, first_gn.eps
+        for i, enc in enumerate(self.encoders):
+            fill(prm.enc[i][0], enc.basic_module.SingleConv1)
+            fill(prm.enc[i][1], enc.basic_module.SingleConv2)
+        for k, dec in enumerate(self.decoders):
+            fill(prm.dec[k][0], dec.basic_module.SingleConv1)
+            fill(prm.dec[k][1], dec.basic_module.SingleConv2)
+        fw = self.final_conv.weight.detach().reshape(self.final_conv.out_channels, -1).contiguous()
+        keep.append(fw)
+        prm.final_w = fw.data_ptr()
+        if self.final_conv.bias is not None:
+            fb = self.final_conv.bias.detach().contiguous()
+            keep.append(fb)
+            prm.final_b = fb.data_ptr()
+        prm.out_channels = self.final_conv.out_channels
+        return prm, keep
+
     def forward_channels_last(self, x):
         """x [B,D,H,W,C] channels-last -> [B,D,H,W,out_channels]; inference only (no autograd).
+        One C-ABI call (vt_unet3d_fwd) runs every launch of the network back to back."""
+        if x.shape[1] == x.shape[2] == x.shape[3]:
+            prm, keep = self._hip_params()
+            y = ops.unet3d_fwd(x.contiguous(), prm, keep)
+            if self.testing and self.final_activation is not None:
+                y = self.final_activation(y) if isinstance(self.final_activation, nn.Sigmoid) else torch.softmax(y, dim=-1)
+            return y
+        return self.forward_channels_last_layers(x)
+
+    def forward_channels_last_layers(self, x):
+        """Layer-by-layer variant of the same computation (non-cubic volumes, debugging).
         GroupNorm statistics are produced by whoever writes a tensor (conv epilogue / a stats pass
         for the input and the pooled tensors) and consumed by the next conv's prologue."""
         skips = []

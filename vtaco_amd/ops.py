@@ -474,3 +474,25 @@ def conv1x1_cl(x, weight, bias):
                                     dev_ptr(_c(bias) if bias is not None else None, "bias"), Cout,
                                     dev_ptr(out, "out"), stream_ptr()), "vt_conv1x1_cl")
     return out
+
+
+_unet_ws = {}
+
+
+def unet3d_fwd(x_cl, params, keep):
+    """Whole UNet3D forward (vt_unet3d_fwd).  ``params``: a filled _lib.UnetParams; ``keep``: the
+    tensors its pointers refer to (kept alive by the caller)."""
+    lib = _lib.load()
+    B, R = x_cl.shape[0], x_cl.shape[1]
+    need = lib.vt_unet3d_workspace_bytes(B, R, ctypes.byref(params))
+    if need == 0:
+        raise VtError("unet3d_fwd: unsupported configuration: " + lib.vt_last_error().decode())
+    key = (x_cl.device, need)
+    ws = _unet_ws.get(key)
+    if ws is None:
+        _unet_ws.clear()
+        ws = _unet_ws[key] = torch.empty(need, dtype=torch.uint8, device=x_cl.device)
+    out = torch.empty((B, R, R, R, params.out_channels), dtype=torch.float32, device=x_cl.device)
+    check(lib.vt_unet3d_fwd(dev_ptr(x_cl, "x"), B, R, ctypes.byref(params), ctypes.c_void_p(ws.data_ptr()), need,
+                            dev_ptr(out, "out"), stream_ptr()), "vt_unet3d_fwd")
+    return out
