@@ -1,0 +1,106 @@
+"""Secondary workloads of BASELINE.json (configs 3-5) on ONE MI355X; prints one JSON line each.
+Not the headline metric (bench.py is); numbers are quoted in DESIGN.md.
+  fusion : AttentionDecoder.forward_img (TransformerFusion) over the 128^3 lattice in chunks of 2048
+  img    : LocalDecoder.forward_img (tactile concat, the shipped VTacO config) 128^3
+  train  : one training step fwd+bwd+Adam, 8 scenes x 2048 points per GPU (config 4's per-GPU share)
+  dense256 : 256^3 decode + marching cubes (config 5 on one GPU)
+"""
+import json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vtaco_amd import ops
+from vtaco_amd.bench_util import build_scene, randomise_fc1, sphere_cloud
+from vtaco_amd.conv_onet.models import decoder_dict
+
+dev = torch.device("cuda:0")
+
+
+def timed(fn, n=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+sc = build_scene(0, dev)
+model, grid = sc["model"], sc["grid"]
+dec = model.decoder
+nx = 128
+out = {}
+
+# --- img: tactile concat over the lattice
+c_img = sc["c_img"](nx)
+t = timed(lambda: dec.decode_lattice(grid, nx, c_img=c_img), 50, 5)
+print(json.dumps({"workload": "forward_img (tactile concat) 128^3 lattice", "ms": t * 1e3, "points_per_s": nx ** 3 / t,
+                  "tflops": 33536 * nx ** 3 / t / 1e12}))
+
+# --- fusion: attention decoder, chunks of 2048 points as a batch of 1024 "scenes" sharing one grid
+torch.manual_seed(0)
+adec = decoder_dict['attention_local'](dim=3, c_dim=32, hidden_size=32).to(dev).eval()
+randomise_fc1(adec, 3)
+N, chunks = 2048, nx ** 3 // 2048
+from vtaco_amd.common import make_3d_grid
+pts = (1.1 * make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)).to(dev)
+ci = c_img.reshape(chunks, N, 32)
+pc = pts.reshape(chunks, N, 3)
+
+
+def fusion_pass(cb=256):
+    outs = []
+    with torch.no_grad():
+        for lo in range(0, chunks, cb):
+            p = pc[lo:lo + cb]
+            c = ops.sample_grid(grid, p.reshape(1, -1, 3)).reshape(-1, N, 32)
+            f = adec.fuser(ci[lo:lo + cb], 1, c, 1)
+            outs.append(ops.decode_mlp_fwd(f, adec._blob(), p))
+    return outs
+
+
+t = timed(fusion_pass, 3, 1)
+flop_pt = 30976 + 576 * N + 61440
+print(json.dumps({"workload": "AttentionDecoder.forward_img 128^3, chunk N=2048 (1024 chunks)", "ms": t * 1e3,
+                  "points_per_s": nx ** 3 / t, "tflops": flop_pt * nx ** 3 / t / 1e12}))
+
+# --- train: 8 scenes/GPU, N=2048, fwd+bwd+Adam through encoder (PointNet + UNet3D host path) and decoder
+B = 8
+model.train()
+cloud = torch.cat([sphere_cloud(i) for i in range(B)]).to(dev)
+g = torch.Generator().manual_seed(1)
+pq = ((torch.rand(B, 2048, 3, generator=g) - 0.5) * 1.1).to(dev)
+occ = torch.rand(B, 2048, generator=g).to(dev)
+cimg_t = (torch.randn(B, 2048, 32, generator=g) * (torch.rand(B, 2048, 1, generator=g) < 0.2)).to(dev)
+opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+
+
+def train_step(with_encoder=True):
+    opt.zero_grad(set_to_none=True)
+    if with_encoder:
+        c = model.encode_inputs(cloud)
+    else:
+        c = {"grid": grid.expand(B, -1, -1, -1, -1).contiguous(memory_format=torch.channels_last_3d)}
+    logits = model.decode_img(pq, c, cimg_t).logits
+    loss = torch.nn.functional.l1_loss(logits, occ)
+    loss.backward()
+    opt.step()
+
+
+t_dec = timed(lambda: train_step(False), 10, 2)
+print(json.dumps({"workload": "train step, decoder only (fwd+bwd+Adam), 8 scenes x 2048 pts", "ms": t_dec * 1e3,
+                  "scenes_per_s": B / t_dec}))
+t_all = timed(lambda: train_step(True), 3, 1)
+print(json.dumps({"workload": "train step incl. PointNet+UNet3D (host PyTorch-ROCm autograd), 8 scenes x 2048 pts",
+                  "ms": t_all * 1e3, "scenes_per_s": B / t_all}))
+model.eval()
+
+# --- dense256: config 5 on one GPU
+nx2 = 256
+buf = torch.empty((1, nx2 ** 3), dtype=torch.float32, device=dev)
+t = timed(lambda: dec.decode_lattice(grid, nx2, out=buf), 10, 2)
+t_mc = timed(lambda: ops.marching_cubes(buf.view(nx2, nx2, nx2), None, rescale=(nx2 / 2, 1.1 / nx2)), 10, 2)
+v, f, _ = ops.marching_cubes(buf.view(nx2, nx2, nx2), None)
+print(json.dumps({"workload": "256^3 decode + marching cubes", "decode_ms": t * 1e3, "points_per_s": nx2 ** 3 / t,
+                  "mc_ms": t_mc * 1e3, "verts": v.shape[0], "faces": f.shape[0]}))
