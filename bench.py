@@ -95,6 +95,11 @@ def stage_times(scene, dec, grid, nx, out, dev):
     from vtaco_amd import ops
     res["marching_cubes"] = timed(lambda: ops.marching_cubes(out.view(nx, nx, nx), None, rescale=(nx / 2, 1.1 / nx)))
     res["end_to_end"] = sum(res.values())
+    if model.encoder is not None:
+        from vtaco_amd.conv_onet.generation import Generator3D
+        gen = Generator3D(model, device=dev, resolution0=nx // 4, padding=0.1)
+        gen.generate_mesh_graphed(pc)               # builds + captures
+        res["end_to_end_hipgraph"] = timed(lambda: gen.generate_mesh_graphed(pc), 20)
     return res
 
 

@@ -113,3 +113,20 @@ def test_generator_end_to_end_mesh_vs_oracle():
     rv, rf, _ = mc.marching_cubes(vol_gpu.numpy())
     assert np.array_equal(mesh.faces.cpu().numpy(), rf)
     assert np.abs(mesh.vertices.cpu().numpy() - orc.mesh_rescale(rv, 32)).max() <= 1e-6
+
+
+def test_graphed_scene_equals_eager():
+    """hipGraph replay of encode + decode + MC classification gives the eager mesh, repeatedly."""
+    from vtaco_amd.conv_onet.generation import Generator3D
+    from vtaco_amd.conv_onet.models import ConvolutionalOccupancyNetwork, decoder_dict
+    a, sd_e = load_golden("g3_pointnet.npz")
+    _, sd_d = load_golden("g1_decode.npz")
+    dec = decoder_dict['simple_local'](dim=3, c_dim=32, hidden_size=32, with_contact=True)
+    dec.load_state_dict(sd_d, strict=True)
+    model = ConvolutionalOccupancyNetwork(dec, _encoder(sd_e), device=DEV)
+    gen = Generator3D(model, device=DEV, resolution0=8, padding=0.1)
+    for b in (0, 1, 0):
+        p = T(a["p"])[b:b + 1]
+        eager = gen.generate_obj_mesh_wnf({"inputs": p})
+        fast = gen.generate_mesh_graphed(p)
+        assert torch.equal(eager.faces, fast.faces) and torch.equal(eager.vertices, fast.vertices)

@@ -152,23 +152,8 @@ def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want
 _mc_ws_cache = {}
 
 
-def marching_cubes(vol, level=None, rescale=None, capacity=None):
-    """Lewiner marching cubes of a device volume [n0,n1,n2] (vt_mc_count/emit).
-
-    Returns (verts f32 [V,3] in array-axis order, faces i32 [F,3], level) as device
-    tensors, numbered exactly as skimage.measure.marching_cubes(vol,
-    gradient_direction='ascent') numbers them.  ``rescale=(shift, scale)`` fuses the
-    reference's `v -= shift; v *= scale` (generation.py:271-272).  ``capacity=(V,F)``
-    skips the host read of the counts (no stream sync); otherwise the counts are read
-    back once to size the outputs.  Raises RuntimeError('No surface found ...') like
-    skimage when the level misses the data.
-    """
+def _mc_workspace(vol):
     lib = _lib.load()
-    if vol.dim() != 3:
-        raise VtError("marching_cubes: volume must be [n0,n1,n2]")
-    vol = vol.detach()
-    if not vol.is_contiguous():
-        vol = vol.contiguous()
     n0, n1, n2 = vol.shape
     nbytes = lib.vt_mc_workspace_bytes(n0, n1, n2)
     if nbytes == 0:
@@ -179,11 +164,30 @@ def marching_cubes(vol, level=None, rescale=None, capacity=None):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=vol.device)
         _mc_ws_cache.clear()
         _mc_ws_cache[key] = ws
+    return ws, nbytes
+
+
+def mc_count(vol, level=None):
+    """Phase 1 of marching cubes (vt_mc_count): classify + scan into the workspace.  Asynchronous
+    and graph-capturable; returns the workspace tensor."""
+    if vol.dim() != 3:
+        raise VtError("marching_cubes: volume must be [n0,n1,n2]")
+    if not vol.is_contiguous():
+        raise VtError("marching_cubes: volume must be contiguous")
+    ws, nbytes = _mc_workspace(vol)
+    n0, n1, n2 = vol.shape
+    check(_lib.load().vt_mc_count(dev_ptr(vol, "vol"), n0, n1, n2, 0.0 if level is None else float(level), int(level is None),
+                                  ctypes.c_void_p(ws.data_ptr()), nbytes, stream_ptr()), "vt_mc_count")
+    return ws
+
+
+def mc_emit(vol, ws, rescale=None, capacity=None):
+    """Phase 2 (vt_mc_read_counts + vt_mc_emit).  Without ``capacity`` the counts are read back
+    (one stream sync) to size the outputs."""
+    lib = _lib.load()
+    n0, n1, n2 = vol.shape
     st = stream_ptr()
-    vp = dev_ptr(vol, "vol")
     wp = ctypes.c_void_p(ws.data_ptr())
-    check(lib.vt_mc_count(vp, n0, n1, n2, 0.0 if level is None else float(level), int(level is None), wp, nbytes, st),
-          "vt_mc_count")
     nv, nf, lvl = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
     if capacity is None:
         check(lib.vt_mc_read_counts(wp, ctypes.byref(nv), ctypes.byref(nf), ctypes.byref(lvl), st), "vt_mc_read_counts")
@@ -195,12 +199,32 @@ def marching_cubes(vol, level=None, rescale=None, capacity=None):
     verts = torch.empty((cap_v, 3), dtype=torch.float32, device=vol.device)
     faces = torch.empty((cap_f, 3), dtype=torch.int32, device=vol.device)
     shift, scale = rescale if rescale is not None else (0.0, 1.0)
-    check(lib.vt_mc_emit(vp, n0, n1, n2, wp, dev_ptr(verts, "verts"), cap_v,
+    check(lib.vt_mc_emit(dev_ptr(vol, "vol"), n0, n1, n2, wp, dev_ptr(verts, "verts"), cap_v,
                          dev_ptr(faces, "faces", torch.int32), cap_f, int(rescale is not None), shift, scale, st),
           "vt_mc_emit")
     if capacity is not None:
         return verts, faces, ws          # counts stay on the device: ws[8:16] = (nverts, nfaces) int32
     return verts, faces, lvl.value
+
+
+def marching_cubes(vol, level=None, rescale=None, capacity=None):
+    """Lewiner marching cubes of a device volume [n0,n1,n2] (vt_mc_count/emit).
+
+    Returns (verts f32 [V,3] in array-axis order, faces i32 [F,3], level) as device
+    tensors, numbered exactly as skimage.measure.marching_cubes(vol,
+    gradient_direction='ascent') numbers them.  ``rescale=(shift, scale)`` fuses the
+    reference's `v -= shift; v *= scale` (generation.py:271-272).  ``capacity=(V,F)``
+    skips the host read of the counts (no stream sync); otherwise the counts are read
+    back once to size the outputs.  Raises RuntimeError('No surface found ...') like
+    skimage when the level misses the data.
+    """
+    if vol.dim() != 3:
+        raise VtError("marching_cubes: volume must be [n0,n1,n2]")
+    vol = vol.detach()
+    if not vol.is_contiguous():
+        vol = vol.contiguous()
+    ws = mc_count(vol, level)
+    return mc_emit(vol, ws, rescale, capacity)
 
 
 # --------------------------------------------------------------------------------------
