@@ -507,8 +507,8 @@ int vt_mc_count(const float *vol, int n0, int n1, int n2, double level, int auto
     if (workspace_bytes < total) return vt_fail(VT_ERR_WORKSPACE, "vt_mc_count: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     McWs ws = mc_ws(workspace, off);
-    hipError_t e = hipMemsetAsync(ws.hdr, 0xFF, 8, s);
-    if (e != hipSuccess) return vt_check(e, "vt_mc_count: memset");
+    int frc = vt_fill32(ws.hdr, 0xFFFFFFFFu, 8, s);
+    if (frc) return frc;
     if (auto_level) {
         const size_t n = (size_t)n0 * n1 * n2;
         unsigned g = (unsigned)((n / 4 + 256 * 4 - 1) / (256 * 4));

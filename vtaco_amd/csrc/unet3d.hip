@@ -560,8 +560,8 @@ int vt_voxel_scatter_mean_cl_fwd(const float *feat, const int *idx, const int *o
     if (!feat || !idx || !order || !seg_lo || !seg_hi || !grid_cl) return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_cl_fwd: null argument");
     if (B <= 0 || T <= 0 || C <= 0 || R < 1) return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_cl_fwd: bad size");
     const size_t V = (size_t)R * R * R, total = (size_t)B * T * C;
-    hipError_t e = hipMemsetAsync(grid_cl, 0, (size_t)B * C * V * sizeof(float), (hipStream_t)stream);
-    if (e != hipSuccess) return vt_check(e, "vt_voxel_scatter_mean_cl_fwd: memset");
+    int frc = vt_fill32(grid_cl, 0u, (size_t)B * C * V * sizeof(float), (hipStream_t)stream);
+    if (frc) return frc;
     size_t g = (total + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(scatter_mean_cl_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,

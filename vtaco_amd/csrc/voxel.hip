@@ -209,8 +209,8 @@ int vt_voxel_scatter_mean_fwd(const float *feat, const int *idx, const int *orde
         return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_fwd: null argument");
     if (B <= 0 || T <= 0 || C <= 0 || R < 1) return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_fwd: bad size");
     const size_t V = (size_t)R * R * R, total = (size_t)B * T * C;
-    hipError_t e = hipMemsetAsync(grid, 0, (size_t)B * C * V * sizeof(float), (hipStream_t)stream);
-    if (e != hipSuccess) return vt_check(e, "vt_voxel_scatter_mean_fwd: memset");
+    int frc = vt_fill32(grid, 0u, (size_t)B * C * V * sizeof(float), (hipStream_t)stream);
+    if (frc) return frc;
     hipLaunchKernelGGL(scatter_mean_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                        feat, idx, order, seg_lo, seg_hi, grid, T, C, V, total);
     return vt_check(hipGetLastError(), "vt_voxel_scatter_mean_fwd");

@@ -1,6 +1,7 @@
 // Error plumbing and device queries shared by every entry point of libvtaco_hip.so.
 #include <stdio.h>
 #include <string.h>
+#include <stdint.h>
 
 #include "vt_common.h"
 
@@ -26,6 +27,24 @@ int vt_num_cus() {
         if (cus <= 0) cus = 256;
     }
     return cus;
+}
+
+__global__ void __launch_bounds__(256) vt_fill32_kernel(unsigned *dst, unsigned pattern, size_t n) {
+    const size_t n4 = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) ? n / 4 : 0;
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+    const uint4 p4 = make_uint4(pattern, pattern, pattern, pattern);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) d4[i] = p4;
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = pattern;
+}
+
+int vt_fill32(void *dst, unsigned pattern, size_t bytes, hipStream_t stream) {
+    const size_t n = bytes / 4;
+    if (!n) return 0;
+    size_t g = (n / 4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(vt_fill32_kernel, dim3((unsigned)g), dim3(256), 0, stream, (unsigned *)dst, pattern, n);
+    return vt_check(hipGetLastError(), "vt_fill32");
 }
 
 extern "C" {

@@ -24,6 +24,9 @@ static_assert((VT_OFF_WPI) * 4 <= 65536, "visual-only fragments must sit below t
 int vt_fail(int code, const char *msg);
 int vt_check(hipError_t e, const char *where);
 int vt_num_cus();
+// capture-safe replacement of hipMemsetAsync (memset nodes misbehaved under hipGraph replay on ROCm 7.0/7.2):
+// fills `bytes` (multiple of 4) at `dst` with the 32-bit pattern
+int vt_fill32(void *dst, unsigned pattern, size_t bytes, hipStream_t stream);
 
 // ---- activations the training forward saves for the backward: [slot][point][32] ---------
 // 0: c (trilinear features)   1..5: relu(x_i) (block inputs)   6..10: relu(h_i)   11: relu(net_5)
