@@ -292,6 +292,8 @@ int vt_conv1x1_cl(const float *x, int64_t V, int Cin, const float *w, const floa
 int vt_voxel_scatter_mean_cl_fwd(const float *feat, const int *idx, const int *order,
                                  const int *seg_lo, const int *seg_hi,
                                  int B, int T, int C, int R, float *grid_cl, void *stream);
+int vt_voxel_scatter_mean_cl_bwd(const float *grad_grid_cl, const int *idx, const int *seg_lo, const int *seg_hi,
+                                 int B, int T, int C, int R, float *grad_feat, void *stream);
 
 #ifdef __cplusplus
 }

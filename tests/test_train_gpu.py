@@ -109,3 +109,38 @@ def test_decode_backward_vs_oracle_autograd(B, N, R, img):
     for n, p in dec.named_parameters():
         if p.grad is not None:
             assert torch.equal(p.grad, first[n]), n
+
+
+def test_train_step_through_unet3d_channels_last_vs_oracle():
+    """Full encoder (HIP voxeliser + host channels_last_3d UNet3D autograd) + HIP decoder: loss and a
+    sample of gradients against the oracle's autograd."""
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd.conv_onet.models import ConvolutionalOccupancyNetwork, decoder_dict
+    from vtaco_amd.encoder import encoder_dict
+    a, sd = load_golden("g4_unet3d.npz")
+    _, sd_d = load_golden("g1_decode.npz")
+    enc = encoder_dict['pointnet_local_pool'](c_dim=32, dim=3, hidden_dim=32, unet3d=True, grid_resolution=16, plane_type='grid',
+                                              unet3d_kwargs=dict(num_levels=3, f_maps=8, in_channels=32, out_channels=32))
+    enc.load_state_dict(sd, strict=True)
+    dec = decoder_dict['simple_local'](dim=3, c_dim=32, hidden_size=32, with_contact=True)
+    dec.load_state_dict(sd_d, strict=True)
+    model = ConvolutionalOccupancyNetwork(dec, enc, device=DEV)
+    g = torch.Generator().manual_seed(4)
+    p_in = T(a["p"])
+    pq = (torch.rand(1, 1024, 3, generator=g) - 0.5) * 1.1
+    occ = torch.rand(1, 1024, generator=g)
+    # oracle
+    esd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    dsd = {k: v.clone().requires_grad_(True) for k, v in sd_d.items()}
+    ref_loss = torch.nn.functional.l1_loss(orc.local_decoder_forward(dsd, pq, orc.pointnet_encoder_forward(esd, p_in, 16)), occ)
+    ref_loss.backward()
+    # HIP + host
+    logits = model.decode(pq.to(DEV), model.encode_inputs(p_in.to(DEV))).logits
+    loss = torch.nn.functional.l1_loss(logits, occ.to(DEV))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-5
+    for name in ("fc_pos.weight", "blocks.2.fc_0.weight", "fc_c.bias", "unet3d.encoders.0.basic_module.SingleConv1.conv.weight",
+                 "unet3d.decoders.1.basic_module.SingleConv2.groupnorm.weight", "unet3d.final_conv.bias"):
+        got = dict(model.encoder.named_parameters())[name].grad
+        _close(got, esd[name].grad.numpy(), name, rel=2e-3, floor=1e-6)
+    _close(model.decoder.fc_c[0].weight.grad, dsd["fc_c.0.weight"].grad.numpy(), "dec.fc_c.0.weight", rel=1e-3)

@@ -438,6 +438,16 @@ def voxel_scatter_mean_cl_fwd(feat, vi):
     return grid
 
 
+def voxel_scatter_mean_cl_bwd(grad_grid_cl, vi, C):
+    """grad of voxel_scatter_mean_cl_fwd: grad_grid_cl [B,R,R,R,C] contiguous -> [B,T,C]."""
+    g = torch.empty((vi.B, vi.T, C), dtype=torch.float32, device=grad_grid_cl.device)
+    check(_lib.load().vt_voxel_scatter_mean_cl_bwd(dev_ptr(_c(grad_grid_cl), "grad_grid"), dev_ptr(vi.idx, "idx", I32),
+                                                   dev_ptr(vi.seg_lo, "seg_lo", I32), dev_ptr(vi.seg_hi, "seg_hi", I32),
+                                                   vi.B, vi.T, C, vi.R, dev_ptr(g, "grad_feat"), stream_ptr()),
+          "vt_voxel_scatter_mean_cl_bwd")
+    return g
+
+
 def conv3d_pack(weight):
     lib = _lib.load()
     Cout, Cin = weight.shape[0], weight.shape[1]
