@@ -102,6 +102,21 @@ int vt_decode_fwd(const float *grid_cl, int B, int R, int C,
                   const float *c_img, const float *blob, double padding,
                   float *out, float *out2, float *save, void *stream);
 
+/* Tactile feature assignment and decode by finger id (SURVEY.md section 8f "next" row 2).        */
+/* Replaces: the scipy cdist + np.where glue that fills the dense c_img_all [1,N,32] at            */
+/*   src/conv_onet/generation.py:186-200 (mode 0: nearest fingertip, radius 0.05, only if that      */
+/*   finger's touch succeeded) and :245-255 (mode 1: within radius 0.015 of any of the finger's      */
+/*   contact points; fingers in ascending order, later ones overwrite).                              */
+/*   anchors [F,K,3], count [F] (valid anchors per finger), success [F] (u8); ids [B,N] u8, 255=none. */
+/* vt_decode_fwd_ids = vt_decode_fwd with c_img[b,n,:] = finger_feats[ids[b,n]] (0 where 255).        */
+int vt_tactile_assign(const float *pts, int B, int64_t N, int lattice_nx, float lattice_box, int64_t lattice_first,
+                      const float *anchors, const int *count, const unsigned char *success, int F, int K,
+                      int mode, double radius, unsigned char *ids, void *stream);
+int vt_decode_fwd_ids(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                      int lattice_nx, float lattice_box, int64_t lattice_first,
+                      const unsigned char *finger_ids, const float *finger_feats, int F,
+                      const float *blob, double padding, float *out, void *stream);
+
 /* The two halves of vt_decode_fwd on their own, for AttentionDecoder.forward_img      */
 /* (decoder.py:237-271), which transforms the sampled features before the MLP:         */
 /*   vt_sample_grid    feat[B,N,C] = trilinear sample only (decoder.py:62-68);          */

@@ -368,3 +368,39 @@ def mc_level(vol):
     in float32 (two np.float32 scalars), the halving is exact."""
     import numpy as np
     return 0.5 * float(np.float32(vol.min()) + np.float32(vol.max()))
+
+
+# --------------------------------------------------------------------------
+# tactile feature assignment (K11)
+# --------------------------------------------------------------------------
+
+
+def tactile_assign_nearest(pts, tips, success, radius=0.05):
+    """VTacOH rule (generation.py:186-200): finger = argmin distance to the 5 fingertips, kept if
+    that distance < radius and that finger's touch succeeded.  float64 distances like scipy's cdist.
+    Returns int64 ids [N], 255 = none."""
+    import numpy as np
+    p = np.asarray(pts, dtype=np.float64)
+    t = np.asarray(tips, dtype=np.float64)
+    d = np.sqrt(((p[:, None, :] - t[None, :, :]) ** 2).sum(-1))
+    ids = np.full(len(p), 255, dtype=np.int64)
+    for f in range(len(t)):
+        if success[f]:
+            sel = (d.min(1) < radius) & (d.argmin(1) == f)
+            ids[sel] = f
+    return ids
+
+
+def tactile_assign_within(pts, clouds, counts, success, radius=0.015):
+    """VTacO rule (generation.py:245-255): a point within radius of any contact point of finger t
+    takes finger t; fingers in ascending order, later ones overwrite."""
+    import numpy as np
+    p = np.asarray(pts, dtype=np.float64)
+    ids = np.full(len(p), 255, dtype=np.int64)
+    for f in range(len(clouds)):
+        if not success[f] or counts[f] == 0:
+            continue
+        c = np.asarray(clouds[f][:counts[f]], dtype=np.float64)
+        d = np.sqrt(((c[:, None, :] - p[None, :, :]) ** 2).sum(-1))
+        ids[(d < radius).any(0)] = f
+    return ids

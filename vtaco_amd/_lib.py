@@ -77,6 +77,8 @@ SIGNATURES = {
     "vt_grid_to_channels_last": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "vt_grid_from_channels_last": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "vt_decode_fwd": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _D, _VP, _VP, _VP, _VP]),
+    "vt_tactile_assign": (_I, [_VP, _I, _I64, _I, _F, _I64, _VP, _VP, _VP, _I, _I, _I, _D, _VP, _VP]),
+    "vt_decode_fwd_ids": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _I, _VP, _D, _VP, _VP]),
     "vt_sample_grid": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _D, _VP, _VP]),
     "vt_decode_mlp_fwd": (_I, [_VP, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP]),
     "vt_fusion_workspace_bytes": (_SZ, [_I, _I]),

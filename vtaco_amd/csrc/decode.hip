@@ -48,7 +48,7 @@ decode_fwd_kernel(DecodeArgs a) {
     const unsigned long long dc_t0 = __builtin_amdgcn_s_memtime(), dc_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const uint32_t ntiles = (a.total + 31u) >> 5;
-    const bool with_img = a.c_img != nullptr;
+    const bool with_img = a.c_img != nullptr || a.cimg_ids != nullptr;
     const int R = a.R;
 
     // XCD-aware tile order: workgroups b and b+8 share an XCD (and its 4 MiB L2), so each XCD
@@ -158,8 +158,20 @@ decode_fwd_kernel(DecodeArgs a) {
             net = mfma(L[VT_OFF_WP + 64 + lane], k1, net);
         }
         if (with_img) {
-            const f32x16 ci = load_frag16(a.c_img + (size_t)g * 32 + 16 * h);
-            net = dense32<false>(net, L + VT_OFF_WPI, ci, lane);
+            if (a.cimg_ids) {
+                // tactile feature by finger id: most tiles touch no finger and skip the 16 MFMAs
+                const unsigned id = a.cimg_ids[g];
+                if (__ballot(id != 255u) != 0ull) {
+                    f32x16 ci;
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) ci[s] = 0.0f;
+                    if (id != 255u) ci = load_frag16(a.cimg_table + (size_t)id * 32 + 16 * h);
+                    net = dense32<false>(net, L + VT_OFF_WPI, ci, lane);
+                }
+            } else {
+                const f32x16 ci = load_frag16(a.c_img + (size_t)g * 32 + 16 * h);
+                net = dense32<false>(net, L + VT_OFF_WPI, ci, lane);
+            }
         }
         net = dense32<false>(net, L + VT_OFF_WL, c, lane);
 
@@ -379,7 +391,8 @@ int vt_grid_from_channels_last(const float *src, float *dst, int B, int C, int D
 
 static int decode_launch(const float *grid_cl, const float *c_direct, int B, int R, int C, const float *pts, int64_t N,
                          int lattice_nx, float lattice_box, int64_t lattice_first,
-                         const float *c_img, const float *blob, double padding,
+                         const float *c_img, const unsigned char *cimg_ids, const float *cimg_table,
+                         const float *blob, double padding,
                          float *out, float *out2, float *save, void *stream) {
     if ((!grid_cl && !c_direct) || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: null argument");
     if (B <= 0 || R < 2 || N < 0) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: bad size");
@@ -392,7 +405,7 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
     if (N == 0) return 0;
     if ((int64_t)B * N >= (int64_t)1 << 31) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd: B*N must be < 2^31");
     DecodeArgs a;
-    a.c_direct = c_direct; a.grid = grid_cl; a.pts = pts; a.brick = 0; a.c_img = c_img; a.blob = blob; a.out = out; a.out2 = out2; a.save = save;
+    a.c_direct = c_direct; a.grid = grid_cl; a.pts = pts; a.brick = 0; a.cimg_ids = cimg_ids; a.cimg_table = cimg_table; a.c_img = c_img; a.blob = blob; a.out = out; a.out2 = out2; a.save = save;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box;
     a.divisor = (float)(1.0 + padding + 10e-4);   // src/common.py:302, rounded to f32 as torch does
@@ -432,15 +445,24 @@ int vt_decode_fwd(const float *grid_cl, int B, int R, int C, const float *pts, i
                   const float *c_img, const float *blob, double padding,
                   float *out, float *out2, float *save, void *stream) {
     if (!grid_cl) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: null grid");
-    return decode_launch(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img, blob, padding,
-                         out, out2, save, stream);
+    return decode_launch(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img, nullptr, nullptr,
+                         blob, padding, out, out2, save, stream);
+}
+
+int vt_decode_fwd_ids(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                      int lattice_nx, float lattice_box, int64_t lattice_first,
+                      const unsigned char *finger_ids, const float *finger_feats, int F,
+                      const float *blob, double padding, float *out, void *stream) {
+    if (!grid_cl || !finger_ids || !finger_feats || F <= 0) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_ids: null argument");
+    return decode_launch(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, finger_ids, finger_feats,
+                         blob, padding, out, nullptr, nullptr, stream);
 }
 
 int vt_decode_mlp_fwd(const float *c, int B, int C, const float *pts, int64_t N,
                       int lattice_nx, float lattice_box, int64_t lattice_first,
                       const float *blob, float *out, void *stream) {
     if (!c) return vt_fail(VT_ERR_INVALID, "vt_decode_mlp_fwd: null features");
-    return decode_launch(nullptr, c, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, blob, 0.1,
+    return decode_launch(nullptr, c, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, nullptr, nullptr, blob, 0.1,
                          out, nullptr, nullptr, stream);
 }
 
@@ -454,7 +476,7 @@ int vt_sample_grid(const float *grid_cl, int B, int R, int C, const float *pts, 
     if (N == 0) return 0;
     if ((int64_t)B * N >= (int64_t)1 << 31) return vt_fail(VT_ERR_UNSUPPORTED, "vt_sample_grid: B*N must be < 2^31");
     DecodeArgs a;
-    a.c_direct = nullptr; a.brick = 0; a.grid = grid_cl; a.pts = pts; a.c_img = nullptr; a.blob = nullptr; a.out = nullptr; a.out2 = nullptr; a.save = nullptr;
+    a.c_direct = nullptr; a.brick = 0; a.cimg_ids = nullptr; a.cimg_table = nullptr; a.grid = grid_cl; a.pts = pts; a.c_img = nullptr; a.blob = nullptr; a.out = nullptr; a.out2 = nullptr; a.save = nullptr;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box; a.divisor = (float)(1.0 + padding + 10e-4);
     int64_t blocks = (((int64_t)a.total + 31) / 32 + 3) / 4;

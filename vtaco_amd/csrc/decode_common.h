@@ -80,6 +80,8 @@ struct DecodeArgs {
     float *out2;
     float *save;         // [VT_SAVE_SLOTS][total][32] activations for the backward, or null
     const float *c_direct;  // [B,N,32] conditioning features given directly (no grid gather), or null
+    const unsigned char *cimg_ids;   // [B,N] finger id per point (255 = none) with cimg_table, instead of c_img
+    const float *cimg_table;         // [F][32] tactile feature per finger
     int brick;           // lattice mode with tiles = 2x4x4 bricks (slab aligned to x-plane pairs, nx % 4 == 0)
     uint32_t N;          // points per batch element
     uint32_t total;      // B*N   (< 2^31, checked by the entry point)

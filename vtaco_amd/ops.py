@@ -530,3 +530,52 @@ def unet3d_fwd(x_cl, params, keep):
     check(lib.vt_unet3d_fwd(dev_ptr(x_cl, "x"), B, R, ctypes.byref(params), ctypes.c_void_p(ws.data_ptr()), need,
                             dev_ptr(out, "out"), stream_ptr()), "vt_unet3d_fwd")
     return out
+
+
+# --------------------------------------------------------------------------------------
+# tactile feature assignment by finger id (vt_tactile_assign / vt_decode_fwd_ids)
+# --------------------------------------------------------------------------------------
+U8 = torch.uint8
+
+
+def tactile_assign(anchors, success, mode, radius, pts=None, lattice=None, count=None, B=1):
+    """Finger id per query point (uint8, 255 = none).  anchors [F,K,3] f32; success [F];
+    mode 'nearest' (K=1, generation.py:186-200) or 'within' (generation.py:245-255)."""
+    anchors = _c(anchors.float())
+    F, K = anchors.shape[0], anchors.shape[1]
+    dev = anchors.device
+    if count is None:
+        count = torch.full((F,), K, dtype=I32, device=dev)
+    count = _c(count.to(I32))
+    success = _c(success.to(U8))
+    if pts is not None:
+        pts = _c(pts.float())
+        B, N = pts.shape[0], pts.shape[1]
+        nx, box, first = 0, 0.0, 0
+    else:
+        nx, box, first, N = lattice
+    ids = torch.empty((B, N), dtype=U8, device=dev)
+    check(_lib.load().vt_tactile_assign(dev_ptr(pts, "pts"), B, N, nx, box, first, dev_ptr(anchors, "anchors"),
+                                        dev_ptr(count, "count", I32), dev_ptr(success, "success", U8), F, K,
+                                        {"nearest": 0, "within": 1}[mode], float(radius), dev_ptr(ids, "ids", U8), stream_ptr()),
+          "vt_tactile_assign")
+    return ids
+
+
+def decode_fwd_ids(grid, blob, ids, feats, pts=None, lattice=None, padding=0.1, out=None):
+    """vt_decode_fwd_ids: forward_img with c_img[b,n] = feats[ids[b,n]] (zeros where ids == 255)."""
+    B, C, D, H, W = grid.shape
+    keep, gptr = _cl_storage(grid)
+    feats = _c(feats.float())
+    if pts is not None:
+        pts = _c(pts.float())
+        N = pts.shape[1]
+        nx, box, first = 0, 0.0, 0
+    else:
+        nx, box, first, N = lattice
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.float32, device=grid.device)
+    check(_lib.load().vt_decode_fwd_ids(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first, dev_ptr(_c(ids), "ids", U8),
+                                        dev_ptr(feats, "feats"), feats.shape[0], dev_ptr(blob, "blob"), float(padding),
+                                        dev_ptr(out, "out"), stream_ptr()), "vt_decode_fwd_ids")
+    return out
