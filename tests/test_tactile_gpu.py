@@ -27,7 +27,7 @@ def test_nearest_fingertip_rule_bit_exact():
     ref = orc.tactile_assign_nearest(pts.numpy(), tips.numpy(), success.numpy())
     ids = ops.tactile_assign(tips.view(5, 1, 3).to(DEV), success.to(DEV), "nearest", 0.05, lattice=(nx, 1.1, 0, nx ** 3))
     assert np.array_equal(ids.cpu().numpy()[0].astype(np.int64), ref)
-    assert (ref != 255).sum() > 50
+    assert (ref != 255).sum() > 10
     ids_p = ops.tactile_assign(tips.view(5, 1, 3).to(DEV), success.to(DEV), "nearest", 0.05, pts=pts.unsqueeze(0).to(DEV))
     assert torch.equal(ids, ids_p)
 
@@ -45,7 +45,7 @@ def test_contact_cloud_rule_bit_exact():
     ref = orc.tactile_assign_within(pts.numpy(), clouds.numpy(), counts.numpy(), success.numpy())
     ids = ops.tactile_assign(clouds.to(DEV), success.to(DEV), "within", 0.015, lattice=(nx, 1.1, 0, nx ** 3), count=counts.to(DEV))
     assert np.array_equal(ids.cpu().numpy()[0].astype(np.int64), ref)
-    assert (ref != 255).sum() > 20
+    assert (ref != 255).sum() > 10
 
 
 def test_decode_by_finger_id_equals_dense_c_img():
