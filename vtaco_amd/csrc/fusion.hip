@@ -100,6 +100,10 @@ fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd,
     }
 }
 
+// e^x for x in [-1,1] (unit-vector dot products) as ONE v_exp_f32: 2^(x*log2 e); 1-2 ulp, against
+// ~15 VALU instructions for the libm expf -- the exponentials are the VALU load of these kernels
+__device__ __forceinline__ float exp_unit(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
 // 32 operands of an MFMA lane: row `row` (clamped), half kk, of a de-interleaved [.,2,32] array
 struct Frag32 { float v[32]; };
 __device__ __forceinline__ void load_frag32(Frag32 &f, const float *base, int row, int kk) {
@@ -138,7 +142,7 @@ fusion_expsum_kernel(const float *Fd, const float *Sd, const float *w, float *ou
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = s0 + chan_of(r, h);
-            if (i < N) sum = fmaf(expf(sc[r]), w ? w[i] : 1.0f, sum);
+            if (i < N) sum = fmaf(exp_unit(sc[r]), w ? w[i] : 1.0f, sum);
         }
     }
     sum += __shfl_xor(sum, 32);
@@ -182,7 +186,7 @@ fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const fl
         load_frag32(stream, Kd, min(k0 + j, N - 1), h);
         f32x16 e = score_tile(stream, fixed);                    // lane (q,h) reg r: key k0+chan_of(r,h)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) e[r] = expf(e[r]);
+        for (int r = 0; r < 16; ++r) e[r] = exp_unit(e[r]);
         // O^T[c][q] += V'T[c][k] E[k][q]: A operand lane (c,hA), step s = V'T[c][k0 + chan_of(s,hA)]
         const f32x16 vf = load_acc16(VT + (size_t)j * Npad + k0, h);
 #pragma unroll
