@@ -298,43 +298,75 @@ __device__ __forceinline__ uint2 block_exscan(unsigned a, unsigned b, uint2 *lds
     return make_uint2(oa + ia - a, ob + ib - b);
 }
 
+// Surface cells are a minority (1-2 % for a trained field, ~16 % for noise) and scattered, so every
+// wave would run the expensive branch with most lanes idle.  Each kernel therefore first COMPACTS its
+// block's active cells into an LDS list (ballot + prefix) and then processes the list densely.
+__device__ __forceinline__ unsigned block_compact(bool flag, unsigned payload, unsigned *list, unsigned *wave_cnt /*[4]*/) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    if (lane == 0) wave_cnt[w] = (unsigned)__popcll(m);
+    __syncthreads();
+    unsigned base = 0, total = 0;
+    for (int i = 0; i < 4; ++i) { if (i < w) base += wave_cnt[i]; total += wave_cnt[i]; }
+    if (flag) list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = payload;
+    __syncthreads();
+    return total;
+}
+
 __global__ void __launch_bounds__(CELLS_PER_BLOCK)
 mc_classify_kernel(const float *vol, McDims d, McWs ws, double level_in, int auto_level) {
-    __shared__ uint2 red[4];
+    __shared__ unsigned list[CELLS_PER_BLOCK];
+    __shared__ unsigned wave_cnt[4];
+    __shared__ unsigned tot[2];
     const unsigned c = blockIdx.x * CELLS_PER_BLOCK + threadIdx.x;
-    unsigned ntri = 0, nnew = 0;
+    const double level = iso_level(ws.hdr, level_in, auto_level);
+    if (threadIdx.x < 2) tot[threadIdx.x] = 0;
+    // phase 1 (all cells): the 8-bit sign pattern; inactive cells are done
+    int index = 0;
     if (c < d.ncells) {
-        const double level = iso_level(ws.hdr, level_in, auto_level);
         int x, y, z;
         cell_xyz(c, d, x, y, z);
+        const size_t s1 = (size_t)d.n2, s0 = (size_t)d.n1 * d.n2;
+        const float *p = vol + (size_t)z * s0 + (size_t)y * s1 + x;
+        // (double)p - level > 0  <=>  (double)p > level  (the subtraction is exact-sign preserving)
+        index = ((double)p[0] - level > 0.0) | ((double)p[1] - level > 0.0) << 1 | ((double)p[s1 + 1] - level > 0.0) << 2 |
+                ((double)p[s1] - level > 0.0) << 3 | ((double)p[s0] - level > 0.0) << 4 | ((double)p[s0 + 1] - level > 0.0) << 5 |
+                ((double)p[s0 + s1 + 1] - level > 0.0) << 6 | ((double)p[s0 + s1] - level > 0.0) << 7;
+    }
+    const bool active = index != 0 && index != 255;
+    if (c < d.ncells && !active) ws.cnt[c] = 0;
+    const unsigned nact = block_compact(active, threadIdx.x, list, wave_cnt);
+    // phase 2 (dense over the active list): Lewiner case analysis + owned-edge ranks
+    if (threadIdx.x < nact) {
+        const unsigned cc = blockIdx.x * CELLS_PER_BLOCK + list[threadIdx.x];
+        int x, y, z;
+        cell_xyz(cc, d, x, y, z);
         double v[8];
         load_cell(vol, d, x, y, z, level, v);
-        int index = 0;
+        int idx2 = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) index |= (v[k] > 0.0) << k;
-        if (index != 0 && index != 255) {
-            int nt = 0;
-            const int off = classify_cell(v, index, nt);
-            const unsigned own = own_mask(x, y, z);
-            unsigned seen = 0;
-            uint64_t rk = 0;
-            for (int i = 0; i < 3 * nt; ++i) {
-                const int e = MC_LUT[off + i];
-                if (!((seen >> e) & 1u)) {
-                    seen |= 1u << e;
-                    if ((own >> e) & 1u) { ++nnew; rk |= (uint64_t)nnew << (4 * e); }
-                }
+        for (int k = 0; k < 8; ++k) idx2 |= (v[k] > 0.0) << k;
+        int nt = 0;
+        const int off = classify_cell(v, idx2, nt);
+        const unsigned own = own_mask(x, y, z);
+        unsigned seen = 0, nnew = 0;
+        uint64_t rk = 0;
+        for (int i = 0; i < 3 * nt; ++i) {
+            const int e = MC_LUT[off + i];
+            if (!((seen >> e) & 1u)) {
+                seen |= 1u << e;
+                if ((own >> e) & 1u) { ++nnew; rk |= (uint64_t)nnew << (4 * e); }
             }
-            ntri = (unsigned)nt;
-            ws.desc[c] = (uint32_t)off;
-            ws.rank[c] = rk;
         }
-        ws.cnt[c] = (uint16_t)(ntri | (nnew << 8));
+        ws.desc[cc] = (uint32_t)off;
+        ws.rank[cc] = rk;
+        ws.cnt[cc] = (uint16_t)((unsigned)nt | (nnew << 8));
+        atomicAdd(&tot[0], (unsigned)nt);
+        atomicAdd(&tot[1], nnew);
     }
-    uint2 tot;
-    block_exscan(ntri, nnew, red, tot);
-    if (threadIdx.x == 0) ws.bsum[blockIdx.x] = tot;
-    if (c == 0) ws.hdr->level = iso_level(ws.hdr, level_in, auto_level);
+    __syncthreads();
+    if (threadIdx.x == 0) ws.bsum[blockIdx.x] = make_uint2(tot[0], tot[1]);
+    if (c == 0) ws.hdr->level = level;
 }
 
 // one block: exclusive scan of the per-block sums
@@ -372,20 +404,24 @@ struct McOut {
 __global__ void __launch_bounds__(CELLS_PER_BLOCK)
 mc_vertices_kernel(const float *vol, McDims d, McWs ws, McOut o) {
     __shared__ uint2 red[4];
+    __shared__ unsigned list[CELLS_PER_BLOCK], lbase[CELLS_PER_BLOCK];
+    __shared__ unsigned wave_cnt[4];
     const unsigned c = blockIdx.x * CELLS_PER_BLOCK + threadIdx.x;
     const unsigned cn = (c < d.ncells) ? ws.cnt[c] : 0;
     uint2 tot;
     const uint2 pre = block_exscan(cn & 0xff, cn >> 8, red, tot);
-    if (!cn) return;
     const unsigned vb = ws.boff[blockIdx.x].y + pre.y;
-    ws.vbase[c] = vb;
-    if (!(cn >> 8)) return;
+    if (cn) ws.vbase[c] = vb;
+    lbase[threadIdx.x] = vb;
+    const unsigned nact = block_compact((cn >> 8) != 0, threadIdx.x, list, wave_cnt);
+    if (threadIdx.x >= nact) return;
+    const unsigned li = list[threadIdx.x], cc = blockIdx.x * CELLS_PER_BLOCK + li, vbase = lbase[li];
     const double level = ws.hdr->level;
     int x, y, z;
-    cell_xyz(c, d, x, y, z);
+    cell_xyz(cc, d, x, y, z);
     double v[8];
     load_cell(vol, d, x, y, z, level, v);
-    const uint64_t rk = ws.rank[c];
+    const uint64_t rk = ws.rank[cc];
     for (int e = 0; e < 13; ++e) {
         const unsigned nib = (unsigned)(rk >> (4 * e)) & 15u;
         if (!nib) continue;
@@ -404,7 +440,7 @@ mc_vertices_kernel(const float *vol, McDims d, McWs ws, McOut o) {
             fx += cx(a) * wa; fy += cy(a) * wa; fz += cz(a) * wa; ff += wa;
             fx += cx(b) * wb; fy += cy(b) * wb; fz += cz(b) * wb; ff += wb;
         }
-        const unsigned vid = vb + nib - 1;
+        const unsigned vid = vbase + nib - 1;
         if (vid < (unsigned)o.max_verts) {
             // array-axis order (axis0, axis1, axis2) = (z, y, x), as skimage returns
             float p0 = (float)((double)z + fz / ff), p1 = (float)((double)y + fy / ff), p2 = (float)((double)x + fx / ff);
@@ -418,16 +454,20 @@ mc_vertices_kernel(const float *vol, McDims d, McWs ws, McOut o) {
 __global__ void __launch_bounds__(CELLS_PER_BLOCK)
 mc_faces_kernel(McDims d, McWs ws, McOut o) {
     __shared__ uint2 red[4];
+    __shared__ unsigned list[CELLS_PER_BLOCK], lbase[CELLS_PER_BLOCK];
+    __shared__ unsigned wave_cnt[4];
     const unsigned c = blockIdx.x * CELLS_PER_BLOCK + threadIdx.x;
     const unsigned cn = (c < d.ncells) ? ws.cnt[c] : 0;
     uint2 tot;
     const uint2 pre = block_exscan(cn & 0xff, cn >> 8, red, tot);
-    const unsigned nt = cn & 0xff;
-    if (!nt) return;
-    const unsigned tb = ws.boff[blockIdx.x].x + pre.x;
+    lbase[threadIdx.x] = ws.boff[blockIdx.x].x + pre.x;
+    const unsigned nact = block_compact((cn & 0xff) != 0, threadIdx.x | (cn & 0xff) << 8, list, wave_cnt);
+    if (threadIdx.x >= nact) return;
+    const unsigned li = list[threadIdx.x] & 0xff, nt = list[threadIdx.x] >> 8;
+    const unsigned cc = blockIdx.x * CELLS_PER_BLOCK + li, tb = lbase[li];
     int x, y, z;
-    cell_xyz(c, d, x, y, z);
-    const unsigned off = ws.desc[c];
+    cell_xyz(cc, d, x, y, z);
+    const unsigned off = ws.desc[cc];
     for (unsigned i = 0; i < 3 * nt; ++i) {
         const int e = MC_LUT[off + i];
         int ox = x, oy = y, oz = z, el = 12;
