@@ -278,6 +278,27 @@ __device__ __forceinline__ void cell_xyz(unsigned c, const McDims &d, int &x, in
     y = (int)(t - (unsigned)z * (unsigned)d.c1);
 }
 
+// (x,y,z) of cell `first + t` given (x0,y0,z0) of cell `first` (wave-uniform) and a small t:
+// avoids two 32-bit integer divisions per thread
+__device__ __forceinline__ void cell_from(int x0, int y0, int z0, unsigned t, const McDims &d, float inv_c2, int &x, int &y, int &z) {
+    const unsigned u = (unsigned)x0 + t;                          // < c2 + 256: exact in float
+    unsigned q = (unsigned)((float)u * inv_c2);
+    int r = (int)(u - q * (unsigned)d.c2);
+    if (r < 0) { --q; r += d.c2; }
+    if (r >= d.c2) { ++q; r -= d.c2; }
+    x = r;
+    y = y0 + (int)q;
+    z = z0;
+    while (y >= d.c1) { y -= d.c1; ++z; }
+}
+
+// smallest float f with (double)f > level: then "(double)v - level > 0" is exactly "v >= f"
+__device__ __forceinline__ float level_threshold(double level) {
+    float t = (float)level;
+    if (!((double)t > level)) t = nextafterf(t, INFINITY);
+    return t;
+}
+
 // block-wide exclusive scan of (a,b) pairs over 256 threads; returns exclusive prefix, totals in tot
 __device__ __forceinline__ uint2 block_exscan(unsigned a, unsigned b, uint2 *lds /*[4]*/, uint2 &tot) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -321,17 +342,23 @@ mc_classify_kernel(const float *vol, McDims d, McWs ws, double level_in, int aut
     const unsigned c = blockIdx.x * CELLS_PER_BLOCK + threadIdx.x;
     const double level = iso_level(ws.hdr, level_in, auto_level);
     if (threadIdx.x < 2) tot[threadIdx.x] = 0;
-    // phase 1 (all cells): the 8-bit sign pattern; inactive cells are done
+    // phase 1 (all cells): the 8-bit sign pattern with f32 compares against an exact threshold;
+    // inactive cells are done
     int index = 0;
+    int bx0, by0, bz0;
+    cell_xyz(blockIdx.x * CELLS_PER_BLOCK, d, bx0, by0, bz0);      // wave-uniform: scalar unit
+    const float inv_c2 = 1.0f / (float)d.c2;
     if (c < d.ncells) {
         int x, y, z;
-        cell_xyz(c, d, x, y, z);
+        cell_from(bx0, by0, bz0, threadIdx.x, d, inv_c2, x, y, z);
+        const float thr = level_threshold(level);
         const size_t s1 = (size_t)d.n2, s0 = (size_t)d.n1 * d.n2;
         const float *p = vol + (size_t)z * s0 + (size_t)y * s1 + x;
-        // (double)p - level > 0  <=>  (double)p > level  (the subtraction is exact-sign preserving)
-        index = ((double)p[0] - level > 0.0) | ((double)p[1] - level > 0.0) << 1 | ((double)p[s1 + 1] - level > 0.0) << 2 |
-                ((double)p[s1] - level > 0.0) << 3 | ((double)p[s0] - level > 0.0) << 4 | ((double)p[s0 + 1] - level > 0.0) << 5 |
-                ((double)p[s0 + s1 + 1] - level > 0.0) << 6 | ((double)p[s0 + s1] - level > 0.0) << 7;
+        typedef float f2 __attribute__((ext_vector_type(2), aligned(4)));
+        const f2 a = *reinterpret_cast<const f2 *>(p), b = *reinterpret_cast<const f2 *>(p + s1);
+        const f2 e = *reinterpret_cast<const f2 *>(p + s0), f = *reinterpret_cast<const f2 *>(p + s0 + s1);
+        index = (a.x >= thr) | (a.y >= thr) << 1 | (b.y >= thr) << 2 | (b.x >= thr) << 3 |
+                (e.x >= thr) << 4 | (e.y >= thr) << 5 | (f.y >= thr) << 6 | (f.x >= thr) << 7;
     }
     const bool active = index != 0 && index != 255;
     if (c < d.ncells && !active) ws.cnt[c] = 0;
@@ -340,7 +367,7 @@ mc_classify_kernel(const float *vol, McDims d, McWs ws, double level_in, int aut
     if (threadIdx.x < nact) {
         const unsigned cc = blockIdx.x * CELLS_PER_BLOCK + list[threadIdx.x];
         int x, y, z;
-        cell_xyz(cc, d, x, y, z);
+        cell_from(bx0, by0, bz0, list[threadIdx.x], d, inv_c2, x, y, z);
         double v[8];
         load_cell(vol, d, x, y, z, level, v);
         int idx2 = 0;
@@ -417,8 +444,9 @@ mc_vertices_kernel(const float *vol, McDims d, McWs ws, McOut o) {
     if (threadIdx.x >= nact) return;
     const unsigned li = list[threadIdx.x], cc = blockIdx.x * CELLS_PER_BLOCK + li, vbase = lbase[li];
     const double level = ws.hdr->level;
-    int x, y, z;
-    cell_xyz(cc, d, x, y, z);
+    int bx0, by0, bz0, x, y, z;
+    cell_xyz(blockIdx.x * CELLS_PER_BLOCK, d, bx0, by0, bz0);
+    cell_from(bx0, by0, bz0, li, d, 1.0f / (float)d.c2, x, y, z);
     double v[8];
     load_cell(vol, d, x, y, z, level, v);
     const uint64_t rk = ws.rank[cc];
@@ -451,25 +479,35 @@ mc_vertices_kernel(const float *vol, McDims d, McWs ws, McOut o) {
     }
 }
 
+// one thread per (active cell, triangle corner): cells carry 1..12 triangles, so a thread per cell
+// would leave most lanes waiting for the few 12-triangle cells
 __global__ void __launch_bounds__(CELLS_PER_BLOCK)
 mc_faces_kernel(McDims d, McWs ws, McOut o) {
     __shared__ uint2 red[4];
-    __shared__ unsigned list[CELLS_PER_BLOCK], lbase[CELLS_PER_BLOCK];
+    __shared__ unsigned list[CELLS_PER_BLOCK], lpre[CELLS_PER_BLOCK];
     __shared__ unsigned wave_cnt[4];
     const unsigned c = blockIdx.x * CELLS_PER_BLOCK + threadIdx.x;
     const unsigned cn = (c < d.ncells) ? ws.cnt[c] : 0;
     uint2 tot;
     const uint2 pre = block_exscan(cn & 0xff, cn >> 8, red, tot);
-    lbase[threadIdx.x] = ws.boff[blockIdx.x].x + pre.x;
-    const unsigned nact = block_compact((cn & 0xff) != 0, threadIdx.x | (cn & 0xff) << 8, list, wave_cnt);
-    if (threadIdx.x >= nact) return;
-    const unsigned li = list[threadIdx.x] & 0xff, nt = list[threadIdx.x] >> 8;
-    const unsigned cc = blockIdx.x * CELLS_PER_BLOCK + li, tb = lbase[li];
-    int x, y, z;
-    cell_xyz(cc, d, x, y, z);
-    const unsigned off = ws.desc[cc];
-    for (unsigned i = 0; i < 3 * nt; ++i) {
-        const int e = MC_LUT[off + i];
+    // active list entry k: (local cell id, first triangle of the cell within the block)
+    const unsigned nact = block_compact((cn & 0xff) != 0, threadIdx.x | pre.x << 8, list, wave_cnt);
+    if (threadIdx.x < nact) lpre[threadIdx.x] = list[threadIdx.x] >> 8;
+    __syncthreads();
+    const unsigned nent = 3u * tot.x, tb0 = ws.boff[blockIdx.x].x;
+    int bx0, by0, bz0;
+    cell_xyz(blockIdx.x * CELLS_PER_BLOCK, d, bx0, by0, bz0);
+    const float inv_c2 = 1.0f / (float)d.c2;
+    for (unsigned ent = threadIdx.x; ent < nent; ent += CELLS_PER_BLOCK) {
+        const unsigned tri = ent / 3u;
+        // the active cell whose triangle range contains `tri`: last k with lpre[k] <= tri
+        unsigned lo = 0, hi = nact;
+        while (hi - lo > 1) { const unsigned mid = (lo + hi) >> 1; if (lpre[mid] <= tri) lo = mid; else hi = mid; }
+        const unsigned li = list[lo] & 0xff, cc = blockIdx.x * CELLS_PER_BLOCK + li;
+        const unsigned i = ent - 3u * lpre[lo];                    // entry index inside the cell's list
+        int x, y, z;
+        cell_from(bx0, by0, bz0, li, d, inv_c2, x, y, z);
+        const int e = MC_LUT[ws.desc[cc] + i];
         int ox = x, oy = y, oz = z, el = 12;
         if (e < 12) {
             // edge base point relative to the cell, and direction
@@ -494,7 +532,7 @@ mc_faces_kernel(McDims d, McWs ws, McOut o) {
         const unsigned oc = ((unsigned)oz * (unsigned)d.c1 + (unsigned)oy) * (unsigned)d.c2 + (unsigned)ox;
         const unsigned nib = (unsigned)(ws.rank[oc] >> (4 * el)) & 15u;
         const unsigned vid = ws.vbase[oc] + nib - 1;
-        const size_t fi = (size_t)tb * 3 + i;
+        const size_t fi = (size_t)tb0 * 3 + ent;
         if (fi < (size_t)o.max_faces * 3) o.faces[fi] = (int)vid;
     }
 }
