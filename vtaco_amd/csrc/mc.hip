@@ -363,11 +363,14 @@ mc_classify_kernel(const float *vol, McDims d, McWs ws, double level_in, int aut
     const bool active = index != 0 && index != 255;
     if (c < d.ncells && !active) ws.cnt[c] = 0;
     const unsigned nact = block_compact(active, threadIdx.x, list, wave_cnt);
-    // phase 2 (dense over the active list): Lewiner case analysis + owned-edge ranks
-    if (threadIdx.x < nact) {
-        const unsigned cc = blockIdx.x * CELLS_PER_BLOCK + list[threadIdx.x];
+    // phase 2 (over the active list): Lewiner case analysis + owned-edge ranks.  The work is a chain of
+    // dependent table look-ups (latency-bound), so the list is dealt round-robin over the block's four
+    // waves: four times as many waves in flight beats packing it into one wave.
+    const unsigned slot = (threadIdx.x & 63u) * 4u + (threadIdx.x >> 6);
+    if (slot < nact) {
+        const unsigned cc = blockIdx.x * CELLS_PER_BLOCK + list[slot];
         int x, y, z;
-        cell_from(bx0, by0, bz0, list[threadIdx.x], d, inv_c2, x, y, z);
+        cell_from(bx0, by0, bz0, list[slot], d, inv_c2, x, y, z);
         double v[8];
         load_cell(vol, d, x, y, z, level, v);
         int idx2 = 0;
@@ -441,8 +444,9 @@ mc_vertices_kernel(const float *vol, McDims d, McWs ws, McOut o) {
     if (cn) ws.vbase[c] = vb;
     lbase[threadIdx.x] = vb;
     const unsigned nact = block_compact((cn >> 8) != 0, threadIdx.x, list, wave_cnt);
-    if (threadIdx.x >= nact) return;
-    const unsigned li = list[threadIdx.x], cc = blockIdx.x * CELLS_PER_BLOCK + li, vbase = lbase[li];
+    const unsigned slot = (threadIdx.x & 63u) * 4u + (threadIdx.x >> 6);     // round-robin over the 4 waves
+    if (slot >= nact) return;
+    const unsigned li = list[slot], cc = blockIdx.x * CELLS_PER_BLOCK + li, vbase = lbase[li];
     const double level = ws.hdr->level;
     int bx0, by0, bz0, x, y, z;
     cell_xyz(blockIdx.x * CELLS_PER_BLOCK, d, bx0, by0, bz0);
