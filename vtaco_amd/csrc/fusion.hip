@@ -123,35 +123,75 @@ __device__ __forceinline__ f32x16 score_tile(const Frag32 &stream, const Frag32 
     return acc;
 }
 
+// ---- streamed-tile machinery shared by the three N x N passes ---------------------------------
+// A workgroup owns 128 fixed rows (one 32-row tile per wave) and streams ALL rows of the other
+// operand through LDS in 32-row tiles, double-buffered: every streamed byte is fetched once per 128
+// fixed rows (the first version let each wave pull its own tiles straight from memory: 4x the
+// traffic, and the pass ran at the Infinity-Cache rate instead of the matrix rate).
+constexpr int SROW = 68;                                    // 64 floats + 4 pad: conflict-free ds_read_b128
+constexpr int STILE = 32 * SROW;
+
+// cooperative global -> register -> LDS copy of one 32 x 64 de-interleaved tile (2 float4 per thread)
+struct TileRegs { f32x4 a, b; };
+__device__ __forceinline__ void tile_fetch(TileRegs &t, const float *base, int row0, int N) {
+    const int i0 = threadIdx.x, i1 = threadIdx.x + 256;     // float4 index within the tile: row = i/16, col4 = i%16
+    t.a = *reinterpret_cast<const f32x4 *>(base + (size_t)min(row0 + (i0 >> 4), N - 1) * 64 + (i0 & 15) * 4);
+    t.b = *reinterpret_cast<const f32x4 *>(base + (size_t)min(row0 + (i1 >> 4), N - 1) * 64 + (i1 & 15) * 4);
+}
+__device__ __forceinline__ void tile_store(float *tile, const TileRegs &t) {
+    const int i0 = threadIdx.x, i1 = threadIdx.x + 256;
+    *reinterpret_cast<f32x4 *>(tile + (i0 >> 4) * SROW + (i0 & 15) * 4) = t.a;
+    *reinterpret_cast<f32x4 *>(tile + (i1 >> 4) * SROW + (i1 & 15) * 4) = t.b;
+}
+// this lane's 32 MFMA operands of the staged tile: row j, half kk
+__device__ __forceinline__ void tile_frag(Frag32 &f, const float *tile, int j, int kk) {
+    const f32x4 *r = reinterpret_cast<const f32x4 *>(tile + j * SROW + kk * 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const f32x4 t = r[i]; f.v[4 * i] = t.x; f.v[4 * i + 1] = t.y; f.v[4 * i + 2] = t.z; f.v[4 * i + 3] = t.w; }
+}
+
 // out[f] = sum over streamed rows i of exp(S_i . F_f) * (w ? w[i] : 1)
 //   rowsum: F = Q, S = K, w = null          colsum: F = K, S = Q, w = 1/l
 __global__ void __launch_bounds__(256)
 fusion_expsum_kernel(const float *Fd, const float *Sd, const float *w, float *out, int N, int recip_out) {
-    __shared__ float part[4][32];
-    const int b = blockIdx.y, f0 = blockIdx.x * 32;
+    __shared__ __attribute__((aligned(16))) float tiles[2][STILE];
+    __shared__ __attribute__((aligned(16))) float wt[2][32];
+    const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int f0 = blockIdx.x * 128 + wave * 32;
     Fd += (size_t)b * N * 64; Sd += (size_t)b * N * 64;
     if (w) w += (size_t)b * N;
     Frag32 fixed;
     load_frag32(fixed, Fd, min(f0 + j, N - 1), h);
+    const int ntile = (N + 31) / 32;
+    TileRegs tr;
+    float wreg = 0.0f;
+    auto fetch = [&](int t) {
+        tile_fetch(tr, Sd, t * 32, N);
+        if (threadIdx.x < 32) { const int i = t * 32 + threadIdx.x; wreg = (i < N) ? (w ? w[i] : 1.0f) : 0.0f; }
+    };
+    fetch(0);
+    tile_store(tiles[0], tr);
+    if (threadIdx.x < 32) wt[0][threadIdx.x] = wreg;
+    __syncthreads();
     float sum = 0.0f;
-    for (int s0 = wave * 32; s0 < N; s0 += 128) {
+    for (int t = 0; t < ntile; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntile) fetch(t + 1);
         Frag32 stream;
-        load_frag32(stream, Sd, min(s0 + j, N - 1), h);
+        tile_frag(stream, tiles[cur], j, h);
         const f32x16 sc = score_tile(stream, fixed);
+        const f32x16 ww = load_acc16(wt[cur], h);               // w of streamed row chan_of(r,h)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = s0 + chan_of(r, h);
-            if (i < N) sum = fmaf(exp_unit(sc[r]), w ? w[i] : 1.0f, sum);
+        for (int r = 0; r < 16; ++r) sum = fmaf(exp_unit(sc[r]), ww[r], sum);
+        if (t + 1 < ntile) {
+            tile_store(tiles[cur ^ 1], tr);
+            if (threadIdx.x < 32) wt[cur ^ 1][threadIdx.x] = wreg;
         }
+        __syncthreads();
     }
     sum += __shfl_xor(sum, 32);
-    if (lane < 32) part[wave][lane] = sum;
-    __syncthreads();
-    if (threadIdx.x < 32 && f0 + threadIdx.x < N) {
-        const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-        out[(size_t)b * N + f0 + threadIdx.x] = recip_out ? 1.0f / t : t;
-    }
+    if (lane < 32 && f0 + lane < N) out[(size_t)b * N + f0 + lane] = recip_out ? 1.0f / sum : sum;
 }
 
 // V'T[b][c][k] = V[b][k][c] / (1e-9 + s[b][k]); columns k >= N (padding to Npad) are zero
@@ -167,41 +207,57 @@ fusion_scalev_kernel(const float *V, const float *s, float *VT, int N, int Npad,
 }
 
 // attention output + RelationUnit tail + TransNonlinear + residual: Z = X_q + LN(...)
+constexpr int VROW = 36;                                    // V'T tile row: 32 keys + 4 pad
 __global__ void __launch_bounds__(256)
 fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const float *linv, const float *Xq,
                      const float *blob, float *Z, int N, int Npad) {
     __shared__ __attribute__((aligned(16))) float lds[FU_BLOB];
-    __shared__ float opart[3][16][64];
+    __shared__ __attribute__((aligned(16))) float tiles[2][STILE];
+    __shared__ __attribute__((aligned(16))) float vts[2][32 * VROW];
     for (int i = threadIdx.x; i < FU_BLOB; i += 256) lds[i] = blob[i];
-    const int b = blockIdx.y, q0 = blockIdx.x * 32;
+    const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 128 + wave * 32;
     Qd += (size_t)b * N * 64; Kd += (size_t)b * N * 64; VT += (size_t)b * 32 * Npad;
     Frag32 fixed;
     load_frag32(fixed, Qd, min(q0 + j, N - 1), h);
     f32x16 o;
 #pragma unroll
     for (int s = 0; s < 16; ++s) o[s] = 0.0f;
-    for (int k0 = wave * 32; k0 < N; k0 += 128) {
+    const int ntile = (N + 31) / 32;
+    TileRegs tr;
+    f32x4 vreg;
+    const int vc = threadIdx.x >> 3, vk = (threadIdx.x & 7) * 4;   // V'T tile: channel row, key quad
+    auto fetch = [&](int t) {
+        tile_fetch(tr, Kd, t * 32, N);
+        vreg = *reinterpret_cast<const f32x4 *>(VT + (size_t)vc * Npad + t * 32 + vk);
+    };
+    fetch(0);
+    tile_store(tiles[0], tr);
+    *reinterpret_cast<f32x4 *>(vts[0] + vc * VROW + vk) = vreg;
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntile) fetch(t + 1);
         Frag32 stream;
-        load_frag32(stream, Kd, min(k0 + j, N - 1), h);
-        f32x16 e = score_tile(stream, fixed);                    // lane (q,h) reg r: key k0+chan_of(r,h)
+        tile_frag(stream, tiles[cur], j, h);
+        f32x16 e = score_tile(stream, fixed);                    // lane (q,h) reg r: key 32t+chan_of(r,h)
 #pragma unroll
         for (int r = 0; r < 16; ++r) e[r] = exp_unit(e[r]);
-        // O^T[c][q] += V'T[c][k] E[k][q]: A operand lane (c,hA), step s = V'T[c][k0 + chan_of(s,hA)]
-        const f32x16 vf = load_acc16(VT + (size_t)j * Npad + k0, h);
+        // O^T[c][q] += V'T[c][k] E[k][q]: A operand lane (c,hA), step s = V'T[c][32t + chan_of(s,hA)]
+        const f32x16 vf = load_acc16(vts[cur] + j * VROW, h);
 #pragma unroll
         for (int s = 0; s < 16; ++s) o = mfma(vf[s], e[s], o);
+        if (t + 1 < ntile) {
+            tile_store(tiles[cur ^ 1], tr);
+            *reinterpret_cast<f32x4 *>(vts[cur ^ 1] + vc * VROW + vk) = vreg;
+        }
+        __syncthreads();
     }
-    if (wave > 0) {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) opart[wave - 1][s][lane] = o[s];
-    }
-    __syncthreads();
-    if (wave != 0) return;
     const int q = min(q0 + j, N - 1);
     const float li = linv[(size_t)b * N + q];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) o[s] = (o[s] + opart[0][s][lane] + opart[1][s][lane] + opart[2][s][lane]) * li;
+    for (int s = 0; s < 16; ++s) o[s] *= li;
     // lane (q,h) reg r = channel chan_of(r,h) of the attention output: the accumulator layout
     const float *xrow = Xq + ((size_t)b * N + q) * 32;
     const f32x16 x = load_acc16(xrow, h);
@@ -214,25 +270,25 @@ fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const fl
     f32x16 ha = load_frag16(lds + FU_BIAS + 0 * 32 + h * 16), hb = load_frag16(lds + FU_BIAS + 1 * 32 + h * 16);
     ha = dense32<false>(ha, lds + FU_W1A, r, lane);
     hb = dense32<false>(hb, lds + FU_W1B, r, lane);
-    f32x16 t = load_frag16(lds + FU_BIAS + 2 * 32 + h * 16);
-    t = dense32<true>(t, lds + FU_W2A, ha, lane);
-    t = dense32<true>(t, lds + FU_W2B, hb, lane);
-    t = t + r;
+    f32x16 t2 = load_frag16(lds + FU_BIAS + 2 * 32 + h * 16);
+    t2 = dense32<true>(t2, lds + FU_W2A, ha, lane);
+    t2 = dense32<true>(t2, lds + FU_W2B, hb, lane);
+    t2 = t2 + r;
     // LayerNorm over the 32 channels of this point (16 registers x 2 lane halves)
     float m = 0.0f;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) m += t[s];
+    for (int s = 0; s < 16; ++s) m += t2[s];
     m += __shfl_xor(m, 32);
     m *= (1.0f / 32.0f);
     float var = 0.0f;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) { const float c = t[s] - m; var = fmaf(c, c, var); }
+    for (int s = 0; s < 16; ++s) { const float c = t2[s] - m; var = fmaf(c, c, var); }
     var += __shfl_xor(var, 32);
     const float rstd = 1.0f / sqrtf(var * (1.0f / 32.0f) + 1e-5f);
     const f32x16 ga = load_frag16(lds + FU_BIAS + 3 * 32 + h * 16), be = load_frag16(lds + FU_BIAS + 4 * 32 + h * 16);
     f32x16 z;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) z[s] = x[s] + ((t[s] - m) * rstd * ga[s] + be[s]);
+    for (int s = 0; s < 16; ++s) z[s] = x[s] + ((t2[s] - m) * rstd * ga[s] + be[s]);
     if (q0 + j < N) store_acc16(Z + ((size_t)b * N + q0 + j) * 32, z, h);
 }
 
@@ -293,7 +349,7 @@ FusionUnitDev unit_of(const vt_fusion_unit &u) {
 void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const float *blob, const FusionWs &w,
               float *out, int B, int N, hipStream_t s) {
     const int P = B * N, Npad = (N + 31) / 32 * 32;
-    const dim3 pg((P + 255) / 256), tg((N + 31) / 32, B);
+    const dim3 pg((P + 255) / 256), tg((N + 127) / 128, B);
     if (Xq == Xk) {
         hipLaunchKernelGGL((fusion_proj_kernel<true, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
     } else {
