@@ -115,3 +115,36 @@ def test_full_size_128_lattice_properties():
     sel = torch.randint(0, nx ** 3, (4096,), generator=g)
     ref = orc.local_decoder_forward(sd, pts[sel].unsqueeze(0), grid)
     assert float((whole.cpu()[:, sel] - ref).abs().max()) <= TOL
+
+
+@pytest.mark.parametrize("nx", [8, 12, 20, 30])
+def test_lattice_batch2_and_odd_sizes(nx):
+    """Lattice mode for B=2 scenes and lattice sizes that are / are not multiples of 4 (brick tiles
+    vs linear tiles) against points mode on the same coordinates."""
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd import ops
+    _, sd = load_golden("g1_decode.npz")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(nx)
+    grid = torch.randn(2, 32, 16, 16, 16, generator=g).to(dev)
+    blob = _blob(sd, dev)
+    pts = (1.1 * orc.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)).to(dev)
+    lat = ops.decode_fwd(grid, blob, lattice=(nx, 1.1, 0, nx ** 3))
+    via = ops.decode_fwd(grid, blob, pts=pts.unsqueeze(0).expand(2, -1, -1).contiguous())
+    assert lat.shape == (2, nx ** 3)
+    assert float((lat - via).abs().max()) <= 2e-5
+    ref = orc.local_decoder_forward(sd, pts.cpu().unsqueeze(0).expand(2, -1, -1), grid.cpu())
+    assert float((lat.cpu() - ref).abs().max()) <= TOL
+
+
+def test_unsupported_shapes_fail_loudly():
+    from vtaco_amd import ops
+    from vtaco_amd._lib import VtError
+    from vtaco_amd.conv_onet.models import decoder_dict
+    dev = torch.device("cuda:0")
+    dec = decoder_dict["simple_local"](dim=3, c_dim=128, hidden_size=256).to(dev)      # the class defaults: not built
+    with pytest.raises(VtError):
+        dec(torch.zeros(1, 4, 3, device=dev), {"grid": torch.zeros(1, 128, 4, 4, 4, device=dev)})
+    _, sd = load_golden("g1_decode.npz")
+    with pytest.raises(VtError):
+        ops.decode_fwd(torch.zeros(1, 32, 4, 5, 6, device=dev), _blob(sd, dev), pts=torch.zeros(1, 4, 3, device=dev))
