@@ -18,6 +18,7 @@ def run(tag, bench, cl, B=2):
     for _ in range(3): step()
     torch.cuda.synchronize()
     print(f"{tag:40s} first {first:7.2f} s   steady {1e3 * (time.perf_counter() - t0) / 3:9.1f} ms per fwd+bwd (B={B})", flush=True)
-run("default (benchmark off, NCDHW)", False, False)
-run("cudnn.benchmark on, NCDHW", True, False)
-run("benchmark on, channels_last_3d", True, True)
+run("benchmark off, channels_last_3d, B=2", False, True, 2)
+run("benchmark on,  channels_last_3d, B=2", True, True, 2)
+run("benchmark off, channels_last_3d, B=8", False, True, 8)
+run("benchmark on,  channels_last_3d, B=8", True, True, 8)

@@ -67,7 +67,9 @@ decode_fwd_kernel(DecodeArgs a) {
         // Re-derive the LDS base every tile behind an opaque asm so the (loop-invariant)
         // weight reads are not hoisted out of the tile loop into ~120 extra VGPRs.
         unsigned lds_off = 0;
+#ifndef VT_NO_LAUNDER
         asm volatile("" : "+v"(lds_off));
+#endif
         const float *L = lds + lds_off;
         uint32_t g, b;
         bool live = true;
