@@ -107,7 +107,7 @@ def measured_traffic():
     """HBM-side bytes per decode launch from the committed PMC passes (profiles/, same command
     as this bench): (2 x FETCH_SIZE + WRITE_SIZE) KB -- the x2 is the guide's gfx950 correction
     for 16-B-per-lane reads; None if no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01c_pmc_summary.csv")
+    path = os.path.join(ROOT, "profiles", "r01d_pmc_summary.csv")
     try:
         vals = {}
         for line in open(path).read().splitlines()[1:]:
@@ -195,7 +195,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": measured_traffic(),
                          "traffic_note": "bytes/launch at the L2's memory side from rocprofv3 FETCH_SIZE/WRITE_SIZE passes "
-                                         "(profiles/r01c_pmc_summary.csv); algorithmic = 33.5 MB grid + 8.4 MB logits",
+                                         "(profiles/r01d_pmc_summary.csv); algorithmic = 33.5 MB grid + 8.4 MB logits",
                          "kernel": "decode_fwd_kernel", "kernel_ms": kern_ms, "flop_per_point": flop_pt},
         }
         if world == 1 and not args.decode_only:

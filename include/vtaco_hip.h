@@ -102,6 +102,20 @@ int vt_decode_fwd(const float *grid_cl, int B, int R, int C,
                   const float *c_img, const float *blob, double padding,
                   float *out, float *out2, float *save, void *stream);
 
+/* Split-bf16 ("bf16x3") inference variant of vt_decode_fwd / vt_decode_fwd_ids for the same   */
+/* reference functions.  Every f32 operand v of the 16 dense 32x32 layers is carried as           */
+/* bf16(v) + bf16(v - bf16(v)) and every product as W_lo*x_hi + W_hi*x_lo + W_hi*x_hi on the       */
+/* bf16 matrix core with f32 accumulation (error ~2^-16 relative per product: 2e-5 abs on the      */
+/* O(1) logits of the golden vectors, inside the 1e-4 parity bar; plain bf16 is ~1e-2).  The        */
+/* gather, fc_p, biases, residuals and the output heads stay f32.  blob_bf16x3 comes from           */
+/* vt_decoder_pack_bf16x3 (same size as the f32 blob).  c_img and finger_ids are alternatives         */
+/* (both NULL = visual-only); no `save`: the training forward is the exact-f32 vt_decode_fwd.          */
+int vt_decoder_pack_bf16x3(const vt_decoder_params *params_host, float *blob, size_t blob_bytes, void *stream);
+int vt_decode_fwd_bf16x3(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                         int lattice_nx, float lattice_box, int64_t lattice_first,
+                         const float *c_img, const unsigned char *finger_ids, const float *finger_feats, int F,
+                         const float *blob_bf16x3, double padding, float *out, float *out2, void *stream);
+
 /* Tactile feature assignment and decode by finger id (SURVEY.md section 8f "next" row 2).        */
 /* Replaces: the scipy cdist + np.where glue that fills the dense c_img_all [1,N,32] at            */
 /*   src/conv_onet/generation.py:186-200 (mode 0: nearest fingertip, radius 0.05, only if that      */

@@ -84,6 +84,8 @@ SIGNATURES = {
     "vt_fusion_workspace_bytes": (_SZ, [_I, _I]),
     "vt_fusion_fwd": (_I, [_VP, _VP, _I, _I, ctypes.POINTER(FusionParams), _VP, _SZ, _VP, _VP]),
     "vt_decoder_blob_t_bytes": (_SZ, [_I, _I, _I]),
+    "vt_decoder_pack_bf16x3": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
+    "vt_decode_fwd_bf16x3": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP, _I, _VP, _D, _VP, _VP, _VP]),
     "vt_decoder_pack_t": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
     "vt_decode_save_bytes": (_SZ, [_I64]),
     "vt_decode_gws_bytes": (_SZ, [_I64]),

@@ -28,8 +28,12 @@ class Generator3D(object):
     def __init__(self, model, points_batch_size=100000, threshold=0.5, refinement_step=0, device=None,
                  resolution0=16, upsampling_steps=3, with_normals=False, padding=0.1, sample=False,
                  input_type=None, vol_info=None, vol_bound=None, simplify_nfaces=None, alpha=0.2,
-                 with_img=False, encode_t2d=False):
+                 with_img=False, encode_t2d=False, decode_precision="bf16x3"):
         self.model = model.to(device)
+        # arithmetic of the dense lattice decode (eval_lattice): "bf16x3" = split-bf16 MFMA, inside the
+        # 1e-4 parity bar and ~3x the exact-f32 rate; "f32" = exact-f32 MFMA.  eval_points follows the
+        # decoder's own ``precision`` attribute (default "f32").
+        self.decode_precision = decode_precision
         self.points_batch_size = points_batch_size
         self.threshold, self.refinement_step = threshold, refinement_step
         self.device = device
@@ -64,7 +68,7 @@ class Generator3D(object):
         if grid.shape[0] != 1:
             raise VtError("eval_lattice: one scene at a time (the lattice is per scene)")
         return self.model.decoder.decode_lattice(grid, nx, box=1 + self.padding, first=first, count=count,
-                                                 c_img=c_img_all, out=out).reshape(-1)
+                                                 c_img=c_img_all, out=out, precision=self.decode_precision).reshape(-1)
 
     def extract_mesh(self, value_grid, level=None):
         """``measure.marching_cubes(value_grid, gradient_direction='ascent')`` followed by

@@ -8,6 +8,8 @@ no torch fallback: CPU tensors raise.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -72,9 +74,12 @@ class LocalDecoder(nn.Module):
         if with_contact:
             self.fc_out_contact = nn.Linear(hidden_size, 1)
         self._blobs = {}
+        # arithmetic of the 16 dense layers on the no-grad paths: "f32" (exact-f32 MFMA) or "bf16x3"
+        # (split-bf16 MFMA, ~2e-5 abs on O(1) logits, ~3x faster); training is always "f32"
+        self.precision = os.environ.get("VTACO_DECODE_PRECISION", "f32")
 
     # -- weights -> MFMA-fragment blob, cached until a parameter changes ---------
-    def _blob(self, img=False, contact=False):
+    def _blob(self, img=False, contact=False, precision="f32"):
         head2 = (self.fc_out_contact.weight, self.fc_out_contact.bias) if contact else None
         first = self.fc_p_img if img else self.fc_p
         params = [first.weight, first.bias, self.fc_out.weight, self.fc_out.bias]
@@ -83,15 +88,15 @@ class LocalDecoder(nn.Module):
         if head2:
             params += list(head2)
         stamp = tuple((p.data_ptr(), p._version) for p in params)
-        hit = self._blobs.get((img, contact))
+        hit = self._blobs.get((img, contact, precision))
         if hit is not None and hit[0] == stamp:
             return hit[1]
         blob = ops.pack_decoder(first.weight, first.bias,
                                 [(l.weight, l.bias) for l in self.fc_c],
                                 [b.packed() for b in self.blocks],
                                 (self.fc_out.weight, self.fc_out.bias), head2,
-                                out=hit[1] if hit is not None else None)
-        self._blobs[(img, contact)] = (stamp, blob)
+                                out=hit[1] if hit is not None else None, precision=precision)
+        self._blobs[(img, contact, precision)] = (stamp, blob)
         return blob
 
     def _blob_t(self, img=False):
@@ -134,38 +139,43 @@ class LocalDecoder(nn.Module):
         grid = self._grid_of(c_plane)
         if self._wants_grad(grid):
             return _DecodeFn.apply(self, p, grid, None, *self._params(False))
-        return ops.decode_fwd(grid, self._blob(), pts=p, padding=self.padding)
+        return ops.decode_fwd(grid, self._blob(precision=self.precision), pts=p, padding=self.padding,
+                              precision=self.precision)
 
     def forward_img(self, p, c_plane, c_img, **kwargs):
         """Tactile concat variant (decoder.py:71-103): fc_p_img([p; c_img])."""
         grid = self._grid_of(c_plane)
         if self._wants_grad(grid, c_img):
             return _DecodeFn.apply(self, p, grid, c_img, *self._params(True))
-        return ops.decode_fwd(grid, self._blob(img=True), pts=p, c_img=c_img, padding=self.padding)
+        return ops.decode_fwd(grid, self._blob(img=True, precision=self.precision), pts=p, c_img=c_img,
+                              padding=self.padding, precision=self.precision)
 
     def forward_contact(self, p, c_plane, **kwargs):
         """(occupancy logits, contact logits) (decoder.py:105-133)."""
         grid = self._grid_of(c_plane)
         if self._wants_grad(grid):
             raise VtError("forward_contact: the backward of the contact head is not built (no shipped config trains it)")
-        return ops.decode_fwd(grid, self._blob(contact=True), pts=p, padding=self.padding, want_contact=True)
+        return ops.decode_fwd(grid, self._blob(contact=True, precision=self.precision), pts=p, padding=self.padding,
+                              want_contact=True, precision=self.precision)
 
     # -- dense fast path: the lattice is generated in-kernel ---------------------
-    def decode_lattice(self, grid, nx, box=1.1, first=0, count=None, c_img=None, out=None):
+    def decode_lattice(self, grid, nx, box=1.1, first=0, count=None, c_img=None, out=None, precision=None):
         """Logits of ``box * make_3d_grid((-.5,)*3,(.5,)*3,(nx,)*3)[first:first+count]``
         (generation.py:155-157 + eval_points) without materialising the points."""
         count = nx ** 3 - first if count is None else count
-        return ops.decode_fwd(grid, self._blob(img=c_img is not None), c_img=c_img, padding=self.padding,
-                              lattice=(nx, box, first, count), out=out)
+        precision = precision or self.precision
+        return ops.decode_fwd(grid, self._blob(img=c_img is not None, precision=precision), c_img=c_img,
+                              padding=self.padding, lattice=(nx, box, first, count), out=out, precision=precision)
 
 
-def _decode_lattice_ids(self, grid, nx, finger_ids, finger_feats, box=1.1, first=0, count=None, out=None):
+def _decode_lattice_ids(self, grid, nx, finger_ids, finger_feats, box=1.1, first=0, count=None, out=None, precision=None):
     """``decode_lattice`` with the tactile feature given as (finger id per point, [F,c_dim] table)
     instead of a dense c_img tensor (what the 256^3 configuration needs: 16.7 MB of ids instead of
     2.1 GB of c_img_all)."""
     count = nx ** 3 - first if count is None else count
-    return ops.decode_fwd_ids(grid, self._blob(img=True), finger_ids, finger_feats, padding=self.padding,
-                              lattice=(nx, box, first, count), out=out)
+    precision = precision or self.precision
+    return ops.decode_fwd_ids(grid, self._blob(img=True, precision=precision), finger_ids, finger_feats,
+                              padding=self.padding, lattice=(nx, box, first, count), out=out, precision=precision)
 
 
 LocalDecoder.decode_lattice_ids = _decode_lattice_ids

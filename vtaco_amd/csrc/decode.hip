@@ -22,9 +22,12 @@
 
 namespace {
 
-template <int THREADS, bool SAVE>
+// SPLIT selects the split-bf16 dense layers (decode_common.h) and expects the blob of
+// vt_decoder_pack_bf16x3; everything around the 16 dense layers is shared.
+template <int THREADS, bool SAVE, bool SPLIT>
 __global__ void __launch_bounds__(THREADS, VT_WAVES_PER_SIMD)
 decode_fwd_kernel(DecodeArgs a) {
+    static_assert(!(SAVE && SPLIT), "the training forward keeps the exact-f32 layers");
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef VT_DIAG_CLOCK
     const unsigned long long dc_entry = __builtin_amdgcn_s_memrealtime();
@@ -168,13 +171,30 @@ decode_fwd_kernel(DecodeArgs a) {
 #pragma unroll
                     for (int s = 0; s < 16; ++s) ci[s] = 0.0f;
                     if (id != 255u) ci = load_frag16(a.cimg_table + (size_t)id * 32 + 16 * h);
-                    net = dense32<false>(net, L + VT_OFF_WPI, ci, lane);
+                    if (SPLIT) net = dense32s(net, L + VT_OFF_WPI, split16<false>(ci), lane);
+                    else net = dense32<false>(net, L + VT_OFF_WPI, ci, lane);
                 }
             } else {
                 const f32x16 ci = load_frag16(a.c_img + (size_t)g * 32 + 16 * h);
-                net = dense32<false>(net, L + VT_OFF_WPI, ci, lane);
+                if (SPLIT) net = dense32s(net, L + VT_OFF_WPI, split16<false>(ci), lane);
+                else net = dense32<false>(net, L + VT_OFF_WPI, ci, lane);
             }
         }
+        if (SPLIT) {
+            // ---- split-bf16 layers: c is split once and feeds all five fc_c ----
+            const Split16 cs = split16<false>(c);
+            net = dense32s(net, L + VT_OFF_WL, cs, lane);
+#pragma unroll 1
+            for (int i = 0; i < 5; ++i) {
+                const float *wl = L + VT_OFF_WL + (1 + 3 * i) * 1024;
+                f32x16 hid = load_frag16(L + VT_OFF_BIAS + (1 + 2 * i) * 32 + h * 16);
+                hid = dense32s(hid, wl, split16<true>(net), lane);
+                net = dense32s(net, wl + 1024, split16<true>(hid), lane);
+                if (i < 4) net = dense32s(net, wl + 2048, cs, lane);
+                const f32x16 bb = load_frag16(L + VT_OFF_BIAS + (2 + 2 * i) * 32 + h * 16);
+                net = net + bb;
+            }
+        } else {
         net = dense32<false>(net, L + VT_OFF_WL, c, lane);
 
         // ---- 5 x (ResnetBlockFC + next block's fc_c) ----
@@ -189,6 +209,7 @@ decode_fwd_kernel(DecodeArgs a) {
             if (i < 4) net = dense32<false>(net, wl + 2048, c, lane);
             const f32x16 bb = load_frag16(L + VT_OFF_BIAS + (2 + 2 * i) * 32 + h * 16);
             net = net + bb;
+        }
         }
 
 #ifdef VT_SETPRIO
@@ -261,12 +282,47 @@ __global__ void __launch_bounds__(256) sample_grid_kernel(DecodeArgs a, float *f
 struct PackArgs {
     vt_decoder_params p;
     float *blob;
+    int split;            // 1: dense layers as split-bf16 fragments (vt_decoder_pack_bf16x3)
 };
+
+__device__ __forceinline__ unsigned bf16_bits(float v) {
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v);
+}
 
 __global__ void decoder_pack_kernel(PackArgs a) {
     const vt_decoder_params &p = a.p;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < VT_BLOB_FLOATS; e += gridDim.x * blockDim.x) {
         float v = 0.0f;
+        if (a.split && e >= VT_OFF_WL) {
+            // layer image [part hi|lo][k-step][lane][8 bf16]; one float slot = elements 2m, 2m+1.
+            // k of element j: the accumulator register 8s+j of lane-half h (or, for the layers
+            // fed by the gather / c_img, gather register 8s+j = channel 16h+8s+j).
+            const int q = e - VT_OFF_WL;
+            const int L = q >> 10, part = (q >> 9) & 1, s = (q >> 8) & 1, l = (q >> 2) & 63, m = q & 3;
+            const int i = l & 31, h = l >> 5;
+            const float *w;
+            int ld = 32, koff = 0;
+            bool gather_fed;
+            if (L == 15) { w = p.fc_p_w; ld = p.p_in; koff = 3; gather_fed = true; }
+            else if (L == 0) { w = p.fc_c_w[0]; gather_fed = true; }
+            else {
+                const int blk = (L - 1) / 3, kind = (L - 1) % 3;
+                if (kind == 0) { w = p.fc0_w[blk]; gather_fed = false; }
+                else if (kind == 1) { w = p.fc1_w[blk]; gather_fed = false; }
+                else { w = p.fc_c_w[blk + 1]; gather_fed = true; }
+            }
+            unsigned bits = 0;
+            for (int z = 0; z < 2; ++z) {
+                const int j = 2 * m + z;
+                const int k = gather_fed ? (16 * h + 8 * s + j) : chan_of(8 * s + j, h);
+                const float wv = (L == 15 && p.p_in <= 3) ? 0.0f : w[i * ld + koff + k];
+                const __bf16 hb = (__bf16)wv;
+                const unsigned b = part ? bf16_bits(wv - (float)hb) : (unsigned)__builtin_bit_cast(unsigned short, hb);
+                bits |= b << (16 * z);
+            }
+            a.blob[e] = __builtin_bit_cast(float, bits);
+            continue;
+        }
         if (e >= VT_OFF_WL && e < VT_OFF_WPI) {
             const int q = e - VT_OFF_WL;
             const int L = q >> 10, s = (q >> 6) & 15, l = q & 63, i = l & 31, h = l >> 5;
@@ -371,8 +427,21 @@ int vt_decoder_pack(const vt_decoder_params *p, float *blob, size_t blob_bytes, 
     PackArgs a;
     a.p = *p;
     a.blob = blob;
+    a.split = 0;
     hipLaunchKernelGGL(decoder_pack_kernel, dim3(17), dim3(1024), 0, (hipStream_t)stream, a);
     return vt_check(hipGetLastError(), "vt_decoder_pack");
+}
+
+int vt_decoder_pack_bf16x3(const vt_decoder_params *p, float *blob, size_t blob_bytes, void *stream) {
+    // same argument checks and blob size as the f32 pack; only the dense-layer images differ
+    const int rc = vt_decoder_pack(p, blob, blob_bytes, stream);
+    if (rc) return rc;
+    PackArgs a;
+    a.p = *p;
+    a.blob = blob;
+    a.split = 1;
+    hipLaunchKernelGGL(decoder_pack_kernel, dim3(17), dim3(1024), 0, (hipStream_t)stream, a);
+    return vt_check(hipGetLastError(), "vt_decoder_pack_bf16x3");
 }
 
 int vt_grid_to_channels_last(const float *src, float *dst, int B, int C, int D, int H, int W, void *stream) {
@@ -395,8 +464,9 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
                          int lattice_nx, float lattice_box, int64_t lattice_first,
                          const float *c_img, const unsigned char *cimg_ids, const float *cimg_table,
                          const float *blob, double padding,
-                         float *out, float *out2, float *save, void *stream) {
+                         float *out, float *out2, float *save, void *stream, bool split = false) {
     if ((!grid_cl && !c_direct) || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: null argument");
+    if (split && save) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd_bf16x3: the training forward (save) is exact-f32 only");
     if (B <= 0 || R < 2 || N < 0) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: bad size");
     if (C != 32) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd: c_dim must be 32");
     if (!pts) {
@@ -427,18 +497,23 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
     const size_t lds_bytes = (size_t)VT_BLOB_FLOATS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS, false>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS, false, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS, true>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS, true, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute");
         attr_set = true;
     }
-    if (save)
-        hipLaunchKernelGGL((decode_fwd_kernel<THREADS, true>), dim3((unsigned)blocks), dim3(THREADS), lds_bytes, (hipStream_t)stream, a);
+    if (split)
+        hipLaunchKernelGGL((decode_fwd_kernel<THREADS, false, true>), dim3((unsigned)blocks), dim3(THREADS), lds_bytes, (hipStream_t)stream, a);
+    else if (save)
+        hipLaunchKernelGGL((decode_fwd_kernel<THREADS, true, false>), dim3((unsigned)blocks), dim3(THREADS), lds_bytes, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL((decode_fwd_kernel<THREADS, false>), dim3((unsigned)blocks), dim3(THREADS), lds_bytes, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((decode_fwd_kernel<THREADS, false, false>), dim3((unsigned)blocks), dim3(THREADS), lds_bytes, (hipStream_t)stream, a);
     return vt_check(hipGetLastError(), "vt_decode_fwd");
 }
 
@@ -458,6 +533,17 @@ int vt_decode_fwd_ids(const float *grid_cl, int B, int R, int C, const float *pt
     if (!grid_cl || !finger_ids || !finger_feats || F <= 0) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_ids: null argument");
     return decode_launch(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, finger_ids, finger_feats,
                          blob, padding, out, nullptr, nullptr, stream);
+}
+
+int vt_decode_fwd_bf16x3(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                         int lattice_nx, float lattice_box, int64_t lattice_first,
+                         const float *c_img, const unsigned char *finger_ids, const float *finger_feats, int F,
+                         const float *blob_bf16x3, double padding, float *out, float *out2, void *stream) {
+    if (!grid_cl) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_bf16x3: null grid");
+    if (c_img && finger_ids) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_bf16x3: give c_img or finger ids, not both");
+    if (finger_ids && (!finger_feats || F <= 0)) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_bf16x3: finger ids without a feature table");
+    return decode_launch(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img,
+                         finger_ids, finger_ids ? finger_feats : nullptr, blob_bf16x3, padding, out, out2, nullptr, stream, true);
 }
 
 int vt_decode_mlp_fwd(const float *c, int B, int C, const float *pts, int64_t N,

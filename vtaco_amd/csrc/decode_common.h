@@ -48,6 +48,48 @@ __device__ __forceinline__ f32x16 dense32(f32x16 acc, const float *wl, const f32
     return acc;
 }
 
+// ---- split-bf16 ("bf16x3") dense layer ------------------------------------------------
+// An f32 value v is carried as hi + lo with hi = bf16(v), lo = bf16(v - hi) (16 mantissa
+// bits), and a product W x as  W_lo x_hi + W_hi x_lo + W_hi x_hi  on the bf16 matrix core
+// with f32 accumulation: 6 x v_mfma_f32_32x32x16_bf16 (192 cycles) per 32x32 layer
+// instead of 16 x v_mfma_f32_32x32x2_f32 (1024 cycles); the dropped lo*lo term is 2^-16
+// relative.  Same accumulator-as-operand chaining as the f32 path: registers 8s..8s+7 of
+// the previous layer's accumulator are the 8 k-elements of k-step s (weights pre-permuted).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Split16 {
+    bf16x8 hi[2], lo[2];
+};
+
+template <bool RELU>
+__device__ __forceinline__ Split16 split16(const f32x16 &x) {
+    Split16 r;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = RELU ? relu1(x[8 * s + j]) : x[8 * s + j];
+            const __bf16 hb = (__bf16)v;
+            r.hi[s][j] = hb;
+            r.lo[s][j] = (__bf16)(v - (float)hb);
+        }
+    }
+    return r;
+}
+
+// wl: the layer's LDS image [part: hi, lo][k-step 0,1][lane] x 16 bytes
+__device__ __forceinline__ f32x16 dense32s(f32x16 acc, const float *wl, const Split16 &x, int lane) {
+    const bf16x8 *w = reinterpret_cast<const bf16x8 *>(wl);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const bf16x8 wh = w[s * 64 + lane], wo = w[(2 + s) * 64 + lane];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo, x.hi[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, x.lo[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, x.hi[s], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 __device__ __forceinline__ f32x16 load_frag16(const float *p) {
     const f32x4 *q = reinterpret_cast<const f32x4 *>(p);
     f32x4 a = q[0], b = q[1], c = q[2], d = q[3];

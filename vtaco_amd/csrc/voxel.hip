@@ -50,15 +50,16 @@ voxel_build_kernel(const float *pts, int T, int Tpad, int R, float divisor,
     // bitonic sort of Tpad (power of two) 64-bit keys: ascending voxel id, then point id
     for (int k = 2; k <= Tpad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < Tpad; i += SORT_THREADS) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const unsigned long long a = keys[i], c = keys[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > c) == up) { keys[i] = c; keys[l] = a; }
-                }
+            for (int q = threadIdx.x; q < (Tpad >> 1); q += SORT_THREADS) {
+                const int i = 2 * q - (q & (j - 1)), l = i + j;    // the q-th pair (i, i^j) with i < l
+                const unsigned long long a = keys[i], c = keys[l];
+                const bool up = (i & k) == 0;
+                if ((a > c) == up) { keys[i] = c; keys[l] = a; }
             }
-            __syncthreads();
+            // a wave's 64 consecutive pairs with j < 64 live in a 128-key window no other wave
+            // touches until j grows again, so those passes only need the wave's own LDS ordering
+            if (j > 64 || j == 1) __syncthreads();
+            else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         }
     }
     // segment bounds: every point learns [lo,hi) of its voxel in sorted order
@@ -79,17 +80,29 @@ voxel_build_kernel(const float *pts, int T, int Tpad, int R, float divisor,
     }
 }
 
+// The per-point kernels below use one thread per (point, channel): a 256-thread block covers
+// 256/CL points x CL channel lanes (CL = min(C,32) ... C), so there is no integer division per thread
+// and a point's feature row is read as one coalesced run.
+__device__ __forceinline__ bool point_lane(int C, uint32_t npts, uint32_t &bt, int &c) {
+    const int cl = C < 256 ? C : 256;                          // channel lanes per point (C <= 256 here)
+    const int ppb = 256 / cl;                                  // points per block
+    const int lp = threadIdx.x / cl;
+    c = threadIdx.x - lp * cl;
+    bt = blockIdx.x * ppb + lp;
+    return lp < ppb && bt < npts;
+}
+
 // out[b,t,c] = max over the voxel-mates of t of feat[b,.,c]; argmax = the point that wins
 __global__ void __launch_bounds__(256)
 pool_max_fwd_kernel(const float *feat, const int *order, const int *seg_lo, const int *seg_hi,
-                    float *out, int *argmax, int T, int C, size_t total) {
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int c = (int)(e % C);
-        const size_t bt = e / C;
-        const size_t b = bt / T;
-        const int lo = seg_lo[bt], hi = seg_hi[bt];
-        const int *ord = order + b * T;
-        const float *fb = feat + b * T * C;
+                    float *out, int *argmax, int T, int C, uint32_t npts) {
+    uint32_t bt; int c0;
+    if (!point_lane(C, npts, bt, c0)) return;
+    const uint32_t b = bt / (uint32_t)T;
+    const int lo = seg_lo[bt], hi = seg_hi[bt];
+    const int *ord = order + (size_t)b * T;
+    const float *fb = feat + (size_t)b * T * C;
+    for (int c = c0; c < C; c += 256) {
         int best = ord[lo];
         float m = fb[(size_t)best * C + c];
         for (int j = lo + 1; j < hi; ++j) {
@@ -97,59 +110,64 @@ pool_max_fwd_kernel(const float *feat, const int *order, const int *seg_lo, cons
             const float v = fb[(size_t)t2 * C + c];
             if (v > m) { m = v; best = t2; }
         }
-        out[e] = m;
-        if (argmax) argmax[e] = best;
+        out[(size_t)bt * C + c] = m;
+        if (argmax) argmax[(size_t)bt * C + c] = best;
     }
 }
 
 // grad_feat[b,t,c] = sum over voxel-mates of grad_out[b,.,c] if t is the arg-max, else 0
 __global__ void __launch_bounds__(256)
 pool_max_bwd_kernel(const float *grad_out, const int *argmax, const int *order, const int *seg_lo, const int *seg_hi,
-                    float *grad_feat, int T, int C, size_t total) {
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int c = (int)(e % C);
-        const size_t bt = e / C;
-        const size_t b = bt / T;
-        const int t = (int)(bt - b * T);
+                    float *grad_feat, int T, int C, uint32_t npts) {
+    uint32_t bt; int c0;
+    if (!point_lane(C, npts, bt, c0)) return;
+    const uint32_t b = bt / (uint32_t)T;
+    const int t = (int)(bt - b * (uint32_t)T);
+    const int lo = seg_lo[bt], hi = seg_hi[bt];
+    const int *ord = order + (size_t)b * T;
+    const float *gb = grad_out + (size_t)b * T * C;
+    for (int c = c0; c < C; c += 256) {
         float g = 0.0f;
-        if (argmax[e] == t) {
-            const int lo = seg_lo[bt], hi = seg_hi[bt];
-            const int *ord = order + b * T;
-            const float *gb = grad_out + b * T * C;
+        if (argmax[(size_t)bt * C + c] == t)
             for (int j = lo; j < hi; ++j) g += gb[(size_t)ord[j] * C + c];
-        }
-        grad_feat[e] = g;
+        grad_feat[(size_t)bt * C + c] = g;
     }
 }
 
 // grid[b,c,voxel] = mean of feat over the voxel's points (grid pre-zeroed); NCDHW output
 __global__ void __launch_bounds__(256)
 scatter_mean_fwd_kernel(const float *feat, const int *idx, const int *order, const int *seg_lo, const int *seg_hi,
-                        float *grid, int T, int C, size_t V, size_t total) {
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int c = (int)(e % C);
-        const size_t bt = e / C;
-        const size_t b = bt / T;
-        const int t = (int)(bt - b * T);
-        const int lo = seg_lo[bt], hi = seg_hi[bt];
-        const int *ord = order + b * T;
-        if (ord[lo] != t) continue;               // the voxel's first point writes
-        const float *fb = feat + b * T * C;
+                        float *grid, int T, int C, size_t V, uint32_t npts) {
+    uint32_t bt; int c0;
+    if (!point_lane(C, npts, bt, c0)) return;
+    const uint32_t b = bt / (uint32_t)T;
+    const int t = (int)(bt - b * (uint32_t)T);
+    const int lo = seg_lo[bt], hi = seg_hi[bt];
+    const int *ord = order + (size_t)b * T;
+    if (ord[lo] != t) return;                                  // the voxel's first point writes
+    const float *fb = feat + (size_t)b * T * C;
+    for (int c = c0; c < C; c += 256) {
         float s = 0.0f;
         for (int j = lo; j < hi; ++j) s += fb[(size_t)ord[j] * C + c];
-        grid[(b * C + c) * V + (size_t)idx[bt]] = s / (float)(hi - lo);
+        grid[((size_t)b * C + c) * V + (size_t)idx[bt]] = s / (float)(hi - lo);
     }
 }
 
 __global__ void __launch_bounds__(256)
 scatter_mean_bwd_kernel(const float *grad_grid, const int *idx, const int *seg_lo, const int *seg_hi,
-                        float *grad_feat, int T, int C, size_t V, size_t total) {
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int c = (int)(e % C);
-        const size_t bt = e / C;
-        const size_t b = bt / T;
-        grad_feat[e] = grad_grid[(b * C + c) * V + (size_t)idx[bt]] / (float)(seg_hi[bt] - seg_lo[bt]);
-    }
+                        float *grad_feat, int T, int C, size_t V, uint32_t npts) {
+    uint32_t bt; int c0;
+    if (!point_lane(C, npts, bt, c0)) return;
+    const uint32_t b = bt / (uint32_t)T;
+    const float inv = 1.0f / (float)(seg_hi[bt] - seg_lo[bt]);
+    for (int c = c0; c < C; c += 256)
+        grad_feat[(size_t)bt * C + c] = grad_grid[((size_t)b * C + c) * V + (size_t)idx[bt]] * inv;
+}
+
+inline unsigned point_blocks(int C, size_t npts) {
+    const int cl = C < 256 ? C : 256;
+    const size_t ppb = 256 / cl;
+    return (unsigned)((npts + ppb - 1) / ppb);
 }
 
 inline unsigned blocks_for(size_t total) {
@@ -186,9 +204,9 @@ int vt_voxel_pool_max_fwd(const float *feat, const int *order, const int *seg_lo
                           int B, int T, int C, float *out, int *argmax, void *stream) {
     if (!feat || !order || !seg_lo || !seg_hi || !out) return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_max_fwd: null argument");
     if (B <= 0 || T <= 0 || C <= 0) return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_max_fwd: bad size");
-    const size_t total = (size_t)B * T * C;
-    hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       feat, order, seg_lo, seg_hi, out, argmax, T, C, total);
+    const size_t npts = (size_t)B * T;
+    hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(point_blocks(C, npts)), dim3(256), 0, (hipStream_t)stream,
+                       feat, order, seg_lo, seg_hi, out, argmax, T, C, (uint32_t)npts);
     return vt_check(hipGetLastError(), "vt_voxel_pool_max_fwd");
 }
 
@@ -197,9 +215,9 @@ int vt_voxel_pool_max_bwd(const float *grad_out, const int *argmax, const int *o
     if (!grad_out || !argmax || !order || !seg_lo || !seg_hi || !grad_feat)
         return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_max_bwd: null argument");
     if (B <= 0 || T <= 0 || C <= 0) return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_max_bwd: bad size");
-    const size_t total = (size_t)B * T * C;
-    hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       grad_out, argmax, order, seg_lo, seg_hi, grad_feat, T, C, total);
+    const size_t npts = (size_t)B * T;
+    hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(point_blocks(C, npts)), dim3(256), 0, (hipStream_t)stream,
+                       grad_out, argmax, order, seg_lo, seg_hi, grad_feat, T, C, (uint32_t)npts);
     return vt_check(hipGetLastError(), "vt_voxel_pool_max_bwd");
 }
 
@@ -211,8 +229,8 @@ int vt_voxel_scatter_mean_fwd(const float *feat, const int *idx, const int *orde
     const size_t V = (size_t)R * R * R, total = (size_t)B * T * C;
     int frc = vt_fill32(grid, 0u, (size_t)B * C * V * sizeof(float), (hipStream_t)stream);
     if (frc) return frc;
-    hipLaunchKernelGGL(scatter_mean_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       feat, idx, order, seg_lo, seg_hi, grid, T, C, V, total);
+    hipLaunchKernelGGL(scatter_mean_fwd_kernel, dim3(point_blocks(C, (size_t)B * T)), dim3(256), 0, (hipStream_t)stream,
+                       feat, idx, order, seg_lo, seg_hi, grid, T, C, V, (uint32_t)((size_t)B * T));
     return vt_check(hipGetLastError(), "vt_voxel_scatter_mean_fwd");
 }
 
@@ -222,8 +240,8 @@ int vt_voxel_scatter_mean_bwd(const float *grad_grid, const int *idx, const int 
         return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_bwd: null argument");
     if (B <= 0 || T <= 0 || C <= 0 || R < 1) return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_bwd: bad size");
     const size_t V = (size_t)R * R * R, total = (size_t)B * T * C;
-    hipLaunchKernelGGL(scatter_mean_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       grad_grid, idx, seg_lo, seg_hi, grad_feat, T, C, V, total);
+    hipLaunchKernelGGL(scatter_mean_bwd_kernel, dim3(point_blocks(C, (size_t)B * T)), dim3(256), 0, (hipStream_t)stream,
+                       grad_grid, idx, seg_lo, seg_hi, grad_feat, T, C, V, (uint32_t)((size_t)B * T));
     return vt_check(hipGetLastError(), "vt_voxel_scatter_mean_bwd");
 }
 

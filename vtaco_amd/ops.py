@@ -22,8 +22,12 @@ def blob_floats(hidden=32, c_dim=32, n_blocks=5):
     return n // 4
 
 
-def pack_decoder(fc_p_w, fc_p_b, fc_c, blocks, fc_out, fc_out2=None, out=None, transposed=False):
-    """Repack decoder parameters into the MFMA-fragment blob (vt_decoder_pack), or with
+PRECISIONS = ("f32", "bf16x3")
+
+
+def pack_decoder(fc_p_w, fc_p_b, fc_c, blocks, fc_out, fc_out2=None, out=None, transposed=False, precision="f32"):
+    """Repack decoder parameters into the MFMA-fragment blob (vt_decoder_pack; with
+    ``precision="bf16x3"`` the split-bf16 blob of vt_decoder_pack_bf16x3), or with
     ``transposed=True`` into the transposed-weight blob of the backward (vt_decoder_pack_t).
 
     fc_c: list of (weight, bias); blocks: list of (fc0_w, fc0_b, fc1_w, fc1_b);
@@ -64,10 +68,15 @@ def pack_decoder(fc_p_w, fc_p_b, fc_c, blocks, fc_out, fc_out2=None, out=None, t
             out = torch.empty(n, dtype=torch.float32, device=fc_p_w.device)
         check(lib.vt_decoder_pack_t(ctypes.byref(prm), dev_ptr(out, "blob_t"), n * 4, stream_ptr()), "vt_decoder_pack_t")
         return out
+    if precision not in PRECISIONS:
+        raise VtError(f"precision must be one of {PRECISIONS} (got {precision!r})")
     n = blob_floats(hidden, c_dim, nb)
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=fc_p_w.device)
-    check(lib.vt_decoder_pack(ctypes.byref(prm), dev_ptr(out, "blob"), n * 4, stream_ptr()), "vt_decoder_pack")
+    if precision == "bf16x3":
+        check(lib.vt_decoder_pack_bf16x3(ctypes.byref(prm), dev_ptr(out, "blob"), n * 4, stream_ptr()), "vt_decoder_pack_bf16x3")
+    else:
+        check(lib.vt_decoder_pack(ctypes.byref(prm), dev_ptr(out, "blob"), n * 4, stream_ptr()), "vt_decoder_pack")
     return out
 
 
@@ -110,8 +119,10 @@ def _cl_storage(grid):
     return g, dev_ptr(g.permute(0, 2, 3, 4, 1), "grid")
 
 
-def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want_contact=False, out=None, save=None):
-    """Fused trilinear gather + conditioned MLP (vt_decode_fwd).
+def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want_contact=False, out=None, save=None,
+               precision="f32"):
+    """Fused trilinear gather + conditioned MLP (vt_decode_fwd; ``precision="bf16x3"``:
+    vt_decode_fwd_bf16x3 with a blob packed for it).
 
     grid  [B,C,R,R,R] (any layout; converted to channels-last if needed)
     pts   [B,N,3] or None with lattice=(nx, box, first, count)
@@ -143,9 +154,18 @@ def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want
     out2 = torch.empty((B, N), dtype=torch.float32, device=grid.device) if want_contact else None
     if N == 0:                                   # empty query set: nothing to launch
         return (out, out2) if want_contact else out
-    check(lib.vt_decode_fwd(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first,
-                            dev_ptr(c_img, "c_img"), dev_ptr(blob, "blob"), float(padding),
-                            dev_ptr(out, "out"), dev_ptr(out2, "out2"), dev_ptr(save, "save"), stream_ptr()), "vt_decode_fwd")
+    if precision == "bf16x3":
+        if save is not None:
+            raise VtError("decode_fwd: the training forward (save) is exact-f32 only")
+        check(lib.vt_decode_fwd_bf16x3(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first,
+                                       dev_ptr(c_img, "c_img"), None, None, 0, dev_ptr(blob, "blob"), float(padding),
+                                       dev_ptr(out, "out"), dev_ptr(out2, "out2"), stream_ptr()), "vt_decode_fwd_bf16x3")
+    elif precision == "f32":
+        check(lib.vt_decode_fwd(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first,
+                                dev_ptr(c_img, "c_img"), dev_ptr(blob, "blob"), float(padding),
+                                dev_ptr(out, "out"), dev_ptr(out2, "out2"), dev_ptr(save, "save"), stream_ptr()), "vt_decode_fwd")
+    else:
+        raise VtError(f"precision must be one of {PRECISIONS} (got {precision!r})")
     return (out, out2) if want_contact else out
 
 
@@ -562,7 +582,7 @@ def tactile_assign(anchors, success, mode, radius, pts=None, lattice=None, count
     return ids
 
 
-def decode_fwd_ids(grid, blob, ids, feats, pts=None, lattice=None, padding=0.1, out=None):
+def decode_fwd_ids(grid, blob, ids, feats, pts=None, lattice=None, padding=0.1, out=None, precision="f32"):
     """vt_decode_fwd_ids: forward_img with c_img[b,n] = feats[ids[b,n]] (zeros where ids == 255)."""
     B, C, D, H, W = grid.shape
     keep, gptr = _cl_storage(grid)
@@ -575,6 +595,12 @@ def decode_fwd_ids(grid, blob, ids, feats, pts=None, lattice=None, padding=0.1, 
         nx, box, first, N = lattice
     if out is None:
         out = torch.empty((B, N), dtype=torch.float32, device=grid.device)
+    if precision == "bf16x3":
+        check(_lib.load().vt_decode_fwd_bf16x3(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first, None,
+                                               dev_ptr(_c(ids), "ids", U8), dev_ptr(feats, "feats"), feats.shape[0],
+                                               dev_ptr(blob, "blob"), float(padding), dev_ptr(out, "out"), None, stream_ptr()),
+              "vt_decode_fwd_bf16x3")
+        return out
     check(_lib.load().vt_decode_fwd_ids(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first, dev_ptr(_c(ids), "ids", U8),
                                         dev_ptr(feats, "feats"), feats.shape[0], dev_ptr(blob, "blob"), float(padding),
                                         dev_ptr(out, "out"), stream_ptr()), "vt_decode_fwd_ids")
