@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nx", type=int, default=128)
     ap.add_argument("--mode", choices=["visual", "img"], default="visual")
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3",
+                    help="arithmetic of the 16 dense layers: exact-f32 MFMA or split-bf16 MFMA (both inside the 1e-4 bar)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-only", action="store_true", help="skip the mesh-extract / stage timings (perf experiments)")
     args = ap.parse_args()
@@ -152,7 +154,7 @@ def main():
     out = torch.empty((1, npts), dtype=torch.float32, device=dev)
 
     def step():
-        dec.decode_lattice(grid, nx, box=1.1, c_img=c_img, out=out)
+        dec.decode_lattice(grid, nx, box=1.1, c_img=c_img, out=out, precision=args.precision)
 
     def fence():
         if dist is not None:

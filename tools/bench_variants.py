@@ -9,7 +9,7 @@ for rnd in range(3):
     for n in names:
         env = dict(os.environ, VTACO_HIP_LIB=os.path.join(root, "vtaco_amd", "variants", f"lib_{n}.so"))
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "100", "--warmup", "10",
-                              "--no-cpu-baseline", "--decode-only"], env=env, capture_output=True, text=True)
+                              "--no-cpu-baseline", "--decode-only"] + os.environ.get("BENCH_ARGS", "").split(), env=env, capture_output=True, text=True)
         try:
             j = json.loads(out.stdout.strip().splitlines()[-1])
             res[n].append(j["roofline"]["kernel_ms"])

@@ -17,10 +17,117 @@
 // lane (p,h) loads channels 16h..16h+15 of each of its point's 8 corners.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "decode_common.h"
 
 namespace {
+
+// ---- everything after the gather: fc_p / fc_p_img, 5 x (fc_c + ResnetBlockFC), output heads ----
+// c: the sampled features in gather layout (register s of lane-half h = channel 16h+s).
+template <bool SAVE, bool SPLIT>
+__device__ __forceinline__ void mlp_and_heads(const DecodeArgs &a, const float *L, const f32x16 &c, float px, float py, float pz,
+                                              uint32_t g, bool live, int lane, int h, bool with_img) {
+    const size_t slot = (size_t)a.total * 32;           // one saved tensor
+    float *srow = SAVE ? a.save + (size_t)g * 32 : nullptr;
+    if (SAVE && live) store_gather16(srow, c, h);        // slot 0: c
+
+#ifdef VT_DIAG_NOMLP
+    {                                             // diagnostic build: gather only
+        float acc = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc += c[s];
+        if (live && h == 0) a.out[g] = acc;
+        return;
+    }
+#endif
+#ifdef VT_SETPRIO
+    __builtin_amdgcn_s_setprio(VT_SETPRIO);       // matrix phase outranks the other waves' gather VALU
+#endif
+    // ---- net = fc_p(p) + fc_c[0](c) (+ fc_p_img's c_img columns) ----
+    f32x16 net = load_frag16(L + VT_OFF_BIAS + 0 * 32 + h * 16);
+    {
+        const float k0 = h ? py : px;          // k = 2s+h : s=0 -> x|y
+        const float k1 = h ? 0.0f : pz;        //            s=1 -> z|pad
+        net = mfma(L[VT_OFF_WP + lane], k0, net);
+        net = mfma(L[VT_OFF_WP + 64 + lane], k1, net);
+    }
+    if (with_img) {
+        if (a.cimg_ids) {
+            // tactile feature by finger id: most tiles touch no finger and skip the 16 MFMAs
+            const unsigned id = a.cimg_ids[g];
+            if (__ballot(id != 255u) != 0ull) {
+                f32x16 ci;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) ci[s] = 0.0f;
+                if (id != 255u) ci = load_frag16(a.cimg_table + (size_t)id * 32 + 16 * h);
+                if (SPLIT) net = dense32s(net, L + VT_OFF_WPI, split16<false>(ci), lane);
+                else net = dense32<false>(net, L + VT_OFF_WPI, ci, lane);
+            }
+        } else {
+            const f32x16 ci = load_frag16(a.c_img + (size_t)g * 32 + 16 * h);
+            if (SPLIT) net = dense32s(net, L + VT_OFF_WPI, split16<false>(ci), lane);
+            else net = dense32<false>(net, L + VT_OFF_WPI, ci, lane);
+        }
+    }
+    if (SPLIT) {
+        // ---- split-bf16 layers: c is split once and feeds all five fc_c ----
+        const Split16 cs = split16<false>(c);
+        net = dense32s(net, L + VT_OFF_WL, cs, lane);
+#pragma unroll 1
+        for (int i = 0; i < 5; ++i) {
+            const float *wl = L + VT_OFF_WL + (1 + 3 * i) * 1024;
+            f32x16 hid = load_frag16(L + VT_OFF_BIAS + (1 + 2 * i) * 32 + h * 16);
+            hid = dense32s(hid, wl, split16<true>(net), lane);
+            net = dense32s(net, wl + 1024, split16<true>(hid), lane);
+            if (i < 4) net = dense32s(net, wl + 2048, cs, lane);
+            const f32x16 bb = load_frag16(L + VT_OFF_BIAS + (2 + 2 * i) * 32 + h * 16);
+            net = net + bb;
+        }
+    } else {
+    net = dense32<false>(net, L + VT_OFF_WL, c, lane);
+
+    // ---- 5 x (ResnetBlockFC + next block's fc_c) ----
+#pragma unroll 1
+    for (int i = 0; i < 5; ++i) {
+        const float *wl = L + VT_OFF_WL + (1 + 3 * i) * 1024;
+        f32x16 hid = load_frag16(L + VT_OFF_BIAS + (1 + 2 * i) * 32 + h * 16);
+        if (SAVE && live) store_acc16(srow + (1 + i) * slot, relu16(net), h);    // slots 1..5: relu(x_i)
+        hid = dense32<true>(hid, wl, net, lane);
+        if (SAVE && live) store_acc16(srow + (6 + i) * slot, relu16(hid), h);    // slots 6..10: relu(h_i)
+        net = dense32<true>(net, wl + 1024, hid, lane);
+        if (i < 4) net = dense32<false>(net, wl + 2048, c, lane);
+        const f32x16 bb = load_frag16(L + VT_OFF_BIAS + (2 + 2 * i) * 32 + h * 16);
+        net = net + bb;
+    }
+    }
+
+#ifdef VT_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    if (SAVE && live) store_acc16(srow + 11 * slot, relu16(net), h);            // slot 11: relu(net_5)
+    // ---- heads: out = fc_out(relu(net)) ----
+    {
+        const f32x16 wo = load_frag16(L + VT_OFF_OUT + h * 16);
+        float acc = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = fmaf(relu1(net[s]), wo[s], acc);
+        acc += __shfl_xor(acc, 32);
+        acc += L[VT_OFF_OUT + 64];
+        if (live && h == 0) a.out[g] = acc;
+#ifndef VT_DIAG_CLOCK
+        if (a.out2) {
+            const f32x16 wo2 = load_frag16(L + VT_OFF_OUT + 32 + h * 16);
+            float acc2 = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc2 = fmaf(relu1(net[s]), wo2[s], acc2);
+            acc2 += __shfl_xor(acc2, 32);
+            acc2 += L[VT_OFF_OUT + 65];
+            if (live && h == 0) a.out2[g] = acc2;
+        }
+#endif
+    }
+}
 
 // SPLIT selects the split-bf16 dense layers (decode_common.h) and expects the blob of
 // vt_decoder_pack_bf16x3; everything around the 16 dense layers is shared.
@@ -138,105 +245,7 @@ decode_fwd_kernel(DecodeArgs a) {
             pin16(c);
             __builtin_amdgcn_sched_barrier(0);
         }
-        const size_t slot = (size_t)a.total * 32;           // one saved tensor
-        float *srow = SAVE ? a.save + (size_t)g * 32 : nullptr;
-        if (SAVE && live) store_gather16(srow, c, h);        // slot 0: c
-
-#ifdef VT_DIAG_NOMLP
-        {                                             // diagnostic build: gather only
-            float acc = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) acc += c[s];
-            if (live && h == 0) a.out[g] = acc;
-            continue;
-        }
-#endif
-#ifdef VT_SETPRIO
-        __builtin_amdgcn_s_setprio(VT_SETPRIO);       // matrix phase outranks the other waves' gather VALU
-#endif
-        // ---- net = fc_p(p) + fc_c[0](c) (+ fc_p_img's c_img columns) ----
-        f32x16 net = load_frag16(L + VT_OFF_BIAS + 0 * 32 + h * 16);
-        {
-            const float k0 = h ? py : px;          // k = 2s+h : s=0 -> x|y
-            const float k1 = h ? 0.0f : pz;        //            s=1 -> z|pad
-            net = mfma(L[VT_OFF_WP + lane], k0, net);
-            net = mfma(L[VT_OFF_WP + 64 + lane], k1, net);
-        }
-        if (with_img) {
-            if (a.cimg_ids) {
-                // tactile feature by finger id: most tiles touch no finger and skip the 16 MFMAs
-                const unsigned id = a.cimg_ids[g];
-                if (__ballot(id != 255u) != 0ull) {
-                    f32x16 ci;
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) ci[s] = 0.0f;
-                    if (id != 255u) ci = load_frag16(a.cimg_table + (size_t)id * 32 + 16 * h);
-                    if (SPLIT) net = dense32s(net, L + VT_OFF_WPI, split16<false>(ci), lane);
-                    else net = dense32<false>(net, L + VT_OFF_WPI, ci, lane);
-                }
-            } else {
-                const f32x16 ci = load_frag16(a.c_img + (size_t)g * 32 + 16 * h);
-                if (SPLIT) net = dense32s(net, L + VT_OFF_WPI, split16<false>(ci), lane);
-                else net = dense32<false>(net, L + VT_OFF_WPI, ci, lane);
-            }
-        }
-        if (SPLIT) {
-            // ---- split-bf16 layers: c is split once and feeds all five fc_c ----
-            const Split16 cs = split16<false>(c);
-            net = dense32s(net, L + VT_OFF_WL, cs, lane);
-#pragma unroll 1
-            for (int i = 0; i < 5; ++i) {
-                const float *wl = L + VT_OFF_WL + (1 + 3 * i) * 1024;
-                f32x16 hid = load_frag16(L + VT_OFF_BIAS + (1 + 2 * i) * 32 + h * 16);
-                hid = dense32s(hid, wl, split16<true>(net), lane);
-                net = dense32s(net, wl + 1024, split16<true>(hid), lane);
-                if (i < 4) net = dense32s(net, wl + 2048, cs, lane);
-                const f32x16 bb = load_frag16(L + VT_OFF_BIAS + (2 + 2 * i) * 32 + h * 16);
-                net = net + bb;
-            }
-        } else {
-        net = dense32<false>(net, L + VT_OFF_WL, c, lane);
-
-        // ---- 5 x (ResnetBlockFC + next block's fc_c) ----
-#pragma unroll 1
-        for (int i = 0; i < 5; ++i) {
-            const float *wl = L + VT_OFF_WL + (1 + 3 * i) * 1024;
-            f32x16 hid = load_frag16(L + VT_OFF_BIAS + (1 + 2 * i) * 32 + h * 16);
-            if (SAVE && live) store_acc16(srow + (1 + i) * slot, relu16(net), h);    // slots 1..5: relu(x_i)
-            hid = dense32<true>(hid, wl, net, lane);
-            if (SAVE && live) store_acc16(srow + (6 + i) * slot, relu16(hid), h);    // slots 6..10: relu(h_i)
-            net = dense32<true>(net, wl + 1024, hid, lane);
-            if (i < 4) net = dense32<false>(net, wl + 2048, c, lane);
-            const f32x16 bb = load_frag16(L + VT_OFF_BIAS + (2 + 2 * i) * 32 + h * 16);
-            net = net + bb;
-        }
-        }
-
-#ifdef VT_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        if (SAVE && live) store_acc16(srow + 11 * slot, relu16(net), h);            // slot 11: relu(net_5)
-        // ---- heads: out = fc_out(relu(net)) ----
-        {
-            const f32x16 wo = load_frag16(L + VT_OFF_OUT + h * 16);
-            float acc = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) acc = fmaf(relu1(net[s]), wo[s], acc);
-            acc += __shfl_xor(acc, 32);
-            acc += L[VT_OFF_OUT + 64];
-            if (live && h == 0) a.out[g] = acc;
-#ifndef VT_DIAG_CLOCK
-            if (a.out2) {
-                const f32x16 wo2 = load_frag16(L + VT_OFF_OUT + 32 + h * 16);
-                float acc2 = 0.0f;
-#pragma unroll
-                for (int s = 0; s < 16; ++s) acc2 = fmaf(relu1(net[s]), wo2[s], acc2);
-                acc2 += __shfl_xor(acc2, 32);
-                acc2 += L[VT_OFF_OUT + 65];
-                if (live && h == 0) a.out2[g] = acc2;
-            }
-#endif
-        }
+        mlp_and_heads<SAVE, SPLIT>(a, L, c, px, py, pz, g, live, lane, h, with_img);
     }
 #ifdef VT_DIAG_CLOCK
     if (threadIdx.x == 0 && a.out2) {
@@ -247,6 +256,169 @@ decode_fwd_kernel(DecodeArgs a) {
         dbg[3] = dc_r0 - dc_entry;                    // weight-staging prologue, 10 ns ticks
     }
 #endif
+}
+
+// ---- lattice decode with the gather staged through LDS -------------------------------------
+// The direct gather above is bound by the L1's address processing: each lane's 16-byte load is
+// its own cache access (46 accesses per wave-instruction measured, 97.5 M per 128^3 launch, one
+// per cycle per CU = the whole 0.17 ms).  Here every wave first copies the 3 x 4 x 4 voxel
+// footprint of its 2 x 4 x 4 point brick (48 rows of 128 B; 16 runs of 384 contiguous bytes)
+// into a private LDS image with six fully coalesced loads, issued one tile ahead so their latency
+// hides behind the previous tile's MLP, and gathers the 8 corners from LDS.  Per-axis corner
+// indices and weights come from a table (all three axes share it: same nx, box, R), so the
+// coordinate maths -- three exact divisions per point in the direct path -- is done nx times
+// per block, not per point.  Same FMA order as the direct path: results are bit-identical.
+// Host-side conditions (decode_launch): brick-aligned lattice, voxels per lattice step < 2/3
+// (the footprint bound), R >= 4, table fits.
+constexpr int ST_ROW_BYTES = 144;                 // 128 B of channels + 16 B pad: rotates the LDS banks row by row
+constexpr int ST_ROWS = 48;
+constexpr int ST_WAVE_FLOATS = ST_ROWS * ST_ROW_BYTES / 4;
+constexpr int ST_THREADS = 768;                   // 12 waves: blob + table + 12 images fit the CU's 160 KiB
+
+struct AxisEnt {                                   // one lattice index along one axis
+    int i0, i1;                                    // lower / upper corner voxel (border-clamped)
+    float w0, w1;                                  // their weights (w1 = 0 where ATen skips the corner)
+};
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(ST_THREADS)
+decode_fwd_staged_kernel(DecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.blob);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
+        for (int i = threadIdx.x; i < VT_BLOB_FLOATS / 4; i += ST_THREADS) dst[i] = src[i];
+    }
+    const int R = a.R;
+    AxisEnt *tab = reinterpret_cast<AxisEnt *>(lds + VT_BLOB_FLOATS);
+    for (int i = threadIdx.x; i < a.nx; i += ST_THREADS) {
+        float p, unused0, unused1;
+        lattice_point(a, (uint32_t)i, 0u, 0u, p, unused0, unused1);
+        const float f = grid_coord(p, a.divisor, R);
+        const float f0 = floorf(f);
+        AxisEnt e;
+        e.i0 = (int)f0;
+        e.w0 = (f0 + 1.0f) - f;
+        e.i1 = min(e.i0 + 1, R - 1);
+        e.w1 = (e.i0 + 1 <= R - 1) ? f - f0 : 0.0f;
+        tab[i] = e;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int pl = lane & 31;
+    const int h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int WPB = ST_THREADS / 64;
+    const uint32_t ntiles = a.total >> 5;
+    const bool with_img = a.c_img != nullptr || a.cimg_ids != nullptr;
+    const uint32_t nx = (uint32_t)a.nx;
+    const uint32_t tpb = a.N >> 5, q4 = nx >> 2;
+    const uint32_t plane0 = a.lattice_first / (nx * nx);
+    char *stage = reinterpret_cast<char *>(lds + VT_BLOB_FLOATS + 4 * a.nx) + wave * (ST_WAVE_FLOATS * 4);
+
+    // the six 1-KiB pieces of a footprint: piece k, lane -> 16-byte chunk m = 64k + lane of the
+    // 16 runs x 24 chunks; run = (dz, dy), chunk q = 8 dx + (16-byte column)
+    uint32_t src_off[6], dst_off[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int m = 64 * k + lane, run = m / 24, q = m - 24 * run;
+        const int dz = run >> 2, dy = run & 3;
+        src_off[k] = (uint32_t)((dz * R + dy) * R) * 128u + (uint32_t)q * 16u;
+        dst_off[k] = (uint32_t)(((dz * 4 + dy) * 3 + (q >> 3)) * ST_ROW_BYTES + (q & 7) * 16);
+    }
+
+    uint32_t t_begin = 0, t_end = ntiles, w_idx = blockIdx.x * WPB + wave, w_cnt = gridDim.x * WPB;
+    if ((gridDim.x & 7u) == 0 && ntiles >= 8u * WPB) {                  // XCD-aware order, as decode_fwd_kernel
+        const uint32_t chunk = (ntiles + 7u) >> 3, xcd = blockIdx.x & 7u;
+        t_begin = min(xcd * chunk, ntiles);
+        t_end = min(t_begin + chunk, ntiles);
+        w_idx = (blockIdx.x >> 3) * WPB + wave;
+        w_cnt = (gridDim.x >> 3) * WPB;
+    }
+
+    // brick -> first lattice indices (wave-uniform)
+    auto brick_of = [&](uint32_t tile, uint32_t &b, uint32_t &X0, uint32_t &Y0, uint32_t &Z0) {
+        b = tile / tpb;
+        const uint32_t t = tile - b * tpb;
+        const uint32_t pp = t / (q4 * q4), rem = t - pp * q4 * q4;
+        const uint32_t by = rem / q4, bz = rem - by * q4;
+        X0 = 2u * pp; Y0 = 4u * by; Z0 = 4u * bz;
+    };
+    // footprint origin (clamped so that the 3 x 4 x 4 block stays inside the grid) and its loads
+    f32x4 pre[6];
+    int ox = 0, oy = 0, oz = 0;
+    auto fetch = [&](uint32_t tile, int &fx, int &fy, int &fz) {
+        uint32_t b, X0, Y0, Z0;
+        brick_of(tile, b, X0, Y0, Z0);
+        fx = min(__builtin_amdgcn_readfirstlane(tab[plane0 + X0].i0), R - 3);
+        fy = min(__builtin_amdgcn_readfirstlane(tab[Y0].i0), R - 4);
+        fz = min(__builtin_amdgcn_readfirstlane(tab[Z0].i0), R - 4);
+        const uint64_t bp = reinterpret_cast<uint64_t>(a.grid + ((((size_t)b * R + fz) * R + fy) * R + fx) * 32);
+        // wave-uniform by construction: keep it in SGPRs so the loads use the saddr + 32-bit voffset form
+        const char *base = reinterpret_cast<const char *>(
+            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bp >> 32)) << 32) |
+            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bp));
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pre[k] = *reinterpret_cast<const f32x4 *>(base + src_off[k]);
+    };
+
+    uint32_t tile = t_begin + w_idx;
+    if (tile < t_end) fetch(tile, ox, oy, oz);
+    for (; tile < t_end; tile += w_cnt) {
+        unsigned lds_off = 0;
+        asm volatile("" : "+v"(lds_off));                                // see decode_fwd_kernel
+        const float *L = lds + lds_off;
+
+        // ---- this tile's footprint: registers -> the wave's LDS image ----
+#pragma unroll
+        for (int k = 0; k < 6; ++k) *reinterpret_cast<f32x4 *>(stage + dst_off[k]) = pre[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        uint32_t b, X0, Y0, Z0;
+        brick_of(tile, b, X0, Y0, Z0);
+        const uint32_t ixl = X0 + (uint32_t)(pl >> 4), iy = Y0 + (uint32_t)((pl >> 2) & 3), iz = Z0 + (uint32_t)(pl & 3);
+        const uint32_t g = b * a.N + (ixl * nx + iy) * nx + iz;
+        float px, py, pz;
+        lattice_point(a, plane0 + ixl, iy, iz, px, py, pz);
+        const AxisEnt ex = tab[plane0 + ixl], ey = tab[iy], ez = tab[iz];
+
+        // ---- trilinear gather from the image (same corner and FMA order as the direct path) ----
+        f32x16 c;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) c[s] = 0.0f;
+        const int rx0 = ex.i0 - ox, rx1 = ex.i1 - ox;
+        const int ry0 = (ey.i0 - oy) * 3, ry1 = (ey.i1 - oy) * 3;
+        const int rz0 = (ez.i0 - oz) * 12, rz1 = (ez.i1 - oz) * 12;
+        const char *img = stage + 64 * h;
+        auto plane = [&](int rz, float wz) {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int ry = dy ? ry1 : ry0;
+                const float wy = dy ? ey.w1 : ey.w0;
+                const f32x16 v0 = load_frag16(reinterpret_cast<const float *>(img + (rz + ry + rx0) * ST_ROW_BYTES));
+                const f32x16 v1 = load_frag16(reinterpret_cast<const float *>(img + (rz + ry + rx1) * ST_ROW_BYTES));
+                const float w0 = (ex.w0 * wy) * wz;
+                const float w1 = (ex.w1 * wy) * wz;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) c[s] = fmaf(v0[s], w0, c[s]);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) c[s] = fmaf(v1[s], w1, c[s]);
+            }
+        };
+        plane(rz0, ez.w0);
+        pin16(c);
+        __builtin_amdgcn_sched_barrier(0);
+        plane(rz1, ez.w1);
+        pin16(c);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- next tile's footprint goes into flight before this tile's MLP ----
+        if (tile + w_cnt < t_end) fetch(tile + w_cnt, ox, oy, oz);
+
+        mlp_and_heads<false, SPLIT>(a, L, c, px, py, pz, g, true, lane, h, with_img);
+    }
 }
 
 // ---- trilinear gather only: feat[b,n,:] = grid sampled at the query point -----------------
@@ -487,6 +659,34 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
     if (!pts && !save && (lattice_nx & 3) == 0) {
         const int64_t pair = 2ll * lattice_nx * lattice_nx;            // two x-planes
         if (lattice_first % pair == 0 && N % pair == 0) a.brick = 1;
+    }
+    // LDS-staged gather (decode_fwd_staged_kernel) when the brick footprint is bounded by 3 x 4 x 4 voxels:
+    // voxels per lattice step s = (R-1) * box / ((nx-1) * divisor) < 2/3 (0.496 at 128^3 / R=64)
+    static const bool force_direct = getenv("VTACO_DECODE_DIRECT") != nullptr;       // A/B knob for tests and benches
+    if (a.brick && !force_direct && R >= 4 && lattice_nx <= 512 && !c_direct) {
+        const double s_vox = (double)(R - 1) * (double)lattice_box / ((double)(lattice_nx - 1) * (double)a.divisor);
+        const size_t lds_st = ((size_t)VT_BLOB_FLOATS + 4u * (size_t)lattice_nx + (size_t)(ST_THREADS / 64) * ST_WAVE_FLOATS) * sizeof(float);
+        if (s_vox > 0.0 && s_vox < 0.66 && lds_st <= 160u * 1024u) {
+            const int64_t nt = (int64_t)a.total / 32;
+            int64_t blocks = (nt + ST_THREADS / 64 - 1) / (ST_THREADS / 64);
+            if (blocks > vt_num_cus()) blocks = vt_num_cus();
+            if (blocks > 8) blocks &= ~7ll;
+            static bool st_attr = false;
+            if (!st_attr) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged_kernel<false>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged_kernel<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute (staged)");
+                st_attr = true;
+            }
+            if (split)
+                hipLaunchKernelGGL((decode_fwd_staged_kernel<true>), dim3((unsigned)blocks), dim3(ST_THREADS), lds_st, (hipStream_t)stream, a);
+            else
+                hipLaunchKernelGGL((decode_fwd_staged_kernel<false>), dim3((unsigned)blocks), dim3(ST_THREADS), lds_st, (hipStream_t)stream, a);
+            return vt_check(hipGetLastError(), "vt_decode_fwd");
+        }
     }
     constexpr int THREADS = VT_THREADS;
     const int64_t ntiles = ((int64_t)a.total + 31) / 32;
