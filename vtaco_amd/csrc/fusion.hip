@@ -48,9 +48,45 @@ __global__ void fusion_pack_kernel(FusionUnitDev u, float *blob) {
     }
 }
 
+// ---- split-bf16 operands --------------------------------------------------------------------
+// The N x N products run on the bf16 matrix core with every f32 operand carried as
+// hi + lo (hi = bf16(v), lo = bf16(v - hi)) and every product as lo*hi + hi*lo + hi*hi with f32
+// accumulation (decode_common.h): 12 x v_mfma_f32_32x32x16_bf16 per 32 x 32 x 64 score tile
+// (384 cycles) instead of 32 x v_mfma_f32_32x32x2_f32 (2048).  Q, K and V' are split ONCE by the
+// kernels that produce them, straight into MFMA fragment order, so the passes do no conversion
+// work except for the exponentials E that feed E x V'.  Unit-vector scores are exact to ~2^-16:
+// 4e-6 .. 9e-6 on the fused features of the golden vectors (the f32 core: 2e-6 .. 3e-6).
+//
+// Q/K row (128 bf16 = 256 B): [kg 2][part hi|lo 2][k-step t 4][e 8], column = 16t + 8kg + e --
+// lane (row, kg) of a 32x32x16 MFMA reads its 4 hi and 4 lo fragments as one 128-B run.
+// Q is stored times log2(e), so exp(S) is a bare v_exp_f32 of the MFMA result.
+struct FragQK {
+    bf16x8 hi[4], lo[4];
+};
+__device__ __forceinline__ void load_fragqk(FragQK &f, const void *rowbase, int kg) {
+    const bf16x8 *r = reinterpret_cast<const bf16x8 *>(reinterpret_cast<const char *>(rowbase) + kg * 128);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { f.hi[t] = r[t]; f.lo[t] = r[4 + t]; }
+}
+__device__ __forceinline__ f32x16 mfma16(const bf16x8 &a, const bf16x8 &b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// D[i][j] = stream_row_i . fixed_row_j over the 64-d keys: lane (j,h) reg r = score of
+// streamed row chan_of(r,h) against fixed row j
+__device__ __forceinline__ f32x16 score_tile(const FragQK &stream, const FragQK &fixed) {
+    f32x16 acc;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        acc = mfma16(stream.lo[t], fixed.hi[t], acc);
+        acc = mfma16(stream.hi[t], fixed.lo[t], acc);
+        acc = mfma16(stream.hi[t], fixed.hi[t], acc);
+    }
+    return acc;
+}
+
 // ---- projections: one thread per point ---------------------------------------------------
-// Qd/Kd are stored de-interleaved, [point][kk][32] with column 2s+kk at [kk][s], so that an
-// MFMA lane (row, kk) reads its 32 operands as one contiguous 128-B run.
 template <bool DO_Q, bool DO_KV>
 __global__ void __launch_bounds__(256)
 fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd, float *Kd, float *V, int total) {
@@ -63,7 +99,7 @@ fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd,
     __syncthreads();
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= total) return;
-    auto project64 = [&](const float *x, const float *W, float *dst) {
+    auto project64 = [&](const float *x, const float *W, float *dst, float post) {
         float out[64];
         float ss = 0.0f;
 #pragma unroll
@@ -75,21 +111,36 @@ fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd,
             ss = fmaf(a, a, ss);
         }
         const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);      // F.normalize(p=2, eps=1e-12)
+        bf16x8 *row = reinterpret_cast<bf16x8 *>(dst);           // 16 fragments of 8 bf16
 #pragma unroll
-        for (int j = 0; j < 64; ++j) dst[(j & 1) * 32 + (j >> 1)] = out[j] * inv;
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg) {
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = (out[16 * t + 8 * kg + e] * inv) * post;
+                    const __bf16 hb = (__bf16)v;
+                    hi[e] = hb;
+                    lo[e] = (__bf16)(v - (float)hb);
+                }
+                row[(kg * 2 + 0) * 4 + t] = hi;
+                row[(kg * 2 + 1) * 4 + t] = lo;
+            }
+        }
     };
     float x[32];
     if (DO_Q) {
         const f32x4 *r = reinterpret_cast<const f32x4 *>(Xq + (size_t)p * 32);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const f32x4 t = r[i]; x[4 * i] = t.x; x[4 * i + 1] = t.y; x[4 * i + 2] = t.z; x[4 * i + 3] = t.w; }
-        project64(x, w, Qd + (size_t)p * 64);
+        project64(x, w, Qd + (size_t)p * 64, 1.44269504088896341f);
     }
     if (DO_KV) {
         const f32x4 *r = reinterpret_cast<const f32x4 *>(Xk + (size_t)p * 32);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const f32x4 t = r[i]; x[4 * i] = t.x; x[4 * i + 1] = t.y; x[4 * i + 2] = t.z; x[4 * i + 3] = t.w; }
-        project64(x, w + 2048, Kd + (size_t)p * 64);
+        project64(x, w + 2048, Kd + (size_t)p * 64, 1.0f);
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             float a = 0.0f;
@@ -100,74 +151,46 @@ fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd,
     }
 }
 
-// e^x for x in [-1,1] (unit-vector dot products) as ONE v_exp_f32: 2^(x*log2 e); 1-2 ulp, against
-// ~15 VALU instructions for the libm expf -- the exponentials are the VALU load of these kernels
-__device__ __forceinline__ float exp_unit(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
-
-// 32 operands of an MFMA lane: row `row` (clamped), half kk, of a de-interleaved [.,2,32] array
-struct Frag32 { float v[32]; };
-__device__ __forceinline__ void load_frag32(Frag32 &f, const float *base, int row, int kk) {
-    const f32x4 *r = reinterpret_cast<const f32x4 *>(base + (size_t)row * 64 + kk * 32);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { const f32x4 t = r[i]; f.v[4 * i] = t.x; f.v[4 * i + 1] = t.y; f.v[4 * i + 2] = t.z; f.v[4 * i + 3] = t.w; }
-}
-
-// D[i][j] = stream_row_i . fixed_row_j over the 64-d keys: lane (j,h) reg r = score of
-// streamed row chan_of(r,h) against fixed row j
-__device__ __forceinline__ f32x16 score_tile(const Frag32 &stream, const Frag32 &fixed) {
-    f32x16 acc;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc[s] = 0.0f;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) acc = mfma(stream.v[s], fixed.v[s], acc);
-    return acc;
-}
-
 // ---- streamed-tile machinery shared by the three N x N passes ---------------------------------
-// A workgroup owns 128 fixed rows (one 32-row tile per wave) and streams ALL rows of the other
-// operand through LDS in 32-row tiles, double-buffered: every streamed byte is fetched once per 128
-// fixed rows (the first version let each wave pull its own tiles straight from memory: 4x the
-// traffic, and the pass ran at the Infinity-Cache rate instead of the matrix rate).
-constexpr int SROW = 68;                                    // 64 floats + 4 pad: conflict-free ds_read_b128
+// A workgroup owns 256 fixed rows (one 32-row tile per wave, 8 waves) and streams ALL rows of the
+// other operand through LDS in 32-row tiles, double-buffered: every streamed byte is fetched once
+// per 256 fixed rows.
+constexpr int FT = 512;                                     // threads per workgroup
+constexpr int FROWS = 256;                                  // fixed rows per workgroup
+constexpr int SROW = 68;                                    // 256-B row + 16 B pad: conflict-free ds_read_b128
 constexpr int STILE = 32 * SROW;
 
-// cooperative global -> register -> LDS copy of one 32 x 64 de-interleaved tile (2 float4 per thread)
-struct TileRegs { f32x4 a, b; };
-__device__ __forceinline__ void tile_fetch(TileRegs &t, const float *base, int row0, int N) {
-    const int i0 = threadIdx.x, i1 = threadIdx.x + 256;     // float4 index within the tile: row = i/16, col4 = i%16
-    t.a = *reinterpret_cast<const f32x4 *>(base + (size_t)min(row0 + (i0 >> 4), N - 1) * 64 + (i0 & 15) * 4);
-    t.b = *reinterpret_cast<const f32x4 *>(base + (size_t)min(row0 + (i1 >> 4), N - 1) * 64 + (i1 & 15) * 4);
+// cooperative global -> register -> LDS copy of one 32 x 256-B tile (one 16-B piece per thread)
+__device__ __forceinline__ f32x4 tile_fetch(const float *base, int row0, int N) {
+    const int i = threadIdx.x;                              // piece: row = i/16, column = i%16
+    return *reinterpret_cast<const f32x4 *>(base + (size_t)min(row0 + (i >> 4), N - 1) * 64 + (i & 15) * 4);
 }
-__device__ __forceinline__ void tile_store(float *tile, const TileRegs &t) {
-    const int i0 = threadIdx.x, i1 = threadIdx.x + 256;
-    *reinterpret_cast<f32x4 *>(tile + (i0 >> 4) * SROW + (i0 & 15) * 4) = t.a;
-    *reinterpret_cast<f32x4 *>(tile + (i1 >> 4) * SROW + (i1 & 15) * 4) = t.b;
+__device__ __forceinline__ void tile_store(float *tile, const f32x4 &t) {
+    const int i = threadIdx.x;
+    *reinterpret_cast<f32x4 *>(tile + (i >> 4) * SROW + (i & 15) * 4) = t;
 }
-// this lane's 32 MFMA operands of the staged tile: row j, half kk
-__device__ __forceinline__ void tile_frag(Frag32 &f, const float *tile, int j, int kk) {
-    const f32x4 *r = reinterpret_cast<const f32x4 *>(tile + j * SROW + kk * 32);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { const f32x4 t = r[i]; f.v[4 * i] = t.x; f.v[4 * i + 1] = t.y; f.v[4 * i + 2] = t.z; f.v[4 * i + 3] = t.w; }
-}
+
+// the exponent is already in base 2 (Q carries log2 e)
+__device__ __forceinline__ float exp2_unit(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // out[f] = sum over streamed rows i of exp(S_i . F_f) * (w ? w[i] : 1)
 //   rowsum: F = Q, S = K, w = null          colsum: F = K, S = Q, w = 1/l
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(FT)
 fusion_expsum_kernel(const float *Fd, const float *Sd, const float *w, float *out, int N, int recip_out) {
     __shared__ __attribute__((aligned(16))) float tiles[2][STILE];
     __shared__ __attribute__((aligned(16))) float wt[2][32];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-    const int f0 = blockIdx.x * 128 + wave * 32;
+    const int f0 = blockIdx.x * FROWS + wave * 32;
     Fd += (size_t)b * N * 64; Sd += (size_t)b * N * 64;
     if (w) w += (size_t)b * N;
-    Frag32 fixed;
-    load_frag32(fixed, Fd, min(f0 + j, N - 1), h);
+    FragQK fixed;
+    load_fragqk(fixed, Fd + (size_t)min(f0 + j, N - 1) * 64, h);
     const int ntile = (N + 31) / 32;
-    TileRegs tr;
+    f32x4 tr;
     float wreg = 0.0f;
     auto fetch = [&](int t) {
-        tile_fetch(tr, Sd, t * 32, N);
+        tr = tile_fetch(Sd, t * 32, N);
         if (threadIdx.x < 32) { const int i = t * 32 + threadIdx.x; wreg = (i < N) ? (w ? w[i] : 1.0f) : 0.0f; }
     };
     fetch(0);
@@ -178,12 +201,12 @@ fusion_expsum_kernel(const float *Fd, const float *Sd, const float *w, float *ou
     for (int t = 0; t < ntile; ++t) {
         const int cur = t & 1;
         if (t + 1 < ntile) fetch(t + 1);
-        Frag32 stream;
-        tile_frag(stream, tiles[cur], j, h);
+        FragQK stream;
+        load_fragqk(stream, tiles[cur] + j * SROW, h);
         const f32x16 sc = score_tile(stream, fixed);
         const f32x16 ww = load_acc16(wt[cur], h);               // w of streamed row chan_of(r,h)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sum = fmaf(exp_unit(sc[r]), ww[r], sum);
+        for (int r = 0; r < 16; ++r) sum = fmaf(exp2_unit(sc[r]), ww[r], sum);
         if (t + 1 < ntile) {
             tile_store(tiles[cur ^ 1], tr);
             if (threadIdx.x < 32) wt[cur ^ 1][threadIdx.x] = wreg;
@@ -194,63 +217,81 @@ fusion_expsum_kernel(const float *Fd, const float *Sd, const float *w, float *ou
     if (lane < 32 && f0 + lane < N) out[(size_t)b * N + f0 + lane] = recip_out ? 1.0f / sum : sum;
 }
 
-// V'T[b][c][k] = V[b][k][c] / (1e-9 + s[b][k]); columns k >= N (padding to Npad) are zero
+// V' = V / (1e-9 + s) per key, split and laid out as the A operand of E x V':
+// VT[b][tile][c][kg][part][k-step 2][e 8] bf16 with key = 32 tile + chan_of(8 step + e, kg) -- the
+// key order of the score accumulator -- and zeros for keys >= N.  One thread per (b, tile, c, kg, step).
 __global__ void __launch_bounds__(256)
-fusion_scalev_kernel(const float *V, const float *s, float *VT, int N, int Npad, size_t total) {
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int k = (int)(e % Npad);
-        const size_t bc = e / Npad;
-        const int c = (int)(bc % 32);
-        const size_t b = bc / 32;
-        VT[e] = (k < N) ? V[(b * N + k) * 32 + c] / (1e-9f + s[b * N + k]) : 0.0f;
+fusion_scalev_kernel(const float *V, const float *s, float *VT, int N, int ntile, size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int step = (int)(idx & 1), kg = (int)((idx >> 1) & 1), c = (int)((idx >> 2) & 31);
+        const size_t bt = idx >> 7;
+        const int tile = (int)(bt % ntile);
+        const size_t b = bt / ntile;
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int key = 32 * tile + chan_of(8 * step + e, kg);
+            const float v = (key < N) ? V[(b * N + key) * 32 + c] / (1e-9f + s[b * N + key]) : 0.0f;
+            const __bf16 hb = (__bf16)v;
+            hi[e] = hb;
+            lo[e] = (__bf16)(v - (float)hb);
+        }
+        bf16x8 *row = reinterpret_cast<bf16x8 *>(VT) + (bt * 32 + c) * 8 + kg * 4;
+        row[step] = hi;
+        row[2 + step] = lo;
     }
 }
 
 // attention output + RelationUnit tail + TransNonlinear + residual: Z = X_q + LN(...)
-constexpr int VROW = 36;                                    // V'T tile row: 32 keys + 4 pad
-__global__ void __launch_bounds__(256)
+constexpr int VROW = 36;                                    // V' tile row: 128 B + 16 B pad
+__global__ void __launch_bounds__(FT)
 fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const float *linv, const float *Xq,
-                     const float *blob, float *Z, int N, int Npad) {
+                     const float *blob, float *Z, int N, int ntile_) {
     __shared__ __attribute__((aligned(16))) float lds[FU_BLOB];
     __shared__ __attribute__((aligned(16))) float tiles[2][STILE];
     __shared__ __attribute__((aligned(16))) float vts[2][32 * VROW];
-    for (int i = threadIdx.x; i < FU_BLOB; i += 256) lds[i] = blob[i];
+    for (int i = threadIdx.x; i < FU_BLOB; i += FT) lds[i] = blob[i];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-    const int q0 = blockIdx.x * 128 + wave * 32;
-    Qd += (size_t)b * N * 64; Kd += (size_t)b * N * 64; VT += (size_t)b * 32 * Npad;
-    Frag32 fixed;
-    load_frag32(fixed, Qd, min(q0 + j, N - 1), h);
+    const int q0 = blockIdx.x * FROWS + wave * 32;
+    const int ntile = ntile_;
+    Qd += (size_t)b * N * 64; Kd += (size_t)b * N * 64; VT += (size_t)b * ntile * 1024;
+    FragQK fixed;
+    load_fragqk(fixed, Qd + (size_t)min(q0 + j, N - 1) * 64, h);
     f32x16 o;
 #pragma unroll
     for (int s = 0; s < 16; ++s) o[s] = 0.0f;
-    const int ntile = (N + 31) / 32;
-    TileRegs tr;
-    f32x4 vreg;
-    const int vc = threadIdx.x >> 3, vk = (threadIdx.x & 7) * 4;   // V'T tile: channel row, key quad
+    f32x4 tr, vreg;
+    const int vc = (threadIdx.x & 255) >> 3, vk = (threadIdx.x & 7) * 4;   // V' tile piece: channel row, 16-B column
     auto fetch = [&](int t) {
-        tile_fetch(tr, Kd, t * 32, N);
-        vreg = *reinterpret_cast<const f32x4 *>(VT + (size_t)vc * Npad + t * 32 + vk);
+        tr = tile_fetch(Kd, t * 32, N);
+        if (threadIdx.x < 256) vreg = *reinterpret_cast<const f32x4 *>(VT + (size_t)t * 1024 + threadIdx.x * 4);
     };
     fetch(0);
     tile_store(tiles[0], tr);
-    *reinterpret_cast<f32x4 *>(vts[0] + vc * VROW + vk) = vreg;
+    if (threadIdx.x < 256) *reinterpret_cast<f32x4 *>(vts[0] + vc * VROW + vk) = vreg;
     __syncthreads();
     for (int t = 0; t < ntile; ++t) {
         const int cur = t & 1;
         if (t + 1 < ntile) fetch(t + 1);
-        Frag32 stream;
-        tile_frag(stream, tiles[cur], j, h);
+        FragQK stream;
+        load_fragqk(stream, tiles[cur] + j * SROW, h);
         f32x16 e = score_tile(stream, fixed);                    // lane (q,h) reg r: key 32t+chan_of(r,h)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) e[r] = exp_unit(e[r]);
-        // O^T[c][q] += V'T[c][k] E[k][q]: A operand lane (c,hA), step s = V'T[c][32t + chan_of(s,hA)]
-        const f32x16 vf = load_acc16(vts[cur] + j * VROW, h);
+        for (int r = 0; r < 16; ++r) e[r] = exp2_unit(e[r]);
+        const Split16 es = split16<false>(e);
+        // O^T[c][q] += V'[c][k] E[k][q]: A operand lane (c,kg), step s = keys chan_of(8s+e, kg)
+        const bf16x8 *vp = reinterpret_cast<const bf16x8 *>(vts[cur] + j * VROW) + h * 4;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) o = mfma(vf[s], e[s], o);
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 vh = vp[s], vl = vp[2 + s];
+            o = mfma16(vl, es.hi[s], o);
+            o = mfma16(vh, es.lo[s], o);
+            o = mfma16(vh, es.hi[s], o);
+        }
         if (t + 1 < ntile) {
             tile_store(tiles[cur ^ 1], tr);
-            *reinterpret_cast<f32x4 *>(vts[cur ^ 1] + vc * VROW + vk) = vreg;
+            if (threadIdx.x < 256) *reinterpret_cast<f32x4 *>(vts[cur ^ 1] + vc * VROW + vk) = vreg;
         }
         __syncthreads();
     }
@@ -349,20 +390,21 @@ FusionUnitDev unit_of(const vt_fusion_unit &u) {
 void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const float *blob, const FusionWs &w,
               float *out, int B, int N, hipStream_t s) {
     const int P = B * N, Npad = (N + 31) / 32 * 32;
-    const dim3 pg((P + 255) / 256), tg((N + 127) / 128, B);
+    const int ntile = (N + 31) / 32;
+    const dim3 pg((P + 255) / 256), tg((N + FROWS - 1) / FROWS, B);
     if (Xq == Xk) {
         hipLaunchKernelGGL((fusion_proj_kernel<true, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
     } else {
         hipLaunchKernelGGL((fusion_proj_kernel<true, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
         hipLaunchKernelGGL((fusion_proj_kernel<false, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
     }
-    hipLaunchKernelGGL(fusion_expsum_kernel, tg, dim3(256), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1);   // 1/l_q
-    hipLaunchKernelGGL(fusion_expsum_kernel, tg, dim3(256), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0);         // s_k
-    const size_t tot = (size_t)B * 32 * Npad;
+    hipLaunchKernelGGL(fusion_expsum_kernel, tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1);   // 1/l_q
+    hipLaunchKernelGGL(fusion_expsum_kernel, tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0);         // s_k
+    const size_t tot = (size_t)B * ntile * 128;                      // (b, tile, c, kg, k-step)
     size_t g = (tot + 255) / 256;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(fusion_scalev_kernel, dim3((unsigned)g), dim3(256), 0, s, w.V, w.s, w.VT, N, Npad, tot);
-    hipLaunchKernelGGL(fusion_attend_kernel, tg, dim3(256), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, Npad);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(fusion_scalev_kernel, dim3((unsigned)g), dim3(256), 0, s, w.V, w.s, w.VT, N, ntile, tot);
+    hipLaunchKernelGGL(fusion_attend_kernel, tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile);
     hipLaunchKernelGGL(fusion_inorm_relu_kernel, dim3(B), dim3(1024), 0, s, w.Z, out, N);
 }
 
