@@ -24,6 +24,8 @@ sys.path.insert(0, ROOT)
 FLOP_PER_POINT = 31488        # 30 976 (16 linear layers) + 512 (8 corners x 32 ch FMA)
 FLOP_PER_POINT_IMG = 33536    # with the tactile concat (forward_img)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
+KERNEL_OF = {"f32": "decode_fwd_staged_kernel<false>", "bf16x3": "decode_fwd_staged_kernel<true>"}
 
 
 def synthetic_scene(seed, device, R=64):
@@ -74,7 +76,7 @@ def mesh_extract_stats(vol, nx, runs=100):
             "note": "latency-dominated (5 launches + 1 sync readback); 8.4 MB volume = 1.3 us at HBM rate"}
 
 
-def stage_times(scene, dec, grid, nx, out, dev):
+def stage_times(scene, dec, grid, nx, out, dev, precision):
     """End-to-end stages for one scene (reported beside the metric, not part of it)."""
     def timed(fn, n=5):
         ts = []
@@ -91,32 +93,52 @@ def stage_times(scene, dec, grid, nx, out, dev):
         pc = scene["cloud"].to(dev)
         with torch.no_grad():
             res["encode_pointnet_unet3d"] = timed(lambda: model.encode_inputs(pc))
-    res["decode_lattice"] = timed(lambda: dec.decode_lattice(grid, nx, box=1.1, out=out))
+    res["decode_lattice"] = timed(lambda: dec.decode_lattice(grid, nx, box=1.1, out=out, precision=precision))
     from vtaco_amd import ops
     res["marching_cubes"] = timed(lambda: ops.marching_cubes(out.view(nx, nx, nx), None, rescale=(nx / 2, 1.1 / nx)))
     res["end_to_end"] = sum(res.values())
     if model.encoder is not None:
         from vtaco_amd.conv_onet.generation import Generator3D
-        gen = Generator3D(model, device=dev, resolution0=nx // 4, padding=0.1)
+        gen = Generator3D(model, device=dev, resolution0=nx // 4, padding=0.1, decode_precision=precision)
         gen.generate_mesh_graphed(pc)               # builds + captures
         res["end_to_end_hipgraph"] = timed(lambda: gen.generate_mesh_graphed(pc), 20)
     return res
 
 
-def measured_traffic():
+PMC_SUMMARY = os.path.join("profiles", "r01e_pmc_summary.csv")
+
+
+def measured_traffic(precision):
     """HBM-side bytes per decode launch from the committed PMC passes (profiles/, same command
     as this bench): (2 x FETCH_SIZE + WRITE_SIZE) KB -- the x2 is the guide's gfx950 correction
-    for 16-B-per-lane reads; None if no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01d_pmc_summary.csv")
+    for 16-B-per-lane reads; None if no profile is committed for this kernel."""
     try:
         vals = {}
-        for line in open(path).read().splitlines()[1:]:
+        for line in open(os.path.join(ROOT, PMC_SUMMARY)).read().splitlines()[1:]:
             k, c, n, mean = line.split(",")
-            if k == "decode_fwd_kernel":
+            if k == "decode_" + precision:
                 vals[c] = float(mean)
         return (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
     except Exception:
         return None
+
+
+def roofline_of(precision, flop_pt, npts, kern_ms):
+    """Roofline object of one decode kernel: algorithmic FLOP / HIP-event time against the dense
+    MFMA peak of the matrix-core input type it runs on."""
+    achieved = flop_pt * npts / (kern_ms * 1e-3) / 1e12
+    peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16x3" else PEAK_F32_MFMA_TFLOPS
+    r = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+         "traffic": measured_traffic(precision),
+         "traffic_note": "bytes/launch at the L2's memory side from rocprofv3 FETCH_SIZE/WRITE_SIZE passes "
+                         f"({PMC_SUMMARY}); algorithmic = 33.5 MB grid + 8.4 MB logits",
+         "kernel": KERNEL_OF[precision], "kernel_ms": kern_ms, "flop_per_point": flop_pt}
+    if precision == "bf16x3":
+        r["note"] = ("split-bf16: each f32 product = 3 bf16 MFMA products (lo*hi + hi*lo + hi*hi), so the matrix pipe "
+                     "executes ~3x the algorithmic FLOP; the kernel is VALU-issue-bound (PMC: VALU issue 55 %, "
+                     "matrix pipe 39 % busy), see DESIGN.md")
+        r["vs_f32_mfma_roofline"] = achieved / PEAK_F32_MFMA_TFLOPS     # SURVEY.md 8d's binding roofline for f32 results
+    return r
 
 
 def main():
@@ -180,7 +202,6 @@ def main():
 
     if rank == 0:
         flop_pt = FLOP_PER_POINT_IMG if args.mode == "img" else FLOP_PER_POINT
-        achieved = flop_pt * npts / (kern_ms * 1e-3) / 1e12
         res = {
             "metric": "occupancy query-points/sec at 128^3 (decode stage, lattice -> logits on device)",
             "value": world * npts * args.steps / wall,
@@ -188,21 +209,34 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * wall / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16x3" if args.precision == "bf16x3" else "f32", "data": "synthetic",
             "config": {"workload": f"visual-only PointNet encoder + LocalDecoder, {nx}^3 lattice, 1 scene/GPU, "
                                    f"R=64 c_dim=32 hidden=32 n_blocks=5, mode={args.mode}, random-init weights "
-                                   "(fc_1 re-randomised), f32 (exact-f32 MFMA; parity bar 1e-4)",
-                       "nx": nx, "points_per_step_per_gpu": npts, "mode": args.mode},
+                                   "(fc_1 re-randomised); f32 in / f32 out, dense layers on "
+                                   + ("the bf16 matrix core with split-bf16 (hi+lo) operands and f32 accumulation"
+                                      if args.precision == "bf16x3" else "the f32 matrix core")
+                                   + "; parity bar 1e-4 vs the f32 oracle",
+                       "nx": nx, "points_per_step_per_gpu": npts, "mode": args.mode, "precision": args.precision},
             "per_gpu": npts * args.steps / wall,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": measured_traffic(),
-                         "traffic_note": "bytes/launch at the L2's memory side from rocprofv3 FETCH_SIZE/WRITE_SIZE passes "
-                                         "(profiles/r01d_pmc_summary.csv); algorithmic = 33.5 MB grid + 8.4 MB logits",
-                         "kernel": "decode_fwd_kernel", "kernel_ms": kern_ms, "flop_per_point": flop_pt},
+            "roofline": roofline_of(args.precision, flop_pt, npts, kern_ms),
         }
+        if world == 1 and args.precision == "bf16x3":
+            # the exact-f32 kernel on the same inputs (what the training forward and precision="f32" run)
+            for _ in range(5):
+                dec.decode_lattice(grid, nx, box=1.1, c_img=c_img, out=out, precision="f32")
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(args.steps):
+                dec.decode_lattice(grid, nx, box=1.1, c_img=c_img, out=out, precision="f32")
+            ev1.record()
+            torch.cuda.synchronize()
+            ms32 = ev0.elapsed_time(ev1) / args.steps
+            res["exact_f32_kernel"] = {"value": npts / (ms32 * 1e-3), "unit": "query-points/s",
+                                       "roofline": roofline_of("f32", flop_pt, npts, ms32)}
+            step()                                                   # leave the bf16x3 logits in `out`
         if world == 1 and not args.decode_only:
             res["mesh_extract"] = mesh_extract_stats(out.view(nx, nx, nx), nx)
-            res["stages_ms"] = stage_times(scene, dec, grid, nx, out, dev)
+            res["stages_ms"] = stage_times(scene, dec, grid, nx, out, dev, args.precision)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(scene["sd_decoder_cpu"], scene["grid_cpu"], nx)
         print(json.dumps(res))

@@ -1,0 +1,20 @@
+# Collect the round's rocprofv3 evidence on the GPU box into gpurun_out/prof_$TAG (every run bounded by its own timeout;
+# --pmc passes carry no trace domain besides --kernel-trace; counter databases are summarised and deleted on the box:
+# gpurun copies back at most 64 MiB).  Usage: TAG=r01e bash tools/collect_profiles.sh
+cd /tmp && export TMPDIR=/tmp
+R=/root/repo
+TAG=${TAG:-r01e}
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_under_profiler.json 2> $O/stats.err; echo "stats rc=$?"
+find $O/stats -name '*kernel_trace*' -delete 2>/dev/null
+echo "kernel,counter,launches,mean_per_launch" > $O/pmc_summary.csv
+for P in bf16x3 f32; do
+  pmc(){ tag=$1; shift; d=$O/pmc_${P}_$tag; timeout 200 rocprofv3 --pmc "$@" --kernel-trace -d $d -o p -- python3 $R/bench.py --steps 10 --warmup 2 --decode-only --no-cpu-baseline --precision $P > /dev/null 2>&1; echo "pmc $P $tag rc=$?"; python3 $R/tools/pmc_summary.py decode_$P=$d | tail -n +2 >> $O/pmc_summary.csv; rm -rf $d; }
+  pmc fetch FETCH_SIZE
+  pmc write WRITE_SIZE
+  pmc sq GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES
+done
+timeout 300 python3 $R/bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+timeout 600 python3 $R/tools/bench_extra.py > $O/bench_extra.jsonl 2> $O/bench_extra.err; echo "extra rc=$?"
+du -sh $O
