@@ -1,5 +1,6 @@
 """Summarise rocprofv3 --pmc result databases as CSV rows `key,counter,launches,mean_per_launch`
-(a launch's value = the sum over the counter's hardware instances): pmc_summary.py key=dir [key=dir ...] [--kernel substr]"""
+(a launch's value = the sum over the counter's hardware instances):
+pmc_summary.py key=dir [key=dir ...] [--kernel pat1,pat2]   (SQL LIKE patterns without the outer %, any may match)"""
 import glob, sqlite3, sys
 kern = "decode_fwd"
 args = [a for a in sys.argv[1:] if "=" in a]
@@ -15,7 +16,7 @@ for a in args:
         disp = [t for t in tabs if 'kernel_dispatch' in t][0]; sym = [t for t in tabs if 'kernel_symbol' in t][0]
         q = f"""select i.name, d.id, sum(e.value) from {pmc} e join {info} i on e.pmc_id=i.id
                 join {disp} d on e.event_id=d.event_id join {sym} s on d.kernel_id=s.id
-                where s.kernel_name like '%{kern}%' group by 1,2"""
+                where {" or ".join(f"s.kernel_name like '%{k}%'" for k in kern.split(","))} group by 1,2"""
         acc = {}
         for name, did, v in c.execute(q):
             acc.setdefault(name, []).append(v)
