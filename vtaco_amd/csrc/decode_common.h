@@ -61,6 +61,8 @@ struct Split16 {
     bf16x8 hi[2], lo[2];
 };
 
+// (v - hi through v_dot2_f32_bf16 saves the expansion of hi back to f32 -- 6 instead of 8 instructions
+// per pair -- but measured no faster, and its result is not the exact difference: parity failed.)
 template <bool RELU>
 __device__ __forceinline__ Split16 split16(const f32x16 &x) {
     Split16 r;
