@@ -86,68 +86,90 @@ __device__ __forceinline__ f32x16 score_tile(const FragQK &stream, const FragQK 
     return acc;
 }
 
-// ---- projections: one thread per point ---------------------------------------------------
+// ---- projections on the f32 matrix core: one wave per 32 points -------------------------------
+// D[out][point] += W[out][k] X^T[k][point] for up to five 32-row groups (Q: 2, K: 2, V: 1).  The rows of
+// the Q/K groups are permuted so that registers 0..7 / 8..15 of lane-half h hold 8 consecutive
+// output columns (16(2g + r/8) + 8h + r%8): exactly one hi and one lo fragment of the split row
+// layout above, written with 16-byte stores.  V keeps the natural order (store_acc16).
 template <bool DO_Q, bool DO_KV>
 __global__ void __launch_bounds__(256)
 fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd, float *Kd, float *V, int total) {
-    __shared__ float w[64 * 32 * 2 + 32 * 32];
-    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
-        if (DO_Q) w[i] = u.WQ[i];
-        if (DO_KV) w[2048 + i] = u.WK[i];
+    __shared__ __attribute__((aligned(16))) float wf[5][16][64];          // [group][k-step][lane] A fragments
+    for (int e = threadIdx.x; e < 5 * 1024; e += 256) {
+        const int g = e >> 10, st = (e >> 6) & 15, l = e & 63, i = l & 31, kk = l >> 5, k = 2 * st + kk;
+        // output row i of the MFMA <-> accumulator register r of lane-half hh with chan_of(r,hh) == i
+        const int hh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3);
+        float v = 0.0f;
+        if (g < 4) {
+            const int gg = g & 1, col = 16 * (2 * gg + (r >> 3)) + 8 * hh + (r & 7);
+            if (g < 2 ? DO_Q : DO_KV) v = (g < 2 ? u.WQ : u.WK)[col * 32 + k];
+        } else if (DO_KV) {
+            v = u.WV[i * 32 + k];
+        }
+        wf[g][st][l] = v;
     }
-    if (DO_KV) for (int i = threadIdx.x; i < 32 * 32; i += 256) w[4096 + i] = u.WV[i];
     __syncthreads();
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= total) return;
-    auto project64 = [&](const float *x, const float *W, float *dst, float post) {
-        float out[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int p0 = (blockIdx.x * 4 + wave) * 32;
+    if (p0 >= total) return;
+    const int p = min(p0 + j, total - 1);
+    const bool live = p0 + j < total;
+    auto load_x = [&](const float *X, float (&x)[16]) {                       // x[s] = X[p][2s + h]
+        const f32x4 *r = reinterpret_cast<const f32x4 *>(X + (size_t)p * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 t = r[i];
+            x[2 * i] = h ? t.y : t.x;
+            x[2 * i + 1] = h ? t.w : t.z;
+        }
+    };
+    auto project = [&](const float (&x)[16], int g) {
+        f32x16 acc;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc[s] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = mfma(wf[g][s][lane], x[s], acc);
+        return acc;
+    };
+    auto store_unit = [&](const f32x16 &a0, const f32x16 &a1, float *dst, float post) {
         float ss = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            float a = 0.0f;
+        for (int s = 0; s < 16; ++s) { ss = fmaf(a0[s], a0[s], ss); ss = fmaf(a1[s], a1[s], ss); }
+        ss += __shfl_xor(ss, 32);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);                     // F.normalize(p=2, eps=1e-12)
+        if (!live) return;
+        bf16x8 *row = reinterpret_cast<bf16x8 *>(dst + (size_t)p * 64);          // 16 fragments of 8 bf16
 #pragma unroll
-            for (int k = 0; k < 32; ++k) a = fmaf(x[k], W[j * 32 + k], a);
-            out[j] = a;
-            ss = fmaf(a, a, ss);
-        }
-        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);      // F.normalize(p=2, eps=1e-12)
-        bf16x8 *row = reinterpret_cast<bf16x8 *>(dst);           // 16 fragments of 8 bf16
+        for (int g = 0; g < 2; ++g) {
+            const f32x16 &a = g ? a1 : a0;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-#pragma unroll
-            for (int kg = 0; kg < 2; ++kg) {
+            for (int half = 0; half < 2; ++half) {
                 bf16x8 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float v = (out[16 * t + 8 * kg + e] * inv) * post;
+                    const float v = (a[8 * half + e] * inv) * post;
                     const __bf16 hb = (__bf16)v;
                     hi[e] = hb;
                     lo[e] = (__bf16)(v - (float)hb);
                 }
-                row[(kg * 2 + 0) * 4 + t] = hi;
-                row[(kg * 2 + 1) * 4 + t] = lo;
+                const int t = 2 * g + half;
+                row[(h * 2 + 0) * 4 + t] = hi;
+                row[(h * 2 + 1) * 4 + t] = lo;
             }
         }
     };
-    float x[32];
+    float x[16];
     if (DO_Q) {
-        const f32x4 *r = reinterpret_cast<const f32x4 *>(Xq + (size_t)p * 32);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { const f32x4 t = r[i]; x[4 * i] = t.x; x[4 * i + 1] = t.y; x[4 * i + 2] = t.z; x[4 * i + 3] = t.w; }
-        project64(x, w, Qd + (size_t)p * 64, 1.44269504088896341f);
+        load_x(Xq, x);
+        const f32x16 q0 = project(x, 0), q1 = project(x, 1);
+        store_unit(q0, q1, Qd, 1.44269504088896341f);
     }
     if (DO_KV) {
-        const f32x4 *r = reinterpret_cast<const f32x4 *>(Xk + (size_t)p * 32);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { const f32x4 t = r[i]; x[4 * i] = t.x; x[4 * i + 1] = t.y; x[4 * i + 2] = t.z; x[4 * i + 3] = t.w; }
-        project64(x, w + 2048, Kd + (size_t)p * 64, 1.0f);
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            float a = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 32; ++k) a = fmaf(x[k], w[4096 + j * 32 + k], a);
-            V[(size_t)p * 32 + j] = a;
-        }
+        if (!DO_Q || Xk != Xq) load_x(Xk, x);
+        const f32x16 k0 = project(x, 2), k1 = project(x, 3);
+        store_unit(k0, k1, Kd, 1.0f);
+        const f32x16 v = project(x, 4);
+        if (live) store_acc16(V + (size_t)p * 32, v, h);
     }
 }
 
@@ -391,7 +413,7 @@ void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const fl
               float *out, int B, int N, hipStream_t s) {
     const int P = B * N, Npad = (N + 31) / 32 * 32;
     const int ntile = (N + 31) / 32;
-    const dim3 pg((P + 255) / 256), tg((N + FROWS - 1) / FROWS, B);
+    const dim3 pg((P + 127) / 128), tg((N + FROWS - 1) / FROWS, B);
     if (Xq == Xk) {
         hipLaunchKernelGGL((fusion_proj_kernel<true, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
     } else {
