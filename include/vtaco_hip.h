@@ -302,6 +302,8 @@ typedef struct vt_unet3d_conv {
     const float *gn_b;    /* groupnorm.bias   [cin] */
     const float *packed;  /* vt_conv3d_pack(conv.weight [cout,cin,3,3,3]) */
     int32_t cin, cout;
+    const float *packed_bf16x3;  /* vt_conv3d_pack_bf16x3(conv.weight) or NULL: run this conv on the bf16 matrix core with */
+                                 /* split-bf16 operands where vt_conv3d_stat_blocks_bf16x3(...) != 0, exact f32 elsewhere */
 } vt_unet3d_conv;
 typedef struct vt_unet3d_params {
     int32_t n_levels;     /* len(f_maps) */
@@ -313,6 +315,16 @@ typedef struct vt_unet3d_params {
     const float *final_b; /* final_conv.bias or NULL */
     int32_t out_channels;
 } vt_unet3d_params;
+/* Split-bf16 form of vt_conv3d_pack / vt_conv3d_stat_blocks / vt_conv3d_gcr (same arguments): the 3x3x3 convolution  */
+/* as W_lo*x_hi + W_hi*x_lo + W_hi*x_hi on the bf16 matrix core with f32 accumulation (hi = bf16(v), lo = bf16(v - hi));  */
+/* GroupNorm, ReLU and the output statistics stay f32.  Covers volumes made of whole 8^3 tiles that fill the chip        */
+/* (stat_blocks returns 0 and gcr VT_ERR_UNSUPPORTED otherwise: use the f32 form).  6.6e-5 abs on the UNet3D golden       */
+/* (scale 2.4), 4e-5 on the logits decoded from the resulting grid.                                                       */
+int vt_conv3d_pack_bf16x3(const float *w, int Cout, int Cin, float *packed, void *stream);
+int vt_conv3d_stat_blocks_bf16x3(int B, int D, int H, int W, int Cin, int Cout);
+int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                         const float *scale_shift, const float *packed_w_bf16x3, int Cout, int relu, float *out,
+                         float *out_part, void *stream);
 size_t vt_unet3d_workspace_bytes(int B, int R, const vt_unet3d_params *params_host);
 int vt_unet3d_fwd(const float *x_cl, int B, int R, const vt_unet3d_params *params_host,
                   void *workspace, size_t workspace_bytes, float *out, void *stream);

@@ -56,7 +56,7 @@ VT_UNET_MAX_LEVELS = 6
 class UnetConv(ctypes.Structure):
     """Mirror of ``vt_unet3d_conv``."""
     _fields_ = [("gn_w", ctypes.c_void_p), ("gn_b", ctypes.c_void_p), ("packed", ctypes.c_void_p),
-                ("cin", ctypes.c_int32), ("cout", ctypes.c_int32)]
+                ("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("packed_bf16x3", ctypes.c_void_p)]
 
 
 class UnetParams(ctypes.Structure):
@@ -106,6 +106,9 @@ SIGNATURES = {
     "vt_conv3d_pack": (_I, [_VP, _I, _I, _VP, _VP]),
     "vt_stats_floats": (_SZ, [_I, _I, _I, _I, _I]),
     "vt_conv3d_stat_blocks": (_I, [_I, _I, _I, _I, _I, _I]),
+    "vt_conv3d_pack_bf16x3": (_I, [_VP, _I, _I, _VP, _VP]),
+    "vt_conv3d_stat_blocks_bf16x3": (_I, [_I, _I, _I, _I, _I, _I]),
+    "vt_conv3d_gcr_bf16x3": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),
     "vt_channel_stats": (_I, [_VP, _I, _I64, _I, _I, _VP, _VP]),
     "vt_gn_scale_shift": (_I, [_VP, _I, _I, _VP, _I, _I, _I, _I64, _I, _VP, _VP, _D, _VP, _VP]),
     "vt_conv3d_gcr": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),

@@ -326,6 +326,185 @@ conv3d_gcr_ksplit_kernel(ConvArgs a) {
     }
 }
 
+// ---- split-bf16 variant of the 'gcr' conv for the large volumes ---------------------------------
+// Same implicit GEMM, on the bf16 matrix core with split operands (decode_common.h): the normalised
+// input is split into hi/lo bf16 ONCE while it is staged (16 channels at a time: an 80-byte LDS row
+// per voxel = 16 hi + 16 lo + pad), the weights once at pack time, and every 16-channel tap is
+// W_lo x_hi + W_hi x_lo + W_hi x_hi = 3 x v_mfma_f32_32x32x16_bf16 per 32 voxels x 32 couts
+// (96 matrix cycles against 8 x 64 on the f32 core).  A workgroup (8 waves) owns an 8 x 8 x 8 output
+// tile; wave w owns z-plane w as two 4 x 8 voxel patches that share every weight fragment (weights
+// come straight from L1/L2 in fragment order: half the traffic per MFMA of one patch per wave).
+// The halo rows are pitched 12 in x: with 4 x 8 patches the 16 lanes of every ds_read_b128 group
+// then fall on 16 distinct bank groups.  The next 16 channels are fetched into registers before
+// the 27 taps run, so the global latency hides behind the matrix work.
+constexpr int SB_ROW = 80;
+constexpr int SB_PX = 12;
+constexpr int SB_ROWS = 10 * 10 * SB_PX;
+constexpr int SB_ITERS = 8;                       // ceil(1000 voxels * 4 threads / 512 threads)
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// weights -> [cin/16][tap][cout/32][hi,lo][64 lanes][8 bf16]: lane (co, kg) element e = cin 16q + 8kg + e
+__global__ void conv3d_pack_s_kernel(const float *w, int Cout, int Cin, float *packed, size_t total) {
+    // one thread per 16-byte fragment
+    for (size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(f & 63), part = (int)((f >> 6) & 1);
+        size_t r = f >> 7;
+        const int nco = Cout / 32;
+        const int cob = (int)(r % nco); r /= nco;
+        const int tap = (int)(r % 27);
+        const int q = (int)(r / 27);
+        const int co = cob * 32 + (l & 31), kg = l >> 5;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = w[((size_t)co * Cin + 16 * q + 8 * kg + e) * 27 + tap];
+            const __bf16 hb = (__bf16)x;
+            v[e] = part ? (__bf16)(x - (float)hb) : hb;
+        }
+        reinterpret_cast<bf16x8 *>(packed)[f] = v;
+    }
+}
+
+template <int NCO>
+__global__ void __launch_bounds__(512)
+conv3d_gcr_s_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char stile[];    // SB_ROWS x SB_ROW, then stats scratch
+    const Src &s = a.s;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, kg = lane >> 5;
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y; t /= a.tiles_y;
+    const int tz = t % a.tiles_z;
+    const int b = t / a.tiles_z;
+    const int x0 = tx * 8, y0 = ty * 8, z0 = tz * 8;
+    const int Cin = s.C1 + s.C2, ncq = Cin / 16;
+    const int co_blk0 = blockIdx.y * NCO, nco_all = a.Cout / 32;
+    const int lx = j & 3, ly = j >> 2;
+    const int center = ((wave + 1) * 10 + (ly + 1)) * SB_PX + (lx + 1);   // patch 0; patch 1 is 4 rows further in x
+
+    // ---- staging: thread -> (voxel, 4 of the 16 channels), SB_ITERS voxels per thread ----
+    const int sc4 = (threadIdx.x & 3) * 4;
+    const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
+    f32x4 pre[SB_ITERS];
+    auto fetch = [&](int q) {
+        const int ch = q * 16 + sc4;
+        const bool from_low = ch >= s.C1;
+#pragma unroll
+        for (int it = 0; it < SB_ITERS; ++it) {
+            const int v = (threadIdx.x >> 2) + it * 128;
+            const int px = v % 10, r2 = v / 10, py = r2 % 10, pz = r2 / 10;
+            const int gx = x0 + px - 1, gy = y0 + py - 1, gz = z0 + pz - 1;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (v < 1000 && gx >= 0 && gx < s.W && gy >= 0 && gy < s.H && gz >= 0 && gz < s.D) {
+                const float *src = from_low
+                    ? s.low + ((((size_t)b * D2 + (gz >> 1)) * H2 + (gy >> 1)) * W2 + (gx >> 1)) * s.C2 + (ch - s.C1)
+                    : s.skip + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * s.C1 + ch;
+                val = *reinterpret_cast<const f32x4 *>(src);
+            }
+            pre[it] = val;
+        }
+    };
+    auto commit = [&](int q) {                     // GroupNorm affine (zero padding AFTER the norm), split, LDS
+        const int ch = q * 16 + sc4;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (a.scale_shift) {
+            const float *ss = a.scale_shift + ((size_t)b * Cin + ch) * 2;
+            sc = f32x4{ss[0], ss[2], ss[4], ss[6]}; sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
+        }
+#pragma unroll
+        for (int it = 0; it < SB_ITERS; ++it) {
+            const int v = (threadIdx.x >> 2) + it * 128;
+            if (v >= 1000) continue;
+            const int px = v % 10, r2 = v / 10, py = r2 % 10, pz = r2 / 10;
+            const int gx = x0 + px - 1, gy = y0 + py - 1, gz = z0 + pz - 1;
+            const bool in = gx >= 0 && gx < s.W && gy >= 0 && gy < s.H && gz >= 0 && gz < s.D;
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = in ? fmaf(pre[it][e], sc[e], sh[e]) : 0.0f;
+                const __bf16 hb = (__bf16)x;
+                hi[e] = hb;
+                lo[e] = (__bf16)(x - (float)hb);
+            }
+            char *row = stile + ((pz * 10 + py) * SB_PX + px) * SB_ROW + sc4 * 2;
+            *reinterpret_cast<bf16x4 *>(row) = hi;
+            *reinterpret_cast<bf16x4 *>(row + 32) = lo;
+        }
+    };
+
+    f32x16 acc[2][NCO];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int n = 0; n < NCO; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][n][r] = 0.0f;
+
+    fetch(0);
+    for (int q = 0; q < ncq; ++q) {
+        __syncthreads();                                           // the previous taps are done with the tile
+        commit(q);
+        __syncthreads();
+        if (q + 1 < ncq) fetch(q + 1);
+        const bf16x8 *wq = reinterpret_cast<const bf16x8 *>(a.wp) + ((size_t)q * 27 * nco_all + co_blk0) * 128 + lane;
+        bf16x8 wn[NCO][2];
+#pragma unroll
+        for (int n = 0; n < NCO; ++n) { wn[n][0] = wq[n * 128]; wn[n][1] = wq[n * 128 + 64]; }
+#pragma unroll 1
+        for (int tap = 0; tap < 27; ++tap) {
+            bf16x8 wc[NCO][2];
+#pragma unroll
+            for (int n = 0; n < NCO; ++n) { wc[n][0] = wn[n][0]; wc[n][1] = wn[n][1]; }
+            if (tap < 26) {
+                const bf16x8 *wt = wq + (size_t)(tap + 1) * nco_all * 128;
+#pragma unroll
+                for (int n = 0; n < NCO; ++n) { wn[n][0] = wt[n * 128]; wn[n][1] = wt[n * 128 + 64]; }
+            }
+            const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+            const char *xin = stile + (center + (dz * 10 + dy) * SB_PX + dx) * SB_ROW + kg * 16;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(xin + g * 4 * SB_ROW);
+                const bf16x8 xl = *reinterpret_cast<const bf16x8 *>(xin + g * 4 * SB_ROW + 32);
+#pragma unroll
+                for (int n = 0; n < NCO; ++n) {
+                    acc[g][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[n][1], xh, acc[g][n], 0, 0, 0);
+                    acc[g][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[n][0], xl, acc[g][n], 0, 0, 0);
+                    acc[g][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[n][0], xh, acc[g][n], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // epilogue: as conv3d_gcr_kernel (lane = voxel, 16 registers = channels chan_of(r,kg))
+    __syncthreads();
+    float *sred = reinterpret_cast<float *>(stile);               // [8 waves][2 patches][NCO*32][2]
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int gx = x0 + lx + 4 * g, gy = y0 + ly, gz = z0 + wave;
+        const bool valid = gx < s.W && gy < s.H && gz < s.D;
+        float *orow = a.out + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.Cout;
+#pragma unroll
+        for (int n = 0; n < NCO; ++n) {
+            f32x16 v = acc[g][n];
+            if (a.relu) v = relu16(v);
+            if (valid) store_acc16(orow + (co_blk0 + n) * 32, v, kg);
+            if (a.part) wave_stats(v, valid, j, kg, sred + ((wave * 2 + g) * NCO + n) * 64);
+        }
+    }
+    if (a.part) {
+        __syncthreads();
+        const int nsp = a.tiles_x * a.tiles_y * a.tiles_z;
+        const int spatial = blockIdx.x % nsp;
+        for (int e = threadIdx.x; e < NCO * 32 * 2; e += 512) {
+            float tsum = 0.0f;
+            for (int w = 0; w < 16; ++w) tsum += sred[w * NCO * 64 + e];
+            const int n = e >> 6, c2 = e & 63;                    // c2 = channel*2 + {sum,sq}
+            a.part[(((size_t)b * nsp + spatial) * a.Cout + (co_blk0 + n) * 32) * 2 + c2] = tsum;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 maxpool3d_cl_kernel(const float *x, float *out, int D, int H, int W, int C, size_t total) {
     const int D2 = D / 2, H2 = H / 2, W2 = W / 2;
@@ -421,6 +600,13 @@ static int conv_waves(int B, int D, int H, int W, int nco) {
         if ((size_t)conv_tile(D, H, W, waves, TX, TY, TZ) * B * nco >= 512) return waves;
     }
     return 1;
+}
+
+// split-bf16 kernel: whole 8^3 tiles, 32-channel multiples, and enough workgroups to fill the chip
+static int conv_s_nco(int Cout) { return (Cout % 64 == 0) ? 2 : 1; }
+static bool conv_s_eligible(int B, int D, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || ((D | H | W) & 7) || Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 31)) return false;
+    return (size_t)(D / 8) * (H / 8) * (W / 8) * B * (Cout / 32 / conv_s_nco(Cout)) >= 256;
 }
 
 template <int NCO, int WAVES>
@@ -546,6 +732,46 @@ int vt_conv3d_gcr(const float *skip, int C1, const float *low, int C2, int B, in
     return vt_check(hipGetLastError(), "vt_conv3d_gcr");
 }
 
+int vt_conv3d_pack_bf16x3(const float *w, int Cout, int Cin, float *packed, void *stream) {
+    if (!w || !packed) return vt_fail(VT_ERR_INVALID, "vt_conv3d_pack_bf16x3: null argument");
+    if (!vt_conv3d_packed_floats(Cout, Cin)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_pack_bf16x3: channel counts must be multiples of 32");
+    const size_t frags = (size_t)27 * Cout * Cin / 4;              // 16-byte fragments: hi and lo of every 8 cin
+    size_t g = (frags + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(conv3d_pack_s_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, packed, frags);
+    return vt_check(hipGetLastError(), "vt_conv3d_pack_bf16x3");
+}
+
+int vt_conv3d_stat_blocks_bf16x3(int B, int D, int H, int W, int Cin, int Cout) {
+    return conv_s_eligible(B, D, H, W, Cin, Cout) ? (D / 8) * (H / 8) * (W / 8) : 0;
+}
+
+int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                         const float *scale_shift, const float *packed_w_bf16x3, int Cout, int relu, float *out,
+                         float *out_part, void *stream) {
+    ConvArgs a;
+    a.s = Src{skip, low, C1, low ? C2 : 0, D, H, W};
+    if (!src_ok(a.s, B) || !packed_w_bf16x3 || !out) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr_bf16x3: bad argument");
+    if (!conv_s_eligible(B, D, H, W, a.s.C1 + a.s.C2, Cout))
+        return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr_bf16x3: shape not covered (see vt_conv3d_stat_blocks_bf16x3); use vt_conv3d_gcr");
+    a.scale_shift = scale_shift; a.wp = packed_w_bf16x3; a.out = out; a.part = out_part; a.Cout = Cout; a.relu = relu;
+    a.TX = a.TY = a.TZ = 8;
+    a.tiles_x = W / 8; a.tiles_y = H / 8; a.tiles_z = D / 8;
+    const int per = conv_s_nco(Cout);
+    const dim3 grid((unsigned)((size_t)a.tiles_x * a.tiles_y * a.tiles_z * B), (unsigned)(Cout / 32 / per));
+    const size_t lds = (size_t)SB_ROWS * SB_ROW;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_bf16x3: hipFuncSetAttribute");
+        attr = true;
+    }
+    if (per == 2) hipLaunchKernelGGL(conv3d_gcr_s_kernel<2>, grid, dim3(512), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv3d_gcr_s_kernel<1>, grid, dim3(512), lds, (hipStream_t)stream, a);
+    return vt_check(hipGetLastError(), "vt_conv3d_gcr_bf16x3");
+}
+
 int vt_maxpool3d_cl(const float *x, int B, int D, int H, int W, int C, float *out, void *stream) {
     if (!x || !out || B <= 0 || C <= 0 || D < 2 || H < 2 || W < 2) return vt_fail(VT_ERR_INVALID, "vt_maxpool3d_cl: bad argument");
     const size_t total = (size_t)B * (D / 2) * (H / 2) * (W / 2) * C;
@@ -623,13 +849,16 @@ int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char 
         if (a.C + C2 != c.cin) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: channel mismatch between levels");
         o.C = c.cout;
         o.x = ws.take((size_t)B * Ri * Ri * Ri * c.cout);
-        o.nblk = vt_conv3d_stat_blocks(B, Ri, Ri, Ri, c.cin, c.cout);
+        const bool split = c.packed_bf16x3 && conv_s_eligible(B, Ri, Ri, Ri, c.cin, c.cout);
+        o.nblk = split ? vt_conv3d_stat_blocks_bf16x3(B, Ri, Ri, Ri, c.cin, c.cout) : vt_conv3d_stat_blocks(B, Ri, Ri, Ri, c.cin, c.cout);
         o.part = ws.take((size_t)B * o.nblk * c.cout * 2);
         if (plan) return 0;
         const int groups = (c.cin >= p->groups) ? p->groups : 1;
         int rc = vt_gn_scale_shift(a.part, a.nblk, a.C, low ? low->part : nullptr, low ? low->nblk : 0, C2, B,
                                    (int64_t)Ri * Ri * Ri, groups, c.gn_w, c.gn_b, p->eps, ss, st);
         if (rc) return rc;
+        if (split)
+            return vt_conv3d_gcr_bf16x3(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed_bf16x3, c.cout, 1, o.x, o.part, st);
         return vt_conv3d_gcr(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed, c.cout, 1, o.x, o.part, st);
     };
     Tensor skips[VT_UNET_MAX_LEVELS];

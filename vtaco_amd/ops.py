@@ -468,15 +468,22 @@ def voxel_scatter_mean_cl_bwd(grad_grid_cl, vi, C):
     return g
 
 
-def conv3d_pack(weight):
+def conv3d_pack(weight, precision="f32"):
+    """Fragment-ordered copy of a [Cout,Cin,3,3,3] conv weight: f32 (vt_conv3d_pack) or split-bf16
+    hi/lo fragments (vt_conv3d_pack_bf16x3); the two blobs have the same size."""
     lib = _lib.load()
     Cout, Cin = weight.shape[0], weight.shape[1]
     n = lib.vt_conv3d_packed_floats(Cout, Cin)
     if n == 0 or tuple(weight.shape[2:]) != (3, 3, 3):
         raise VtError(f"conv3d_pack: unsupported weight shape {tuple(weight.shape)}")
+    if precision not in PRECISIONS:
+        raise VtError(f"precision must be one of {PRECISIONS} (got {precision!r})")
     w = _c(weight)
     out = torch.empty(n, dtype=torch.float32, device=w.device)
-    check(lib.vt_conv3d_pack(dev_ptr(w, "w"), Cout, Cin, dev_ptr(out, "packed"), stream_ptr()), "vt_conv3d_pack")
+    if precision == "bf16x3":
+        check(lib.vt_conv3d_pack_bf16x3(dev_ptr(w, "w"), Cout, Cin, dev_ptr(out, "packed"), stream_ptr()), "vt_conv3d_pack_bf16x3")
+    else:
+        check(lib.vt_conv3d_pack(dev_ptr(w, "w"), Cout, Cin, dev_ptr(out, "packed"), stream_ptr()), "vt_conv3d_pack")
     return out
 
 
@@ -490,9 +497,11 @@ def channel_stats(x):
     return part, nblk
 
 
-def gn_conv3d_relu(x, x_stats, low, low_stats, gamma, beta, groups, packed_w, Cout, eps=1e-5, relu=True):
+def gn_conv3d_relu(x, x_stats, low, low_stats, gamma, beta, groups, packed_w, Cout, eps=1e-5, relu=True,
+                   packed_w_bf16x3=None):
     """relu(conv3x3x3(GroupNorm([x | upsample(low)]))) on channels-last tensors; the statistics
-    come from the producers' partial sums.  Returns (out, out_stats)."""
+    come from the producers' partial sums.  Returns (out, out_stats).  With ``packed_w_bf16x3`` the
+    convolution runs on the bf16 matrix core with split-bf16 operands where that kernel covers the shape."""
     lib = _lib.load()
     B, D, H, W, C1 = x.shape
     C2 = low.shape[-1] if low is not None else 0
@@ -504,6 +513,13 @@ def gn_conv3d_relu(x, x_stats, low, low_stats, gamma, beta, groups, packed_w, Co
                                 groups, dev_ptr(_c(gamma), "gamma"), dev_ptr(_c(beta), "beta"), float(eps),
                                 dev_ptr(ss, "scale_shift"), st), "vt_gn_scale_shift")
     out = torch.empty((B, D, H, W, Cout), dtype=torch.float32, device=dev)
+    nblk = lib.vt_conv3d_stat_blocks_bf16x3(B, D, H, W, C1 + C2, Cout) if packed_w_bf16x3 is not None else 0
+    if nblk:
+        part = torch.empty((B, nblk, Cout, 2), dtype=torch.float32, device=dev)
+        check(lib.vt_conv3d_gcr_bf16x3(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
+                                       dev_ptr(packed_w_bf16x3, "packed_w"), Cout, int(relu), dev_ptr(out, "out"),
+                                       dev_ptr(part, "part"), st), "vt_conv3d_gcr_bf16x3")
+        return out, (part, nblk)
     nblk = lib.vt_conv3d_stat_blocks(B, D, H, W, C1 + C2, Cout)
     part = torch.empty((B, nblk, Cout, 2), dtype=torch.float32, device=dev)
     check(lib.vt_conv3d_gcr(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
