@@ -331,16 +331,17 @@ conv3d_gcr_ksplit_kernel(ConvArgs a) {
 // input is split into hi/lo bf16 ONCE while it is staged (16 channels at a time: an 80-byte LDS row
 // per voxel = 16 hi + 16 lo + pad), the weights once at pack time, and every 16-channel tap is
 // W_lo x_hi + W_hi x_lo + W_hi x_hi = 3 x v_mfma_f32_32x32x16_bf16 per 32 voxels x 32 couts
-// (96 matrix cycles against 8 x 64 on the f32 core).  A workgroup (8 waves) owns an 8 x 8 x 8 output
-// tile; wave w owns z-plane w as two 4 x 8 voxel patches that share every weight fragment (weights
-// come straight from L1/L2 in fragment order: half the traffic per MFMA of one patch per wave).
+// (96 matrix cycles against 8 x 64 on the f32 core).  A workgroup (16 waves) owns an 8 x 8 x 8 output
+// tile; each wave owns one 4 x 8 voxel patch of one z-plane; the 27 taps' weight fragments of the
+// current 16 channels sit in LDS next to the input tile (54 KB).
 // The halo rows are pitched 12 in x: with 4 x 8 patches the 16 lanes of every ds_read_b128 group
-// then fall on 16 distinct bank groups.  The next 16 channels are fetched into registers before
-// the 27 taps run, so the global latency hides behind the matrix work.
+// then fall on 16 distinct bank groups.  The next 16 channels (input and weights) are fetched into
+// registers before the 27 taps run, so the global latency hides behind the matrix work.
 constexpr int SB_ROW = 80;
 constexpr int SB_PX = 12;
 constexpr int SB_ROWS = 10 * 10 * SB_PX;
-constexpr int SB_ITERS = 8;                       // ceil(1000 voxels * 4 threads / 512 threads)
+constexpr int SB_THREADS = 1024;                  // 16 waves: wave w owns z-plane w/2, x-half w%2 (one 4 x 8 patch)
+constexpr int SB_ITERS = 4;                       // ceil(1000 voxels * 4 threads / 1024 threads)
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // weights -> [cin/16][tap][cout/32][hi,lo][64 lanes][8 bf16]: lane (co, kg) element e = cin 16q + 8kg + e
@@ -365,10 +366,13 @@ __global__ void conv3d_pack_s_kernel(const float *w, int Cout, int Cin, float *p
     }
 }
 
-template <int NCO>
-__global__ void __launch_bounds__(512)
+constexpr int SB_WFRAGS = 27 * 128;               // one (16-channel block, cout block)'s weight fragments: 27 taps x (hi, lo) x 64 lanes
+constexpr int SB_WITERS = (SB_WFRAGS + SB_THREADS - 1) / SB_THREADS;
+constexpr size_t SB_LDS = (size_t)SB_ROWS * SB_ROW + (size_t)SB_WFRAGS * 16;
+
+__global__ void __launch_bounds__(SB_THREADS)
 conv3d_gcr_s_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char stile[];    // SB_ROWS x SB_ROW, then stats scratch
+    extern __shared__ __attribute__((aligned(16))) char stile[];    // [SB_ROWS x SB_ROW input][27 x 2 KB weights]; then stats scratch
     const Src &s = a.s;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, kg = lane >> 5;
@@ -379,30 +383,47 @@ conv3d_gcr_s_kernel(ConvArgs a) {
     const int b = t / a.tiles_z;
     const int x0 = tx * 8, y0 = ty * 8, z0 = tz * 8;
     const int Cin = s.C1 + s.C2, ncq = Cin / 16;
-    const int co_blk0 = blockIdx.y * NCO, nco_all = a.Cout / 32;
+    const int co_blk = blockIdx.y, nco_all = a.Cout / 32;
     const int lx = j & 3, ly = j >> 2;
-    const int center = ((wave + 1) * 10 + (ly + 1)) * SB_PX + (lx + 1);   // patch 0; patch 1 is 4 rows further in x
+    const int wz = wave >> 1, wx = (wave & 1) * 4;
+    const int center = ((wz + 1) * 10 + (ly + 1)) * SB_PX + (lx + wx + 1);
+    bf16x8 *wlds = reinterpret_cast<bf16x8 *>(stile + (size_t)SB_ROWS * SB_ROW);
 
-    // ---- staging: thread -> (voxel, 4 of the 16 channels), SB_ITERS voxels per thread ----
+    // ---- staging plan (the same for every channel block): thread -> (voxel, 4 of the 16 channels) ----
     const int sc4 = (threadIdx.x & 3) * 4;
     const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
+    int vskip[SB_ITERS], vlow[SB_ITERS], lrow[SB_ITERS];
+    unsigned inside = 0;
+#pragma unroll
+    for (int it = 0; it < SB_ITERS; ++it) {
+        const int v = (threadIdx.x >> 2) + it * (SB_THREADS / 4);
+        const int px = v % 10, r2 = v / 10, py = r2 % 10, pz = r2 / 10;
+        const int gx = x0 + px - 1, gy = y0 + py - 1, gz = z0 + pz - 1;
+        const bool in = v < 1000 && gx >= 0 && gx < s.W && gy >= 0 && gy < s.H && gz >= 0 && gz < s.D;
+        vskip[it] = in ? ((b * s.D + gz) * s.H + gy) * s.W + gx : 0;
+        vlow[it] = in ? ((b * D2 + (gz >> 1)) * H2 + (gy >> 1)) * W2 + (gx >> 1) : 0;
+        lrow[it] = v < 1000 ? ((pz * 10 + py) * SB_PX + px) * SB_ROW + sc4 * 2 : -1;
+        if (in) inside |= 1u << it;
+    }
     f32x4 pre[SB_ITERS];
-    auto fetch = [&](int q) {
+    bf16x8 wpre[SB_WITERS];
+    auto fetch = [&](int q) {                      // next 16 input channels and their 27 taps of weights -> registers
         const int ch = q * 16 + sc4;
         const bool from_low = ch >= s.C1;
 #pragma unroll
         for (int it = 0; it < SB_ITERS; ++it) {
-            const int v = (threadIdx.x >> 2) + it * 128;
-            const int px = v % 10, r2 = v / 10, py = r2 % 10, pz = r2 / 10;
-            const int gx = x0 + px - 1, gy = y0 + py - 1, gz = z0 + pz - 1;
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (v < 1000 && gx >= 0 && gx < s.W && gy >= 0 && gy < s.H && gz >= 0 && gz < s.D) {
-                const float *src = from_low
-                    ? s.low + ((((size_t)b * D2 + (gz >> 1)) * H2 + (gy >> 1)) * W2 + (gx >> 1)) * s.C2 + (ch - s.C1)
-                    : s.skip + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * s.C1 + ch;
+            if (inside >> it & 1u) {
+                const float *src = from_low ? s.low + (size_t)vlow[it] * s.C2 + (ch - s.C1) : s.skip + (size_t)vskip[it] * s.C1 + ch;
                 val = *reinterpret_cast<const f32x4 *>(src);
             }
             pre[it] = val;
+        }
+        const bf16x8 *wq = reinterpret_cast<const bf16x8 *>(a.wp) + ((size_t)q * 27 * nco_all + co_blk) * 128;
+#pragma unroll
+        for (int it = 0; it < SB_WITERS; ++it) {
+            const int f = threadIdx.x + it * SB_THREADS;
+            if (f < SB_WFRAGS) wpre[it] = wq[(size_t)(f >> 7) * nco_all * 128 + (f & 127)];
         }
     };
     auto commit = [&](int q) {                     // GroupNorm affine (zero padding AFTER the norm), split, LDS
@@ -414,11 +435,8 @@ conv3d_gcr_s_kernel(ConvArgs a) {
         }
 #pragma unroll
         for (int it = 0; it < SB_ITERS; ++it) {
-            const int v = (threadIdx.x >> 2) + it * 128;
-            if (v >= 1000) continue;
-            const int px = v % 10, r2 = v / 10, py = r2 % 10, pz = r2 / 10;
-            const int gx = x0 + px - 1, gy = y0 + py - 1, gz = z0 + pz - 1;
-            const bool in = gx >= 0 && gx < s.W && gy >= 0 && gy < s.H && gz >= 0 && gz < s.D;
+            if (lrow[it] < 0) continue;
+            const bool in = inside >> it & 1u;
             bf16x4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -427,19 +445,19 @@ conv3d_gcr_s_kernel(ConvArgs a) {
                 hi[e] = hb;
                 lo[e] = (__bf16)(x - (float)hb);
             }
-            char *row = stile + ((pz * 10 + py) * SB_PX + px) * SB_ROW + sc4 * 2;
-            *reinterpret_cast<bf16x4 *>(row) = hi;
-            *reinterpret_cast<bf16x4 *>(row + 32) = lo;
+            *reinterpret_cast<bf16x4 *>(stile + lrow[it]) = hi;
+            *reinterpret_cast<bf16x4 *>(stile + lrow[it] + 32) = lo;
+        }
+#pragma unroll
+        for (int it = 0; it < SB_WITERS; ++it) {
+            const int f = threadIdx.x + it * SB_THREADS;
+            if (f < SB_WFRAGS) wlds[f] = wpre[it];
         }
     };
 
-    f32x16 acc[2][NCO];
+    f32x16 acc;
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int n = 0; n < NCO; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[g][n][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
     fetch(0);
     for (int q = 0; q < ncq; ++q) {
@@ -447,60 +465,38 @@ conv3d_gcr_s_kernel(ConvArgs a) {
         commit(q);
         __syncthreads();
         if (q + 1 < ncq) fetch(q + 1);
-        const bf16x8 *wq = reinterpret_cast<const bf16x8 *>(a.wp) + ((size_t)q * 27 * nco_all + co_blk0) * 128 + lane;
-        bf16x8 wn[NCO][2];
-#pragma unroll
-        for (int n = 0; n < NCO; ++n) { wn[n][0] = wq[n * 128]; wn[n][1] = wq[n * 128 + 64]; }
-#pragma unroll 1
+#pragma unroll 3
         for (int tap = 0; tap < 27; ++tap) {
-            bf16x8 wc[NCO][2];
-#pragma unroll
-            for (int n = 0; n < NCO; ++n) { wc[n][0] = wn[n][0]; wc[n][1] = wn[n][1]; }
-            if (tap < 26) {
-                const bf16x8 *wt = wq + (size_t)(tap + 1) * nco_all * 128;
-#pragma unroll
-                for (int n = 0; n < NCO; ++n) { wn[n][0] = wt[n * 128]; wn[n][1] = wt[n * 128 + 64]; }
-            }
+            const bf16x8 wh = wlds[tap * 128 + lane], wl = wlds[tap * 128 + 64 + lane];
             const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
             const char *xin = stile + (center + (dz * 10 + dy) * SB_PX + dx) * SB_ROW + kg * 16;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(xin + g * 4 * SB_ROW);
-                const bf16x8 xl = *reinterpret_cast<const bf16x8 *>(xin + g * 4 * SB_ROW + 32);
-#pragma unroll
-                for (int n = 0; n < NCO; ++n) {
-                    acc[g][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[n][1], xh, acc[g][n], 0, 0, 0);
-                    acc[g][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[n][0], xl, acc[g][n], 0, 0, 0);
-                    acc[g][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[n][0], xh, acc[g][n], 0, 0, 0);
-                }
-            }
+            const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(xin);
+            const bf16x8 xl = *reinterpret_cast<const bf16x8 *>(xin + 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc, 0, 0, 0);
         }
     }
     // epilogue: as conv3d_gcr_kernel (lane = voxel, 16 registers = channels chan_of(r,kg))
     __syncthreads();
-    float *sred = reinterpret_cast<float *>(stile);               // [8 waves][2 patches][NCO*32][2]
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int gx = x0 + lx + 4 * g, gy = y0 + ly, gz = z0 + wave;
+    float *sred = reinterpret_cast<float *>(stile);               // [16 waves][32][2]
+    {
+        const int gx = x0 + lx + wx, gy = y0 + ly, gz = z0 + wz;
         const bool valid = gx < s.W && gy < s.H && gz < s.D;
         float *orow = a.out + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.Cout;
-#pragma unroll
-        for (int n = 0; n < NCO; ++n) {
-            f32x16 v = acc[g][n];
-            if (a.relu) v = relu16(v);
-            if (valid) store_acc16(orow + (co_blk0 + n) * 32, v, kg);
-            if (a.part) wave_stats(v, valid, j, kg, sred + ((wave * 2 + g) * NCO + n) * 64);
-        }
+        f32x16 v = acc;
+        if (a.relu) v = relu16(v);
+        if (valid) store_acc16(orow + co_blk * 32, v, kg);
+        if (a.part) wave_stats(v, valid, j, kg, sred + wave * 64);
     }
     if (a.part) {
         __syncthreads();
         const int nsp = a.tiles_x * a.tiles_y * a.tiles_z;
         const int spatial = blockIdx.x % nsp;
-        for (int e = threadIdx.x; e < NCO * 32 * 2; e += 512) {
+        if (threadIdx.x < 64) {
             float tsum = 0.0f;
-            for (int w = 0; w < 16; ++w) tsum += sred[w * NCO * 64 + e];
-            const int n = e >> 6, c2 = e & 63;                    // c2 = channel*2 + {sum,sq}
-            a.part[(((size_t)b * nsp + spatial) * a.Cout + (co_blk0 + n) * 32) * 2 + c2] = tsum;
+            for (int w = 0; w < 16; ++w) tsum += sred[w * 64 + threadIdx.x];
+            a.part[(((size_t)b * nsp + spatial) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
         }
     }
 }
@@ -603,10 +599,10 @@ static int conv_waves(int B, int D, int H, int W, int nco) {
 }
 
 // split-bf16 kernel: whole 8^3 tiles, 32-channel multiples, and enough workgroups to fill the chip
-static int conv_s_nco(int Cout) { return (Cout % 64 == 0) ? 2 : 1; }
 static bool conv_s_eligible(int B, int D, int H, int W, int Cin, int Cout) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || ((D | H | W) & 7) || Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 31)) return false;
-    return (size_t)(D / 8) * (H / 8) * (W / 8) * B * (Cout / 32 / conv_s_nco(Cout)) >= 256;
+    if ((size_t)B * D * H * W >= ((size_t)1 << 31)) return false;                    // 32-bit voxel indices
+    return (size_t)(D / 8) * (H / 8) * (W / 8) * B * (Cout / 32) >= 256;
 }
 
 template <int NCO, int WAVES>
@@ -757,18 +753,14 @@ int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, in
     a.scale_shift = scale_shift; a.wp = packed_w_bf16x3; a.out = out; a.part = out_part; a.Cout = Cout; a.relu = relu;
     a.TX = a.TY = a.TZ = 8;
     a.tiles_x = W / 8; a.tiles_y = H / 8; a.tiles_z = D / 8;
-    const int per = conv_s_nco(Cout);
-    const dim3 grid((unsigned)((size_t)a.tiles_x * a.tiles_y * a.tiles_z * B), (unsigned)(Cout / 32 / per));
-    const size_t lds = (size_t)SB_ROWS * SB_ROW;
+    const dim3 grid((unsigned)((size_t)a.tiles_x * a.tiles_y * a.tiles_z * B), (unsigned)(Cout / 32));
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_bf16x3: hipFuncSetAttribute");
         attr = true;
     }
-    if (per == 2) hipLaunchKernelGGL(conv3d_gcr_s_kernel<2>, grid, dim3(512), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(conv3d_gcr_s_kernel<1>, grid, dim3(512), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv3d_gcr_s_kernel, grid, dim3(SB_THREADS), SB_LDS, (hipStream_t)stream, a);
     return vt_check(hipGetLastError(), "vt_conv3d_gcr_bf16x3");
 }
 
