@@ -602,7 +602,7 @@ static int conv_waves(int B, int D, int H, int W, int nco) {
 static bool conv_s_eligible(int B, int D, int H, int W, int Cin, int Cout) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || ((D | H | W) & 7) || Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 31)) return false;
     if ((size_t)B * D * H * W >= ((size_t)1 << 31)) return false;                    // 32-bit voxel indices
-    return (size_t)(D / 8) * (H / 8) * (W / 8) * B * (Cout / 32) >= 256;
+    return (size_t)(D / 8) * (H / 8) * (W / 8) * B * (Cout / 32) >= 64;
 }
 
 template <int NCO, int WAVES>
