@@ -3,8 +3,9 @@
 // (reference src/conv_onet/models/decoder.py:135-161, 71-103, 105-133).
 //
 // Mapping.  One wave owns a tile of 32 query points.  Every dense layer
-// y = W x (32x32) is computed transposed on the f32 matrix core,
-//     D[out][point] += A[out][k] * B[k][point]      (v_mfma_f32_32x32x2_f32),
+// y = W x (32x32) is computed transposed on the matrix core,
+//     D[out][point] += A[out][k] * B[k][point]
+// (exact f32: v_mfma_f32_32x32x2_f32, described here; split-bf16: decode_common.h),
 // so the accumulator of one layer (point on the lane, 16 output channels in the
 // 16 accumulator registers) IS the B operand of the next layer with no lane
 // movement: register r of lane-half h holds channel o(r,h) = (r&3)+8(r>>2)+4h,

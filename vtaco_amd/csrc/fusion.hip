@@ -11,8 +11,8 @@
 //   out = relu(InstanceNorm_N(z))
 // Q and K are unit vectors, so scores lie in [-1,1] and exp() needs no running max; the
 // column re-normalisation makes the usual one-pass online softmax impossible, so the N x N
-// scores are recomputed three times on the f32 matrix core instead of being stored
-// (3 x 64-deep MFMA passes; N=2048 would need 16 MB per matrix per scene otherwise):
+// scores are recomputed three times on the matrix core (bf16 MFMA, split-bf16 operands: see
+// below) instead of being stored (N=2048 would need 16 MB per matrix per scene otherwise):
 //   rowsum  l_q = sum_k e^{S_qk}          colsum  s_k = sum_q e^{S_qk} / l_q
 //   attend  O_q = (1/l_q) sum_k e^{S_qk} V_k / (1e-9 + s_k), chained into the epilogue MLP.
 // Score tiles come out of the MFMA with the fixed index on the lane and the streamed index

@@ -1,7 +1,10 @@
 """3-D U-Net that refines the scattered feature grid.
 
-Host PyTorch-ROCm (MIOpen conv3d / group_norm): north_star names no HIP kernel for
-it.  Same parameter tree as the reference's ``UNet3D`` (src/encoder/unet3d.py:361-491:
+Two paths over one parameter tree: inference (no grad) runs the HIP UNet3D of
+``csrc/unet3d.hip`` through ``vt_unet3d_fwd`` (channels-last implicit-GEMM conv3d with fused
+GroupNorm / ReLU / upsample / concat; ``precision`` selects split-bf16 or exact-f32 matrix
+cores), training runs host PyTorch-ROCm autograd (MIOpen conv3d / group_norm; north_star
+names no HIP kernel for the UNet3D backward).  Same parameter tree as the reference's ``UNet3D`` (src/encoder/unet3d.py:361-491:
 ``encoders.{i}.basic_module.SingleConv{1,2}.{groupnorm,conv}``, ``decoders.{i}...``,
 ``final_conv``) so checkpoints load unchanged; only what the shipped configs use is
 built: DoubleConv blocks, layer order 'gcr', max-pool down, nearest-neighbour up +
