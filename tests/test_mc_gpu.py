@@ -77,3 +77,21 @@ def test_errors():
         run(np.zeros((4, 4, 4), np.float32), 1.0)
     with pytest.raises(ValueError):
         ops.marching_cubes(torch.zeros(1, 4, 4, device=DEV))
+
+
+def test_speculative_emit_small_large_small_surface():
+    """Same volume shape three times: the first call sizes the outputs from the counts, the second
+    (a far larger surface) overflows the speculative buffers and is re-emitted at the exact size, the
+    third runs entirely in the speculative buffers -- all three numbered exactly as the oracle."""
+    from oracle import mc
+    from vtaco_amd import ops
+    ops._mc_guess.clear()
+    n = 40
+    zz, yy, xx = np.meshgrid(*(np.arange(n, dtype=np.float32),) * 3, indexing="ij")
+    ball = lambda r: (r - np.sqrt((xx - 19.3) ** 2 + (yy - 20.1) ** 2 + (zz - 18.7) ** 2)).astype(np.float32)
+    noise = np.random.RandomState(4).randn(n, n, n).astype(np.float32)
+    for vol in (ball(5.0), noise, ball(7.5), ball(4.0)):
+        rv, rf, _ = mc.marching_cubes(vol, 0.0)
+        v, f, _ = run(vol, 0.0)
+        assert np.array_equal(f, rf) and v.shape == rv.shape and np.abs(v - rv).max() <= 1e-5
+    assert (0, n, n, n) in ops._mc_guess or (torch.cuda.current_device(), n, n, n) in ops._mc_guess

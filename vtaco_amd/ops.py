@@ -201,29 +201,44 @@ def mc_count(vol, level=None):
     return ws
 
 
+_mc_guess = {}          # volume shape -> (vertex, face) capacity that covered the last extraction there
+
+
 def mc_emit(vol, ws, rescale=None, capacity=None):
-    """Phase 2 (vt_mc_read_counts + vt_mc_emit).  Without ``capacity`` the counts are read back
-    (one stream sync) to size the outputs."""
+    """Phase 2 (vt_mc_emit + vt_mc_read_counts).  With ``capacity=(V,F)`` nothing is read back
+    (no stream sync; the counts stay in the workspace).  Otherwise the outputs are sized by the
+    counts, which costs one host read: after the first extraction of a shape the emit kernels are
+    launched SPECULATIVELY into buffers 25 % larger than the previous result before that read, so
+    the read is the only synchronisation of the call; if the surface outgrew the guess the emit is
+    repeated at the exact size (the kernels never write past their capacity)."""
     lib = _lib.load()
     n0, n1, n2 = vol.shape
     st = stream_ptr()
     wp = ctypes.c_void_p(ws.data_ptr())
-    nv, nf, lvl = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
-    if capacity is None:
-        check(lib.vt_mc_read_counts(wp, ctypes.byref(nv), ctypes.byref(nf), ctypes.byref(lvl), st), "vt_mc_read_counts")
-        if nv.value == 0:
-            raise RuntimeError("No surface found at the given iso value.")
-        cap_v, cap_f = nv.value, nf.value
-    else:
-        cap_v, cap_f = capacity
-    verts = torch.empty((cap_v, 3), dtype=torch.float32, device=vol.device)
-    faces = torch.empty((cap_f, 3), dtype=torch.int32, device=vol.device)
     shift, scale = rescale if rescale is not None else (0.0, 1.0)
-    check(lib.vt_mc_emit(dev_ptr(vol, "vol"), n0, n1, n2, wp, dev_ptr(verts, "verts"), cap_v,
-                         dev_ptr(faces, "faces", torch.int32), cap_f, int(rescale is not None), shift, scale, st),
-          "vt_mc_emit")
+
+    def emit(cap_v, cap_f):
+        verts = torch.empty((cap_v, 3), dtype=torch.float32, device=vol.device)
+        faces = torch.empty((cap_f, 3), dtype=torch.int32, device=vol.device)
+        check(lib.vt_mc_emit(dev_ptr(vol, "vol"), n0, n1, n2, wp, dev_ptr(verts, "verts"), cap_v,
+                             dev_ptr(faces, "faces", torch.int32), cap_f, int(rescale is not None), shift, scale, st),
+              "vt_mc_emit")
+        return verts, faces
+
     if capacity is not None:
+        verts, faces = emit(*capacity)
         return verts, faces, ws          # counts stay on the device: ws[8:16] = (nverts, nfaces) int32
+    key = (vol.device.index, n0, n1, n2)
+    guess = _mc_guess.get(key)
+    spec = emit(*guess) if guess is not None else None
+    nv, nf, lvl = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+    check(lib.vt_mc_read_counts(wp, ctypes.byref(nv), ctypes.byref(nf), ctypes.byref(lvl), st), "vt_mc_read_counts")
+    if nv.value == 0:
+        raise RuntimeError("No surface found at the given iso value.")
+    _mc_guess[key] = (nv.value + nv.value // 4 + 1024, nf.value + nf.value // 4 + 1024)
+    if spec is not None and nv.value <= guess[0] and nf.value <= guess[1]:
+        return spec[0][:nv.value], spec[1][:nf.value], lvl.value
+    verts, faces = emit(nv.value, nf.value)
     return verts, faces, lvl.value
 
 
