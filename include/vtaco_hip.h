@@ -336,6 +336,36 @@ int vt_voxel_scatter_mean_cl_fwd(const float *feat, const int *idx, const int *o
 int vt_voxel_scatter_mean_cl_bwd(const float *grad_grid_cl, const int *idx, const int *seg_lo, const int *seg_hi,
                                  int B, int T, int C, int R, float *grad_feat, void *stream);
 
+
+/* ------------------------------------------------------------------------- */
+/* UNet3D backward (training), channels-last.                                   */
+/* Replaces: PyTorch autograd of the 'gcr' SingleConv, MaxPool3d and the        */
+/*   upsample+concat of src/encoder/unet3d.py:20-72, 219-238, 283-293, run by    */
+/*   loss.backward() (src/conv_onet/training.py:79,89,96).  For one block         */
+/*   y = relu(conv(xn)), xn = GroupNorm([skip | upsample(low)]) and a gradient dy: */
+/*   vt_relu_mask      g = dy where y > 0, else 0;                                 */
+/*   (data gradient)   dxn = vt_conv3d_gcr[_bf16x3](g, pack(W^T flipped), no norm, */
+/*                     no relu): the forward kernels on repacked weights;           */
+/*   vt_conv3d_wgrad   dW[Cout][Cin][3][3][3] = sum_v g[v] (x) xn[v+tap] (xn is      */
+/*                     re-normalised from skip/low with the forward scale_shift);     */
+/*   vt_gn_bwd         GroupNorm backward from dxn: dskip [B,D,H,W,C1], dlow           */
+/*                     [B,D/2,H/2,W/2,C2] (children summed; either may be NULL),        */
+/*                     dgb[B][C][2] = per-scene (dgamma, dbeta); part1/part2 are the     */
+/*                     FORWARD statistics of skip/low; bpart [B][nblkb][C][2] and coef    */
+/*                     [B][C][3] are scratch;                                              */
+/*   vt_maxpool3d_cl_bwd  routes dy to the first maximum of each 2x2x2 window.             */
+/* ------------------------------------------------------------------------- */
+int vt_relu_mask(const float *dy, const float *y, float *g, int64_t n, void *stream);
+size_t vt_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int vt_conv3d_wgrad(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                    const float *scale_shift, const float *g, int Cout, void *workspace, size_t workspace_bytes,
+                    float *dw, void *stream);
+int vt_gn_bwd(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+              const float *part1, int nblk1, const float *part2, int nblk2,
+              const float *dxn, int groups, const float *gamma, double eps,
+              float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow, void *stream);
+int vt_maxpool3d_cl_bwd(const float *x, const float *dy, int B, int D, int H, int W, int C, float *dx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,3 +100,95 @@ def test_hip_unet3d_at_64_split_bf16_vs_f32_and_oracle():
     es = float((outs["bf16x3"].permute(0, 4, 1, 2, 3).cpu() - ref).abs().max())
     assert e32 <= 1e-4 * scale and es <= 1e-4 * scale, (e32, es, scale)
     assert not torch.equal(outs["f32"], outs["bf16x3"])
+
+
+def _rel(a, b):
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+
+
+@pytest.mark.parametrize("C1,C2,Cout,R,B,prec", [(32, 0, 32, 8, 2, "f32"), (32, 64, 32, 8, 1, "f32"), (64, 0, 64, 16, 1, "f32"),
+                                                 (64, 128, 64, 8, 2, "f32"), (32, 0, 32, 16, 2, "f32"),
+                                                 (32, 0, 32, 64, 1, "bf16x3"), (32, 64, 32, 32, 2, "bf16x3")])
+def test_gcr_block_backward_vs_torch_autograd(C1, C2, Cout, R, B, prec):
+    """One differentiable 'gcr' block (vt_gn_scale_shift + conv forward; backward = vt_relu_mask, the forward conv
+    kernels on the flipped/transposed weight, vt_conv3d_wgrad, vt_gn_bwd) against torch autograd of
+    relu(conv3d(group_norm(cat[x, upsample(low)]))): dx, dlow, dW, dgamma, dbeta."""
+    import torch.nn.functional as F
+    from vtaco_amd import ops
+    from vtaco_amd.encoder.unet3d import _GcrFn
+    g = torch.Generator().manual_seed(C1 + C2 + R)
+    x = torch.randn(B, C1, R, R, R, generator=g)
+    low = torch.randn(B, C2, R // 2, R // 2, R // 2, generator=g) if C2 else None
+    w = torch.randn(Cout, C1 + C2, 3, 3, 3, generator=g) * 0.05
+    gamma = 1 + 0.2 * torch.randn(C1 + C2, generator=g)
+    beta = 0.2 * torch.randn(C1 + C2, generator=g)
+    wgt = torch.randn(B, Cout, R, R, R, generator=g)
+    cl = lambda t: t.to(DEV).permute(0, 2, 3, 4, 1).contiguous()
+    xh = cl(x).requires_grad_()
+    lh = cl(low).requires_grad_() if C2 else None
+    wh, gh, bh = (t.to(DEV).requires_grad_() for t in (w, gamma, beta))
+    xp = ops.channel_stats(xh.detach())[0]
+    lp = ops.channel_stats(lh.detach())[0] if C2 else None
+    yh, _ = _GcrFn.apply(xh, lh, gh, bh, wh, xp, lp, 8, 1e-5, prec)
+    (yh * cl(wgt)).sum().backward()
+    # reference on the CPU.  The ReLU decisions are taken from the HIP forward: with split-bf16 convs the
+    # pre-activations move by ~2e-5, which flips a handful of near-zero ones and with them single entries of
+    # the gradient by O(1 %) -- a property of ReLU, not of the backward kernels under test.
+    xr, wr, gr, br = (t.clone().requires_grad_() for t in (x, w, gamma, beta))
+    lr = low.clone().requires_grad_() if C2 else None
+    xin = torch.cat([xr, F.interpolate(lr, scale_factor=2, mode="nearest")], 1) if C2 else xr
+    pre = F.conv3d(F.group_norm(xin, 8, gr, br, 1e-5), wr, None, padding=1)
+    yh_cpu = yh.detach().permute(0, 4, 1, 2, 3).cpu()
+    assert _rel(yh_cpu, F.relu(pre).detach()) <= (1e-5 if prec == "f32" else 5e-5)
+    (pre * (yh_cpu > 0) * wgt).sum().backward()
+    tol = 1e-5 if prec == "f32" else 1e-4
+    assert _rel(xh.grad.permute(0, 4, 1, 2, 3).cpu(), xr.grad) <= tol
+    assert _rel(wh.grad.cpu(), wr.grad) <= tol
+    assert _rel(gh.grad.cpu(), gr.grad) <= tol and _rel(bh.grad.cpu(), br.grad) <= tol
+    if C2:
+        assert _rel(lh.grad.permute(0, 4, 1, 2, 3).cpu(), lr.grad) <= tol
+
+
+def test_maxpool_backward_first_maximum():
+    import torch.nn.functional as F
+    from vtaco_amd.encoder.unet3d import _MaxPoolFn
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 8, 8, 8, generator=g).relu()          # exact ties among the zeros
+    wgt = torch.randn(2, 32, 4, 4, 4, generator=g)
+    xr = x.clone().requires_grad_()
+    (F.max_pool3d(xr, 2) * wgt).sum().backward()
+    xh = x.to(DEV).permute(0, 2, 3, 4, 1).contiguous().requires_grad_()
+    (_MaxPoolFn.apply(xh) * wgt.to(DEV).permute(0, 2, 3, 4, 1)).sum().backward()
+    assert torch.equal(xh.grad.permute(0, 4, 1, 2, 3).cpu(), xr.grad)
+
+
+@pytest.mark.parametrize("R,levels,B", [(16, 3, 2), (32, 4, 1)])
+def test_hip_unet3d_training_path_vs_host_autograd(R, levels, B):
+    """Whole network, forward_channels_last_train (HIP forward + HIP backward) against the host PyTorch-ROCm
+    autograd path of the same module.  The forward must agree to f32 rounding.  The gradients of this
+    GroupNorm/ReLU/max-pool stack at random init are discontinuous in the input at the 1e-6 level (the host path
+    against itself under such a perturbation moves by ~1 % in L2), so the gradient bound is relative to that
+    measured sensitivity; every block's backward is checked exactly in test_gcr_block_backward_vs_torch_autograd."""
+    net = _unet(32, levels, R + 1).to(DEV)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, 32, R, R, R, generator=g).to(DEV)
+    wgt = torch.randn(B, 32, R, R, R, generator=g).to(DEV)
+    l2 = lambda a, b: float((a - b).norm()) / max(float(b.norm()), 1e-20)
+
+    def host(xin):
+        net.zero_grad(set_to_none=True)
+        xg = xin.clone().requires_grad_()
+        out = net(xg)
+        (out * wgt).sum().backward()
+        return out.detach(), xg.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters()}
+    y0, gx0, gp0 = host(x)
+    _, gx1, gp1 = host(x + 1e-6 * torch.randn(x.shape, generator=g).to(DEV))
+    sens = max([l2(gx1, gx0)] + [l2(gp1[n], gp0[n]) for n in gp0])
+    net.zero_grad(set_to_none=True)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().requires_grad_()
+    y = net.forward_channels_last_train(x_cl)
+    assert _rel(y.detach().permute(0, 4, 1, 2, 3), y0) <= 2e-5
+    (y * wgt.permute(0, 2, 3, 4, 1)).sum().backward()
+    err = max([l2(x_cl.grad.permute(0, 4, 1, 2, 3), gx0)] + [l2(p.grad, gp0[n]) for n, p in net.named_parameters()])
+    assert err <= 3.0 * sens + 1e-4, (err, sens)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())

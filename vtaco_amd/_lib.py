@@ -106,6 +106,11 @@ SIGNATURES = {
     "vt_conv3d_pack": (_I, [_VP, _I, _I, _VP, _VP]),
     "vt_stats_floats": (_SZ, [_I, _I, _I, _I, _I]),
     "vt_conv3d_stat_blocks": (_I, [_I, _I, _I, _I, _I, _I]),
+    "vt_relu_mask": (_I, [_VP, _VP, _VP, _I64, _VP]),
+    "vt_conv3d_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
+    "vt_conv3d_wgrad": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _SZ, _VP, _VP]),
+    "vt_gn_bwd": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _I, _VP, _I, _VP, _I, _VP, _D, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
+    "vt_maxpool3d_cl_bwd": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP, _VP]),
     "vt_conv3d_pack_bf16x3": (_I, [_VP, _I, _I, _VP, _VP]),
     "vt_conv3d_stat_blocks_bf16x3": (_I, [_I, _I, _I, _I, _I, _I]),
     "vt_conv3d_gcr_bf16x3": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),

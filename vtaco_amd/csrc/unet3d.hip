@@ -904,3 +904,384 @@ int vt_unet3d_fwd(const float *x_cl, int B, int R, const vt_unet3d_params *param
 }
 
 }  // extern "C"
+
+// =====================================================================================
+// Backward of the 'gcr' block, max-pool and concat/upsample (training; reference: PyTorch
+// autograd of src/encoder/unet3d.py:20-72, 219-238, 283-293 triggered by loss.backward(),
+// training.py:79,89,96).  With y = relu(conv(xn)), xn = GroupNorm(x_cat):
+//   g    = dy * (y > 0)                                   relu_mask_kernel
+//   dxn  = conv3x3x3(g, W^T flipped)                       the FORWARD conv kernels on repacked weights
+//   dW   = sum_v g[v] (x) xn[v + tap]                      conv3d_wgrad_kernel (f32 MFMA, K = voxels)
+//   dx   = A_c dxn + B_g x + C_g,  dgamma, dbeta           gn_bwd_stats / gn_bwd_coeffs / gn_bwd_apply
+// =====================================================================================
+namespace {
+
+__global__ void __launch_bounds__(256) relu_mask_kernel(const f32x4 *dy, const f32x4 *y, f32x4 *g, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 a = dy[i], b = y[i];
+        g[i] = f32x4{b.x > 0.f ? a.x : 0.f, b.y > 0.f ? a.y : 0.f, b.z > 0.f ? a.z : 0.f, b.w > 0.f ? a.w : 0.f};
+    }
+}
+
+// ---- weight gradient ---------------------------------------------------------------------------
+// One workgroup = one (cout block, cin block) pair and a chunk of 8x8x4 voxel tiles; per tile the
+// normalised input (+halo) and the masked output gradient are staged in LDS and every tap is an
+// MFMA product D[co][ci] += g^T[co][v] xn[v + tap][ci] over the tile's 256 voxels (K).  Seven waves
+// split the 27 taps (4 each); accumulators live in registers across the chunk's tiles; the per-chunk
+// partials are summed in chunk order by conv3d_wgrad_reduce_kernel (bit-reproducible).
+constexpr int WG_WAVES = 7, WG_TAPS = 4;
+constexpr int WG_TX = 8, WG_TY = 8, WG_TZ = 4, WG_VOX = WG_TX * WG_TY * WG_TZ;
+constexpr int WG_PX = WG_TX + 2, WG_PY = WG_TY + 2, WG_PZ = WG_TZ + 2, WG_HALO = WG_PX * WG_PY * WG_PZ;
+
+struct WgradArgs {
+    ConvArgs c;              // s, scale_shift (forward's), tiles_*; TX.. unused
+    const float *g;          // [B,D,H,W,Cout] masked output gradient
+    float *partial;          // [chunks][nco][ncib][27][32 co][32 ci]
+    int ntiles;              // B * tiles per scene
+};
+
+__global__ void __launch_bounds__(WG_WAVES * 64)
+conv3d_wgrad_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];       // [WG_HALO][CPAD] xn, then [WG_VOX][CPAD] g
+    float *xs = wl, *gs = wl + WG_HALO * CPAD;
+    const Src &s = a.c.s;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, kk = lane >> 5;
+    const int ncib = (s.C1 + s.C2) / 32, nco = a.c.Cout / 32;
+    const int cob = blockIdx.y / ncib, cib = blockIdx.y % ncib;
+    const int tap0 = wave * WG_TAPS;
+    f32x16 acc[WG_TAPS];
+#pragma unroll
+    for (int t = 0; t < WG_TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    int toff[WG_TAPS];
+#pragma unroll
+    for (int t = 0; t < WG_TAPS; ++t) {
+        const int tap = min(tap0 + t, 26);
+        toff[t] = (((tap / 9 - 1) * WG_PY + ((tap / 3) % 3 - 1)) * WG_PX + (tap % 3 - 1)) * CPAD;
+    }
+    const int tiles_per_scene = a.c.tiles_x * a.c.tiles_y * a.c.tiles_z;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_scene;
+        int t = tile - b * tiles_per_scene;
+        const int tx = t % a.c.tiles_x; t /= a.c.tiles_x;
+        const int ty = t % a.c.tiles_y, tz = t / a.c.tiles_y;
+        const int x0 = tx * WG_TX, y0 = ty * WG_TY, z0 = tz * WG_TZ;
+        __syncthreads();
+        stage_tile(xs, a.c, b, cib, x0, y0, z0, WG_PX, WG_PY, WG_HALO, threadIdx.x, WG_WAVES * 64);
+        for (int e = threadIdx.x; e < WG_VOX * 8; e += WG_WAVES * 64) {          // g tile: 8 float4 per voxel
+            const int v = e >> 3, c4 = (e & 7) * 4;
+            const int gx = x0 + (v & 7), gy = y0 + ((v >> 3) & 7), gz = z0 + (v >> 6);
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (gx < s.W && gy < s.H && gz < s.D)
+                val = *reinterpret_cast<const f32x4 *>(a.g + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.c.Cout + cob * 32 + c4);
+            float *d = gs + v * CPAD + c4;
+            d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int zy = 0; zy < WG_TZ * WG_TY; ++zy) {
+            const int z = zy >> 3, y = zy & 7;
+            const float *grow = gs + (zy * 8 + kk) * CPAD + i;
+            const float *xrow = xs + (((z + 1) * WG_PY + (y + 1)) * WG_PX + 1 + kk) * CPAD + i;
+#pragma unroll
+            for (int xp = 0; xp < 4; ++xp) {                              // voxels 2xp + kk of this row
+                const float av = grow[2 * xp * CPAD];
+#pragma unroll
+                for (int t = 0; t < WG_TAPS; ++t) acc[t] = mfma(av, xrow[2 * xp * CPAD + toff[t]], acc[t]);
+            }
+        }
+    }
+    // partial[chunk][cob][cib][tap][co][ci]: lane (ci = i, h = kk) register r = co chan_of(r, kk)
+    float *dst = a.partial + (((size_t)blockIdx.x * nco + cob) * ncib + cib) * 27 * 1024;
+#pragma unroll
+    for (int t = 0; t < WG_TAPS; ++t) {
+        const int tap = tap0 + t;
+        if (tap >= 27) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(size_t)tap * 1024 + chan_of(r, kk) * 32 + i] = acc[t][r];
+    }
+}
+
+// dW[co][ci][tap] (torch layout [Cout][Cin][3][3][3]) = sum over chunks, in chunk order
+__global__ void __launch_bounds__(256)
+conv3d_wgrad_reduce_kernel(const float *partial, int chunks, int Cout, int Cin, float *dw) {
+    const int nco = Cout / 32, ncib = Cin / 32;
+    const size_t total = (size_t)Cout * Cin * 27, per_chunk = (size_t)nco * ncib * 27 * 1024;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        // e indexes the partial layout (coalesced reads): [cob][cib][tap][co][ci]
+        const int ci = (int)(e & 31), co = (int)((e >> 5) & 31);
+        size_t r = e >> 10;
+        const int tap = (int)(r % 27); r /= 27;
+        const int cib = (int)(r % ncib), cob = (int)(r / ncib);
+        float sum = 0.0f;
+        for (int c = 0; c < chunks; ++c) sum += partial[(size_t)c * per_chunk + e];
+        dw[((size_t)(cob * 32 + co) * Cin + cib * 32 + ci) * 27 + tap] = sum;
+    }
+}
+
+// ---- GroupNorm backward ------------------------------------------------------------------------
+// part[b][blk][c] = (sum_v dxn, sum_v dxn * x) over the block's voxels; x is the virtual concat input
+__global__ void __launch_bounds__(256)
+gn_bwd_stats_kernel(Src s, const float *dxn, int nblk, float *part) {
+    __shared__ float red[8][32][2];
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int C = s.C1 + s.C2;
+    const size_t V = (size_t)s.D * s.H * s.W;
+    const size_t v0 = V * blk / nblk, v1 = V * (blk + 1) / nblk;
+    const int c = threadIdx.x & 31, vg = threadIdx.x >> 5;
+    for (int cb = 0; cb < C; cb += 32) {
+        float p1 = 0.0f, p2 = 0.0f;
+        for (size_t v = v0 + vg; v < v1; v += 8) {
+            const int x = (int)(v % s.W);
+            const size_t r = v / s.W;
+            const int y = (int)(r % s.H), z = (int)(r / s.H);
+            const float d = dxn[((size_t)b * V + v) * C + cb + c];
+            p1 += d;
+            p2 = fmaf(d, src_at(s, b, z, y, x, cb + c), p2);
+        }
+        red[vg][c][0] = p1; red[vg][c][1] = p2;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            float a = 0.0f, q = 0.0f;
+            for (int k = 0; k < 8; ++k) { a += red[k][c][0]; q += red[k][c][1]; }
+            float *dst = part + (((size_t)b * nblk + blk) * C + cb + c) * 2;
+            dst[0] = a; dst[1] = q;
+        }
+        __syncthreads();
+    }
+}
+
+// one block per (scene, group): forward statistics again (same reduction as gn_finalize_kernel) and
+// the backward coefficients coef[b][c] = (A_c, B_g, C_g): dx = A dxn + B x + C;
+// dgb[b][c] = (dgamma, dbeta) contributions of this scene
+__global__ void __launch_bounds__(256)
+gn_bwd_coeffs_kernel(StatSrc s1, StatSrc s2, const float *bpart, int nblkb, int groups, double count,
+                     const float *gamma, float eps, float *coef, float *dgb) {
+    __shared__ double red[256][4];
+    __shared__ double stat[4];
+    const int b = blockIdx.x, g = blockIdx.y;
+    const int C = s1.C + s2.C, cpg = C / groups;
+    double sum = 0.0, sq = 0.0;
+    for (int k = 0; k < cpg; ++k) {
+        const int c = g * cpg + k;
+        const StatSrc &s = (c < s1.C) ? s1 : s2;
+        const int cc = (c < s1.C) ? c : c - s1.C;
+        const double mult = (c < s1.C) ? 1.0 : 8.0;
+        for (int blk = threadIdx.x; blk < s.nblk; blk += 256) {
+            const float *p = s.part + (((size_t)b * s.nblk + blk) * s.C + cc) * 2;
+            sum += mult * (double)p[0]; sq += mult * (double)p[1];
+        }
+    }
+    // per-channel backward sums: thread t < cpg owns channel g*cpg + t (cpg <= 256)
+    double p1 = 0.0, p2 = 0.0;
+    if ((int)threadIdx.x < cpg) {
+        const int c = g * cpg + threadIdx.x;
+        for (int blk = 0; blk < nblkb; ++blk) {
+            const float *p = bpart + (((size_t)b * nblkb + blk) * C + c) * 2;
+            p1 += (double)p[0]; p2 += (double)p[1];
+        }
+    }
+    red[threadIdx.x][0] = sum; red[threadIdx.x][1] = sq;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[threadIdx.x][0] += red[threadIdx.x + o][0]; red[threadIdx.x][1] += red[threadIdx.x + o][1]; }
+        __syncthreads();
+    }
+    const double n = count * cpg;
+    if (threadIdx.x == 0) {
+        const double mean = red[0][0] / n;
+        double var = red[0][1] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat[0] = mean; stat[1] = 1.0 / sqrt(var + (double)eps);
+    }
+    __syncthreads();
+    const double mean = stat[0], rstd = stat[1];
+    // m1 = mean_g(gamma dxn), m2 = mean_g(gamma dxn xhat)
+    double t1 = 0.0, t2 = 0.0;
+    if ((int)threadIdx.x < cpg) {
+        const double gm = (double)gamma[g * cpg + threadIdx.x];
+        t1 = gm * p1; t2 = gm * rstd * (p2 - mean * p1);
+    }
+    red[threadIdx.x][2] = t1; red[threadIdx.x][3] = t2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int k = 0; k < cpg; ++k) { a1 += red[k][2]; a2 += red[k][3]; }
+        stat[2] = a1 / n; stat[3] = a2 / n;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cpg) {
+        const int c = g * cpg + threadIdx.x;
+        const double m1 = stat[2], m2 = stat[3];
+        float *cf = coef + ((size_t)b * C + c) * 3;
+        cf[0] = (float)(rstd * (double)gamma[c]);
+        cf[1] = (float)(-rstd * rstd * m2);
+        cf[2] = (float)(-rstd * m1 + rstd * rstd * m2 * mean);
+        dgb[((size_t)b * C + c) * 2 + 0] = (float)(rstd * (p2 - mean * p1));
+        dgb[((size_t)b * C + c) * 2 + 1] = (float)p1;
+    }
+}
+
+// dskip[v][c] = A dxn + B x + C  (c < C1);   dlow[v2][c] = sum over the 8 children of the same (c >= C1)
+__global__ void __launch_bounds__(256)
+gn_bwd_apply_kernel(Src s, const float *dxn, const float *coef, float *dskip, float *dlow) {
+    const int C = s.C1 + s.C2;
+    const size_t V = (size_t)s.D * s.H * s.W;
+    const int b = blockIdx.y;
+    if (dskip) {
+        const size_t total = V * (s.C1 / 4);
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+            const int c4 = (int)(e % (s.C1 / 4)) * 4;
+            const size_t v = e / (s.C1 / 4);
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(dxn + ((size_t)b * V + v) * C + c4);
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(s.skip + ((size_t)b * V + v) * s.C1 + c4);
+            const float *cf = coef + ((size_t)b * C + c4) * 3;
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = fmaf(cf[3 * k], d[k], fmaf(cf[3 * k + 1], x[k], cf[3 * k + 2]));
+            *reinterpret_cast<f32x4 *>(dskip + ((size_t)b * V + v) * s.C1 + c4) = o;
+        }
+    }
+    if (dlow && s.low) {
+        const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
+        const size_t V2 = (size_t)D2 * H2 * W2, total = V2 * (s.C2 / 4);
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+            const int c4 = (int)(e % (s.C2 / 4)) * 4;
+            size_t v2 = e / (s.C2 / 4);
+            const int x2 = (int)(v2 % W2); size_t r = v2 / W2;
+            const int y2 = (int)(r % H2), z2 = (int)(r / H2);
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(s.low + ((size_t)b * V2 + v2) * s.C2 + c4);
+            const float *cf = coef + ((size_t)b * C + s.C1 + c4) * 3;
+            f32x4 dsum = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < 8; ++k) {
+                const size_t v = ((size_t)(2 * z2 + (k >> 2)) * s.H + (2 * y2 + ((k >> 1) & 1))) * s.W + 2 * x2 + (k & 1);
+                const f32x4 d = *reinterpret_cast<const f32x4 *>(dxn + ((size_t)b * V + v) * C + s.C1 + c4);
+                dsum.x += d.x; dsum.y += d.y; dsum.z += d.z; dsum.w += d.w;
+            }
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = fmaf(cf[3 * k], dsum[k], 8.0f * fmaf(cf[3 * k + 1], x[k], cf[3 * k + 2]));
+            *reinterpret_cast<f32x4 *>(dlow + ((size_t)b * V2 + v2) * s.C2 + c4) = o;
+        }
+    }
+}
+
+// dx = dy routed to the first maximum of each 2x2x2 window (scan order z,y,x: ATen's max_pool3d)
+__global__ void __launch_bounds__(256)
+maxpool3d_cl_bwd_kernel(const float *x, const float *dy, float *dx, int D, int H, int W, int C, size_t total) {
+    const int D2 = D / 2, H2 = H / 2, W2 = W / 2;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        size_t v = e / C;
+        const int ox = (int)(v % W2); v /= W2;
+        const int oy = (int)(v % H2); v /= H2;
+        const int oz = (int)(v % D2);
+        const size_t b = v / D2;
+        float m = -INFINITY;
+        int best = 0;
+        size_t idx[8];
+        for (int k = 0; k < 8; ++k) {
+            const int z = 2 * oz + (k >> 2), y = 2 * oy + ((k >> 1) & 1), xx = 2 * ox + (k & 1);
+            idx[k] = ((((size_t)b * D + z) * H + y) * W + xx) * C + c;
+            const float t = x[idx[k]];
+            if (t > m) { m = t; best = k; }
+        }
+        const float gval = dy[e];
+        for (int k = 0; k < 8; ++k) dx[idx[k]] = (k == best) ? gval : 0.0f;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vt_relu_mask(const float *dy, const float *y, float *g, int64_t n, void *stream) {
+    if (!dy || !y || !g || n <= 0 || (n & 3)) return vt_fail(VT_ERR_INVALID, "vt_relu_mask: bad argument (n must be a positive multiple of 4)");
+    size_t blocks = ((size_t)n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4 *>(dy), reinterpret_cast<const f32x4 *>(y), reinterpret_cast<f32x4 *>(g), (size_t)n / 4);
+    return vt_check(hipGetLastError(), "vt_relu_mask");
+}
+
+static int wgrad_chunks(int B, int D, int H, int W, int pairs) {
+    const int ntiles = B * ((W + WG_TX - 1) / WG_TX) * ((H + WG_TY - 1) / WG_TY) * ((D + WG_TZ - 1) / WG_TZ);
+    int chunks = 512 / pairs;
+    if (chunks < 1) chunks = 1;
+    if (chunks > ntiles) chunks = ntiles;
+    return chunks;
+}
+
+size_t vt_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 31)) return 0;
+    const int pairs = (Cin / 32) * (Cout / 32);
+    return (size_t)wgrad_chunks(B, D, H, W, pairs) * pairs * 27 * 1024 * sizeof(float);
+}
+
+int vt_conv3d_wgrad(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                    const float *scale_shift, const float *g, int Cout, void *workspace, size_t workspace_bytes,
+                    float *dw, void *stream) {
+    WgradArgs a;
+    a.c.s = Src{skip, low, C1, low ? C2 : 0, D, H, W};
+    if (!src_ok(a.c.s, B) || !g || !workspace || !dw) return vt_fail(VT_ERR_INVALID, "vt_conv3d_wgrad: bad argument");
+    if (Cout <= 0 || (Cout & 31)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_wgrad: Cout must be a multiple of 32");
+    const int Cin = a.c.s.C1 + a.c.s.C2;
+    if (workspace_bytes < vt_conv3d_wgrad_workspace_bytes(B, D, H, W, Cin, Cout)) return vt_fail(VT_ERR_WORKSPACE, "vt_conv3d_wgrad: workspace too small");
+    a.c.scale_shift = scale_shift; a.c.wp = nullptr; a.c.out = nullptr; a.c.part = nullptr; a.c.Cout = Cout; a.c.relu = 0;
+    a.c.TX = WG_TX; a.c.TY = WG_TY; a.c.TZ = WG_TZ;
+    a.c.tiles_x = (W + WG_TX - 1) / WG_TX; a.c.tiles_y = (H + WG_TY - 1) / WG_TY; a.c.tiles_z = (D + WG_TZ - 1) / WG_TZ;
+    a.g = g; a.partial = (float *)workspace;
+    a.ntiles = B * a.c.tiles_x * a.c.tiles_y * a.c.tiles_z;
+    const int pairs = (Cin / 32) * (Cout / 32), chunks = wgrad_chunks(B, D, H, W, pairs);
+    const size_t lds = (size_t)(WG_HALO + WG_VOX) * CPAD * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return vt_check(e, "vt_conv3d_wgrad: hipFuncSetAttribute");
+        attr = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv3d_wgrad_kernel, dim3((unsigned)chunks, (unsigned)pairs), dim3(WG_WAVES * 64), lds, st, a);
+    const size_t total = (size_t)Cout * Cin * 27;
+    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const float *)workspace, chunks, Cout, Cin, dw);
+    return vt_check(hipGetLastError(), "vt_conv3d_wgrad");
+}
+
+int vt_gn_bwd(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+              const float *part1, int nblk1, const float *part2, int nblk2,
+              const float *dxn, int groups, const float *gamma, double eps,
+              float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow, void *stream) {
+    Src s{skip, low, C1, low ? C2 : 0, D, H, W};
+    if (!src_ok(s, B) || !part1 || nblk1 <= 0 || !dxn || !gamma || !bpart || nblkb <= 0 || !coef || !dgb)
+        return vt_fail(VT_ERR_INVALID, "vt_gn_bwd: bad argument");
+    if (low && (!part2 || nblk2 <= 0)) return vt_fail(VT_ERR_INVALID, "vt_gn_bwd: statistics of `low` missing");
+    const int C = s.C1 + s.C2;
+    if (groups <= 0 || C % groups || C / groups > 256) return vt_fail(VT_ERR_INVALID, "vt_gn_bwd: bad group count");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nblkb, B), dim3(256), 0, st, s, dxn, nblkb, bpart);
+    StatSrc s1{part1, nblk1, s.C1}, s2{low ? part2 : nullptr, low ? nblk2 : 0, s.C2};
+    hipLaunchKernelGGL(gn_bwd_coeffs_kernel, dim3(B, groups), dim3(256), 0, st, s1, s2, (const float *)bpart, nblkb, groups,
+                       (double)D * H * W, gamma, (float)eps, coef, dgb);
+    if (dskip || dlow) {
+        const size_t V = (size_t)D * H * W;
+        size_t blocks = (V * (size_t)(s.C1 / 4) + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)blocks, B), dim3(256), 0, st, s, dxn, (const float *)coef, dskip, dlow);
+    }
+    return vt_check(hipGetLastError(), "vt_gn_bwd");
+}
+
+int vt_maxpool3d_cl_bwd(const float *x, const float *dy, int B, int D, int H, int W, int C, float *dx, void *stream) {
+    if (!x || !dy || !dx || B <= 0 || C <= 0 || D < 2 || H < 2 || W < 2 || ((D | H | W) & 1))
+        return vt_fail(VT_ERR_INVALID, "vt_maxpool3d_cl_bwd: bad argument (even extents)");
+    const size_t total = (size_t)B * (D / 2) * (H / 2) * (W / 2) * C;
+    size_t g = (total + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(maxpool3d_cl_bwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, dy, dx, D, H, W, C, total);
+    return vt_check(hipGetLastError(), "vt_maxpool3d_cl_bwd");
+}
+
+}  // extern "C"

@@ -79,6 +79,57 @@ class _Up(nn.Module):
         return self.basic_module(torch.cat((skip, x), dim=1))
 
 
+class _GcrFn(torch.autograd.Function):
+    """One 'gcr' SingleConv on channels-last tensors through the C ABI, differentiable:
+    forward vt_gn_scale_shift + vt_conv3d_gcr[_bf16x3]; backward vt_relu_mask, the forward conv
+    kernels on the transposed/flipped weight (data gradient), vt_conv3d_wgrad and vt_gn_bwd.
+    ``x_part`` / ``low_part`` are the producers' GroupNorm partial sums (not differentiated:
+    vt_gn_bwd accounts for the statistics' dependence on x)."""
+
+    @staticmethod
+    def forward(ctx, x, low, gamma, beta, weight, x_part, low_part, groups, eps, precision):
+        B, D, H, W, C1 = x.shape
+        C2 = low.shape[-1] if low is not None else 0
+        Cout = weight.shape[0]
+        x_st = (x_part, x_part.shape[1])
+        low_st = (low_part, low_part.shape[1]) if low is not None else None
+        ss = ops.gn_scale_shift(x_st, low_st, C1, C2, B, D * H * W, gamma, beta, groups, eps, x.device)
+        split = ops.conv3d_pack(weight, "bf16x3") if precision == "bf16x3" else None
+        y, (part, _) = ops.conv3d_gcr(x, low, ss, ops.conv3d_pack(weight), Cout, True, split)
+        ctx.save_for_backward(x, low, gamma, weight, ss, y, x_part, low_part)
+        ctx.cfg = (groups, eps, precision)
+        ctx.mark_non_differentiable(part)
+        return y, part
+
+    @staticmethod
+    def backward(ctx, dy, _dpart):
+        x, low, gamma, weight, ss, y, x_part, low_part = ctx.saved_tensors
+        groups, eps, precision = ctx.cfg
+        g = ops.relu_mask(dy, y)
+        w_t = weight.flip(2, 3, 4).transpose(0, 1).contiguous()          # [Cin,Cout,3,3,3]: conv of g with it = dxn
+        split = ops.conv3d_pack(w_t, "bf16x3") if precision == "bf16x3" else None
+        dxn, _ = ops.conv3d_gcr(g, None, None, ops.conv3d_pack(w_t), w_t.shape[0], False, split, want_stats=False)
+        dw = ops.conv3d_wgrad(x, low, ss, g) if ctx.needs_input_grad[4] else None
+        x_st = (x_part, x_part.shape[1])
+        low_st = (low_part, low_part.shape[1]) if low is not None else None
+        dskip, dlow, dgamma, dbeta = ops.gn_bwd(x, x_st, low, low_st, dxn, gamma, groups, eps,
+                                                want_skip=ctx.needs_input_grad[0],
+                                                want_low=low is not None and ctx.needs_input_grad[1])
+        return dskip, dlow, dgamma, dbeta, dw, None, None, None, None, None
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.maxpool3d_cl(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool3d_cl_bwd(x, dy)
+
+
 class UNet3D(nn.Module):
     def __init__(self, in_channels, out_channels, final_sigmoid=True, f_maps=64, layer_order='gcr',
                  num_groups=8, num_levels=4, is_segmentation=True, testing=False, **kwargs):
@@ -99,6 +150,10 @@ class UNet3D(nn.Module):
         # bf16 matrix core for the large volumes (6.6e-5 abs on the golden grid, 4e-5 on the decoded logits),
         # "f32" = exact-f32 matrix core everywhere.  Training (host autograd) is unaffected.
         self.precision = os.environ.get("VTACO_UNET_PRECISION", "bf16x3")
+        # the differentiable HIP path (forward_channels_last_train) keeps the exact-f32 convs by default: at random
+        # init this network's gradients move by ~1 % (L2) under a 1e-6 input perturbation (ReLU / max-pool decisions),
+        # and the 2e-5 deviations of the split form flip more of them (~2 %)
+        self.train_precision = os.environ.get("VTACO_UNET_TRAIN_PRECISION", "f32")
         self.final_activation = (nn.Sigmoid() if final_sigmoid else nn.Softmax(dim=1)) if is_segmentation else None
 
     # ---- HIP inference path (channels-last, vt_conv3d_gcr) ------------------------------
@@ -193,6 +248,36 @@ class UNet3D(nn.Module):
             x, st = self._gcr(dec.basic_module.SingleConv2, x, st)
         x = ops.conv1x1_cl(x, self.final_conv.weight.detach(), self.final_conv.bias.detach()
                            if self.final_conv.bias is not None else None)
+        if self.testing and self.final_activation is not None:
+            x = self.final_activation(x) if isinstance(self.final_activation, nn.Sigmoid) else torch.softmax(x, dim=-1)
+        return x
+
+    def forward_channels_last_train(self, x):
+        """Differentiable channels-last forward on the HIP kernels (training): same layers as
+        ``forward_channels_last_layers`` as autograd Functions whose backward is HIP too (data gradient
+        = the forward conv kernels on flipped weights, vt_conv3d_wgrad, vt_gn_bwd, vt_maxpool3d_cl_bwd);
+        the final 1x1x1 conv is a plain matmul.  x [B,D,H,W,C] contiguous."""
+        def stats(t):
+            return ops.channel_stats(t.detach())[0]
+
+        def gcr(single, t, part, low=None, low_part=None):
+            gn, conv = single.groupnorm, single.conv
+            return _GcrFn.apply(t, low, gn.weight, gn.bias, conv.weight, part, low_part, gn.num_groups, gn.eps, self.train_precision)
+        skips = []
+        part = None
+        for i, enc in enumerate(self.encoders):
+            if i > 0:
+                x = _MaxPoolFn.apply(x)
+            if i > 0 or part is None:
+                part = stats(x)
+            x, part = gcr(enc.basic_module.SingleConv1, x, part)
+            x, part = gcr(enc.basic_module.SingleConv2, x, part)
+            skips.append((x, part))
+        for dec, (skip, skip_part) in zip(self.decoders, skips[-2::-1]):
+            x, part = gcr(dec.basic_module.SingleConv1, skip, skip_part, low=x, low_part=part)
+            x, part = gcr(dec.basic_module.SingleConv2, x, part)
+        w = self.final_conv.weight.reshape(self.final_conv.out_channels, -1)
+        x = F.linear(x, w, self.final_conv.bias)
         if self.testing and self.final_activation is not None:
             x = self.final_activation(x) if isinstance(self.final_activation, nn.Sigmoid) else torch.softmax(x, dim=-1)
         return x

@@ -512,35 +512,103 @@ def channel_stats(x):
     return part, nblk
 
 
-def gn_conv3d_relu(x, x_stats, low, low_stats, gamma, beta, groups, packed_w, Cout, eps=1e-5, relu=True,
-                   packed_w_bf16x3=None):
-    """relu(conv3x3x3(GroupNorm([x | upsample(low)]))) on channels-last tensors; the statistics
-    come from the producers' partial sums.  Returns (out, out_stats).  With ``packed_w_bf16x3`` the
-    convolution runs on the bf16 matrix core with split-bf16 operands where that kernel covers the shape."""
+def gn_scale_shift(x_stats, low_stats, C1, C2, B, voxels, gamma, beta, groups, eps, device):
+    """GroupNorm statistics of [x | upsample(low)] from the producers' partial sums -> scale_shift [B,C,2]."""
+    ss = torch.empty((B, C1 + C2, 2), dtype=torch.float32, device=device)
+    p2, n2 = low_stats if low_stats is not None else (None, 0)
+    check(_lib.load().vt_gn_scale_shift(dev_ptr(x_stats[0], "part1"), x_stats[1], C1, dev_ptr(p2, "part2"), n2, C2, B, voxels,
+                                        groups, dev_ptr(_c(gamma), "gamma"), dev_ptr(_c(beta), "beta"), float(eps),
+                                        dev_ptr(ss, "scale_shift"), stream_ptr()), "vt_gn_scale_shift")
+    return ss
+
+
+def conv3d_gcr(x, low, ss, packed_w, Cout, relu=True, packed_w_bf16x3=None, want_stats=True):
+    """relu?(conv3x3x3(x_cat * scale + shift)) on channels-last tensors (``ss`` None: no normalisation);
+    returns (out, (part, nblk) or None).  With ``packed_w_bf16x3`` the convolution runs on the bf16 matrix
+    core with split-bf16 operands where that kernel covers the shape."""
     lib = _lib.load()
     B, D, H, W, C1 = x.shape
     C2 = low.shape[-1] if low is not None else 0
     dev = x.device
-    ss = torch.empty((B, C1 + C2, 2), dtype=torch.float32, device=dev)
     st = stream_ptr()
-    p2, n2 = low_stats if low is not None else (None, 0)
-    check(lib.vt_gn_scale_shift(dev_ptr(x_stats[0], "part1"), x_stats[1], C1, dev_ptr(p2, "part2"), n2, C2, B, D * H * W,
-                                groups, dev_ptr(_c(gamma), "gamma"), dev_ptr(_c(beta), "beta"), float(eps),
-                                dev_ptr(ss, "scale_shift"), st), "vt_gn_scale_shift")
     out = torch.empty((B, D, H, W, Cout), dtype=torch.float32, device=dev)
     nblk = lib.vt_conv3d_stat_blocks_bf16x3(B, D, H, W, C1 + C2, Cout) if packed_w_bf16x3 is not None else 0
-    if nblk:
-        part = torch.empty((B, nblk, Cout, 2), dtype=torch.float32, device=dev)
-        check(lib.vt_conv3d_gcr_bf16x3(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
-                                       dev_ptr(packed_w_bf16x3, "packed_w"), Cout, int(relu), dev_ptr(out, "out"),
-                                       dev_ptr(part, "part"), st), "vt_conv3d_gcr_bf16x3")
-        return out, (part, nblk)
-    nblk = lib.vt_conv3d_stat_blocks(B, D, H, W, C1 + C2, Cout)
-    part = torch.empty((B, nblk, Cout, 2), dtype=torch.float32, device=dev)
-    check(lib.vt_conv3d_gcr(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
-                            dev_ptr(packed_w, "packed_w"), Cout, int(relu), dev_ptr(out, "out"), dev_ptr(part, "part"), st),
-          "vt_conv3d_gcr")
-    return out, (part, nblk)
+    split = nblk != 0
+    if not split:
+        nblk = lib.vt_conv3d_stat_blocks(B, D, H, W, C1 + C2, Cout)
+    part = torch.empty((B, nblk, Cout, 2), dtype=torch.float32, device=dev) if want_stats else None
+    fn, name, pw = (lib.vt_conv3d_gcr_bf16x3, "vt_conv3d_gcr_bf16x3", packed_w_bf16x3) if split else \
+                   (lib.vt_conv3d_gcr, "vt_conv3d_gcr", packed_w)
+    check(fn(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
+             dev_ptr(pw, "packed_w"), Cout, int(relu), dev_ptr(out, "out"), dev_ptr(part, "part"), st), name)
+    return out, ((part, nblk) if want_stats else None)
+
+
+def gn_conv3d_relu(x, x_stats, low, low_stats, gamma, beta, groups, packed_w, Cout, eps=1e-5, relu=True,
+                   packed_w_bf16x3=None):
+    """relu(conv3x3x3(GroupNorm([x | upsample(low)]))) on channels-last tensors; the statistics
+    come from the producers' partial sums.  Returns (out, out_stats)."""
+    B, D, H, W, C1 = x.shape
+    C2 = low.shape[-1] if low is not None else 0
+    ss = gn_scale_shift(x_stats, low_stats if low is not None else None, C1, C2, B, D * H * W, gamma, beta, groups, eps, x.device)
+    return conv3d_gcr(x, low, ss, packed_w, Cout, relu, packed_w_bf16x3)
+
+
+def relu_mask(dy, y):
+    """g = dy where y > 0 else 0 (vt_relu_mask)."""
+    dy = _c(dy)
+    g = torch.empty_like(dy)
+    check(_lib.load().vt_relu_mask(dev_ptr(dy, "dy"), dev_ptr(y, "y"), dev_ptr(g, "g"), dy.numel(), stream_ptr()), "vt_relu_mask")
+    return g
+
+
+def conv3d_wgrad(x, low, ss, g):
+    """dW [Cout,Cin,3,3,3] of the 3x3x3 conv over xn = [x | upsample(low)] * scale + shift (vt_conv3d_wgrad)."""
+    lib = _lib.load()
+    B, D, H, W, C1 = x.shape
+    C2 = low.shape[-1] if low is not None else 0
+    Cout = g.shape[-1]
+    nbytes = lib.vt_conv3d_wgrad_workspace_bytes(B, D, H, W, C1 + C2, Cout)
+    if nbytes == 0:
+        raise VtError("conv3d_wgrad: unsupported shape")
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    dw = torch.empty((Cout, C1 + C2, 3, 3, 3), dtype=torch.float32, device=x.device)
+    check(lib.vt_conv3d_wgrad(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
+                              dev_ptr(g, "g"), Cout, ctypes.c_void_p(ws.data_ptr()), nbytes, dev_ptr(dw, "dw"), stream_ptr()),
+          "vt_conv3d_wgrad")
+    return dw
+
+
+def gn_bwd(x, x_stats, low, low_stats, dxn, gamma, groups, eps, want_skip=True, want_low=True):
+    """GroupNorm backward of xn = GN([x | upsample(low)]) given dxn (vt_gn_bwd): returns
+    (dskip or None, dlow or None, dgamma [C], dbeta [C])."""
+    B, D, H, W, C1 = x.shape
+    C2 = low.shape[-1] if low is not None else 0
+    C = C1 + C2
+    dev = x.device
+    V = D * H * W
+    nblkb = max(1, min(1024, V // 64))
+    bpart = torch.empty((B, nblkb, C, 2), dtype=torch.float32, device=dev)
+    coef = torch.empty((B, C, 3), dtype=torch.float32, device=dev)
+    dgb = torch.empty((B, C, 2), dtype=torch.float32, device=dev)
+    dskip = torch.empty_like(x) if want_skip else None
+    dlow = torch.empty_like(low) if (low is not None and want_low) else None
+    p2, n2 = low_stats if low is not None else (None, 0)
+    check(_lib.load().vt_gn_bwd(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W,
+                                dev_ptr(x_stats[0], "part1"), x_stats[1], dev_ptr(p2, "part2"), n2,
+                                dev_ptr(_c(dxn), "dxn"), groups, dev_ptr(_c(gamma), "gamma"), float(eps),
+                                dev_ptr(bpart, "bpart"), nblkb, dev_ptr(coef, "coef"), dev_ptr(dgb, "dgb"),
+                                dev_ptr(dskip, "dskip"), dev_ptr(dlow, "dlow"), stream_ptr()), "vt_gn_bwd")
+    g = dgb.sum(0)
+    return dskip, dlow, g[:, 0].contiguous(), g[:, 1].contiguous()
+
+
+def maxpool3d_cl_bwd(x, dy):
+    B, D, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.load().vt_maxpool3d_cl_bwd(dev_ptr(x, "x"), dev_ptr(_c(dy), "dy"), B, D, H, W, C, dev_ptr(dx, "dx"), stream_ptr()),
+          "vt_maxpool3d_cl_bwd")
+    return dx
 
 
 def maxpool3d_cl(x):
