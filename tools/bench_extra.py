@@ -104,9 +104,10 @@ if "train" in SECTIONS:
     torch.cuda.synchronize()
     t_first = time.perf_counter() - t0
     t_all = timed(lambda: train_step(True), 5, 1)
-    print(json.dumps({"workload": "train step incl. PointNet+UNet3D (host PyTorch-ROCm autograd, MIOpen find mode), "
-                                  "8 scenes x 2048 pts", "ms": t_all * 1e3, "scenes_per_s": B / t_all,
-                      "first_call_s": t_first}))
+    print(json.dumps({"workload": "train step incl. PointNet+UNet3D, 8 scenes x 2048 pts; UNet3D under autograd = "
+                                  + model.encoder.train_unet3d + (" (convs " + model.encoder.unet3d.train_precision + ")"
+                                                                   if model.encoder.train_unet3d == "hip" else " (MIOpen find mode)"),
+                      "ms": t_all * 1e3, "scenes_per_s": B / t_all, "first_call_s": t_first}))
 model.eval()
 
 # --- dense256: config 5 on one GPU

@@ -1074,15 +1074,26 @@ gn_bwd_coeffs_kernel(StatSrc s1, StatSrc s2, const float *bpart, int nblkb, int 
             sum += mult * (double)p[0]; sq += mult * (double)p[1];
         }
     }
-    // per-channel backward sums: thread t < cpg owns channel g*cpg + t (cpg <= 256)
+    // per-channel backward sums over the partial blocks (fixed order: thread-strided, then a tree)
+    __shared__ double chs[256][2];
     double p1 = 0.0, p2 = 0.0;
-    if ((int)threadIdx.x < cpg) {
-        const int c = g * cpg + threadIdx.x;
-        for (int blk = 0; blk < nblkb; ++blk) {
+    for (int k = 0; k < cpg; ++k) {
+        const int c = g * cpg + k;
+        double a1 = 0.0, a2 = 0.0;
+        for (int blk = threadIdx.x; blk < nblkb; blk += 256) {
             const float *p = bpart + (((size_t)b * nblkb + blk) * C + c) * 2;
-            p1 += (double)p[0]; p2 += (double)p[1];
+            a1 += (double)p[0]; a2 += (double)p[1];
         }
+        red[threadIdx.x][2] = a1; red[threadIdx.x][3] = a2;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) { red[threadIdx.x][2] += red[threadIdx.x + o][2]; red[threadIdx.x][3] += red[threadIdx.x + o][3]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { chs[k][0] = red[0][2]; chs[k][1] = red[0][3]; }
+        __syncthreads();
     }
+    if ((int)threadIdx.x < cpg) { p1 = chs[threadIdx.x][0]; p2 = chs[threadIdx.x][1]; }
     red[threadIdx.x][0] = sum; red[threadIdx.x][1] = sq;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {

@@ -9,6 +9,8 @@ wrapped in autograd Functions whose backward is also HIP.  Plane features
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -88,6 +90,9 @@ class LocalPoolPointnet(nn.Module):
         self.unet3d = UNet3D(**unet3d_kwargs).to(memory_format=torch.channels_last_3d) if unet3d else None
         self.reso_plane, self.reso_grid = plane_resolution, grid_resolution
         self.plane_type, self.padding = plane_type, padding
+        # UNet3D under autograd: "hip" = vt_* forward and backward kernels (UNet3D.forward_channels_last_train),
+        # "host" = PyTorch-ROCm autograd (MIOpen; fast only in find mode, torch.backends.cudnn.benchmark = True)
+        self.train_unet3d = os.environ.get("VTACO_TRAIN_UNET3D", "hip")
 
     def point_features(self, p, vi):
         """fc_pos -> block0 -> 4 x (local max-pool, concat, block) -> fc_c  (pointnet.py:154-162)."""
@@ -107,7 +112,11 @@ class LocalPoolPointnet(nn.Module):
             # and hand the decoder the layout it samples (shape [B,C,R,R,R], channels-last strides)
             grid = self.unet3d.forward_channels_last(ops.voxel_scatter_mean_cl_fwd(feat, vi))
             return {'grid': grid.permute(0, 4, 1, 2, 3)}
+        if self.unet3d is not None and self.unet3d.hip_supported() and self.train_unet3d == "hip":
+            # training on the HIP kernels: differentiable channels-last forward, HIP backward
+            grid_cl = _ScatterMeanCL.apply(feat, vi).permute(0, 2, 3, 4, 1)
+            return {'grid': self.unet3d.forward_channels_last_train(grid_cl).permute(0, 4, 1, 2, 3)}
         if self.unet3d is not None:
-            # training: host PyTorch-ROCm autograd, channels-last end to end
+            # training through host PyTorch-ROCm autograd (MIOpen), channels-last end to end
             return {'grid': self.unet3d(_ScatterMeanCL.apply(feat, vi))}
         return {'grid': _ScatterMean.apply(feat, vi)}
