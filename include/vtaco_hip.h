@@ -141,6 +141,20 @@ int vt_sample_grid(const float *grid_cl, int B, int R, int C, const float *pts, 
 int vt_decode_mlp_fwd(const float *c, int B, int C, const float *pts, int64_t N,
                       int lattice_nx, float lattice_box, int64_t lattice_first,
                       const float *blob, float *out, void *stream);
+/* ... and their training forms (autograd of decoder.py:237-271 around the fuser): the MLP forward   */
+/* that saves activations (save: vt_decode_save_bytes), its backward to the features it was given      */
+/* (grad_c [B,N,C]; parameter gradients: vt_decode_wgrad on the same save/gws), and the backward of     */
+/* vt_sample_grid (scatter-add of grad_feat into grad_grid_cl, which the caller zeroes).                 */
+int vt_decode_mlp_fwd_train(const float *c, int B, int C, const float *pts, int64_t N,
+                            int lattice_nx, float lattice_box, int64_t lattice_first,
+                            const float *blob, float *out, float *save, void *stream);
+int vt_decode_mlp_bwd(int B, int C, const float *pts, int64_t N,
+                      int lattice_nx, float lattice_box, int64_t lattice_first,
+                      const float *blob_t, const float *grad_out, const float *save, float *gws,
+                      float *grad_c, void *stream);
+int vt_sample_grid_bwd(int B, int R, int C, const float *pts, int64_t N,
+                       int lattice_nx, float lattice_box, int64_t lattice_first, double padding,
+                       const float *grad_feat, float *grad_grid_cl, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* TransformerFusion forward (eval mode).                                       */

@@ -106,6 +106,9 @@ SIGNATURES = {
     "vt_conv3d_pack": (_I, [_VP, _I, _I, _VP, _VP]),
     "vt_stats_floats": (_SZ, [_I, _I, _I, _I, _I]),
     "vt_conv3d_stat_blocks": (_I, [_I, _I, _I, _I, _I, _I]),
+    "vt_decode_mlp_fwd_train": (_I, [_VP, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP, _VP]),
+    "vt_decode_mlp_bwd": (_I, [_I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "vt_sample_grid_bwd": (_I, [_I, _I, _I, _VP, _I64, _I, _F, _I64, _D, _VP, _VP, _VP]),
     "vt_relu_mask": (_I, [_VP, _VP, _VP, _I64, _VP]),
     "vt_conv3d_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "vt_conv3d_wgrad": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _SZ, _VP, _VP]),

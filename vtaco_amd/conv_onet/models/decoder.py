@@ -50,6 +50,40 @@ class _DecodeFn(torch.autograd.Function):
         return (None, None, ggrid, gimg, *grads)
 
 
+class _SampleGridFn(torch.autograd.Function):
+    """Trilinear sampling alone (vt_sample_grid / vt_sample_grid_bwd), differentiable in the grid."""
+
+    @staticmethod
+    def forward(ctx, grid, p, padding):
+        ctx.shape, ctx.p, ctx.padding = tuple(grid.shape), p.detach(), padding
+        return ops.sample_grid(grid, p, padding)
+
+    @staticmethod
+    def backward(ctx, grad_feat):
+        return ops.sample_grid_bwd(ctx.shape, ctx.p, grad_feat, ctx.padding), None, None
+
+
+class _DecodeMlpFn(torch.autograd.Function):
+    """The conditioned MLP on given features (vt_decode_mlp_fwd_train; backward vt_decode_mlp_bwd +
+    vt_decode_wgrad): gradients to the features and to every decoder parameter (fc_p form)."""
+
+    @staticmethod
+    def forward(ctx, dec, p, c, *params):
+        out, save = ops.decode_mlp_fwd_train(c, dec._blob(), p)
+        ctx.dec, ctx.save, ctx.p = dec, save, p.detach()
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        dec = ctx.dec
+        grad_c, flat = ops.decode_mlp_bwd(dec._blob_t(img=False), grad_out, ctx.save, ctx.p, dec.c_dim)
+        g = ops.split_decoder_grads(flat, 3)
+        grads = []
+        for key, idx in dec._param_order(False):
+            grads.append(g[key] if idx is None else g[key][idx])
+        return (None, None, grad_c, *grads)
+
+
 class LocalDecoder(nn.Module):
     """Decoder conditioned on a local 3-D feature grid.
 
@@ -198,8 +232,12 @@ class AttentionDecoder(LocalDecoder):
 
     def forward_img(self, p, c_plane, c_img, **kwargs):
         grid = self._grid_of(c_plane)
-        if self._wants_grad(grid, c_img) and self.training:
-            raise VtError("AttentionDecoder.forward_img: training through the fuser is not built")
+        if self._wants_grad(grid, c_img):
+            # under autograd: HIP sampling and MLP (forward + backward kernels) around the fuser's
+            # host-PyTorch form (train-mode dropout and its backward come from torch)
+            c = _SampleGridFn.apply(grid, p, self.padding)
+            c = self.fuser.forward_torch(c_img, c)
+            return _DecodeMlpFn.apply(self, p, c, *self._params(False))
         c = ops.sample_grid(grid, p, self.padding)
         c = self.fuser(c_img, 1, c, 1)
         return ops.decode_mlp_fwd(c, self._blob(), p)

@@ -755,6 +755,14 @@ int vt_decode_mlp_fwd(const float *c, int B, int C, const float *pts, int64_t N,
                          out, nullptr, nullptr, stream);
 }
 
+int vt_decode_mlp_fwd_train(const float *c, int B, int C, const float *pts, int64_t N,
+                            int lattice_nx, float lattice_box, int64_t lattice_first,
+                            const float *blob, float *out, float *save, void *stream) {
+    if (!c || !save) return vt_fail(VT_ERR_INVALID, "vt_decode_mlp_fwd_train: null argument");
+    return decode_launch(nullptr, c, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, nullptr, nullptr, blob, 0.1,
+                         out, nullptr, save, stream);
+}
+
 int vt_sample_grid(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
                    int lattice_nx, float lattice_box, int64_t lattice_first, double padding,
                    float *feat, void *stream) {

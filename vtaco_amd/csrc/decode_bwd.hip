@@ -61,6 +61,7 @@ struct BwdArgs {
     float *gws;              // [11][total][32]
     float *grad_grid;        // [B,R,R,R,32] channels-last, accumulated
     float *grad_c_img;       // [total][32] or null
+    float *grad_c;           // [total][32] or null: d(sampled features), for callers that transform them
 };
 
 template <int THREADS>
@@ -137,6 +138,7 @@ decode_bwd_data_kernel(BwdArgs a) {
             if (live) store_gather16(a.grad_c_img + (size_t)g * 32, di, h);
         }
 
+        if (live && a.grad_c) store_gather16(a.grad_c + (size_t)g * 32, dc, h);
         // ---- d grid: scatter d c (channels 16h..16h+15 on this lane) to the 8 corners ----
         if (live && a.grad_grid) {
             const uint32_t b = g / a.d.N, n = g - b * a.d.N;
@@ -153,6 +155,34 @@ decode_bwd_data_kernel(BwdArgs a) {
 #pragma unroll
                     for (int s = 0; s < 16; ++s) atomicAdd(dst + s, w * dc[s]);
                 }
+            }
+        }
+    }
+}
+
+// backward of vt_sample_grid alone: scatter d feat [total][32] to the 8 corners of every point
+__global__ void __launch_bounds__(256)
+sample_grid_bwd_kernel(DecodeArgs d, const float *grad_feat, float *grad_grid) {
+    const int lane = threadIdx.x & 63, pl = lane & 31, h = lane >> 5;
+    const uint32_t ntiles = (d.total + 31u) >> 5;
+    const int R = d.R;
+    for (uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += gridDim.x * 4) {
+        const uint32_t g = tile * 32u + pl;
+        if (g >= d.total) continue;
+        const uint32_t b = g / d.N, n = g - b * d.N;
+        float px, py, pz;
+        point_of(d, g, n, px, py, pz);
+        const Tri t = tri_setup(px, py, pz, d.divisor, R);
+        const f32x16 dc = load_frag16(grad_feat + (size_t)g * 32 + 16 * h);
+        float *gb = grad_grid + (size_t)b * R * R * R * 32 + 16 * h;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int zz = (k & 4) ? t.z1 : t.z0, yy = (k & 2) ? t.y1 : t.y0, xx = (k & 1) ? t.x1 : t.x0;
+            const float w = (((k & 1) ? t.wx1 : t.wx0) * ((k & 2) ? t.wy1 : t.wy0)) * ((k & 4) ? t.wz1 : t.wz0);
+            if (w != 0.0f) {
+                float *dst = gb + (((size_t)zz * R + yy) * R + xx) * 32;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) atomicAdd(dst + s, w * dc[s]);
             }
         }
     }
@@ -301,15 +331,7 @@ int vt_decoder_pack_t(const vt_decoder_params *p, float *blob, size_t blob_bytes
 size_t vt_decode_save_bytes(int64_t total_points) { return (size_t)VT_SAVE_SLOTS * (size_t)total_points * 32 * sizeof(float); }
 size_t vt_decode_gws_bytes(int64_t total_points) { return (size_t)VT_GWS_SLOTS * (size_t)total_points * 32 * sizeof(float); }
 
-int vt_decode_bwd(int B, int R, int C, const float *pts, int64_t N,
-                  int lattice_nx, float lattice_box, int64_t lattice_first, double padding,
-                  const float *blob_t, const float *grad_out, const float *save, float *gws,
-                  float *grad_grid_cl, float *grad_c_img, void *stream) {
-    if (!blob_t || !grad_out || !save || !gws) return vt_fail(VT_ERR_INVALID, "vt_decode_bwd: null argument");
-    BwdArgs a;
-    int rc;
-    if (!fill_decode_args(a.d, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, padding, "vt_decode_bwd: bad size", rc)) return rc;
-    a.blobT = blob_t; a.grad_out = grad_out; a.save = save; a.gws = gws; a.grad_grid = grad_grid_cl; a.grad_c_img = grad_c_img;
+static int decode_bwd_launch(BwdArgs &a, void *stream) {
     constexpr int THREADS = 512;
     const int64_t ntiles = ((int64_t)a.d.total + 31) / 32;
     int64_t blocks = (ntiles + THREADS / 64 - 1) / (THREADS / 64);
@@ -325,6 +347,46 @@ int vt_decode_bwd(int B, int R, int C, const float *pts, int64_t N,
     }
     hipLaunchKernelGGL(decode_bwd_data_kernel<THREADS>, dim3((unsigned)blocks), dim3(THREADS), lds_bytes, (hipStream_t)stream, a);
     return vt_check(hipGetLastError(), "vt_decode_bwd");
+}
+
+int vt_decode_bwd(int B, int R, int C, const float *pts, int64_t N,
+                  int lattice_nx, float lattice_box, int64_t lattice_first, double padding,
+                  const float *blob_t, const float *grad_out, const float *save, float *gws,
+                  float *grad_grid_cl, float *grad_c_img, void *stream) {
+    if (!blob_t || !grad_out || !save || !gws) return vt_fail(VT_ERR_INVALID, "vt_decode_bwd: null argument");
+    BwdArgs a;
+    int rc;
+    if (!fill_decode_args(a.d, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, padding, "vt_decode_bwd: bad size", rc)) return rc;
+    a.blobT = blob_t; a.grad_out = grad_out; a.save = save; a.gws = gws; a.grad_grid = grad_grid_cl; a.grad_c_img = grad_c_img;
+    a.grad_c = nullptr;
+    return decode_bwd_launch(a, stream);
+}
+
+int vt_decode_mlp_bwd(int B, int C, const float *pts, int64_t N,
+                      int lattice_nx, float lattice_box, int64_t lattice_first,
+                      const float *blob_t, const float *grad_out, const float *save, float *gws,
+                      float *grad_c, void *stream) {
+    if (!blob_t || !grad_out || !save || !gws || !grad_c) return vt_fail(VT_ERR_INVALID, "vt_decode_mlp_bwd: null argument");
+    BwdArgs a;
+    int rc;
+    if (!fill_decode_args(a.d, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, 0.1, "vt_decode_mlp_bwd: bad size", rc)) return rc;
+    a.blobT = blob_t; a.grad_out = grad_out; a.save = save; a.gws = gws; a.grad_grid = nullptr; a.grad_c_img = nullptr;
+    a.grad_c = grad_c;
+    return decode_bwd_launch(a, stream);
+}
+
+int vt_sample_grid_bwd(int B, int R, int C, const float *pts, int64_t N,
+                       int lattice_nx, float lattice_box, int64_t lattice_first, double padding,
+                       const float *grad_feat, float *grad_grid_cl, void *stream) {
+    if (!grad_feat || !grad_grid_cl) return vt_fail(VT_ERR_INVALID, "vt_sample_grid_bwd: null argument");
+    DecodeArgs d;
+    int rc;
+    if (!fill_decode_args(d, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, padding, "vt_sample_grid_bwd: bad size", rc)) return rc;
+    int64_t blocks = (((int64_t)d.total + 31) / 32 + 3) / 4;
+    const int64_t cap = 8 * vt_num_cus();
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(sample_grid_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d, grad_feat, grad_grid_cl);
+    return vt_check(hipGetLastError(), "vt_sample_grid_bwd");
 }
 
 size_t vt_decode_wgrad_workspace_bytes(int64_t total_points) {

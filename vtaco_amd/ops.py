@@ -417,6 +417,53 @@ def sample_grid(grid, pts, padding=0.1):
     return feat
 
 
+def sample_grid_bwd(grid_shape, pts, grad_feat, padding=0.1):
+    """Backward of :func:`sample_grid` w.r.t. the grid (vt_sample_grid_bwd): [B,C,R,R,R] with channels-last strides."""
+    B, C, R = grid_shape[0], grid_shape[1], grid_shape[2]
+    pts = _c(pts.float())
+    grad_feat = _c(grad_feat.float())
+    ggrid = torch.zeros((B, R, R, R, C), dtype=torch.float32, device=grad_feat.device)
+    check(_lib.load().vt_sample_grid_bwd(B, R, C, dev_ptr(pts, "pts"), pts.shape[1], 0, 0.0, 0, float(padding),
+                                         dev_ptr(grad_feat, "grad_feat"), dev_ptr(ggrid, "grad_grid"), stream_ptr()),
+          "vt_sample_grid_bwd")
+    return ggrid.permute(0, 4, 1, 2, 3)
+
+
+def decode_mlp_fwd_train(c, blob, pts):
+    """:func:`decode_mlp_fwd` that also returns the activations its backward needs (vt_decode_mlp_fwd_train)."""
+    lib = _lib.load()
+    c = _c(c)
+    pts = _c(pts.float())
+    B, N, C = c.shape
+    out = torch.empty((B, N), dtype=torch.float32, device=c.device)
+    save = torch.empty(lib.vt_decode_save_bytes(B * N) // 4, dtype=torch.float32, device=c.device)
+    check(lib.vt_decode_mlp_fwd_train(dev_ptr(c, "c"), B, C, dev_ptr(pts, "pts"), N, 0, 0.0, 0,
+                                      dev_ptr(blob, "blob"), dev_ptr(out, "out"), dev_ptr(save, "save"), stream_ptr()),
+          "vt_decode_mlp_fwd_train")
+    return out, save
+
+
+def decode_mlp_bwd(blob_t, grad_out, save, pts, C=32):
+    """vt_decode_mlp_bwd + vt_decode_wgrad: (grad_c [B,N,C], flat parameter gradients with p_in = 3)."""
+    lib = _lib.load()
+    pts = _c(pts.float())
+    grad_out = _c(grad_out.float())
+    B, N = grad_out.shape
+    dev = grad_out.device
+    total = B * N
+    gws = torch.empty(lib.vt_decode_gws_bytes(total) // 4, dtype=torch.float32, device=dev)
+    grad_c = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+    st = stream_ptr()
+    check(lib.vt_decode_mlp_bwd(B, C, dev_ptr(pts, "pts"), N, 0, 0.0, 0, dev_ptr(blob_t, "blob_t"), dev_ptr(grad_out, "grad_out"),
+                                dev_ptr(save, "save"), dev_ptr(gws, "gws"), dev_ptr(grad_c, "grad_c"), st), "vt_decode_mlp_bwd")
+    wsb = lib.vt_decode_wgrad_workspace_bytes(total)
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+    flat = torch.empty(lib.vt_decode_wgrad_floats(3), dtype=torch.float32, device=dev)
+    check(lib.vt_decode_wgrad(B, dev_ptr(pts, "pts"), N, 0, 0.0, 0, None, dev_ptr(grad_out, "grad_out"), dev_ptr(save, "save"),
+                              dev_ptr(gws, "gws"), ctypes.c_void_p(ws.data_ptr()), wsb, dev_ptr(flat, "grads"), st), "vt_decode_wgrad")
+    return grad_c, flat
+
+
 def decode_mlp_fwd(c, blob, pts):
     """The conditioned MLP on given features c [B,N,C] (vt_decode_mlp_fwd)."""
     c = _c(c)

@@ -4,8 +4,9 @@ Keeps the reference's parameter tree -- ``encoder.layers.0.self_attn.head.0.{WK,
 trans_conv,after_norm}``, ``...extra_nonlinear.0.{linear1,linear2,norm2}``,
 ``decoder.layers.0.{self_attn,cross_attn}...`` -- including the fact that the encoder
 layer and the decoder layer's self-attention are the SAME module (state_dict lists it
-under both names).  The forward is the HIP pipeline ``vt_fusion_fwd`` (eval mode: the
-reference's dropout layers are identity there; training of the fuser is not built).
+under both names).  Without autograd the forward is the HIP pipeline ``vt_fusion_fwd`` (eval
+mode: the reference's dropout layers are identity there); under autograd it is the same
+arithmetic as host-PyTorch ops (``forward_torch``: train-mode dropout, torch's backward).
 """
 from __future__ import annotations
 
@@ -13,6 +14,8 @@ import math
 
 import torch
 from torch import nn
+
+from torch.nn import functional as F
 
 from . import ops
 from ._lib import VtError
@@ -37,6 +40,7 @@ class TransNonlinear(nn.Module):
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.linear2 = nn.Linear(dim_feedforward, d_model)
         self.norm2 = nn.LayerNorm(d_model)
+        self.p_drop = dropout                 # the reference's `dropout` and `dropout2` (TransformerFusion.py:13-23)
 
 
 class MultiheadAttention(nn.Module):
@@ -47,6 +51,18 @@ class MultiheadAttention(nn.Module):
         self.Nh = n_head
         self.head = nn.ModuleList([RelationUnit(feature_dim, key_feature_dim)])
         self.extra_nonlinear = nn.ModuleList([TransNonlinear(feature_dim, key_feature_dim)])
+
+    def forward_torch(self, q, k, v):
+        """RelationUnit + TransNonlinear as differentiable torch ops on [B,N,C] tensors
+        (TransformerFusion.py:92-113, 21-25); dropout is active in training mode only."""
+        h, e = self.head[0], self.extra_nonlinear[0]
+        wk = F.normalize(h.WK(k), p=2, dim=-1)
+        wq = F.normalize(h.WQ(q), p=2, dim=-1)
+        aff = F.softmax(torch.bmm(wq, wk.transpose(1, 2)), dim=-1)
+        aff = aff / (1e-9 + aff.sum(dim=1, keepdim=True))                    # the reference's column re-normalisation
+        r = F.relu(h.trans_conv(q - torch.bmm(aff, h.WV(v))))
+        y = e.linear2(F.dropout(F.relu(e.linear1(r)), e.p_drop, self.training))
+        return e.norm2(r + F.dropout(y, e.p_drop, self.training))
 
     def unit_tensors(self):
         h, e = self.head[0], self.extra_nonlinear[0]
@@ -81,10 +97,26 @@ class TransformerFusion(nn.Module):
         self.decoder = _Stack(_Layer(shared, MultiheadAttention(feature_dim=d_model, n_head=1,
                                                                 key_feature_dim=key_feature_dim)))
 
+    @staticmethod
+    def _inorm_relu(x):
+        m = x.mean(dim=1, keepdim=True)
+        return F.relu((x - m) / torch.sqrt(x.var(dim=1, unbiased=False, keepdim=True) + 1e-5))
+
+    def forward_torch(self, search_feature, template_feature):
+        """The same fusion as differentiable host-PyTorch ops (training: the HIP pipeline has no backward).
+        InstanceNorm1d over the N points, no affine (TransformerFusion.py:144-145, 209-218)."""
+        layer = self.decoder.layers[0]
+        sa, ca = layer.self_attn, layer.cross_attn
+        c, ci = template_feature, search_feature
+        mem = self._inorm_relu(c + sa.forward_torch(c, c, c))
+        tgt = self._inorm_relu(ci + sa.forward_torch(ci, ci, ci))
+        return self._inorm_relu(tgt + ca.forward_torch(tgt, mem, mem))
+
     def forward(self, search_feature, search_coord, template_feature, template_coord):
         """fuse(search=c_img [B,N,C], template=c [B,N,C]) -> [B,N,C]  (TransformerFusion.py:311-333)."""
-        if self.training and torch.is_grad_enabled():
-            raise VtError("TransformerFusion: only the eval-mode forward is built (train-mode dropout + backward: not yet)")
+        if torch.is_grad_enabled() and (self.training or search_feature.requires_grad or template_feature.requires_grad
+                                        or any(p.requires_grad for p in self.parameters())):
+            return self.forward_torch(search_feature, template_feature)
         layer = self.decoder.layers[0]
         return ops.fusion_fwd(search_feature, template_feature, layer.self_attn.unit_tensors(),
                               layer.cross_attn.unit_tensors())
