@@ -105,7 +105,7 @@ def stage_times(scene, dec, grid, nx, out, dev, precision):
     return res
 
 
-PMC_SUMMARY = os.path.join("profiles", "r01e_pmc_summary.csv")
+PMC_SUMMARY = os.path.join("profiles", "r01f_pmc_summary.csv")
 
 
 def measured_traffic(precision):
