@@ -159,12 +159,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; VTACO_BENCH_BACKEND=gloo lets the multi-process path be dry-run on a box with fewer
+    # GPUs than ranks (ranks then share devices; RCCL refuses that)
+    backend = os.environ.get("VTACO_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from vtaco_amd import ops
     scene = synthetic_scene(rank, dev)
@@ -195,7 +202,7 @@ def main():
     fence()
     wall = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps      # HIP events on the launch stream
-    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    t = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = float(t.item())
