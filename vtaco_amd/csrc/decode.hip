@@ -466,6 +466,22 @@ __global__ void decoder_pack_kernel(PackArgs a) {
     const vt_decoder_params &p = a.p;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < VT_BLOB_FLOATS; e += gridDim.x * blockDim.x) {
         float v = 0.0f;
+        if (e >= VT_OFF_BFRAG) {
+            // bias fragment of block blk: lane (i, kg), elements 0..2 of kg = 0 carry hi / mid / lo
+            const int q = e - VT_OFF_BFRAG, blk = q >> 8, l = (q >> 2) & 63, m = q & 3, i = l & 31, kg = l >> 5;
+            unsigned bits = 0;
+            if (a.split && kg == 0 && m < 2) {
+                const float bv = p.fc1_b[blk][i] + ((blk < 4) ? p.fc_c_b[blk + 1][i] : 0.0f);
+                const __bf16 hb = (__bf16)bv;
+                const float r1 = bv - (float)hb;
+                const __bf16 mb = (__bf16)r1;
+                const __bf16 lb = (__bf16)(r1 - (float)mb);
+                if (m == 0) bits = (unsigned)__builtin_bit_cast(unsigned short, hb) | ((unsigned)__builtin_bit_cast(unsigned short, mb) << 16);
+                else bits = (unsigned)__builtin_bit_cast(unsigned short, lb);
+            }
+            a.blob[e] = __builtin_bit_cast(float, bits);
+            continue;
+        }
         if (a.split && e >= VT_OFF_WL) {
             // layer image [part hi|lo][k-step][lane][8 bf16]; one float slot = elements 2m, 2m+1.
             // k of element j: the accumulator register 8s+j of lane-half h (or, for the layers

@@ -17,7 +17,10 @@ constexpr int VT_OFF_WP = VT_OFF_OUT + 64 + 32;
 constexpr int VT_OFF_WL = VT_OFF_WP + 128;
 // fc_p_img columns 3..34 (tactile concat): [16][64]
 constexpr int VT_OFF_WPI = VT_OFF_WL + 15 * 1024;
-constexpr int VT_BLOB_FLOATS = VT_OFF_WPI + 1024;
+// split-bf16 blob only: the five block-end biases as A fragments of one 32x32x16 bf16 MFMA each
+// ([64 lanes][8 bf16]; k-slots 0..2 = bf16 hi/mid/lo of the bias, against a B operand of ones)
+constexpr int VT_OFF_BFRAG = VT_OFF_WPI + 1024;
+constexpr int VT_BLOB_FLOATS = VT_OFF_BFRAG + 5 * 256;
 static_assert(VT_BLOB_FLOATS % 4 == 0, "blob is copied as float4");
 static_assert((VT_OFF_WPI) * 4 <= 65536, "visual-only fragments must sit below the 64 KiB ds_read offset limit");
 
