@@ -422,6 +422,206 @@ decode_fwd_staged_kernel(DecodeArgs a) {
     }
 }
 
+// ---- two bricks per wave (split-bf16, visual-only lattice) ---------------------------------------
+// Same staged gather, but a wave owns a 2 x 4 x 8 double brick = two 32-point MFMA column groups A and B
+// that share every weight fragment (half the LDS weight reads per point) and whose dependent
+// MFMA / split chains interleave inside the wave: while A's six MFMAs of a layer are in the matrix
+// pipe, B's relu + hi/lo split issues on the VALU, without relying on another wave being in the
+// complementary phase.  Footprint 3 x 4 x 6 voxels (72 rows: 24 runs of 384 bytes, nine coalesced
+// loads); eight waves per CU use the same LDS as the twelve single-brick images.  Same per-point
+// operation sequence as the other paths; the logits agree with them to the last bit for ~96 % of the
+// points and to 1 ulp for the rest (running the two MLPs one after the other instead of interleaved is
+// bit-identical -- and no faster).  Conditions: nx % 8 == 0, voxels per step < 0.55.
+constexpr int ST2_ROWS = 72;
+constexpr int ST2_WAVE_BYTES = ST2_ROWS * ST_ROW_BYTES;
+constexpr int ST2_THREADS = 512;
+constexpr int ST2_PIECES = 9;
+
+__device__ __forceinline__ void dense32s2(f32x16 &accA, f32x16 &accB, const float *wl, const Split16 &xA, const Split16 &xB, int lane) {
+    const bf16x8 *w = reinterpret_cast<const bf16x8 *>(wl);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const bf16x8 wh = w[s * 64 + lane], wo = w[(2 + s) * 64 + lane];
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo, xA.hi[s], accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo, xB.hi[s], accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xA.lo[s], accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xB.lo[s], accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xA.hi[s], accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xB.hi[s], accB, 0, 0, 0);
+    }
+}
+
+__global__ void __launch_bounds__(ST2_THREADS)
+decode_fwd_staged2_kernel(DecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.blob);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
+        for (int i = threadIdx.x; i < VT_BLOB_FLOATS / 4; i += ST2_THREADS) dst[i] = src[i];
+    }
+    const int R = a.R;
+    AxisEnt *tab = reinterpret_cast<AxisEnt *>(lds + VT_BLOB_FLOATS);
+    for (int i = threadIdx.x; i < a.nx; i += ST2_THREADS) {
+        float p, unused0, unused1;
+        lattice_point(a, (uint32_t)i, 0u, 0u, p, unused0, unused1);
+        const float f = grid_coord(p, a.divisor, R);
+        const float f0 = floorf(f);
+        AxisEnt e;
+        e.i0 = (int)f0;
+        e.w0 = (f0 + 1.0f) - f;
+        e.i1 = min(e.i0 + 1, R - 1);
+        e.w1 = (e.i0 + 1 <= R - 1) ? f - f0 : 0.0f;
+        tab[i] = e;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int pl = lane & 31;
+    const int h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int WPB = ST2_THREADS / 64;
+    const uint32_t ntiles = a.total >> 6;                                // double bricks
+    const uint32_t nx = (uint32_t)a.nx;
+    const uint32_t tpb = a.N >> 6, q4 = nx >> 2, q8 = nx >> 3;
+    const uint32_t plane0 = a.lattice_first / (nx * nx);
+    char *stage = reinterpret_cast<char *>(lds + VT_BLOB_FLOATS + 4 * a.nx) + wave * ST2_WAVE_BYTES;
+
+    uint32_t src_off[ST2_PIECES], dst_off[ST2_PIECES];
+#pragma unroll
+    for (int k = 0; k < ST2_PIECES; ++k) {
+        const int m = 64 * k + lane, run = m / 24, q = m - 24 * run;      // 24 runs (dz 0..5, dy 0..3) x 24 chunks
+        const int dz = run >> 2, dy = run & 3;
+        src_off[k] = (uint32_t)((dz * R + dy) * R) * 128u + (uint32_t)q * 16u;
+        dst_off[k] = (uint32_t)(((dz * 4 + dy) * 3 + (q >> 3)) * ST_ROW_BYTES + (q & 7) * 16);
+    }
+
+    uint32_t t_begin = 0, t_end = ntiles, w_idx = blockIdx.x * WPB + wave, w_cnt = gridDim.x * WPB;
+    if ((gridDim.x & 7u) == 0 && ntiles >= 8u * WPB) {                  // XCD-aware order, as decode_fwd_kernel
+        const uint32_t chunk = (ntiles + 7u) >> 3, xcd = blockIdx.x & 7u;
+        t_begin = min(xcd * chunk, ntiles);
+        t_end = min(t_begin + chunk, ntiles);
+        w_idx = (blockIdx.x >> 3) * WPB + wave;
+        w_cnt = (gridDim.x >> 3) * WPB;
+    }
+    auto brick_of = [&](uint32_t tile, uint32_t &b, uint32_t &X0, uint32_t &Y0, uint32_t &Z0) {
+        b = tile / tpb;
+        const uint32_t t = tile - b * tpb;
+        const uint32_t pp = t / (q4 * q8), rem = t - pp * q4 * q8;
+        const uint32_t by = rem / q8, bz = rem - by * q8;
+        X0 = 2u * pp; Y0 = 4u * by; Z0 = 8u * bz;
+    };
+    f32x4 pre[ST2_PIECES];
+    int ox = 0, oy = 0, oz = 0;
+    auto fetch = [&](uint32_t tile, int &fx, int &fy, int &fz) {
+        uint32_t b, X0, Y0, Z0;
+        brick_of(tile, b, X0, Y0, Z0);
+        fx = min(__builtin_amdgcn_readfirstlane(tab[plane0 + X0].i0), R - 3);
+        fy = min(__builtin_amdgcn_readfirstlane(tab[Y0].i0), R - 4);
+        fz = min(__builtin_amdgcn_readfirstlane(tab[Z0].i0), R - 6);
+        const uint64_t bp = reinterpret_cast<uint64_t>(a.grid + ((((size_t)b * R + fz) * R + fy) * R + fx) * 32);
+        const char *base = reinterpret_cast<const char *>(
+            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bp >> 32)) << 32) |
+            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bp));
+#pragma unroll
+        for (int k = 0; k < ST2_PIECES; ++k) pre[k] = *reinterpret_cast<const f32x4 *>(base + src_off[k]);
+    };
+
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)((h == 0 && e < 3) ? 1.0f : 0.0f);
+
+    uint32_t tile = t_begin + w_idx;
+    if (tile < t_end) fetch(tile, ox, oy, oz);
+    for (; tile < t_end; tile += w_cnt) {
+        unsigned lds_off = 0;
+        asm volatile("" : "+v"(lds_off));
+        const float *L = lds + lds_off;
+#pragma unroll
+        for (int k = 0; k < ST2_PIECES; ++k) *reinterpret_cast<f32x4 *>(stage + dst_off[k]) = pre[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        uint32_t b, X0, Y0, Z0;
+        brick_of(tile, b, X0, Y0, Z0);
+        const uint32_t ixl = X0 + (uint32_t)(pl >> 4), iy = Y0 + (uint32_t)((pl >> 2) & 3), izA = Z0 + (uint32_t)(pl & 3), izB = izA + 4u;
+        const uint32_t gA = b * a.N + (ixl * nx + iy) * nx + izA, gB = gA + 4u;
+        float px, py, pzA, pzB, unused0, unused1;
+        lattice_point(a, plane0 + ixl, iy, izA, px, py, pzA);
+        lattice_point(a, plane0 + ixl, iy, izB, unused0, unused1, pzB);
+        const AxisEnt ex = tab[plane0 + ixl], ey = tab[iy], ezA = tab[izA], ezB = tab[izB];
+        const int rx0 = ex.i0 - ox, rx1 = ex.i1 - ox;
+        const int ry0 = (ey.i0 - oy) * 3, ry1 = (ey.i1 - oy) * 3;
+        const char *img = stage + 64 * h;
+        auto gather = [&](const AxisEnt &ez) {
+            f32x16 c;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) c[s] = 0.0f;
+            const int rz0 = (ez.i0 - oz) * 12, rz1 = (ez.i1 - oz) * 12;
+            auto plane = [&](int rz, float wz) {
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    const int ry = dy ? ry1 : ry0;
+                    const float wy = dy ? ey.w1 : ey.w0;
+                    const f32x16 v0 = load_frag16(reinterpret_cast<const float *>(img + (rz + ry + rx0) * ST_ROW_BYTES));
+                    const f32x16 v1 = load_frag16(reinterpret_cast<const float *>(img + (rz + ry + rx1) * ST_ROW_BYTES));
+                    const float w0 = (ex.w0 * wy) * wz;
+                    const float w1 = (ex.w1 * wy) * wz;
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) c[s] = fmaf(v0[s], w0, c[s]);
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) c[s] = fmaf(v1[s], w1, c[s]);
+                }
+            };
+            plane(rz0, ez.w0);
+            pin16(c);
+            __builtin_amdgcn_sched_barrier(0);
+            plane(rz1, ez.w1);
+            pin16(c);
+            __builtin_amdgcn_sched_barrier(0);
+            return c;
+        };
+        const f32x16 cA = gather(ezA);
+        const f32x16 cB = gather(ezB);
+        if (tile + w_cnt < t_end) fetch(tile + w_cnt, ox, oy, oz);
+
+        // ---- MLP on both column groups (mlp_and_heads<false, true>, visual-only, two chains) ----
+        const f32x16 b0 = load_frag16(L + VT_OFF_BIAS + h * 16);
+        f32x16 netA = b0, netB = b0;
+        {
+            const float k0 = h ? py : px;
+            const float wp0 = L[VT_OFF_WP + lane], wp1 = L[VT_OFF_WP + 64 + lane];
+            netA = mfma(wp0, k0, netA);
+            netB = mfma(wp0, k0, netB);
+            netA = mfma(wp1, h ? 0.0f : pzA, netA);
+            netB = mfma(wp1, h ? 0.0f : pzB, netB);
+        }
+        const Split16 csA = split16<false>(cA), csB = split16<false>(cB);
+        dense32s2(netA, netB, L + VT_OFF_WL, csA, csB, lane);
+#pragma unroll 1
+        for (int i = 0; i < 5; ++i) {
+            const float *wl = L + VT_OFF_WL + (1 + 3 * i) * 1024;
+            const f32x16 hb = load_frag16(L + VT_OFF_BIAS + (1 + 2 * i) * 32 + h * 16);
+            f32x16 hidA = hb, hidB = hb;
+            dense32s2(hidA, hidB, wl, split16<true>(netA), split16<true>(netB), lane);
+            dense32s2(netA, netB, wl + 1024, split16<true>(hidA), split16<true>(hidB), lane);
+            if (i < 4) dense32s2(netA, netB, wl + 2048, csA, csB, lane);
+            const bf16x8 bf = reinterpret_cast<const bf16x8 *>(L + VT_OFF_BFRAG + i * 256)[lane];
+            netA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, ones, netA, 0, 0, 0);
+            netB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, ones, netB, 0, 0, 0);
+        }
+        {
+            const f32x16 wo = load_frag16(L + VT_OFF_OUT + h * 16);
+            float accA = 0.0f, accB = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { accA = fmaf(relu1(netA[s]), wo[s], accA); accB = fmaf(relu1(netB[s]), wo[s], accB); }
+            accA += __shfl_xor(accA, 32);
+            accB += __shfl_xor(accB, 32);
+            const float ob = L[VT_OFF_OUT + 64];
+            if (h == 0) { a.out[gA] = accA + ob; a.out[gB] = accB + ob; }
+        }
+    }
+}
+
 // ---- trilinear gather only: feat[b,n,:] = grid sampled at the query point -----------------
 __global__ void __launch_bounds__(256) sample_grid_kernel(DecodeArgs a, float *feat) {
     const int lane = threadIdx.x & 63, pl = lane & 31, h = lane >> 5;
@@ -680,9 +880,28 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
     // LDS-staged gather (decode_fwd_staged_kernel) when the brick footprint is bounded by 3 x 4 x 4 voxels:
     // voxels per lattice step s = (R-1) * box / ((nx-1) * divisor) < 2/3 (0.496 at 128^3 / R=64)
     static const bool force_direct = getenv("VTACO_DECODE_DIRECT") != nullptr;       // A/B knob for tests and benches
+    const bool with_any_img = c_img != nullptr || cimg_ids != nullptr;
     if (a.brick && !force_direct && R >= 4 && lattice_nx <= 512 && !c_direct) {
         const double s_vox = (double)(R - 1) * (double)lattice_box / ((double)(lattice_nx - 1) * (double)a.divisor);
         const size_t lds_st = ((size_t)VT_BLOB_FLOATS + 4u * (size_t)lattice_nx + (size_t)(ST_THREADS / 64) * ST_WAVE_FLOATS) * sizeof(float);
+        const size_t lds_st2 = ((size_t)VT_BLOB_FLOATS + 4u * (size_t)lattice_nx) * sizeof(float) + (size_t)(ST2_THREADS / 64) * ST2_WAVE_BYTES;
+        static const bool no_pair = getenv("VTACO_DECODE_NO_PAIR") != nullptr;    // A/B knob
+        if (split && !no_pair && !with_any_img && !out2 && (lattice_nx & 7) == 0 && R >= 6 && s_vox > 0.0 && s_vox < 0.55 &&
+            lds_st2 <= 160u * 1024u) {
+            const int64_t nt = (int64_t)a.total / 64;
+            int64_t blocks = (nt + ST2_THREADS / 64 - 1) / (ST2_THREADS / 64);
+            if (blocks > vt_num_cus()) blocks = vt_num_cus();
+            if (blocks > 8) blocks &= ~7ll;
+            static bool st2_attr = false;
+            if (!st2_attr) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged2_kernel),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute (staged2)");
+                st2_attr = true;
+            }
+            hipLaunchKernelGGL(decode_fwd_staged2_kernel, dim3((unsigned)blocks), dim3(ST2_THREADS), lds_st2, (hipStream_t)stream, a);
+            return vt_check(hipGetLastError(), "vt_decode_fwd");
+        }
         if (s_vox > 0.0 && s_vox < 0.66 && lds_st <= 160u * 1024u) {
             const int64_t nt = (int64_t)a.total / 32;
             int64_t blocks = (nt + ST_THREADS / 64 - 1) / (ST_THREADS / 64);
