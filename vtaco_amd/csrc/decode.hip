@@ -422,7 +422,7 @@ decode_fwd_staged_kernel(DecodeArgs a) {
     }
 }
 
-// ---- two bricks per wave (split-bf16, visual-only lattice) ---------------------------------------
+// ---- two bricks per wave (split-bf16 lattice: visual-only, tactile concat, finger ids) -------------
 // Same staged gather, but a wave owns a 2 x 4 x 8 double brick = two 32-point MFMA column groups A and B
 // that share every weight fragment (half the LDS weight reads per point) and whose dependent
 // MFMA / split chains interleave inside the wave: while A's six MFMAs of a layer are in the matrix
@@ -594,6 +594,22 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
             netB = mfma(wp0, k0, netB);
             netA = mfma(wp1, h ? 0.0f : pzA, netA);
             netB = mfma(wp1, h ? 0.0f : pzB, netB);
+        }
+        if (a.cimg_ids) {
+            // tactile feature by finger id: most double bricks touch no finger and skip the layer
+            const unsigned idA = a.cimg_ids[gA], idB = a.cimg_ids[gB];
+            if (__ballot(idA != 255u || idB != 255u) != 0ull) {
+                f32x16 ciA, ciB;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) { ciA[s] = 0.0f; ciB[s] = 0.0f; }
+                if (idA != 255u) ciA = load_frag16(a.cimg_table + (size_t)idA * 32 + 16 * h);
+                if (idB != 255u) ciB = load_frag16(a.cimg_table + (size_t)idB * 32 + 16 * h);
+                dense32s2(netA, netB, L + VT_OFF_WPI, split16<false>(ciA), split16<false>(ciB), lane);
+            }
+        } else if (a.c_img) {
+            const f32x16 ciA = load_frag16(a.c_img + (size_t)gA * 32 + 16 * h);
+            const f32x16 ciB = load_frag16(a.c_img + (size_t)gB * 32 + 16 * h);
+            dense32s2(netA, netB, L + VT_OFF_WPI, split16<false>(ciA), split16<false>(ciB), lane);
         }
         const Split16 csA = split16<false>(cA), csB = split16<false>(cB);
         dense32s2(netA, netB, L + VT_OFF_WL, csA, csB, lane);
@@ -880,13 +896,12 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
     // LDS-staged gather (decode_fwd_staged_kernel) when the brick footprint is bounded by 3 x 4 x 4 voxels:
     // voxels per lattice step s = (R-1) * box / ((nx-1) * divisor) < 2/3 (0.496 at 128^3 / R=64)
     static const bool force_direct = getenv("VTACO_DECODE_DIRECT") != nullptr;       // A/B knob for tests and benches
-    const bool with_any_img = c_img != nullptr || cimg_ids != nullptr;
     if (a.brick && !force_direct && R >= 4 && lattice_nx <= 512 && !c_direct) {
         const double s_vox = (double)(R - 1) * (double)lattice_box / ((double)(lattice_nx - 1) * (double)a.divisor);
         const size_t lds_st = ((size_t)VT_BLOB_FLOATS + 4u * (size_t)lattice_nx + (size_t)(ST_THREADS / 64) * ST_WAVE_FLOATS) * sizeof(float);
         const size_t lds_st2 = ((size_t)VT_BLOB_FLOATS + 4u * (size_t)lattice_nx) * sizeof(float) + (size_t)(ST2_THREADS / 64) * ST2_WAVE_BYTES;
         static const bool no_pair = getenv("VTACO_DECODE_NO_PAIR") != nullptr;    // A/B knob
-        if (split && !no_pair && !with_any_img && !out2 && (lattice_nx & 7) == 0 && R >= 6 && s_vox > 0.0 && s_vox < 0.55 &&
+        if (split && !no_pair && !out2 && (lattice_nx & 7) == 0 && R >= 6 && s_vox > 0.0 && s_vox < 0.55 &&
             lds_st2 <= 160u * 1024u) {
             const int64_t nt = (int64_t)a.total / 64;
             int64_t blocks = (nt + ST2_THREADS / 64 - 1) / (ST2_THREADS / 64);
