@@ -108,6 +108,19 @@ def stage_times(scene, dec, grid, nx, out, dev, precision):
 PMC_SUMMARY = os.path.join("profiles", "r01g_pmc_summary.csv")
 
 
+def pmc_counters(precision):
+    """Per-launch counter sums of this precision's decode kernel from the committed PMC passes (or {})."""
+    vals = {}
+    try:
+        for line in open(os.path.join(ROOT, PMC_SUMMARY)).read().splitlines()[1:]:
+            k, c, n, mean = line.split(",")
+            if k == "decode_" + precision:
+                vals[c] = float(mean)
+    except Exception:
+        pass
+    return vals
+
+
 def measured_traffic(precision):
     """HBM-side bytes per decode launch from the committed PMC passes (profiles/, same command
     as this bench): (2 x FETCH_SIZE + WRITE_SIZE) KB -- the x2 is the guide's gfx950 correction
@@ -133,10 +146,16 @@ def roofline_of(precision, flop_pt, npts, kern_ms):
          "traffic_note": "bytes/launch at the L2's memory side from rocprofv3 FETCH_SIZE/WRITE_SIZE passes "
                          f"({PMC_SUMMARY}); algorithmic = 33.5 MB grid + 8.4 MB logits",
          "kernel": KERNEL_OF[precision], "kernel_ms": kern_ms, "flop_per_point": flop_pt}
+    pmc = pmc_counters(precision)
+    if "GRBM_GUI_ACTIVE" in pmc and "SQ_VALU_MFMA_BUSY_CYCLES" in pmc:
+        simd_cycles = 1024.0 * pmc["GRBM_GUI_ACTIVE"] / 8.0                 # 256 CUs x 4 SIMDs x cycles per launch (8 XCDs summed)
+        r["pmc"] = {"matrix_pipe_busy": pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,
+                    "valu_issue": 4.0 * pmc.get("SQ_INSTS_VALU", 0.0) / simd_cycles,
+                    "source": PMC_SUMMARY + " (profiled launches of the same command)"}
     if precision == "bf16x3":
         r["note"] = ("split-bf16: each f32 product = 3 bf16 MFMA products (lo*hi + hi*lo + hi*hi), so the matrix pipe "
-                     "executes ~3x the algorithmic FLOP; the kernel is VALU-issue-bound (PMC: VALU issue 55 %, "
-                     "matrix pipe 39 % busy), see DESIGN.md")
+                     "executes ~3x the algorithmic FLOP; the kernel is bound by VALU issue (relu, hi/lo split, trilinear FMAs: "
+                     "see `pmc`), not by the matrix pipe; DESIGN.md section 4")
         r["vs_f32_mfma_roofline"] = achieved / PEAK_F32_MFMA_TFLOPS     # SURVEY.md 8d's binding roofline for f32 results
     return r
 
