@@ -25,7 +25,7 @@ FLOP_PER_POINT = 31488        # 30 976 (16 linear layers) + 512 (8
 FLOP_PER_POINT_IMG = 33536    # with the tactile concat (forward_img)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
-KERNEL_OF = {"f32": "decode_fwd_staged_kernel<false>", "bf16x3": "decode_fwd_staged2_kernel"}
+KERNEL_OF = {"f32": "decode_fwd_staged2_kernel<false>", "bf16x3": "decode_fwd_staged2_kernel<true>"}
 
 
 def synthetic_scene(seed, device, R=64):

@@ -451,6 +451,24 @@ __device__ __forceinline__ void dense32s2(f32x16 &accA, f32x16 &accB, const floa
     }
 }
 
+// exact-f32 layer for two column groups: one weight read per k-step feeds both chains
+template <bool RELU>
+__device__ __forceinline__ void dense32x2(f32x16 &accA, f32x16 &accB, const float *wl, const f32x16 &xA, const f32x16 &xB, int lane) {
+    f32x16 bA = xA, bB = xB;
+    if (RELU) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { bA[s] = relu1(xA[s]); bB[s] = relu1(xB[s]); }
+        asm volatile("" : "+v"(bA), "+v"(bB));
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float w = wl[s * 64 + lane];
+        accA = mfma(w, bA[s], accA);
+        accB = mfma(w, bB[s], accB);
+    }
+}
+
+template <bool SPLIT>
 __global__ void __launch_bounds__(ST2_THREADS)
 decode_fwd_staged2_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -595,35 +613,54 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
             netA = mfma(wp1, h ? 0.0f : pzA, netA);
             netB = mfma(wp1, h ? 0.0f : pzB, netB);
         }
+        f32x16 ciA, ciB;
+        bool has_img = false;
         if (a.cimg_ids) {
             // tactile feature by finger id: most double bricks touch no finger and skip the layer
             const unsigned idA = a.cimg_ids[gA], idB = a.cimg_ids[gB];
             if (__ballot(idA != 255u || idB != 255u) != 0ull) {
-                f32x16 ciA, ciB;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) { ciA[s] = 0.0f; ciB[s] = 0.0f; }
                 if (idA != 255u) ciA = load_frag16(a.cimg_table + (size_t)idA * 32 + 16 * h);
                 if (idB != 255u) ciB = load_frag16(a.cimg_table + (size_t)idB * 32 + 16 * h);
-                dense32s2(netA, netB, L + VT_OFF_WPI, split16<false>(ciA), split16<false>(ciB), lane);
+                has_img = true;
             }
         } else if (a.c_img) {
-            const f32x16 ciA = load_frag16(a.c_img + (size_t)gA * 32 + 16 * h);
-            const f32x16 ciB = load_frag16(a.c_img + (size_t)gB * 32 + 16 * h);
-            dense32s2(netA, netB, L + VT_OFF_WPI, split16<false>(ciA), split16<false>(ciB), lane);
+            ciA = load_frag16(a.c_img + (size_t)gA * 32 + 16 * h);
+            ciB = load_frag16(a.c_img + (size_t)gB * 32 + 16 * h);
+            has_img = true;
         }
-        const Split16 csA = split16<false>(cA), csB = split16<false>(cB);
-        dense32s2(netA, netB, L + VT_OFF_WL, csA, csB, lane);
+        if constexpr (SPLIT) {
+            if (has_img) dense32s2(netA, netB, L + VT_OFF_WPI, split16<false>(ciA), split16<false>(ciB), lane);
+            const Split16 csA = split16<false>(cA), csB = split16<false>(cB);
+            dense32s2(netA, netB, L + VT_OFF_WL, csA, csB, lane);
 #pragma unroll 1
-        for (int i = 0; i < 5; ++i) {
-            const float *wl = L + VT_OFF_WL + (1 + 3 * i) * 1024;
-            const f32x16 hb = load_frag16(L + VT_OFF_BIAS + (1 + 2 * i) * 32 + h * 16);
-            f32x16 hidA = hb, hidB = hb;
-            dense32s2(hidA, hidB, wl, split16<true>(netA), split16<true>(netB), lane);
-            dense32s2(netA, netB, wl + 1024, split16<true>(hidA), split16<true>(hidB), lane);
-            if (i < 4) dense32s2(netA, netB, wl + 2048, csA, csB, lane);
-            const bf16x8 bf = reinterpret_cast<const bf16x8 *>(L + VT_OFF_BFRAG + i * 256)[lane];
-            netA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, ones, netA, 0, 0, 0);
-            netB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, ones, netB, 0, 0, 0);
+            for (int i = 0; i < 5; ++i) {
+                const float *wl = L + VT_OFF_WL + (1 + 3 * i) * 1024;
+                const f32x16 hb = load_frag16(L + VT_OFF_BIAS + (1 + 2 * i) * 32 + h * 16);
+                f32x16 hidA = hb, hidB = hb;
+                dense32s2(hidA, hidB, wl, split16<true>(netA), split16<true>(netB), lane);
+                dense32s2(netA, netB, wl + 1024, split16<true>(hidA), split16<true>(hidB), lane);
+                if (i < 4) dense32s2(netA, netB, wl + 2048, csA, csB, lane);
+                const bf16x8 bf = reinterpret_cast<const bf16x8 *>(L + VT_OFF_BFRAG + i * 256)[lane];
+                netA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, ones, netA, 0, 0, 0);
+                netB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, ones, netB, 0, 0, 0);
+            }
+        } else {
+            if (has_img) dense32x2<false>(netA, netB, L + VT_OFF_WPI, ciA, ciB, lane);
+            dense32x2<false>(netA, netB, L + VT_OFF_WL, cA, cB, lane);
+#pragma unroll 1
+            for (int i = 0; i < 5; ++i) {
+                const float *wl = L + VT_OFF_WL + (1 + 3 * i) * 1024;
+                const f32x16 hb = load_frag16(L + VT_OFF_BIAS + (1 + 2 * i) * 32 + h * 16);
+                f32x16 hidA = hb, hidB = hb;
+                dense32x2<true>(hidA, hidB, wl, netA, netB, lane);
+                dense32x2<true>(netA, netB, wl + 1024, hidA, hidB, lane);
+                if (i < 4) dense32x2<false>(netA, netB, wl + 2048, cA, cB, lane);
+                const f32x16 bb = load_frag16(L + VT_OFF_BIAS + (2 + 2 * i) * 32 + h * 16);
+                netA = netA + bb;
+                netB = netB + bb;
+            }
         }
         {
             const f32x16 wo = load_frag16(L + VT_OFF_OUT + h * 16);
@@ -901,7 +938,7 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
         const size_t lds_st = ((size_t)VT_BLOB_FLOATS + 4u * (size_t)lattice_nx + (size_t)(ST_THREADS / 64) * ST_WAVE_FLOATS) * sizeof(float);
         const size_t lds_st2 = ((size_t)VT_BLOB_FLOATS + 4u * (size_t)lattice_nx) * sizeof(float) + (size_t)(ST2_THREADS / 64) * ST2_WAVE_BYTES;
         static const bool no_pair = getenv("VTACO_DECODE_NO_PAIR") != nullptr;    // A/B knob
-        if (split && !no_pair && !out2 && (lattice_nx & 7) == 0 && R >= 6 && s_vox > 0.0 && s_vox < 0.55 &&
+        if (!no_pair && !out2 && (lattice_nx & 7) == 0 && R >= 6 && s_vox > 0.0 && s_vox < 0.55 &&
             lds_st2 <= 160u * 1024u) {
             const int64_t nt = (int64_t)a.total / 64;
             int64_t blocks = (nt + ST2_THREADS / 64 - 1) / (ST2_THREADS / 64);
@@ -909,12 +946,18 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
             if (blocks > 8) blocks &= ~7ll;
             static bool st2_attr = false;
             if (!st2_attr) {
-                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged2_kernel),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged2_kernel<true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged2_kernel<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute (staged2)");
                 st2_attr = true;
             }
-            hipLaunchKernelGGL(decode_fwd_staged2_kernel, dim3((unsigned)blocks), dim3(ST2_THREADS), lds_st2, (hipStream_t)stream, a);
+            if (split)
+                hipLaunchKernelGGL(decode_fwd_staged2_kernel<true>, dim3((unsigned)blocks), dim3(ST2_THREADS), lds_st2, (hipStream_t)stream, a);
+            else
+                hipLaunchKernelGGL(decode_fwd_staged2_kernel<false>, dim3((unsigned)blocks), dim3(ST2_THREADS), lds_st2, (hipStream_t)stream, a);
             return vt_check(hipGetLastError(), "vt_decode_fwd");
         }
         if (s_vox > 0.0 && s_vox < 0.66 && lds_st <= 160u * 1024u) {
