@@ -3,7 +3,7 @@
 # gpurun copies back at most 64 MiB).  Usage: TAG=r01e bash tools/collect_profiles.sh
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
-TAG=${TAG:-r01g}
+TAG=${TAG:-r01h}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_under_profiler.json 2> $O/stats.err; echo "stats rc=$?"
@@ -11,7 +11,7 @@ find $O/stats -name '*kernel_trace*' -delete 2>/dev/null
 echo "kernel,counter,launches,mean_per_launch" > $O/pmc_summary.csv
 for P in bf16x3 f32; do
   # the bench also launches the other precision's kernel (its exact-f32 side measurement): keep one kernel per key
-  if [ $P = bf16x3 ]; then KPAT='staged2_kernel'; else KPAT='staged_kernelILb0E,staged_kernel<false>'; fi
+  if [ $P = bf16x3 ]; then KPAT='staged2_kernelILb1E,staged2_kernel<true>'; else KPAT='staged2_kernelILb0E,staged2_kernel<false>'; fi
   pmc(){ tag=$1; shift; d=$O/pmc_${P}_$tag; timeout 200 rocprofv3 --pmc "$@" --kernel-trace -d $d -o p -- python3 $R/bench.py --steps 10 --warmup 2 --decode-only --no-cpu-baseline --precision $P > /dev/null 2>&1; echo "pmc $P $tag rc=$?"; python3 $R/tools/pmc_summary.py decode_$P=$d --kernel "$KPAT" | tail -n +2 >> $O/pmc_summary.csv; rm -rf $d; }
   pmc fetch FETCH_SIZE
   pmc write WRITE_SIZE
