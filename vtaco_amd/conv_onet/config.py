@@ -38,3 +38,23 @@ def get_generator(model, cfg, device, **kwargs):
                        refinement_step=g.get('refinement_step', 0), simplify_nfaces=g.get('simplify_nfaces'),
                        input_type=cfg['data']['input_type'], padding=cfg['data']['padding'],
                        with_img=cfg['model'].get('with_img', False), encode_t2d=cfg['model'].get('encoder_t2d', False))
+
+
+def get_data_fields(mode, cfg):
+    """Method-specific fields of a sample (reference conv_onet/config.py:272-318): the query points
+    with occupancies ('points'), and for val / test the IoU points ('points_iou')."""
+    from .. import data
+    d = cfg['data']
+    if d['input_type'] == 'pointcloud_crop':
+        raise VtError("get_data_fields: crop / sliding-window mode is not built (no shipped config uses it)")
+    fields = {}
+    if d['points_file'] is not None:
+        fields['points'] = data.PointsField(d['points_file'], data.SubsamplePoints(d['points_subsample']),
+                                            unpackbits=d['points_unpackbits'], multi_files=d['multi_files'])
+    if mode in ('val', 'test', 'vis'):
+        if d['points_iou_file'] is not None:
+            fields['points_iou'] = data.PointsField(d['points_iou_file'], unpackbits=d['points_unpackbits'],
+                                                    multi_files=d['multi_files'])
+        if d.get('voxels_file') is not None:
+            raise VtError("get_data_fields: voxel (.binvox) fields are not built; set data.voxels_file: null")
+    return fields
