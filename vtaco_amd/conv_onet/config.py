@@ -40,6 +40,14 @@ def get_generator(model, cfg, device, **kwargs):
                        with_img=cfg['model'].get('with_img', False), encode_t2d=cfg['model'].get('encoder_t2d', False))
 
 
+def get_trainer(model, optimizer, cfg, device, **kwargs):
+    """reference conv_onet/config.py:146-212."""
+    from .training import Trainer
+    return Trainer(model, optimizer, device=device, input_type=cfg['data']['input_type'],
+                   threshold=cfg['test']['threshold'], with_img=cfg['model'].get('with_img', False),
+                   with_contact=cfg['model'].get('with_contact', False), encode_t2d=cfg['model'].get('encoder_t2d', False))
+
+
 def get_data_fields(mode, cfg):
     """Method-specific fields of a sample (reference conv_onet/config.py:272-318): the query points
     with occupancies ('points'), and for val / test the IoU points ('points_iou')."""
