@@ -22,12 +22,16 @@ from ..eval import compute_iou
 class Trainer:
     def __init__(self, model, optimizer, device=None, input_type='pointcloud', vis_dir=None, threshold=0.5,
                  eval_sample=False, num_sample=2048, with_img=False, with_contact=False, train_tactile=False,
-                 encode_t2d=False, pretrained_t2d=True):
+                 encode_t2d=False, pretrained_t2d=True, grad_sync=None):
         if with_img or encode_t2d or with_contact or train_tactile:
             raise VtError("Trainer: only the visual object branch is built (with_img / encode_t2d / with_contact / "
                           "train_tactile need the reference's CPU tactile-assembly glue; use the model-level API)")
         self.model, self.optimizer, self.device = model, optimizer, device
         self.input_type, self.threshold = input_type, threshold
+        # data-parallel training (one process per GPU): a callable run between backward and the optimizer step,
+        # e.g. vtaco_amd.dist.GradAllReduce(model.parameters()) -- one flat-bucket RCCL all-reduce per step that
+        # also covers the parameters a step leaves without gradient (fc_p_img, the contact head)
+        self.grad_sync = grad_sync
 
     def compute_loss(self, data):
         """(loss, loss_mano, loss_pc) -- the last two are the hand branch's and stay 0."""
@@ -44,6 +48,8 @@ class Trainer:
         self.optimizer.zero_grad()
         loss, loss_mano, loss_pc = self.compute_loss(data)
         loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync()
         self.optimizer.step()
         return loss.item(), loss_mano.item(), loss_pc.item()
 
