@@ -1,0 +1,125 @@
+"""Randomised differential testing on the GPU (not collected by pytest: run `python tests/stress_gpu.py [seconds]`).
+Marching cubes against the C oracle on random shapes / fields / levels, the decode kernels against the torch oracle on
+random (B, N, R) and lattices, the voxeliser against the oracle on random clouds.  Prints a summary; exits 1 on a mismatch."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import load_golden  # noqa: E402
+from oracle import mc, vtaco_oracle as orc  # noqa: E402
+from vtaco_amd import ops  # noqa: E402
+
+DEV = torch.device("cuda:0")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.RandomState(int(os.environ.get("STRESS_SEED", "0")))
+fails = []
+counts = {"mc": 0, "decode": 0, "voxel": 0}
+
+
+def blur(v):
+    for ax in range(3):
+        v = (v + np.roll(v, 1, ax) + np.roll(v, -1, ax)) / 3
+    return v
+
+
+def one_mc():
+    shape = tuple(int(rng.randint(2, 40)) for _ in range(3))
+    kind = rng.randint(4)
+    vol = rng.randn(*shape).astype(np.float32)
+    if kind == 1:
+        vol = blur(vol).astype(np.float32)
+    elif kind == 2:
+        vol = np.round(vol * 2) / 2                      # many exact ties
+    elif kind == 3:
+        vol = (vol > 0.3).astype(np.float32)             # binary field
+    level = None if rng.rand() < 0.5 else float(rng.choice([0.0, 0.25, -0.1, 0.5]))
+    try:
+        rv, rf, rl = mc.marching_cubes(vol, level)
+    except RuntimeError:
+        try:
+            ops.marching_cubes(torch.from_numpy(vol).to(DEV), level)
+        except RuntimeError:
+            return
+        fails.append(("mc: oracle found no surface but the GPU did", shape, kind, level))
+        return
+    v, f, l = ops.marching_cubes(torch.from_numpy(vol).to(DEV), level)
+    if not (np.array_equal(f.cpu().numpy(), rf) and v.shape[0] == rv.shape[0] and np.abs(v.cpu().numpy() - rv).max() <= 1e-5 and l == rl):
+        fails.append(("mc", shape, kind, level))
+
+
+_, SD = load_golden("g1_decode.npz")
+
+
+def blob(precision, img):
+    g = lambda k: SD[k].to(DEV)
+    pw, pb = (g("fc_p_img.weight"), g("fc_p_img.bias")) if img else (g("fc_p.weight"), g("fc_p.bias"))
+    return ops.pack_decoder(pw, pb, [(g(f"fc_c.{i}.weight"), g(f"fc_c.{i}.bias")) for i in range(5)],
+                            [(g(f"blocks.{i}.fc_0.weight"), g(f"blocks.{i}.fc_0.bias"), g(f"blocks.{i}.fc_1.weight"),
+                              g(f"blocks.{i}.fc_1.bias")) for i in range(5)], (g("fc_out.weight"), g("fc_out.bias")),
+                            precision=precision)
+
+
+BLOBS = {(p, i): blob(p, i) for p in ("f32", "bf16x3") for i in (False, True)}
+
+
+def one_decode():
+    B, R = int(rng.randint(1, 4)), int(rng.choice([4, 6, 8, 16, 24]))
+    g = torch.Generator().manual_seed(int(rng.randint(1 << 30)))
+    grid = torch.randn(B, 32, R, R, R, generator=g)
+    precision = str(rng.choice(["f32", "bf16x3"]))
+    img = bool(rng.rand() < 0.3)
+    if rng.rand() < 0.5:                                   # explicit points, some outside the box
+        N = int(rng.randint(1, 3000))
+        pts = (torch.rand(B, N, 3, generator=g) - 0.5) * 1.4
+        c_img = torch.randn(B, N, 32, generator=g) if img else None
+        ref = orc.local_decoder_forward_img(SD, pts, grid, c_img) if img else orc.local_decoder_forward(SD, pts, grid)
+        got = ops.decode_fwd(grid.to(DEV), BLOBS[(precision, img)], pts=pts.to(DEV), c_img=c_img.to(DEV) if img else None,
+                             precision=precision).cpu()
+    else:                                                  # lattice slabs, aligned or not
+        nx = int(rng.choice([4, 8, 12, 16, 24, 32]))
+        first = int(rng.randint(0, nx)) * nx * nx if rng.rand() < 0.7 else int(rng.randint(0, nx ** 3 - 1))
+        count = min(nx ** 3 - first, int(rng.randint(1, 4)) * nx * nx * 2 if rng.rand() < 0.7 else int(rng.randint(1, nx ** 3)))
+        pts_all = 1.1 * orc.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)
+        pts = pts_all[first:first + count].unsqueeze(0).expand(B, -1, -1).contiguous()
+        c_img = torch.randn(B, count, 32, generator=g) if img else None
+        ref = orc.local_decoder_forward_img(SD, pts, grid, c_img) if img else orc.local_decoder_forward(SD, pts, grid)
+        got = ops.decode_fwd(grid.to(DEV), BLOBS[(precision, img)], lattice=(nx, 1.1, first, count),
+                             c_img=c_img.to(DEV) if img else None, precision=precision).cpu()
+    err = float((got - ref).abs().max())
+    if not err <= 1e-4:
+        fails.append(("decode", B, R, precision, img, tuple(got.shape), err))
+
+
+def one_voxel():
+    B, T, R = int(rng.randint(1, 4)), int(rng.randint(1, 5000)), int(rng.choice([4, 16, 32, 64]))
+    g = torch.Generator().manual_seed(int(rng.randint(1 << 30)))
+    p = (torch.rand(B, T, 3, generator=g) - 0.5) * float(rng.choice([0.2, 1.0, 1.3]))
+    feat = torch.randn(B, T, 32, generator=g)
+    idx = orc.voxel_index(p, R, 0.1)
+    vi = ops.VoxelIndex(p.to(DEV), R, 0.1)
+    if not torch.equal(vi.idx.cpu().long(), idx):
+        fails.append(("voxel ids", B, T, R))
+        return
+    pooled = ops.voxel_pool_max_fwd(feat.to(DEV), vi)[0].cpu()
+    if not torch.equal(pooled, orc.segment_pool_max(feat, idx)):
+        fails.append(("pool_max", B, T, R))
+    grid = ops.voxel_scatter_mean_fwd(feat.to(DEV), vi).cpu()
+    if float((grid - orc.scatter_mean_grid(feat, idx, R)).abs().max()) > 1e-5:
+        fails.append(("scatter_mean", B, T, R))
+
+
+t0 = time.time()
+while time.time() - t0 < budget and len(fails) < 5:
+    for name, fn in (("mc", one_mc), ("decode", one_decode), ("voxel", one_voxel)):
+        fn()
+        counts[name] += 1
+print("cases:", counts, "failures:", len(fails))
+for f in fails:
+    print("  FAIL", f)
+sys.exit(1 if fails else 0)
