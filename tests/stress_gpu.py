@@ -1,6 +1,7 @@
 """Randomised differential testing on the GPU (not collected by pytest: run `python tests/stress_gpu.py [seconds]`).
 Marching cubes against the C oracle on random shapes / fields / levels, the decode kernels against the torch oracle on
-random (B, N, R) and lattices, the voxeliser against the oracle on random clouds.  Prints a summary; exits 1 on a mismatch."""
+random (B, N, R) and lattices, the voxeliser against the oracle on random clouds, the fusion pipeline on ragged N, the
+UNet3D forward (both conv precisions) on small volumes.  Prints a summary; exits 1 on a mismatch."""
 import os
 import sys
 import time
@@ -114,9 +115,60 @@ def one_voxel():
         fails.append(("scatter_mean", B, T, R))
 
 
+_, SD5 = load_golden("g5_fusion.npz")
+_ADEC = None
+
+
+def one_fusion():
+    global _ADEC
+    from vtaco_amd.conv_onet.models import decoder_dict
+    if _ADEC is None:
+        _ADEC = decoder_dict['attention_local'](dim=3, c_dim=32, hidden_size=32)
+        _ADEC.load_state_dict(SD5, strict=True)
+        _ADEC = _ADEC.to(DEV).eval()
+    # N >= 31: InstanceNorm over a handful of points is ill-conditioned (at N = 2 the f32 oracle differs from an f64
+    # evaluation of itself by up to 1e-3), which says nothing about the kernels
+    B, N = int(rng.randint(1, 5)), int(rng.choice([31, 32, 33, 64, 100, 255, 256, 257, 700]))
+    g = torch.Generator().manual_seed(int(rng.randint(1 << 30)))
+    ci = torch.randn(B, N, 32, generator=g) * (torch.rand(B, N, 1, generator=g) < 0.4)
+    cc = torch.randn(B, N, 32, generator=g) * float(rng.choice([0.3, 1.0, 3.0]))
+    ref = orc.transformer_fusion({k[len("fuser."):]: v for k, v in SD5.items() if k.startswith("fuser.")}, ci, cc)
+    with torch.no_grad():
+        out = _ADEC.fuser(ci.to(DEV), 1, cc.to(DEV), 1).cpu()
+    err = float((out - ref).abs().max())
+    if not err <= 1e-4 * max(1.0, float(ref.abs().max())):
+        fails.append(("fusion", B, N, err))
+
+
+def one_unet():
+    from vtaco_amd.encoder.unet3d import UNet3D
+    R, levels = ((16, 2), (16, 3), (32, 3), (32, 4))[int(rng.randint(4))]
+    B = int(rng.randint(1, 3))
+    torch.manual_seed(int(rng.randint(1 << 30)))
+    net = UNet3D(in_channels=32, out_channels=32, f_maps=32, num_levels=levels)
+    g = torch.Generator().manual_seed(int(rng.randint(1 << 30)))
+    x = torch.randn(B, 32, R, R, R, generator=g) * (torch.rand(B, 1, R, R, R, generator=g) < float(rng.choice([0.02, 0.3, 1.0])))
+    ref = orc.unet3d_forward({k: v.detach() for k, v in net.state_dict().items()}, x)
+    net = net.to(DEV)
+    net.precision = str(rng.choice(["f32", "bf16x3"]))
+    with torch.no_grad():
+        got = net.forward_channels_last(x.to(DEV).permute(0, 2, 3, 4, 1).contiguous()).permute(0, 4, 1, 2, 3).cpu()
+    err = float((got - ref).abs().max())
+    if not err <= 1e-4 * max(1.0, float(ref.abs().max())):
+        fails.append(("unet3d", R, levels, B, net.precision, err))
+
+
+counts.update({"fusion": 0, "unet3d": 0})
 t0 = time.time()
+it = 0
 while time.time() - t0 < budget and len(fails) < 5:
-    for name, fn in (("mc", one_mc), ("decode", one_decode), ("voxel", one_voxel)):
+    it += 1
+    jobs = [("mc", one_mc), ("decode", one_decode), ("voxel", one_voxel)]
+    if it % 4 == 0:
+        jobs.append(("fusion", one_fusion))
+    if it % 40 == 0:
+        jobs.append(("unet3d", one_unet))
+    for name, fn in jobs:
         fn()
         counts[name] += 1
 print("cases:", counts, "failures:", len(fails))
