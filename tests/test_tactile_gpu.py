@@ -69,3 +69,36 @@ def test_decode_by_finger_id_equals_dense_c_img():
         by_id = dec.decode_lattice_ids(grid, nx, ids.to(DEV), feats.to(DEV))
         ref = dec.decode_lattice(grid, nx, c_img=dense.to(DEV))
     assert torch.equal(by_id, ref)
+
+
+def test_generator_tactile_mesh_equals_dense_c_img_all_path():
+    """Generator3D.generate_obj_mesh_tactile (finger ids + feature table) produces the mesh of the reference-style path
+    that materialises c_img_all [1, nx^3, C] from the oracle's assignment rule and decodes with forward_img."""
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd.conv_onet.generation import Generator3D
+    from vtaco_amd.conv_onet.models import ConvolutionalOccupancyNetwork, decoder_dict
+    from vtaco_amd.encoder import encoder_dict
+    a, sd_e = load_golden("g3_pointnet.npz")
+    _, sd_d = load_golden("g1_decode.npz")
+    dec = decoder_dict['simple_local'](dim=3, c_dim=32, hidden_size=32, with_contact=True)
+    dec.load_state_dict(sd_d, strict=True)
+    enc = encoder_dict['pointnet_local_pool'](c_dim=32, dim=3, hidden_dim=32, grid_resolution=16, plane_type='grid')
+    enc.load_state_dict(sd_e, strict=True)
+    model = ConvolutionalOccupancyNetwork(dec, enc, device=DEV)
+    gen = Generator3D(model, device=DEV, resolution0=8, padding=0.1, with_img=True)
+    g = torch.Generator().manual_seed(4)
+    nx = 32
+    d = torch.randn(5, 40, 3, generator=g)
+    clouds = 0.3 * d / d.norm(dim=-1, keepdim=True) + 0.01 * torch.randn(5, 40, 3, generator=g)
+    count = torch.tensor([40, 25, 40, 1, 33])
+    success = torch.tensor([1, 1, 0, 1, 1])
+    feats = torch.randn(5, 32, generator=g)
+    p = torch.from_numpy(a["p"])[:1]
+    mesh = gen.generate_obj_mesh_tactile({"inputs": p}, feats, clouds, success, mode="within", count=count)
+    ids = orc.tactile_assign_within(_lattice(nx).numpy(), clouds.numpy(), count.numpy(), success.numpy())
+    dense = torch.zeros(1, nx ** 3, 32)
+    hit = torch.from_numpy(ids != 255)
+    dense[0, hit] = feats[torch.from_numpy(ids[ids != 255]).long()]
+    assert int(hit.sum()) > 20
+    ref = gen.generate_obj_mesh_wnf({"inputs": p}, c_img_all=dense.to(DEV))
+    assert torch.equal(mesh.faces, ref.faces) and torch.equal(mesh.vertices, ref.vertices)

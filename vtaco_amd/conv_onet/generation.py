@@ -114,6 +114,27 @@ class Generator3D(object):
         verts, faces, _ = ops.mc_emit(vol, ws, rescale=(nx / 2, (1 + self.padding) / nx))
         return Mesh(verts, faces)
 
+    def generate_obj_mesh_tactile(self, data, finger_feats, anchors, success, mode='within', radius=None, count=None):
+        """Tactile branch of ``generate_obj_mesh_wnf`` (generation.py:159-257) without the dense
+        ``c_img_all [1,nx^3,C]`` tensor and its CPU cdist glue: every lattice point gets the id of the finger whose
+        contact points lie within ``radius`` (``mode='within'``, radius 0.015: VTacO, :245-255) or of the nearest
+        successful fingertip (``mode='nearest'``, radius 0.05: VTacOH, :186-200) from ``vt_tactile_assign``, and the
+        decoder reads ``finger_feats [F,C]`` by id (``vt_decode_fwd_ids``): 1 byte per point instead of 4*C.
+        ``anchors [F,K,3]`` (K = 1 for 'nearest'), ``count [F]`` valid anchors per finger, ``success [F]``."""
+        self.model.eval()
+        nx = self.resolution0 * 4
+        radius = (0.015 if mode == 'within' else 0.05) if radius is None else radius
+        inputs = data.get('inputs').to(self.device)
+        with torch.no_grad():
+            c = self.model.encode_inputs(inputs)
+            grid = c['grid'] if isinstance(c, dict) else c
+            lattice = (nx, 1 + self.padding, 0, nx ** 3)
+            ids = ops.tactile_assign(anchors.to(self.device), success.to(self.device), mode, radius, lattice=lattice,
+                                     count=None if count is None else count.to(self.device))
+            values = self.model.decoder.decode_lattice_ids(grid, nx, ids, finger_feats.to(self.device), box=1 + self.padding,
+                                                           precision=self.decode_precision)
+        return self.extract_mesh(values.reshape(nx, nx, nx))
+
     def generate_obj_mesh_wnf(self, data, c_img_all=None):
         """Encode -> dense decode -> marching cubes for one scene; ``data['inputs']`` is the
         point cloud [1,T,3].  Returns Mesh(vertices [V,3] f32, faces [F,3] i32) on the device."""
