@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from vtaco_amd.dist import GradAllReduce, all_gather_slabs, decode_lattice_sharded, slab_of
+from vtaco_amd.dist import GradAllReduce, all_gather_slabs, decode_lattice_sharded, lattice_align, slab_of
 
 
 def test_slabs_partition_exactly():
@@ -18,6 +18,18 @@ def test_slabs_partition_exactly():
             assert spans[0][0] == 0 and sum(c for _, c in spans) == total
             for (f0, c0), (f1, _) in zip(spans, spans[1:]):
                 assert f0 + c0 == f1 and (c0 % 32 == 0 or f1 == total)
+
+
+def test_lattice_slabs_are_whole_plane_pairs_when_possible():
+    """128^3 / 256^3 over 2, 4, 8 ranks: every slab starts and ends on a pair of x-planes (the brick-tiled,
+    LDS-staged decode kernels' alignment); tiny lattices fall back to the 32-point tile."""
+    for nx, world in ((128, 2), (128, 8), (256, 8), (128, 3), (32, 8)):
+        align = lattice_align(nx, world)
+        assert align == 2 * nx * nx
+        spans = [slab_of(nx ** 3, r, world, align) for r in range(world)]
+        assert sum(c for _, c in spans) == nx ** 3
+        assert all(f % align == 0 and (c % align == 0) for f, c in spans)
+    assert lattice_align(8, 8) == 32 and lattice_align(11, 2) == 2 * 121
 
 
 def _free_port():
@@ -30,9 +42,10 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        nx = 11                                           # 1331 points: ragged slabs
-        full = decode_lattice_sharded(lambda first, count: torch.arange(first, first + count, dtype=torch.float32) * 0.5, nx)
-        ok1 = torch.equal(full, torch.arange(nx ** 3, dtype=torch.float32) * 0.5)
+        ok1 = True
+        for nx in (11, 8, 16):                            # ragged plane-pair slabs, 32-point slabs, even plane pairs
+            full = decode_lattice_sharded(lambda first, count: torch.arange(first, first + count, dtype=torch.float32) * 0.5, nx)
+            ok1 = ok1 and torch.equal(full, torch.arange(nx ** 3, dtype=torch.float32) * 0.5)
         # gradient all-reduce: rank-dependent grads, one parameter without a gradient on rank 1
         torch.manual_seed(0)
         a, b, c = (torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)),

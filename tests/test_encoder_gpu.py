@@ -115,6 +115,32 @@ def test_generator_end_to_end_mesh_vs_oracle():
     assert np.abs(mesh.vertices.cpu().numpy() - orc.mesh_rescale(rv, 32)).max() <= 1e-6
 
 
+def test_sharded_generation_single_rank_equals_plain():
+    """generate_obj_mesh_sharded without a process group is the single-GPU path; slab decomposition of the lattice
+    (what the ranks of a group evaluate) reproduces the whole lattice bit for bit."""
+    from vtaco_amd.conv_onet.generation import Generator3D
+    from vtaco_amd.conv_onet.models import ConvolutionalOccupancyNetwork, decoder_dict
+    from vtaco_amd.dist import lattice_align, slab_of
+    a, sd_e = load_golden("g3_pointnet.npz")
+    _, sd_d = load_golden("g1_decode.npz")
+    dec = decoder_dict['simple_local'](dim=3, c_dim=32, hidden_size=32, with_contact=True)
+    dec.load_state_dict(sd_d, strict=True)
+    model = ConvolutionalOccupancyNetwork(dec, _encoder(sd_e), device=DEV)
+    gen = Generator3D(model, device=DEV, resolution0=8, padding=0.1)
+    p = T(a["p"])[:1]
+    plain = gen.generate_obj_mesh_wnf({"inputs": p})
+    shard = gen.generate_obj_mesh_sharded({"inputs": p})
+    assert torch.equal(plain.faces, shard.faces) and torch.equal(plain.vertices, shard.vertices)
+    nx = 32
+    with torch.no_grad():
+        c = model.encode_inputs(p.to(DEV))
+        whole = gen.eval_lattice(c, nx)
+        for world in (2, 8):
+            align = lattice_align(nx, world)
+            parts = [gen.eval_lattice(c, nx, first=f, count=n) for f, n in (slab_of(nx ** 3, r, world, align) for r in range(world))]
+            assert torch.equal(torch.cat(parts), whole)
+
+
 def test_graphed_scene_equals_eager():
     """hipGraph replay of encode + decode + MC classification gives the eager mesh, repeatedly."""
     from vtaco_amd.conv_onet.generation import Generator3D

@@ -114,6 +114,20 @@ class Generator3D(object):
         verts, faces, _ = ops.mc_emit(vol, ws, rescale=(nx / 2, (1 + self.padding) / nx))
         return Mesh(verts, faces)
 
+    def generate_obj_mesh_sharded(self, data, group=None):
+        """``generate_obj_mesh_wnf`` with the lattice split over the ranks of a process group (one process per GPU):
+        every rank encodes the scene (cheap, deterministic: no broadcast), decodes its slab of x-plane pairs with no
+        data-path collective, one all_gather of the logit slabs (8.4 MB at 128^3, 67 MB at 256^3) rebuilds the value
+        grid, and every rank extracts the (identical) mesh.  Without an initialised group this is the single-GPU path."""
+        from .. import dist as vdist
+        self.model.eval()
+        nx = self.resolution0 * 4
+        inputs = data.get('inputs').to(self.device)
+        with torch.no_grad():
+            c = self.model.encode_inputs(inputs)
+            values = vdist.decode_lattice_sharded(lambda first, count: self.eval_lattice(c, nx, first=first, count=count), nx, group)
+        return self.extract_mesh(values.reshape(nx, nx, nx))
+
     def generate_obj_mesh_tactile(self, data, finger_feats, anchors, success, mode='within', radius=None, count=None):
         """Tactile branch of ``generate_obj_mesh_wnf`` (generation.py:159-257) without the dense
         ``c_img_all [1,nx^3,C]`` tensor and its CPU cdist glue: every lattice point gets the id of the finger whose

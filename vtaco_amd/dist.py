@@ -27,12 +27,19 @@ def slab_of(total, rank, world, align=32):
     return first, max(0, min(per, total - first))
 
 
-def all_gather_slabs(local, total, group=None):
+def lattice_align(nx, world):
+    """Slab granularity for an nx^3 lattice: whole pairs of x-planes (what the brick-tiled decode kernels want)
+    when every rank still gets work that way, else the 32-point tile."""
+    pair = 2 * nx * nx
+    return pair if pair * world <= nx ** 3 else 32
+
+
+def all_gather_slabs(local, total, group=None, align=32):
     """Concatenate per-rank 1-D slabs (possibly ragged) into the full [total] tensor on every rank."""
     world = dist.get_world_size(group)
     if world == 1:
         return local
-    counts = [slab_of(total, r, world)[1] for r in range(world)]
+    counts = [slab_of(total, r, world, align)[1] for r in range(world)]
     width = max(counts)
     pad = torch.zeros(width, dtype=local.dtype, device=local.device)
     pad[:local.numel()] = local
@@ -47,11 +54,12 @@ def decode_lattice_sharded(decode_slab, nx, group=None):
     total = nx ** 3
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    first, count = slab_of(total, rank, world)
+    align = lattice_align(nx, world)
+    first, count = slab_of(total, rank, world, align)
     local = decode_slab(first, count)
     if world == 1:
         return local
-    return all_gather_slabs(local, total, group)
+    return all_gather_slabs(local, total, group, align)
 
 
 class GradAllReduce:
