@@ -1,0 +1,78 @@
+"""Two ranks on ONE GPU (gloo carries the HIP tensors through the host): the multi-process code path of the sharded
+mesh generation and of a data-parallel training step, with real kernels.  RCCL itself needs one GPU per rank and is
+exercised by the driver's scaling bench only.
+
+The worker processes must be started by a parent that has NOT initialised the GPU (a process that has may not be the
+origin of an exec on the GPU boxes), hence the file name -- pytest collects it first -- and the skip below."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import load_golden
+    from vtaco_amd.conv_onet.generation import Generator3D
+    from vtaco_amd.conv_onet.models import ConvolutionalOccupancyNetwork, decoder_dict
+    from vtaco_amd.conv_onet.training import Trainer
+    from vtaco_amd.dist import GradAllReduce
+    from vtaco_amd.encoder import encoder_dict
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = "cuda:0"
+        a, sd_e = load_golden("g3_pointnet.npz")
+        _, sd_d = load_golden("g1_decode.npz")
+        dec = decoder_dict['simple_local'](dim=3, c_dim=32, hidden_size=32, with_contact=True)
+        dec.load_state_dict(sd_d, strict=True)
+        enc = encoder_dict['pointnet_local_pool'](c_dim=32, dim=3, hidden_dim=32, grid_resolution=16, plane_type='grid')
+        enc.load_state_dict(sd_e, strict=True)
+        model = ConvolutionalOccupancyNetwork(dec, enc, device=dev)
+        gen = Generator3D(model, device=dev, resolution0=8, padding=0.1)
+        p = torch.from_numpy(a["p"])[:1]
+        plain = gen.generate_obj_mesh_wnf({"inputs": p})
+        shard = gen.generate_obj_mesh_sharded({"inputs": p})
+        ok_mesh = torch.equal(plain.faces, shard.faces) and torch.equal(plain.vertices, shard.vertices)
+        # data-parallel step: different batches per rank, one flat all-reduce -> identical parameters afterwards
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+        trainer = Trainer(model, opt, device=dev, grad_sync=GradAllReduce(model.parameters()))
+        g = torch.Generator().manual_seed(100 + rank)
+        batch = {"inputs": torch.from_numpy(a["p"])[rank:rank + 1], "points": (torch.rand(1, 512, 3, generator=g) - 0.5),
+                 "points.occ": torch.rand(1, 512, generator=g)}
+        trainer.train_step(batch)
+        flat = torch.cat([q.detach().reshape(-1) for q in model.parameters()]).cpu()
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        ok_sync = all(torch.equal(gathered[0], t) for t in gathered[1:])
+        q.put((rank, bool(ok_mesh), bool(ok_sync)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_gpu_gloo():
+    if torch.cuda.is_initialized():
+        pytest.skip("the GPU is already initialised in this process: run this file on its own (or first)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True, True), (1, True, True)]
