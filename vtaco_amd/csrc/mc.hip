@@ -401,28 +401,49 @@ mc_classify_kernel(const float *vol, McDims d, McWs ws, double level_in, int aut
 
 // one block: exclusive scan of the per-block sums
 __global__ void __launch_bounds__(1024) mc_scan_kernel(McWs ws, unsigned nblk) {
-    __shared__ uint2 part[1024];
+    __shared__ uint2 wtot[16];
     const unsigned per = (nblk + 1023) / 1024;
     const unsigned lo = threadIdx.x * per, hi = min(lo + per, nblk);
     unsigned a = 0, b = 0;
-    for (unsigned i = lo; i < hi; ++i) { a += ws.bsum[i].x; b += ws.bsum[i].y; }
-    part[threadIdx.x] = make_uint2(a, b);
+    uint2 v[8];                                                  // up to 8 entries per thread (128^3) stay in registers:
+    const bool small = per <= 8;                                 // independent loads instead of a dependent chain
+    if (small) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (lo + k < hi) ? ws.bsum[lo + k] : make_uint2(0u, 0u);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a += v[k].x; b += v[k].y; }
+    } else {
+        for (unsigned i = lo; i < hi; ++i) { a += ws.bsum[i].x; b += ws.bsum[i].y; }
+    }
+    // inclusive scan of the 1024 per-thread sums: shuffles inside a wave, then the 16 wave totals
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned ia = a, ib = b;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned ta = __shfl_up(ia, o), tb = __shfl_up(ib, o);
+        if (lane >= o) { ia += ta; ib += tb; }
+    }
+    if (lane == 63) wtot[w] = make_uint2(ia, ib);
     __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (int o = 1; o < 1024; o <<= 1) {
-        uint2 t = make_uint2(0, 0);
-        if ((int)threadIdx.x >= o) t = part[threadIdx.x - o];
-        __syncthreads();
-        part[threadIdx.x].x += t.x; part[threadIdx.x].y += t.y;
-        __syncthreads();
+    unsigned oa = 0, ob = 0, sa = 0, sb = 0;
+    for (int i = 0; i < 16; ++i) {
+        if (i < w) { oa += wtot[i].x; ob += wtot[i].y; }
+        sa += wtot[i].x; sb += wtot[i].y;
     }
-    unsigned ra = part[threadIdx.x].x - a, rb = part[threadIdx.x].y - b;
-    for (unsigned i = lo; i < hi; ++i) {
-        const uint2 s = ws.bsum[i];
-        ws.boff[i] = make_uint2(ra, rb);
-        ra += s.x; rb += s.y;
+    unsigned ra = oa + ia - a, rb = ob + ib - b;                  // exclusive prefix of this thread's first entry
+    if (small) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (lo + k < hi) ws.boff[lo + k] = make_uint2(ra, rb);
+            ra += v[k].x; rb += v[k].y;
+        }
+    } else {
+        for (unsigned i = lo; i < hi; ++i) {
+            const uint2 s = ws.bsum[i];
+            ws.boff[i] = make_uint2(ra, rb);
+            ra += s.x; rb += s.y;
+        }
     }
-    if (threadIdx.x == 1023) { ws.hdr->nfaces = (int)part[1023].x; ws.hdr->nverts = (int)part[1023].y; }
+    if (threadIdx.x == 0) { ws.hdr->nfaces = (int)sa; ws.hdr->nverts = (int)sb; }
 }
 
 struct McOut {
