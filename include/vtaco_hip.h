@@ -380,6 +380,36 @@ int vt_gn_bwd(const float *skip, int C1, const float *low, int C2, int B, int D,
               float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow, void *stream);
 int vt_maxpool3d_cl_bwd(const float *x, const float *dy, int B, int D, int H, int W, int C, float *dx, void *stream);
 
+/* ------------------------------------------------------------------------- */
+/* Hand branch (SURVEY.md section 8f "next" row 3).                              */
+/* Plane-mode PointNet: replaces normalize_coordinate + coordinate2index('2d')   */
+/*   (src/common.py:268-291, 333-345; call sites src/encoder/pointnet.py:141-149) */
+/*   and the scatter_mean of generate_plane_features (pointnet.py:85-95).         */
+/*   vt_plane_build: plane 0 = 'xz', 1 = 'xy', 2 = 'yz'; idx[b,t] = i(first axis)  */
+/*   + R * i(second axis) with the plane constants (divisor 1 + padding + 10e-6,    */
+/*   upper clamp 1 - 10e-6); order/seg_lo/seg_hi as vt_voxel_build, so the          */
+/*   vt_voxel_pool_max_* kernels serve every plane (pool_local, pointnet.py:116-132, */
+/*   sums the per-plane results).  vt_plane_scatter_mean_*: plane [B,C,R,R].          */
+/* MANO layer: replaces ManoLayer.forward (src/encoder/manolayer.py:160-364) for the  */
+/*   shipped configuration (axis-angle root + joints, use_pca False, hands_mean added, */
+/*   model betas, no translation, right hand).  vt_mano_pack lays the model out once:  */
+/*   v_template [778,3], shapedirs [778,3,10] + betas [10] (both may be NULL: betas 0), */
+/*   posedirs [778,3,135], j_regressor [16,778] dense, weights [778,16], hands_mean [45] */
+/*   -> blob[VT_MANO_BLOB_FLOATS].  vt_mano_fwd: pose [B,48] = root axis-angle + 45 joint */
+/*   angles -> verts [B,778,3], joints [B,21,3], both minus joint center_idx (-1: none).   */
+/* ------------------------------------------------------------------------- */
+#define VT_MANO_BLOB_FLOATS 330240
+int vt_plane_build(const float *pts, int B, int T, int R, double padding, int plane,
+                   int *idx, int *order, int *seg_lo, int *seg_hi, void *stream);
+int vt_plane_scatter_mean_fwd(const float *feat, const int *idx, const int *order,
+                              const int *seg_lo, const int *seg_hi,
+                              int B, int T, int C, int R, float *plane, void *stream);
+int vt_plane_scatter_mean_bwd(const float *grad_plane, const int *idx, const int *seg_lo, const int *seg_hi,
+                              int B, int T, int C, int R, float *grad_feat, void *stream);
+int vt_mano_pack(const float *v_template, const float *shapedirs, const float *betas, const float *posedirs,
+                 const float *j_regressor, const float *weights, const float *hands_mean, float *blob, void *stream);
+int vt_mano_fwd(const float *pose, int B, const float *blob, int center_idx, float *verts, float *joints, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -404,3 +404,156 @@ def tactile_assign_within(pts, clouds, counts, success, radius=0.015):
         d = np.sqrt(((c[:, None, :] - p[None, :, :]) ** 2).sum(-1))
         ids[(d < radius).any(0)] = f
     return ids
+
+
+# --------------------------------------------------------------------------
+# hand branch: plane-mode PointNet, 2-D UNet, MANO head
+# --------------------------------------------------------------------------
+
+PLANE_AXES = {"xz": (0, 2), "xy": (0, 1), "yz": (1, 2)}
+
+
+def normalize_coordinate(p, padding=0.1, plane="xz"):
+    """Plane projection -> [0,1) (src/common.py:268-291): divisor 1 + padding + 10e-6,
+    values >= 1 become 1 - 10e-6 (NOT the 3-D variant's 10e-4 constants)."""
+    a, b = PLANE_AXES[plane]
+    q = torch.stack([p[..., a], p[..., b]], dim=-1) / (1 + padding + 10e-6) + 0.5
+    q = torch.where(q >= 1, torch.full_like(q, 1 - 10e-6), q)
+    q = torch.where(q < 0, torch.zeros_like(q), q)
+    return q
+
+
+def plane_index(p, reso, padding=0.1, plane="xz"):
+    """``coordinate2index(.., '2d')`` (src/common.py:333-345): first projected axis fastest."""
+    xi = (normalize_coordinate(p, padding, plane) * reso).long()
+    return xi[..., 0] + reso * xi[..., 1]
+
+
+def scatter_mean_plane(feat, index, reso):
+    """``generate_plane_features`` scatter part (pointnet.py:85-95): per-cell mean, [B,C,R,R]."""
+    B, T, C = feat.shape
+    acc = torch.zeros(B, reso * reso, C)
+    cnt = torch.zeros(B, reso * reso, 1)
+    acc.scatter_add_(1, index.unsqueeze(-1).expand(-1, -1, C), feat)
+    cnt.scatter_add_(1, index.unsqueeze(-1), torch.ones(B, T, 1))
+    return (acc / cnt.clamp(min=1)).permute(0, 2, 1).reshape(B, C, reso, reso)
+
+
+def unet2d_forward(sd, x):
+    """``UNet.forward`` (src/encoder/unet.py:218-233): depth x {conv3x3+ReLU twice, maxpool except last},
+    depth-1 x {ConvTranspose2d 2x2 s2, cat(up, skip), conv3x3+ReLU twice}, conv1x1.  merge 'concat'."""
+    depth = 0
+    while f"down_convs.{depth}.conv1.weight" in sd:
+        depth += 1
+    skips = []
+    for i in range(depth):
+        pre = f"down_convs.{i}."
+        x = F.relu(F.conv2d(x, sd[pre + "conv1.weight"], sd[pre + "conv1.bias"], padding=1))
+        x = F.relu(F.conv2d(x, sd[pre + "conv2.weight"], sd[pre + "conv2.bias"], padding=1))
+        skips.append(x)
+        if i < depth - 1:
+            x = F.max_pool2d(x, 2)
+    for i in range(depth - 1):
+        pre = f"up_convs.{i}."
+        up = F.conv_transpose2d(x, sd[pre + "upconv.weight"], sd[pre + "upconv.bias"], stride=2)
+        x = torch.cat((up, skips[-(i + 2)]), dim=1)
+        x = F.relu(F.conv2d(x, sd[pre + "conv1.weight"], sd[pre + "conv1.bias"], padding=1))
+        x = F.relu(F.conv2d(x, sd[pre + "conv2.weight"], sd[pre + "conv2.bias"], padding=1))
+    return F.conv2d(x, sd["conv_final.weight"], sd["conv_final.bias"])
+
+
+def plane_pointnet_forward(sd, p, reso, padding=0.1, planes=("xz", "xy", "yz"), return_stages=False):
+    """``LocalPoolPointnet.forward`` with plane_type=['xz','xy','yz'] (pointnet.py:135-176):
+    pool_local SUMS the per-plane max-pools (:116-132); one scatter-mean plane (+ shared UNet) per key.
+    Returns {plane: [B,C,R,R]} in the reference's dict order (xz, xy, yz)."""
+    idx = {k: plane_index(p, reso, padding, k) for k in planes}
+    net = _lin(sd, "fc_pos", p)
+    net = resnet_block_fc(sd, "blocks.0", net)
+    stages = [net]
+    for i in range(1, _n_blocks(sd)):
+        pooled = sum(segment_pool_max(net, idx[k]) for k in planes)
+        net = resnet_block_fc(sd, f"blocks.{i}", torch.cat([net, pooled], dim=2))
+        stages.append(net)
+    c = _lin(sd, "fc_c", net)
+    usd = {k[len("unet."):]: v for k, v in sd.items() if k.startswith("unet.")}
+    fea = {}
+    for k in planes:
+        f = scatter_mean_plane(c, idx[k], reso)
+        fea[k] = unet2d_forward(usd, f) if usd else f
+    if return_stages:
+        return fea, idx, stages, c
+    return fea
+
+
+def mano_param_head(sd, fea):
+    """out_mano head (pointnet.py:179-192): channel-concat the planes, global average pool, fc_mano."""
+    cat = torch.cat([fea[k] for k in fea], dim=1)
+    return _lin(sd, "fc_mano", cat.mean(dim=(2, 3)))
+
+
+def rodrigues(axisang):
+    """manopth batch_rodrigues (src/encoder/manopth/rodrigues_layer.py:49-60 with quat2mat :15-46):
+    angle = ||v + 1e-8||, quaternion (cos a/2, sin a/2 * v/angle) re-normalised, then the rotation matrix."""
+    angle = torch.norm(axisang + 1e-8, p=2, dim=1, keepdim=True)
+    axis = axisang / angle
+    half = angle * 0.5
+    q = torch.cat([torch.cos(half), torch.sin(half) * axis], dim=1)
+    q = q / q.norm(p=2, dim=1, keepdim=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    w2, x2, y2, z2 = w * w, x * x, y * y, z * z
+    wx, wy, wz, xy, xz, yz = w * x, w * y, w * z, x * y, x * z, y * z
+    return torch.stack([w2 + x2 - y2 - z2, 2 * xy - 2 * wz, 2 * wy + 2 * xz,
+                        2 * wz + 2 * xy, w2 - x2 + y2 - z2, 2 * yz - 2 * wx,
+                        2 * xz - 2 * wy, 2 * wx + 2 * yz, w2 - x2 - y2 + z2], dim=1).view(-1, 3, 3)
+
+
+MANO_PARENTS = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14]        # three joints per finger off the wrist
+MANO_TIPS_RIGHT = [745, 317, 444, 556, 673]
+MANO_JOINT_ORDER = [0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20]
+
+
+def mano_forward(model, pose, center_idx=9):
+    """``ManoLayer.forward`` (src/encoder/manolayer.py:160-364) for the shipped configuration
+    (axis-angle root + joints, use_pca False, flat_hand_mean False, betas = the model's zeros,
+    th_trans = 0, right hand).  ``model``: dict of f32 tensors v_template [778,3], shapedirs [778,3,10],
+    posedirs [778,3,135], J_regressor [16,778], weights [778,16], hands_mean [45], betas [10].
+    pose [B,48] -> (verts [B,778,3], joints [B,21,3]) centred on joint ``center_idx``."""
+    B = pose.shape[0]
+    full = torch.cat([pose[:, :3], model["hands_mean"].unsqueeze(0) + pose[:, 3:48]], dim=1)
+    rots = rodrigues(full.reshape(-1, 3)).view(B, 16, 3, 3)
+    pose_map = (rots[:, 1:] - torch.eye(3)).reshape(B, 135)
+    v_shaped = torch.matmul(model["shapedirs"], model["betas"]) + model["v_template"]          # [778,3]
+    J = torch.matmul(model["J_regressor"], v_shaped)                                            # [16,3]
+    v_posed = v_shaped.unsqueeze(0) + torch.matmul(model["posedirs"], pose_map.t()).permute(2, 0, 1)
+    # kinematic chain (manolayer.py:264-303): G_root = [R_0 | J_0], G_j = G_parent * [R_j | J_j - J_parent]
+    G = [None] * 16
+    for j in range(16):
+        par = MANO_PARENTS[j]
+        t = J[j] if par < 0 else J[j] - J[par]
+        local = torch.zeros(B, 4, 4)
+        local[:, :3, :3] = rots[:, j]
+        local[:, :3, 3] = t
+        local[:, 3, 3] = 1.0
+        G[j] = local if par < 0 else torch.matmul(G[par], local)
+    G = torch.stack(G, dim=1)                                                                   # [B,16,4,4]
+    # remove the rest pose: A_j = G_j with translation G_j[:3,3] - G_j[:3,:3] J_j  (manolayer.py:305-307)
+    A = G.clone()
+    A[:, :, :3, 3] = G[:, :, :3, 3] - torch.matmul(G[:, :, :3, :3], J.view(1, 16, 3, 1)).squeeze(-1)
+    T = torch.einsum("vj,bjrc->bvrc", model["weights"], A)                                      # [B,778,4,4]
+    vh = torch.cat([v_posed, torch.ones(B, v_posed.shape[1], 1)], dim=2)
+    verts = torch.einsum("bvrc,bvc->bvr", T, vh)[:, :, :3]
+    jtr = torch.cat([G[:, :, :3, 3], verts[:, MANO_TIPS_RIGHT]], dim=1)[:, MANO_JOINT_ORDER]
+    centre = jtr[:, center_idx:center_idx + 1] if center_idx is not None else torch.zeros(B, 1, 3)
+    return verts - centre, jtr - centre
+
+
+def hand_encoder_forward(sd, model, p, reso, padding=0.1, out_dim=51, center_idx=9):
+    """The hand encoder end to end (pointnet.py:135-206, out_mano=True): plane features -> mano_param;
+    for out_dim > 30 the MANO layer runs on [0,0,0 | mano_param[6:]] (wrist position zeroed, :195-197)."""
+    fea = plane_pointnet_forward(sd, p, reso, padding)
+    param = mano_param_head(sd, fea)
+    out = {"mano_param": param}
+    if out_dim > 30:
+        full = torch.cat([torch.zeros(param.shape[0], 3), param[:, 6:]], dim=1)
+        out["mano_verts"], out["mano_joints"] = mano_forward(model, full, center_idx)
+    return out

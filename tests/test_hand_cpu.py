@@ -1,0 +1,158 @@
+"""CPU: the hand-branch oracle against golden vectors from the real reference (g10_hand.npz, made by
+tests/golden/make_hand_goldens.py with the synthetic MANO asset of tests/synth_mano.py), the chumpy-free
+MANO loader, and the host modules' construction / checkpoint names (no compute without a GPU)."""
+import pickle
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import synth_mano
+from conftest import load_golden
+from oracle import vtaco_oracle as orc
+
+T = torch.from_numpy
+PLANES = ("xz", "xy", "yz")
+
+
+def maxdiff(a, b):
+    return float((torch.as_tensor(a) - torch.as_tensor(b)).abs().max())
+
+
+def test_plane_ids_bit_exact_with_the_plane_constants():
+    a, _ = load_golden("g10_hand.npz")
+    p = T(a["p"])
+    for k in PLANES:
+        assert torch.equal(orc.plane_index(p, 32, 0.1, k), T(a["idx_" + k]).long())
+    # the planes use the 10e-6 constants, the grid 10e-4: near the border the two rules pick different cells
+    edge = torch.tensor([[[0.5499, 0.0, -0.5503]]])
+    assert int(orc.plane_index(edge, 10000, 0.1, "xz")[0, 0]) == 9999 + 10000 * 0
+    assert int(orc.voxel_index(edge, 10000, 0.1)[0, 0]) % 10000 == 9994
+
+
+def test_plane_pointnet_unet_and_mano_head():
+    a, sd = load_golden("g10_hand.npz")
+    fea = orc.plane_pointnet_forward(sd, T(a["p"]), 32)
+    assert list(fea) == list(PLANES)
+    for k in PLANES:
+        assert maxdiff(fea[k], a["plane_" + k]) <= 2e-5
+    param = orc.mano_param_head(sd, fea)
+    assert maxdiff(param, a["mano_param"]) <= 1e-5
+    out = orc.hand_encoder_forward(sd, synth_mano.as_model(synth_mano.make_asset(0)), T(a["p"]), 32)
+    assert maxdiff(out["mano_verts"], a["mano_verts"]) <= 1e-5
+    assert maxdiff(out["mano_joints"], a["mano_joints"]) <= 1e-5
+
+
+def test_mano_layer_on_seeded_poses():
+    a, _ = load_golden("g10_hand.npz")
+    model = synth_mano.as_model(synth_mano.make_asset(0))
+    v, j = orc.mano_forward(model, T(a["pose"]))
+    assert v.shape == (4, 778, 3) and j.shape == (4, 21, 3)
+    assert maxdiff(v, a["pose_verts"]) <= 1e-6 and maxdiff(j, a["pose_joints"]) <= 1e-6
+    assert float(j[:, 9].abs().max()) == 0.0                   # centred on joint 9
+    # zero pose = mean pose, not the flat hand (flat_hand_mean False): hands_mean moves the fingers
+    flat = dict(model, hands_mean=torch.zeros(45))
+    assert maxdiff(orc.mano_forward(flat, T(a["pose"])[:1])[0], v[:1]) > 1e-3
+
+
+def test_mano_loader_resolves_chumpy_objects_without_chumpy(tmp_path):
+    """MANO_RIGHT.pkl stores shapedirs as chumpy.reordering.Select over a chumpy.ch.Ch: pickle exactly
+    that structure with stand-in classes, drop the stand-in module, and read it back."""
+    from vtaco_amd._lib import VtError
+    from vtaco_amd.encoder.manolayer import load_mano_pkl
+    asset = synth_mano.make_asset(3)
+    assert "chumpy" not in sys.modules
+    ch, chch, chre = types.ModuleType("chumpy"), types.ModuleType("chumpy.ch"), types.ModuleType("chumpy.reordering")
+
+    class Ch(object):
+        pass
+
+    class Select(object):
+        pass
+
+    Ch.__module__, Ch.__qualname__ = "chumpy.ch", "Ch"
+    Select.__module__, Select.__qualname__ = "chumpy.reordering", "Select"
+    chch.Ch, chre.Select = Ch, Select
+    sys.modules.update({"chumpy": ch, "chumpy.ch": chch, "chumpy.reordering": chre})
+    try:
+        base = Ch()
+        padded = np.concatenate([asset["shapedirs"].ravel(), np.full(100, 7.0)])     # Select picks a subset
+        base.__dict__.update(x=padded, _dirty_vars=set())
+        sel = Select()
+        sel.__dict__.update(a=base, idxs=np.arange(asset["shapedirs"].size), preferred_shape=(778, 3, 10), _itr=None)
+        import scipy.sparse as sp
+        dd = dict(asset, shapedirs=sel, J_regressor=sp.csc_matrix(asset["J_regressor"]))
+        path = tmp_path / "MANO_RIGHT.pkl"
+        with open(path, "wb") as fh:
+            pickle.dump(dd, fh, protocol=2)
+    finally:
+        for m in ("chumpy", "chumpy.ch", "chumpy.reordering"):
+            sys.modules.pop(m)
+    got = load_mano_pkl(str(path))
+    assert np.array_equal(got["shapedirs"], asset["shapedirs"]) and got["shapedirs"].shape == (778, 3, 10)
+    assert np.array_equal(got["J_regressor"], asset["J_regressor"])
+    assert got["betas"].shape == (10,) and not got["betas"].any()
+    with pytest.raises(VtError, match="not found"):
+        load_mano_pkl(str(tmp_path / "nope.pkl"))
+    bad = dict(asset, kintree_table=asset["kintree_table"][:, ::-1].copy())
+    synth_mano.write_pkl(bad, str(tmp_path / "bad"))
+    with pytest.raises(VtError, match="kinematic tree"):
+        load_mano_pkl(str(tmp_path / "bad" / "MANO_RIGHT.pkl"))
+
+
+def test_hand_encoder_modules_build_with_reference_checkpoint_names(tmp_path):
+    from vtaco_amd._lib import VtError
+    from vtaco_amd.encoder import encoder_dict
+    a, sd = load_golden("g10_hand.npz")
+    synth_mano.write_pkl(synth_mano.make_asset(0), str(tmp_path))
+    kw = dict(center_idx=9, flat_hand_mean=False, ncomps=45, side="right", mano_root=str(tmp_path), use_pca=False,
+              root_rot_mode="axisang", joint_rot_mode="axisang", robust_rot=False, return_transf=False)
+    enc = encoder_dict["pointnet_local_pool"](
+        dim=3, c_dim=32, padding=0.1, hidden_dim=32, plane_type=["xz", "xy", "yz"], plane_resolution=32, unet=True,
+        unet_kwargs=dict(depth=3, merge_mode="concat", start_filts=16), out_mano=True, out_dim=51, manolayer_kwargs=kw)
+    own = enc.state_dict()
+    assert set(sd) <= set(own)                                   # every reference parameter has a home ...
+    assert {k for k in own if k not in sd} == {k for k in own if k.startswith("mano_layer.")}   # ... the rest are MANO buffers
+    for k, v in sd.items():
+        assert tuple(own[k].shape) == tuple(v.shape), k
+    assert tuple(own["mano_layer.th_posedirs"].shape) == (778, 3, 135)
+    assert tuple(own["mano_layer.th_hands_mean"].shape) == (1, 45) and tuple(own["mano_layer.th_faces"].shape) == (1538, 3)
+    with pytest.raises(VtError, match="HIP device"):
+        enc(torch.zeros(1, 16, 3))                               # no CPU fallback
+    with pytest.raises(VtError, match="HIP device"):
+        enc.mano_layer(torch.zeros(1, 48))
+    with pytest.raises(VtError):
+        encoder_dict["pointnet_local_pool"](c_dim=32, hidden_dim=32, plane_type=["grid", "xz"], plane_resolution=32,
+                                            grid_resolution=32)
+    with pytest.raises(VtError, match="rotmat"):
+        from vtaco_amd.encoder.manolayer import ManoLayer
+        ManoLayer(**dict(kw, root_rot_mode="rotmat", joint_rot_mode="rotmat"))
+    # the 2-D U-Net alone on the CPU (host PyTorch module) equals the oracle's restatement
+    usd = {k[len("unet."):]: v for k, v in sd.items() if k.startswith("unet.")}
+    enc.unet.load_state_dict(usd)
+    x = torch.randn(2, 32, 32, 32, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        assert maxdiff(enc.unet(x), orc.unet2d_forward(usd, x)) <= 1e-5
+
+
+def test_get_model_builds_the_hand_encoder(tmp_path):
+    from vtaco_amd.conv_onet import config
+    synth_mano.write_pkl(synth_mano.make_asset(0), str(tmp_path))
+    kw = dict(center_idx=9, flat_hand_mean=False, ncomps=45, side="right", mano_root=str(tmp_path), use_pca=False,
+              root_rot_mode="axisang", joint_rot_mode="axisang", robust_rot=False, return_transf=False)
+    hand = dict(hidden_dim=32, plane_type=["xz", "xy", "yz"], plane_resolution=32, unet=True,
+                unet_kwargs=dict(depth=2, merge_mode="concat", start_filts=8), out_mano=True, out_dim=51, manolayer_kwargs=kw)
+    cfg = {"data": {"dim": 3, "padding": 0.1, "input_type": "pointcloud"},
+           "model": {"c_dim": 32, "decoder": "simple_local", "decoder_kwargs": {"hidden_size": 32},
+                     "encoder": False, "encoder_hand": "pointnet_local_pool", "encoder_hand_kwargs": hand,
+                     "with_img": False, "encoder_t2d": "pointnet_local_pool",
+                     "encoder_t2d_kwargs": {"encoder_img": "UNet",
+                                            "encoder_img_kwargs": dict(num_classes=1, in_channels=3, depth=3, start_filts=8),
+                                            "encoder_hand": "pointnet_local_pool",
+                                            "encoder_hand_kwargs": dict(hand, c_dim=16, out_dim=30, manolayer_kwargs=None)}}}
+    model = config.get_model(cfg, device=None)
+    assert model.encoder_hand.fc_mano.in_features == 96 and model.encoder_hand.fc_mano.out_features == 51
+    assert model.encoder_t2d.encoder_hand.fc_mano.in_features == 48 and model.encoder_t2d.encoder_hand.out_dim == 30
+    assert hasattr(model, "encode_hand_mano")

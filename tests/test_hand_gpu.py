@@ -1,0 +1,171 @@
+"""GPU parity of the hand branch through the C ABI: plane cell ids and scatter-mean planes
+(vt_plane_*), the shared max-pool kernels over planes, the MANO layer (vt_mano_*), and the
+LocalPoolPointnet hand encoder end to end -- against the oracle and the reference-made golden
+g10_hand.npz (synthetic MANO asset of tests/synth_mano.py)."""
+import numpy as np
+import pytest
+import torch
+
+import synth_mano
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+PLANES = ("xz", "xy", "yz")
+MANO_KW = dict(center_idx=9, flat_hand_mean=False, ncomps=45, side="right", use_pca=False,
+               root_rot_mode="axisang", joint_rot_mode="axisang", robust_rot=False, return_transf=False)
+
+
+def maxdiff(a, b):
+    return float((torch.as_tensor(a).cpu() - torch.as_tensor(b).cpu()).abs().max())
+
+
+def test_plane_ids_bit_exact_and_scatter_mean():
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd import ops
+    a, _ = load_golden("g10_hand.npz")
+    dev = torch.device("cuda:0")
+    p = T(a["p"]).to(dev)
+    g = torch.Generator().manual_seed(7)
+    feat = torch.randn(2, 3000, 32, generator=g)
+    for k in PLANES:
+        pi = ops.PlaneIndex(p, 32, 0.1, k)
+        assert torch.equal(pi.idx.cpu(), T(a["idx_" + k]))              # golden ids from the reference, bit-exact
+        got = ops.plane_scatter_mean_fwd(feat.to(dev), pi)
+        ref = orc.scatter_mean_plane(feat, T(a["idx_" + k]).long(), 32)
+        assert maxdiff(got, ref) <= 1e-6
+        assert torch.equal(got.cpu() == 0, ref == 0)                    # empty cells exactly zero
+        # backward: d feat = d plane[cell] / count
+        gp = torch.randn(2, 32, 32, 32, generator=g)
+        f = feat.clone().requires_grad_(True)
+        (orc.scatter_mean_plane(f, T(a["idx_" + k]).long(), 32) * gp).sum().backward()
+        assert maxdiff(ops.plane_scatter_mean_bwd(gp.to(dev), pi, 32), f.grad) <= 1e-6
+    # ragged sizes, other resolutions, points far outside the box
+    for (B, Tn, R) in ((1, 1, 8), (3, 257, 64), (2, 8192, 128)):
+        pts = (torch.rand(B, Tn, 3, generator=g) - 0.5) * 1.6
+        for k in PLANES:
+            pi = ops.PlaneIndex(pts.to(dev), R, 0.1, k)
+            assert torch.equal(pi.idx.cpu().long(), orc.plane_index(pts, R, 0.1, k))
+    from vtaco_amd._lib import VtError
+    with pytest.raises(VtError):
+        ops.PlaneIndex(p, 32, 0.1, "zx")
+
+
+def test_pool_local_sums_the_three_planes():
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd import ops
+    a, _ = load_golden("g10_hand.npz")
+    dev = torch.device("cuda:0")
+    p = T(a["p"])
+    feat = torch.randn(2, 3000, 32, generator=torch.Generator().manual_seed(8))
+    ref = sum(orc.segment_pool_max(feat, T(a["idx_" + k]).long()) for k in PLANES)
+    got = 0
+    for k in PLANES:
+        got = got + ops.voxel_pool_max_fwd(feat.to(dev), ops.PlaneIndex(p.to(dev), 32, 0.1, k))[0]
+    assert maxdiff(got, ref) <= 1e-6
+
+
+@pytest.mark.parametrize("center_idx", [9, None, 0])
+def test_mano_layer_kernel(center_idx, tmp_path):
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd.encoder.manolayer import ManoLayer
+    a, _ = load_golden("g10_hand.npz")
+    asset = synth_mano.make_asset(0)
+    synth_mano.write_pkl(asset, str(tmp_path))
+    dev = torch.device("cuda:0")
+    layer = ManoLayer(**dict(MANO_KW, mano_root=str(tmp_path), center_idx=center_idx)).to(dev)
+    pose = T(a["pose"])
+    with torch.no_grad():
+        v, j = layer(pose.to(dev))
+    if center_idx == 9:                                            # the reference's own outputs
+        assert maxdiff(v, a["pose_verts"]) <= 1e-6 and maxdiff(j, a["pose_joints"]) <= 1e-6
+    rv, rj = orc.mano_forward(synth_mano.as_model(asset), pose, center_idx)
+    assert maxdiff(v, rv) <= 1e-6 and maxdiff(j, rj) <= 1e-6
+    # seeded batch incl. B not a multiple of anything, large angles
+    big = torch.randn(37, 48, generator=torch.Generator().manual_seed(2)) * 2.0
+    with torch.no_grad():
+        v, j = layer(big.to(dev))
+    rv, rj = orc.mano_forward(synth_mano.as_model(asset), big, center_idx)
+    assert maxdiff(v, rv) <= 2e-6 and maxdiff(j, rj) <= 2e-6
+    v0, j0 = layer(torch.zeros(0, 48, device=dev))                 # empty batch
+    assert v0.shape == (0, 778, 3) and j0.shape == (0, 21, 3)
+    # the differentiable host form is the same function, and its gradient matches the oracle's autograd
+    pg = pose.clone().to(dev).requires_grad_(True)
+    vt, jt = layer(pg)
+    assert vt.requires_grad
+    assert maxdiff(vt.detach(), orc.mano_forward(synth_mano.as_model(asset), pose, center_idx)[0]) <= 1e-6
+    w = torch.randn(4, 778, 3, generator=torch.Generator().manual_seed(3))
+    (vt * w.to(dev)).sum().backward()
+    pr = pose.clone().requires_grad_(True)
+    (orc.mano_forward(synth_mano.as_model(asset), pr, center_idx)[0] * w).sum().backward()
+    assert maxdiff(pg.grad, pr.grad) <= 1e-4 * float(pr.grad.abs().max())
+
+
+def test_pca_pose_space_and_refused_arguments(tmp_path):
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd._lib import VtError
+    from vtaco_amd.encoder.manolayer import ManoLayer
+    asset = synth_mano.make_asset(0)
+    synth_mano.write_pkl(asset, str(tmp_path))
+    dev = torch.device("cuda:0")
+    layer = ManoLayer(**dict(MANO_KW, mano_root=str(tmp_path), use_pca=True, ncomps=6)).to(dev)
+    coeffs = torch.randn(3, 9, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        v, _ = layer(coeffs.to(dev))
+    comps = T(asset["hands_components"][:6].astype(np.float32))
+    pose = torch.cat([coeffs[:, :3], coeffs[:, 3:].mm(comps)], dim=1)          # manolayer.py:186-188
+    assert maxdiff(v, orc.mano_forward(synth_mano.as_model(asset), pose)[0]) <= 1e-6
+    with pytest.raises(VtError):
+        layer(coeffs.to(dev), th_trans=torch.zeros(3, 3, device=dev))
+    with pytest.raises(VtError):
+        layer(torch.zeros(3, 5, device=dev))
+
+
+def test_hand_encoder_end_to_end_golden_and_training_gradients(tmp_path):
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd.encoder import encoder_dict
+    a, sd = load_golden("g10_hand.npz")
+    asset = synth_mano.make_asset(0)
+    synth_mano.write_pkl(asset, str(tmp_path))
+    dev = torch.device("cuda:0")
+    enc = encoder_dict["pointnet_local_pool"](
+        dim=3, c_dim=32, padding=0.1, hidden_dim=32, plane_type=["xz", "xy", "yz"], plane_resolution=32, unet=True,
+        unet_kwargs=dict(depth=3, merge_mode="concat", start_filts=16), out_mano=True, out_dim=51,
+        manolayer_kwargs=dict(MANO_KW, mano_root=str(tmp_path)))
+    enc.load_state_dict(sd, strict=False)                          # MANO buffers come from the asset
+    enc = enc.to(dev).eval()
+    p = T(a["p"]).to(dev)
+    with torch.no_grad():
+        out = enc(p)
+        enc.out_mano = False
+        planes = enc(p)
+        enc.out_mano = True
+    for k in PLANES:
+        assert maxdiff(planes[k], a["plane_" + k]) <= 1e-4
+    assert maxdiff(out["mano_param"], a["mano_param"]) <= 1e-4
+    assert maxdiff(out["mano_verts"], a["mano_verts"]) <= 1e-4
+    assert maxdiff(out["mano_joints"], a["mano_joints"]) <= 1e-4
+    assert torch.equal(out["mano_faces"].cpu(), T(a["mano_faces"]).long())
+    # training: loss_mano + loss_pc (training.py:493-494) backward through MANO layer, U-Net, HIP scatter / pool kernels
+    g = torch.Generator().manual_seed(5)
+    mano_gt, pc_gt = torch.randn(2, 51, generator=g) * 0.3, torch.randn(2, 778, 3, generator=g) * 0.05
+    enc.train()
+    enc.zero_grad()
+    out = enc(p)
+    loss = torch.nn.functional.mse_loss(out["mano_param"], mano_gt.to(dev)) + \
+        torch.nn.functional.mse_loss(out["mano_verts"], pc_gt.to(dev))
+    loss.backward()
+    # reference gradients: autograd of the oracle on the CPU
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ro = orc.hand_encoder_forward(leaves, synth_mano.as_model(asset), T(a["p"]), 32)
+    rl = torch.nn.functional.mse_loss(ro["mano_param"], mano_gt) + torch.nn.functional.mse_loss(ro["mano_verts"], pc_gt)
+    rl.backward()
+    assert abs(float(loss) - float(rl)) <= 1e-5 * max(1.0, abs(float(rl)))
+    checked = 0
+    for name, prm in enc.named_parameters():
+        ref = leaves[name].grad
+        assert ref is not None, name
+        scale = float(ref.abs().max())
+        assert maxdiff(prm.grad, ref) <= 2e-3 * scale + 1e-7, name
+        checked += 1
+    assert checked == len(sd)

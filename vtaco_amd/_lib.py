@@ -102,6 +102,11 @@ SIGNATURES = {
     "vt_voxel_pool_max_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
     "vt_voxel_scatter_mean_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "vt_voxel_scatter_mean_bwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
+    "vt_plane_build": (_I, [_VP, _I, _I, _I, _D, _I, _VP, _VP, _VP, _VP, _VP]),
+    "vt_plane_scatter_mean_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
+    "vt_plane_scatter_mean_bwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
+    "vt_mano_pack": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "vt_mano_fwd": (_I, [_VP, _I, _VP, _I, _VP, _VP, _VP]),
     "vt_conv3d_packed_floats": (_SZ, [_I, _I]),
     "vt_conv3d_pack": (_I, [_VP, _I, _I, _VP, _VP]),
     "vt_stats_floats": (_SZ, [_I, _I, _I, _I, _I]),

@@ -18,8 +18,11 @@ def get_model(cfg, device=None, dataset=None, **kwargs):
     encoder = None
     if m['encoder']:
         encoder = encoder_dict[m['encoder']](dim=dim, c_dim=c_dim, padding=padding, **(m.get('encoder_kwargs') or {}))
+    encoder_hand = None
     if m.get('encoder_hand'):
-        raise VtError("get_model: the hand / MANO branch (encoder_hand) is out of scope here; set encoder_hand: False")
+        # reference config.py:104-110: same registry, the hand encoder's own kwargs (planes, 2-D U-Net, MANO head)
+        encoder_hand = encoder_dict[m['encoder_hand']](dim=dim, c_dim=c_dim, padding=padding,
+                                                        **(m.get('encoder_hand_kwargs') or {}))
     encoder_img = None
     if m.get('with_img') and m.get('encoder_img'):
         encoder_img = encoder_dict[m['encoder_img']](**(m.get('encoder_img_kwargs') or {}))
@@ -27,8 +30,12 @@ def get_model(cfg, device=None, dataset=None, **kwargs):
     if m.get('encoder_t2d'):
         kw = m['encoder_t2d_kwargs']
         img_t2d = encoder_dict[kw['encoder_img']](**kw['encoder_img_kwargs'])
-        encoder_t2d = models.ConvolutionalOccupancyNetwork(None, None, None, img_t2d, None, device=device)
-    return models.ConvolutionalOccupancyNetwork(decoder, encoder, None, encoder_img, encoder_t2d, device=device)
+        hand_t2d = None
+        if kw.get('encoder_hand'):
+            # the digit-pose regressor of the t2d model (config.py:126-131): c_dim comes from its own kwargs
+            hand_t2d = encoder_dict[kw['encoder_hand']](dim=dim, padding=padding, **(kw.get('encoder_hand_kwargs') or {}))
+        encoder_t2d = models.ConvolutionalOccupancyNetwork(None, None, hand_t2d, img_t2d, None, device=device)
+    return models.ConvolutionalOccupancyNetwork(decoder, encoder, encoder_hand, encoder_img, encoder_t2d, device=device)
 
 
 def get_generator(model, cfg, device, **kwargs):

@@ -41,6 +41,10 @@ class ConvolutionalOccupancyNetwork(nn.Module):
     def encode_hand_inputs(self, inputs):
         return self._encode_with(self.encoder_hand, inputs)
 
+    def encode_hand_mano(self, inputs):
+        """MANO layer alone on given pose parameters (models/__init__.py:104-112)."""
+        return self.encoder_hand.forward_mano(inputs)
+
     def encode_img_inputs(self, imgs):
         """Per-scene loop over the 5 tactile images (models/__init__.py:115-136): keeps
         train-mode BatchNorm statistics per scene, as the reference does."""

@@ -12,6 +12,7 @@
 // sequential scatter_add order of the CPU path).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "vt_common.h"
 
@@ -21,15 +22,16 @@ constexpr int SORT_THREADS = 1024;
 constexpr int MAX_T = 8192;          // points per scene the in-LDS sort covers (64 KiB of u64)
 
 // reference src/common.py:293-309 + :333-348 in f32, truncating cast
-__device__ __forceinline__ int voxel_coord(float v, float divisor, int R) {
+// (planes: src/common.py:268-291, divisor 1 + padding + 10e-6 and upper clamp 1 - 10e-6 instead)
+__device__ __forceinline__ int voxel_coord(float v, float divisor, float clamp_hi, int R) {
     float q = v / divisor + 0.5f;
-    q = (q >= 1.0f) ? 0.999f : q;
+    q = (q >= 1.0f) ? clamp_hi : q;
     q = (q < 0.0f) ? 0.0f : q;
     return (int)(q * (float)R);
 }
 
 __global__ void __launch_bounds__(SORT_THREADS)
-voxel_build_kernel(const float *pts, int T, int Tpad, int R, float divisor,
+voxel_build_kernel(const float *pts, int T, int Tpad, int R, float divisor, float clamp_hi, int a0, int a1, int a2,
                    int *idx, int *order, int *seg_lo, int *seg_hi) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
     const int b = blockIdx.x;
@@ -37,9 +39,10 @@ voxel_build_kernel(const float *pts, int T, int Tpad, int R, float divisor,
     for (int t = threadIdx.x; t < Tpad; t += SORT_THREADS) {
         unsigned long long k = ~0ull;
         if (t < T) {
-            const int ix = voxel_coord(p[3 * t + 0], divisor, R);
-            const int iy = voxel_coord(p[3 * t + 1], divisor, R);
-            const int iz = voxel_coord(p[3 * t + 2], divisor, R);
+            // cell id = i(a0) + R * (i(a1) + R * i(a2)); a plane has no third axis (a2 < 0)
+            const int ix = voxel_coord(p[3 * t + a0], divisor, clamp_hi, R);
+            const int iy = voxel_coord(p[3 * t + a1], divisor, clamp_hi, R);
+            const int iz = a2 >= 0 ? voxel_coord(p[3 * t + a2], divisor, clamp_hi, R) : 0;
             const int id = ix + R * (iy + R * iz);
             idx[(size_t)b * T + t] = id;
             k = ((unsigned long long)(unsigned)id << 32) | (unsigned)t;
@@ -137,7 +140,7 @@ pool_max_bwd_kernel(const float *grad_out, const int *argmax, const int *order, 
 // grid[b,c,voxel] = mean of feat over the voxel's points (grid pre-zeroed); NCDHW output
 __global__ void __launch_bounds__(256)
 scatter_mean_fwd_kernel(const float *feat, const int *idx, const int *order, const int *seg_lo, const int *seg_hi,
-                        float *grid, int T, int C, size_t V, uint32_t npts) {
+                        float *grid, int T, int C, size_t V, uint32_t npts) {   // V = cells per channel (R^3 or R^2)
     uint32_t bt; int c0;
     if (!point_lane(C, npts, bt, c0)) return;
     const uint32_t b = bt / (uint32_t)T;
@@ -176,15 +179,13 @@ inline unsigned blocks_for(size_t total) {
     return (unsigned)(g < cap ? (g ? g : 1) : cap);
 }
 
-}  // namespace
-
-extern "C" {
-
-int vt_voxel_build(const float *pts, int B, int T, int R, double padding,
-                   int *idx, int *order, int *seg_lo, int *seg_hi, void *stream) {
-    if (!pts || !idx || !order || !seg_lo || !seg_hi) return vt_fail(VT_ERR_INVALID, "vt_voxel_build: null argument");
-    if (B <= 0 || T <= 0 || R < 1 || R > 1024) return vt_fail(VT_ERR_INVALID, "vt_voxel_build: bad size");
-    if (T > MAX_T) return vt_fail(VT_ERR_UNSUPPORTED, "vt_voxel_build: more than 8192 points per scene");
+int build_launch(const char *who, const float *pts, int B, int T, int R, float divisor, float clamp_hi,
+                 int a0, int a1, int a2, int *idx, int *order, int *seg_lo, int *seg_hi, void *stream) {
+    char msg[96];
+    auto fail = [&](int code, const char *what) { snprintf(msg, sizeof msg, "%s: %s", who, what); return vt_fail(code, msg); };
+    if (!pts || !idx || !order || !seg_lo || !seg_hi) return fail(VT_ERR_INVALID, "null argument");
+    if (B <= 0 || T <= 0 || R < 1 || R > 1024) return fail(VT_ERR_INVALID, "bad size");
+    if (T > MAX_T) return fail(VT_ERR_UNSUPPORTED, "more than 8192 points per scene");
     int Tpad = 2;
     while (Tpad < T) Tpad <<= 1;
     const size_t lds = (size_t)Tpad * sizeof(unsigned long long);
@@ -196,8 +197,49 @@ int vt_voxel_build(const float *pts, int B, int T, int R, double padding,
         attr_set = true;
     }
     hipLaunchKernelGGL(voxel_build_kernel, dim3(B), dim3(SORT_THREADS), lds, (hipStream_t)stream,
-                       pts, T, Tpad, R, (float)(1.0 + padding + 10e-4), idx, order, seg_lo, seg_hi);
-    return vt_check(hipGetLastError(), "vt_voxel_build");
+                       pts, T, Tpad, R, divisor, clamp_hi, a0, a1, a2, idx, order, seg_lo, seg_hi);
+    return vt_check(hipGetLastError(), who);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vt_voxel_build(const float *pts, int B, int T, int R, double padding,
+                   int *idx, int *order, int *seg_lo, int *seg_hi, void *stream) {
+    return build_launch("vt_voxel_build", pts, B, T, R, (float)(1.0 + padding + 10e-4), 0.999f, 0, 1, 2,
+                        idx, order, seg_lo, seg_hi, stream);
+}
+
+int vt_plane_build(const float *pts, int B, int T, int R, double padding, int plane,
+                   int *idx, int *order, int *seg_lo, int *seg_hi, void *stream) {
+    if (plane < 0 || plane > 2) return vt_fail(VT_ERR_INVALID, "vt_plane_build: plane must be 0 (xz), 1 (xy) or 2 (yz)");
+    const int a0 = plane == 2 ? 1 : 0, a1 = plane == 1 ? 1 : 2;
+    return build_launch("vt_plane_build", pts, B, T, R, (float)(1.0 + padding + 10e-6), (float)(1.0 - 10e-6), a0, a1, -1,
+                        idx, order, seg_lo, seg_hi, stream);
+}
+
+int vt_plane_scatter_mean_fwd(const float *feat, const int *idx, const int *order, const int *seg_lo, const int *seg_hi,
+                              int B, int T, int C, int R, float *plane, void *stream) {
+    if (!feat || !idx || !order || !seg_lo || !seg_hi || !plane)
+        return vt_fail(VT_ERR_INVALID, "vt_plane_scatter_mean_fwd: null argument");
+    if (B <= 0 || T <= 0 || C <= 0 || R < 1) return vt_fail(VT_ERR_INVALID, "vt_plane_scatter_mean_fwd: bad size");
+    const size_t V = (size_t)R * R;
+    int frc = vt_fill32(plane, 0u, (size_t)B * C * V * sizeof(float), (hipStream_t)stream);
+    if (frc) return frc;
+    hipLaunchKernelGGL(scatter_mean_fwd_kernel, dim3(point_blocks(C, (size_t)B * T)), dim3(256), 0, (hipStream_t)stream,
+                       feat, idx, order, seg_lo, seg_hi, plane, T, C, V, (uint32_t)((size_t)B * T));
+    return vt_check(hipGetLastError(), "vt_plane_scatter_mean_fwd");
+}
+
+int vt_plane_scatter_mean_bwd(const float *grad_plane, const int *idx, const int *seg_lo, const int *seg_hi,
+                              int B, int T, int C, int R, float *grad_feat, void *stream) {
+    if (!grad_plane || !idx || !seg_lo || !seg_hi || !grad_feat)
+        return vt_fail(VT_ERR_INVALID, "vt_plane_scatter_mean_bwd: null argument");
+    if (B <= 0 || T <= 0 || C <= 0 || R < 1) return vt_fail(VT_ERR_INVALID, "vt_plane_scatter_mean_bwd: bad size");
+    hipLaunchKernelGGL(scatter_mean_bwd_kernel, dim3(point_blocks(C, (size_t)B * T)), dim3(256), 0, (hipStream_t)stream,
+                       grad_plane, idx, seg_lo, seg_hi, grad_feat, T, C, (size_t)R * R, (uint32_t)((size_t)B * T));
+    return vt_check(hipGetLastError(), "vt_plane_scatter_mean_bwd");
 }
 
 int vt_voxel_pool_max_fwd(const float *feat, const int *order, const int *seg_lo, const int *seg_hi,

@@ -4,8 +4,11 @@ src/encoder/pointnet.py:12-210, ``plane_type='grid'``).
 The per-point MLP (fc_pos, 5 ResnetBlockFC, fc_c: 0.16 GFLOP/scene) is host
 PyTorch-ROCm; the voxel bookkeeping, the 4 local max-pool rounds and the final
 scatter-mean -- torch_scatter in the reference -- are HIP kernels (vt_voxel_*),
-wrapped in autograd Functions whose backward is also HIP.  Plane features
-('xz','xy','yz') belong to the hand branch and are not built.
+wrapped in autograd Functions whose backward is also HIP.
+
+The hand branch (``encoder_hand``: plane_type ['xz','xy','yz'], 2-D U-Net, ``out_mano``) uses the
+same pooling kernels over per-plane cell ids (vt_plane_build), scatter-means into [B,C,R,R] planes
+(vt_plane_scatter_mean_*), and ends in the MANO layer (manolayer.py).
 """
 from __future__ import annotations
 
@@ -17,6 +20,8 @@ from torch import nn
 from .. import ops
 from .._lib import VtError
 from ..layers import ResnetBlockFC
+from .manolayer import ManoLayer
+from .unet import UNet
 from .unet3d import UNet3D
 
 
@@ -61,9 +66,22 @@ class _ScatterMeanCL(torch.autograd.Function):
         return ops.voxel_scatter_mean_cl_bwd(grad.permute(0, 2, 3, 4, 1).contiguous(), ctx.vi, ctx.C), None
 
 
+class _ScatterMeanPlane(torch.autograd.Function):
+    """generate_plane_features' scatter (pointnet.py:85-95): [B,T,C] -> [B,C,R,R]."""
+
+    @staticmethod
+    def forward(ctx, feat, pi):
+        ctx.pi, ctx.C = pi, feat.shape[2]
+        return ops.plane_scatter_mean_fwd(feat, pi)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return ops.plane_scatter_mean_bwd(grad, ctx.pi, ctx.C), None
+
+
 class LocalPoolPointnet(nn.Module):
-    """Args as the reference (pointnet.py:32-35); only scatter_type='max',
-    plane_type='grid' (or ['grid']) are built."""
+    """Args as the reference (pointnet.py:32-35).  Built: scatter_type='max' with plane_type 'grid'
+    (object encoder) or any of 'xz','xy','yz' (hand encoder; 'grid' and planes are not mixed)."""
 
     def __init__(self, c_dim=128, dim=3, hidden_dim=128, scatter_type='max', unet=False, unet_kwargs=None,
                  unet3d=False, unet3d_kwargs=None, plane_resolution=None, grid_resolution=None,
@@ -75,16 +93,38 @@ class LocalPoolPointnet(nn.Module):
                 raise VtError("LocalPoolPointnet: scatter_type='mean' pooling is not built (configs use 'max')")
             raise ValueError('incorrect scatter type')
         planes = [plane_type] if isinstance(plane_type, str) else list(plane_type)
-        if planes != ['grid'] or unet or out_mano or manolayer_kwargs is not None:
-            raise VtError("LocalPoolPointnet: only plane_type='grid' without the hand/MANO head is built "
-                          "(plane features / MANO: out of scope, SURVEY.md section 2 rows 10, 17)")
-        if grid_resolution is None:
+        # the reference walks the keys in this fixed order whatever the list says (pointnet.py:141-176)
+        self.planes = [k for k in ('grid', 'xz', 'xy', 'yz') if k in planes]
+        if not self.planes or len(self.planes) != len(planes):
+            raise VtError(f"LocalPoolPointnet: plane_type {plane_type!r} has entries other than 'grid','xz','xy','yz'")
+        if 'grid' in self.planes and len(self.planes) > 1:
+            raise VtError("LocalPoolPointnet: 'grid' mixed with canonical planes is not built (no config uses it)")
+        if self.planes == ['grid'] and grid_resolution is None:
             raise VtError("LocalPoolPointnet: grid_resolution is required")
+        if self.planes != ['grid'] and plane_resolution is None:
+            raise VtError("LocalPoolPointnet: plane_resolution is required")
+        if self.planes == ['grid'] and unet:
+            raise VtError("LocalPoolPointnet: unet=True needs canonical planes (plane_type 'xz'/'xy'/'yz')")
         self.c_dim, self.hidden_dim = c_dim, hidden_dim
         self.fc_pos = nn.Linear(dim, 2 * hidden_dim)
         self.blocks = nn.ModuleList(ResnetBlockFC(2 * hidden_dim, hidden_dim) for _ in range(n_blocks))
         self.fc_c = nn.Linear(hidden_dim, c_dim)
-        self.unet = None
+        self.unet = UNet(c_dim, in_channels=c_dim, **(unet_kwargs or {})) if unet else None
+        self.out_mano, self.out_dim = out_mano, out_dim
+        if manolayer_kwargs is not None:
+            self.mano_layer = ManoLayer(**manolayer_kwargs)
+        if out_mano:
+            if out_dim is None:
+                raise VtError("LocalPoolPointnet: out_mano=True needs out_dim")
+            # pointnet.py:78-82: the three-plane head reads 3*c_dim pooled channels, the grid head c_dim
+            if self.planes == ['xz', 'xy', 'yz']:
+                self.fc_mano = nn.Linear(c_dim * 3, out_dim)
+            elif self.planes == ['grid']:
+                self.fc_mano = nn.Linear(c_dim, out_dim)
+            else:
+                raise VtError("LocalPoolPointnet: out_mano=True is defined for the three planes or the grid only")
+            if out_dim > 30 and manolayer_kwargs is None:
+                raise VtError("LocalPoolPointnet: out_dim > 30 runs the MANO layer (pointnet.py:194-201): pass manolayer_kwargs")
         # channels_last_3d parameters: MIOpen's f32 conv3d is ~14x faster in that layout on gfx950
         # (26 vs 382 ms fwd+bwd for two 64^3 scenes), and it is the layout the HIP kernels use
         self.unet3d = UNet3D(**unet3d_kwargs).to(memory_format=torch.channels_last_3d) if unet3d else None
@@ -95,16 +135,52 @@ class LocalPoolPointnet(nn.Module):
         self.train_unet3d = os.environ.get("VTACO_TRAIN_UNET3D", "hip")
 
     def point_features(self, p, vi):
-        """fc_pos -> block0 -> 4 x (local max-pool, concat, block) -> fc_c  (pointnet.py:154-162)."""
+        """fc_pos -> block0 -> 4 x (local max-pool, concat, block) -> fc_c  (pointnet.py:154-162).
+        ``vi``: one VoxelIndex, or a list of PlaneIndex whose pooled features are summed (pointnet.py:116-132)."""
         net = self.blocks[0](self.fc_pos(p))
         for blk in self.blocks[1:]:
-            pooled = _PoolMax.apply(net, vi)
+            if isinstance(vi, (list, tuple)):
+                pooled = _PoolMax.apply(net, vi[0])
+                for other in vi[1:]:
+                    pooled = pooled + _PoolMax.apply(net, other)
+            else:
+                pooled = _PoolMax.apply(net, vi)
             net = blk(torch.cat([net, pooled], dim=2))
         return self.fc_c(net)
+
+    def _mano_head(self, fea):
+        """out_mano (pointnet.py:179-201): pooled plane/grid features -> mano_param (-> MANO layer)."""
+        cat = torch.cat([fea[k] for k in fea], dim=1)
+        pooled = cat.mean(dim=tuple(range(2, cat.dim())))
+        param = self.fc_mano(pooled)
+        out = {'mano_param': param}
+        if self.out_dim > 30:
+            # the wrist position slot is zeroed and what follows the six wrist numbers is the hand pose (:195-197)
+            full = torch.cat([torch.zeros_like(param[:, :3]), param[:, 6:]], dim=1)
+            out.update(self.forward_mano(full))
+        return out
+
+    def forward_mano(self, fea_m_full):
+        """pointnet.py:204-212."""
+        verts, joints = self.mano_layer(fea_m_full)[:2]
+        return {'mano_verts': verts, 'mano_joints': joints, 'mano_faces': self.mano_layer.th_faces}
+
+    def forward_planes(self, p):
+        pis = [ops.PlaneIndex(p, self.reso_plane, self.padding, k) for k in self.planes]
+        feat = self.point_features(p.float(), pis)
+        fea = {}
+        for k, pi in zip(self.planes, pis):
+            plane = _ScatterMeanPlane.apply(feat, pi)
+            fea[k] = self.unet(plane) if self.unet is not None else plane
+        return fea
 
     def forward(self, p):
         if not p.is_cuda:
             raise VtError(f"LocalPoolPointnet: inputs must live on a HIP device (got {p.device})")
+        fea = self.forward_planes(p) if self.planes != ['grid'] else self.forward_grid(p)
+        return self._mano_head(fea) if self.out_mano else fea
+
+    def forward_grid(self, p):
         vi = ops.VoxelIndex(p, self.reso_grid, self.padding)
         feat = self.point_features(p.float(), vi)
         if self.unet3d is not None and not torch.is_grad_enabled() and self.unet3d.hip_supported():

@@ -340,6 +340,91 @@ def voxel_scatter_mean_bwd(grad_grid, vi, C):
 
 
 # --------------------------------------------------------------------------------------
+# hand branch: plane bookkeeping (vt_plane_*) and the MANO layer (vt_mano_*)
+# --------------------------------------------------------------------------------------
+PLANES = {"xz": 0, "xy": 1, "yz": 2}
+
+
+class PlaneIndex(VoxelIndex):
+    """VoxelIndex of one canonical plane (vt_plane_build): same fields, R^2 cells, so the
+    voxel_pool_max_* wrappers take it unchanged."""
+
+    def __init__(self, pts, reso, padding=0.1, plane="xz"):
+        if plane not in PLANES:
+            raise _lib.VtError(f"PlaneIndex: unknown plane {plane!r} (one of {sorted(PLANES)})")
+        pts = pts.detach().float()
+        if not pts.is_contiguous():
+            pts = pts.contiguous()
+        B, T, _ = pts.shape
+        self.B, self.T, self.R, self.plane = B, T, reso, plane
+        dev = pts.device
+        self.idx, self.order, self.seg_lo, self.seg_hi = (torch.empty((B, T), dtype=I32, device=dev) for _ in range(4))
+        check(_lib.load().vt_plane_build(dev_ptr(pts, "pts"), B, T, reso, float(padding), PLANES[plane],
+                                         dev_ptr(self.idx, "idx", I32), dev_ptr(self.order, "order", I32),
+                                         dev_ptr(self.seg_lo, "seg_lo", I32), dev_ptr(self.seg_hi, "seg_hi", I32),
+                                         stream_ptr()), "vt_plane_build")
+
+
+def plane_scatter_mean_fwd(feat, pi):
+    feat = _c(feat)
+    B, T, C = feat.shape
+    plane = torch.empty((B, C, pi.R, pi.R), dtype=torch.float32, device=feat.device)
+    check(_lib.load().vt_plane_scatter_mean_fwd(dev_ptr(feat, "feat"), dev_ptr(pi.idx, "idx", I32),
+                                                dev_ptr(pi.order, "order", I32), dev_ptr(pi.seg_lo, "seg_lo", I32),
+                                                dev_ptr(pi.seg_hi, "seg_hi", I32), B, T, C, pi.R, dev_ptr(plane, "plane"),
+                                                stream_ptr()), "vt_plane_scatter_mean_fwd")
+    return plane
+
+
+def plane_scatter_mean_bwd(grad_plane, pi, C):
+    grad_plane = _c(grad_plane)
+    g = torch.empty((pi.B, pi.T, C), dtype=torch.float32, device=grad_plane.device)
+    check(_lib.load().vt_plane_scatter_mean_bwd(dev_ptr(grad_plane, "grad_plane"), dev_ptr(pi.idx, "idx", I32),
+                                                dev_ptr(pi.seg_lo, "seg_lo", I32), dev_ptr(pi.seg_hi, "seg_hi", I32),
+                                                pi.B, pi.T, C, pi.R, dev_ptr(g, "grad_feat"), stream_ptr()),
+          "vt_plane_scatter_mean_bwd")
+    return g
+
+
+MANO_BLOB_FLOATS = 330240
+
+
+def mano_pack(v_template, shapedirs, betas, posedirs, j_regressor, weights, hands_mean):
+    """Model arrays (f32, on the device) -> the blob vt_mano_fwd reads (vt_mano_pack)."""
+    dev = v_template.device
+    want = {"v_template": (v_template, (778, 3)), "posedirs": (posedirs, (778, 3, 135)),
+            "j_regressor": (j_regressor, (16, 778)), "weights": (weights, (778, 16)), "hands_mean": (hands_mean, (45,))}
+    if betas is not None:
+        want["shapedirs"], want["betas"] = (shapedirs, (778, 3, 10)), (betas, (10,))
+    arrs = {}
+    for name, (t, shape) in want.items():
+        if tuple(t.shape) != shape:
+            raise _lib.VtError(f"mano_pack: {name} has shape {tuple(t.shape)}, expected {shape}")
+        arrs[name] = _c(t.float())
+    blob = torch.empty(MANO_BLOB_FLOATS, dtype=torch.float32, device=dev)
+    check(_lib.load().vt_mano_pack(dev_ptr(arrs["v_template"], "v_template"), dev_ptr(arrs.get("shapedirs"), "shapedirs"),
+                                   dev_ptr(arrs.get("betas"), "betas"), dev_ptr(arrs["posedirs"], "posedirs"),
+                                   dev_ptr(arrs["j_regressor"], "j_regressor"), dev_ptr(arrs["weights"], "weights"),
+                                   dev_ptr(arrs["hands_mean"], "hands_mean"), dev_ptr(blob, "blob"), stream_ptr()),
+          "vt_mano_pack")
+    return blob
+
+
+def mano_fwd(pose, blob, center_idx=9):
+    """pose [B,48] -> (verts [B,778,3], joints [B,21,3]) (vt_mano_fwd)."""
+    pose = _c(pose.float())
+    if pose.dim() != 2 or pose.shape[1] != 48:
+        raise _lib.VtError(f"mano_fwd: pose must be [B,48] (root axis-angle + 45 joint angles), got {tuple(pose.shape)}")
+    B = pose.shape[0]
+    verts = torch.empty((B, 778, 3), dtype=torch.float32, device=pose.device)
+    joints = torch.empty((B, 21, 3), dtype=torch.float32, device=pose.device)
+    check(_lib.load().vt_mano_fwd(dev_ptr(pose, "pose"), B, dev_ptr(blob, "blob"),
+                                  -1 if center_idx is None else int(center_idx),
+                                  dev_ptr(verts, "verts"), dev_ptr(joints, "joints"), stream_ptr()), "vt_mano_fwd")
+    return verts, joints
+
+
+# --------------------------------------------------------------------------------------
 # decode backward (training)
 # --------------------------------------------------------------------------------------
 def decode_save_buffer(total_points, device):
