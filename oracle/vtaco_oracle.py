@@ -557,3 +557,32 @@ def hand_encoder_forward(sd, model, p, reso, padding=0.1, out_dim=51, center_idx
         full = torch.cat([torch.zeros(param.shape[0], 3), param[:, 6:]], dim=1)
         out["mano_verts"], out["mano_joints"] = mano_forward(model, full, center_idx)
     return out
+
+
+def rot_from_pyr(angles):
+    """``R_from_PYR`` (src/common.py:591-604): R_pitch(angles[1]) @ R_yaw(angles[2]) @ R_roll(angles[0]) with the
+    reference's sign conventions (roll about z; pitch about x and yaw about y, both transposed)."""
+    import numpy as np
+    roll, pitch, yaw = angles
+    r_roll = np.array([[np.cos(roll), -np.sin(roll), 0], [np.sin(roll), np.cos(roll), 0], [0, 0, 1]])
+    r_pitch = np.array([[1, 0, 0], [0, np.cos(pitch), np.sin(pitch)], [0, -np.sin(pitch), np.cos(pitch)]])
+    r_yaw = np.array([[np.cos(yaw), 0, -np.sin(yaw)], [0, 1, 0], [np.sin(yaw), 0, np.cos(yaw)]])
+    return r_pitch @ r_yaw @ r_roll
+
+
+def hand_mesh_vertices(verts, mano_param, pc_ply):
+    """Vertex post-processing of ``Generator3D.generate_hand_mesh`` (generation.py:88-110): remove the MANO
+    frame offset and the fixed frame rotation, undo the predicted wrist rotation (rotation vector -> 'XYZ'
+    Euler angles -> R_from_PYR), add the wrist position, normalise like the object cloud (norm_pc_1,
+    common.py:606-612).  numpy in, float64 [V,3] out."""
+    import numpy as np
+    from scipy.spatial.transform import Rotation
+    wrist_pos, wrist_rotvec = mano_param[:3], mano_param[3:6]
+    euler = Rotation.from_rotvec(wrist_rotvec).as_euler("XYZ", degrees=False)
+    v = verts.astype(np.float32) - np.array([0.11, 0.005, 0], dtype=np.float32)
+    v = np.linalg.inv(rot_from_pyr(np.array([-np.pi / 2, np.pi / 2, 0]))) @ v.T
+    v = np.linalg.inv(rot_from_pyr(np.array(euler))) @ v
+    v = v.T + wrist_pos
+    centroid = np.mean(pc_ply, axis=0)
+    m = np.max(np.sqrt(np.sum((pc_ply - centroid) ** 2, axis=1)))
+    return (v - centroid) / (2 * m)

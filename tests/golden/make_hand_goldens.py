@@ -61,6 +61,47 @@ def _install_mano_stubs():
     sys.modules["cv2"] = cv2
 
 
+def _reference_hand_mesh(out, pc_ply):
+    """Generator3D.generate_hand_mesh (generation.py:74-115) of the real reference on given encoder outputs.
+    generation.py imports trimesh / skimage (not installed) and reads a dataset file at import: stand-ins
+    for the two modules, and np.loadtxt answers that one read with zeros (the array is unused here)."""
+    import importlib
+
+    class Trimesh(object):
+        def __init__(self, vertices, faces):
+            self.vertices, self.faces = np.asarray(vertices), np.asarray(faces)
+
+    tm = types.ModuleType("trimesh")
+    tm.Trimesh = Trimesh
+    sk, skm = types.ModuleType("skimage"), types.ModuleType("skimage.measure")
+    sk.measure = skm
+    sys.modules.update({"trimesh": tm, "skimage": sk, "skimage.measure": skm})
+    loadtxt = np.loadtxt
+    np.loadtxt = lambda *a, **k: np.zeros((320, 240))
+    try:
+        generation = importlib.import_module("src.conv_onet.generation")
+    finally:
+        np.loadtxt = loadtxt
+
+    class FakeModel(object):
+        def to(self, device):
+            return self
+
+        def eval(self):
+            return self
+
+        def encode_hand_inputs(self, inputs):
+            return out
+
+    gen = generation.Generator3D(FakeModel(), device="cpu")
+    B = out["mano_param"].shape[0]
+    assert B == 1
+    data = {"inputs": torch.zeros(1, 4, 3), "inputs.pc_ply": pc_ply, "points.mano": torch.zeros(1, 51),
+            "points.wrist": torch.zeros(1, 3)}
+    mesh = gen.generate_hand_mesh(data)
+    return mesh.vertices, mesh.faces
+
+
 MANO_KW = dict(center_idx=9, flat_hand_mean=False, ncomps=45, side="right", use_pca=False,
                root_rot_mode="axisang", joint_rot_mode="axisang", robust_rot=False, return_transf=False)
 
@@ -109,6 +150,9 @@ def main():
     pose[3] *= 3.0
     with torch.no_grad():
         mv, mj = enc.mano_layer(pose)
+    # hand mesh post-processing of the generator on scene 0 (wrist pose un-rotation, normalisation by the object cloud)
+    pc_ply = torch.randn(1, 500, 3, generator=g) * 0.2 + 0.1
+    hv, hf = _reference_hand_mesh({k: (v[:1] if k != "mano_faces" else v) for k, v in out.items()}, pc_ply)
     sd = {k: v for k, v in mg._sd(enc, "sd.").items() if "mano_layer" not in k}
     mg._save("g10_hand.npz", p=p_in.numpy(),
              idx_xz=idx["xz"].numpy().astype(np.int32), idx_xy=idx["xy"].numpy().astype(np.int32),
@@ -116,7 +160,9 @@ def main():
              plane_xz=planes["xz"].numpy(), plane_xy=planes["xy"].numpy(), plane_yz=planes["yz"].numpy(),
              mano_param=out["mano_param"].numpy(), mano_verts=out["mano_verts"].numpy(),
              mano_joints=out["mano_joints"].numpy(), mano_faces=out["mano_faces"].numpy().astype(np.int32),
-             pose=pose.numpy(), pose_verts=mv.numpy(), pose_joints=mj.numpy(), **sd)
+             pose=pose.numpy(), pose_verts=mv.numpy(), pose_joints=mj.numpy(),
+             pc_ply=pc_ply.numpy(), hand_mesh_verts=np.asarray(hv, dtype=np.float64), hand_mesh_faces=np.asarray(hf, dtype=np.int32),
+             **sd)
 
     # oracle vs the reference on the synthetic asset
     model = synth_mano.as_model(asset)

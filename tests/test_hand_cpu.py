@@ -156,3 +156,14 @@ def test_get_model_builds_the_hand_encoder(tmp_path):
     assert model.encoder_hand.fc_mano.in_features == 96 and model.encoder_hand.fc_mano.out_features == 51
     assert model.encoder_t2d.encoder_hand.fc_mano.in_features == 48 and model.encoder_t2d.encoder_hand.out_dim == 30
     assert hasattr(model, "encode_hand_mano")
+
+
+def test_hand_mesh_post_processing():
+    a, _ = load_golden("g10_hand.npz")
+    v = orc.hand_mesh_vertices(a["mano_verts"][0], a["mano_param"][0], a["pc_ply"][0])
+    assert v.dtype == np.float64 and float(np.abs(v - a["hand_mesh_verts"]).max()) <= 1e-9
+    # R_from_PYR's conventions: roll is a plain z rotation, pitch / yaw are the transposed x / y rotations
+    r = orc.rot_from_pyr(np.array([0.3, 0.0, 0.0]))
+    assert np.allclose(r @ np.array([1.0, 0, 0]), [np.cos(0.3), np.sin(0.3), 0])
+    r = orc.rot_from_pyr(np.array([0.0, 0.3, 0.0]))
+    assert np.allclose(r @ np.array([0, 1.0, 0]), [0, np.cos(0.3), -np.sin(0.3)])

@@ -160,7 +160,7 @@ def test_hand_encoder_end_to_end_golden_and_training_gradients(tmp_path):
     ro = orc.hand_encoder_forward(leaves, synth_mano.as_model(asset), T(a["p"]), 32)
     rl = torch.nn.functional.mse_loss(ro["mano_param"], mano_gt) + torch.nn.functional.mse_loss(ro["mano_verts"], pc_gt)
     rl.backward()
-    assert abs(float(loss) - float(rl)) <= 1e-5 * max(1.0, abs(float(rl)))
+    assert abs(float(loss.detach()) - float(rl.detach())) <= 1e-5 * max(1.0, abs(float(rl.detach())))
     checked = 0
     for name, prm in enc.named_parameters():
         ref = leaves[name].grad
@@ -169,3 +169,70 @@ def test_hand_encoder_end_to_end_golden_and_training_gradients(tmp_path):
         assert maxdiff(prm.grad, ref) <= 2e-3 * scale + 1e-7, name
         checked += 1
     assert checked == len(sd)
+
+
+def _hand_encoder(tmp_path, sd, dev):
+    from vtaco_amd.encoder import encoder_dict
+    synth_mano.write_pkl(synth_mano.make_asset(0), str(tmp_path))
+    enc = encoder_dict["pointnet_local_pool"](
+        dim=3, c_dim=32, padding=0.1, hidden_dim=32, plane_type=["xz", "xy", "yz"], plane_resolution=32, unet=True,
+        unet_kwargs=dict(depth=3, merge_mode="concat", start_filts=16), out_mano=True, out_dim=51,
+        manolayer_kwargs=dict(MANO_KW, mano_root=str(tmp_path)))
+    enc.load_state_dict(sd, strict=False)
+    return enc.to(dev)
+
+
+def test_generator_hand_mesh_matches_the_reference_generator(tmp_path):
+    from vtaco_amd.conv_onet import models
+    from vtaco_amd.conv_onet.generation import Generator3D
+    from vtaco_amd._lib import VtError
+    a, sd = load_golden("g10_hand.npz")
+    dev = torch.device("cuda:0")
+    model = models.ConvolutionalOccupancyNetwork(None, None, _hand_encoder(tmp_path, sd, dev), device=dev)
+    gen = Generator3D(model, device=dev)
+    mesh = gen.generate_hand_mesh({"inputs": T(a["p"])[:1], "inputs.pc_ply": T(a["pc_ply"])})
+    assert mesh.vertices.dtype == torch.float64 and mesh.vertices.shape == (778, 3)
+    assert maxdiff(mesh.vertices, a["hand_mesh_verts"]) <= 2e-4           # /(2m) with m ~ 0.5 scales the 1e-4 encoder bar
+    assert torch.equal(mesh.faces.cpu(), T(a["hand_mesh_faces"]).long())
+    with pytest.raises(VtError, match="one scene"):
+        gen.generate_hand_mesh({"inputs": T(a["p"]), "inputs.pc_ply": T(a["pc_ply"])})
+    # the MANO layer alone through the container (models/__init__.py:104-112)
+    out = model.encode_hand_mano(T(a["pose"]).to(dev))
+    assert maxdiff(out["mano_verts"], a["pose_verts"]) <= 1e-6 and out["mano_faces"].shape == (1538, 3)
+
+
+def test_trainer_with_hand_encoder_on_synthetic_dataset(tmp_path):
+    """Object branch + hand branch in one Trainer step (training.py:454-500): loss = l1 + loss_mano + loss_pc."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from synth_dataset import make_cfg, make_synthetic_dataset
+    from vtaco_amd import data
+    from vtaco_amd.config import get_dataset
+    from vtaco_amd.conv_onet import config as cfgmod
+    dev = torch.device("cuda:0")
+    os.makedirs(tmp_path / "ds")
+    make_synthetic_dataset(str(tmp_path / "ds"), seed=5)
+    synth_mano.write_pkl(synth_mano.make_asset(0), str(tmp_path / "mano"))
+    cfg = make_cfg(str(tmp_path / "ds"), points_subsample=128)
+    cfg["model"] = {"decoder": "simple_local", "encoder": "pointnet_local_pool", "c_dim": 32,
+                    "decoder_kwargs": {"sample_mode": "bilinear", "hidden_size": 32},
+                    "encoder_kwargs": {"hidden_dim": 32, "plane_type": "grid", "grid_resolution": 32, "unet3d": True,
+                                       "unet3d_kwargs": {"num_levels": 3, "f_maps": 32, "in_channels": 32, "out_channels": 32}},
+                    "encoder_hand": "pointnet_local_pool",
+                    "encoder_hand_kwargs": {"hidden_dim": 32, "plane_type": ["xz", "xy", "yz"], "plane_resolution": 32,
+                                            "unet": True, "unet_kwargs": {"depth": 3, "merge_mode": "concat", "start_filts": 16},
+                                            "out_mano": True, "out_dim": 51,
+                                            "manolayer_kwargs": dict(MANO_KW, mano_root=str(tmp_path / "mano"))}}
+    cfg["test"] = {"threshold": 0.5}
+    torch.manual_seed(0)
+    model = cfgmod.get_model(cfg, device=dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    trainer = cfgmod.get_trainer(model, opt, cfg, dev)
+    np.random.seed(0)
+    batch = next(iter(torch.utils.data.DataLoader(get_dataset("train", cfg), batch_size=3, collate_fn=data.collate_remove_none)))
+    first = trainer.train_step(batch)
+    for _ in range(25):
+        last = trainer.train_step(batch)
+    assert all(np.isfinite(x) for x in first) and first[1] > 0 and first[2] > 0
+    assert last[0] < 0.8 * first[0] and last[1] < first[1], (first, last)
+    assert all(p.grad is not None for p in model.encoder_hand.parameters())

@@ -6,9 +6,9 @@ The reference builds the nx^3 lattice on the CPU, ships it to the GPU in 100k-po
 chunks, copies every chunk's logits back and runs scikit-image's marching cubes on
 the CPU.  Here the lattice is generated inside the decode kernel, the logits stay on
 the device and marching cubes is a HIP kernel; the results (logits within 1e-4,
-vertex numbering bit-exact) are the same.  Tactile feature assignment (K11, the CPU
-cdist glue of generation.py:159-255), hand mesh and CD/EMD metrics are out of scope;
-``c_img_all`` can be passed in pre-built.
+vertex numbering bit-exact) are the same.  ``generate_hand_mesh`` (:74-115) runs the hand
+encoder + MANO layer on the device and the reference's wrist-frame post-processing on the
+778 vertices.  ``c_img_all`` can be passed in pre-built or as finger ids (generate_obj_mesh_tactile).
 """
 from __future__ import annotations
 
@@ -148,6 +148,44 @@ class Generator3D(object):
             values = self.model.decoder.decode_lattice_ids(grid, nx, ids, finger_feats.to(self.device), box=1 + self.padding,
                                                            precision=self.decode_precision)
         return self.extract_mesh(values.reshape(nx, nx, nx))
+
+    def generate_hand_mesh(self, data):
+        """Hand mesh of one scene (generation.py:74-115): encoder_hand -> MANO vertices, then out of the MANO
+        frame (fixed offset and rotation), out of the predicted wrist rotation (rotation vector -> 'XYZ' Euler
+        -> the reference's R_from_PYR convention, common.py:591-604), plus the wrist position, normalised by
+        the object's ``inputs.pc_ply`` cloud (norm_pc_1, common.py:606-612).  Returns Mesh(vertices [778,3]
+        f64, faces [1538,3] i64) on the device (the reference wraps the same arrays in a trimesh.Trimesh)."""
+        import numpy as np
+        from scipy.spatial.transform import Rotation
+        self.model.eval()
+        inputs = data.get('inputs').to(self.device)
+        pc_ply = data.get('inputs.pc_ply').to(self.device)
+        if inputs.shape[0] != 1:
+            raise VtError(f"generate_hand_mesh: one scene at a time (got a batch of {inputs.shape[0]})")
+        with torch.no_grad():
+            c_hand = self.model.encode_hand_inputs(inputs)
+        if 'mano_verts' not in c_hand:
+            raise VtError("generate_hand_mesh: the hand encoder has no MANO layer (out_dim <= 30 regresses digit poses only)")
+        param = c_hand['mano_param'][0].double().cpu().numpy()
+
+        def pyr(roll, pitch, yaw):                                  # 3x3, host side: nine numbers
+            cr, sr, cp, sp, cy, sy = np.cos(roll), np.sin(roll), np.cos(pitch), np.sin(pitch), np.cos(yaw), np.sin(yaw)
+            about_z = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+            about_x_t = np.array([[1, 0, 0], [0, cp, sp], [0, -sp, cp]])
+            about_y_t = np.array([[cy, 0, -sy], [0, 1, 0], [sy, 0, cy]])
+            return about_x_t @ about_y_t @ about_z
+
+        euler = Rotation.from_rotvec(param[3:6]).as_euler('XYZ', degrees=False)
+        undo = np.linalg.inv(pyr(*euler)) @ np.linalg.inv(pyr(-np.pi / 2, np.pi / 2, 0.0))
+        dev = c_hand['mano_verts'].device
+        undo_t = torch.from_numpy(undo).to(dev)
+        v = (c_hand['mano_verts'][0] - torch.tensor([0.11, 0.005, 0.0], device=dev)).double()
+        v = v @ undo_t.t() + torch.from_numpy(param[:3]).to(dev)
+        cloud = pc_ply[0].float()
+        centroid = cloud.mean(dim=0)
+        m = (cloud - centroid).pow(2).sum(dim=1).sqrt().max()
+        v = (v - centroid.double()) / (2.0 * m.double())
+        return Mesh(v, c_hand['mano_faces'])
 
     def generate_obj_mesh_wnf(self, data, c_img_all=None):
         """Encode -> dense decode -> marching cubes for one scene; ``data['inputs']`` is the

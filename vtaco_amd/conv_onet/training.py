@@ -2,10 +2,12 @@
 
 ``train_step(data)`` consumes the dictionaries ``vtaco_amd.data`` (or the reference loader) produces:
 ``inputs`` [B,T,3] -> encode_inputs -> feature grid; ``points`` [B,N,3] -> decode -> logits;
-``loss = F.l1_loss(logits, points.occ)`` exactly as the reference's ``compute_loss`` (:487-497) -- its two
-other terms, ``loss_mano`` and ``loss_pc``, belong to the hand / MANO branch, which is out of scope here
- and are reported as 0.  Forward and backward of the whole step (voxeliser, UNet3D,
-decoder) run on the HIP kernels.  The tactile variants (``with_img`` / ``encode_t2d``) need the per-point
+``loss = F.l1_loss(logits, points.occ)`` exactly as the reference's ``compute_loss`` (:487-497).  With a hand
+encoder (``model.encoder_hand``) its two other terms are added as the reference does (:493-498):
+``loss_mano = mse(mano_param, points.mano)`` and ``loss_pc = mse(mano_verts, points.pc_hand)``; without one
+they are reported as 0.  Forward and backward of the whole step (voxeliser, UNet3D, decoder; plane pooling
+and scatter of the hand encoder) run on the HIP kernels; the MANO layer and the 2-D U-Net differentiate
+through host PyTorch ops.  The tactile variants (``with_img`` / ``encode_t2d``) need the per-point
 contact features the reference assembles with CPU geometry (igl / cdist, training.py:817-866): feed them
 at model level (``model.decode_img(p, c, c_img)``) or as finger ids (``vt_tactile_assign``) instead.
 """
@@ -34,14 +36,20 @@ class Trainer:
         self.grad_sync = grad_sync
 
     def compute_loss(self, data):
-        """(loss, loss_mano, loss_pc) -- the last two are the hand branch's and stay 0."""
+        """(loss, loss_mano, loss_pc) -- the last two are the hand branch's (0 without a hand encoder)."""
         p = data.get('points').to(self.device)
         occ = data.get('points.occ').to(self.device)
         inputs = data.get('inputs').to(self.device)
         c = self.model.encode_inputs(inputs)
         logits = self.model.decode(p, c).logits
-        zero = logits.new_zeros(())
-        return F.l1_loss(logits, occ), zero, zero
+        loss = F.l1_loss(logits, occ)
+        if getattr(self.model, 'encoder_hand', None) is None:
+            zero = logits.new_zeros(())
+            return loss, zero, zero
+        c_hand = self.model.encode_hand_inputs(inputs)
+        loss_mano = F.mse_loss(c_hand['mano_param'], data.get('points.mano').to(self.device).float())
+        loss_pc = F.mse_loss(c_hand['mano_verts'], data.get('points.pc_hand').to(self.device).float())
+        return loss + loss_mano + loss_pc, loss_mano, loss_pc
 
     def train_step(self, data, vf_dict=None):
         self.model.train()
