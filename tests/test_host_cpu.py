@@ -75,7 +75,11 @@ def test_unsupported_configurations_raise():
     with pytest.raises(ValueError, match="incorrect scatter type"):
         encoder_dict["pointnet_local_pool"](scatter_type="median", plane_type="grid", grid_resolution=8)
     with pytest.raises(VtError):
-        encoder_dict["pointnet_local_pool"](plane_type=["xz", "xy", "yz"], plane_resolution=32)
+        encoder_dict["pointnet_local_pool"](plane_type=["xz", "xy", "yz"])                      # planes need plane_resolution
+    with pytest.raises(VtError):
+        encoder_dict["pointnet_local_pool"](plane_type=["xz", "grid"], plane_resolution=32, grid_resolution=32)
+    with pytest.raises(VtError):
+        encoder_dict["pointnet_local_pool"](plane_type=["xz", "xy", "yz"], plane_resolution=32, out_mano=True, out_dim=51)  # no MANO asset given
     with pytest.raises(VtError):
         decoder_dict["simple_local"](dim=3, c_dim=32, hidden_size=32, leaky=True)
     with pytest.raises(KeyError):
