@@ -4,6 +4,7 @@ Not the headline metric (bench.py is); numbers are quoted in DESIGN.md.
   img    : LocalDecoder.forward_img (tactile concat, the shipped VTacO config) 128^3
   train  : one training step fwd+bwd+Adam, 8 scenes x 2048 points per GPU (config 4's per-GPU share)
   dense256 : 256^3 decode + marching cubes (config 5 on one GPU)
+  hand   : the hand encoder (plane PointNet + 2-D U-Net + MANO layer) and the MANO kernel alone
 """
 import json, os, sys, time
 import torch
@@ -13,7 +14,7 @@ from vtaco_amd.bench_util import build_scene, randomise_fc1, sphere_cloud
 from vtaco_amd.conv_onet.models import decoder_dict
 
 dev = torch.device("cuda:0")
-SECTIONS = set(sys.argv[1:]) or {"img", "fusion", "train", "dense256"}
+SECTIONS = set(sys.argv[1:]) or {"img", "fusion", "train", "dense256", "hand"}
 # MIOpen only picks its fast f32 conv3d kernels for channels_last_3d tensors in find mode, and only if
 # the flag is set before the first convolution of the process (26 ms vs 382 ms fwd+bwd at B=2)
 torch.backends.cudnn.benchmark = True
@@ -120,3 +121,33 @@ if "dense256" in SECTIONS:
         v, f, _ = ops.marching_cubes(buf.view(nx2, nx2, nx2), None)
         print(json.dumps({"workload": f"256^3 decode + marching cubes, {prec}", "decode_ms": t * 1e3,
                           "points_per_s": nx2 ** 3 / t, "mc_ms": t_mc * 1e3, "verts": v.shape[0], "faces": f.shape[0]}))
+
+# --- hand: the hand encoder as configs/VTacO/VTacO_YCB.yaml:33-56 builds it, on a synthetic MANO-format asset
+if "hand" in SECTIONS:
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import synth_mano
+    from vtaco_amd.encoder import encoder_dict
+    root = tempfile.mkdtemp(prefix="vt_mano_")
+    synth_mano.write_pkl(synth_mano.make_asset(0), root)
+    torch.manual_seed(0)
+    henc = encoder_dict["pointnet_local_pool"](
+        dim=3, c_dim=32, padding=0.1, hidden_dim=32, plane_type=["xz", "xy", "yz"], plane_resolution=32, unet=True,
+        unet_kwargs=dict(depth=4, merge_mode="concat", start_filts=32), out_mano=True, out_dim=51,
+        manolayer_kwargs=dict(center_idx=9, flat_hand_mean=False, ncomps=45, side="right", mano_root=root, use_pca=False,
+                              root_rot_mode="axisang", joint_rot_mode="axisang", robust_rot=False, return_transf=False)
+    ).to(dev).eval()
+    hcloud = sphere_cloud(0).to(dev)
+    with torch.no_grad():
+        t_enc = timed(lambda: henc(hcloud), 50, 5)
+        pis = [ops.PlaneIndex(hcloud, 32, 0.1, k) for k in ("xz", "xy", "yz")]
+        t_idx = timed(lambda: [ops.PlaneIndex(hcloud, 32, 0.1, k) for k in ("xz", "xy", "yz")], 50, 5)
+        feat = torch.randn(1, 3000, 32, device=dev)
+        t_pool = timed(lambda: [ops.voxel_pool_max_fwd(feat, pi, want_argmax=False) for pi in pis], 50, 5)
+        for Bh in (1, 64, 1024):
+            pose = torch.randn(Bh, 48, device=dev) * 0.5
+            t_m = timed(lambda: henc.mano_layer(pose), 100, 10)
+            print(json.dumps({"workload": f"MANO layer (vt_mano_fwd), {Bh} hands", "ms": t_m * 1e3, "hands_per_s": Bh / t_m,
+                              "gflops": 0.95e-3 * Bh / t_m}))
+    print(json.dumps({"workload": "hand encoder: 3000 pts -> 3 planes @32^2 -> U-Net (depth 4, 32 filters, MIOpen) -> MANO",
+                      "ms": t_enc * 1e3, "plane_build_x3_ms": t_idx * 1e3, "pool_max_x3_ms": t_pool * 1e3}))

@@ -168,11 +168,12 @@ class LocalPoolPointnet(nn.Module):
     def forward_planes(self, p):
         pis = [ops.PlaneIndex(p, self.reso_plane, self.padding, k) for k in self.planes]
         feat = self.point_features(p.float(), pis)
-        fea = {}
-        for k, pi in zip(self.planes, pis):
-            plane = _ScatterMeanPlane.apply(feat, pi)
-            fea[k] = self.unet(plane) if self.unet is not None else plane
-        return fea
+        planes = [_ScatterMeanPlane.apply(feat, pi) for pi in pis]
+        if self.unet is not None:
+            # one U-Net pass over the planes stacked on the batch axis: the net has no cross-sample op
+            # (no normalisation layers), so this equals the reference's per-plane calls with a third of the launches
+            planes = self.unet(torch.cat(planes, dim=0)).split(p.shape[0], dim=0)
+        return dict(zip(self.planes, planes))
 
     def forward(self, p):
         if not p.is_cuda:
