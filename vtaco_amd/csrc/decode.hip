@@ -17,6 +17,7 @@
 // + fc_p (K=3 padded to 4: 2).  The trilinear gather reads the channels-last grid:
 // lane (p,h) loads channels 16h..16h+15 of each of its point's 8 corners.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -79,11 +80,16 @@ __device__ __forceinline__ void mlp_and_heads(const DecodeArgs &a, const float *
         for (int i = 0; i < 5; ++i) {
             const float *wl = L + VT_OFF_WL + (1 + 3 * i) * 1024;
             f32x16 hid = load_frag16(L + VT_OFF_BIAS + (1 + 2 * i) * 32 + h * 16);
-            hid = dense32s(hid, wl, split16<true>(net), lane);
-            net = dense32s(net, wl + 1024, split16<true>(hid), lane);
-            if (i < 4) net = dense32s(net, wl + 2048, cs, lane);
+            // same accumulation order as the two-brick kernel: net + cond(k-step 0) + bias + cond(k-step 1) + fc_1(..),
+            // the conditioning MFMAs placed where the VALU is busy splitting relu(net) / relu(hid)
+            const Split16 sn = split16<true>(net);
+            if (i < 4) net = dense32s_half(net, wl + 2048, cs, lane, 0);
             const f32x16 bb = load_frag16(L + VT_OFF_BIAS + (2 + 2 * i) * 32 + h * 16);
             net = net + bb;
+            hid = dense32s(hid, wl, sn, lane);
+            const Split16 sh = split16<true>(hid);
+            if (i < 4) net = dense32s_half(net, wl + 2048, cs, lane, 1);
+            net = dense32s(net, wl + 1024, sh, lane);
         }
     } else {
     net = dense32<false>(net, L + VT_OFF_WL, c, lane);
@@ -451,6 +457,19 @@ __device__ __forceinline__ void dense32s2(f32x16 &accA, f32x16 &accB, const floa
     }
 }
 
+// one k-step (s = 0 or 1) of dense32s2: six of the layer's twelve MFMAs
+__device__ __forceinline__ void dense32s2_half(f32x16 &accA, f32x16 &accB, const float *wl, const Split16 &xA, const Split16 &xB,
+                                               int lane, int s) {
+    const bf16x8 *w = reinterpret_cast<const bf16x8 *>(wl);
+    const bf16x8 wh = w[s * 64 + lane], wo = w[(2 + s) * 64 + lane];
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo, xA.hi[s], accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo, xB.hi[s], accB, 0, 0, 0);
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xA.lo[s], accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xB.lo[s], accB, 0, 0, 0);
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xA.hi[s], accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xB.hi[s], accB, 0, 0, 0);
+}
+
 // exact-f32 layer for two column groups: one weight read per k-step feeds both chains
 template <bool RELU>
 __device__ __forceinline__ void dense32x2(f32x16 &accA, f32x16 &accB, const float *wl, const f32x16 &xA, const f32x16 &xB, int lane) {
@@ -634,18 +653,32 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
             if (has_img) dense32s2(netA, netB, L + VT_OFF_WPI, split16<false>(ciA), split16<false>(ciB), lane);
             const Split16 csA = split16<false>(cA), csB = split16<false>(cB);
             dense32s2(netA, netB, L + VT_OFF_WL, csA, csB, lane);
-#pragma unroll 1
-            for (int i = 0; i < 5; ++i) {
+            // The block's c-conditioning and bias MFMAs (net += fc_c{i+1}(c) + b_1) depend on nothing the block
+            // computes, only on net having been READ by the relu: they issue while the VALU splits relu(net) and
+            // relu(hid), instead of back to back behind fc_1 with the VALU idle (net = net + cond + fc_1(..)).
+            auto block = [&](int i, auto cond_tag) {
+                constexpr bool COND = decltype(cond_tag)::value;
                 const float *wl = L + VT_OFF_WL + (1 + 3 * i) * 1024;
                 const f32x16 hb = load_frag16(L + VT_OFF_BIAS + (1 + 2 * i) * 32 + h * 16);
-                f32x16 hidA = hb, hidB = hb;
-                dense32s2(hidA, hidB, wl, split16<true>(netA), split16<true>(netB), lane);
-                dense32s2(netA, netB, wl + 1024, split16<true>(hidA), split16<true>(hidB), lane);
-                if (i < 4) dense32s2(netA, netB, wl + 2048, csA, csB, lane);
+                f32x16 rA, rB;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { rA[q] = relu1(netA[q]); rB[q] = relu1(netB[q]); }
+                asm volatile("" : "+v"(rA), "+v"(rB));
+                if constexpr (COND) dense32s2_half(netA, netB, wl + 2048, csA, csB, lane, 0);
                 const bf16x8 bf = reinterpret_cast<const bf16x8 *>(L + VT_OFF_BFRAG + i * 256)[lane];
                 netA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, ones, netA, 0, 0, 0);
                 netB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, ones, netB, 0, 0, 0);
-            }
+                f32x16 hidA = hb, hidB = hb;
+                dense32s2(hidA, hidB, wl, split16<false>(rA), split16<false>(rB), lane);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { rA[q] = relu1(hidA[q]); rB[q] = relu1(hidB[q]); }
+                asm volatile("" : "+v"(rA), "+v"(rB));
+                if constexpr (COND) dense32s2_half(netA, netB, wl + 2048, csA, csB, lane, 1);
+                dense32s2(netA, netB, wl + 1024, split16<false>(rA), split16<false>(rB), lane);
+            };
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) block(i, std::true_type{});
+            block(4, std::false_type{});
         } else {
             if (has_img) dense32x2<false>(netA, netB, L + VT_OFF_WPI, ciA, ciB, lane);
             dense32x2<false>(netA, netB, L + VT_OFF_WL, cA, cB, lane);

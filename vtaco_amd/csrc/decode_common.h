@@ -92,6 +92,16 @@ __device__ __forceinline__ f32x16 dense32s(f32x16 acc, const float *wl, const Sp
     return acc;
 }
 
+// one k-step (s = 0 or 1) of dense32s
+__device__ __forceinline__ f32x16 dense32s_half(f32x16 acc, const float *wl, const Split16 &x, int lane, int s) {
+    const bf16x8 *w = reinterpret_cast<const bf16x8 *>(wl);
+    const bf16x8 wh = w[s * 64 + lane], wo = w[(2 + s) * 64 + lane];
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo, x.hi[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, x.lo[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, x.hi[s], acc, 0, 0, 0);
+    return acc;
+}
+
 __device__ __forceinline__ f32x16 load_frag16(const float *p) {
     const f32x4 *q = reinterpret_cast<const f32x4 *>(p);
     f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
