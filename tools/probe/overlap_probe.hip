@@ -8,6 +8,49 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// same MFMA work per group in the 16x16x32 shape: two 4-pass MFMAs instead of one 8-pass MFMA, V/2 VALU ops after each
+template <int V>
+__global__ void __launch_bounds__(512) k16(float *out, int iters) {
+    f32x4 acc[4];
+    for (int j = 0; j < 4; ++j) for (int s = 0; s < 4; ++s) acc[j][s] = threadIdx.x * 0.01f + s + j;
+    bf16x8 wa, xb;
+    for (int j = 0; j < 8; ++j) { wa[j] = (__bf16)(0.001f * (threadIdx.x + j)); xb[j] = (__bf16)(0.5f + 0.01f * j); }
+    float v[8];
+    for (int j = 0; j < 8; ++j) v[j] = 1.0f + 0.001f * (threadIdx.x + j);
+    const float c1 = 0.999f, c2 = 1e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            acc[m & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[m & 3], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < V / 2; ++q) {
+                float &r = v[(q + 4 * (m & 1)) & 7];
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r) : "v"(c1), "v"(c2));
+            }
+        }
+    }
+    float r = 0;
+    for (int j = 0; j < 4; ++j) for (int s = 0; s < 4; ++s) r += acc[j][s];
+    for (int j = 0; j < 8; ++j) r += v[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+template <int V>
+void run16(int threads) {
+    float *out; hipMalloc(&out, 256 * 1024 * 4);
+    const int iters = 4000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k16<V><<<256, threads>>>(out, 10);
+    hipEventRecord(e0);
+    k16<V><<<256, threads>>>(out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double steps = (double)iters * 8 * (threads / 256);                 // groups of two 16x16x32 MFMAs + V VALU
+    printf("16x16x32   mfma+valu V=%2d waves/SIMD %d: %.3f ms, %.1f ns per group (2 MFMAs) per SIMD\n", V, threads / 256, ms, ms * 1e6 / steps);
+    hipFree(out);
+}
 
 template <int V, int KIND, bool MFMA>
 __global__ void __launch_bounds__(512) k(float *out, int iters) {
@@ -64,5 +107,6 @@ int main() {
     run<8, 0, false>(256, "fma"); run<16, 0, false>(256, "fma"); run<8, 0, false>(512, "fma");
     run<8, 1, true>(256, "max"); run<8, 1, false>(256, "max");
     run<8, 2, true>(256, "cvt_pk"); run<8, 2, false>(256, "cvt_pk"); run<8, 2, true>(512, "cvt_pk");
+    run16<0>(256); run16<0>(512); run16<4>(512); run16<8>(512); run16<12>(512); run16<16>(512); run16<8>(256); run16<16>(256);
     return 0;
 }

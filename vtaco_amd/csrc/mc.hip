@@ -334,48 +334,87 @@ __device__ __forceinline__ unsigned block_compact(bool flag, unsigned payload, u
     return total;
 }
 
+// One workgroup classifies CLS_CHUNKS consecutive 256-cell chunks (the chunk stays the unit of the count /
+// offset tables the other kernels use).  The kernel is a chain of dependent memory round trips (header, volume,
+// table look-ups), so its time is rounds x latency: four chunks per workgroup put four times the loads in
+// flight per round and run the case analysis once over the combined active list.
+constexpr int CLS_CHUNKS = 4;
+
 __global__ void __launch_bounds__(CELLS_PER_BLOCK)
-mc_classify_kernel(const float *vol, McDims d, McWs ws, double level_in, int auto_level) {
-    __shared__ unsigned list[CELLS_PER_BLOCK];
-    __shared__ unsigned wave_cnt[4];
-    __shared__ unsigned tot[2];
-    const unsigned c = blockIdx.x * CELLS_PER_BLOCK + threadIdx.x;
+mc_classify_kernel(const float *vol, McDims d, McWs ws, double level_in, int auto_level, unsigned nblk) {
+    __shared__ unsigned list[CLS_CHUNKS * CELLS_PER_BLOCK];
+    __shared__ unsigned wave_cnt[CLS_CHUNKS * 4];
+    __shared__ unsigned tot[CLS_CHUNKS][2];
+    __shared__ int base_xyz[CLS_CHUNKS][3];
+    const unsigned chunk0 = blockIdx.x * CLS_CHUNKS;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const double level = iso_level(ws.hdr, level_in, auto_level);
-    if (threadIdx.x < 2) tot[threadIdx.x] = 0;
-    // phase 1 (all cells): the 8-bit sign pattern with f32 compares against an exact threshold;
-    // inactive cells are done
-    int index = 0;
-    int bx0, by0, bz0;
-    cell_xyz(blockIdx.x * CELLS_PER_BLOCK, d, bx0, by0, bz0);      // wave-uniform: scalar unit
+    if (threadIdx.x < 2 * CLS_CHUNKS) tot[threadIdx.x >> 1][threadIdx.x & 1] = 0;
     const float inv_c2 = 1.0f / (float)d.c2;
-    if (c < d.ncells) {
-        int x, y, z;
-        cell_from(bx0, by0, bz0, threadIdx.x, d, inv_c2, x, y, z);
-        const float thr = level_threshold(level);
-        const size_t s1 = (size_t)d.n2, s0 = (size_t)d.n1 * d.n2;
-        const float *p = vol + (size_t)z * s0 + (size_t)y * s1 + x;
-        typedef float f2 __attribute__((ext_vector_type(2), aligned(4)));
-        const f2 a = *reinterpret_cast<const f2 *>(p), b = *reinterpret_cast<const f2 *>(p + s1);
-        const f2 e = *reinterpret_cast<const f2 *>(p + s0), f = *reinterpret_cast<const f2 *>(p + s0 + s1);
-        index = (a.x >= thr) | (a.y >= thr) << 1 | (b.y >= thr) << 2 | (b.x >= thr) << 3 |
-                (e.x >= thr) << 4 | (e.y >= thr) << 5 | (f.y >= thr) << 6 | (f.x >= thr) << 7;
+    const float thr = level_threshold(level);
+    const size_t s1 = (size_t)d.n2, s0 = (size_t)d.n1 * d.n2;
+    // phase 1 (all cells): the 8-bit sign pattern with f32 compares against an exact threshold;
+    // inactive cells are done.  All chunks' loads are issued before the first compare.
+    typedef float f2 __attribute__((ext_vector_type(2), aligned(4)));
+    f2 va[CLS_CHUNKS], vb[CLS_CHUNKS], ve[CLS_CHUNKS], vf[CLS_CHUNKS];
+    bool inside[CLS_CHUNKS];
+#pragma unroll
+    for (int k = 0; k < CLS_CHUNKS; ++k) {
+        const unsigned first = (chunk0 + k) * CELLS_PER_BLOCK, c = first + threadIdx.x;
+        inside[k] = c < d.ncells;
+        int bx0 = 0, by0 = 0, bz0 = 0;
+        if (first < d.ncells) cell_xyz(first, d, bx0, by0, bz0);      // wave-uniform: scalar unit
+        if (threadIdx.x == 0) { base_xyz[k][0] = bx0; base_xyz[k][1] = by0; base_xyz[k][2] = bz0; }
+        va[k] = vb[k] = ve[k] = vf[k] = f2{0.0f, 0.0f};
+        if (inside[k]) {
+            int x, y, z;
+            cell_from(bx0, by0, bz0, threadIdx.x, d, inv_c2, x, y, z);
+            const float *p = vol + (size_t)z * s0 + (size_t)y * s1 + x;
+            va[k] = *reinterpret_cast<const f2 *>(p);      vb[k] = *reinterpret_cast<const f2 *>(p + s1);
+            ve[k] = *reinterpret_cast<const f2 *>(p + s0); vf[k] = *reinterpret_cast<const f2 *>(p + s0 + s1);
+        }
     }
-    const bool active = index != 0 && index != 255;
-    if (c < d.ncells && !active) ws.cnt[c] = 0;
-    const unsigned nact = block_compact(active, threadIdx.x, list, wave_cnt);
+    bool active[CLS_CHUNKS];
+    unsigned long long ball[CLS_CHUNKS];
+#pragma unroll
+    for (int k = 0; k < CLS_CHUNKS; ++k) {
+        const f2 a = va[k], b = vb[k], e = ve[k], f = vf[k];
+        const int index = (a.x >= thr) | (a.y >= thr) << 1 | (b.y >= thr) << 2 | (b.x >= thr) << 3 |
+                          (e.x >= thr) << 4 | (e.y >= thr) << 5 | (f.y >= thr) << 6 | (f.x >= thr) << 7;
+        active[k] = inside[k] && index != 0 && index != 255;
+        if (inside[k] && !active[k]) ws.cnt[(chunk0 + k) * CELLS_PER_BLOCK + threadIdx.x] = 0;
+        ball[k] = __ballot(active[k]);
+        if (lane == 0) wave_cnt[k * 4 + w] = (unsigned)__popcll(ball[k]);
+    }
+    __syncthreads();
+    // compact the active cells of all chunks into one list (chunk-major, then cell order)
+    unsigned nact = 0;
+    {
+        unsigned run = 0, mine[CLS_CHUNKS];
+#pragma unroll
+        for (int i = 0; i < CLS_CHUNKS * 4; ++i) {
+            if ((i & 3) == w) mine[i >> 2] = run;
+            run += wave_cnt[i];
+        }
+        nact = run;
+#pragma unroll
+        for (int k = 0; k < CLS_CHUNKS; ++k)
+            if (active[k]) list[mine[k] + (unsigned)__popcll(ball[k] & ((1ull << lane) - 1ull))] = (unsigned)k << 8 | threadIdx.x;
+    }
+    __syncthreads();
     // phase 2 (over the active list): Lewiner case analysis + owned-edge ranks.  The work is a chain of
     // dependent table look-ups (latency-bound), so the list is dealt round-robin over the block's four
     // waves: four times as many waves in flight beats packing it into one wave.
-    const unsigned slot = (threadIdx.x & 63u) * 4u + (threadIdx.x >> 6);
-    if (slot < nact) {
-        const unsigned cc = blockIdx.x * CELLS_PER_BLOCK + list[slot];
+    for (unsigned slot = (threadIdx.x & 63u) * 4u + (threadIdx.x >> 6); slot < nact; slot += CELLS_PER_BLOCK) {
+        const unsigned ent = list[slot], k = ent >> 8, t = ent & 255u;
+        const unsigned cc = (chunk0 + k) * CELLS_PER_BLOCK + t;
         int x, y, z;
-        cell_from(bx0, by0, bz0, list[slot], d, inv_c2, x, y, z);
+        cell_from(base_xyz[k][0], base_xyz[k][1], base_xyz[k][2], t, d, inv_c2, x, y, z);
         double v[8];
         load_cell(vol, d, x, y, z, level, v);
         int idx2 = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) idx2 |= (v[k] > 0.0) << k;
+        for (int q = 0; q < 8; ++q) idx2 |= (v[q] > 0.0) << q;
         int nt = 0;
         const int off = classify_cell(v, idx2, nt);
         const unsigned own = own_mask(x, y, z);
@@ -391,12 +430,13 @@ mc_classify_kernel(const float *vol, McDims d, McWs ws, double level_in, int aut
         ws.desc[cc] = (uint32_t)off;
         ws.rank[cc] = rk;
         ws.cnt[cc] = (uint16_t)((unsigned)nt | (nnew << 8));
-        atomicAdd(&tot[0], (unsigned)nt);
-        atomicAdd(&tot[1], nnew);
+        atomicAdd(&tot[k][0], (unsigned)nt);
+        atomicAdd(&tot[k][1], nnew);
     }
     __syncthreads();
-    if (threadIdx.x == 0) ws.bsum[blockIdx.x] = make_uint2(tot[0], tot[1]);
-    if (c == 0) ws.hdr->level = level;
+    if (threadIdx.x < CLS_CHUNKS && chunk0 + threadIdx.x < nblk)
+        ws.bsum[chunk0 + threadIdx.x] = make_uint2(tot[threadIdx.x][0], tot[threadIdx.x][1]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) ws.hdr->level = level;
 }
 
 // one block: exclusive scan of the per-block sums
@@ -619,7 +659,8 @@ int vt_mc_count(const float *vol, int n0, int n1, int n2, double level, int auto
         if (g < 1) g = 1;
         hipLaunchKernelGGL(mc_minmax_kernel, dim3(g), dim3(256), 0, s, vol, n, ws.hdr);
     }
-    hipLaunchKernelGGL(mc_classify_kernel, dim3(nblk), dim3(CELLS_PER_BLOCK), 0, s, vol, d, ws, level, auto_level);
+    hipLaunchKernelGGL(mc_classify_kernel, dim3((nblk + CLS_CHUNKS - 1) / CLS_CHUNKS), dim3(CELLS_PER_BLOCK), 0, s,
+                       vol, d, ws, level, auto_level, nblk);
     hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, s, ws, nblk);
     return vt_check(hipGetLastError(), "vt_mc_count");
 }
