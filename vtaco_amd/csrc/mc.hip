@@ -299,6 +299,10 @@ __device__ __forceinline__ float level_threshold(double level) {
     return t;
 }
 
+// Surface cells are a minority (1-2 % for a trained field, ~16 % for noise) and scattered, so every
+// wave would run the expensive branch with most lanes idle.  Each kernel therefore first COMPACTS its
+// workgroup's active cells into an LDS list (ballot + prefix) and then processes the list densely.
+
 // block-wide exclusive scan of (a,b) pairs over 256 threads; returns exclusive prefix, totals in tot
 __device__ __forceinline__ uint2 block_exscan(unsigned a, unsigned b, uint2 *lds /*[4]*/, uint2 &tot) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -319,9 +323,6 @@ __device__ __forceinline__ uint2 block_exscan(unsigned a, unsigned b, uint2 *lds
     return make_uint2(oa + ia - a, ob + ib - b);
 }
 
-// Surface cells are a minority (1-2 % for a trained field, ~16 % for noise) and scattered, so every
-// wave would run the expensive branch with most lanes idle.  Each kernel therefore first COMPACTS its
-// block's active cells into an LDS list (ballot + prefix) and then processes the list densely.
 __device__ __forceinline__ unsigned block_compact(bool flag, unsigned payload, unsigned *list, unsigned *wave_cnt /*[4]*/) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned long long m = __ballot(flag);
@@ -492,58 +493,122 @@ struct McOut {
     int rescale; float shift, scale;
 };
 
+// The vertex kernel uses the same four-chunks-per-workgroup scheme as the classify kernel: the chunks' count
+// loads are in flight together and the dependent tail (rank / volume look-ups) runs once per workgroup.
+constexpr int EM_CHUNKS = 4;
+
+// inclusive prefix over the wave
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
 __global__ void __launch_bounds__(CELLS_PER_BLOCK)
-mc_vertices_kernel(const float *vol, McDims d, McWs ws, McOut o) {
-    __shared__ uint2 red[4];
-    __shared__ unsigned list[CELLS_PER_BLOCK], lbase[CELLS_PER_BLOCK];
-    __shared__ unsigned wave_cnt[4];
-    const unsigned c = blockIdx.x * CELLS_PER_BLOCK + threadIdx.x;
-    const unsigned cn = (c < d.ncells) ? ws.cnt[c] : 0;
-    uint2 tot;
-    const uint2 pre = block_exscan(cn & 0xff, cn >> 8, red, tot);
-    const unsigned vb = ws.boff[blockIdx.x].y + pre.y;
-    if (cn) ws.vbase[c] = vb;
-    lbase[threadIdx.x] = vb;
-    const unsigned nact = block_compact((cn >> 8) != 0, threadIdx.x, list, wave_cnt);
-    const unsigned slot = (threadIdx.x & 63u) * 4u + (threadIdx.x >> 6);     // round-robin over the 4 waves
-    if (slot >= nact) return;
-    const unsigned li = list[slot], cc = blockIdx.x * CELLS_PER_BLOCK + li, vbase = lbase[li];
-    const double level = ws.hdr->level;
-    int bx0, by0, bz0, x, y, z;
-    cell_xyz(blockIdx.x * CELLS_PER_BLOCK, d, bx0, by0, bz0);
-    cell_from(bx0, by0, bz0, li, d, 1.0f / (float)d.c2, x, y, z);
-    double v[8];
-    load_cell(vol, d, x, y, z, level, v);
-    const uint64_t rk = ws.rank[cc];
-    for (int e = 0; e < 13; ++e) {
-        const unsigned nib = (unsigned)(rk >> (4 * e)) & 15u;
-        if (!nib) continue;
-        double fx = 0, fy = 0, fz = 0, ff = 0;
-        if (e == 12) {
+mc_vertices_kernel(const float *vol, McDims d, McWs ws, McOut o, unsigned nblk) {
+    __shared__ unsigned wsum[EM_CHUNKS * 4];                       // vertices per (chunk, wave)
+    __shared__ unsigned wave_cnt[EM_CHUNKS * 4];                   // vertex-owning cells per (chunk, wave)
+    __shared__ unsigned list[EM_CHUNKS * CELLS_PER_BLOCK], lbase[EM_CHUNKS * CELLS_PER_BLOCK];
+    __shared__ int base_xyz[EM_CHUNKS][3];
+    const unsigned chunk0 = blockIdx.x * EM_CHUNKS;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {
+        // most workgroups see no surface at all: their chunks' (triangle, vertex) sums say so in one scalar load each
+        unsigned any = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const double w = 1.0 / (MC_EPS + fabs(v[k]));
-                fx += cx(k) * w; fy += cy(k) * w; fz += cz(k) * w; ff += w;
-            }
-        } else {
-            const int a = (e < 8) ? e : e - 8;                       // E0
-            const int b = (e < 8) ? ((e & 4) | ((e + 1) & 3)) : e - 4;  // E1
-            const double wa = 1.0 / (MC_EPS + fabs(pick(v, a)));
-            const double wb = 1.0 / (MC_EPS + fabs(pick(v, b)));
-            fx += cx(a) * wa; fy += cy(a) * wa; fz += cz(a) * wa; ff += wa;
-            fx += cx(b) * wb; fy += cy(b) * wb; fz += cz(b) * wb; ff += wb;
+        for (int k = 0; k < EM_CHUNKS; ++k)
+            if (chunk0 + k < nblk) { const uint2 bs = ws.bsum[chunk0 + k]; any |= bs.x | bs.y; }
+        if (!any) return;
+    }
+    const double level = ws.hdr->level;
+    unsigned cn[EM_CHUNKS], boffv[EM_CHUNKS];
+#pragma unroll
+    for (int k = 0; k < EM_CHUNKS; ++k) {
+        const unsigned c = (chunk0 + k) * CELLS_PER_BLOCK + threadIdx.x;
+        cn[k] = (c < d.ncells) ? ws.cnt[c] : 0;
+        boffv[k] = (chunk0 + k < nblk) ? ws.boff[chunk0 + k].y : 0;
+        if (threadIdx.x == 0) {
+            int bx0 = 0, by0 = 0, bz0 = 0;
+            if ((chunk0 + k) * CELLS_PER_BLOCK < d.ncells) cell_xyz((chunk0 + k) * CELLS_PER_BLOCK, d, bx0, by0, bz0);
+            base_xyz[k][0] = bx0; base_xyz[k][1] = by0; base_xyz[k][2] = bz0;
         }
-        const unsigned vid = vbase + nib - 1;
-        if (vid < (unsigned)o.max_verts) {
-            // array-axis order (axis0, axis1, axis2) = (z, y, x), as skimage returns
-            float p0 = (float)((double)z + fz / ff), p1 = (float)((double)y + fy / ff), p2 = (float)((double)x + fx / ff);
-            if (o.rescale) { p0 = (p0 - o.shift) * o.scale; p1 = (p1 - o.shift) * o.scale; p2 = (p2 - o.shift) * o.scale; }
-            float *dst = o.verts + (size_t)vid * 3;
-            dst[0] = p0; dst[1] = p1; dst[2] = p2;
+    }
+    unsigned incl[EM_CHUNKS];
+    unsigned long long ball[EM_CHUNKS];
+#pragma unroll
+    for (int k = 0; k < EM_CHUNKS; ++k) {
+        incl[k] = wave_incl_scan(cn[k] >> 8, lane);
+        ball[k] = __ballot((cn[k] >> 8) != 0);
+        if (lane == 63) wsum[k * 4 + w] = incl[k];
+        if (lane == 0) wave_cnt[k * 4 + w] = (unsigned)__popcll(ball[k]);
+    }
+    __syncthreads();
+    unsigned nact = 0;
+    {
+        unsigned run = 0, mine[EM_CHUNKS];
+#pragma unroll
+        for (int i = 0; i < EM_CHUNKS * 4; ++i) {
+            if ((i & 3) == w) mine[i >> 2] = run;
+            run += wave_cnt[i];
+        }
+        nact = run;
+#pragma unroll
+        for (int k = 0; k < EM_CHUNKS; ++k) {
+            unsigned before = 0;
+            for (int i = 0; i < 4; ++i) if (i < w) before += wsum[k * 4 + i];
+            const unsigned nv = cn[k] >> 8, vb = boffv[k] + before + incl[k] - nv;     // first vertex id of the cell
+            if (cn[k]) ws.vbase[(chunk0 + k) * CELLS_PER_BLOCK + threadIdx.x] = vb;
+            if (nv) {
+                const unsigned pos = mine[k] + (unsigned)__popcll(ball[k] & ((1ull << lane) - 1ull));
+                list[pos] = (unsigned)k << 8 | threadIdx.x;
+                lbase[pos] = vb;
+            }
+        }
+    }
+    __syncthreads();
+    const float inv_c2 = 1.0f / (float)d.c2;
+    for (unsigned slot = (threadIdx.x & 63u) * 4u + (threadIdx.x >> 6); slot < nact; slot += CELLS_PER_BLOCK) {   // round-robin over the 4 waves
+        const unsigned ent = list[slot], k = ent >> 8, li = ent & 255u;
+        const unsigned cc = (chunk0 + k) * CELLS_PER_BLOCK + li, vbase = lbase[slot];
+        int x, y, z;
+        cell_from(base_xyz[k][0], base_xyz[k][1], base_xyz[k][2], li, d, inv_c2, x, y, z);
+        double v[8];
+        load_cell(vol, d, x, y, z, level, v);
+        const uint64_t rk = ws.rank[cc];
+        for (int e = 0; e < 13; ++e) {
+            const unsigned nib = (unsigned)(rk >> (4 * e)) & 15u;
+            if (!nib) continue;
+            double fx = 0, fy = 0, fz = 0, ff = 0;
+            if (e == 12) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const double wq = 1.0 / (MC_EPS + fabs(v[q]));
+                    fx += cx(q) * wq; fy += cy(q) * wq; fz += cz(q) * wq; ff += wq;
+                }
+            } else {
+                const int a = (e < 8) ? e : e - 8;                       // E0
+                const int b = (e < 8) ? ((e & 4) | ((e + 1) & 3)) : e - 4;  // E1
+                const double wa = 1.0 / (MC_EPS + fabs(pick(v, a)));
+                const double wb = 1.0 / (MC_EPS + fabs(pick(v, b)));
+                fx += cx(a) * wa; fy += cy(a) * wa; fz += cz(a) * wa; ff += wa;
+                fx += cx(b) * wb; fy += cy(b) * wb; fz += cz(b) * wb; ff += wb;
+            }
+            const unsigned vid = vbase + nib - 1;
+            if (vid < (unsigned)o.max_verts) {
+                // array-axis order (axis0, axis1, axis2) = (z, y, x), as skimage returns
+                float p0 = (float)((double)z + fz / ff), p1 = (float)((double)y + fy / ff), p2 = (float)((double)x + fx / ff);
+                if (o.rescale) { p0 = (p0 - o.shift) * o.scale; p1 = (p1 - o.shift) * o.scale; p2 = (p2 - o.shift) * o.scale; }
+                float *dst = o.verts + (size_t)vid * 3;
+                dst[0] = p0; dst[1] = p1; dst[2] = p2;
+            }
         }
     }
 }
 
+// (one 256-cell chunk per workgroup here: the entry loop below is itself a chain of dependent look-ups per
+// iteration, and four chunks per workgroup would run four times as many iterations back to back -- measured slower)
 // one thread per (active cell, triangle corner): cells carry 1..12 triangles, so a thread per cell
 // would leave most lanes waiting for the few 12-triangle cells
 __global__ void __launch_bounds__(CELLS_PER_BLOCK)
@@ -551,6 +616,7 @@ mc_faces_kernel(McDims d, McWs ws, McOut o) {
     __shared__ uint2 red[4];
     __shared__ unsigned list[CELLS_PER_BLOCK], lpre[CELLS_PER_BLOCK];
     __shared__ unsigned wave_cnt[4];
+    if (ws.bsum[blockIdx.x].x == 0) return;                       // no triangle in this chunk (one scalar load)
     const unsigned c = blockIdx.x * CELLS_PER_BLOCK + threadIdx.x;
     const unsigned cn = (c < d.ncells) ? ws.cnt[c] : 0;
     uint2 tot;
@@ -687,7 +753,8 @@ int vt_mc_emit(const float *vol, int n0, int n1, int n2, void *workspace,
     McOut o; o.verts = verts; o.max_verts = max_verts; o.faces = faces; o.max_faces = max_faces;
     o.rescale = rescale; o.shift = shift; o.scale = scale;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(mc_vertices_kernel, dim3(nblk), dim3(CELLS_PER_BLOCK), 0, s, vol, d, ws, o);
+    const unsigned ngrp = (nblk + EM_CHUNKS - 1) / EM_CHUNKS;
+    hipLaunchKernelGGL(mc_vertices_kernel, dim3(ngrp), dim3(CELLS_PER_BLOCK), 0, s, vol, d, ws, o, nblk);
     hipLaunchKernelGGL(mc_faces_kernel, dim3(nblk), dim3(CELLS_PER_BLOCK), 0, s, d, ws, o);
     return vt_check(hipGetLastError(), "vt_mc_emit");
 }
