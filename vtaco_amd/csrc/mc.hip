@@ -67,15 +67,25 @@ __device__ __forceinline__ float key_to_float(unsigned k) {
     return __uint_as_float(u);
 }
 
-__global__ void __launch_bounds__(256) mc_minmax_kernel(const float *vol, size_t n, McHeader *hdr) {
-    __shared__ float slo[4], shi[4];
+__global__ void __launch_bounds__(1024) mc_minmax_kernel(const float *vol, size_t n, McHeader *hdr) {
+    __shared__ float slo[16], shi[16];
     float lo = INFINITY, hi = -INFINITY;
     const size_t n4 = ((reinterpret_cast<uintptr_t>(vol) & 15) == 0) ? n / 4 : 0;   // 16-B loads need alignment
     const float4 *v4 = reinterpret_cast<const float4 *>(vol);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const float4 v = v4[i];
-        lo = fminf(fminf(lo, v.x), fminf(v.y, fminf(v.z, v.w)));
-        hi = fmaxf(fmaxf(hi, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+    // eight independent 16-byte loads in flight per thread: the pass is latency-bound (8 MB at 128^3), not bandwidth-bound
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 8 * stride) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const size_t i = i0 + k * stride;
+            v[k] = i < n4 ? v4[i] : v4[i0];                          // past the end: repeat a value already counted
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            lo = fminf(fminf(lo, v[k].x), fminf(v[k].y, fminf(v[k].z, v[k].w)));
+            hi = fmaxf(fmaxf(hi, v[k].x), fmaxf(v[k].y, fmaxf(v[k].z, v[k].w)));
+        }
     }
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float v = vol[i];                                // tail (or everything, if unaligned)
@@ -88,9 +98,9 @@ __global__ void __launch_bounds__(256) mc_minmax_kernel(const float *vol, size_t
     }
     if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
     __syncthreads();
-    if (threadIdx.x == 0) {                                   // ONE atomic pair per block: same-address
-        lo = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));   // atomics serialise (~11 ns each)
-        hi = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+    if (threadIdx.x == 0) {                                   // ONE atomic pair per block, and few, large blocks:
+        lo = slo[0]; hi = shi[0];                              // same-address atomics serialise (~11 ns each)
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) { lo = fminf(lo, slo[i]); hi = fmaxf(hi, shi[i]); }
         atomicMin(&hdr->min_key, ordered_key(lo));
         atomicMin(&hdr->max_key_inv, ~ordered_key(hi));
     }
@@ -720,10 +730,10 @@ int vt_mc_count(const float *vol, int n0, int n1, int n2, double level, int auto
     if (frc) return frc;
     if (auto_level) {
         const size_t n = (size_t)n0 * n1 * n2;
-        unsigned g = (unsigned)((n / 4 + 256 * 4 - 1) / (256 * 4));
-        if (g > 256) g = 256;
+        unsigned g = (unsigned)((n / 4 + 1024 * 8 - 1) / (1024 * 8));
+        if (g > 64) g = 64;
         if (g < 1) g = 1;
-        hipLaunchKernelGGL(mc_minmax_kernel, dim3(g), dim3(256), 0, s, vol, n, ws.hdr);
+        hipLaunchKernelGGL(mc_minmax_kernel, dim3(g), dim3(1024), 0, s, vol, n, ws.hdr);
     }
     hipLaunchKernelGGL(mc_classify_kernel, dim3((nblk + CLS_CHUNKS - 1) / CLS_CHUNKS), dim3(CELLS_PER_BLOCK), 0, s,
                        vol, d, ws, level, auto_level, nblk);
