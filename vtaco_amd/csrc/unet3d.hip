@@ -339,9 +339,11 @@ conv3d_gcr_ksplit_kernel(ConvArgs a) {
 // registers before the 27 taps run, so the global latency hides behind the matrix work.
 constexpr int SB_ROW = 80;
 constexpr int SB_PX = 12;
-constexpr int SB_ROWS = 10 * 10 * SB_PX;
-constexpr int SB_THREADS = 1024;                  // 16 waves: wave w owns z-plane w/2, x-half w%2 (one 4 x 8 patch)
-constexpr int SB_ITERS = 4;                       // ceil(1000 voxels * 4 threads / 1024 threads)
+// Tile 8 x 8 x TZ voxels, 2*TZ waves: wave w owns z-plane w/2, x-half w%2 (one 4 x 8 patch).  TZ = 8 (16 waves) for the
+// large levels; TZ = 2 (4 waves, 4x the workgroups) for the 16^3 / 8^3 levels, where 8^3 tiles cannot fill the chip.
+constexpr int sb_rows(int TZ) { return (TZ + 2) * 10 * SB_PX; }
+constexpr int sb_threads(int TZ) { return 128 * TZ; }
+constexpr int sb_iters(int TZ) { return ((TZ + 2) * 100 * 4 + sb_threads(TZ) - 1) / sb_threads(TZ); }
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // weights -> [cin/16][tap][cout/32][hi,lo][64 lanes][8 bf16]: lane (co, kg) element e = cin 16q + 8kg + e
@@ -367,11 +369,14 @@ __global__ void conv3d_pack_s_kernel(const float *w, int Cout, int Cin, float *p
 }
 
 constexpr int SB_WFRAGS = 27 * 128;               // one (16-channel block, cout block)'s weight fragments: 27 taps x (hi, lo) x 64 lanes
-constexpr int SB_WITERS = (SB_WFRAGS + SB_THREADS - 1) / SB_THREADS;
-constexpr size_t SB_LDS = (size_t)SB_ROWS * SB_ROW + (size_t)SB_WFRAGS * 16;
+constexpr int sb_witers(int TZ) { return (SB_WFRAGS + sb_threads(TZ) - 1) / sb_threads(TZ); }
+constexpr size_t sb_lds(int TZ) { return (size_t)sb_rows(TZ) * SB_ROW + (size_t)SB_WFRAGS * 16; }
 
-__global__ void __launch_bounds__(SB_THREADS)
+template <int TZ>
+__global__ void __launch_bounds__(sb_threads(TZ))
 conv3d_gcr_s_kernel(ConvArgs a) {
+    constexpr int SB_ROWS = sb_rows(TZ), SB_THREADS = sb_threads(TZ), SB_ITERS = sb_iters(TZ), SB_WITERS = sb_witers(TZ);
+    constexpr int NVOX = (TZ + 2) * 100;                            // padded tile voxels
     extern __shared__ __attribute__((aligned(16))) char stile[];    // [SB_ROWS x SB_ROW input][27 x 2 KB weights]; then stats scratch
     const Src &s = a.s;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -381,7 +386,7 @@ conv3d_gcr_s_kernel(ConvArgs a) {
     const int ty = t % a.tiles_y; t /= a.tiles_y;
     const int tz = t % a.tiles_z;
     const int b = t / a.tiles_z;
-    const int x0 = tx * 8, y0 = ty * 8, z0 = tz * 8;
+    const int x0 = tx * 8, y0 = ty * 8, z0 = tz * TZ;
     const int Cin = s.C1 + s.C2, ncq = Cin / 16;
     const int co_blk = blockIdx.y, nco_all = a.Cout / 32;
     const int lx = j & 3, ly = j >> 2;
@@ -399,10 +404,10 @@ conv3d_gcr_s_kernel(ConvArgs a) {
         const int v = (threadIdx.x >> 2) + it * (SB_THREADS / 4);
         const int px = v % 10, r2 = v / 10, py = r2 % 10, pz = r2 / 10;
         const int gx = x0 + px - 1, gy = y0 + py - 1, gz = z0 + pz - 1;
-        const bool in = v < 1000 && gx >= 0 && gx < s.W && gy >= 0 && gy < s.H && gz >= 0 && gz < s.D;
+        const bool in = v < NVOX && gx >= 0 && gx < s.W && gy >= 0 && gy < s.H && gz >= 0 && gz < s.D;
         vskip[it] = in ? ((b * s.D + gz) * s.H + gy) * s.W + gx : 0;
         vlow[it] = in ? ((b * D2 + (gz >> 1)) * H2 + (gy >> 1)) * W2 + (gx >> 1) : 0;
-        lrow[it] = v < 1000 ? ((pz * 10 + py) * SB_PX + px) * SB_ROW + sc4 * 2 : -1;
+        lrow[it] = v < NVOX ? ((pz * 10 + py) * SB_PX + px) * SB_ROW + sc4 * 2 : -1;
         if (in) inside |= 1u << it;
     }
     f32x4 pre[SB_ITERS];
@@ -479,7 +484,7 @@ conv3d_gcr_s_kernel(ConvArgs a) {
     }
     // epilogue: as conv3d_gcr_kernel (lane = voxel, 16 registers = channels chan_of(r,kg))
     __syncthreads();
-    float *sred = reinterpret_cast<float *>(stile);               // [16 waves][32][2]
+    float *sred = reinterpret_cast<float *>(stile);               // [2*TZ waves][32][2]
     {
         const int gx = x0 + lx + wx, gy = y0 + ly, gz = z0 + wz;
         const bool valid = gx < s.W && gy < s.H && gz < s.D;
@@ -495,7 +500,7 @@ conv3d_gcr_s_kernel(ConvArgs a) {
         const int spatial = blockIdx.x % nsp;
         if (threadIdx.x < 64) {
             float tsum = 0.0f;
-            for (int w = 0; w < 16; ++w) tsum += sred[w * 64 + threadIdx.x];
+            for (int w = 0; w < 2 * TZ; ++w) tsum += sred[w * 64 + threadIdx.x];
             a.part[(((size_t)b * nsp + spatial) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
         }
     }
@@ -598,11 +603,18 @@ static int conv_waves(int B, int D, int H, int W, int nco) {
     return 1;
 }
 
-// split-bf16 kernel: whole 8^3 tiles, 32-channel multiples, and enough workgroups to fill the chip
+// split-bf16 kernel: dimensions in multiples of 8, 32-channel multiples, enough tiles
 static bool conv_s_eligible(int B, int D, int H, int W, int Cin, int Cout) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || ((D | H | W) & 7) || Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 31)) return false;
     if ((size_t)B * D * H * W >= ((size_t)1 << 31)) return false;                    // 32-bit voxel indices
-    return (size_t)(D / 8) * (H / 8) * (W / 8) * B * (Cout / 32) >= 64;
+    // even the thin 8 x 8 x 2 tiles must give 64 workgroups (one per four CUs): below that (the 8^3 level of one scene)
+    // the exact-f32 K-split kernel is as fast
+    return (size_t)(D / 2) * (H / 8) * (W / 8) * B * (Cout / 32) >= 64;
+}
+
+// tile depth: 8^3 tiles when they give the chip enough workgroups, 8 x 8 x 2 tiles below that
+static int conv_s_tz(int B, int D, int H, int W, int Cout) {
+    return (size_t)(D / 8) * (H / 8) * (W / 8) * B * (Cout / 32) >= 64 ? 8 : 2;
 }
 
 template <int NCO, int WAVES>
@@ -739,7 +751,7 @@ int vt_conv3d_pack_bf16x3(const float *w, int Cout, int Cin, float *packed, void
 }
 
 int vt_conv3d_stat_blocks_bf16x3(int B, int D, int H, int W, int Cin, int Cout) {
-    return conv_s_eligible(B, D, H, W, Cin, Cout) ? (D / 8) * (H / 8) * (W / 8) : 0;
+    return conv_s_eligible(B, D, H, W, Cin, Cout) ? (D / conv_s_tz(B, D, H, W, Cout)) * (H / 8) * (W / 8) : 0;
 }
 
 int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
@@ -751,16 +763,19 @@ int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, in
     if (!conv_s_eligible(B, D, H, W, a.s.C1 + a.s.C2, Cout))
         return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr_bf16x3: shape not covered (see vt_conv3d_stat_blocks_bf16x3); use vt_conv3d_gcr");
     a.scale_shift = scale_shift; a.wp = packed_w_bf16x3; a.out = out; a.part = out_part; a.Cout = Cout; a.relu = relu;
-    a.TX = a.TY = a.TZ = 8;
-    a.tiles_x = W / 8; a.tiles_y = H / 8; a.tiles_z = D / 8;
+    const int tz = conv_s_tz(B, D, H, W, Cout);
+    a.TX = a.TY = 8; a.TZ = tz;
+    a.tiles_x = W / 8; a.tiles_y = H / 8; a.tiles_z = D / tz;
     const dim3 grid((unsigned)((size_t)a.tiles_x * a.tiles_y * a.tiles_z * B), (unsigned)(Cout / 32));
     static bool attr = false;
     if (!attr) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_bf16x3: hipFuncSetAttribute");
         attr = true;
     }
-    hipLaunchKernelGGL(conv3d_gcr_s_kernel, grid, dim3(SB_THREADS), SB_LDS, (hipStream_t)stream, a);
+    if (tz == 8) hipLaunchKernelGGL(conv3d_gcr_s_kernel<8>, grid, dim3(sb_threads(8)), sb_lds(8), (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv3d_gcr_s_kernel<2>, grid, dim3(sb_threads(2)), sb_lds(2), (hipStream_t)stream, a);
     return vt_check(hipGetLastError(), "vt_conv3d_gcr_bf16x3");
 }
 
