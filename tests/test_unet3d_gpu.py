@@ -192,3 +192,19 @@ def test_hip_unet3d_training_path_vs_host_autograd(R, levels, B):
     err = max([l2(x_cl.grad.permute(0, 4, 1, 2, 3), gx0)] + [l2(p.grad, gp0[n]) for n, p in net.named_parameters()])
     assert err <= 3.0 * sens + 1e-4, (err, sens)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+@pytest.mark.parametrize("Cin,Cout,shape,bias", [(32, 32, (1, 8, 8, 8), True), (64, 32, (2, 3, 5, 7), True),
+                                                  (32, 96, (1, 1, 1, 33), False), (16, 8, (1, 4, 4, 5), True)])
+def test_conv1x1_channels_last(Cin, Cout, shape, bias):
+    """vt_conv1x1_cl: f32-MFMA kernel for 32-channel multiples (ragged voxel counts), scalar kernel otherwise."""
+    from vtaco_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Cin * 100 + Cout)
+    x = torch.randn(*shape, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, 1, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g) if bias else None
+    got = ops.conv1x1_cl(x.to(dev), w.to(dev), b.to(dev) if bias else None).cpu()
+    ref = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3), w, b).permute(0, 2, 3, 4, 1)
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))

@@ -543,6 +543,36 @@ conv1x1_cl_kernel(const float *x, const float *w, const float *bias, float *out,
     }
 }
 
+// The same 1x1x1 conv on the f32 matrix core for 32-channel multiples (the UNet3D's final layer): one wave per
+// 32-voxel tile, lane (voxel, k-half) reads its half row of x as four 16-byte loads, the weight rows come from L1.
+// 64 MFMA cycles per 4 KB of input: the kernel streams at memory speed (the scalar form above issues one load
+// instruction per input channel and thread and runs at a quarter of that).
+__global__ void __launch_bounds__(256)
+conv1x1_mfma_kernel(const float *x, const float *w, const float *bias, float *out, int Cin, int Cout, size_t V) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, kh = lane >> 5;
+    const int ncib = Cin / 32, ncob = Cout / 32;
+    const size_t ntile = (V + 31) / 32;
+    for (size_t tile = (size_t)blockIdx.x * 4 + wave; tile < ntile; tile += (size_t)gridDim.x * 4) {
+        const size_t v = tile * 32 + j;
+        const bool valid = v < V;
+        for (int cob = 0; cob < ncob; ++cob) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bias ? bias[cob * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh] : 0.0f;
+            for (int cib = 0; cib < ncib; ++cib) {
+                f32x16 xv, wv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xv[r] = 0.0f;
+                if (valid) xv = load_frag16(x + v * Cin + cib * 32 + 16 * kh);
+                wv = load_frag16(w + (size_t)(cob * 32 + j) * Cin + cib * 32 + 16 * kh);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc = mfma(wv[q], xv[q], acc);
+            }
+            if (valid) store_acc16(out + v * Cout + cob * 32, acc, kh);
+        }
+    }
+}
+
 // scatter-mean straight into a channels-last grid (see voxel.hip for the segment bookkeeping)
 __global__ void __launch_bounds__(256)
 scatter_mean_cl_kernel(const float *feat, const int *idx, const int *order, const int *seg_lo, const int *seg_hi,
@@ -790,6 +820,13 @@ int vt_maxpool3d_cl(const float *x, int B, int D, int H, int W, int C, float *ou
 
 int vt_conv1x1_cl(const float *x, int64_t V, int Cin, const float *w, const float *bias, int Cout, float *out, void *stream) {
     if (!x || !w || !out || V <= 0 || Cin <= 0 || Cout <= 0) return vt_fail(VT_ERR_INVALID, "vt_conv1x1_cl: bad argument");
+    if (!(Cin & 31) && !(Cout & 31)) {
+        size_t g = ((size_t)V + 127) / 128;
+        const size_t cap = (size_t)vt_num_cus() * 8;
+        if (g > cap) g = cap;
+        hipLaunchKernelGGL(conv1x1_mfma_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, Cin, Cout, (size_t)V);
+        return vt_check(hipGetLastError(), "vt_conv1x1_cl");
+    }
     const size_t lds = ((size_t)Cout * (Cin + 1) + Cout) * sizeof(float);
     if (lds > 64 * 1024) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv1x1_cl: weights do not fit 64 KiB of LDS");
     size_t g = ((size_t)V * Cout + 255) / 256;
