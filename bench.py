@@ -105,7 +105,7 @@ def stage_times(scene, dec, grid, nx, out, dev, precision):
     return res
 
 
-PMC_SUMMARY = os.path.join("profiles", "r01h_pmc_summary.csv")
+PMC_SUMMARY = os.path.join("profiles", "r01i_pmc_summary.csv")
 
 
 def pmc_counters(precision):

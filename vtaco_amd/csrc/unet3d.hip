@@ -67,34 +67,44 @@ channel_stats_kernel(const float *x, int C, size_t V, int nblk, float *part) {
 
 struct StatSrc { const float *part; int nblk, C; };
 
-// one block per (scene, group): scale[b][c] = rstd*gamma, shift[b][c] = beta - mean*rstd*gamma
+// one block per (scene, group): scale[b][c] = rstd*gamma, shift[b][c] = beta - mean*rstd*gamma.
+// The (channel, partial block) pairs of the group are flattened over the threads (8-byte loads, consecutive
+// threads on consecutive channels of one partial block) and reduced with wave shuffles: the kernel is a
+// latency chain in front of every convolution, so it is kept short.
 __global__ void __launch_bounds__(256)
 gn_finalize_kernel(StatSrc s1, StatSrc s2, int groups, double count, const float *gamma, const float *beta,
                    float eps, float *scale_shift) {
-    __shared__ double red[256][2];
+    __shared__ double wred[4][2];
     __shared__ double stat[2];
     const int b = blockIdx.x, g = blockIdx.y;
     const int C = s1.C + s2.C, cpg = C / groups;
+    const int c_lo = g * cpg, c_hi = c_lo + cpg;
     double sum = 0.0, sq = 0.0;
-    for (int k = 0; k < cpg; ++k) {
-        const int c = g * cpg + k;
-        const StatSrc &s = (c < s1.C) ? s1 : s2;
-        const int cc = (c < s1.C) ? c : c - s1.C;
-        const double mult = (c < s1.C) ? 1.0 : 8.0;
-        for (int blk = threadIdx.x; blk < s.nblk; blk += 256) {
-            const float *p = s.part + (((size_t)b * s.nblk + blk) * s.C + cc) * 2;
-            sum += mult * (double)p[0]; sq += mult * (double)p[1];
+#pragma unroll
+    for (int src = 0; src < 2; ++src) {
+        const StatSrc &s = src ? s2 : s1;
+        const int coff = src ? s1.C : 0;
+        const double mult = src ? 8.0 : 1.0;                     // a `low` voxel stands for its 8 upsampled copies
+        if (!s.part) continue;
+        const int k0 = (c_lo > coff ? c_lo : coff) - coff, k1 = (c_hi < coff + s.C ? c_hi : coff + s.C) - coff;
+        const int nk = k1 - k0;
+        if (nk <= 0) continue;
+        const int total = nk * s.nblk;
+        const float2 *base = reinterpret_cast<const float2 *>(s.part) + (size_t)b * s.nblk * s.C + k0;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const int blk = i / nk, k = i - blk * nk;
+            const float2 p = base[(size_t)blk * s.C + k];
+            sum += mult * (double)p.x; sq += mult * (double)p.y;
         }
     }
-    red[threadIdx.x][0] = sum; red[threadIdx.x][1] = sq;
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); sq += __shfl_xor(sq, o); }
+    if ((threadIdx.x & 63) == 0) { wred[threadIdx.x >> 6][0] = sum; wred[threadIdx.x >> 6][1] = sq; }
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { red[threadIdx.x][0] += red[threadIdx.x + o][0]; red[threadIdx.x][1] += red[threadIdx.x + o][1]; }
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        const double n = count * cpg, mean = red[0][0] / n;
-        double var = red[0][1] / n - mean * mean;                // biased variance, as torch
+        const double tsum = wred[0][0] + wred[1][0] + wred[2][0] + wred[3][0];
+        const double tsq = wred[0][1] + wred[1][1] + wred[2][1] + wred[3][1];
+        const double n = count * cpg, mean = tsum / n;
+        double var = tsq / n - mean * mean;                      // biased variance, as torch
         if (var < 0.0) var = 0.0;
         stat[0] = mean; stat[1] = 1.0 / sqrt(var + (double)eps);
     }
