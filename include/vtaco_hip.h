@@ -411,6 +411,21 @@ int vt_mano_pack(const float *v_template, const float *shapedirs, const float *b
                  const float *j_regressor, const float *weights, const float *hands_mean, float *blob, void *stream);
 int vt_mano_fwd(const float *pose, int B, const float *blob, int center_idx, float *verts, float *joints, void *stream);
 
+/* ------------------------------------------------------------------------- */
+/* PointNet per-point MLP (inference).  Replaces the nn.Linear / ResnetBlockFC   */
+/* calls of LocalPoolPointnet.forward (src/encoder/pointnet.py:154-162;           */
+/* src/layers.py:8-50): rows are points, weights in nn.Linear layout [out][in].   */
+/*   vt_linear_rows  out[n] = b + W x[n]            (fc_pos, fc_c; b may be NULL)   */
+/*   vt_resblock_fc  x = [x1[n] | x2[n]] (x2 may be NULL: no concat);                */
+/*                   h = b0 + W0 relu(x); out[n] = b1 + W1 relu(h) + Ws x           */
+/*                   (ws NULL: identity shortcut, needs C1 + C2 == O).               */
+/* At most 256 hidden / output channels; weights must fit 64 KiB of LDS.             */
+/* ------------------------------------------------------------------------- */
+int vt_linear_rows(const float *x, const float *w, const float *b, int64_t N, int Cin, int Cout, float *out, void *stream);
+int vt_resblock_fc(const float *x1, int C1, const float *x2, int C2, int64_t N,
+                   const float *w0, const float *b0, const float *w1, const float *b1, const float *ws,
+                   int H, int O, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

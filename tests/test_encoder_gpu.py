@@ -103,7 +103,8 @@ def test_generator_end_to_end_mesh_vs_oracle():
     mesh = gen.generate_obj_mesh_wnf({"inputs": p})
     grid = orc.pointnet_encoder_forward(sd_e, p, 16, unet3d=False)
     vol = orc.eval_points_dense(sd_d, grid, 32).reshape(32, 32, 32)
-    vol_gpu = gen.eval_lattice(model.encode_inputs(p.to(DEV)), 32).reshape(32, 32, 32).cpu()
+    with torch.no_grad():                 # the generator encodes without autograd (fused PointNet MLP): same volume
+        vol_gpu = gen.eval_lattice(model.encode_inputs(p.to(DEV)), 32).reshape(32, 32, 32).cpu()
     assert float((vol_gpu - vol).abs().max()) <= 1e-4
     # eval_points (reference API: explicit points, CPU result) agrees with the lattice path
     pts = 1.1 * orc.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (32,) * 3)
@@ -156,3 +157,56 @@ def test_graphed_scene_equals_eager():
         eager = gen.generate_obj_mesh_wnf({"inputs": p})
         fast = gen.generate_mesh_graphed(p)
         assert torch.equal(eager.faces, fast.faces) and torch.equal(eager.vertices, fast.vertices)
+
+
+@pytest.mark.parametrize("N,C1,C2,H,O,shortcut", [(3000, 32, 32, 32, 32, True), (1, 64, 0, 32, 32, True), (257, 32, 0, 16, 32, False),
+                                                   (1000, 24, 24, 48, 40, True), (5, 48, 16, 64, 64, False)])
+def test_resblock_fc_and_linear_rows_against_torch(N, C1, C2, H, O, shortcut):
+    """vt_resblock_fc / vt_linear_rows (the PointNet MLP at inference) against the nn.Module they replace."""
+    from vtaco_amd import ops
+    from vtaco_amd.layers import ResnetBlockFC
+    dev = torch.device("cuda:0")
+    torch.manual_seed(N + C1)
+    blk = ResnetBlockFC(C1 + C2, O, H)
+    assert (blk.shortcut is not None) == shortcut
+    with torch.no_grad():
+        blk.fc_1.weight.normal_(0, 0.2)
+    g = torch.Generator().manual_seed(7)
+    x1 = torch.randn(2, N, C1, generator=g)
+    x2 = torch.randn(2, N, C2, generator=g) if C2 else None
+    with torch.no_grad():
+        ref = blk(torch.cat([x1, x2], dim=2) if C2 else x1)
+    blk = blk.to(dev)
+    got = ops.resblock_fc(x1.to(dev), x2.to(dev) if C2 else None, blk.fc_0, blk.fc_1, blk.shortcut).cpu()
+    assert got.shape == ref.shape and float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    lin = torch.nn.Linear(C1, O)
+    with torch.no_grad():
+        lref = lin(x1)
+    lin = lin.to(dev)
+    lgot = ops.linear_rows(x1.to(dev), lin.weight, lin.bias).cpu()
+    assert float((lgot - lref).abs().max()) <= 1e-5 * max(1.0, float(lref.abs().max()))
+    assert ops.linear_rows(x1[:, :0].to(dev), lin.weight, None).shape == (2, 0, O)          # empty point set
+    from vtaco_amd._lib import VtError
+    wide = ResnetBlockFC(256, 128).to(dev)                                                    # 320 KB of weights: no LDS fit
+    with pytest.raises(VtError, match="LDS"):
+        ops.resblock_fc(torch.zeros(1, 4, 256, device=dev), None, wide.fc_0, wide.fc_1, wide.shortcut)
+
+
+def test_fused_point_features_equal_the_module_path():
+    """LocalPoolPointnet.point_features: the fused inference path against the nn.Module (autograd) path."""
+    from vtaco_amd import ops
+    a, sd = load_golden("g3_pointnet.npz")
+    dev = torch.device("cuda:0")
+    from vtaco_amd.encoder import encoder_dict
+    enc = encoder_dict["pointnet_local_pool"](c_dim=32, dim=3, hidden_dim=32, scatter_type="max", unet3d=False,
+                                              grid_resolution=16, plane_type="grid", padding=0.1, n_blocks=5)
+    enc.load_state_dict(sd)
+    enc = enc.to(dev).eval()
+    p = torch.from_numpy(a["p"]).to(dev)
+    vi = ops.VoxelIndex(p, 16, 0.1)
+    with torch.no_grad():
+        fused = enc.point_features(p, vi)
+    with torch.enable_grad():
+        module = enc.point_features(p, vi).detach()
+    assert float((fused - module).abs().max()) <= 1e-5
+    assert float((fused.cpu() - torch.from_numpy(a["fc_c"])).abs().max()) <= 1e-5      # the reference's own output

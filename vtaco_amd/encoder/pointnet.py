@@ -137,6 +137,8 @@ class LocalPoolPointnet(nn.Module):
     def point_features(self, p, vi):
         """fc_pos -> block0 -> 4 x (local max-pool, concat, block) -> fc_c  (pointnet.py:154-162).
         ``vi``: one VoxelIndex, or a list of PlaneIndex whose pooled features are summed (pointnet.py:116-132)."""
+        if not torch.is_grad_enabled() and self._fused_mlp_fits():
+            return self._point_features_fused(p, vi)
         net = self.blocks[0](self.fc_pos(p))
         for blk in self.blocks[1:]:
             if isinstance(vi, (list, tuple)):
@@ -147,6 +149,29 @@ class LocalPoolPointnet(nn.Module):
                 pooled = _PoolMax.apply(net, vi)
             net = blk(torch.cat([net, pooled], dim=2))
         return self.fc_c(net)
+
+    def _fused_mlp_fits(self):
+        """vt_resblock_fc keeps a block's three weight matrices in 64 KiB of LDS (hidden_dim <= 48 or so: the shipped
+        configs use 32); wider PointNets keep the nn.Linear (hipBLASLt) path."""
+        h = self.hidden_dim
+        floats = 2 * h * h + h * h + 2 * h * h + (256 // h if h <= 256 else 0) * 3 * h
+        return h <= 256 and floats * 4 <= 64 * 1024 and 2 * h <= 256
+
+    def _point_features_fused(self, p, vi):
+        """The same layers without autograd: one HIP launch per linear layer / ResnetBlockFC (vt_linear_rows,
+        vt_resblock_fc, the concat with the pooled features read in place) instead of ~9 framework launches per block."""
+        net = ops.linear_rows(p, self.fc_pos.weight, self.fc_pos.bias)
+        b0 = self.blocks[0]
+        net = ops.resblock_fc(net, None, b0.fc_0, b0.fc_1, b0.shortcut)
+        for blk in self.blocks[1:]:
+            if isinstance(vi, (list, tuple)):
+                pooled = ops.voxel_pool_max_fwd(net, vi[0], want_argmax=False)[0]
+                for other in vi[1:]:
+                    pooled = pooled + ops.voxel_pool_max_fwd(net, other, want_argmax=False)[0]
+            else:
+                pooled = ops.voxel_pool_max_fwd(net, vi, want_argmax=False)[0]
+            net = ops.resblock_fc(net, pooled, blk.fc_0, blk.fc_1, blk.shortcut)
+        return ops.linear_rows(net, self.fc_c.weight, self.fc_c.bias)
 
     def _mano_head(self, fea):
         """out_mano (pointnet.py:179-201): pooled plane/grid features -> mano_param (-> MANO layer)."""

@@ -340,6 +340,36 @@ def voxel_scatter_mean_bwd(grad_grid, vi, C):
 
 
 # --------------------------------------------------------------------------------------
+# PointNet per-point MLP, inference (vt_linear_rows, vt_resblock_fc)
+# --------------------------------------------------------------------------------------
+def linear_rows(x, weight, bias=None):
+    """nn.Linear over the rows of x [..., Cin] -> [..., Cout]."""
+    x = _c(x)
+    Cout, Cin = weight.shape
+    out = torch.empty(x.shape[:-1] + (Cout,), dtype=torch.float32, device=x.device)
+    check(_lib.load().vt_linear_rows(dev_ptr(x, "x"), dev_ptr(_c(weight), "weight"),
+                                     dev_ptr(_c(bias) if bias is not None else None, "bias"),
+                                     x.numel() // Cin, Cin, Cout, dev_ptr(out, "out"), stream_ptr()), "vt_linear_rows")
+    return out
+
+
+def resblock_fc(x1, x2, fc_0, fc_1, shortcut):
+    """ResnetBlockFC (layers.py:8-50) on the rows of cat([x1, x2], -1) (x2 may be None); the arguments after x2 are
+    the block's nn.Linear modules (shortcut None = identity)."""
+    x1 = _c(x1)
+    x2 = _c(x2) if x2 is not None else None
+    C1, C2 = x1.shape[-1], (x2.shape[-1] if x2 is not None else 0)
+    H, O = fc_0.weight.shape[0], fc_1.weight.shape[0]
+    out = torch.empty(x1.shape[:-1] + (O,), dtype=torch.float32, device=x1.device)
+    check(_lib.load().vt_resblock_fc(dev_ptr(x1, "x1"), C1, dev_ptr(x2, "x2"), C2, x1.numel() // C1,
+                                     dev_ptr(_c(fc_0.weight), "fc_0.weight"), dev_ptr(_c(fc_0.bias), "fc_0.bias"),
+                                     dev_ptr(_c(fc_1.weight), "fc_1.weight"), dev_ptr(_c(fc_1.bias), "fc_1.bias"),
+                                     dev_ptr(_c(shortcut.weight) if shortcut is not None else None, "shortcut.weight"),
+                                     H, O, dev_ptr(out, "out"), stream_ptr()), "vt_resblock_fc")
+    return out
+
+
+# --------------------------------------------------------------------------------------
 # hand branch: plane bookkeeping (vt_plane_*) and the MANO layer (vt_mano_*)
 # --------------------------------------------------------------------------------------
 PLANES = {"xz": 0, "xy": 1, "yz": 2}
