@@ -154,7 +154,11 @@ def one_unet():
     with torch.no_grad():
         got = net.forward_channels_last(x.to(DEV).permute(0, 2, 3, 4, 1).contiguous()).permute(0, 4, 1, 2, 3).cpu()
     err = float((got - ref).abs().max())
-    if not err <= 1e-4 * max(1.0, float(ref.abs().max())):
+    # exact-f32 convs: 1e-4.  Split-bf16 convs carry 2^-18 per product, and random-init nets whose bottom level is 4^3 voxels
+    # amplify it through GroupNorm over a few dozen values: up to 1.1e-4 of the output scale measured
+    # (tools/debug_unet_precision.py); the bar that matters -- logits decoded from the grid -- sits at 2.6e-5 on the bench scene
+    tol = 1e-4 if net.precision == "f32" else 3e-4
+    if not err <= tol * max(1.0, float(ref.abs().max())):
         fails.append(("unet3d", R, levels, B, net.precision, err))
 
 

@@ -648,8 +648,10 @@ static bool conv_s_eligible(int B, int D, int H, int W, int Cin, int Cout) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || ((D | H | W) & 7) || Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 31)) return false;
     if ((size_t)B * D * H * W >= ((size_t)1 << 31)) return false;                    // 32-bit voxel indices
     // even the thin 8 x 8 x 2 tiles must give 64 workgroups (one per four CUs): below that (the 8^3 level of one scene)
-    // the exact-f32 K-split kernel is as fast
-    return (size_t)(D / 2) * (H / 8) * (W / 8) * B * (Cout / 32) >= 64;
+    // the exact-f32 K-split kernel is as fast.  VTACO_CONV_THIN=0 keeps the thin tiles off (A/B runs).
+    static const bool thin = !(getenv("VTACO_CONV_THIN") && getenv("VTACO_CONV_THIN")[0] == '0');
+    if ((size_t)(D / 8) * (H / 8) * (W / 8) * B * (Cout / 32) >= 64) return true;
+    return thin && (size_t)(D / 2) * (H / 8) * (W / 8) * B * (Cout / 32) >= 64;
 }
 
 // tile depth: 8^3 tiles when they give the chip enough workgroups, 8 x 8 x 2 tiles below that
