@@ -208,3 +208,22 @@ def test_conv1x1_channels_last(Cin, Cout, shape, bias):
     ref = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3), w, b).permute(0, 2, 3, 4, 1)
     assert got.shape == ref.shape
     assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_split_unet3d_keeps_the_logit_bar_on_the_bench_scene():
+    """BASELINE config 2 end to end: the encoder with split-bf16 convs (8^3 and thin 8x8x2 tiles, the default at inference)
+    against the encoder with exact-f32 convs, both decoded by the exact-f32 decode kernel: logits within north_star's 1e-4."""
+    from vtaco_amd.bench_util import build_scene
+    sc = build_scene(0, DEV)
+    model, pc = sc["model"], sc["cloud"].to(DEV)
+    outs = {}
+    with torch.no_grad():
+        for prec in ("f32", "bf16x3"):
+            model.encoder.unet3d.precision = prec
+            grid = model.encode_inputs(pc)["grid"]
+            outs[prec] = (grid.clone(), model.decoder.decode_lattice(grid, 128, precision="f32").clone())
+    model.encoder.unet3d.precision = "bf16x3"
+    gerr = float((outs["f32"][0] - outs["bf16x3"][0]).abs().max())
+    lerr = float((outs["f32"][1] - outs["bf16x3"][1]).abs().max())
+    assert 0.0 < lerr <= 1e-4, (gerr, lerr)
+    assert gerr <= 1e-4 * max(1.0, float(outs["f32"][0].abs().max()))
