@@ -1,7 +1,8 @@
 """Randomised differential testing on the GPU (not collected by pytest: run `python tests/stress_gpu.py [seconds]`).
 Marching cubes against the C oracle on random shapes / fields / levels, the decode kernels against the torch oracle on
 random (B, N, R) and lattices, the voxeliser against the oracle on random clouds, the fusion pipeline on ragged N, the
-UNet3D forward (both conv precisions) on small volumes.  Prints a summary; exits 1 on a mismatch."""
+UNet3D forward (both conv precisions) on small volumes, the hand branch (plane ids / scatter, the PointNet MLP kernels,
+the MANO layer on random synthetic assets).  Prints a summary; exits 1 on a mismatch."""
 import os
 import sys
 import time
@@ -162,7 +163,60 @@ def one_unet():
         fails.append(("unet3d", R, levels, B, net.precision, err))
 
 
-counts.update({"fusion": 0, "unet3d": 0})
+_MANO = {}
+
+
+def one_hand():
+    import tempfile
+    import synth_mano
+    from vtaco_amd.encoder.manolayer import ManoLayer
+    from vtaco_amd.layers import ResnetBlockFC
+    B, T, R = int(rng.randint(1, 4)), int(rng.randint(1, 5000)), int(rng.choice([8, 32, 64, 128]))
+    g = torch.Generator().manual_seed(int(rng.randint(1 << 30)))
+    p = (torch.rand(B, T, 3, generator=g) - 0.5) * float(rng.choice([0.2, 1.0, 1.3]))
+    feat = torch.randn(B, T, 32, generator=g)
+    plane = str(rng.choice(["xz", "xy", "yz"]))
+    idx = orc.plane_index(p, R, 0.1, plane)
+    pi = ops.PlaneIndex(p.to(DEV), R, 0.1, plane)
+    if not torch.equal(pi.idx.cpu().long(), idx):
+        fails.append(("plane ids", plane, B, T, R))
+        return
+    if not torch.equal(ops.voxel_pool_max_fwd(feat.to(DEV), pi)[0].cpu(), orc.segment_pool_max(feat, idx)):
+        fails.append(("plane pool_max", plane, B, T, R))
+    if float((ops.plane_scatter_mean_fwd(feat.to(DEV), pi).cpu() - orc.scatter_mean_plane(feat, idx, R)).abs().max()) > 1e-5:
+        fails.append(("plane scatter_mean", plane, B, T, R))
+    # PointNet MLP kernels against the nn.Module
+    C1, C2 = int(rng.choice([8, 32, 64])), int(rng.choice([0, 32]))
+    H, O = int(rng.choice([16, 32, 48])), int(rng.choice([16, 32, C1 + C2]))
+    torch.manual_seed(int(rng.randint(1 << 30)))
+    blk = ResnetBlockFC(C1 + C2, O, H)
+    with torch.no_grad():
+        blk.fc_1.weight.normal_(0, 0.2)
+    x1, x2 = torch.randn(B, T, C1, generator=g), (torch.randn(B, T, C2, generator=g) if C2 else None)
+    with torch.no_grad():
+        ref = blk(torch.cat([x1, x2], dim=2) if C2 else x1)
+    blk = blk.to(DEV)
+    got = ops.resblock_fc(x1.to(DEV), x2.to(DEV) if C2 else None, blk.fc_0, blk.fc_1, blk.shortcut).cpu()
+    if float((got - ref).abs().max()) > 2e-5 * max(1.0, float(ref.abs().max())):
+        fails.append(("resblock_fc", T, C1, C2, H, O, float((got - ref).abs().max())))
+    # MANO layer on a random synthetic asset
+    seed = int(rng.randint(4))
+    if seed not in _MANO:
+        asset = synth_mano.make_asset(seed)
+        root = tempfile.mkdtemp(prefix="vt_mano_")
+        synth_mano.write_pkl(asset, root)
+        _MANO[seed] = (synth_mano.as_model(asset), ManoLayer(center_idx=9, flat_hand_mean=False, ncomps=45, side="right",
+                                                              mano_root=root, use_pca=False).to(DEV))
+    model, layer = _MANO[seed]
+    pose = torch.randn(int(rng.randint(1, 70)), 48, generator=g) * float(rng.choice([0.0, 0.3, 2.0]))
+    with torch.no_grad():
+        v, j = layer(pose.to(DEV))
+    rv, rj = orc.mano_forward(model, pose)
+    if float((v.cpu() - rv).abs().max()) > 3e-6 or float((j.cpu() - rj).abs().max()) > 3e-6:
+        fails.append(("mano", seed, pose.shape[0], float((v.cpu() - rv).abs().max())))
+
+
+counts.update({"fusion": 0, "unet3d": 0, "hand": 0})
 t0 = time.time()
 it = 0
 while time.time() - t0 < budget and len(fails) < 5:
@@ -170,6 +224,7 @@ while time.time() - t0 < budget and len(fails) < 5:
     jobs = [("mc", one_mc), ("decode", one_decode), ("voxel", one_voxel)]
     if it % 4 == 0:
         jobs.append(("fusion", one_fusion))
+        jobs.append(("hand", one_hand))
     if it % 40 == 0:
         jobs.append(("unet3d", one_unet))
     for name, fn in jobs:
