@@ -480,16 +480,30 @@ conv3d_gcr_s_kernel(ConvArgs a) {
         commit(q);
         __syncthreads();
         if (q + 1 < ncq) fetch(q + 1);
-#pragma unroll 3
-        for (int tap = 0; tap < 27; ++tap) {
-            const bf16x8 wh = wlds[tap * 128 + lane], wl = wlds[tap * 128 + 64 + lane];
+        // the four operand fragments of tap t+1 are requested before the three MFMAs of tap t issue: one LDS latency
+        // per tap hides under the matrix pipe instead of two being exposed in front of it (two taps ahead spills the
+        // 16-wave kernel past its 128 registers and was slower)
+        struct TapOps { bf16x8 wh, wl, xh, xl; };
+        auto tap_ops = [&](int tap) {
+            TapOps o;
+            o.wh = wlds[tap * 128 + lane]; o.wl = wlds[tap * 128 + 64 + lane];
             const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
             const char *xin = stile + (center + (dz * 10 + dy) * SB_PX + dx) * SB_ROW + kg * 16;
-            const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(xin);
-            const bf16x8 xl = *reinterpret_cast<const bf16x8 *>(xin + 32);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc, 0, 0, 0);
+            o.xh = *reinterpret_cast<const bf16x8 *>(xin);
+            o.xl = *reinterpret_cast<const bf16x8 *>(xin + 32);
+            return o;
+        };
+        TapOps cur = tap_ops(0);
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            TapOps nxt = cur;
+            if (tap + 1 < 27) nxt = tap_ops(tap + 1);
+            __builtin_amdgcn_sched_barrier(0);                     // keep the requests ahead of the MFMAs (the scheduler sinks them otherwise)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.wl, cur.xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.wh, cur.xl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.wh, cur.xh, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
         }
     }
     // epilogue: as conv3d_gcr_kernel (lane = voxel, 16 registers = channels chan_of(r,kg))
