@@ -332,7 +332,7 @@ typedef struct vt_unet3d_params {
 /* Split-bf16 form of vt_conv3d_pack / vt_conv3d_stat_blocks / vt_conv3d_gcr (same arguments): the 3x3x3 convolution  */
 /* as W_lo*x_hi + W_hi*x_lo + W_hi*x_hi on the bf16 matrix core with f32 accumulation (hi = bf16(v), lo = bf16(v - hi));  */
 /* GroupNorm, ReLU and the output statistics stay f32.  Covers volumes whose sides are multiples of 8 and that give at     */
-/* least 64 workgroups of 8x8x8 (large levels) or 8x8x2 (16^3-class levels) tiles per cout block                           */
+/* least 64 workgroups of 8x8x8 / 8x8x4 (large levels) or 8x8x2 (16^3-class levels) tiles per cout block                   */
 /* (stat_blocks returns 0 and gcr VT_ERR_UNSUPPORTED otherwise: use the f32 form).  6.6e-5 abs on the UNet3D golden       */
 /* (scale 2.4), 4e-5 on the logits decoded from the resulting grid.                                                       */
 int vt_conv3d_pack_bf16x3(const float *w, int Cout, int Cin, float *packed, void *stream);

@@ -57,12 +57,13 @@ def test_encoder_inference_uses_hip_unet_and_matches_training_path():
 
 
 def test_split_bf16_conv_layers_match_f32_kernel():
-    """vt_conv3d_gcr_bf16x3 against vt_conv3d_gcr on the shapes the 64^3 level uses: plain 32->32, the
-    virtual concat [skip | upsample(low)] 96->32, and a 64-wide output (two cout blocks per workgroup)."""
+    """vt_conv3d_gcr_bf16x3 against vt_conv3d_gcr on the shapes the UNet3D levels use (all three tile shapes): plain
+    32->32, the virtual concat [skip | upsample(low)], 64-wide outputs (two cout blocks)."""
     from vtaco_amd import ops
     g = torch.Generator().manual_seed(11)
-    R = 64
-    for C1, C2, Cout in ((32, 0, 32), (32, 64, 32), (32, 0, 64)):
+    # R = 64: 8^3 tiles, one workgroup per CU; R = 32: 8x8x4 tiles, two workgroups per CU; R = 16: 8x8x2 tiles
+    for R, C1, C2, Cout in ((64, 32, 0, 32), (64, 32, 64, 32), (64, 32, 0, 64), (32, 32, 0, 32), (32, 64, 128, 64), (16, 64, 0, 64)):
+        tile_z = 8 if R == 64 else (4 if R == 32 else 2)
         x = (torch.randn(1, R, R, R, C1, generator=g) * (torch.rand(1, R, R, R, 1, generator=g) < 0.3)).to(DEV)
         low = torch.randn(1, R // 2, R // 2, R // 2, C2, generator=g).to(DEV) if C2 else None
         w = (torch.randn(Cout, C1 + C2, 3, 3, 3, generator=g) * 0.05).to(DEV)
@@ -73,7 +74,7 @@ def test_split_bf16_conv_layers_match_f32_kernel():
         pf, ps = ops.conv3d_pack(w), ops.conv3d_pack(w, precision="bf16x3")
         ref, (rp, rn) = ops.gn_conv3d_relu(x, xs, low, ls, gamma, beta, 8, pf, Cout)
         got, (gp, gn) = ops.gn_conv3d_relu(x, xs, low, ls, gamma, beta, 8, pf, Cout, packed_w_bf16x3=ps)
-        assert gn == (R // 8) ** 3 and rn != gn                     # it really took the split kernel
+        assert gn == (R // 8) ** 2 * (R // tile_z) and rn != gn    # it really took the split kernel, on the expected tiles
         scale = float(ref.abs().max())
         err = float((got - ref).abs().max())
         assert 0.0 < err <= 3e-5 * max(1.0, scale), (C1, C2, Cout, err, scale)

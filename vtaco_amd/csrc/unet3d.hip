@@ -530,6 +530,180 @@ conv3d_gcr_s_kernel(ConvArgs a) {
     }
 }
 
+// ---- the same convolution for TWO workgroups per CU --------------------------------------------------------
+// The kernel above keeps one workgroup per CU (94-151 KB of LDS), so its memory half (global fetch round trips,
+// barriers, the output store) and its tap half never overlap: 34 + 28 us on a 32->32 conv at 64^3.  Here the tile is
+// 8 x 8 x 4 (8 waves, 57.6 KB) and the 27 taps of weights pass through LDS in three 9-tap slabs (18.4 KB, fetched one
+// slab ahead into registers): 76 KB, 128 registers -- two workgroups share a CU and one's taps run under the other's
+// fetch / commit / store.  Costs: six barriers per 16-channel block instead of two, halo factor 2.34 instead of 1.95.
+constexpr int S4_TZ = 4, S4_THREADS = 512, S4_NVOX = 600, S4_ROWS = (S4_TZ + 2) * 10 * SB_PX;
+constexpr int S4_ITERS = (S4_NVOX * 4 + S4_THREADS - 1) / S4_THREADS;         // 5
+constexpr int S4_SLAB = 9 * 128;                                               // fragments per slab
+constexpr int S4_WITERS = (S4_SLAB + S4_THREADS - 1) / S4_THREADS;             // 3
+constexpr size_t S4_LDS = (size_t)S4_ROWS * SB_ROW + (size_t)S4_SLAB * 16;
+static_assert(S4_LDS <= 80 * 1024, "two workgroups must fit the 160 KB of a CU");
+
+__global__ void __launch_bounds__(S4_THREADS, 4)        // second argument: waves per SIMD (HIP), i.e. two workgroups per CU -> 128 registers
+conv3d_gcr_s4_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char stile[];    // [S4_ROWS x SB_ROW input][9 x 2 KB weights]; then stats scratch
+    const Src &s = a.s;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, kg = lane >> 5;
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y; t /= a.tiles_y;
+    const int tz = t % a.tiles_z;
+    const int b = t / a.tiles_z;
+    const int x0 = tx * 8, y0 = ty * 8, z0 = tz * S4_TZ;
+    const int Cin = s.C1 + s.C2, ncq = Cin / 16;
+    const int co_blk = blockIdx.y, nco_all = a.Cout / 32;
+    const int lx = j & 3, ly = j >> 2;
+    const int wz = wave >> 1, wx = (wave & 1) * 4;
+    const int center = ((wz + 1) * 10 + (ly + 1)) * SB_PX + (lx + wx + 1);
+    bf16x8 *wlds = reinterpret_cast<bf16x8 *>(stile + (size_t)S4_ROWS * SB_ROW);
+
+    const int sc4 = (threadIdx.x & 3) * 4;
+    const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
+    int vskip[S4_ITERS], vlow[S4_ITERS], lrow[S4_ITERS];
+    unsigned inside = 0;
+#pragma unroll
+    for (int it = 0; it < S4_ITERS; ++it) {
+        const int v = (threadIdx.x >> 2) + it * (S4_THREADS / 4);
+        const int px = v % 10, r2 = v / 10, py = r2 % 10, pz = r2 / 10;
+        const int gx = x0 + px - 1, gy = y0 + py - 1, gz = z0 + pz - 1;
+        const bool in = v < S4_NVOX && gx >= 0 && gx < s.W && gy >= 0 && gy < s.H && gz >= 0 && gz < s.D;
+        vskip[it] = in ? ((b * s.D + gz) * s.H + gy) * s.W + gx : 0;
+        vlow[it] = in ? ((b * D2 + (gz >> 1)) * H2 + (gy >> 1)) * W2 + (gx >> 1) : 0;
+        lrow[it] = v < S4_NVOX ? ((pz * 10 + py) * SB_PX + px) * SB_ROW + sc4 * 2 : -1;
+        if (in) inside |= 1u << it;
+    }
+    f32x4 pre[S4_ITERS];
+    bf16x8 wpre[S4_WITERS];
+    auto fetch_in = [&](int q) {                   // next 16 input channels -> registers
+        const int ch = q * 16 + sc4;
+        const bool from_low = ch >= s.C1;
+#pragma unroll
+        for (int it = 0; it < S4_ITERS; ++it) {
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (inside >> it & 1u) {
+                const float *src = from_low ? s.low + (size_t)vlow[it] * s.C2 + (ch - s.C1) : s.skip + (size_t)vskip[it] * s.C1 + ch;
+                val = *reinterpret_cast<const f32x4 *>(src);
+            }
+            pre[it] = val;
+        }
+    };
+    auto fetch_w = [&](int q, int slab) {          // nine taps of weights of channel block q -> registers
+        const bf16x8 *wq = reinterpret_cast<const bf16x8 *>(a.wp) + (((size_t)q * 27 + slab * 9) * nco_all + co_blk) * 128;
+#pragma unroll
+        for (int it = 0; it < S4_WITERS; ++it) {
+            const int f = threadIdx.x + it * S4_THREADS;
+            if (f < S4_SLAB) wpre[it] = wq[(size_t)(f >> 7) * nco_all * 128 + (f & 127)];
+        }
+    };
+    auto commit_in = [&](int q) {                  // GroupNorm affine (zero padding AFTER the norm), split, LDS
+        const int ch = q * 16 + sc4;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (a.scale_shift) {
+            const float *ss = a.scale_shift + ((size_t)b * Cin + ch) * 2;
+            sc = f32x4{ss[0], ss[2], ss[4], ss[6]}; sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
+        }
+#pragma unroll
+        for (int it = 0; it < S4_ITERS; ++it) {
+            if (lrow[it] < 0) continue;
+            const bool in = inside >> it & 1u;
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = in ? fmaf(pre[it][e], sc[e], sh[e]) : 0.0f;
+                const __bf16 hb = (__bf16)x;
+                hi[e] = hb;
+                lo[e] = (__bf16)(x - (float)hb);
+            }
+            *reinterpret_cast<bf16x4 *>(stile + lrow[it]) = hi;
+            *reinterpret_cast<bf16x4 *>(stile + lrow[it] + 32) = lo;
+        }
+    };
+    auto commit_w = [&]() {
+#pragma unroll
+        for (int it = 0; it < S4_WITERS; ++it) {
+            const int f = threadIdx.x + it * S4_THREADS;
+            if (f < S4_SLAB) wlds[f] = wpre[it];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    struct TapOps { bf16x8 wh, wl, xh, xl; };
+    auto run_slab = [&](int slab) {                // nine taps: dz = slab - 1
+        auto tap_ops = [&](int tl) {
+            TapOps o;
+            o.wh = wlds[tl * 128 + lane]; o.wl = wlds[tl * 128 + 64 + lane];
+            const int dy = tl / 3 - 1, dx = tl % 3 - 1;
+            const char *xin = stile + (center + ((slab - 1) * 10 + dy) * SB_PX + dx) * SB_ROW + kg * 16;
+            o.xh = *reinterpret_cast<const bf16x8 *>(xin);
+            o.xl = *reinterpret_cast<const bf16x8 *>(xin + 32);
+            return o;
+        };
+        TapOps cur = tap_ops(0);
+#pragma unroll
+        for (int tl = 0; tl < 9; ++tl) {
+            TapOps nxt = cur;
+            if (tl + 1 < 9) nxt = tap_ops(tl + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.wl, cur.xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.wh, cur.xl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.wh, cur.xh, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+    };
+
+    fetch_in(0);
+    fetch_w(0, 0);
+    for (int q = 0; q < ncq; ++q) {
+        __syncthreads();                                           // the previous taps are done with the tile and the slab
+        commit_in(q);
+        commit_w();
+        __syncthreads();
+        fetch_w(q, 1);
+        if (q + 1 < ncq) fetch_in(q + 1);
+        run_slab(0);
+        __syncthreads();
+        commit_w();
+        __syncthreads();
+        fetch_w(q, 2);
+        run_slab(1);
+        __syncthreads();
+        commit_w();
+        __syncthreads();
+        if (q + 1 < ncq) fetch_w(q + 1, 0);
+        run_slab(2);
+    }
+    // epilogue: as conv3d_gcr_s_kernel
+    __syncthreads();
+    float *sred = reinterpret_cast<float *>(stile);               // [8 waves][32][2]
+    {
+        const int gx = x0 + lx + wx, gy = y0 + ly, gz = z0 + wz;
+        const bool valid = gx < s.W && gy < s.H && gz < s.D;
+        float *orow = a.out + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.Cout;
+        f32x16 v = acc;
+        if (a.relu) v = relu16(v);
+        if (valid) store_acc16(orow + co_blk * 32, v, kg);
+        if (a.part) wave_stats(v, valid, j, kg, sred + wave * 64);
+    }
+    if (a.part) {
+        __syncthreads();
+        const int nsp = a.tiles_x * a.tiles_y * a.tiles_z;
+        const int spatial = blockIdx.x % nsp;
+        if (threadIdx.x < 64) {
+            float tsum = 0.0f;
+            for (int w = 0; w < 2 * S4_TZ; ++w) tsum += sred[w * 64 + threadIdx.x];
+            a.part[(((size_t)b * nsp + spatial) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 maxpool3d_cl_kernel(const float *x, float *out, int D, int H, int W, int C, size_t total) {
     const int D2 = D / 2, H2 = H / 2, W2 = W / 2;
@@ -670,7 +844,13 @@ static bool conv_s_eligible(int B, int D, int H, int W, int Cin, int Cout) {
 
 // tile depth: 8^3 tiles when they give the chip enough workgroups, 8 x 8 x 2 tiles below that
 static int conv_s_tz(int B, int D, int H, int W, int Cout) {
-    return (size_t)(D / 8) * (H / 8) * (W / 8) * B * (Cout / 32) >= 64 ? 8 : 2;
+    // 8^3 tiles, one workgroup per CU, where they give every CU two rounds or more (the 64^3 level: 61 vs 60 us for either
+    // kernel); the two-workgroups-per-CU kernel on 8x8x4 tiles between that and 64 tiles (the 32^3 level: 192->64 97 -> 74 us);
+    // thin 8x8x2 tiles below.  VTACO_CONV_TZ=8 / 4 forces one of the first two (A/B runs).
+    static const int forced = getenv("VTACO_CONV_TZ") ? atoi(getenv("VTACO_CONV_TZ")) : 0;
+    const size_t tiles8 = (size_t)(D / 8) * (H / 8) * (W / 8) * B * (Cout / 32);
+    if (tiles8 >= 64) return (forced == 8 || forced == 4) ? forced : (tiles8 >= 512 ? 8 : 4);
+    return 2;
 }
 
 template <int NCO, int WAVES>
@@ -830,7 +1010,15 @@ int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, in
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_bf16x3: hipFuncSetAttribute");
         attr = true;
     }
-    if (tz == 8) hipLaunchKernelGGL(conv3d_gcr_s_kernel<8>, grid, dim3(sb_threads(8)), sb_lds(8), (hipStream_t)stream, a);
+    if (tz == 4) {
+        static bool attr4 = false;
+        if (!attr4) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4_LDS);
+            if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_bf16x3: hipFuncSetAttribute");
+            attr4 = true;
+        }
+        hipLaunchKernelGGL(conv3d_gcr_s4_kernel, grid, dim3(S4_THREADS), S4_LDS, (hipStream_t)stream, a);
+    } else if (tz == 8) hipLaunchKernelGGL(conv3d_gcr_s_kernel<8>, grid, dim3(sb_threads(8)), sb_lds(8), (hipStream_t)stream, a);
     else hipLaunchKernelGGL(conv3d_gcr_s_kernel<2>, grid, dim3(sb_threads(2)), sb_lds(2), (hipStream_t)stream, a);
     return vt_check(hipGetLastError(), "vt_conv3d_gcr_bf16x3");
 }
