@@ -176,3 +176,39 @@ def test_trainer_on_synthetic_dataset_end_to_end(tmp_path):
     val = next(iter(torch.utils.data.DataLoader(get_dataset("val", cfg), batch_size=2, collate_fn=data.collate_remove_none)))
     ev = trainer.eval_step(val)
     assert np.isfinite(ev["loss"]) and 0.0 <= ev["iou"] <= 1.0
+
+
+def test_forward_contact_is_differentiable_and_matches_oracle_autograd():
+    """LocalDecoder.forward_contact under autograd (decoder.py:105-133): both heads' losses back to the grid and to every
+    parameter, against autograd of the oracle on the CPU."""
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd.conv_onet.models import decoder_dict
+    a, sd = load_golden("g1_decode.npz")
+    dec = decoder_dict['simple_local'](dim=3, c_dim=32, hidden_size=32, with_contact=True)
+    dec.load_state_dict(sd, strict=True)
+    dec = dec.to(DEV).train()
+    g = torch.Generator().manual_seed(21)
+    grid = torch.from_numpy(a["grid2"])
+    p = torch.from_numpy(a["prand"])
+    occ, con = torch.rand(p.shape[:2], generator=g), torch.rand(p.shape[:2], generator=g)
+    gd = grid.to(DEV).requires_grad_(True)
+    o, oc = dec.forward_contact(p.to(DEV), {"grid": gd})
+    # the no-grad kernel path gives the same two outputs
+    with torch.no_grad():
+        k, kc = dec.forward_contact(p.to(DEV), {"grid": grid.to(DEV)})
+    assert float((o - k).abs().max()) <= 1e-5 and float((oc - kc).abs().max()) <= 1e-5
+    loss = torch.nn.functional.l1_loss(o, occ.to(DEV)) + torch.nn.functional.mse_loss(oc, con.to(DEV))
+    loss.backward()
+    leaves = {k_: v.clone().requires_grad_(True) for k_, v in sd.items()}
+    gr = grid.clone().requires_grad_(True)
+    ro, roc = orc.local_decoder_forward_contact(leaves, p, gr)
+    rl = torch.nn.functional.l1_loss(ro, occ) + torch.nn.functional.mse_loss(roc, con)
+    rl.backward()
+    assert abs(float(loss.detach()) - float(rl.detach())) <= 1e-5
+    assert float((gd.grad.cpu() - gr.grad).abs().max()) <= 1e-4 * float(gr.grad.abs().max()) + 1e-9
+    for name, prm in dec.named_parameters():
+        ref = leaves[name].grad
+        if ref is None:                                   # fc_p_img takes no part in forward_contact
+            assert prm.grad is None or not prm.grad.any(), name
+            continue
+        assert float((prm.grad.cpu() - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-8, name

@@ -188,7 +188,15 @@ class LocalDecoder(nn.Module):
         """(occupancy logits, contact logits) (decoder.py:105-133)."""
         grid = self._grid_of(c_plane)
         if self._wants_grad(grid):
-            raise VtError("forward_contact: the backward of the contact head is not built (no shipped config trains it)")
+            # training with the contact head (no shipped config does: with_contact is False in all of them): the trilinear
+            # gather and its backward are the HIP kernels (vt_sample_grid / vt_sample_grid_bwd); the 17 k-parameter MLP with
+            # its two heads differentiates as host PyTorch ops -- correct, not tuned
+            c = _SampleGridFn.apply(grid, p, self.padding)
+            net = self.fc_p(p.float())
+            for lin, blk in zip(self.fc_c, self.blocks):
+                net = blk(net + lin(c))
+            net = torch.relu(net)
+            return self.fc_out(net).squeeze(-1), self.fc_out_contact(net).squeeze(-1)
         return ops.decode_fwd(grid, self._blob(contact=True, precision=self.precision), pts=p, padding=self.padding,
                               want_contact=True, precision=self.precision)
 
