@@ -586,3 +586,61 @@ def hand_mesh_vertices(verts, mano_param, pc_ply):
     centroid = np.mean(pc_ply, axis=0)
     m = np.max(np.sqrt(np.sum((pc_ply - centroid) ** 2, axis=1)))
     return (v - centroid) / (2 * m)
+
+
+# --------------------------------------------------------------------------
+# tactile training-sample assembly of the VTacOH trainer (A13, training.py:502-626)
+# --------------------------------------------------------------------------
+
+MANO_TIP_JOINTS = [4, 8, 12, 16, 20]
+
+
+def hand_tips_world(joints, wrist_pos, wrist_euler, pc_ply):
+    """Fingertip joints in the object's normalised frame (training.py:547-556): the same frame change as
+    ``hand_mesh_vertices`` but with the GROUND-TRUTH wrist position and the dataset's wrist Euler angles.
+    numpy: joints [21,3] f32, wrist_pos [3], wrist_euler [3], pc_ply [M,3] -> float32 [5,3] (the reference stores the
+    float64 result back into a float32 array)."""
+    import numpy as np
+    t = joints[MANO_TIP_JOINTS].astype(np.float32) - np.array([0.11, 0.005, 0], dtype=np.float32)
+    t = np.linalg.inv(rot_from_pyr(np.array([-np.pi / 2, np.pi / 2, 0]))) @ t.T
+    t = np.linalg.inv(rot_from_pyr(np.array(wrist_euler))) @ t
+    t = t.T + wrist_pos
+    centroid = np.mean(pc_ply, axis=0)
+    m = np.max(np.sqrt(np.sum((pc_ply - centroid) ** 2, axis=1)))
+    return ((t - centroid) / (2 * m)).astype(np.float32)
+
+
+def trainer_img_assembly(p, occ, tips, touch_success, num_sample, rng=None):
+    """Which query points a VTacOH training step decodes and which finger's tactile feature each carries
+    (training.py:559-611).  Per scene: points within 0.05 of their nearest fingertip take that finger (if its touch
+    succeeded; at most 512 per finger, drawn with ``choice`` -- with replacement -- beyond that), listed finger by finger;
+    the remaining rows are drawn with ``randint(len(rest))`` and -- as the reference does -- used as indices into ALL
+    points, not into the rest.  ``rng``: numpy's global generator by default (the reference's), consumed in the same
+    order: every scene's ``choice`` calls first, then one ``randint`` per scene.
+    numpy in; returns (rows [B,S] int64 point index of every sample row, finger [B,S] int64, -1 = no tactile feature)."""
+    import numpy as np
+    rng = np.random if rng is None else rng
+    B, N = p.shape[:2]
+    picked = []
+    for b in range(B):
+        d = np.sqrt(((p[b].astype(np.float64)[:, None, :] - tips[b].astype(np.float64)[None, :, :]) ** 2).sum(-1))
+        idx_b, fin_b = [], []
+        for f in range(5):
+            if touch_success[b, f]:
+                idx = np.where((d.min(1) < 0.05) & (d.argmin(1) == f))[0]
+                if idx.shape[0] > 512:
+                    idx = idx[rng.choice(idx.shape[0], 512)]
+                idx_b += list(idx)
+                fin_b += [f] * len(idx)
+        picked.append((idx_b, fin_b))
+    rows = np.zeros((B, num_sample), dtype=np.int64)
+    finger = np.full((B, num_sample), -1, dtype=np.int64)
+    everything = np.arange(N)
+    for b in range(B):
+        idx_b, fin_b = picked[b]
+        k = len(idx_b)
+        rows[b, :k] = idx_b
+        finger[b, :k] = fin_b
+        rest = everything[~np.isin(everything, idx_b)]
+        rows[b, k:] = rng.randint(len(rest), size=num_sample - k)
+    return rows, finger

@@ -167,3 +167,25 @@ def test_hand_mesh_post_processing():
     assert np.allclose(r @ np.array([1.0, 0, 0]), [np.cos(0.3), np.sin(0.3), 0])
     r = orc.rot_from_pyr(np.array([0.0, 0.3, 0.0]))
     assert np.allclose(r @ np.array([0, 1.0, 0]), [0, np.cos(0.3), -np.sin(0.3)])
+
+
+def test_trainer_img_assembly_against_the_reference_trainer():
+    """g11_trainer_img.npz: what the real reference's Trainer.compute_loss_img handed to decode_img (p_sample, c_img_all),
+    its re-sampled occupancies and its fingertips, under numpy seed 123 -- the oracle draws the same samples."""
+    z = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "g11_trainer_img.npz"))
+    B = z["p"].shape[0]
+    tips = np.stack([orc.hand_tips_world(z["mano_joints"][b], z["mano"][b, :3], z["wrist"][b], z["pc_ply"][b]) for b in range(B)])
+    assert tips.dtype == np.float32 and np.array_equal(tips, z["tips"])
+    state = np.random.get_state()
+    try:
+        np.random.seed(int(z["seed"]))
+        rows, finger = orc.trainer_img_assembly(z["p"], z["occ"], tips, z["touch"], int(z["num_sample"]))
+    finally:
+        np.random.set_state(state)
+    assert np.array_equal(np.stack([z["p"][b][rows[b]] for b in range(B)]), z["p_sample"])
+    assert np.array_equal(np.stack([z["occ"][b][rows[b]] for b in range(B)]), z["occ_new"])
+    feat = np.stack([z["c_img"][b][np.maximum(finger[b], 0)] for b in range(B)]) * (finger[..., None] >= 0)
+    assert np.array_equal(feat.astype(np.float32), z["c_img_all"])
+    # the fixture exercises the 512-point cap and failed touches (scene 0 finger 2, scene 1 finger 1)
+    per_finger = [[int((finger[b] == f).sum()) for f in range(5)] for b in range(B)]
+    assert per_finger[0][0] == 512 and per_finger[0][2] == 0 and per_finger[1][1] == 0 and per_finger[1][0] == 512

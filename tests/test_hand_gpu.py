@@ -236,3 +236,96 @@ def test_trainer_with_hand_encoder_on_synthetic_dataset(tmp_path):
     assert all(np.isfinite(x) for x in first) and first[1] > 0 and first[2] > 0
     assert last[0] < 0.8 * first[0] and last[1] < first[1], (first, last)
     assert all(p.grad is not None for p in model.encoder_hand.parameters())
+
+
+def test_trainer_compute_loss_img_matches_the_reference_trainer():
+    """Trainer.compute_loss_img (VTacOH step) on stand-in encoders that return the fixture's tensors: with numpy seeded as the
+    reference run was, the three losses equal the real reference Trainer's (g11_trainer_img.npz) and decode_img receives the
+    same points and tactile features."""
+    import os
+    import types
+    from conftest import GOLDEN
+    from vtaco_amd.conv_onet.training import Trainer
+    z = np.load(os.path.join(GOLDEN, "g11_trainer_img.npz"))
+    dev = torch.device("cuda:0")
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    seen = {}
+
+    class StandIn(object):
+        encoder_hand = encoder_img = object()
+
+        def train(self):
+            return self
+
+        def encode_inputs(self, inputs):
+            return "c"
+
+        def encode_hand_inputs(self, inputs):
+            return {"mano_param": t("mano_param"), "mano_verts": t("mano_verts"), "mano_joints": t("mano_joints")}
+
+        def encode_img_inputs(self, imgs):
+            return t("c_img")
+
+        def decode_img(self, p_sample, c, c_img_all, **kw):
+            seen["p_sample"], seen["c_img_all"] = p_sample, c_img_all
+            return types.SimpleNamespace(logits=p_sample.sum(-1) * 0.5 + c_img_all.sum(-1) * 0.1)
+
+    data = {"points": t("p"), "points.occ": t("occ"), "points.mano": t("mano"), "points.pc_hand": t("pc_hand"),
+            "points.wrist": t("wrist"), "inputs": torch.zeros(2, 16, 3), "inputs.pc_ply": t("pc_ply"),
+            "inputs.img": torch.zeros(2, 5, 3, 8, 6), "inputs.touch_success": t("touch")}
+    trainer = Trainer(StandIn(), None, device=dev, num_sample=int(z["num_sample"]), with_img=True)
+    state = np.random.get_state()
+    try:
+        np.random.seed(int(z["seed"]))
+        loss, loss_mano, loss_pc = trainer.compute_loss_img(data)
+    finally:
+        np.random.set_state(state)
+    assert torch.equal(seen["p_sample"].cpu(), torch.from_numpy(z["p_sample"]))
+    assert torch.equal(seen["c_img_all"].cpu(), torch.from_numpy(z["c_img_all"]))
+    for got, ref in zip((loss, loss_mano, loss_pc), z["loss"]):
+        assert abs(float(got) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+
+
+def test_trainer_vtacoh_step_on_synthetic_dataset(tmp_path):
+    """The whole VTacOH training step on real modules: object encoder + UNet3D, hand encoder + MANO layer, tactile U-Net on the
+    five images, forward_img decoder; loss = l1 + loss_mano + loss_pc goes down on a fixed batch and every branch gets gradients."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from synth_dataset import make_cfg, make_synthetic_dataset
+    from vtaco_amd import data
+    from vtaco_amd.config import get_dataset
+    from vtaco_amd.conv_onet import config as cfgmod
+    dev = torch.device("cuda:0")
+    os.makedirs(tmp_path / "ds")
+    make_synthetic_dataset(str(tmp_path / "ds"), seed=6)
+    synth_mano.write_pkl(synth_mano.make_asset(0), str(tmp_path / "mano"))
+    cfg = make_cfg(str(tmp_path / "ds"), points_subsample=512)
+    cfg["data"]["num_sample"] = 256
+    cfg["model"] = {"decoder": "simple_local", "encoder": "pointnet_local_pool", "c_dim": 32, "with_img": True,
+                    "decoder_kwargs": {"sample_mode": "bilinear", "hidden_size": 32},
+                    "encoder_kwargs": {"hidden_dim": 32, "plane_type": "grid", "grid_resolution": 32, "unet3d": True,
+                                       "unet3d_kwargs": {"num_levels": 3, "f_maps": 32, "in_channels": 32, "out_channels": 32}},
+                    "encoder_hand": "pointnet_local_pool",
+                    "encoder_hand_kwargs": {"hidden_dim": 32, "plane_type": ["xz", "xy", "yz"], "plane_resolution": 32,
+                                            "unet": True, "unet_kwargs": {"depth": 3, "merge_mode": "concat", "start_filts": 16},
+                                            "out_mano": True, "out_dim": 51,
+                                            "manolayer_kwargs": dict(MANO_KW, mano_root=str(tmp_path / "mano"))},
+                    "encoder_img": "UNet", "encoder_img_kwargs": {"num_classes": 1, "in_channels": 3, "depth": 3, "start_filts": 8}}
+    cfg["test"] = {"threshold": 0.5}
+    torch.manual_seed(0)
+    model = cfgmod.get_model(cfg, device=dev)
+    batch = next(iter(torch.utils.data.DataLoader(get_dataset("train", cfg), batch_size=2, collate_fn=data.collate_remove_none)))
+    # the tactile U-Net maps an image to one channel per pixel: its flattened output is the finger's feature, c_dim wide
+    H, W = batch["inputs.img"].shape[-2:]
+    if H * W != 32:
+        batch["inputs.img"] = torch.nn.functional.interpolate(batch["inputs.img"].flatten(0, 1), size=(8, 4)).unflatten(0, (2, 5))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    trainer = cfgmod.get_trainer(model, opt, cfg, dev)
+    assert trainer.with_img and trainer.num_sample == 256
+    np.random.seed(0)
+    first = trainer.train_step(batch)
+    for _ in range(15):
+        last = trainer.train_step(batch)
+    assert all(np.isfinite(x) for x in first) and last[0] < first[0], (first, last)
+    for name in ("encoder", "encoder_hand", "decoder"):
+        assert all(p.grad is not None for n, p in getattr(model, name).named_parameters() if "fc_out_contact" not in n and "fc_p." not in n), name

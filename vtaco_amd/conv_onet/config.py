@@ -51,7 +51,8 @@ def get_trainer(model, optimizer, cfg, device, **kwargs):
     """reference conv_onet/config.py:146-212."""
     from .training import Trainer
     return Trainer(model, optimizer, device=device, input_type=cfg['data']['input_type'],
-                   threshold=cfg['test']['threshold'], with_img=cfg['model'].get('with_img', False),
+                   threshold=cfg['test']['threshold'], num_sample=cfg['data'].get('num_sample', 2048),
+                   with_img=cfg['model'].get('with_img', False),
                    with_contact=cfg['model'].get('with_contact', False), encode_t2d=cfg['model'].get('encoder_t2d', False))
 
 

@@ -7,7 +7,9 @@ encoder (``model.encoder_hand``) its two other terms are added as the reference 
 ``loss_mano = mse(mano_param, points.mano)`` and ``loss_pc = mse(mano_verts, points.pc_hand)``; without one
 they are reported as 0.  Forward and backward of the whole step (voxeliser, UNet3D, decoder; plane pooling
 and scatter of the hand encoder) run on the HIP kernels; the MANO layer and the 2-D U-Net differentiate
-through host PyTorch ops.  The tactile variants (``with_img`` / ``encode_t2d``) need the per-point
+through host PyTorch ops.  ``with_img=True`` selects the VTacOH step (``compute_loss_img``, training.py:502-626): fingertips from
+the MANO joints, nearest-fingertip assignment of the query points on the device (vt_tactile_assign), the reference's re-sampling
+of the query points (same numpy draws under the same seed), ``decode_img`` with the per-point tactile features.  The tactile variants (``with_img`` / ``encode_t2d``) need the per-point
 contact features the reference assembles with CPU geometry (igl / cdist, training.py:817-866): feed them
 at model level (``model.decode_img(p, c, c_img)``) or as finger ids (``vt_tactile_assign``) instead.
 """
@@ -25,11 +27,13 @@ class Trainer:
     def __init__(self, model, optimizer, device=None, input_type='pointcloud', vis_dir=None, threshold=0.5,
                  eval_sample=False, num_sample=2048, with_img=False, with_contact=False, train_tactile=False,
                  encode_t2d=False, pretrained_t2d=True, grad_sync=None):
-        if with_img or encode_t2d or with_contact or train_tactile:
-            raise VtError("Trainer: only the visual object branch is built (with_img / encode_t2d / with_contact / "
-                          "train_tactile need the reference's CPU tactile-assembly glue; use the model-level API)")
+        if encode_t2d or with_contact or train_tactile:
+            raise VtError("Trainer: the visual branch (compute_loss) and the VTacOH tactile branch (with_img: compute_loss_img) "
+                          "are built; encode_t2d / with_contact / train_tactile need the reference's depth-to-contact CPU "
+                          "geometry (igl winding numbers, camera unprojection) -- use the model-level API")
         self.model, self.optimizer, self.device = model, optimizer, device
         self.input_type, self.threshold = input_type, threshold
+        self.with_img, self.num_sample = with_img, num_sample
         # data-parallel training (one process per GPU): a callable run between backward and the optimizer step,
         # e.g. vtaco_amd.dist.GradAllReduce(model.parameters()) -- one flat-bucket RCCL all-reduce per step that
         # also covers the parameters a step leaves without gradient (fc_p_img, the contact head)
@@ -51,10 +55,98 @@ class Trainer:
         loss_pc = F.mse_loss(c_hand['mano_verts'], data.get('points.pc_hand').to(self.device).float())
         return loss + loss_mano + loss_pc, loss_mano, loss_pc
 
+    # -- VTacOH: tactile features concatenated to the points near a fingertip (training.py:502-626) -------------------
+    @staticmethod
+    def _pyr(roll, pitch, yaw):
+        """R_from_PYR (common.py:591-604): z rotation by roll after the transposed y rotation by yaw and x rotation by pitch."""
+        cr, sr, cp, sp, cy, sy = np.cos(roll), np.sin(roll), np.cos(pitch), np.sin(pitch), np.cos(yaw), np.sin(yaw)
+        about_z = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+        about_x_t = np.array([[1, 0, 0], [0, cp, sp], [0, -sp, cp]])
+        about_y_t = np.array([[cy, 0, -sy], [0, 1, 0], [sy, 0, cy]])
+        return about_x_t @ about_y_t @ about_z
+
+    def fingertips(self, mano_joints, mano_gt, wrist_euler, pc_ply):
+        """The five fingertip joints of every scene in the object's normalised frame (training.py:543-556): host-side
+        numpy on 5 x 3 numbers per scene, in the reference's operation order (float64, stored as float32)."""
+        joints = mano_joints.detach().float().cpu().numpy()[:, [4, 8, 12, 16, 20]]
+        mano_gt, wrist_euler = mano_gt.detach().cpu().numpy(), wrist_euler.detach().cpu().numpy()
+        cloud = pc_ply.detach().float().cpu().numpy()
+        fixed = np.linalg.inv(self._pyr(-np.pi / 2, np.pi / 2, 0.0))
+        tips = np.empty_like(joints)
+        for b in range(joints.shape[0]):
+            t = joints[b] - np.array([0.11, 0.005, 0], dtype=np.float32)
+            t = np.linalg.inv(self._pyr(*wrist_euler[b])) @ (fixed @ t.T)
+            t = t.T + mano_gt[b, :3]
+            centroid = np.mean(cloud[b], axis=0)
+            m = np.max(np.sqrt(np.sum((cloud[b] - centroid) ** 2, axis=1)))
+            tips[b] = (t - centroid) / (2 * m)
+        return tips
+
+    def tactile_rows(self, p, tips, touch_success):
+        """(rows [B,S], finger [B,S]) on the host: which points a step decodes and whose tactile feature each carries
+        (training.py:559-608).  The nearest-fingertip test (cdist + argmin + radius 0.05 + touch success) is vt_tactile_assign
+        on the device; what remains is index bookkeeping that consumes numpy's global generator exactly as the reference
+        does (``choice`` beyond 512 points per finger, then ``randint`` for the rest -- used, as there, as indices into all
+        points), so a seeded run draws the same samples."""
+        from .. import ops
+        B, N = p.shape[:2]
+        S = self.num_sample
+        ids = torch.stack([ops.tactile_assign(torch.from_numpy(tips[b]).to(p.device).unsqueeze(1), touch_success[b], 'nearest',
+                                              0.05, pts=p[b:b + 1])[0] for b in range(B)]).cpu().numpy()
+        picked = []
+        for b in range(B):
+            idx_b, fin_b = [], []
+            for f in range(5):
+                idx = np.where(ids[b] == f)[0]
+                if idx.shape[0] > 512:
+                    idx = idx[np.random.choice(idx.shape[0], 512)]
+                idx_b += list(idx)
+                fin_b += [f] * len(idx)
+            picked.append((idx_b, fin_b))
+        rows = np.zeros((B, S), dtype=np.int64)
+        finger = np.full((B, S), -1, dtype=np.int64)
+        everything = np.arange(N)
+        for b in range(B):
+            idx_b, fin_b = picked[b]
+            k = len(idx_b)
+            if k > S:
+                raise VtError(f"Trainer.compute_loss_img: {k} tactile points do not fit num_sample = {S}")
+            rows[b, :k], finger[b, :k] = idx_b, fin_b
+            rest = everything[~np.isin(everything, idx_b)]
+            rows[b, k:] = np.random.randint(len(rest), size=S - k)
+        return rows, finger
+
+    def compute_loss_img(self, data):
+        """(loss, loss_mano, loss_pc) of the VTacOH step: object encoder, hand encoder + MANO layer, tactile encoder on the five
+        images; the points near a fingertip whose touch succeeded take that finger's feature; LocalDecoder.forward_img."""
+        dev = self.device
+        p = data.get('points').to(dev)
+        occ = data.get('points.occ').to(dev)
+        inputs = data.get('inputs').to(dev)
+        if getattr(self.model, 'encoder_hand', None) is None or getattr(self.model, 'encoder_img', None) is None:
+            raise VtError("Trainer.compute_loss_img needs model.encoder_hand (fingertips) and model.encoder_img (tactile features)")
+        c = self.model.encode_inputs(inputs)
+        c_hand = self.model.encode_hand_inputs(inputs)
+        if 'mano_joints' not in c_hand:
+            raise VtError("Trainer.compute_loss_img: the hand encoder has no MANO layer (out_dim <= 30)")
+        c_img = self.model.encode_img_inputs(data.get('inputs.img').to(dev))                     # [B,5,C]
+        tips = self.fingertips(c_hand['mano_joints'], data.get('points.mano'), data.get('points.wrist'), data.get('inputs.pc_ply'))
+        rows, finger = self.tactile_rows(p, tips, data.get('inputs.touch_success').to(dev))
+        rows_t, finger_t = torch.from_numpy(rows).to(dev), torch.from_numpy(finger).to(dev)
+        p_sample = torch.gather(p, 1, rows_t.unsqueeze(-1).expand(-1, -1, 3))
+        occ_new = torch.gather(occ, 1, rows_t)
+        feat = torch.gather(c_img, 1, finger_t.clamp(min=0).unsqueeze(-1).expand(-1, -1, c_img.shape[2]))
+        c_img_all = feat * (finger_t >= 0).unsqueeze(-1).to(feat.dtype)
+        logits = self.model.decode_img(p_sample, c, c_img_all).logits
+        loss_l1 = F.l1_loss(logits, occ_new)
+        loss_mano = F.mse_loss(c_hand['mano_param'], data.get('points.mano').to(dev).float())
+        loss_pc = F.mse_loss(c_hand['mano_verts'], data.get('points.pc_hand').to(dev).float())
+        return loss_l1 + loss_mano + loss_pc, loss_mano, loss_pc
+
     def train_step(self, data, vf_dict=None):
         self.model.train()
         self.optimizer.zero_grad()
-        loss, loss_mano, loss_pc = self.compute_loss(data)
+        loss, loss_mano, loss_pc = self.compute_loss_img(data) if self.with_img else self.compute_loss(data)
         loss.backward()
         if self.grad_sync is not None:
             self.grad_sync()
