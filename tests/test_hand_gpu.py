@@ -329,3 +329,70 @@ def test_trainer_vtacoh_step_on_synthetic_dataset(tmp_path):
     assert all(np.isfinite(x) for x in first) and last[0] < first[0], (first, last)
     for name in ("encoder", "encoder_hand", "decoder"):
         assert all(p.grad is not None for n, p in getattr(model, name).named_parameters() if "fc_out_contact" not in n and "fc_p." not in n), name
+
+
+def test_generator_vtacoh_route_equals_dense_c_img_all(tmp_path):
+    """generate_obj_mesh_wnf with with_img=True (generation.py:161-200): the finger-id route (fingertips from the hand encoder,
+    vt_tactile_assign, decode by id) against the reference's construction -- the dense c_img_all assembled with the oracle's
+    cdist rule -- decoded by the same model: identical logits, identical mesh."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import vtaco_oracle as orc
+    from synth_dataset import make_cfg, make_synthetic_dataset
+    from vtaco_amd import data as vdata
+    from vtaco_amd.config import get_dataset
+    from vtaco_amd.conv_onet import config as cfgmod
+    dev = torch.device("cuda:0")
+    os.makedirs(tmp_path / "ds")
+    make_synthetic_dataset(str(tmp_path / "ds"), seed=7)
+    synth_mano.write_pkl(synth_mano.make_asset(0), str(tmp_path / "mano"))
+    cfg = make_cfg(str(tmp_path / "ds"), points_subsample=64)
+    cfg["model"] = {"decoder": "simple_local", "encoder": "pointnet_local_pool", "c_dim": 32, "with_img": True,
+                    "decoder_kwargs": {"sample_mode": "bilinear", "hidden_size": 32},
+                    "encoder_kwargs": {"hidden_dim": 32, "plane_type": "grid", "grid_resolution": 16, "unet3d": False},
+                    "encoder_hand": "pointnet_local_pool",
+                    "encoder_hand_kwargs": {"hidden_dim": 32, "plane_type": ["xz", "xy", "yz"], "plane_resolution": 32,
+                                            "unet": False, "out_mano": True, "out_dim": 51,
+                                            "manolayer_kwargs": dict(MANO_KW, mano_root=str(tmp_path / "mano"))},
+                    "encoder_img": "UNet", "encoder_img_kwargs": {"num_classes": 1, "in_channels": 3, "depth": 2, "start_filts": 8}}
+    cfg["test"] = {"threshold": 0.5}
+    cfg["generation"] = {"resolution_0": 8, "upsampling_steps": 0}
+    torch.manual_seed(1)
+    model = cfgmod.get_model(cfg, device=dev)
+    for blk in list(model.decoder.blocks) + list(model.encoder.blocks):
+        torch.nn.init.normal_(blk.fc_1.weight, 0, 0.1)
+    gen = cfgmod.get_generator(model, cfg, dev)
+    gen.decode_precision = "f32"
+    batch = next(iter(torch.utils.data.DataLoader(get_dataset("test", cfg), batch_size=1, collate_fn=vdata.collate_remove_none)))
+    batch["inputs.img"] = torch.nn.functional.interpolate(batch["inputs.img"].flatten(0, 1), size=(8, 4)).unflatten(0, (1, 5))
+    batch["inputs.touch_success"] = torch.tensor([[True, False, True, True, True]])
+    # put the wrist where the first fingertip lands at the lattice centre: the synthetic sample's pose is arbitrary
+    from vtaco_amd.common import fingertips_in_object_frame
+    with torch.no_grad():
+        joints = model.encode_hand_inputs(batch["inputs"].to(dev))["mano_joints"].cpu().numpy()
+    cloud = batch["inputs.pc_ply"][0].numpy()
+    m = np.max(np.sqrt(np.sum((cloud - cloud.mean(0)) ** 2, axis=1)))
+    tips0 = fingertips_in_object_frame(joints, np.zeros((1, 3)), batch["points.wrist"].numpy(), batch["inputs.pc_ply"].numpy())
+    batch["points.mano"][0, :3] = torch.from_numpy(-tips0[0, 0] * 2 * m).float()
+    mesh = gen.generate_obj_mesh_wnf(batch)
+    # the reference's construction, with the oracle's assignment rule on the CPU
+    nx = 32
+    with torch.no_grad():
+        c = model.encode_inputs(batch["inputs"].to(dev))
+        c_hand = model.encode_hand_inputs(batch["inputs"].to(dev))
+        c_img = model.encode_img_inputs(batch["inputs.img"].to(dev))
+    tips = orc.hand_tips_world(c_hand["mano_joints"][0].cpu().numpy(), batch["points.mano"][0, :3].numpy(),
+                               batch["points.wrist"][0].numpy(), batch["inputs.pc_ply"][0].numpy())
+    pts = 1.1 * orc.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)
+    ids = orc.tactile_assign_nearest(pts.numpy(), tips, batch["inputs.touch_success"][0].numpy(), radius=0.05)
+    dense = torch.zeros(1, nx ** 3, 32)
+    hit = torch.from_numpy(ids != 255)
+    dense[0, hit] = c_img[0].cpu()[torch.from_numpy(ids[ids != 255])]
+    with torch.no_grad():
+        ref_vals = model.decoder.decode_lattice(c["grid"], nx, c_img=dense.to(dev), precision="f32")
+    ref_mesh = gen.extract_mesh(ref_vals.reshape(nx, nx, nx))
+    assert torch.equal(mesh.faces, ref_mesh.faces) and torch.equal(mesh.vertices, ref_mesh.vertices)
+    assert int(hit.sum()) >= 8                                     # the ball of radius 0.05 around the centred fingertip
+    with torch.no_grad():
+        plain = model.decoder.decode_lattice(c["grid"], nx, c_img=torch.zeros_like(dense).to(dev), precision="f32")
+    assert not torch.equal(plain, ref_vals)                        # ... and its feature really changes the logits

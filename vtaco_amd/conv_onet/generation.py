@@ -193,7 +193,31 @@ class Generator3D(object):
         self.model.eval()
         nx = self.resolution0 * 4                       # generation.py:120
         inputs = data.get('inputs').to(self.device)
+        if self.with_img and c_img_all is None and not self.encode_t2d:
+            return self._generate_vtacoh(data)
         with torch.no_grad():
             c = self.model.encode_inputs(inputs)
             values = self.eval_lattice(c, nx, c_img_all=c_img_all if self.with_img else None)
         return self.extract_mesh(values.reshape(nx, nx, nx))
+
+    def _generate_vtacoh(self, data):
+        """The VTacOH branch of generate_obj_mesh_wnf (generation.py:161-200): fingertips from the hand encoder's MANO joints
+        in the object's frame (ground-truth wrist position and wrist Euler angles from the sample), every lattice point
+        within 0.05 of its nearest fingertip takes that finger's tactile feature if its touch succeeded -- by finger id
+        (vt_tactile_assign + vt_decode_fwd_ids) instead of the reference's dense [1, nx^3, C] tensor and CPU cdist."""
+        from ..common import fingertips_in_object_frame
+        if getattr(self.model, 'encoder_hand', None) is None or getattr(self.model, 'encoder_img', None) is None:
+            raise VtError("generate_obj_mesh_wnf(with_img): the model needs encoder_hand (fingertips) and encoder_img "
+                          "(tactile features), or pass c_img_all / use generate_obj_mesh_tactile")
+        inputs = data.get('inputs').to(self.device)
+        if inputs.shape[0] != 1:
+            raise VtError(f"generate_obj_mesh_wnf: one scene at a time (got a batch of {inputs.shape[0]})")
+        with torch.no_grad():
+            c_hand = self.model.encode_hand_inputs(inputs)
+            if 'mano_joints' not in c_hand:
+                raise VtError("generate_obj_mesh_wnf(with_img): the hand encoder has no MANO layer (out_dim <= 30)")
+            c_img = self.model.encode_img_inputs(data.get('inputs.img').to(self.device))          # [1,5,C]
+        tips = fingertips_in_object_frame(c_hand['mano_joints'].float().cpu().numpy(), data.get('points.mano').cpu().numpy()[:, :3],
+                                          data.get('points.wrist').cpu().numpy(), data.get('inputs.pc_ply').float().cpu().numpy())
+        anchors = torch.from_numpy(tips[0]).float().unsqueeze(1)                                   # [5,1,3]
+        return self.generate_obj_mesh_tactile(data, c_img[0], anchors, data.get('inputs.touch_success')[0], mode='nearest')

@@ -20,6 +20,7 @@ import torch
 from torch.nn import functional as F
 
 from .._lib import VtError
+from ..common import fingertips_in_object_frame
 from ..eval import compute_iou
 
 
@@ -56,31 +57,12 @@ class Trainer:
         return loss + loss_mano + loss_pc, loss_mano, loss_pc
 
     # -- VTacOH: tactile features concatenated to the points near a fingertip (training.py:502-626) -------------------
-    @staticmethod
-    def _pyr(roll, pitch, yaw):
-        """R_from_PYR (common.py:591-604): z rotation by roll after the transposed y rotation by yaw and x rotation by pitch."""
-        cr, sr, cp, sp, cy, sy = np.cos(roll), np.sin(roll), np.cos(pitch), np.sin(pitch), np.cos(yaw), np.sin(yaw)
-        about_z = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
-        about_x_t = np.array([[1, 0, 0], [0, cp, sp], [0, -sp, cp]])
-        about_y_t = np.array([[cy, 0, -sy], [0, 1, 0], [sy, 0, cy]])
-        return about_x_t @ about_y_t @ about_z
-
     def fingertips(self, mano_joints, mano_gt, wrist_euler, pc_ply):
-        """The five fingertip joints of every scene in the object's normalised frame (training.py:543-556): host-side
-        numpy on 5 x 3 numbers per scene, in the reference's operation order (float64, stored as float32)."""
-        joints = mano_joints.detach().float().cpu().numpy()[:, [4, 8, 12, 16, 20]]
-        mano_gt, wrist_euler = mano_gt.detach().cpu().numpy(), wrist_euler.detach().cpu().numpy()
-        cloud = pc_ply.detach().float().cpu().numpy()
-        fixed = np.linalg.inv(self._pyr(-np.pi / 2, np.pi / 2, 0.0))
-        tips = np.empty_like(joints)
-        for b in range(joints.shape[0]):
-            t = joints[b] - np.array([0.11, 0.005, 0], dtype=np.float32)
-            t = np.linalg.inv(self._pyr(*wrist_euler[b])) @ (fixed @ t.T)
-            t = t.T + mano_gt[b, :3]
-            centroid = np.mean(cloud[b], axis=0)
-            m = np.max(np.sqrt(np.sum((cloud[b] - centroid) ** 2, axis=1)))
-            tips[b] = (t - centroid) / (2 * m)
-        return tips
+        """The five fingertip joints of every scene in the object's normalised frame (training.py:543-556), stored as
+        float32 like the reference's ``tips_pos`` array."""
+        tips = fingertips_in_object_frame(mano_joints.detach().float().cpu().numpy(), mano_gt.detach().cpu().numpy()[:, :3],
+                                          wrist_euler.detach().cpu().numpy(), pc_ply.detach().float().cpu().numpy())
+        return tips.astype(np.float32)
 
     def tactile_rows(self, p, tips, touch_success):
         """(rows [B,S], finger [B,S]) on the host: which points a step decodes and whose tactile feature each carries
