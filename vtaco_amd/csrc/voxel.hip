@@ -4,8 +4,8 @@
 // reference src/encoder/pointnet.py:116-132 and :102-110, plus the index math of
 // src/common.py:293-309, 333-348.
 //
-// No dense [C, R^3] transient and no float atomics: one workgroup per scene sorts the
-// (voxel id, point id) pairs in LDS once per forward (the ids do not change between the
+// No dense [C, R^3] transient and no float atomics: one workgroup per scene radix-sorts the
+// points by voxel id in LDS once per forward (the ids do not change between the
 // four pooling rounds), which gives every point the contiguous range of its voxel-mates
 // in sorted order.  Reductions then run over those ranges in ascending point order, so
 // max/argmax and the mean are bit-reproducible run to run (the sum order equals the
@@ -19,7 +19,7 @@
 namespace {
 
 constexpr int SORT_THREADS = 1024;
-constexpr int MAX_T = 8192;          // points per scene the in-LDS sort covers (64 KiB of u64)
+constexpr int MAX_T = 8192;          // points per scene the in-LDS sort covers
 
 // reference src/common.py:293-309 + :333-348 in f32, truncating cast
 // (planes: src/common.py:268-291, divisor 1 + padding + 10e-6 and upper clamp 1 - 10e-6 instead)
@@ -30,52 +30,97 @@ __device__ __forceinline__ int voxel_coord(float v, float divisor, float clamp_h
     return (int)(q * (float)R);
 }
 
+// LDS image of the sort: cell ids by point, two permutation buffers, the (digit, chunk) count table
+constexpr int RADIX_BITS = 6, RADIX = 1 << RADIX_BITS;
+constexpr int MAX_CHUNKS = MAX_T / 64;                                  // a chunk = the 64 elements one wave ranks at a time
+constexpr size_t SORT_LDS = (size_t)MAX_T * 4 + 2 * (size_t)MAX_T * 2 + (size_t)RADIX * MAX_CHUNKS * 2;     // 80 KB
+
+// Stable LSD radix sort of the points by cell id, six bits per pass (three passes for 64^3 cells): the points start in
+// ascending point order, so a stable sort by cell gives (cell, point) order.  Per pass every wave ranks its 64 elements
+// among equal digits with six ballots (no atomics: the first lane of each digit class writes the class size into the
+// (digit, chunk) table), one block-wide exclusive scan of the table in (digit, chunk) order turns the sizes into
+// offsets, and the elements scatter to offset + rank.  Deterministic; 3 passes x ~3 us instead of 78 bitonic passes.
 __global__ void __launch_bounds__(SORT_THREADS)
-voxel_build_kernel(const float *pts, int T, int Tpad, int R, float divisor, float clamp_hi, int a0, int a1, int a2,
+voxel_build_kernel(const float *pts, int T, int nbits, int R, float divisor, float clamp_hi, int a0, int a1, int a2,
                    int *idx, int *order, int *seg_lo, int *seg_hi) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
-    const int b = blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+    unsigned *ids = reinterpret_cast<unsigned *>(sort_lds);                         // [MAX_T]
+    unsigned short *perm_a = reinterpret_cast<unsigned short *>(ids + MAX_T);       // [MAX_T]
+    unsigned short *perm_b = perm_a + MAX_T;                                         // [MAX_T]
+    unsigned short *table = perm_b + MAX_T;                                          // [RADIX][nchunk]
+    __shared__ unsigned wave_tot[SORT_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *p = pts + (size_t)b * T * 3;
-    for (int t = threadIdx.x; t < Tpad; t += SORT_THREADS) {
-        unsigned long long k = ~0ull;
-        if (t < T) {
-            // cell id = i(a0) + R * (i(a1) + R * i(a2)); a plane has no third axis (a2 < 0)
-            const int ix = voxel_coord(p[3 * t + a0], divisor, clamp_hi, R);
-            const int iy = voxel_coord(p[3 * t + a1], divisor, clamp_hi, R);
-            const int iz = a2 >= 0 ? voxel_coord(p[3 * t + a2], divisor, clamp_hi, R) : 0;
-            const int id = ix + R * (iy + R * iz);
-            idx[(size_t)b * T + t] = id;
-            k = ((unsigned long long)(unsigned)id << 32) | (unsigned)t;
-        }
-        keys[t] = k;
+    const int nround = (T + SORT_THREADS - 1) / SORT_THREADS, nchunk = nround * (SORT_THREADS / 64);
+    for (int t = tid; t < T; t += SORT_THREADS) {
+        // cell id = i(a0) + R * (i(a1) + R * i(a2)); a plane has no third axis (a2 < 0)
+        const int ix = voxel_coord(p[3 * t + a0], divisor, clamp_hi, R);
+        const int iy = voxel_coord(p[3 * t + a1], divisor, clamp_hi, R);
+        const int iz = a2 >= 0 ? voxel_coord(p[3 * t + a2], divisor, clamp_hi, R) : 0;
+        const int id = ix + R * (iy + R * iz);
+        idx[(size_t)b * T + t] = id;
+        ids[t] = (unsigned)id;
+        perm_a[t] = (unsigned short)t;
     }
     __syncthreads();
-    // bitonic sort of Tpad (power of two) 64-bit keys: ascending voxel id, then point id
-    for (int k = 2; k <= Tpad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int q = threadIdx.x; q < (Tpad >> 1); q += SORT_THREADS) {
-                const int i = 2 * q - (q & (j - 1)), l = i + j;    // the q-th pair (i, i^j) with i < l
-                const unsigned long long a = keys[i], c = keys[l];
-                const bool up = (i & k) == 0;
-                if ((a > c) == up) { keys[i] = c; keys[l] = a; }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int shift = 0; shift < nbits; shift += RADIX_BITS) {
+        for (int e = tid; e < RADIX * nchunk; e += SORT_THREADS) table[e] = 0;
+        __syncthreads();
+        unsigned rank[MAX_T / SORT_THREADS], dig[MAX_T / SORT_THREADS], val[MAX_T / SORT_THREADS];
+#pragma unroll
+        for (int r = 0; r < MAX_T / SORT_THREADS; ++r) {
+            if (r >= nround) break;
+            const int i = r * SORT_THREADS + tid;
+            const bool valid = i < T;
+            const unsigned v = valid ? perm_a[i] : 0u;
+            const unsigned d = valid ? (ids[v] >> shift) & (RADIX - 1) : 0u;
+            unsigned long long same = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < RADIX_BITS; ++bit) {
+                const unsigned long long ones = __ballot((d >> bit) & 1u);
+                same &= ((d >> bit) & 1u) ? ones : ~ones;
             }
-            // a wave's 64 consecutive pairs with j < 64 live in a 128-key window no other wave
-            // touches until j grows again, so those passes only need the wave's own LDS ordering
-            if (j > 64 || j == 1) __syncthreads();
-            else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+            val[r] = v; dig[r] = d;
+            rank[r] = (unsigned)__popcll(same & lt);
+            if (valid && rank[r] == 0) table[d * nchunk + r * (SORT_THREADS / 64) + wave] = (unsigned short)__popcll(same);
         }
+        __syncthreads();
+        // exclusive scan of the table (digit-major, chunk order inside a digit): RADIX * nchunk <= 8192 entries, 8 per thread
+        {
+            const int per = (RADIX * nchunk + SORT_THREADS - 1) / SORT_THREADS;
+            const int lo = tid * per, hi = min(lo + per, RADIX * nchunk);
+            unsigned sum = 0;
+            for (int e = lo; e < hi; ++e) sum += table[e];
+            unsigned incl = sum;
+            for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+            if (lane == 63) wave_tot[wave] = incl;
+            __syncthreads();
+            unsigned base = incl - sum;
+            for (int w = 0; w < wave; ++w) base += wave_tot[w];
+            for (int e = lo; e < hi; ++e) { const unsigned c = table[e]; table[e] = (unsigned short)base; base += c; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < MAX_T / SORT_THREADS; ++r) {
+            if (r >= nround) break;
+            const int i = r * SORT_THREADS + tid;
+            if (i < T) perm_b[table[dig[r] * nchunk + r * (SORT_THREADS / 64) + wave] + rank[r]] = (unsigned short)val[r];
+        }
+        __syncthreads();
+        unsigned short *sw = perm_a; perm_a = perm_b; perm_b = sw;
     }
-    // segment bounds: every point learns [lo,hi) of its voxel in sorted order
-    for (int j = threadIdx.x; j < T; j += SORT_THREADS) {
-        const unsigned id = (unsigned)(keys[j] >> 32);
-        const int t = (int)(unsigned)keys[j];
+    // segment bounds: every point learns [lo,hi) of its cell in sorted order
+    for (int j = tid; j < T; j += SORT_THREADS) {
+        const int t = perm_a[j];
+        const unsigned id = ids[t];
         order[(size_t)b * T + j] = t;
-        const bool first = (j == 0) || ((unsigned)(keys[j - 1] >> 32) != id);
+        const bool first = (j == 0) || (ids[perm_a[j - 1]] != id);
         if (first) {
             int e = j + 1;
-            while (e < T && (unsigned)(keys[e] >> 32) == id) ++e;
+            while (e < T && ids[perm_a[e]] == id) ++e;
             for (int q = j; q < e; ++q) {
-                const int tq = (int)(unsigned)keys[q];
+                const int tq = perm_a[q];
                 seg_lo[(size_t)b * T + tq] = j;
                 seg_hi[(size_t)b * T + tq] = e;
             }
@@ -186,18 +231,19 @@ int build_launch(const char *who, const float *pts, int B, int T, int R, float d
     if (!pts || !idx || !order || !seg_lo || !seg_hi) return fail(VT_ERR_INVALID, "null argument");
     if (B <= 0 || T <= 0 || R < 1 || R > 1024) return fail(VT_ERR_INVALID, "bad size");
     if (T > MAX_T) return fail(VT_ERR_UNSUPPORTED, "more than 8192 points per scene");
-    int Tpad = 2;
-    while (Tpad < T) Tpad <<= 1;
-    const size_t lds = (size_t)Tpad * sizeof(unsigned long long);
+    // bits of the largest cell id
+    unsigned long long cells = (unsigned long long)R * R * (a2 >= 0 ? (unsigned long long)R : 1ull);
+    int nbits = 1;
+    while (nbits < 32 && (1ull << nbits) < cells) ++nbits;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_build_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MAX_T * sizeof(unsigned long long)));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT_LDS);
         if (e != hipSuccess) return vt_check(e, "vt_voxel_build: hipFuncSetAttribute");
         attr_set = true;
     }
-    hipLaunchKernelGGL(voxel_build_kernel, dim3(B), dim3(SORT_THREADS), lds, (hipStream_t)stream,
-                       pts, T, Tpad, R, divisor, clamp_hi, a0, a1, a2, idx, order, seg_lo, seg_hi);
+    hipLaunchKernelGGL(voxel_build_kernel, dim3(B), dim3(SORT_THREADS), SORT_LDS, (hipStream_t)stream,
+                       pts, T, nbits, R, divisor, clamp_hi, a0, a1, a2, idx, order, seg_lo, seg_hi);
     return vt_check(hipGetLastError(), who);
 }
 
