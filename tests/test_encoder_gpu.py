@@ -210,3 +210,25 @@ def test_fused_point_features_equal_the_module_path():
         module = enc.point_features(p, vi).detach()
     assert float((fused - module).abs().max()) <= 1e-5
     assert float((fused.cpu() - torch.from_numpy(a["fc_c"])).abs().max()) <= 1e-5      # the reference's own output
+
+
+@pytest.mark.parametrize("B,Tn,R", [(1, 8192, 1024), (2, 8191, 512), (3, 1, 2), (1, 65, 1), (2, 4097, 100)])
+def test_voxel_sort_extremes(B, Tn, R):
+    """vt_voxel_build at the limits of its radix sort: the maximum point count, 30-bit cell ids (five passes), a single
+    point, a single cell, a non-power-of-two resolution: ids bit-exact, order = stable sort by cell, segments consistent."""
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + Tn + R)
+    p = (torch.rand(B, Tn, 3, generator=g) - 0.5) * 1.2
+    p[:, : Tn // 3] = p[:, Tn // 3: 2 * (Tn // 3)]                       # many points share a cell
+    vi = ops.VoxelIndex(p.to(DEV), R, 0.1)
+    idx = orc.voxel_index(p, R, 0.1)
+    assert torch.equal(vi.idx.cpu().long(), idx)
+    order, lo, hi = vi.order.cpu().long(), vi.seg_lo.cpu().long(), vi.seg_hi.cpu().long()
+    for b in range(B):
+        ref = torch.sort(idx[b], stable=True).indices                     # (cell, point) order
+        assert torch.equal(order[b], ref)
+        sorted_ids = idx[b][ref]
+        first = torch.searchsorted(sorted_ids, idx[b], right=False)
+        last = torch.searchsorted(sorted_ids, idx[b], right=True)
+        assert torch.equal(lo[b], first) and torch.equal(hi[b], last)
