@@ -33,8 +33,8 @@ constexpr double MC_EPS = 2.220446049250313e-16;   // skimage's "FLT_EPSILON" = 
 constexpr int CELLS_PER_BLOCK = 256;
 
 struct McHeader {
-    unsigned min_key;      // ordered key of the minimum (atomicMin)
-    unsigned max_key_inv;  // ~ordered key of the maximum (atomicMin)
+    unsigned unused0;      // (formerly the atomic min / max keys)
+    unsigned unused1;
     int nverts;
     int nfaces;
     double level;
@@ -58,16 +58,10 @@ struct McWs {
     uint2 *boff;           // per block exclusive offsets
 };
 
-__device__ __forceinline__ unsigned ordered_key(float f) {
-    unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key_to_float(unsigned k) {
-    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-    return __uint_as_float(u);
-}
-
-__global__ void __launch_bounds__(1024) mc_minmax_kernel(const float *vol, size_t n, McHeader *hdr) {
+// per-workgroup (min, max) of the volume into part[blockIdx.x] (at most MC_MM_BLOCKS of them: the classify kernel
+// reduces them again in every wave -- 512 bytes from L2 -- which needs neither atomics nor a pre-initialised header)
+constexpr int MC_MM_BLOCKS = 64;
+__global__ void __launch_bounds__(1024) mc_minmax_kernel(const float *vol, size_t n, float2 *part) {
     __shared__ float slo[16], shi[16];
     float lo = INFINITY, hi = -INFINITY;
     const size_t n4 = ((reinterpret_cast<uintptr_t>(vol) & 15) == 0) ? n / 4 : 0;   // 16-B loads need alignment
@@ -98,18 +92,24 @@ __global__ void __launch_bounds__(1024) mc_minmax_kernel(const float *vol, size_
     }
     if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
     __syncthreads();
-    if (threadIdx.x == 0) {                                   // ONE atomic pair per block, and few, large blocks:
-        lo = slo[0]; hi = shi[0];                              // same-address atomics serialise (~11 ns each)
+    if (threadIdx.x == 0) {
+        lo = slo[0]; hi = shi[0];
         for (int i = 1; i < (int)(blockDim.x >> 6); ++i) { lo = fminf(lo, slo[i]); hi = fmaxf(hi, shi[i]); }
-        atomicMin(&hdr->min_key, ordered_key(lo));
-        atomicMin(&hdr->max_key_inv, ~ordered_key(hi));
+        part[blockIdx.x] = make_float2(lo, hi);
     }
 }
 
-__device__ __forceinline__ double iso_level(const McHeader *hdr, double level, int auto_level) {
+// skimage's default level 0.5 * (volume.min() + volume.max()), the sum rounded in float32; `part`: the npart partial
+// (min, max) pairs of mc_minmax_kernel (npart <= 64: one per lane)
+__device__ __forceinline__ double iso_level(const float2 *part, int npart, double level, int auto_level) {
     if (!auto_level) return level;
-    // skimage: 0.5 * (volume.min() + volume.max()), the sum rounded in float32
-    const float lo = key_to_float(hdr->min_key), hi = key_to_float(~hdr->max_key_inv);
+    const int lane = threadIdx.x & 63;
+    float lo = INFINITY, hi = -INFINITY;
+    if (lane < npart) { const float2 p = part[lane]; lo = p.x; hi = p.y; }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
     return 0.5 * (double)(lo + hi);
 }
 
@@ -352,14 +352,15 @@ __device__ __forceinline__ unsigned block_compact(bool flag, unsigned payload, u
 constexpr int CLS_CHUNKS = 4;
 
 __global__ void __launch_bounds__(CELLS_PER_BLOCK)
-mc_classify_kernel(const float *vol, McDims d, McWs ws, double level_in, int auto_level, unsigned nblk) {
+mc_classify_kernel(const float *vol, McDims d, McWs ws, double level_in, int auto_level, unsigned nblk, int npart) {
     __shared__ unsigned list[CLS_CHUNKS * CELLS_PER_BLOCK];
     __shared__ unsigned wave_cnt[CLS_CHUNKS * 4];
     __shared__ unsigned tot[CLS_CHUNKS][2];
     __shared__ int base_xyz[CLS_CHUNKS][3];
     const unsigned chunk0 = blockIdx.x * CLS_CHUNKS;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const double level = iso_level(ws.hdr, level_in, auto_level);
+    // the min/max partials sit in the (not yet written) block-offset table: the scan kernel fills it after this kernel
+    const double level = iso_level(reinterpret_cast<const float2 *>(ws.boff), npart, level_in, auto_level);
     if (threadIdx.x < 2 * CLS_CHUNKS) tot[threadIdx.x >> 1][threadIdx.x & 1] = 0;
     const float inv_c2 = 1.0f / (float)d.c2;
     const float thr = level_threshold(level);
@@ -726,17 +727,17 @@ int vt_mc_count(const float *vol, int n0, int n1, int n2, double level, int auto
     if (workspace_bytes < total) return vt_fail(VT_ERR_WORKSPACE, "vt_mc_count: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     McWs ws = mc_ws(workspace, off);
-    int frc = vt_fill32(ws.hdr, 0xFFFFFFFFu, 8, s);
-    if (frc) return frc;
+    unsigned g = 0;
     if (auto_level) {
         const size_t n = (size_t)n0 * n1 * n2;
-        unsigned g = (unsigned)((n / 4 + 1024 * 8 - 1) / (1024 * 8));
-        if (g > 64) g = 64;
+        g = (unsigned)((n / 4 + 1024 * 8 - 1) / (1024 * 8));
+        if (g > MC_MM_BLOCKS) g = MC_MM_BLOCKS;
+        if (g > nblk) g = nblk;                                    // the partials borrow the block-offset table
         if (g < 1) g = 1;
-        hipLaunchKernelGGL(mc_minmax_kernel, dim3(g), dim3(1024), 0, s, vol, n, ws.hdr);
+        hipLaunchKernelGGL(mc_minmax_kernel, dim3(g), dim3(1024), 0, s, vol, n, reinterpret_cast<float2 *>(ws.boff));
     }
     hipLaunchKernelGGL(mc_classify_kernel, dim3((nblk + CLS_CHUNKS - 1) / CLS_CHUNKS), dim3(CELLS_PER_BLOCK), 0, s,
-                       vol, d, ws, level, auto_level, nblk);
+                       vol, d, ws, level, auto_level, nblk, (int)g);
     hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, s, ws, nblk);
     return vt_check(hipGetLastError(), "vt_mc_count");
 }
