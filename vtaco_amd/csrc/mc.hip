@@ -59,10 +59,10 @@ struct McWs {
 };
 
 // per-workgroup (min, max) of the volume into part[blockIdx.x] (at most MC_MM_BLOCKS of them: the classify kernel
-// reduces them again in every wave -- 512 bytes from L2 -- which needs neither atomics nor a pre-initialised header)
-constexpr int MC_MM_BLOCKS = 64;
-__global__ void __launch_bounds__(1024) mc_minmax_kernel(const float *vol, size_t n, float2 *part) {
-    __shared__ float slo[16], shi[16];
+// reduces them again in every wave -- 2 KB from L2 -- which needs neither atomics nor a pre-initialised header)
+constexpr int MC_MM_BLOCKS = 256;
+__global__ void __launch_bounds__(256) mc_minmax_kernel(const float *vol, size_t n, float2 *part) {
+    __shared__ float slo[4], shi[4];
     float lo = INFINITY, hi = -INFINITY;
     const size_t n4 = ((reinterpret_cast<uintptr_t>(vol) & 15) == 0) ? n / 4 : 0;   // 16-B loads need alignment
     const float4 *v4 = reinterpret_cast<const float4 *>(vol);
@@ -100,12 +100,12 @@ __global__ void __launch_bounds__(1024) mc_minmax_kernel(const float *vol, size_
 }
 
 // skimage's default level 0.5 * (volume.min() + volume.max()), the sum rounded in float32; `part`: the npart partial
-// (min, max) pairs of mc_minmax_kernel (npart <= 64: one per lane)
+// (min, max) pairs of mc_minmax_kernel (npart <= 256: four per lane)
 __device__ __forceinline__ double iso_level(const float2 *part, int npart, double level, int auto_level) {
     if (!auto_level) return level;
     const int lane = threadIdx.x & 63;
     float lo = INFINITY, hi = -INFINITY;
-    if (lane < npart) { const float2 p = part[lane]; lo = p.x; hi = p.y; }
+    for (int i = lane; i < npart; i += 64) { const float2 p = part[i]; lo = fminf(lo, p.x); hi = fmaxf(hi, p.y); }
     for (int o = 32; o > 0; o >>= 1) {
         lo = fminf(lo, __shfl_xor(lo, o));
         hi = fmaxf(hi, __shfl_xor(hi, o));
@@ -730,11 +730,11 @@ int vt_mc_count(const float *vol, int n0, int n1, int n2, double level, int auto
     unsigned g = 0;
     if (auto_level) {
         const size_t n = (size_t)n0 * n1 * n2;
-        g = (unsigned)((n / 4 + 1024 * 8 - 1) / (1024 * 8));
+        g = (unsigned)((n / 4 + 256 * 8 - 1) / (256 * 8));
         if (g > MC_MM_BLOCKS) g = MC_MM_BLOCKS;
         if (g > nblk) g = nblk;                                    // the partials borrow the block-offset table
         if (g < 1) g = 1;
-        hipLaunchKernelGGL(mc_minmax_kernel, dim3(g), dim3(1024), 0, s, vol, n, reinterpret_cast<float2 *>(ws.boff));
+        hipLaunchKernelGGL(mc_minmax_kernel, dim3(g), dim3(256), 0, s, vol, n, reinterpret_cast<float2 *>(ws.boff));
     }
     hipLaunchKernelGGL(mc_classify_kernel, dim3((nblk + CLS_CHUNKS - 1) / CLS_CHUNKS), dim3(CELLS_PER_BLOCK), 0, s,
                        vol, d, ws, level, auto_level, nblk, (int)g);
