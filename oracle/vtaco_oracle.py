@@ -644,3 +644,63 @@ def trainer_img_assembly(p, occ, tips, touch_success, num_sample, rng=None):
         rest = everything[~np.isin(everything, idx_b)]
         rows[b, k:] = rng.randint(len(rest), size=num_sample - k)
     return rows, finger
+
+
+# --------------------------------------------------------------------------
+# VTacO (t2d) contact clouds from the tactile depth images (generation.py:202-257, training.py:817-853)
+# --------------------------------------------------------------------------
+
+T2D_W, T2D_H, T2D_NEAR, T2D_FAR, T2D_FOV = 240, 320, 0.019, 0.022, 60        # generation.py:18-19, 148-151
+
+
+def depth_to_camera_cloud(depth):
+    """``RFUniverseCamera.depth_2_camera_pointcloud`` (src/common.py:553-588), the unfiltered cloud: pinhole unprojection with
+    f = H / (2 tan(fov/2)) and the principal point at (W/2, H/2), axes reordered to (z, -x, -y).  depth [H,W] -> [H*W,3] f64."""
+    import numpy as np
+    f = T2D_H / (2 * math.tan(math.radians(T2D_FOV / 2)))
+    xmap, ymap = np.meshgrid(np.arange(T2D_W), np.arange(T2D_H))
+    z = depth
+    x = (xmap - T2D_W / 2) * z / f
+    y = (ymap - T2D_H / 2) * z / f
+    return np.stack([z, -x, -y], axis=-1).reshape(-1, 3)
+
+
+def cam_to_world(pc, rot, trans):
+    """``pc_cam_to_world`` (src/common.py:614-640): the three factor matrices as the reference writes them (its ``rot_z`` is not
+    a rotation matrix), composed rot_z @ rot_x @ rot_y, the 3x3 block of the INVERSE of [R | t; 0 1] applied, then + t."""
+    import numpy as np
+    dx, dy, dz = rot
+    rx = np.array([[np.cos(dx), 0, np.sin(dx)], [0, 1, 0], [-np.sin(dx), 0, np.cos(dx)]])
+    ry = np.array([[np.cos(dy), -np.sin(dy), 0], [np.sin(dy), np.cos(dy), 0], [0, 0, 1]])
+    rz = np.array([[0, 0, 1], [np.cos(dz), np.sin(dz), 0], [-np.sin(dz), np.cos(dz), 0]])
+    ext = np.zeros((4, 4))
+    ext[:3, :3] = rz @ rx @ ry
+    ext[:3, 3] = trans
+    ext[3, 3] = 1
+    r_inv = np.linalg.inv(ext)[:3, :3]
+    return (r_inv @ pc.T).T + np.asarray(trans)
+
+
+def t2d_contact_clouds(depths, depth_origin, cam_pos, cam_rot, pc_ply, touch_success, rng=None):
+    """Per finger of ONE scene: the contact point cloud in the object's normalised frame (generation.py:224-244).  Pixels whose
+    depth differs from the flat reading ``depth_origin`` by more than 1e-4 are unprojected, at most 128 kept (``randint`` draws,
+    with replacement, from numpy's global generator unless ``rng`` is given), moved to the world with the sample's camera pose
+    (rotation + [-pi/2, 0, pi/2]) and normalised like the object cloud.  depths [5,H*W] f32 -> list of 5 arrays [k,3] f64 (k = 0 for
+    failed touches)."""
+    import numpy as np
+    rng = np.random if rng is None else rng
+    centroid = np.mean(pc_ply, axis=0)
+    m = np.max(np.sqrt(np.sum((pc_ply - centroid) ** 2, axis=1)))
+    clouds = []
+    for t in range(5):
+        if not touch_success[t]:
+            clouds.append(np.zeros((0, 3)))
+            continue
+        depth = depths[t].reshape(T2D_H, T2D_W)
+        idx = np.where(np.abs(depth.reshape(-1) - depth_origin) > 0.0001)[0]
+        pc = depth_to_camera_cloud(depth)[idx]
+        if pc.shape[0] > 128:
+            pc = pc[rng.randint(pc.shape[0], size=128)]
+        world = cam_to_world(pc, np.asarray(cam_rot[t]) + np.array([-np.pi / 2, 0, np.pi / 2]), cam_pos[t])
+        clouds.append((world - centroid) / (2 * m))
+    return clouds

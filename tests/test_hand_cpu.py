@@ -189,3 +189,42 @@ def test_trainer_img_assembly_against_the_reference_trainer():
     # the fixture exercises the 512-point cap and failed touches (scene 0 finger 2, scene 1 finger 1)
     per_finger = [[int((finger[b] == f).sum()) for f in range(5)] for b in range(B)]
     assert per_finger[0][0] == 512 and per_finger[0][2] == 0 and per_finger[1][1] == 0 and 0 < per_finger[1][0] <= 512
+
+
+def _lattice_ids_within(clouds, nx, radius=0.015):
+    """The reference's rule on the nx^3 lattice (later fingers overwrite), evaluated only near each cloud."""
+    pts = (1.1 * orc.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)).numpy()
+    ids = np.full(len(pts), 255, dtype=np.uint8)
+    for f, c in enumerate(clouds):
+        if len(c) == 0:
+            continue
+        sel = np.where(((pts >= c.min(0) - 0.02) & (pts <= c.max(0) + 0.02)).all(1))[0]
+        d = np.sqrt(((c[:, None, :] - pts[sel][None, :, :].astype(np.float64)) ** 2).sum(-1))
+        ids[sel[(d < radius).any(0)]] = f
+    return ids
+
+
+def test_t2d_contact_clouds_against_the_reference_generator():
+    """g12_t2d.npz: which of the 128^3 lattice points the real reference generator (VTacO branch, generation.py:202-257) gave
+    which finger's feature, under numpy seed 321.  The oracle's contact clouds reproduce it point for point, and the product's
+    host-side helper (vtaco_amd.common.contact_clouds_from_depth, plain numpy) builds the same clouds."""
+    import os
+    from conftest import GOLDEN
+    from vtaco_amd.common import contact_clouds_from_depth
+    z = np.load(os.path.join(GOLDEN, "g12_t2d.npz"))
+    state = np.random.get_state()
+    try:
+        np.random.seed(int(z["seed"]))
+        clouds = orc.t2d_contact_clouds(z["depths"], z["depth_origin"], z["cam_pos"][0], z["cam_rot"][0], z["pc_ply"][0], z["touch"][0])
+        np.random.seed(int(z["seed"]))
+        anchors, count = contact_clouds_from_depth(z["depths"], z["depth_origin"], z["cam_pos"][0], z["cam_rot"][0], z["pc_ply"][0],
+                                                   z["touch"][0])
+    finally:
+        np.random.set_state(state)
+    assert [len(c) for c in clouds] == [128, 128, 128, 0, 128] and count.tolist() == [128, 128, 128, 0, 128]
+    for f in range(5):
+        assert np.abs(anchors[f, :count[f]] - clouds[f]).max(initial=0.0) <= 1e-12
+    ids = _lattice_ids_within(clouds, int(z["nx"]))
+    assert np.array_equal(ids, z["ids"]) and int((ids != 255).sum()) > 80
+    with pytest.raises(ValueError, match="sensor image"):
+        contact_clouds_from_depth(z["depths"][:, :100], z["depth_origin"], z["cam_pos"][0], z["cam_rot"][0], z["pc_ply"][0], z["touch"][0])

@@ -102,3 +102,55 @@ def test_generator_tactile_mesh_equals_dense_c_img_all_path():
     assert int(hit.sum()) > 20
     ref = gen.generate_obj_mesh_wnf({"inputs": p}, c_img_all=dense.to(DEV))
     assert torch.equal(mesh.faces, ref.faces) and torch.equal(mesh.vertices, ref.vertices)
+
+
+def test_vtaco_t2d_route_matches_the_reference_generator():
+    """Generator3D's VTacO branch (generation.py:202-257) against the real reference generator's assignment (g12_t2d.npz):
+    contact clouds from the depth images -> vt_tactile_assign('within') on the 128^3 lattice gives the same finger per lattice
+    point, and generate_obj_mesh_wnf(with_img, encode_t2d) runs the chain end to end (at another lattice size, which the
+    reference cannot)."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from vtaco_amd import ops
+    from vtaco_amd.common import contact_clouds_from_depth
+    from vtaco_amd.conv_onet.generation import Generator3D
+    from vtaco_amd.conv_onet.models import ConvolutionalOccupancyNetwork, decoder_dict
+    from vtaco_amd.encoder import encoder_dict
+    from vtaco_amd._lib import VtError
+    z = np.load(os.path.join(GOLDEN, "g12_t2d.npz"))
+    dev = torch.device("cuda:0")
+    state = np.random.get_state()
+    try:
+        np.random.seed(int(z["seed"]))
+        anchors, count = contact_clouds_from_depth(z["depths"], z["depth_origin"], z["cam_pos"][0], z["cam_rot"][0], z["pc_ply"][0],
+                                                   z["touch"][0])
+    finally:
+        np.random.set_state(state)
+    nx = int(z["nx"])
+    ids = ops.tactile_assign(torch.from_numpy(anchors).float().to(dev), torch.from_numpy((count > 0).astype(np.uint8)).to(dev), "within",
+                             0.015, lattice=(nx, 1.1, 0, nx ** 3), count=torch.from_numpy(count).int().to(dev))
+    assert torch.equal(ids[0].cpu(), torch.from_numpy(z["ids"]))
+    # end to end on a small model
+    torch.manual_seed(3)
+    dec = decoder_dict["simple_local"](dim=3, c_dim=32, hidden_size=32)
+    enc = encoder_dict["pointnet_local_pool"](c_dim=32, dim=3, hidden_dim=32, grid_resolution=16, plane_type="grid", unet3d=False)
+    for blk in list(dec.blocks) + list(enc.blocks):
+        torch.nn.init.normal_(blk.fc_1.weight, 0, 0.1)
+    img = encoder_dict["UNet"](num_classes=1, in_channels=3, depth=2, start_filts=8)
+    model = ConvolutionalOccupancyNetwork(dec, enc, None, img, None, device=dev)
+    g = torch.Generator().manual_seed(4)
+    d = torch.randn(1, 3000, 3, generator=g)
+    data = {"inputs": 0.3 * d / d.norm(dim=-1, keepdim=True), "inputs.img": torch.rand(1, 5, 3, 8, 4, generator=g),
+            "inputs.depth": torch.from_numpy(z["depths"])[None], "inputs.touch_success": torch.from_numpy(z["touch"]),
+            "inputs.pc_ply": torch.from_numpy(z["pc_ply"]), "points.cam_pos": torch.from_numpy(z["cam_pos"]),
+            "points.cam_rot": torch.from_numpy(z["cam_rot"])}
+    gen = Generator3D(model, device=dev, resolution0=16, padding=0.1, with_img=True, encode_t2d=True, decode_precision="f32",
+                      depth_origin=z["depth_origin"])
+    mesh = gen.generate_obj_mesh_wnf(data)
+    assert mesh.vertices.shape[0] > 0 and mesh.faces.shape[1] == 3
+    plain = Generator3D(model, device=dev, resolution0=16, padding=0.1, decode_precision="f32").generate_obj_mesh_wnf(data)
+    assert plain.vertices.shape != mesh.vertices.shape or not torch.equal(plain.vertices, mesh.vertices)   # the touch changed the surface
+    with pytest.raises(VtError, match="depth_origin"):
+        Generator3D(model, device=dev, resolution0=16, with_img=True, encode_t2d=True,
+                    depth_origin="/nonexistent/depth_origin.txt").generate_obj_mesh_wnf(data)

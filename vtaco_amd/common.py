@@ -59,3 +59,51 @@ def fingertips_in_object_frame(mano_joints, wrist_pos, wrist_euler, pc_ply):
         m = np.max(np.sqrt(np.sum((cloud - centroid) ** 2, axis=1)))
         tips[b] = (t - centroid) / (2 * m)
     return tips
+
+
+def contact_clouds_from_depth(depths, depth_origin, cam_pos, cam_rot, pc_ply, touch_success, width=240, height=320, fov=60.0,
+                              max_points=128, threshold=1e-4):
+    """Contact point clouds of one scene's five tactile sensors in the object's normalised frame -- the VTacO (t2d) rule
+    (generation.py:224-244, training.py:817-853): pixels whose depth departs from the sensor's flat reading ``depth_origin``
+    by more than ``threshold`` are unprojected through the pinhole model (f = height / (2 tan(fov/2)), principal point at the
+    image centre, axes (z, -x, -y)), at most ``max_points`` of them are kept (``np.random.randint`` draws, with replacement,
+    from numpy's GLOBAL generator, as the reference: a seeded run picks the same pixels), moved to the world with the sample's
+    camera pose and normalised like the object cloud (norm_pc_1).  Host-side numpy on 5 x 76 800 pixels, float64 like the
+    reference.  depths [5, H*W]; cam_pos, cam_rot [5,3]; returns (anchors [5,max_points,3] float64, count [5] int)."""
+    import math
+    import numpy as np
+    depths = np.asarray(depths, dtype=np.float32)
+    origin = np.asarray(depth_origin, dtype=np.float64).reshape(-1)
+    if depths.shape != (5, width * height) or origin.shape[0] != width * height:
+        raise ValueError(f"contact_clouds_from_depth: depths {depths.shape} / depth_origin {origin.shape} do not match a "
+                         f"{height}x{width} sensor image")
+    cloud = np.asarray(pc_ply, dtype=np.float32)
+    centroid = np.mean(cloud, axis=0)
+    scale = 2 * np.max(np.sqrt(np.sum((cloud - centroid) ** 2, axis=1)))
+    f = height / (2 * math.tan(math.radians(fov / 2)))
+    px, py = np.meshgrid(np.arange(width), np.arange(height))
+    anchors = np.zeros((5, max_points, 3))
+    count = np.zeros(5, dtype=np.int64)
+    for t in range(5):
+        if not bool(touch_success[t]):
+            continue
+        z = depths[t].reshape(height, width)
+        touched = np.where(np.abs(z.reshape(-1) - origin) > threshold)[0]
+        cam = np.stack([z, -(px - width / 2) * z / f, -(py - height / 2) * z / f], axis=-1).reshape(-1, 3)[touched]
+        if cam.shape[0] > max_points:
+            cam = cam[np.random.randint(cam.shape[0], size=max_points)]
+        # camera -> world (pc_cam_to_world, common.py:614-640, with the sample rotation + [-pi/2, 0, pi/2]): the reference composes
+        # three hand-written factor matrices (the last is not a rotation) and applies the linear part of the INVERSE pose, plus t
+        ax, ay, az = np.asarray(cam_rot[t], dtype=np.float64) + np.array([-np.pi / 2, 0.0, np.pi / 2])
+        m_x = np.array([[np.cos(ax), 0, np.sin(ax)], [0, 1, 0], [-np.sin(ax), 0, np.cos(ax)]])
+        m_y = np.array([[np.cos(ay), -np.sin(ay), 0], [np.sin(ay), np.cos(ay), 0], [0, 0, 1]])
+        m_z = np.array([[0, 0, 1], [np.cos(az), np.sin(az), 0], [-np.sin(az), np.cos(az), 0]])
+        pose = np.zeros((4, 4))
+        pose[:3, :3] = m_z @ m_x @ m_y
+        pose[:3, 3] = np.asarray(cam_pos[t], dtype=np.float64)
+        pose[3, 3] = 1
+        world = (np.linalg.inv(pose)[:3, :3] @ cam.T).T + pose[:3, 3]
+        k = world.shape[0]
+        anchors[t, :k] = (world - centroid) / scale
+        count[t] = k
+    return anchors, count

@@ -28,7 +28,7 @@ class Generator3D(object):
     def __init__(self, model, points_batch_size=100000, threshold=0.5, refinement_step=0, device=None,
                  resolution0=16, upsampling_steps=3, with_normals=False, padding=0.1, sample=False,
                  input_type=None, vol_info=None, vol_bound=None, simplify_nfaces=None, alpha=0.2,
-                 with_img=False, encode_t2d=False, decode_precision="bf16x3"):
+                 with_img=False, encode_t2d=False, decode_precision="bf16x3", depth_origin=None):
         self.model = model.to(device)
         # arithmetic of the dense lattice decode (eval_lattice): "bf16x3" = split-bf16 MFMA, inside the
         # 1e-4 parity bar and ~3x the exact-f32 rate; "f32" = exact-f32 MFMA.  eval_points follows the
@@ -41,6 +41,9 @@ class Generator3D(object):
         self.with_normals, self.input_type, self.padding, self.sample = with_normals, input_type, padding, sample
         self.simplify_nfaces, self.alpha = simplify_nfaces, alpha
         self.with_img, self.encode_t2d = with_img, encode_t2d
+        # the tactile sensor's flat depth reading [240*320] (the VTacO branch compares every depth image with it): an array, a
+        # path, or None = the reference's ./data/VTacO_mesh/depth_origin.txt (generation.py:17), read when first needed
+        self.depth_origin = depth_origin
         self.vol_bound = vol_bound
         if input_type == 'pointcloud_crop':
             raise VtError("Generator3D: crop / sliding-window mode is not built (no shipped config uses it)")
@@ -193,12 +196,48 @@ class Generator3D(object):
         self.model.eval()
         nx = self.resolution0 * 4                       # generation.py:120
         inputs = data.get('inputs').to(self.device)
-        if self.with_img and c_img_all is None and not self.encode_t2d:
-            return self._generate_vtacoh(data)
+        if self.with_img and c_img_all is None:
+            return self._generate_vtaco_t2d(data) if self.encode_t2d else self._generate_vtacoh(data)
         with torch.no_grad():
             c = self.model.encode_inputs(inputs)
             values = self.eval_lattice(c, nx, c_img_all=c_img_all if self.with_img else None)
         return self.extract_mesh(values.reshape(nx, nx, nx))
+
+    def _depth_origin(self):
+        import numpy as np
+        src = self.depth_origin
+        if src is None:
+            src = "./data/VTacO_mesh/depth_origin.txt"
+        if isinstance(src, str):
+            import os
+            if not os.path.exists(src):
+                raise VtError(f"Generator3D: the VTacO branch needs the sensor's flat depth reading; {src} not found "
+                              "(pass depth_origin=<array or path>)")
+            src = np.loadtxt(src)
+            self.depth_origin = src
+        return np.asarray(src.cpu() if torch.is_tensor(src) else src, dtype=np.float64).reshape(-1)
+
+    def _generate_vtaco_t2d(self, data):
+        """The VTacO branch of generate_obj_mesh_wnf (generation.py:202-257): per finger whose touch succeeded, the contact cloud
+        unprojected from the sample's depth image (as the reference: the dataset's depth, not the predicted one, and the dataset's
+        camera poses), at most 128 points; every lattice point within 0.015 of a contact point takes that finger's tactile feature
+        (later fingers overwrite earlier ones) -- by finger id (vt_tactile_assign 'within' + vt_decode_fwd_ids) at any lattice
+        size, where the reference builds a dense [1, 128^3, C] tensor with eight CPU cdist passes hard-wired to 128^3."""
+        from ..common import contact_clouds_from_depth
+        if getattr(self.model, 'encoder_img', None) is None:
+            raise VtError("generate_obj_mesh_wnf(with_img, encode_t2d): the model needs encoder_img (tactile features)")
+        inputs = data.get('inputs').to(self.device)
+        if inputs.shape[0] != 1:
+            raise VtError(f"generate_obj_mesh_wnf: one scene at a time (got a batch of {inputs.shape[0]})")
+        with torch.no_grad():
+            c_img = self.model.encode_img_inputs(data.get('inputs.img').to(self.device))          # [1,5,C]
+        anchors, count = contact_clouds_from_depth(
+            data.get('inputs.depth')[0].float().cpu().numpy(), self._depth_origin(),
+            data.get('points.cam_pos').reshape(1, 5, 3)[0].cpu().numpy(), data.get('points.cam_rot').reshape(1, 5, 3)[0].cpu().numpy(),
+            data.get('inputs.pc_ply')[0].float().cpu().numpy(), data.get('inputs.touch_success')[0].cpu().numpy())
+        success = torch.from_numpy((count > 0).astype('uint8'))
+        return self.generate_obj_mesh_tactile(data, c_img[0], torch.from_numpy(anchors).float(), success, mode='within',
+                                              count=torch.from_numpy(count).int())
 
     def _generate_vtacoh(self, data):
         """The VTacOH branch of generate_obj_mesh_wnf (generation.py:161-200): fingertips from the hand encoder's MANO joints
