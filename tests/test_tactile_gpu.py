@@ -154,3 +154,41 @@ def test_vtaco_t2d_route_matches_the_reference_generator():
     with pytest.raises(VtError, match="depth_origin"):
         Generator3D(model, device=dev, resolution0=16, with_img=True, encode_t2d=True,
                     depth_origin="/nonexistent/depth_origin.txt").generate_obj_mesh_wnf(data)
+
+
+def test_tactile_generation_with_the_attention_decoder():
+    """BASELINE config 3's decoder (attention_local) through generate_obj_mesh_tactile: chunked like eval_points (the chunk is
+    part of the function), per-chunk features gathered from the finger ids -- equal to eval_points on the dense c_img_all."""
+    import numpy as np
+    from vtaco_amd import ops
+    from vtaco_amd.conv_onet.generation import Generator3D
+    from vtaco_amd.conv_onet.models import ConvolutionalOccupancyNetwork, decoder_dict
+    from vtaco_amd.encoder import encoder_dict
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    dec = decoder_dict["attention_local"](dim=3, c_dim=32, hidden_size=32)
+    enc = encoder_dict["pointnet_local_pool"](c_dim=32, dim=3, hidden_dim=32, grid_resolution=16, plane_type="grid", unet3d=False)
+    for blk in list(dec.blocks) + list(enc.blocks):
+        torch.nn.init.normal_(blk.fc_1.weight, 0, 0.1)
+    model = ConvolutionalOccupancyNetwork(dec, enc, device=dev).eval()
+    g = torch.Generator().manual_seed(6)
+    d = torch.randn(1, 3000, 3, generator=g)
+    data = {"inputs": 0.3 * d / d.norm(dim=-1, keepdim=True)}
+    feats = torch.randn(5, 32, generator=g)
+    anchors = (torch.rand(5, 16, 3, generator=g) - 0.5) * 0.8
+    success = torch.tensor([1, 1, 0, 1, 1], dtype=torch.uint8)
+    gen = Generator3D(model, device=dev, resolution0=4, padding=0.1, with_img=True, points_batch_size=1024, decode_precision="f32")
+    nx = 16
+    mesh = gen.generate_obj_mesh_tactile(data, feats, anchors, success, mode="within", radius=0.08)
+    ids = ops.tactile_assign(anchors.to(dev), success.to(dev), "within", 0.08, lattice=(nx, 1.1, 0, nx ** 3))
+    assert int((ids != 255).sum()) > 20
+    dense = torch.zeros(nx ** 3, 32, device=dev)
+    sel = ids[0] != 255
+    dense[sel] = feats.to(dev)[ids[0][sel].long()]
+    from oracle import vtaco_oracle as orc
+    pts = 1.1 * orc.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)
+    with torch.no_grad():
+        c = model.encode_inputs(data["inputs"].to(dev))
+    vals = gen.eval_points(pts, c, dense.unsqueeze(0))                    # the reference's chunk loop, dense features
+    ref = gen.extract_mesh(vals.to(dev).reshape(nx, nx, nx))
+    assert torch.equal(mesh.faces, ref.faces) and torch.equal(mesh.vertices, ref.vertices)

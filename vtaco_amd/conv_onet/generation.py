@@ -148,9 +148,28 @@ class Generator3D(object):
             lattice = (nx, 1 + self.padding, 0, nx ** 3)
             ids = ops.tactile_assign(anchors.to(self.device), success.to(self.device), mode, radius, lattice=lattice,
                                      count=None if count is None else count.to(self.device))
-            values = self.model.decoder.decode_lattice_ids(grid, nx, ids, finger_feats.to(self.device), box=1 + self.padding,
-                                                           precision=self.decode_precision)
+            if hasattr(self.model.decoder, 'fuser'):
+                values = self._eval_lattice_fused(c, nx, ids, finger_feats.to(self.device))
+            else:
+                values = self.model.decoder.decode_lattice_ids(grid, nx, ids, finger_feats.to(self.device), box=1 + self.padding,
+                                                               precision=self.decode_precision)
         return self.extract_mesh(values.reshape(nx, nx, nx))
+
+    def _eval_lattice_fused(self, c, nx, ids, finger_feats):
+        """``decoder: attention_local`` over the lattice (BASELINE config 3's decoder): TransformerFusion couples the points
+        of a chunk (attention + InstanceNorm over the chunk), so the chunk is part of the function -- ``points_batch_size``
+        points at a time in lattice order, exactly as ``eval_points`` walks them (the reference default of 100 000 needs a
+        40 GB attention matrix; 2048 is the workable setting).  The per-chunk tactile features are gathered from the finger ids."""
+        from ..common import make_3d_grid
+        chunk = self.points_batch_size
+        pts = ((1 + self.padding) * make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)).to(self.device)
+        table = torch.cat([finger_feats.float(), finger_feats.new_zeros(1, finger_feats.shape[1]).float()], dim=0)   # row F = no feature
+        row = torch.where(ids[0] == 255, torch.full_like(ids[0], finger_feats.shape[0]), ids[0]).long()
+        out = torch.empty(nx ** 3, dtype=torch.float32, device=self.device)
+        for lo in range(0, nx ** 3, chunk):
+            hi = min(lo + chunk, nx ** 3)
+            out[lo:hi] = self.model.decoder.forward_img(pts[lo:hi].unsqueeze(0), c, table[row[lo:hi]].unsqueeze(0))[0]
+        return out
 
     def generate_hand_mesh(self, data):
         """Hand mesh of one scene (generation.py:74-115): encoder_hand -> MANO vertices, then out of the MANO
