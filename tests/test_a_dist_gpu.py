@@ -46,6 +46,25 @@ def _worker(rank, world, port, q):
         plain = gen.generate_obj_mesh_wnf({"inputs": p})
         shard = gen.generate_obj_mesh_sharded({"inputs": p})
         ok_mesh = torch.equal(plain.faces, shard.faces) and torch.equal(plain.vertices, shard.vertices)
+        # tactile (VTacO t2d) generation sharded: the contact clouds are drawn with numpy's generator -- rank 0's draw is
+        # broadcast, so ranks seeded differently still assemble rank 0's mesh
+        import numpy as np
+        from conftest import GOLDEN
+        z = np.load(os.path.join(GOLDEN, "g12_t2d.npz"))
+        torch.manual_seed(0)
+        img = encoder_dict["UNet"](num_classes=1, in_channels=3, depth=2, start_filts=8)
+        model_t = ConvolutionalOccupancyNetwork(dec, enc, None, img, None, device=dev)
+        gen_t = Generator3D(model_t, device=dev, resolution0=8, padding=0.1, with_img=True, encode_t2d=True,
+                            depth_origin=z["depth_origin"])
+        gi = torch.Generator().manual_seed(1)
+        data_t = {"inputs": p, "inputs.img": torch.rand(1, 5, 3, 8, 4, generator=gi), "inputs.depth": torch.from_numpy(z["depths"])[None],
+                  "inputs.touch_success": torch.from_numpy(z["touch"]), "inputs.pc_ply": torch.from_numpy(z["pc_ply"]),
+                  "points.cam_pos": torch.from_numpy(z["cam_pos"]), "points.cam_rot": torch.from_numpy(z["cam_rot"])}
+        np.random.seed(7)
+        plain_t = gen_t.generate_obj_mesh_wnf(data_t)
+        np.random.seed(7 if rank == 0 else 99)
+        shard_t = gen_t.generate_obj_mesh_sharded(data_t)
+        ok_mesh = ok_mesh and torch.equal(plain_t.faces, shard_t.faces) and torch.equal(plain_t.vertices, shard_t.vertices)
         # data-parallel step: different batches per rank, one flat all-reduce -> identical parameters afterwards
         opt = torch.optim.SGD(model.parameters(), lr=1e-2)
         trainer = Trainer(model, opt, device=dev, grad_sync=GradAllReduce(model.parameters()))

@@ -128,7 +128,21 @@ class Generator3D(object):
         inputs = data.get('inputs').to(self.device)
         with torch.no_grad():
             c = self.model.encode_inputs(inputs)
-            values = vdist.decode_lattice_sharded(lambda first, count: self.eval_lattice(c, nx, first=first, count=count), nx, group)
+            if self.with_img:
+                # the tactile branches (VTacOH fingertips / VTacO contact clouds): every rank assigns finger ids to ITS slab and
+                # decodes by id; the VTacO clouds are drawn with numpy's generator, so rank 0's go to everybody (a few KB)
+                setup = self._tactile_setup(data)
+                if vdist.dist.is_initialized() and vdist.dist.get_world_size(group) > 1:
+                    for key in ('anchors', 'count', 'success'):
+                        t = setup[key].to(self.device)
+                        vdist.dist.broadcast(t, src=vdist.dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                        setup[key] = t
+                fused = hasattr(self.model.decoder, 'fuser')
+                values = vdist.decode_lattice_sharded(
+                    lambda first, count: self._eval_lattice_tactile(c, nx, setup, first, count), nx, group,
+                    align=self.points_batch_size if fused else None)
+            else:
+                values = vdist.decode_lattice_sharded(lambda first, count: self.eval_lattice(c, nx, first=first, count=count), nx, group)
         return self.extract_mesh(values.reshape(nx, nx, nx))
 
     def generate_obj_mesh_tactile(self, data, finger_feats, anchors, success, mode='within', radius=None, count=None):
@@ -140,34 +154,44 @@ class Generator3D(object):
         ``anchors [F,K,3]`` (K = 1 for 'nearest'), ``count [F]`` valid anchors per finger, ``success [F]``."""
         self.model.eval()
         nx = self.resolution0 * 4
-        radius = (0.015 if mode == 'within' else 0.05) if radius is None else radius
+        setup = {'feats': finger_feats, 'anchors': anchors, 'success': success, 'mode': mode,
+                 'radius': (0.015 if mode == 'within' else 0.05) if radius is None else radius,
+                 'count': count if count is not None else torch.full((anchors.shape[0],), anchors.shape[1], dtype=torch.int32)}
         inputs = data.get('inputs').to(self.device)
         with torch.no_grad():
             c = self.model.encode_inputs(inputs)
-            grid = c['grid'] if isinstance(c, dict) else c
-            lattice = (nx, 1 + self.padding, 0, nx ** 3)
-            ids = ops.tactile_assign(anchors.to(self.device), success.to(self.device), mode, radius, lattice=lattice,
-                                     count=None if count is None else count.to(self.device))
-            if hasattr(self.model.decoder, 'fuser'):
-                values = self._eval_lattice_fused(c, nx, ids, finger_feats.to(self.device))
-            else:
-                values = self.model.decoder.decode_lattice_ids(grid, nx, ids, finger_feats.to(self.device), box=1 + self.padding,
-                                                               precision=self.decode_precision)
+            values = self._eval_lattice_tactile(c, nx, setup)
         return self.extract_mesh(values.reshape(nx, nx, nx))
 
-    def _eval_lattice_fused(self, c, nx, ids, finger_feats):
+    def _eval_lattice_tactile(self, c, nx, setup, first=0, count=None):
+        """Logits of lattice points [first, first+count) with the tactile features of ``setup`` (finger features, anchors, rule)."""
+        count = nx ** 3 - first if count is None else count
+        grid = c['grid'] if isinstance(c, dict) else c
+        ids = ops.tactile_assign(setup['anchors'].to(self.device), setup['success'].to(self.device), setup['mode'], setup['radius'],
+                                 lattice=(nx, 1 + self.padding, first, count), count=setup['count'].to(self.device))
+        feats = setup['feats'].to(self.device)
+        if hasattr(self.model.decoder, 'fuser'):
+            return self._eval_lattice_fused(c, nx, ids, feats, first, count)
+        return self.model.decoder.decode_lattice_ids(grid, nx, ids, feats, box=1 + self.padding, first=first, count=count,
+                                                     precision=self.decode_precision).reshape(-1)
+
+    def _eval_lattice_fused(self, c, nx, ids, finger_feats, first=0, count=None):
         """``decoder: attention_local`` over the lattice (BASELINE config 3's decoder): TransformerFusion couples the points
         of a chunk (attention + InstanceNorm over the chunk), so the chunk is part of the function -- ``points_batch_size``
         points at a time in lattice order, exactly as ``eval_points`` walks them (the reference default of 100 000 needs a
-        40 GB attention matrix; 2048 is the workable setting).  The per-chunk tactile features are gathered from the finger ids."""
+        40 GB attention matrix; 2048 is the workable setting).  The per-chunk tactile features are gathered from the finger ids.
+        A slab must start on a chunk boundary (sharded generation aligns its slabs to the chunk)."""
         from ..common import make_3d_grid
         chunk = self.points_batch_size
-        pts = ((1 + self.padding) * make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)).to(self.device)
+        count = nx ** 3 - first if count is None else count
+        if first % chunk:
+            raise VtError(f"_eval_lattice_fused: slab start {first} splits a chunk of {chunk} points")
+        pts = ((1 + self.padding) * make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3))[first:first + count].to(self.device)
         table = torch.cat([finger_feats.float(), finger_feats.new_zeros(1, finger_feats.shape[1]).float()], dim=0)   # row F = no feature
         row = torch.where(ids[0] == 255, torch.full_like(ids[0], finger_feats.shape[0]), ids[0]).long()
-        out = torch.empty(nx ** 3, dtype=torch.float32, device=self.device)
-        for lo in range(0, nx ** 3, chunk):
-            hi = min(lo + chunk, nx ** 3)
+        out = torch.empty(count, dtype=torch.float32, device=self.device)
+        for lo in range(0, count, chunk):
+            hi = min(lo + chunk, count)
             out[lo:hi] = self.model.decoder.forward_img(pts[lo:hi].unsqueeze(0), c, table[row[lo:hi]].unsqueeze(0))[0]
         return out
 
@@ -216,7 +240,7 @@ class Generator3D(object):
         nx = self.resolution0 * 4                       # generation.py:120
         inputs = data.get('inputs').to(self.device)
         if self.with_img and c_img_all is None:
-            return self._generate_vtaco_t2d(data) if self.encode_t2d else self._generate_vtacoh(data)
+            return self._generate_tactile(data)
         with torch.no_grad():
             c = self.model.encode_inputs(inputs)
             values = self.eval_lattice(c, nx, c_img_all=c_img_all if self.with_img else None)
@@ -236,7 +260,16 @@ class Generator3D(object):
             self.depth_origin = src
         return np.asarray(src.cpu() if torch.is_tensor(src) else src, dtype=np.float64).reshape(-1)
 
-    def _generate_vtaco_t2d(self, data):
+    def _tactile_setup(self, data):
+        """Finger features, anchors and assignment rule of the configured tactile branch (VTacO t2d or VTacOH)."""
+        return self._setup_vtaco_t2d(data) if self.encode_t2d else self._setup_vtacoh(data)
+
+    def _generate_tactile(self, data):
+        setup = self._tactile_setup(data)
+        return self.generate_obj_mesh_tactile(data, setup['feats'], setup['anchors'], setup['success'], mode=setup['mode'],
+                                              radius=setup['radius'], count=setup['count'])
+
+    def _setup_vtaco_t2d(self, data):
         """The VTacO branch of generate_obj_mesh_wnf (generation.py:202-257): per finger whose touch succeeded, the contact cloud
         unprojected from the sample's depth image (as the reference: the dataset's depth, not the predicted one, and the dataset's
         camera poses), at most 128 points; every lattice point within 0.015 of a contact point takes that finger's tactile feature
@@ -248,17 +281,17 @@ class Generator3D(object):
         inputs = data.get('inputs').to(self.device)
         if inputs.shape[0] != 1:
             raise VtError(f"generate_obj_mesh_wnf: one scene at a time (got a batch of {inputs.shape[0]})")
+        self.model.eval()
         with torch.no_grad():
             c_img = self.model.encode_img_inputs(data.get('inputs.img').to(self.device))          # [1,5,C]
         anchors, count = contact_clouds_from_depth(
             data.get('inputs.depth')[0].float().cpu().numpy(), self._depth_origin(),
             data.get('points.cam_pos').reshape(1, 5, 3)[0].cpu().numpy(), data.get('points.cam_rot').reshape(1, 5, 3)[0].cpu().numpy(),
             data.get('inputs.pc_ply')[0].float().cpu().numpy(), data.get('inputs.touch_success')[0].cpu().numpy())
-        success = torch.from_numpy((count > 0).astype('uint8'))
-        return self.generate_obj_mesh_tactile(data, c_img[0], torch.from_numpy(anchors).float(), success, mode='within',
-                                              count=torch.from_numpy(count).int())
+        return {'feats': c_img[0], 'anchors': torch.from_numpy(anchors).float(), 'success': torch.from_numpy((count > 0).astype('uint8')),
+                'mode': 'within', 'radius': 0.015, 'count': torch.from_numpy(count).int()}
 
-    def _generate_vtacoh(self, data):
+    def _setup_vtacoh(self, data):
         """The VTacOH branch of generate_obj_mesh_wnf (generation.py:161-200): fingertips from the hand encoder's MANO joints
         in the object's frame (ground-truth wrist position and wrist Euler angles from the sample), every lattice point
         within 0.05 of its nearest fingertip takes that finger's tactile feature if its touch succeeded -- by finger id
@@ -270,6 +303,7 @@ class Generator3D(object):
         inputs = data.get('inputs').to(self.device)
         if inputs.shape[0] != 1:
             raise VtError(f"generate_obj_mesh_wnf: one scene at a time (got a batch of {inputs.shape[0]})")
+        self.model.eval()
         with torch.no_grad():
             c_hand = self.model.encode_hand_inputs(inputs)
             if 'mano_joints' not in c_hand:
@@ -278,4 +312,5 @@ class Generator3D(object):
         tips = fingertips_in_object_frame(c_hand['mano_joints'].float().cpu().numpy(), data.get('points.mano').cpu().numpy()[:, :3],
                                           data.get('points.wrist').cpu().numpy(), data.get('inputs.pc_ply').float().cpu().numpy())
         anchors = torch.from_numpy(tips[0]).float().unsqueeze(1)                                   # [5,1,3]
-        return self.generate_obj_mesh_tactile(data, c_img[0], anchors, data.get('inputs.touch_success')[0], mode='nearest')
+        return {'feats': c_img[0], 'anchors': anchors, 'success': data.get('inputs.touch_success')[0].to(torch.uint8),
+                'mode': 'nearest', 'radius': 0.05, 'count': torch.ones(5, dtype=torch.int32)}

@@ -48,13 +48,15 @@ def all_gather_slabs(local, total, group=None, align=32):
     return torch.cat([o[:c] for o, c in zip(out, counts)])
 
 
-def decode_lattice_sharded(decode_slab, nx, group=None):
+def decode_lattice_sharded(decode_slab, nx, group=None, align=None):
     """`decode_slab(first, count) -> [count]` logits of that lattice slab; returns the whole
-    [nx^3] value grid on every rank.  With one rank this is a plain call."""
+    [nx^3] value grid on every rank.  With one rank this is a plain call.  ``align``: slab granularity
+    (default: whole x-plane pairs; a decoder that couples the points of a chunk passes its chunk size, so
+    that no chunk is split between ranks)."""
     total = nx ** 3
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    align = lattice_align(nx, world)
+    align = lattice_align(nx, world) if align is None else align
     first, count = slab_of(total, rank, world, align)
     local = decode_slab(first, count)
     if world == 1:
