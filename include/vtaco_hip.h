@@ -426,6 +426,18 @@ int vt_resblock_fc(const float *x1, int C1, const float *x2, int C2, int64_t N,
                    const float *w0, const float *b0, const float *w1, const float *b1, const float *ws,
                    int H, int O, float *out, void *stream);
 
+/* ------------------------------------------------------------------------- */
+/* Generalized winding number of query points against a triangle mesh.          */
+/* Stands where the VTacO (t2d) training step calls                              */
+/*   igl.fast_winding_number_for_meshes(V, F, Q) (src/conv_onet/training.py:723,  */
+/*   862) to label its re-sampled query points.  libigl is an un-vendored,        */
+/*   absent dependency and its routine is a hierarchical approximation: this is    */
+/*   the exact sum it approximates, w(q) = 1/(4 pi) sum_f Omega_f(q) (float64        */
+/*   solid angles): 1 inside a closed outward-oriented mesh, 0 outside.               */
+/*   verts [V,3] f32, faces [F,3] i32, pts [N,3] f32 -> out [N] f32.                    */
+/* ------------------------------------------------------------------------- */
+int vt_winding_number(const float *verts, int V, const int32_t *faces, int F, const float *pts, int64_t N, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -704,3 +704,57 @@ def t2d_contact_clouds(depths, depth_origin, cam_pos, cam_rot, pc_ply, touch_suc
         world = cam_to_world(pc, np.asarray(cam_rot[t]) + np.array([-np.pi / 2, 0, np.pi / 2]), cam_pos[t])
         clouds.append((world - centroid) / (2 * m))
     return clouds
+
+
+# --------------------------------------------------------------------------
+# VTacO (t2d) training step (A13, training.py:757-894): occupancy labels and sample assembly
+# --------------------------------------------------------------------------
+
+
+def winding_number(verts, faces, pts, chunk=2048):
+    """Generalized winding number w(q) = 1/(4 pi) sum_f Omega_f(q) (Van Oosterom-Strackee solid angles, float64).
+    The reference calls ``igl.fast_winding_number_for_meshes`` (training.py:723, 862), libigl's hierarchical approximation of
+    this sum; libigl is un-vendored and absent here -> this restates the quantity it approximates (**parity unpinned** against
+    igl itself; pinned by known answers: 1 inside / 0 outside closed meshes, 0.5 on a face of a cube from inside the face plane
+    limit, additivity over a split mesh).  numpy: verts [V,3], faces [F,3] int, pts [N,3] -> float64 [N]."""
+    import numpy as np
+    v = np.asarray(verts, dtype=np.float64)
+    tri = v[np.asarray(faces, dtype=np.int64)]                                    # [F,3,3]
+    q = np.asarray(pts, dtype=np.float64)
+    out = np.zeros(len(q))
+    for lo in range(0, len(q), chunk):
+        d = tri[None, :, :, :] - q[lo:lo + chunk, None, None, :]                     # [n,F,3,3]
+        a, b, c = d[:, :, 0], d[:, :, 1], d[:, :, 2]
+        la, lb, lc = (np.linalg.norm(x, axis=-1) for x in (a, b, c))
+        num = np.einsum("nfi,nfi->nf", a, np.cross(b, c))
+        den = la * lb * lc + (a * b).sum(-1) * lc + (b * c).sum(-1) * la + (c * a).sum(-1) * lb
+        out[lo:lo + chunk] = (2.0 * np.arctan2(num, den)).sum(-1) / (4.0 * np.pi)
+    return out
+
+
+def trainer_t2d_assembly(p, depths, depth_origin, cam_pos, cam_rot, pc_ply, touch_success, c_img, meshes, num_sample, rng=None):
+    """Sample assembly of the VTacO (t2d) training step (training.py:809-866).  Per scene: the contact clouds of the fingers whose
+    touch succeeded (``t2d_contact_clouds``; their ``randint`` draws come first), stored as float32, become the first query
+    points and carry the finger's tactile feature; the remaining ``num_sample - k`` points are ``randint(N)`` draws from the
+    scene's points (with replacement) and carry ONES (the reference fills c_img_all with ones, not zeros); the occupancy target of
+    every row is the winding number of the scene's mesh.  ``meshes``: list of (verts, faces) per scene.
+    numpy; returns (p_sample [B,S,3] f32, c_img_all [B,S,C] f32, occ_new [B,S] f64)."""
+    import numpy as np
+    rng = np.random if rng is None else rng
+    B, N = p.shape[:2]
+    C = c_img.shape[2]
+    p_sample = np.zeros((B, num_sample, 3), dtype=np.float32)
+    feats = np.ones((B, num_sample, C), dtype=np.float32)
+    occ_new = np.zeros((B, num_sample))
+    for b in range(B):
+        clouds = t2d_contact_clouds(depths[b], depth_origin, cam_pos[b], cam_rot[b], pc_ply[b], touch_success[b], rng)
+        k = 0
+        for t in range(5):
+            n = len(clouds[t])
+            if touch_success[b][t]:
+                feats[b, k:k + n] = c_img[b, t]
+                p_sample[b, k:k + n] = clouds[t].astype(np.float32)
+                k += n
+        p_sample[b, k:] = p[b][rng.randint(N, size=num_sample - k)]
+        occ_new[b] = winding_number(meshes[b][0], meshes[b][1], p_sample[b])
+    return p_sample, feats, occ_new

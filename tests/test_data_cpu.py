@@ -83,3 +83,19 @@ def test_compute_iou_matches_reference_semantics():
     b = a + 0.1
     d = chamfer_distance_naive(a, b)
     assert (d > 0).all() and torch.allclose(d, chamfer_distance_naive(b, a))
+
+
+def test_mesh_dict_reads_off_and_obj(tmp_path):
+    """vtaco_amd.data.load_mesh_dict: the vf_dict of train.py:161-174 (.off preferred, .obj fallback, polygons triangulated)."""
+    import numpy as np
+    from vtaco_amd.data import load_mesh_dict
+    (tmp_path / "cube.off").write_text("OFF\n8 6 0\n" + "\n".join(f"{x} {y} {z}" for z in (0, 1) for y in (0, 1) for x in (0, 1)) +
+                                       "\n4 0 2 3 1\n4 4 5 7 6\n4 0 1 5 4\n4 2 6 7 3\n4 0 4 6 2\n4 1 3 7 5\n")
+    (tmp_path / "tet.obj").write_text("# a tetrahedron\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nf 1/1 3/2 2/3\nf 1 2 4\nf 1 4 3\nf -3 -2 -1\n")
+    d = load_mesh_dict(str(tmp_path), ["cube", "tet", "cube"])
+    assert set(d) == {"cube", "tet"}
+    assert d["cube"]["v"].dtype == np.float32 and d["cube"]["v"].shape == (8, 3) and d["cube"]["f"].shape == (12, 3)
+    assert d["tet"]["f"].tolist() == [[0, 2, 1], [0, 1, 3], [0, 3, 2], [1, 2, 3]]
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        load_mesh_dict(str(tmp_path), ["sphere"])

@@ -228,3 +228,31 @@ def test_t2d_contact_clouds_against_the_reference_generator():
     assert np.array_equal(ids, z["ids"]) and int((ids != 255).sum()) > 80
     with pytest.raises(ValueError, match="sensor image"):
         contact_clouds_from_depth(z["depths"][:, :100], z["depth_origin"], z["cam_pos"][0], z["cam_rot"][0], z["pc_ply"][0], z["touch"][0])
+
+
+def test_winding_number_known_answers_and_t2d_trainer_assembly():
+    """The oracle's exact winding number on known answers, and its t2d training-sample assembly against the real reference Trainer
+    (g13_trainer_t2d.npz; the reference's libigl call answered by that same exact winding number: what is pinned is everything
+    around it)."""
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "g13_trainer_t2d.npz"))
+    z12 = np.load(os.path.join(GOLDEN, "g12_t2d.npz"))
+    cube = (z["cube_v"], z["cube_f"])
+    q = np.array([[0, 0, 0], [0.29, -0.29, 0.29], [0.31, 0, 0], [5, 5, 5]], dtype=np.float64)
+    assert np.allclose(orc.winding_number(*cube, q), [1, 1, 0, 0], atol=1e-12)
+    # additivity: the faces split in two open halves sum to the closed mesh; an open half is fractional
+    half = orc.winding_number(cube[0], cube[1][:6], q) + orc.winding_number(cube[0], cube[1][6:], q)
+    assert np.allclose(half, [1, 1, 0, 0], atol=1e-12) and 0.0 < orc.winding_number(cube[0], cube[1][:6], q[:1])[0] < 1.0
+    # flipping the orientation flips the sign
+    assert np.allclose(orc.winding_number(cube[0], cube[1][:, ::-1], q), [-1, -1, 0, 0], atol=1e-12)
+    depths = np.stack([z12["depths"], np.roll(z12["depths"], 7, axis=0)])
+    state = np.random.get_state()
+    try:
+        np.random.seed(int(z["seed"]))
+        ps, fe, on = orc.trainer_t2d_assembly(z["p"], depths, z12["depth_origin"], z["cam_pos"], z["cam_rot"], z["pc_ply"], z["touch"],
+                                              z["c_img"], [cube, (z["tet_v"], z["tet_f"])], int(z["num_sample"]))
+    finally:
+        np.random.set_state(state)
+    assert np.array_equal(ps, z["p_sample"]) and np.array_equal(fe, z["c_img_all"])
+    assert np.abs(on - z["occ_new"]).max() <= 1e-6

@@ -113,3 +113,29 @@ def test_common_helpers_match_oracle():
     q = common.normalize_3d_coordinate(p)
     assert torch.equal(q, orc.normalize_3d_coordinate(p))
     assert torch.equal(common.coordinate2index(q, 16)[:, 0], orc.coordinate2index_3d(q, 16))
+
+
+def test_tactile_resnet18_against_the_reference_module():
+    """encoder_dict['Resnet18'] (the shipped configs' tactile feature encoder) against the reference module's outputs
+    (g14_resnet.npz); the 11 M parameters are rebuilt on both sides by the same seeded fill, in state_dict order."""
+    import os
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from make_resnet_goldens import deterministic_fill
+    from vtaco_amd.encoder import encoder_dict
+    z = np.load(os.path.join(GOLDEN, "g14_resnet.npz"))
+    net = encoder_dict["Resnet18"](num_classes=32)
+    keys = [f"{k}:{tuple(v.shape)}" for k, v in net.state_dict().items() if "num_batches_tracked" not in k]
+    assert keys == list(z["keys"])                                   # same checkpoint names, shapes and ORDER
+    deterministic_fill(net, 90)
+    x = T(z["x"])
+    net.eval()
+    with torch.no_grad():
+        y = net(x)
+    assert y.shape == (2, 32) and float((y - T(z["y_eval"])).abs().max()) <= 1e-4 * float(T(z["y_eval"]).abs().max())
+    net.train()
+    with torch.no_grad():
+        y = net(x)
+    assert float((y - T(z["y_train"])).abs().max()) <= 1e-4 * float(T(z["y_train"]).abs().max())
+    assert sum(p.numel() for p in encoder_dict["Resnet34"](num_classes=32).parameters()) > sum(p.numel() for p in net.parameters())

@@ -192,3 +192,164 @@ def test_tactile_generation_with_the_attention_decoder():
     vals = gen.eval_points(pts, c, dense.unsqueeze(0))                    # the reference's chunk loop, dense features
     ref = gen.extract_mesh(vals.to(dev).reshape(nx, nx, nx))
     assert torch.equal(mesh.faces, ref.faces) and torch.equal(mesh.vertices, ref.vertices)
+
+
+def test_winding_number_kernel_against_the_oracle():
+    import numpy as np
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd import ops
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(0)
+    # a closed, outward-oriented mesh with many faces: a subdivided cube surface projected on a sphere
+    n = 9
+    g = np.linspace(-1, 1, n)
+    verts, faces, index = [], [], {}
+
+    def vid(p):
+        key = tuple(np.round(p, 9))
+        if key not in index:
+            index[key] = len(verts)
+            verts.append(np.array(p) / np.linalg.norm(p) * 0.4)
+        return index[key]
+
+    for axis in range(3):
+        for sign in (-1.0, 1.0):
+            for i in range(n - 1):
+                for j in range(n - 1):
+                    def pt(a, b):
+                        q = [0.0, 0.0, 0.0]
+                        q[axis] = sign
+                        q[(axis + 1) % 3], q[(axis + 2) % 3] = g[a], g[b]
+                        return q
+                    quad = [vid(pt(i, j)), vid(pt(i + 1, j)), vid(pt(i + 1, j + 1)), vid(pt(i, j + 1))]
+                    if sign < 0:
+                        quad = quad[::-1]
+                    faces += [[quad[0], quad[1], quad[2]], [quad[0], quad[2], quad[3]]]
+    verts, faces = np.array(verts, dtype=np.float32), np.array(faces, dtype=np.int64)
+    pts = ((rs.rand(3001, 3) - 0.5) * 1.2).astype(np.float32)
+    ref = orc.winding_number(verts, faces, pts)
+    got = ops.winding_number(torch.from_numpy(verts).to(dev), torch.from_numpy(faces).to(dev), torch.from_numpy(pts).to(dev)).cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-6
+    inside = np.linalg.norm(pts, axis=1) < 0.39
+    outside = np.linalg.norm(pts, axis=1) > 0.41
+    assert np.allclose(ref[inside], 1, atol=1e-9) and np.allclose(ref[outside], 0, atol=1e-9) and inside.sum() > 100
+    assert ops.winding_number(torch.from_numpy(verts).to(dev), torch.from_numpy(faces).to(dev), torch.zeros(0, 3, device=dev)).shape == (0,)
+
+
+def test_trainer_compute_loss_t2d_img_matches_the_reference_trainer():
+    """Trainer.compute_loss_t2d_img (VTacO step) on stand-in encoders returning the fixture's tensors: under the reference run's
+    numpy seed, decode_img receives the same points and features and the losses equal the real reference Trainer's -- with and
+    without the t2d net's own losses (g13_trainer_t2d.npz; libigl's call answered by the exact winding number there)."""
+    import os
+    import types
+    import numpy as np
+    from conftest import GOLDEN
+    from vtaco_amd.conv_onet.training import Trainer
+    z = np.load(os.path.join(GOLDEN, "g13_trainer_t2d.npz"))
+    z12 = np.load(os.path.join(GOLDEN, "g12_t2d.npz"))
+    dev = torch.device("cuda:0")
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    depths = torch.from_numpy(np.stack([z12["depths"], np.roll(z12["depths"], 7, axis=0)]))
+    pred_depth = (torch.linspace(0, 1, 240 * 320).view(1, 1, -1) * torch.tensor([0.2, 0.4, 0.6, 0.8, 1.0]).view(1, 5, 1)).expand(2, 5, -1)
+    seen = {}
+
+    class StandIn(object):
+        def train(self):
+            return self
+
+        def encode_t2d(self, inputs, imgs):
+            return pred_depth.to(dev), {"mano_param": t("digit")}
+
+        def encode_inputs(self, inputs):
+            return "c"
+
+        def encode_hand_inputs(self, inputs):
+            return {"mano_param": t("mano_param"), "mano_verts": t("mano_verts")}
+
+        def encode_img_inputs(self, imgs):
+            return t("c_img")
+
+        def decode_img(self, p_sample, c, c_img_all, **kw):
+            seen["p_sample"], seen["c_img_all"] = p_sample, c_img_all
+            return types.SimpleNamespace(logits=p_sample.sum(-1) * 0.5 + c_img_all.sum(-1) * 0.01)
+
+    data = {"points": t("p"), "points.mano": t("mano"), "points.pc_hand": t("pc_hand"), "points.name": ["cube", "tet"],
+            "points.cam_pos": t("cam_pos"), "points.cam_rot": t("cam_rot"), "inputs": torch.zeros(2, 16, 3), "inputs.pc_ply": t("pc_ply"),
+            "inputs.img": torch.zeros(2, 5, 3, 8, 6), "inputs.depth": depths, "inputs.touch_success": t("touch")}
+    vf = {"cube": {"v": z["cube_v"], "f": z["cube_f"]}, "tet": {"v": z["tet_v"], "f": z["tet_f"]}}
+    for pretrained, key in ((True, "loss_pretrained"), (False, "loss_joint")):
+        trainer = Trainer(StandIn(), None, device=dev, num_sample=int(z["num_sample"]), with_img=True, encode_t2d=True,
+                          pretrained_t2d=pretrained, depth_origin=z12["depth_origin"])
+        state = np.random.get_state()
+        try:
+            np.random.seed(int(z["seed"]))
+            out = trainer.compute_loss_t2d_img(data, vf)
+        finally:
+            np.random.set_state(state)
+        assert torch.equal(seen["p_sample"].cpu(), torch.from_numpy(z["p_sample"]))
+        assert torch.equal(seen["c_img_all"].cpu(), torch.from_numpy(z["c_img_all"]))
+        for got, ref in zip(out, z[key]):
+            assert abs(float(got) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), (key, float(got), float(ref))
+
+
+def test_trainer_vtaco_t2d_step_with_the_shipped_module_types(tmp_path):
+    """One VTacO training step built by get_model / get_trainer from a config shaped like configs/VTacO/VTacO_YCB.yaml: object
+    encoder + UNet3D, hand encoder + MANO layer, Resnet18 tactile features, the t2d net (depth U-Net + digit-pose regressor),
+    concat decoder; contact clouds from the depth images, winding-number targets from meshes read from .off / .obj files."""
+    import os
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import synth_mano
+    from conftest import GOLDEN
+    from vtaco_amd.conv_onet import config as cfgmod
+    from vtaco_amd.data import load_mesh_dict
+    z12 = np.load(os.path.join(GOLDEN, "g12_t2d.npz"))
+    z13 = np.load(os.path.join(GOLDEN, "g13_trainer_t2d.npz"))
+    dev = torch.device("cuda:0")
+    synth_mano.write_pkl(synth_mano.make_asset(0), str(tmp_path / "mano"))
+    (tmp_path / "cube.off").write_text("OFF\n8 12 0\n" + "\n".join(" ".join(str(float(c)) for c in v) for v in z13["cube_v"]) + "\n" +
+                                       "\n".join("3 " + " ".join(str(int(i)) for i in f) for f in z13["cube_f"]) + "\n")
+    (tmp_path / "tet.obj").write_text("\n".join("v " + " ".join(str(float(c)) for c in v) for v in z13["tet_v"]) + "\n" +
+                                      "\n".join("f " + " ".join(str(int(i) + 1) for i in f) for f in z13["tet_f"]) + "\n")
+    vf = load_mesh_dict(str(tmp_path), ["cube", "tet"])
+    mano_kw = dict(center_idx=9, flat_hand_mean=False, ncomps=45, side="right", mano_root=str(tmp_path / "mano"), use_pca=False,
+                   root_rot_mode="axisang", joint_rot_mode="axisang", robust_rot=False, return_transf=False)
+    hand = {"hidden_dim": 32, "plane_type": ["xz", "xy", "yz"], "plane_resolution": 32, "unet": True,
+            "unet_kwargs": {"depth": 2, "merge_mode": "concat", "start_filts": 8}, "out_mano": True}
+    cfg = {"data": {"dim": 3, "padding": 0.1, "input_type": "pointcloud", "num_sample": 640}, "test": {"threshold": 0.5},
+           "model": {"c_dim": 32, "decoder": "simple_local", "decoder_kwargs": {"sample_mode": "bilinear", "hidden_size": 32},
+                     "encoder": "pointnet_local_pool",
+                     "encoder_kwargs": {"hidden_dim": 32, "plane_type": "grid", "grid_resolution": 32, "unet3d": True,
+                                        "unet3d_kwargs": {"num_levels": 3, "f_maps": 32, "in_channels": 32, "out_channels": 32}},
+                     "encoder_hand": "pointnet_local_pool", "encoder_hand_kwargs": dict(hand, out_dim=51, manolayer_kwargs=mano_kw),
+                     "with_img": True, "encoder_img": "Resnet18", "encoder_img_kwargs": {"num_classes": 32},
+                     "encoder_t2d": True,
+                     "encoder_t2d_kwargs": {"pretrained": False, "encoder_img": "UNet",
+                                            "encoder_img_kwargs": {"num_classes": 1, "in_channel": 3, "start_filts": 8, "depth": 2},
+                                            "encoder_hand": "pointnet_local_pool", "encoder_hand_kwargs": dict(hand, c_dim=16, out_dim=30)}}}
+    torch.manual_seed(0)
+    model = cfgmod.get_model(cfg, device=dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    trainer = cfgmod.get_trainer(model, opt, cfg, dev, depth_origin=z12["depth_origin"])
+    assert trainer.encode_t2d and trainer.with_img and not trainer.pretrained_t2d and trainer.num_sample == 640
+    g = torch.Generator().manual_seed(2)
+    d = torch.randn(2, 300, 3, generator=g)
+    batch = {"inputs": 0.3 * d / d.norm(dim=-1, keepdim=True), "points": (torch.rand(2, 900, 3, generator=g) - 0.5) * 1.1,
+             "points.mano": torch.randn(2, 51, generator=g) * 0.2, "points.pc_hand": torch.randn(2, 778, 3, generator=g) * 0.05,
+             "points.name": ["cube", "tet"], "points.cam_pos": torch.from_numpy(z13["cam_pos"]), "points.cam_rot": torch.from_numpy(z13["cam_rot"]),
+             "inputs.pc_ply": torch.from_numpy(z13["pc_ply"]), "inputs.img": torch.rand(2, 5, 3, 320, 240, generator=g),
+             "inputs.depth": torch.from_numpy(np.stack([z12["depths"], np.roll(z12["depths"], 7, axis=0)])),
+             "inputs.touch_success": torch.from_numpy(z13["touch"])}
+    np.random.seed(0)
+    first = trainer.train_step(batch, vf)
+    for _ in range(4):
+        last = trainer.train_step(batch, vf)
+    assert all(np.isfinite(x) for x in first + last) and last[0] < first[0], (first, last)
+    for name in ("encoder", "encoder_hand", "encoder_img", "decoder"):
+        got = [p.grad is not None for n, p in getattr(model, name).named_parameters() if "fc_out_contact" not in n and "fc_p." not in n]
+        assert all(got), name
+    assert any(p.grad is not None and p.grad.abs().sum() > 0 for p in model.encoder_t2d.parameters())       # joint training of the t2d net
+    from vtaco_amd._lib import VtError
+    with pytest.raises(VtError, match="vf_dict"):
+        trainer.train_step(batch)

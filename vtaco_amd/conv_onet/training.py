@@ -9,7 +9,9 @@ they are reported as 0.  Forward and backward of the whole step (voxeliser, UNet
 and scatter of the hand encoder) run on the HIP kernels; the MANO layer and the 2-D U-Net differentiate
 through host PyTorch ops.  ``with_img=True`` selects the VTacOH step (``compute_loss_img``, training.py:502-626): fingertips from
 the MANO joints, nearest-fingertip assignment of the query points on the device (vt_tactile_assign), the reference's re-sampling
-of the query points (same numpy draws under the same seed), ``decode_img`` with the per-point tactile features.  The tactile variants (``with_img`` / ``encode_t2d``) need the per-point
+of the query points (same numpy draws under the same seed), ``decode_img`` with the per-point tactile features.
+``with_img=True, encode_t2d=True`` selects the VTacO step (``compute_loss_t2d_img``, training.py:757-894): contact clouds from the
+depth images as query points, winding-number occupancy targets from the object mesh (vt_winding_number).  The tactile variants (``with_img`` / ``encode_t2d``) need the per-point
 contact features the reference assembles with CPU geometry (igl / cdist, training.py:817-866): feed them
 at model level (``model.decode_img(p, c, c_img)``) or as finger ids (``vt_tactile_assign``) instead.
 """
@@ -27,14 +29,17 @@ from ..eval import compute_iou
 class Trainer:
     def __init__(self, model, optimizer, device=None, input_type='pointcloud', vis_dir=None, threshold=0.5,
                  eval_sample=False, num_sample=2048, with_img=False, with_contact=False, train_tactile=False,
-                 encode_t2d=False, pretrained_t2d=True, grad_sync=None):
-        if encode_t2d or with_contact or train_tactile:
-            raise VtError("Trainer: the visual branch (compute_loss) and the VTacOH tactile branch (with_img: compute_loss_img) "
-                          "are built; encode_t2d / with_contact / train_tactile need the reference's depth-to-contact CPU "
-                          "geometry (igl winding numbers, camera unprojection) -- use the model-level API")
+                 encode_t2d=False, pretrained_t2d=True, grad_sync=None, depth_origin=None):
+        if with_contact or train_tactile or (encode_t2d and not with_img):
+            raise VtError("Trainer: built are the visual branch (compute_loss), the VTacOH tactile branch (with_img: "
+                          "compute_loss_img) and the VTacO branch (with_img + encode_t2d: compute_loss_t2d_img); with_contact, "
+                          "train_tactile and encode_t2d without with_img are not")
         self.model, self.optimizer, self.device = model, optimizer, device
         self.input_type, self.threshold = input_type, threshold
         self.with_img, self.num_sample = with_img, num_sample
+        self.encode_t2d, self.pretrained_t2d = encode_t2d, pretrained_t2d
+        # the tactile sensor's flat depth reading [240*320] (array or path; None = the reference's ./data/VTacO_mesh/depth_origin.txt)
+        self.depth_origin = depth_origin
         # data-parallel training (one process per GPU): a callable run between backward and the optimizer step,
         # e.g. vtaco_amd.dist.GradAllReduce(model.parameters()) -- one flat-bucket RCCL all-reduce per step that
         # also covers the parameters a step leaves without gradient (fc_p_img, the contact head)
@@ -125,10 +130,93 @@ class Trainer:
         loss_pc = F.mse_loss(c_hand['mano_verts'], data.get('points.pc_hand').to(dev).float())
         return loss_l1 + loss_mano + loss_pc, loss_mano, loss_pc
 
+    # -- VTacO (t2d): contact clouds from the tactile depth images become query points (training.py:757-894) --------------
+    def _depth_origin(self):
+        src = self.depth_origin
+        if src is None:
+            src = "./data/VTacO_mesh/depth_origin.txt"
+        if isinstance(src, str):
+            import os
+            if not os.path.exists(src):
+                raise VtError(f"Trainer: the VTacO branch needs the sensor's flat depth reading; {src} not found "
+                              "(pass depth_origin=<array or path>)")
+            src = np.loadtxt(src)
+            self.depth_origin = src
+        return np.asarray(src, dtype=np.float64).reshape(-1)
+
+    def compute_loss_t2d_img(self, data, vf_dict):
+        """(loss, loss_mano, loss_pc) of the VTacO step.  Per scene the contact clouds of the successful touches
+        (vtaco_amd.common.contact_clouds_from_depth: the sample's depth images against the sensor's flat reading, the reference's
+        numpy draws) are the first query points and carry their finger's tactile feature; the rest are ``randint`` draws from
+        the scene's points and carry ONES, as in the reference; every row's occupancy target is the winding number of the
+        scene's mesh ``vf_dict[name]`` -- vt_winding_number, the exact sum where the reference calls libigl's fast
+        approximation.  With ``pretrained_t2d=False`` the depth and digit-pose losses of the t2d net are added (:887-891)."""
+        from .. import ops
+        from ..common import contact_clouds_from_depth
+        dev = self.device
+        p = data.get('points').to(dev)
+        B, N = p.shape[:2]
+        S = self.num_sample
+        inputs = data.get('inputs').to(dev)
+        imgs = data.get('inputs.img').to(dev)
+        depths = data.get('inputs.depth').to(dev)
+        cam_pos = data.get('points.cam_pos').reshape(B, 5, 3)
+        cam_rot = data.get('points.cam_rot').reshape(B, 5, 3)
+        pred_depth, c_hand_d = self.model.encode_t2d(inputs, imgs)
+        digit_param = c_hand_d['mano_param']
+        c_img = self.model.encode_img_inputs(imgs)                                          # [B,5,C]
+        origin = self._depth_origin()
+        p_host = p.detach().float().cpu().numpy()
+        pc_ply = data.get('inputs.pc_ply').float().cpu().numpy()
+        touch = data.get('inputs.touch_success').cpu().numpy()
+        depths_host = depths.detach().float().cpu().numpy()
+        p_sample = np.zeros((B, S, 3), dtype=np.float32)
+        finger = np.full((B, S), -1, dtype=np.int64)
+        for b in range(B):
+            anchors, count = contact_clouds_from_depth(depths_host[b], origin, cam_pos[b].cpu().numpy(), cam_rot[b].cpu().numpy(),
+                                                       pc_ply[b], touch[b])
+            k = 0
+            for t in range(5):
+                n = int(count[t])
+                if touch[b][t]:
+                    if k + n > S:
+                        raise VtError(f"Trainer.compute_loss_t2d_img: {k + n} contact points do not fit num_sample = {S}")
+                    p_sample[b, k:k + n] = anchors[t, :n].astype(np.float32)
+                    finger[b, k:k + n] = t
+                    k += n
+            p_sample[b, k:] = p_host[b][np.random.randint(N, size=S - k)]
+        p_sample_t = torch.from_numpy(p_sample).to(dev)
+        finger_t = torch.from_numpy(finger).to(dev)
+        names = data.get('points.name')
+        occ_new = torch.stack([ops.winding_number(torch.as_tensor(vf_dict[names[b]]['v']).to(dev),
+                                                  torch.as_tensor(np.asarray(vf_dict[names[b]]['f']).astype(np.int32)).to(dev),
+                                                  p_sample_t[b]) for b in range(B)])
+        feat = torch.gather(c_img, 1, finger_t.clamp(min=0).unsqueeze(-1).expand(-1, -1, c_img.shape[2]))
+        has = (finger_t >= 0).unsqueeze(-1)
+        c_img_all = torch.where(has, feat, torch.ones_like(feat))                             # ones where there is no touch
+        c = self.model.encode_inputs(inputs)
+        c_hand = self.model.encode_hand_inputs(inputs)
+        logits = self.model.decode_img(p_sample_t, c, c_img_all).logits
+        loss_l1 = F.l1_loss(logits, occ_new)
+        loss_mano = F.mse_loss(c_hand['mano_param'], data.get('points.mano').to(dev).float())
+        loss_pc = F.mse_loss(c_hand['mano_verts'], data.get('points.pc_hand').to(dev).float())
+        loss = loss_l1 + loss_mano + loss_pc
+        if not self.pretrained_t2d:
+            d = depths.float()
+            d = (d - d.min()) / (d.max() - d.min())
+            cam_info = torch.cat((cam_pos.reshape(B, -1), cam_rot.reshape(B, -1)), dim=1).to(dev).float()
+            loss = loss + F.l1_loss(pred_depth, d) + F.mse_loss(digit_param, cam_info)
+        return loss, loss_mano, loss_pc
+
     def train_step(self, data, vf_dict=None):
         self.model.train()
         self.optimizer.zero_grad()
-        loss, loss_mano, loss_pc = self.compute_loss_img(data) if self.with_img else self.compute_loss(data)
+        if self.with_img and self.encode_t2d:
+            if vf_dict is None:
+                raise VtError("Trainer.train_step: the VTacO branch needs vf_dict (object meshes by name, vtaco_amd.data.load_mesh_dict)")
+            loss, loss_mano, loss_pc = self.compute_loss_t2d_img(data, vf_dict)
+        else:
+            loss, loss_mano, loss_pc = self.compute_loss_img(data) if self.with_img else self.compute_loss(data)
         loss.backward()
         if self.grad_sync is not None:
             self.grad_sync()

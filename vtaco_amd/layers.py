@@ -100,3 +100,68 @@ class TactileUNet(nn.Module):
         for i, up in enumerate(self.up_convs):
             x = up(skips[-(i + 2)], x)
         return torch.sigmoid(self.conv_final(x)) * 1
+
+
+class _ResidualPair(nn.Module):
+    """Two 3x3 conv + BatchNorm stages with an identity (or 1x1-projected) skip: the basic ResNet block
+    (reference ``BasicBlock``, src/layers.py:52-82; parameter names conv1/bn1/conv2/bn2/downsample)."""
+    expansion = 1
+
+    def __init__(self, in_channel, out_channel, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channel, out_channel, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(out_channel)
+        self.conv2 = nn.Conv2d(out_channel, out_channel, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(out_channel)
+        self.downsample = downsample
+
+    def forward(self, x):
+        skip = x if self.downsample is None else self.downsample(x)
+        y = self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))
+        return F.relu(y + skip)
+
+
+class TactileResNet(nn.Module):
+    """Tactile feature encoder of the shipped VTacO / VTacOH configs (``encoder_img: Resnet18``; reference ``ResNet`` with
+    BasicBlocks, src/layers.py:127-195): 7x7/2 stem, 3x3/2 max-pool, four stages of residual pairs (64, 128, 256, 512; stride 2
+    from the second), global average pool, Linear(512, 100), Linear(100, num_classes) -- no activation between the two.
+    Host PyTorch-ROCm (MIOpen), like the tactile depth U-Net: five 320x240 images per scene."""
+
+    def __init__(self, blocks_num=(2, 2, 2, 2), num_classes=32):
+        super().__init__()
+        self.in_channel = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.layer1 = self._stage(64, blocks_num[0], 1)
+        self.layer2 = self._stage(128, blocks_num[1], 2)
+        self.layer3 = self._stage(256, blocks_num[2], 2)
+        self.layer4 = self._stage(512, blocks_num[3], 2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.linear = nn.Linear(512, 100)
+        self.fc = nn.Linear(100, num_classes)
+        for m in self.modules():                                       # src/layers.py:150-152
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+    def _stage(self, channel, count, stride):
+        project = None
+        if stride != 1 or self.in_channel != channel:
+            project = nn.Sequential(nn.Conv2d(self.in_channel, channel, 1, stride=stride, bias=False), nn.BatchNorm2d(channel))
+        blocks = [_ResidualPair(self.in_channel, channel, stride=stride, downsample=project)]
+        self.in_channel = channel
+        blocks += [_ResidualPair(channel, channel) for _ in range(1, count)]
+        return nn.Sequential(*blocks)
+
+    def forward(self, x):
+        x = self.maxpool(F.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.fc(self.linear(torch.flatten(self.avgpool(x), 1)))
+
+
+def Resnet18(num_classes=32):
+    return TactileResNet((2, 2, 2, 2), num_classes=num_classes)
+
+
+def Resnet34(num_classes=32):
+    return TactileResNet((3, 4, 6, 3), num_classes=num_classes)

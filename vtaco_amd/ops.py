@@ -340,6 +340,20 @@ def voxel_scatter_mean_bwd(grad_grid, vi, C):
 
 
 # --------------------------------------------------------------------------------------
+# generalized winding number (vt_winding_number)
+# --------------------------------------------------------------------------------------
+def winding_number(verts, faces, pts):
+    """w(q) of every query point pts [..., 3] against the mesh (verts [V,3] f32, faces [F,3] int): 1 inside a closed,
+    outward-oriented mesh, 0 outside (the exact sum igl.fast_winding_number_for_meshes approximates)."""
+    verts, pts = _c(verts.float()), _c(pts.float())
+    faces = _c(faces.to(I32))
+    out = torch.empty(pts.shape[:-1], dtype=torch.float32, device=pts.device)
+    check(_lib.load().vt_winding_number(dev_ptr(verts, "verts"), verts.shape[0], dev_ptr(faces, "faces", I32), faces.shape[0],
+                                        dev_ptr(pts, "pts"), pts.numel() // 3, dev_ptr(out, "out"), stream_ptr()), "vt_winding_number")
+    return out
+
+
+# --------------------------------------------------------------------------------------
 # PointNet per-point MLP, inference (vt_linear_rows, vt_resblock_fc)
 # --------------------------------------------------------------------------------------
 def linear_rows(x, weight, bias=None):
