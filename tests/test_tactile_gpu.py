@@ -353,3 +353,38 @@ def test_trainer_vtaco_t2d_step_with_the_shipped_module_types(tmp_path):
     from vtaco_amd._lib import VtError
     with pytest.raises(VtError, match="vf_dict"):
         trainer.train_step(batch)
+
+
+def test_trainer_train_tactile_step():
+    """The t2d net trained on its own (training.py:950-986): depth L1 + digit-pose MSE, against the same two terms written out."""
+    import numpy as np
+    from vtaco_amd.conv_onet.models import ConvolutionalOccupancyNetwork
+    from vtaco_amd.conv_onet.training import Trainer
+    from vtaco_amd.encoder import encoder_dict
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    depth_net = encoder_dict["UNet"](num_classes=1, in_channels=3, depth=2, start_filts=8)
+    digits = encoder_dict["pointnet_local_pool"](dim=3, c_dim=16, padding=0.1, hidden_dim=32, plane_type=["xz", "xy", "yz"],
+                                                 plane_resolution=32, unet=False, out_mano=True, out_dim=30)
+    model = ConvolutionalOccupancyNetwork(None, None, digits, depth_net, None, device=dev)
+    g = torch.Generator().manual_seed(2)
+    data = {"inputs": torch.randn(2, 300, 3, generator=g) * 0.2, "inputs.img": torch.rand(2, 5, 3, 16, 12, generator=g),
+            "inputs.depth": 0.019 + 0.003 * torch.rand(2, 5, 16 * 12, generator=g), "points.cam_pos": torch.randn(2, 5, 3, generator=g) * 0.1,
+            "points.cam_rot": torch.randn(2, 5, 3, generator=g)}
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    trainer = Trainer(model, opt, device=dev, train_tactile=True)
+    model.train()
+    loss, ld, lg = trainer.compute_loss_tactile(data)
+    d = data["inputs.depth"].to(dev)
+    d = (d - d.min()) / (d.max() - d.min())
+    ref_d = torch.nn.functional.l1_loss(model.encode_img_inputs(data["inputs.img"].to(dev)), d)
+    ref_g = torch.nn.functional.mse_loss(model.encode_hand_inputs(data["inputs"].to(dev))["mano_param"],
+                                         torch.cat((data["points.cam_pos"].reshape(2, -1), data["points.cam_rot"].reshape(2, -1)), 1).to(dev))
+    f = lambda t: float(t.detach())
+    assert abs(f(ld) - f(ref_d)) <= 1e-6 and abs(f(lg) - f(ref_g)) <= 1e-6 and abs(f(loss) - f(ref_d + ref_g)) <= 1e-6
+    first = trainer.train_step(data)
+    for _ in range(10):
+        last = trainer.train_step(data)
+    assert len(first) == 3 and last[0] < first[0]
+    model.encoder_hand = None
+    assert len(Trainer(model, torch.optim.Adam(model.parameters(), lr=1e-3), device=dev, train_tactile=True).train_step(data)) == 2

@@ -53,7 +53,8 @@ def get_trainer(model, optimizer, cfg, device, **kwargs):
     return Trainer(model, optimizer, device=device, input_type=cfg['data']['input_type'],
                    threshold=cfg['test']['threshold'], num_sample=cfg['data'].get('num_sample', 2048),
                    with_img=cfg['model'].get('with_img', False),
-                   with_contact=cfg['model'].get('with_contact', False), encode_t2d=bool(cfg['model'].get('encoder_t2d', False)),
+                   with_contact=cfg['model'].get('with_contact', False), train_tactile=cfg['model'].get('train_tactile', False),
+                   encode_t2d=bool(cfg['model'].get('encoder_t2d', False)),
                    pretrained_t2d=(cfg['model'].get('encoder_t2d_kwargs') or {}).get('pretrained', True),
                    depth_origin=kwargs.get('depth_origin'))
 

@@ -30,10 +30,11 @@ class Trainer:
     def __init__(self, model, optimizer, device=None, input_type='pointcloud', vis_dir=None, threshold=0.5,
                  eval_sample=False, num_sample=2048, with_img=False, with_contact=False, train_tactile=False,
                  encode_t2d=False, pretrained_t2d=True, grad_sync=None, depth_origin=None):
-        if with_contact or train_tactile or (encode_t2d and not with_img):
+        if with_contact or (encode_t2d and not with_img and not train_tactile):
             raise VtError("Trainer: built are the visual branch (compute_loss), the VTacOH tactile branch (with_img: "
-                          "compute_loss_img) and the VTacO branch (with_img + encode_t2d: compute_loss_t2d_img); with_contact, "
-                          "train_tactile and encode_t2d without with_img are not")
+                          "compute_loss_img), the VTacO branch (with_img + encode_t2d: compute_loss_t2d_img) and the t2d net's own "
+                          "training (train_tactile: compute_loss_tactile); with_contact and encode_t2d without with_img are not")
+        self.train_tactile = train_tactile
         self.model, self.optimizer, self.device = model, optimizer, device
         self.input_type, self.threshold = input_type, threshold
         self.with_img, self.num_sample = with_img, num_sample
@@ -208,9 +209,33 @@ class Trainer:
             loss = loss + F.l1_loss(pred_depth, d) + F.mse_loss(digit_param, cam_info)
         return loss, loss_mano, loss_pc
 
+    def compute_loss_tactile(self, data):
+        """(loss, loss_depth, loss_digit) of the t2d net trained on its own (training.py:950-986; the model is the t2d
+        ``ConvolutionalOccupancyNetwork``: depth U-Net as encoder_img, digit-pose regressor as encoder_hand): L1 between the
+        predicted depth images and the batch-normalised ground truth, MSE between the regressed digit poses and the cameras'.
+        ``loss_digit`` is None without a hand encoder."""
+        dev = self.device
+        inputs = data.get('inputs').to(dev)
+        depths = data.get('inputs.depth').to(dev).float()
+        B = inputs.shape[0]
+        depths = (depths - depths.min()) / (depths.max() - depths.min())
+        loss_depth = F.l1_loss(self.model.encode_img_inputs(data.get('inputs.img').to(dev)), depths)
+        if getattr(self.model, 'encoder_hand', None) is None:
+            return loss_depth, loss_depth, None
+        cam_info = torch.cat((data.get('points.cam_pos').reshape(B, -1), data.get('points.cam_rot').reshape(B, -1)), dim=1).to(dev).float()
+        loss_digit = F.mse_loss(self.model.encode_hand_inputs(inputs)['mano_param'], cam_info)
+        return loss_depth + loss_digit, loss_depth, loss_digit
+
     def train_step(self, data, vf_dict=None):
         self.model.train()
         self.optimizer.zero_grad()
+        if self.train_tactile:
+            loss, loss_depth, loss_digit = self.compute_loss_tactile(data)
+            loss.backward()
+            if self.grad_sync is not None:
+                self.grad_sync()
+            self.optimizer.step()
+            return (loss.item(), loss_depth.item(), loss_digit.item()) if loss_digit is not None else (loss.item(), loss_depth.item())
         if self.with_img and self.encode_t2d:
             if vf_dict is None:
                 raise VtError("Trainer.train_step: the VTacO branch needs vf_dict (object meshes by name, vtaco_amd.data.load_mesh_dict)")
