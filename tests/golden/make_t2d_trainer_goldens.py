@@ -66,7 +66,7 @@ def main():
     digit = torch.randn(B, 30, generator=g) * 0.3
     mano_gt = torch.randn(B, 51, generator=g) * 0.2
     pc_hand = torch.randn(B, 778, 3, generator=g) * 0.05
-    data = {"points": p, "points.occ": torch.zeros(B, N), "points.mano": mano_gt, "points.pc_hand": pc_hand,
+    data = {"points": p, "points.occ": torch.zeros(B, N), "points.mano": mano_gt, "points.pc_hand": pc_hand, "points.wrist": torch.zeros(B, 3),
             "points.name": ["cube", "tet"], "points.cam_pos": cam_pos, "points.cam_rot": cam_rot,
             "inputs": torch.zeros(B, 16, 3), "inputs.pc_ply": pc_ply, "inputs.img": torch.zeros(B, 5, 3, 8, 6),
             "inputs.depth": depths, "inputs.touch_success": touch}
@@ -84,6 +84,10 @@ def main():
 
         def encode_img_inputs(self, imgs):
             return c_img
+
+        def decode(self, p_sample, c, **kw):
+            seen["p_sample_plain"] = p_sample.detach().clone()
+            return types.SimpleNamespace(logits=p_sample.sum(-1) * 0.5)
 
         def decode_img(self, p_sample, c, c_img_all, **kw):
             seen["p_sample"], seen["c_img_all"] = p_sample.detach().clone(), c_img_all.detach().clone()
@@ -112,6 +116,18 @@ def main():
         losses[pretrained] = [float(x) for x in out]
         if pretrained:
             seen["occ_new"] = calls[0]
+    # the variant without tactile features (compute_loss_t2d, training.py:628-755): same assembly, plain decode
+    plain = {}
+    for pretrained in (True, False):
+        trainer = training.Trainer(FakeModel(), None, device="cpu", num_sample=NS, with_img=False, encode_t2d=True, pretrained_t2d=pretrained)
+        np.random.seed(77)
+        torch.Tensor.to = lambda self, *a, **k: (to(self, *a, **k).clone() if self.is_leaf and self.requires_grad else to(self, *a, **k))
+        try:
+            plain[pretrained] = [float(x) for x in trainer.compute_loss_t2d(data, meshes())]
+        finally:
+            torch.Tensor.to = to
+    # (that variant normalises the depth images to [0,1] BEFORE looking for contact pixels -- training.py:643-644 -- so nearly every
+    # pixel "touches" and its samples differ from the with_img variant's)
     ones_rows = (seen["c_img_all"] == 1).all(-1).sum(1)
     print("rows without a tactile feature (ones):", ones_rows.tolist(), "losses", losses)
     m = meshes()
@@ -119,7 +135,8 @@ def main():
              touch=touch.numpy(), c_img=c_img.numpy(), digit=digit.numpy(),
              mano=mano_gt.numpy(), pc_hand=pc_hand.numpy(), mano_param=hand["mano_param"].numpy(), mano_verts=hand["mano_verts"].numpy(),
              p_sample=seen["p_sample"].numpy(), c_img_all=seen["c_img_all"].numpy(), occ_new=seen["occ_new"].numpy(),
-             loss_pretrained=np.array(losses[True]), loss_joint=np.array(losses[False]), num_sample=np.array(NS), seed=np.array(77),
+             loss_pretrained=np.array(losses[True]), loss_joint=np.array(losses[False]),
+             loss_plain_pretrained=np.array(plain[True]), loss_plain_joint=np.array(plain[False]), p_sample_plain=seen["p_sample_plain"].numpy(), num_sample=np.array(NS), seed=np.array(77),
              cube_v=m["cube"]["v"], cube_f=m["cube"]["f"], tet_v=m["tet"]["v"], tet_f=m["tet"]["f"])
 
 

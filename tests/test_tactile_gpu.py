@@ -269,6 +269,10 @@ def test_trainer_compute_loss_t2d_img_matches_the_reference_trainer():
         def encode_img_inputs(self, imgs):
             return t("c_img")
 
+        def decode(self, p_sample, c, **kw):
+            seen["p_sample_plain"] = p_sample
+            return types.SimpleNamespace(logits=p_sample.sum(-1) * 0.5)
+
         def decode_img(self, p_sample, c, c_img_all, **kw):
             seen["p_sample"], seen["c_img_all"] = p_sample, c_img_all
             return types.SimpleNamespace(logits=p_sample.sum(-1) * 0.5 + c_img_all.sum(-1) * 0.01)
@@ -288,6 +292,19 @@ def test_trainer_compute_loss_t2d_img_matches_the_reference_trainer():
             np.random.set_state(state)
         assert torch.equal(seen["p_sample"].cpu(), torch.from_numpy(z["p_sample"]))
         assert torch.equal(seen["c_img_all"].cpu(), torch.from_numpy(z["c_img_all"]))
+        for got, ref in zip(out, z[key]):
+            assert abs(float(got) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), (key, float(got), float(ref))
+    # the variant without tactile features (compute_loss_t2d): it normalises the depth images before looking for contact pixels
+    for pretrained, key in ((True, "loss_plain_pretrained"), (False, "loss_plain_joint")):
+        trainer = Trainer(StandIn(), None, device=dev, num_sample=int(z["num_sample"]), with_img=False, encode_t2d=True,
+                          pretrained_t2d=pretrained, depth_origin=z12["depth_origin"])
+        state = np.random.get_state()
+        try:
+            np.random.seed(int(z["seed"]))
+            out = trainer.compute_loss_t2d(data, vf)
+        finally:
+            np.random.set_state(state)
+        assert torch.equal(seen["p_sample_plain"].cpu(), torch.from_numpy(z["p_sample_plain"]))
         for got, ref in zip(out, z[key]):
             assert abs(float(got) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), (key, float(got), float(ref))
 

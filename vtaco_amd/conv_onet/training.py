@@ -30,10 +30,10 @@ class Trainer:
     def __init__(self, model, optimizer, device=None, input_type='pointcloud', vis_dir=None, threshold=0.5,
                  eval_sample=False, num_sample=2048, with_img=False, with_contact=False, train_tactile=False,
                  encode_t2d=False, pretrained_t2d=True, grad_sync=None, depth_origin=None):
-        if with_contact or (encode_t2d and not with_img and not train_tactile):
+        if with_contact:
             raise VtError("Trainer: built are the visual branch (compute_loss), the VTacOH tactile branch (with_img: "
-                          "compute_loss_img), the VTacO branch (with_img + encode_t2d: compute_loss_t2d_img) and the t2d net's own "
-                          "training (train_tactile: compute_loss_tactile); with_contact and encode_t2d without with_img are not")
+                          "compute_loss_img), the VTacO branches (encode_t2d: compute_loss_t2d_img / compute_loss_t2d) and the t2d "
+                          "net's own training (train_tactile: compute_loss_tactile); with_contact is not")
         self.train_tactile = train_tactile
         self.model, self.optimizer, self.device = model, optimizer, device
         self.input_type, self.threshold = input_type, threshold
@@ -145,13 +145,9 @@ class Trainer:
             self.depth_origin = src
         return np.asarray(src, dtype=np.float64).reshape(-1)
 
-    def compute_loss_t2d_img(self, data, vf_dict):
-        """(loss, loss_mano, loss_pc) of the VTacO step.  Per scene the contact clouds of the successful touches
-        (vtaco_amd.common.contact_clouds_from_depth: the sample's depth images against the sensor's flat reading, the reference's
-        numpy draws) are the first query points and carry their finger's tactile feature; the rest are ``randint`` draws from
-        the scene's points and carry ONES, as in the reference; every row's occupancy target is the winding number of the
-        scene's mesh ``vf_dict[name]`` -- vt_winding_number, the exact sum where the reference calls libigl's fast
-        approximation.  With ``pretrained_t2d=False`` the depth and digit-pose losses of the t2d net are added (:887-891)."""
+    def _t2d_samples(self, data, vf_dict, normalise_depth):
+        """Query points, finger per row and winding-number targets of a VTacO step (training.py:809-866 / 672-733), plus the t2d
+        net's outputs and the depth images as the calling variant uses them."""
         from .. import ops
         from ..common import contact_clouds_from_depth
         dev = self.device
@@ -160,17 +156,17 @@ class Trainer:
         S = self.num_sample
         inputs = data.get('inputs').to(dev)
         imgs = data.get('inputs.img').to(dev)
-        depths = data.get('inputs.depth').to(dev)
+        depths = data.get('inputs.depth').to(dev).float()
+        if normalise_depth:
+            depths = (depths - depths.min()) / (depths.max() - depths.min())
         cam_pos = data.get('points.cam_pos').reshape(B, 5, 3)
         cam_rot = data.get('points.cam_rot').reshape(B, 5, 3)
         pred_depth, c_hand_d = self.model.encode_t2d(inputs, imgs)
-        digit_param = c_hand_d['mano_param']
-        c_img = self.model.encode_img_inputs(imgs)                                          # [B,5,C]
         origin = self._depth_origin()
         p_host = p.detach().float().cpu().numpy()
         pc_ply = data.get('inputs.pc_ply').float().cpu().numpy()
         touch = data.get('inputs.touch_success').cpu().numpy()
-        depths_host = depths.detach().float().cpu().numpy()
+        depths_host = depths.detach().cpu().numpy()
         p_sample = np.zeros((B, S, 3), dtype=np.float32)
         finger = np.full((B, S), -1, dtype=np.int64)
         for b in range(B):
@@ -181,33 +177,54 @@ class Trainer:
                 n = int(count[t])
                 if touch[b][t]:
                     if k + n > S:
-                        raise VtError(f"Trainer.compute_loss_t2d_img: {k + n} contact points do not fit num_sample = {S}")
+                        raise VtError(f"Trainer: {k + n} contact points do not fit num_sample = {S}")
                     p_sample[b, k:k + n] = anchors[t, :n].astype(np.float32)
                     finger[b, k:k + n] = t
                     k += n
             p_sample[b, k:] = p_host[b][np.random.randint(N, size=S - k)]
         p_sample_t = torch.from_numpy(p_sample).to(dev)
-        finger_t = torch.from_numpy(finger).to(dev)
         names = data.get('points.name')
         occ_new = torch.stack([ops.winding_number(torch.as_tensor(vf_dict[names[b]]['v']).to(dev),
                                                   torch.as_tensor(np.asarray(vf_dict[names[b]]['f']).astype(np.int32)).to(dev),
                                                   p_sample_t[b]) for b in range(B)])
-        feat = torch.gather(c_img, 1, finger_t.clamp(min=0).unsqueeze(-1).expand(-1, -1, c_img.shape[2]))
-        has = (finger_t >= 0).unsqueeze(-1)
-        c_img_all = torch.where(has, feat, torch.ones_like(feat))                             # ones where there is no touch
-        c = self.model.encode_inputs(inputs)
-        c_hand = self.model.encode_hand_inputs(inputs)
-        logits = self.model.decode_img(p_sample_t, c, c_img_all).logits
-        loss_l1 = F.l1_loss(logits, occ_new)
+        cam_info = torch.cat((cam_pos.reshape(B, -1), cam_rot.reshape(B, -1)), dim=1).to(dev).float()
+        return {'inputs': inputs, 'imgs': imgs, 'p_sample': p_sample_t, 'finger': torch.from_numpy(finger).to(dev), 'occ': occ_new,
+                'pred_depth': pred_depth, 'digit': c_hand_d['mano_param'], 'depths': depths, 'cam_info': cam_info}
+
+    def _t2d_losses(self, data, s, logits, depth_target):
+        dev = self.device
+        c_hand = self.model.encode_hand_inputs(s['inputs'])
         loss_mano = F.mse_loss(c_hand['mano_param'], data.get('points.mano').to(dev).float())
         loss_pc = F.mse_loss(c_hand['mano_verts'], data.get('points.pc_hand').to(dev).float())
-        loss = loss_l1 + loss_mano + loss_pc
+        loss = F.l1_loss(logits, s['occ']) + loss_mano + loss_pc
         if not self.pretrained_t2d:
-            d = depths.float()
-            d = (d - d.min()) / (d.max() - d.min())
-            cam_info = torch.cat((cam_pos.reshape(B, -1), cam_rot.reshape(B, -1)), dim=1).to(dev).float()
-            loss = loss + F.l1_loss(pred_depth, d) + F.mse_loss(digit_param, cam_info)
+            loss = loss + F.l1_loss(s['pred_depth'], depth_target) + F.mse_loss(s['digit'], s['cam_info'])
         return loss, loss_mano, loss_pc
+
+    def compute_loss_t2d_img(self, data, vf_dict):
+        """(loss, loss_mano, loss_pc) of the VTacO step.  Per scene the contact clouds of the successful touches
+        (vtaco_amd.common.contact_clouds_from_depth: the sample's depth images against the sensor's flat reading, the reference's
+        numpy draws) are the first query points and carry their finger's tactile feature; the rest are ``randint`` draws from
+        the scene's points and carry ONES, as in the reference; every row's occupancy target is the winding number of the
+        scene's mesh ``vf_dict[name]`` -- vt_winding_number, the exact sum where the reference calls libigl's fast
+        approximation.  With ``pretrained_t2d=False`` the depth and digit-pose losses of the t2d net are added (:887-891)."""
+        s = self._t2d_samples(data, vf_dict, normalise_depth=False)
+        c_img = self.model.encode_img_inputs(s['imgs'])                                     # [B,5,C]
+        feat = torch.gather(c_img, 1, s['finger'].clamp(min=0).unsqueeze(-1).expand(-1, -1, c_img.shape[2]))
+        c_img_all = torch.where((s['finger'] >= 0).unsqueeze(-1), feat, torch.ones_like(feat))   # ones where there is no touch
+        c = self.model.encode_inputs(s['inputs'])
+        logits = self.model.decode_img(s['p_sample'], c, c_img_all).logits
+        d = s['depths']
+        return self._t2d_losses(data, s, logits, (d - d.min()) / (d.max() - d.min()))
+
+    def compute_loss_t2d(self, data, vf_dict):
+        """The VTacO step without tactile features (training.py:628-755): the same sample assembly decoded by the plain decoder.
+        As in the reference this variant normalises the depth images to [0, 1] BEFORE looking for contact pixels (:643-644), so
+        nearly every pixel counts as touched -- reproduced as is."""
+        s = self._t2d_samples(data, vf_dict, normalise_depth=True)
+        c = self.model.encode_inputs(s['inputs'])
+        logits = self.model.decode(s['p_sample'], c).logits
+        return self._t2d_losses(data, s, logits, s['depths'])
 
     def compute_loss_tactile(self, data):
         """(loss, loss_depth, loss_digit) of the t2d net trained on its own (training.py:950-986; the model is the t2d
@@ -236,10 +253,10 @@ class Trainer:
                 self.grad_sync()
             self.optimizer.step()
             return (loss.item(), loss_depth.item(), loss_digit.item()) if loss_digit is not None else (loss.item(), loss_depth.item())
-        if self.with_img and self.encode_t2d:
+        if self.encode_t2d:
             if vf_dict is None:
                 raise VtError("Trainer.train_step: the VTacO branch needs vf_dict (object meshes by name, vtaco_amd.data.load_mesh_dict)")
-            loss, loss_mano, loss_pc = self.compute_loss_t2d_img(data, vf_dict)
+            loss, loss_mano, loss_pc = (self.compute_loss_t2d_img if self.with_img else self.compute_loss_t2d)(data, vf_dict)
         else:
             loss, loss_mano, loss_pc = self.compute_loss_img(data) if self.with_img else self.compute_loss(data)
         loss.backward()
