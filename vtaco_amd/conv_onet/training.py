@@ -30,11 +30,9 @@ class Trainer:
     def __init__(self, model, optimizer, device=None, input_type='pointcloud', vis_dir=None, threshold=0.5,
                  eval_sample=False, num_sample=2048, with_img=False, with_contact=False, train_tactile=False,
                  encode_t2d=False, pretrained_t2d=True, grad_sync=None, depth_origin=None):
-        if with_contact:
-            raise VtError("Trainer: built are the visual branch (compute_loss), the VTacOH tactile branch (with_img: "
-                          "compute_loss_img), the VTacO branches (encode_t2d: compute_loss_t2d_img / compute_loss_t2d) and the t2d "
-                          "net's own training (train_tactile: compute_loss_tactile); with_contact is not")
-        self.train_tactile = train_tactile
+        if with_contact and (encode_t2d or train_tactile):
+            raise VtError("Trainer: with_contact combines with the visual / VTacOH branches only (as the reference's train_step)")
+        self.train_tactile, self.with_contact = train_tactile, with_contact
         self.model, self.optimizer, self.device = model, optimizer, device
         self.input_type, self.threshold = input_type, threshold
         self.with_img, self.num_sample = with_img, num_sample
@@ -226,6 +224,24 @@ class Trainer:
         logits = self.model.decode(s['p_sample'], c).logits
         return self._t2d_losses(data, s, logits, s['depths'])
 
+    def compute_loss_contact(self, data):
+        """(loss, loss_mano, loss_pc, loss_contact) with the decoder's contact head (training.py:896-948): L1 on the occupancy
+        logits + binary cross-entropy of the contact logits against ``points.contact`` + the hand terms."""
+        dev = self.device
+        p = data.get('points').to(dev)
+        inputs = data.get('inputs').to(dev)
+        c = self.model.encode_inputs(inputs)
+        p_r, pred_contact = self.model.decode_contact(p, c)
+        loss_l1 = F.l1_loss(p_r.logits, data.get('points.occ').to(dev))
+        loss_contact = F.binary_cross_entropy_with_logits(pred_contact, data.get('points.contact').to(dev).float(), reduction='mean')
+        zero = loss_l1.new_zeros(())
+        loss_mano = loss_pc = zero
+        if getattr(self.model, 'encoder_hand', None) is not None:
+            c_hand = self.model.encode_hand_inputs(inputs)
+            loss_mano = F.mse_loss(c_hand['mano_param'], data.get('points.mano').to(dev).float())
+            loss_pc = F.mse_loss(c_hand['mano_verts'], data.get('points.pc_hand').to(dev).float())
+        return loss_contact + loss_l1 + loss_mano + loss_pc, loss_mano, loss_pc, loss_contact
+
     def compute_loss_tactile(self, data):
         """(loss, loss_depth, loss_digit) of the t2d net trained on its own (training.py:950-986; the model is the t2d
         ``ConvolutionalOccupancyNetwork``: depth U-Net as encoder_img, digit-pose regressor as encoder_hand): L1 between the
@@ -253,6 +269,13 @@ class Trainer:
                 self.grad_sync()
             self.optimizer.step()
             return (loss.item(), loss_depth.item(), loss_digit.item()) if loss_digit is not None else (loss.item(), loss_depth.item())
+        if self.with_contact:
+            loss, loss_mano, loss_pc, loss_contact = self.compute_loss_contact(data)
+            loss.backward()
+            if self.grad_sync is not None:
+                self.grad_sync()
+            self.optimizer.step()
+            return loss.item(), loss_mano.item(), loss_pc.item(), loss_contact.item()
         if self.encode_t2d:
             if vf_dict is None:
                 raise VtError("Trainer.train_step: the VTacO branch needs vf_dict (object meshes by name, vtaco_amd.data.load_mesh_dict)")
