@@ -2,7 +2,7 @@
 // its re-sampled query points with igl.fast_winding_number_for_meshes(V, F, Q) (src/conv_onet/training.py:723, 862) -- libigl's
 // hierarchical APPROXIMATION of w(q) = 1/(4 pi) sum_f Omega_f(q).  libigl is an un-vendored dependency that is absent here, so
 // this kernel evaluates the exact sum it approximates (Van Oosterom-Strackee solid angles, float64): 1 inside a closed,
-// outward-oriented mesh, 0 outside, fractional for open meshes.  Thread per query point, faces through LDS in tiles.
+// outward-oriented mesh, 0 outside, fractional for open meshes.  Sixteen lanes per query point, faces through LDS in tiles.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -12,11 +12,14 @@
 namespace {
 
 constexpr int WN_THREADS = 256;
+constexpr int WN_SUB = 16;                       // lanes per query point: each takes every 16th face of a tile
+constexpr int WN_POINTS = WN_THREADS / WN_SUB;   // 16 points per workgroup (a training step has ~16 k points: 1024 workgroups)
 
 __global__ void __launch_bounds__(WN_THREADS)
 winding_kernel(const float *verts, int V, const int32_t *faces, int F, const float *pts, int64_t N, float *out) {
     __shared__ float tri[WN_THREADS][9];
-    const int64_t n = (int64_t)blockIdx.x * WN_THREADS + threadIdx.x;
+    const int sub = threadIdx.x % WN_SUB;
+    const int64_t n = (int64_t)blockIdx.x * WN_POINTS + threadIdx.x / WN_SUB;
     double px = 0, py = 0, pz = 0;
     if (n < N) { px = pts[3 * n]; py = pts[3 * n + 1]; pz = pts[3 * n + 2]; }
     double sum = 0.0;
@@ -33,7 +36,7 @@ winding_kernel(const float *verts, int V, const int32_t *faces, int F, const flo
         }
         __syncthreads();
         const int cnt = min(WN_THREADS, F - f0);
-        for (int j = 0; j < cnt; ++j) {
+        for (int j = sub; j < cnt; j += WN_SUB) {
             const float *t = tri[j];
             const double ax = t[0] - px, ay = t[1] - py, az = t[2] - pz;
             const double bx = t[3] - px, by = t[4] - py, bz = t[5] - pz;
@@ -45,7 +48,9 @@ winding_kernel(const float *verts, int V, const int32_t *faces, int F, const flo
             sum += 2.0 * atan2(num, den);
         }
     }
-    if (n < N) out[n] = (float)(sum / (4.0 * 3.14159265358979323846));
+    // the 16 partial sums of a point, combined in a fixed butterfly order (deterministic)
+    for (int o = WN_SUB / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (n < N && sub == 0) out[n] = (float)(sum / (4.0 * 3.14159265358979323846));
 }
 
 }  // namespace
@@ -55,7 +60,7 @@ extern "C" {
 int vt_winding_number(const float *verts, int V, const int32_t *faces, int F, const float *pts, int64_t N, float *out, void *stream) {
     if (N == 0) return 0;
     if (!verts || !faces || !pts || !out || V <= 0 || F < 0 || N < 0) return vt_fail(VT_ERR_INVALID, "vt_winding_number: bad argument");
-    hipLaunchKernelGGL(winding_kernel, dim3((unsigned)((N + WN_THREADS - 1) / WN_THREADS)), dim3(WN_THREADS), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(winding_kernel, dim3((unsigned)((N + WN_POINTS - 1) / WN_POINTS)), dim3(WN_THREADS), 0, (hipStream_t)stream,
                        verts, V, faces, F, pts, N, out);
     return vt_check(hipGetLastError(), "vt_winding_number");
 }
