@@ -329,6 +329,9 @@ def test_trainer_vtacoh_step_on_synthetic_dataset(tmp_path):
     assert all(np.isfinite(x) for x in first) and last[0] < first[0], (first, last)
     for name in ("encoder", "encoder_hand", "decoder"):
         assert all(p.grad is not None for n, p in getattr(model, name).named_parameters() if "fc_out_contact" not in n and "fc_p." not in n), name
+    batch["points_iou"], batch["points_iou.occ"] = batch["points"], batch["points.occ"]
+    ev = trainer.eval_step(batch)                                   # tactile-aware evaluation: features by the generator's rule
+    assert np.isfinite(ev["loss"]) and 0.0 <= ev["iou"] <= 1.0
 
 
 def test_generator_vtacoh_route_equals_dense_c_img_all(tmp_path):

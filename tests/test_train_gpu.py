@@ -38,7 +38,7 @@ def test_train_step_matches_reference_golden():
     logits = model.decode_img(T(a["pq"]).to(DEV), c, c_img).logits
     loss = torch.nn.functional.l1_loss(logits, T(a["occ"]).to(DEV))
     loss.backward()
-    assert abs(float(loss) - float(a["loss"])) <= 1e-6
+    assert abs(float(loss.detach()) - float(a["loss"])) <= 1e-6
     _close(logits, a["logits"], "logits", rel=0, floor=1e-4)
     for n, prm in model.decoder.named_parameters():
         ref = a["g.dec." + n]

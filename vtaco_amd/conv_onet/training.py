@@ -288,17 +288,57 @@ class Trainer:
         self.optimizer.step()
         return loss.item(), loss_mano.item(), loss_pc.item()
 
+    def _tactile_features_at(self, data, pts):
+        """c_img [B,N,C] for arbitrary query points with the configured tactile branch's assignment rule (the generator's:
+        nearest successful fingertip within 0.05 for VTacOH, within 0.015 of a contact point for VTacO), zeros elsewhere."""
+        from .. import ops
+        from ..common import contact_clouds_from_depth
+        dev = self.device
+        inputs = data.get('inputs').to(dev)
+        B = pts.shape[0]
+        c_img = self.model.encode_img_inputs(data.get('inputs.img').to(dev))
+        touch = data.get('inputs.touch_success')
+        if self.encode_t2d:
+            origin = self._depth_origin()
+            cam_pos, cam_rot = data.get('points.cam_pos').reshape(B, 5, 3), data.get('points.cam_rot').reshape(B, 5, 3)
+            ids = []
+            for b in range(B):
+                anchors, count = contact_clouds_from_depth(data.get('inputs.depth')[b].float().cpu().numpy(), origin, cam_pos[b].cpu().numpy(),
+                                                           cam_rot[b].cpu().numpy(), data.get('inputs.pc_ply')[b].float().cpu().numpy(),
+                                                           touch[b].cpu().numpy())
+                ids.append(ops.tactile_assign(torch.from_numpy(anchors).float().to(dev), torch.from_numpy((count > 0).astype(np.uint8)).to(dev),
+                                              'within', 0.015, pts=pts[b:b + 1], count=torch.from_numpy(count).int().to(dev))[0])
+        else:
+            c_hand = self.model.encode_hand_inputs(inputs)
+            tips = self.fingertips(c_hand['mano_joints'], data.get('points.mano'), data.get('points.wrist'), data.get('inputs.pc_ply'))
+            ids = [ops.tactile_assign(torch.from_numpy(tips[b]).to(dev).unsqueeze(1), touch[b].to(dev), 'nearest', 0.05, pts=pts[b:b + 1])[0]
+                   for b in range(B)]
+        ids = torch.stack(ids).long()
+        feat = torch.gather(c_img, 1, ids.clamp(max=4).unsqueeze(-1).expand(-1, -1, c_img.shape[2]))
+        return feat * (ids != 255).unsqueeze(-1).to(feat.dtype)
+
     def eval_step(self, data, vf_dict=None):
-        """{'loss', 'iou'}: L1 loss on ``points`` and the reference's IoU (compute_iou: both sides cut at the
-        mean ground-truth occupancy) on ``points_iou``."""
+        """{'loss', 'iou'}: L1 loss on ``points`` and the reference's IoU (compute_iou: both sides cut at the mean ground-truth
+        occupancy) on ``points_iou``; with ``with_img`` the query points carry tactile features assigned by the generator's rule
+        (the reference's eval_step re-labels its points with libigl winding numbers instead, training.py:105-452: not mirrored).
+        ``train_tactile``: {'loss', 'loss_depth'} of the t2d net (training.py:424-452)."""
         self.model.eval()
+        dev = self.device
         with torch.no_grad():
-            inputs = data.get('inputs').to(self.device)
+            if self.train_tactile:
+                loss, loss_depth, _ = self.compute_loss_tactile(data)
+                return {'loss': loss.item(), 'loss_depth': loss_depth.item()}
+            inputs = data.get('inputs').to(dev)
             c = self.model.encode_inputs(inputs)
-            logits = self.model.decode(data.get('points').to(self.device), c).logits
-            out = {'loss': F.l1_loss(logits, data.get('points.occ').to(self.device)).item()}
+
+            def logits_at(pts):
+                pts = pts.to(dev)
+                if self.with_img:
+                    return self.model.decode_img(pts, c, self._tactile_features_at(data, pts)).logits
+                return self.model.decode(pts, c).logits
+            out = {'loss': F.l1_loss(logits_at(data.get('points')), data.get('points.occ').to(dev)).item()}
             if data.get('points_iou') is not None:
-                occ_hat = self.model.decode(data.get('points_iou').to(self.device), c).probs
+                occ_hat = torch.sigmoid(logits_at(data.get('points_iou')))
                 occ_iou = data.get('points_iou.occ')
                 out['iou'] = float(np.mean(compute_iou(occ_hat.cpu().numpy(), occ_iou.numpy(), self.threshold)))
         return out
