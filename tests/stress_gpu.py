@@ -2,7 +2,7 @@
 Marching cubes against the C oracle on random shapes / fields / levels, the decode kernels against the torch oracle on
 random (B, N, R) and lattices, the voxeliser against the oracle on random clouds, the fusion pipeline on ragged N, the
 UNet3D forward (both conv precisions) on small volumes, the hand branch (plane ids / scatter, the PointNet MLP kernels,
-the MANO layer on random synthetic assets).  Prints a summary; exits 1 on a mismatch."""
+the MANO layer on random synthetic assets), the winding-number kernel on random triangle soups.  Prints a summary; exits 1 on a mismatch."""
 import os
 import sys
 import time
@@ -216,7 +216,20 @@ def one_hand():
         fails.append(("mano", seed, pose.shape[0], float((v.cpu() - rv).abs().max())))
 
 
-counts.update({"fusion": 0, "unet3d": 0, "hand": 0})
+def one_winding():
+    """vt_winding_number against the oracle on a random (possibly open, possibly self-intersecting) triangle soup."""
+    V, Fn, N = int(rng.randint(4, 60)), int(rng.randint(1, 300)), int(rng.randint(1, 700))
+    g = torch.Generator().manual_seed(int(rng.randint(1 << 30)))
+    verts = torch.randn(V, 3, generator=g) * 0.4
+    faces = torch.randint(0, V, (Fn, 3), generator=g)
+    pts = (torch.rand(N, 3, generator=g) - 0.5) * 1.5
+    ref = orc.winding_number(verts.numpy(), faces.numpy(), pts.numpy())
+    got = ops.winding_number(verts.to(DEV), faces.to(DEV), pts.to(DEV)).cpu().numpy()
+    if not np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()):
+        fails.append(("winding", V, Fn, N, float(np.abs(got - ref).max())))
+
+
+counts.update({"fusion": 0, "unet3d": 0, "hand": 0, "winding": 0})
 t0 = time.time()
 it = 0
 while time.time() - t0 < budget and len(fails) < 5:
@@ -225,6 +238,7 @@ while time.time() - t0 < budget and len(fails) < 5:
     if it % 4 == 0:
         jobs.append(("fusion", one_fusion))
         jobs.append(("hand", one_hand))
+        jobs.append(("winding", one_winding))
     if it % 40 == 0:
         jobs.append(("unet3d", one_unet))
     for name, fn in jobs:
