@@ -19,7 +19,7 @@ from torch import nn
 
 from .. import ops
 from .._lib import VtError
-from ..layers import ResnetBlockFC
+from ..layers import ResnetBlockFC, tall_linear
 from .manolayer import ManoLayer
 from .unet import UNet
 from .unet3d import UNet3D
@@ -139,7 +139,7 @@ class LocalPoolPointnet(nn.Module):
         ``vi``: one VoxelIndex, or a list of PlaneIndex whose pooled features are summed (pointnet.py:116-132)."""
         if not torch.is_grad_enabled() and self._fused_mlp_fits():
             return self._point_features_fused(p, vi)
-        net = self.blocks[0](self.fc_pos(p))
+        net = self.blocks[0](tall_linear(self.fc_pos, p))
         for blk in self.blocks[1:]:
             if isinstance(vi, (list, tuple)):
                 pooled = _PoolMax.apply(net, vi[0])
@@ -148,7 +148,7 @@ class LocalPoolPointnet(nn.Module):
             else:
                 pooled = _PoolMax.apply(net, vi)
             net = blk(torch.cat([net, pooled], dim=2))
-        return self.fc_c(net)
+        return tall_linear(self.fc_c, net)
 
     def _fused_mlp_fits(self):
         """vt_resblock_fc keeps a block's three weight matrices in 64 KiB of LDS (hidden_dim <= 48 or so: the shipped

@@ -13,6 +13,41 @@ from torch import nn
 from torch.nn import functional as F
 
 
+class _TallLinear(torch.autograd.Function):
+    """nn.Linear over a tall, skinny activation matrix ([tens of thousands of points] x [32..64 channels]) whose weight
+    gradient dW = dy^T x is a 32 x 64 GEMM with K = 24 000: hipBLASLt runs that as one workgroup-starved kernel (0.5 ms,
+    0.2 TFLOP/s -- the third largest item of the training step's profile).  The backward here splits K into batches
+    (a batched GEMM of [S, out, N/S] x [S, N/S, in], then a sum over S): same arithmetic, all CUs busy."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dw = db = None
+        dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ weight).view_as(x)
+        if ctx.needs_input_grad[1]:
+            n = x2.shape[0]
+            s = next((k for k in (128, 96, 64, 48, 32, 24, 16, 8, 4, 2) if n % k == 0), 1)
+            dw = torch.bmm(dy2.view(s, n // s, -1).transpose(1, 2), x2.view(s, n // s, -1)).sum(0)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dw, db
+
+
+def tall_linear(lin, x):
+    """``lin(x)``; under autograd on tall inputs (>= 4096 rows) with the split-K weight gradient of _TallLinear."""
+    if torch.is_grad_enabled() and x.is_cuda and x.numel() // x.shape[-1] >= 4096 and (lin.weight.requires_grad or x.requires_grad):
+        return _TallLinear.apply(x, lin.weight, lin.bias)
+    return lin(x)
+
+
 class ResnetBlockFC(nn.Module):
     """x -> shortcut(x) + fc_1(relu(fc_0(relu(x)))); fc_1.weight starts at zero."""
 
@@ -27,8 +62,8 @@ class ResnetBlockFC(nn.Module):
         nn.init.zeros_(self.fc_1.weight)
 
     def forward(self, x):
-        dx = self.fc_1(F.relu(self.fc_0(F.relu(x))))
-        return (x if self.shortcut is None else self.shortcut(x)) + dx
+        dx = tall_linear(self.fc_1, F.relu(tall_linear(self.fc_0, F.relu(x))))
+        return (x if self.shortcut is None else tall_linear(self.shortcut, x)) + dx
 
     def packed(self):
         """(fc_0.weight, fc_0.bias, fc_1.weight, fc_1.bias) for vt_decoder_pack."""
