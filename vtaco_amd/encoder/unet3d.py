@@ -21,6 +21,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from .. import ops
+from ..layers import _TallLinear
 
 
 def _norm_conv_relu(cin, cout, order, num_groups):
@@ -277,7 +278,8 @@ class UNet3D(nn.Module):
             x, part = gcr(dec.basic_module.SingleConv1, skip, skip_part, low=x, low_part=part)
             x, part = gcr(dec.basic_module.SingleConv2, x, part)
         w = self.final_conv.weight.reshape(self.final_conv.out_channels, -1)
-        x = F.linear(x, w, self.final_conv.bias)
+        # 2 M voxels x 32 channels: the weight gradient is a 32 x 32 GEMM with K = 2 M (hipBLASLt: one 2.6 ms kernel) -> split-K
+        x = _TallLinear.apply(x, w, self.final_conv.bias) if x.numel() // x.shape[-1] >= 4096 else F.linear(x, w, self.final_conv.bias)
         if self.testing and self.final_activation is not None:
             x = self.final_activation(x) if isinstance(self.final_activation, nn.Sigmoid) else torch.softmax(x, dim=-1)
         return x
