@@ -20,6 +20,26 @@ def test_slabs_partition_exactly():
                 assert f0 + c0 == f1 and (c0 % 32 == 0 or f1 == total)
 
 
+def test_slabs_with_empty_tails_still_partition():
+    """Rounding the share up to the alignment leaves trailing ranks empty (nx=32 over 7 ranks in plane pairs; a
+    100 000-point chunk alignment at 128^3 over 8 ranks): the spans still tile [0,total) and the empty ones are (total, 0)."""
+    seen_empty = 0
+    for nx in (8, 11, 16, 32, 128):
+        for world in range(1, 9):
+            for align in (lattice_align(nx, world), 32, 2048, 100000):
+                total = nx ** 3
+                spans = [slab_of(total, r, world, align) for r in range(world)]
+                assert sum(c for _, c in spans) == total and spans[0][0] == 0
+                for (f0, c0), (f1, c1) in zip(spans, spans[1:]):
+                    assert f0 + c0 == f1
+                    if c0 == 0:
+                        assert c1 == 0 and f0 == total            # once empty, empty to the end
+                seen_empty += sum(c == 0 for _, c in spans)
+    assert slab_of(32 ** 3, 6, 7, lattice_align(32, 7))[1] == 0      # the advisor's example
+    assert slab_of(128 ** 3, 7, 8, 100000) == (128 ** 3, 0)            # 100 000-point chunks at 128^3 over 8 ranks
+    assert seen_empty > 0
+
+
 def test_lattice_slabs_are_whole_plane_pairs_when_possible():
     """128^3 / 256^3 over 2, 4, 8 ranks: every slab starts and ends on a pair of x-planes (the brick-tiled,
     LDS-staged decode kernels' alignment); tiny lattices fall back to the 32-point tile."""
@@ -38,14 +58,77 @@ def _free_port():
         return s.getsockname()[1]
 
 
+class _Net(torch.nn.Module):
+    """Two heads (only one is used per step, like fc_p / fc_p_img), a layer used twice (shared weights, like the
+    fuser's encoder / decoder self-attention) and a parameter no step ever touches."""
+
+    def __init__(self):
+        super().__init__()
+        self.head_a, self.head_b = torch.nn.Linear(6, 16), torch.nn.Linear(6, 16)
+        self.shared = torch.nn.Linear(16, 16)
+        self.out = torch.nn.Linear(16, 1)
+        self.unused = torch.nn.Parameter(torch.ones(3))
+
+    def forward(self, x, use_b):
+        h = (self.head_b if use_b else self.head_a)(x)
+        h = self.shared(torch.relu(self.shared(torch.relu(h))))
+        return self.out(h).squeeze(-1)
+
+
+def _ddp_steps(rank, world, steps=4):
+    """Bucketed, hook-launched all-reduce under a real backward + Adam: after every step the weights equal the ones a single
+    process reaches with the mean of the per-rank gradients; tiny buckets (1 KB) force several collectives per step, the
+    bucket order is rebuilt from the observed hook order after step 1, the unused head / parameter count as zeros."""
+    def data(r, step):
+        g = torch.Generator().manual_seed(100 * step + r)
+        return torch.randn(32, 6, generator=g), torch.randn(32, generator=g)
+    torch.manual_seed(7)
+    net, ref = _Net(), _Net()
+    ref.load_state_dict(net.state_dict())
+    opt, opt_ref = torch.optim.Adam(net.parameters(), lr=1e-2), torch.optim.Adam(ref.parameters(), lr=1e-2)
+    sync = GradAllReduce(net.parameters(), bucket_bytes=1024)
+    ok = True
+    for step in range(steps):
+        use_b = step % 2 == 1
+        opt.zero_grad(set_to_none=(step != 2))             # both zero_grad flavours
+        x, y = data(rank, step)
+        torch.nn.functional.l1_loss(net(x, use_b), y).backward()
+        sync()
+        opt.step()
+        opt_ref.zero_grad()
+        for r in range(world):
+            x, y = data(r, step)
+            (torch.nn.functional.l1_loss(ref(x, use_b), y) / world).backward()
+        for p in ref.parameters():                         # parameters without gradient count as zeros on the DDP side
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        opt_ref.step()
+        ok = ok and all(torch.allclose(a, b, atol=1e-6, rtol=1e-5) for a, b in zip(net.parameters(), ref.parameters()))
+        ok = ok and all(p.grad is not None for p in net.parameters())
+    ok = ok and sync.stats["buckets"] >= 3 and sync._rebuilt and sync.stats["launched_in_backward"] > 0
+    # the ranks hold identical weights
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    return ok and all(torch.equal(both[0], t) for t in both)
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ok1 = True
+        def slab(first, count):
+            assert count > 0                              # an empty slab must not reach the kernels
+            return torch.arange(first, first + count, dtype=torch.float32) * 0.5
         for nx in (11, 8, 16):                            # ragged plane-pair slabs, 32-point slabs, even plane pairs
-            full = decode_lattice_sharded(lambda first, count: torch.arange(first, first + count, dtype=torch.float32) * 0.5, nx)
+            full = decode_lattice_sharded(slab, nx)
             ok1 = ok1 and torch.equal(full, torch.arange(nx ** 3, dtype=torch.float32) * 0.5)
+        # alignment larger than half the lattice: rank 1's slab is empty, it still joins the all-gather
+        full = decode_lattice_sharded(slab, 8, align=400)
+        ok1 = ok1 and slab_of(512, 1, 2, 400) == (400, 112) and torch.equal(full, torch.arange(512, dtype=torch.float32) * 0.5)
+        full = decode_lattice_sharded(slab, 8, align=512)
+        ok1 = ok1 and slab_of(512, 1, 2, 512) == (512, 0) and torch.equal(full, torch.arange(512, dtype=torch.float32) * 0.5)
         # gradient all-reduce: rank-dependent grads, one parameter without a gradient on rank 1
         torch.manual_seed(0)
         a, b, c = (torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)),
@@ -54,9 +137,10 @@ def _worker(rank, world, port, q):
         b.grad = torch.arange(7.0) * (rank + 1)
         if rank == 0:
             c.grad = torch.ones(2, 2)
-        GradAllReduce([a, b, c])()
+        GradAllReduce([a, b, c], overlap=False)()
         ok2 = torch.allclose(a.grad, torch.full((5, 3), 1.5)) and torch.allclose(b.grad, torch.arange(7.0) * 1.5) \
             and torch.allclose(c.grad, torch.full((2, 2), 0.5))
+        ok2 = ok2 and _ddp_steps(rank, world)
         q.put((rank, bool(ok1), bool(ok2)))
     finally:
         dist.destroy_process_group()

@@ -139,3 +139,135 @@ def test_tactile_resnet18_against_the_reference_module():
         y = net(x)
     assert float((y - T(z["y_train"])).abs().max()) <= 1e-4 * float(T(z["y_train"]).abs().max())
     assert sum(p.numel() for p in encoder_dict["Resnet34"](num_classes=32).parameters()) > sum(p.numel() for p in net.parameters())
+
+
+VTACO_YCB_SHAPED_YAML = """
+# a config with the KEYS of the reference's shipped configs/VTacO/VTacO_YCB.yaml (method, model.*, encoder_t2d_kwargs ...),
+# small sizes where a size does not matter to the factory; written by this test, not copied
+method: vtaco
+data:
+  dataset: Shapes3D
+  input_type: pointcloud
+  classes: null
+  path: {root}
+  dim: 3
+  padding: 0.1
+  train_split: train
+  val_split: val
+  test_split: val
+  multi_files: null
+  pointcloud_n: 150
+  pointcloud_noise: 0.005
+  points_subsample: 128
+  num_sample: 64
+  points_file: points.npz
+  points_iou_file: points.npz
+  voxels_file: null
+  pointcloud_file: pointcloud.npz
+  points_unpackbits: False
+model:
+  train_tactile: False
+  with_img: True
+  with_contact: False
+  encoder: pointnet_local_pool
+  encoder_kwargs:
+    hidden_dim: 32
+    plane_type: 'grid'
+    grid_resolution: 64
+    unet3d: True
+    unet3d_kwargs: {{num_levels: 4, f_maps: 32, in_channels: 32, out_channels: 32}}
+  encoder_hand: pointnet_local_pool
+  encoder_hand_kwargs:
+    hidden_dim: 32
+    plane_type: ['xz', 'xy', 'yz']
+    plane_resolution: 32
+    unet: True
+    unet_kwargs: {{depth: 4, merge_mode: concat, start_filts: 32}}
+    out_mano: True
+    out_dim: 51
+    manolayer_kwargs: &manolayer_k
+      center_idx: 9
+      flat_hand_mean: False
+      ncomps: 45
+      side: right
+      mano_root: {mano}
+      use_pca: False
+      root_rot_mode: axisang
+      joint_rot_mode: axisang
+      robust_rot: False
+      return_transf: False
+      return_full_pose: True
+  encoder_img: Resnet18
+  encoder_img_kwargs: {{num_classes: 32}}
+  encoder_t2d: True
+  encoder_t2d_kwargs:
+    pretrained: True
+    model_file: {ckpt}
+    encoder_img: UNet
+    encoder_img_kwargs: {{num_classes: 1, in_channel: 3, start_filts: 32, depth: 3}}
+    encoder_hand: pointnet_local_pool
+    encoder_hand_kwargs:
+      c_dim: 512
+      hidden_dim: 32
+      plane_type: ['xz', 'xy', 'yz']
+      plane_resolution: 64
+      unet: True
+      unet_kwargs: {{depth: 4, merge_mode: concat, start_flits: 32}}
+      out_mano: True
+      out_dim: 30
+      manolayer_kwargs: *manolayer_k
+  decoder: simple_local
+  decoder_kwargs: {{sample_mode: bilinear, hidden_size: 32}}
+  c_dim: 32
+training: {{out_dir: {out}, batch_size: 3}}
+test: {{threshold: 0.5}}
+generation: {{resolution_0: 32, upsampling_steps: 0}}
+"""
+
+
+def test_shipped_shape_yaml_builds_dataset_model_trainer_and_loads_the_t2d_checkpoint(tmp_path):
+    """``method: vtaco`` (reference src/config.py:7-9) resolves; ``get_model`` builds every module of the shipped VTacO config
+    (20 011 415 parameters) and LOADS ``encoder_t2d_kwargs.model_file`` into the t2d net
+    (reference conv_onet/config.py:131-133: CheckpointIO -> state['model']); a missing file raises as the reference does."""
+    import os
+    import sys
+    import yaml
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import synth_dataset
+    import synth_mano
+    from vtaco_amd import config as topcfg
+    from vtaco_amd._lib import VtError
+    root = str(tmp_path / "data")
+    os.makedirs(root)
+    synth_dataset.make_synthetic_dataset(root)
+    synth_mano.write_pkl(synth_mano.make_asset(0), str(tmp_path / "mano"))
+    out = tmp_path / "out"
+    out.mkdir()
+    text = VTACO_YCB_SHAPED_YAML.format(root=root, mano=str(tmp_path / "mano"), ckpt="t2d/model.pt", out=str(out))
+    cfg = yaml.safe_load(text)
+    assert cfg["method"] == "vtaco" and topcfg.method_dict["vtaco"] is topcfg.method_dict["conv_onet"]
+    ds = topcfg.get_dataset("train", cfg)
+    assert len(ds) > 0 and "points" in ds[0] and "inputs" in ds[0]
+    method = topcfg.method_dict[cfg["method"]]
+    with pytest.raises(FileNotFoundError):                 # pretrained: True and nothing to load
+        method.get_model(cfg, device=None)
+    # a checkpoint as the reference's CheckpointIO.save writes it: {'model': state_dict, scalars...} relative to out_dir
+    cfg_np = yaml.safe_load(text)
+    cfg_np["model"]["encoder_t2d_kwargs"]["pretrained"] = False
+    torch.manual_seed(3)
+    donor = method.get_model(cfg_np, device=None)
+    assert sum(p.numel() for p in donor.parameters()) == 20011415
+    (out / "t2d").mkdir()
+    torch.save({"model": donor.encoder_t2d.state_dict(), "epoch_it": 7, "loss_val_best": 0.5}, str(out / "t2d" / "model.pt"))
+    torch.manual_seed(4)
+    model = method.get_model(cfg, device=None)
+    for (k, a), (_, b) in zip(model.encoder_t2d.state_dict().items(), donor.encoder_t2d.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert not torch.equal(model.decoder.fc_p.weight, donor.decoder.fc_p.weight)      # everything else is a fresh init
+    torch.save({"epoch_it": 7}, str(out / "t2d" / "model.pt"))
+    with pytest.raises(VtError):                              # a checkpoint without a 'model' entry
+        method.get_model(cfg, device=None)
+    trainer = method.get_trainer(donor, torch.optim.Adam(donor.parameters(), lr=1e-4), cfg, None)
+    assert trainer.encode_t2d and trainer.with_img and trainer.pretrained_t2d and trainer.num_sample == 64
+    gen = method.get_generator(donor, cfg, None)
+    assert gen.with_img and gen.encode_t2d and gen.resolution0 == 32

@@ -6,7 +6,8 @@ from __future__ import annotations
 from . import data
 from .conv_onet import config as conv_onet_config
 
-method_dict = {'conv_onet': conv_onet_config}
+# every shipped config says ``method: vtaco`` (reference src/config.py:7-9); 'conv_onet' is kept as an alias
+method_dict = {'vtaco': conv_onet_config, 'conv_onet': conv_onet_config}
 
 
 class Compose:

@@ -35,7 +35,28 @@ def get_model(cfg, device=None, dataset=None, **kwargs):
             # the digit-pose regressor of the t2d model (config.py:126-131): c_dim comes from its own kwargs
             hand_t2d = encoder_dict[kw['encoder_hand']](dim=dim, padding=padding, **(kw.get('encoder_hand_kwargs') or {}))
         encoder_t2d = models.ConvolutionalOccupancyNetwork(None, None, hand_t2d, img_t2d, None, device=device)
+        if kw.get('pretrained'):
+            # reference config.py:131-133: CheckpointIO(out_dir, model=encoder_t2d).load(model_file) -- the file's 'model' entry
+            # is the t2d net's state_dict (checkpoints.py:37-40, 91-93, strict).  A pretrained t2d net that was never loaded
+            # would be neither trained (get_trainer drops its losses) nor meaningful, so a missing file raises like the reference
+            load_t2d_checkpoint(encoder_t2d, kw.get('model_file'), (cfg.get('training') or {}).get('out_dir', '.'), device)
     return models.ConvolutionalOccupancyNetwork(decoder, encoder, encoder_hand, encoder_img, encoder_t2d, device=device)
+
+
+def load_t2d_checkpoint(net, model_file, out_dir, device=None):
+    """``CheckpointIO.load_file`` for the one module the factory loads (checkpoints.py:53-70, 84-98): relative paths are
+    relative to ``training.out_dir``; the checkpoint is a dict whose ``'model'`` entry is the state_dict."""
+    import os
+    import torch
+    if not model_file:
+        raise VtError("get_model: encoder_t2d_kwargs.pretrained is true but no model_file is given")
+    path = model_file if os.path.isabs(model_file) else os.path.join(out_dir, model_file)
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    state = torch.load(path, map_location=device if device is not None else 'cpu')
+    if 'model' not in state:
+        raise VtError(f"get_model: {path} has no 'model' entry (keys: {sorted(state)[:8]})")
+    net.load_state_dict(state['model'])
 
 
 def get_generator(model, cfg, device, **kwargs):

@@ -70,6 +70,8 @@ class Generator3D(object):
         grid = c['grid'] if isinstance(c, dict) else c
         if grid.shape[0] != 1:
             raise VtError("eval_lattice: one scene at a time (the lattice is per scene)")
+        if count == 0:                                   # an empty slab of a sharded lattice: no kernel
+            return torch.empty(0, dtype=torch.float32, device=grid.device)
         return self.model.decoder.decode_lattice(grid, nx, box=1 + self.padding, first=first, count=count,
                                                  c_img=c_img_all, out=out, precision=self.decode_precision).reshape(-1)
 
@@ -140,9 +142,10 @@ class Generator3D(object):
                 fused = hasattr(self.model.decoder, 'fuser')
                 values = vdist.decode_lattice_sharded(
                     lambda first, count: self._eval_lattice_tactile(c, nx, setup, first, count), nx, group,
-                    align=self.points_batch_size if fused else None)
+                    align=self.points_batch_size if fused else None, device=self.device)
             else:
-                values = vdist.decode_lattice_sharded(lambda first, count: self.eval_lattice(c, nx, first=first, count=count), nx, group)
+                values = vdist.decode_lattice_sharded(lambda first, count: self.eval_lattice(c, nx, first=first, count=count), nx, group,
+                                                      device=self.device)
         return self.extract_mesh(values.reshape(nx, nx, nx))
 
     def generate_obj_mesh_tactile(self, data, finger_feats, anchors, success, mode='within', radius=None, count=None):
@@ -167,6 +170,8 @@ class Generator3D(object):
         """Logits of lattice points [first, first+count) with the tactile features of ``setup`` (finger features, anchors, rule)."""
         count = nx ** 3 - first if count is None else count
         grid = c['grid'] if isinstance(c, dict) else c
+        if count == 0:                                   # an empty slab of a sharded lattice: no kernel
+            return torch.empty(0, dtype=torch.float32, device=grid.device)
         ids = ops.tactile_assign(setup['anchors'].to(self.device), setup['success'].to(self.device), setup['mode'], setup['radius'],
                                  lattice=(nx, 1 + self.padding, first, count), count=setup['count'].to(self.device))
         feats = setup['feats'].to(self.device)
