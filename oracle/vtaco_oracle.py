@@ -228,7 +228,7 @@ def segment_pool_max(feat, index):
     out = torch.empty_like(feat)
     for b in range(feat.shape[0]):
         uniq, inv = torch.unique(index[b], return_inverse=True)
-        seg = torch.full((uniq.numel(), feat.shape[2]), -float("inf"))
+        seg = torch.full((uniq.numel(), feat.shape[2]), -float("inf"), dtype=feat.dtype)
         seg = seg.scatter_reduce(0, inv.unsqueeze(-1).expand_as(feat[b]), feat[b], "amax", include_self=True)
         out[b] = seg[inv]
     return out
@@ -238,17 +238,18 @@ def scatter_mean_grid(feat, index, reso):
     """``generate_grid_features`` scatter part (pointnet.py:102-110):
     per-voxel mean, empty voxels 0; returns [B,C,R,R,R] (dims z,y,x)."""
     B, T, C = feat.shape
-    grid = torch.zeros(B, reso ** 3, C)
-    cnt = torch.zeros(B, reso ** 3, 1)
+    grid = torch.zeros(B, reso ** 3, C, dtype=feat.dtype)
+    cnt = torch.zeros(B, reso ** 3, 1, dtype=feat.dtype)
     grid.scatter_add_(1, index.unsqueeze(-1).expand(-1, -1, C), feat)
-    cnt.scatter_add_(1, index.unsqueeze(-1), torch.ones(B, T, 1))
+    cnt.scatter_add_(1, index.unsqueeze(-1), torch.ones(B, T, 1, dtype=feat.dtype))
     grid = grid / cnt.clamp(min=1)
     return grid.permute(0, 2, 1).reshape(B, C, reso, reso, reso)
 
 
 def pointnet_point_features(sd, p, reso, padding=0.1, return_stages=False):
-    """``LocalPoolPointnet.forward`` up to ``fc_c`` (pointnet.py:135-162)."""
-    idx = voxel_index(p, reso, padding)
+    """``LocalPoolPointnet.forward`` up to ``fc_c`` (pointnet.py:135-162).  The voxel ids are f32 arithmetic by
+    definition (a float64 run of the oracle -- the yardstick tests measure f32 rounding noise against -- keeps them)."""
+    idx = voxel_index(p.float(), reso, padding)
     net = _lin(sd, "fc_pos", p)
     net = resnet_block_fc(sd, "blocks.0", net)
     stages = [net]
@@ -268,7 +269,10 @@ def _gcr(sd, pre, x, groups=8):
     ch = x.shape[1]
     g = groups if ch >= groups else 1
     x = F.group_norm(x, g, sd[pre + ".groupnorm.weight"], sd[pre + ".groupnorm.bias"], 1e-5)
-    x = F.conv3d(x, sd[pre + ".conv.weight"], None, padding=1)
+    # .contiguous(): a state_dict taken from a module kept in channels_last_3d hands F.conv3d strided weights, and torch's CPU
+    # conv then takes a different (and, measured against a float64 run at R = 64 / 4 levels, 20-300x less accurate, thread-count
+    # dependent) path than the reference's contiguous nn.Conv3d weights do; with contiguous weights this IS the reference's op
+    x = F.conv3d(x, sd[pre + ".conv.weight"].contiguous(), None, padding=1)
     return F.relu(x)
 
 
@@ -290,7 +294,7 @@ def unet3d_forward(sd, x):
         x = torch.cat((skip, x), dim=1)
         x = _gcr(sd, f"decoders.{i}.basic_module.SingleConv1", x)
         x = _gcr(sd, f"decoders.{i}.basic_module.SingleConv2", x)
-    return F.conv3d(x, sd["final_conv.weight"], sd["final_conv.bias"])
+    return F.conv3d(x, sd["final_conv.weight"].contiguous(), sd["final_conv.bias"])
 
 
 def pointnet_encoder_forward(sd, p, reso, padding=0.1, unet3d=True):

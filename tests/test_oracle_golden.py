@@ -103,3 +103,28 @@ def test_train_step_loss_and_grads_via_autograd_of_oracle():
     gi = a["grid_grad_idx"]
     gg = grid.grad.permute(0, 2, 3, 4, 1).reshape(2, -1, 32)
     assert maxdiff(gg[gi[:, 0], gi[:, 1]], a["grid_grad_val"]) <= 1e-7
+
+
+def test_oracle_at_the_shipped_shape_of_config2():
+    """g15_config2.npz (real reference; R = 64, UNet3D 4 levels x f_maps 32, LocalDecoder on the 128^3 lattice): the oracle's
+    encoder grid and logits, and its UNet3D alone on the two f_maps-32 cases the HIP network is tested with."""
+    import config2_case as c2
+    z = c2.fixture()
+    for tag in ("u16", "u32"):
+        net, x = c2.unet_case(z, tag)
+        y = orc.unet3d_forward(c2.cpu_sd(net), x)
+        scale = float(z[f"{tag}_ystat"][2])
+        if tag == "u16":
+            assert maxdiff(y, z["u16_y"]) <= 2e-5 * scale
+        else:
+            assert maxdiff(y[0].reshape(32, -1)[:, T(z["u32_vox"])], z["u32_y_at"]) <= 2e-5 * scale
+    enc, dec = c2.models(z)
+    grid = orc.pointnet_encoder_forward(c2.cpu_sd(enc), T(z["cloud"]), 64)
+    gmax = float(z["grid_stat"][2])
+    assert maxdiff(grid[0].reshape(32, -1)[:, T(z["grid_vox"])], z["grid_at"]) <= 2e-5 * gmax
+    assert maxdiff(grid[0].double().mean(dim=(1, 2, 3)), z["grid_chan_mean"]) <= 1e-6
+    dsd = c2.cpu_sd(dec)
+    for name in ("sample", "near"):
+        p = c2.lattice_points(z[name]).unsqueeze(0)
+        key = "logits" if name == "sample" else "logits_near"
+        assert maxdiff(orc.local_decoder_forward(dsd, p, grid)[0], z[key]) <= 1e-5
