@@ -5,18 +5,31 @@ A "step" is one pass of the decode hot path (lattice -> logits grid on device:
 in-kernel lattice generation, trilinear gather of the channels-last feature grid,
 per-point conditioned ResNet MLP) over one synthetic scene; weights and feature
 grid are resident in HBM when the timed region starts.
-With --gpus N every rank decodes its own scene (the unit is the query point; no
-data-path collective), so value = N * nx^3 * steps / max-over-ranks time ("weak").
+
+    python bench.py --gpus N --steps K --warmup W
+
+* ``--gpus N`` with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU and starts
+  N ranks (``python -m torch.distributed.run``, one process per GPU, RCCL) of itself; under a launcher
+  (WORLD_SIZE set) ``--gpus`` must agree with it.
+* ``--scaling weak`` (default): every rank decodes its own scene -- the unit is the query point, there is
+  no data-path collective -- value = N * nx^3 * steps / max-over-ranks time.
+  ``--scaling strong``: ONE scene, every rank decodes its slab of the lattice (whole x-plane pairs) and one
+  all-gather rebuilds the value grid on every rank; value = nx^3 * steps / time (N = 1: the same number).
+* Unless ``--decode-only``: the same JSON line carries ``sharded_scene`` (BASELINE config 5's shape of work:
+  redundant encode, slab decode, one all-gather, marching cubes on rank 0; at 128^3 and 256^3) and
+  ``train_step`` (config 4: the VTacO training step, 8 scenes x 2048 points per GPU, bucketed gradient
+  all-reduce over RCCL overlapped with backward; ms/step and the all-reduce's share), and at N = 1 the
+  mesh-extract latency, the stage times and the CPU baseline.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -26,17 +39,39 @@ FLOP_PER_POINT_IMG = 33536    # with the tactile concat (forward_img)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 KERNEL_OF = {"f32": "decode_fwd_staged2_kernel<false>", "bf16x3": "decode_fwd_staged2_kernel<true>"}
+MIN_WARM_S = 0.25             # launches before any timed region, whatever --warmup says (clocks settle)
 
 
-def synthetic_scene(seed, device, R=64):
-    """Seeded synthetic inputs: sphere point cloud -> encoder -> grid."""
-    from vtaco_amd.bench_util import build_scene
-    return build_scene(seed, device, R)
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: --gpus N without a launcher around us
+# ---------------------------------------------------------------------------------------------------------------------
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Start n ranks of this script as CHILD processes (this process has not touched the GPU and never will; a process
+    that has must not be replaced by exec on this pool) and exit with their code.  Rank 0's JSON line passes through."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env)
+    sys.exit(proc.returncode)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# pieces
+# ---------------------------------------------------------------------------------------------------------------------
 
 def cpu_baseline(sd, grid_cpu, nx, budget_s=15.0):
     """The oracle (a port, not the reference itself) timed on the host cores on a
     bounded sample: whole 100k-point chunks of the same lattice until ~budget_s."""
+    import torch
     from oracle import vtaco_oracle as orc
     # torch's CPU kernels on 100k x 32 operands stop scaling (and then collapse) beyond a few
     # tens of threads; use what the host has, capped at 32, and report that number as `cores`
@@ -59,6 +94,7 @@ def mesh_extract_stats(vol, nx, runs=100):
     """mesh-extract latency (BASELINE.json metric, second half): HIP marching cubes on the
     device-resident logit grid -> device verts/faces, including the one host read of the
     counts that sizes the outputs.  p50 over `runs`."""
+    import torch
     from vtaco_amd import ops
     lat = []
     for i in range(runs + 5):
@@ -73,11 +109,13 @@ def mesh_extract_stats(vol, nx, runs=100):
     nbytes = 4 * nx ** 3 + 12 * v.shape[0] + 12 * f.shape[0]      # algorithmic bytes
     return {"p50_ms": p50, "p90_ms": lat[int(len(lat) * 0.9)], "min_ms": lat[0], "runs": runs, "verts": v.shape[0],
             "faces": f.shape[0], "level": lvl, "algorithmic_GBps": nbytes / (p50 * 1e-3) / 1e9,
-            "note": "latency-dominated (5 launches + 1 sync readback); 8.4 MB volume = 1.3 us at HBM rate"}
+            "note": "latency-dominated (dependent launches + 1 sync readback); 8.4 MB volume = 1.3 us at HBM rate"}
 
 
 def stage_times(scene, dec, grid, nx, out, dev, precision):
     """End-to-end stages for one scene (reported beside the metric, not part of it)."""
+    import torch
+
     def timed(fn, n=5):
         ts = []
         for _ in range(n):
@@ -125,15 +163,10 @@ def measured_traffic(precision):
     """HBM-side bytes per decode launch from the committed PMC passes (profiles/, same command
     as this bench): (2 x FETCH_SIZE + WRITE_SIZE) KB -- the x2 is the guide's gfx950 correction
     for 16-B-per-lane reads; None if no profile is committed for this kernel."""
-    try:
-        vals = {}
-        for line in open(os.path.join(ROOT, PMC_SUMMARY)).read().splitlines()[1:]:
-            k, c, n, mean = line.split(",")
-            if k == "decode_" + precision:
-                vals[c] = float(mean)
-        return (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-    except Exception:
+    vals = pmc_counters(precision)
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None
+    return (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
 def roofline_of(precision, flop_pt, npts, kern_ms):
@@ -160,6 +193,150 @@ def roofline_of(precision, flop_pt, npts, kern_ms):
     return r
 
 
+class Fences:
+    """barrier + synchronize on both sides of a timed region; max over ranks of a host time."""
+
+    def __init__(self, dist, dev, backend):
+        self.dist, self.dev, self.backend = dist, dev, backend
+
+    def fence(self):
+        import torch
+        if self.dist is not None:
+            self.dist.barrier()
+        if self.dev is not None:
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        import torch
+        if self.dist is None:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def warm_up(step, min_steps, sync, min_s=MIN_WARM_S):
+    """At least `min_steps` untimed steps AND at least `min_s` seconds of them."""
+    t0, n = time.perf_counter(), 0
+    while n < min_steps or time.perf_counter() - t0 < min_s:
+        step()
+        n += 1
+        if n % 16 == 0:
+            sync()
+    sync()
+    return n
+
+
+def sharded_scene(scene, dev, fx, rank, world, dist, precision, sizes=(128, 256), iters=10):
+    """BASELINE config 5's shape of work, strong scaling over the ranks: ONE scene; every rank encodes it (cheap, deterministic:
+    no broadcast), decodes its slab of x-plane pairs, one all-gather of the logit slabs rebuilds the value grid, rank 0 extracts
+    the mesh.  Times are per scene, max over ranks; the stage breakdown is rank 0's (HIP events on the launch stream)."""
+    import torch
+    from vtaco_amd import dist as vdist
+    from vtaco_amd.conv_onet.generation import Generator3D
+    model = scene["model"]
+    pc = scene["cloud"].to(dev)
+    res = {}
+    for nx in sizes:
+        gen = Generator3D(model, device=dev, resolution0=nx // 4, padding=0.1, decode_precision=precision)
+        total = nx ** 3
+        align = vdist.lattice_align(nx, world)
+        first, count = vdist.slab_of(total, rank, world, align)
+        full = torch.empty(total, dtype=torch.float32, device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        mesh = [None]
+
+        def one(record=False):
+            with torch.no_grad():
+                if record:
+                    ev[0].record()
+                c = model.encode_inputs(pc)
+                if record:
+                    ev[1].record()
+                local = gen.eval_lattice(c, nx, first=first, count=count) if count else torch.empty(0, dtype=torch.float32, device=dev)
+                if record:
+                    ev[2].record()
+                vol = vdist.all_gather_slabs(local, total, None, align, out=full) if world > 1 else local
+                if record:
+                    ev[3].record()
+                if rank == 0:
+                    mesh[0] = gen.extract_mesh(vol.reshape(nx, nx, nx))
+                if record:
+                    ev[4].record()
+        warm_up(one, 2, torch.cuda.synchronize, 0.1)
+        fx.fence()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            one()
+        fx.fence()
+        ms = 1e3 * fx.max_over_ranks(time.perf_counter() - t0) / iters
+        one(True)
+        torch.cuda.synchronize()
+        st = [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
+        res[str(nx)] = {"ms_per_scene": ms, "points_per_s": total / (ms * 1e-3), "slab_points_per_rank": count,
+                        "rank0_stage_ms": {"encode": st[0], "decode_slab": st[1], "all_gather": st[2], "marching_cubes": st[3]},
+                        "all_gather_bytes": 4 * total,
+                        "verts": int(mesh[0].vertices.shape[0]) if rank == 0 else None}
+    return res
+
+
+def train_step_section(dev, fx, rank, world, dist, steps=8):
+    """BASELINE config 4: the VTacO training step (forward + backward + gradient all-reduce + Adam) on 8 synthetic scenes x 2048
+    query points per GPU; weak scaling (global batch = 8 N: 64 scenes at N = 8).  The all-reduce's share = what the step loses
+    to it: (ms with the bucketed all-reduce) - (ms of the same step without any gradient exchange)."""
+    import numpy as np
+    import torch
+    from vtaco_amd.bench_util import build_train_case
+    B = 8
+    model, trainer, batch, vf = build_train_case(dev, rank, scenes=B)
+    sync = trainer.grad_sync
+    n_param = sum(p.numel() for p in model.parameters())
+    np.random.seed(1234 + rank)
+
+    def step():
+        trainer.train_step(batch, vf)
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    first_s = time.perf_counter() - t0
+    for _ in range(2):
+        step()
+
+    def timed(n):
+        fx.fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        fx.fence()
+        return 1e3 * fx.max_over_ranks(time.perf_counter() - t0) / n
+    ms_sync = timed(steps)
+    res = {"ms_per_step": ms_sync, "scenes_per_s": world * B / (ms_sync * 1e-3), "global_batch": world * B,
+           "points_per_scene": 2048, "parameters": n_param, "allreduce_bytes": 4 * sync.numel, "first_step_s": first_s,
+           "workload": "Trainer(with_img, encode_t2d).train_step: shipped VTacO model (get_model), contact clouds from depth images, "
+                       "winding-number targets, Adam 1e-4; synthetic batch"}
+    if world > 1:
+        res["buckets"] = dict(sync.stats)
+        # the all-reduce alone: the same buckets, nothing to overlap with
+        flats = [bk["flat"] for bk in sync._buckets]
+        fx.fence()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            works = [dist.all_reduce(f, async_op=True) for f in flats]
+            for w in works:
+                w.wait()
+        fx.fence()
+        res["allreduce_alone_ms"] = 1e3 * fx.max_over_ranks(time.perf_counter() - t0) / 5
+        res["allreduce_alone_GBps_per_gpu"] = 2 * (world - 1) / world * 4 * sync.numel / (res["allreduce_alone_ms"] * 1e-3) / 1e9
+        trainer.grad_sync = None
+        ms_local = timed(steps)
+        trainer.grad_sync = sync
+        res["ms_per_step_without_allreduce"] = ms_local
+        res["allreduce_share"] = max(0.0, (ms_sync - ms_local) / ms_sync)
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,100 +346,163 @@ def main():
     ap.add_argument("--mode", choices=["visual", "img"], default="visual")
     ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the 16 dense layers: exact-f32 MFMA or split-bf16 MFMA (both inside the 1e-4 bar)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: one scene per rank, no collective; strong: one scene, slab decode + one all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--decode-only", action="store_true", help="skip the mesh-extract / stage timings (perf experiments)")
+    ap.add_argument("--decode-only", action="store_true", help="only the decode metric (perf experiments)")
+    ap.add_argument("--no-train", action="store_true", help="skip the config-4 training-step section")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / reduction plumbing only: no kernel runs, value is null (CPU tests of --gpus N)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    # one rank per GPU; VTACO_BENCH_BACKEND=gloo lets the multi-process path be dry-run on a box with fewer
-    # GPUs than ranks (ranks then share devices; RCCL refuses that)
-    backend = os.environ.get("VTACO_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    # ---- ranks ---------------------------------------------------------------------------------------------------
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            launch_ranks(args.gpus, sys.argv[1:])          # does not return
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
-    from vtaco_amd import ops
-    scene = synthetic_scene(rank, dev)
-    model, grid = scene["model"], scene["grid"]
+    import torch
+    backend = os.environ.get("VTACO_BENCH_BACKEND", "nccl")
+    dist = None
+    if args.dry_run:
+        dev = None
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+        backend = "gloo"
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+        # one rank per GPU; VTACO_BENCH_BACKEND=gloo lets the multi-process path be dry-run on a box with fewer
+        # GPUs than ranks (ranks then share devices; RCCL refuses that)
+        dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+        if world > 1:
+            import torch.distributed as dist
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+    fx = Fences(dist, dev, backend)
     nx = args.nx
     npts = nx ** 3
+
+    if args.dry_run:
+        fx.fence()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        fx.fence()
+        wall = fx.max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            print(json.dumps({"metric": "occupancy query-points/sec at 128^3 (decode stage, lattice -> logits on device)",
+                              "value": None, "unit": "query-points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+                              "dry_run": True, "wall_s": wall}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    from vtaco_amd import dist as vdist
+    from vtaco_amd.bench_util import build_scene
+    strong = args.scaling == "strong"
+    scene = build_scene(0 if strong else rank, dev)
+    model, grid = scene["model"], scene["grid"]
     dec = model.decoder
     c_img = scene["c_img"](nx) if args.mode == "img" else None
     out = torch.empty((1, npts), dtype=torch.float32, device=dev)
+    if strong and world > 1:
+        if args.mode == "img":
+            raise SystemExit("bench.py: --scaling strong covers the visual decode")
+        align = vdist.lattice_align(nx, world)
+        first, count = vdist.slab_of(npts, rank, world, align)
+        slab = torch.empty((1, max(count, 1)), dtype=torch.float32, device=dev)
+        full = out.view(-1)
 
-    def step():
-        dec.decode_lattice(grid, nx, box=1.1, c_img=c_img, out=out, precision=args.precision)
+        def step():
+            if count:
+                dec.decode_lattice(grid, nx, box=1.1, first=first, count=count, out=slab[:, :count], precision=args.precision)
+            vdist.all_gather_slabs(slab[0, :count], npts, None, align, out=full)
+    else:
+        def step():
+            dec.decode_lattice(grid, nx, box=1.1, c_img=c_img, out=out, precision=args.precision)
 
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
+    warm_steps = warm_up(step, args.warmup, torch.cuda.synchronize)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fence()
+    fx.fence()
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
         step()
     ev1.record()
-    fence()
-    wall = time.perf_counter() - t0
+    fx.fence()
+    wall = fx.max_over_ranks(time.perf_counter() - t0)
     kern_ms = ev0.elapsed_time(ev1) / args.steps      # HIP events on the launch stream
-    t = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall = float(t.item())
 
+    res = None
     if rank == 0:
         flop_pt = FLOP_PER_POINT_IMG if args.mode == "img" else FLOP_PER_POINT
+        units = npts if strong else world * npts
         res = {
             "metric": "occupancy query-points/sec at 128^3 (decode stage, lattice -> logits on device)",
-            "value": world * npts * args.steps / wall,
+            "value": units * args.steps / wall,
             "unit": "query-points/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_steps,
             "ms_per_step": 1e3 * wall / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "bf16x3" if args.precision == "bf16x3" else "f32", "data": "synthetic",
-            "config": {"workload": f"visual-only PointNet encoder + LocalDecoder, {nx}^3 lattice, 1 scene/GPU, "
-                                   f"R=64 c_dim=32 hidden=32 n_blocks=5, mode={args.mode}, random-init weights "
+            "config": {"workload": f"visual-only PointNet encoder + LocalDecoder, {nx}^3 lattice, "
+                                   + ("ONE scene, slab per GPU + one all-gather of the logits, "
+                                      if strong else "1 scene/GPU, no collective, ")
+                                   + f"R=64 c_dim=32 hidden=32 n_blocks=5, mode={args.mode}, random-init weights "
                                    "(fc_1 re-randomised); f32 in / f32 out, dense layers on "
                                    + ("the bf16 matrix core with split-bf16 (hi+lo) operands and f32 accumulation"
                                       if args.precision == "bf16x3" else "the f32 matrix core")
                                    + "; parity bar 1e-4 vs the f32 oracle",
-                       "nx": nx, "points_per_step_per_gpu": npts, "mode": args.mode, "precision": args.precision},
-            "per_gpu": npts * args.steps / wall,
-            "roofline": roofline_of(args.precision, flop_pt, npts, kern_ms),
+                       "nx": nx, "points_per_step_per_gpu": npts if not strong else npts // world, "mode": args.mode,
+                       "precision": args.precision},
+            "per_gpu": units * args.steps / wall / world,
         }
+        if not strong or world == 1:
+            res["roofline"] = roofline_of(args.precision, flop_pt, npts, kern_ms)
         if world == 1 and args.precision == "bf16x3":
             # the exact-f32 kernel on the same inputs (what the training forward and precision="f32" run)
-            for _ in range(5):
-                dec.decode_lattice(grid, nx, box=1.1, c_img=c_img, out=out, precision="f32")
+            f32_step = lambda: dec.decode_lattice(grid, nx, box=1.1, c_img=c_img, out=out, precision="f32")
+            warm_up(f32_step, 5, torch.cuda.synchronize)
             torch.cuda.synchronize()
+            t0 = time.perf_counter()
             ev0.record()
             for _ in range(args.steps):
-                dec.decode_lattice(grid, nx, box=1.1, c_img=c_img, out=out, precision="f32")
+                f32_step()
             ev1.record()
             torch.cuda.synchronize()
+            wall32 = time.perf_counter() - t0
             ms32 = ev0.elapsed_time(ev1) / args.steps
-            res["exact_f32_kernel"] = {"value": npts / (ms32 * 1e-3), "unit": "query-points/s",
+            res["value_f32"] = npts * args.steps / wall32
+            res["exact_f32_kernel"] = {"value": npts * args.steps / wall32, "unit": "query-points/s",
                                        "roofline": roofline_of("f32", flop_pt, npts, ms32)}
             step()                                                   # leave the bf16x3 logits in `out`
         if world == 1 and not args.decode_only:
             res["mesh_extract"] = mesh_extract_stats(out.view(nx, nx, nx), nx)
             res["stages_ms"] = stage_times(scene, dec, grid, nx, out, dev, args.precision)
+    if not args.decode_only and args.mode == "visual":
+        if strong or world == 1:
+            one_scene = scene
+        else:
+            one_scene = build_scene(0, dev)                          # every rank the SAME scene
+        sh = sharded_scene(one_scene, dev, fx, rank, world, dist, args.precision)
+        tr = None if args.no_train else train_step_section(dev, fx, rank, world, dist)
+        if rank == 0:
+            res["sharded_scene"] = sh
+            if tr is not None:
+                res["train_step"] = tr
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(scene["sd_decoder_cpu"], scene["grid_cpu"], nx)
         print(json.dumps(res))

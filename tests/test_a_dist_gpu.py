@@ -95,3 +95,25 @@ def test_two_ranks_share_one_gpu_gloo():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True, True), (1, True, True)]
+
+
+def test_bench_gpus_2_starts_two_ranks_and_strong_equals_the_lattice():
+    """``python bench.py --gpus 2`` with no launcher around it: the parent starts two ranks (here sharing the one GPU over gloo),
+    rank 0 prints ONE JSON line with n_gpus == 2; strong scaling = one scene, slab decode + one all-gather."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.is_initialized():
+        pytest.skip("the GPU is already initialised in this process: run this file on its own (or first)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VTACO_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    for scaling in ("strong", "weak"):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                              "--scaling", scaling, "--decode-only"], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        res = json.loads(lines[0])
+        assert res["n_gpus"] == 2 and res["scaling"] == scaling and res["steps"] == 3 and res["value"] > 1e8
+        assert res["config"]["points_per_step_per_gpu"] == (128 ** 3 // 2 if scaling == "strong" else 128 ** 3)

@@ -158,3 +158,25 @@ def test_two_ranks_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True, True), (1, True, True)]
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """``bench.py --gpus 2`` without a launcher starts two ranks of itself before touching any GPU (here: --dry-run, the
+    launcher / rendezvous / max-over-ranks plumbing only -- no kernel runs and the value is null) and reports n_gpus == 2;
+    under a launcher a --gpus that disagrees with WORLD_SIZE is an error, not a silent one-rank run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["dry_run"] is True and res["value"] is None and res["steps"] == 4
+    assert res["wall_s"] >= 0.02                       # the max over the ranks (rank 1 sleeps 20 ms), not rank 0's 10 ms
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr

@@ -56,3 +56,109 @@ def build_scene(seed, device, R=64):
 
     return {"model": model, "grid": grid, "grid_cpu": grid.detach().cpu().contiguous(),
             "sd_decoder_cpu": sd_cpu, "c_img": c_img, "cloud": cloud}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 4: the VTacO training step on synthetic data (shapes of configs/VTacO/VTacO_YCB.yaml and SURVEY.md
+# Appendix B: 3000-point clouds, 5 tactile images of 320 x 240, 5 depth images of 76 800 pixels, 2048 query points per scene)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def vtaco_cfg(mano_root, num_sample=2048):
+    """A config dict with the shipped VTacO model section (20 011 415 parameters); the t2d net stays at its init
+    (``pretrained`` false in the factory: there is no checkpoint to load on a synthetic run)."""
+    mano_kw = dict(center_idx=9, flat_hand_mean=False, ncomps=45, side="right", mano_root=mano_root, use_pca=False,
+                   root_rot_mode="axisang", joint_rot_mode="axisang", robust_rot=False, return_transf=False, return_full_pose=True)
+    hand = dict(hidden_dim=32, plane_type=["xz", "xy", "yz"], unet=True, out_mano=True)
+    return {"method": "vtaco",
+            "data": {"dim": 3, "padding": 0.1, "input_type": "pointcloud", "num_sample": num_sample},
+            "test": {"threshold": 0.5},
+            "model": {"c_dim": 32, "decoder": "simple_local", "decoder_kwargs": {"sample_mode": "bilinear", "hidden_size": 32},
+                      "encoder": "pointnet_local_pool",
+                      "encoder_kwargs": {"hidden_dim": 32, "plane_type": "grid", "grid_resolution": 64, "unet3d": True,
+                                         "unet3d_kwargs": {"num_levels": 4, "f_maps": 32, "in_channels": 32, "out_channels": 32}},
+                      "encoder_hand": "pointnet_local_pool",
+                      "encoder_hand_kwargs": dict(hand, plane_resolution=32, out_dim=51, manolayer_kwargs=mano_kw,
+                                                  unet_kwargs={"depth": 4, "merge_mode": "concat", "start_filts": 32}),
+                      "with_img": True, "with_contact": False, "train_tactile": False,
+                      "encoder_img": "Resnet18", "encoder_img_kwargs": {"num_classes": 32},
+                      "encoder_t2d": True,
+                      "encoder_t2d_kwargs": {"pretrained": False, "encoder_img": "UNet",
+                                             "encoder_img_kwargs": {"num_classes": 1, "in_channel": 3, "start_filts": 32, "depth": 3},
+                                             "encoder_hand": "pointnet_local_pool",
+                                             "encoder_hand_kwargs": dict(hand, c_dim=512, plane_resolution=64, out_dim=30, manolayer_kwargs=mano_kw,
+                                                                         unet_kwargs={"depth": 4, "merge_mode": "concat", "start_flits": 32})}}}
+
+
+def icosphere(radius=0.3, level=3):
+    """A closed triangle mesh (the scene's object: winding-number targets).  (verts f64 [V,3], faces i32 [F,3])."""
+    import numpy as np
+    t = (1 + 5 ** 0.5) / 2
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [np.array(x, dtype=np.float64) / np.linalg.norm(x) for x in v]
+    for _ in range(level):
+        mid, nf = {}, []
+
+        def midpoint(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in mid:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                mid[key] = len(v) - 1
+            return mid[key]
+        for a, b, c in f:
+            ab, bc, ca = midpoint(a, b), midpoint(b, c), midpoint(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return radius * np.stack(v), np.asarray(f, dtype=np.int32)
+
+
+def build_train_case(device, rank=0, scenes=8, num_sample=2048, n_points=8192, grad_sync=True):
+    """(model, trainer, batch, vf_dict) of one rank's share of config 4: the shipped VTacO model built by ``get_model`` on a synthetic
+    MANO-format asset, ``Trainer(with_img, encode_t2d)`` (compute_loss_t2d_img: contact clouds from the depth images, winding-number
+    targets from the object mesh, tactile features from Resnet18, hand terms), Adam(1e-4), and a seeded synthetic batch of ``scenes``
+    scenes.  Every rank builds the same weights (seed 0) and its own data (seed by rank)."""
+    import tempfile
+
+    import numpy as np
+
+    from . import synth_mano
+    from .conv_onet import config as cfgmod
+    from .dist import GradAllReduce
+    root = tempfile.mkdtemp(prefix="vt_mano_")
+    synth_mano.write_pkl(synth_mano.make_asset(0), root)
+    cfg = vtaco_cfg(root, num_sample)
+    torch.manual_seed(0)
+    model = cfgmod.get_model(cfg, device=device)
+    randomise_fc1(model.decoder, 1)
+    randomise_fc1(model.encoder, 2)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    H, W = 320, 240
+    depth_origin = np.full(H * W, 0.02, dtype=np.float64)
+    trainer = cfgmod.get_trainer(model, opt, cfg, device, depth_origin=depth_origin)
+    if grad_sync:
+        trainer.grad_sync = GradAllReduce(model.parameters())
+    g = torch.Generator().manual_seed(5000 + rank)
+    B = scenes
+    cloud = torch.cat([sphere_cloud(1000 * rank + i) for i in range(B)])
+    # depth images: the flat reading with a pressed-in disc of a few hundred pixels on the touched sensors
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    depth = torch.full((B, 5, H * W), 0.02)
+    touch = (torch.rand(B, 5, generator=g) < 0.7)
+    touch[:, 0] = True
+    for b in range(B):
+        for t in range(5):
+            if touch[b, t]:
+                cy, cx = int(torch.randint(60, H - 60, (1,), generator=g)), int(torch.randint(60, W - 60, (1,), generator=g))
+                disc = ((yy - cy) ** 2 + (xx - cx) ** 2) < 12 ** 2
+                depth[b, t][disc.reshape(-1)] = 0.02 - 0.002 * torch.rand(int(disc.sum()), generator=g) - 0.0005
+    d = torch.randn(B, 5, 3, generator=g)
+    verts, faces = icosphere(0.3, 3)
+    batch = {"inputs": cloud, "points": (torch.rand(B, n_points, 3, generator=g) - 0.5) * 1.1,
+             "points.mano": torch.randn(B, 51, generator=g) * 0.2, "points.pc_hand": torch.randn(B, 778, 3, generator=g) * 0.05,
+             "points.name": ["ico"] * B, "points.cam_pos": (0.32 * d / d.norm(dim=-1, keepdim=True)).double(),
+             "points.cam_rot": (torch.rand(B, 5, 3, generator=g) * 2 - 1).double(),
+             "inputs.pc_ply": cloud.clone(), "inputs.img": torch.rand(B, 5, 3, H, W, generator=g) / 255.0,
+             "inputs.depth": depth, "inputs.touch_success": touch.to(torch.uint8)}
+    return model, trainer, batch, {"ico": {"v": verts, "f": faces}}

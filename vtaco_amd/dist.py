@@ -39,18 +39,25 @@ def lattice_align(nx, world):
     return pair if pair * world <= nx ** 3 else 32
 
 
-def all_gather_slabs(local, total, group=None, align=32):
-    """Concatenate per-rank 1-D slabs (possibly ragged) into the full [total] tensor on every rank."""
+def all_gather_slabs(local, total, group=None, align=32, out=None):
+    """Concatenate per-rank 1-D slabs into the full [total] tensor on every rank: ONE collective.  Equal slabs (the
+    plane-pair slabs of 128^3 / 256^3 over 2, 4, 8 ranks) are gathered straight into the output (``all_gather_into_tensor``:
+    no staging copies); ragged ones go through equal-width padded rows."""
     world = dist.get_world_size(group)
     if world == 1:
         return local
     counts = [slab_of(total, r, world, align)[1] for r in range(world)]
+    if min(counts) == max(counts) and dist.get_backend(group) == "nccl":
+        if out is None:
+            out = torch.empty(total, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
     width = max(counts)
     pad = torch.zeros(width, dtype=local.dtype, device=local.device)
     pad[:local.numel()] = local
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad, group=group)
-    return torch.cat([o[:c] for o, c in zip(out, counts)])
+    rows = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(rows, pad, group=group)
+    return torch.cat([o[:c] for o, c in zip(rows, counts)])
 
 
 def decode_lattice_sharded(decode_slab, nx, group=None, align=None, device=None):
