@@ -215,16 +215,22 @@ class Fences:
         return float(t.item())
 
 
-def warm_up(step, min_steps, sync, min_s=MIN_WARM_S):
-    """At least `min_steps` untimed steps AND at least `min_s` seconds of them."""
+def warm_up(step, min_steps, fx, min_s=MIN_WARM_S, collective=False):
+    """At least `min_steps` untimed steps AND at least `min_s` seconds of them.  A step that contains a collective must run
+    the SAME number of times on every rank: the ranks then agree on "enough" after every round of 8 steps (max over ranks
+    of the elapsed time) instead of each consulting its own clock."""
+    import torch
     t0, n = time.perf_counter(), 0
-    while n < min_steps or time.perf_counter() - t0 < min_s:
-        step()
-        n += 1
-        if n % 16 == 0:
-            sync()
-    sync()
-    return n
+    while True:
+        for _ in range(8):
+            step()
+        n += 8
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if collective:
+            elapsed = fx.max_over_ranks(elapsed)
+        if n >= min_steps and elapsed >= min_s:
+            return n
 
 
 def sharded_scene(scene, dev, fx, rank, world, dist, precision, sizes=(128, 256), iters=10):
@@ -263,7 +269,7 @@ def sharded_scene(scene, dev, fx, rank, world, dist, precision, sizes=(128, 256)
                     mesh[0] = gen.extract_mesh(vol.reshape(nx, nx, nx))
                 if record:
                     ev[4].record()
-        warm_up(one, 2, torch.cuda.synchronize, 0.1)
+        warm_up(one, 2, fx, 0.1, collective=world > 1)
         fx.fence()
         t0 = time.perf_counter()
         for _ in range(iters):
@@ -433,7 +439,7 @@ def main():
         def step():
             dec.decode_lattice(grid, nx, box=1.1, c_img=c_img, out=out, precision=args.precision)
 
-    warm_steps = warm_up(step, args.warmup, torch.cuda.synchronize)
+    warm_steps = warm_up(step, args.warmup, fx, collective=strong and world > 1)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fx.fence()
     t0 = time.perf_counter()
@@ -474,7 +480,7 @@ def main():
         if world == 1 and args.precision == "bf16x3":
             # the exact-f32 kernel on the same inputs (what the training forward and precision="f32" run)
             f32_step = lambda: dec.decode_lattice(grid, nx, box=1.1, c_img=c_img, out=out, precision="f32")
-            warm_up(f32_step, 5, torch.cuda.synchronize)
+            warm_up(f32_step, 5, fx)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             ev0.record()
