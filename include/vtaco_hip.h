@@ -193,6 +193,48 @@ int vt_fusion_fwd(const float *c_img, const float *c, int B, int N, const vt_fus
                   void *workspace, size_t workspace_bytes, float *out, void *stream);
 
 /* ------------------------------------------------------------------------- */
+/* TransformerFusion under autograd (training).                                  */
+/* Replaces: PyTorch autograd of self.fuser(c_img, 1, c, 1) (decoder.py:258)      */
+/*   triggered by loss.backward() at src/conv_onet/training.py:79,89,96:          */
+/*   RelationUnit.forward (src/TransformerFusion.py:92-113: l2-normalised WK/WQ,  */
+/*   softmax over keys, the column re-normalisation :104, WV, trans_conv, relu),  */
+/*   TransNonlinear.forward (:21-25, with its two train-mode dropouts :13-19),     */
+/*   the encoder / decoder layers' InstanceNorm1d + relu (:144-145, :209-218).      */
+/* vt_fusion_fwd_train = vt_fusion_fwd that (a) applies the dropouts with          */
+/*   probability p_drop (0 = eval), masks a pure function of `seed`, and            */
+/*   (b) leaves, in `saved` (vt_fusion_saved_bytes, caller-owned, kept until the     */
+/*   backward), per attention call the softmax row sums, column sums, value rows,     */
+/*   attention outputs and pre-InstanceNorm sums -- O(N) state, never N x N.          */
+/* vt_fusion_bwd: d_out [B,N,32] -> d_c_img, d_c [B,N,32] (overwritten) and the     */
+/*   gradient of every parameter, written to the buffers of `grads` (overwritten;   */
+/*   the self-attention unit is ONE module used twice, :291-309: its gradient is     */
+/*   the sum of both uses).  The N x N scores are recomputed tile by tile on the      */
+/*   matrix core; reductions are in a fixed order (bit-reproducible).                 */
+/* vt_fusion_dropout_mask: the factors (0 or 1/(1-p)) the kernels apply for           */
+/*   (call 0 = encoder self-attention, 1 = decoder self-attention, 2 = cross;          */
+/*   which 0 = TransNonlinear.dropout [points,64], 1 = dropout2 [points,32]) --         */
+/*   lets a test feed the same masks to a reference implementation.                     */
+/* ------------------------------------------------------------------------- */
+typedef struct vt_fusion_unit_grads {
+    float *WK, *WQ, *WV, *trans_conv, *linear1_w, *linear1_b, *linear2_w, *linear2_b, *norm2_w, *norm2_b;
+} vt_fusion_unit_grads;
+
+typedef struct vt_fusion_grads {
+    vt_fusion_unit_grads self_attn;
+    vt_fusion_unit_grads cross_attn;
+} vt_fusion_grads;
+
+size_t vt_fusion_saved_bytes(int B, int N);
+size_t vt_fusion_bwd_workspace_bytes(int B, int N);
+int vt_fusion_fwd_train(const float *c_img, const float *c, int B, int N, const vt_fusion_params *params_host, float p_drop,
+                        unsigned long long seed, void *workspace, size_t workspace_bytes, void *saved, size_t saved_bytes,
+                        float *out, void *stream);
+int vt_fusion_bwd(const float *d_out, const float *c_img, const float *c, int B, int N, const vt_fusion_params *params_host,
+                  float p_drop, unsigned long long seed, const void *saved, size_t saved_bytes, void *workspace,
+                  size_t workspace_bytes, float *d_c_img, float *d_c, const vt_fusion_grads *grads_host, void *stream);
+int vt_fusion_dropout_mask(float p_drop, unsigned long long seed, int call, int which, int points, float *mask, void *stream);
+
+/* ------------------------------------------------------------------------- */
 /* Backward of vt_decode_fwd (training).                                        */
 /* Replaces: PyTorch autograd of LocalDecoder.forward / forward_img, triggered   */
 /*   by loss.backward() at src/conv_onet/training.py:79,89,96 (grid_sampler_3d   */

@@ -176,16 +176,23 @@ def _relation_unit(sd, pre, q, k, v):
     return F.relu((q - out) @ sd[pre + ".trans_conv.weight"].t())
 
 
-def _trans_nonlinear(sd, pre, x):
-    """``TransNonlinear.forward`` in eval mode (TransformerFusion.py:21-25)."""
-    y = _lin(sd, pre + ".linear2", F.relu(_lin(sd, pre + ".linear1", x)))
+def _trans_nonlinear(sd, pre, x, masks=None):
+    """``TransNonlinear.forward`` (TransformerFusion.py:21-25).  Eval mode by default; ``masks = (m1 [..,64], m2 [..,32])``
+    are the factors (0 or 1/(1-p)) of its two train-mode dropouts (:13-19), given explicitly so that a test can replay
+    the masks another implementation drew."""
+    h = F.relu(_lin(sd, pre + ".linear1", x))
+    if masks is not None:
+        h = h * masks[0]
+    y = _lin(sd, pre + ".linear2", h)
+    if masks is not None:
+        y = y * masks[1]
     x = x + y
     return F.layer_norm(x, (x.shape[-1],), sd[pre + ".norm2.weight"], sd[pre + ".norm2.bias"], 1e-5)
 
 
-def _mha1(sd, pre, q, k, v):
+def _mha1(sd, pre, q, k, v, masks=None):
     """Single-head ``MultiheadAttention`` (TransformerFusion.py:42-62)."""
-    return _trans_nonlinear(sd, pre + ".extra_nonlinear.0", _relation_unit(sd, pre + ".head.0", q, k, v))
+    return _trans_nonlinear(sd, pre + ".extra_nonlinear.0", _relation_unit(sd, pre + ".head.0", q, k, v), masks)
 
 
 def _inorm_relu(x):
@@ -196,16 +203,18 @@ def _inorm_relu(x):
     return F.relu((x - m) / torch.sqrt(var + 1e-5))
 
 
-def transformer_fusion(sd, c_img, c):
+def transformer_fusion(sd, c_img, c, masks=None):
     """``TransformerFusion.forward(search=c_img, template=c)`` with
-    ``num_layers=1, with_pos_embed=False`` in eval mode
-    (TransformerFusion.py:311-333).  ``sd`` keys are relative to ``fuser.``."""
+    ``num_layers=1, with_pos_embed=False`` (TransformerFusion.py:311-333); eval mode unless ``masks`` (three pairs of
+    dropout factors: encoder self-attention, decoder self-attention, cross-attention) is given.
+    ``sd`` keys are relative to ``fuser.``."""
+    masks = masks or (None, None, None)
     sa = "encoder.layers.0.self_attn"                       # shared with decoder's self_attn
-    mem = _inorm_relu(c + _mha1(sd, sa, c, c, c))
+    mem = _inorm_relu(c + _mha1(sd, sa, c, c, c, masks[0]))
     sa_d = "decoder.layers.0.self_attn"
-    tgt = _inorm_relu(c_img + _mha1(sd, sa_d, c_img, c_img, c_img))
+    tgt = _inorm_relu(c_img + _mha1(sd, sa_d, c_img, c_img, c_img, masks[1]))
     ca = "decoder.layers.0.cross_attn"
-    return _inorm_relu(tgt + _mha1(sd, ca, tgt, mem, mem))
+    return _inorm_relu(tgt + _mha1(sd, ca, tgt, mem, mem, masks[2]))
 
 
 def attention_decoder_forward_img(sd, p, grid, c_img, padding=0.1):

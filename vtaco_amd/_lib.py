@@ -50,6 +50,11 @@ class FusionParams(ctypes.Structure):
                 ("self_attn", FusionUnit), ("cross_attn", FusionUnit)]
 
 
+class FusionGrads(ctypes.Structure):
+    """Mirror of ``vt_fusion_grads`` (two ``vt_fusion_unit_grads``: the same ten names, gradient buffers)."""
+    _fields_ = [("self_attn", FusionUnit), ("cross_attn", FusionUnit)]
+
+
 VT_UNET_MAX_LEVELS = 6
 
 
@@ -83,6 +88,12 @@ SIGNATURES = {
     "vt_decode_mlp_fwd": (_I, [_VP, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP]),
     "vt_fusion_workspace_bytes": (_SZ, [_I, _I]),
     "vt_fusion_fwd": (_I, [_VP, _VP, _I, _I, ctypes.POINTER(FusionParams), _VP, _SZ, _VP, _VP]),
+    "vt_fusion_saved_bytes": (_SZ, [_I, _I]),
+    "vt_fusion_bwd_workspace_bytes": (_SZ, [_I, _I]),
+    "vt_fusion_fwd_train": (_I, [_VP, _VP, _I, _I, ctypes.POINTER(FusionParams), _F, ctypes.c_ulonglong, _VP, _SZ, _VP, _SZ, _VP, _VP]),
+    "vt_fusion_bwd": (_I, [_VP, _VP, _VP, _I, _I, ctypes.POINTER(FusionParams), _F, ctypes.c_ulonglong, _VP, _SZ, _VP, _SZ, _VP, _VP,
+                           ctypes.POINTER(FusionGrads), _VP]),
+    "vt_fusion_dropout_mask": (_I, [_F, ctypes.c_ulonglong, _I, _I, _I, _VP, _VP]),
     "vt_decoder_blob_t_bytes": (_SZ, [_I, _I, _I]),
     "vt_decoder_pack_bf16x3": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
     "vt_decode_fwd_bf16x3": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP, _I, _VP, _D, _VP, _VP, _VP]),

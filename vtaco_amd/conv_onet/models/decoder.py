@@ -241,10 +241,10 @@ class AttentionDecoder(LocalDecoder):
     def forward_img(self, p, c_plane, c_img, **kwargs):
         grid = self._grid_of(c_plane)
         if self._wants_grad(grid, c_img):
-            # under autograd: HIP sampling and MLP (forward + backward kernels) around the fuser's
-            # host-PyTorch form (train-mode dropout and its backward come from torch)
+            # under autograd every stage is HIP, forward and backward: vt_sample_grid[_bwd], vt_fusion_fwd_train / vt_fusion_bwd
+            # (train-mode dropout replayed from a seed), vt_decode_mlp_fwd_train / vt_decode_mlp_bwd / vt_decode_wgrad
             c = _SampleGridFn.apply(grid, p, self.padding)
-            c = self.fuser.forward_torch(c_img, c)
+            c = self.fuser.forward_train(c_img, c)
             return _DecodeMlpFn.apply(self, p, c, *self._params(False))
         c = ops.sample_grid(grid, p, self.padding)
         c = self.fuser(c_img, 1, c, 1)

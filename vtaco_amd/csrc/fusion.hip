@@ -17,36 +17,9 @@
 //   attend  O_q = (1/l_q) sum_k e^{S_qk} V_k / (1e-9 + s_k), chained into the epilogue MLP.
 // Score tiles come out of the MFMA with the fixed index on the lane and the streamed index
 // in the 16 registers, which is exactly the B operand the next MFMA (E x V') needs.
-#include "decode_common.h"
+#include "fusion_common.h"
 
 namespace {
-
-constexpr int FU_WT = 0, FU_W1A = 1024, FU_W1B = 2048, FU_W2A = 3072, FU_W2B = 4096;
-constexpr int FU_BIAS = 5120;           // b1a, b1b, b2, gamma, beta fragments [2][16] each
-constexpr int FU_BLOB = FU_BIAS + 5 * 32;
-
-struct FusionUnitDev {
-    const float *WK, *WQ, *WV, *Wt, *l1w, *l1b, *l2w, *l2b, *lnw, *lnb;
-};
-
-// epilogue weights -> accumulator-fed fragment order (k = chan_of(s, h))
-__global__ void fusion_pack_kernel(FusionUnitDev u, float *blob) {
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < FU_BLOB; e += gridDim.x * blockDim.x) {
-        float v;
-        if (e < FU_BIAS) {
-            const int L = e >> 10, s = (e >> 6) & 15, l = e & 63, i = l & 31, h = l >> 5, k = chan_of(s, h);
-            if (L == 0) v = u.Wt[i * 32 + k];
-            else if (L == 1) v = u.l1w[i * 32 + k];               // linear1 rows 0..31
-            else if (L == 2) v = u.l1w[(32 + i) * 32 + k];        // linear1 rows 32..63
-            else if (L == 3) v = u.l2w[i * 64 + k];               // linear2 cols 0..31
-            else v = u.l2w[i * 64 + 32 + k];                      // linear2 cols 32..63
-        } else {
-            const int q = e - FU_BIAS, j = q >> 5, h = (q >> 4) & 1, r = q & 15, o = chan_of(r, h);
-            v = j == 0 ? u.l1b[o] : j == 1 ? u.l1b[32 + o] : j == 2 ? u.l2b[o] : j == 3 ? u.lnw[o] : u.lnb[o];
-        }
-        blob[e] = v;
-    }
-}
 
 // ---- split-bf16 operands --------------------------------------------------------------------
 // The N x N products run on the bf16 matrix core with every f32 operand carried as
@@ -266,9 +239,11 @@ fusion_scalev_kernel(const float *V, const float *s, float *VT, int N, int ntile
 
 // attention output + RelationUnit tail + TransNonlinear + residual: Z = X_q + LN(...)
 constexpr int VROW = 36;                                    // V' tile row: 128 B + 16 B pad
+// TRAIN: the attention output O is kept for the backward and TransNonlinear's two dropouts are applied (masks: drop_mask).
+template <bool TRAIN>
 __global__ void __launch_bounds__(FT)
 fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const float *linv, const float *Xq,
-                     const float *blob, float *Z, int N, int ntile_) {
+                     const float *blob, float *Z, int N, int ntile_, float *Osave, DropCfg dc) {
     __shared__ __attribute__((aligned(16))) float lds[FU_BLOB];
     __shared__ __attribute__((aligned(16))) float tiles[2][STILE];
     __shared__ __attribute__((aligned(16))) float vts[2][32 * VROW];
@@ -324,6 +299,8 @@ fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const fl
     // lane (q,h) reg r = channel chan_of(r,h) of the attention output: the accumulator layout
     const float *xrow = Xq + ((size_t)b * N + q) * 32;
     const f32x16 x = load_acc16(xrow, h);
+    const uint32_t pt = (uint32_t)((size_t)b * N + q);
+    if (TRAIN && q0 + j < N) store_acc16(Osave + (size_t)pt * 32, o, h);
     f32x16 d = x - o;
     f32x16 r;
 #pragma unroll
@@ -334,8 +311,16 @@ fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const fl
     ha = dense32<false>(ha, lds + FU_W1A, r, lane);
     hb = dense32<false>(hb, lds + FU_W1B, r, lane);
     f32x16 t2 = load_frag16(lds + FU_BIAS + 2 * 32 + h * 16);
-    t2 = dense32<true>(t2, lds + FU_W2A, ha, lane);
-    t2 = dense32<true>(t2, lds + FU_W2B, hb, lane);
+    if (TRAIN) {
+        ha = drop16(relu16(ha), dc, 0, pt, h, 0);
+        hb = drop16(relu16(hb), dc, 0, pt, h, 32);
+        t2 = dense32<false>(t2, lds + FU_W2A, ha, lane);
+        t2 = dense32<false>(t2, lds + FU_W2B, hb, lane);
+        t2 = drop16(t2, dc, 1, pt, h, 0);
+    } else {
+        t2 = dense32<true>(t2, lds + FU_W2A, ha, lane);
+        t2 = dense32<true>(t2, lds + FU_W2B, hb, lane);
+    }
     t2 = t2 + r;
     // LayerNorm over the 32 channels of this point (16 registers x 2 lane halves)
     float m = 0.0f;
@@ -404,13 +389,10 @@ size_t fusion_layout(int B, int N, FusionWs *ws, char *base) {
     return off;
 }
 
-FusionUnitDev unit_of(const vt_fusion_unit &u) {
-    return FusionUnitDev{u.WK, u.WQ, u.WV, u.trans_conv, u.linear1_w, u.linear1_b, u.linear2_w, u.linear2_b, u.norm2_w, u.norm2_b};
-}
-
-// one attention unit: Xq against Xk -> out = relu(IN(Xq + MHA(Xq, Xk, Xk)))
+// one attention unit: Xq against Xk -> out = relu(IN(Xq + MHA(Xq, Xk, Xk))).  ``Osave`` != null: training forward (w.l / w.s /
+// w.V / w.Z then point into the caller's saved state instead of the scratch workspace, and the dropouts of ``dc`` are applied)
 void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const float *blob, const FusionWs &w,
-              float *out, int B, int N, hipStream_t s) {
+              float *out, int B, int N, hipStream_t s, float *Osave = nullptr, DropCfg dc = DropCfg{0, 0, 1.0f, 0}) {
     const int P = B * N, Npad = (N + 31) / 32 * 32;
     const int ntile = (N + 31) / 32;
     const dim3 pg((P + 127) / 128), tg((N + FROWS - 1) / FROWS, B);
@@ -426,7 +408,10 @@ void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const fl
     size_t g = (tot + 255) / 256;
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(fusion_scalev_kernel, dim3((unsigned)g), dim3(256), 0, s, w.V, w.s, w.VT, N, ntile, tot);
-    hipLaunchKernelGGL(fusion_attend_kernel, tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile);
+    if (Osave)
+        hipLaunchKernelGGL(fusion_attend_kernel<true>, tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
+    else
+        hipLaunchKernelGGL(fusion_attend_kernel<false>, tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
     hipLaunchKernelGGL(fusion_inorm_relu_kernel, dim3(B), dim3(1024), 0, s, w.Z, out, N);
 }
 
@@ -454,6 +439,37 @@ int vt_fusion_fwd(const float *c_img, const float *c, int B, int N, const vt_fus
     run_unit(c_img, c_img, us, w.blob_s, w, w.T, B, N, s);         // decoder self-attention (SAME weights)
     run_unit(w.T, w.M, ux, w.blob_x, w, out, B, N, s);             // decoder cross-attention
     return vt_check(hipGetLastError(), "vt_fusion_fwd");
+}
+
+size_t vt_fusion_saved_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return fusion_saved_layout(B, N, nullptr, nullptr);
+}
+
+int vt_fusion_fwd_train(const float *c_img, const float *c, int B, int N, const vt_fusion_params *p, float p_drop,
+                        unsigned long long seed, void *workspace, size_t workspace_bytes, void *saved, size_t saved_bytes,
+                        float *out, void *stream) {
+    if (!c_img || !c || !p || !workspace || !saved || !out) return vt_fail(VT_ERR_INVALID, "vt_fusion_fwd_train: null argument");
+    if (B <= 0 || N <= 0) return vt_fail(VT_ERR_INVALID, "vt_fusion_fwd_train: bad size");
+    if (!(p_drop >= 0.0f && p_drop < 1.0f)) return vt_fail(VT_ERR_INVALID, "vt_fusion_fwd_train: p_drop must be in [0, 1)");
+    if (p->d_model != 32 || p->key_dim != 64) return vt_fail(VT_ERR_UNSUPPORTED, "vt_fusion_fwd_train: d_model=32, key_feature_dim=64 only");
+    FusionWs w;
+    FusionSaved sv;
+    if (workspace_bytes < fusion_layout(B, N, &w, (char *)workspace)) return vt_fail(VT_ERR_WORKSPACE, "vt_fusion_fwd_train: workspace too small");
+    if (saved_bytes < fusion_saved_layout(B, N, &sv, (char *)saved)) return vt_fail(VT_ERR_WORKSPACE, "vt_fusion_fwd_train: saved-state buffer too small");
+    hipStream_t s = (hipStream_t)stream;
+    const FusionUnitDev us = unit_of(p->self_attn), ux = unit_of(p->cross_attn);
+    hipLaunchKernelGGL(fusion_pack_kernel, dim3(6), dim3(1024), 0, s, us, w.blob_s);
+    hipLaunchKernelGGL(fusion_pack_kernel, dim3(6), dim3(1024), 0, s, ux, w.blob_x);
+    auto call = [&](int k, const float *Xq, const float *Xk, const FusionUnitDev &u, const float *blob, float *dst) {
+        FusionWs wk = w;
+        wk.l = sv.linv[k]; wk.s = sv.s[k]; wk.V = sv.V[k]; wk.Z = sv.Z[k];
+        run_unit(Xq, Xk, u, blob, wk, dst, B, N, s, sv.O[k], drop_cfg(p_drop, seed, (uint32_t)k));
+    };
+    call(0, c, c, us, w.blob_s, sv.M);                             // encoder: memory from the grid features
+    call(1, c_img, c_img, us, w.blob_s, sv.T);                     // decoder self-attention (SAME weights)
+    call(2, sv.T, sv.M, ux, w.blob_x, out);                        // decoder cross-attention
+    return vt_check(hipGetLastError(), "vt_fusion_fwd_train");
 }
 
 }  // extern "C"

@@ -605,6 +605,23 @@ def decode_mlp_fwd(c, blob, pts):
     return out
 
 
+FUSION_TENSORS = tuple(n for n, _t in _lib.FusionUnit._fields_)
+
+
+def _fusion_params(self_attn, cross_attn, C, keep):
+    def unit(d):
+        u = _lib.FusionUnit()
+        for name in FUSION_TENSORS:
+            t = _c(d[name].detach())
+            keep.append(t)
+            setattr(u, name, dev_ptr(t, name).value)
+        return u
+    prm = _lib.FusionParams()
+    prm.d_model, prm.key_dim = C, self_attn["WK"].shape[0]
+    prm.self_attn, prm.cross_attn = unit(self_attn), unit(cross_attn)
+    return prm
+
+
 def fusion_fwd(c_img, c, self_attn, cross_attn):
     """TransformerFusion forward, eval mode (vt_fusion_fwd).  ``self_attn`` / ``cross_attn``:
     dicts with the ten tensors of a vt_fusion_unit."""
@@ -614,22 +631,64 @@ def fusion_fwd(c_img, c, self_attn, cross_attn):
     if tuple(c_img.shape) != (B, N, C):
         raise VtError(f"fusion: c_img {tuple(c_img.shape)} and c {tuple(c.shape)} must match")
     keep = []
-
-    def unit(d):
-        u = _lib.FusionUnit()
-        for name, _t in _lib.FusionUnit._fields_:
-            t = _c(d[name])
-            keep.append(t)
-            setattr(u, name, dev_ptr(t, name).value)
-        return u
-    prm = _lib.FusionParams()
-    prm.d_model, prm.key_dim = C, self_attn["WK"].shape[0]
-    prm.self_attn, prm.cross_attn = unit(self_attn), unit(cross_attn)
+    prm = _fusion_params(self_attn, cross_attn, C, keep)
     nbytes = lib.vt_fusion_workspace_bytes(B, N)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=c.device)
     out = torch.empty((B, N, C), dtype=torch.float32, device=c.device)
     check(lib.vt_fusion_fwd(dev_ptr(c_img, "c_img"), dev_ptr(c, "c"), B, N, ctypes.byref(prm),
                             ctypes.c_void_p(ws.data_ptr()), nbytes, dev_ptr(out, "out"), stream_ptr()), "vt_fusion_fwd")
+    return out
+
+
+def fusion_fwd_train(c_img, c, self_attn, cross_attn, p_drop=0.0, seed=0):
+    """TransformerFusion forward for training (vt_fusion_fwd_train): dropout with probability ``p_drop`` (masks a function
+    of ``seed``) and the O(N) state the backward needs.  Returns (out [B,N,C], saved: opaque uint8 tensor)."""
+    lib = _lib.load()
+    c_img, c = _c(c_img.float()), _c(c.float())
+    B, N, C = c.shape
+    if tuple(c_img.shape) != (B, N, C):
+        raise VtError(f"fusion: c_img {tuple(c_img.shape)} and c {tuple(c.shape)} must match")
+    keep = []
+    prm = _fusion_params(self_attn, cross_attn, C, keep)
+    nbytes, sbytes = lib.vt_fusion_workspace_bytes(B, N), lib.vt_fusion_saved_bytes(B, N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=c.device)
+    saved = torch.empty(sbytes, dtype=torch.uint8, device=c.device)
+    out = torch.empty((B, N, C), dtype=torch.float32, device=c.device)
+    check(lib.vt_fusion_fwd_train(dev_ptr(c_img, "c_img"), dev_ptr(c, "c"), B, N, ctypes.byref(prm), float(p_drop), int(seed),
+                                  ctypes.c_void_p(ws.data_ptr()), nbytes, ctypes.c_void_p(saved.data_ptr()), sbytes,
+                                  dev_ptr(out, "out"), stream_ptr()), "vt_fusion_fwd_train")
+    return out, saved
+
+
+def fusion_bwd(d_out, c_img, c, self_attn, cross_attn, saved, p_drop=0.0, seed=0):
+    """Backward of ``fusion_fwd_train`` (vt_fusion_bwd).  Returns (d_c_img, d_c, grads_self, grads_cross): the last two are
+    dicts name -> gradient tensor with the shapes of the unit's parameters (the self unit's: the sum of its two uses)."""
+    lib = _lib.load()
+    d_out, c_img, c = _c(d_out.float()), _c(c_img.float()), _c(c.float())
+    B, N, C = c.shape
+    keep = []
+    prm = _fusion_params(self_attn, cross_attn, C, keep)
+    grads = _lib.FusionGrads()
+    outs = []
+    for unit, src in ((grads.self_attn, self_attn), (grads.cross_attn, cross_attn)):
+        g = {name: torch.empty_like(src[name], memory_format=torch.contiguous_format) for name in FUSION_TENSORS}
+        for name in FUSION_TENSORS:
+            setattr(unit, name, dev_ptr(g[name], "grad " + name).value)
+        outs.append(g)
+    d_c_img, d_c = torch.empty_like(c), torch.empty_like(c)
+    nbytes = lib.vt_fusion_bwd_workspace_bytes(B, N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=c.device)
+    check(lib.vt_fusion_bwd(dev_ptr(d_out, "d_out"), dev_ptr(c_img, "c_img"), dev_ptr(c, "c"), B, N, ctypes.byref(prm), float(p_drop),
+                            int(seed), ctypes.c_void_p(saved.data_ptr()), saved.numel(), ctypes.c_void_p(ws.data_ptr()), nbytes,
+                            dev_ptr(d_c_img, "d_c_img"), dev_ptr(d_c, "d_c"), ctypes.byref(grads), stream_ptr()), "vt_fusion_bwd")
+    return d_c_img, d_c, outs[0], outs[1]
+
+
+def fusion_dropout_mask(p_drop, seed, call, which, points, device):
+    """The dropout factors (0 or 1/(1-p)) the fusion kernels apply: [points, 64] for which=0, [points, 32] for which=1."""
+    out = torch.empty((points, 64 if which == 0 else 32), dtype=torch.float32, device=device)
+    check(_lib.load().vt_fusion_dropout_mask(float(p_drop), int(seed), int(call), int(which), int(points), dev_ptr(out, "mask"),
+                                            stream_ptr()), "vt_fusion_dropout_mask")
     return out
 
 

@@ -5,8 +5,11 @@ trans_conv,after_norm}``, ``...extra_nonlinear.0.{linear1,linear2,norm2}``,
 ``decoder.layers.0.{self_attn,cross_attn}...`` -- including the fact that the encoder
 layer and the decoder layer's self-attention are the SAME module (state_dict lists it
 under both names).  Without autograd the forward is the HIP pipeline ``vt_fusion_fwd`` (eval
-mode: the reference's dropout layers are identity there); under autograd it is the same
-arithmetic as host-PyTorch ops (``forward_torch``: train-mode dropout, torch's backward).
+mode: the reference's dropout layers are identity there); under autograd it is ``_FusionFn``:
+``vt_fusion_fwd_train`` (the same pipeline with TransNonlinear's two train-mode dropouts, masks a
+function of a per-call seed drawn from torch's generator) and ``vt_fusion_bwd`` (gradients of
+c_img, c and all twenty parameter tensors; the shared self-attention's are the sum of its two uses).
+``forward_torch`` keeps the same arithmetic as host-PyTorch ops for reference.
 """
 from __future__ import annotations
 
@@ -85,6 +88,30 @@ class _Stack(nn.Module):
         self.layers = nn.ModuleList([layer])
 
 
+class _FusionFn(torch.autograd.Function):
+    """fuse(c_img, c) under autograd on the HIP kernels; ``tensors`` = the ten tensors of the self-attention unit followed by the
+    ten of the cross-attention unit (ops.FUSION_TENSORS order)."""
+
+    @staticmethod
+    def forward(ctx, c_img, c, p_drop, seed, *tensors):
+        n = len(ops.FUSION_TENSORS)
+        sa, ca = dict(zip(ops.FUSION_TENSORS, tensors[:n])), dict(zip(ops.FUSION_TENSORS, tensors[n:]))
+        out, saved = ops.fusion_fwd_train(c_img, c, sa, ca, p_drop, seed)
+        ctx.save_for_backward(c_img, c, saved, *tensors)
+        ctx.cfg = (p_drop, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        c_img, c, saved, *tensors = ctx.saved_tensors
+        n = len(ops.FUSION_TENSORS)
+        sa, ca = dict(zip(ops.FUSION_TENSORS, tensors[:n])), dict(zip(ops.FUSION_TENSORS, tensors[n:]))
+        p_drop, seed = ctx.cfg
+        d_c_img, d_c, g_sa, g_ca = ops.fusion_bwd(d_out, c_img, c, sa, ca, saved, p_drop, seed)
+        grads = [g_sa[k] for k in ops.FUSION_TENSORS] + [g_ca[k] for k in ops.FUSION_TENSORS]
+        return (d_c_img, d_c, None, None, *grads)
+
+
 class TransformerFusion(nn.Module):
     def __init__(self, use_xyz=True, input_size=2048, d_model=32, num_layers=1, key_feature_dim=128,
                  with_pos_embed=True, encoder_pos_embed_input_dim=3, decoder_pos_embed_input_dim=3):
@@ -114,9 +141,32 @@ class TransformerFusion(nn.Module):
 
     def forward(self, search_feature, search_coord, template_feature, template_coord):
         """fuse(search=c_img [B,N,C], template=c [B,N,C]) -> [B,N,C]  (TransformerFusion.py:311-333)."""
-        if torch.is_grad_enabled() and (self.training or search_feature.requires_grad or template_feature.requires_grad
-                                        or any(p.requires_grad for p in self.parameters())):
-            return self.forward_torch(search_feature, template_feature)
         layer = self.decoder.layers[0]
-        return ops.fusion_fwd(search_feature, template_feature, layer.self_attn.unit_tensors(),
-                              layer.cross_attn.unit_tensors())
+        sa, ca = layer.self_attn.unit_tensors(), layer.cross_attn.unit_tensors()
+        if torch.is_grad_enabled() and (search_feature.requires_grad or template_feature.requires_grad
+                                        or any(p.requires_grad for p in self.parameters())):
+            return self.forward_train(search_feature, template_feature)
+        if self.training and self.p_drop > 0:
+            # train mode without autograd (no_grad evaluation of a model left in train()): dropout still applies
+            return ops.fusion_fwd_train(search_feature, template_feature, sa, ca, self.p_drop, self._draw_seed())[0]
+        return ops.fusion_fwd(search_feature, template_feature, sa, ca)
+
+    @property
+    def p_drop(self):
+        return self.decoder.layers[0].self_attn.extra_nonlinear[0].p_drop
+
+    @staticmethod
+    def _draw_seed():
+        """A fresh 63-bit seed from torch's CPU generator (so ``torch.manual_seed`` makes a run repeatable)."""
+        return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+    def forward_train(self, search_feature, template_feature, seed=None):
+        """Differentiable HIP path (vt_fusion_fwd_train / vt_fusion_bwd); dropout active in training mode only."""
+        layer = self.decoder.layers[0]
+        sa, ca = layer.self_attn.unit_tensors(), layer.cross_attn.unit_tensors()
+        p = self.p_drop if self.training else 0.0
+        if seed is None:
+            seed = self._draw_seed() if p > 0 else 0
+        self.last_seed = seed
+        return _FusionFn.apply(search_feature, template_feature, p, seed,
+                               *[sa[k] for k in ops.FUSION_TENSORS], *[ca[k] for k in ops.FUSION_TENSORS])
