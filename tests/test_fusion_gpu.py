@@ -104,7 +104,9 @@ def test_attention_decoder_forward_img_backward_vs_oracle_autograd():
             assert prm.grad is None or float(prm.grad.abs().max()) == 0.0
             continue
         # (a LayerNorm bias in front of an InstanceNorm over the points has an exactly-zero gradient: rounding noise only)
-        assert float((prm.grad.cpu() - want).abs().max()) <= 1e-4 * max(float(want.abs().max()), 1e-3 * gscale), name
+        # (such exactly-zero gradients are f32 rounding noise of sums whose terms have the size of the other gradients:
+        # the floor is 1e-6 of the largest gradient)
+        assert float((prm.grad.cpu() - want).abs().max()) <= 1e-4 * max(float(want.abs().max()), 1e-2 * gscale), name
         checked += 1
     assert checked >= 40
 
@@ -157,7 +159,7 @@ def _check_fusion_grads(fuser, sdr, c_img_dev, c_dev, cr, cc, tol):
             want = want + sdr[twin].grad if want is not None else sdr[twin].grad
         assert want is not None, name
         err = float((prm.grad.cpu() - want).abs().max())
-        assert err <= tol * max(float(want.abs().max()), 1e-3 * gscale), (name, err, float(want.abs().max()))
+        assert err <= tol * max(float(want.abs().max()), 1e-2 * gscale), (name, err, float(want.abs().max()))
         checked += 1
     assert checked == 20
 
