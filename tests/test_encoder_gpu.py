@@ -159,6 +159,56 @@ def test_graphed_scene_equals_eager():
         assert torch.equal(eager.faces, fast.faces) and torch.equal(eager.vertices, fast.vertices)
 
 
+def test_graphed_scene_survives_weight_updates_and_other_shapes():
+    """A captured scene graph holds raw pointers to packed weights, the decoder blob and the UNet3D workspace.  After an in-place
+    weight update (optimizer.step / load_state_dict), after an eager encode of ANOTHER shape (which re-allocates the shared
+    workspace) and after allocator churn, a replay must still equal the eager result -- it re-captures when the weight stamps
+    changed and keeps its buffers alive otherwise."""
+    from vtaco_amd.bench_util import randomise_fc1, sphere_cloud
+    from vtaco_amd.conv_onet.generation import Generator3D
+    from vtaco_amd.conv_onet.models import ConvolutionalOccupancyNetwork, decoder_dict
+    from vtaco_amd.encoder import encoder_dict
+    torch.manual_seed(0)
+    dec = decoder_dict['simple_local'](dim=3, c_dim=32, hidden_size=32)
+    randomise_fc1(dec, 1)
+    enc = encoder_dict['pointnet_local_pool'](c_dim=32, dim=3, hidden_dim=32, unet3d=True, grid_resolution=32, plane_type='grid',
+                                              unet3d_kwargs=dict(num_levels=3, f_maps=32, in_channels=32, out_channels=32))
+    randomise_fc1(enc, 2)
+    model = ConvolutionalOccupancyNetwork(dec, enc, device=DEV)
+    gen = Generator3D(model, device=DEV, resolution0=16, padding=0.1)
+    p = sphere_cloud(0, T=1500)
+
+    def same():
+        eager = gen.generate_obj_mesh_wnf({"inputs": p})
+        fast = gen.generate_mesh_graphed(p)
+        return torch.equal(eager.faces, fast.faces) and torch.equal(eager.vertices, fast.vertices) and eager.faces.shape[0] > 0
+    assert same()
+    g0 = gen._graphs[next(iter(gen._graphs))]["graph"]
+    assert same() and gen._graphs[next(iter(gen._graphs))]["graph"] is g0          # unchanged weights: the same graph replays
+    # (1) in-place weight update
+    with torch.no_grad():
+        for prm in model.parameters():
+            prm.mul_(1.01)
+    assert same() and gen._graphs[next(iter(gen._graphs))]["graph"] is not g0      # stamps changed: captured afresh
+    g1 = gen._graphs[next(iter(gen._graphs))]["graph"]
+    # (2) eager work of another batch size / resolution re-allocates the shared UNet3D workspace; then allocator churn
+    with torch.no_grad():
+        model.encode_inputs(torch.cat([sphere_cloud(1, T=1500), sphere_cloud(2, T=1500)]).to(DEV))
+    junk = [torch.randn(1 << 20, device=DEV) for _ in range(64)]
+    del junk
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 18,), float("nan"), device=DEV) for _ in range(256)]  # recycled blocks would poison a stale graph
+    fast = gen.generate_mesh_graphed(p)
+    assert gen._graphs[next(iter(gen._graphs))]["graph"] is g1
+    del junk
+    eager = gen.generate_obj_mesh_wnf({"inputs": p})
+    assert torch.equal(eager.faces, fast.faces) and torch.equal(eager.vertices, fast.vertices)
+    # (3) load_state_dict (in-place copy of other values)
+    sd = {k: v.clone() * 0.99 if v.dtype.is_floating_point else v for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    assert same()
+
+
 @pytest.mark.parametrize("N,C1,C2,H,O,shortcut", [(3000, 32, 32, 32, 32, True), (1, 64, 0, 32, 32, True), (257, 32, 0, 16, 32, False),
                                                    (1000, 24, 24, 48, 40, True), (5, 48, 16, 64, 64, False)])
 def test_resblock_fc_and_linear_rows_against_torch(N, C1, C2, H, O, shortcut):
@@ -232,3 +282,98 @@ def test_voxel_sort_extremes(B, Tn, R):
         first = torch.searchsorted(sorted_ids, idx[b], right=False)
         last = torch.searchsorted(sorted_ids, idx[b], right=True)
         assert torch.equal(lo[b], first) and torch.equal(hi[b], last)
+
+
+def _dense_cloud(kind, T, seed):
+    """Clouds whose cells are DENSE: 'one' = all T points in one cell; 'mixed' = a few cells of 1..3000 points (lengths on both
+    sides of the 32-point switch between the per-head and the cooperative reduction, segments that start on / straddle the
+    32-aligned positions); 'planes' = a surface sampled so that 32^2 plane cells hold dozens of points."""
+    g = torch.Generator().manual_seed(seed)
+    if kind == "one":
+        return 0.2 + 0.001 * torch.rand(1, T, 3, generator=g)
+    if kind == "mixed":
+        sizes = [1, 31, 32, 33, 64, 65, 1, 2, 700, 3000, 5, 40]
+        sizes.append(T - sum(sizes))
+        centres = (torch.rand(len(sizes), 3, generator=g) - 0.5) * 0.9
+        pts = torch.cat([centres[i] + 0.0005 * torch.rand(n, 3, generator=g) for i, n in enumerate(sizes)])
+        return pts[torch.randperm(T, generator=g)].unsqueeze(0)
+    d = torch.randn(2, T, 3, generator=g)
+    return 0.3 * d / d.norm(dim=-1, keepdim=True)
+
+
+@pytest.mark.parametrize("kind,T,R,plane", [("one", 8192, 64, None), ("mixed", 8192, 16, None), ("one", 8192, 32, "xz"),
+                                            ("planes", 3000, 32, "xy"), ("mixed", 5000, 8, "yz")])
+def test_dense_cells_one_pass_per_segment(kind, T, R, plane):
+    """The per-segment reductions on dense cells (the quadratic case of a per-point rescan: all 8192 points in ONE cell, plane
+    cells with dozens of points, lengths around the 32-point switch): max + argmax bit-exact against the oracle (ties to the
+    first point), mean and both backwards within f32 summation noise; channels-last and NCDHW scatter agree; and it is fast --
+    the all-in-one-cell case used to take ~2e9 loads."""
+    import time
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd import ops
+    p = _dense_cloud(kind, T, 11)
+    B = p.shape[0]
+    g = torch.Generator().manual_seed(12)
+    feat = torch.randn(B, T, 32, generator=g)
+    feat[:, ::7] = feat[:, ::7].round()                          # plenty of exact ties
+    if plane is None:
+        idx = orc.voxel_index(p, R)
+        vi = ops.VoxelIndex(p.to(DEV), R)
+    else:
+        idx = orc.plane_index(p, R, plane=plane)
+        vi = ops.PlaneIndex(p.to(DEV), R, 0.1, plane)
+    assert torch.equal(vi.idx.cpu().long(), idx)
+    counts = torch.bincount(idx[0])
+    assert int(counts.max()) > 32
+    fd = feat.to(DEV)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out, arg = ops.voxel_pool_max_fwd(fd, vi)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ref = orc.segment_pool_max(feat, idx)
+    assert torch.equal(out.cpu(), ref)
+    # argmax = the FIRST point of the cell that attains the maximum
+    a = arg.cpu().long()
+    for b in range(B):
+        got = feat[b].gather(0, a[b])
+        assert torch.equal(got, ref[b])
+        first = torch.full((int(idx[b].max()) + 1, 32), T, dtype=torch.long)
+        hit = feat[b] == ref[b]
+        tt = torch.arange(T).unsqueeze(1).expand(T, 32)
+        first.scatter_reduce_(0, idx[b].unsqueeze(1).expand(T, 32), torch.where(hit, tt, torch.full_like(tt, T)), "amin")
+        assert torch.equal(a[b], first[idx[b]])
+    assert dt < 0.05, dt                                         # one pass per segment (a per-point rescan of 8192^2 x 32 takes seconds)
+    # backward of the pooling: the winner receives the segment's gradient sum
+    w = torch.randn(B, T, 32, generator=g)
+    gf = ops.voxel_pool_max_bwd(w.to(DEV), arg, vi).cpu()
+    f0 = feat.clone().requires_grad_(True)
+    # torch's amax backward splits ties evenly; the reference (scatter_max + gather) routes to ONE winner: build that reference directly
+    want = torch.zeros(B, T, 32)
+    for b in range(B):
+        seg = torch.zeros(int(idx[b].max()) + 1, 32).index_add_(0, idx[b], w[b])
+        win = a[b] == torch.arange(T).unsqueeze(1)
+        want[b] = torch.where(win, seg[idx[b]], torch.zeros(()))
+    scale = float(want.abs().max())
+    assert float((gf - want).abs().max()) <= 2e-6 * max(1.0, scale) * max(1.0, float(counts.max()) ** 0.5 / 8)
+    # scatter-mean, both layouts, and its backward
+    if plane is None:
+        grid = ops.voxel_scatter_mean_fwd(fd, vi).cpu()
+        grid_cl = ops.voxel_scatter_mean_cl_fwd(fd, vi).cpu()
+        assert torch.equal(grid_cl.permute(0, 4, 1, 2, 3), grid)
+        refg = orc.scatter_mean_grid(feat, idx, R)
+        wg = torch.randn(grid.shape, generator=g)
+        gb = ops.voxel_scatter_mean_bwd(wg.to(DEV), vi, 32).cpu()
+        gb_cl = ops.voxel_scatter_mean_cl_bwd(wg.permute(0, 2, 3, 4, 1).contiguous().to(DEV), vi, 32).cpu()
+        assert torch.equal(gb, gb_cl)
+        flat = wg.reshape(B, 32, -1)
+    else:
+        grid = ops.plane_scatter_mean_fwd(fd, vi).cpu()
+        refg = orc.scatter_mean_plane(feat, idx, R)
+        wg = torch.randn(grid.shape, generator=g)
+        gb = ops.plane_scatter_mean_bwd(wg.to(DEV), vi, 32).cpu()
+        flat = wg.reshape(B, 32, -1)
+    assert float((grid - refg).abs().max()) <= 2e-6
+    for b in range(B):
+        wantb = flat[b][:, idx[b]].t() / counts[idx[b]].unsqueeze(1) if b == 0 else flat[b][:, idx[b]].t() / torch.bincount(idx[b])[idx[b]].unsqueeze(1)
+        assert float((gb[b] - wantb).abs().max()) <= 1e-6 * max(1.0, float(wantb.abs().max()))

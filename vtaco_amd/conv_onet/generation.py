@@ -83,40 +83,54 @@ class Generator3D(object):
         return Mesh(verts, faces)
 
     # -- whole scene as ONE hipGraph replay (encode + dense decode + marching-cubes count) --------
+    def _weight_stamps(self):
+        """(storage address, version counter) of every parameter and buffer: changes when a weight is updated in place
+        (optimizer.step, load_state_dict) or replaced (``.to()``, a new tensor)."""
+        return tuple((t.data_ptr(), t._version) for t in list(self.model.parameters()) + list(self.model.buffers()))
+
     def _scene_graph(self, shape, nx):
-        key = (tuple(shape), nx)
-        hit = getattr(self, "_graphs", {}).get(key)
-        if hit is not None:
+        """The captured graph of one (input shape, lattice size).  A graph holds raw pointers to derived buffers -- packed conv
+        weights, the decoder blob, the UNet3D workspace -- that live in caches keyed on the weights' versions and on the last
+        shape run; so the entry (a) keeps every such tensor alive next to the graph (``ops.graph_keepalive``) and (b) records the
+        weight stamps at capture: a replay after ``optimizer.step()`` / ``load_state_dict`` / ``.to()`` finds different stamps and
+        captures afresh instead of reading stale or recycled memory."""
+        key = (tuple(shape), nx, self.decode_precision)
+        self._graphs = getattr(self, "_graphs", {})
+        hit = self._graphs.get(key)
+        stamps = self._weight_stamps()
+        if hit is not None and hit["stamps"] == stamps:
             return hit
+        self._graphs.pop(key, None)                      # stale: drop the old graph (and its keep-alive list) first
         static_in = torch.zeros(shape, dtype=torch.float32, device=self.device)
 
         def run():
             c = self.model.encode_inputs(static_in)
             vol = self.eval_lattice(c, nx).reshape(nx, nx, nx)
             return vol, ops.mc_count(vol)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(2):                      # warm-up: fills every cache / workspace outside the capture
-                run()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph):
-            vol, ws = run()
-        self._graphs = getattr(self, "_graphs", {})
-        self._graphs[key] = (graph, static_in, vol, ws)
+        with ops.graph_keepalive() as keep:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(2):                      # warm-up: fills every cache / workspace outside the capture
+                    run()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(graph):
+                vol, ws = run()
+        self._graphs[key] = {"graph": graph, "in": static_in, "vol": vol, "ws": ws, "keep": list(keep), "stamps": stamps}
         return self._graphs[key]
 
     def generate_mesh_graphed(self, inputs):
         """Same result as ``generate_obj_mesh_wnf({'inputs': inputs})`` for the visual branch, with the
         ~110 launches of encode + decode + marching-cubes classification replayed as one hipGraph
-        (launch-bound otherwise); only the data-dependent output sizing leaves the graph."""
+        (launch-bound otherwise); only the data-dependent output sizing leaves the graph.  Safe across weight
+        updates and interleaved eager calls of other shapes (see ``_scene_graph``)."""
         self.model.eval()
         nx = self.resolution0 * 4
-        graph, static_in, vol, ws = self._scene_graph(inputs.shape, nx)
-        static_in.copy_(inputs.to(self.device), non_blocking=True)
-        graph.replay()
-        verts, faces, _ = ops.mc_emit(vol, ws, rescale=(nx / 2, (1 + self.padding) / nx))
+        g = self._scene_graph(inputs.shape, nx)
+        g["in"].copy_(inputs.to(self.device), non_blocking=True)
+        g["graph"].replay()
+        verts, faces, _ = ops.mc_emit(g["vol"], g["ws"], rescale=(nx / 2, (1 + self.padding) / nx))
         return Mesh(verts, faces)
 
     def generate_obj_mesh_sharded(self, data, group=None):

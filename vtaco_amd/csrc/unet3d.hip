@@ -771,34 +771,6 @@ conv1x1_mfma_kernel(const float *x, const float *w, const float *bias, float *ou
     }
 }
 
-// scatter-mean straight into a channels-last grid (see voxel.hip for the segment bookkeeping)
-__global__ void __launch_bounds__(256)
-scatter_mean_cl_kernel(const float *feat, const int *idx, const int *order, const int *seg_lo, const int *seg_hi,
-                       float *grid, int T, int C, size_t V, size_t total) {
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int c = (int)(e % C);
-        const size_t bt = e / C, b = bt / T;
-        const int t = (int)(bt - b * T);
-        const int lo = seg_lo[bt], hi = seg_hi[bt];
-        const int *ord = order + b * T;
-        if (ord[lo] != t) continue;
-        const float *fb = feat + b * T * C;
-        float sum = 0.0f;
-        for (int q = lo; q < hi; ++q) sum += fb[(size_t)ord[q] * C + c];
-        grid[(b * V + (size_t)idx[bt]) * C + c] = sum / (float)(hi - lo);
-    }
-}
-
-__global__ void __launch_bounds__(256)
-scatter_mean_cl_bwd_kernel(const float *grad_grid, const int *idx, const int *seg_lo, const int *seg_hi,
-                           float *grad_feat, int T, int C, size_t V, size_t total) {
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int c = (int)(e % C);
-        const size_t bt = e / C, b = bt / T;
-        grad_feat[e] = grad_grid[(b * V + (size_t)idx[bt]) * C + c] / (float)(seg_hi[bt] - seg_lo[bt]);
-    }
-}
-
 bool src_ok(const Src &s, int B) {
     if (!s.skip || B <= 0 || s.D <= 0 || s.H <= 0 || s.W <= 0 || s.C1 <= 0 || (s.C1 & 31)) return false;
     if (s.low && (s.C2 <= 0 || (s.C2 & 31) || (s.D & 1) || (s.H & 1) || (s.W & 1))) return false;
@@ -1047,32 +1019,6 @@ int vt_conv1x1_cl(const float *x, int64_t V, int Cin, const float *w, const floa
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(conv1x1_cl_kernel, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, x, w, bias, out, Cin, Cout, (size_t)V);
     return vt_check(hipGetLastError(), "vt_conv1x1_cl");
-}
-
-int vt_voxel_scatter_mean_cl_fwd(const float *feat, const int *idx, const int *order, const int *seg_lo, const int *seg_hi,
-                                 int B, int T, int C, int R, float *grid_cl, void *stream) {
-    if (!feat || !idx || !order || !seg_lo || !seg_hi || !grid_cl) return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_cl_fwd: null argument");
-    if (B <= 0 || T <= 0 || C <= 0 || R < 1) return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_cl_fwd: bad size");
-    const size_t V = (size_t)R * R * R, total = (size_t)B * T * C;
-    int frc = vt_fill32(grid_cl, 0u, (size_t)B * C * V * sizeof(float), (hipStream_t)stream);
-    if (frc) return frc;
-    size_t g = (total + 255) / 256;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(scatter_mean_cl_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
-                       feat, idx, order, seg_lo, seg_hi, grid_cl, T, C, V, total);
-    return vt_check(hipGetLastError(), "vt_voxel_scatter_mean_cl_fwd");
-}
-
-int vt_voxel_scatter_mean_cl_bwd(const float *grad_grid_cl, const int *idx, const int *seg_lo, const int *seg_hi,
-                                 int B, int T, int C, int R, float *grad_feat, void *stream) {
-    if (!grad_grid_cl || !idx || !seg_lo || !seg_hi || !grad_feat) return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_cl_bwd: null argument");
-    if (B <= 0 || T <= 0 || C <= 0 || R < 1) return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_cl_bwd: bad size");
-    const size_t V = (size_t)R * R * R, total = (size_t)B * T * C;
-    size_t g = (total + 255) / 256;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(scatter_mean_cl_bwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
-                       grad_grid_cl, idx, seg_lo, seg_hi, grad_feat, T, C, V, total);
-    return vt_check(hipGetLastError(), "vt_voxel_scatter_mean_cl_bwd");
 }
 
 // ---- the whole UNet3D.forward in one call (no host round trips between its ~45 launches) ---------

@@ -129,8 +129,19 @@ voxel_build_kernel(const float *pts, int T, int nbits, int R, float divisor, flo
 }
 
 // The per-point kernels below use one thread per (point, channel): a 256-thread block covers
-// 256/CL points x CL channel lanes (CL = min(C,32) ... C), so there is no integer division per thread
+// 256/CL points x CL channel lanes (CL = min(C,256)), so there is no integer division per thread
 // and a point's feature row is read as one coalesced run.
+//
+// ONE PASS PER SEGMENT.  A segment (the points of one cell) of at most SEG_SMALL points is reduced by the threads of its
+// first point (its "head") and the result written to every member -- O(length) per segment, O(T C) per call.  A longer
+// segment (dense cells: hand planes at 32^2, degenerate clouds with thousands of points in one cell) is reduced by a whole
+// workgroup: the extra blocks of the launch each look at one SEG_SMALL-aligned position of the sorted order, and the block
+// whose position is the first aligned one inside a long segment takes that segment (every long segment contains exactly one
+// such position).  Max / argmax are order-independent up to ties, and ties go to the smallest sorted position in both
+// paths (= the smallest point index = torch's first maximum); sums of long segments are accumulated as 256/CL interleaved
+// partial sums combined in a fixed order -- deterministic, not the sequential order of the short path.
+constexpr int SEG_SMALL = 32;
+
 __device__ __forceinline__ bool point_lane(int C, uint32_t npts, uint32_t &bt, int &c) {
     const int cl = C < 256 ? C : 256;                          // channel lanes per point (C <= 256 here)
     const int ppb = 256 / cl;                                  // points per block
@@ -140,67 +151,175 @@ __device__ __forceinline__ bool point_lane(int C, uint32_t npts, uint32_t &bt, i
     return lp < ppb && bt < npts;
 }
 
+// Large-segment role of block `tile` (0-based among the extra blocks): (scene b, sorted range [lo,hi)) or false
+__device__ __forceinline__ bool large_segment(uint32_t tile, int T, const int *order, const int *seg_lo, const int *seg_hi,
+                                              uint32_t &b, int &lo, int &hi) {
+    const uint32_t tiles = (uint32_t)((T + SEG_SMALL - 1) / SEG_SMALL);
+    b = tile / tiles;
+    const int pos = (int)(tile - b * tiles) * SEG_SMALL;
+    const int t = order[(size_t)b * T + pos];
+    lo = seg_lo[(size_t)b * T + t];
+    hi = seg_hi[(size_t)b * T + t];
+    return hi - lo > SEG_SMALL && lo > pos - SEG_SMALL;       // long, and `pos` is the first aligned position inside it
+}
+
 // out[b,t,c] = max over the voxel-mates of t of feat[b,.,c]; argmax = the point that wins
 __global__ void __launch_bounds__(256)
 pool_max_fwd_kernel(const float *feat, const int *order, const int *seg_lo, const int *seg_hi,
-                    float *out, int *argmax, int T, int C, uint32_t npts) {
-    uint32_t bt; int c0;
-    if (!point_lane(C, npts, bt, c0)) return;
-    const uint32_t b = bt / (uint32_t)T;
-    const int lo = seg_lo[bt], hi = seg_hi[bt];
+                    float *out, int *argmax, int T, int C, uint32_t npts, uint32_t small_blocks) {
+    if (blockIdx.x < small_blocks) {
+        uint32_t bt; int c0;
+        if (!point_lane(C, npts, bt, c0)) return;
+        const uint32_t b = bt / (uint32_t)T;
+        const int t = (int)(bt - b * (uint32_t)T);
+        const int lo = seg_lo[bt], hi = seg_hi[bt];
+        const int *ord = order + (size_t)b * T;
+        if (hi - lo > SEG_SMALL || ord[lo] != t) return;       // long segments: the cooperative blocks; otherwise the head works
+        const float *fb = feat + (size_t)b * T * C;
+        for (int c = c0; c < C; c += 256) {
+            int best = t;
+            float m = fb[(size_t)t * C + c];
+            for (int j = lo + 1; j < hi; ++j) {
+                const int t2 = ord[j];
+                const float v = fb[(size_t)t2 * C + c];
+                if (v > m) { m = v; best = t2; }
+            }
+            for (int j = lo; j < hi; ++j) {
+                const size_t o = ((size_t)b * T + ord[j]) * C + c;
+                out[o] = m;
+                if (argmax) argmax[o] = best;
+            }
+        }
+        return;
+    }
+    __shared__ float red_m[256];
+    __shared__ int red_j[256];
+    uint32_t b; int lo, hi;
+    if (!large_segment(blockIdx.x - small_blocks, T, order, seg_lo, seg_hi, b, lo, hi)) return;
+    const int cl = C < 256 ? C : 256, G = 256 / cl, grp = threadIdx.x / cl, c0 = threadIdx.x - grp * cl;
     const int *ord = order + (size_t)b * T;
     const float *fb = feat + (size_t)b * T * C;
     for (int c = c0; c < C; c += 256) {
-        int best = ord[lo];
-        float m = fb[(size_t)best * C + c];
-        for (int j = lo + 1; j < hi; ++j) {
-            const int t2 = ord[j];
-            const float v = fb[(size_t)t2 * C + c];
-            if (v > m) { m = v; best = t2; }
+        float m = 0.0f;
+        int bj = -1;
+        if (grp < G)
+            for (int j = lo + grp; j < hi; j += G) {
+                const float v = fb[(size_t)ord[j] * C + c];
+                if (bj < 0 || v > m) { m = v; bj = j; }
+            }
+        red_m[threadIdx.x] = m; red_j[threadIdx.x] = bj;
+        __syncthreads();
+        if (grp == 0) {
+            for (int g = 1; g < G; ++g) {
+                const float v = red_m[g * cl + c0];
+                const int j = red_j[g * cl + c0];
+                if (j >= 0 && (v > m || (v == m && j < bj))) { m = v; bj = j; }
+            }
+            red_m[c0] = m; red_j[c0] = bj;
         }
-        out[(size_t)bt * C + c] = m;
-        if (argmax) argmax[(size_t)bt * C + c] = best;
+        __syncthreads();
+        m = red_m[c0];
+        const int best = ord[red_j[c0]];
+        if (grp < G)
+            for (int j = lo + grp; j < hi; j += G) {
+                const size_t o = ((size_t)b * T + ord[j]) * C + c;
+                out[o] = m;
+                if (argmax) argmax[o] = best;
+            }
+        __syncthreads();
     }
+}
+
+// sum over the sorted range [lo,hi) of src[b, ord[j], c] by the whole block (threads = channel lanes x groups); every
+// thread of channel lane c0 returns the total.  red: 256 floats of LDS.
+__device__ __forceinline__ float block_segment_sum(const float *src_b, const int *ord, int lo, int hi, int C, int c, int cl, int G,
+                                                   int grp, int c0, float *red) {
+    float s = 0.0f;
+    if (grp < G)
+        for (int j = lo + grp; j < hi; j += G) s += src_b[(size_t)ord[j] * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    float tot = 0.0f;
+    for (int g = 0; g < G; ++g) tot += red[g * cl + c0];
+    __syncthreads();
+    return tot;
 }
 
 // grad_feat[b,t,c] = sum over voxel-mates of grad_out[b,.,c] if t is the arg-max, else 0
 __global__ void __launch_bounds__(256)
 pool_max_bwd_kernel(const float *grad_out, const int *argmax, const int *order, const int *seg_lo, const int *seg_hi,
-                    float *grad_feat, int T, int C, uint32_t npts) {
-    uint32_t bt; int c0;
-    if (!point_lane(C, npts, bt, c0)) return;
-    const uint32_t b = bt / (uint32_t)T;
-    const int t = (int)(bt - b * (uint32_t)T);
-    const int lo = seg_lo[bt], hi = seg_hi[bt];
+                    float *grad_feat, int T, int C, uint32_t npts, uint32_t small_blocks) {
+    if (blockIdx.x < small_blocks) {
+        uint32_t bt; int c0;
+        if (!point_lane(C, npts, bt, c0)) return;
+        const uint32_t b = bt / (uint32_t)T;
+        const int t = (int)(bt - b * (uint32_t)T);
+        const int lo = seg_lo[bt], hi = seg_hi[bt];
+        if (hi - lo > SEG_SMALL) return;
+        const int *ord = order + (size_t)b * T;
+        const float *gb = grad_out + (size_t)b * T * C;
+        for (int c = c0; c < C; c += 256) {
+            float g = 0.0f;
+            if (argmax[(size_t)bt * C + c] == t)
+                for (int j = lo; j < hi; ++j) g += gb[(size_t)ord[j] * C + c];
+            grad_feat[(size_t)bt * C + c] = g;
+        }
+        return;
+    }
+    __shared__ float red[256];
+    uint32_t b; int lo, hi;
+    if (!large_segment(blockIdx.x - small_blocks, T, order, seg_lo, seg_hi, b, lo, hi)) return;
+    const int cl = C < 256 ? C : 256, G = 256 / cl, grp = threadIdx.x / cl, c0 = threadIdx.x - grp * cl;
     const int *ord = order + (size_t)b * T;
-    const float *gb = grad_out + (size_t)b * T * C;
     for (int c = c0; c < C; c += 256) {
-        float g = 0.0f;
-        if (argmax[(size_t)bt * C + c] == t)
-            for (int j = lo; j < hi; ++j) g += gb[(size_t)ord[j] * C + c];
-        grad_feat[(size_t)bt * C + c] = g;
+        const float tot = block_segment_sum(grad_out + (size_t)b * T * C, ord, lo, hi, C, c, cl, G, grp, c0, red);
+        if (grp < G)
+            for (int j = lo + grp; j < hi; j += G) {
+                const int t = ord[j];
+                const size_t o = ((size_t)b * T + t) * C + c;
+                grad_feat[o] = argmax[o] == t ? tot : 0.0f;
+            }
     }
 }
 
-// grid[b,c,voxel] = mean of feat over the voxel's points (grid pre-zeroed); NCDHW output
+// grid cell = mean of feat over the cell's points (grid pre-zeroed).  CL = false: NCDHW / NCHW [b][c][cell];
+// CL = true: channels-last [b][cell][c] (what the UNet3D kernels read)
+template <bool CL>
 __global__ void __launch_bounds__(256)
 scatter_mean_fwd_kernel(const float *feat, const int *idx, const int *order, const int *seg_lo, const int *seg_hi,
-                        float *grid, int T, int C, size_t V, uint32_t npts) {   // V = cells per channel (R^3 or R^2)
-    uint32_t bt; int c0;
-    if (!point_lane(C, npts, bt, c0)) return;
-    const uint32_t b = bt / (uint32_t)T;
-    const int t = (int)(bt - b * (uint32_t)T);
-    const int lo = seg_lo[bt], hi = seg_hi[bt];
+                        float *grid, int T, int C, size_t V, uint32_t npts, uint32_t small_blocks) {   // V = cells per channel
+    auto cell = [&](uint32_t b, int c, int id) -> size_t {
+        return CL ? ((size_t)b * V + (size_t)id) * C + c : ((size_t)b * C + c) * V + (size_t)id;
+    };
+    if (blockIdx.x < small_blocks) {
+        uint32_t bt; int c0;
+        if (!point_lane(C, npts, bt, c0)) return;
+        const uint32_t b = bt / (uint32_t)T;
+        const int t = (int)(bt - b * (uint32_t)T);
+        const int lo = seg_lo[bt], hi = seg_hi[bt];
+        const int *ord = order + (size_t)b * T;
+        if (hi - lo > SEG_SMALL || ord[lo] != t) return;       // the cell's first point writes
+        const float *fb = feat + (size_t)b * T * C;
+        for (int c = c0; c < C; c += 256) {
+            float s = 0.0f;
+            for (int j = lo; j < hi; ++j) s += fb[(size_t)ord[j] * C + c];
+            grid[cell(b, c, idx[bt])] = s / (float)(hi - lo);
+        }
+        return;
+    }
+    __shared__ float red[256];
+    uint32_t b; int lo, hi;
+    if (!large_segment(blockIdx.x - small_blocks, T, order, seg_lo, seg_hi, b, lo, hi)) return;
+    const int cl = C < 256 ? C : 256, G = 256 / cl, grp = threadIdx.x / cl, c0 = threadIdx.x - grp * cl;
     const int *ord = order + (size_t)b * T;
-    if (ord[lo] != t) return;                                  // the voxel's first point writes
-    const float *fb = feat + (size_t)b * T * C;
+    const int id = idx[(size_t)b * T + ord[lo]];
     for (int c = c0; c < C; c += 256) {
-        float s = 0.0f;
-        for (int j = lo; j < hi; ++j) s += fb[(size_t)ord[j] * C + c];
-        grid[((size_t)b * C + c) * V + (size_t)idx[bt]] = s / (float)(hi - lo);
+        const float tot = block_segment_sum(feat + (size_t)b * T * C, ord, lo, hi, C, c, cl, G, grp, c0, red);
+        if (grp == 0) grid[cell(b, c, id)] = tot / (float)(hi - lo);
     }
 }
 
+template <bool CL>
 __global__ void __launch_bounds__(256)
 scatter_mean_bwd_kernel(const float *grad_grid, const int *idx, const int *seg_lo, const int *seg_hi,
                         float *grad_feat, int T, int C, size_t V, uint32_t npts) {
@@ -208,9 +327,14 @@ scatter_mean_bwd_kernel(const float *grad_grid, const int *idx, const int *seg_l
     if (!point_lane(C, npts, bt, c0)) return;
     const uint32_t b = bt / (uint32_t)T;
     const float inv = 1.0f / (float)(seg_hi[bt] - seg_lo[bt]);
-    for (int c = c0; c < C; c += 256)
-        grad_feat[(size_t)bt * C + c] = grad_grid[((size_t)b * C + c) * V + (size_t)idx[bt]] * inv;
+    for (int c = c0; c < C; c += 256) {
+        const size_t g = CL ? ((size_t)b * V + (size_t)idx[bt]) * C + c : ((size_t)b * C + c) * V + (size_t)idx[bt];
+        grad_feat[(size_t)bt * C + c] = grad_grid[g] * inv;
+    }
 }
+
+// the extra blocks of a launch that look for long segments: one per SEG_SMALL sorted positions per scene
+inline unsigned large_blocks(int B, int T) { return (unsigned)B * (unsigned)((T + SEG_SMALL - 1) / SEG_SMALL); }
 
 inline unsigned point_blocks(int C, size_t npts) {
     const int cl = C < 256 ? C : 256;
@@ -273,8 +397,9 @@ int vt_plane_scatter_mean_fwd(const float *feat, const int *idx, const int *orde
     const size_t V = (size_t)R * R;
     int frc = vt_fill32(plane, 0u, (size_t)B * C * V * sizeof(float), (hipStream_t)stream);
     if (frc) return frc;
-    hipLaunchKernelGGL(scatter_mean_fwd_kernel, dim3(point_blocks(C, (size_t)B * T)), dim3(256), 0, (hipStream_t)stream,
-                       feat, idx, order, seg_lo, seg_hi, plane, T, C, V, (uint32_t)((size_t)B * T));
+    const unsigned sb = point_blocks(C, (size_t)B * T);
+    hipLaunchKernelGGL(scatter_mean_fwd_kernel<false>, dim3(sb + large_blocks(B, T)), dim3(256), 0, (hipStream_t)stream,
+                       feat, idx, order, seg_lo, seg_hi, plane, T, C, V, (uint32_t)((size_t)B * T), sb);
     return vt_check(hipGetLastError(), "vt_plane_scatter_mean_fwd");
 }
 
@@ -283,7 +408,7 @@ int vt_plane_scatter_mean_bwd(const float *grad_plane, const int *idx, const int
     if (!grad_plane || !idx || !seg_lo || !seg_hi || !grad_feat)
         return vt_fail(VT_ERR_INVALID, "vt_plane_scatter_mean_bwd: null argument");
     if (B <= 0 || T <= 0 || C <= 0 || R < 1) return vt_fail(VT_ERR_INVALID, "vt_plane_scatter_mean_bwd: bad size");
-    hipLaunchKernelGGL(scatter_mean_bwd_kernel, dim3(point_blocks(C, (size_t)B * T)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(scatter_mean_bwd_kernel<false>, dim3(point_blocks(C, (size_t)B * T)), dim3(256), 0, (hipStream_t)stream,
                        grad_plane, idx, seg_lo, seg_hi, grad_feat, T, C, (size_t)R * R, (uint32_t)((size_t)B * T));
     return vt_check(hipGetLastError(), "vt_plane_scatter_mean_bwd");
 }
@@ -293,8 +418,9 @@ int vt_voxel_pool_max_fwd(const float *feat, const int *order, const int *seg_lo
     if (!feat || !order || !seg_lo || !seg_hi || !out) return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_max_fwd: null argument");
     if (B <= 0 || T <= 0 || C <= 0) return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_max_fwd: bad size");
     const size_t npts = (size_t)B * T;
-    hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(point_blocks(C, npts)), dim3(256), 0, (hipStream_t)stream,
-                       feat, order, seg_lo, seg_hi, out, argmax, T, C, (uint32_t)npts);
+    const unsigned sb = point_blocks(C, npts);
+    hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(sb + large_blocks(B, T)), dim3(256), 0, (hipStream_t)stream,
+                       feat, order, seg_lo, seg_hi, out, argmax, T, C, (uint32_t)npts, sb);
     return vt_check(hipGetLastError(), "vt_voxel_pool_max_fwd");
 }
 
@@ -304,8 +430,9 @@ int vt_voxel_pool_max_bwd(const float *grad_out, const int *argmax, const int *o
         return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_max_bwd: null argument");
     if (B <= 0 || T <= 0 || C <= 0) return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_max_bwd: bad size");
     const size_t npts = (size_t)B * T;
-    hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(point_blocks(C, npts)), dim3(256), 0, (hipStream_t)stream,
-                       grad_out, argmax, order, seg_lo, seg_hi, grad_feat, T, C, (uint32_t)npts);
+    const unsigned sb = point_blocks(C, npts);
+    hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(sb + large_blocks(B, T)), dim3(256), 0, (hipStream_t)stream,
+                       grad_out, argmax, order, seg_lo, seg_hi, grad_feat, T, C, (uint32_t)npts, sb);
     return vt_check(hipGetLastError(), "vt_voxel_pool_max_bwd");
 }
 
@@ -317,8 +444,9 @@ int vt_voxel_scatter_mean_fwd(const float *feat, const int *idx, const int *orde
     const size_t V = (size_t)R * R * R, total = (size_t)B * T * C;
     int frc = vt_fill32(grid, 0u, (size_t)B * C * V * sizeof(float), (hipStream_t)stream);
     if (frc) return frc;
-    hipLaunchKernelGGL(scatter_mean_fwd_kernel, dim3(point_blocks(C, (size_t)B * T)), dim3(256), 0, (hipStream_t)stream,
-                       feat, idx, order, seg_lo, seg_hi, grid, T, C, V, (uint32_t)((size_t)B * T));
+    const unsigned sb = point_blocks(C, (size_t)B * T);
+    hipLaunchKernelGGL(scatter_mean_fwd_kernel<false>, dim3(sb + large_blocks(B, T)), dim3(256), 0, (hipStream_t)stream,
+                       feat, idx, order, seg_lo, seg_hi, grid, T, C, V, (uint32_t)((size_t)B * T), sb);
     return vt_check(hipGetLastError(), "vt_voxel_scatter_mean_fwd");
 }
 
@@ -328,9 +456,32 @@ int vt_voxel_scatter_mean_bwd(const float *grad_grid, const int *idx, const int 
         return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_bwd: null argument");
     if (B <= 0 || T <= 0 || C <= 0 || R < 1) return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_bwd: bad size");
     const size_t V = (size_t)R * R * R, total = (size_t)B * T * C;
-    hipLaunchKernelGGL(scatter_mean_bwd_kernel, dim3(point_blocks(C, (size_t)B * T)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(scatter_mean_bwd_kernel<false>, dim3(point_blocks(C, (size_t)B * T)), dim3(256), 0, (hipStream_t)stream,
                        grad_grid, idx, seg_lo, seg_hi, grad_feat, T, C, V, (uint32_t)((size_t)B * T));
     return vt_check(hipGetLastError(), "vt_voxel_scatter_mean_bwd");
+}
+
+// the same scatter straight into / out of a channels-last grid [B,R,R,R,C] (the layout the UNet3D kernels read)
+int vt_voxel_scatter_mean_cl_fwd(const float *feat, const int *idx, const int *order, const int *seg_lo, const int *seg_hi,
+                                 int B, int T, int C, int R, float *grid_cl, void *stream) {
+    if (!feat || !idx || !order || !seg_lo || !seg_hi || !grid_cl) return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_cl_fwd: null argument");
+    if (B <= 0 || T <= 0 || C <= 0 || R < 1) return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_cl_fwd: bad size");
+    const size_t V = (size_t)R * R * R;
+    int frc = vt_fill32(grid_cl, 0u, (size_t)B * C * V * sizeof(float), (hipStream_t)stream);
+    if (frc) return frc;
+    const unsigned sb = point_blocks(C, (size_t)B * T);
+    hipLaunchKernelGGL(scatter_mean_fwd_kernel<true>, dim3(sb + large_blocks(B, T)), dim3(256), 0, (hipStream_t)stream,
+                       feat, idx, order, seg_lo, seg_hi, grid_cl, T, C, V, (uint32_t)((size_t)B * T), sb);
+    return vt_check(hipGetLastError(), "vt_voxel_scatter_mean_cl_fwd");
+}
+
+int vt_voxel_scatter_mean_cl_bwd(const float *grad_grid_cl, const int *idx, const int *seg_lo, const int *seg_hi,
+                                 int B, int T, int C, int R, float *grad_feat, void *stream) {
+    if (!grad_grid_cl || !idx || !seg_lo || !seg_hi || !grad_feat) return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_cl_bwd: null argument");
+    if (B <= 0 || T <= 0 || C <= 0 || R < 1) return vt_fail(VT_ERR_INVALID, "vt_voxel_scatter_mean_cl_bwd: bad size");
+    hipLaunchKernelGGL(scatter_mean_bwd_kernel<true>, dim3(point_blocks(C, (size_t)B * T)), dim3(256), 0, (hipStream_t)stream,
+                       grad_grid_cl, idx, seg_lo, seg_hi, grad_feat, T, C, (size_t)R * R * R, (uint32_t)((size_t)B * T));
+    return vt_check(hipGetLastError(), "vt_voxel_scatter_mean_cl_bwd");
 }
 
 }  // extern "C"

@@ -14,6 +14,33 @@ from . import _lib
 from ._lib import VtError, check, dev_ptr, stream_ptr
 
 
+# ---- hipGraph capture support -------------------------------------------------------------------------------------
+# A captured graph holds RAW POINTERS to everything its launches read: derived buffers (packed weights, the decoder
+# blob, the UNet3D workspace) live in caches that re-allocate when a weight changes or another shape runs.  While a
+# capture is being prepared every launcher hands such tensors to ``keep_for_graph``; the graph's owner stores the list
+# next to the graph, so the memory cannot be recycled under a live graph.
+_graph_keep = None
+
+
+class graph_keepalive:
+    """``with ops.graph_keepalive() as keep:`` -- collects every derived tensor the launchers inside touch."""
+
+    def __enter__(self):
+        global _graph_keep
+        self._prev, _graph_keep = _graph_keep, []
+        return _graph_keep
+
+    def __exit__(self, *exc):
+        global _graph_keep
+        _graph_keep = self._prev
+        return False
+
+
+def keep_for_graph(*tensors):
+    if _graph_keep is not None:
+        _graph_keep.extend(t for t in tensors if t is not None)
+
+
 def blob_floats(hidden=32, c_dim=32, n_blocks=5):
     n = _lib.load().vt_decoder_blob_bytes(hidden, c_dim, n_blocks)
     if n == 0:
@@ -154,6 +181,7 @@ def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want
     out2 = torch.empty((B, N), dtype=torch.float32, device=grid.device) if want_contact else None
     if N == 0:                                   # empty query set: nothing to launch
         return (out, out2) if want_contact else out
+    keep_for_graph(blob, keep)
     if precision == "bf16x3":
         if save is not None:
             raise VtError("decode_fwd: the training forward (save) is exact-f32 only")
@@ -880,6 +908,7 @@ def unet3d_fwd(x_cl, params, keep):
     if ws is None:
         _unet_ws.clear()
         ws = _unet_ws[key] = torch.empty(need, dtype=torch.uint8, device=x_cl.device)
+    keep_for_graph(ws, *keep)
     out = torch.empty((B, R, R, R, params.out_channels), dtype=torch.float32, device=x_cl.device)
     check(lib.vt_unet3d_fwd(dev_ptr(x_cl, "x"), B, R, ctypes.byref(params), ctypes.c_void_p(ws.data_ptr()), need,
                             dev_ptr(out, "out"), stream_ptr()), "vt_unet3d_fwd")
