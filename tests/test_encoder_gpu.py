@@ -302,7 +302,7 @@ def _dense_cloud(kind, T, seed):
 
 
 @pytest.mark.parametrize("kind,T,R,plane", [("one", 8192, 64, None), ("mixed", 8192, 16, None), ("one", 8192, 32, "xz"),
-                                            ("planes", 3000, 32, "xy"), ("mixed", 5000, 8, "yz")])
+                                            ("planes", 8192, 32, "xy"), ("mixed", 5000, 8, "yz")])
 def test_dense_cells_one_pass_per_segment(kind, T, R, plane):
     """The per-segment reductions on dense cells (the quadratic case of a per-point rescan: all 8192 points in ONE cell, plane
     cells with dozens of points, lengths around the 32-point switch): max + argmax bit-exact against the oracle (ties to the
