@@ -92,7 +92,7 @@ def trilinear_sample(grid, p, padding=0.1):
                 inb = (xi <= W - 1) & (yi <= H - 1) & (zi <= D - 1)
                 lin = (zi.clamp(max=D - 1) * H + yi.clamp(max=H - 1)) * W + xi.clamp(max=W - 1)
                 vals = torch.gather(gcl, 1, lin.unsqueeze(-1).expand(-1, -1, C))
-                w = (wx * wy * wz) * inb.to(grid.dtype)
+                w = ((wx * wy * wz) * inb.to(wx.dtype)).to(grid.dtype)   # corner weights are f32 arithmetic by definition
                 out = out + vals * w.unsqueeze(-1)
     return out
 
@@ -139,14 +139,14 @@ def decoder_mlp(sd, net, c):
 def local_decoder_forward(sd, p, grid, padding=0.1):
     """``LocalDecoder.forward`` (decoder.py:135-161): logits [B,N]."""
     c = trilinear_sample(grid, p, padding)
-    net = decoder_mlp(sd, _lin(sd, "fc_p", p.float()), c)
+    net = decoder_mlp(sd, _lin(sd, "fc_p", p.to(sd["fc_p.weight"].dtype)), c)
     return _lin(sd, "fc_out", F.relu(net)).squeeze(-1)
 
 
 def local_decoder_forward_img(sd, p, grid, c_img, padding=0.1):
     """``LocalDecoder.forward_img`` (decoder.py:71-103): tactile concat."""
     c = trilinear_sample(grid, p, padding)
-    net = _lin(sd, "fc_p_img", torch.cat((p.float(), c_img), dim=2))
+    net = _lin(sd, "fc_p_img", torch.cat((p.to(c_img.dtype), c_img), dim=2))
     net = decoder_mlp(sd, net, c)
     return _lin(sd, "fc_out", F.relu(net)).squeeze(-1)
 
@@ -154,7 +154,7 @@ def local_decoder_forward_img(sd, p, grid, c_img, padding=0.1):
 def local_decoder_forward_contact(sd, p, grid, padding=0.1):
     """``LocalDecoder.forward_contact`` (decoder.py:105-133)."""
     c = trilinear_sample(grid, p, padding)
-    net = decoder_mlp(sd, _lin(sd, "fc_p", p.float()), c)
+    net = decoder_mlp(sd, _lin(sd, "fc_p", p.to(sd["fc_p.weight"].dtype)), c)
     a = F.relu(net)
     return _lin(sd, "fc_out", a).squeeze(-1), _lin(sd, "fc_out_contact", a).squeeze(-1)
 
@@ -222,7 +222,7 @@ def attention_decoder_forward_img(sd, p, grid, c_img, padding=0.1):
     c = trilinear_sample(grid, p, padding)
     fsd = {k[len("fuser."):]: v for k, v in sd.items() if k.startswith("fuser.")}
     c = transformer_fusion(fsd, c_img, c)
-    net = decoder_mlp(sd, _lin(sd, "fc_p", p.float()), c)
+    net = decoder_mlp(sd, _lin(sd, "fc_p", p.to(sd["fc_p.weight"].dtype)), c)
     return _lin(sd, "fc_out", F.relu(net)).squeeze(-1)
 
 
