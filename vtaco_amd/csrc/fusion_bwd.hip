@@ -88,10 +88,11 @@ fb_inorm_bwd_kernel(const float *Z, const float *dOut, float *dZ, int N) {
         }
         __syncthreads();
     };
+    const float shift = z[c];                                      // mean = z_0 + mean(z - z_0), as the forward
     float s = 0.0f;
-    for (int n = g; n < N; n += 32) s += z[(size_t)n * 32 + c];
+    for (int n = g; n < N; n += 32) s += z[(size_t)n * 32 + c] - shift;
     reduce(s, 0.0f, 0, 3, 1.0f / (float)N);
-    const float m = st[0][c];
+    const float m = shift + st[0][c];
     s = 0.0f;
     for (int n = g; n < N; n += 32) { const float d = z[(size_t)n * 32 + c] - m; s = fmaf(d, d, s); }
     reduce(s, 0.0f, 1, 3, 1.0f / (float)N);
