@@ -161,4 +161,7 @@ def build_train_case(device, rank=0, scenes=8, num_sample=2048, n_points=8192, g
              "points.cam_rot": (torch.rand(B, 5, 3, generator=g) * 2 - 1).double(),
              "inputs.pc_ply": cloud.clone(), "inputs.img": torch.rand(B, 5, 3, H, W, generator=g) / 255.0,
              "inputs.depth": depth, "inputs.touch_success": touch.to(torch.uint8)}
+    if torch.cuda.is_available():
+        # page-locked host tensors, as a DataLoader(pin_memory=True) hands them over (50 MB of images and depths per step)
+        batch = {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in batch.items()}
     return model, trainer, batch, {"ico": {"v": verts, "f": faces}}

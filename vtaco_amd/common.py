@@ -87,9 +87,11 @@ def contact_clouds_from_depth(depths, depth_origin, cam_pos, cam_rot, pc_ply, to
     for t in range(5):
         if not bool(touch_success[t]):
             continue
-        z = depths[t].reshape(height, width)
-        touched = np.where(np.abs(z.reshape(-1) - origin) > threshold)[0]
-        cam = np.stack([z, -(px - width / 2) * z / f, -(py - height / 2) * z / f], axis=-1).reshape(-1, 3)[touched]
+        z = depths[t]
+        touched = np.where(np.abs(z - origin) > threshold)[0]
+        # unproject the touched pixels only (same arithmetic and dtypes as unprojecting the whole image and selecting)
+        zt, pxt, pyt = z[touched], px.reshape(-1)[touched], py.reshape(-1)[touched]
+        cam = np.stack([zt, -(pxt - width / 2) * zt / f, -(pyt - height / 2) * zt / f], axis=-1)
         if cam.shape[0] > max_points:
             cam = cam[np.random.randint(cam.shape[0], size=max_points)]
         # camera -> world (pc_cam_to_world, common.py:614-640, with the sample rotation + [-pi/2, 0, pi/2]): the reference composes

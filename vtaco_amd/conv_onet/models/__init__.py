@@ -56,15 +56,17 @@ class ConvolutionalOccupancyNetwork(nn.Module):
     def encode_t2d(self, inputs, imgs):
         return self.encoder_t2d.encode_img_inputs(imgs), self.encoder_t2d.encode_hand_inputs(inputs)
 
+    # validate_args=False: the constructor's argument check reads the logits back to the host -- a device synchronisation
+    # (8 ms of a training step) that the reference's callers, who only read .logits / .probs, have no use for
     def decode(self, p, c, **kwargs):
-        return dist.Bernoulli(logits=self.decoder(p, c, **kwargs))
+        return dist.Bernoulli(logits=self.decoder(p, c, **kwargs), validate_args=False)
 
     def decode_img(self, p, c, c_img=None, **kwargs):
-        return dist.Bernoulli(logits=self.decoder.forward_img(p, c, c_img, **kwargs))
+        return dist.Bernoulli(logits=self.decoder.forward_img(p, c, c_img, **kwargs), validate_args=False)
 
     def decode_contact(self, p, c, **kwargs):
         logits, contact = self.decoder.forward_contact(p, c, **kwargs)
-        return dist.Bernoulli(logits=logits), contact
+        return dist.Bernoulli(logits=logits, validate_args=False), contact
 
     def to(self, device):
         model = super().to(device)

@@ -159,7 +159,12 @@ class Trainer:
             depths = (depths - depths.min()) / (depths.max() - depths.min())
         cam_pos = data.get('points.cam_pos').reshape(B, 5, 3)
         cam_rot = data.get('points.cam_rot').reshape(B, 5, 3)
-        pred_depth, c_hand_d = self.model.encode_t2d(inputs, imgs)
+        if self.pretrained_t2d:
+            # the reference runs the t2d net here in every case (training.py:776-778) and then uses its two outputs only in the
+            # depth / digit-pose losses, which a pretrained (frozen) t2d net does not have (:887-891): skipped -- 40 U-Net passes
+            pred_depth, c_hand_d = None, {'mano_param': None}
+        else:
+            pred_depth, c_hand_d = self.model.encode_t2d(inputs, imgs)
         origin = self._depth_origin()
         p_host = p.detach().float().cpu().numpy()
         pc_ply = data.get('inputs.pc_ply').float().cpu().numpy()
