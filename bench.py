@@ -38,7 +38,8 @@ FLOP_PER_POINT = 31488        # 30 976 (16 linear layers) + 512 (8
 FLOP_PER_POINT_IMG = 33536    # with the tactile concat (forward_img)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
-KERNEL_OF = {"f32": "decode_fwd_staged2_kernel<false>", "bf16x3": "decode_fwd_staged2_kernel<true>"}
+KERNEL_OF = {"f32": "decode_fwd_staged2_kernel<0>", "bf16x3": "decode_fwd_staged2_kernel<1>", "f16x3": "decode_fwd_staged2_kernel<2>"}
+SPLIT = ("bf16x3", "f16x3")   # dense layers on the 16-bit matrix core, operands as hi + lo
 MIN_WARM_S = 0.25             # launches before any timed region, whatever --warmup says (clocks settle)
 
 
@@ -143,7 +144,7 @@ def stage_times(scene, dec, grid, nx, out, dev, precision):
     return res
 
 
-PMC_SUMMARY = os.path.join("profiles", "r01i_pmc_summary.csv")
+PMC_SUMMARY = os.path.join("profiles", "r02b_pmc_summary.csv")
 
 
 def pmc_counters(precision):
@@ -173,7 +174,7 @@ def roofline_of(precision, flop_pt, npts, kern_ms):
     """Roofline object of one decode kernel: algorithmic FLOP / HIP-event time against the dense
     MFMA peak of the matrix-core input type it runs on."""
     achieved = flop_pt * npts / (kern_ms * 1e-3) / 1e12
-    peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16x3" else PEAK_F32_MFMA_TFLOPS
+    peak = PEAK_BF16_MFMA_TFLOPS if precision in SPLIT else PEAK_F32_MFMA_TFLOPS
     r = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
          "traffic": measured_traffic(precision),
          "traffic_note": "bytes/launch at the L2's memory side from rocprofv3 FETCH_SIZE/WRITE_SIZE passes "
@@ -185,10 +186,10 @@ def roofline_of(precision, flop_pt, npts, kern_ms):
         r["pmc"] = {"matrix_pipe_busy": pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,
                     "valu_issue": 4.0 * pmc.get("SQ_INSTS_VALU", 0.0) / simd_cycles,
                     "source": PMC_SUMMARY + " (profiled launches of the same command)"}
-    if precision == "bf16x3":
-        r["note"] = ("split-bf16: each f32 product = 3 bf16 MFMA products (lo*hi + hi*lo + hi*hi), so the matrix pipe "
-                     "executes ~3x the algorithmic FLOP; the kernel is bound by VALU issue (relu, hi/lo split, trilinear FMAs: "
-                     "see `pmc`), not by the matrix pipe; DESIGN.md section 4")
+    if precision in SPLIT:
+        r["note"] = ("split 16-bit operands: each f32 product = 3 MFMA products (lo*hi + hi*lo + hi*hi) on the bf16 / f16 matrix "
+                     "core (same rate), so the matrix pipe executes ~3x the algorithmic FLOP: frac <= 0.33 by construction; the "
+                     "rest is VALU issue (relu, hi/lo split, trilinear FMAs: see `pmc`); DESIGN.md section 4")
         r["vs_f32_mfma_roofline"] = achieved / PEAK_F32_MFMA_TFLOPS     # SURVEY.md 8d's binding roofline for f32 results
     return r
 
@@ -350,8 +351,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nx", type=int, default=128)
     ap.add_argument("--mode", choices=["visual", "img"], default="visual")
-    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3",
-                    help="arithmetic of the 16 dense layers: exact-f32 MFMA or split-bf16 MFMA (both inside the 1e-4 bar)")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x3"], default="f16x3",
+                    help="arithmetic of the 16 dense layers: exact-f32 MFMA, split-bf16 or split-f16 MFMA (all inside the 1e-4 bar)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: one scene per rank, no collective; strong: one scene, slab decode + one all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -462,14 +463,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_steps,
             "ms_per_step": 1e3 * wall / args.steps,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "bf16x3" if args.precision == "bf16x3" else "f32", "data": "synthetic",
+            "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"visual-only PointNet encoder + LocalDecoder, {nx}^3 lattice, "
                                    + ("ONE scene, slab per GPU + one all-gather of the logits, "
                                       if strong else "1 scene/GPU, no collective, ")
                                    + f"R=64 c_dim=32 hidden=32 n_blocks=5, mode={args.mode}, random-init weights "
                                    "(fc_1 re-randomised); f32 in / f32 out, dense layers on "
-                                   + ("the bf16 matrix core with split-bf16 (hi+lo) operands and f32 accumulation"
-                                      if args.precision == "bf16x3" else "the f32 matrix core")
+                                   + ({"bf16x3": "the bf16 matrix core with split-bf16 (hi+lo) operands and f32 accumulation",
+                                       "f16x3": "the f16 matrix core with split-f16 (hi+lo) operands and f32 accumulation",
+                                       "f32": "the f32 matrix core"}[args.precision])
                                    + "; parity bar 1e-4 vs the f32 oracle",
                        "nx": nx, "points_per_step_per_gpu": npts if not strong else npts // world, "mode": args.mode,
                        "precision": args.precision},
@@ -477,23 +479,28 @@ def main():
         }
         if not strong or world == 1:
             res["roofline"] = roofline_of(args.precision, flop_pt, npts, kern_ms)
-        if world == 1 and args.precision == "bf16x3":
-            # the exact-f32 kernel on the same inputs (what the training forward and precision="f32" run)
-            f32_step = lambda: dec.decode_lattice(grid, nx, box=1.1, c_img=c_img, out=out, precision="f32")
-            warm_up(f32_step, 5, fx)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            ev0.record()
-            for _ in range(args.steps):
-                f32_step()
-            ev1.record()
-            torch.cuda.synchronize()
-            wall32 = time.perf_counter() - t0
-            ms32 = ev0.elapsed_time(ev1) / args.steps
-            res["value_f32"] = npts * args.steps / wall32
-            res["exact_f32_kernel"] = {"value": npts * args.steps / wall32, "unit": "query-points/s",
-                                       "roofline": roofline_of("f32", flop_pt, npts, ms32)}
-            step()                                                   # leave the bf16x3 logits in `out`
+        if world == 1 and args.precision in SPLIT:
+            # the other kernels on the same inputs: exact f32 (what the training forward and precision="f32" run) and the
+            # other split form
+            def side(prec):
+                fn = lambda: dec.decode_lattice(grid, nx, box=1.1, c_img=c_img, out=out, precision=prec)
+                warm_up(fn, 5, fx)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ev0.record()
+                for _ in range(args.steps):
+                    fn()
+                ev1.record()
+                torch.cuda.synchronize()
+                w = time.perf_counter() - t0
+                return {"value": npts * args.steps / w, "unit": "query-points/s",
+                        "roofline": roofline_of(prec, flop_pt, npts, ev0.elapsed_time(ev1) / args.steps)}
+            res["exact_f32_kernel"] = side("f32")
+            res["value_f32"] = res["exact_f32_kernel"]["value"]
+            other = "bf16x3" if args.precision == "f16x3" else "f16x3"
+            res["split_" + other + "_kernel"] = side(other)
+            res["value_" + other] = res["split_" + other + "_kernel"]["value"]
+            step()                                                   # leave the headline kernel's logits in `out`
         if world == 1 and not args.decode_only:
             res["mesh_extract"] = mesh_extract_stats(out.view(nx, nx, nx), nx)
             res["stages_ms"] = stage_times(scene, dec, grid, nx, out, dev, args.precision)

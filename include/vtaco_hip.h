@@ -116,6 +116,20 @@ int vt_decode_fwd_bf16x3(const float *grid_cl, int B, int R, int C, const float 
                          const float *c_img, const unsigned char *finger_ids, const float *finger_feats, int F,
                          const float *blob_bf16x3, double padding, float *out, float *out2, void *stream);
 
+/* Split-f16 ("f16x3") variant: the same three-product scheme with IEEE half hi / lo parts on      */
+/* v_mfma_f32_32x32x16_f16 (the same matrix rate as bf16).  hi + lo carries 21-22 mantissa bits     */
+/* (logit error ~1e-6 on the goldens against ~1.6e-5 for bf16x3) for operand magnitudes below       */
+/* 65504 -- activations beyond that saturate, so networks with huge hidden activations belong on     */
+/* bf16x3 or f32 -- and relu + split costs two VALU instructions per value instead of four            */
+/* (v_cvt_pkrtz_f16_f32, v_pk_max_f16, v_fma_mix{lo,hi}_f16 with clamp): the lattice decode's       */
+/* fastest form.  Same arguments and blob size as the bf16x3 pair; blob from vt_decoder_pack_f16x3.  */
+/* Replaces the same reference functions (decoder.py:135-161, 71-103 on no-grad paths).              */
+int vt_decoder_pack_f16x3(const vt_decoder_params *params_host, float *blob, size_t blob_bytes, void *stream);
+int vt_decode_fwd_f16x3(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                        int lattice_nx, float lattice_box, int64_t lattice_first,
+                        const float *c_img, const unsigned char *finger_ids, const float *finger_feats, int F,
+                        const float *blob_f16x3, double padding, float *out, float *out2, void *stream);
+
 /* Tactile feature assignment and decode by finger id (SURVEY.md section 8f "next" row 2).        */
 /* Replaces: the scipy cdist + np.where glue that fills the dense c_img_all [1,N,32] at            */
 /*   src/conv_onet/generation.py:186-200 (mode 0: nearest fingertip, radius 0.05, only if that      */
@@ -360,6 +374,8 @@ typedef struct vt_unet3d_conv {
     int32_t cin, cout;
     const float *packed_bf16x3;  /* vt_conv3d_pack_bf16x3(conv.weight) or NULL: run this conv on the bf16 matrix core with */
                                  /* split-bf16 operands where vt_conv3d_stat_blocks_bf16x3(...) != 0, exact f32 elsewhere */
+    const float *packed_f16x3;   /* vt_conv3d_pack_f16x3(conv.weight) or NULL: where vt_conv3d_stat_blocks_f16x3(...) != 0 this conv runs */
+                                 /* the persistent split-f16 kernel (takes precedence over packed_bf16x3)                              */
 } vt_unet3d_conv;
 typedef struct vt_unet3d_params {
     int32_t n_levels;     /* len(f_maps) */
@@ -382,6 +398,20 @@ int vt_conv3d_stat_blocks_bf16x3(int B, int D, int H, int W, int Cin, int Cout);
 int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                          const float *scale_shift, const float *packed_w_bf16x3, int Cout, int relu, float *out,
                          float *out_part, void *stream);
+/* Split-f16 form ("f16x3") for the large volumes (same reference layer: unet3d.py:20-72 SingleConv 'gcr'): operands as */
+/* IEEE-half hi + lo pairs (21-22 mantissa bits: f32-rounding-level error on GroupNorm outputs and conv weights) on      */
+/* v_mfma_f32_32x32x16_f16, in a persistent, double-buffered kernel: input channels in chunks of eight with a PAIR of     */
+/* taps per MFMA k-step, the next chunk's image and weight fragments written to the other LDS buffer while the current    */
+/* chunk's taps run, one barrier per chunk, workgroups walking their tiles of a scene without per-tile prologues; the       */
+/* output's GroupNorm partial sums are per workgroup (stat_blocks = workgroups per scene).  Covers side lengths that are     */
+/* multiples of 8 with >= 256 tiles of 8x8x8 or >= 128 tiles of 8x8x4 per launch (stat_blocks returns 0 otherwise).          */
+/* The packed blob has its own size (28 instead of 27 tap slots per channel pair): vt_conv3d_packed_floats_f16x3.            */
+size_t vt_conv3d_packed_floats_f16x3(int Cout, int Cin);
+int vt_conv3d_pack_f16x3(const float *w, int Cout, int Cin, float *packed, void *stream);
+int vt_conv3d_stat_blocks_f16x3(int B, int D, int H, int W, int Cin, int Cout);
+int vt_conv3d_gcr_f16x3(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                        const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
+                        float *out_part, void *stream);
 size_t vt_unet3d_workspace_bytes(int B, int R, const vt_unet3d_params *params_host);
 int vt_unet3d_fwd(const float *x_cl, int B, int R, const vt_unet3d_params *params_host,
                   void *workspace, size_t workspace_bytes, float *out, void *stream);

@@ -35,7 +35,7 @@ def test_marching_cubes_256_vs_c_oracle(scene):
     assert np.abs(v2.cpu().numpy() - (rv2 - nx / 2) * (1.1 / nx)).max() <= 1e-6
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
 def test_decode_by_finger_id_256_equals_dense_on_slabs(scene, precision):
     """Config 5's decode at full size: finger ids for all 16.7 M lattice points (vt_tactile_assign) + decode by id
     (vt_decode_fwd_ids) against the dense [1, n, 32] c_img_all the reference would build, on three slabs of the lattice

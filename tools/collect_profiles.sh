@@ -3,15 +3,15 @@
 # gpurun copies back at most 64 MiB).  Usage: TAG=r01e bash tools/collect_profiles.sh
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
-TAG=${TAG:-r01i}
+TAG=${TAG:-r02b}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_under_profiler.json 2> $O/stats.err; echo "stats rc=$?"
 find $O/stats -name '*kernel_trace*' -delete 2>/dev/null
 echo "kernel,counter,launches,mean_per_launch" > $O/pmc_summary.csv
-for P in bf16x3 f32; do
+for P in f16x3 bf16x3 f32; do
   # the bench also launches the other precision's kernel (its exact-f32 side measurement): keep one kernel per key
-  if [ $P = bf16x3 ]; then KPAT='staged2_kernelILb1E,staged2_kernel<true>'; else KPAT='staged2_kernelILb0E,staged2_kernel<false>'; fi
+  case $P in f16x3) KPAT='staged2_kernelILi2E,staged2_kernel<2>';; bf16x3) KPAT='staged2_kernelILi1E,staged2_kernel<1>';; *) KPAT='staged2_kernelILi0E,staged2_kernel<0>';; esac
   pmc(){ tag=$1; shift; d=$O/pmc_${P}_$tag; timeout 200 rocprofv3 --pmc "$@" --kernel-trace -d $d -o p -- python3 $R/bench.py --steps 10 --warmup 2 --decode-only --no-cpu-baseline --precision $P > /dev/null 2>&1; echo "pmc $P $tag rc=$?"; python3 $R/tools/pmc_summary.py decode_$P=$d --kernel "$KPAT" | tail -n +2 >> $O/pmc_summary.csv; rm -rf $d; }
   pmc fetch FETCH_SIZE
   pmc write WRITE_SIZE

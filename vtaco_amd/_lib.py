@@ -61,7 +61,8 @@ VT_UNET_MAX_LEVELS = 6
 class UnetConv(ctypes.Structure):
     """Mirror of ``vt_unet3d_conv``."""
     _fields_ = [("gn_w", ctypes.c_void_p), ("gn_b", ctypes.c_void_p), ("packed", ctypes.c_void_p),
-                ("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("packed_bf16x3", ctypes.c_void_p)]
+                ("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("packed_bf16x3", ctypes.c_void_p),
+                ("packed_f16x3", ctypes.c_void_p)]
 
 
 class UnetParams(ctypes.Structure):
@@ -97,6 +98,8 @@ SIGNATURES = {
     "vt_decoder_blob_t_bytes": (_SZ, [_I, _I, _I]),
     "vt_decoder_pack_bf16x3": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
     "vt_decode_fwd_bf16x3": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP, _I, _VP, _D, _VP, _VP, _VP]),
+    "vt_decoder_pack_f16x3": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
+    "vt_decode_fwd_f16x3": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP, _I, _VP, _D, _VP, _VP, _VP]),
     "vt_decoder_pack_t": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
     "vt_decode_save_bytes": (_SZ, [_I64]),
     "vt_decode_gws_bytes": (_SZ, [_I64]),
@@ -134,6 +137,10 @@ SIGNATURES = {
     "vt_gn_bwd": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _I, _VP, _I, _VP, _I, _VP, _D, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "vt_maxpool3d_cl_bwd": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP, _VP]),
     "vt_conv3d_pack_bf16x3": (_I, [_VP, _I, _I, _VP, _VP]),
+    "vt_conv3d_packed_floats_f16x3": (_SZ, [_I, _I]),
+    "vt_conv3d_pack_f16x3": (_I, [_VP, _I, _I, _VP, _VP]),
+    "vt_conv3d_stat_blocks_f16x3": (_I, [_I, _I, _I, _I, _I, _I]),
+    "vt_conv3d_gcr_f16x3": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),
     "vt_conv3d_stat_blocks_bf16x3": (_I, [_I, _I, _I, _I, _I, _I]),
     "vt_conv3d_gcr_bf16x3": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),
     "vt_channel_stats": (_I, [_VP, _I, _I64, _I, _I, _VP, _VP]),

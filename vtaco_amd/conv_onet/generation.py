@@ -28,11 +28,12 @@ class Generator3D(object):
     def __init__(self, model, points_batch_size=100000, threshold=0.5, refinement_step=0, device=None,
                  resolution0=16, upsampling_steps=3, with_normals=False, padding=0.1, sample=False,
                  input_type=None, vol_info=None, vol_bound=None, simplify_nfaces=None, alpha=0.2,
-                 with_img=False, encode_t2d=False, decode_precision="bf16x3", depth_origin=None):
+                 with_img=False, encode_t2d=False, decode_precision="f16x3", depth_origin=None):
         self.model = model.to(device)
-        # arithmetic of the dense lattice decode (eval_lattice): "bf16x3" = split-bf16 MFMA, inside the
-        # 1e-4 parity bar and ~3x the exact-f32 rate; "f32" = exact-f32 MFMA.  eval_points follows the
-        # decoder's own ``precision`` attribute (default "f32").
+        # arithmetic of the dense lattice decode (eval_lattice): "f16x3" = split-f16 MFMA (f32-level logit error,
+        # ~1e-6 on the goldens, for hidden activations below 65504; ~2.5x the exact-f32 rate), "bf16x3" = split-bf16
+        # MFMA (f32's exponent range, ~1.6e-5), "f32" = exact-f32 MFMA.  eval_points follows the decoder's own
+        # ``precision`` attribute (default "f32").
         self.decode_precision = decode_precision
         self.points_batch_size = points_batch_size
         self.threshold, self.refinement_step = threshold, refinement_step

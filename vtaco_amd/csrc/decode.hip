@@ -27,7 +27,7 @@ namespace {
 
 // ---- everything after the gather: fc_p / fc_p_img, 5 x (fc_c + ResnetBlockFC), output heads ----
 // c: the sampled features in gather layout (register s of lane-half h = channel 16h+s).
-template <bool SAVE, bool SPLIT>
+template <bool SAVE, int P>
 __device__ __forceinline__ void mlp_and_heads(const DecodeArgs &a, const float *L, const f32x16 &c, float px, float py, float pz,
                                               uint32_t g, bool live, int lane, int h, bool with_img) {
     const size_t slot = (size_t)a.total * 32;           // one saved tensor
@@ -63,33 +63,33 @@ __device__ __forceinline__ void mlp_and_heads(const DecodeArgs &a, const float *
 #pragma unroll
                 for (int s = 0; s < 16; ++s) ci[s] = 0.0f;
                 if (id != 255u) ci = load_frag16(a.cimg_table + (size_t)id * 32 + 16 * h);
-                if (SPLIT) net = dense32s(net, L + VT_OFF_WPI, split16<false>(ci), lane);
+                if constexpr (P != 0) net = dense32s<P>(net, L + VT_OFF_WPI, split16<false, P>(ci), lane);
                 else net = dense32<false>(net, L + VT_OFF_WPI, ci, lane);
             }
         } else {
             const f32x16 ci = load_frag16(a.c_img + (size_t)g * 32 + 16 * h);
-            if (SPLIT) net = dense32s(net, L + VT_OFF_WPI, split16<false>(ci), lane);
+            if constexpr (P != 0) net = dense32s<P>(net, L + VT_OFF_WPI, split16<false, P>(ci), lane);
             else net = dense32<false>(net, L + VT_OFF_WPI, ci, lane);
         }
     }
-    if (SPLIT) {
-        // ---- split-bf16 layers: c is split once and feeds all five fc_c ----
-        const Split16 cs = split16<false>(c);
-        net = dense32s(net, L + VT_OFF_WL, cs, lane);
+    if constexpr (P != 0) {
+        // ---- split 16-bit layers: c is split once and feeds all five fc_c ----
+        const SplitP<P> cs = split16<false, P>(c);
+        net = dense32s<P>(net, L + VT_OFF_WL, cs, lane);
 #pragma unroll 1
         for (int i = 0; i < 5; ++i) {
             const float *wl = L + VT_OFF_WL + (1 + 3 * i) * 1024;
             f32x16 hid = load_frag16(L + VT_OFF_BIAS + (1 + 2 * i) * 32 + h * 16);
             // same accumulation order as the two-brick kernel: net + cond(k-step 0) + bias + cond(k-step 1) + fc_1(..),
             // the conditioning MFMAs placed where the VALU is busy splitting relu(net) / relu(hid)
-            const Split16 sn = split16<true>(net);
-            if (i < 4) net = dense32s_half(net, wl + 2048, cs, lane, 0);
+            const SplitP<P> sn = split16<true, P>(net);
+            if (i < 4) net = dense32s_half<P>(net, wl + 2048, cs, lane, 0);
             const f32x16 bb = load_frag16(L + VT_OFF_BIAS + (2 + 2 * i) * 32 + h * 16);
             net = net + bb;
-            hid = dense32s(hid, wl, sn, lane);
-            const Split16 sh = split16<true>(hid);
-            if (i < 4) net = dense32s_half(net, wl + 2048, cs, lane, 1);
-            net = dense32s(net, wl + 1024, sh, lane);
+            hid = dense32s<P>(hid, wl, sn, lane);
+            const SplitP<P> sh = split16<true, P>(hid);
+            if (i < 4) net = dense32s_half<P>(net, wl + 2048, cs, lane, 1);
+            net = dense32s<P>(net, wl + 1024, sh, lane);
         }
     } else {
     net = dense32<false>(net, L + VT_OFF_WL, c, lane);
@@ -136,12 +136,12 @@ __device__ __forceinline__ void mlp_and_heads(const DecodeArgs &a, const float *
     }
 }
 
-// SPLIT selects the split-bf16 dense layers (decode_common.h) and expects the blob of
-// vt_decoder_pack_bf16x3; everything around the 16 dense layers is shared.
-template <int THREADS, bool SAVE, bool SPLIT>
+// P selects the dense layers (decode_common.h): 0 exact f32, 1 split-bf16, 2 split-f16, and expects the
+// blob of vt_decoder_pack / _bf16x3 / _f16x3; everything around the 16 dense layers is shared.
+template <int THREADS, bool SAVE, int P>
 __global__ void __launch_bounds__(THREADS, VT_WAVES_PER_SIMD)
 decode_fwd_kernel(DecodeArgs a) {
-    static_assert(!(SAVE && SPLIT), "the training forward keeps the exact-f32 layers");
+    static_assert(!(SAVE && P != 0), "the training forward keeps the exact-f32 layers");
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef VT_DIAG_CLOCK
     const unsigned long long dc_entry = __builtin_amdgcn_s_memrealtime();
@@ -252,7 +252,7 @@ decode_fwd_kernel(DecodeArgs a) {
             pin16(c);
             __builtin_amdgcn_sched_barrier(0);
         }
-        mlp_and_heads<SAVE, SPLIT>(a, L, c, px, py, pz, g, live, lane, h, with_img);
+        mlp_and_heads<SAVE, P>(a, L, c, px, py, pz, g, live, lane, h, with_img);
     }
 #ifdef VT_DIAG_CLOCK
     if (threadIdx.x == 0 && a.out2) {
@@ -287,7 +287,7 @@ struct AxisEnt {                                   // one lattice index along on
     float w0, w1;                                  // their weights (w1 = 0 where ATen skips the corner)
 };
 
-template <bool SPLIT>
+template <int P>
 __global__ void __launch_bounds__(ST_THREADS)
 decode_fwd_staged_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -424,7 +424,7 @@ decode_fwd_staged_kernel(DecodeArgs a) {
         // ---- next tile's footprint goes into flight before this tile's MLP ----
         if (tile + w_cnt < t_end) fetch(tile + w_cnt, ox, oy, oz);
 
-        mlp_and_heads<false, SPLIT>(a, L, c, px, py, pz, g, true, lane, h, with_img);
+        mlp_and_heads<false, P>(a, L, c, px, py, pz, g, true, lane, h, with_img);
     }
 }
 
@@ -438,36 +438,49 @@ decode_fwd_staged_kernel(DecodeArgs a) {
 // operation sequence as the other paths; the logits agree with them to the last bit for ~96 % of the
 // points and to 1 ulp for the rest (running the two MLPs one after the other instead of interleaved is
 // bit-identical -- and no faster).  Conditions: nx % 8 == 0, voxels per step < 0.55.
+#ifdef VT_DIAG_PHASES
+// diagnostic build only (tools/diag_phases.py): per-wave shader-clock sums of the phases of the two-brick kernel
+__device__ unsigned long long vt_diag_phase_buf[4096 * 8];
+#define VT_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                         dg_sum[i] += t_ - dg_last; dg_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define VT_STAMP(i) do { } while (0)
+#endif
 constexpr int ST2_ROWS = 72;
 constexpr int ST2_WAVE_BYTES = ST2_ROWS * ST_ROW_BYTES;
-constexpr int ST2_THREADS = 512;
+#ifndef VT_ST2_THREADS
+#define VT_ST2_THREADS 512
+#endif
+constexpr int ST2_THREADS = VT_ST2_THREADS;       // 8 waves per CU (A/B knob: 256 = one wave per SIMD)
 constexpr int ST2_PIECES = 9;
 
-__device__ __forceinline__ void dense32s2(f32x16 &accA, f32x16 &accB, const float *wl, const Split16 &xA, const Split16 &xB, int lane) {
-    const bf16x8 *w = reinterpret_cast<const bf16x8 *>(wl);
+template <int P>
+__device__ __forceinline__ void dense32s2(f32x16 &accA, f32x16 &accB, const float *wl, const SplitP<P> &xA, const SplitP<P> &xB, int lane) {
+    const mx8<P> *w = reinterpret_cast<const mx8<P> *>(wl);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const bf16x8 wh = w[s * 64 + lane], wo = w[(2 + s) * 64 + lane];
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo, xA.hi[s], accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo, xB.hi[s], accB, 0, 0, 0);
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xA.lo[s], accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xB.lo[s], accB, 0, 0, 0);
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xA.hi[s], accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xB.hi[s], accB, 0, 0, 0);
+        const mx8<P> wh = w[s * 64 + lane], wo = w[(2 + s) * 64 + lane];
+        accA = mfma_s(wo, xA.hi[s], accA);
+        accB = mfma_s(wo, xB.hi[s], accB);
+        accA = mfma_s(wh, xA.lo[s], accA);
+        accB = mfma_s(wh, xB.lo[s], accB);
+        accA = mfma_s(wh, xA.hi[s], accA);
+        accB = mfma_s(wh, xB.hi[s], accB);
     }
 }
 
 // one k-step (s = 0 or 1) of dense32s2: six of the layer's twelve MFMAs
-__device__ __forceinline__ void dense32s2_half(f32x16 &accA, f32x16 &accB, const float *wl, const Split16 &xA, const Split16 &xB,
+template <int P>
+__device__ __forceinline__ void dense32s2_half(f32x16 &accA, f32x16 &accB, const float *wl, const SplitP<P> &xA, const SplitP<P> &xB,
                                                int lane, int s) {
-    const bf16x8 *w = reinterpret_cast<const bf16x8 *>(wl);
-    const bf16x8 wh = w[s * 64 + lane], wo = w[(2 + s) * 64 + lane];
-    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo, xA.hi[s], accA, 0, 0, 0);
-    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo, xB.hi[s], accB, 0, 0, 0);
-    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xA.lo[s], accA, 0, 0, 0);
-    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xB.lo[s], accB, 0, 0, 0);
-    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xA.hi[s], accA, 0, 0, 0);
-    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xB.hi[s], accB, 0, 0, 0);
+    const mx8<P> *w = reinterpret_cast<const mx8<P> *>(wl);
+    const mx8<P> wh = w[s * 64 + lane], wo = w[(2 + s) * 64 + lane];
+    accA = mfma_s(wo, xA.hi[s], accA);
+    accB = mfma_s(wo, xB.hi[s], accB);
+    accA = mfma_s(wh, xA.lo[s], accA);
+    accB = mfma_s(wh, xB.lo[s], accB);
+    accA = mfma_s(wh, xA.hi[s], accA);
+    accB = mfma_s(wh, xB.hi[s], accB);
 }
 
 // exact-f32 layer for two column groups: one weight read per k-step feeds both chains
@@ -487,7 +500,7 @@ __device__ __forceinline__ void dense32x2(f32x16 &accA, f32x16 &accB, const floa
     }
 }
 
-template <bool SPLIT>
+template <int P>
 __global__ void __launch_bounds__(ST2_THREADS)
 decode_fwd_staged2_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -563,16 +576,34 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
         for (int k = 0; k < ST2_PIECES; ++k) pre[k] = *reinterpret_cast<const f32x4 *>(base + src_off[k]);
     };
 
-    bf16x8 ones;
+    // B operand of the bias MFMA: ones in the three k-slots that carry the bias's hi / mid / lo parts
+    auto make_ones = [&]() {
+        if constexpr (P == 2) {
+            f16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)((h == 0 && e < 3) ? 1.0f : 0.0f);
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)((h == 0 && e < 3) ? 1.0f : 0.0f);
+            return o;
+        } else {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)((h == 0 && e < 3) ? 1.0f : 0.0f);
+            return o;
+        }
+    };
+    const auto ones = make_ones();
 
     uint32_t tile = t_begin + w_idx;
     if (tile < t_end) fetch(tile, ox, oy, oz);
+#ifdef VT_DIAG_PHASES
+    unsigned long long dg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dg_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long dg_first = dg_last;
+#endif
     for (; tile < t_end; tile += w_cnt) {
         unsigned lds_off = 0;
         asm volatile("" : "+v"(lds_off));
         const float *L = lds + lds_off;
+        VT_STAMP(0);                                                     // loop overhead / previous tile's tail
 #pragma unroll
         for (int k = 0; k < ST2_PIECES; ++k) *reinterpret_cast<f32x4 *>(stage + dst_off[k]) = pre[k];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -617,9 +648,12 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             return c;
         };
+        VT_STAMP(1);                                                     // footprint registers -> LDS (waits for the prefetch), indices
         const f32x16 cA = gather(ezA);
         const f32x16 cB = gather(ezB);
+        VT_STAMP(2);                                                     // trilinear gather from LDS
         if (tile + w_cnt < t_end) fetch(tile + w_cnt, ox, oy, oz);
+        VT_STAMP(3);                                                     // next footprint's loads issued
 
         // ---- MLP on both column groups (mlp_and_heads<false, true>, visual-only, two chains) ----
         const f32x16 b0 = load_frag16(L + VT_OFF_BIAS + h * 16);
@@ -649,10 +683,11 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
             ciB = load_frag16(a.c_img + (size_t)gB * 32 + 16 * h);
             has_img = true;
         }
-        if constexpr (SPLIT) {
-            if (has_img) dense32s2(netA, netB, L + VT_OFF_WPI, split16<false>(ciA), split16<false>(ciB), lane);
-            const Split16 csA = split16<false>(cA), csB = split16<false>(cB);
-            dense32s2(netA, netB, L + VT_OFF_WL, csA, csB, lane);
+        if constexpr (P != 0) {
+            constexpr int Q = P ? P : 1;
+            if (has_img) dense32s2<Q>(netA, netB, L + VT_OFF_WPI, split16<false, Q>(ciA), split16<false, Q>(ciB), lane);
+            const SplitP<Q> csA = split16<false, Q>(cA), csB = split16<false, Q>(cB);
+            dense32s2<Q>(netA, netB, L + VT_OFF_WL, csA, csB, lane);
             // The block's c-conditioning and bias MFMAs (net += fc_c{i+1}(c) + b_1) depend on nothing the block
             // computes, only on net having been READ by the relu: they issue while the VALU splits relu(net) and
             // relu(hid), instead of back to back behind fc_1 with the VALU idle (net = net + cond + fc_1(..)).
@@ -660,25 +695,44 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
                 constexpr bool COND = decltype(cond_tag)::value;
                 const float *wl = L + VT_OFF_WL + (1 + 3 * i) * 1024;
                 const f32x16 hb = load_frag16(L + VT_OFF_BIAS + (1 + 2 * i) * 32 + h * 16);
-                f32x16 rA, rB;
+                const mx8<Q> bf = reinterpret_cast<const mx8<Q> *>(L + VT_OFF_BFRAG + i * 256)[lane];
+                if constexpr (P == 1) {
+                    f32x16 rA, rB;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) { rA[q] = relu1(netA[q]); rB[q] = relu1(netB[q]); }
-                asm volatile("" : "+v"(rA), "+v"(rB));
-                if constexpr (COND) dense32s2_half(netA, netB, wl + 2048, csA, csB, lane, 0);
-                const bf16x8 bf = reinterpret_cast<const bf16x8 *>(L + VT_OFF_BFRAG + i * 256)[lane];
-                netA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, ones, netA, 0, 0, 0);
-                netB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, ones, netB, 0, 0, 0);
-                f32x16 hidA = hb, hidB = hb;
-                dense32s2(hidA, hidB, wl, split16<false>(rA), split16<false>(rB), lane);
+                    for (int q = 0; q < 16; ++q) { rA[q] = relu1(netA[q]); rB[q] = relu1(netB[q]); }
+                    asm volatile("" : "+v"(rA), "+v"(rB));
+                    if constexpr (COND) dense32s2_half<Q>(netA, netB, wl + 2048, csA, csB, lane, 0);
+                    netA = mfma_s(bf, ones, netA);
+                    netB = mfma_s(bf, ones, netB);
+                    f32x16 hidA = hb, hidB = hb;
+                    dense32s2<Q>(hidA, hidB, wl, split16<false, Q>(rA), split16<false, Q>(rB), lane);
 #pragma unroll
-                for (int q = 0; q < 16; ++q) { rA[q] = relu1(hidA[q]); rB[q] = relu1(hidB[q]); }
-                asm volatile("" : "+v"(rA), "+v"(rB));
-                if constexpr (COND) dense32s2_half(netA, netB, wl + 2048, csA, csB, lane, 1);
-                dense32s2(netA, netB, wl + 1024, split16<false>(rA), split16<false>(rB), lane);
+                    for (int q = 0; q < 16; ++q) { rA[q] = relu1(hidA[q]); rB[q] = relu1(hidB[q]); }
+                    asm volatile("" : "+v"(rA), "+v"(rB));
+                    if constexpr (COND) dense32s2_half<Q>(netA, netB, wl + 2048, csA, csB, lane, 1);
+                    dense32s2<Q>(netA, netB, wl + 1024, split16<false, Q>(rA), split16<false, Q>(rB), lane);
+                } else {
+                    // split-f16: relu + split reads net directly (two instructions per value); the conditioning and
+                    // bias MFMAs may only overwrite net once the split has read it
+                    SplitP<Q> sA = split16<true, Q>(netA), sB = split16<true, Q>(netB);
+                    asm volatile("" : "+v"(sA.hi[0]), "+v"(sA.hi[1]), "+v"(sA.lo[0]), "+v"(sA.lo[1]));
+                    asm volatile("" : "+v"(sB.hi[0]), "+v"(sB.hi[1]), "+v"(sB.lo[0]), "+v"(sB.lo[1]));
+                    if constexpr (COND) dense32s2_half<Q>(netA, netB, wl + 2048, csA, csB, lane, 0);
+                    netA = mfma_s(bf, ones, netA);
+                    netB = mfma_s(bf, ones, netB);
+                    f32x16 hidA = hb, hidB = hb;
+                    dense32s2<Q>(hidA, hidB, wl, sA, sB, lane);
+                    if constexpr (COND) dense32s2_half<Q>(netA, netB, wl + 2048, csA, csB, lane, 1);
+                    sA = split16<true, Q>(hidA);
+                    sB = split16<true, Q>(hidB);
+                    dense32s2<Q>(netA, netB, wl + 1024, sA, sB, lane);
+                }
             };
+            VT_STAMP(4);                                                 // fc_p, c split, fc_c[0]
 #pragma unroll 1
             for (int i = 0; i < 4; ++i) block(i, std::true_type{});
             block(4, std::false_type{});
+            VT_STAMP(5);                                                 // five blocks
         } else {
             if (has_img) dense32x2<false>(netA, netB, L + VT_OFF_WPI, ciA, ciB, lane);
             dense32x2<false>(netA, netB, L + VT_OFF_WL, cA, cB, lane);
@@ -705,9 +759,19 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
             const float ob = L[VT_OFF_OUT + 64];
             if (h == 0) { a.out[gA] = accA + ob; a.out[gB] = accB + ob; }
         }
+        VT_STAMP(6);                                                     // head + store
     }
+#ifdef VT_DIAG_PHASES
+    if (lane == 0) {
+        unsigned long long *d = vt_diag_phase_buf + (size_t)(blockIdx.x * WPB + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) d[i] = dg_sum[i];
+        d[7] = __builtin_amdgcn_s_memtime() - dg_first;
+    }
+#endif
 }
 
+#ifndef VT_DECODE_F16_TU      // the remaining kernels exist once, in decode.o
 // ---- trilinear gather only: feat[b,n,:] = grid sampled at the query point -----------------
 __global__ void __launch_bounds__(256) sample_grid_kernel(DecodeArgs a, float *feat) {
     const int lane = threadIdx.x & 63, pl = lane & 31, h = lane >> 5;
@@ -741,11 +805,24 @@ __global__ void __launch_bounds__(256) sample_grid_kernel(DecodeArgs a, float *f
 struct PackArgs {
     vt_decoder_params p;
     float *blob;
-    int split;            // 1: dense layers as split-bf16 fragments (vt_decoder_pack_bf16x3)
+    int split;            // 1: dense layers as split-bf16 fragments (vt_decoder_pack_bf16x3), 2: split-f16 (vt_decoder_pack_f16x3)
 };
 
-__device__ __forceinline__ unsigned bf16_bits(float v) {
-    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v);
+// v as hi + mid + lo 16-bit floats (round to nearest each time); fmt 1 = bf16, 2 = IEEE half
+__device__ __forceinline__ void split3_bits(float v, int fmt, unsigned &hi, unsigned &mid, unsigned &lo) {
+    if (fmt == 2) {
+        const _Float16 h = (_Float16)v;
+        const float r1 = v - (float)h;
+        const _Float16 m = (_Float16)r1;
+        const _Float16 l = (_Float16)(r1 - (float)m);
+        hi = __builtin_bit_cast(unsigned short, h); mid = __builtin_bit_cast(unsigned short, m); lo = __builtin_bit_cast(unsigned short, l);
+    } else {
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const __bf16 l = (__bf16)(r1 - (float)m);
+        hi = __builtin_bit_cast(unsigned short, h); mid = __builtin_bit_cast(unsigned short, m); lo = __builtin_bit_cast(unsigned short, l);
+    }
 }
 
 __global__ void decoder_pack_kernel(PackArgs a) {
@@ -758,12 +835,9 @@ __global__ void decoder_pack_kernel(PackArgs a) {
             unsigned bits = 0;
             if (a.split && kg == 0 && m < 2) {
                 const float bv = p.fc1_b[blk][i] + ((blk < 4) ? p.fc_c_b[blk + 1][i] : 0.0f);
-                const __bf16 hb = (__bf16)bv;
-                const float r1 = bv - (float)hb;
-                const __bf16 mb = (__bf16)r1;
-                const __bf16 lb = (__bf16)(r1 - (float)mb);
-                if (m == 0) bits = (unsigned)__builtin_bit_cast(unsigned short, hb) | ((unsigned)__builtin_bit_cast(unsigned short, mb) << 16);
-                else bits = (unsigned)__builtin_bit_cast(unsigned short, lb);
+                unsigned hb, mb, lb;
+                split3_bits(bv, a.split, hb, mb, lb);
+                bits = (m == 0) ? (hb | (mb << 16)) : lb;
             }
             a.blob[e] = __builtin_bit_cast(float, bits);
             continue;
@@ -791,9 +865,9 @@ __global__ void decoder_pack_kernel(PackArgs a) {
                 const int j = 2 * m + z;
                 const int k = gather_fed ? (16 * h + 8 * s + j) : chan_of(8 * s + j, h);
                 const float wv = (L == 15 && p.p_in <= 3) ? 0.0f : w[i * ld + koff + k];
-                const __bf16 hb = (__bf16)wv;
-                const unsigned b = part ? bf16_bits(wv - (float)hb) : (unsigned)__builtin_bit_cast(unsigned short, hb);
-                bits |= b << (16 * z);
+                unsigned hb, mb, lb;
+                split3_bits(wv, a.split, hb, mb, lb);
+                bits |= (part ? mb : hb) << (16 * z);
             }
             a.blob[e] = __builtin_bit_cast(float, bits);
             continue;
@@ -877,11 +951,15 @@ __global__ void __launch_bounds__(256) grid_from_cl_kernel(const float *src, flo
     }
 }
 
+#endif  // !VT_DECODE_F16_TU
+
 }  // namespace
 
 // =====================================================================================
-// C ABI
+// C ABI.  This file is compiled twice: as decode.o (everything except the split-f16 kernels) and, through
+// decode_f16.hip with VT_DECODE_F16_TU and -fno-slp-vectorize, as decode_f16.o (vt_decode_fwd_f16x3 only).
 // =====================================================================================
+#ifndef VT_DECODE_F16_TU
 extern "C" {
 
 size_t vt_decoder_blob_bytes(int hidden, int c_dim, int n_blocks) {
@@ -919,6 +997,17 @@ int vt_decoder_pack_bf16x3(const vt_decoder_params *p, float *blob, size_t blob_
     return vt_check(hipGetLastError(), "vt_decoder_pack_bf16x3");
 }
 
+int vt_decoder_pack_f16x3(const vt_decoder_params *p, float *blob, size_t blob_bytes, void *stream) {
+    const int rc = vt_decoder_pack(p, blob, blob_bytes, stream);
+    if (rc) return rc;
+    PackArgs a;
+    a.p = *p;
+    a.blob = blob;
+    a.split = 2;
+    hipLaunchKernelGGL(decoder_pack_kernel, dim3(17), dim3(1024), 0, (hipStream_t)stream, a);
+    return vt_check(hipGetLastError(), "vt_decoder_pack_f16x3");
+}
+
 int vt_grid_to_channels_last(const float *src, float *dst, int B, int C, int D, int H, int W, void *stream) {
     if (!src || !dst || B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return vt_fail(VT_ERR_INVALID, "vt_grid_to_channels_last: bad argument");
     const int64_t V = (int64_t)D * H * W;
@@ -935,13 +1024,18 @@ int vt_grid_from_channels_last(const float *src, float *dst, int B, int C, int D
     return vt_check(hipGetLastError(), "vt_grid_from_channels_last");
 }
 
+}  // extern "C"
+#endif  // !VT_DECODE_F16_TU
+
+// P: 0 exact f32, 1 split-bf16, 2 split-f16 (the dense layers; decode_common.h)
+template <int P>
 static int decode_launch(const float *grid_cl, const float *c_direct, int B, int R, int C, const float *pts, int64_t N,
                          int lattice_nx, float lattice_box, int64_t lattice_first,
                          const float *c_img, const unsigned char *cimg_ids, const float *cimg_table,
                          const float *blob, double padding,
-                         float *out, float *out2, float *save, void *stream, bool split = false) {
+                         float *out, float *out2, float *save, void *stream) {
     if ((!grid_cl && !c_direct) || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: null argument");
-    if (split && save) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd_bf16x3: the training forward (save) is exact-f32 only");
+    if (P != 0 && save) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd_bf16x3 / _f16x3: the training forward (save) is exact-f32 only");
     if (B <= 0 || R < 2 || N < 0) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: bad size");
     if (C != 32) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd: c_dim must be 32");
     if (!pts) {
@@ -979,18 +1073,12 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
             if (blocks > 8) blocks &= ~7ll;
             static bool st2_attr = false;
             if (!st2_attr) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged2_kernel<true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e == hipSuccess)
-                    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged2_kernel<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged2_kernel<P>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute (staged2)");
                 st2_attr = true;
             }
-            if (split)
-                hipLaunchKernelGGL(decode_fwd_staged2_kernel<true>, dim3((unsigned)blocks), dim3(ST2_THREADS), lds_st2, (hipStream_t)stream, a);
-            else
-                hipLaunchKernelGGL(decode_fwd_staged2_kernel<false>, dim3((unsigned)blocks), dim3(ST2_THREADS), lds_st2, (hipStream_t)stream, a);
+            hipLaunchKernelGGL(decode_fwd_staged2_kernel<P>, dim3((unsigned)blocks), dim3(ST2_THREADS), lds_st2, (hipStream_t)stream, a);
             return vt_check(hipGetLastError(), "vt_decode_fwd");
         }
         if (s_vox > 0.0 && s_vox < 0.66 && lds_st <= 160u * 1024u) {
@@ -1000,18 +1088,12 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
             if (blocks > 8) blocks &= ~7ll;
             static bool st_attr = false;
             if (!st_attr) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged_kernel<false>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e == hipSuccess)
-                    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged_kernel<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged_kernel<P>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute (staged)");
                 st_attr = true;
             }
-            if (split)
-                hipLaunchKernelGGL((decode_fwd_staged_kernel<true>), dim3((unsigned)blocks), dim3(ST_THREADS), lds_st, (hipStream_t)stream, a);
-            else
-                hipLaunchKernelGGL((decode_fwd_staged_kernel<false>), dim3((unsigned)blocks), dim3(ST_THREADS), lds_st, (hipStream_t)stream, a);
+            hipLaunchKernelGGL((decode_fwd_staged_kernel<P>), dim3((unsigned)blocks), dim3(ST_THREADS), lds_st, (hipStream_t)stream, a);
             return vt_check(hipGetLastError(), "vt_decode_fwd");
         }
     }
@@ -1024,33 +1106,57 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
     const size_t lds_bytes = (size_t)VT_BLOB_FLOATS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS, false, false>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS, false, P>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS, true, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS, false, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if constexpr (P == 0) {
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS, true, 0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        }
         if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute");
         attr_set = true;
     }
-    if (split)
-        hipLaunchKernelGGL((decode_fwd_kernel<THREADS, false, true>), dim3((unsigned)blocks), dim3(THREADS), lds_bytes, (hipStream_t)stream, a);
-    else if (save)
-        hipLaunchKernelGGL((decode_fwd_kernel<THREADS, true, false>), dim3((unsigned)blocks), dim3(THREADS), lds_bytes, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL((decode_fwd_kernel<THREADS, false, false>), dim3((unsigned)blocks), dim3(THREADS), lds_bytes, (hipStream_t)stream, a);
+    if constexpr (P == 0) {
+        if (save) {
+            hipLaunchKernelGGL((decode_fwd_kernel<THREADS, true, 0>), dim3((unsigned)blocks), dim3(THREADS), lds_bytes, (hipStream_t)stream, a);
+            return vt_check(hipGetLastError(), "vt_decode_fwd");
+        }
+    }
+    hipLaunchKernelGGL((decode_fwd_kernel<THREADS, false, P>), dim3((unsigned)blocks), dim3(THREADS), lds_bytes, (hipStream_t)stream, a);
     return vt_check(hipGetLastError(), "vt_decode_fwd");
 }
 
+extern "C" {
+
+#ifdef VT_DECODE_F16_TU
+#ifdef VT_DIAG_PHASES
+int vt_diag_phases_read_f16(unsigned long long *host, size_t count) {
+    return vt_check(hipMemcpyFromSymbol(host, HIP_SYMBOL(vt_diag_phase_buf), count * sizeof(unsigned long long)), "vt_diag_phases_read_f16");
+}
+#endif
+int vt_decode_fwd_f16x3(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                        int lattice_nx, float lattice_box, int64_t lattice_first,
+                        const float *c_img, const unsigned char *finger_ids, const float *finger_feats, int F,
+                        const float *blob_f16x3, double padding, float *out, float *out2, void *stream) {
+    if (!grid_cl) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_f16x3: null grid");
+    if (c_img && finger_ids) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_f16x3: give c_img or finger ids, not both");
+    if (finger_ids && (!finger_feats || F <= 0)) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_f16x3: finger ids without a feature table");
+    return decode_launch<2>(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img,
+                            finger_ids, finger_ids ? finger_feats : nullptr, blob_f16x3, padding, out, out2, nullptr, stream);
+}
+#else
+#ifdef VT_DIAG_PHASES
+int vt_diag_phases_read(unsigned long long *host, size_t count) {
+    return vt_check(hipMemcpyFromSymbol(host, HIP_SYMBOL(vt_diag_phase_buf), count * sizeof(unsigned long long)), "vt_diag_phases_read");
+}
+#endif
 int vt_decode_fwd(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
                   int lattice_nx, float lattice_box, int64_t lattice_first,
                   const float *c_img, const float *blob, double padding,
                   float *out, float *out2, float *save, void *stream) {
     if (!grid_cl) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: null grid");
-    return decode_launch(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img, nullptr, nullptr,
-                         blob, padding, out, out2, save, stream);
+    return decode_launch<0>(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img, nullptr, nullptr,
+                            blob, padding, out, out2, save, stream);
 }
 
 int vt_decode_fwd_ids(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
@@ -1058,8 +1164,8 @@ int vt_decode_fwd_ids(const float *grid_cl, int B, int R, int C, const float *pt
                       const unsigned char *finger_ids, const float *finger_feats, int F,
                       const float *blob, double padding, float *out, void *stream) {
     if (!grid_cl || !finger_ids || !finger_feats || F <= 0) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_ids: null argument");
-    return decode_launch(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, finger_ids, finger_feats,
-                         blob, padding, out, nullptr, nullptr, stream);
+    return decode_launch<0>(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, finger_ids, finger_feats,
+                            blob, padding, out, nullptr, nullptr, stream);
 }
 
 int vt_decode_fwd_bf16x3(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
@@ -1069,24 +1175,24 @@ int vt_decode_fwd_bf16x3(const float *grid_cl, int B, int R, int C, const float 
     if (!grid_cl) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_bf16x3: null grid");
     if (c_img && finger_ids) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_bf16x3: give c_img or finger ids, not both");
     if (finger_ids && (!finger_feats || F <= 0)) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_bf16x3: finger ids without a feature table");
-    return decode_launch(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img,
-                         finger_ids, finger_ids ? finger_feats : nullptr, blob_bf16x3, padding, out, out2, nullptr, stream, true);
+    return decode_launch<1>(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img,
+                            finger_ids, finger_ids ? finger_feats : nullptr, blob_bf16x3, padding, out, out2, nullptr, stream);
 }
 
 int vt_decode_mlp_fwd(const float *c, int B, int C, const float *pts, int64_t N,
                       int lattice_nx, float lattice_box, int64_t lattice_first,
                       const float *blob, float *out, void *stream) {
     if (!c) return vt_fail(VT_ERR_INVALID, "vt_decode_mlp_fwd: null features");
-    return decode_launch(nullptr, c, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, nullptr, nullptr, blob, 0.1,
-                         out, nullptr, nullptr, stream);
+    return decode_launch<0>(nullptr, c, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, nullptr, nullptr, blob, 0.1,
+                            out, nullptr, nullptr, stream);
 }
 
 int vt_decode_mlp_fwd_train(const float *c, int B, int C, const float *pts, int64_t N,
                             int lattice_nx, float lattice_box, int64_t lattice_first,
                             const float *blob, float *out, float *save, void *stream) {
     if (!c || !save) return vt_fail(VT_ERR_INVALID, "vt_decode_mlp_fwd_train: null argument");
-    return decode_launch(nullptr, c, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, nullptr, nullptr, blob, 0.1,
-                         out, nullptr, save, stream);
+    return decode_launch<0>(nullptr, c, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, nullptr, nullptr, blob, 0.1,
+                            out, nullptr, save, stream);
 }
 
 int vt_sample_grid(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
@@ -1108,5 +1214,6 @@ int vt_sample_grid(const float *grid_cl, int B, int R, int C, const float *pts, 
     hipLaunchKernelGGL(sample_grid_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, feat);
     return vt_check(hipGetLastError(), "vt_sample_grid");
 }
+#endif  // VT_DECODE_F16_TU
 
 }  // extern "C"

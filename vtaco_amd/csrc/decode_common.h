@@ -48,57 +48,128 @@ __device__ __forceinline__ f32x16 dense32(f32x16 acc, const float *wl, const f32
     return acc;
 }
 
-// ---- split-bf16 ("bf16x3") dense layer ------------------------------------------------
-// An f32 value v is carried as hi + lo with hi = bf16(v), lo = bf16(v - hi) (16 mantissa
-// bits), and a product W x as  W_lo x_hi + W_hi x_lo + W_hi x_hi  on the bf16 matrix core
-// with f32 accumulation: 6 x v_mfma_f32_32x32x16_bf16 (192 cycles) per 32x32 layer
-// instead of 16 x v_mfma_f32_32x32x2_f32 (1024 cycles); the dropped lo*lo term is 2^-16
-// relative.  Same accumulator-as-operand chaining as the f32 path: registers 8s..8s+7 of
-// the previous layer's accumulator are the 8 k-elements of k-step s (weights pre-permuted).
+// ---- split 16-bit ("bf16x3" / "f16x3") dense layers -------------------------------------
+// An f32 value v is carried as hi + lo, two 16-bit floats, and a product W x as
+// W_lo x_hi + W_hi x_lo + W_hi x_hi  on the 16-bit matrix core with f32 accumulation:
+// 6 x v_mfma_f32_32x32x16_{bf16,f16} (192 cycles) per 32x32 layer instead of
+// 16 x v_mfma_f32_32x32x2_f32 (1024 cycles).  Same accumulator-as-operand chaining as the f32
+// path: registers 8s..8s+7 of the previous layer's accumulator are the 8 k-elements of k-step s
+// (weights pre-permuted).
+//   P = 1, split-bf16: hi = bf16(v), lo = bf16(v - hi): 16 mantissa bits, f32's exponent range; the
+//          dropped lo*lo term is 2^-16 relative.  relu + split costs ~4 VALU instructions per value.
+//   P = 2, split-f16:  hi, lo are IEEE halves: 21-22 mantissa bits (dropped term 2^-21) for |v| < 65504
+//          (larger magnitudes saturate; absolute resolution 6e-8 from the half subnormals).  The point
+//          of this form is the VALU: relu + split is TWO instructions per value --
+//              hi2 = v_cvt_pkrtz_f16_f32(a, b)      (round toward zero: hi <= v for v > 0)
+//              hi2 = v_pk_max_f16(hi2, 0)           (relu on the packed halves)
+//              lo  = v_fma_mix{lo,hi}_f16(-hi, 1.0, v) clamp
+//          the mix instruction reads the half straight out of the packed register, subtracts in f32,
+//          rounds to f16 into one half of the destination; its clamp to [0,1] is the relu of lo
+//          (v > 0: 0 <= v - hi < ulp(hi) << 1 is left alone; v <= 0: hi = 0 and v - 0 <= 0 clamps to 0).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-struct Split16 {
-    bf16x8 hi[2], lo[2];
+template <int P> struct MxT;
+template <> struct MxT<1> { typedef bf16x8 v8; };
+template <> struct MxT<2> { typedef f16x8 v8; };
+template <int P> using mx8 = typename MxT<P>::v8;
+
+__device__ __forceinline__ f32x16 mfma_s(const bf16x8 &a, const bf16x8 &b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_s(const f16x8 &a, const f16x8 &b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <int P> struct SplitP {
+    mx8<P> hi[2], lo[2];
 };
+typedef SplitP<1> Split16;
 
-// (v - hi through v_dot2_f32_bf16 saves the expansion of hi back to f32 -- 6 instead of 8 instructions
-// per pair -- but measured no faster, and its result is not the exact difference: parity failed.)
+// lo = (half)fma((float)hi, m1, v) with m1 = -1 hidden from the optimiser (it would fold the fma to a subtract,
+// which has no mix form) selects v_fma_mixlo_f16 / v_fma_mixhi_f16, and the packed min/max pair becomes their
+// clamp bit -- provided the SLP vectoriser does not pair the two fmas into a v_pk_fma_f32 first: the split-f16
+// kernels are compiled in their own translation unit with -fno-slp-vectorize (decode_f16.hip).
+__device__ __forceinline__ float opaque_minus_one() {
+    float m1 = -1.0f;
+    asm("" : "+s"(m1));
+    return m1;
+}
 template <bool RELU>
-__device__ __forceinline__ Split16 split16(const f32x16 &x) {
-    Split16 r;
+__device__ __forceinline__ void split_pair_f16(float a, float b, float m1, unsigned &hw, unsigned &lw) {
+    f16x2 hp, lo;
+    const f16x2 zero = {(_Float16)0.0f, (_Float16)0.0f}, one = {(_Float16)1.0f, (_Float16)1.0f};
+    if (RELU) {
+        hp = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+        hp = __builtin_elementwise_max(hp, zero);
+    } else {
+        hp = f16x2{(_Float16)a, (_Float16)b};
+    }
+    lo[0] = (_Float16)__builtin_fmaf((float)hp[0], m1, a);
+    lo[1] = (_Float16)__builtin_fmaf((float)hp[1], m1, b);
+    if (RELU) lo = __builtin_elementwise_min(__builtin_elementwise_max(lo, zero), one);
+    hw = __builtin_bit_cast(unsigned, hp);
+    lw = __builtin_bit_cast(unsigned, lo);
+}
+
+// (bf16: v - hi through v_dot2_f32_bf16 saves the expansion of hi back to f32 -- 6 instead of 8 instructions
+// per pair -- but measured no faster, and its result is not the exact difference: parity failed.)
+template <bool RELU, int P = 1>
+__device__ __forceinline__ SplitP<P> split16(const f32x16 &x) {
+    SplitP<P> r;
+    if constexpr (P == 1) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = RELU ? relu1(x[8 * s + j]) : x[8 * s + j];
-            const __bf16 hb = (__bf16)v;
-            r.hi[s][j] = hb;
-            r.lo[s][j] = (__bf16)(v - (float)hb);
+            for (int j = 0; j < 8; ++j) {
+                const float v = RELU ? relu1(x[8 * s + j]) : x[8 * s + j];
+                const __bf16 hb = (__bf16)v;
+                r.hi[s][j] = hb;
+                r.lo[s][j] = (__bf16)(v - (float)hb);
+            }
+        }
+    } else {
+        const float m1 = opaque_minus_one();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 hw, lw;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned h, l;
+                split_pair_f16<RELU>(x[8 * s + 2 * q], x[8 * s + 2 * q + 1], m1, h, l);
+                hw[q] = h; lw[q] = l;
+            }
+            r.hi[s] = __builtin_bit_cast(f16x8, hw);
+            r.lo[s] = __builtin_bit_cast(f16x8, lw);
         }
     }
     return r;
 }
 
 // wl: the layer's LDS image [part: hi, lo][k-step 0,1][lane] x 16 bytes
-__device__ __forceinline__ f32x16 dense32s(f32x16 acc, const float *wl, const Split16 &x, int lane) {
-    const bf16x8 *w = reinterpret_cast<const bf16x8 *>(wl);
+template <int P>
+__device__ __forceinline__ f32x16 dense32s(f32x16 acc, const float *wl, const SplitP<P> &x, int lane) {
+    const mx8<P> *w = reinterpret_cast<const mx8<P> *>(wl);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const bf16x8 wh = w[s * 64 + lane], wo = w[(2 + s) * 64 + lane];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo, x.hi[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, x.lo[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, x.hi[s], acc, 0, 0, 0);
+        const mx8<P> wh = w[s * 64 + lane], wo = w[(2 + s) * 64 + lane];
+        acc = mfma_s(wo, x.hi[s], acc);
+        acc = mfma_s(wh, x.lo[s], acc);
+        acc = mfma_s(wh, x.hi[s], acc);
     }
     return acc;
 }
 
 // one k-step (s = 0 or 1) of dense32s
-__device__ __forceinline__ f32x16 dense32s_half(f32x16 acc, const float *wl, const Split16 &x, int lane, int s) {
-    const bf16x8 *w = reinterpret_cast<const bf16x8 *>(wl);
-    const bf16x8 wh = w[s * 64 + lane], wo = w[(2 + s) * 64 + lane];
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo, x.hi[s], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, x.lo[s], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, x.hi[s], acc, 0, 0, 0);
+template <int P>
+__device__ __forceinline__ f32x16 dense32s_half(f32x16 acc, const float *wl, const SplitP<P> &x, int lane, int s) {
+    const mx8<P> *w = reinterpret_cast<const mx8<P> *>(wl);
+    const mx8<P> wh = w[s * 64 + lane], wo = w[(2 + s) * 64 + lane];
+    acc = mfma_s(wo, x.hi[s], acc);
+    acc = mfma_s(wh, x.lo[s], acc);
+    acc = mfma_s(wh, x.hi[s], acc);
     return acc;
 }
 

@@ -704,6 +704,247 @@ conv3d_gcr_s4_kernel(ConvArgs a) {
     }
 }
 
+// ---- split-f16 'gcr' conv, persistent and double-buffered ("f16x3"; the 64^3 and 32^3 levels) -----------------
+// The split-bf16 kernels above alternate "stage 16 channels" and "run 27 taps" behind workgroup barriers with ONE LDS
+// image: on a 32->32 conv at 64^3 the staging half (global round trips, barriers, the output store) takes 34 of the
+// 62 us and the matrix pipe idles through it.  This kernel removes the alternation:
+//   * channel chunks of EIGHT: an MFMA k-step (K = 16) is a PAIR of taps x 8 input channels (lane half 0 reads tap 2s,
+//     lane half 1 tap 2s+1; 27 taps = 14 k-steps, the 28th half-step has zero weights), so a chunk's image is half the
+//     size -- the hi and lo planes are 16-byte rows (8 halves), conflict-free at the 12-voxel row pitch without padding --
+//     and BOTH the image (2 x 38.4 KB at 8^3) and the chunk's weight fragments (2 x 28 KB) are double-buffered in LDS:
+//     chunk n+1 is normalised, split and written while chunk n's taps run, chunk n+2 is in flight from global memory
+//     into registers; ONE barrier per chunk.
+//   * half of the waves of every SIMD write the next chunk before their taps, the other half between their 7th and 8th
+//     k-step, so the VALU work of the commit issues under the other waves' MFMAs instead of all 16 waves committing at once.
+//   * persistent workgroups: a workgroup walks its tiles of one scene with the same pipeline running across tile
+//     boundaries (no per-tile prologue), keeps the GroupNorm partial sums of its outputs per lane and reduces them once.
+//   * operands are IEEE halves (hi = half(x), lo = half(x - hi): 21-22 mantissa bits; the inputs are GroupNorm outputs
+//     and conv weights, far inside the half range): the error against the exact-f32 kernel is at f32 rounding level.
+// Tile 8 x 8 x TZ, 2*TZ waves (TZ = 8: 16 waves, 64^3-class volumes; TZ = 4: 8 waves for the 32^3 class).
+constexpr int HB_PX = 12;
+constexpr int hb_rows(int TZ) { return (TZ + 2) * 10 * HB_PX; }
+constexpr int hb_nvox(int TZ) { return (TZ + 2) * 100; }
+constexpr int hb_threads(int TZ) { return 128 * TZ; }
+constexpr int hb_iters(int TZ) { return (hb_nvox(TZ) * 2 + hb_threads(TZ) - 1) / hb_threads(TZ); }     // float4 items per thread and chunk
+constexpr int HB_KSTEPS = 14;
+constexpr int HB_WFRAGS = HB_KSTEPS * 2 * 64;                                                             // 16-byte fragments per chunk
+constexpr int hb_witers(int TZ) { return (HB_WFRAGS + hb_threads(TZ) - 1) / hb_threads(TZ); }
+constexpr size_t hb_img_bytes(int TZ) { return (size_t)hb_rows(TZ) * 32; }                               // hi plane + lo plane
+constexpr size_t hb_lds(int TZ) { return 2 * hb_img_bytes(TZ) + 2 * (size_t)HB_WFRAGS * 16 + (size_t)2 * TZ * 64 * sizeof(float); }
+static_assert(hb_lds(8) <= 160 * 1024, "split-f16 conv: LDS budget");
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// weights -> [cin/8][cout/32][k-step 0..13][hi,lo][64 lanes][8 halves]: lane (co, kg), element e = cin 8q + e of tap 2s + kg
+__global__ void conv3d_pack_h_kernel(const float *w, int Cout, int Cin, float *packed, size_t total) {
+    for (size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(f & 63), part = (int)((f >> 6) & 1);
+        size_t r = f >> 7;
+        const int ks = (int)(r % HB_KSTEPS); r /= HB_KSTEPS;
+        const int nco = Cout / 32;
+        const int cob = (int)(r % nco);
+        const int q = (int)(r / nco);
+        const int co = cob * 32 + (l & 31), kg = l >> 5, tap = 2 * ks + kg;
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = tap < 27 ? w[((size_t)co * Cin + 8 * q + e) * 27 + tap] : 0.0f;
+            const _Float16 hb = (_Float16)x;
+            v[e] = part ? (_Float16)(x - (float)hb) : hb;
+        }
+        reinterpret_cast<f16x8 *>(packed)[f] = v;
+    }
+}
+
+struct HbArgs {
+    ConvArgs c;
+    int wgs_per_scene;          // persistent workgroups per scene (= partial-statistics blocks per scene)
+};
+
+template <int TZ>
+__global__ void __launch_bounds__(hb_threads(TZ))
+conv3d_gcr_h_kernel(HbArgs ha) {
+    constexpr int ROWS = hb_rows(TZ), NVOX = hb_nvox(TZ), THREADS = hb_threads(TZ), ITERS = hb_iters(TZ), WITERS = hb_witers(TZ);
+    constexpr int IMG = (int)hb_img_bytes(TZ), WBUF = HB_WFRAGS * 16;
+    extern __shared__ __attribute__((aligned(16))) char hl[];      // [2 images][2 weight buffers][stats scratch]
+    const ConvArgs &a = ha.c;
+    const Src &s = a.s;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, kg = lane >> 5;
+    const int b = blockIdx.x / ha.wgs_per_scene, wg = blockIdx.x - b * ha.wgs_per_scene;
+    const int nsp = a.tiles_x * a.tiles_y * a.tiles_z;
+    const int ntile = (nsp - wg + ha.wgs_per_scene - 1) / ha.wgs_per_scene;      // this workgroup's tiles: wg, wg + wgs, ...
+    const int Cin = s.C1 + s.C2, ncq = Cin / 8;
+    const int co_blk = blockIdx.y, nco_all = a.Cout / 32;
+    const int lx = j & 3, ly = j >> 2;
+    const int wz = wave >> 1, wx = (wave & 1) * 4;
+    const int center = ((wz + 1) * 10 + (ly + 1)) * HB_PX + (lx + wx + 1);
+    char *wbase = hl + 2 * IMG;
+    float *sred = reinterpret_cast<float *>(hl + 2 * IMG + 2 * WBUF);
+    const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
+
+    // staging plan, the same for every tile: item -> (halo voxel, which four of the chunk's eight channels)
+    int pxyz[ITERS], lrow[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int item = threadIdx.x + it * THREADS, v = item >> 1;
+        const int px = v % 10, r2 = v / 10, py = r2 % 10, pz = r2 / 10;
+        pxyz[it] = px | (py << 8) | (pz << 16);
+        lrow[it] = v < NVOX ? ((pz * 10 + py) * HB_PX + px) * 16 + (item & 1) * 8 : -1;
+    }
+    const int c4 = (threadIdx.x & 1) * 4;                           // THREADS is even: the item's channel half is the thread's
+    auto tile_origin = [&](int k, int &x0, int &y0, int &z0) {
+        int t = wg + k * ha.wgs_per_scene;
+        const int tx = t % a.tiles_x; t /= a.tiles_x;
+        const int ty = t % a.tiles_y; t /= a.tiles_y;
+        x0 = tx * 8; y0 = ty * 8; z0 = t * TZ;
+    };
+
+    f32x4 pre[ITERS];
+    f16x8 wpre[WITERS];
+    unsigned pre_in = 0;                                           // which of pre[] lie inside the volume
+    auto fetch = [&](int n) {                                      // chunk n = (tile n / ncq, channels 8 (n % ncq) ..) -> registers
+        const int k = n / ncq, q = n - k * ncq;
+        int x0, y0, z0;
+        tile_origin(k, x0, y0, z0);
+        const int ch = q * 8 + c4;
+        const bool from_low = ch >= s.C1;
+        pre_in = 0;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int gx = x0 + (pxyz[it] & 255) - 1, gy = y0 + ((pxyz[it] >> 8) & 255) - 1, gz = z0 + (pxyz[it] >> 16) - 1;
+            const bool in = lrow[it] >= 0 && gx >= 0 && gx < s.W && gy >= 0 && gy < s.H && gz >= 0 && gz < s.D;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (in) {
+                const float *src = from_low
+                    ? s.low + (size_t)(((b * D2 + (gz >> 1)) * H2 + (gy >> 1)) * W2 + (gx >> 1)) * s.C2 + (ch - s.C1)
+                    : s.skip + (size_t)(((b * s.D + gz) * s.H + gy) * s.W + gx) * s.C1 + ch;
+                val = *reinterpret_cast<const f32x4 *>(src);
+                pre_in |= 1u << it;
+            }
+            pre[it] = val;
+        }
+        const f16x8 *wq = reinterpret_cast<const f16x8 *>(a.wp) + ((size_t)q * nco_all + co_blk) * HB_WFRAGS;
+#pragma unroll
+        for (int it = 0; it < WITERS; ++it) {
+            const int f = threadIdx.x + it * THREADS;
+            if (f < HB_WFRAGS) wpre[it] = wq[f];
+        }
+    };
+    auto commit = [&](int n) {                                     // registers -> LDS buffers n & 1: GroupNorm affine (zero padding AFTER the norm), split
+        const int q = n % ncq;
+        const int ch = q * 8 + c4;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (a.scale_shift) {
+            const float *ss = a.scale_shift + ((size_t)b * Cin + ch) * 2;
+            sc = f32x4{ss[0], ss[2], ss[4], ss[6]}; sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
+        }
+        char *img = hl + (n & 1) * IMG;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (lrow[it] < 0) continue;
+            const bool in = pre_in >> it & 1u;
+            f16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = in ? fmaf(pre[it][e], sc[e], sh[e]) : 0.0f;
+                const _Float16 hb = (_Float16)x;
+                hi[e] = hb;
+                lo[e] = (_Float16)(x - (float)hb);
+            }
+            *reinterpret_cast<f16x4 *>(img + lrow[it]) = hi;
+            *reinterpret_cast<f16x4 *>(img + ROWS * 16 + lrow[it]) = lo;
+        }
+        f16x8 *wl = reinterpret_cast<f16x8 *>(wbase + (n & 1) * WBUF);
+#pragma unroll
+        for (int it = 0; it < WITERS; ++it) {
+            const int f = threadIdx.x + it * THREADS;
+            if (f < HB_WFRAGS) wl[f] = wpre[it];
+        }
+    };
+
+    f32x16 acc, ssum, ssq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; ssum[r] = 0.0f; ssq[r] = 0.0f; }
+
+    struct Ops { f16x8 wh, wl, xh, xl; };
+    auto ops_of = [&](int n, int ks) {
+        Ops o;
+        const f16x8 *wl = reinterpret_cast<const f16x8 *>(wbase + (n & 1) * WBUF);
+        o.wh = wl[ks * 128 + lane]; o.wl = wl[ks * 128 + 64 + lane];
+        const int t0 = 2 * ks, t1 = 2 * ks + 1 < 27 ? 2 * ks + 1 : 13;                 // the 28th half-step: any row, its weights are zero
+        const int r0 = ((t0 / 9 - 1) * 10 + ((t0 / 3) % 3 - 1)) * HB_PX + (t0 % 3 - 1);
+        const int r1 = ((t1 / 9 - 1) * 10 + ((t1 / 3) % 3 - 1)) * HB_PX + (t1 % 3 - 1);
+        const char *xin = hl + (n & 1) * IMG + (center + (kg ? r1 : r0)) * 16;
+        o.xh = *reinterpret_cast<const f16x8 *>(xin);
+        o.xl = *reinterpret_cast<const f16x8 *>(xin + ROWS * 16);
+        return o;
+    };
+    auto taps = [&](int n, int ks0, int ks1) {
+        Ops cur = ops_of(n, ks0);
+#pragma unroll
+        for (int ks = ks0; ks < ks1; ++ks) {
+            Ops nxt = cur;
+            if (ks + 1 < ks1) nxt = ops_of(n, ks + 1);
+            __builtin_amdgcn_sched_barrier(0);                     // keep the requests ahead of the MFMAs
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wl, cur.xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wh, cur.xl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wh, cur.xh, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+    };
+
+    const int N = ntile * ncq;
+    const bool late = (wave >> 2) & 1;                              // waves w and w + 4 share a SIMD: one commits first, one mid-taps
+    if (N > 0) {
+        fetch(0);
+        commit(0);
+        if (N > 1) fetch(1);
+    }
+    __syncthreads();
+    for (int n = 0; n < N; ++n) {
+        if (!late) {
+            if (n + 1 < N) commit(n + 1);
+            if (n + 2 < N) fetch(n + 2);
+            taps(n, 0, HB_KSTEPS);
+        } else {
+            taps(n, 0, HB_KSTEPS / 2);
+            if (n + 1 < N) commit(n + 1);
+            if (n + 2 < N) fetch(n + 2);
+            taps(n, HB_KSTEPS / 2, HB_KSTEPS);
+        }
+        const int k = n / ncq;
+        if (n - k * ncq == ncq - 1) {                                // the tile's last chunk: relu, store, statistics, fresh accumulator
+            int x0, y0, z0;
+            tile_origin(k, x0, y0, z0);
+            const int gx = x0 + lx + wx, gy = y0 + ly, gz = z0 + wz;
+            float *orow = a.out + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.Cout;
+            f32x16 v = acc;
+            if (a.relu) v = relu16(v);
+            store_acc16(orow + co_blk * 32, v, kg);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ssum[r] += v[r]; ssq[r] = fmaf(v[r], v[r], ssq[r]); acc[r] = 0.0f; }
+        }
+        __syncthreads();
+    }
+    if (a.part) {
+        // per-channel (sum, sumsq) of everything this workgroup wrote: lanes -> wave (shuffles) -> workgroup (LDS), fixed order
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float sm = ssum[r], sq = ssq[r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
+            if (j == 0) { sred[wave * 64 + chan_of(r, kg) * 2] = sm; sred[wave * 64 + chan_of(r, kg) * 2 + 1] = sq; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float tsum = 0.0f;
+            for (int w = 0; w < 2 * TZ; ++w) tsum += sred[w * 64 + threadIdx.x];
+            a.part[(((size_t)b * ha.wgs_per_scene + wg) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 maxpool3d_cl_kernel(const float *x, float *out, int D, int H, int W, int C, size_t total) {
     const int D2 = D / 2, H2 = H / 2, W2 = W / 2;
@@ -823,6 +1064,25 @@ static int conv_s_tz(int B, int D, int H, int W, int Cout) {
     const size_t tiles8 = (size_t)(D / 8) * (H / 8) * (W / 8) * B * (Cout / 32);
     if (tiles8 >= 64) return (forced == 8 || forced == 4) ? forced : (tiles8 >= 512 ? 8 : 4);
     return 2;
+}
+
+// split-f16 persistent kernel: 8^3 tiles (16 waves) when they give every CU a workgroup, 8x8x4 tiles (8 waves) when those do;
+// 0 = not covered (the 16^3-class levels stay on the thin-tile split-bf16 kernel or the f32 kernels)
+static int conv_h_tz(int B, int D, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || ((D | H | W) & 7) || Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 31)) return 0;
+    if ((size_t)B * D * H * W >= ((size_t)1 << 31)) return 0;
+    static const int forced = getenv("VTACO_CONV_HTZ") ? atoi(getenv("VTACO_CONV_HTZ")) : 0;     // A/B knob
+    const size_t nco = Cout / 32, t8 = (size_t)(D / 8) * (H / 8) * (W / 8) * B * nco, t4 = 2 * t8;
+    if (forced == 8 || forced == 4) return (forced == 8 ? t8 : t4) >= 64 ? forced : 0;
+    if (t8 >= 256) return 8;
+    if (t4 >= 128) return 4;
+    return 0;
+}
+static int conv_h_wgs_per_scene(int B, int D, int H, int W, int Cout, int tz) {
+    const int nsp = (D / tz) * (H / 8) * (W / 8);
+    int wgs = vt_num_cus() / (B * (Cout / 32));
+    if (wgs < 1) wgs = 1;
+    return wgs < nsp ? wgs : nsp;
 }
 
 template <int NCO, int WAVES>
@@ -995,6 +1255,52 @@ int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, in
     return vt_check(hipGetLastError(), "vt_conv3d_gcr_bf16x3");
 }
 
+size_t vt_conv3d_packed_floats_f16x3(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0 || (Cout & 31) || (Cin & 31)) return 0;
+    return (size_t)(Cin / 8) * (Cout / 32) * HB_WFRAGS * 4;          // 14 k-steps (27 taps + one zero half-step) of 16-byte fragments
+}
+
+int vt_conv3d_pack_f16x3(const float *w, int Cout, int Cin, float *packed, void *stream) {
+    if (!w || !packed) return vt_fail(VT_ERR_INVALID, "vt_conv3d_pack_f16x3: null argument");
+    const size_t frags = vt_conv3d_packed_floats_f16x3(Cout, Cin) / 4;
+    if (!frags) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_pack_f16x3: channel counts must be multiples of 32");
+    size_t g = (frags + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(conv3d_pack_h_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, packed, frags);
+    return vt_check(hipGetLastError(), "vt_conv3d_pack_f16x3");
+}
+
+int vt_conv3d_stat_blocks_f16x3(int B, int D, int H, int W, int Cin, int Cout) {
+    const int tz = conv_h_tz(B, D, H, W, Cin, Cout);
+    return tz ? conv_h_wgs_per_scene(B, D, H, W, Cout, tz) : 0;
+}
+
+int vt_conv3d_gcr_f16x3(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                        const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
+                        float *out_part, void *stream) {
+    HbArgs ha;
+    ConvArgs &a = ha.c;
+    a.s = Src{skip, low, C1, low ? C2 : 0, D, H, W};
+    if (!src_ok(a.s, B) || !packed_w_f16x3 || !out) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr_f16x3: bad argument");
+    const int tz = conv_h_tz(B, D, H, W, a.s.C1 + a.s.C2, Cout);
+    if (!tz) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr_f16x3: shape not covered (see vt_conv3d_stat_blocks_f16x3); use vt_conv3d_gcr[_bf16x3]");
+    a.scale_shift = scale_shift; a.wp = packed_w_f16x3; a.out = out; a.part = out_part; a.Cout = Cout; a.relu = relu;
+    a.TX = a.TY = 8; a.TZ = tz;
+    a.tiles_x = W / 8; a.tiles_y = H / 8; a.tiles_z = D / tz;
+    ha.wgs_per_scene = conv_h_wgs_per_scene(B, D, H, W, Cout, tz);
+    const dim3 grid((unsigned)(ha.wgs_per_scene * B), (unsigned)(Cout / 32));
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_h_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(8));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_h_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(4));
+        if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3: hipFuncSetAttribute");
+        attr = true;
+    }
+    if (tz == 8) hipLaunchKernelGGL(conv3d_gcr_h_kernel<8>, grid, dim3(hb_threads(8)), hb_lds(8), (hipStream_t)stream, ha);
+    else hipLaunchKernelGGL(conv3d_gcr_h_kernel<4>, grid, dim3(hb_threads(4)), hb_lds(4), (hipStream_t)stream, ha);
+    return vt_check(hipGetLastError(), "vt_conv3d_gcr_f16x3");
+}
+
 int vt_maxpool3d_cl(const float *x, int B, int D, int H, int W, int C, float *out, void *stream) {
     if (!x || !out || B <= 0 || C <= 0 || D < 2 || H < 2 || W < 2) return vt_fail(VT_ERR_INVALID, "vt_maxpool3d_cl: bad argument");
     const size_t total = (size_t)B * (D / 2) * (H / 2) * (W / 2) * C;
@@ -1053,14 +1359,18 @@ int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char 
         if (a.C + C2 != c.cin) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: channel mismatch between levels");
         o.C = c.cout;
         o.x = ws.take((size_t)B * Ri * Ri * Ri * c.cout);
-        const bool split = c.packed_bf16x3 && conv_s_eligible(B, Ri, Ri, Ri, c.cin, c.cout);
-        o.nblk = split ? vt_conv3d_stat_blocks_bf16x3(B, Ri, Ri, Ri, c.cin, c.cout) : vt_conv3d_stat_blocks(B, Ri, Ri, Ri, c.cin, c.cout);
+        const bool half = c.packed_f16x3 && conv_h_tz(B, Ri, Ri, Ri, c.cin, c.cout) != 0;
+        const bool split = !half && c.packed_bf16x3 && conv_s_eligible(B, Ri, Ri, Ri, c.cin, c.cout);
+        o.nblk = half ? vt_conv3d_stat_blocks_f16x3(B, Ri, Ri, Ri, c.cin, c.cout)
+                      : split ? vt_conv3d_stat_blocks_bf16x3(B, Ri, Ri, Ri, c.cin, c.cout) : vt_conv3d_stat_blocks(B, Ri, Ri, Ri, c.cin, c.cout);
         o.part = ws.take((size_t)B * o.nblk * c.cout * 2);
         if (plan) return 0;
         const int groups = (c.cin >= p->groups) ? p->groups : 1;
         int rc = vt_gn_scale_shift(a.part, a.nblk, a.C, low ? low->part : nullptr, low ? low->nblk : 0, C2, B,
                                    (int64_t)Ri * Ri * Ri, groups, c.gn_w, c.gn_b, p->eps, ss, st);
         if (rc) return rc;
+        if (half)
+            return vt_conv3d_gcr_f16x3(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.cout, 1, o.x, o.part, st);
         if (split)
             return vt_conv3d_gcr_bf16x3(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed_bf16x3, c.cout, 1, o.x, o.part, st);
         return vt_conv3d_gcr(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed, c.cout, 1, o.x, o.part, st);

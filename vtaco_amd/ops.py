@@ -49,12 +49,13 @@ def blob_floats(hidden=32, c_dim=32, n_blocks=5):
     return n // 4
 
 
-PRECISIONS = ("f32", "bf16x3")
+PRECISIONS = ("f32", "bf16x3", "f16x3")
+SPLIT_PRECISIONS = ("bf16x3", "f16x3")        # dense layers on the 16-bit matrix core with hi + lo operands
 
 
 def pack_decoder(fc_p_w, fc_p_b, fc_c, blocks, fc_out, fc_out2=None, out=None, transposed=False, precision="f32"):
     """Repack decoder parameters into the MFMA-fragment blob (vt_decoder_pack; with
-    ``precision="bf16x3"`` the split-bf16 blob of vt_decoder_pack_bf16x3), or with
+    ``precision="bf16x3"`` / ``"f16x3"`` the split blob of vt_decoder_pack_bf16x3 / _f16x3), or with
     ``transposed=True`` into the transposed-weight blob of the backward (vt_decoder_pack_t).
 
     fc_c: list of (weight, bias); blocks: list of (fc0_w, fc0_b, fc1_w, fc1_b);
@@ -100,8 +101,9 @@ def pack_decoder(fc_p_w, fc_p_b, fc_c, blocks, fc_out, fc_out2=None, out=None, t
     n = blob_floats(hidden, c_dim, nb)
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=fc_p_w.device)
-    if precision == "bf16x3":
-        check(lib.vt_decoder_pack_bf16x3(ctypes.byref(prm), dev_ptr(out, "blob"), n * 4, stream_ptr()), "vt_decoder_pack_bf16x3")
+    if precision in SPLIT_PRECISIONS:
+        name = "vt_decoder_pack_" + precision
+        check(getattr(lib, name)(ctypes.byref(prm), dev_ptr(out, "blob"), n * 4, stream_ptr()), name)
     else:
         check(lib.vt_decoder_pack(ctypes.byref(prm), dev_ptr(out, "blob"), n * 4, stream_ptr()), "vt_decoder_pack")
     return out
@@ -148,8 +150,8 @@ def _cl_storage(grid):
 
 def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want_contact=False, out=None, save=None,
                precision="f32"):
-    """Fused trilinear gather + conditioned MLP (vt_decode_fwd; ``precision="bf16x3"``:
-    vt_decode_fwd_bf16x3 with a blob packed for it).
+    """Fused trilinear gather + conditioned MLP (vt_decode_fwd; ``precision="bf16x3"`` / ``"f16x3"``:
+    vt_decode_fwd_bf16x3 / vt_decode_fwd_f16x3 with a blob packed for it).
 
     grid  [B,C,R,R,R] (any layout; converted to channels-last if needed)
     pts   [B,N,3] or None with lattice=(nx, box, first, count)
@@ -182,12 +184,13 @@ def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want
     if N == 0:                                   # empty query set: nothing to launch
         return (out, out2) if want_contact else out
     keep_for_graph(blob, keep)
-    if precision == "bf16x3":
+    if precision in SPLIT_PRECISIONS:
         if save is not None:
             raise VtError("decode_fwd: the training forward (save) is exact-f32 only")
-        check(lib.vt_decode_fwd_bf16x3(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first,
-                                       dev_ptr(c_img, "c_img"), None, None, 0, dev_ptr(blob, "blob"), float(padding),
-                                       dev_ptr(out, "out"), dev_ptr(out2, "out2"), stream_ptr()), "vt_decode_fwd_bf16x3")
+        name = "vt_decode_fwd_" + precision
+        check(getattr(lib, name)(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first,
+                                 dev_ptr(c_img, "c_img"), None, None, 0, dev_ptr(blob, "blob"), float(padding),
+                                 dev_ptr(out, "out"), dev_ptr(out2, "out2"), stream_ptr()), name)
     elif precision == "f32":
         check(lib.vt_decode_fwd(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first,
                                 dev_ptr(c_img, "c_img"), dev_ptr(blob, "blob"), float(padding),
@@ -958,11 +961,11 @@ def decode_fwd_ids(grid, blob, ids, feats, pts=None, lattice=None, padding=0.1, 
         nx, box, first, N = lattice
     if out is None:
         out = torch.empty((B, N), dtype=torch.float32, device=grid.device)
-    if precision == "bf16x3":
-        check(_lib.load().vt_decode_fwd_bf16x3(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first, None,
-                                               dev_ptr(_c(ids), "ids", U8), dev_ptr(feats, "feats"), feats.shape[0],
-                                               dev_ptr(blob, "blob"), float(padding), dev_ptr(out, "out"), None, stream_ptr()),
-              "vt_decode_fwd_bf16x3")
+    if precision in SPLIT_PRECISIONS:
+        name = "vt_decode_fwd_" + precision
+        check(getattr(_lib.load(), name)(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first, None,
+                                         dev_ptr(_c(ids), "ids", U8), dev_ptr(feats, "feats"), feats.shape[0],
+                                         dev_ptr(blob, "blob"), float(padding), dev_ptr(out, "out"), None, stream_ptr()), name)
         return out
     check(_lib.load().vt_decode_fwd_ids(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first, dev_ptr(_c(ids), "ids", U8),
                                         dev_ptr(feats, "feats"), feats.shape[0], dev_ptr(blob, "blob"), float(padding),
