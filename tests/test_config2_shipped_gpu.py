@@ -31,7 +31,7 @@ def _flush_report():
 
 
 @pytest.mark.parametrize("tag", ["u16", "u32"])
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
 def test_hip_unet3d_against_reference_golden(tag, precision):
     """A reference-made UNet3D golden that the HIP network (not the MIOpen host path) answers."""
     z = c2.fixture()
@@ -65,7 +65,7 @@ def shipped():
     return {"z": z, "enc": enc.to(DEV), "dec": dec.to(DEV), "cloud": cloud, "dsd": dsd, "grid_orc": grid_orc, "orc": orc, "oracle_vs_fixture": o_err}
 
 
-@pytest.mark.parametrize("enc_precision,dec_precision", [("f32", "f32"), ("bf16x3", "f32"), ("bf16x3", "bf16x3"), ("bf16x3", "f16x3")])
+@pytest.mark.parametrize("enc_precision,dec_precision", [("f32", "f32"), ("bf16x3", "f32"), ("bf16x3", "bf16x3"), ("f16x3", "f32"), ("f16x3", "f16x3")])
 def test_config2_end_to_end_at_the_shipped_shape(shipped, enc_precision, dec_precision):
     s, z, orc = shipped, shipped["z"], shipped["orc"]
     enc, dec = s["enc"], s["dec"]

@@ -82,6 +82,36 @@ def test_split_bf16_conv_layers_match_f32_kernel():
         assert float((gp.sum(1) - rp.sum(1)).abs().max()) <= 1e-3 * float(rp.sum(1).abs().max())
 
 
+def test_split_f16_conv_layers_match_f32_kernel():
+    """vt_conv3d_gcr_f16x3 (persistent, double-buffered, tap-pair k-steps) against vt_conv3d_gcr on the shapes it covers:
+    8^3 tiles at 64^3 (two tiles per workgroup), 8x8x4 tiles at 32^3, the virtual concat, two cout blocks, a batch of two
+    scenes (workgroups per scene) -- the error must sit at f32 rounding level, far below the split-bf16 kernel's."""
+    from vtaco_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(12)
+    for B, R, C1, C2, Cout in ((1, 64, 32, 0, 32), (1, 64, 32, 64, 32), (1, 64, 32, 0, 64), (1, 32, 32, 0, 64), (1, 32, 64, 128, 64),
+                               (2, 32, 64, 0, 64), (2, 64, 32, 0, 32)):
+        x = (torch.randn(B, R, R, R, C1, generator=g) * (torch.rand(B, R, R, R, 1, generator=g) < 0.3)).to(DEV)
+        low = torch.randn(B, R // 2, R // 2, R // 2, C2, generator=g).to(DEV) if C2 else None
+        w = (torch.randn(Cout, C1 + C2, 3, 3, 3, generator=g) * 0.05).to(DEV)
+        gamma = (1 + 0.2 * torch.randn(C1 + C2, generator=g)).to(DEV)
+        beta = (0.2 * torch.randn(C1 + C2, generator=g)).to(DEV)
+        xs = ops.channel_stats(x)
+        ls = ops.channel_stats(low) if C2 else None
+        pf, ph, pb = ops.conv3d_pack(w), ops.conv3d_pack(w, precision="f16x3"), ops.conv3d_pack(w, precision="bf16x3")
+        ref, (rp, rn) = ops.gn_conv3d_relu(x, xs, low, ls, gamma, beta, 8, pf, Cout)
+        got, (gp, gn) = ops.gn_conv3d_relu(x, xs, low, ls, gamma, beta, 8, pf, Cout, packed_w_f16x3=ph)
+        bf, _ = ops.gn_conv3d_relu(x, xs, low, ls, gamma, beta, 8, pf, Cout, packed_w_bf16x3=pb)
+        assert gn == lib.vt_conv3d_stat_blocks_f16x3(B, R, R, R, C1 + C2, Cout) and gn > 0
+        scale = max(1.0, float(ref.abs().max()))
+        err, err_bf = float((got - ref).abs().max()), float((bf - ref).abs().max())
+        # both kernels accumulate K = 27 (C1 + C2) products in f32 in different orders: their mutual distance grows like sqrt(K)
+        # times f32 rounding; the split-f16 operands add nothing visible on top, the split-bf16 operands do (2^-16 per product)
+        K = 27 * (C1 + C2)
+        assert 0.0 < err <= 1.5e-7 * K ** 0.5 * scale and err < err_bf, (B, R, C1, C2, Cout, err, err_bf, scale)
+        assert float((gp.sum(1) - rp.sum(1)).abs().max()) <= 1e-3 * float(rp.sum(1).abs().max())
+
+
 def test_hip_unet3d_at_64_split_bf16_vs_f32_and_oracle():
     from oracle import vtaco_oracle as orc
     net = _unet(32, 3, 64)
@@ -92,15 +122,16 @@ def test_hip_unet3d_at_64_split_bf16_vs_f32_and_oracle():
     x_cl = x.to(DEV).permute(0, 2, 3, 4, 1).contiguous()
     outs = {}
     with torch.no_grad():
-        for prec in ("f32", "bf16x3"):
+        for prec in ("f32", "bf16x3", "f16x3"):
             net.precision = prec
             outs[prec] = net.forward_channels_last(x_cl)
             assert torch.equal(outs[prec], net.forward_channels_last_layers(x_cl))
     scale = max(1.0, float(ref.abs().max()))
     e32 = float((outs["f32"].permute(0, 4, 1, 2, 3).cpu() - ref).abs().max())
     es = float((outs["bf16x3"].permute(0, 4, 1, 2, 3).cpu() - ref).abs().max())
-    assert e32 <= 1e-4 * scale and es <= 1e-4 * scale, (e32, es, scale)
-    assert not torch.equal(outs["f32"], outs["bf16x3"])
+    eh = float((outs["f16x3"].permute(0, 4, 1, 2, 3).cpu() - ref).abs().max())
+    assert e32 <= 1e-4 * scale and es <= 1e-4 * scale and eh <= 1e-4 * scale, (e32, es, eh, scale)
+    assert not torch.equal(outs["f32"], outs["bf16x3"]) and not torch.equal(outs["bf16x3"], outs["f16x3"])
 
 
 def _rel(a, b):
@@ -219,12 +250,14 @@ def test_split_unet3d_keeps_the_logit_bar_on_the_bench_scene():
     model, pc = sc["model"], sc["cloud"].to(DEV)
     outs = {}
     with torch.no_grad():
-        for prec in ("f32", "bf16x3"):
+        for prec in ("f32", "bf16x3", "f16x3"):
             model.encoder.unet3d.precision = prec
             grid = model.encode_inputs(pc)["grid"]
             outs[prec] = (grid.clone(), model.decoder.decode_lattice(grid, 128, precision="f32").clone())
-    model.encoder.unet3d.precision = "bf16x3"
-    gerr = float((outs["f32"][0] - outs["bf16x3"][0]).abs().max())
-    lerr = float((outs["f32"][1] - outs["bf16x3"][1]).abs().max())
-    assert 0.0 < lerr <= 1e-4, (gerr, lerr)
-    assert gerr <= 1e-4 * max(1.0, float(outs["f32"][0].abs().max()))
+    model.encoder.unet3d.precision = "f16x3"
+    for prec in ("bf16x3", "f16x3"):
+        gerr = float((outs["f32"][0] - outs[prec][0]).abs().max())
+        lerr = float((outs["f32"][1] - outs[prec][1]).abs().max())
+        print(prec, "grid drift", gerr, "logit drift", lerr)
+        assert 0.0 < lerr <= 1e-4, (prec, gerr, lerr)
+        assert gerr <= 1e-4 * max(1.0, float(outs["f32"][0].abs().max()))

@@ -207,14 +207,28 @@ __device__ __forceinline__ void conv_taps(f32x16 (&acc)[NCO], const float *tile,
     }
 }
 
+// Sum of x over each 32-lane half of the wave, valid in the half's LAST lane (31 / 63): four row-shift adds (an inclusive
+// scan inside each row of 16 lanes) and one row broadcast, all DPP modifiers of v_add_f32 -- no LDS traffic.  (The five
+// __shfl_xor steps this replaces compile to ds_bpermute: 160 of them per output tile and wave were ~15 000 cycles, more
+// than the tile's 27 taps -- in-kernel stamps, tools/diag_conv.py.)
+__device__ __forceinline__ float half_wave_sum(float x) {
+#define VT_DPP_ADD(CTRL, ROWMASK) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWMASK, 0xF, true))
+    VT_DPP_ADD(0x111, 0xF);     // row_shr:1
+    VT_DPP_ADD(0x112, 0xF);     // row_shr:2
+    VT_DPP_ADD(0x114, 0xF);     // row_shr:4
+    VT_DPP_ADD(0x118, 0xF);     // row_shr:8  -> lane 15 of every row holds the row's sum
+    VT_DPP_ADD(0x142, 0xA);     // row_bcast:15 into rows 1 and 3 -> lanes 31 and 63 hold their half's sum
+#undef VT_DPP_ADD
+    return x;
+}
+
 // per-channel (sum, sumsq) over the wave's 32 voxels of one 32-channel block -> sred[chan][2]
 __device__ __forceinline__ void wave_stats(const f32x16 &v, bool valid, int j, int kk, float *sred) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        float sm = valid ? v[r] : 0.0f, sq = sm * sm;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
-        if (j == 0) { sred[chan_of(r, kk) * 2] = sm; sred[chan_of(r, kk) * 2 + 1] = sq; }
+        const float x = valid ? v[r] : 0.0f;
+        const float sm = half_wave_sum(x), sq = half_wave_sum(x * x);
+        if (j == 31) { sred[chan_of(r, kk) * 2] = sm; sred[chan_of(r, kk) * 2 + 1] = sq; }
     }
 }
 
@@ -730,7 +744,8 @@ constexpr int HB_KSTEPS = 14;
 constexpr int HB_WFRAGS = HB_KSTEPS * 2 * 64;                                                             // 16-byte fragments per chunk
 constexpr int hb_witers(int TZ) { return (HB_WFRAGS + hb_threads(TZ) - 1) / hb_threads(TZ); }
 constexpr size_t hb_img_bytes(int TZ) { return (size_t)hb_rows(TZ) * 32; }                               // hi plane + lo plane
-constexpr size_t hb_lds(int TZ) { return 2 * hb_img_bytes(TZ) + 2 * (size_t)HB_WFRAGS * 16 + (size_t)2 * TZ * 64 * sizeof(float); }
+constexpr int HB_MAX_CIN = 512;                                                                          // scale / shift table in LDS
+constexpr size_t hb_lds(int TZ) { return 2 * hb_img_bytes(TZ) + 2 * (size_t)HB_WFRAGS * 16 + (size_t)2 * TZ * 64 * sizeof(float) + HB_MAX_CIN * 2 * sizeof(float); }
 static_assert(hb_lds(8) <= 160 * 1024, "split-f16 conv: LDS budget");
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
@@ -755,6 +770,14 @@ __global__ void conv3d_pack_h_kernel(const float *w, int Cout, int Cin, float *p
     }
 }
 
+#ifdef VT_DIAG_HB
+// diagnostic build only (tools/diag_conv.py): per-wave shader-clock sums of the phases of conv3d_gcr_h_kernel
+__device__ unsigned long long vt_diag_hb_buf[8192 * 8];
+#define HB_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                         dg_sum[i] += t_ - dg_last; dg_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define HB_STAMP(i) do { } while (0)
+#endif
 struct HbArgs {
     ConvArgs c;
     int wgs_per_scene;          // persistent workgroups per scene (= partial-statistics blocks per scene)
@@ -763,7 +786,7 @@ struct HbArgs {
 template <int TZ>
 __global__ void __launch_bounds__(hb_threads(TZ))
 conv3d_gcr_h_kernel(HbArgs ha) {
-    constexpr int ROWS = hb_rows(TZ), NVOX = hb_nvox(TZ), THREADS = hb_threads(TZ), ITERS = hb_iters(TZ), WITERS = hb_witers(TZ);
+    constexpr int ROWS = hb_rows(TZ), NVOX = hb_nvox(TZ), THREADS = hb_threads(TZ), ITERS = hb_iters(TZ);
     constexpr int IMG = (int)hb_img_bytes(TZ), WBUF = HB_WFRAGS * 16;
     extern __shared__ __attribute__((aligned(16))) char hl[];      // [2 images][2 weight buffers][stats scratch]
     const ConvArgs &a = ha.c;
@@ -780,7 +803,11 @@ conv3d_gcr_h_kernel(HbArgs ha) {
     const int center = ((wz + 1) * 10 + (ly + 1)) * HB_PX + (lx + wx + 1);
     char *wbase = hl + 2 * IMG;
     float *sred = reinterpret_cast<float *>(hl + 2 * IMG + 2 * WBUF);
+    float *ssl = sred + 2 * TZ * 64;                                // [Cin][2] GroupNorm scale / shift of this scene (read by every commit)
     const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
+    for (int i = threadIdx.x; i < 2 * Cin; i += THREADS)
+        ssl[i] = a.scale_shift ? a.scale_shift[(size_t)b * Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f);
+    __syncthreads();
 
     // staging plan, the same for every tile: item -> (halo voxel, which four of the chunk's eight channels)
     int pxyz[ITERS], lrow[ITERS];
@@ -800,12 +827,26 @@ conv3d_gcr_h_kernel(HbArgs ha) {
     };
 
     f32x4 pre[ITERS];
-    f16x8 wpre[WITERS];
     unsigned pre_in = 0;                                           // which of pre[] lie inside the volume
-    auto fetch = [&](int n) {                                      // chunk n = (tile n / ncq, channels 8 (n % ncq) ..) -> registers
-        const int k = n / ncq, q = n - k * ncq;
-        int x0, y0, z0;
-        tile_origin(k, x0, y0, z0);
+    // chunk n's weight fragments: global -> LDS buffer n & 1 by LDS-DMA (fragment order = LDS order: 28 pieces of 1 KiB,
+    // no registers, no VALU); counted in vmcnt in issue order with the other vector-memory operations of the wave
+    int d_q = 0;
+    auto dma_w = [&](int n) {
+        const int q = d_q;
+        if (++d_q == ncq) d_q = 0;
+        const f16x8 *wq = reinterpret_cast<const f16x8 *>(a.wp) + ((size_t)q * nco_all + co_blk) * HB_WFRAGS;
+        char *dst = wbase + (n & 1) * WBUF;
+        for (int p = wave; p < HB_WFRAGS / 64; p += 2 * TZ)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wq + p * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)(dst + p * 1024), 16, 0, 0);
+    };
+    // chunks are fetched, committed and consumed in order n = 0, 1, 2, ...: running (tile, channel chunk) counters instead of
+    // divisions per call
+    int f_q = 0, f_x0, f_y0, f_z0, f_k = 0;
+    tile_origin(0, f_x0, f_y0, f_z0);
+    auto fetch = [&](int) {                                        // the next chunk = (tile f_k, channels 8 f_q ..) -> registers
+        const int q = f_q, x0 = f_x0, y0 = f_y0, z0 = f_z0;
+        if (++f_q == ncq) { f_q = 0; ++f_k; tile_origin(f_k, f_x0, f_y0, f_z0); }
         const int ch = q * 8 + c4;
         const bool from_low = ch >= s.C1;
         pre_in = 0;
@@ -813,31 +854,22 @@ conv3d_gcr_h_kernel(HbArgs ha) {
         for (int it = 0; it < ITERS; ++it) {
             const int gx = x0 + (pxyz[it] & 255) - 1, gy = y0 + ((pxyz[it] >> 8) & 255) - 1, gz = z0 + (pxyz[it] >> 16) - 1;
             const bool in = lrow[it] >= 0 && gx >= 0 && gx < s.W && gy >= 0 && gy < s.H && gz >= 0 && gz < s.D;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (in) {
-                const float *src = from_low
-                    ? s.low + (size_t)(((b * D2 + (gz >> 1)) * H2 + (gy >> 1)) * W2 + (gx >> 1)) * s.C2 + (ch - s.C1)
-                    : s.skip + (size_t)(((b * s.D + gz) * s.H + gy) * s.W + gx) * s.C1 + ch;
-                val = *reinterpret_cast<const f32x4 *>(src);
-                pre_in |= 1u << it;
-            }
-            pre[it] = val;
-        }
-        const f16x8 *wq = reinterpret_cast<const f16x8 *>(a.wp) + ((size_t)q * nco_all + co_blk) * HB_WFRAGS;
-#pragma unroll
-        for (int it = 0; it < WITERS; ++it) {
-            const int f = threadIdx.x + it * THREADS;
-            if (f < HB_WFRAGS) wpre[it] = wq[f];
+            // every wave issues exactly ITERS loads per chunk (the counted vmcnt wait relies on it): out-of-volume items
+            // read a clamped, valid address and are zeroed at the commit
+            const int cx = min(max(gx, 0), s.W - 1), cy = min(max(gy, 0), s.H - 1), cz = min(max(gz, 0), s.D - 1);
+            const float *src = from_low
+                ? s.low + (size_t)(((b * D2 + (cz >> 1)) * H2 + (cy >> 1)) * W2 + (cx >> 1)) * s.C2 + (ch - s.C1)
+                : s.skip + (size_t)(((b * s.D + cz) * s.H + cy) * s.W + cx) * s.C1 + ch;
+            pre[it] = *reinterpret_cast<const f32x4 *>(src);
+            if (in) pre_in |= 1u << it;
         }
     };
+    int c_q = 0;
     auto commit = [&](int n) {                                     // registers -> LDS buffers n & 1: GroupNorm affine (zero padding AFTER the norm), split
-        const int q = n % ncq;
-        const int ch = q * 8 + c4;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (a.scale_shift) {
-            const float *ss = a.scale_shift + ((size_t)b * Cin + ch) * 2;
-            sc = f32x4{ss[0], ss[2], ss[4], ss[6]}; sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
-        }
+        const int ch = c_q * 8 + c4;
+        if (++c_q == ncq) c_q = 0;
+        const float *ss = ssl + ch * 2;
+        const f32x4 sc = {ss[0], ss[2], ss[4], ss[6]}, sh = {ss[1], ss[3], ss[5], ss[7]};
         char *img = hl + (n & 1) * IMG;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
@@ -854,17 +886,12 @@ conv3d_gcr_h_kernel(HbArgs ha) {
             *reinterpret_cast<f16x4 *>(img + lrow[it]) = hi;
             *reinterpret_cast<f16x4 *>(img + ROWS * 16 + lrow[it]) = lo;
         }
-        f16x8 *wl = reinterpret_cast<f16x8 *>(wbase + (n & 1) * WBUF);
-#pragma unroll
-        for (int it = 0; it < WITERS; ++it) {
-            const int f = threadIdx.x + it * THREADS;
-            if (f < HB_WFRAGS) wl[f] = wpre[it];
-        }
     };
 
-    f32x16 acc, ssum, ssq;
+    f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; ssum[r] = 0.0f; ssq[r] = 0.0f; }
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    sred[wave * 64 + lane] = 0.0f;                                 // the wave's running (sum, sumsq) per output channel (only this wave touches it)
 
     struct Ops { f16x8 wh, wl, xh, xl; };
     auto ops_of = [&](int n, int ks) {
@@ -895,48 +922,84 @@ conv3d_gcr_h_kernel(HbArgs ha) {
     };
 
     const int N = ntile * ncq;
+    int e_q = 0, e_k = 0;
+#ifdef VT_HB_NOSKEW
+    const bool late = false;
+#else
     const bool late = (wave >> 2) & 1;                              // waves w and w + 4 share a SIMD: one commits first, one mid-taps
+#endif
+    // s_waitcnt vmcnt(ITERS) alone: everything but the wave's ITERS youngest vector-memory operations (the register fetch of
+    // chunk n + 2, issued after the DMA of chunk n + 1) has landed
+    constexpr int WAIT_DMA = 0x0F70 | ITERS;
+#ifdef VT_DIAG_HB
+    unsigned long long dg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dg_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long dg_first = dg_last;
+#endif
     if (N > 0) {
+        dma_w(0);
         fetch(0);
         commit(0);
         if (N > 1) fetch(1);
     }
+    if (N > 1) __builtin_amdgcn_s_waitcnt(WAIT_DMA); else __builtin_amdgcn_s_waitcnt(0x0F70);   // chunk 0's weights are in LDS; chunk 1's fetch stays in flight
     __syncthreads();
+    HB_STAMP(0);                                                    // prologue
     for (int n = 0; n < N; ++n) {
         if (!late) {
-            if (n + 1 < N) commit(n + 1);
+            if (n + 1 < N) { commit(n + 1); dma_w(n + 1); }
+            HB_STAMP(1);                                            // commit + DMA issue
             if (n + 2 < N) fetch(n + 2);
+            HB_STAMP(2);                                            // fetch issue
             taps(n, 0, HB_KSTEPS);
+            HB_STAMP(3);                                            // taps
         } else {
             taps(n, 0, HB_KSTEPS / 2);
-            if (n + 1 < N) commit(n + 1);
+            HB_STAMP(3);
+            if (n + 1 < N) { commit(n + 1); dma_w(n + 1); }
+            HB_STAMP(1);
             if (n + 2 < N) fetch(n + 2);
+            HB_STAMP(2);
             taps(n, HB_KSTEPS / 2, HB_KSTEPS);
+            HB_STAMP(3);
         }
-        const int k = n / ncq;
-        if (n - k * ncq == ncq - 1) {                                // the tile's last chunk: relu, store, statistics, fresh accumulator
+        if (++e_q == ncq) {                                          // the tile's last chunk: relu, store, statistics, fresh accumulator
             int x0, y0, z0;
-            tile_origin(k, x0, y0, z0);
+            tile_origin(e_k, x0, y0, z0);
+            e_q = 0; ++e_k;
             const int gx = x0 + lx + wx, gy = y0 + ly, gz = z0 + wz;
             float *orow = a.out + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.Cout;
             f32x16 v = acc;
             if (a.relu) v = relu16(v);
             store_acc16(orow + co_blk * 32, v, kg);
+            HB_STAMP(7);                                            // (diagnostic: relu + store part of the epilogue)
+            if (a.part) {
+                // per-channel (sum, sumsq) over the wave's 32 voxels, added to the wave's running sums in LDS (tile order: fixed)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { ssum[r] += v[r]; ssq[r] = fmaf(v[r], v[r], ssq[r]); acc[r] = 0.0f; }
+                for (int r = 0; r < 16; ++r) {
+                    const float sm = half_wave_sum(v[r]), sq = half_wave_sum(v[r] * v[r]);
+                    if (j == 31) { float *d = sred + wave * 64 + chan_of(r, kg) * 2; d[0] += sm; d[1] += sq; }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         }
+        HB_STAMP(4);                                                // tile epilogue
+        if (n + 2 < N) __builtin_amdgcn_s_waitcnt(WAIT_DMA); else __builtin_amdgcn_s_waitcnt(0x0F70);
+        HB_STAMP(5);                                                // wait for the DMA
         __syncthreads();
+        HB_STAMP(6);                                                // barrier
     }
+#ifdef VT_DIAG_HB
+    if (lane == 0) {
+        unsigned long long *d = vt_diag_hb_buf + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * 2 * TZ + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) d[i] = dg_sum[i];
+        d[0] += dg_sum[7] << 40;                                   // the store part rides in the prologue slot's upper bits
+        d[7] = __builtin_amdgcn_s_memtime() - dg_first;
+    }
+#endif
     if (a.part) {
-        // per-channel (sum, sumsq) of everything this workgroup wrote: lanes -> wave (shuffles) -> workgroup (LDS), fixed order
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float sm = ssum[r], sq = ssq[r];
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
-            if (j == 0) { sred[wave * 64 + chan_of(r, kg) * 2] = sm; sred[wave * 64 + chan_of(r, kg) * 2 + 1] = sq; }
-        }
-        __syncthreads();
         if (threadIdx.x < 64) {
             float tsum = 0.0f;
             for (int w = 0; w < 2 * TZ; ++w) tsum += sred[w * 64 + threadIdx.x];
@@ -1072,10 +1135,12 @@ static int conv_h_tz(int B, int D, int H, int W, int Cin, int Cout) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || ((D | H | W) & 7) || Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 31)) return 0;
     if ((size_t)B * D * H * W >= ((size_t)1 << 31)) return 0;
     static const int forced = getenv("VTACO_CONV_HTZ") ? atoi(getenv("VTACO_CONV_HTZ")) : 0;     // A/B knob
-    const size_t nco = Cout / 32, t8 = (size_t)(D / 8) * (H / 8) * (W / 8) * B * nco, t4 = 2 * t8;
-    if (forced == 8 || forced == 4) return (forced == 8 ? t8 : t4) >= 64 ? forced : 0;
+    const size_t nco = Cout / 32, t8 = (size_t)(D / 8) * (H / 8) * (W / 8) * B * nco, t4 = 2 * t8, t2 = 4 * t8;
+    if (forced == 8 || forced == 4 || forced == 2) return (forced == 8 ? t8 : forced == 4 ? t4 : t2) >= 64 ? forced : 0;
     if (t8 >= 256) return 8;
     if (t4 >= 128) return 4;
+    static const bool thin = getenv("VTACO_CONV_HTHIN") != nullptr;      // A/B knob: 8x8x2 tiles (4 waves) for the 16^3-class levels
+    if (thin && t2 >= 64) return 2;
     return 0;
 }
 static int conv_h_wgs_per_scene(int B, int D, int H, int W, int Cout, int tz) {
@@ -1255,6 +1320,11 @@ int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, in
     return vt_check(hipGetLastError(), "vt_conv3d_gcr_bf16x3");
 }
 
+#ifdef VT_DIAG_HB
+int vt_diag_hb_read(unsigned long long *host, size_t count) {
+    return vt_check(hipMemcpyFromSymbol(host, HIP_SYMBOL(vt_diag_hb_buf), count * sizeof(unsigned long long)), "vt_diag_hb_read");
+}
+#endif
 size_t vt_conv3d_packed_floats_f16x3(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0 || (Cout & 31) || (Cin & 31)) return 0;
     return (size_t)(Cin / 8) * (Cout / 32) * HB_WFRAGS * 4;          // 14 k-steps (27 taps + one zero half-step) of 16-byte fragments
@@ -1293,11 +1363,13 @@ int vt_conv3d_gcr_f16x3(const float *skip, int C1, const float *low, int C2, int
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_h_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(8));
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_h_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(4));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_h_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(2));
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3: hipFuncSetAttribute");
         attr = true;
     }
     if (tz == 8) hipLaunchKernelGGL(conv3d_gcr_h_kernel<8>, grid, dim3(hb_threads(8)), hb_lds(8), (hipStream_t)stream, ha);
-    else hipLaunchKernelGGL(conv3d_gcr_h_kernel<4>, grid, dim3(hb_threads(4)), hb_lds(4), (hipStream_t)stream, ha);
+    else if (tz == 4) hipLaunchKernelGGL(conv3d_gcr_h_kernel<4>, grid, dim3(hb_threads(4)), hb_lds(4), (hipStream_t)stream, ha);
+    else hipLaunchKernelGGL(conv3d_gcr_h_kernel<2>, grid, dim3(hb_threads(2)), hb_lds(2), (hipStream_t)stream, ha);
     return vt_check(hipGetLastError(), "vt_conv3d_gcr_f16x3");
 }
 

@@ -147,10 +147,11 @@ class UNet3D(nn.Module):
         self.testing = testing
         self.layer_order = layer_order
         self._pack_cache = {}
-        # arithmetic of the 3x3x3 convolutions on the HIP inference path: "bf16x3" = split-bf16 operands on the
-        # bf16 matrix core for the large volumes (6.6e-5 abs on the golden grid, 4e-5 on the decoded logits),
-        # "f32" = exact-f32 matrix core everywhere.  Training (host autograd) is unaffected.
-        self.precision = os.environ.get("VTACO_UNET_PRECISION", "bf16x3")
+        # arithmetic of the 3x3x3 convolutions on the HIP inference path: "f16x3" = split-f16 operands in the persistent
+        # double-buffered kernel on the 64^3 / 32^3-class levels (f32-rounding-level error) and split-bf16 thin tiles on
+        # the 16^3-class levels; "bf16x3" = split-bf16 operands on all of those (6.6e-5 abs on the golden grid, 4e-5 on
+        # the decoded logits); "f32" = exact-f32 matrix core everywhere.  Training (host autograd) is unaffected.
+        self.precision = os.environ.get("VTACO_UNET_PRECISION", "f16x3")
         # the differentiable HIP path (forward_channels_last_train) keeps the exact-f32 convs by default: at random
         # init this network's gradients move by ~1 % (L2) under a 1e-6 input perturbation (ReLU / max-pool decisions),
         # and the 2e-5 deviations of the split form flip more of them (~2 %)
@@ -180,9 +181,11 @@ class UNet3D(nn.Module):
 
     def _gcr(self, single, x, x_stats, low=None, low_stats=None):
         gn, conv = single.groupnorm, single.conv
-        split = self._packed(conv, "bf16x3") if self.precision == "bf16x3" else None
+        split = self._packed(conv, "bf16x3") if self.precision in ("bf16x3", "f16x3") else None
+        half = self._packed(conv, "f16x3") if self.precision == "f16x3" else None
         return ops.gn_conv3d_relu(x, x_stats, low, low_stats, gn.weight.detach(), gn.bias.detach(), gn.num_groups,
-                                  self._packed(conv), conv.out_channels, eps=gn.eps, relu=True, packed_w_bf16x3=split)
+                                  self._packed(conv), conv.out_channels, eps=gn.eps, relu=True, packed_w_bf16x3=split,
+                                  packed_w_f16x3=half)
 
     def _hip_params(self):
         """vt_unet3d_params for the current weights (re-packed only when a conv weight changed)."""
@@ -196,10 +199,14 @@ class UNet3D(nn.Module):
             keep.extend(tensors)
             dst.gn_w, dst.gn_b, dst.packed = (t.data_ptr() for t in tensors)
             dst.cin, dst.cout = conv.in_channels, conv.out_channels
-            if self.precision == "bf16x3":
+            if self.precision in ("bf16x3", "f16x3"):
                 split = self._packed(conv, "bf16x3")
                 keep.append(split)
                 dst.packed_bf16x3 = split.data_ptr()
+            if self.precision == "f16x3":
+                half = self._packed(conv, "f16x3")
+                keep.append(half)
+                dst.packed_f16x3 = half.data_ptr()
         prm.n_levels = len(self.encoders)
         first_gn = self.encoders[-1].basic_module.SingleConv1.groupnorm
         prm.groups, prm.eps = first_gn.num_groups, first_gn.eps

@@ -750,19 +750,20 @@ def voxel_scatter_mean_cl_bwd(grad_grid_cl, vi, C):
 
 
 def conv3d_pack(weight, precision="f32"):
-    """Fragment-ordered copy of a [Cout,Cin,3,3,3] conv weight: f32 (vt_conv3d_pack) or split-bf16
-    hi/lo fragments (vt_conv3d_pack_bf16x3); the two blobs have the same size."""
+    """Fragment-ordered copy of a [Cout,Cin,3,3,3] conv weight: f32 (vt_conv3d_pack), split-bf16 hi/lo fragments
+    (vt_conv3d_pack_bf16x3; same size) or split-f16 tap-pair fragments (vt_conv3d_pack_f16x3; its own size)."""
     lib = _lib.load()
     Cout, Cin = weight.shape[0], weight.shape[1]
-    n = lib.vt_conv3d_packed_floats(Cout, Cin)
+    n = lib.vt_conv3d_packed_floats_f16x3(Cout, Cin) if precision == "f16x3" else lib.vt_conv3d_packed_floats(Cout, Cin)
     if n == 0 or tuple(weight.shape[2:]) != (3, 3, 3):
         raise VtError(f"conv3d_pack: unsupported weight shape {tuple(weight.shape)}")
     if precision not in PRECISIONS:
         raise VtError(f"precision must be one of {PRECISIONS} (got {precision!r})")
     w = _c(weight)
     out = torch.empty(n, dtype=torch.float32, device=w.device)
-    if precision == "bf16x3":
-        check(lib.vt_conv3d_pack_bf16x3(dev_ptr(w, "w"), Cout, Cin, dev_ptr(out, "packed"), stream_ptr()), "vt_conv3d_pack_bf16x3")
+    if precision in SPLIT_PRECISIONS:
+        name = "vt_conv3d_pack_" + precision
+        check(getattr(lib, name)(dev_ptr(w, "w"), Cout, Cin, dev_ptr(out, "packed"), stream_ptr()), name)
     else:
         check(lib.vt_conv3d_pack(dev_ptr(w, "w"), Cout, Cin, dev_ptr(out, "packed"), stream_ptr()), "vt_conv3d_pack")
     return out
@@ -788,36 +789,40 @@ def gn_scale_shift(x_stats, low_stats, C1, C2, B, voxels, gamma, beta, groups, e
     return ss
 
 
-def conv3d_gcr(x, low, ss, packed_w, Cout, relu=True, packed_w_bf16x3=None, want_stats=True):
+def conv3d_gcr(x, low, ss, packed_w, Cout, relu=True, packed_w_bf16x3=None, want_stats=True, packed_w_f16x3=None):
     """relu?(conv3x3x3(x_cat * scale + shift)) on channels-last tensors (``ss`` None: no normalisation);
-    returns (out, (part, nblk) or None).  With ``packed_w_bf16x3`` the convolution runs on the bf16 matrix
-    core with split-bf16 operands where that kernel covers the shape."""
+    returns (out, (part, nblk) or None).  With ``packed_w_f16x3`` / ``packed_w_bf16x3`` the convolution runs on the
+    16-bit matrix core with split operands where that kernel covers the shape (f16x3 first)."""
     lib = _lib.load()
     B, D, H, W, C1 = x.shape
     C2 = low.shape[-1] if low is not None else 0
     dev = x.device
     st = stream_ptr()
     out = torch.empty((B, D, H, W, Cout), dtype=torch.float32, device=dev)
-    nblk = lib.vt_conv3d_stat_blocks_bf16x3(B, D, H, W, C1 + C2, Cout) if packed_w_bf16x3 is not None else 0
-    split = nblk != 0
-    if not split:
-        nblk = lib.vt_conv3d_stat_blocks(B, D, H, W, C1 + C2, Cout)
+    fn, name, pw = lib.vt_conv3d_gcr, "vt_conv3d_gcr", packed_w
+    nblk = lib.vt_conv3d_stat_blocks_f16x3(B, D, H, W, C1 + C2, Cout) if packed_w_f16x3 is not None else 0
+    if nblk:
+        fn, name, pw = lib.vt_conv3d_gcr_f16x3, "vt_conv3d_gcr_f16x3", packed_w_f16x3
+    else:
+        nblk = lib.vt_conv3d_stat_blocks_bf16x3(B, D, H, W, C1 + C2, Cout) if packed_w_bf16x3 is not None else 0
+        if nblk:
+            fn, name, pw = lib.vt_conv3d_gcr_bf16x3, "vt_conv3d_gcr_bf16x3", packed_w_bf16x3
+        else:
+            nblk = lib.vt_conv3d_stat_blocks(B, D, H, W, C1 + C2, Cout)
     part = torch.empty((B, nblk, Cout, 2), dtype=torch.float32, device=dev) if want_stats else None
-    fn, name, pw = (lib.vt_conv3d_gcr_bf16x3, "vt_conv3d_gcr_bf16x3", packed_w_bf16x3) if split else \
-                   (lib.vt_conv3d_gcr, "vt_conv3d_gcr", packed_w)
     check(fn(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
              dev_ptr(pw, "packed_w"), Cout, int(relu), dev_ptr(out, "out"), dev_ptr(part, "part"), st), name)
     return out, ((part, nblk) if want_stats else None)
 
 
 def gn_conv3d_relu(x, x_stats, low, low_stats, gamma, beta, groups, packed_w, Cout, eps=1e-5, relu=True,
-                   packed_w_bf16x3=None):
+                   packed_w_bf16x3=None, packed_w_f16x3=None):
     """relu(conv3x3x3(GroupNorm([x | upsample(low)]))) on channels-last tensors; the statistics
     come from the producers' partial sums.  Returns (out, out_stats)."""
     B, D, H, W, C1 = x.shape
     C2 = low.shape[-1] if low is not None else 0
     ss = gn_scale_shift(x_stats, low_stats if low is not None else None, C1, C2, B, D * H * W, gamma, beta, groups, eps, x.device)
-    return conv3d_gcr(x, low, ss, packed_w, Cout, relu, packed_w_bf16x3)
+    return conv3d_gcr(x, low, ss, packed_w, Cout, relu, packed_w_bf16x3, packed_w_f16x3=packed_w_f16x3)
 
 
 def relu_mask(dy, y):
