@@ -412,6 +412,13 @@ int vt_conv3d_stat_blocks_f16x3(int B, int D, int H, int W, int Cin, int Cout);
 int vt_conv3d_gcr_f16x3(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                         const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
                         float *out_part, void *stream);
+/* The same kernel for inputs far below the half range (the data-gradient convolution of the backward: dxn =           */
+/* conv(g, W^T flipped) with g = dy * [y > 0], autograd of unet3d.py:20-72): `in_absmax` is a device scalar holding         */
+/* max |input|; the kernel multiplies the input by the power of two that brings it to ~2^10 before the split and            */
+/* divides the result by it (both exact), so the split keeps ~21 bits relative to the tensor's largest element.             */
+int vt_conv3d_gcr_f16x3_scaled(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                               const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
+                               float *out_part, const float *in_absmax, void *stream);
 size_t vt_unet3d_workspace_bytes(int B, int R, const vt_unet3d_params *params_host);
 int vt_unet3d_fwd(const float *x_cl, int B, int R, const vt_unet3d_params *params_host,
                   void *workspace, size_t workspace_bytes, float *out, void *stream);

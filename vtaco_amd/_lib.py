@@ -141,6 +141,7 @@ SIGNATURES = {
     "vt_conv3d_pack_f16x3": (_I, [_VP, _I, _I, _VP, _VP]),
     "vt_conv3d_stat_blocks_f16x3": (_I, [_I, _I, _I, _I, _I, _I]),
     "vt_conv3d_gcr_f16x3": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),
+    "vt_conv3d_gcr_f16x3_scaled": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP]),
     "vt_conv3d_stat_blocks_bf16x3": (_I, [_I, _I, _I, _I, _I, _I]),
     "vt_conv3d_gcr_bf16x3": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),
     "vt_channel_stats": (_I, [_VP, _I, _I64, _I, _I, _VP, _VP]),

@@ -781,6 +781,9 @@ __device__ unsigned long long vt_diag_hb_buf[8192 * 8];
 struct HbArgs {
     ConvArgs c;
     int wgs_per_scene;          // persistent workgroups per scene (= partial-statistics blocks per scene)
+    const float *in_absmax;     // or null.  Device scalar max |input|: the input is multiplied by the power of two that brings
+                                // it to ~2^10 before the split (and the result divided by it), so that tensors far below the
+                                // half range -- output gradients in the data-gradient convolution -- keep all their bits
 };
 
 template <int TZ>
@@ -805,8 +808,17 @@ conv3d_gcr_h_kernel(HbArgs ha) {
     float *sred = reinterpret_cast<float *>(hl + 2 * IMG + 2 * WBUF);
     float *ssl = sred + 2 * TZ * 64;                                // [Cin][2] GroupNorm scale / shift of this scene (read by every commit)
     const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
+    float pre_scale = 1.0f, post_scale = 1.0f;
+    if (ha.in_absmax) {
+        const float m = *ha.in_absmax;
+        if (m > 0.0f && m < 3.0e38f) {
+            const int e = 10 - ilogbf(m);                               // 2^e * m in [2^10, 2^11)
+            pre_scale = ldexpf(1.0f, e < -100 ? -100 : (e > 100 ? 100 : e));
+            post_scale = 1.0f / pre_scale;                              // exact: a power of two
+        }
+    }
     for (int i = threadIdx.x; i < 2 * Cin; i += THREADS)
-        ssl[i] = a.scale_shift ? a.scale_shift[(size_t)b * Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f);
+        ssl[i] = pre_scale * (a.scale_shift ? a.scale_shift[(size_t)b * Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f));
     __syncthreads();
 
     // staging plan, the same for every tile: item -> (halo voxel, which four of the chunk's eight channels)
@@ -970,6 +982,10 @@ conv3d_gcr_h_kernel(HbArgs ha) {
             const int gx = x0 + lx + wx, gy = y0 + ly, gz = z0 + wz;
             float *orow = a.out + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.Cout;
             f32x16 v = acc;
+            if (ha.in_absmax) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] *= post_scale;
+            }
             if (a.relu) v = relu16(v);
             store_acc16(orow + co_blk * 32, v, kg);
             HB_STAMP(7);                                            // (diagnostic: relu + store part of the epilogue)
@@ -1348,7 +1364,14 @@ int vt_conv3d_stat_blocks_f16x3(int B, int D, int H, int W, int Cin, int Cout) {
 int vt_conv3d_gcr_f16x3(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                         const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
                         float *out_part, void *stream) {
+    return vt_conv3d_gcr_f16x3_scaled(skip, C1, low, C2, B, D, H, W, scale_shift, packed_w_f16x3, Cout, relu, out, out_part, nullptr, stream);
+}
+
+int vt_conv3d_gcr_f16x3_scaled(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                               const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
+                               float *out_part, const float *in_absmax, void *stream) {
     HbArgs ha;
+    ha.in_absmax = in_absmax;
     ConvArgs &a = ha.c;
     a.s = Src{skip, low, C1, low ? C2 : 0, D, H, W};
     if (!src_ok(a.s, B) || !packed_w_f16x3 || !out) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr_f16x3: bad argument");

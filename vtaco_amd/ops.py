@@ -789,7 +789,8 @@ def gn_scale_shift(x_stats, low_stats, C1, C2, B, voxels, gamma, beta, groups, e
     return ss
 
 
-def conv3d_gcr(x, low, ss, packed_w, Cout, relu=True, packed_w_bf16x3=None, want_stats=True, packed_w_f16x3=None):
+def conv3d_gcr(x, low, ss, packed_w, Cout, relu=True, packed_w_bf16x3=None, want_stats=True, packed_w_f16x3=None,
+               in_absmax=None):
     """relu?(conv3x3x3(x_cat * scale + shift)) on channels-last tensors (``ss`` None: no normalisation);
     returns (out, (part, nblk) or None).  With ``packed_w_f16x3`` / ``packed_w_bf16x3`` the convolution runs on the
     16-bit matrix core with split operands where that kernel covers the shape (f16x3 first)."""
@@ -810,6 +811,12 @@ def conv3d_gcr(x, low, ss, packed_w, Cout, relu=True, packed_w_bf16x3=None, want
         else:
             nblk = lib.vt_conv3d_stat_blocks(B, D, H, W, C1 + C2, Cout)
     part = torch.empty((B, nblk, Cout, 2), dtype=torch.float32, device=dev) if want_stats else None
+    if in_absmax is not None and name == "vt_conv3d_gcr_f16x3":
+        # input far below the half range (output gradients): the kernel rescales it by a power of two around the split
+        check(lib.vt_conv3d_gcr_f16x3_scaled(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
+                                             dev_ptr(pw, "packed_w"), Cout, int(relu), dev_ptr(out, "out"), dev_ptr(part, "part"),
+                                             dev_ptr(in_absmax, "in_absmax"), st), "vt_conv3d_gcr_f16x3_scaled")
+        return out, ((part, nblk) if want_stats else None)
     check(fn(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
              dev_ptr(pw, "packed_w"), Cout, int(relu), dev_ptr(out, "out"), dev_ptr(part, "part"), st), name)
     return out, ((part, nblk) if want_stats else None)
