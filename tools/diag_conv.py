@@ -36,6 +36,16 @@ store = (raw[:, 0] >> np.uint64(40)).astype(np.float64)
 a[:, 0] = (raw[:, 0] & np.uint64((1 << 40) - 1)).astype(np.float64)
 print(f"  (of the tile epilogue: relu + store median {np.median(store):.0f} cycles per wave)")
 names = ["prologue", "commit + DMA issue", "fetch issue", "taps", "tile epilogue", "wait DMA", "barrier", "TOTAL"]
-print(f"{a.shape[0]} waves")
-for i, nm in enumerate(names):
-    print(f"  {nm:20s} median {np.median(a[:, i]):9.0f} cycles per wave   ({100 * a[:, i].sum() / a[:, 7].sum():5.1f} %)")
+def table(rows, title):
+    print(f"{title}: {rows.shape[0]} waves")
+    for i, nm in enumerate(names):
+        print(f"  {nm:20s} median {np.median(rows[:, i]):9.0f} cycles per wave   ({100 * rows[:, i].sum() / rows[:, 7].sum():5.1f} %)")
+if os.environ.get("VTACO_CONV_SPEC", "1") != "0":
+    # specialised waves: in every workgroup the first half of the waves run taps (slots 3 = taps, 4 = taps + tile epilogue of the
+    # tile's last chunk, 6 = barrier), the second half load (1 = commit + DMA issue, 2 = fetch issue, 5 = wait, 6 = barrier)
+    per_wg = 16 if R >= 64 else 8
+    w = np.arange(a.shape[0]) % per_wg
+    table(a[w < per_wg // 2], "tap waves")
+    table(a[w >= per_wg // 2], "loader waves")
+else:
+    table(a, "all waves")

@@ -1024,6 +1024,321 @@ conv3d_gcr_h_kernel(HbArgs ha) {
     }
 }
 
+// ---- the same kernel with specialised waves ------------------------------------------------------------------------
+// In conv3d_gcr_h_kernel every wave alternates between its taps and its share of the next chunk's commit / fetch; the stamps
+// show a wave spending 27 k cycles of a 91 k-cycle layer in taps and most of the rest in phases that a wave busy with MFMAs
+// issues slowly (commit 13 k, fetch issue 9 k, barrier skew 14 k).  Here the first TZ waves only run taps -- each owns a whole
+// z-plane of the tile: two 4 x 8 patches, two accumulators fed by the same weight fragments (6 LDS reads per 6 MFMAs instead of
+// 4 per 3) -- and the other TZ waves only load: commit chunk n+1, DMA its weights, fetch chunk n+2.  One barrier per chunk.
+// Workgroup barrier that orders LDS traffic only: __syncthreads() is a full workgroup fence, and with LDS-DMA writes in flight the
+// compiler implements its release half (also of a fence restricted to the local address space) as s_waitcnt vmcnt(0) -- draining the
+// register prefetch of the chunks ahead at every chunk barrier, so that each iteration pays a full memory latency.  Here: a bare
+// s_barrier behind lgkmcnt(0); the weights' DMA is waited for by hand (counted vmcnt) before it.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);                            // lgkmcnt(0) alone: this wave's LDS writes and reads have completed
+    asm volatile("" ::: "memory");                                 // (compiler: no LDS access moves across the barrier)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int TZ>
+__global__ void __launch_bounds__(hb_threads(TZ))
+conv3d_gcr_hw_kernel(HbArgs ha) {
+    constexpr int ROWS = hb_rows(TZ), NVOX = hb_nvox(TZ), THREADS = hb_threads(TZ), LTHREADS = 64 * TZ;
+    constexpr int ITERS = (2 * NVOX + LTHREADS - 1) / LTHREADS;
+    constexpr int IMG = (int)hb_img_bytes(TZ), WBUF = HB_WFRAGS * 16;
+    extern __shared__ __attribute__((aligned(16))) char hl[];      // [2 images][2 weight buffers][stats scratch][scale / shift]
+    const ConvArgs &a = ha.c;
+    const Src &s = a.s;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, kg = lane >> 5;
+    const int b = blockIdx.x / ha.wgs_per_scene, wg = blockIdx.x - b * ha.wgs_per_scene;
+    const int nsp = a.tiles_x * a.tiles_y * a.tiles_z;
+    const int ntile = (nsp - wg + ha.wgs_per_scene - 1) / ha.wgs_per_scene;
+    const int Cin = s.C1 + s.C2, ncq = Cin / 8;
+    const int co_blk = blockIdx.y, nco_all = a.Cout / 32;
+    char *wbase = hl + 2 * IMG;
+    float *sred = reinterpret_cast<float *>(hl + 2 * IMG + 2 * WBUF);
+    float *ssl = sred + 2 * TZ * 64;
+    float pre_scale = 1.0f, post_scale = 1.0f;
+    if (ha.in_absmax) {
+        const float m = *ha.in_absmax;
+        if (m > 0.0f && m < 3.0e38f) {
+            const int e = 10 - ilogbf(m);
+            pre_scale = ldexpf(1.0f, e < -100 ? -100 : (e > 100 ? 100 : e));
+            post_scale = 1.0f / pre_scale;
+        }
+    }
+    for (int i = threadIdx.x; i < 2 * Cin; i += THREADS)
+        ssl[i] = pre_scale * (a.scale_shift ? a.scale_shift[(size_t)b * Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f));
+    if (wave < TZ) sred[wave * 64 + lane] = 0.0f;
+    __syncthreads();
+    auto tile_origin = [&](int k, int &x0, int &y0, int &z0) {
+        int t = wg + k * ha.wgs_per_scene;
+        const int tx = t % a.tiles_x; t /= a.tiles_x;
+        const int ty = t % a.tiles_y; t /= a.tiles_y;
+        x0 = tx * 8; y0 = ty * 8; z0 = t * TZ;
+    };
+    const int N = ntile * ncq;
+
+    if (wave >= TZ) {
+        // ================================================ loader waves ================================================
+        // (s_setprio 3 here moves time from these waves to the tap waves, 1:1: beside waves that issue MFMAs back to back a wave's
+        // VALU instructions get about one issue slot per 32-cycle MFMA, whatever the priority -- the ~210 VALU instructions per
+        // chunk of a loader wave, x 2 waves per SIMD, are what keeps this kernel at ~58 % of its matrix time)
+        const int lt = threadIdx.x - LTHREADS, lwave = wave - TZ;
+        const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
+        // per item, once: its halo position, its LDS row, and its linear voxel offsets from the tile origin in the full-resolution
+        // source and in the half-resolution `low` source (tile origins are multiples of 8, so the halving distributes) -- a chunk's
+        // request is then one add, one clamp and one multiply-add per item instead of ~35 instructions of coordinate arithmetic
+        int pxyz[ITERS], lrow[ITERS], voff[ITERS], loff[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int item = lt + it * LTHREADS, v = item >> 1;
+            const int px = v % 10, r2 = v / 10, py = r2 % 10, pz = r2 / 10;
+            pxyz[it] = px | (py << 8) | (pz << 16);
+            lrow[it] = v < NVOX ? ((pz * 10 + py) * HB_PX + px) * 16 + (item & 1) * 8 : -1;
+            voff[it] = ((pz - 1) * s.H + (py - 1)) * s.W + (px - 1);
+            loff[it] = (((pz - 1) >> 1) * H2 + ((py - 1) >> 1)) * W2 + ((px - 1) >> 1);
+        }
+        const int c4 = (lt & 1) * 4;
+        const int vmax = (int)((size_t)gridDim.x / ha.wgs_per_scene * s.D * s.H * s.W) - 1, lmax = s.low ? vmax / 8 : 0;
+        // two register sets for the input prefetch: chunk n lives in set n & 1 and is requested two chunks ahead, so a
+        // request has a full chunk period (and more) to land -- with one set the commit stalled ~6 k cycles per chunk on it
+        struct PreSet { f32x4 v[ITERS]; unsigned in; };
+        PreSet preA, preB;
+        int d_q = 0;
+        auto dma_w = [&](int n) {
+            const int q = d_q;
+            if (++d_q == ncq) d_q = 0;
+            const f16x8 *wq = reinterpret_cast<const f16x8 *>(a.wp) + ((size_t)q * nco_all + co_blk) * HB_WFRAGS;
+            char *dst = wbase + (n & 1) * WBUF;
+            // a FIXED number of DMA instructions per wave (the last piece is issued twice by some waves: same bytes to the same place),
+            // so that the compiler can count the vector-memory operations in flight instead of waiting for all of them (vmcnt(0))
+            // in front of every commit -- which is what made the two-deep prefetch above worthless at first
+            constexpr int NP = HB_WFRAGS / 64, PW = (NP + TZ - 1) / TZ;
+#pragma unroll
+            for (int i = 0; i < PW; ++i) {
+                const int p = min(lwave + i * TZ, NP - 1);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wq + p * 64 + lane),
+                                                 (__attribute__((address_space(3))) void *)(dst + p * 1024), 16, 0, 0);
+            }
+        };
+        int f_q = 0, f_k = 0, f_vbase = 0, f_lbase = 0;
+        unsigned f_in = 0;                                         // which items of the current tile lie inside the volume
+        auto enter_tile = [&](int k) {                             // once per tile: origin (wave-uniform) and the inside mask
+            int x0, y0, z0;
+            tile_origin(k, x0, y0, z0);
+            f_vbase = ((b * s.D + z0) * s.H + y0) * s.W + x0;
+            f_lbase = ((b * D2 + (z0 >> 1)) * H2 + (y0 >> 1)) * W2 + (x0 >> 1);
+            f_in = 0;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int gx = x0 + (pxyz[it] & 255) - 1, gy = y0 + ((pxyz[it] >> 8) & 255) - 1, gz = z0 + (pxyz[it] >> 16) - 1;
+                if (lrow[it] >= 0 && gx >= 0 && gx < s.W && gy >= 0 && gy < s.H && gz >= 0 && gz < s.D) f_in |= 1u << it;
+            }
+        };
+        enter_tile(0);
+        auto fetch = [&](PreSet &ps) {
+            const int ch = f_q * 8 + c4;
+            ps.in = f_in;
+            // out-of-volume items read a clamped (valid, unrelated) voxel and are zeroed at the commit; every wave issues exactly
+            // ITERS loads per chunk (the counted vmcnt wait relies on it)
+            if (ch >= s.C1) {
+                const float *base = s.low + (ch - s.C1);
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it)
+                    ps.v[it] = *reinterpret_cast<const f32x4 *>(base + (size_t)(unsigned)min(max(f_lbase + loff[it], 0), lmax) * s.C2);
+            } else {
+                const float *base = s.skip + ch;
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it)
+                    ps.v[it] = *reinterpret_cast<const f32x4 *>(base + (size_t)(unsigned)min(max(f_vbase + voff[it], 0), vmax) * s.C1);
+            }
+            if (++f_q == ncq) { f_q = 0; ++f_k; enter_tile(f_k); }
+        };
+        int c_q = 0;
+        auto commit = [&](int n, const PreSet &ps) {
+            const int ch = c_q * 8 + c4;
+            if (++c_q == ncq) c_q = 0;
+            const float *ss = ssl + ch * 2;
+            const f32x4 sc = {ss[0], ss[2], ss[4], ss[6]}, sh = {ss[1], ss[3], ss[5], ss[7]};
+            char *img = hl + (n & 1) * IMG;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                if (lrow[it] < 0) continue;
+                const bool in = ps.in >> it & 1u;
+                float x[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = in ? fmaf(ps.v[it][e], sc[e], sh[e]) : 0.0f;
+                // hi = half(x) (packed conversion), lo = half(x - hi) with the subtraction reading the half in place
+                // (v_fma_mix_f32): 8 instructions per 4 values instead of the 20 the plain C++ form compiles to; the two pairs
+                // are interleaved so that no mix instruction directly follows the conversion it reads
+                unsigned h01, h23, l01, l23;
+                float t0, t1, t2, t3;
+                asm("v_cvt_pk_f16_f32 %0, %8, %9\n\t"
+                    "v_cvt_pk_f16_f32 %1, %10, %11\n\t"
+                    "v_fma_mix_f32 %4, %0, -1.0, %8 op_sel_hi:[1,0,0]\n\t"
+                    "v_fma_mix_f32 %5, %0, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                    "v_fma_mix_f32 %6, %1, -1.0, %10 op_sel_hi:[1,0,0]\n\t"
+                    "v_fma_mix_f32 %7, %1, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                    "v_cvt_pk_f16_f32 %2, %4, %5\n\t"
+                    "v_cvt_pk_f16_f32 %3, %6, %7"
+                    : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                    : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2 *>(img + lrow[it]) = u32x2{h01, h23};
+                *reinterpret_cast<u32x2 *>(img + ROWS * 16 + lrow[it]) = u32x2{l01, l23};
+            }
+        };
+        constexpr int WAIT_DMA = 0x0F70 | ITERS;                  // vmcnt(ITERS): all but the youngest ITERS operations (the register fetch) have landed
+        if (N > 0) {
+            dma_w(0);
+            fetch(preA);
+            if (N > 1) fetch(preB);
+            commit(0, preA);
+            if (N > 2) fetch(preA);
+        }
+        constexpr int WAIT_DMA0 = 0x0F70 | (2 * ITERS > 15 ? 15 : 2 * ITERS);
+        if (N > 2) __builtin_amdgcn_s_waitcnt(WAIT_DMA0); else __builtin_amdgcn_s_waitcnt(0x0F70);   // chunk 0's weights have landed
+        lds_barrier();
+#ifdef VT_DIAG_HB
+        unsigned long long dg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long dg_last = __builtin_amdgcn_s_memtime();
+        const unsigned long long dg_first = dg_last;
+#endif
+        // iteration n: commit chunk n+1 (requested two iterations ago), DMA its weights, request chunk n+3 into the freed set;
+        // the counted wait lets that youngest request fly on and, vmcnt being in order, also covers chunk n+2's request
+        auto iteration = [&](int n, PreSet &ps) {
+#if defined(VT_HBX) && VT_HBX == 2
+            if (n + 1 < N) { commit(n + 1, ps); }
+#elif defined(VT_HBX) && VT_HBX == 3
+            if (n + 1 < N) { dma_w(n + 1); }
+#else
+            if (n + 1 < N) { commit(n + 1, ps); dma_w(n + 1); }
+#endif
+            HB_STAMP(1);
+            if (n + 3 < N) {
+                fetch(ps); HB_STAMP(2);
+#ifdef VT_DIAG_LATENCY
+                __builtin_amdgcn_s_waitcnt(0x0F70); HB_STAMP(7);       // diagnostic: how long until the requests just issued have landed
+#endif
+                __builtin_amdgcn_s_waitcnt(WAIT_DMA);
+            } else __builtin_amdgcn_s_waitcnt(0x0F70);
+            HB_STAMP(5);
+            lds_barrier();
+            HB_STAMP(6);
+        };
+        for (int n = 0; n < N; n += 2) {
+            iteration(n, preB);                                    // chunk n + 1 is odd
+            if (n + 1 < N) iteration(n + 1, preA);
+        }
+#ifdef VT_DIAG_HB
+        if (lane == 0) {
+            unsigned long long *d = vt_diag_hb_buf + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * 2 * TZ + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) d[i] = dg_sum[i];
+            d[0] = dg_sum[7];                                      // (VT_DIAG_LATENCY: request -> landed)
+            d[7] = __builtin_amdgcn_s_memtime() - dg_first;
+        }
+#endif
+    } else {
+        // ================================================= tap waves ==================================================
+        const int lx = j & 3, ly = j >> 2;
+        const int center = ((wave + 1) * 10 + (ly + 1)) * HB_PX + (lx + 1);      // patch 0; patch 1 sits 4 voxels along x
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+        struct Ops { f16x8 wh, wl, x0h, x0l, x1h, x1l; };
+        auto ops_of = [&](int n, int ks) {
+            Ops o;
+            const f16x8 *wl = reinterpret_cast<const f16x8 *>(wbase + (n & 1) * WBUF);
+            o.wh = wl[ks * 128 + lane]; o.wl = wl[ks * 128 + 64 + lane];
+            const int t0 = 2 * ks, t1 = 2 * ks + 1 < 27 ? 2 * ks + 1 : 13;
+            const int r0 = ((t0 / 9 - 1) * 10 + ((t0 / 3) % 3 - 1)) * HB_PX + (t0 % 3 - 1);
+            const int r1 = ((t1 / 9 - 1) * 10 + ((t1 / 3) % 3 - 1)) * HB_PX + (t1 % 3 - 1);
+            const char *xin = hl + (n & 1) * IMG + (center + (kg ? r1 : r0)) * 16;
+            o.x0h = *reinterpret_cast<const f16x8 *>(xin);
+            o.x0l = *reinterpret_cast<const f16x8 *>(xin + ROWS * 16);
+            o.x1h = *reinterpret_cast<const f16x8 *>(xin + 64);
+            o.x1l = *reinterpret_cast<const f16x8 *>(xin + ROWS * 16 + 64);
+            return o;
+        };
+        int e_q = 0, e_k = 0;
+        lds_barrier();                                           // the loaders' prologue
+#ifdef VT_DIAG_HB
+        unsigned long long dg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long dg_last = __builtin_amdgcn_s_memtime();
+        const unsigned long long dg_first = dg_last;
+#endif
+        for (int n = 0; n < N; ++n) {
+            Ops cur = ops_of(n, 0);
+#pragma unroll
+            for (int ks = 0; ks < HB_KSTEPS; ++ks) {
+                Ops nxt = cur;
+                if (ks + 1 < HB_KSTEPS) nxt = ops_of(n, ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wl, cur.x0h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wl, cur.x1h, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wh, cur.x0l, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wh, cur.x1l, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wh, cur.x0h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wh, cur.x1h, acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
+            }
+            if (++e_q == ncq) {                                      // the tile's last chunk: relu, store, statistics, fresh accumulators
+                int x0, y0, z0;
+                tile_origin(e_k, x0, y0, z0);
+                e_q = 0; ++e_k;
+                f32x16 ssum, ssq;
+#pragma unroll
+                for (int pch = 0; pch < 2; ++pch) {
+                    f32x16 v = pch ? acc1 : acc0;
+                    const int gx = x0 + lx + 4 * pch, gy = y0 + ly, gz = z0 + wave;
+                    float *orow = a.out + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.Cout;
+                    if (ha.in_absmax) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] *= post_scale;
+                    }
+                    if (a.relu) v = relu16(v);
+                    store_acc16(orow + co_blk * 32, v, kg);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {                  // the two patches' contributions per lane first: ONE lane reduction per tile
+                        ssum[r] = pch ? ssum[r] + v[r] : v[r];
+                        ssq[r] = pch ? fmaf(v[r], v[r], ssq[r]) : v[r] * v[r];
+                    }
+                }
+                if (a.part) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float sm = half_wave_sum(ssum[r]), sq = half_wave_sum(ssq[r]);
+                        if (j == 31) { float *d = sred + wave * 64 + chan_of(r, kg) * 2; d[0] += sm; d[1] += sq; }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+                HB_STAMP(4);
+            } else HB_STAMP(3);
+            lds_barrier();
+            HB_STAMP(6);
+        }
+#ifdef VT_DIAG_HB
+        if (lane == 0) {
+            unsigned long long *d = vt_diag_hb_buf + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * 2 * TZ + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) d[i] = dg_sum[i];
+            d[7] = __builtin_amdgcn_s_memtime() - dg_first;
+        }
+#endif
+    }
+    if (a.part && threadIdx.x < 64) {
+        float tsum = 0.0f;
+        for (int w = 0; w < TZ; ++w) tsum += sred[w * 64 + threadIdx.x];
+        a.part[(((size_t)b * ha.wgs_per_scene + wg) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 maxpool3d_cl_kernel(const float *x, float *out, int D, int H, int W, int C, size_t total) {
     const int D2 = D / 2, H2 = H / 2, W2 = W / 2;
@@ -1149,7 +1464,7 @@ static int conv_s_tz(int B, int D, int H, int W, int Cout) {
 // 0 = not covered (the 16^3-class levels stay on the thin-tile split-bf16 kernel or the f32 kernels)
 static int conv_h_tz(int B, int D, int H, int W, int Cin, int Cout) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || ((D | H | W) & 7) || Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 31)) return 0;
-    if ((size_t)B * D * H * W >= ((size_t)1 << 31)) return 0;
+    if ((size_t)B * D * H * W >= ((size_t)1 << 31) || Cin > HB_MAX_CIN) return 0;          // 32-bit voxel indices; the scale / shift table in LDS
     static const int forced = getenv("VTACO_CONV_HTZ") ? atoi(getenv("VTACO_CONV_HTZ")) : 0;     // A/B knob
     const size_t nco = Cout / 32, t8 = (size_t)(D / 8) * (H / 8) * (W / 8) * B * nco, t4 = 2 * t8, t2 = 4 * t8;
     if (forced == 8 || forced == 4 || forced == 2) return (forced == 8 ? t8 : forced == 4 ? t4 : t2) >= 64 ? forced : 0;
@@ -1389,6 +1704,19 @@ int vt_conv3d_gcr_f16x3_scaled(const float *skip, int C1, const float *low, int 
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_h_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(2));
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3: hipFuncSetAttribute");
         attr = true;
+    }
+    static const bool spec = !(getenv("VTACO_CONV_SPEC") && getenv("VTACO_CONV_SPEC")[0] == '0');   // specialised tap / loader waves (0: the uniform-wave kernel)
+    if (spec && tz != 2) {
+        static bool attr_w = false;
+        if (!attr_w) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(8));
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(4));
+            if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3: hipFuncSetAttribute");
+            attr_w = true;
+        }
+        if (tz == 8) hipLaunchKernelGGL(conv3d_gcr_hw_kernel<8>, grid, dim3(hb_threads(8)), hb_lds(8), (hipStream_t)stream, ha);
+        else hipLaunchKernelGGL(conv3d_gcr_hw_kernel<4>, grid, dim3(hb_threads(4)), hb_lds(4), (hipStream_t)stream, ha);
+        return vt_check(hipGetLastError(), "vt_conv3d_gcr_f16x3");
     }
     if (tz == 8) hipLaunchKernelGGL(conv3d_gcr_h_kernel<8>, grid, dim3(hb_threads(8)), hb_lds(8), (hipStream_t)stream, ha);
     else if (tz == 4) hipLaunchKernelGGL(conv3d_gcr_h_kernel<4>, grid, dim3(hb_threads(4)), hb_lds(4), (hipStream_t)stream, ha);
