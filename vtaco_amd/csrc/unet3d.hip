@@ -34,68 +34,6 @@ __device__ __forceinline__ float src_at(const Src &s, int b, int z, int y, int x
     return s.low[((((size_t)b * D2 + (z >> 1)) * H2 + (y >> 1)) * W2 + (x >> 1)) * s.C2 + (c - s.C1)];
 }
 
-struct StatSrc { const float *part; int nblk, C; };
-
-// GroupNorm finalisation (see gn_finalize_kernel below) done by the LAST workgroup of the kernel that produces the statistics (vt_unet3d_fwd): every producer ends
-// with gn_tail(); the workgroup whose ticket is the last one reduces the partial sums of the NEXT convolution's input(s) into that
-// convolution's scale / shift table, so the 14 gn_finalize launches of a forward (~4.8 us each, almost all of it launch latency)
-// disappear.  Called by ONE wave of the workgroup (the wave that wrote this workgroup's partial sums); `fin.ss_out == nullptr`: no-op.
-struct FinArgs {
-    float *ss_out;              // [B][C1+C2][2] scale / shift of the consumer, or null
-    const float *gamma, *beta;  // the consumer's GroupNorm parameters
-    StatSrc s1, s2;             // its sources' partial sums (s2: the nearest-upsampled `low`, counted 8 times; part null if absent)
-    int groups, B;
-    double count;               // voxels per scene of the consumer's input
-    float eps;
-    unsigned *ticket;           // zero before the launch; reset to zero by the last workgroup
-    unsigned total;             // workgroups of this launch
-};
-
-__device__ __forceinline__ void gn_tail(const FinArgs &f) {
-    if (!f.ss_out) return;
-    const int lane = threadIdx.x & 63;
-    __threadfence();                                               // this wave's partial sums are visible device-wide
-    unsigned t = 0;
-    if (lane == 0) t = atomicAdd(f.ticket, 1u);
-    t = __builtin_amdgcn_readfirstlane(t);
-    if (t != f.total - 1) return;
-    __threadfence();                                               // ... and everybody else's are visible here
-    const int C = f.s1.C + f.s2.C, cpg = C / f.groups;
-    for (int b = 0; b < f.B; ++b)
-        for (int g = 0; g < f.groups; ++g) {
-            const int c_lo = g * cpg, c_hi = c_lo + cpg;
-            double sum = 0.0, sq = 0.0;
-#pragma unroll
-            for (int src = 0; src < 2; ++src) {
-                const StatSrc &s = src ? f.s2 : f.s1;
-                const int coff = src ? f.s1.C : 0;
-                const double mult = src ? 8.0 : 1.0;
-                if (!s.part) continue;
-                const int k0 = (c_lo > coff ? c_lo : coff) - coff, k1 = (c_hi < coff + s.C ? c_hi : coff + s.C) - coff;
-                const int nk = k1 - k0;
-                if (nk <= 0) continue;
-                const int total = nk * s.nblk;
-                const float2 *base = reinterpret_cast<const float2 *>(s.part) + (size_t)b * s.nblk * s.C + k0;
-                for (int i = lane; i < total; i += 64) {
-                    const int blk = i / nk, k = i - blk * nk;
-                    const float2 p = base[(size_t)blk * s.C + k];
-                    sum += mult * (double)p.x; sq += mult * (double)p.y;
-                }
-            }
-            for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); sq += __shfl_xor(sq, o); }
-            const double n = f.count * cpg, mean = sum / n;
-            double var = sq / n - mean * mean;                     // biased variance, as torch
-            if (var < 0.0) var = 0.0;
-            const double rstd = 1.0 / sqrt(var + (double)f.eps);
-            for (int c = c_lo + lane; c < c_hi; c += 64) {
-                const double sc = rstd * (double)f.gamma[c];
-                f.ss_out[((size_t)b * C + c) * 2 + 0] = (float)sc;
-                f.ss_out[((size_t)b * C + c) * 2 + 1] = (float)((double)f.beta[c] - mean * sc);
-            }
-        }
-    if (lane == 0) *f.ticket = 0u;
-}
-
 // ---- GroupNorm statistics ---------------------------------------------------------------------
 // Every producer of a tensor leaves per-block partial sums part[b][blk][c] = (sum, sumsq) over its
 // voxels (the conv epilogue for conv outputs, channel_stats_kernel for pooled tensors and the
@@ -103,7 +41,7 @@ __device__ __forceinline__ void gn_tail(const FinArgs &f) {
 // statistics of the virtual concat [skip | upsample(low)] are the per-channel sums of skip plus
 // 8x those of low (nearest upsampling repeats every value 8 times).
 __global__ void __launch_bounds__(256)
-channel_stats_kernel(const float *x, int C, size_t V, int nblk, float *part, FinArgs fin) {
+channel_stats_kernel(const float *x, int C, size_t V, int nblk, float *part) {
     __shared__ float red[8][32][2];
     const int b = blockIdx.y, blk = blockIdx.x;
     const size_t v0 = V * blk / nblk, v1 = V * (blk + 1) / nblk;
@@ -125,9 +63,9 @@ channel_stats_kernel(const float *x, int C, size_t V, int nblk, float *part, Fin
         }
         __syncthreads();
     }
-    if (threadIdx.x < 64) gn_tail(fin);                            // (the partial sums above were written by this wave)
 }
 
+struct StatSrc { const float *part; int nblk, C; };
 
 // one block per (scene, group): scale[b][c] = rstd*gamma, shift[b][c] = beta - mean*rstd*gamma.
 // The (channel, partial block) pairs of the group are flattened over the threads (8-byte loads, consecutive
@@ -202,7 +140,6 @@ struct ConvArgs {
     int Cout, relu;
     int TX, TY, TZ;             // block tile of output voxels (TX*TY*TZ = 32 * waves)
     int tiles_x, tiles_y, tiles_z;
-    FinArgs fin;                // vt_unet3d_fwd: the last workgroup finalises the next layer's GroupNorm (ss_out null otherwise)
 };
 
 // stage channels [32 cib, 32 cib+32) of the normalised input tile (origin x0-1,y0-1,z0-1) into LDS;
@@ -355,11 +292,6 @@ conv3d_gcr_kernel(ConvArgs a) {
             const int n = e >> 6, c2 = e & 63;                    // c2 = channel*2 + {sum,sq}
             a.part[(((size_t)b * nsp + spatial) * a.Cout + (co_blk0 + n) * 32) * 2 + c2] = tsum;
         }
-        if (a.fin.ss_out) {                                        // (several waves wrote partial sums: order them before the ticket)
-            __threadfence();
-            __syncthreads();
-            if (wave == 0) gn_tail(a.fin);
-        }
     }
 }
 
@@ -415,7 +347,6 @@ conv3d_gcr_ksplit_kernel(ConvArgs a) {
     if (a.part) {
         const int nsp = a.tiles_x * a.tiles_y * a.tiles_z;
         wave_stats(v, valid, j, kk, a.part + (((size_t)b * nsp + blockIdx.x % nsp) * a.Cout + co_blk * 32) * 2);
-        gn_tail(a.fin);                                            // wave 0 is the only wave here
     }
 }
 
@@ -609,7 +540,6 @@ conv3d_gcr_s_kernel(ConvArgs a) {
             float tsum = 0.0f;
             for (int w = 0; w < 2 * TZ; ++w) tsum += sred[w * 64 + threadIdx.x];
             a.part[(((size_t)b * nsp + spatial) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
-            gn_tail(a.fin);
         }
     }
 }
@@ -784,7 +714,6 @@ conv3d_gcr_s4_kernel(ConvArgs a) {
             float tsum = 0.0f;
             for (int w = 0; w < 2 * S4_TZ; ++w) tsum += sred[w * 64 + threadIdx.x];
             a.part[(((size_t)b * nsp + spatial) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
-            gn_tail(a.fin);
         }
     }
 }
@@ -1091,7 +1020,6 @@ conv3d_gcr_h_kernel(HbArgs ha) {
             float tsum = 0.0f;
             for (int w = 0; w < 2 * TZ; ++w) tsum += sred[w * 64 + threadIdx.x];
             a.part[(((size_t)b * ha.wgs_per_scene + wg) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
-            gn_tail(a.fin);
         }
     }
 }
@@ -1408,7 +1336,6 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
         float tsum = 0.0f;
         for (int w = 0; w < TZ; ++w) tsum += sred[w * 64 + threadIdx.x];
         a.part[(((size_t)b * ha.wgs_per_scene + wg) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
-        gn_tail(a.fin);
     }
 }
 
@@ -1477,15 +1404,6 @@ conv1x1_mfma_kernel(const float *x, const float *w, const float *bias, float *ou
             if (valid) store_acc16(out + v * Cout + cob * 32, acc, kh);
         }
     }
-}
-
-// vt_unet3d_fwd hands the next launch its finalisation job through this slot (host side, per thread): the C entry points below
-// take it (and clear it) when they build their kernel arguments, so their signatures stay what the header declares
-static thread_local FinArgs tl_fin = {};
-static FinArgs take_fin() {
-    const FinArgs f = tl_fin;
-    tl_fin = FinArgs{};
-    return f;
 }
 
 bool src_ok(const Src &s, int B) {
@@ -1615,9 +1533,7 @@ int vt_conv3d_stat_blocks(int B, int D, int H, int W, int Cin, int Cout) {
 
 int vt_channel_stats(const float *x, int B, int64_t V, int C, int nblk, float *part, void *stream) {
     if (!x || !part || B <= 0 || V <= 0 || C <= 0 || (C & 31) || nblk <= 0) return vt_fail(VT_ERR_INVALID, "vt_channel_stats: bad argument");
-    FinArgs fin = take_fin();
-    fin.total = (unsigned)nblk * (unsigned)B;
-    hipLaunchKernelGGL(channel_stats_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, x, C, (size_t)V, nblk, part, fin);
+    hipLaunchKernelGGL(channel_stats_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, x, C, (size_t)V, nblk, part);
     return vt_check(hipGetLastError(), "vt_channel_stats");
 }
 
@@ -1639,7 +1555,6 @@ int vt_conv3d_gcr(const float *skip, int C1, const float *low, int C2, int B, in
                   const float *scale_shift, const float *packed_w, int Cout, int relu, float *out,
                   float *out_part, void *stream) {
     ConvArgs a;
-    a.fin = take_fin();
     a.s = Src{skip, low, C1, low ? C2 : 0, D, H, W};
     if (!src_ok(a.s, B) || !packed_w || !out) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr: bad argument");
     if (Cout <= 0 || (Cout & 31)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr: Cout must be a multiple of 32");
@@ -1655,7 +1570,6 @@ int vt_conv3d_gcr(const float *skip, int C1, const float *low, int C2, int B, in
         size_t lds = one * kw;
         if (lds < (size_t)(kw - 1) * 16 * 64 * sizeof(float)) lds = (size_t)(kw - 1) * 16 * 64 * sizeof(float);
         const dim3 grid((unsigned)((size_t)nsp1 * B), (unsigned)nco);
-        a.fin.total = grid.x * grid.y;
         static bool ks_attr = false;
         if (!ks_attr) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_ksplit_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1681,7 +1595,6 @@ int vt_conv3d_gcr(const float *skip, int C1, const float *low, int C2, int B, in
     if (stat_lds > lds) lds = stat_lds;
     if (lds > 160 * 1024) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr: tile does not fit LDS");
     const dim3 grid((unsigned)spatial_blocks, (unsigned)(nco / per));
-    a.fin.total = grid.x * grid.y;
     int rc = 0;
     if (waves == 8) rc = per == 4 ? conv_launch<4, 8>(a, grid, lds, st) : per == 2 ? conv_launch<2, 8>(a, grid, lds, st) : conv_launch<1, 8>(a, grid, lds, st);
     else if (waves == 4) rc = conv_launch<1, 4>(a, grid, lds, st);
@@ -1709,7 +1622,6 @@ int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, in
                          const float *scale_shift, const float *packed_w_bf16x3, int Cout, int relu, float *out,
                          float *out_part, void *stream) {
     ConvArgs a;
-    a.fin = take_fin();
     a.s = Src{skip, low, C1, low ? C2 : 0, D, H, W};
     if (!src_ok(a.s, B) || !packed_w_bf16x3 || !out) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr_bf16x3: bad argument");
     if (!conv_s_eligible(B, D, H, W, a.s.C1 + a.s.C2, Cout))
@@ -1719,7 +1631,6 @@ int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, in
     a.TX = a.TY = 8; a.TZ = tz;
     a.tiles_x = W / 8; a.tiles_y = H / 8; a.tiles_z = D / tz;
     const dim3 grid((unsigned)((size_t)a.tiles_x * a.tiles_y * a.tiles_z * B), (unsigned)(Cout / 32));
-    a.fin.total = grid.x * grid.y;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1777,7 +1688,6 @@ int vt_conv3d_gcr_f16x3_scaled(const float *skip, int C1, const float *low, int 
     HbArgs ha;
     ha.in_absmax = in_absmax;
     ConvArgs &a = ha.c;
-    a.fin = take_fin();
     a.s = Src{skip, low, C1, low ? C2 : 0, D, H, W};
     if (!src_ok(a.s, B) || !packed_w_f16x3 || !out) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr_f16x3: bad argument");
     const int tz = conv_h_tz(B, D, H, W, a.s.C1 + a.s.C2, Cout);
@@ -1787,7 +1697,6 @@ int vt_conv3d_gcr_f16x3_scaled(const float *skip, int C1, const float *low, int 
     a.tiles_x = W / 8; a.tiles_y = H / 8; a.tiles_z = D / tz;
     ha.wgs_per_scene = conv_h_wgs_per_scene(B, D, H, W, Cout, tz);
     const dim3 grid((unsigned)(ha.wgs_per_scene * B), (unsigned)(Cout / 32));
-    a.fin.total = grid.x * grid.y;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_h_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(8));
@@ -1856,100 +1765,70 @@ int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char 
     if (L < 1 || L > VT_UNET_MAX_LEVELS) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: bad level count");
     if (R % (1 << (L - 1))) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: resolution must be divisible by 2^(levels-1)");
     const bool plan = wsbase == nullptr;
+    Bump ws{wsbase, 0};
     int maxC = 0;
     for (int i = 0; i < L; ++i) for (int k = 0; k < 2; ++k) { if (p->enc[i][k].cin > maxC) maxC = p->enc[i][k].cin; }
     for (int i = 0; i + 1 < L; ++i) for (int k = 0; k < 2; ++k) { if (p->dec[i][k].cin > maxC) maxC = p->dec[i][k].cin; }
-    // The GroupNorm finalisation of conv n runs in the last workgroup of the launch in front of it (gn_tail): the layer walk is
-    // done twice over the same deterministic workspace layout -- pass 0 sizes the workspace and records every conv's finalisation
-    // job, pass 1 launches, handing each producer the job of the conv that follows it.  Scale / shift tables alternate between two
-    // buffers (conv n reads ss[n & 1] while its last workgroup writes ss[(n + 1) & 1]).
-    constexpr int MAXCONV = 4 * VT_UNET_MAX_LEVELS;
-    FinArgs fins[MAXCONV + 1] = {};
-    size_t need = 0;
-    for (int pass = 0; pass < (plan ? 1 : 2); ++pass) {
-        const bool launch = pass == 1;
-        Bump ws{wsbase, 0};
-        float *ssb[2] = {ws.take((size_t)B * maxC * 2), ws.take((size_t)B * maxC * 2)};
-        unsigned *tickets = reinterpret_cast<unsigned *>(ws.take(64));
-        if (launch) {
-            const hipError_t e = hipMemsetAsync(tickets, 0, 64 * sizeof(unsigned), st);
-            if (e != hipSuccess) return vt_check(e, "vt_unet3d_fwd: hipMemsetAsync");
-        }
-        int nconv = 0;
-        auto stats_of = [&](const float *x, int Ri, int C, Tensor &t) -> int {     // always followed by conv `nconv`
-            const int64_t V = (int64_t)Ri * Ri * Ri;
-            t.nblk = (int)(V / 64 < 1 ? 1 : (V / 64 > 1024 ? 1024 : V / 64));
-            t.part = ws.take((size_t)B * t.nblk * C * 2);
-            t.C = C;
-            if (!launch) return 0;
-            tl_fin = fins[nconv];
-            return vt_channel_stats(x, B, V, C, t.nblk, t.part, st);
-        };
-        auto gcr = [&](const vt_unet3d_conv &c, const Tensor &a, const Tensor *low, int Ri, Tensor &o, bool next_is_conv) -> int {
-            const int n = nconv++;
-            if (n >= MAXCONV) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: too many levels");
-            const int C2 = low ? low->C : 0;
-            if (a.C + C2 != c.cin) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: channel mismatch between levels");
-            o.C = c.cout;
-            o.x = ws.take((size_t)B * Ri * Ri * Ri * c.cout);
-            const bool half = c.packed_f16x3 && conv_h_tz(B, Ri, Ri, Ri, c.cin, c.cout) != 0;
-            const bool split = !half && c.packed_bf16x3 && conv_s_eligible(B, Ri, Ri, Ri, c.cin, c.cout);
-            o.nblk = half ? vt_conv3d_stat_blocks_f16x3(B, Ri, Ri, Ri, c.cin, c.cout)
-                          : split ? vt_conv3d_stat_blocks_bf16x3(B, Ri, Ri, Ri, c.cin, c.cout) : vt_conv3d_stat_blocks(B, Ri, Ri, Ri, c.cin, c.cout);
-            o.part = ws.take((size_t)B * o.nblk * c.cout * 2);
-            const int groups = (c.cin >= p->groups) ? p->groups : 1;
-            if (c.cin % groups || c.cin / groups > 256) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: bad group count");
-            if (!launch) {
-                FinArgs &f = fins[n];
-                f.ss_out = ssb[n & 1]; f.gamma = c.gn_w; f.beta = c.gn_b;
-                f.s1 = StatSrc{a.part, a.nblk, a.C};
-                f.s2 = StatSrc{low ? low->part : nullptr, low ? low->nblk : 0, C2};
-                f.groups = groups; f.B = B; f.count = (double)Ri * Ri * Ri; f.eps = (float)p->eps;
-                f.ticket = tickets + n; f.total = 0;
-                return 0;
-            }
-            float *ss = ssb[n & 1];
-            tl_fin = next_is_conv ? fins[n + 1] : FinArgs{};
-            if (half)
-                return vt_conv3d_gcr_f16x3(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.cout, 1, o.x, o.part, st);
-            if (split)
-                return vt_conv3d_gcr_bf16x3(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed_bf16x3, c.cout, 1, o.x, o.part, st);
-            return vt_conv3d_gcr(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed, c.cout, 1, o.x, o.part, st);
-        };
-        Tensor skips[VT_UNET_MAX_LEVELS];
-        Tensor cur;
-        cur.x = const_cast<float *>(x_cl); cur.C = p->enc[0][0].cin;
-        int rc = stats_of(x_cl, R, cur.C, cur);
+    float *ss = ws.take((size_t)B * maxC * 2);
+    auto stats_of = [&](const float *x, int Ri, int C, Tensor &t) -> int {
+        const int64_t V = (int64_t)Ri * Ri * Ri;
+        t.nblk = (int)(V / 64 < 1 ? 1 : (V / 64 > 1024 ? 1024 : V / 64));
+        t.part = ws.take((size_t)B * t.nblk * C * 2);
+        t.C = C;
+        return plan ? 0 : vt_channel_stats(x, B, V, C, t.nblk, t.part, st);
+    };
+    auto gcr = [&](const vt_unet3d_conv &c, const Tensor &a, const Tensor *low, int Ri, Tensor &o) -> int {
+        const int C2 = low ? low->C : 0;
+        if (a.C + C2 != c.cin) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: channel mismatch between levels");
+        o.C = c.cout;
+        o.x = ws.take((size_t)B * Ri * Ri * Ri * c.cout);
+        const bool half = c.packed_f16x3 && conv_h_tz(B, Ri, Ri, Ri, c.cin, c.cout) != 0;
+        const bool split = !half && c.packed_bf16x3 && conv_s_eligible(B, Ri, Ri, Ri, c.cin, c.cout);
+        o.nblk = half ? vt_conv3d_stat_blocks_f16x3(B, Ri, Ri, Ri, c.cin, c.cout)
+                      : split ? vt_conv3d_stat_blocks_bf16x3(B, Ri, Ri, Ri, c.cin, c.cout) : vt_conv3d_stat_blocks(B, Ri, Ri, Ri, c.cin, c.cout);
+        o.part = ws.take((size_t)B * o.nblk * c.cout * 2);
+        if (plan) return 0;
+        const int groups = (c.cin >= p->groups) ? p->groups : 1;
+        int rc = vt_gn_scale_shift(a.part, a.nblk, a.C, low ? low->part : nullptr, low ? low->nblk : 0, C2, B,
+                                   (int64_t)Ri * Ri * Ri, groups, c.gn_w, c.gn_b, p->eps, ss, st);
         if (rc) return rc;
-        for (int i = 0; i < L; ++i) {
-            const int Ri = R >> i;
-            if (i > 0) {
-                Tensor pooled;
-                pooled.C = cur.C;
-                pooled.x = ws.take((size_t)B * Ri * Ri * Ri * cur.C);
-                if (launch && (rc = vt_maxpool3d_cl(cur.x, B, 2 * Ri, 2 * Ri, 2 * Ri, cur.C, pooled.x, st))) return rc;
-                if ((rc = stats_of(pooled.x, Ri, pooled.C, pooled))) return rc;
-                cur = pooled;
-            }
-            Tensor t1, t2;
-            if ((rc = gcr(p->enc[i][0], cur, nullptr, Ri, t1, true))) return rc;
-            if ((rc = gcr(p->enc[i][1], t1, nullptr, Ri, t2, i + 1 == L && L > 1))) return rc;     // else a max-pool (or the final conv) follows
-            skips[i] = t2;
-            cur = t2;
+        if (half)
+            return vt_conv3d_gcr_f16x3(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.cout, 1, o.x, o.part, st);
+        if (split)
+            return vt_conv3d_gcr_bf16x3(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed_bf16x3, c.cout, 1, o.x, o.part, st);
+        return vt_conv3d_gcr(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed, c.cout, 1, o.x, o.part, st);
+    };
+    Tensor skips[VT_UNET_MAX_LEVELS];
+    Tensor cur;
+    cur.x = const_cast<float *>(x_cl); cur.C = p->enc[0][0].cin;
+    int rc = stats_of(x_cl, R, cur.C, cur);
+    if (rc) return rc;
+    for (int i = 0; i < L; ++i) {
+        const int Ri = R >> i;
+        if (i > 0) {
+            Tensor pooled;
+            pooled.C = cur.C;
+            pooled.x = ws.take((size_t)B * Ri * Ri * Ri * cur.C);
+            if (!plan && (rc = vt_maxpool3d_cl(cur.x, B, 2 * Ri, 2 * Ri, 2 * Ri, cur.C, pooled.x, st))) return rc;
+            if ((rc = stats_of(pooled.x, Ri, pooled.C, pooled))) return rc;
+            cur = pooled;
         }
-        for (int k = 0; k + 1 < L; ++k) {
-            const int lvl = L - 2 - k, Ri = R >> lvl;
-            Tensor t1, t2;
-            if ((rc = gcr(p->dec[k][0], skips[lvl], &cur, Ri, t1, true))) return rc;
-            if ((rc = gcr(p->dec[k][1], t1, nullptr, Ri, t2, k + 2 < L))) return rc;
-            cur = t2;
-        }
-        need = ws.off;
-        if (launch)
-            return vt_conv1x1_cl(cur.x, (int64_t)B * R * R * R, cur.C, p->final_w, p->final_b, p->out_channels, out, st);
+        Tensor t1, t2;
+        if ((rc = gcr(p->enc[i][0], cur, nullptr, Ri, t1))) return rc;
+        if ((rc = gcr(p->enc[i][1], t1, nullptr, Ri, t2))) return rc;
+        skips[i] = t2;
+        cur = t2;
     }
-    if (ws_need) *ws_need = need;
-    return 0;
+    for (int k = 0; k + 1 < L; ++k) {
+        const int lvl = L - 2 - k, Ri = R >> lvl;
+        Tensor t1, t2;
+        if ((rc = gcr(p->dec[k][0], skips[lvl], &cur, Ri, t1))) return rc;
+        if ((rc = gcr(p->dec[k][1], t1, nullptr, Ri, t2))) return rc;
+        cur = t2;
+    }
+    if (ws_need) *ws_need = ws.off;
+    if (plan) return 0;
+    return vt_conv1x1_cl(cur.x, (int64_t)B * R * R * R, cur.C, p->final_w, p->final_b, p->out_channels, out, st);
 }
 }  // namespace
 
