@@ -279,6 +279,20 @@ int vt_decode_wgrad(int B, const float *pts, int64_t N, int lattice_nx, float la
                     const float *c_img, const float *grad_out, const float *save, const float *gws,
                     void *workspace, size_t workspace_bytes, float *grads, void *stream);
 
+/* The same two calls with the contact head (LocalDecoder.forward_contact under autograd,  */
+/* decoder.py:105-133 -> training.py:896-948): grad_out2 [B,N] is the gradient of the      */
+/* contact logits; `grads` has vt_decode_wgrad_floats_contact(p_in) floats: the layout     */
+/* above followed by fc_out_contact.w[32] fc_out_contact.b[1].  blob_t must come from a    */
+/* vt_decoder_pack_t call whose params carry fc_out2_w.  grad_out2 NULL = the plain calls. */
+int vt_decode_bwd_contact(int B, int R, int C, const float *pts, int64_t N,
+                          int lattice_nx, float lattice_box, int64_t lattice_first, double padding,
+                          const float *blob_t, const float *grad_out, const float *grad_out2, const float *save, float *gws,
+                          float *grad_grid_cl, float *grad_c_img, void *stream);
+size_t vt_decode_wgrad_floats_contact(int p_in);
+int vt_decode_wgrad_contact(int B, const float *pts, int64_t N, int lattice_nx, float lattice_box, int64_t lattice_first,
+                            const float *c_img, const float *grad_out, const float *grad_out2, const float *save, const float *gws,
+                            void *workspace, size_t workspace_bytes, float *grads, void *stream);
+
 /* ------------------------------------------------------------------------- */
 /* Marching cubes (Lewiner), vertex numbering identical to scikit-image's.      */
 /* Replaces: skimage.measure.marching_cubes(value_grid,                         */

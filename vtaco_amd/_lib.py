@@ -107,6 +107,9 @@ SIGNATURES = {
     "vt_decode_wgrad_workspace_bytes": (_SZ, [_I64]),
     "vt_decode_wgrad_floats": (_SZ, [_I]),
     "vt_decode_wgrad": (_I, [_I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP, _VP, _VP, _SZ, _VP, _VP]),
+    "vt_decode_bwd_contact": (_I, [_I, _I, _I, _VP, _I64, _I, _F, _I64, _D, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "vt_decode_wgrad_floats_contact": (_SZ, [_I]),
+    "vt_decode_wgrad_contact": (_I, [_I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP, _VP]),
     "vt_mc_workspace_bytes": (_SZ, [_I, _I, _I]),
     "vt_mc_count": (_I, [_VP, _I, _I, _I, _D, _I, _VP, _SZ, _VP]),
     "vt_mc_read_counts": (_I, [_VP, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_D), _VP]),

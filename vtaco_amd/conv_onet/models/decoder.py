@@ -50,6 +50,28 @@ class _DecodeFn(torch.autograd.Function):
         return (None, None, ggrid, gimg, *grads)
 
 
+class _DecodeContactFn(torch.autograd.Function):
+    """forward_contact, differentiable (decoder.py:105-133; training.py:896-948): the fused decode with both heads
+    (vt_decode_fwd with out2 and the saved activations), backward = vt_decode_bwd_contact + vt_decode_wgrad_contact."""
+
+    @staticmethod
+    def forward(ctx, dec, p, grid, *params):
+        B, N = p.shape[0], p.shape[1]
+        save = ops.decode_save_buffer(B * N, grid.device)
+        out, out2 = ops.decode_fwd(grid, dec._blob(contact=True), pts=p, padding=dec.padding, save=save, want_contact=True)
+        ctx.dec, ctx.save, ctx.grid_shape, ctx.p, ctx.need_grid = dec, save, tuple(grid.shape), p.detach(), grid.requires_grad
+        return out, out2
+
+    @staticmethod
+    def backward(ctx, grad_out, grad_out2):
+        dec = ctx.dec
+        ggrid, _, flat = ops.decode_bwd(ctx.grid_shape, dec._blob_t(contact=True), grad_out, ctx.save, pts=ctx.p,
+                                        padding=dec.padding, want_grid_grad=ctx.need_grid, grad_out2=grad_out2)
+        g = ops.split_decoder_grads(flat, 3)
+        grads = [g[key] if idx is None else g[key][idx] for key, idx in dec._param_order(False)]
+        return (None, None, ggrid, *grads, g["fc_out_contact.weight"], g["fc_out_contact.bias"])
+
+
 class _SampleGridFn(torch.autograd.Function):
     """Trilinear sampling alone (vt_sample_grid / vt_sample_grid_bwd), differentiable in the grid."""
 
@@ -133,10 +155,11 @@ class LocalDecoder(nn.Module):
         self._blobs[(img, contact, precision)] = (stamp, blob)
         return blob
 
-    def _blob_t(self, img=False):
+    def _blob_t(self, img=False, contact=False):
         first = self.fc_p_img if img else self.fc_p
+        out2 = (self.fc_out_contact.weight, self.fc_out_contact.bias) if contact else None
         return ops.pack_decoder(first.weight, first.bias, [(l.weight, l.bias) for l in self.fc_c],
-                                [b.packed() for b in self.blocks], (self.fc_out.weight, self.fc_out.bias),
+                                [b.packed() for b in self.blocks], (self.fc_out.weight, self.fc_out.bias), out2,
                                 transposed=True)
 
     def _param_order(self, img):
@@ -188,15 +211,9 @@ class LocalDecoder(nn.Module):
         """(occupancy logits, contact logits) (decoder.py:105-133)."""
         grid = self._grid_of(c_plane)
         if self._wants_grad(grid):
-            # training with the contact head (no shipped config does: with_contact is False in all of them): the trilinear
-            # gather and its backward are the HIP kernels (vt_sample_grid / vt_sample_grid_bwd); the 17 k-parameter MLP with
-            # its two heads differentiates as host PyTorch ops -- correct, not tuned
-            c = _SampleGridFn.apply(grid, p, self.padding)
-            net = self.fc_p(p.float())
-            for lin, blk in zip(self.fc_c, self.blocks):
-                net = blk(net + lin(c))
-            net = torch.relu(net)
-            return self.fc_out(net).squeeze(-1), self.fc_out_contact(net).squeeze(-1)
+            # training with the contact head: the fused decode kernel with both heads and its HIP backward
+            return _DecodeContactFn.apply(self, p.float(), grid, *self._params(False),
+                                          self.fc_out_contact.weight, self.fc_out_contact.bias)
         return ops.decode_fwd(grid, self._blob(contact=True, precision=self.precision), pts=p, padding=self.padding,
                               want_contact=True, precision=self.precision)
 

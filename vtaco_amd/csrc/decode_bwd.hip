@@ -22,9 +22,10 @@ namespace {
 // 16 layers x [16 k-steps][64 lanes]:  0..4 fc_c{i}^T (output in gather layout)
 //                                      5..9 fc_1{i}^T, 10..14 fc_0{i}^T (accumulator layout)
 //                                      15   fc_p_img[:,3:]^T (gather layout)
-// then fc_out.weight fragment [2][16] (accumulator layout)
+// then fc_out.weight fragment [2][16] and fc_out_contact.weight fragment [2][16] (accumulator layout; zeros without a contact head)
 constexpr int VT_OFFT_OUT = 16 * 1024;
-constexpr int VT_BLOBT_FLOATS = VT_OFFT_OUT + 32;
+constexpr int VT_OFFT_OUT2 = VT_OFFT_OUT + 32;
+constexpr int VT_BLOBT_FLOATS = VT_OFFT_OUT2 + 32;
 
 struct PackArgs {
     vt_decoder_params p;
@@ -45,9 +46,12 @@ __global__ void decoder_pack_t_kernel(PackArgs a) {
             else if (L < 10) v = p.fc1_w[L - 5][k * 32 + i];
             else if (L < 15) v = p.fc0_w[L - 10][k * 32 + i];
             else v = (p.p_in > 3) ? p.fc_p_w[k * p.p_in + 3 + gather_row] : 0.0f;
-        } else {
+        } else if (e < VT_OFFT_OUT2) {
             const int q = e - VT_OFFT_OUT;
             v = p.fc_out_w[chan_of(q & 15, q >> 4)];
+        } else {
+            const int q = e - VT_OFFT_OUT2;
+            v = p.fc_out2_w ? p.fc_out2_w[chan_of(q & 15, q >> 4)] : 0.0f;
         }
         a.blob[e] = v;
     }
@@ -57,6 +61,7 @@ struct BwdArgs {
     DecodeArgs d;            // grid (unused), pts / lattice, c_img (only its presence), N, total, R, ...
     const float *blobT;
     const float *grad_out;   // [total]
+    const float *grad_out2;  // [total] gradient of the contact head's logits (forward_contact), or null
     const float *save;       // [12][total][32]
     float *gws;              // [11][total][32]
     float *grad_grid;        // [B,R,R,R,32] channels-last, accumulated
@@ -92,13 +97,20 @@ decode_bwd_data_kernel(BwdArgs a) {
         const float *srow = a.save + (size_t)g * 32;
         float *grow = a.gws + (size_t)g * 32;
 
-        // d net_5 = go * fc_out.weight (.) relu'(net_5)
+        // d net_5 = (go * fc_out.weight + go2 * fc_out_contact.weight) (.) relu'(net_5)
         f32x16 G;
         {
             const f32x16 wo = load_frag16(L + VT_OFFT_OUT + h * 16);
             const f32x16 rn = load_acc16(srow + 11 * slot, h);
+            if (a.grad_out2) {
+                const float go2 = live ? a.grad_out2[g] : 0.0f;
+                const f32x16 wo2 = load_frag16(L + VT_OFFT_OUT2 + h * 16);
 #pragma unroll
-            for (int s = 0; s < 16; ++s) G[s] = (rn[s] > 0.0f) ? go * wo[s] : 0.0f;
+                for (int s = 0; s < 16; ++s) G[s] = (rn[s] > 0.0f) ? fmaf(go2, wo2[s], go * wo[s]) : 0.0f;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) G[s] = (rn[s] > 0.0f) ? go * wo[s] : 0.0f;
+            }
         }
         f32x16 dc;
 #pragma unroll
@@ -191,13 +203,13 @@ sample_grid_bwd_kernel(DecodeArgs d, const float *grad_feat, float *grad_grid) {
 // ---- weight gradients ----------------------------------------------------------------------
 // jobs: 0..4 fc_c{i} (G: i==0 ? gws0 : gws[6+i-1]; X: save0)    5..9 fc_0{i} (gws[1+i], save[1+i])
 //       10..14 fc_1{i} (gws[6+i], save[6+i])    15 fc_p[:, :3] (gws0, pts)    16 fc_p_img[:, 3:] (gws0, c_img)
-//       17 fc_out (grad_out as row 0, save[11])
+//       17 fc_out (grad_out as row 0, the contact head's grad_out2 as row 1, save[11])
 constexpr int N_JOBS = 18;
 constexpr int CHUNK = 1024;
 constexpr int PART = 1024 + 32;       // D[16 regs][64 lanes] + column sums of G
 
 struct WgradArgs {
-    const float *save, *gws, *grad_out, *pts, *c_img;
+    const float *save, *gws, *grad_out, *grad_out2, *pts, *c_img;
     float *partial;          // [N_JOBS][nchunks][PART]
     DecodeArgs d;            // for lattice-mode points
     uint32_t total, nchunks;
@@ -228,7 +240,7 @@ decode_wgrad_kernel(WgradArgs a) {
         for (uint32_t p = p0 + kk; p < p1 + kk; p += 2) {     // each MFMA contracts two points
             const bool ok = p < p1;
             float gv, xv;
-            if (job == 17) gv = (ok && col == 0) ? a.grad_out[p] : 0.0f;
+            if (job == 17) gv = !ok ? 0.0f : (col == 0 ? a.grad_out[p] : ((col == 1 && a.grad_out2) ? a.grad_out2[p] : 0.0f));
             else gv = ok ? G[(size_t)p * 32 + col] : 0.0f;
             if (job == 15) {
                 xv = 0.0f;
@@ -259,6 +271,7 @@ struct ReduceArgs {
     float *out;              // flat parameter gradients, see vt_decode_wgrad
     uint32_t nchunks;
     int p_in;
+    int contact;             // 1: the flat buffer ends with fc_out_contact.w [32] | fc_out_contact.b [1]
 };
 
 // flat layout: fc_p.w [32*p_in] | fc_p.b [32] | fc_c.w [5][1024] | fc_c.b [5][32] | fc_0.w [5][1024] | fc_0.b [5][32]
@@ -270,7 +283,7 @@ decode_wgrad_reduce_kernel(ReduceArgs a) {
     const int off_cw = off_pb + 32, off_cb = off_cw + 5 * 1024;
     const int off_0w = off_cb + 5 * 32, off_0b = off_0w + 5 * 1024;
     const int off_1w = off_0b + 5 * 32, off_1b = off_1w + 5 * 1024;
-    const int off_ow = off_1b + 5 * 32, off_ob = off_ow + 32;
+    const int off_ow = off_1b + 5 * 32, off_ob = off_ow + 32, off_ow2 = off_ob + 1, off_ob2 = off_ow2 + 32;
     for (int e = threadIdx.x; e < PART; e += 256) {
         float s = 0.0f;
         const float *src = a.partial + (size_t)job * a.nchunks * PART + e;
@@ -282,7 +295,7 @@ decode_wgrad_reduce_kernel(ReduceArgs a) {
             else if (job < 15) a.out[off_1w + (job - 10) * 1024 + out * 32 + in] = s;
             else if (job == 15) { if (in < 3) a.out[off_pw + out * a.p_in + in] = s; }
             else if (job == 16) { if (a.p_in > 3) a.out[off_pw + out * a.p_in + 3 + in] = s; }
-            else { if (out == 0) a.out[off_ow + in] = s; }
+            else { if (out == 0) a.out[off_ow + in] = s; else if (out == 1 && a.contact) a.out[off_ow2 + in] = s; }
         } else {
             const int o = e - 1024;
             if (job == 0) { a.out[off_cb + o] = s; a.out[off_pb + o] = s; }
@@ -290,6 +303,7 @@ decode_wgrad_reduce_kernel(ReduceArgs a) {
             else if (job < 10) a.out[off_0b + (job - 5) * 32 + o] = s;
             else if (job < 15) a.out[off_1b + (job - 10) * 32 + o] = s;
             else if (job == 17 && o == 0) a.out[off_ob] = s;
+            else if (job == 17 && o == 1 && a.contact) a.out[off_ob2] = s;
         }
     }
 }
@@ -353,11 +367,19 @@ int vt_decode_bwd(int B, int R, int C, const float *pts, int64_t N,
                   int lattice_nx, float lattice_box, int64_t lattice_first, double padding,
                   const float *blob_t, const float *grad_out, const float *save, float *gws,
                   float *grad_grid_cl, float *grad_c_img, void *stream) {
+    return vt_decode_bwd_contact(B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, padding, blob_t, grad_out, nullptr, save, gws,
+                                 grad_grid_cl, grad_c_img, stream);
+}
+
+int vt_decode_bwd_contact(int B, int R, int C, const float *pts, int64_t N,
+                          int lattice_nx, float lattice_box, int64_t lattice_first, double padding,
+                          const float *blob_t, const float *grad_out, const float *grad_out2, const float *save, float *gws,
+                          float *grad_grid_cl, float *grad_c_img, void *stream) {
     if (!blob_t || !grad_out || !save || !gws) return vt_fail(VT_ERR_INVALID, "vt_decode_bwd: null argument");
     BwdArgs a;
     int rc;
     if (!fill_decode_args(a.d, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, padding, "vt_decode_bwd: bad size", rc)) return rc;
-    a.blobT = blob_t; a.grad_out = grad_out; a.save = save; a.gws = gws; a.grad_grid = grad_grid_cl; a.grad_c_img = grad_c_img;
+    a.blobT = blob_t; a.grad_out = grad_out; a.grad_out2 = grad_out2; a.save = save; a.gws = gws; a.grad_grid = grad_grid_cl; a.grad_c_img = grad_c_img;
     a.grad_c = nullptr;
     return decode_bwd_launch(a, stream);
 }
@@ -370,7 +392,7 @@ int vt_decode_mlp_bwd(int B, int C, const float *pts, int64_t N,
     BwdArgs a;
     int rc;
     if (!fill_decode_args(a.d, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, 0.1, "vt_decode_mlp_bwd: bad size", rc)) return rc;
-    a.blobT = blob_t; a.grad_out = grad_out; a.save = save; a.gws = gws; a.grad_grid = nullptr; a.grad_c_img = nullptr;
+    a.blobT = blob_t; a.grad_out = grad_out; a.grad_out2 = nullptr; a.save = save; a.gws = gws; a.grad_grid = nullptr; a.grad_c_img = nullptr;
     a.grad_c = grad_c;
     return decode_bwd_launch(a, stream);
 }
@@ -395,10 +417,18 @@ size_t vt_decode_wgrad_workspace_bytes(int64_t total_points) {
 }
 
 size_t vt_decode_wgrad_floats(int p_in) { return (size_t)32 * p_in + 32 + 3 * (5 * 1024 + 5 * 32) + 32 + 1; }
+size_t vt_decode_wgrad_floats_contact(int p_in) { return vt_decode_wgrad_floats(p_in) + 32 + 1; }
 
 int vt_decode_wgrad(int B, const float *pts, int64_t N, int lattice_nx, float lattice_box, int64_t lattice_first,
                     const float *c_img, const float *grad_out, const float *save, const float *gws,
                     void *workspace, size_t workspace_bytes, float *grads, void *stream) {
+    return vt_decode_wgrad_contact(B, pts, N, lattice_nx, lattice_box, lattice_first, c_img, grad_out, nullptr, save, gws,
+                                   workspace, workspace_bytes, grads, stream);
+}
+
+int vt_decode_wgrad_contact(int B, const float *pts, int64_t N, int lattice_nx, float lattice_box, int64_t lattice_first,
+                            const float *c_img, const float *grad_out, const float *grad_out2, const float *save, const float *gws,
+                            void *workspace, size_t workspace_bytes, float *grads, void *stream) {
     if (!grad_out || !save || !gws || !workspace || !grads) return vt_fail(VT_ERR_INVALID, "vt_decode_wgrad: null argument");
     WgradArgs a;
     int rc;
@@ -406,10 +436,10 @@ int vt_decode_wgrad(int B, const float *pts, int64_t N, int lattice_nx, float la
     a.total = a.d.total;
     a.nchunks = (a.total + CHUNK - 1) / CHUNK;
     if (workspace_bytes < (size_t)N_JOBS * a.nchunks * PART * sizeof(float)) return vt_fail(VT_ERR_WORKSPACE, "vt_decode_wgrad: workspace too small");
-    a.save = save; a.gws = gws; a.grad_out = grad_out; a.pts = pts; a.c_img = c_img; a.partial = (float *)workspace;
+    a.save = save; a.gws = gws; a.grad_out = grad_out; a.grad_out2 = grad_out2; a.pts = pts; a.c_img = c_img; a.partial = (float *)workspace;
     hipLaunchKernelGGL(decode_wgrad_kernel, dim3(a.nchunks, N_JOBS), dim3(256), 0, (hipStream_t)stream, a);
     ReduceArgs r;
-    r.partial = a.partial; r.out = grads; r.nchunks = a.nchunks; r.p_in = c_img ? 35 : 3;
+    r.partial = a.partial; r.out = grads; r.nchunks = a.nchunks; r.p_in = c_img ? 35 : 3; r.contact = grad_out2 ? 1 : 0;
     hipLaunchKernelGGL(decode_wgrad_reduce_kernel, dim3(N_JOBS), dim3(256), 0, (hipStream_t)stream, r);
     return vt_check(hipGetLastError(), "vt_decode_wgrad");
 }

@@ -508,9 +508,9 @@ def decode_save_buffer(total_points, device):
 
 
 def decode_bwd(grid_shape, blob_t, grad_out, save, pts=None, lattice=None, with_c_img=False, c_img=None,
-               padding=0.1, want_grid_grad=True):
-    """vt_decode_bwd + vt_decode_wgrad.  Returns (grad_grid [B,C,R,R,R] channels-last strided
-    or None, grad_c_img [B,N,C] or None, flat parameter gradients)."""
+               padding=0.1, want_grid_grad=True, grad_out2=None):
+    """vt_decode_bwd + vt_decode_wgrad (with ``grad_out2``, the contact head's logit gradient: the _contact forms).
+    Returns (grad_grid [B,C,R,R,R] channels-last strided or None, grad_c_img [B,N,C] or None, flat parameter gradients)."""
     lib = _lib.load()
     B, C, R = grid_shape[0], grid_shape[1], grid_shape[2]
     grad_out = _c(grad_out.float())
@@ -526,17 +526,21 @@ def decode_bwd(grid_shape, blob_t, grad_out, save, pts=None, lattice=None, with_
     ggrid = torch.zeros((B, R, R, R, C), dtype=torch.float32, device=dev) if want_grid_grad else None
     gimg = torch.empty((B, N, C), dtype=torch.float32, device=dev) if with_c_img else None
     st = stream_ptr()
-    check(lib.vt_decode_bwd(B, R, C, dev_ptr(pts, "pts"), N, nx, box, first, float(padding),
-                            dev_ptr(blob_t, "blob_t"), dev_ptr(grad_out, "grad_out"), dev_ptr(save, "save"),
-                            dev_ptr(gws, "gws"), dev_ptr(ggrid, "grad_grid"), dev_ptr(gimg, "grad_c_img"), st), "vt_decode_bwd")
+    g2 = _c(grad_out2.float()) if grad_out2 is not None else None
+    check(lib.vt_decode_bwd_contact(B, R, C, dev_ptr(pts, "pts"), N, nx, box, first, float(padding),
+                                    dev_ptr(blob_t, "blob_t"), dev_ptr(grad_out, "grad_out"), dev_ptr(g2, "grad_out2"),
+                                    dev_ptr(save, "save"), dev_ptr(gws, "gws"), dev_ptr(ggrid, "grad_grid"),
+                                    dev_ptr(gimg, "grad_c_img"), st), "vt_decode_bwd")
     wsb = lib.vt_decode_wgrad_workspace_bytes(total)
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
     p_in = 3 + C if with_c_img else 3
-    flat = torch.empty(lib.vt_decode_wgrad_floats(p_in), dtype=torch.float32, device=dev)
+    nflat = lib.vt_decode_wgrad_floats_contact(p_in) if g2 is not None else lib.vt_decode_wgrad_floats(p_in)
+    flat = torch.empty(nflat, dtype=torch.float32, device=dev)
     ci = _c(c_img) if with_c_img else None
-    check(lib.vt_decode_wgrad(B, dev_ptr(pts, "pts"), N, nx, box, first, dev_ptr(ci, "c_img"),
-                              dev_ptr(grad_out, "grad_out"), dev_ptr(save, "save"), dev_ptr(gws, "gws"),
-                              ctypes.c_void_p(ws.data_ptr()), wsb, dev_ptr(flat, "grads"), st), "vt_decode_wgrad")
+    check(lib.vt_decode_wgrad_contact(B, dev_ptr(pts, "pts"), N, nx, box, first, dev_ptr(ci, "c_img"),
+                                      dev_ptr(grad_out, "grad_out"), dev_ptr(g2, "grad_out2"), dev_ptr(save, "save"),
+                                      dev_ptr(gws, "gws"), ctypes.c_void_p(ws.data_ptr()), wsb, dev_ptr(flat, "grads"), st),
+          "vt_decode_wgrad")
     return (ggrid.permute(0, 4, 1, 2, 3) if ggrid is not None else None), gimg, flat
 
 
@@ -558,6 +562,9 @@ def split_decoder_grads(flat, p_in, hidden=32, c_dim=32, nb=5):
     g["fc_1.bias"] = take(nb * hidden, (nb, hidden))
     g["fc_out.weight"] = take(hidden, (1, hidden))
     g["fc_out.bias"] = take(1, (1,))
+    if flat.numel() - o >= hidden + 1:                  # the _contact layout
+        g["fc_out_contact.weight"] = take(hidden, (1, hidden))
+        g["fc_out_contact.bias"] = take(1, (1,))
     return g
 
 
