@@ -518,6 +518,22 @@ int vt_linear_rows(const float *x, const float *w, const float *b, int64_t N, in
 int vt_resblock_fc(const float *x1, int C1, const float *x2, int C2, int64_t N,
                    const float *w0, const float *b0, const float *w1, const float *b1, const float *ws,
                    int H, int O, float *out, void *stream);
+/* Backward of the two (training; PyTorch autograd of layers.py:8-50 and of the nn.Linear calls at    */
+/* pointnet.py:154-162 under loss.backward(), training.py:79,89,96):                                    */
+/*   vt_resblock_fc_bwd  d out [N][O] -> d x1 [N][C1], d x2 [N][C2] (NULL: not wanted), and the two       */
+/*                       [N][H] tensors the weight gradients contract over: act = relu(h) (recomputed)   */
+/*                       and dh = (W1^T d out) . [h > 0];                                                 */
+/*   vt_rows_wgrad       dW [M][K] = sum_n G[n][m] X[n][k], db [M] = sum_n G[n][m] (db may be NULL) with    */
+/*                       X = [x1 | x2] (x2 may be NULL), relu'd when relu_x: f32 MFMA outer products over  */
+/*                       1024-point chunks, partials summed in chunk order (bit-reproducible).             */
+/*                       fc_1: (d out, act); fc_0: (dh, relu [x1|x2]); shortcut: (d out, [x1|x2]);          */
+/*                       a plain linear layer: (d out, x).  Its data gradient is vt_linear_rows on W^T.     */
+int vt_resblock_fc_bwd(const float *x1, int C1, const float *x2, int C2, int64_t N,
+                       const float *w0, const float *b0, const float *w1, const float *ws, int H, int O,
+                       const float *dout, float *dx1, float *dx2, float *act, float *dh, void *stream);
+size_t vt_rows_wgrad_workspace_bytes(int64_t N, int M, int K);
+int vt_rows_wgrad(const float *G, int M, const float *x1, int C1, const float *x2, int C2, int relu_x, int64_t N,
+                  void *workspace, size_t workspace_bytes, float *dW, float *db, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* Generalized winding number of query points against a triangle mesh.          */

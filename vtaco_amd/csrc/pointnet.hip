@@ -111,6 +111,123 @@ resblock_fc_kernel(const float *x1, int C1, const float *x2, int C2, int N,
     }
 }
 
+// ---- backward (training): autograd of the layers above (reference: loss.backward() through src/layers.py:8-50 and the
+// nn.Linear calls of pointnet.py:154-162) ---------------------------------------------------------------------------
+// natural-layout copy w[rows][n] -> LDS [rows][ld]: sum_j w[j][k] v[j] is then dot_cols(w, ld, k, v, rows)
+__device__ __forceinline__ void copy_to_lds(float *dst, int ld, const float *w, int rows, int n) {
+    for (int i = threadIdx.x; i < rows * n; i += PN_THREADS) { const int j = i / n, k = i - j * n; dst[j * ld + k] = w[i]; }
+}
+
+// Data gradient of ResnetBlockFC at the rows [x1 | x2] given d out [N][O]:
+//   h = b0 + W0 relu(x) (recomputed), a = relu(h);  d h = (W1^T d out) . [h > 0];  d x = (W0^T d h) . [x > 0] + Ws^T d out (or + d out)
+// Writes d x1 / d x2 and leaves a and d h ([N][H] each) for the weight-gradient GEMMs.
+__global__ void __launch_bounds__(PN_THREADS)
+resblock_fc_bwd_kernel(const float *x1, int C1, const float *x2, int C2, int N,
+                       const float *w0, const float *b0, const float *w1, const float *ws, int H, int O,
+                       const float *dout, float *dx1, float *dx2, float *act, float *dh) {
+    extern __shared__ float lds[];   // w0t [C][H|1] | w0n [H][C|1] | w1n [O][H|1] | wsn [O][C|1] | xr [PTS][C] | dor [PTS][O] | dhr [PTS][H] | hr [PTS][H]
+    const int C = C1 + C2;
+    int width = C > H ? C : H; if (O > width) width = O;
+    const int pts = PN_THREADS / width;
+    const int ldh = H | 1, ldc = C | 1;
+    float *w0t = lds, *w0n = w0t + (size_t)C * ldh, *w1n = w0n + (size_t)H * ldc, *wsn = w1n + (size_t)O * ldh;
+    float *xr = wsn + (ws ? (size_t)O * ldc : 0), *dor = xr + (size_t)pts * C, *dhr = dor + (size_t)pts * O, *hr = dhr + (size_t)pts * H;
+    transpose_to_lds(w0t, ldh, w0, H, C);
+    copy_to_lds(w0n, ldc, w0, H, C);
+    copy_to_lds(w1n, ldh, w1, O, H);
+    if (ws) copy_to_lds(wsn, ldc, ws, O, C);
+    const int lp = threadIdx.x / width, j = threadIdx.x - lp * width;
+    for (int n0 = blockIdx.x * pts; n0 < N; n0 += gridDim.x * pts) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < pts * C; i += PN_THREADS) {
+            const int pq = i / C, k = i - pq * C, n = n0 + pq;
+            float v = 0.0f;
+            if (n < N) v = k < C1 ? x1[(size_t)n * C1 + k] : x2[(size_t)n * C2 + (k - C1)];
+            xr[i] = v;
+        }
+        for (int i = threadIdx.x; i < pts * O; i += PN_THREADS) {
+            const int pq = i / O, n = n0 + pq;
+            dor[i] = n < N ? dout[(size_t)n * O + (i - pq * O)] : 0.0f;
+        }
+        __syncthreads();
+        const int n = n0 + lp;
+        const bool live = lp < pts && n < N;
+        const float *r = xr + lp * C, *go = dor + lp * O;
+        if (live && j < H) {
+            const float h = b0[j] + dot_cols<true>(w0t, ldh, j, r, C);
+            hr[lp * H + j] = h;
+            act[(size_t)n * H + j] = fmaxf(h, 0.0f);
+            const float da = dot_cols<false>(w1n, ldh, j, go, O);
+            const float g = h > 0.0f ? da : 0.0f;
+            dhr[lp * H + j] = g;
+            dh[(size_t)n * H + j] = g;
+        }
+        __syncthreads();
+        if (live && j < C) {
+            const float back = dot_cols<false>(w0n, ldc, j, dhr + lp * H, H);
+            const float v = (r[j] > 0.0f ? back : 0.0f) + (ws ? dot_cols<false>(wsn, ldc, j, go, O) : go[j]);
+            if (j < C1) dx1[(size_t)n * C1 + j] = v;
+            else if (dx2) dx2[(size_t)n * C2 + (j - C1)] = v;
+        }
+    }
+}
+
+// Weight gradient of a linear layer over tall inputs: dW[m][k] = sum_n G[n][m] X[n][k], db[m] = sum_n G[n][m], with
+// X = [x1 | x2] (optionally relu'd), as f32 MFMA outer products (two points per v_mfma_f32_32x32x2_f32) over chunks of
+// 1024 points; the per-chunk partials are summed in chunk order by rows_wgrad_reduce_kernel (bit-reproducible).
+typedef float pf32x16 __attribute__((ext_vector_type(16)));
+constexpr int RW_CHUNK = 1024, RW_PART = 1024 + 32;
+
+__global__ void __launch_bounds__(256)
+rows_wgrad_kernel(const float *G, int M, const float *x1, int C1, const float *x2, int C2, int relu_x, int N, float *partial) {
+    __shared__ float red[4][RW_PART];
+    const int K = C1 + C2;
+    const int chunk = blockIdx.x, mt = blockIdx.y, kt = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, kk = lane >> 5;
+    const int m = mt * 32 + col, k = kt * 32 + col;
+    pf32x16 acc;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = 0.0f;
+    float csum = 0.0f;
+    const int p0 = chunk * RW_CHUNK + wave * (RW_CHUNK / 4);
+    const int p1 = min(p0 + RW_CHUNK / 4, N);
+    for (int p = p0 + kk; p < p1 + kk; p += 2) {             // each MFMA contracts two points
+        const bool ok = p < p1;
+        const float gv = (ok && m < M) ? G[(size_t)p * M + m] : 0.0f;
+        float xv = 0.0f;
+        if (ok && k < K) {
+            xv = k < C1 ? x1[(size_t)p * C1 + k] : x2[(size_t)p * C2 + (k - C1)];
+            if (relu_x) xv = fmaxf(xv, 0.0f);
+        }
+        csum += gv;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, xv, acc, 0, 0, 0);     // D[m][k] += G[p][m] * X[p][k]
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) red[wave][s * 64 + lane] = acc[s];
+    csum += __shfl_xor(csum, 32);
+    if (lane < 32) red[wave][1024 + lane] = csum;
+    __syncthreads();
+    float *dst = partial + (((size_t)chunk * gridDim.y + mt) * gridDim.z + kt) * RW_PART;
+    for (int e = threadIdx.x; e < RW_PART; e += 256) dst[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+__global__ void __launch_bounds__(256)
+rows_wgrad_reduce_kernel(const float *partial, int nchunks, int M, int K, int MT, int KT, float *dW, float *db) {
+    const int mt = blockIdx.x, kt = blockIdx.y;
+    for (int e = threadIdx.x; e < RW_PART; e += 256) {
+        float s = 0.0f;
+        for (int c = 0; c < nchunks; ++c) s += partial[(((size_t)c * MT + mt) * KT + kt) * RW_PART + e];
+        if (e < 1024) {
+            const int r = e >> 6, l = e & 63;
+            const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), k = kt * 32 + (l & 31);   // accumulator row of register r, lane half
+            if (m < M && k < K) dW[(size_t)m * K + k] = s;
+        } else if (kt == 0 && db) {
+            const int m = mt * 32 + (e - 1024);
+            if (m < M) db[m] = s;
+        }
+    }
+}
+
 inline unsigned rows_grid(int N, int pts) {
     size_t g = ((size_t)N + pts - 1) / pts;
     const size_t cap = (size_t)vt_num_cus() * 4;
@@ -149,6 +266,47 @@ int vt_resblock_fc(const float *x1, int C1, const float *x2, int C2, int64_t N,
     hipLaunchKernelGGL(resblock_fc_kernel, dim3(rows_grid((int)N, pts)), dim3(PN_THREADS), lds, (hipStream_t)stream,
                        x1, C1, x2, C2, (int)N, w0, b0, w1, b1, ws, H, O, out);
     return vt_check(hipGetLastError(), "vt_resblock_fc");
+}
+
+int vt_resblock_fc_bwd(const float *x1, int C1, const float *x2, int C2, int64_t N,
+                       const float *w0, const float *b0, const float *w1, const float *ws, int H, int O,
+                       const float *dout, float *dx1, float *dx2, float *act, float *dh, void *stream) {
+    if (N == 0) return 0;
+    if (!x1 || C1 <= 0 || (x2 && C2 <= 0) || !w0 || !b0 || !w1 || !dout || !dx1 || !act || !dh || N < 0 || N > INT32_MAX || H <= 0 || O <= 0)
+        return vt_fail(VT_ERR_INVALID, "vt_resblock_fc_bwd: bad argument");
+    if (!x2) C2 = 0;
+    const int C = C1 + C2;
+    if (!ws && C != O) return vt_fail(VT_ERR_INVALID, "vt_resblock_fc_bwd: no shortcut layer needs size_in == size_out");
+    int width = C > H ? C : H; if (O > width) width = O;
+    if (width > PN_THREADS) return vt_fail(VT_ERR_UNSUPPORTED, "vt_resblock_fc_bwd: more than 256 channels");
+    const int pts = PN_THREADS / width;
+    const size_t lds = ((size_t)C * (H | 1) + (size_t)H * (C | 1) + (size_t)O * (H | 1) + (ws ? (size_t)O * (C | 1) : 0) +
+                        (size_t)pts * (C + O + 2 * H)) * sizeof(float);
+    if (lds > 64 * 1024) return vt_fail(VT_ERR_UNSUPPORTED, "vt_resblock_fc_bwd: weights do not fit 64 KiB of LDS");
+    hipLaunchKernelGGL(resblock_fc_bwd_kernel, dim3(rows_grid((int)N, pts)), dim3(PN_THREADS), lds, (hipStream_t)stream,
+                       x1, C1, x2, C2, (int)N, w0, b0, w1, ws, H, O, dout, dx1, dx2, act, dh);
+    return vt_check(hipGetLastError(), "vt_resblock_fc_bwd");
+}
+
+size_t vt_rows_wgrad_workspace_bytes(int64_t N, int M, int K) {
+    if (N <= 0 || M <= 0 || K <= 0) return 0;
+    const size_t nchunks = (size_t)((N + RW_CHUNK - 1) / RW_CHUNK);
+    return nchunks * (size_t)((M + 31) / 32) * (size_t)((K + 31) / 32) * RW_PART * sizeof(float);
+}
+
+int vt_rows_wgrad(const float *G, int M, const float *x1, int C1, const float *x2, int C2, int relu_x, int64_t N,
+                  void *workspace, size_t workspace_bytes, float *dW, float *db, void *stream) {
+    if (!G || M <= 0 || !x1 || C1 <= 0 || (x2 && C2 <= 0) || N <= 0 || N > INT32_MAX || !workspace || !dW)
+        return vt_fail(VT_ERR_INVALID, "vt_rows_wgrad: bad argument");
+    if (!x2) C2 = 0;
+    const int K = C1 + C2, MT = (M + 31) / 32, KT = (K + 31) / 32;
+    const int nchunks = (int)((N + RW_CHUNK - 1) / RW_CHUNK);
+    if (workspace_bytes < vt_rows_wgrad_workspace_bytes(N, M, K)) return vt_fail(VT_ERR_WORKSPACE, "vt_rows_wgrad: workspace too small");
+    hipLaunchKernelGGL(rows_wgrad_kernel, dim3(nchunks, MT, KT), dim3(256), 0, (hipStream_t)stream,
+                       G, M, x1, C1, x2, C2, relu_x, (int)N, (float *)workspace);
+    hipLaunchKernelGGL(rows_wgrad_reduce_kernel, dim3(MT, KT), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)workspace, nchunks, M, K, MT, KT, dW, db);
+    return vt_check(hipGetLastError(), "vt_rows_wgrad");
 }
 
 }  // extern "C"

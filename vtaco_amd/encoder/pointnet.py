@@ -39,6 +39,52 @@ class _PoolMax(torch.autograd.Function):
         return ops.voxel_pool_max_bwd(grad, ctx.arg, ctx.vi), None
 
 
+class _LinearRowsFn(torch.autograd.Function):
+    """nn.Linear over the rows of [B,T,Cin] on the HIP kernels: forward vt_linear_rows; backward vt_linear_rows on the
+    transposed weight (data gradient) and vt_rows_wgrad (weight / bias gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return ops.linear_rows(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = ops.linear_rows(dy, weight.t().contiguous(), None) if ctx.needs_input_grad[0] else None
+        dw, db = ops.rows_wgrad(dy, x, want_bias=ctx.has_bias)
+        return dx, dw, db
+
+
+class _ResBlockFcFn(torch.autograd.Function):
+    """ResnetBlockFC on the virtual concat [x1 | x2] (layers.py:8-50): forward vt_resblock_fc, backward
+    vt_resblock_fc_bwd (data gradient; h is recomputed) + three vt_rows_wgrad calls (fc_1, fc_0, shortcut)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w0, b0, w1, b1, ws):
+        ctx.save_for_backward(x1, x2, w0, b0, w1, ws)
+        lib = ops._lib.load()
+        C1, C2 = x1.shape[-1], (x2.shape[-1] if x2 is not None else 0)
+        H, O = w0.shape[0], w1.shape[0]
+        out = torch.empty(x1.shape[:-1] + (O,), dtype=torch.float32, device=x1.device)
+        c = ops._c
+        ops.check(lib.vt_resblock_fc(ops.dev_ptr(c(x1), "x1"), C1, ops.dev_ptr(c(x2) if x2 is not None else None, "x2"), C2,
+                                     x1.numel() // C1, ops.dev_ptr(c(w0), "w0"), ops.dev_ptr(c(b0), "b0"), ops.dev_ptr(c(w1), "w1"),
+                                     ops.dev_ptr(c(b1), "b1"), ops.dev_ptr(c(ws) if ws is not None else None, "ws"), H, O,
+                                     ops.dev_ptr(out, "out"), ops.stream_ptr()), "vt_resblock_fc")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x1, x2, w0, b0, w1, ws = ctx.saved_tensors
+        dx1, dx2, act, dh = ops.resblock_fc_bwd(x1, x2, w0, b0, w1, ws, dout, want_dx2=x2 is not None and ctx.needs_input_grad[1])
+        dw1, db1 = ops.rows_wgrad(dout, act)
+        dw0, db0 = ops.rows_wgrad(dh, x1, x2, relu_x=True)
+        dws = ops.rows_wgrad(dout, x1, x2, want_bias=False)[0] if ws is not None else None
+        return dx1, dx2, dw0, db0, dw1, db1, dws
+
+
 class _ScatterMean(torch.autograd.Function):
     """generate_grid_features' scatter (pointnet.py:102-110)."""
 
@@ -133,13 +179,23 @@ class LocalPoolPointnet(nn.Module):
         # UNet3D under autograd: "hip" = vt_* forward and backward kernels (UNet3D.forward_channels_last_train),
         # "host" = PyTorch-ROCm autograd (MIOpen; fast only in find mode, torch.backends.cudnn.benchmark = True)
         self.train_unet3d = os.environ.get("VTACO_TRAIN_UNET3D", "hip")
+        # the per-point MLP under autograd: "hip" = vt_linear_rows / vt_resblock_fc forward, vt_resblock_fc_bwd / vt_rows_wgrad
+        # backward; "host" = nn.Linear (hipBLASLt) with the split-K weight gradient of layers._TallLinear
+        self.train_mlp = os.environ.get("VTACO_TRAIN_POINTNET_MLP", "hip")
 
     def point_features(self, p, vi):
         """fc_pos -> block0 -> 4 x (local max-pool, concat, block) -> fc_c  (pointnet.py:154-162).
         ``vi``: one VoxelIndex, or a list of PlaneIndex whose pooled features are summed (pointnet.py:116-132)."""
         if not torch.is_grad_enabled() and self._fused_mlp_fits():
             return self._point_features_fused(p, vi)
-        net = self.blocks[0](tall_linear(self.fc_pos, p))
+        hip = self._fused_mlp_fits() and self.train_mlp == "hip"
+
+        def block(blk, x1, x2=None):
+            if hip:          # HIP forward and backward (the concat with the pooled features is read in place)
+                return _ResBlockFcFn.apply(x1, x2, blk.fc_0.weight, blk.fc_0.bias, blk.fc_1.weight, blk.fc_1.bias,
+                                           blk.shortcut.weight if blk.shortcut is not None else None)
+            return blk(x1 if x2 is None else torch.cat([x1, x2], dim=2))
+        net = block(self.blocks[0], _LinearRowsFn.apply(p, self.fc_pos.weight, self.fc_pos.bias) if hip else tall_linear(self.fc_pos, p))
         for blk in self.blocks[1:]:
             if isinstance(vi, (list, tuple)):
                 pooled = _PoolMax.apply(net, vi[0])
@@ -147,7 +203,9 @@ class LocalPoolPointnet(nn.Module):
                     pooled = pooled + _PoolMax.apply(net, other)
             else:
                 pooled = _PoolMax.apply(net, vi)
-            net = blk(torch.cat([net, pooled], dim=2))
+            net = block(blk, net, pooled)
+        if hip:
+            return _LinearRowsFn.apply(net, self.fc_c.weight, self.fc_c.bias)
         return tall_linear(self.fc_c, net)
 
     def _fused_mlp_fits(self):

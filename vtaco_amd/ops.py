@@ -414,6 +414,43 @@ def resblock_fc(x1, x2, fc_0, fc_1, shortcut):
     return out
 
 
+def resblock_fc_bwd(x1, x2, fc_0_w, fc_0_b, fc_1_w, shortcut_w, dout, want_dx2=True):
+    """vt_resblock_fc_bwd: (dx1, dx2 or None, act = relu(h) [.., H], dh [.., H])."""
+    x1, dout = _c(x1), _c(dout)
+    x2 = _c(x2) if x2 is not None else None
+    C1, C2 = x1.shape[-1], (x2.shape[-1] if x2 is not None else 0)
+    H, O = fc_0_w.shape[0], fc_1_w.shape[0]
+    N = x1.numel() // C1
+    dev = x1.device
+    dx1 = torch.empty_like(x1)
+    dx2 = torch.empty_like(x2) if (x2 is not None and want_dx2) else None
+    act = torch.empty(x1.shape[:-1] + (H,), dtype=torch.float32, device=dev)
+    dh = torch.empty_like(act)
+    check(_lib.load().vt_resblock_fc_bwd(dev_ptr(x1, "x1"), C1, dev_ptr(x2, "x2"), C2, N, dev_ptr(_c(fc_0_w), "fc_0.weight"),
+                                         dev_ptr(_c(fc_0_b), "fc_0.bias"), dev_ptr(_c(fc_1_w), "fc_1.weight"),
+                                         dev_ptr(_c(shortcut_w) if shortcut_w is not None else None, "shortcut.weight"), H, O,
+                                         dev_ptr(dout, "dout"), dev_ptr(dx1, "dx1"), dev_ptr(dx2, "dx2"), dev_ptr(act, "act"),
+                                         dev_ptr(dh, "dh"), stream_ptr()), "vt_resblock_fc_bwd")
+    return dx1, dx2, act, dh
+
+
+def rows_wgrad(g, x1, x2=None, relu_x=False, want_bias=True):
+    """vt_rows_wgrad: dW [M, K] = g^T [x1 | x2] over the rows (x relu'd when ``relu_x``), db [M] = column sums of g."""
+    g, x1 = _c(g), _c(x1)
+    x2 = _c(x2) if x2 is not None else None
+    M, C1, C2 = g.shape[-1], x1.shape[-1], (x2.shape[-1] if x2 is not None else 0)
+    N = g.numel() // M
+    lib = _lib.load()
+    dev = g.device
+    wsb = lib.vt_rows_wgrad_workspace_bytes(N, M, C1 + C2)
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+    dW = torch.empty((M, C1 + C2), dtype=torch.float32, device=dev)
+    db = torch.empty((M,), dtype=torch.float32, device=dev) if want_bias else None
+    check(lib.vt_rows_wgrad(dev_ptr(g, "g"), M, dev_ptr(x1, "x1"), C1, dev_ptr(x2, "x2"), C2, int(relu_x), N,
+                            ctypes.c_void_p(ws.data_ptr()), wsb, dev_ptr(dW, "dW"), dev_ptr(db, "db"), stream_ptr()), "vt_rows_wgrad")
+    return dW, db
+
+
 # --------------------------------------------------------------------------------------
 # hand branch: plane bookkeeping (vt_plane_*) and the MANO layer (vt_mano_*)
 # --------------------------------------------------------------------------------------
