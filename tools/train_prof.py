@@ -56,6 +56,9 @@ pr.disable()
 buf = io.StringIO()
 pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(35)
 print(buf.getvalue()[:6000])
+buf = io.StringIO()
+pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_callers("'item'|'cpu'|synchronize")     # who waits for the device
+print(buf.getvalue()[:5000])
 
 # ---- the tactile feature encoder alone (host PyTorch-ROCm / MIOpen): default vs find mode, NCHW vs channels_last
 if os.environ.get("VTACO_PROF_RESNET"):

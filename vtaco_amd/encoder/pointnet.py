@@ -195,7 +195,11 @@ class LocalPoolPointnet(nn.Module):
                 return _ResBlockFcFn.apply(x1, x2, blk.fc_0.weight, blk.fc_0.bias, blk.fc_1.weight, blk.fc_1.bias,
                                            blk.shortcut.weight if blk.shortcut is not None else None)
             return blk(x1 if x2 is None else torch.cat([x1, x2], dim=2))
-        net = block(self.blocks[0], _LinearRowsFn.apply(p, self.fc_pos.weight, self.fc_pos.bias) if hip else tall_linear(self.fc_pos, p))
+        def linear(lin, x):
+            if hip and self._linear_fits(lin):
+                return _LinearRowsFn.apply(x, lin.weight, lin.bias)
+            return tall_linear(lin, x)
+        net = block(self.blocks[0], linear(self.fc_pos, p))
         for blk in self.blocks[1:]:
             if isinstance(vi, (list, tuple)):
                 pooled = _PoolMax.apply(net, vi[0])
@@ -204,9 +208,7 @@ class LocalPoolPointnet(nn.Module):
             else:
                 pooled = _PoolMax.apply(net, vi)
             net = block(blk, net, pooled)
-        if hip:
-            return _LinearRowsFn.apply(net, self.fc_c.weight, self.fc_c.bias)
-        return tall_linear(self.fc_c, net)
+        return linear(self.fc_c, net)
 
     def _fused_mlp_fits(self):
         """vt_resblock_fc keeps a block's three weight matrices in 64 KiB of LDS (hidden_dim <= 48 or so: the shipped
@@ -215,10 +217,18 @@ class LocalPoolPointnet(nn.Module):
         floats = 2 * h * h + h * h + 2 * h * h + (256 // h if h <= 256 else 0) * 3 * h
         return h <= 256 and floats * 4 <= 64 * 1024 and 2 * h <= 256
 
+    @staticmethod
+    def _linear_fits(lin):
+        """vt_linear_rows: at most 256 output channels, the transposed weight and a few input rows in 64 KiB of LDS (the t2d hand
+        encoder's fc_c -- 32 -> 512 -- does not: it keeps nn.Linear)."""
+        cout, cin = lin.weight.shape
+        return cout <= 256 and (cin * (cout | 1) + max(1, 256 // cout) * cin) * 4 <= 64 * 1024
+
     def _point_features_fused(self, p, vi):
         """The same layers without autograd: one HIP launch per linear layer / ResnetBlockFC (vt_linear_rows,
         vt_resblock_fc, the concat with the pooled features read in place) instead of ~9 framework launches per block."""
-        net = ops.linear_rows(p, self.fc_pos.weight, self.fc_pos.bias)
+        lin = lambda l, x: ops.linear_rows(x, l.weight, l.bias) if self._linear_fits(l) else l(x)
+        net = lin(self.fc_pos, p)
         b0 = self.blocks[0]
         net = ops.resblock_fc(net, None, b0.fc_0, b0.fc_1, b0.shortcut)
         for blk in self.blocks[1:]:
@@ -229,7 +239,7 @@ class LocalPoolPointnet(nn.Module):
             else:
                 pooled = ops.voxel_pool_max_fwd(net, vi, want_argmax=False)[0]
             net = ops.resblock_fc(net, pooled, blk.fc_0, blk.fc_1, blk.shortcut)
-        return ops.linear_rows(net, self.fc_c.weight, self.fc_c.bias)
+        return lin(self.fc_c, net)
 
     def _mano_head(self, fea):
         """out_mano (pointnet.py:179-201): pooled plane/grid features -> mano_param (-> MANO layer)."""
