@@ -313,14 +313,21 @@ __device__ __forceinline__ float level_threshold(double level) {
 // wave would run the expensive branch with most lanes idle.  Each kernel therefore first COMPACTS its
 // workgroup's active cells into an LDS list (ballot + prefix) and then processes the list densely.
 
+// inclusive prefix over the wave on the DPP path (row shifts, then the row-15 / row-31 broadcasts): six adds, no LDS round trip
+__device__ __forceinline__ unsigned wave_incl_scan_dpp(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);      // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);      // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);      // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);      // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1, 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);      // row_bcast:31 into rows 2, 3
+    return v;
+}
+
 // block-wide exclusive scan of (a,b) pairs over 256 threads; returns exclusive prefix, totals in tot
 __device__ __forceinline__ uint2 block_exscan(unsigned a, unsigned b, uint2 *lds /*[4]*/, uint2 &tot) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned ia = a, ib = b;
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned ta = __shfl_up(ia, o), tb = __shfl_up(ib, o);
-        if (lane >= o) { ia += ta; ib += tb; }
-    }
+    const unsigned ia = wave_incl_scan_dpp(a), ib = wave_incl_scan_dpp(b);
     if (lane == 63) lds[w] = make_uint2(ia, ib);
     __syncthreads();
     unsigned oa = 0, ob = 0, sa = 0, sb = 0;
@@ -451,48 +458,51 @@ mc_classify_kernel(const float *vol, McDims d, McWs ws, double level_in, int aut
     if (blockIdx.x == 0 && threadIdx.x == 0) ws.hdr->level = level;
 }
 
-// one block: exclusive scan of the per-block sums
+// one block: exclusive scan of the per-block sums.  Every wave owns a contiguous 1/16 of the table and walks it in
+// rows of 64 entries (one coalesced 512-byte load per row, SC_BATCH rows in flight): pass 1 adds its rows up for the
+// wave's total, pass 2 -- after the 16 totals met in LDS -- re-reads them (L2) and writes the exclusive offsets, a
+// DPP prefix per row plus a running carry.  (The table has 8 192 entries at 128^3 and 65 536 at 256^3; a thread
+// walking its own 64 strided entries took 134 us there.)
+constexpr int SC_BATCH = 16;
+
 __global__ void __launch_bounds__(1024) mc_scan_kernel(McWs ws, unsigned nblk) {
     __shared__ uint2 wtot[16];
-    const unsigned per = (nblk + 1023) / 1024;
-    const unsigned lo = threadIdx.x * per, hi = min(lo + per, nblk);
-    unsigned a = 0, b = 0;
-    uint2 v[8];                                                  // up to 8 entries per thread (128^3) stay in registers:
-    const bool small = per <= 8;                                 // independent loads instead of a dependent chain
-    if (small) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (lo + k < hi) ? ws.bsum[lo + k] : make_uint2(0u, 0u);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { a += v[k].x; b += v[k].y; }
-    } else {
-        for (unsigned i = lo; i < hi; ++i) { a += ws.bsum[i].x; b += ws.bsum[i].y; }
-    }
-    // inclusive scan of the 1024 per-thread sums: shuffles inside a wave, then the 16 wave totals
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned ia = a, ib = b;
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned ta = __shfl_up(ia, o), tb = __shfl_up(ib, o);
-        if (lane >= o) { ia += ta; ib += tb; }
+    const unsigned rows = ((nblk + 1023) / 1024), seg = rows * 64;            // rows per wave, entries per wave
+    const unsigned lo = (unsigned)w * seg;
+    unsigned a = 0, b = 0;
+    for (unsigned r0 = 0; r0 < rows; r0 += SC_BATCH) {
+        uint2 v[SC_BATCH];
+#pragma unroll
+        for (int k = 0; k < SC_BATCH; ++k) {
+            const unsigned i = lo + (r0 + k) * 64 + lane;
+            v[k] = (r0 + k < rows && i < nblk) ? ws.bsum[i] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < SC_BATCH; ++k) { a += v[k].x; b += v[k].y; }
     }
-    if (lane == 63) wtot[w] = make_uint2(ia, ib);
+    a = wave_incl_scan_dpp(a); b = wave_incl_scan_dpp(b);
+    if (lane == 63) wtot[w] = make_uint2(a, b);
     __syncthreads();
-    unsigned oa = 0, ob = 0, sa = 0, sb = 0;
+    unsigned ca = 0, cb = 0, sa = 0, sb = 0;                                  // carry = totals of the waves before this one
     for (int i = 0; i < 16; ++i) {
-        if (i < w) { oa += wtot[i].x; ob += wtot[i].y; }
+        if (i < w) { ca += wtot[i].x; cb += wtot[i].y; }
         sa += wtot[i].x; sb += wtot[i].y;
     }
-    unsigned ra = oa + ia - a, rb = ob + ib - b;                  // exclusive prefix of this thread's first entry
-    if (small) {
+    for (unsigned r0 = 0; r0 < rows; r0 += SC_BATCH) {
+        uint2 v[SC_BATCH];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (lo + k < hi) ws.boff[lo + k] = make_uint2(ra, rb);
-            ra += v[k].x; rb += v[k].y;
+        for (int k = 0; k < SC_BATCH; ++k) {
+            const unsigned i = lo + (r0 + k) * 64 + lane;
+            v[k] = (r0 + k < rows && i < nblk) ? ws.bsum[i] : make_uint2(0u, 0u);
         }
-    } else {
-        for (unsigned i = lo; i < hi; ++i) {
-            const uint2 s = ws.bsum[i];
-            ws.boff[i] = make_uint2(ra, rb);
-            ra += s.x; rb += s.y;
+#pragma unroll
+        for (int k = 0; k < SC_BATCH; ++k) {
+            const unsigned i = lo + (r0 + k) * 64 + lane;
+            const unsigned ia = wave_incl_scan_dpp(v[k].x), ib = wave_incl_scan_dpp(v[k].y);
+            if (r0 + k < rows && i < nblk) ws.boff[i] = make_uint2(ca + ia - v[k].x, cb + ib - v[k].y);
+            ca += (unsigned)__builtin_amdgcn_readlane((int)ia, 63);
+            cb += (unsigned)__builtin_amdgcn_readlane((int)ib, 63);
         }
     }
     if (threadIdx.x == 0) { ws.hdr->nfaces = (int)sa; ws.hdr->nverts = (int)sb; }
@@ -507,15 +517,6 @@ struct McOut {
 // The vertex kernel uses the same four-chunks-per-workgroup scheme as the classify kernel: the chunks' count
 // loads are in flight together and the dependent tail (rank / volume look-ups) runs once per workgroup.
 constexpr int EM_CHUNKS = 4;
-
-// inclusive prefix over the wave
-__device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
 
 __global__ void __launch_bounds__(CELLS_PER_BLOCK)
 mc_vertices_kernel(const float *vol, McDims d, McWs ws, McOut o, unsigned nblk) {
@@ -550,7 +551,7 @@ mc_vertices_kernel(const float *vol, McDims d, McWs ws, McOut o, unsigned nblk) 
     unsigned long long ball[EM_CHUNKS];
 #pragma unroll
     for (int k = 0; k < EM_CHUNKS; ++k) {
-        incl[k] = wave_incl_scan(cn[k] >> 8, lane);
+        incl[k] = wave_incl_scan_dpp(cn[k] >> 8);
         ball[k] = __ballot((cn[k] >> 8) != 0);
         if (lane == 63) wsum[k * 4 + w] = incl[k];
         if (lane == 0) wave_cnt[k * 4 + w] = (unsigned)__popcll(ball[k]);
