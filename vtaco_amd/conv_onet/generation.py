@@ -12,6 +12,7 @@ encoder + MANO layer on the device and the reference's wrist-frame post-processi
 """
 from __future__ import annotations
 
+import operator
 from collections import namedtuple
 
 import torch
@@ -20,6 +21,7 @@ from .. import ops
 from .._lib import VtError
 
 Mesh = namedtuple("Mesh", ["vertices", "faces"])
+_tensor_version = operator.attrgetter("_version")
 
 
 class Generator3D(object):
@@ -84,10 +86,27 @@ class Generator3D(object):
         return Mesh(verts, faces)
 
     # -- whole scene as ONE hipGraph replay (encode + dense decode + marching-cubes count) --------
+    def _module_tables(self):
+        """The model's modules and their parameter / buffer dicts, listed once per model object: the per-scene checks below
+        walk these lists instead of ``nn.Module``'s recursive generators (0.3 ms each for the ~110 tensors of the shipped model,
+        more than a quarter of a graphed scene).  A module's dict is updated in place when a weight is replaced, so the lists
+        stay valid; submodules (or a module's first parameter) added after the first call are not followed."""
+        tab = getattr(self, "_tables", None)
+        if tab is None or tab[0] is not self.model:
+            mods = list(self.model.modules())
+            tab = self._tables = (self.model, mods, [d for m in mods for d in (m._parameters, m._buffers) if d])
+        return tab
+
+    def _eval_mode(self):
+        """``self.model.eval()`` (generation.py:66, 131), skipped when every module already is in eval mode."""
+        if any(m.training for m in self._module_tables()[1]):
+            self.model.eval()
+
     def _weight_stamps(self):
-        """(storage address, version counter) of every parameter and buffer: changes when a weight is updated in place
-        (optimizer.step, load_state_dict) or replaced (``.to()``, a new tensor)."""
-        return tuple((t.data_ptr(), t._version) for t in list(self.model.parameters()) + list(self.model.buffers()))
+        """(object, storage address, version counter) of every parameter and buffer: changes when a weight is updated in place
+        (optimizer.step, load_state_dict), moved (``.to()`` swaps the storage under the same Parameter) or replaced."""
+        ts = [t for d in self._module_tables()[2] for t in d.values() if t is not None]
+        return tuple(map(id, ts)), tuple(map(torch.Tensor.data_ptr, ts)), tuple(map(_tensor_version, ts))
 
     def _scene_graph(self, shape, nx):
         """The captured graph of one (input shape, lattice size).  A graph holds raw pointers to derived buffers -- packed conv
@@ -126,7 +145,7 @@ class Generator3D(object):
         ~110 launches of encode + decode + marching-cubes classification replayed as one hipGraph
         (launch-bound otherwise); only the data-dependent output sizing leaves the graph.  Safe across weight
         updates and interleaved eager calls of other shapes (see ``_scene_graph``)."""
-        self.model.eval()
+        self._eval_mode()
         nx = self.resolution0 * 4
         g = self._scene_graph(inputs.shape, nx)
         g["in"].copy_(inputs.to(self.device), non_blocking=True)
@@ -140,7 +159,7 @@ class Generator3D(object):
         data-path collective, one all_gather of the logit slabs (8.4 MB at 128^3, 67 MB at 256^3) rebuilds the value
         grid, and every rank extracts the (identical) mesh.  Without an initialised group this is the single-GPU path."""
         from .. import dist as vdist
-        self.model.eval()
+        self._eval_mode()
         nx = self.resolution0 * 4
         inputs = data.get('inputs').to(self.device)
         with torch.no_grad():
@@ -170,7 +189,7 @@ class Generator3D(object):
         successful fingertip (``mode='nearest'``, radius 0.05: VTacOH, :186-200) from ``vt_tactile_assign``, and the
         decoder reads ``finger_feats [F,C]`` by id (``vt_decode_fwd_ids``): 1 byte per point instead of 4*C.
         ``anchors [F,K,3]`` (K = 1 for 'nearest'), ``count [F]`` valid anchors per finger, ``success [F]``."""
-        self.model.eval()
+        self._eval_mode()
         nx = self.resolution0 * 4
         setup = {'feats': finger_feats, 'anchors': anchors, 'success': success, 'mode': mode,
                  'radius': (0.015 if mode == 'within' else 0.05) if radius is None else radius,
@@ -223,7 +242,7 @@ class Generator3D(object):
         f64, faces [1538,3] i64) on the device (the reference wraps the same arrays in a trimesh.Trimesh)."""
         import numpy as np
         from scipy.spatial.transform import Rotation
-        self.model.eval()
+        self._eval_mode()
         inputs = data.get('inputs').to(self.device)
         pc_ply = data.get('inputs.pc_ply').to(self.device)
         if inputs.shape[0] != 1:
@@ -256,7 +275,7 @@ class Generator3D(object):
     def generate_obj_mesh_wnf(self, data, c_img_all=None):
         """Encode -> dense decode -> marching cubes for one scene; ``data['inputs']`` is the
         point cloud [1,T,3].  Returns Mesh(vertices [V,3] f32, faces [F,3] i32) on the device."""
-        self.model.eval()
+        self._eval_mode()
         nx = self.resolution0 * 4                       # generation.py:120
         inputs = data.get('inputs').to(self.device)
         if self.with_img and c_img_all is None:
@@ -301,7 +320,7 @@ class Generator3D(object):
         inputs = data.get('inputs').to(self.device)
         if inputs.shape[0] != 1:
             raise VtError(f"generate_obj_mesh_wnf: one scene at a time (got a batch of {inputs.shape[0]})")
-        self.model.eval()
+        self._eval_mode()
         with torch.no_grad():
             c_img = self.model.encode_img_inputs(data.get('inputs.img').to(self.device))          # [1,5,C]
         anchors, count = contact_clouds_from_depth(
@@ -323,7 +342,7 @@ class Generator3D(object):
         inputs = data.get('inputs').to(self.device)
         if inputs.shape[0] != 1:
             raise VtError(f"generate_obj_mesh_wnf: one scene at a time (got a batch of {inputs.shape[0]})")
-        self.model.eval()
+        self._eval_mode()
         with torch.no_grad():
             c_hand = self.model.encode_hand_inputs(inputs)
             if 'mano_joints' not in c_hand:
