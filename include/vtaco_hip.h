@@ -412,6 +412,18 @@ int vt_conv3d_stat_blocks_bf16x3(int B, int D, int H, int W, int Cin, int Cout);
 int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                          const float *scale_shift, const float *packed_w_bf16x3, int Cout, int relu, float *out,
                          float *out_part, void *stream);
+/* K-split form of vt_conv3d_gcr_bf16x3 for the levels whose output tiles cannot fill the chip (the 16^3 and 8^3 levels of  */
+/* ONE scene, unet3d.py:449-474 at num_levels 4): the 16-channel blocks of the input are dealt over 2-8 workgroups per     */
+/* output tile, the raw partial sums go through `workspace` and a second launch adds them in slice order (bit-reproducible), */
+/* applies the ReLU and writes the GroupNorm partial sums of every 128-voxel block (stat_blocks = D*H*W/128).  Same packed   */
+/* weights as vt_conv3d_gcr_bf16x3.  workspace_bytes / stat_blocks return 0 where the plain kernels already fill the chip   */
+/* (fewer than eight 16-channel blocks, or VTACO_CONV_KSPLIT=0): use them there.  One scene, both launches: 384->128 at   */
+/* 16^3 77 -> 40 us, 128->128 at 16^3 29 -> 22 us, 128->128 / 128->256 at 8^3 33 -> 13 us (f32 K-split kernel before).          */
+size_t vt_conv3d_ksplit_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int vt_conv3d_stat_blocks_ksplit(int B, int D, int H, int W, int Cin, int Cout);
+int vt_conv3d_gcr_bf16x3_ksplit(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                                const float *scale_shift, const float *packed_w_bf16x3, int Cout, int relu, float *out,
+                                float *out_part, void *workspace, size_t workspace_bytes, void *stream);
 /* Split-f16 form ("f16x3") for the large volumes (same reference layer: unet3d.py:20-72 SingleConv 'gcr'): operands as */
 /* IEEE-half hi + lo pairs (21-22 mantissa bits: f32-rounding-level error on GroupNorm outputs and conv weights) on      */
 /* v_mfma_f32_32x32x16_f16, in a persistent, double-buffered kernel: input channels in chunks of eight with a PAIR of     */

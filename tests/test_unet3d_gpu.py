@@ -74,12 +74,46 @@ def test_split_bf16_conv_layers_match_f32_kernel():
         pf, ps = ops.conv3d_pack(w), ops.conv3d_pack(w, precision="bf16x3")
         ref, (rp, rn) = ops.gn_conv3d_relu(x, xs, low, ls, gamma, beta, 8, pf, Cout)
         got, (gp, gn) = ops.gn_conv3d_relu(x, xs, low, ls, gamma, beta, 8, pf, Cout, packed_w_bf16x3=ps)
-        assert gn == (R // 8) ** 2 * (R // tile_z) and rn != gn    # it really took the split kernel, on the expected tiles
+        # it really took the split kernel, on the expected tiles
+        assert gn == (R // 8) ** 2 * (R // tile_z) and rn != gn
         scale = float(ref.abs().max())
         err = float((got - ref).abs().max())
         assert 0.0 < err <= 3e-5 * max(1.0, scale), (C1, C2, Cout, err, scale)
         # the epilogue's GroupNorm partial sums describe the same tensor
         assert float((gp.sum(1) - rp.sum(1)).abs().max()) <= 1e-3 * float(rp.sum(1).abs().max())
+
+
+def test_ksplit_conv_layers_match_f32_kernel():
+    """vt_conv3d_gcr_bf16x3_ksplit (input channels dealt over several workgroups per output tile + the slice-order sum) on the
+    thin levels of the shipped UNet3D -- 16^3 and 8^3 of one scene, the 384-channel virtual concat, a batch of two at 8^3, no
+    ReLU -- against the exact-f32 kernel; its statistics blocks against sums of its own output; bit-reproducible."""
+    from vtaco_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(13)
+    for B, R, C1, C2, Cout, relu in ((1, 16, 128, 0, 64, True), (1, 16, 128, 256, 128, True), (1, 16, 128, 0, 128, False),
+                                     (1, 8, 128, 0, 128, True), (1, 8, 128, 0, 256, True), (2, 8, 128, 0, 256, True), (1, 8, 256, 0, 32, True)):
+        assert lib.vt_conv3d_ksplit_workspace_bytes(B, R, R, R, C1 + C2, Cout) > 0
+        x = (torch.randn(B, R, R, R, C1, generator=g) * (torch.rand(B, R, R, R, 1, generator=g) < 0.5)).to(DEV)
+        low = torch.randn(B, R // 2, R // 2, R // 2, C2, generator=g).to(DEV) if C2 else None
+        w = (torch.randn(Cout, C1 + C2, 3, 3, 3, generator=g) * 0.05).to(DEV)
+        gamma = (1 + 0.2 * torch.randn(C1 + C2, generator=g)).to(DEV)
+        beta = (0.2 * torch.randn(C1 + C2, generator=g)).to(DEV)
+        ss = ops.gn_scale_shift(ops.channel_stats(x), ops.channel_stats(low) if C2 else None, C1, C2, B, R ** 3, gamma, beta, 8, 1e-5, DEV)
+        pf, ps = ops.conv3d_pack(w), ops.conv3d_pack(w, precision="bf16x3")
+        ref, _ = ops.conv3d_gcr(x, low, ss, pf, Cout, relu=relu)
+        got, (gp, gn) = ops.conv3d_gcr(x, low, ss, pf, Cout, relu=relu, packed_w_bf16x3=ps)
+        again, (gp2, _) = ops.conv3d_gcr(x, low, ss, pf, Cout, relu=relu, packed_w_bf16x3=ps)
+        assert gn == R ** 3 // 128 == lib.vt_conv3d_stat_blocks_ksplit(B, R, R, R, C1 + C2, Cout)
+        assert torch.equal(got, again) and torch.equal(gp, gp2)
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        assert 0.0 < err <= 3e-5 * max(1.0, scale), (B, R, C1, C2, Cout, err, scale)
+        blocks = got.reshape(B, gn, 128, Cout).double()
+        want = torch.stack((blocks.sum(2), (blocks * blocks).sum(2)), dim=-1)
+        assert float((gp.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    # where the plain kernels have the workgroups the form steps aside
+    assert lib.vt_conv3d_ksplit_workspace_bytes(1, 32, 32, 32, 128, 64) == 0 and lib.vt_conv3d_ksplit_workspace_bytes(8, 16, 16, 16, 128, 64) == 0
+    assert lib.vt_conv3d_ksplit_workspace_bytes(1, 16, 16, 16, 64, 64) == 0          # four 16-channel blocks: not worth a second launch
 
 
 def test_split_f16_conv_layers_match_f32_kernel():

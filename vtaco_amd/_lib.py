@@ -150,6 +150,9 @@ SIGNATURES = {
     "vt_conv3d_gcr_f16x3_scaled": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP]),
     "vt_conv3d_stat_blocks_bf16x3": (_I, [_I, _I, _I, _I, _I, _I]),
     "vt_conv3d_gcr_bf16x3": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),
+    "vt_conv3d_ksplit_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
+    "vt_conv3d_stat_blocks_ksplit": (_I, [_I, _I, _I, _I, _I, _I]),
+    "vt_conv3d_gcr_bf16x3_ksplit": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
     "vt_channel_stats": (_I, [_VP, _I, _I64, _I, _I, _VP, _VP]),
     "vt_gn_scale_shift": (_I, [_VP, _I, _I, _VP, _I, _I, _I, _I64, _I, _VP, _VP, _D, _VP, _VP]),
     "vt_conv3d_gcr": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),

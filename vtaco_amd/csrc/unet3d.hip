@@ -15,6 +15,7 @@
 //                            be the virtual concat [skip | nearest-upsampled low] of a decoder
 //                            level: neither the upsample nor the concat is materialised.
 //   maxpool / conv1x1        the 2x2x2 max-pool between encoder levels and the final 1x1x1 conv.
+#include <string.h>
 #include "decode_common.h"
 
 namespace {
@@ -140,6 +141,8 @@ struct ConvArgs {
     int Cout, relu;
     int TX, TY, TZ;             // block tile of output voxels (TX*TY*TZ = 32 * waves)
     int tiles_x, tiles_y, tiles_z;
+    float *kws = nullptr;       // K-split launches (gridDim.z slices of the input channels): [ksplit][B,D,H,W,Cout] raw partial sums
+    int ksplit = 1;
 };
 
 // stage channels [32 cib, 32 cib+32) of the normalised input tile (origin x0-1,y0-1,z0-1) into LDS;
@@ -396,7 +399,11 @@ constexpr int SB_WFRAGS = 27 * 128;               // one (16-channel block, cout
 constexpr int sb_witers(int TZ) { return (SB_WFRAGS + sb_threads(TZ) - 1) / sb_threads(TZ); }
 constexpr size_t sb_lds(int TZ) { return (size_t)sb_rows(TZ) * SB_ROW + (size_t)SB_WFRAGS * 16; }
 
-template <int TZ>
+// KSPLIT: gridDim.z workgroups share an output tile, each over its contiguous 1/gridDim.z of the 16-channel blocks; the raw
+// accumulators go to a.kws[blockIdx.z] and conv_ksum_kernel adds them up in slice order (ReLU and the statistics move there).
+// For the thin levels of ONE scene (16^3, 8^3): 16-128 output tiles cannot fill 256 CUs, and a workgroup that walks 24
+// channel blocks alone is a 77 us chain (384 -> 128 at 16^3).
+template <int TZ, bool KSPLIT = false>
 __global__ void __launch_bounds__(sb_threads(TZ))
 conv3d_gcr_s_kernel(ConvArgs a) {
     constexpr int SB_ROWS = sb_rows(TZ), SB_THREADS = sb_threads(TZ), SB_ITERS = sb_iters(TZ), SB_WITERS = sb_witers(TZ);
@@ -488,12 +495,13 @@ conv3d_gcr_s_kernel(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
-    fetch(0);
-    for (int q = 0; q < ncq; ++q) {
+    const int q_lo = KSPLIT ? (int)blockIdx.z * (ncq / a.ksplit) : 0, q_hi = KSPLIT ? q_lo + ncq / a.ksplit : ncq;
+    fetch(q_lo);
+    for (int q = q_lo; q < q_hi; ++q) {
         __syncthreads();                                           // the previous taps are done with the tile
         commit(q);
         __syncthreads();
-        if (q + 1 < ncq) fetch(q + 1);
+        if (q + 1 < q_hi) fetch(q + 1);
         // the four operand fragments of tap t+1 are requested before the three MFMAs of tap t issue: one LDS latency
         // per tap hides under the matrix pipe instead of two being exposed in front of it (two taps ahead spills the
         // 16-wave kernel past its 128 registers and was slower)
@@ -526,7 +534,13 @@ conv3d_gcr_s_kernel(ConvArgs a) {
     {
         const int gx = x0 + lx + wx, gy = y0 + ly, gz = z0 + wz;
         const bool valid = gx < s.W && gy < s.H && gz < s.D;
-        float *orow = a.out + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.Cout;
+        const size_t off = ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.Cout;
+        if (KSPLIT) {
+            const size_t slab = (size_t)(gridDim.x / (a.tiles_x * a.tiles_y * a.tiles_z)) * s.D * s.H * s.W * a.Cout;
+            if (valid) store_acc16(a.kws + blockIdx.z * slab + off + co_blk * 32, acc, kg);
+            return;
+        }
+        float *orow = a.out + off;
         f32x16 v = acc;
         if (a.relu) v = relu16(v);
         if (valid) store_acc16(orow + co_blk * 32, v, kg);
@@ -541,6 +555,48 @@ conv3d_gcr_s_kernel(ConvArgs a) {
             for (int w = 0; w < 2 * TZ; ++w) tsum += sred[w * 64 + threadIdx.x];
             a.part[(((size_t)b * nsp + spatial) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
         }
+    }
+}
+
+// out = relu(sum over the K slices, in slice order) and the (sum, sumsq) partials of every 128-voxel block: one workgroup per
+// (block, 32 output channels), thread = (voxel lane 0..31, 4 channels), four voxels each -- every slice load of a thread is
+// independent of the others (the kernel is one round trip deep)
+constexpr int KSUM_VOX = 128;
+template <int KS>       // slices known at compile time (0: run-time `ks`): their loads are issued together, not one round trip each
+__global__ void __launch_bounds__(256)
+conv_ksum_kernel(const float *kws, int ks, size_t slab, int Cout, int relu, float *out, float *part) {
+    __shared__ float red[32][8][8];
+    const int vl = threadIdx.x >> 3, q = threadIdx.x & 7;
+    f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KSUM_VOX / 32; ++i) {
+        const size_t e = ((size_t)blockIdx.x * KSUM_VOX + i * 32 + vl) * Cout + blockIdx.y * 32 + q * 4;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(kws + e);
+        if (KS) {
+            f32x4 w[KS ? KS : 1];
+#pragma unroll
+            for (int k = 1; k < KS; ++k) w[k] = *reinterpret_cast<const f32x4 *>(kws + k * slab + e);
+#pragma unroll
+            for (int k = 1; k < KS; ++k) { v.x += w[k].x; v.y += w[k].y; v.z += w[k].z; v.w += w[k].w; }
+        } else {
+            for (int k = 1; k < ks; ++k) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(kws + k * slab + e);
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+        }
+        if (relu) v = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+        *reinterpret_cast<f32x4 *>(out + e) = v;
+        sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+        sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+    }
+    if (!part) return;
+    float *r = red[vl][q];
+    r[0] = sm.x; r[1] = sq.x; r[2] = sm.y; r[3] = sq.y; r[4] = sm.z; r[5] = sq.z; r[6] = sm.w; r[7] = sq.w;
+    __syncthreads();
+    if (threadIdx.x < 64) {                                        // threadIdx.x = channel * 2 + {sum, sumsq} of the 32-channel block
+        float t = 0.0f;
+        for (int v = 0; v < 32; ++v) t += red[v][threadIdx.x >> 3][threadIdx.x & 7];
+        part[((size_t)blockIdx.x * Cout + blockIdx.y * 32) * 2 + threadIdx.x] = t;
     }
 }
 
@@ -1460,6 +1516,35 @@ static int conv_s_tz(int B, int D, int H, int W, int Cout) {
     return 2;
 }
 
+// K-split plan of the split-bf16 kernel for the levels whose output tiles cannot fill the chip (16^3 and 8^3 of one scene):
+// returns the number of K slices (0: not applicable) and the tile depth.  8^3 tiles when they and up to 8 slices give >= 128
+// workgroups (every 16-channel block of weights -- 54 KB -- is then fetched once per 512 voxels instead of once per 128),
+// 8 x 8 x 2 tiles otherwise; slices = the power of two that brings the launch nearest to one workgroup per CU.
+// VTACO_CONV_KSPLIT=0 turns the path off, VTACO_CONV_KSPLIT=<tz>,<ks> forces a plan where it is valid (A/B runs).
+static int conv_sk_plan(int B, int D, int H, int W, int Cin, int Cout, int &tz) {
+    tz = 0;
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || ((D | H | W) & 7) || Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 31) || Cout > 1024) return 0;
+    static const char *knob = getenv("VTACO_CONV_KSPLIT");
+    if (knob && knob[0] == '0') return 0;
+    const int ncq = Cin / 16;
+    const size_t t8 = (size_t)(D / 8) * (H / 8) * (W / 8) * B * (Cout / 32), t2 = 4 * t8;
+    if (t2 > 128) return 0;                                        // the plain kernels have the workgroups (one per two CUs or more)
+    const bool forced = knob && strchr(knob, ',');
+    if (ncq < 8 && !forced) return 0;                              // 64 input channels: four blocks -- the second launch costs what the split saves (measured)
+    if (forced) {
+        const int ftz = atoi(knob), fks = atoi(strchr(knob, ',') + 1);
+        if ((ftz == 8 || ftz == 2) && fks >= 2 && fks <= 16 && ncq % fks == 0) { tz = ftz; return fks; }
+    }
+    int best = 0;
+    for (int ks = 8; ks >= 2; ks >>= 1)
+        if (ncq % ks == 0 && t8 * ks >= 128 && t8 * ks <= 256) { best = ks; break; }
+    if (best) { tz = 8; return best; }
+    for (int ks = 2; ks <= 8; ks <<= 1)
+        if (ncq % ks == 0) { best = ks; if (t2 * ks >= 256) break; }
+    if (best) tz = 2;
+    return best;
+}
+
 // split-f16 persistent kernel: 8^3 tiles (16 waves) when they give every CU a workgroup, 8x8x4 tiles (8 waves) when those do;
 // 0 = not covered (the 16^3-class levels stay on the thin-tile split-bf16 kernel or the f32 kernels)
 static int conv_h_tz(int B, int D, int H, int W, int Cin, int Cout) {
@@ -1651,6 +1736,51 @@ int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, in
     return vt_check(hipGetLastError(), "vt_conv3d_gcr_bf16x3");
 }
 
+// ---- the K-split form of vt_conv3d_gcr_bf16x3 for the thin levels (conv_sk_plan) ----
+size_t vt_conv3d_ksplit_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+    int tz;
+    const int ks = conv_sk_plan(B, D, H, W, Cin, Cout, tz);
+    return ks ? (size_t)ks * B * D * H * W * Cout * sizeof(float) : 0;
+}
+
+int vt_conv3d_stat_blocks_ksplit(int B, int D, int H, int W, int Cin, int Cout) {
+    int tz;
+    return conv_sk_plan(B, D, H, W, Cin, Cout, tz) ? (int)((size_t)D * H * W / KSUM_VOX) : 0;
+}
+
+int vt_conv3d_gcr_bf16x3_ksplit(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                                const float *scale_shift, const float *packed_w_bf16x3, int Cout, int relu, float *out,
+                                float *out_part, void *workspace, size_t workspace_bytes, void *stream) {
+    ConvArgs a;
+    a.s = Src{skip, low, C1, low ? C2 : 0, D, H, W};
+    if (!src_ok(a.s, B) || !packed_w_bf16x3 || !out || !workspace) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr_bf16x3_ksplit: bad argument");
+    int tz;
+    const int ks = conv_sk_plan(B, D, H, W, a.s.C1 + a.s.C2, Cout, tz);
+    if (!ks) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr_bf16x3_ksplit: shape not covered (see vt_conv3d_ksplit_workspace_bytes)");
+    const size_t slab = (size_t)B * D * H * W * Cout;
+    if (workspace_bytes < slab * ks * sizeof(float)) return vt_fail(VT_ERR_WORKSPACE, "vt_conv3d_gcr_bf16x3_ksplit: workspace too small");
+    a.scale_shift = scale_shift; a.wp = packed_w_bf16x3; a.out = nullptr; a.part = nullptr; a.Cout = Cout; a.relu = 0;
+    a.kws = (float *)workspace; a.ksplit = ks;
+    a.TX = a.TY = 8; a.TZ = tz;
+    a.tiles_x = W / 8; a.tiles_y = H / 8; a.tiles_z = D / tz;
+    const dim3 grid((unsigned)((size_t)a.tiles_x * a.tiles_y * a.tiles_z * B), (unsigned)(Cout / 32), (unsigned)ks);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_bf16x3_ksplit: hipFuncSetAttribute");
+        attr = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (tz == 8) hipLaunchKernelGGL((conv3d_gcr_s_kernel<8, true>), grid, dim3(sb_threads(8)), sb_lds(8), st, a);
+    else hipLaunchKernelGGL((conv3d_gcr_s_kernel<2, true>), grid, dim3(sb_threads(2)), sb_lds(2), st, a);
+    const dim3 sgrid((unsigned)((size_t)B * D * H * W / KSUM_VOX), (unsigned)(Cout / 32));
+#define VT_KSUM(KS) hipLaunchKernelGGL(conv_ksum_kernel<KS>, sgrid, dim3(256), 0, st, (const float *)workspace, ks, slab, Cout, relu, out, out_part)
+    if (ks == 8) VT_KSUM(8); else if (ks == 4) VT_KSUM(4); else if (ks == 2) VT_KSUM(2); else VT_KSUM(0);
+#undef VT_KSUM
+    return vt_check(hipGetLastError(), "vt_conv3d_gcr_bf16x3_ksplit");
+}
+
 #ifdef VT_DIAG_HB
 int vt_diag_hb_read(unsigned long long *host, size_t count) {
     return vt_check(hipMemcpyFromSymbol(host, HIP_SYMBOL(vt_diag_hb_buf), count * sizeof(unsigned long long)), "vt_diag_hb_read");
@@ -1783,10 +1913,13 @@ int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char 
         o.C = c.cout;
         o.x = ws.take((size_t)B * Ri * Ri * Ri * c.cout);
         const bool half = c.packed_f16x3 && conv_h_tz(B, Ri, Ri, Ri, c.cin, c.cout) != 0;
-        const bool split = !half && c.packed_bf16x3 && conv_s_eligible(B, Ri, Ri, Ri, c.cin, c.cout);
+        const size_t ksbytes = (!half && c.packed_bf16x3) ? vt_conv3d_ksplit_workspace_bytes(B, Ri, Ri, Ri, c.cin, c.cout) : 0;
+        const bool split = !half && !ksbytes && c.packed_bf16x3 && conv_s_eligible(B, Ri, Ri, Ri, c.cin, c.cout);
         o.nblk = half ? vt_conv3d_stat_blocks_f16x3(B, Ri, Ri, Ri, c.cin, c.cout)
+                      : ksbytes ? vt_conv3d_stat_blocks_ksplit(B, Ri, Ri, Ri, c.cin, c.cout)
                       : split ? vt_conv3d_stat_blocks_bf16x3(B, Ri, Ri, Ri, c.cin, c.cout) : vt_conv3d_stat_blocks(B, Ri, Ri, Ri, c.cin, c.cout);
         o.part = ws.take((size_t)B * o.nblk * c.cout * 2);
+        float *kws = ksbytes ? ws.take(ksbytes / sizeof(float)) : nullptr;
         if (plan) return 0;
         const int groups = (c.cin >= p->groups) ? p->groups : 1;
         int rc = vt_gn_scale_shift(a.part, a.nblk, a.C, low ? low->part : nullptr, low ? low->nblk : 0, C2, B,
@@ -1794,6 +1927,9 @@ int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char 
         if (rc) return rc;
         if (half)
             return vt_conv3d_gcr_f16x3(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.cout, 1, o.x, o.part, st);
+        if (ksbytes)
+            return vt_conv3d_gcr_bf16x3_ksplit(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed_bf16x3, c.cout, 1, o.x, o.part,
+                                               kws, ksbytes, st);
         if (split)
             return vt_conv3d_gcr_bf16x3(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed_bf16x3, c.cout, 1, o.x, o.part, st);
         return vt_conv3d_gcr(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed, c.cout, 1, o.x, o.part, st);

@@ -849,6 +849,17 @@ def conv3d_gcr(x, low, ss, packed_w, Cout, relu=True, packed_w_bf16x3=None, want
     if nblk:
         fn, name, pw = lib.vt_conv3d_gcr_f16x3, "vt_conv3d_gcr_f16x3", packed_w_f16x3
     else:
+        ksbytes = lib.vt_conv3d_ksplit_workspace_bytes(B, D, H, W, C1 + C2, Cout) if packed_w_bf16x3 is not None else 0
+        if ksbytes:
+            # thin level (16^3 / 8^3 of one scene): the input channels dealt over several workgroups per output tile
+            nblk = lib.vt_conv3d_stat_blocks_ksplit(B, D, H, W, C1 + C2, Cout)
+            part = torch.empty((B, nblk, Cout, 2), dtype=torch.float32, device=dev) if want_stats else None
+            ws = torch.empty(ksbytes // 4, dtype=torch.float32, device=dev)
+            check(lib.vt_conv3d_gcr_bf16x3_ksplit(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
+                                                  dev_ptr(packed_w_bf16x3, "packed_w"), Cout, int(relu), dev_ptr(out, "out"),
+                                                  dev_ptr(part, "part"), ctypes.c_void_p(ws.data_ptr()), ksbytes, st),
+                  "vt_conv3d_gcr_bf16x3_ksplit")
+            return out, ((part, nblk) if want_stats else None)
         nblk = lib.vt_conv3d_stat_blocks_bf16x3(B, D, H, W, C1 + C2, Cout) if packed_w_bf16x3 is not None else 0
         if nblk:
             fn, name, pw = lib.vt_conv3d_gcr_bf16x3, "vt_conv3d_gcr_bf16x3", packed_w_bf16x3
