@@ -218,6 +218,34 @@ def test_gcr_block_backward_vs_torch_autograd(C1, C2, Cout, R, B, prec):
         assert _rel(lh.grad.permute(0, 4, 1, 2, 3).cpu(), lr.grad) <= tol
 
 
+def test_wgrad_f16x3_matches_f32_kernel():
+    """vt_conv3d_wgrad_f16x3 (split-half operands, K = voxels, transposing staging) against the exact-f32 weight-gradient kernel:
+    plain and concatenated inputs, several cout / cin blocks, batches, gradients six orders of magnitude below the half range
+    (power-of-two rescale from g_absmax); error at f32 accumulation-order level; bit-reproducible."""
+    from vtaco_amd import ops
+    g = torch.Generator().manual_seed(21)
+    for B, R, C1, C2, Cout, gs in ((1, 8, 32, 0, 32, 1.0), (2, 16, 32, 0, 64, 1e-6), (1, 16, 32, 64, 32, 1e-6), (2, 8, 64, 128, 64, 1e-3),
+                                   (1, 32, 32, 0, 32, 1e-6), (1, 64, 32, 0, 32, 1e-7)):
+        x = torch.randn(B, R, R, R, C1, generator=g).to(DEV)
+        low = torch.randn(B, R // 2, R // 2, R // 2, C2, generator=g).to(DEV) if C2 else None
+        gamma = (1 + 0.2 * torch.randn(C1 + C2, generator=g)).to(DEV)
+        beta = (0.2 * torch.randn(C1 + C2, generator=g)).to(DEV)
+        ss = ops.gn_scale_shift(ops.channel_stats(x), ops.channel_stats(low) if C2 else None, C1, C2, B, R ** 3, gamma, beta, 8, 1e-5, DEV)
+        gr = (torch.randn(B, R, R, R, Cout, generator=g) * (torch.rand(B, R, R, R, 1, generator=g) < 0.6) * gs).to(DEV)
+        gmax = gr.abs().max().reshape(1)
+        ref = ops.conv3d_wgrad(x, low, ss, gr)
+        got = ops.conv3d_wgrad(x, low, ss, gr, precision="f16x3", g_absmax=gmax)
+        again = ops.conv3d_wgrad(x, low, ss, gr, precision="f16x3", g_absmax=gmax)
+        assert torch.equal(got, again)
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        # both kernels accumulate B * R^3 products per entry in f32, in different orders
+        assert 0.0 < err <= 2e-7 * (B * R ** 3) ** 0.5 * scale, (B, R, C1, C2, Cout, err, scale)
+        nomax = ops.conv3d_wgrad(x, low, ss, gr, precision="f16x3")              # without the rescale small gradients lose bits
+        if gs == 1.0:
+            assert torch.equal(nomax, got) or float((nomax - ref).abs().max()) <= 2e-7 * (B * R ** 3) ** 0.5 * scale
+
+
 def test_maxpool_backward_first_maximum():
     import torch.nn.functional as F
     from vtaco_amd.encoder.unet3d import _MaxPoolFn

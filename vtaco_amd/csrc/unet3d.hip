@@ -2102,6 +2102,269 @@ conv3d_wgrad_reduce_kernel(const float *partial, int chunks, int Cout, int Cin, 
     }
 }
 
+// ---- weight gradient on the f16 matrix core (split operands, "f16x3") ---------------------------------------------
+// The contraction index of dW[co][ci][tap] = sum_v g[v][co] xn[v + tap][ci] is the VOXEL, so both MFMA operands want eight
+// consecutive voxels of one channel per lane (v_mfma_f32_32x32x16_f16: lane = (channel, k-group), k-group 0 / 1 = two x-rows
+// of eight voxels): the staging TRANSPOSES the channels-last tensors into per-channel planes of IEEE-half hi / lo pairs
+// (hi = rtz_half(v), lo = half(v - hi): 21-22 mantissa bits; g is first scaled by the power of two that brings its largest
+// element to ~2^10 -- output gradients sit far below the half range -- and the reduce kernel scales dW back, exactly).
+// One workgroup = one (cout block, cin block) pair over a chunk of 8 x 8 x 2 tiles, four waves x seven taps (112 accumulator
+// registers); per k-step (16 voxels) a wave reads the g fragment once and each halo row (y + dy, z + dz) of xn once: the
+// row's ten voxels are five dwords, and the three dx windows are dwords 0-3, the byte-aligned middle, dwords 1-4.
+// 79 KB of LDS and 4 waves: two workgroups per CU, one's staging under the other's MFMAs.
+constexpr int WH_TZ = 2, WH_ROWS = (WH_TZ + 2) * 10;
+constexpr int WH_ROWB = 24;                              // a halo row in one channel's plane: 10 voxels + 2 pad, 2 bytes each
+constexpr int WH_XCH = WH_ROWS * WH_ROWB + 8;            // 968 B = 242 dwords per channel: the 16 lanes of an 8-byte read pass tile the 32 banks
+constexpr int WH_XPLANE = 32 * WH_XCH;
+constexpr int WH_GROWS = WH_TZ * 8;
+constexpr int WH_GCH = WH_GROWS * 16 + 16;               // 272 B per channel (68 dwords: 16-byte reads of 8 lanes tile the banks)
+constexpr int WH_GPLANE = 32 * WH_GCH;
+constexpr size_t WH_LDS = 2 * (size_t)WH_XPLANE + 2 * (size_t)WH_GPLANE;
+constexpr int WH_THREADS = 256, WH_XITEMS = WH_ROWS * 5 * 8, WH_GITEMS = WH_GROWS * 4 * 8;
+constexpr int WH_XITERS = (WH_XITEMS + WH_THREADS - 1) / WH_THREADS, WH_GITERS = WH_GITEMS / WH_THREADS;
+static_assert(2 * WH_LDS <= 160 * 1024, "two workgroups per CU");
+
+struct WgradHArgs {
+    WgradArgs w;
+    const float *g_absmax;      // device scalar max |g| (or null: no rescale)
+};
+
+__device__ __forceinline__ float pow2_scale_for(const float *absmax) {
+    if (!absmax) return 1.0f;
+    const float m = *absmax;
+    if (!(m > 0.0f && m < 3.0e38f)) return 1.0f;
+    const int e = 10 - ilogbf(m);                                       // 2^e * m in [2^10, 2^11)
+    return ldexpf(1.0f, e < -100 ? -100 : (e > 100 ? 100 : e));
+}
+
+// hi / lo half pairs of two values: hi by round-toward-zero (one v_cvt_pkrtz), lo = half(v - hi)
+__device__ __forceinline__ void split_pair_h(float a, float b, unsigned &hi, unsigned &lo) {
+    const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]));
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// the k-steps of one staged tile for wave W (taps 7W .. 7W+6)
+template <int W>
+__device__ __forceinline__ void wgrad_h_ksteps(const char *xh, const char *xl, const char *gh, const char *gl, f32x16 (&acc)[7], int lane) {
+    const int ch = lane & 31, kg = lane >> 5;
+    constexpr int T0 = 7 * W, T1 = (T0 + 7 < 27) ? T0 + 7 : 27;
+#pragma unroll 1
+    for (int ks = 0; ks < WH_TZ * 4; ++ks) {
+        const int z = ks >> 2, y = (ks & 3) * 2 + kg;
+        const int goff = ch * WH_GCH + (z * 8 + y) * 16;
+        const f16x8 ah = *reinterpret_cast<const f16x8 *>(gh + goff), al = *reinterpret_cast<const f16x8 *>(gl + goff);
+        // the wave's halo rows one after the other, each row's ten dwords requested while the previous row's MFMAs run (the
+        // scheduler would otherwise hoist every row's loads to the top: 40 registers the prefetched tile needs)
+        struct Row { unsigned dh[5], dl[5]; u32x4 ph, pl; };            // ph / pl: dwords 1-4 again, as an aligned register tuple
+        auto load_row = [&](int r) {
+            Row o;
+            const int dz = r / 3 - 1, dy = r % 3 - 1;
+            const int xoff = ch * WH_XCH + ((z + dz + 1) * 10 + (y + dy + 1)) * WH_ROWB;
+            const u32x2 a0 = *reinterpret_cast<const u32x2 *>(xh + xoff), a1 = *reinterpret_cast<const u32x2 *>(xh + xoff + 8);
+            const u32x2 b0 = *reinterpret_cast<const u32x2 *>(xl + xoff), b1 = *reinterpret_cast<const u32x2 *>(xl + xoff + 8);
+            o.dh[0] = a0.x; o.dh[1] = a0.y; o.dh[2] = a1.x; o.dh[3] = a1.y; o.dh[4] = *reinterpret_cast<const unsigned *>(xh + xoff + 16);
+            o.dl[0] = b0.x; o.dl[1] = b0.y; o.dl[2] = b1.x; o.dl[3] = b1.y; o.dl[4] = *reinterpret_cast<const unsigned *>(xl + xoff + 16);
+            if (3 * r + 2 >= T0 && 3 * r + 2 < T1) {
+                // the dx = +1 window (dwords 1-4) read a second time, 4-byte aligned (two ds_read2_b32): as registers 1-4 of the
+                // five above it is not an MFMA operand tuple, and copying it into one cost eight v_mov per tap
+                typedef unsigned u1 __attribute__((aligned(4)));
+                const u1 *qh = reinterpret_cast<const u1 *>(xh + xoff + 4), *ql = reinterpret_cast<const u1 *>(xl + xoff + 4);
+                o.ph = u32x4{qh[0], qh[1], qh[2], qh[3]}; o.pl = u32x4{ql[0], ql[1], ql[2], ql[3]};
+            }
+            return o;
+        };
+        constexpr int R0 = T0 / 3, R1 = (T1 - 1) / 3;                     // first and last halo row with a tap of this wave
+#ifdef VT_WH_ROWPIPE
+        Row nxt = load_row(R0);
+#endif
+#pragma unroll
+        for (int r = R0; r <= R1; ++r) {
+#ifdef VT_WH_ROWPIPE
+            const Row cur = nxt;
+            if (r < R1) nxt = load_row(r + 1);
+#else
+            const Row cur = load_row(r);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned *dh = cur.dh, *dl = cur.dl;
+#pragma unroll
+            for (int dxi = 0; dxi < 3; ++dxi) {
+                const int t = 3 * r + dxi;
+                if (t < T0 || t >= T1) continue;
+                u32x4 bh, bl;
+                if (dxi == 0) { bh = u32x4{dh[0], dh[1], dh[2], dh[3]}; bl = u32x4{dl[0], dl[1], dl[2], dl[3]}; }
+                else if (dxi == 2) { bh = cur.ph; bl = cur.pl; }
+                else {
+                    bh = u32x4{__builtin_amdgcn_alignbyte(dh[1], dh[0], 2), __builtin_amdgcn_alignbyte(dh[2], dh[1], 2),
+                               __builtin_amdgcn_alignbyte(dh[3], dh[2], 2), __builtin_amdgcn_alignbyte(dh[4], dh[3], 2)};
+                    bl = u32x4{__builtin_amdgcn_alignbyte(dl[1], dl[0], 2), __builtin_amdgcn_alignbyte(dl[2], dl[1], 2),
+                               __builtin_amdgcn_alignbyte(dl[3], dl[2], 2), __builtin_amdgcn_alignbyte(dl[4], dl[3], 2)};
+                }
+                const f16x8 xhv = __builtin_bit_cast(f16x8, bh), xlv = __builtin_bit_cast(f16x8, bl);
+                f32x16 &c = acc[t - T0];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xhv, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xlv, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xhv, c, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+#ifndef VT_WH_WPS
+#define VT_WH_WPS 2                 // waves per SIMD the register budget is sized for (A/B: 1 = 512 registers, one workgroup per CU)
+#endif
+// everything a wave does, instantiated per wave index: one straight tile loop per variant (a wave switch INSIDE the loop made the
+// allocator shuffle the 112 accumulator registers at every join: 48 v_mov_b64 per k-step)
+template <int W>
+__device__ __forceinline__ void wgrad_h_wave(const WgradHArgs &ha, char *whl) {
+    char *xh = whl, *xl = whl + WH_XPLANE, *gh = whl + 2 * WH_XPLANE, *gl = gh + WH_GPLANE;
+    const WgradArgs &a = ha.w;
+    const Src &s = a.c.s;
+    const int lane = threadIdx.x & 63;
+    constexpr int wave = W;
+    const int Cin = s.C1 + s.C2, ncib = Cin / 32, nco = a.c.Cout / 32;
+    const int cob = blockIdx.y / ncib, cib = blockIdx.y % ncib;
+    const float pre = pow2_scale_for(ha.g_absmax);
+    f32x16 acc[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    // staging plan: item -> (halo row, x pair, four channels); the channel quad is the thread's for the whole kernel
+    const int q = threadIdx.x & 7, chq = cib * 32 + q * 4;
+    const bool from_low = chq >= s.C1;
+    const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
+    const float *xbase = from_low ? s.low : s.skip;
+    const int tiles_per_scene = a.c.tiles_x * a.c.tiles_y * a.c.tiles_z;
+    // A tile's global loads are issued one tile ahead (fetch: 18 x 16 bytes per thread, in flight under the previous tile's
+    // k-steps) and turned into the half planes when the k-steps are done with the LDS (commit).
+    f32x4 px0[WH_XITERS], px1[WH_XITERS], pg0[WH_GITERS], pg1[WH_GITERS], sc, sh;
+    unsigned inmask = 0;
+    auto fetch = [&](int tile) {
+        const int b = tile / tiles_per_scene;
+        int t = tile - b * tiles_per_scene;
+        const int tx = t % a.c.tiles_x; t /= a.c.tiles_x;
+        const int ty = t % a.c.tiles_y, tz = t / a.c.tiles_y;
+        const int x0 = tx * 8, y0 = ty * 8, z0 = tz * WH_TZ;
+        sc = f32x4{1.f, 1.f, 1.f, 1.f}; sh = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.c.scale_shift) {
+            const float *ss = a.c.scale_shift + ((size_t)b * Cin + chq) * 2;
+            sc = f32x4{ss[0], ss[2], ss[4], ss[6]}; sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
+        }
+        inmask = 0;
+#pragma unroll
+        for (int it = 0; it < WH_XITERS; ++it) {
+            const int id = min((int)threadIdx.x + it * WH_THREADS, WH_XITEMS - 1);      // (the last iteration's idle threads repeat an item)
+            const int rp = id >> 3, p = rp % 5, row = rp / 5, py = row % 10, pz = row / 10;
+            const int gx = x0 - 1 + 2 * p, gy = y0 - 1 + py, gz = z0 - 1 + pz;        // gx is odd: the pair's `low` voxels are neighbours too
+            const bool rowin = (unsigned)gy < (unsigned)s.H && (unsigned)gz < (unsigned)s.D;
+            if (rowin && gx >= 0) inmask |= 1u << (2 * it);
+            if (rowin && gx + 1 < s.W) inmask |= 2u << (2 * it);
+            // branch-free: both loads always issue, from addresses clamped into the volume (the zero padding is a select at
+            // commit); 32-bit element offsets from one uniform base pointer
+            const int cz = min(max(gz, 0), s.D - 1), cy = min(max(gy, 0), s.H - 1), cx0 = max(gx, 0), cx1 = min(gx + 1, s.W - 1);
+            unsigned voff0, voff1;
+            if (from_low) {
+                voff0 = (unsigned)(((b * D2 + (cz >> 1)) * H2 + (cy >> 1)) * W2 + (cx0 >> 1)) * (unsigned)s.C2 + (unsigned)(chq - s.C1);
+                voff1 = voff0 + (unsigned)((cx1 >> 1) - (cx0 >> 1)) * (unsigned)s.C2;
+            } else {
+                voff0 = (unsigned)(((b * s.D + cz) * s.H + cy) * s.W + cx0) * (unsigned)s.C1 + (unsigned)chq;
+                voff1 = voff0 + (unsigned)(cx1 - cx0) * (unsigned)s.C1;
+            }
+            px0[it] = *reinterpret_cast<const f32x4 *>(xbase + voff0);
+            px1[it] = *reinterpret_cast<const f32x4 *>(xbase + voff1);
+        }
+#pragma unroll
+        for (int it = 0; it < WH_GITERS; ++it) {
+            const int id = threadIdx.x + it * WH_THREADS;
+            const int rp = id >> 3, p = rp & 3, row = rp >> 2, y = row & 7, z = row >> 3;
+            const unsigned goff = (unsigned)(((b * s.D + z0 + z) * s.H + y0 + y) * s.W + x0 + 2 * p) * (unsigned)a.c.Cout + (unsigned)(cob * 32 + q * 4);
+            pg0[it] = *reinterpret_cast<const f32x4 *>(a.g + goff);
+            pg1[it] = *reinterpret_cast<const f32x4 *>(a.g + goff + (unsigned)a.c.Cout);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int it = 0; it < WH_XITERS; ++it) {
+            const int id = threadIdx.x + it * WH_THREADS;
+            if (id >= WH_XITEMS) continue;
+            const int rp = id >> 3, p = rp % 5, row = rp / 5;
+            const bool in0 = inmask >> (2 * it) & 1u, in1 = inmask >> (2 * it + 1) & 1u;
+            const int off = (q * 4) * WH_XCH + row * WH_ROWB + p * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned hi, lo;
+                split_pair_h(in0 ? fmaf(px0[it][c], sc[c], sh[c]) : 0.0f, in1 ? fmaf(px1[it][c], sc[c], sh[c]) : 0.0f, hi, lo);
+                *reinterpret_cast<unsigned *>(xh + off + c * WH_XCH) = hi;
+                *reinterpret_cast<unsigned *>(xl + off + c * WH_XCH) = lo;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < WH_GITERS; ++it) {
+            const int id = threadIdx.x + it * WH_THREADS;
+            const int rp = id >> 3, p = rp & 3, row = rp >> 2;
+            const int off = (q * 4) * WH_GCH + row * 16 + p * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned hi, lo;
+                split_pair_h(pg0[it][c] * pre, pg1[it][c] * pre, hi, lo);
+                *reinterpret_cast<unsigned *>(gh + off + c * WH_GCH) = hi;
+                *reinterpret_cast<unsigned *>(gl + off + c * WH_GCH) = lo;
+            }
+        }
+    };
+    if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        __syncthreads();                                                   // the previous tile's k-steps are done with the planes
+        commit();
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+        wgrad_h_ksteps<W>(xh, xl, gh, gl, acc, lane);
+    }
+    // partial[chunk][cob][cib][tap][co][ci]: lane (ci, half kk) register r = co chan_of(r, kk)
+    float *dst = a.partial + (((size_t)blockIdx.x * nco + cob) * ncib + cib) * 27 * 1024;
+    const int i = lane & 31, kk = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+        const int tap = wave * 7 + t;
+        if (tap >= 27) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(size_t)tap * 1024 + chan_of(r, kk) * 32 + i] = acc[t][r];
+    }
+}
+
+__global__ void __launch_bounds__(WH_THREADS, VT_WH_WPS)
+conv3d_wgrad_h_kernel(WgradHArgs ha) {
+    extern __shared__ __attribute__((aligned(16))) char whl[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == 0) wgrad_h_wave<0>(ha, whl);
+    else if (wave == 1) wgrad_h_wave<1>(ha, whl);
+    else if (wave == 2) wgrad_h_wave<2>(ha, whl);
+    else wgrad_h_wave<3>(ha, whl);
+}
+
+// as conv3d_wgrad_reduce_kernel, with the power-of-two scale of the output gradient taken back out
+__global__ void __launch_bounds__(256)
+conv3d_wgrad_reduce_scaled_kernel(const float *partial, int chunks, int Cout, int Cin, const float *g_absmax, float *dw) {
+    const int nco = Cout / 32, ncib = Cin / 32;
+    const size_t total = (size_t)Cout * Cin * 27, per_chunk = (size_t)nco * ncib * 27 * 1024;
+    const float post = 1.0f / pow2_scale_for(g_absmax);
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int ci = (int)(e & 31), co = (int)((e >> 5) & 31);
+        size_t r = e >> 10;
+        const int tap = (int)(r % 27); r /= 27;
+        const int cib = (int)(r % ncib), cob = (int)(r / ncib);
+        float sum = 0.0f;
+        for (int c = 0; c < chunks; ++c) sum += partial[(size_t)c * per_chunk + e];
+        dw[((size_t)(cob * 32 + co) * Cin + cib * 32 + ci) * 27 + tap] = sum * post;
+    }
+}
+
 // ---- GroupNorm backward ------------------------------------------------------------------------
 // part[b][blk][c] = (sum_v dxn, sum_v dxn * x) over the block's voxels; x is the virtual concat input
 __global__ void __launch_bounds__(256)
@@ -2340,6 +2603,53 @@ int vt_conv3d_wgrad(const float *skip, int C1, const float *low, int C2, int B, 
     hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        (const float *)workspace, chunks, Cout, Cin, dw);
     return vt_check(hipGetLastError(), "vt_conv3d_wgrad");
+}
+
+static int wgrad_h_chunks(int B, int D, int H, int W, int pairs) {
+    const int ntiles = B * (W / 8) * (H / 8) * (D / WH_TZ);
+    int chunks = 512 / pairs;                                      // two workgroups per CU
+    if (chunks < 1) chunks = 1;
+    if (chunks > ntiles) chunks = ntiles;
+    return chunks;
+}
+
+size_t vt_conv3d_wgrad_f16x3_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || (D % WH_TZ) || (H & 7) || (W & 7) || Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 31)) return 0;
+    if ((size_t)B * D * H * W * (Cin > Cout ? Cin : Cout) >= ((size_t)1 << 32)) return 0;        // 32-bit element offsets
+    const int pairs = (Cin / 32) * (Cout / 32);
+    return (size_t)wgrad_h_chunks(B, D, H, W, pairs) * pairs * 27 * 1024 * sizeof(float);
+}
+
+int vt_conv3d_wgrad_f16x3(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                          const float *scale_shift, const float *g, int Cout, const float *g_absmax,
+                          void *workspace, size_t workspace_bytes, float *dw, void *stream) {
+    WgradHArgs ha;
+    WgradArgs &a = ha.w;
+    a.c.s = Src{skip, low, C1, low ? C2 : 0, D, H, W};
+    if (!src_ok(a.c.s, B) || !g || !workspace || !dw) return vt_fail(VT_ERR_INVALID, "vt_conv3d_wgrad_f16x3: bad argument");
+    const int Cin = a.c.s.C1 + a.c.s.C2;
+    const size_t need = vt_conv3d_wgrad_f16x3_workspace_bytes(B, D, H, W, Cin, Cout);
+    if (!need) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_wgrad_f16x3: shape not covered (sides in multiples of 8, channels of 32); use vt_conv3d_wgrad");
+    if (workspace_bytes < need) return vt_fail(VT_ERR_WORKSPACE, "vt_conv3d_wgrad_f16x3: workspace too small");
+    a.c.scale_shift = scale_shift; a.c.wp = nullptr; a.c.out = nullptr; a.c.part = nullptr; a.c.Cout = Cout; a.c.relu = 0;
+    a.c.TX = 8; a.c.TY = 8; a.c.TZ = WH_TZ;
+    a.c.tiles_x = W / 8; a.c.tiles_y = H / 8; a.c.tiles_z = D / WH_TZ;
+    a.g = g; a.partial = (float *)workspace;
+    a.ntiles = B * a.c.tiles_x * a.c.tiles_y * a.c.tiles_z;
+    ha.g_absmax = g_absmax;
+    const int pairs = (Cin / 32) * (Cout / 32), chunks = wgrad_h_chunks(B, D, H, W, pairs);
+    static bool attr = false;
+    if (!attr) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WH_LDS);
+        if (e != hipSuccess) return vt_check(e, "vt_conv3d_wgrad_f16x3: hipFuncSetAttribute");
+        attr = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv3d_wgrad_h_kernel, dim3((unsigned)chunks, (unsigned)pairs), dim3(WH_THREADS), WH_LDS, st, ha);
+    const size_t total = (size_t)Cout * Cin * 27;
+    hipLaunchKernelGGL(conv3d_wgrad_reduce_scaled_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const float *)workspace, chunks, Cout, Cin, g_absmax, dw);
+    return vt_check(hipGetLastError(), "vt_conv3d_wgrad_f16x3");
 }
 
 int vt_gn_bwd(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,

@@ -12,9 +12,8 @@ concat, 1x1x1 final conv, no final activation (``testing=False``).
 """
 from __future__ import annotations
 
-from collections import OrderedDict
-
 import os
+from collections import OrderedDict
 
 import torch
 from torch import nn
@@ -80,6 +79,9 @@ class _Up(nn.Module):
         return self.basic_module(torch.cat((skip, x), dim=1))
 
 
+_WGRAD_F16 = os.environ.get("VTACO_UNET_WGRAD_PRECISION", "f16x3") != "f32"     # A/B knob: "f32" keeps the exact-f32 weight-gradient kernel
+
+
 class _GcrFn(torch.autograd.Function):
     """One 'gcr' SingleConv on channels-last tensors through the C ABI, differentiable:
     forward vt_gn_scale_shift + vt_conv3d_gcr[_bf16x3]; backward vt_relu_mask, the forward conv
@@ -120,7 +122,9 @@ class _GcrFn(torch.autograd.Function):
             gmax = torch.linalg.vector_norm(g, ord=float("inf")).reshape(1)
         dxn, _ = ops.conv3d_gcr(g, None, None, ops.conv3d_pack(w_t), w_t.shape[0], False, split, want_stats=False,
                                 packed_w_f16x3=half, in_absmax=gmax)
-        dw = ops.conv3d_wgrad(x, low, ss, g) if ctx.needs_input_grad[4] else None
+        # weight gradient: split-half operands as well (K = voxels; g under the same power-of-two rescale)
+        dw = ops.conv3d_wgrad(x, low, ss, g, precision="f16x3" if precision == "f16x3" and _WGRAD_F16 else "f32",
+                              g_absmax=gmax) if ctx.needs_input_grad[4] else None
         x_st = (x_part, x_part.shape[1])
         low_st = (low_part, low_part.shape[1]) if low is not None else None
         dskip, dlow, dgamma, dbeta = ops.gn_bwd(x, x_st, low, low_st, dxn, gamma, groups, eps,

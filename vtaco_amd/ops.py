@@ -895,12 +895,22 @@ def relu_mask(dy, y):
     return g
 
 
-def conv3d_wgrad(x, low, ss, g):
-    """dW [Cout,Cin,3,3,3] of the 3x3x3 conv over xn = [x | upsample(low)] * scale + shift (vt_conv3d_wgrad)."""
+def conv3d_wgrad(x, low, ss, g, precision="f32", g_absmax=None):
+    """dW [Cout,Cin,3,3,3] of the 3x3x3 conv over xn = [x | upsample(low)] * scale + shift (vt_conv3d_wgrad).
+    ``precision="f16x3"``: vt_conv3d_wgrad_f16x3 where it covers the shape (split-half operands on the f16 matrix core;
+    ``g_absmax`` = device scalar max |g| for its power-of-two rescale of g), the f32 kernel elsewhere."""
     lib = _lib.load()
     B, D, H, W, C1 = x.shape
     C2 = low.shape[-1] if low is not None else 0
     Cout = g.shape[-1]
+    hbytes = lib.vt_conv3d_wgrad_f16x3_workspace_bytes(B, D, H, W, C1 + C2, Cout) if precision == "f16x3" else 0
+    if hbytes:
+        ws = torch.empty(hbytes // 4, dtype=torch.float32, device=x.device)
+        dw = torch.empty((Cout, C1 + C2, 3, 3, 3), dtype=torch.float32, device=x.device)
+        check(lib.vt_conv3d_wgrad_f16x3(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
+                                        dev_ptr(g, "g"), Cout, dev_ptr(g_absmax, "g_absmax"), ctypes.c_void_p(ws.data_ptr()), hbytes,
+                                        dev_ptr(dw, "dw"), stream_ptr()), "vt_conv3d_wgrad_f16x3")
+        return dw
     nbytes = lib.vt_conv3d_wgrad_workspace_bytes(B, D, H, W, C1 + C2, Cout)
     if nbytes == 0:
         raise VtError("conv3d_wgrad: unsupported shape")
