@@ -476,6 +476,8 @@ int vt_voxel_scatter_mean_cl_bwd(const float *grad_grid_cl, const int *idx, cons
 /*   vt_maxpool3d_cl_bwd  routes dy to the first maximum of each 2x2x2 window.             */
 /* ------------------------------------------------------------------------- */
 int vt_relu_mask(const float *dy, const float *y, float *g, int64_t n, void *stream);
+/* the same, and *absmax = max |g| (device scalar; feeds the power-of-two rescale of the split-half data / weight gradient kernels) */
+int vt_relu_mask_absmax(const float *dy, const float *y, float *g, int64_t n, float *absmax, void *stream);
 size_t vt_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int vt_conv3d_wgrad(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                     const float *scale_shift, const float *g, int Cout, void *workspace, size_t workspace_bytes,

@@ -191,16 +191,29 @@ rows_wgrad_kernel(const float *G, int M, const float *x1, int C1, const float *x
     float csum = 0.0f;
     const int p0 = chunk * RW_CHUNK + wave * (RW_CHUNK / 4);
     const int p1 = min(p0 + RW_CHUNK / 4, N);
-    for (int p = p0 + kk; p < p1 + kk; p += 2) {             // each MFMA contracts two points
-        const bool ok = p < p1;
-        const float gv = (ok && m < M) ? G[(size_t)p * M + m] : 0.0f;
-        float xv = 0.0f;
-        if (ok && k < K) {
-            xv = k < C1 ? x1[(size_t)p * C1 + k] : x2[(size_t)p * C2 + (k - C1)];
-            if (relu_x) xv = fmaxf(xv, 0.0f);
+    // each MFMA contracts two points; eight MFMAs' operands are loaded together, branch-free (indices clamped into the
+    // arrays, zeros selected afterwards): one load round trip per 16 points instead of one per 2 (45 -> ~10 us per layer)
+    const int mc = min(m, M - 1), kc = min(k, K - 1);
+    const float *xsrc = kc < C1 ? x1 + kc : x2 + (kc - C1);
+    const int xstride = kc < C1 ? C1 : C2;
+    const bool mok = m < M, kok = k < K;
+    for (int pb = p0; pb < p1; pb += 16) {
+        float gv[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = min(pb + 2 * u + kk, N - 1);
+            gv[u] = G[(size_t)p * M + mc];
+            xv[u] = xsrc[(size_t)p * xstride];
         }
-        csum += gv;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, xv, acc, 0, 0, 0);     // D[m][k] += G[p][m] * X[p][k]
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = pb + 2 * u + kk < p1;
+            const float g1 = (ok && mok) ? gv[u] : 0.0f;
+            float x1v = (ok && kok) ? xv[u] : 0.0f;
+            if (relu_x) x1v = fmaxf(x1v, 0.0f);
+            csum += g1;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, x1v, acc, 0, 0, 0);     // D[m][k] += G[p][m] * X[p][k]
+        }
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) red[wave][s * 64 + lane] = acc[s];
@@ -216,7 +229,15 @@ rows_wgrad_reduce_kernel(const float *partial, int nchunks, int M, int K, int MT
     const int mt = blockIdx.x, kt = blockIdx.y;
     for (int e = threadIdx.x; e < RW_PART; e += 256) {
         float s = 0.0f;
-        for (int c = 0; c < nchunks; ++c) s += partial[(((size_t)c * MT + mt) * KT + kt) * RW_PART + e];
+        int c = 0;
+        for (; c + 8 <= nchunks; c += 8) {                       // eight partials in flight, added in chunk order
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = partial[(((size_t)(c + u) * MT + mt) * KT + kt) * RW_PART + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; c < nchunks; ++c) s += partial[(((size_t)c * MT + mt) * KT + kt) * RW_PART + e];
         if (e < 1024) {
             const int r = e >> 6, l = e & 63;
             const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), k = kt * 32 + (l & 31);   // accumulator row of register r, lane half

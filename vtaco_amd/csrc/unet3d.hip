@@ -1997,10 +1997,27 @@ int vt_unet3d_fwd(const float *x_cl, int B, int R, const vt_unet3d_params *param
 // =====================================================================================
 namespace {
 
-__global__ void __launch_bounds__(256) relu_mask_kernel(const f32x4 *dy, const f32x4 *y, f32x4 *g, size_t n4) {
+// absmax (or null): max |g| as the bit pattern of a non-negative float, which orders like an unsigned integer: one atomicMax per
+// workgroup on a cell the launcher zeroed -- exact and independent of the order of arrival (NaN gradients land above every
+// finite value and stop the consumers' rescale, as a NaN maximum would)
+__global__ void __launch_bounds__(256) relu_mask_kernel(const f32x4 *dy, const f32x4 *y, f32x4 *g, size_t n4, unsigned *absmax) {
+    unsigned u = 0;
+    auto bits = [](float x) { return __builtin_bit_cast(unsigned, x) & 0x7fffffffu; };
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const f32x4 a = dy[i], b = y[i];
-        g[i] = f32x4{b.x > 0.f ? a.x : 0.f, b.y > 0.f ? a.y : 0.f, b.z > 0.f ? a.z : 0.f, b.w > 0.f ? a.w : 0.f};
+        const f32x4 v = f32x4{b.x > 0.f ? a.x : 0.f, b.y > 0.f ? a.y : 0.f, b.z > 0.f ? a.z : 0.f, b.w > 0.f ? a.w : 0.f};
+        g[i] = v;
+        const unsigned m01 = max(bits(v.x), bits(v.y)), m23 = max(bits(v.z), bits(v.w));
+        u = max(u, max(m01, m23));
+    }
+    if (!absmax) return;
+    __shared__ unsigned wmax[4];
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)u, o); u = t > u ? t : u; }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned a0 = wmax[0] > wmax[1] ? wmax[0] : wmax[1], a1 = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+        atomicMax(absmax, a0 > a1 ? a0 : a1);
     }
 }
 
@@ -2557,8 +2574,21 @@ int vt_relu_mask(const float *dy, const float *y, float *g, int64_t n, void *str
     size_t blocks = ((size_t)n / 4 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const f32x4 *>(dy), reinterpret_cast<const f32x4 *>(y), reinterpret_cast<f32x4 *>(g), (size_t)n / 4);
+                       reinterpret_cast<const f32x4 *>(dy), reinterpret_cast<const f32x4 *>(y), reinterpret_cast<f32x4 *>(g), (size_t)n / 4,
+                       (unsigned *)nullptr);
     return vt_check(hipGetLastError(), "vt_relu_mask");
+}
+
+int vt_relu_mask_absmax(const float *dy, const float *y, float *g, int64_t n, float *absmax, void *stream) {
+    if (!dy || !y || !g || !absmax || n <= 0 || (n & 3)) return vt_fail(VT_ERR_INVALID, "vt_relu_mask_absmax: bad argument (n must be a positive multiple of 4)");
+    size_t blocks = ((size_t)n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    const hipError_t e = hipMemsetAsync(absmax, 0, sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return vt_check(e, "vt_relu_mask_absmax: hipMemsetAsync");
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4 *>(dy), reinterpret_cast<const f32x4 *>(y), reinterpret_cast<f32x4 *>(g), (size_t)n / 4,
+                       reinterpret_cast<unsigned *>(absmax));
+    return vt_check(hipGetLastError(), "vt_relu_mask_absmax");
 }
 
 static int wgrad_chunks(int B, int D, int H, int W, int pairs) {

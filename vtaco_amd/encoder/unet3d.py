@@ -111,15 +111,17 @@ class _GcrFn(torch.autograd.Function):
     def backward(ctx, dy, _dpart):
         x, low, gamma, weight, ss, y, x_part, low_part = ctx.saved_tensors
         groups, eps, precision = ctx.cfg
-        g = ops.relu_mask(dy, y)
+        if precision == "f16x3":
+            g, gmax = ops.relu_mask(dy, y, want_absmax=True)                # max |g| from the same pass (the kernels' power-of-two rescale)
+        else:
+            g, gmax = ops.relu_mask(dy, y), None
         w_t = weight.flip(2, 3, 4).transpose(0, 1).contiguous()          # [Cin,Cout,3,3,3]: conv of g with it = dxn
         split = ops.conv3d_pack(w_t, "bf16x3") if precision == "bf16x3" else None
-        half, gmax = None, None
+        half = None
         if precision == "f16x3":
             # output gradients sit many orders of magnitude below the half range: the kernel scales them by a power of two
             # taken from their largest element before the split (exact), so the data gradient keeps f32-level accuracy
             half = ops.conv3d_pack(w_t, "f16x3")
-            gmax = torch.linalg.vector_norm(g, ord=float("inf")).reshape(1)
         dxn, _ = ops.conv3d_gcr(g, None, None, ops.conv3d_pack(w_t), w_t.shape[0], False, split, want_stats=False,
                                 packed_w_f16x3=half, in_absmax=gmax)
         # weight gradient: split-half operands as well (K = voxels; g under the same power-of-two rescale)

@@ -887,10 +887,16 @@ def gn_conv3d_relu(x, x_stats, low, low_stats, gamma, beta, groups, packed_w, Co
     return conv3d_gcr(x, low, ss, packed_w, Cout, relu, packed_w_bf16x3, packed_w_f16x3=packed_w_f16x3)
 
 
-def relu_mask(dy, y):
-    """g = dy where y > 0 else 0 (vt_relu_mask)."""
+def relu_mask(dy, y, want_absmax=False):
+    """g = dy where y > 0 else 0 (vt_relu_mask); with ``want_absmax`` also max |g| as a device scalar [1] from the same pass
+    (vt_relu_mask_absmax): returns (g, absmax)."""
     dy = _c(dy)
     g = torch.empty_like(dy)
+    if want_absmax:
+        m = torch.empty(1, dtype=torch.float32, device=dy.device)
+        check(_lib.load().vt_relu_mask_absmax(dev_ptr(dy, "dy"), dev_ptr(y, "y"), dev_ptr(g, "g"), dy.numel(), dev_ptr(m, "absmax"),
+                                              stream_ptr()), "vt_relu_mask_absmax")
+        return g, m
     check(_lib.load().vt_relu_mask(dev_ptr(dy, "dy"), dev_ptr(y, "y"), dev_ptr(g, "g"), dy.numel(), stream_ptr()), "vt_relu_mask")
     return g
 
