@@ -526,6 +526,11 @@ int vt_plane_scatter_mean_bwd(const float *grad_plane, const int *idx, const int
 int vt_mano_pack(const float *v_template, const float *shapedirs, const float *betas, const float *posedirs,
                  const float *j_regressor, const float *weights, const float *hands_mean, float *blob, void *stream);
 int vt_mano_fwd(const float *pose, int B, const float *blob, int center_idx, float *verts, float *joints, void *stream);
+/* Backward of vt_mano_fwd (PyTorch autograd through manolayer.py:186-347 under loss_mano / loss_pc, training.py:59-60):   */
+/* dpose [B,48] from dverts [B,778,3] and djoints [B,21,3]; one workgroup per hand, the forward's intermediates recomputed,  */
+/* every sum in a fixed order (bit-reproducible).                                                                          */
+int vt_mano_bwd(const float *pose, int B, const float *blob, int center_idx, const float *dverts, const float *djoints,
+                float *dpose, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* PointNet per-point MLP (inference).  Replaces the nn.Linear / ResnetBlockFC   */

@@ -543,7 +543,7 @@ def mano_forward(model, pose, center_idx=9):
     for j in range(16):
         par = MANO_PARENTS[j]
         t = J[j] if par < 0 else J[j] - J[par]
-        local = torch.zeros(B, 4, 4)
+        local = torch.zeros(B, 4, 4, dtype=pose.dtype)                 # (float64 poses give a float64 reference for gradient checks)
         local[:, :3, :3] = rots[:, j]
         local[:, :3, 3] = t
         local[:, 3, 3] = 1.0
@@ -553,10 +553,10 @@ def mano_forward(model, pose, center_idx=9):
     A = G.clone()
     A[:, :, :3, 3] = G[:, :, :3, 3] - torch.matmul(G[:, :, :3, :3], J.view(1, 16, 3, 1)).squeeze(-1)
     T = torch.einsum("vj,bjrc->bvrc", model["weights"], A)                                      # [B,778,4,4]
-    vh = torch.cat([v_posed, torch.ones(B, v_posed.shape[1], 1)], dim=2)
+    vh = torch.cat([v_posed, torch.ones(B, v_posed.shape[1], 1, dtype=pose.dtype)], dim=2)
     verts = torch.einsum("bvrc,bvc->bvr", T, vh)[:, :, :3]
     jtr = torch.cat([G[:, :, :3, 3], verts[:, MANO_TIPS_RIGHT]], dim=1)[:, MANO_JOINT_ORDER]
-    centre = jtr[:, center_idx:center_idx + 1] if center_idx is not None else torch.zeros(B, 1, 3)
+    centre = jtr[:, center_idx:center_idx + 1] if center_idx is not None else torch.zeros(B, 1, 3, dtype=pose.dtype)
     return verts - centre, jtr - centre
 
 

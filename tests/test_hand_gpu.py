@@ -99,6 +99,27 @@ def test_mano_layer_kernel(center_idx, tmp_path):
     pr = pose.clone().requires_grad_(True)
     (orc.mano_forward(synth_mano.as_model(asset), pr, center_idx)[0] * w).sum().backward()
     assert maxdiff(pg.grad, pr.grad) <= 1e-4 * float(pr.grad.abs().max())
+    # vt_mano_bwd with verts AND joints gradients (tips, centring), B = 37, large angles, against the oracle's autograd in float64
+    gen = torch.Generator().manual_seed(4)
+    wv, wj = torch.randn(37, 778, 3, generator=gen), torch.randn(37, 21, 3, generator=gen) * 20.0
+    pg = big.clone().to(dev).requires_grad_(True)
+    vt, jt = layer(pg)
+    ((vt * wv.to(dev)).sum() + (jt * wj.to(dev)).sum()).backward()
+    pr = big.clone().double().requires_grad_(True)
+    model64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in synth_mano.as_model(asset).items()}
+    rv, rj = orc.mano_forward(model64, pr, center_idx)
+    ((rv * wv.double()).sum() + (rj * wj.double()).sum()).backward()
+    assert maxdiff(pg.grad, pr.grad.float()) <= 2e-5 * float(pr.grad.abs().max())
+    again = big.clone().to(dev).requires_grad_(True)
+    v2, j2 = layer(again)
+    ((v2 * wv.to(dev)).sum() + (j2 * wj.to(dev)).sum()).backward()
+    assert torch.equal(again.grad, pg.grad)                        # fixed summation order
+    # joints only (d verts absent)
+    pj = big.clone().to(dev).requires_grad_(True)
+    (layer(pj)[1] * wj.to(dev)).sum().backward()
+    pr2 = big.clone().double().requires_grad_(True)
+    (orc.mano_forward(model64, pr2, center_idx)[1] * wj.double()).sum().backward()
+    assert maxdiff(pj.grad, pr2.grad.float()) <= 2e-5 * float(pr2.grad.abs().max())
 
 
 def test_pca_pose_space_and_refused_arguments(tmp_path):

@@ -271,3 +271,42 @@ def test_shipped_shape_yaml_builds_dataset_model_trainer_and_loads_the_t2d_check
     assert trainer.encode_t2d and trainer.with_img and trainer.pretrained_t2d and trainer.num_sample == 64
     gen = method.get_generator(donor, cfg, None)
     assert gen.with_img and gen.encode_t2d and gen.resolution0 == 32
+
+
+def test_generator_weight_stamps_and_eval_mode_follow_the_model():
+    """Generator3D's per-scene checks (the captured scene graph is replayed only while they are unchanged) walk cached module
+    tables instead of nn.Module's recursive generators: a weight updated in place, moved / cast (``.to()`` swaps the storage under the
+    same Parameter), replaced by a new Parameter, or a buffer written in place must all change the stamps; ``_eval_mode`` must
+    put every submodule in eval mode whichever one was switched to train."""
+    from vtaco_amd.conv_onet.generation import Generator3D
+    from vtaco_amd.conv_onet.models import ConvolutionalOccupancyNetwork, decoder_dict
+    from vtaco_amd.encoder import encoder_dict
+    dec = decoder_dict['simple_local'](dim=3, c_dim=32, hidden_size=32, n_blocks=5, padding=0.1)
+    model = ConvolutionalOccupancyNetwork(dec, None, device='cpu')
+    model.encoder = encoder_dict['pointnet_local_pool'](dim=3, c_dim=32, padding=0.1, hidden_dim=32, plane_type='grid', grid_resolution=16,
+                                                        unet3d=True, unet3d_kwargs=dict(num_levels=2, f_maps=32, in_channels=32, out_channels=32))
+    model.register_buffer("some_buffer", torch.zeros(3))
+    gen = Generator3D(model, device='cpu', resolution0=8, padding=0.1)
+    want = tuple((id(t), t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers()))
+    got = gen._weight_stamps()
+    assert sorted(zip(*got)) == sorted(want)                          # the same tensors as the recursive walk finds
+    s0 = gen._weight_stamps()
+    assert gen._weight_stamps() == s0
+    with torch.no_grad():
+        model.decoder.fc_out.weight.add_(1.0)                         # optimizer.step / load_state_dict
+    s1 = gen._weight_stamps()
+    assert s1 != s0
+    model.decoder.fc_out.weight = torch.nn.Parameter(torch.zeros_like(model.decoder.fc_out.weight))
+    s2 = gen._weight_stamps()
+    assert s2 != s1
+    model.double()                                                    # .to(): new storage under the same Parameter objects
+    s3 = gen._weight_stamps()
+    assert s3 != s2
+    model.some_buffer.add_(1.0)
+    assert gen._weight_stamps() != s3
+    model.train()
+    gen._eval_mode()
+    assert not any(m.training for m in model.modules())
+    model.encoder.unet3d.train()                                      # one branch only
+    gen._eval_mode()
+    assert not any(m.training for m in model.modules())

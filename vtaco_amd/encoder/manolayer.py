@@ -4,9 +4,10 @@ Built for the configuration the shipped configs use (configs/VTacO/VTacO_YCB.yam
 root and joint rotations, ``use_pca: False``, ``flat_hand_mean: False``, right hand); the PCA pose
 space is kept because it is one matmul in front, the rotmat/quat input modes are refused loudly.
 
-Inference (no autograd) runs ``vt_mano_fwd`` -- one HIP workgroup per hand.  Under autograd the same
-arithmetic runs as host PyTorch ops (``forward_torch``): the layer has no parameters and 0.95 MFLOP per
-hand, its backward is plumbing between ``loss_pc`` and ``fc_mano`` (training.py:493-494).
+``vt_mano_fwd`` -- one HIP workgroup per hand -- runs the layer; under autograd its backward is
+``vt_mano_bwd`` (d pose from d verts / d joints: the plumbing between ``loss_pc`` and ``fc_mano``,
+training.py:493-494).  ``forward_torch`` is the same arithmetic as differentiable host PyTorch ops: the left
+hand (the kernels carry the right hand's tip table) and the ``VTACO_MANO_BACKWARD=host`` A/B knob use it.
 
 The model file is read WITHOUT chumpy: MANO_RIGHT.pkl holds one chumpy object (``shapedirs``, a
 ``chumpy.reordering.Select`` over a ``Ch``), resolved here from its pickled state.  The asset itself is
@@ -94,6 +95,21 @@ def _rodrigues(axisang):
             2 * w * z + 2 * x * y, w * w - x * x + y * y - z * z, 2 * y * z - 2 * w * x,
             2 * x * z - 2 * w * y, 2 * w * x + 2 * y * z, w * w - x * x - y * y + z * z]
     return torch.stack(rows, dim=1).view(-1, 3, 3)
+
+
+class _ManoFn(torch.autograd.Function):
+    """vt_mano_fwd under autograd: the backward is vt_mano_bwd (d pose from d verts, d joints; the model blob is a constant)."""
+
+    @staticmethod
+    def forward(ctx, pose48, blob, center_idx):
+        ctx.save_for_backward(pose48, blob)
+        ctx.center_idx = center_idx
+        return ops.mano_fwd(pose48, blob, center_idx)
+
+    @staticmethod
+    def backward(ctx, dverts, djoints):
+        pose48, blob = ctx.saved_tensors
+        return ops.mano_bwd(pose48, blob, ctx.center_idx, dverts, djoints), None, None
 
 
 class ManoLayer(nn.Module):
@@ -190,11 +206,13 @@ class ManoLayer(nn.Module):
         if not th_pose_coeffs.is_cuda:
             raise VtError(f"ManoLayer: inputs must live on a HIP device (got {th_pose_coeffs.device})")
         pose48 = self._axis_angles(th_pose_coeffs.float())
-        if torch.is_grad_enabled() and pose48.requires_grad:
-            verts, jtr = self.forward_torch(pose48)
-        elif self.side != "right":
-            with torch.no_grad():
-                verts, jtr = self.forward_torch(pose48)              # the kernel's tip table is the right hand's
+        if self.side != "right":
+            verts, jtr = self.forward_torch(pose48)                  # the kernels' tip table is the right hand's
+        elif torch.is_grad_enabled() and pose48.requires_grad:
+            if os.environ.get("VTACO_MANO_BACKWARD", "hip") == "host":
+                verts, jtr = self.forward_torch(pose48)              # A/B knob: host-PyTorch autograd
+            else:
+                verts, jtr = _ManoFn.apply(pose48.contiguous(), self._packed(), self.center_idx)
         else:
             verts, jtr = ops.mano_fwd(pose48, self._packed(), self.center_idx)
         results = [verts, jtr]

@@ -536,6 +536,18 @@ def mano_fwd(pose, blob, center_idx=9):
     return verts, joints
 
 
+def mano_bwd(pose, blob, center_idx, dverts, djoints):
+    """d pose [B,48] of mano_fwd from d verts [B,778,3] and d joints [B,21,3] (vt_mano_bwd)."""
+    pose = _c(pose.float())
+    B = pose.shape[0]
+    dverts = _c(dverts.float()) if dverts is not None else torch.zeros((B, 778, 3), dtype=torch.float32, device=pose.device)
+    djoints = _c(djoints.float()) if djoints is not None else torch.zeros((B, 21, 3), dtype=torch.float32, device=pose.device)
+    dpose = torch.empty((B, 48), dtype=torch.float32, device=pose.device)
+    check(_lib.load().vt_mano_bwd(dev_ptr(pose, "pose"), B, dev_ptr(blob, "blob"), -1 if center_idx is None else int(center_idx),
+                                  dev_ptr(dverts, "dverts"), dev_ptr(djoints, "djoints"), dev_ptr(dpose, "dpose"), stream_ptr()), "vt_mano_bwd")
+    return dpose
+
+
 # --------------------------------------------------------------------------------------
 # decode backward (training)
 # --------------------------------------------------------------------------------------
