@@ -141,6 +141,8 @@ def stage_times(scene, dec, grid, nx, out, dev, precision):
         gen = Generator3D(model, device=dev, resolution0=nx // 4, padding=0.1, decode_precision=precision)
         gen.generate_mesh_graphed(pc)               # builds + captures
         res["end_to_end_hipgraph"] = timed(lambda: gen.generate_mesh_graphed(pc), 20)
+        # the reference's entry point (generation.py:117-273): replays the same graph by default
+        res["generate_obj_mesh_wnf"] = timed(lambda: gen.generate_obj_mesh_wnf({"inputs": pc}), 20)
     return res
 
 

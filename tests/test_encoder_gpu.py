@@ -142,6 +142,15 @@ def test_sharded_generation_single_rank_equals_plain():
             assert torch.equal(torch.cat(parts), whole)
 
 
+def _eager_mesh(gen, p):
+    """generate_obj_mesh_wnf with plain launches (its default replays the visual branch as a captured graph)."""
+    gen.scene_graph = False
+    try:
+        return gen.generate_obj_mesh_wnf({"inputs": p})
+    finally:
+        del gen.scene_graph
+
+
 def test_graphed_scene_equals_eager():
     """hipGraph replay of encode + decode + MC classification gives the eager mesh, repeatedly."""
     from vtaco_amd.conv_onet.generation import Generator3D
@@ -154,9 +163,11 @@ def test_graphed_scene_equals_eager():
     gen = Generator3D(model, device=DEV, resolution0=8, padding=0.1)
     for b in (0, 1, 0):
         p = T(a["p"])[b:b + 1]
-        eager = gen.generate_obj_mesh_wnf({"inputs": p})
+        eager = _eager_mesh(gen, p)
         fast = gen.generate_mesh_graphed(p)
         assert torch.equal(eager.faces, fast.faces) and torch.equal(eager.vertices, fast.vertices)
+        default = gen.generate_obj_mesh_wnf({"inputs": p})          # the reference entry point takes the graph by default
+        assert torch.equal(default.faces, fast.faces) and torch.equal(default.vertices, fast.vertices) and len(gen._graphs) == 1
 
 
 def test_graphed_scene_survives_weight_updates_and_other_shapes():
@@ -179,7 +190,7 @@ def test_graphed_scene_survives_weight_updates_and_other_shapes():
     p = sphere_cloud(0, T=1500)
 
     def same():
-        eager = gen.generate_obj_mesh_wnf({"inputs": p})
+        eager = _eager_mesh(gen, p)
         fast = gen.generate_mesh_graphed(p)
         return torch.equal(eager.faces, fast.faces) and torch.equal(eager.vertices, fast.vertices) and eager.faces.shape[0] > 0
     assert same()
@@ -201,11 +212,16 @@ def test_graphed_scene_survives_weight_updates_and_other_shapes():
     fast = gen.generate_mesh_graphed(p)
     assert gen._graphs[next(iter(gen._graphs))]["graph"] is g1
     del junk
-    eager = gen.generate_obj_mesh_wnf({"inputs": p})
+    eager = _eager_mesh(gen, p)
     assert torch.equal(eager.faces, fast.faces) and torch.equal(eager.vertices, fast.vertices)
     # (3) load_state_dict (in-place copy of other values)
     sd = {k: v.clone() * 0.99 if v.dtype.is_floating_point else v for k, v in model.state_dict().items()}
     model.load_state_dict(sd)
+    assert same()
+    # (4) at most MAX_SCENE_GRAPHS shapes stay captured (each pins its workspaces); the oldest goes first
+    for t in (700, 800, 900, 1000, 1100):
+        gen.generate_obj_mesh_wnf({"inputs": sphere_cloud(3, T=t)})
+    assert len(gen._graphs) == gen.MAX_SCENE_GRAPHS and all(k[0][1] != 1500 for k in gen._graphs)
     assert same()
 
 

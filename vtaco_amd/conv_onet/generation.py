@@ -13,6 +13,7 @@ encoder + MANO layer on the device and the reference's wrist-frame post-processi
 from __future__ import annotations
 
 import operator
+import os
 from collections import namedtuple
 
 import torch
@@ -26,6 +27,10 @@ _tensor_version = operator.attrgetter("_version")
 
 class Generator3D(object):
     """Constructor arguments as the reference (generation.py:42-52)."""
+
+    MAX_SCENE_GRAPHS = 4
+    # generate_obj_mesh_wnf replays the visual branch as a captured hipGraph (VTACO_SCENE_GRAPH=0: eager launches)
+    scene_graph = os.environ.get("VTACO_SCENE_GRAPH", "1") != "0"
 
     def __init__(self, model, points_batch_size=100000, threshold=0.5, refinement_step=0, device=None,
                  resolution0=16, upsampling_steps=3, with_normals=False, padding=0.1, sample=False,
@@ -119,8 +124,12 @@ class Generator3D(object):
         hit = self._graphs.get(key)
         stamps = self._weight_stamps()
         if hit is not None and hit["stamps"] == stamps:
+            if len(self._graphs) > 1:
+                self._graphs[key] = self._graphs.pop(key)   # most recently used last
             return hit
         self._graphs.pop(key, None)                      # stale: drop the old graph (and its keep-alive list) first
+        while len(self._graphs) >= self.MAX_SCENE_GRAPHS:   # every graph pins its workspaces (~0.5 GB at 128^3): keep a few shapes
+            self._graphs.pop(next(iter(self._graphs)))
         static_in = torch.zeros(shape, dtype=torch.float32, device=self.device)
 
         def run():
@@ -280,6 +289,9 @@ class Generator3D(object):
         inputs = data.get('inputs').to(self.device)
         if self.with_img and c_img_all is None:
             return self._generate_tactile(data)
+        if not self.with_img and self.scene_graph and inputs.dim() == 3 and inputs.shape[0] == 1:
+            # the visual branch: the same launches replayed as one hipGraph per (cloud shape, lattice) -- 1.1 instead of 1.5 ms
+            return self.generate_mesh_graphed(inputs)
         with torch.no_grad():
             c = self.model.encode_inputs(inputs)
             values = self.eval_lattice(c, nx, c_img_all=c_img_all if self.with_img else None)
