@@ -168,6 +168,10 @@ def test_graphed_scene_equals_eager():
         assert torch.equal(eager.faces, fast.faces) and torch.equal(eager.vertices, fast.vertices)
         default = gen.generate_obj_mesh_wnf({"inputs": p})          # the reference entry point takes the graph by default
         assert torch.equal(default.faces, fast.faces) and torch.equal(default.vertices, fast.vertices) and len(gen._graphs) == 1
+    if type(gen).scene_graph:                                       # (VTACO_SCENE_GRAPH=0 turns the default off)
+        fresh = Generator3D(model, device=DEV, resolution0=8, padding=0.1)
+        fresh.generate_obj_mesh_wnf({"inputs": T(a["p"])[:1]})
+        assert len(fresh._graphs) == 1
 
 
 def test_graphed_scene_survives_weight_updates_and_other_shapes():
@@ -220,7 +224,7 @@ def test_graphed_scene_survives_weight_updates_and_other_shapes():
     assert same()
     # (4) at most MAX_SCENE_GRAPHS shapes stay captured (each pins its workspaces); the oldest goes first
     for t in (700, 800, 900, 1000, 1100):
-        gen.generate_obj_mesh_wnf({"inputs": sphere_cloud(3, T=t)})
+        gen.generate_mesh_graphed(sphere_cloud(3, T=t))
     assert len(gen._graphs) == gen.MAX_SCENE_GRAPHS and all(k[0][1] != 1500 for k in gen._graphs)
     assert same()
 

@@ -87,7 +87,10 @@ def test_ksplit_conv_layers_match_f32_kernel():
     """vt_conv3d_gcr_bf16x3_ksplit (input channels dealt over several workgroups per output tile + the slice-order sum) on the
     thin levels of the shipped UNet3D -- 16^3 and 8^3 of one scene, the 384-channel virtual concat, a batch of two at 8^3, no
     ReLU -- against the exact-f32 kernel; its statistics blocks against sums of its own output; bit-reproducible."""
+    import os
     from vtaco_amd import _lib, ops
+    if os.environ.get("VTACO_CONV_KSPLIT"):
+        pytest.skip("the K-split plan is forced or turned off by VTACO_CONV_KSPLIT")
     lib = _lib.load()
     g = torch.Generator().manual_seed(13)
     for B, R, C1, C2, Cout, relu in ((1, 16, 128, 0, 64, True), (1, 16, 128, 256, 128, True), (1, 16, 128, 0, 128, False),
@@ -284,7 +287,8 @@ def test_hip_unet3d_training_path_vs_host_autograd(R, levels, B):
     net.zero_grad(set_to_none=True)
     x_cl = x.permute(0, 2, 3, 4, 1).contiguous().requires_grad_()
     y = net.forward_channels_last_train(x_cl)
-    assert _rel(y.detach().permute(0, 4, 1, 2, 3), y0) <= 2e-5
+    # (VTACO_UNET_TRAIN_PRECISION=bf16x3: 16-bit mantissas in the conv operands)
+    assert _rel(y.detach().permute(0, 4, 1, 2, 3), y0) <= (1e-4 if net.train_precision == "bf16x3" else 2e-5)
     (y * wgt.permute(0, 2, 3, 4, 1)).sum().backward()
     err = max([l2(x_cl.grad.permute(0, 4, 1, 2, 3), gx0)] + [l2(p.grad, gp0[n]) for n, p in net.named_parameters()])
     assert err <= 3.0 * sens + 1e-4, (err, sens)
