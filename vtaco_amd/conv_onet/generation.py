@@ -113,13 +113,13 @@ class Generator3D(object):
         ts = [t for d in self._module_tables()[2] for t in d.values() if t is not None]
         return tuple(map(id, ts)), tuple(map(torch.Tensor.data_ptr, ts)), tuple(map(_tensor_version, ts))
 
-    def _scene_graph(self, shape, nx):
-        """The captured graph of one (input shape, lattice size).  A graph holds raw pointers to derived buffers -- packed conv
-        weights, the decoder blob, the UNet3D workspace -- that live in caches keyed on the weights' versions and on the last
-        shape run; so the entry (a) keeps every such tensor alive next to the graph (``ops.graph_keepalive``) and (b) records the
-        weight stamps at capture: a replay after ``optimizer.step()`` / ``load_state_dict`` / ``.to()`` finds different stamps and
-        captures afresh instead of reading stale or recycled memory."""
-        key = (tuple(shape), nx, self.decode_precision)
+    def _captured(self, key, shapes, run):
+        """The captured graph of ``run(*static_inputs)`` for one key (kind, input shapes, ...): ``{"graph", "in": static inputs, "out":
+        what run returned, ...}``.  A graph holds raw pointers to derived buffers -- packed conv weights, the decoder blob, the UNet3D
+        workspace -- that live in caches keyed on the weights' versions and on the last shape run; so the entry (a) keeps every such
+        tensor alive next to the graph (``ops.graph_keepalive``) and (b) records the weight stamps at capture: a replay after
+        ``optimizer.step()`` / ``load_state_dict`` / ``.to()`` finds different stamps and captures afresh instead of reading stale
+        or recycled memory.  At most MAX_SCENE_GRAPHS entries stay captured, least recently used first out."""
         self._graphs = getattr(self, "_graphs", {})
         hit = self._graphs.get(key)
         stamps = self._weight_stamps()
@@ -130,24 +130,41 @@ class Generator3D(object):
         self._graphs.pop(key, None)                      # stale: drop the old graph (and its keep-alive list) first
         while len(self._graphs) >= self.MAX_SCENE_GRAPHS:   # every graph pins its workspaces (~0.5 GB at 128^3): keep a few shapes
             self._graphs.pop(next(iter(self._graphs)))
-        static_in = torch.zeros(shape, dtype=torch.float32, device=self.device)
-
-        def run():
-            c = self.model.encode_inputs(static_in)
-            vol = self.eval_lattice(c, nx).reshape(nx, nx, nx)
-            return vol, ops.mc_count(vol)
+        static = [torch.zeros(shape, dtype=torch.float32, device=self.device) for shape in shapes]
         with ops.graph_keepalive() as keep:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side), torch.no_grad():
                 for _ in range(2):                      # warm-up: fills every cache / workspace outside the capture
-                    run()
+                    run(*static)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(graph):
-                vol, ws = run()
-        self._graphs[key] = {"graph": graph, "in": static_in, "vol": vol, "ws": ws, "keep": list(keep), "stamps": stamps}
+                out = run(*static)
+        self._graphs[key] = {"graph": graph, "in": static, "out": out, "keep": list(keep), "stamps": stamps}
         return self._graphs[key]
+
+    def _scene_graph(self, shape, nx):
+        """Encode + dense decode + marching-cubes classification of one (input shape, lattice size) as one graph."""
+        def run(static_in):
+            c = self.model.encode_inputs(static_in)
+            vol = self.eval_lattice(c, nx).reshape(nx, nx, nx)
+            return vol, ops.mc_count(vol)
+        g = self._captured((tuple(shape), nx, self.decode_precision), [shape], run)
+        g["vol"], g["ws"] = g["out"]
+        return g
+
+    def _replay(self, kind, tensors, run):
+        """``run(*tensors)`` through a captured graph per (kind, shapes) when ``self.scene_graph`` is on: the result lives in the
+        graph's static buffers (valid until the next replay of the same key).  Plain call otherwise."""
+        if not self.scene_graph:
+            with torch.no_grad():
+                return run(*tensors)
+        g = self._captured((kind,) + tuple(tuple(t.shape) for t in tensors), [t.shape for t in tensors], run)
+        for dst, src in zip(g["in"], tensors):
+            dst.copy_(src.to(self.device), non_blocking=True)
+        g["graph"].replay()
+        return g["out"]
 
     def generate_mesh_graphed(self, inputs):
         """Same result as ``generate_obj_mesh_wnf({'inputs': inputs})`` for the visual branch, with the
@@ -157,7 +174,7 @@ class Generator3D(object):
         self._eval_mode()
         nx = self.resolution0 * 4
         g = self._scene_graph(inputs.shape, nx)
-        g["in"].copy_(inputs.to(self.device), non_blocking=True)
+        g["in"][0].copy_(inputs.to(self.device), non_blocking=True)
         g["graph"].replay()
         verts, faces, _ = ops.mc_emit(g["vol"], g["ws"], rescale=(nx / 2, (1 + self.padding) / nx))
         return Mesh(verts, faces)
@@ -204,8 +221,8 @@ class Generator3D(object):
                  'radius': (0.015 if mode == 'within' else 0.05) if radius is None else radius,
                  'count': count if count is not None else torch.full((anchors.shape[0],), anchors.shape[1], dtype=torch.int32)}
         inputs = data.get('inputs').to(self.device)
+        c = self._replay("encode_inputs", [inputs], self.model.encode_inputs)        # the encoder's ~55 launches as one graph
         with torch.no_grad():
-            c = self.model.encode_inputs(inputs)
             values = self._eval_lattice_tactile(c, nx, setup)
         return self.extract_mesh(values.reshape(nx, nx, nx))
 
@@ -333,8 +350,8 @@ class Generator3D(object):
         if inputs.shape[0] != 1:
             raise VtError(f"generate_obj_mesh_wnf: one scene at a time (got a batch of {inputs.shape[0]})")
         self._eval_mode()
-        with torch.no_grad():
-            c_img = self.model.encode_img_inputs(data.get('inputs.img').to(self.device))          # [1,5,C]
+        # [1,5,C]; the feature encoder (Resnet18 in eval mode: ~60 launch-bound MIOpen / ATen kernels) replayed as a graph
+        c_img = self._replay("encode_img", [data.get('inputs.img')], self.model.encode_img_inputs).clone()
         anchors, count = contact_clouds_from_depth(
             data.get('inputs.depth')[0].float().cpu().numpy(), self._depth_origin(),
             data.get('points.cam_pos').reshape(1, 5, 3)[0].cpu().numpy(), data.get('points.cam_rot').reshape(1, 5, 3)[0].cpu().numpy(),
@@ -359,7 +376,7 @@ class Generator3D(object):
             c_hand = self.model.encode_hand_inputs(inputs)
             if 'mano_joints' not in c_hand:
                 raise VtError("generate_obj_mesh_wnf(with_img): the hand encoder has no MANO layer (out_dim <= 30)")
-            c_img = self.model.encode_img_inputs(data.get('inputs.img').to(self.device))          # [1,5,C]
+        c_img = self._replay("encode_img", [data.get('inputs.img')], self.model.encode_img_inputs).clone()    # [1,5,C]
         tips = fingertips_in_object_frame(c_hand['mano_joints'].float().cpu().numpy(), data.get('points.mano').cpu().numpy()[:, :3],
                                           data.get('points.wrist').cpu().numpy(), data.get('inputs.pc_ply').float().cpu().numpy())
         anchors = torch.from_numpy(tips[0]).float().unsqueeze(1)                                   # [5,1,3]
