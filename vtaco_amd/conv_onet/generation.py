@@ -188,8 +188,8 @@ class Generator3D(object):
         self._eval_mode()
         nx = self.resolution0 * 4
         inputs = data.get('inputs').to(self.device)
+        c = self._replay("encode_inputs", [inputs], self.model.encode_inputs)        # the encoder's launches as one graph
         with torch.no_grad():
-            c = self.model.encode_inputs(inputs)
             if self.with_img:
                 # the tactile branches (VTacOH fingertips / VTacO contact clouds): every rank assigns finger ids to ITS slab and
                 # decodes by id; the VTacO clouds are drawn with numpy's generator, so rank 0's go to everybody (a few KB)
@@ -273,8 +273,7 @@ class Generator3D(object):
         pc_ply = data.get('inputs.pc_ply').to(self.device)
         if inputs.shape[0] != 1:
             raise VtError(f"generate_hand_mesh: one scene at a time (got a batch of {inputs.shape[0]})")
-        with torch.no_grad():
-            c_hand = self.model.encode_hand_inputs(inputs)
+        c_hand = self._replay("encode_hand_inputs", [inputs], self.model.encode_hand_inputs)   # ~70 launches as one graph
         if 'mano_verts' not in c_hand:
             raise VtError("generate_hand_mesh: the hand encoder has no MANO layer (out_dim <= 30 regresses digit poses only)")
         param = c_hand['mano_param'][0].double().cpu().numpy()
@@ -372,8 +371,8 @@ class Generator3D(object):
         if inputs.shape[0] != 1:
             raise VtError(f"generate_obj_mesh_wnf: one scene at a time (got a batch of {inputs.shape[0]})")
         self._eval_mode()
+        c_hand = self._replay("encode_hand_inputs", [inputs], self.model.encode_hand_inputs)   # plane PointNet + 2-D U-Net + MANO as one graph
         with torch.no_grad():
-            c_hand = self.model.encode_hand_inputs(inputs)
             if 'mano_joints' not in c_hand:
                 raise VtError("generate_obj_mesh_wnf(with_img): the hand encoder has no MANO layer (out_dim <= 30)")
         c_img = self._replay("encode_img", [data.get('inputs.img')], self.model.encode_img_inputs).clone()    # [1,5,C]
