@@ -249,6 +249,31 @@ def test_wgrad_f16x3_matches_f32_kernel():
             assert torch.equal(nomax, got) or float((nomax - ref).abs().max()) <= 2e-7 * (B * R ** 3) ** 0.5 * scale
 
 
+def test_relu_mask_absmax_and_degenerate_gradients():
+    """vt_relu_mask_absmax: the mask of vt_relu_mask plus max |g| from the same pass (integer atomicMax on the float bits: exact);
+    an all-zero gradient leaves the rescale off (no division by zero), a NaN gradient surfaces as a NaN maximum."""
+    from vtaco_amd import ops
+    g = torch.Generator().manual_seed(31)
+    dy = (torch.randn(2, 8, 8, 8, 32, generator=g) * 3e-7).to(DEV)
+    y = torch.randn(2, 8, 8, 8, 32, generator=g).to(DEV)
+    ref = ops.relu_mask(dy, y)
+    got, m = ops.relu_mask(dy, y, want_absmax=True)
+    assert torch.equal(got, ref) and torch.equal(ref, torch.where(y > 0, dy, torch.zeros_like(dy)))
+    assert float(m) == float(ref.abs().max()) > 0.0
+    z, mz = ops.relu_mask(torch.zeros_like(dy), y, want_absmax=True)
+    assert float(mz) == 0.0 and float(z.abs().max()) == 0.0
+    x = torch.randn(2, 8, 8, 8, 32, generator=g).to(DEV)
+    ss = torch.stack((torch.ones(2, 32), torch.zeros(2, 32)), -1).to(DEV).contiguous()
+    dw0 = ops.conv3d_wgrad(x, None, ss, z, precision="f16x3", g_absmax=mz)
+    assert float(dw0.abs().max()) == 0.0
+    bad = dy.clone()
+    bad[0, 0, 0, 0, 0] = float("nan")
+    _, mn = ops.relu_mask(bad, torch.ones_like(y), want_absmax=True)
+    assert torch.isnan(mn).all()
+    dwn = ops.conv3d_wgrad(x, None, ss, torch.where(torch.isnan(bad), bad, dy), precision="f16x3", g_absmax=mn)
+    assert torch.isnan(dwn).any()                                  # a NaN gradient stays visible in dW
+
+
 def test_maxpool_backward_first_maximum():
     import torch.nn.functional as F
     from vtaco_amd.encoder.unet3d import _MaxPoolFn
