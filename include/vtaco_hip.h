@@ -449,6 +449,9 @@ size_t vt_unet3d_workspace_bytes(int B, int R, const vt_unet3d_params *params_ho
 int vt_unet3d_fwd(const float *x_cl, int B, int R, const vt_unet3d_params *params_host,
                   void *workspace, size_t workspace_bytes, float *out, void *stream);
 int vt_maxpool3d_cl(const float *x, int B, int D, int H, int W, int C, float *out, void *stream);
+/* the same max-pool and, from the same pass, the pooled tensor's GroupNorm partial sums as vt_channel_stats would leave them   */
+/* (bit-identical: same blocks, same order): part [B][nblk][C][2].                                                          */
+int vt_maxpool3d_cl_stats(const float *x, int B, int D, int H, int W, int C, float *out, int nblk, float *part, void *stream);
 int vt_conv1x1_cl(const float *x, int64_t V, int Cin, const float *w, const float *bias, int Cout, float *out, void *stream);
 int vt_voxel_scatter_mean_cl_fwd(const float *feat, const int *idx, const int *order,
                                  const int *seg_lo, const int *seg_hi,

@@ -348,10 +348,12 @@ def test_dense_cells_one_pass_per_segment(kind, T, R, plane):
     fd = feat.to(DEV)
     ops.voxel_pool_max_fwd(fd, vi)                               # first call: code object load, allocator growth
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out, arg = ops.voxel_pool_max_fwd(fd, vi)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = 1e9
+    for _ in range(3):                                           # best of three: a busy host must not fail a correctness suite
+        t0 = time.perf_counter()
+        out, arg = ops.voxel_pool_max_fwd(fd, vi)
+        torch.cuda.synchronize()
+        dt = min(dt, time.perf_counter() - t0)
     ref = orc.segment_pool_max(feat, idx)
     assert torch.equal(out.cpu(), ref)
     # argmax = the FIRST point of the cell that attains the maximum

@@ -274,6 +274,20 @@ def test_relu_mask_absmax_and_degenerate_gradients():
     assert torch.isnan(dwn).any()                                  # a NaN gradient stays visible in dW
 
 
+def test_maxpool_with_statistics_equals_the_two_passes():
+    """vt_maxpool3d_cl_stats = vt_maxpool3d_cl followed by vt_channel_stats, bit for bit (same blocks, same summation order)."""
+    from vtaco_amd import ops
+    g = torch.Generator().manual_seed(41)
+    for B, R, C in ((1, 64, 32), (2, 16, 64), (1, 8, 128), (3, 4, 32), (1, 32, 96)):
+        x = torch.randn(B, R, R, R, C, generator=g).relu().to(DEV)
+        ref = ops.maxpool3d_cl(x)
+        rp, rn = ops.channel_stats(ref)
+        got, (gp, gn) = ops.maxpool3d_cl_stats(x)
+        assert gn == rn and torch.equal(got, ref) and torch.equal(gp, rp)
+        want = torch.nn.functional.max_pool3d(x.permute(0, 4, 1, 2, 3), 2).permute(0, 2, 3, 4, 1)
+        assert torch.equal(got, want.contiguous())
+
+
 def test_maxpool_backward_first_maximum():
     import torch.nn.functional as F
     from vtaco_amd.encoder.unet3d import _MaxPoolFn

@@ -163,6 +163,7 @@ SIGNATURES = {
     "vt_unet3d_workspace_bytes": (_SZ, [_I, _I, ctypes.POINTER(UnetParams)]),
     "vt_unet3d_fwd": (_I, [_VP, _I, _I, ctypes.POINTER(UnetParams), _VP, _SZ, _VP, _VP]),
     "vt_maxpool3d_cl": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP]),
+    "vt_maxpool3d_cl_stats": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _I, _VP, _VP]),
     "vt_conv1x1_cl": (_I, [_VP, _I64, _I, _VP, _VP, _I, _VP, _VP]),
     "vt_voxel_scatter_mean_cl_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "vt_voxel_scatter_mean_cl_bwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),

@@ -262,8 +262,10 @@ class UNet3D(nn.Module):
         st = None
         for i, enc in enumerate(self.encoders):
             if i > 0:
-                x = ops.maxpool3d_cl(x)
-            if i > 0 or st is None:
+                # pool + statistics in one pass where the statistics have their 1024 blocks (as vt_unet3d_fwd chooses)
+                fused = x.shape[-1] % 32 == 0 and (x.shape[1] // 2) * (x.shape[2] // 2) * (x.shape[3] // 2) // 16 >= 1024
+                x, st = ops.maxpool3d_cl_stats(x) if fused else (ops.maxpool3d_cl(x), None)
+            if st is None:
                 st = ops.channel_stats(x)
             x, st = self._gcr(enc.basic_module.SingleConv1, x, st)
             x, st = self._gcr(enc.basic_module.SingleConv2, x, st)

@@ -829,7 +829,7 @@ def channel_stats(x):
     """Per-block partial (sum, sumsq) of a channels-last tensor: (part, nblk)."""
     B, D, H, W, C = x.shape
     V = D * H * W
-    nblk = max(1, min(1024, V // 64))
+    nblk = max(1, min(1024, V // 16))
     part = torch.empty((B, nblk, C, 2), dtype=torch.float32, device=x.device)
     check(_lib.load().vt_channel_stats(dev_ptr(x, "x"), B, V, C, nblk, dev_ptr(part, "part"), stream_ptr()), "vt_channel_stats")
     return part, nblk
@@ -977,6 +977,19 @@ def maxpool3d_cl(x):
     out = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
     check(_lib.load().vt_maxpool3d_cl(dev_ptr(x, "x"), B, D, H, W, C, dev_ptr(out, "out"), stream_ptr()), "vt_maxpool3d_cl")
     return out
+
+
+def maxpool3d_cl_stats(x):
+    """2x2x2 max-pool and the pooled tensor's GroupNorm partial sums from one pass: (out, (part, nblk)) -- what maxpool3d_cl followed by
+    channel_stats returns, bit for bit (vt_maxpool3d_cl_stats)."""
+    B, D, H, W, C = x.shape
+    out = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+    V = (D // 2) * (H // 2) * (W // 2)
+    nblk = max(1, min(1024, V // 16))
+    part = torch.empty((B, nblk, C, 2), dtype=torch.float32, device=x.device)
+    check(_lib.load().vt_maxpool3d_cl_stats(dev_ptr(x, "x"), B, D, H, W, C, dev_ptr(out, "out"), nblk, dev_ptr(part, "part"), stream_ptr()),
+          "vt_maxpool3d_cl_stats")
+    return out, (part, nblk)
 
 
 def conv1x1_cl(x, weight, bias):
