@@ -259,7 +259,7 @@ def sharded_scene(scene, dev, fx, rank, world, dist, precision, sizes=(128, 256)
             with torch.no_grad():
                 if record:
                     ev[0].record()
-                c = model.encode_inputs(pc)
+                c = gen._replay("encode_inputs", [pc], model.encode_inputs)      # as generate_obj_mesh_sharded: the encoder as one graph
                 if record:
                     ev[1].record()
                 local = gen.eval_lattice(c, nx, first=first, count=count) if count else torch.empty(0, dtype=torch.float32, device=dev)
