@@ -3,7 +3,7 @@
 # gpurun copies back at most 64 MiB).  Usage: TAG=r01e bash tools/collect_profiles.sh
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
-TAG=${TAG:-r02d}
+TAG=${TAG:-r02e}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_under_profiler.json 2> $O/stats.err; echo "stats rc=$?"
