@@ -549,6 +549,15 @@ int vt_linear_rows(const float *x, const float *w, const float *b, int64_t N, in
 int vt_resblock_fc(const float *x1, int C1, const float *x2, int C2, int64_t N,
                    const float *w0, const float *b0, const float *w1, const float *b1, const float *ws,
                    int H, int O, float *out, void *stream);
+/* The whole per-point MLP of LocalPoolPointnet.forward (pointnet.py:154-162) in one launch for inference with ONE voxel index:     */
+/* fc_pos -> block 0 -> 4 x (pool_local, concat, block) -> fc_c.  A workgroup owns every cell whose first sorted point falls into  */
+/* its window of 8-16 sorted positions -- complete cells of any size -- so pooling needs no grid-wide step; same arithmetic and        */
+/* summation order as vt_linear_rows / vt_resblock_fc / vt_voxel_pool_max_fwd: bit-identical features.  block_w: 25 device pointers, */
+/* per block fc_0.weight [32][64], fc_0.bias, fc_1.weight [32][32], fc_1.bias, shortcut.weight [32][64]; hidden must be 32, c_dim     */
+/* <= 64 (VT_ERR_UNSUPPORTED otherwise: use the per-layer kernels); scratch [B,T,32] floats; out [B,T,c_dim] by point.               */
+int vt_pointnet_mlp_fused(const float *pts, int B, int T, const int *order, const int *seg_lo, const int *seg_hi,
+                          const float *pos_w, const float *pos_b, const float *const *block_w, int hidden,
+                          const float *c_w, const float *c_b, int c_dim, float *scratch, float *out, void *stream);
 /* Backward of the two (training; PyTorch autograd of layers.py:8-50 and of the nn.Linear calls at    */
 /* pointnet.py:154-162 under loss.backward(), training.py:79,89,96):                                    */
 /*   vt_resblock_fc_bwd  d out [N][O] -> d x1 [N][C1], d x2 [N][C2] (NULL: not wanted), and the two       */

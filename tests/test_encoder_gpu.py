@@ -304,6 +304,33 @@ def test_voxel_sort_extremes(B, Tn, R):
         assert torch.equal(lo[b], first) and torch.equal(hi[b], last)
 
 
+@pytest.mark.parametrize("kind,T,R,c_dim", [("sphere", 3000, 64, 32), ("sphere", 1, 16, 32), ("sphere", 37, 16, 64), ("one", 8192, 64, 32),
+                                            ("mixed", 8192, 16, 32), ("planes", 8192, 32, 16)])
+def test_pointnet_mlp_in_one_launch_equals_the_per_layer_path(kind, T, R, c_dim, monkeypatch):
+    """vt_pointnet_mlp_fused (fc_pos, five blocks, four local pools, fc_c in one launch: a workgroup owns complete cells) against the
+    launch-per-layer path (vt_linear_rows / vt_resblock_fc / vt_voxel_pool_max_fwd): bit-identical features -- sparse clouds, a
+    single point, a batch of two, every point in ONE cell (one workgroup walks 8192 points), cells of 1..3000 points."""
+    from vtaco_amd import ops
+    from vtaco_amd.bench_util import randomise_fc1, sphere_cloud
+    from vtaco_amd.encoder import encoder_dict
+    torch.manual_seed(5)
+    enc = encoder_dict['pointnet_local_pool'](c_dim=c_dim, dim=3, hidden_dim=32, grid_resolution=R, plane_type='grid').to(DEV)
+    randomise_fc1(enc, 3)
+    p = (sphere_cloud(4, T=T) if kind == "sphere" else _dense_cloud(kind, T, 13)).to(DEV)
+    vi = ops.VoxelIndex(p, R)
+    with torch.no_grad():
+        monkeypatch.setenv("VTACO_POINTNET_ONE_LAUNCH", "0")
+        assert not enc._one_launch_fits(vi)
+        ref = enc.point_features(p, vi)
+        monkeypatch.setenv("VTACO_POINTNET_ONE_LAUNCH", "1")
+        assert enc._one_launch_fits(vi)
+        got = enc.point_features(p, vi)
+        again = enc.point_features(p, vi)
+    assert got.shape == ref.shape == (p.shape[0], T, c_dim)
+    assert torch.equal(got, ref) and torch.equal(again, got)
+    assert not enc._one_launch_fits([vi, vi])                       # the hand encoder's three planes keep the per-layer path
+
+
 def _dense_cloud(kind, T, seed):
     """Clouds whose cells are DENSE: 'one' = all T points in one cell; 'mixed' = a few cells of 1..3000 points (lengths on both
     sides of the 32-point switch between the per-head and the cooperative reduction, segments that start on / straddle the

@@ -122,6 +122,7 @@ SIGNATURES = {
     "vt_winding_number": (_I, [_VP, _I, _VP, _I, _VP, _I64, _VP, _VP]),
     "vt_linear_rows": (_I, [_VP, _VP, _VP, _I64, _I, _I, _VP, _VP]),
     "vt_resblock_fc": (_I, [_VP, _I, _VP, _I, _I64, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
+    "vt_pointnet_mlp_fused": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP]),
     "vt_resblock_fc_bwd": (_I, [_VP, _I, _VP, _I, _I64, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vt_rows_wgrad_workspace_bytes": (_SZ, [_I64, _I, _I]),
     "vt_rows_wgrad": (_I, [_VP, _I, _VP, _I, _VP, _I, _I, _I64, _VP, _SZ, _VP, _VP, _VP]),

@@ -49,6 +49,47 @@ __device__ __forceinline__ float dot_cols(const float *wt, int ld, int j, const 
     return (a0 + a1) + (a2 + a3);
 }
 
+// the same sum with a compile-time length: fully unrolled, so the 2 N LDS reads are in flight together instead of one dependent
+// read per FMA step (the run-time form is bound by LDS latency: ~37 cycles per FMA measured in the one-launch kernel).  Same partial
+// sums, same order: bit-identical to dot_cols.
+template <bool RELU, int N>
+__device__ __forceinline__ float dot_cols_n(const float *wt, int ld, int j, const float *r) {
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    float rv[N], wv[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) { rv[k] = RELU ? fmaxf(r[k], 0.0f) : r[k]; wv[k] = wt[k * ld + j]; }
+#pragma unroll
+    for (int k = 0; k + 4 <= N; k += 4) {
+        a0 = fmaf(wv[k], rv[k], a0);
+        a1 = fmaf(wv[k + 1], rv[k + 1], a1);
+        a2 = fmaf(wv[k + 2], rv[k + 2], a2);
+        a3 = fmaf(wv[k + 3], rv[k + 3], a3);
+    }
+#pragma unroll
+    for (int k = N & ~3; k < N; ++k) a0 = fmaf(wv[k], rv[k], a0);
+    return (a0 + a1) + (a2 + a3);
+}
+
+// two rows against the same weight column: each weight read feeds two FMAs (per row the sum is dot_cols's, bit for bit)
+template <bool RELU, int N>
+__device__ __forceinline__ void dot_cols_n2(const float *wt, int ld, int j, const float *r0, const float *r1, float &s0, float &s1) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
+    float wv[N], u0[N], u1[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        wv[k] = wt[k * ld + j];
+        u0[k] = RELU ? fmaxf(r0[k], 0.0f) : r0[k];
+        u1[k] = RELU ? fmaxf(r1[k], 0.0f) : r1[k];
+    }
+#pragma unroll
+    for (int k = 0; k + 4 <= N; k += 4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = fmaf(wv[k + e], u0[k + e], a[e]); c[e] = fmaf(wv[k + e], u1[k + e], c[e]); }
+    static_assert((N & 3) == 0, "multiple of four");
+    s0 = (a[0] + a[1]) + (a[2] + a[3]);
+    s1 = (c[0] + c[1]) + (c[2] + c[3]);
+}
+
 // out[n][j] = b[j] + sum_k w[j][k] * x[n][k]
 __global__ void __launch_bounds__(PN_THREADS)
 linear_rows_kernel(const float *x, const float *w, const float *b, float *out, int N, int Cin, int Cout) {
@@ -107,6 +148,168 @@ resblock_fc_kernel(const float *x1, int C1, const float *x2, int C2, int N,
             const float dx = b1[j] + dot_cols<false>(w1t, ldo, j, hid + lp * H, H);
             const float xs = ws ? dot_cols<false>(wst, ldo, j, r, C) : r[j];      // no layer: size_in == size_out, identity
             out[(size_t)n * O + j] = xs + dx;
+        }
+    }
+}
+
+// ---- the whole per-point MLP in ONE launch (inference, one voxel index) ------------------------------------------------
+// fc_pos -> block 0 -> 4 x (local max-pool over the point's cell, concat, block) -> fc_c used to be eleven launches (two linear
+// layers, five blocks, four pools: ~75 us of an 0.75 ms encode, each a chain of three dependent global round trips in front of a few
+// hundred FMAs).  The pooling couples only the points of one cell, and the voxel index holds the points sorted by cell: a workgroup
+// that owns every cell whose FIRST sorted point falls into its window of 8-16 sorted positions holds complete cells -- its points
+// are one contiguous range of sorted positions, of any length (a cell of 8192 points is one workgroup's range) -- so all five blocks
+// and the four pools run inside the workgroup with no grid-wide step: the per-cell maxima live in LDS (at most PF_WIN cells), the
+// points' feature rows pass from block to block through a scratch array the workgroup alone reads and writes.  Arithmetic and
+// summation order are those of linear_rows_kernel / resblock_fc_kernel (same dot_cols): the result equals the launch-per-layer path
+// bit for bit (the per-cell maxima are LDS float-max atomics: exact in any order).
+constexpr int PF_WIN = 16, PF_PTS = 16, PF_H = 32, PF_BLOCKS = 5, PF_CACHE = 64;
+
+struct PnFusedArgs {
+    const float *pts;                     // [B,T,3]
+    const int *order, *seg_lo, *seg_hi;   // the voxel index (vt_voxel_build)
+    const float *pos_w, *pos_b;           // fc_pos [2H][3], [2H]
+    const float *w0[PF_BLOCKS], *b0[PF_BLOCKS], *w1[PF_BLOCKS], *b1[PF_BLOCKS], *ws[PF_BLOCKS];   // fc_0 [H][2H], fc_1 [H][H], shortcut [H][2H]
+    const float *c_w, *c_b;               // fc_c [c_dim][H], [c_dim]
+    float *scratch;                       // [B,T,H] feature rows by sorted position
+    float *out;                           // [B,T,c_dim] by point
+    int T, c_dim;
+    int win;                              // window of sorted positions per workgroup (<= PF_WIN): chosen so that one round of workgroups covers the cloud
+};
+
+__global__ void __launch_bounds__(PN_THREADS)
+pointnet_fused_kernel(PnFusedArgs a) {
+    constexpr int H = PF_H, C = 2 * H, LDH = H | 1;
+    __shared__ float w0t[C * LDH], w1t[H * LDH], wst[C * LDH];
+    __shared__ float post[3 * (C | 1)], cwt[H * 65];
+    __shared__ float bias[3][64];                                  // fc_0.bias | fc_1.bias of the current block, fc_pos.bias / fc_c.bias
+    __shared__ float rows[PF_PTS][C], hid[PF_PTS][H], outs[PF_PTS][H];
+    __shared__ float smax[PF_WIN][H], pcur[PF_WIN][H];
+    // the first PF_CACHE points of the workgroup's range (all of them unless a cell is dense) stay in LDS: point index, cell,
+    // coordinates and the feature row between blocks -- a pass then touches no global memory (every global access inside the
+    // pass loop is a dependent round trip of ~1.5 us: with them the kernel took 60 us)
+    __shared__ int meta_t[PF_CACHE], meta_sg[PF_CACHE];
+    __shared__ float srow[PF_CACHE][H], spts[PF_CACHE][3];
+    __shared__ int head_rank[PF_WIN], range[2];
+    const int b = blockIdx.y, T = a.T, win = a.win, wstart = blockIdx.x * win;
+    const int *order = a.order + (size_t)b * T, *seg_lo = a.seg_lo + (size_t)b * T, *seg_hi = a.seg_hi + (size_t)b * T;
+    const float *pts = a.pts + (size_t)b * T * 3;
+    float *scratch = a.scratch + (size_t)b * T * H;
+    if (threadIdx.x < 64) {
+        // the cells this workgroup owns: their first sorted point lies in the window
+        const int i = threadIdx.x, jpos = wstart + i;
+        int t = 0, lo = -1, hi = 0;
+        if (i < win && jpos < T) { t = order[jpos]; lo = seg_lo[t]; hi = seg_hi[t]; }
+        const bool head = i < win && jpos < T && lo == jpos;
+        const unsigned long long m = __ballot(head);
+        if (i < PF_WIN) head_rank[i] = __popcll(m & ((1ull << i) - 1ull));
+        const int last = m ? 63 - __builtin_clzll(m) : 0;
+        const int end = __shfl(hi, last);
+        if (i == 0) { range[0] = m ? wstart + __builtin_ctzll(m) : -1; range[1] = end; }
+    }
+    __syncthreads();
+    const int first = range[0], end = range[1];
+    if (first < 0) return;                                          // the window lies inside a cell owned further left
+    const int lp = threadIdx.x / H, j = threadIdx.x - lp * H;
+    transpose_to_lds(post, C | 1, a.pos_w, C, 3);
+    transpose_to_lds(cwt, 65, a.c_w, a.c_dim, H);
+    if (threadIdx.x < 64) { bias[2][threadIdx.x] = a.pos_b[threadIdx.x]; }
+    for (int i = threadIdx.x; i < PF_WIN * H; i += PN_THREADS) (&smax[0][0])[i] = -INFINITY;
+    for (int i = threadIdx.x; i < PF_CACHE && first + i < end; i += PN_THREADS) {
+        const int t = order[first + i];
+        meta_t[i] = t; meta_sg[i] = seg_lo[t] - wstart;             // (window offset of the cell's head; its rank below)
+        spts[i][0] = pts[3 * t]; spts[i][1] = pts[3 * t + 1]; spts[i][2] = pts[3 * t + 2];
+    }
+    // a block's weights: five 16-byte pieces and one bias value per thread, requested one block AHEAD (under the previous block's
+    // passes) and transposed into LDS at the block's start -- three dependent fetch + store rounds per block otherwise
+    float4 wr[5];
+    float br = 0.0f;
+    auto wfetch = [&](int blk) {
+        const float4 *p0 = reinterpret_cast<const float4 *>(a.w0[blk]), *p1 = reinterpret_cast<const float4 *>(a.w1[blk]),
+                     *ps = reinterpret_cast<const float4 *>(a.ws[blk]);
+        wr[0] = p0[threadIdx.x]; wr[1] = p0[threadIdx.x + PN_THREADS]; wr[2] = p1[threadIdx.x];
+        wr[3] = ps[threadIdx.x]; wr[4] = ps[threadIdx.x + PN_THREADS];
+        if (threadIdx.x < H) br = a.b0[blk][threadIdx.x];
+        else if (threadIdx.x < 2 * H) br = a.b1[blk][threadIdx.x - H];
+    };
+    auto put = [&](float *wt, int n4, int i, const float4 &v) {     // piece i of a [rows][4 n4] matrix -> wt[k][row]
+        const int row = i / n4, k = (i - row * n4) * 4;
+        wt[k * LDH + row] = v.x; wt[(k + 1) * LDH + row] = v.y; wt[(k + 2) * LDH + row] = v.z; wt[(k + 3) * LDH + row] = v.w;
+    };
+    wfetch(0);
+#ifndef PF_DBG_BLOCKS
+#define PF_DBG_BLOCKS PF_BLOCKS            // (timing experiments only: fewer blocks)
+#endif
+    for (int blk = 0; blk < PF_DBG_BLOCKS; ++blk) {
+        __syncthreads();                                            // the previous block is done with the weights and with pcur
+        put(w0t, C / 4, threadIdx.x, wr[0]); put(w0t, C / 4, threadIdx.x + PN_THREADS, wr[1]);
+        put(w1t, H / 4, threadIdx.x, wr[2]);
+        put(wst, C / 4, threadIdx.x, wr[3]); put(wst, C / 4, threadIdx.x + PN_THREADS, wr[4]);
+        if (threadIdx.x < H) bias[0][threadIdx.x] = br;
+        else if (threadIdx.x < 2 * H) bias[1][threadIdx.x - H] = br;
+        if (blk + 1 < PF_BLOCKS) wfetch(blk + 1);
+        if (blk > 0)
+            for (int i = threadIdx.x; i < PF_WIN * H; i += PN_THREADS) { (&pcur[0][0])[i] = (&smax[0][0])[i]; (&smax[0][0])[i] = -INFINITY; }
+        for (int q0 = first; q0 < end; q0 += PF_PTS) {
+            __syncthreads();
+            // a thread serves output channel j of TWO points of the pass (lp and lp + 8): every weight read from LDS feeds two FMAs
+            int tq[2], sgv[2];
+            bool livev[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pl = lp + 8 * u, q = q0 + pl, ci = q - first;
+                const bool live = q < end, cached = ci < PF_CACHE;
+                int t = 0, sg = 0;
+                if (live) {
+                    if (cached) { t = meta_t[ci]; sg = head_rank[meta_sg[ci]]; }
+                    else { t = order[q]; sg = head_rank[seg_lo[t] - wstart]; }
+                }
+                tq[u] = t; livev[u] = live; sgv[u] = sg;
+                if (blk == 0) {
+                    // rows = fc_pos(p): two outputs per thread and point
+                    float p3[3] = {0.f, 0.f, 0.f};
+                    if (live) {
+                        if (cached) { p3[0] = spts[ci][0]; p3[1] = spts[ci][1]; p3[2] = spts[ci][2]; }
+                        else { p3[0] = pts[3 * t]; p3[1] = pts[3 * t + 1]; p3[2] = pts[3 * t + 2]; }
+                    }
+                    rows[pl][j] = bias[2][j] + dot_cols_n<false, 3>(post, C | 1, j, p3);
+                    rows[pl][j + H] = bias[2][j + H] + dot_cols_n<false, 3>(post, C | 1, j + H, p3);
+                } else {
+                    rows[pl][j] = live ? (cached ? srow[ci][j] : scratch[(size_t)q * H + j]) : 0.0f;
+                    rows[pl][j + H] = live ? pcur[sg][j] : 0.0f;
+                }
+            }
+            __syncthreads();
+            {
+                float h0, h1;
+                dot_cols_n2<true, C>(w0t, LDH, j, rows[lp], rows[lp + 8], h0, h1);
+                hid[lp][j] = fmaxf(bias[0][j] + h0, 0.0f);
+                hid[lp + 8][j] = fmaxf(bias[0][j] + h1, 0.0f);
+            }
+            __syncthreads();
+            float d0, d1, x0, x1;
+            dot_cols_n2<false, H>(w1t, LDH, j, hid[lp], hid[lp + 8], d0, d1);
+            dot_cols_n2<false, C>(wst, LDH, j, rows[lp], rows[lp + 8], x0, x1);
+            const float o[2] = {x0 + (bias[1][j] + d0), x1 + (bias[1][j] + d1)};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pl = lp + 8 * u, q = q0 + pl, ci = q - first;
+                outs[pl][j] = o[u];
+                if (livev[u] && blk + 1 < PF_BLOCKS) {
+                    if (ci < PF_CACHE) srow[ci][j] = o[u]; else scratch[(size_t)q * H + j] = o[u];
+                    // into the cell's maximum: an LDS float max per (point, channel), all in parallel (max is exact in any order; a
+                    // single thread walking the pass's points was a chain of ~50 dependent LDS round trips: 2.3 us per pass)
+                    __hip_atomic_fetch_max(&smax[sgv[u]][j], o[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            __syncthreads();
+            if (blk + 1 < PF_BLOCKS) {
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (livev[u])
+                        for (int oc = j; oc < a.c_dim; oc += H)     // fc_c straight from the last block's rows
+                            a.out[((size_t)b * T + tq[u]) * a.c_dim + oc] = a.c_b[oc] + dot_cols_n<false, H>(cwt, 65, oc, outs[lp + 8 * u]);
+            }
         }
     }
 }
@@ -307,6 +510,34 @@ int vt_resblock_fc_bwd(const float *x1, int C1, const float *x2, int C2, int64_t
     hipLaunchKernelGGL(resblock_fc_bwd_kernel, dim3(rows_grid((int)N, pts)), dim3(PN_THREADS), lds, (hipStream_t)stream,
                        x1, C1, x2, C2, (int)N, w0, b0, w1, ws, H, O, dout, dx1, dx2, act, dh);
     return vt_check(hipGetLastError(), "vt_resblock_fc_bwd");
+}
+
+int vt_pointnet_mlp_fused(const float *pts, int B, int T, const int *order, const int *seg_lo, const int *seg_hi,
+                          const float *pos_w, const float *pos_b, const float *const *block_w, int hidden,
+                          const float *c_w, const float *c_b, int c_dim, float *scratch, float *out, void *stream) {
+    if (!pts || !order || !seg_lo || !seg_hi || !pos_w || !pos_b || !block_w || !c_w || !c_b || !scratch || !out || B <= 0 || T <= 0)
+        return vt_fail(VT_ERR_INVALID, "vt_pointnet_mlp_fused: bad argument");
+    if (hidden != PF_H || c_dim <= 0 || c_dim > 64)
+        return vt_fail(VT_ERR_UNSUPPORTED, "vt_pointnet_mlp_fused: built for hidden_dim 32 and c_dim <= 64 (the shipped encoders); use the per-layer kernels");
+    for (int i = 0; i < 5 * PF_BLOCKS; ++i)
+        if (i % 5 != 1 && i % 5 != 3 && (reinterpret_cast<uintptr_t>(block_w[i]) & 15))
+            return vt_fail(VT_ERR_UNSUPPORTED, "vt_pointnet_mlp_fused: weight matrices must be 16-byte aligned");
+    PnFusedArgs a;
+    a.pts = pts; a.order = order; a.seg_lo = seg_lo; a.seg_hi = seg_hi; a.pos_w = pos_w; a.pos_b = pos_b;
+    for (int i = 0; i < PF_BLOCKS; ++i) {
+        a.w0[i] = block_w[5 * i]; a.b0[i] = block_w[5 * i + 1]; a.w1[i] = block_w[5 * i + 2]; a.b1[i] = block_w[5 * i + 3]; a.ws[i] = block_w[5 * i + 4];
+        if (!a.w0[i] || !a.b0[i] || !a.w1[i] || !a.b1[i] || !a.ws[i]) return vt_fail(VT_ERR_INVALID, "vt_pointnet_mlp_fused: null block weight");
+    }
+    a.c_w = c_w; a.c_b = c_b; a.scratch = scratch; a.out = out; a.T = T; a.c_dim = c_dim;
+    // one workgroup per CU is resident (256 registers x 4 waves): the smallest window that still covers the cloud in one round of
+    // workgroups keeps a workgroup at one 16-point pass per block (3000 points: 12 positions -> 250 workgroups, 25 us; 16 -> 40 us; 10 -> 44 us)
+    const int64_t pts_total = (int64_t)B * T, cus = vt_num_cus();
+    int win = (int)((pts_total + cus - 1) / cus);
+    if (win < 8) win = 8;
+    if (win > PF_WIN) win = PF_WIN;
+    a.win = win;
+    hipLaunchKernelGGL(pointnet_fused_kernel, dim3((unsigned)((T + win - 1) / win), (unsigned)B), dim3(PN_THREADS), 0, (hipStream_t)stream, a);
+    return vt_check(hipGetLastError(), "vt_pointnet_mlp_fused");
 }
 
 size_t vt_rows_wgrad_workspace_bytes(int64_t N, int M, int K) {

@@ -224,9 +224,21 @@ class LocalPoolPointnet(nn.Module):
         cout, cin = lin.weight.shape
         return cout <= 256 and (cin * (cout | 1) + max(1, 256 // cout) * cin) * 4 <= 64 * 1024
 
+    def _one_launch_fits(self, vi):
+        """vt_pointnet_mlp_fused: one voxel index (the object grid; the hand encoder sums three planes' pools), the shipped widths
+        (hidden 32, five blocks with shortcut layers, c_dim <= 64).  VTACO_POINTNET_ONE_LAUNCH=0: the launch-per-layer path."""
+        if isinstance(vi, (list, tuple)) or os.environ.get("VTACO_POINTNET_ONE_LAUNCH", "1") == "0":
+            return False
+        return (self.hidden_dim == 32 and len(self.blocks) == 5 and all(b.shortcut is not None for b in self.blocks)
+                and tuple(self.fc_pos.weight.shape) == (64, 3) and self.fc_c.weight.shape[0] <= 64 and self.fc_c.weight.shape[1] == 32
+                and self.fc_pos.bias is not None and self.fc_c.bias is not None
+                and all(w.data_ptr() % 16 == 0 for b in self.blocks for w in (b.fc_0.weight, b.fc_1.weight, b.shortcut.weight)))
+
     def _point_features_fused(self, p, vi):
         """The same layers without autograd: one HIP launch per linear layer / ResnetBlockFC (vt_linear_rows,
         vt_resblock_fc, the concat with the pooled features read in place) instead of ~9 framework launches per block."""
+        if self._one_launch_fits(vi):
+            return ops.pointnet_mlp_fused(p, vi, self.fc_pos, self.blocks, self.fc_c)
         lin = lambda l, x: ops.linear_rows(x, l.weight, l.bias) if self._linear_fits(l) else l(x)
         net = lin(self.fc_pos, p)
         b0 = self.blocks[0]

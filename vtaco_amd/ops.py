@@ -536,6 +536,27 @@ def mano_fwd(pose, blob, center_idx=9):
     return verts, joints
 
 
+def pointnet_mlp_fused(p, vi, fc_pos, blocks, fc_c):
+    """fc_pos -> block 0 -> 4 x (pool over the point's cell, concat, block) -> fc_c for one voxel index in ONE launch
+    (vt_pointnet_mlp_fused; inference): [B,T,c_dim], bit-identical to the launch-per-layer path."""
+    p = _c(p.float())
+    B, T, _ = p.shape
+    c_dim = fc_c.weight.shape[0]
+    ws = []
+    for blk in blocks:
+        ws += [_c(blk.fc_0.weight), _c(blk.fc_0.bias), _c(blk.fc_1.weight), _c(blk.fc_1.bias), _c(blk.shortcut.weight)]
+    ptrs = (ctypes.c_void_p * len(ws))(*[t.data_ptr() for t in ws])
+    scratch = torch.empty((B, T, 32), dtype=torch.float32, device=p.device)
+    out = torch.empty((B, T, c_dim), dtype=torch.float32, device=p.device)
+    keep = [_c(fc_pos.weight), _c(fc_pos.bias), _c(fc_c.weight), _c(fc_c.bias)]
+    check(_lib.load().vt_pointnet_mlp_fused(dev_ptr(p, "p"), B, T, dev_ptr(vi.order, "order", I32), dev_ptr(vi.seg_lo, "seg_lo", I32),
+                                            dev_ptr(vi.seg_hi, "seg_hi", I32), dev_ptr(keep[0], "fc_pos.weight"), dev_ptr(keep[1], "fc_pos.bias"),
+                                            ptrs, 32, dev_ptr(keep[2], "fc_c.weight"), dev_ptr(keep[3], "fc_c.bias"), c_dim,
+                                            dev_ptr(scratch, "scratch"), dev_ptr(out, "out"), stream_ptr()), "vt_pointnet_mlp_fused")
+    keep_for_graph(scratch, *ws, *keep)
+    return out
+
+
 def mano_bwd(pose, blob, center_idx, dverts, djoints):
     """d pose [B,48] of mano_fwd from d verts [B,778,3] and d joints [B,21,3] (vt_mano_bwd)."""
     pose = _c(pose.float())
