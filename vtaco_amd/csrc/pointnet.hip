@@ -70,6 +70,14 @@ __device__ __forceinline__ float dot_cols_n(const float *wt, int ld, int j, cons
     return (a0 + a1) + (a2 + a3);
 }
 
+// run-time length, compile-time code for the widths the shipped encoders use (32, 64): the per-layer kernels' dot products
+template <bool RELU>
+__device__ __forceinline__ float dot_cols_fast(const float *wt, int ld, int j, const float *r, int n) {
+    if (n == 64) return dot_cols_n<RELU, 64>(wt, ld, j, r);
+    if (n == 32) return dot_cols_n<RELU, 32>(wt, ld, j, r);
+    return dot_cols<RELU>(wt, ld, j, r, n);
+}
+
 // two rows against the same weight column: each weight read feeds two FMAs (per row the sum is dot_cols's, bit for bit)
 template <bool RELU, int N>
 __device__ __forceinline__ void dot_cols_n2(const float *wt, int ld, int j, const float *r0, const float *r1, float &s0, float &s1) {
@@ -108,7 +116,7 @@ linear_rows_kernel(const float *x, const float *w, const float *b, float *out, i
         __syncthreads();
         const int n = n0 + lp;
         if (lp < pts && n < N) {
-            out[(size_t)n * Cout + j] = (b ? b[j] : 0.0f) + dot_cols<false>(wt, ldo, j, rows + lp * Cin, Cin);
+            out[(size_t)n * Cout + j] = (b ? b[j] : 0.0f) + dot_cols_fast<false>(wt, ldo, j, rows + lp * Cin, Cin);
         }
     }
 }
@@ -141,12 +149,12 @@ resblock_fc_kernel(const float *x1, int C1, const float *x2, int C2, int N,
         const bool live = lp < pts && n < N;
         const float *r = rows + lp * C;
         if (live && j < H) {
-            hid[lp * H + j] = fmaxf(b0[j] + dot_cols<true>(w0t, ldh, j, r, C), 0.0f);
+            hid[lp * H + j] = fmaxf(b0[j] + dot_cols_fast<true>(w0t, ldh, j, r, C), 0.0f);
         }
         __syncthreads();
         if (live && j < O) {
-            const float dx = b1[j] + dot_cols<false>(w1t, ldo, j, hid + lp * H, H);
-            const float xs = ws ? dot_cols<false>(wst, ldo, j, r, C) : r[j];      // no layer: size_in == size_out, identity
+            const float dx = b1[j] + dot_cols_fast<false>(w1t, ldo, j, hid + lp * H, H);
+            const float xs = ws ? dot_cols_fast<false>(wst, ldo, j, r, C) : r[j];      // no layer: size_in == size_out, identity
             out[(size_t)n * O + j] = xs + dx;
         }
     }
@@ -357,18 +365,18 @@ resblock_fc_bwd_kernel(const float *x1, int C1, const float *x2, int C2, int N,
         const bool live = lp < pts && n < N;
         const float *r = xr + lp * C, *go = dor + lp * O;
         if (live && j < H) {
-            const float h = b0[j] + dot_cols<true>(w0t, ldh, j, r, C);
+            const float h = b0[j] + dot_cols_fast<true>(w0t, ldh, j, r, C);
             hr[lp * H + j] = h;
             act[(size_t)n * H + j] = fmaxf(h, 0.0f);
-            const float da = dot_cols<false>(w1n, ldh, j, go, O);
+            const float da = dot_cols_fast<false>(w1n, ldh, j, go, O);
             const float g = h > 0.0f ? da : 0.0f;
             dhr[lp * H + j] = g;
             dh[(size_t)n * H + j] = g;
         }
         __syncthreads();
         if (live && j < C) {
-            const float back = dot_cols<false>(w0n, ldc, j, dhr + lp * H, H);
-            const float v = (r[j] > 0.0f ? back : 0.0f) + (ws ? dot_cols<false>(wsn, ldc, j, go, O) : go[j]);
+            const float back = dot_cols_fast<false>(w0n, ldc, j, dhr + lp * H, H);
+            const float v = (r[j] > 0.0f ? back : 0.0f) + (ws ? dot_cols_fast<false>(wsn, ldc, j, go, O) : go[j]);
             if (j < C1) dx1[(size_t)n * C1 + j] = v;
             else if (dx2) dx2[(size_t)n * C2 + (j - C1)] = v;
         }
