@@ -60,17 +60,14 @@ mano_pack_kernel(const float *v_template, const float *shapedirs, const float *b
     }
 }
 
-__global__ void __launch_bounds__(THREADS)
-mano_fwd_kernel(const float *pose, const float *blob, int center_idx, float *verts, float *joints) {
-    __shared__ float rot[NJ][9];        // per-joint rotations
-    __shared__ float pm[NPD + 1];       // pose map: (R_j - I) of the 15 finger joints, row-major
-    __shared__ float G[NJ][12];         // chain transforms [R | t], then rest-pose-removed in place (A)
-    __shared__ float gt[NJ][3];         // chain translations before the rest pose is removed (= joints)
-    __shared__ float vp[NCP];           // posed rest vertices, then the skinned vertices
-    __shared__ float jout[21][3];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    const float *p = pose + (size_t)b * 48;
-
+// What both kernels start from, per hand (all 256 threads call it; it ends with a barrier): the joint rotations (Rodrigues through
+// the re-normalised quaternion) with the pose map of the 15 finger joints, the kinematic chain G_j = [Rg_j | tg_j] off the wrist, the
+// skinning transforms A_j = [Rg_j | tg_j - Rg_j J_j] and the posed rest vertices vp = v_shaped + posedirs . pose_map.  `qa` (or null)
+// receives per joint (a[3], |a + 1e-8|, sin, cos of half the angle, |quaternion| before normalisation) for the backward.
+__device__ __forceinline__ void mano_state(const float *p, const float *blob, float (*rot)[9], float *pm, float (*G)[12], float (*A)[12],
+                                           float *vp, float (*qa)[8]) {
+    const int tid = threadIdx.x;
+    const float *J = blob + OFF_J;
     if (tid < NJ) {
         // full pose = [root axis-angle | hands_mean + joint angles]  (manolayer.py:191)
         float a[3];
@@ -80,9 +77,10 @@ mano_fwd_kernel(const float *pose, const float *blob, int center_idx, float *ver
         }
         const float e0 = a[0] + 1e-8f, e1 = a[1] + 1e-8f, e2 = a[2] + 1e-8f;
         const float angle = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
-        const float half = angle * 0.5f, sn = sinf(half);
-        float w = cosf(half), x = sn * (a[0] / angle), y = sn * (a[1] / angle), z = sn * (a[2] / angle);
+        const float half = angle * 0.5f, sn = sinf(half), cs = cosf(half);
+        float w = cs, x = sn * (a[0] / angle), y = sn * (a[1] / angle), z = sn * (a[2] / angle);
         const float qn = sqrtf(w * w + x * x + y * y + z * z);
+        if (qa) { qa[tid][0] = a[0]; qa[tid][1] = a[1]; qa[tid][2] = a[2]; qa[tid][3] = angle; qa[tid][4] = sn; qa[tid][5] = cs; qa[tid][6] = qn; }
         w /= qn; x /= qn; y /= qn; z /= qn;
         const float w2 = w * w, x2 = x * x, y2 = y * y, z2 = z * z;
         const float wx = w * x, wy = w * y, wz = w * z, xy = x * y, xz = x * z, yz = y * z;
@@ -94,9 +92,7 @@ mano_fwd_kernel(const float *pose, const float *blob, int center_idx, float *ver
             for (int k = 0; k < 9; ++k) pm[9 * (tid - 1) + k] = r[k] - ((k == 0 || k == 4 || k == 8) ? 1.0f : 0.0f);
     }
     __syncthreads();
-
     // kinematic chain, one level per step: G_j = G_parent * [R_j | J_j - J_parent]  (manolayer.py:264-303)
-    const float *J = blob + OFF_J;
     for (int level = 0; level < 4; ++level) {
         if (tid < NJ) {
             const int par = PARENT[tid];
@@ -122,11 +118,12 @@ mano_fwd_kernel(const float *pose, const float *blob, int center_idx, float *ver
         __syncthreads();
     }
     if (tid < NJ) {
-        // joints are the chain translations; skinning uses A_j = [R | t - R J_j]  (manolayer.py:305-307)
+        // skinning uses A_j = [R | t - R J_j]  (manolayer.py:305-307); the joints are the chain translations G[j][.][3]
         for (int r = 0; r < 3; ++r) {
-            float *g = &G[tid][4 * r];
-            gt[tid][r] = g[3];
-            g[3] = g[3] - (g[0] * J[3 * tid] + g[1] * J[3 * tid + 1] + g[2] * J[3 * tid + 2]);
+            const float *g = &G[tid][4 * r];
+            float *o = &A[tid][4 * r];
+            o[0] = g[0]; o[1] = g[1]; o[2] = g[2];
+            o[3] = g[3] - (g[0] * J[3 * tid] + g[1] * J[3 * tid + 1] + g[2] * J[3 * tid + 2]);
         }
     }
     // pose blend shapes: v_posed = v_shaped + posedirs . pose_map, ten coordinates per thread, coalesced rows
@@ -151,6 +148,18 @@ mano_fwd_kernel(const float *pose, const float *blob, int center_idx, float *ver
         }
     }
     __syncthreads();
+}
+
+__global__ void __launch_bounds__(THREADS)
+mano_fwd_kernel(const float *pose, const float *blob, int center_idx, float *verts, float *joints) {
+    __shared__ float rot[NJ][9];        // per-joint rotations
+    __shared__ float pm[NPD + 1];       // pose map: (R_j - I) of the 15 finger joints, row-major
+    __shared__ float Gc[NJ][12];        // chain transforms [Rg | tg]: the translations are the joints
+    __shared__ float G[NJ][12];         // skinning transforms A_j
+    __shared__ float vp[NCP];           // posed rest vertices, then the skinned vertices
+    __shared__ float jout[21][3];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    mano_state(pose + (size_t)b * 48, blob, rot, pm, Gc, G, vp, nullptr);
     // linear blend skinning: T_v = sum_j w[v][j] A_j, vertex = T_v [v_posed; 1]
     const float *W = blob + OFF_W;
     float out[4][3];
@@ -177,7 +186,7 @@ mano_fwd_kernel(const float *pose, const float *blob, int center_idx, float *ver
     __syncthreads();
     if (tid < 21) {
         const int src = JORDER[tid];
-        for (int r = 0; r < 3; ++r) jout[tid][r] = src < NJ ? gt[src][r] : vp[3 * TIPS[src - NJ] + r];
+        for (int r = 0; r < 3; ++r) jout[tid][r] = src < NJ ? Gc[src][4 * r + 3] : vp[3 * TIPS[src - NJ] + r];
     }
     __syncthreads();
     float ctr[3] = {0.0f, 0.0f, 0.0f};
@@ -221,82 +230,7 @@ mano_bwd_kernel(const float *pose, const float *blob, int center_idx, const floa
     const float *p = pose + (size_t)b * 48;
     const float *J = blob + OFF_J;
 
-    // ---------------- forward intermediates (as mano_fwd_kernel) ----------------
-    if (tid < NJ) {
-        float a[3];
-        for (int c = 0; c < 3; ++c) {
-            const int i = 3 * tid + c;
-            a[c] = i < 3 ? p[i] : blob[OFF_MEAN + i - 3] + p[i];
-        }
-        const float e0 = a[0] + 1e-8f, e1 = a[1] + 1e-8f, e2 = a[2] + 1e-8f;
-        const float angle = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
-        const float half = angle * 0.5f, sn = sinf(half), cs = cosf(half);
-        float w = cs, x = sn * (a[0] / angle), y = sn * (a[1] / angle), z = sn * (a[2] / angle);
-        const float qn = sqrtf(w * w + x * x + y * y + z * z);
-        qa[tid][0] = a[0]; qa[tid][1] = a[1]; qa[tid][2] = a[2]; qa[tid][3] = angle; qa[tid][4] = sn; qa[tid][5] = cs; qa[tid][6] = qn;
-        w /= qn; x /= qn; y /= qn; z /= qn;
-        const float w2 = w * w, x2 = x * x, y2 = y * y, z2 = z * z;
-        const float wx = w * x, wy = w * y, wz = w * z, xy = x * y, xz = x * z, yz = y * z;
-        float *r = rot[tid];
-        r[0] = w2 + x2 - y2 - z2; r[1] = 2 * xy - 2 * wz;     r[2] = 2 * wy + 2 * xz;
-        r[3] = 2 * wz + 2 * xy;     r[4] = w2 - x2 + y2 - z2; r[5] = 2 * yz - 2 * wx;
-        r[6] = 2 * xz - 2 * wy;     r[7] = 2 * wx + 2 * yz;     r[8] = w2 - x2 - y2 + z2;
-        if (tid > 0)
-            for (int k = 0; k < 9; ++k) pm[9 * (tid - 1) + k] = r[k] - ((k == 0 || k == 4 || k == 8) ? 1.0f : 0.0f);
-    }
-    __syncthreads();
-    for (int level = 0; level < 4; ++level) {
-        if (tid < NJ) {
-            const int par = PARENT[tid];
-            const int my_level = tid == 0 ? 0 : ((tid - 1) % 3) + 1;
-            if (my_level == level) {
-                float t[3];
-                for (int c = 0; c < 3; ++c) t[c] = par < 0 ? J[c] : J[3 * tid + c] - J[3 * par + c];
-                if (par < 0) {
-                    for (int r = 0; r < 3; ++r) {
-                        for (int c = 0; c < 3; ++c) G[0][4 * r + c] = rot[0][3 * r + c];
-                        G[0][4 * r + 3] = t[r];
-                    }
-                } else {
-                    for (int r = 0; r < 3; ++r) {
-                        const float *gp = &G[par][4 * r];
-                        for (int c = 0; c < 3; ++c)
-                            G[tid][4 * r + c] = gp[0] * rot[tid][c] + gp[1] * rot[tid][3 + c] + gp[2] * rot[tid][6 + c];
-                        G[tid][4 * r + 3] = gp[0] * t[0] + gp[1] * t[1] + gp[2] * t[2] + gp[3];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (tid < NJ) {
-        for (int r = 0; r < 3; ++r) {
-            const float *g = &G[tid][4 * r];
-            float *a = &A[tid][4 * r];
-            a[0] = g[0]; a[1] = g[1]; a[2] = g[2];
-            a[3] = g[3] - (g[0] * J[3 * tid] + g[1] * J[3 * tid + 1] + g[2] * J[3 * tid + 2]);
-        }
-    }
-    {
-        float acc[10];
-        const float *vs = blob + OFF_VS, *pd = blob + OFF_PD;
-#pragma unroll
-        for (int i = 0; i < 10; ++i) acc[i] = 0.0f;
-        for (int k = 0; k < NPD; ++k) {
-            const float m = pm[k];
-            const float *row = pd + (size_t)k * NCP;
-#pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                const int e = tid + THREADS * i;
-                if (e < NCP) acc[i] = fmaf(row[e], m, acc[i]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            const int e = tid + THREADS * i;
-            if (e < NCP) vp[e] = vs[e] + acc[i];
-        }
-    }
+    mano_state(p, blob, rot, pm, G, A, vp, qa);                     // the forward's intermediates
     // ---------------- d out_v, d tg_j from the outputs' gradients ----------------
     const float *dV = dverts + (size_t)b * NC, *dJ = djoints + (size_t)b * 63;
     float s3[3] = {0.0f, 0.0f, 0.0f};
