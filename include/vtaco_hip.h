@@ -448,6 +448,10 @@ int vt_conv3d_gcr_f16x3_scaled(const float *skip, int C1, const float *low, int 
 size_t vt_unet3d_workspace_bytes(int B, int R, const vt_unet3d_params *params_host);
 int vt_unet3d_fwd(const float *x_cl, int B, int R, const vt_unet3d_params *params_host,
                   void *workspace, size_t workspace_bytes, float *out, void *stream);
+/* the same with the input's GroupNorm partial sums supplied by its producer (in_part [B][in_nblk][C][2], e.g. from                 */
+/* vt_pointnet_mlp_fused): no statistics pass over the input grid.                                                              */
+int vt_unet3d_fwd_stats(const float *x_cl, const float *in_part, int in_nblk, int B, int R, const vt_unet3d_params *params_host,
+                        void *workspace, size_t workspace_bytes, float *out, void *stream);
 int vt_maxpool3d_cl(const float *x, int B, int D, int H, int W, int C, float *out, void *stream);
 /* the same max-pool and, from the same pass, the pooled tensor's GroupNorm partial sums as vt_channel_stats would leave them   */
 /* (bit-identical: same blocks, same order): part [B][nblk][C][2].                                                          */
@@ -554,10 +558,16 @@ int vt_resblock_fc(const float *x1, int C1, const float *x2, int C2, int64_t N,
 /* its window of 8-16 sorted positions -- complete cells of any size -- so pooling needs no grid-wide step; same arithmetic and        */
 /* summation order as vt_linear_rows / vt_resblock_fc / vt_voxel_pool_max_fwd: bit-identical features.  block_w: 25 device pointers, */
 /* per block fc_0.weight [32][64], fc_0.bias, fc_1.weight [32][32], fc_1.bias, shortcut.weight [32][64]; hidden must be 32, c_dim     */
-/* <= 64 (VT_ERR_UNSUPPORTED otherwise: use the per-layer kernels); scratch [B,T,32] floats; out [B,T,c_dim] by point.               */
+/* <= 64 (VT_ERR_UNSUPPORTED otherwise: use the per-layer kernels); scratch [B,T,32] floats; out [B,T,c_dim] by point (or NULL).     */
+/* With grid_cl != NULL the kernel is also generate_grid_features (pointnet.py:102-110, scatter_mean): every cell's mean feature,     */
+/* summed in ascending point order like vt_voxel_scatter_mean_cl_fwd, goes into the ZERO-FILLED channels-last grid [B,R,R,R,c_dim]   */
+/* (idx [B,T] = the points' cell ids) and grid_part [B][vt_pointnet_mlp_stat_blocks(B,T)][c_dim][2] receives the GroupNorm partial    */
+/* sums of that grid (the empty voxels contribute nothing): what vt_channel_stats would compute in a pass over the whole grid.        */
+int vt_pointnet_mlp_stat_blocks(int B, int T);
 int vt_pointnet_mlp_fused(const float *pts, int B, int T, const int *order, const int *seg_lo, const int *seg_hi,
                           const float *pos_w, const float *pos_b, const float *const *block_w, int hidden,
-                          const float *c_w, const float *c_b, int c_dim, float *scratch, float *out, void *stream);
+                          const float *c_w, const float *c_b, int c_dim, float *scratch, float *out,
+                          const int *idx, int R, float *grid_cl, float *grid_part, void *stream);
 /* Backward of the two (training; PyTorch autograd of layers.py:8-50 and of the nn.Linear calls at    */
 /* pointnet.py:154-162 under loss.backward(), training.py:79,89,96):                                    */
 /*   vt_resblock_fc_bwd  d out [N][O] -> d x1 [N][C1], d x2 [N][C2] (NULL: not wanted), and the two       */

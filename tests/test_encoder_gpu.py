@@ -329,6 +329,35 @@ def test_pointnet_mlp_in_one_launch_equals_the_per_layer_path(kind, T, R, c_dim,
     assert got.shape == ref.shape == (p.shape[0], T, c_dim)
     assert torch.equal(got, ref) and torch.equal(again, got)
     assert not enc._one_launch_fits([vi, vi])                       # the hand encoder's three planes keep the per-layer path
+    # the same launch as voxeliser: the cells' mean features into the channels-last grid + the grid's GroupNorm partial sums
+    with torch.no_grad():
+        want = ops.voxel_scatter_mean_cl_fwd(ref, vi)
+        grid, (part, nblk) = ops.pointnet_mlp_fused(p, vi, enc.fc_pos, enc.blocks, enc.fc_c, want_grid=True)
+    assert grid.shape == want.shape and part.shape == (p.shape[0], nblk, c_dim, 2)
+    if kind == "sphere":
+        assert torch.equal(grid, want)                              # short cells: the voxeliser's own summation order
+    else:                                                           # dense cells: the voxeliser sums long cells cooperatively
+        assert float((grid - want).abs().max()) <= 5e-5 * max(1.0, float(want.abs().max()))    # (8192 addends in two different orders)
+    assert torch.equal((grid != 0).any(-1), (want != 0).any(-1))
+    g64 = grid.double().reshape(p.shape[0], -1, c_dim)
+    tot = torch.stack((g64.sum(1), (g64 * g64).sum(1)), dim=-1)
+    assert float((part.double().sum(1) - tot).abs().max()) <= 1e-5 * max(1.0, float(tot.abs().max()))
+
+
+def test_encoder_grid_through_the_one_launch_path_matches_the_per_layer_path(monkeypatch):
+    """LocalPoolPointnet.forward (PointNet + voxeliser + UNet3D) with the one-launch MLP handing the UNet3D the grid and its statistics
+    against the launch-per-layer path: the same grid up to the order in which the input statistics are summed."""
+    from vtaco_amd.bench_util import build_scene
+    sc = build_scene(0, DEV)
+    enc, pc = sc["model"].encoder, sc["cloud"].to(DEV)
+    with torch.no_grad():
+        monkeypatch.setenv("VTACO_POINTNET_ONE_LAUNCH", "0")
+        ref = enc(pc)["grid"]
+        monkeypatch.setenv("VTACO_POINTNET_ONE_LAUNCH", "1")
+        got = enc(pc)["grid"]
+        again = enc(pc)["grid"]
+    assert torch.equal(got, again)
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
 def _dense_cloud(kind, T, seed):

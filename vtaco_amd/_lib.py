@@ -122,7 +122,8 @@ SIGNATURES = {
     "vt_winding_number": (_I, [_VP, _I, _VP, _I, _VP, _I64, _VP, _VP]),
     "vt_linear_rows": (_I, [_VP, _VP, _VP, _I64, _I, _I, _VP, _VP]),
     "vt_resblock_fc": (_I, [_VP, _I, _VP, _I, _I64, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
-    "vt_pointnet_mlp_fused": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP]),
+    "vt_pointnet_mlp_stat_blocks": (_I, [_I, _I]),
+    "vt_pointnet_mlp_fused": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "vt_resblock_fc_bwd": (_I, [_VP, _I, _VP, _I, _I64, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vt_rows_wgrad_workspace_bytes": (_SZ, [_I64, _I, _I]),
     "vt_rows_wgrad": (_I, [_VP, _I, _VP, _I, _VP, _I, _I, _I64, _VP, _SZ, _VP, _VP, _VP]),
@@ -163,6 +164,7 @@ SIGNATURES = {
     "vt_conv3d_gcr": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),
     "vt_unet3d_workspace_bytes": (_SZ, [_I, _I, ctypes.POINTER(UnetParams)]),
     "vt_unet3d_fwd": (_I, [_VP, _I, _I, ctypes.POINTER(UnetParams), _VP, _SZ, _VP, _VP]),
+    "vt_unet3d_fwd_stats": (_I, [_VP, _VP, _I, _I, _I, ctypes.POINTER(UnetParams), _VP, _SZ, _VP, _VP]),
     "vt_maxpool3d_cl": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP]),
     "vt_maxpool3d_cl_stats": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _I, _VP, _VP]),
     "vt_conv1x1_cl": (_I, [_VP, _I64, _I, _VP, _VP, _I, _VP, _VP]),

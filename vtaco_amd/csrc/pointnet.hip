@@ -179,7 +179,13 @@ struct PnFusedArgs {
     const float *w0[PF_BLOCKS], *b0[PF_BLOCKS], *w1[PF_BLOCKS], *b1[PF_BLOCKS], *ws[PF_BLOCKS];   // fc_0 [H][2H], fc_1 [H][H], shortcut [H][2H]
     const float *c_w, *c_b;               // fc_c [c_dim][H], [c_dim]
     float *scratch;                       // [B,T,H] feature rows by sorted position
-    float *out;                           // [B,T,c_dim] by point
+    float *out;                           // [B,T,c_dim] by point, or null
+    // the voxeliser's mean (generate_grid_features) from the same kernel: every owned cell's mean feature into the zero-filled
+    // channels-last grid, and the workgroup's (sum, sum of squares) of those means = GroupNorm partial sums of the grid
+    const int *idx;                       // [B,T] cell id per point (with grid_cl)
+    float *grid_cl;                       // [B,V,c_dim] or null
+    float *part;                          // [B][workgroups per scene][c_dim][2] (with grid_cl)
+    long long V;
     int T, c_dim;
     int win;                              // window of sorted positions per workgroup (<= PF_WIN): chosen so that one round of workgroups covers the cloud
 };
@@ -198,6 +204,8 @@ pointnet_fused_kernel(PnFusedArgs a) {
     __shared__ int meta_t[PF_CACHE], meta_sg[PF_CACHE];
     __shared__ float srow[PF_CACHE][H], spts[PF_CACHE][3];
     __shared__ int head_rank[PF_WIN], range[2];
+    __shared__ int cell_n[PF_WIN], cell_id[PF_WIN], seg_pass[PF_PTS];
+    __shared__ float couts[PF_PTS][64];
     const int b = blockIdx.y, T = a.T, win = a.win, wstart = blockIdx.x * win;
     const int *order = a.order + (size_t)b * T, *seg_lo = a.seg_lo + (size_t)b * T, *seg_hi = a.seg_hi + (size_t)b * T;
     const float *pts = a.pts + (size_t)b * T * 3;
@@ -209,14 +217,28 @@ pointnet_fused_kernel(PnFusedArgs a) {
         if (i < win && jpos < T) { t = order[jpos]; lo = seg_lo[t]; hi = seg_hi[t]; }
         const bool head = i < win && jpos < T && lo == jpos;
         const unsigned long long m = __ballot(head);
-        if (i < PF_WIN) head_rank[i] = __popcll(m & ((1ull << i) - 1ull));
+        const int rk = __popcll(m & ((1ull << i) - 1ull));
+        if (i < win) head_rank[i] = rk;
+        if (head && a.grid_cl) { cell_n[rk] = hi - lo; cell_id[rk] = a.idx[(size_t)b * T + t]; }
         const int last = m ? 63 - __builtin_clzll(m) : 0;
         const int end = __shfl(hi, last);
         if (i == 0) { range[0] = m ? wstart + __builtin_ctzll(m) : -1; range[1] = end; }
     }
     __syncthreads();
     const int first = range[0], end = range[1];
-    if (first < 0) return;                                          // the window lies inside a cell owned further left
+    if (first < 0) {                                                // the window lies inside a cell owned further left
+        if (a.part && (int)threadIdx.x < 2 * a.c_dim) a.part[((size_t)b * gridDim.x + blockIdx.x) * a.c_dim * 2 + threadIdx.x] = 0.0f;
+        return;
+    }
+    // grid mode: thread c < c_dim adds its channel of the pass's points to the running sum of the current cell, in sorted order
+    // (the order of the voxeliser's own mean), and closes a cell when the next one starts
+    int run_seg = -1;
+    float run_acc = 0.0f, st_sum = 0.0f, st_sq = 0.0f;
+    auto close_cell = [&](int sgc, float acc) {
+        const float mean = acc / (float)cell_n[sgc];
+        a.grid_cl[((size_t)b * a.V + (size_t)cell_id[sgc]) * a.c_dim + threadIdx.x] = mean;
+        st_sum += mean; st_sq = fmaf(mean, mean, st_sq);
+    };
     const int lp = threadIdx.x / H, j = threadIdx.x - lp * H;
     transpose_to_lds(post, C | 1, a.pos_w, C, 3);
     transpose_to_lds(cwt, 65, a.c_w, a.c_dim, H);
@@ -313,12 +335,38 @@ pointnet_fused_kernel(PnFusedArgs a) {
             if (blk + 1 < PF_BLOCKS) {
             } else {
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 2; ++u) {
+                    const int pl = lp + 8 * u;
+                    if (j == 0) seg_pass[pl] = livev[u] ? sgv[u] : -1;
                     if (livev[u])
-                        for (int oc = j; oc < a.c_dim; oc += H)     // fc_c straight from the last block's rows
-                            a.out[((size_t)b * T + tq[u]) * a.c_dim + oc] = a.c_b[oc] + dot_cols_n<false, H>(cwt, 65, oc, outs[lp + 8 * u]);
+                        for (int oc = j; oc < a.c_dim; oc += H) {   // fc_c straight from the last block's rows
+                            const float cv = a.c_b[oc] + dot_cols_n<false, H>(cwt, 65, oc, outs[pl]);
+                            if (a.out) a.out[((size_t)b * T + tq[u]) * a.c_dim + oc] = cv;
+                            couts[pl][oc] = cv;
+                        }
+                }
+                if (a.grid_cl) {
+                    __syncthreads();
+                    if ((int)threadIdx.x < a.c_dim) {
+                        int sg16[PF_PTS];
+                        float v16[PF_PTS];
+#pragma unroll
+                        for (int i = 0; i < PF_PTS; ++i) { sg16[i] = seg_pass[i]; v16[i] = couts[i][threadIdx.x]; }
+#pragma unroll
+                        for (int i = 0; i < PF_PTS; ++i) {
+                            if (sg16[i] < 0) continue;
+                            if (sg16[i] != run_seg) { if (run_seg >= 0) close_cell(run_seg, run_acc); run_seg = sg16[i]; run_acc = 0.0f; }
+                            run_acc += v16[i];
+                        }
+                    }
+                }
             }
         }
+    }
+    if (a.grid_cl && (int)threadIdx.x < a.c_dim) {
+        if (run_seg >= 0) close_cell(run_seg, run_acc);
+        float *dst = a.part + (((size_t)b * gridDim.x + blockIdx.x) * a.c_dim + threadIdx.x) * 2;
+        dst[0] = st_sum; dst[1] = st_sq;
     }
 }
 
@@ -520,11 +568,29 @@ int vt_resblock_fc_bwd(const float *x1, int C1, const float *x2, int C2, int64_t
     return vt_check(hipGetLastError(), "vt_resblock_fc_bwd");
 }
 
+static int pointnet_window(int B, int T) {
+    // one workgroup per CU is resident (256 registers x 4 waves): the smallest window that still covers the cloud in one round of
+    // workgroups keeps a workgroup at one 16-point pass per block (3000 points: 12 positions -> 250 workgroups, 25 us; 16 -> 40 us; 10 -> 44 us)
+    const int64_t pts_total = (int64_t)B * T, cus = vt_num_cus();
+    int win = (int)((pts_total + cus - 1) / cus);
+    if (win < 8) win = 8;
+    if (win > PF_WIN) win = PF_WIN;
+    return win;
+}
+
+int vt_pointnet_mlp_stat_blocks(int B, int T) {
+    if (B <= 0 || T <= 0) return 0;
+    const int win = pointnet_window(B, T);
+    return (T + win - 1) / win;
+}
+
 int vt_pointnet_mlp_fused(const float *pts, int B, int T, const int *order, const int *seg_lo, const int *seg_hi,
                           const float *pos_w, const float *pos_b, const float *const *block_w, int hidden,
-                          const float *c_w, const float *c_b, int c_dim, float *scratch, float *out, void *stream) {
-    if (!pts || !order || !seg_lo || !seg_hi || !pos_w || !pos_b || !block_w || !c_w || !c_b || !scratch || !out || B <= 0 || T <= 0)
+                          const float *c_w, const float *c_b, int c_dim, float *scratch, float *out,
+                          const int *idx, int R, float *grid_cl, float *grid_part, void *stream) {
+    if (!pts || !order || !seg_lo || !seg_hi || !pos_w || !pos_b || !block_w || !c_w || !c_b || !scratch || (!out && !grid_cl) || B <= 0 || T <= 0)
         return vt_fail(VT_ERR_INVALID, "vt_pointnet_mlp_fused: bad argument");
+    if (grid_cl && (!idx || !grid_part || R < 1)) return vt_fail(VT_ERR_INVALID, "vt_pointnet_mlp_fused: the grid output needs idx, R and grid_part");
     if (hidden != PF_H || c_dim <= 0 || c_dim > 64)
         return vt_fail(VT_ERR_UNSUPPORTED, "vt_pointnet_mlp_fused: built for hidden_dim 32 and c_dim <= 64 (the shipped encoders); use the per-layer kernels");
     for (int i = 0; i < 5 * PF_BLOCKS; ++i)
@@ -537,12 +603,8 @@ int vt_pointnet_mlp_fused(const float *pts, int B, int T, const int *order, cons
         if (!a.w0[i] || !a.b0[i] || !a.w1[i] || !a.b1[i] || !a.ws[i]) return vt_fail(VT_ERR_INVALID, "vt_pointnet_mlp_fused: null block weight");
     }
     a.c_w = c_w; a.c_b = c_b; a.scratch = scratch; a.out = out; a.T = T; a.c_dim = c_dim;
-    // one workgroup per CU is resident (256 registers x 4 waves): the smallest window that still covers the cloud in one round of
-    // workgroups keeps a workgroup at one 16-point pass per block (3000 points: 12 positions -> 250 workgroups, 25 us; 16 -> 40 us; 10 -> 44 us)
-    const int64_t pts_total = (int64_t)B * T, cus = vt_num_cus();
-    int win = (int)((pts_total + cus - 1) / cus);
-    if (win < 8) win = 8;
-    if (win > PF_WIN) win = PF_WIN;
+    a.idx = idx; a.grid_cl = grid_cl; a.part = grid_cl ? grid_part : nullptr; a.V = (long long)R * R * R;
+    const int win = pointnet_window(B, T);
     a.win = win;
     hipLaunchKernelGGL(pointnet_fused_kernel, dim3((unsigned)((T + win - 1) / win), (unsigned)B), dim3(PN_THREADS), 0, (hipStream_t)stream, a);
     return vt_check(hipGetLastError(), "vt_pointnet_mlp_fused");

@@ -1933,7 +1933,7 @@ struct Tensor { float *x; float *part; int nblk; int C; };
 
 // plan == true only sizes the workspace
 int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char *wsbase, size_t *ws_need, float *out,
-               hipStream_t st) {
+               hipStream_t st, const float *in_part = nullptr, int in_nblk = 0) {
     const int L = p->n_levels;
     if (L < 1 || L > VT_UNET_MAX_LEVELS) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: bad level count");
     if (R % (1 << (L - 1))) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: resolution must be divisible by 2^(levels-1)");
@@ -1980,7 +1980,9 @@ int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char 
     Tensor skips[VT_UNET_MAX_LEVELS];
     Tensor cur;
     cur.x = const_cast<float *>(x_cl); cur.C = p->enc[0][0].cin;
-    int rc = stats_of(x_cl, R, cur.C, cur);
+    int rc = 0;
+    if (in_part) { cur.part = const_cast<float *>(in_part); cur.nblk = in_nblk; }      // the producer of x left its partial sums
+    else rc = stats_of(x_cl, R, cur.C, cur);
     if (rc) return rc;
     for (int i = 0; i < L; ++i) {
         const int Ri = R >> i;
@@ -2026,6 +2028,15 @@ size_t vt_unet3d_workspace_bytes(int B, int R, const vt_unet3d_params *params_ho
     if (!params_host || B <= 0 || R <= 0) return 0;
     if (unet3d_run(nullptr, B, R, params_host, nullptr, &need, nullptr, nullptr)) return 0;
     return need;
+}
+
+int vt_unet3d_fwd_stats(const float *x_cl, const float *in_part, int in_nblk, int B, int R, const vt_unet3d_params *params_host,
+                        void *workspace, size_t workspace_bytes, float *out, void *stream) {
+    if (!x_cl || !in_part || in_nblk <= 0 || !params_host || !workspace || !out) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd_stats: bad argument");
+    const size_t need = vt_unet3d_workspace_bytes(B, R, params_host);
+    if (!need) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd_stats: bad configuration");
+    if (workspace_bytes < need) return vt_fail(VT_ERR_WORKSPACE, "vt_unet3d_fwd_stats: workspace too small");
+    return unet3d_run(x_cl, B, R, params_host, (char *)workspace, nullptr, out, (hipStream_t)stream, in_part, in_nblk);
 }
 
 int vt_unet3d_fwd(const float *x_cl, int B, int R, const vt_unet3d_params *params_host,

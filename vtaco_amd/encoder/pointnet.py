@@ -288,6 +288,11 @@ class LocalPoolPointnet(nn.Module):
 
     def forward_grid(self, p):
         vi = ops.VoxelIndex(p, self.reso_grid, self.padding)
+        if (self.unet3d is not None and not torch.is_grad_enabled() and self.unet3d.hip_supported() and self._fused_mlp_fits()
+                and self._one_launch_fits(vi) and self.unet3d.encoders[0].basic_module.SingleConv1.conv.in_channels == self.c_dim):
+            # inference: the per-point MLP, the voxeliser's mean and the grid's GroupNorm statistics from one launch, then the UNet3D
+            grid, stats = ops.pointnet_mlp_fused(p.float(), vi, self.fc_pos, self.blocks, self.fc_c, want_grid=True)
+            return {'grid': self.unet3d.forward_channels_last(grid, in_stats=stats).permute(0, 4, 1, 2, 3)}
         feat = self.point_features(p.float(), vi)
         if self.unet3d is not None and not torch.is_grad_enabled() and self.unet3d.hip_supported():
             # inference: scatter straight into a channels-last grid, UNet3D on the HIP conv kernels,

@@ -536,9 +536,11 @@ def mano_fwd(pose, blob, center_idx=9):
     return verts, joints
 
 
-def pointnet_mlp_fused(p, vi, fc_pos, blocks, fc_c):
+def pointnet_mlp_fused(p, vi, fc_pos, blocks, fc_c, want_grid=False):
     """fc_pos -> block 0 -> 4 x (pool over the point's cell, concat, block) -> fc_c for one voxel index in ONE launch
-    (vt_pointnet_mlp_fused; inference): [B,T,c_dim], bit-identical to the launch-per-layer path."""
+    (vt_pointnet_mlp_fused; inference): [B,T,c_dim], bit-identical to the launch-per-layer path.  ``want_grid``: instead of the
+    point features, the voxeliser's channels-last mean grid [B,R,R,R,c_dim] and its GroupNorm partial sums (part, nblk) from
+    the same kernel (scatter_mean + channel_stats without their launches and the pass over the grid)."""
     p = _c(p.float())
     B, T, _ = p.shape
     c_dim = fc_c.weight.shape[0]
@@ -546,15 +548,25 @@ def pointnet_mlp_fused(p, vi, fc_pos, blocks, fc_c):
     for blk in blocks:
         ws += [_c(blk.fc_0.weight), _c(blk.fc_0.bias), _c(blk.fc_1.weight), _c(blk.fc_1.bias), _c(blk.shortcut.weight)]
     ptrs = (ctypes.c_void_p * len(ws))(*[t.data_ptr() for t in ws])
+    lib = _lib.load()
     scratch = torch.empty((B, T, 32), dtype=torch.float32, device=p.device)
-    out = torch.empty((B, T, c_dim), dtype=torch.float32, device=p.device)
+    out = grid = part = None
+    nblk = 0
+    if want_grid:
+        R = vi.R
+        grid = torch.zeros((B, R, R, R, c_dim), dtype=torch.float32, device=p.device)
+        nblk = lib.vt_pointnet_mlp_stat_blocks(B, T)
+        part = torch.empty((B, nblk, c_dim, 2), dtype=torch.float32, device=p.device)
+    else:
+        out = torch.empty((B, T, c_dim), dtype=torch.float32, device=p.device)
     keep = [_c(fc_pos.weight), _c(fc_pos.bias), _c(fc_c.weight), _c(fc_c.bias)]
-    check(_lib.load().vt_pointnet_mlp_fused(dev_ptr(p, "p"), B, T, dev_ptr(vi.order, "order", I32), dev_ptr(vi.seg_lo, "seg_lo", I32),
-                                            dev_ptr(vi.seg_hi, "seg_hi", I32), dev_ptr(keep[0], "fc_pos.weight"), dev_ptr(keep[1], "fc_pos.bias"),
-                                            ptrs, 32, dev_ptr(keep[2], "fc_c.weight"), dev_ptr(keep[3], "fc_c.bias"), c_dim,
-                                            dev_ptr(scratch, "scratch"), dev_ptr(out, "out"), stream_ptr()), "vt_pointnet_mlp_fused")
+    check(lib.vt_pointnet_mlp_fused(dev_ptr(p, "p"), B, T, dev_ptr(vi.order, "order", I32), dev_ptr(vi.seg_lo, "seg_lo", I32),
+                                    dev_ptr(vi.seg_hi, "seg_hi", I32), dev_ptr(keep[0], "fc_pos.weight"), dev_ptr(keep[1], "fc_pos.bias"),
+                                    ptrs, 32, dev_ptr(keep[2], "fc_c.weight"), dev_ptr(keep[3], "fc_c.bias"), c_dim,
+                                    dev_ptr(scratch, "scratch"), dev_ptr(out, "out"), dev_ptr(vi.idx, "idx", I32) if want_grid else None,
+                                    vi.R if want_grid else 0, dev_ptr(grid, "grid"), dev_ptr(part, "part"), stream_ptr()), "vt_pointnet_mlp_fused")
     keep_for_graph(scratch, *ws, *keep)
-    return out
+    return (grid, (part, nblk)) if want_grid else out
 
 
 def mano_bwd(pose, blob, center_idx, dverts, djoints):
@@ -1027,9 +1039,10 @@ def conv1x1_cl(x, weight, bias):
 _unet_ws = {}
 
 
-def unet3d_fwd(x_cl, params, keep):
+def unet3d_fwd(x_cl, params, keep, in_stats=None):
     """Whole UNet3D forward (vt_unet3d_fwd).  ``params``: a filled _lib.UnetParams; ``keep``: the
-    tensors its pointers refer to (kept alive by the caller)."""
+    tensors its pointers refer to (kept alive by the caller).  ``in_stats`` = (part, nblk): GroupNorm partial sums of the
+    input that its producer already has (vt_unet3d_fwd_stats: no statistics pass over the input)."""
     lib = _lib.load()
     B, R = x_cl.shape[0], x_cl.shape[1]
     need = lib.vt_unet3d_workspace_bytes(B, R, ctypes.byref(params))
@@ -1042,6 +1055,11 @@ def unet3d_fwd(x_cl, params, keep):
         ws = _unet_ws[key] = torch.empty(need, dtype=torch.uint8, device=x_cl.device)
     keep_for_graph(ws, *keep)
     out = torch.empty((B, R, R, R, params.out_channels), dtype=torch.float32, device=x_cl.device)
+    if in_stats is not None:
+        keep_for_graph(in_stats[0])
+        check(lib.vt_unet3d_fwd_stats(dev_ptr(x_cl, "x"), dev_ptr(in_stats[0], "in_part"), int(in_stats[1]), B, R, ctypes.byref(params),
+                                      ctypes.c_void_p(ws.data_ptr()), need, dev_ptr(out, "out"), stream_ptr()), "vt_unet3d_fwd_stats")
+        return out
     check(lib.vt_unet3d_fwd(dev_ptr(x_cl, "x"), B, R, ctypes.byref(params), ctypes.c_void_p(ws.data_ptr()), need,
                             dev_ptr(out, "out"), stream_ptr()), "vt_unet3d_fwd")
     return out
