@@ -101,7 +101,7 @@ class _GcrFn(torch.autograd.Function):
         # "f16x3": the forward conv on split-f16 operands where that kernel covers the shape (its inputs are GroupNorm outputs:
         # inside the half range, error at f32 rounding level)
         half = ops.conv3d_pack(weight, "f16x3") if precision == "f16x3" else None
-        y, (part, _) = ops.conv3d_gcr(x, low, ss, ops.conv3d_pack(weight), Cout, True, split, packed_w_f16x3=half)
+        y, (part, _) = ops.conv3d_gcr(x, low, ss, lambda: ops.conv3d_pack(weight), Cout, True, split, packed_w_f16x3=half)    # f32 pack on demand
         ctx.save_for_backward(x, low, gamma, weight, ss, y, x_part, low_part)
         ctx.cfg = (groups, eps, precision)
         ctx.mark_non_differentiable(part)
@@ -122,7 +122,7 @@ class _GcrFn(torch.autograd.Function):
             # output gradients sit many orders of magnitude below the half range: the kernel scales them by a power of two
             # taken from their largest element before the split (exact), so the data gradient keeps f32-level accuracy
             half = ops.conv3d_pack(w_t, "f16x3")
-        dxn, _ = ops.conv3d_gcr(g, None, None, ops.conv3d_pack(w_t), w_t.shape[0], False, split, want_stats=False,
+        dxn, _ = ops.conv3d_gcr(g, None, None, lambda: ops.conv3d_pack(w_t), w_t.shape[0], False, split, want_stats=False,
                                 packed_w_f16x3=half, in_absmax=gmax)
         # weight gradient: split-half operands as well (K = voxels; g under the same power-of-two rescale)
         dw = ops.conv3d_wgrad(x, low, ss, g, precision="f16x3" if precision == "f16x3" and _WGRAD_F16 else "f32",

@@ -889,7 +889,9 @@ def conv3d_gcr(x, low, ss, packed_w, Cout, relu=True, packed_w_bf16x3=None, want
     dev = x.device
     st = stream_ptr()
     out = torch.empty((B, D, H, W, Cout), dtype=torch.float32, device=dev)
-    fn, name, pw = lib.vt_conv3d_gcr, "vt_conv3d_gcr", packed_w
+    if callable(packed_w) and packed_w_f16x3 is None and packed_w_bf16x3 is None:
+        packed_w = packed_w()
+    fn, name, pw = lib.vt_conv3d_gcr, "vt_conv3d_gcr", packed_w      # (a callable: packed on demand, only if the f32 kernel runs)
     nblk = lib.vt_conv3d_stat_blocks_f16x3(B, D, H, W, C1 + C2, Cout) if packed_w_f16x3 is not None else 0
     if nblk:
         fn, name, pw = lib.vt_conv3d_gcr_f16x3, "vt_conv3d_gcr_f16x3", packed_w_f16x3
@@ -910,6 +912,8 @@ def conv3d_gcr(x, low, ss, packed_w, Cout, relu=True, packed_w_bf16x3=None, want
             fn, name, pw = lib.vt_conv3d_gcr_bf16x3, "vt_conv3d_gcr_bf16x3", packed_w_bf16x3
         else:
             nblk = lib.vt_conv3d_stat_blocks(B, D, H, W, C1 + C2, Cout)
+            if callable(pw):
+                pw = pw()
     part = torch.empty((B, nblk, Cout, 2), dtype=torch.float32, device=dev) if want_stats else None
     if in_absmax is not None and name == "vt_conv3d_gcr_f16x3":
         # input far below the half range (output gradients): the kernel rescales it by a power of two around the split
