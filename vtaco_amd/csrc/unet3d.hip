@@ -2468,32 +2468,42 @@ conv3d_wgrad_reduce_scaled_kernel(const float *partial, int chunks, int Cout, in
 }
 
 // ---- GroupNorm backward ------------------------------------------------------------------------
-// part[b][blk][c] = (sum_v dxn, sum_v dxn * x) over the block's voxels; x is the virtual concat input
+// part[b][blk][c] = (sum_v dxn, sum_v dxn * x) over the block's voxels; x is the virtual concat input.
+// Thread = (voxel group of 32, four channels): 16-byte loads of dxn and x, 32-bit voxel arithmetic (the scalar-load form with
+// 64-bit div / mod per element ran at half the memory rate: 1.23 ms of a 16 ms training step).
 __global__ void __launch_bounds__(256)
 gn_bwd_stats_kernel(Src s, const float *dxn, int nblk, float *part) {
-    __shared__ float red[8][32][2];
+    __shared__ float red[32][8][8];
     const int b = blockIdx.y, blk = blockIdx.x;
     const int C = s.C1 + s.C2;
-    const size_t V = (size_t)s.D * s.H * s.W;
-    const size_t v0 = V * blk / nblk, v1 = V * (blk + 1) / nblk;
-    const int c = threadIdx.x & 31, vg = threadIdx.x >> 5;
+    const unsigned V = (unsigned)s.D * s.H * s.W;
+    const unsigned v0 = (unsigned)((size_t)V * blk / nblk), v1 = (unsigned)((size_t)V * (blk + 1) / nblk);
+    const int q = threadIdx.x & 7, vg = threadIdx.x >> 3;
+    const unsigned HW = (unsigned)s.H * s.W;
+    const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
     for (int cb = 0; cb < C; cb += 32) {
-        float p1 = 0.0f, p2 = 0.0f;
-        for (size_t v = v0 + vg; v < v1; v += 8) {
-            const int x = (int)(v % s.W);
-            const size_t r = v / s.W;
-            const int y = (int)(r % s.H), z = (int)(r / s.H);
-            const float d = dxn[((size_t)b * V + v) * C + cb + c];
-            p1 += d;
-            p2 = fmaf(d, src_at(s, b, z, y, x, cb + c), p2);
+        const int ch = cb + 4 * q;
+        const bool from_low = ch >= s.C1;
+        f32x4 p1 = {0.f, 0.f, 0.f, 0.f}, p2 = {0.f, 0.f, 0.f, 0.f};
+        for (unsigned v = v0 + vg; v < v1; v += 32) {
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(dxn + ((size_t)b * V + v) * C + ch);
+            f32x4 x;
+            if (!from_low) {
+                x = *reinterpret_cast<const f32x4 *>(s.skip + ((size_t)b * V + v) * s.C1 + ch);
+            } else {
+                const unsigned z = v / HW, r = v - z * HW, y = r / (unsigned)s.W, xx = r - y * (unsigned)s.W;
+                x = *reinterpret_cast<const f32x4 *>(s.low + ((((size_t)b * D2 + (z >> 1)) * H2 + (y >> 1)) * W2 + (xx >> 1)) * s.C2 + (ch - s.C1));
+            }
+            p1.x += d.x; p1.y += d.y; p1.z += d.z; p1.w += d.w;
+            p2.x = fmaf(d.x, x.x, p2.x); p2.y = fmaf(d.y, x.y, p2.y); p2.z = fmaf(d.z, x.z, p2.z); p2.w = fmaf(d.w, x.w, p2.w);
         }
-        red[vg][c][0] = p1; red[vg][c][1] = p2;
+        float *r = red[vg][q];
+        r[0] = p1.x; r[1] = p2.x; r[2] = p1.y; r[3] = p2.y; r[4] = p1.z; r[5] = p2.z; r[6] = p1.w; r[7] = p2.w;
         __syncthreads();
-        if (threadIdx.x < 32) {
-            float a = 0.0f, q = 0.0f;
-            for (int k = 0; k < 8; ++k) { a += red[k][c][0]; q += red[k][c][1]; }
-            float *dst = part + (((size_t)b * nblk + blk) * C + cb + c) * 2;
-            dst[0] = a; dst[1] = q;
+        if (threadIdx.x < 64) {                                       // threadIdx.x = (channel of the 32-block) * 2 + {sum, sum x}
+            float a = 0.0f;
+            for (int k = 0; k < 32; ++k) a += red[k][threadIdx.x >> 3][threadIdx.x & 7];
+            part[(((size_t)b * nblk + blk) * C + cb) * 2 + threadIdx.x] = a;
         }
         __syncthreads();
     }
