@@ -754,6 +754,45 @@ int vt_mc_read_counts(const void *workspace, int *nverts_host, int *nfaces_host,
     return 0;
 }
 
+// The same read split in two, so that work launched in between overlaps it: _begin copies the header into a page-locked slot and
+// records an event right behind the copy; _end waits for THAT event only (not for what was launched after it -- the speculative
+// vertex / face kernels of a marching-cubes call) and returns the counts.  A ring of 16 slots; a token is valid for one _end.
+namespace {
+constexpr int MC_SLOTS = 16;
+struct McSlot { McHeader *host; hipEvent_t ev; };
+McSlot mc_slots[MC_SLOTS];
+bool mc_slots_ready = false;
+unsigned mc_slot_next = 0;
+}  // namespace
+
+int vt_mc_read_counts_begin(const void *workspace, void *stream, int *token) {
+    if (!workspace || !token) return vt_fail(VT_ERR_INVALID, "vt_mc_read_counts_begin: null argument");
+    if (!mc_slots_ready) {
+        for (int i = 0; i < MC_SLOTS; ++i) {
+            hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&mc_slots[i].host), sizeof(McHeader), hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&mc_slots[i].ev, hipEventDisableTiming);
+            if (e != hipSuccess) return vt_check(e, "vt_mc_read_counts_begin: page-locked slot");
+        }
+        mc_slots_ready = true;
+    }
+    const int t = (int)(mc_slot_next++ % MC_SLOTS);
+    hipError_t e = hipMemcpyAsync(mc_slots[t].host, workspace, sizeof(McHeader), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipEventRecord(mc_slots[t].ev, (hipStream_t)stream);
+    if (e != hipSuccess) return vt_check(e, "vt_mc_read_counts_begin");
+    *token = t;
+    return 0;
+}
+
+int vt_mc_read_counts_end(int token, int *nverts_host, int *nfaces_host, double *level_host) {
+    if (token < 0 || token >= MC_SLOTS || !mc_slots_ready || !nverts_host || !nfaces_host)
+        return vt_fail(VT_ERR_INVALID, "vt_mc_read_counts_end: bad token or null argument");
+    const hipError_t e = hipEventSynchronize(mc_slots[token].ev);
+    if (e != hipSuccess) return vt_check(e, "vt_mc_read_counts_end");
+    *nverts_host = mc_slots[token].host->nverts; *nfaces_host = mc_slots[token].host->nfaces;
+    if (level_host) *level_host = mc_slots[token].host->level;
+    return 0;
+}
+
 int vt_mc_emit(const float *vol, int n0, int n1, int n2, void *workspace,
                float *verts, int max_verts, int *faces, int max_faces,
                int rescale, float shift, float scale, void *stream) {

@@ -261,9 +261,13 @@ def mc_emit(vol, ws, rescale=None, capacity=None):
         return verts, faces, ws          # counts stay on the device: ws[8:16] = (nverts, nfaces) int32
     key = (vol.device.index, n0, n1, n2)
     guess = _mc_guess.get(key)
+    # the copy of the counts is queued FIRST (it needs the classify / scan launches only) and waited for by its own event, so
+    # the speculative emit kernels run under that wait instead of in front of the copy
+    tok = ctypes.c_int()
+    check(lib.vt_mc_read_counts_begin(wp, st, ctypes.byref(tok)), "vt_mc_read_counts_begin")
     spec = emit(*guess) if guess is not None else None
     nv, nf, lvl = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
-    check(lib.vt_mc_read_counts(wp, ctypes.byref(nv), ctypes.byref(nf), ctypes.byref(lvl), st), "vt_mc_read_counts")
+    check(lib.vt_mc_read_counts_end(tok.value, ctypes.byref(nv), ctypes.byref(nf), ctypes.byref(lvl)), "vt_mc_read_counts_end")
     if nv.value == 0:
         raise RuntimeError("No surface found at the given iso value.")
     _mc_guess[key] = (nv.value + nv.value // 4 + 1024, nf.value + nf.value // 4 + 1024)
