@@ -22,6 +22,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "vt_common.h"
 
 #define MC_TABLE_QUALIFIER __device__ const
@@ -762,11 +765,13 @@ constexpr int MC_SLOTS = 16;
 struct McSlot { McHeader *host; hipEvent_t ev; };
 McSlot mc_slots[MC_SLOTS];
 bool mc_slots_ready = false;
-unsigned mc_slot_next = 0;
+std::atomic<unsigned> mc_slot_next{0};
+std::mutex mc_slots_mutex;                              // guards the one-time creation of the slots
 }  // namespace
 
 int vt_mc_read_counts_begin(const void *workspace, void *stream, int *token) {
     if (!workspace || !token) return vt_fail(VT_ERR_INVALID, "vt_mc_read_counts_begin: null argument");
+    std::lock_guard<std::mutex> lock(mc_slots_mutex);
     if (!mc_slots_ready) {
         for (int i = 0; i < MC_SLOTS; ++i) {
             hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&mc_slots[i].host), sizeof(McHeader), hipHostMallocDefault);
@@ -775,7 +780,7 @@ int vt_mc_read_counts_begin(const void *workspace, void *stream, int *token) {
         }
         mc_slots_ready = true;
     }
-    const int t = (int)(mc_slot_next++ % MC_SLOTS);
+    const int t = (int)(mc_slot_next.fetch_add(1) % MC_SLOTS);
     hipError_t e = hipMemcpyAsync(mc_slots[t].host, workspace, sizeof(McHeader), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipEventRecord(mc_slots[t].ev, (hipStream_t)stream);
     if (e != hipSuccess) return vt_check(e, "vt_mc_read_counts_begin");
