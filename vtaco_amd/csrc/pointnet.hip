@@ -266,10 +266,7 @@ pointnet_fused_kernel(PnFusedArgs a) {
         wt[k * LDH + row] = v.x; wt[(k + 1) * LDH + row] = v.y; wt[(k + 2) * LDH + row] = v.z; wt[(k + 3) * LDH + row] = v.w;
     };
     wfetch(0);
-#ifndef PF_DBG_BLOCKS
-#define PF_DBG_BLOCKS PF_BLOCKS            // (timing experiments only: fewer blocks)
-#endif
-    for (int blk = 0; blk < PF_DBG_BLOCKS; ++blk) {
+    for (int blk = 0; blk < PF_BLOCKS; ++blk) {
         __syncthreads();                                            // the previous block is done with the weights and with pcur
         put(w0t, C / 4, threadIdx.x, wr[0]); put(w0t, C / 4, threadIdx.x + PN_THREADS, wr[1]);
         put(w1t, H / 4, threadIdx.x, wr[2]);

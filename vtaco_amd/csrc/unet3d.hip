@@ -2238,8 +2238,9 @@ __device__ __forceinline__ void wgrad_h_ksteps(const char *xh, const char *xl, c
         const int z = ks >> 2, y = (ks & 3) * 2 + kg;
         const int goff = ch * WH_GCH + (z * 8 + y) * 16;
         const f16x8 ah = *reinterpret_cast<const f16x8 *>(gh + goff), al = *reinterpret_cast<const f16x8 *>(gl + goff);
-        // the wave's halo rows one after the other, each row's ten dwords requested while the previous row's MFMAs run (the
-        // scheduler would otherwise hoist every row's loads to the top: 40 registers the prefetched tile needs)
+        // the wave's halo rows one after the other, a scheduling barrier between them (the scheduler would otherwise hoist every
+        // row's loads to the top: 40 registers the prefetched tile needs; requesting row r + 1 under row r's MFMAs spilled 63
+        // registers -- the other workgroup on the SIMD covers the LDS latency instead)
         struct Row { unsigned dh[5], dl[5]; u32x4 ph, pl; };            // ph / pl: dwords 1-4 again, as an aligned register tuple
         auto load_row = [&](int r) {
             Row o;
@@ -2259,17 +2260,9 @@ __device__ __forceinline__ void wgrad_h_ksteps(const char *xh, const char *xl, c
             return o;
         };
         constexpr int R0 = T0 / 3, R1 = (T1 - 1) / 3;                     // first and last halo row with a tap of this wave
-#ifdef VT_WH_ROWPIPE
-        Row nxt = load_row(R0);
-#endif
 #pragma unroll
         for (int r = R0; r <= R1; ++r) {
-#ifdef VT_WH_ROWPIPE
-            const Row cur = nxt;
-            if (r < R1) nxt = load_row(r + 1);
-#else
             const Row cur = load_row(r);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             const unsigned *dh = cur.dh, *dl = cur.dl;
 #pragma unroll
