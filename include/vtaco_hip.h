@@ -405,6 +405,8 @@ typedef struct vt_unet3d_params {
     const float *final_w; /* final_conv.weight [out_channels, f_maps[0]] */
     const float *final_b; /* final_conv.bias or NULL */
     int32_t out_channels;
+    const float *final_packed_f16x3; /* vt_conv1x1_pack_f16x3(final_w) or NULL: the final conv runs in the last layer's epilogue */
+                                     /* where that layer is on the specialised-wave split-f16 kernel and both are 32 channels wide */
 } vt_unet3d_params;
 /* Split-bf16 form of vt_conv3d_pack / vt_conv3d_stat_blocks / vt_conv3d_gcr (same arguments): the 3x3x3 convolution  */
 /* as W_lo*x_hi + W_hi*x_lo + W_hi*x_hi on the bf16 matrix core with f32 accumulation (hi = bf16(v), lo = bf16(v - hi));  */
@@ -450,6 +452,14 @@ int vt_conv3d_gcr_f16x3(const float *skip, int C1, const float *low, int C2, int
 int vt_conv3d_gcr_f16x3_scaled(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                                const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
                                float *out_part, const float *in_absmax, void *stream);
+/* The last 'gcr' layer of the UNet3D together with final_conv (unet3d.py:470-474, a 1x1x1 conv 32 -> 32): relu(conv) stays in      */
+/* registers, is split into half pairs and multiplied by the packed final weight in the epilogue -- no intermediate tensor, no     */
+/* second launch.  Cout must be 32 and the shape one the specialised-wave kernel covers (VT_ERR_UNSUPPORTED otherwise).            */
+int vt_conv3d_final_fusable(int B, int D, int H, int W, int Cin, int Cout);   /* 1 where _final covers the layer */
+int vt_conv1x1_pack_f16x3(const float *w, int Cout, int Cin, float *packed /* 1024 floats */, void *stream);
+int vt_conv3d_gcr_f16x3_final(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                              const float *scale_shift, const float *packed_w_f16x3, int Cout,
+                              const float *final_packed_f16x3, const float *final_b, float *out, void *stream);
 size_t vt_unet3d_workspace_bytes(int B, int R, const vt_unet3d_params *params_host);
 int vt_unet3d_fwd(const float *x_cl, int B, int R, const vt_unet3d_params *params_host,
                   void *workspace, size_t workspace_bytes, float *out, void *stream);

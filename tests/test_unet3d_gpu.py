@@ -369,3 +369,35 @@ def test_split_unet3d_keeps_the_logit_bar_on_the_bench_scene():
         print(prec, "grid drift", gerr, "logit drift", lerr)
         assert 0.0 < lerr <= 1e-4, (prec, gerr, lerr)
         assert gerr <= 1e-4 * max(1.0, float(outs["f32"][0].abs().max()))
+
+
+def test_final_conv_in_the_last_layers_epilogue(monkeypatch):
+    """vt_conv3d_gcr_f16x3_final (the UNet3D's final 1x1x1 conv in the epilogue of its last 'gcr' layer) against the two launches
+    it replaces -- directly on one layer, and through vt_unet3d_fwd at the shipped shape (the env knob turns the fusion off)."""
+    from vtaco_amd import _lib, ops
+    from vtaco_amd.bench_util import build_scene
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(51)
+    for B, R in ((1, 64), (2, 32)):
+        x = torch.randn(B, R, R, R, 32, generator=g).to(DEV)
+        w = (torch.randn(32, 32, 3, 3, 3, generator=g) * 0.05).to(DEV)
+        fw, fb = (torch.randn(32, 32, generator=g) * 0.2).to(DEV), torch.randn(32, generator=g).to(DEV)
+        gamma, beta = (1 + 0.2 * torch.randn(32, generator=g)).to(DEV), (0.2 * torch.randn(32, generator=g)).to(DEV)
+        ss = ops.gn_scale_shift(ops.channel_stats(x), None, 32, 0, B, R ** 3, gamma, beta, 8, 1e-5, DEV)
+        ph = ops.conv3d_pack(w, precision="f16x3")
+        y, _ = ops.conv3d_gcr(x, None, ss, ops.conv3d_pack(w), 32, True, packed_w_f16x3=ph)
+        ref = ops.conv1x1_cl(y, fw, fb)
+        out = torch.empty_like(ref)
+        pf = ops.conv1x1_pack_f16x3(fw)
+        _lib.check(lib.vt_conv3d_gcr_f16x3_final(x.data_ptr(), 32, None, 0, B, R, R, R, ss.data_ptr(), ph.data_ptr(), 32, pf.data_ptr(),
+                                                 fb.data_ptr(), out.data_ptr(), ops.stream_ptr()), "vt_conv3d_gcr_f16x3_final")
+        err = float((out - ref).abs().max())
+        assert err <= 2e-6 * max(1.0, float(ref.abs().max())), (B, R, err)
+    sc = build_scene(0, DEV)
+    enc, pc = sc["model"].encoder, sc["cloud"].to(DEV)
+    with torch.no_grad():
+        monkeypatch.setenv("VTACO_UNET_FUSED_FINAL", "0")
+        ref = enc(pc)["grid"]
+        monkeypatch.setenv("VTACO_UNET_FUSED_FINAL", "1")
+        got = enc(pc)["grid"]
+    assert float((got - ref).abs().max()) <= 5e-6 * float(ref.abs().max()) and not torch.equal(got, ref)

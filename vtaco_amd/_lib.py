@@ -69,7 +69,8 @@ class UnetParams(ctypes.Structure):
     """Mirror of ``vt_unet3d_params``."""
     _fields_ = [("n_levels", ctypes.c_int32), ("groups", ctypes.c_int32), ("eps", ctypes.c_double),
                 ("enc", (UnetConv * 2) * VT_UNET_MAX_LEVELS), ("dec", (UnetConv * 2) * VT_UNET_MAX_LEVELS),
-                ("final_w", ctypes.c_void_p), ("final_b", ctypes.c_void_p), ("out_channels", ctypes.c_int32)]
+                ("final_w", ctypes.c_void_p), ("final_b", ctypes.c_void_p), ("out_channels", ctypes.c_int32),
+                ("final_packed_f16x3", ctypes.c_void_p)]
 
 
 # name -> (restype, argtypes); kept in step with include/vtaco_hip.h (tests/test_abi.py
@@ -156,6 +157,9 @@ SIGNATURES = {
     "vt_conv3d_stat_blocks_f16x3": (_I, [_I, _I, _I, _I, _I, _I]),
     "vt_conv3d_gcr_f16x3": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),
     "vt_conv3d_gcr_f16x3_scaled": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP]),
+    "vt_conv3d_final_fusable": (_I, [_I, _I, _I, _I, _I, _I]),
+    "vt_conv1x1_pack_f16x3": (_I, [_VP, _I, _I, _VP, _VP]),
+    "vt_conv3d_gcr_f16x3_final": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "vt_conv3d_stat_blocks_bf16x3": (_I, [_I, _I, _I, _I, _I, _I]),
     "vt_conv3d_gcr_bf16x3": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),
     "vt_conv3d_ksplit_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),

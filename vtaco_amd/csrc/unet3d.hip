@@ -840,6 +840,11 @@ struct HbArgs {
     const float *in_absmax;     // or null.  Device scalar max |input|: the input is multiplied by the power of two that brings
                                 // it to ~2^10 before the split (and the result divided by it), so that tensors far below the
                                 // half range -- output gradients in the data-gradient convolution -- keep all their bits
+    // the UNet3D's final 1x1x1 convolution in the epilogue of its last 3x3x3 layer (Cout = 32 -> 32 channels, specialised-wave kernel
+    // only): relu(conv) stays in registers, is split into half pairs -- the accumulator layout is the next MFMA's B operand, as
+    // between the decoder's layers -- and six MFMAs against fin_w (vt_conv1x1_pack_f16x3) + fin_b give what is stored
+    const float *fin_w = nullptr;
+    const float *fin_b = nullptr;
 };
 
 template <int TZ>
@@ -1097,7 +1102,9 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int TZ>
+// FIN: the variant with the final 1x1x1 conv in the epilogue (its own instantiation: the extra registers must not cost the other
+// layers their fourth wave per SIMD)
+template <int TZ, bool FIN = false>
 __global__ void __launch_bounds__(hb_threads(TZ))
 conv3d_gcr_hw_kernel(HbArgs ha) {
     constexpr int ROWS = hb_rows(TZ), NVOX = hb_nvox(TZ), THREADS = hb_threads(TZ), LTHREADS = 64 * TZ;
@@ -1358,6 +1365,15 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
                         for (int r = 0; r < 16; ++r) v[r] *= post_scale;
                     }
                     if (a.relu) v = relu16(v);
+                    if (FIN) {                                      // the final 1x1x1 conv on the registers; no statistics: nothing reads them
+                        const SplitP<2> xs = split16<false, 2>(v);
+                        f32x16 o;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[r] = ha.fin_b ? ha.fin_b[chan_of(r, kg)] : 0.0f;
+                        o = dense32s<2>(o, ha.fin_w, xs, lane);
+                        store_acc16(orow, o, kg);
+                        continue;
+                    }
                     store_acc16(orow + co_blk * 32, v, kg);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {                  // the two patches' contributions per lane first: ONE lane reduction per tile
@@ -1365,7 +1381,7 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
                         ssq[r] = pch ? fmaf(v[r], v[r], ssq[r]) : v[r] * v[r];
                     }
                 }
-                if (a.part) {
+                if (a.part && !FIN) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float sm = half_wave_sum(ssum[r]), sq = half_wave_sum(ssq[r]);
@@ -1848,11 +1864,68 @@ int vt_conv3d_gcr_f16x3(const float *skip, int C1, const float *low, int C2, int
     return vt_conv3d_gcr_f16x3_scaled(skip, C1, low, C2, B, D, H, W, scale_shift, packed_w_f16x3, Cout, relu, out, out_part, nullptr, stream);
 }
 
+// is the specialised-wave kernel the one vt_conv3d_gcr_f16x3 launches for this shape?  (the final-conv epilogue lives there only)
+static bool conv_h_specialised(int tz) {
+    static const bool spec = !(getenv("VTACO_CONV_SPEC") && getenv("VTACO_CONV_SPEC")[0] == '0');
+    return spec && tz != 0 && tz != 2;
+}
+
+static int conv_h_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                         const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
+                         float *out_part, const float *in_absmax, const float *fin_w, const float *fin_b, void *stream);
+
 int vt_conv3d_gcr_f16x3_scaled(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                                const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
                                float *out_part, const float *in_absmax, void *stream) {
+    return conv_h_launch(skip, C1, low, C2, B, D, H, W, scale_shift, packed_w_f16x3, Cout, relu, out, out_part, in_absmax, nullptr, nullptr, stream);
+}
+
+// does vt_conv3d_gcr_f16x3_final cover this layer?  (32 output channels, a shape of the specialised-wave kernel)
+int vt_conv3d_final_fusable(int B, int D, int H, int W, int Cin, int Cout) {
+    return Cout == 32 && conv_h_specialised(conv_h_tz(B, D, H, W, Cin, Cout)) ? 1 : 0;
+}
+
+// out[v][o] = fin_b[o] + sum_c fin_w[o][c] relu(conv(...))[v][c]: the last 'gcr' layer and the final 1x1x1 conv (32 -> 32) in one launch
+int vt_conv3d_gcr_f16x3_final(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                              const float *scale_shift, const float *packed_w_f16x3, int Cout,
+                              const float *final_packed_f16x3, const float *final_b, float *out, void *stream) {
+    if (!final_packed_f16x3) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr_f16x3_final: null argument");
+    if (Cout != 32 || !conv_h_specialised(conv_h_tz(B, D, H, W, C1 + (low ? C2 : 0), Cout)))
+        return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr_f16x3_final: needs Cout = 32 and a shape of the specialised-wave kernel; use vt_conv3d_gcr_f16x3 + vt_conv1x1_cl");
+    return conv_h_launch(skip, C1, low, C2, B, D, H, W, scale_shift, packed_w_f16x3, Cout, 1, out, nullptr, nullptr, final_packed_f16x3, final_b, stream);
+}
+
+// w [32][32] (out, in) -> the A-operand fragments of dense32s<2>: [part: hi, lo][k-step 0, 1][64 lanes][8 halves], lane = (out row,
+// k-group), element e of k-step s = input channel chan_of(8 s + e, k-group) -- the channel that register 8 s + e of the 3x3x3
+// layer's accumulator holds in that half of the wave
+__global__ void conv1x1_pack_h_kernel(const float *w, float *packed) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;            // fragment: part * 128 + s * 64 + lane
+    if (f >= 256) return;
+    const int l = f & 63, s = (f >> 6) & 1, part = f >> 7;
+    const int o = l & 31, kg = l >> 5;
+    f16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = w[o * 32 + chan_of(8 * s + e, kg)];
+        const _Float16 h = (_Float16)x;
+        v[e] = part ? (_Float16)(x - (float)h) : h;
+    }
+    reinterpret_cast<f16x8 *>(packed)[f] = v;
+}
+
+int vt_conv1x1_pack_f16x3(const float *w, int Cout, int Cin, float *packed, void *stream) {
+    if (!w || !packed) return vt_fail(VT_ERR_INVALID, "vt_conv1x1_pack_f16x3: null argument");
+    if (Cout != 32 || Cin != 32) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv1x1_pack_f16x3: the fused final conv is built for 32 -> 32 channels");
+    hipLaunchKernelGGL(conv1x1_pack_h_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w, packed);
+    return vt_check(hipGetLastError(), "vt_conv1x1_pack_f16x3");
+}
+
+static int conv_h_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                         const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
+                         float *out_part, const float *in_absmax, const float *fin_w, const float *fin_b, void *stream) {
     HbArgs ha;
     ha.in_absmax = in_absmax;
+    ha.fin_w = fin_w; ha.fin_b = fin_b;
     ConvArgs &a = ha.c;
     a.s = Src{skip, low, C1, low ? C2 : 0, D, H, W};
     if (!src_ok(a.s, B) || !packed_w_f16x3 || !out) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr_f16x3: bad argument");
@@ -1871,14 +1944,26 @@ int vt_conv3d_gcr_f16x3_scaled(const float *skip, int C1, const float *low, int 
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3: hipFuncSetAttribute");
         attr = true;
     }
-    static const bool spec = !(getenv("VTACO_CONV_SPEC") && getenv("VTACO_CONV_SPEC")[0] == '0');   // specialised tap / loader waves (0: the uniform-wave kernel)
-    if (spec && tz != 2) {
+    if (fin_w && !conv_h_specialised(tz)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr_f16x3_final: shape not on the specialised-wave kernel");
+    if (conv_h_specialised(tz)) {                                  // specialised tap / loader waves (VTACO_CONV_SPEC=0: the uniform-wave kernel)
         static bool attr_w = false;
         if (!attr_w) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(8));
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(4));
             if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3: hipFuncSetAttribute");
             attr_w = true;
+        }
+        if (fin_w) {
+            static bool attr_f = false;
+            if (!attr_f) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(8));
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(4));
+                if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3_final: hipFuncSetAttribute");
+                attr_f = true;
+            }
+            if (tz == 8) hipLaunchKernelGGL((conv3d_gcr_hw_kernel<8, true>), grid, dim3(hb_threads(8)), hb_lds(8), (hipStream_t)stream, ha);
+            else hipLaunchKernelGGL((conv3d_gcr_hw_kernel<4, true>), grid, dim3(hb_threads(4)), hb_lds(4), (hipStream_t)stream, ha);
+            return vt_check(hipGetLastError(), "vt_conv3d_gcr_f16x3_final");
         }
         if (tz == 8) hipLaunchKernelGGL(conv3d_gcr_hw_kernel<8>, grid, dim3(hb_threads(8)), hb_lds(8), (hipStream_t)stream, ha);
         else hipLaunchKernelGGL(conv3d_gcr_hw_kernel<4>, grid, dim3(hb_threads(4)), hb_lds(4), (hipStream_t)stream, ha);
@@ -2014,7 +2099,17 @@ int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char 
         const int lvl = L - 2 - k, Ri = R >> lvl;
         Tensor t1, t2;
         if ((rc = gcr(p->dec[k][0], skips[lvl], &cur, Ri, t1))) return rc;
-        if ((rc = gcr(p->dec[k][1], t1, nullptr, Ri, t2))) return rc;
+        const vt_unet3d_conv &last = p->dec[k][1];
+        if (k + 2 == L && p->final_packed_f16x3 && last.packed_f16x3 && p->out_channels == 32 &&
+            vt_conv3d_final_fusable(B, Ri, Ri, Ri, last.cin, last.cout)) {
+            // the last 'gcr' layer with the final 1x1x1 conv in its epilogue: one launch and a 67 MB round trip less
+            if (ws_need) *ws_need = ws.off;
+            if (plan) return 0;
+            const int groups = (last.cin >= p->groups) ? p->groups : 1;
+            if ((rc = vt_gn_scale_shift(t1.part, t1.nblk, t1.C, nullptr, 0, 0, B, (int64_t)Ri * Ri * Ri, groups, last.gn_w, last.gn_b, p->eps, ss, st))) return rc;
+            return vt_conv3d_gcr_f16x3_final(t1.x, t1.C, nullptr, 0, B, Ri, Ri, Ri, ss, last.packed_f16x3, last.cout, p->final_packed_f16x3, p->final_b, out, st);
+        }
+        if ((rc = gcr(last, t1, nullptr, Ri, t2))) return rc;
         cur = t2;
     }
     if (ws_need) *ws_need = ws.off;

@@ -241,7 +241,26 @@ class UNet3D(nn.Module):
             keep.append(fb)
             prm.final_b = fb.data_ptr()
         prm.out_channels = self.final_conv.out_channels
+        fp = self._final_packed()
+        if fp is not None:
+            keep.append(fp)
+            prm.final_packed_f16x3 = fp.data_ptr()
         return prm, keep
+
+    def _final_packed(self):
+        """The final 1x1x1 conv's weight packed for the epilogue of the last 'gcr' layer (used where that layer runs on the
+        specialised-wave split-f16 kernel; VTACO_UNET_FUSED_FINAL=0 keeps the separate launch), re-packed when it changes; None
+        when the fusion does not apply."""
+        w = self.final_conv.weight
+        if self.precision != "f16x3" or tuple(w.shape[:2]) != (32, 32) or os.environ.get("VTACO_UNET_FUSED_FINAL", "1") == "0":
+            return None
+        key = ("final", "f16x3")
+        stamp = (w.data_ptr(), w._version)
+        hit = self._pack_cache.get(key)
+        if hit is None or hit[0] != stamp:
+            hit = (stamp, ops.conv1x1_pack_f16x3(w.detach().reshape(32, 32)))
+            self._pack_cache[key] = hit
+        return hit[1]
 
     def forward_channels_last(self, x, in_stats=None):
         """x [B,D,H,W,C] channels-last -> [B,D,H,W,out_channels]; inference only (no autograd).
@@ -271,11 +290,23 @@ class UNet3D(nn.Module):
             x, st = self._gcr(enc.basic_module.SingleConv1, x, st)
             x, st = self._gcr(enc.basic_module.SingleConv2, x, st)
             skips.append((x, st))
-        for dec, (skip, skip_st) in zip(self.decoders, skips[-2::-1]):
+        fused_final = self._final_packed()
+        for k, (dec, (skip, skip_st)) in enumerate(zip(self.decoders, skips[-2::-1])):
             x, st = self._gcr(dec.basic_module.SingleConv1, skip, skip_st, low=x, low_stats=st)
-            x, st = self._gcr(dec.basic_module.SingleConv2, x, st)
-        x = ops.conv1x1_cl(x, self.final_conv.weight.detach(), self.final_conv.bias.detach()
-                           if self.final_conv.bias is not None else None)
+            last = dec.basic_module.SingleConv2
+            if (k + 1 == len(self.decoders) and fused_final is not None and self.final_conv.out_channels == 32
+                    and ops.final_fusable(x, last.conv.out_channels)):
+                # as vt_unet3d_fwd: the final 1x1x1 conv in the last layer's epilogue
+                gn = last.groupnorm
+                ss = ops.gn_scale_shift(st, None, x.shape[-1], 0, x.shape[0], x.shape[1] * x.shape[2] * x.shape[3], gn.weight.detach(),
+                                        gn.bias.detach(), gn.num_groups, gn.eps, x.device)
+                x = ops.conv3d_gcr_final(x, ss, self._packed(last.conv, "f16x3"), fused_final,
+                                         self.final_conv.bias.detach().contiguous() if self.final_conv.bias is not None else None)
+                break
+            x, st = self._gcr(last, x, st)
+        else:
+            x = ops.conv1x1_cl(x, self.final_conv.weight.detach(), self.final_conv.bias.detach()
+                               if self.final_conv.bias is not None else None)
         if self.testing and self.final_activation is not None:
             x = self.final_activation(x) if isinstance(self.final_activation, nn.Sigmoid) else torch.softmax(x, dim=-1)
         return x

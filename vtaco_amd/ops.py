@@ -862,6 +862,33 @@ def conv3d_pack(weight, precision="f32"):
     return out
 
 
+def conv3d_gcr_final(x, ss, packed_w_f16x3, final_packed, final_bias):
+    """relu(conv3x3x3(x * scale + shift)) followed by the final 1x1x1 conv (32 -> 32) in the same launch
+    (vt_conv3d_gcr_f16x3_final); check ``final_fusable`` first."""
+    B, D, H, W, C1 = x.shape
+    out = torch.empty((B, D, H, W, 32), dtype=torch.float32, device=x.device)
+    check(_lib.load().vt_conv3d_gcr_f16x3_final(dev_ptr(x, "x"), C1, None, 0, B, D, H, W, dev_ptr(ss, "scale_shift"),
+                                                dev_ptr(packed_w_f16x3, "packed_w"), 32, dev_ptr(final_packed, "final_packed"),
+                                                dev_ptr(final_bias, "final_bias"), dev_ptr(out, "out"), stream_ptr()),
+          "vt_conv3d_gcr_f16x3_final")
+    return out
+
+
+def final_fusable(x, Cout):
+    B, D, H, W, C1 = x.shape
+    return bool(_lib.load().vt_conv3d_final_fusable(B, D, H, W, C1, Cout))
+
+
+def conv1x1_pack_f16x3(weight):
+    """Split-half A-operand fragments of a [32,32(,1,1,1)] final conv weight (vt_conv1x1_pack_f16x3), for the fused epilogue of
+    vt_conv3d_gcr_f16x3_final."""
+    w = _c(weight).reshape(weight.shape[0], -1)
+    out = torch.empty(1024, dtype=torch.float32, device=w.device)
+    check(_lib.load().vt_conv1x1_pack_f16x3(dev_ptr(w, "w"), w.shape[0], w.shape[1], dev_ptr(out, "packed"), stream_ptr()),
+          "vt_conv1x1_pack_f16x3")
+    return out
+
+
 def channel_stats(x):
     """Per-block partial (sum, sumsq) of a channels-last tensor: (part, nblk)."""
     B, D, H, W, C = x.shape
