@@ -59,6 +59,12 @@ def launch_ranks(n, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    if env.get("VTACO_BENCH_BACKEND", "nccl") == "nccl" and "--dry-run" not in argv:
+        import torch                                   # (device_count() does not initialise the GPU on this image)
+        have = torch.cuda.device_count()
+        if 0 < have < n:
+            sys.exit(f"bench.py: --gpus {n} needs {n} visible GPUs, this node shows {have} (RCCL refuses ranks that share a device; "
+                     "VTACO_BENCH_BACKEND=gloo dry-runs the multi-process path on fewer)")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
     proc = subprocess.run(cmd, env=env)
