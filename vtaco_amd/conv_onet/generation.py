@@ -154,12 +154,21 @@ class Generator3D(object):
         g["vol"], g["ws"] = g["out"]
         return g
 
+    def _graphs_allowed(self):
+        """Captured graphs are used in single-process runs only: with several ranks per node the launches stay eager -- two processes
+        replaying graphs on ONE device (the gloo dry-run of the multi-rank bench) took 180 ms per replay, and the one-process-per-GPU
+        case could not be measured on this pool (the encoder is then 1.0 instead of 0.7 ms per scene)."""
+        if not self.scene_graph:
+            return False
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
     def _replay(self, kind, tensors, run):
         """``run(*tensors)`` through a captured graph per (kind, shapes) when ``self.scene_graph`` is on: the result lives in the
         graph's static buffers (valid until the next replay of the same key).  Plain call otherwise."""
-        if not self.scene_graph:
+        if not self._graphs_allowed():
             with torch.no_grad():
-                return run(*tensors)
+                return run(*[t.to(self.device) for t in tensors])
         g = self._captured((kind,) + tuple(tuple(t.shape) for t in tensors), [t.shape for t in tensors], run)
         for dst, src in zip(g["in"], tensors):
             dst.copy_(src.to(self.device), non_blocking=True)
@@ -305,7 +314,7 @@ class Generator3D(object):
         inputs = data.get('inputs').to(self.device)
         if self.with_img and c_img_all is None:
             return self._generate_tactile(data)
-        if not self.with_img and self.scene_graph and inputs.dim() == 3 and inputs.shape[0] == 1:
+        if not self.with_img and self._graphs_allowed() and inputs.dim() == 3 and inputs.shape[0] == 1:
             # the visual branch: the same launches replayed as one hipGraph per (cloud shape, lattice) -- 1.1 instead of 1.5 ms
             return self.generate_mesh_graphed(inputs)
         with torch.no_grad():
