@@ -205,7 +205,25 @@ class UNet3D(nn.Module):
                                   packed_w_f16x3=half)
 
     def _hip_params(self):
-        """vt_unet3d_params for the current weights (re-packed only when a conv weight changed)."""
+        """vt_unet3d_params for the current weights (re-packed only when a conv weight changed); the filled structure itself is
+        kept while no parameter changed (stamps of the ~45 tensors: 15 us instead of 70 us of packing-cache lookups per encode)."""
+        from .. import _lib
+        tensors = getattr(self, "_prm_tensors", None)
+        if tensors is None or tensors[0] is not self.final_conv.weight:
+            tensors = self._prm_tensors = [self.final_conv.weight, self.final_conv.bias] + [
+                t for blk in list(self.encoders) + list(self.decoders)
+                for single in (blk.basic_module.SingleConv1, blk.basic_module.SingleConv2)
+                for t in (single.groupnorm.weight, single.groupnorm.bias, single.conv.weight)]
+        stamp = (self.precision, os.environ.get("VTACO_UNET_FUSED_FINAL", "1")) + tuple(
+            (id(t), t.data_ptr(), t._version) for t in tensors if t is not None)
+        hit = getattr(self, "_prm_cache", None)
+        if hit is not None and hit[0] == stamp:
+            return hit[1], hit[2]
+        prm, keep = self._build_hip_params()
+        self._prm_cache = (stamp, prm, keep)
+        return prm, keep
+
+    def _build_hip_params(self):
         from .. import _lib
         prm = _lib.UnetParams()
         keep = []
