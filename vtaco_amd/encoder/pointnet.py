@@ -224,6 +224,16 @@ class LocalPoolPointnet(nn.Module):
         cout, cin = lin.weight.shape
         return cout <= 256 and (cin * (cout | 1) + max(1, 256 // cout) * cin) * 4 <= 64 * 1024
 
+    def _fused_weights(self):
+        """The one-launch kernel's weight pointers, gathered again only when a parameter changed its storage (29 tensors)."""
+        ts = [self.fc_pos.weight, self.fc_pos.bias, self.fc_c.weight, self.fc_c.bias] + [
+            t for b in self.blocks for t in (b.fc_0.weight, b.fc_0.bias, b.fc_1.weight, b.fc_1.bias, b.shortcut.weight)]
+        stamp = tuple((id(t), t.data_ptr()) for t in ts)
+        hit = getattr(self, "_fused_w", None)
+        if hit is None or hit[0] != stamp:
+            hit = self._fused_w = (stamp, ops.pointnet_mlp_weights(self.fc_pos, self.blocks, self.fc_c))
+        return hit[1]
+
     def _one_launch_fits(self, vi):
         """vt_pointnet_mlp_fused: one voxel index (the object grid; the hand encoder sums three planes' pools), the shipped widths
         (hidden 32, five blocks with shortcut layers, c_dim <= 64).  VTACO_POINTNET_ONE_LAUNCH=0: the launch-per-layer path."""
@@ -238,7 +248,7 @@ class LocalPoolPointnet(nn.Module):
         """The same layers without autograd: one HIP launch per linear layer / ResnetBlockFC (vt_linear_rows,
         vt_resblock_fc, the concat with the pooled features read in place) instead of ~9 framework launches per block."""
         if self._one_launch_fits(vi):
-            return ops.pointnet_mlp_fused(p, vi, self.fc_pos, self.blocks, self.fc_c)
+            return ops.pointnet_mlp_fused(p, vi, self.fc_pos, self.blocks, self.fc_c, weights=self._fused_weights())
         lin = lambda l, x: ops.linear_rows(x, l.weight, l.bias) if self._linear_fits(l) else l(x)
         net = lin(self.fc_pos, p)
         b0 = self.blocks[0]
@@ -291,7 +301,8 @@ class LocalPoolPointnet(nn.Module):
         if (self.unet3d is not None and not torch.is_grad_enabled() and self.unet3d.hip_supported() and self._fused_mlp_fits()
                 and self._one_launch_fits(vi) and self.unet3d.encoders[0].basic_module.SingleConv1.conv.in_channels == self.c_dim):
             # inference: the per-point MLP, the voxeliser's mean and the grid's GroupNorm statistics from one launch, then the UNet3D
-            grid, stats = ops.pointnet_mlp_fused(p.float(), vi, self.fc_pos, self.blocks, self.fc_c, want_grid=True)
+            grid, stats = ops.pointnet_mlp_fused(p.float(), vi, self.fc_pos, self.blocks, self.fc_c, want_grid=True,
+                                                 weights=self._fused_weights())
             return {'grid': self.unet3d.forward_channels_last(grid, in_stats=stats).permute(0, 4, 1, 2, 3)}
         feat = self.point_features(p.float(), vi)
         if self.unet3d is not None and not torch.is_grad_enabled() and self.unet3d.hip_supported():

@@ -540,7 +540,17 @@ def mano_fwd(pose, blob, center_idx=9):
     return verts, joints
 
 
-def pointnet_mlp_fused(p, vi, fc_pos, blocks, fc_c, want_grid=False):
+def pointnet_mlp_weights(fc_pos, blocks, fc_c):
+    """The weight pointers vt_pointnet_mlp_fused takes, gathered once: (ctypes pointer array of the 25 block tensors, those tensors,
+    [fc_pos.weight, fc_pos.bias, fc_c.weight, fc_c.bias]); valid while the parameters keep their storage."""
+    ws = []
+    for blk in blocks:
+        ws += [_c(blk.fc_0.weight), _c(blk.fc_0.bias), _c(blk.fc_1.weight), _c(blk.fc_1.bias), _c(blk.shortcut.weight)]
+    ptrs = (ctypes.c_void_p * len(ws))(*[t.data_ptr() for t in ws])
+    return ptrs, ws, [_c(fc_pos.weight), _c(fc_pos.bias), _c(fc_c.weight), _c(fc_c.bias)]
+
+
+def pointnet_mlp_fused(p, vi, fc_pos, blocks, fc_c, want_grid=False, weights=None):
     """fc_pos -> block 0 -> 4 x (pool over the point's cell, concat, block) -> fc_c for one voxel index in ONE launch
     (vt_pointnet_mlp_fused; inference): [B,T,c_dim], bit-identical to the launch-per-layer path.  ``want_grid``: instead of the
     point features, the voxeliser's channels-last mean grid [B,R,R,R,c_dim] and its GroupNorm partial sums (part, nblk) from
@@ -548,10 +558,7 @@ def pointnet_mlp_fused(p, vi, fc_pos, blocks, fc_c, want_grid=False):
     p = _c(p.float())
     B, T, _ = p.shape
     c_dim = fc_c.weight.shape[0]
-    ws = []
-    for blk in blocks:
-        ws += [_c(blk.fc_0.weight), _c(blk.fc_0.bias), _c(blk.fc_1.weight), _c(blk.fc_1.bias), _c(blk.shortcut.weight)]
-    ptrs = (ctypes.c_void_p * len(ws))(*[t.data_ptr() for t in ws])
+    ptrs, ws, keep = weights if weights is not None else pointnet_mlp_weights(fc_pos, blocks, fc_c)
     lib = _lib.load()
     scratch = torch.empty((B, T, 32), dtype=torch.float32, device=p.device)
     out = grid = part = None
@@ -563,7 +570,6 @@ def pointnet_mlp_fused(p, vi, fc_pos, blocks, fc_c, want_grid=False):
         part = torch.empty((B, nblk, c_dim, 2), dtype=torch.float32, device=p.device)
     else:
         out = torch.empty((B, T, c_dim), dtype=torch.float32, device=p.device)
-    keep = [_c(fc_pos.weight), _c(fc_pos.bias), _c(fc_c.weight), _c(fc_c.bias)]
     check(lib.vt_pointnet_mlp_fused(dev_ptr(p, "p"), B, T, dev_ptr(vi.order, "order", I32), dev_ptr(vi.seg_lo, "seg_lo", I32),
                                     dev_ptr(vi.seg_hi, "seg_hi", I32), dev_ptr(keep[0], "fc_pos.weight"), dev_ptr(keep[1], "fc_pos.bias"),
                                     ptrs, 32, dev_ptr(keep[2], "fc_c.weight"), dev_ptr(keep[3], "fc_c.bias"), c_dim,
