@@ -170,8 +170,11 @@ def test_graphed_scene_equals_eager():
         assert torch.equal(default.faces, fast.faces) and torch.equal(default.vertices, fast.vertices) and len(gen._graphs) == 1
     if type(gen).scene_graph:                                       # (VTACO_SCENE_GRAPH=0 turns the default off)
         fresh = Generator3D(model, device=DEV, resolution0=8, padding=0.1)
-        fresh.generate_obj_mesh_wnf({"inputs": T(a["p"])[:1]})
-        assert len(fresh._graphs) == 1
+        first = fresh.generate_obj_mesh_wnf({"inputs": T(a["p"])[:1]})
+        assert not getattr(fresh, "_graphs", None)                   # a shape seen once runs on plain launches ...
+        second = fresh.generate_obj_mesh_wnf({"inputs": T(a["p"])[:1]})
+        assert len(fresh._graphs) == 1                               # ... and is captured when it comes back
+        assert torch.equal(first.faces, second.faces) and torch.equal(first.vertices, second.vertices)
 
 
 def test_graphed_scene_survives_weight_updates_and_other_shapes():

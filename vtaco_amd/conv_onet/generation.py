@@ -163,13 +163,27 @@ class Generator3D(object):
         import torch.distributed as dist
         return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
 
+    def _worth_capturing(self, key):
+        """A capture costs two warm-up runs and a recording (tens of milliseconds): a shape is captured when it comes back, not the
+        first time it is seen -- callers whose clouds all differ in size stay on plain launches instead of recording a graph per call."""
+        if key in getattr(self, "_graphs", {}):
+            return True
+        seen = self.__dict__.setdefault("_seen_shapes", {})
+        if key in seen:
+            return True
+        if len(seen) >= 64:
+            seen.pop(next(iter(seen)))
+        seen[key] = True
+        return False
+
     def _replay(self, kind, tensors, run):
         """``run(*tensors)`` through a captured graph per (kind, shapes) when ``self.scene_graph`` is on: the result lives in the
         graph's static buffers (valid until the next replay of the same key).  Plain call otherwise."""
-        if not self._graphs_allowed():
+        key = (kind,) + tuple(tuple(t.shape) for t in tensors)
+        if not self._graphs_allowed() or not self._worth_capturing(key):
             with torch.no_grad():
                 return run(*[t.to(self.device) for t in tensors])
-        g = self._captured((kind,) + tuple(tuple(t.shape) for t in tensors), [t.shape for t in tensors], run)
+        g = self._captured(key, [t.shape for t in tensors], run)
         for dst, src in zip(g["in"], tensors):
             dst.copy_(src.to(self.device), non_blocking=True)
         g["graph"].replay()
@@ -314,7 +328,8 @@ class Generator3D(object):
         inputs = data.get('inputs').to(self.device)
         if self.with_img and c_img_all is None:
             return self._generate_tactile(data)
-        if not self.with_img and self._graphs_allowed() and inputs.dim() == 3 and inputs.shape[0] == 1:
+        if (not self.with_img and self._graphs_allowed() and inputs.dim() == 3 and inputs.shape[0] == 1
+                and self._worth_capturing((tuple(inputs.shape), nx, self.decode_precision))):
             # the visual branch: the same launches replayed as one hipGraph per (cloud shape, lattice) -- 1.1 instead of 1.5 ms
             return self.generate_mesh_graphed(inputs)
         with torch.no_grad():
