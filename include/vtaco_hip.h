@@ -315,7 +315,7 @@ int vt_mc_count(const float *vol, int n0, int n1, int n2, double level, int auto
 int vt_mc_read_counts(const void *workspace, int *nverts_host, int *nfaces_host, double *level_host, void *stream);
 /* the same read in two halves: _begin queues the copy (page-locked slot, an event right behind it) and returns a token; _end      */
 /* waits for that event only -- launches made between the two (the speculative vt_mc_emit) run under the wait instead of in front  */
-/* of it.  Sixteen tokens may be outstanding.                                                                                     */
+/* of it.  Sixteen tokens may be outstanding; a seventeenth _begin fails (VT_ERR_INVALID), _end spends its token.                 */
 int vt_mc_read_counts_begin(const void *workspace, void *stream, int *token);
 int vt_mc_read_counts_end(int token, int *nverts_host, int *nfaces_host, double *level_host);
 int vt_mc_emit(const float *vol, int n0, int n1, int n2, void *workspace,

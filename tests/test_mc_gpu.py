@@ -95,3 +95,30 @@ def test_speculative_emit_small_large_small_surface():
         v, f, _ = run(vol, 0.0)
         assert np.array_equal(f, rf) and v.shape == rv.shape and np.abs(v - rv).max() <= 1e-5
     assert (0, n, n, n) in ops._mc_guess or (torch.cuda.current_device(), n, n, n) in ops._mc_guess
+
+
+def test_read_back_tokens_are_counted():
+    """vt_mc_read_counts_begin hands out sixteen page-locked slots: a seventeenth outstanding read-back is refused instead of
+    overwriting one that is still waited for, a spent token is refused, and every slot comes back into use."""
+    import ctypes
+    from vtaco_amd import _lib, ops
+    lib = _lib.load()
+    vol = torch.randn(12, 12, 12, device=DEV)
+    ws = ops.mc_count(vol, 0.0)
+    wp, st = ctypes.c_void_p(ws.data_ptr()), ops.stream_ptr()
+    want = ops.marching_cubes(vol, 0.0)
+    toks = []
+    for _ in range(16):
+        t = ctypes.c_int(-1)
+        assert lib.vt_mc_read_counts_begin(wp, st, ctypes.byref(t)) == 0
+        toks.append(t.value)
+    assert sorted(toks) == list(range(16))
+    t = ctypes.c_int(-1)
+    assert lib.vt_mc_read_counts_begin(wp, st, ctypes.byref(t)) != 0 and b"in flight" in lib.vt_last_error()
+    nv, nf, lvl = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+    for k in toks:
+        assert lib.vt_mc_read_counts_end(k, ctypes.byref(nv), ctypes.byref(nf), ctypes.byref(lvl)) == 0
+        assert (nv.value, nf.value) == (want[0].shape[0], want[1].shape[0])
+    assert lib.vt_mc_read_counts_end(toks[3], ctypes.byref(nv), ctypes.byref(nf), ctypes.byref(lvl)) != 0
+    got = ops.marching_cubes(vol, 0.0)                  # the ring is whole again
+    assert torch.equal(got[1], want[1])

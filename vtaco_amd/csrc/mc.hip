@@ -762,40 +762,60 @@ int vt_mc_read_counts(const void *workspace, int *nverts_host, int *nfaces_host,
 // vertex / face kernels of a marching-cubes call) and returns the counts.  A ring of 16 slots; a token is valid for one _end.
 namespace {
 constexpr int MC_SLOTS = 16;
-struct McSlot { McHeader *host; hipEvent_t ev; };
-McSlot mc_slots[MC_SLOTS];
-bool mc_slots_ready = false;
-std::atomic<unsigned> mc_slot_next{0};
-std::mutex mc_slots_mutex;                              // guards the one-time creation of the slots
+struct McSlot { McHeader *host; hipEvent_t ev; bool made, busy; };
+McSlot mc_slots[MC_SLOTS];                              // zero-initialised: nothing made, nothing busy
+unsigned mc_slot_next = 0;
+std::mutex mc_slots_mutex;                              // guards the slots' creation and their busy flags
 }  // namespace
 
 int vt_mc_read_counts_begin(const void *workspace, void *stream, int *token) {
     if (!workspace || !token) return vt_fail(VT_ERR_INVALID, "vt_mc_read_counts_begin: null argument");
-    std::lock_guard<std::mutex> lock(mc_slots_mutex);
-    if (!mc_slots_ready) {
-        for (int i = 0; i < MC_SLOTS; ++i) {
-            hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&mc_slots[i].host), sizeof(McHeader), hipHostMallocDefault);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&mc_slots[i].ev, hipEventDisableTiming);
-            if (e != hipSuccess) return vt_check(e, "vt_mc_read_counts_begin: page-locked slot");
+    int t = -1;
+    {
+        std::lock_guard<std::mutex> lock(mc_slots_mutex);
+        for (int i = 0; i < MC_SLOTS && t < 0; ++i) {       // the next slot no read-back is waiting in
+            const int c = (int)((mc_slot_next + i) % MC_SLOTS);
+            if (!mc_slots[c].busy) t = c;
         }
-        mc_slots_ready = true;
+        if (t < 0) return vt_fail(VT_ERR_INVALID, "vt_mc_read_counts_begin: 16 read-backs are already in flight (call vt_mc_read_counts_end)");
+        McSlot &sl = mc_slots[t];
+        if (!sl.made) {
+            hipError_t e = sl.host ? hipSuccess : hipHostMalloc(reinterpret_cast<void **>(&sl.host), sizeof(McHeader), hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming);
+            if (e != hipSuccess) return vt_check(e, "vt_mc_read_counts_begin: page-locked slot");
+            sl.made = true;
+        }
+        sl.busy = true;
+        mc_slot_next = (unsigned)t + 1;
     }
-    const int t = (int)(mc_slot_next.fetch_add(1) % MC_SLOTS);
     hipError_t e = hipMemcpyAsync(mc_slots[t].host, workspace, sizeof(McHeader), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipEventRecord(mc_slots[t].ev, (hipStream_t)stream);
-    if (e != hipSuccess) return vt_check(e, "vt_mc_read_counts_begin");
+    if (e != hipSuccess) {
+        std::lock_guard<std::mutex> lock(mc_slots_mutex);
+        mc_slots[t].busy = false;
+        return vt_check(e, "vt_mc_read_counts_begin");
+    }
     *token = t;
     return 0;
 }
 
 int vt_mc_read_counts_end(int token, int *nverts_host, int *nfaces_host, double *level_host) {
-    if (token < 0 || token >= MC_SLOTS || !mc_slots_ready || !nverts_host || !nfaces_host)
+    if (token < 0 || token >= MC_SLOTS || !nverts_host || !nfaces_host)
         return vt_fail(VT_ERR_INVALID, "vt_mc_read_counts_end: bad token or null argument");
+    {
+        std::lock_guard<std::mutex> lock(mc_slots_mutex);
+        if (!mc_slots[token].busy) return vt_fail(VT_ERR_INVALID, "vt_mc_read_counts_end: no read-back is in flight under this token");
+    }
     const hipError_t e = hipEventSynchronize(mc_slots[token].ev);
-    if (e != hipSuccess) return vt_check(e, "vt_mc_read_counts_end");
-    *nverts_host = mc_slots[token].host->nverts; *nfaces_host = mc_slots[token].host->nfaces;
-    if (level_host) *level_host = mc_slots[token].host->level;
-    return 0;
+    if (e == hipSuccess) {
+        *nverts_host = mc_slots[token].host->nverts; *nfaces_host = mc_slots[token].host->nfaces;
+        if (level_host) *level_host = mc_slots[token].host->level;
+    }
+    {
+        std::lock_guard<std::mutex> lock(mc_slots_mutex);
+        mc_slots[token].busy = false;                       // the token is spent either way
+    }
+    return e == hipSuccess ? 0 : vt_check(e, "vt_mc_read_counts_end");
 }
 
 int vt_mc_emit(const float *vol, int n0, int n1, int n2, void *workspace,

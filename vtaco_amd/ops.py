@@ -265,9 +265,12 @@ def mc_emit(vol, ws, rescale=None, capacity=None):
     # the speculative emit kernels run under that wait instead of in front of the copy
     tok = ctypes.c_int()
     check(lib.vt_mc_read_counts_begin(wp, st, ctypes.byref(tok)), "vt_mc_read_counts_begin")
-    spec = emit(*guess) if guess is not None else None
     nv, nf, lvl = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
-    check(lib.vt_mc_read_counts_end(tok.value, ctypes.byref(nv), ctypes.byref(nf), ctypes.byref(lvl)), "vt_mc_read_counts_end")
+    try:
+        spec = emit(*guess) if guess is not None else None
+    finally:                             # the token is handed back whatever the emit did (sixteen exist)
+        rc = lib.vt_mc_read_counts_end(tok.value, ctypes.byref(nv), ctypes.byref(nf), ctypes.byref(lvl))
+    check(rc, "vt_mc_read_counts_end")
     if nv.value == 0:
         raise RuntimeError("No surface found at the given iso value.")
     _mc_guess[key] = (nv.value + nv.value // 4 + 1024, nf.value + nf.value // 4 + 1024)
