@@ -152,7 +152,7 @@ def stage_times(scene, dec, grid, nx, out, dev, precision):
     return res
 
 
-PMC_SUMMARY = os.path.join("profiles", "r02e_pmc_summary.csv")
+PMC_SUMMARY = os.path.join("profiles", "r02f_pmc_summary.csv")
 
 
 def pmc_counters(precision):
