@@ -331,7 +331,9 @@ int vt_mc_emit(const float *vol, int n0, int n1, int n2, void *workspace,
 /*                                                                             */
 /* vt_voxel_build runs once per forward: idx[b,t] = ix + R*(iy + R*iz) (bit-exact */
 /* with the reference's f32 maths), order[b,j] = point ids sorted by (voxel,      */
-/* point), seg_lo/seg_hi[b,t] = the sorted range of t's voxel.  T <= 8192.        */
+/* point), seg_lo/seg_hi[b,t] = the sorted range of t's voxel.  Up to 8192 points  */
+/* per scene sort inside one workgroup's LDS (one launch); larger clouds take the  */
+/* same stable radix sort through global memory (2 + 3 launches per five id bits). */
 /* pool_max: out[b,t,c] = max_{t' in voxel(t)} feat[b,t',c], argmax = winning t'.  */
 /* scatter_mean: grid[b,c,z,y,x] (NCDHW, zero-filled inside) = per-voxel mean.     */
 /* All reductions run in ascending point order: bit-reproducible.                 */

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "vt_common.h"
 
@@ -126,6 +127,101 @@ voxel_build_kernel(const float *pts, int T, int nbits, int R, float divisor, flo
             }
         }
     }
+}
+
+// ---- more than MAX_T points per scene: the same stable LSD radix sort through global memory -------------------------------
+// Five bits per pass, a 64-element chunk per wave, the (digit, chunk) table scanned by one workgroup per scene.  The call's
+// outputs double as its scratch: `order` and `seg_lo` hold the two permutations in turn (the pass count decides which one
+// starts, so the last pass lands in `order`), `seg_hi` the table -- 32 * ceil(T/64) <= T entries.  Segment bounds by binary
+// search over the sorted ids (a cell of 10^5 points costs the same 2 x 17 probes per point as a cell of one).
+constexpr int GBITS = 5, GRADIX = 1 << GBITS;
+
+__global__ void __launch_bounds__(256)
+voxel_ids_kernel(const float *pts, int T, int R, float divisor, float clamp_hi, int a0, int a1, int a2, int *idx, int *perm) {
+    const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const float *p = pts + ((size_t)b * T + t) * 3;
+    const int ix = voxel_coord(p[a0], divisor, clamp_hi, R);
+    const int iy = voxel_coord(p[a1], divisor, clamp_hi, R);
+    const int iz = a2 >= 0 ? voxel_coord(p[a2], divisor, clamp_hi, R) : 0;
+    idx[(size_t)b * T + t] = ix + R * (iy + R * iz);
+    perm[(size_t)b * T + t] = t;
+}
+
+// every wave counts the digits of its chunk: lane d < 32 intersects the five bit ballots into the class of digit d
+__global__ void __launch_bounds__(256)
+gsort_count_kernel(const int *idx, const int *perm_in, int T, int nchunk, int shift, int *table) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (chunk >= nchunk) return;
+    const int i = chunk * 64 + lane;
+    const bool valid = i < T;
+    const unsigned d = valid ? ((unsigned)idx[(size_t)b * T + perm_in[(size_t)b * T + i]] >> shift) & (GRADIX - 1) : 0u;
+    unsigned long long cls = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < GBITS; ++bit) {
+        const unsigned long long ones = __ballot((d >> bit) & 1u);
+        cls &= ((lane >> bit) & 1) ? ones : ~ones;
+    }
+    if (lane < GRADIX) table[(size_t)b * T + (size_t)lane * nchunk + chunk] = __popcll(cls);
+}
+
+// exclusive scan of one scene's table in (digit, chunk) order: tiles of 1024 x 4 entries with a running carry
+__global__ void __launch_bounds__(1024)
+gsort_scan_kernel(int *table, int T, int n) {
+    __shared__ unsigned wave_tot[16];
+    __shared__ unsigned carry_s;
+    int *tb = table + (size_t)blockIdx.x * T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned carry = 0;
+    for (int base = 0; base < n; base += 4096) {
+        const int e0 = base + tid * 4;
+        unsigned v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = e0 + k < n ? (unsigned)tb[e0 + k] : 0u; sum += v[k]; }
+        unsigned incl = sum;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        unsigned pre = carry + incl - sum;
+        for (int w = 0; w < wave; ++w) pre += wave_tot[w];
+        if (tid == 1023) carry_s = pre + sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (e0 + k < n) tb[e0 + k] = (int)pre; pre += v[k]; }
+        __syncthreads();
+        carry = carry_s;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+gsort_scatter_kernel(const int *idx, const int *perm_in, int T, int nchunk, int shift, const int *table, int *perm_out) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (chunk >= nchunk) return;
+    const int i = chunk * 64 + lane;
+    const bool valid = i < T;
+    const int v = valid ? perm_in[(size_t)b * T + i] : 0;
+    const unsigned d = valid ? ((unsigned)idx[(size_t)b * T + v] >> shift) & (GRADIX - 1) : 0u;
+    unsigned long long same = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < GBITS; ++bit) {
+        const unsigned long long ones = __ballot((d >> bit) & 1u);
+        same &= ((d >> bit) & 1u) ? ones : ~ones;
+    }
+    const int rank = __popcll(same & ((1ull << lane) - 1ull));            // equal digits keep their order: stable
+    if (valid) perm_out[(size_t)b * T + table[(size_t)b * T + (size_t)d * nchunk + chunk] + rank] = v;
+}
+
+__global__ void __launch_bounds__(256)
+segment_bounds_kernel(const int *idx, const int *order, int T, int *seg_lo, int *seg_hi) {
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= T) return;
+    const int *ib = idx + (size_t)b * T, *ob = order + (size_t)b * T;
+    const int t = ob[j], id = ib[t];
+    int lo = 0, hi = j;                                                   // first position whose id is not below `id`
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (ib[ob[m]] < id) lo = m + 1; else hi = m; }
+    int lo2 = j + 1, hi2 = T;                                             // first position whose id is above `id`
+    while (lo2 < hi2) { const int m = (lo2 + hi2) >> 1; if (ib[ob[m]] <= id) lo2 = m + 1; else hi2 = m; }
+    seg_lo[(size_t)b * T + t] = lo;
+    seg_hi[(size_t)b * T + t] = lo2;
 }
 
 // The per-point kernels below use one thread per (point, channel): a 256-thread block covers
@@ -354,11 +450,27 @@ int build_launch(const char *who, const float *pts, int B, int T, int R, float d
     auto fail = [&](int code, const char *what) { snprintf(msg, sizeof msg, "%s: %s", who, what); return vt_fail(code, msg); };
     if (!pts || !idx || !order || !seg_lo || !seg_hi) return fail(VT_ERR_INVALID, "null argument");
     if (B <= 0 || T <= 0 || R < 1 || R > 1024) return fail(VT_ERR_INVALID, "bad size");
-    if (T > MAX_T) return fail(VT_ERR_UNSUPPORTED, "more than 8192 points per scene");
+    if ((unsigned long long)B * (unsigned long long)T > 0x7fffffffull) return fail(VT_ERR_UNSUPPORTED, "more than 2^31 points per call");
     // bits of the largest cell id
     unsigned long long cells = (unsigned long long)R * R * (a2 >= 0 ? (unsigned long long)R : 1ull);
     int nbits = 1;
     while (nbits < 32 && (1ull << nbits) < cells) ++nbits;
+    static const bool force_global = getenv("VTACO_VOXEL_GLOBAL_SORT") != nullptr;     // tests: the large-cloud path on small clouds
+    if (T > MAX_T || (force_global && T >= 64)) {
+        hipStream_t s = (hipStream_t)stream;
+        const int nchunk = (T + 63) / 64, passes = (nbits + GBITS - 1) / GBITS;
+        int *cur = (passes & 1) ? seg_lo : order, *oth = (passes & 1) ? order : seg_lo;   // an odd pass count ends in the other buffer
+        const dim3 pg((unsigned)((T + 255) / 256), (unsigned)B), cg((unsigned)((nchunk + 3) / 4), (unsigned)B);
+        hipLaunchKernelGGL(voxel_ids_kernel, pg, dim3(256), 0, s, pts, T, R, divisor, clamp_hi, a0, a1, a2, idx, cur);
+        for (int pass = 0; pass < passes; ++pass) {
+            hipLaunchKernelGGL(gsort_count_kernel, cg, dim3(256), 0, s, idx, cur, T, nchunk, pass * GBITS, seg_hi);
+            hipLaunchKernelGGL(gsort_scan_kernel, dim3(B), dim3(1024), 0, s, seg_hi, T, GRADIX * nchunk);
+            hipLaunchKernelGGL(gsort_scatter_kernel, cg, dim3(256), 0, s, idx, cur, T, nchunk, pass * GBITS, seg_hi, oth);
+            int *sw = cur; cur = oth; oth = sw;
+        }
+        hipLaunchKernelGGL(segment_bounds_kernel, pg, dim3(256), 0, s, idx, order, T, seg_lo, seg_hi);
+        return vt_check(hipGetLastError(), who);
+    }
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_build_kernel),
