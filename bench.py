@@ -29,6 +29,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -153,6 +154,7 @@ def stage_times(scene, dec, grid, nx, out, dev, precision):
 
 
 PMC_SUMMARY = os.path.join("profiles", "r02f_pmc_summary.csv")
+EXTRAS_LIMIT_S = 420            # the sections after the headline (sharded scene, training step, CPU baseline) take well under a minute
 
 
 def pmc_counters(precision):
@@ -512,23 +514,50 @@ def main():
         if world == 1 and not args.decode_only:
             res["mesh_extract"] = mesh_extract_stats(out.view(nx, nx, nx), nx)
             res["stages_ms"] = stage_times(scene, dec, grid, nx, out, dev, args.precision)
+    # The headline is measured; the sections below (sharded scene, training step: the multi-rank ones run collectives) must not be
+    # able to lose it: an exception is recorded in the line instead of ending the run, and a rank that is still waiting in a
+    # collective after EXTRAS_LIMIT_S (a peer failed) prints what it has and leaves.
+    printed = threading.Event()
+
+    def give_up():
+        if rank == 0 and not printed.is_set():
+            res["extras_error"] = f"the sections after the headline did not finish within {EXTRAS_LIMIT_S} s"
+            print(json.dumps(res), flush=True)
+        os._exit(0)
+    watchdog = threading.Timer(EXTRAS_LIMIT_S, give_up)
+    watchdog.daemon = True
+    watchdog.start()
     if not args.decode_only and args.mode == "visual":
-        if strong or world == 1:
-            one_scene = scene
-        else:
-            one_scene = build_scene(0, dev)                          # every rank the SAME scene
-        sh = sharded_scene(one_scene, dev, fx, rank, world, dist, args.precision)
-        tr = None if args.no_train else train_step_section(dev, fx, rank, world, dist)
-        if rank == 0:
-            res["sharded_scene"] = sh
-            if tr is not None:
+        try:
+            if strong or world == 1:
+                one_scene = scene
+            else:
+                one_scene = build_scene(0, dev)                          # every rank the SAME scene
+            sh = sharded_scene(one_scene, dev, fx, rank, world, dist, args.precision)
+            if rank == 0:
+                res["sharded_scene"] = sh
+            tr = None if args.no_train else train_step_section(dev, fx, rank, world, dist)
+            if rank == 0 and tr is not None:
                 res["train_step"] = tr
+        except Exception as e:                                           # noqa: BLE001 -- reported in the line
+            if rank == 0:
+                res["extras_error"] = f"{type(e).__name__}: {e}"[:400]
+            else:
+                sys.stderr.write(f"bench.py rank {rank}: {type(e).__name__}: {e}\n")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(scene["sd_decoder_cpu"], scene["grid_cpu"], nx)
-        print(json.dumps(res))
+            try:
+                res["cpu_baseline"] = cpu_baseline(scene["sd_decoder_cpu"], scene["grid_cpu"], nx)
+            except Exception as e:                                       # noqa: BLE001
+                res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        printed.set()
+        print(json.dumps(res), flush=True)
     if dist is not None:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()                                 # still under the watchdog: a failed peer may never arrive
+        except Exception:                                                # noqa: BLE001 -- a peer that failed above cannot take the line back
+            pass
+    watchdog.cancel()
 
 
 if __name__ == "__main__":
