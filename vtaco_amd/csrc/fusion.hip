@@ -17,27 +17,31 @@
 //   attend  O_q = (1/l_q) sum_k e^{S_qk} V_k / (1e-9 + s_k), chained into the epilogue MLP.
 // Score tiles come out of the MFMA with the fixed index on the lane and the streamed index
 // in the 16 registers, which is exactly the B operand the next MFMA (E x V') needs.
+#include <stdlib.h>
+
 #include "fusion_common.h"
 
 namespace {
 
-// ---- split-bf16 operands --------------------------------------------------------------------
-// The N x N products run on the bf16 matrix core with every f32 operand carried as
-// hi + lo (hi = bf16(v), lo = bf16(v - hi)) and every product as lo*hi + hi*lo + hi*hi with f32
-// accumulation (decode_common.h): 12 x v_mfma_f32_32x32x16_bf16 per 32 x 32 x 64 score tile
-// (384 cycles) instead of 32 x v_mfma_f32_32x32x2_f32 (2048).  Q, K and V' are split ONCE by the
-// kernels that produce them, straight into MFMA fragment order, so the passes do no conversion
-// work except for the exponentials E that feed E x V'.  Unit-vector scores are exact to ~2^-16:
-// 4e-6 .. 9e-6 on the fused features of the golden vectors (the f32 core: 2e-6 .. 3e-6).
+// ---- split 16-bit operands ------------------------------------------------------------------
+// The N x N products run on the 16-bit matrix core with every f32 operand carried as
+// hi + lo (hi = round16(v), lo = round16(v - hi)), f32 accumulation (decode_common.h), instead of
+// 32 x v_mfma_f32_32x32x2_f32 (2048 cycles) per 32 x 32 x 64 score tile.  Q, K and V' are split ONCE
+// by the kernels that produce them, straight into MFMA fragment order, so the passes do no conversion
+// work except for the exponentials E that feed E x V'.
+//   scores: HALF pairs (unit vectors, Q times log2 e: |component| <= 1.45, no range issue; the lo halves
+//     are half subnormals, hi + lo carries ~22 bits).  Training forward: lo*hi + hi*lo + hi*hi, 12
+//     v_mfma_f32_32x32x16_f16 (384 cycles).  Inference: the keys rounded to half, 8 MFMAs (score_tile).
+//   E x V': bf16 pairs, three products (V' = V / (1e-9 + s) has no bound).
 //
-// Q/K row (128 bf16 = 256 B): [kg 2][part hi|lo 2][k-step t 4][e 8], column = 16t + 8kg + e --
+// Q/K row (128 halves = 256 B): [kg 2][part hi|lo 2][k-step t 4][e 8], column = 16t + 8kg + e --
 // lane (row, kg) of a 32x32x16 MFMA reads its 4 hi and 4 lo fragments as one 128-B run.
 // Q is stored times log2(e), so exp(S) is a bare v_exp_f32 of the MFMA result.
 struct FragQK {
-    bf16x8 hi[4], lo[4];
+    f16x8 hi[4], lo[4];
 };
 __device__ __forceinline__ void load_fragqk(FragQK &f, const void *rowbase, int kg) {
-    const bf16x8 *r = reinterpret_cast<const bf16x8 *>(reinterpret_cast<const char *>(rowbase) + kg * 128);
+    const f16x8 *r = reinterpret_cast<const f16x8 *>(reinterpret_cast<const char *>(rowbase) + kg * 128);
 #pragma unroll
     for (int t = 0; t < 4; ++t) { f.hi[t] = r[t]; f.lo[t] = r[4 + t]; }
 }
@@ -46,15 +50,20 @@ __device__ __forceinline__ f32x16 mfma16(const bf16x8 &a, const bf16x8 &b, f32x1
 }
 // D[i][j] = stream_row_i . fixed_row_j over the 64-d keys: lane (j,h) reg r = score of
 // streamed row chan_of(r,h) against fixed row j
+// STREAM_KEYS: the streamed rows are the keys, otherwise the fixed rows are.  FULL: all three products (queries and keys to ~22
+// bits); otherwise the KEYS enter rounded to half precision (q_hi k_hi + q_lo k_hi: 8 MFMAs instead of 12) -- every pass then
+// computes the exact attention of the rounded keys, whose rounding errors are independent from key to key and average out over
+// the keys a query attends (rounding the queries instead would put one common error on a whole row of scores).
+template <bool STREAM_KEYS, bool FULL>
 __device__ __forceinline__ f32x16 score_tile(const FragQK &stream, const FragQK &fixed) {
     f32x16 acc;
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc[s] = 0.0f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        acc = mfma16(stream.lo[t], fixed.hi[t], acc);
-        acc = mfma16(stream.hi[t], fixed.lo[t], acc);
-        acc = mfma16(stream.hi[t], fixed.hi[t], acc);
+        if (FULL || !STREAM_KEYS) acc = mfma_s(stream.lo[t], fixed.hi[t], acc);
+        if (FULL || STREAM_KEYS) acc = mfma_s(stream.hi[t], fixed.lo[t], acc);
+        acc = mfma_s(stream.hi[t], fixed.hi[t], acc);
     }
     return acc;
 }
@@ -111,19 +120,19 @@ fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd,
         ss += __shfl_xor(ss, 32);
         const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);                     // F.normalize(p=2, eps=1e-12)
         if (!live) return;
-        bf16x8 *row = reinterpret_cast<bf16x8 *>(dst + (size_t)p * 64);          // 16 fragments of 8 bf16
+        f16x8 *row = reinterpret_cast<f16x8 *>(dst + (size_t)p * 64);            // 16 fragments of 8 halves
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const f32x16 &a = g ? a1 : a0;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                bf16x8 hi, lo;
+                f16x8 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float v = (a[8 * half + e] * inv) * post;
-                    const __bf16 hb = (__bf16)v;
+                    const float v = (a[8 * half + e] * inv) * post;                // |v| <= log2(e): far inside the half range
+                    const _Float16 hb = (_Float16)v;
                     hi[e] = hb;
-                    lo[e] = (__bf16)(v - (float)hb);
+                    lo[e] = (_Float16)(v - (float)hb);
                 }
                 const int t = 2 * g + half;
                 row[(h * 2 + 0) * 4 + t] = hi;
@@ -170,6 +179,7 @@ __device__ __forceinline__ float exp2_unit(float x) { return __builtin_amdgcn_ex
 
 // out[f] = sum over streamed rows i of exp(S_i . F_f) * (w ? w[i] : 1)
 //   rowsum: F = Q, S = K, w = null          colsum: F = K, S = Q, w = 1/l
+template <bool STREAM_KEYS, bool FULL>
 __global__ void __launch_bounds__(FT)
 fusion_expsum_kernel(const float *Fd, const float *Sd, const float *w, float *out, int N, int recip_out) {
     __shared__ __attribute__((aligned(16))) float tiles[2][STILE];
@@ -198,7 +208,7 @@ fusion_expsum_kernel(const float *Fd, const float *Sd, const float *w, float *ou
         if (t + 1 < ntile) fetch(t + 1);
         FragQK stream;
         load_fragqk(stream, tiles[cur] + j * SROW, h);
-        const f32x16 sc = score_tile(stream, fixed);
+        const f32x16 sc = score_tile<STREAM_KEYS, FULL>(stream, fixed);
         const f32x16 ww = load_acc16(wt[cur], h);               // w of streamed row chan_of(r,h)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sum = fmaf(exp2_unit(sc[r]), ww[r], sum);
@@ -240,7 +250,8 @@ fusion_scalev_kernel(const float *V, const float *s, float *VT, int N, int ntile
 // attention output + RelationUnit tail + TransNonlinear + residual: Z = X_q + LN(...)
 constexpr int VROW = 36;                                    // V' tile row: 128 B + 16 B pad
 // TRAIN: the attention output O is kept for the backward and TransNonlinear's two dropouts are applied (masks: drop_mask).
-template <bool TRAIN>
+// FULL: all three products of the scores (see score_tile)
+template <bool TRAIN, bool FULL>
 __global__ void __launch_bounds__(FT)
 fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const float *linv, const float *Xq,
                      const float *blob, float *Z, int N, int ntile_, float *Osave, DropCfg dc) {
@@ -273,7 +284,7 @@ fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const fl
         if (t + 1 < ntile) fetch(t + 1);
         FragQK stream;
         load_fragqk(stream, tiles[cur] + j * SROW, h);
-        f32x16 e = score_tile(stream, fixed);                    // lane (q,h) reg r: key 32t+chan_of(r,h)
+        f32x16 e = score_tile<true, FULL>(stream, fixed);                  // lane (q,h) reg r: key 32t+chan_of(r,h)
 #pragma unroll
         for (int r = 0; r < 16; ++r) e[r] = exp2_unit(e[r]);
         const Split16 es = split16<false>(e);
@@ -406,16 +417,27 @@ void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const fl
         hipLaunchKernelGGL((fusion_proj_kernel<true, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
         hipLaunchKernelGGL((fusion_proj_kernel<false, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
     }
-    hipLaunchKernelGGL(fusion_expsum_kernel, tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1);   // 1/l_q
-    hipLaunchKernelGGL(fusion_expsum_kernel, tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0);         // s_k
+    // the training forward keeps every product (its backward recomputes the scores on the f32 core); inference rounds the keys
+    // unless VTACO_FUSION_SCORE_TERMS=3
+    static const bool env_full = getenv("VTACO_FUSION_SCORE_TERMS") && getenv("VTACO_FUSION_SCORE_TERMS")[0] == '3';
+    const bool full = Osave != nullptr || env_full;
+    if (full) {
+        hipLaunchKernelGGL((fusion_expsum_kernel<true, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1);   // 1/l_q
+        hipLaunchKernelGGL((fusion_expsum_kernel<false, true>), tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0);       // s_k
+    } else {
+        hipLaunchKernelGGL((fusion_expsum_kernel<true, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1);
+        hipLaunchKernelGGL((fusion_expsum_kernel<false, false>), tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0);
+    }
     const size_t tot = (size_t)B * ntile * 128;                      // (b, tile, c, kg, k-step)
     size_t g = (tot + 255) / 256;
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(fusion_scalev_kernel, dim3((unsigned)g), dim3(256), 0, s, w.V, w.s, w.VT, N, ntile, tot);
     if (Osave)
-        hipLaunchKernelGGL(fusion_attend_kernel<true>, tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
+        hipLaunchKernelGGL((fusion_attend_kernel<true, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
+    else if (full)
+        hipLaunchKernelGGL((fusion_attend_kernel<false, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
     else
-        hipLaunchKernelGGL(fusion_attend_kernel<false>, tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
+        hipLaunchKernelGGL((fusion_attend_kernel<false, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
     hipLaunchKernelGGL(fusion_inorm_relu_kernel, dim3(B), dim3(1024), 0, s, w.Z, out, N);
 }
 
