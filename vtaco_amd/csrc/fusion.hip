@@ -73,6 +73,7 @@ __device__ __forceinline__ f32x16 score_tile(const FragQK &stream, const FragQK 
 // the Q/K groups are permuted so that registers 0..7 / 8..15 of lane-half h hold 8 consecutive
 // output columns (16(2g + r/8) + 8h + r%8): exactly one hi and one lo fragment of the split row
 // layout above, written with 16-byte stores.  V keeps the natural order (store_acc16).
+constexpr int PROJ_TILES = 8;
 template <bool DO_Q, bool DO_KV>
 __global__ void __launch_bounds__(256)
 fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd, float *Kd, float *V, int total) {
@@ -92,7 +93,10 @@ fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd,
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-    const int p0 = (blockIdx.x * 4 + wave) * 32;
+    // PROJ_TILES 32-point tiles per wave: the staging of the weight fragments above (20 loads per thread) is paid once per
+    // 128 * PROJ_TILES points instead of once per 128
+    for (int tile = 0; tile < PROJ_TILES; ++tile) {
+    const int p0 = ((blockIdx.x * PROJ_TILES + tile) * 4 + wave) * 32;
     if (p0 >= total) return;
     const int p = min(p0 + j, total - 1);
     const bool live = p0 + j < total;
@@ -152,6 +156,7 @@ fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd,
         store_unit(k0, k1, Kd, 1.0f);
         const f32x16 v = project(x, 4);
         if (live) store_acc16(V + (size_t)p * 32, v, h);
+    }
     }
 }
 
@@ -389,6 +394,62 @@ fusion_inorm_relu_kernel(const float *Z, float *out, int N) {
     for (int n = g; n < N; n += 32) o[(size_t)n * 32 + c] = fmaxf((z[(size_t)n * 32 + c] - m) * rs, 0.0f);
 }
 
+// The same for chunks of at most 2048 points (the reference's chunk size): a thread keeps its 16 x 4 values in registers --
+// one read of z instead of three; thread = (row group of 128, channel quad), 16-byte accesses.
+constexpr int IN_ROWS = 16;
+__global__ void __launch_bounds__(1024)
+fusion_inorm_relu_cached_kernel(const float *Z, float *out, int N) {
+    __shared__ float red[16][32];
+    __shared__ float stat[32];
+    const int q = threadIdx.x & 7, g = threadIdx.x >> 3, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *z = Z + (size_t)blockIdx.x * N * 32 + q * 4;
+    float *o = out + (size_t)blockIdx.x * N * 32 + q * 4;
+    f32x4 v[IN_ROWS];
+#pragma unroll
+    for (int k = 0; k < IN_ROWS; ++k) {
+        const int n = g + 128 * k;
+        v[k] = n < N ? *reinterpret_cast<const f32x4 *>(z + (size_t)n * 32) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    const f32x4 shift = *reinterpret_cast<const f32x4 *>(z);                 // row 0 (see the kernel above)
+    // sum over the chunk of one f32x4 per thread: lanes q, q+8, .. of a wave, then the 16 waves
+    auto chunk_sum = [&](f32x4 t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { t[e] += __shfl_xor(t[e], 8); t[e] += __shfl_xor(t[e], 16); t[e] += __shfl_xor(t[e], 32); }
+        __syncthreads();                                                     // (the previous round's readers are done)
+        if (lane < 8) *reinterpret_cast<f32x4 *>(&red[wave][lane * 4]) = t;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            float a = 0.0f;
+            for (int w = 0; w < 16; ++w) a += red[w][threadIdx.x];
+            stat[threadIdx.x] = a;
+        }
+        __syncthreads();
+        return *reinterpret_cast<const f32x4 *>(&stat[q * 4]);
+    };
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < IN_ROWS; ++k) if (g + 128 * k < N) acc += v[k] - shift;
+    const f32x4 m = shift + chunk_sum(acc) / (float)N;
+    acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < IN_ROWS; ++k)
+        if (g + 128 * k < N) { const f32x4 d = v[k] - m; for (int e = 0; e < 4; ++e) acc[e] = fmaf(d[e], d[e], acc[e]); }
+    const f32x4 var = chunk_sum(acc) / (float)N;
+    f32x4 rs;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rs[e] = 1.0f / sqrtf(var[e] + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < IN_ROWS; ++k) {
+        const int n = g + 128 * k;
+        if (n < N) {
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = fmaxf((v[k][e] - m[e]) * rs[e], 0.0f);
+            *reinterpret_cast<f32x4 *>(o + (size_t)n * 32) = r;
+        }
+    }
+}
+
 struct FusionWs {
     float *Qd, *Kd, *V, *VT, *l, *s, *Z, *M, *T, *blob_s, *blob_x;
 };
@@ -410,7 +471,7 @@ void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const fl
               float *out, int B, int N, hipStream_t s, float *Osave = nullptr, DropCfg dc = DropCfg{0, 0, 1.0f, 0}) {
     const int P = B * N, Npad = (N + 31) / 32 * 32;
     const int ntile = (N + 31) / 32;
-    const dim3 pg((P + 127) / 128), tg((N + FROWS - 1) / FROWS, B);
+    const dim3 pg((P + 128 * PROJ_TILES - 1) / (128 * PROJ_TILES)), tg((N + FROWS - 1) / FROWS, B);
     if (Xq == Xk) {
         hipLaunchKernelGGL((fusion_proj_kernel<true, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
     } else {
@@ -438,7 +499,8 @@ void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const fl
         hipLaunchKernelGGL((fusion_attend_kernel<false, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
     else
         hipLaunchKernelGGL((fusion_attend_kernel<false, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
-    hipLaunchKernelGGL(fusion_inorm_relu_kernel, dim3(B), dim3(1024), 0, s, w.Z, out, N);
+    if (N <= 128 * IN_ROWS) hipLaunchKernelGGL(fusion_inorm_relu_cached_kernel, dim3(B), dim3(1024), 0, s, w.Z, out, N);
+    else hipLaunchKernelGGL(fusion_inorm_relu_kernel, dim3(B), dim3(1024), 0, s, w.Z, out, N);
 }
 
 }  // namespace
