@@ -121,3 +121,37 @@ def test_attention_decoder_over_a_whole_64_lattice_vs_oracle():
         else:
             assert err <= max(1e-4, 3 * own), (ch, touched, own, err)
     assert seen_touched >= 4
+
+
+def test_attention_decoder_chunks_in_batches_equal_chunks_one_by_one():
+    """``_eval_lattice_fused`` hands the kernels whole chunks as a batch (FUSED_CHUNKS_PER_CALL at a time) and the ragged last chunk
+    on its own: the same logits, bit for bit, as one ``forward_img`` call per chunk (what the reference's ``eval_points`` loop does) --
+    a slab of 7 chunks and a tail with 3 chunks per call, and with all of them in one call."""
+    from vtaco_amd import ops
+    from vtaco_amd.bench_util import randomise_fc1
+    from vtaco_amd.common import make_3d_grid
+    from vtaco_amd.conv_onet.generation import Generator3D
+    from vtaco_amd.conv_onet.models import ConvolutionalOccupancyNetwork, decoder_dict
+    torch.manual_seed(1)
+    adec = decoder_dict['attention_local'](dim=3, c_dim=32, hidden_size=32).eval()
+    randomise_fc1(adec, 5)
+    g = torch.Generator().manual_seed(9)
+    model = ConvolutionalOccupancyNetwork(adec, None, device=DEV)
+    nx, chunk = 32, 512
+    first, count = 3 * chunk, 7 * chunk + 100
+    gen = Generator3D(model, device=DEV, resolution0=8, padding=0.1, points_batch_size=chunk, with_img=True)
+    c = {"grid": ops.grid_to_channels_last(torch.randn(1, 32, 16, 16, 16, generator=g).to(DEV))}
+    feats = torch.randn(5, 32, generator=g).to(DEV)
+    ids = torch.randint(0, 6, (1, count), generator=g).to(torch.uint8)
+    ids[ids == 5] = 255
+    ids = ids.to(DEV)
+    pts = ((1.1 * make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3))[first:first + count]).to(DEV)
+    table = torch.cat([feats, feats.new_zeros(1, 32)])
+    row = torch.where(ids[0] == 255, torch.full_like(ids[0], 5), ids[0]).long()
+    with torch.no_grad():
+        one_by_one = torch.cat([model.decoder.forward_img(pts[lo:lo + chunk].unsqueeze(0), c, table[row[lo:lo + chunk]].unsqueeze(0))[0]
+                                for lo in range(0, count, chunk)])
+        for per_call in (3, 256):
+            gen.FUSED_CHUNKS_PER_CALL = per_call
+            got = gen._eval_lattice_fused(c, nx, ids, feats, first, count)
+            assert got.shape == (count,) and torch.equal(got, one_by_one), per_call

@@ -72,6 +72,22 @@ if "fusion" in SECTIONS:
     flop_pt = 30976 + 576 * N + 61440
     print(json.dumps({"workload": "AttentionDecoder.forward_img 128^3, chunk N=2048 (1024 chunks)", "ms": t * 1e3,
                       "points_per_s": nx ** 3 / t, "tflops": flop_pt * nx ** 3 / t / 1e12}))
+    # the same lattice through the product path: Generator3D (decoder: attention_local, points_batch_size 2048) assigning finger
+    # ids to the lattice and decoding it chunk by chunk (whole chunks batched per call)
+    from vtaco_amd.conv_onet.generation import Generator3D
+    from vtaco_amd.conv_onet.models import ConvolutionalOccupancyNetwork
+    agen = Generator3D(ConvolutionalOccupancyNetwork(adec, None, device=dev), device=dev, resolution0=nx // 4, padding=0.1,
+                       points_batch_size=N, with_img=True)
+    gs = torch.Generator().manual_seed(2)
+    tips = torch.randn(5, 1, 3, generator=gs)
+    setup = {'feats': torch.randn(5, 32, generator=gs), 'anchors': 0.3 * tips / tips.norm(dim=-1, keepdim=True),
+             'success': torch.tensor([1, 0, 1, 1, 1], dtype=torch.uint8), 'mode': 'nearest', 'radius': 0.08,
+             'count': torch.ones(5, dtype=torch.int32)}
+    cg = {"grid": grid}
+    with torch.no_grad():
+        t = timed(lambda: agen._eval_lattice_tactile(cg, nx, setup), 3, 1)
+    print(json.dumps({"workload": "Generator3D._eval_lattice_tactile, decoder attention_local, 128^3, points_batch_size 2048 (finger ids + "
+                                  "batched chunks)", "ms": t * 1e3, "points_per_s": nx ** 3 / t}))
 
 # --- train: 8 scenes/GPU, N=2048, fwd+bwd+Adam through encoder (PointNet + UNet3D host path) and decoder
 B = 8

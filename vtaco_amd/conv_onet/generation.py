@@ -29,6 +29,7 @@ class Generator3D(object):
     """Constructor arguments as the reference (generation.py:42-52)."""
 
     MAX_SCENE_GRAPHS = 4
+    FUSED_CHUNKS_PER_CALL = 256          # attention_local: chunks of points_batch_size points evaluated per launch sequence (~0.7 GB of workspace at 2048)
     # generate_obj_mesh_wnf replays the visual branch as a captured hipGraph (VTACO_SCENE_GRAPH=0: eager launches)
     scene_graph = os.environ.get("VTACO_SCENE_GRAPH", "1") != "0"
 
@@ -274,13 +275,34 @@ class Generator3D(object):
         count = nx ** 3 - first if count is None else count
         if first % chunk:
             raise VtError(f"_eval_lattice_fused: slab start {first} splits a chunk of {chunk} points")
-        pts = ((1 + self.padding) * make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3))[first:first + count].to(self.device)
+        # the lattice as the reference builds it (host arithmetic, generation.py:155-157), kept on the device per (nx, padding):
+        # 25 MB at 128^3 that every scene of a run shares
+        cache = self.__dict__.setdefault("_lattice_points", {})
+        key = (nx, float(self.padding))
+        if key not in cache:
+            if len(cache) >= 2:
+                cache.pop(next(iter(cache)))
+            cache[key] = ((1 + self.padding) * make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)).to(self.device)
+        pts = cache[key][first:first + count]
         table = torch.cat([finger_feats.float(), finger_feats.new_zeros(1, finger_feats.shape[1]).float()], dim=0)   # row F = no feature
         row = torch.where(ids[0] == 255, torch.full_like(ids[0], finger_feats.shape[0]), ids[0]).long()
         out = torch.empty(count, dtype=torch.float32, device=self.device)
-        for lo in range(0, count, chunk):
-            hi = min(lo + chunk, count)
-            out[lo:hi] = self.model.decoder.forward_img(pts[lo:hi].unsqueeze(0), c, table[row[lo:hi]].unsqueeze(0))[0]
+        dec = self.model.decoder
+        grid = dec._grid_of(c)
+        # whole chunks go through the kernels as a BATCH of chunks (each is its own attention / InstanceNorm problem, exactly as
+        # in a call of its own: the same logits bit for bit) -- one chunk per call is ~20 launches per 2048 points, 100 ms of
+        # launches for a 128^3 lattice whose arithmetic takes 15
+        full = count // chunk
+        for lo in range(0, full, self.FUSED_CHUNKS_PER_CALL):
+            nb = min(self.FUSED_CHUNKS_PER_CALL, full - lo)
+            sl = slice(lo * chunk, (lo + nb) * chunk)
+            p = pts[sl].reshape(nb, chunk, 3)
+            feat = ops.sample_grid(grid, pts[sl].unsqueeze(0), dec.padding).reshape(nb, chunk, -1)
+            fused = dec.fuser(table[row[sl]].reshape(nb, chunk, -1), 1, feat, 1)
+            out[sl] = ops.decode_mlp_fwd(fused, dec._blob(), p).reshape(-1)
+        if full * chunk < count:                          # the ragged last chunk
+            sl = slice(full * chunk, count)
+            out[sl] = dec.forward_img(pts[sl].unsqueeze(0), c, table[row[sl]].unsqueeze(0))[0]
         return out
 
     def generate_hand_mesh(self, data):
