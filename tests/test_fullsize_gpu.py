@@ -155,3 +155,6 @@ def test_attention_decoder_chunks_in_batches_equal_chunks_one_by_one():
             gen.FUSED_CHUNKS_PER_CALL = per_call
             got = gen._eval_lattice_fused(c, nx, ids, feats, first, count)
             assert got.shape == (count,) and torch.equal(got, one_by_one), per_call
+            # the generic entry point (the reference's eval_points: arbitrary points, dense features, a CPU tensor back)
+            ev = gen.eval_points(pts.cpu(), c, table[row].unsqueeze(0).cpu())
+            assert ev.device.type == "cpu" and torch.equal(ev, one_by_one.cpu()), per_call

@@ -64,7 +64,21 @@ class Generator3D(object):
         ci = None if c_img_all is None else c_img_all.reshape(-1, c_img_all.shape[-1]).to(self.device)
         outs = []
         with torch.no_grad():
-            for lo in range(0, p.shape[0], self.points_batch_size):
+            lo0 = 0
+            if self.with_img and ci is not None and hasattr(self.model.decoder, 'fuser'):
+                # decoder attention_local: the whole chunks as batches of chunks (see _eval_lattice_fused), the ragged rest below
+                dec, chunk = self.model.decoder, self.points_batch_size
+                grid = dec._grid_of(c)
+                full = p.shape[0] // chunk
+                for lo in range(0, full, self.FUSED_CHUNKS_PER_CALL):
+                    nb = min(self.FUSED_CHUNKS_PER_CALL, full - lo)
+                    sl = slice(lo * chunk, (lo + nb) * chunk)
+                    pb = p[sl].float()
+                    feat = ops.sample_grid(grid, pb.unsqueeze(0), dec.padding).reshape(nb, chunk, -1)
+                    fused = dec.fuser(ci[sl].float().reshape(nb, chunk, -1), 1, feat, 1)
+                    outs.append(ops.decode_mlp_fwd(fused, dec._blob(), pb.reshape(nb, chunk, 3)).reshape(-1))
+                lo0 = full * chunk
+            for lo in range(lo0, p.shape[0], self.points_batch_size):
                 pi = p[lo:lo + self.points_batch_size].unsqueeze(0)
                 if self.with_img and ci is not None:
                     occ = self.model.decode_img(pi, c, ci[lo:lo + self.points_batch_size].unsqueeze(0), **kwargs).logits
