@@ -29,7 +29,7 @@ class Generator3D(object):
     """Constructor arguments as the reference (generation.py:42-52)."""
 
     MAX_SCENE_GRAPHS = 4
-    FUSED_CHUNKS_PER_CALL = 256          # attention_local: chunks of points_batch_size points evaluated per launch sequence (~0.7 GB of workspace at 2048)
+    FUSED_CHUNKS_PER_CALL = 256          # attention_local: chunks of points_batch_size points evaluated per launch sequence (see _fused_chunks_per_call)
     # generate_obj_mesh_wnf replays the visual branch as a captured hipGraph (VTACO_SCENE_GRAPH=0: eager launches)
     scene_graph = os.environ.get("VTACO_SCENE_GRAPH", "1") != "0"
 
@@ -70,8 +70,9 @@ class Generator3D(object):
                 dec, chunk = self.model.decoder, self.points_batch_size
                 grid = dec._grid_of(c)
                 full = p.shape[0] // chunk
-                for lo in range(0, full, self.FUSED_CHUNKS_PER_CALL):
-                    nb = min(self.FUSED_CHUNKS_PER_CALL, full - lo)
+                per_call = self._fused_chunks_per_call(chunk)
+                for lo in range(0, full, per_call):
+                    nb = min(per_call, full - lo)
                     sl = slice(lo * chunk, (lo + nb) * chunk)
                     pb = p[sl].float()
                     feat = ops.sample_grid(grid, pb.unsqueeze(0), dec.padding).reshape(nb, chunk, -1)
@@ -86,6 +87,11 @@ class Generator3D(object):
                     occ = self.model.decode(pi, c, **kwargs).logits
                 outs.append(occ.squeeze(0))
         return torch.cat(outs, dim=0).detach().cpu()
+
+    def _fused_chunks_per_call(self, chunk):
+        """Chunks of ``chunk`` points per launch sequence of the attention decoder: FUSED_CHUNKS_PER_CALL, but at most 2^19 points
+        (the fusion workspace is ~1.3 KB per point: 0.7 GB there, whatever the chunk size)."""
+        return max(1, min(self.FUSED_CHUNKS_PER_CALL, (1 << 19) // max(int(chunk), 1)))
 
     # -- fast path: the nx^3 lattice never exists as a tensor ----------------------
     def eval_lattice(self, c, nx, c_img_all=None, first=0, count=None, out=None):
@@ -307,8 +313,9 @@ class Generator3D(object):
         # in a call of its own: the same logits bit for bit) -- one chunk per call is ~20 launches per 2048 points, 100 ms of
         # launches for a 128^3 lattice whose arithmetic takes 15
         full = count // chunk
-        for lo in range(0, full, self.FUSED_CHUNKS_PER_CALL):
-            nb = min(self.FUSED_CHUNKS_PER_CALL, full - lo)
+        per_call = self._fused_chunks_per_call(chunk)
+        for lo in range(0, full, per_call):
+            nb = min(per_call, full - lo)
             sl = slice(lo * chunk, (lo + nb) * chunk)
             p = pts[sl].reshape(nb, chunk, 3)
             feat = ops.sample_grid(grid, pts[sl].unsqueeze(0), dec.padding).reshape(nb, chunk, -1)
