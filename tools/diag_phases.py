@@ -31,6 +31,8 @@ assert rc == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
 a = a[a[:, 7] > 0]
 names = ["loop/tail", "regs->LDS+idx", "gather", "fetch issue", "fc_p,c split,fc_c0", "5 blocks", "head+store", "TOTAL"]
+if os.environ.get("VTACO_DECODE_ST3", "1") != "0" and prec == "f16x3":
+    names = ["indices + DMA wait", "gather", "fetch issue", "fc_p operands, img", "prologue (c split, fc_p, fc_c0)", "blocks 0-3", "block 4 + heads", "TOTAL"]
 tiles = 32768 / a.shape[0]
 print(f"{prec}: {ms:.4f} ms per launch (with stamps), {a.shape[0]} waves, {tiles:.1f} double bricks per wave")
 for i, nm in enumerate(names):

@@ -771,6 +771,12 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
 #endif
 }
 
+}  // namespace
+#ifdef VT_DECODE_F16_TU
+#include "decode_st3.h"       // decode_fwd_staged3_kernel: the slot-pipelined form of the split-f16 lattice decode
+#endif
+namespace {
+
 #ifndef VT_DECODE_F16_TU      // the remaining kernels exist once, in decode.o
 // ---- trilinear gather only: feat[b,n,:] = grid sampled at the query point -----------------
 __global__ void __launch_bounds__(256) sample_grid_kernel(DecodeArgs a, float *feat) {
@@ -813,7 +819,10 @@ __device__ __forceinline__ void split3_bits(float v, int fmt, unsigned &hi, unsi
     if (fmt == 2) {
         const _Float16 h = (_Float16)v;
         const float r1 = v - (float)h;
-        const _Float16 m = (_Float16)r1;
+        _Float16 m = (_Float16)r1;
+#ifdef VT_WLO_DROP_BITS                     /* experiment: fewer significant bits in the lo parts of the weights (operand toggling) */
+        m = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, m) & (unsigned short)~((1u << VT_WLO_DROP_BITS) - 1u)));
+#endif
         const _Float16 l = (_Float16)(r1 - (float)m);
         hi = __builtin_bit_cast(unsigned short, h); mid = __builtin_bit_cast(unsigned short, m); lo = __builtin_bit_cast(unsigned short, l);
     } else {
@@ -829,6 +838,19 @@ __global__ void decoder_pack_kernel(PackArgs a) {
     const vt_decoder_params &p = a.p;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < VT_BLOB_FLOATS; e += gridDim.x * blockDim.x) {
         float v = 0.0f;
+        if (e >= VT_OFF_PFRAG) {
+            // fc_p's coordinate columns for the one-MFMA form (vt_common.h): lane (i, kg), dword m = halves 2m, 2m+1
+            const int q = e - VT_OFF_PFRAG, l = (q >> 2) & 63, m = q & 3, i = l & 31, kg = l >> 5;
+            unsigned bits = 0;
+            if (a.split == 2) {
+                unsigned hi[3], lo[3], unused;
+                for (int k = 0; k < 3; ++k) split3_bits(p.fc_p_w[i * p.p_in + k], 2, hi[k], lo[k], unused);
+                if (kg == 0) bits = (m < 3) ? (hi[m] | (hi[m] << 16)) : (lo[0] | (lo[1] << 16));
+                else bits = (m == 0) ? lo[2] : 0u;
+            }
+            a.blob[e] = __builtin_bit_cast(float, bits);
+            continue;
+        }
         if (e >= VT_OFF_BFRAG) {
             // bias fragment of block blk: lane (i, kg), elements 0..2 of kg = 0 carry hi / mid / lo
             const int q = e - VT_OFF_BFRAG, blk = q >> 8, l = (q >> 2) & 63, m = q & 3, i = l & 31, kg = l >> 5;
@@ -1065,6 +1087,34 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
         const size_t lds_st = ((size_t)VT_BLOB_FLOATS + 4u * (size_t)lattice_nx + (size_t)(ST_THREADS / 64) * ST_WAVE_FLOATS) * sizeof(float);
         const size_t lds_st2 = ((size_t)VT_BLOB_FLOATS + 4u * (size_t)lattice_nx) * sizeof(float) + (size_t)(ST2_THREADS / 64) * ST2_WAVE_BYTES;
         static const bool no_pair = getenv("VTACO_DECODE_NO_PAIR") != nullptr;    // A/B knob
+#ifdef VT_DECODE_F16_TU
+        if constexpr (P == 2) {
+            // slot-pipelined double-brick kernel (decode_st3.h); VTACO_DECODE_ST3=0 falls back to the compiler-scheduled one,
+            // VTACO_DECODE_ST3_SPLIT=0 selects the 4-instruction relu/split (mix-to-half) instead of the 5-instruction one
+            static const bool no_st3 = getenv("VTACO_DECODE_ST3") != nullptr && atoi(getenv("VTACO_DECODE_ST3")) == 0;
+            static const bool mix_half = getenv("VTACO_DECODE_ST3_SPLIT") != nullptr && atoi(getenv("VTACO_DECODE_ST3_SPLIT")) == 0;
+            const size_t lds_st3 = ((size_t)VT_BLOB_FLOATS + 5u * (size_t)lattice_nx) * sizeof(float) + (size_t)(ST3_THREADS / 64) * ST2_WAVE_BYTES;
+            if (!no_st3 && !no_pair && !out2 && (lattice_nx & 7) == 0 && R >= 6 && s_vox > 0.0 && s_vox < 0.55 && lds_st3 <= 160u * 1024u) {
+                const int64_t nt = (int64_t)a.total / 64;
+                int64_t blocks = (nt + ST3_THREADS / 64 - 1) / (ST3_THREADS / 64);
+                if (blocks > vt_num_cus()) blocks = vt_num_cus();
+                if (blocks > 8) blocks &= ~7ll;
+                static bool st3_attr = false;
+                if (!st3_attr) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<0>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (e == hipSuccess)
+                        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<1>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute (staged3)");
+                    st3_attr = true;
+                }
+                if (mix_half) hipLaunchKernelGGL(decode_fwd_staged3_kernel<0>, dim3((unsigned)blocks), dim3(ST3_THREADS), lds_st3, (hipStream_t)stream, a);
+                else hipLaunchKernelGGL(decode_fwd_staged3_kernel<1>, dim3((unsigned)blocks), dim3(ST3_THREADS), lds_st3, (hipStream_t)stream, a);
+                return vt_check(hipGetLastError(), "vt_decode_fwd");
+            }
+        }
+#endif
         if (!no_pair && !out2 && (lattice_nx & 7) == 0 && R >= 6 && s_vox > 0.0 && s_vox < 0.55 &&
             lds_st2 <= 160u * 1024u) {
             const int64_t nt = (int64_t)a.total / 64;

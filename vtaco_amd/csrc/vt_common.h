@@ -20,7 +20,11 @@ constexpr int VT_OFF_WPI = VT_OFF_WL + 15 * 1024;
 // split-bf16 blob only: the five block-end biases as A fragments of one 32x32x16 bf16 MFMA each
 // ([64 lanes][8 bf16]; k-slots 0..2 = bf16 hi/mid/lo of the bias, against a B operand of ones)
 constexpr int VT_OFF_BFRAG = VT_OFF_WPI + 1024;
-constexpr int VT_BLOB_FLOATS = VT_OFF_BFRAG + 5 * 256;
+// split-f16 blob only: fc_p's coordinate columns as the A fragment of ONE 32x32x16 f16 MFMA ([64 lanes][8 halves]):
+// lane half 0 = [Wx_hi, Wx_hi, Wy_hi, Wy_hi, Wz_hi, Wz_hi, Wx_lo, Wy_lo], half 1 = [Wz_lo, 0 x 7], against the B operand
+// [x_hi, x_mid, y_hi, y_mid, z_hi, z_mid, x_hi, y_hi | z_hi, 0 x 7] of the slot-pipelined lattice kernel (decode_st3.h)
+constexpr int VT_OFF_PFRAG = VT_OFF_BFRAG + 5 * 256;
+constexpr int VT_BLOB_FLOATS = VT_OFF_PFRAG + 256;
 static_assert(VT_BLOB_FLOATS % 4 == 0, "blob is copied as float4");
 static_assert((VT_OFF_WPI) * 4 <= 65536, "visual-only fragments must sit below the 64 KiB ds_read offset limit");
 
