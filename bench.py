@@ -39,8 +39,9 @@ FLOP_PER_POINT = 31488        # 30 976 (16 linear layers) + 512 (8
 FLOP_PER_POINT_IMG = 33536    # with the tactile concat (forward_img)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
-KERNEL_OF = {"f32": "decode_fwd_staged2_kernel<0>", "bf16x3": "decode_fwd_staged2_kernel<1>", "f16x3": "decode_fwd_staged2_kernel<2>"}
-SPLIT = ("bf16x3", "f16x3")   # dense layers on the 16-bit matrix core, operands as hi + lo
+KERNEL_OF = {"f32": "decode_fwd_staged2_kernel<0>", "bf16x3": "decode_fwd_staged2_kernel<1>", "f16x3": "decode_fwd_staged3_kernel<1>",
+             "f16f8": "decode_fwd_staged3_kernel<2>"}
+SPLIT = ("bf16x3", "f16x3", "f16f8")   # dense layers on the 16-bit matrix core, operands as hi + lo
 MIN_WARM_S = 0.25             # launches before any timed region, whatever --warmup says (clocks settle)
 
 
@@ -361,8 +362,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nx", type=int, default=128)
     ap.add_argument("--mode", choices=["visual", "img"], default="visual")
-    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x3"], default="f16x3",
-                    help="arithmetic of the 16 dense layers: exact-f32 MFMA, split-bf16 or split-f16 MFMA (all inside the 1e-4 bar)")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x3", "f16f8"], default="f16f8",
+                    help="arithmetic of the 16 dense layers: exact-f32 MFMA, split-bf16 / split-f16 MFMA, or f16 products with fp8 "
+                         "correction products (all inside the 1e-4 bar)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: one scene per rank, no collective; strong: one scene, slab decode + one all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -481,6 +483,7 @@ def main():
                                    "(fc_1 re-randomised); f32 in / f32 out, dense layers on "
                                    + ({"bf16x3": "the bf16 matrix core with split-bf16 (hi+lo) operands and f32 accumulation",
                                        "f16x3": "the f16 matrix core with split-f16 (hi+lo) operands and f32 accumulation",
+                                       "f16f8": "the f16 matrix core (hi parts) + one fp8 MFMA per layer for the two correction products, f32 accumulation",
                                        "f32": "the f32 matrix core"}[args.precision])
                                    + "; parity bar 1e-4 vs the f32 oracle",
                        "nx": nx, "points_per_step_per_gpu": npts if not strong else npts // world, "mode": args.mode,
@@ -507,9 +510,10 @@ def main():
                         "roofline": roofline_of(prec, flop_pt, npts, ev0.elapsed_time(ev1) / args.steps)}
             res["exact_f32_kernel"] = side("f32")
             res["value_f32"] = res["exact_f32_kernel"]["value"]
-            other = "bf16x3" if args.precision == "f16x3" else "f16x3"
-            res["split_" + other + "_kernel"] = side(other)
-            res["value_" + other] = res["split_" + other + "_kernel"]["value"]
+            for other in ("f16x3", "bf16x3"):                       # the f32-level split form and the round-1 one
+                if other != args.precision:
+                    res["split_" + other + "_kernel"] = side(other)
+                    res["value_" + other] = res["split_" + other + "_kernel"]["value"]
             step()                                                   # leave the headline kernel's logits in `out`
         if world == 1 and not args.decode_only:
             res["mesh_extract"] = mesh_extract_stats(out.view(nx, nx, nx), nx)

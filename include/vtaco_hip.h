@@ -130,6 +130,24 @@ int vt_decode_fwd_f16x3(const float *grid_cl, int B, int R, int C, const float *
                         const float *c_img, const unsigned char *finger_ids, const float *finger_feats, int F,
                         const float *blob_f16x3, double padding, float *out, float *out2, void *stream);
 
+/* "f16f8": the dense lattice decode with the two correction products of every layer on ONE fp8   */
+/* (e4m3) 32x32x64 MFMA: W x = W_hi x_hi (two f16 MFMAs, as f16x3) + [W_lo 2^15 | W_hi 2^4] .       */
+/* [x_hi 2^-2 | x_lo 2^9] with the MFMA's block scales undoing the shifts -- 128 matrix cycles per   */
+/* layer instead of 192 and ~40 % less matrix-pipe energy (the kernel is power-limited).  The        */
+/* corrections carry 4 significant bits per operand: logits within ~4e-5 of the f32 reference on    */
+/* the golden decoder (inside the 1e-4 parity bar; f16x3: ~1e-6); activations beyond 448 * 4          */
+/* saturate in the correction (never NaN).  Lattice mode only, for slabs the slot-pipelined kernel   */
+/* covers (vt_decode_f16f8_covers: whole x-plane pairs, nx % 8 == 0, < 0.55 voxels per lattice       */
+/* step, c_dim 32); everything else is vt_decode_fwd_f16x3's.  blob from vt_decoder_pack_f16f8       */
+/* (same size).  Replaces the same reference functions on the generator's no-grad path               */
+/* (decoder.py:135-161, 71-103 via generation.py:338-383).                                            */
+int vt_decoder_pack_f16f8(const vt_decoder_params *params_host, float *blob, size_t blob_bytes, void *stream);
+int vt_decode_f16f8_covers(int R, int C, int lattice_nx, float lattice_box, int64_t lattice_first, int64_t N, double padding);
+int vt_decode_fwd_f16f8(const float *grid_cl, int B, int R, int C, int64_t N,
+                        int lattice_nx, float lattice_box, int64_t lattice_first,
+                        const float *c_img, const unsigned char *finger_ids, const float *finger_feats, int F,
+                        const float *blob_f16f8, double padding, float *out, void *stream);
+
 /* Tactile feature assignment and decode by finger id (SURVEY.md section 8f "next" row 2).        */
 /* Replaces: the scipy cdist + np.where glue that fills the dense c_img_all [1,N,32] at            */
 /*   src/conv_onet/generation.py:186-200 (mode 0: nearest fingertip, radius 0.05, only if that      */

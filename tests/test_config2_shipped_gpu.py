@@ -65,7 +65,8 @@ def shipped():
     return {"z": z, "enc": enc.to(DEV), "dec": dec.to(DEV), "cloud": cloud, "dsd": dsd, "grid_orc": grid_orc, "orc": orc, "oracle_vs_fixture": o_err}
 
 
-@pytest.mark.parametrize("enc_precision,dec_precision", [("f32", "f32"), ("bf16x3", "f32"), ("bf16x3", "bf16x3"), ("f16x3", "f32"), ("f16x3", "f16x3")])
+@pytest.mark.parametrize("enc_precision,dec_precision", [("f32", "f32"), ("bf16x3", "f32"), ("bf16x3", "bf16x3"), ("f16x3", "f32"), ("f16x3", "f16x3"),
+                                                         ("f16x3", "f16f8")])
 def test_config2_end_to_end_at_the_shipped_shape(shipped, enc_precision, dec_precision):
     s, z, orc = shipped, shipped["z"], shipped["orc"]
     enc, dec = s["enc"], s["dec"]
@@ -102,6 +103,6 @@ def test_config2_end_to_end_at_the_shipped_shape(shipped, enc_precision, dec_pre
     bar = 1e-4
     assert rep["logit_err_end_to_end_sample"] <= bar and rep["logit_err_end_to_end_near"] <= bar, rep
     assert rep["logit_err_end_to_end_vs_oracle_65536"] <= bar, rep
-    assert rep["logit_err_decoder_only_sample"] <= (5e-6 if dec_precision == "f32" else 5e-5), rep      # measured 2.2e-6 / 5.5e-6
+    assert rep["logit_err_decoder_only_sample"] <= {"f32": 5e-6, "f16f8": 9e-5}.get(dec_precision, 5e-5), rep      # measured 2.2e-6 / 5.5e-6
     # encoder drift, reported separately: f32 convs stay at f32 rounding noise, the split-bf16 convs within 1e-4 of the grid's scale
     assert rep["encoder_drift_vs_oracle_whole_grid"] <= (2e-5 if enc_precision == "f32" else 1e-4) * gmax, rep

@@ -24,14 +24,14 @@ ms = ev0.elapsed_time(ev1) / 50
 lib = _lib.load()
 n = 2048 * 8
 buf = (ctypes.c_ulonglong * n)()
-read = lib.vt_diag_phases_read_f16 if prec == "f16x3" else lib.vt_diag_phases_read      # one buffer per translation unit
+read = lib.vt_diag_phases_read_f16 if prec in ("f16x3", "f16f8") else lib.vt_diag_phases_read      # one buffer per translation unit
 read.restype = ctypes.c_int
 rc = read(buf, ctypes.c_size_t(n))
 assert rc == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
 a = a[a[:, 7] > 0]
 names = ["loop/tail", "regs->LDS+idx", "gather", "fetch issue", "fc_p,c split,fc_c0", "5 blocks", "head+store", "TOTAL"]
-if os.environ.get("VTACO_DECODE_ST3", "1") != "0" and prec == "f16x3":
+if os.environ.get("VTACO_DECODE_ST3", "1") != "0" and prec in ("f16x3", "f16f8"):
     names = ["indices + DMA wait", "gather", "fetch issue", "fc_p operands, img", "prologue (c split, fc_p, fc_c0)", "blocks 0-3", "block 4 + heads", "TOTAL"]
 tiles = 32768 / a.shape[0]
 print(f"{prec}: {ms:.4f} ms per launch (with stamps), {a.shape[0]} waves, {tiles:.1f} double bricks per wave")

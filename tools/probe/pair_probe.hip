@@ -25,6 +25,9 @@ __device__ __forceinline__ void body(f32x16 &acc, const f16x8 &wa, const f16x8 &
                 else if (KIND == 2) asm volatile("v_pk_max_f16 %0, %0, 0" : "+v"(w));
                 else if (KIND == 3) asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0] clamp" : "=v"(r) : "v"(w), "v"(c1));
                 else if (KIND == 4) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0] clamp" : "+v"(w) : "v"(u[(q + 1) & 7]), "v"(r));
+                else if (KIND == 5) asm volatile("v_cvt_scalef32_pk_fp8_f16 %0, %1, 4.0" : "+v"(w) : "v"(u[(q + 1) & 7]));
+                else if (KIND == 6) asm volatile("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, 4.0" : "+v"(w) : "v"(r), "v"(c1));
+                else if (KIND == 7) asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2" : "+v"(w) : "v"(r), "v"(c1));
             }
             if (!M && !V) asm volatile("s_nop 0");
         }
@@ -93,5 +96,19 @@ int main() {
     run<1, 8, 1, 8, 3>("mfma + 8 fma_mix_f32 | same");
     run<1, 8, 1, 8, 4>("mfma + 8 fma_mixlo_f16 | same");
     run<1, 0, 0, 8, 4>("mfma chain | 8 fma_mixlo_f16");
+    run<0, 8, 0, 0, 0>("8 v_fma alone");
+    run<0, 8, 0, 0, 1>("8 cvt_pkrtz alone");
+    run<0, 8, 0, 0, 5>("8 cvt_scalef32_pk_fp8_f16 alone");
+    run<0, 8, 0, 0, 6>("8 cvt_scalef32_pk_fp8_f32 alone");
+    run<0, 8, 0, 0, 7>("8 cvt_pk_fp8_f32 alone");
+    run<0, 8, 0, 8, 5>("8 cvt_scalef32_pk_fp8_f16 | same");
+    run<1, 4, 0, 0, 5>("mfma + 4 cvt_scalef32_pk_fp8_f16 alone");
+    run<1, 4, 0, 0, 6>("mfma + 4 cvt_scalef32_pk_fp8_f32 alone");
+    run<1, 4, 0, 0, 7>("mfma + 4 cvt_pk_fp8_f32 alone");
+    run<1, 0, 0, 8, 5>("mfma chain | 8 cvt_scalef32_pk_fp8_f16");
+    run<1, 0, 0, 8, 6>("mfma chain | 8 cvt_scalef32_pk_fp8_f32");
+    run<1, 0, 0, 8, 7>("mfma chain | 8 cvt_pk_fp8_f32");
+    run<1, 0, 0, 8, 1>("mfma chain | 8 cvt_pkrtz");
+    run<1, 0, 0, 8, 3>("mfma chain | 8 fma_mix_f32");
     return 0;
 }

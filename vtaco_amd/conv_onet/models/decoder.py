@@ -130,9 +130,13 @@ class LocalDecoder(nn.Module):
         if with_contact:
             self.fc_out_contact = nn.Linear(hidden_size, 1)
         self._blobs = {}
-        # arithmetic of the 16 dense layers on the no-grad paths: "f32" (exact-f32 MFMA) or "bf16x3"
-        # (split-bf16 MFMA, ~2e-5 abs on O(1) logits, ~3x faster); training is always "f32"
+        # arithmetic of the 16 dense layers on the no-grad paths: "f32" (exact-f32 MFMA), "bf16x3" / "f16x3" (split 16-bit MFMA
+        # operands: ~2e-5 / ~1e-6 abs on O(1) logits) or "f16f8" (f16 products + fp8 corrections, lattice slabs only: ~4e-5, the
+        # fastest; point queries then run as "f16x3"); training is always "f32"
         self.precision = os.environ.get("VTACO_DECODE_PRECISION", "f32")
+
+    def _point_precision(self):
+        return "f16x3" if self.precision == "f16f8" else self.precision
 
     # -- weights -> MFMA-fragment blob, cached until a parameter changes ---------
     def _blob(self, img=False, contact=False, precision="f32"):
@@ -196,16 +200,16 @@ class LocalDecoder(nn.Module):
         grid = self._grid_of(c_plane)
         if self._wants_grad(grid):
             return _DecodeFn.apply(self, p, grid, None, *self._params(False))
-        return ops.decode_fwd(grid, self._blob(precision=self.precision), pts=p, padding=self.padding,
-                              precision=self.precision)
+        prec = self._point_precision()
+        return ops.decode_fwd(grid, self._blob(precision=prec), pts=p, padding=self.padding, precision=prec)
 
     def forward_img(self, p, c_plane, c_img, **kwargs):
         """Tactile concat variant (decoder.py:71-103): fc_p_img([p; c_img])."""
         grid = self._grid_of(c_plane)
         if self._wants_grad(grid, c_img):
             return _DecodeFn.apply(self, p, grid, c_img, *self._params(True))
-        return ops.decode_fwd(grid, self._blob(img=True, precision=self.precision), pts=p, c_img=c_img,
-                              padding=self.padding, precision=self.precision)
+        prec = self._point_precision()
+        return ops.decode_fwd(grid, self._blob(img=True, precision=prec), pts=p, c_img=c_img, padding=self.padding, precision=prec)
 
     def forward_contact(self, p, c_plane, **kwargs):
         """(occupancy logits, contact logits) (decoder.py:105-133)."""
@@ -214,8 +218,9 @@ class LocalDecoder(nn.Module):
             # training with the contact head: the fused decode kernel with both heads and its HIP backward
             return _DecodeContactFn.apply(self, p.float(), grid, *self._params(False),
                                           self.fc_out_contact.weight, self.fc_out_contact.bias)
-        return ops.decode_fwd(grid, self._blob(contact=True, precision=self.precision), pts=p, padding=self.padding,
-                              want_contact=True, precision=self.precision)
+        prec = self._point_precision()
+        return ops.decode_fwd(grid, self._blob(contact=True, precision=prec), pts=p, padding=self.padding, want_contact=True,
+                              precision=prec)
 
     # -- dense fast path: the lattice is generated in-kernel ---------------------
     def decode_lattice(self, grid, nx, box=1.1, first=0, count=None, c_img=None, out=None, precision=None):
@@ -223,6 +228,8 @@ class LocalDecoder(nn.Module):
         (generation.py:155-157 + eval_points) without materialising the points."""
         count = nx ** 3 - first if count is None else count
         precision = precision or self.precision
+        if precision == "f16f8" and not ops.f16f8_covers(grid, (nx, box, first, count), self.padding):
+            precision = "f16x3"                   # slabs the fp8-corrected kernel does not cover
         return ops.decode_fwd(grid, self._blob(img=c_img is not None, precision=precision), c_img=c_img,
                               padding=self.padding, lattice=(nx, box, first, count), out=out, precision=precision)
 
@@ -233,6 +240,8 @@ def _decode_lattice_ids(self, grid, nx, finger_ids, finger_feats, box=1.1, first
     2.1 GB of c_img_all)."""
     count = nx ** 3 - first if count is None else count
     precision = precision or self.precision
+    if precision == "f16f8" and not ops.f16f8_covers(grid, (nx, box, first, count), self.padding):
+        precision = "f16x3"
     return ops.decode_fwd_ids(grid, self._blob(img=True, precision=precision), finger_ids, finger_feats,
                               padding=self.padding, lattice=(nx, box, first, count), out=out, precision=precision)
 

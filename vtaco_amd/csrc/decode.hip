@@ -34,18 +34,6 @@ __device__ __forceinline__ void mlp_and_heads(const DecodeArgs &a, const float *
     float *srow = SAVE ? a.save + (size_t)g * 32 : nullptr;
     if (SAVE && live) store_gather16(srow, c, h);        // slot 0: c
 
-#ifdef VT_DIAG_NOMLP
-    {                                             // diagnostic build: gather only
-        float acc = 0.0f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc += c[s];
-        if (live && h == 0) a.out[g] = acc;
-        return;
-    }
-#endif
-#ifdef VT_SETPRIO
-    __builtin_amdgcn_s_setprio(VT_SETPRIO);       // matrix phase outranks the other waves' gather VALU
-#endif
     // ---- net = fc_p(p) + fc_c[0](c) (+ fc_p_img's c_img columns) ----
     f32x16 net = load_frag16(L + VT_OFF_BIAS + 0 * 32 + h * 16);
     {
@@ -109,9 +97,6 @@ __device__ __forceinline__ void mlp_and_heads(const DecodeArgs &a, const float *
     }
     }
 
-#ifdef VT_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     if (SAVE && live) store_acc16(srow + 11 * slot, relu16(net), h);            // slot 11: relu(net_5)
     // ---- heads: out = fc_out(relu(net)) ----
     {
@@ -122,7 +107,6 @@ __device__ __forceinline__ void mlp_and_heads(const DecodeArgs &a, const float *
         acc += __shfl_xor(acc, 32);
         acc += L[VT_OFF_OUT + 64];
         if (live && h == 0) a.out[g] = acc;
-#ifndef VT_DIAG_CLOCK
         if (a.out2) {
             const f32x16 wo2 = load_frag16(L + VT_OFF_OUT + 32 + h * 16);
             float acc2 = 0.0f;
@@ -132,7 +116,6 @@ __device__ __forceinline__ void mlp_and_heads(const DecodeArgs &a, const float *
             acc2 += L[VT_OFF_OUT + 65];
             if (live && h == 0) a.out2[g] = acc2;
         }
-#endif
     }
 }
 
@@ -143,9 +126,6 @@ __global__ void __launch_bounds__(THREADS, VT_WAVES_PER_SIMD)
 decode_fwd_kernel(DecodeArgs a) {
     static_assert(!(SAVE && P != 0), "the training forward keeps the exact-f32 layers");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-#ifdef VT_DIAG_CLOCK
-    const unsigned long long dc_entry = __builtin_amdgcn_s_memrealtime();
-#endif
     // stage the packed weights (identical for every block) into LDS
     {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(a.blob);
@@ -160,10 +140,6 @@ decode_fwd_kernel(DecodeArgs a) {
     // wave-uniform by construction: tell the compiler, so tile/brick index maths runs on the SALU
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int WPB = THREADS / 64;
-#ifdef VT_DIAG_CLOCK
-    // diagnostic build only: shader-clock vs 100 MHz real-time stamps around the tile loop
-    const unsigned long long dc_t0 = __builtin_amdgcn_s_memtime(), dc_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
     const uint32_t ntiles = (a.total + 31u) >> 5;
     const bool with_img = a.c_img != nullptr || a.cimg_ids != nullptr;
     const int R = a.R;
@@ -184,9 +160,7 @@ decode_fwd_kernel(DecodeArgs a) {
         // Re-derive the LDS base every tile behind an opaque asm so the (loop-invariant)
         // weight reads are not hoisted out of the tile loop into ~120 extra VGPRs.
         unsigned lds_off = 0;
-#ifndef VT_NO_LAUNDER
         asm volatile("" : "+v"(lds_off));
-#endif
         const float *L = lds + lds_off;
         uint32_t g, b;
         bool live = true;
@@ -215,12 +189,6 @@ decode_fwd_kernel(DecodeArgs a) {
         f32x16 c;
 #pragma unroll
         for (int s = 0; s < 16; ++s) c[s] = 0.0f;
-#ifdef VT_DIAG_NOGATHER
-        if (true) {                                   // diagnostic build: no grid traffic at all
-#pragma unroll
-            for (int s = 0; s < 16; ++s) c[s] = px + (float)s;
-        } else
-#endif
         if (a.c_direct) {
             c = load_frag16(a.c_direct + (size_t)g * 32 + 16 * h);
         } else {
@@ -254,15 +222,6 @@ decode_fwd_kernel(DecodeArgs a) {
         }
         mlp_and_heads<SAVE, P>(a, L, c, px, py, pz, g, live, lane, h, with_img);
     }
-#ifdef VT_DIAG_CLOCK
-    if (threadIdx.x == 0 && a.out2) {
-        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(a.out2) + 4 * blockIdx.x;
-        dbg[0] = __builtin_amdgcn_s_memtime() - dc_t0;
-        dbg[1] = __builtin_amdgcn_s_memrealtime() - dc_r0;
-        dbg[2] = dc_r0;
-        dbg[3] = dc_r0 - dc_entry;                    // weight-staging prologue, 10 ns ticks
-    }
-#endif
 }
 
 // ---- lattice decode with the gather staged through LDS -------------------------------------
@@ -438,20 +397,9 @@ decode_fwd_staged_kernel(DecodeArgs a) {
 // operation sequence as the other paths; the logits agree with them to the last bit for ~96 % of the
 // points and to 1 ulp for the rest (running the two MLPs one after the other instead of interleaved is
 // bit-identical -- and no faster).  Conditions: nx % 8 == 0, voxels per step < 0.55.
-#ifdef VT_DIAG_PHASES
-// diagnostic build only (tools/diag_phases.py): per-wave shader-clock sums of the phases of the two-brick kernel
-__device__ unsigned long long vt_diag_phase_buf[4096 * 8];
-#define VT_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-                         dg_sum[i] += t_ - dg_last; dg_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define VT_STAMP(i) do { } while (0)
-#endif
 constexpr int ST2_ROWS = 72;
 constexpr int ST2_WAVE_BYTES = ST2_ROWS * ST_ROW_BYTES;
-#ifndef VT_ST2_THREADS
-#define VT_ST2_THREADS 512
-#endif
-constexpr int ST2_THREADS = VT_ST2_THREADS;       // 8 waves per CU (A/B knob: 256 = one wave per SIMD)
+constexpr int ST2_THREADS = 512;                  // 8 waves per CU
 constexpr int ST2_PIECES = 9;
 
 template <int P>
@@ -594,16 +542,10 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
 
     uint32_t tile = t_begin + w_idx;
     if (tile < t_end) fetch(tile, ox, oy, oz);
-#ifdef VT_DIAG_PHASES
-    unsigned long long dg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long dg_last = __builtin_amdgcn_s_memtime();
-    const unsigned long long dg_first = dg_last;
-#endif
     for (; tile < t_end; tile += w_cnt) {
         unsigned lds_off = 0;
         asm volatile("" : "+v"(lds_off));
         const float *L = lds + lds_off;
-        VT_STAMP(0);                                                     // loop overhead / previous tile's tail
 #pragma unroll
         for (int k = 0; k < ST2_PIECES; ++k) *reinterpret_cast<f32x4 *>(stage + dst_off[k]) = pre[k];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -648,12 +590,9 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             return c;
         };
-        VT_STAMP(1);                                                     // footprint registers -> LDS (waits for the prefetch), indices
         const f32x16 cA = gather(ezA);
         const f32x16 cB = gather(ezB);
-        VT_STAMP(2);                                                     // trilinear gather from LDS
         if (tile + w_cnt < t_end) fetch(tile + w_cnt, ox, oy, oz);
-        VT_STAMP(3);                                                     // next footprint's loads issued
 
         // ---- MLP on both column groups (mlp_and_heads<false, true>, visual-only, two chains) ----
         const f32x16 b0 = load_frag16(L + VT_OFF_BIAS + h * 16);
@@ -728,11 +667,9 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
                     dense32s2<Q>(netA, netB, wl + 1024, sA, sB, lane);
                 }
             };
-            VT_STAMP(4);                                                 // fc_p, c split, fc_c[0]
 #pragma unroll 1
             for (int i = 0; i < 4; ++i) block(i, std::true_type{});
             block(4, std::false_type{});
-            VT_STAMP(5);                                                 // five blocks
         } else {
             if (has_img) dense32x2<false>(netA, netB, L + VT_OFF_WPI, ciA, ciB, lane);
             dense32x2<false>(netA, netB, L + VT_OFF_WL, cA, cB, lane);
@@ -759,16 +696,7 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
             const float ob = L[VT_OFF_OUT + 64];
             if (h == 0) { a.out[gA] = accA + ob; a.out[gB] = accB + ob; }
         }
-        VT_STAMP(6);                                                     // head + store
     }
-#ifdef VT_DIAG_PHASES
-    if (lane == 0) {
-        unsigned long long *d = vt_diag_phase_buf + (size_t)(blockIdx.x * WPB + wave) * 8;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) d[i] = dg_sum[i];
-        d[7] = __builtin_amdgcn_s_memtime() - dg_first;
-    }
-#endif
 }
 
 }  // namespace
@@ -811,7 +739,8 @@ __global__ void __launch_bounds__(256) sample_grid_kernel(DecodeArgs a, float *f
 struct PackArgs {
     vt_decoder_params p;
     float *blob;
-    int split;            // 1: dense layers as split-bf16 fragments (vt_decoder_pack_bf16x3), 2: split-f16 (vt_decoder_pack_f16x3)
+    int split;            // 1: dense layers as split-bf16 fragments (vt_decoder_pack_bf16x3), 2: split-f16 (vt_decoder_pack_f16x3),
+                          // 3: f16 hi parts + fp8 correction fragments (vt_decoder_pack_f16f8)
 };
 
 // v as hi + mid + lo 16-bit floats (round to nearest each time); fmt 1 = bf16, 2 = IEEE half
@@ -820,9 +749,6 @@ __device__ __forceinline__ void split3_bits(float v, int fmt, unsigned &hi, unsi
         const _Float16 h = (_Float16)v;
         const float r1 = v - (float)h;
         _Float16 m = (_Float16)r1;
-#ifdef VT_WLO_DROP_BITS                     /* experiment: fewer significant bits in the lo parts of the weights (operand toggling) */
-        m = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, m) & (unsigned short)~((1u << VT_WLO_DROP_BITS) - 1u)));
-#endif
         const _Float16 l = (_Float16)(r1 - (float)m);
         hi = __builtin_bit_cast(unsigned short, h); mid = __builtin_bit_cast(unsigned short, m); lo = __builtin_bit_cast(unsigned short, l);
     } else {
@@ -834,6 +760,21 @@ __device__ __forceinline__ void split3_bits(float v, int fmt, unsigned &hi, unsi
     }
 }
 
+// f32 -> OCP fp8 e4m3 (round to nearest even, saturating at 448; no NaN is produced for finite input)
+__device__ __forceinline__ unsigned f32_to_e4m3(float v) {
+    const unsigned sign = (__builtin_bit_cast(unsigned, v) >> 31) << 7;
+    float a = fabsf(v);
+    if (!(a < 448.0f)) return sign | 0x7eu;
+    int e;
+    (void)frexpf(a, &e);                               // a = f * 2^e, f in [0.5, 1)
+    e = max(e - 1, -6);                                // exponent of the leading bit, clamped into the subnormal range
+    const float step = ldexpf(1.0f, e - 3);
+    int n = (int)rintf(a / step);                      // 8..16 for a normal, 0..8 for a subnormal
+    if (n >= 16) { n = 8; ++e; }
+    const unsigned bits = (n >= 8) ? (unsigned)(((e + 7) << 3) | (n - 8)) : (unsigned)n;
+    return sign | bits;
+}
+
 __global__ void decoder_pack_kernel(PackArgs a) {
     const vt_decoder_params &p = a.p;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < VT_BLOB_FLOATS; e += gridDim.x * blockDim.x) {
@@ -842,7 +783,7 @@ __global__ void decoder_pack_kernel(PackArgs a) {
             // fc_p's coordinate columns for the one-MFMA form (vt_common.h): lane (i, kg), dword m = halves 2m, 2m+1
             const int q = e - VT_OFF_PFRAG, l = (q >> 2) & 63, m = q & 3, i = l & 31, kg = l >> 5;
             unsigned bits = 0;
-            if (a.split == 2) {
+            if (a.split >= 2) {
                 unsigned hi[3], lo[3], unused;
                 for (int k = 0; k < 3; ++k) split3_bits(p.fc_p_w[i * p.p_in + k], 2, hi[k], lo[k], unused);
                 if (kg == 0) bits = (m < 3) ? (hi[m] | (hi[m] << 16)) : (lo[0] | (lo[1] << 16));
@@ -858,7 +799,7 @@ __global__ void decoder_pack_kernel(PackArgs a) {
             if (a.split && kg == 0 && m < 2) {
                 const float bv = p.fc1_b[blk][i] + ((blk < 4) ? p.fc_c_b[blk + 1][i] : 0.0f);
                 unsigned hb, mb, lb;
-                split3_bits(bv, a.split, hb, mb, lb);
+                split3_bits(bv, a.split == 1 ? 1 : 2, hb, mb, lb);
                 bits = (m == 0) ? (hb | (mb << 16)) : lb;
             }
             a.blob[e] = __builtin_bit_cast(float, bits);
@@ -883,12 +824,28 @@ __global__ void decoder_pack_kernel(PackArgs a) {
                 else { w = p.fc_c_w[blk + 1]; gather_fed = true; }
             }
             unsigned bits = 0;
+            if (a.split == 3 && part) {
+                // "f16f8": the layer's second half is the fp8 (e4m3) A fragment of the correction MFMA, eight dwords per lane as
+                // two 16-byte fragments: byte j < 16 pairs W_lo 2^(11+SW) with the k of accumulator register j, byte 16 + j
+                // W_hi 2^SW with the same k (decode_st3.h); W_hi is the half the main product uses, W_lo = W - W_hi
+                const int d8 = 4 * s + m;
+                for (int b = 0; b < 4; ++b) {
+                    const int j = 4 * d8 + b, r = j & 15;
+                    const int k = gather_fed ? (16 * h + r) : chan_of(r, h);
+                    const float wv = (L == 15 && p.p_in <= 3) ? 0.0f : w[i * ld + koff + k];
+                    const float whi = (float)(_Float16)wv;
+                    const float v = (j < 16) ? (wv - whi) * (float)(1 << (11 + VT_F8_SW)) : whi * (float)(1 << VT_F8_SW);
+                    bits |= f32_to_e4m3(v) << (8 * b);
+                }
+                a.blob[e] = __builtin_bit_cast(float, bits);
+                continue;
+            }
             for (int z = 0; z < 2; ++z) {
                 const int j = 2 * m + z;
                 const int k = gather_fed ? (16 * h + 8 * s + j) : chan_of(8 * s + j, h);
                 const float wv = (L == 15 && p.p_in <= 3) ? 0.0f : w[i * ld + koff + k];
                 unsigned hb, mb, lb;
-                split3_bits(wv, a.split, hb, mb, lb);
+                split3_bits(wv, a.split == 1 ? 1 : 2, hb, mb, lb);
                 bits |= (part ? mb : hb) << (16 * z);
             }
             a.blob[e] = __builtin_bit_cast(float, bits);
@@ -1030,6 +987,17 @@ int vt_decoder_pack_f16x3(const vt_decoder_params *p, float *blob, size_t blob_b
     return vt_check(hipGetLastError(), "vt_decoder_pack_f16x3");
 }
 
+int vt_decoder_pack_f16f8(const vt_decoder_params *p, float *blob, size_t blob_bytes, void *stream) {
+    const int rc = vt_decoder_pack(p, blob, blob_bytes, stream);
+    if (rc) return rc;
+    PackArgs a;
+    a.p = *p;
+    a.blob = blob;
+    a.split = 3;
+    hipLaunchKernelGGL(decoder_pack_kernel, dim3(17), dim3(1024), 0, (hipStream_t)stream, a);
+    return vt_check(hipGetLastError(), "vt_decoder_pack_f16f8");
+}
+
 int vt_grid_to_channels_last(const float *src, float *dst, int B, int C, int D, int H, int W, void *stream) {
     if (!src || !dst || B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return vt_fail(VT_ERR_INVALID, "vt_grid_to_channels_last: bad argument");
     const int64_t V = (int64_t)D * H * W;
@@ -1048,6 +1016,37 @@ int vt_grid_from_channels_last(const float *src, float *dst, int B, int C, int D
 
 }  // extern "C"
 #endif  // !VT_DECODE_F16_TU
+
+#ifdef VT_DECODE_F16_TU
+// the slot-pipelined lattice kernels (decode_st3.h) cover: whole 2 x 4 x 8 double bricks (nx % 8 == 0, a slab of x-plane pairs),
+// less than 0.55 voxels per lattice step (the 3 x 4 x 6 footprint), blob + tables + eight images within the CU's 160 KiB
+static bool st3_covers(int nx, int R, double s_vox) {
+    const size_t lds = ((size_t)VT_BLOB_FLOATS + 5u * (size_t)nx) * sizeof(float) + (size_t)(ST3_THREADS / 64) * ST2_WAVE_BYTES;
+    return (nx & 7) == 0 && R >= 6 && s_vox > 0.0 && s_vox < 0.55 && lds <= 160u * 1024u;
+}
+static int st3_launch(const DecodeArgs &a, int variant, void *stream) {
+    const size_t lds = ((size_t)VT_BLOB_FLOATS + 5u * (size_t)a.nx) * sizeof(float) + (size_t)(ST3_THREADS / 64) * ST2_WAVE_BYTES;
+    const int64_t nt = (int64_t)a.total / 64;
+    int64_t blocks = (nt + ST3_THREADS / 64 - 1) / (ST3_THREADS / 64);
+    if (blocks > vt_num_cus()) blocks = vt_num_cus();
+    if (blocks > 8) blocks &= ~7ll;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute (staged3)");
+        attr = true;
+    }
+    if (variant == 0) hipLaunchKernelGGL(decode_fwd_staged3_kernel<0>, dim3((unsigned)blocks), dim3(ST3_THREADS), lds, (hipStream_t)stream, a);
+    else if (variant == 1) hipLaunchKernelGGL(decode_fwd_staged3_kernel<1>, dim3((unsigned)blocks), dim3(ST3_THREADS), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(decode_fwd_staged3_kernel<2>, dim3((unsigned)blocks), dim3(ST3_THREADS), lds, (hipStream_t)stream, a);
+    return vt_check(hipGetLastError(), "vt_decode_fwd");
+}
+static double lattice_step_voxels(int R, int nx, float box, double padding) {
+    return (double)(R - 1) * (double)box / ((double)(nx - 1) * (double)(float)(1.0 + padding + 10e-4));
+}
+#endif
 
 // P: 0 exact f32, 1 split-bf16, 2 split-f16 (the dense layers; decode_common.h)
 template <int P>
@@ -1072,9 +1071,6 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box;
     a.divisor = (float)(1.0 + padding + 10e-4);   // src/common.py:302, rounded to f32 as torch does
-#ifndef VT_THREADS
-#define VT_THREADS 512
-#endif
     if (!pts && !save && (lattice_nx & 3) == 0) {
         const int64_t pair = 2ll * lattice_nx * lattice_nx;            // two x-planes
         if (lattice_first % pair == 0 && N % pair == 0) a.brick = 1;
@@ -1093,26 +1089,7 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
             // VTACO_DECODE_ST3_SPLIT=0 selects the 4-instruction relu/split (mix-to-half) instead of the 5-instruction one
             static const bool no_st3 = getenv("VTACO_DECODE_ST3") != nullptr && atoi(getenv("VTACO_DECODE_ST3")) == 0;
             static const bool mix_half = getenv("VTACO_DECODE_ST3_SPLIT") != nullptr && atoi(getenv("VTACO_DECODE_ST3_SPLIT")) == 0;
-            const size_t lds_st3 = ((size_t)VT_BLOB_FLOATS + 5u * (size_t)lattice_nx) * sizeof(float) + (size_t)(ST3_THREADS / 64) * ST2_WAVE_BYTES;
-            if (!no_st3 && !no_pair && !out2 && (lattice_nx & 7) == 0 && R >= 6 && s_vox > 0.0 && s_vox < 0.55 && lds_st3 <= 160u * 1024u) {
-                const int64_t nt = (int64_t)a.total / 64;
-                int64_t blocks = (nt + ST3_THREADS / 64 - 1) / (ST3_THREADS / 64);
-                if (blocks > vt_num_cus()) blocks = vt_num_cus();
-                if (blocks > 8) blocks &= ~7ll;
-                static bool st3_attr = false;
-                if (!st3_attr) {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<0>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    if (e == hipSuccess)
-                        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<1>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute (staged3)");
-                    st3_attr = true;
-                }
-                if (mix_half) hipLaunchKernelGGL(decode_fwd_staged3_kernel<0>, dim3((unsigned)blocks), dim3(ST3_THREADS), lds_st3, (hipStream_t)stream, a);
-                else hipLaunchKernelGGL(decode_fwd_staged3_kernel<1>, dim3((unsigned)blocks), dim3(ST3_THREADS), lds_st3, (hipStream_t)stream, a);
-                return vt_check(hipGetLastError(), "vt_decode_fwd");
-            }
+            if (!no_st3 && !no_pair && !out2 && st3_covers(lattice_nx, R, s_vox)) return st3_launch(a, mix_half ? 0 : 1, stream);
         }
 #endif
         if (!no_pair && !out2 && (lattice_nx & 7) == 0 && R >= 6 && s_vox > 0.0 && s_vox < 0.55 &&
@@ -1147,7 +1124,7 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
             return vt_check(hipGetLastError(), "vt_decode_fwd");
         }
     }
-    constexpr int THREADS = VT_THREADS;
+    constexpr int THREADS = 512;
     const int64_t ntiles = ((int64_t)a.total + 31) / 32;
     int64_t blocks = (ntiles + THREADS / 64 - 1) / (THREADS / 64);
     const int64_t cap = (int64_t)(1024 / THREADS) * vt_num_cus();
@@ -1179,11 +1156,33 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
 extern "C" {
 
 #ifdef VT_DECODE_F16_TU
-#ifdef VT_DIAG_PHASES
-int vt_diag_phases_read_f16(unsigned long long *host, size_t count) {
-    return vt_check(hipMemcpyFromSymbol(host, HIP_SYMBOL(vt_diag_phase_buf), count * sizeof(unsigned long long)), "vt_diag_phases_read_f16");
+int vt_decode_f16f8_covers(int R, int C, int lattice_nx, float lattice_box, int64_t lattice_first, int64_t N, double padding) {
+    if (C != 32 || lattice_nx < 8 || N <= 0) return 0;
+    const int64_t pair = 2ll * lattice_nx * lattice_nx;
+    if (lattice_first % pair != 0 || N % pair != 0) return 0;
+    return st3_covers(lattice_nx, R, lattice_step_voxels(R, lattice_nx, lattice_box, padding)) ? 1 : 0;
 }
-#endif
+
+int vt_decode_fwd_f16f8(const float *grid_cl, int B, int R, int C, int64_t N, int lattice_nx, float lattice_box, int64_t lattice_first,
+                        const float *c_img, const unsigned char *finger_ids, const float *finger_feats, int F,
+                        const float *blob_f16f8, double padding, float *out, void *stream) {
+    if (!grid_cl || !blob_f16f8 || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_f16f8: null argument");
+    if (c_img && finger_ids) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_f16f8: give c_img or finger ids, not both");
+    if (finger_ids && (!finger_feats || F <= 0)) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_f16f8: finger ids without a feature table");
+    if (B <= 0 || N < 0) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_f16f8: bad size");
+    if (N == 0) return 0;
+    if ((int64_t)B * N >= (int64_t)1 << 31) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd_f16f8: B*N must be < 2^31");
+    if (!vt_decode_f16f8_covers(R, C, lattice_nx, lattice_box, lattice_first, N, padding))
+        return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd_f16f8: covers lattice slabs of whole x-plane pairs with nx % 8 == 0 and < 0.55 voxels per "
+                                           "step (vt_decode_f16f8_covers); use vt_decode_fwd_f16x3 otherwise");
+    DecodeArgs a;
+    a.c_direct = nullptr; a.grid = grid_cl; a.pts = nullptr; a.brick = 1; a.cimg_ids = finger_ids; a.cimg_table = finger_ids ? finger_feats : nullptr;
+    a.c_img = c_img; a.blob = blob_f16f8; a.out = out; a.out2 = nullptr; a.save = nullptr;
+    a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
+    a.R = R; a.nx = lattice_nx; a.box = lattice_box; a.divisor = (float)(1.0 + padding + 10e-4);
+    return st3_launch(a, 2, stream);
+}
+
 int vt_decode_fwd_f16x3(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
                         int lattice_nx, float lattice_box, int64_t lattice_first,
                         const float *c_img, const unsigned char *finger_ids, const float *finger_feats, int F,
@@ -1195,11 +1194,6 @@ int vt_decode_fwd_f16x3(const float *grid_cl, int B, int R, int C, const float *
                             finger_ids, finger_ids ? finger_feats : nullptr, blob_f16x3, padding, out, out2, nullptr, stream);
 }
 #else
-#ifdef VT_DIAG_PHASES
-int vt_diag_phases_read(unsigned long long *host, size_t count) {
-    return vt_check(hipMemcpyFromSymbol(host, HIP_SYMBOL(vt_diag_phase_buf), count * sizeof(unsigned long long)), "vt_diag_phases_read");
-}
-#endif
 int vt_decode_fwd(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
                   int lattice_nx, float lattice_box, int64_t lattice_first,
                   const float *c_img, const float *blob, double padding,

@@ -39,9 +39,7 @@ __device__ __forceinline__ f32x16 dense32(f32x16 acc, const float *wl, const f32
     if (RELU) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) b[s] = relu1(x[s]);
-#ifndef VT_RELU_INTERLEAVED
         asm volatile("" : "+v"(b));
-#endif
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc = mfma(wl[s * 64 + lane], b[s], acc);

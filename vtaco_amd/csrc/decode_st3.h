@@ -24,20 +24,42 @@
 
 namespace {
 
-struct Sp {                                        // one column group's split activations: k-step s -> 8 halves
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+// V selects the arithmetic of the dense layers and the relu + split that feeds them:
+//   0, 1  split-f16 ("f16x3", decode_common.h): W x = W_lo x_hi + W_hi x_lo + W_hi x_hi on six f16 MFMAs; V = 0 forms x_lo with
+//         v_fma_mixlo / mixhi_f16 (4 instructions per register pair; the mix-to-half forms do not issue in an MFMA's shadow:
+//         tools/probe/issue_probe.hip), V = 1 with 2 x v_fma_mix_f32 + v_cvt_pkrtz_f16_f32 (5 instructions that do);
+//   2     "f16f8": W_hi x_hi on two f16 MFMAs + ONE fp8 (e4m3) 32x32x64 MFMA for both correction products -- k-slots 0..15 of a lane
+//         half pair W_lo 2^(11+SW) with x_hi 2^-SX, k-slots 16..31 W_hi 2^SW with x_lo 2^(11-SX), the MFMA's block scales undo the
+//         shifts -- 128 matrix cycles per layer instead of 192 at 40 % less matrix-pipe energy (tools/probe/shape_probe.hip); the
+//         corrections carry 4 significant bits each: logits within ~4e-5 of f32 on the golden decoder (tools/probe/decode_f8_emul.py).
+constexpr int ST3_F8_SX = VT_F8_SX;                 // activations enter the fp8 copies as x 2^-SX (|x_hi| up to 448 * 2^SX, then saturating)
+constexpr int ST3_F8_SW = VT_F8_SW;                 // weights as W 2^SW (vt_decoder_pack_f16f8)
+
+template <int V> struct SpT {                       // one column group's split activations: k-step s -> 8 halves
     u32x4 hi[2], lo[2];
+};
+template <> struct SpT<2> {
+    u32x4 hi[2];
+    u32x8 q;                                        // fp8 operand: dwords 0-3 = x_hi copies (registers 4d .. 4d+3), 4-7 = x_lo copies
 };
 
 __device__ __forceinline__ f32x16 mfma_h(const u32x4 &a, const u32x4 &b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+// both correction products of a layer: D += 2^(SX - SW - 11) A8 B8 (E8M0 block scales, bias 127, the same in every lane)
+__device__ __forceinline__ f32x16 mfma_q(const u32x8 &a, const u32x8 &b, f32x16 c) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_bit_cast(i32x8, a), __builtin_bit_cast(i32x8, b), c, 0, 0,
+                                                           0, 127 - 11 - ST3_F8_SW, 0, 127 + ST3_F8_SX);
+}
 
 // relu + split of one register pair in two halves, so that the head of pair p + 1 sits between the instructions of pair p's
 // tail (no dependent instruction directly behind its producer):
-//   head: hi = v_pk_max_f16(v_cvt_pkrtz_f16_f32(a, b), 0)
-//   tail: V = 0: lo = v_fma_mixlo_f16 / v_fma_mixhi_f16 (clamp) -- 2 instructions, but the mix-to-half forms do not issue in an
-//                MFMA's shadow (tools/probe/issue_probe.hip);
-//         V = 1: 2 x v_fma_mix_f32 (clamp) + v_cvt_pkrtz_f16_f32 -- 3 instructions that do.
+//   head: hi = v_pk_max_f16(v_cvt_pkrtz_f16_f32(a, b), 0)            [V = 2: + v_cvt_scalef32_pk_fp8_f16 of hi]
+//   tail: the differences lo = v - hi (clamped to [0, 1]: the relu of lo), then their pack [V = 2: v_cvt_scalef32_pk_fp8_f32]
 template <bool RELU>
 __device__ __forceinline__ unsigned split_head(float a, float b) {
     const f16x2 zero = {(_Float16)0.0f, (_Float16)0.0f};
@@ -45,7 +67,7 @@ __device__ __forceinline__ unsigned split_head(float a, float b) {
     if (RELU) hp = __builtin_elementwise_max(hp, zero);
     return __builtin_bit_cast(unsigned, hp);
 }
-// tail, first part: the two differences lo = v - hi (V = 1: as f32, still to be packed; V = 0: mix-to-half, already packed in l0's bits)
+// tail, first part: the two differences (V = 0: mix-to-half, already packed in l0's bits)
 template <int V, bool RELU>
 __device__ __forceinline__ void split_tail_a(float a, float b, unsigned hw, float m1, float &l0, float &l1) {
     const f16x2 zero = {(_Float16)0.0f, (_Float16)0.0f}, one = {(_Float16)1.0f, (_Float16)1.0f};
@@ -66,52 +88,83 @@ __device__ __forceinline__ void split_tail_a(float a, float b, unsigned hw, floa
         }
     }
 }
-template <int V>
-__device__ __forceinline__ unsigned split_tail_b(float l0, float l1) {
-    if constexpr (V == 0) return __builtin_bit_cast(unsigned, l0);
-    else return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+// two fp8 (e4m3) values v / scale into word (PAIR & 1) of a dword of the fp8 operand, the other word kept.  An even pair opens its
+// dword: whatever the register holds is fine (the odd pair overwrites the other word), so no instruction initialises it.
+template <int PAIR>
+__device__ __forceinline__ i16x2 fp8_old(unsigned old) {
+    if constexpr (PAIR & 1) return __builtin_bit_cast(i16x2, old);
+    else { i16x2 o; asm volatile("" : "=v"(o)); return o; }
 }
-// pair p (0..7) of an accumulator <-> dword p & 3 of k-step p >> 2
-template <bool RELU, int PAIR>
-__device__ __forceinline__ void head_to(Sp &s, const f32x16 &x) {
+template <int PAIR>
+__device__ __forceinline__ unsigned fp8_pair_f16(unsigned old, unsigned hw, float scale) {
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(fp8_old<PAIR>(old), __builtin_bit_cast(f16x2, hw), scale, (PAIR & 1) != 0));
+}
+template <int PAIR>
+__device__ __forceinline__ unsigned fp8_pair_f32(unsigned old, float l0, float l1, float scale) {
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(fp8_old<PAIR>(old), l0, l1, scale, (PAIR & 1) != 0));
+}
+// pair p (0..7) of an accumulator <-> dword p & 3 of k-step p >> 2 (f16 operands), word p & 1 of dword p >> 1 (fp8 operand)
+template <int V, bool RELU, int PAIR>
+__device__ __forceinline__ void head_a(SpT<V> &s, const f32x16 &x) {                  // hi = relu(half(v))
     s.hi[PAIR >> 2][PAIR & 3] = split_head<RELU>(x[2 * PAIR], x[2 * PAIR + 1]);
 }
-// the split of an accumulator as eight steps for eight MFMA gaps: H0 H1 | T0 H2 | T1 H3 | T2 H4 | T3 H5 | T4 H6 | T5 H7 | T6 T7.
-// Inside a step the head of the next pair sits between the tail's two differences and the pack that consumes them (a pack directly
-// behind its producers costs a wait state); scheduling barriers keep that order.
+template <int V, int PAIR>
+__device__ __forceinline__ void head_b(SpT<V> &s) {                                    // V = 2: the fp8 copy of hi
+    if constexpr (V == 2) s.q[PAIR >> 1] = fp8_pair_f16<PAIR>(s.q[PAIR >> 1], s.hi[PAIR >> 2][PAIR & 3], (float)(1 << ST3_F8_SX));
+}
+template <int V, int PAIR>
+__device__ __forceinline__ void pack_to(SpT<V> &s, float l0, float l1) {
+    if constexpr (V == 0) s.lo[PAIR >> 2][PAIR & 3] = __builtin_bit_cast(unsigned, l0);
+    else if constexpr (V == 1) s.lo[PAIR >> 2][PAIR & 3] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+    else s.q[4 + (PAIR >> 1)] = fp8_pair_f32<PAIR>(s.q[4 + (PAIR >> 1)], l0, l1, 1.0f / (float)(1 << (11 - ST3_F8_SX)));
+}
+// the split of an accumulator as eight steps for the MFMA gaps: H0 H1 | T0 H2 | T1 H3 | T2 H4 | T3 H5 | T4 H6 | T5 H7 | T6 T7
+// (H = half conversion + relu of a pair, T = its differences and their pack; V = 2: a pair's fp8 copy of hi one step behind its H).
+// Inside a step no instruction sits behind its producer closer than the hardware wants (each miss is a wait state): this pair's two
+// differences, the next pair's conversion and relu, the fp8 copy, the pack; scheduling barriers keep that order.
 template <int V, bool RELU, int K>
-__device__ __forceinline__ void split_step(Sp &s, const f32x16 &x, float m1) {
+__device__ __forceinline__ void split_step(SpT<V> &s, const f32x16 &x, float m1) {
     if constexpr (K == 0) {
-        head_to<RELU, 0>(s, x);
-        head_to<RELU, 1>(s, x);
+        head_a<V, RELU, 0>(s, x);
+        head_a<V, RELU, 1>(s, x);
+        __builtin_amdgcn_sched_barrier(0);
+        head_b<V, 0>(s);
     } else if constexpr (K == 7) {
         float a0, a1, b0, b1;
         split_tail_a<V, RELU>(x[12], x[13], s.hi[1][2], m1, a0, a1);
         split_tail_a<V, RELU>(x[14], x[15], s.hi[1][3], m1, b0, b1);
         __builtin_amdgcn_sched_barrier(0);
-        s.lo[1][2] = split_tail_b<V>(a0, a1);
-        s.lo[1][3] = split_tail_b<V>(b0, b1);
+        head_b<V, 7>(s);
+        pack_to<V, 6>(s, a0, a1);
+        pack_to<V, 7>(s, b0, b1);
     } else {
         constexpr int P = K - 1;
         float l0, l1;
         split_tail_a<V, RELU>(x[2 * P], x[2 * P + 1], s.hi[P >> 2][P & 3], m1, l0, l1);
         __builtin_amdgcn_sched_barrier(0);
-        head_to<RELU, K + 1>(s, x);
+        head_a<V, RELU, K + 1>(s, x);
         __builtin_amdgcn_sched_barrier(0);
-        s.lo[P >> 2][P & 3] = split_tail_b<V>(l0, l1);
+        head_b<V, K>(s);
+        pack_to<V, P>(s, l0, l1);
     }
 }
+template <int V, bool RELU>
+__device__ __forceinline__ SpT<V> split_all(const f32x16 &x, float m1) {
+    SpT<V> s;
+    split_step<V, RELU, 0>(s, x, m1); split_step<V, RELU, 1>(s, x, m1); split_step<V, RELU, 2>(s, x, m1); split_step<V, RELU, 3>(s, x, m1);
+    split_step<V, RELU, 4>(s, x, m1); split_step<V, RELU, 5>(s, x, m1); split_step<V, RELU, 6>(s, x, m1); split_step<V, RELU, 7>(s, x, m1);
+    return s;
+}
 
-#ifndef VT_ST3_THREADS
-#define VT_ST3_THREADS 512
-#endif
-constexpr int ST3_THREADS = VT_ST3_THREADS;
+constexpr int ST3_THREADS = 512;                  // 8 waves per CU, two per SIMD
 constexpr int ST3_CHUNKS = ST2_ROWS * (ST_ROW_BYTES / 16);            // 16-byte chunks of a wave's image, pad chunks included: 648
 constexpr int ST3_PIECES = ST3_CHUNKS / 64;                           // whole 1-KiB LDS-DMA pieces: 10 (+ one of 8 lanes)
 static_assert(ST3_CHUNKS - 64 * ST3_PIECES == 8, "the last LDS-DMA piece is eight lanes");
 
 #define ST3_GAP() __builtin_amdgcn_sched_barrier(0)
 #define ST3_M(acc, w, x) do { acc = mfma_h(w, x, acc); ST3_GAP(); } while (0)   /* the MFMA opens its gap */
+#define ST3_Q(acc, w, x) do { acc = mfma_q(w, x, acc); ST3_GAP(); } while (0)   /* fp8 correction MFMA (V = 2) */
+#define ST3_RUN_BLOCKS() do { _Pragma("unroll 1") for (int i = 0; i < 4; ++i) block(i, std::true_type{}); block(4, std::false_type{}); } while (0)
 #define ST3_S(dst, src, k) split_step<V, true, k>(dst, src, m1)      /* step k of a relu + split */
 #define ST3_C(dst, src, k) split_step<V, false, k>(dst, src, m1)     /* step k of a plain split (the sampled features) */
 
@@ -119,6 +172,8 @@ template <int V>
 __global__ void __launch_bounds__(ST3_THREADS)
 decode_fwd_staged3_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // V = 2: MODE.FP16_OVFL = 1 -- the fp8 conversions then saturate at +-448 instead of producing NaN (hwreg MODE = 1, bit 23)
+    if constexpr (V == 2) __builtin_amdgcn_s_setreg((1 - 1) << 11 | 23 << 6 | 1, 1);
     {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(a.blob);
         f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
@@ -240,16 +295,10 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
 
     uint32_t tile = t_begin + w_idx;
     if (tile < t_end) fetch(tile, ox, oy, oz);
-#ifdef VT_DIAG_PHASES
-    unsigned long long dg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long dg_last = __builtin_amdgcn_s_memtime();
-    const unsigned long long dg_first = dg_last;
-#endif
     for (; tile < t_end; tile += w_cnt) {
         unsigned lds_off = 0;
         asm volatile("" : "+v"(lds_off));                                // see decode_fwd_kernel
         const float *L = lds + lds_off;
-        VT_STAMP(0);
 
         uint32_t b, X0, Y0, Z0;
         brick_of(tile, b, X0, Y0, Z0);
@@ -264,7 +313,6 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
         const unsigned c00 = cy0 + cx0, c01 = cy0 + cx1, c10 = cy1 + cx0, c11 = cy1 + cx1;
         const float w00 = ex.w0 * ey.w0, w01 = ex.w1 * ey.w0, w10 = ex.w0 * ey.w1, w11 = ex.w1 * ey.w1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this tile's footprint has landed in the image
-        VT_STAMP(1);
         typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
         auto corner = [&](unsigned addr) {
             lds_f32x4 *q = reinterpret_cast<lds_f32x4 *>(addr);
@@ -305,9 +353,7 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
         const f32x16 cA = gather(ezA);
         const f32x16 cB = gather(ezB);
         // every read of the image has returned (the FMAs above consumed it): the next footprint may overwrite it
-        VT_STAMP(2);
         if (tile + w_cnt < t_end) fetch(tile + w_cnt, ox, oy, oz);
-        VT_STAMP(3);
 
         // ---- fc_p operands: the point's coordinates as half pairs from the per-axis table ----
         u32x4 pA, pB;
@@ -319,10 +365,14 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
         }
         const u32x4 *W = reinterpret_cast<const u32x4 *>(L);             // 16-byte fragments: [float offset / 4 + lane]
         auto frag = [&](int float_off) { return W[float_off / 4 + lane]; };
+        [[maybe_unused]] auto frag8 = [&](int float_off) {                // two fragments = the eight dwords of an fp8 operand
+            const u32x4 lo4 = W[float_off / 4 + lane], hi4 = W[float_off / 4 + 64 + lane];
+            return u32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        };
 
         f32x16 netA = load_frag16(L + VT_OFF_BIAS + h * 16);
         f32x16 netB = netA;
-        Sp csA, csB, sA, sB;
+        SpT<V> csA, csB, sA, sB;
 
         // ---- optional tactile concat (fc_p_img's c_img columns): plain, not pipelined ----
         if (a.cimg_ids || a.c_img) {
@@ -339,334 +389,35 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
                 ciA = load_frag16(a.c_img + (size_t)gA * 32 + 16 * h);
                 ciB = load_frag16(a.c_img + (size_t)gB * 32 + 16 * h);
             }
-            if (has_img) dense32s2<2>(netA, netB, L + VT_OFF_WPI, split16<false, 2>(ciA), split16<false, 2>(ciB), lane);
+            if (has_img) {
+                if constexpr (V == 2) {
+                    const SpT<2> iA = split_all<2, false>(ciA, m1), iB = split_all<2, false>(ciB, m1);
+                    const u32x4 ih0 = frag(VT_OFF_WPI), ih1 = frag(VT_OFF_WPI + 256);
+                    const u32x8 iq = frag8(VT_OFF_WPI + 512);
+                    netA = mfma_h(ih0, iA.hi[0], netA); netB = mfma_h(ih0, iB.hi[0], netB);
+                    netA = mfma_h(ih1, iA.hi[1], netA); netB = mfma_h(ih1, iB.hi[1], netB);
+                    netA = mfma_q(iq, iA.q, netA); netB = mfma_q(iq, iB.q, netB);
+                } else {
+                    dense32s2<2>(netA, netB, L + VT_OFF_WPI, split16<false, 2>(ciA), split16<false, 2>(ciB), lane);
+                }
+            }
         }
 
-        // weight fragments in flight: w0 = fc_0, w1 = fc_1 of the current block ([hi k0, hi k1, lo k0, lo k1]), cw = fc_c of the
-        // next block, bf = the block-end bias fragment
-        u32x4 w0h0, w0h1, w0o0, w0o1, w1h0, w1h1, w1o0, w1o1, ch0, ch1, co0, co1, bf;
+        // weight fragments in flight: w0 = fc_0, w1 = fc_1 of the current block, c = fc_c of the next block (h = hi part of k-step
+        // 0 / 1; o = lo part (V = 0, 1); q = fp8 correction fragment (V = 2)), bf = the block-end bias fragment
+        u32x4 w0h0, w0h1, w1h0, w1h1, ch0, ch1, bf;
+        [[maybe_unused]] u32x4 w0o0, w0o1, w1o0, w1o1, co0, co1;
+        [[maybe_unused]] u32x8 w0q, w1q, cq;
         f32x16 hidA, hidB;
-
-        VT_STAMP(4);
-        // ---- pipeline prologue: c split, fc_p, fc_c[0], first split of net_A; block 0's first fragments are requested ----
-        {
-            const u32x4 wp = frag(VT_OFF_PFRAG);
-            const u32x4 f0h0 = frag(VT_OFF_WL), f0h1 = frag(VT_OFF_WL + 256), f0o0 = frag(VT_OFF_WL + 512), f0o1 = frag(VT_OFF_WL + 768);
-            ST3_M(netA, wp, pA);
-            ST3_C(csA, cA, 0);
-            ST3_C(csA, cA, 1);
-            ST3_C(csA, cA, 2);
-            ST3_C(csA, cA, 3);
-            ST3_C(csA, cA, 4);
-            ST3_GAP();
-            ST3_M(netA, f0o0, csA.hi[0]);
-            ST3_C(csA, cA, 5);
-            ST3_GAP();
-            ST3_M(netA, f0h0, csA.lo[0]);
-            ST3_C(csA, cA, 6);
-            ST3_GAP();
-            ST3_M(netA, f0h0, csA.hi[0]);
-            ST3_C(csA, cA, 7);
-            ST3_GAP();
-            ST3_M(netA, f0o1, csA.hi[1]);
-            ST3_C(csB, cB, 0);
-            ST3_C(csB, cB, 1);
-            ST3_GAP();
-            ST3_M(netA, f0h1, csA.lo[1]);
-            ST3_C(csB, cB, 2);
-            ST3_C(csB, cB, 3);
-            ST3_GAP();
-            ST3_M(netA, f0h1, csA.hi[1]);
-            ST3_C(csB, cB, 4);
-            ST3_C(csB, cB, 5);
-            ST3_GAP();
-            ST3_M(netB, wp, pB);
-            ST3_C(csB, cB, 6);
-            ST3_C(csB, cB, 7);
-            w0h0 = frag(VT_OFF_WL + 1024); w0o0 = frag(VT_OFF_WL + 1024 + 512);
-            ST3_GAP();
-            ST3_M(netB, f0o0, csB.hi[0]);
-            w0h1 = frag(VT_OFF_WL + 1024 + 256); w0o1 = frag(VT_OFF_WL + 1024 + 768);
-            ST3_GAP();
-            ST3_M(netB, f0h0, csB.lo[0]);
-            ST3_S(sA, netA, 0);
-            ch0 = frag(VT_OFF_WL + 3 * 1024); co0 = frag(VT_OFF_WL + 3 * 1024 + 512);
-            ST3_GAP();
-            ST3_M(netB, f0h0, csB.hi[0]);
-            ST3_S(sA, netA, 1);
-            ST3_S(sA, netA, 2);
-            hidA = load_frag16(L + VT_OFF_BIAS + 32 + h * 16);
-            ST3_GAP();
-            ST3_M(netB, f0o1, csB.hi[1]);
-            ST3_S(sA, netA, 3);
-            ST3_S(sA, netA, 4);
-            ST3_GAP();
-            ST3_M(netB, f0h1, csB.lo[1]);
-            ST3_S(sA, netA, 5);
-            ST3_S(sA, netA, 6);
-            ST3_GAP();
-            ST3_M(netB, f0h1, csB.hi[1]);
-            ST3_S(sA, netA, 7);
-            ST3_GAP();
+        // the pipeline itself -- prologue and the `block` lambda -- is written out by gen_st3.py
+        if constexpr (V == 2) {
+#include "decode_st3_f16f8.inc"
+            ST3_RUN_BLOCKS();
+        } else {
+#include "decode_st3_f16x3.inc"
+            ST3_RUN_BLOCKS();
         }
-
-        VT_STAMP(5);
-        // ---- five blocks of four slots (on entry: w0*, ch0 / co0, hidA = fc_0's bias, sA = split relu(net_A)) ----
-        // A slot's first one or two MFMAs carry the LDS requests of the next slot's fragments and no split step: the first
-        // step reads the chain the previous slot's last MFMA completed.
-        auto block = [&](int i, auto cond_tag) {
-            constexpr bool COND = decltype(cond_tag)::value;             // blocks 0..3 carry the next block's fc_c; block 4 the heads
-            const int wl = VT_OFF_WL + (1 + 3 * i) * 1024;              // fc_0 | fc_1 | fc_c{i+1}: [hi k0, hi k1, lo k0, lo k1] x 256 floats
-            const int hb = VT_OFF_BIAS + (1 + 2 * i) * 32 + h * 16;
-            // ---- slot 0: A.cond k-step 0, A.fc_0 | split relu(net_B) ----
-            if constexpr (COND) {
-                ST3_M(netA, co0, csA.hi[0]);
-                hidB = load_frag16(L + hb);
-                bf = frag(VT_OFF_BFRAG + i * 256);
-                ST3_GAP();
-                ST3_M(netA, ch0, csA.lo[0]);
-                co1 = frag(wl + 2048 + 768);
-                ST3_S(sB, netB, 0);
-                ST3_GAP();
-                ST3_M(netA, ch0, csA.hi[0]);
-                ch1 = frag(wl + 2048 + 256);
-                ST3_S(sB, netB, 1);
-                ST3_GAP();
-                ST3_M(hidA, w0o0, sA.hi[0]);
-                ST3_S(sB, netB, 2);
-                ST3_GAP();
-                ST3_M(hidA, w0h0, sA.lo[0]);
-                ST3_S(sB, netB, 3);
-                ST3_GAP();
-                ST3_M(hidA, w0h0, sA.hi[0]);
-                ST3_S(sB, netB, 4);
-                ST3_GAP();
-                ST3_M(hidA, w0o1, sA.hi[1]);
-                ST3_S(sB, netB, 5);
-                ST3_GAP();
-                ST3_M(hidA, w0h1, sA.lo[1]);
-                ST3_S(sB, netB, 6);
-                ST3_GAP();
-                ST3_M(hidA, w0h1, sA.hi[1]);
-                ST3_S(sB, netB, 7);
-                ST3_GAP();
-            } else {
-                ST3_M(hidA, w0o0, sA.hi[0]);
-                hidB = load_frag16(L + hb);
-                bf = frag(VT_OFF_BFRAG + i * 256);
-                ST3_GAP();
-                ST3_M(hidA, w0h0, sA.lo[0]);
-                ST3_S(sB, netB, 0);
-                ST3_S(sB, netB, 1);
-                ST3_GAP();
-                ST3_M(hidA, w0h0, sA.hi[0]);
-                ST3_S(sB, netB, 2);
-                ST3_S(sB, netB, 3);
-                ST3_GAP();
-                ST3_M(hidA, w0o1, sA.hi[1]);
-                ST3_S(sB, netB, 4);
-                ST3_S(sB, netB, 5);
-                ST3_GAP();
-                ST3_M(hidA, w0h1, sA.lo[1]);
-                ST3_S(sB, netB, 6);
-                ST3_GAP();
-                ST3_M(hidA, w0h1, sA.hi[1]);
-                ST3_S(sB, netB, 7);
-                ST3_GAP();
-            }
-            // ---- slot 1: A.bias, A.cond k-step 1, B.fc_0 | split relu(hid_A); fc_1's fragments are requested ----
-            if constexpr (COND) {
-                ST3_M(netA, bf, ones);
-                w1o0 = frag(wl + 1024 + 512); w1h0 = frag(wl + 1024);
-                ST3_GAP();
-                ST3_M(netA, co1, csA.hi[1]);
-                w1o1 = frag(wl + 1024 + 768);
-                ST3_GAP();
-                ST3_M(netA, ch1, csA.lo[1]);
-                w1h1 = frag(wl + 1024 + 256);
-                ST3_S(sA, hidA, 0);
-                ST3_GAP();
-                ST3_M(netA, ch1, csA.hi[1]);
-                ST3_S(sA, hidA, 1);
-                ST3_GAP();
-                ST3_M(hidB, w0o0, sB.hi[0]);
-                ST3_S(sA, hidA, 2);
-                ST3_GAP();
-                ST3_M(hidB, w0h0, sB.lo[0]);
-                ST3_S(sA, hidA, 3);
-                ST3_GAP();
-                ST3_M(hidB, w0h0, sB.hi[0]);
-                ST3_S(sA, hidA, 4);
-                ST3_GAP();
-                ST3_M(hidB, w0o1, sB.hi[1]);
-                ST3_S(sA, hidA, 5);
-                ST3_GAP();
-                ST3_M(hidB, w0h1, sB.lo[1]);
-                ST3_S(sA, hidA, 6);
-                ST3_GAP();
-                ST3_M(hidB, w0h1, sB.hi[1]);
-                ST3_S(sA, hidA, 7);
-                ST3_GAP();
-            } else {
-                ST3_M(netA, bf, ones);
-                w1o0 = frag(wl + 1024 + 512); w1h0 = frag(wl + 1024);
-                ST3_GAP();
-                ST3_M(hidB, w0o0, sB.hi[0]);
-                w1o1 = frag(wl + 1024 + 768);
-                ST3_S(sA, hidA, 0);
-                ST3_S(sA, hidA, 1);
-                ST3_GAP();
-                ST3_M(hidB, w0h0, sB.lo[0]);
-                w1h1 = frag(wl + 1024 + 256);
-                ST3_S(sA, hidA, 2);
-                ST3_S(sA, hidA, 3);
-                ST3_GAP();
-                ST3_M(hidB, w0h0, sB.hi[0]);
-                ST3_S(sA, hidA, 4);
-                ST3_GAP();
-                ST3_M(hidB, w0o1, sB.hi[1]);
-                ST3_S(sA, hidA, 5);
-                ST3_GAP();
-                ST3_M(hidB, w0h1, sB.lo[1]);
-                ST3_S(sA, hidA, 6);
-                ST3_GAP();
-                ST3_M(hidB, w0h1, sB.hi[1]);
-                ST3_S(sA, hidA, 7);
-                ST3_GAP();
-            }
-            // ---- slot 2: B.bias, B.cond k-step 0, A.fc_1 | split relu(hid_B) ----
-            if constexpr (COND) {
-                ST3_M(netB, bf, ones);
-                ST3_GAP();
-                ST3_M(netB, co0, csB.hi[0]);
-                ST3_GAP();
-                ST3_M(netB, ch0, csB.lo[0]);
-                ST3_S(sB, hidB, 0);
-                ST3_GAP();
-                ST3_M(netB, ch0, csB.hi[0]);
-                ST3_S(sB, hidB, 1);
-                ST3_GAP();
-                ST3_M(netA, w1o0, sA.hi[0]);
-                ST3_S(sB, hidB, 2);
-                ST3_GAP();
-                ST3_M(netA, w1h0, sA.lo[0]);
-                ST3_S(sB, hidB, 3);
-                ST3_GAP();
-                ST3_M(netA, w1h0, sA.hi[0]);
-                ST3_S(sB, hidB, 4);
-                ST3_GAP();
-                ST3_M(netA, w1o1, sA.hi[1]);
-                ST3_S(sB, hidB, 5);
-                ST3_GAP();
-                ST3_M(netA, w1h1, sA.lo[1]);
-                ST3_S(sB, hidB, 6);
-                ST3_GAP();
-                ST3_M(netA, w1h1, sA.hi[1]);
-                ST3_S(sB, hidB, 7);
-                ST3_GAP();
-            } else {
-                ST3_M(netB, bf, ones);
-                ST3_GAP();
-                ST3_M(netA, w1o0, sA.hi[0]);
-                ST3_S(sB, hidB, 0);
-                ST3_S(sB, hidB, 1);
-                ST3_GAP();
-                ST3_M(netA, w1h0, sA.lo[0]);
-                ST3_S(sB, hidB, 2);
-                ST3_S(sB, hidB, 3);
-                ST3_GAP();
-                ST3_M(netA, w1h0, sA.hi[0]);
-                ST3_S(sB, hidB, 4);
-                ST3_GAP();
-                ST3_M(netA, w1o1, sA.hi[1]);
-                ST3_S(sB, hidB, 5);
-                ST3_GAP();
-                ST3_M(netA, w1h1, sA.lo[1]);
-                ST3_S(sB, hidB, 6);
-                ST3_GAP();
-                ST3_M(netA, w1h1, sA.hi[1]);
-                ST3_S(sB, hidB, 7);
-                ST3_GAP();
-            }
-            // ---- slot 3: B.cond k-step 1, B.fc_1 | split relu(net_A) for the next block, whose first fragments are requested ----
-            if constexpr (COND) {
-                ST3_M(netB, co1, csB.hi[1]);
-                w0o0 = frag(wl + 3072 + 512); w0h0 = frag(wl + 3072);
-                ST3_GAP();
-                ST3_M(netB, ch1, csB.lo[1]);
-                w0o1 = frag(wl + 3072 + 768); w0h1 = frag(wl + 3072 + 256);
-                ST3_S(sA, netA, 0);
-                ST3_GAP();
-                ST3_M(netB, ch1, csB.hi[1]);
-                co0 = frag(wl + 3072 + 2048 + 512); ch0 = frag(wl + 3072 + 2048);
-                ST3_S(sA, netA, 1);
-                ST3_GAP();
-                ST3_M(netB, w1o0, sB.hi[0]);
-                hidA = load_frag16(L + hb + 64);
-                ST3_S(sA, netA, 2);
-                ST3_GAP();
-                ST3_M(netB, w1h0, sB.lo[0]);
-                ST3_S(sA, netA, 3);
-                ST3_GAP();
-                ST3_M(netB, w1h0, sB.hi[0]);
-                ST3_S(sA, netA, 4);
-                ST3_GAP();
-                ST3_M(netB, w1o1, sB.hi[1]);
-                ST3_S(sA, netA, 5);
-                ST3_GAP();
-                ST3_M(netB, w1h1, sB.lo[1]);
-                ST3_S(sA, netA, 6);
-                ST3_GAP();
-                ST3_M(netB, w1h1, sB.hi[1]);
-                ST3_S(sA, netA, 7);
-                ST3_GAP();
-            } else {
-                // last block: group A's output head runs under group B's fc_1, group B's behind it
-                const f32x16 wo = load_frag16(L + VT_OFF_OUT + h * 16);
-                const float ob = L[VT_OFF_OUT + 64];
-                float accA = 0.0f, accB = 0.0f;
-                ST3_M(netB, w1o0, sB.hi[0]);
-                ST3_GAP();
-                ST3_M(netB, w1h0, sB.lo[0]);
-                #pragma unroll
-                for (int s = 0; s < 4; ++s) accA = fmaf(relu1(netA[s]), wo[s], accA);
-                ST3_GAP();
-                ST3_M(netB, w1h0, sB.hi[0]);
-                #pragma unroll
-                for (int s = 4; s < 8; ++s) accA = fmaf(relu1(netA[s]), wo[s], accA);
-                ST3_GAP();
-                ST3_M(netB, w1o1, sB.hi[1]);
-                #pragma unroll
-                for (int s = 8; s < 12; ++s) accA = fmaf(relu1(netA[s]), wo[s], accA);
-                ST3_GAP();
-                ST3_M(netB, w1h1, sB.lo[1]);
-                #pragma unroll
-                for (int s = 12; s < 16; ++s) accA = fmaf(relu1(netA[s]), wo[s], accA);
-                ST3_GAP();
-                ST3_M(netB, w1h1, sB.hi[1]);
-                accA += __shfl_xor(accA, 32);
-                if (h == 0) a.out[gA] = accA + ob;
-                ST3_GAP();
-#pragma unroll
-                for (int s = 0; s < 16; ++s) accB = fmaf(relu1(netB[s]), wo[s], accB);
-                accB += __shfl_xor(accB, 32);
-                if (h == 0) a.out[gB] = accB + ob;
-            }
-        };
-#pragma unroll 1
-        for (int i = 0; i < 4; ++i) block(i, std::true_type{});
-        VT_STAMP(6);
-        block(4, std::false_type{});
-        VT_STAMP(7);
     }
-#ifdef VT_DIAG_PHASES
-    if (lane == 0) {
-        unsigned long long *d = vt_diag_phase_buf + (size_t)(blockIdx.x * WPB + wave) * 8;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) d[i] = dg_sum[i + 1];
-        d[7] = __builtin_amdgcn_s_memtime() - dg_first;
-    }
-#endif
 }
 
 #undef ST3_GAP

@@ -25,6 +25,10 @@ constexpr int VT_OFF_BFRAG = VT_OFF_WPI + 1024;
 // [x_hi, x_mid, y_hi, y_mid, z_hi, z_mid, x_hi, y_hi | z_hi, 0 x 7] of the slot-pipelined lattice kernel (decode_st3.h)
 constexpr int VT_OFF_PFRAG = VT_OFF_BFRAG + 5 * 256;
 constexpr int VT_BLOB_FLOATS = VT_OFF_PFRAG + 256;
+// "f16f8" blob (vt_decoder_pack_f16f8): the lo half of every dense layer image is the fp8 (e4m3) A fragment of the correction MFMA;
+// weights enter it as W 2^VT_F8_SW, activations as x 2^-VT_F8_SX (decode_st3.h)
+constexpr int VT_F8_SW = 4;
+constexpr int VT_F8_SX = 2;
 static_assert(VT_BLOB_FLOATS % 4 == 0, "blob is copied as float4");
 static_assert((VT_OFF_WPI) * 4 <= 65536, "visual-only fragments must sit below the 64 KiB ds_read offset limit");
 

@@ -49,8 +49,19 @@ def blob_floats(hidden=32, c_dim=32, n_blocks=5):
     return n // 4
 
 
-PRECISIONS = ("f32", "bf16x3", "f16x3")
-SPLIT_PRECISIONS = ("bf16x3", "f16x3")        # dense layers on the 16-bit matrix core with hi + lo operands
+PRECISIONS = ("f32", "bf16x3", "f16x3", "f16f8")
+SPLIT_PRECISIONS = ("bf16x3", "f16x3", "f16f8")   # dense layers on the 16-bit matrix core with hi + lo operands
+# "f16f8": f16 hi products + ONE fp8 MFMA for both correction products of a layer (vt_decode_fwd_f16f8: ~4e-5 on the golden logits,
+# the fastest form); it exists for lattice slabs only -- see f16f8_covers -- and LocalDecoder falls back to "f16x3" elsewhere
+
+
+def f16f8_covers(grid, lattice, padding=0.1):
+    """True if vt_decode_fwd_f16f8 covers this lattice slab (whole x-plane pairs, nx % 8 == 0, < 0.55 voxels per step)."""
+    if lattice is None:
+        return False
+    nx, box, first, count = lattice
+    B, C, D, H, W = grid.shape
+    return bool(_lib.load().vt_decode_f16f8_covers(D, C, int(nx), float(box), int(first), int(count), float(padding)))
 
 
 def pack_decoder(fc_p_w, fc_p_b, fc_c, blocks, fc_out, fc_out2=None, out=None, transposed=False, precision="f32"):
@@ -184,7 +195,12 @@ def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want
     if N == 0:                                   # empty query set: nothing to launch
         return (out, out2) if want_contact else out
     keep_for_graph(blob, keep)
-    if precision in SPLIT_PRECISIONS:
+    if precision == "f16f8":
+        if pts is not None or want_contact or save is not None:
+            raise VtError("decode_fwd: precision 'f16f8' covers lattice slabs only (ops.f16f8_covers); use 'f16x3'")
+        check(lib.vt_decode_fwd_f16f8(gptr, B, D, C, N, nx, box, first, dev_ptr(c_img, "c_img"), None, None, 0,
+                                      dev_ptr(blob, "blob"), float(padding), dev_ptr(out, "out"), stream_ptr()), "vt_decode_fwd_f16f8")
+    elif precision in SPLIT_PRECISIONS:
         if save is not None:
             raise VtError("decode_fwd: the training forward (save) is exact-f32 only")
         name = "vt_decode_fwd_" + precision
@@ -1152,6 +1168,13 @@ def decode_fwd_ids(grid, blob, ids, feats, pts=None, lattice=None, padding=0.1, 
         nx, box, first, N = lattice
     if out is None:
         out = torch.empty((B, N), dtype=torch.float32, device=grid.device)
+    if precision == "f16f8":
+        if pts is not None:
+            raise VtError("decode_fwd_ids: precision 'f16f8' covers lattice slabs only (ops.f16f8_covers); use 'f16x3'")
+        check(_lib.load().vt_decode_fwd_f16f8(gptr, B, D, C, N, nx, box, first, None, dev_ptr(_c(ids), "ids", U8), dev_ptr(feats, "feats"),
+                                              feats.shape[0], dev_ptr(blob, "blob"), float(padding), dev_ptr(out, "out"), stream_ptr()),
+              "vt_decode_fwd_f16f8")
+        return out
     if precision in SPLIT_PRECISIONS:
         name = "vt_decode_fwd_" + precision
         check(getattr(_lib.load(), name)(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first, None,
