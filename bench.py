@@ -77,11 +77,15 @@ def launch_ranks(n, argv):
 # pieces
 # ---------------------------------------------------------------------------------------------------------------------
 
-def cpu_baseline(sd, grid_cpu, nx, budget_s=15.0):
-    """The oracle (a port, not the reference itself) timed on the host cores on a
-    bounded sample: whole 100k-point chunks of the same lattice until ~budget_s."""
+def cpu_baseline(scene, nx, budget_s=15.0):
+    """The oracle (a port, not the reference itself) timed on the host cores: the decode metric on a bounded sample -- whole
+    100k-point chunks of the same lattice until ~budget_s -- and, beside it, the other two stages of the scene on the same
+    inputs (encode / decode in 100k chunks / C marching cubes): the PointNet + UNet3D encode of the bench cloud
+    (median of 3) and oracle/mc_lewiner.c on the oracle's own 128^3 logit grid of a coarser lattice pass (median of 3)."""
+    import numpy as np
     import torch
     from oracle import vtaco_oracle as orc
+    sd, grid_cpu = scene["sd_decoder_cpu"], scene["grid_cpu"]
     # torch's CPU kernels on 100k x 32 operands stop scaling (and then collapse) beyond a few
     # tens of threads; use what the host has, capped at 32, and report that number as `cores`
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
@@ -95,8 +99,35 @@ def cpu_baseline(sd, grid_cpu, nx, budget_s=15.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "query-points/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{done} of {nx ** 3} lattice points in 100k-point chunks, oracle/vtaco_oracle.py (torch CPU f32)"}
+    res = {"value": done / dt, "unit": "query-points/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{done} of {nx ** 3} lattice points in 100k-point chunks, oracle/vtaco_oracle.py (torch CPU f32)"}
+    stages = {}
+    try:
+        enc = scene["model"].encoder
+        if enc is not None:
+            esd = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                orc.pointnet_encoder_forward(esd, scene["cloud"], 64)
+                ts.append(time.perf_counter() - t0)
+            stages["encode_pointnet_unet3d_ms"] = 1e3 * sorted(ts)[1]
+        stages["decode_lattice_ms_extrapolated"] = 1e3 * dt * nx ** 3 / done
+        from oracle import mc as omc
+        vol = scene.get("logits_cpu")                                      # the GPU's logit grid of this scene (same surface)
+        if vol is not None:
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                v, f = omc.marching_cubes(np.ascontiguousarray(vol))[:2]
+                ts.append(time.perf_counter() - t0)
+            stages["marching_cubes_ms"] = 1e3 * sorted(ts)[1]
+            stages["marching_cubes_note"] = f"oracle/mc_lewiner.c, one thread, {len(v)} vertices / {len(f)} faces"
+        stages["threads_torch"] = torch.get_num_threads()
+    except Exception as e:                                                 # noqa: BLE001 -- the decode baseline stands on its own
+        stages["error"] = f"{type(e).__name__}: {e}"[:300]
+    res["stages_ms"] = stages
+    return res
 
 
 def mesh_extract_stats(vol, nx, runs=100):
@@ -291,47 +322,60 @@ def sharded_scene(scene, dev, fx, rank, world, dist, precision, sizes=(128, 256)
         one(True)
         torch.cuda.synchronize()
         st = [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
+        per_rank = None
+        if world > 1:
+            # every rank's stage times in the line: a sub-linear curve can then be read without a re-run
+            mine = torch.tensor(st, dtype=torch.float64, device=dev if fx.backend == "nccl" else "cpu")
+            rows = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(rows, mine)
+            per_rank = [{"encode": float(r[0]), "decode_slab": float(r[1]), "all_gather": float(r[2]), "marching_cubes": float(r[3])}
+                        for r in rows]
         res[str(nx)] = {"ms_per_scene": ms, "points_per_s": total / (ms * 1e-3), "slab_points_per_rank": count,
                         "rank0_stage_ms": {"encode": st[0], "decode_slab": st[1], "all_gather": st[2], "marching_cubes": st[3]},
+                        "per_rank_stage_ms": per_rank,
                         "all_gather_bytes": 4 * total,
                         "verts": int(mesh[0].vertices.shape[0]) if rank == 0 else None}
     return res
 
 
-def train_step_section(dev, fx, rank, world, dist, steps=8):
-    """BASELINE config 4: the VTacO training step (forward + backward + gradient all-reduce + Adam) on 8 synthetic scenes x 2048
-    query points per GPU; weak scaling (global batch = 8 N: 64 scenes at N = 8).  The all-reduce's share = what the step loses
-    to it: (ms with the bucketed all-reduce) - (ms of the same step without any gradient exchange)."""
+def train_step_section(dev, fx, rank, world, dist, steps=8, scenes=8):
+    """BASELINE config 4: the VTacO training step (forward + backward + gradient all-reduce + Adam) on `scenes` synthetic scenes x
+    2048 query points per GPU; weak scaling (global batch = 8 N: 64 scenes at N = 8).  The shipped configuration: the t2d net is
+    PRETRAINED (configs/VTacO/VTacO_YCB.yaml:65; here a synthetic checkpoint loaded through the factory) and therefore not trained
+    (training.py:749-752).  Beside it: the all-reduce's share = (ms with the bucketed all-reduce) - (ms of the same step without
+    any gradient exchange); at N = 1 also the step with the t2d net trained (`pretrained: False`, what round 2 timed) and the part
+    of the step that runs on this repository's kernels (the same model's visual + hand branches alone: PointNet, voxeliser, UNet3D,
+    decoder, hand encoder forward + backward + Adam -- the tactile U-Net and Resnet18 stay host PyTorch by north_star)."""
     import numpy as np
     import torch
     from vtaco_amd.bench_util import build_train_case
-    B = 8
-    model, trainer, batch, vf = build_train_case(dev, rank, scenes=B)
+    B = scenes
+    model, trainer, batch, vf = build_train_case(dev, rank, scenes=B, pretrained_t2d=True)
     sync = trainer.grad_sync
     n_param = sum(p.numel() for p in model.parameters())
     np.random.seed(1234 + rank)
 
-    def step():
-        trainer.train_step(batch, vf)
-    t0 = time.perf_counter()
-    step()
-    torch.cuda.synchronize()
-    first_s = time.perf_counter() - t0
-    for _ in range(2):
+    def timed_steps(tr, n, warm=2):
+        def step():
+            tr.train_step(batch, vf)
+        t0 = time.perf_counter()
         step()
-
-    def timed(n):
+        torch.cuda.synchronize()
+        first_s = time.perf_counter() - t0
+        for _ in range(warm):                                           # untimed: MIOpen's find / first-touch work is over
+            step()
         fx.fence()
         t0 = time.perf_counter()
         for _ in range(n):
             step()
         fx.fence()
-        return 1e3 * fx.max_over_ranks(time.perf_counter() - t0) / n
-    ms_sync = timed(steps)
+        return 1e3 * fx.max_over_ranks(time.perf_counter() - t0) / n, first_s
+    ms_sync, first_s = timed_steps(trainer, steps)
     res = {"ms_per_step": ms_sync, "scenes_per_s": world * B / (ms_sync * 1e-3), "global_batch": world * B,
            "points_per_scene": 2048, "parameters": n_param, "allreduce_bytes": 4 * sync.numel, "first_step_s": first_s,
-           "workload": "Trainer(with_img, encode_t2d).train_step: shipped VTacO model (get_model), contact clouds from depth images, "
-                       "winding-number targets, Adam 1e-4; synthetic batch"}
+           "t2d_pretrained": True,
+           "workload": "Trainer(with_img, encode_t2d).train_step: shipped VTacO model (get_model) with the pretrained (frozen) t2d net, "
+                       "contact clouds from depth images, winding-number targets, Adam 1e-4; synthetic batch"}
     if world > 1:
         res["buckets"] = dict(sync.stats)
         # the all-reduce alone: the same buckets, nothing to overlap with
@@ -345,11 +389,24 @@ def train_step_section(dev, fx, rank, world, dist, steps=8):
         fx.fence()
         res["allreduce_alone_ms"] = 1e3 * fx.max_over_ranks(time.perf_counter() - t0) / 5
         res["allreduce_alone_GBps_per_gpu"] = 2 * (world - 1) / world * 4 * sync.numel / (res["allreduce_alone_ms"] * 1e-3) / 1e9
-        trainer.grad_sync = None
-        ms_local = timed(steps)
-        trainer.grad_sync = sync
+        # the same step with no gradient exchange at all: the hooks are switched off too (they would launch the buckets)
+        with sync.no_sync():
+            ms_local, _ = timed_steps(trainer, steps, warm=1)
         res["ms_per_step_without_allreduce"] = ms_local
         res["allreduce_share"] = max(0.0, (ms_sync - ms_local) / ms_sync)
+    else:
+        try:
+            from vtaco_amd.conv_onet.training import Trainer
+            vis = Trainer(model, trainer.optimizer, device=dev, input_type="pointcloud", threshold=0.5, num_sample=2048,
+                          with_img=False, encode_t2d=False)
+            res["ms_hip_part"], _ = timed_steps(vis, max(2, steps // 2), warm=1)
+            res["ms_hip_part_note"] = "Trainer(with_img=False, encode_t2d=False).train_step on the same model and batch"
+        except Exception as e:                                           # noqa: BLE001
+            res["ms_hip_part_error"] = f"{type(e).__name__}: {e}"[:300]
+        del trainer, model
+        torch.cuda.empty_cache()
+        model2, trainer2, batch, vf = build_train_case(dev, rank, scenes=B, pretrained_t2d=False)
+        res["ms_per_step_t2d_trained"], _ = timed_steps(trainer2, max(2, steps // 2), warm=1)
     return res
 
 
@@ -370,6 +427,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-only", action="store_true", help="only the decode metric (perf experiments)")
     ap.add_argument("--no-train", action="store_true", help="skip the config-4 training-step section")
+    ap.add_argument("--train-scenes", type=int, default=8, help="scenes per GPU of the training-step section (config 4: 8)")
+    ap.add_argument("--train-steps", type=int, default=8, help="timed steps of the training-step section")
+    ap.add_argument("--sharded-sizes", default="128,256", help="lattice sizes of the sharded-scene section (config 5: 128,256)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction plumbing only: no kernel runs, value is null (CPU tests of --gpus N)")
     args = ap.parse_args()
@@ -521,13 +581,22 @@ def main():
     # The headline is measured; the sections below (sharded scene, training step: the multi-rank ones run collectives) must not be
     # able to lose it: an exception is recorded in the line instead of ending the run, and a rank that is still waiting in a
     # collective after EXTRAS_LIMIT_S (a peer failed) prints what it has and leaves.
-    printed = threading.Event()
+    print_lock = threading.Lock()
+    printed = [False]
+
+    def print_line_once():
+        with print_lock:
+            if rank == 0 and not printed[0]:
+                printed[0] = True
+                print(json.dumps(res), flush=True)
 
     def give_up():
-        if rank == 0 and not printed.is_set():
+        # a rank stuck in a collective (a peer died, RCCL deadlocked): the headline still goes out -- once -- and the process
+        # leaves with a NON-ZERO status, so that the launcher and the harness see the failure and not only `extras_error`
+        if rank == 0 and not printed[0]:
             res["extras_error"] = f"the sections after the headline did not finish within {EXTRAS_LIMIT_S} s"
-            print(json.dumps(res), flush=True)
-        os._exit(0)
+        print_line_once()
+        os._exit(3)
     watchdog = threading.Timer(EXTRAS_LIMIT_S, give_up)
     watchdog.daemon = True
     watchdog.start()
@@ -537,10 +606,11 @@ def main():
                 one_scene = scene
             else:
                 one_scene = build_scene(0, dev)                          # every rank the SAME scene
-            sh = sharded_scene(one_scene, dev, fx, rank, world, dist, args.precision)
+            sizes = tuple(int(v) for v in args.sharded_sizes.split(",") if v)
+            sh = sharded_scene(one_scene, dev, fx, rank, world, dist, args.precision, sizes=sizes)
             if rank == 0:
                 res["sharded_scene"] = sh
-            tr = None if args.no_train else train_step_section(dev, fx, rank, world, dist)
+            tr = None if args.no_train else train_step_section(dev, fx, rank, world, dist, steps=args.train_steps, scenes=args.train_scenes)
             if rank == 0 and tr is not None:
                 res["train_step"] = tr
         except Exception as e:                                           # noqa: BLE001 -- reported in the line
@@ -551,11 +621,11 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(scene["sd_decoder_cpu"], scene["grid_cpu"], nx)
+                scene["logits_cpu"] = out.view(nx, nx, nx).cpu().numpy()
+                res["cpu_baseline"] = cpu_baseline(scene, nx)
             except Exception as e:                                       # noqa: BLE001
                 res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:400]}
-        printed.set()
-        print(json.dumps(res), flush=True)
+        print_line_once()
     if dist is not None:
         try:
             dist.destroy_process_group()                                 # still under the watchdog: a failed peer may never arrive

@@ -117,3 +117,32 @@ def test_bench_gpus_2_starts_two_ranks_and_strong_equals_the_lattice():
         res = json.loads(lines[0])
         assert res["n_gpus"] == 2 and res["scaling"] == scaling and res["steps"] == 3 and res["value"] > 1e8
         assert res["config"]["points_per_step_per_gpu"] == (128 ** 3 // 2 if scaling == "strong" else 128 ** 3)
+
+
+def test_bench_gpus_2_runs_the_multi_rank_sections():
+    """Pre-flight of the driver's scaling run: ``bench.py --gpus 2`` WITHOUT --decode-only (two ranks sharing the one GPU over gloo,
+    small knobs) executes the sections that only exist with world > 1 -- the sharded scene's all-gather with every rank's stage
+    times, the training step's bucketed gradient all-reduce, its share -- and leaves no ``extras_error``."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.is_initialized():
+        pytest.skip("the GPU is already initialised in this process: run this file on its own (or first)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VTACO_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--train-scenes", "1", "--train-steps", "1", "--sharded-sizes", "128"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and "extras_error" not in res, res.get("extras_error")
+    sh = res["sharded_scene"]["128"]
+    assert sh["slab_points_per_rank"] == 128 ** 3 // 2 and sh["verts"] > 0
+    assert len(sh["per_rank_stage_ms"]) == 2 and all(r["decode_slab"] > 0 and r["all_gather"] > 0 for r in sh["per_rank_stage_ms"])
+    tr = res["train_step"]
+    assert tr["global_batch"] == 2 and tr["t2d_pretrained"] is True
+    assert tr["buckets"]["buckets"] >= 2 and tr["buckets"]["launched_in_backward"] + tr["buckets"]["launched_at_sync"] > 0
+    assert 0.0 <= tr["allreduce_share"] <= 1.0 and tr["ms_per_step_without_allreduce"] > 0 and tr["allreduce_alone_ms"] > 0

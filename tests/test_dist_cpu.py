@@ -113,6 +113,47 @@ def _ddp_steps(rank, world, steps=4):
     return ok and all(torch.equal(both[0], t) for t in both)
 
 
+def _accumulation_steps(rank, world):
+    """Two backward() calls per step: inside ``no_sync()`` the first one accumulates locally and the second launches the buckets
+    with the totals (the synchronised gradient is the mean over ranks of the SUM of both micro-batches, with .grad already a view
+    of its bucket from the step before); outside ``no_sync()`` the second backward raises instead of synchronising half a step."""
+    def data(r, step, micro):
+        g = torch.Generator().manual_seed(1000 * step + 10 * micro + r)
+        return torch.randn(16, 6, generator=g), torch.randn(16, generator=g)
+    torch.manual_seed(11)
+    net, ref = _Net(), _Net()
+    ref.load_state_dict(net.state_dict())
+    sync = GradAllReduce(net.parameters(), bucket_bytes=1024)
+    ok = True
+    for step in range(3):
+        net.zero_grad(set_to_none=False) if step else None
+        ref.zero_grad()
+        x, y = data(rank, step, 0)
+        with sync.no_sync():
+            torch.nn.functional.l1_loss(net(x, False), y).backward()
+        x, y = data(rank, step, 1)
+        torch.nn.functional.l1_loss(net(x, True), y).backward()
+        sync()
+        for r in range(world):
+            for micro, use_b in ((0, False), (1, True)):
+                x, y = data(r, step, micro)
+                (torch.nn.functional.l1_loss(ref(x, use_b), y) / world).backward()
+        for p, q in zip(net.parameters(), ref.parameters()):
+            want = q.grad if q.grad is not None else torch.zeros_like(q)
+            ok = ok and torch.allclose(p.grad, want, atol=1e-6, rtol=1e-5)
+    # the misuse is loud
+    net.zero_grad(set_to_none=False)
+    x, y = data(rank, 9, 0)
+    torch.nn.functional.l1_loss(net(x, False), y).backward()
+    try:
+        torch.nn.functional.l1_loss(net(x, False), y).backward()
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "no_sync" in str(e)
+    sync.remove_hooks()
+    return ok
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -141,6 +182,7 @@ def _worker(rank, world, port, q):
         ok2 = torch.allclose(a.grad, torch.full((5, 3), 1.5)) and torch.allclose(b.grad, torch.arange(7.0) * 1.5) \
             and torch.allclose(c.grad, torch.full((2, 2), 0.5))
         ok2 = ok2 and _ddp_steps(rank, world)
+        ok2 = ok2 and _accumulation_steps(rank, world)
         q.put((rank, bool(ok1), bool(ok2)))
     finally:
         dist.destroy_process_group()

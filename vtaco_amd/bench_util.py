@@ -1,6 +1,8 @@
 """Synthetic scenes for bench.py / smoke (SURVEY.md section 8d inputs)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .conv_onet.models import ConvolutionalOccupancyNetwork, decoder_dict
@@ -114,7 +116,7 @@ def icosphere(radius=0.3, level=3):
     return radius * np.stack(v), np.asarray(f, dtype=np.int32)
 
 
-def build_train_case(device, rank=0, scenes=8, num_sample=2048, n_points=8192, grad_sync=True):
+def build_train_case(device, rank=0, scenes=8, num_sample=2048, n_points=8192, grad_sync=True, pretrained_t2d=True):
     """(model, trainer, batch, vf_dict) of one rank's share of config 4: the shipped VTacO model built by ``get_model`` on a synthetic
     MANO-format asset, ``Trainer(with_img, encode_t2d)`` (compute_loss_t2d_img: contact clouds from the depth images, winding-number
     targets from the object mesh, tactile features from Resnet18, hand terms), Adam(1e-4), and a seeded synthetic batch of ``scenes``
@@ -131,6 +133,15 @@ def build_train_case(device, rank=0, scenes=8, num_sample=2048, n_points=8192, g
     cfg = vtaco_cfg(root, num_sample)
     torch.manual_seed(0)
     model = cfgmod.get_model(cfg, device=device)
+    if pretrained_t2d:
+        # the shipped configuration (configs/VTacO/VTacO_YCB.yaml:65 `pretrained: True`): the t2d net comes from a checkpoint and is
+        # not trained (training.py:749-752: its losses are dropped, its outputs reach the step detached).  The checkpoint here is a
+        # synthetic one -- the freshly initialised t2d net saved in the reference's format -- loaded through the factory's own path
+        ck = os.path.join(root, "t2d_pretrained.pt")
+        torch.save({"model": model.encoder_t2d.state_dict()}, ck)
+        cfg["model"]["encoder_t2d_kwargs"].update(pretrained=True, model_file=ck)
+        torch.manual_seed(0)
+        model = cfgmod.get_model(cfg, device=device)
     randomise_fc1(model.decoder, 1)
     randomise_fc1(model.encoder, 2)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
@@ -156,6 +167,7 @@ def build_train_case(device, rank=0, scenes=8, num_sample=2048, n_points=8192, g
     d = torch.randn(B, 5, 3, generator=g)
     verts, faces = icosphere(0.3, 3)
     batch = {"inputs": cloud, "points": (torch.rand(B, n_points, 3, generator=g) - 0.5) * 1.1,
+             "points.occ": torch.rand(B, n_points, generator=g),           # read by the visual-only step only (bench.py ms_hip_part)
              "points.mano": torch.randn(B, 51, generator=g) * 0.2, "points.pc_hand": torch.randn(B, 778, 3, generator=g) * 0.05,
              "points.name": ["ico"] * B, "points.cam_pos": (0.32 * d / d.norm(dim=-1, keepdim=True)).double(),
              "points.cam_rot": (torch.rand(B, 5, 3, generator=g) * 2 - 1).double(),

@@ -99,6 +99,12 @@ class GradAllReduce:
       when ``.grad`` already is the slice -- after a step every ``.grad`` is a view of its bucket, so with
       ``zero_grad(set_to_none=False)`` the steady state is copy-free); averaging is one multiply per bucket.
     ``overlap=False`` keeps the buckets but launches everything from ``__call__`` (one ``_foreach_copy_``).
+
+    Several ``backward()`` calls per step (gradient accumulation, two losses backpropagated one after the other): wrap all but
+    the LAST one in ``with sync.no_sync():`` -- the hooks then leave the gradients to accumulate locally and the last backward
+    launches the buckets with the totals.  A hook that finds its gradient already handed to a bucket (a second backward outside
+    ``no_sync``: the bucket's all-reduce may be in flight, and with ``.grad`` a view of the bucket autograd has just accumulated
+    into the very buffer RCCL is reducing) raises instead of synchronising half a step's gradients.
     """
 
     def __init__(self, params, group=None, bucket_bytes=20 << 20, overlap=True):
@@ -115,6 +121,7 @@ class GradAllReduce:
         self._fired = []                                         # hook order of the current backward
         self._buckets = None
         self._hooks = []
+        self._enabled = True                                     # False inside no_sync(): hooks and __call__ do nothing
         self.stats = {"buckets": 0, "launched_in_backward": 0, "launched_at_sync": 0}
         if overlap:
             for p in self.params:
@@ -167,7 +174,7 @@ class GradAllReduce:
             self._next += 1
 
     def _on_grad(self, p):
-        if not self._active():
+        if not self._enabled or not self._active():
             return
         if self._buckets is None or self._buckets[0]["flat"].device != p.device:
             self._build()
@@ -175,7 +182,8 @@ class GradAllReduce:
         b, k = self._slot[i]
         bk = self._buckets[b]
         if bk["ready"][k]:
-            return
+            raise RuntimeError("GradAllReduce: a parameter received a second gradient before grad_sync() ran -- with several "
+                               "backward() calls per step wrap all but the last one in `with grad_sync.no_sync():`")
         view = bk["views"][k]
         if p.grad.data_ptr() != view.data_ptr():
             view.copy_(p.grad)
@@ -184,9 +192,22 @@ class GradAllReduce:
         self._fired.append(i)
         self._launch_ready(True)
 
+    def no_sync(self):
+        """Context manager for every backward() of a step except the last: gradients accumulate locally, nothing is launched."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            was, self._enabled = self._enabled, False
+            try:
+                yield self
+            finally:
+                self._enabled = was
+        return ctx()
+
     # -- between backward and optimizer.step() -------------------------------------------------------------
     def __call__(self):
-        if not self._active():
+        if not self._enabled or not self._active():
             return
         if self._buckets is None or self._buckets[0]["flat"].device != self.params[0].device:
             self._build()
