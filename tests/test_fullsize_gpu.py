@@ -64,8 +64,10 @@ def test_decode_by_finger_id_256_equals_dense_on_slabs(scene, precision):
         assert bool((ids[0, mid:mid + 4 * nx * nx] != 255).any())
 
 
-def test_attention_decoder_over_a_whole_64_lattice_vs_oracle():
-    """Config 3's decoder at lattice scale: ``decoder: attention_local`` evaluates the 64^3 lattice in 128 chunks of 2048 points
+@pytest.mark.parametrize("nx,R", [(64, 32), (128, 64)])
+def test_attention_decoder_over_a_whole_lattice_vs_oracle(nx, R):
+    """Config 3's decoder at lattice scale (128^3 = BASELINE config 3 at its literal size: 1024 chunks): ``decoder: attention_local``
+    evaluates the 64^3 lattice in 128 chunks of 2048 points
     (TransformerFusion couples the points of a chunk), features by finger id; the oracle (torch CPU) re-computes eight of the
     chunks -- first, last, and the ones holding the most touched points -- from the same inputs: <= 1e-4 on the logits.
 
@@ -83,10 +85,10 @@ def test_attention_decoder_over_a_whole_64_lattice_vs_oracle():
     adec = decoder_dict['attention_local'](dim=3, c_dim=32, hidden_size=32).eval()
     randomise_fc1(adec, 3)
     g = torch.Generator().manual_seed(4)
-    grid = torch.randn(1, 32, 32, 32, 32, generator=g)
+    grid = torch.randn(1, 32, R, R, R, generator=g)
     model = ConvolutionalOccupancyNetwork(adec, None, device=DEV)
-    gen = Generator3D(model, device=DEV, resolution0=16, padding=0.1, points_batch_size=2048, with_img=True)
-    nx, chunk = 64, 2048
+    gen = Generator3D(model, device=DEV, resolution0=nx // 4, padding=0.1, points_batch_size=2048, with_img=True)
+    chunk = 2048
     tips = torch.randn(5, 1, 3, generator=g)
     tips = 0.3 * tips / tips.norm(dim=-1, keepdim=True)
     success = torch.tensor([1, 0, 1, 1, 1], dtype=torch.uint8)

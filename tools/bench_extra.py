@@ -70,8 +70,16 @@ def fusion_pass(cb=256):
 if "fusion" in SECTIONS:
     t = timed(fusion_pass, 3, 1)
     flop_pt = 30976 + 576 * N + 61440
+    tf = flop_pt * nx ** 3 / t / 1e12
     print(json.dumps({"workload": "AttentionDecoder.forward_img 128^3, chunk N=2048 (1024 chunks)", "ms": t * 1e3,
-                      "points_per_s": nx ** 3 / t, "tflops": flop_pt * nx ** 3 / t / 1e12}))
+                      "points_per_s": nx ** 3 / t, "tflops": tf,
+                      "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None,
+                                   "flop_per_point": flop_pt,
+                                   "note": "algorithmic FLOP (SURVEY.md 8d: 30 976 + 576 N + 61 440 per point at chunk size N = 2048) over the "
+                                           "wall time of the whole pass (sample, 3 attention units, MLP) against the dense 16-bit MFMA peak; "
+                                           "the kernels recompute every N x N score tile three times (row sums, column sums, attend) with "
+                                           "split operands, so the matrix pipe executes several times the algorithmic FLOP: per-kernel time "
+                                           "and counters in profiles/r03*_fusion_*"}}))
     # the same lattice through the product path: Generator3D (decoder: attention_local, points_batch_size 2048) assigning finger
     # ids to the lattice and decoding it chunk by chunk (whole chunks batched per call)
     from vtaco_amd.conv_onet.generation import Generator3D
