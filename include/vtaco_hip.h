@@ -148,6 +148,15 @@ int vt_decode_fwd_f16f8(const float *grid_cl, int B, int R, int C, int64_t N,
                         const float *c_img, const unsigned char *finger_ids, const float *finger_feats, int F,
                         const float *blob_f16f8, double padding, float *out, void *stream);
 
+/* Range guard of the half-precision decodes (vt_decode_fwd_f16x3 / _f16f8): their hi operand     */
+/* saturates at 65504 (round toward zero: never an infinity), after which the logits silently lose  */
+/* parity.  Every launch samples its relu'd hi operands (two of a lane's sixteen channels, every     */
+/* point and layer) and sets bit 0 of a per-process device word when the largest half shows up.       */
+/* vt_decode_range_status copies that word to the host (synchronises `stream`) and, with `reset`,    */
+/* clears it: the caller re-runs the affected scenes with vt_decode_fwd_bf16x3 or the exact-f32        */
+/* kernel (the host mirror's Generator3D does).  No reference counterpart: the reference is f32.        */
+int vt_decode_range_status(unsigned *host_status, int reset, void *stream);
+
 /* Tactile feature assignment and decode by finger id (SURVEY.md section 8f "next" row 2).        */
 /* Replaces: the scipy cdist + np.where glue that fills the dense c_img_all [1,N,32] at            */
 /*   src/conv_onet/generation.py:186-200 (mode 0: nearest fingertip, radius 0.05, only if that      */

@@ -194,5 +194,13 @@ def test_f16x3_large_activations_saturate_not_overflow():
     big = {k: v.clone() for k, v in sd.items()}
     big["fc_p.bias"] = big["fc_p.bias"] + 1.0e5            # pushes net_0 past 65504
     grid = torch.from_numpy(a["grid"]).to(dev)
-    got = ops.decode_fwd(grid, _blob(big, dev), lattice=(32, 1.1, 0, 32 ** 3), precision=P)
-    assert bool(torch.isfinite(got).all())
+    pts = torch.from_numpy(a["pts"]).to(dev)
+    ops.decode_range_status(reset=True)
+    ops.decode_fwd(grid, _blob(sd, dev), lattice=(32, 1.1, 0, 32 ** 3), precision=P)
+    assert ops.decode_range_status(reset=True) == 0            # ordinary activations leave the range guard alone
+    # the guard is LOUD: every f16 kernel form (slot-pipelined lattice, unaligned slab on the generic kernel, point queries) reports
+    for kw in (dict(lattice=(32, 1.1, 0, 32 ** 3)), dict(lattice=(32, 1.1, 7, 5000)), dict(pts=pts)):
+        got = ops.decode_fwd(grid, _blob(big, dev), precision=P, **kw)
+        assert bool(torch.isfinite(got).all())
+        assert ops.decode_range_status(reset=True) & 1, kw
+        assert ops.decode_range_status(reset=True) == 0        # reading with reset clears the word

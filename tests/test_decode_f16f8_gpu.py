@@ -124,9 +124,37 @@ def test_huge_activations_saturate_the_correction_instead_of_poisoning_it():
     big = dict(sd)
     big["fc_p.bias"] = sd["fc_p.bias"] + 3.0e4
     lat = (32, 1.1, 0, 32 ** 3)
+    ops.decode_range_status(reset=True)
     got = ops.decode_fwd(grid, _blob(big, dev), lattice=lat, precision="f16f8")
+    assert ops.decode_range_status(reset=True) == 0            # 3e4 is beyond the fp8 copies' range, not beyond the half range
     ref = ops.decode_fwd(grid, _blob(big, dev, precision="f32"), lattice=lat, precision="f32")
     assert torch.isfinite(got).all()
     rel = float(((got - ref).abs() / ref.abs().clamp_min(1.0)).max())
     print("f16f8 with activations ~3e4: max relative error", rel)
     assert rel <= 2e-3
+
+
+def test_the_generator_falls_back_when_the_range_guard_trips():
+    """A decoder whose hidden activations leave the half range: the launch reports it (vt_decode_range_status), the generator
+    warns, switches its lattice decode to 'bf16x3' and generates the scene again."""
+    import warnings
+    from vtaco_amd import ops
+    from vtaco_amd.bench_util import build_scene
+    from vtaco_amd.conv_onet.generation import Generator3D
+    dev = torch.device(DEV)
+    sc = build_scene(0, dev)
+    model = sc["model"]
+    with torch.no_grad():
+        model.decoder.fc_p.bias += 1.0e5
+        model.decoder.fc_out.weight *= 1e-5                       # keeps the logits (and the surface) at a sane scale
+    pc = sc["cloud"].to(dev)
+    ref = Generator3D(model, device=dev, resolution0=16, padding=0.1, decode_precision="bf16x3").generate_obj_mesh_wnf({"inputs": pc})
+    gen = Generator3D(model, device=dev, resolution0=16, padding=0.1)
+    assert gen.decode_precision == "f16f8"
+    ops.decode_range_status(reset=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        mesh = gen.generate_obj_mesh_wnf({"inputs": pc})
+    assert gen.decode_precision == "bf16x3" and any("half-precision range" in str(x.message) for x in w)
+    # the scene it hands back is the split-bf16 generator's, vertex for vertex
+    assert torch.equal(mesh.faces, ref.faces) and torch.equal(mesh.vertices, ref.vertices)

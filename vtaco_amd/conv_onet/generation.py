@@ -25,6 +25,38 @@ Mesh = namedtuple("Mesh", ["vertices", "faces"])
 _tensor_version = operator.attrgetter("_version")
 
 
+def _range_guarded(method):
+    """A generation entry point under the half-precision decodes' range guard: when the decode of this scene reported
+    activations at the edge of the half range (ops.decode_range_status; "f16x3" / "f16f8" saturate there and silently lose
+    parity), the generator switches its lattice decode to "bf16x3" (f32's exponent range) -- for good -- warns, and generates
+    the scene again.  One 4-byte read-back per scene, behind the synchronisation the mesh extraction has just done."""
+    import functools
+    import warnings
+
+    @functools.wraps(method)
+    def guarded(self, *args, **kwargs):
+        if getattr(self, "_guard_depth", 0) or self.decode_precision not in ("f16x3", "f16f8"):
+            return method(self, *args, **kwargs)
+        self._guard_depth = 1
+        try:
+            out = method(self, *args, **kwargs)
+            tripped = ops.decode_range_status(reset=True) & 1
+            if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                # sharded generation: the ranks must agree on re-running their collectives
+                t = torch.tensor([tripped], dtype=torch.int32, device=self.device if torch.distributed.get_backend() == "nccl" else "cpu")
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                tripped = int(t.item())
+            if tripped:
+                warnings.warn(f"Generator3D: hidden activations of the decoder reach the half-precision range limit (65504); "
+                              f"decode_precision {self.decode_precision!r} -> 'bf16x3' and the scene is generated again")
+                self.decode_precision = "bf16x3"
+                out = method(self, *args, **kwargs)
+            return out
+        finally:
+            self._guard_depth = 0
+    return guarded
+
+
 class Generator3D(object):
     """Constructor arguments as the reference (generation.py:42-52)."""
 
@@ -160,9 +192,16 @@ class Generator3D(object):
                 for _ in range(2):                      # warm-up: fills every cache / workspace outside the capture
                     run(*static)
             torch.cuda.current_stream().wait_stream(side)
+            # the stamps the entry is valid for are taken AFTER the warm-up (a module that bumps a buffer's version during its
+            # forward would otherwise look changed at every call and be captured again each time) ...
+            stamps = self._weight_stamps()
             graph = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(graph):
                 out = run(*static)
+            # ... and must not move while the graph is recorded: a capture that changes a weight cannot be replayed safely
+            if self._weight_stamps() != stamps:
+                raise VtError("Generator3D: the model's parameters or buffers changed while its launches were being captured; "
+                              "set scene_graph = False for models whose forward updates state")
         self._graphs[key] = {"graph": graph, "in": static, "out": out, "keep": list(keep), "stamps": stamps}
         return self._graphs[key]
 
@@ -199,8 +238,11 @@ class Generator3D(object):
         return False
 
     def _replay(self, kind, tensors, run):
-        """``run(*tensors)`` through a captured graph per (kind, shapes) when ``self.scene_graph`` is on: the result lives in the
-        graph's static buffers (valid until the next replay of the same key).  Plain call otherwise."""
+        """``run(*tensors)`` through a captured graph per (kind, shapes) when ``self.scene_graph`` is on.  LIFETIME of the result:
+        it lives in the graph's static buffers -- the next replay of the same (kind, shapes) overwrites it in place, and the entry
+        can be evicted (MAX_SCENE_GRAPHS, least recently used) -- so it is for use within the current scene; a caller that keeps
+        encoder outputs across scenes (``c`` of one cloud next to the ``c`` of another of the same shape) clones them.  The
+        generator's own entry points consume the result before they return.  Plain call otherwise."""
         key = (kind,) + tuple(tuple(t.shape) for t in tensors)
         if not self._graphs_allowed() or not self._worth_capturing(key):
             with torch.no_grad():
@@ -211,6 +253,7 @@ class Generator3D(object):
         g["graph"].replay()
         return g["out"]
 
+    @_range_guarded
     def generate_mesh_graphed(self, inputs):
         """Same result as ``generate_obj_mesh_wnf({'inputs': inputs})`` for the visual branch, with the
         ~110 launches of encode + decode + marching-cubes classification replayed as one hipGraph
@@ -224,6 +267,7 @@ class Generator3D(object):
         verts, faces, _ = ops.mc_emit(g["vol"], g["ws"], rescale=(nx / 2, (1 + self.padding) / nx))
         return Mesh(verts, faces)
 
+    @_range_guarded
     def generate_obj_mesh_sharded(self, data, group=None):
         """``generate_obj_mesh_wnf`` with the lattice split over the ranks of a process group (one process per GPU):
         every rank encodes the scene (cheap, deterministic: no broadcast), decodes its slab of x-plane pairs with no
@@ -253,6 +297,7 @@ class Generator3D(object):
                                                       device=self.device)
         return self.extract_mesh(values.reshape(nx, nx, nx))
 
+    @_range_guarded
     def generate_obj_mesh_tactile(self, data, finger_feats, anchors, success, mode='within', radius=None, count=None):
         """Tactile branch of ``generate_obj_mesh_wnf`` (generation.py:159-257) without the dense
         ``c_img_all [1,nx^3,C]`` tensor and its CPU cdist glue: every lattice point gets the id of the finger whose
@@ -364,6 +409,7 @@ class Generator3D(object):
         v = (v - centroid.double()) / (2.0 * m.double())
         return Mesh(v, c_hand['mano_faces'])
 
+    @_range_guarded
     def generate_obj_mesh_wnf(self, data, c_img_all=None):
         """Encode -> dense decode -> marching cubes for one scene; ``data['inputs']`` is the
         point cloud [1,T,3].  Returns Mesh(vertices [V,3] f32, faces [F,3] i32) on the device."""

@@ -29,7 +29,7 @@ namespace {
 // c: the sampled features in gather layout (register s of lane-half h = channel 16h+s).
 template <bool SAVE, int P>
 __device__ __forceinline__ void mlp_and_heads(const DecodeArgs &a, const float *L, const f32x16 &c, float px, float py, float pz,
-                                              uint32_t g, bool live, int lane, int h, bool with_img) {
+                                              uint32_t g, bool live, int lane, int h, bool with_img, unsigned &rmax) {
     const size_t slot = (size_t)a.total * 32;           // one saved tensor
     float *srow = SAVE ? a.save + (size_t)g * 32 : nullptr;
     if (SAVE && live) store_gather16(srow, c, h);        // slot 0: c
@@ -71,11 +71,13 @@ __device__ __forceinline__ void mlp_and_heads(const DecodeArgs &a, const float *
             // same accumulation order as the two-brick kernel: net + cond(k-step 0) + bias + cond(k-step 1) + fc_1(..),
             // the conditioning MFMAs placed where the VALU is busy splitting relu(net) / relu(hid)
             const SplitP<P> sn = split16<true, P>(net);
+            if constexpr (P == 2) range_track(rmax, __builtin_bit_cast(u32x4, sn.hi[0])[0]);
             if (i < 4) net = dense32s_half<P>(net, wl + 2048, cs, lane, 0);
             const f32x16 bb = load_frag16(L + VT_OFF_BIAS + (2 + 2 * i) * 32 + h * 16);
             net = net + bb;
             hid = dense32s<P>(hid, wl, sn, lane);
             const SplitP<P> sh = split16<true, P>(hid);
+            if constexpr (P == 2) range_track(rmax, __builtin_bit_cast(u32x4, sh.hi[0])[0]);
             if (i < 4) net = dense32s_half<P>(net, wl + 2048, cs, lane, 1);
             net = dense32s<P>(net, wl + 1024, sh, lane);
         }
@@ -156,6 +158,7 @@ decode_fwd_kernel(DecodeArgs a) {
         w_idx = (blockIdx.x >> 3) * WPB + wave;
         w_cnt = (gridDim.x >> 3) * WPB;
     }
+    unsigned rmax = 0;                                                   // range guard (decode_common.h)
     for (uint32_t tile = t_begin + w_idx; tile < t_end; tile += w_cnt) {
         // Re-derive the LDS base every tile behind an opaque asm so the (loop-invariant)
         // weight reads are not hoisted out of the tile loop into ~120 extra VGPRs.
@@ -220,8 +223,9 @@ decode_fwd_kernel(DecodeArgs a) {
             pin16(c);
             __builtin_amdgcn_sched_barrier(0);
         }
-        mlp_and_heads<SAVE, P>(a, L, c, px, py, pz, g, live, lane, h, with_img);
+        mlp_and_heads<SAVE, P>(a, L, c, px, py, pz, g, live, lane, h, with_img, rmax);
     }
+    if constexpr (P == 2) range_report(rmax, a.status);
 }
 
 // ---- lattice decode with the gather staged through LDS -------------------------------------
@@ -329,6 +333,7 @@ decode_fwd_staged_kernel(DecodeArgs a) {
         for (int k = 0; k < 6; ++k) pre[k] = *reinterpret_cast<const f32x4 *>(base + src_off[k]);
     };
 
+    unsigned rmax = 0;                                                   // range guard (decode_common.h)
     uint32_t tile = t_begin + w_idx;
     if (tile < t_end) fetch(tile, ox, oy, oz);
     for (; tile < t_end; tile += w_cnt) {
@@ -383,8 +388,9 @@ decode_fwd_staged_kernel(DecodeArgs a) {
         // ---- next tile's footprint goes into flight before this tile's MLP ----
         if (tile + w_cnt < t_end) fetch(tile + w_cnt, ox, oy, oz);
 
-        mlp_and_heads<false, P>(a, L, c, px, py, pz, g, true, lane, h, with_img);
+        mlp_and_heads<false, P>(a, L, c, px, py, pz, g, true, lane, h, with_img, rmax);
     }
+    if constexpr (P == 2) range_report(rmax, a.status);
 }
 
 // ---- two bricks per wave (split-bf16 lattice: visual-only, tactile concat, finger ids) -------------
@@ -540,6 +546,7 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
     };
     const auto ones = make_ones();
 
+    unsigned rmax = 0;                                                   // range guard (decode_common.h)
     uint32_t tile = t_begin + w_idx;
     if (tile < t_end) fetch(tile, ox, oy, oz);
     for (; tile < t_end; tile += w_cnt) {
@@ -654,6 +661,8 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
                     // split-f16: relu + split reads net directly (two instructions per value); the conditioning and
                     // bias MFMAs may only overwrite net once the split has read it
                     SplitP<Q> sA = split16<true, Q>(netA), sB = split16<true, Q>(netB);
+                    range_track(rmax, __builtin_bit_cast(u32x4, sA.hi[0])[0]);
+                    range_track(rmax, __builtin_bit_cast(u32x4, sB.hi[0])[0]);
                     asm volatile("" : "+v"(sA.hi[0]), "+v"(sA.hi[1]), "+v"(sA.lo[0]), "+v"(sA.lo[1]));
                     asm volatile("" : "+v"(sB.hi[0]), "+v"(sB.hi[1]), "+v"(sB.lo[0]), "+v"(sB.lo[1]));
                     if constexpr (COND) dense32s2_half<Q>(netA, netB, wl + 2048, csA, csB, lane, 0);
@@ -664,6 +673,8 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
                     if constexpr (COND) dense32s2_half<Q>(netA, netB, wl + 2048, csA, csB, lane, 1);
                     sA = split16<true, Q>(hidA);
                     sB = split16<true, Q>(hidB);
+                    range_track(rmax, __builtin_bit_cast(u32x4, sA.hi[0])[0]);
+                    range_track(rmax, __builtin_bit_cast(u32x4, sB.hi[0])[0]);
                     dense32s2<Q>(netA, netB, wl + 1024, sA, sB, lane);
                 }
             };
@@ -697,6 +708,7 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
             if (h == 0) { a.out[gA] = accA + ob; a.out[gB] = accB + ob; }
         }
     }
+    if constexpr (P == 2) range_report(rmax, a.status);
 }
 
 }  // namespace
@@ -939,6 +951,19 @@ __global__ void __launch_bounds__(256) grid_from_cl_kernel(const float *src, flo
 // decode_f16.hip with VT_DECODE_F16_TU and -fno-slp-vectorize, as decode_f16.o (vt_decode_fwd_f16x3 only).
 // =====================================================================================
 #ifndef VT_DECODE_F16_TU
+// ---- range guard of the half-precision decodes: one device word per process ----
+static unsigned *g_decode_status = nullptr;
+unsigned *vt_decode_status_dev() {
+    if (!g_decode_status) {
+        // first use: an allocation (the packers call this too, so that it never falls into a stream capture)
+        unsigned *p = nullptr;
+        if (hipMalloc(&p, 16) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 16) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        g_decode_status = p;
+    }
+    return g_decode_status;
+}
+
 extern "C" {
 
 size_t vt_decoder_blob_bytes(int hidden, int c_dim, int n_blocks) {
@@ -979,6 +1004,7 @@ int vt_decoder_pack_bf16x3(const vt_decoder_params *p, float *blob, size_t blob_
 int vt_decoder_pack_f16x3(const vt_decoder_params *p, float *blob, size_t blob_bytes, void *stream) {
     const int rc = vt_decoder_pack(p, blob, blob_bytes, stream);
     if (rc) return rc;
+    (void)vt_decode_status_dev();
     PackArgs a;
     a.p = *p;
     a.blob = blob;
@@ -990,12 +1016,24 @@ int vt_decoder_pack_f16x3(const vt_decoder_params *p, float *blob, size_t blob_b
 int vt_decoder_pack_f16f8(const vt_decoder_params *p, float *blob, size_t blob_bytes, void *stream) {
     const int rc = vt_decoder_pack(p, blob, blob_bytes, stream);
     if (rc) return rc;
+    (void)vt_decode_status_dev();
     PackArgs a;
     a.p = *p;
     a.blob = blob;
     a.split = 3;
     hipLaunchKernelGGL(decoder_pack_kernel, dim3(17), dim3(1024), 0, (hipStream_t)stream, a);
     return vt_check(hipGetLastError(), "vt_decoder_pack_f16f8");
+}
+
+int vt_decode_range_status(unsigned *host_status, int reset, void *stream) {
+    if (!host_status) return vt_fail(VT_ERR_INVALID, "vt_decode_range_status: null argument");
+    unsigned *d = vt_decode_status_dev();
+    if (!d) return vt_fail(VT_ERR_INVALID, "vt_decode_range_status: no device memory for the status word");
+    hipError_t e = hipMemcpyAsync(host_status, d, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return vt_check(e, "vt_decode_range_status");
+    if (reset && *host_status) return vt_fill32(d, 0u, sizeof(unsigned), (hipStream_t)stream);
+    return 0;
 }
 
 int vt_grid_to_channels_last(const float *src, float *dst, int B, int C, int D, int H, int W, void *stream) {
@@ -1067,6 +1105,7 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
     if (N == 0) return 0;
     if ((int64_t)B * N >= (int64_t)1 << 31) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd: B*N must be < 2^31");
     DecodeArgs a;
+    a.status = (P == 2) ? vt_decode_status_dev() : nullptr;
     a.c_direct = c_direct; a.grid = grid_cl; a.pts = pts; a.brick = 0; a.cimg_ids = cimg_ids; a.cimg_table = cimg_table; a.c_img = c_img; a.blob = blob; a.out = out; a.out2 = out2; a.save = save;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box;
@@ -1176,6 +1215,7 @@ int vt_decode_fwd_f16f8(const float *grid_cl, int B, int R, int C, int64_t N, in
         return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd_f16f8: covers lattice slabs of whole x-plane pairs with nx % 8 == 0 and < 0.55 voxels per "
                                            "step (vt_decode_f16f8_covers); use vt_decode_fwd_f16x3 otherwise");
     DecodeArgs a;
+    a.status = vt_decode_status_dev();
     a.c_direct = nullptr; a.grid = grid_cl; a.pts = nullptr; a.brick = 1; a.cimg_ids = finger_ids; a.cimg_table = finger_ids ? finger_feats : nullptr;
     a.c_img = c_img; a.blob = blob_f16f8; a.out = out; a.out2 = nullptr; a.save = nullptr;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
@@ -1249,6 +1289,7 @@ int vt_sample_grid(const float *grid_cl, int B, int R, int C, const float *pts, 
     if (N == 0) return 0;
     if ((int64_t)B * N >= (int64_t)1 << 31) return vt_fail(VT_ERR_UNSUPPORTED, "vt_sample_grid: B*N must be < 2^31");
     DecodeArgs a;
+    a.status = nullptr;
     a.c_direct = nullptr; a.brick = 0; a.cimg_ids = nullptr; a.cimg_table = nullptr; a.grid = grid_cl; a.pts = pts; a.c_img = nullptr; a.blob = nullptr; a.out = nullptr; a.out2 = nullptr; a.save = nullptr;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box; a.divisor = (float)(1.0 + padding + 10e-4);

@@ -146,6 +146,20 @@ __device__ __forceinline__ SplitP<P> split16(const f32x16 &x) {
     return r;
 }
 
+// ---- range guard of the split-f16 layers ----------------------------------------------------------------------------
+// hi = v_cvt_pkrtz_f16_f32(v) saturates at 65504 for |v| >= 65504 (round toward zero never produces an infinity): the layers
+// then silently lose parity.  Every relu + split hands its FIRST hi pair (two of a lane's sixteen channels, all points, all
+// layers) to a running unsigned maximum (one v_pk_max_u16 per split: the values are >= 0 after the relu); a wave that ends
+// with the largest half in it sets bit 0 of the status word (vt_decode_range_status).  A sample, not a proof: a network whose
+// activations leave the half range does so on whole channels and regions, not on one value.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void range_track(unsigned &rmax, unsigned hi_pair) {
+    rmax = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, rmax), __builtin_bit_cast(u16x2, hi_pair)));
+}
+__device__ __forceinline__ void range_report(unsigned rmax, unsigned *status) {
+    if (status != nullptr && ((rmax & 0xffffu) >= 0x7bffu || (rmax >> 16) >= 0x7bffu)) atomicOr(status, 1u);
+}
+
 // wl: the layer's LDS image [part: hi, lo][k-step 0,1][lane] x 16 bytes
 template <int P>
 __device__ __forceinline__ f32x16 dense32s(f32x16 acc, const float *wl, const SplitP<P> &x, int lane) {
@@ -213,6 +227,7 @@ struct DecodeArgs {
     int nx;
     float box;
     float divisor;       // 1 + padding + 10e-4
+    unsigned *status;    // device word of the range guard (bit 0: a half-precision operand saturated), or null
 };
 
 

@@ -123,11 +123,12 @@ __device__ __forceinline__ void pack_to(SpT<V> &s, float l0, float l1) {
 // Inside a step no instruction sits behind its producer closer than the hardware wants (each miss is a wait state): this pair's two
 // differences, the next pair's conversion and relu, the fp8 copy, the pack; scheduling barriers keep that order.
 template <int V, bool RELU, int K>
-__device__ __forceinline__ void split_step(SpT<V> &s, const f32x16 &x, float m1) {
+__device__ __forceinline__ void split_step(SpT<V> &s, const f32x16 &x, float m1, unsigned &rmax) {
     if constexpr (K == 0) {
         head_a<V, RELU, 0>(s, x);
         head_a<V, RELU, 1>(s, x);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (RELU) range_track(rmax, s.hi[0][0]);          // the range guard's sample (decode_common.h)
         head_b<V, 0>(s);
     } else if constexpr (K == 7) {
         float a0, a1, b0, b1;
@@ -151,8 +152,10 @@ __device__ __forceinline__ void split_step(SpT<V> &s, const f32x16 &x, float m1)
 template <int V, bool RELU>
 __device__ __forceinline__ SpT<V> split_all(const f32x16 &x, float m1) {
     SpT<V> s;
-    split_step<V, RELU, 0>(s, x, m1); split_step<V, RELU, 1>(s, x, m1); split_step<V, RELU, 2>(s, x, m1); split_step<V, RELU, 3>(s, x, m1);
-    split_step<V, RELU, 4>(s, x, m1); split_step<V, RELU, 5>(s, x, m1); split_step<V, RELU, 6>(s, x, m1); split_step<V, RELU, 7>(s, x, m1);
+    unsigned unused = 0;
+    split_step<V, RELU, 0>(s, x, m1, unused); split_step<V, RELU, 1>(s, x, m1, unused); split_step<V, RELU, 2>(s, x, m1, unused);
+    split_step<V, RELU, 3>(s, x, m1, unused); split_step<V, RELU, 4>(s, x, m1, unused); split_step<V, RELU, 5>(s, x, m1, unused);
+    split_step<V, RELU, 6>(s, x, m1, unused); split_step<V, RELU, 7>(s, x, m1, unused);
     return s;
 }
 
@@ -165,8 +168,8 @@ static_assert(ST3_CHUNKS - 64 * ST3_PIECES == 8, "the last LDS-DMA piece is eigh
 #define ST3_M(acc, w, x) do { acc = mfma_h(w, x, acc); ST3_GAP(); } while (0)   /* the MFMA opens its gap */
 #define ST3_Q(acc, w, x) do { acc = mfma_q(w, x, acc); ST3_GAP(); } while (0)   /* fp8 correction MFMA (V = 2) */
 #define ST3_RUN_BLOCKS() do { _Pragma("unroll 1") for (int i = 0; i < 4; ++i) block(i, std::true_type{}); block(4, std::false_type{}); } while (0)
-#define ST3_S(dst, src, k) split_step<V, true, k>(dst, src, m1)      /* step k of a relu + split */
-#define ST3_C(dst, src, k) split_step<V, false, k>(dst, src, m1)     /* step k of a plain split (the sampled features) */
+#define ST3_S(dst, src, k) split_step<V, true, k>(dst, src, m1, rmax)   /* step k of a relu + split */
+#define ST3_C(dst, src, k) split_step<V, false, k>(dst, src, m1, rmax)  /* step k of a plain split (the sampled features) */
 
 template <int V>
 __global__ void __launch_bounds__(ST3_THREADS)
@@ -292,6 +295,7 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
         ones = __builtin_bit_cast(u32x4, o);
     }
     const float m1 = opaque_minus_one();
+    unsigned rmax = 0;                                                   // range guard: largest sampled hi half of this wave
 
     uint32_t tile = t_begin + w_idx;
     if (tile < t_end) fetch(tile, ox, oy, oz);
@@ -418,6 +422,7 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
             ST3_RUN_BLOCKS();
         }
     }
+    range_report(rmax, a.status);
 }
 
 #undef ST3_GAP

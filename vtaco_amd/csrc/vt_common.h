@@ -35,6 +35,8 @@ static_assert((VT_OFF_WPI) * 4 <= 65536, "visual-only fragments must sit below t
 int vt_fail(int code, const char *msg);
 int vt_check(hipError_t e, const char *where);
 int vt_num_cus();
+// the device word of the half-precision decodes' range guard (decode_common.h; read by vt_decode_range_status), allocated at first use
+unsigned *vt_decode_status_dev();
 // capture-safe replacement of hipMemsetAsync (memset nodes misbehaved under hipGraph replay on ROCm 7.0/7.2):
 // fills `bytes` (multiple of 4) at `dst` with the 32-bit pattern
 int vt_fill32(void *dst, unsigned pattern, size_t bytes, hipStream_t stream);

@@ -34,78 +34,94 @@ class Field:
         raise NotImplementedError
 
 
+def _subdirs(folder):
+    return [d for d in os.listdir(folder) if d and os.path.isdir(os.path.join(folder, d))]
+
+
+def _category_table(root, categories):
+    """{category: {'id', 'name', 'idx'}}: metadata.yaml where the dataset has one, placeholders otherwise; ``idx`` is the
+    category's position in ``categories`` (what the fields receive as their third argument)."""
+    meta_file = os.path.join(root, 'metadata.yaml')
+    if os.path.exists(meta_file):
+        with open(meta_file) as fh:
+            table = yaml.safe_load(fh)
+    else:
+        table = {c: {'id': c, 'name': 'n/a'} for c in categories}
+    for position, c in enumerate(categories):
+        table[c]['idx'] = position
+    return table
+
+
+def _models_of(root, category, split):
+    """Model names of one category: every sub-directory, or the lines of ``<split>.lst`` minus ONE empty entry (the reference
+    removes exactly one, core.py:88-89; a file with several blank lines keeps the rest, and so does this)."""
+    folder = os.path.join(root, category)
+    if not os.path.isdir(folder):
+        log.warning('Category %s does not exist in dataset.', category)
+    if split is None:
+        return _subdirs(folder)
+    with open(os.path.join(folder, split + '.lst')) as fh:
+        names = fh.read().split('\n')
+    if '' in names:
+        names.remove('')
+    return names
+
+
+def _flatten(name, value, sample):
+    """A field's value into the flat sample: arrays as float32 under ``name`` (the unnamed entry) or ``name.key``; the model's
+    name string stays a string."""
+    if not isinstance(value, dict):
+        sample[name] = value
+        return
+    for key, item in value.items():
+        if key is None:
+            sample[name] = item.astype(np.float32)
+        else:
+            sample[f'{name}.{key}'] = item if key == 'name' else item.astype(np.float32)
+
+
 class Shapes3dDataset(tdata.Dataset):
-    """``Shapes3dDataset(dataset_folder, fields, split, categories, no_except, transform, cfg)``
-    (core.py:34-141).  Crop / sliding-window mode (``input_type: pointcloud_crop``) is not built: no
-    shipped VTacO config uses it."""
+    """``Shapes3dDataset(dataset_folder, fields, split, categories, no_except, transform, cfg)``: the reference's dataset class
+    (src/data/core.py:34-183) over the layout in this module's header -- same constructor, same samples, same draw order.
+    Crop / sliding-window mode (``input_type: pointcloud_crop``) is not built: no shipped VTacO config uses it."""
 
     def __init__(self, dataset_folder, fields, split=None, categories=None, no_except=True, transform=None, cfg=None):
-        self.dataset_folder, self.fields = dataset_folder, fields
-        self.no_except, self.transform, self.cfg = no_except, transform, cfg
         if cfg is not None and cfg.get('data', {}).get('input_type') == 'pointcloud_crop':
             raise NotImplementedError("Shapes3dDataset: input_type 'pointcloud_crop' is not built")
-        if categories is None:
-            categories = [c for c in os.listdir(dataset_folder) if os.path.isdir(os.path.join(dataset_folder, c))]
-        meta_path = os.path.join(dataset_folder, 'metadata.yaml')
-        if os.path.exists(meta_path):
-            with open(meta_path) as fh:
-                self.metadata = yaml.safe_load(fh)
-        else:
-            self.metadata = {c: {'id': c, 'name': 'n/a'} for c in categories}
-        for c_idx, c in enumerate(categories):
-            self.metadata[c]['idx'] = c_idx
-        self.models = []
-        for c in categories:
-            sub = os.path.join(dataset_folder, c)
-            if not os.path.isdir(sub):
-                log.warning('Category %s does not exist in dataset.', c)
-            if split is None:
-                names = [d for d in os.listdir(sub) if d != '' and os.path.isdir(os.path.join(sub, d))]
-            else:
-                with open(os.path.join(sub, split + '.lst')) as fh:
-                    names = fh.read().split('\n')
-                if '' in names:
-                    names.remove('')                  # the reference drops ONE empty entry (core.py:88-89)
-            self.models += [{'category': c, 'model': m} for m in names]
+        self.dataset_folder, self.fields = dataset_folder, fields
+        self.no_except, self.transform, self.cfg = no_except, transform, cfg
+        categories = _subdirs(dataset_folder) if categories is None else categories
+        self.metadata = _category_table(dataset_folder, categories)
+        self.models = [{'category': c, 'model': m} for c in categories for m in _models_of(dataset_folder, c, split)]
 
     def __len__(self):
         return len(self.models)
 
     def __getitem__(self, idx):
-        category, model = self.models[idx]['category'], self.models[idx]['model']
-        c_idx = self.metadata[category]['idx']
-        model_path = os.path.join(self.dataset_folder, category, model)
+        entry = self.models[idx]
+        folder = os.path.join(self.dataset_folder, entry['category'], entry['model'])
+        category_index = self.metadata[entry['category']]['idx']
         sample = {}
         for name, field in self.fields.items():
             try:
-                value = field.load(model_path, idx, c_idx)
+                _flatten(name, field.load(folder, idx, category_index), sample)
             except Exception:
-                if self.no_except:
-                    log.warning('Error occured when loading field %s of model %s', name, model)
-                    return None
-                raise
-            if isinstance(value, dict):
-                for k, v in value.items():
-                    if k is None:
-                        sample[name] = v.astype(np.float32)
-                    elif k == 'name':
-                        sample['%s.%s' % (name, k)] = v
-                    else:
-                        sample['%s.%s' % (name, k)] = v.astype(np.float32)
-            else:
-                sample[name] = value
-        if self.transform is not None:
-            sample = self.transform(sample)
-        return sample
+                if not self.no_except:
+                    raise
+                # the reference swallows a broken sample and lets collate_remove_none drop it (core.py:154-164)
+                log.warning('Error occured when loading field %s of model %s', name, entry['model'])
+                return None
+        return sample if self.transform is None else self.transform(sample)
 
     def get_model_dict(self, idx):
         return self.models[idx]
 
     def test_model_complete(self, category, model):
-        files = os.listdir(os.path.join(self.dataset_folder, category, model))
+        folder = os.path.join(self.dataset_folder, category, model)
+        present = os.listdir(folder)
         for name, field in self.fields.items():
-            if not field.check_complete(files):
-                log.warning('Field "%s" is incomplete: %s', name, os.path.join(self.dataset_folder, category, model))
+            if not field.check_complete(present):
+                log.warning('Field "%s" is incomplete: %s', name, folder)
                 return False
         return True
 

@@ -168,11 +168,19 @@ class UNet3D(nn.Module):
         # the 16^3-class levels; "bf16x3" = split-bf16 operands on all of those (6.6e-5 abs on the golden grid, 4e-5 on
         # the decoded logits); "f32" = exact-f32 matrix core everywhere.  Training (host autograd) is unaffected.
         self.precision = os.environ.get("VTACO_UNET_PRECISION", "f16x3")
-        # the differentiable HIP path (forward_channels_last_train): "f16x3" = split-f16 forward convs (f32-rounding-level
-        # error) and data-gradient convs (input rescaled by a power of two), exact-f32 weight gradients; "f32" = everything exact f32; "bf16x3" = split-bf16 forward and data
-        # gradient (at random init this network's gradients move by ~1 % (L2) under a 1e-6 input perturbation -- ReLU /
-        # max-pool decisions -- and the 2e-5 deviations of the split-bf16 form flip more of them, ~2 %)
+        # the differentiable HIP path (forward_channels_last_train): "f16x3" (the default) = split-f16 forward, data-gradient
+        # (input rescaled by a power of two) AND weight-gradient convolutions -- all three at f32 accumulation-order level against
+        # the exact-f32 kernels (tests/test_unet3d_gpu.py; VTACO_UNET_WGRAD_PRECISION=f32 keeps the exact-f32 weight gradient);
+        # "f32" = everything on the exact-f32 matrix core; "bf16x3" = split-bf16 forward and data gradient (at random init this
+        # network's gradients move by ~1 % (L2) under a 1e-6 input perturbation -- ReLU / max-pool decisions -- and the 2e-5
+        # deviations of the split-bf16 form flip more of them, ~2 %).  Settable per model: the constructor's ``train_precision`` /
+        # ``precision`` keywords (``unet3d_kwargs`` in the config), then these attributes, then the environment.
         self.train_precision = os.environ.get("VTACO_UNET_TRAIN_PRECISION", "f16x3")
+        for key in ("precision", "train_precision"):            # model-level setting (config: model.encoder_kwargs.unet3d_kwargs)
+            if kwargs.get(key) is not None:
+                if kwargs[key] not in ("f32", "bf16x3", "f16x3"):
+                    raise ValueError(f"UNet3D: {key} must be 'f32', 'bf16x3' or 'f16x3' (got {kwargs[key]!r})")
+                setattr(self, key, kwargs[key])
         self.final_activation = (nn.Sigmoid() if final_sigmoid else nn.Softmax(dim=1)) if is_segmentation else None
 
     # ---- HIP inference path (channels-last, vt_conv3d_gcr) ------------------------------

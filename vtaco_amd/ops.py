@@ -120,6 +120,14 @@ def pack_decoder(fc_p_w, fc_p_b, fc_c, blocks, fc_out, fc_out2=None, out=None, t
     return out
 
 
+def decode_range_status(reset=True):
+    """Bit 0: a half-precision lattice decode ("f16x3" / "f16f8") since the last reset met activations at the edge of the half
+    range (its hi operand saturated at 65504: the logits of those launches are not to be trusted).  Synchronises the stream."""
+    word = ctypes.c_uint32(0)
+    check(_lib.load().vt_decode_range_status(ctypes.byref(word), int(bool(reset)), stream_ptr()), "vt_decode_range_status")
+    return int(word.value)
+
+
 def is_channels_last_grid(grid):
     """True if ``grid`` [B,C,D,H,W] is laid out b,z,y,x,c in memory."""
     B, C, D, H, W = grid.shape
