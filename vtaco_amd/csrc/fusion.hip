@@ -18,6 +18,7 @@
 // Score tiles come out of the MFMA with the fixed index on the lane and the streamed index
 // in the 16 registers, which is exactly the B operand the next MFMA (E x V') needs.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "fusion_common.h"
 
@@ -68,16 +69,63 @@ __device__ __forceinline__ f32x16 score_tile(const FragQK &stream, const FragQK 
     return acc;
 }
 
+// ---- inference: the correction product on ONE fp8 MFMA ("f16f8", as the lattice decode's layers: decode_st3.h) ----------------
+// Keys rounded to half as above; the queries' remainder q_lo enters as fp8 (e4m3) against an fp8 copy of k_hi:
+//     S = q_hi . k_hi  (4 x v_mfma_f32_32x32x16_f16)  +  2^-18 fp8(q_lo 2^14) . fp8(k_hi 2^4)  (1 x v_mfma_scale_f32_32x32x64_f8f6f4)
+// 192 matrix cycles per 32 x 32 x 64 tile instead of 256 and ~30 % less matrix-pipe energy (tools/probe/shape_probe.hip); the
+// correction is 2^-11 of the score and carries 4 significant bits -- far below the rounding of the keys.  Both fp8 vectors are
+// written ONCE by the projection kernel.  Row (192 B): [kg 2][hi: k-step t 4 x 8 halves | fp8: 32 bytes, byte 8t + e], column
+// = 16t + 8kg + e; Q rows carry fp8(q_lo 2^14), K rows fp8(k_hi 2^4).
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+constexpr int F8_QL = 14, F8_KH = 4;                  // power-of-two shifts of the two fp8 vectors
+struct FragQK8 {
+    f16x8 hi[4];
+    u32x8 q;
+};
+__device__ __forceinline__ void load_fragqk8(FragQK8 &f, const void *rowbase, int kg) {
+    const f16x8 *r = reinterpret_cast<const f16x8 *>(reinterpret_cast<const char *>(rowbase) + kg * 96);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f.hi[t] = r[t];
+    const u32x4 a = __builtin_bit_cast(u32x4, r[4]), b = __builtin_bit_cast(u32x4, r[5]);
+    f.q = u32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+template <int SHIFT>
+__device__ __forceinline__ f32x16 mfma_f8(const u32x8 &a, const u32x8 &b, f32x16 c) {       // c += 2^-SHIFT a8 . b8
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_bit_cast(i32x8, a), __builtin_bit_cast(i32x8, b), c, 0, 0,
+                                                           0, 127 - SHIFT, 0, 127);
+}
+__device__ __forceinline__ f32x16 score_tile8(const FragQK8 &stream, const FragQK8 &fixed) {
+    f32x16 acc;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = mfma_s(stream.hi[t], fixed.hi[t], acc);
+    return mfma_f8<F8_QL + F8_KH>(stream.q, fixed.q, acc);
+}
+// MODE.FP16_OVFL = 1: the fp8 conversions saturate at +-448 instead of producing NaN (hwreg MODE = 1, bit 23)
+// four values / scale as fp8 (e4m3) bytes 0..3 of a dword
+__device__ __forceinline__ unsigned fp8x4(float a, float b, float c, float d, float scale) {
+    i16x2 w;
+    asm volatile("" : "=v"(w));                          // both halves are written below: nothing to initialise
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, a, b, scale, false);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, c, d, scale, true);
+    return __builtin_bit_cast(unsigned, w);
+}
+__device__ __forceinline__ void fp8_saturating_mode() { __builtin_amdgcn_s_setreg((1 - 1) << 11 | 23 << 6 | 1, 1); }
+
 // ---- projections on the f32 matrix core: one wave per 32 points -------------------------------
 // D[out][point] += W[out][k] X^T[k][point] for up to five 32-row groups (Q: 2, K: 2, V: 1).  The rows of
 // the Q/K groups are permuted so that registers 0..7 / 8..15 of lane-half h hold 8 consecutive
 // output columns (16(2g + r/8) + 8h + r%8): exactly one hi and one lo fragment of the split row
 // layout above, written with 16-byte stores.  V keeps the natural order (store_acc16).
 constexpr int PROJ_TILES = 8;
-template <bool DO_Q, bool DO_KV>
+template <bool DO_Q, bool DO_KV, bool F8>
 __global__ void __launch_bounds__(256)
 fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd, float *Kd, float *V, int total) {
     __shared__ __attribute__((aligned(16))) float wf[5][16][64];          // [group][k-step][lane] A fragments
+    if constexpr (F8) fp8_saturating_mode();
     for (int e = threadIdx.x; e < 5 * 1024; e += 256) {
         const int g = e >> 10, st = (e >> 6) & 15, l = e & 63, i = l & 31, kk = l >> 5, k = 2 * st + kk;
         // output row i of the MFMA <-> accumulator register r of lane-half hh with chan_of(r,hh) == i
@@ -117,13 +165,42 @@ fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd,
         for (int s = 0; s < 16; ++s) acc = mfma(wf[g][s][lane], x[s], acc);
         return acc;
     };
-    auto store_unit = [&](const f32x16 &a0, const f32x16 &a1, float *dst, float post) {
+    auto store_unit = [&](const f32x16 &a0, const f32x16 &a1, float *dst, float post, bool is_q) {
         float ss = 0.0f;
 #pragma unroll
         for (int s = 0; s < 16; ++s) { ss = fmaf(a0[s], a0[s], ss); ss = fmaf(a1[s], a1[s], ss); }
         ss += __shfl_xor(ss, 32);
         const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);                     // F.normalize(p=2, eps=1e-12)
         if (!live) return;
+        if constexpr (F8) {
+            // 192-byte rows: per kg four hi fragments and the 32 fp8 bytes (Q: the remainders, K: a copy of the halves)
+            f16x8 *row = reinterpret_cast<f16x8 *>(reinterpret_cast<char *>(dst) + (size_t)p * 192 + h * 96);
+            u32x8 q8;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x16 &a = g ? a1 : a0;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int t = 2 * g + half;
+                    f16x8 hi;
+                    float w[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = (a[8 * half + e] * inv) * post;
+                        const _Float16 hb = (_Float16)v;
+                        hi[e] = hb;
+                        w[e] = is_q ? v - (float)hb : (float)hb;               // what the fp8 vector carries
+                    }
+                    const float sc = is_q ? 1.0f / (float)(1 << F8_QL) : 1.0f / (float)(1 << F8_KH);
+                    q8[2 * t] = fp8x4(w[0], w[1], w[2], w[3], sc);
+                    q8[2 * t + 1] = fp8x4(w[4], w[5], w[6], w[7], sc);
+                    row[t] = hi;
+                }
+            }
+            reinterpret_cast<u32x4 *>(row)[4] = u32x4{q8[0], q8[1], q8[2], q8[3]};
+            reinterpret_cast<u32x4 *>(row)[5] = u32x4{q8[4], q8[5], q8[6], q8[7]};
+            return;
+        }
         f16x8 *row = reinterpret_cast<f16x8 *>(dst + (size_t)p * 64);            // 16 fragments of 8 halves
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -148,12 +225,12 @@ fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd,
     if (DO_Q) {
         load_x(Xq, x);
         const f32x16 q0 = project(x, 0), q1 = project(x, 1);
-        store_unit(q0, q1, Qd, 1.44269504088896341f);
+        store_unit(q0, q1, Qd, 1.44269504088896341f, true);
     }
     if (DO_KV) {
         if (!DO_Q || Xk != Xq) load_x(Xk, x);
         const f32x16 k0 = project(x, 2), k1 = project(x, 3);
-        store_unit(k0, k1, Kd, 1.0f);
+        store_unit(k0, k1, Kd, 1.0f, false);
         const f32x16 v = project(x, 4);
         if (live) store_acc16(V + (size_t)p * 32, v, h);
     }
@@ -227,6 +304,62 @@ fusion_expsum_kernel(const float *Fd, const float *Sd, const float *w, float *ou
     if (lane < 32 && f0 + lane < N) out[(size_t)b * N + f0 + lane] = recip_out ? 1.0f / sum : sum;
 }
 
+// ---- the same passes on the fp8-corrected tiles (inference) ----
+constexpr int SROW8 = 52;                                   // 192-B row + 16 B pad: conflict-free ds_read_b128 (13 slots per row)
+constexpr int STILE8 = 32 * SROW8;
+// cooperative copy of one 32 x 192-B tile: 384 16-byte pieces, threads 0..383
+__device__ __forceinline__ f32x4 tile_fetch8(const float *base, int row0, int N) {
+    const int i = threadIdx.x, r = i / 12, c = i - 12 * r;
+    return *reinterpret_cast<const f32x4 *>(base + (size_t)min(row0 + r, N - 1) * 48 + c * 4);
+}
+__device__ __forceinline__ void tile_store8(float *tile, const f32x4 &t) {
+    const int i = threadIdx.x, r = i / 12, c = i - 12 * r;
+    *reinterpret_cast<f32x4 *>(tile + r * SROW8 + c * 4) = t;
+}
+
+__global__ void __launch_bounds__(FT)
+fusion_expsum8_kernel(const float *Fd, const float *Sd, const float *w, float *out, int N, int recip_out) {
+    __shared__ __attribute__((aligned(16))) float tiles[2][STILE8];
+    __shared__ __attribute__((aligned(16))) float wt[2][32];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int f0 = blockIdx.x * FROWS + wave * 32;
+    Fd += (size_t)b * N * 48; Sd += (size_t)b * N * 48;
+    if (w) w += (size_t)b * N;
+    FragQK8 fixed;
+    load_fragqk8(fixed, Fd + (size_t)min(f0 + j, N - 1) * 48, h);
+    const int ntile = (N + 31) / 32;
+    const bool mover = threadIdx.x < 384;
+    f32x4 tr;
+    float wreg = 0.0f;
+    auto fetch = [&](int t) {
+        if (mover) tr = tile_fetch8(Sd, t * 32, N);
+        if (threadIdx.x < 32) { const int i = t * 32 + threadIdx.x; wreg = (i < N) ? (w ? w[i] : 1.0f) : 0.0f; }
+    };
+    fetch(0);
+    if (mover) tile_store8(tiles[0], tr);
+    if (threadIdx.x < 32) wt[0][threadIdx.x] = wreg;
+    __syncthreads();
+    float sum = 0.0f;
+    for (int t = 0; t < ntile; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntile) fetch(t + 1);
+        FragQK8 stream;
+        load_fragqk8(stream, tiles[cur] + j * SROW8, h);
+        const f32x16 sc = score_tile8(stream, fixed);
+        const f32x16 ww = load_acc16(wt[cur], h);               // w of streamed row chan_of(r,h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum = fmaf(exp2_unit(sc[r]), ww[r], sum);
+        if (t + 1 < ntile) {
+            if (mover) tile_store8(tiles[cur ^ 1], tr);
+            if (threadIdx.x < 32) wt[cur ^ 1][threadIdx.x] = wreg;
+        }
+        __syncthreads();
+    }
+    sum += __shfl_xor(sum, 32);
+    if (lane < 32 && f0 + lane < N) out[(size_t)b * N + f0 + lane] = recip_out ? 1.0f / sum : sum;
+}
+
 // V' = V / (1e-9 + s) per key, split and laid out as the A operand of E x V':
 // VT[b][tile][c][kg][part][k-step 2][e 8] bf16 with key = 32 tile + chan_of(8 step + e, kg) -- the
 // key order of the score accumulator -- and zeros for keys >= N.  One thread per (b, tile, c, kg, step).
@@ -252,41 +385,124 @@ fusion_scalev_kernel(const float *V, const float *s, float *VT, int N, int ntile
     }
 }
 
+// The same for the fp8-corrected E x V' (inference): V' as half + remainder; per (b, tile, c, kg) 64 bytes = [hi: k-step 0, 1 x 8 halves |
+// fp8: bytes j < 16 = V'_lo 2^10 of key chan_of(j, kg), bytes 16 + j = V'_hi of the same key] against E's [E_hi 2^4 | E_lo 2^14]
+// (fusion_attend8_kernel), result times 2^-14.  V' beyond the half range saturates (a key no query attends to: s ~ 0).
+constexpr int F8_VL = 10, F8_EH = 4, F8_EL = 14;           // V'_lo 2^10 . E_hi 2^4  and  V'_hi 2^0 . E_lo 2^14: both 2^14
+__global__ void __launch_bounds__(256)
+fusion_scalev8_kernel(const float *V, const float *s, float *VT, int N, int ntile, size_t total) {
+    fp8_saturating_mode();
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int kg = (int)(idx & 1), c = (int)((idx >> 1) & 31);
+        const size_t bt = idx >> 6;
+        const int tile = (int)(bt % ntile);
+        const size_t b = bt / ntile;
+        float hi[16], lo[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * tile + chan_of(r, kg);
+            float v = (key < N) ? V[(b * N + key) * 32 + c] / (1e-9f + s[b * N + key]) : 0.0f;
+            v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+            const _Float16 hb = (_Float16)v;
+            hi[r] = (float)hb;
+            lo[r] = v - (float)hb;
+        }
+        u32x4 *row = reinterpret_cast<u32x4 *>(VT) + ((bt * 32 + c) * 2 + kg) * 4;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            f16x8 f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (_Float16)hi[8 * st + e];
+            row[st] = __builtin_bit_cast(u32x4, f);
+        }
+        const float sl = 1.0f / (float)(1 << F8_VL);
+        row[2] = u32x4{fp8x4(lo[0], lo[1], lo[2], lo[3], sl), fp8x4(lo[4], lo[5], lo[6], lo[7], sl),
+                       fp8x4(lo[8], lo[9], lo[10], lo[11], sl), fp8x4(lo[12], lo[13], lo[14], lo[15], sl)};
+        row[3] = u32x4{fp8x4(hi[0], hi[1], hi[2], hi[3], 1.0f), fp8x4(hi[4], hi[5], hi[6], hi[7], 1.0f),
+                       fp8x4(hi[8], hi[9], hi[10], hi[11], 1.0f), fp8x4(hi[12], hi[13], hi[14], hi[15], 1.0f)};
+    }
+}
+
 // attention output + RelationUnit tail + TransNonlinear + residual: Z = X_q + LN(...)
 constexpr int VROW = 36;                                    // V' tile row: 128 B + 16 B pad
 // TRAIN: the attention output O is kept for the backward and TransNonlinear's two dropouts are applied (masks: drop_mask).
 // FULL: all three products of the scores (see score_tile)
-template <bool TRAIN, bool FULL>
+// F8: the inference form on fp8-corrected tiles (score_tile8; E x V' as V'_hi E_hi on two f16 MFMAs + one fp8 MFMA for both
+// correction products: fusion_scalev8_kernel)
+template <bool TRAIN, bool FULL, bool F8>
 __global__ void __launch_bounds__(FT)
 fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const float *linv, const float *Xq,
                      const float *blob, float *Z, int N, int ntile_, float *Osave, DropCfg dc) {
+    static_assert(!(F8 && (TRAIN || FULL)), "the fp8-corrected tiles are the inference form");
     __shared__ __attribute__((aligned(16))) float lds[FU_BLOB];
-    __shared__ __attribute__((aligned(16))) float tiles[2][STILE];
+    __shared__ __attribute__((aligned(16))) float tiles[2][F8 ? STILE8 : STILE];
     __shared__ __attribute__((aligned(16))) float vts[2][32 * VROW];
     for (int i = threadIdx.x; i < FU_BLOB; i += FT) lds[i] = blob[i];
+    if constexpr (F8) fp8_saturating_mode();
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
     const int q0 = blockIdx.x * FROWS + wave * 32;
     const int ntile = ntile_;
-    Qd += (size_t)b * N * 64; Kd += (size_t)b * N * 64; VT += (size_t)b * ntile * 1024;
-    FragQK fixed;
-    load_fragqk(fixed, Qd + (size_t)min(q0 + j, N - 1) * 64, h);
+    constexpr int RS = F8 ? 48 : 64;                                     // floats per Q / K row
+    Qd += (size_t)b * N * RS; Kd += (size_t)b * N * RS; VT += (size_t)b * ntile * 1024;
+    typename std::conditional<F8, FragQK8, FragQK>::type fixed;
+    if constexpr (F8) load_fragqk8(fixed, Qd + (size_t)min(q0 + j, N - 1) * RS, h);
+    else load_fragqk(fixed, Qd + (size_t)min(q0 + j, N - 1) * RS, h);
     f32x16 o;
 #pragma unroll
     for (int s = 0; s < 16; ++s) o[s] = 0.0f;
     f32x4 tr, vreg;
     const int vc = (threadIdx.x & 255) >> 3, vk = (threadIdx.x & 7) * 4;   // V' tile piece: channel row, 16-B column
+    const bool mover = !F8 || threadIdx.x < 384;
     auto fetch = [&](int t) {
-        tr = tile_fetch(Kd, t * 32, N);
+        if constexpr (F8) { if (mover) tr = tile_fetch8(Kd, t * 32, N); }
+        else tr = tile_fetch(Kd, t * 32, N);
         if (threadIdx.x < 256) vreg = *reinterpret_cast<const f32x4 *>(VT + (size_t)t * 1024 + threadIdx.x * 4);
     };
+    auto put = [&](int buf) {
+        if constexpr (F8) { if (mover) tile_store8(tiles[buf], tr); }
+        else tile_store(tiles[buf], tr);
+        if (threadIdx.x < 256) *reinterpret_cast<f32x4 *>(vts[buf] + vc * VROW + vk) = vreg;
+    };
     fetch(0);
-    tile_store(tiles[0], tr);
-    if (threadIdx.x < 256) *reinterpret_cast<f32x4 *>(vts[0] + vc * VROW + vk) = vreg;
+    put(0);
     __syncthreads();
+    const float m1 = opaque_minus_one();
     for (int t = 0; t < ntile; ++t) {
         const int cur = t & 1;
         if (t + 1 < ntile) fetch(t + 1);
+        if constexpr (F8) {
+            FragQK8 stream;
+            load_fragqk8(stream, tiles[cur] + j * SROW8, h);
+            f32x16 e = score_tile8(stream, fixed);                          // lane (q,h) reg r: key 32t+chan_of(r,h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = exp2_unit(e[r]);
+            // E = E_hi (halves, round toward zero) + E_lo; fp8 copies [E_hi 2^4 | E_lo 2^14] for the correction MFMA
+            u32x4 eh[2];
+            u32x8 eq;
+#pragma unroll
+            for (int p = 0; p < 8; p += 2) {
+                const unsigned ha = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e[2 * p], e[2 * p + 1]));
+                const unsigned hb = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e[2 * p + 2], e[2 * p + 3]));
+                eh[p >> 2][p & 3] = ha;
+                eh[p >> 2][(p & 3) + 1] = hb;
+                const f16x2 fa = __builtin_bit_cast(f16x2, ha), fb = __builtin_bit_cast(f16x2, hb);
+                const float l0 = __builtin_fmaf((float)fa[0], m1, e[2 * p]), l1 = __builtin_fmaf((float)fa[1], m1, e[2 * p + 1]);
+                const float l2 = __builtin_fmaf((float)fb[0], m1, e[2 * p + 2]), l3 = __builtin_fmaf((float)fb[1], m1, e[2 * p + 3]);
+                i16x2 w;
+                asm volatile("" : "=v"(w));
+                w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, fa, 1.0f / (float)(1 << F8_EH), false);
+                w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, fb, 1.0f / (float)(1 << F8_EH), true);
+                eq[p >> 1] = __builtin_bit_cast(unsigned, w);
+                eq[4 + (p >> 1)] = fp8x4(l0, l1, l2, l3, 1.0f / (float)(1 << F8_EL));
+            }
+            // O^T[c][q] += V'[c][k] E[k][q]: A operand lane (c,kg): [hi k-step 0 | hi k-step 1 | fp8 32 B]
+            const u32x4 *vp = reinterpret_cast<const u32x4 *>(vts[cur] + j * VROW) + h * 4;
+            const u32x4 v2 = vp[2], v3 = vp[3];
+            o = mfma_s(__builtin_bit_cast(f16x8, vp[0]), __builtin_bit_cast(f16x8, eh[0]), o);
+            o = mfma_s(__builtin_bit_cast(f16x8, vp[1]), __builtin_bit_cast(f16x8, eh[1]), o);
+            o = mfma_f8<F8_EL>(u32x8{v2[0], v2[1], v2[2], v2[3], v3[0], v3[1], v3[2], v3[3]}, eq, o);
+        } else {
         FragQK stream;
         load_fragqk(stream, tiles[cur] + j * SROW, h);
         f32x16 e = score_tile<true, FULL>(stream, fixed);                  // lane (q,h) reg r: key 32t+chan_of(r,h)
@@ -302,10 +518,8 @@ fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const fl
             o = mfma16(vh, es.lo[s], o);
             o = mfma16(vh, es.hi[s], o);
         }
-        if (t + 1 < ntile) {
-            tile_store(tiles[cur ^ 1], tr);
-            if (threadIdx.x < 256) *reinterpret_cast<f32x4 *>(vts[cur ^ 1] + vc * VROW + vk) = vreg;
         }
+        if (t + 1 < ntile) put(cur ^ 1);
         __syncthreads();
     }
     const int q = min(q0 + j, N - 1);
@@ -472,33 +686,53 @@ void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const fl
     const int P = B * N, Npad = (N + 31) / 32 * 32;
     const int ntile = (N + 31) / 32;
     const dim3 pg((P + 128 * PROJ_TILES - 1) / (128 * PROJ_TILES)), tg((N + FROWS - 1) / FROWS, B);
+    // the training forward keeps every product (its backward recomputes the scores on the f32 core); inference runs the
+    // fp8-corrected tiles (keys rounded to half, the queries' remainder and both E x V' corrections on fp8 MFMAs) unless
+    // VTACO_FUSION_SCORE_TERMS is set: 3 = all three half products, 2 = the half-pair form with rounded keys (round 2's)
+    static const char *env_terms = getenv("VTACO_FUSION_SCORE_TERMS");
+    const bool full = Osave != nullptr || (env_terms && env_terms[0] == '3');
+    // (chunks of fewer than 512 points keep the half-pair form: with few keys the fp8 corrections' errors do not average out --
+    // 8e-5 on the fused features at N = 33 against 4e-5, 1.4e-5 against 1.7e-5 at N = 2048; tools/probe/fusion_ragged_err.py)
+    const bool f8 = !full && N >= 512 && !(env_terms && env_terms[0] == '2');
     if (Xq == Xk) {
-        hipLaunchKernelGGL((fusion_proj_kernel<true, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
+        if (f8) hipLaunchKernelGGL((fusion_proj_kernel<true, true, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
+        else hipLaunchKernelGGL((fusion_proj_kernel<true, true, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
+    } else if (f8) {
+        hipLaunchKernelGGL((fusion_proj_kernel<true, false, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
+        hipLaunchKernelGGL((fusion_proj_kernel<false, true, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
     } else {
-        hipLaunchKernelGGL((fusion_proj_kernel<true, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
-        hipLaunchKernelGGL((fusion_proj_kernel<false, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
+        hipLaunchKernelGGL((fusion_proj_kernel<true, false, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
+        hipLaunchKernelGGL((fusion_proj_kernel<false, true, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
     }
-    // the training forward keeps every product (its backward recomputes the scores on the f32 core); inference rounds the keys
-    // unless VTACO_FUSION_SCORE_TERMS=3
-    static const bool env_full = getenv("VTACO_FUSION_SCORE_TERMS") && getenv("VTACO_FUSION_SCORE_TERMS")[0] == '3';
-    const bool full = Osave != nullptr || env_full;
-    if (full) {
-        hipLaunchKernelGGL((fusion_expsum_kernel<true, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1);   // 1/l_q
-        hipLaunchKernelGGL((fusion_expsum_kernel<false, true>), tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0);       // s_k
+    if (f8) {
+        hipLaunchKernelGGL(fusion_expsum8_kernel, tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1);                // 1/l_q
+        hipLaunchKernelGGL(fusion_expsum8_kernel, tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0);                    // s_k
+    } else if (full) {
+        hipLaunchKernelGGL((fusion_expsum_kernel<true, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1);
+        hipLaunchKernelGGL((fusion_expsum_kernel<false, true>), tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0);
     } else {
         hipLaunchKernelGGL((fusion_expsum_kernel<true, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1);
         hipLaunchKernelGGL((fusion_expsum_kernel<false, false>), tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0);
     }
-    const size_t tot = (size_t)B * ntile * 128;                      // (b, tile, c, kg, k-step)
-    size_t g = (tot + 255) / 256;
-    if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(fusion_scalev_kernel, dim3((unsigned)g), dim3(256), 0, s, w.V, w.s, w.VT, N, ntile, tot);
+    if (f8) {
+        const size_t tot = (size_t)B * ntile * 64;                   // (b, tile, c, kg)
+        size_t g = (tot + 255) / 256;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(fusion_scalev8_kernel, dim3((unsigned)g), dim3(256), 0, s, w.V, w.s, w.VT, N, ntile, tot);
+    } else {
+        const size_t tot = (size_t)B * ntile * 128;                  // (b, tile, c, kg, k-step)
+        size_t g = (tot + 255) / 256;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(fusion_scalev_kernel, dim3((unsigned)g), dim3(256), 0, s, w.V, w.s, w.VT, N, ntile, tot);
+    }
     if (Osave)
-        hipLaunchKernelGGL((fusion_attend_kernel<true, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
+        hipLaunchKernelGGL((fusion_attend_kernel<true, true, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
     else if (full)
-        hipLaunchKernelGGL((fusion_attend_kernel<false, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
+        hipLaunchKernelGGL((fusion_attend_kernel<false, true, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
+    else if (f8)
+        hipLaunchKernelGGL((fusion_attend_kernel<false, false, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
     else
-        hipLaunchKernelGGL((fusion_attend_kernel<false, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
+        hipLaunchKernelGGL((fusion_attend_kernel<false, false, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
     if (N <= 128 * IN_ROWS) hipLaunchKernelGGL(fusion_inorm_relu_cached_kernel, dim3(B), dim3(1024), 0, s, w.Z, out, N);
     else hipLaunchKernelGGL(fusion_inorm_relu_kernel, dim3(B), dim3(1024), 0, s, w.Z, out, N);
 }
