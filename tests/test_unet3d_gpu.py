@@ -401,3 +401,34 @@ def test_final_conv_in_the_last_layers_epilogue(monkeypatch):
         monkeypatch.setenv("VTACO_UNET_FUSED_FINAL", "1")
         got = enc(pc)["grid"]
     assert float((got - ref).abs().max()) <= 5e-6 * float(ref.abs().max()) and not torch.equal(got, ref)
+
+
+def test_groupnorm_statistics_through_accumulator_rows(monkeypatch):
+    """vt_unet3d_fwd with the GroupNorm statistics in integer accumulator rows that the consumer's workgroups reduce in their
+    prologue (GnOut / GnIn, the default where every layer is on a split kernel) against the finalising launches
+    (VTACO_GN_FOLD=0): same result to float rounding of the scale / shift, bit-identical from run to run (the accumulators
+    do not depend on the order of arrival), and a NaN in the input does to the output what it does through the launches."""
+    for R, levels, B, seed in ((64, 3, 1, 3), (32, 4, 2, 4), (16, 3, 3, 5)):
+        net = _unet(32, levels, seed).to(DEV)
+        g = torch.Generator().manual_seed(seed)
+        x = (torch.randn(B, R, R, R, 32, generator=g) * (torch.rand(B, R, R, R, 1, generator=g) < 0.05)).to(DEV)
+        with torch.no_grad():
+            for prec in ("f16x3", "bf16x3"):
+                net.precision = prec
+                monkeypatch.setenv("VTACO_GN_FOLD", "0")
+                ref = net.forward_channels_last(x).clone()
+                monkeypatch.setenv("VTACO_GN_FOLD", "1")
+                got = net.forward_channels_last(x).clone()
+                again = net.forward_channels_last(x)
+                assert torch.equal(got, again), (R, prec)
+                err = float((got - ref).abs().max())
+                assert err <= 2e-6 * max(1.0, float(ref.abs().max())), (R, levels, prec, err)
+            bad = x.clone()
+            bad[B - 1, 3, 4, 5, 6] = float("nan")
+            got_bad = net.forward_channels_last(bad).clone()         # the scene's non-finite flag stands in for the NaN sums
+            monkeypatch.setenv("VTACO_GN_FOLD", "0")
+            ref_bad = net.forward_channels_last(bad)
+            assert torch.equal(torch.isnan(got_bad), torch.isnan(ref_bad))
+            assert torch.allclose(got_bad, ref_bad, rtol=0.0, atol=2e-6 * max(1.0, float(ref.abs().max())), equal_nan=True)
+            if B > 1:
+                assert torch.equal(got_bad[0], got[0])

@@ -35,6 +35,166 @@ __device__ __forceinline__ float src_at(const Src &s, int b, int z, int y, int x
     return s.low[((((size_t)b * D2 + (z >> 1)) * H2 + (y >> 1)) * W2 + (x >> 1)) * s.C2 + (c - s.C1)];
 }
 
+// ---- GroupNorm statistics without a finalising launch ---------------------------------------------------------------
+// vt_unet3d_fwd runs 14 normalised convolutions; a finalising launch in front of each (gn_finalize_kernel: ~5 us of
+// dependent-launch latency around a microsecond of work) was 70 us of a 0.67 ms encoder.  Here the producer of a tensor
+// adds its workgroup's (sum, sumsq) to a few accumulator rows (GnOut) and every workgroup of the consumer reduces those
+// rows to the layer's scale / shift table in LDS during its prologue (GnIn) -- no launch, no ticket, no tail.
+//   * The accumulators are integers: a workgroup's float sum t enters as trunc(t * 2^40) split into its low 32 bits and
+//     the rest, each added to its own 64-bit cell -- exact for |t| >= 2^-17, overflow-free below 2^45 per 1024 arrivals --
+//     so the total does not depend on the order of arrival: replays are bit-identical.
+//   * One cell group per ATOM of 4 adjacent channels (summed exactly, as integers, before the atomics) and per row; a
+//     workgroup adds to row (its index mod rows).  Device-scope atomics on one address retire at ~50 ns each (measured:
+//     1024 arrivals on one address stretched a 9 us kernel to 60 us), so rows = arrivals / 8.
+//   * (An earlier form had the last-arriving workgroup finalise behind a ticket: the ticket's own serialisation and the
+//     three dependent round trips at the tail cost what the launch did.)
+//   * A non-finite workgroup sum raises the scene's flag and the consumer's scale / shift come out NaN, as in float.
+struct GnOut {
+    unsigned long long *acc = nullptr;              // [B][rows][C/4][sum, sumsq][low word, high part]; null: not collected
+    unsigned *flag = nullptr;                       // [B] non-finite flag
+    int C = 0, rows = 1;                            // rows: a power of two
+};
+struct GnIn {                                       // the virtual concat [src 0 | upsample(src 1)]; src 1 optional
+    const unsigned long long *acc[2] = {nullptr, nullptr};
+    const unsigned *flag[2] = {nullptr, nullptr};
+    int C[2] = {0, 0}, rows[2] = {1, 1};
+    const float *gamma = nullptr, *beta = nullptr;
+    int groups = 1;
+    float eps = 0.0f;
+    double count = 0.0;                             // voxels per scene at the consumer's resolution
+};
+
+constexpr int GN_ATOM = 4;
+constexpr int GN_MAX_CIN = 512;                                     // channels a consumer's table holds (= HB_MAX_CIN)
+constexpr size_t GN_SCRATCH_BYTES = (size_t)(GN_MAX_CIN / GN_ATOM) * 4 * 8 + 64 * 2 * 8;
+__host__ __device__ inline size_t gn_acc_words(int B, int rows, int C) { return (size_t)B * rows * (C / GN_ATOM) * 4; }
+
+// wave 0 of a workgroup, all 64 lanes: lane = channel * 2 + {sum, sumsq} of the channels [c0, c0 + 32) of scene b
+__device__ __forceinline__ void gn_out_add(const GnOut &o, int b, unsigned wg, int c0, float tsum) {
+    const int lane = threadIdx.x & 63;
+    const bool finite = fabsf(tsum) <= 3.0e38f;                     // false for NaN
+    const double v = finite ? (double)tsum * 0x1p40 : 0.0;          // exact
+    const double h = floor(v * 0x1p-32);
+    long long hi = (long long)h;
+    unsigned long long lo = (unsigned long long)(v - h * 0x1p32);   // in [0, 2^32): what lies below 2^-40 is dropped
+#pragma unroll
+    for (int x = 2; x <= 4; x <<= 1) { hi += __shfl_xor(hi, x); lo += __shfl_xor(lo, x); }     // the atom's 4 channels, exactly
+    if (__builtin_amdgcn_ballot_w64(!finite) && lane == 0) atomicOr(o.flag + b, 1u);
+    if ((lane & 6) == 0) {
+        const int A = o.C / GN_ATOM, row = (int)(wg & (unsigned)(o.rows - 1));
+        unsigned long long *d = o.acc + ((((size_t)b * o.rows + row) * A + (c0 >> 2) + (lane >> 3)) * 2 + (lane & 1)) * 2;
+        atomicAdd(d, lo);
+        atomicAdd(d + 1, (unsigned long long)hi);
+    }
+}
+
+__device__ __forceinline__ double gn_cell_value(long long hi, unsigned long long lo) {
+    return ((double)hi * 0x1p32 + (double)lo) * 0x1p-40;
+}
+
+// Every thread of the workgroup (nthr of them): ssl[c] = pre * (scale, shift) of the consumer's channels for scene b, in two steps.
+// gn_in_request asks for everything that comes from global memory (the rows, the flags, gamma / beta) at once -- ONE round trip (with
+// the loads where they are used it was three, and cost a workgroup more than the finalising launch had) -- and the caller may put
+// its own first requests behind it; gn_in_finish reduces in LDS and ends with a barrier.  scratch: GN_SCRATCH_BYTES of LDS nobody
+// else touches during the call.  LDS_ONLY: the barriers wait for LDS traffic only (a caller with vector-memory requests in flight
+// that must stay in flight).  The arithmetic after the sums is gn_finalize_kernel's.
+template <int GN_PRE>                                               // row words a thread keeps in flight (the rest, if any, are read late)
+struct GnReq { unsigned long long w[GN_PRE]; float gm[2], bt[2]; unsigned bad; };
+
+template <int GN_PRE>
+__device__ __forceinline__ GnReq<GN_PRE> gn_in_request(const GnIn &in, int b, int tid, int nthr) {
+    GnReq<GN_PRE> r;
+    const int A0 = in.C[0] / GN_ATOM, A1 = in.acc[1] ? in.C[1] / GN_ATOM : 0, Ct = in.C[0] + (in.acc[1] ? in.C[1] : 0);
+    const int n0 = in.rows[0] * A0 * 4, n = n0 + in.rows[1] * A1 * 4;
+    const unsigned long long *base0 = in.acc[0] + (size_t)b * n0, *base1 = A1 ? in.acc[1] + (size_t)b * (n - n0) : nullptr;
+#pragma unroll
+    for (int k = 0; k < GN_PRE; ++k) {
+        const int i = tid + k * nthr;
+        r.w[k] = i < n0 ? base0[i] : (i < n ? base1[i - n0] : 0ull);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = tid + k * nthr;
+        r.gm[k] = c < Ct ? in.gamma[c] : 0.0f;
+        r.bt[k] = c < Ct ? in.beta[c] : 0.0f;
+    }
+    r.bad = tid < in.groups ? (in.flag[0][b] | (in.flag[1] ? in.flag[1][b] : 0u)) : 0u;
+    return r;
+}
+
+template <bool LDS_ONLY>
+__device__ __forceinline__ void gn_barrier() {
+    if (LDS_ONLY) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);                         // lgkmcnt(0) alone
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    } else __syncthreads();
+}
+
+template <bool LDS_ONLY, int GN_PRE>
+__device__ __forceinline__ void gn_in_finish(const GnIn &in, const GnReq<GN_PRE> &r, int b, float pre, float *ssl, void *scratch, int tid, int nthr) {
+    unsigned long long *cell = reinterpret_cast<unsigned long long *>(scratch);     // [atom of the concat][sum, sumsq][low, high]
+    const int A0 = in.C[0] / GN_ATOM, A1 = in.acc[1] ? in.C[1] / GN_ATOM : 0, Ct = in.C[0] + (in.acc[1] ? in.C[1] : 0);
+    double *stat = reinterpret_cast<double *>(cell + (size_t)(A0 + A1) * 4);       // [group][mean, rstd]
+    const int per0 = A0 * 4, n0 = in.rows[0] * per0, per1 = A1 * 4, n = n0 + in.rows[1] * per1;
+    for (int i = tid; i < (A0 + A1) * 4; i += nthr) cell[i] = 0ull;
+    gn_barrier<LDS_ONLY>();
+    auto slot = [&](int i) { return i < n0 ? i % per0 : per0 + (i - n0) % per1; };
+#pragma unroll
+    for (int k = 0; k < GN_PRE; ++k) {
+        const int i = tid + k * nthr;
+        if (i < n) atomicAdd(cell + slot(i), r.w[k]);               // ds_add_u64: integers, any order
+    }
+    if (n > GN_PRE * nthr) {                                        // (more rows than the request covers: not on the shipped shapes)
+        const unsigned long long *base0 = in.acc[0] + (size_t)b * n0, *base1 = A1 ? in.acc[1] + (size_t)b * (n - n0) : nullptr;
+        for (int i = tid + GN_PRE * nthr; i < n; i += nthr) atomicAdd(cell + slot(i), i < n0 ? base0[i] : base1[i - n0]);
+    }
+    gn_barrier<LDS_ONLY>();
+    const int cpg = Ct / in.groups, apg = cpg / GN_ATOM;
+    if (tid < in.groups) {
+        long long hi[2][2] = {{0, 0}, {0, 0}};                      // [src][sum, sumsq]
+        unsigned long long lo[2][2] = {{0, 0}, {0, 0}};
+        for (int k = 0; k < apg; ++k) {
+            const int at = tid * apg + k, src = at >= A0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { lo[src][q] += cell[at * 4 + q * 2]; hi[src][q] += (long long)cell[at * 4 + q * 2 + 1]; }
+        }
+        const double tsum = gn_cell_value(hi[0][0], lo[0][0]) + 8.0 * gn_cell_value(hi[1][0], lo[1][0]);   // a `low` voxel stands for
+        const double tsq = gn_cell_value(hi[0][1], lo[0][1]) + 8.0 * gn_cell_value(hi[1][1], lo[1][1]);    // its 8 upsampled copies
+        const double cnt = in.count * cpg;
+        double mean = tsum / cnt;
+        double var = tsq / cnt - mean * mean;                       // biased variance, as torch
+        if (var < 0.0) var = 0.0;
+        double rstd = 1.0 / sqrt(var + (double)in.eps);
+        if (r.bad) { mean = __builtin_nan(""); rstd = __builtin_nan(""); }
+        stat[tid * 2] = mean; stat[tid * 2 + 1] = rstd;
+    }
+    gn_barrier<LDS_ONLY>();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = tid + k * nthr;
+        if (c < Ct) {
+            const int g = c / cpg;
+            const double sc = stat[g * 2 + 1] * (double)r.gm[k];
+            ssl[c * 2] = pre * (float)sc;
+            ssl[c * 2 + 1] = pre * (float)((double)r.bt[k] - stat[g * 2] * sc);
+        }
+    }
+    for (int c = tid + 2 * nthr; c < Ct; c += nthr) {
+        const int g = c / cpg;
+        const double sc = stat[g * 2 + 1] * (double)in.gamma[c];
+        ssl[c * 2] = pre * (float)sc;
+        ssl[c * 2 + 1] = pre * (float)((double)in.beta[c] - stat[g * 2] * sc);
+    }
+    gn_barrier<LDS_ONLY>();
+}
+
+__device__ __forceinline__ void gn_in_scale_shift(const GnIn &in, int b, float pre, float *ssl, void *scratch, int tid, int nthr) {
+    const GnReq<8> r = gn_in_request<8>(in, b, tid, nthr);
+    gn_in_finish<false>(in, r, b, pre, ssl, scratch, tid, nthr);
+}
+
 // ---- GroupNorm statistics ---------------------------------------------------------------------
 // Every producer of a tensor leaves per-block partial sums part[b][blk][c] = (sum, sumsq) over its
 // voxels (the conv epilogue for conv outputs, channel_stats_kernel for pooled tensors and the
@@ -42,7 +202,7 @@ __device__ __forceinline__ float src_at(const Src &s, int b, int z, int y, int x
 // statistics of the virtual concat [skip | upsample(low)] are the per-channel sums of skip plus
 // 8x those of low (nearest upsampling repeats every value 8 times).
 __global__ void __launch_bounds__(256)
-channel_stats_kernel(const float *x, int C, size_t V, int nblk, float *part) {
+channel_stats_kernel(const float *x, int C, size_t V, int nblk, float *part, GnOut stat_out) {
     __shared__ float red[8][32][2];
     const int b = blockIdx.y, blk = blockIdx.x;
     const size_t v0 = V * blk / nblk, v1 = V * (blk + 1) / nblk;
@@ -56,11 +216,16 @@ channel_stats_kernel(const float *x, int C, size_t V, int nblk, float *part) {
         }
         red[vg][c][0] = sum; red[vg][c][1] = sq;
         __syncthreads();
-        if (threadIdx.x < 32) {
+        if (part && threadIdx.x < 32) {
             float a = 0.0f, q = 0.0f;
             for (int i = 0; i < 8; ++i) { a += red[i][c][0]; q += red[i][c][1]; }
             float *dst = part + (((size_t)b * nblk + blk) * C + cb + c) * 2;
             dst[0] = a; dst[1] = q;
+        }
+        if (stat_out.acc && threadIdx.x < 64) {                    // thread = channel * 2 + {sum, sumsq}: the same eight terms in the same order
+            float a = 0.0f;
+            for (int i = 0; i < 8; ++i) a += red[i][threadIdx.x >> 1][threadIdx.x & 1];
+            gn_out_add(stat_out, b, (unsigned)blk, cb, a);
         }
         __syncthreads();
     }
@@ -74,10 +239,12 @@ struct StatSrc { const float *part; int nblk, C; };
 // latency chain in front of every convolution, so it is kept short.
 __global__ void __launch_bounds__(256)
 gn_finalize_kernel(StatSrc s1, StatSrc s2, int groups, double count, const float *gamma, const float *beta,
-                   float eps, float *scale_shift) {
+                   float eps, float *scale_shift, unsigned long long *zero, size_t zero_words) {
     __shared__ double wred[4][2];
     __shared__ double stat[2];
     const int b = blockIdx.x, g = blockIdx.y;
+    // vt_unet3d_fwd's first finalisation also clears the accumulator rows (GnOut) of the launches behind it
+    for (size_t i = (size_t)(g * gridDim.x + b) * 256 + threadIdx.x; i < zero_words; i += (size_t)gridDim.x * gridDim.y * 256) zero[i] = 0ull;
     const int C = s1.C + s2.C, cpg = C / groups;
     const int c_lo = g * cpg, c_hi = c_lo + cpg;
     double sum = 0.0, sq = 0.0;
@@ -143,6 +310,8 @@ struct ConvArgs {
     int tiles_x, tiles_y, tiles_z;
     float *kws = nullptr;       // K-split launches (gridDim.z slices of the input channels): [ksplit][B,D,H,W,Cout] raw partial sums
     int ksplit = 1;
+    GnOut stat_out;             // the output's statistics into accumulator rows (instead of `part`)
+    GnIn stat_in;               // the input's statistics from accumulator rows: scale / shift computed in the prologue (instead of `scale_shift`)
 };
 
 // stage channels [32 cib, 32 cib+32) of the normalised input tile (origin x0-1,y0-1,z0-1) into LDS;
@@ -397,7 +566,7 @@ __global__ void conv3d_pack_s_kernel(const float *w, int Cout, int Cin, float *p
 
 constexpr int SB_WFRAGS = 27 * 128;               // one (16-channel block, cout block)'s weight fragments: 27 taps x (hi, lo) x 64 lanes
 constexpr int sb_witers(int TZ) { return (SB_WFRAGS + sb_threads(TZ) - 1) / sb_threads(TZ); }
-constexpr size_t sb_lds(int TZ) { return (size_t)sb_rows(TZ) * SB_ROW + (size_t)SB_WFRAGS * 16; }
+constexpr size_t sb_lds(int TZ) { return (size_t)sb_rows(TZ) * SB_ROW + (size_t)SB_WFRAGS * 16 + (size_t)GN_MAX_CIN * 2 * sizeof(float); }
 
 // KSPLIT: gridDim.z workgroups share an output tile, each over its contiguous 1/gridDim.z of the 16-channel blocks; the raw
 // accumulators go to a.kws[blockIdx.z] and conv_ksum_kernel adds them up in slice order (ReLU and the statistics move there).
@@ -424,6 +593,7 @@ conv3d_gcr_s_kernel(ConvArgs a) {
     const int wz = wave >> 1, wx = (wave & 1) * 4;
     const int center = ((wz + 1) * 10 + (ly + 1)) * SB_PX + (lx + wx + 1);
     bf16x8 *wlds = reinterpret_cast<bf16x8 *>(stile + (size_t)SB_ROWS * SB_ROW);
+    float *ssl = reinterpret_cast<float *>(stile + (size_t)SB_ROWS * SB_ROW + (size_t)SB_WFRAGS * 16);   // GnIn: the layer's scale / shift table
 
     // ---- staging plan (the same for every channel block): thread -> (voxel, 4 of the 16 channels) ----
     const int sc4 = (threadIdx.x & 3) * 4;
@@ -465,7 +635,10 @@ conv3d_gcr_s_kernel(ConvArgs a) {
     auto commit = [&](int q) {                     // GroupNorm affine (zero padding AFTER the norm), split, LDS
         const int ch = q * 16 + sc4;
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (a.scale_shift) {
+        if (a.stat_in.acc[0]) {
+            const float *ss = ssl + ch * 2;
+            sc = f32x4{ss[0], ss[2], ss[4], ss[6]}; sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
+        } else if (a.scale_shift) {
             const float *ss = a.scale_shift + ((size_t)b * Cin + ch) * 2;
             sc = f32x4{ss[0], ss[2], ss[4], ss[6]}; sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
         }
@@ -496,7 +669,10 @@ conv3d_gcr_s_kernel(ConvArgs a) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
     const int q_lo = KSPLIT ? (int)blockIdx.z * (ncq / a.ksplit) : 0, q_hi = KSPLIT ? q_lo + ncq / a.ksplit : ncq;
-    fetch(q_lo);
+    // the 4-wave form has the registers to keep the first chunk's request in flight across the statistics' round trip
+    if (TZ == 2) fetch(q_lo);
+    if (a.stat_in.acc[0]) gn_in_scale_shift(a.stat_in, b, 1.0f, ssl, stile, threadIdx.x, SB_THREADS);
+    if (TZ != 2) fetch(q_lo);
     for (int q = q_lo; q < q_hi; ++q) {
         __syncthreads();                                           // the previous taps are done with the tile
         commit(q);
@@ -544,16 +720,17 @@ conv3d_gcr_s_kernel(ConvArgs a) {
         f32x16 v = acc;
         if (a.relu) v = relu16(v);
         if (valid) store_acc16(orow + co_blk * 32, v, kg);
-        if (a.part) wave_stats(v, valid, j, kg, sred + wave * 64);
+        if (a.part || a.stat_out.acc) wave_stats(v, valid, j, kg, sred + wave * 64);
     }
-    if (a.part) {
+    if (a.part || a.stat_out.acc) {
         __syncthreads();
         const int nsp = a.tiles_x * a.tiles_y * a.tiles_z;
         const int spatial = blockIdx.x % nsp;
         if (threadIdx.x < 64) {
             float tsum = 0.0f;
             for (int w = 0; w < 2 * TZ; ++w) tsum += sred[w * 64 + threadIdx.x];
-            a.part[(((size_t)b * nsp + spatial) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
+            if (a.part) a.part[(((size_t)b * nsp + spatial) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
+            if (a.stat_out.acc) gn_out_add(a.stat_out, b, (unsigned)spatial, co_blk * 32, tsum);
         }
     }
 }
@@ -564,7 +741,7 @@ conv3d_gcr_s_kernel(ConvArgs a) {
 constexpr int KSUM_VOX = 128;
 template <int KS>       // slices known at compile time (0: run-time `ks`): their loads are issued together, not one round trip each
 __global__ void __launch_bounds__(256)
-conv_ksum_kernel(const float *kws, int ks, size_t slab, int Cout, int relu, float *out, float *part) {
+conv_ksum_kernel(const float *kws, int ks, size_t slab, int Cout, int relu, float *out, float *part, GnOut stat_out, int blocks_per_scene) {
     __shared__ float red[32][8][8];
     const int vl = threadIdx.x >> 3, q = threadIdx.x & 7;
     f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
@@ -589,14 +766,15 @@ conv_ksum_kernel(const float *kws, int ks, size_t slab, int Cout, int relu, floa
         sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
         sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
     }
-    if (!part) return;
+    if (!part && !stat_out.acc) return;
     float *r = red[vl][q];
     r[0] = sm.x; r[1] = sq.x; r[2] = sm.y; r[3] = sq.y; r[4] = sm.z; r[5] = sq.z; r[6] = sm.w; r[7] = sq.w;
     __syncthreads();
     if (threadIdx.x < 64) {                                        // threadIdx.x = channel * 2 + {sum, sumsq} of the 32-channel block
         float t = 0.0f;
         for (int v = 0; v < 32; ++v) t += red[v][threadIdx.x >> 3][threadIdx.x & 7];
-        part[((size_t)blockIdx.x * Cout + blockIdx.y * 32) * 2 + threadIdx.x] = t;
+        if (part) part[((size_t)blockIdx.x * Cout + blockIdx.y * 32) * 2 + threadIdx.x] = t;
+        if (stat_out.acc) gn_out_add(stat_out, blockIdx.x / blocks_per_scene, blockIdx.x % blocks_per_scene, blockIdx.y * 32, t);
     }
 }
 
@@ -610,7 +788,7 @@ constexpr int S4_TZ = 4, S4_THREADS = 512, S4_NVOX = 600, S4_ROWS = (S4_TZ + 2) 
 constexpr int S4_ITERS = (S4_NVOX * 4 + S4_THREADS - 1) / S4_THREADS;         // 5
 constexpr int S4_SLAB = 9 * 128;                                               // fragments per slab
 constexpr int S4_WITERS = (S4_SLAB + S4_THREADS - 1) / S4_THREADS;             // 3
-constexpr size_t S4_LDS = (size_t)S4_ROWS * SB_ROW + (size_t)S4_SLAB * 16;
+constexpr size_t S4_LDS = (size_t)S4_ROWS * SB_ROW + (size_t)S4_SLAB * 16 + (size_t)GN_MAX_CIN * 2 * sizeof(float);
 static_assert(S4_LDS <= 80 * 1024, "two workgroups must fit the 160 KB of a CU");
 
 __global__ void __launch_bounds__(S4_THREADS, 4)        // second argument: waves per SIMD (HIP), i.e. two workgroups per CU -> 128 registers
@@ -631,6 +809,8 @@ conv3d_gcr_s4_kernel(ConvArgs a) {
     const int wz = wave >> 1, wx = (wave & 1) * 4;
     const int center = ((wz + 1) * 10 + (ly + 1)) * SB_PX + (lx + wx + 1);
     bf16x8 *wlds = reinterpret_cast<bf16x8 *>(stile + (size_t)S4_ROWS * SB_ROW);
+    float *ssl = reinterpret_cast<float *>(stile + (size_t)S4_ROWS * SB_ROW + (size_t)S4_SLAB * 16);     // GnIn: the layer's scale / shift table
+    if (a.stat_in.acc[0]) gn_in_scale_shift(a.stat_in, b, 1.0f, ssl, stile, threadIdx.x, S4_THREADS);
 
     const int sc4 = (threadIdx.x & 3) * 4;
     const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
@@ -673,7 +853,10 @@ conv3d_gcr_s4_kernel(ConvArgs a) {
     auto commit_in = [&](int q) {                  // GroupNorm affine (zero padding AFTER the norm), split, LDS
         const int ch = q * 16 + sc4;
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (a.scale_shift) {
+        if (a.stat_in.acc[0]) {
+            const float *ss = ssl + ch * 2;
+            sc = f32x4{ss[0], ss[2], ss[4], ss[6]}; sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
+        } else if (a.scale_shift) {
             const float *ss = a.scale_shift + ((size_t)b * Cin + ch) * 2;
             sc = f32x4{ss[0], ss[2], ss[4], ss[6]}; sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
         }
@@ -760,16 +943,17 @@ conv3d_gcr_s4_kernel(ConvArgs a) {
         f32x16 v = acc;
         if (a.relu) v = relu16(v);
         if (valid) store_acc16(orow + co_blk * 32, v, kg);
-        if (a.part) wave_stats(v, valid, j, kg, sred + wave * 64);
+        if (a.part || a.stat_out.acc) wave_stats(v, valid, j, kg, sred + wave * 64);
     }
-    if (a.part) {
+    if (a.part || a.stat_out.acc) {
         __syncthreads();
         const int nsp = a.tiles_x * a.tiles_y * a.tiles_z;
         const int spatial = blockIdx.x % nsp;
         if (threadIdx.x < 64) {
             float tsum = 0.0f;
             for (int w = 0; w < 2 * S4_TZ; ++w) tsum += sred[w * 64 + threadIdx.x];
-            a.part[(((size_t)b * nsp + spatial) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
+            if (a.part) a.part[(((size_t)b * nsp + spatial) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
+            if (a.stat_out.acc) gn_out_add(a.stat_out, b, (unsigned)spatial, co_blk * 32, tsum);
         }
     }
 }
@@ -826,14 +1010,6 @@ __global__ void conv3d_pack_h_kernel(const float *w, int Cout, int Cin, float *p
     }
 }
 
-#ifdef VT_DIAG_HB
-// diagnostic build only (tools/diag_conv.py): per-wave shader-clock sums of the phases of conv3d_gcr_h_kernel
-__device__ unsigned long long vt_diag_hb_buf[8192 * 8];
-#define HB_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-                         dg_sum[i] += t_ - dg_last; dg_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define HB_STAMP(i) do { } while (0)
-#endif
 struct HbArgs {
     ConvArgs c;
     int wgs_per_scene;          // persistent workgroups per scene (= partial-statistics blocks per scene)
@@ -878,8 +1054,10 @@ conv3d_gcr_h_kernel(HbArgs ha) {
             post_scale = 1.0f / pre_scale;                              // exact: a power of two
         }
     }
-    for (int i = threadIdx.x; i < 2 * Cin; i += THREADS)
-        ssl[i] = pre_scale * (a.scale_shift ? a.scale_shift[(size_t)b * Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f));
+    if (a.stat_in.acc[0]) gn_in_scale_shift(a.stat_in, b, pre_scale, ssl, hl, threadIdx.x, THREADS);   // (scratch: the first image buffer, still idle)
+    else
+        for (int i = threadIdx.x; i < 2 * Cin; i += THREADS)
+            ssl[i] = pre_scale * (a.scale_shift ? a.scale_shift[(size_t)b * Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f));
     __syncthreads();
 
     // staging plan, the same for every tile: item -> (halo voxel, which four of the chunk's eight channels)
@@ -1004,11 +1182,6 @@ conv3d_gcr_h_kernel(HbArgs ha) {
     // s_waitcnt vmcnt(ITERS) alone: everything but the wave's ITERS youngest vector-memory operations (the register fetch of
     // chunk n + 2, issued after the DMA of chunk n + 1) has landed
     constexpr int WAIT_DMA = 0x0F70 | ITERS;
-#ifdef VT_DIAG_HB
-    unsigned long long dg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long dg_last = __builtin_amdgcn_s_memtime();
-    const unsigned long long dg_first = dg_last;
-#endif
     if (N > 0) {
         dma_w(0);
         fetch(0);
@@ -1017,24 +1190,16 @@ conv3d_gcr_h_kernel(HbArgs ha) {
     }
     if (N > 1) __builtin_amdgcn_s_waitcnt(WAIT_DMA); else __builtin_amdgcn_s_waitcnt(0x0F70);   // chunk 0's weights are in LDS; chunk 1's fetch stays in flight
     __syncthreads();
-    HB_STAMP(0);                                                    // prologue
     for (int n = 0; n < N; ++n) {
         if (!late) {
             if (n + 1 < N) { commit(n + 1); dma_w(n + 1); }
-            HB_STAMP(1);                                            // commit + DMA issue
             if (n + 2 < N) fetch(n + 2);
-            HB_STAMP(2);                                            // fetch issue
             taps(n, 0, HB_KSTEPS);
-            HB_STAMP(3);                                            // taps
         } else {
             taps(n, 0, HB_KSTEPS / 2);
-            HB_STAMP(3);
             if (n + 1 < N) { commit(n + 1); dma_w(n + 1); }
-            HB_STAMP(1);
             if (n + 2 < N) fetch(n + 2);
-            HB_STAMP(2);
             taps(n, HB_KSTEPS / 2, HB_KSTEPS);
-            HB_STAMP(3);
         }
         if (++e_q == ncq) {                                          // the tile's last chunk: relu, store, statistics, fresh accumulator
             int x0, y0, z0;
@@ -1049,8 +1214,7 @@ conv3d_gcr_h_kernel(HbArgs ha) {
             }
             if (a.relu) v = relu16(v);
             store_acc16(orow + co_blk * 32, v, kg);
-            HB_STAMP(7);                                            // (diagnostic: relu + store part of the epilogue)
-            if (a.part) {
+            if (a.part || a.stat_out.acc) {
                 // per-channel (sum, sumsq) over the wave's 32 voxels, added to the wave's running sums in LDS (tile order: fixed)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1061,26 +1225,15 @@ conv3d_gcr_h_kernel(HbArgs ha) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         }
-        HB_STAMP(4);                                                // tile epilogue
         if (n + 2 < N) __builtin_amdgcn_s_waitcnt(WAIT_DMA); else __builtin_amdgcn_s_waitcnt(0x0F70);
-        HB_STAMP(5);                                                // wait for the DMA
         __syncthreads();
-        HB_STAMP(6);                                                // barrier
     }
-#ifdef VT_DIAG_HB
-    if (lane == 0) {
-        unsigned long long *d = vt_diag_hb_buf + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * 2 * TZ + wave) * 8;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) d[i] = dg_sum[i];
-        d[0] += dg_sum[7] << 40;                                   // the store part rides in the prologue slot's upper bits
-        d[7] = __builtin_amdgcn_s_memtime() - dg_first;
-    }
-#endif
-    if (a.part) {
+    if (a.part || a.stat_out.acc) {
         if (threadIdx.x < 64) {
             float tsum = 0.0f;
             for (int w = 0; w < 2 * TZ; ++w) tsum += sred[w * 64 + threadIdx.x];
-            a.part[(((size_t)b * ha.wgs_per_scene + wg) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
+            if (a.part) a.part[(((size_t)b * ha.wgs_per_scene + wg) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
+            if (a.stat_out.acc) gn_out_add(a.stat_out, b, (unsigned)wg, co_blk * 32, tsum);
         }
     }
 }
@@ -1132,8 +1285,15 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
             post_scale = 1.0f / pre_scale;
         }
     }
-    for (int i = threadIdx.x; i < 2 * Cin; i += THREADS)
-        ssl[i] = pre_scale * (a.scale_shift ? a.scale_shift[(size_t)b * Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f));
+    // GnIn: the statistics are requested here and reduced (gn_in_finish, scratch: the first image buffer) behind the loaders' first
+    // requests, so that the two round trips overlap
+    const bool stats_in = a.stat_in.acc[0] != nullptr;
+    constexpr int GN_PRE = TZ == 8 ? 4 : 8;                         // (1024 threads: 4 words each cover the shipped rows, and 8 spill)
+    GnReq<GN_PRE> gn_rq;
+    if (stats_in) gn_rq = gn_in_request<GN_PRE>(a.stat_in, b, threadIdx.x, THREADS);
+    else
+        for (int i = threadIdx.x; i < 2 * Cin; i += THREADS)
+            ssl[i] = pre_scale * (a.scale_shift ? a.scale_shift[(size_t)b * Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f));
     if (wave < TZ) sred[wave * 64 + lane] = 0.0f;
     __syncthreads();
     auto tile_origin = [&](int k, int &x0, int &y0, int &z0) {
@@ -1259,17 +1419,15 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
             dma_w(0);
             fetch(preA);
             if (N > 1) fetch(preB);
+        }
+        if (stats_in) gn_in_finish<true>(a.stat_in, gn_rq, b, pre_scale, ssl, hl, threadIdx.x, THREADS);
+        if (N > 0) {
             commit(0, preA);
             if (N > 2) fetch(preA);
         }
         constexpr int WAIT_DMA0 = 0x0F70 | (2 * ITERS > 15 ? 15 : 2 * ITERS);
         if (N > 2) __builtin_amdgcn_s_waitcnt(WAIT_DMA0); else __builtin_amdgcn_s_waitcnt(0x0F70);   // chunk 0's weights have landed
         lds_barrier();
-#ifdef VT_DIAG_HB
-        unsigned long long dg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        unsigned long long dg_last = __builtin_amdgcn_s_memtime();
-        const unsigned long long dg_first = dg_last;
-#endif
         // iteration n: commit chunk n+1 (requested two iterations ago), DMA its weights, request chunk n+3 into the freed set;
         // the counted wait lets that youngest request fly on and, vmcnt being in order, also covers chunk n+2's request
         auto iteration = [&](int n, PreSet &ps) {
@@ -1280,35 +1438,21 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
 #else
             if (n + 1 < N) { commit(n + 1, ps); dma_w(n + 1); }
 #endif
-            HB_STAMP(1);
             if (n + 3 < N) {
-                fetch(ps); HB_STAMP(2);
-#ifdef VT_DIAG_LATENCY
-                __builtin_amdgcn_s_waitcnt(0x0F70); HB_STAMP(7);       // diagnostic: how long until the requests just issued have landed
-#endif
+                fetch(ps);
                 __builtin_amdgcn_s_waitcnt(WAIT_DMA);
             } else __builtin_amdgcn_s_waitcnt(0x0F70);
-            HB_STAMP(5);
             lds_barrier();
-            HB_STAMP(6);
         };
         for (int n = 0; n < N; n += 2) {
             iteration(n, preB);                                    // chunk n + 1 is odd
             if (n + 1 < N) iteration(n + 1, preA);
         }
-#ifdef VT_DIAG_HB
-        if (lane == 0) {
-            unsigned long long *d = vt_diag_hb_buf + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * 2 * TZ + wave) * 8;
-#pragma unroll
-            for (int i = 0; i < 7; ++i) d[i] = dg_sum[i];
-            d[0] = dg_sum[7];                                      // (VT_DIAG_LATENCY: request -> landed)
-            d[7] = __builtin_amdgcn_s_memtime() - dg_first;
-        }
-#endif
     } else {
         // ================================================= tap waves ==================================================
         const int lx = j & 3, ly = j >> 2;
         const int center = ((wave + 1) * 10 + (ly + 1)) * HB_PX + (lx + 1);      // patch 0; patch 1 sits 4 voxels along x
+        if (stats_in) gn_in_finish<true>(a.stat_in, gn_rq, b, pre_scale, ssl, hl, threadIdx.x, THREADS);
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
@@ -1329,11 +1473,6 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
         };
         int e_q = 0, e_k = 0;
         lds_barrier();                                           // the loaders' prologue
-#ifdef VT_DIAG_HB
-        unsigned long long dg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        unsigned long long dg_last = __builtin_amdgcn_s_memtime();
-        const unsigned long long dg_first = dg_last;
-#endif
         for (int n = 0; n < N; ++n) {
             Ops cur = ops_of(n, 0);
 #pragma unroll
@@ -1381,7 +1520,7 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
                         ssq[r] = pch ? fmaf(v[r], v[r], ssq[r]) : v[r] * v[r];
                     }
                 }
-                if (a.part && !FIN) {
+                if ((a.part || a.stat_out.acc) && !FIN) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float sm = half_wave_sum(ssum[r]), sq = half_wave_sum(ssq[r]);
@@ -1390,24 +1529,15 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-                HB_STAMP(4);
-            } else HB_STAMP(3);
+            }
             lds_barrier();
-            HB_STAMP(6);
         }
-#ifdef VT_DIAG_HB
-        if (lane == 0) {
-            unsigned long long *d = vt_diag_hb_buf + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * 2 * TZ + wave) * 8;
-#pragma unroll
-            for (int i = 0; i < 7; ++i) d[i] = dg_sum[i];
-            d[7] = __builtin_amdgcn_s_memtime() - dg_first;
-        }
-#endif
     }
-    if (a.part && threadIdx.x < 64) {
+    if ((a.part || a.stat_out.acc) && threadIdx.x < 64) {
         float tsum = 0.0f;
         for (int w = 0; w < TZ; ++w) tsum += sred[w * 64 + threadIdx.x];
-        a.part[(((size_t)b * ha.wgs_per_scene + wg) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
+        if (a.part) a.part[(((size_t)b * ha.wgs_per_scene + wg) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
+        if (a.stat_out.acc) gn_out_add(a.stat_out, b, (unsigned)wg, co_blk * 32, tsum);
     }
 }
 
@@ -1434,7 +1564,7 @@ maxpool3d_cl_kernel(const float *x, float *out, int D, int H, int W, int C, size
 // channel_stats_kernel over the pooled tensor (bit-identical partials), the eight inputs of a pooled value read where that
 // kernel read the value (one launch and one 2-8 MB round trip less per encoder level)
 __global__ void __launch_bounds__(256)
-maxpool3d_cl_stats_kernel(const float *x, float *out, int D, int H, int W, int C, int nblk, float *part) {
+maxpool3d_cl_stats_kernel(const float *x, float *out, int D, int H, int W, int C, int nblk, float *part, GnOut stat_out) {
     __shared__ float red[8][32][2];
     const int b = blockIdx.y, blk = blockIdx.x;
     const int D2 = D / 2, H2 = H / 2, W2 = W / 2;
@@ -1456,11 +1586,16 @@ maxpool3d_cl_stats_kernel(const float *x, float *out, int D, int H, int W, int C
         }
         red[vg][c][0] = sum; red[vg][c][1] = sq;
         __syncthreads();
-        if (threadIdx.x < 32) {
+        if (part && threadIdx.x < 32) {
             float a = 0.0f, q = 0.0f;
             for (int i = 0; i < 8; ++i) { a += red[i][c][0]; q += red[i][c][1]; }
             float *dst = part + (((size_t)b * nblk + blk) * C + cb + c) * 2;
             dst[0] = a; dst[1] = q;
+        }
+        if (stat_out.acc && threadIdx.x < 64) {                    // thread = channel * 2 + {sum, sumsq}: the same eight terms in the same order
+            float a = 0.0f;
+            for (int i = 0; i < 8; ++i) a += red[i][threadIdx.x >> 1][threadIdx.x & 1];
+            gn_out_add(stat_out, b, (unsigned)blk, cb, a);
         }
         __syncthreads();
     }
@@ -1668,15 +1803,20 @@ int vt_conv3d_stat_blocks(int B, int D, int H, int W, int Cin, int Cout) {
     return conv_tile(D, H, W, conv_waves(B, D, H, W, nco), TX, TY, TZ);
 }
 
-int vt_channel_stats(const float *x, int B, int64_t V, int C, int nblk, float *part, void *stream) {
-    if (!x || !part || B <= 0 || V <= 0 || C <= 0 || (C & 31) || nblk <= 0) return vt_fail(VT_ERR_INVALID, "vt_channel_stats: bad argument");
-    hipLaunchKernelGGL(channel_stats_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, x, C, (size_t)V, nblk, part);
+static int channel_stats_launch(const float *x, int B, int64_t V, int C, int nblk, float *part, const GnOut &stat_out, void *stream) {
+    if (!x || (!part && !stat_out.acc) || B <= 0 || V <= 0 || C <= 0 || (C & 31) || nblk <= 0) return vt_fail(VT_ERR_INVALID, "vt_channel_stats: bad argument");
+    hipLaunchKernelGGL(channel_stats_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, x, C, (size_t)V, nblk, part, stat_out);
     return vt_check(hipGetLastError(), "vt_channel_stats");
 }
 
-int vt_gn_scale_shift(const float *part1, int nblk1, int C1, const float *part2, int nblk2, int C2,
-                      int B, int64_t voxels, int groups, const float *gamma, const float *beta, double eps,
-                      float *scale_shift, void *stream) {
+int vt_channel_stats(const float *x, int B, int64_t V, int C, int nblk, float *part, void *stream) {
+    if (!part) return vt_fail(VT_ERR_INVALID, "vt_channel_stats: bad argument");
+    return channel_stats_launch(x, B, V, C, nblk, part, GnOut{}, stream);
+}
+
+static int gn_scale_shift_launch(const float *part1, int nblk1, int C1, const float *part2, int nblk2, int C2,
+                                 int B, int64_t voxels, int groups, const float *gamma, const float *beta, double eps,
+                                 float *scale_shift, unsigned long long *zero, size_t zero_words, void *stream) {
     if (!part1 || nblk1 <= 0 || C1 <= 0 || !gamma || !beta || !scale_shift || B <= 0 || voxels <= 0)
         return vt_fail(VT_ERR_INVALID, "vt_gn_scale_shift: bad argument");
     if (!part2) { nblk2 = 0; C2 = 0; }
@@ -1684,8 +1824,14 @@ int vt_gn_scale_shift(const float *part1, int nblk1, int C1, const float *part2,
     if (groups <= 0 || C % groups || C / groups > 256) return vt_fail(VT_ERR_INVALID, "vt_gn_scale_shift: bad group count");
     StatSrc s1{part1, nblk1, C1}, s2{part2, nblk2, C2};
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B, groups), dim3(256), 0, (hipStream_t)stream, s1, s2, groups,
-                       (double)voxels, gamma, beta, (float)eps, scale_shift);
+                       (double)voxels, gamma, beta, (float)eps, scale_shift, zero, zero_words);
     return vt_check(hipGetLastError(), "vt_gn_scale_shift");
+}
+
+int vt_gn_scale_shift(const float *part1, int nblk1, int C1, const float *part2, int nblk2, int C2,
+                      int B, int64_t voxels, int groups, const float *gamma, const float *beta, double eps,
+                      float *scale_shift, void *stream) {
+    return gn_scale_shift_launch(part1, nblk1, C1, part2, nblk2, C2, B, voxels, groups, gamma, beta, eps, scale_shift, nullptr, 0, stream);
 }
 
 int vt_conv3d_gcr(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
@@ -1755,10 +1901,11 @@ int vt_conv3d_stat_blocks_bf16x3(int B, int D, int H, int W, int Cin, int Cout) 
     return conv_s_eligible(B, D, H, W, Cin, Cout) ? (D / conv_s_tz(B, D, H, W, Cout)) * (H / 8) * (W / 8) : 0;
 }
 
-int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+static int conv_s_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                          const float *scale_shift, const float *packed_w_bf16x3, int Cout, int relu, float *out,
-                         float *out_part, void *stream) {
+                         float *out_part, const GnIn &stat_in, const GnOut &stat_out, void *stream) {
     ConvArgs a;
+    a.stat_in = stat_in; a.stat_out = stat_out;
     a.s = Src{skip, low, C1, low ? C2 : 0, D, H, W};
     if (!src_ok(a.s, B) || !packed_w_bf16x3 || !out) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr_bf16x3: bad argument");
     if (!conv_s_eligible(B, D, H, W, a.s.C1 + a.s.C2, Cout))
@@ -1788,6 +1935,12 @@ int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, in
     return vt_check(hipGetLastError(), "vt_conv3d_gcr_bf16x3");
 }
 
+int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                         const float *scale_shift, const float *packed_w_bf16x3, int Cout, int relu, float *out,
+                         float *out_part, void *stream) {
+    return conv_s_launch(skip, C1, low, C2, B, D, H, W, scale_shift, packed_w_bf16x3, Cout, relu, out, out_part, GnIn{}, GnOut{}, stream);
+}
+
 // ---- the K-split form of vt_conv3d_gcr_bf16x3 for the thin levels (conv_sk_plan) ----
 size_t vt_conv3d_ksplit_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout) {
     int tz;
@@ -1800,10 +1953,11 @@ int vt_conv3d_stat_blocks_ksplit(int B, int D, int H, int W, int Cin, int Cout) 
     return conv_sk_plan(B, D, H, W, Cin, Cout, tz) ? (int)((size_t)D * H * W / KSUM_VOX) : 0;
 }
 
-int vt_conv3d_gcr_bf16x3_ksplit(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
-                                const float *scale_shift, const float *packed_w_bf16x3, int Cout, int relu, float *out,
-                                float *out_part, void *workspace, size_t workspace_bytes, void *stream) {
+static int conv_sk_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                          const float *scale_shift, const float *packed_w_bf16x3, int Cout, int relu, float *out,
+                          float *out_part, const GnIn &stat_in, const GnOut &stat_out, void *workspace, size_t workspace_bytes, void *stream) {
     ConvArgs a;
+    a.stat_in = stat_in;
     a.s = Src{skip, low, C1, low ? C2 : 0, D, H, W};
     if (!src_ok(a.s, B) || !packed_w_bf16x3 || !out || !workspace) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr_bf16x3_ksplit: bad argument");
     int tz;
@@ -1827,17 +1981,19 @@ int vt_conv3d_gcr_bf16x3_ksplit(const float *skip, int C1, const float *low, int
     if (tz == 8) hipLaunchKernelGGL((conv3d_gcr_s_kernel<8, true>), grid, dim3(sb_threads(8)), sb_lds(8), st, a);
     else hipLaunchKernelGGL((conv3d_gcr_s_kernel<2, true>), grid, dim3(sb_threads(2)), sb_lds(2), st, a);
     const dim3 sgrid((unsigned)((size_t)B * D * H * W / KSUM_VOX), (unsigned)(Cout / 32));
-#define VT_KSUM(KS) hipLaunchKernelGGL(conv_ksum_kernel<KS>, sgrid, dim3(256), 0, st, (const float *)workspace, ks, slab, Cout, relu, out, out_part)
+#define VT_KSUM(KS) hipLaunchKernelGGL(conv_ksum_kernel<KS>, sgrid, dim3(256), 0, st, (const float *)workspace, ks, slab, Cout, relu, out, out_part, \
+                                       stat_out, (int)((size_t)D * H * W / KSUM_VOX))
     if (ks == 8) VT_KSUM(8); else if (ks == 4) VT_KSUM(4); else if (ks == 2) VT_KSUM(2); else VT_KSUM(0);
 #undef VT_KSUM
     return vt_check(hipGetLastError(), "vt_conv3d_gcr_bf16x3_ksplit");
 }
 
-#ifdef VT_DIAG_HB
-int vt_diag_hb_read(unsigned long long *host, size_t count) {
-    return vt_check(hipMemcpyFromSymbol(host, HIP_SYMBOL(vt_diag_hb_buf), count * sizeof(unsigned long long)), "vt_diag_hb_read");
+int vt_conv3d_gcr_bf16x3_ksplit(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                                const float *scale_shift, const float *packed_w_bf16x3, int Cout, int relu, float *out,
+                                float *out_part, void *workspace, size_t workspace_bytes, void *stream) {
+    return conv_sk_launch(skip, C1, low, C2, B, D, H, W, scale_shift, packed_w_bf16x3, Cout, relu, out, out_part, GnIn{}, GnOut{}, workspace, workspace_bytes, stream);
 }
-#endif
+
 size_t vt_conv3d_packed_floats_f16x3(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0 || (Cout & 31) || (Cin & 31)) return 0;
     return (size_t)(Cin / 8) * (Cout / 32) * HB_WFRAGS * 4;          // 14 k-steps (27 taps + one zero half-step) of 16-byte fragments
@@ -1872,7 +2028,8 @@ static bool conv_h_specialised(int tz) {
 
 static int conv_h_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                          const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
-                         float *out_part, const float *in_absmax, const float *fin_w, const float *fin_b, void *stream);
+                         float *out_part, const float *in_absmax, const float *fin_w, const float *fin_b, void *stream,
+                         const GnIn &stat_in = GnIn{}, const GnOut &stat_out = GnOut{});
 
 int vt_conv3d_gcr_f16x3_scaled(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                                const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
@@ -1922,8 +2079,10 @@ int vt_conv1x1_pack_f16x3(const float *w, int Cout, int Cin, float *packed, void
 
 static int conv_h_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                          const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
-                         float *out_part, const float *in_absmax, const float *fin_w, const float *fin_b, void *stream) {
+                         float *out_part, const float *in_absmax, const float *fin_w, const float *fin_b, void *stream,
+                         const GnIn &stat_in, const GnOut &stat_out) {
     HbArgs ha;
+    ha.c.stat_in = stat_in; ha.c.stat_out = stat_out;
     ha.in_absmax = in_absmax;
     ha.fin_w = fin_w; ha.fin_b = fin_b;
     ConvArgs &a = ha.c;
@@ -1984,11 +2143,16 @@ int vt_maxpool3d_cl(const float *x, int B, int D, int H, int W, int C, float *ou
     return vt_check(hipGetLastError(), "vt_maxpool3d_cl");
 }
 
-int vt_maxpool3d_cl_stats(const float *x, int B, int D, int H, int W, int C, float *out, int nblk, float *part, void *stream) {
-    if (!x || !out || !part || B <= 0 || C <= 0 || (C & 31) || D < 2 || H < 2 || W < 2 || nblk <= 0)
+static int maxpool_stats_launch(const float *x, int B, int D, int H, int W, int C, float *out, int nblk, float *part, const GnOut &stat_out, void *stream) {
+    if (!x || !out || (!part && !stat_out.acc) || B <= 0 || C <= 0 || (C & 31) || D < 2 || H < 2 || W < 2 || nblk <= 0)
         return vt_fail(VT_ERR_INVALID, "vt_maxpool3d_cl_stats: bad argument");
-    hipLaunchKernelGGL(maxpool3d_cl_stats_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, out, D, H, W, C, nblk, part);
+    hipLaunchKernelGGL(maxpool3d_cl_stats_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, out, D, H, W, C, nblk, part, stat_out);
     return vt_check(hipGetLastError(), "vt_maxpool3d_cl_stats");
+}
+
+int vt_maxpool3d_cl_stats(const float *x, int B, int D, int H, int W, int C, float *out, int nblk, float *part, void *stream) {
+    if (!part) return vt_fail(VT_ERR_INVALID, "vt_maxpool3d_cl_stats: bad argument");
+    return maxpool_stats_launch(x, B, D, H, W, C, out, nblk, part, GnOut{}, stream);
 }
 
 int vt_conv1x1_cl(const float *x, int64_t V, int Cin, const float *w, const float *bias, int Cout, float *out, void *stream) {
@@ -2014,7 +2178,164 @@ struct Bump {
     char *base; size_t off;
     float *take(size_t floats) { float *p = base ? (float *)(base + off) : nullptr; off += (floats * sizeof(float) + 255) / 256 * 256; return p; }
 };
-struct Tensor { float *x; float *part; int nblk; int C; };
+struct Tensor { float *x; float *part; int nblk; int C; unsigned long long *acc = nullptr; unsigned *flag = nullptr; int rows = 1; };
+
+// which kernel family a layer runs on (0: the exact-f32 kernels, which leave partial rows only)
+enum ConvKind { CONV_F32 = 0, CONV_HALF, CONV_KSPLIT, CONV_SPLIT };
+ConvKind conv_kind(const vt_unet3d_conv &c, int B, int Ri) {
+    if (c.packed_f16x3 && conv_h_tz(B, Ri, Ri, Ri, c.cin, c.cout) != 0) return CONV_HALF;
+    if (!c.packed_bf16x3) return CONV_F32;
+    if (vt_conv3d_ksplit_workspace_bytes(B, Ri, Ri, Ri, c.cin, c.cout)) return CONV_KSPLIT;
+    return conv_s_eligible(B, Ri, Ri, Ri, c.cin, c.cout) ? CONV_SPLIT : CONV_F32;
+}
+int conv_stat_blocks(ConvKind k, const vt_unet3d_conv &c, int B, int Ri) {
+    return k == CONV_HALF ? vt_conv3d_stat_blocks_f16x3(B, Ri, Ri, Ri, c.cin, c.cout)
+         : k == CONV_KSPLIT ? vt_conv3d_stat_blocks_ksplit(B, Ri, Ri, Ri, c.cin, c.cout)
+         : k == CONV_SPLIT ? vt_conv3d_stat_blocks_bf16x3(B, Ri, Ri, Ri, c.cin, c.cout) : vt_conv3d_stat_blocks(B, Ri, Ri, Ri, c.cin, c.cout);
+}
+
+// GroupNorm statistics through accumulator rows (GnOut / GnIn) where every layer runs on a kernel family that carries them and
+// the group / atom arithmetic divides; VTACO_GN_FOLD=0 keeps the finalising launches (A/B)
+bool unet3d_fold_ok(int B, int R, const vt_unet3d_params *p) {
+    const char *e = getenv("VTACO_GN_FOLD");
+    if (e && e[0] == '0') return false;
+    const int L = p->n_levels;
+    auto ok = [&](const vt_unet3d_conv &c, int Ri, int c_skip) {
+        const int groups = (c.cin >= p->groups) ? p->groups : 1;
+        return conv_kind(c, B, Ri) != CONV_F32 && groups <= 64 && c.cin % groups == 0 && (c.cin / groups) % GN_ATOM == 0 &&
+               c_skip % GN_ATOM == 0 && c.cout % 32 == 0 && c.cin <= GN_MAX_CIN;
+    };
+    for (int i = 0; i < L; ++i) for (int k = 0; k < 2; ++k) { if (!ok(p->enc[i][k], R >> i, 0)) return false; }
+    for (int k = 0; k + 1 < L; ++k) {
+        const int lvl = L - 2 - k;
+        if (!ok(p->dec[k][0], R >> lvl, p->enc[lvl][1].cout) || !ok(p->dec[k][1], R >> lvl, 0)) return false;
+    }
+    return true;
+}
+
+struct StatRegion { size_t off = 0, words = 0; };                  // the accumulators' place in the workspace (known after a planning pass)
+
+// vt_unet3d_fwd with the statistics in accumulator rows: 13 launches fewer (the first finalisation stays: the statistics of x
+// come as partial rows from its producer, and that launch also clears the accumulators)
+int unet3d_run_fold(const float *x_cl, int B, int R, const vt_unet3d_params *p, char *wsbase, size_t *ws_need, float *out,
+                    hipStream_t st, const float *in_part, int in_nblk, StatRegion *region) {
+    const int L = p->n_levels;
+    const bool plan = wsbase == nullptr;
+    StatRegion reg;
+    if (!plan) {
+        const int rc = unet3d_run_fold(x_cl, B, R, p, nullptr, nullptr, nullptr, st, in_part, in_nblk, &reg);
+        if (rc) return rc;
+    }
+    Bump ws{wsbase, 0};
+    unsigned long long *zbase = plan ? nullptr : reinterpret_cast<unsigned long long *>(wsbase + reg.off);
+    size_t zoff = 0;
+    // rows and flags of tensor t, written by `nblk` workgroups per scene and channel block
+    auto cells = [&](Tensor &t, int nblk) -> GnOut {
+        GnOut o;
+        o.C = t.C;
+        o.rows = 1;
+        while (o.rows < 64 && o.rows * 8 < nblk) o.rows <<= 1;
+        o.acc = zbase ? zbase + zoff : nullptr; zoff += gn_acc_words(B, o.rows, t.C);
+        o.flag = zbase ? reinterpret_cast<unsigned *>(zbase + zoff) : nullptr; zoff += (size_t)(B + 1) / 2;
+        t.part = nullptr; t.nblk = 0;
+        t.acc = o.acc; t.flag = o.flag; t.rows = o.rows;
+        return o;
+    };
+    auto stat_in = [&](const vt_unet3d_conv &c, const Tensor &a, const Tensor *low, int Ri) {
+        GnIn in;
+        in.acc[0] = a.acc; in.flag[0] = a.flag; in.C[0] = a.C; in.rows[0] = a.rows;
+        if (low) { in.acc[1] = low->acc; in.flag[1] = low->flag; in.C[1] = low->C; in.rows[1] = low->rows; }
+        in.gamma = c.gn_w; in.beta = c.gn_b;
+        in.groups = (c.cin >= p->groups) ? p->groups : 1;
+        in.eps = (float)p->eps;
+        in.count = (double)Ri * Ri * Ri;
+        return in;
+    };
+    int rc = 0;
+    // one 'gcr' layer; ss: a finished scale / shift table (the first layer's), else the statistics come through GnIn
+    auto gcr = [&](const vt_unet3d_conv &c, const float *ss, const Tensor &a, const Tensor *low, int Ri, Tensor &o, bool want_stats) -> int {
+        const int C2 = low ? low->C : 0;
+        if (a.C + C2 != c.cin) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: channel mismatch between levels");
+        o.C = c.cout;
+        o.x = ws.take((size_t)B * Ri * Ri * Ri * c.cout);
+        const ConvKind kind = conv_kind(c, B, Ri);
+        const size_t ksbytes = kind == CONV_KSPLIT ? vt_conv3d_ksplit_workspace_bytes(B, Ri, Ri, Ri, c.cin, c.cout) : 0;
+        float *kws = ksbytes ? ws.take(ksbytes / sizeof(float)) : nullptr;
+        GnOut so;
+        if (want_stats) so = cells(o, conv_stat_blocks(kind, c, B, Ri));
+        if (plan) return 0;
+        const GnIn si = ss ? GnIn{} : stat_in(c, a, low, Ri);
+        const float *lx = low ? low->x : nullptr;
+        if (kind == CONV_HALF)
+            return conv_h_launch(a.x, a.C, lx, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.cout, 1, o.x, nullptr, nullptr, nullptr, nullptr, st, si, so);
+        if (kind == CONV_KSPLIT)
+            return conv_sk_launch(a.x, a.C, lx, C2, B, Ri, Ri, Ri, ss, c.packed_bf16x3, c.cout, 1, o.x, nullptr, si, so, kws, ksbytes, st);
+        return conv_s_launch(a.x, a.C, lx, C2, B, Ri, Ri, Ri, ss, c.packed_bf16x3, c.cout, 1, o.x, nullptr, si, so, st);
+    };
+    Tensor skips[VT_UNET_MAX_LEVELS];
+    Tensor cur;
+    cur.x = const_cast<float *>(x_cl); cur.C = p->enc[0][0].cin;
+    float *ss0 = nullptr;
+    {
+        const vt_unet3d_conv &c0 = p->enc[0][0];
+        const int64_t V = (int64_t)R * R * R;
+        if (in_part) {                                              // the producer of x left partial rows: finalise them and clear the cells
+            ss0 = ws.take((size_t)B * c0.cin * 2);
+            if (!plan && (rc = gn_scale_shift_launch(in_part, in_nblk, cur.C, nullptr, 0, 0, B, V, (c0.cin >= p->groups) ? p->groups : 1,
+                                                     c0.gn_w, c0.gn_b, p->eps, ss0, zbase, reg.words, st))) return rc;
+        } else {
+            if (!plan && (rc = vt_check(hipMemsetAsync(zbase, 0, reg.words * sizeof(unsigned long long), st), "vt_unet3d_fwd: hipMemsetAsync"))) return rc;
+            const int nblk = (int)(V / 16 < 1 ? 1 : (V / 16 > 1024 ? 1024 : V / 16));
+            const GnOut so = cells(cur, nblk);
+            if (!plan && (rc = channel_stats_launch(x_cl, B, V, cur.C, nblk, nullptr, so, st))) return rc;
+        }
+    }
+    for (int i = 0; i < L; ++i) {
+        const int Ri = R >> i;
+        if (i > 0) {
+            Tensor pooled;
+            pooled.C = cur.C;
+            pooled.x = ws.take((size_t)B * Ri * Ri * Ri * cur.C);
+            const int64_t Vp = (int64_t)Ri * Ri * Ri;
+            const int nblk = (int)(Vp / 16 < 1 ? 1 : (Vp / 16 > 1024 ? 1024 : Vp / 16));
+            const GnOut so = cells(pooled, nblk);
+            if (Vp / 16 >= 1024) {                                  // pool and statistics in one pass where the statistics fill the chip (see unet3d_run)
+                if (!plan && (rc = maxpool_stats_launch(cur.x, B, 2 * Ri, 2 * Ri, 2 * Ri, cur.C, pooled.x, nblk, nullptr, so, st))) return rc;
+            } else {
+                if (!plan && (rc = vt_maxpool3d_cl(cur.x, B, 2 * Ri, 2 * Ri, 2 * Ri, cur.C, pooled.x, st))) return rc;
+                if (!plan && (rc = channel_stats_launch(pooled.x, B, Vp, pooled.C, nblk, nullptr, so, st))) return rc;
+            }
+            cur = pooled;
+        }
+        Tensor t1, t2;
+        if ((rc = gcr(p->enc[i][0], i == 0 ? ss0 : nullptr, cur, nullptr, Ri, t1, true))) return rc;
+        if ((rc = gcr(p->enc[i][1], nullptr, t1, nullptr, Ri, t2, L > 1))) return rc;
+        skips[i] = t2;
+        cur = t2;
+    }
+    for (int k = 0; k + 1 < L; ++k) {
+        const int lvl = L - 2 - k, Ri = R >> lvl;
+        Tensor t1, t2;
+        if ((rc = gcr(p->dec[k][0], nullptr, skips[lvl], &cur, Ri, t1, true))) return rc;
+        const vt_unet3d_conv &last = p->dec[k][1];
+        if (k + 2 == L && p->final_packed_f16x3 && last.packed_f16x3 && p->out_channels == 32 &&
+            vt_conv3d_final_fusable(B, Ri, Ri, Ri, last.cin, last.cout)) {
+            if (region) { region->off = ws.off; region->words = zoff; }
+            ws.take(zoff * 2);
+            if (ws_need) *ws_need = ws.off;
+            if (plan) return 0;
+            return conv_h_launch(t1.x, t1.C, nullptr, 0, B, Ri, Ri, Ri, nullptr, last.packed_f16x3, last.cout, 1, out, nullptr, nullptr,
+                                 p->final_packed_f16x3, p->final_b, st, stat_in(last, t1, nullptr, Ri), GnOut{});
+        }
+        if ((rc = gcr(last, nullptr, t1, nullptr, Ri, t2, k + 2 < L))) return rc;
+        cur = t2;
+    }
+    if (region) { region->off = ws.off; region->words = zoff; }
+    ws.take(zoff * 2);
+    if (ws_need) *ws_need = ws.off;
+    if (plan) return 0;
+    return vt_conv1x1_cl(cur.x, (int64_t)B * R * R * R, cur.C, p->final_w, p->final_b, p->out_channels, out, st);
+}
 
 // plan == true only sizes the workspace
 int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char *wsbase, size_t *ws_need, float *out,
@@ -2022,6 +2343,7 @@ int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char 
     const int L = p->n_levels;
     if (L < 1 || L > VT_UNET_MAX_LEVELS) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: bad level count");
     if (R % (1 << (L - 1))) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: resolution must be divisible by 2^(levels-1)");
+    if (unet3d_fold_ok(B, R, p)) return unet3d_run_fold(x_cl, B, R, p, wsbase, ws_need, out, st, in_part, in_nblk, nullptr);
     const bool plan = wsbase == nullptr;
     Bump ws{wsbase, 0};
     int maxC = 0;
