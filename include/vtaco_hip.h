@@ -367,6 +367,10 @@ int vt_mc_emit(const float *vol, int n0, int n1, int n2, void *workspace,
 /* ------------------------------------------------------------------------- */
 int vt_voxel_build(const float *pts, int B, int T, int R, double padding,
                    int *idx, int *order, int *seg_lo, int *seg_hi, void *stream);
+/* vt_voxel_build that also zero-fills `clear` (clear_bytes, both multiples of 16; e.g. the grid the scatter-mean fills next) with */
+/* the workgroups the sort leaves idle: the torch.zeros of generate_grid_features (pointnet.py:102-110) without a launch of its own. */
+int vt_voxel_build_clear(const float *pts, int B, int T, int R, double padding,
+                         int *idx, int *order, int *seg_lo, int *seg_hi, void *clear, size_t clear_bytes, void *stream);
 int vt_voxel_pool_max_fwd(const float *feat, const int *order, const int *seg_lo, const int *seg_hi,
                           int B, int T, int C, float *out, int *argmax, void *stream);
 int vt_voxel_pool_max_bwd(const float *grad_out, const int *argmax, const int *order,

@@ -312,6 +312,22 @@ def test_voxel_sort_extremes(B, Tn, R):
         assert torch.equal(lo[b], first) and torch.equal(hi[b], last)
 
 
+@pytest.mark.parametrize("B,Tn,R,shape", [(1, 3000, 64, (1, 64, 64, 64, 32)), (3, 8192, 16, (3, 16, 16, 16, 32)), (2, 5, 8, (2, 4)),
+                                          (2, 20001, 32, (2, 32, 32, 32, 32))])
+def test_voxel_build_clears_a_buffer_in_the_same_launch(B, Tn, R, shape):
+    """vt_voxel_build_clear: the index arrays of vt_voxel_build, and the caller's buffer zero-filled by the launch's other
+    workgroups (by a fill launch on the global-memory sort of large clouds)."""
+    from vtaco_amd import ops
+    g = torch.Generator().manual_seed(B + Tn)
+    p = ((torch.rand(B, Tn, 3, generator=g) - 0.5) * 1.1).to(DEV)
+    plain = ops.VoxelIndex(p, R, 0.1)
+    buf = torch.full(shape, float("nan"), device=DEV)
+    both = ops.VoxelIndex(p, R, 0.1, clear=buf)
+    for name in ("idx", "order", "seg_lo", "seg_hi"):
+        assert torch.equal(getattr(plain, name), getattr(both, name)), name
+    assert int(torch.count_nonzero(buf.view(torch.int32))) == 0
+
+
 @pytest.mark.parametrize("kind,T,R,c_dim", [("sphere", 3000, 64, 32), ("sphere", 1, 16, 32), ("sphere", 37, 16, 64), ("one", 8192, 64, 32),
                                             ("mixed", 8192, 16, 32), ("planes", 8192, 32, 16), ("sphere", 20000, 64, 32),
                                             ("mixed", 30000, 16, 32)])

@@ -122,6 +122,7 @@ SIGNATURES = {
     "vt_mc_read_counts_end": (_I, [_I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_D)]),
     "vt_mc_emit": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _VP, _I, _I, _F, _F, _VP]),
     "vt_voxel_build": (_I, [_VP, _I, _I, _I, _D, _VP, _VP, _VP, _VP, _VP]),
+    "vt_voxel_build_clear": (_I, [_VP, _I, _I, _I, _D, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "vt_voxel_pool_max_fwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "vt_voxel_pool_max_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
     "vt_voxel_scatter_mean_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),

@@ -43,8 +43,15 @@ constexpr size_t SORT_LDS = (size_t)MAX_T * 4 + 2 * (size_t)MAX_T * 2 + (size_t)
 // offsets, and the elements scatter to offset + rank.  Deterministic; 3 passes x ~3 us instead of 78 bitonic passes.
 __global__ void __launch_bounds__(SORT_THREADS)
 voxel_build_kernel(const float *pts, int T, int nbits, int R, float divisor, float clamp_hi, int a0, int a1, int a2,
-                   int *idx, int *order, int *seg_lo, int *seg_hi) {
+                   int *idx, int *order, int *seg_lo, int *seg_hi, int B, uint4 *fill, size_t fill16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+    if ((int)blockIdx.x >= B) {
+        // the workgroups behind the B sorting ones clear a buffer of the caller's (the grid the scatter-mean fills next): the sort keeps
+        // one CU per scene busy for ~18 us, the other CUs stream 33 MB of zeros in that time instead of in a launch of their own
+        const uint4 z = {0u, 0u, 0u, 0u};
+        for (size_t i = (size_t)(blockIdx.x - B) * SORT_THREADS + threadIdx.x; i < fill16; i += (size_t)(gridDim.x - B) * SORT_THREADS) fill[i] = z;
+        return;
+    }
     unsigned *ids = reinterpret_cast<unsigned *>(sort_lds);                         // [MAX_T]
     unsigned short *perm_a = reinterpret_cast<unsigned short *>(ids + MAX_T);       // [MAX_T]
     unsigned short *perm_b = perm_a + MAX_T;                                         // [MAX_T]
@@ -445,7 +452,8 @@ inline unsigned blocks_for(size_t total) {
 }
 
 int build_launch(const char *who, const float *pts, int B, int T, int R, float divisor, float clamp_hi,
-                 int a0, int a1, int a2, int *idx, int *order, int *seg_lo, int *seg_hi, void *stream) {
+                 int a0, int a1, int a2, int *idx, int *order, int *seg_lo, int *seg_hi, void *stream,
+                 void *fill = nullptr, size_t fill_bytes = 0) {
     char msg[96];
     auto fail = [&](int code, const char *what) { snprintf(msg, sizeof msg, "%s: %s", who, what); return vt_fail(code, msg); };
     if (!pts || !idx || !order || !seg_lo || !seg_hi) return fail(VT_ERR_INVALID, "null argument");
@@ -456,8 +464,10 @@ int build_launch(const char *who, const float *pts, int B, int T, int R, float d
     int nbits = 1;
     while (nbits < 32 && (1ull << nbits) < cells) ++nbits;
     static const bool force_global = getenv("VTACO_VOXEL_GLOBAL_SORT") != nullptr;     // tests: the large-cloud path on small clouds
+    if (fill_bytes && (!fill || (fill_bytes & 15) || ((size_t)fill & 15))) return fail(VT_ERR_INVALID, "the buffer to clear must be 16-byte aligned and sized");
     if (T > MAX_T || (force_global && T >= 64)) {
         hipStream_t s = (hipStream_t)stream;
+        if (fill_bytes) { const int frc = vt_fill32(fill, 0u, fill_bytes, s); if (frc) return frc; }
         const int nchunk = (T + 63) / 64, passes = (nbits + GBITS - 1) / GBITS;
         int *cur = (passes & 1) ? seg_lo : order, *oth = (passes & 1) ? order : seg_lo;   // an odd pass count ends in the other buffer
         const dim3 pg((unsigned)((T + 255) / 256), (unsigned)B), cg((unsigned)((nchunk + 3) / 4), (unsigned)B);
@@ -478,8 +488,11 @@ int build_launch(const char *who, const float *pts, int B, int T, int R, float d
         if (e != hipSuccess) return vt_check(e, "vt_voxel_build: hipFuncSetAttribute");
         attr_set = true;
     }
-    hipLaunchKernelGGL(voxel_build_kernel, dim3(B), dim3(SORT_THREADS), SORT_LDS, (hipStream_t)stream,
-                       pts, T, nbits, R, divisor, clamp_hi, a0, a1, a2, idx, order, seg_lo, seg_hi);
+    const size_t fill16 = fill_bytes / 16;
+    size_t fb = (fill16 + SORT_THREADS * 16 - 1) / (SORT_THREADS * 16);                 // >= 16 stores per thread, at most two rounds of the chip
+    if (fb > (size_t)vt_num_cus() * 2) fb = (size_t)vt_num_cus() * 2;
+    hipLaunchKernelGGL(voxel_build_kernel, dim3((unsigned)(B + fb)), dim3(SORT_THREADS), SORT_LDS, (hipStream_t)stream,
+                       pts, T, nbits, R, divisor, clamp_hi, a0, a1, a2, idx, order, seg_lo, seg_hi, B, (uint4 *)fill, fill16);
     return vt_check(hipGetLastError(), who);
 }
 
@@ -491,6 +504,12 @@ int vt_voxel_build(const float *pts, int B, int T, int R, double padding,
                    int *idx, int *order, int *seg_lo, int *seg_hi, void *stream) {
     return build_launch("vt_voxel_build", pts, B, T, R, (float)(1.0 + padding + 10e-4), 0.999f, 0, 1, 2,
                         idx, order, seg_lo, seg_hi, stream);
+}
+
+int vt_voxel_build_clear(const float *pts, int B, int T, int R, double padding,
+                         int *idx, int *order, int *seg_lo, int *seg_hi, void *clear, size_t clear_bytes, void *stream) {
+    return build_launch("vt_voxel_build_clear", pts, B, T, R, (float)(1.0 + padding + 10e-4), 0.999f, 0, 1, 2,
+                        idx, order, seg_lo, seg_hi, stream, clear, clear_bytes);
 }
 
 int vt_plane_build(const float *pts, int B, int T, int R, double padding, int plane,

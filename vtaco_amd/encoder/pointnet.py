@@ -297,12 +297,16 @@ class LocalPoolPointnet(nn.Module):
         return self._mano_head(fea) if self.out_mano else fea
 
     def forward_grid(self, p):
-        vi = ops.VoxelIndex(p, self.reso_grid, self.padding)
-        if (self.unet3d is not None and not torch.is_grad_enabled() and self.unet3d.hip_supported() and self._fused_mlp_fits()
-                and self._one_launch_fits(vi) and self.unet3d.encoders[0].basic_module.SingleConv1.conv.in_channels == self.c_dim):
+        one_launch = (self.unet3d is not None and not torch.is_grad_enabled() and self.unet3d.hip_supported() and self._fused_mlp_fits()
+                      and self.unet3d.encoders[0].basic_module.SingleConv1.conv.in_channels == self.c_dim)
+        # the mean grid is cleared by the voxel sort's idle workgroups (one launch less; unused if a cell overflows the one-launch MLP)
+        R = self.reso_grid
+        zeroed = torch.empty((p.shape[0], R, R, R, self.c_dim), dtype=torch.float32, device=p.device) if one_launch else None
+        vi = ops.VoxelIndex(p, self.reso_grid, self.padding, clear=zeroed)
+        if one_launch and self._one_launch_fits(vi):
             # inference: the per-point MLP, the voxeliser's mean and the grid's GroupNorm statistics from one launch, then the UNet3D
             grid, stats = ops.pointnet_mlp_fused(p.float(), vi, self.fc_pos, self.blocks, self.fc_c, want_grid=True,
-                                                 weights=self._fused_weights())
+                                                 weights=self._fused_weights(), zeroed_grid=zeroed)
             return {'grid': self.unet3d.forward_channels_last(grid, in_stats=stats).permute(0, 4, 1, 2, 3)}
         feat = self.point_features(p.float(), vi)
         if self.unet3d is not None and not torch.is_grad_enabled() and self.unet3d.hip_supported():

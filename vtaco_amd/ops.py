@@ -331,9 +331,10 @@ I32 = torch.int32
 
 
 class VoxelIndex:
-    """Per-forward voxel bookkeeping of a point cloud [B,T,3] (vt_voxel_build)."""
+    """Per-forward voxel bookkeeping of a point cloud [B,T,3] (vt_voxel_build).  ``clear``: a contiguous float tensor the same
+    launch zero-fills with the workgroups the sort leaves idle (vt_voxel_build_clear: the mean grid, without a fill launch)."""
 
-    def __init__(self, pts, reso, padding=0.1):
+    def __init__(self, pts, reso, padding=0.1, clear=None):
         pts = pts.detach().float()
         if not pts.is_contiguous():
             pts = pts.contiguous()
@@ -344,6 +345,13 @@ class VoxelIndex:
         self.order = torch.empty((B, T), dtype=I32, device=dev)
         self.seg_lo = torch.empty((B, T), dtype=I32, device=dev)
         self.seg_hi = torch.empty((B, T), dtype=I32, device=dev)
+        if clear is not None:
+            check(_lib.load().vt_voxel_build_clear(dev_ptr(pts, "pts"), B, T, reso, float(padding),
+                                                   dev_ptr(self.idx, "idx", I32), dev_ptr(self.order, "order", I32),
+                                                   dev_ptr(self.seg_lo, "seg_lo", I32), dev_ptr(self.seg_hi, "seg_hi", I32),
+                                                   dev_ptr(clear, "clear"), clear.numel() * clear.element_size(), stream_ptr()),
+                  "vt_voxel_build_clear")
+            return
         check(_lib.load().vt_voxel_build(dev_ptr(pts, "pts"), B, T, reso, float(padding),
                                          dev_ptr(self.idx, "idx", I32), dev_ptr(self.order, "order", I32),
                                          dev_ptr(self.seg_lo, "seg_lo", I32), dev_ptr(self.seg_hi, "seg_hi", I32),
@@ -577,11 +585,12 @@ def pointnet_mlp_weights(fc_pos, blocks, fc_c):
     return ptrs, ws, [_c(fc_pos.weight), _c(fc_pos.bias), _c(fc_c.weight), _c(fc_c.bias)]
 
 
-def pointnet_mlp_fused(p, vi, fc_pos, blocks, fc_c, want_grid=False, weights=None):
+def pointnet_mlp_fused(p, vi, fc_pos, blocks, fc_c, want_grid=False, weights=None, zeroed_grid=None):
     """fc_pos -> block 0 -> 4 x (pool over the point's cell, concat, block) -> fc_c for one voxel index in ONE launch
     (vt_pointnet_mlp_fused; inference): [B,T,c_dim], bit-identical to the launch-per-layer path.  ``want_grid``: instead of the
     point features, the voxeliser's channels-last mean grid [B,R,R,R,c_dim] and its GroupNorm partial sums (part, nblk) from
-    the same kernel (scatter_mean + channel_stats without their launches and the pass over the grid)."""
+    the same kernel (scatter_mean + channel_stats without their launches and the pass over the grid); ``zeroed_grid``: that grid,
+    already cleared (VoxelIndex(clear=...))."""
     p = _c(p.float())
     B, T, _ = p.shape
     c_dim = fc_c.weight.shape[0]
@@ -592,7 +601,9 @@ def pointnet_mlp_fused(p, vi, fc_pos, blocks, fc_c, want_grid=False, weights=Non
     nblk = 0
     if want_grid:
         R = vi.R
-        grid = torch.zeros((B, R, R, R, c_dim), dtype=torch.float32, device=p.device)
+        if zeroed_grid is not None and tuple(zeroed_grid.shape) != (B, R, R, R, c_dim):
+            raise VtError(f"pointnet_mlp_fused: zeroed_grid must be {(B, R, R, R, c_dim)}, got {tuple(zeroed_grid.shape)}")
+        grid = zeroed_grid if zeroed_grid is not None else torch.zeros((B, R, R, R, c_dim), dtype=torch.float32, device=p.device)
         nblk = lib.vt_pointnet_mlp_stat_blocks(B, T)
         part = torch.empty((B, nblk, c_dim, 2), dtype=torch.float32, device=p.device)
     else:
