@@ -136,26 +136,32 @@ def decoder_mlp(sd, net, c):
     return net
 
 
-def local_decoder_forward(sd, p, grid, padding=0.1):
+def _head_actvn(x, leaky):
+    """``LocalDecoder.actvn`` (decoder.py:46-49): relu, or leaky_relu(0.2) with ``leaky`` -- applied in front of the output heads
+    only; the ResnetBlockFC activations are nn.ReLU whatever ``leaky`` says (layers.py:33)."""
+    return F.leaky_relu(x, 0.2) if leaky else F.relu(x)
+
+
+def local_decoder_forward(sd, p, grid, padding=0.1, leaky=False):
     """``LocalDecoder.forward`` (decoder.py:135-161): logits [B,N]."""
     c = trilinear_sample(grid, p, padding)
     net = decoder_mlp(sd, _lin(sd, "fc_p", p.to(sd["fc_p.weight"].dtype)), c)
-    return _lin(sd, "fc_out", F.relu(net)).squeeze(-1)
+    return _lin(sd, "fc_out", _head_actvn(net, leaky)).squeeze(-1)
 
 
-def local_decoder_forward_img(sd, p, grid, c_img, padding=0.1):
+def local_decoder_forward_img(sd, p, grid, c_img, padding=0.1, leaky=False):
     """``LocalDecoder.forward_img`` (decoder.py:71-103): tactile concat."""
     c = trilinear_sample(grid, p, padding)
     net = _lin(sd, "fc_p_img", torch.cat((p.to(c_img.dtype), c_img), dim=2))
     net = decoder_mlp(sd, net, c)
-    return _lin(sd, "fc_out", F.relu(net)).squeeze(-1)
+    return _lin(sd, "fc_out", _head_actvn(net, leaky)).squeeze(-1)
 
 
-def local_decoder_forward_contact(sd, p, grid, padding=0.1):
+def local_decoder_forward_contact(sd, p, grid, padding=0.1, leaky=False):
     """``LocalDecoder.forward_contact`` (decoder.py:105-133)."""
     c = trilinear_sample(grid, p, padding)
     net = decoder_mlp(sd, _lin(sd, "fc_p", p.to(sd["fc_p.weight"].dtype)), c)
-    a = F.relu(net)
+    a = _head_actvn(net, leaky)
     return _lin(sd, "fc_out", a).squeeze(-1), _lin(sd, "fc_out_contact", a).squeeze(-1)
 
 

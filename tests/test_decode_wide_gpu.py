@@ -1,0 +1,110 @@
+"""GPU parity of vt_decode_fwd_wide -- LocalDecoder beyond the shipped 32 / 32 shape: hidden_size and c_dim multiples of 32 up
+to 256, leaky heads (reference src/conv_onet/models/decoder.py:24-161) -- through the module the reference's users call:
+against the reference's own outputs (tests/golden/g16_decode_wide.npz) and against the oracle on seeded shapes in between.
+Exact-f32 arithmetic on v_mfma_f32_32x32x2_f32: the bar is 1e-5 on O(1) logits (summation order only)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = torch.from_numpy
+
+
+def _case(tag):
+    a, sd = load_golden("g16_decode_wide.npz")
+    arrs = {k[2:]: v for k, v in a.items() if k.startswith(tag + ".")}
+    sdc = {k[2:]: v.float() for k, v in sd.items() if k.startswith(tag + ".")}
+    hidden, c_dim, nb, leaky, nx = (int(x) for x in arrs["shape"])
+    return arrs, sdc, hidden, c_dim, nb, bool(leaky), nx
+
+
+def _decoder(hidden, c_dim, nb, leaky, sd=None, seed=0, contact=True):
+    from vtaco_amd.conv_onet.models.decoder import LocalDecoder
+    torch.manual_seed(seed)
+    dec = LocalDecoder(dim=3, c_dim=c_dim, hidden_size=hidden, n_blocks=nb, leaky=leaky, padding=0.1, with_contact=contact)
+    if sd is not None:
+        dec.load_state_dict(sd)
+    else:
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():
+            for n, p in dec.named_parameters():
+                p.add_(torch.randn(p.shape, generator=g) * (0.1 if n.endswith("fc_1.weight") else 0.03))
+    return dec.to(DEV)
+
+
+def _err(got, ref):
+    return float((got.cpu() - torch.as_tensor(ref)).abs().max())
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_wide_decoder_against_the_reference_fixture(tag):
+    a, sd, hidden, c_dim, nb, leaky, nx = _case(tag)
+    dec = _decoder(hidden, c_dim, nb, leaky, sd)
+    assert dec._wide
+    grid = T(a["grid"].astype(np.float32)).to(DEV)
+    p, c_img = T(a["prand"]).to(DEV), T(a["c_img"].astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        assert _err(dec(p, {"grid": grid}), a["logits"]) <= 1e-5
+        assert _err(dec.forward_img(p, {"grid": grid}, c_img), a["logits_img"]) <= 1e-5
+        o, oc = dec.forward_contact(p, {"grid": grid})
+        assert _err(o, a["logits_contact"]) <= 1e-5 and _err(oc, a["logits_contact2"]) <= 1e-5
+        lat = dec.decode_lattice(grid[:1], nx)
+        assert _err(lat, a["logits_lattice"]) <= 1e-5
+        # a slab of the lattice, and the same through explicit points
+        half = dec.decode_lattice(grid[:1], nx, first=nx * nx * 3, count=nx * nx * 2)
+        assert torch.equal(half, lat[:, nx * nx * 3: nx * nx * 5])
+
+
+@pytest.mark.parametrize("hidden,c_dim,nb,leaky,B,N,R", [(32, 32, 5, True, 2, 1000, 16), (96, 64, 2, False, 1, 33, 8),
+                                                        (128, 256, 1, True, 3, 257, 8), (256, 32, 8, False, 1, 64, 4),
+                                                        (64, 96, 3, False, 2, 1, 8)])
+def test_wide_decoder_against_the_oracle(hidden, c_dim, nb, leaky, B, N, R):
+    """Shapes between the fixture's: a leaky 32 / 32 decoder (routed to the wide kernel), c_dim > hidden (fc_p_img's K = 3 + c_dim
+    exceeds the hidden width), one and eight blocks, ragged point counts (one point; a tile and a bit)."""
+    from oracle import vtaco_oracle as orc
+    dec = _decoder(hidden, c_dim, nb, leaky, seed=hidden + c_dim + nb)
+    sd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
+    g = torch.Generator().manual_seed(N)
+    grid = torch.randn(B, c_dim, R, R, R, generator=g)
+    p = (torch.rand(B, N, 3, generator=g) - 0.5) * 1.3
+    c_img = torch.randn(B, N, c_dim, generator=g) * (torch.rand(B, N, 1, generator=g) < 0.4)
+    with torch.no_grad():
+        got = dec(p.to(DEV), {"grid": grid.to(DEV)})
+        got_img = dec.forward_img(p.to(DEV), {"grid": grid.to(DEV)}, c_img.to(DEV))
+        got_c, got_cc = dec.forward_contact(p.to(DEV), {"grid": grid.to(DEV)})
+    ref = orc.local_decoder_forward(sd, p, grid, leaky=leaky)
+    scale = max(1.0, float(ref.abs().max()))
+    assert _err(got, ref) <= 1e-5 * scale
+    assert _err(got_img, orc.local_decoder_forward_img(sd, p, grid, c_img, leaky=leaky)) <= 1e-5 * scale
+    rc, rcc = orc.local_decoder_forward_contact(sd, p, grid, leaky=leaky)
+    assert _err(got_c, rc) <= 1e-5 * scale and _err(got_cc, rcc) <= 1e-5 * scale
+
+
+def test_wide_decoder_finger_ids_and_errors():
+    from vtaco_amd._lib import VtError
+    from vtaco_amd.conv_onet.models.decoder import AttentionDecoder, LocalDecoder
+    dec = _decoder(64, 32, 2, True, seed=5)
+    g = torch.Generator().manual_seed(6)
+    grid = torch.randn(1, 32, 8, 8, 8, generator=g).to(DEV)
+    nx = 8
+    ids = torch.randint(0, 6, (1, nx ** 3), generator=g).to(torch.uint8)
+    ids[ids == 5] = 255                                           # no finger
+    feats = torch.randn(5, 32, generator=g)
+    with torch.no_grad():
+        got = dec.decode_lattice_ids(grid, nx, ids.to(DEV), feats.to(DEV))
+        table = torch.cat([feats, torch.zeros(1, 32)])
+        c_img = table[torch.where(ids == 255, torch.full_like(ids, 5), ids).long()]
+        ref = dec.decode_lattice(grid, nx, c_img=c_img.to(DEV))
+    assert torch.equal(got, ref)
+    # training at these shapes is not built: loud, not a silent fallback
+    with pytest.raises(VtError, match="training is built for the shipped shape"):
+        dec(torch.zeros(1, 4, 3, device=DEV), {"grid": grid})
+    for bad in (dict(hidden_size=48, c_dim=32), dict(hidden_size=288, c_dim=32), dict(hidden_size=64, c_dim=16)):
+        d = LocalDecoder(n_blocks=2, **bad).to(DEV)
+        with torch.no_grad(), pytest.raises(VtError, match="multiples of 32 up to 256"):
+            d(torch.zeros(1, 4, 3, device=DEV), {"grid": torch.zeros(1, bad["c_dim"], 4, 4, 4, device=DEV)})
+    with pytest.raises(VtError, match="shipped shape"):
+        AttentionDecoder(c_dim=64, hidden_size=64)

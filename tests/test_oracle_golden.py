@@ -1,6 +1,7 @@
 """CPU: the oracle (oracle/vtaco_oracle.py) against golden vectors produced by
 the real reference (tests/golden/make_goldens.py).  This is what pins it."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import load_golden, sub_sd
@@ -27,6 +28,32 @@ def test_local_decoder_forward_variants():
     assert maxdiff(orc.local_decoder_forward_img(sd, pts, grid, c_img), a["logits_img"]) <= 2e-5
     o, oc = orc.local_decoder_forward_contact(sd, pts, grid)
     assert maxdiff(o, a["logits_contact"]) <= 2e-5 and maxdiff(oc, a["logits_contact2"]) <= 2e-5
+
+
+def _wide_case(tag):
+    """One case of g16_decode_wide.npz: (arrays of the case, its state dict in f32, hidden, c_dim, n_blocks, leaky, nx)."""
+    a, sd = load_golden("g16_decode_wide.npz")
+    arrs = {k[2:]: v for k, v in a.items() if k.startswith(tag + ".")}
+    sdc = {k[2:]: v.float() for k, v in sd.items() if k.startswith(tag + ".")}
+    hidden, c_dim, nb, leaky, nx = (int(x) for x in arrs["shape"])
+    return arrs, sdc, hidden, c_dim, nb, bool(leaky), nx
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_local_decoder_beyond_the_shipped_shape(tag):
+    """The reference's LocalDecoder at 64/32/5 with leaky heads and at 256/128/3 (decoder.py:24-51): the oracle's restatement is
+    shape-generic and takes ``leaky`` -- pinned here against the reference's own outputs."""
+    a, sd, hidden, c_dim, nb, leaky, nx = _wide_case(tag)
+    grid, p, c_img = T(a["grid"].astype(np.float32)), T(a["prand"]), T(a["c_img"].astype(np.float32))
+    assert sd["fc_p.weight"].shape == (hidden, 3) and sd["fc_c.0.weight"].shape == (hidden, c_dim)
+    assert maxdiff(orc.local_decoder_forward(sd, p, grid, leaky=leaky), a["logits"]) <= 2e-5
+    assert maxdiff(orc.local_decoder_forward_img(sd, p, grid, c_img, leaky=leaky), a["logits_img"]) <= 2e-5
+    o, oc = orc.local_decoder_forward_contact(sd, p, grid, leaky=leaky)
+    assert maxdiff(o, a["logits_contact"]) <= 2e-5 and maxdiff(oc, a["logits_contact2"]) <= 2e-5
+    pts = (1.1 * orc.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)).unsqueeze(0)
+    assert maxdiff(orc.local_decoder_forward(sd, pts, grid[:1], leaky=leaky), a["logits_lattice"]) <= 2e-5
+    if leaky:                                                    # the flag matters on this fixture
+        assert maxdiff(orc.local_decoder_forward(sd, p, grid, leaky=False), a["logits"]) > 1e-3
 
 
 def test_trilinear_with_clamped_points():

@@ -5,6 +5,7 @@ Not the headline metric (bench.py is); numbers are quoted in DESIGN.md.
   train  : one training step fwd+bwd+Adam, 8 scenes x 2048 points per GPU (config 4's per-GPU share)
   dense256 : 256^3 decode + marching cubes (config 5 on one GPU)
   hand   : the hand encoder (plane PointNet + 2-D U-Net + MANO layer) and the MANO kernel alone
+  wide   : LocalDecoder at the reference's class-default widths (hidden 256, c_dim 128; vt_decode_fwd_wide) over the 128^3 lattice
 """
 import json, os, sys, time
 import torch
@@ -14,7 +15,7 @@ from vtaco_amd.bench_util import build_scene, randomise_fc1, sphere_cloud
 from vtaco_amd.conv_onet.models import decoder_dict
 
 dev = torch.device("cuda:0")
-SECTIONS = set(sys.argv[1:]) or {"img", "fusion", "train", "dense256", "hand"}
+SECTIONS = set(sys.argv[1:]) or {"img", "fusion", "train", "dense256", "hand", "wide"}
 # MIOpen only picks its fast f32 conv3d kernels for channels_last_3d tensors in find mode, and only if
 # the flag is set before the first convolution of the process (26 ms vs 382 ms fwd+bwd at B=2)
 torch.backends.cudnn.benchmark = True
@@ -44,6 +45,21 @@ if "img" in SECTIONS:
         t = timed(lambda: dec.decode_lattice(grid, nx, c_img=c_img, precision=prec), 50, 5)
         print(json.dumps({"workload": f"forward_img (tactile concat) 128^3 lattice, {prec}", "ms": t * 1e3,
                           "points_per_s": nx ** 3 / t, "tflops": 33536 * nx ** 3 / t / 1e12}))
+
+# --- wide: the general-shape decoder (exact f32, weights streamed from L2)
+if "wide" in SECTIONS:
+    for hidden, cd in ((256, 128), (64, 32)):
+        torch.manual_seed(1)
+        wdec = decoder_dict['simple_local'](dim=3, c_dim=cd, hidden_size=hidden, n_blocks=5).to(dev).eval()
+        randomise_fc1(wdec, 4)
+        wgrid = torch.randn(1, cd, 64, 64, 64, device=dev)
+        with torch.no_grad():
+            t = timed(lambda: wdec.decode_lattice(wgrid, nx), 5, 1)
+        flop = 2 * (3 * hidden + 5 * (cd + 2 * hidden) * hidden + hidden)
+        print(json.dumps({"workload": f"LocalDecoder hidden {hidden} / c_dim {cd} / 5 blocks, 128^3 lattice (vt_decode_fwd_wide, exact f32)",
+                          "ms": t * 1e3, "points_per_s": nx ** 3 / t, "tflops": flop * nx ** 3 / t / 1e12,
+                          "roofline": {"bound": "mfma", "achieved": flop * nx ** 3 / t / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                                       "frac": flop * nx ** 3 / t / 1e12 / 157.3, "traffic": None}}))
 
 # --- fusion: attention decoder, chunks of 2048 points as a batch of 1024 "scenes" sharing one grid
 torch.manual_seed(0)

@@ -103,6 +103,9 @@ SIGNATURES = {
     "vt_decode_fwd_f16x3": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP, _I, _VP, _D, _VP, _VP, _VP]),
     "vt_decode_range_status": (_I, [ctypes.POINTER(ctypes.c_uint32), _I, _VP]),
     "vt_decoder_pack_f16f8": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
+    "vt_decoder_wide_blob_bytes": (_SZ, [_I, _I, _I, _I]),
+    "vt_decoder_pack_wide": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
+    "vt_decode_fwd_wide": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _I, _I, _I, _D, _VP, _VP, _VP]),
     "vt_decode_f16f8_covers": (_I, [_I, _I, _I, _F, _I64, _I64, _D]),
     "vt_decode_fwd_f16f8": (_I, [_VP, _I, _I, _I, _I64, _I, _F, _I64, _VP, _VP, _VP, _I, _VP, _D, _VP, _VP]),
     "vt_decoder_pack_t": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),

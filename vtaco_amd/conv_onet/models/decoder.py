@@ -118,9 +118,14 @@ class LocalDecoder(nn.Module):
         super().__init__()
         if dim != 3:
             raise VtError("LocalDecoder: only dim=3 is built")
-        if leaky or sample_mode != 'bilinear':
-            raise VtError("LocalDecoder: the HIP path implements relu + trilinear ('bilinear') sampling only")
+        if sample_mode != 'bilinear':
+            raise VtError("LocalDecoder: the HIP path implements trilinear ('bilinear') sampling only")
         self.c_dim, self.n_blocks, self.hidden_size = c_dim, n_blocks, hidden_size
+        # `leaky`: leaky_relu(0.2) in front of the output heads (reference decoder.py:46-49, 157; the blocks stay ReLU).  The shipped
+        # shape (32 / 32, relu) runs on the LDS-resident kernels of decode.hip, training included; every other shape -- hidden_size
+        # and c_dim multiples of 32 up to 256, e.g. the class defaults 256 / 128 -- on vt_decode_fwd_wide: exact f32, inference only
+        self.leaky = bool(leaky)
+        self._wide = self.leaky or hidden_size != 32 or c_dim != 32
         self.sample_mode, self.padding = sample_mode, padding
         self.fc_c = nn.ModuleList(nn.Linear(c_dim, hidden_size) for _ in range(n_blocks))
         self.fc_p = nn.Linear(dim, hidden_size)
@@ -148,6 +153,8 @@ class LocalDecoder(nn.Module):
         if head2:
             params += list(head2)
         stamp = tuple((p.data_ptr(), p._version) for p in params)
+        if self._wide:
+            precision = "wide"
         hit = self._blobs.get((img, contact, precision))
         if hit is not None and hit[0] == stamp:
             return hit[1]
@@ -184,8 +191,16 @@ class LocalDecoder(nn.Module):
     def _wants_grad(self, grid, c_img=None):
         if not torch.is_grad_enabled():
             return False
-        return grid.requires_grad or (c_img is not None and c_img.requires_grad) or any(
+        wants = grid.requires_grad or (c_img is not None and c_img.requires_grad) or any(
             p.requires_grad for p in self.parameters())
+        if wants and self._wide:
+            raise VtError(f"LocalDecoder: training is built for the shipped shape only (hidden_size = c_dim = 32, relu); hidden_size="
+                          f"{self.hidden_size}, c_dim={self.c_dim}, leaky={self.leaky} run under torch.no_grad()")
+        return wants
+
+    def _wide_fwd(self, grid, **kw):
+        return ops.decode_fwd(grid, self._blob(img=kw.get("c_img") is not None, contact=kw.get("want_contact", False)),
+                              padding=self.padding, precision="wide", wide=(self.hidden_size, self.n_blocks, self.leaky), **kw)
 
     @staticmethod
     def _grid_of(c_plane):
@@ -200,6 +215,8 @@ class LocalDecoder(nn.Module):
         grid = self._grid_of(c_plane)
         if self._wants_grad(grid):
             return _DecodeFn.apply(self, p, grid, None, *self._params(False))
+        if self._wide:
+            return self._wide_fwd(grid, pts=p)
         prec = self._point_precision()
         return ops.decode_fwd(grid, self._blob(precision=prec), pts=p, padding=self.padding, precision=prec)
 
@@ -208,6 +225,8 @@ class LocalDecoder(nn.Module):
         grid = self._grid_of(c_plane)
         if self._wants_grad(grid, c_img):
             return _DecodeFn.apply(self, p, grid, c_img, *self._params(True))
+        if self._wide:
+            return self._wide_fwd(grid, pts=p, c_img=c_img.float())
         prec = self._point_precision()
         return ops.decode_fwd(grid, self._blob(img=True, precision=prec), pts=p, c_img=c_img, padding=self.padding, precision=prec)
 
@@ -218,6 +237,8 @@ class LocalDecoder(nn.Module):
             # training with the contact head: the fused decode kernel with both heads and its HIP backward
             return _DecodeContactFn.apply(self, p.float(), grid, *self._params(False),
                                           self.fc_out_contact.weight, self.fc_out_contact.bias)
+        if self._wide:
+            return self._wide_fwd(grid, pts=p, want_contact=True)
         prec = self._point_precision()
         return ops.decode_fwd(grid, self._blob(contact=True, precision=prec), pts=p, padding=self.padding, want_contact=True,
                               precision=prec)
@@ -227,6 +248,8 @@ class LocalDecoder(nn.Module):
         """Logits of ``box * make_3d_grid((-.5,)*3,(.5,)*3,(nx,)*3)[first:first+count]``
         (generation.py:155-157 + eval_points) without materialising the points."""
         count = nx ** 3 - first if count is None else count
+        if self._wide:
+            return self._wide_fwd(grid, lattice=(nx, box, first, count), out=out, **({} if c_img is None else {"c_img": c_img.float()}))
         precision = precision or self.precision
         if precision == "f16f8" and not ops.f16f8_covers(grid, (nx, box, first, count), self.padding):
             precision = "f16x3"                   # slabs the fp8-corrected kernel does not cover
@@ -239,6 +262,12 @@ def _decode_lattice_ids(self, grid, nx, finger_ids, finger_feats, box=1.1, first
     instead of a dense c_img tensor (what the 256^3 configuration needs: 16.7 MB of ids instead of
     2.1 GB of c_img_all)."""
     count = nx ** 3 - first if count is None else count
+    if self._wide:
+        # the wide kernel takes the dense tensor: finger_feats[ids], zeros where ids == 255 (B * count * c_dim floats)
+        table = torch.cat([finger_feats.float(), finger_feats.new_zeros((1, finger_feats.shape[1]), dtype=torch.float32)])
+        ids = finger_ids.reshape(grid.shape[0], count).long()
+        c_img = table[torch.where(ids == 255, torch.full_like(ids, finger_feats.shape[0]), ids)]
+        return self._wide_fwd(grid, lattice=(nx, box, first, count), out=out, c_img=c_img)
     precision = precision or self.precision
     if precision == "f16f8" and not ops.f16f8_covers(grid, (nx, box, first, count), self.padding):
         precision = "f16x3"
@@ -259,6 +288,9 @@ class AttentionDecoder(LocalDecoder):
                  sample_mode='bilinear', padding=0.1, with_contact=False, **kwargs):
         super().__init__(dim=dim, c_dim=c_dim, hidden_size=hidden_size, n_blocks=n_blocks, leaky=leaky,
                          sample_mode=sample_mode, padding=padding, with_contact=with_contact)
+        if self._wide:
+            raise VtError("AttentionDecoder: the TransformerFusion kernels and the MLP behind them are built for the shipped shape "
+                          "(hidden_size = c_dim = 32, relu) only")
         self.fuser = TransformerFusion(use_xyz=True, input_size=input_size, d_model=c_dim, num_layers=1,
                                        key_feature_dim=64, with_pos_embed=False,
                                        encoder_pos_embed_input_dim=3, decoder_pos_embed_input_dim=3)
