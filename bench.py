@@ -185,7 +185,7 @@ def stage_times(scene, dec, grid, nx, out, dev, precision):
     return res
 
 
-PMC_SUMMARY = os.path.join("profiles", "r02f_pmc_summary.csv")
+PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.csv")
 EXTRAS_LIMIT_S = 420            # the sections after the headline (sharded scene, training step, CPU baseline) take well under a minute
 
 
@@ -228,7 +228,13 @@ def roofline_of(precision, flop_pt, npts, kern_ms):
         r["pmc"] = {"matrix_pipe_busy": pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,
                     "valu_issue": 4.0 * pmc.get("SQ_INSTS_VALU", 0.0) / simd_cycles,
                     "source": PMC_SUMMARY + " (profiled launches of the same command)"}
-    if precision in SPLIT:
+    if precision == "f16f8":
+        r["note"] = ("f16 hi products (2 MFMAs per 32x32x32 layer half) + ONE fp8 32x32x64 MFMA for both correction products: 128 matrix "
+                     "cycles per layer against 192 for three f16 products and 64 for a plain f16 layer, so frac <= 0.50 by construction; "
+                     "the rest is VALU issue (relu, hi/lo split, fp8 conversion: see `pmc`) and the clock the chip holds under this load; "
+                     "DESIGN.md section 4")
+        r["vs_f32_mfma_roofline"] = achieved / PEAK_F32_MFMA_TFLOPS
+    elif precision in SPLIT:
         r["note"] = ("split 16-bit operands: each f32 product = 3 MFMA products (lo*hi + hi*lo + hi*hi) on the bf16 / f16 matrix "
                      "core (same rate), so the matrix pipe executes ~3x the algorithmic FLOP: frac <= 0.33 by construction; the "
                      "rest is VALU issue (relu, hi/lo split, trilinear FMAs: see `pmc`); DESIGN.md section 4")

@@ -3,7 +3,7 @@
 # gpurun copies back at most 64 MiB).  Usage: TAG=r01e bash tools/collect_profiles.sh
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
-TAG=${TAG:-r02f}
+TAG=${TAG:-r03}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_under_profiler.json 2> $O/stats.err; echo "stats rc=$?"
@@ -12,9 +12,10 @@ find $O/stats -name '*kernel_trace*' -delete 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_decode -o decode -- python3 $R/bench.py --steps 200 --warmup 20 --decode-only --no-cpu-baseline > $O/bench_decode_under_profiler.json 2> $O/stats_decode.err; echo "decode stats rc=$?"
 find $O/stats_decode -name '*kernel_trace*' -delete 2>/dev/null
 echo "kernel,counter,launches,mean_per_launch" > $O/pmc_summary.csv
-for P in f16x3 bf16x3 f32; do
+for P in f16f8 f16x3 bf16x3 f32; do
   # the bench also launches the other precision's kernel (its exact-f32 side measurement): keep one kernel per key
-  case $P in f16x3) KPAT='staged2_kernelILi2E,staged2_kernel<2>';; bf16x3) KPAT='staged2_kernelILi1E,staged2_kernel<1>';; *) KPAT='staged2_kernelILi0E,staged2_kernel<0>';; esac
+  case $P in f16f8) KPAT='staged3_kernelILi2E,staged3_kernel<2>';; f16x3) KPAT='staged3_kernelILi1E,staged3_kernel<1>';;
+             bf16x3) KPAT='staged2_kernelILi1E,staged2_kernel<1>';; *) KPAT='staged2_kernelILi0E,staged2_kernel<0>';; esac
   pmc(){ tag=$1; shift; d=$O/pmc_${P}_$tag; timeout 200 rocprofv3 --pmc "$@" --kernel-trace -d $d -o p -- python3 $R/bench.py --steps 10 --warmup 2 --decode-only --no-cpu-baseline --precision $P > /dev/null 2>&1; echo "pmc $P $tag rc=$?"; python3 $R/tools/pmc_summary.py decode_$P=$d --kernel "$KPAT" | tail -n +2 >> $O/pmc_summary.csv; rm -rf $d; }
   pmc fetch FETCH_SIZE
   pmc write WRITE_SIZE
