@@ -45,9 +45,9 @@ const char *vt_last_error(void);
 /* into the MFMA-fragment order vt_decode_fwd reads from LDS.                   */
 /* ------------------------------------------------------------------------- */
 typedef struct vt_decoder_params {
-    int32_t hidden;      /* hidden_size, must be 32                                  */
-    int32_t c_dim;       /* c_dim, must be 32                                        */
-    int32_t n_blocks;    /* n_blocks, must be 5                                      */
+    int32_t hidden;      /* hidden_size: 32 (vt_decoder_pack*), 32..256 (_pack_wide)  */
+    int32_t c_dim;       /* c_dim: 32 (vt_decoder_pack*), 32..256 (_pack_wide)        */
+    int32_t n_blocks;    /* n_blocks: 5 (vt_decoder_pack*), 1..8 (_pack_wide)         */
     int32_t p_in;        /* columns of fc_p_w: 3 (fc_p) or 3+c_dim (fc_p_img)        */
     const float *fc_p_w; /* [hidden, p_in]  fc_p.weight or fc_p_img.weight           */
     const float *fc_p_b; /* [hidden]                                                 */
@@ -156,6 +156,22 @@ int vt_decode_fwd_f16f8(const float *grid_cl, int B, int R, int C, int64_t N,
 /* clears it: the caller re-runs the affected scenes with vt_decode_fwd_bf16x3 or the exact-f32        */
 /* kernel (the host mirror's Generator3D does).  No reference counterpart: the reference is f32.        */
 int vt_decode_range_status(unsigned *host_status, int reset, void *stream);
+
+/* LocalDecoder beyond the shipped shape.  Replaces the same reference functions (decoder.py:135-161, */
+/* 71-103, 105-133) for hidden_size and c_dim any multiples of 32 up to 256 (the class defaults are      */
+/* 256 / 128, decoder.py:24), n_blocks <= VT_MAX_BLOCKS, and `leaky`: leaky_relu(0.2) in front of the       */
+/* output heads (decoder.py:46-49, 157; the ResnetBlockFC activations are ReLU regardless, layers.py:33).    */
+/* Exact f32 (v_mfma_f32_32x32x2_f32), inference only.  The weights stream from L2 in the fragment order      */
+/* vt_decoder_pack_wide writes (params_host->hidden / c_dim / n_blocks / p_in describe the shape; p_in = 3,    */
+/* or 3 + c_dim for forward_img); blob_bytes from vt_decoder_wide_blob_bytes (0: shape not covered).           */
+/* vt_decode_fwd_wide: the arguments of vt_decode_fwd (pts or lattice, optional c_img [B,N,c_dim], out2 for     */
+/* the contact head) plus the shape the blob was packed for; C = c_dim = the grid's channel count.               */
+size_t vt_decoder_wide_blob_bytes(int hidden, int c_dim, int n_blocks, int p_in);
+int vt_decoder_pack_wide(const vt_decoder_params *params_host, float *blob, size_t blob_bytes, void *stream);
+int vt_decode_fwd_wide(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                       int lattice_nx, float lattice_box, int64_t lattice_first,
+                       const float *c_img, const float *blob_wide, int hidden, int n_blocks, int leaky, double padding,
+                       float *out, float *out2, void *stream);
 
 /* Tactile feature assignment and decode by finger id (SURVEY.md section 8f "next" row 2).        */
 /* Replaces: the scipy cdist + np.where glue that fills the dense c_img_all [1,N,32] at            */

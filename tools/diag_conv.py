@@ -1,4 +1,4 @@
-"""Diagnostic (VT_DIAG_HB build only): per-wave shader-clock sums of the phases of the persistent split-f16 conv on one
+"""Diagnostic (VT_DIAG_HB build only; the stamps live in tools/probe/conv_diag.patch, see tools/README.md): per-wave shader-clock sums of the phases of the persistent split-f16 conv on one
 32->32 layer at 64^3.  bash tools/build_variant.sh hb "-DVT_DIAG_HB"; VTACO_HIP_LIB=variants/lib_hb.so python tools/diag_conv.py"""
 import ctypes, os, sys
 import numpy as np

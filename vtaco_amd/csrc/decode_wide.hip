@@ -4,10 +4,11 @@
 // (decoder.py:46-49, 157; the ResnetBlockFC activations are ReLU whatever `leaky` says, layers.py:33).  Inference
 // only, exact f32: v_mfma_f32_32x32x2_f32 with f32 operands, so the result is the f32 network's up to summation order.
 //
-// A workgroup of four waves owns 32 query points.  The weights do not fit LDS at these widths (256/128/5: 3.3 MB), so they stream
+// A workgroup of eight waves owns 32 query points.  The weights do not fit LDS at these widths (256/128/5: 3.3 MB), so they stream
 // from L2 in fragment order (one coalesced 16-byte load per lane = four k-steps of one 32-row block) and the ACTIVATIONS live in
 // LDS: the sampled features c [c_dim][32 points] and two [hidden][32] buffers the layers ping-pong through; the residual
-// stream `net` never leaves the registers of the wave that owns its 32-row blocks (wave w: blocks w, w + 4).
+// stream `net` never leaves the registers of the wave that owns its 32-row block (wave w: rows 32 w .. 32 w + 31; with four waves
+// and two blocks each a 256-wide decoder kept one wave per SIMD: 55.7 ms per 128^3 against 0.0 with eight).
 //   per point: 2 * (p_in + n_blocks * (c_dim + 2 hidden) * hidden) flop; at 256/128/5 the f32 matrix pipe bounds a 128^3 lattice
 //   at ~22 ms (157 TFLOP/s), the weight stream at 3.3 MB per 32 points from L2 at about the same.
 #include <hip/hip_runtime.h>
@@ -17,7 +18,7 @@
 
 namespace {
 
-constexpr int WIDE_THREADS = 256, WIDE_PTS = 32, WIDE_PITCH = 33;    // pitch 33: the channel-major writes of a wave hit 32 banks
+constexpr int WIDE_THREADS = 512, WIDE_WAVES = WIDE_THREADS / 64, WIDE_PTS = 32, WIDE_PITCH = 33;    // pitch 33: the channel-major writes of a wave hit 32 banks
 constexpr int WIDE_MAX = 256;
 
 struct WideArgs {
@@ -86,7 +87,7 @@ __device__ __forceinline__ f32x16 bias16(const float *b, int ob, int kg) {
 
 __global__ void __launch_bounds__(WIDE_THREADS)
 decode_wide_kernel(WideArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];      // c [C][33] | buffer A [max(H, Kp)][33] | buffer B [H][33] | heads [4][2][2][32]
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // c [C][33] | buffer A [max(H, Kp)][33] | buffer B [H][33] | heads [8 waves][2 lane halves][2 heads][32]
     const DecodeArgs &d = a.d;
     const int H = a.H, C = a.C, nh = H / 32, Kp = a.Kp;
     const int rowsA = H > Kp ? H : Kp;
@@ -98,10 +99,11 @@ decode_wide_kernel(WideArgs a) {
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // ---- the tile's inputs: sampled features c (decoder.py:62-68), fc_p's input rows [p | c_img | 0] ----
         {
-            const int ch = tid & 31, pg = tid >> 5;                 // thread = (channel lane, point group): points pg, pg + 8, ...
+            constexpr int PG = WIDE_THREADS / 32;
+            const int ch = tid & 31, pg = tid >> 5;                 // thread = (channel lane, point group): points pg, pg + PG, ...
 #pragma unroll
-            for (int i = 0; i < WIDE_PTS / 8; ++i) {
-                const int pt = pg + 8 * i;
+            for (int i = 0; i < WIDE_PTS / PG; ++i) {
+                const int pt = pg + PG * i;
                 uint32_t g = tile * WIDE_PTS + pt;
                 if (g >= d.total) g = d.total - 1u;
                 const uint32_t b = g / d.N;
@@ -133,59 +135,44 @@ decode_wide_kernel(WideArgs a) {
         }
         __syncthreads();
         // ---- fc_p (decoder.py:139 / 81) ----
-        f32x16 net[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int ob = wave + 4 * s;
-            if (ob < nh) net[s] = wide_gemm(bias16(bias, ob, kg), a.blob + lay.w_p, ob, Kp, bufA, lane);
-        }
+        f32x16 net;
+        const int ob = wave;                                        // nh <= WIDE_WAVES; waves beyond the width only keep the barriers
+        if (ob < nh) net = wide_gemm(bias16(bias, ob, kg), a.blob + lay.w_p, ob, Kp, bufA, lane);
         __syncthreads();                                            // bufA is free again
         // ---- n_blocks x (fc_c add, ResnetBlockFC: layers.py:41-50; its activations are ReLU) ----
         for (int blk = 0; blk < a.nb; ++blk) {
             const float *wb = a.blob + lay.w_blk + (size_t)blk * (lay.w_c + lay.w_0 + lay.w_1);
             const float *bb = bias + (size_t)H * (1 + 3 * blk);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int ob = wave + 4 * s;
-                if (ob >= nh) continue;
+            if (ob < nh) {
                 const f32x16 bc = bias16(bb, ob, kg);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) net[s][i] += bc[i];
-                net[s] = wide_gemm(net[s], wb, ob, C, cl, lane);
+                for (int i = 0; i < 16; ++i) net[i] += bc[i];
+                net = wide_gemm(net, wb, ob, C, cl, lane);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) bufA[(32 * ob + chan_of(i, kg)) * WIDE_PITCH + j] = actvn(net[s][i], 0);
+                for (int i = 0; i < 16; ++i) bufA[(32 * ob + chan_of(i, kg)) * WIDE_PITCH + j] = actvn(net[i], 0);
             }
             __syncthreads();
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int ob = wave + 4 * s;
-                if (ob >= nh) continue;
+            if (ob < nh) {
                 const f32x16 hid = wide_gemm(bias16(bb + H, ob, kg), wb + lay.w_c, ob, H, bufA, lane);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) bufB[(32 * ob + chan_of(i, kg)) * WIDE_PITCH + j] = actvn(hid[i], 0);
             }
             __syncthreads();
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int ob = wave + 4 * s;
-                if (ob >= nh) continue;
+            if (ob < nh) {
                 const f32x16 b1 = bias16(bb + 2 * H, ob, kg);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) net[s][i] += b1[i];
-                net[s] = wide_gemm(net[s], wb + lay.w_c + lay.w_0, ob, H, bufB, lane);
+                for (int i = 0; i < 16; ++i) net[i] += b1[i];
+                net = wide_gemm(net, wb + lay.w_c + lay.w_0, ob, H, bufB, lane);
             }
         }
         // ---- fc_out / fc_out_contact on actvn(net) (decoder.py:157-158, 128-131) ----
         const float *ow = bias + (size_t)H * (1 + 3 * a.nb), *ow2 = ow + H + 1;
         float o1 = 0.0f, o2 = 0.0f;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int ob = wave + 4 * s;
-            if (ob >= nh) continue;
+        if (ob < nh) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = 32 * ob + chan_of(i, kg);
-                const float v = actvn(net[s][i], a.leaky);
+                const float v = actvn(net[i], a.leaky);
                 o1 = fmaf(ow[row], v, o1);
                 o2 = fmaf(ow2[row], v, o2);
             }
@@ -197,7 +184,7 @@ decode_wide_kernel(WideArgs a) {
             const int pt = tid & 31, which = tid >> 5;
             float o = which ? ow2[H] : ow[H];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) o += heads[(w * 2 + which) * 32 + pt];     // waves and lane halves in a fixed order
+            for (int w = 0; w < 2 * WIDE_WAVES; ++w) o += heads[(w * 2 + which) * 32 + pt];     // waves and lane halves in a fixed order
             const uint32_t g = tile * WIDE_PTS + pt;
             float *dst = which ? d.out2 : d.out;
             if (g < d.total && dst) dst[g] = o;
@@ -278,7 +265,7 @@ int vt_decode_fwd_wide(const float *grid_cl, int B, int R, int C, const float *p
     a.d.R = R; a.d.nx = lattice_nx; a.d.box = lattice_box; a.d.divisor = (float)(1.0 + padding + 10e-4);
     a.blob = blob; a.H = hidden; a.C = C; a.nb = n_blocks; a.p_in = p_in; a.Kp = (p_in + 7) / 8 * 8; a.leaky = leaky ? 1 : 0;
     const int rowsA = hidden > a.Kp ? hidden : a.Kp;
-    const size_t lds = ((size_t)(C + rowsA + hidden) * WIDE_PITCH + 4 * 2 * 2 * 32) * sizeof(float);
+    const size_t lds = ((size_t)(C + rowsA + hidden) * WIDE_PITCH + WIDE_WAVES * 2 * 2 * 32) * sizeof(float);
     static bool attr = false;
     if (!attr) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
