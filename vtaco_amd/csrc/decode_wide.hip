@@ -8,7 +8,8 @@
 // from L2 in fragment order (one coalesced 16-byte load per lane = four k-steps of one 32-row block) and the ACTIVATIONS live in
 // LDS: the sampled features c [c_dim][32 points] and two [hidden][32] buffers the layers ping-pong through; the residual
 // stream `net` never leaves the registers of the wave that owns its 32-row block (wave w: rows 32 w .. 32 w + 31; with four waves
-// and two blocks each a 256-wide decoder kept one wave per SIMD: 55.7 ms per 128^3 against 0.0 with eight).
+// and two blocks each a 256-wide decoder kept one wave per SIMD: 55.7 ms per 128^3 against 36.6 with eight; widths up to 128
+// run four waves: eight, half of them idle, took 7.1 ms at 64 / 32 against 5.3).
 //   per point: 2 * (p_in + n_blocks * (c_dim + 2 hidden) * hidden) flop; at 256/128/5 the f32 matrix pipe bounds a 128^3 lattice
 //   at ~22 ms (157 TFLOP/s), the weight stream at 3.3 MB per 32 points from L2 at about the same.
 #include <hip/hip_runtime.h>
@@ -18,7 +19,7 @@
 
 namespace {
 
-constexpr int WIDE_THREADS = 512, WIDE_WAVES = WIDE_THREADS / 64, WIDE_PTS = 32, WIDE_PITCH = 33;    // pitch 33: the channel-major writes of a wave hit 32 banks
+constexpr int WIDE_PTS = 32, WIDE_PITCH = 33;                           // pitch 33: the channel-major writes of a wave hit 32 banks
 constexpr int WIDE_MAX = 256;
 
 struct WideArgs {
@@ -85,9 +86,11 @@ __device__ __forceinline__ f32x16 bias16(const float *b, int ob, int kg) {
     return r;
 }
 
-__global__ void __launch_bounds__(WIDE_THREADS)
+template <int WIDE_WAVES>                                           // 4 for hidden <= 128, 8 above: one 32-row block per wave at most
+__global__ void __launch_bounds__(WIDE_WAVES * 64)
 decode_wide_kernel(WideArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];      // c [C][33] | buffer A [max(H, Kp)][33] | buffer B [H][33] | heads [8 waves][2 lane halves][2 heads][32]
+    constexpr int WIDE_THREADS = WIDE_WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // c [C][33] | buffer A [max(H, Kp)][33] | buffer B [H][33] | heads [waves][2 lane halves][2 heads][32]
     const DecodeArgs &d = a.d;
     const int H = a.H, C = a.C, nh = H / 32, Kp = a.Kp;
     const int rowsA = H > Kp ? H : Kp;
@@ -265,16 +268,20 @@ int vt_decode_fwd_wide(const float *grid_cl, int B, int R, int C, const float *p
     a.d.R = R; a.d.nx = lattice_nx; a.d.box = lattice_box; a.d.divisor = (float)(1.0 + padding + 10e-4);
     a.blob = blob; a.H = hidden; a.C = C; a.nb = n_blocks; a.p_in = p_in; a.Kp = (p_in + 7) / 8 * 8; a.leaky = leaky ? 1 : 0;
     const int rowsA = hidden > a.Kp ? hidden : a.Kp;
-    const size_t lds = ((size_t)(C + rowsA + hidden) * WIDE_PITCH + WIDE_WAVES * 2 * 2 * 32) * sizeof(float);
+    const int waves = hidden <= 128 ? 4 : 8;
+    const size_t lds = ((size_t)(C + rowsA + hidden) * WIDE_PITCH + (size_t)waves * 2 * 2 * 32) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_wide_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_wide_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return vt_check(e, "vt_decode_fwd_wide: hipFuncSetAttribute");
         attr = true;
     }
     const uint32_t ntiles = (a.d.total + WIDE_PTS - 1) / WIDE_PTS;
     const uint32_t cap = (uint32_t)vt_num_cus() * 8u;
-    hipLaunchKernelGGL(decode_wide_kernel, dim3(ntiles < cap ? ntiles : cap), dim3(WIDE_THREADS), lds, (hipStream_t)stream, a);
+    const dim3 grid(ntiles < cap ? ntiles : cap);
+    if (waves == 4) hipLaunchKernelGGL(decode_wide_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(decode_wide_kernel<8>, grid, dim3(512), lds, (hipStream_t)stream, a);
     return vt_check(hipGetLastError(), "vt_decode_fwd_wide");
 }
 
