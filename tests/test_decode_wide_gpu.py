@@ -99,12 +99,43 @@ def test_wide_decoder_finger_ids_and_errors():
         c_img = table[torch.where(ids == 255, torch.full_like(ids, 5), ids).long()]
         ref = dec.decode_lattice(grid, nx, c_img=c_img.to(DEV))
     assert torch.equal(got, ref)
-    # training at these shapes is not built: loud, not a silent fallback
-    with pytest.raises(VtError, match="training is built for the shipped shape"):
-        dec(torch.zeros(1, 4, 3, device=DEV), {"grid": grid})
     for bad in (dict(hidden_size=48, c_dim=32), dict(hidden_size=288, c_dim=32), dict(hidden_size=64, c_dim=16)):
         d = LocalDecoder(n_blocks=2, **bad).to(DEV)
         with torch.no_grad(), pytest.raises(VtError, match="multiples of 32 up to 256"):
             d(torch.zeros(1, 4, 3, device=DEV), {"grid": torch.zeros(1, bad["c_dim"], 4, 4, 4, device=DEV)})
     with pytest.raises(VtError, match="shipped shape"):
         AttentionDecoder(c_dim=64, hidden_size=64)
+
+
+def test_wide_decoder_under_autograd_runs_the_reference_arithmetic_on_the_device():
+    """At shapes beyond 32 / 32 the library has a forward kernel and no backward: under autograd LocalDecoder evaluates the
+    reference's operators through PyTorch-ROCm on the device (`_host_forward`).  Its logits equal the HIP kernel's, and its
+    gradients the oracle's autograd (CPU, float64 accumulation aside): a wide decoder trains."""
+    from oracle import vtaco_oracle as orc
+    hidden, c_dim, nb = 96, 64, 2
+    dec = _decoder(hidden, c_dim, nb, True, seed=11)
+    g = torch.Generator().manual_seed(12)
+    grid = torch.randn(2, c_dim, 8, 8, 8, generator=g)
+    p = (torch.rand(2, 200, 3, generator=g) - 0.5) * 1.2
+    c_img = torch.randn(2, 200, c_dim, generator=g)
+    gd = grid.to(DEV).requires_grad_(True)
+    out = dec.forward_img(p.to(DEV), {"grid": gd}, c_img.to(DEV))
+    assert out.requires_grad
+    with torch.no_grad():
+        fast = dec.forward_img(p.to(DEV), {"grid": gd.detach()}, c_img.to(DEV))
+    assert _err(out.detach(), fast.cpu()) <= 1e-5
+    out.square().sum().backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+    gc = grid.clone().requires_grad_(True)
+    ref = orc.local_decoder_forward_img(sd, p, gc, c_img, leaky=True)
+    ref.square().sum().backward()
+    scale = float(gc.grad.abs().max())
+    assert _err(gd.grad, gc.grad) <= 1e-4 * scale
+    for name, prm in dec.named_parameters():
+        if sd[name].grad is None:
+            continue
+        assert _err(prm.grad, sd[name].grad) <= 1e-4 * max(1.0, float(sd[name].grad.abs().max())), name
+    # forward_contact and forward under autograd as well
+    o, oc = dec.forward_contact(p.to(DEV), {"grid": gd})
+    r, rc = orc.local_decoder_forward_contact({k: v.detach() for k, v in sd.items()}, p, grid, leaky=True)
+    assert _err(o.detach(), r) <= 1e-5 and _err(oc.detach(), rc) <= 1e-5

@@ -12,9 +12,11 @@ import os
 
 import torch
 from torch import nn
+from torch.nn import functional as F
 
 from ... import ops
 from ..._lib import VtError
+from ...common import normalize_3d_coordinate
 from ...layers import ResnetBlockFC
 from ...transformer_fusion import TransformerFusion
 
@@ -123,7 +125,9 @@ class LocalDecoder(nn.Module):
         self.c_dim, self.n_blocks, self.hidden_size = c_dim, n_blocks, hidden_size
         # `leaky`: leaky_relu(0.2) in front of the output heads (reference decoder.py:46-49, 157; the blocks stay ReLU).  The shipped
         # shape (32 / 32, relu) runs on the LDS-resident kernels of decode.hip, training included; every other shape -- hidden_size
-        # and c_dim multiples of 32 up to 256, e.g. the class defaults 256 / 128 -- on vt_decode_fwd_wide: exact f32, inference only
+        # and c_dim multiples of 32 up to 256, e.g. the class defaults 256 / 128 -- on vt_decode_fwd_wide (exact f32) without
+        # autograd, and under autograd through PyTorch-ROCm's own operators (_host_forward: grid_sample + rocBLAS linears; no
+        # kernel of this library -- the HIP backward exists for the shipped shape)
         self.leaky = bool(leaky)
         self._wide = self.leaky or hidden_size != 32 or c_dim != 32
         self.sample_mode, self.padding = sample_mode, padding
@@ -191,12 +195,24 @@ class LocalDecoder(nn.Module):
     def _wants_grad(self, grid, c_img=None):
         if not torch.is_grad_enabled():
             return False
-        wants = grid.requires_grad or (c_img is not None and c_img.requires_grad) or any(
+        return grid.requires_grad or (c_img is not None and c_img.requires_grad) or any(
             p.requires_grad for p in self.parameters())
-        if wants and self._wide:
-            raise VtError(f"LocalDecoder: training is built for the shipped shape only (hidden_size = c_dim = 32, relu); hidden_size="
-                          f"{self.hidden_size}, c_dim={self.c_dim}, leaky={self.leaky} run under torch.no_grad()")
-        return wants
+
+    def _host_forward(self, p, grid, c_img=None, contact=False):
+        """The reference's arithmetic in PyTorch-ROCm operators on the device (decoder.py:62-68, 71-161): what runs UNDER AUTOGRAD at
+        the shapes beyond 32 / 32 (`_wide`), where this library has a forward kernel but no backward.  Not a CPU path and not used by
+        inference."""
+        if not grid.is_cuda:
+            raise VtError(f"LocalDecoder: inputs must live on a HIP device (got {grid.device})")
+        vgrid = 2.0 * normalize_3d_coordinate(p.float(), padding=self.padding)[:, :, None, None] - 1.0
+        c = F.grid_sample(grid, vgrid, padding_mode='border', align_corners=True, mode='bilinear').squeeze(-1).squeeze(-1).transpose(1, 2)
+        net = self.fc_p(p.float()) if c_img is None else self.fc_p_img(torch.cat((p.float(), c_img), dim=2))
+        for lin, blk in zip(self.fc_c, self.blocks):
+            net = net + lin(c)
+            net = net + blk.fc_1(F.relu(blk.fc_0(F.relu(net))))
+        a = F.leaky_relu(net, 0.2) if self.leaky else F.relu(net)
+        out = self.fc_out(a).squeeze(-1)
+        return (out, self.fc_out_contact(a).squeeze(-1)) if contact else out
 
     def _wide_fwd(self, grid, **kw):
         return ops.decode_fwd(grid, self._blob(img=kw.get("c_img") is not None, contact=kw.get("want_contact", False)),
@@ -214,7 +230,7 @@ class LocalDecoder(nn.Module):
         """logits [B,N] for points p [B,N,3] (decoder.py:135-161)."""
         grid = self._grid_of(c_plane)
         if self._wants_grad(grid):
-            return _DecodeFn.apply(self, p, grid, None, *self._params(False))
+            return self._host_forward(p, grid) if self._wide else _DecodeFn.apply(self, p, grid, None, *self._params(False))
         if self._wide:
             return self._wide_fwd(grid, pts=p)
         prec = self._point_precision()
@@ -224,7 +240,7 @@ class LocalDecoder(nn.Module):
         """Tactile concat variant (decoder.py:71-103): fc_p_img([p; c_img])."""
         grid = self._grid_of(c_plane)
         if self._wants_grad(grid, c_img):
-            return _DecodeFn.apply(self, p, grid, c_img, *self._params(True))
+            return self._host_forward(p, grid, c_img) if self._wide else _DecodeFn.apply(self, p, grid, c_img, *self._params(True))
         if self._wide:
             return self._wide_fwd(grid, pts=p, c_img=c_img.float())
         prec = self._point_precision()
@@ -233,6 +249,8 @@ class LocalDecoder(nn.Module):
     def forward_contact(self, p, c_plane, **kwargs):
         """(occupancy logits, contact logits) (decoder.py:105-133)."""
         grid = self._grid_of(c_plane)
+        if self._wants_grad(grid) and self._wide:
+            return self._host_forward(p, grid, contact=True)
         if self._wants_grad(grid):
             # training with the contact head: the fused decode kernel with both heads and its HIP backward
             return _DecodeContactFn.apply(self, p.float(), grid, *self._params(False),
