@@ -80,8 +80,11 @@ def test_unsupported_configurations_raise():
         encoder_dict["pointnet_local_pool"](plane_type=["xz", "grid"], plane_resolution=32, grid_resolution=32)
     with pytest.raises(VtError):
         encoder_dict["pointnet_local_pool"](plane_type=["xz", "xy", "yz"], plane_resolution=32, out_mano=True, out_dim=51)  # no MANO asset given
+    assert decoder_dict["simple_local"](dim=3, c_dim=32, hidden_size=32, leaky=True)._wide       # leaky heads: the wide kernel (round 3)
     with pytest.raises(VtError):
-        decoder_dict["simple_local"](dim=3, c_dim=32, hidden_size=32, leaky=True)
+        decoder_dict["simple_local"](dim=3, c_dim=32, hidden_size=32, sample_mode="nearest")
+    with pytest.raises(VtError):
+        decoder_dict["attention_local"](dim=3, c_dim=64, hidden_size=64)                          # fusion kernels: the shipped shape only
     with pytest.raises(KeyError):
         decoder_dict["simple_local_crop"]
 
