@@ -8,4 +8,4 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d /root/repo/gpurun_out/et_r03 -o e -- python3 /root/repo/tools/enc_timeline.py > /dev/null 2>&1
 python3 /root/repo/tools/enc_timeline.py /root/repo/gpurun_out/et_r03/e_kernel_trace.csv > /root/repo/gpurun_out/r03_encoder_timeline.txt; tail -2 /root/repo/gpurun_out/r03_encoder_timeline.txt
 rm -rf /root/repo/gpurun_out/et_r03
-timeout 300 python3 bench.py > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err; echo "bench rc=$?"
+cd /root/repo && timeout 300 python3 bench.py > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err; echo "bench rc=$?"
