@@ -2180,6 +2180,13 @@ struct Bump {
 };
 struct Tensor { float *x; float *part; int nblk; int C; unsigned long long *acc = nullptr; unsigned *flag = nullptr; int rows = 1; };
 
+// blocks of a statistics pass over V voxels (the Python mirror uses the same rule, ops.stat_blocks: the per-block float sums -- and with them
+// the results -- are then the same whichever path computes them): 16-voxel blocks where that fills 1024 workgroups, 8-voxel blocks below
+int stat_blocks(int64_t V) {
+    const int64_t n = V / (V >= 16384 ? 16 : 8);
+    return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
+}
+
 // which kernel family a layer runs on (0: the exact-f32 kernels, which leave partial rows only)
 enum ConvKind { CONV_F32 = 0, CONV_HALF, CONV_KSPLIT, CONV_SPLIT };
 ConvKind conv_kind(const vt_unet3d_conv &c, int B, int Ri) {
@@ -2285,7 +2292,7 @@ int unet3d_run_fold(const float *x_cl, int B, int R, const vt_unet3d_params *p, 
                                                      c0.gn_w, c0.gn_b, p->eps, ss0, zbase, reg.words, st))) return rc;
         } else {
             if (!plan && (rc = vt_check(hipMemsetAsync(zbase, 0, reg.words * sizeof(unsigned long long), st), "vt_unet3d_fwd: hipMemsetAsync"))) return rc;
-            const int nblk = (int)(V / 16 < 1 ? 1 : (V / 16 > 1024 ? 1024 : V / 16));
+            const int nblk = stat_blocks(V);
             const GnOut so = cells(cur, nblk);
             if (!plan && (rc = channel_stats_launch(x_cl, B, V, cur.C, nblk, nullptr, so, st))) return rc;
         }
@@ -2297,14 +2304,12 @@ int unet3d_run_fold(const float *x_cl, int B, int R, const vt_unet3d_params *p, 
             pooled.C = cur.C;
             pooled.x = ws.take((size_t)B * Ri * Ri * Ri * cur.C);
             const int64_t Vp = (int64_t)Ri * Ri * Ri;
-            const int nblk = (int)(Vp / 16 < 1 ? 1 : (Vp / 16 > 1024 ? 1024 : Vp / 16));
+            // pool and statistics in ONE pass on every level: with partial rows that paid only where the blocks fill the chip (unet3d_run);
+            // accumulator rows have no finalisation that reads per-block rows, and 8-voxel blocks (stat_blocks) give the small levels the
+            // workgroups (16^3 and 8^3: 5.7 + 5.3 and 4.8 + 5.6 us as two launches each, 5.2 and 6.9 us as one)
+            const int nblk = stat_blocks(Vp);
             const GnOut so = cells(pooled, nblk);
-            if (Vp / 16 >= 1024) {                                  // pool and statistics in one pass where the statistics fill the chip (see unet3d_run)
-                if (!plan && (rc = maxpool_stats_launch(cur.x, B, 2 * Ri, 2 * Ri, 2 * Ri, cur.C, pooled.x, nblk, nullptr, so, st))) return rc;
-            } else {
-                if (!plan && (rc = vt_maxpool3d_cl(cur.x, B, 2 * Ri, 2 * Ri, 2 * Ri, cur.C, pooled.x, st))) return rc;
-                if (!plan && (rc = channel_stats_launch(pooled.x, B, Vp, pooled.C, nblk, nullptr, so, st))) return rc;
-            }
+            if (!plan && (rc = maxpool_stats_launch(cur.x, B, 2 * Ri, 2 * Ri, 2 * Ri, cur.C, pooled.x, nblk, nullptr, so, st))) return rc;
             cur = pooled;
         }
         Tensor t1, t2;
@@ -2352,7 +2357,7 @@ int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char 
     float *ss = ws.take((size_t)B * maxC * 2);
     auto stats_of = [&](const float *x, int Ri, int C, Tensor &t) -> int {
         const int64_t V = (int64_t)Ri * Ri * Ri;
-        t.nblk = (int)(V / 16 < 1 ? 1 : (V / 16 > 1024 ? 1024 : V / 16));     // 16+ voxels per block: the 8^3 level still gives 32 workgroups
+        t.nblk = stat_blocks(V);
         t.part = ws.take((size_t)B * t.nblk * C * 2);
         t.C = C;
         return plan ? 0 : vt_channel_stats(x, B, V, C, t.nblk, t.part, st);

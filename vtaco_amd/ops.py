@@ -951,11 +951,17 @@ def conv1x1_pack_f16x3(weight):
     return out
 
 
+def stat_blocks(V):
+    """Blocks of a GroupNorm statistics pass over V voxels: vt_unet3d_fwd's rule (unet3d.hip::stat_blocks), so that the per-layer path
+    sums the same blocks in the same order."""
+    return max(1, min(1024, V // (16 if V >= 16384 else 8)))
+
+
 def channel_stats(x):
     """Per-block partial (sum, sumsq) of a channels-last tensor: (part, nblk)."""
     B, D, H, W, C = x.shape
     V = D * H * W
-    nblk = max(1, min(1024, V // 16))
+    nblk = stat_blocks(V)
     part = torch.empty((B, nblk, C, 2), dtype=torch.float32, device=x.device)
     check(_lib.load().vt_channel_stats(dev_ptr(x, "x"), B, V, C, nblk, dev_ptr(part, "part"), stream_ptr()), "vt_channel_stats")
     return part, nblk
@@ -1115,7 +1121,7 @@ def maxpool3d_cl_stats(x):
     B, D, H, W, C = x.shape
     out = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
     V = (D // 2) * (H // 2) * (W // 2)
-    nblk = max(1, min(1024, V // 16))
+    nblk = stat_blocks(V)
     part = torch.empty((B, nblk, C, 2), dtype=torch.float32, device=x.device)
     check(_lib.load().vt_maxpool3d_cl_stats(dev_ptr(x, "x"), B, D, H, W, C, dev_ptr(out, "out"), nblk, dev_ptr(part, "part"), stream_ptr()),
           "vt_maxpool3d_cl_stats")
