@@ -142,9 +142,12 @@ def test_unsupported_shapes_fail_loudly():
     from vtaco_amd._lib import VtError
     from vtaco_amd.conv_onet.models import decoder_dict
     dev = torch.device("cuda:0")
-    dec = decoder_dict["simple_local"](dim=3, c_dim=128, hidden_size=256).to(dev)      # the class defaults: not built
-    with pytest.raises(VtError):
-        dec(torch.zeros(1, 4, 3, device=dev), {"grid": torch.zeros(1, 128, 4, 4, 4, device=dev)})
+    dec = decoder_dict["simple_local"](dim=3, c_dim=120, hidden_size=256).to(dev)      # widths must be multiples of 32 (<= 256)
+    with torch.no_grad(), pytest.raises(VtError, match="multiples of 32"):
+        dec(torch.zeros(1, 4, 3, device=dev), {"grid": torch.zeros(1, 120, 4, 4, 4, device=dev)})
+    dec = decoder_dict["simple_local"](dim=3, c_dim=128, hidden_size=256).to(dev)      # the class defaults: vt_decode_fwd_wide (round 3)
+    with torch.no_grad():
+        assert dec(torch.zeros(1, 4, 3, device=dev), {"grid": torch.zeros(1, 128, 4, 4, 4, device=dev)}).shape == (1, 4)
     _, sd = load_golden("g1_decode.npz")
     with pytest.raises(VtError):
         ops.decode_fwd(torch.zeros(1, 32, 4, 5, 6, device=dev), _blob(sd, dev), pts=torch.zeros(1, 4, 3, device=dev))
