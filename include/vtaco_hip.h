@@ -165,12 +165,16 @@ int vt_decode_range_status(unsigned *host_status, int reset, void *stream);
 /* vt_decoder_pack_wide writes (params_host->hidden / c_dim / n_blocks / p_in describe the shape; p_in = 3,    */
 /* or 3 + c_dim for forward_img); blob_bytes from vt_decoder_wide_blob_bytes (0: shape not covered).           */
 /* vt_decode_fwd_wide: the arguments of vt_decode_fwd (pts or lattice, optional c_img [B,N,c_dim], out2 for     */
-/* the contact head) plus the shape the blob was packed for; C = c_dim = the grid's channel count.               */
+/* the contact head) plus the shape the blob was packed for; C = c_dim = the grid's channel count; flags:        */
+/* VT_WIDE_LEAKY (leaky=True), VT_WIDE_NEAREST (sample_mode='nearest': F.grid_sample mode 'nearest', i.e. the     */
+/* voxel at the half-to-even rounded coordinate, decoder.py:62-68).                                               */
+#define VT_WIDE_LEAKY 1
+#define VT_WIDE_NEAREST 2
 size_t vt_decoder_wide_blob_bytes(int hidden, int c_dim, int n_blocks, int p_in);
 int vt_decoder_pack_wide(const vt_decoder_params *params_host, float *blob, size_t blob_bytes, void *stream);
 int vt_decode_fwd_wide(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
                        int lattice_nx, float lattice_box, int64_t lattice_first,
-                       const float *c_img, const float *blob_wide, int hidden, int n_blocks, int leaky, double padding,
+                       const float *c_img, const float *blob_wide, int hidden, int n_blocks, int flags, double padding,
                        float *out, float *out2, void *stream);
 
 /* Tactile feature assignment and decode by finger id (SURVEY.md section 8f "next" row 2).        */

@@ -62,6 +62,25 @@ def voxel_index(p, reso, padding=0.1):
 # --------------------------------------------------------------------------
 
 
+def nearest_sample(grid, p, padding=0.1):
+    """``F.grid_sample(c, 2*p_nor-1, padding_mode='border', align_corners=True, mode='nearest')`` (decoder.py:62-68 with
+    ``sample_mode='nearest'``): the voxel at the coordinate rounded half-to-even (ATen's nearbyint) after the border clip.
+    Returns [B,N,C]."""
+    B, C, D, H, W = grid.shape
+    v = 2.0 * normalize_3d_coordinate(p.float(), padding) - 1.0
+
+    def index(coord, size):
+        return torch.round(torch.clamp(((coord + 1.0) / 2) * (size - 1), 0, size - 1)).long()   # torch.round: half to even
+
+    lin = (index(v[..., 2], D) * H + index(v[..., 1], H)) * W + index(v[..., 0], W)
+    gcl = grid.permute(0, 2, 3, 4, 1).reshape(B, D * H * W, C)
+    return torch.gather(gcl, 1, lin.unsqueeze(-1).expand(-1, -1, C))
+
+
+def _sample(grid, p, padding, sample_mode):
+    return nearest_sample(grid, p, padding) if sample_mode == "nearest" else trilinear_sample(grid, p, padding)
+
+
 def trilinear_sample(grid, p, padding=0.1):
     """Trilinear interpolation of ``grid`` [B,C,D,H,W] at points ``p`` [B,N,3].
 
@@ -142,24 +161,24 @@ def _head_actvn(x, leaky):
     return F.leaky_relu(x, 0.2) if leaky else F.relu(x)
 
 
-def local_decoder_forward(sd, p, grid, padding=0.1, leaky=False):
+def local_decoder_forward(sd, p, grid, padding=0.1, leaky=False, sample_mode="bilinear"):
     """``LocalDecoder.forward`` (decoder.py:135-161): logits [B,N]."""
-    c = trilinear_sample(grid, p, padding)
+    c = _sample(grid, p, padding, sample_mode)
     net = decoder_mlp(sd, _lin(sd, "fc_p", p.to(sd["fc_p.weight"].dtype)), c)
     return _lin(sd, "fc_out", _head_actvn(net, leaky)).squeeze(-1)
 
 
-def local_decoder_forward_img(sd, p, grid, c_img, padding=0.1, leaky=False):
+def local_decoder_forward_img(sd, p, grid, c_img, padding=0.1, leaky=False, sample_mode="bilinear"):
     """``LocalDecoder.forward_img`` (decoder.py:71-103): tactile concat."""
-    c = trilinear_sample(grid, p, padding)
+    c = _sample(grid, p, padding, sample_mode)
     net = _lin(sd, "fc_p_img", torch.cat((p.to(c_img.dtype), c_img), dim=2))
     net = decoder_mlp(sd, net, c)
     return _lin(sd, "fc_out", _head_actvn(net, leaky)).squeeze(-1)
 
 
-def local_decoder_forward_contact(sd, p, grid, padding=0.1, leaky=False):
+def local_decoder_forward_contact(sd, p, grid, padding=0.1, leaky=False, sample_mode="bilinear"):
     """``LocalDecoder.forward_contact`` (decoder.py:105-133)."""
-    c = trilinear_sample(grid, p, padding)
+    c = _sample(grid, p, padding, sample_mode)
     net = decoder_mlp(sd, _lin(sd, "fc_p", p.to(sd["fc_p.weight"].dtype)), c)
     a = _head_actvn(net, leaky)
     return _lin(sd, "fc_out", a).squeeze(-1), _lin(sd, "fc_out_contact", a).squeeze(-1)

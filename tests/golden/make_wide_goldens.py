@@ -4,6 +4,7 @@ LocalDecoder.forward / forward_img / forward_contact (src/conv_onet/models/decod
 
     A: hidden_size 64,  c_dim 32,  n_blocks 5, leaky=True  (leaky_relu(0.2) in front of the heads), with_contact
     B: hidden_size 256, c_dim 128, n_blocks 3, leaky=False (the class defaults' widths)
+    C: hidden_size 32,  c_dim 32,  n_blocks 2, sample_mode='nearest' (F.grid_sample's other mode for 5-D input)
 
 on random points (both clamps hit) and on an 8^3 lattice.  Runs only in the build container (/root/reference).  Weights, grids and
 c_img are rounded to f16-representable values so the fixture stores them in half the bytes without changing the arithmetic.
@@ -28,10 +29,11 @@ def main():
     decoder = importlib.import_module("src.conv_onet.models.decoder")
     torch.set_num_threads(8)
     out = {}
-    for tag, hidden, c_dim, nb, leaky, seed in (("A", 64, 32, 5, True, 160), ("B", 256, 128, 3, False, 161)):
+    for tag, hidden, c_dim, nb, leaky, seed, mode in (("A", 64, 32, 5, True, 160, "bilinear"), ("B", 256, 128, 3, False, 161, "bilinear"),
+                                                     ("C", 32, 32, 2, False, 162, "nearest")):
         torch.manual_seed(seed)
         dec = decoder.LocalDecoder(dim=3, c_dim=c_dim, hidden_size=hidden, n_blocks=nb, leaky=leaky, padding=0.1,
-                                   sample_mode="bilinear", with_contact=True)
+                                   sample_mode=mode, with_contact=True)
         _randomise(dec, seed + 10)
         with torch.no_grad():
             for prm in dec.parameters():
@@ -50,7 +52,7 @@ def main():
         out.update({f"{tag}.grid": grid.numpy().astype(np.float16), f"{tag}.prand": prand.numpy(),
                     f"{tag}.c_img": c_img.numpy().astype(np.float16), f"{tag}.logits": lo.numpy(), f"{tag}.logits_img": lo_img.numpy(),
                     f"{tag}.logits_contact": lo_c.numpy(), f"{tag}.logits_contact2": lo_cc.numpy(), f"{tag}.logits_lattice": lo_lat.numpy(),
-                    f"{tag}.shape": np.array([hidden, c_dim, nb, int(leaky), nx], dtype=np.int64)})
+                    f"{tag}.shape": np.array([hidden, c_dim, nb, int(leaky), nx, int(mode == "nearest")], dtype=np.int64)})
         out.update({f"sd.{tag}.{k}": v.detach().numpy().astype(np.float16) for k, v in dec.state_dict().items()})
     _save("g16_decode_wide.npz", **out)
 

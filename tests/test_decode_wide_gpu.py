@@ -17,14 +17,15 @@ def _case(tag):
     a, sd = load_golden("g16_decode_wide.npz")
     arrs = {k[2:]: v for k, v in a.items() if k.startswith(tag + ".")}
     sdc = {k[2:]: v.float() for k, v in sd.items() if k.startswith(tag + ".")}
-    hidden, c_dim, nb, leaky, nx = (int(x) for x in arrs["shape"])
-    return arrs, sdc, hidden, c_dim, nb, bool(leaky), nx
+    hidden, c_dim, nb, leaky, nx, nearest = (int(x) for x in arrs["shape"])
+    return arrs, sdc, hidden, c_dim, nb, bool(leaky), nx, "nearest" if nearest else "bilinear"
 
 
-def _decoder(hidden, c_dim, nb, leaky, sd=None, seed=0, contact=True):
+def _decoder(hidden, c_dim, nb, leaky, sd=None, seed=0, contact=True, mode="bilinear"):
     from vtaco_amd.conv_onet.models.decoder import LocalDecoder
     torch.manual_seed(seed)
-    dec = LocalDecoder(dim=3, c_dim=c_dim, hidden_size=hidden, n_blocks=nb, leaky=leaky, padding=0.1, with_contact=contact)
+    dec = LocalDecoder(dim=3, c_dim=c_dim, hidden_size=hidden, n_blocks=nb, leaky=leaky, padding=0.1, with_contact=contact,
+                       sample_mode=mode)
     if sd is not None:
         dec.load_state_dict(sd)
     else:
@@ -39,10 +40,10 @@ def _err(got, ref):
     return float((got.cpu() - torch.as_tensor(ref)).abs().max())
 
 
-@pytest.mark.parametrize("tag", ["A", "B"])
+@pytest.mark.parametrize("tag", ["A", "B", "C"])
 def test_wide_decoder_against_the_reference_fixture(tag):
-    a, sd, hidden, c_dim, nb, leaky, nx = _case(tag)
-    dec = _decoder(hidden, c_dim, nb, leaky, sd)
+    a, sd, hidden, c_dim, nb, leaky, nx, mode = _case(tag)
+    dec = _decoder(hidden, c_dim, nb, leaky, sd, mode=mode)
     assert dec._wide
     grid = T(a["grid"].astype(np.float32)).to(DEV)
     p, c_img = T(a["prand"]).to(DEV), T(a["c_img"].astype(np.float32)).to(DEV)
@@ -58,14 +59,16 @@ def test_wide_decoder_against_the_reference_fixture(tag):
         assert torch.equal(half, lat[:, nx * nx * 3: nx * nx * 5])
 
 
+@pytest.mark.parametrize("mode", ["bilinear", "nearest"])
 @pytest.mark.parametrize("hidden,c_dim,nb,leaky,B,N,R", [(32, 32, 5, True, 2, 1000, 16), (96, 64, 2, False, 1, 33, 8),
                                                         (128, 256, 1, True, 3, 257, 8), (256, 32, 8, False, 1, 64, 4),
                                                         (64, 96, 3, False, 2, 1, 8)])
-def test_wide_decoder_against_the_oracle(hidden, c_dim, nb, leaky, B, N, R):
+def test_wide_decoder_against_the_oracle(hidden, c_dim, nb, leaky, B, N, R, mode):
     """Shapes between the fixture's: a leaky 32 / 32 decoder (routed to the wide kernel), c_dim > hidden (fc_p_img's K = 3 + c_dim
     exceeds the hidden width), one and eight blocks, ragged point counts (one point; a tile and a bit)."""
     from oracle import vtaco_oracle as orc
-    dec = _decoder(hidden, c_dim, nb, leaky, seed=hidden + c_dim + nb)
+    dec = _decoder(hidden, c_dim, nb, leaky, seed=hidden + c_dim + nb, mode=mode)
+    kw = dict(leaky=leaky, sample_mode=mode)
     sd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
     g = torch.Generator().manual_seed(N)
     grid = torch.randn(B, c_dim, R, R, R, generator=g)
@@ -75,11 +78,11 @@ def test_wide_decoder_against_the_oracle(hidden, c_dim, nb, leaky, B, N, R):
         got = dec(p.to(DEV), {"grid": grid.to(DEV)})
         got_img = dec.forward_img(p.to(DEV), {"grid": grid.to(DEV)}, c_img.to(DEV))
         got_c, got_cc = dec.forward_contact(p.to(DEV), {"grid": grid.to(DEV)})
-    ref = orc.local_decoder_forward(sd, p, grid, leaky=leaky)
+    ref = orc.local_decoder_forward(sd, p, grid, **kw)
     scale = max(1.0, float(ref.abs().max()))
     assert _err(got, ref) <= 1e-5 * scale
-    assert _err(got_img, orc.local_decoder_forward_img(sd, p, grid, c_img, leaky=leaky)) <= 1e-5 * scale
-    rc, rcc = orc.local_decoder_forward_contact(sd, p, grid, leaky=leaky)
+    assert _err(got_img, orc.local_decoder_forward_img(sd, p, grid, c_img, **kw)) <= 1e-5 * scale
+    rc, rcc = orc.local_decoder_forward_contact(sd, p, grid, **kw)
     assert _err(got_c, rc) <= 1e-5 * scale and _err(got_cc, rcc) <= 1e-5 * scale
 
 

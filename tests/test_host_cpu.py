@@ -81,8 +81,9 @@ def test_unsupported_configurations_raise():
     with pytest.raises(VtError):
         encoder_dict["pointnet_local_pool"](plane_type=["xz", "xy", "yz"], plane_resolution=32, out_mano=True, out_dim=51)  # no MANO asset given
     assert decoder_dict["simple_local"](dim=3, c_dim=32, hidden_size=32, leaky=True)._wide       # leaky heads: the wide kernel (round 3)
+    assert decoder_dict["simple_local"](dim=3, c_dim=32, hidden_size=32, sample_mode="nearest")._wide   # F.grid_sample's other mode: wide kernel
     with pytest.raises(VtError):
-        decoder_dict["simple_local"](dim=3, c_dim=32, hidden_size=32, sample_mode="nearest")
+        decoder_dict["simple_local"](dim=3, c_dim=32, hidden_size=32, sample_mode="bicubic")         # not a 5-D grid_sample mode
     with pytest.raises(VtError):
         decoder_dict["attention_local"](dim=3, c_dim=64, hidden_size=64)                          # fusion kernels: the shipped shape only
     with pytest.raises(KeyError):

@@ -35,25 +35,28 @@ def _wide_case(tag):
     a, sd = load_golden("g16_decode_wide.npz")
     arrs = {k[2:]: v for k, v in a.items() if k.startswith(tag + ".")}
     sdc = {k[2:]: v.float() for k, v in sd.items() if k.startswith(tag + ".")}
-    hidden, c_dim, nb, leaky, nx = (int(x) for x in arrs["shape"])
-    return arrs, sdc, hidden, c_dim, nb, bool(leaky), nx
+    hidden, c_dim, nb, leaky, nx, nearest = (int(x) for x in arrs["shape"])
+    return arrs, sdc, hidden, c_dim, nb, bool(leaky), nx, "nearest" if nearest else "bilinear"
 
 
-@pytest.mark.parametrize("tag", ["A", "B"])
+@pytest.mark.parametrize("tag", ["A", "B", "C"])
 def test_local_decoder_beyond_the_shipped_shape(tag):
-    """The reference's LocalDecoder at 64/32/5 with leaky heads and at 256/128/3 (decoder.py:24-51): the oracle's restatement is
-    shape-generic and takes ``leaky`` -- pinned here against the reference's own outputs."""
-    a, sd, hidden, c_dim, nb, leaky, nx = _wide_case(tag)
+    """The reference's LocalDecoder at 64/32/5 with leaky heads, at 256/128/3 and with sample_mode='nearest' (decoder.py:24-68): the
+    oracle's restatement is shape-generic and takes ``leaky`` / ``sample_mode`` -- pinned here against the reference's own outputs."""
+    a, sd, hidden, c_dim, nb, leaky, nx, mode = _wide_case(tag)
+    kw = dict(leaky=leaky, sample_mode=mode)
     grid, p, c_img = T(a["grid"].astype(np.float32)), T(a["prand"]), T(a["c_img"].astype(np.float32))
     assert sd["fc_p.weight"].shape == (hidden, 3) and sd["fc_c.0.weight"].shape == (hidden, c_dim)
-    assert maxdiff(orc.local_decoder_forward(sd, p, grid, leaky=leaky), a["logits"]) <= 2e-5
-    assert maxdiff(orc.local_decoder_forward_img(sd, p, grid, c_img, leaky=leaky), a["logits_img"]) <= 2e-5
-    o, oc = orc.local_decoder_forward_contact(sd, p, grid, leaky=leaky)
+    assert maxdiff(orc.local_decoder_forward(sd, p, grid, **kw), a["logits"]) <= 2e-5
+    assert maxdiff(orc.local_decoder_forward_img(sd, p, grid, c_img, **kw), a["logits_img"]) <= 2e-5
+    o, oc = orc.local_decoder_forward_contact(sd, p, grid, **kw)
     assert maxdiff(o, a["logits_contact"]) <= 2e-5 and maxdiff(oc, a["logits_contact2"]) <= 2e-5
     pts = (1.1 * orc.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)).unsqueeze(0)
-    assert maxdiff(orc.local_decoder_forward(sd, pts, grid[:1], leaky=leaky), a["logits_lattice"]) <= 2e-5
+    assert maxdiff(orc.local_decoder_forward(sd, pts, grid[:1], **kw), a["logits_lattice"]) <= 2e-5
     if leaky:                                                    # the flag matters on this fixture
         assert maxdiff(orc.local_decoder_forward(sd, p, grid, leaky=False), a["logits"]) > 1e-3
+    if mode == "nearest":
+        assert maxdiff(orc.local_decoder_forward(sd, p, grid), a["logits"]) > 1e-3
 
 
 def test_trilinear_with_clamped_points():

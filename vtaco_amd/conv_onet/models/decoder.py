@@ -120,8 +120,8 @@ class LocalDecoder(nn.Module):
         super().__init__()
         if dim != 3:
             raise VtError("LocalDecoder: only dim=3 is built")
-        if sample_mode != 'bilinear':
-            raise VtError("LocalDecoder: the HIP path implements trilinear ('bilinear') sampling only")
+        if sample_mode not in ('bilinear', 'nearest'):
+            raise VtError(f"LocalDecoder: sample_mode must be 'bilinear' or 'nearest' (F.grid_sample's modes for 5-D input), got {sample_mode!r}")
         self.c_dim, self.n_blocks, self.hidden_size = c_dim, n_blocks, hidden_size
         # `leaky`: leaky_relu(0.2) in front of the output heads (reference decoder.py:46-49, 157; the blocks stay ReLU).  The shipped
         # shape (32 / 32, relu) runs on the LDS-resident kernels of decode.hip, training included; every other shape -- hidden_size
@@ -129,7 +129,7 @@ class LocalDecoder(nn.Module):
         # autograd, and under autograd through PyTorch-ROCm's own operators (_host_forward: grid_sample + rocBLAS linears; no
         # kernel of this library -- the HIP backward exists for the shipped shape)
         self.leaky = bool(leaky)
-        self._wide = self.leaky or hidden_size != 32 or c_dim != 32
+        self._wide = self.leaky or hidden_size != 32 or c_dim != 32 or sample_mode == 'nearest'
         self.sample_mode, self.padding = sample_mode, padding
         self.fc_c = nn.ModuleList(nn.Linear(c_dim, hidden_size) for _ in range(n_blocks))
         self.fc_p = nn.Linear(dim, hidden_size)
@@ -205,7 +205,7 @@ class LocalDecoder(nn.Module):
         if not grid.is_cuda:
             raise VtError(f"LocalDecoder: inputs must live on a HIP device (got {grid.device})")
         vgrid = 2.0 * normalize_3d_coordinate(p.float(), padding=self.padding)[:, :, None, None] - 1.0
-        c = F.grid_sample(grid, vgrid, padding_mode='border', align_corners=True, mode='bilinear').squeeze(-1).squeeze(-1).transpose(1, 2)
+        c = F.grid_sample(grid, vgrid, padding_mode='border', align_corners=True, mode=self.sample_mode).squeeze(-1).squeeze(-1).transpose(1, 2)
         net = self.fc_p(p.float()) if c_img is None else self.fc_p_img(torch.cat((p.float(), c_img), dim=2))
         for lin, blk in zip(self.fc_c, self.blocks):
             net = net + lin(c)
@@ -216,7 +216,8 @@ class LocalDecoder(nn.Module):
 
     def _wide_fwd(self, grid, **kw):
         return ops.decode_fwd(grid, self._blob(img=kw.get("c_img") is not None, contact=kw.get("want_contact", False)),
-                              padding=self.padding, precision="wide", wide=(self.hidden_size, self.n_blocks, self.leaky), **kw)
+                              padding=self.padding, precision="wide",
+                              wide=(self.hidden_size, self.n_blocks, self.leaky, self.sample_mode == 'nearest'), **kw)
 
     @staticmethod
     def _grid_of(c_plane):

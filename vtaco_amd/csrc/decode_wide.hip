@@ -27,6 +27,7 @@ struct WideArgs {
     const float *blob;
     int H, C, nb, Kp, p_in;     // hidden, c_dim, blocks, fc_p's K padded to a multiple of 8
     int leaky;
+    int nearest;                // sample_mode 'nearest': the voxel at the rounded coordinate instead of the trilinear blend
 };
 
 // blob layout, in floats (host and device agree through these)
@@ -114,7 +115,11 @@ decode_wide_kernel(WideArgs a) {
                 point_of(d, g, g - b * d.N, px, py, pz);
                 const Tri t = tri_setup(px, py, pz, d.divisor, d.R);
                 const float *gb = d.grid + (size_t)b * d.R * d.R * d.R * C;
+                // F.grid_sample(mode='nearest', padding_mode='border', align_corners=True): nearbyint (half to even) of the clipped coordinate
+                const size_t near = a.nearest ? (((size_t)__builtin_rintf(grid_coord(pz, d.divisor, d.R)) * d.R + (size_t)__builtin_rintf(grid_coord(py, d.divisor, d.R))) * d.R +
+                                                 (size_t)__builtin_rintf(grid_coord(px, d.divisor, d.R))) * C : 0;
                 for (int cb = 0; cb < C; cb += 32) {
+                    if (a.nearest) { cl[(cb + ch) * WIDE_PITCH + pt] = gb[near + cb + ch]; continue; }
                     float acc = 0.0f;
 #pragma unroll
                     for (int dz = 0; dz < 2; ++dz) {
@@ -250,7 +255,7 @@ int vt_decoder_pack_wide(const vt_decoder_params *p, float *blob, size_t blob_by
 
 int vt_decode_fwd_wide(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
                        int lattice_nx, float lattice_box, int64_t lattice_first,
-                       const float *c_img, const float *blob, int hidden, int n_blocks, int leaky, double padding,
+                       const float *c_img, const float *blob, int hidden, int n_blocks, int flags, double padding,
                        float *out, float *out2, void *stream) {
     if (!grid_cl || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide: null argument");
     const int p_in = c_img ? 3 + C : 3;
@@ -266,7 +271,7 @@ int vt_decode_fwd_wide(const float *grid_cl, int B, int R, int C, const float *p
     a.d.grid = grid_cl; a.d.pts = pts; a.d.c_img = c_img; a.d.out = out; a.d.out2 = out2;
     a.d.N = (uint32_t)N; a.d.total = (uint32_t)((uint64_t)B * (uint64_t)N); a.d.lattice_first = (uint32_t)lattice_first;
     a.d.R = R; a.d.nx = lattice_nx; a.d.box = lattice_box; a.d.divisor = (float)(1.0 + padding + 10e-4);
-    a.blob = blob; a.H = hidden; a.C = C; a.nb = n_blocks; a.p_in = p_in; a.Kp = (p_in + 7) / 8 * 8; a.leaky = leaky ? 1 : 0;
+    a.blob = blob; a.H = hidden; a.C = C; a.nb = n_blocks; a.p_in = p_in; a.Kp = (p_in + 7) / 8 * 8; a.leaky = (flags & VT_WIDE_LEAKY) ? 1 : 0; a.nearest = (flags & VT_WIDE_NEAREST) ? 1 : 0;
     const int rowsA = hidden > a.Kp ? hidden : a.Kp;
     const int waves = hidden <= 128 ? 4 : 8;
     const size_t lds = ((size_t)(C + rowsA + hidden) * WIDE_PITCH + (size_t)waves * 2 * 2 * 32) * sizeof(float);

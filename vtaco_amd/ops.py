@@ -181,7 +181,7 @@ def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want
                precision="f32", wide=None):
     """Fused trilinear gather + conditioned MLP (vt_decode_fwd; ``precision="bf16x3"`` / ``"f16x3"``:
     vt_decode_fwd_bf16x3 / vt_decode_fwd_f16x3 with a blob packed for it; ``precision="wide"`` with
-    ``wide=(hidden_size, n_blocks, leaky)``: vt_decode_fwd_wide, the exact-f32 kernel of the shapes beyond 32/32).
+    ``wide=(hidden_size, n_blocks, leaky[, nearest])``: vt_decode_fwd_wide, the exact-f32 kernel of the shapes beyond 32/32).
 
     grid  [B,C,R,R,R] (any layout; converted to channels-last if needed)
     pts   [B,N,3] or None with lattice=(nx, box, first, count)
@@ -217,9 +217,10 @@ def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want
     if precision == "wide":
         if save is not None or wide is None:
             raise VtError("decode_fwd: precision 'wide' is inference only and needs wide=(hidden_size, n_blocks, leaky)")
-        hidden, nb, leaky = wide
+        hidden, nb, leaky = wide[:3]
+        flags = (1 if leaky else 0) | (2 if len(wide) > 3 and wide[3] else 0)          # VT_WIDE_LEAKY | VT_WIDE_NEAREST
         check(lib.vt_decode_fwd_wide(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first, dev_ptr(c_img, "c_img"),
-                                     dev_ptr(blob, "blob"), int(hidden), int(nb), int(bool(leaky)), float(padding),
+                                     dev_ptr(blob, "blob"), int(hidden), int(nb), flags, float(padding),
                                      dev_ptr(out, "out"), dev_ptr(out2, "out2"), stream_ptr()), "vt_decode_fwd_wide")
     elif precision == "f16f8":
         if pts is not None or want_contact or save is not None:
