@@ -8,7 +8,7 @@ if len(sys.argv) > 1 and sys.argv[1].endswith(".csv"):
     last = rows[-7:]
     t0 = int(last[0]["Start_Timestamp"])
     for r in last:
-        print("%-28s start %7.1f us  dur %6.1f us" % (r["Kernel_Name"].split("(")[0][-28:], (int(r["Start_Timestamp"]) - t0) / 1e3,
+        print("%-28s start %7.1f us  dur %6.1f us" % (r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-28:], (int(r["Start_Timestamp"]) - t0) / 1e3,
                                                       (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     sys.exit(0)
 import torch
