@@ -149,7 +149,7 @@ def mesh_extract_stats(vol, nx, runs=100):
     nbytes = 4 * nx ** 3 + 12 * v.shape[0] + 12 * f.shape[0]      # algorithmic bytes
     return {"p50_ms": p50, "p90_ms": lat[int(len(lat) * 0.9)], "min_ms": lat[0], "runs": runs, "verts": v.shape[0],
             "faces": f.shape[0], "level": lvl, "algorithmic_GBps": nbytes / (p50 * 1e-3) / 1e9,
-            "note": "latency-dominated (dependent launches + 1 sync readback); 8.4 MB volume = 1.3 us at HBM rate"}
+            "note": "latency-dominated (five dependent launches, the counts polled from a page-locked slot); 8.4 MB volume = 1.3 us at HBM rate"}
 
 
 def stage_times(scene, dec, grid, nx, out, dev, precision):

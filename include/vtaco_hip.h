@@ -365,6 +365,11 @@ int vt_mc_read_counts(const void *workspace, int *nverts_host, int *nfaces_host,
 /* of it.  Sixteen tokens may be outstanding; a seventeenth _begin fails (VT_ERR_INVALID), _end spends its token.                 */
 int vt_mc_read_counts_begin(const void *workspace, void *stream, int *token);
 int vt_mc_read_counts_end(int token, int *nverts_host, int *nfaces_host, double *level_host);
+/* vt_mc_count whose last kernel also writes the counts, the level and then a sequence number into a page-locked host slot: no copy */
+/* command and no event in the stream (the emit kernels queued behind it start when the scan ends); returns the token               */
+/* vt_mc_read_counts_end takes, which then polls the slot for that sequence number instead of waiting for an event.                 */
+int vt_mc_count_notify(const float *vol, int n0, int n1, int n2, double level, int auto_level,
+                       void *workspace, size_t workspace_bytes, void *stream, int *token);
 int vt_mc_emit(const float *vol, int n0, int n1, int n2, void *workspace,
                float *verts, int max_verts, int *faces, int max_faces,
                int rescale, float shift, float scale, void *stream);

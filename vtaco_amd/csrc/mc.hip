@@ -21,8 +21,10 @@
 // HBM-class kernels, latency-dominated at 128^3 (8.4 MB volume).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <mutex>
 
 #include "vt_common.h"
@@ -468,7 +470,7 @@ mc_classify_kernel(const float *vol, McDims d, McWs ws, double level_in, int aut
 // walking its own 64 strided entries took 134 us there.)
 constexpr int SC_BATCH = 16;
 
-__global__ void __launch_bounds__(1024) mc_scan_kernel(McWs ws, unsigned nblk) {
+__global__ void __launch_bounds__(1024) mc_scan_kernel(McWs ws, unsigned nblk, McHeader *host_hdr, int host_seq) {
     __shared__ uint2 wtot[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned rows = ((nblk + 1023) / 1024), seg = rows * 64;            // rows per wave, entries per wave
@@ -508,7 +510,17 @@ __global__ void __launch_bounds__(1024) mc_scan_kernel(McWs ws, unsigned nblk) {
             cb += (unsigned)__builtin_amdgcn_readlane((int)ib, 63);
         }
     }
-    if (threadIdx.x == 0) { ws.hdr->nfaces = (int)sa; ws.hdr->nverts = (int)sb; }
+    if (threadIdx.x == 0) {
+        ws.hdr->nfaces = (int)sa; ws.hdr->nverts = (int)sb;
+        // vt_mc_count_notify: the counts (and the level the classify kernel left) straight into a page-locked host slot -- no copy command
+        // between this kernel and the emit kernels behind it
+        // between this kernel and the emit kernels behind it, and no event either: the host polls the sequence number, written last
+        if (host_hdr) {
+            host_hdr->nfaces = (int)sa; host_hdr->nverts = (int)sb; host_hdr->level = ws.hdr->level;
+            __threadfence_system();
+            __hip_atomic_store(&host_hdr->reserved[0], host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 struct McOut {
@@ -722,8 +734,8 @@ size_t vt_mc_workspace_bytes(int n0, int n1, int n2) {
     return total;
 }
 
-int vt_mc_count(const float *vol, int n0, int n1, int n2, double level, int auto_level,
-                void *workspace, size_t workspace_bytes, void *stream) {
+static int mc_count_impl(const float *vol, int n0, int n1, int n2, double level, int auto_level,
+                         void *workspace, size_t workspace_bytes, void *stream, McHeader *host_hdr, int host_seq) {
     if (!vol || !workspace) return vt_fail(VT_ERR_INVALID, "vt_mc_count: null argument");
     McDims d; size_t off[8], total; unsigned nblk;
     if (!mc_layout(n0, n1, n2, d, off, total, nblk))
@@ -742,8 +754,13 @@ int vt_mc_count(const float *vol, int n0, int n1, int n2, double level, int auto
     }
     hipLaunchKernelGGL(mc_classify_kernel, dim3((nblk + CLS_CHUNKS - 1) / CLS_CHUNKS), dim3(CELLS_PER_BLOCK), 0, s,
                        vol, d, ws, level, auto_level, nblk, (int)g);
-    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, s, ws, nblk);
+    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, s, ws, nblk, host_hdr, host_seq);
     return vt_check(hipGetLastError(), "vt_mc_count");
+}
+
+int vt_mc_count(const float *vol, int n0, int n1, int n2, double level, int auto_level,
+                void *workspace, size_t workspace_bytes, void *stream) {
+    return mc_count_impl(vol, n0, n1, n2, level, auto_level, workspace, workspace_bytes, stream, nullptr, 0);
 }
 
 int vt_mc_read_counts(const void *workspace, int *nverts_host, int *nfaces_host, double *level_host, void *stream) {
@@ -762,32 +779,59 @@ int vt_mc_read_counts(const void *workspace, int *nverts_host, int *nfaces_host,
 // vertex / face kernels of a marching-cubes call) and returns the counts.  A ring of 16 slots; a token is valid for one _end.
 namespace {
 constexpr int MC_SLOTS = 16;
-struct McSlot { McHeader *host; hipEvent_t ev; bool made, busy; };
+struct McSlot { McHeader *host; hipEvent_t ev; bool made, busy; int seq, polled; };   // polled: the scan kernel writes `seq` into the slot (vt_mc_count_notify)
 McSlot mc_slots[MC_SLOTS];                              // zero-initialised: nothing made, nothing busy
 unsigned mc_slot_next = 0;
 std::mutex mc_slots_mutex;                              // guards the slots' creation and their busy flags
 }  // namespace
 
+// the next page-locked slot no read-back is waiting in (made on first use), marked busy
+static int mc_slot_acquire(int &t) {
+    t = -1;
+    std::lock_guard<std::mutex> lock(mc_slots_mutex);
+    for (int i = 0; i < MC_SLOTS && t < 0; ++i) {
+        const int c = (int)((mc_slot_next + i) % MC_SLOTS);
+        if (!mc_slots[c].busy) t = c;
+    }
+    if (t < 0) return vt_fail(VT_ERR_INVALID, "vt_mc_read_counts_begin: 16 read-backs are already in flight (call vt_mc_read_counts_end)");
+    McSlot &sl = mc_slots[t];
+    if (!sl.made) {
+        hipError_t e = sl.host ? hipSuccess : hipHostMalloc(reinterpret_cast<void **>(&sl.host), sizeof(McHeader), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming);
+        if (e != hipSuccess) return vt_check(e, "vt_mc_read_counts_begin: page-locked slot");
+        memset(sl.host, 0, sizeof(McHeader));               // the polled sequence number starts at 0 (no launch ever writes 0)
+        sl.made = true;
+    }
+    sl.busy = true;
+    mc_slot_next = (unsigned)t + 1;
+    return 0;
+}
+
+int vt_mc_count_notify(const float *vol, int n0, int n1, int n2, double level, int auto_level,
+                       void *workspace, size_t workspace_bytes, void *stream, int *token) {
+    if (!token) return vt_fail(VT_ERR_INVALID, "vt_mc_count_notify: null argument");
+    int t;
+    int rc = mc_slot_acquire(t);
+    if (rc) return rc;
+    McSlot &sl = mc_slots[t];
+    sl.seq = sl.seq == 0x7fffffff ? 1 : sl.seq + 1;             // never 0: a fresh slot reads 0
+    sl.polled = 1;
+    rc = mc_count_impl(vol, n0, n1, n2, level, auto_level, workspace, workspace_bytes, stream, sl.host, sl.seq);
+    if (rc) {
+        std::lock_guard<std::mutex> lock(mc_slots_mutex);
+        mc_slots[t].busy = false;
+        return rc;
+    }
+    *token = t;
+    return 0;
+}
+
 int vt_mc_read_counts_begin(const void *workspace, void *stream, int *token) {
     if (!workspace || !token) return vt_fail(VT_ERR_INVALID, "vt_mc_read_counts_begin: null argument");
-    int t = -1;
-    {
-        std::lock_guard<std::mutex> lock(mc_slots_mutex);
-        for (int i = 0; i < MC_SLOTS && t < 0; ++i) {       // the next slot no read-back is waiting in
-            const int c = (int)((mc_slot_next + i) % MC_SLOTS);
-            if (!mc_slots[c].busy) t = c;
-        }
-        if (t < 0) return vt_fail(VT_ERR_INVALID, "vt_mc_read_counts_begin: 16 read-backs are already in flight (call vt_mc_read_counts_end)");
-        McSlot &sl = mc_slots[t];
-        if (!sl.made) {
-            hipError_t e = sl.host ? hipSuccess : hipHostMalloc(reinterpret_cast<void **>(&sl.host), sizeof(McHeader), hipHostMallocDefault);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming);
-            if (e != hipSuccess) return vt_check(e, "vt_mc_read_counts_begin: page-locked slot");
-            sl.made = true;
-        }
-        sl.busy = true;
-        mc_slot_next = (unsigned)t + 1;
-    }
+    int t;
+    const int arc = mc_slot_acquire(t);
+    if (arc) return arc;
+    mc_slots[t].polled = 0;
     hipError_t e = hipMemcpyAsync(mc_slots[t].host, workspace, sizeof(McHeader), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipEventRecord(mc_slots[t].ev, (hipStream_t)stream);
     if (e != hipSuccess) {
@@ -806,7 +850,21 @@ int vt_mc_read_counts_end(int token, int *nverts_host, int *nfaces_host, double 
         std::lock_guard<std::mutex> lock(mc_slots_mutex);
         if (!mc_slots[token].busy) return vt_fail(VT_ERR_INVALID, "vt_mc_read_counts_end: no read-back is in flight under this token");
     }
-    const hipError_t e = hipEventSynchronize(mc_slots[token].ev);
+    hipError_t e = hipSuccess;
+    if (mc_slots[token].polled) {
+        // the scan kernel stores the sequence number behind the counts (system-scope release): spin on it -- a stream wait would need
+        // an event packet between the scan and the emit kernels (~5 us of the ~85 the extraction takes)
+        volatile int *seq = &mc_slots[token].host->reserved[0];
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != mc_slots[token].seq) {
+            if ((++spins & 0xfffu) == 0) {
+                if (hipPeekAtLastError() != hipSuccess) { e = hipGetLastError(); break; }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) { e = hipErrorNotReady; break; }
+            }
+        }
+        mc_slots[token].polled = 0;
+    } else e = hipEventSynchronize(mc_slots[token].ev);
     if (e == hipSuccess) {
         *nverts_host = mc_slots[token].host->nverts; *nfaces_host = mc_slots[token].host->nfaces;
         if (level_host) *level_host = mc_slots[token].host->level;

@@ -275,10 +275,24 @@ def mc_count(vol, level=None):
     return ws
 
 
+def mc_count_notify(vol, level=None):
+    """``mc_count`` whose scan kernel also writes the counts into a page-locked host slot (vt_mc_count_notify): returns
+    (workspace, token); hand the token to ``mc_emit`` -- the count read then needs no copy command between the count and the emit
+    kernels.  Not for graph capture (it records an event): captured scenes use ``mc_count``."""
+    if vol.dim() != 3 or not vol.is_contiguous():
+        raise VtError("marching_cubes: volume must be a contiguous [n0,n1,n2] tensor")
+    ws, nbytes = _mc_workspace(vol)
+    n0, n1, n2 = vol.shape
+    tok = ctypes.c_int()
+    check(_lib.load().vt_mc_count_notify(dev_ptr(vol, "vol"), n0, n1, n2, 0.0 if level is None else float(level), int(level is None),
+                                         ctypes.c_void_p(ws.data_ptr()), nbytes, stream_ptr(), ctypes.byref(tok)), "vt_mc_count_notify")
+    return ws, tok.value
+
+
 _mc_guess = {}          # volume shape -> (vertex, face) capacity that covered the last extraction there
 
 
-def mc_emit(vol, ws, rescale=None, capacity=None):
+def mc_emit(vol, ws, rescale=None, capacity=None, token=None):
     """Phase 2 (vt_mc_emit + vt_mc_read_counts).  With ``capacity=(V,F)`` nothing is read back
     (no stream sync; the counts stay in the workspace).  Otherwise the outputs are sized by the
     counts, which costs one host read: after the first extraction of a shape the emit kernels are
@@ -306,8 +320,9 @@ def mc_emit(vol, ws, rescale=None, capacity=None):
     guess = _mc_guess.get(key)
     # the copy of the counts is queued FIRST (it needs the classify / scan launches only) and waited for by its own event, so
     # the speculative emit kernels run under that wait instead of in front of the copy
-    tok = ctypes.c_int()
-    check(lib.vt_mc_read_counts_begin(wp, st, ctypes.byref(tok)), "vt_mc_read_counts_begin")
+    tok = ctypes.c_int(-1 if token is None else token)
+    if token is None:
+        check(lib.vt_mc_read_counts_begin(wp, st, ctypes.byref(tok)), "vt_mc_read_counts_begin")
     nv, nf, lvl = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
     try:
         spec = emit(*guess) if guess is not None else None
@@ -339,8 +354,10 @@ def marching_cubes(vol, level=None, rescale=None, capacity=None):
     vol = vol.detach()
     if not vol.is_contiguous():
         vol = vol.contiguous()
-    ws = mc_count(vol, level)
-    return mc_emit(vol, ws, rescale, capacity)
+    if capacity is not None or torch.cuda.is_current_stream_capturing():
+        return mc_emit(vol, mc_count(vol, level), rescale, capacity)
+    ws, tok = mc_count_notify(vol, level)            # the counts arrive in a page-locked slot: no copy between count and emit
+    return mc_emit(vol, ws, rescale, None, token=tok)
 
 
 # --------------------------------------------------------------------------------------
