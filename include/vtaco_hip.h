@@ -202,6 +202,10 @@ int vt_sample_grid(const float *grid_cl, int B, int R, int C, const float *pts, 
 int vt_decode_mlp_fwd(const float *c, int B, int C, const float *pts, int64_t N,
                       int lattice_nx, float lattice_box, int64_t lattice_first,
                       const float *blob, float *out, void *stream);
+/* the same with split-f16 layers (blob from vt_decoder_pack_f16x3; inference: 2.6x the f32 form's rate at f32-level logits) */
+int vt_decode_mlp_fwd_f16x3(const float *c, int B, int C, const float *pts, int64_t N,
+                            int lattice_nx, float lattice_box, int64_t lattice_first,
+                            const float *blob_f16x3, float *out, void *stream);
 /* ... and their training forms (autograd of decoder.py:237-271 around the fuser): the MLP forward   */
 /* that saves activations (save: vt_decode_save_bytes), its backward to the features it was given      */
 /* (grad_c [B,N,C]; parameter gradients: vt_decode_wgrad on the same save/gws), and the backward of     */

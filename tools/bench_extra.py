@@ -79,7 +79,7 @@ def fusion_pass(cb=256):
             p = pc[lo:lo + cb]
             c = ops.sample_grid(grid, p.reshape(1, -1, 3)).reshape(-1, N, 32)
             f = adec.fuser(ci[lo:lo + cb], 1, c, 1)
-            outs.append(ops.decode_mlp_fwd(f, adec._blob(), p))
+            outs.append(adec._mlp_fwd(f, p))
     return outs
 
 

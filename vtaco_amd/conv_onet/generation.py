@@ -50,6 +50,8 @@ def _range_guarded(method):
                 warnings.warn(f"Generator3D: hidden activations of the decoder reach the half-precision range limit (65504); "
                               f"decode_precision {self.decode_precision!r} -> 'bf16x3' and the scene is generated again")
                 self.decode_precision = "bf16x3"
+                if hasattr(self.model.decoder, "mlp_precision"):
+                    self.model.decoder.mlp_precision = "f32"          # the attention decoder's MLP: back to the exact kernel
                 out = method(self, *args, **kwargs)
             return out
         finally:
@@ -110,7 +112,7 @@ class Generator3D(object):
                     pb = p[sl].float()
                     feat = ops.sample_grid(grid, pb.unsqueeze(0), dec.padding).reshape(nb, chunk, -1)
                     fused = dec.fuser(ci[sl].float().reshape(nb, chunk, -1), 1, feat, 1)
-                    outs.append(ops.decode_mlp_fwd(fused, dec._blob(), pb.reshape(nb, chunk, 3)).reshape(-1))
+                    outs.append(dec._mlp_fwd(fused, pb.reshape(nb, chunk, 3)).reshape(-1))
                 lo0 = full * chunk
             for lo in range(lo0, p.shape[0], self.points_batch_size):
                 pi = p[lo:lo + self.points_batch_size].unsqueeze(0)
@@ -366,7 +368,7 @@ class Generator3D(object):
             p = pts[sl].reshape(nb, chunk, 3)
             feat = ops.sample_grid(grid, pts[sl].unsqueeze(0), dec.padding).reshape(nb, chunk, -1)
             fused = dec.fuser(table[row[sl]].reshape(nb, chunk, -1), 1, feat, 1)
-            out[sl] = ops.decode_mlp_fwd(fused, dec._blob(), p).reshape(-1)
+            out[sl] = dec._mlp_fwd(fused, p).reshape(-1)
         if full * chunk < count:                          # the ragged last chunk
             sl = slice(full * chunk, count)
             out[sl] = dec.forward_img(pts[sl].unsqueeze(0), c, table[row[sl]].unsqueeze(0))[0]

@@ -310,6 +310,7 @@ class AttentionDecoder(LocalDecoder):
         if self._wide:
             raise VtError("AttentionDecoder: the TransformerFusion kernels and the MLP behind them are built for the shipped shape "
                           "(hidden_size = c_dim = 32, relu) only")
+        self.mlp_precision = os.environ.get("VTACO_ATTENTION_MLP_PRECISION", "f16x3")
         self.fuser = TransformerFusion(use_xyz=True, input_size=input_size, d_model=c_dim, num_layers=1,
                                        key_feature_dim=64, with_pos_embed=False,
                                        encoder_pos_embed_input_dim=3, decoder_pos_embed_input_dim=3)
@@ -325,4 +326,11 @@ class AttentionDecoder(LocalDecoder):
             return _DecodeMlpFn.apply(self, p, c, *self._params(False))
         c = ops.sample_grid(grid, p, self.padding)
         c = self.fuser(c_img, 1, c, 1)
-        return ops.decode_mlp_fwd(c, self._blob(), p)
+        return self._mlp_fwd(c, p)
+
+    def _mlp_fwd(self, c, p):
+        """The conditioned MLP behind the fusion (inference): split-f16 layers by default (vt_decode_mlp_fwd_f16x3: f32-level logits at
+        2.6x the exact-f32 kernel's rate; `mlp_precision = "f32"` / VTACO_ATTENTION_MLP_PRECISION for the exact form, which the
+        generator's range guard also falls back to)."""
+        prec = self.mlp_precision
+        return ops.decode_mlp_fwd(c, self._blob(precision=prec), p, precision=prec)

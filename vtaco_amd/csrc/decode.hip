@@ -1233,6 +1233,15 @@ int vt_decode_fwd_f16x3(const float *grid_cl, int B, int R, int C, const float *
     return decode_launch<2>(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img,
                             finger_ids, finger_ids ? finger_feats : nullptr, blob_f16x3, padding, out, out2, nullptr, stream);
 }
+
+// vt_decode_mlp_fwd with split-f16 layers (inference: the MLP behind the TransformerFusion of AttentionDecoder.forward_img)
+int vt_decode_mlp_fwd_f16x3(const float *c, int B, int C, const float *pts, int64_t N,
+                            int lattice_nx, float lattice_box, int64_t lattice_first,
+                            const float *blob_f16x3, float *out, void *stream) {
+    if (!c) return vt_fail(VT_ERR_INVALID, "vt_decode_mlp_fwd_f16x3: null features");
+    return decode_launch<2>(nullptr, c, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, nullptr, nullptr, blob_f16x3, 0.1,
+                            out, nullptr, nullptr, stream);
+}
 #else
 int vt_decode_fwd(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
                   int lattice_nx, float lattice_box, int64_t lattice_first,

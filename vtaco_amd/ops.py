@@ -797,15 +797,19 @@ def decode_mlp_bwd(blob_t, grad_out, save, pts, C=32):
     return grad_c, flat
 
 
-def decode_mlp_fwd(c, blob, pts):
-    """The conditioned MLP on given features c [B,N,C] (vt_decode_mlp_fwd)."""
+def decode_mlp_fwd(c, blob, pts, precision="f32"):
+    """The conditioned MLP on given features c [B,N,C] (vt_decode_mlp_fwd; ``precision="f16x3"`` with a blob packed for it:
+    vt_decode_mlp_fwd_f16x3)."""
+    if precision not in ("f32", "f16x3"):
+        raise VtError(f"decode_mlp_fwd: precision must be 'f32' or 'f16x3' (got {precision!r})")
     c = _c(c)
     pts = _c(pts.float())
     B, N, C = c.shape
     out = torch.empty((B, N), dtype=torch.float32, device=c.device)
     if N:
-        check(_lib.load().vt_decode_mlp_fwd(dev_ptr(c, "c"), B, C, dev_ptr(pts, "pts"), N, 0, 0.0, 0,
-                                            dev_ptr(blob, "blob"), dev_ptr(out, "out"), stream_ptr()), "vt_decode_mlp_fwd")
+        name = "vt_decode_mlp_fwd" if precision == "f32" else "vt_decode_mlp_fwd_f16x3"
+        check(getattr(_lib.load(), name)(dev_ptr(c, "c"), B, C, dev_ptr(pts, "pts"), N, 0, 0.0, 0,
+                                         dev_ptr(blob, "blob"), dev_ptr(out, "out"), stream_ptr()), name)
     return out
 
 
