@@ -122,3 +122,28 @@ def test_read_back_tokens_are_counted():
     assert lib.vt_mc_read_counts_end(toks[3], ctypes.byref(nv), ctypes.byref(nf), ctypes.byref(lvl)) != 0
     got = ops.marching_cubes(vol, 0.0)                  # the ring is whole again
     assert torch.equal(got[1], want[1])
+
+
+def test_counts_by_notification_equal_the_copied_counts():
+    """vt_mc_count_notify (the scan kernel writes the counts and a sequence number into a page-locked slot the host polls) against
+    vt_mc_count + vt_mc_read_counts: the same counts, level and mesh over many calls on alternating shapes -- slots are reused, their
+    sequence numbers advance, an event-waited read-back in between leaves the polled ones alone."""
+    import ctypes
+    from vtaco_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    vols = [torch.randn(n, n, n, generator=g).to(DEV) for n in (12, 20, 33)]
+    for it in range(40):
+        vol = vols[it % 3]
+        level = None if it % 2 else 0.1
+        ws = ops.mc_count(vol, level)
+        nv, nf, lvl = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+        assert lib.vt_mc_read_counts(ctypes.c_void_p(ws.data_ptr()), ctypes.byref(nv), ctypes.byref(nf), ctypes.byref(lvl), ops.stream_ptr()) == 0
+        ref_v, ref_f, _ = ops.mc_emit(vol, ws, None, capacity=(nv.value, nf.value))
+        ref_v, ref_f = ref_v.clone(), ref_f.clone()
+        ws2, tok = ops.mc_count_notify(vol, level)
+        nv2, nf2, lvl2 = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+        assert lib.vt_mc_read_counts_end(tok, ctypes.byref(nv2), ctypes.byref(nf2), ctypes.byref(lvl2)) == 0
+        assert (nv2.value, nf2.value, lvl2.value) == (nv.value, nf.value, lvl.value)
+        v, f, l3 = ops.marching_cubes(vol, level)                    # notify + speculative emit
+        assert l3 == lvl.value and torch.equal(f, ref_f) and torch.equal(v, ref_v)
