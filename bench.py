@@ -43,6 +43,7 @@ KERNEL_OF = {"f32": "decode_fwd_staged2_kernel<0>", "bf16x3": "decode_fwd_staged
              "f16f8": "decode_fwd_staged3_kernel<2>"}
 SPLIT = ("bf16x3", "f16x3", "f16f8")   # dense layers on the 16-bit matrix core, operands as hi + lo
 MIN_WARM_S = 0.25             # launches before any timed region, whatever --warmup says (clocks settle)
+MIN_TIMED_S = 0.05            # the timed region is REPS x --steps steps, REPS chosen so that it lasts at least this long
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -185,21 +186,54 @@ def stage_times(scene, dec, grid, nx, out, dev, precision):
     return res
 
 
-PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.csv")
+PMC_SUMMARY = os.path.join("profiles", "r04_pmc_summary.csv")
 EXTRAS_LIMIT_S = 420            # the sections after the headline (sharded scene, training step, CPU baseline) take well under a minute
+DECODE_SOURCES = ("decode.hip", "decode_f16.hip", "decode_common.h", "decode_st3.h", "decode_st3_f16x3.inc", "decode_st3_f16f8.inc",
+                  "vt_common.h", "Makefile")
+
+
+def decode_source_hash():
+    """sha256 over the sources the decode kernels are built from (tools/src_hash.py prints the same): the committed counter
+    summary carries it in its first line, and counters collected on other sources are not reported."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in DECODE_SOURCES:
+        with open(os.path.join(ROOT, "vtaco_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+_pmc_cache = {}
+
+
+def pmc_table():
+    """{kernel key: {counter: mean per launch}} from the committed PMC passes -- only if the file's stamp (`# decode_sources=<hash>`,
+    written by tools/collect_profiles.sh on the box that collected them) equals the hash of the sources in this tree; a summary
+    collected on other kernel sources gives {} (the line then carries no `pmc` / `traffic` instead of stale ones)."""
+    if "t" in _pmc_cache:
+        return _pmc_cache["t"]
+    tab, stamp = {}, None
+    try:
+        for line in open(os.path.join(ROOT, PMC_SUMMARY)).read().splitlines():
+            if line.startswith("#"):
+                if "decode_sources=" in line:
+                    stamp = line.split("decode_sources=", 1)[1].strip()
+                continue
+            if line.startswith("kernel,"):
+                continue
+            k, c, n, mean = line.split(",")
+            tab.setdefault(k, {})[c] = float(mean)
+        if stamp != decode_source_hash():
+            tab = {}
+    except Exception:
+        tab = {}
+    _pmc_cache["t"] = tab
+    return tab
 
 
 def pmc_counters(precision):
     """Per-launch counter sums of this precision's decode kernel from the committed PMC passes (or {})."""
-    vals = {}
-    try:
-        for line in open(os.path.join(ROOT, PMC_SUMMARY)).read().splitlines()[1:]:
-            k, c, n, mean = line.split(",")
-            if k == "decode_" + precision:
-                vals[c] = float(mean)
-    except Exception:
-        pass
-    return vals
+    return pmc_table().get("decode_" + precision, {})
 
 
 def measured_traffic(precision):
@@ -212,7 +246,7 @@ def measured_traffic(precision):
     return (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
-def roofline_of(precision, flop_pt, npts, kern_ms):
+def roofline_of(precision, flop_pt, npts, kern_ms, clock=None):
     """Roofline object of one decode kernel: algorithmic FLOP / HIP-event time against the dense
     MFMA peak of the matrix-core input type it runs on."""
     achieved = flop_pt * npts / (kern_ms * 1e-3) / 1e12
@@ -220,14 +254,17 @@ def roofline_of(precision, flop_pt, npts, kern_ms):
     r = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
          "traffic": measured_traffic(precision),
          "traffic_note": "bytes/launch at the L2's memory side from rocprofv3 FETCH_SIZE/WRITE_SIZE passes "
-                         f"({PMC_SUMMARY}); algorithmic = 33.5 MB grid + 8.4 MB logits",
+                         f"({PMC_SUMMARY}, stamped with the hash of the kernel sources it was collected on; null when that is "
+                         "not this tree's); algorithmic = 33.5 MB grid + 8.4 MB logits",
          "kernel": KERNEL_OF[precision], "kernel_ms": kern_ms, "flop_per_point": flop_pt}
+    if clock is not None:
+        r["clock"] = clock
     pmc = pmc_counters(precision)
     if "GRBM_GUI_ACTIVE" in pmc and "SQ_VALU_MFMA_BUSY_CYCLES" in pmc:
         simd_cycles = 1024.0 * pmc["GRBM_GUI_ACTIVE"] / 8.0                 # 256 CUs x 4 SIMDs x cycles per launch (8 XCDs summed)
         r["pmc"] = {"matrix_pipe_busy": pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,
                     "valu_issue": 4.0 * pmc.get("SQ_INSTS_VALU", 0.0) / simd_cycles,
-                    "source": PMC_SUMMARY + " (profiled launches of the same command)"}
+                    "source": PMC_SUMMARY + " (profiled launches of the same command on the same kernel sources)"}
     if precision == "f16f8":
         r["note"] = ("f16 hi products (2 MFMAs per 32x32x32 layer half) + ONE fp8 32x32x64 MFMA for both correction products: 128 matrix "
                      "cycles per layer against 192 for three f16 products and 64 for a plain f16 layer, so frac <= 0.50 by construction; "
@@ -280,6 +317,43 @@ def warm_up(step, min_steps, fx, min_s=MIN_WARM_S, collective=False):
             elapsed = fx.max_over_ranks(elapsed)
         if n >= min_steps and elapsed >= min_s:
             return n
+
+
+def timed_region(step, steps, fx, collective=False):
+    """The timed region of one kernel: REPS back-to-back repetitions of EXACTLY `steps` steps between two barrier +
+    synchronize fences, REPS = the smallest count that makes the region last MIN_TIMED_S (a 20-step region of this kernel is
+    ~3 ms: the fences' own ~0.3 ms was a tenth of it in round 3's record).  One HIP event per repetition on the launch stream
+    gives the per-repetition kernel time: their spread is in the line.  Returns (wall seconds max over ranks, timed steps,
+    stats of the per-repetition ms per step)."""
+    import math
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        step()
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - t0) / 8
+    if collective:
+        est = fx.max_over_ranks(est)
+    reps = max(1, min(4096, int(math.ceil(MIN_TIMED_S / max(est * steps, 1e-9)))))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    fx.fence()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for r in range(reps):
+        for _ in range(steps):
+            step()
+        ev[r + 1].record()
+    fx.fence()
+    wall = fx.max_over_ranks(time.perf_counter() - t0)
+    per = [ev[r].elapsed_time(ev[r + 1]) / steps for r in range(reps)]
+    mean = sum(per) / reps
+    std = (sum((x - mean) ** 2 for x in per) / reps) ** 0.5
+    stats = {"reps": reps, "steps_per_rep": steps, "timed_steps": reps * steps, "kernel_ms_mean": mean, "kernel_ms_std": std,
+             "kernel_ms_min": min(per), "kernel_ms_max": max(per), "std_over_mean": std / mean if mean > 0 else None,
+             "kernel_ms_total_events": ev[0].elapsed_time(ev[reps]) / (reps * steps),
+             "wall_over_events": wall * 1e3 / ev[0].elapsed_time(ev[reps]) if ev[0].elapsed_time(ev[reps]) > 0 else None}
+    return wall, reps * steps, stats
 
 
 def sharded_scene(scene, dev, fx, rank, world, dist, precision, sizes=(128, 256), iters=10):
@@ -425,9 +499,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nx", type=int, default=128)
     ap.add_argument("--mode", choices=["visual", "img"], default="visual")
-    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x3", "f16f8"], default="f16f8",
-                    help="arithmetic of the 16 dense layers: exact-f32 MFMA, split-bf16 / split-f16 MFMA, or f16 products with fp8 "
-                         "correction products (all inside the 1e-4 bar)")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x3", "f16f8"], default="f16x3",
+                    help="arithmetic of the 16 dense layers: exact-f32 MFMA, split-bf16 / split-f16 MFMA (default: f32-level logits, "
+                         "the fewest shader cycles), or f16 products with fp8 correction products (opt-in: relative error ~3e-5 |logit|)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: one scene per rank, no collective; strong: one scene, slab decode + one all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -518,17 +592,11 @@ def main():
         def step():
             dec.decode_lattice(grid, nx, box=1.1, c_img=c_img, out=out, precision=args.precision)
 
+    from vtaco_amd import ops as vops
     warm_steps = warm_up(step, args.warmup, fx, collective=strong and world > 1)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fx.fence()
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    fx.fence()
-    wall = fx.max_over_ranks(time.perf_counter() - t0)
-    kern_ms = ev0.elapsed_time(ev1) / args.steps      # HIP events on the launch stream
+    wall, timed_steps, timing = timed_region(step, args.steps, fx, collective=strong and world > 1)
+    kern_ms = timing["kernel_ms_total_events"]          # HIP events on the launch stream, over the whole timed region
+    clock = vops.decode_last_clock()                    # workgroup 0's lifetime of the LAST launch: the clock the chip held
 
     res = None
     if rank == 0:
@@ -536,10 +604,14 @@ def main():
         units = npts if strong else world * npts
         res = {
             "metric": "occupancy query-points/sec at 128^3 (decode stage, lattice -> logits on device)",
-            "value": units * args.steps / wall,
+            "value": units * timed_steps / wall,
             "unit": "query-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_steps,
-            "ms_per_step": 1e3 * wall / args.steps,
+            "ms_per_step": 1e3 * wall / timed_steps,
+            "timing": dict(timing, note="the timed region is `reps` back-to-back repetitions of exactly `steps` steps between ONE pair "
+                                        f"of barrier + synchronize fences (reps = what makes it last >= {MIN_TIMED_S} s); value and "
+                                        "ms_per_step are over all of them (wall clock, max over ranks); kernel_ms_* are HIP-event times "
+                                        "per repetition on the launch stream"),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"visual-only PointNet encoder + LocalDecoder, {nx}^3 lattice, "
@@ -554,32 +626,27 @@ def main():
                                    + "; parity bar 1e-4 vs the f32 oracle",
                        "nx": nx, "points_per_step_per_gpu": npts if not strong else npts // world, "mode": args.mode,
                        "precision": args.precision},
-            "per_gpu": units * args.steps / wall / world,
+            "per_gpu": units * timed_steps / wall / world,
         }
         if not strong or world == 1:
-            res["roofline"] = roofline_of(args.precision, flop_pt, npts, kern_ms)
+            res["roofline"] = roofline_of(args.precision, flop_pt, npts, kern_ms, clock)
         if world == 1 and args.precision in SPLIT:
             # the other kernels on the same inputs: exact f32 (what the training forward and precision="f32" run) and the
             # other split form
             def side(prec):
                 fn = lambda: dec.decode_lattice(grid, nx, box=1.1, c_img=c_img, out=out, precision=prec)
                 warm_up(fn, 5, fx)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                ev0.record()
-                for _ in range(args.steps):
-                    fn()
-                ev1.record()
-                torch.cuda.synchronize()
-                w = time.perf_counter() - t0
-                return {"value": npts * args.steps / w, "unit": "query-points/s",
-                        "roofline": roofline_of(prec, flop_pt, npts, ev0.elapsed_time(ev1) / args.steps)}
+                w, n, tm = timed_region(fn, args.steps, fx)
+                return {"value": npts * n / w, "unit": "query-points/s",
+                        "timing": {k: tm[k] for k in ("reps", "timed_steps", "kernel_ms_mean", "kernel_ms_std", "std_over_mean", "wall_over_events")},
+                        "roofline": roofline_of(prec, flop_pt, npts, tm["kernel_ms_total_events"], vops.decode_last_clock())}
             res["exact_f32_kernel"] = side("f32")
             res["value_f32"] = res["exact_f32_kernel"]["value"]
-            for other in ("f16x3", "bf16x3"):                       # the f32-level split form and the round-1 one
+            for other in ("f16x3", "f16f8", "bf16x3"):              # the other 16-bit forms: fp8-corrected (opt-in), round 1's split-bf16
                 if other != args.precision:
-                    res["split_" + other + "_kernel"] = side(other)
-                    res["value_" + other] = res["split_" + other + "_kernel"]["value"]
+                    key = ("f16_fp8_corrected" if other == "f16f8" else "split_" + other) + "_kernel"
+                    res[key] = side(other)
+                    res["value_" + other] = res[key]["value"]
             step()                                                   # leave the headline kernel's logits in `out`
         if world == 1 and not args.decode_only:
             res["mesh_extract"] = mesh_extract_stats(out.view(nx, nx, nx), nx)

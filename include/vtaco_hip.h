@@ -151,11 +151,23 @@ int vt_decode_fwd_f16f8(const float *grid_cl, int B, int R, int C, int64_t N,
 /* Range guard of the half-precision decodes (vt_decode_fwd_f16x3 / _f16f8): their hi operand     */
 /* saturates at 65504 (round toward zero: never an infinity), after which the logits silently lose  */
 /* parity.  Every launch samples its relu'd hi operands (two of a lane's sixteen channels, every     */
-/* point and layer) and sets bit 0 of a per-process device word when the largest half shows up.       */
+/* point and layer) and sets bits of a per-DEVICE status word (the current device's):                 */
+/*   bit 0: a sampled half reached 65504 -- re-run with vt_decode_fwd_bf16x3 or the exact-f32 kernel; */
+/*   bit 1 (vt_decode_fwd_f16f8 only): a sampled half reached 1024, where the fp8 copies of the       */
+/*          correction products begin to clip and the 1e-4 contract of that kernel ends -- re-run     */
+/*          with vt_decode_fwd_f16x3;                                                                  */
+/*   bit 2 (vt_decode_fwd_f16f8 only): a logit beyond 2.5 in magnitude was written -- that kernel's    */
+/*          error is relative (~3e-5 |logit|), its 1e-4 absolute contract ends there: re-run likewise.  */
 /* vt_decode_range_status copies that word to the host (synchronises `stream`) and, with `reset`,    */
-/* clears it: the caller re-runs the affected scenes with vt_decode_fwd_bf16x3 or the exact-f32        */
-/* kernel (the host mirror's Generator3D does).  No reference counterpart: the reference is f32.        */
+/* clears it (the host mirror's Generator3D does the re-runs).  No reference counterpart: the          */
+/* reference is f32 (decoder.py:135-161).                                                              */
 int vt_decode_range_status(unsigned *host_status, int reset, void *stream);
+
+/* Measurement aid (bench.py's clock evidence; no reference counterpart): the lattice kernels of      */
+/* vt_decode_fwd* stamp workgroup 0's lifetime with the shader-clock counter and the constant-rate     */
+/* counter; this returns the last launch's two differences on the current device and the constant      */
+/* counter's rate in kHz (synchronises `stream`): shader MHz = cycles / ticks * ref_khz / 1000.        */
+int vt_decode_last_clock(unsigned long long *shader_cycles, unsigned long long *ref_ticks, int *ref_khz, void *stream);
 
 /* LocalDecoder beyond the shipped shape.  Replaces the same reference functions (decoder.py:135-161, */
 /* 71-103, 105-133) for hidden_size and c_dim any multiples of 32 up to 256 (the class defaults are      */

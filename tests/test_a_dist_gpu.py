@@ -46,6 +46,17 @@ def _worker(rank, world, port, q):
         plain = gen.generate_obj_mesh_wnf({"inputs": p})
         shard = gen.generate_obj_mesh_sharded({"inputs": p})
         ok_mesh = torch.equal(plain.faces, shard.faces) and torch.equal(plain.vertices, shard.vertices)
+        # the range guard of the (default) half-precision decode is rank-local outside the sharded entry point: a mesh that only
+        # rank 0 exports -- during distributed training, or with uneven scene counts -- must meet no collective ...
+        assert gen.decode_precision == "f16x3"
+        if rank == 0:
+            solo = gen.generate_obj_mesh_wnf({"inputs": p})
+            ok_mesh = ok_mesh and torch.equal(solo.faces, plain.faces) and torch.equal(solo.vertices, plain.vertices)
+        # ... and sharded generation on a SUB-group reduces its flag over that group only (here: rank 0 alone)
+        g0 = dist.new_group([0])
+        if rank == 0:
+            sub = gen.generate_obj_mesh_sharded({"inputs": p}, group=g0)
+            ok_mesh = ok_mesh and torch.equal(sub.faces, plain.faces) and torch.equal(sub.vertices, plain.vertices)
         # tactile (VTacO t2d) generation sharded: the contact clouds are drawn with numpy's generator -- rank 0's draw is
         # broadcast, so ranks seeded differently still assemble rank 0's mesh
         import numpy as np

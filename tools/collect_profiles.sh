@@ -3,7 +3,7 @@
 # gpurun copies back at most 64 MiB).  Usage: TAG=r01e bash tools/collect_profiles.sh
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_under_profiler.json 2> $O/stats.err; echo "stats rc=$?"
@@ -11,8 +11,9 @@ find $O/stats -name '*kernel_trace*' -delete 2>/dev/null
 # the headline kernel alone (128^3 launches only: the full bench above also decodes 256^3 slabs with the same kernel, which skews its average)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_decode -o decode -- python3 $R/bench.py --steps 200 --warmup 20 --decode-only --no-cpu-baseline > $O/bench_decode_under_profiler.json 2> $O/stats_decode.err; echo "decode stats rc=$?"
 find $O/stats_decode -name '*kernel_trace*' -delete 2>/dev/null
-echo "kernel,counter,launches,mean_per_launch" > $O/pmc_summary.csv
-for P in f16f8 f16x3 bf16x3 f32; do
+echo "# decode_sources=$(python3 $R/tools/src_hash.py)" > $O/pmc_summary.csv
+echo "kernel,counter,launches,mean_per_launch" >> $O/pmc_summary.csv
+for P in f16x3 f16f8 bf16x3 f32; do
   # the bench also launches the other precision's kernel (its exact-f32 side measurement): keep one kernel per key
   case $P in f16f8) KPAT='staged3_kernelILi2E,staged3_kernel<2>';; f16x3) KPAT='staged3_kernelILi1E,staged3_kernel<1>';;
              bf16x3) KPAT='staged2_kernelILi1E,staged2_kernel<1>';; *) KPAT='staged2_kernelILi0E,staged2_kernel<0>';; esac

@@ -25,38 +25,68 @@ Mesh = namedtuple("Mesh", ["vertices", "faces"])
 _tensor_version = operator.attrgetter("_version")
 
 
-def _range_guarded(method):
-    """A generation entry point under the half-precision decodes' range guard: when the decode of this scene reported
-    activations at the edge of the half range (ops.decode_range_status; "f16x3" / "f16f8" saturate there and silently lose
-    parity), the generator switches its lattice decode to "bf16x3" (f32's exponent range) -- for good -- warns, and generates
-    the scene again.  One 4-byte read-back per scene, behind the synchronisation the mesh extraction has just done."""
+def _range_guarded(method=None, *, collective=False):
+    """A generation entry point under the half-precision decodes' range guard (ops.decode_range_status, one word per device).
+    "f16f8" that met activations >= 1024 (RANGE_FP8: its fp8 correction copies begin to clip) or wrote a logit beyond 2.5
+    (RANGE_LOGIT: its error is relative, ~3e-5 |logit|) has left its 1e-4 contract and moves to "f16x3"; a half-precision form that met activations at the edge of the half range (RANGE_HALF: 65504, hi operands saturate)
+    moves to "bf16x3" (f32's exponent range) -- for good, with a warning -- and the scene is generated again.  One 4-byte
+    read-back per scene, behind the synchronisation the mesh extraction has just done.
+
+    The decision is RANK-LOCAL for every entry point except the sharded one: a rank-0-only mesh export during distributed
+    training or per-rank evaluation with uneven scene counts must not meet a collective here.  ``collective=True``
+    (generate_obj_mesh_sharded, whose ranks re-run their all-gather together or not at all) reduces the word over the
+    ``group`` the call was given, and only over that group."""
     import functools
     import warnings
 
-    @functools.wraps(method)
-    def guarded(self, *args, **kwargs):
-        if getattr(self, "_guard_depth", 0) or self.decode_precision not in ("f16x3", "f16f8"):
-            return method(self, *args, **kwargs)
-        self._guard_depth = 1
-        try:
-            out = method(self, *args, **kwargs)
-            tripped = ops.decode_range_status(reset=True) & 1
-            if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-                # sharded generation: the ranks must agree on re-running their collectives
-                t = torch.tensor([tripped], dtype=torch.int32, device=self.device if torch.distributed.get_backend() == "nccl" else "cpu")
-                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-                tripped = int(t.item())
-            if tripped:
-                warnings.warn(f"Generator3D: hidden activations of the decoder reach the half-precision range limit (65504); "
-                              f"decode_precision {self.decode_precision!r} -> 'bf16x3' and the scene is generated again")
-                self.decode_precision = "bf16x3"
-                if hasattr(self.model.decoder, "mlp_precision"):
-                    self.model.decoder.mlp_precision = "f32"          # the attention decoder's MLP: back to the exact kernel
+    def wrap(method):
+        @functools.wraps(method)
+        def guarded(self, *args, **kwargs):
+            if getattr(self, "_guard_depth", 0) or self.decode_precision not in ("f16x3", "f16f8"):
+                return method(self, *args, **kwargs)
+            self._guard_depth = 1
+            try:
                 out = method(self, *args, **kwargs)
-            return out
-        finally:
-            self._guard_depth = 0
-    return guarded
+                for _ in range(2):                                   # f16f8 -> f16x3 -> bf16x3 at most
+                    if self.decode_precision not in ("f16x3", "f16f8"):
+                        break
+                    word = ops.decode_range_status(reset=True)
+                    if collective:
+                        word = _reduce_or(word, kwargs.get("group", args[1] if len(args) > 1 else None), self.device)
+                    if word & ops.RANGE_HALF:
+                        nxt, why = "bf16x3", "reach the half-precision range limit (65504)"
+                    elif (word & ops.RANGE_FP8) and self.decode_precision == "f16f8":
+                        nxt, why = "f16x3", "reach 1024, where the fp8 correction products of 'f16f8' begin to clip"
+                    elif (word & ops.RANGE_LOGIT) and self.decode_precision == "f16f8":
+                        nxt, why = "f16x3", "produce logits beyond 2.5, where the relative error of 'f16f8' (~3e-5 |logit|) leaves the 1e-4 bar"
+                    else:
+                        break
+                    warnings.warn(f"Generator3D: the decoder's activations {why}; "
+                                  f"decode_precision {self.decode_precision!r} -> {nxt!r} and the scene is generated again")
+                    self.decode_precision = nxt
+                    if nxt == "bf16x3" and hasattr(self.model.decoder, "mlp_precision"):
+                        self.model.decoder.mlp_precision = "f32"      # the attention decoder's MLP: back to the exact kernel
+                    out = method(self, *args, **kwargs)
+                return out
+            finally:
+                self._guard_depth = 0
+        return guarded
+    return wrap if method is None else wrap(method)
+
+
+def _reduce_or(word, group, device):
+    """Bitwise OR of a small status word over the ranks of ``group`` (None = the default group); the word itself without an
+    initialised process group.  With the nccl (RCCL) backend the scratch tensor lives on this rank's device."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        return word
+    if dist.get_backend(group) == "nccl":
+        dev = device if device is not None and torch.device(device).type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+    else:
+        dev = "cpu"
+    t = torch.tensor([(word >> b) & 1 for b in range(8)], dtype=torch.int32, device=dev)      # RCCL has no bitwise OR: MAX per bit
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return sum(int(v) << b for b, v in enumerate(t.tolist()))
 
 
 class Generator3D(object):
@@ -70,13 +100,14 @@ class Generator3D(object):
     def __init__(self, model, points_batch_size=100000, threshold=0.5, refinement_step=0, device=None,
                  resolution0=16, upsampling_steps=3, with_normals=False, padding=0.1, sample=False,
                  input_type=None, vol_info=None, vol_bound=None, simplify_nfaces=None, alpha=0.2,
-                 with_img=False, encode_t2d=False, decode_precision="f16f8", depth_origin=None):
+                 with_img=False, encode_t2d=False, decode_precision="f16x3", depth_origin=None):
         self.model = model.to(device)
-        # arithmetic of the dense lattice decode (eval_lattice): "f16f8" = f16 products + fp8 correction products (the fastest:
-        # ~4e-5 on the golden logits, 2e-5 end to end at the shipped shape, bar 1e-4; slabs it does not cover run as "f16x3"),
-        # "f16x3" = split-f16 MFMA (f32-level logit error, ~1e-6 on the goldens, for hidden activations below 65504),
-        # "bf16x3" = split-bf16 MFMA (f32's exponent range, ~1.6e-5), "f32" = exact-f32 MFMA.  eval_points follows the decoder's
-        # own ``precision`` attribute (default "f32").
+        # arithmetic of the dense lattice decode (eval_lattice): "f16x3" = split-f16 MFMA (the default: f32-level logit error,
+        # ~1e-6 on the goldens, for hidden activations below 65504 -- guarded, see _range_guarded), "bf16x3" = split-bf16 MFMA
+        # (f32's exponent range, ~1.6e-5), "f32" = exact-f32 MFMA, "f16f8" = f16 products + fp8 correction products (opt-in:
+        # fewer matrix cycles, but its error is RELATIVE, ~3e-5 |logit| -- inside the 1e-4 bar for |logit| <~ 2.5 only -- and
+        # the mesh is not vertex-for-vertex the f32 path's; slabs it does not cover run as "f16x3").  eval_points follows the
+        # decoder's own ``precision`` attribute (default "f32").
         self.decode_precision = decode_precision
         self.points_batch_size = points_batch_size
         self.threshold, self.refinement_step = threshold, refinement_step
@@ -269,7 +300,7 @@ class Generator3D(object):
         verts, faces, _ = ops.mc_emit(g["vol"], g["ws"], rescale=(nx / 2, (1 + self.padding) / nx))
         return Mesh(verts, faces)
 
-    @_range_guarded
+    @_range_guarded(collective=True)
     def generate_obj_mesh_sharded(self, data, group=None):
         """``generate_obj_mesh_wnf`` with the lattice split over the ranks of a process group (one process per GPU):
         every rank encodes the scene (cheap, deterministic: no broadcast), decodes its slab of x-plane pairs with no

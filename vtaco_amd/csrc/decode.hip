@@ -17,6 +17,8 @@
 // + fc_p (K=3 padded to 4: 2).  The trilinear gather reads the channels-last grid:
 // lane (p,h) loads channels 16h..16h+15 of each of its point's 8 corners.
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
@@ -458,6 +460,7 @@ template <int P>
 __global__ void __launch_bounds__(ST2_THREADS)
 decode_fwd_staged2_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ClockStamp stamp = clock_begin(a.clk);
     {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(a.blob);
         f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
@@ -709,6 +712,7 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
         }
     }
     if constexpr (P == 2) range_report(rmax, a.status);
+    clock_end(a.clk, stamp);
 }
 
 }  // namespace
@@ -951,19 +955,28 @@ __global__ void __launch_bounds__(256) grid_from_cl_kernel(const float *src, flo
 // decode_f16.hip with VT_DECODE_F16_TU and -fno-slp-vectorize, as decode_f16.o (vt_decode_fwd_f16x3 only).
 // =====================================================================================
 #ifndef VT_DECODE_F16_TU
-// ---- range guard of the half-precision decodes: one device word per process ----
-static unsigned *g_decode_status = nullptr;
+// ---- range guard of the half-precision decodes: one status block PER DEVICE (kernels of a process that drives several
+// GPUs must not atomicOr into another GPU's memory), created under a mutex at a device's first use.
+//   bytes 0..3: VT_RANGE_* bits; 8..23: the last lattice kernel's clock stamps (ClockStamp differences, decode_common.h)
+constexpr int VT_MAX_DEVICES = 64;
+constexpr size_t VT_STATUS_BYTES = 32;
+static std::mutex g_status_mutex;
+static std::atomic<unsigned *> g_decode_status[VT_MAX_DEVICES];
 unsigned *vt_decode_status_dev() {
-    if (!g_decode_status) {
-        // first use: an allocation (the packers call this too, so that it never falls into a stream capture)
-        unsigned *p = nullptr;
-        if (hipMalloc(&p, 16) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, 16) != hipSuccess) { (void)hipFree(p); return nullptr; }
-        g_decode_status = p;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VT_MAX_DEVICES) return nullptr;
+    unsigned *p = g_decode_status[dev].load(std::memory_order_acquire);
+    if (p) return p;
+    std::lock_guard<std::mutex> lock(g_status_mutex);
+    p = g_decode_status[dev].load(std::memory_order_relaxed);
+    if (!p) {
+        // first use on this device: an allocation (the packers call this too, so that it never falls into a stream capture)
+        if (hipMalloc(&p, VT_STATUS_BYTES) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, VT_STATUS_BYTES) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        g_decode_status[dev].store(p, std::memory_order_release);
     }
-    return g_decode_status;
+    return p;
 }
-
 extern "C" {
 
 size_t vt_decoder_blob_bytes(int hidden, int c_dim, int n_blocks) {
@@ -1036,6 +1049,21 @@ int vt_decode_range_status(unsigned *host_status, int reset, void *stream) {
     return 0;
 }
 
+int vt_decode_last_clock(unsigned long long *shader_cycles, unsigned long long *ref_ticks, int *ref_khz, void *stream) {
+    if (!shader_cycles || !ref_ticks || !ref_khz) return vt_fail(VT_ERR_INVALID, "vt_decode_last_clock: null argument");
+    unsigned *d = vt_decode_status_dev();
+    if (!d) return vt_fail(VT_ERR_INVALID, "vt_decode_last_clock: no device memory for the status block");
+    unsigned long long h[2] = {0ull, 0ull};
+    hipError_t e = hipMemcpyAsync(h, status_clk(d), sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    int dev = 0, khz = 0;
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev);   // the rate of s_memrealtime
+    if (e != hipSuccess) return vt_check(e, "vt_decode_last_clock");
+    *shader_cycles = h[0]; *ref_ticks = h[1]; *ref_khz = khz;
+    return 0;
+}
+
 int vt_grid_to_channels_last(const float *src, float *dst, int B, int C, int D, int H, int W, void *stream) {
     if (!src || !dst || B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return vt_fail(VT_ERR_INVALID, "vt_grid_to_channels_last: bad argument");
     const int64_t V = (int64_t)D * H * W;
@@ -1062,7 +1090,9 @@ static bool st3_covers(int nx, int R, double s_vox) {
     const size_t lds = ((size_t)VT_BLOB_FLOATS + 5u * (size_t)nx) * sizeof(float) + (size_t)(ST3_THREADS / 64) * ST2_WAVE_BYTES;
     return (nx & 7) == 0 && R >= 6 && s_vox > 0.0 && s_vox < 0.55 && lds <= 160u * 1024u;
 }
-static int st3_launch(const DecodeArgs &a, int variant, void *stream) {
+static int st3_launch(const DecodeArgs &a_in, int variant, void *stream) {
+    DecodeArgs a = a_in;
+    a.clk = status_clk(a.status);
     const size_t lds = ((size_t)VT_BLOB_FLOATS + 5u * (size_t)a.nx) * sizeof(float) + (size_t)(ST3_THREADS / 64) * ST2_WAVE_BYTES;
     const int64_t nt = (int64_t)a.total / 64;
     int64_t blocks = (nt + ST3_THREADS / 64 - 1) / (ST3_THREADS / 64);
@@ -1105,7 +1135,9 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
     if (N == 0) return 0;
     if ((int64_t)B * N >= (int64_t)1 << 31) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd: B*N must be < 2^31");
     DecodeArgs a;
-    a.status = (P == 2) ? vt_decode_status_dev() : nullptr;
+    unsigned *const status_block = vt_decode_status_dev();
+    a.status = (P == 2) ? status_block : nullptr;
+    a.clk = nullptr;                                       // set for the lattice kernels below
     a.c_direct = c_direct; a.grid = grid_cl; a.pts = pts; a.brick = 0; a.cimg_ids = cimg_ids; a.cimg_table = cimg_table; a.c_img = c_img; a.blob = blob; a.out = out; a.out2 = out2; a.save = save;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box;
@@ -1144,6 +1176,7 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
                 if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute (staged2)");
                 st2_attr = true;
             }
+            a.clk = status_clk(status_block);
             hipLaunchKernelGGL(decode_fwd_staged2_kernel<P>, dim3((unsigned)blocks), dim3(ST2_THREADS), lds_st2, (hipStream_t)stream, a);
             return vt_check(hipGetLastError(), "vt_decode_fwd");
         }
@@ -1216,6 +1249,7 @@ int vt_decode_fwd_f16f8(const float *grid_cl, int B, int R, int C, int64_t N, in
                                            "step (vt_decode_f16f8_covers); use vt_decode_fwd_f16x3 otherwise");
     DecodeArgs a;
     a.status = vt_decode_status_dev();
+    a.clk = nullptr;
     a.c_direct = nullptr; a.grid = grid_cl; a.pts = nullptr; a.brick = 1; a.cimg_ids = finger_ids; a.cimg_table = finger_ids ? finger_feats : nullptr;
     a.c_img = c_img; a.blob = blob_f16f8; a.out = out; a.out2 = nullptr; a.save = nullptr;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
@@ -1298,7 +1332,7 @@ int vt_sample_grid(const float *grid_cl, int B, int R, int C, const float *pts, 
     if (N == 0) return 0;
     if ((int64_t)B * N >= (int64_t)1 << 31) return vt_fail(VT_ERR_UNSUPPORTED, "vt_sample_grid: B*N must be < 2^31");
     DecodeArgs a;
-    a.status = nullptr;
+    a.status = nullptr; a.clk = nullptr;
     a.c_direct = nullptr; a.brick = 0; a.cimg_ids = nullptr; a.cimg_table = nullptr; a.grid = grid_cl; a.pts = pts; a.c_img = nullptr; a.blob = nullptr; a.out = nullptr; a.out2 = nullptr; a.save = nullptr;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box; a.divisor = (float)(1.0 + padding + 10e-4);

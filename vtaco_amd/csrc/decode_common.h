@@ -156,8 +156,43 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void range_track(unsigned &rmax, unsigned hi_pair) {
     rmax = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, rmax), __builtin_bit_cast(u16x2, hi_pair)));
 }
-__device__ __forceinline__ void range_report(unsigned rmax, unsigned *status) {
-    if (status != nullptr && ((rmax & 0xffffu) >= 0x7bffu || (rmax >> 16) >= 0x7bffu)) atomicOr(status, 1u);
+// bit 0 (VT_RANGE_HALF): a sampled hi half reached 65504 (0x7bff) -- every half-precision form has lost parity there.
+// bit 1 (VT_RANGE_FP8, only the "f16f8" kernel reports it): a sampled hi half reached 2^(8 + VT_F8_SX) = 1024 -- beyond that
+// the fp8 copies of the correction products start to clip (x_lo 2^(11 - SX) < 2 x_hi 2^-SX against e4m3's 448; the x_hi copy
+// itself saturates at 448 2^SX = 1792) and the result degrades towards two-product f16 accuracy (2^-11 relative): the 1e-4
+// contract of that kernel no longer holds although nothing overflows.
+// bit 2 (VT_RANGE_LOGIT, "f16f8" only): a logit beyond VT_F16F8_LOGIT_LIMIT was written.  The fp8 form's error is RELATIVE
+// (~3e-5 |logit|: 4-bit corrections of 2^-11 terms), so its 1e-4 ABSOLUTE contract holds for |logit| <= 2.5 and no further.
+constexpr unsigned VT_RANGE_HALF = 1u, VT_RANGE_FP8 = 2u, VT_RANGE_LOGIT = 4u;
+constexpr float VT_F16F8_LOGIT_LIMIT = 2.5f;
+__device__ __forceinline__ void range_report(unsigned rmax, unsigned *status, bool fp8_copies = false) {
+    if (status == nullptr) return;
+    const unsigned top = max(rmax & 0xffffu, rmax >> 16);
+    constexpr unsigned FP8_LIMIT = (unsigned)(15 + 8 + VT_F8_SX) << 10;          // the half 2^(8 + SX)
+    const unsigned bits = (top >= 0x7bffu ? VT_RANGE_HALF : 0u) | ((fp8_copies && top >= FP8_LIMIT) ? VT_RANGE_FP8 : 0u);
+    if (bits) atomicOr(status, bits);
+}
+
+// ---- in-kernel clock stamps of the lattice kernels (bench.py's evidence of the clock the chip held) ------------------------
+// Workgroup 0 is persistent over its share of the tiles, so its lifetime is the launch's: its first thread reads the shader
+// clock counter (s_memtime) and the constant-rate counter (s_memrealtime) at both ends and leaves the two differences in the
+// device's status block (vt_decode_last_clock).  Two scalar reads per end of one wave: nothing measurable.
+struct ClockStamp {
+    unsigned long long t0, r0;
+};
+__device__ __forceinline__ ClockStamp clock_begin(const unsigned long long *clk) {
+    ClockStamp c{0ull, 0ull};
+    if (clk != nullptr && blockIdx.x == 0) {                 // a scalar condition: the stamps live in SGPRs across the kernel
+        c.t0 = __builtin_readcyclecounter();
+        c.r0 = __builtin_amdgcn_s_memrealtime();
+    }
+    return c;
+}
+__device__ __forceinline__ void clock_end(unsigned long long *clk, const ClockStamp &c) {
+    if (clk != nullptr && blockIdx.x == 0) {
+        const unsigned long long dt = __builtin_readcyclecounter() - c.t0, dr = __builtin_amdgcn_s_memrealtime() - c.r0;
+        if (threadIdx.x == 0) { clk[0] = dt; clk[1] = dr; }
+    }
 }
 
 // wl: the layer's LDS image [part: hi, lo][k-step 0,1][lane] x 16 bytes
@@ -227,7 +262,8 @@ struct DecodeArgs {
     int nx;
     float box;
     float divisor;       // 1 + padding + 10e-4
-    unsigned *status;    // device word of the range guard (bit 0: a half-precision operand saturated), or null
+    unsigned *status;    // device word of the range guard (VT_RANGE_* bits), or null
+    unsigned long long *clk;   // [2] shader-clock / constant-clock ticks of workgroup 0's lifetime (lattice kernels), or null
 };
 
 

@@ -175,6 +175,7 @@ template <int V>
 __global__ void __launch_bounds__(ST3_THREADS)
 decode_fwd_staged3_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ClockStamp stamp = clock_begin(a.clk);
     // V = 2: MODE.FP16_OVFL = 1 -- the fp8 conversions then saturate at +-448 instead of producing NaN (hwreg MODE = 1, bit 23)
     if constexpr (V == 2) __builtin_amdgcn_s_setreg((1 - 1) << 11 | 23 << 6 | 1, 1);
     {
@@ -296,6 +297,7 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
     }
     const float m1 = opaque_minus_one();
     unsigned rmax = 0;                                                   // range guard: largest sampled hi half of this wave
+    [[maybe_unused]] float lmax = 0.0f;                                  // V = 2: largest |logit| this lane wrote (VT_RANGE_LOGIT)
 
     uint32_t tile = t_begin + w_idx;
     if (tile < t_end) fetch(tile, ox, oy, oz);
@@ -422,7 +424,11 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
             ST3_RUN_BLOCKS();
         }
     }
-    range_report(rmax, a.status);
+    range_report(rmax, a.status, V == 2);
+    if constexpr (V == 2) {
+        if (a.status != nullptr && lmax > VT_F16F8_LOGIT_LIMIT) atomicOr(a.status, VT_RANGE_LOGIT);
+    }
+    clock_end(a.clk, stamp);
 }
 
 #undef ST3_GAP

@@ -779,7 +779,7 @@ int vt_mc_read_counts(const void *workspace, int *nverts_host, int *nfaces_host,
 // vertex / face kernels of a marching-cubes call) and returns the counts.  A ring of 16 slots; a token is valid for one _end.
 namespace {
 constexpr int MC_SLOTS = 16;
-struct McSlot { McHeader *host; hipEvent_t ev; bool made, busy; int seq, polled; };   // polled: the scan kernel writes `seq` into the slot (vt_mc_count_notify)
+struct McSlot { McHeader *host; hipEvent_t ev; bool made, busy; int seq, polled; hipStream_t stream; };   // polled: the scan kernel writes `seq` into the slot (vt_mc_count_notify, on `stream`)
 McSlot mc_slots[MC_SLOTS];                              // zero-initialised: nothing made, nothing busy
 unsigned mc_slot_next = 0;
 std::mutex mc_slots_mutex;                              // guards the slots' creation and their busy flags
@@ -816,6 +816,7 @@ int vt_mc_count_notify(const float *vol, int n0, int n1, int n2, double level, i
     McSlot &sl = mc_slots[t];
     sl.seq = sl.seq == 0x7fffffff ? 1 : sl.seq + 1;             // never 0: a fresh slot reads 0
     sl.polled = 1;
+    sl.stream = (hipStream_t)stream;
     rc = mc_count_impl(vol, n0, n1, n2, level, auto_level, workspace, workspace_bytes, stream, sl.host, sl.seq);
     if (rc) {
         std::lock_guard<std::mutex> lock(mc_slots_mutex);
@@ -860,7 +861,13 @@ int vt_mc_read_counts_end(int token, int *nverts_host, int *nfaces_host, double 
         while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != mc_slots[token].seq) {
             if ((++spins & 0xfffu) == 0) {
                 if (hipPeekAtLastError() != hipSuccess) { e = hipGetLastError(); break; }
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) { e = hipErrorNotReady; break; }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                    // a long backlog in front of the scan kernel (or a paused process): stop spinning and WAIT for the stream --
+                    // the slot must not be handed out again while that kernel can still write into it
+                    e = hipStreamSynchronize(mc_slots[token].stream);
+                    if (e == hipSuccess && __atomic_load_n(seq, __ATOMIC_ACQUIRE) != mc_slots[token].seq) e = hipErrorUnknown;
+                    break;
+                }
             }
         }
         mc_slots[token].polled = 0;

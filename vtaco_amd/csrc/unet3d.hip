@@ -72,7 +72,10 @@ __host__ __device__ inline size_t gn_acc_words(int B, int rows, int C) { return 
 // wave 0 of a workgroup, all 64 lanes: lane = channel * 2 + {sum, sumsq} of the channels [c0, c0 + 32) of scene b
 __device__ __forceinline__ void gn_out_add(const GnOut &o, int b, unsigned wg, int c0, float tsum) {
     const int lane = threadIdx.x & 63;
-    const bool finite = fabsf(tsum) <= 3.0e38f;                     // false for NaN
+    // "finite" = inside the accumulators' capacity: |t| < 2^45 keeps 1024 arrivals below 2^63 in the high cell (and the
+    // double -> integer conversion below defined); a larger sum (sumsq beyond ~3.5e13 per workgroup), an infinity or a NaN
+    // raises the scene's flag instead of wrapping silently -- the consumer's scale / shift then come out NaN
+    const bool finite = fabsf(tsum) < 0x1p45f;                      // false for NaN
     const double v = finite ? (double)tsum * 0x1p40 : 0.0;          // exact
     const double h = floor(v * 0x1p-32);
     long long hi = (long long)h;
@@ -1174,11 +1177,7 @@ conv3d_gcr_h_kernel(HbArgs ha) {
 
     const int N = ntile * ncq;
     int e_q = 0, e_k = 0;
-#ifdef VT_HB_NOSKEW
-    const bool late = false;
-#else
     const bool late = (wave >> 2) & 1;                              // waves w and w + 4 share a SIMD: one commits first, one mid-taps
-#endif
     // s_waitcnt vmcnt(ITERS) alone: everything but the wave's ITERS youngest vector-memory operations (the register fetch of
     // chunk n + 2, issued after the DMA of chunk n + 1) has landed
     constexpr int WAIT_DMA = 0x0F70 | ITERS;
@@ -1431,13 +1430,7 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
         // iteration n: commit chunk n+1 (requested two iterations ago), DMA its weights, request chunk n+3 into the freed set;
         // the counted wait lets that youngest request fly on and, vmcnt being in order, also covers chunk n+2's request
         auto iteration = [&](int n, PreSet &ps) {
-#if defined(VT_HBX) && VT_HBX == 2
-            if (n + 1 < N) { commit(n + 1, ps); }
-#elif defined(VT_HBX) && VT_HBX == 3
-            if (n + 1 < N) { dma_w(n + 1); }
-#else
             if (n + 1 < N) { commit(n + 1, ps); dma_w(n + 1); }
-#endif
             if (n + 3 < N) {
                 fetch(ps);
                 __builtin_amdgcn_s_waitcnt(WAIT_DMA);

@@ -36,7 +36,11 @@ int vt_fail(int code, const char *msg);
 int vt_check(hipError_t e, const char *where);
 int vt_num_cus();
 // the device word of the half-precision decodes' range guard (decode_common.h; read by vt_decode_range_status), allocated at first use
+// (one block per device: bytes 0..3 the VT_RANGE_* bits, bytes 8..23 the last lattice kernel's clock stamps)
 unsigned *vt_decode_status_dev();
+static inline unsigned long long *status_clk(unsigned *status) {
+    return status ? reinterpret_cast<unsigned long long *>(status + 2) : nullptr;
+}
 // capture-safe replacement of hipMemsetAsync (memset nodes misbehaved under hipGraph replay on ROCm 7.0/7.2):
 // fills `bytes` (multiple of 4) at `dst` with the 32-bit pattern
 int vt_fill32(void *dst, unsigned pattern, size_t bytes, hipStream_t stream);

@@ -130,12 +130,30 @@ def pack_decoder(fc_p_w, fc_p_b, fc_c, blocks, fc_out, fc_out2=None, out=None, t
     return out
 
 
+RANGE_HALF, RANGE_FP8, RANGE_LOGIT = 1, 2, 4
+
+
 def decode_range_status(reset=True):
-    """Bit 0: a half-precision lattice decode ("f16x3" / "f16f8") since the last reset met activations at the edge of the half
-    range (its hi operand saturated at 65504: the logits of those launches are not to be trusted).  Synchronises the stream."""
+    """The current device's range-guard word (vt_decode_range_status).  Bit 0 (RANGE_HALF): a half-precision lattice decode
+    ("f16x3" / "f16f8") since the last reset met activations at the edge of the half range (its hi operand saturated at 65504:
+    the logits of those launches are not to be trusted).  Bit 1 (RANGE_FP8): an "f16f8" decode met activations >= 1024, where
+    the fp8 copies of its correction products begin to clip, bit 2 (RANGE_LOGIT): an "f16f8" decode wrote a logit beyond 2.5 in
+    magnitude (its error is relative, ~3e-5 |logit|) -- in both cases its 1e-4 contract ends and "f16x3" is the form to use.
+    Synchronises the stream."""
     word = ctypes.c_uint32(0)
     check(_lib.load().vt_decode_range_status(ctypes.byref(word), int(bool(reset)), stream_ptr()), "vt_decode_range_status")
     return int(word.value)
+
+
+def decode_last_clock():
+    """Clock evidence of the last lattice decode launch on the current device (vt_decode_last_clock): workgroup 0's lifetime in
+    shader cycles and in ticks of the constant-rate counter -> {"shader_mhz", "kernel_us", "shader_cycles"}.  Synchronises."""
+    cyc, ref, khz = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_int(0)
+    check(_lib.load().vt_decode_last_clock(ctypes.byref(cyc), ctypes.byref(ref), ctypes.byref(khz), stream_ptr()), "vt_decode_last_clock")
+    if ref.value == 0 or khz.value <= 0:
+        return None
+    us = ref.value / (khz.value * 1e-3)
+    return {"shader_mhz": cyc.value / us, "kernel_us": us, "shader_cycles": int(cyc.value), "ref_khz": int(khz.value)}
 
 
 def is_channels_last_grid(grid):
@@ -278,7 +296,8 @@ def mc_count(vol, level=None):
 def mc_count_notify(vol, level=None):
     """``mc_count`` whose scan kernel also writes the counts into a page-locked host slot (vt_mc_count_notify): returns
     (workspace, token); hand the token to ``mc_emit`` -- the count read then needs no copy command between the count and the emit
-    kernels.  Not for graph capture (it records an event): captured scenes use ``mc_count``."""
+    kernels.  Not for graph capture: the slot's sequence number is baked into the scan kernel's arguments, so a replay would write
+    a number nobody waits for; captured scenes use ``mc_count``."""
     if vol.dim() != 3 or not vol.is_contiguous():
         raise VtError("marching_cubes: volume must be a contiguous [n0,n1,n2] tensor")
     ws, nbytes = _mc_workspace(vol)
@@ -300,6 +319,9 @@ def mc_emit(vol, ws, rescale=None, capacity=None, token=None):
     the read is the only synchronisation of the call; if the surface outgrew the guess the emit is
     repeated at the exact size (the kernels never write past their capacity)."""
     lib = _lib.load()
+    if capacity is not None and token is not None:
+        raise VtError("mc_emit: a token (mc_count_notify) is handed back by reading the counts; with capacity= nothing is read -- "
+                      "use mc_count for fixed-capacity extraction")
     n0, n1, n2 = vol.shape
     st = stream_ptr()
     wp = ctypes.c_void_p(ws.data_ptr())
