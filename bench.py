@@ -319,6 +319,17 @@ def warm_up(step, min_steps, fx, min_s=MIN_WARM_S, collective=False):
             return n
 
 
+def clock_of_last_launch(vops):
+    """In-kernel stamps of the last lattice launch (ops.decode_last_clock) without the raw per-workgroup list."""
+    c = vops.decode_last_clock(workgroups=True)
+    if c is not None:
+        c.pop("wg_ticks", None)
+        c["note"] = ("shader_mhz = workgroup 0's s_memtime cycles / its s_memrealtime ticks (the clock the chip held under this kernel); "
+                     "span_us = first workgroup start to last workgroup end of that launch, start_spread_us = the dispatch ramp, wg_us_* = "
+                     "workgroup lifetimes (persistent workgroups, equal tile counts)")
+    return c
+
+
 def timed_region(step, steps, fx, collective=False):
     """The timed region of one kernel: REPS back-to-back repetitions of EXACTLY `steps` steps between two barrier +
     synchronize fences, REPS = the smallest count that makes the region last MIN_TIMED_S (a 20-step region of this kernel is
@@ -596,7 +607,7 @@ def main():
     warm_steps = warm_up(step, args.warmup, fx, collective=strong and world > 1)
     wall, timed_steps, timing = timed_region(step, args.steps, fx, collective=strong and world > 1)
     kern_ms = timing["kernel_ms_total_events"]          # HIP events on the launch stream, over the whole timed region
-    clock = vops.decode_last_clock()                    # workgroup 0's lifetime of the LAST launch: the clock the chip held
+    clock = clock_of_last_launch(vops)                  # stamps of the LAST launch: the clock the chip held, ramp and tail
 
     res = None
     if rank == 0:
@@ -639,7 +650,7 @@ def main():
                 w, n, tm = timed_region(fn, args.steps, fx)
                 return {"value": npts * n / w, "unit": "query-points/s",
                         "timing": {k: tm[k] for k in ("reps", "timed_steps", "kernel_ms_mean", "kernel_ms_std", "std_over_mean", "wall_over_events")},
-                        "roofline": roofline_of(prec, flop_pt, npts, tm["kernel_ms_total_events"], vops.decode_last_clock())}
+                        "roofline": roofline_of(prec, flop_pt, npts, tm["kernel_ms_total_events"], clock_of_last_launch(vops))}
             res["exact_f32_kernel"] = side("f32")
             res["value_f32"] = res["exact_f32_kernel"]["value"]
             for other in ("f16x3", "f16f8", "bf16x3"):              # the other 16-bit forms: fp8-corrected (opt-in), round 1's split-bf16

@@ -164,10 +164,13 @@ int vt_decode_fwd_f16f8(const float *grid_cl, int B, int R, int C, int64_t N,
 int vt_decode_range_status(unsigned *host_status, int reset, void *stream);
 
 /* Measurement aid (bench.py's clock evidence; no reference counterpart): the lattice kernels of      */
-/* vt_decode_fwd* stamp workgroup 0's lifetime with the shader-clock counter and the constant-rate     */
-/* counter; this returns the last launch's two differences on the current device and the constant      */
-/* counter's rate in kHz (synchronises `stream`): shader MHz = cycles / ticks * ref_khz / 1000.        */
-int vt_decode_last_clock(unsigned long long *shader_cycles, unsigned long long *ref_ticks, int *ref_khz, void *stream);
+/* vt_decode_fwd* stamp every workgroup's lifetime with the constant-rate counter and workgroup 0's     */
+/* also with the shader-clock counter; this returns the last launch's differences of workgroup 0 on     */
+/* the current device and the constant counter's rate in kHz (synchronises `stream`):                   */
+/* shader MHz = cycles / ticks * ref_khz / 1000; and, with max_wgs > 0, the (start, end) ticks of the   */
+/* first min(max_wgs, workgroups, 512) workgroups -- the launch's ramp and tail.                         */
+int vt_decode_last_clock(unsigned long long *shader_cycles, unsigned long long *ref_ticks, int *ref_khz,
+                         unsigned long long *wg_ticks, int max_wgs, int *n_wgs, void *stream);
 
 /* LocalDecoder beyond the shipped shape.  Replaces the same reference functions (decoder.py:135-161, */
 /* 71-103, 105-133) for hidden_size and c_dim any multiples of 32 up to 256 (the class defaults are      */

@@ -46,6 +46,7 @@ def _worker(rank, world, port, q):
         plain = gen.generate_obj_mesh_wnf({"inputs": p})
         shard = gen.generate_obj_mesh_sharded({"inputs": p})
         ok_mesh = torch.equal(plain.faces, shard.faces) and torch.equal(plain.vertices, shard.vertices)
+        why = [] if ok_mesh else ["visual: sharded != plain"]
         # the range guard of the (default) half-precision decode is rank-local outside the sharded entry point: a mesh that only
         # rank 0 exports -- during distributed training, or with uneven scene counts -- must meet no collective ...
         assert gen.decode_precision == "f16x3"
@@ -75,7 +76,10 @@ def _worker(rank, world, port, q):
         plain_t = gen_t.generate_obj_mesh_wnf(data_t)
         np.random.seed(7 if rank == 0 else 99)
         shard_t = gen_t.generate_obj_mesh_sharded(data_t)
-        ok_mesh = ok_mesh and torch.equal(plain_t.faces, shard_t.faces) and torch.equal(plain_t.vertices, shard_t.vertices)
+        ok_t = torch.equal(plain_t.faces, shard_t.faces) and torch.equal(plain_t.vertices, shard_t.vertices)
+        if not ok_t:
+            why.append(f"tactile: sharded != plain ({plain_t.vertices.shape[0]} vs {shard_t.vertices.shape[0]} vertices)")
+        ok_mesh = ok_mesh and ok_t
         # data-parallel step: different batches per rank, one flat all-reduce -> identical parameters afterwards
         opt = torch.optim.SGD(model.parameters(), lr=1e-2)
         trainer = Trainer(model, opt, device=dev, grad_sync=GradAllReduce(model.parameters()))
@@ -87,6 +91,8 @@ def _worker(rank, world, port, q):
         gathered = [torch.empty_like(flat) for _ in range(world)]
         dist.all_gather(gathered, flat)
         ok_sync = all(torch.equal(gathered[0], t) for t in gathered[1:])
+        if why:
+            sys.stderr.write(f"rank {rank}: {why}\n")
         q.put((rank, bool(ok_mesh), bool(ok_sync)))
     finally:
         dist.destroy_process_group()

@@ -103,7 +103,8 @@ SIGNATURES = {
     "vt_decoder_pack_f16x3": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
     "vt_decode_fwd_f16x3": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP, _I, _VP, _D, _VP, _VP, _VP]),
     "vt_decode_range_status": (_I, [ctypes.POINTER(ctypes.c_uint32), _I, _VP]),
-    "vt_decode_last_clock": (_I, [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int), _VP]),
+    "vt_decode_last_clock": (_I, [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int),
+                                  ctypes.POINTER(ctypes.c_uint64), _I, ctypes.POINTER(ctypes.c_int), _VP]),
     "vt_decoder_pack_f16f8": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
     "vt_decoder_wide_blob_bytes": (_SZ, [_I, _I, _I, _I]),
     "vt_decoder_pack_wide": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),

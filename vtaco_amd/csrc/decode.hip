@@ -957,9 +957,10 @@ __global__ void __launch_bounds__(256) grid_from_cl_kernel(const float *src, flo
 #ifndef VT_DECODE_F16_TU
 // ---- range guard of the half-precision decodes: one status block PER DEVICE (kernels of a process that drives several
 // GPUs must not atomicOr into another GPU's memory), created under a mutex at a device's first use.
-//   bytes 0..3: VT_RANGE_* bits; 8..23: the last lattice kernel's clock stamps (ClockStamp differences, decode_common.h)
+//   bytes 0..3: VT_RANGE_* bits; from byte 8: the last lattice kernel's clock stamps (clock_end, decode_common.h):
+//   [cycles of workgroup 0, its ticks, workgroups, -, then (start tick, end tick) per workgroup]
 constexpr int VT_MAX_DEVICES = 64;
-constexpr size_t VT_STATUS_BYTES = 32;
+constexpr size_t VT_STATUS_BYTES = 8 + (4 + 2 * VT_CLK_MAX_WGS) * 8;
 static std::mutex g_status_mutex;
 static std::atomic<unsigned *> g_decode_status[VT_MAX_DEVICES];
 unsigned *vt_decode_status_dev() {
@@ -1049,11 +1050,13 @@ int vt_decode_range_status(unsigned *host_status, int reset, void *stream) {
     return 0;
 }
 
-int vt_decode_last_clock(unsigned long long *shader_cycles, unsigned long long *ref_ticks, int *ref_khz, void *stream) {
+int vt_decode_last_clock(unsigned long long *shader_cycles, unsigned long long *ref_ticks, int *ref_khz,
+                         unsigned long long *wg_ticks, int max_wgs, int *n_wgs, void *stream) {
     if (!shader_cycles || !ref_ticks || !ref_khz) return vt_fail(VT_ERR_INVALID, "vt_decode_last_clock: null argument");
+    if (max_wgs < 0 || (max_wgs > 0 && (!wg_ticks || !n_wgs))) return vt_fail(VT_ERR_INVALID, "vt_decode_last_clock: bad workgroup buffer");
     unsigned *d = vt_decode_status_dev();
     if (!d) return vt_fail(VT_ERR_INVALID, "vt_decode_last_clock: no device memory for the status block");
-    unsigned long long h[2] = {0ull, 0ull};
+    static thread_local unsigned long long h[4 + 2 * VT_CLK_MAX_WGS];
     hipError_t e = hipMemcpyAsync(h, status_clk(d), sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     int dev = 0, khz = 0;
@@ -1061,6 +1064,12 @@ int vt_decode_last_clock(unsigned long long *shader_cycles, unsigned long long *
     if (e == hipSuccess) e = hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev);   // the rate of s_memrealtime
     if (e != hipSuccess) return vt_check(e, "vt_decode_last_clock");
     *shader_cycles = h[0]; *ref_ticks = h[1]; *ref_khz = khz;
+    if (max_wgs > 0) {
+        int n = (int)(h[2] < (unsigned long long)VT_CLK_MAX_WGS ? h[2] : VT_CLK_MAX_WGS);
+        if (n > max_wgs) n = max_wgs;
+        for (int i = 0; i < 2 * n; ++i) wg_ticks[i] = h[4 + i];
+        *n_wgs = n;
+    }
     return 0;
 }
 

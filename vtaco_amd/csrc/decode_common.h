@@ -174,24 +174,31 @@ __device__ __forceinline__ void range_report(unsigned rmax, unsigned *status, bo
 }
 
 // ---- in-kernel clock stamps of the lattice kernels (bench.py's evidence of the clock the chip held) ------------------------
-// Workgroup 0 is persistent over its share of the tiles, so its lifetime is the launch's: its first thread reads the shader
-// clock counter (s_memtime) and the constant-rate counter (s_memrealtime) at both ends and leaves the two differences in the
-// device's status block (vt_decode_last_clock).  Two scalar reads per end of one wave: nothing measurable.
+// Every workgroup is persistent over its share of the tiles.  Each reads the constant-rate counter (s_memrealtime: one time
+// base for the whole chip) at both ends and leaves (start, end) in the device's status block: the spread of the starts and
+// the ends is the launch's ramp and tail.  Workgroup 0 also reads the shader clock counter (s_memtime) at both ends: cycles
+// over ticks is the clock the chip held under this kernel's load (vt_decode_last_clock).  A few scalar reads per workgroup
+// and one 16-byte store: nothing measurable.
+constexpr int VT_CLK_MAX_WGS = 512;                  // (start, end) pairs kept per launch
 struct ClockStamp {
     unsigned long long t0, r0;
 };
 __device__ __forceinline__ ClockStamp clock_begin(const unsigned long long *clk) {
     ClockStamp c{0ull, 0ull};
-    if (clk != nullptr && blockIdx.x == 0) {                 // a scalar condition: the stamps live in SGPRs across the kernel
-        c.t0 = __builtin_readcyclecounter();
+    if (clk != nullptr) {                                    // scalar conditions: the stamps live in SGPRs across the kernel
         c.r0 = __builtin_amdgcn_s_memrealtime();
+        if (blockIdx.x == 0) c.t0 = __builtin_readcyclecounter();
     }
     return c;
 }
 __device__ __forceinline__ void clock_end(unsigned long long *clk, const ClockStamp &c) {
-    if (clk != nullptr && blockIdx.x == 0) {
-        const unsigned long long dt = __builtin_readcyclecounter() - c.t0, dr = __builtin_amdgcn_s_memrealtime() - c.r0;
-        if (threadIdx.x == 0) { clk[0] = dt; clk[1] = dr; }
+    if (clk != nullptr) {
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+        if (blockIdx.x == 0) {
+            const unsigned long long dt = __builtin_readcyclecounter() - c.t0;
+            if (threadIdx.x == 0) { clk[0] = dt; clk[1] = r1 - c.r0; clk[2] = gridDim.x; }
+        }
+        if (threadIdx.x == 0 && blockIdx.x < VT_CLK_MAX_WGS) { clk[4 + 2 * blockIdx.x] = c.r0; clk[5 + 2 * blockIdx.x] = r1; }
     }
 }
 

@@ -263,12 +263,13 @@ __device__ __forceinline__ float exp2_unit(float x) { return __builtin_amdgcn_ex
 //   rowsum: F = Q, S = K, w = null          colsum: F = K, S = Q, w = 1/l
 template <bool STREAM_KEYS, bool FULL>
 __global__ void __launch_bounds__(FT)
-fusion_expsum_kernel(const float *Fd, const float *Sd, const float *w, float *out, int N, int recip_out) {
+fusion_expsum_kernel(const float *Fd, const float *Sd, const float *w, float *out, int N, int recip_out, int nrb, int B) {
     __shared__ __attribute__((aligned(16))) float tiles[2][STILE];
     __shared__ __attribute__((aligned(16))) float wt[2][32];
-    const int b = blockIdx.y;
+    int rb, b;
+    chunk_of_workgroup(nrb, B, rb, b);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-    const int f0 = blockIdx.x * FROWS + wave * 32;
+    const int f0 = rb * FROWS + wave * 32;
     Fd += (size_t)b * N * 64; Sd += (size_t)b * N * 64;
     if (w) w += (size_t)b * N;
     FragQK fixed;
@@ -318,12 +319,13 @@ __device__ __forceinline__ void tile_store8(float *tile, const f32x4 &t) {
 }
 
 __global__ void __launch_bounds__(FT)
-fusion_expsum8_kernel(const float *Fd, const float *Sd, const float *w, float *out, int N, int recip_out) {
+fusion_expsum8_kernel(const float *Fd, const float *Sd, const float *w, float *out, int N, int recip_out, int nrb, int B) {
     __shared__ __attribute__((aligned(16))) float tiles[2][STILE8];
     __shared__ __attribute__((aligned(16))) float wt[2][32];
-    const int b = blockIdx.y;
+    int rb, b;
+    chunk_of_workgroup(nrb, B, rb, b);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-    const int f0 = blockIdx.x * FROWS + wave * 32;
+    const int f0 = rb * FROWS + wave * 32;
     Fd += (size_t)b * N * 48; Sd += (size_t)b * N * 48;
     if (w) w += (size_t)b * N;
     FragQK8 fixed;
@@ -432,16 +434,17 @@ constexpr int VROW = 36;                                    // V' tile row: 128 
 template <bool TRAIN, bool FULL, bool F8>
 __global__ void __launch_bounds__(FT)
 fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const float *linv, const float *Xq,
-                     const float *blob, float *Z, int N, int ntile_, float *Osave, DropCfg dc) {
+                     const float *blob, float *Z, int N, int ntile_, float *Osave, DropCfg dc, int nrb, int B) {
     static_assert(!(F8 && (TRAIN || FULL)), "the fp8-corrected tiles are the inference form");
     __shared__ __attribute__((aligned(16))) float lds[FU_BLOB];
     __shared__ __attribute__((aligned(16))) float tiles[2][F8 ? STILE8 : STILE];
     __shared__ __attribute__((aligned(16))) float vts[2][32 * VROW];
     for (int i = threadIdx.x; i < FU_BLOB; i += FT) lds[i] = blob[i];
     if constexpr (F8) fp8_saturating_mode();
-    const int b = blockIdx.y;
+    int rb, b;
+    chunk_of_workgroup(nrb, B, rb, b);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-    const int q0 = blockIdx.x * FROWS + wave * 32;
+    const int q0 = rb * FROWS + wave * 32;
     const int ntile = ntile_;
     constexpr int RS = F8 ? 48 : 64;                                     // floats per Q / K row
     Qd += (size_t)b * N * RS; Kd += (size_t)b * N * RS; VT += (size_t)b * ntile * 1024;
@@ -685,7 +688,8 @@ void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const fl
               float *out, int B, int N, hipStream_t s, float *Osave = nullptr, DropCfg dc = DropCfg{0, 0, 1.0f, 0}) {
     const int P = B * N, Npad = (N + 31) / 32 * 32;
     const int ntile = (N + 31) / 32;
-    const dim3 pg((P + 128 * PROJ_TILES - 1) / (128 * PROJ_TILES)), tg((N + FROWS - 1) / FROWS, B);
+    const int nrb = (N + FROWS - 1) / FROWS;
+    const dim3 pg((P + 128 * PROJ_TILES - 1) / (128 * PROJ_TILES)), tg((unsigned)nrb * (unsigned)B);   // see chunk_of_workgroup
     // the training forward keeps every product (its backward recomputes the scores on the f32 core); inference runs the
     // fp8-corrected tiles (keys rounded to half, the queries' remainder and both E x V' corrections on fp8 MFMAs) unless
     // VTACO_FUSION_SCORE_TERMS is set: 3 = all three half products, 2 = the half-pair form with rounded keys (round 2's)
@@ -705,14 +709,14 @@ void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const fl
         hipLaunchKernelGGL((fusion_proj_kernel<false, true, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
     }
     if (f8) {
-        hipLaunchKernelGGL(fusion_expsum8_kernel, tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1);                // 1/l_q
-        hipLaunchKernelGGL(fusion_expsum8_kernel, tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0);                    // s_k
+        hipLaunchKernelGGL(fusion_expsum8_kernel, tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1, nrb, B);                // 1/l_q
+        hipLaunchKernelGGL(fusion_expsum8_kernel, tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0, nrb, B);                    // s_k
     } else if (full) {
-        hipLaunchKernelGGL((fusion_expsum_kernel<true, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1);
-        hipLaunchKernelGGL((fusion_expsum_kernel<false, true>), tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0);
+        hipLaunchKernelGGL((fusion_expsum_kernel<true, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1, nrb, B);
+        hipLaunchKernelGGL((fusion_expsum_kernel<false, true>), tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0, nrb, B);
     } else {
-        hipLaunchKernelGGL((fusion_expsum_kernel<true, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1);
-        hipLaunchKernelGGL((fusion_expsum_kernel<false, false>), tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0);
+        hipLaunchKernelGGL((fusion_expsum_kernel<true, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1, nrb, B);
+        hipLaunchKernelGGL((fusion_expsum_kernel<false, false>), tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0, nrb, B);
     }
     if (f8) {
         const size_t tot = (size_t)B * ntile * 64;                   // (b, tile, c, kg)
@@ -726,13 +730,13 @@ void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const fl
         hipLaunchKernelGGL(fusion_scalev_kernel, dim3((unsigned)g), dim3(256), 0, s, w.V, w.s, w.VT, N, ntile, tot);
     }
     if (Osave)
-        hipLaunchKernelGGL((fusion_attend_kernel<true, true, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
+        hipLaunchKernelGGL((fusion_attend_kernel<true, true, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc, nrb, B);
     else if (full)
-        hipLaunchKernelGGL((fusion_attend_kernel<false, true, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
+        hipLaunchKernelGGL((fusion_attend_kernel<false, true, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc, nrb, B);
     else if (f8)
-        hipLaunchKernelGGL((fusion_attend_kernel<false, false, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
+        hipLaunchKernelGGL((fusion_attend_kernel<false, false, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc, nrb, B);
     else
-        hipLaunchKernelGGL((fusion_attend_kernel<false, false, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc);
+        hipLaunchKernelGGL((fusion_attend_kernel<false, false, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc, nrb, B);
     if (N <= 128 * IN_ROWS) hipLaunchKernelGGL(fusion_inorm_relu_cached_kernel, dim3(B), dim3(1024), 0, s, w.Z, out, N);
     else hipLaunchKernelGGL(fusion_inorm_relu_kernel, dim3(B), dim3(1024), 0, s, w.Z, out, N);
 }

@@ -298,13 +298,14 @@ __device__ __forceinline__ void load_fixed32(float (&f)[16], const float *row, i
 
 // pass "dv": dV_k = sum_q A_qk dO_q and t'_k.  fixed: K rows; streamed: Q rows with payload linv_q dO_q
 __global__ void __launch_bounds__(NT)
-fb_dv_kernel(const float *Qf, const float *Kf, const float *dOs, const float *V, const float *scol, float *dV, float *tp, int N) {
+fb_dv_kernel(const float *Qf, const float *Kf, const float *dOs, const float *V, const float *scol, float *dV, float *tp, int N, int nrb, int B) {
     __shared__ __attribute__((aligned(16))) StreamTile tiles[2];
-    const int b = blockIdx.y;
+    int rb, b;
+    chunk_of_workgroup(nrb, B, rb, b);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
     const size_t base = (size_t)b * N;
     Qf += base * 64; Kf += base * 64; dOs += base * 32; V += base * 32; scol += base; dV += base * 32; tp += base;
-    const int k0 = blockIdx.x * NFIX + wave * 32, k = min(k0 + j, N - 1);
+    const int k0 = rb * NFIX + wave * 32, k = min(k0 + j, N - 1);
     float fixed[32];
     load_fixed64(fixed, Kf + (size_t)k * 64, h, LOG2E);
     f32x16 acc;
@@ -342,13 +343,14 @@ fb_dv_kernel(const float *Qf, const float *Kf, const float *dOs, const float *V,
 // pass "dq": dQ_q = M1_q - u_q M2_q and u_q.  fixed: Q rows (+ dO_q, 1/l_q); streamed: K rows with payload V'_k, scalar t'_k
 __global__ void __launch_bounds__(NT)
 fb_dq_kernel(const float *Qf, const float *Kf, const float *dO, const float *V, const float *scol, const float *tp,
-             const float *linv, float *dQ, float *u, int N) {
+             const float *linv, float *dQ, float *u, int N, int nrb, int B) {
     __shared__ __attribute__((aligned(16))) StreamTile tiles[2];
-    const int b = blockIdx.y;
+    int rb, b;
+    chunk_of_workgroup(nrb, B, rb, b);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
     const size_t base = (size_t)b * N;
     Qf += base * 64; Kf += base * 64; dO += base * 32; V += base * 32; scol += base; tp += base; linv += base; dQ += base * 64; u += base;
-    const int q0 = blockIdx.x * NFIX + wave * 32, q = min(q0 + j, N - 1);
+    const int q0 = rb * NFIX + wave * 32, q = min(q0 + j, N - 1);
     float fixed[32], dofix[16];
     load_fixed64(fixed, Qf + (size_t)q * 64, h, LOG2E);
     load_fixed32(dofix, dO + (size_t)q * 32, h, 1.0f);
@@ -401,13 +403,14 @@ fb_dq_kernel(const float *Qf, const float *Kf, const float *dO, const float *V, 
 // pass "dk": dK_k = sum_q dS_qk Q_q.  fixed: K rows (+ V'_k, t'_k); streamed: Q rows with payload dO_q, scalars 1/l_q and u_q
 __global__ void __launch_bounds__(NT)
 fb_dk_kernel(const float *Qf, const float *Kf, const float *dO, const float *V, const float *scol, const float *tp,
-             const float *linv, const float *u, float *dK, int N) {
+             const float *linv, const float *u, float *dK, int N, int nrb, int B) {
     __shared__ __attribute__((aligned(16))) StreamTile tiles[2];
-    const int b = blockIdx.y;
+    int rb, b;
+    chunk_of_workgroup(nrb, B, rb, b);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
     const size_t base = (size_t)b * N;
     Qf += base * 64; Kf += base * 64; dO += base * 32; V += base * 32; scol += base; tp += base; linv += base; u += base; dK += base * 64;
-    const int k0 = blockIdx.x * NFIX + wave * 32, k = min(k0 + j, N - 1);
+    const int k0 = rb * NFIX + wave * 32, k = min(k0 + j, N - 1);
     float fixed[32], vfix[16];
     load_fixed64(fixed, Kf + (size_t)k * 64, h, LOG2E);
     load_fixed32(vfix, V + (size_t)k * 32, h, 1.0f / (1e-9f + scol[k]));
@@ -576,19 +579,20 @@ void unit_bwd(int call, const float *Xq, const float *Xk, const float *dOut, con
               int accumulate, const float *blob_f, const float *blob_t, const FusionSaved &sv, const BwdWs &w, float *dXq, float *dXk,
               int B, int N, float p_drop, unsigned long long seed, hipStream_t s) {
     const int P = B * N;
-    const dim3 pg((P + 3) / 4), eg((P + 127) / 128), tg((N + NFIX - 1) / NFIX, B);
+    const dim3 pg((P + 3) / 4), eg((P + 127) / 128), tg((unsigned)((N + NFIX - 1) / NFIX) * (unsigned)B);
+    const int nrb = (N + NFIX - 1) / NFIX;
     hipLaunchKernelGGL(fb_proj_kernel, pg, dim3(256), 0, s, Xq, Xk, u, w.Qf, w.Kf, w.nq, w.nk, P);
     hipLaunchKernelGGL(fb_inorm_bwd_kernel, dim3(B), dim3(1024), 0, s, (const float *)sv.Z[call], dOut, w.dZ, N);
     const EpiOut eo{w.gXq, w.dO, w.dOs, w.D, w.dR0, w.R, w.dH0, w.Hd, w.dY, w.dy, w.dyxh};
     hipLaunchKernelGGL(fb_epilogue_bwd_kernel, eg, dim3(256), 0, s, Xq, (const float *)sv.O[call], (const float *)w.dZ,
                        (const float *)sv.linv[call], blob_f, blob_t, eo, P, drop_cfg(p_drop, seed, (uint32_t)call));
     hipLaunchKernelGGL(fb_dv_kernel, tg, dim3(NT), 0, s, (const float *)w.Qf, (const float *)w.Kf, (const float *)w.dOs,
-                       (const float *)sv.V[call], (const float *)sv.s[call], w.dV, w.tp, N);
+                       (const float *)sv.V[call], (const float *)sv.s[call], w.dV, w.tp, N, nrb, B);
     hipLaunchKernelGGL(fb_dq_kernel, tg, dim3(NT), 0, s, (const float *)w.Qf, (const float *)w.Kf, (const float *)w.dO,
-                       (const float *)sv.V[call], (const float *)sv.s[call], (const float *)w.tp, (const float *)sv.linv[call], w.dQ, w.u, N);
+                       (const float *)sv.V[call], (const float *)sv.s[call], (const float *)w.tp, (const float *)sv.linv[call], w.dQ, w.u, N, nrb, B);
     hipLaunchKernelGGL(fb_dk_kernel, tg, dim3(NT), 0, s, (const float *)w.Qf, (const float *)w.Kf, (const float *)w.dO,
                        (const float *)sv.V[call], (const float *)sv.s[call], (const float *)w.tp, (const float *)sv.linv[call],
-                       (const float *)w.u, w.dK, N);
+                       (const float *)w.u, w.dK, N, nrb, B);
     hipLaunchKernelGGL(fb_proj_bwd_kernel, pg, dim3(256), 0, s, (const float *)w.Qf, (const float *)w.Kf, (const float *)w.nq,
                        (const float *)w.nk, w.dQ, w.dK, (const float *)w.dV, u, w.gXq, w.gXk, P);
     WJobs jobs;

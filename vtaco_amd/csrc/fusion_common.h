@@ -86,6 +86,26 @@ inline size_t fusion_saved_layout(int B, int N, FusionSaved *sv, char *base) {
     return off;
 }
 
+// ---- workgroup -> (row block, chunk): the row blocks of ONE chunk on ONE XCD --------------------------------------------
+// The N x N passes (forward and backward) launch nrb = ceil(N / rows per workgroup) workgroups per chunk, each streaming the
+// chunk's complete other operand (N rows of 192 or 256 B).  Workgroups are dealt to the eight XCDs round robin by linear id,
+// so with the row block as the fast grid index the eight workgroups of a 2048-point chunk landed on eight different L2s and
+// every one of them fetched the same rows from the fabric (profiles/r03_fusion_pmc_summary.csv: 2.2-4.4 x the unique bytes
+// per launch).  With a 1-D grid of nrb * B workgroups, id w runs on XCD w & 7 and is the (w >> 3)-th workgroup there: XCD x
+// takes the chunks x, x + 8, x + 16, ... and walks each chunk's row blocks back to back, so a chunk's streamed rows are
+// fetched once into ONE L2 and hit there for the other row blocks (consecutive ids of an XCD are resident together).
+__device__ __forceinline__ void chunk_of_workgroup(int nrb, int B, int &rb, int &b) {
+    const unsigned w = blockIdx.x;
+    if ((B & 7) == 0) {
+        const unsigned idx = w >> 3;
+        rb = (int)(idx % (unsigned)nrb);
+        b = (int)(idx / (unsigned)nrb) * 8 + (int)(w & 7u);
+    } else {                                                    // fewer than eight chunks or a ragged count: plain order
+        rb = (int)(w % (unsigned)nrb);
+        b = (int)(w / (unsigned)nrb);
+    }
+}
+
 inline FusionUnitDev unit_of(const vt_fusion_unit &u) {
     return FusionUnitDev{u.WK, u.WQ, u.WV, u.trans_conv, u.linear1_w, u.linear1_b, u.linear2_w, u.linear2_b, u.norm2_w, u.norm2_b};
 }

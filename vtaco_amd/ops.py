@@ -145,15 +145,31 @@ def decode_range_status(reset=True):
     return int(word.value)
 
 
-def decode_last_clock():
+def decode_last_clock(workgroups=False):
     """Clock evidence of the last lattice decode launch on the current device (vt_decode_last_clock): workgroup 0's lifetime in
-    shader cycles and in ticks of the constant-rate counter -> {"shader_mhz", "kernel_us", "shader_cycles"}.  Synchronises."""
-    cyc, ref, khz = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_int(0)
-    check(_lib.load().vt_decode_last_clock(ctypes.byref(cyc), ctypes.byref(ref), ctypes.byref(khz), stream_ptr()), "vt_decode_last_clock")
+    shader cycles and in ticks of the constant-rate counter -> {"shader_mhz", "wg0_us", "shader_cycles"}; with
+    ``workgroups=True`` also the launch's shape in time from every workgroup's (start, end) stamps: "span_us" (first start to
+    last end: the kernel's duration as the chip saw it), "start_spread_us" (the dispatch ramp), "wg_us_min/median/max" and
+    the raw stamps as "wg_ticks" ([n, 2] list, ticks of "ref_khz").  Synchronises."""
+    cyc, ref, khz, n = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_int(0), ctypes.c_int(0)
+    cap = 512 if workgroups else 0
+    buf = (ctypes.c_uint64 * (2 * cap))() if cap else None
+    check(_lib.load().vt_decode_last_clock(ctypes.byref(cyc), ctypes.byref(ref), ctypes.byref(khz), buf, cap, ctypes.byref(n),
+                                           stream_ptr()), "vt_decode_last_clock")
     if ref.value == 0 or khz.value <= 0:
         return None
-    us = ref.value / (khz.value * 1e-3)
-    return {"shader_mhz": cyc.value / us, "kernel_us": us, "shader_cycles": int(cyc.value), "ref_khz": int(khz.value)}
+    tick_us = 1e3 / khz.value
+    us = ref.value * tick_us
+    res = {"shader_mhz": cyc.value / us, "wg0_us": us, "shader_cycles": int(cyc.value), "ref_khz": int(khz.value)}
+    if workgroups and n.value > 0:
+        st = [(buf[2 * i], buf[2 * i + 1]) for i in range(n.value)]
+        t0 = min(a for a, _ in st)
+        dur = sorted((b - a) * tick_us for a, b in st)
+        res.update({"workgroups": n.value, "span_us": (max(b for _, b in st) - t0) * tick_us,
+                    "start_spread_us": (max(a for a, _ in st) - t0) * tick_us,
+                    "wg_us_min": dur[0], "wg_us_median": dur[len(dur) // 2], "wg_us_max": dur[-1],
+                    "wg_ticks": [[int(a - t0), int(b - t0)] for a, b in st]})
+    return res
 
 
 def is_channels_last_grid(grid):
