@@ -226,9 +226,10 @@ def test_the_generator_moves_f16f8_to_f16x3_when_its_own_contract_ends():
     from vtaco_amd.conv_onet.generation import Generator3D
     dev = torch.device(DEV)
     model, pc = _tampered_scene(dev, 3.0e3, 3e-4)
-    ref = Generator3D(model, device=dev, resolution0=16, padding=0.1, decode_precision="f16x3").generate_obj_mesh_wnf({"inputs": pc})
+    # (128^3: the fp8 form covers lattices of less than 0.55 voxels per step; at 64^3 it would run as 'f16x3' by itself)
+    ref = Generator3D(model, device=dev, resolution0=32, padding=0.1, decode_precision="f16x3").generate_obj_mesh_wnf({"inputs": pc})
     assert ops.decode_range_status(reset=True) == 0
-    gen = Generator3D(model, device=dev, resolution0=16, padding=0.1, decode_precision="f16f8")
+    gen = Generator3D(model, device=dev, resolution0=32, padding=0.1, decode_precision="f16f8")
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         mesh = gen.generate_obj_mesh_wnf({"inputs": pc})

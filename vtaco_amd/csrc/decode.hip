@@ -480,6 +480,9 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
         e.w1 = (e.i0 + 1 <= R - 1) ? f - f0 : 0.0f;
         tab[i] = e;
     }
+    // the workgroup's tile counter and the waves' end stamps: VT_TAIL_LDS_BYTES behind the images
+    unsigned *claim_ctr = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(lds + VT_BLOB_FLOATS + 4 * a.nx) + (ST2_THREADS / 64) * ST2_WAVE_BYTES);
+    if (threadIdx.x == 0) *claim_ctr = 0u;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -550,9 +553,21 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
     const auto ones = make_ones();
 
     unsigned rmax = 0;                                                   // range guard (decode_common.h)
-    uint32_t tile = t_begin + w_idx;
+    // tiles are claimed from an LDS counter, not pre-assigned: the two waves of a SIMD do not share it evenly (VALU issue is
+    // arbitrated by age), and with fixed shares the older wave finished early and left its partner to run alone -- see
+    // decode_st3.h.  The workgroup's set of tiles is the one the fixed assignment gave it.
+    const uint32_t wg_first = t_begin + w_idx - (uint32_t)wave;
+    auto claim = [&]() -> uint32_t {
+        unsigned i = 0;
+        if (lane == 0) i = __hip_atomic_fetch_add(claim_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        i = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
+        const uint32_t t = wg_first + (i % (unsigned)WPB) + (i / (unsigned)WPB) * w_cnt;
+        return i < 0x10000u ? t : t_end;
+    };
+    uint32_t tile = claim();
     if (tile < t_end) fetch(tile, ox, oy, oz);
-    for (; tile < t_end; tile += w_cnt) {
+    uint32_t next_tile = t_end;
+    for (; tile < t_end; tile = next_tile) {
         unsigned lds_off = 0;
         asm volatile("" : "+v"(lds_off));
         const float *L = lds + lds_off;
@@ -602,7 +617,8 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
         };
         const f32x16 cA = gather(ezA);
         const f32x16 cB = gather(ezB);
-        if (tile + w_cnt < t_end) fetch(tile + w_cnt, ox, oy, oz);
+        next_tile = claim();
+        if (next_tile < t_end) fetch(next_tile, ox, oy, oz);
 
         // ---- MLP on both column groups (mlp_and_heads<false, true>, visual-only, two chains) ----
         const f32x16 b0 = load_frag16(L + VT_OFF_BIAS + h * 16);
@@ -712,7 +728,7 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
         }
     }
     if constexpr (P == 2) range_report(rmax, a.status);
-    clock_end(a.clk, stamp);
+    clock_end(a.clk, stamp, reinterpret_cast<unsigned long long *>(claim_ctr + 4));
 }
 
 }  // namespace
@@ -1096,13 +1112,13 @@ int vt_grid_from_channels_last(const float *src, float *dst, int B, int C, int D
 // the slot-pipelined lattice kernels (decode_st3.h) cover: whole 2 x 4 x 8 double bricks (nx % 8 == 0, a slab of x-plane pairs),
 // less than 0.55 voxels per lattice step (the 3 x 4 x 6 footprint), blob + tables + eight images within the CU's 160 KiB
 static bool st3_covers(int nx, int R, double s_vox) {
-    const size_t lds = ((size_t)VT_BLOB_FLOATS + 5u * (size_t)nx) * sizeof(float) + (size_t)(ST3_THREADS / 64) * ST2_WAVE_BYTES;
+    const size_t lds = ((size_t)VT_BLOB_FLOATS + 5u * (size_t)nx) * sizeof(float) + (size_t)(ST3_THREADS / 64) * ST2_WAVE_BYTES + VT_TAIL_LDS_BYTES;
     return (nx & 7) == 0 && R >= 6 && s_vox > 0.0 && s_vox < 0.55 && lds <= 160u * 1024u;
 }
 static int st3_launch(const DecodeArgs &a_in, int variant, void *stream) {
     DecodeArgs a = a_in;
     a.clk = status_clk(a.status);
-    const size_t lds = ((size_t)VT_BLOB_FLOATS + 5u * (size_t)a.nx) * sizeof(float) + (size_t)(ST3_THREADS / 64) * ST2_WAVE_BYTES;
+    const size_t lds = ((size_t)VT_BLOB_FLOATS + 5u * (size_t)a.nx) * sizeof(float) + (size_t)(ST3_THREADS / 64) * ST2_WAVE_BYTES + VT_TAIL_LDS_BYTES;   // + the tile counter and the end stamps
     const int64_t nt = (int64_t)a.total / 64;
     int64_t blocks = (nt + ST3_THREADS / 64 - 1) / (ST3_THREADS / 64);
     if (blocks > vt_num_cus()) blocks = vt_num_cus();
@@ -1161,7 +1177,7 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
     if (a.brick && !force_direct && R >= 4 && lattice_nx <= 512 && !c_direct) {
         const double s_vox = (double)(R - 1) * (double)lattice_box / ((double)(lattice_nx - 1) * (double)a.divisor);
         const size_t lds_st = ((size_t)VT_BLOB_FLOATS + 4u * (size_t)lattice_nx + (size_t)(ST_THREADS / 64) * ST_WAVE_FLOATS) * sizeof(float);
-        const size_t lds_st2 = ((size_t)VT_BLOB_FLOATS + 4u * (size_t)lattice_nx) * sizeof(float) + (size_t)(ST2_THREADS / 64) * ST2_WAVE_BYTES;
+        const size_t lds_st2 = ((size_t)VT_BLOB_FLOATS + 4u * (size_t)lattice_nx) * sizeof(float) + (size_t)(ST2_THREADS / 64) * ST2_WAVE_BYTES + VT_TAIL_LDS_BYTES;
         static const bool no_pair = getenv("VTACO_DECODE_NO_PAIR") != nullptr;    // A/B knob
 #ifdef VT_DECODE_F16_TU
         if constexpr (P == 2) {

@@ -180,6 +180,7 @@ __device__ __forceinline__ void range_report(unsigned rmax, unsigned *status, bo
 // over ticks is the clock the chip held under this kernel's load (vt_decode_last_clock).  A few scalar reads per workgroup
 // and one 16-byte store: nothing measurable.
 constexpr int VT_CLK_MAX_WGS = 512;                  // (start, end) pairs kept per launch
+constexpr unsigned VT_TAIL_LDS_BYTES = 256;          // behind a lattice kernel's images: the tile counter (16 B) + the waves' end stamps
 struct ClockStamp {
     unsigned long long t0, r0;
 };
@@ -191,14 +192,21 @@ __device__ __forceinline__ ClockStamp clock_begin(const unsigned long long *clk)
     }
     return c;
 }
-__device__ __forceinline__ void clock_end(unsigned long long *clk, const ClockStamp &c) {
+// wave_ends: LDS scratch of (workgroup waves) 64-bit words nobody else uses any more.  Every wave leaves its own end there
+// and the workgroup meets at a barrier (finished waves wait instead of exiting: free), so the recorded end is the LAST wave's.
+__device__ __forceinline__ void clock_end(unsigned long long *clk, const ClockStamp &c, unsigned long long *wave_ends) {
     if (clk != nullptr) {
         const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-        if (blockIdx.x == 0) {
-            const unsigned long long dt = __builtin_readcyclecounter() - c.t0;
-            if (threadIdx.x == 0) { clk[0] = dt; clk[1] = r1 - c.r0; clk[2] = gridDim.x; }
+        const unsigned long long dt = blockIdx.x == 0 ? __builtin_readcyclecounter() - c.t0 : 0ull;
+        const int nwaves = (int)(blockDim.x >> 6);
+        if ((threadIdx.x & 63) == 0) wave_ends[threadIdx.x >> 6] = r1;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long last = r1;
+            for (int w = 1; w < nwaves; ++w) last = wave_ends[w] > last ? wave_ends[w] : last;
+            if (blockIdx.x == 0) { clk[0] = dt; clk[1] = r1 - c.r0; clk[2] = gridDim.x; }      // wave 0's own lifetime: the clock
+            if (blockIdx.x < VT_CLK_MAX_WGS) { clk[4 + 2 * blockIdx.x] = c.r0; clk[5 + 2 * blockIdx.x] = last; }
         }
-        if (threadIdx.x == 0 && blockIdx.x < VT_CLK_MAX_WGS) { clk[4 + 2 * blockIdx.x] = c.r0; clk[5 + 2 * blockIdx.x] = r1; }
     }
 }
 

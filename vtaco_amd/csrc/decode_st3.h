@@ -201,6 +201,8 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
         const _Float16 pm = (_Float16)(p - (float)ph);
         ptab[i] = (unsigned)__builtin_bit_cast(unsigned short, ph) | ((unsigned)__builtin_bit_cast(unsigned short, pm) << 16);
     }
+    if (threadIdx.x == 0)
+        *reinterpret_cast<unsigned *>(reinterpret_cast<char *>(lds + VT_BLOB_FLOATS + 5 * a.nx) + (ST3_THREADS / 64) * ST2_WAVE_BYTES) = 0u;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -213,6 +215,8 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
     const uint32_t tpb = a.N >> 6, q4 = nx >> 2, q8 = nx >> 3;
     const uint32_t plane0 = a.lattice_first / (nx * nx);
     char *stage = reinterpret_cast<char *>(lds + VT_BLOB_FLOATS + 5 * a.nx) + wave * ST2_WAVE_BYTES;
+    // the workgroup's tile counter (behind the images): waves CLAIM their tiles, see below
+    unsigned *claim_ctr = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(lds + VT_BLOB_FLOATS + 5 * a.nx) + WPB * ST2_WAVE_BYTES);
     // LDS byte address of the wave's image (M0 of the LDS-DMA pieces): the low half of the generic pointer
     const unsigned stage_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)reinterpret_cast<size_t>(stage));
     const unsigned stage_lds_last = (unsigned)__builtin_amdgcn_readfirstlane((int)(stage_lds + 1024u * ST3_PIECES));
@@ -299,9 +303,24 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
     unsigned rmax = 0;                                                   // range guard: largest sampled hi half of this wave
     [[maybe_unused]] float lmax = 0.0f;                                  // V = 2: largest |logit| this lane wrote (VT_RANGE_LOGIT)
 
-    uint32_t tile = t_begin + w_idx;
+    // Tiles are CLAIMED, not pre-assigned.  The two waves that share a SIMD do not share it evenly: VALU issue is arbitrated by
+    // age, so with a fixed 16 tiles each the older wave (0-3) was done after ~70 % of the launch and its partner ran the rest
+    // alone -- without the other wave's MFMAs to overlap its relu / split with (tools/diag_wg.py: workgroup 0's first wave
+    // 114 us of a 164 us launch).  The workgroup owns the same set of tiles as before (tile i of it = the i-th of the strided
+    // list below); a wave takes the next one from an LDS counter when it issues its prefetch, so the waves end within a tile of
+    // each other.  Which wave computes a tile changes nothing in its result.
+    const uint32_t wg_first = t_begin + w_idx - (uint32_t)wave;          // this workgroup's first tile
+    auto claim = [&]() -> uint32_t {
+        unsigned i = 0;
+        if (lane == 0) i = __hip_atomic_fetch_add(claim_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        i = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
+        const uint32_t t = wg_first + (i % (unsigned)WPB) + (i / (unsigned)WPB) * w_cnt;
+        return i < 0x10000u ? t : t_end;                                 // (the list is a few dozen tiles long)
+    };
+    uint32_t tile = claim();
     if (tile < t_end) fetch(tile, ox, oy, oz);
-    for (; tile < t_end; tile += w_cnt) {
+    uint32_t next_tile = t_end;
+    for (; tile < t_end; tile = next_tile) {
         unsigned lds_off = 0;
         asm volatile("" : "+v"(lds_off));                                // see decode_fwd_kernel
         const float *L = lds + lds_off;
@@ -359,7 +378,8 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
         const f32x16 cA = gather(ezA);
         const f32x16 cB = gather(ezB);
         // every read of the image has returned (the FMAs above consumed it): the next footprint may overwrite it
-        if (tile + w_cnt < t_end) fetch(tile + w_cnt, ox, oy, oz);
+        next_tile = claim();
+        if (next_tile < t_end) fetch(next_tile, ox, oy, oz);
 
         // ---- fc_p operands: the point's coordinates as half pairs from the per-axis table ----
         u32x4 pA, pB;
@@ -428,7 +448,7 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
     if constexpr (V == 2) {
         if (a.status != nullptr && lmax > VT_F16F8_LOGIT_LIMIT) atomicOr(a.status, VT_RANGE_LOGIT);
     }
-    clock_end(a.clk, stamp);
+    clock_end(a.clk, stamp, reinterpret_cast<unsigned long long *>(claim_ctr + 4));
 }
 
 #undef ST3_GAP
