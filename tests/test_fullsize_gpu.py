@@ -160,3 +160,43 @@ def test_attention_decoder_chunks_in_batches_equal_chunks_one_by_one():
             # the generic entry point (the reference's eval_points: arbitrary points, dense features, a CPU tensor back)
             ev = gen.eval_points(pts.cpu(), c, table[row].unsqueeze(0).cpu())
             assert ev.device.type == "cpu" and torch.equal(ev, one_by_one.cpu()), per_call
+
+
+def test_chunks_without_tactile_features_skip_the_fuser_bit_for_bit():
+    """fuse(0, c) = 0: a chunk no point of which carries a tactile feature needs no attention (InstanceNorm over a chunk whose
+    rows are all equal leaves exact zeros, twice -- Generator3D._eval_lattice_fused).  The 64^3 lattice with four fingertips
+    touches a minority of its 128 chunks; the logits with the shortcut are the logits of sending every chunk through the three
+    attention units, bit for bit, and the fuser itself returns exact zeros on an untouched chunk."""
+    from vtaco_amd import ops
+    from vtaco_amd.bench_util import randomise_fc1
+    from vtaco_amd.conv_onet.generation import Generator3D
+    from vtaco_amd.conv_onet.models import ConvolutionalOccupancyNetwork, decoder_dict
+    torch.manual_seed(0)
+    adec = decoder_dict['attention_local'](dim=3, c_dim=32, hidden_size=32).eval()
+    randomise_fc1(adec, 3)
+    g = torch.Generator().manual_seed(4)
+    nx, R, chunk = 64, 32, 2048
+    grid = torch.randn(1, 32, R, R, R, generator=g)
+    model = ConvolutionalOccupancyNetwork(adec, None, device=DEV)
+    gen = Generator3D(model, device=DEV, resolution0=nx // 4, padding=0.1, points_batch_size=chunk, with_img=True)
+    tips = torch.randn(5, 1, 3, generator=g)
+    setup = {'feats': torch.randn(5, 32, generator=g), 'anchors': 0.3 * tips / tips.norm(dim=-1, keepdim=True),
+             'success': torch.tensor([1, 0, 1, 1, 1], dtype=torch.uint8), 'mode': 'nearest', 'radius': 0.08,
+             'count': torch.ones(5, dtype=torch.int32)}
+    with torch.no_grad():
+        c = {"grid": ops.grid_to_channels_last(grid.to(DEV))}
+        assert gen.skip_untouched_chunks
+        fast = gen._eval_lattice_tactile(c, nx, setup)
+        gen.skip_untouched_chunks = False
+        dense = gen._eval_lattice_tactile(c, nx, setup)
+        ids = ops.tactile_assign(setup['anchors'].to(DEV), setup['success'].to(DEV), 'nearest', 0.08, lattice=(nx, 1.1, 0, nx ** 3))[0]
+        touched = (ids != 255).reshape(-1, chunk).any(dim=1)
+        print(f"{int(touched.sum())} of {touched.numel()} chunks carry tactile features")
+        assert 0 < int(touched.sum()) < touched.numel() // 2
+        assert torch.equal(fast, dense)
+        # the fuser on chunks without features: exact zeros for every chunk size the kernels distinguish (fp8-corrected tiles at
+        # N >= 512, half pairs below, a ragged size)
+        for n in (2048, 512, 256, 100):
+            feat = torch.randn(3, n, 32, generator=g).to(DEV)
+            z = adec.fuser(torch.zeros(3, n, 32, device=DEV), 1, feat, 1)
+            assert float(z.abs().max()) == 0.0, n

@@ -393,17 +393,50 @@ class Generator3D(object):
         # launches for a 128^3 lattice whose arithmetic takes 15
         full = count // chunk
         per_call = self._fused_chunks_per_call(chunk)
-        for lo in range(0, full, per_call):
-            nb = min(per_call, full - lo)
-            sl = slice(lo * chunk, (lo + nb) * chunk)
-            p = pts[sl].reshape(nb, chunk, 3)
-            feat = ops.sample_grid(grid, pts[sl].unsqueeze(0), dec.padding).reshape(nb, chunk, -1)
-            fused = dec.fuser(table[row[sl]].reshape(nb, chunk, -1), 1, feat, 1)
-            out[sl] = dec._mlp_fwd(fused, p).reshape(-1)
+        C = table.shape[1]
+        P3, R2, O2 = pts[:full * chunk].reshape(full, chunk, 3), row[:full * chunk].reshape(full, chunk), out[:full * chunk].view(full, chunk)
+
+        def fused_chunks(sel):
+            """The attention decoder on the chunks ``sel`` (a slice of consecutive chunks, or an index tensor)."""
+            p = P3[sel]
+            nb = p.shape[0]
+            feat = ops.sample_grid(grid, p.reshape(1, -1, 3), dec.padding).reshape(nb, chunk, -1)
+            fused = dec.fuser(table[R2[sel]], 1, feat, 1)
+            O2[sel] = dec._mlp_fwd(fused, p)
+
+        if full and self.skip_untouched_chunks:
+            # A chunk NO point of which carries a tactile feature (the fingers touch a few per cent of a scene's chunks) needs no
+            # attention at all: with c_img = 0 on the whole chunk the decoder's self-attention block returns the same vector for
+            # every point, InstanceNorm over the chunk turns that into zeros, the cross-attention of an all-zero query block is
+            # constant over the points again, and the last InstanceNorm leaves fuse(0, c) = 0 -- in exact arithmetic and, bit for
+            # bit, in these kernels (constant rows leave the norm as exact zeros: fusion.hip, fusion_inorm_relu*; asserted in
+            # tests/test_fusion_gpu.py; the reference's own f32 evaluation leaves rounding noise of ~1e-5 there, TransformerFusion.py
+            # :144, 209-218).  Such chunks go through the conditioned MLP with zero features; the others through the whole fuser.
+            touched = (R2 != finger_feats.shape[0]).any(dim=1)
+            t_idx, u_idx = torch.nonzero(touched).flatten(), torch.nonzero(~touched).flatten()      # one host read per lattice
+            for lo in range(0, u_idx.numel(), per_call):
+                sel = u_idx[lo:lo + per_call]
+                O2[sel] = dec._mlp_fwd(self._zero_features(sel.numel() * chunk, C).view(-1, chunk, C), P3[sel])
+            for lo in range(0, t_idx.numel(), per_call):
+                fused_chunks(t_idx[lo:lo + per_call])
+        else:
+            for lo in range(0, full, per_call):
+                fused_chunks(slice(lo, min(lo + per_call, full)))
         if full * chunk < count:                          # the ragged last chunk
             sl = slice(full * chunk, count)
             out[sl] = dec.forward_img(pts[sl].unsqueeze(0), c, table[row[sl]].unsqueeze(0))[0]
         return out
+
+    # attention_local over a lattice: chunks without any tactile feature skip the fuser (see _eval_lattice_fused; VTACO_FUSION_SKIP_UNTOUCHED=0
+    # or ``gen.skip_untouched_chunks = False`` sends every chunk through the three attention units)
+    skip_untouched_chunks = os.environ.get("VTACO_FUSION_SKIP_UNTOUCHED", "1") != "0"
+
+    def _zero_features(self, rows, C):
+        """[rows, C] zeros on the device, never written: the fused features of chunks without tactile input."""
+        z = self.__dict__.get("_zero_feat")
+        if z is None or z.shape[0] < rows or z.shape[1] != C or z.device != torch.device(self.device):
+            z = self._zero_feat = torch.zeros((rows, C), dtype=torch.float32, device=self.device)
+        return z[:rows]
 
     def generate_hand_mesh(self, data):
         """Hand mesh of one scene (generation.py:74-115): encoder_hand -> MANO vertices, then out of the MANO
