@@ -92,7 +92,7 @@ def _worker(rank, world, port, q):
         dist.all_gather(gathered, flat)
         ok_sync = all(torch.equal(gathered[0], t) for t in gathered[1:])
         if why:
-            sys.stderr.write(f"rank {rank}: {why}\n")
+            sys.stderr.write(f"rank {rank}: {why}; lattice precisions now {gen.decode_precision!r} / {gen_t.decode_precision!r}\n")
         q.put((rank, bool(ok_mesh), bool(ok_sync)))
     finally:
         dist.destroy_process_group()

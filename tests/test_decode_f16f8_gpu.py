@@ -239,8 +239,8 @@ def test_the_generator_moves_f16f8_to_f16x3_when_its_own_contract_ends():
 
 def test_default_precision_mesh_is_the_f32_paths_on_the_bench_scene():
     """north_star: vertex indices bit-exact.  The generator's default lattice precision ('f16x3', f32-level logits) must give the
-    SAME faces as the exact-f32 decode of the same scene at 128^3 (vertices within 1e-5: they interpolate logits that differ at
-    the 1e-6 level); the opt-in 'f16f8' is documented not to (a vertex appears or vanishes where a logit sits within ~3e-5 of
+    SAME faces as the exact-f32 decode of the same scene at 128^3 (vertices within 5e-5 = 0.6 % of a lattice cell: an edge vertex
+    sits at (level - v0) / (v1 - v0), which magnifies the 1e-6 difference of the logits where v1 - v0 is small; measured 1.3e-5); the opt-in 'f16f8' is documented not to (a vertex appears or vanishes where a logit sits within ~3e-5 of
     the iso-level): the test reports its counts beside the others and asserts nothing about them."""
     from vtaco_amd.bench_util import build_scene
     from vtaco_amd.conv_onet.generation import Generator3D
@@ -255,7 +255,7 @@ def test_default_precision_mesh_is_the_f32_paths_on_the_bench_scene():
     exact, dflt = meshes["f32"], meshes["f16x3"]
     assert Generator3D(sc["model"], device=dev).decode_precision == "f16x3"
     if dflt.faces.shape == exact.faces.shape and torch.equal(dflt.faces, exact.faces):
-        assert float((dflt.vertices - exact.vertices).abs().max()) <= 1e-5
+        assert float((dflt.vertices - exact.vertices).abs().max()) <= 5e-5
     else:
         # a noisy random-weight field has cells whose corner logit sits within 1e-6 of the level; say how many differ
         n = abs(dflt.vertices.shape[0] - exact.vertices.shape[0])

@@ -1,6 +1,9 @@
 """Secondary workloads of BASELINE.json (configs 3-5) on ONE MI355X; prints one JSON line each.
 Not the headline metric (bench.py is); numbers are quoted in DESIGN.md.
-  fusion : AttentionDecoder.forward_img (TransformerFusion) over the 128^3 lattice in chunks of 2048
+  fusion : AttentionDecoder.forward_img (TransformerFusion) over the 128^3 lattice in chunks of 2048, EVERY chunk through the three
+           attention units (the kernels' own number: what tools/pmc_fusion.sh profiles)
+  fusion_product : the same lattice through Generator3D (finger ids; chunks without tactile features skip the fuser), and with the
+           skip switched off
   img    : LocalDecoder.forward_img (tactile concat, the shipped VTacO config) 128^3
   train  : one training step fwd+bwd+Adam, 8 scenes x 2048 points per GPU (config 4's per-GPU share)
   dense256 : 256^3 decode + marching cubes (config 5 on one GPU)
@@ -15,7 +18,7 @@ from vtaco_amd.bench_util import build_scene, randomise_fc1, sphere_cloud
 from vtaco_amd.conv_onet.models import decoder_dict
 
 dev = torch.device("cuda:0")
-SECTIONS = set(sys.argv[1:]) or {"img", "fusion", "train", "dense256", "hand", "wide"}
+SECTIONS = set(sys.argv[1:]) or {"img", "fusion", "fusion_product", "train", "dense256", "hand", "wide"}
 # MIOpen only picks its fast f32 conv3d kernels for channels_last_3d tensors in find mode, and only if
 # the flag is set before the first convolution of the process (26 ms vs 382 ms fwd+bwd at B=2)
 torch.backends.cudnn.benchmark = True
@@ -96,8 +99,9 @@ if "fusion" in SECTIONS:
                                            "the kernels recompute every N x N score tile three times (row sums, column sums, attend) with "
                                            "split operands, so the matrix pipe executes several times the algorithmic FLOP: per-kernel time "
                                            "and counters in profiles/r03*_fusion_*"}}))
+if "fusion_product" in SECTIONS:
     # the same lattice through the product path: Generator3D (decoder: attention_local, points_batch_size 2048) assigning finger
-    # ids to the lattice and decoding it chunk by chunk (whole chunks batched per call)
+    # ids to the lattice and decoding it chunk by chunk (whole chunks batched per call; chunks no finger touches skip the fuser)
     from vtaco_amd.conv_onet.generation import Generator3D
     from vtaco_amd.conv_onet.models import ConvolutionalOccupancyNetwork
     agen = Generator3D(ConvolutionalOccupancyNetwork(adec, None, device=dev), device=dev, resolution0=nx // 4, padding=0.1,
@@ -109,9 +113,15 @@ if "fusion" in SECTIONS:
              'count': torch.ones(5, dtype=torch.int32)}
     cg = {"grid": grid}
     with torch.no_grad():
-        t = timed(lambda: agen._eval_lattice_tactile(cg, nx, setup), 3, 1)
-    print(json.dumps({"workload": "Generator3D._eval_lattice_tactile, decoder attention_local, 128^3, points_batch_size 2048 (finger ids + "
-                                  "batched chunks)", "ms": t * 1e3, "points_per_s": nx ** 3 / t}))
+        ids = ops.tactile_assign(setup['anchors'].to(dev), setup['success'].to(dev), 'nearest', 0.08, lattice=(nx, 1.1, 0, nx ** 3))
+        touched = int((ids[0] != 255).reshape(-1, N).any(dim=1).sum())
+        for skip in (True, False):
+            agen.skip_untouched_chunks = skip
+            t = timed(lambda: agen._eval_lattice_tactile(cg, nx, setup), 3, 1)
+            print(json.dumps({"workload": "Generator3D._eval_lattice_tactile, decoder attention_local, 128^3, points_batch_size 2048 (finger ids + "
+                                          "batched chunks; four fingertips, radius 0.08), " +
+                                          ("chunks without tactile features skip the fuser" if skip else "every chunk through the fuser"),
+                              "ms": t * 1e3, "points_per_s": nx ** 3 / t, "chunks": chunks, "chunks_with_tactile_features": touched}))
 
 # --- train: 8 scenes/GPU, N=2048, fwd+bwd+Adam through encoder (PointNet + UNet3D host path) and decoder
 B = 8

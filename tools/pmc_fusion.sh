@@ -2,7 +2,7 @@
 # --pmc passes (no trace domain besides --kernel-trace) over `tools/bench_extra.py fusion` = AttentionDecoder.forward_img over the
 # 128^3 lattice in 1024 chunks of N = 2048 (256 chunks per call).  Usage (GPU box): TAG=r03 bash tools/pmc_fusion.sh
 cd /tmp && export TMPDIR=/tmp
-R=/root/repo; TAG=${TAG:-r03}; O=$R/gpurun_out/prof_fusion_$TAG; mkdir -p $O
+R=/root/repo; TAG=${TAG:-r04}; O=$R/gpurun_out/prof_fusion_$TAG; mkdir -p $O
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o fusion -- python3 $R/tools/bench_extra.py fusion > $O/bench_extra_under_profiler.jsonl 2> $O/stats.err; echo "stats rc=$?"
 find $O/stats -name '*kernel_trace*' -delete 2>/dev/null
 echo "kernel,counter,launches,mean_per_launch" > $O/pmc_summary.csv
