@@ -176,7 +176,7 @@ int vt_decode_last_clock(unsigned long long *shader_cycles, unsigned long long *
 /* 71-103, 105-133) for hidden_size and c_dim any multiples of 32 up to 256 (the class defaults are      */
 /* 256 / 128, decoder.py:24), n_blocks <= VT_MAX_BLOCKS, and `leaky`: leaky_relu(0.2) in front of the       */
 /* output heads (decoder.py:46-49, 157; the ResnetBlockFC activations are ReLU regardless, layers.py:33).    */
-/* Exact f32 (v_mfma_f32_32x32x2_f32), inference only.  The weights stream from L2 in the fragment order      */
+/* Exact f32 (v_mfma_f32_32x32x2_f32); training: below.  The weights stream from L2 in the fragment order      */
 /* vt_decoder_pack_wide writes (params_host->hidden / c_dim / n_blocks / p_in describe the shape; p_in = 3,    */
 /* or 3 + c_dim for forward_img); blob_bytes from vt_decoder_wide_blob_bytes (0: shape not covered).           */
 /* vt_decode_fwd_wide: the arguments of vt_decode_fwd (pts or lattice, optional c_img [B,N,c_dim], out2 for     */
@@ -191,6 +191,32 @@ int vt_decode_fwd_wide(const float *grid_cl, int B, int R, int C, const float *p
                        int lattice_nx, float lattice_box, int64_t lattice_first,
                        const float *c_img, const float *blob_wide, int hidden, int n_blocks, int flags, double padding,
                        float *out, float *out2, void *stream);
+
+/* The same shapes under autograd (the reference trains them through torch autograd: decoder.py:24-51,     */
+/* 135-161 called from training.py:476-489, 734-740, 879).                                                   */
+/*   vt_decode_fwd_wide_train  vt_decode_fwd_wide on query points that also keeps, point-major, the inputs     */
+/*                       of every layer: save = vt_decode_wide_save_floats floats laid out as                    */
+/*                       c [P][c_dim] | per block relu(net + fc_c(c)) [P][H], relu(fc_0(.)) [P][H] | actvn(net) [P][H]. */
+/*   vt_decoder_pack_wide_t    the transposed weight fragments the backward streams (W1^T, W0^T, Wc^T per block,    */
+/*                       fc_p_img's c_img columns transposed, the two head vectors).                               */
+/*   vt_decode_bwd_wide  grad_out [P] (and grad_out2 for the contact head, or NULL) -> d grid (channels-last, f32     */
+/*                       atomics into a ZEROED buffer; NULL: not wanted), d c_img [P][c_dim] (NULL: not wanted), and  */
+/*                       gws = vt_decode_wide_gws_floats floats: dN_i [P][H] for i = 0..n_blocks (gradient of the     */
+/*                       residual stream in front of block i; dN_nb: behind the last block) then dH_i [P][H]          */
+/*                       (gradient of fc_0_i's output).  The weight gradients are vt_rows_wgrad over these rows:       */
+/*                       fc_p <- (dN_0, [p | c_img]); fc_c_i <- (dN_i, c); fc_0_i <- (dH_i, save a0_i);                */
+/*                       fc_1_i <- (dN_{i+1}, save a1_i); fc_out <- (grad_out, save actvn(net)).  No gradient with     */
+/*                       respect to the query points (the reference never reads it: SURVEY.md 8a row A14).             */
+size_t vt_decode_wide_save_floats(int64_t total_points, int hidden, int c_dim, int n_blocks);
+size_t vt_decode_wide_gws_floats(int64_t total_points, int hidden, int c_dim, int n_blocks);
+int vt_decode_fwd_wide_train(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                             const float *c_img, const float *blob_wide, int hidden, int n_blocks, int flags, double padding,
+                             float *out, float *out2, float *save, void *stream);
+size_t vt_decoder_wide_blob_t_bytes(int hidden, int c_dim, int n_blocks);
+int vt_decoder_pack_wide_t(const vt_decoder_params *params_host, float *blob_t, size_t blob_bytes, void *stream);
+int vt_decode_bwd_wide(int B, int R, int C, const float *pts, int64_t N, const float *blob_wide_t, int hidden, int n_blocks, int flags,
+                       double padding, const float *grad_out, const float *grad_out2, const float *save, float *gws,
+                       float *grad_grid_cl, float *grad_c_img, void *stream);
 
 /* Tactile feature assignment and decode by finger id (SURVEY.md section 8f "next" row 2).        */
 /* Replaces: the scipy cdist + np.where glue that fills the dense c_img_all [1,N,32] at            */

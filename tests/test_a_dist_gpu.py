@@ -76,7 +76,17 @@ def _worker(rank, world, port, q):
         plain_t = gen_t.generate_obj_mesh_wnf(data_t)
         np.random.seed(7 if rank == 0 else 99)
         shard_t = gen_t.generate_obj_mesh_sharded(data_t)
-        ok_t = torch.equal(plain_t.faces, shard_t.faces) and torch.equal(plain_t.vertices, shard_t.vertices)
+        # rank 0's clouds AND tactile features are broadcast: the sharded mesh is rank 0's single-process mesh bit for bit.  Another
+        # rank's own single-process mesh may differ in the last bits (its features come out of MIOpen convolutions whose algorithm
+        # is chosen per process by timing): there the comparison allows 1e-5 on the vertices
+        if rank == 0:
+            ok_t = torch.equal(plain_t.faces, shard_t.faces) and torch.equal(plain_t.vertices, shard_t.vertices)
+        else:
+            ok_t = (plain_t.faces.shape == shard_t.faces.shape and plain_t.vertices.shape == shard_t.vertices.shape
+                    and float((plain_t.vertices - shard_t.vertices).abs().max()) <= 1e-5)
+        meshes = [None, None]
+        dist.all_gather_object(meshes, (shard_t.vertices.cpu(), shard_t.faces.cpu()))
+        ok_t = ok_t and torch.equal(meshes[0][0], meshes[1][0]) and torch.equal(meshes[0][1], meshes[1][1])   # every rank holds the SAME mesh
         if not ok_t:
             why.append(f"tactile: sharded != plain ({plain_t.vertices.shape[0]} vs {shard_t.vertices.shape[0]} vertices)")
         ok_mesh = ok_mesh and ok_t

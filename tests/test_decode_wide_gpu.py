@@ -110,35 +110,73 @@ def test_wide_decoder_finger_ids_and_errors():
         AttentionDecoder(c_dim=64, hidden_size=64)
 
 
-def test_wide_decoder_under_autograd_runs_the_reference_arithmetic_on_the_device():
-    """At shapes beyond 32 / 32 the library has a forward kernel and no backward: under autograd LocalDecoder evaluates the
-    reference's operators through PyTorch-ROCm on the device (`_host_forward`).  Its logits equal the HIP kernel's, and its
-    gradients the oracle's autograd (CPU, float64 accumulation aside): a wide decoder trains."""
+def _forbid_framework_ops(monkeypatch):
+    """LocalDecoder must not reach F.grid_sample / F.linear on any path: make them raise for the duration of a test."""
+    import torch.nn.functional as F
+
+    def boom(*a, **k):
+        raise AssertionError("a framework operator was reached from LocalDecoder")
+    monkeypatch.setattr(F, "grid_sample", boom)
+    monkeypatch.setattr(F, "linear", boom)
+
+
+@pytest.mark.parametrize("hidden,c_dim,nb,leaky,mode,npts", [(96, 64, 2, True, "bilinear", 200), (256, 128, 3, False, "bilinear", 333),
+                                                              (32, 160, 2, True, "bilinear", 65), (64, 32, 2, False, "nearest", 100)])
+def test_wide_decoder_trains_on_hip_kernels(hidden, c_dim, nb, leaky, mode, npts, monkeypatch):
+    """Shapes beyond 32 / 32 under autograd (the reference trains its class defaults 256 / 128 through torch autograd,
+    decoder.py:24-51, 135-161): forward vt_decode_fwd_wide_train, backward vt_decode_bwd_wide + vt_rows_wgrad -- no framework
+    operator (F.grid_sample / F.linear raise while the test runs).  Logits equal the inference kernel's; the gradients of the
+    grid, of c_img and of every parameter equal the oracle's autograd (torch CPU) to 1e-4 of their scale: forward_img, forward
+    and forward_contact."""
     from oracle import vtaco_oracle as orc
-    hidden, c_dim, nb = 96, 64, 2
-    dec = _decoder(hidden, c_dim, nb, True, seed=11)
+    _forbid_framework_ops(monkeypatch)
+    dec = _decoder(hidden, c_dim, nb, leaky, seed=11, mode=mode)
     g = torch.Generator().manual_seed(12)
     grid = torch.randn(2, c_dim, 8, 8, 8, generator=g)
-    p = (torch.rand(2, 200, 3, generator=g) - 0.5) * 1.2
-    c_img = torch.randn(2, 200, c_dim, generator=g)
-    gd = grid.to(DEV).requires_grad_(True)
-    out = dec.forward_img(p.to(DEV), {"grid": gd}, c_img.to(DEV))
-    assert out.requires_grad
+    p = (torch.rand(2, npts, 3, generator=g) - 0.5) * 1.2
+    c_img = torch.randn(2, npts, c_dim, generator=g)
+    sd0 = {k: v.detach().cpu().clone() for k, v in dec.state_dict().items()}
+
+    def check(tag, run_hip, run_ref, with_cimg):
+        dec.zero_grad(set_to_none=True)
+        gd = grid.to(DEV).requires_grad_(True)
+        cd = c_img.to(DEV).requires_grad_(True) if with_cimg else None
+        outs = run_hip(gd, cd)
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        assert all(o.requires_grad for o in outs)
+        loss = sum((k + 1) * o.square().sum() for k, o in enumerate(outs))
+        loss.backward()
+        with monkeypatch.context() as m:                              # the oracle is torch CPU: it may use its operators
+            m.undo()
+            sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+            gc = grid.clone().requires_grad_(True)
+            cc = c_img.clone().requires_grad_(True) if with_cimg else None
+            refs = run_ref(sd, gc, cc)
+            refs = refs if isinstance(refs, tuple) else (refs,)
+            sum((k + 1) * r.square().sum() for k, r in enumerate(refs)).backward()
+        for o, r in zip(outs, refs):
+            assert _err(o.detach(), r.detach()) <= 2e-5 * max(1.0, float(r.abs().max())), tag
+        assert _err(gd.grad, gc.grad) <= 1e-4 * float(gc.grad.abs().max()), tag
+        if with_cimg:
+            assert _err(cd.grad, cc.grad) <= 1e-4 * float(cc.grad.abs().max()), tag
+        seen = 0
+        for name, prm in dec.named_parameters():
+            if sd[name].grad is None:
+                assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, (tag, name)
+                continue
+            seen += 1
+            assert prm.grad is not None, (tag, name)
+            assert _err(prm.grad, sd[name].grad) <= 1e-4 * max(1.0, float(sd[name].grad.abs().max())), (tag, name)
+        assert seen >= 4 + 6 * nb
+        return outs
+
+    pd = p.to(DEV)
+    out = check("forward_img", lambda gd, cd: dec.forward_img(pd, {"grid": gd}, cd),
+                lambda sd, gc, cc: orc.local_decoder_forward_img(sd, p, gc, cc, leaky=leaky, sample_mode=mode), True)[0]
     with torch.no_grad():
-        fast = dec.forward_img(p.to(DEV), {"grid": gd.detach()}, c_img.to(DEV))
-    assert _err(out.detach(), fast.cpu()) <= 1e-5
-    out.square().sum().backward()
-    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
-    gc = grid.clone().requires_grad_(True)
-    ref = orc.local_decoder_forward_img(sd, p, gc, c_img, leaky=True)
-    ref.square().sum().backward()
-    scale = float(gc.grad.abs().max())
-    assert _err(gd.grad, gc.grad) <= 1e-4 * scale
-    for name, prm in dec.named_parameters():
-        if sd[name].grad is None:
-            continue
-        assert _err(prm.grad, sd[name].grad) <= 1e-4 * max(1.0, float(sd[name].grad.abs().max())), name
-    # forward_contact and forward under autograd as well
-    o, oc = dec.forward_contact(p.to(DEV), {"grid": gd})
-    r, rc = orc.local_decoder_forward_contact({k: v.detach() for k, v in sd.items()}, p, grid, leaky=True)
-    assert _err(o.detach(), r) <= 1e-5 and _err(oc.detach(), rc) <= 1e-5
+        fast = dec.forward_img(pd, {"grid": grid.to(DEV)}, c_img.to(DEV))
+    assert torch.equal(out.detach(), fast)                            # the training forward IS the inference kernel plus stores
+    check("forward", lambda gd, cd: dec(pd, {"grid": gd}),
+          lambda sd, gc, cc: orc.local_decoder_forward(sd, p, gc, leaky=leaky, sample_mode=mode), False)
+    check("forward_contact", lambda gd, cd: dec.forward_contact(pd, {"grid": gd}),
+          lambda sd, gc, cc: orc.local_decoder_forward_contact(sd, p, gc, leaky=leaky, sample_mode=mode), False)

@@ -314,10 +314,14 @@ class Generator3D(object):
         with torch.no_grad():
             if self.with_img:
                 # the tactile branches (VTacOH fingertips / VTacO contact clouds): every rank assigns finger ids to ITS slab and
-                # decodes by id; the VTacO clouds are drawn with numpy's generator, so rank 0's go to everybody (a few KB)
+                # decodes by id; the VTacO clouds are drawn with numpy's generator, so rank 0's go to everybody (a few KB) -- and so
+                # do rank 0's tactile FEATURES (F x C floats): they come out of the host framework's convolutions (MIOpen), whose
+                # algorithm choice is made per process by timing, so two ranks may hold features that differ in the last bits and
+                # the slabs of one value grid would not belong to one function
                 setup = self._tactile_setup(data)
                 if vdist.dist.is_initialized() and vdist.dist.get_world_size(group) > 1:
-                    for key in ('anchors', 'count', 'success'):
+                    setup['feats'] = setup['feats'].float().contiguous()
+                    for key in ('anchors', 'count', 'success', 'feats'):
                         t = setup[key].to(self.device)
                         vdist.dist.broadcast(t, src=vdist.dist.get_global_rank(group, 0) if group is not None else 0, group=group)
                         setup[key] = t

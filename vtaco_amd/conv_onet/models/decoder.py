@@ -12,11 +12,9 @@ import os
 
 import torch
 from torch import nn
-from torch.nn import functional as F
 
 from ... import ops
 from ..._lib import VtError
-from ...common import normalize_3d_coordinate
 from ...layers import ResnetBlockFC
 from ...transformer_fusion import TransformerFusion
 
@@ -74,6 +72,41 @@ class _DecodeContactFn(torch.autograd.Function):
         return (None, None, ggrid, *grads, g["fc_out_contact.weight"], g["fc_out_contact.bias"])
 
 
+class _DecodeWideFn(torch.autograd.Function):
+    """The decoder at the shapes beyond 32 / 32 (hidden_size / c_dim multiples of 32 up to 256, `leaky`, 'nearest'), differentiable:
+    forward = vt_decode_fwd_wide_train (keeps every layer's input), backward = vt_decode_bwd_wide (data gradients on transposed
+    weight fragments, the grid gradient by atomics) + vt_rows_wgrad per layer.  Gradients to the feature grid, c_img and every
+    parameter; with ``contact`` both heads (forward_contact)."""
+
+    @staticmethod
+    def forward(ctx, dec, p, grid, c_img, contact, *params):
+        img = c_img is not None
+        nearest = dec.sample_mode == 'nearest'
+        out, out2, save = ops.decode_fwd_wide_train(grid, dec._blob(img=img, contact=contact), p, c_img, dec.hidden_size, dec.n_blocks,
+                                                    dec.leaky, nearest, dec.padding, want_contact=contact)
+        ctx.dec, ctx.img, ctx.contact, ctx.save, ctx.grid_shape = dec, img, contact, save, tuple(grid.shape)
+        ctx.p, ctx.c_img = p.detach(), (c_img.detach() if img else None)
+        ctx.need_grid = grid.requires_grad
+        ctx.need_img = img and c_img.requires_grad
+        return (out, out2) if contact else out
+
+    @staticmethod
+    def backward(ctx, grad_out, grad_out2=None):
+        dec, img = ctx.dec, ctx.img
+        first = dec.fc_p_img if img else dec.fc_p
+        blob_t = ops.pack_decoder_wide_t(first.weight, [l.weight for l in dec.fc_c], [(b.fc_0.weight, b.fc_1.weight) for b in dec.blocks],
+                                         dec.fc_out.weight, dec.fc_out_contact.weight if ctx.contact else None)
+        if ctx.contact and grad_out2 is None:
+            grad_out2 = torch.zeros_like(grad_out)
+        ggrid, gimg, g = ops.decode_bwd_wide(ctx.grid_shape, blob_t, grad_out, ctx.save, ctx.p, dec.hidden_size, dec.n_blocks, dec.leaky,
+                                             dec.sample_mode == 'nearest', dec.padding, c_img=ctx.c_img, want_grid_grad=ctx.need_grid,
+                                             grad_out2=grad_out2 if ctx.contact else None)
+        grads = [g[key] if idx is None else g[key][idx] for key, idx in dec._param_order(img)]
+        if ctx.contact:
+            grads += [g["fc_out_contact.weight"], g["fc_out_contact.bias"]]
+        return (None, None, ggrid, gimg if ctx.need_img else None, None, *grads)
+
+
 class _SampleGridFn(torch.autograd.Function):
     """Trilinear sampling alone (vt_sample_grid / vt_sample_grid_bwd), differentiable in the grid."""
 
@@ -125,9 +158,9 @@ class LocalDecoder(nn.Module):
         self.c_dim, self.n_blocks, self.hidden_size = c_dim, n_blocks, hidden_size
         # `leaky`: leaky_relu(0.2) in front of the output heads (reference decoder.py:46-49, 157; the blocks stay ReLU).  The shipped
         # shape (32 / 32, relu) runs on the LDS-resident kernels of decode.hip, training included; every other shape -- hidden_size
-        # and c_dim multiples of 32 up to 256, e.g. the class defaults 256 / 128 -- on vt_decode_fwd_wide (exact f32) without
-        # autograd, and under autograd through PyTorch-ROCm's own operators (_host_forward: grid_sample + rocBLAS linears; no
-        # kernel of this library -- the HIP backward exists for the shipped shape)
+        # and c_dim multiples of 32 up to 256, e.g. the class defaults 256 / 128 -- on the weight-streaming kernels of
+        # decode_wide.hip (exact f32): vt_decode_fwd_wide, and under autograd vt_decode_fwd_wide_train / vt_decode_bwd_wide /
+        # vt_rows_wgrad (_DecodeWideFn)
         self.leaky = bool(leaky)
         self._wide = self.leaky or hidden_size != 32 or c_dim != 32 or sample_mode == 'nearest'
         self.sample_mode, self.padding = sample_mode, padding
@@ -198,21 +231,14 @@ class LocalDecoder(nn.Module):
         return grid.requires_grad or (c_img is not None and c_img.requires_grad) or any(
             p.requires_grad for p in self.parameters())
 
-    def _host_forward(self, p, grid, c_img=None, contact=False):
-        """The reference's arithmetic in PyTorch-ROCm operators on the device (decoder.py:62-68, 71-161): what runs UNDER AUTOGRAD at
-        the shapes beyond 32 / 32 (`_wide`), where this library has a forward kernel but no backward.  Not a CPU path and not used by
-        inference."""
+    def _wide_train(self, p, grid, c_img=None, contact=False):
+        """The wide shapes under autograd: _DecodeWideFn (HIP forward and backward)."""
         if not grid.is_cuda:
             raise VtError(f"LocalDecoder: inputs must live on a HIP device (got {grid.device})")
-        vgrid = 2.0 * normalize_3d_coordinate(p.float(), padding=self.padding)[:, :, None, None] - 1.0
-        c = F.grid_sample(grid, vgrid, padding_mode='border', align_corners=True, mode=self.sample_mode).squeeze(-1).squeeze(-1).transpose(1, 2)
-        net = self.fc_p(p.float()) if c_img is None else self.fc_p_img(torch.cat((p.float(), c_img), dim=2))
-        for lin, blk in zip(self.fc_c, self.blocks):
-            net = net + lin(c)
-            net = net + blk.fc_1(F.relu(blk.fc_0(F.relu(net))))
-        a = F.leaky_relu(net, 0.2) if self.leaky else F.relu(net)
-        out = self.fc_out(a).squeeze(-1)
-        return (out, self.fc_out_contact(a).squeeze(-1)) if contact else out
+        params = self._params(c_img is not None)
+        if contact:
+            params = params + [self.fc_out_contact.weight, self.fc_out_contact.bias]
+        return _DecodeWideFn.apply(self, p.float(), grid, None if c_img is None else c_img.float(), contact, *params)
 
     def _wide_fwd(self, grid, **kw):
         return ops.decode_fwd(grid, self._blob(img=kw.get("c_img") is not None, contact=kw.get("want_contact", False)),
@@ -231,7 +257,7 @@ class LocalDecoder(nn.Module):
         """logits [B,N] for points p [B,N,3] (decoder.py:135-161)."""
         grid = self._grid_of(c_plane)
         if self._wants_grad(grid):
-            return self._host_forward(p, grid) if self._wide else _DecodeFn.apply(self, p, grid, None, *self._params(False))
+            return self._wide_train(p, grid) if self._wide else _DecodeFn.apply(self, p, grid, None, *self._params(False))
         if self._wide:
             return self._wide_fwd(grid, pts=p)
         prec = self._point_precision()
@@ -241,7 +267,7 @@ class LocalDecoder(nn.Module):
         """Tactile concat variant (decoder.py:71-103): fc_p_img([p; c_img])."""
         grid = self._grid_of(c_plane)
         if self._wants_grad(grid, c_img):
-            return self._host_forward(p, grid, c_img) if self._wide else _DecodeFn.apply(self, p, grid, c_img, *self._params(True))
+            return self._wide_train(p, grid, c_img) if self._wide else _DecodeFn.apply(self, p, grid, c_img, *self._params(True))
         if self._wide:
             return self._wide_fwd(grid, pts=p, c_img=c_img.float())
         prec = self._point_precision()
@@ -251,7 +277,7 @@ class LocalDecoder(nn.Module):
         """(occupancy logits, contact logits) (decoder.py:105-133)."""
         grid = self._grid_of(c_plane)
         if self._wants_grad(grid) and self._wide:
-            return self._host_forward(p, grid, contact=True)
+            return self._wide_train(p, grid, contact=True)
         if self._wants_grad(grid):
             # training with the contact head: the fused decode kernel with both heads and its HIP backward
             return _DecodeContactFn.apply(self, p.float(), grid, *self._params(False),

@@ -1,8 +1,11 @@
 // LocalDecoder.forward / forward_img for the shapes the shipped kernels (decode.hip: hidden = c_dim = 32, relu) do not cover:
 // hidden_size and c_dim any multiples of 32 up to 256 (the class defaults of the reference are 256 / 128,
 // src/conv_onet/models/decoder.py:24-51), n_blocks up to VT_MAX_BLOCKS, and `leaky`: leaky_relu(0.2) in front of the output heads
-// (decoder.py:46-49, 157; the ResnetBlockFC activations are ReLU whatever `leaky` says, layers.py:33).  Inference
-// only, exact f32: v_mfma_f32_32x32x2_f32 with f32 operands, so the result is the f32 network's up to summation order.
+// (decoder.py:46-49, 157; the ResnetBlockFC activations are ReLU whatever `leaky` says, layers.py:33).  Exact f32:
+// v_mfma_f32_32x32x2_f32 with f32 operands, so the result is the f32 network's up to summation order.  Inference
+// (vt_decode_fwd_wide) and training: vt_decode_fwd_wide_train saves the layer inputs point-major, vt_decode_bwd_wide walks the
+// network back on transposed weight fragments (same streaming scheme) and leaves the per-layer output gradients for the weight
+// gradients, which are vt_rows_wgrad's tall-skinny products over those two sets of rows (pointnet.hip).
 //
 // A workgroup of eight waves owns 32 query points.  The weights do not fit LDS at these widths (256/128/5: 3.3 MB), so they stream
 // from L2 in fragment order (one coalesced 16-byte load per lane = four k-steps of one 32-row block) and the ACTIVATIONS live in
@@ -28,7 +31,38 @@ struct WideArgs {
     int H, C, nb, Kp, p_in;     // hidden, c_dim, blocks, fc_p's K padded to a multiple of 8
     int leaky;
     int nearest;                // sample_mode 'nearest': the voxel at the rounded coordinate instead of the trilinear blend
+    float *save;                // training forward: the layer inputs, point-major (wide_save_layout), or null
 };
+
+// what the training forward keeps for the backward, point-major rows (the X operands of the weight gradients):
+//   c [P][C] | per block i: a0_i = relu(net + fc_c_i(c)) [P][H], a1_i = relu(fc_0_i(a0_i)) [P][H] | af = actvn(net_final) [P][H]
+struct WideSave { size_t c, blk, af, total; };
+__host__ __device__ inline WideSave wide_save_layout(size_t P, int H, int C, int nb) {
+    WideSave l;
+    l.c = 0; l.blk = P * C; l.af = l.blk + (size_t)nb * 2 * P * H; l.total = l.af + P * H;
+    return l;
+}
+// output-side gradients vt_decode_bwd_wide leaves for the weight gradients, point-major:
+//   DN_i [P][H], i = 0 .. nb: gradient of the residual stream in front of block i (DN_nb: behind the last block)
+//   DH_i [P][H], i = 0 .. nb - 1: gradient of fc_0_i's output
+struct WideGws { size_t dn, dh, total; };
+__host__ __device__ inline WideGws wide_gws_layout(size_t P, int H, int nb) {
+    WideGws l;
+    l.dn = 0; l.dh = (size_t)(nb + 1) * P * H; l.total = l.dh + (size_t)nb * P * H;
+    return l;
+}
+// transposed-weight blob of the backward: per block W1^T [H][H], W0^T [H][H], Wc^T [C][H] as fragments; then fc_p_img's
+// c_img columns transposed [C][H] (zeros for a decoder without tactile concat); then fc_out.w [H], fc_out_contact.w [H]
+struct WideLayoutT { size_t w_blk, w_1, w_0, w_c, w_pc, heads, total; };
+__host__ __device__ inline WideLayoutT wide_layout_t(int H, int C, int nb) {
+    WideLayoutT l;
+    l.w_1 = (size_t)H * H; l.w_0 = (size_t)H * H; l.w_c = (size_t)C * H;
+    l.w_blk = 0;
+    l.w_pc = (size_t)nb * (l.w_1 + l.w_0 + l.w_c);
+    l.heads = l.w_pc + (size_t)C * H;
+    l.total = l.heads + 2 * (size_t)H + 4;
+    return l;
+}
 
 // blob layout, in floats (host and device agree through these)
 struct WideLayout {
@@ -47,14 +81,15 @@ __host__ __device__ inline WideLayout wide_layout(int H, int C, int nb, int Kp) 
 
 // W [H][K] (row stride `ld`, columns >= `kin` read as zero) -> fragments [H/32][K/8][64 lanes][4]: lane (row r = l & 31, kg = l >> 5),
 // element e = W[32 ob + r][8 kq + 2 e + kg] -- the A operands of four consecutive 32x32x2 k-steps
-__global__ void wide_pack_kernel(const float *w, int H, int K, int kin, int ld, float *dst) {
+// (rs, ks): strides of the source in rows and columns -- (ld, 1) for W itself, (1, ld) for its transpose
+__global__ void wide_pack_kernel(const float *w, int H, int K, int kin, size_t rs, size_t ks, float *dst) {
     const size_t total = (size_t)H * K;
     for (size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (size_t)gridDim.x * blockDim.x) {
         const int e = (int)(f & 3), l = (int)((f >> 2) & 63);
         const size_t q = f >> 8;
         const int kq = (int)(q % (K / 8)), ob = (int)(q / (K / 8));
         const int row = 32 * ob + (l & 31), k = 8 * kq + 2 * e + (l >> 5);
-        dst[f] = k < kin ? w[(size_t)row * ld + k] : 0.0f;
+        dst[f] = (w && k < kin) ? w[(size_t)row * rs + (size_t)k * ks] : 0.0f;
     }
 }
 __global__ void wide_copy_kernel(const float *src, float *dst, int n) {
@@ -119,7 +154,12 @@ decode_wide_kernel(WideArgs a) {
                 const size_t near = a.nearest ? (((size_t)__builtin_rintf(grid_coord(pz, d.divisor, d.R)) * d.R + (size_t)__builtin_rintf(grid_coord(py, d.divisor, d.R))) * d.R +
                                                  (size_t)__builtin_rintf(grid_coord(px, d.divisor, d.R))) * C : 0;
                 for (int cb = 0; cb < C; cb += 32) {
-                    if (a.nearest) { cl[(cb + ch) * WIDE_PITCH + pt] = gb[near + cb + ch]; continue; }
+                    if (a.nearest) {
+                        const float v = gb[near + cb + ch];
+                        cl[(cb + ch) * WIDE_PITCH + pt] = v;
+                        if (a.save && tile * WIDE_PTS + pt < d.total) a.save[(size_t)g * C + cb + ch] = v;
+                        continue;
+                    }
                     float acc = 0.0f;
 #pragma unroll
                     for (int dz = 0; dz < 2; ++dz) {
@@ -135,6 +175,7 @@ decode_wide_kernel(WideArgs a) {
                         }
                     }
                     cl[(cb + ch) * WIDE_PITCH + pt] = acc;
+                    if (a.save && tile * WIDE_PTS + pt < d.total) a.save[(size_t)g * C + cb + ch] = acc;
                 }
                 if (ch < 3) bufA[ch * WIDE_PITCH + pt] = ch == 0 ? px : (ch == 1 ? py : pz);
                 for (int k = 3 + ch; k < Kp; k += 32)
@@ -145,6 +186,10 @@ decode_wide_kernel(WideArgs a) {
         // ---- fc_p (decoder.py:139 / 81) ----
         f32x16 net;
         const int ob = wave;                                        // nh <= WIDE_WAVES; waves beyond the width only keep the barriers
+        // training forward: this lane's point row in the point-major save slots
+        const uint32_t gj = tile * WIDE_PTS + (uint32_t)j;
+        const bool keep = a.save != nullptr && gj < d.total && ob < nh;
+        const WideSave sv = wide_save_layout(d.total, H, C, a.nb);
         if (ob < nh) net = wide_gemm(bias16(bias, ob, kg), a.blob + lay.w_p, ob, Kp, bufA, lane);
         __syncthreads();                                            // bufA is free again
         // ---- n_blocks x (fc_c add, ResnetBlockFC: layers.py:41-50; its activations are ReLU) ----
@@ -158,12 +203,14 @@ decode_wide_kernel(WideArgs a) {
                 net = wide_gemm(net, wb, ob, C, cl, lane);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) bufA[(32 * ob + chan_of(i, kg)) * WIDE_PITCH + j] = actvn(net[i], 0);
+                if (keep) store_acc16(a.save + sv.blk + ((size_t)(2 * blk) * d.total + gj) * H + 32 * ob, relu16(net), kg);
             }
             __syncthreads();
             if (ob < nh) {
                 const f32x16 hid = wide_gemm(bias16(bb + H, ob, kg), wb + lay.w_c, ob, H, bufA, lane);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) bufB[(32 * ob + chan_of(i, kg)) * WIDE_PITCH + j] = actvn(hid[i], 0);
+                if (keep) store_acc16(a.save + sv.blk + ((size_t)(2 * blk + 1) * d.total + gj) * H + 32 * ob, relu16(hid), kg);
             }
             __syncthreads();
             if (ob < nh) {
@@ -177,13 +224,16 @@ decode_wide_kernel(WideArgs a) {
         const float *ow = bias + (size_t)H * (1 + 3 * a.nb), *ow2 = ow + H + 1;
         float o1 = 0.0f, o2 = 0.0f;
         if (ob < nh) {
+            f32x16 af;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = 32 * ob + chan_of(i, kg);
                 const float v = actvn(net[i], a.leaky);
+                af[i] = v;
                 o1 = fmaf(ow[row], v, o1);
                 o2 = fmaf(ow2[row], v, o2);
             }
+            if (keep) store_acc16(a.save + sv.af + (size_t)gj * H + 32 * ob, af, kg);
         }
         heads[((wave * 2 + kg) * 2 + 0) * 32 + j] = o1;
         heads[((wave * 2 + kg) * 2 + 1) * 32 + j] = o2;
@@ -198,6 +248,135 @@ decode_wide_kernel(WideArgs a) {
             if (g < d.total && dst) dst[g] = o;
         }
         __syncthreads();
+    }
+}
+
+
+// ---- backward: data gradients ----------------------------------------------------------------------------------------------
+// With N_i the residual stream in front of block i, mid_i = N_i + fc_c_i(c), a0 = relu(mid_i), hid = fc_0(a0), a1 = relu(hid),
+// N_{i+1} = mid_i + fc_1(a1):      d a1 = W1^T dN_{i+1},  dH_i = d a1 . [a1 > 0],  dN_i = dN_{i+1} + (W0^T dH_i) . [a0 > 0],
+// d c += Wc_i^T dN_i,  and at the front  d c_img = Wp[:, 3:]^T dN_0.  The wave that owns rows 32 ob .. 32 ob + 31 keeps its
+// slice of dN in registers through the whole walk; the full dN / dH of the 32 points pass through two LDS buffers, the B
+// operands of the transposed-weight GEMMs (two barriers per block).  dN_i / dH_i also go to the point-major workspace the
+// weight gradients read; d c is scattered to the channels-last grid gradient with f32 atomics (the 8 trilinear corners, or
+// the one voxel of 'nearest').
+struct WideBwdArgs {
+    DecodeArgs d;               // pts, N, total, R, divisor; grid / out unused
+    const float *blob_t, *save, *grad_out, *grad_out2;
+    float *gws, *grad_grid, *grad_cimg;
+    int H, C, nb, leaky, nearest;
+};
+
+template <int WIDE_WAVES>
+__global__ void __launch_bounds__(WIDE_WAVES * 64)
+decode_wide_bwd_kernel(WideBwdArgs a) {
+    constexpr int WIDE_THREADS = WIDE_WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // bufG [H][33] | bufH [H][33] | d c [C][33]
+    const DecodeArgs &d = a.d;
+    const int H = a.H, C = a.C, nh = H / 32, nc = C / 32;
+    float *bufG = wl, *bufH = bufG + (size_t)H * WIDE_PITCH, *cl = bufH + (size_t)H * WIDE_PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kg = lane >> 5;
+    const int ob = wave;
+    const WideLayoutT lay = wide_layout_t(H, C, a.nb);
+    const WideSave sv = wide_save_layout(d.total, H, C, a.nb);
+    const WideGws gw = wide_gws_layout(d.total, H, a.nb);
+    const float *ow = a.blob_t + lay.heads, *ow2 = ow + H;
+    const uint32_t ntiles = (d.total + WIDE_PTS - 1) / WIDE_PTS;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t gj = tile * WIDE_PTS + (uint32_t)j;
+        const bool live = gj < d.total;
+        const size_t gr = live ? gj : d.total - 1u;                  // row to read for a lane past the end (its results are dropped)
+        auto put = [&](float *buf, const f32x16 &v) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) buf[(32 * ob + chan_of(i, kg)) * WIDE_PITCH + j] = v[i];
+        };
+        // ---- the heads: dN_nb = (g w_out + g2 w_out2) . actvn'(net) ----
+        f32x16 dn;
+        if (ob < nh) {
+            const float go = live ? a.grad_out[gj] : 0.0f, go2 = (live && a.grad_out2) ? a.grad_out2[gj] : 0.0f;
+            const f32x16 af = load_acc16(a.save + sv.af + gr * H + 32 * ob, kg);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = 32 * ob + chan_of(i, kg);
+                const float slope = af[i] > 0.0f ? 1.0f : (a.leaky ? 0.2f : 0.0f);     // leaky_relu's / relu's derivative as ATen takes it at 0
+                dn[i] = (go * ow[row] + go2 * ow2[row]) * slope;
+            }
+            put(bufG, dn);
+            if (live) store_acc16(a.gws + gw.dn + ((size_t)a.nb * d.total + gj) * H + 32 * ob, dn, kg);
+        }
+        f32x16 dc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dc[i] = 0.0f;
+        __syncthreads();
+        for (int blk = a.nb - 1; blk >= 0; --blk) {
+            const float *wb = a.blob_t + lay.w_blk + (size_t)blk * (lay.w_1 + lay.w_0 + lay.w_c);
+            f32x16 z;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+            if (ob < nh) {
+                f32x16 dh = wide_gemm(z, wb, ob, H, bufG, lane);                       // W1^T dN_{i+1}
+                const f32x16 a1 = load_acc16(a.save + sv.blk + ((size_t)(2 * blk + 1) * d.total + gr) * H + 32 * ob, kg);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dh[i] = a1[i] > 0.0f ? dh[i] : 0.0f;
+                put(bufH, dh);
+                if (live) store_acc16(a.gws + gw.dh + ((size_t)blk * d.total + gj) * H + 32 * ob, dh, kg);
+            }
+            __syncthreads();                                          // bufH complete; every read of bufG (dN_{i+1}) done
+            if (ob < nh) {
+                const f32x16 da = wide_gemm(z, wb + lay.w_1, ob, H, bufH, lane);       // W0^T dH_i
+                const f32x16 a0 = load_acc16(a.save + sv.blk + ((size_t)(2 * blk) * d.total + gr) * H + 32 * ob, kg);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dn[i] += a0[i] > 0.0f ? da[i] : 0.0f;
+                put(bufG, dn);                                        // dN_i
+                if (live) store_acc16(a.gws + gw.dn + ((size_t)blk * d.total + gj) * H + 32 * ob, dn, kg);
+            }
+            __syncthreads();                                          // bufG = dN_i complete; every read of bufH done
+            if (ob < nc && a.grad_grid) dc = wide_gemm(dc, wb + lay.w_1 + lay.w_0, ob, H, bufG, lane);     // Wc_i^T dN_i
+        }
+        // ---- the front: d c_img = Wp[:, 3:]^T dN_0 (bufG still holds dN_0) ----
+        if (ob < nc && a.grad_cimg) {
+            f32x16 z;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+            const f32x16 dci = wide_gemm(z, a.blob_t + lay.w_pc, ob, H, bufG, lane);
+            if (live) store_acc16(a.grad_cimg + (size_t)gj * C + 32 * ob, dci, kg);
+        }
+        // ---- d c -> the grid gradient ----
+        if (a.grad_grid) {
+            if (ob < nc) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) cl[(32 * ob + chan_of(i, kg)) * WIDE_PITCH + j] = dc[i];
+            }
+            __syncthreads();
+            constexpr int PG = WIDE_THREADS / 32;
+            const int ch = tid & 31, pg = tid >> 5;
+#pragma unroll 1
+            for (int i = 0; i < WIDE_PTS / PG; ++i) {
+                const int pt = pg + PG * i;
+                const uint32_t g = tile * WIDE_PTS + pt;
+                if (g >= d.total) continue;
+                const uint32_t b = g / d.N;
+                float px, py, pz;
+                point_of(d, g, g - b * d.N, px, py, pz);
+                float *gb = a.grad_grid + (size_t)b * d.R * d.R * d.R * C;
+                if (a.nearest) {
+                    const size_t near = (((size_t)__builtin_rintf(grid_coord(pz, d.divisor, d.R)) * d.R + (size_t)__builtin_rintf(grid_coord(py, d.divisor, d.R))) * d.R +
+                                         (size_t)__builtin_rintf(grid_coord(px, d.divisor, d.R))) * C;
+                    for (int cb = 0; cb < C; cb += 32) atomicAdd(gb + near + cb + ch, cl[(cb + ch) * WIDE_PITCH + pt]);
+                    continue;
+                }
+                const Tri t = tri_setup(px, py, pz, d.divisor, d.R);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int zz = (k & 4) ? t.z1 : t.z0, yy = (k & 2) ? t.y1 : t.y0, xx = (k & 1) ? t.x1 : t.x0;
+                    const float w = (((k & 1) ? t.wx1 : t.wx0) * ((k & 2) ? t.wy1 : t.wy0)) * ((k & 4) ? t.wz1 : t.wz0);
+                    if (w == 0.0f) continue;
+                    float *dst = gb + (((size_t)zz * d.R + yy) * d.R + xx) * C;
+                    for (int cb = 0; cb < C; cb += 32) atomicAdd(dst + cb + ch, w * cl[(cb + ch) * WIDE_PITCH + pt]);
+                }
+            }
+        }
+        __syncthreads();                                              // the buffers are free for the next tile
     }
 }
 
@@ -226,7 +405,7 @@ int vt_decoder_pack_wide(const vt_decoder_params *p, float *blob, size_t blob_by
     hipStream_t st = (hipStream_t)stream;
     auto pack = [&](const float *w, int K, int kin, int ld, float *dst) {
         const size_t total = (size_t)H * K;
-        hipLaunchKernelGGL(wide_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, H, K, kin, ld, dst);
+        hipLaunchKernelGGL(wide_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, H, K, kin, (size_t)ld, (size_t)1, dst);
     };
     auto copy = [&](const float *src, float *dst, int n) {
         hipLaunchKernelGGL(wide_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
@@ -253,10 +432,12 @@ int vt_decoder_pack_wide(const vt_decoder_params *p, float *blob, size_t blob_by
     return vt_check(hipGetLastError(), "vt_decoder_pack_wide");
 }
 
-int vt_decode_fwd_wide(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
-                       int lattice_nx, float lattice_box, int64_t lattice_first,
-                       const float *c_img, const float *blob, int hidden, int n_blocks, int flags, double padding,
-                       float *out, float *out2, void *stream) {
+}  // extern "C"
+
+static int wide_fwd_impl(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                         int lattice_nx, float lattice_box, int64_t lattice_first,
+                         const float *c_img, const float *blob, int hidden, int n_blocks, int flags, double padding,
+                         float *out, float *out2, float *save, void *stream) {
     if (!grid_cl || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide: null argument");
     const int p_in = c_img ? 3 + C : 3;
     if (!wide_shape_ok(hidden, C, n_blocks, p_in))
@@ -272,6 +453,7 @@ int vt_decode_fwd_wide(const float *grid_cl, int B, int R, int C, const float *p
     a.d.N = (uint32_t)N; a.d.total = (uint32_t)((uint64_t)B * (uint64_t)N); a.d.lattice_first = (uint32_t)lattice_first;
     a.d.R = R; a.d.nx = lattice_nx; a.d.box = lattice_box; a.d.divisor = (float)(1.0 + padding + 10e-4);
     a.blob = blob; a.H = hidden; a.C = C; a.nb = n_blocks; a.p_in = p_in; a.Kp = (p_in + 7) / 8 * 8; a.leaky = (flags & VT_WIDE_LEAKY) ? 1 : 0; a.nearest = (flags & VT_WIDE_NEAREST) ? 1 : 0;
+    a.save = save;
     const int rowsA = hidden > a.Kp ? hidden : a.Kp;
     const int waves = hidden <= 128 ? 4 : 8;
     const size_t lds = ((size_t)(C + rowsA + hidden) * WIDE_PITCH + (size_t)waves * 2 * 2 * 32) * sizeof(float);
@@ -288,6 +470,102 @@ int vt_decode_fwd_wide(const float *grid_cl, int B, int R, int C, const float *p
     if (waves == 4) hipLaunchKernelGGL(decode_wide_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(decode_wide_kernel<8>, grid, dim3(512), lds, (hipStream_t)stream, a);
     return vt_check(hipGetLastError(), "vt_decode_fwd_wide");
+}
+
+extern "C" {
+
+int vt_decode_fwd_wide(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                       int lattice_nx, float lattice_box, int64_t lattice_first,
+                       const float *c_img, const float *blob, int hidden, int n_blocks, int flags, double padding,
+                       float *out, float *out2, void *stream) {
+    return wide_fwd_impl(grid_cl, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img, blob, hidden, n_blocks, flags, padding,
+                         out, out2, nullptr, stream);
+}
+
+// ---- training (decoder.py:24-51, 135-161 under autograd: training.py:476-489, 879) ----
+size_t vt_decode_wide_save_floats(int64_t total_points, int hidden, int c_dim, int n_blocks) {
+    if (total_points <= 0 || !wide_shape_ok(hidden, c_dim, n_blocks, 3)) return 0;
+    return wide_save_layout((size_t)total_points, hidden, c_dim, n_blocks).total;
+}
+
+size_t vt_decode_wide_gws_floats(int64_t total_points, int hidden, int c_dim, int n_blocks) {
+    if (total_points <= 0 || !wide_shape_ok(hidden, c_dim, n_blocks, 3)) return 0;
+    return wide_gws_layout((size_t)total_points, hidden, n_blocks).total;
+}
+
+int vt_decode_fwd_wide_train(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                             const float *c_img, const float *blob, int hidden, int n_blocks, int flags, double padding,
+                             float *out, float *out2, float *save, void *stream) {
+    if (!pts || !save) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_train: null argument");
+    return wide_fwd_impl(grid_cl, B, R, C, pts, N, 0, 0.0f, 0, c_img, blob, hidden, n_blocks, flags, padding, out, out2, save, stream);
+}
+
+size_t vt_decoder_wide_blob_t_bytes(int hidden, int c_dim, int n_blocks) {
+    if (!wide_shape_ok(hidden, c_dim, n_blocks, 3)) return 0;
+    return wide_layout_t(hidden, c_dim, n_blocks).total * sizeof(float);
+}
+
+int vt_decoder_pack_wide_t(const vt_decoder_params *p, float *blob_t, size_t blob_bytes, void *stream) {
+    if (!p || !blob_t) return vt_fail(VT_ERR_INVALID, "vt_decoder_pack_wide_t: null argument");
+    const int H = p->hidden, C = p->c_dim, nb = p->n_blocks;
+    if (!wide_shape_ok(H, C, nb, p->p_in))
+        return vt_fail(VT_ERR_UNSUPPORTED, "vt_decoder_pack_wide_t: hidden and c_dim must be multiples of 32 up to 256, p_in 3 or 3 + c_dim");
+    const WideLayoutT lay = wide_layout_t(H, C, nb);
+    if (blob_bytes < lay.total * sizeof(float)) return vt_fail(VT_ERR_WORKSPACE, "vt_decoder_pack_wide_t: blob too small");
+    if (!p->fc_p_w || !p->fc_out_w) return vt_fail(VT_ERR_INVALID, "vt_decoder_pack_wide_t: null parameter");
+    hipStream_t st = (hipStream_t)stream;
+    // fragments of M [rows][K] with M[r][k] = src[r * rs + k * ks]
+    auto pack = [&](const float *src, int rows, int K, size_t rs, size_t ks, float *dst) {
+        const size_t total = (size_t)rows * K;
+        hipLaunchKernelGGL(wide_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, rows, K, K, rs, ks, dst);
+    };
+    auto copy = [&](const float *src, float *dst, int n) {
+        hipLaunchKernelGGL(wide_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+    };
+    for (int i = 0; i < nb; ++i) {
+        if (!p->fc_c_w[i] || !p->fc0_w[i] || !p->fc1_w[i]) return vt_fail(VT_ERR_INVALID, "vt_decoder_pack_wide_t: null block parameter");
+        float *wb = blob_t + lay.w_blk + (size_t)i * (lay.w_1 + lay.w_0 + lay.w_c);
+        pack(p->fc1_w[i], H, H, 1, (size_t)H, wb);                         // W1^T [H][H]: (r, k) = W1[k][r]
+        pack(p->fc0_w[i], H, H, 1, (size_t)H, wb + lay.w_1);
+        pack(p->fc_c_w[i], C, H, 1, (size_t)C, wb + lay.w_1 + lay.w_0);    // Wc^T [C][H]: (r, k) = Wc[k][r], Wc is [H][C]
+    }
+    // fc_p_img's c_img columns transposed [C][H]: (r, k) = Wp[k][3 + r]; a decoder packed with fc_p (p_in = 3) has none
+    pack(p->p_in > 3 ? p->fc_p_w + 3 : nullptr, C, H, 1, (size_t)p->p_in, blob_t + lay.w_pc);
+    copy(p->fc_out_w, blob_t + lay.heads, H);
+    copy(p->fc_out2_w, blob_t + lay.heads + H, H);
+    return vt_check(hipGetLastError(), "vt_decoder_pack_wide_t");
+}
+
+int vt_decode_bwd_wide(int B, int R, int C, const float *pts, int64_t N, const float *blob_t, int hidden, int n_blocks, int flags,
+                       double padding, const float *grad_out, const float *grad_out2, const float *save, float *gws,
+                       float *grad_grid_cl, float *grad_c_img, void *stream) {
+    if (!pts || !blob_t || !grad_out || !save || !gws) return vt_fail(VT_ERR_INVALID, "vt_decode_bwd_wide: null argument");
+    if (!wide_shape_ok(hidden, C, n_blocks, 3))
+        return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_bwd_wide: hidden and c_dim must be multiples of 32 up to 256");
+    if (B <= 0 || R < 2 || N <= 0) return vt_fail(VT_ERR_INVALID, "vt_decode_bwd_wide: bad size");
+    if ((unsigned long long)B * (unsigned long long)N >= 0x7fffffffull) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_bwd_wide: B*N must stay below 2^31");
+    WideBwdArgs a{};
+    a.d.pts = pts; a.d.N = (uint32_t)N; a.d.total = (uint32_t)((uint64_t)B * (uint64_t)N); a.d.R = R;
+    a.d.divisor = (float)(1.0 + padding + 10e-4);
+    a.blob_t = blob_t; a.save = save; a.grad_out = grad_out; a.grad_out2 = grad_out2; a.gws = gws;
+    a.grad_grid = grad_grid_cl; a.grad_cimg = grad_c_img;
+    a.H = hidden; a.C = C; a.nb = n_blocks; a.leaky = (flags & VT_WIDE_LEAKY) ? 1 : 0; a.nearest = (flags & VT_WIDE_NEAREST) ? 1 : 0;
+    const int widest = hidden > C ? hidden : C;
+    const int waves = widest <= 128 ? 4 : 8;
+    const size_t lds = (size_t)(2 * hidden + C) * WIDE_PITCH * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_wide_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_wide_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return vt_check(e, "vt_decode_bwd_wide: hipFuncSetAttribute");
+        attr = true;
+    }
+    const uint32_t ntiles = (a.d.total + WIDE_PTS - 1) / WIDE_PTS;
+    const uint32_t cap = (uint32_t)vt_num_cus() * 8u;
+    const dim3 grid(ntiles < cap ? ntiles : cap);
+    if (waves == 4) hipLaunchKernelGGL(decode_wide_bwd_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(decode_wide_bwd_kernel<8>, grid, dim3(512), lds, (hipStream_t)stream, a);
+    return vt_check(hipGetLastError(), "vt_decode_bwd_wide");
 }
 
 }  // extern "C"

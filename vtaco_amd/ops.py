@@ -772,6 +772,106 @@ def split_decoder_grads(flat, p_in, hidden=32, c_dim=32, nb=5):
     return g
 
 
+# ---- the wide decoder (hidden_size / c_dim beyond 32 / 32) under autograd ---------------------------------------------
+def _wide_flags(leaky, nearest):
+    return (1 if leaky else 0) | (2 if nearest else 0)          # VT_WIDE_LEAKY | VT_WIDE_NEAREST
+
+
+def decode_fwd_wide_train(grid, blob, pts, c_img, hidden, nb, leaky, nearest, padding=0.1, want_contact=False):
+    """vt_decode_fwd_wide_train: logits [B,N] (and the contact logits) plus the saved layer inputs (opaque f32 tensor)."""
+    lib = _lib.load()
+    B, C, D, H, W = grid.shape
+    keep, gptr = _cl_storage(grid)
+    pts = _c(pts.detach().float())
+    N = pts.shape[1]
+    ci = _c(c_img.detach().float()) if c_img is not None else None
+    dev = grid.device
+    out = torch.empty((B, N), dtype=torch.float32, device=dev)
+    out2 = torch.empty((B, N), dtype=torch.float32, device=dev) if want_contact else None
+    nsave = lib.vt_decode_wide_save_floats(B * N, int(hidden), C, int(nb))
+    if nsave == 0:
+        raise VtError(f"decoder shape hidden={hidden}, c_dim={C}, n_blocks={nb} is not built (multiples of 32 up to 256)")
+    save = torch.empty(nsave, dtype=torch.float32, device=dev)
+    if N:
+        check(lib.vt_decode_fwd_wide_train(gptr, B, D, C, dev_ptr(pts, "pts"), N, dev_ptr(ci, "c_img"), dev_ptr(blob, "blob"),
+                                           int(hidden), int(nb), _wide_flags(leaky, nearest), float(padding), dev_ptr(out, "out"),
+                                           dev_ptr(out2, "out2"), dev_ptr(save, "save"), stream_ptr()), "vt_decode_fwd_wide_train")
+    return out, out2, save
+
+
+def pack_decoder_wide_t(fc_p_w, fc_c, blocks, fc_out_w, fc_out2_w=None):
+    """vt_decoder_pack_wide_t: the transposed weight fragments vt_decode_bwd_wide streams."""
+    lib = _lib.load()
+    hidden, p_in = fc_p_w.shape
+    c_dim, nb = fc_c[0].shape[1], len(blocks)
+    keep = []
+
+    def ptr(t, name):
+        t = t.detach()
+        t = t if t.is_contiguous() else t.contiguous()
+        keep.append(t)
+        return dev_ptr(t, name)
+    prm = _lib.DecoderParams()
+    prm.hidden, prm.c_dim, prm.n_blocks, prm.p_in = hidden, c_dim, nb, p_in
+    prm.fc_p_w = ptr(fc_p_w, "fc_p.weight")
+    for i, w in enumerate(fc_c):
+        prm.fc_c_w[i] = ptr(w, f"fc_c.{i}.weight").value
+    for i, (w0, w1) in enumerate(blocks):
+        prm.fc0_w[i], prm.fc1_w[i] = ptr(w0, "fc_0.weight").value, ptr(w1, "fc_1.weight").value
+    prm.fc_out_w = ptr(fc_out_w, "fc_out.weight")
+    if fc_out2_w is not None:
+        prm.fc_out2_w = ptr(fc_out2_w, "fc_out_contact.weight")
+    n = lib.vt_decoder_wide_blob_t_bytes(hidden, c_dim, nb)
+    if n == 0:
+        raise VtError(f"decoder shape hidden={hidden}, c_dim={c_dim}, n_blocks={nb} is not built (multiples of 32 up to 256)")
+    out = torch.empty(n // 4, dtype=torch.float32, device=fc_p_w.device)
+    check(lib.vt_decoder_pack_wide_t(ctypes.byref(prm), dev_ptr(out, "blob_t"), n, stream_ptr()), "vt_decoder_pack_wide_t")
+    return out
+
+
+def decode_bwd_wide(grid_shape, blob_t, grad_out, save, pts, hidden, nb, leaky, nearest, padding=0.1, c_img=None,
+                    want_grid_grad=True, grad_out2=None):
+    """vt_decode_bwd_wide + the weight gradients (vt_rows_wgrad over the saved layer inputs and the output gradients the data pass
+    leaves).  Returns (grad_grid channels-last strided [B,C,R,R,R] or None, grad_c_img [B,N,C] or None, dict of parameter gradients
+    keyed like split_decoder_grads)."""
+    lib = _lib.load()
+    B, C, R = grid_shape[0], grid_shape[1], grid_shape[2]
+    H = int(hidden)
+    grad_out = _c(grad_out.float())
+    dev = grad_out.device
+    pts = _c(pts.float())
+    N = pts.shape[1]
+    P = B * N
+    g2 = _c(grad_out2.float()) if grad_out2 is not None else None
+    gws = torch.empty(lib.vt_decode_wide_gws_floats(P, H, C, int(nb)), dtype=torch.float32, device=dev)
+    ggrid = torch.zeros((B, R, R, R, C), dtype=torch.float32, device=dev) if want_grid_grad else None
+    gimg = torch.empty((B, N, C), dtype=torch.float32, device=dev) if c_img is not None else None
+    check(lib.vt_decode_bwd_wide(B, R, C, dev_ptr(pts, "pts"), N, dev_ptr(blob_t, "blob_t"), H, int(nb), _wide_flags(leaky, nearest),
+                                 float(padding), dev_ptr(grad_out, "grad_out"), dev_ptr(g2, "grad_out2"), dev_ptr(save, "save"),
+                                 dev_ptr(gws, "gws"), dev_ptr(ggrid, "grad_grid"), dev_ptr(gimg, "grad_c_img"), stream_ptr()),
+          "vt_decode_bwd_wide")
+    # the slots of the two buffers as [P, width] views (layouts: decode_wide.hip wide_save_layout / wide_gws_layout)
+    sv_c = save[:P * C].view(P, C)
+    sv_blk = save[P * C:P * C + 2 * nb * P * H].view(nb, 2, P, H)
+    sv_af = save[P * C + 2 * nb * P * H:].view(P, H)
+    dn = gws[:(nb + 1) * P * H].view(nb + 1, P, H)
+    dh = gws[(nb + 1) * P * H:].view(nb, P, H)
+    g = {}
+    x2 = _c(c_img.float()).view(P, C) if c_img is not None else None
+    g["fc_p.weight"], g["fc_p.bias"] = rows_wgrad(dn[0], pts.view(P, 3), x2)
+    wc, bc, w0, b0, w1, b1 = [], [], [], [], [], []
+    for i in range(nb):
+        a, b = rows_wgrad(dn[i], sv_c); wc.append(a); bc.append(b)
+        a, b = rows_wgrad(dh[i], sv_blk[i, 0]); w0.append(a); b0.append(b)
+        a, b = rows_wgrad(dn[i + 1], sv_blk[i, 1]); w1.append(a); b1.append(b)
+    g["fc_c.weight"], g["fc_c.bias"] = wc, bc
+    g["fc_0.weight"], g["fc_0.bias"], g["fc_1.weight"], g["fc_1.bias"] = w0, b0, w1, b1
+    g["fc_out.weight"], g["fc_out.bias"] = rows_wgrad(grad_out.view(P, 1), sv_af)
+    if g2 is not None:
+        g["fc_out_contact.weight"], g["fc_out_contact.bias"] = rows_wgrad(g2.view(P, 1), sv_af)
+    return (ggrid.permute(0, 4, 1, 2, 3) if ggrid is not None else None), gimg, g
+
+
 # --------------------------------------------------------------------------------------
 # AttentionDecoder pieces: sample-only, MLP-only, TransformerFusion
 # --------------------------------------------------------------------------------------
