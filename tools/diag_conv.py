@@ -1,4 +1,4 @@
-"""Diagnostic (VT_DIAG_HB build only; the stamps live in tools/probe/conv_diag.patch, see tools/README.md): per-wave shader-clock sums of the phases of the persistent split-f16 conv on one
+"""Diagnostic (VT_DIAG_HB build only; the stamps live in tools/probe/conv_diag.patch: `patch vtaco_amd/csrc/unet3d.hip tools/probe/conv_diag.patch`, build the variant, `patch -R` afterwards): per-wave shader-clock sums of the phases of the persistent split-f16 conv on one
 32->32 layer at 64^3.  bash tools/build_variant.sh hb "-DVT_DIAG_HB"; VTACO_HIP_LIB=variants/lib_hb.so python tools/diag_conv.py"""
 import ctypes, os, sys
 import numpy as np
@@ -32,20 +32,21 @@ a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
 raw = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8)
 raw = raw[raw[:, 7] > 0]
 a = a[a[:, 7] > 0]
-store = (raw[:, 0] >> np.uint64(40)).astype(np.float64)
-a[:, 0] = (raw[:, 0] & np.uint64((1 << 40) - 1)).astype(np.float64)
-print(f"  (of the tile epilogue: relu + store median {np.median(store):.0f} cycles per wave)")
 names = ["prologue", "commit + DMA issue", "fetch issue", "taps", "tile epilogue", "wait DMA", "barrier", "TOTAL"]
-def table(rows, title):
+tap_names = ["prologue (to the first barrier)", "taps (14 k-steps x chunks)", "epilogue: relu + stores", "epilogue: statistics", "barrier", "-", "-", "TOTAL"]
+load_names = ["prologue", "commit (normalise, split, LDS)", "weights DMA + fetch issue", "wait (vmcnt)", "barrier", "-", "-", "TOTAL"]
+def table(rows, title, names=names):
     print(f"{title}: {rows.shape[0]} waves")
     for i, nm in enumerate(names):
+        if nm == "-":
+            continue
         print(f"  {nm:20s} median {np.median(rows[:, i]):9.0f} cycles per wave   ({100 * rows[:, i].sum() / rows[:, 7].sum():5.1f} %)")
 if os.environ.get("VTACO_CONV_SPEC", "1") != "0":
     # specialised waves: in every workgroup the first half of the waves run taps (slots 3 = taps, 4 = taps + tile epilogue of the
     # tile's last chunk, 6 = barrier), the second half load (1 = commit + DMA issue, 2 = fetch issue, 5 = wait, 6 = barrier)
     per_wg = 16 if R >= 64 else 8
     w = np.arange(a.shape[0]) % per_wg
-    table(a[w < per_wg // 2], "tap waves")
-    table(a[w >= per_wg // 2], "loader waves")
+    table(a[w < per_wg // 2], "tap waves", tap_names)
+    table(a[w >= per_wg // 2], "loader waves", load_names)
 else:
     table(a, "all waves")

@@ -16,6 +16,7 @@
 //                            level: neither the upsample nor the concat is materialised.
 //   maxpool / conv1x1        the 2x2x2 max-pool between encoder levels and the final 1x1x1 conv.
 #include <string.h>
+#include <type_traits>
 #include "decode_common.h"
 
 namespace {
@@ -1323,6 +1324,9 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
             voff[it] = ((pz - 1) * s.H + (py - 1)) * s.W + (px - 1);
             loff[it] = (((pz - 1) >> 1) * H2 + ((py - 1) >> 1)) * W2 + ((px - 1) >> 1);
         }
+        unsigned f_full = 0;                                       // the items this thread has at all (lrow >= 0)
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) if (lrow[it] >= 0) f_full |= 1u << it;
         const int c4 = (lt & 1) * 4;
         const int vmax = (int)((size_t)gridDim.x / ha.wgs_per_scene * s.D * s.H * s.W) - 1, lmax = s.low ? vmax / 8 : 0;
         // two register sets for the input prefetch: chunk n lives in set n & 1 and is requested two chunks ahead, so a
@@ -1380,7 +1384,8 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
             if (++f_q == ncq) { f_q = 0; ++f_k; enter_tile(f_k); }
         };
         int c_q = 0;
-        auto commit = [&](int n, const PreSet &ps) {
+        auto commit_as = [&](int n, const PreSet &ps, auto padded_tag) {
+            constexpr bool PADDED = decltype(padded_tag)::value;
             const int ch = c_q * 8 + c4;
             if (++c_q == ncq) c_q = 0;
             const float *ss = ssl + ch * 2;
@@ -1389,10 +1394,15 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 if (lrow[it] < 0) continue;
-                const bool in = ps.in >> it & 1u;
                 float x[4];
+                if constexpr (PADDED) {
+                    const bool in = ps.in >> it & 1u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = in ? fmaf(ps.v[it][e], sc[e], sh[e]) : 0.0f;
+                    for (int e = 0; e < 4; ++e) x[e] = in ? fmaf(ps.v[it][e], sc[e], sh[e]) : 0.0f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = fmaf(ps.v[it][e], sc[e], sh[e]);
+                }
                 // hi = half(x) (packed conversion), lo = half(x - hi) with the subtraction reading the half in place
                 // (v_fma_mix_f32): 8 instructions per 4 values instead of the 20 the plain C++ form compiles to; the two pairs
                 // are interleaved so that no mix instruction directly follows the conversion it reads
@@ -1412,6 +1422,12 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
                 *reinterpret_cast<u32x2 *>(img + lrow[it]) = u32x2{h01, h23};
                 *reinterpret_cast<u32x2 *>(img + ROWS * 16 + lrow[it]) = u32x2{l01, l23};
             }
+        };
+        // tiles inside the volume (216 of the 512 of a 64^3 level) need no zero padding: one wave-uniform test per chunk saves the
+        // four selects per item -- a fifth of the commit's instructions, which compete with the tap waves' MFMAs for issue slots
+        auto commit = [&](int n, const PreSet &ps) {
+            if (__builtin_amdgcn_ballot_w64(ps.in != f_full) == 0ull) commit_as(n, ps, std::false_type{});
+            else commit_as(n, ps, std::true_type{});
         };
         constexpr int WAIT_DMA = 0x0F70 | ITERS;                  // vmcnt(ITERS): all but the youngest ITERS operations (the register fetch) have landed
         if (N > 0) {
@@ -1517,7 +1533,9 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float sm = half_wave_sum(ssum[r]), sq = half_wave_sum(ssq[r]);
-                        if (j == 31) { float *d = sred + wave * 64 + chan_of(r, kg) * 2; d[0] += sm; d[1] += sq; }
+                        // (ds_add_f32 without a return value: the read-modify-write chains `d[0] += sm` compiled to were 32 dependent LDS
+                        // round trips per tile; the slot belongs to this wave alone, whose LDS operations complete in order)
+                        if (j == 31) { float *d = sred + wave * 64 + chan_of(r, kg) * 2; atomicAdd(d, sm); atomicAdd(d + 1, sq); }
                     }
                 }
 #pragma unroll
