@@ -318,6 +318,12 @@ __device__ __forceinline__ void tile_store8(float *tile, const f32x4 &t) {
     *reinterpret_cast<f32x4 *>(tile + r * SROW8 + c * 4) = t;
 }
 
+// HAS_W = false: the row-sum pass (w == 1 for every streamed row): no weight tile in LDS, no multiply -- the weights were 4 of the
+// 10 ds_read_b128 a wave issues per score tile, and the LDS pipe (8 cycles per 16-byte wave read, 16+ waves per CU) is the busiest
+// unit of this kernel: 13.15 -> 12.59 ms per 128^3.  (Measured and not kept: two 32-row fixed tiles per wave against every streamed
+// fragment -- 3 / 5 reads per score tile instead of 6 / 10 -- needs ~140 registers: at two or three waves per SIMD the per-tile
+// barrier is exposed, 13.5 ms with 8-wave and with 4-wave workgroups; forced into 128 registers it spills: 13.6 ms.)
+template <bool HAS_W>
 __global__ void __launch_bounds__(FT)
 fusion_expsum8_kernel(const float *Fd, const float *Sd, const float *w, float *out, int N, int recip_out, int nrb, int B) {
     __shared__ __attribute__((aligned(16))) float tiles[2][STILE8];
@@ -336,11 +342,15 @@ fusion_expsum8_kernel(const float *Fd, const float *Sd, const float *w, float *o
     float wreg = 0.0f;
     auto fetch = [&](int t) {
         if (mover) tr = tile_fetch8(Sd, t * 32, N);
-        if (threadIdx.x < 32) { const int i = t * 32 + threadIdx.x; wreg = (i < N) ? (w ? w[i] : 1.0f) : 0.0f; }
+        if (HAS_W || t == ntile - 1) {
+            if (threadIdx.x < 32) { const int i = t * 32 + threadIdx.x; wreg = (i < N) ? (w ? w[i] : 1.0f) : 0.0f; }
+        }
     };
     fetch(0);
     if (mover) tile_store8(tiles[0], tr);
     if (threadIdx.x < 32) wt[0][threadIdx.x] = wreg;
+    // without weights only a ragged LAST tile needs them (zeros for the rows beyond N): buffer 1 holds that tile's
+    if (!HAS_W && threadIdx.x < 32) { const int i = (ntile - 1) * 32 + threadIdx.x; wt[1][threadIdx.x] = i < N ? 1.0f : 0.0f; }
     __syncthreads();
     float sum = 0.0f;
     for (int t = 0; t < ntile; ++t) {
@@ -349,12 +359,17 @@ fusion_expsum8_kernel(const float *Fd, const float *Sd, const float *w, float *o
         FragQK8 stream;
         load_fragqk8(stream, tiles[cur] + j * SROW8, h);
         const f32x16 sc = score_tile8(stream, fixed);
-        const f32x16 ww = load_acc16(wt[cur], h);               // w of streamed row chan_of(r,h)
+        if (HAS_W || (t == ntile - 1 && (N & 31) != 0)) {
+            const f32x16 ww = load_acc16(HAS_W ? wt[cur] : wt[1], h);   // w of streamed row chan_of(r,h)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sum = fmaf(exp2_unit(sc[r]), ww[r], sum);
+            for (int r = 0; r < 16; ++r) sum = fmaf(exp2_unit(sc[r]), ww[r], sum);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += exp2_unit(sc[r]);
+        }
         if (t + 1 < ntile) {
             if (mover) tile_store8(tiles[cur ^ 1], tr);
-            if (threadIdx.x < 32) wt[cur ^ 1][threadIdx.x] = wreg;
+            if (HAS_W && threadIdx.x < 32) wt[cur ^ 1][threadIdx.x] = wreg;
         }
         __syncthreads();
     }
@@ -709,8 +724,8 @@ void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const fl
         hipLaunchKernelGGL((fusion_proj_kernel<false, true, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
     }
     if (f8) {
-        hipLaunchKernelGGL(fusion_expsum8_kernel, tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1, nrb, B);                // 1/l_q
-        hipLaunchKernelGGL(fusion_expsum8_kernel, tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0, nrb, B);                    // s_k
+        hipLaunchKernelGGL(fusion_expsum8_kernel<false>, tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1, nrb, B);                // 1/l_q
+        hipLaunchKernelGGL(fusion_expsum8_kernel<true>, tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0, nrb, B);                    // s_k
     } else if (full) {
         hipLaunchKernelGGL((fusion_expsum_kernel<true, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1, nrb, B);
         hipLaunchKernelGGL((fusion_expsum_kernel<false, true>), tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0, nrb, B);
