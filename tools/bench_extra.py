@@ -44,7 +44,7 @@ out = {}
 # --- img: tactile concat over the lattice
 c_img = sc["c_img"](nx)
 if "img" in SECTIONS:
-    for prec in ("f32", "bf16x3", "f16f8"):
+    for prec in ("f32", "bf16x3", "f16x3", "f16f8"):
         t = timed(lambda: dec.decode_lattice(grid, nx, c_img=c_img, precision=prec), 50, 5)
         print(json.dumps({"workload": f"forward_img (tactile concat) 128^3 lattice, {prec}", "ms": t * 1e3,
                           "points_per_s": nx ** 3 / t, "tflops": 33536 * nx ** 3 / t / 1e12}))
@@ -165,7 +165,7 @@ model.eval()
 if "dense256" in SECTIONS:
     nx2 = 256
     buf = torch.empty((1, nx2 ** 3), dtype=torch.float32, device=dev)
-    for prec in ("f32", "bf16x3", "f16f8"):
+    for prec in ("f32", "bf16x3", "f16x3", "f16f8"):
         t = timed(lambda: dec.decode_lattice(grid, nx2, out=buf, precision=prec), 10, 2)
         t_mc = timed(lambda: ops.marching_cubes(buf.view(nx2, nx2, nx2), None, rescale=(nx2 / 2, 1.1 / nx2)), 10, 2)
         v, f, _ = ops.marching_cubes(buf.view(nx2, nx2, nx2), None)
