@@ -480,6 +480,16 @@ def train_step_section(dev, fx, rank, world, dist, steps=8, scenes=8):
         fx.fence()
         res["allreduce_alone_ms"] = 1e3 * fx.max_over_ranks(time.perf_counter() - t0) / 5
         res["allreduce_alone_GBps_per_gpu"] = 2 * (world - 1) / world * 4 * sync.numel / (res["allreduce_alone_ms"] * 1e-3) / 1e9
+        # assertion-free diagnostic: where the measured all-reduce sits between the two wire-time bounds of a fully connected xGMI node
+        # (7 links x ~153 GB/s per GPU): a RING moves 2 (w-1)/w S bytes over ONE link per GPU; a DIRECT
+        # reduce-scatter + all-gather sends S/w to every peer at once, twice
+        link, S = 153e9, 4.0 * sync.numel
+        ring_ms, direct_ms = 1e3 * 2 * (world - 1) / world * S / link, 1e3 * 2 * (S / world) / link
+        res["allreduce_alone_vs_xgmi_bounds"] = {
+            "ring_bound_ms": ring_ms, "direct_bound_ms": direct_ms, "measured_over_ring": res["allreduce_alone_ms"] / ring_ms,
+            "measured_over_direct": res["allreduce_alone_ms"] / direct_ms,
+            "reads_as": "ring-like (per-link bound)" if res["allreduce_alone_ms"] > 0.7 * ring_ms else "uses several links at once",
+            "note": f"{world} ranks, {S / 1e6:.1f} MB of gradients in {len(flats)} buckets launched together; wire time only (no reduction arithmetic, no launch latency)"}
         # the same step with no gradient exchange at all: the hooks are switched off too (they would launch the buckets)
         with sync.no_sync():
             ms_local, _ = timed_steps(trainer, steps, warm=1)
