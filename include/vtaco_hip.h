@@ -261,6 +261,17 @@ int vt_decode_mlp_bwd(int B, int C, const float *pts, int64_t N,
 int vt_sample_grid_bwd(int B, int R, int C, const float *pts, int64_t N,
                        int lattice_nx, float lattice_box, int64_t lattice_first, double padding,
                        const float *grad_feat, float *grad_grid_cl, void *stream);
+/* vt_sample_grid_bwd with the points grouped by trilinear cell: order / seg_lo / seg_hi from vt_voxel_build(pts, B, N, R - 1,       */
+/* padding, ...) (a point's bin at resolution R - 1 is the cell whose eight corners it touches).  One wave per cell sums its points'    */
+/* contributions in ascending point order and issues its atomics once per cell: the form for clustered query points (the contact        */
+/* clouds of training.py:817-866 put up to 128 points of a scene into a few cells, whose per-point atomics collide).  Same sums.         */
+int vt_sample_grid_bwd_sorted(int B, int R, int C, const float *pts, int64_t N, double padding, const float *grad_feat,
+                              const int *order, const int *seg_lo, const int *seg_hi, float *grad_grid_cl, void *stream);
+/* vt_decode_bwd_contact that leaves d c (the gradient of the sampled features, [B*N][32]) in `grad_c` instead of scattering it:  */
+/* the caller scatters with vt_sample_grid_bwd_sorted (query points given explicitly; grad_out2 / grad_c_img may be NULL).            */
+int vt_decode_bwd_dc(int B, int R, int C, const float *pts, int64_t N, double padding,
+                     const float *blob_t, const float *grad_out, const float *grad_out2, const float *save, float *gws,
+                     float *grad_c, float *grad_c_img, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* TransformerFusion forward (eval mode).                                       */

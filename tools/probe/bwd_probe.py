@@ -27,3 +27,13 @@ print("clustered points", timed(lambda: ops.decode_bwd(tuple(grid.shape), bt, go
 print("zeros 268MB", timed(lambda: torch.zeros((B, 64, 64, 64, 32), device=dev)), "ms")
 gf = torch.randn(B, N, 32, device=dev)
 print("sample_grid_bwd", timed(lambda: ops.sample_grid_bwd(tuple(grid.shape), p, gf)), "ms")
+# sorted (by trilinear cell) against per-point scatter: same gradient to rounding, time on uniform and on clustered points
+import importlib
+for name, pp, sv in (("uniform", p, save), ("clustered", p2, save2)):
+    outs = {}
+    for mode in (True, False):
+        ops.GRID_SCATTER_SORTED = mode
+        outs[mode] = ops.decode_bwd(tuple(grid.shape), bt, go, sv, pts=pp, want_grid_grad=True)[0]
+        print(name, "sorted" if mode else "per point", timed(lambda: ops.decode_bwd(tuple(grid.shape), bt, go, sv, pts=pp, want_grid_grad=True)), "ms")
+    d = (outs[True] - outs[False]).abs().max().item(); m = outs[False].abs().max().item()
+    print(name, "max abs difference", d, "of", m)

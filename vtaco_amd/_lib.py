@@ -161,6 +161,8 @@ SIGNATURES = {
     "vt_decode_mlp_fwd_train": (_I, [_VP, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP, _VP]),
     "vt_decode_mlp_bwd": (_I, [_I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vt_sample_grid_bwd": (_I, [_I, _I, _I, _VP, _I64, _I, _F, _I64, _D, _VP, _VP, _VP]),
+    "vt_sample_grid_bwd_sorted": (_I, [_I, _I, _I, _VP, _I64, _D, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "vt_decode_bwd_dc": (_I, [_I, _I, _I, _VP, _I64, _D, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vt_relu_mask": (_I, [_VP, _VP, _VP, _I64, _VP]),
     "vt_relu_mask_absmax": (_I, [_VP, _VP, _VP, _I64, _VP, _VP]),
     "vt_conv3d_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
