@@ -222,3 +222,35 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run"],
                          env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
+def _guard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vtaco_amd.conv_onet.generation import _reduce_or
+        # whole group: the OR of the ranks' words
+        got_all = _reduce_or(1 if rank == 0 else 4, None, None)
+        # a sub-group of rank 0 alone (every rank creates it, only its member uses it): no other rank is waited for
+        g0 = dist.new_group([0])
+        got_sub = _reduce_or(2, g0, None) if rank == 0 else None
+        dist.barrier()
+        q.put((rank, got_all, got_sub))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_range_guard_word_is_reduced_over_the_given_group_only():
+    """generate_obj_mesh_sharded's flag exchange: bitwise OR over the ranks of the group the call was given (per-bit MAX: RCCL
+    has no BOR), a one-rank sub-group exchanges nothing."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, 5, 2), (1, 5, None)]

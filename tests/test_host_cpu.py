@@ -314,3 +314,56 @@ def test_generator_weight_stamps_and_eval_mode_follow_the_model():
     model.encoder.unet3d.train()                                      # one branch only
     gen._eval_mode()
     assert not any(m.training for m in model.modules())
+
+
+def test_range_guard_walks_f16f8_to_f16x3_to_bf16x3_and_stays_rank_local(monkeypatch):
+    """Generator3D's range guard (host logic; the device word is played by a stub): RANGE_FP8 / RANGE_LOGIT move an 'f16f8'
+    generator to 'f16x3', RANGE_HALF moves either half-precision form to 'bf16x3', each with a warning and ONE regeneration per
+    move; a clean word changes nothing; the non-sharded entry points never touch torch.distributed (a collective hidden there
+    would hang a rank-0-only export)."""
+    import warnings
+    import torch.distributed as dist
+    from vtaco_amd import ops
+    from vtaco_amd.conv_onet import generation as gen_mod
+
+    class Dummy:
+        def __init__(self, precision):
+            self.decode_precision, self.device, self.calls = precision, None, []
+            self.model = type("M", (), {"decoder": type("D", (), {})()})()
+
+        @gen_mod._range_guarded
+        def make(self, x):
+            self.calls.append(self.decode_precision)
+            return (x, self.decode_precision)
+
+    def forbid(*a, **k):
+        raise AssertionError("a collective was reached from a non-sharded entry point")
+    for name in ("all_reduce", "broadcast", "all_gather", "barrier"):
+        monkeypatch.setattr(dist, name, forbid)
+    words = []
+    monkeypatch.setattr(ops, "decode_range_status", lambda reset=True: words.pop(0) if words else 0)
+    # clean
+    g = Dummy("f16f8")
+    assert g.make(1) == (1, "f16f8") and g.calls == ["f16f8"]
+    # the fp8 copies clipped, then the half range too: two moves, three generations
+    g, words[:] = Dummy("f16f8"), [ops.RANGE_FP8, ops.RANGE_HALF, 0]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert g.make(2) == (2, "bf16x3")
+    assert g.calls == ["f16f8", "f16x3", "bf16x3"] and len(w) == 2 and g.model.decoder.__dict__ == {}
+    # a logit beyond 2.5: only 'f16f8' cares
+    g, words[:] = Dummy("f16f8"), [ops.RANGE_LOGIT, 0]
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        assert g.make(3) == (3, "f16x3") and g.calls == ["f16f8", "f16x3"]
+    g, words[:] = Dummy("f16x3"), [ops.RANGE_LOGIT | ops.RANGE_FP8]
+    assert g.make(4) == (4, "f16x3") and g.calls == ["f16x3"]
+    # the half range from the default precision; the attention decoder's MLP goes back to the exact kernel with it
+    g, words[:] = Dummy("f16x3"), [ops.RANGE_HALF, 0]
+    g.model.decoder.mlp_precision = "f16x3"
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        assert g.make(5) == (5, "bf16x3") and g.model.decoder.mlp_precision == "f32"
+    # other precisions are not guarded at all (no status read)
+    g, words[:] = Dummy("f32"), [ops.RANGE_HALF]
+    assert g.make(6) == (6, "f32") and words == [ops.RANGE_HALF]
