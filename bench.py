@@ -344,8 +344,8 @@ def timed_region(step, steps, fx, collective=False):
         step()
     torch.cuda.synchronize()
     est = (time.perf_counter() - t0) / 8
-    if collective:
-        est = fx.max_over_ranks(est)
+    if collective or fx.dist is not None:
+        est = fx.max_over_ranks(est)                       # every rank times the SAME number of steps (value = all ranks' units / max time)
     reps = max(1, min(4096, int(math.ceil(MIN_TIMED_S / max(est * steps, 1e-9)))))
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
     fx.fence()
