@@ -1011,6 +1011,7 @@ int vt_decoder_pack(const vt_decoder_params *p, float *blob, size_t blob_bytes, 
     for (int i = 0; i < 5; ++i)
         if (!p->fc_c_w[i] || !p->fc_c_b[i] || !p->fc0_w[i] || !p->fc0_b[i] || !p->fc1_w[i] || !p->fc1_b[i])
             return vt_fail(VT_ERR_INVALID, "vt_decoder_pack: null block weight");
+    (void)vt_decode_status_dev();          // the device's status block exists before any launch can be captured into a graph
     PackArgs a;
     a.p = *p;
     a.blob = blob;
