@@ -557,10 +557,14 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
     // arbitrated by age), and with fixed shares the older wave finished early and left its partner to run alone -- see
     // decode_st3.h.  The workgroup's set of tiles is the one the fixed assignment gave it.
     const uint32_t wg_first = t_begin + w_idx - (uint32_t)wave;
+    unsigned fixed_next = (unsigned)wave;
     auto claim = [&]() -> uint32_t {
         unsigned i = 0;
-        if (lane == 0) i = __hip_atomic_fetch_add(claim_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        i = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
+        if (!a.claim) { i = fixed_next; fixed_next += (unsigned)WPB; }                      // A/B: the fixed share (wave w: w, w + WPB, ...)
+        else {
+            if (lane == 0) i = __hip_atomic_fetch_add(claim_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            i = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
+        }
         const uint32_t t = wg_first + (i % (unsigned)WPB) + (i / (unsigned)WPB) * w_cnt;
         return i < 0x10000u ? t : t_end;
     };
@@ -1164,6 +1168,9 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
     unsigned *const status_block = vt_decode_status_dev();
     a.status = (P == 2) ? status_block : nullptr;
     a.clk = nullptr;                                       // set for the lattice kernels below
+    static const int claim_tiles = !(getenv("VTACO_DECODE_CLAIM") && atoi(getenv("VTACO_DECODE_CLAIM")) == 0);
+    a.claim = claim_tiles && P != 0;                       // (same box, claims / fixed shares: f16x3 163.2 / 167.2 us, f16f8 149.5 / 155.0,
+                                                           // bf16x3 186.0 / 190.1 -- and exact f32 502.9 / 496.3: its waves are matrix-bound, not issue-bound)
     a.c_direct = c_direct; a.grid = grid_cl; a.pts = pts; a.brick = 0; a.cimg_ids = cimg_ids; a.cimg_table = cimg_table; a.c_img = c_img; a.blob = blob; a.out = out; a.out2 = out2; a.save = save;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box;
@@ -1276,6 +1283,7 @@ int vt_decode_fwd_f16f8(const float *grid_cl, int B, int R, int C, int64_t N, in
     DecodeArgs a;
     a.status = vt_decode_status_dev();
     a.clk = nullptr;
+    a.claim = !(getenv("VTACO_DECODE_CLAIM") && atoi(getenv("VTACO_DECODE_CLAIM")) == 0);
     a.c_direct = nullptr; a.grid = grid_cl; a.pts = nullptr; a.brick = 1; a.cimg_ids = finger_ids; a.cimg_table = finger_ids ? finger_feats : nullptr;
     a.c_img = c_img; a.blob = blob_f16f8; a.out = out; a.out2 = nullptr; a.save = nullptr;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
@@ -1358,7 +1366,7 @@ int vt_sample_grid(const float *grid_cl, int B, int R, int C, const float *pts, 
     if (N == 0) return 0;
     if ((int64_t)B * N >= (int64_t)1 << 31) return vt_fail(VT_ERR_UNSUPPORTED, "vt_sample_grid: B*N must be < 2^31");
     DecodeArgs a;
-    a.status = nullptr; a.clk = nullptr;
+    a.status = nullptr; a.clk = nullptr; a.claim = 0;
     a.c_direct = nullptr; a.brick = 0; a.cimg_ids = nullptr; a.cimg_table = nullptr; a.grid = grid_cl; a.pts = pts; a.c_img = nullptr; a.blob = nullptr; a.out = nullptr; a.out2 = nullptr; a.save = nullptr;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box; a.divisor = (float)(1.0 + padding + 10e-4);

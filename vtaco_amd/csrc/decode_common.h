@@ -278,7 +278,8 @@ struct DecodeArgs {
     float box;
     float divisor;       // 1 + padding + 10e-4
     unsigned *status;    // device word of the range guard (VT_RANGE_* bits), or null
-    unsigned long long *clk;   // [2] shader-clock / constant-clock ticks of workgroup 0's lifetime (lattice kernels), or null
+    unsigned long long *clk;   // the device's clock-stamp block (lattice kernels: clock_begin / clock_end), or null
+    int claim;                 // lattice kernels: waves claim tiles from the workgroup's LDS counter (1) or walk a fixed share (0)
 };
 
 

@@ -310,10 +310,14 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
     // list below); a wave takes the next one from an LDS counter when it issues its prefetch, so the waves end within a tile of
     // each other.  Which wave computes a tile changes nothing in its result.
     const uint32_t wg_first = t_begin + w_idx - (uint32_t)wave;          // this workgroup's first tile
+    unsigned fixed_next = (unsigned)wave;
     auto claim = [&]() -> uint32_t {
         unsigned i = 0;
-        if (lane == 0) i = __hip_atomic_fetch_add(claim_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        i = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
+        if (!a.claim) { i = fixed_next; fixed_next += (unsigned)WPB; }                      // A/B: the fixed share (wave w: w, w + WPB, ...)
+        else {
+            if (lane == 0) i = __hip_atomic_fetch_add(claim_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            i = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
+        }
         const uint32_t t = wg_first + (i % (unsigned)WPB) + (i / (unsigned)WPB) * w_cnt;
         return i < 0x10000u ? t : t_end;                                 // (the list is a few dozen tiles long)
     };
