@@ -151,3 +151,21 @@ def test_unsupported_shapes_fail_loudly():
     _, sd = load_golden("g1_decode.npz")
     with pytest.raises(VtError):
         ops.decode_fwd(torch.zeros(1, 32, 4, 5, 6, device=dev), _blob(sd, dev), pts=torch.zeros(1, 4, 3, device=dev))
+
+
+def test_sample_grid_over_lattice_slabs_equals_the_point_form():
+    """vt_sample_grid in lattice mode (points generated in the kernel; slabs of the staged kernel's shape take its LDS-staged
+    gather) returns the features of the explicit points, bit for bit: whole 64^3 and 128^3 lattices on an R = 32 / 64 grid, an
+    aligned slab, and an unaligned range (direct gather)."""
+    from vtaco_amd import ops
+    from vtaco_amd.common import make_3d_grid
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(3)
+    for nx, R in ((64, 32), (128, 64)):
+        grid = ops.grid_to_channels_last(torch.randn(1, 32, R, R, R, generator=g).to(dev))
+        pts = (1.1 * make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)).to(dev)
+        pair = 2 * nx * nx
+        for first, count in ((0, nx ** 3), (3 * pair, 5 * pair), (7, 1000)):
+            want = ops.sample_grid(grid, pts[first:first + count].unsqueeze(0))
+            got = ops.sample_grid(grid, None, lattice=(nx, 1.1, first, count))
+            assert got.shape == want.shape and torch.equal(got, want), (nx, first, count)

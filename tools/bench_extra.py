@@ -80,7 +80,7 @@ def fusion_pass(cb=256):
     with torch.no_grad():
         for lo in range(0, chunks, cb):
             p = pc[lo:lo + cb]
-            c = ops.sample_grid(grid, p.reshape(1, -1, 3)).reshape(-1, N, 32)
+            c = ops.sample_grid(grid, None, lattice=(nx, 1.1, lo * N, p.shape[0] * N)).reshape(-1, N, 32)   # the lattice range: staged gather
             f = adec.fuser(ci[lo:lo + cb], 1, c, 1)
             outs.append(adec._mlp_fwd(f, p))
     return outs

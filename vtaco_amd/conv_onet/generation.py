@@ -404,7 +404,11 @@ class Generator3D(object):
             """The attention decoder on the chunks ``sel`` (a slice of consecutive chunks, or an index tensor)."""
             p = P3[sel]
             nb = p.shape[0]
-            feat = ops.sample_grid(grid, p.reshape(1, -1, 3), dec.padding).reshape(nb, chunk, -1)
+            if isinstance(sel, slice):                      # consecutive chunks: the lattice range itself (points generated in the kernel)
+                feat = ops.sample_grid(grid, None, dec.padding, lattice=(nx, 1 + self.padding, first + sel.start * chunk, nb * chunk))
+                feat = feat.reshape(nb, chunk, -1)
+            else:
+                feat = ops.sample_grid(grid, p.reshape(1, -1, 3), dec.padding).reshape(nb, chunk, -1)
             fused = dec.fuser(table[R2[sel]], 1, feat, 1)
             O2[sel] = dec._mlp_fwd(fused, p)
 

@@ -1133,16 +1133,39 @@ static int st3_launch(const DecodeArgs &a_in, int variant, void *stream) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute (staged3)");
         attr = true;
     }
     if (variant == 0) hipLaunchKernelGGL(decode_fwd_staged3_kernel<0>, dim3((unsigned)blocks), dim3(ST3_THREADS), lds, (hipStream_t)stream, a);
     else if (variant == 1) hipLaunchKernelGGL(decode_fwd_staged3_kernel<1>, dim3((unsigned)blocks), dim3(ST3_THREADS), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(decode_fwd_staged3_kernel<2>, dim3((unsigned)blocks), dim3(ST3_THREADS), lds, (hipStream_t)stream, a);
+    else if (variant == 2) hipLaunchKernelGGL(decode_fwd_staged3_kernel<2>, dim3((unsigned)blocks), dim3(ST3_THREADS), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(decode_fwd_staged3_kernel<3>, dim3((unsigned)blocks), dim3(ST3_THREADS), lds, (hipStream_t)stream, a);
     return vt_check(hipGetLastError(), "vt_decode_fwd");
 }
 static double lattice_step_voxels(int R, int nx, float box, double padding) {
     return (double)(R - 1) * (double)box / ((double)(nx - 1) * (double)(float)(1.0 + padding + 10e-4));
+}
+// vt_sample_grid over a lattice slab the staged double-brick kernel covers (whole x-plane pairs, nx % 8 == 0, < 0.55 voxels per
+// step): the gather of decode_fwd_staged3_kernel alone -- footprints by LDS-DMA, corners from LDS -- writing the features.  Same
+// corner and FMA order as sample_grid_kernel: the same bits.  *covered = 0: not such a slab, nothing launched.
+int vt_st3_sample_lattice(const float *grid_cl, int B, int R, int C, int64_t N, int nx, float box, int64_t first, double padding,
+                          float *feat, void *stream, int *covered) {
+    *covered = 0;
+    if (C != 32 || nx < 8 || N <= 0 || (int64_t)B * N >= (int64_t)1 << 31) return 0;
+    const int64_t pair = 2ll * nx * nx;
+    if (first % pair != 0 || N % pair != 0) return 0;
+    if (!st3_covers(nx, R, lattice_step_voxels(R, nx, box, padding))) return 0;
+    static const bool off = getenv("VTACO_SAMPLE_STAGED") != nullptr && atoi(getenv("VTACO_SAMPLE_STAGED")) == 0;
+    if (off) return 0;
+    DecodeArgs a;
+    a.status = nullptr; a.clk = nullptr; a.claim = 1;
+    a.c_direct = nullptr; a.grid = grid_cl; a.pts = nullptr; a.brick = 1; a.cimg_ids = nullptr; a.cimg_table = nullptr; a.c_img = nullptr;
+    a.blob = nullptr; a.out = feat; a.out2 = nullptr; a.save = nullptr;
+    a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)first;
+    a.R = R; a.nx = nx; a.box = box; a.divisor = (float)(1.0 + padding + 10e-4);
+    *covered = 1;
+    return st3_launch(a, 3, stream);
 }
 #endif
 
@@ -1365,6 +1388,11 @@ int vt_sample_grid(const float *grid_cl, int B, int R, int C, const float *pts, 
     if (!pts && lattice_nx < 2) return vt_fail(VT_ERR_INVALID, "vt_sample_grid: lattice mode needs nx >= 2");
     if (N == 0) return 0;
     if ((int64_t)B * N >= (int64_t)1 << 31) return vt_fail(VT_ERR_UNSUPPORTED, "vt_sample_grid: B*N must be < 2^31");
+    if (!pts) {                                           // lattice slabs of the staged kernel's shape: its gather alone (decode_f16.o)
+        int covered = 0;
+        const int rc = vt_st3_sample_lattice(grid_cl, B, R, C, N, lattice_nx, lattice_box, lattice_first, padding, feat, stream, &covered);
+        if (rc || covered) return rc;
+    }
     DecodeArgs a;
     a.status = nullptr; a.clk = nullptr; a.claim = 0;
     a.c_direct = nullptr; a.brick = 0; a.cimg_ids = nullptr; a.cimg_table = nullptr; a.grid = grid_cl; a.pts = pts; a.c_img = nullptr; a.blob = nullptr; a.out = nullptr; a.out2 = nullptr; a.save = nullptr;

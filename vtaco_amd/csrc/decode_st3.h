@@ -32,6 +32,7 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 //   0, 1  split-f16 ("f16x3", decode_common.h): W x = W_lo x_hi + W_hi x_lo + W_hi x_hi on six f16 MFMAs; V = 0 forms x_lo with
 //         v_fma_mixlo / mixhi_f16 (4 instructions per register pair; the mix-to-half forms do not issue in an MFMA's shadow:
 //         tools/probe/issue_probe.hip), V = 1 with 2 x v_fma_mix_f32 + v_cvt_pkrtz_f16_f32 (5 instructions that do);
+//   3     no MLP at all: the staged gather alone, the sampled features written out (vt_sample_grid over a lattice slab)
 //   2     "f16f8": W_hi x_hi on two f16 MFMAs + ONE fp8 (e4m3) 32x32x64 MFMA for both correction products -- k-slots 0..15 of a lane
 //         half pair W_lo 2^(11+SW) with x_hi 2^-SX, k-slots 16..31 W_hi 2^SW with x_lo 2^(11-SX), the MFMA's block scales undo the
 //         shifts -- 128 matrix cycles per layer instead of 192 at 40 % less matrix-pipe energy (tools/probe/shape_probe.hip); the
@@ -178,7 +179,7 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
     const ClockStamp stamp = clock_begin(a.clk);
     // V = 2: MODE.FP16_OVFL = 1 -- the fp8 conversions then saturate at +-448 instead of producing NaN (hwreg MODE = 1, bit 23)
     if constexpr (V == 2) __builtin_amdgcn_s_setreg((1 - 1) << 11 | 23 << 6 | 1, 1);
-    {
+    if constexpr (V != 3) {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(a.blob);
         f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
         for (int i = threadIdx.x; i < VT_BLOB_FLOATS / 4; i += ST3_THREADS) dst[i] = src[i];
@@ -385,6 +386,10 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
         next_tile = claim();
         if (next_tile < t_end) fetch(next_tile, ox, oy, oz);
 
+        if constexpr (V == 3) {                                         // sample only: a.out is [points of the slab][32]
+            store_gather16(a.out + (size_t)gA * 32, cA, h);
+            store_gather16(a.out + (size_t)gB * 32, cB, h);
+        } else {
         // ---- fc_p operands: the point's coordinates as half pairs from the per-axis table ----
         u32x4 pA, pB;
         {
@@ -447,6 +452,7 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
 #include "decode_st3_f16x3.inc"
             ST3_RUN_BLOCKS();
         }
+        }                                                                // V != 3
     }
     range_report(rmax, a.status, V == 2);
     if constexpr (V == 2) {

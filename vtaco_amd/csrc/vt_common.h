@@ -41,6 +41,9 @@ unsigned *vt_decode_status_dev();
 static inline unsigned long long *status_clk(unsigned *status) {
     return status ? reinterpret_cast<unsigned long long *>(status + 2) : nullptr;
 }
+// the staged lattice gather alone (decode_f16.o; vt_sample_grid tries it first): *covered = 0 when the slab is not of its shape
+__attribute__((visibility("hidden"))) int vt_st3_sample_lattice(const float *grid_cl, int B, int R, int C, int64_t N, int nx, float box, int64_t first,
+                                                                   double padding, float *feat, void *stream, int *covered);
 // capture-safe replacement of hipMemsetAsync (memset nodes misbehaved under hipGraph replay on ROCm 7.0/7.2):
 // fills `bytes` (multiple of 4) at `dst` with the 32-bit pattern
 int vt_fill32(void *dst, unsigned pattern, size_t bytes, hipStream_t stream);

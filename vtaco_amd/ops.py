@@ -886,15 +886,20 @@ def decode_bwd_wide(grid_shape, blob_t, grad_out, save, pts, hidden, nb, leaky, 
 # --------------------------------------------------------------------------------------
 # AttentionDecoder pieces: sample-only, MLP-only, TransformerFusion
 # --------------------------------------------------------------------------------------
-def sample_grid(grid, pts, padding=0.1):
-    """Trilinear features [B,N,C] of ``grid`` at ``pts`` (vt_sample_grid)."""
+def sample_grid(grid, pts=None, padding=0.1, lattice=None):
+    """Trilinear features [B,N,C] of ``grid`` at ``pts`` [B,N,3], or with ``lattice=(nx, box, first, count)`` at the points
+    ``box * make_3d_grid(...)[first:first+count]`` generated in the kernel (vt_sample_grid; slabs of whole x-plane pairs with
+    nx % 8 == 0 and < 0.55 voxels per step run the LDS-staged gather: the same bits, ~2.5x the rate)."""
     B, C, D, H, W = grid.shape
     keep, gptr = _cl_storage(grid)
-    pts = _c(pts.float())
-    N = pts.shape[1]
+    if pts is not None:
+        pts = _c(pts.float())
+        N, nx, box, first = pts.shape[1], 0, 0.0, 0
+    else:
+        nx, box, first, N = lattice
     feat = torch.empty((B, N, C), dtype=torch.float32, device=grid.device)
     if N:
-        check(_lib.load().vt_sample_grid(gptr, B, D, C, dev_ptr(pts, "pts"), N, 0, 0.0, 0, float(padding),
+        check(_lib.load().vt_sample_grid(gptr, B, D, C, dev_ptr(pts, "pts"), N, int(nx), float(box), int(first), float(padding),
                                          dev_ptr(feat, "feat"), stream_ptr()), "vt_sample_grid")
     return feat
 
