@@ -159,7 +159,7 @@ def test_sample_grid_over_lattice_slabs_equals_the_point_form():
     aligned slab, and an unaligned range (direct gather)."""
     from vtaco_amd import ops
     from vtaco_amd.common import make_3d_grid
-    dev = torch.device(DEV)
+    dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(3)
     for nx, R in ((64, 32), (128, 64)):
         grid = ops.grid_to_channels_last(torch.randn(1, 32, R, R, R, generator=g).to(dev))
@@ -169,3 +169,22 @@ def test_sample_grid_over_lattice_slabs_equals_the_point_form():
             want = ops.sample_grid(grid, pts[first:first + count].unsqueeze(0))
             got = ops.sample_grid(grid, None, lattice=(nx, 1.1, first, count))
             assert got.shape == want.shape and torch.equal(got, want), (nx, first, count)
+
+
+def test_lattice_decode_equals_point_decode_at_full_size():
+    """The in-kernel lattice is torch's linspace to the bit (one rounding per element, as its CPU kernel evaluates start + step i), so
+    the exact-f32 lattice decode of 64^3 / 128^3 / 256^3 slabs equals the decode of the explicit points of generation.py:155-157 --
+    logit for logit -- not only at the goldens' 32^3 (where a separate multiply and add happens to round the same way)."""
+    from vtaco_amd import ops
+    from vtaco_amd.bench_util import build_scene
+    from vtaco_amd.common import make_3d_grid
+    dev = torch.device("cuda:0")
+    sc = build_scene(0, dev)
+    dec, grid = sc["model"].decoder, sc["grid"]
+    for nx in (64, 128, 256):
+        pts = (1.1 * make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3))
+        first, count = (nx // 2) * nx * nx, 4 * nx * nx                # four x-planes from the middle of the lattice
+        with torch.no_grad():
+            lat = dec.decode_lattice(grid, nx, first=first, count=count, precision="f32").reshape(-1)
+            pnt = dec(pts[first:first + count].unsqueeze(0).to(dev), {"grid": grid}).reshape(-1)
+        assert torch.equal(lat, pnt), nx

@@ -322,7 +322,11 @@ __device__ __forceinline__ void lattice_point(const DecodeArgs &a, uint32_t ix, 
     const float step = 1.0f / (float)(a.nx - 1);
     const int half = a.nx / 2;
     auto lin = [&](int i) {
-        float v = (i < half) ? (-0.5f + step * (float)i) : (0.5f - step * (float)(a.nx - i - 1));
+        // ONE rounding per element, as torch's CPU linspace kernel evaluates start + step * i (a fused multiply-add: against
+        // torch 2.10 -- the oracle's and the goldens' arithmetic -- 0 mismatching indices for nx = 32 .. 256; a separate multiply
+        // and add differs in the last bit on 28 / 42 / 124 of the 64 / 128 / 256 indices of an axis, which moves sampled features by
+        // up to 2e-5 on a rough grid)
+        float v = (i < half) ? fmaf(step, (float)i, -0.5f) : fmaf(-step, (float)(a.nx - i - 1), 0.5f);
         return a.box * v;
     };
     px = lin((int)ix); py = lin((int)iy); pz = lin((int)iz);
