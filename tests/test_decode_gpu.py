@@ -188,3 +188,30 @@ def test_lattice_decode_equals_point_decode_at_full_size():
             lat = dec.decode_lattice(grid, nx, first=first, count=count, precision="f32").reshape(-1)
             pnt = dec(pts[first:first + count].unsqueeze(0).to(dev), {"grid": grid}).reshape(-1)
         assert torch.equal(lat, pnt), nx
+
+
+def test_lattice_launches_leave_their_clock_stamps():
+    """bench.py's clock evidence (vt_decode_last_clock): every lattice launch stamps its workgroups' lifetimes with the constant-rate
+    counter and workgroup 0's with the shader clock.  The stamps of the last launch: a clock between 0.5 and 3 GHz, all workgroups
+    started within a few microseconds, and a span that agrees with the launch's HIP-event time."""
+    from vtaco_amd import ops
+    from vtaco_amd.bench_util import build_scene
+    dev = torch.device("cuda:0")
+    sc = build_scene(0, dev)
+    dec, grid = sc["model"].decoder, sc["grid"]
+    for prec in ("f16x3", "f32"):
+        with torch.no_grad():
+            for _ in range(20):
+                dec.decode_lattice(grid, 128, precision=prec)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dec.decode_lattice(grid, 128, precision=prec)
+            e1.record()
+            torch.cuda.synchronize()
+        c = ops.decode_last_clock(workgroups=True)
+        assert c is not None and c["workgroups"] >= 8 and len(c["wg_ticks"]) == c["workgroups"]
+        assert 500.0 < c["shader_mhz"] < 3000.0, c["shader_mhz"]
+        assert c["start_spread_us"] < 20.0 and c["wg_us_min"] > 0.0 and c["wg_us_max"] <= c["span_us"] + 1e-6
+        ms = e0.elapsed_time(e1)
+        assert 0.5 * ms <= c["span_us"] * 1e-3 <= 1.05 * ms, (prec, c["span_us"], ms)
