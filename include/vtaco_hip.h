@@ -509,6 +509,8 @@ typedef struct vt_unet3d_conv {
                                  /* split-bf16 operands where vt_conv3d_stat_blocks_bf16x3(...) != 0, exact f32 elsewhere */
     const float *packed_f16x3;   /* vt_conv3d_pack_f16x3(conv.weight) or NULL: where vt_conv3d_stat_blocks_f16x3(...) != 0 this conv runs */
                                  /* the persistent split-f16 kernel (takes precedence over packed_bf16x3)                              */
+    const float *packed_f16x3_thin; /* vt_conv3d_pack_f16x3_thin(conv.weight) or NULL: the shapes of packed_bf16x3 (the thin-tile and */
+                                 /* K-split kernels) on IEEE-half pairs instead of bf16 pairs; takes precedence over packed_bf16x3     */
 } vt_unet3d_conv;
 typedef struct vt_unet3d_params {
     int32_t n_levels;     /* len(f_maps) */
@@ -540,6 +542,16 @@ int vt_conv3d_gcr_bf16x3(const float *skip, int C1, const float *low, int C2, in
 /* weights as vt_conv3d_gcr_bf16x3.  workspace_bytes / stat_blocks return 0 where the plain kernels already fill the chip   */
 /* (fewer than eight 16-channel blocks, or VTACO_CONV_KSPLIT=0): use them there.  One scene, both launches: 384->128 at   */
 /* 16^3 77 -> 40 us, 128->128 at 16^3 29 -> 22 us, 128->128 / 128->256 at 8^3 33 -> 13 us (f32 K-split kernel before).          */
+/* The same two kernels on IEEE-half hi + lo pairs (21-22 mantissa bits instead of 16; same fragment layout, sizes, coverage and    */
+/* arguments): for the thin levels of a network whose large levels run the split-f16 kernels -- with bf16 pairs there they were  */
+/* most of the encoder's remaining drift against the f32 reference.  Inputs are GroupNorm outputs: inside the half range.        */
+int vt_conv3d_pack_f16x3_thin(const float *w, int Cout, int Cin, float *packed, void *stream);
+int vt_conv3d_gcr_f16x3_thin(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                             const float *scale_shift, const float *packed_w_f16x3_thin, int Cout, int relu, float *out,
+                             float *out_part, void *stream);
+int vt_conv3d_gcr_f16x3_thin_ksplit(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                                    const float *scale_shift, const float *packed_w_f16x3_thin, int Cout, int relu, float *out,
+                                    float *out_part, void *workspace, size_t workspace_bytes, void *stream);
 size_t vt_conv3d_ksplit_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int vt_conv3d_stat_blocks_ksplit(int B, int D, int H, int W, int Cin, int Cout);
 int vt_conv3d_gcr_bf16x3_ksplit(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,

@@ -62,7 +62,7 @@ class UnetConv(ctypes.Structure):
     """Mirror of ``vt_unet3d_conv``."""
     _fields_ = [("gn_w", ctypes.c_void_p), ("gn_b", ctypes.c_void_p), ("packed", ctypes.c_void_p),
                 ("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("packed_bf16x3", ctypes.c_void_p),
-                ("packed_f16x3", ctypes.c_void_p)]
+                ("packed_f16x3", ctypes.c_void_p), ("packed_f16x3_thin", ctypes.c_void_p)]
 
 
 class UnetParams(ctypes.Structure):
@@ -185,6 +185,9 @@ SIGNATURES = {
     "vt_conv3d_ksplit_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "vt_conv3d_stat_blocks_ksplit": (_I, [_I, _I, _I, _I, _I, _I]),
     "vt_conv3d_gcr_bf16x3_ksplit": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
+    "vt_conv3d_gcr_f16x3_thin_ksplit": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
+    "vt_conv3d_gcr_f16x3_thin": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),
+    "vt_conv3d_pack_f16x3_thin": (_I, [_VP, _I, _I, _VP, _VP]),
     "vt_channel_stats": (_I, [_VP, _I, _I64, _I, _I, _VP, _VP]),
     "vt_gn_scale_shift": (_I, [_VP, _I, _I, _VP, _I, _I, _I, _I64, _I, _VP, _VP, _D, _VP, _VP]),
     "vt_conv3d_gcr": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),

@@ -545,9 +545,11 @@ constexpr int sb_rows(int TZ) { return (TZ + 2) * 10 * SB_PX; }
 constexpr int sb_threads(int TZ) { return 128 * TZ; }
 constexpr int sb_iters(int TZ) { return ((TZ + 2) * 100 * 4 + sb_threads(TZ) - 1) / sb_threads(TZ); }
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // weights -> [cin/16][tap][cout/32][hi,lo][64 lanes][8 bf16]: lane (co, kg) element e = cin 16q + 8kg + e
-__global__ void conv3d_pack_s_kernel(const float *w, int Cout, int Cin, float *packed, size_t total) {
+// half != 0: the same fragments with IEEE-half hi / lo parts (vt_conv3d_pack_f16x3_thin; conv3d_gcr_s_kernel<.., .., true>)
+__global__ void conv3d_pack_s_kernel(const float *w, int Cout, int Cin, float *packed, size_t total, int half) {
     // one thread per 16-byte fragment
     for (size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (size_t)gridDim.x * blockDim.x) {
         const int l = (int)(f & 63), part = (int)((f >> 6) & 1);
@@ -558,13 +560,17 @@ __global__ void conv3d_pack_s_kernel(const float *w, int Cout, int Cin, float *p
         const int q = (int)(r / 27);
         const int co = cob * 32 + (l & 31), kg = l >> 5;
         bf16x8 v;
+        f16x8 vh;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float x = w[((size_t)co * Cin + 16 * q + 8 * kg + e) * 27 + tap];
             const __bf16 hb = (__bf16)x;
             v[e] = part ? (__bf16)(x - (float)hb) : hb;
+            const _Float16 hh = (_Float16)x;
+            vh[e] = part ? (_Float16)(x - (float)hh) : hh;
         }
-        reinterpret_cast<bf16x8 *>(packed)[f] = v;
+        if (half) reinterpret_cast<f16x8 *>(packed)[f] = vh;
+        else reinterpret_cast<bf16x8 *>(packed)[f] = v;
     }
 }
 
@@ -576,9 +582,15 @@ constexpr size_t sb_lds(int TZ) { return (size_t)sb_rows(TZ) * SB_ROW + (size_t)
 // accumulators go to a.kws[blockIdx.z] and conv_ksum_kernel adds them up in slice order (ReLU and the statistics move there).
 // For the thin levels of ONE scene (16^3, 8^3): 16-128 output tiles cannot fill 256 CUs, and a workgroup that walks 24
 // channel blocks alone is a 77 us chain (384 -> 128 at 16^3).
-template <int TZ, bool KSPLIT = false>
+// HALF: the operands as IEEE-half hi / lo pairs instead of bf16 pairs (21-22 mantissa bits instead of 16; the inputs are GroupNorm
+// outputs and conv weights, inside the half range): the thin levels of a network whose large levels run the split-f16 kernels -- the
+// 16^3-class levels on bf16 pairs were most of the encoder's remaining drift
+template <int TZ, bool KSPLIT = false, bool HALF = false>
 __global__ void __launch_bounds__(sb_threads(TZ))
 conv3d_gcr_s_kernel(ConvArgs a) {
+    typedef typename std::conditional<HALF, f16x8, bf16x8>::type e8;
+    typedef typename std::conditional<HALF, f16x4, bf16x4>::type e4;
+    typedef typename std::conditional<HALF, _Float16, __bf16>::type e1;
     constexpr int SB_ROWS = sb_rows(TZ), SB_THREADS = sb_threads(TZ), SB_ITERS = sb_iters(TZ), SB_WITERS = sb_witers(TZ);
     constexpr int NVOX = (TZ + 2) * 100;                            // padded tile voxels
     extern __shared__ __attribute__((aligned(16))) char stile[];    // [SB_ROWS x SB_ROW input][27 x 2 KB weights]; then stats scratch
@@ -596,7 +608,7 @@ conv3d_gcr_s_kernel(ConvArgs a) {
     const int lx = j & 3, ly = j >> 2;
     const int wz = wave >> 1, wx = (wave & 1) * 4;
     const int center = ((wz + 1) * 10 + (ly + 1)) * SB_PX + (lx + wx + 1);
-    bf16x8 *wlds = reinterpret_cast<bf16x8 *>(stile + (size_t)SB_ROWS * SB_ROW);
+    e8 *wlds = reinterpret_cast<e8 *>(stile + (size_t)SB_ROWS * SB_ROW);
     float *ssl = reinterpret_cast<float *>(stile + (size_t)SB_ROWS * SB_ROW + (size_t)SB_WFRAGS * 16);   // GnIn: the layer's scale / shift table
 
     // ---- staging plan (the same for every channel block): thread -> (voxel, 4 of the 16 channels) ----
@@ -616,7 +628,7 @@ conv3d_gcr_s_kernel(ConvArgs a) {
         if (in) inside |= 1u << it;
     }
     f32x4 pre[SB_ITERS];
-    bf16x8 wpre[SB_WITERS];
+    e8 wpre[SB_WITERS];
     auto fetch = [&](int q) {                      // next 16 input channels and their 27 taps of weights -> registers
         const int ch = q * 16 + sc4;
         const bool from_low = ch >= s.C1;
@@ -629,7 +641,7 @@ conv3d_gcr_s_kernel(ConvArgs a) {
             }
             pre[it] = val;
         }
-        const bf16x8 *wq = reinterpret_cast<const bf16x8 *>(a.wp) + ((size_t)q * 27 * nco_all + co_blk) * 128;
+        const e8 *wq = reinterpret_cast<const e8 *>(a.wp) + ((size_t)q * 27 * nco_all + co_blk) * 128;
 #pragma unroll
         for (int it = 0; it < SB_WITERS; ++it) {
             const int f = threadIdx.x + it * SB_THREADS;
@@ -650,16 +662,16 @@ conv3d_gcr_s_kernel(ConvArgs a) {
         for (int it = 0; it < SB_ITERS; ++it) {
             if (lrow[it] < 0) continue;
             const bool in = inside >> it & 1u;
-            bf16x4 hi, lo;
+            e4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float x = in ? fmaf(pre[it][e], sc[e], sh[e]) : 0.0f;
-                const __bf16 hb = (__bf16)x;
+                const e1 hb = (e1)x;
                 hi[e] = hb;
-                lo[e] = (__bf16)(x - (float)hb);
+                lo[e] = (e1)(x - (float)hb);
             }
-            *reinterpret_cast<bf16x4 *>(stile + lrow[it]) = hi;
-            *reinterpret_cast<bf16x4 *>(stile + lrow[it] + 32) = lo;
+            *reinterpret_cast<e4 *>(stile + lrow[it]) = hi;
+            *reinterpret_cast<e4 *>(stile + lrow[it] + 32) = lo;
         }
 #pragma unroll
         for (int it = 0; it < SB_WITERS; ++it) {
@@ -685,14 +697,14 @@ conv3d_gcr_s_kernel(ConvArgs a) {
         // the four operand fragments of tap t+1 are requested before the three MFMAs of tap t issue: one LDS latency
         // per tap hides under the matrix pipe instead of two being exposed in front of it (two taps ahead spills the
         // 16-wave kernel past its 128 registers and was slower)
-        struct TapOps { bf16x8 wh, wl, xh, xl; };
+        struct TapOps { e8 wh, wl, xh, xl; };
         auto tap_ops = [&](int tap) {
             TapOps o;
             o.wh = wlds[tap * 128 + lane]; o.wl = wlds[tap * 128 + 64 + lane];
             const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
             const char *xin = stile + (center + (dz * 10 + dy) * SB_PX + dx) * SB_ROW + kg * 16;
-            o.xh = *reinterpret_cast<const bf16x8 *>(xin);
-            o.xl = *reinterpret_cast<const bf16x8 *>(xin + 32);
+            o.xh = *reinterpret_cast<const e8 *>(xin);
+            o.xl = *reinterpret_cast<const e8 *>(xin + 32);
             return o;
         };
         TapOps cur = tap_ops(0);
@@ -701,9 +713,9 @@ conv3d_gcr_s_kernel(ConvArgs a) {
             TapOps nxt = cur;
             if (tap + 1 < 27) nxt = tap_ops(tap + 1);
             __builtin_amdgcn_sched_barrier(0);                     // keep the requests ahead of the MFMAs (the scheduler sinks them otherwise)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.wl, cur.xh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.wh, cur.xl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.wh, cur.xh, acc, 0, 0, 0);
+            acc = mfma_s(cur.wl, cur.xh, acc);                     // (decode_common.h: the bf16 or the f16 32x32x16 MFMA by operand type)
+            acc = mfma_s(cur.wh, cur.xl, acc);
+            acc = mfma_s(cur.wh, cur.xh, acc);
             __builtin_amdgcn_sched_barrier(0);
             cur = nxt;
         }
@@ -795,8 +807,12 @@ constexpr int S4_WITERS = (S4_SLAB + S4_THREADS - 1) / S4_THREADS;             /
 constexpr size_t S4_LDS = (size_t)S4_ROWS * SB_ROW + (size_t)S4_SLAB * 16 + (size_t)GN_MAX_CIN * 2 * sizeof(float);
 static_assert(S4_LDS <= 80 * 1024, "two workgroups must fit the 160 KB of a CU");
 
+template <bool HALF = false>
 __global__ void __launch_bounds__(S4_THREADS, 4)        // second argument: waves per SIMD (HIP), i.e. two workgroups per CU -> 128 registers
 conv3d_gcr_s4_kernel(ConvArgs a) {
+    typedef typename std::conditional<HALF, f16x8, bf16x8>::type e8;
+    typedef typename std::conditional<HALF, f16x4, bf16x4>::type e4;
+    typedef typename std::conditional<HALF, _Float16, __bf16>::type e1;
     extern __shared__ __attribute__((aligned(16))) char stile[];    // [S4_ROWS x SB_ROW input][9 x 2 KB weights]; then stats scratch
     const Src &s = a.s;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -812,7 +828,7 @@ conv3d_gcr_s4_kernel(ConvArgs a) {
     const int lx = j & 3, ly = j >> 2;
     const int wz = wave >> 1, wx = (wave & 1) * 4;
     const int center = ((wz + 1) * 10 + (ly + 1)) * SB_PX + (lx + wx + 1);
-    bf16x8 *wlds = reinterpret_cast<bf16x8 *>(stile + (size_t)S4_ROWS * SB_ROW);
+    e8 *wlds = reinterpret_cast<e8 *>(stile + (size_t)S4_ROWS * SB_ROW);
     float *ssl = reinterpret_cast<float *>(stile + (size_t)S4_ROWS * SB_ROW + (size_t)S4_SLAB * 16);     // GnIn: the layer's scale / shift table
     if (a.stat_in.acc[0]) gn_in_scale_shift(a.stat_in, b, 1.0f, ssl, stile, threadIdx.x, S4_THREADS);
 
@@ -832,7 +848,7 @@ conv3d_gcr_s4_kernel(ConvArgs a) {
         if (in) inside |= 1u << it;
     }
     f32x4 pre[S4_ITERS];
-    bf16x8 wpre[S4_WITERS];
+    e8 wpre[S4_WITERS];
     auto fetch_in = [&](int q) {                   // next 16 input channels -> registers
         const int ch = q * 16 + sc4;
         const bool from_low = ch >= s.C1;
@@ -847,7 +863,7 @@ conv3d_gcr_s4_kernel(ConvArgs a) {
         }
     };
     auto fetch_w = [&](int q, int slab) {          // nine taps of weights of channel block q -> registers
-        const bf16x8 *wq = reinterpret_cast<const bf16x8 *>(a.wp) + (((size_t)q * 27 + slab * 9) * nco_all + co_blk) * 128;
+        const e8 *wq = reinterpret_cast<const e8 *>(a.wp) + (((size_t)q * 27 + slab * 9) * nco_all + co_blk) * 128;
 #pragma unroll
         for (int it = 0; it < S4_WITERS; ++it) {
             const int f = threadIdx.x + it * S4_THREADS;
@@ -868,16 +884,16 @@ conv3d_gcr_s4_kernel(ConvArgs a) {
         for (int it = 0; it < S4_ITERS; ++it) {
             if (lrow[it] < 0) continue;
             const bool in = inside >> it & 1u;
-            bf16x4 hi, lo;
+            e4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float x = in ? fmaf(pre[it][e], sc[e], sh[e]) : 0.0f;
-                const __bf16 hb = (__bf16)x;
+                const e1 hb = (e1)x;
                 hi[e] = hb;
-                lo[e] = (__bf16)(x - (float)hb);
+                lo[e] = (e1)(x - (float)hb);
             }
-            *reinterpret_cast<bf16x4 *>(stile + lrow[it]) = hi;
-            *reinterpret_cast<bf16x4 *>(stile + lrow[it] + 32) = lo;
+            *reinterpret_cast<e4 *>(stile + lrow[it]) = hi;
+            *reinterpret_cast<e4 *>(stile + lrow[it] + 32) = lo;
         }
     };
     auto commit_w = [&]() {
@@ -891,15 +907,15 @@ conv3d_gcr_s4_kernel(ConvArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    struct TapOps { bf16x8 wh, wl, xh, xl; };
+    struct TapOps { e8 wh, wl, xh, xl; };
     auto run_slab = [&](int slab) {                // nine taps: dz = slab - 1
         auto tap_ops = [&](int tl) {
             TapOps o;
             o.wh = wlds[tl * 128 + lane]; o.wl = wlds[tl * 128 + 64 + lane];
             const int dy = tl / 3 - 1, dx = tl % 3 - 1;
             const char *xin = stile + (center + ((slab - 1) * 10 + dy) * SB_PX + dx) * SB_ROW + kg * 16;
-            o.xh = *reinterpret_cast<const bf16x8 *>(xin);
-            o.xl = *reinterpret_cast<const bf16x8 *>(xin + 32);
+            o.xh = *reinterpret_cast<const e8 *>(xin);
+            o.xl = *reinterpret_cast<const e8 *>(xin + 32);
             return o;
         };
         TapOps cur = tap_ops(0);
@@ -908,9 +924,9 @@ conv3d_gcr_s4_kernel(ConvArgs a) {
             TapOps nxt = cur;
             if (tl + 1 < 9) nxt = tap_ops(tl + 1);
             __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.wl, cur.xh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.wh, cur.xl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.wh, cur.xh, acc, 0, 0, 0);
+            acc = mfma_s(cur.wl, cur.xh, acc);
+            acc = mfma_s(cur.wh, cur.xl, acc);
+            acc = mfma_s(cur.wh, cur.xh, acc);
             __builtin_amdgcn_sched_barrier(0);
             cur = nxt;
         }
@@ -991,7 +1007,6 @@ constexpr size_t hb_img_bytes(int TZ) { return (size_t)hb_rows(TZ) * 32; }      
 constexpr int HB_MAX_CIN = 512;                                                                          // scale / shift table in LDS
 constexpr size_t hb_lds(int TZ) { return 2 * hb_img_bytes(TZ) + 2 * (size_t)HB_WFRAGS * 16 + (size_t)2 * TZ * 64 * sizeof(float) + HB_MAX_CIN * 2 * sizeof(float); }
 static_assert(hb_lds(8) <= 160 * 1024, "split-f16 conv: LDS budget");
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // weights -> [cin/8][cout/32][k-step 0..13][hi,lo][64 lanes][8 halves]: lane (co, kg), element e = cin 8q + e of tap 2s + kg
 __global__ void conv3d_pack_h_kernel(const float *w, int Cout, int Cin, float *packed, size_t total) {
@@ -1904,7 +1919,7 @@ int vt_conv3d_pack_bf16x3(const float *w, int Cout, int Cin, float *packed, void
     const size_t frags = (size_t)27 * Cout * Cin / 4;              // 16-byte fragments: hi and lo of every 8 cin
     size_t g = (frags + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(conv3d_pack_s_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, packed, frags);
+    hipLaunchKernelGGL(conv3d_pack_s_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, packed, frags, 0);
     return vt_check(hipGetLastError(), "vt_conv3d_pack_bf16x3");
 }
 
@@ -1912,9 +1927,10 @@ int vt_conv3d_stat_blocks_bf16x3(int B, int D, int H, int W, int Cin, int Cout) 
     return conv_s_eligible(B, D, H, W, Cin, Cout) ? (D / conv_s_tz(B, D, H, W, Cout)) * (H / 8) * (W / 8) : 0;
 }
 
+// half: the packed weights and the kernel's operands are IEEE-half pairs (vt_conv3d_pack_f16x3_thin) instead of bf16 pairs
 static int conv_s_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                          const float *scale_shift, const float *packed_w_bf16x3, int Cout, int relu, float *out,
-                         float *out_part, const GnIn &stat_in, const GnOut &stat_out, void *stream) {
+                         float *out_part, const GnIn &stat_in, const GnOut &stat_out, void *stream, bool half = false) {
     ConvArgs a;
     a.stat_in = stat_in; a.stat_out = stat_out;
     a.s = Src{skip, low, C1, low ? C2 : 0, D, H, W};
@@ -1930,19 +1946,24 @@ static int conv_s_launch(const float *skip, int C1, const float *low, int C2, in
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4_LDS);
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_bf16x3: hipFuncSetAttribute");
         attr = true;
     }
+    hipStream_t st = (hipStream_t)stream;
     if (tz == 4) {
-        static bool attr4 = false;
-        if (!attr4) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4_LDS);
-            if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_bf16x3: hipFuncSetAttribute");
-            attr4 = true;
-        }
-        hipLaunchKernelGGL(conv3d_gcr_s4_kernel, grid, dim3(S4_THREADS), S4_LDS, (hipStream_t)stream, a);
-    } else if (tz == 8) hipLaunchKernelGGL(conv3d_gcr_s_kernel<8>, grid, dim3(sb_threads(8)), sb_lds(8), (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(conv3d_gcr_s_kernel<2>, grid, dim3(sb_threads(2)), sb_lds(2), (hipStream_t)stream, a);
+        if (half) hipLaunchKernelGGL(conv3d_gcr_s4_kernel<true>, grid, dim3(S4_THREADS), S4_LDS, st, a);
+        else hipLaunchKernelGGL(conv3d_gcr_s4_kernel<false>, grid, dim3(S4_THREADS), S4_LDS, st, a);
+    } else if (tz == 8) {
+        if (half) hipLaunchKernelGGL((conv3d_gcr_s_kernel<8, false, true>), grid, dim3(sb_threads(8)), sb_lds(8), st, a);
+        else hipLaunchKernelGGL(conv3d_gcr_s_kernel<8>, grid, dim3(sb_threads(8)), sb_lds(8), st, a);
+    } else {
+        if (half) hipLaunchKernelGGL((conv3d_gcr_s_kernel<2, false, true>), grid, dim3(sb_threads(2)), sb_lds(2), st, a);
+        else hipLaunchKernelGGL(conv3d_gcr_s_kernel<2>, grid, dim3(sb_threads(2)), sb_lds(2), st, a);
+    }
     return vt_check(hipGetLastError(), "vt_conv3d_gcr_bf16x3");
 }
 
@@ -1966,7 +1987,8 @@ int vt_conv3d_stat_blocks_ksplit(int B, int D, int H, int W, int Cin, int Cout) 
 
 static int conv_sk_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                           const float *scale_shift, const float *packed_w_bf16x3, int Cout, int relu, float *out,
-                          float *out_part, const GnIn &stat_in, const GnOut &stat_out, void *workspace, size_t workspace_bytes, void *stream) {
+                          float *out_part, const GnIn &stat_in, const GnOut &stat_out, void *workspace, size_t workspace_bytes, void *stream,
+                          bool half = false) {
     ConvArgs a;
     a.stat_in = stat_in;
     a.s = Src{skip, low, C1, low ? C2 : 0, D, H, W};
@@ -1985,11 +2007,15 @@ static int conv_sk_launch(const float *skip, int C1, const float *low, int C2, i
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_bf16x3_ksplit: hipFuncSetAttribute");
         attr = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (tz == 8) hipLaunchKernelGGL((conv3d_gcr_s_kernel<8, true>), grid, dim3(sb_threads(8)), sb_lds(8), st, a);
+    if (tz == 8 && half) hipLaunchKernelGGL((conv3d_gcr_s_kernel<8, true, true>), grid, dim3(sb_threads(8)), sb_lds(8), st, a);
+    else if (tz == 8) hipLaunchKernelGGL((conv3d_gcr_s_kernel<8, true>), grid, dim3(sb_threads(8)), sb_lds(8), st, a);
+    else if (half) hipLaunchKernelGGL((conv3d_gcr_s_kernel<2, true, true>), grid, dim3(sb_threads(2)), sb_lds(2), st, a);
     else hipLaunchKernelGGL((conv3d_gcr_s_kernel<2, true>), grid, dim3(sb_threads(2)), sb_lds(2), st, a);
     const dim3 sgrid((unsigned)((size_t)B * D * H * W / KSUM_VOX), (unsigned)(Cout / 32));
 #define VT_KSUM(KS) hipLaunchKernelGGL(conv_ksum_kernel<KS>, sgrid, dim3(256), 0, st, (const float *)workspace, ks, slab, Cout, relu, out, out_part, \
@@ -2003,6 +2029,30 @@ int vt_conv3d_gcr_bf16x3_ksplit(const float *skip, int C1, const float *low, int
                                 const float *scale_shift, const float *packed_w_bf16x3, int Cout, int relu, float *out,
                                 float *out_part, void *workspace, size_t workspace_bytes, void *stream) {
     return conv_sk_launch(skip, C1, low, C2, B, D, H, W, scale_shift, packed_w_bf16x3, Cout, relu, out, out_part, GnIn{}, GnOut{}, workspace, workspace_bytes, stream);
+}
+
+// the thin-level kernels (vt_conv3d_gcr_bf16x3 / _ksplit shapes) on IEEE-half pairs: same fragment layout, same sizes, same arguments
+int vt_conv3d_pack_f16x3_thin(const float *w, int Cout, int Cin, float *packed, void *stream) {
+    if (!w || !packed) return vt_fail(VT_ERR_INVALID, "vt_conv3d_pack_f16x3_thin: null argument");
+    if (!vt_conv3d_packed_floats(Cout, Cin)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_pack_f16x3_thin: channel counts must be multiples of 32");
+    const size_t frags = (size_t)Cout * Cin * 27 / 4;
+    size_t g = (frags + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(conv3d_pack_s_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, packed, frags, 1);
+    return vt_check(hipGetLastError(), "vt_conv3d_pack_f16x3_thin");
+}
+
+int vt_conv3d_gcr_f16x3_thin(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                             const float *scale_shift, const float *packed_w_f16x3_thin, int Cout, int relu, float *out,
+                             float *out_part, void *stream) {
+    return conv_s_launch(skip, C1, low, C2, B, D, H, W, scale_shift, packed_w_f16x3_thin, Cout, relu, out, out_part, GnIn{}, GnOut{}, stream, true);
+}
+
+int vt_conv3d_gcr_f16x3_thin_ksplit(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                                    const float *scale_shift, const float *packed_w_f16x3_thin, int Cout, int relu, float *out,
+                                    float *out_part, void *workspace, size_t workspace_bytes, void *stream) {
+    return conv_sk_launch(skip, C1, low, C2, B, D, H, W, scale_shift, packed_w_f16x3_thin, Cout, relu, out, out_part, GnIn{}, GnOut{},
+                          workspace, workspace_bytes, stream, true);
 }
 
 size_t vt_conv3d_packed_floats_f16x3(int Cout, int Cin) {
@@ -2202,7 +2252,7 @@ int stat_blocks(int64_t V) {
 enum ConvKind { CONV_F32 = 0, CONV_HALF, CONV_KSPLIT, CONV_SPLIT };
 ConvKind conv_kind(const vt_unet3d_conv &c, int B, int Ri) {
     if (c.packed_f16x3 && conv_h_tz(B, Ri, Ri, Ri, c.cin, c.cout) != 0) return CONV_HALF;
-    if (!c.packed_bf16x3) return CONV_F32;
+    if (!c.packed_bf16x3 && !c.packed_f16x3_thin) return CONV_F32;
     if (vt_conv3d_ksplit_workspace_bytes(B, Ri, Ri, Ri, c.cin, c.cout)) return CONV_KSPLIT;
     return conv_s_eligible(B, Ri, Ri, Ri, c.cin, c.cout) ? CONV_SPLIT : CONV_F32;
 }
@@ -2286,9 +2336,12 @@ int unet3d_run_fold(const float *x_cl, int B, int R, const vt_unet3d_params *p, 
         const float *lx = low ? low->x : nullptr;
         if (kind == CONV_HALF)
             return conv_h_launch(a.x, a.C, lx, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.cout, 1, o.x, nullptr, nullptr, nullptr, nullptr, st, si, so);
+        // the thin levels: IEEE-half pairs where the caller packed them (a network whose large levels run the split-f16 kernels)
+        const bool thin_half = c.packed_f16x3_thin != nullptr;
+        const float *thin_w = thin_half ? c.packed_f16x3_thin : c.packed_bf16x3;
         if (kind == CONV_KSPLIT)
-            return conv_sk_launch(a.x, a.C, lx, C2, B, Ri, Ri, Ri, ss, c.packed_bf16x3, c.cout, 1, o.x, nullptr, si, so, kws, ksbytes, st);
-        return conv_s_launch(a.x, a.C, lx, C2, B, Ri, Ri, Ri, ss, c.packed_bf16x3, c.cout, 1, o.x, nullptr, si, so, st);
+            return conv_sk_launch(a.x, a.C, lx, C2, B, Ri, Ri, Ri, ss, thin_w, c.cout, 1, o.x, nullptr, si, so, kws, ksbytes, st, thin_half);
+        return conv_s_launch(a.x, a.C, lx, C2, B, Ri, Ri, Ri, ss, thin_w, c.cout, 1, o.x, nullptr, si, so, st, thin_half);
     };
     Tensor skips[VT_UNET_MAX_LEVELS];
     Tensor cur;
@@ -2379,8 +2432,10 @@ int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char 
         o.C = c.cout;
         o.x = ws.take((size_t)B * Ri * Ri * Ri * c.cout);
         const bool half = c.packed_f16x3 && conv_h_tz(B, Ri, Ri, Ri, c.cin, c.cout) != 0;
-        const size_t ksbytes = (!half && c.packed_bf16x3) ? vt_conv3d_ksplit_workspace_bytes(B, Ri, Ri, Ri, c.cin, c.cout) : 0;
-        const bool split = !half && !ksbytes && c.packed_bf16x3 && conv_s_eligible(B, Ri, Ri, Ri, c.cin, c.cout);
+        const bool thin_half = c.packed_f16x3_thin != nullptr;
+        const float *thin_w = thin_half ? c.packed_f16x3_thin : c.packed_bf16x3;
+        const size_t ksbytes = (!half && thin_w) ? vt_conv3d_ksplit_workspace_bytes(B, Ri, Ri, Ri, c.cin, c.cout) : 0;
+        const bool split = !half && !ksbytes && thin_w && conv_s_eligible(B, Ri, Ri, Ri, c.cin, c.cout);
         o.nblk = half ? vt_conv3d_stat_blocks_f16x3(B, Ri, Ri, Ri, c.cin, c.cout)
                       : ksbytes ? vt_conv3d_stat_blocks_ksplit(B, Ri, Ri, Ri, c.cin, c.cout)
                       : split ? vt_conv3d_stat_blocks_bf16x3(B, Ri, Ri, Ri, c.cin, c.cout) : vt_conv3d_stat_blocks(B, Ri, Ri, Ri, c.cin, c.cout);
@@ -2394,10 +2449,10 @@ int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char 
         if (half)
             return vt_conv3d_gcr_f16x3(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.cout, 1, o.x, o.part, st);
         if (ksbytes)
-            return vt_conv3d_gcr_bf16x3_ksplit(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed_bf16x3, c.cout, 1, o.x, o.part,
-                                               kws, ksbytes, st);
+            return conv_sk_launch(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, thin_w, c.cout, 1, o.x, o.part, GnIn{}, GnOut{},
+                                  kws, ksbytes, st, thin_half);
         if (split)
-            return vt_conv3d_gcr_bf16x3(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed_bf16x3, c.cout, 1, o.x, o.part, st);
+            return conv_s_launch(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, thin_w, c.cout, 1, o.x, o.part, GnIn{}, GnOut{}, st, thin_half);
         return vt_conv3d_gcr(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed, c.cout, 1, o.x, o.part, st);
     };
     Tensor skips[VT_UNET_MAX_LEVELS];

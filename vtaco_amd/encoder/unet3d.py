@@ -176,6 +176,9 @@ class UNet3D(nn.Module):
         # deviations of the split-bf16 form flip more of them, ~2 %).  Settable per model: the constructor's ``train_precision`` /
         # ``precision`` keywords (``unet3d_kwargs`` in the config), then these attributes, then the environment.
         self.train_precision = os.environ.get("VTACO_UNET_TRAIN_PRECISION", "f16x3")
+        # inference with precision "f16x3": the thin levels (16^3 / 8^3 of one scene) on IEEE-half pairs too (VTACO_UNET_THIN_HALF=0:
+        # bf16 pairs there, as in rounds 1-3)
+        self.thin_half = os.environ.get("VTACO_UNET_THIN_HALF", "1") != "0"
         for key in ("precision", "train_precision"):            # model-level setting (config: model.encoder_kwargs.unet3d_kwargs)
             if kwargs.get(key) is not None:
                 if kwargs[key] not in ("f32", "bf16x3", "f16x3"):
@@ -206,11 +209,14 @@ class UNet3D(nn.Module):
 
     def _gcr(self, single, x, x_stats, low=None, low_stats=None):
         gn, conv = single.groupnorm, single.conv
-        split = self._packed(conv, "bf16x3") if self.precision in ("bf16x3", "f16x3") else None
+        # "f16x3": IEEE-half pairs on every level -- the persistent kernels where they cover the shape, the thin-tile / K-split
+        # kernels with half-pair fragments below (self.thin_half; bf16 pairs there were most of the encoder's drift)
+        thin_half = self.precision == "f16x3" and self.thin_half
+        split = self._packed(conv, "f16x3_thin" if thin_half else "bf16x3") if self.precision in ("bf16x3", "f16x3") else None
         half = self._packed(conv, "f16x3") if self.precision == "f16x3" else None
         return ops.gn_conv3d_relu(x, x_stats, low, low_stats, gn.weight.detach(), gn.bias.detach(), gn.num_groups,
                                   self._packed(conv), conv.out_channels, eps=gn.eps, relu=True, packed_w_bf16x3=split,
-                                  packed_w_f16x3=half)
+                                  packed_w_f16x3=half, thin_half=thin_half)
 
     def _hip_params(self):
         """vt_unet3d_params for the current weights (re-packed only when a conv weight changed); the filled structure itself is
@@ -222,7 +228,7 @@ class UNet3D(nn.Module):
                 t for blk in list(self.encoders) + list(self.decoders)
                 for single in (blk.basic_module.SingleConv1, blk.basic_module.SingleConv2)
                 for t in (single.groupnorm.weight, single.groupnorm.bias, single.conv.weight)]
-        stamp = (self.precision, os.environ.get("VTACO_UNET_FUSED_FINAL", "1")) + tuple(
+        stamp = (self.precision, self.thin_half, os.environ.get("VTACO_UNET_FUSED_FINAL", "1")) + tuple(
             (id(t), t.data_ptr(), t._version) for t in tensors if t is not None)
         hit = getattr(self, "_prm_cache", None)
         if hit is not None and hit[0] == stamp:
@@ -242,7 +248,11 @@ class UNet3D(nn.Module):
             keep.extend(tensors)
             dst.gn_w, dst.gn_b, dst.packed = (t.data_ptr() for t in tensors)
             dst.cin, dst.cout = conv.in_channels, conv.out_channels
-            if self.precision in ("bf16x3", "f16x3"):
+            if self.precision == "f16x3" and self.thin_half:
+                thin = self._packed(conv, "f16x3_thin")
+                keep.append(thin)
+                dst.packed_f16x3_thin = thin.data_ptr()
+            elif self.precision in ("bf16x3", "f16x3"):
                 split = self._packed(conv, "bf16x3")
                 keep.append(split)
                 dst.packed_bf16x3 = split.data_ptr()

@@ -1106,10 +1106,13 @@ def conv3d_pack(weight, precision="f32"):
     n = lib.vt_conv3d_packed_floats_f16x3(Cout, Cin) if precision == "f16x3" else lib.vt_conv3d_packed_floats(Cout, Cin)
     if n == 0 or tuple(weight.shape[2:]) != (3, 3, 3):
         raise VtError(f"conv3d_pack: unsupported weight shape {tuple(weight.shape)}")
-    if precision not in PRECISIONS:
-        raise VtError(f"precision must be one of {PRECISIONS} (got {precision!r})")
     w = _c(weight)
     out = torch.empty(n, dtype=torch.float32, device=w.device)
+    if precision == "f16x3_thin":      # the thin-tile / K-split kernels' fragments (vt_conv3d_pack_bf16x3's layout) with IEEE-half pairs
+        check(lib.vt_conv3d_pack_f16x3_thin(dev_ptr(w, "w"), Cout, Cin, dev_ptr(out, "packed"), stream_ptr()), "vt_conv3d_pack_f16x3_thin")
+        return out
+    if precision not in PRECISIONS:
+        raise VtError(f"precision must be one of {PRECISIONS} (got {precision!r})")
     if precision in SPLIT_PRECISIONS:
         name = "vt_conv3d_pack_" + precision
         check(getattr(lib, name)(dev_ptr(w, "w"), Cout, Cin, dev_ptr(out, "packed"), stream_ptr()), name)
@@ -1172,10 +1175,11 @@ def gn_scale_shift(x_stats, low_stats, C1, C2, B, voxels, gamma, beta, groups, e
 
 
 def conv3d_gcr(x, low, ss, packed_w, Cout, relu=True, packed_w_bf16x3=None, want_stats=True, packed_w_f16x3=None,
-               in_absmax=None):
+               in_absmax=None, thin_half=False):
     """relu?(conv3x3x3(x_cat * scale + shift)) on channels-last tensors (``ss`` None: no normalisation);
     returns (out, (part, nblk) or None).  With ``packed_w_f16x3`` / ``packed_w_bf16x3`` the convolution runs on the
-    16-bit matrix core with split operands where that kernel covers the shape (f16x3 first)."""
+    16-bit matrix core with split operands where that kernel covers the shape (f16x3 first).  ``thin_half``: ``packed_w_bf16x3``
+    holds conv3d_pack(..., "f16x3_thin") fragments and the thin-tile / K-split kernels run on IEEE-half pairs."""
     lib = _lib.load()
     B, D, H, W, C1 = x.shape
     C2 = low.shape[-1] if low is not None else 0
@@ -1195,14 +1199,17 @@ def conv3d_gcr(x, low, ss, packed_w, Cout, relu=True, packed_w_bf16x3=None, want
             nblk = lib.vt_conv3d_stat_blocks_ksplit(B, D, H, W, C1 + C2, Cout)
             part = torch.empty((B, nblk, Cout, 2), dtype=torch.float32, device=dev) if want_stats else None
             ws = torch.empty(ksbytes // 4, dtype=torch.float32, device=dev)
-            check(lib.vt_conv3d_gcr_bf16x3_ksplit(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
-                                                  dev_ptr(packed_w_bf16x3, "packed_w"), Cout, int(relu), dev_ptr(out, "out"),
-                                                  dev_ptr(part, "part"), ctypes.c_void_p(ws.data_ptr()), ksbytes, st),
-                  "vt_conv3d_gcr_bf16x3_ksplit")
+            kfn = lib.vt_conv3d_gcr_f16x3_thin_ksplit if thin_half else lib.vt_conv3d_gcr_bf16x3_ksplit
+            check(kfn(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
+                      dev_ptr(packed_w_bf16x3, "packed_w"), Cout, int(relu), dev_ptr(out, "out"),
+                      dev_ptr(part, "part"), ctypes.c_void_p(ws.data_ptr()), ksbytes, st),
+                  "vt_conv3d_gcr_f16x3_thin_ksplit" if thin_half else "vt_conv3d_gcr_bf16x3_ksplit")
             return out, ((part, nblk) if want_stats else None)
         nblk = lib.vt_conv3d_stat_blocks_bf16x3(B, D, H, W, C1 + C2, Cout) if packed_w_bf16x3 is not None else 0
         if nblk:
             fn, name, pw = lib.vt_conv3d_gcr_bf16x3, "vt_conv3d_gcr_bf16x3", packed_w_bf16x3
+            if thin_half:
+                fn, name = lib.vt_conv3d_gcr_f16x3_thin, "vt_conv3d_gcr_f16x3_thin"
         else:
             nblk = lib.vt_conv3d_stat_blocks(B, D, H, W, C1 + C2, Cout)
             if callable(pw):
@@ -1220,13 +1227,13 @@ def conv3d_gcr(x, low, ss, packed_w, Cout, relu=True, packed_w_bf16x3=None, want
 
 
 def gn_conv3d_relu(x, x_stats, low, low_stats, gamma, beta, groups, packed_w, Cout, eps=1e-5, relu=True,
-                   packed_w_bf16x3=None, packed_w_f16x3=None):
+                   packed_w_bf16x3=None, packed_w_f16x3=None, thin_half=False):
     """relu(conv3x3x3(GroupNorm([x | upsample(low)]))) on channels-last tensors; the statistics
     come from the producers' partial sums.  Returns (out, out_stats)."""
     B, D, H, W, C1 = x.shape
     C2 = low.shape[-1] if low is not None else 0
     ss = gn_scale_shift(x_stats, low_stats if low is not None else None, C1, C2, B, D * H * W, gamma, beta, groups, eps, x.device)
-    return conv3d_gcr(x, low, ss, packed_w, Cout, relu, packed_w_bf16x3, packed_w_f16x3=packed_w_f16x3)
+    return conv3d_gcr(x, low, ss, packed_w, Cout, relu, packed_w_bf16x3, packed_w_f16x3=packed_w_f16x3, thin_half=thin_half)
 
 
 def relu_mask(dy, y, want_absmax=False):
