@@ -432,3 +432,38 @@ def test_groupnorm_statistics_through_accumulator_rows(monkeypatch):
             assert torch.allclose(got_bad, ref_bad, rtol=0.0, atol=2e-6 * max(1.0, float(ref.abs().max())), equal_nan=True)
             if B > 1:
                 assert torch.equal(got_bad[0], got[0])
+
+
+_CONV_VARIANT_SCRIPT = r"""
+import hashlib, sys, torch
+from vtaco_amd import ops
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(21)
+for B, R, C1, C2, Cout in ((1, 64, 32, 0, 32), (1, 64, 32, 64, 32), (1, 32, 32, 0, 64), (2, 32, 64, 128, 64), (2, 64, 32, 0, 32)):
+    x = (torch.randn(B, R, R, R, C1, generator=g) * (torch.rand(B, R, R, R, 1, generator=g) < 0.3)).to(dev)
+    low = torch.randn(B, R // 2, R // 2, R // 2, C2, generator=g).to(dev) if C2 else None
+    w = (torch.randn(Cout, C1 + C2, 3, 3, 3, generator=g) * 0.05).to(dev)
+    gamma, beta = (1 + 0.2 * torch.randn(C1 + C2, generator=g)).to(dev), (0.2 * torch.randn(C1 + C2, generator=g)).to(dev)
+    xs, ls = ops.channel_stats(x), (ops.channel_stats(low) if C2 else None)
+    out, (part, nblk) = ops.gn_conv3d_relu(x, xs, low, ls, gamma, beta, 8, ops.conv3d_pack(w), Cout, packed_w_f16x3=ops.conv3d_pack(w, precision="f16x3"))
+    assert bool(torch.isfinite(out).all()) and float(out.abs().max()) > 0
+    print(hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest(), hashlib.sha256(part.cpu().numpy().tobytes()).hexdigest(), nblk)
+"""
+
+
+def test_split_f16_conv_variants_agree_bit_for_bit():
+    """The three schedules of the persistent split-f16 conv -- uniform waves (VTACO_CONV_SPEC=0), tap + loader waves (the default) and
+    the staging in the tap waves' own MFMA gaps (=2) -- stage the same LDS images and run the same MFMA order per accumulator: outputs
+    and GroupNorm partial sums must be identical bits (the switch is read once per process, hence the subprocesses)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = {}
+    for spec in ("1", "2", "0"):
+        env = dict(os.environ, VTACO_CONV_SPEC=spec, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", _CONV_VARIANT_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        seen[spec] = [ln for ln in r.stdout.splitlines() if len(ln.split()) == 3]
+        assert len(seen[spec]) == 5, r.stdout
+    assert seen["2"] == seen["1"]
+    # the uniform-wave kernel gives every wave ONE patch: the same products, but its statistics reduce per patch -- outputs identical
+    assert [ln.split()[0] for ln in seen["0"]] == [ln.split()[0] for ln in seen["1"]]

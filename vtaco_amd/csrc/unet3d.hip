@@ -1253,6 +1253,26 @@ conv3d_gcr_h_kernel(HbArgs ha) {
     }
 }
 
+#ifndef VT_HX_ABL
+#define VT_HX_ABL 0     // ablations for timing only (wrong results): 1 = no staging pieces, 2 = no chunk barrier, 4 = no operand reads after a chunk's first
+#endif
+#ifdef VT_DIAG_HB
+// diagnostic build only (tools/build_variant.sh hb "-DVT_DIAG_HB"; tools/diag_conv.py): per-wave shader-clock sums of the kernel's phases
+// (slots 0..13), the wave's lifetime in 100 MHz ticks (14) and in shader-clock counts (15)
+__device__ unsigned long long vt_diag_hb_buf[8192 * 16];
+#define HB_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                         dg_sum[i] += t_ - dg_last; dg_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define HB_DIAG_BEGIN unsigned long long dg_sum[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long dg_last = __builtin_amdgcn_s_memtime(); \
+                      const unsigned long long dg_first = dg_last, dg_real = __builtin_amdgcn_s_memrealtime();
+#define HB_DIAG_END(WAVES) do { if (lane == 0) { unsigned long long *d_ = vt_diag_hb_buf + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * (WAVES) + wave) * 16; \
+                         for (int i_ = 0; i_ < 14; ++i_) d_[i_] = dg_sum[i_]; d_[14] = __builtin_amdgcn_s_memrealtime() - dg_real; \
+                         d_[15] = __builtin_amdgcn_s_memtime() - dg_first; } } while (0)
+#else
+#define HB_STAMP(i) do { } while (0)
+#define HB_DIAG_BEGIN
+#define HB_DIAG_END(WAVES) do { } while (0)
+#endif
+
 // ---- the same kernel with specialised waves ------------------------------------------------------------------------
 // In conv3d_gcr_h_kernel every wave alternates between its taps and its share of the next chunk's commit / fetch; the stamps
 // show a wave spending 27 k cycles of a 91 k-cycle layer in taps and most of the rest in phases that a wave busy with MFMAs
@@ -1302,6 +1322,7 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
     }
     // GnIn: the statistics are requested here and reduced (gn_in_finish, scratch: the first image buffer) behind the loaders' first
     // requests, so that the two round trips overlap
+    HB_DIAG_BEGIN
     const bool stats_in = a.stat_in.acc[0] != nullptr;
     constexpr int GN_PRE = TZ == 8 ? 4 : 8;                         // (1024 threads: 4 words each cover the shipped rows, and 8 spill)
     GnReq<GN_PRE> gn_rq;
@@ -1458,15 +1479,19 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
         constexpr int WAIT_DMA0 = 0x0F70 | (2 * ITERS > 15 ? 15 : 2 * ITERS);
         if (N > 2) __builtin_amdgcn_s_waitcnt(WAIT_DMA0); else __builtin_amdgcn_s_waitcnt(0x0F70);   // chunk 0's weights have landed
         lds_barrier();
+        HB_STAMP(0);
         // iteration n: commit chunk n+1 (requested two iterations ago), DMA its weights, request chunk n+3 into the freed set;
         // the counted wait lets that youngest request fly on and, vmcnt being in order, also covers chunk n+2's request
         auto iteration = [&](int n, PreSet &ps) {
-            if (n + 1 < N) { commit(n + 1, ps); dma_w(n + 1); }
+            if (n + 1 < N) { commit(n + 1, ps); HB_STAMP(1); dma_w(n + 1); }
             if (n + 3 < N) {
                 fetch(ps);
+                HB_STAMP(2);
                 __builtin_amdgcn_s_waitcnt(WAIT_DMA);
             } else __builtin_amdgcn_s_waitcnt(0x0F70);
+            HB_STAMP(3);
             lds_barrier();
+            HB_STAMP(4);
         };
         for (int n = 0; n < N; n += 2) {
             iteration(n, preB);                                    // chunk n + 1 is odd
@@ -1497,6 +1522,7 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
         };
         int e_q = 0, e_k = 0;
         lds_barrier();                                           // the loaders' prologue
+        HB_STAMP(0);
         for (int n = 0; n < N; ++n) {
             Ops cur = ops_of(n, 0);
 #pragma unroll
@@ -1513,6 +1539,7 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
                 __builtin_amdgcn_sched_barrier(0);
                 cur = nxt;
             }
+            HB_STAMP(1);
             if (++e_q == ncq) {                                      // the tile's last chunk: relu, store, statistics, fresh accumulators
                 int x0, y0, z0;
                 tile_origin(e_k, x0, y0, z0);
@@ -1544,6 +1571,7 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
                         ssq[r] = pch ? fmaf(v[r], v[r], ssq[r]) : v[r] * v[r];
                     }
                 }
+                HB_STAMP(2);
                 if ((a.part || a.stat_out.acc) && !FIN) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -1555,8 +1583,10 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+                HB_STAMP(3);
             }
             lds_barrier();
+            HB_STAMP(4);
         }
     }
     if ((a.part || a.stat_out.acc) && threadIdx.x < 64) {
@@ -1565,6 +1595,356 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
         if (a.part) a.part[(((size_t)b * ha.wgs_per_scene + wg) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
         if (a.stat_out.acc) gn_out_add(a.stat_out, b, (unsigned)wg, co_blk * 32, tsum);
     }
+    HB_DIAG_END(2 * TZ);
+}
+
+// ---- the same kernel with the support work in the tap waves' own instruction streams -----------------------------------------
+// conv3d_gcr_hw_kernel's loader waves are what bounds it: beside waves that issue MFMAs back to back ANOTHER wave's vector
+// instructions get about one issue slot per 32-cycle MFMA (a chunk's ~150 loader instructions take as long as the tap waves' 168
+// MFMAs and then some: chunk period 7.5 k cycles against 5.4 k of matrix time), while a wave's OWN vector instructions, placed
+// behind an MFMA in program order, issue in that MFMA's shadow.  Here there are no loader waves: TZ waves, each runs the taps of
+// its z-plane (two patches, as before) and carries an eighth of the next chunk's commit, weight DMA and the request two chunks
+// further on as one small piece per MFMA gap (2-4 vector instructions, pinned there by scheduling barriers).  Same LDS images, same
+// MFMA order per accumulator: bit-identical output.
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+template <int TZ, bool FIN = false>
+__global__ void __launch_bounds__(64 * TZ)
+conv3d_gcr_hx_kernel(HbArgs ha) {
+    constexpr int ROWS = hb_rows(TZ), NVOX = hb_nvox(TZ), THREADS = 64 * TZ;
+    constexpr int ITERS = (2 * NVOX + THREADS - 1) / THREADS;
+    constexpr int IMG = (int)hb_img_bytes(TZ), WBUF = HB_WFRAGS * 16;
+    constexpr int NP = HB_WFRAGS / 64, PW = (NP + TZ - 1) / TZ;        // weight DMA: 1-KiB pieces per chunk, per wave
+    // the gaps of a chunk (14 k-steps x 6 MFMAs): commit item i in gaps [8 i, 8 i + 8), then the DMA pieces, then the requests
+    constexpr int G_DMA = ITERS * 8 + 2, G_FETCH = G_DMA + PW + 2;
+    static_assert(G_FETCH + ITERS <= HB_KSTEPS * 6, "conv3d_gcr_hx_kernel: more pieces than gaps");
+    extern __shared__ __attribute__((aligned(16))) char hl[];      // [2 images][2 weight buffers][stats scratch][scale / shift]
+    const ConvArgs &a = ha.c;
+    const Src &s = a.s;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, kg = lane >> 5;
+    const int b = blockIdx.x / ha.wgs_per_scene, wg = blockIdx.x - b * ha.wgs_per_scene;
+    const int nsp = a.tiles_x * a.tiles_y * a.tiles_z;
+    const int ntile = (nsp - wg + ha.wgs_per_scene - 1) / ha.wgs_per_scene;
+    const int Cin = s.C1 + s.C2, ncq = Cin / 8;
+    const int co_blk = blockIdx.y, nco_all = a.Cout / 32;
+    char *wbase = hl + 2 * IMG;
+    float *sred = reinterpret_cast<float *>(hl + 2 * IMG + 2 * WBUF);
+    float *ssl = sred + 2 * TZ * 64;
+    float pre_scale = 1.0f, post_scale = 1.0f;
+    if (ha.in_absmax) {
+        const float m = *ha.in_absmax;
+        if (m > 0.0f && m < 3.0e38f) {
+            const int e = 10 - ilogbf(m);
+            pre_scale = ldexpf(1.0f, e < -100 ? -100 : (e > 100 ? 100 : e));
+            post_scale = 1.0f / pre_scale;
+        }
+    }
+    HB_DIAG_BEGIN
+    const bool stats_in = a.stat_in.acc[0] != nullptr;
+    constexpr int GN_PRE = 8;
+    GnReq<GN_PRE> gn_rq;
+    if (stats_in) gn_rq = gn_in_request<GN_PRE>(a.stat_in, b, threadIdx.x, THREADS);
+    else
+        for (int i = threadIdx.x; i < 2 * Cin; i += THREADS)
+            ssl[i] = pre_scale * (a.scale_shift ? a.scale_shift[(size_t)b * Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f));
+    sred[wave * 64 + lane] = 0.0f;
+    __syncthreads();
+    HB_STAMP(0);
+    auto tile_origin = [&](int k, int &x0, int &y0, int &z0) {
+        int t = wg + k * ha.wgs_per_scene;
+        const int tx = t % a.tiles_x; t /= a.tiles_x;
+        const int ty = t % a.tiles_y; t /= a.tiles_y;
+        x0 = tx * 8; y0 = ty * 8; z0 = t * TZ;
+    };
+    const int N = ntile * ncq;
+
+    // ---- the wave's share of the staging: items lt + i THREADS (halo voxel, channel half), as the loader waves of the hw kernel ----
+    const int lt = threadIdx.x;
+    const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
+    int pxyz[ITERS], lrow[ITERS], voff[ITERS], loff[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int item = lt + it * THREADS, v = item >> 1;
+        const int px = v % 10, r2 = v / 10, py = r2 % 10, pz = r2 / 10;
+        pxyz[it] = v < NVOX ? (px | (py << 8) | (pz << 16)) : (0xFF | (0xFF << 8));      // no item: a position outside every volume
+        // (a thread without an item writes its zeros to a padding row -- px = 10 of the first image row -- that no tap reads)
+        lrow[it] = (v < NVOX ? ((pz * 10 + py) * HB_PX + px) * 16 : 10 * 16) + (item & 1) * 8;
+        voff[it] = ((pz - 1) * s.H + (py - 1)) * s.W + (px - 1);
+        loff[it] = (((pz - 1) >> 1) * H2 + ((py - 1) >> 1)) * W2 + ((px - 1) >> 1);
+    }
+    const int c4 = (lt & 1) * 4;
+    const int vmax = (int)((size_t)gridDim.x / ha.wgs_per_scene * s.D * s.H * s.W) - 1, lmax = s.low ? vmax / 8 : 0;
+    struct PreSet { f32x4 v[ITERS]; unsigned in; };
+    PreSet preA, preB;
+    int d_q = 0;
+    int f_q = 0, f_k = 0, f_vbase = 0, f_lbase = 0;
+    unsigned f_in = 0;
+    auto enter_tile = [&](int k) {
+        int x0, y0, z0;
+        tile_origin(k, x0, y0, z0);
+        f_vbase = ((b * s.D + z0) * s.H + y0) * s.W + x0;
+        f_lbase = ((b * D2 + (z0 >> 1)) * H2 + (y0 >> 1)) * W2 + (x0 >> 1);
+        f_in = 0;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int gx = x0 + (pxyz[it] & 255) - 1, gy = y0 + ((pxyz[it] >> 8) & 255) - 1, gz = z0 + (pxyz[it] >> 16) - 1;
+            f_in |= (unsigned)(((unsigned)gx < (unsigned)s.W) & ((unsigned)gy < (unsigned)s.H) & ((unsigned)gz < (unsigned)s.D)) << it;
+        }
+    };
+    enter_tile(0);
+    // one item's request; the last of a chunk advances the (tile, channel chunk) counters
+    auto fetch_item = [&](PreSet &ps, auto it_tag) {
+        constexpr int it = decltype(it_tag)::value;
+        if (f_q * 8 >= s.C1)                                        // wave-uniform: a chunk lies in one source
+            ps.v[it] = *reinterpret_cast<const f32x4 *>(s.low + (f_q * 8 - s.C1) + c4 + (size_t)(unsigned)min(max(f_lbase + loff[it], 0), lmax) * (unsigned)s.C2);
+        else
+            ps.v[it] = *reinterpret_cast<const f32x4 *>(s.skip + f_q * 8 + c4 + (size_t)(unsigned)min(max(f_vbase + voff[it], 0), vmax) * (unsigned)s.C1);
+        if constexpr (it == 0) ps.in = f_in;
+        if constexpr (it == ITERS - 1) {
+            if (++f_q == ncq) { f_q = 0; ++f_k; enter_tile(f_k); }
+        }
+    };
+    auto fetch = [&](PreSet &ps) { static_for<0, ITERS>([&](auto it) { fetch_item(ps, it); }); };
+    auto dma_piece = [&](int n, int q, int i) {
+        const f16x8 *wq = reinterpret_cast<const f16x8 *>(a.wp) + ((size_t)q * nco_all + co_blk) * HB_WFRAGS;
+        char *dst = wbase + (n & 1) * WBUF;
+        const int p = min(wave + i * TZ, NP - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wq + p * 64 + lane),
+                                         (__attribute__((address_space(3))) void *)(dst + p * 1024), 16, 0, 0);
+    };
+    auto dma_w = [&](int n) {
+        const int q = d_q;
+        if (++d_q == ncq) d_q = 0;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) dma_piece(n, q, i);
+    };
+    int c_q = 0;
+    // the commit of one item in eight steps of 2-4 vector instructions (GroupNorm affine with the zero padding after it; hi =
+    // half(x), lo = half(x - hi): see the hw kernel)
+    struct CommitRegs { float x0, x1, x2, x3, t0, t1, t2, t3; unsigned h01, h23, l01, l23; };
+    auto commit_step = [&](CommitRegs &r, const PreSet &ps, const f32x4 &sc, const f32x4 &sh, char *img, auto it_tag, auto st_tag) {
+        constexpr int it = decltype(it_tag)::value, st = decltype(st_tag)::value;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        if constexpr (st == 0) {
+            const bool in = ps.in >> it & 1u;
+            r.x0 = in ? fmaf(ps.v[it][0], sc[0], sh[0]) : 0.0f;
+            r.x1 = in ? fmaf(ps.v[it][1], sc[1], sh[1]) : 0.0f;
+        } else if constexpr (st == 1) {
+            const bool in = ps.in >> it & 1u;
+            r.x2 = in ? fmaf(ps.v[it][2], sc[2], sh[2]) : 0.0f;
+            r.x3 = in ? fmaf(ps.v[it][3], sc[3], sh[3]) : 0.0f;
+        } else if constexpr (st == 2) {
+            asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5"
+                         : "=&v"(r.h01), "=&v"(r.h23) : "v"(r.x0), "v"(r.x1), "v"(r.x2), "v"(r.x3));
+        } else if constexpr (st == 3) {
+            asm volatile("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                         : "=&v"(r.t0), "=&v"(r.t1) : "v"(r.h01), "v"(r.x0), "v"(r.x1));
+        } else if constexpr (st == 4) {
+            asm volatile("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                         : "=&v"(r.t2), "=&v"(r.t3) : "v"(r.h23), "v"(r.x2), "v"(r.x3));
+        } else if constexpr (st == 5) {
+            asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5"
+                         : "=&v"(r.l01), "=&v"(r.l23) : "v"(r.t0), "v"(r.t1), "v"(r.t2), "v"(r.t3));
+        } else if constexpr (st == 6) {
+            *reinterpret_cast<u32x2 *>(img + lrow[it]) = u32x2{r.h01, r.h23};
+        } else {
+            *reinterpret_cast<u32x2 *>(img + ROWS * 16 + lrow[it]) = u32x2{r.l01, r.l23};
+        }
+    };
+    auto chunk_scale = [&](f32x4 &sc, f32x4 &sh) {                  // the scale / shift of the next chunk to commit (this thread's four channels)
+        const int ch = c_q * 8 + c4;
+        if (++c_q == ncq) c_q = 0;
+        const f32x4 *ss = reinterpret_cast<const f32x4 *>(ssl + ch * 2);
+        const f32x4 s01 = ss[0], s23 = ss[1];
+        sc = f32x4{s01[0], s01[2], s23[0], s23[2]};
+        sh = f32x4{s01[1], s01[3], s23[1], s23[3]};
+    };
+    auto commit = [&](int n, const PreSet &ps) {                    // (prologue: chunk 0 in one go)
+        f32x4 sc, sh;
+        chunk_scale(sc, sh);
+        char *img = hl + (n & 1) * IMG;
+        static_for<0, ITERS>([&](auto it) {
+            CommitRegs r;
+            static_for<0, 8>([&](auto st) { commit_step(r, ps, sc, sh, img, it, st); });
+        });
+    };
+
+    // ---- the wave's taps: z-plane `wave` of the tile, patches at x = 0..3 and 4..7 ----
+    const int lx = j & 3, ly = j >> 2;
+    const int center = ((wave + 1) * 10 + (ly + 1)) * HB_PX + (lx + 1);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    struct Ops { f16x8 wh, wl, x0h, x0l, x1h, x1l; };
+    auto ops_of = [&](int n, int ks) {
+        Ops o;
+        const f16x8 *wl = reinterpret_cast<const f16x8 *>(wbase + (n & 1) * WBUF);
+        o.wh = wl[ks * 128 + lane]; o.wl = wl[ks * 128 + 64 + lane];
+        const int t0 = 2 * ks, t1 = 2 * ks + 1 < 27 ? 2 * ks + 1 : 13;
+        const int r0 = ((t0 / 9 - 1) * 10 + ((t0 / 3) % 3 - 1)) * HB_PX + (t0 % 3 - 1);
+        const int r1 = ((t1 / 9 - 1) * 10 + ((t1 / 3) % 3 - 1)) * HB_PX + (t1 % 3 - 1);
+        const char *xin = hl + (n & 1) * IMG + (center + (kg ? r1 : r0)) * 16;
+        o.x0h = *reinterpret_cast<const f16x8 *>(xin);
+        o.x0l = *reinterpret_cast<const f16x8 *>(xin + ROWS * 16);
+        o.x1h = *reinterpret_cast<const f16x8 *>(xin + 64);
+        o.x1l = *reinterpret_cast<const f16x8 *>(xin + ROWS * 16 + 64);
+        return o;
+    };
+
+    constexpr int WAIT_DMA = 0x0F70 | ITERS;                      // vmcnt(ITERS): all but the youngest ITERS operations (the register fetch) have landed
+    HB_STAMP(11);
+    if (N > 0) {
+        dma_w(0);
+        HB_STAMP(12);
+        fetch(preA);
+        HB_STAMP(13);
+        if (N > 1) fetch(preB);
+    }
+    HB_STAMP(1);
+    if (stats_in) gn_in_finish<true>(a.stat_in, gn_rq, b, pre_scale, ssl, hl, threadIdx.x, THREADS);
+    HB_STAMP(2);
+    if (N > 0) {
+        commit(0, preA);
+        HB_STAMP(3);
+        if (N > 2) fetch(preA);
+    }
+    constexpr int WAIT_DMA0 = 0x0F70 | (2 * ITERS > 15 ? 15 : 2 * ITERS);
+    if (N > 2) __builtin_amdgcn_s_waitcnt(WAIT_DMA0); else __builtin_amdgcn_s_waitcnt(0x0F70);
+    HB_STAMP(4);
+    lds_barrier();
+    HB_STAMP(5);
+
+    int e_q = 0, e_k = 0;
+    // chunk n: its taps, with chunk n+1's commit (from ps, requested two chunks ago), its weight DMA and chunk n+3's request (into
+    // ps again) in the gaps.  ALL: every one of those exists (the steady state: no branches in the gaps)
+    auto body = [&](int n, PreSet &ps, auto all_tag) {
+        constexpr bool ALL = decltype(all_tag)::value;
+        const bool do_c = ALL || n + 1 < N, do_f = ALL || n + 3 < N;
+        f32x4 sc = {0.0f, 0.0f, 0.0f, 0.0f}, sh = sc;
+        int dq = 0;
+        if (do_c) {
+            chunk_scale(sc, sh);
+            dq = d_q;
+            if (++d_q == ncq) d_q = 0;
+        }
+        char *img = hl + ((n + 1) & 1) * IMG;
+        CommitRegs cr;
+        auto piece = [&](auto g_tag) {
+            constexpr int g = decltype(g_tag)::value;
+            if constexpr ((VT_HX_ABL & 1) != 0) {
+            } else if constexpr (g < ITERS * 8) {
+                if constexpr ((VT_HX_ABL & 8) == 0)
+                if (do_c) commit_step(cr, ps, sc, sh, img, std::integral_constant<int, g / 8>{}, std::integral_constant<int, g % 8>{});
+            } else if constexpr (g >= G_DMA && g < G_DMA + PW) {
+                if constexpr ((VT_HX_ABL & 16) == 0)
+                if (do_c) dma_piece(n + 1, dq, g - G_DMA);
+            } else if constexpr (g >= G_FETCH && g < G_FETCH + ITERS) {
+                if constexpr ((VT_HX_ABL & 32) == 0)
+                if (do_f) fetch_item(ps, std::integral_constant<int, g - G_FETCH>{});
+            }
+        };
+        Ops cur = ops_of(n, 0);
+        static_for<0, HB_KSTEPS>([&](auto ks_tag) {
+            constexpr int ks = decltype(ks_tag)::value;
+            Ops nxt = cur;
+            if constexpr (ks + 1 < HB_KSTEPS && (VT_HX_ABL & 4) == 0) nxt = ops_of(n, ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wl, cur.x0h, acc0, 0, 0, 0);
+            piece(std::integral_constant<int, ks * 6 + 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wl, cur.x1h, acc1, 0, 0, 0);
+            piece(std::integral_constant<int, ks * 6 + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wh, cur.x0l, acc0, 0, 0, 0);
+            piece(std::integral_constant<int, ks * 6 + 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wh, cur.x1l, acc1, 0, 0, 0);
+            piece(std::integral_constant<int, ks * 6 + 3>{});
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wh, cur.x0h, acc0, 0, 0, 0);
+            piece(std::integral_constant<int, ks * 6 + 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wh, cur.x1h, acc1, 0, 0, 0);
+            piece(std::integral_constant<int, ks * 6 + 5>{});
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        });
+        HB_STAMP(6);
+        if (++e_q == ncq) {                                          // the tile's last chunk: relu, store, statistics, fresh accumulators
+            int x0, y0, z0;
+            tile_origin(e_k, x0, y0, z0);
+            e_q = 0; ++e_k;
+            f32x16 ssum, ssq;
+#pragma unroll
+            for (int pch = 0; pch < 2; ++pch) {
+                f32x16 v = pch ? acc1 : acc0;
+                const int gx = x0 + lx + 4 * pch, gy = y0 + ly, gz = z0 + wave;
+                float *orow = a.out + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.Cout;
+                if (ha.in_absmax) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] *= post_scale;
+                }
+                if (a.relu) v = relu16(v);
+                if (FIN) {
+                    const SplitP<2> xs = split16<false, 2>(v);
+                    f32x16 o;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] = ha.fin_b ? ha.fin_b[chan_of(r, kg)] : 0.0f;
+                    o = dense32s<2>(o, ha.fin_w, xs, lane);
+                    store_acc16(orow, o, kg);
+                    continue;
+                }
+                store_acc16(orow + co_blk * 32, v, kg);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    ssum[r] = pch ? ssum[r] + v[r] : v[r];
+                    ssq[r] = pch ? fmaf(v[r], v[r], ssq[r]) : v[r] * v[r];
+                }
+            }
+            HB_STAMP(7);
+            if ((a.part || a.stat_out.acc) && !FIN) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float sm = half_wave_sum(ssum[r]), sq = half_wave_sum(ssq[r]);
+                    // (inline asm: the compiler puts s_waitcnt vmcnt(0) in front of an LDS atomic while LDS-DMA is in flight -- here the
+                    // next chunk's weights and two chunks of input requests, a full memory latency per tile)
+                    if (j == 31) {
+                        const unsigned d = (unsigned)(size_t)(sred + wave * 64 + chan_of(r, kg) * 2) & 0xFFFFFu;
+                        asm volatile("ds_add_f32 %0, %1\n\tds_add_f32 %0, %2 offset:4" :: "v"(d), "v"(sm), "v"(sq) : "memory");
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+            HB_STAMP(8);
+        }
+        // chunk n+1's weights have landed (the stores of an epilogue count in vmcnt too: they are younger than the request, so the
+        // counted wait only waits longer)
+        if (do_f) __builtin_amdgcn_s_waitcnt(WAIT_DMA); else __builtin_amdgcn_s_waitcnt(0x0F70);
+        HB_STAMP(9);
+        if constexpr ((VT_HX_ABL & 2) == 0) lds_barrier();
+        HB_STAMP(10);
+    };
+    int n = 0;
+    for (; n + 4 < N; n += 2) {
+        body(n, preB, std::true_type{});                           // chunk n + 1 is odd: set B
+        body(n + 1, preA, std::true_type{});
+    }
+    for (; n < N; ++n) {
+        if (n & 1) body(n, preA, std::false_type{}); else body(n, preB, std::false_type{});
+    }
+    if ((a.part || a.stat_out.acc) && threadIdx.x < 64) {
+        float tsum = 0.0f;
+        for (int w = 0; w < TZ; ++w) tsum += sred[w * 64 + threadIdx.x];
+        if (a.part) a.part[(((size_t)b * ha.wgs_per_scene + wg) * a.Cout + co_blk * 32) * 2 + threadIdx.x] = tsum;
+        if (a.stat_out.acc) gn_out_add(a.stat_out, b, (unsigned)wg, co_blk * 32, tsum);
+    }
+    HB_DIAG_END(TZ);
 }
 
 __global__ void __launch_bounds__(256)
@@ -2087,6 +2467,11 @@ static bool conv_h_specialised(int tz) {
     return spec && tz != 0 && tz != 2;
 }
 
+static bool conv_h_inline() {
+    static const bool on = getenv("VTACO_CONV_SPEC") && getenv("VTACO_CONV_SPEC")[0] == '2';
+    return on;
+}
+
 static int conv_h_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                          const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
                          float *out_part, const float *in_absmax, const float *fin_w, const float *fin_b, void *stream,
@@ -2165,6 +2550,25 @@ static int conv_h_launch(const float *skip, int C1, const float *low, int C2, in
         attr = true;
     }
     if (fin_w && !conv_h_specialised(tz)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr_f16x3_final: shape not on the specialised-wave kernel");
+    if (conv_h_specialised(tz) && conv_h_inline()) {               // the support work in the tap waves' MFMA gaps (VTACO_CONV_SPEC=2)
+        static bool attr_x = false;
+        if (!attr_x) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hx_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(8));
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hx_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(4));
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hx_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(8));
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hx_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(4));
+            if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3: hipFuncSetAttribute");
+            attr_x = true;
+        }
+        if (fin_w) {
+            if (tz == 8) hipLaunchKernelGGL((conv3d_gcr_hx_kernel<8, true>), grid, dim3(64 * 8), hb_lds(8), (hipStream_t)stream, ha);
+            else hipLaunchKernelGGL((conv3d_gcr_hx_kernel<4, true>), grid, dim3(64 * 4), hb_lds(4), (hipStream_t)stream, ha);
+        } else {
+            if (tz == 8) hipLaunchKernelGGL(conv3d_gcr_hx_kernel<8>, grid, dim3(64 * 8), hb_lds(8), (hipStream_t)stream, ha);
+            else hipLaunchKernelGGL(conv3d_gcr_hx_kernel<4>, grid, dim3(64 * 4), hb_lds(4), (hipStream_t)stream, ha);
+        }
+        return vt_check(hipGetLastError(), "vt_conv3d_gcr_f16x3");
+    }
     if (conv_h_specialised(tz)) {                                  // specialised tap / loader waves (VTACO_CONV_SPEC=0: the uniform-wave kernel)
         static bool attr_w = false;
         if (!attr_w) {
@@ -2194,6 +2598,12 @@ static int conv_h_launch(const float *skip, int C1, const float *low, int C2, in
     else hipLaunchKernelGGL(conv3d_gcr_h_kernel<2>, grid, dim3(hb_threads(2)), hb_lds(2), (hipStream_t)stream, ha);
     return vt_check(hipGetLastError(), "vt_conv3d_gcr_f16x3");
 }
+
+#ifdef VT_DIAG_HB
+int vt_diag_hb_read(unsigned long long *host, size_t n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(vt_diag_hb_buf), n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int vt_maxpool3d_cl(const float *x, int B, int D, int H, int W, int C, float *out, void *stream) {
     if (!x || !out || B <= 0 || C <= 0 || D < 2 || H < 2 || W < 2) return vt_fail(VT_ERR_INVALID, "vt_maxpool3d_cl: bad argument");
