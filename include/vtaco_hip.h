@@ -452,6 +452,14 @@ int vt_voxel_build(const float *pts, int B, int T, int R, double padding,
 /* the workgroups the sort leaves idle: the torch.zeros of generate_grid_features (pointnet.py:102-110) without a launch of its own. */
 int vt_voxel_build_clear(const float *pts, int B, int T, int R, double padding,
                          int *idx, int *order, int *seg_lo, int *seg_hi, void *clear, size_t clear_bytes, void *stream);
+/* flags [B][(R/8)^3] bytes: 1 where no point of the scene lies in the 10^3 halo of that 8^3 voxel block, i.e. the mean grid of   */
+/* generate_grid_features (pointnet.py:102-110) is zero over everything a 3x3x3 conv of the block reads (idx from vt_voxel_build; */
+/* R a multiple of 8, at most 128).  Consumed by vt_unet3d_fwd_skip / vt_conv3d_gcr_f16x3_skip.                                  */
+int vt_voxel_tile_flags(const int *idx, int B, int T, int R, unsigned char *flags, void *stream);
+/* vt_voxel_build_clear (clear may be NULL with clear_bytes 0) that leaves those flags as well: the sorting workgroup marks the blocks */
+/* while it computes the voxel ids (no launch of its own, no second pass over the points).                                       */
+int vt_voxel_build_clear_flags(const float *pts, int B, int T, int R, double padding, int *idx, int *order, int *seg_lo, int *seg_hi,
+                               void *clear, size_t clear_bytes, unsigned char *tile_flags, void *stream);
 int vt_voxel_pool_max_fwd(const float *feat, const int *order, const int *seg_lo, const int *seg_hi,
                           int B, int T, int C, float *out, int *argmax, void *stream);
 int vt_voxel_pool_max_bwd(const float *grad_out, const int *argmax, const int *order,
@@ -565,6 +573,15 @@ int vt_conv3d_gcr_bf16x3_ksplit(const float *skip, int C1, const float *low, int
 /* output's GroupNorm partial sums are per workgroup (stat_blocks = workgroups per scene).  Covers side lengths that are     */
 /* multiples of 8 with >= 256 tiles of 8x8x8 or >= 128 tiles of 8x8x4 per launch (stat_blocks returns 0 otherwise).          */
 /* The packed blob has its own size (28 instead of 27 tap slots per channel pair): vt_conv3d_packed_floats_f16x3.            */
+/* vt_conv3d_gcr_f16x3 on a plain layer (no `low`) whose input is ZERO before the normalisation over the halo of the flagged 8^3    */
+/* blocks (tile_flags [B][(D/8)(H/8)(W/8)], vt_voxel_tile_flags): the normalised input there is the per-channel shift, so a block's */
+/* output is, per voxel, the sum over the taps inside the volume of T[tap][cout] = sum_cin W[cout][cin][tap] shift[cin] -- the     */
+/* workgroups of a scene deal the blocks that need their taps among themselves and fill the others from T (the UNet3D's first      */
+/* layer, unet3d.py:449-474 on the grid of pointnet.py:102-110: a 3000-point cloud leaves 3/4 of the 512 blocks of a 64^3 grid     */
+/* empty).  Equal to the dense kernel to f32 rounding of T (the dense kernel sums the same products in another order).  Shapes    */
+/* the specialised-wave kernel does not run, or lists of more than 64 blocks per workgroup, fall back to the dense walk.           */
+int vt_conv3d_gcr_f16x3_skip(const float *x, int C, int B, int D, int H, int W, const float *scale_shift, const float *packed_w_f16x3,
+                             int Cout, int relu, const unsigned char *tile_flags, float *out, float *out_part, void *stream);
 size_t vt_conv3d_packed_floats_f16x3(int Cout, int Cin);
 int vt_conv3d_pack_f16x3(const float *w, int Cout, int Cin, float *packed, void *stream);
 int vt_conv3d_stat_blocks_f16x3(int B, int D, int H, int W, int Cin, int Cout);
@@ -593,6 +610,10 @@ int vt_unet3d_fwd(const float *x_cl, int B, int R, const vt_unet3d_params *param
 /* vt_pointnet_mlp_fused): no statistics pass over the input grid.                                                              */
 int vt_unet3d_fwd_stats(const float *x_cl, const float *in_part, int in_nblk, int B, int R, const vt_unet3d_params *params_host,
                         void *workspace, size_t workspace_bytes, float *out, void *stream);
+/* vt_unet3d_fwd / vt_unet3d_fwd_stats (in_part may be NULL: statistics pass over x) with the first layer's empty blocks skipped:   */
+/* tile_flags [B][(R/8)^3] from vt_voxel_tile_flags on the cloud that x was scattered from (vt_conv3d_gcr_f16x3_skip).              */
+int vt_unet3d_fwd_skip(const float *x_cl, const float *in_part, int in_nblk, const unsigned char *tile_flags, int B, int R,
+                       const vt_unet3d_params *params_host, void *workspace, size_t workspace_bytes, float *out, void *stream);
 int vt_maxpool3d_cl(const float *x, int B, int D, int H, int W, int C, float *out, void *stream);
 /* the same max-pool and, from the same pass, the pooled tensor's GroupNorm partial sums as vt_channel_stats would leave them   */
 /* (bit-identical: same blocks, same order): part [B][nblk][C][2].                                                          */

@@ -577,3 +577,44 @@ def test_rows_wgrad_and_resblock_bwd_vs_torch():
         got = torch.cat([dx1, dx2], 1).cpu() if C2 else dx1.cpu()
         assert float((got - x.grad).abs().max()) <= 2e-5 * max(1.0, float(x.grad.abs().max()))
         assert float((act.cpu() - h.detach().relu()).abs().max()) <= 2e-5
+
+
+def test_encoder_skips_the_empty_blocks_of_the_first_layer():
+    """LocalPoolPointnet at the shipped shape (64^3 grid, UNet3D f_maps 32): the inference path hands the UNet3D the blocks of the mean
+    grid that no point comes near (ops.voxel_tile_flags) and its first layer fills them from the per-border-class constant instead of
+    running their taps -- same grid as the dense first layer to f32 rounding, for the one-launch PointNet and the module path."""
+    from vtaco_amd.bench_util import sphere_cloud
+    from vtaco_amd.encoder import encoder_dict
+    torch.manual_seed(5)
+    enc = encoder_dict['pointnet_local_pool'](c_dim=32, dim=3, hidden_dim=32, unet3d=True, grid_resolution=64, plane_type='grid',
+                                              unet3d_kwargs=dict(num_levels=3, f_maps=32, in_channels=32, out_channels=32)).to(DEV).eval()
+    assert enc.skip_empty
+    pc = torch.cat([sphere_cloud(0), sphere_cloud(1) * 0.5 + 0.2]).to(DEV)
+    with torch.no_grad():
+        sparse = enc(pc)["grid"]
+        enc.skip_empty = False
+        dense = enc(pc)["grid"]
+        enc.skip_empty = True
+        again = enc(pc)["grid"]
+    assert torch.equal(again, sparse)
+    scale = float(dense.abs().max())
+    err = float((sparse - dense).abs().max())
+    assert 0.0 < err <= 1e-5 * scale, (err, scale)
+
+
+def test_block_flags_from_the_voxel_sort_equal_the_standalone_kernel(monkeypatch):
+    """vt_voxel_build_clear_flags marks the empty blocks while it computes the voxel ids; vt_voxel_tile_flags does it from the ids.
+    Same flags on clouds of different spread, with and without the buffer to clear, also through the large-cloud path."""
+    from vtaco_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for B, T, R, spread in ((2, 3000, 64, 0.3), (1, 500, 32, 0.5), (3, 2000, 128, 0.2), (1, 100, 8, 0.5)):
+        p = ((torch.rand(B, T, 3, generator=g) - 0.5) * 2 * spread).to(DEV)
+        clear = torch.full((B * R * R * 16,), 3.0, device=DEV)
+        vi = ops.VoxelIndex(p, R, 0.1, clear=clear, want_tile_flags=True)
+        ref = ops.VoxelIndex(p, R, 0.1)
+        assert torch.equal(vi.idx, ref.idx) and torch.equal(vi.order, ref.order) and float(clear.abs().max()) == 0.0
+        want = ops.voxel_tile_flags(ref)
+        assert vi.tile_flags is not None and torch.equal(vi.tile_flags, want)
+        assert spread > 0.3 or R == 8 or 0 < int(want.sum()) < want.numel()         # a compact cloud leaves empty blocks
+        assert torch.equal(ops.VoxelIndex(p, R, 0.1, want_tile_flags=True).tile_flags, want)
+    assert ops.VoxelIndex(p, 12, 0.1, want_tile_flags=True).tile_flags is None      # not a multiple of 8: no flags, dense first layer

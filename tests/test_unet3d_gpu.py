@@ -467,3 +467,62 @@ def test_split_f16_conv_variants_agree_bit_for_bit():
     assert seen["2"] == seen["1"]
     # the uniform-wave kernel gives every wave ONE patch: the same products, but its statistics reduce per patch -- outputs identical
     assert [ln.split()[0] for ln in seen["0"]] == [ln.split()[0] for ln in seen["1"]]
+
+
+def _sparse_case(B, R, C, g, n_pts, lo=0.0, hi=1.0):
+    """A channels-last grid that is zero except at the voxels of a random cloud, the cloud's voxel ids, and the numpy rule for the
+    flags: 1 = no point in the 10^3 halo of the 8^3 block."""
+    import numpy as np
+    xyz = (torch.rand(B, n_pts, 3, generator=g) * (hi - lo) + lo).clamp(0, 0.999)
+    v = (xyz * R).long()
+    idx = (v[..., 0] + R * (v[..., 1] + R * v[..., 2])).int()
+    x = torch.zeros(B, R ** 3, C)
+    for b in range(B):
+        x[b, idx[b].long()] = torch.randn(n_pts, C, generator=g)
+    occ = (x.abs().sum(-1) > 0).reshape(B, R, R, R).numpy()
+    nt = R // 8
+    flags = np.ones((B, nt, nt, nt), np.uint8)
+    for b in range(B):
+        for tz in range(nt):
+            for ty in range(nt):
+                for tx in range(nt):
+                    sub = occ[b, max(8 * tz - 1, 0):8 * tz + 9, max(8 * ty - 1, 0):8 * ty + 9, max(8 * tx - 1, 0):8 * tx + 9]
+                    flags[b, tz, ty, tx] = 0 if sub.any() else 1
+    return x.reshape(B, R, R, R, C), idx, flags.reshape(B, -1)
+
+
+def test_tile_flags_and_the_first_layer_without_its_empty_blocks():
+    """vt_voxel_tile_flags against the numpy rule, and vt_conv3d_gcr_f16x3_skip against the dense kernel on grids that are zero away from
+    a cloud: clouds in the middle (every border block empty), clouds touching the volume's border, an empty scene beside a full one,
+    8x8x4 tiles with two cout blocks, and flags that are all zero (nothing to skip).  Skipped blocks are filled from
+    T[tap][cout] = sum_cin W shift, the dense kernel sums the same products in its own order: f32-rounding-level distance."""
+    from types import SimpleNamespace
+    from vtaco_amd import ops
+    g = torch.Generator().manual_seed(31)
+    cases = [(1, 64, 32, 32, 300, 0.3, 0.7), (2, 64, 32, 32, 400, 0.0, 1.0), (1, 32, 32, 64, 60, 0.35, 0.6), (2, 32, 32, 64, 40, 0.0, 0.3),
+             (2, 64, 32, 32, 3000, 0.2, 0.8)]
+    for B, R, C, Cout, n_pts, lo, hi in cases:
+        x, idx, want = _sparse_case(B, R, C, g, n_pts, lo, hi)
+        if B == 2 and n_pts == 400:
+            x[1] = 0                                                  # a scene without points (its ids still say otherwise: flag from x)
+        x, idx = x.to(DEV), idx.to(DEV)
+        vi = SimpleNamespace(idx=idx.contiguous(), B=B, T=idx.shape[1], R=R)
+        flags = ops.voxel_tile_flags(vi)
+        assert flags.dtype == torch.uint8 and flags.shape == (B, (R // 8) ** 3)
+        assert (flags.cpu().numpy() == want).all()
+        if B == 2 and n_pts == 400:
+            flags[1] = 1                                              # ... and the empty scene skips every block
+        w = (torch.randn(Cout, C, 3, 3, 3, generator=g) * 0.05).to(DEV)
+        gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV), (0.3 * torch.randn(C, generator=g)).to(DEV)
+        xs = ops.channel_stats(x)
+        ss = ops.gn_scale_shift(xs, None, C, 0, B, R ** 3, gamma, beta, 8, 1e-5, x.device)
+        ph = ops.conv3d_pack(w, precision="f16x3")
+        ref, (rp, rn) = ops.conv3d_gcr(x, None, ss, None, Cout, True, None, packed_w_f16x3=ph)
+        got, (gp, gn) = ops.conv3d_gcr_skip(x, ss, ph, Cout, flags)
+        assert gn == rn and int(flags.sum()) > 0
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((got - ref).abs().max()) <= 2e-6 * scale, (B, R, C, Cout, float((got - ref).abs().max()), scale)
+        # (the workgroups walk other tiles than in the dense launch: the per-workgroup rows differ, their sums agree)
+        assert float((gp.sum(1) - rp.sum(1)).abs().max()) <= 2e-5 * float(rp.sum(1).abs().max())
+        none, _ = ops.conv3d_gcr_skip(x, ss, ph, Cout, torch.zeros_like(flags))
+        assert torch.equal(none, ref)                                 # nothing flagged: the dense walk through the lists, same bits

@@ -136,6 +136,7 @@ SIGNATURES = {
     "vt_mc_emit": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _VP, _I, _I, _F, _F, _VP]),
     "vt_voxel_build": (_I, [_VP, _I, _I, _I, _D, _VP, _VP, _VP, _VP, _VP]),
     "vt_voxel_build_clear": (_I, [_VP, _I, _I, _I, _D, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "vt_voxel_build_clear_flags": (_I, [_VP, _I, _I, _I, _D, _VP, _VP, _VP, _VP, _VP, _SZ, _VP, _VP]),
     "vt_voxel_pool_max_fwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "vt_voxel_pool_max_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
     "vt_voxel_scatter_mean_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
@@ -194,6 +195,9 @@ SIGNATURES = {
     "vt_unet3d_workspace_bytes": (_SZ, [_I, _I, ctypes.POINTER(UnetParams)]),
     "vt_unet3d_fwd": (_I, [_VP, _I, _I, ctypes.POINTER(UnetParams), _VP, _SZ, _VP, _VP]),
     "vt_unet3d_fwd_stats": (_I, [_VP, _VP, _I, _I, _I, ctypes.POINTER(UnetParams), _VP, _SZ, _VP, _VP]),
+    "vt_unet3d_fwd_skip": (_I, [_VP, _VP, _I, _VP, _I, _I, ctypes.POINTER(UnetParams), _VP, _SZ, _VP, _VP]),
+    "vt_conv3d_gcr_f16x3_skip": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP]),
+    "vt_voxel_tile_flags": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "vt_maxpool3d_cl": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP]),
     "vt_maxpool3d_cl_stats": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _I, _VP, _VP]),
     "vt_conv1x1_cl": (_I, [_VP, _I64, _I, _VP, _VP, _I, _VP, _VP]),

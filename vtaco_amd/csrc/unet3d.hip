@@ -1040,7 +1040,15 @@ struct HbArgs {
     // between the decoder's layers -- and six MFMAs against fin_w (vt_conv1x1_pack_f16x3) + fin_b give what is stored
     const float *fin_w = nullptr;
     const float *fin_b = nullptr;
+    // or null.  [B][D/8][H/8][W/8] bytes: 1 = no voxel of that 8^3 block's halo (as far as this layer reads) differs from zero before
+    // the GroupNorm, i.e. the normalised input there is the per-channel shift.  The specialised-wave kernel then skips the block's taps:
+    // its output is sum over the in-volume taps of T[tap][cout] = sum_cin W[cout][cin][tap] shift[cin] (vt_voxel_tile_flags makes the
+    // flags; plain layers only: no `low`, no in_absmax)
+    const unsigned char *tile_skip = nullptr;
 };
+constexpr int HB_SKIP_LIST = 64;                                     // tiles of either kind a workgroup can hold in its lists
+constexpr size_t hb_lds_sparse(int TZ) { return hb_lds(TZ) + 2 * 27 * 32 * sizeof(float) + 2 * HB_SKIP_LIST * sizeof(unsigned short) + 64 * sizeof(int); }
+static_assert(hb_lds_sparse(8) <= 160 * 1024, "split-f16 conv with skip lists: LDS budget");
 
 template <int TZ>
 __global__ void __launch_bounds__(hb_threads(TZ))
@@ -1332,13 +1340,55 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
             ssl[i] = pre_scale * (a.scale_shift ? a.scale_shift[(size_t)b * Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f));
     if (wave < TZ) sred[wave * 64 + lane] = 0.0f;
     __syncthreads();
+    // ---- tiles to skip (ha.tile_skip): the workgroups of a scene deal the tiles that need their taps among themselves in tile order, and
+    // likewise the tiles whose output is a constant per border class; without flags a workgroup walks wg, wg + wgs, ... as before
+    float *ttab = ssl + HB_MAX_CIN * 2, *ktab = ttab + 27 * 32;      // [27 taps][32 couts], [27 border classes][32 couts]
+    unsigned short *list_ne = reinterpret_cast<unsigned short *>(ktab + 27 * 32), *list_e = list_ne + HB_SKIP_LIST;
+    int *lcnt = reinterpret_cast<int *>(list_e + HB_SKIP_LIST);      // [0..31] per-wave counts of a round, [32], [33] running totals
+    const bool sparse = !FIN && ha.tile_skip != nullptr;
+    int n_ne = ntile, n_e = 0;
+    if (sparse) {
+        const int t8x = s.W >> 3, t8y = s.H >> 3;
+        const unsigned char *flags = ha.tile_skip + (size_t)b * (s.D >> 3) * t8y * t8x;
+        if (threadIdx.x < 2) lcnt[32 + threadIdx.x] = 0;
+        __syncthreads();
+        for (int base = 0; base < nsp; base += THREADS) {
+            const int t = base + threadIdx.x;
+            bool valid = t < nsp, skip = false;
+            if (valid) {
+                const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, tz = t / (a.tiles_x * a.tiles_y);
+                skip = flags[(((tz * TZ) >> 3) * t8y + ty) * t8x + tx] != 0;
+            }
+            const unsigned long long m_ne = __ballot(valid && !skip), m_e = __ballot(valid && skip);
+            if (lane == 0) { lcnt[wave] = __popcll(m_ne); lcnt[16 + wave] = __popcll(m_e); }
+            __syncthreads();
+            int r_ne = lcnt[32], r_e = lcnt[33];
+            for (int w = 0; w < wave; ++w) { r_ne += lcnt[w]; r_e += lcnt[16 + w]; }
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            r_ne += __popcll(m_ne & lt); r_e += __popcll(m_e & lt);
+            if (valid && !skip && r_ne % ha.wgs_per_scene == wg && r_ne / ha.wgs_per_scene < HB_SKIP_LIST) list_ne[r_ne / ha.wgs_per_scene] = (unsigned short)t;
+            // (dealt from the last workgroup backwards: the first ones hold the blocks with taps)
+            if (valid && skip && r_e % ha.wgs_per_scene == ha.wgs_per_scene - 1 - wg && r_e / ha.wgs_per_scene < HB_SKIP_LIST) list_e[r_e / ha.wgs_per_scene] = (unsigned short)t;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int a_ne = 0, a_e = 0;
+                for (int w = 0; w < THREADS / 64; ++w) { a_ne += lcnt[w]; a_e += lcnt[16 + w]; }
+                lcnt[32] += a_ne; lcnt[33] += a_e;
+            }
+            __syncthreads();
+        }
+        const int tot_ne = lcnt[32], tot_e = lcnt[33];
+        n_ne = tot_ne > wg ? (tot_ne - wg + ha.wgs_per_scene - 1) / ha.wgs_per_scene : 0;
+        const int wge = ha.wgs_per_scene - 1 - wg;
+        n_e = tot_e > wge ? (tot_e - wge + ha.wgs_per_scene - 1) / ha.wgs_per_scene : 0;
+    }
     auto tile_origin = [&](int k, int &x0, int &y0, int &z0) {
-        int t = wg + k * ha.wgs_per_scene;
+        int t = sparse ? (int)list_ne[k] : wg + k * ha.wgs_per_scene;
         const int tx = t % a.tiles_x; t /= a.tiles_x;
         const int ty = t % a.tiles_y; t /= a.tiles_y;
         x0 = tx * 8; y0 = ty * 8; z0 = t * TZ;
     };
-    const int N = ntile * ncq;
+    const int N = n_ne * ncq;
 
     if (wave >= TZ) {
         // ================================================ loader waves ================================================
@@ -1476,6 +1526,7 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
             commit(0, preA);
             if (N > 2) fetch(preA);
         }
+        if (sparse) lds_barrier();                                  // (the tap waves: T is complete, the class table follows)
         constexpr int WAIT_DMA0 = 0x0F70 | (2 * ITERS > 15 ? 15 : 2 * ITERS);
         if (N > 2) __builtin_amdgcn_s_waitcnt(WAIT_DMA0); else __builtin_amdgcn_s_waitcnt(0x0F70);   // chunk 0's weights have landed
         lds_barrier();
@@ -1502,6 +1553,37 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
         const int lx = j & 3, ly = j >> 2;
         const int center = ((wave + 1) * 10 + (ly + 1)) * HB_PX + (lx + 1);      // patch 0; patch 1 sits 4 voxels along x
         if (stats_in) gn_in_finish<true>(a.stat_in, gn_rq, b, pre_scale, ssl, hl, threadIdx.x, THREADS);
+        if (sparse && n_e > 0) {
+            // T[tap][cout] = sum_cin W[cout][cin][tap] shift[cin] from the packed fragments (hi + lo), while the loaders stage chunk 0
+            for (int id = threadIdx.x; id < 27 * 32; id += LTHREADS) {
+                const int tap = id >> 5, co = id & 31, fl = (tap >> 1) * 128 + co + 32 * (tap & 1);
+                float t = 0.0f;
+                for (int q = 0; q < ncq; ++q) {
+                    const f16x8 *wq = reinterpret_cast<const f16x8 *>(a.wp) + ((size_t)q * nco_all + co_blk) * HB_WFRAGS;
+                    const f16x8 wh = wq[fl], wl = wq[fl + 64];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t = fmaf((float)wh[e] + (float)wl[e], ssl[(q * 8 + e) * 2 + 1], t);
+                }
+                ttab[id] = t;
+            }
+        }
+        if (sparse) {
+            // K[class][cout] = the sum of T over the taps a voxel of that border class has inside the volume (class = per axis: first
+            // voxel, inner, last voxel)
+            lds_barrier();
+            if (n_e > 0)
+                for (int id = threadIdx.x; id < 27 * 32; id += LTHREADS) {
+                    const int cls = id >> 5, co = id & 31, cz = cls / 9, cy = (cls / 3) % 3, cx = cls % 3;
+                    float k = 0.0f;
+                    for (int tap = 0; tap < 27; ++tap) {
+                        const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+                        const bool in = !(cz == 0 && dz < 0) && !(cz == 2 && dz > 0) && !(cy == 0 && dy < 0) && !(cy == 2 && dy > 0) &&
+                                        !(cx == 0 && dx < 0) && !(cx == 2 && dx > 0);
+                        k += in ? ttab[tap * 32 + co] : 0.0f;
+                    }
+                    ktab[id] = k;
+                }
+        }
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
@@ -1521,6 +1603,49 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
             return o;
         };
         int e_q = 0, e_k = 0;
+        // relu, store, statistics of one finished tile (its two patches in acc0 / acc1)
+        auto finish_tile = [&](int x0, int y0, int z0) {
+            f32x16 ssum, ssq;
+#pragma unroll
+            for (int pch = 0; pch < 2; ++pch) {
+                f32x16 v = pch ? acc1 : acc0;
+                const int gx = x0 + lx + 4 * pch, gy = y0 + ly, gz = z0 + wave;
+                float *orow = a.out + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.Cout;
+                if (ha.in_absmax) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] *= post_scale;
+                }
+                if (a.relu) v = relu16(v);
+                if (FIN) {                                      // the final 1x1x1 conv on the registers; no statistics: nothing reads them
+                    const SplitP<2> xs = split16<false, 2>(v);
+                    f32x16 o;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] = ha.fin_b ? ha.fin_b[chan_of(r, kg)] : 0.0f;
+                    o = dense32s<2>(o, ha.fin_w, xs, lane);
+                    store_acc16(orow, o, kg);
+                    continue;
+                }
+                store_acc16(orow + co_blk * 32, v, kg);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {                  // the two patches' contributions per lane first: ONE lane reduction per tile
+                    ssum[r] = pch ? ssum[r] + v[r] : v[r];
+                    ssq[r] = pch ? fmaf(v[r], v[r], ssq[r]) : v[r] * v[r];
+                }
+            }
+            HB_STAMP(2);
+            if ((a.part || a.stat_out.acc) && !FIN) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float sm = half_wave_sum(ssum[r]), sq = half_wave_sum(ssq[r]);
+                    // (ds_add_f32 without a return value: the read-modify-write chains `d[0] += sm` compiled to were 32 dependent LDS
+                    // round trips per tile; the slot belongs to this wave alone, whose LDS operations complete in order)
+                    if (j == 31) { float *d = sred + wave * 64 + chan_of(r, kg) * 2; atomicAdd(d, sm); atomicAdd(d + 1, sq); }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+            HB_STAMP(3);
+        };
         lds_barrier();                                           // the loaders' prologue
         HB_STAMP(0);
         for (int n = 0; n < N; ++n) {
@@ -1544,51 +1669,37 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
                 int x0, y0, z0;
                 tile_origin(e_k, x0, y0, z0);
                 e_q = 0; ++e_k;
-                f32x16 ssum, ssq;
-#pragma unroll
-                for (int pch = 0; pch < 2; ++pch) {
-                    f32x16 v = pch ? acc1 : acc0;
-                    const int gx = x0 + lx + 4 * pch, gy = y0 + ly, gz = z0 + wave;
-                    float *orow = a.out + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.Cout;
-                    if (ha.in_absmax) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] *= post_scale;
-                    }
-                    if (a.relu) v = relu16(v);
-                    if (FIN) {                                      // the final 1x1x1 conv on the registers; no statistics: nothing reads them
-                        const SplitP<2> xs = split16<false, 2>(v);
-                        f32x16 o;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) o[r] = ha.fin_b ? ha.fin_b[chan_of(r, kg)] : 0.0f;
-                        o = dense32s<2>(o, ha.fin_w, xs, lane);
-                        store_acc16(orow, o, kg);
-                        continue;
-                    }
-                    store_acc16(orow + co_blk * 32, v, kg);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {                  // the two patches' contributions per lane first: ONE lane reduction per tile
-                        ssum[r] = pch ? ssum[r] + v[r] : v[r];
-                        ssq[r] = pch ? fmaf(v[r], v[r], ssq[r]) : v[r] * v[r];
-                    }
-                }
-                HB_STAMP(2);
-                if ((a.part || a.stat_out.acc) && !FIN) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float sm = half_wave_sum(ssum[r]), sq = half_wave_sum(ssq[r]);
-                        // (ds_add_f32 without a return value: the read-modify-write chains `d[0] += sm` compiled to were 32 dependent LDS
-                        // round trips per tile; the slot belongs to this wave alone, whose LDS operations complete in order)
-                        if (j == 31) { float *d = sred + wave * 64 + chan_of(r, kg) * 2; atomicAdd(d, sm); atomicAdd(d + 1, sq); }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-                HB_STAMP(3);
+                finish_tile(x0, y0, z0);
             }
             lds_barrier();
             HB_STAMP(4);
         }
+        // the tiles whose normalised input is the shift everywhere: every voxel takes the constant of its border class
+#pragma unroll 1
+        for (int k = 0; k < n_e; ++k) {
+            int t = list_e[k];
+            const int tx = t % a.tiles_x; t /= a.tiles_x;
+            const int ty = t % a.tiles_y; t /= a.tiles_y;
+            const int x0 = tx * 8, y0 = ty * 8, z0 = t * TZ;
+#pragma unroll
+            for (int pch = 0; pch < 2; ++pch) {
+                const int gx = x0 + lx + 4 * pch, gy = y0 + ly, gz = z0 + wave;
+                const int cls = ((gz == 0 ? 0 : gz == s.D - 1 ? 2 : 1) * 3 + (gy == 0 ? 0 : gy == s.H - 1 ? 2 : 1)) * 3 + (gx == 0 ? 0 : gx == s.W - 1 ? 2 : 1);
+                const f32x4 *kr = reinterpret_cast<const f32x4 *>(ktab + cls * 32 + 4 * kg);
+                f32x16 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 kv = kr[2 * q];                     // channels chan_of(4 q .. 4 q + 3, kg) = 8 q + 4 kg + (0..3)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * q + e] = kv[e];
+                }
+                if (pch) acc1 = v; else acc0 = v;
+            }
+            HB_STAMP(5);
+            finish_tile(x0, y0, z0);
+        }
     }
+    if (sparse) lds_barrier();                                      // the statistics of the constant tiles are in before wave 0 reads them
     if ((a.part || a.stat_out.acc) && threadIdx.x < 64) {
         float tsum = 0.0f;
         for (int w = 0; w < TZ; ++w) tsum += sred[w * 64 + threadIdx.x];
@@ -2475,13 +2586,21 @@ static bool conv_h_inline() {
 static int conv_h_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                          const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
                          float *out_part, const float *in_absmax, const float *fin_w, const float *fin_b, void *stream,
-                         const GnIn &stat_in = GnIn{}, const GnOut &stat_out = GnOut{});
+                         const GnIn &stat_in = GnIn{}, const GnOut &stat_out = GnOut{}, const unsigned char *tile_skip = nullptr);
 
 int vt_conv3d_gcr_f16x3_scaled(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                                const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
                                float *out_part, const float *in_absmax, void *stream) {
     return conv_h_launch(skip, C1, low, C2, B, D, H, W, scale_shift, packed_w_f16x3, Cout, relu, out, out_part, in_absmax, nullptr, nullptr, stream);
 }
+
+int vt_conv3d_gcr_f16x3_skip(const float *x, int C, int B, int D, int H, int W, const float *scale_shift, const float *packed_w_f16x3,
+                             int Cout, int relu, const unsigned char *tile_flags, float *out, float *out_part, void *stream) {
+    if (!tile_flags) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr_f16x3_skip: null flags");
+    return conv_h_launch(x, C, nullptr, 0, B, D, H, W, scale_shift, packed_w_f16x3, Cout, relu, out, out_part, nullptr, nullptr, nullptr, stream,
+                         GnIn{}, GnOut{}, tile_flags);
+}
+
 
 // does vt_conv3d_gcr_f16x3_final cover this layer?  (32 output channels, a shape of the specialised-wave kernel)
 int vt_conv3d_final_fusable(int B, int D, int H, int W, int Cin, int Cout) {
@@ -2526,7 +2645,7 @@ int vt_conv1x1_pack_f16x3(const float *w, int Cout, int Cin, float *packed, void
 static int conv_h_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                          const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
                          float *out_part, const float *in_absmax, const float *fin_w, const float *fin_b, void *stream,
-                         const GnIn &stat_in, const GnOut &stat_out) {
+                         const GnIn &stat_in, const GnOut &stat_out, const unsigned char *tile_skip) {
     HbArgs ha;
     ha.c.stat_in = stat_in; ha.c.stat_out = stat_out;
     ha.in_absmax = in_absmax;
@@ -2540,6 +2659,10 @@ static int conv_h_launch(const float *skip, int C1, const float *low, int C2, in
     a.TX = a.TY = 8; a.TZ = tz;
     a.tiles_x = W / 8; a.tiles_y = H / 8; a.tiles_z = D / tz;
     ha.wgs_per_scene = conv_h_wgs_per_scene(B, D, H, W, Cout, tz);
+    // skip flags: the specialised-wave kernel on a plain layer whose workgroups' tile lists fit
+    if (tile_skip && !low && !in_absmax && !fin_w && conv_h_specialised(tz) && !conv_h_inline() &&
+        (a.tiles_x * a.tiles_y * a.tiles_z + ha.wgs_per_scene - 1) / ha.wgs_per_scene <= HB_SKIP_LIST)
+        ha.tile_skip = tile_skip;
     const dim3 grid((unsigned)(ha.wgs_per_scene * B), (unsigned)(Cout / 32));
     static bool attr = false;
     if (!attr) {
@@ -2572,8 +2695,8 @@ static int conv_h_launch(const float *skip, int C1, const float *low, int C2, in
     if (conv_h_specialised(tz)) {                                  // specialised tap / loader waves (VTACO_CONV_SPEC=0: the uniform-wave kernel)
         static bool attr_w = false;
         if (!attr_w) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(8));
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(4));
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds_sparse(8));
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds_sparse(4));
             if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3: hipFuncSetAttribute");
             attr_w = true;
         }
@@ -2589,8 +2712,8 @@ static int conv_h_launch(const float *skip, int C1, const float *low, int C2, in
             else hipLaunchKernelGGL((conv3d_gcr_hw_kernel<4, true>), grid, dim3(hb_threads(4)), hb_lds(4), (hipStream_t)stream, ha);
             return vt_check(hipGetLastError(), "vt_conv3d_gcr_f16x3_final");
         }
-        if (tz == 8) hipLaunchKernelGGL(conv3d_gcr_hw_kernel<8>, grid, dim3(hb_threads(8)), hb_lds(8), (hipStream_t)stream, ha);
-        else hipLaunchKernelGGL(conv3d_gcr_hw_kernel<4>, grid, dim3(hb_threads(4)), hb_lds(4), (hipStream_t)stream, ha);
+        if (tz == 8) hipLaunchKernelGGL(conv3d_gcr_hw_kernel<8>, grid, dim3(hb_threads(8)), hb_lds_sparse(8), (hipStream_t)stream, ha);
+        else hipLaunchKernelGGL(conv3d_gcr_hw_kernel<4>, grid, dim3(hb_threads(4)), hb_lds_sparse(4), (hipStream_t)stream, ha);
         return vt_check(hipGetLastError(), "vt_conv3d_gcr_f16x3");
     }
     if (tz == 8) hipLaunchKernelGGL(conv3d_gcr_h_kernel<8>, grid, dim3(hb_threads(8)), hb_lds(8), (hipStream_t)stream, ha);
@@ -2696,12 +2819,12 @@ struct StatRegion { size_t off = 0, words = 0; };                  // the accumu
 // vt_unet3d_fwd with the statistics in accumulator rows: 13 launches fewer (the first finalisation stays: the statistics of x
 // come as partial rows from its producer, and that launch also clears the accumulators)
 int unet3d_run_fold(const float *x_cl, int B, int R, const vt_unet3d_params *p, char *wsbase, size_t *ws_need, float *out,
-                    hipStream_t st, const float *in_part, int in_nblk, StatRegion *region) {
+                    hipStream_t st, const float *in_part, int in_nblk, StatRegion *region, const unsigned char *tile_flags = nullptr) {
     const int L = p->n_levels;
     const bool plan = wsbase == nullptr;
     StatRegion reg;
     if (!plan) {
-        const int rc = unet3d_run_fold(x_cl, B, R, p, nullptr, nullptr, nullptr, st, in_part, in_nblk, &reg);
+        const int rc = unet3d_run_fold(x_cl, B, R, p, nullptr, nullptr, nullptr, st, in_part, in_nblk, &reg, nullptr);
         if (rc) return rc;
     }
     Bump ws{wsbase, 0};
@@ -2731,7 +2854,8 @@ int unet3d_run_fold(const float *x_cl, int B, int R, const vt_unet3d_params *p, 
     };
     int rc = 0;
     // one 'gcr' layer; ss: a finished scale / shift table (the first layer's), else the statistics come through GnIn
-    auto gcr = [&](const vt_unet3d_conv &c, const float *ss, const Tensor &a, const Tensor *low, int Ri, Tensor &o, bool want_stats) -> int {
+    auto gcr = [&](const vt_unet3d_conv &c, const float *ss, const Tensor &a, const Tensor *low, int Ri, Tensor &o, bool want_stats,
+                   const unsigned char *skipf = nullptr) -> int {
         const int C2 = low ? low->C : 0;
         if (a.C + C2 != c.cin) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: channel mismatch between levels");
         o.C = c.cout;
@@ -2745,7 +2869,7 @@ int unet3d_run_fold(const float *x_cl, int B, int R, const vt_unet3d_params *p, 
         const GnIn si = ss ? GnIn{} : stat_in(c, a, low, Ri);
         const float *lx = low ? low->x : nullptr;
         if (kind == CONV_HALF)
-            return conv_h_launch(a.x, a.C, lx, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.cout, 1, o.x, nullptr, nullptr, nullptr, nullptr, st, si, so);
+            return conv_h_launch(a.x, a.C, lx, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.cout, 1, o.x, nullptr, nullptr, nullptr, nullptr, st, si, so, skipf);
         // the thin levels: IEEE-half pairs where the caller packed them (a network whose large levels run the split-f16 kernels)
         const bool thin_half = c.packed_f16x3_thin != nullptr;
         const float *thin_w = thin_half ? c.packed_f16x3_thin : c.packed_bf16x3;
@@ -2787,7 +2911,8 @@ int unet3d_run_fold(const float *x_cl, int B, int R, const vt_unet3d_params *p, 
             cur = pooled;
         }
         Tensor t1, t2;
-        if ((rc = gcr(p->enc[i][0], i == 0 ? ss0 : nullptr, cur, nullptr, Ri, t1, true))) return rc;
+        // (the first layer reads x: where the caller flagged x as zero over a block's halo, the block's taps are skipped)
+        if ((rc = gcr(p->enc[i][0], i == 0 ? ss0 : nullptr, cur, nullptr, Ri, t1, true, i == 0 ? tile_flags : nullptr))) return rc;
         if ((rc = gcr(p->enc[i][1], nullptr, t1, nullptr, Ri, t2, L > 1))) return rc;
         skips[i] = t2;
         cur = t2;
@@ -2818,11 +2943,11 @@ int unet3d_run_fold(const float *x_cl, int B, int R, const vt_unet3d_params *p, 
 
 // plan == true only sizes the workspace
 int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char *wsbase, size_t *ws_need, float *out,
-               hipStream_t st, const float *in_part = nullptr, int in_nblk = 0) {
+               hipStream_t st, const float *in_part = nullptr, int in_nblk = 0, const unsigned char *tile_flags = nullptr) {
     const int L = p->n_levels;
     if (L < 1 || L > VT_UNET_MAX_LEVELS) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: bad level count");
     if (R % (1 << (L - 1))) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: resolution must be divisible by 2^(levels-1)");
-    if (unet3d_fold_ok(B, R, p)) return unet3d_run_fold(x_cl, B, R, p, wsbase, ws_need, out, st, in_part, in_nblk, nullptr);
+    if (unet3d_fold_ok(B, R, p)) return unet3d_run_fold(x_cl, B, R, p, wsbase, ws_need, out, st, in_part, in_nblk, nullptr, tile_flags);
     const bool plan = wsbase == nullptr;
     Bump ws{wsbase, 0};
     int maxC = 0;
@@ -2836,7 +2961,7 @@ int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char 
         t.C = C;
         return plan ? 0 : vt_channel_stats(x, B, V, C, t.nblk, t.part, st);
     };
-    auto gcr = [&](const vt_unet3d_conv &c, const Tensor &a, const Tensor *low, int Ri, Tensor &o) -> int {
+    auto gcr = [&](const vt_unet3d_conv &c, const Tensor &a, const Tensor *low, int Ri, Tensor &o, const unsigned char *skipf = nullptr) -> int {
         const int C2 = low ? low->C : 0;
         if (a.C + C2 != c.cin) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: channel mismatch between levels");
         o.C = c.cout;
@@ -2857,7 +2982,8 @@ int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char 
                                    (int64_t)Ri * Ri * Ri, groups, c.gn_w, c.gn_b, p->eps, ss, st);
         if (rc) return rc;
         if (half)
-            return vt_conv3d_gcr_f16x3(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.cout, 1, o.x, o.part, st);
+            return conv_h_launch(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.cout, 1, o.x, o.part, nullptr, nullptr, nullptr, st,
+                                 GnIn{}, GnOut{}, skipf);
         if (ksbytes)
             return conv_sk_launch(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, thin_w, c.cout, 1, o.x, o.part, GnIn{}, GnOut{},
                                   kws, ksbytes, st, thin_half);
@@ -2893,7 +3019,7 @@ int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char 
             cur = pooled;
         }
         Tensor t1, t2;
-        if ((rc = gcr(p->enc[i][0], cur, nullptr, Ri, t1))) return rc;
+        if ((rc = gcr(p->enc[i][0], cur, nullptr, Ri, t1, i == 0 ? tile_flags : nullptr))) return rc;
         if ((rc = gcr(p->enc[i][1], t1, nullptr, Ri, t2))) return rc;
         skips[i] = t2;
         cur = t2;
@@ -2935,6 +3061,16 @@ int vt_unet3d_fwd_stats(const float *x_cl, const float *in_part, int in_nblk, in
     if (!need) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd_stats: bad configuration");
     if (workspace_bytes < need) return vt_fail(VT_ERR_WORKSPACE, "vt_unet3d_fwd_stats: workspace too small");
     return unet3d_run(x_cl, B, R, params_host, (char *)workspace, nullptr, out, (hipStream_t)stream, in_part, in_nblk);
+}
+
+int vt_unet3d_fwd_skip(const float *x_cl, const float *in_part, int in_nblk, const unsigned char *tile_flags, int B, int R,
+                       const vt_unet3d_params *params_host, void *workspace, size_t workspace_bytes, float *out, void *stream) {
+    if (!x_cl || !tile_flags || !params_host || !workspace || !out || (in_part && in_nblk <= 0))
+        return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd_skip: bad argument");
+    const size_t need = vt_unet3d_workspace_bytes(B, R, params_host);
+    if (!need) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd_skip: bad configuration");
+    if (workspace_bytes < need) return vt_fail(VT_ERR_WORKSPACE, "vt_unet3d_fwd_skip: workspace too small");
+    return unet3d_run(x_cl, B, R, params_host, (char *)workspace, nullptr, out, (hipStream_t)stream, in_part, in_nblk, tile_flags);
 }
 
 int vt_unet3d_fwd(const float *x_cl, int B, int R, const vt_unet3d_params *params_host,

@@ -41,10 +41,13 @@ constexpr size_t SORT_LDS = (size_t)MAX_T * 4 + 2 * (size_t)MAX_T * 2 + (size_t)
 // among equal digits with six ballots (no atomics: the first lane of each digit class writes the class size into the
 // (digit, chunk) table), one block-wide exclusive scan of the table in (digit, chunk) order turns the sizes into
 // offsets, and the elements scatter to offset + rank.  Deterministic; 3 passes x ~3 us instead of 78 bitonic passes.
+constexpr int FLAG_MAX_TILES = 4096;                               // 8^3 blocks of a volume of up to 128^3 voxels
+// `tile_flags` (or null; volumes only): [B][(R/8)^3] bytes, 1 = no point of the scene in the 10^3 halo of that 8^3 block (vt_voxel_tile_flags)
 __global__ void __launch_bounds__(SORT_THREADS)
 voxel_build_kernel(const float *pts, int T, int nbits, int R, float divisor, float clamp_hi, int a0, int a1, int a2,
-                   int *idx, int *order, int *seg_lo, int *seg_hi, int B, uint4 *fill, size_t fill16) {
+                   int *idx, int *order, int *seg_lo, int *seg_hi, int B, uint4 *fill, size_t fill16, unsigned char *tile_flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+    __shared__ unsigned char tflag[FLAG_MAX_TILES];
     if ((int)blockIdx.x >= B) {
         // the workgroups behind the B sorting ones clear a buffer of the caller's (the grid the scatter-mean fills next): the sort keeps
         // one CU per scene busy for ~18 us, the other CUs stream 33 MB of zeros in that time instead of in a launch of their own
@@ -60,6 +63,11 @@ voxel_build_kernel(const float *pts, int T, int nbits, int R, float divisor, flo
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *p = pts + (size_t)b * T * 3;
     const int nround = (T + SORT_THREADS - 1) / SORT_THREADS, nchunk = nround * (SORT_THREADS / 64);
+    const int nt1 = R >> 3;
+    if (tile_flags) {
+        for (int t = tid; t < nt1 * nt1 * nt1; t += SORT_THREADS) tflag[t] = 1;
+        __syncthreads();
+    }
     for (int t = tid; t < T; t += SORT_THREADS) {
         // cell id = i(a0) + R * (i(a1) + R * i(a2)); a plane has no third axis (a2 < 0)
         const int ix = voxel_coord(p[3 * t + a0], divisor, clamp_hi, R);
@@ -69,8 +77,14 @@ voxel_build_kernel(const float *pts, int T, int nbits, int R, float divisor, flo
         idx[(size_t)b * T + t] = id;
         ids[t] = (unsigned)id;
         perm_a[t] = (unsigned short)t;
+        if (tile_flags)                                             // the blocks whose halo [8 t - 1, 8 t + 8] holds the voxel
+            for (int tz = max((iz - 1) >> 3, 0); tz <= min((iz + 1) >> 3, nt1 - 1); ++tz)
+                for (int ty = max((iy - 1) >> 3, 0); ty <= min((iy + 1) >> 3, nt1 - 1); ++ty)
+                    for (int tx = max((ix - 1) >> 3, 0); tx <= min((ix + 1) >> 3, nt1 - 1); ++tx) tflag[(tz * nt1 + ty) * nt1 + tx] = 0;
     }
     __syncthreads();
+    if (tile_flags)
+        for (int t = tid; t < nt1 * nt1 * nt1; t += SORT_THREADS) tile_flags[(size_t)b * nt1 * nt1 * nt1 + t] = tflag[t];
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int shift = 0; shift < nbits; shift += RADIX_BITS) {
         for (int e = tid; e < RADIX * nchunk; e += SORT_THREADS) table[e] = 0;
@@ -451,9 +465,32 @@ inline unsigned blocks_for(size_t total) {
     return (unsigned)(g < cap ? (g ? g : 1) : cap);
 }
 
+// flags[b][tile] = 1 where no point of scene b lies in the 10^3 halo of the 8^3 voxel block `tile` (the voxels a 3x3x3 conv over the
+// block reads): the scatter-mean grid is zero there.  One workgroup per scene; the flags of a scene fit its LDS (R <= 128: 4096 blocks).
+__global__ void __launch_bounds__(256)
+tile_flags_kernel(const int *idx, int T, int R, unsigned char *flags) {
+    __shared__ unsigned char f[FLAG_MAX_TILES];
+    const int b = blockIdx.x, nt1 = R >> 3, nt = nt1 * nt1 * nt1;
+    for (int t = threadIdx.x; t < nt; t += 256) f[t] = 1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += 256) {
+        const int id = idx[(size_t)b * T + i];
+        const int x = id % R, y = (id / R) % R, z = id / (R * R);
+        // the blocks whose halo [8 t - 1, 8 t + 8] contains the voxel: t from (v - 8) / 8 rounded up to (v + 1) / 8
+        const int x0 = max((x - 1) >> 3, 0), x1 = min((x + 1) >> 3, nt1 - 1);
+        const int y0 = max((y - 1) >> 3, 0), y1 = min((y + 1) >> 3, nt1 - 1);
+        const int z0 = max((z - 1) >> 3, 0), z1 = min((z + 1) >> 3, nt1 - 1);
+        for (int tz = z0; tz <= z1; ++tz)
+            for (int ty = y0; ty <= y1; ++ty)
+                for (int tx = x0; tx <= x1; ++tx) f[(tz * nt1 + ty) * nt1 + tx] = 0;         // (racing stores of the same value)
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nt; t += 256) flags[(size_t)b * nt + t] = f[t];
+}
+
 int build_launch(const char *who, const float *pts, int B, int T, int R, float divisor, float clamp_hi,
                  int a0, int a1, int a2, int *idx, int *order, int *seg_lo, int *seg_hi, void *stream,
-                 void *fill = nullptr, size_t fill_bytes = 0) {
+                 void *fill = nullptr, size_t fill_bytes = 0, unsigned char *tile_flags = nullptr) {
     char msg[96];
     auto fail = [&](int code, const char *what) { snprintf(msg, sizeof msg, "%s: %s", who, what); return vt_fail(code, msg); };
     if (!pts || !idx || !order || !seg_lo || !seg_hi) return fail(VT_ERR_INVALID, "null argument");
@@ -465,6 +502,7 @@ int build_launch(const char *who, const float *pts, int B, int T, int R, float d
     while (nbits < 32 && (1ull << nbits) < cells) ++nbits;
     static const bool force_global = getenv("VTACO_VOXEL_GLOBAL_SORT") != nullptr;     // tests: the large-cloud path on small clouds
     if (fill_bytes && (!fill || (fill_bytes & 15) || ((size_t)fill & 15))) return fail(VT_ERR_INVALID, "the buffer to clear must be 16-byte aligned and sized");
+    if (tile_flags && (a2 < 0 || R < 8 || (R & 7) || R > 128)) return fail(VT_ERR_UNSUPPORTED, "block flags: a volume whose resolution is a multiple of 8, at most 128");
     if (T > MAX_T || (force_global && T >= 64)) {
         hipStream_t s = (hipStream_t)stream;
         if (fill_bytes) { const int frc = vt_fill32(fill, 0u, fill_bytes, s); if (frc) return frc; }
@@ -479,6 +517,7 @@ int build_launch(const char *who, const float *pts, int B, int T, int R, float d
             int *sw = cur; cur = oth; oth = sw;
         }
         hipLaunchKernelGGL(segment_bounds_kernel, pg, dim3(256), 0, s, idx, order, T, seg_lo, seg_hi);
+        if (tile_flags) hipLaunchKernelGGL(tile_flags_kernel, dim3((unsigned)B), dim3(256), 0, s, idx, T, R, tile_flags);
         return vt_check(hipGetLastError(), who);
     }
     static bool attr_set = false;
@@ -492,13 +531,20 @@ int build_launch(const char *who, const float *pts, int B, int T, int R, float d
     size_t fb = (fill16 + SORT_THREADS * 16 - 1) / (SORT_THREADS * 16);                 // >= 16 stores per thread, at most two rounds of the chip
     if (fb > (size_t)vt_num_cus() * 2) fb = (size_t)vt_num_cus() * 2;
     hipLaunchKernelGGL(voxel_build_kernel, dim3((unsigned)(B + fb)), dim3(SORT_THREADS), SORT_LDS, (hipStream_t)stream,
-                       pts, T, nbits, R, divisor, clamp_hi, a0, a1, a2, idx, order, seg_lo, seg_hi, B, (uint4 *)fill, fill16);
+                       pts, T, nbits, R, divisor, clamp_hi, a0, a1, a2, idx, order, seg_lo, seg_hi, B, (uint4 *)fill, fill16, tile_flags);
     return vt_check(hipGetLastError(), who);
 }
 
 }  // namespace
 
 extern "C" {
+
+int vt_voxel_tile_flags(const int *idx, int B, int T, int R, unsigned char *flags, void *stream) {
+    if (!idx || !flags || B <= 0 || T <= 0) return vt_fail(VT_ERR_INVALID, "vt_voxel_tile_flags: bad argument");
+    if (R < 8 || (R & 7) || R > 128) return vt_fail(VT_ERR_UNSUPPORTED, "vt_voxel_tile_flags: resolution must be a multiple of 8, at most 128");
+    hipLaunchKernelGGL(tile_flags_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, idx, T, R, flags);
+    return vt_check(hipGetLastError(), "vt_voxel_tile_flags");
+}
 
 int vt_voxel_build(const float *pts, int B, int T, int R, double padding,
                    int *idx, int *order, int *seg_lo, int *seg_hi, void *stream) {
@@ -510,6 +556,13 @@ int vt_voxel_build_clear(const float *pts, int B, int T, int R, double padding,
                          int *idx, int *order, int *seg_lo, int *seg_hi, void *clear, size_t clear_bytes, void *stream) {
     return build_launch("vt_voxel_build_clear", pts, B, T, R, (float)(1.0 + padding + 10e-4), 0.999f, 0, 1, 2,
                         idx, order, seg_lo, seg_hi, stream, clear, clear_bytes);
+}
+
+int vt_voxel_build_clear_flags(const float *pts, int B, int T, int R, double padding, int *idx, int *order, int *seg_lo, int *seg_hi,
+                               void *clear, size_t clear_bytes, unsigned char *tile_flags, void *stream) {
+    if (!tile_flags) return vt_fail(VT_ERR_INVALID, "vt_voxel_build_clear_flags: null flags");
+    return build_launch("vt_voxel_build_clear_flags", pts, B, T, R, (float)(1.0 + padding + 10e-4), 0.999f, 0, 1, 2,
+                        idx, order, seg_lo, seg_hi, stream, clear, clear_bytes, tile_flags);
 }
 
 int vt_plane_build(const float *pts, int B, int T, int R, double padding, int plane,

@@ -176,6 +176,8 @@ class LocalPoolPointnet(nn.Module):
         self.unet3d = UNet3D(**unet3d_kwargs).to(memory_format=torch.channels_last_3d) if unet3d else None
         self.reso_plane, self.reso_grid = plane_resolution, grid_resolution
         self.plane_type, self.padding = plane_type, padding
+        # inference: the UNet3D's first layer skips the 8^3 blocks of the mean grid that no point comes near (ops.voxel_tile_flags)
+        self.skip_empty = os.environ.get("VTACO_UNET_SKIP", "1") != "0"
         # UNet3D under autograd: "hip" = vt_* forward and backward kernels (UNet3D.forward_channels_last_train),
         # "host" = PyTorch-ROCm autograd (MIOpen; fast only in find mode, torch.backends.cudnn.benchmark = True)
         self.train_unet3d = os.environ.get("VTACO_TRAIN_UNET3D", "hip")
@@ -302,17 +304,20 @@ class LocalPoolPointnet(nn.Module):
         # the mean grid is cleared by the voxel sort's idle workgroups (one launch less; unused if a cell overflows the one-launch MLP)
         R = self.reso_grid
         zeroed = torch.empty((p.shape[0], R, R, R, self.c_dim), dtype=torch.float32, device=p.device) if one_launch else None
-        vi = ops.VoxelIndex(p, self.reso_grid, self.padding, clear=zeroed)
+        # inference: the blocks of the grid no point comes near are zero, and the UNet3D's first layer skips them (VTACO_UNET_SKIP=0: dense)
+        skip = self.skip_empty and self.unet3d is not None and not torch.is_grad_enabled() and self.unet3d.hip_supported()
+        vi = ops.VoxelIndex(p, self.reso_grid, self.padding, clear=zeroed, want_tile_flags=skip)
+        flags = vi.tile_flags
         if one_launch and self._one_launch_fits(vi):
             # inference: the per-point MLP, the voxeliser's mean and the grid's GroupNorm statistics from one launch, then the UNet3D
             grid, stats = ops.pointnet_mlp_fused(p.float(), vi, self.fc_pos, self.blocks, self.fc_c, want_grid=True,
                                                  weights=self._fused_weights(), zeroed_grid=zeroed)
-            return {'grid': self.unet3d.forward_channels_last(grid, in_stats=stats).permute(0, 4, 1, 2, 3)}
+            return {'grid': self.unet3d.forward_channels_last(grid, in_stats=stats, tile_flags=flags).permute(0, 4, 1, 2, 3)}
         feat = self.point_features(p.float(), vi)
         if self.unet3d is not None and not torch.is_grad_enabled() and self.unet3d.hip_supported():
             # inference: scatter straight into a channels-last grid, UNet3D on the HIP conv kernels,
             # and hand the decoder the layout it samples (shape [B,C,R,R,R], channels-last strides)
-            grid = self.unet3d.forward_channels_last(ops.voxel_scatter_mean_cl_fwd(feat, vi))
+            grid = self.unet3d.forward_channels_last(ops.voxel_scatter_mean_cl_fwd(feat, vi), tile_flags=flags)
             return {'grid': grid.permute(0, 4, 1, 2, 3)}
         if self.unet3d is not None and self.unet3d.hip_supported() and self.train_unet3d == "hip":
             # training on the HIP kernels: differentiable channels-last forward, HIP backward

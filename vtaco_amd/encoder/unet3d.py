@@ -298,13 +298,14 @@ class UNet3D(nn.Module):
             self._pack_cache[key] = hit
         return hit[1]
 
-    def forward_channels_last(self, x, in_stats=None):
+    def forward_channels_last(self, x, in_stats=None, tile_flags=None):
         """x [B,D,H,W,C] channels-last -> [B,D,H,W,out_channels]; inference only (no autograd).
         One C-ABI call (vt_unet3d_fwd) runs every launch of the network back to back.  ``in_stats`` = (part, nblk): the input's
-        GroupNorm partial sums when its producer already has them (the one-launch PointNet MLP)."""
+        GroupNorm partial sums when its producer already has them (the one-launch PointNet MLP).  ``tile_flags``
+        (ops.voxel_tile_flags): the 8^3 blocks over whose halo x is zero; the first layer skips their taps."""
         if x.shape[1] == x.shape[2] == x.shape[3]:
             prm, keep = self._hip_params()
-            y = ops.unet3d_fwd(x.contiguous(), prm, keep, in_stats=in_stats)
+            y = ops.unet3d_fwd(x.contiguous(), prm, keep, in_stats=in_stats, tile_flags=tile_flags)
             if self.testing and self.final_activation is not None:
                 y = self.final_activation(y) if isinstance(self.final_activation, nn.Sigmoid) else torch.softmax(y, dim=-1)
             return y

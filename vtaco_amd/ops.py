@@ -409,7 +409,7 @@ class VoxelIndex:
     """Per-forward voxel bookkeeping of a point cloud [B,T,3] (vt_voxel_build).  ``clear``: a contiguous float tensor the same
     launch zero-fills with the workgroups the sort leaves idle (vt_voxel_build_clear: the mean grid, without a fill launch)."""
 
-    def __init__(self, pts, reso, padding=0.1, clear=None):
+    def __init__(self, pts, reso, padding=0.1, clear=None, want_tile_flags=False):
         pts = pts.detach().float()
         if not pts.is_contiguous():
             pts = pts.contiguous()
@@ -420,6 +420,19 @@ class VoxelIndex:
         self.order = torch.empty((B, T), dtype=I32, device=dev)
         self.seg_lo = torch.empty((B, T), dtype=I32, device=dev)
         self.seg_hi = torch.empty((B, T), dtype=I32, device=dev)
+        # ``want_tile_flags``: uint8 [B, (reso/8)^3], 1 where no point lies in the 10^3 halo of that 8^3 block (voxel_tile_flags),
+        # marked by the same launch (vt_voxel_build_clear_flags); None where the resolution is not covered
+        self.tile_flags = None
+        if want_tile_flags and reso % 8 == 0 and 8 <= reso <= 128:
+            self.tile_flags = torch.empty((B, (reso // 8) ** 3), dtype=torch.uint8, device=dev)
+            check(_lib.load().vt_voxel_build_clear_flags(dev_ptr(pts, "pts"), B, T, reso, float(padding),
+                                                         dev_ptr(self.idx, "idx", I32), dev_ptr(self.order, "order", I32),
+                                                         dev_ptr(self.seg_lo, "seg_lo", I32), dev_ptr(self.seg_hi, "seg_hi", I32),
+                                                         dev_ptr(clear, "clear") if clear is not None else None,
+                                                         clear.numel() * clear.element_size() if clear is not None else 0,
+                                                         dev_ptr(self.tile_flags, "tile_flags", torch.uint8), stream_ptr()),
+                  "vt_voxel_build_clear_flags")
+            return
         if clear is not None:
             check(_lib.load().vt_voxel_build_clear(dev_ptr(pts, "pts"), B, T, reso, float(padding),
                                                    dev_ptr(self.idx, "idx", I32), dev_ptr(self.order, "order", I32),
@@ -431,6 +444,18 @@ class VoxelIndex:
                                          dev_ptr(self.idx, "idx", I32), dev_ptr(self.order, "order", I32),
                                          dev_ptr(self.seg_lo, "seg_lo", I32), dev_ptr(self.seg_hi, "seg_hi", I32),
                                          stream_ptr()), "vt_voxel_build")
+
+
+def voxel_tile_flags(vi):
+    """uint8 [B, (R/8)^3]: 1 where no point of the scene lies in the 10^3 halo of that 8^3 voxel block (vt_voxel_tile_flags) -- the
+    mean grid is zero over everything a 3x3x3 conv of the block reads, so the UNet3D's first layer can skip the block's taps
+    (unet3d_fwd(tile_flags=...)).  None where the resolution is not covered (not a multiple of 8, or above 128)."""
+    if vi.R % 8 or vi.R < 8 or vi.R > 128:
+        return None
+    flags = torch.empty((vi.B, (vi.R // 8) ** 3), dtype=torch.uint8, device=vi.idx.device)
+    check(_lib.load().vt_voxel_tile_flags(dev_ptr(vi.idx, "idx", I32), vi.B, vi.T, vi.R, dev_ptr(flags, "flags", torch.uint8), stream_ptr()),
+          "vt_voxel_tile_flags")
+    return flags
 
 
 def _c(t):
@@ -1133,6 +1158,23 @@ def conv3d_gcr_final(x, ss, packed_w_f16x3, final_packed, final_bias):
     return out
 
 
+def conv3d_gcr_skip(x, ss, packed_w_f16x3, Cout, tile_flags, relu=True):
+    """relu?(conv3x3x3(x * scale + shift)) with the taps of the flagged 8^3 blocks skipped (vt_conv3d_gcr_f16x3_skip; plain layers on
+    the persistent split-f16 kernel): returns (out, (part, nblk)).  ``tile_flags`` [B, (D/8)(H/8)(W/8)] uint8, 1 = x is zero over the
+    block's halo."""
+    lib = _lib.load()
+    B, D, H, W, C = x.shape
+    nblk = lib.vt_conv3d_stat_blocks_f16x3(B, D, H, W, C, Cout)
+    if not nblk:
+        raise VtError("conv3d_gcr_skip: shape not covered by the split-f16 kernel")
+    out = torch.empty((B, D, H, W, Cout), dtype=torch.float32, device=x.device)
+    part = torch.empty((B, nblk, Cout, 2), dtype=torch.float32, device=x.device)
+    check(lib.vt_conv3d_gcr_f16x3_skip(dev_ptr(x, "x"), C, B, D, H, W, dev_ptr(ss, "scale_shift"), dev_ptr(packed_w_f16x3, "packed_w"), Cout,
+                                       int(relu), dev_ptr(tile_flags, "tile_flags", torch.uint8), dev_ptr(out, "out"), dev_ptr(part, "part"),
+                                       stream_ptr()), "vt_conv3d_gcr_f16x3_skip")
+    return out, (part, nblk)
+
+
 def final_fusable(x, Cout):
     B, D, H, W, C1 = x.shape
     return bool(_lib.load().vt_conv3d_final_fusable(B, D, H, W, C1, Cout))
@@ -1343,10 +1385,11 @@ def conv1x1_cl(x, weight, bias):
 _unet_ws = {}
 
 
-def unet3d_fwd(x_cl, params, keep, in_stats=None):
+def unet3d_fwd(x_cl, params, keep, in_stats=None, tile_flags=None):
     """Whole UNet3D forward (vt_unet3d_fwd).  ``params``: a filled _lib.UnetParams; ``keep``: the
     tensors its pointers refer to (kept alive by the caller).  ``in_stats`` = (part, nblk): GroupNorm partial sums of the
-    input that its producer already has (vt_unet3d_fwd_stats: no statistics pass over the input)."""
+    input that its producer already has (vt_unet3d_fwd_stats: no statistics pass over the input).  ``tile_flags``
+    (voxel_tile_flags): the 8^3 blocks over whose halo x is zero -- the first layer skips their taps (vt_unet3d_fwd_skip)."""
     lib = _lib.load()
     B, R = x_cl.shape[0], x_cl.shape[1]
     need = lib.vt_unet3d_workspace_bytes(B, R, ctypes.byref(params))
@@ -1359,6 +1402,13 @@ def unet3d_fwd(x_cl, params, keep, in_stats=None):
         ws = _unet_ws[key] = torch.empty(need, dtype=torch.uint8, device=x_cl.device)
     keep_for_graph(ws, *keep)
     out = torch.empty((B, R, R, R, params.out_channels), dtype=torch.float32, device=x_cl.device)
+    if tile_flags is not None:
+        keep_for_graph(tile_flags, *([in_stats[0]] if in_stats is not None else []))
+        check(lib.vt_unet3d_fwd_skip(dev_ptr(x_cl, "x"), dev_ptr(in_stats[0], "in_part") if in_stats is not None else None,
+                                     int(in_stats[1]) if in_stats is not None else 0, dev_ptr(tile_flags, "tile_flags", torch.uint8), B, R,
+                                     ctypes.byref(params), ctypes.c_void_p(ws.data_ptr()), need, dev_ptr(out, "out"), stream_ptr()),
+              "vt_unet3d_fwd_skip")
+        return out
     if in_stats is not None:
         keep_for_graph(in_stats[0])
         check(lib.vt_unet3d_fwd_stats(dev_ptr(x_cl, "x"), dev_ptr(in_stats[0], "in_part"), int(in_stats[1]), B, R, ctypes.byref(params),
