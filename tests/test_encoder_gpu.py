@@ -618,3 +618,33 @@ def test_block_flags_from_the_voxel_sort_equal_the_standalone_kernel(monkeypatch
         assert spread > 0.3 or R == 8 or 0 < int(want.sum()) < want.numel()         # a compact cloud leaves empty blocks
         assert torch.equal(ops.VoxelIndex(p, R, 0.1, want_tile_flags=True).tile_flags, want)
     assert ops.VoxelIndex(p, 12, 0.1, want_tile_flags=True).tile_flags is None      # not a multiple of 8: no flags, dense first layer
+
+
+def test_training_forward_skips_the_empty_blocks_too():
+    """LocalPoolPointnet(train_unet3d="hip") under autograd: the first layer's forward takes the block flags as in inference, the backward is
+    unchanged -- the grid agrees with the dense first layer to rounding, the parameter gradients to the stack's own sensitivity."""
+    from vtaco_amd.bench_util import sphere_cloud
+    from vtaco_amd.encoder import encoder_dict
+    torch.manual_seed(6)
+    enc = encoder_dict['pointnet_local_pool'](c_dim=32, dim=3, hidden_dim=32, unet3d=True, grid_resolution=64, plane_type='grid',
+                                              unet3d_kwargs=dict(num_levels=3, f_maps=32, in_channels=32, out_channels=32)).to(DEV).train()
+    enc.train_unet3d = "hip"
+    pc = torch.cat([sphere_cloud(2), sphere_cloud(3) * 0.6 - 0.1]).to(DEV)
+    probe = torch.randn(2, 32, 64, 64, 64, generator=torch.Generator().manual_seed(1)).to(DEV)
+
+    def run(skip):
+        enc.skip_empty = skip
+        enc.zero_grad()
+        grid = enc(pc)["grid"]
+        (grid * probe).sum().backward()
+        return grid.detach().clone(), {n: p.grad.detach().clone() for n, p in enc.named_parameters() if p.grad is not None}
+    g1, d1 = run(True)
+    g0, d0 = run(False)
+    assert float((g1 - g0).abs().max()) <= 1e-5 * float(g0.abs().max())
+    assert d1.keys() == d0.keys() and len(d0) > 20
+    # the gradients of this GroupNorm / ReLU / max-pool stack are discontinuous in its activations at the 1e-6 level (ReLU masks flip:
+    # test_hip_unet3d_training_path_vs_host_autograd measures ~1 % in L2 under such a perturbation), and the skipped blocks differ from
+    # the dense ones by the rounding of their constants: the bound is that sensitivity, not rounding
+    l2 = lambda a, b: float((a - b).norm()) / max(float(b.norm()), 1e-20)
+    worst = max(l2(d1[n], d0[n]) for n in d0)
+    assert worst <= 1e-2, worst

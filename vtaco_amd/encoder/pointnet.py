@@ -304,8 +304,8 @@ class LocalPoolPointnet(nn.Module):
         # the mean grid is cleared by the voxel sort's idle workgroups (one launch less; unused if a cell overflows the one-launch MLP)
         R = self.reso_grid
         zeroed = torch.empty((p.shape[0], R, R, R, self.c_dim), dtype=torch.float32, device=p.device) if one_launch else None
-        # inference: the blocks of the grid no point comes near are zero, and the UNet3D's first layer skips them (VTACO_UNET_SKIP=0: dense)
-        skip = self.skip_empty and self.unet3d is not None and not torch.is_grad_enabled() and self.unet3d.hip_supported()
+        # the blocks of the grid no point comes near are zero, and the UNet3D's first layer skips their taps (VTACO_UNET_SKIP=0: dense)
+        skip = self.skip_empty and self.unet3d is not None and self.unet3d.hip_supported() and (not torch.is_grad_enabled() or self.train_unet3d == "hip")
         vi = ops.VoxelIndex(p, self.reso_grid, self.padding, clear=zeroed, want_tile_flags=skip)
         flags = vi.tile_flags
         if one_launch and self._one_launch_fits(vi):
@@ -322,7 +322,7 @@ class LocalPoolPointnet(nn.Module):
         if self.unet3d is not None and self.unet3d.hip_supported() and self.train_unet3d == "hip":
             # training on the HIP kernels: differentiable channels-last forward, HIP backward
             grid_cl = _ScatterMeanCL.apply(feat, vi).permute(0, 2, 3, 4, 1)
-            return {'grid': self.unet3d.forward_channels_last_train(grid_cl).permute(0, 4, 1, 2, 3)}
+            return {'grid': self.unet3d.forward_channels_last_train(grid_cl, tile_flags=flags).permute(0, 4, 1, 2, 3)}
         if self.unet3d is not None:
             # training through host PyTorch-ROCm autograd (MIOpen), channels-last end to end
             return {'grid': self.unet3d(_ScatterMeanCL.apply(feat, vi))}

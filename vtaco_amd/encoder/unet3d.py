@@ -90,7 +90,7 @@ class _GcrFn(torch.autograd.Function):
     vt_gn_bwd accounts for the statistics' dependence on x)."""
 
     @staticmethod
-    def forward(ctx, x, low, gamma, beta, weight, x_part, low_part, groups, eps, precision):
+    def forward(ctx, x, low, gamma, beta, weight, x_part, low_part, groups, eps, precision, tile_flags=None):
         B, D, H, W, C1 = x.shape
         C2 = low.shape[-1] if low is not None else 0
         Cout = weight.shape[0]
@@ -101,7 +101,11 @@ class _GcrFn(torch.autograd.Function):
         # "f16x3": the forward conv on split-f16 operands where that kernel covers the shape (its inputs are GroupNorm outputs:
         # inside the half range, error at f32 rounding level)
         half = ops.conv3d_pack(weight, "f16x3") if precision == "f16x3" else None
-        y, (part, _) = ops.conv3d_gcr(x, low, ss, lambda: ops.conv3d_pack(weight), Cout, True, split, packed_w_f16x3=half)    # f32 pack on demand
+        if tile_flags is not None and half is not None and low is None and ops.conv3d_skip_covers(x, Cout):
+            # the network's first layer on a mean grid: the blocks no point comes near are filled from the border-class constants
+            y, (part, _) = ops.conv3d_gcr_skip(x, ss, half, Cout, tile_flags)
+        else:
+            y, (part, _) = ops.conv3d_gcr(x, low, ss, lambda: ops.conv3d_pack(weight), Cout, True, split, packed_w_f16x3=half)    # f32 pack on demand
         ctx.save_for_backward(x, low, gamma, weight, ss, y, x_part, low_part)
         ctx.cfg = (groups, eps, precision)
         ctx.mark_non_differentiable(part)
@@ -132,7 +136,7 @@ class _GcrFn(torch.autograd.Function):
         dskip, dlow, dgamma, dbeta = ops.gn_bwd(x, x_st, low, low_st, dxn, gamma, groups, eps,
                                                 want_skip=ctx.needs_input_grad[0],
                                                 want_low=low is not None and ctx.needs_input_grad[1])
-        return dskip, dlow, dgamma, dbeta, dw, None, None, None, None, None
+        return dskip, dlow, dgamma, dbeta, dw, None, None, None, None, None, None
 
 
 class _MaxPoolFn(torch.autograd.Function):
@@ -348,7 +352,7 @@ class UNet3D(nn.Module):
             x = self.final_activation(x) if isinstance(self.final_activation, nn.Sigmoid) else torch.softmax(x, dim=-1)
         return x
 
-    def forward_channels_last_train(self, x):
+    def forward_channels_last_train(self, x, tile_flags=None):
         """Differentiable channels-last forward on the HIP kernels (training): same layers as
         ``forward_channels_last_layers`` as autograd Functions whose backward is HIP too (data gradient
         = the forward conv kernels on flipped weights, vt_conv3d_wgrad, vt_gn_bwd, vt_maxpool3d_cl_bwd);
@@ -356,9 +360,9 @@ class UNet3D(nn.Module):
         def stats(t):
             return ops.channel_stats(t.detach())[0]
 
-        def gcr(single, t, part, low=None, low_part=None):
+        def gcr(single, t, part, low=None, low_part=None, flags=None):
             gn, conv = single.groupnorm, single.conv
-            return _GcrFn.apply(t, low, gn.weight, gn.bias, conv.weight, part, low_part, gn.num_groups, gn.eps, self.train_precision)
+            return _GcrFn.apply(t, low, gn.weight, gn.bias, conv.weight, part, low_part, gn.num_groups, gn.eps, self.train_precision, flags)
         skips = []
         part = None
         for i, enc in enumerate(self.encoders):
@@ -366,7 +370,7 @@ class UNet3D(nn.Module):
                 x = _MaxPoolFn.apply(x)
             if i > 0 or part is None:
                 part = stats(x)
-            x, part = gcr(enc.basic_module.SingleConv1, x, part)
+            x, part = gcr(enc.basic_module.SingleConv1, x, part, flags=tile_flags if i == 0 else None)
             x, part = gcr(enc.basic_module.SingleConv2, x, part)
             skips.append((x, part))
         for dec, (skip, skip_part) in zip(self.decoders, skips[-2::-1]):

@@ -1158,6 +1158,12 @@ def conv3d_gcr_final(x, ss, packed_w_f16x3, final_packed, final_bias):
     return out
 
 
+def conv3d_skip_covers(x, Cout):
+    """Does the persistent split-f16 kernel (the one that takes block flags) run a plain layer of this shape?"""
+    B, D, H, W, C = x.shape
+    return bool(_lib.load().vt_conv3d_stat_blocks_f16x3(B, D, H, W, C, Cout))
+
+
 def conv3d_gcr_skip(x, ss, packed_w_f16x3, Cout, tile_flags, relu=True):
     """relu?(conv3x3x3(x * scale + shift)) with the taps of the flagged 8^3 blocks skipped (vt_conv3d_gcr_f16x3_skip; plain layers on
     the persistent split-f16 kernel): returns (out, (part, nblk)).  ``tile_flags`` [B, (D/8)(H/8)(W/8)] uint8, 1 = x is zero over the
