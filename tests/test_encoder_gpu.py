@@ -602,12 +602,13 @@ def test_encoder_skips_the_empty_blocks_of_the_first_layer():
     assert 0.0 < err <= 1e-5 * scale, (err, scale)
 
 
-def test_block_flags_from_the_voxel_sort_equal_the_standalone_kernel(monkeypatch):
+def test_block_flags_from_the_voxel_sort_equal_the_standalone_kernel():
     """vt_voxel_build_clear_flags marks the empty blocks while it computes the voxel ids; vt_voxel_tile_flags does it from the ids.
-    Same flags on clouds of different spread, with and without the buffer to clear, also through the large-cloud path."""
+    Same flags on clouds of different spread, with and without the buffer to clear, also for a cloud of more than 8192 points (the
+    sort through global memory, which flags with the standalone kernel)."""
     from vtaco_amd import ops
     g = torch.Generator().manual_seed(9)
-    for B, T, R, spread in ((2, 3000, 64, 0.3), (1, 500, 32, 0.5), (3, 2000, 128, 0.2), (1, 100, 8, 0.5)):
+    for B, T, R, spread in ((2, 3000, 64, 0.3), (1, 500, 32, 0.5), (3, 2000, 128, 0.2), (1, 100, 8, 0.5), (1, 9000, 64, 0.25)):
         p = ((torch.rand(B, T, 3, generator=g) - 0.5) * 2 * spread).to(DEV)
         clear = torch.full((B * R * R * 16,), 3.0, device=DEV)
         vi = ops.VoxelIndex(p, R, 0.1, clear=clear, want_tile_flags=True)
