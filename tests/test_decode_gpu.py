@@ -200,18 +200,25 @@ def test_lattice_launches_leave_their_clock_stamps():
     sc = build_scene(0, dev)
     dec, grid = sc["model"].decoder, sc["grid"]
     for prec in ("f16x3", "f32"):
-        with torch.no_grad():
-            for _ in range(20):
+        seen = []
+        for attempt in range(5):                                    # (the event pair also times the host's launch: a hiccup there is retried)
+            with torch.no_grad():
+                for _ in range(20):
+                    dec.decode_lattice(grid, 128, precision=prec)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 dec.decode_lattice(grid, 128, precision=prec)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            dec.decode_lattice(grid, 128, precision=prec)
-            e1.record()
-            torch.cuda.synchronize()
-        c = ops.decode_last_clock(workgroups=True)
-        assert c is not None and c["workgroups"] >= 8 and len(c["wg_ticks"]) == c["workgroups"]
-        assert 500.0 < c["shader_mhz"] < 3000.0, c["shader_mhz"]
-        assert c["start_spread_us"] < 20.0 and c["wg_us_min"] > 0.0 and c["wg_us_max"] <= c["span_us"] + 1e-6
-        ms = e0.elapsed_time(e1)
-        assert 0.5 * ms <= c["span_us"] * 1e-3 <= 1.05 * ms, (prec, c["span_us"], ms)
+                e1.record()
+                torch.cuda.synchronize()
+            c = ops.decode_last_clock(workgroups=True)
+            assert c is not None and c["workgroups"] >= 8 and len(c["wg_ticks"]) == c["workgroups"]
+            assert 500.0 < c["shader_mhz"] < 3000.0, c["shader_mhz"]
+            assert c["start_spread_us"] < 20.0 and c["wg_us_min"] > 0.0 and c["wg_us_max"] <= c["span_us"] + 1e-6
+            ms = e0.elapsed_time(e1)
+            seen.append((c["span_us"], ms))
+            assert c["span_us"] * 1e-3 <= 1.05 * ms, (prec, seen)   # the kernel's own span never exceeds what the events saw
+            if 0.5 * ms <= c["span_us"] * 1e-3:
+                break
+        else:
+            raise AssertionError((prec, seen))
