@@ -1,7 +1,7 @@
 """Randomised differential testing on the GPU (not collected by pytest: run `python tests/stress_gpu.py [seconds]`).
 Marching cubes against the C oracle on random shapes / fields / levels, the decode kernels against the torch oracle on
 random (B, N, R) and lattices, the voxeliser against the oracle on random clouds, the fusion pipeline on ragged N, the
-UNet3D forward (both conv precisions) on small volumes, the hand branch (plane ids / scatter, the PointNet MLP kernels,
+UNet3D forward (both conv precisions) on small volumes, its first layer with the empty blocks skipped, the hand branch (plane ids / scatter, the PointNet MLP kernels,
 the MANO layer on random synthetic assets), the winding-number kernel on random triangle soups.  Prints a summary; exits 1 on a mismatch."""
 import os
 import sys
@@ -163,6 +163,40 @@ def one_unet():
         fails.append(("unet3d", R, levels, B, net.precision, err))
 
 
+def one_skip():
+    """The first layer without its empty blocks (vt_voxel_build_clear_flags + vt_conv3d_gcr_f16x3_skip) against the dense kernel on the
+    mean grid of a random cloud: random spread / offset (clouds in a corner, on the border, everywhere), scenes, resolution, widths."""
+    B, R = int(rng.randint(1, 4)), int(rng.choice([32, 64]))
+    C, Cout = 32, int(rng.choice([32, 64]))
+    if not ops._lib.load().vt_conv3d_stat_blocks_f16x3(B, R, R, R, C, Cout):
+        return
+    g = torch.Generator().manual_seed(int(rng.randint(1 << 30)))
+    T = int(rng.choice([1, 50, 3000]))
+    spread, off = float(rng.choice([0.02, 0.2, 0.55])), (torch.rand(B, 1, 3, generator=g) - 0.5) * float(rng.choice([0.0, 0.6, 1.0]))
+    p = ((torch.rand(B, T, 3, generator=g) - 0.5) * 2 * spread + off).clamp(-0.54, 0.54).to(DEV)
+    grid = torch.empty(B, R, R, R, C, device=DEV)
+    vi = ops.VoxelIndex(p, R, 0.1, clear=grid, want_tile_flags=True)
+    feat = torch.randn(B, T, C, generator=g).to(DEV)
+    x = ops.voxel_scatter_mean_cl_fwd(feat, vi)
+    w = (torch.randn(Cout, C, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV), (0.3 * torch.randn(C, generator=g)).to(DEV)
+    ss = ops.gn_scale_shift(ops.channel_stats(x), None, C, 0, B, R ** 3, gamma, beta, 8, 1e-5, DEV)
+    ph = ops.conv3d_pack(w, precision="f16x3")
+    ref, (rp, _) = ops.conv3d_gcr(x, None, ss, None, Cout, True, None, packed_w_f16x3=ph)
+    got, (gp, _) = ops.conv3d_gcr_skip(x, ss, ph, Cout, vi.tile_flags)
+    # the flags may only mark blocks whose halo is zero in x
+    occ = (x.abs().sum(-1) > 0)
+    nt = R // 8
+    halo = torch.nn.functional.max_pool3d(occ.float().unsqueeze(1), 3, 1, 1)                   # a voxel or one of its 26 neighbours occupied
+    blocks = torch.nn.functional.max_pool3d(halo, 8, 8).reshape(B, nt ** 3) > 0
+    if bool((vi.tile_flags.bool() & blocks).any()):
+        fails.append(("skip-flags", B, R, T, spread))
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    if not (err <= 2e-6 * scale and float((gp.sum(1) - rp.sum(1)).abs().max()) <= 5e-5 * max(1e-3, float(rp.sum(1).abs().max()))):
+        fails.append(("skip", B, R, T, Cout, spread, err, scale, int(vi.tile_flags.sum())))
+
+
 _MANO = {}
 
 
@@ -229,7 +263,7 @@ def one_winding():
         fails.append(("winding", V, Fn, N, float(np.abs(got - ref).max())))
 
 
-counts.update({"fusion": 0, "unet3d": 0, "hand": 0, "winding": 0})
+counts.update({"fusion": 0, "unet3d": 0, "hand": 0, "winding": 0, "skip": 0})
 t0 = time.time()
 it = 0
 while time.time() - t0 < budget and len(fails) < 5:
@@ -239,6 +273,7 @@ while time.time() - t0 < budget and len(fails) < 5:
         jobs.append(("fusion", one_fusion))
         jobs.append(("hand", one_hand))
         jobs.append(("winding", one_winding))
+        jobs.append(("skip", one_skip))
     if it % 40 == 0:
         jobs.append(("unet3d", one_unet))
     for name, fn in jobs:
