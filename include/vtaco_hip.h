@@ -191,6 +191,17 @@ int vt_decode_fwd_wide(const float *grid_cl, int B, int R, int C, const float *p
                        int lattice_nx, float lattice_box, int64_t lattice_first,
                        const float *c_img, const float *blob_wide, int hidden, int n_blocks, int flags, double padding,
                        float *out, float *out2, void *stream);
+/* Split-f16 form of the same forward (inference): W x = W_lo x_hi + W_hi x_lo + W_hi x_hi on v_mfma_f32_32x32x16_f16 with f32     */
+/* accumulation, operands as IEEE-half hi + lo pairs (21-22 mantissa bits: f32-level logits while the hidden activations stay      */
+/* inside the half range -- watched like the shipped-shape kernels': vt_decode_range_status).  A workgroup owns 64 points as two   */
+/* groups that share every streamed weight fragment.  Blob: vt_decoder_pack_wide_f16x3 (its own fragment format and size).         */
+/* Same arguments and coverage as vt_decode_fwd_wide.  256 / 128 / 5 at 128^3: see profiles/ (exact f32: 36 ms).                   */
+size_t vt_decoder_wide_blob_f16x3_bytes(int hidden, int c_dim, int n_blocks, int p_in);
+int vt_decoder_pack_wide_f16x3(const vt_decoder_params *params_host, float *blob, size_t blob_bytes, void *stream);
+int vt_decode_fwd_wide_f16x3(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                             int lattice_nx, float lattice_box, int64_t lattice_first,
+                             const float *c_img, const float *blob_wide_f16x3, int hidden, int n_blocks, int flags, double padding,
+                             float *out, float *out2, void *stream);
 
 /* The same shapes under autograd (the reference trains them through torch autograd: decoder.py:24-51,     */
 /* 135-161 called from training.py:476-489, 734-740, 879).                                                   */

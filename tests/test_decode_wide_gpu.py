@@ -180,3 +180,73 @@ def test_wide_decoder_trains_on_hip_kernels(hidden, c_dim, nb, leaky, mode, npts
           lambda sd, gc, cc: orc.local_decoder_forward(sd, p, gc, leaky=leaky, sample_mode=mode), False)
     check("forward_contact", lambda gd, cd: dec.forward_contact(pd, {"grid": gd}),
           lambda sd, gc, cc: orc.local_decoder_forward_contact(sd, p, gc, leaky=leaky, sample_mode=mode), False)
+
+
+# ---- the split-f16 form (vt_decode_fwd_wide_f16x3): LocalDecoder.precision = "f16x3" / decode_lattice(precision="f16x3") on the wide shapes.
+# Half hi + lo operands carry 21-22 mantissa bits: the bar is f32 rounding over the layer widths, far inside north_star's 1e-4.
+@pytest.mark.parametrize("tag", ["A", "B", "C"])
+def test_wide_split_f16_against_the_reference_fixture(tag):
+    a, sd, hidden, c_dim, nb, leaky, nx, mode = _case(tag)
+    dec = _decoder(hidden, c_dim, nb, leaky, sd, mode=mode)
+    dec.precision = "f16x3"
+    grid = T(a["grid"].astype(np.float32)).to(DEV)
+    p, c_img = T(a["prand"]).to(DEV), T(a["c_img"].astype(np.float32)).to(DEV)
+    from vtaco_amd import ops
+    ops.decode_range_status(reset=True)
+    with torch.no_grad():
+        exact = dec.decode_lattice(grid[:1], nx, precision="f32")
+        assert _err(dec(p, {"grid": grid}), a["logits"]) <= 2e-5
+        assert _err(dec.forward_img(p, {"grid": grid}, c_img), a["logits_img"]) <= 2e-5
+        o, oc = dec.forward_contact(p, {"grid": grid})
+        assert _err(o, a["logits_contact"]) <= 2e-5 and _err(oc, a["logits_contact2"]) <= 2e-5
+        lat = dec.decode_lattice(grid[:1], nx)
+        assert _err(lat, a["logits_lattice"]) <= 2e-5
+        assert not torch.equal(lat, exact)                          # really the other kernel
+        assert torch.equal(dec.decode_lattice(grid[:1], nx, precision="bf16x3"), exact)      # the range guard's way out: the exact kernel
+        half = dec.decode_lattice(grid[:1], nx, first=nx * nx * 3, count=nx * nx * 2)
+        assert _err(half, lat[:, nx * nx * 3: nx * nx * 5].cpu()) <= 1e-6
+    assert ops.decode_range_status() == 0
+
+
+@pytest.mark.parametrize("mode", ["bilinear", "nearest"])
+@pytest.mark.parametrize("hidden,c_dim,nb,leaky,B,N,R", [(32, 32, 5, True, 2, 1000, 16), (96, 64, 2, False, 1, 33, 8),
+                                                        (128, 256, 1, True, 3, 257, 8), (256, 32, 8, False, 1, 64, 4),
+                                                        (64, 96, 3, False, 2, 1, 8), (256, 128, 5, False, 1, 4097, 16)])
+def test_wide_split_f16_against_the_oracle(hidden, c_dim, nb, leaky, B, N, R, mode):
+    from oracle import vtaco_oracle as orc
+    dec = _decoder(hidden, c_dim, nb, leaky, seed=hidden + c_dim + nb, mode=mode)
+    dec.precision = "f16x3"
+    kw = dict(leaky=leaky, sample_mode=mode)
+    sd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
+    g = torch.Generator().manual_seed(N)
+    grid = torch.randn(B, c_dim, R, R, R, generator=g)
+    p = (torch.rand(B, N, 3, generator=g) - 0.5) * 1.3
+    c_img = torch.randn(B, N, c_dim, generator=g) * (torch.rand(B, N, 1, generator=g) < 0.4)
+    with torch.no_grad():
+        got = dec(p.to(DEV), {"grid": grid.to(DEV)})
+        got_img = dec.forward_img(p.to(DEV), {"grid": grid.to(DEV)}, c_img.to(DEV))
+        got_c, got_cc = dec.forward_contact(p.to(DEV), {"grid": grid.to(DEV)})
+    ref = orc.local_decoder_forward(sd, p, grid, **kw)
+    scale = max(1.0, float(ref.abs().max()))
+    assert _err(got, ref) <= 2e-5 * scale
+    assert _err(got_img, orc.local_decoder_forward_img(sd, p, grid, c_img, **kw)) <= 2e-5 * scale
+    rc, rcc = orc.local_decoder_forward_contact(sd, p, grid, **kw)
+    assert _err(got_c, rc) <= 2e-5 * scale and _err(got_cc, rcc) <= 2e-5 * scale
+
+
+def test_wide_split_f16_reports_activations_at_the_half_limit():
+    """Hidden activations beyond 65504 saturate the hi halves: the kernel raises RANGE_HALF in the device's status word (the generator's
+    guard then moves to the exact kernel), and stays silent on ordinary weights."""
+    from vtaco_amd import ops
+    dec = _decoder(64, 32, 2, False, seed=3)
+    dec.precision = "f16x3"
+    g = torch.Generator().manual_seed(4)
+    grid = torch.randn(1, 32, 8, 8, 8, generator=g).to(DEV)
+    p = ((torch.rand(1, 500, 3, generator=g) - 0.5)).to(DEV)
+    ops.decode_range_status(reset=True)
+    with torch.no_grad():
+        dec(p, {"grid": grid})
+        assert ops.decode_range_status(reset=True) == 0
+        dec.fc_c[0].weight.mul_(3e5)
+        dec(p, {"grid": grid})
+    assert ops.decode_range_status(reset=True) & ops.RANGE_HALF

@@ -49,20 +49,24 @@ if "img" in SECTIONS:
         print(json.dumps({"workload": f"forward_img (tactile concat) 128^3 lattice, {prec}", "ms": t * 1e3,
                           "points_per_s": nx ** 3 / t, "tflops": 33536 * nx ** 3 / t / 1e12}))
 
-# --- wide: the general-shape decoder (exact f32, weights streamed from L2)
+# --- wide: the general-shape decoder (weights streamed from L2): exact f32 and split-f16
 if "wide" in SECTIONS:
     for hidden, cd in ((256, 128), (64, 32)):
         torch.manual_seed(1)
         wdec = decoder_dict['simple_local'](dim=3, c_dim=cd, hidden_size=hidden, n_blocks=5).to(dev).eval()
         randomise_fc1(wdec, 4)
         wgrid = torch.randn(1, cd, 64, 64, 64, device=dev)
-        with torch.no_grad():
-            t = timed(lambda: wdec.decode_lattice(wgrid, nx), 5, 1)
         flop = 2 * (3 * hidden + 5 * (cd + 2 * hidden) * hidden + hidden)
-        print(json.dumps({"workload": f"LocalDecoder hidden {hidden} / c_dim {cd} / 5 blocks, 128^3 lattice (vt_decode_fwd_wide, exact f32)",
-                          "ms": t * 1e3, "points_per_s": nx ** 3 / t, "tflops": flop * nx ** 3 / t / 1e12,
-                          "roofline": {"bound": "mfma", "achieved": flop * nx ** 3 / t / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                                       "frac": flop * nx ** 3 / t / 1e12 / 157.3, "traffic": None}}))
+        with torch.no_grad():
+            exact = wdec.decode_lattice(wgrid, nx, precision="f32")
+            for prec, kernel, peak in (("f32", "vt_decode_fwd_wide, exact f32", 157.3), ("f16x3", "vt_decode_fwd_wide_f16x3, split f16", 2500.0)):
+                t = timed(lambda: wdec.decode_lattice(wgrid, nx, precision=prec), 5, 1)
+                err = float((wdec.decode_lattice(wgrid, nx, precision=prec) - exact).abs().max())
+                print(json.dumps({"workload": f"LocalDecoder hidden {hidden} / c_dim {cd} / 5 blocks, 128^3 lattice ({kernel})",
+                                  "ms": t * 1e3, "points_per_s": nx ** 3 / t, "tflops": flop * nx ** 3 / t / 1e12,
+                                  "max_abs_vs_exact_f32": err, "logit_absmax": float(exact.abs().max()),
+                                  "roofline": {"bound": "mfma", "achieved": flop * nx ** 3 / t / 1e12, "peak": peak, "unit": "TFLOP/s",
+                                               "frac": flop * nx ** 3 / t / 1e12 / peak, "traffic": None}}))
 
 # --- fusion: attention decoder, chunks of 2048 points as a batch of 1024 "scenes" sharing one grid
 torch.manual_seed(0)

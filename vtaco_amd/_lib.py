@@ -107,8 +107,11 @@ SIGNATURES = {
                                   ctypes.POINTER(ctypes.c_uint64), _I, ctypes.POINTER(ctypes.c_int), _VP]),
     "vt_decoder_pack_f16f8": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
     "vt_decoder_wide_blob_bytes": (_SZ, [_I, _I, _I, _I]),
+    "vt_decoder_wide_blob_f16x3_bytes": (_SZ, [_I, _I, _I, _I]),
     "vt_decoder_pack_wide": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
+    "vt_decoder_pack_wide_f16x3": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
     "vt_decode_fwd_wide": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _I, _I, _I, _D, _VP, _VP, _VP]),
+    "vt_decode_fwd_wide_f16x3": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _I, _I, _I, _D, _VP, _VP, _VP]),
     "vt_decode_wide_save_floats": (_SZ, [_I64, _I, _I, _I]),
     "vt_decode_wide_gws_floats": (_SZ, [_I64, _I, _I, _I]),
     "vt_decode_fwd_wide_train": (_I, [_VP, _I, _I, _I, _VP, _I64, _VP, _VP, _I, _I, _I, _D, _VP, _VP, _VP, _VP]),

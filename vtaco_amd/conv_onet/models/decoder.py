@@ -191,7 +191,7 @@ class LocalDecoder(nn.Module):
             params += list(head2)
         stamp = tuple((p.data_ptr(), p._version) for p in params)
         if self._wide:
-            precision = "wide"
+            precision = self._wide_precision(precision)
         hit = self._blobs.get((img, contact, precision))
         if hit is not None and hit[0] == stamp:
             return hit[1]
@@ -240,9 +240,16 @@ class LocalDecoder(nn.Module):
             params = params + [self.fc_out_contact.weight, self.fc_out_contact.bias]
         return _DecodeWideFn.apply(self, p.float(), grid, None if c_img is None else c_img.float(), contact, *params)
 
-    def _wide_fwd(self, grid, **kw):
-        return ops.decode_fwd(grid, self._blob(img=kw.get("c_img") is not None, contact=kw.get("want_contact", False)),
-                              padding=self.padding, precision="wide",
+    @staticmethod
+    def _wide_precision(precision):
+        """The kernel of the shapes beyond 32 / 32 for a requested arithmetic: the split-f16 forward (vt_decode_fwd_wide_f16x3) for the
+        half-precision forms, the exact-f32 one (vt_decode_fwd_wide) for "f32" and for "bf16x3" (the range guard's way out)."""
+        return "wide_f16x3" if precision in ("f16x3", "f16f8", "wide_f16x3") else "wide"
+
+    def _wide_fwd(self, grid, precision=None, **kw):
+        wp = self._wide_precision(precision or self._point_precision())
+        return ops.decode_fwd(grid, self._blob(img=kw.get("c_img") is not None, contact=kw.get("want_contact", False), precision=wp),
+                              padding=self.padding, precision=wp,
                               wide=(self.hidden_size, self.n_blocks, self.leaky, self.sample_mode == 'nearest'), **kw)
 
     @staticmethod
@@ -294,7 +301,8 @@ class LocalDecoder(nn.Module):
         (generation.py:155-157 + eval_points) without materialising the points."""
         count = nx ** 3 - first if count is None else count
         if self._wide:
-            return self._wide_fwd(grid, lattice=(nx, box, first, count), out=out, **({} if c_img is None else {"c_img": c_img.float()}))
+            return self._wide_fwd(grid, precision=precision or self.precision, lattice=(nx, box, first, count), out=out,
+                                  **({} if c_img is None else {"c_img": c_img.float()}))
         precision = precision or self.precision
         if precision == "f16f8" and not ops.f16f8_covers(grid, (nx, box, first, count), self.padding):
             precision = "f16x3"                   # slabs the fp8-corrected kernel does not cover
@@ -312,7 +320,7 @@ def _decode_lattice_ids(self, grid, nx, finger_ids, finger_feats, box=1.1, first
         table = torch.cat([finger_feats.float(), finger_feats.new_zeros((1, finger_feats.shape[1]), dtype=torch.float32)])
         ids = finger_ids.reshape(grid.shape[0], count).long()
         c_img = table[torch.where(ids == 255, torch.full_like(ids, finger_feats.shape[0]), ids)]
-        return self._wide_fwd(grid, lattice=(nx, box, first, count), out=out, c_img=c_img)
+        return self._wide_fwd(grid, precision=precision or self.precision, lattice=(nx, box, first, count), out=out, c_img=c_img)
     precision = precision or self.precision
     if precision == "f16f8" and not ops.f16f8_covers(grid, (nx, box, first, count), self.padding):
         precision = "f16x3"

@@ -380,6 +380,226 @@ decode_wide_bwd_kernel(WideBwdArgs a) {
     }
 }
 
+
+// ---- the same forward on the f16 matrix core with split operands ("f16x3": W x = W_lo x_hi + W_hi x_lo + W_hi x_hi on
+// v_mfma_f32_32x32x16_f16, f32 accumulation; 21-22 mantissa bits per operand: f32-level logits while the hidden activations stay
+// inside the half range, which the kernel watches as the shipped-shape kernels do -- decode_common.h, range_report) -------------
+// The exact-f32 kernel above is bound by the slow f32 MFMA (0.61 of its peak at 256 / 128) and, right behind it, by the weight
+// stream (3.3 MB per 32 points from L2).  Here a workgroup owns 64 points as TWO 32-point groups that share every weight fragment
+// (half the stream per point), the fragments are [32 rows][16 k] half pairs -- two 16-byte loads per lane and k-step, the same
+// bytes as f32 -- and the activations live in LDS point-major as hi / lo half planes, so that a lane's B operand (8 consecutive
+// channels of its point) is one ds_read_b128.  One activation buffer instead of two (64 points x 256 channels x 4 bytes x 2 would not
+// fit beside the sampled features): a layer's output is written behind a barrier that waits for the readers of its input, i.e.
+// four barriers per block; the fc_c product of the next block, which reads the sampled features only, runs in front of the first.
+constexpr int WH_PTS = 64;
+struct WideHArgs {
+    DecodeArgs d;
+    const float *blob;
+    int H, C, nb, Kp, p_in, leaky, nearest;
+    unsigned *status;
+};
+__host__ __device__ inline int wideh_pitch(int ch) { return ch * 2 + 16; }             // bytes per point row of a half plane: 16 lanes x 16 bytes tile the 64 banks
+
+__device__ __forceinline__ void wideh_split2(float a, float b, unsigned &hi, unsigned &lo) {
+    const f16x2 hp = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+    hi = __builtin_bit_cast(unsigned, hp);
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)hp[0], b - (float)hp[1]));
+}
+
+// acc_g += W[rows 32 ob ..][K] . X_g[K][32 points], g = 0, 1; wf: the layer's fragments [ob][K / 16][hi, lo][64 lanes][8 halves]
+__device__ __forceinline__ void wideh_gemm(f32x16 &acc0, f32x16 &acc1, const float *wf, int ob, int K, const char *xh, const char *xl, int pitch, int lane) {
+    const u32x4 *w = reinterpret_cast<const u32x4 *>(wf) + (size_t)ob * (K / 16) * 128 + lane;
+    const int j = lane & 31, kg = lane >> 5;
+    const char *r0h = xh + j * pitch + kg * 16, *r0l = xl + j * pitch + kg * 16;
+    const char *r1h = r0h + 32 * pitch, *r1l = r0l + 32 * pitch;
+#pragma unroll 2
+    for (int ks = 0; ks < K / 16; ++ks) {
+        const f16x8 wh = __builtin_bit_cast(f16x8, w[(size_t)ks * 128]), wl = __builtin_bit_cast(f16x8, w[(size_t)ks * 128 + 64]);
+        const f16x8 b0h = *reinterpret_cast<const f16x8 *>(r0h + ks * 32), b0l = *reinterpret_cast<const f16x8 *>(r0l + ks * 32);
+        const f16x8 b1h = *reinterpret_cast<const f16x8 *>(r1h + ks * 32), b1l = *reinterpret_cast<const f16x8 *>(r1l + ks * 32);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b0h, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b1h, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b0l, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b1l, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b0h, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b1h, acc1, 0, 0, 0);
+    }
+}
+
+// relu(v) of one group's 16 accumulator values -> the hi / lo planes: rows 32 ob + chan_of(r, kg) of point `pt` (four runs of four channels)
+__device__ __forceinline__ void wideh_store(char *ah, char *al, int pitch, int pt, int ob, int kg, const f32x16 &v, unsigned &rmax) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned h0, l0, h1, l1;
+        wideh_split2(fmaxf(v[4 * q], 0.0f), fmaxf(v[4 * q + 1], 0.0f), h0, l0);
+        wideh_split2(fmaxf(v[4 * q + 2], 0.0f), fmaxf(v[4 * q + 3], 0.0f), h1, l1);
+        range_track(rmax, h0); range_track(rmax, h1);
+        const int off = pt * pitch + (32 * ob + 8 * q + 4 * kg) * 2;
+        *reinterpret_cast<u32x2 *>(ah + off) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2 *>(al + off) = u32x2{l0, l1};
+    }
+}
+
+template <int WIDE_WAVES>
+__global__ void __launch_bounds__(WIDE_WAVES * 64)
+decode_wide_h_kernel(WideHArgs a) {
+    constexpr int WIDE_THREADS = WIDE_WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) char whs[];      // c hi | c lo [64][pitch(C)] ; act hi | act lo [64][pitch(max(H, Kp))] ; heads
+    const DecodeArgs &d = a.d;
+    const int H = a.H, C = a.C, nh = H / 32, Kp = a.Kp;
+    const int pc = wideh_pitch(C), pa = wideh_pitch(H > Kp ? H : Kp);
+    char *ch_ = whs, *cl_ = ch_ + WH_PTS * pc, *ah = cl_ + WH_PTS * pc, *al = ah + WH_PTS * pa;
+    float *heads = reinterpret_cast<float *>(al + WH_PTS * pa);     // [waves][2 lane halves][2 heads][64 points]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kg = lane >> 5;
+    const WideLayout lay = wide_layout(H, C, a.nb, Kp);
+    const float *bias = a.blob + lay.bias;
+    const uint32_t ntiles = (d.total + WH_PTS - 1) / WH_PTS;
+    unsigned rmax = 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // ---- the tile's inputs as half pairs: sampled features c (decoder.py:62-68), fc_p's input rows [p | c_img | 0] ----
+        {
+            constexpr int PG = WIDE_THREADS / 32;
+            const int ch = tid & 31, pg = tid >> 5;
+            for (int pt = pg; pt < WH_PTS; pt += PG) {
+                uint32_t g = tile * WH_PTS + pt;
+                if (g >= d.total) g = d.total - 1u;
+                const uint32_t b = g / d.N;
+                float px, py, pz;
+                point_of(d, g, g - b * d.N, px, py, pz);
+                const Tri t = tri_setup(px, py, pz, d.divisor, d.R);
+                const float *gb = d.grid + (size_t)b * d.R * d.R * d.R * C;
+                const size_t near = a.nearest ? (((size_t)__builtin_rintf(grid_coord(pz, d.divisor, d.R)) * d.R + (size_t)__builtin_rintf(grid_coord(py, d.divisor, d.R))) * d.R +
+                                                 (size_t)__builtin_rintf(grid_coord(px, d.divisor, d.R))) * C : 0;
+                for (int cb = 0; cb < C; cb += 32) {
+                    float acc = 0.0f;
+                    if (a.nearest) acc = gb[near + cb + ch];
+                    else {
+#pragma unroll
+                        for (int dz = 0; dz < 2; ++dz) {
+                            const int zz = dz ? t.z1 : t.z0;
+                            const float wz = dz ? t.wz1 : t.wz0;
+#pragma unroll
+                            for (int dy = 0; dy < 2; ++dy) {
+                                const int yy = dy ? t.y1 : t.y0;
+                                const float wy = dy ? t.wy1 : t.wy0;
+                                const size_t row = ((size_t)zz * d.R + yy) * d.R;
+                                acc = fmaf(gb[(row + t.x0) * C + cb + ch], (t.wx0 * wy) * wz, acc);
+                                acc = fmaf(gb[(row + t.x1) * C + cb + ch], (t.wx1 * wy) * wz, acc);
+                            }
+                        }
+                    }
+                    const _Float16 hv = (_Float16)acc;
+                    *reinterpret_cast<_Float16 *>(ch_ + pt * pc + (cb + ch) * 2) = hv;
+                    *reinterpret_cast<_Float16 *>(cl_ + pt * pc + (cb + ch) * 2) = (_Float16)(acc - (float)hv);
+                }
+                for (int k = ch; k < Kp; k += 32) {
+                    float v = 0.0f;
+                    if (k < 3) v = k == 0 ? px : (k == 1 ? py : pz);
+                    else if (d.c_img && k < a.p_in) v = d.c_img[(size_t)g * (a.p_in - 3) + (k - 3)];
+                    const _Float16 hv = (_Float16)v;
+                    *reinterpret_cast<_Float16 *>(ah + pt * pa + k * 2) = hv;
+                    *reinterpret_cast<_Float16 *>(al + pt * pa + k * 2) = (_Float16)(v - (float)hv);
+                }
+            }
+        }
+        __syncthreads();
+        const int ob = wave;                                        // nh <= WIDE_WAVES; waves beyond the width only keep the barriers
+        const bool on = ob < nh;
+        // ---- fc_p (decoder.py:139 / 81) ----
+        f32x16 net0, net1;
+        if (on) {
+            net0 = bias16(bias, ob, kg); net1 = net0;
+            wideh_gemm(net0, net1, a.blob + lay.w_p, ob, Kp, ah, al, pa, lane);
+        }
+        // ---- n_blocks x (fc_c add, ResnetBlockFC: layers.py:41-50; its activations are ReLU) ----
+        for (int blk = 0; blk < a.nb; ++blk) {
+            const float *wb = a.blob + lay.w_blk + (size_t)blk * (lay.w_c + lay.w_0 + lay.w_1);
+            const float *bb = bias + (size_t)H * (1 + 3 * blk);
+            if (on) {
+                const f32x16 bc = bias16(bb, ob, kg);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { net0[i] += bc[i]; net1[i] += bc[i]; }
+                wideh_gemm(net0, net1, wb, ob, C, ch_, cl_, pc, lane);
+            }
+            __syncthreads();                                        // the readers of the activation buffer (fc_p / the last fc_1) are done
+            if (on) {
+                wideh_store(ah, al, pa, j, ob, kg, net0, rmax);
+                wideh_store(ah, al, pa, j + 32, ob, kg, net1, rmax);
+            }
+            __syncthreads();
+            f32x16 hid0, hid1;
+            if (on) {
+                hid0 = bias16(bb + H, ob, kg); hid1 = hid0;
+                wideh_gemm(hid0, hid1, wb + lay.w_c, ob, H, ah, al, pa, lane);
+            }
+            __syncthreads();                                        // fc_0's readers are done
+            if (on) {
+                wideh_store(ah, al, pa, j, ob, kg, hid0, rmax);
+                wideh_store(ah, al, pa, j + 32, ob, kg, hid1, rmax);
+            }
+            __syncthreads();
+            if (on) {
+                const f32x16 b1 = bias16(bb + 2 * H, ob, kg);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { net0[i] += b1[i]; net1[i] += b1[i]; }
+                wideh_gemm(net0, net1, wb + lay.w_c + lay.w_0, ob, H, ah, al, pa, lane);
+            }
+        }
+        // ---- fc_out / fc_out_contact on actvn(net) (decoder.py:157-158, 128-131): f32 dot products, as in the exact kernel ----
+        const float *ow = bias + (size_t)H * (1 + 3 * a.nb), *ow2 = ow + H + 1;
+        float o1[2] = {0.0f, 0.0f}, o2[2] = {0.0f, 0.0f};
+        if (on) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = 32 * ob + chan_of(i, kg);
+                const float v0 = actvn(net0[i], a.leaky), v1 = actvn(net1[i], a.leaky);
+                o1[0] = fmaf(ow[row], v0, o1[0]); o2[0] = fmaf(ow2[row], v0, o2[0]);
+                o1[1] = fmaf(ow[row], v1, o1[1]); o2[1] = fmaf(ow2[row], v1, o2[1]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            heads[((wave * 2 + kg) * 2 + 0) * WH_PTS + j + 32 * g] = o1[g];
+            heads[((wave * 2 + kg) * 2 + 1) * WH_PTS + j + 32 * g] = o2[g];
+        }
+        __syncthreads();
+        if (tid < 2 * WH_PTS) {
+            const int pt = tid & (WH_PTS - 1), which = tid >> 6;
+            float o = which ? ow2[H] : ow[H];
+#pragma unroll
+            for (int w = 0; w < 2 * WIDE_WAVES; ++w) o += heads[(w * 2 + which) * WH_PTS + pt];       // waves and lane halves in a fixed order
+            const uint32_t g = tile * WH_PTS + pt;
+            float *dst = which ? d.out2 : d.out;
+            if (g < d.total && dst) dst[g] = o;
+        }
+        __syncthreads();
+    }
+    range_report(rmax, a.status);
+}
+
+// W [H][K] (row stride ld, columns >= kin read as zero) -> split-f16 fragments [H/32][K/16][hi, lo][64 lanes][8 halves]:
+// lane (row r = l & 31, kg = l >> 5), element e = W[32 ob + r][16 ks + 8 kg + e]
+__global__ void wideh_pack_kernel(const float *w, int H, int K, int kin, int ld, float *dst) {
+    const size_t frags = (size_t)H * K / 8;                          // (hi, lo) fragment pairs of eight values: one per (row block, k-step, lane)
+    for (size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x; f < frags; f += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(f & 63);
+        const size_t r = f >> 6;
+        const int ks = (int)(r % (K / 16)), ob = (int)(r / (K / 16));
+        const int row = 32 * ob + (l & 31), k0 = 16 * ks + 8 * (l >> 5);
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = k0 + e < kin ? w[(size_t)row * ld + k0 + e] : 0.0f;
+            const _Float16 h = (_Float16)x;
+            hi[e] = h;
+            lo[e] = (_Float16)(x - (float)h);
+        }
+        f16x8 *o = reinterpret_cast<f16x8 *>(dst) + ((size_t)ob * (K / 16) + ks) * 128 + l;
+        o[0] = hi; o[64] = lo;
+    }
+}
+
 int wide_shape_ok(int hidden, int c_dim, int n_blocks, int p_in) {
     return hidden >= 32 && hidden <= WIDE_MAX && hidden % 32 == 0 && c_dim >= 32 && c_dim <= WIDE_MAX && c_dim % 32 == 0 &&
            n_blocks >= 1 && n_blocks <= VT_MAX_BLOCKS && (p_in == 3 || p_in == 3 + c_dim);
@@ -480,6 +700,88 @@ int vt_decode_fwd_wide(const float *grid_cl, int B, int R, int C, const float *p
                        float *out, float *out2, void *stream) {
     return wide_fwd_impl(grid_cl, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img, blob, hidden, n_blocks, flags, padding,
                          out, out2, nullptr, stream);
+}
+
+// ---- split-f16 form of the same forward (inference) ----
+size_t vt_decoder_wide_blob_f16x3_bytes(int hidden, int c_dim, int n_blocks, int p_in) {
+    if (!wide_shape_ok(hidden, c_dim, n_blocks, p_in)) return 0;
+    return wide_layout(hidden, c_dim, n_blocks, (p_in + 15) / 16 * 16).total * sizeof(float);
+}
+
+int vt_decoder_pack_wide_f16x3(const vt_decoder_params *p, float *blob, size_t blob_bytes, void *stream) {
+    if (!p || !blob) return vt_fail(VT_ERR_INVALID, "vt_decoder_pack_wide_f16x3: null argument");
+    const int H = p->hidden, C = p->c_dim, nb = p->n_blocks, Kp = (p->p_in + 15) / 16 * 16;
+    if (!wide_shape_ok(H, C, nb, p->p_in))
+        return vt_fail(VT_ERR_UNSUPPORTED, "vt_decoder_pack_wide_f16x3: hidden and c_dim must be multiples of 32 up to 256, p_in 3 or 3 + c_dim");
+    const WideLayout lay = wide_layout(H, C, nb, Kp);
+    if (blob_bytes < lay.total * sizeof(float)) return vt_fail(VT_ERR_WORKSPACE, "vt_decoder_pack_wide_f16x3: blob too small");
+    if (!p->fc_p_w || !p->fc_p_b || !p->fc_out_w || !p->fc_out_b) return vt_fail(VT_ERR_INVALID, "vt_decoder_pack_wide_f16x3: null parameter");
+    (void)vt_decode_status_dev();                                      // the device's status block exists before a launch can be captured into a graph
+    hipStream_t st = (hipStream_t)stream;
+    auto pack = [&](const float *w, int K, int kin, int ld, float *dst) {
+        const size_t frags = (size_t)H * K / 8;
+        hipLaunchKernelGGL(wideh_pack_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, st, w, H, K, kin, ld, dst);
+    };
+    auto copy = [&](const float *src, float *dst, int n) {
+        hipLaunchKernelGGL(wide_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+    };
+    pack(p->fc_p_w, Kp, p->p_in, p->p_in, blob + lay.w_p);
+    float *bias = blob + lay.bias;
+    copy(p->fc_p_b, bias, H);
+    for (int i = 0; i < nb; ++i) {
+        if (!p->fc_c_w[i] || !p->fc_c_b[i] || !p->fc0_w[i] || !p->fc0_b[i] || !p->fc1_w[i] || !p->fc1_b[i])
+            return vt_fail(VT_ERR_INVALID, "vt_decoder_pack_wide_f16x3: null block parameter");
+        float *wb = blob + lay.w_blk + (size_t)i * (lay.w_c + lay.w_0 + lay.w_1);
+        pack(p->fc_c_w[i], C, C, C, wb);
+        pack(p->fc0_w[i], H, H, H, wb + lay.w_c);
+        pack(p->fc1_w[i], H, H, H, wb + lay.w_c + lay.w_0);
+        copy(p->fc_c_b[i], bias + (size_t)H * (1 + 3 * i), H);
+        copy(p->fc0_b[i], bias + (size_t)H * (2 + 3 * i), H);
+        copy(p->fc1_b[i], bias + (size_t)H * (3 + 3 * i), H);
+    }
+    float *ow = bias + (size_t)H * (1 + 3 * nb);
+    copy(p->fc_out_w, ow, H);
+    copy(p->fc_out_b, ow + H, 1);
+    copy(p->fc_out2_w, ow + H + 1, H);
+    copy(p->fc_out2_b, ow + 2 * H + 1, 1);
+    return vt_check(hipGetLastError(), "vt_decoder_pack_wide_f16x3");
+}
+
+int vt_decode_fwd_wide_f16x3(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                             int lattice_nx, float lattice_box, int64_t lattice_first,
+                             const float *c_img, const float *blob, int hidden, int n_blocks, int flags, double padding,
+                             float *out, float *out2, void *stream) {
+    if (!grid_cl || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3: null argument");
+    const int p_in = c_img ? 3 + C : 3;
+    if (!wide_shape_ok(hidden, C, n_blocks, p_in))
+        return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd_wide_f16x3: hidden and c_dim must be multiples of 32 up to 256");
+    if (B <= 0 || R < 2 || N <= 0) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3: bad size");
+    if ((unsigned long long)B * (unsigned long long)N >= 0x7fffffffull) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd_wide_f16x3: B*N must stay below 2^31");
+    if (!pts && (lattice_nx < 2 || lattice_first < 0 || lattice_first + N > (int64_t)lattice_nx * lattice_nx * lattice_nx))
+        return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3: lattice range outside nx^3");
+    WideHArgs a{};
+    a.d.grid = grid_cl; a.d.pts = pts; a.d.c_img = c_img; a.d.out = out; a.d.out2 = out2;
+    a.d.N = (uint32_t)N; a.d.total = (uint32_t)((uint64_t)B * (uint64_t)N); a.d.lattice_first = (uint32_t)lattice_first;
+    a.d.R = R; a.d.nx = lattice_nx; a.d.box = lattice_box; a.d.divisor = (float)(1.0 + padding + 10e-4);
+    a.blob = blob; a.H = hidden; a.C = C; a.nb = n_blocks; a.p_in = p_in; a.Kp = (p_in + 15) / 16 * 16;
+    a.leaky = (flags & VT_WIDE_LEAKY) ? 1 : 0; a.nearest = (flags & VT_WIDE_NEAREST) ? 1 : 0;
+    a.status = vt_decode_status_dev();
+    const int waves = hidden <= 128 ? 4 : 8;
+    const int wid = hidden > a.Kp ? hidden : a.Kp;
+    const size_t lds = (size_t)2 * WH_PTS * wideh_pitch(C) + (size_t)2 * WH_PTS * wideh_pitch(wid) + (size_t)waves * 2 * 2 * WH_PTS * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_wide_h_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_wide_h_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return vt_check(e, "vt_decode_fwd_wide_f16x3: hipFuncSetAttribute");
+        attr = true;
+    }
+    const uint32_t ntiles = (a.d.total + WH_PTS - 1) / WH_PTS;
+    const uint32_t cap = (uint32_t)vt_num_cus() * 4u;
+    const dim3 grid(ntiles < cap ? ntiles : cap);
+    if (waves == 4) hipLaunchKernelGGL(decode_wide_h_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(decode_wide_h_kernel<8>, grid, dim3(512), lds, (hipStream_t)stream, a);
+    return vt_check(hipGetLastError(), "vt_decode_fwd_wide_f16x3");
 }
 
 // ---- training (decoder.py:24-51, 135-161 under autograd: training.py:476-489, 879) ----

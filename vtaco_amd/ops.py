@@ -108,6 +108,16 @@ def pack_decoder(fc_p_w, fc_p_b, fc_c, blocks, fc_out, fc_out2=None, out=None, t
             out = torch.empty(n, dtype=torch.float32, device=fc_p_w.device)
         check(lib.vt_decoder_pack_t(ctypes.byref(prm), dev_ptr(out, "blob_t"), n * 4, stream_ptr()), "vt_decoder_pack_t")
         return out
+    if precision == "wide_f16x3":
+        # the same shapes on the f16 matrix core with split operands (vt_decode_fwd_wide_f16x3): its own fragment format
+        n = lib.vt_decoder_wide_blob_f16x3_bytes(hidden, c_dim, nb, p_in) // 4
+        if n == 0:
+            raise VtError(f"decoder shape hidden={hidden}, c_dim={c_dim}, n_blocks={nb} is not built: hidden_size and c_dim must be "
+                          f"multiples of 32 up to 256, n_blocks <= {_lib.VT_MAX_BLOCKS}")
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=fc_p_w.device)
+        check(lib.vt_decoder_pack_wide_f16x3(ctypes.byref(prm), dev_ptr(out, "blob"), n * 4, stream_ptr()), "vt_decoder_pack_wide_f16x3")
+        return out
     if precision == "wide":
         # the general-shape kernel (vt_decode_fwd_wide): hidden / c_dim multiples of 32 up to 256, weights streamed in fragment order
         n = lib.vt_decoder_wide_blob_bytes(hidden, c_dim, nb, p_in) // 4
@@ -215,8 +225,9 @@ def _cl_storage(grid):
 def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want_contact=False, out=None, save=None,
                precision="f32", wide=None):
     """Fused trilinear gather + conditioned MLP (vt_decode_fwd; ``precision="bf16x3"`` / ``"f16x3"``:
-    vt_decode_fwd_bf16x3 / vt_decode_fwd_f16x3 with a blob packed for it; ``precision="wide"`` with
-    ``wide=(hidden_size, n_blocks, leaky[, nearest])``: vt_decode_fwd_wide, the exact-f32 kernel of the shapes beyond 32/32).
+    vt_decode_fwd_bf16x3 / vt_decode_fwd_f16x3 with a blob packed for it; ``precision="wide"`` /
+    ``"wide_f16x3"`` with ``wide=(hidden_size, n_blocks, leaky[, nearest])``: vt_decode_fwd_wide[_f16x3], the exact-f32 / split-f16
+    kernels of the shapes beyond 32/32).
 
     grid  [B,C,R,R,R] (any layout; converted to channels-last if needed)
     pts   [B,N,3] or None with lattice=(nx, box, first, count)
@@ -249,14 +260,15 @@ def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want
     if N == 0:                                   # empty query set: nothing to launch
         return (out, out2) if want_contact else out
     keep_for_graph(blob, keep)
-    if precision == "wide":
+    if precision in ("wide", "wide_f16x3"):
         if save is not None or wide is None:
             raise VtError("decode_fwd: precision 'wide' is inference only and needs wide=(hidden_size, n_blocks, leaky)")
         hidden, nb, leaky = wide[:3]
         flags = (1 if leaky else 0) | (2 if len(wide) > 3 and wide[3] else 0)          # VT_WIDE_LEAKY | VT_WIDE_NEAREST
-        check(lib.vt_decode_fwd_wide(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first, dev_ptr(c_img, "c_img"),
-                                     dev_ptr(blob, "blob"), int(hidden), int(nb), flags, float(padding),
-                                     dev_ptr(out, "out"), dev_ptr(out2, "out2"), stream_ptr()), "vt_decode_fwd_wide")
+        name = "vt_decode_fwd_wide" if precision == "wide" else "vt_decode_fwd_wide_f16x3"
+        check(getattr(lib, name)(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first, dev_ptr(c_img, "c_img"),
+                                 dev_ptr(blob, "blob"), int(hidden), int(nb), flags, float(padding),
+                                 dev_ptr(out, "out"), dev_ptr(out2, "out2"), stream_ptr()), name)
     elif precision == "f16f8":
         if pts is not None or want_contact or save is not None:
             raise VtError("decode_fwd: precision 'f16f8' covers lattice slabs only (ops.f16f8_covers); use 'f16x3'")
