@@ -159,8 +159,8 @@ class LocalDecoder(nn.Module):
         # `leaky`: leaky_relu(0.2) in front of the output heads (reference decoder.py:46-49, 157; the blocks stay ReLU).  The shipped
         # shape (32 / 32, relu) runs on the LDS-resident kernels of decode.hip, training included; every other shape -- hidden_size
         # and c_dim multiples of 32 up to 256, e.g. the class defaults 256 / 128 -- on the weight-streaming kernels of
-        # decode_wide.hip (exact f32): vt_decode_fwd_wide, and under autograd vt_decode_fwd_wide_train / vt_decode_bwd_wide /
-        # vt_rows_wgrad (_DecodeWideFn)
+        # decode_wide.hip: vt_decode_fwd_wide (exact f32) or vt_decode_fwd_wide_f16x3 (split-f16 operands, for the half-precision
+        # settings of ``precision``), and under autograd vt_decode_fwd_wide_train / vt_decode_bwd_wide / vt_rows_wgrad (_DecodeWideFn)
         self.leaky = bool(leaky)
         self._wide = self.leaky or hidden_size != 32 or c_dim != 32 or sample_mode == 'nearest'
         self.sample_mode, self.padding = sample_mode, padding

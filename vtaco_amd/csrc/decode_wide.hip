@@ -406,23 +406,51 @@ __device__ __forceinline__ void wideh_split2(float a, float b, unsigned &hi, uns
     lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)hp[0], b - (float)hp[1]));
 }
 
-// acc_g += W[rows 32 ob ..][K] . X_g[K][32 points], g = 0, 1; wf: the layer's fragments [ob][K / 16][hi, lo][64 lanes][8 halves]
+// acc_g += W[rows 32 ob ..][K] . X_g[K][32 points], g = 0, 1; wf: the layer's fragments [ob][K / 16][hi, lo][64 lanes][8 halves].
+// The fragments come from L2 (a round trip is ~10 k-steps of MFMAs): WIDEH_AHEAD k-steps of them are kept in flight in registers.
+// (hidden <= 128 runs four-wave workgroups, several per CU: there the plain loop with its 122 registers hides the latency by occupancy)
+template <int WIDEH_AHEAD>
 __device__ __forceinline__ void wideh_gemm(f32x16 &acc0, f32x16 &acc1, const float *wf, int ob, int K, const char *xh, const char *xl, int pitch, int lane) {
-    const u32x4 *w = reinterpret_cast<const u32x4 *>(wf) + (size_t)ob * (K / 16) * 128 + lane;
+    const int nks = K / 16;
+    const u32x4 *w = reinterpret_cast<const u32x4 *>(wf) + (size_t)ob * nks * 128 + lane;
     const int j = lane & 31, kg = lane >> 5;
     const char *r0h = xh + j * pitch + kg * 16, *r0l = xl + j * pitch + kg * 16;
     const char *r1h = r0h + 32 * pitch, *r1l = r0l + 32 * pitch;
+    if constexpr (WIDEH_AHEAD <= 1) {
 #pragma unroll 2
-    for (int ks = 0; ks < K / 16; ++ks) {
-        const f16x8 wh = __builtin_bit_cast(f16x8, w[(size_t)ks * 128]), wl = __builtin_bit_cast(f16x8, w[(size_t)ks * 128 + 64]);
-        const f16x8 b0h = *reinterpret_cast<const f16x8 *>(r0h + ks * 32), b0l = *reinterpret_cast<const f16x8 *>(r0l + ks * 32);
-        const f16x8 b1h = *reinterpret_cast<const f16x8 *>(r1h + ks * 32), b1l = *reinterpret_cast<const f16x8 *>(r1l + ks * 32);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b0h, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b1h, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b0l, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b1l, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b0h, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b1h, acc1, 0, 0, 0);
+        for (int ks = 0; ks < nks; ++ks) {
+            const f16x8 wh = __builtin_bit_cast(f16x8, w[(size_t)ks * 128]), wl = __builtin_bit_cast(f16x8, w[(size_t)ks * 128 + 64]);
+            const f16x8 b0h = *reinterpret_cast<const f16x8 *>(r0h + ks * 32), b0l = *reinterpret_cast<const f16x8 *>(r0l + ks * 32);
+            const f16x8 b1h = *reinterpret_cast<const f16x8 *>(r1h + ks * 32), b1l = *reinterpret_cast<const f16x8 *>(r1l + ks * 32);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b1h, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b0l, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b1l, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b1h, acc1, 0, 0, 0);
+        }
+        return;
+    }
+    u32x4 wq[WIDEH_AHEAD][2];
+#pragma unroll
+    for (int i = 0; i < WIDEH_AHEAD; ++i)
+        if (i < nks) { wq[i][0] = w[(size_t)i * 128]; wq[i][1] = w[(size_t)i * 128 + 64]; }
+    for (int base = 0; base < nks; base += WIDEH_AHEAD) {
+#pragma unroll
+        for (int i = 0; i < WIDEH_AHEAD; ++i) {
+            const int ks = base + i;
+            if (ks >= nks) break;
+            const f16x8 wh = __builtin_bit_cast(f16x8, wq[i][0]), wl = __builtin_bit_cast(f16x8, wq[i][1]);
+            if (ks + WIDEH_AHEAD < nks) { wq[i][0] = w[(size_t)(ks + WIDEH_AHEAD) * 128]; wq[i][1] = w[(size_t)(ks + WIDEH_AHEAD) * 128 + 64]; }
+            const f16x8 b0h = *reinterpret_cast<const f16x8 *>(r0h + ks * 32), b0l = *reinterpret_cast<const f16x8 *>(r0l + ks * 32);
+            const f16x8 b1h = *reinterpret_cast<const f16x8 *>(r1h + ks * 32), b1l = *reinterpret_cast<const f16x8 *>(r1l + ks * 32);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b1h, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b0l, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b1l, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b1h, acc1, 0, 0, 0);
+        }
     }
 }
 
@@ -444,7 +472,7 @@ __device__ __forceinline__ void wideh_store(char *ah, char *al, int pitch, int p
 template <int WIDE_WAVES>
 __global__ void __launch_bounds__(WIDE_WAVES * 64)
 decode_wide_h_kernel(WideHArgs a) {
-    constexpr int WIDE_THREADS = WIDE_WAVES * 64;
+    constexpr int WIDE_THREADS = WIDE_WAVES * 64, AH = WIDE_WAVES >= 8 ? 4 : 1;         // weight k-steps in flight per wave
     extern __shared__ __attribute__((aligned(16))) char whs[];      // c hi | c lo [64][pitch(C)] ; act hi | act lo [64][pitch(max(H, Kp))] ; heads
     const DecodeArgs &d = a.d;
     const int H = a.H, C = a.C, nh = H / 32, Kp = a.Kp;
@@ -510,7 +538,7 @@ decode_wide_h_kernel(WideHArgs a) {
         f32x16 net0, net1;
         if (on) {
             net0 = bias16(bias, ob, kg); net1 = net0;
-            wideh_gemm(net0, net1, a.blob + lay.w_p, ob, Kp, ah, al, pa, lane);
+            wideh_gemm<AH>(net0, net1, a.blob + lay.w_p, ob, Kp, ah, al, pa, lane);
         }
         // ---- n_blocks x (fc_c add, ResnetBlockFC: layers.py:41-50; its activations are ReLU) ----
         for (int blk = 0; blk < a.nb; ++blk) {
@@ -520,7 +548,7 @@ decode_wide_h_kernel(WideHArgs a) {
                 const f32x16 bc = bias16(bb, ob, kg);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { net0[i] += bc[i]; net1[i] += bc[i]; }
-                wideh_gemm(net0, net1, wb, ob, C, ch_, cl_, pc, lane);
+                wideh_gemm<AH>(net0, net1, wb, ob, C, ch_, cl_, pc, lane);
             }
             __syncthreads();                                        // the readers of the activation buffer (fc_p / the last fc_1) are done
             if (on) {
@@ -531,7 +559,7 @@ decode_wide_h_kernel(WideHArgs a) {
             f32x16 hid0, hid1;
             if (on) {
                 hid0 = bias16(bb + H, ob, kg); hid1 = hid0;
-                wideh_gemm(hid0, hid1, wb + lay.w_c, ob, H, ah, al, pa, lane);
+                wideh_gemm<AH>(hid0, hid1, wb + lay.w_c, ob, H, ah, al, pa, lane);
             }
             __syncthreads();                                        // fc_0's readers are done
             if (on) {
@@ -543,7 +571,7 @@ decode_wide_h_kernel(WideHArgs a) {
                 const f32x16 b1 = bias16(bb + 2 * H, ob, kg);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { net0[i] += b1[i]; net1[i] += b1[i]; }
-                wideh_gemm(net0, net1, wb + lay.w_c + lay.w_0, ob, H, ah, al, pa, lane);
+                wideh_gemm<AH>(net0, net1, wb + lay.w_c + lay.w_0, ob, H, ah, al, pa, lane);
             }
         }
         // ---- fc_out / fc_out_contact on actvn(net) (decoder.py:157-158, 128-131): f32 dot products, as in the exact kernel ----
