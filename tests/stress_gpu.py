@@ -1,7 +1,7 @@
 """Randomised differential testing on the GPU (not collected by pytest: run `python tests/stress_gpu.py [seconds]`).
 Marching cubes against the C oracle on random shapes / fields / levels, the decode kernels against the torch oracle on
 random (B, N, R) and lattices, the voxeliser against the oracle on random clouds, the fusion pipeline on ragged N, the
-UNet3D forward (both conv precisions) on small volumes, its first layer with the empty blocks skipped, the hand branch (plane ids / scatter, the PointNet MLP kernels,
+UNet3D forward (both conv precisions) on small volumes, its first layer with the empty blocks skipped, LocalDecoder at random widths beyond 32 / 32 (exact and split-f16 kernels), the hand branch (plane ids / scatter, the PointNet MLP kernels,
 the MANO layer on random synthetic assets), the winding-number kernel on random triangle soups.  Prints a summary; exits 1 on a mismatch."""
 import os
 import sys
@@ -96,6 +96,44 @@ def one_decode():
     err = float((got - ref).abs().max())
     if not err <= 1e-4:
         fails.append(("decode", B, R, precision, img, tuple(got.shape), err))
+
+
+def one_wide():
+    """LocalDecoder at random widths beyond 32 / 32 (both kernels: exact f32 and split f16) against the oracle: random points or
+    lattice slabs, with / without tactile concat and contact head, leaky, nearest."""
+    from vtaco_amd.conv_onet.models.decoder import LocalDecoder
+    hidden, c_dim = int(rng.choice([32, 64, 96, 160, 256])), int(rng.choice([32, 64, 128]))
+    nb, leaky, mode = int(rng.randint(1, 6)), bool(rng.rand() < 0.3), str(rng.choice(["bilinear", "nearest"]))
+    if hidden == 32 and c_dim == 32 and not leaky and mode == "bilinear":
+        leaky = True
+    torch.manual_seed(int(rng.randint(1 << 30)))
+    dec = LocalDecoder(dim=3, c_dim=c_dim, hidden_size=hidden, n_blocks=nb, leaky=leaky, padding=0.1, with_contact=True, sample_mode=mode)
+    g = torch.Generator().manual_seed(int(rng.randint(1 << 30)))
+    with torch.no_grad():
+        for n, p in dec.named_parameters():
+            p.add_(torch.randn(p.shape, generator=g) * (0.1 if n.endswith("fc_1.weight") else 0.03))
+    sd = {k: v.detach().clone() for k, v in dec.state_dict().items()}
+    dec = dec.to(DEV)
+    dec.precision = str(rng.choice(["f32", "f16x3"]))
+    B, R, N = int(rng.randint(1, 3)), int(rng.choice([4, 8, 16])), int(rng.choice([1, 63, 64, 65, 500, 2049]))
+    grid = torch.randn(B, c_dim, R, R, R, generator=g)
+    pts = (torch.rand(B, N, 3, generator=g) - 0.5) * 1.3
+    kw = dict(leaky=leaky, sample_mode=mode)
+    kind = int(rng.randint(3))
+    with torch.no_grad():
+        if kind == 0:
+            got, ref = dec(pts.to(DEV), {"grid": grid.to(DEV)}).cpu(), orc.local_decoder_forward(sd, pts, grid, **kw)
+        elif kind == 1:
+            c_img = torch.randn(B, N, c_dim, generator=g)
+            got = dec.forward_img(pts.to(DEV), {"grid": grid.to(DEV)}, c_img.to(DEV)).cpu()
+            ref = orc.local_decoder_forward_img(sd, pts, grid, c_img, **kw)
+        else:
+            o, oc = dec.forward_contact(pts.to(DEV), {"grid": grid.to(DEV)})
+            r, rc = orc.local_decoder_forward_contact(sd, pts, grid, **kw)
+            got, ref = torch.stack([o.cpu(), oc.cpu()]), torch.stack([r, rc])
+    err, scale = float((got - ref).abs().max()), max(1.0, float(ref.abs().max()))
+    if not err <= 3e-5 * scale:
+        fails.append(("wide", hidden, c_dim, nb, leaky, mode, dec.precision, B, R, N, kind, err, scale))
 
 
 def one_voxel():
@@ -263,7 +301,7 @@ def one_winding():
         fails.append(("winding", V, Fn, N, float(np.abs(got - ref).max())))
 
 
-counts.update({"fusion": 0, "unet3d": 0, "hand": 0, "winding": 0, "skip": 0})
+counts.update({"fusion": 0, "unet3d": 0, "hand": 0, "winding": 0, "skip": 0, "wide": 0})
 t0 = time.time()
 it = 0
 while time.time() - t0 < budget and len(fails) < 5:
@@ -274,6 +312,7 @@ while time.time() - t0 < budget and len(fails) < 5:
         jobs.append(("hand", one_hand))
         jobs.append(("winding", one_winding))
         jobs.append(("skip", one_skip))
+        jobs.append(("wide", one_wide))
     if it % 40 == 0:
         jobs.append(("unet3d", one_unet))
     for name, fn in jobs:
