@@ -367,3 +367,24 @@ def test_range_guard_walks_f16f8_to_f16x3_to_bf16x3_and_stays_rank_local(monkeyp
     # other precisions are not guarded at all (no status read)
     g, words[:] = Dummy("f32"), [ops.RANGE_HALF]
     assert g.make(6) == (6, "f32") and words == [ops.RANGE_HALF]
+
+
+def test_wide_decoder_precision_routing_and_encoder_skip_switch(monkeypatch):
+    """Host logic without a device: a decoder beyond 32 / 32 maps the half-precision settings to the split-f16 wide kernel and "f32" /
+    "bf16x3" (the range guard's way out) to the exact one; the encoder's block skipping is on by default and VTACO_UNET_SKIP=0 turns
+    it off; block flags exist only for resolutions the 8^3 blocks tile."""
+    from types import SimpleNamespace
+    from vtaco_amd import ops
+    from vtaco_amd.conv_onet.models.decoder import LocalDecoder
+    from vtaco_amd.encoder import encoder_dict
+    dec = LocalDecoder(dim=3, c_dim=128, hidden_size=256, n_blocks=2)
+    assert dec._wide
+    assert [dec._wide_precision(p) for p in ("f16x3", "f16f8", "f32", "bf16x3")] == ["wide_f16x3", "wide_f16x3", "wide", "wide"]
+    assert not LocalDecoder(dim=3, c_dim=32, hidden_size=32)._wide
+    kw = dict(c_dim=32, dim=3, hidden_dim=32, unet3d=True, grid_resolution=64, plane_type='grid',
+              unet3d_kwargs=dict(num_levels=3, f_maps=32, in_channels=32, out_channels=32))
+    assert encoder_dict['pointnet_local_pool'](**kw).skip_empty
+    monkeypatch.setenv("VTACO_UNET_SKIP", "0")
+    assert not encoder_dict['pointnet_local_pool'](**kw).skip_empty
+    for R in (12, 4, 136):                                         # not a multiple of 8 / below a block / beyond the flags' LDS table
+        assert ops.voxel_tile_flags(SimpleNamespace(R=R, B=1, T=1, idx=None)) is None
