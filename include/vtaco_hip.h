@@ -530,6 +530,8 @@ typedef struct vt_unet3d_conv {
                                  /* the persistent split-f16 kernel (takes precedence over packed_bf16x3)                              */
     const float *packed_f16x3_thin; /* vt_conv3d_pack_f16x3_thin(conv.weight) or NULL: the shapes of packed_bf16x3 (the thin-tile and */
                                  /* K-split kernels) on IEEE-half pairs instead of bf16 pairs; takes precedence over packed_bf16x3     */
+    const float *packed_f16x3_up;   /* decoder-entry layers (dec[k][0]) only, or NULL: vt_conv3d_pack_f16x3_up(conv.weight, C1 = the skip's */
+                                 /* channels); where vt_conv3d_up_covers(...) the layer runs in per-parity form (vt_conv3d_gcr_f16x3_up)  */
 } vt_unet3d_conv;
 typedef struct vt_unet3d_params {
     int32_t n_levels;     /* len(f_maps) */
@@ -606,6 +608,20 @@ int vt_conv3d_gcr_f16x3(const float *skip, int C1, const float *low, int C2, int
 int vt_conv3d_gcr_f16x3_scaled(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                                const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
                                float *out_part, const float *in_absmax, void *stream);
+/* Decoder-entry layers in per-parity form (reference unet3d.py:195-293: Decoder.forward = nearest upsample of the lower level,   */
+/* torch.cat((encoder_features, x)), DoubleConv; :449-474 the call order).  The layer reads the virtual [skip | upsample(low)]; over   */
+/* the upsampled channels a 3x3x3 conv is, per output parity class (x&1, y&1, z&1), a 2x2x2 conv over `low` itself with the taps that  */
+/* share a low voxel summed in the weights -- 8 instead of 27 taps and a 6^3 instead of a 10^3 halo for those channels.  `packed_up`   */
+/* = vt_conv3d_pack_f16x3_up(w [Cout][C1+C2][3][3][3], C1): the eight classes' merged taps of the low channels as half pairs           */
+/* (vt_conv3d_up_packed_floats(Cout, C2) floats); the skip channels keep vt_conv3d_pack_f16x3's fragments (`packed_w_f16x3`, the       */
+/* whole layer's blob).  Same arguments, statistics blocks and output as vt_conv3d_gcr_f16x3, equal to it to f32 rounding of the merged */
+/* weights.  Covers what vt_conv3d_up_covers reports: a shape of the specialised-wave kernel with C1, C2 multiples of 16.              */
+size_t vt_conv3d_up_packed_floats(int Cout, int C2);
+int vt_conv3d_pack_f16x3_up(const float *w, int Cout, int Cin, int C1, float *packed, void *stream);
+int vt_conv3d_up_covers(int C1, int C2, int B, int D, int H, int W, int Cout);
+int vt_conv3d_gcr_f16x3_up(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                           const float *scale_shift, const float *packed_w_f16x3, const float *packed_up, int Cout, int relu, float *out,
+                           float *out_part, void *stream);
 /* The last 'gcr' layer of the UNet3D together with final_conv (unet3d.py:470-474, a 1x1x1 conv 32 -> 32): relu(conv) stays in      */
 /* registers, is split into half pairs and multiplied by the packed final weight in the epilogue -- no intermediate tensor, no     */
 /* second launch.  Cout must be 32 and the shape one the specialised-wave kernel covers (VT_ERR_UNSUPPORTED otherwise).            */

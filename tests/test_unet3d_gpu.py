@@ -526,3 +526,56 @@ def test_tile_flags_and_the_first_layer_without_its_empty_blocks():
         assert float((gp.sum(1) - rp.sum(1)).abs().max()) <= 2e-5 * float(rp.sum(1).abs().max())
         none, _ = ops.conv3d_gcr_skip(x, ss, ph, Cout, torch.zeros_like(flags))
         assert torch.equal(none, ref)                                 # nothing flagged: the dense walk through the lists, same bits
+
+
+def test_decoder_entry_per_parity_conv_matches_the_27_tap_kernels():
+    """vt_conv3d_gcr_f16x3_up (the upsampled channels as a 2x2x2 conv per output parity class with merged weights, the skip
+    channels on class-uniform patches of a parity-split image) against the exact-f32 kernel and the 27-tap split-f16 kernel on
+    the decoder-entry shapes (reference unet3d.py:195-293): 8^3 tiles at 64^3, 8x8x4 tiles at 32^3 with two cout blocks, a batch of
+    two scenes, and a volume whose every tile touches the border (zero padding of the merged taps)."""
+    from vtaco_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(21)
+    for B, R, C1, C2, Cout in ((1, 64, 32, 64, 32), (1, 32, 64, 128, 64), (2, 32, 32, 64, 64), (2, 64, 32, 32, 32), (8, 16, 32, 64, 32)):
+        assert lib.vt_conv3d_up_covers(C1, C2, B, R, R, R, Cout), (B, R, C1, C2, Cout)
+        x = (torch.randn(B, R, R, R, C1, generator=g) * (torch.rand(B, R, R, R, 1, generator=g) < 0.3)).to(DEV)
+        low = torch.randn(B, R // 2, R // 2, R // 2, C2, generator=g).to(DEV)
+        w = (torch.randn(Cout, C1 + C2, 3, 3, 3, generator=g) * 0.05).to(DEV)
+        gamma = (1 + 0.2 * torch.randn(C1 + C2, generator=g)).to(DEV)
+        beta = (0.2 * torch.randn(C1 + C2, generator=g)).to(DEV)
+        xs, ls = ops.channel_stats(x), ops.channel_stats(low)
+        pf, ph = ops.conv3d_pack(w), ops.conv3d_pack(w, precision="f16x3")
+        pu = ops.conv3d_pack_up(w, C1)
+        assert pu is not None and pu.numel() == lib.vt_conv3d_up_packed_floats(Cout, C2)
+        ref, (rp, rn) = ops.gn_conv3d_relu(x, xs, low, ls, gamma, beta, 8, pf, Cout)
+        old, _ = ops.gn_conv3d_relu(x, xs, low, ls, gamma, beta, 8, pf, Cout, packed_w_f16x3=ph)
+        got, (gp, gn) = ops.gn_conv3d_relu(x, xs, low, ls, gamma, beta, 8, pf, Cout, packed_w_f16x3=ph, packed_w_up=pu)
+        assert gn == lib.vt_conv3d_stat_blocks_f16x3(B, R, R, R, C1 + C2, Cout) and gn > 0
+        scale = max(1.0, float(ref.abs().max()))
+        K = 27 * (C1 + C2)
+        err, err_old = float((got - ref).abs().max()), float((old - ref).abs().max())
+        assert not torch.equal(got, old)                      # the per-parity kernel did run (another summation order)
+        assert 0.0 < err <= 1.5e-7 * K ** 0.5 * scale, (B, R, C1, C2, Cout, err, err_old, scale)
+        assert float((gp.sum(1) - rp.sum(1)).abs().max()) <= 1e-3 * float(rp.sum(1).abs().max())
+        again, (gp2, _) = ops.gn_conv3d_relu(x, xs, low, ls, gamma, beta, 8, pf, Cout, packed_w_f16x3=ph, packed_w_up=pu)
+        assert torch.equal(again, got) and torch.equal(gp2, gp)
+
+
+def test_decoder_entry_per_parity_conv_vs_torch_cpu():
+    """The same layer against plain torch on the CPU: GroupNorm(cat(skip, upsample(low))) -> conv3d -> relu (reference
+    unet3d.py:20-72, 283-293)."""
+    import torch.nn.functional as F
+    from vtaco_amd import ops
+    g = torch.Generator().manual_seed(22)
+    B, R, C1, C2, Cout = 2, 32, 32, 64, 64
+    x = torch.randn(B, R, R, R, C1, generator=g)
+    low = torch.randn(B, R // 2, R // 2, R // 2, C2, generator=g)
+    w = torch.randn(Cout, C1 + C2, 3, 3, 3, generator=g) * 0.05
+    gamma, beta = 1 + 0.2 * torch.randn(C1 + C2, generator=g), 0.2 * torch.randn(C1 + C2, generator=g)
+    cat = torch.cat([x.permute(0, 4, 1, 2, 3), F.interpolate(low.permute(0, 4, 1, 2, 3), scale_factor=2, mode="nearest")], 1)
+    ref = F.relu(F.conv3d(F.group_norm(cat, 8, gamma, beta, 1e-5), w, padding=1)).permute(0, 2, 3, 4, 1)
+    xd, ld, wd = x.to(DEV), low.to(DEV), w.to(DEV)
+    got, _ = ops.gn_conv3d_relu(xd, ops.channel_stats(xd), ld, ops.channel_stats(ld), gamma.to(DEV), beta.to(DEV), 8,
+                                ops.conv3d_pack(wd), Cout, packed_w_f16x3=ops.conv3d_pack(wd, precision="f16x3"),
+                                packed_w_up=ops.conv3d_pack_up(wd, C1))
+    assert float((got.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))

@@ -62,7 +62,8 @@ class UnetConv(ctypes.Structure):
     """Mirror of ``vt_unet3d_conv``."""
     _fields_ = [("gn_w", ctypes.c_void_p), ("gn_b", ctypes.c_void_p), ("packed", ctypes.c_void_p),
                 ("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("packed_bf16x3", ctypes.c_void_p),
-                ("packed_f16x3", ctypes.c_void_p), ("packed_f16x3_thin", ctypes.c_void_p)]
+                ("packed_f16x3", ctypes.c_void_p), ("packed_f16x3_thin", ctypes.c_void_p),
+                ("packed_f16x3_up", ctypes.c_void_p)]
 
 
 class UnetParams(ctypes.Structure):
@@ -180,6 +181,10 @@ SIGNATURES = {
     "vt_conv3d_pack_f16x3": (_I, [_VP, _I, _I, _VP, _VP]),
     "vt_conv3d_stat_blocks_f16x3": (_I, [_I, _I, _I, _I, _I, _I]),
     "vt_conv3d_gcr_f16x3": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),
+    "vt_conv3d_up_packed_floats": (_SZ, [_I, _I]),
+    "vt_conv3d_pack_f16x3_up": (_I, [_VP, _I, _I, _I, _VP, _VP]),
+    "vt_conv3d_up_covers": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "vt_conv3d_gcr_f16x3_up": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP]),
     "vt_conv3d_gcr_f16x3_scaled": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP]),
     "vt_conv3d_final_fusable": (_I, [_I, _I, _I, _I, _I, _I]),
     "vt_conv1x1_pack_f16x3": (_I, [_VP, _I, _I, _VP, _VP]),

@@ -1045,6 +1045,9 @@ struct HbArgs {
     // its output is sum over the in-volume taps of T[tap][cout] = sum_cin W[cout][cin][tap] shift[cin] (vt_voxel_tile_flags makes the
     // flags; plain layers only: no `low`, no in_absmax)
     const unsigned char *tile_skip = nullptr;
+    // decoder-entry layers in per-parity form (conv3d_gcr_up_kernel): the merged class weights of the `low` channels
+    // (vt_conv3d_pack_f16x3_up); c.wp then only serves the skip channels' chunks
+    const float *wp_up = nullptr;
 };
 constexpr int HB_SKIP_LIST = 64;                                     // tiles of either kind a workgroup can hold in its lists
 constexpr size_t hb_lds_sparse(int TZ) { return hb_lds(TZ) + 2 * 27 * 32 * sizeof(float) + 2 * HB_SKIP_LIST * sizeof(unsigned short) + 64 * sizeof(int); }
@@ -1708,6 +1711,8 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
     }
     HB_DIAG_END(2 * TZ);
 }
+
+#include "unet3d_up.inc"
 
 // ---- the same kernel with the support work in the tap waves' own instruction streams -----------------------------------------
 // conv3d_gcr_hw_kernel's loader waves are what bounds it: beside waves that issue MFMAs back to back ANOTHER wave's vector
@@ -2722,6 +2727,72 @@ static int conv_h_launch(const float *skip, int C1, const float *low, int C2, in
     return vt_check(hipGetLastError(), "vt_conv3d_gcr_f16x3");
 }
 
+// ---- decoder-entry layers in per-parity form (unet3d_up.inc) ---------------------------------------------------------------
+// covered: a concat layer ([skip | upsample(low)]) of a shape the specialised-wave kernel takes, with both halves in multiples
+// of 16 channels (an even number of 8-channel chunks per phase)
+static int conv_up_tz(int C1, int C2, int B, int D, int H, int W, int Cout) {
+    static const bool off = getenv("VTACO_CONV_UP") && getenv("VTACO_CONV_UP")[0] == '0';      // A/B knob: the 27-tap kernel on every layer
+    if (off || C2 <= 0 || (C1 & 15) || (C2 & 15)) return 0;
+    const int tz = conv_h_tz(B, D, H, W, C1 + C2, Cout);
+    return (tz == 8 || tz == 4) && conv_h_specialised(tz) && !conv_h_inline() ? tz : 0;
+}
+
+static int conv_up_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                          const float *scale_shift, const float *packed_w_f16x3, const float *packed_up, int Cout, int relu, float *out,
+                          float *out_part, void *stream, const GnIn &stat_in = GnIn{}, const GnOut &stat_out = GnOut{}) {
+    HbArgs ha;
+    ha.c.stat_in = stat_in; ha.c.stat_out = stat_out;
+    ConvArgs &a = ha.c;
+    a.s = Src{skip, low, C1, C2, D, H, W};
+    if (!low || !src_ok(a.s, B) || !packed_w_f16x3 || !packed_up || !out) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr_f16x3_up: bad argument");
+    const int tz = conv_up_tz(C1, C2, B, D, H, W, Cout);
+    if (!tz) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr_f16x3_up: shape not covered (see vt_conv3d_up_covers); use vt_conv3d_gcr_f16x3");
+    a.scale_shift = scale_shift; a.wp = packed_w_f16x3; a.out = out; a.part = out_part; a.Cout = Cout; a.relu = relu;
+    ha.wp_up = packed_up;
+    a.TX = a.TY = 8; a.TZ = tz;
+    a.tiles_x = W / 8; a.tiles_y = H / 8; a.tiles_z = D / tz;
+    ha.wgs_per_scene = conv_h_wgs_per_scene(B, D, H, W, Cout, tz);
+    const dim3 grid((unsigned)(ha.wgs_per_scene * B), (unsigned)(Cout / 32));
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    static bool attr[64] = {};                                      // (the attribute is per device)
+    if (!attr[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_up_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)up_lds(8));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_up_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)up_lds(4));
+        if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3_up: hipFuncSetAttribute");
+        attr[dev] = true;
+    }
+    if (tz == 8) hipLaunchKernelGGL(conv3d_gcr_up_kernel<8>, grid, dim3(hb_threads(8)), up_lds(8), (hipStream_t)stream, ha);
+    else hipLaunchKernelGGL(conv3d_gcr_up_kernel<4>, grid, dim3(hb_threads(4)), up_lds(4), (hipStream_t)stream, ha);
+    return vt_check(hipGetLastError(), "vt_conv3d_gcr_f16x3_up");
+}
+
+size_t vt_conv3d_up_packed_floats(int Cout, int C2) {
+    if (Cout <= 0 || C2 <= 0 || (Cout & 31) || (C2 & 15)) return 0;
+    return (size_t)(C2 / 8) * (Cout / 32) * (UP_CW / 4);
+}
+
+int vt_conv3d_pack_f16x3_up(const float *w, int Cout, int Cin, int C1, float *packed, void *stream) {
+    if (!w || !packed) return vt_fail(VT_ERR_INVALID, "vt_conv3d_pack_f16x3_up: null argument");
+    if (C1 <= 0 || C1 >= Cin || !vt_conv3d_up_packed_floats(Cout, Cin - C1))
+        return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_pack_f16x3_up: Cout must be a multiple of 32, the low channels a multiple of 16");
+    const size_t frags = vt_conv3d_up_packed_floats(Cout, Cin - C1) / 4;
+    size_t g = (frags + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(conv3d_pack_up_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, C1, packed, frags);
+    return vt_check(hipGetLastError(), "vt_conv3d_pack_f16x3_up");
+}
+
+int vt_conv3d_up_covers(int C1, int C2, int B, int D, int H, int W, int Cout) {
+    return conv_up_tz(C1, C2, B, D, H, W, Cout) != 0 ? 1 : 0;
+}
+
+int vt_conv3d_gcr_f16x3_up(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                           const float *scale_shift, const float *packed_w_f16x3, const float *packed_up, int Cout, int relu, float *out,
+                           float *out_part, void *stream) {
+    return conv_up_launch(skip, C1, low, C2, B, D, H, W, scale_shift, packed_w_f16x3, packed_up, Cout, relu, out, out_part, stream);
+}
+
 #ifdef VT_DIAG_HB
 int vt_diag_hb_read(unsigned long long *host, size_t n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(vt_diag_hb_buf), n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
@@ -2868,6 +2939,8 @@ int unet3d_run_fold(const float *x_cl, int B, int R, const vt_unet3d_params *p, 
         if (plan) return 0;
         const GnIn si = ss ? GnIn{} : stat_in(c, a, low, Ri);
         const float *lx = low ? low->x : nullptr;
+        if (kind == CONV_HALF && low && c.packed_f16x3_up && conv_up_tz(a.C, C2, B, Ri, Ri, Ri, c.cout))     // decoder entry: per-parity form
+            return conv_up_launch(a.x, a.C, lx, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.packed_f16x3_up, c.cout, 1, o.x, nullptr, st, si, so);
         if (kind == CONV_HALF)
             return conv_h_launch(a.x, a.C, lx, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.cout, 1, o.x, nullptr, nullptr, nullptr, nullptr, st, si, so, skipf);
         // the thin levels: IEEE-half pairs where the caller packed them (a network whose large levels run the split-f16 kernels)
@@ -2981,6 +3054,8 @@ int unet3d_run(const float *x_cl, int B, int R, const vt_unet3d_params *p, char 
         int rc = vt_gn_scale_shift(a.part, a.nblk, a.C, low ? low->part : nullptr, low ? low->nblk : 0, C2, B,
                                    (int64_t)Ri * Ri * Ri, groups, c.gn_w, c.gn_b, p->eps, ss, st);
         if (rc) return rc;
+        if (half && low && c.packed_f16x3_up && conv_up_tz(a.C, C2, B, Ri, Ri, Ri, c.cout))
+            return conv_up_launch(a.x, a.C, low->x, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.packed_f16x3_up, c.cout, 1, o.x, o.part, st);
         if (half)
             return conv_h_launch(a.x, a.C, low ? low->x : nullptr, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.cout, 1, o.x, o.part, nullptr, nullptr, nullptr, st,
                                  GnIn{}, GnOut{}, skipf);

@@ -211,6 +211,19 @@ class UNet3D(nn.Module):
             self._pack_cache[key] = hit
         return hit[1]
 
+    def _packed_up(self, conv, c_skip):
+        """Merged class weights of a decoder-entry conv (ops.conv3d_pack_up), cached like _packed; None where not applicable
+        (precision other than "f16x3", VTACO_CONV_UP=0, channel counts the kernel does not take)."""
+        if self.precision != "f16x3" or os.environ.get("VTACO_CONV_UP", "1") == "0":
+            return None
+        key = (id(conv), "f16x3_up", c_skip)
+        stamp = (conv.weight.data_ptr(), conv.weight._version)
+        hit = self._pack_cache.get(key)
+        if hit is None or hit[0] != stamp:
+            hit = (stamp, ops.conv3d_pack_up(conv.weight.detach(), c_skip))
+            self._pack_cache[key] = hit
+        return hit[1]
+
     def _gcr(self, single, x, x_stats, low=None, low_stats=None):
         gn, conv = single.groupnorm, single.conv
         # "f16x3": IEEE-half pairs on every level -- the persistent kernels where they cover the shape, the thin-tile / K-split
@@ -218,9 +231,10 @@ class UNet3D(nn.Module):
         thin_half = self.precision == "f16x3" and self.thin_half
         split = self._packed(conv, "f16x3_thin" if thin_half else "bf16x3") if self.precision in ("bf16x3", "f16x3") else None
         half = self._packed(conv, "f16x3") if self.precision == "f16x3" else None
+        up = self._packed_up(conv, x.shape[-1]) if low is not None else None
         return ops.gn_conv3d_relu(x, x_stats, low, low_stats, gn.weight.detach(), gn.bias.detach(), gn.num_groups,
                                   self._packed(conv), conv.out_channels, eps=gn.eps, relu=True, packed_w_bf16x3=split,
-                                  packed_w_f16x3=half, thin_half=thin_half)
+                                  packed_w_f16x3=half, thin_half=thin_half, packed_w_up=up)
 
     def _hip_params(self):
         """vt_unet3d_params for the current weights (re-packed only when a conv weight changed); the filled structure itself is
@@ -232,7 +246,7 @@ class UNet3D(nn.Module):
                 t for blk in list(self.encoders) + list(self.decoders)
                 for single in (blk.basic_module.SingleConv1, blk.basic_module.SingleConv2)
                 for t in (single.groupnorm.weight, single.groupnorm.bias, single.conv.weight)]
-        stamp = (self.precision, self.thin_half, os.environ.get("VTACO_UNET_FUSED_FINAL", "1")) + tuple(
+        stamp = (self.precision, self.thin_half, os.environ.get("VTACO_UNET_FUSED_FINAL", "1"), os.environ.get("VTACO_CONV_UP", "1")) + tuple(
             (id(t), t.data_ptr(), t._version) for t in tensors if t is not None)
         hit = getattr(self, "_prm_cache", None)
         if hit is not None and hit[0] == stamp:
@@ -246,7 +260,7 @@ class UNet3D(nn.Module):
         prm = _lib.UnetParams()
         keep = []
 
-        def fill(dst, single):
+        def fill(dst, single, c_skip=None):
             gn, conv = single.groupnorm, single.conv
             tensors = (gn.weight.detach().contiguous(), gn.bias.detach().contiguous(), self._packed(conv))
             keep.extend(tensors)
@@ -264,6 +278,10 @@ class UNet3D(nn.Module):
                 half = self._packed(conv, "f16x3")
                 keep.append(half)
                 dst.packed_f16x3 = half.data_ptr()
+                up = self._packed_up(conv, c_skip) if c_skip else None      # decoder entry: [skip | upsample(low)] in per-parity form
+                if up is not None:
+                    keep.append(up)
+                    dst.packed_f16x3_up = up.data_ptr()
         prm.n_levels = len(self.encoders)
         first_gn = self.encoders[-1].basic_module.SingleConv1.groupnorm
         prm.groups, prm.eps = first_gn.num_groups, first_gn.eps
@@ -271,7 +289,8 @@ class UNet3D(nn.Module):
             fill(prm.enc[i][0], enc.basic_module.SingleConv1)
             fill(prm.enc[i][1], enc.basic_module.SingleConv2)
         for k, dec in enumerate(self.decoders):
-            fill(prm.dec[k][0], dec.basic_module.SingleConv1)
+            skip_c = self.encoders[len(self.encoders) - 2 - k].basic_module.SingleConv2.conv.out_channels
+            fill(prm.dec[k][0], dec.basic_module.SingleConv1, c_skip=skip_c)
             fill(prm.dec[k][1], dec.basic_module.SingleConv2)
         fw = self.final_conv.weight.detach().reshape(self.final_conv.out_channels, -1).contiguous()
         keep.append(fw)

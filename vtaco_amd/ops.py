@@ -1158,6 +1158,21 @@ def conv3d_pack(weight, precision="f32"):
     return out
 
 
+def conv3d_pack_up(weight, c_skip):
+    """The merged class weights of a decoder-entry conv's upsampled channels (vt_conv3d_pack_f16x3_up): ``weight``
+    [Cout, c_skip + C2, 3, 3, 3] of the layer that reads [skip | upsample(low)]; None where the per-parity kernel does not
+    take the channel counts."""
+    lib = _lib.load()
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    n = lib.vt_conv3d_up_packed_floats(Cout, Cin - c_skip) if 0 < c_skip < Cin else 0
+    if n == 0 or tuple(weight.shape[2:]) != (3, 3, 3):
+        return None
+    w = _c(weight)
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(lib.vt_conv3d_pack_f16x3_up(dev_ptr(w, "w"), Cout, Cin, c_skip, dev_ptr(out, "packed"), stream_ptr()), "vt_conv3d_pack_f16x3_up")
+    return out
+
+
 def conv3d_gcr_final(x, ss, packed_w_f16x3, final_packed, final_bias):
     """relu(conv3x3x3(x * scale + shift)) followed by the final 1x1x1 conv (32 -> 32) in the same launch
     (vt_conv3d_gcr_f16x3_final); check ``final_fusable`` first."""
@@ -1235,7 +1250,7 @@ def gn_scale_shift(x_stats, low_stats, C1, C2, B, voxels, gamma, beta, groups, e
 
 
 def conv3d_gcr(x, low, ss, packed_w, Cout, relu=True, packed_w_bf16x3=None, want_stats=True, packed_w_f16x3=None,
-               in_absmax=None, thin_half=False):
+               in_absmax=None, thin_half=False, packed_w_up=None):
     """relu?(conv3x3x3(x_cat * scale + shift)) on channels-last tensors (``ss`` None: no normalisation);
     returns (out, (part, nblk) or None).  With ``packed_w_f16x3`` / ``packed_w_bf16x3`` the convolution runs on the
     16-bit matrix core with split operands where that kernel covers the shape (f16x3 first).  ``thin_half``: ``packed_w_bf16x3``
@@ -1275,6 +1290,13 @@ def conv3d_gcr(x, low, ss, packed_w, Cout, relu=True, packed_w_bf16x3=None, want
             if callable(pw):
                 pw = pw()
     part = torch.empty((B, nblk, Cout, 2), dtype=torch.float32, device=dev) if want_stats else None
+    if (packed_w_up is not None and low is not None and in_absmax is None and name == "vt_conv3d_gcr_f16x3"
+            and lib.vt_conv3d_up_covers(C1, C2, B, D, H, W, Cout)):
+        # decoder entry [skip | upsample(low)]: the low channels as a 2x2x2 conv per output parity class (conv3d_pack_up)
+        check(lib.vt_conv3d_gcr_f16x3_up(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
+                                         dev_ptr(pw, "packed_w"), dev_ptr(packed_w_up, "packed_up"), Cout, int(relu),
+                                         dev_ptr(out, "out"), dev_ptr(part, "part"), st), "vt_conv3d_gcr_f16x3_up")
+        return out, ((part, nblk) if want_stats else None)
     if in_absmax is not None and name == "vt_conv3d_gcr_f16x3":
         # input far below the half range (output gradients): the kernel rescales it by a power of two around the split
         check(lib.vt_conv3d_gcr_f16x3_scaled(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
@@ -1287,13 +1309,14 @@ def conv3d_gcr(x, low, ss, packed_w, Cout, relu=True, packed_w_bf16x3=None, want
 
 
 def gn_conv3d_relu(x, x_stats, low, low_stats, gamma, beta, groups, packed_w, Cout, eps=1e-5, relu=True,
-                   packed_w_bf16x3=None, packed_w_f16x3=None, thin_half=False):
+                   packed_w_bf16x3=None, packed_w_f16x3=None, thin_half=False, packed_w_up=None):
     """relu(conv3x3x3(GroupNorm([x | upsample(low)]))) on channels-last tensors; the statistics
     come from the producers' partial sums.  Returns (out, out_stats)."""
     B, D, H, W, C1 = x.shape
     C2 = low.shape[-1] if low is not None else 0
     ss = gn_scale_shift(x_stats, low_stats if low is not None else None, C1, C2, B, D * H * W, gamma, beta, groups, eps, x.device)
-    return conv3d_gcr(x, low, ss, packed_w, Cout, relu, packed_w_bf16x3, packed_w_f16x3=packed_w_f16x3, thin_half=thin_half)
+    return conv3d_gcr(x, low, ss, packed_w, Cout, relu, packed_w_bf16x3, packed_w_f16x3=packed_w_f16x3, thin_half=thin_half,
+                      packed_w_up=packed_w_up)
 
 
 def relu_mask(dy, y, want_absmax=False):
