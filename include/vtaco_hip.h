@@ -159,7 +159,8 @@ int vt_decode_fwd_f16f8(const float *grid_cl, int B, int R, int C, int64_t N,
 /*   bit 2 (vt_decode_fwd_f16f8 only): a logit beyond 2.5 in magnitude was written -- that kernel's    */
 /*          error is relative (~3e-5 |logit|), its 1e-4 absolute contract ends there: re-run likewise.  */
 /* vt_decode_range_status copies that word to the host (synchronises `stream`) and, with `reset`,    */
-/* clears it (the host mirror's Generator3D does the re-runs).  No reference counterpart: the          */
+/* clears it (the host mirror's Generator3D does the re-runs); host_status NULL with `reset`: clear    */
+/* only, asynchronously on `stream` (the start of a scene).  No reference counterpart: the             */
 /* reference is f32 (decoder.py:135-161).                                                              */
 int vt_decode_range_status(unsigned *host_status, int reset, void *stream);
 

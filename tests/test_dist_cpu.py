@@ -254,3 +254,80 @@ def test_range_guard_word_is_reduced_over_the_given_group_only():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, 5, 2), (1, 5, None)]
+
+
+def _agree_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import warnings
+        from types import SimpleNamespace
+        from vtaco_amd import ops
+        from vtaco_amd.conv_onet import generation as gen
+        # no GPU here: the device's status word is a local variable, the scene a counter
+        state = {"word": 0, "runs": 0}
+        ops_clear, ops_status = ops.decode_range_clear, ops.decode_range_status
+        ops.decode_range_clear = lambda: state.__setitem__("word", 0)
+        def _status(reset=True):
+            w = state["word"]
+            if reset:
+                state["word"] = 0
+            return w
+        ops.decode_range_status = _status
+
+        class Fake:
+            device = None
+            def __init__(self, precision):
+                self.decode_precision = precision
+                self.model = SimpleNamespace(decoder=SimpleNamespace(mlp_precision="f16x3"))
+            _set_decode_precision = gen.Generator3D._set_decode_precision
+
+            @gen._range_guarded(collective=True)
+            def sharded(self, data, group=None):
+                state["runs"] += 1
+                # rank 1's decode trips the half range on its first run in a half precision
+                if rank == 1 and self.decode_precision in ("f16x3", "f16f8") and state["runs"] == 1:
+                    state["word"] |= ops.RANGE_HALF
+                t = torch.tensor([float(gen._PRECISION_ORDER.index(self.decode_precision))])
+                dist.all_reduce(t, group=group)                     # the slabs' all-gather stands in: every rank must arrive
+                return self.decode_precision, float(t.item())
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            # (1) rank 0 was downgraded earlier by a rank-local guard: the ranks agree on bf16x3 BEFORE any decode, no hang
+            a = Fake("bf16x3" if rank == 0 else "f16x3")
+            r1 = a.sharded(None, None)
+            # (2) both in f16x3, rank 1 trips RANGE_HALF: both regenerate in bf16x3
+            state["runs"] = 0
+            b = Fake("f16x3")
+            r2 = b.sharded(None, None)
+            runs2 = state["runs"]
+            # (3) a stale bit from an earlier launch on this device is not this scene's
+            state["runs"] = 5; state["word"] = ops.RANGE_HALF
+            c = Fake("f16x3")
+            r3 = c.sharded(None, None)
+        ops.decode_range_clear, ops.decode_range_status = ops_clear, ops_status
+        dist.barrier()
+        q.put((rank, r1, a.model.decoder.mlp_precision, r2, runs2, r3))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_guard_agrees_on_one_precision_and_every_rank_enters_every_collective():
+    """a rank whose precision was downgraded by a rank-local guard must not skip the sharded entry point's
+    reduction (mismatched collective = hang), and the slabs of one value grid must be decoded in ONE arithmetic."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, r1, mlp, r2, runs2, r3 in res:
+        assert r1 == ("bf16x3", 4.0)                 # both ranks decoded in bf16x3 (index 2 + 2)
+        assert mlp == ("f32" if rank == 1 else "f16x3")   # the rank that FOLLOWED also took its attention MLP to the exact kernel
+        assert r2 == ("bf16x3", 4.0) and runs2 == 2    # tripped on rank 1 only: BOTH regenerate once
+        assert r3 == ("f16x3", 2.0)                  # the stale bit was cleared when the scene began

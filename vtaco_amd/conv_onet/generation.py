@@ -25,47 +25,86 @@ Mesh = namedtuple("Mesh", ["vertices", "faces"])
 _tensor_version = operator.attrgetter("_version")
 
 
+_PRECISION_ORDER = ("f16f8", "f16x3", "bf16x3", "f32")            # least to most conservative
+
+
+def _guard_step(word, precision):
+    """What the range word of a finished scene asks of a half-precision decode: (next precision, reason) or None."""
+    if precision not in ("f16x3", "f16f8"):
+        return None
+    if word & ops.RANGE_HALF:
+        return "bf16x3", "reach the half-precision range limit (65504)"
+    if (word & ops.RANGE_FP8) and precision == "f16f8":
+        return "f16x3", "reach 1024, where the fp8 correction products of 'f16f8' begin to clip"
+    if (word & ops.RANGE_LOGIT) and precision == "f16f8":
+        return "f16x3", "produce logits beyond 2.5, where the relative error of 'f16f8' (~3e-5 |logit|) leaves the 1e-4 bar"
+    return None
+
+
+def _agree_precision(precision, group, device):
+    """The most conservative decode precision held by any rank of ``group`` (one MAX all-reduce of its rank in _PRECISION_ORDER);
+    ``precision`` itself without an initialised process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        return precision
+    mine = _PRECISION_ORDER.index(precision) if precision in _PRECISION_ORDER else len(_PRECISION_ORDER) - 1
+    if dist.get_backend(group) == "nccl":
+        dev = device if device is not None and torch.device(device).type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+    else:
+        dev = "cpu"
+    t = torch.tensor([mine], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return _PRECISION_ORDER[int(t.item())] if int(t.item()) != mine else precision
+
+
 def _range_guarded(method=None, *, collective=False):
     """A generation entry point under the half-precision decodes' range guard (ops.decode_range_status, one word per device).
     "f16f8" that met activations >= 1024 (RANGE_FP8: its fp8 correction copies begin to clip) or wrote a logit beyond 2.5
     (RANGE_LOGIT: its error is relative, ~3e-5 |logit|) has left its 1e-4 contract and moves to "f16x3"; a half-precision form that met activations at the edge of the half range (RANGE_HALF: 65504, hi operands saturate)
-    moves to "bf16x3" (f32's exponent range) -- for good, with a warning -- and the scene is generated again.  One 4-byte
-    read-back per scene, behind the synchronisation the mesh extraction has just done.
+    moves to "bf16x3" (f32's exponent range) -- for good, with a warning -- and the scene is generated again.  The word is
+    cleared (asynchronously) when the outermost guarded call begins, so that only THIS scene's launches are judged, and read
+    back once per scene behind the synchronisation the mesh extraction has just done.
 
     The decision is RANK-LOCAL for every entry point except the sharded one: a rank-0-only mesh export during distributed
     training or per-rank evaluation with uneven scene counts must not meet a collective here.  ``collective=True``
-    (generate_obj_mesh_sharded, whose ranks re-run their all-gather together or not at all) reduces the word over the
-    ``group`` the call was given, and only over that group."""
+    (generate_obj_mesh_sharded) is a collective on the ``group`` the call was given whatever the ranks' precisions are: the
+    ranks first agree on the most conservative precision any of them holds (a rank-local guard may have moved one rank
+    earlier: the slabs of one value grid must be decoded in one arithmetic, and every rank must enter the same reductions),
+    then every round reduces the word over the group, so that all ranks take the same decision."""
     import functools
     import warnings
 
     def wrap(method):
         @functools.wraps(method)
         def guarded(self, *args, **kwargs):
-            if getattr(self, "_guard_depth", 0) or self.decode_precision not in ("f16x3", "f16f8"):
+            if getattr(self, "_guard_depth", 0):
+                return method(self, *args, **kwargs)
+            group = kwargs.get("group", args[1] if len(args) > 1 else None) if collective else None
+            if collective:
+                agreed = _agree_precision(self.decode_precision, group, self.device)
+                if agreed != self.decode_precision:
+                    warnings.warn(f"Generator3D: another rank of the group decodes in {agreed!r}; this rank follows "
+                                  f"(decode_precision {self.decode_precision!r} -> {agreed!r})")
+                    self._set_decode_precision(agreed)
+            if self.decode_precision not in ("f16x3", "f16f8"):
                 return method(self, *args, **kwargs)
             self._guard_depth = 1
             try:
+                ops.decode_range_clear()                             # bits left by earlier launches on this device are not this scene's
                 out = method(self, *args, **kwargs)
                 for _ in range(2):                                   # f16f8 -> f16x3 -> bf16x3 at most
                     if self.decode_precision not in ("f16x3", "f16f8"):
                         break
                     word = ops.decode_range_status(reset=True)
                     if collective:
-                        word = _reduce_or(word, kwargs.get("group", args[1] if len(args) > 1 else None), self.device)
-                    if word & ops.RANGE_HALF:
-                        nxt, why = "bf16x3", "reach the half-precision range limit (65504)"
-                    elif (word & ops.RANGE_FP8) and self.decode_precision == "f16f8":
-                        nxt, why = "f16x3", "reach 1024, where the fp8 correction products of 'f16f8' begin to clip"
-                    elif (word & ops.RANGE_LOGIT) and self.decode_precision == "f16f8":
-                        nxt, why = "f16x3", "produce logits beyond 2.5, where the relative error of 'f16f8' (~3e-5 |logit|) leaves the 1e-4 bar"
-                    else:
+                        word = _reduce_or(word, group, self.device)
+                    step = _guard_step(word, self.decode_precision)
+                    if step is None:
                         break
+                    nxt, why = step
                     warnings.warn(f"Generator3D: the decoder's activations {why}; "
                                   f"decode_precision {self.decode_precision!r} -> {nxt!r} and the scene is generated again")
-                    self.decode_precision = nxt
-                    if nxt == "bf16x3" and hasattr(self.model.decoder, "mlp_precision"):
-                        self.model.decoder.mlp_precision = "f32"      # the attention decoder's MLP: back to the exact kernel
+                    self._set_decode_precision(nxt)
                     out = method(self, *args, **kwargs)
                 return out
             finally:
@@ -188,6 +227,13 @@ class Generator3D(object):
             mods = list(self.model.modules())
             tab = self._tables = (self.model, mods, [d for m in mods for d in (m._parameters, m._buffers) if d])
         return tab
+
+    def _set_decode_precision(self, precision):
+        """Move the lattice decode to ``precision`` (the range guard's downgrade); "bf16x3" / "f32" also take the attention decoder's
+        MLP back to the exact kernel."""
+        self.decode_precision = precision
+        if precision in ("bf16x3", "f32") and hasattr(self.model.decoder, "mlp_precision"):
+            self.model.decoder.mlp_precision = "f32"
 
     def _eval_mode(self):
         """``self.model.eval()`` (generation.py:66, 131), skipped when every module already is in eval mode."""

@@ -1061,9 +1061,10 @@ int vt_decoder_pack_f16f8(const vt_decoder_params *p, float *blob, size_t blob_b
 }
 
 int vt_decode_range_status(unsigned *host_status, int reset, void *stream) {
-    if (!host_status) return vt_fail(VT_ERR_INVALID, "vt_decode_range_status: null argument");
+    if (!host_status && !reset) return vt_fail(VT_ERR_INVALID, "vt_decode_range_status: null argument");
     unsigned *d = vt_decode_status_dev();
     if (!d) return vt_fail(VT_ERR_INVALID, "vt_decode_range_status: no device memory for the status word");
+    if (!host_status) return vt_fill32(d, 0u, sizeof(unsigned), (hipStream_t)stream);      // clear without a read-back: asynchronous
     hipError_t e = hipMemcpyAsync(host_status, d, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return vt_check(e, "vt_decode_range_status");

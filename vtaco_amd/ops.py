@@ -156,6 +156,12 @@ def decode_range_status(reset=True):
     return int(word.value)
 
 
+def decode_range_clear():
+    """Clear the current device's range-guard word without reading it (an asynchronous 4-byte fill on the current stream: what
+    the generator does when a scene begins, so that bits left by earlier launches are not attributed to it)."""
+    check(_lib.load().vt_decode_range_status(None, 1, stream_ptr()), "vt_decode_range_status")
+
+
 def decode_last_clock(workgroups=False):
     """Clock evidence of the last lattice decode launch on the current device (vt_decode_last_clock): workgroup 0's lifetime in
     shader cycles and in ticks of the constant-rate counter -> {"shader_mhz", "wg0_us", "shader_cycles"}; with
