@@ -203,6 +203,19 @@ int vt_decode_fwd_wide_f16x3(const float *grid_cl, int B, int R, int C, const fl
                              int lattice_nx, float lattice_box, int64_t lattice_first,
                              const float *c_img, const float *blob_wide_f16x3, int hidden, int n_blocks, int flags, double padding,
                              float *out, float *out2, void *stream);
+/* The two forwards above with the tactile feature given per point as a finger id (255 = none) and the [n_fingers][C] table of   */
+/* finger features instead of the dense c_img tensor (reference generation.py:159-255 builds c_img_all [1, nx^3, C] on the host:   */
+/* 8.6 GB at 256^3 / c_dim 128); the blob is the one packed with fc_p_img (p_in = 3 + C).  Equal to the dense form bit for bit.   */
+int vt_decode_fwd_wide_ids(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                           int lattice_nx, float lattice_box, int64_t lattice_first,
+                           const unsigned char *finger_ids, const float *finger_feats, int n_fingers,
+                           const float *blob_wide, int hidden, int n_blocks, int flags, double padding,
+                           float *out, float *out2, void *stream);
+int vt_decode_fwd_wide_f16x3_ids(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                                 int lattice_nx, float lattice_box, int64_t lattice_first,
+                                 const unsigned char *finger_ids, const float *finger_feats, int n_fingers,
+                                 const float *blob_wide_f16x3, int hidden, int n_blocks, int flags, double padding,
+                                 float *out, float *out2, void *stream);
 
 /* The same shapes under autograd (the reference trains them through torch autograd: decoder.py:24-51,     */
 /* 135-161 called from training.py:476-489, 734-740, 879).                                                   */

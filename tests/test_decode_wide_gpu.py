@@ -101,7 +101,17 @@ def test_wide_decoder_finger_ids_and_errors():
         table = torch.cat([feats, torch.zeros(1, 32)])
         c_img = table[torch.where(ids == 255, torch.full_like(ids, 5), ids).long()]
         ref = dec.decode_lattice(grid, nx, c_img=c_img.to(DEV))
-    assert torch.equal(got, ref)
+        # the split-f16 kernel reads the ids itself as well; a slab; two scenes with their own ids
+        got_h = dec.decode_lattice_ids(grid, nx, ids.to(DEV), feats.to(DEV), precision="f16x3")
+        ref_h = dec.decode_lattice(grid, nx, c_img=c_img.to(DEV), precision="f16x3")
+        first, count = nx * nx * 2, nx * nx * 3
+        got_s = dec.decode_lattice_ids(grid, nx, ids[:, first:first + count].contiguous().to(DEV), feats.to(DEV), first=first, count=count)
+        grid2 = torch.cat([grid, grid.flip(2)])
+        ids2 = torch.cat([ids, ids.flip(1)])
+        got_2 = dec.decode_lattice_ids(grid2, nx, ids2.to(DEV), feats.to(DEV))
+        ref_2 = dec.decode_lattice(grid2, nx, c_img=torch.cat([c_img, c_img.flip(1)]).to(DEV))
+    assert torch.equal(got, ref) and torch.equal(got_h, ref_h) and not torch.equal(got_h, got)
+    assert torch.equal(got_s, ref[:, first:first + count]) and torch.equal(got_2, ref_2)
     for bad in (dict(hidden_size=48, c_dim=32), dict(hidden_size=288, c_dim=32), dict(hidden_size=64, c_dim=16)):
         d = LocalDecoder(n_blocks=2, **bad).to(DEV)
         with torch.no_grad(), pytest.raises(VtError, match="multiples of 32 up to 256"):
@@ -250,3 +260,51 @@ def test_wide_split_f16_reports_activations_at_the_half_limit():
         dec.fc_c[0].weight.mul_(3e5)
         dec(p, {"grid": grid})
     assert ops.decode_range_status(reset=True) & ops.RANGE_HALF
+
+
+def test_wide_decoder_by_finger_id_at_the_reference_default_widths_needs_no_dense_tensor():
+    """256 / 128 (the reference's class defaults, decoder.py:24) over a 64^3 slab by finger id: the dense c_img the round-4 path
+    built with torch indexing would be B * count * c_dim floats (8.6 GB at 256^3); the kernels read ids and the [F, C] table.
+    Equal to the dense form bit for bit, and the call allocates nothing of the dense tensor's size."""
+    dec = _decoder(256, 128, 2, False, seed=7)
+    g = torch.Generator().manual_seed(8)
+    nx, first, count = 64, 64 * 64 * 16, 64 * 64 * 8
+    grid = torch.randn(1, 128, 8, 8, 8, generator=g).to(DEV)
+    ids = torch.randint(0, 6, (1, count), generator=g).to(torch.uint8)
+    ids[ids == 5] = 255
+    feats = torch.randn(5, 128, generator=g)
+    with torch.no_grad():
+        idd, fd = ids.to(DEV), feats.to(DEV)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        got = dec.decode_lattice_ids(grid, nx, idd, fd, first=first, count=count, precision="f16x3")
+        torch.cuda.synchronize()
+        extra = torch.cuda.max_memory_allocated() - base
+        dense_bytes = count * 128 * 4
+        assert extra < dense_bytes // 4, (extra, dense_bytes)       # logits + blobs only
+        table = torch.cat([feats, torch.zeros(1, 128)])
+        c_img = table[torch.where(ids == 255, torch.full_like(ids, 5), ids).long()].to(DEV)
+        ref = dec.decode_lattice(grid, nx, first=first, count=count, c_img=c_img, precision="f16x3")
+    assert torch.equal(got, ref)
+
+
+def test_empty_query_sets_under_autograd():
+    """N = 0 in the training paths (shipped shape and wide): empty logits, zero gradients, no 'shape not built'."""
+    from vtaco_amd.conv_onet.models.decoder import LocalDecoder
+    for kw in (dict(hidden_size=32, c_dim=32, n_blocks=5), dict(hidden_size=64, c_dim=32, n_blocks=2)):
+        torch.manual_seed(0)
+        dec = LocalDecoder(dim=3, padding=0.1, with_contact=True, **kw).to(DEV)
+        grid = torch.randn(2, 32, 8, 8, 8, device=DEV, requires_grad=True)
+        p = torch.zeros(2, 0, 3, device=DEV)
+        out = dec(p, {"grid": grid})
+        assert tuple(out.shape) == (2, 0)
+        oi = dec.forward_img(p, {"grid": grid}, torch.zeros(2, 0, 32, device=DEV, requires_grad=True))
+        o1, o2 = dec.forward_contact(p, {"grid": grid})
+        (out.sum() + oi.sum() + o1.sum() + o2.sum()).backward()
+        assert grid.grad is not None and float(grid.grad.abs().max()) == 0.0
+        for prm in dec.parameters():
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0
+    from vtaco_amd import ops
+    gg = ops.sample_grid_bwd((1, 32, 8, 8, 8), torch.zeros(1, 0, 3, device=DEV), torch.zeros(1, 0, 32, device=DEV))
+    assert float(gg.abs().max()) == 0.0

@@ -113,6 +113,8 @@ SIGNATURES = {
     "vt_decoder_pack_wide_f16x3": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
     "vt_decode_fwd_wide": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _I, _I, _I, _D, _VP, _VP, _VP]),
     "vt_decode_fwd_wide_f16x3": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _I, _I, _I, _D, _VP, _VP, _VP]),
+    "vt_decode_fwd_wide_ids": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _I, _VP, _I, _I, _I, _D, _VP, _VP, _VP]),
+    "vt_decode_fwd_wide_f16x3_ids": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _I, _VP, _I, _I, _I, _D, _VP, _VP, _VP]),
     "vt_decode_wide_save_floats": (_SZ, [_I64, _I, _I, _I]),
     "vt_decode_wide_gws_floats": (_SZ, [_I64, _I, _I, _I]),
     "vt_decode_fwd_wide_train": (_I, [_VP, _I, _I, _I, _VP, _I64, _VP, _VP, _I, _I, _I, _D, _VP, _VP, _VP, _VP]),

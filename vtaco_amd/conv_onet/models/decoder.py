@@ -248,7 +248,8 @@ class LocalDecoder(nn.Module):
 
     def _wide_fwd(self, grid, precision=None, **kw):
         wp = self._wide_precision(precision or self._point_precision())
-        return ops.decode_fwd(grid, self._blob(img=kw.get("c_img") is not None, contact=kw.get("want_contact", False), precision=wp),
+        img = kw.get("c_img") is not None or kw.get("finger_ids") is not None
+        return ops.decode_fwd(grid, self._blob(img=img, contact=kw.get("want_contact", False), precision=wp),
                               padding=self.padding, precision=wp,
                               wide=(self.hidden_size, self.n_blocks, self.leaky, self.sample_mode == 'nearest'), **kw)
 
@@ -316,11 +317,9 @@ def _decode_lattice_ids(self, grid, nx, finger_ids, finger_feats, box=1.1, first
     2.1 GB of c_img_all)."""
     count = nx ** 3 - first if count is None else count
     if self._wide:
-        # the wide kernel takes the dense tensor: finger_feats[ids], zeros where ids == 255 (B * count * c_dim floats)
-        table = torch.cat([finger_feats.float(), finger_feats.new_zeros((1, finger_feats.shape[1]), dtype=torch.float32)])
-        ids = finger_ids.reshape(grid.shape[0], count).long()
-        c_img = table[torch.where(ids == 255, torch.full_like(ids, finger_feats.shape[0]), ids)]
-        return self._wide_fwd(grid, precision=precision or self.precision, lattice=(nx, box, first, count), out=out, c_img=c_img)
+        # the wide kernels read the ids themselves (vt_decode_fwd_wide[_f16x3]_ids): no dense [B, count, c_dim] tensor
+        return self._wide_fwd(grid, precision=precision or self.precision, lattice=(nx, box, first, count), out=out,
+                              finger_ids=finger_ids.reshape(grid.shape[0], count), finger_feats=finger_feats)
     precision = precision or self.precision
     if precision == "f16f8" and not ops.f16f8_covers(grid, (nx, box, first, count), self.padding):
         precision = "f16x3"

@@ -1129,12 +1129,12 @@ static int st3_launch(const DecodeArgs &a_in, int variant, void *stream) {
     int64_t blocks = (nt + ST3_THREADS / 64 - 1) / (ST3_THREADS / 64);
     if (blocks > vt_num_cus()) blocks = vt_num_cus();
     if (blocks > 8) blocks &= ~7ll;
-    static bool attr = false;
+    bool attr = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<0>), 160 * 1024);
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<1>), 160 * 1024);
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<2>), 160 * 1024);
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_fwd_staged3_kernel<3>), 160 * 1024);
         if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute (staged3)");
         attr = true;
     }
@@ -1228,8 +1228,7 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
             if (blocks > 8) blocks &= ~7ll;
             static bool st2_attr = false;
             if (!st2_attr) {
-                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged2_kernel<P>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                const hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_fwd_staged2_kernel<P>), 160 * 1024);
                 if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute (staged2)");
                 st2_attr = true;
             }
@@ -1242,10 +1241,9 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
             int64_t blocks = (nt + ST_THREADS / 64 - 1) / (ST_THREADS / 64);
             if (blocks > vt_num_cus()) blocks = vt_num_cus();
             if (blocks > 8) blocks &= ~7ll;
-            static bool st_attr = false;
+            bool st_attr = false;        // (vt_max_dyn_lds keeps the per-device record)
             if (!st_attr) {
-                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_staged_kernel<P>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                const hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_fwd_staged_kernel<P>), 160 * 1024);
                 if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute (staged)");
                 st_attr = true;
             }
@@ -1260,14 +1258,12 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
     if (blocks > cap) blocks = cap;
     if (blocks > 8) blocks &= ~7ll;                                     // whole workgroups per XCD
     const size_t lds_bytes = (size_t)VT_BLOB_FLOATS * sizeof(float);
-    static bool attr_set = false;
+    bool attr_set = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS, false, P>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS, false, P>), (int)lds_bytes);
         if constexpr (P == 0) {
             if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS, true, 0>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_fwd_kernel<THREADS, true, 0>), (int)lds_bytes);
         }
         if (e != hipSuccess) return vt_check(e, "vt_decode_fwd: hipFuncSetAttribute");
         attr_set = true;

@@ -405,10 +405,9 @@ static int decode_bwd_launch(BwdArgs &a, void *stream) {
     const int64_t cap = 2 * vt_num_cus();
     if (blocks > cap) blocks = cap;
     const size_t lds_bytes = (size_t)VT_BLOBT_FLOATS * sizeof(float);
-    static bool attr_set = false;
+    bool attr_set = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_bwd_data_kernel<THREADS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_bwd_data_kernel<THREADS>), (int)lds_bytes);
         if (e != hipSuccess) return vt_check(e, "vt_decode_bwd: hipFuncSetAttribute");
         attr_set = true;
     }

@@ -99,6 +99,16 @@ __global__ void wide_copy_kernel(const float *src, float *dst, int n) {
 
 __device__ __forceinline__ float actvn(float x, int leaky) { return x > 0.0f ? x : (leaky ? 0.2f * x : 0.0f); }
 
+// column k3 of point g's tactile feature: the dense tensor [total][C], or the finger's row of the [F][C] table by id (255: none --
+// the form the 256^3 configuration needs: one byte per point instead of 4 C)
+__device__ __forceinline__ float wide_cimg(const DecodeArgs &d, uint32_t g, int k3, int C) {
+    if (d.cimg_ids) {
+        const unsigned id = d.cimg_ids[g];
+        return id == 255u ? 0.0f : d.cimg_table[(size_t)id * C + k3];
+    }
+    return d.c_img[(size_t)g * C + k3];
+}
+
 // acc += W[32 rows of block ob][K] . X[K][32 points]; wf: the layer's fragments, x: LDS [K][WIDE_PITCH]
 __device__ __forceinline__ f32x16 wide_gemm(f32x16 acc, const float *wf, int ob, int K, const float *x, int lane) {
     const f32x4 *w4 = reinterpret_cast<const f32x4 *>(wf) + (size_t)ob * (K / 8) * 64 + lane;
@@ -179,7 +189,7 @@ decode_wide_kernel(WideArgs a) {
                 }
                 if (ch < 3) bufA[ch * WIDE_PITCH + pt] = ch == 0 ? px : (ch == 1 ? py : pz);
                 for (int k = 3 + ch; k < Kp; k += 32)
-                    bufA[k * WIDE_PITCH + pt] = (d.c_img && k < a.p_in) ? d.c_img[(size_t)g * (a.p_in - 3) + (k - 3)] : 0.0f;
+                    bufA[k * WIDE_PITCH + pt] = (a.p_in > 3 && k < a.p_in) ? wide_cimg(d, g, k - 3, a.p_in - 3) : 0.0f;
             }
         }
         __syncthreads();
@@ -524,7 +534,7 @@ decode_wide_h_kernel(WideHArgs a) {
                 for (int k = ch; k < Kp; k += 32) {
                     float v = 0.0f;
                     if (k < 3) v = k == 0 ? px : (k == 1 ? py : pz);
-                    else if (d.c_img && k < a.p_in) v = d.c_img[(size_t)g * (a.p_in - 3) + (k - 3)];
+                    else if (a.p_in > 3 && k < a.p_in) v = wide_cimg(d, g, k - 3, a.p_in - 3);
                     const _Float16 hv = (_Float16)v;
                     *reinterpret_cast<_Float16 *>(ah + pt * pa + k * 2) = hv;
                     *reinterpret_cast<_Float16 *>(al + pt * pa + k * 2) = (_Float16)(v - (float)hv);
@@ -685,9 +695,11 @@ int vt_decoder_pack_wide(const vt_decoder_params *p, float *blob, size_t blob_by
 static int wide_fwd_impl(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
                          int lattice_nx, float lattice_box, int64_t lattice_first,
                          const float *c_img, const float *blob, int hidden, int n_blocks, int flags, double padding,
-                         float *out, float *out2, float *save, void *stream) {
+                         float *out, float *out2, float *save, void *stream,
+                         const unsigned char *finger_ids = nullptr, const float *finger_feats = nullptr) {
     if (!grid_cl || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide: null argument");
-    const int p_in = c_img ? 3 + C : 3;
+    if (c_img && finger_ids) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide: give c_img or finger ids, not both");
+    const int p_in = (c_img || finger_ids) ? 3 + C : 3;
     if (!wide_shape_ok(hidden, C, n_blocks, p_in))
         return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd_wide: hidden and c_dim must be multiples of 32 up to 256");
     if (B <= 0 || R < 2 || N <= 0) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide: bad size");
@@ -698,6 +710,7 @@ static int wide_fwd_impl(const float *grid_cl, int B, int R, int C, const float 
     }
     WideArgs a{};
     a.d.grid = grid_cl; a.d.pts = pts; a.d.c_img = c_img; a.d.out = out; a.d.out2 = out2;
+    a.d.cimg_ids = finger_ids; a.d.cimg_table = finger_ids ? finger_feats : nullptr;
     a.d.N = (uint32_t)N; a.d.total = (uint32_t)((uint64_t)B * (uint64_t)N); a.d.lattice_first = (uint32_t)lattice_first;
     a.d.R = R; a.d.nx = lattice_nx; a.d.box = lattice_box; a.d.divisor = (float)(1.0 + padding + 10e-4);
     a.blob = blob; a.H = hidden; a.C = C; a.nb = n_blocks; a.p_in = p_in; a.Kp = (p_in + 7) / 8 * 8; a.leaky = (flags & VT_WIDE_LEAKY) ? 1 : 0; a.nearest = (flags & VT_WIDE_NEAREST) ? 1 : 0;
@@ -705,10 +718,10 @@ static int wide_fwd_impl(const float *grid_cl, int B, int R, int C, const float 
     const int rowsA = hidden > a.Kp ? hidden : a.Kp;
     const int waves = hidden <= 128 ? 4 : 8;
     const size_t lds = ((size_t)(C + rowsA + hidden) * WIDE_PITCH + (size_t)waves * 2 * 2 * 32) * sizeof(float);
-    static bool attr = false;
+    bool attr = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_wide_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_wide_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_wide_kernel<4>), 160 * 1024);
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_wide_kernel<8>), 160 * 1024);
         if (e != hipSuccess) return vt_check(e, "vt_decode_fwd_wide: hipFuncSetAttribute");
         attr = true;
     }
@@ -728,6 +741,18 @@ int vt_decode_fwd_wide(const float *grid_cl, int B, int R, int C, const float *p
                        float *out, float *out2, void *stream) {
     return wide_fwd_impl(grid_cl, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img, blob, hidden, n_blocks, flags, padding,
                          out, out2, nullptr, stream);
+}
+
+// the same forward with the tactile feature by finger id (generation.py:159-255 builds the dense [1, nx^3, C] tensor on the host:
+// 8.6 GB at 256^3 / c_dim 128; here one byte per point and the [F][C] table)
+int vt_decode_fwd_wide_ids(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                           int lattice_nx, float lattice_box, int64_t lattice_first,
+                           const unsigned char *finger_ids, const float *finger_feats, int n_fingers,
+                           const float *blob, int hidden, int n_blocks, int flags, double padding,
+                           float *out, float *out2, void *stream) {
+    if (!finger_ids || !finger_feats || n_fingers <= 0 || n_fingers > 255) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_ids: bad finger table");
+    return wide_fwd_impl(grid_cl, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, blob, hidden, n_blocks, flags, padding,
+                         out, out2, nullptr, stream, finger_ids, finger_feats);
 }
 
 // ---- split-f16 form of the same forward (inference) ----
@@ -775,12 +800,14 @@ int vt_decoder_pack_wide_f16x3(const vt_decoder_params *p, float *blob, size_t b
     return vt_check(hipGetLastError(), "vt_decoder_pack_wide_f16x3");
 }
 
-int vt_decode_fwd_wide_f16x3(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
-                             int lattice_nx, float lattice_box, int64_t lattice_first,
-                             const float *c_img, const float *blob, int hidden, int n_blocks, int flags, double padding,
-                             float *out, float *out2, void *stream) {
+static int wideh_fwd_impl(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                          int lattice_nx, float lattice_box, int64_t lattice_first,
+                          const float *c_img, const unsigned char *finger_ids, const float *finger_feats,
+                          const float *blob, int hidden, int n_blocks, int flags, double padding,
+                          float *out, float *out2, void *stream) {
     if (!grid_cl || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3: null argument");
-    const int p_in = c_img ? 3 + C : 3;
+    if (c_img && finger_ids) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3: give c_img or finger ids, not both");
+    const int p_in = (c_img || finger_ids) ? 3 + C : 3;
     if (!wide_shape_ok(hidden, C, n_blocks, p_in))
         return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd_wide_f16x3: hidden and c_dim must be multiples of 32 up to 256");
     if (B <= 0 || R < 2 || N <= 0) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3: bad size");
@@ -789,6 +816,7 @@ int vt_decode_fwd_wide_f16x3(const float *grid_cl, int B, int R, int C, const fl
         return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3: lattice range outside nx^3");
     WideHArgs a{};
     a.d.grid = grid_cl; a.d.pts = pts; a.d.c_img = c_img; a.d.out = out; a.d.out2 = out2;
+    a.d.cimg_ids = finger_ids; a.d.cimg_table = finger_ids ? finger_feats : nullptr;
     a.d.N = (uint32_t)N; a.d.total = (uint32_t)((uint64_t)B * (uint64_t)N); a.d.lattice_first = (uint32_t)lattice_first;
     a.d.R = R; a.d.nx = lattice_nx; a.d.box = lattice_box; a.d.divisor = (float)(1.0 + padding + 10e-4);
     a.blob = blob; a.H = hidden; a.C = C; a.nb = n_blocks; a.p_in = p_in; a.Kp = (p_in + 15) / 16 * 16;
@@ -797,10 +825,10 @@ int vt_decode_fwd_wide_f16x3(const float *grid_cl, int B, int R, int C, const fl
     const int waves = hidden <= 128 ? 4 : 8;
     const int wid = hidden > a.Kp ? hidden : a.Kp;
     const size_t lds = (size_t)2 * WH_PTS * wideh_pitch(C) + (size_t)2 * WH_PTS * wideh_pitch(wid) + (size_t)waves * 2 * 2 * WH_PTS * sizeof(float);
-    static bool attr = false;
+    bool attr = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_wide_h_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_wide_h_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_wide_h_kernel<4>), 160 * 1024);
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_wide_h_kernel<8>), 160 * 1024);
         if (e != hipSuccess) return vt_check(e, "vt_decode_fwd_wide_f16x3: hipFuncSetAttribute");
         attr = true;
     }
@@ -810,6 +838,24 @@ int vt_decode_fwd_wide_f16x3(const float *grid_cl, int B, int R, int C, const fl
     if (waves == 4) hipLaunchKernelGGL(decode_wide_h_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(decode_wide_h_kernel<8>, grid, dim3(512), lds, (hipStream_t)stream, a);
     return vt_check(hipGetLastError(), "vt_decode_fwd_wide_f16x3");
+}
+
+int vt_decode_fwd_wide_f16x3(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                             int lattice_nx, float lattice_box, int64_t lattice_first,
+                             const float *c_img, const float *blob, int hidden, int n_blocks, int flags, double padding,
+                             float *out, float *out2, void *stream) {
+    return wideh_fwd_impl(grid_cl, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img, nullptr, nullptr, blob, hidden, n_blocks,
+                          flags, padding, out, out2, stream);
+}
+
+int vt_decode_fwd_wide_f16x3_ids(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                                 int lattice_nx, float lattice_box, int64_t lattice_first,
+                                 const unsigned char *finger_ids, const float *finger_feats, int n_fingers,
+                                 const float *blob, int hidden, int n_blocks, int flags, double padding,
+                                 float *out, float *out2, void *stream) {
+    if (!finger_ids || !finger_feats || n_fingers <= 0 || n_fingers > 255) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3_ids: bad finger table");
+    return wideh_fwd_impl(grid_cl, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, finger_ids, finger_feats, blob, hidden,
+                          n_blocks, flags, padding, out, out2, stream);
 }
 
 // ---- training (decoder.py:24-51, 135-161 under autograd: training.py:476-489, 879) ----
@@ -883,10 +929,10 @@ int vt_decode_bwd_wide(int B, int R, int C, const float *pts, int64_t N, const f
     const int widest = hidden > C ? hidden : C;
     const int waves = widest <= 128 ? 4 : 8;
     const size_t lds = (size_t)(2 * hidden + C) * WIDE_PITCH * sizeof(float);
-    static bool attr = false;
+    bool attr = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_wide_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_wide_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_wide_bwd_kernel<4>), 160 * 1024);
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_wide_bwd_kernel<8>), 160 * 1024);
         if (e != hipSuccess) return vt_check(e, "vt_decode_bwd_wide: hipFuncSetAttribute");
         attr = true;
     }

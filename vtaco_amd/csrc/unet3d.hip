@@ -2277,10 +2277,9 @@ static int conv_h_wgs_per_scene(int B, int D, int H, int W, int Cout, int tz) {
 
 template <int NCO, int WAVES>
 static int conv_launch(const ConvArgs &a, dim3 grid, size_t lds, hipStream_t st) {
-    static bool attr_set = false;
+    bool attr_set = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_kernel<NCO, WAVES>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_kernel<NCO, WAVES>), 160 * 1024);
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr: hipFuncSetAttribute");
         attr_set = true;
     }
@@ -2375,10 +2374,10 @@ int vt_conv3d_gcr(const float *skip, int C1, const float *low, int C2, int B, in
         size_t lds = one * kw;
         if (lds < (size_t)(kw - 1) * 16 * 64 * sizeof(float)) lds = (size_t)(kw - 1) * 16 * 64 * sizeof(float);
         const dim3 grid((unsigned)((size_t)nsp1 * B), (unsigned)nco);
-        static bool ks_attr = false;
+        bool ks_attr = false;        // (vt_max_dyn_lds keeps the per-device record)
         if (!ks_attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_ksplit_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_ksplit_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_ksplit_kernel<4>), 160 * 1024);
+            if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_ksplit_kernel<2>), 160 * 1024);
             if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr: hipFuncSetAttribute");
             ks_attr = true;
         }
@@ -2438,14 +2437,14 @@ static int conv_s_launch(const float *skip, int C1, const float *low, int C2, in
     a.TX = a.TY = 8; a.TZ = tz;
     a.tiles_x = W / 8; a.tiles_y = H / 8; a.tiles_z = D / tz;
     const dim3 grid((unsigned)((size_t)a.tiles_x * a.tiles_y * a.tiles_z * B), (unsigned)(Cout / 32));
-    static bool attr = false;
+    bool attr = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4_LDS);
+        hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<8>), 160 * 1024);
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<2>), 160 * 1024);
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<8, false, true>), 160 * 1024);
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<2, false, true>), 160 * 1024);
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_s4_kernel<false>), (int)S4_LDS);
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_s4_kernel<true>), (int)S4_LDS);
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_bf16x3: hipFuncSetAttribute");
         attr = true;
     }
@@ -2499,12 +2498,12 @@ static int conv_sk_launch(const float *skip, int C1, const float *low, int C2, i
     a.TX = a.TY = 8; a.TZ = tz;
     a.tiles_x = W / 8; a.tiles_y = H / 8; a.tiles_z = D / tz;
     const dim3 grid((unsigned)((size_t)a.tiles_x * a.tiles_y * a.tiles_z * B), (unsigned)(Cout / 32), (unsigned)ks);
-    static bool attr = false;
+    bool attr = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<8, true>), 160 * 1024);
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<2, true>), 160 * 1024);
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<8, true, true>), 160 * 1024);
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_s_kernel<2, true, true>), 160 * 1024);
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_bf16x3_ksplit: hipFuncSetAttribute");
         attr = true;
     }
@@ -2669,22 +2668,22 @@ static int conv_h_launch(const float *skip, int C1, const float *low, int C2, in
         (a.tiles_x * a.tiles_y * a.tiles_z + ha.wgs_per_scene - 1) / ha.wgs_per_scene <= HB_SKIP_LIST)
         ha.tile_skip = tile_skip;
     const dim3 grid((unsigned)(ha.wgs_per_scene * B), (unsigned)(Cout / 32));
-    static bool attr = false;
+    bool attr = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_h_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(8));
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_h_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(4));
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_h_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(2));
+        hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_h_kernel<8>), (int)hb_lds(8));
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_h_kernel<4>), (int)hb_lds(4));
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_h_kernel<2>), (int)hb_lds(2));
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3: hipFuncSetAttribute");
         attr = true;
     }
     if (fin_w && !conv_h_specialised(tz)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr_f16x3_final: shape not on the specialised-wave kernel");
     if (conv_h_specialised(tz) && conv_h_inline()) {               // the support work in the tap waves' MFMA gaps (VTACO_CONV_SPEC=2)
-        static bool attr_x = false;
+        bool attr_x = false;        // (vt_max_dyn_lds keeps the per-device record)
         if (!attr_x) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hx_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(8));
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hx_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(4));
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hx_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(8));
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hx_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(4));
+            hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_hx_kernel<8>), (int)hb_lds(8));
+            if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_hx_kernel<4>), (int)hb_lds(4));
+            if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_hx_kernel<8, true>), (int)hb_lds(8));
+            if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_hx_kernel<4, true>), (int)hb_lds(4));
             if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3: hipFuncSetAttribute");
             attr_x = true;
         }
@@ -2698,18 +2697,18 @@ static int conv_h_launch(const float *skip, int C1, const float *low, int C2, in
         return vt_check(hipGetLastError(), "vt_conv3d_gcr_f16x3");
     }
     if (conv_h_specialised(tz)) {                                  // specialised tap / loader waves (VTACO_CONV_SPEC=0: the uniform-wave kernel)
-        static bool attr_w = false;
+        bool attr_w = false;        // (vt_max_dyn_lds keeps the per-device record)
         if (!attr_w) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds_sparse(8));
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds_sparse(4));
+            hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<8>), (int)hb_lds_sparse(8));
+            if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<4>), (int)hb_lds_sparse(4));
             if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3: hipFuncSetAttribute");
             attr_w = true;
         }
         if (fin_w) {
-            static bool attr_f = false;
+            bool attr_f = false;        // (vt_max_dyn_lds keeps the per-device record)
             if (!attr_f) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(8));
-                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hb_lds(4));
+                hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<8, true>), (int)hb_lds(8));
+                if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<4, true>), (int)hb_lds(4));
                 if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3_final: hipFuncSetAttribute");
                 attr_f = true;
             }
@@ -2753,14 +2752,10 @@ static int conv_up_launch(const float *skip, int C1, const float *low, int C2, i
     a.tiles_x = W / 8; a.tiles_y = H / 8; a.tiles_z = D / tz;
     ha.wgs_per_scene = conv_h_wgs_per_scene(B, D, H, W, Cout, tz);
     const dim3 grid((unsigned)(ha.wgs_per_scene * B), (unsigned)(Cout / 32));
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    static bool attr[64] = {};                                      // (the attribute is per device)
-    if (!attr[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_up_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)up_lds(8));
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_gcr_up_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)up_lds(4));
+    {
+        hipError_t e = tz == 8 ? vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_up_kernel<8>), (int)up_lds(8))
+                               : vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_up_kernel<4>), (int)up_lds(4));
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3_up: hipFuncSetAttribute");
-        attr[dev] = true;
     }
     if (tz == 8) hipLaunchKernelGGL(conv3d_gcr_up_kernel<8>, grid, dim3(hb_threads(8)), up_lds(8), (hipStream_t)stream, ha);
     else hipLaunchKernelGGL(conv3d_gcr_up_kernel<4>, grid, dim3(hb_threads(4)), up_lds(4), (hipStream_t)stream, ha);
@@ -3818,9 +3813,9 @@ int vt_conv3d_wgrad(const float *skip, int C1, const float *low, int C2, int B, 
     a.ntiles = B * a.c.tiles_x * a.c.tiles_y * a.c.tiles_z;
     const int pairs = (Cin / 32) * (Cout / 32), chunks = wgrad_chunks(B, D, H, W, pairs);
     const size_t lds = (size_t)(WG_HALO + WG_VOX) * CPAD * sizeof(float);
-    static bool attr = false;
+    bool attr = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_wgrad_kernel), 160 * 1024);
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_wgrad: hipFuncSetAttribute");
         attr = true;
     }
@@ -3865,9 +3860,9 @@ int vt_conv3d_wgrad_f16x3(const float *skip, int C1, const float *low, int C2, i
     a.ntiles = B * a.c.tiles_x * a.c.tiles_y * a.c.tiles_z;
     ha.g_absmax = g_absmax;
     const int pairs = (Cin / 32) * (Cout / 32), chunks = wgrad_h_chunks(B, D, H, W, pairs);
-    static bool attr = false;
+    bool attr = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WH_LDS);
+        const hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_wgrad_h_kernel), (int)WH_LDS);
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_wgrad_f16x3: hipFuncSetAttribute");
         attr = true;
     }

@@ -520,10 +520,9 @@ int build_launch(const char *who, const float *pts, int B, int T, int R, float d
         if (tile_flags) hipLaunchKernelGGL(tile_flags_kernel, dim3((unsigned)B), dim3(256), 0, s, idx, T, R, tile_flags);
         return vt_check(hipGetLastError(), who);
     }
-    static bool attr_set = false;
+    bool attr_set = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_build_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT_LDS);
+        hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&voxel_build_kernel), (int)SORT_LDS);
         if (e != hipSuccess) return vt_check(e, "vt_voxel_build: hipFuncSetAttribute");
         attr_set = true;
     }

@@ -2,6 +2,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdint.h>
+#include <mutex>
+#include <set>
+#include <utility>
 
 #include "vt_common.h"
 
@@ -27,6 +30,19 @@ int vt_num_cus() {
         if (cus <= 0) cus = 256;
     }
     return cus;
+}
+
+hipError_t vt_max_dyn_lds(const void *fn, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, fn})) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({dev, fn});
+    return e;
 }
 
 __global__ void __launch_bounds__(256) vt_fill32_kernel(unsigned *dst, unsigned pattern, size_t n) {

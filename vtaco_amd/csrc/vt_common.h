@@ -35,6 +35,10 @@ static_assert((VT_OFF_WPI) * 4 <= 65536, "visual-only fragments must sit below t
 int vt_fail(int code, const char *msg);
 int vt_check(hipError_t e, const char *where);
 int vt_num_cus();
+// hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), once per (device, kernel): the attribute belongs to
+// the device the call is made on, so a process that drives several GPUs must set it on each (a process-wide `static bool` would
+// leave the second device's > 64 KiB launches failing)
+hipError_t vt_max_dyn_lds(const void *fn, int bytes);
 // the device word of the half-precision decodes' range guard (decode_common.h; read by vt_decode_range_status), allocated at first use
 // (one block per device: bytes 0..3 the VT_RANGE_* bits, bytes 8..23 the last lattice kernel's clock stamps)
 unsigned *vt_decode_status_dev();

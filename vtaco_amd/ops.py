@@ -229,7 +229,7 @@ def _cl_storage(grid):
 
 
 def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want_contact=False, out=None, save=None,
-               precision="f32", wide=None):
+               precision="f32", wide=None, finger_ids=None, finger_feats=None):
     """Fused trilinear gather + conditioned MLP (vt_decode_fwd; ``precision="bf16x3"`` / ``"f16x3"``:
     vt_decode_fwd_bf16x3 / vt_decode_fwd_f16x3 with a blob packed for it; ``precision="wide"`` /
     ``"wide_f16x3"`` with ``wide=(hidden_size, n_blocks, leaky[, nearest])``: vt_decode_fwd_wide[_f16x3], the exact-f32 / split-f16
@@ -272,6 +272,17 @@ def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want
         hidden, nb, leaky = wide[:3]
         flags = (1 if leaky else 0) | (2 if len(wide) > 3 and wide[3] else 0)          # VT_WIDE_LEAKY | VT_WIDE_NEAREST
         name = "vt_decode_fwd_wide" if precision == "wide" else "vt_decode_fwd_wide_f16x3"
+        if finger_ids is not None:
+            # the tactile feature by finger id (uint8 [B,N], 255 = none) and the [F,C] table: no dense [B,N,C] tensor
+            ids, feats = _c(finger_ids), _c(finger_feats.detach().float())
+            if c_img is not None or ids.dtype != torch.uint8 or ids.numel() != B * N or feats.dim() != 2 or feats.shape[1] != C:
+                raise VtError(f"decode_fwd: finger ids must be uint8 [B,N] with a [F,{C}] feature table (and no c_img)")
+            keep_for_graph(ids, feats)
+            check(getattr(lib, name + "_ids")(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first, dev_ptr(ids, "finger_ids", torch.uint8),
+                                              dev_ptr(feats, "finger_feats"), int(feats.shape[0]), dev_ptr(blob, "blob"), int(hidden),
+                                              int(nb), flags, float(padding), dev_ptr(out, "out"), dev_ptr(out2, "out2"), stream_ptr()),
+                  name + "_ids")
+            return (out, out2) if want_contact else out
         check(getattr(lib, name)(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first, dev_ptr(c_img, "c_img"),
                                  dev_ptr(blob, "blob"), int(hidden), int(nb), flags, float(padding),
                                  dev_ptr(out, "out"), dev_ptr(out2, "out2"), stream_ptr()), name)
@@ -770,11 +781,16 @@ def decode_bwd(grid_shape, blob_t, grad_out, save, pts=None, lattice=None, with_
     else:
         nx, box, first, N = lattice
     total = B * N
-    gws = torch.empty(lib.vt_decode_gws_bytes(total) // 4, dtype=torch.float32, device=dev)
     ggrid = torch.zeros((B, R, R, R, C), dtype=torch.float32, device=dev) if want_grid_grad else None
     gimg = torch.empty((B, N, C), dtype=torch.float32, device=dev) if with_c_img else None
-    st = stream_ptr()
     g2 = _c(grad_out2.float()) if grad_out2 is not None else None
+    if total == 0:                                                  # an empty query set: every gradient is zero, no launch
+        p_in = 3 + C if with_c_img else 3
+        nflat = lib.vt_decode_wgrad_floats_contact(p_in) if g2 is not None else lib.vt_decode_wgrad_floats(p_in)
+        return ((ggrid.permute(0, 4, 1, 2, 3) if ggrid is not None else None), gimg,
+                torch.zeros(nflat, dtype=torch.float32, device=dev))
+    gws = torch.empty(lib.vt_decode_gws_bytes(total) // 4, dtype=torch.float32, device=dev)
+    st = stream_ptr()
     if ggrid is not None and pts is not None and GRID_SCATTER_SORTED and R >= 3:
         # grid gradient by cell (vt_sample_grid_bwd_sorted): the data pass leaves d c, the points are binned by trilinear cell
         # (vt_voxel_build at R - 1) and every cell scatters once -- training points cluster (contact clouds), and per-point f32
@@ -842,9 +858,10 @@ def decode_fwd_wide_train(grid, blob, pts, c_img, hidden, nb, leaky, nearest, pa
     dev = grid.device
     out = torch.empty((B, N), dtype=torch.float32, device=dev)
     out2 = torch.empty((B, N), dtype=torch.float32, device=dev) if want_contact else None
-    nsave = lib.vt_decode_wide_save_floats(B * N, int(hidden), C, int(nb))
-    if nsave == 0:
+    # (an empty query set is not 'shape not built': the shape is judged on one point, the save of no points is empty)
+    if lib.vt_decode_wide_save_floats(1, int(hidden), C, int(nb)) == 0:
         raise VtError(f"decoder shape hidden={hidden}, c_dim={C}, n_blocks={nb} is not built (multiples of 32 up to 256)")
+    nsave = lib.vt_decode_wide_save_floats(B * N, int(hidden), C, int(nb)) if B * N else 0
     save = torch.empty(nsave, dtype=torch.float32, device=dev)
     if N:
         check(lib.vt_decode_fwd_wide_train(gptr, B, D, C, dev_ptr(pts, "pts"), N, dev_ptr(ci, "c_img"), dev_ptr(blob, "blob"),
@@ -897,9 +914,19 @@ def decode_bwd_wide(grid_shape, blob_t, grad_out, save, pts, hidden, nb, leaky, 
     N = pts.shape[1]
     P = B * N
     g2 = _c(grad_out2.float()) if grad_out2 is not None else None
-    gws = torch.empty(lib.vt_decode_wide_gws_floats(P, H, C, int(nb)), dtype=torch.float32, device=dev)
     ggrid = torch.zeros((B, R, R, R, C), dtype=torch.float32, device=dev) if want_grid_grad else None
     gimg = torch.empty((B, N, C), dtype=torch.float32, device=dev) if c_img is not None else None
+    if P == 0:                                                      # an empty query set: every gradient is zero, no launch
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        p_in = 3 + C if c_img is not None else 3
+        g = {"fc_p.weight": z(H, p_in), "fc_p.bias": z(H), "fc_c.weight": [z(H, C) for _ in range(nb)], "fc_c.bias": [z(H) for _ in range(nb)],
+             "fc_0.weight": [z(H, H) for _ in range(nb)], "fc_0.bias": [z(H) for _ in range(nb)],
+             "fc_1.weight": [z(H, H) for _ in range(nb)], "fc_1.bias": [z(H) for _ in range(nb)],
+             "fc_out.weight": z(1, H), "fc_out.bias": z(1)}
+        if g2 is not None:
+            g["fc_out_contact.weight"], g["fc_out_contact.bias"] = z(1, H), z(1)
+        return (ggrid.permute(0, 4, 1, 2, 3) if ggrid is not None else None), gimg, g
+    gws = torch.empty(lib.vt_decode_wide_gws_floats(P, H, C, int(nb)), dtype=torch.float32, device=dev)
     check(lib.vt_decode_bwd_wide(B, R, C, dev_ptr(pts, "pts"), N, dev_ptr(blob_t, "blob_t"), H, int(nb), _wide_flags(leaky, nearest),
                                  float(padding), dev_ptr(grad_out, "grad_out"), dev_ptr(g2, "grad_out2"), dev_ptr(save, "save"),
                                  dev_ptr(gws, "gws"), dev_ptr(ggrid, "grad_grid"), dev_ptr(gimg, "grad_c_img"), stream_ptr()),
@@ -955,6 +982,8 @@ def sample_grid_bwd_sorted_into(ggrid_cl, pts, grad_feat, padding=0.1):
     by trilinear cell (vt_voxel_build at resolution R - 1 + vt_sample_grid_bwd_sorted)."""
     B, R, C = ggrid_cl.shape[0], ggrid_cl.shape[1], ggrid_cl.shape[4]
     N = pts.shape[1]
+    if B * N == 0:                                                  # no points: the zeroed gradient is the answer
+        return
     vi = VoxelIndex(pts, R - 1, padding)
     check(_lib.load().vt_sample_grid_bwd_sorted(B, R, C, dev_ptr(pts, "pts"), N, float(padding), dev_ptr(grad_feat, "grad_feat"),
                                                 dev_ptr(vi.order, "order", I32), dev_ptr(vi.seg_lo, "seg_lo", I32),
