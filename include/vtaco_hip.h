@@ -333,6 +333,14 @@ typedef struct vt_fusion_params {
 size_t vt_fusion_workspace_bytes(int B, int N);
 int vt_fusion_fwd(const float *c_img, const float *c, int B, int N, const vt_fusion_params *params_host,
                   void *workspace, size_t workspace_bytes, float *out, void *stream);
+/* The same forward with the tactile features of the decoder's self-attention given per point as a finger id (255 = none: a zero  */
+/* row) and the [n_fingers][32] table -- what the reference gathers into c_img_all on the host (generation.py:159-255, consumed by */
+/* AttentionDecoder.forward_img, decoder.py:237-271).  finger_ids [rows][N]; batch element b reads row chunk_index[b] (device      */
+/* int32 [B]: the chunks a generator picked out of a lattice) or row b when chunk_index is NULL.  Equal to vt_fusion_fwd on the    */
+/* gathered tensor bit for bit.                                                                                                    */
+int vt_fusion_fwd_ids(const unsigned char *finger_ids, const float *finger_feats, int n_fingers, const int *chunk_index,
+                      const float *c, int B, int N, const vt_fusion_params *params_host,
+                      void *workspace, size_t workspace_bytes, float *out, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* TransformerFusion under autograd (training).                                  */

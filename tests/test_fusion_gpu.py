@@ -221,3 +221,36 @@ def test_fusion_train_mode_dropout_replayed_against_the_oracle():
         other = ops.fusion_fwd_train(c_img.to(DEV), c.to(DEV), fuser.decoder.layers[0].self_attn.unit_tensors(),
                                      fuser.decoder.layers[0].cross_attn.unit_tensors(), fuser.p_drop, 999)[0]
     assert torch.equal(again, out.detach()) and not torch.equal(other, out.detach())
+
+
+def test_fusion_by_finger_id_equals_the_gathered_tensor_bit_for_bit():
+    """vt_fusion_fwd_ids (the tactile rows of the decoder's self-attention by finger id + table, what generation.py:159-255 gathers on
+    the host) against vt_fusion_fwd on the gathered [B, N, C] tensor: identical bits -- whole chunks (fp8-corrected tiles, N >= 512), a
+    short ragged chunk (half-pair tiles), and chunks picked out of a larger id array through chunk_index."""
+    from vtaco_amd import ops
+    from vtaco_amd.transformer_fusion import TransformerFusion
+    torch.manual_seed(3)
+    fuser = TransformerFusion(use_xyz=True, input_size=2048, d_model=32, num_layers=1, key_feature_dim=64, with_pos_embed=False,
+                              encoder_pos_embed_input_dim=3, decoder_pos_embed_input_dim=3).to(DEV).eval()
+    g = torch.Generator().manual_seed(4)
+    feats = torch.randn(5, 32, generator=g).to(DEV)
+    table = torch.cat([feats, torch.zeros(1, 32, device=DEV)])
+    for rows, N in ((6, 1024), (1, 77)):
+        ids = torch.randint(0, 6, (rows, N), generator=g).to(torch.uint8)
+        ids[ids == 5] = 255
+        ids[0] = 255                                                   # a chunk no finger touches
+        c = torch.randn(rows, N, 32, generator=g).to(DEV)
+        idd = ids.to(DEV)
+        gathered = table[torch.where(idd == 255, torch.full_like(idd, 5), idd).long()]
+        with torch.no_grad():
+            ref = fuser(gathered, 1, c, 1)
+            got = fuser.forward_ids(idd, feats, c)
+            assert torch.equal(got, ref)
+            assert float(got[0].abs().max()) == 0.0                    # fuse(0, c) = 0 exactly (the generator's shortcut relies on it)
+            if rows > 2:
+                pick = torch.tensor([4, 1, 3], dtype=torch.int32, device=DEV)
+                got_p = fuser.forward_ids(idd, feats, c[pick.long()], chunk_index=pick)
+                assert torch.equal(got_p, ref[pick.long()])
+    fuser.train()
+    with pytest.raises(Exception, match="eval-mode"):
+        fuser.forward_ids(idd, feats, c)

@@ -92,6 +92,7 @@ SIGNATURES = {
 "vt_decode_mlp_fwd_f16x3": (_I, [_VP, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP]),
     "vt_fusion_workspace_bytes": (_SZ, [_I, _I]),
     "vt_fusion_fwd": (_I, [_VP, _VP, _I, _I, ctypes.POINTER(FusionParams), _VP, _SZ, _VP, _VP]),
+    "vt_fusion_fwd_ids": (_I, [_VP, _VP, _I, _VP, _VP, _I, _I, ctypes.POINTER(FusionParams), _VP, _SZ, _VP, _VP]),
     "vt_fusion_saved_bytes": (_SZ, [_I, _I]),
     "vt_fusion_bwd_workspace_bytes": (_SZ, [_I, _I]),
     "vt_fusion_fwd_train": (_I, [_VP, _VP, _I, _I, ctypes.POINTER(FusionParams), _F, ctypes.c_ulonglong, _VP, _SZ, _VP, _SZ, _VP, _VP]),

@@ -433,8 +433,7 @@ class Generator3D(object):
                 cache.pop(next(iter(cache)))
             cache[key] = ((1 + self.padding) * make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)).to(self.device)
         pts = cache[key][first:first + count]
-        table = torch.cat([finger_feats.float(), finger_feats.new_zeros(1, finger_feats.shape[1]).float()], dim=0)   # row F = no feature
-        row = torch.where(ids[0] == 255, torch.full_like(ids[0], finger_feats.shape[0]), ids[0]).long()
+        feats = finger_feats.float().contiguous()
         out = torch.empty(count, dtype=torch.float32, device=self.device)
         dec = self.model.decoder
         grid = dec._grid_of(c)
@@ -443,8 +442,10 @@ class Generator3D(object):
         # launches for a 128^3 lattice whose arithmetic takes 15
         full = count // chunk
         per_call = self._fused_chunks_per_call(chunk)
-        C = table.shape[1]
-        P3, R2, O2 = pts[:full * chunk].reshape(full, chunk, 3), row[:full * chunk].reshape(full, chunk), out[:full * chunk].view(full, chunk)
+        C = feats.shape[1]
+        # the finger ids of the whole chunks, [full, chunk] (a view): the fusion kernels read the tactile rows by id
+        # (vt_fusion_fwd_ids) -- no gathered [chunks, chunk, C] tensor, no framework indexing between vt_tactile_assign and the fuser
+        P3, I2, O2 = pts[:full * chunk].reshape(full, chunk, 3), ids.reshape(-1)[:full * chunk].view(full, chunk), out[:full * chunk].view(full, chunk)
 
         def fused_chunks(sel):
             """The attention decoder on the chunks ``sel`` (a slice of consecutive chunks, or an index tensor)."""
@@ -452,13 +453,16 @@ class Generator3D(object):
             nb = p.shape[0]
             if isinstance(sel, slice):                      # consecutive chunks: the lattice range itself (points generated in the kernel)
                 feat = ops.sample_grid(grid, None, dec.padding, lattice=(nx, 1 + self.padding, first + sel.start * chunk, nb * chunk))
-                feat = feat.reshape(nb, chunk, -1)
-            else:
+                fused = dec.fuser.forward_ids(I2[sel], feats, feat.reshape(nb, chunk, -1))
+            else:                                           # picked chunks: their id rows through the index list, in the kernel
                 feat = ops.sample_grid(grid, p.reshape(1, -1, 3), dec.padding).reshape(nb, chunk, -1)
-            fused = dec.fuser(table[R2[sel]], 1, feat, 1)
+                fused = dec.fuser.forward_ids(I2, feats, feat, chunk_index=sel.to(torch.int32))
             O2[sel] = dec._mlp_fwd(fused, p)
 
-        if full and self.skip_untouched_chunks:
+        # (the shortcut below holds in eval mode only: under model.train() the reference's dropout breaks the 'constant row ->
+        # InstanceNorm -> 0' argument; generation always runs in eval mode (_eval_mode), asserted here.  It costs one host read per
+        # lattice (torch.nonzero), so a lattice that takes it cannot be captured into a hipGraph.)
+        if full and self.skip_untouched_chunks and not dec.training:
             # A chunk NO point of which carries a tactile feature (the fingers touch a few per cent of a scene's chunks) needs no
             # attention at all: with c_img = 0 on the whole chunk the decoder's self-attention block returns the same vector for
             # every point, InstanceNorm over the chunk turns that into zeros, the cross-attention of an all-zero query block is
@@ -466,7 +470,7 @@ class Generator3D(object):
             # bit, in these kernels (constant rows leave the norm as exact zeros: fusion.hip, fusion_inorm_relu*; asserted in
             # tests/test_fusion_gpu.py; the reference's own f32 evaluation leaves rounding noise of ~1e-5 there, TransformerFusion.py
             # :144, 209-218).  Such chunks go through the conditioned MLP with zero features; the others through the whole fuser.
-            touched = (R2 != finger_feats.shape[0]).any(dim=1)
+            touched = (I2 != 255).any(dim=1)
             t_idx, u_idx = torch.nonzero(touched).flatten(), torch.nonzero(~touched).flatten()      # one host read per lattice
             for lo in range(0, u_idx.numel(), per_call):
                 sel = u_idx[lo:lo + per_call]
@@ -478,7 +482,9 @@ class Generator3D(object):
                 fused_chunks(slice(lo, min(lo + per_call, full)))
         if full * chunk < count:                          # the ragged last chunk
             sl = slice(full * chunk, count)
-            out[sl] = dec.forward_img(pts[sl].unsqueeze(0), c, table[row[sl]].unsqueeze(0))[0]
+            tail = ids.reshape(-1)[sl].view(1, -1)
+            feat = ops.sample_grid(grid, pts[sl].unsqueeze(0), dec.padding)
+            out[sl] = dec._mlp_fwd(dec.fuser.forward_ids(tail, feats, feat), pts[sl].unsqueeze(0))[0]
         return out
 
     # attention_local over a lattice: chunks without any tactile feature skip the fuser (see _eval_lattice_fused; VTACO_FUSION_SKIP_UNTOUCHED=0

@@ -123,7 +123,7 @@ __device__ __forceinline__ void fp8_saturating_mode() { __builtin_amdgcn_s_setre
 constexpr int PROJ_TILES = 8;
 template <bool DO_Q, bool DO_KV, bool F8>
 __global__ void __launch_bounds__(256)
-fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd, float *Kd, float *V, int total) {
+fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd, float *Kd, float *V, int total, XIds xi) {
     __shared__ __attribute__((aligned(16))) float wf[5][16][64];          // [group][k-step][lane] A fragments
     if constexpr (F8) fp8_saturating_mode();
     for (int e = threadIdx.x; e < 5 * 1024; e += 256) {
@@ -149,7 +149,7 @@ fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd,
     const int p = min(p0 + j, total - 1);
     const bool live = p0 + j < total;
     auto load_x = [&](const float *X, float (&x)[16]) {                       // x[s] = X[p][2s + h]
-        const f32x4 *r = reinterpret_cast<const f32x4 *>(X + (size_t)p * 32);
+        const f32x4 *r = reinterpret_cast<const f32x4 *>(X ? X + (size_t)p * 32 : xi.row((size_t)p));      // (null: the rows by finger id)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const f32x4 t = r[i];
@@ -449,7 +449,7 @@ constexpr int VROW = 36;                                    // V' tile row: 128 
 template <bool TRAIN, bool FULL, bool F8>
 __global__ void __launch_bounds__(FT)
 fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const float *linv, const float *Xq,
-                     const float *blob, float *Z, int N, int ntile_, float *Osave, DropCfg dc, int nrb, int B) {
+                     const float *blob, float *Z, int N, int ntile_, float *Osave, DropCfg dc, int nrb, int B, XIds xi) {
     static_assert(!(F8 && (TRAIN || FULL)), "the fp8-corrected tiles are the inference form");
     __shared__ __attribute__((aligned(16))) float lds[FU_BLOB];
     __shared__ __attribute__((aligned(16))) float tiles[2][F8 ? STILE8 : STILE];
@@ -545,7 +545,7 @@ fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const fl
 #pragma unroll
     for (int s = 0; s < 16; ++s) o[s] *= li;
     // lane (q,h) reg r = channel chan_of(r,h) of the attention output: the accumulator layout
-    const float *xrow = Xq + ((size_t)b * N + q) * 32;
+    const float *xrow = Xq ? Xq + ((size_t)b * N + q) * 32 : xi.row((size_t)b * N + q);
     const f32x16 x = load_acc16(xrow, h);
     const uint32_t pt = (uint32_t)((size_t)b * N + q);
     if (TRAIN && q0 + j < N) store_acc16(Osave + (size_t)pt * 32, o, h);
@@ -700,7 +700,7 @@ size_t fusion_layout(int B, int N, FusionWs *ws, char *base) {
 // one attention unit: Xq against Xk -> out = relu(IN(Xq + MHA(Xq, Xk, Xk))).  ``Osave`` != null: training forward (w.l / w.s /
 // w.V / w.Z then point into the caller's saved state instead of the scratch workspace, and the dropouts of ``dc`` are applied)
 void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const float *blob, const FusionWs &w,
-              float *out, int B, int N, hipStream_t s, float *Osave = nullptr, DropCfg dc = DropCfg{0, 0, 1.0f, 0}) {
+              float *out, int B, int N, hipStream_t s, float *Osave = nullptr, DropCfg dc = DropCfg{0, 0, 1.0f, 0}, XIds xi = XIds{}) {
     const int P = B * N, Npad = (N + 31) / 32 * 32;
     const int ntile = (N + 31) / 32;
     const int nrb = (N + FROWS - 1) / FROWS;
@@ -714,14 +714,14 @@ void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const fl
     // 8e-5 on the fused features at N = 33 against 4e-5, 1.4e-5 against 1.7e-5 at N = 2048; tools/probe/fusion_ragged_err.py)
     const bool f8 = !full && N >= 512 && !(env_terms && env_terms[0] == '2');
     if (Xq == Xk) {
-        if (f8) hipLaunchKernelGGL((fusion_proj_kernel<true, true, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
-        else hipLaunchKernelGGL((fusion_proj_kernel<true, true, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
+        if (f8) hipLaunchKernelGGL((fusion_proj_kernel<true, true, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi);
+        else hipLaunchKernelGGL((fusion_proj_kernel<true, true, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi);
     } else if (f8) {
-        hipLaunchKernelGGL((fusion_proj_kernel<true, false, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
-        hipLaunchKernelGGL((fusion_proj_kernel<false, true, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
+        hipLaunchKernelGGL((fusion_proj_kernel<true, false, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi);
+        hipLaunchKernelGGL((fusion_proj_kernel<false, true, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi);
     } else {
-        hipLaunchKernelGGL((fusion_proj_kernel<true, false, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
-        hipLaunchKernelGGL((fusion_proj_kernel<false, true, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P);
+        hipLaunchKernelGGL((fusion_proj_kernel<true, false, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi);
+        hipLaunchKernelGGL((fusion_proj_kernel<false, true, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi);
     }
     if (f8) {
         hipLaunchKernelGGL(fusion_expsum8_kernel<false>, tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1, nrb, B);                // 1/l_q
@@ -745,13 +745,13 @@ void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const fl
         hipLaunchKernelGGL(fusion_scalev_kernel, dim3((unsigned)g), dim3(256), 0, s, w.V, w.s, w.VT, N, ntile, tot);
     }
     if (Osave)
-        hipLaunchKernelGGL((fusion_attend_kernel<true, true, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc, nrb, B);
+        hipLaunchKernelGGL((fusion_attend_kernel<true, true, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc, nrb, B, xi);
     else if (full)
-        hipLaunchKernelGGL((fusion_attend_kernel<false, true, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc, nrb, B);
+        hipLaunchKernelGGL((fusion_attend_kernel<false, true, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc, nrb, B, xi);
     else if (f8)
-        hipLaunchKernelGGL((fusion_attend_kernel<false, false, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc, nrb, B);
+        hipLaunchKernelGGL((fusion_attend_kernel<false, false, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc, nrb, B, xi);
     else
-        hipLaunchKernelGGL((fusion_attend_kernel<false, false, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc, nrb, B);
+        hipLaunchKernelGGL((fusion_attend_kernel<false, false, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, blob, w.Z, N, ntile, Osave, dc, nrb, B, xi);
     if (N <= 128 * IN_ROWS) hipLaunchKernelGGL(fusion_inorm_relu_cached_kernel, dim3(B), dim3(1024), 0, s, w.Z, out, N);
     else hipLaunchKernelGGL(fusion_inorm_relu_kernel, dim3(B), dim3(1024), 0, s, w.Z, out, N);
 }
@@ -780,6 +780,28 @@ int vt_fusion_fwd(const float *c_img, const float *c, int B, int N, const vt_fus
     run_unit(c_img, c_img, us, w.blob_s, w, w.T, B, N, s);         // decoder self-attention (SAME weights)
     run_unit(w.T, w.M, ux, w.blob_x, w, out, B, N, s);             // decoder cross-attention
     return vt_check(hipGetLastError(), "vt_fusion_fwd");
+}
+
+// vt_fusion_fwd with the tactile rows by finger id: finger_ids [rows][N] (255 = no feature), finger_feats [n_fingers][32]; batch
+// element b reads ids row chunk_index[b] (device ints; NULL: row b)
+int vt_fusion_fwd_ids(const unsigned char *finger_ids, const float *finger_feats, int n_fingers, const int *chunk_index,
+                      const float *c, int B, int N, const vt_fusion_params *p,
+                      void *workspace, size_t workspace_bytes, float *out, void *stream) {
+    if (!finger_ids || !finger_feats || !c || !p || !workspace || !out) return vt_fail(VT_ERR_INVALID, "vt_fusion_fwd_ids: null argument");
+    if (B <= 0 || N <= 0 || n_fingers <= 0 || n_fingers > 255) return vt_fail(VT_ERR_INVALID, "vt_fusion_fwd_ids: bad size");
+    if (p->d_model != 32 || p->key_dim != 64) return vt_fail(VT_ERR_UNSUPPORTED, "vt_fusion_fwd_ids: d_model=32, key_feature_dim=64 only");
+    FusionWs w;
+    if (workspace_bytes < fusion_layout(B, N, &w, (char *)workspace)) return vt_fail(VT_ERR_WORKSPACE, "vt_fusion_fwd_ids: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const FusionUnitDev us = unit_of(p->self_attn), ux = unit_of(p->cross_attn);
+    hipLaunchKernelGGL(fusion_pack_kernel, dim3(6), dim3(1024), 0, s, us, w.blob_s);
+    hipLaunchKernelGGL(fusion_pack_kernel, dim3(6), dim3(1024), 0, s, ux, w.blob_x);
+    XIds xi;
+    xi.ids = finger_ids; xi.table = finger_feats; xi.chunk = chunk_index; xi.N = N;
+    run_unit(c, c, us, w.blob_s, w, w.M, B, N, s);                 // encoder: memory from the grid features
+    run_unit(nullptr, nullptr, us, w.blob_s, w, w.T, B, N, s, nullptr, DropCfg{0, 0, 1.0f, 0}, xi);   // decoder self-attention on the rows by id
+    run_unit(w.T, w.M, ux, w.blob_x, w, out, B, N, s);             // decoder cross-attention
+    return vt_check(hipGetLastError(), "vt_fusion_fwd_ids");
 }
 
 size_t vt_fusion_saved_bytes(int B, int N) {

@@ -13,6 +13,23 @@ struct FusionUnitDev {
     const float *WK, *WQ, *WV, *Wt, *l1w, *l1b, *l2w, *l2b, *lnw, *lnb;
 };
 
+// The tactile rows of the decoder's self-attention unit given by finger id instead of a dense [B][N][32] tensor (vt_fusion_fwd_ids:
+// what the reference gathers on the host, generation.py:159-255): point n of batch element b reads table[ids[row(b)][n]], a zero
+// row where the id is 255; row(b) = chunk[b] (the chunks a generator picked out of a lattice) or b.
+__device__ const float vt_fusion_zero_row[32] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                                                 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+struct XIds {
+    const unsigned char *ids = nullptr;     // [rows][N]
+    const float *table = nullptr;           // [F][32]
+    const int *chunk = nullptr;
+    int N = 0;
+    __device__ __forceinline__ const float *row(size_t p) const {
+        const size_t b = p / (size_t)N, n = p - b * (size_t)N;
+        const unsigned id = ids[(chunk ? (size_t)chunk[b] : b) * (size_t)N + n];
+        return id == 255u ? vt_fusion_zero_row : table + (size_t)id * 32;
+    }
+};
+
 // epilogue weights -> accumulator-fed fragment order (k = chan_of(s, h))
 __global__ void fusion_pack_kernel(FusionUnitDev u, float *blob) {
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < FU_BLOB; e += gridDim.x * blockDim.x) {

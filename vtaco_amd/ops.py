@@ -1092,6 +1092,32 @@ def fusion_fwd(c_img, c, self_attn, cross_attn):
     return out
 
 
+def fusion_fwd_ids(finger_ids, finger_feats, c, self_attn, cross_attn, chunk_index=None):
+    """TransformerFusion forward, eval mode, with the tactile rows by finger id (vt_fusion_fwd_ids): ``finger_ids`` uint8 [rows, N]
+    (255 = none), ``finger_feats`` [F, C]; batch element b of ``c`` [B, N, C] reads ids row ``chunk_index[b]`` (int32 [B] on the
+    device) or row b.  No [B, N, C] tensor of gathered features exists."""
+    lib = _lib.load()
+    c = _c(c.float())
+    B, N, C = c.shape
+    ids, feats = _c(finger_ids), _c(finger_feats.detach().float())
+    if ids.dtype != torch.uint8 or ids.dim() != 2 or ids.shape[1] != N or feats.dim() != 2 or feats.shape[1] != C:
+        raise VtError(f"fusion_fwd_ids: finger ids must be uint8 [rows,{N}] with a [F,{C}] table (got {tuple(ids.shape)}, {tuple(feats.shape)})")
+    if chunk_index is None and ids.shape[0] != B:
+        raise VtError(f"fusion_fwd_ids: {ids.shape[0]} id rows for {B} chunks and no chunk_index")
+    ci = _c(chunk_index) if chunk_index is not None else None
+    if ci is not None and (ci.dtype != torch.int32 or ci.numel() != B):
+        raise VtError("fusion_fwd_ids: chunk_index must be int32 [B]")
+    keep = []
+    prm = _fusion_params(self_attn, cross_attn, C, keep)
+    nbytes = lib.vt_fusion_workspace_bytes(B, N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=c.device)
+    out = torch.empty((B, N, C), dtype=torch.float32, device=c.device)
+    check(lib.vt_fusion_fwd_ids(dev_ptr(ids, "finger_ids", torch.uint8), dev_ptr(feats, "finger_feats"), int(feats.shape[0]),
+                                dev_ptr(ci, "chunk_index", torch.int32), dev_ptr(c, "c"), B, N, ctypes.byref(prm),
+                                ctypes.c_void_p(ws.data_ptr()), nbytes, dev_ptr(out, "out"), stream_ptr()), "vt_fusion_fwd_ids")
+    return out
+
+
 def fusion_fwd_train(c_img, c, self_attn, cross_attn, p_drop=0.0, seed=0):
     """TransformerFusion forward for training (vt_fusion_fwd_train): dropout with probability ``p_drop`` (masks a function
     of ``seed``) and the O(N) state the backward needs.  Returns (out [B,N,C], saved: opaque uint8 tensor)."""

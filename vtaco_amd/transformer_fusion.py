@@ -151,6 +151,15 @@ class TransformerFusion(nn.Module):
             return ops.fusion_fwd_train(search_feature, template_feature, sa, ca, self.p_drop, self._draw_seed())[0]
         return ops.fusion_fwd(search_feature, template_feature, sa, ca)
 
+    def forward_ids(self, finger_ids, finger_feats, template_feature, chunk_index=None):
+        """``forward`` in eval mode with the search features given by finger id (ops.fusion_fwd_ids): the generator's lattice
+        chunks, whose tactile rows the reference gathers on the host (generation.py:159-255)."""
+        layer = self.decoder.layers[0]
+        if self.training and self.p_drop > 0:
+            raise VtError("TransformerFusion.forward_ids is the eval-mode path (dropout would apply in train mode)")
+        return ops.fusion_fwd_ids(finger_ids, finger_feats, template_feature, layer.self_attn.unit_tensors(),
+                                  layer.cross_attn.unit_tensors(), chunk_index=chunk_index)
+
     @property
     def p_drop(self):
         return self.decoder.layers[0].self_attn.extra_nonlinear[0].p_drop
