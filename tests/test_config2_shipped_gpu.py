@@ -73,6 +73,16 @@ def test_config2_end_to_end_at_the_shipped_shape(shipped, enc_precision, dec_pre
     enc.unet3d.precision = enc_precision
     nx = 128
     with torch.no_grad():
+        # this test is what pins the encoder's work-skipping paths against the reference fixture, so make sure they are the ones
+        # that run: the first layer's empty blocks (flags non-zero on this scene) and, with half pairs, the per-parity decoder entries
+        from vtaco_amd import _lib, ops as _ops
+        assert enc.skip_empty and enc.unet3d.hip_supported()
+        flags = _ops.VoxelIndex(s["cloud"].to(DEV), enc.reso_grid, enc.padding, want_tile_flags=True).tile_flags
+        assert flags is not None and 0 < int(flags.sum()) < flags.numel(), "the scene must have empty AND occupied 8^3 blocks"
+        if enc_precision == "f16x3":
+            up = enc.unet3d.decoders[-1].basic_module.SingleConv1.conv
+            assert enc.unet3d._packed_up(up, up.out_channels) is not None
+            assert _lib.load().vt_conv3d_up_covers(up.out_channels, up.in_channels - up.out_channels, 1, 64, 64, 64, up.out_channels) == 1
         grid = enc(s["cloud"].to(DEV))["grid"]                                         # HIP: pointnet.hip, voxel.hip, unet3d.hip
         logits = dec.decode_lattice(grid, nx, box=1.1, precision=dec_precision).reshape(-1)   # HIP: decode.hip, whole 128^3 lattice
         # the same decode kernel on the ORACLE's grid: the decoder's own error, free of encoder drift

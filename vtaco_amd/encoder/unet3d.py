@@ -82,6 +82,9 @@ class _Up(nn.Module):
 _WGRAD_F16 = os.environ.get("VTACO_UNET_WGRAD_PRECISION", "f16x3") != "f32"     # A/B knob: "f32" keeps the exact-f32 weight-gradient kernel
 
 
+_UP_TRAIN = os.environ.get("VTACO_CONV_UP_TRAIN", os.environ.get("VTACO_CONV_UP", "1")) != "0"      # A/B knob: per-parity forward convs in training
+
+
 class _GcrFn(torch.autograd.Function):
     """One 'gcr' SingleConv on channels-last tensors through the C ABI, differentiable:
     forward vt_gn_scale_shift + vt_conv3d_gcr[_bf16x3]; backward vt_relu_mask, the forward conv
@@ -105,7 +108,12 @@ class _GcrFn(torch.autograd.Function):
             # the network's first layer on a mean grid: the blocks no point comes near are filled from the border-class constants
             y, (part, _) = ops.conv3d_gcr_skip(x, ss, half, Cout, tile_flags)
         else:
-            y, (part, _) = ops.conv3d_gcr(x, low, ss, lambda: ops.conv3d_pack(weight), Cout, True, split, packed_w_f16x3=half)    # f32 pack on demand
+            # a decoder entry [skip | upsample(low)]: the upsampled channels as a 2x2x2 conv per output parity class (forward only:
+            # the data gradient reads a dense output gradient)
+            up = (ops.conv3d_pack_up(weight, C1) if half is not None and low is not None and _UP_TRAIN
+                  and ops.conv3d_up_covers(C1, C2, B, D, H, W, Cout) else None)
+            y, (part, _) = ops.conv3d_gcr(x, low, ss, lambda: ops.conv3d_pack(weight), Cout, True, split, packed_w_f16x3=half,
+                                          packed_w_up=up)                                  # f32 pack on demand
         ctx.save_for_backward(x, low, gamma, weight, ss, y, x_part, low_part)
         ctx.cfg = (groups, eps, precision)
         ctx.mark_non_differentiable(part)

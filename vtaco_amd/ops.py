@@ -1234,6 +1234,11 @@ def conv3d_pack_up(weight, c_skip):
     return out
 
 
+def conv3d_up_covers(C1, C2, B, D, H, W, Cout):
+    """Does the per-parity kernel take this decoder-entry layer (vt_conv3d_up_covers)?"""
+    return bool(_lib.load().vt_conv3d_up_covers(int(C1), int(C2), int(B), int(D), int(H), int(W), int(Cout)))
+
+
 def conv3d_gcr_final(x, ss, packed_w_f16x3, final_packed, final_bias):
     """relu(conv3x3x3(x * scale + shift)) followed by the final 1x1x1 conv (32 -> 32) in the same launch
     (vt_conv3d_gcr_f16x3_final); check ``final_fusable`` first."""
