@@ -75,6 +75,8 @@ elif os.environ.get("VTACO_CONV_SPEC", "1") != "0":
     per_wg = 16 if R >= 64 else 8
     w = np.arange(a.shape[0]) % per_wg
     table(a[w < per_wg // 2], "tap waves", ["prologue (to the first barrier)", "taps (14 k-steps x chunks)", "epilogue: relu + stores", "epilogue: statistics", "barrier", "constant blocks: values"])
-    table(a[w >= per_wg // 2], "loader waves", ["prologue", "commit (normalise, split, LDS)", "weights DMA + request issue", "wait (vmcnt)", "barrier"])
+    table(a[w >= per_wg // 2], "loader waves", ["prologue: the first barrier", "commit (normalise, split, LDS)", "weights DMA + request issue", "wait (vmcnt)", "barrier",
+                                                "-", "-", "-", "-", "prologue: start -> item tables, first tile", "prologue: weights DMA + two chunks' requests",
+                                                "prologue: GroupNorm statistics -> table", "prologue: commit of chunk 0 + third request", "prologue: wait (weights of chunk 0)"])
 else:
     print("the uniform-wave kernel carries no stamps")

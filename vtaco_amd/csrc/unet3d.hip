@@ -136,7 +136,12 @@ __device__ __forceinline__ void gn_barrier() {
     } else __syncthreads();
 }
 
-template <bool LDS_ONLY, int GN_PRE>
+// table slot of channel c: [c][scale, shift], or (QUAD) per channel quad [4 scales][4 shifts] -- the layout the specialised-wave conv
+// kernels read as 16-byte vectors
+template <bool QUAD>
+__device__ __forceinline__ int gn_slot(int c, int shift) { return QUAD ? (c >> 2) * 8 + shift * 4 + (c & 3) : c * 2 + shift; }
+
+template <bool LDS_ONLY, int GN_PRE, bool QUAD = false>
 __device__ __forceinline__ void gn_in_finish(const GnIn &in, const GnReq<GN_PRE> &r, int b, float pre, float *ssl, void *scratch, int tid, int nthr) {
     unsigned long long *cell = reinterpret_cast<unsigned long long *>(scratch);     // [atom of the concat][sum, sumsq][low, high]
     const int A0 = in.C[0] / GN_ATOM, A1 = in.acc[1] ? in.C[1] / GN_ATOM : 0, Ct = in.C[0] + (in.acc[1] ? in.C[1] : 0);
@@ -181,15 +186,15 @@ __device__ __forceinline__ void gn_in_finish(const GnIn &in, const GnReq<GN_PRE>
         if (c < Ct) {
             const int g = c / cpg;
             const double sc = stat[g * 2 + 1] * (double)r.gm[k];
-            ssl[c * 2] = pre * (float)sc;
-            ssl[c * 2 + 1] = pre * (float)((double)r.bt[k] - stat[g * 2] * sc);
+            ssl[gn_slot<QUAD>(c, 0)] = pre * (float)sc;
+            ssl[gn_slot<QUAD>(c, 1)] = pre * (float)((double)r.bt[k] - stat[g * 2] * sc);
         }
     }
     for (int c = tid + 2 * nthr; c < Ct; c += nthr) {
         const int g = c / cpg;
         const double sc = stat[g * 2 + 1] * (double)in.gamma[c];
-        ssl[c * 2] = pre * (float)sc;
-        ssl[c * 2 + 1] = pre * (float)((double)in.beta[c] - stat[g * 2] * sc);
+        ssl[gn_slot<QUAD>(c, 0)] = pre * (float)sc;
+        ssl[gn_slot<QUAD>(c, 1)] = pre * (float)((double)in.beta[c] - stat[g * 2] * sc);
     }
     gn_barrier<LDS_ONLY>();
 }
@@ -1307,7 +1312,7 @@ template <int TZ, bool FIN = false>
 __global__ void __launch_bounds__(hb_threads(TZ))
 conv3d_gcr_hw_kernel(HbArgs ha) {
     constexpr int ROWS = hb_rows(TZ), NVOX = hb_nvox(TZ), THREADS = hb_threads(TZ), LTHREADS = 64 * TZ;
-    constexpr int ITERS = (2 * NVOX + LTHREADS - 1) / LTHREADS;
+    constexpr int ITERS = (NVOX + LTHREADS - 1) / LTHREADS;        // loader items (a halo voxel x the chunk's eight channels) per thread
     constexpr int IMG = (int)hb_img_bytes(TZ), WBUF = HB_WFRAGS * 16;
     extern __shared__ __attribute__((aligned(16))) char hl[];      // [2 images][2 weight buffers][stats scratch][scale / shift]
     const ConvArgs &a = ha.c;
@@ -1339,8 +1344,8 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
     GnReq<GN_PRE> gn_rq;
     if (stats_in) gn_rq = gn_in_request<GN_PRE>(a.stat_in, b, threadIdx.x, THREADS);
     else
-        for (int i = threadIdx.x; i < 2 * Cin; i += THREADS)
-            ssl[i] = pre_scale * (a.scale_shift ? a.scale_shift[(size_t)b * Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f));
+        for (int i = threadIdx.x; i < 2 * Cin; i += THREADS)       // (the per-quad layout: [4 scales][4 shifts])
+            ssl[gn_slot<true>(i >> 1, i & 1)] = pre_scale * (a.scale_shift ? a.scale_shift[(size_t)b * Cin * 2 + i] : ((i & 1) ? 0.0f : 1.0f));
     if (wave < TZ) sred[wave * 64 + lane] = 0.0f;
     __syncthreads();
     // ---- tiles to skip (ha.tile_skip): the workgroups of a scene deal the tiles that need their taps among themselves in tile order, and
@@ -1395,156 +1400,174 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
 
     if (wave >= TZ) {
         // ================================================ loader waves ================================================
-        // (s_setprio 3 here moves time from these waves to the tap waves, 1:1: beside waves that issue MFMAs back to back a wave's
-        // VALU instructions get about one issue slot per 32-cycle MFMA, whatever the priority -- the ~210 VALU instructions per
-        // chunk of a loader wave, x 2 waves per SIMD, are what keeps this kernel at ~58 % of its matrix time)
+        // (beside waves that issue MFMAs back to back every instruction of a loader wave -- vector, scalar or memory -- costs ~25-60
+        // shader-clock counts, so the loaders are bounded by instruction COUNT: items of eight channels (two 16-byte requests, one
+        // 16-byte row per plane: half the LDS stores), buffer loads whose per-chunk address is `per-tile voffset + scalar soffset`
+        // (no address arithmetic per chunk; an offset in front of or behind the tensor returns zeros instead of faulting), the affine
+        // table read as 16-byte vectors, LDS-DMA pieces addressed by a scalar base)
         const int lt = threadIdx.x - LTHREADS, lwave = wave - TZ;
         const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
-        // per item, once: its halo position, its LDS row, and its linear voxel offsets from the tile origin in the full-resolution
-        // source and in the half-resolution `low` source (tile origins are multiples of 8, so the halving distributes) -- a chunk's
-        // request is then one add, one clamp and one multiply-add per item instead of ~35 instructions of coordinate arithmetic
+        const unsigned nscene = gridDim.x / ha.wgs_per_scene;
+        const __amdgpu_buffer_rsrc_t r_skip = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.skip), 0, nscene * (unsigned)(s.D * s.H * s.W) * (unsigned)s.C1 * 4u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_low = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.low ? s.low : s.skip), 0,
+                                                                                s.low ? nscene * (unsigned)(D2 * H2 * W2) * (unsigned)s.C2 * 4u : 0u, 0x00020000);
+        // per item, once: its halo position, its LDS row, and its byte offsets from the tile origin in the full-resolution source and in
+        // the half-resolution `low` source (tile origins are multiples of 8, so the halving distributes)
         int pxyz[ITERS], lrow[ITERS], voff[ITERS], loff[ITERS];
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int item = lt + it * LTHREADS, v = item >> 1;
+            const int v = lt + it * LTHREADS;
             const int px = v % 10, r2 = v / 10, py = r2 % 10, pz = r2 / 10;
             pxyz[it] = px | (py << 8) | (pz << 16);
-            lrow[it] = v < NVOX ? ((pz * 10 + py) * HB_PX + px) * 16 + (item & 1) * 8 : -1;
-            voff[it] = ((pz - 1) * s.H + (py - 1)) * s.W + (px - 1);
-            loff[it] = (((pz - 1) >> 1) * H2 + ((py - 1) >> 1)) * W2 + ((px - 1) >> 1);
+            lrow[it] = v < NVOX ? ((pz * 10 + py) * HB_PX + px) * 16 : -1;
+            voff[it] = (((pz - 1) * s.H + (py - 1)) * s.W + (px - 1)) * s.C1 * 4;
+            loff[it] = ((((pz - 1) >> 1) * H2 + ((py - 1) >> 1)) * W2 + ((px - 1) >> 1)) * s.C2 * 4;
         }
         unsigned f_full = 0;                                       // the items this thread has at all (lrow >= 0)
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) if (lrow[it] >= 0) f_full |= 1u << it;
-        const int c4 = (lt & 1) * 4;
-        const int vmax = (int)((size_t)gridDim.x / ha.wgs_per_scene * s.D * s.H * s.W) - 1, lmax = s.low ? vmax / 8 : 0;
-        // two register sets for the input prefetch: chunk n lives in set n & 1 and is requested two chunks ahead, so a
-        // request has a full chunk period (and more) to land -- with one set the commit stalled ~6 k cycles per chunk on it
-        struct PreSet { f32x4 v[ITERS]; unsigned in; };
+        // two register sets for the input prefetch: chunk n lives in set n & 1 and is requested two chunks ahead
+        struct PreSet { f32x4 v[2 * ITERS]; unsigned in; };
         PreSet preA, preB;
+        const unsigned lane16 = (unsigned)lane * 16u, lds0 = (unsigned)(size_t)hl;
         int d_q = 0;
         auto dma_w = [&](int n) {
             const int q = d_q;
             if (++d_q == ncq) d_q = 0;
-            const f16x8 *wq = reinterpret_cast<const f16x8 *>(a.wp) + ((size_t)q * nco_all + co_blk) * HB_WFRAGS;
-            char *dst = wbase + (n & 1) * WBUF;
-            // a FIXED number of DMA instructions per wave (the last piece is issued twice by some waves: same bytes to the same place),
-            // so that the compiler can count the vector-memory operations in flight instead of waiting for all of them (vmcnt(0))
-            // in front of every commit -- which is what made the two-deep prefetch above worthless at first
+            const char *wq = reinterpret_cast<const char *>(a.wp) + ((size_t)q * nco_all + co_blk) * (HB_WFRAGS * 16);
+            const unsigned dst = lds0 + 2 * IMG + (n & 1) * WBUF;
+            // a FIXED number of DMA instructions per wave (the last piece is issued twice by some waves: same bytes to the same place);
+            // inline assembly: `scalar piece base + the lane's 32-bit offset` (through the builtin the compiler keeps a per-lane 64-bit
+            // address of every piece in registers and adds one vector instruction per piece)
             constexpr int NP = HB_WFRAGS / 64, PW = (NP + TZ - 1) / TZ;
 #pragma unroll
             for (int i = 0; i < PW; ++i) {
                 const int p = min(lwave + i * TZ, NP - 1);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wq + p * 64 + lane),
-                                                 (__attribute__((address_space(3))) void *)(dst + p * 1024), 16, 0, 0);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + p * 1024), "v"(lane16), "s"(wq + p * 1024) : "memory");
             }
         };
-        int f_q = 0, f_k = 0, f_vbase = 0, f_lbase = 0;
+        int f_q = 0, f_k = 0;
+        unsigned vo[ITERS], lo[ITERS];                             // this tile's byte offsets of the items (wrapped when in front of the tensor)
         unsigned f_in = 0;                                         // which items of the current tile lie inside the volume
-        auto enter_tile = [&](int k) {                             // once per tile: origin (wave-uniform) and the inside mask
+        auto enter_tile = [&](int k) {                             // once per tile: origin (wave-uniform), offsets and the inside mask
             int x0, y0, z0;
             tile_origin(k, x0, y0, z0);
-            f_vbase = ((b * s.D + z0) * s.H + y0) * s.W + x0;
-            f_lbase = ((b * D2 + (z0 >> 1)) * H2 + (y0 >> 1)) * W2 + (x0 >> 1);
+            const unsigned vbase = (unsigned)((((b * s.D + z0) * s.H + y0) * s.W + x0) * s.C1) * 4u;
+            const unsigned lbase = (unsigned)((((b * D2 + (z0 >> 1)) * H2 + (y0 >> 1)) * W2 + (x0 >> 1)) * s.C2) * 4u;
             f_in = 0;
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
+                vo[it] = vbase + (unsigned)voff[it];
+                lo[it] = lbase + (unsigned)loff[it];
                 const int gx = x0 + (pxyz[it] & 255) - 1, gy = y0 + ((pxyz[it] >> 8) & 255) - 1, gz = z0 + (pxyz[it] >> 16) - 1;
                 if (lrow[it] >= 0 && gx >= 0 && gx < s.W && gy >= 0 && gy < s.H && gz >= 0 && gz < s.D) f_in |= 1u << it;
             }
         };
         enter_tile(0);
+        HB_STAMP(9);
         auto fetch = [&](PreSet &ps) {
-            const int ch = f_q * 8 + c4;
+            const int ch = f_q * 8;
             ps.in = f_in;
-            // out-of-volume items read a clamped (valid, unrelated) voxel and are zeroed at the commit; every wave issues exactly
-            // ITERS loads per chunk (the counted vmcnt wait relies on it)
+            // every wave issues exactly 2 ITERS loads per chunk (the counted vmcnt wait relies on it); halo voxels outside the volume
+            // but inside the tensor read a neighbouring row and are zeroed at the commit
             if (ch >= s.C1) {
-                const float *base = s.low + (ch - s.C1);
 #pragma unroll
-                for (int it = 0; it < ITERS; ++it)
-                    ps.v[it] = *reinterpret_cast<const f32x4 *>(base + (size_t)(unsigned)min(max(f_lbase + loff[it], 0), lmax) * s.C2);
+                for (int it = 0; it < ITERS; ++it) {
+                    ps.v[2 * it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_low, lo[it], (ch - s.C1) * 4, 0));
+                    ps.v[2 * it + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_low, lo[it] + 16, (ch - s.C1) * 4, 0));
+                }
             } else {
-                const float *base = s.skip + ch;
 #pragma unroll
-                for (int it = 0; it < ITERS; ++it)
-                    ps.v[it] = *reinterpret_cast<const f32x4 *>(base + (size_t)(unsigned)min(max(f_vbase + voff[it], 0), vmax) * s.C1);
+                for (int it = 0; it < ITERS; ++it) {
+                    ps.v[2 * it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_skip, vo[it], ch * 4, 0));
+                    ps.v[2 * it + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_skip, vo[it] + 16, ch * 4, 0));
+                }
             }
             if (++f_q == ncq) { f_q = 0; ++f_k; enter_tile(f_k); }
         };
         int c_q = 0;
         auto commit_as = [&](int n, const PreSet &ps, auto padded_tag) {
             constexpr bool PADDED = decltype(padded_tag)::value;
-            const int ch = c_q * 8 + c4;
+            const f32x4 *tq = reinterpret_cast<const f32x4 *>(ssl) + c_q * 4;        // the chunk's two channel quads: [4 scales][4 shifts] each
             if (++c_q == ncq) c_q = 0;
-            const float *ss = ssl + ch * 2;
-            const f32x4 sc = {ss[0], ss[2], ss[4], ss[6]}, sh = {ss[1], ss[3], ss[5], ss[7]};
+            const f32x4 sc[2] = {tq[0], tq[2]}, sh[2] = {tq[1], tq[3]};
             char *img = hl + (n & 1) * IMG;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 if (lrow[it] < 0) continue;
-                float x[4];
+                float x[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[4 * h + e] = fmaf(ps.v[2 * it + h][e], sc[h][e], sh[h][e]);
                 if constexpr (PADDED) {
-                    const bool in = ps.in >> it & 1u;
+                    if (!(ps.in >> it & 1u)) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = in ? fmaf(ps.v[it][e], sc[e], sh[e]) : 0.0f;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = fmaf(ps.v[it][e], sc[e], sh[e]);
+                        for (int e = 0; e < 8; ++e) x[e] = 0.0f;
+                    }
                 }
-                // hi = half(x) (packed conversion), lo = half(x - hi) with the subtraction reading the half in place
-                // (v_fma_mix_f32): 8 instructions per 4 values instead of the 20 the plain C++ form compiles to; the two pairs
-                // are interleaved so that no mix instruction directly follows the conversion it reads
-                unsigned h01, h23, l01, l23;
-                float t0, t1, t2, t3;
-                asm("v_cvt_pk_f16_f32 %0, %8, %9\n\t"
-                    "v_cvt_pk_f16_f32 %1, %10, %11\n\t"
-                    "v_fma_mix_f32 %4, %0, -1.0, %8 op_sel_hi:[1,0,0]\n\t"
-                    "v_fma_mix_f32 %5, %0, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-                    "v_fma_mix_f32 %6, %1, -1.0, %10 op_sel_hi:[1,0,0]\n\t"
-                    "v_fma_mix_f32 %7, %1, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-                    "v_cvt_pk_f16_f32 %2, %4, %5\n\t"
-                    "v_cvt_pk_f16_f32 %3, %6, %7"
-                    : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-                    : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                *reinterpret_cast<u32x2 *>(img + lrow[it]) = u32x2{h01, h23};
-                *reinterpret_cast<u32x2 *>(img + ROWS * 16 + lrow[it]) = u32x2{l01, l23};
+                // hi = half(x) (packed conversion), lo = half(x - hi) with the subtraction reading the half in place (v_fma_mix_f32):
+                // 8 instructions per 4 values
+                unsigned hw_[4], lw_[4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float t0, t1, t2, t3;
+                    asm("v_cvt_pk_f16_f32 %0, %8, %9\n\t"
+                        "v_cvt_pk_f16_f32 %1, %10, %11\n\t"
+                        "v_fma_mix_f32 %4, %0, -1.0, %8 op_sel_hi:[1,0,0]\n\t"
+                        "v_fma_mix_f32 %5, %0, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                        "v_fma_mix_f32 %6, %1, -1.0, %10 op_sel_hi:[1,0,0]\n\t"
+                        "v_fma_mix_f32 %7, %1, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                        "v_cvt_pk_f16_f32 %2, %4, %5\n\t"
+                        "v_cvt_pk_f16_f32 %3, %6, %7"
+                        : "=&v"(hw_[2 * h]), "=&v"(hw_[2 * h + 1]), "=&v"(lw_[2 * h]), "=&v"(lw_[2 * h + 1]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                        : "v"(x[4 * h]), "v"(x[4 * h + 1]), "v"(x[4 * h + 2]), "v"(x[4 * h + 3]));
+                }
+                *reinterpret_cast<u32x4 *>(img + lrow[it]) = u32x4{hw_[0], hw_[1], hw_[2], hw_[3]};
+                *reinterpret_cast<u32x4 *>(img + ROWS * 16 + lrow[it]) = u32x4{lw_[0], lw_[1], lw_[2], lw_[3]};
             }
+            __builtin_amdgcn_sched_barrier(0);                      // (the requests into these registers stay behind the commit)
         };
-        // tiles inside the volume (216 of the 512 of a 64^3 level) need no zero padding: one wave-uniform test per chunk saves the
-        // four selects per item -- a fifth of the commit's instructions, which compete with the tap waves' MFMAs for issue slots
+        // tiles inside the volume (216 of the 512 of a 64^3 level) need no zero padding: one wave-uniform test per chunk saves the selects
         auto commit = [&](int n, const PreSet &ps) {
             if (__builtin_amdgcn_ballot_w64(ps.in != f_full) == 0ull) commit_as(n, ps, std::false_type{});
             else commit_as(n, ps, std::true_type{});
         };
-        constexpr int WAIT_DMA = 0x0F70 | ITERS;                  // vmcnt(ITERS): all but the youngest ITERS operations (the register fetch) have landed
+        constexpr int REQ = 2 * ITERS;
+        constexpr int WAIT_DMA = 0x0F70 | (REQ > 15 ? 15 : REQ);  // vmcnt(REQ): all but the youngest request (the register fetch) have landed
         if (N > 0) {
             dma_w(0);
             fetch(preA);
             if (N > 1) fetch(preB);
         }
-        if (stats_in) gn_in_finish<true>(a.stat_in, gn_rq, b, pre_scale, ssl, hl, threadIdx.x, THREADS);
+        HB_STAMP(10);
+        if (stats_in) gn_in_finish<true, GN_PRE, true>(a.stat_in, gn_rq, b, pre_scale, ssl, hl, threadIdx.x, THREADS);
+        HB_STAMP(11);
         if (N > 0) {
             commit(0, preA);
             if (N > 2) fetch(preA);
         }
+        HB_STAMP(12);
         if (sparse) lds_barrier();                                  // (the tap waves: T is complete, the class table follows)
-        constexpr int WAIT_DMA0 = 0x0F70 | (2 * ITERS > 15 ? 15 : 2 * ITERS);
+        constexpr int WAIT_DMA0 = 0x0F70 | (2 * REQ > 15 ? 15 : 2 * REQ);
         if (N > 2) __builtin_amdgcn_s_waitcnt(WAIT_DMA0); else __builtin_amdgcn_s_waitcnt(0x0F70);   // chunk 0's weights have landed
+        HB_STAMP(13);
         lds_barrier();
         HB_STAMP(0);
-        // iteration n: commit chunk n+1 (requested two iterations ago), DMA its weights, request chunk n+3 into the freed set;
-        // the counted wait lets that youngest request fly on and, vmcnt being in order, also covers chunk n+2's request
+        // iteration n: DMA chunk n+1's weights, commit chunk n+1 (requested two iterations ago), request chunk n+3 into the freed set;
+        // the counted wait lets that youngest request fly on and, vmcnt being in order, also covers the DMA and chunk n+2's request
         auto iteration = [&](int n, PreSet &ps) {
-            if (n + 1 < N) { commit(n + 1, ps); HB_STAMP(1); dma_w(n + 1); }
+            if (n + 1 < N) { dma_w(n + 1); commit(n + 1, ps); HB_STAMP(1); }
             if (n + 3 < N) {
                 fetch(ps);
                 HB_STAMP(2);
+                __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_waitcnt(WAIT_DMA);
             } else __builtin_amdgcn_s_waitcnt(0x0F70);
             HB_STAMP(3);
             lds_barrier();
+            __builtin_amdgcn_sched_barrier(0);
             HB_STAMP(4);
         };
         for (int n = 0; n < N; n += 2) {
@@ -1555,7 +1578,7 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
         // ================================================= tap waves ==================================================
         const int lx = j & 3, ly = j >> 2;
         const int center = ((wave + 1) * 10 + (ly + 1)) * HB_PX + (lx + 1);      // patch 0; patch 1 sits 4 voxels along x
-        if (stats_in) gn_in_finish<true>(a.stat_in, gn_rq, b, pre_scale, ssl, hl, threadIdx.x, THREADS);
+        if (stats_in) gn_in_finish<true, GN_PRE, true>(a.stat_in, gn_rq, b, pre_scale, ssl, hl, threadIdx.x, THREADS);
         if (sparse && n_e > 0) {
             // T[tap][cout] = sum_cin W[cout][cin][tap] shift[cin] from the packed fragments (hi + lo), while the loaders stage chunk 0
             for (int id = threadIdx.x; id < 27 * 32; id += LTHREADS) {
@@ -1565,7 +1588,7 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
                     const f16x8 *wq = reinterpret_cast<const f16x8 *>(a.wp) + ((size_t)q * nco_all + co_blk) * HB_WFRAGS;
                     const f16x8 wh = wq[fl], wl = wq[fl + 64];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) t = fmaf((float)wh[e] + (float)wl[e], ssl[(q * 8 + e) * 2 + 1], t);
+                    for (int e = 0; e < 8; ++e) t = fmaf((float)wh[e] + (float)wl[e], ssl[(2 * q + (e >> 2)) * 8 + 4 + (e & 3)], t);   // (shift of channel 8 q + e)
                 }
                 ttab[id] = t;
             }
@@ -2581,6 +2604,13 @@ static bool conv_h_specialised(int tz) {
     static const bool spec = !(getenv("VTACO_CONV_SPEC") && getenv("VTACO_CONV_SPEC")[0] == '0');
     return spec && tz != 0 && tz != 2;
 }
+// the specialised-wave kernels address their sources through buffer descriptors (32-bit byte offsets): tensors of 4 GiB and more
+// stay on the uniform-wave kernel's 64-bit addressing
+static bool conv_h_fits_32bit(const Src &s, int B) {
+    const size_t lim = (size_t)1 << 32;
+    if ((size_t)B * s.D * s.H * s.W * s.C1 * 4 >= lim) return false;
+    return !s.low || (size_t)B * (s.D / 2) * (s.H / 2) * (s.W / 2) * s.C2 * 4 < lim;
+}
 
 static bool conv_h_inline() {
     static const bool on = getenv("VTACO_CONV_SPEC") && getenv("VTACO_CONV_SPEC")[0] == '2';
@@ -2608,7 +2638,8 @@ int vt_conv3d_gcr_f16x3_skip(const float *x, int C, int B, int D, int H, int W, 
 
 // does vt_conv3d_gcr_f16x3_final cover this layer?  (32 output channels, a shape of the specialised-wave kernel)
 int vt_conv3d_final_fusable(int B, int D, int H, int W, int Cin, int Cout) {
-    return Cout == 32 && conv_h_specialised(conv_h_tz(B, D, H, W, Cin, Cout)) ? 1 : 0;
+    const Src src{nullptr, nullptr, Cin, 0, D, H, W};              // (the fused layer is a plain one: no `low`)
+    return Cout == 32 && conv_h_specialised(conv_h_tz(B, D, H, W, Cin, Cout)) && conv_h_fits_32bit(src, B) ? 1 : 0;
 }
 
 // out[v][o] = fin_b[o] + sum_c fin_w[o][c] relu(conv(...))[v][c]: the last 'gcr' layer and the final 1x1x1 conv (32 -> 32) in one launch
@@ -2676,8 +2707,10 @@ static int conv_h_launch(const float *skip, int C1, const float *low, int C2, in
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3: hipFuncSetAttribute");
         attr = true;
     }
-    if (fin_w && !conv_h_specialised(tz)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr_f16x3_final: shape not on the specialised-wave kernel");
-    if (conv_h_specialised(tz) && conv_h_inline()) {               // the support work in the tap waves' MFMA gaps (VTACO_CONV_SPEC=2)
+    const bool spec = conv_h_specialised(tz) && conv_h_fits_32bit(a.s, B);
+    if (fin_w && !spec) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr_f16x3_final: shape not on the specialised-wave kernel");
+    if (!spec) ha.tile_skip = nullptr;
+    if (spec && conv_h_inline()) {               // the support work in the tap waves' MFMA gaps (VTACO_CONV_SPEC=2)
         bool attr_x = false;        // (vt_max_dyn_lds keeps the per-device record)
         if (!attr_x) {
             hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_hx_kernel<8>), (int)hb_lds(8));
@@ -2696,7 +2729,7 @@ static int conv_h_launch(const float *skip, int C1, const float *low, int C2, in
         }
         return vt_check(hipGetLastError(), "vt_conv3d_gcr_f16x3");
     }
-    if (conv_h_specialised(tz)) {                                  // specialised tap / loader waves (VTACO_CONV_SPEC=0: the uniform-wave kernel)
+    if (spec) {                                                    // specialised tap / loader waves (VTACO_CONV_SPEC=0: the uniform-wave kernel)
         bool attr_w = false;        // (vt_max_dyn_lds keeps the per-device record)
         if (!attr_w) {
             hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<8>), (int)hb_lds_sparse(8));
@@ -2733,7 +2766,8 @@ static int conv_up_tz(int C1, int C2, int B, int D, int H, int W, int Cout) {
     static const bool off = getenv("VTACO_CONV_UP") && getenv("VTACO_CONV_UP")[0] == '0';      // A/B knob: the 27-tap kernel on every layer
     if (off || C2 <= 0 || (C1 & 15) || (C2 & 15)) return 0;
     const int tz = conv_h_tz(B, D, H, W, C1 + C2, Cout);
-    return (tz == 8 || tz == 4) && conv_h_specialised(tz) && !conv_h_inline() ? tz : 0;
+    const Src src{nullptr, reinterpret_cast<const float *>(1), C1, C2, D, H, W};
+    return (tz == 8 || tz == 4) && conv_h_specialised(tz) && !conv_h_inline() && conv_h_fits_32bit(src, B) ? tz : 0;
 }
 
 static int conv_up_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
