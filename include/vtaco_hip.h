@@ -216,6 +216,14 @@ int vt_decode_fwd_wide_f16x3_ids(const float *grid_cl, int B, int R, int C, cons
                                  const unsigned char *finger_ids, const float *finger_feats, int n_fingers,
                                  const float *blob_wide_f16x3, int hidden, int n_blocks, int flags, double padding,
                                  float *out, float *out2, void *stream);
+/* The conditioned MLP of the wide shapes on features given per point, c [B][N][C], instead of the grid gather: what runs behind the  */
+/* fuser in AttentionDecoder.forward_img (decoder.py:259-271) at the reference's default widths; blob packed with fc_p (p_in = 3).  */
+int vt_decode_mlp_fwd_wide(const float *c, int B, int C, const float *pts, int64_t N,
+                           int lattice_nx, float lattice_box, int64_t lattice_first,
+                           const float *blob_wide, int hidden, int n_blocks, int flags, float *out, float *out2, void *stream);
+int vt_decode_mlp_fwd_wide_f16x3(const float *c, int B, int C, const float *pts, int64_t N,
+                                 int lattice_nx, float lattice_box, int64_t lattice_first,
+                                 const float *blob_wide_f16x3, int hidden, int n_blocks, int flags, float *out, float *out2, void *stream);
 
 /* The same shapes under autograd (the reference trains them through torch autograd: decoder.py:24-51,     */
 /* 135-161 called from training.py:476-489, 734-740, 879).                                                   */
@@ -324,13 +332,18 @@ typedef struct vt_fusion_unit {
 } vt_fusion_unit;
 
 typedef struct vt_fusion_params {
-    int32_t d_model;         /* must be 32 */
+    int32_t d_model;         /* 32 (every entry point) or 64 / 96 / 128 (vt_fusion_fwd only) */
     int32_t key_dim;         /* must be 64 */
     vt_fusion_unit self_attn;   /* fuser.encoder.layers.0.self_attn (== decoder.layers.0.self_attn) */
     vt_fusion_unit cross_attn;  /* fuser.decoder.layers.0.cross_attn                                 */
 } vt_fusion_params;
 
 size_t vt_fusion_workspace_bytes(int B, int N);
+/* d_model beyond 32 (the reference's AttentionDecoder defaults to c_dim = d_model = 128, decoder.py:176-207; key_feature_dim stays 64):  */
+/* vt_fusion_fwd takes d_model in {32, 64, 96, 128} (c_img, c, out: [B][N][d_model]; vt_fusion_unit's shapes with 32 -> d_model: WK / WQ  */
+/* [64][d], WV / trans_conv [d][d], linear1 [64][d], linear2 [d][64], norm2 [d]) with a workspace of vt_fusion_workspace_bytes_wide.      */
+/* Eval mode; the wider rows run generic-width projection / epilogue kernels around the same N x N passes.                                */
+size_t vt_fusion_workspace_bytes_wide(int B, int N, int d_model);
 int vt_fusion_fwd(const float *c_img, const float *c, int B, int N, const vt_fusion_params *params_host,
                   void *workspace, size_t workspace_bytes, float *out, void *stream);
 /* The same forward with the tactile features of the decoder's self-attention given per point as a finger id (255 = none: a zero  */

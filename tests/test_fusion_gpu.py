@@ -254,3 +254,63 @@ def test_fusion_by_finger_id_equals_the_gathered_tensor_bit_for_bit():
     fuser.train()
     with pytest.raises(Exception, match="eval-mode"):
         fuser.forward_ids(idd, feats, c)
+
+
+@pytest.mark.parametrize("tag", ["D", "E"])
+def test_attention_decoder_beyond_the_shipped_widths_against_the_reference_fixture(tag):
+    """AttentionDecoder at c_dim 128 / hidden_size 256 / 5 blocks (the reference's class defaults, decoder.py:176-207; one chunk of
+    512 points) and at 64 / 64 / 2 on two ragged chunks of 300 points: the fuser's output and the logits of forward_img against the
+    REAL reference's (tests/golden/g17_attention_wide.npz, make_attn_wide_goldens.py).  vt_fusion_fwd at d_model 64 / 128 (generic-width
+    projection / epilogue kernels around the N x N passes), vt_sample_grid at c_dim > 32, vt_decode_mlp_fwd_wide[_f16x3]."""
+    from conftest import load_golden
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd.conv_onet.models.decoder import AttentionDecoder
+    a, sd = load_golden("g17_attention_wide.npz")
+    arrs = {k[2:]: v for k, v in a.items() if k.startswith(tag + ".")}
+    sdc = {k[2:]: v.float() for k, v in sd.items() if k.startswith(tag + ".")}
+    c_dim, hidden, nb, B, N = (int(x) for x in arrs["shape"])
+    dec = AttentionDecoder(dim=3, c_dim=c_dim, hidden_size=hidden, n_blocks=nb, padding=0.1)
+    dec.load_state_dict(sdc)
+    dec = dec.to(DEV).eval()
+    T = torch.from_numpy
+    grid, p, c_img = T(arrs["grid"].astype("float32")).to(DEV), T(arrs["p"]).to(DEV), T(arrs["c_img"].astype("float32")).to(DEV)
+    with torch.no_grad():
+        from vtaco_amd import ops
+        c = ops.sample_grid(grid, p, 0.1)
+        assert float((c.cpu() - T(arrs["c"])).abs().max()) <= 2e-6
+        fused = dec.fuser(c_img, 1, c, 1)
+        ref_f = T(arrs["fused"])
+        assert float((fused.cpu() - ref_f).abs().max()) <= 5e-5 * max(1.0, float(ref_f.abs().max()))
+        for prec in ("f16x3", "f32"):
+            dec.mlp_precision = prec
+            logits = dec.forward_img(p, {"grid": grid}, c_img)
+            ref = T(arrs["logits_img"])
+            assert float((logits.cpu() - ref).abs().max()) <= 5e-5 * max(1.0, float(ref.abs().max())), prec
+    # the oracle (width-generic restatement) agrees with the fixture as well: it is the checker of the shapes in between
+    o = orc.attention_decoder_forward_img(sdc, T(arrs["p"]), T(arrs["grid"].astype("float32")), T(arrs["c_img"].astype("float32")))
+    assert float((o - T(arrs["logits_img"])).abs().max()) <= 2e-5
+    grid.requires_grad_(True)
+    with pytest.raises(Exception, match="training is built at the shipped shape"):
+        dec.forward_img(p, {"grid": grid}, c_img)
+
+
+def test_wide_fusion_against_the_oracle_on_a_whole_chunk():
+    """d_model 96 (three 32-channel slices, three waves in the epilogue) on a chunk of 2048 points and a short one, against the oracle."""
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd.transformer_fusion import TransformerFusion
+    torch.manual_seed(5)
+    for N, B in ((2048, 1), (50, 2)):
+        fuser = TransformerFusion(use_xyz=True, input_size=2048, d_model=96, num_layers=1, key_feature_dim=64, with_pos_embed=False,
+                                  encoder_pos_embed_input_dim=3, decoder_pos_embed_input_dim=3).eval()
+        g = torch.Generator().manual_seed(6)
+        with torch.no_grad():
+            for n, prm in fuser.named_parameters():
+                if n.endswith("norm2.weight") or n.endswith("norm2.bias") or n.endswith(".bias"):
+                    prm.add_(torch.randn(prm.shape, generator=g) * 0.1)
+        c = torch.randn(B, N, 96, generator=g)
+        c_img = torch.randn(B, N, 96, generator=g) * (torch.rand(B, N, 1, generator=g) < 0.3)
+        ref = orc.transformer_fusion({k: v.detach() for k, v in fuser.state_dict().items()}, c_img, c)
+        fd = fuser.to(DEV)
+        with torch.no_grad():
+            got = fd(c_img.to(DEV), 1, c.to(DEV), 1)
+        assert float((got.cpu() - ref).abs().max()) <= 5e-5 * max(1.0, float(ref.abs().max())), (N, B)

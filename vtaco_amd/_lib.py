@@ -91,6 +91,7 @@ SIGNATURES = {
     "vt_decode_mlp_fwd": (_I, [_VP, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP]),
 "vt_decode_mlp_fwd_f16x3": (_I, [_VP, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP]),
     "vt_fusion_workspace_bytes": (_SZ, [_I, _I]),
+    "vt_fusion_workspace_bytes_wide": (_SZ, [_I, _I, _I]),
     "vt_fusion_fwd": (_I, [_VP, _VP, _I, _I, ctypes.POINTER(FusionParams), _VP, _SZ, _VP, _VP]),
     "vt_fusion_fwd_ids": (_I, [_VP, _VP, _I, _VP, _VP, _I, _I, ctypes.POINTER(FusionParams), _VP, _SZ, _VP, _VP]),
     "vt_fusion_saved_bytes": (_SZ, [_I, _I]),
@@ -116,6 +117,8 @@ SIGNATURES = {
     "vt_decode_fwd_wide_f16x3": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _I, _I, _I, _D, _VP, _VP, _VP]),
     "vt_decode_fwd_wide_ids": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _I, _VP, _I, _I, _I, _D, _VP, _VP, _VP]),
     "vt_decode_fwd_wide_f16x3_ids": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _I, _VP, _I, _I, _I, _D, _VP, _VP, _VP]),
+    "vt_decode_mlp_fwd_wide": (_I, [_VP, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _I, _I, _I, _VP, _VP, _VP]),
+    "vt_decode_mlp_fwd_wide_f16x3": (_I, [_VP, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "vt_decode_wide_save_floats": (_SZ, [_I64, _I, _I, _I]),
     "vt_decode_wide_gws_floats": (_SZ, [_I64, _I, _I, _I]),
     "vt_decode_fwd_wide_train": (_I, [_VP, _I, _I, _I, _VP, _I64, _VP, _VP, _I, _I, _I, _D, _VP, _VP, _VP, _VP]),

@@ -340,9 +340,9 @@ class AttentionDecoder(LocalDecoder):
                  sample_mode='bilinear', padding=0.1, with_contact=False, **kwargs):
         super().__init__(dim=dim, c_dim=c_dim, hidden_size=hidden_size, n_blocks=n_blocks, leaky=leaky,
                          sample_mode=sample_mode, padding=padding, with_contact=with_contact)
-        if self._wide:
-            raise VtError("AttentionDecoder: the TransformerFusion kernels and the MLP behind them are built for the shipped shape "
-                          "(hidden_size = c_dim = 32, relu) only")
+        if self._wide and (c_dim not in (32, 64, 96, 128) or sample_mode != 'bilinear'):
+            raise VtError("AttentionDecoder: the TransformerFusion kernels take c_dim (= d_model) 32, 64, 96 or 128 (the reference's "
+                          "default) and the trilinear sample")
         self.mlp_precision = os.environ.get("VTACO_ATTENTION_MLP_PRECISION", "f16x3")
         self.fuser = TransformerFusion(use_xyz=True, input_size=input_size, d_model=c_dim, num_layers=1,
                                        key_feature_dim=64, with_pos_embed=False,
@@ -351,6 +351,9 @@ class AttentionDecoder(LocalDecoder):
 
     def forward_img(self, p, c_plane, c_img, **kwargs):
         grid = self._grid_of(c_plane)
+        if self._wants_grad(grid, c_img) and self._wide:
+            raise VtError("AttentionDecoder: training is built at the shipped shape (hidden_size = c_dim = 32); the wider shapes run "
+                          "inference (torch.no_grad)")
         if self._wants_grad(grid, c_img):
             # under autograd every stage is HIP, forward and backward: vt_sample_grid[_bwd], vt_fusion_fwd_train / vt_fusion_bwd
             # (train-mode dropout replayed from a seed), vt_decode_mlp_fwd_train / vt_decode_mlp_bwd / vt_decode_wgrad
@@ -366,4 +369,7 @@ class AttentionDecoder(LocalDecoder):
         2.6x the exact-f32 kernel's rate; `mlp_precision = "f32"` / VTACO_ATTENTION_MLP_PRECISION for the exact form, which the
         generator's range guard also falls back to)."""
         prec = self.mlp_precision
+        if self._wide:                                  # widths beyond 32 / 32 (the reference's defaults are 128 / 256): decode_wide.hip
+            wp = self._wide_precision(prec)
+            return ops.decode_mlp_fwd(c, self._blob(precision=wp), p, precision=wp, wide=(self.hidden_size, self.n_blocks, self.leaky))
         return ops.decode_mlp_fwd(c, self._blob(precision=prec), p, precision=prec)

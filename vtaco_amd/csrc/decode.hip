@@ -743,7 +743,7 @@ namespace {
 
 #ifndef VT_DECODE_F16_TU      // the remaining kernels exist once, in decode.o
 // ---- trilinear gather only: feat[b,n,:] = grid sampled at the query point -----------------
-__global__ void __launch_bounds__(256) sample_grid_kernel(DecodeArgs a, float *feat) {
+__global__ void __launch_bounds__(256) sample_grid_kernel(DecodeArgs a, float *feat, int C) {
     const int lane = threadIdx.x & 63, pl = lane & 31, h = lane >> 5;
     const uint32_t ntiles = (a.total + 31u) >> 5;
     const int R = a.R;
@@ -755,19 +755,21 @@ __global__ void __launch_bounds__(256) sample_grid_kernel(DecodeArgs a, float *f
         float px, py, pz;
         point_of(a, g, n, px, py, pz);
         const Tri t = tri_setup(px, py, pz, a.divisor, R);
-        const float *gb = a.grid + (size_t)b * R * R * R * 32 + 16 * h;
-        f32x16 c;
+        for (int cb = 0; cb < C; cb += 32) {                     // c_dim in blocks of 32 channels (one block at the shipped shape)
+            const float *gb = a.grid + (size_t)b * R * R * R * C + cb + 16 * h;
+            f32x16 c;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) c[s] = 0.0f;
+            for (int s = 0; s < 16; ++s) c[s] = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int zz = (k & 4) ? t.z1 : t.z0, yy = (k & 2) ? t.y1 : t.y0, xx = (k & 1) ? t.x1 : t.x0;
-            const float w = (((k & 1) ? t.wx1 : t.wx0) * ((k & 2) ? t.wy1 : t.wy0)) * ((k & 4) ? t.wz1 : t.wz0);
-            const f32x16 v = load_frag16(gb + (((size_t)zz * R + yy) * R + xx) * 32);
+            for (int k = 0; k < 8; ++k) {
+                const int zz = (k & 4) ? t.z1 : t.z0, yy = (k & 2) ? t.y1 : t.y0, xx = (k & 1) ? t.x1 : t.x0;
+                const float w = (((k & 1) ? t.wx1 : t.wx0) * ((k & 2) ? t.wy1 : t.wy0)) * ((k & 4) ? t.wz1 : t.wz0);
+                const f32x16 v = load_frag16(gb + (((size_t)zz * R + yy) * R + xx) * C);
 #pragma unroll
-            for (int s = 0; s < 16; ++s) c[s] = fmaf(v[s], w, c[s]);
+                for (int s = 0; s < 16; ++s) c[s] = fmaf(v[s], w, c[s]);
+            }
+            if (live) store_gather16(feat + (size_t)g * C + cb, c, h);
         }
-        if (live) store_gather16(feat + (size_t)g * 32, c, h);
     }
 }
 
@@ -1381,7 +1383,7 @@ int vt_sample_grid(const float *grid_cl, int B, int R, int C, const float *pts, 
                    float *feat, void *stream) {
     if (!grid_cl || !feat) return vt_fail(VT_ERR_INVALID, "vt_sample_grid: null argument");
     if (B <= 0 || R < 2 || N < 0) return vt_fail(VT_ERR_INVALID, "vt_sample_grid: bad size");
-    if (C != 32) return vt_fail(VT_ERR_UNSUPPORTED, "vt_sample_grid: c_dim must be 32");
+    if (C <= 0 || (C & 31)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_sample_grid: c_dim must be a multiple of 32");
     if (!pts && lattice_nx < 2) return vt_fail(VT_ERR_INVALID, "vt_sample_grid: lattice mode needs nx >= 2");
     if (N == 0) return 0;
     if ((int64_t)B * N >= (int64_t)1 << 31) return vt_fail(VT_ERR_UNSUPPORTED, "vt_sample_grid: B*N must be < 2^31");
@@ -1398,7 +1400,7 @@ int vt_sample_grid(const float *grid_cl, int B, int R, int C, const float *pts, 
     int64_t blocks = (((int64_t)a.total + 31) / 32 + 3) / 4;
     const int64_t cap = 8 * vt_num_cus();
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(sample_grid_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, feat);
+    hipLaunchKernelGGL(sample_grid_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, feat, C);
     return vt_check(hipGetLastError(), "vt_sample_grid");
 }
 #endif  // VT_DECODE_F16_TU

@@ -164,6 +164,10 @@ decode_wide_kernel(WideArgs a) {
                 const size_t near = a.nearest ? (((size_t)__builtin_rintf(grid_coord(pz, d.divisor, d.R)) * d.R + (size_t)__builtin_rintf(grid_coord(py, d.divisor, d.R))) * d.R +
                                                  (size_t)__builtin_rintf(grid_coord(px, d.divisor, d.R))) * C : 0;
                 for (int cb = 0; cb < C; cb += 32) {
+                    if (d.c_direct) {                               // the conditioning features given directly (the MLP behind a fuser)
+                        cl[(cb + ch) * WIDE_PITCH + pt] = d.c_direct[(size_t)g * C + cb + ch];
+                        continue;
+                    }
                     if (a.nearest) {
                         const float v = gb[near + cb + ch];
                         cl[(cb + ch) * WIDE_PITCH + pt] = v;
@@ -511,7 +515,8 @@ decode_wide_h_kernel(WideHArgs a) {
                                                  (size_t)__builtin_rintf(grid_coord(px, d.divisor, d.R))) * C : 0;
                 for (int cb = 0; cb < C; cb += 32) {
                     float acc = 0.0f;
-                    if (a.nearest) acc = gb[near + cb + ch];
+                    if (d.c_direct) acc = d.c_direct[(size_t)g * C + cb + ch];      // the conditioning features given directly
+                    else if (a.nearest) acc = gb[near + cb + ch];
                     else {
 #pragma unroll
                         for (int dz = 0; dz < 2; ++dz) {
@@ -696,8 +701,8 @@ static int wide_fwd_impl(const float *grid_cl, int B, int R, int C, const float 
                          int lattice_nx, float lattice_box, int64_t lattice_first,
                          const float *c_img, const float *blob, int hidden, int n_blocks, int flags, double padding,
                          float *out, float *out2, float *save, void *stream,
-                         const unsigned char *finger_ids = nullptr, const float *finger_feats = nullptr) {
-    if (!grid_cl || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide: null argument");
+                         const unsigned char *finger_ids = nullptr, const float *finger_feats = nullptr, const float *c_direct = nullptr) {
+    if ((!grid_cl && !c_direct) || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide: null argument");
     if (c_img && finger_ids) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide: give c_img or finger ids, not both");
     const int p_in = (c_img || finger_ids) ? 3 + C : 3;
     if (!wide_shape_ok(hidden, C, n_blocks, p_in))
@@ -710,7 +715,7 @@ static int wide_fwd_impl(const float *grid_cl, int B, int R, int C, const float 
     }
     WideArgs a{};
     a.d.grid = grid_cl; a.d.pts = pts; a.d.c_img = c_img; a.d.out = out; a.d.out2 = out2;
-    a.d.cimg_ids = finger_ids; a.d.cimg_table = finger_ids ? finger_feats : nullptr;
+    a.d.cimg_ids = finger_ids; a.d.cimg_table = finger_ids ? finger_feats : nullptr; a.d.c_direct = c_direct;
     a.d.N = (uint32_t)N; a.d.total = (uint32_t)((uint64_t)B * (uint64_t)N); a.d.lattice_first = (uint32_t)lattice_first;
     a.d.R = R; a.d.nx = lattice_nx; a.d.box = lattice_box; a.d.divisor = (float)(1.0 + padding + 10e-4);
     a.blob = blob; a.H = hidden; a.C = C; a.nb = n_blocks; a.p_in = p_in; a.Kp = (p_in + 7) / 8 * 8; a.leaky = (flags & VT_WIDE_LEAKY) ? 1 : 0; a.nearest = (flags & VT_WIDE_NEAREST) ? 1 : 0;
@@ -804,8 +809,8 @@ static int wideh_fwd_impl(const float *grid_cl, int B, int R, int C, const float
                           int lattice_nx, float lattice_box, int64_t lattice_first,
                           const float *c_img, const unsigned char *finger_ids, const float *finger_feats,
                           const float *blob, int hidden, int n_blocks, int flags, double padding,
-                          float *out, float *out2, void *stream) {
-    if (!grid_cl || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3: null argument");
+                          float *out, float *out2, void *stream, const float *c_direct = nullptr) {
+    if ((!grid_cl && !c_direct) || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3: null argument");
     if (c_img && finger_ids) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3: give c_img or finger ids, not both");
     const int p_in = (c_img || finger_ids) ? 3 + C : 3;
     if (!wide_shape_ok(hidden, C, n_blocks, p_in))
@@ -816,7 +821,7 @@ static int wideh_fwd_impl(const float *grid_cl, int B, int R, int C, const float
         return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3: lattice range outside nx^3");
     WideHArgs a{};
     a.d.grid = grid_cl; a.d.pts = pts; a.d.c_img = c_img; a.d.out = out; a.d.out2 = out2;
-    a.d.cimg_ids = finger_ids; a.d.cimg_table = finger_ids ? finger_feats : nullptr;
+    a.d.cimg_ids = finger_ids; a.d.cimg_table = finger_ids ? finger_feats : nullptr; a.d.c_direct = c_direct;
     a.d.N = (uint32_t)N; a.d.total = (uint32_t)((uint64_t)B * (uint64_t)N); a.d.lattice_first = (uint32_t)lattice_first;
     a.d.R = R; a.d.nx = lattice_nx; a.d.box = lattice_box; a.d.divisor = (float)(1.0 + padding + 10e-4);
     a.blob = blob; a.H = hidden; a.C = C; a.nb = n_blocks; a.p_in = p_in; a.Kp = (p_in + 15) / 16 * 16;
@@ -856,6 +861,24 @@ int vt_decode_fwd_wide_f16x3_ids(const float *grid_cl, int B, int R, int C, cons
     if (!finger_ids || !finger_feats || n_fingers <= 0 || n_fingers > 255) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3_ids: bad finger table");
     return wideh_fwd_impl(grid_cl, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, finger_ids, finger_feats, blob, hidden,
                           n_blocks, flags, padding, out, out2, stream);
+}
+
+// the conditioned MLP alone on features given per point (AttentionDecoder.forward_img behind its fuser, decoder.py:259-271): c [B][N][C]
+// instead of the grid gather; the blob is the one packed with fc_p (p_in = 3)
+int vt_decode_mlp_fwd_wide(const float *c, int B, int C, const float *pts, int64_t N,
+                           int lattice_nx, float lattice_box, int64_t lattice_first,
+                           const float *blob, int hidden, int n_blocks, int flags, float *out, float *out2, void *stream) {
+    if (!c) return vt_fail(VT_ERR_INVALID, "vt_decode_mlp_fwd_wide: null features");
+    return wide_fwd_impl(nullptr, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, blob, hidden, n_blocks, flags, 0.1,
+                         out, out2, nullptr, stream, nullptr, nullptr, c);
+}
+
+int vt_decode_mlp_fwd_wide_f16x3(const float *c, int B, int C, const float *pts, int64_t N,
+                                 int lattice_nx, float lattice_box, int64_t lattice_first,
+                                 const float *blob, int hidden, int n_blocks, int flags, float *out, float *out2, void *stream) {
+    if (!c) return vt_fail(VT_ERR_INVALID, "vt_decode_mlp_fwd_wide_f16x3: null features");
+    return wideh_fwd_impl(nullptr, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, nullptr, nullptr, blob, hidden, n_blocks,
+                          flags, 0.1, out, out2, stream, c);
 }
 
 // ---- training (decoder.py:24-51, 135-161 under autograd: training.py:476-489, 879) ----

@@ -381,7 +381,7 @@ fusion_expsum8_kernel(const float *Fd, const float *Sd, const float *w, float *o
 // VT[b][tile][c][kg][part][k-step 2][e 8] bf16 with key = 32 tile + chan_of(8 step + e, kg) -- the
 // key order of the score accumulator -- and zeros for keys >= N.  One thread per (b, tile, c, kg, step).
 __global__ void __launch_bounds__(256)
-fusion_scalev_kernel(const float *V, const float *s, float *VT, int N, int ntile, size_t total) {
+fusion_scalev_kernel(const float *V, const float *s, float *VT, int N, int ntile, size_t total, int vpitch = 32, int voff = 0) {
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int step = (int)(idx & 1), kg = (int)((idx >> 1) & 1), c = (int)((idx >> 2) & 31);
         const size_t bt = idx >> 7;
@@ -391,7 +391,7 @@ fusion_scalev_kernel(const float *V, const float *s, float *VT, int N, int ntile
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int key = 32 * tile + chan_of(8 * step + e, kg);
-            const float v = (key < N) ? V[(b * N + key) * 32 + c] / (1e-9f + s[b * N + key]) : 0.0f;
+            const float v = (key < N) ? V[(b * N + key) * vpitch + voff + c] / (1e-9f + s[b * N + key]) : 0.0f;
             const __bf16 hb = (__bf16)v;
             hi[e] = hb;
             lo[e] = (__bf16)(v - (float)hb);
@@ -449,7 +449,7 @@ constexpr int VROW = 36;                                    // V' tile row: 128 
 template <bool TRAIN, bool FULL, bool F8>
 __global__ void __launch_bounds__(FT)
 fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const float *linv, const float *Xq,
-                     const float *blob, float *Z, int N, int ntile_, float *Osave, DropCfg dc, int nrb, int B, XIds xi) {
+                     const float *blob, float *Z, int N, int ntile_, float *Osave, DropCfg dc, int nrb, int B, XIds xi, int o_pitch = 0) {
     static_assert(!(F8 && (TRAIN || FULL)), "the fp8-corrected tiles are the inference form");
     __shared__ __attribute__((aligned(16))) float lds[FU_BLOB];
     __shared__ __attribute__((aligned(16))) float tiles[2][F8 ? STILE8 : STILE];
@@ -544,6 +544,10 @@ fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const fl
     const float li = linv[(size_t)b * N + q];
 #pragma unroll
     for (int s = 0; s < 16; ++s) o[s] *= li;
+    if (o_pitch > 0) {          // d_model beyond 32: this launch is one 32-channel slice of V'; leave the attention output, no epilogue
+        if (q0 + j < N) store_acc16(Osave + ((size_t)b * N + q0 + j) * o_pitch, o, h);
+        return;
+    }
     // lane (q,h) reg r = channel chan_of(r,h) of the attention output: the accumulator layout
     const float *xrow = Xq ? Xq + ((size_t)b * N + q) * 32 : xi.row((size_t)b * N + q);
     const f32x16 x = load_acc16(xrow, h);
@@ -590,18 +594,18 @@ fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const fl
 
 // out = relu((z - mean_N) / sqrt(var_N + 1e-5)) per (scene, channel); one block per scene
 __global__ void __launch_bounds__(1024)
-fusion_inorm_relu_kernel(const float *Z, float *out, int N) {
+fusion_inorm_relu_kernel(const float *Z, float *out, int N, int pitch = 32) {
     __shared__ float red[32][33];
     __shared__ float mean[32], rstd[32];
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;        // 32 row groups
-    const float *z = Z + (size_t)blockIdx.x * N * 32;
-    float *o = out + (size_t)blockIdx.x * N * 32;
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;        // 32 row groups; blockIdx.y: the 32-channel slice of a wider row
+    const float *z = Z + (size_t)blockIdx.x * N * pitch + blockIdx.y * 32;
+    float *o = out + (size_t)blockIdx.x * N * pitch + blockIdx.y * 32;
     // mean = z_0 + mean(z - z_0): a channel that is constant over the chunk (an untouched chunk's tactile branch: all-zero
     // inputs give every point the same vector) then has residuals of exactly 0 instead of the rounding noise of a 2048-term
     // sum, which 1/sqrt(0 + 1e-5) would multiply by 316
     const float shift = z[c];
     float s = 0.0f;
-    for (int n = g; n < N; n += 32) s += z[(size_t)n * 32 + c] - shift;
+    for (int n = g; n < N; n += 32) s += z[(size_t)n * pitch + c] - shift;
     red[g][c] = s;
     __syncthreads();
     if (threadIdx.x < 32) {
@@ -612,7 +616,7 @@ fusion_inorm_relu_kernel(const float *Z, float *out, int N) {
     __syncthreads();
     const float m = mean[c];
     s = 0.0f;
-    for (int n = g; n < N; n += 32) { const float d = z[(size_t)n * 32 + c] - m; s = fmaf(d, d, s); }
+    for (int n = g; n < N; n += 32) { const float d = z[(size_t)n * pitch + c] - m; s = fmaf(d, d, s); }
     __syncthreads();
     red[g][c] = s;
     __syncthreads();
@@ -623,7 +627,7 @@ fusion_inorm_relu_kernel(const float *Z, float *out, int N) {
     }
     __syncthreads();
     const float rs = rstd[c];
-    for (int n = g; n < N; n += 32) o[(size_t)n * 32 + c] = fmaxf((z[(size_t)n * 32 + c] - m) * rs, 0.0f);
+    for (int n = g; n < N; n += 32) o[(size_t)n * pitch + c] = fmaxf((z[(size_t)n * pitch + c] - m) * rs, 0.0f);
 }
 
 // The same for chunks of at most 2048 points (the reference's chunk size): a thread keeps its 16 x 4 values in registers --
@@ -756,6 +760,265 @@ void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const fl
     else hipLaunchKernelGGL(fusion_inorm_relu_kernel, dim3(B), dim3(1024), 0, s, w.Z, out, N);
 }
 
+
+// ---- TransformerFusion at d_model = C beyond 32 (64, 96, 128: the reference's AttentionDecoder defaults to c_dim 128, ----------------
+// decoder.py:176-207).  The N x N passes depend on d_model only through V: the scores take the same 64-dim split Q / K rows, so the
+// exp-sum kernels run unchanged (all three half products: the form the training forward uses), and the attend kernel runs once per
+// 32-channel slice of V' and leaves the attention output (o_pitch) instead of chaining into the 32-wide epilogue.  Around them:
+//   fusionw_proj_kernel      Q, K rows in the passes' split format, V [P][C]: f32 MFMA, the weights staged in LDS in fragment order
+//   fusionw_epilogue_kernel  z = x + LN(r + linear2(relu(linear1(r)))), r = relu(trans_conv(x - o)): f32 MFMA, 32 points per workgroup
+//   fusion_inorm_relu_kernel InstanceNorm over the chunk + ReLU per (chunk, 32-channel slice)
+// Eval mode only (the generator's path); exact f32 outside the score / E x V' products.
+constexpr int FW_MAX = 128;
+
+template <int C>
+__global__ void __launch_bounds__(256)
+fusionw_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd, float *Kd, float *V, int total, int do_q, int do_kv) {
+    constexpr int KS = C / 2, NV = C / 32;                           // k-steps of the 32x32x2 MFMA; 32-row blocks of V
+    extern __shared__ __attribute__((aligned(16))) float fw_wf[];   // [4 + NV groups][KS][64 lanes] A fragments
+    for (int e = threadIdx.x; e < (4 + NV) * KS * 64; e += 256) {
+        const int l = e & 63, st = (e >> 6) % KS, g = e / (64 * KS), i = l & 31, kk = l >> 5, k = 2 * st + kk;
+        const int hh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3);    // output row i <-> accumulator register r of lane half hh
+        float v = 0.0f;
+        if (g < 4) {
+            const int gg = g & 1, col = 16 * (2 * gg + (r >> 3)) + 8 * hh + (r & 7);
+            if (g < 2 ? do_q : do_kv) v = (g < 2 ? u.WQ : u.WK)[col * C + k];
+        } else if (do_kv) {
+            v = u.WV[(32 * (g - 4) + i) * C + k];
+        }
+        fw_wf[e] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    for (int tile = 0; tile < PROJ_TILES; ++tile) {
+        const int p0 = ((blockIdx.x * PROJ_TILES + tile) * 4 + wave) * 32;
+        if (p0 >= total) return;
+        const int p = min(p0 + j, total - 1);
+        const bool live = p0 + j < total;
+        float x[KS];
+        auto load_x = [&](const float *X) {                          // x[s] = X[p][2 s + h]
+            const f32x4 *r = reinterpret_cast<const f32x4 *>(X + (size_t)p * C);
+#pragma unroll
+            for (int i = 0; i < C / 4; ++i) {
+                const f32x4 t = r[i];
+                x[2 * i] = h ? t.y : t.x;
+                x[2 * i + 1] = h ? t.w : t.z;
+            }
+        };
+        auto project = [&](int g) {
+            f32x16 acc;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc[s] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = mfma(fw_wf[(g * KS + s) * 64 + lane], x[s], acc);
+            return acc;
+        };
+        auto store_unit = [&](const f32x16 &a0, const f32x16 &a1, float *dst, float post) {
+            float ss = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { ss = fmaf(a0[s], a0[s], ss); ss = fmaf(a1[s], a1[s], ss); }
+            ss += __shfl_xor(ss, 32);
+            const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);                     // F.normalize(p=2, eps=1e-12)
+            if (!live) return;
+            f16x8 *row = reinterpret_cast<f16x8 *>(dst + (size_t)p * 64);            // 16 fragments of 8 halves (fusion_proj_kernel's rows)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x16 &a = g ? a1 : a0;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    f16x8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = (a[8 * half + e] * inv) * post;
+                        const _Float16 hb = (_Float16)v;
+                        hi[e] = hb;
+                        lo[e] = (_Float16)(v - (float)hb);
+                    }
+                    const int t = 2 * g + half;
+                    row[(h * 2 + 0) * 4 + t] = hi;
+                    row[(h * 2 + 1) * 4 + t] = lo;
+                }
+            }
+        };
+        if (do_q) {
+            load_x(Xq);
+            const f32x16 q0 = project(0), q1 = project(1);
+            store_unit(q0, q1, Qd, 1.44269504088896341f);
+        }
+        if (do_kv) {
+            if (!do_q || Xk != Xq) load_x(Xk);
+            const f32x16 k0 = project(2), k1 = project(3);
+            store_unit(k0, k1, Kd, 1.0f);
+#pragma unroll
+            for (int vb = 0; vb < NV; ++vb) {
+                const f32x16 v = project(4 + vb);
+                if (live) store_acc16(V + (size_t)p * C + 32 * vb, v, h);
+            }
+        }
+    }
+}
+
+// W [H][K] -> fragments [H/32][K/8][64 lanes][4]: lane (row r = l & 31, kg = l >> 5), element e = W[32 ob + r][8 kq + 2 e + kg] -- the A
+// operands of four consecutive 32x32x2 k-steps (the layout of decode_wide.hip's weight stream)
+__global__ void fusionw_pack_kernel(const float *w, int H, int K, float *dst) {
+    const size_t total = (size_t)H * K;
+    for (size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(f & 3), l = (int)((f >> 2) & 63);
+        const size_t q = f >> 8;
+        const int kq = (int)(q % (K / 8)), ob = (int)(q / (K / 8));
+        dst[f] = w[(size_t)(32 * ob + (l & 31)) * K + 8 * kq + 2 * e + (l >> 5)];
+    }
+}
+constexpr int FW_PITCH = 33;
+// acc += W[32 rows of block ob][K] . X[K][32 points]; wf: the layer's fragments, x: LDS [K][FW_PITCH]
+__device__ __forceinline__ f32x16 fusionw_gemm(f32x16 acc, const float *wf, int ob, int K, const float *x, int lane) {
+    const f32x4 *w4 = reinterpret_cast<const f32x4 *>(wf) + (size_t)ob * (K / 8) * 64 + lane;
+    const float *xb = x + (lane >> 5) * FW_PITCH + (lane & 31);
+    for (int kq = 0; kq < K / 8; ++kq) {
+        const f32x4 a = w4[(size_t)kq * 64];
+        const float *xr = xb + kq * 8 * FW_PITCH;
+        acc = mfma(a.x, xr[0], acc);
+        acc = mfma(a.y, xr[2 * FW_PITCH], acc);
+        acc = mfma(a.z, xr[4 * FW_PITCH], acc);
+        acc = mfma(a.w, xr[6 * FW_PITCH], acc);
+    }
+    return acc;
+}
+struct FusionwEpi { const float *wt, *w1, *w2, *b1, *b2, *lnw, *lnb; };     // packed fragments (wt [C][C], w1 [64][C], w2 [C][64]) and f32 vectors
+// z[p] = x[p] + LayerNorm(r + linear2(relu(linear1(r))))  with  r = relu(trans_conv(x[p] - o[p]))   (TransformerFusion.py:21-25, 110-113)
+// C / 32 waves, 32 points per tile; wave ob owns the output rows 32 ob .. 32 ob + 31, waves 0 and 1 the 64 hidden rows of linear1
+template <int C>
+__global__ void __launch_bounds__(C * 2)
+fusionw_epilogue_kernel(const float *X, const float *O, FusionwEpi e, float *Z, int total) {
+    constexpr int NW = C / 32;
+    __shared__ float bufD[C * FW_PITCH], bufR[C * FW_PITCH], bufH[64 * FW_PITCH], red[2][NW][32];
+    const int tid = threadIdx.x, lane = tid & 63, ob = tid >> 6, j = lane & 31, kg = lane >> 5;
+    const int ntiles = (total + 31) / 32;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (int i = tid; i < 32 * C; i += C * 2) {                  // d = x - o, channel-major [c][pt]
+            const int pt = i / C, c = i - pt * C;
+            const int p = min(tile * 32 + pt, total - 1);
+            bufD[c * FW_PITCH + pt] = X[(size_t)p * C + c] - O[(size_t)p * C + c];
+        }
+        __syncthreads();
+        f32x16 r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r[i] = 0.0f;
+        r = relu16(fusionw_gemm(r, e.wt, ob, C, bufD, lane));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bufR[(32 * ob + chan_of(i, kg)) * FW_PITCH + j] = r[i];
+        __syncthreads();
+        if (ob < 2) {
+            f32x16 hd;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) hd[i] = e.b1[32 * ob + chan_of(i, kg)];
+            hd = relu16(fusionw_gemm(hd, e.w1, ob, C, bufR, lane));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bufH[(32 * ob + chan_of(i, kg)) * FW_PITCH + j] = hd[i];
+        }
+        __syncthreads();
+        f32x16 t;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = e.b2[32 * ob + chan_of(i, kg)];
+        t = fusionw_gemm(t, e.w2, ob, 64, bufH, lane);
+        t = t + r;
+        // LayerNorm over the C channels of a point: this wave's 32 (16 registers x 2 lane halves), then the waves' sums through LDS
+        float m = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m += t[i];
+        m += __shfl_xor(m, 32);
+        if (kg == 0) red[0][ob][j] = m;
+        __syncthreads();
+        m = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) m += red[0][w][j];
+        m *= 1.0f / (float)C;
+        float var = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const float c = t[i] - m; var = fmaf(c, c, var); }
+        var += __shfl_xor(var, 32);
+        if (kg == 0) red[1][ob][j] = var;
+        __syncthreads();
+        var = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) var += red[1][w][j];
+        const float rstd = 1.0f / sqrtf(var * (1.0f / (float)C) + 1e-5f);
+        const int p = tile * 32 + j;
+        if (p < total) {
+            const f32x16 x = load_acc16(X + (size_t)p * C + 32 * ob, kg);
+            f32x16 z;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ch = 32 * ob + chan_of(i, kg);
+                z[i] = x[i] + ((t[i] - m) * rstd * e.lnw[ch] + e.lnb[ch]);
+            }
+            store_acc16(Z + (size_t)p * C + 32 * ob, z, kg);
+        }
+        __syncthreads();                                              // the buffers and `red` are free again
+    }
+}
+
+struct FusionwWs {
+    float *Qd, *Kd, *V, *VT, *l, *s, *O, *Z, *M, *T, *blob;        // blob: the 32-wide attend kernel's (unused) epilogue image
+    float *pk[2];                                                   // per unit: packed wt | w1 | w2
+};
+size_t fusionw_layout(int B, int N, int C, FusionwWs *ws, char *base) {
+    const size_t P = (size_t)B * N, Npad = (size_t)(N + 31) / 32 * 32;
+    size_t off = 0;
+    auto take = [&](size_t floats) { float *p = base ? (float *)(base + off) : nullptr; off += (floats * 4 + 255) / 256 * 256; return p; };
+    FusionwWs w;
+    w.Qd = take(P * 64); w.Kd = take(P * 64); w.V = take(P * C); w.VT = take((size_t)B * 32 * Npad);
+    w.l = take(P); w.s = take(P); w.O = take(P * C); w.Z = take(P * C); w.M = take(P * C); w.T = take(P * C);
+    w.blob = take(FU_BLOB);
+    for (int k = 0; k < 2; ++k) w.pk[k] = take((size_t)C * C + 2 * 64 * (size_t)C);
+    if (ws) *ws = w;
+    return off;
+}
+
+template <int C>
+void run_unit_wide(const float *Xq, const float *Xk, const FusionUnitDev &u, const float *pk, const FusionwWs &w, float *out, int B, int N, hipStream_t s) {
+    const int P = B * N, ntile = (N + 31) / 32, nrb = (N + FROWS - 1) / FROWS;
+    const dim3 pg((P + 128 * PROJ_TILES - 1) / (128 * PROJ_TILES)), tg((unsigned)nrb * (unsigned)B);
+    const size_t plds = (size_t)(4 + C / 32) * (C / 2) * 64 * sizeof(float);
+    hipLaunchKernelGGL(fusionw_proj_kernel<C>, pg, dim3(256), plds, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, 1, 1);
+    hipLaunchKernelGGL((fusion_expsum_kernel<true, true>), tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1, nrb, B);
+    hipLaunchKernelGGL((fusion_expsum_kernel<false, true>), tg, dim3(FT), 0, s, w.Kd, w.Qd, (const float *)w.l, w.s, N, 0, nrb, B);
+    const size_t tot = (size_t)B * ntile * 128;
+    size_t g = (tot + 255) / 256;
+    if (g > 8192) g = 8192;
+    for (int sl = 0; sl < C / 32; ++sl) {                            // the attention output, one 32-channel slice of V' at a time
+        hipLaunchKernelGGL(fusion_scalev_kernel, dim3((unsigned)g), dim3(256), 0, s, w.V, w.s, w.VT, N, ntile, tot, C, 32 * sl);
+        hipLaunchKernelGGL((fusion_attend_kernel<false, true, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, w.blob, w.Z, N, ntile,
+                           w.O + 32 * sl, DropCfg{0, 0, 1.0f, 0}, nrb, B, XIds{}, C);
+    }
+    FusionwEpi e{pk, pk + (size_t)C * C, pk + (size_t)C * C + 64 * (size_t)C, u.l1b, u.l2b, u.lnw, u.lnb};
+    int eg = (P + 31) / 32;
+    if (eg > vt_num_cus() * 4) eg = vt_num_cus() * 4;
+    hipLaunchKernelGGL(fusionw_epilogue_kernel<C>, dim3(eg), dim3(C * 2), 0, s, Xq, w.O, e, w.Z, P);
+    hipLaunchKernelGGL(fusion_inorm_relu_kernel, dim3(B, C / 32), dim3(1024), 0, s, w.Z, out, N, C);
+}
+
+template <int C>
+int fusion_fwd_wide(const float *c_img, const float *c, int B, int N, const vt_fusion_params *p, void *workspace, size_t workspace_bytes,
+                    float *out, hipStream_t s) {
+    FusionwWs w;
+    if (workspace_bytes < fusionw_layout(B, N, C, &w, (char *)workspace)) return vt_fail(VT_ERR_WORKSPACE, "vt_fusion_fwd: workspace too small");
+    hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&fusionw_proj_kernel<C>), 160 * 1024);
+    if (e != hipSuccess) return vt_check(e, "vt_fusion_fwd: hipFuncSetAttribute");
+    const FusionUnitDev us = unit_of(p->self_attn), ux = unit_of(p->cross_attn);
+    hipLaunchKernelGGL(fusion_pack_kernel, dim3(6), dim3(1024), 0, s, us, w.blob);          // (any valid image: the slices return before using it)
+    for (int k = 0; k < 2; ++k) {
+        const FusionUnitDev &u = k ? ux : us;
+        hipLaunchKernelGGL(fusionw_pack_kernel, dim3(64), dim3(256), 0, s, u.Wt, C, C, w.pk[k]);
+        hipLaunchKernelGGL(fusionw_pack_kernel, dim3(32), dim3(256), 0, s, u.l1w, 64, C, w.pk[k] + (size_t)C * C);
+        hipLaunchKernelGGL(fusionw_pack_kernel, dim3(32), dim3(256), 0, s, u.l2w, C, 64, w.pk[k] + (size_t)C * C + 64 * (size_t)C);
+    }
+    run_unit_wide<C>(c, c, us, w.pk[0], w, w.M, B, N, s);              // encoder: memory from the grid features
+    run_unit_wide<C>(c_img, c_img, us, w.pk[0], w, w.T, B, N, s);      // decoder self-attention (SAME weights)
+    run_unit_wide<C>(w.T, w.M, ux, w.pk[1], w, out, B, N, s);          // decoder cross-attention
+    return vt_check(hipGetLastError(), "vt_fusion_fwd");
+}
+
 }  // namespace
 
 extern "C" {
@@ -765,11 +1028,20 @@ size_t vt_fusion_workspace_bytes(int B, int N) {
     return fusion_layout(B, N, nullptr, nullptr);
 }
 
+size_t vt_fusion_workspace_bytes_wide(int B, int N, int d_model) {
+    if (B <= 0 || N <= 0 || d_model <= 0 || (d_model & 31) || d_model > FW_MAX) return 0;
+    return d_model == 32 ? fusion_layout(B, N, nullptr, nullptr) : fusionw_layout(B, N, d_model, nullptr, nullptr);
+}
+
 int vt_fusion_fwd(const float *c_img, const float *c, int B, int N, const vt_fusion_params *p,
                   void *workspace, size_t workspace_bytes, float *out, void *stream) {
     if (!c_img || !c || !p || !workspace || !out) return vt_fail(VT_ERR_INVALID, "vt_fusion_fwd: null argument");
     if (B <= 0 || N <= 0) return vt_fail(VT_ERR_INVALID, "vt_fusion_fwd: bad size");
-    if (p->d_model != 32 || p->key_dim != 64) return vt_fail(VT_ERR_UNSUPPORTED, "vt_fusion_fwd: d_model=32, key_feature_dim=64 only");
+    if (p->key_dim == 64 && p->d_model == 64) return fusion_fwd_wide<64>(c_img, c, B, N, p, workspace, workspace_bytes, out, (hipStream_t)stream);
+    if (p->key_dim == 64 && p->d_model == 96) return fusion_fwd_wide<96>(c_img, c, B, N, p, workspace, workspace_bytes, out, (hipStream_t)stream);
+    if (p->key_dim == 64 && p->d_model == 128) return fusion_fwd_wide<128>(c_img, c, B, N, p, workspace, workspace_bytes, out, (hipStream_t)stream);
+    if (p->d_model != 32 || p->key_dim != 64)
+        return vt_fail(VT_ERR_UNSUPPORTED, "vt_fusion_fwd: d_model in {32, 64, 96, 128} with key_feature_dim = 64 (workspace: vt_fusion_workspace_bytes_wide)");
     FusionWs w;
     if (workspace_bytes < fusion_layout(B, N, &w, (char *)workspace)) return vt_fail(VT_ERR_WORKSPACE, "vt_fusion_fwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;

@@ -1041,15 +1041,24 @@ def decode_mlp_bwd(blob_t, grad_out, save, pts, C=32):
     return grad_c, flat
 
 
-def decode_mlp_fwd(c, blob, pts, precision="f32"):
+def decode_mlp_fwd(c, blob, pts, precision="f32", wide=None):
     """The conditioned MLP on given features c [B,N,C] (vt_decode_mlp_fwd; ``precision="f16x3"`` with a blob packed for it:
-    vt_decode_mlp_fwd_f16x3)."""
-    if precision not in ("f32", "f16x3"):
-        raise VtError(f"decode_mlp_fwd: precision must be 'f32' or 'f16x3' (got {precision!r})")
-    c = _c(c)
+    vt_decode_mlp_fwd_f16x3).  ``precision="wide"`` / ``"wide_f16x3"`` with ``wide=(hidden_size, n_blocks, leaky)``: the shapes
+    beyond 32 / 32 (vt_decode_mlp_fwd_wide[_f16x3], blob from pack_decoder(..., precision="wide" / "wide_f16x3"))."""
+    if precision not in ("f32", "f16x3", "wide", "wide_f16x3"):
+        raise VtError(f"decode_mlp_fwd: precision must be 'f32', 'f16x3', 'wide' or 'wide_f16x3' (got {precision!r})")
+    c = _c(c.float())
     pts = _c(pts.float())
     B, N, C = c.shape
     out = torch.empty((B, N), dtype=torch.float32, device=c.device)
+    if N and precision in ("wide", "wide_f16x3"):
+        if wide is None:
+            raise VtError("decode_mlp_fwd: precision 'wide' needs wide=(hidden_size, n_blocks, leaky)")
+        hidden, nb, leaky = wide[:3]
+        name = "vt_decode_mlp_fwd_wide" if precision == "wide" else "vt_decode_mlp_fwd_wide_f16x3"
+        check(getattr(_lib.load(), name)(dev_ptr(c, "c"), B, C, dev_ptr(pts, "pts"), N, 0, 0.0, 0, dev_ptr(blob, "blob"),
+                                         int(hidden), int(nb), 1 if leaky else 0, dev_ptr(out, "out"), None, stream_ptr()), name)
+        return out
     if N:
         name = "vt_decode_mlp_fwd" if precision == "f32" else "vt_decode_mlp_fwd_f16x3"
         check(getattr(_lib.load(), name)(dev_ptr(c, "c"), B, C, dev_ptr(pts, "pts"), N, 0, 0.0, 0,
@@ -1084,7 +1093,9 @@ def fusion_fwd(c_img, c, self_attn, cross_attn):
         raise VtError(f"fusion: c_img {tuple(c_img.shape)} and c {tuple(c.shape)} must match")
     keep = []
     prm = _fusion_params(self_attn, cross_attn, C, keep)
-    nbytes = lib.vt_fusion_workspace_bytes(B, N)
+    nbytes = lib.vt_fusion_workspace_bytes_wide(B, N, C)              # (d_model 32, or the generic-width kernels up to 128)
+    if nbytes == 0:
+        raise VtError(f"fusion: d_model = {C} is not built (32, 64, 96 or 128 with key_feature_dim 64)")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=c.device)
     out = torch.empty((B, N, C), dtype=torch.float32, device=c.device)
     check(lib.vt_fusion_fwd(dev_ptr(c_img, "c_img"), dev_ptr(c, "c"), B, N, ctypes.byref(prm),

@@ -157,6 +157,13 @@ class TransformerFusion(nn.Module):
         layer = self.decoder.layers[0]
         if self.training and self.p_drop > 0:
             raise VtError("TransformerFusion.forward_ids is the eval-mode path (dropout would apply in train mode)")
+        if template_feature.shape[-1] != 32:
+            # d_model beyond 32 (vt_fusion_fwd's generic-width kernels take the dense rows): gather them from the table
+            feats = finger_feats.float()
+            table = torch.cat([feats, feats.new_zeros(1, feats.shape[1])])
+            rows = finger_ids if chunk_index is None else finger_ids[chunk_index.long()]
+            gathered = table[torch.where(rows == 255, torch.full_like(rows, feats.shape[0]), rows).long()]
+            return ops.fusion_fwd(gathered, template_feature, layer.self_attn.unit_tensors(), layer.cross_attn.unit_tensors())
         return ops.fusion_fwd_ids(finger_ids, finger_feats, template_feature, layer.self_attn.unit_tensors(),
                                   layer.cross_attn.unit_tensors(), chunk_index=chunk_index)
 
