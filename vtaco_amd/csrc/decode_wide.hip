@@ -406,6 +406,8 @@ decode_wide_bwd_kernel(WideBwdArgs a) {
 // fit beside the sampled features): a layer's output is written behind a barrier that waits for the readers of its input, i.e.
 // four barriers per block; the fc_c product of the next block, which reads the sampled features only, runs in front of the first.
 constexpr int WH_PTS = 64;
+// pairs of 32-point groups per workgroup tile: the waves a narrow layer leaves over take further pairs (LDS: <= 4 pairs)
+__host__ __device__ inline int wideh_pairs(int waves, int nh) { const int n = waves / nh; return n < 1 ? 1 : (n > 4 ? 4 : n); }
 struct WideHArgs {
     DecodeArgs d;
     const float *blob;
@@ -491,20 +493,24 @@ decode_wide_h_kernel(WideHArgs a) {
     const DecodeArgs &d = a.d;
     const int H = a.H, C = a.C, nh = H / 32, Kp = a.Kp;
     const int pc = wideh_pitch(C), pa = wideh_pitch(H > Kp ? H : Kp);
-    char *ch_ = whs, *cl_ = ch_ + WH_PTS * pc, *ah = cl_ + WH_PTS * pc, *al = ah + WH_PTS * pa;
-    float *heads = reinterpret_cast<float *>(al + WH_PTS * pa);     // [waves][2 lane halves][2 heads][64 points]
+    // narrow layers leave waves over (hidden 64: two 32-row blocks for four waves): the spare waves take further PAIRS of 32-point
+    // groups instead of idling -- wave w owns rows 32 (w % nh) of pair w / nh, the tile grows to `npair` pairs' worth of points, and a
+    // weight fragment streamed from L2 serves `npair` times the points (the second wave's load of it hits L1)
+    const int npair = wideh_pairs(WIDE_WAVES, nh), PTS = WH_PTS * npair;
+    char *ch_ = whs, *cl_ = ch_ + PTS * pc, *ah = cl_ + PTS * pc, *al = ah + PTS * pa;
+    float *heads = reinterpret_cast<float *>(al + PTS * pa);       // [waves][2 lane halves][2 heads][64 points of the wave's pair]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kg = lane >> 5;
     const WideLayout lay = wide_layout(H, C, a.nb, Kp);
     const float *bias = a.blob + lay.bias;
-    const uint32_t ntiles = (d.total + WH_PTS - 1) / WH_PTS;
+    const uint32_t ntiles = (d.total + PTS - 1) / PTS;
     unsigned rmax = 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // ---- the tile's inputs as half pairs: sampled features c (decoder.py:62-68), fc_p's input rows [p | c_img | 0] ----
         {
             constexpr int PG = WIDE_THREADS / 32;
             const int ch = tid & 31, pg = tid >> 5;
-            for (int pt = pg; pt < WH_PTS; pt += PG) {
-                uint32_t g = tile * WH_PTS + pt;
+            for (int pt = pg; pt < PTS; pt += PG) {
+                uint32_t g = tile * PTS + pt;
                 if (g >= d.total) g = d.total - 1u;
                 const uint32_t b = g / d.N;
                 float px, py, pz;
@@ -547,13 +553,15 @@ decode_wide_h_kernel(WideHArgs a) {
             }
         }
         __syncthreads();
-        const int ob = wave;                                        // nh <= WIDE_WAVES; waves beyond the width only keep the barriers
-        const bool on = ob < nh;
+        const int ob = wave % nh, pr = wave / nh;                   // nh <= WIDE_WAVES; waves beyond nh * npair only keep the barriers
+        const bool on = pr < npair;
+        // this wave's pair of point groups: rows 64 pr .. 64 pr + 63 of the planes
+        char *const chp = ch_ + pr * WH_PTS * pc, *const clp = cl_ + pr * WH_PTS * pc, *const ahp = ah + pr * WH_PTS * pa, *const alp = al + pr * WH_PTS * pa;
         // ---- fc_p (decoder.py:139 / 81) ----
         f32x16 net0, net1;
         if (on) {
             net0 = bias16(bias, ob, kg); net1 = net0;
-            wideh_gemm<AH>(net0, net1, a.blob + lay.w_p, ob, Kp, ah, al, pa, lane);
+            wideh_gemm<AH>(net0, net1, a.blob + lay.w_p, ob, Kp, ahp, alp, pa, lane);
         }
         // ---- n_blocks x (fc_c add, ResnetBlockFC: layers.py:41-50; its activations are ReLU) ----
         for (int blk = 0; blk < a.nb; ++blk) {
@@ -563,30 +571,30 @@ decode_wide_h_kernel(WideHArgs a) {
                 const f32x16 bc = bias16(bb, ob, kg);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { net0[i] += bc[i]; net1[i] += bc[i]; }
-                wideh_gemm<AH>(net0, net1, wb, ob, C, ch_, cl_, pc, lane);
+                wideh_gemm<AH>(net0, net1, wb, ob, C, chp, clp, pc, lane);
             }
             __syncthreads();                                        // the readers of the activation buffer (fc_p / the last fc_1) are done
             if (on) {
-                wideh_store(ah, al, pa, j, ob, kg, net0, rmax);
-                wideh_store(ah, al, pa, j + 32, ob, kg, net1, rmax);
+                wideh_store(ahp, alp, pa, j, ob, kg, net0, rmax);
+                wideh_store(ahp, alp, pa, j + 32, ob, kg, net1, rmax);
             }
             __syncthreads();
             f32x16 hid0, hid1;
             if (on) {
                 hid0 = bias16(bb + H, ob, kg); hid1 = hid0;
-                wideh_gemm<AH>(hid0, hid1, wb + lay.w_c, ob, H, ah, al, pa, lane);
+                wideh_gemm<AH>(hid0, hid1, wb + lay.w_c, ob, H, ahp, alp, pa, lane);
             }
             __syncthreads();                                        // fc_0's readers are done
             if (on) {
-                wideh_store(ah, al, pa, j, ob, kg, hid0, rmax);
-                wideh_store(ah, al, pa, j + 32, ob, kg, hid1, rmax);
+                wideh_store(ahp, alp, pa, j, ob, kg, hid0, rmax);
+                wideh_store(ahp, alp, pa, j + 32, ob, kg, hid1, rmax);
             }
             __syncthreads();
             if (on) {
                 const f32x16 b1 = bias16(bb + 2 * H, ob, kg);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { net0[i] += b1[i]; net1[i] += b1[i]; }
-                wideh_gemm<AH>(net0, net1, wb + lay.w_c + lay.w_0, ob, H, ah, al, pa, lane);
+                wideh_gemm<AH>(net0, net1, wb + lay.w_c + lay.w_0, ob, H, ahp, alp, pa, lane);
             }
         }
         // ---- fc_out / fc_out_contact on actvn(net) (decoder.py:157-158, 128-131): f32 dot products, as in the exact kernel ----
@@ -607,12 +615,12 @@ decode_wide_h_kernel(WideHArgs a) {
             heads[((wave * 2 + kg) * 2 + 1) * WH_PTS + j + 32 * g] = o2[g];
         }
         __syncthreads();
-        if (tid < 2 * WH_PTS) {
-            const int pt = tid & (WH_PTS - 1), which = tid >> 6;
+        for (int e = tid; e < 2 * PTS; e += WIDE_THREADS) {
+            const int pt = e % PTS, which = e / PTS, pp = pt / WH_PTS, q = pt % WH_PTS;
             float o = which ? ow2[H] : ow[H];
-#pragma unroll
-            for (int w = 0; w < 2 * WIDE_WAVES; ++w) o += heads[(w * 2 + which) * WH_PTS + pt];       // waves and lane halves in a fixed order
-            const uint32_t g = tile * WH_PTS + pt;
+            for (int w = 2 * pp * nh; w < 2 * (pp + 1) * nh; ++w)     // the waves of this point's pair and their lane halves, in a fixed order
+                o += heads[(w * 2 + which) * WH_PTS + q];
+            const uint32_t g = tile * PTS + pt;
             float *dst = which ? d.out2 : d.out;
             if (g < d.total && dst) dst[g] = o;
         }
@@ -829,7 +837,8 @@ static int wideh_fwd_impl(const float *grid_cl, int B, int R, int C, const float
     a.status = vt_decode_status_dev();
     const int waves = hidden <= 128 ? 4 : 8;
     const int wid = hidden > a.Kp ? hidden : a.Kp;
-    const size_t lds = (size_t)2 * WH_PTS * wideh_pitch(C) + (size_t)2 * WH_PTS * wideh_pitch(wid) + (size_t)waves * 2 * 2 * WH_PTS * sizeof(float);
+    const int tile_pts = WH_PTS * wideh_pairs(waves, hidden / 32);
+    const size_t lds = (size_t)2 * tile_pts * wideh_pitch(C) + (size_t)2 * tile_pts * wideh_pitch(wid) + (size_t)waves * 2 * 2 * WH_PTS * sizeof(float);
     bool attr = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr) {
         hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_wide_h_kernel<4>), 160 * 1024);
@@ -837,7 +846,7 @@ static int wideh_fwd_impl(const float *grid_cl, int B, int R, int C, const float
         if (e != hipSuccess) return vt_check(e, "vt_decode_fwd_wide_f16x3: hipFuncSetAttribute");
         attr = true;
     }
-    const uint32_t ntiles = (a.d.total + WH_PTS - 1) / WH_PTS;
+    const uint32_t ntiles = (a.d.total + tile_pts - 1) / tile_pts;
     const uint32_t cap = (uint32_t)vt_num_cus() * 4u;
     const dim3 grid(ntiles < cap ? ntiles : cap);
     if (waves == 4) hipLaunchKernelGGL(decode_wide_h_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, a);
