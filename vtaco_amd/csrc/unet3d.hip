@@ -1411,6 +1411,24 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
         const __amdgpu_buffer_rsrc_t r_skip = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.skip), 0, nscene * (unsigned)(s.D * s.H * s.W) * (unsigned)s.C1 * 4u, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_low = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.low ? s.low : s.skip), 0,
                                                                                 s.low ? nscene * (unsigned)(D2 * H2 * W2) * (unsigned)s.C2 * 4u : 0u, 0x00020000);
+        const unsigned lane16 = (unsigned)lane * 16u, lds0 = (unsigned)(size_t)hl;
+        int d_q = 0;
+        auto dma_w = [&](int n) {
+            const int q = d_q;
+            if (++d_q == ncq) d_q = 0;
+            const char *wq = reinterpret_cast<const char *>(a.wp) + ((size_t)q * nco_all + co_blk) * (HB_WFRAGS * 16);
+            const unsigned dst = lds0 + 2 * IMG + (n & 1) * WBUF;
+            // a FIXED number of DMA instructions per wave (the last piece is issued twice by some waves: same bytes to the same place);
+            // inline assembly: `scalar piece base + the lane's 32-bit offset` (through the builtin the compiler keeps a per-lane 64-bit
+            // address of every piece in registers and adds one vector instruction per piece)
+            constexpr int NP = HB_WFRAGS / 64, PW = (NP + TZ - 1) / TZ;
+#pragma unroll
+            for (int i = 0; i < PW; ++i) {
+                const int p = min(lwave + i * TZ, NP - 1);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + p * 1024), "v"(lane16), "s"(wq + p * 1024) : "memory");
+            }
+        };
+        if (N > 0) dma_w(0);                                        // chunk 0's weights travel while the item tables are built
         // per item, once: its halo position, its LDS row, and its byte offsets from the tile origin in the full-resolution source and in
         // the half-resolution `low` source (tile origins are multiples of 8, so the halving distributes)
         int pxyz[ITERS], lrow[ITERS], voff[ITERS], loff[ITERS];
@@ -1429,23 +1447,6 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
         // two register sets for the input prefetch: chunk n lives in set n & 1 and is requested two chunks ahead
         struct PreSet { f32x4 v[2 * ITERS]; unsigned in; };
         PreSet preA, preB;
-        const unsigned lane16 = (unsigned)lane * 16u, lds0 = (unsigned)(size_t)hl;
-        int d_q = 0;
-        auto dma_w = [&](int n) {
-            const int q = d_q;
-            if (++d_q == ncq) d_q = 0;
-            const char *wq = reinterpret_cast<const char *>(a.wp) + ((size_t)q * nco_all + co_blk) * (HB_WFRAGS * 16);
-            const unsigned dst = lds0 + 2 * IMG + (n & 1) * WBUF;
-            // a FIXED number of DMA instructions per wave (the last piece is issued twice by some waves: same bytes to the same place);
-            // inline assembly: `scalar piece base + the lane's 32-bit offset` (through the builtin the compiler keeps a per-lane 64-bit
-            // address of every piece in registers and adds one vector instruction per piece)
-            constexpr int NP = HB_WFRAGS / 64, PW = (NP + TZ - 1) / TZ;
-#pragma unroll
-            for (int i = 0; i < PW; ++i) {
-                const int p = min(lwave + i * TZ, NP - 1);
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + p * 1024), "v"(lane16), "s"(wq + p * 1024) : "memory");
-            }
-        };
         int f_q = 0, f_k = 0;
         unsigned vo[ITERS], lo[ITERS];                             // this tile's byte offsets of the items (wrapped when in front of the tensor)
         unsigned f_in = 0;                                         // which items of the current tile lie inside the volume
@@ -1536,16 +1537,22 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
         };
         constexpr int REQ = 2 * ITERS;
         constexpr int WAIT_DMA = 0x0F70 | (REQ > 15 ? 15 : REQ);  // vmcnt(REQ): all but the youngest request (the register fetch) have landed
+        // (all workgroups of a launch start together, and what they request first comes in at ~11 bytes per cycle and CU: chunk 0 and its
+        // weights travel alone; chunk 1's request follows chunk 0's commit -- VT_CONV_EARLY_REQ: the former order, for A/B)
         if (N > 0) {
-            dma_w(0);
             fetch(preA);
+#ifdef VT_CONV_EARLY_REQ
             if (N > 1) fetch(preB);
+#endif
         }
         HB_STAMP(10);
         if (stats_in) gn_in_finish<true, GN_PRE, true>(a.stat_in, gn_rq, b, pre_scale, ssl, hl, threadIdx.x, THREADS);
         HB_STAMP(11);
         if (N > 0) {
             commit(0, preA);
+#ifndef VT_CONV_EARLY_REQ
+            if (N > 1) fetch(preB);
+#endif
             if (N > 2) fetch(preA);
         }
         HB_STAMP(12);
