@@ -84,8 +84,9 @@ def test_unsupported_configurations_raise():
     assert decoder_dict["simple_local"](dim=3, c_dim=32, hidden_size=32, sample_mode="nearest")._wide   # F.grid_sample's other mode: wide kernel
     with pytest.raises(VtError):
         decoder_dict["simple_local"](dim=3, c_dim=32, hidden_size=32, sample_mode="bicubic")         # not a 5-D grid_sample mode
+    assert decoder_dict["attention_local"](dim=3, c_dim=128, hidden_size=256)._wide               # the reference's default widths: built (round 5)
     with pytest.raises(VtError):
-        decoder_dict["attention_local"](dim=3, c_dim=64, hidden_size=64)                          # fusion kernels: the shipped shape only
+        decoder_dict["attention_local"](dim=3, c_dim=160, hidden_size=64)                         # fusion kernels: d_model 32 / 64 / 96 / 128
     with pytest.raises(KeyError):
         decoder_dict["simple_local_crop"]
 
@@ -331,6 +332,8 @@ def test_range_guard_walks_f16f8_to_f16x3_to_bf16x3_and_stays_rank_local(monkeyp
             self.decode_precision, self.device, self.calls = precision, None, []
             self.model = type("M", (), {"decoder": type("D", (), {})()})()
 
+        _set_decode_precision = gen_mod.Generator3D._set_decode_precision
+
         @gen_mod._range_guarded
         def make(self, x):
             self.calls.append(self.decode_precision)
@@ -340,11 +343,12 @@ def test_range_guard_walks_f16f8_to_f16x3_to_bf16x3_and_stays_rank_local(monkeyp
         raise AssertionError("a collective was reached from a non-sharded entry point")
     for name in ("all_reduce", "broadcast", "all_gather", "barrier"):
         monkeypatch.setattr(dist, name, forbid)
-    words = []
+    words, clears = [], []
     monkeypatch.setattr(ops, "decode_range_status", lambda reset=True: words.pop(0) if words else 0)
+    monkeypatch.setattr(ops, "decode_range_clear", lambda: clears.append(1))     # the scene-start clear (asynchronous on the device)
     # clean
     g = Dummy("f16f8")
-    assert g.make(1) == (1, "f16f8") and g.calls == ["f16f8"]
+    assert g.make(1) == (1, "f16f8") and g.calls == ["f16f8"] and clears == [1]    # one clear per guarded scene, before its launches
     # the fp8 copies clipped, then the half range too: two moves, three generations
     g, words[:] = Dummy("f16f8"), [ops.RANGE_FP8, ops.RANGE_HALF, 0]
     with warnings.catch_warnings(record=True) as w:
@@ -366,7 +370,8 @@ def test_range_guard_walks_f16f8_to_f16x3_to_bf16x3_and_stays_rank_local(monkeyp
         assert g.make(5) == (5, "bf16x3") and g.model.decoder.mlp_precision == "f32"
     # other precisions are not guarded at all (no status read)
     g, words[:] = Dummy("f32"), [ops.RANGE_HALF]
-    assert g.make(6) == (6, "f32") and words == [ops.RANGE_HALF]
+    n_clears = len(clears)
+    assert g.make(6) == (6, "f32") and words == [ops.RANGE_HALF] and len(clears) == n_clears
 
 
 def test_wide_decoder_precision_routing_and_encoder_skip_switch(monkeypatch):
