@@ -309,3 +309,21 @@ def test_empty_query_sets_under_autograd():
     from vtaco_amd import ops
     gg = ops.sample_grid_bwd((1, 32, 8, 8, 8), torch.zeros(1, 0, 3, device=DEV), torch.zeros(1, 0, 32, device=DEV))
     assert float(gg.abs().max()) == 0.0
+
+
+def test_wide_split_f16_tile_fits_the_lds_at_every_width():
+    """Regression (found by tests/stress_gpu.py): narrow hidden layers let spare waves take further point-group pairs, and the tile's
+    activation planes grow with them -- at hidden 32 / c_dim 256 four pairs would need 270 KB of LDS.  The launcher caps the pairs by
+    what fits; every corner of the (hidden, c_dim) range must launch and agree with the exact kernel."""
+    g = torch.Generator().manual_seed(31)
+    for hidden, c_dim in ((32, 256), (32, 32), (64, 256), (96, 160), (128, 256), (256, 32)):
+        dec = _decoder(hidden, c_dim, 1, True, seed=hidden + c_dim)
+        grid = torch.randn(1, c_dim, 4, 4, 4, generator=g).to(DEV)
+        p = ((torch.rand(1, 300, 3, generator=g) - 0.5) * 1.1).to(DEV)
+        c_img = torch.randn(1, 300, c_dim, generator=g).to(DEV)
+        with torch.no_grad():
+            dec.precision = "f32"
+            ref = dec.forward_img(p, {"grid": grid}, c_img)
+            dec.precision = "f16x3"
+            got = dec.forward_img(p, {"grid": grid}, c_img)
+        assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), (hidden, c_dim)

@@ -413,6 +413,7 @@ struct WideHArgs {
     const float *blob;
     int H, C, nb, Kp, p_in, leaky, nearest;
     unsigned *status;
+    int npair;                  // pairs of 32-point groups per workgroup tile (the launcher sizes it: spare waves, LDS)
 };
 __host__ __device__ inline int wideh_pitch(int ch) { return ch * 2 + 16; }             // bytes per point row of a half plane: 16 lanes x 16 bytes tile the 64 banks
 
@@ -496,7 +497,7 @@ decode_wide_h_kernel(WideHArgs a) {
     // narrow layers leave waves over (hidden 64: two 32-row blocks for four waves): the spare waves take further PAIRS of 32-point
     // groups instead of idling -- wave w owns rows 32 (w % nh) of pair w / nh, the tile grows to `npair` pairs' worth of points, and a
     // weight fragment streamed from L2 serves `npair` times the points (the second wave's load of it hits L1)
-    const int npair = wideh_pairs(WIDE_WAVES, nh), PTS = WH_PTS * npair;
+    const int npair = a.npair, PTS = WH_PTS * npair;
     char *ch_ = whs, *cl_ = ch_ + PTS * pc, *ah = cl_ + PTS * pc, *al = ah + PTS * pa;
     float *heads = reinterpret_cast<float *>(al + PTS * pa);       // [waves][2 lane halves][2 heads][64 points of the wave's pair]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kg = lane >> 5;
@@ -837,8 +838,14 @@ static int wideh_fwd_impl(const float *grid_cl, int B, int R, int C, const float
     a.status = vt_decode_status_dev();
     const int waves = hidden <= 128 ? 4 : 8;
     const int wid = hidden > a.Kp ? hidden : a.Kp;
-    const int tile_pts = WH_PTS * wideh_pairs(waves, hidden / 32);
-    const size_t lds = (size_t)2 * tile_pts * wideh_pitch(C) + (size_t)2 * tile_pts * wideh_pitch(wid) + (size_t)waves * 2 * 2 * WH_PTS * sizeof(float);
+    // pairs of point groups per tile: what the spare waves can take, as far as the planes fit the LDS
+    int npair = wideh_pairs(waves, hidden / 32);
+    auto lds_of = [&](int np) { return (size_t)2 * WH_PTS * np * wideh_pitch(C) + (size_t)2 * WH_PTS * np * wideh_pitch(wid) + (size_t)waves * 2 * 2 * WH_PTS * sizeof(float); };
+    while (npair > 1 && lds_of(npair) > 150 * 1024) --npair;
+    a.npair = npair;
+    const int tile_pts = WH_PTS * npair;
+    const size_t lds = lds_of(npair);
+    if (lds > 160 * 1024) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd_wide_f16x3: the activation planes of this shape do not fit the LDS");
     bool attr = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr) {
         hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_wide_h_kernel<4>), 160 * 1024);
