@@ -582,3 +582,26 @@ def test_decoder_entry_per_parity_conv_vs_torch_cpu():
                                 ops.conv3d_pack(wd), Cout, packed_w_f16x3=ops.conv3d_pack(wd, precision="f16x3"),
                                 packed_w_up=ops.conv3d_pack_up(wd, C1))
     assert float((got.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_decoder_entry_per_parity_conv_on_a_non_cubic_volume():
+    """D != H != W (the layered forward's case, unet3d.py:449-474 on any volume): the tile walk, the parity-split image and the low halo
+    take their extents per axis."""
+    from vtaco_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(24)
+    for B, D, H, W, C1, C2, Cout in ((1, 32, 16, 64, 32, 64, 32), (2, 16, 64, 32, 32, 32, 64)):
+        assert lib.vt_conv3d_up_covers(C1, C2, B, D, H, W, Cout)
+        x = torch.randn(B, D, H, W, C1, generator=g).to(DEV)
+        low = torch.randn(B, D // 2, H // 2, W // 2, C2, generator=g).to(DEV)
+        w = (torch.randn(Cout, C1 + C2, 3, 3, 3, generator=g) * 0.05).to(DEV)
+        gamma = (1 + 0.2 * torch.randn(C1 + C2, generator=g)).to(DEV)
+        beta = (0.2 * torch.randn(C1 + C2, generator=g)).to(DEV)
+        xs, ls = ops.channel_stats(x), ops.channel_stats(low)
+        pf, ph, pu = ops.conv3d_pack(w), ops.conv3d_pack(w, precision="f16x3"), ops.conv3d_pack_up(w, C1)
+        ref, _ = ops.gn_conv3d_relu(x, xs, low, ls, gamma, beta, 8, pf, Cout)
+        got, _ = ops.gn_conv3d_relu(x, xs, low, ls, gamma, beta, 8, pf, Cout, packed_w_f16x3=ph, packed_w_up=pu)
+        old, _ = ops.gn_conv3d_relu(x, xs, low, ls, gamma, beta, 8, pf, Cout, packed_w_f16x3=ph)
+        assert not torch.equal(got, old)
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((got - ref).abs().max()) <= 1.5e-7 * (27 * (C1 + C2)) ** 0.5 * scale, (B, D, H, W)
