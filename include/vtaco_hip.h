@@ -498,9 +498,10 @@ int vt_voxel_build(const float *pts, int B, int T, int R, double padding,
 /* the workgroups the sort leaves idle: the torch.zeros of generate_grid_features (pointnet.py:102-110) without a launch of its own. */
 int vt_voxel_build_clear(const float *pts, int B, int T, int R, double padding,
                          int *idx, int *order, int *seg_lo, int *seg_hi, void *clear, size_t clear_bytes, void *stream);
-/* flags [B][(R/8)^3] bytes: 1 where no point of the scene lies in the 10^3 halo of that 8^3 voxel block, i.e. the mean grid of   */
-/* generate_grid_features (pointnet.py:102-110) is zero over everything a 3x3x3 conv of the block reads (idx from vt_voxel_build; */
-/* R a multiple of 8, at most 128).  Consumed by vt_unet3d_fwd_skip / vt_conv3d_gcr_f16x3_skip.                                  */
+/* flags [B][(R/8)^3] bytes: bit 0 where no point of the scene lies in the 10^3 halo of that 8^3 voxel block, i.e. the mean grid  */
+/* of generate_grid_features (pointnet.py:102-110) is zero over everything a 3x3x3 conv of the block reads; bit 1 where none lies */
+/* in its 12^3 halo either (what a second 3x3x3 conv behind the first depends on): values 0, 1 and 3 (idx from vt_voxel_build;    */
+/* R a multiple of 8, at most 128).  Consumed by vt_unet3d_fwd_skip / vt_conv3d_gcr_f16x3_skip (any non-zero flag skips there).  */
 int vt_voxel_tile_flags(const int *idx, int B, int T, int R, unsigned char *flags, void *stream);
 /* vt_voxel_build_clear (clear may be NULL with clear_bytes 0) that leaves those flags as well: the sorting workgroup marks the blocks */
 /* while it computes the voxel ids (no launch of its own, no second pass over the points).                                       */
@@ -673,7 +674,13 @@ int vt_unet3d_fwd(const float *x_cl, int B, int R, const vt_unet3d_params *param
 int vt_unet3d_fwd_stats(const float *x_cl, const float *in_part, int in_nblk, int B, int R, const vt_unet3d_params *params_host,
                         void *workspace, size_t workspace_bytes, float *out, void *stream);
 /* vt_unet3d_fwd / vt_unet3d_fwd_stats (in_part may be NULL: statistics pass over x) with the first layer's empty blocks skipped:   */
-/* tile_flags [B][(R/8)^3] from vt_voxel_tile_flags on the cloud that x was scattered from (vt_conv3d_gcr_f16x3_skip).              */
+/* tile_flags [B][(R/8)^3] from vt_voxel_tile_flags on the cloud that x was scattered from (vt_conv3d_gcr_f16x3_skip).  Where the    */
+/* first DoubleConv is 32 -> 32 -> 32 channels with 8 groups (unet3d.py:96-127, the shipped f_maps) the SECOND layer skips the       */
+/* blocks whose 12^3 halo is empty (flag bit 1) as well: the first layer's output is a constant per border class around them, so    */
+/* the second's is one per class of a two-voxel rim (125 classes) -- sums over taps of W2 gamma2 relu(K1), W2 gamma2 and W2 beta2     */
+/* that the first launch leaves per GroupNorm group, combined with the second GroupNorm's statistics by the second launch.          */
+/* vt_unet3d_skip_layers: how many layers of this network take the flags at this batch and resolution (0, 1 or 2).                 */
+int vt_unet3d_skip_layers(int B, int R, const vt_unet3d_params *params_host);
 int vt_unet3d_fwd_skip(const float *x_cl, const float *in_part, int in_nblk, const unsigned char *tile_flags, int B, int R,
                        const vt_unet3d_params *params_host, void *workspace, size_t workspace_bytes, float *out, void *stream);
 int vt_maxpool3d_cl(const float *x, int B, int D, int H, int W, int C, float *out, void *stream);

@@ -78,7 +78,7 @@ def test_config2_end_to_end_at_the_shipped_shape(shipped, enc_precision, dec_pre
         from vtaco_amd import _lib, ops as _ops
         assert enc.skip_empty and enc.unet3d.hip_supported()
         flags = _ops.VoxelIndex(s["cloud"].to(DEV), enc.reso_grid, enc.padding, want_tile_flags=True).tile_flags
-        assert flags is not None and 0 < int(flags.sum()) < flags.numel(), "the scene must have empty AND occupied 8^3 blocks"
+        assert flags is not None and 0 < int((flags != 0).sum()) < flags.numel(), "the scene must have empty AND occupied 8^3 blocks"
         if enc_precision == "f16x3":
             up = enc.unet3d.decoders[-1].basic_module.SingleConv1.conv
             assert enc.unet3d._packed_up(up, up.out_channels) is not None

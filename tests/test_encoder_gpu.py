@@ -582,13 +582,17 @@ def test_rows_wgrad_and_resblock_bwd_vs_torch():
 def test_encoder_skips_the_empty_blocks_of_the_first_layer():
     """LocalPoolPointnet at the shipped shape (64^3 grid, UNet3D f_maps 32): the inference path hands the UNet3D the blocks of the mean
     grid that no point comes near (ops.voxel_tile_flags) and its first layer fills them from the per-border-class constant instead of
-    running their taps -- same grid as the dense first layer to f32 rounding, for the one-launch PointNet and the module path."""
+    running their taps; the second layer does the same over the blocks with an empty 12^3 halo (125 classes of a two-voxel rim) -- same
+    grid as the dense layers to f32 rounding, for the one-launch PointNet and the module path."""
     from vtaco_amd.bench_util import sphere_cloud
     from vtaco_amd.encoder import encoder_dict
     torch.manual_seed(5)
     enc = encoder_dict['pointnet_local_pool'](c_dim=32, dim=3, hidden_dim=32, unet3d=True, grid_resolution=64, plane_type='grid',
                                               unet3d_kwargs=dict(num_levels=3, f_maps=32, in_channels=32, out_channels=32)).to(DEV).eval()
     assert enc.skip_empty
+    from vtaco_amd import ops
+    # (the shipped first DoubleConv is 32 -> 32 -> 32 with 8 groups: its second layer takes the flags too)
+    assert ops.unet3d_skip_layers(2, 64, enc.unet3d._hip_params()[0]) == 2
     pc = torch.cat([sphere_cloud(0), sphere_cloud(1) * 0.5 + 0.2]).to(DEV)
     with torch.no_grad():
         sparse = enc(pc)["grid"]
@@ -616,7 +620,7 @@ def test_block_flags_from_the_voxel_sort_equal_the_standalone_kernel():
         assert torch.equal(vi.idx, ref.idx) and torch.equal(vi.order, ref.order) and float(clear.abs().max()) == 0.0
         want = ops.voxel_tile_flags(ref)
         assert vi.tile_flags is not None and torch.equal(vi.tile_flags, want)
-        assert spread > 0.3 or R == 8 or 0 < int(want.sum()) < want.numel()         # a compact cloud leaves empty blocks
+        assert spread > 0.3 or R == 8 or 0 < int((want != 0).sum()) < want.numel()       # a compact cloud leaves empty blocks
         assert torch.equal(ops.VoxelIndex(p, R, 0.1, want_tile_flags=True).tile_flags, want)
     assert ops.VoxelIndex(p, 12, 0.1, want_tile_flags=True).tile_flags is None      # not a multiple of 8: no flags, dense first layer
 

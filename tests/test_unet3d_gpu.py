@@ -471,7 +471,7 @@ def test_split_f16_conv_variants_agree_bit_for_bit():
 
 def _sparse_case(B, R, C, g, n_pts, lo=0.0, hi=1.0):
     """A channels-last grid that is zero except at the voxels of a random cloud, the cloud's voxel ids, and the numpy rule for the
-    flags: 1 = no point in the 10^3 halo of the 8^3 block."""
+    flags: bit 0 = no point in the 10^3 halo of the 8^3 block, bit 1 = none in its 12^3 halo either (values 0, 1, 3)."""
     import numpy as np
     xyz = (torch.rand(B, n_pts, 3, generator=g) * (hi - lo) + lo).clamp(0, 0.999)
     v = (xyz * R).long()
@@ -487,7 +487,8 @@ def _sparse_case(B, R, C, g, n_pts, lo=0.0, hi=1.0):
             for ty in range(nt):
                 for tx in range(nt):
                     sub = occ[b, max(8 * tz - 1, 0):8 * tz + 9, max(8 * ty - 1, 0):8 * ty + 9, max(8 * tx - 1, 0):8 * tx + 9]
-                    flags[b, tz, ty, tx] = 0 if sub.any() else 1
+                    sub2 = occ[b, max(8 * tz - 2, 0):8 * tz + 10, max(8 * ty - 2, 0):8 * ty + 10, max(8 * tx - 2, 0):8 * tx + 10]
+                    flags[b, tz, ty, tx] = (0 if sub.any() else 1) | (0 if sub2.any() else 2)
     return x.reshape(B, R, R, R, C), idx, flags.reshape(B, -1)
 
 
@@ -511,7 +512,7 @@ def test_tile_flags_and_the_first_layer_without_its_empty_blocks():
         assert flags.dtype == torch.uint8 and flags.shape == (B, (R // 8) ** 3)
         assert (flags.cpu().numpy() == want).all()
         if B == 2 and n_pts == 400:
-            flags[1] = 1                                              # ... and the empty scene skips every block
+            flags[1] = 3                                              # ... and the empty scene skips every block
         w = (torch.randn(Cout, C, 3, 3, 3, generator=g) * 0.05).to(DEV)
         gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV), (0.3 * torch.randn(C, generator=g)).to(DEV)
         xs = ops.channel_stats(x)
@@ -519,13 +520,50 @@ def test_tile_flags_and_the_first_layer_without_its_empty_blocks():
         ph = ops.conv3d_pack(w, precision="f16x3")
         ref, (rp, rn) = ops.conv3d_gcr(x, None, ss, None, Cout, True, None, packed_w_f16x3=ph)
         got, (gp, gn) = ops.conv3d_gcr_skip(x, ss, ph, Cout, flags)
-        assert gn == rn and int(flags.sum()) > 0
+        assert gn == rn and int((flags != 0).sum()) > 0
         scale = max(1.0, float(ref.abs().max()))
         assert float((got - ref).abs().max()) <= 2e-6 * scale, (B, R, C, Cout, float((got - ref).abs().max()), scale)
         # (the workgroups walk other tiles than in the dense launch: the per-workgroup rows differ, their sums agree)
         assert float((gp.sum(1) - rp.sum(1)).abs().max()) <= 2e-5 * float(rp.sum(1).abs().max())
         none, _ = ops.conv3d_gcr_skip(x, ss, ph, Cout, torch.zeros_like(flags))
         assert torch.equal(none, ref)                                 # nothing flagged: the dense walk through the lists, same bits
+
+
+def test_second_layer_without_the_blocks_whose_rim_is_empty(monkeypatch):
+    """vt_unet3d_fwd_skip on a 32 -> 32 -> 32 first DoubleConv: the second layer skips the blocks whose 12^3 halo holds no point (flag
+    bit 1) -- around them the first layer's output is a constant per border class, so the second's is one per class of a two-voxel rim
+    (125 classes: every corner, edge and face of the volume is covered by a cloud in the middle), from class rows the first launch
+    leaves.  Against the second layer run densely (VTACO_CONV_SKIP2=0) and against the network without flags: one scene, a batch of two
+    with a cloud that touches faces of the volume and a scene without points, a batch of three (85 workgroups per scene: the class rows
+    dealt in two parts), and a 32^3 volume, where only the first layer takes the flags."""
+    from types import SimpleNamespace
+    from vtaco_amd import ops
+    g = torch.Generator().manual_seed(77)
+    for B, R, levels, n_pts, lo, hi in ((1, 64, 3, 600, 0.3, 0.7), (2, 64, 3, 500, 0.0, 0.45), (3, 64, 3, 900, 0.55, 1.0), (2, 32, 3, 30, 0.55, 1.0)):
+        net = _unet(32, levels, 11 + R + B).to(DEV)
+        net.precision = "f16x3"
+        x, idx, want = _sparse_case(B, R, 32, g, n_pts, lo, hi)
+        if B == 2 and R == 64:
+            x[1] = 0
+        x, idx = x.to(DEV), idx.to(DEV)
+        flags = ops.voxel_tile_flags(SimpleNamespace(idx=idx.contiguous(), B=B, T=idx.shape[1], R=R))
+        assert (flags.cpu().numpy() == want).all() and int((flags == 3).sum()) > 0
+        if B == 2 and R == 64:
+            flags[1] = 3
+        prm = net._hip_params()[0]
+        monkeypatch.setenv("VTACO_CONV_SKIP2", "1")
+        assert ops.unet3d_skip_layers(B, R, prm) == (2 if R == 64 else 1)
+        with torch.no_grad():
+            dense = net.forward_channels_last(x).clone()
+            both = net.forward_channels_last(x, tile_flags=flags).clone()
+            again = net.forward_channels_last(x, tile_flags=flags).clone()
+            monkeypatch.setenv("VTACO_CONV_SKIP2", "0")
+            assert ops.unet3d_skip_layers(B, R, prm) == 1
+            first = net.forward_channels_last(x, tile_flags=flags).clone()
+        assert torch.equal(both, again)
+        scale = max(1.0, float(dense.abs().max()))
+        e2, e1 = float((both - first).abs().max()), float((both - dense).abs().max())
+        assert (0.0 < e2 if R == 64 else e2 == 0.0) and e2 <= 4e-6 * scale and e1 <= 4e-6 * scale, (B, R, e2, e1, scale)
 
 
 def test_decoder_entry_per_parity_conv_matches_the_27_tap_kernels():

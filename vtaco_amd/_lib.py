@@ -209,6 +209,7 @@ SIGNATURES = {
     "vt_unet3d_workspace_bytes": (_SZ, [_I, _I, ctypes.POINTER(UnetParams)]),
     "vt_unet3d_fwd": (_I, [_VP, _I, _I, ctypes.POINTER(UnetParams), _VP, _SZ, _VP, _VP]),
     "vt_unet3d_fwd_stats": (_I, [_VP, _VP, _I, _I, _I, ctypes.POINTER(UnetParams), _VP, _SZ, _VP, _VP]),
+    "vt_unet3d_skip_layers": (_I, [_I, _I, ctypes.POINTER(UnetParams)]),
     "vt_unet3d_fwd_skip": (_I, [_VP, _VP, _I, _VP, _I, _I, ctypes.POINTER(UnetParams), _VP, _SZ, _VP, _VP]),
     "vt_conv3d_gcr_f16x3_skip": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP]),
     "vt_voxel_tile_flags": (_I, [_VP, _I, _I, _I, _VP, _VP]),

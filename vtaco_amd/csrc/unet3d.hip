@@ -141,8 +141,10 @@ __device__ __forceinline__ void gn_barrier() {
 template <bool QUAD>
 __device__ __forceinline__ int gn_slot(int c, int shift) { return QUAD ? (c >> 2) * 8 + shift * 4 + (c & 3) : c * 2 + shift; }
 
+// grp (or null): [group][mean, rstd] as floats, somewhere that outlives the scratch
 template <bool LDS_ONLY, int GN_PRE, bool QUAD = false>
-__device__ __forceinline__ void gn_in_finish(const GnIn &in, const GnReq<GN_PRE> &r, int b, float pre, float *ssl, void *scratch, int tid, int nthr) {
+__device__ __forceinline__ void gn_in_finish(const GnIn &in, const GnReq<GN_PRE> &r, int b, float pre, float *ssl, void *scratch, int tid, int nthr,
+                                             float *grp = nullptr) {
     unsigned long long *cell = reinterpret_cast<unsigned long long *>(scratch);     // [atom of the concat][sum, sumsq][low, high]
     const int A0 = in.C[0] / GN_ATOM, A1 = in.acc[1] ? in.C[1] / GN_ATOM : 0, Ct = in.C[0] + (in.acc[1] ? in.C[1] : 0);
     double *stat = reinterpret_cast<double *>(cell + (size_t)(A0 + A1) * 4);       // [group][mean, rstd]
@@ -178,6 +180,7 @@ __device__ __forceinline__ void gn_in_finish(const GnIn &in, const GnReq<GN_PRE>
         double rstd = 1.0 / sqrt(var + (double)in.eps);
         if (r.bad) { mean = __builtin_nan(""); rstd = __builtin_nan(""); }
         stat[tid * 2] = mean; stat[tid * 2 + 1] = rstd;
+        if (grp) { grp[tid * 2] = (float)mean; grp[tid * 2 + 1] = (float)rstd; }
     }
     gn_barrier<LDS_ONLY>();
 #pragma unroll
@@ -1050,11 +1053,23 @@ struct HbArgs {
     // its output is sum over the in-volume taps of T[tap][cout] = sum_cin W[cout][cin][tap] shift[cin] (vt_voxel_tile_flags makes the
     // flags; plain layers only: no `low`, no in_absmax)
     const unsigned char *tile_skip = nullptr;
+    unsigned skip_mask = 0xffu;         // which bits of a flag byte count (vt_voxel_tile_flags: bit 0 = 10^3 halo empty, bit 1 = 12^3 halo too)
+    // The layer BEHIND a flagged first layer (32 -> 32 channels, 8 groups): over a block whose 12^3 halo holds no point the first layer's
+    // output is a constant per border class, so this layer's output is one too -- per voxel class c2 (per axis: coordinate 0, 1, inner,
+    // R - 2, R - 1: 125 classes)  K2[c2][co] = sum_g rstd_g (A_g - mean_g C_g) + B_g  with the second GroupNorm's group statistics and
+    //   A_g = sum over the in-volume taps and the group's channels of W2 gamma2 relu(K1[class of the neighbour]),  C_g = ... of W2 gamma2,
+    //   B_g = ... of W2 beta2
+    // which depend on the FIRST layer's statistics only.  The first layer's launch writes them (cls_out [B][125][32][24]; cls_w: the second
+    // layer's packed weights, cls_gamma / cls_beta its GroupNorm), the second layer's reads them (cls_in) with tile_skip / skip_mask = 2.
+    const float *cls_w = nullptr, *cls_gamma = nullptr, *cls_beta = nullptr;
+    float *cls_out = nullptr;
+    const float *cls_in = nullptr;
     // decoder-entry layers in per-parity form (conv3d_gcr_up_kernel): the merged class weights of the `low` channels
     // (vt_conv3d_pack_f16x3_up); c.wp then only serves the skip channels' chunks
     const float *wp_up = nullptr;
 };
 constexpr int HB_SKIP_LIST = 64;                                     // tiles of either kind a workgroup can hold in its lists
+constexpr int HB_CLS = 125, HB_CLS_ROW = 24;                        // border classes of the layer behind a flagged one; floats per (class, cout)
 constexpr size_t hb_lds_sparse(int TZ) { return hb_lds(TZ) + 2 * 27 * 32 * sizeof(float) + 2 * HB_SKIP_LIST * sizeof(unsigned short) + 64 * sizeof(int); }
 static_assert(hb_lds_sparse(8) <= 160 * 1024, "split-f16 conv with skip lists: LDS budget");
 
@@ -1353,7 +1368,9 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
     float *ttab = ssl + HB_MAX_CIN * 2, *ktab = ttab + 27 * 32;      // [27 taps][32 couts], [27 border classes][32 couts]
     unsigned short *list_ne = reinterpret_cast<unsigned short *>(ktab + 27 * 32), *list_e = list_ne + HB_SKIP_LIST;
     int *lcnt = reinterpret_cast<int *>(list_e + HB_SKIP_LIST);      // [0..31] per-wave counts of a round, [32], [33] running totals
+    float *grp = reinterpret_cast<float *>(lcnt + 40);               // [8 groups][mean, rstd] of the input's GroupNorm (cls_in)
     const bool sparse = !FIN && ha.tile_skip != nullptr;
+    const bool cls_make = sparse && ha.cls_out != nullptr, cls_use = sparse && ha.cls_in != nullptr;
     int n_ne = ntile, n_e = 0;
     if (sparse) {
         const int t8x = s.W >> 3, t8y = s.H >> 3;
@@ -1365,7 +1382,7 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
             bool valid = t < nsp, skip = false;
             if (valid) {
                 const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, tz = t / (a.tiles_x * a.tiles_y);
-                skip = flags[(((tz * TZ) >> 3) * t8y + ty) * t8x + tx] != 0;
+                skip = (flags[(((tz * TZ) >> 3) * t8y + ty) * t8x + tx] & ha.skip_mask) != 0;
             }
             const unsigned long long m_ne = __ballot(valid && !skip), m_e = __ballot(valid && skip);
             if (lane == 0) { lcnt[wave] = __popcll(m_ne); lcnt[16 + wave] = __popcll(m_e); }
@@ -1546,7 +1563,7 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
 #endif
         }
         HB_STAMP(10);
-        if (stats_in) gn_in_finish<true, GN_PRE, true>(a.stat_in, gn_rq, b, pre_scale, ssl, hl, threadIdx.x, THREADS);
+        if (stats_in) gn_in_finish<true, GN_PRE, true>(a.stat_in, gn_rq, b, pre_scale, ssl, hl, threadIdx.x, THREADS, cls_use ? grp : nullptr);
         HB_STAMP(11);
         if (N > 0) {
             commit(0, preA);
@@ -1556,7 +1573,8 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
             if (N > 2) fetch(preA);
         }
         HB_STAMP(12);
-        if (sparse) lds_barrier();                                  // (the tap waves: T is complete, the class table follows)
+        if (sparse && !cls_use) lds_barrier();                      // (the tap waves: T is complete, the class table follows)
+        if (cls_make) { lds_barrier(); lds_barrier(); }             // (... the class table is complete; the next layer's weights are in LDS)
         constexpr int WAIT_DMA0 = 0x0F70 | (2 * REQ > 15 ? 15 : 2 * REQ);
         if (N > 2) __builtin_amdgcn_s_waitcnt(WAIT_DMA0); else __builtin_amdgcn_s_waitcnt(0x0F70);   // chunk 0's weights have landed
         HB_STAMP(13);
@@ -1581,12 +1599,38 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
             iteration(n, preB);                                    // chunk n + 1 is odd
             if (n + 1 < N) iteration(n + 1, preA);
         }
+        // the layer behind a flagged one: the class table of constant tile k (its 27 classes, two voxels deep at a face of the volume)
+        // from the class rows and this layer's group statistics, while the tap waves finish the tiles before it; two tables (K's and
+        // T's place) alternate, one barrier per tile
+        if (cls_use)
+            for (int k = 0; k < n_e; ++k) {
+                int t = list_e[k];
+                const int tx = t % a.tiles_x; t /= a.tiles_x;
+                const int ty = t % a.tiles_y; t /= a.tiles_y;
+                const int x0 = tx * 8, y0 = ty * 8, z0 = t * TZ;
+                const bool lox = x0 == 0, hix = x0 + 8 == s.W, loy = y0 == 0, hiy = y0 + 8 == s.H, loz = z0 == 0, hiz = z0 + TZ == s.D;
+                float *tab = (k & 1) ? ttab : ktab;
+                for (int id = lt; id < 27 * 32; id += LTHREADS) {
+                    const int cls = id >> 5, co = id & 31, lz = cls / 9, ly = (cls / 3) % 3, lxx = cls % 3;
+                    const int gz = loz ? lz : hiz ? 4 - lz : 2, gy = loy ? ly : hiy ? 4 - ly : 2, gx = lox ? lxx : hix ? 4 - lxx : 2;
+                    const f32x4 *row = reinterpret_cast<const f32x4 *>(ha.cls_in + ((size_t)b * HB_CLS * 32 + ((gz * 5 + gy) * 5 + gx) * 32 + co) * HB_CLS_ROW);
+                    const f32x4 A0 = row[0], A1 = row[1], C0 = row[2], C1 = row[3], B0 = row[4], B1 = row[5];
+                    float kk = 0.0f;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        kk += fmaf(grp[2 * g + 1], fmaf(-grp[2 * g], C0[g], A0[g]), B0[g]);
+                        kk += fmaf(grp[2 * g + 9], fmaf(-grp[2 * g + 8], C1[g], A1[g]), B1[g]);
+                    }
+                    tab[id] = kk;
+                }
+                lds_barrier();
+            }
     } else {
         // ================================================= tap waves ==================================================
         const int lx = j & 3, ly = j >> 2;
         const int center = ((wave + 1) * 10 + (ly + 1)) * HB_PX + (lx + 1);      // patch 0; patch 1 sits 4 voxels along x
-        if (stats_in) gn_in_finish<true, GN_PRE, true>(a.stat_in, gn_rq, b, pre_scale, ssl, hl, threadIdx.x, THREADS);
-        if (sparse && n_e > 0) {
+        if (stats_in) gn_in_finish<true, GN_PRE, true>(a.stat_in, gn_rq, b, pre_scale, ssl, hl, threadIdx.x, THREADS, cls_use ? grp : nullptr);
+        if (sparse && !cls_use && (n_e > 0 || cls_make)) {
             // T[tap][cout] = sum_cin W[cout][cin][tap] shift[cin] from the packed fragments (hi + lo), while the loaders stage chunk 0
             for (int id = threadIdx.x; id < 27 * 32; id += LTHREADS) {
                 const int tap = id >> 5, co = id & 31, fl = (tap >> 1) * 128 + co + 32 * (tap & 1);
@@ -1600,11 +1644,11 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
                 ttab[id] = t;
             }
         }
-        if (sparse) {
+        if (sparse && !cls_use) {
             // K[class][cout] = the sum of T over the taps a voxel of that border class has inside the volume (class = per axis: first
             // voxel, inner, last voxel)
             lds_barrier();
-            if (n_e > 0)
+            if (n_e > 0 || cls_make)
                 for (int id = threadIdx.x; id < 27 * 32; id += LTHREADS) {
                     const int cls = id >> 5, co = id & 31, cz = cls / 9, cy = (cls / 3) % 3, cx = cls % 3;
                     float k = 0.0f;
@@ -1616,6 +1660,62 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
                     }
                     ktab[id] = k;
                 }
+        }
+        if (cls_make) {
+            // the class rows of the layer behind this one (HbArgs::cls_out).  Unit u = index among the F sharing workgroups: cout u % 32 and
+            // every P-th class from u / 32 (P = min(F / 32, 8); the launcher asks for >= 32 per scene); the unit's 27 x 32 weights go through LDS once
+            // (T's place: T is dead), then eight threads per row, one per GroupNorm group of four input channels
+            lds_barrier();
+            // (where at least 32 workgroups of the scene have no tile with taps, those share the rows: they have nothing else to do)
+            const int tot_ne = lcnt[32], spare = ha.wgs_per_scene - tot_ne;
+            const int F = spare >= 32 ? spare : ha.wgs_per_scene, wi = spare >= 32 ? wg - tot_ne : wg;
+            const int P = F >= 256 ? 8 : F >> 5, co = wi & 31, part = wi >> 5;
+            const bool unit = wi >= 0 && wi < 32 * P;
+            if (unit && threadIdx.x < 27 * 4) {
+                const int tap = threadIdx.x >> 2, q = threadIdx.x & 3, fl = (tap >> 1) * 128 + co + 32 * (tap & 1);
+                const f16x8 *w2 = reinterpret_cast<const f16x8 *>(ha.cls_w) + (size_t)q * HB_WFRAGS;
+                const f16x8 wh = w2[fl], wl = w2[fl + 64];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ttab[tap * 32 + 8 * q + e] = (float)wh[e] + (float)wl[e];
+            }
+            lds_barrier();
+            // class of the neighbour at offset d of a voxel of axis class c (0, 1, inner, R - 2, R - 1): first / inner / last, -1: outside
+            auto nb = [](int c, int d) { return c == 0 ? (d < 0 ? -1 : d) : c == 1 ? (d < 0 ? 0 : 1) : c == 2 ? 1 : c == 3 ? (d > 0 ? 2 : 1) : (d < 0 ? 1 : d == 0 ? 2 : -1); };
+            const int nrows = unit ? (HB_CLS - part + P - 1) / P : 0;
+            // four lanes per (row, group): one per z offset of the taps (the fourth idles), summed with two lane exchanges -- a lone
+            // wave issues an instruction every ~6 cycles here, so the work is spread over every tap wave
+            for (int item = threadIdx.x; item < nrows * 32; item += LTHREADS) {
+                const int d = item & 3, g = (item >> 2) & 7, c2 = part + P * (item >> 5), cz = c2 / 25, cy = (c2 / 5) % 5, cx = c2 % 5;
+                const f32x4 gm = *reinterpret_cast<const f32x4 *>(ha.cls_gamma + 4 * g), bt = *reinterpret_cast<const f32x4 *>(ha.cls_beta + 4 * g);
+                const int nz = d < 3 ? nb(cz, d - 1) : -1;
+                float A = 0.0f, C = 0.0f, Bv = 0.0f;
+                if (nz >= 0) {
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int ny = nb(cy, dy - 1);
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const int nx = nb(cx, dx - 1);
+                            if (ny < 0 || nx < 0) continue;
+                            const f32x4 k1 = *reinterpret_cast<const f32x4 *>(ktab + ((nz * 3 + ny) * 3 + nx) * 32 + 4 * g);
+                            const f32x4 w = *reinterpret_cast<const f32x4 *>(ttab + (d * 9 + dy * 3 + dx) * 32 + 4 * g);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float wgm = w[e] * gm[e];
+                                A = fmaf(wgm, fmaxf(k1[e], 0.0f), A);
+                                C += wgm;
+                                Bv = fmaf(w[e], bt[e], Bv);
+                            }
+                        }
+                    }
+                }
+                A += __shfl_xor(A, 1); C += __shfl_xor(C, 1); Bv += __shfl_xor(Bv, 1);
+                A += __shfl_xor(A, 2); C += __shfl_xor(C, 2); Bv += __shfl_xor(Bv, 2);
+                if (d == 0) {
+                    float *o = ha.cls_out + ((size_t)b * HB_CLS * 32 + c2 * 32 + co) * HB_CLS_ROW;
+                    o[g] = A; o[8 + g] = C; o[16 + g] = Bv;
+                }
+            }
         }
         f32x16 acc0, acc1;
 #pragma unroll
@@ -1708,17 +1808,27 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
             HB_STAMP(4);
         }
         // the tiles whose normalised input is the shift everywhere: every voxel takes the constant of its border class
+        // (cls_use: the layer behind such a layer -- the tile's 27 classes, two voxels deep at a face of the volume, from the class rows
+        // and this layer's group statistics)
 #pragma unroll 1
         for (int k = 0; k < n_e; ++k) {
             int t = list_e[k];
             const int tx = t % a.tiles_x; t /= a.tiles_x;
             const int ty = t % a.tiles_y; t /= a.tiles_y;
             const int x0 = tx * 8, y0 = ty * 8, z0 = t * TZ;
+            const bool lox = x0 == 0, hix = x0 + 8 == s.W, loy = y0 == 0, hiy = y0 + 8 == s.H, loz = z0 == 0, hiz = z0 + TZ == s.D;
+            if (cls_use) lds_barrier();                             // (the loaders have built this tile's class table)
+            const float *tab = (cls_use && (k & 1)) ? ttab : ktab;
 #pragma unroll
             for (int pch = 0; pch < 2; ++pch) {
                 const int gx = x0 + lx + 4 * pch, gy = y0 + ly, gz = z0 + wave;
-                const int cls = ((gz == 0 ? 0 : gz == s.D - 1 ? 2 : 1) * 3 + (gy == 0 ? 0 : gy == s.H - 1 ? 2 : 1)) * 3 + (gx == 0 ? 0 : gx == s.W - 1 ? 2 : 1);
-                const f32x4 *kr = reinterpret_cast<const f32x4 *>(ktab + cls * 32 + 4 * kg);
+                int cls;
+                if (cls_use) {
+                    const int cz = loz ? min(gz, 2) : hiz ? min(s.D - 1 - gz, 2) : 2, cy = loy ? min(gy, 2) : hiy ? min(s.H - 1 - gy, 2) : 2;
+                    const int cx = lox ? min(gx, 2) : hix ? min(s.W - 1 - gx, 2) : 2;
+                    cls = (cz * 3 + cy) * 3 + cx;
+                } else cls = ((gz == 0 ? 0 : gz == s.D - 1 ? 2 : 1) * 3 + (gy == 0 ? 0 : gy == s.H - 1 ? 2 : 1)) * 3 + (gx == 0 ? 0 : gx == s.W - 1 ? 2 : 1);
+                const f32x4 *kr = reinterpret_cast<const f32x4 *>(tab + cls * 32 + 4 * kg);
                 f32x16 v;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -2624,10 +2734,17 @@ static bool conv_h_inline() {
     return on;
 }
 
+// the link between a flagged first layer and the layer behind it (HbArgs::cls_*): `out` on the first layer's launch (with the second
+// layer's packed weights and GroupNorm parameters), `in` on the second's
+struct ClsLink { const float *w = nullptr, *gamma = nullptr, *beta = nullptr; float *out = nullptr; const float *in = nullptr; };
 static int conv_h_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                          const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
                          float *out_part, const float *in_absmax, const float *fin_w, const float *fin_b, void *stream,
-                         const GnIn &stat_in = GnIn{}, const GnOut &stat_out = GnOut{}, const unsigned char *tile_skip = nullptr);
+                         const GnIn &stat_in = GnIn{}, const GnOut &stat_out = GnOut{}, const unsigned char *tile_skip = nullptr,
+                         const ClsLink &cls = ClsLink{});
+// would conv_h_launch take skip flags on this plain layer?
+static bool conv_h_skip_accepts(int B, int D, int H, int W, int Cin, int Cout);
+static int conv_h_wgs_of(int B, int D, int H, int W, int Cin, int Cout);
 
 int vt_conv3d_gcr_f16x3_scaled(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                                const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
@@ -2687,7 +2804,7 @@ int vt_conv1x1_pack_f16x3(const float *w, int Cout, int Cin, float *packed, void
 static int conv_h_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                          const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
                          float *out_part, const float *in_absmax, const float *fin_w, const float *fin_b, void *stream,
-                         const GnIn &stat_in, const GnOut &stat_out, const unsigned char *tile_skip) {
+                         const GnIn &stat_in, const GnOut &stat_out, const unsigned char *tile_skip, const ClsLink &cls) {
     HbArgs ha;
     ha.c.stat_in = stat_in; ha.c.stat_out = stat_out;
     ha.in_absmax = in_absmax;
@@ -2717,6 +2834,14 @@ static int conv_h_launch(const float *skip, int C1, const float *low, int C2, in
     const bool spec = conv_h_specialised(tz) && conv_h_fits_32bit(a.s, B);
     if (fin_w && !spec) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr_f16x3_final: shape not on the specialised-wave kernel");
     if (!spec) ha.tile_skip = nullptr;
+    if (cls.out || cls.in) {
+        // (the caller asked conv_h_skip_accepts for both layers; a layer that reads class rows nobody wrote must not run)
+        if (!ha.tile_skip || Cout != 32 || a.s.C1 + a.s.C2 > HB_MAX_CIN || (cls.in && (a.s.C1 != 32 || !stat_in.acc[0] || stat_in.groups != 8)) ||
+            (cls.out && (!cls.w || !cls.gamma || !cls.beta)) || (cls.in && cls.out) || D < 16 || H < 16 || W < 16 || ha.wgs_per_scene < 32)
+            return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr_f16x3: class rows on a layer that does not take them");
+        ha.cls_w = cls.w; ha.cls_gamma = cls.gamma; ha.cls_beta = cls.beta; ha.cls_out = cls.out; ha.cls_in = cls.in;
+        if (cls.in) ha.skip_mask = 2u;
+    }
     if (spec && conv_h_inline()) {               // the support work in the tap waves' MFMA gaps (VTACO_CONV_SPEC=2)
         bool attr_x = false;        // (vt_max_dyn_lds keeps the per-device record)
         if (!attr_x) {
@@ -2764,6 +2889,18 @@ static int conv_h_launch(const float *skip, int C1, const float *low, int C2, in
     else if (tz == 4) hipLaunchKernelGGL(conv3d_gcr_h_kernel<4>, grid, dim3(hb_threads(4)), hb_lds(4), (hipStream_t)stream, ha);
     else hipLaunchKernelGGL(conv3d_gcr_h_kernel<2>, grid, dim3(hb_threads(2)), hb_lds(2), (hipStream_t)stream, ha);
     return vt_check(hipGetLastError(), "vt_conv3d_gcr_f16x3");
+}
+
+static bool conv_h_skip_accepts(int B, int D, int H, int W, int Cin, int Cout) {
+    const int tz = conv_h_tz(B, D, H, W, Cin, Cout);
+    if (!tz || !conv_h_specialised(tz) || conv_h_inline()) return false;
+    const Src src{nullptr, nullptr, Cin, 0, D, H, W};
+    const int wgs = conv_h_wgs_per_scene(B, D, H, W, Cout, tz);
+    return conv_h_fits_32bit(src, B) && ((W / 8) * (H / 8) * (D / tz) + wgs - 1) / wgs <= HB_SKIP_LIST;
+}
+static int conv_h_wgs_of(int B, int D, int H, int W, int Cin, int Cout) {
+    const int tz = conv_h_tz(B, D, H, W, Cin, Cout);
+    return tz ? conv_h_wgs_per_scene(B, D, H, W, Cout, tz) : 0;
 }
 
 // ---- decoder-entry layers in per-parity form (unet3d_up.inc) ---------------------------------------------------------------
@@ -2921,6 +3058,17 @@ bool unet3d_fold_ok(int B, int R, const vt_unet3d_params *p) {
     return true;
 }
 
+// does the SECOND layer of level 0 take block flags too (the class rows of HbArgs::cls_*)?  By the shape alone.
+bool unet3d_skip2_shape(int B, int R, const vt_unet3d_params *p) {
+    const char *e2 = getenv("VTACO_CONV_SKIP2");                     // (A/B and tests: read per call)
+    const bool off2 = e2 && e2[0] == '0';
+    const vt_unet3d_conv &c0 = p->enc[0][0], &c1 = p->enc[0][1];
+    return !off2 && R >= 16 && c0.cout == 32 && c1.cin == 32 && c1.cout == 32 && p->groups == 8 && p->n_levels > 1 &&
+           conv_kind(c0, B, R) == CONV_HALF && conv_kind(c1, B, R) == CONV_HALF &&
+           conv_h_skip_accepts(B, R, R, R, c0.cin, c0.cout) && conv_h_skip_accepts(B, R, R, R, c1.cin, c1.cout) &&
+           conv_h_wgs_of(B, R, R, R, c0.cin, c0.cout) >= 32;
+}
+
 struct StatRegion { size_t off = 0, words = 0; };                  // the accumulators' place in the workspace (known after a planning pass)
 
 // vt_unet3d_fwd with the statistics in accumulator rows: 13 launches fewer (the first finalisation stays: the statistics of x
@@ -2962,7 +3110,7 @@ int unet3d_run_fold(const float *x_cl, int B, int R, const vt_unet3d_params *p, 
     int rc = 0;
     // one 'gcr' layer; ss: a finished scale / shift table (the first layer's), else the statistics come through GnIn
     auto gcr = [&](const vt_unet3d_conv &c, const float *ss, const Tensor &a, const Tensor *low, int Ri, Tensor &o, bool want_stats,
-                   const unsigned char *skipf = nullptr) -> int {
+                   const unsigned char *skipf = nullptr, const ClsLink &cls = ClsLink{}) -> int {
         const int C2 = low ? low->C : 0;
         if (a.C + C2 != c.cin) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd: channel mismatch between levels");
         o.C = c.cout;
@@ -2978,7 +3126,7 @@ int unet3d_run_fold(const float *x_cl, int B, int R, const vt_unet3d_params *p, 
         if (kind == CONV_HALF && low && c.packed_f16x3_up && conv_up_tz(a.C, C2, B, Ri, Ri, Ri, c.cout))     // decoder entry: per-parity form
             return conv_up_launch(a.x, a.C, lx, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.packed_f16x3_up, c.cout, 1, o.x, nullptr, st, si, so);
         if (kind == CONV_HALF)
-            return conv_h_launch(a.x, a.C, lx, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.cout, 1, o.x, nullptr, nullptr, nullptr, nullptr, st, si, so, skipf);
+            return conv_h_launch(a.x, a.C, lx, C2, B, Ri, Ri, Ri, ss, c.packed_f16x3, c.cout, 1, o.x, nullptr, nullptr, nullptr, nullptr, st, si, so, skipf, cls);
         // the thin levels: IEEE-half pairs where the caller packed them (a network whose large levels run the split-f16 kernels)
         const bool thin_half = c.packed_f16x3_thin != nullptr;
         const float *thin_w = thin_half ? c.packed_f16x3_thin : c.packed_bf16x3;
@@ -3020,9 +3168,24 @@ int unet3d_run_fold(const float *x_cl, int B, int R, const vt_unet3d_params *p, 
             cur = pooled;
         }
         Tensor t1, t2;
-        // (the first layer reads x: where the caller flagged x as zero over a block's halo, the block's taps are skipped)
-        if ((rc = gcr(p->enc[i][0], i == 0 ? ss0 : nullptr, cur, nullptr, Ri, t1, true, i == 0 ? tile_flags : nullptr))) return rc;
-        if ((rc = gcr(p->enc[i][1], nullptr, t1, nullptr, Ri, t2, L > 1))) return rc;
+        // (the first layer reads x: where the caller flagged x as zero over a block's halo, the block's taps are skipped; where the
+        // 12^3 halo is empty too the second layer's are as well: its output there follows from class rows the first launch leaves)
+        ClsLink mk, use;
+        const unsigned char *skip2 = nullptr;
+        if (i == 0) {
+            const vt_unet3d_conv &c1 = p->enc[0][1];
+            const bool shape2 = unet3d_skip2_shape(B, R, p);
+            if (shape2) {                                           // (sized by the shape alone: the planning pass has no flags)
+                float *rows = ws.take((size_t)B * HB_CLS * 32 * HB_CLS_ROW);
+                if (tile_flags) {
+                    mk.w = c1.packed_f16x3; mk.gamma = c1.gn_w; mk.beta = c1.gn_b; mk.out = rows;
+                    use.in = rows;
+                    skip2 = tile_flags;
+                }
+            }
+        }
+        if ((rc = gcr(p->enc[i][0], i == 0 ? ss0 : nullptr, cur, nullptr, Ri, t1, true, i == 0 ? tile_flags : nullptr, mk))) return rc;
+        if ((rc = gcr(p->enc[i][1], nullptr, t1, nullptr, Ri, t2, L > 1, skip2, use))) return rc;
         skips[i] = t2;
         cur = t2;
     }
@@ -3172,6 +3335,13 @@ int vt_unet3d_fwd_stats(const float *x_cl, const float *in_part, int in_nblk, in
     if (!need) return vt_fail(VT_ERR_INVALID, "vt_unet3d_fwd_stats: bad configuration");
     if (workspace_bytes < need) return vt_fail(VT_ERR_WORKSPACE, "vt_unet3d_fwd_stats: workspace too small");
     return unet3d_run(x_cl, B, R, params_host, (char *)workspace, nullptr, out, (hipStream_t)stream, in_part, in_nblk);
+}
+
+int vt_unet3d_skip_layers(int B, int R, const vt_unet3d_params *params_host) {
+    if (!params_host || B <= 0 || R <= 0 || params_host->n_levels < 1) return 0;
+    const vt_unet3d_conv &c0 = params_host->enc[0][0];
+    if (!c0.packed_f16x3 || conv_kind(c0, B, R) != CONV_HALF || !conv_h_skip_accepts(B, R, R, R, c0.cin, c0.cout)) return 0;
+    return unet3d_fold_ok(B, R, params_host) && unet3d_skip2_shape(B, R, params_host) ? 2 : 1;
 }
 
 int vt_unet3d_fwd_skip(const float *x_cl, const float *in_part, int in_nblk, const unsigned char *tile_flags, int B, int R,

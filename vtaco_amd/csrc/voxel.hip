@@ -42,12 +42,13 @@ constexpr size_t SORT_LDS = (size_t)MAX_T * 4 + 2 * (size_t)MAX_T * 2 + (size_t)
 // (digit, chunk) table), one block-wide exclusive scan of the table in (digit, chunk) order turns the sizes into
 // offsets, and the elements scatter to offset + rank.  Deterministic; 3 passes x ~3 us instead of 78 bitonic passes.
 constexpr int FLAG_MAX_TILES = 4096;                               // 8^3 blocks of a volume of up to 128^3 voxels
-// `tile_flags` (or null; volumes only): [B][(R/8)^3] bytes, 1 = no point of the scene in the 10^3 halo of that 8^3 block (vt_voxel_tile_flags)
+// `tile_flags` (or null; volumes only): [B][(R/8)^3] bytes, bit 0 = no point of the scene in the 10^3 halo of that 8^3 block, bit 1 = none
+// in its 12^3 halo either (vt_voxel_tile_flags)
 __global__ void __launch_bounds__(SORT_THREADS)
 voxel_build_kernel(const float *pts, int T, int nbits, int R, float divisor, float clamp_hi, int a0, int a1, int a2,
                    int *idx, int *order, int *seg_lo, int *seg_hi, int B, uint4 *fill, size_t fill16, unsigned char *tile_flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
-    __shared__ unsigned char tflag[FLAG_MAX_TILES];
+    __shared__ unsigned char tflag[FLAG_MAX_TILES], tflag2[FLAG_MAX_TILES];
     if ((int)blockIdx.x >= B) {
         // the workgroups behind the B sorting ones clear a buffer of the caller's (the grid the scatter-mean fills next): the sort keeps
         // one CU per scene busy for ~18 us, the other CUs stream 33 MB of zeros in that time instead of in a launch of their own
@@ -65,7 +66,7 @@ voxel_build_kernel(const float *pts, int T, int nbits, int R, float divisor, flo
     const int nround = (T + SORT_THREADS - 1) / SORT_THREADS, nchunk = nround * (SORT_THREADS / 64);
     const int nt1 = R >> 3;
     if (tile_flags) {
-        for (int t = tid; t < nt1 * nt1 * nt1; t += SORT_THREADS) tflag[t] = 1;
+        for (int t = tid; t < nt1 * nt1 * nt1; t += SORT_THREADS) { tflag[t] = 1; tflag2[t] = 2; }
         __syncthreads();
     }
     for (int t = tid; t < T; t += SORT_THREADS) {
@@ -77,14 +78,18 @@ voxel_build_kernel(const float *pts, int T, int nbits, int R, float divisor, flo
         idx[(size_t)b * T + t] = id;
         ids[t] = (unsigned)id;
         perm_a[t] = (unsigned short)t;
-        if (tile_flags)                                             // the blocks whose halo [8 t - 1, 8 t + 8] holds the voxel
+        if (tile_flags) {                                           // the blocks whose halo [8 t - 1, 8 t + 8] holds the voxel
             for (int tz = max((iz - 1) >> 3, 0); tz <= min((iz + 1) >> 3, nt1 - 1); ++tz)
                 for (int ty = max((iy - 1) >> 3, 0); ty <= min((iy + 1) >> 3, nt1 - 1); ++ty)
                     for (int tx = max((ix - 1) >> 3, 0); tx <= min((ix + 1) >> 3, nt1 - 1); ++tx) tflag[(tz * nt1 + ty) * nt1 + tx] = 0;
+            for (int tz = max((iz - 2) >> 3, 0); tz <= min((iz + 2) >> 3, nt1 - 1); ++tz)      // ... whose halo [8 t - 2, 8 t + 9] does
+                for (int ty = max((iy - 2) >> 3, 0); ty <= min((iy + 2) >> 3, nt1 - 1); ++ty)
+                    for (int tx = max((ix - 2) >> 3, 0); tx <= min((ix + 2) >> 3, nt1 - 1); ++tx) tflag2[(tz * nt1 + ty) * nt1 + tx] = 0;
+        }
     }
     __syncthreads();
     if (tile_flags)
-        for (int t = tid; t < nt1 * nt1 * nt1; t += SORT_THREADS) tile_flags[(size_t)b * nt1 * nt1 * nt1 + t] = tflag[t];
+        for (int t = tid; t < nt1 * nt1 * nt1; t += SORT_THREADS) tile_flags[(size_t)b * nt1 * nt1 * nt1 + t] = tflag[t] | tflag2[t];
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int shift = 0; shift < nbits; shift += RADIX_BITS) {
         for (int e = tid; e < RADIX * nchunk; e += SORT_THREADS) table[e] = 0;
@@ -465,13 +470,14 @@ inline unsigned blocks_for(size_t total) {
     return (unsigned)(g < cap ? (g ? g : 1) : cap);
 }
 
-// flags[b][tile] = 1 where no point of scene b lies in the 10^3 halo of the 8^3 voxel block `tile` (the voxels a 3x3x3 conv over the
-// block reads): the scatter-mean grid is zero there.  One workgroup per scene; the flags of a scene fit its LDS (R <= 128: 4096 blocks).
+// flags[b][tile]: bit 0 where no point of scene b lies in the 10^3 halo of the 8^3 voxel block `tile` (the voxels a 3x3x3 conv over the
+// block reads): the scatter-mean grid is zero there; bit 1 where none lies in its 12^3 halo either (what a second 3x3x3 conv behind the
+// first depends on), so the values are 0, 1 and 3.  One workgroup per scene; the flags of a scene fit its LDS (R <= 128: 4096 blocks).
 __global__ void __launch_bounds__(256)
 tile_flags_kernel(const int *idx, int T, int R, unsigned char *flags) {
-    __shared__ unsigned char f[FLAG_MAX_TILES];
+    __shared__ unsigned char f[FLAG_MAX_TILES], f2[FLAG_MAX_TILES];
     const int b = blockIdx.x, nt1 = R >> 3, nt = nt1 * nt1 * nt1;
-    for (int t = threadIdx.x; t < nt; t += 256) f[t] = 1;
+    for (int t = threadIdx.x; t < nt; t += 256) { f[t] = 1; f2[t] = 2; }
     __syncthreads();
     for (int i = threadIdx.x; i < T; i += 256) {
         const int id = idx[(size_t)b * T + i];
@@ -483,9 +489,12 @@ tile_flags_kernel(const int *idx, int T, int R, unsigned char *flags) {
         for (int tz = z0; tz <= z1; ++tz)
             for (int ty = y0; ty <= y1; ++ty)
                 for (int tx = x0; tx <= x1; ++tx) f[(tz * nt1 + ty) * nt1 + tx] = 0;         // (racing stores of the same value)
+        for (int tz = max((z - 2) >> 3, 0); tz <= min((z + 2) >> 3, nt1 - 1); ++tz)
+            for (int ty = max((y - 2) >> 3, 0); ty <= min((y + 2) >> 3, nt1 - 1); ++ty)
+                for (int tx = max((x - 2) >> 3, 0); tx <= min((x + 2) >> 3, nt1 - 1); ++tx) f2[(tz * nt1 + ty) * nt1 + tx] = 0;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < nt; t += 256) flags[(size_t)b * nt + t] = f[t];
+    for (int t = threadIdx.x; t < nt; t += 256) flags[(size_t)b * nt + t] = f[t] | f2[t];
 }
 
 int build_launch(const char *who, const float *pts, int B, int T, int R, float divisor, float clamp_hi,

@@ -1503,6 +1503,12 @@ def conv1x1_cl(x, weight, bias):
 _unet_ws = {}
 
 
+def unet3d_skip_layers(B, R, params):
+    """How many layers of this UNet3D take the block flags at this batch and resolution (vt_unet3d_skip_layers): 0, 1 (the first layer)
+    or 2 (the first DoubleConv: the second layer over the blocks whose 12^3 halo is empty)."""
+    return int(_lib.load().vt_unet3d_skip_layers(int(B), int(R), ctypes.byref(params)))
+
+
 def unet3d_fwd(x_cl, params, keep, in_stats=None, tile_flags=None):
     """Whole UNet3D forward (vt_unet3d_fwd).  ``params``: a filled _lib.UnetParams; ``keep``: the
     tensors its pointers refer to (kept alive by the caller).  ``in_stats`` = (part, nblk): GroupNorm partial sums of the
