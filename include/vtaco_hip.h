@@ -211,6 +211,18 @@ int vt_decode_fwd_wide_ids(const float *grid_cl, int B, int R, int C, const floa
                            const unsigned char *finger_ids, const float *finger_feats, int n_fingers,
                            const float *blob_wide, int hidden, int n_blocks, int flags, double padding,
                            float *out, float *out2, void *stream);
+/* vt_decode_fwd_wide_f16x3 with a workspace.  At hidden 64 / c_dim 32 / n_blocks <= 5 without tactile input columns (c_img NULL)   */
+/* the whole network fits the registers of one workgroup: 2 n_blocks waves each keep 32 rows of one block's three layers as MFMA    */
+/* operands for the whole launch and the 32-point tiles move through them as a pipeline (three barriers per tick, no weight         */
+/* traffic; decode_wide_pipe.inc), fed with per-point features.  With `workspace` of vt_decode_wide_f16x3_workspace_bytes(B N,      */
+/* ...) bytes (0: the shape does not use one) a pre-pass leaves the grid's samples there (same sums, same order) and the pipeline   */
+/* runs on them; without it (or through vt_decode_fwd_wide_f16x3) the streaming kernel runs.  vt_decode_mlp_fwd_wide_f16x3, whose    */
+/* features are given, takes the pipeline by itself.  decoder.py:24-51, 71-103.                                                     */
+size_t vt_decode_wide_f16x3_workspace_bytes(int64_t total_points, int hidden, int c_dim, int n_blocks, int tactile);
+int vt_decode_fwd_wide_f16x3_ws(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                                int lattice_nx, float lattice_box, int64_t lattice_first,
+                                const float *c_img, const float *blob, int hidden, int n_blocks, int flags, double padding,
+                                float *out, float *out2, void *workspace, size_t workspace_bytes, void *stream);
 int vt_decode_fwd_wide_f16x3_ids(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
                                  int lattice_nx, float lattice_box, int64_t lattice_first,
                                  const unsigned char *finger_ids, const float *finger_feats, int n_fingers,

@@ -245,6 +245,53 @@ def test_wide_split_f16_against_the_oracle(hidden, c_dim, nb, leaky, B, N, R, mo
     assert _err(got_c, rc) <= 2e-5 * scale and _err(got_cc, rcc) <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("nb,leaky,B,N,R,mode", [(5, False, 1, 70001, 16, "bilinear"), (5, True, 2, 1000, 8, "bilinear"), (1, False, 1, 1, 8, "bilinear"),
+                                                 (2, True, 3, 31, 8, "nearest"), (3, False, 1, 33, 8, "bilinear"), (4, True, 1, 8191, 16, "nearest")])
+def test_register_resident_pipeline_at_64_32_equals_the_streaming_kernel(nb, leaky, B, N, R, mode):
+    """hidden 64 / c_dim 32 / n_blocks <= 5 (decode_wide_pipe.inc): every layer's weights stay in the registers of a pipeline of waves
+    and the grid's samples come from a pre-pass in the caller's workspace (vt_decode_fwd_wide_f16x3_ws, what ops.decode_fwd calls).
+    Against the streaming split-f16 kernel (vt_decode_fwd_wide_f16x3: same products, the heads summed in another order) and the
+    exact-f32 kernel: ragged tile counts (fewer tiles than pipeline stages, one point), batches, both sample modes, the contact
+    head, query points and lattice ranges; and the MLP on given features (vt_decode_mlp_fwd_wide_f16x3) takes the pipeline too."""
+    import ctypes
+    from vtaco_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.vt_decode_wide_f16x3_workspace_bytes(B * N, 64, 32, nb, 0) == B * N * 32 * 4
+    assert lib.vt_decode_wide_f16x3_workspace_bytes(B * N, 64, 32, nb, 1) == 0          # tactile input columns: the streaming kernel
+    assert lib.vt_decode_wide_f16x3_workspace_bytes(B * N, 96, 32, nb, 0) == 0
+    dec = _decoder(64, 32, nb, leaky, seed=7 + nb, mode=mode)
+    g = torch.Generator().manual_seed(N + nb)
+    grid = torch.randn(B, 32, R, R, R, generator=g).to(DEV)
+    p = ((torch.rand(B, N, 3, generator=g) - 0.5) * 1.3).to(DEV)
+    wide = (64, nb, leaky, mode == "nearest")
+    flags = (1 if leaky else 0) | (2 if mode == "nearest" else 0)
+    with torch.no_grad():
+        blob = dec._blob(img=False, contact=True, precision="wide_f16x3")
+        got, got2 = ops.decode_fwd(grid, blob, pts=p, padding=0.1, precision="wide_f16x3", wide=wide, want_contact=True)
+        exact, exact2 = ops.decode_fwd(grid, dec._blob(img=False, contact=True, precision="wide"), pts=p, padding=0.1, precision="wide",
+                                       wide=wide, want_contact=True)
+        keep, gptr = ops._cl_storage(grid)
+        old, old2 = torch.empty_like(got), torch.empty_like(got)
+        ops.check(lib.vt_decode_fwd_wide_f16x3(gptr, B, R, 32, ops.dev_ptr(p, "pts"), N, 0, 0.0, 0, None, ops.dev_ptr(blob, "blob"), 64, nb, flags, 0.1,
+                                               ops.dev_ptr(old, "out"), ops.dev_ptr(old2, "out2"), ops.stream_ptr()), "vt_decode_fwd_wide_f16x3")
+        scale = max(1.0, float(exact.abs().max()), float(exact2.abs().max()))
+        for a, b, c in ((got, old, exact), (got2, old2, exact2)):
+            assert float((a - b).abs().max()) <= 2e-6 * scale and float((a - c).abs().max()) <= 5e-6 * scale, (nb, N, float((a - b).abs().max()), float((a - c).abs().max()))
+        assert not torch.equal(got, old) or N < 4                      # really another kernel
+        # a lattice range that starts inside a tile
+        nx = 24
+        first, count = 5 * nx + 3, min(nx ** 3 - 5 * nx - 3, 40000)
+        lat = ops.decode_fwd(grid[:1], blob, lattice=(nx, 1.1, first, count), padding=0.1, precision="wide_f16x3", wide=wide)
+        lat_exact = ops.decode_fwd(grid[:1], dec._blob(img=False, contact=True, precision="wide"), lattice=(nx, 1.1, first, count), padding=0.1,
+                                   precision="wide", wide=wide)
+        assert float((lat - lat_exact).abs().max()) <= 5e-6 * max(1.0, float(lat_exact.abs().max()))
+        # the MLP behind a fuser: features given per point
+        c = torch.randn(B, N, 32, generator=g).to(DEV)
+        mlp = ops.decode_mlp_fwd(c, dec._blob(img=False, contact=False, precision="wide_f16x3"), p, precision="wide_f16x3", wide=(64, nb, leaky))
+        mlp_exact = ops.decode_mlp_fwd(c, dec._blob(img=False, contact=False, precision="wide"), p, precision="wide", wide=(64, nb, leaky))
+        assert float((mlp - mlp_exact).abs().max()) <= 5e-6 * max(1.0, float(mlp_exact.abs().max()))
+
+
 def test_wide_split_f16_reports_activations_at_the_half_limit():
     """Hidden activations beyond 65504 saturate the hi halves: the kernel raises RANGE_HALF in the device's status word (the generator's
     guard then moves to the exact kernel), and stays silent on ordinary weights."""

@@ -116,6 +116,8 @@ SIGNATURES = {
     "vt_decode_fwd_wide": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _I, _I, _I, _D, _VP, _VP, _VP]),
     "vt_decode_fwd_wide_f16x3": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _I, _I, _I, _D, _VP, _VP, _VP]),
     "vt_decode_fwd_wide_ids": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _I, _VP, _I, _I, _I, _D, _VP, _VP, _VP]),
+    "vt_decode_wide_f16x3_workspace_bytes": (_SZ, [_I64, _I, _I, _I, _I]),
+    "vt_decode_fwd_wide_f16x3_ws": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _I, _I, _I, _D, _VP, _VP, _VP, _SZ, _VP]),
     "vt_decode_fwd_wide_f16x3_ids": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _I, _VP, _I, _I, _I, _D, _VP, _VP, _VP]),
     "vt_decode_mlp_fwd_wide": (_I, [_VP, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "vt_decode_mlp_fwd_wide_f16x3": (_I, [_VP, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _I, _I, _I, _VP, _VP, _VP]),

@@ -652,6 +652,14 @@ __global__ void wideh_pack_kernel(const float *w, int H, int K, int kin, int ld,
     }
 }
 
+#include "decode_wide_pipe.inc"
+
+// the shapes of decode_wide_p_kernel (VTACO_WIDE_PIPE=0: the streaming kernel, A/B)
+static bool wide_pipe_shape(int hidden, int c_dim, int n_blocks, int p_in) {
+    static const bool off = getenv("VTACO_WIDE_PIPE") && getenv("VTACO_WIDE_PIPE")[0] == '0';
+    return !off && hidden == 64 && c_dim == 32 && n_blocks >= 1 && n_blocks <= 5 && p_in == 3;
+}
+
 int wide_shape_ok(int hidden, int c_dim, int n_blocks, int p_in) {
     return hidden >= 32 && hidden <= WIDE_MAX && hidden % 32 == 0 && c_dim >= 32 && c_dim <= WIDE_MAX && c_dim % 32 == 0 &&
            n_blocks >= 1 && n_blocks <= VT_MAX_BLOCKS && (p_in == 3 || p_in == 3 + c_dim);
@@ -818,7 +826,7 @@ static int wideh_fwd_impl(const float *grid_cl, int B, int R, int C, const float
                           int lattice_nx, float lattice_box, int64_t lattice_first,
                           const float *c_img, const unsigned char *finger_ids, const float *finger_feats,
                           const float *blob, int hidden, int n_blocks, int flags, double padding,
-                          float *out, float *out2, void *stream, const float *c_direct = nullptr) {
+                          float *out, float *out2, void *stream, const float *c_direct = nullptr, void *ws = nullptr, size_t ws_bytes = 0) {
     if ((!grid_cl && !c_direct) || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3: null argument");
     if (c_img && finger_ids) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3: give c_img or finger ids, not both");
     const int p_in = (c_img || finger_ids) ? 3 + C : 3;
@@ -836,6 +844,22 @@ static int wideh_fwd_impl(const float *grid_cl, int B, int R, int C, const float
     a.blob = blob; a.H = hidden; a.C = C; a.nb = n_blocks; a.p_in = p_in; a.Kp = (p_in + 15) / 16 * 16;
     a.leaky = (flags & VT_WIDE_LEAKY) ? 1 : 0; a.nearest = (flags & VT_WIDE_NEAREST) ? 1 : 0;
     a.status = vt_decode_status_dev();
+    // 64 / 32 / <= 5 without tactile input columns: the weights in registers, the tiles through a pipeline of waves (decode_wide_pipe.inc)
+    // on features given per point -- the caller's (c_direct), or the grid's samples left in the caller's workspace by a pre-pass
+    if (wide_pipe_shape(hidden, C, n_blocks, p_in) && (c_direct || (ws && ws_bytes >= (size_t)a.d.total * C * sizeof(float)))) {
+        if (!c_direct) {
+            const unsigned long long items = (unsigned long long)a.d.total * (C / 4);
+            const unsigned long long want = (items + 255) / 256, cap = (unsigned long long)vt_num_cus() * 32ull;
+            hipLaunchKernelGGL(wide_sample_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, (hipStream_t)stream, a.d, a.nearest, C, (float *)ws);
+            a.d.c_direct = (const float *)ws;
+        }
+        const size_t lds = wp_lds_bytes(n_blocks);
+        hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_wide_p_kernel), 160 * 1024);
+        if (e != hipSuccess) return vt_check(e, "vt_decode_fwd_wide_f16x3: hipFuncSetAttribute");
+        const uint32_t ntiles = (a.d.total + WP_PTS - 1) / WP_PTS, cap = (uint32_t)vt_num_cus();
+        hipLaunchKernelGGL(decode_wide_p_kernel, dim3(ntiles < cap ? ntiles : cap), dim3((2 * n_blocks + 2) * 64), lds, (hipStream_t)stream, a);
+        return vt_check(hipGetLastError(), "vt_decode_fwd_wide_f16x3");
+    }
     const int waves = hidden <= 128 ? 4 : 8;
     const int wid = hidden > a.Kp ? hidden : a.Kp;
     // pairs of point groups per tile: what the spare waves can take, as far as the planes fit the LDS
@@ -867,6 +891,19 @@ int vt_decode_fwd_wide_f16x3(const float *grid_cl, int B, int R, int C, const fl
                              float *out, float *out2, void *stream) {
     return wideh_fwd_impl(grid_cl, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img, nullptr, nullptr, blob, hidden, n_blocks,
                           flags, padding, out, out2, stream);
+}
+
+size_t vt_decode_wide_f16x3_workspace_bytes(int64_t total_points, int hidden, int c_dim, int n_blocks, int tactile) {
+    if (total_points <= 0 || !wide_pipe_shape(hidden, c_dim, n_blocks, tactile ? 3 + c_dim : 3)) return 0;
+    return (size_t)total_points * c_dim * sizeof(float);
+}
+
+int vt_decode_fwd_wide_f16x3_ws(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,
+                                int lattice_nx, float lattice_box, int64_t lattice_first,
+                                const float *c_img, const float *blob, int hidden, int n_blocks, int flags, double padding,
+                                float *out, float *out2, void *workspace, size_t workspace_bytes, void *stream) {
+    return wideh_fwd_impl(grid_cl, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img, nullptr, nullptr, blob, hidden, n_blocks,
+                          flags, padding, out, out2, stream, nullptr, workspace, workspace_bytes);
 }
 
 int vt_decode_fwd_wide_f16x3_ids(const float *grid_cl, int B, int R, int C, const float *pts, int64_t N,

@@ -228,6 +228,9 @@ def _cl_storage(grid):
     return g, dev_ptr(g.permute(0, 2, 3, 4, 1), "grid")
 
 
+_wide_ws = {}          # per device: the sampling workspace of the 64 / 32 pipeline (vt_decode_fwd_wide_f16x3_ws)
+
+
 def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want_contact=False, out=None, save=None,
                precision="f32", wide=None, finger_ids=None, finger_feats=None):
     """Fused trilinear gather + conditioned MLP (vt_decode_fwd; ``precision="bf16x3"`` / ``"f16x3"``:
@@ -282,6 +285,18 @@ def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want
                                               dev_ptr(feats, "finger_feats"), int(feats.shape[0]), dev_ptr(blob, "blob"), int(hidden),
                                               int(nb), flags, float(padding), dev_ptr(out, "out"), dev_ptr(out2, "out2"), stream_ptr()),
                   name + "_ids")
+            return (out, out2) if want_contact else out
+        wsb = lib.vt_decode_wide_f16x3_workspace_bytes(B * N, int(hidden), C, int(nb), 0 if c_img is None else 1) if precision == "wide_f16x3" else 0
+        if wsb:
+            # 64 / 32 / <= 5: the register-resident pipeline on the grid's samples, which a pre-pass leaves in this workspace
+            ws = _wide_ws.get(grid.device)
+            if ws is None or ws.numel() < wsb:
+                ws = _wide_ws[grid.device] = torch.empty(wsb, dtype=torch.uint8, device=grid.device)
+            keep_for_graph(ws)
+            check(lib.vt_decode_fwd_wide_f16x3_ws(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first, dev_ptr(c_img, "c_img"),
+                                                  dev_ptr(blob, "blob"), int(hidden), int(nb), flags, float(padding), dev_ptr(out, "out"),
+                                                  dev_ptr(out2, "out2"), ctypes.c_void_p(ws.data_ptr()), wsb, stream_ptr()),
+                  "vt_decode_fwd_wide_f16x3_ws")
             return (out, out2) if want_contact else out
         check(getattr(lib, name)(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first, dev_ptr(c_img, "c_img"),
                                  dev_ptr(blob, "blob"), int(hidden), int(nb), flags, float(padding),
