@@ -645,6 +645,10 @@ int vt_conv3d_gcr_f16x3_skip(const float *x, int C, int B, int D, int H, int W, 
                              int Cout, int relu, const unsigned char *tile_flags, float *out, float *out_part, void *stream);
 size_t vt_conv3d_packed_floats_f16x3(int Cout, int Cin);
 int vt_conv3d_pack_f16x3(const float *w, int Cout, int Cin, float *packed, void *stream);
+/* the fragments of the conv that computes this layer's DATA GRADIENT (autograd of unet3d.py:20-72: conv_transpose = the forward    */
+/* kernels on W with channels swapped and taps flipped) straight from w [Cout][Cin][27]: vt_conv3d_packed_floats_f16x3(Cin, Cout)   */
+/* floats, equal to vt_conv3d_pack_f16x3 of w.flip(2,3,4).transpose(0,1) without that copy.                                         */
+int vt_conv3d_pack_f16x3_t(const float *w, int Cout, int Cin, float *packed, void *stream);
 int vt_conv3d_stat_blocks_f16x3(int B, int D, int H, int W, int Cin, int Cout);
 int vt_conv3d_gcr_f16x3(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                         const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
@@ -745,6 +749,15 @@ int vt_gn_bwd(const float *skip, int C1, const float *low, int C2, int B, int D,
               const float *part1, int nblk1, const float *part2, int nblk2,
               const float *dxn, int groups, const float *gamma, double eps,
               float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow, void *stream);
+/* vt_gn_bwd that also does the relu_mask pass of the layer(s) in front (autograd of unet3d.py:20-72: ReLU behind the conv whose   */
+/* output this GroupNorm reads).  mask_flags bit 0: `skip` is such a ReLU output and dskip is its only gradient -- dskip comes out  */
+/* as (skip > 0 ? dskip : 0) with max |dskip| in the device scalar absmax_skip, exactly what vt_relu_mask_absmax(dskip, skip)      */
+/* would leave; bit 1: the same for `low` / dlow / absmax_low.  The layer in front then skips its vt_relu_mask_absmax.             */
+int vt_gn_bwd_masked(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                     const float *part1, int nblk1, const float *part2, int nblk2,
+                     const float *dxn, int groups, const float *gamma, double eps,
+                     float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow,
+                     int mask_flags, float *absmax_skip, float *absmax_low, void *stream);
 int vt_maxpool3d_cl_bwd(const float *x, const float *dy, int B, int D, int H, int W, int C, float *dx, void *stream);
 
 /* ------------------------------------------------------------------------- */

@@ -274,6 +274,33 @@ def test_relu_mask_absmax_and_degenerate_gradients():
     assert torch.isnan(dwn).any()                                  # a NaN gradient stays visible in dW
 
 
+def test_masked_groupnorm_backward_and_the_transposed_pack_equal_their_two_step_forms():
+    """vt_gn_bwd_masked leaves the gradients of `skip` / `low` already masked by (skip > 0) / (low > 0) with their max |.| -- the
+    relu_mask pass of the layer in front folded into the GroupNorm backward of the layer that reads it (bit for bit what
+    vt_relu_mask_absmax computes from the unmasked gradients); vt_conv3d_pack_f16x3_t packs the data-gradient conv's fragments
+    straight from the weight (bit for bit the pack of weight.flip(2, 3, 4).transpose(0, 1))."""
+    from vtaco_amd import ops
+    g = torch.Generator().manual_seed(91)
+    for B, R, C1, C2 in ((2, 16, 32, 0), (1, 16, 32, 64), (3, 8, 64, 32)):
+        x = torch.randn(B, R, R, R, C1, generator=g).relu().to(DEV)
+        low = torch.randn(B, R // 2, R // 2, R // 2, C2, generator=g).relu().to(DEV) if C2 else None
+        dxn = (torch.randn(B, R, R, R, C1 + C2, generator=g) * 1e-4).to(DEV)
+        gamma = (1 + 0.2 * torch.randn(C1 + C2, generator=g)).to(DEV)
+        xs, ls = ops.channel_stats(x), (ops.channel_stats(low) if C2 else None)
+        dskip, dlow, dg, db = ops.gn_bwd(x, xs, low, ls, dxn, gamma, 8, 1e-5)
+        mskip, mlow, mg, mb, am_s, am_l = ops.gn_bwd(x, xs, low, ls, dxn, gamma, 8, 1e-5, mask_skip=True, mask_low=C2 > 0)
+        want, wmax = ops.relu_mask(dskip, x, want_absmax=True)
+        assert torch.equal(mskip, want) and torch.equal(am_s, wmax.reshape(1)) and torch.equal(mg, dg) and torch.equal(mb, db)
+        if C2:
+            want, wmax = ops.relu_mask(dlow, low, want_absmax=True)
+            assert torch.equal(mlow, want) and torch.equal(am_l, wmax.reshape(1))
+        else:
+            assert mlow is None and am_l is None
+    for Cout, Cin in ((32, 32), (64, 96), (128, 32)):
+        w = torch.randn(Cout, Cin, 3, 3, 3, generator=g).to(DEV)
+        assert torch.equal(ops.conv3d_pack_t(w), ops.conv3d_pack(w.flip(2, 3, 4).transpose(0, 1).contiguous(), precision="f16x3"))
+
+
 def test_maxpool_with_statistics_equals_the_two_passes():
     """vt_maxpool3d_cl_stats = vt_maxpool3d_cl followed by vt_channel_stats, bit for bit (same blocks, same summation order)."""
     from vtaco_amd import ops

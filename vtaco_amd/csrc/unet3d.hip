@@ -1017,7 +1017,9 @@ constexpr size_t hb_lds(int TZ) { return 2 * hb_img_bytes(TZ) + 2 * (size_t)HB_W
 static_assert(hb_lds(8) <= 160 * 1024, "split-f16 conv: LDS budget");
 
 // weights -> [cin/8][cout/32][k-step 0..13][hi,lo][64 lanes][8 halves]: lane (co, kg), element e = cin 8q + e of tap 2s + kg
-__global__ void conv3d_pack_h_kernel(const float *w, int Cout, int Cin, float *packed, size_t total) {
+// transposed: w is the [Cin][Cout][27] weight of the conv whose DATA GRADIENT this one is -- (co, ci, tap) reads w[ci][co][26 - tap]
+// (channels swapped, taps flipped) without a flipped / transposed copy of the tensor
+__global__ void conv3d_pack_h_kernel(const float *w, int Cout, int Cin, float *packed, size_t total, int transposed = 0) {
     for (size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (size_t)gridDim.x * blockDim.x) {
         const int l = (int)(f & 63), part = (int)((f >> 6) & 1);
         size_t r = f >> 7;
@@ -1029,7 +1031,7 @@ __global__ void conv3d_pack_h_kernel(const float *w, int Cout, int Cin, float *p
         f16x8 v;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float x = tap < 27 ? w[((size_t)co * Cin + 8 * q + e) * 27 + tap] : 0.0f;
+            const float x = tap >= 27 ? 0.0f : transposed ? w[((size_t)(8 * q + e) * Cout + co) * 27 + (26 - tap)] : w[((size_t)co * Cin + 8 * q + e) * 27 + tap];
             const _Float16 hb = (_Float16)x;
             v[e] = part ? (_Float16)(x - (float)hb) : hb;
         }
@@ -2705,6 +2707,16 @@ int vt_conv3d_pack_f16x3(const float *w, int Cout, int Cin, float *packed, void 
     return vt_check(hipGetLastError(), "vt_conv3d_pack_f16x3");
 }
 
+int vt_conv3d_pack_f16x3_t(const float *w, int Cout, int Cin, float *packed, void *stream) {
+    if (!w || !packed) return vt_fail(VT_ERR_INVALID, "vt_conv3d_pack_f16x3_t: null argument");
+    const size_t frags = vt_conv3d_packed_floats_f16x3(Cin, Cout) / 4;          // the data-gradient conv maps Cout -> Cin channels
+    if (!frags) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_pack_f16x3_t: channel counts must be multiples of 32");
+    size_t g = (frags + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(conv3d_pack_h_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, packed, frags, 1);
+    return vt_check(hipGetLastError(), "vt_conv3d_pack_f16x3_t");
+}
+
 int vt_conv3d_stat_blocks_f16x3(int B, int D, int H, int W, int Cin, int Cout) {
     const int tz = conv_h_tz(B, D, H, W, Cin, Cout);
     return tz ? conv_h_wgs_per_scene(B, D, H, W, Cout, tz) : 0;
@@ -3900,11 +3912,17 @@ gn_bwd_coeffs_kernel(StatSrc s1, StatSrc s2, const float *bpart, int nblkb, int 
 }
 
 // dskip[v][c] = A dxn + B x + C  (c < C1);   dlow[v2][c] = sum over the 8 children of the same (c >= C1)
+// mask bit 0 / bit 1: `skip` / `low` is the ReLU output of the layer in front and this gradient is that layer's only one, so the
+// layer's relu_mask pass happens here -- (x > 0 ? d : 0) with the running max |.| for its power-of-two rescale (amax_skip /
+// amax_low: cells the launcher zeroed, one atomicMax per workgroup as relu_mask_kernel) -- instead of in a pass of its own
 __global__ void __launch_bounds__(256)
-gn_bwd_apply_kernel(Src s, const float *dxn, const float *coef, float *dskip, float *dlow) {
+gn_bwd_apply_kernel(Src s, const float *dxn, const float *coef, float *dskip, float *dlow, int mask, unsigned *amax_skip, unsigned *amax_low) {
     const int C = s.C1 + s.C2;
     const size_t V = (size_t)s.D * s.H * s.W;
     const int b = blockIdx.y;
+    auto bits = [](float x) { return __builtin_bit_cast(unsigned, x) & 0x7fffffffu; };
+    __shared__ unsigned wmax[2][4];
+    unsigned us = 0, ul = 0;
     if (dskip) {
         const size_t total = V * (s.C1 / 4);
         for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
@@ -3916,6 +3934,10 @@ gn_bwd_apply_kernel(Src s, const float *dxn, const float *coef, float *dskip, fl
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = fmaf(cf[3 * k], d[k], fmaf(cf[3 * k + 1], x[k], cf[3 * k + 2]));
+            if (mask & 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { o[k] = x[k] > 0.f ? o[k] : 0.f; us = max(us, bits(o[k])); }
+            }
             *reinterpret_cast<f32x4 *>(dskip + ((size_t)b * V + v) * s.C1 + c4) = o;
         }
     }
@@ -3938,8 +3960,25 @@ gn_bwd_apply_kernel(Src s, const float *dxn, const float *coef, float *dskip, fl
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = fmaf(cf[3 * k], dsum[k], 8.0f * fmaf(cf[3 * k + 1], x[k], cf[3 * k + 2]));
+            if (mask & 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { o[k] = x[k] > 0.f ? o[k] : 0.f; ul = max(ul, bits(o[k])); }
+            }
             *reinterpret_cast<f32x4 *>(dlow + ((size_t)b * V2 + v2) * s.C2 + c4) = o;
         }
+    }
+    if (!mask) return;
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)us, o), u = (unsigned)__shfl_xor((int)ul, o);
+        us = t > us ? t : us; ul = u > ul ? u : ul;
+    }
+    if ((threadIdx.x & 63) == 0) { wmax[0][threadIdx.x >> 6] = us; wmax[1][threadIdx.x >> 6] = ul; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const unsigned *w = wmax[threadIdx.x];
+        const unsigned a0 = w[0] > w[1] ? w[0] : w[1], a1 = w[2] > w[3] ? w[2] : w[3];
+        unsigned *dst = threadIdx.x ? amax_low : amax_skip;
+        if (dst && ((mask >> threadIdx.x) & 1)) atomicMax(dst, a0 > a1 ? a0 : a1);
     }
 }
 
@@ -4085,14 +4124,17 @@ int vt_conv3d_wgrad_f16x3(const float *skip, int C1, const float *low, int C2, i
     return vt_check(hipGetLastError(), "vt_conv3d_wgrad_f16x3");
 }
 
-int vt_gn_bwd(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
-              const float *part1, int nblk1, const float *part2, int nblk2,
-              const float *dxn, int groups, const float *gamma, double eps,
-              float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow, void *stream) {
+int vt_gn_bwd_masked(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                     const float *part1, int nblk1, const float *part2, int nblk2,
+                     const float *dxn, int groups, const float *gamma, double eps,
+                     float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow,
+                     int mask_flags, float *absmax_skip, float *absmax_low, void *stream) {
     Src s{skip, low, C1, low ? C2 : 0, D, H, W};
     if (!src_ok(s, B) || !part1 || nblk1 <= 0 || !dxn || !gamma || !bpart || nblkb <= 0 || !coef || !dgb)
         return vt_fail(VT_ERR_INVALID, "vt_gn_bwd: bad argument");
     if (low && (!part2 || nblk2 <= 0)) return vt_fail(VT_ERR_INVALID, "vt_gn_bwd: statistics of `low` missing");
+    if ((mask_flags & ~3) || ((mask_flags & 1) && (!dskip || !absmax_skip)) || ((mask_flags & 2) && (!dlow || !low || !absmax_low)))
+        return vt_fail(VT_ERR_INVALID, "vt_gn_bwd_masked: a masked gradient needs its output and its absmax cell");
     const int C = s.C1 + s.C2;
     if (groups <= 0 || C % groups || C / groups > 256) return vt_fail(VT_ERR_INVALID, "vt_gn_bwd: bad group count");
     hipStream_t st = (hipStream_t)stream;
@@ -4104,9 +4146,27 @@ int vt_gn_bwd(const float *skip, int C1, const float *low, int C2, int B, int D,
         const size_t V = (size_t)D * H * W;
         size_t blocks = (V * (size_t)(s.C1 / 4) + 255) / 256;
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)blocks, B), dim3(256), 0, st, s, dxn, (const float *)coef, dskip, dlow);
+        if (mask_flags) {
+            // (one atomicMax per workgroup on one address: a thousand of them at most, as vt_relu_mask_absmax)
+            const size_t cap = (size_t)(1024 / B > 1 ? 1024 / B : 1);
+            if (blocks > cap) blocks = cap;
+            hipError_t e = hipSuccess;
+            if (mask_flags & 1) e = hipMemsetAsync(absmax_skip, 0, sizeof(float), st);
+            if (e == hipSuccess && (mask_flags & 2)) e = hipMemsetAsync(absmax_low, 0, sizeof(float), st);
+            if (e != hipSuccess) return vt_check(e, "vt_gn_bwd_masked: hipMemsetAsync");
+        }
+        hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)blocks, B), dim3(256), 0, st, s, dxn, (const float *)coef, dskip, dlow,
+                           mask_flags, reinterpret_cast<unsigned *>(absmax_skip), reinterpret_cast<unsigned *>(absmax_low));
     }
     return vt_check(hipGetLastError(), "vt_gn_bwd");
+}
+
+int vt_gn_bwd(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+              const float *part1, int nblk1, const float *part2, int nblk2,
+              const float *dxn, int groups, const float *gamma, double eps,
+              float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow, void *stream) {
+    return vt_gn_bwd_masked(skip, C1, low, C2, B, D, H, W, part1, nblk1, part2, nblk2, dxn, groups, gamma, eps, bpart, nblkb, coef, dgb,
+                            dskip, dlow, 0, nullptr, nullptr, stream);
 }
 
 int vt_maxpool3d_cl_bwd(const float *x, const float *dy, int B, int D, int H, int W, int C, float *dx, void *stream) {

@@ -85,6 +85,19 @@ _WGRAD_F16 = os.environ.get("VTACO_UNET_WGRAD_PRECISION", "f16x3") != "f32"     
 _UP_TRAIN = os.environ.get("VTACO_CONV_UP_TRAIN", os.environ.get("VTACO_CONV_UP", "1")) != "0"      # A/B knob: per-parity forward convs in training
 
 
+class _MaskLink:
+    """Between a 'gcr' layer and the ONE layer that reads its output (forward_channels_last_train wires them): the reader's
+    GroupNorm backward leaves the gradient already masked by (output > 0), with its max |.| (ops.gn_bwd(mask_...)), and says so
+    here; the layer then skips its own relu_mask pass."""
+    __slots__ = ("ready", "gmax")
+
+    def __init__(self):
+        self.ready, self.gmax = False, None
+
+
+_MASK_FUSE = os.environ.get("VTACO_UNET_MASK_FUSE", "1") != "0"     # A/B knob
+
+
 class _GcrFn(torch.autograd.Function):
     """One 'gcr' SingleConv on channels-last tensors through the C ABI, differentiable:
     forward vt_gn_scale_shift + vt_conv3d_gcr[_bf16x3]; backward vt_relu_mask, the forward conv
@@ -93,7 +106,8 @@ class _GcrFn(torch.autograd.Function):
     vt_gn_bwd accounts for the statistics' dependence on x)."""
 
     @staticmethod
-    def forward(ctx, x, low, gamma, beta, weight, x_part, low_part, groups, eps, precision, tile_flags=None):
+    def forward(ctx, x, low, gamma, beta, weight, x_part, low_part, groups, eps, precision, tile_flags=None, out_link=None,
+                x_link=None, low_link=None):
         B, D, H, W, C1 = x.shape
         C2 = low.shape[-1] if low is not None else 0
         Cout = weight.shape[0]
@@ -116,6 +130,7 @@ class _GcrFn(torch.autograd.Function):
                                           packed_w_up=up)                                  # f32 pack on demand
         ctx.save_for_backward(x, low, gamma, weight, ss, y, x_part, low_part)
         ctx.cfg = (groups, eps, precision)
+        ctx.links = (out_link, x_link, low_link)
         ctx.mark_non_differentiable(part)
         return y, part
 
@@ -123,28 +138,45 @@ class _GcrFn(torch.autograd.Function):
     def backward(ctx, dy, _dpart):
         x, low, gamma, weight, ss, y, x_part, low_part = ctx.saved_tensors
         groups, eps, precision = ctx.cfg
-        if precision == "f16x3":
+        out_link, x_link, low_link = ctx.links
+        if out_link is not None and out_link.ready:
+            # the layer that reads y masked this gradient in its GroupNorm backward (and took its maximum)
+            g, gmax = (dy if dy.is_contiguous() else dy.contiguous()), out_link.gmax
+            out_link.ready, out_link.gmax = False, None
+        elif precision == "f16x3":
             g, gmax = ops.relu_mask(dy, y, want_absmax=True)                # max |g| from the same pass (the kernels' power-of-two rescale)
         else:
             g, gmax = ops.relu_mask(dy, y), None
-        w_t = weight.flip(2, 3, 4).transpose(0, 1).contiguous()          # [Cin,Cout,3,3,3]: conv of g with it = dxn
-        split = ops.conv3d_pack(w_t, "bf16x3") if precision == "bf16x3" else None
+        # dxn = conv of g with the weight's channels swapped and taps flipped ([Cin,Cout,3,3,3]); the copy only where a kernel wants it
+        w_tc = []
+
+        def w_t():
+            if not w_tc:
+                w_tc.append(weight.flip(2, 3, 4).transpose(0, 1).contiguous())
+            return w_tc[0]
+        split = ops.conv3d_pack(w_t(), "bf16x3") if precision == "bf16x3" else None
         half = None
         if precision == "f16x3":
             # output gradients sit many orders of magnitude below the half range: the kernel scales them by a power of two
             # taken from their largest element before the split (exact), so the data gradient keeps f32-level accuracy
-            half = ops.conv3d_pack(w_t, "f16x3")
-        dxn, _ = ops.conv3d_gcr(g, None, None, lambda: ops.conv3d_pack(w_t), w_t.shape[0], False, split, want_stats=False,
+            half = ops.conv3d_pack_t(weight)
+        dxn, _ = ops.conv3d_gcr(g, None, None, lambda: ops.conv3d_pack(w_t()), weight.shape[1], False, split, want_stats=False,
                                 packed_w_f16x3=half, in_absmax=gmax)
         # weight gradient: split-half operands as well (K = voxels; g under the same power-of-two rescale)
         dw = ops.conv3d_wgrad(x, low, ss, g, precision="f16x3" if precision == "f16x3" and _WGRAD_F16 else "f32",
                               g_absmax=gmax) if ctx.needs_input_grad[4] else None
         x_st = (x_part, x_part.shape[1])
         low_st = (low_part, low_part.shape[1]) if low is not None else None
-        dskip, dlow, dgamma, dbeta = ops.gn_bwd(x, x_st, low, low_st, dxn, gamma, groups, eps,
-                                                want_skip=ctx.needs_input_grad[0],
-                                                want_low=low is not None and ctx.needs_input_grad[1])
-        return dskip, dlow, dgamma, dbeta, dw, None, None, None, None, None, None
+        m_skip = x_link is not None and ctx.needs_input_grad[0]
+        m_low = low_link is not None and low is not None and ctx.needs_input_grad[1]
+        res = ops.gn_bwd(x, x_st, low, low_st, dxn, gamma, groups, eps, want_skip=ctx.needs_input_grad[0],
+                         want_low=low is not None and ctx.needs_input_grad[1], mask_skip=m_skip, mask_low=m_low)
+        dskip, dlow, dgamma, dbeta = res[:4]
+        if m_skip:
+            x_link.ready, x_link.gmax = True, res[4]
+        if m_low:
+            low_link.ready, low_link.gmax = True, res[5]
+        return dskip, dlow, dgamma, dbeta, dw, None, None, None, None, None, None, None, None, None
 
 
 class _MaxPoolFn(torch.autograd.Function):
@@ -387,22 +419,36 @@ class UNet3D(nn.Module):
         def stats(t):
             return ops.channel_stats(t.detach())[0]
 
-        def gcr(single, t, part, low=None, low_part=None, flags=None):
+        def gcr(single, t, part, low=None, low_part=None, flags=None, out_link=None, x_link=None, low_link=None):
             gn, conv = single.groupnorm, single.conv
-            return _GcrFn.apply(t, low, gn.weight, gn.bias, conv.weight, part, low_part, gn.num_groups, gn.eps, self.train_precision, flags)
+            return _GcrFn.apply(t, low, gn.weight, gn.bias, conv.weight, part, low_part, gn.num_groups, gn.eps, self.train_precision, flags,
+                                out_link, x_link, low_link)
+
+        def link():
+            return _MaskLink() if _MASK_FUSE else None
+        # (a layer whose output has ONE reader hands its relu_mask pass to that reader's GroupNorm backward: the first conv of every
+        # DoubleConv, and the last conv of the bottom level and of every decoder level but the last, whose output is the `low` of the
+        # next decoder's entry conv; an encoder level's output feeds the pool AND its skip: two gradients, summed by autograd first)
         skips = []
         part = None
+        n_enc = len(self.encoders)
+        low_link = None
         for i, enc in enumerate(self.encoders):
             if i > 0:
                 x = _MaxPoolFn.apply(x)
             if i > 0 or part is None:
                 part = stats(x)
-            x, part = gcr(enc.basic_module.SingleConv1, x, part, flags=tile_flags if i == 0 else None)
-            x, part = gcr(enc.basic_module.SingleConv2, x, part)
+            l12 = link()
+            x, part = gcr(enc.basic_module.SingleConv1, x, part, flags=tile_flags if i == 0 else None, out_link=l12)
+            low_link = link() if (i == n_enc - 1 and len(self.decoders) > 0) else None
+            x, part = gcr(enc.basic_module.SingleConv2, x, part, x_link=l12, out_link=low_link)
             skips.append((x, part))
-        for dec, (skip, skip_part) in zip(self.decoders, skips[-2::-1]):
-            x, part = gcr(dec.basic_module.SingleConv1, skip, skip_part, low=x, low_part=part)
-            x, part = gcr(dec.basic_module.SingleConv2, x, part)
+        n_dec = len(self.decoders)
+        for k, (dec, (skip, skip_part)) in enumerate(zip(self.decoders, skips[-2::-1])):
+            l12 = link()
+            x, part = gcr(dec.basic_module.SingleConv1, skip, skip_part, low=x, low_part=part, out_link=l12, low_link=low_link)
+            low_link = link() if k + 1 < n_dec else None
+            x, part = gcr(dec.basic_module.SingleConv2, x, part, x_link=l12, out_link=low_link)
         w = self.final_conv.weight.reshape(self.final_conv.out_channels, -1)
         # 2 M voxels x 32 channels: the weight gradient is a 32 x 32 GEMM with K = 2 M (hipBLASLt: one 2.6 ms kernel) -> split-K
         x = _TallLinear.apply(x, w, self.final_conv.bias) if x.numel() // x.shape[-1] >= 4096 else F.linear(x, w, self.final_conv.bias)

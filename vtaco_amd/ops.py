@@ -1245,6 +1245,20 @@ def conv3d_pack(weight, precision="f32"):
     return out
 
 
+def conv3d_pack_t(weight):
+    """vt_conv3d_pack_f16x3_t: the split-f16 fragments of the data-gradient conv of a [Cout,Cin,3,3,3] weight (channels swapped, taps
+    flipped) without materialising weight.flip(2, 3, 4).transpose(0, 1)."""
+    lib = _lib.load()
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    n = lib.vt_conv3d_packed_floats_f16x3(Cin, Cout)
+    if n == 0 or tuple(weight.shape[2:]) != (3, 3, 3):
+        raise VtError(f"conv3d_pack_t: unsupported weight shape {tuple(weight.shape)}")
+    w = _c(weight)
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(lib.vt_conv3d_pack_f16x3_t(dev_ptr(w, "w"), Cout, Cin, dev_ptr(out, "packed"), stream_ptr()), "vt_conv3d_pack_f16x3_t")
+    return out
+
+
 def conv3d_pack_up(weight, c_skip):
     """The merged class weights of a decoder-entry conv's upsampled channels (vt_conv3d_pack_f16x3_up): ``weight``
     [Cout, c_skip + C2, 3, 3, 3] of the layer that reads [skip | upsample(low)]; None where the per-parity kernel does not
@@ -1452,9 +1466,12 @@ def conv3d_wgrad(x, low, ss, g, precision="f32", g_absmax=None):
     return dw
 
 
-def gn_bwd(x, x_stats, low, low_stats, dxn, gamma, groups, eps, want_skip=True, want_low=True):
+def gn_bwd(x, x_stats, low, low_stats, dxn, gamma, groups, eps, want_skip=True, want_low=True, mask_skip=False, mask_low=False):
     """GroupNorm backward of xn = GN([x | upsample(low)]) given dxn (vt_gn_bwd): returns
-    (dskip or None, dlow or None, dgamma [C], dbeta [C])."""
+    (dskip or None, dlow or None, dgamma [C], dbeta [C]).  ``mask_skip`` / ``mask_low`` (vt_gn_bwd_masked): x / low is the ReLU
+    output of the layer in front and this is its only gradient -- the gradient comes out masked by (x > 0) and the call returns
+    (dskip, dlow, dgamma, dbeta, absmax_skip, absmax_low) with the device scalars max |gradient| (None where not asked): what that
+    layer's relu_mask(..., want_absmax=True) would compute in a pass of its own."""
     B, D, H, W, C1 = x.shape
     C2 = low.shape[-1] if low is not None else 0
     C = C1 + C2
@@ -1467,13 +1484,20 @@ def gn_bwd(x, x_stats, low, low_stats, dxn, gamma, groups, eps, want_skip=True, 
     dskip = torch.empty_like(x) if want_skip else None
     dlow = torch.empty_like(low) if (low is not None and want_low) else None
     p2, n2 = low_stats if low is not None else (None, 0)
-    check(_lib.load().vt_gn_bwd(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W,
-                                dev_ptr(x_stats[0], "part1"), x_stats[1], dev_ptr(p2, "part2"), n2,
-                                dev_ptr(_c(dxn), "dxn"), groups, dev_ptr(_c(gamma), "gamma"), float(eps),
-                                dev_ptr(bpart, "bpart"), nblkb, dev_ptr(coef, "coef"), dev_ptr(dgb, "dgb"),
-                                dev_ptr(dskip, "dskip"), dev_ptr(dlow, "dlow"), stream_ptr()), "vt_gn_bwd")
-    g = dgb.sum(0)
-    return dskip, dlow, g[:, 0].contiguous(), g[:, 1].contiguous()
+    mask_skip = bool(mask_skip and dskip is not None)
+    mask_low = bool(mask_low and dlow is not None)
+    am_s = torch.empty(1, dtype=torch.float32, device=dev) if mask_skip else None
+    am_l = torch.empty(1, dtype=torch.float32, device=dev) if mask_low else None
+    check(_lib.load().vt_gn_bwd_masked(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W,
+                                       dev_ptr(x_stats[0], "part1"), x_stats[1], dev_ptr(p2, "part2"), n2,
+                                       dev_ptr(_c(dxn), "dxn"), groups, dev_ptr(_c(gamma), "gamma"), float(eps),
+                                       dev_ptr(bpart, "bpart"), nblkb, dev_ptr(coef, "coef"), dev_ptr(dgb, "dgb"),
+                                       dev_ptr(dskip, "dskip"), dev_ptr(dlow, "dlow"), (1 if mask_skip else 0) | (2 if mask_low else 0),
+                                       dev_ptr(am_s, "absmax_skip"), dev_ptr(am_l, "absmax_low"), stream_ptr()), "vt_gn_bwd_masked")
+    g = dgb.sum(0).t().contiguous()              # [2, C]: dgamma, dbeta as rows
+    if mask_skip or mask_low:
+        return dskip, dlow, g[0], g[1], am_s, am_l
+    return dskip, dlow, g[0], g[1]
 
 
 def maxpool3d_cl_bwd(x, dy):
