@@ -9,7 +9,7 @@ O=/tmp/vt_variant_$NAME; mkdir -p $O $R/variants
 cd $R/vtaco_amd/csrc
 for f in *.hip; do
   b=${f%.hip}; extra=""
-  case $b in decode|decode_bwd|fusion) extra="-fno-honor-nans";; decode_f16) extra="-fno-honor-nans -fno-slp-vectorize";; esac
+  case $b in decode|decode_bwd|fusion) extra="-fno-honor-nans";; decode_f16|decode_wide) extra="-fno-honor-nans -fno-slp-vectorize";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DVT_WAVES_PER_SIMD=4 -I../../include $extra $FLAGS -c $f -o $O/$b.o &
 done
 wait
