@@ -327,7 +327,7 @@ template <bool HAS_W>
 __global__ void __launch_bounds__(FT)
 fusion_expsum8_kernel(const float *Fd, const float *Sd, const float *w, float *out, int N, int recip_out, int nrb, int B) {
     __shared__ __attribute__((aligned(16))) float tiles[2][STILE8];
-    __shared__ __attribute__((aligned(16))) float wt[2][32];
+    __shared__ __attribute__((aligned(16))) float wt[32];
     int rb, b;
     chunk_of_workgroup(nrb, B, rb, b);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
@@ -339,38 +339,43 @@ fusion_expsum8_kernel(const float *Fd, const float *Sd, const float *w, float *o
     const int ntile = (N + 31) / 32;
     const bool mover = threadIdx.x < 384;
     f32x4 tr;
-    float wreg = 0.0f;
-    auto fetch = [&](int t) {
-        if (mover) tr = tile_fetch8(Sd, t * 32, N);
-        if (HAS_W || t == ntile - 1) {
-            if (threadIdx.x < 32) { const int i = t * 32 + threadIdx.x; wreg = (i < N) ? (w ? w[i] : 1.0f) : 0.0f; }
-        }
-    };
+    auto fetch = [&](int t) { if (mover) tr = tile_fetch8(Sd, t * 32, N); };
     fetch(0);
     if (mover) tile_store8(tiles[0], tr);
-    if (threadIdx.x < 32) wt[0][threadIdx.x] = wreg;
-    // without weights only a ragged LAST tile needs them (zeros for the rows beyond N): buffer 1 holds that tile's
-    if (!HAS_W && threadIdx.x < 32) { const int i = (ntile - 1) * 32 + threadIdx.x; wt[1][threadIdx.x] = i < N ? 1.0f : 0.0f; }
+    // a ragged LAST tile needs weights that are zero for the rows beyond N (and w, or 1, for the others): in LDS; every other tile's
+    // weights (HAS_W) come straight from global memory -- 16 floats per lane, the same for all lanes of a half wave, requested
+    // before the tile's score MFMAs: they were 4 of the 10 ds_read_b128 per tile on the pipe that bounds this kernel
+    if (threadIdx.x < 32) { const int i = (ntile - 1) * 32 + threadIdx.x; wt[threadIdx.x] = i < N ? (w ? w[i] : 1.0f) : 0.0f; }
     __syncthreads();
     float sum = 0.0f;
+    const bool ragged = (N & 31) != 0;
     for (int t = 0; t < ntile; ++t) {
         const int cur = t & 1;
         if (t + 1 < ntile) fetch(t + 1);
-        FragQK8 stream;
-        load_fragqk8(stream, tiles[cur] + j * SROW8, h);
-        const f32x16 sc = score_tile8(stream, fixed);
-        if (HAS_W || (t == ntile - 1 && (N & 31) != 0)) {
-            const f32x16 ww = load_acc16(HAS_W ? wt[cur] : wt[1], h);   // w of streamed row chan_of(r,h)
+        const bool last_ragged = ragged && t == ntile - 1;
+        if constexpr (HAS_W) {
+            f32x16 ww;
+            if (!last_ragged) ww = load_acc16(w + (size_t)t * 32, h);           // w of streamed row chan_of(r,h)
+            FragQK8 stream;
+            load_fragqk8(stream, tiles[cur] + j * SROW8, h);
+            const f32x16 sc = score_tile8(stream, fixed);
+            if (last_ragged) ww = load_acc16(wt, h);
 #pragma unroll
             for (int r = 0; r < 16; ++r) sum = fmaf(exp2_unit(sc[r]), ww[r], sum);
         } else {
+            FragQK8 stream;
+            load_fragqk8(stream, tiles[cur] + j * SROW8, h);
+            const f32x16 sc = score_tile8(stream, fixed);
+            if (last_ragged) {
+                const f32x16 ww = load_acc16(wt, h);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sum += exp2_unit(sc[r]);
+                for (int r = 0; r < 16; ++r) sum = fmaf(exp2_unit(sc[r]), ww[r], sum);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += exp2_unit(sc[r]);
+            }
         }
-        if (t + 1 < ntile) {
-            if (mover) tile_store8(tiles[cur ^ 1], tr);
-            if (HAS_W && threadIdx.x < 32) wt[cur ^ 1][threadIdx.x] = wreg;
-        }
+        if (t + 1 < ntile && mover) tile_store8(tiles[cur ^ 1], tr);
         __syncthreads();
     }
     sum += __shfl_xor(sum, 32);
@@ -424,18 +429,20 @@ fusion_scalev8_kernel(const float *V, const float *s, float *VT, int N, int ntil
             hi[r] = (float)hb;
             lo[r] = v - (float)hb;
         }
-        u32x4 *row = reinterpret_cast<u32x4 *>(VT) + ((bt * 32 + c) * 2 + kg) * 4;
+        // piece i of lane (c, kg) at [tile][i][c * 2 + kg]: the 64 lanes of a wave read one contiguous KB per piece (the attend kernel
+        // takes its operand straight from here)
+        u32x4 *row = reinterpret_cast<u32x4 *>(VT) + bt * 256 + c * 2 + kg;
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             f16x8 f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = (_Float16)hi[8 * st + e];
-            row[st] = __builtin_bit_cast(u32x4, f);
+            row[st * 64] = __builtin_bit_cast(u32x4, f);
         }
         const float sl = 1.0f / (float)(1 << F8_VL);
-        row[2] = u32x4{fp8x4(lo[0], lo[1], lo[2], lo[3], sl), fp8x4(lo[4], lo[5], lo[6], lo[7], sl),
+        row[2 * 64] = u32x4{fp8x4(lo[0], lo[1], lo[2], lo[3], sl), fp8x4(lo[4], lo[5], lo[6], lo[7], sl),
                        fp8x4(lo[8], lo[9], lo[10], lo[11], sl), fp8x4(lo[12], lo[13], lo[14], lo[15], sl)};
-        row[3] = u32x4{fp8x4(hi[0], hi[1], hi[2], hi[3], 1.0f), fp8x4(hi[4], hi[5], hi[6], hi[7], 1.0f),
+        row[3 * 64] = u32x4{fp8x4(hi[0], hi[1], hi[2], hi[3], 1.0f), fp8x4(hi[4], hi[5], hi[6], hi[7], 1.0f),
                        fp8x4(hi[8], hi[9], hi[10], hi[11], 1.0f), fp8x4(hi[12], hi[13], hi[14], hi[15], 1.0f)};
     }
 }
@@ -453,7 +460,9 @@ fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const fl
     static_assert(!(F8 && (TRAIN || FULL)), "the fp8-corrected tiles are the inference form");
     __shared__ __attribute__((aligned(16))) float lds[FU_BLOB];
     __shared__ __attribute__((aligned(16))) float tiles[2][F8 ? STILE8 : STILE];
-    __shared__ __attribute__((aligned(16))) float vts[2][32 * VROW];
+    // (F8: V' does not go through LDS -- every lane's A operand is 64 contiguous bytes of the tile in global memory, requested a tile
+    // ahead: the LDS pipe, which the score tiles' fragments keep as busy as the matrix pipe, loses 4 of its 10 reads per tile)
+    __shared__ __attribute__((aligned(16))) float vts[2][F8 ? 4 : 32 * VROW];
     for (int i = threadIdx.x; i < FU_BLOB; i += FT) lds[i] = blob[i];
     if constexpr (F8) fp8_saturating_mode();
     int rb, b;
@@ -474,15 +483,27 @@ fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const fl
     const bool mover = !F8 || threadIdx.x < 384;
     auto fetch = [&](int t) {
         if constexpr (F8) { if (mover) tr = tile_fetch8(Kd, t * 32, N); }
-        else tr = tile_fetch(Kd, t * 32, N);
-        if (threadIdx.x < 256) vreg = *reinterpret_cast<const f32x4 *>(VT + (size_t)t * 1024 + threadIdx.x * 4);
+        else {
+            tr = tile_fetch(Kd, t * 32, N);
+            if (threadIdx.x < 256) vreg = *reinterpret_cast<const f32x4 *>(VT + (size_t)t * 1024 + threadIdx.x * 4);
+        }
     };
     auto put = [&](int buf) {
         if constexpr (F8) { if (mover) tile_store8(tiles[buf], tr); }
-        else tile_store(tiles[buf], tr);
-        if (threadIdx.x < 256) *reinterpret_cast<f32x4 *>(vts[buf] + vc * VROW + vk) = vreg;
+        else {
+            tile_store(tiles[buf], tr);
+            if (threadIdx.x < 256) *reinterpret_cast<f32x4 *>(vts[buf] + vc * VROW + vk) = vreg;
+        }
+    };
+    // F8: lane (channel j, k-group h)'s V' operand of tile t: [hi k-step 0 | hi k-step 1 | fp8 32 B]
+    u32x4 vq[4];
+    auto vload = [&](int t) {
+        const u32x4 *g = reinterpret_cast<const u32x4 *>(VT + (size_t)t * 1024) + j * 2 + h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vq[i] = g[i * 64];
     };
     fetch(0);
+    if constexpr (F8) vload(0);
     put(0);
     __syncthreads();
     const float m1 = opaque_minus_one();
@@ -515,11 +536,11 @@ fusion_attend_kernel(const float *Qd, const float *Kd, const float *VT, const fl
                 eq[4 + (p >> 1)] = fp8x4(l0, l1, l2, l3, 1.0f / (float)(1 << F8_EL));
             }
             // O^T[c][q] += V'[c][k] E[k][q]: A operand lane (c,kg): [hi k-step 0 | hi k-step 1 | fp8 32 B]
-            const u32x4 *vp = reinterpret_cast<const u32x4 *>(vts[cur] + j * VROW) + h * 4;
-            const u32x4 v2 = vp[2], v3 = vp[3];
-            o = mfma_s(__builtin_bit_cast(f16x8, vp[0]), __builtin_bit_cast(f16x8, eh[0]), o);
-            o = mfma_s(__builtin_bit_cast(f16x8, vp[1]), __builtin_bit_cast(f16x8, eh[1]), o);
+            const u32x4 v2 = vq[2], v3 = vq[3];
+            o = mfma_s(__builtin_bit_cast(f16x8, vq[0]), __builtin_bit_cast(f16x8, eh[0]), o);
+            o = mfma_s(__builtin_bit_cast(f16x8, vq[1]), __builtin_bit_cast(f16x8, eh[1]), o);
             o = mfma_f8<F8_EL>(u32x8{v2[0], v2[1], v2[2], v2[3], v3[0], v3[1], v3[2], v3[3]}, eq, o);
+            if (t + 1 < ntile) vload(t + 1);
         } else {
         FragQK stream;
         load_fragqk(stream, tiles[cur] + j * SROW, h);
