@@ -857,6 +857,25 @@ static int wideh_fwd_impl(const float *grid_cl, int B, int R, int C, const float
         hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_wide_p_kernel), 160 * 1024);
         if (e != hipSuccess) return vt_check(e, "vt_decode_fwd_wide_f16x3: hipFuncSetAttribute");
         const uint32_t ntiles = (a.d.total + WP_PTS - 1) / WP_PTS, cap = (uint32_t)vt_num_cus();
+#ifdef VT_DIAG_WP
+        {   // (variant build: the stage waves' phase counts of this launch, printed per wave index)
+            static unsigned long long *dbg = nullptr;
+            if (!dbg) hipMalloc(&dbg, (size_t)cap * 16 * 8 * sizeof(unsigned long long));
+            hipMemsetAsync(dbg, 0, (size_t)cap * 16 * 8 * sizeof(unsigned long long), (hipStream_t)stream);
+            a.d.save = reinterpret_cast<float *>(dbg);
+            hipLaunchKernelGGL(decode_wide_p_kernel, dim3(ntiles < cap ? ntiles : cap), dim3((2 * n_blocks + 2) * 64), lds, (hipStream_t)stream, a);
+            hipStreamSynchronize((hipStream_t)stream);
+            static unsigned long long host[512 * 16 * 8];
+            hipMemcpy(host, dbg, (size_t)cap * 16 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            if (getenv("VTACO_WP_PRINT"))
+                for (int w = 0; w < 2 * n_blocks; ++w) {
+                    double s_[8] = {0};
+                    for (uint32_t g = 0; g < cap; ++g) for (int i = 0; i < 8; ++i) s_[i] += (double)host[((size_t)g * 16 + w) * 8 + i] / cap;
+                    fprintf(stderr, "wave %2d: wait-res %8.0f  A %8.0f  bar1 %8.0f  B1 %8.0f  bar2 %8.0f  B2 %8.0f  loop %8.0f   (counts per launch)\n", w, s_[1], s_[2], s_[3], s_[4], s_[5], s_[6], s_[0]);
+                }
+            return vt_check(hipGetLastError(), "vt_decode_fwd_wide_f16x3");
+        }
+#endif
         hipLaunchKernelGGL(decode_wide_p_kernel, dim3(ntiles < cap ? ntiles : cap), dim3((2 * n_blocks + 2) * 64), lds, (hipStream_t)stream, a);
         return vt_check(hipGetLastError(), "vt_decode_fwd_wide_f16x3");
     }
