@@ -846,7 +846,9 @@ static int wideh_fwd_impl(const float *grid_cl, int B, int R, int C, const float
     a.status = vt_decode_status_dev();
     // 64 / 32 / <= 5 without tactile input columns: the weights in registers, the tiles through a pipeline of waves (decode_wide_pipe.inc)
     // on features given per point -- the caller's (c_direct), or the grid's samples left in the caller's workspace by a pre-pass
-    if (wide_pipe_shape(hidden, C, n_blocks, p_in) && (c_direct || (ws && ws_bytes >= (size_t)a.d.total * C * sizeof(float)))) {
+    // (the pipeline reads the features as 16-byte pieces: a feature tensor or workspace that is not 16-byte aligned keeps the streaming kernel)
+    if (wide_pipe_shape(hidden, C, n_blocks, p_in) &&
+        (c_direct ? ((size_t)c_direct & 15) == 0 : (ws && ((size_t)ws & 15) == 0 && ws_bytes >= (size_t)a.d.total * C * sizeof(float)))) {
         if (!c_direct) {
             const unsigned long long items = (unsigned long long)a.d.total * (C / 4);
             const unsigned long long want = (items + 255) / 256, cap = (unsigned long long)vt_num_cus() * 32ull;
