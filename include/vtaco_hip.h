@@ -521,6 +521,10 @@ int vt_voxel_build_clear_flags(const float *pts, int B, int T, int R, double pad
                                void *clear, size_t clear_bytes, unsigned char *tile_flags, void *stream);
 int vt_voxel_pool_max_fwd(const float *feat, const int *order, const int *seg_lo, const int *seg_hi,
                           int B, int T, int C, float *out, int *argmax, void *stream);
+/* pool_local with scatter_type = 'mean' (pointnet.py:64-69, 116-132: scatter_mean over the cells, gathered back to the points):  */
+/* out[b][t][c] = mean of feat over the points of t's cell (cells of a volume or a plane: the segments of vt_voxel_build /          */
+/* vt_plane_build).  Its backward is the same call on the gradient.                                                              */
+int vt_voxel_pool_mean(const float *feat, const int *order, const int *seg_lo, const int *seg_hi, int B, int T, int C, float *out, void *stream);
 int vt_voxel_pool_max_bwd(const float *grad_out, const int *argmax, const int *order,
                           const int *seg_lo, const int *seg_hi,
                           int B, int T, int C, float *grad_feat, void *stream);

@@ -268,6 +268,18 @@ def segment_pool_max(feat, index):
     return out
 
 
+def segment_pool_mean(feat, index):
+    """``pool_local`` with ``scatter_type='mean'`` (pointnet.py:64-69, 116-132: torch_scatter.scatter_mean over the cells,
+    gathered back to the points).  feat [B,T,C], index [B,T]."""
+    out = torch.empty_like(feat)
+    for b in range(feat.shape[0]):
+        uniq, inv = torch.unique(index[b], return_inverse=True)
+        acc = torch.zeros((uniq.numel(), feat.shape[2]), dtype=feat.dtype).index_add_(0, inv, feat[b])
+        cnt = torch.zeros(uniq.numel(), dtype=feat.dtype).index_add_(0, inv, torch.ones(index.shape[1], dtype=feat.dtype))
+        out[b] = (acc / cnt.unsqueeze(-1))[inv]
+    return out
+
+
 def scatter_mean_grid(feat, index, reso):
     """``generate_grid_features`` scatter part (pointnet.py:102-110):
     per-voxel mean, empty voxels 0; returns [B,C,R,R,R] (dims z,y,x)."""
@@ -280,7 +292,7 @@ def scatter_mean_grid(feat, index, reso):
     return grid.permute(0, 2, 1).reshape(B, C, reso, reso, reso)
 
 
-def pointnet_point_features(sd, p, reso, padding=0.1, return_stages=False):
+def pointnet_point_features(sd, p, reso, padding=0.1, return_stages=False, scatter_type="max"):
     """``LocalPoolPointnet.forward`` up to ``fc_c`` (pointnet.py:135-162).  The voxel ids are f32 arithmetic by
     definition (a float64 run of the oracle -- the yardstick tests measure f32 rounding noise against -- keeps them)."""
     idx = voxel_index(p.float(), reso, padding)
@@ -288,7 +300,7 @@ def pointnet_point_features(sd, p, reso, padding=0.1, return_stages=False):
     net = resnet_block_fc(sd, "blocks.0", net)
     stages = [net]
     for i in range(1, _n_blocks(sd)):
-        pooled = segment_pool_max(net, idx)
+        pooled = segment_pool_max(net, idx) if scatter_type == "max" else segment_pool_mean(net, idx)
         net = resnet_block_fc(sd, f"blocks.{i}", torch.cat([net, pooled], dim=2))
         stages.append(net)
     c = _lin(sd, "fc_c", net)
@@ -500,7 +512,7 @@ def unet2d_forward(sd, x):
     return F.conv2d(x, sd["conv_final.weight"], sd["conv_final.bias"])
 
 
-def plane_pointnet_forward(sd, p, reso, padding=0.1, planes=("xz", "xy", "yz"), return_stages=False):
+def plane_pointnet_forward(sd, p, reso, padding=0.1, planes=("xz", "xy", "yz"), return_stages=False, scatter_type="max"):
     """``LocalPoolPointnet.forward`` with plane_type=['xz','xy','yz'] (pointnet.py:135-176):
     pool_local SUMS the per-plane max-pools (:116-132); one scatter-mean plane (+ shared UNet) per key.
     Returns {plane: [B,C,R,R]} in the reference's dict order (xz, xy, yz)."""
@@ -509,7 +521,8 @@ def plane_pointnet_forward(sd, p, reso, padding=0.1, planes=("xz", "xy", "yz"), 
     net = resnet_block_fc(sd, "blocks.0", net)
     stages = [net]
     for i in range(1, _n_blocks(sd)):
-        pooled = sum(segment_pool_max(net, idx[k]) for k in planes)
+        pool = segment_pool_max if scatter_type == "max" else segment_pool_mean
+        pooled = sum(pool(net, idx[k]) for k in planes)
         net = resnet_block_fc(sd, f"blocks.{i}", torch.cat([net, pooled], dim=2))
         stages.append(net)
     c = _lin(sd, "fc_c", net)

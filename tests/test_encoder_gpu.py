@@ -52,6 +52,38 @@ def test_pointnet_stages_grid_vs_golden_and_determinism():
         assert torch.equal(occ, T(a[f"occ{b}"]))                    # empty voxels exactly zero
 
 
+def test_mean_pooling_vs_the_reference_fixture_and_its_backward():
+    """LocalPoolPointnet(scatter_type='mean') (pointnet.py:64-69, 116-132): the object grid and the hand encoder's three planes against
+    the reference's own outputs (g18: a cloud with outliers and 300 points in one cell), eval path and autograd path; the gradients of
+    every parameter against the oracle's autograd (vt_voxel_pool_mean is its own backward)."""
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd.encoder import encoder_dict
+    a, sd = load_golden("g18_pointnet_mean.npz")
+    p = T(a["p"])
+    for tag, kw in (("grid", dict(grid_resolution=16, plane_type='grid')), ("planes", dict(plane_resolution=16, plane_type=['xz', 'xy', 'yz']))):
+        enc = encoder_dict['pointnet_local_pool'](c_dim=32, dim=3, hidden_dim=32, scatter_type='mean', unet3d=False, unet=False, **kw)
+        enc.load_state_dict(sub_sd(sd, tag + "."), strict=True)
+        enc = enc.to(DEV)
+        with torch.no_grad():
+            fea = enc(p.to(DEV))
+        out = enc(p.to(DEV))                                       # under autograd: the module path with _PoolMean
+        for k in fea:
+            ref = T(a[f"{tag}.fea.{k}"])
+            assert float((fea[k].cpu() - ref).abs().max()) <= 1e-5 and float((out[k].detach().cpu() - ref).abs().max()) <= 1e-5, (tag, k)
+        w = {k: torch.randn(v.shape, generator=torch.Generator().manual_seed(7)) for k, v in out.items()}
+        sum((out[k] * w[k].to(DEV)).sum() for k in out).backward()
+        osd = {k: v.clone().requires_grad_(True) for k, v in sub_sd(sd, tag + ".").items()}
+        if tag == "grid":
+            c, idx = orc.pointnet_point_features(osd, p, 16, scatter_type="mean")
+            ofea = {"grid": orc.scatter_mean_grid(c, idx, 16)}
+        else:
+            ofea = orc.plane_pointnet_forward(osd, p, 16, scatter_type="mean")
+        sum((ofea[k] * w[k]).sum() for k in ofea).backward()
+        for name, prm in enc.named_parameters():
+            g, r = prm.grad.cpu(), osd[name].grad
+            assert float((g - r).abs().max()) <= 2e-4 * max(1.0, float(r.abs().max())), (tag, name)
+
+
 def test_full_encoder_with_unet3d_vs_golden():
     a, sd = load_golden("g4_unet3d.npz")
     enc = _encoder(sd, dict(num_levels=3, f_maps=8, in_channels=32, out_channels=32))

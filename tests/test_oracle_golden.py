@@ -81,6 +81,24 @@ def test_pointnet_stages_and_grid():
         assert torch.equal(occ, T(a[f"occ{b}"]))
 
 
+def test_pointnet_with_mean_pooling():
+    """pool_local with scatter_type='mean' (pointnet.py:64-69, 116-132) on the object grid and on the three planes, against the
+    reference's own outputs (g18, make_pointnet_mean_goldens.py): a cloud with outliers and 300 points in one cell."""
+    a, sd = load_golden("g18_pointnet_mean.npz")
+    p = T(a["p"])
+    c, idx, stages = orc.pointnet_point_features(sub_sd(sd, "grid."), p, 16, return_stages=True, scatter_type="mean")
+    assert maxdiff(stages[0], a["grid.stage0"]) <= 1e-5 and maxdiff(stages[4], a["grid.stage4"]) <= 1e-5
+    assert maxdiff(c, a["grid.fc_c"]) <= 1e-5
+    assert maxdiff(orc.scatter_mean_grid(c, idx, 16), a["grid.fea.grid"]) <= 1e-5
+    fea, _, stages, c = orc.plane_pointnet_forward(sub_sd(sd, "planes."), p, 16, return_stages=True, scatter_type="mean")
+    assert maxdiff(stages[4], a["planes.stage4"]) <= 1e-5 and maxdiff(c, a["planes.fc_c"]) <= 1e-5
+    for k in ("xz", "xy", "yz"):
+        assert maxdiff(fea[k], a[f"planes.fea.{k}"]) <= 1e-5
+    # and it is not the max pool
+    cm, _ = orc.pointnet_point_features(sub_sd(sd, "grid."), p, 16)
+    assert maxdiff(cm, a["grid.fc_c"]) > 1e-3
+
+
 def test_unet3d_and_full_encoder():
     a, sd = load_golden("g4_unet3d.npz")
     y = orc.unet3d_forward(sub_sd(sd, "unet3d."), T(a["x"]))

@@ -150,6 +150,7 @@ SIGNATURES = {
     "vt_voxel_build_clear": (_I, [_VP, _I, _I, _I, _D, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "vt_voxel_build_clear_flags": (_I, [_VP, _I, _I, _I, _D, _VP, _VP, _VP, _VP, _VP, _SZ, _VP, _VP]),
     "vt_voxel_pool_max_fwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
+    "vt_voxel_pool_mean": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
     "vt_voxel_pool_max_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
     "vt_voxel_scatter_mean_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "vt_voxel_scatter_mean_bwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),

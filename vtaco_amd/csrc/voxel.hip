@@ -367,6 +367,29 @@ __device__ __forceinline__ float block_segment_sum(const float *src_b, const int
     return tot;
 }
 
+// pool_local with scatter_type = 'mean' (pointnet.py:64-69, 116-132: torch_scatter.scatter_mean, gathered back): every point gets
+// the mean of the features of its cell.  The cell's first point (in sorted order) sums in that order and writes every member.
+// The backward is the same map applied to the gradient (the mean over a cell is self-adjoint).
+__global__ void __launch_bounds__(256)
+pool_mean_kernel(const float *feat, const int *order, const int *seg_lo, const int *seg_hi, float *out, int T, int C, uint32_t npts) {
+    uint32_t bt; int c0;
+    if (!point_lane(C, npts, bt, c0)) return;
+    const uint32_t b = bt / (uint32_t)T;
+    const int t = (int)(bt - b * (uint32_t)T);
+    const int lo = seg_lo[bt], hi = seg_hi[bt];
+    const int *ord = order + (size_t)b * T;
+    if (ord[lo] != t) return;                                   // the head of the cell works
+    const float *fb = feat + (size_t)b * T * C;
+    const float inv = 1.0f / (float)(hi - lo);
+    for (int c = c0; c < C; c += 256) {
+        float a = 0.0f;
+        for (int j = lo; j < hi; ++j) a += fb[(size_t)ord[j] * C + c];
+        a *= inv;
+        for (int j = lo; j < hi; ++j) out[((size_t)b * T + ord[j]) * C + c] = a;
+    }
+}
+
+
 // grad_feat[b,t,c] = sum over voxel-mates of grad_out[b,.,c] if t is the arg-max, else 0
 __global__ void __launch_bounds__(256)
 pool_max_bwd_kernel(const float *grad_out, const int *argmax, const int *order, const int *seg_lo, const int *seg_hi,
@@ -614,6 +637,15 @@ int vt_voxel_pool_max_fwd(const float *feat, const int *order, const int *seg_lo
     hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(sb + large_blocks(B, T)), dim3(256), 0, (hipStream_t)stream,
                        feat, order, seg_lo, seg_hi, out, argmax, T, C, (uint32_t)npts, sb);
     return vt_check(hipGetLastError(), "vt_voxel_pool_max_fwd");
+}
+
+int vt_voxel_pool_mean(const float *feat, const int *order, const int *seg_lo, const int *seg_hi, int B, int T, int C, float *out, void *stream) {
+    if (!feat || !order || !seg_lo || !seg_hi || !out) return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_mean: null argument");
+    if (B <= 0 || T <= 0 || C <= 0) return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_mean: bad size");
+    const size_t npts = (size_t)B * T;
+    hipLaunchKernelGGL(pool_mean_kernel, dim3(point_blocks(C, npts)), dim3(256), 0, (hipStream_t)stream, feat, order, seg_lo, seg_hi, out, T, C,
+                       (uint32_t)npts);
+    return vt_check(hipGetLastError(), "vt_voxel_pool_mean");
 }
 
 int vt_voxel_pool_max_bwd(const float *grad_out, const int *argmax, const int *order, const int *seg_lo, const int *seg_hi,

@@ -39,6 +39,19 @@ class _PoolMax(torch.autograd.Function):
         return ops.voxel_pool_max_bwd(grad, ctx.arg, ctx.vi), None
 
 
+class _PoolMean(torch.autograd.Function):
+    """pool_local with scatter_type='mean' (pointnet.py:64-69, 116-132): per-cell mean, gathered back; self-adjoint."""
+
+    @staticmethod
+    def forward(ctx, feat, vi):
+        ctx.vi = vi
+        return ops.voxel_pool_mean(feat, vi)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return ops.voxel_pool_mean(grad, ctx.vi), None
+
+
 class _LinearRowsFn(torch.autograd.Function):
     """nn.Linear over the rows of [B,T,Cin] on the HIP kernels: forward vt_linear_rows; backward vt_linear_rows on the
     transposed weight (data gradient) and vt_rows_wgrad (weight / bias gradients)."""
@@ -126,7 +139,7 @@ class _ScatterMeanPlane(torch.autograd.Function):
 
 
 class LocalPoolPointnet(nn.Module):
-    """Args as the reference (pointnet.py:32-35).  Built: scatter_type='max' with plane_type 'grid'
+    """Args as the reference (pointnet.py:32-35).  Built: scatter_type 'max' (the configs') and 'mean' with plane_type 'grid'
     (object encoder) or any of 'xz','xy','yz' (hand encoder; 'grid' and planes are not mixed)."""
 
     def __init__(self, c_dim=128, dim=3, hidden_dim=128, scatter_type='max', unet=False, unet_kwargs=None,
@@ -134,10 +147,9 @@ class LocalPoolPointnet(nn.Module):
                  plane_type='xz', padding=0.1, n_blocks=5, out_mano=False, out_dim=None,
                  manolayer_kwargs=None, **kwargs):
         super().__init__()
-        if scatter_type != 'max':
-            if scatter_type == 'mean':
-                raise VtError("LocalPoolPointnet: scatter_type='mean' pooling is not built (configs use 'max')")
+        if scatter_type not in ('max', 'mean'):
             raise ValueError('incorrect scatter type')
+        self.scatter_type = scatter_type
         planes = [plane_type] if isinstance(plane_type, str) else list(plane_type)
         # the reference walks the keys in this fixed order whatever the list says (pointnet.py:141-176)
         self.planes = [k for k in ('grid', 'xz', 'xy', 'yz') if k in planes]
@@ -202,13 +214,14 @@ class LocalPoolPointnet(nn.Module):
                 return _LinearRowsFn.apply(x, lin.weight, lin.bias)
             return tall_linear(lin, x)
         net = block(self.blocks[0], linear(self.fc_pos, p))
+        pool = _PoolMax.apply if self.scatter_type == 'max' else _PoolMean.apply
         for blk in self.blocks[1:]:
             if isinstance(vi, (list, tuple)):
-                pooled = _PoolMax.apply(net, vi[0])
+                pooled = pool(net, vi[0])
                 for other in vi[1:]:
-                    pooled = pooled + _PoolMax.apply(net, other)
+                    pooled = pooled + pool(net, other)
             else:
-                pooled = _PoolMax.apply(net, vi)
+                pooled = pool(net, vi)
             net = block(blk, net, pooled)
         return linear(self.fc_c, net)
 
@@ -239,7 +252,7 @@ class LocalPoolPointnet(nn.Module):
     def _one_launch_fits(self, vi):
         """vt_pointnet_mlp_fused: one voxel index (the object grid; the hand encoder sums three planes' pools), the shipped widths
         (hidden 32, five blocks with shortcut layers, c_dim <= 64).  VTACO_POINTNET_ONE_LAUNCH=0: the launch-per-layer path."""
-        if isinstance(vi, (list, tuple)) or os.environ.get("VTACO_POINTNET_ONE_LAUNCH", "1") == "0":
+        if isinstance(vi, (list, tuple)) or os.environ.get("VTACO_POINTNET_ONE_LAUNCH", "1") == "0" or self.scatter_type != 'max':
             return False
         return (self.hidden_dim == 32 and len(self.blocks) == 5 and all(b.shortcut is not None for b in self.blocks)
                 and tuple(self.fc_pos.weight.shape) == (64, 3) and self.fc_c.weight.shape[0] <= 64 and self.fc_c.weight.shape[1] == 32
@@ -255,13 +268,14 @@ class LocalPoolPointnet(nn.Module):
         net = lin(self.fc_pos, p)
         b0 = self.blocks[0]
         net = ops.resblock_fc(net, None, b0.fc_0, b0.fc_1, b0.shortcut)
+        pool = (lambda f, v: ops.voxel_pool_max_fwd(f, v, want_argmax=False)[0]) if self.scatter_type == 'max' else ops.voxel_pool_mean
         for blk in self.blocks[1:]:
             if isinstance(vi, (list, tuple)):
-                pooled = ops.voxel_pool_max_fwd(net, vi[0], want_argmax=False)[0]
+                pooled = pool(net, vi[0])
                 for other in vi[1:]:
-                    pooled = pooled + ops.voxel_pool_max_fwd(net, other, want_argmax=False)[0]
+                    pooled = pooled + pool(net, other)
             else:
-                pooled = ops.voxel_pool_max_fwd(net, vi, want_argmax=False)[0]
+                pooled = pool(net, vi)
             net = ops.resblock_fc(net, pooled, blk.fc_0, blk.fc_1, blk.shortcut)
         return lin(self.fc_c, net)
 

@@ -519,6 +519,17 @@ def voxel_pool_max_fwd(feat, vi, want_argmax=True):
     return out, arg
 
 
+def voxel_pool_mean(feat, vi):
+    """pool_local with scatter_type='mean' (vt_voxel_pool_mean): every point gets the mean of the features of its cell; its
+    backward is the same call on the gradient."""
+    feat = _c(feat.float())
+    B, T, C = feat.shape
+    out = torch.empty_like(feat)
+    check(_lib.load().vt_voxel_pool_mean(dev_ptr(feat, "feat"), dev_ptr(vi.order, "order", I32), dev_ptr(vi.seg_lo, "seg_lo", I32),
+                                         dev_ptr(vi.seg_hi, "seg_hi", I32), B, T, C, dev_ptr(out, "out"), stream_ptr()), "vt_voxel_pool_mean")
+    return out
+
+
 def voxel_pool_max_bwd(grad_out, argmax, vi):
     grad_out = _c(grad_out)
     B, T, C = grad_out.shape
