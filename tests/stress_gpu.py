@@ -1,7 +1,8 @@
 """Randomised differential testing on the GPU (not collected by pytest: run `python tests/stress_gpu.py [seconds]`).
 Marching cubes against the C oracle on random shapes / fields / levels, the decode kernels against the torch oracle on
 random (B, N, R) and lattices, the voxeliser against the oracle on random clouds, the fusion pipeline on ragged N, the
-UNet3D forward (both conv precisions) on small volumes, its first layer with the empty blocks skipped, LocalDecoder at random widths beyond 32 / 32 (exact and split-f16 kernels), the hand branch (plane ids / scatter, the PointNet MLP kernels,
+UNet3D forward (both conv precisions) on small volumes, its first layer with the empty blocks skipped, its first two layers
+likewise inside vt_unet3d_fwd_skip at 64^3, LocalDecoder at random widths beyond 32 / 32 (exact and split-f16 kernels), the hand branch (plane ids / scatter, the PointNet MLP kernels,
 the MANO layer on random synthetic assets), the winding-number kernel on random triangle soups.  Prints a summary; exits 1 on a mismatch."""
 import os
 import sys
@@ -235,6 +236,46 @@ def one_skip():
         fails.append(("skip", B, R, T, Cout, spread, err, scale, int(vi.tile_flags.sum())))
 
 
+_SKIP2_NET = {}
+
+
+def one_skip2():
+    """The UNet3D with its first two layers' empty blocks skipped (vt_unet3d_fwd_skip: flag bit 0 for the first layer, bit 1 -- the
+    12^3 halo -- for the second) against the same network without flags, on the mean grid of a random cloud at 64^3: clouds in a
+    corner, on a face, everywhere; one to three scenes."""
+    from vtaco_amd.encoder.unet3d import UNet3D
+    B, R, C = int(rng.randint(1, 4)), 64, 32
+    if "net" not in _SKIP2_NET:
+        torch.manual_seed(1234)
+        net = UNet3D(in_channels=32, out_channels=32, f_maps=32, num_levels=3)
+        gg = torch.Generator().manual_seed(1235)
+        with torch.no_grad():
+            for n, prm in net.named_parameters():
+                if "groupnorm" in n:
+                    prm.add_(torch.randn(prm.shape, generator=gg) * 0.2)
+        _SKIP2_NET["net"] = net.to(DEV)
+    net = _SKIP2_NET["net"]
+    g = torch.Generator().manual_seed(int(rng.randint(1 << 30)))
+    T = int(rng.choice([1, 50, 3000]))
+    spread, off = float(rng.choice([0.02, 0.2, 0.55])), (torch.rand(B, 1, 3, generator=g) - 0.5) * float(rng.choice([0.0, 0.6, 1.0]))
+    p = ((torch.rand(B, T, 3, generator=g) - 0.5) * 2 * spread + off).clamp(-0.54, 0.54).to(DEV)
+    grid = torch.empty(B, R, R, R, C, device=DEV)
+    vi = ops.VoxelIndex(p, R, 0.1, clear=grid, want_tile_flags=True)
+    x = ops.voxel_scatter_mean_cl_fwd(torch.randn(B, T, C, generator=g).to(DEV), vi)
+    occ = (x.abs().sum(-1) > 0).float().unsqueeze(1)
+    halo2 = torch.nn.functional.max_pool3d(occ, 5, 1, 2)                                        # a voxel within two of an occupied one
+    blocks2 = torch.nn.functional.max_pool3d(halo2, 8, 8).reshape(B, (R // 8) ** 3) > 0
+    if bool((((vi.tile_flags & 2) != 0) & blocks2).any()) or bool(((vi.tile_flags & 2) != 0).logical_and((vi.tile_flags & 1) == 0).any()):
+        fails.append(("skip2-flags", B, T, spread))
+    with torch.no_grad():
+        dense = net.forward_channels_last(x).clone()
+        got = net.forward_channels_last(x, tile_flags=vi.tile_flags)
+    scale = max(1.0, float(dense.abs().max()))
+    err = float((got - dense).abs().max())
+    if not err <= 6e-6 * scale:
+        fails.append(("skip2", B, T, spread, err, scale, int((vi.tile_flags == 3).sum())))
+
+
 _MANO = {}
 
 
@@ -301,7 +342,7 @@ def one_winding():
         fails.append(("winding", V, Fn, N, float(np.abs(got - ref).max())))
 
 
-counts.update({"fusion": 0, "unet3d": 0, "hand": 0, "winding": 0, "skip": 0, "wide": 0})
+counts.update({"fusion": 0, "unet3d": 0, "hand": 0, "winding": 0, "skip": 0, "skip2": 0, "wide": 0})
 t0 = time.time()
 it = 0
 while time.time() - t0 < budget and len(fails) < 5:
@@ -313,6 +354,8 @@ while time.time() - t0 < budget and len(fails) < 5:
         jobs.append(("winding", one_winding))
         jobs.append(("skip", one_skip))
         jobs.append(("wide", one_wide))
+    if it % 8 == 0:
+        jobs.append(("skip2", one_skip2))
     if it % 40 == 0:
         jobs.append(("unet3d", one_unet))
     for name, fn in jobs:
