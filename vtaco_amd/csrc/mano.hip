@@ -64,8 +64,41 @@ mano_pack_kernel(const float *v_template, const float *shapedirs, const float *b
 // the re-normalised quaternion) with the pose map of the 15 finger joints, the kinematic chain G_j = [Rg_j | tg_j] off the wrist, the
 // skinning transforms A_j = [Rg_j | tg_j - Rg_j J_j] and the posed rest vertices vp = v_shaped + posedirs . pose_map.  `qa` (or null)
 // receives per joint (a[3], |a + 1e-8|, sin, cos of half the angle, |quaternion| before normalisation) for the backward.
-__device__ __forceinline__ void mano_state(const float *p, const float *blob, float (*rot)[9], float *pm, float (*G)[12], float (*A)[12],
-                                           float *vp, float (*qa)[8]) {
+// mano_chain: everything but the blend shapes (16 threads' worth of work); mano_blend: vp[e] for the coordinates [e0, e1) -- per
+// element the sum runs over k in order whichever thread or workgroup computes it, four rows of posedirs requested at a time (a
+// workgroup that streams the 1.26 MB matrix one row per round trip is bound by the latency of a cold row: 285 us per launch in the
+// training step, where other kernels evict the model from L2 between two calls).
+__device__ __forceinline__ void mano_blend(const float *blob, const float *pm, float *vp, int e0, int e1) {
+    const float *vs = blob + OFF_VS, *pd = blob + OFF_PD;
+    constexpr int NE = 4, NK = 4;                                   // coordinates per thread and pass, rows per request round: 16 loads in flight
+    for (int base = e0 + (int)threadIdx.x; base < e1; base += THREADS * NE) {
+        float acc[NE];
+        int e[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) { acc[i] = 0.0f; e[i] = min(base + THREADS * i, e1 - 1); }      // (a clamped lane repeats the last coordinate and does not store)
+        int k = 0;
+        for (; k + NK <= NPD; k += NK) {
+            float r[NK][NE];
+#pragma unroll
+            for (int u = 0; u < NK; ++u)
+#pragma unroll
+                for (int i = 0; i < NE; ++i) r[u][i] = pd[(size_t)(k + u) * NCP + e[i]];
+#pragma unroll
+            for (int u = 0; u < NK; ++u)
+#pragma unroll
+                for (int i = 0; i < NE; ++i) acc[i] = fmaf(r[u][i], pm[k + u], acc[i]);
+        }
+        for (; k < NPD; ++k)
+#pragma unroll
+            for (int i = 0; i < NE; ++i) acc[i] = fmaf(pd[(size_t)k * NCP + e[i]], pm[k], acc[i]);
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+            if (base + THREADS * i < e1) vp[base + THREADS * i] = vs[base + THREADS * i] + acc[i];
+    }
+}
+
+__device__ __forceinline__ void mano_chain(const float *p, const float *blob, float (*rot)[9], float *pm, float (*G)[12], float (*A)[12],
+                                           float (*qa)[8]) {
     const int tid = threadIdx.x;
     const float *J = blob + OFF_J;
     if (tid < NJ) {
@@ -126,73 +159,70 @@ __device__ __forceinline__ void mano_state(const float *p, const float *blob, fl
             o[3] = g[3] - (g[0] * J[3 * tid] + g[1] * J[3 * tid + 1] + g[2] * J[3 * tid + 2]);
         }
     }
-    // pose blend shapes: v_posed = v_shaped + posedirs . pose_map, ten coordinates per thread, coalesced rows
-    {
-        float acc[10];
-        const float *vs = blob + OFF_VS, *pd = blob + OFF_PD;
-#pragma unroll
-        for (int i = 0; i < 10; ++i) acc[i] = 0.0f;
-        for (int k = 0; k < NPD; ++k) {
-            const float m = pm[k];
-            const float *row = pd + (size_t)k * NCP;
-#pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                const int e = tid + THREADS * i;
-                if (e < NCP) acc[i] = fmaf(row[e], m, acc[i]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            const int e = tid + THREADS * i;
-            if (e < NCP) vp[e] = vs[e] + acc[i];
-        }
-    }
     __syncthreads();
 }
 
+__device__ __forceinline__ void mano_state(const float *p, const float *blob, float (*rot)[9], float *pm, float (*G)[12], float (*A)[12],
+                                           float *vp, float (*qa)[8]) {
+    mano_chain(p, blob, rot, pm, G, A, qa);
+    // pose blend shapes: v_posed = v_shaped + posedirs . pose_map, coalesced rows
+    mano_blend(blob, pm, vp, 0, NCP);
+    __syncthreads();
+}
+
+// One workgroup per (hand, slice of MANO_VS vertices): every workgroup repeats the chain (tiny) and computes the blend shapes and
+// the skinning of its own vertices only -- 158 KB of posedirs instead of 1.26 MB per workgroup, eight times the workgroups; slice 0
+// writes the chain joints, the slice that owns a finger-tip vertex that tip's joint row.  A centre joint that is a tip (center_idx
+// 4, 8, 12, 16, 20) is one more vertex that every slice computes for itself.  Same arithmetic per element as one workgroup per hand.
+constexpr int MANO_SLICES = 8, MANO_VS = (NV + MANO_SLICES - 1) / MANO_SLICES;
 __global__ void __launch_bounds__(THREADS)
 mano_fwd_kernel(const float *pose, const float *blob, int center_idx, float *verts, float *joints) {
     __shared__ float rot[NJ][9];        // per-joint rotations
     __shared__ float pm[NPD + 1];       // pose map: (R_j - I) of the 15 finger joints, row-major
     __shared__ float Gc[NJ][12];        // chain transforms [Rg | tg]: the translations are the joints
     __shared__ float G[NJ][12];         // skinning transforms A_j
-    __shared__ float vp[NCP];           // posed rest vertices, then the skinned vertices
-    __shared__ float jout[21][3];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    mano_state(pose + (size_t)b * 48, blob, rot, pm, Gc, G, vp, nullptr);
+    __shared__ float vp[3 * (MANO_VS + 1)];     // posed rest vertices of the slice (+ the centre tip), then the skinned ones
+    __shared__ float ctr_s[3];
+    const int tid = threadIdx.x, b = blockIdx.x / MANO_SLICES, sl = blockIdx.x - b * MANO_SLICES;
+    const int v0 = sl * MANO_VS, nv = min(MANO_VS, NV - v0);
+    const int csrc = center_idx >= 0 ? JORDER[center_idx] : -1, ctip = csrc >= NJ ? TIPS[csrc - NJ] : -1;     // the centre, if it is a tip vertex
+    mano_chain(pose + (size_t)b * 48, blob, rot, pm, Gc, G, nullptr);
+    mano_blend(blob, pm, vp - 3 * v0, 3 * v0, 3 * (v0 + nv));
+    if (ctip >= 0) mano_blend(blob, pm, vp + 3 * nv - 3 * ctip, 3 * ctip, 3 * ctip + 3);
+    __syncthreads();
     // linear blend skinning: T_v = sum_j w[v][j] A_j, vertex = T_v [v_posed; 1]
     const float *W = blob + OFF_W;
-    float out[4][3];
-    for (int i = 0; i < 4; ++i) {
-        const int v = tid + THREADS * i;
-        if (v < NV) {
-            float T[12];
+    float out[3] = {0.0f, 0.0f, 0.0f};
+    const bool mine = tid < nv || (ctip >= 0 && tid == nv);
+    if (mine) {
+        const int v = tid < nv ? v0 + tid : ctip;
+        float T[12];
 #pragma unroll
-            for (int q = 0; q < 12; ++q) T[q] = 0.0f;
-            for (int j = 0; j < NJ; ++j) {
-                const float w = W[v * NJ + j];
+        for (int q = 0; q < 12; ++q) T[q] = 0.0f;
+        for (int j = 0; j < NJ; ++j) {
+            const float w = W[v * NJ + j];
 #pragma unroll
-                for (int q = 0; q < 12; ++q) T[q] = fmaf(w, G[j][q], T[q]);
-            }
-            const float x = vp[3 * v], y = vp[3 * v + 1], z = vp[3 * v + 2];
-            for (int r = 0; r < 3; ++r) out[i][r] = T[4 * r] * x + T[4 * r + 1] * y + T[4 * r + 2] * z + T[4 * r + 3];
+            for (int q = 0; q < 12; ++q) T[q] = fmaf(w, G[j][q], T[q]);
+        }
+        const float x = vp[3 * tid], y = vp[3 * tid + 1], z = vp[3 * tid + 2];
+        for (int r = 0; r < 3; ++r) out[r] = T[4 * r] * x + T[4 * r + 1] * y + T[4 * r + 2] * z + T[4 * r + 3];
+    }
+    __syncthreads();
+    if (mine) for (int r = 0; r < 3; ++r) vp[3 * tid + r] = out[r];
+    if (tid < 3) ctr_s[tid] = center_idx < 0 ? 0.0f : (csrc < NJ ? Gc[csrc][4 * tid + 3] : 0.0f);
+    __syncthreads();
+    if (ctip >= 0 && tid < 3) ctr_s[tid] = vp[3 * nv + tid];
+    __syncthreads();
+    const float ctr[3] = {ctr_s[0], ctr_s[1], ctr_s[2]};
+    for (int e = tid; e < 3 * nv; e += THREADS) verts[(size_t)b * NC + 3 * v0 + e] = vp[e] - ctr[e % 3];
+    if (tid < 63) {
+        const int i = tid / 3, r = tid - 3 * i, src = JORDER[i];
+        if (src < NJ) { if (sl == 0) joints[(size_t)b * 63 + tid] = Gc[src][4 * r + 3] - ctr[r]; }
+        else {
+            const int tv = TIPS[src - NJ];
+            if (tv >= v0 && tv < v0 + nv) joints[(size_t)b * 63 + tid] = vp[3 * (tv - v0) + r] - ctr[r];
         }
     }
-    __syncthreads();
-    for (int i = 0; i < 4; ++i) {
-        const int v = tid + THREADS * i;
-        if (v < NV) for (int r = 0; r < 3; ++r) vp[3 * v + r] = out[i][r];
-    }
-    __syncthreads();
-    if (tid < 21) {
-        const int src = JORDER[tid];
-        for (int r = 0; r < 3; ++r) jout[tid][r] = src < NJ ? Gc[src][4 * r + 3] : vp[3 * TIPS[src - NJ] + r];
-    }
-    __syncthreads();
-    float ctr[3] = {0.0f, 0.0f, 0.0f};
-    if (center_idx >= 0) for (int r = 0; r < 3; ++r) ctr[r] = jout[center_idx][r];
-    for (int e = tid; e < NC; e += THREADS) verts[(size_t)b * NC + e] = vp[e] - ctr[e % 3];
-    if (tid < 63) joints[(size_t)b * 63 + tid] = jout[tid / 3][tid % 3] - ctr[tid % 3];
 }
 
 
@@ -320,7 +350,15 @@ mano_bwd_kernel(const float *pose, const float *blob, int center_idx, const floa
         for (int k = wave; k < NPD; k += 4) {
             const float *row = pd + (size_t)k * NCP;
             float acc = 0.0f;
-            for (int e = lane; e < NC; e += 64) acc = fmaf(row[e], dout[e], acc);
+            int e = lane;
+            for (; e + 64 * 7 < NC; e += 64 * 8) {                 // (eight requests in flight; the sum keeps its order)
+                float r[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) r[u] = row[e + 64 * u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = fmaf(r[u], dout[e + 64 * u], acc);
+            }
+            for (; e < NC; e += 64) acc = fmaf(row[e], dout[e], acc);
             acc = wave_sum_fixed(acc);
             if (lane == 0) dpm[k] = acc;
         }
@@ -370,7 +408,7 @@ int vt_mano_fwd(const float *pose, int B, const float *blob, int center_idx, flo
     if (B == 0) return 0;
     if (!pose || !blob || !verts || !joints) return vt_fail(VT_ERR_INVALID, "vt_mano_fwd: null argument");
     if (B < 0 || center_idx < -1 || center_idx > 20) return vt_fail(VT_ERR_INVALID, "vt_mano_fwd: bad size or centre joint");
-    hipLaunchKernelGGL(mano_fwd_kernel, dim3(B), dim3(THREADS), 0, (hipStream_t)stream, pose, blob, center_idx, verts, joints);
+    hipLaunchKernelGGL(mano_fwd_kernel, dim3((unsigned)B * MANO_SLICES), dim3(THREADS), 0, (hipStream_t)stream, pose, blob, center_idx, verts, joints);
     return vt_check(hipGetLastError(), "vt_mano_fwd");
 }
 
