@@ -561,12 +561,13 @@ def test_second_layer_without_the_blocks_whose_rim_is_empty(monkeypatch):
     bit 1) -- around them the first layer's output is a constant per border class, so the second's is one per class of a two-voxel rim
     (125 classes: every corner, edge and face of the volume is covered by a cloud in the middle), from class rows the first launch
     leaves.  Against the second layer run densely (VTACO_CONV_SKIP2=0) and against the network without flags: one scene, a batch of two
-    with a cloud that touches faces of the volume and a scene without points, a batch of three (85 workgroups per scene: the class rows
-    dealt in two parts), and a 32^3 volume, where only the first layer takes the flags."""
+    with a cloud that touches faces of the volume and a scene without points, batches of three, four and eight (85, 64 and 32
+    workgroups per scene: the class rows dealt in two parts, in two, in one), and a 32^3 volume, where only the first layer takes the flags."""
     from types import SimpleNamespace
     from vtaco_amd import ops
     g = torch.Generator().manual_seed(77)
-    for B, R, levels, n_pts, lo, hi in ((1, 64, 3, 600, 0.3, 0.7), (2, 64, 3, 500, 0.0, 0.45), (3, 64, 3, 900, 0.55, 1.0), (2, 32, 3, 30, 0.55, 1.0)):
+    for B, R, levels, n_pts, lo, hi in ((1, 64, 3, 600, 0.3, 0.7), (2, 64, 3, 500, 0.0, 0.45), (3, 64, 3, 900, 0.55, 1.0), (2, 32, 3, 30, 0.55, 1.0),
+                                        (8, 64, 2, 400, 0.25, 0.75), (4, 64, 3, 2000, 0.1, 0.6)):
         net = _unet(32, levels, 11 + R + B).to(DEV)
         net.precision = "f16x3"
         x, idx, want = _sparse_case(B, R, 32, g, n_pts, lo, hi)
