@@ -1409,6 +1409,18 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
         const int wge = ha.wgs_per_scene - 1 - wg;
         n_e = tot_e > wge ? (tot_e - wge + ha.wgs_per_scene - 1) / ha.wgs_per_scene : 0;
     }
+    // cls_make: which workgroups compute class rows (unit u = index among the F sharing workgroups: cout u % 32 and every P-th class
+    // from u / 32; where at least 32 workgroups of the scene have no tile with taps, those share the rows -- they have nothing else to
+    // do -- else all do; the launcher asks for >= 32 workgroups per scene).  Only they pay the two barriers of that step.
+    int cls_P = 0, cls_wi = 0;
+    bool cls_unit = false;
+    if (cls_make) {
+        const int tot_ne = lcnt[32], spare = ha.wgs_per_scene - tot_ne;
+        const int F = spare >= 32 ? spare : ha.wgs_per_scene;
+        cls_wi = spare >= 32 ? wg - tot_ne : wg;
+        cls_P = F >= 256 ? 8 : F >> 5;
+        cls_unit = cls_wi >= 0 && cls_wi < 32 * cls_P;
+    }
     auto tile_origin = [&](int k, int &x0, int &y0, int &z0) {
         int t = sparse ? (int)list_ne[k] : wg + k * ha.wgs_per_scene;
         const int tx = t % a.tiles_x; t /= a.tiles_x;
@@ -1576,7 +1588,7 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
         }
         HB_STAMP(12);
         if (sparse && !cls_use) lds_barrier();                      // (the tap waves: T is complete, the class table follows)
-        if (cls_make) { lds_barrier(); lds_barrier(); }             // (... the class table is complete; the next layer's weights are in LDS)
+        if (cls_unit) { lds_barrier(); lds_barrier(); }             // (... the class table is complete; the next layer's weights are in LDS)
         constexpr int WAIT_DMA0 = 0x0F70 | (2 * REQ > 15 ? 15 : 2 * REQ);
         if (N > 2) __builtin_amdgcn_s_waitcnt(WAIT_DMA0); else __builtin_amdgcn_s_waitcnt(0x0F70);   // chunk 0's weights have landed
         HB_STAMP(13);
@@ -1632,7 +1644,7 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
         const int lx = j & 3, ly = j >> 2;
         const int center = ((wave + 1) * 10 + (ly + 1)) * HB_PX + (lx + 1);      // patch 0; patch 1 sits 4 voxels along x
         if (stats_in) gn_in_finish<true, GN_PRE, true>(a.stat_in, gn_rq, b, pre_scale, ssl, hl, threadIdx.x, THREADS, cls_use ? grp : nullptr);
-        if (sparse && !cls_use && (n_e > 0 || cls_make)) {
+        if (sparse && !cls_use && (n_e > 0 || cls_unit)) {
             // T[tap][cout] = sum_cin W[cout][cin][tap] shift[cin] from the packed fragments (hi + lo), while the loaders stage chunk 0
             for (int id = threadIdx.x; id < 27 * 32; id += LTHREADS) {
                 const int tap = id >> 5, co = id & 31, fl = (tap >> 1) * 128 + co + 32 * (tap & 1);
@@ -1650,7 +1662,7 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
             // K[class][cout] = the sum of T over the taps a voxel of that border class has inside the volume (class = per axis: first
             // voxel, inner, last voxel)
             lds_barrier();
-            if (n_e > 0 || cls_make)
+            if (n_e > 0 || cls_unit)
                 for (int id = threadIdx.x; id < 27 * 32; id += LTHREADS) {
                     const int cls = id >> 5, co = id & 31, cz = cls / 9, cy = (cls / 3) % 3, cx = cls % 3;
                     float k = 0.0f;
@@ -1663,16 +1675,12 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
                     ktab[id] = k;
                 }
         }
-        if (cls_make) {
-            // the class rows of the layer behind this one (HbArgs::cls_out).  Unit u = index among the F sharing workgroups: cout u % 32 and
-            // every P-th class from u / 32 (P = min(F / 32, 8); the launcher asks for >= 32 per scene); the unit's 27 x 32 weights go through LDS once
-            // (T's place: T is dead), then eight threads per row, one per GroupNorm group of four input channels
+        if (cls_unit) {
+            // the class rows of the layer behind this one (HbArgs::cls_out): the unit's 27 x 32 weights go through LDS once (T's place: T is
+            // dead), then the rows
             lds_barrier();
-            // (where at least 32 workgroups of the scene have no tile with taps, those share the rows: they have nothing else to do)
-            const int tot_ne = lcnt[32], spare = ha.wgs_per_scene - tot_ne;
-            const int F = spare >= 32 ? spare : ha.wgs_per_scene, wi = spare >= 32 ? wg - tot_ne : wg;
-            const int P = F >= 256 ? 8 : F >> 5, co = wi & 31, part = wi >> 5;
-            const bool unit = wi >= 0 && wi < 32 * P;
+            const int P = cls_P, co = cls_wi & 31, part = cls_wi >> 5;
+            const bool unit = true;
             if (unit && threadIdx.x < 27 * 4) {
                 const int tap = threadIdx.x >> 2, q = threadIdx.x & 3, fl = (tap >> 1) * 128 + co + 32 * (tap & 1);
                 const f16x8 *w2 = reinterpret_cast<const f16x8 *>(ha.cls_w) + (size_t)q * HB_WFRAGS;
