@@ -763,6 +763,11 @@ int vt_gn_bwd_masked(const float *skip, int C1, const float *low, int C2, int B,
                      float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow,
                      int mask_flags, float *absmax_skip, float *absmax_low, void *stream);
 int vt_maxpool3d_cl_bwd(const float *x, const float *dy, int B, int D, int H, int W, int C, float *dx, void *stream);
+/* The gradient of an encoder level's output y (unet3d.py:449-474: it feeds the next level's max-pool AND the decoder's skip) in one  */
+/* pass: g = (y > 0 ? dskip + maxpool_backward(dpooled) : 0) -- vt_maxpool3d_cl_bwd, the framework's add of the two gradients and    */
+/* the vt_relu_mask_absmax of the layer that produced y -- with max |g| in the device scalar absmax (or NULL).                        */
+int vt_maxpool3d_cl_bwd_fork(const float *y, const float *dskip, const float *dpooled, int B, int D, int H, int W, int C, float *g,
+                             float *absmax, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* Hand branch (SURVEY.md section 8f "next" row 3).                              */

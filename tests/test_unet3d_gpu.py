@@ -299,6 +299,17 @@ def test_masked_groupnorm_backward_and_the_transposed_pack_equal_their_two_step_
     for Cout, Cin in ((32, 32), (64, 96), (128, 32)):
         w = torch.randn(Cout, Cin, 3, 3, 3, generator=g).to(DEV)
         assert torch.equal(ops.conv3d_pack_t(w), ops.conv3d_pack(w.flip(2, 3, 4).transpose(0, 1).contiguous(), precision="f16x3"))
+    # an encoder level's output feeds the pool and the skip: vt_maxpool3d_cl_bwd_fork = pool backward + add + relu mask, bit for bit
+    # (ties between window entries included: half of y is exactly zero, and some windows hold equal positive values)
+    for B, R, C in ((2, 16, 32), (1, 8, 64), (3, 4, 128)):
+        y = torch.randn(B, R, R, R, C, generator=g).relu()
+        y[:, ::2, ::2, ::2] = y[:, 1::2, ::2, ::2]                  # equal maxima inside windows: the first in scan order wins
+        y = y.to(DEV)
+        dskip = (torch.randn(B, R, R, R, C, generator=g) * 1e-3).to(DEV)
+        dpool = (torch.randn(B, R // 2, R // 2, R // 2, C, generator=g) * 1e-3).to(DEV)
+        want, wmax = ops.relu_mask(dskip + ops.maxpool3d_cl_bwd(y, dpool), y, want_absmax=True)
+        got, gmax = ops.maxpool3d_cl_bwd_fork(y, dskip, dpool)
+        assert torch.equal(got, want) and torch.equal(gmax, wmax)
 
 
 def test_maxpool_with_statistics_equals_the_two_passes():

@@ -186,6 +186,7 @@ SIGNATURES = {
     "vt_gn_bwd_masked": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _I, _VP, _I, _VP, _I, _VP, _D, _VP, _I, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "vt_gn_bwd": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _I, _VP, _I, _VP, _I, _VP, _D, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "vt_maxpool3d_cl_bwd": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP, _VP]),
+    "vt_maxpool3d_cl_bwd_fork": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "vt_conv3d_pack_bf16x3": (_I, [_VP, _I, _I, _VP, _VP]),
     "vt_conv3d_packed_floats_f16x3": (_SZ, [_I, _I]),
     "vt_conv3d_pack_f16x3": (_I, [_VP, _I, _I, _VP, _VP]),

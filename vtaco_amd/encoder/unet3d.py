@@ -191,6 +191,30 @@ class _MaxPoolFn(torch.autograd.Function):
         return ops.maxpool3d_cl_bwd(x, dy)
 
 
+class _PoolForkFn(torch.autograd.Function):
+    """An encoder level's output y -> (y for the decoder's skip, maxpool(y) for the next level).  The two gradients meet here: one
+    pass routes the pooled gradient to the windows' first maxima, adds the skip's and applies the (y > 0) mask of the layer that
+    produced y (ops.maxpool3d_cl_bwd_fork), which that layer then skips (``link``)."""
+
+    @staticmethod
+    def forward(ctx, y, link):
+        ctx.save_for_backward(y)
+        ctx.link = link
+        return y.view_as(y), ops.maxpool3d_cl(y)
+
+    @staticmethod
+    def backward(ctx, dskip, dpooled):
+        (y,) = ctx.saved_tensors
+        if dskip is None or dpooled is None:        # one branch unused: the plain forms
+            dx = ops.maxpool3d_cl_bwd(y, dpooled) if dpooled is not None else dskip
+            return dx, None
+        g, gmax = ops.maxpool3d_cl_bwd_fork(y, dskip, dpooled)
+        if ctx.link is not None:
+            ctx.link.ready, ctx.link.gmax = True, gmax
+            return g, None
+        return g, None
+
+
 class UNet3D(nn.Module):
     def __init__(self, in_channels, out_channels, final_sigmoid=True, f_maps=64, layer_order='gcr',
                  num_groups=8, num_levels=4, is_segmentation=True, testing=False, **kwargs):
@@ -433,15 +457,23 @@ class UNet3D(nn.Module):
         part = None
         n_enc = len(self.encoders)
         low_link = None
+        pooled = None
         for i, enc in enumerate(self.encoders):
             if i > 0:
-                x = _MaxPoolFn.apply(x)
+                x = pooled if pooled is not None else _MaxPoolFn.apply(x)
             if i > 0 or part is None:
                 part = stats(x)
             l12 = link()
             x, part = gcr(enc.basic_module.SingleConv1, x, part, flags=tile_flags if i == 0 else None, out_link=l12)
-            low_link = link() if (i == n_enc - 1 and len(self.decoders) > 0) else None
-            x, part = gcr(enc.basic_module.SingleConv2, x, part, x_link=l12, out_link=low_link)
+            last = i == n_enc - 1
+            # the level's output: `low` of the first decoder (bottom level), else the pool's and the skip's input -- their two gradients
+            # meet in _PoolForkFn, which also applies this layer's mask
+            out_link = link() if (not last or len(self.decoders) > 0) else None
+            x, part = gcr(enc.basic_module.SingleConv2, x, part, x_link=l12, out_link=out_link)
+            low_link = out_link if last else None
+            pooled = None
+            if not last and _MASK_FUSE:
+                x, pooled = _PoolForkFn.apply(x, out_link)
             skips.append((x, part))
         n_dec = len(self.decoders)
         for k, (dec, (skip, skip_part)) in enumerate(zip(self.decoders, skips[-2::-1])):

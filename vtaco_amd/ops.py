@@ -1519,6 +1519,18 @@ def maxpool3d_cl_bwd(x, dy):
     return dx
 
 
+def maxpool3d_cl_bwd_fork(y, dskip, dpooled, want_absmax=True):
+    """g = (y > 0 ? dskip + maxpool_backward(dpooled) : 0) for a tensor y that feeds a 2x2x2 max-pool and a skip connection
+    (vt_maxpool3d_cl_bwd_fork); with ``want_absmax`` also the device scalar max |g|: returns (g, absmax or None)."""
+    B, D, H, W, C = y.shape
+    dskip, dpooled = _c(dskip), _c(dpooled)
+    g = torch.empty_like(y)
+    m = torch.empty(1, dtype=torch.float32, device=y.device) if want_absmax else None
+    check(_lib.load().vt_maxpool3d_cl_bwd_fork(dev_ptr(y, "y"), dev_ptr(dskip, "dskip"), dev_ptr(dpooled, "dpooled"), B, D, H, W, C,
+                                               dev_ptr(g, "g"), dev_ptr(m, "absmax"), stream_ptr()), "vt_maxpool3d_cl_bwd_fork")
+    return g, m
+
+
 def maxpool3d_cl(x):
     B, D, H, W, C = x.shape
     out = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
