@@ -753,6 +753,20 @@ int vt_gn_bwd(const float *skip, int C1, const float *low, int C2, int B, int D,
               const float *part1, int nblk1, const float *part2, int nblk2,
               const float *dxn, int groups, const float *gamma, double eps,
               float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow, void *stream);
+/* The data-gradient conv of a plain 'gcr' layer (autograd of unet3d.py:20-72: the forward kernels on the weight with channels      */
+/* swapped and taps flipped, vt_conv3d_pack_f16x3_t) that also leaves the GroupNorm backward's two sums: out_part                  */
+/* [B][vt_conv3d_xstats_blocks][Cout][2] = per workgroup (sum dxn, sum dxn * stat_x) with stat_x [B][D][H][W][Cout] the layer's     */
+/* input -- what vt_gn_bwd's statistics pass over dxn and x computes, from the conv's epilogue.  vt_gn_bwd_from_part is            */
+/* vt_gn_bwd_masked on such sums (bpart, nblkb = the blocks count) without that pass.  vt_conv3d_xstats_blocks: 0 where the shape    */
+/* is not on the specialised-wave kernel (use vt_conv3d_gcr_f16x3_scaled + vt_gn_bwd).                                              */
+int vt_conv3d_xstats_blocks(int B, int D, int H, int W, int Cin, int Cout);
+int vt_conv3d_gcr_f16x3_xstats(const float *g, int C, int B, int D, int H, int W, const float *packed_w_f16x3, int Cout,
+                               const float *in_absmax, const float *stat_x, float *out, float *out_part, void *stream);
+int vt_gn_bwd_from_part(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                        const float *part1, int nblk1, const float *part2, int nblk2,
+                        const float *dxn, int groups, const float *gamma, double eps,
+                        const float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow,
+                        int mask_flags, float *absmax_skip, float *absmax_low, void *stream);
 /* vt_gn_bwd that also does the relu_mask pass of the layer(s) in front (autograd of unet3d.py:20-72: ReLU behind the conv whose   */
 /* output this GroupNorm reads).  mask_flags bit 0: `skip` is such a ReLU output and dskip is its only gradient -- dskip comes out  */
 /* as (skip > 0 ? dskip : 0) with max |dskip| in the device scalar absmax_skip, exactly what vt_relu_mask_absmax(dskip, skip)      */

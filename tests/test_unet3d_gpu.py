@@ -312,6 +312,35 @@ def test_masked_groupnorm_backward_and_the_transposed_pack_equal_their_two_step_
         assert torch.equal(got, want) and torch.equal(gmax, wmax)
 
 
+def test_data_gradient_conv_leaves_the_groupnorm_backward_sums():
+    """vt_conv3d_gcr_f16x3_xstats: the data-gradient conv of a plain layer with (sum dxn, sum dxn * x) per workgroup in its epilogue --
+    the same dxn bit for bit as the plain launch, sums equal to the statistics pass's to f32 summation order, and vt_gn_bwd_from_part
+    on them equal to vt_gn_bwd (gradients to 1e-6 of their scale)."""
+    from vtaco_amd import _lib, ops
+    g_ = torch.Generator().manual_seed(57)
+    for B, R, Cin, Cout in ((1, 64, 32, 32), (2, 32, 64, 32), (8, 32, 32, 64)):
+        assert _lib.load().vt_conv3d_xstats_blocks(B, R, R, R, Cout, Cin) > 0
+        x = torch.randn(B, R, R, R, Cin, generator=g_).relu().to(DEV)
+        g = (torch.randn(B, R, R, R, Cout, generator=g_) * 1e-4 * (torch.rand(B, R, R, R, Cout, generator=g_) < 0.5)).to(DEV)
+        w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g_) * 0.05).to(DEV)
+        gamma = (1 + 0.2 * torch.randn(Cin, generator=g_)).to(DEV)
+        gmax = g.abs().max().reshape(1)
+        half = ops.conv3d_pack_t(w)
+        plain, _ = ops.conv3d_gcr(g, None, None, None, Cin, False, None, want_stats=False, packed_w_f16x3=half, in_absmax=gmax)
+        dxn, (bpart, nblk) = ops.conv3d_dgrad_xstats(g, half, Cin, gmax, x)
+        assert torch.equal(dxn, plain)
+        s1, s2 = dxn.double().sum((1, 2, 3)), (dxn.double() * x.double()).sum((1, 2, 3))
+        got = bpart.double().sum(1)
+        assert float((got[..., 0] - s1).abs().max()) <= 1e-5 * float(s1.abs().max()) + 1e-12
+        assert float((got[..., 1] - s2).abs().max()) <= 1e-5 * float(s2.abs().max()) + 1e-12
+        xs = ops.channel_stats(x)
+        ref = ops.gn_bwd(x, xs, None, None, dxn, gamma, 8, 1e-5)
+        fast = ops.gn_bwd(x, xs, None, None, dxn, gamma, 8, 1e-5, bpart=(bpart, nblk))
+        for a, b in zip(fast, ref):
+            if a is not None:
+                assert float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-30), (B, R, Cin, Cout)
+
+
 def test_maxpool_with_statistics_equals_the_two_passes():
     """vt_maxpool3d_cl_stats = vt_maxpool3d_cl followed by vt_channel_stats, bit for bit (same blocks, same summation order)."""
     from vtaco_amd import ops

@@ -1063,6 +1063,10 @@ struct HbArgs {
     //   B_g = ... of W2 beta2
     // which depend on the FIRST layer's statistics only.  The first layer's launch writes them (cls_out [B][125][32][24]; cls_w: the second
     // layer's packed weights, cls_gamma / cls_beta its GroupNorm), the second layer's reads them (cls_in) with tile_skip / skip_mask = 2.
+    // data-gradient convs (training): the tensor x [B][D][H][W][Cout] whose product with the output replaces the squares in the
+    // per-workgroup statistics -- (sum out, sum out * x) per channel are the GroupNorm backward's two sums (gn_bwd_stats_kernel),
+    // so that pass over dxn and x is not launched (the XST instantiation of the specialised-wave kernel)
+    const float *stat_x = nullptr;
     const float *cls_w = nullptr, *cls_gamma = nullptr, *cls_beta = nullptr;
     float *cls_out = nullptr;
     const float *cls_in = nullptr;
@@ -1325,7 +1329,7 @@ __device__ __forceinline__ void lds_barrier() {
 
 // FIN: the variant with the final 1x1x1 conv in the epilogue (its own instantiation: the extra registers must not cost the other
 // layers their fourth wave per SIMD)
-template <int TZ, bool FIN = false>
+template <int TZ, bool FIN = false, bool XST = false>
 __global__ void __launch_bounds__(hb_threads(TZ))
 conv3d_gcr_hw_kernel(HbArgs ha) {
     constexpr int ROWS = hb_rows(TZ), NVOX = hb_nvox(TZ), THREADS = hb_threads(TZ), LTHREADS = 64 * TZ;
@@ -1753,7 +1757,10 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
             for (int pch = 0; pch < 2; ++pch) {
                 f32x16 v = pch ? acc1 : acc0;
                 const int gx = x0 + lx + 4 * pch, gy = y0 + ly, gz = z0 + wave;
-                float *orow = a.out + ((((size_t)b * s.D + gz) * s.H + gy) * s.W + gx) * a.Cout;
+                const size_t vox = (((size_t)b * s.D + gz) * s.H + gy) * s.W + gx;
+                float *orow = a.out + vox * a.Cout;
+                f32x16 xv;
+                if constexpr (XST) xv = load_acc16(ha.stat_x + vox * a.Cout + co_blk * 32, kg);     // (requested ahead of the stores)
                 if (ha.in_absmax) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) v[r] *= post_scale;
@@ -1771,8 +1778,9 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
                 store_acc16(orow + co_blk * 32, v, kg);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {                  // the two patches' contributions per lane first: ONE lane reduction per tile
+                    const float w2 = XST ? xv[r] : v[r];
                     ssum[r] = pch ? ssum[r] + v[r] : v[r];
-                    ssq[r] = pch ? fmaf(v[r], v[r], ssq[r]) : v[r] * v[r];
+                    ssq[r] = pch ? fmaf(v[r], w2, ssq[r]) : v[r] * w2;
                 }
             }
             HB_STAMP(2);
@@ -2761,7 +2769,7 @@ static int conv_h_launch(const float *skip, int C1, const float *low, int C2, in
                          const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
                          float *out_part, const float *in_absmax, const float *fin_w, const float *fin_b, void *stream,
                          const GnIn &stat_in = GnIn{}, const GnOut &stat_out = GnOut{}, const unsigned char *tile_skip = nullptr,
-                         const ClsLink &cls = ClsLink{});
+                         const ClsLink &cls = ClsLink{}, const float *stat_x = nullptr);
 // would conv_h_launch take skip flags on this plain layer?
 static bool conv_h_skip_accepts(int B, int D, int H, int W, int Cin, int Cout);
 static int conv_h_wgs_of(int B, int D, int H, int W, int Cin, int Cout);
@@ -2770,6 +2778,20 @@ int vt_conv3d_gcr_f16x3_scaled(const float *skip, int C1, const float *low, int 
                                const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
                                float *out_part, const float *in_absmax, void *stream) {
     return conv_h_launch(skip, C1, low, C2, B, D, H, W, scale_shift, packed_w_f16x3, Cout, relu, out, out_part, in_absmax, nullptr, nullptr, stream);
+}
+
+int vt_conv3d_xstats_blocks(int B, int D, int H, int W, int Cin, int Cout) {
+    const int tz = conv_h_tz(B, D, H, W, Cin, Cout);
+    const Src src{nullptr, nullptr, Cin, 0, D, H, W};
+    if (!tz || !conv_h_specialised(tz) || conv_h_inline() || !conv_h_fits_32bit(src, B)) return 0;
+    return conv_h_wgs_per_scene(B, D, H, W, Cout, tz);
+}
+
+int vt_conv3d_gcr_f16x3_xstats(const float *g, int C, int B, int D, int H, int W, const float *packed_w_f16x3, int Cout,
+                               const float *in_absmax, const float *stat_x, float *out, float *out_part, void *stream) {
+    if (!stat_x || !out_part) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr_f16x3_xstats: null argument");
+    return conv_h_launch(g, C, nullptr, 0, B, D, H, W, nullptr, packed_w_f16x3, Cout, 0, out, out_part, in_absmax, nullptr, nullptr, stream,
+                         GnIn{}, GnOut{}, nullptr, ClsLink{}, stat_x);
 }
 
 int vt_conv3d_gcr_f16x3_skip(const float *x, int C, int B, int D, int H, int W, const float *scale_shift, const float *packed_w_f16x3,
@@ -2824,8 +2846,9 @@ int vt_conv1x1_pack_f16x3(const float *w, int Cout, int Cin, float *packed, void
 static int conv_h_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                          const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
                          float *out_part, const float *in_absmax, const float *fin_w, const float *fin_b, void *stream,
-                         const GnIn &stat_in, const GnOut &stat_out, const unsigned char *tile_skip, const ClsLink &cls) {
+                         const GnIn &stat_in, const GnOut &stat_out, const unsigned char *tile_skip, const ClsLink &cls, const float *stat_x) {
     HbArgs ha;
+    ha.stat_x = stat_x;
     ha.c.stat_in = stat_in; ha.c.stat_out = stat_out;
     ha.in_absmax = in_absmax;
     ha.fin_w = fin_w; ha.fin_b = fin_b;
@@ -2880,6 +2903,16 @@ static int conv_h_launch(const float *skip, int C1, const float *low, int C2, in
             else hipLaunchKernelGGL(conv3d_gcr_hx_kernel<4>, grid, dim3(64 * 4), hb_lds(4), (hipStream_t)stream, ha);
         }
         return vt_check(hipGetLastError(), "vt_conv3d_gcr_f16x3");
+    }
+    if (stat_x) {                                                  // data gradient with the GroupNorm backward's sums in the epilogue
+        if (!spec || conv_h_inline() || fin_w || ha.tile_skip || !out_part || low)
+            return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr_f16x3_xstats: needs a plain layer on the specialised-wave kernel and a partial-sum buffer");
+        hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<8, false, true>), (int)hb_lds_sparse(8));
+        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_gcr_hw_kernel<4, false, true>), (int)hb_lds_sparse(4));
+        if (e != hipSuccess) return vt_check(e, "vt_conv3d_gcr_f16x3_xstats: hipFuncSetAttribute");
+        if (tz == 8) hipLaunchKernelGGL((conv3d_gcr_hw_kernel<8, false, true>), grid, dim3(hb_threads(8)), hb_lds_sparse(8), (hipStream_t)stream, ha);
+        else hipLaunchKernelGGL((conv3d_gcr_hw_kernel<4, false, true>), grid, dim3(hb_threads(4)), hb_lds_sparse(4), (hipStream_t)stream, ha);
+        return vt_check(hipGetLastError(), "vt_conv3d_gcr_f16x3_xstats");
     }
     if (spec) {                                                    // specialised tap / loader waves (VTACO_CONV_SPEC=0: the uniform-wave kernel)
         bool attr_w = false;        // (vt_max_dyn_lds keeps the per-device record)
@@ -4195,11 +4228,35 @@ int vt_conv3d_wgrad_f16x3(const float *skip, int C1, const float *low, int C2, i
     return vt_check(hipGetLastError(), "vt_conv3d_wgrad_f16x3");
 }
 
+static int gn_bwd_impl(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                       const float *part1, int nblk1, const float *part2, int nblk2,
+                       const float *dxn, int groups, const float *gamma, double eps,
+                       float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow,
+                       int mask_flags, float *absmax_skip, float *absmax_low, void *stream, bool bpart_ready);
+
 int vt_gn_bwd_masked(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                      const float *part1, int nblk1, const float *part2, int nblk2,
                      const float *dxn, int groups, const float *gamma, double eps,
                      float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow,
                      int mask_flags, float *absmax_skip, float *absmax_low, void *stream) {
+    return gn_bwd_impl(skip, C1, low, C2, B, D, H, W, part1, nblk1, part2, nblk2, dxn, groups, gamma, eps, bpart, nblkb, coef, dgb, dskip, dlow,
+                       mask_flags, absmax_skip, absmax_low, stream, false);
+}
+
+int vt_gn_bwd_from_part(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                        const float *part1, int nblk1, const float *part2, int nblk2,
+                        const float *dxn, int groups, const float *gamma, double eps,
+                        const float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow,
+                        int mask_flags, float *absmax_skip, float *absmax_low, void *stream) {
+    return gn_bwd_impl(skip, C1, low, C2, B, D, H, W, part1, nblk1, part2, nblk2, dxn, groups, gamma, eps, const_cast<float *>(bpart), nblkb, coef, dgb,
+                       dskip, dlow, mask_flags, absmax_skip, absmax_low, stream, true);
+}
+
+static int gn_bwd_impl(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                       const float *part1, int nblk1, const float *part2, int nblk2,
+                       const float *dxn, int groups, const float *gamma, double eps,
+                       float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow,
+                       int mask_flags, float *absmax_skip, float *absmax_low, void *stream, bool bpart_ready) {
     Src s{skip, low, C1, low ? C2 : 0, D, H, W};
     if (!src_ok(s, B) || !part1 || nblk1 <= 0 || !dxn || !gamma || !bpart || nblkb <= 0 || !coef || !dgb)
         return vt_fail(VT_ERR_INVALID, "vt_gn_bwd: bad argument");
@@ -4209,7 +4266,8 @@ int vt_gn_bwd_masked(const float *skip, int C1, const float *low, int C2, int B,
     const int C = s.C1 + s.C2;
     if (groups <= 0 || C % groups || C / groups > 256) return vt_fail(VT_ERR_INVALID, "vt_gn_bwd: bad group count");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nblkb, B), dim3(256), 0, st, s, dxn, nblkb, bpart);
+    // (bpart_ready: the data-gradient conv left the two sums per workgroup -- vt_conv3d_gcr_f16x3_xstats)
+    if (!bpart_ready) hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nblkb, B), dim3(256), 0, st, s, dxn, nblkb, bpart);
     StatSrc s1{part1, nblk1, s.C1}, s2{low ? part2 : nullptr, low ? nblk2 : 0, s.C2};
     hipLaunchKernelGGL(gn_bwd_coeffs_kernel, dim3(B, groups), dim3(256), 0, st, s1, s2, (const float *)bpart, nblkb, groups,
                        (double)D * H * W, gamma, (float)eps, coef, dgb);

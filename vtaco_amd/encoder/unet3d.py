@@ -96,6 +96,7 @@ class _MaskLink:
 
 
 _MASK_FUSE = os.environ.get("VTACO_UNET_MASK_FUSE", "1") != "0"     # A/B knob
+_XSTATS = os.environ.get("VTACO_UNET_DGRAD_XSTATS", "1") != "0"      # A/B knob: GroupNorm-backward sums from the data-gradient conv's epilogue
 
 
 class _GcrFn(torch.autograd.Function):
@@ -160,8 +161,14 @@ class _GcrFn(torch.autograd.Function):
             # output gradients sit many orders of magnitude below the half range: the kernel scales them by a power of two
             # taken from their largest element before the split (exact), so the data gradient keeps f32-level accuracy
             half = ops.conv3d_pack_t(weight)
-        dxn, _ = ops.conv3d_gcr(g, None, None, lambda: ops.conv3d_pack(w_t()), weight.shape[1], False, split, want_stats=False,
-                                packed_w_f16x3=half, in_absmax=gmax)
+        # a plain layer on the split-f16 kernel: the GroupNorm backward's sums (sum dxn, sum dxn x) come out of the conv's epilogue
+        fused = ops.conv3d_dgrad_xstats(g, half, weight.shape[1], gmax, x) if (_XSTATS and half is not None and low is None) else None
+        if fused is not None:
+            dxn, bpart = fused
+        else:
+            bpart = None
+            dxn, _ = ops.conv3d_gcr(g, None, None, lambda: ops.conv3d_pack(w_t()), weight.shape[1], False, split, want_stats=False,
+                                    packed_w_f16x3=half, in_absmax=gmax)
         # weight gradient: split-half operands as well (K = voxels; g under the same power-of-two rescale)
         dw = ops.conv3d_wgrad(x, low, ss, g, precision="f16x3" if precision == "f16x3" and _WGRAD_F16 else "f32",
                               g_absmax=gmax) if ctx.needs_input_grad[4] else None
@@ -170,7 +177,7 @@ class _GcrFn(torch.autograd.Function):
         m_skip = x_link is not None and ctx.needs_input_grad[0]
         m_low = low_link is not None and low is not None and ctx.needs_input_grad[1]
         res = ops.gn_bwd(x, x_st, low, low_st, dxn, gamma, groups, eps, want_skip=ctx.needs_input_grad[0],
-                         want_low=low is not None and ctx.needs_input_grad[1], mask_skip=m_skip, mask_low=m_low)
+                         want_low=low is not None and ctx.needs_input_grad[1], mask_skip=m_skip, mask_low=m_low, bpart=bpart)
         dskip, dlow, dgamma, dbeta = res[:4]
         if m_skip:
             x_link.ready, x_link.gmax = True, res[4]

@@ -1477,19 +1477,40 @@ def conv3d_wgrad(x, low, ss, g, precision="f32", g_absmax=None):
     return dw
 
 
-def gn_bwd(x, x_stats, low, low_stats, dxn, gamma, groups, eps, want_skip=True, want_low=True, mask_skip=False, mask_low=False):
+def conv3d_dgrad_xstats(g, packed_t, Cin, g_absmax, x):
+    """The data gradient of a plain 'gcr' layer with the GroupNorm backward's sums from its epilogue (vt_conv3d_gcr_f16x3_xstats):
+    ``g`` [B,D,H,W,Cout] the masked output gradient, ``packed_t`` = conv3d_pack_t(weight), ``x`` [B,D,H,W,Cin] the layer's input.
+    Returns (dxn, (bpart, nblk)) or None where the shape is not on that kernel."""
+    lib = _lib.load()
+    B, D, H, W, C = g.shape
+    nblk = lib.vt_conv3d_xstats_blocks(B, D, H, W, C, int(Cin)) if g_absmax is not None else 0
+    if not nblk or tuple(x.shape) != (B, D, H, W, Cin):
+        return None
+    dxn = torch.empty((B, D, H, W, Cin), dtype=torch.float32, device=g.device)
+    part = torch.empty((B, nblk, Cin, 2), dtype=torch.float32, device=g.device)
+    check(lib.vt_conv3d_gcr_f16x3_xstats(dev_ptr(_c(g), "g"), C, B, D, H, W, dev_ptr(packed_t, "packed_w"), int(Cin), dev_ptr(g_absmax, "in_absmax"),
+                                         dev_ptr(_c(x), "x"), dev_ptr(dxn, "out"), dev_ptr(part, "part"), stream_ptr()), "vt_conv3d_gcr_f16x3_xstats")
+    return dxn, (part, nblk)
+
+
+def gn_bwd(x, x_stats, low, low_stats, dxn, gamma, groups, eps, want_skip=True, want_low=True, mask_skip=False, mask_low=False, bpart=None):
     """GroupNorm backward of xn = GN([x | upsample(low)]) given dxn (vt_gn_bwd): returns
     (dskip or None, dlow or None, dgamma [C], dbeta [C]).  ``mask_skip`` / ``mask_low`` (vt_gn_bwd_masked): x / low is the ReLU
     output of the layer in front and this is its only gradient -- the gradient comes out masked by (x > 0) and the call returns
     (dskip, dlow, dgamma, dbeta, absmax_skip, absmax_low) with the device scalars max |gradient| (None where not asked): what that
-    layer's relu_mask(..., want_absmax=True) would compute in a pass of its own."""
+    layer's relu_mask(..., want_absmax=True) would compute in a pass of its own.  ``bpart`` = (part, nblk) from conv3d_dgrad_xstats:
+    the statistics pass over dxn and x is not launched (vt_gn_bwd_from_part)."""
     B, D, H, W, C1 = x.shape
     C2 = low.shape[-1] if low is not None else 0
     C = C1 + C2
     dev = x.device
     V = D * H * W
-    nblkb = max(1, min(1024, V // 64))
-    bpart = torch.empty((B, nblkb, C, 2), dtype=torch.float32, device=dev)
+    have_part = bpart is not None
+    if have_part:
+        bpart, nblkb = bpart
+    else:
+        nblkb = max(1, min(1024, V // 64))
+        bpart = torch.empty((B, nblkb, C, 2), dtype=torch.float32, device=dev)
     coef = torch.empty((B, C, 3), dtype=torch.float32, device=dev)
     dgb = torch.empty((B, C, 2), dtype=torch.float32, device=dev)
     dskip = torch.empty_like(x) if want_skip else None
@@ -1499,12 +1520,13 @@ def gn_bwd(x, x_stats, low, low_stats, dxn, gamma, groups, eps, want_skip=True, 
     mask_low = bool(mask_low and dlow is not None)
     am_s = torch.empty(1, dtype=torch.float32, device=dev) if mask_skip else None
     am_l = torch.empty(1, dtype=torch.float32, device=dev) if mask_low else None
-    check(_lib.load().vt_gn_bwd_masked(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W,
-                                       dev_ptr(x_stats[0], "part1"), x_stats[1], dev_ptr(p2, "part2"), n2,
-                                       dev_ptr(_c(dxn), "dxn"), groups, dev_ptr(_c(gamma), "gamma"), float(eps),
-                                       dev_ptr(bpart, "bpart"), nblkb, dev_ptr(coef, "coef"), dev_ptr(dgb, "dgb"),
-                                       dev_ptr(dskip, "dskip"), dev_ptr(dlow, "dlow"), (1 if mask_skip else 0) | (2 if mask_low else 0),
-                                       dev_ptr(am_s, "absmax_skip"), dev_ptr(am_l, "absmax_low"), stream_ptr()), "vt_gn_bwd_masked")
+    fn = _lib.load().vt_gn_bwd_from_part if have_part else _lib.load().vt_gn_bwd_masked
+    check(fn(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W,
+             dev_ptr(x_stats[0], "part1"), x_stats[1], dev_ptr(p2, "part2"), n2,
+             dev_ptr(_c(dxn), "dxn"), groups, dev_ptr(_c(gamma), "gamma"), float(eps),
+             dev_ptr(bpart, "bpart"), nblkb, dev_ptr(coef, "coef"), dev_ptr(dgb, "dgb"),
+             dev_ptr(dskip, "dskip"), dev_ptr(dlow, "dlow"), (1 if mask_skip else 0) | (2 if mask_low else 0),
+             dev_ptr(am_s, "absmax_skip"), dev_ptr(am_l, "absmax_low"), stream_ptr()), "vt_gn_bwd_from_part" if have_part else "vt_gn_bwd_masked")
     g = dgb.sum(0).t().contiguous()              # [2, C]: dgamma, dbeta as rows
     if mask_skip or mask_low:
         return dskip, dlow, g[0], g[1], am_s, am_l
