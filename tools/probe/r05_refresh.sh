@@ -7,3 +7,4 @@ timeout 400 python3 bench.py > gpurun_out/r05_bench_final.json 2> gpurun_out/r05
 timeout 900 python3 tools/bench_extra.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/r05_bench_extra.jsonl; wc -l gpurun_out/r05_bench_extra.jsonl
 python3 tools/probe/train_hip_step.py 2>&1 | grep -v "amdgpu.ids\|Warn\|warn" | head -40 > gpurun_out/r05_train_hip_step.txt; head -2 gpurun_out/r05_train_hip_step.txt
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -1
+bash tools/probe/enc_tl.sh r05 > /dev/null 2>&1; tail -1 gpurun_out/enc_timeline_r05.txt

@@ -29,3 +29,4 @@ pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(28)
+st.sort_stats("cumulative").print_stats("vtaco_amd|training", 30)
