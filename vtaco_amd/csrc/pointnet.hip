@@ -10,6 +10,7 @@
 // (k mod 4), a dependent chain of 64 FMAs otherwise being the whole kernel time.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "vt_common.h"
 #include "vtaco_hip.h"
@@ -428,6 +429,106 @@ resblock_fc_bwd_kernel(const float *x1, int C1, const float *x2, int C2, int N,
     }
 }
 
+// ---- ResnetBlockFC backward on the f32 matrix core (hidden 32: the shipped encoders) -------------------------------------------
+// resblock_fc_bwd_kernel spends 58 us per call on 24 000 points: every FMA of its dot products reads LDS.  Here a wave owns 32
+// points and every product is D[row][point] += A[row][k] B[k][point] on v_mfma_f32_32x32x2_f32 (exact f32 products, f32
+// accumulation; the sums run in another order than the per-thread dot products: f32 rounding level):
+//   h   = b0 + W0 relu(x)           32 (C = 64) k-steps     act = relu(h)
+//   da  = W1^T dout                 16                      dh  = (h > 0 ? da : 0)          (both in the accumulator layout: no exchange)
+//   dx  = (x > 0 ? W0^T dh : 0)     16 per 32 input rows    (dh through LDS: the B operand wants it by k, the accumulator has it by lane)
+//       + Ws^T dout (or dout)       16 per 32 input rows    on the same accumulators
+// Weights as [row][K | 1] in LDS (odd pitches: conflict-free for both operand orders), a wave's x / dout / dh tiles likewise.
+typedef float pn_f32x16 __attribute__((ext_vector_type(16)));
+typedef float pn_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int pn_chan(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ void pn_store16(float *row, const pn_f32x16 &v, int h) {
+    pn_f32x4 *q = reinterpret_cast<pn_f32x4 *>(row + 4 * h);
+    q[0] = pn_f32x4{v[0], v[1], v[2], v[3]}; q[2] = pn_f32x4{v[4], v[5], v[6], v[7]};
+    q[4] = pn_f32x4{v[8], v[9], v[10], v[11]}; q[6] = pn_f32x4{v[12], v[13], v[14], v[15]};
+}
+constexpr int RM_WAVES = 4;
+__host__ __device__ inline size_t rm_lds_floats(int C, bool has_ws) {
+    return (size_t)32 * (C | 1) + 32 * 33 + (has_ws ? (size_t)32 * (C | 1) : 0) + (size_t)RM_WAVES * (32 * (C | 1) + 2 * 32 * 33);
+}
+
+// (C and the shortcut are template parameters: with run-time trip counts every k-step waited for its own two LDS reads -- 39 us per
+// call; unrolled, a product's reads are all in flight before its first MFMA)
+template <int C, bool HAS_WS>
+__global__ void __launch_bounds__(RM_WAVES * 64)
+resblock_fc_bwd_mfma_kernel(const float *x1, int C1, const float *x2, int C2, int N, const float *w0, const float *b0, const float *w1,
+                            const float *ws_, const float *dout, float *dx1, float *dx2, float *act, float *dh) {
+    extern __shared__ float rl[];
+    constexpr int ldc = C | 1, nkb = C / 32;
+    const float *ws = HAS_WS ? ws_ : nullptr;
+    float *w0n = rl, *w1n = w0n + 32 * ldc, *wsn = w1n + 32 * 33;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, kk = lane >> 5;
+    float *xr = wsn + (HAS_WS ? 32 * ldc : 0) + wave * (32 * ldc + 2 * 32 * 33), *dor = xr + 32 * ldc, *gr = dor + 32 * 33;
+    for (int i = threadIdx.x; i < 32 * C; i += RM_WAVES * 64) { const int r = i / C, k = i - r * C; w0n[r * ldc + k] = w0[i]; if (HAS_WS) wsn[r * ldc + k] = ws[i]; }
+    for (int i = threadIdx.x; i < 32 * 32; i += RM_WAVES * 64) w1n[(i >> 5) * 33 + (i & 31)] = w1[i];
+    const int ntile = (N + 31) / 32;
+    for (int tile = blockIdx.x * RM_WAVES + wave; tile - wave < ntile; tile += gridDim.x * RM_WAVES) {
+        const int n0 = tile * 32;
+        const bool live = tile < ntile;
+        __syncthreads();                                            // the weights; the previous tile's readers
+        if (live) {
+            for (int i = lane; i < 32 * C; i += 64) {
+                const int p = i / C, k = i - p * C, n = min(n0 + p, N - 1);
+                xr[p * ldc + k] = k < C1 ? x1[(size_t)n * C1 + k] : x2[(size_t)n * C2 + (k - C1)];
+            }
+            for (int i = lane; i < 32 * 32; i += 64) { const int p = i >> 5, n = min(n0 + p, N - 1); dor[p * 33 + (i & 31)] = dout[(size_t)n * 32 + (i & 31)]; }
+        }
+        __syncthreads();
+        pn_f32x16 h, da;
+        const int n = n0 + m;                                       // this lane's point (accumulator column)
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { h[r] = b0[pn_chan(r, kk)]; da[r] = 0.0f; }
+#pragma unroll
+            for (int s = 0; s < C / 2; ++s)
+                h = __builtin_amdgcn_mfma_f32_32x32x2f32(w0n[m * ldc + 2 * s + kk], fmaxf(xr[m * ldc + 2 * s + kk], 0.0f), h, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                da = __builtin_amdgcn_mfma_f32_32x32x2f32(w1n[(2 * s + kk) * 33 + m], dor[m * 33 + 2 * s + kk], da, 0, 0, 0);
+            pn_f32x16 a, g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                a[r] = fmaxf(h[r], 0.0f);
+                g[r] = h[r] > 0.0f ? da[r] : 0.0f;
+                gr[m * 33 + pn_chan(r, kk)] = g[r];
+            }
+            if (n < N) { pn_store16(act + (size_t)n * 32, a, kk); pn_store16(dh + (size_t)n * 32, g, kk); }
+        }
+        __syncthreads();                                            // dh by k for the next products
+        if (live) {
+#pragma unroll
+            for (int kb = 0; kb < nkb; ++kb) {
+                pn_f32x16 d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(w0n[(2 * s + kk) * ldc + kb * 32 + m], gr[m * 33 + 2 * s + kk], d, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = kb * 32 + pn_chan(r, kk);
+                    d[r] = (xr[m * ldc + k] > 0.0f ? d[r] : 0.0f) + (HAS_WS ? 0.0f : dor[m * 33 + k]);
+                }
+                if (HAS_WS) {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s)
+                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(wsn[(2 * s + kk) * ldc + kb * 32 + m], dor[m * 33 + 2 * s + kk], d, 0, 0, 0);
+                }
+                if (n < N) {
+                    const int c0 = kb * 32;
+                    if (c0 < C1) pn_store16(dx1 + (size_t)n * C1 + c0, d, kk);
+                    else if (dx2) pn_store16(dx2 + (size_t)n * C2 + (c0 - C1), d, kk);
+                }
+            }
+        }
+    }
+}
+
+
 // Weight gradient of a linear layer over tall inputs: dW[m][k] = sum_n G[n][m] X[n][k], db[m] = sum_n G[n][m], with
 // X = [x1 | x2] (optionally relu'd), as f32 MFMA outer products (two points per v_mfma_f32_32x32x2_f32) over chunks of
 // 1024 points; the per-chunk partials are summed in chunk order by rows_wgrad_reduce_kernel (bit-reproducible).
@@ -554,6 +655,23 @@ int vt_resblock_fc_bwd(const float *x1, int C1, const float *x2, int C2, int64_t
     if (!x2) C2 = 0;
     const int C = C1 + C2;
     if (!ws && C != O) return vt_fail(VT_ERR_INVALID, "vt_resblock_fc_bwd: no shortcut layer needs size_in == size_out");
+    // hidden 32 (the shipped encoders): the products on the f32 matrix core, a wave per 32 points (VTACO_RESBLOCK_MFMA=0: the FMA kernel)
+    static const bool mfma_off = getenv("VTACO_RESBLOCK_MFMA") && getenv("VTACO_RESBLOCK_MFMA")[0] == '0';
+    const bool aligned = ((reinterpret_cast<uintptr_t>(dx1) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(dh) |
+                           reinterpret_cast<uintptr_t>(dx2)) & 15) == 0;
+    if (!mfma_off && H == 32 && O == 32 && (C == 32 || C == 64) && (C1 & 31) == 0 && (C2 & 31) == 0 && aligned) {
+        const size_t lb = rm_lds_floats(C, ws != nullptr) * sizeof(float);
+        const int ntile = (int)((N + 31) / 32), wgs = (ntile + RM_WAVES - 1) / RM_WAVES, cap = vt_num_cus();
+        const dim3 grid((unsigned)(wgs < cap ? wgs : cap)), block(RM_WAVES * 64);
+        auto launch = [&](auto kern) -> int {
+            const hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(kern), 160 * 1024);
+            if (e != hipSuccess) return vt_check(e, "vt_resblock_fc_bwd: hipFuncSetAttribute");
+            hipLaunchKernelGGL(kern, grid, block, lb, (hipStream_t)stream, x1, C1, x2, C2, (int)N, w0, b0, w1, ws, dout, dx1, dx2, act, dh);
+            return vt_check(hipGetLastError(), "vt_resblock_fc_bwd");
+        };
+        if (C == 64) return ws ? launch(&resblock_fc_bwd_mfma_kernel<64, true>) : launch(&resblock_fc_bwd_mfma_kernel<64, false>);
+        return ws ? launch(&resblock_fc_bwd_mfma_kernel<32, true>) : launch(&resblock_fc_bwd_mfma_kernel<32, false>);
+    }
     int width = C > H ? C : H; if (O > width) width = O;
     if (width > PN_THREADS) return vt_fail(VT_ERR_UNSUPPORTED, "vt_resblock_fc_bwd: more than 256 channels");
     const int pts = PN_THREADS / width;
