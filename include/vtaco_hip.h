@@ -863,6 +863,13 @@ int vt_resblock_fc_bwd(const float *x1, int C1, const float *x2, int C2, int64_t
 size_t vt_rows_wgrad_workspace_bytes(int64_t N, int M, int K);
 int vt_rows_wgrad(const float *G, int M, const float *x1, int C1, const float *x2, int C2, int relu_x, int64_t N,
                   void *workspace, size_t workspace_bytes, float *dW, float *db, void *stream);
+/* The three weight gradients of a ResnetBlockFC (layers.py:8-50: fc_1 from (dout, relu(h)), fc_0 from (dh, relu(x)), the shortcut  */
+/* from (dout, x); x = [x1 | x2]) in one pair of launches instead of three: the same tiles, partial sums and chunk-ordered          */
+/* reduction as vt_rows_wgrad (bit for bit).  act / dh: vt_resblock_fc_bwd's outputs; dws NULL without a shortcut layer.           */
+size_t vt_resblock_wgrad_workspace_bytes(int64_t N, int C, int H, int O, int has_shortcut);
+int vt_resblock_wgrad(const float *x1, int C1, const float *x2, int C2, int64_t N, const float *act, const float *dh, const float *dout,
+                      int H, int O, void *workspace, size_t workspace_bytes,
+                      float *dw0, float *db0, float *dw1, float *db1, float *dws, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* Generalized winding number of query points against a triangle mesh.          */

@@ -611,6 +611,23 @@ def test_rows_wgrad_and_resblock_bwd_vs_torch():
         assert float((act.cpu() - h.detach().relu()).abs().max()) <= 2e-5
 
 
+def test_block_weight_gradients_in_one_launch_pair_equal_the_three_products():
+    """vt_resblock_wgrad (fc_1, fc_0 and shortcut weight gradients of a ResnetBlockFC over the same rows: one pair of launches) against
+    three vt_rows_wgrad calls: same tiles, same partial sums, same chunk order -- bit for bit; with and without a shortcut, ragged N."""
+    from vtaco_amd import ops
+    g = torch.Generator().manual_seed(33)
+    for N, C1, C2, short in ((24000, 32, 32, True), (3001, 64, 0, True), (1, 32, 0, False), (5000, 32, 32, True)):
+        x1 = torch.randn(N, C1, generator=g).to(DEV)
+        x2 = torch.randn(N, C2, generator=g).to(DEV) if C2 else None
+        act, dh, dout = (torch.randn(N, 32, generator=g).to(DEV) for _ in range(3))
+        got = ops.resblock_wgrad(x1, x2, act, dh, dout, short)
+        dw1, db1 = ops.rows_wgrad(dout, act)
+        dw0, db0 = ops.rows_wgrad(dh, x1, x2, relu_x=True)
+        dws = ops.rows_wgrad(dout, x1, x2, want_bias=False)[0] if short else None
+        for a, b in zip(got, (dw0, db0, dw1, db1, dws)):
+            assert (a is None and b is None) or torch.equal(a, b)
+
+
 def test_encoder_skips_the_empty_blocks_of_the_first_layer():
     """LocalPoolPointnet at the shipped shape (64^3 grid, UNet3D f_maps 32): the inference path hands the UNet3D the blocks of the mean
     grid that no point comes near (ops.voxel_tile_flags) and its first layer fills them from the per-border-class constant instead of

@@ -535,11 +535,9 @@ resblock_fc_bwd_mfma_kernel(const float *x1, int C1, const float *x2, int C2, in
 typedef float pf32x16 __attribute__((ext_vector_type(16)));
 constexpr int RW_CHUNK = 1024, RW_PART = 1024 + 32;
 
-__global__ void __launch_bounds__(256)
-rows_wgrad_kernel(const float *G, int M, const float *x1, int C1, const float *x2, int C2, int relu_x, int N, float *partial) {
-    __shared__ float red[4][RW_PART];
+__device__ __forceinline__ void rows_wgrad_tile(const float *G, int M, const float *x1, int C1, const float *x2, int C2, int relu_x, int N,
+                                                float *dst, int chunk, int mt, int kt, float (*red)[RW_PART]) {
     const int K = C1 + C2;
-    const int chunk = blockIdx.x, mt = blockIdx.y, kt = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, kk = lane >> 5;
     const int m = mt * 32 + col, k = kt * 32 + col;
     pf32x16 acc;
@@ -577,24 +575,29 @@ rows_wgrad_kernel(const float *G, int M, const float *x1, int C1, const float *x
     csum += __shfl_xor(csum, 32);
     if (lane < 32) red[wave][1024 + lane] = csum;
     __syncthreads();
-    float *dst = partial + (((size_t)chunk * gridDim.y + mt) * gridDim.z + kt) * RW_PART;
     for (int e = threadIdx.x; e < RW_PART; e += 256) dst[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 __global__ void __launch_bounds__(256)
-rows_wgrad_reduce_kernel(const float *partial, int nchunks, int M, int K, int MT, int KT, float *dW, float *db) {
-    const int mt = blockIdx.x, kt = blockIdx.y;
+rows_wgrad_kernel(const float *G, int M, const float *x1, int C1, const float *x2, int C2, int relu_x, int N, float *partial) {
+    __shared__ float red[4][RW_PART];
+    const int chunk = blockIdx.x, mt = blockIdx.y, kt = blockIdx.z;
+    rows_wgrad_tile(G, M, x1, C1, x2, C2, relu_x, N, partial + (((size_t)chunk * gridDim.y + mt) * gridDim.z + kt) * RW_PART, chunk, mt, kt, red);
+}
+
+__device__ __forceinline__ void rows_wgrad_reduce_tile(const float *partial, size_t chunk_stride, int nchunks, int M, int K, int mt, int kt,
+                                                       float *dW, float *db) {
     for (int e = threadIdx.x; e < RW_PART; e += 256) {
         float s = 0.0f;
         int c = 0;
         for (; c + 8 <= nchunks; c += 8) {                       // eight partials in flight, added in chunk order
             float t[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = partial[(((size_t)(c + u) * MT + mt) * KT + kt) * RW_PART + e];
+            for (int u = 0; u < 8; ++u) t[u] = partial[(size_t)(c + u) * chunk_stride + e];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += t[u];
         }
-        for (; c < nchunks; ++c) s += partial[(((size_t)c * MT + mt) * KT + kt) * RW_PART + e];
+        for (; c < nchunks; ++c) s += partial[(size_t)c * chunk_stride + e];
         if (e < 1024) {
             const int r = e >> 6, l = e & 63;
             const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), k = kt * 32 + (l & 31);   // accumulator row of register r, lane half
@@ -604,6 +607,34 @@ rows_wgrad_reduce_kernel(const float *partial, int nchunks, int M, int K, int MT
             if (m < M) db[m] = s;
         }
     }
+}
+
+__global__ void __launch_bounds__(256)
+rows_wgrad_reduce_kernel(const float *partial, int nchunks, int M, int K, int MT, int KT, float *dW, float *db) {
+    const int mt = blockIdx.x, kt = blockIdx.y;
+    rows_wgrad_reduce_tile(partial + ((size_t)mt * KT + kt) * RW_PART, (size_t)MT * KT * RW_PART, nchunks, M, K, mt, kt, dW, db);
+}
+
+// Several such products over the same rows in ONE pair of launches (a ResnetBlockFC's three weight gradients -- fc_1, fc_0, the
+// shortcut -- were six launches of ~10 us each for a few MFLOP): blockIdx.y walks the 32 x 32 tiles of all jobs; every tile has its own
+// partials [chunk][RW_PART] behind `tile_base` floats of the workspace.
+constexpr int RW_MAX_JOBS = 3, RW_MAX_TILES = 16;
+struct RowsJob { const float *G, *x1, *x2; int M, C1, C2, relu_x; float *dW, *db; };
+struct RowsJobs { RowsJob job[RW_MAX_JOBS]; int njobs, ntiles, tile_job[RW_MAX_TILES], tile_mt[RW_MAX_TILES], tile_kt[RW_MAX_TILES]; };
+
+__global__ void __launch_bounds__(256)
+rows_wgrad_multi_kernel(RowsJobs js, int N, int nchunks, float *partial) {
+    __shared__ float red[4][RW_PART];
+    const int chunk = blockIdx.x, t = blockIdx.y;
+    const RowsJob &j = js.job[js.tile_job[t]];
+    rows_wgrad_tile(j.G, j.M, j.x1, j.C1, j.x2, j.C2, j.relu_x, N, partial + ((size_t)t * nchunks + chunk) * RW_PART, chunk, js.tile_mt[t], js.tile_kt[t], red);
+}
+
+__global__ void __launch_bounds__(256)
+rows_wgrad_multi_reduce_kernel(RowsJobs js, int nchunks, const float *partial) {
+    const int t = blockIdx.x;
+    const RowsJob &j = js.job[js.tile_job[t]];
+    rows_wgrad_reduce_tile(partial + (size_t)t * nchunks * RW_PART, RW_PART, nchunks, j.M, j.C1 + j.C2, js.tile_mt[t], js.tile_kt[t], j.dW, j.db);
 }
 
 inline unsigned rows_grid(int N, int pts) {
@@ -744,6 +775,42 @@ int vt_rows_wgrad(const float *G, int M, const float *x1, int C1, const float *x
     hipLaunchKernelGGL(rows_wgrad_reduce_kernel, dim3(MT, KT), dim3(256), 0, (hipStream_t)stream,
                        (const float *)workspace, nchunks, M, K, MT, KT, dW, db);
     return vt_check(hipGetLastError(), "vt_rows_wgrad");
+}
+
+size_t vt_resblock_wgrad_workspace_bytes(int64_t N, int C, int H, int O, int has_shortcut) {
+    if (N <= 0 || C <= 0 || H <= 0 || O <= 0) return 0;
+    const size_t nchunks = (size_t)((N + RW_CHUNK - 1) / RW_CHUNK);
+    const size_t tiles = (size_t)((O + 31) / 32) * ((H + 31) / 32) + (size_t)((H + 31) / 32) * ((C + 31) / 32) +
+                         (has_shortcut ? (size_t)((O + 31) / 32) * ((C + 31) / 32) : 0);
+    return tiles > RW_MAX_TILES ? 0 : tiles * nchunks * RW_PART * sizeof(float);
+}
+
+int vt_resblock_wgrad(const float *x1, int C1, const float *x2, int C2, int64_t N, const float *act, const float *dh, const float *dout,
+                      int H, int O, void *workspace, size_t workspace_bytes,
+                      float *dw0, float *db0, float *dw1, float *db1, float *dws, void *stream) {
+    if (!x1 || C1 <= 0 || (x2 && C2 <= 0) || !act || !dh || !dout || N <= 0 || N > INT32_MAX || H <= 0 || O <= 0 || !workspace || !dw0 || !dw1)
+        return vt_fail(VT_ERR_INVALID, "vt_resblock_wgrad: bad argument");
+    if (!x2) C2 = 0;
+    const int C = C1 + C2;
+    const size_t need = vt_resblock_wgrad_workspace_bytes(N, C, H, O, dws != nullptr);
+    if (!need) return vt_fail(VT_ERR_UNSUPPORTED, "vt_resblock_wgrad: more than 16 tiles of 32 x 32: use vt_rows_wgrad per product");
+    if (workspace_bytes < need) return vt_fail(VT_ERR_WORKSPACE, "vt_resblock_wgrad: workspace too small");
+    RowsJobs js{};
+    js.job[0] = RowsJob{dout, act, nullptr, O, H, 0, 0, dw1, db1};              // fc_1:     dW1 = dout^T relu(h)
+    js.job[1] = RowsJob{dh, x1, x2, H, C1, C2, 1, dw0, db0};                    // fc_0:     dW0 = dh^T relu(x)
+    js.job[2] = RowsJob{dout, x1, x2, O, C1, C2, 0, dws, nullptr};              // shortcut: dWs = dout^T x
+    js.njobs = dws ? 3 : 2;
+    int t = 0;
+    for (int j = 0; j < js.njobs; ++j) {
+        const int MT = (js.job[j].M + 31) / 32, KT = (js.job[j].C1 + js.job[j].C2 + 31) / 32;
+        for (int mt = 0; mt < MT; ++mt)
+            for (int kt = 0; kt < KT; ++kt) { js.tile_job[t] = j; js.tile_mt[t] = mt; js.tile_kt[t] = kt; ++t; }
+    }
+    js.ntiles = t;
+    const int nchunks = (int)((N + RW_CHUNK - 1) / RW_CHUNK);
+    hipLaunchKernelGGL(rows_wgrad_multi_kernel, dim3(nchunks, t), dim3(256), 0, (hipStream_t)stream, js, (int)N, nchunks, (float *)workspace);
+    hipLaunchKernelGGL(rows_wgrad_multi_reduce_kernel, dim3(t), dim3(256), 0, (hipStream_t)stream, js, nchunks, (const float *)workspace);
+    return vt_check(hipGetLastError(), "vt_resblock_wgrad");
 }
 
 }  // extern "C"

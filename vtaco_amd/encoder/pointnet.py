@@ -92,6 +92,10 @@ class _ResBlockFcFn(torch.autograd.Function):
     def backward(ctx, dout):
         x1, x2, w0, b0, w1, ws = ctx.saved_tensors
         dx1, dx2, act, dh = ops.resblock_fc_bwd(x1, x2, w0, b0, w1, ws, dout, want_dx2=x2 is not None and ctx.needs_input_grad[1])
+        grads = ops.resblock_wgrad(x1, x2, act, dh, dout, ws is not None)       # the three products in one pair of launches
+        if grads is not None:
+            dw0, db0, dw1, db1, dws = grads
+            return dx1, dx2, dw0, db0, dw1, db1, dws
         dw1, db1 = ops.rows_wgrad(dout, act)
         dw0, db0 = ops.rows_wgrad(dh, x1, x2, relu_x=True)
         dws = ops.rows_wgrad(dout, x1, x2, want_bias=False)[0] if ws is not None else None

@@ -645,6 +645,31 @@ def rows_wgrad(g, x1, x2=None, relu_x=False, want_bias=True):
     return dW, db
 
 
+def resblock_wgrad(x1, x2, act, dh, dout, has_shortcut):
+    """The three weight gradients of a ResnetBlockFC in one pair of launches (vt_resblock_wgrad): returns (dw0, db0, dw1, db1, dws or
+    None), or None where the block is too wide for it (use rows_wgrad per product)."""
+    x1, act, dh, dout = _c(x1), _c(act), _c(dh), _c(dout)
+    x2 = _c(x2) if x2 is not None else None
+    C1, C2 = x1.shape[-1], (x2.shape[-1] if x2 is not None else 0)
+    H, O = act.shape[-1], dout.shape[-1]
+    N = x1.numel() // C1
+    lib = _lib.load()
+    wsb = lib.vt_resblock_wgrad_workspace_bytes(N, C1 + C2, H, O, 1 if has_shortcut else 0)
+    if not wsb:
+        return None
+    dev = x1.device
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+    dw0 = torch.empty((H, C1 + C2), dtype=torch.float32, device=dev)
+    db0 = torch.empty((H,), dtype=torch.float32, device=dev)
+    dw1 = torch.empty((O, H), dtype=torch.float32, device=dev)
+    db1 = torch.empty((O,), dtype=torch.float32, device=dev)
+    dws = torch.empty((O, C1 + C2), dtype=torch.float32, device=dev) if has_shortcut else None
+    check(lib.vt_resblock_wgrad(dev_ptr(x1, "x1"), C1, dev_ptr(x2, "x2"), C2, N, dev_ptr(act, "act"), dev_ptr(dh, "dh"), dev_ptr(dout, "dout"),
+                                H, O, ctypes.c_void_p(ws.data_ptr()), wsb, dev_ptr(dw0, "dw0"), dev_ptr(db0, "db0"), dev_ptr(dw1, "dw1"),
+                                dev_ptr(db1, "db1"), dev_ptr(dws, "dws"), stream_ptr()), "vt_resblock_wgrad")
+    return dw0, db0, dw1, db1, dws
+
+
 # --------------------------------------------------------------------------------------
 # hand branch: plane bookkeeping (vt_plane_*) and the MANO layer (vt_mano_*)
 # --------------------------------------------------------------------------------------
