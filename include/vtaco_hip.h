@@ -766,16 +766,17 @@ int vt_gn_bwd_from_part(const float *skip, int C1, const float *low, int C2, int
                         const float *part1, int nblk1, const float *part2, int nblk2,
                         const float *dxn, int groups, const float *gamma, double eps,
                         const float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow,
-                        int mask_flags, float *absmax_skip, float *absmax_low, void *stream);
+                        int mask_flags, float *absmax_skip, float *absmax_low, float *dgb_sum, void *stream);
 /* vt_gn_bwd that also does the relu_mask pass of the layer(s) in front (autograd of unet3d.py:20-72: ReLU behind the conv whose   */
 /* output this GroupNorm reads).  mask_flags bit 0: `skip` is such a ReLU output and dskip is its only gradient -- dskip comes out  */
 /* as (skip > 0 ? dskip : 0) with max |dskip| in the device scalar absmax_skip, exactly what vt_relu_mask_absmax(dskip, skip)      */
 /* would leave; bit 1: the same for `low` / dlow / absmax_low.  The layer in front then skips its vt_relu_mask_absmax.             */
+/* dgb_sum (or NULL; needs dskip or dlow): [2][C] = (dgamma, dbeta) summed over the scenes in scene order (dgb keeps them per scene). */
 int vt_gn_bwd_masked(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                      const float *part1, int nblk1, const float *part2, int nblk2,
                      const float *dxn, int groups, const float *gamma, double eps,
                      float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow,
-                     int mask_flags, float *absmax_skip, float *absmax_low, void *stream);
+                     int mask_flags, float *absmax_skip, float *absmax_low, float *dgb_sum, void *stream);
 int vt_maxpool3d_cl_bwd(const float *x, const float *dy, int B, int D, int H, int W, int C, float *dx, void *stream);
 /* The gradient of an encoder level's output y (unet3d.py:449-474: it feeds the next level's max-pool AND the decoder's skip) in one  */
 /* pass: g = (y > 0 ? dskip + maxpool_backward(dpooled) : 0) -- vt_maxpool3d_cl_bwd, the framework's add of the two gradients and    */

@@ -3962,10 +3962,20 @@ gn_bwd_coeffs_kernel(StatSrc s1, StatSrc s2, const float *bpart, int nblkb, int 
 // layer's relu_mask pass happens here -- (x > 0 ? d : 0) with the running max |.| for its power-of-two rescale (amax_skip /
 // amax_low: cells the launcher zeroed, one atomicMax per workgroup as relu_mask_kernel) -- instead of in a pass of its own
 __global__ void __launch_bounds__(256)
-gn_bwd_apply_kernel(Src s, const float *dxn, const float *coef, float *dskip, float *dlow, int mask, unsigned *amax_skip, unsigned *amax_low) {
+gn_bwd_apply_kernel(Src s, const float *dxn, const float *coef, float *dskip, float *dlow, int mask, unsigned *amax_skip, unsigned *amax_low,
+                    const float *dgb, float *dgb_sum, int B) {
     const int C = s.C1 + s.C2;
     const size_t V = (size_t)s.D * s.H * s.W;
     const int b = blockIdx.y;
+    // (one workgroup also adds the scenes' (dgamma, dbeta) contributions in scene order: [2][C], what the framework's sum + transpose
+    // + copy took two launches for)
+    if (dgb_sum && blockIdx.x == 0 && b == 0)
+        for (int i = threadIdx.x; i < 2 * C; i += 256) {
+            const int c = i % C, q = i / C;
+            float a = 0.0f;
+            for (int bb = 0; bb < B; ++bb) a += dgb[((size_t)bb * C + c) * 2 + q];
+            dgb_sum[i] = a;
+        }
     auto bits = [](float x) { return __builtin_bit_cast(unsigned, x) & 0x7fffffffu; };
     __shared__ unsigned wmax[2][4];
     unsigned us = 0, ul = 0;
@@ -4232,32 +4242,33 @@ static int gn_bwd_impl(const float *skip, int C1, const float *low, int C2, int 
                        const float *part1, int nblk1, const float *part2, int nblk2,
                        const float *dxn, int groups, const float *gamma, double eps,
                        float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow,
-                       int mask_flags, float *absmax_skip, float *absmax_low, void *stream, bool bpart_ready);
+                       int mask_flags, float *absmax_skip, float *absmax_low, void *stream, bool bpart_ready, float *dgb_sum = nullptr);
 
 int vt_gn_bwd_masked(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                      const float *part1, int nblk1, const float *part2, int nblk2,
                      const float *dxn, int groups, const float *gamma, double eps,
                      float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow,
-                     int mask_flags, float *absmax_skip, float *absmax_low, void *stream) {
+                     int mask_flags, float *absmax_skip, float *absmax_low, float *dgb_sum, void *stream) {
     return gn_bwd_impl(skip, C1, low, C2, B, D, H, W, part1, nblk1, part2, nblk2, dxn, groups, gamma, eps, bpart, nblkb, coef, dgb, dskip, dlow,
-                       mask_flags, absmax_skip, absmax_low, stream, false);
+                       mask_flags, absmax_skip, absmax_low, stream, false, dgb_sum);
 }
 
 int vt_gn_bwd_from_part(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                         const float *part1, int nblk1, const float *part2, int nblk2,
                         const float *dxn, int groups, const float *gamma, double eps,
                         const float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow,
-                        int mask_flags, float *absmax_skip, float *absmax_low, void *stream) {
+                        int mask_flags, float *absmax_skip, float *absmax_low, float *dgb_sum, void *stream) {
     return gn_bwd_impl(skip, C1, low, C2, B, D, H, W, part1, nblk1, part2, nblk2, dxn, groups, gamma, eps, const_cast<float *>(bpart), nblkb, coef, dgb,
-                       dskip, dlow, mask_flags, absmax_skip, absmax_low, stream, true);
+                       dskip, dlow, mask_flags, absmax_skip, absmax_low, stream, true, dgb_sum);
 }
 
 static int gn_bwd_impl(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                        const float *part1, int nblk1, const float *part2, int nblk2,
                        const float *dxn, int groups, const float *gamma, double eps,
                        float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow,
-                       int mask_flags, float *absmax_skip, float *absmax_low, void *stream, bool bpart_ready) {
+                       int mask_flags, float *absmax_skip, float *absmax_low, void *stream, bool bpart_ready, float *dgb_sum) {
     Src s{skip, low, C1, low ? C2 : 0, D, H, W};
+    if (dgb_sum && !dskip && !dlow) return vt_fail(VT_ERR_INVALID, "vt_gn_bwd: the summed (dgamma, dbeta) come out of the pass that writes dskip / dlow");
     if (!src_ok(s, B) || !part1 || nblk1 <= 0 || !dxn || !gamma || !bpart || nblkb <= 0 || !coef || !dgb)
         return vt_fail(VT_ERR_INVALID, "vt_gn_bwd: bad argument");
     if (low && (!part2 || nblk2 <= 0)) return vt_fail(VT_ERR_INVALID, "vt_gn_bwd: statistics of `low` missing");
@@ -4285,7 +4296,7 @@ static int gn_bwd_impl(const float *skip, int C1, const float *low, int C2, int 
             if (e != hipSuccess) return vt_check(e, "vt_gn_bwd_masked: hipMemsetAsync");
         }
         hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)blocks, B), dim3(256), 0, st, s, dxn, (const float *)coef, dskip, dlow,
-                           mask_flags, reinterpret_cast<unsigned *>(absmax_skip), reinterpret_cast<unsigned *>(absmax_low));
+                           mask_flags, reinterpret_cast<unsigned *>(absmax_skip), reinterpret_cast<unsigned *>(absmax_low), (const float *)dgb, dgb_sum, B);
     }
     return vt_check(hipGetLastError(), "vt_gn_bwd");
 }
@@ -4295,7 +4306,7 @@ int vt_gn_bwd(const float *skip, int C1, const float *low, int C2, int B, int D,
               const float *dxn, int groups, const float *gamma, double eps,
               float *bpart, int nblkb, float *coef, float *dgb, float *dskip, float *dlow, void *stream) {
     return vt_gn_bwd_masked(skip, C1, low, C2, B, D, H, W, part1, nblk1, part2, nblk2, dxn, groups, gamma, eps, bpart, nblkb, coef, dgb,
-                            dskip, dlow, 0, nullptr, nullptr, stream);
+                            dskip, dlow, 0, nullptr, nullptr, nullptr, stream);
 }
 
 int vt_maxpool3d_cl_bwd_fork(const float *y, const float *dskip, const float *dpooled, int B, int D, int H, int W, int C, float *g,

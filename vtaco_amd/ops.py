@@ -1545,14 +1545,17 @@ def gn_bwd(x, x_stats, low, low_stats, dxn, gamma, groups, eps, want_skip=True, 
     mask_low = bool(mask_low and dlow is not None)
     am_s = torch.empty(1, dtype=torch.float32, device=dev) if mask_skip else None
     am_l = torch.empty(1, dtype=torch.float32, device=dev) if mask_low else None
+    # (dgamma, dbeta) summed over the scenes by the pass that writes the gradients, where there is one
+    gsum = torch.empty((2, C), dtype=torch.float32, device=dev) if (dskip is not None or dlow is not None) else None
     fn = _lib.load().vt_gn_bwd_from_part if have_part else _lib.load().vt_gn_bwd_masked
     check(fn(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W,
              dev_ptr(x_stats[0], "part1"), x_stats[1], dev_ptr(p2, "part2"), n2,
              dev_ptr(_c(dxn), "dxn"), groups, dev_ptr(_c(gamma), "gamma"), float(eps),
              dev_ptr(bpart, "bpart"), nblkb, dev_ptr(coef, "coef"), dev_ptr(dgb, "dgb"),
              dev_ptr(dskip, "dskip"), dev_ptr(dlow, "dlow"), (1 if mask_skip else 0) | (2 if mask_low else 0),
-             dev_ptr(am_s, "absmax_skip"), dev_ptr(am_l, "absmax_low"), stream_ptr()), "vt_gn_bwd_from_part" if have_part else "vt_gn_bwd_masked")
-    g = dgb.sum(0).t().contiguous()              # [2, C]: dgamma, dbeta as rows
+             dev_ptr(am_s, "absmax_skip"), dev_ptr(am_l, "absmax_low"), dev_ptr(gsum, "dgb_sum"), stream_ptr()),
+          "vt_gn_bwd_from_part" if have_part else "vt_gn_bwd_masked")
+    g = gsum if gsum is not None else dgb.sum(0).t().contiguous()              # [2, C]: dgamma, dbeta as rows
     if mask_skip or mask_low:
         return dskip, dlow, g[0], g[1], am_s, am_l
     return dskip, dlow, g[0], g[1]
