@@ -749,6 +749,16 @@ size_t vt_conv3d_wgrad_f16x3_workspace_bytes(int B, int D, int H, int W, int Cin
 int vt_conv3d_wgrad_f16x3(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                           const float *scale_shift, const float *g, int Cout, const float *g_absmax,
                           void *workspace, size_t workspace_bytes, float *dw, void *stream);
+/* The same dW for a layer whose input x [B,D,H,W,C] is EXACTLY zero over most of the volume -- the UNet3D's first layer on a scene's */
+/* mean grid (reference: src/encoder/pointnet.py:102-114 leaves >= 98.8 % of the grid zero; its gradient, src/conv_onet/training.py   */
+/* :757-894).  xn = x * scale + shift inside the volume, 0 outside, so dW = sum_v g[v] (x * scale)[v + tap] + shift * (sum of g over   */
+/* the voxels whose tap neighbour is inside): the first sum runs over the 8 x 8 x 2 tiles of the blocks `tile_flags` does not mark     */
+/* (vt_voxel_build_clear_flags: bit 0 = no point in the block's 10^3 halo) only, in ascending tile order (bit-reproducible); the       */
+/* second is 27 box sums of g per scene times the shift, added by the reduction.  Sides in multiples of 8, channels of 32.            */
+size_t vt_conv3d_wgrad_f16x3_sparse_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int vt_conv3d_wgrad_f16x3_sparse(const float *x, int C, int B, int D, int H, int W, const float *scale_shift,
+                                 const unsigned char *tile_flags, const float *g, int Cout, const float *g_absmax,
+                                 void *workspace, size_t workspace_bytes, float *dw, void *stream);
 int vt_gn_bwd(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
               const float *part1, int nblk1, const float *part2, int nblk2,
               const float *dxn, int groups, const float *gamma, double eps,

@@ -596,6 +596,39 @@ def test_tile_flags_and_the_first_layer_without_its_empty_blocks():
         assert torch.equal(none, ref)                                 # nothing flagged: the dense walk through the lists, same bits
 
 
+def test_weight_gradient_without_the_blocks_whose_input_is_zero():
+    """vt_conv3d_wgrad_f16x3_sparse against the dense split-f16 kernel and against the f64 definition on grids that are zero away from a
+    cloud: the taps over the unflagged blocks' tiles plus shift x (27 box sums of g) -- clouds in the middle, clouds touching the
+    border (the box sums' border planes), an empty scene beside a full one (the rank-one term alone), two cout blocks, and flags that
+    are all zero (every tile listed: the dense sum in the same tile order)."""
+    from vtaco_amd import ops
+    g = torch.Generator().manual_seed(47)
+    cases = [(1, 32, 32, 32, 300, 0.3, 0.7), (2, 32, 32, 64, 400, 0.0, 1.0), (2, 64, 32, 32, 3000, 0.2, 0.8), (1, 16, 64, 32, 40, 0.0, 0.3)]
+    for B, R, C, Cout, n_pts, lo, hi in cases:
+        x, idx, want = _sparse_case(B, R, C, g, n_pts, lo, hi)
+        if B == 2 and n_pts == 400:
+            x[1] = 0
+            want[1] = 3
+        x, flags = x.to(DEV), torch.from_numpy(want).to(DEV)
+        gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV), (0.3 * torch.randn(C, generator=g)).to(DEV)
+        ss = ops.gn_scale_shift(ops.channel_stats(x), None, C, 0, B, R ** 3, gamma, beta, 8, 1e-5, x.device)
+        dy = (torch.randn(B, R, R, R, Cout, generator=g) * 1e-4).to(DEV)
+        gmax = dy.abs().max().reshape(1)
+        dense = ops.conv3d_wgrad(x, None, ss, dy, precision="f16x3", g_absmax=gmax)
+        got = ops.conv3d_wgrad_sparse(x, ss, dy, flags, g_absmax=gmax)
+        assert got is not None and int((flags & 1).sum()) > 0
+        scale = float(dense.abs().max())
+        assert float((got - dense).abs().max()) <= 2e-5 * scale, (B, R, C, Cout, float((got - dense).abs().max()), scale)
+        assert torch.equal(got, ops.conv3d_wgrad_sparse(x, ss, dy, flags, g_absmax=gmax))          # fixed summation order
+        allt = ops.conv3d_wgrad_sparse(x, ss, dy, torch.zeros_like(flags), g_absmax=gmax)
+        assert float((allt - dense).abs().max()) <= 2e-5 * scale
+        if R <= 32:
+            # the definition in f64: dW = conv-weight gradient of xn = x * scale + shift (zero padding after the norm)
+            xn = (x.double() * ss[:, :, 0].double()[:, None, None, None, :] + ss[:, :, 1].double()[:, None, None, None, :]).permute(0, 4, 1, 2, 3)
+            ref = torch.nn.grad.conv3d_weight(xn.cpu(), (Cout, C, 3, 3, 3), dy.double().permute(0, 4, 1, 2, 3).cpu(), padding=1)
+            assert float((got.cpu().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
 def test_second_layer_without_the_blocks_whose_rim_is_empty(monkeypatch):
     """vt_unet3d_fwd_skip on a 32 -> 32 -> 32 first DoubleConv: the second layer skips the blocks whose 12^3 halo holds no point (flag
     bit 1) -- around them the first layer's output is a constant per border class, so the second's is one per class of a two-voxel rim

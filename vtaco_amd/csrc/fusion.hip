@@ -120,10 +120,10 @@ __device__ __forceinline__ void fp8_saturating_mode() { __builtin_amdgcn_s_setre
 // the Q/K groups are permuted so that registers 0..7 / 8..15 of lane-half h hold 8 consecutive
 // output columns (16(2g + r/8) + 8h + r%8): exactly one hi and one lo fragment of the split row
 // layout above, written with 16-byte stores.  V keeps the natural order (store_acc16).
-constexpr int PROJ_TILES = 8;
+constexpr int PROJ_TILES = 8;                                  // the most 32-point tiles one wave takes (proj_tiles below)
 template <bool DO_Q, bool DO_KV, bool F8>
 __global__ void __launch_bounds__(256)
-fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd, float *Kd, float *V, int total, XIds xi) {
+fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd, float *Kd, float *V, int total, XIds xi, int tiles) {
     __shared__ __attribute__((aligned(16))) float wf[5][16][64];          // [group][k-step][lane] A fragments
     if constexpr (F8) fp8_saturating_mode();
     for (int e = threadIdx.x; e < 5 * 1024; e += 256) {
@@ -141,10 +141,10 @@ fusion_proj_kernel(const float *Xq, const float *Xk, FusionUnitDev u, float *Qd,
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-    // PROJ_TILES 32-point tiles per wave: the staging of the weight fragments above (20 loads per thread) is paid once per
-    // 128 * PROJ_TILES points instead of once per 128
-    for (int tile = 0; tile < PROJ_TILES; ++tile) {
-    const int p0 = ((blockIdx.x * PROJ_TILES + tile) * 4 + wave) * 32;
+    // ``tiles`` 32-point tiles per wave: the staging of the weight fragments above (20 loads per thread) is paid once per
+    // 128 * tiles points instead of once per 128
+    for (int tile = 0; tile < tiles; ++tile) {
+    const int p0 = ((blockIdx.x * tiles + tile) * 4 + wave) * 32;
     if (p0 >= total) return;
     const int p = min(p0 + j, total - 1);
     const bool live = p0 + j < total;
@@ -722,6 +722,14 @@ size_t fusion_layout(int B, int N, FusionWs *ws, char *base) {
     return off;
 }
 
+// tiles per wave of the projection kernel.  At 256 chunks of 2048 points the kernel moves 400 MB in 111 us (3.6 TB/s: its rows are
+// its bound, 8 / 4 / 2 / 1 tiles per wave all give the same time); launches of a few ten thousand points (the training step's) want
+// the workgroups first: 1.29 -> 1.25 ms per unit chain at 64 chunks
+static int proj_tiles(int P) {
+    int t = P / (128 * 1536);
+    return t < 1 ? 1 : t > PROJ_TILES ? PROJ_TILES : t;
+}
+
 // one attention unit: Xq against Xk -> out = relu(IN(Xq + MHA(Xq, Xk, Xk))).  ``Osave`` != null: training forward (w.l / w.s /
 // w.V / w.Z then point into the caller's saved state instead of the scratch workspace, and the dropouts of ``dc`` are applied)
 void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const float *blob, const FusionWs &w,
@@ -729,7 +737,8 @@ void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const fl
     const int P = B * N, Npad = (N + 31) / 32 * 32;
     const int ntile = (N + 31) / 32;
     const int nrb = (N + FROWS - 1) / FROWS;
-    const dim3 pg((P + 128 * PROJ_TILES - 1) / (128 * PROJ_TILES)), tg((unsigned)nrb * (unsigned)B);   // see chunk_of_workgroup
+    const int tiles = proj_tiles(P);
+    const dim3 pg((P + 128 * tiles - 1) / (128 * tiles)), tg((unsigned)nrb * (unsigned)B);   // see chunk_of_workgroup
     // the training forward keeps every product (its backward recomputes the scores on the f32 core); inference runs the
     // fp8-corrected tiles (keys rounded to half, the queries' remainder and both E x V' corrections on fp8 MFMAs) unless
     // VTACO_FUSION_SCORE_TERMS is set: 3 = all three half products, 2 = the half-pair form with rounded keys (round 2's)
@@ -739,14 +748,14 @@ void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const fl
     // 8e-5 on the fused features at N = 33 against 4e-5, 1.4e-5 against 1.7e-5 at N = 2048; tools/probe/fusion_ragged_err.py)
     const bool f8 = !full && N >= 512 && !(env_terms && env_terms[0] == '2');
     if (Xq == Xk) {
-        if (f8) hipLaunchKernelGGL((fusion_proj_kernel<true, true, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi);
-        else hipLaunchKernelGGL((fusion_proj_kernel<true, true, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi);
+        if (f8) hipLaunchKernelGGL((fusion_proj_kernel<true, true, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi, tiles);
+        else hipLaunchKernelGGL((fusion_proj_kernel<true, true, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi, tiles);
     } else if (f8) {
-        hipLaunchKernelGGL((fusion_proj_kernel<true, false, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi);
-        hipLaunchKernelGGL((fusion_proj_kernel<false, true, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi);
+        hipLaunchKernelGGL((fusion_proj_kernel<true, false, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi, tiles);
+        hipLaunchKernelGGL((fusion_proj_kernel<false, true, true>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi, tiles);
     } else {
-        hipLaunchKernelGGL((fusion_proj_kernel<true, false, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi);
-        hipLaunchKernelGGL((fusion_proj_kernel<false, true, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi);
+        hipLaunchKernelGGL((fusion_proj_kernel<true, false, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi, tiles);
+        hipLaunchKernelGGL((fusion_proj_kernel<false, true, false>), pg, dim3(256), 0, s, Xq, Xk, u, w.Qd, w.Kd, w.V, P, xi, tiles);
     }
     if (f8) {
         hipLaunchKernelGGL(fusion_expsum8_kernel<false>, tg, dim3(FT), 0, s, w.Qd, w.Kd, (const float *)nullptr, w.l, N, 1, nrb, B);                // 1/l_q

@@ -3576,6 +3576,9 @@ static_assert(2 * WH_LDS <= 160 * 1024, "two workgroups per CU");
 struct WgradHArgs {
     WgradArgs w;
     const float *g_absmax;      // device scalar max |g| (or null: no rescale)
+    const int *list;            // null: every tile.  Else [0] = n, [1 .. n] = the tiles to visit, ascending (wgrad_tile_list_kernel):
+                                // the staged input is then x * scale WITHOUT the shift (zero wherever x is), and the shift's share of dW
+                                // is the rank-one term the reduce kernel adds (vt_conv3d_wgrad_f16x3_sparse)
 };
 
 __device__ __forceinline__ float pow2_scale_for(const float *absmax) {
@@ -3662,7 +3665,7 @@ __device__ __forceinline__ void wgrad_h_ksteps(const char *xh, const char *xl, c
 #endif
 // everything a wave does, instantiated per wave index: one straight tile loop per variant (a wave switch INSIDE the loop made the
 // allocator shuffle the 112 accumulator registers at every join: 48 v_mov_b64 per k-step)
-template <int W>
+template <int W, bool LIST>
 __device__ __forceinline__ void wgrad_h_wave(const WgradHArgs &ha, char *whl) {
     char *xh = whl, *xl = whl + WH_XPLANE, *gh = whl + 2 * WH_XPLANE, *gl = gh + WH_GPLANE;
     const WgradArgs &a = ha.w;
@@ -3696,7 +3699,8 @@ __device__ __forceinline__ void wgrad_h_wave(const WgradHArgs &ha, char *whl) {
         sc = f32x4{1.f, 1.f, 1.f, 1.f}; sh = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.c.scale_shift) {
             const float *ss = a.c.scale_shift + ((size_t)b * Cin + chq) * 2;
-            sc = f32x4{ss[0], ss[2], ss[4], ss[6]}; sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
+            sc = f32x4{ss[0], ss[2], ss[4], ss[6]};
+            if (!LIST) sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
         }
         inmask = 0;
 #pragma unroll
@@ -3760,13 +3764,29 @@ __device__ __forceinline__ void wgrad_h_wave(const WgradHArgs &ha, char *whl) {
             }
         }
     };
-    if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        __syncthreads();                                                   // the previous tile's k-steps are done with the planes
-        commit();
-        __syncthreads();
-        if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
-        wgrad_h_ksteps<W>(xh, xl, gh, gl, acc, lane);
+    if constexpr (LIST) {
+        // the list's tiles, every gridDim.x-th; an entry is read one visit ahead of its fetch
+        const int *list = ha.list;
+        const int nvisit = __builtin_amdgcn_readfirstlane(list[0]), G = gridDim.x;
+        auto tile_at = [&](int i) { return __builtin_amdgcn_readfirstlane(list[1 + min(i, nvisit - 1)]); };
+        int t_ahead = 0;
+        if ((int)blockIdx.x < nvisit) { fetch(tile_at(blockIdx.x)); t_ahead = tile_at(blockIdx.x + G); }
+        for (int i = blockIdx.x; i < nvisit; i += G) {
+            __syncthreads();
+            commit();
+            __syncthreads();
+            if (i + G < nvisit) { fetch(t_ahead); t_ahead = tile_at(i + 2 * G); }
+            wgrad_h_ksteps<W>(xh, xl, gh, gl, acc, lane);
+        }
+    } else {
+        if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
+        for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+            __syncthreads();                                                   // the previous tile's k-steps are done with the planes
+            commit();
+            __syncthreads();
+            if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+            wgrad_h_ksteps<W>(xh, xl, gh, gl, acc, lane);
+        }
     }
     // partial[chunk][cob][cib][tap][co][ci]: lane (ci, half kk) register r = co chan_of(r, kk)
     float *dst = a.partial + (((size_t)blockIdx.x * nco + cob) * ncib + cib) * 27 * 1024;
@@ -3780,22 +3800,150 @@ __device__ __forceinline__ void wgrad_h_wave(const WgradHArgs &ha, char *whl) {
     }
 }
 
+template <bool LIST = false>
 __global__ void __launch_bounds__(WH_THREADS, VT_WH_WPS)
 conv3d_wgrad_h_kernel(WgradHArgs ha) {
     extern __shared__ __attribute__((aligned(16))) char whl[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0) wgrad_h_wave<0>(ha, whl);
-    else if (wave == 1) wgrad_h_wave<1>(ha, whl);
-    else if (wave == 2) wgrad_h_wave<2>(ha, whl);
-    else wgrad_h_wave<3>(ha, whl);
+    if (wave == 0) wgrad_h_wave<0, LIST>(ha, whl);
+    else if (wave == 1) wgrad_h_wave<1, LIST>(ha, whl);
+    else if (wave == 2) wgrad_h_wave<2, LIST>(ha, whl);
+    else wgrad_h_wave<3, LIST>(ha, whl);
+}
+
+// ---- weight gradient of a layer whose input is mostly EXACT zeros (the network's first layer on a scene's mean grid) -------------
+// xn = x * scale + shift inside the volume and 0 outside, so
+//     dW[co][ci][tap] = sum_v g[v][co] (x * scale)[v + tap][ci]  +  shift[ci] * sum_{v : v + tap inside} g[v][co]
+// and the first sum has no term from a tile over whose halo x is zero: the 8 x 8 x 2 tiles of a block flagged by the voxel sort
+// (bit 0: no point in the block's 10^3 halo; unet3d's first-layer skip reads the same bytes).  wgrad_tile_list_kernel lists the other
+// tiles in ascending order (so the kernel's summation order is fixed), wgrad_gsum_plane_kernel / wgrad_gsum_final_kernel leave the 27
+// box sums of g per scene, the reduce kernel adds the rank-one term.
+__global__ void __launch_bounds__(1024)
+wgrad_tile_list_kernel(const unsigned char *flags, int ntiles, int tiles_x, int tiles_y, int tiles_z, int *list) {
+    __shared__ int cnt[1024];
+    const int per = (ntiles + 1023) / 1024, t0 = threadIdx.x * per, t1 = min(t0 + per, ntiles);
+    const int tps = tiles_x * tiles_y * tiles_z, t8z = (tiles_z * WH_TZ) >> 3;
+    auto keep = [&](int tile) {
+        const int b = tile / tps;
+        int t = tile - b * tps;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y, tz = t / tiles_y;
+        return !(flags[(size_t)b * t8z * tiles_y * tiles_x + ((size_t)((tz * WH_TZ) >> 3) * tiles_y + ty) * tiles_x + tx] & 1);
+    };
+    int n = 0;
+    for (int t = t0; t < t1; ++t) n += keep(t) ? 1 : 0;
+    cnt[threadIdx.x] = n;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                           // inclusive scan
+        const int v = threadIdx.x >= d ? cnt[threadIdx.x - d] : 0;
+        __syncthreads();
+        cnt[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int o = cnt[threadIdx.x] - n;
+    for (int t = t0; t < t1; ++t)
+        if (keep(t)) list[1 + o++] = t;
+    if (threadIdx.x == 1023) list[0] = cnt[1023];
+}
+
+// P[b][z][yc][xc][Cout]: sums of g over plane z of scene b by row class yc (y = 0, inner, y = H - 1) and xc = (all x, x = 0, x = W - 1).
+// Thread = (x lane 0..31, four channels); grid (D, B).
+__global__ void __launch_bounds__(256)
+wgrad_gsum_plane_kernel(const float *g, int D, int H, int W, int Cout, float *P) {
+    __shared__ float red[4][9][8][4];
+    const int z = blockIdx.x, b = blockIdx.y, q = threadIdx.x & 7, vl = threadIdx.x >> 3, wave = threadIdx.x >> 6;
+    for (int cb = 0; cb < Cout; cb += 32) {
+        f32x4 acc[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *pl = g + ((size_t)((b * D + z) * H) * W) * Cout + cb + q * 4;
+        for (int x = vl; x < W; x += 32) {
+            const float *col = pl + (size_t)x * Cout;
+            const size_t pitch = (size_t)W * Cout;
+            const f32x4 r0 = *reinterpret_cast<const f32x4 *>(col), r1 = *reinterpret_cast<const f32x4 *>(col + (size_t)(H - 1) * pitch);
+            f32x4 mid = {0.f, 0.f, 0.f, 0.f};
+            for (int y = 1; y < H - 1; y += 8) {                    // eight rows in flight per thread
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(col + (size_t)min(y + u, H - 2) * pitch);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (y + u < H - 1) mid += v[u];
+            }
+            const f32x4 rows[3] = {r0, mid, r1};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                acc[i][0] += rows[i];
+                if (x == 0) acc[i][1] += rows[i];
+                if (x == W - 1) acc[i][2] += rows[i];
+            }
+        }
+        // lanes of a wave with the same q: bits 3..5 of the lane
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][k][e];
+                    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+                    acc[i][k][e] = v;
+                }
+        __syncthreads();
+        if ((threadIdx.x & 63) < 8)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) red[wave][i * 3 + k][q][e] = acc[i][k][e];
+        __syncthreads();
+        for (int t = threadIdx.x; t < 9 * 32; t += 256) {
+            const int cls = t >> 5, c = t & 31;
+            const float v = ((red[0][cls][c >> 2][c & 3] + red[1][cls][c >> 2][c & 3]) + red[2][cls][c >> 2][c & 3]) + red[3][cls][c >> 2][c & 3];
+            P[(((size_t)(b * D + z)) * 9 + cls) * Cout + cb + c] = v;
+        }
+    }
+}
+
+// S[b][tap][co] = sum of g over the voxels v of scene b with v + tap inside the volume, from the plane sums (planes in ascending z)
+__global__ void __launch_bounds__(256)
+wgrad_gsum_final_kernel(const float *P, int D, int Cout, float *S) {
+    const int b = blockIdx.y;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < 27 * Cout; t += gridDim.x * 256) {
+        const int tap = t / Cout, co = t - tap * Cout;
+        const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+        const int z0 = dz < 0 ? 1 : 0, z1 = dz > 0 ? D - 1 : D;
+        float sum = 0.0f;
+        for (int z = z0; z < z1; ++z) {
+            const float *p = P + ((size_t)(b * D + z)) * 9 * Cout + co;
+            float pl = 0.0f;
+#pragma unroll
+            for (int yc = 0; yc < 3; ++yc) {
+                if ((dy < 0 && yc == 0) || (dy > 0 && yc == 2)) continue;
+                float v = p[(yc * 3 + 0) * Cout];
+                if (dx < 0) v -= p[(yc * 3 + 1) * Cout];
+                if (dx > 0) v -= p[(yc * 3 + 2) * Cout];
+                pl += v;
+            }
+            sum += pl;
+        }
+        S[((size_t)b * 27 + tap) * Cout + co] = sum;
+    }
 }
 
 // as conv3d_wgrad_reduce_kernel, with the power-of-two scale of the output gradient taken back out.  The 512 chunk partials of
 // an entry are dealt over four thread groups (each adds its contiguous quarter in chunk order, eight loads in flight), the four
 // sums meet in LDS and are added in group order: a fixed tree (bit-reproducible), 4x the workgroups of one thread per entry
 // (56 MB of partials per layer: 54 -> ~20 us).
+// ``rank_s`` (or null): S[b][tap][co] = the sum of the UNSCALED output gradient over the voxels whose tap neighbour lies inside the
+// volume; dW[co][ci][tap] += sum_b shift_b[ci] S_b[tap][co] -- the share of the GroupNorm shift, which the list form of the kernel
+// above leaves out of its staged input
 __global__ void __launch_bounds__(256)
-conv3d_wgrad_reduce_scaled_kernel(const float *partial, int chunks, int Cout, int Cin, const float *g_absmax, float *dw) {
+conv3d_wgrad_reduce_scaled_kernel(const float *partial, int chunks, int Cout, int Cin, const float *g_absmax, float *dw,
+                                  const float *rank_s = nullptr, const float *scale_shift = nullptr, int B = 0) {
     __shared__ float quarter[4][64];
     const int nco = Cout / 32, ncib = Cin / 32;
     const size_t total = (size_t)Cout * Cin * 27, per_chunk = (size_t)nco * ncib * 27 * 1024;
@@ -3822,7 +3970,11 @@ conv3d_wgrad_reduce_scaled_kernel(const float *partial, int chunks, int Cout, in
             size_t r = e >> 10;
             const int tap = (int)(r % 27); r /= 27;
             const int cib = (int)(r % ncib), cob = (int)(r / ncib);
-            dw[((size_t)(cob * 32 + co) * Cin + cib * 32 + ci) * 27 + tap] = tot4 * post;
+            float v = tot4 * post;
+            if (rank_s)
+                for (int b = 0; b < B; ++b)
+                    v = fmaf(scale_shift[((size_t)b * Cin + cib * 32 + ci) * 2 + 1], rank_s[((size_t)b * 27 + tap) * Cout + cob * 32 + co], v);
+            dw[((size_t)(cob * 32 + co) * Cin + cib * 32 + ci) * 27 + tap] = v;
         }
         __syncthreads();
     }
@@ -4223,19 +4375,75 @@ int vt_conv3d_wgrad_f16x3(const float *skip, int C1, const float *low, int C2, i
     a.g = g; a.partial = (float *)workspace;
     a.ntiles = B * a.c.tiles_x * a.c.tiles_y * a.c.tiles_z;
     ha.g_absmax = g_absmax;
+    ha.list = nullptr;
     const int pairs = (Cin / 32) * (Cout / 32), chunks = wgrad_h_chunks(B, D, H, W, pairs);
     bool attr = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr) {
-        const hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_wgrad_h_kernel), (int)WH_LDS);
+        const hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_wgrad_h_kernel<false>), (int)WH_LDS);
         if (e != hipSuccess) return vt_check(e, "vt_conv3d_wgrad_f16x3: hipFuncSetAttribute");
         attr = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv3d_wgrad_h_kernel, dim3((unsigned)chunks, (unsigned)pairs), dim3(WH_THREADS), WH_LDS, st, ha);
+    hipLaunchKernelGGL(conv3d_wgrad_h_kernel<false>, dim3((unsigned)chunks, (unsigned)pairs), dim3(WH_THREADS), WH_LDS, st, ha);
     const size_t total = (size_t)Cout * Cin * 27;
     hipLaunchKernelGGL(conv3d_wgrad_reduce_scaled_kernel, dim3((unsigned)(total / 64 < 4096 ? total / 64 : 4096)), dim3(256), 0, st,
                        (const float *)workspace, chunks, Cout, Cin, g_absmax, dw);
     return vt_check(hipGetLastError(), "vt_conv3d_wgrad_f16x3");
+}
+
+// the same weight gradient for an input that is exactly zero over most of the volume (see wgrad_tile_list_kernel): workspace =
+// [chunk partials][tile list][plane sums][box sums]
+static size_t wgrad_sparse_layout(int B, int D, int H, int W, int Cin, int Cout, size_t *list_off, size_t *p_off, size_t *s_off) {
+    const size_t part = vt_conv3d_wgrad_f16x3_workspace_bytes(B, D, H, W, Cin, Cout);
+    if (!part || (D & 7)) return 0;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    size_t off = up(part);
+    if (list_off) *list_off = off;
+    off += up((size_t)(1 + B * (W / 8) * (H / 8) * (D / WH_TZ)) * sizeof(int));
+    if (p_off) *p_off = off;
+    off += up((size_t)B * D * 9 * Cout * sizeof(float));
+    if (s_off) *s_off = off;
+    off += up((size_t)B * 27 * Cout * sizeof(float));
+    return off;
+}
+
+size_t vt_conv3d_wgrad_f16x3_sparse_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+    return wgrad_sparse_layout(B, D, H, W, Cin, Cout, nullptr, nullptr, nullptr);
+}
+
+int vt_conv3d_wgrad_f16x3_sparse(const float *x, int C, int B, int D, int H, int W, const float *scale_shift,
+                                 const unsigned char *tile_flags, const float *g, int Cout, const float *g_absmax,
+                                 void *workspace, size_t workspace_bytes, float *dw, void *stream) {
+    WgradHArgs ha;
+    WgradArgs &a = ha.w;
+    a.c.s = Src{x, nullptr, C, 0, D, H, W};
+    if (!src_ok(a.c.s, B) || !g || !workspace || !dw || !scale_shift || !tile_flags)
+        return vt_fail(VT_ERR_INVALID, "vt_conv3d_wgrad_f16x3_sparse: bad argument");
+    size_t list_off, p_off, s_off;
+    const size_t need = wgrad_sparse_layout(B, D, H, W, C, Cout, &list_off, &p_off, &s_off);
+    if (!need) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_wgrad_f16x3_sparse: shape not covered (sides in multiples of 8, channels of 32)");
+    if (workspace_bytes < need) return vt_fail(VT_ERR_WORKSPACE, "vt_conv3d_wgrad_f16x3_sparse: workspace too small");
+    a.c.scale_shift = scale_shift; a.c.wp = nullptr; a.c.out = nullptr; a.c.part = nullptr; a.c.Cout = Cout; a.c.relu = 0;
+    a.c.TX = 8; a.c.TY = 8; a.c.TZ = WH_TZ;
+    a.c.tiles_x = W / 8; a.c.tiles_y = H / 8; a.c.tiles_z = D / WH_TZ;
+    a.g = g; a.partial = (float *)workspace;
+    a.ntiles = B * a.c.tiles_x * a.c.tiles_y * a.c.tiles_z;
+    ha.g_absmax = g_absmax;
+    int *list = reinterpret_cast<int *>((char *)workspace + list_off);
+    float *P = reinterpret_cast<float *>((char *)workspace + p_off), *S = reinterpret_cast<float *>((char *)workspace + s_off);
+    ha.list = list;
+    const int pairs = (C / 32) * (Cout / 32), chunks = wgrad_h_chunks(B, D, H, W, pairs);
+    const hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_wgrad_h_kernel<true>), (int)WH_LDS);
+    if (e != hipSuccess) return vt_check(e, "vt_conv3d_wgrad_f16x3_sparse: hipFuncSetAttribute");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wgrad_tile_list_kernel, dim3(1), dim3(1024), 0, st, tile_flags, a.ntiles, a.c.tiles_x, a.c.tiles_y, a.c.tiles_z, list);
+    hipLaunchKernelGGL(wgrad_gsum_plane_kernel, dim3((unsigned)D, (unsigned)B), dim3(256), 0, st, g, D, H, W, Cout, P);
+    hipLaunchKernelGGL(wgrad_gsum_final_kernel, dim3((unsigned)((27 * Cout + 255) / 256), (unsigned)B), dim3(256), 0, st, (const float *)P, D, Cout, S);
+    hipLaunchKernelGGL(conv3d_wgrad_h_kernel<true>, dim3((unsigned)chunks, (unsigned)pairs), dim3(WH_THREADS), WH_LDS, st, ha);
+    const size_t total = (size_t)Cout * C * 27;
+    hipLaunchKernelGGL(conv3d_wgrad_reduce_scaled_kernel, dim3((unsigned)(total / 64 < 4096 ? total / 64 : 4096)), dim3(256), 0, st,
+                       (const float *)workspace, chunks, Cout, C, g_absmax, dw, (const float *)S, scale_shift, B);
+    return vt_check(hipGetLastError(), "vt_conv3d_wgrad_f16x3_sparse");
 }
 
 static int gn_bwd_impl(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,

@@ -97,6 +97,7 @@ class _MaskLink:
 
 _MASK_FUSE = os.environ.get("VTACO_UNET_MASK_FUSE", "1") != "0"     # A/B knob
 _XSTATS = os.environ.get("VTACO_UNET_DGRAD_XSTATS", "1") != "0"      # A/B knob: GroupNorm-backward sums from the data-gradient conv's epilogue
+_WGRAD_SPARSE = os.environ.get("VTACO_UNET_WGRAD_SPARSE", "1") != "0"   # A/B knob: the first layer's weight gradient without the blocks whose input is zero
 
 
 class _GcrFn(torch.autograd.Function):
@@ -119,9 +120,11 @@ class _GcrFn(torch.autograd.Function):
         # "f16x3": the forward conv on split-f16 operands where that kernel covers the shape (its inputs are GroupNorm outputs:
         # inside the half range, error at f32 rounding level)
         half = ops.conv3d_pack(weight, "f16x3") if precision == "f16x3" else None
+        ctx.flags = None
         if tile_flags is not None and half is not None and low is None and ops.conv3d_skip_covers(x, Cout):
             # the network's first layer on a mean grid: the blocks no point comes near are filled from the border-class constants
             y, (part, _) = ops.conv3d_gcr_skip(x, ss, half, Cout, tile_flags)
+            ctx.flags = tile_flags                                          # (the weight gradient leaves the same blocks out)
         else:
             # a decoder entry [skip | upsample(low)]: the upsampled channels as a 2x2x2 conv per output parity class (forward only:
             # the data gradient reads a dense output gradient)
@@ -170,8 +173,13 @@ class _GcrFn(torch.autograd.Function):
             dxn, _ = ops.conv3d_gcr(g, None, None, lambda: ops.conv3d_pack(w_t()), weight.shape[1], False, split, want_stats=False,
                                     packed_w_f16x3=half, in_absmax=gmax)
         # weight gradient: split-half operands as well (K = voxels; g under the same power-of-two rescale)
-        dw = ops.conv3d_wgrad(x, low, ss, g, precision="f16x3" if precision == "f16x3" and _WGRAD_F16 else "f32",
-                              g_absmax=gmax) if ctx.needs_input_grad[4] else None
+        dw = None
+        if ctx.needs_input_grad[4]:
+            # x zero over most blocks (the first layer): the taps over the other blocks + the GroupNorm shift's rank-one share
+            if ctx.flags is not None and _WGRAD_SPARSE and _WGRAD_F16 and gmax is not None:
+                dw = ops.conv3d_wgrad_sparse(x, ss, g, ctx.flags, g_absmax=gmax)
+            if dw is None:
+                dw = ops.conv3d_wgrad(x, low, ss, g, precision="f16x3" if precision == "f16x3" and _WGRAD_F16 else "f32", g_absmax=gmax)
         x_st = (x_part, x_part.shape[1])
         low_st = (low_part, low_part.shape[1]) if low is not None else None
         m_skip = x_link is not None and ctx.needs_input_grad[0]

@@ -1502,6 +1502,23 @@ def conv3d_wgrad(x, low, ss, g, precision="f32", g_absmax=None):
     return dw
 
 
+def conv3d_wgrad_sparse(x, ss, g, tile_flags, g_absmax=None):
+    """dW of a layer whose input is exactly zero over the blocks ``tile_flags`` marks (vt_conv3d_wgrad_f16x3_sparse: the taps over the
+    other blocks' tiles + the GroupNorm shift's rank-one share); None where the shape is not on that kernel."""
+    lib = _lib.load()
+    B, D, H, W, C = x.shape
+    Cout = g.shape[-1]
+    nbytes = lib.vt_conv3d_wgrad_f16x3_sparse_workspace_bytes(B, D, H, W, C, Cout)
+    if not nbytes or tile_flags is None or tile_flags.numel() != B * (D // 8) * (H // 8) * (W // 8):
+        return None
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    dw = torch.empty((Cout, C, 3, 3, 3), dtype=torch.float32, device=x.device)
+    check(lib.vt_conv3d_wgrad_f16x3_sparse(dev_ptr(x, "x"), C, B, D, H, W, dev_ptr(ss, "scale_shift"),
+                                           dev_ptr(tile_flags, "tile_flags", torch.uint8), dev_ptr(g, "g"), Cout, dev_ptr(g_absmax, "g_absmax"), ctypes.c_void_p(ws.data_ptr()), nbytes,
+                                           dev_ptr(dw, "dw"), stream_ptr()), "vt_conv3d_wgrad_f16x3_sparse")
+    return dw
+
+
 def conv3d_dgrad_xstats(g, packed_t, Cin, g_absmax, x):
     """The data gradient of a plain 'gcr' layer with the GroupNorm backward's sums from its epilogue (vt_conv3d_gcr_f16x3_xstats):
     ``g`` [B,D,H,W,Cout] the masked output gradient, ``packed_t`` = conv3d_pack_t(weight), ``x`` [B,D,H,W,Cin] the layer's input.
