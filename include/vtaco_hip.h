@@ -736,6 +736,14 @@ int vt_voxel_scatter_mean_cl_bwd(const float *grad_grid_cl, const int *idx, cons
 int vt_relu_mask(const float *dy, const float *y, float *g, int64_t n, void *stream);
 /* the same, and *absmax = max |g| (device scalar; feeds the power-of-two rescale of the split-half data / weight gradient kernels) */
 int vt_relu_mask_absmax(const float *dy, const float *y, float *g, int64_t n, float *absmax, void *stream);
+/* Backward of the UNet3D's final 1x1x1 conv (32 -> 32 channels; reference: src/encoder/unet3d.py final_conv under autograd,           */
+/* src/conv_onet/training.py:757-894) fused with the ReLU mask of the layer in front of it: dout, y [n,32] (y = that layer's ReLU        */
+/* output = the conv's input), w [32,32] (out, in).  g[v] = (y[v] > 0) * (dout[v] W), *absmax = max |g| (device scalar, or NULL),         */
+/* dw [32,32] = dout^T y, db [32] = column sums of dout (either may be NULL).  Exact f32 (v_mfma_f32_32x32x2_f32), fixed summation        */
+/* order.  One pass over dout and y instead of the framework's GEMM + vt_relu_mask_absmax + batched GEMM + two reductions.               */
+size_t vt_conv1x1_bwd_workspace_bytes(void);
+int vt_conv1x1_bwd_masked(const float *dout, const float *y, const float *w, int64_t n, float *g, float *absmax, float *dw, float *db,
+                          void *workspace, size_t workspace_bytes, void *stream);
 size_t vt_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int vt_conv3d_wgrad(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                     const float *scale_shift, const float *g, int Cout, void *workspace, size_t workspace_bytes,

@@ -596,6 +596,32 @@ def test_tile_flags_and_the_first_layer_without_its_empty_blocks():
         assert torch.equal(none, ref)                                 # nothing flagged: the dense walk through the lists, same bits
 
 
+def test_final_pointwise_conv_backward_with_the_last_layers_mask():
+    """vt_conv1x1_bwd_masked against autograd of relu -> linear in f64: g = (y > 0) * (dout W) with its maximum, dW = dout^T y, db --
+    row counts that are and are not multiples of 32 (the ragged last wave turn), gradients at 1e-6 scale, bit-identical reruns."""
+    from vtaco_amd import ops
+    gen = torch.Generator().manual_seed(53)
+    for n in (32 * 4096, 32 * 777 + 17, 5):
+        pre = torch.randn(n, 32, generator=gen).to(DEV)
+        y = torch.relu(pre)
+        w = (torch.randn(32, 32, generator=gen) * 0.2).to(DEV)
+        dout = (torch.randn(n, 32, generator=gen) * 1e-6).to(DEV)
+        g, gmax, dw, db = ops.conv1x1_bwd_masked(dout, y, w)
+        p64 = pre.double().requires_grad_(True)
+        w64 = w.double().requires_grad_(True)
+        b64 = torch.zeros(32, dtype=torch.float64, device=DEV, requires_grad=True)
+        torch.nn.functional.linear(torch.relu(p64), w64, b64).backward(dout.double())
+        scale = float(p64.grad.abs().max())
+        assert float((g.double() - p64.grad).abs().max()) <= 2e-6 * scale
+        assert float(gmax) == float(g.abs().max())
+        assert float((dw.double() - w64.grad).abs().max()) <= 1e-5 * float(w64.grad.abs().max())
+        assert float((db.double() - b64.grad).abs().max()) <= 1e-5 * float(b64.grad.abs().max())
+        g2, gmax2, dw2, db2 = ops.conv1x1_bwd_masked(dout, y, w)
+        assert torch.equal(g, g2) and torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(gmax, gmax2)
+        g3, _, dw3, db3 = ops.conv1x1_bwd_masked(dout, y, w, want_dw=False, want_db=False)
+        assert torch.equal(g, g3) and dw3 is None and db3 is None
+
+
 def test_weight_gradient_without_the_blocks_whose_input_is_zero():
     """vt_conv3d_wgrad_f16x3_sparse against the dense split-f16 kernel and against the f64 definition on grids that are zero away from a
     cloud: the taps over the unflagged blocks' tiles plus shift x (27 box sums of g) -- clouds in the middle, clouds touching the

@@ -97,6 +97,7 @@ class _MaskLink:
 
 _MASK_FUSE = os.environ.get("VTACO_UNET_MASK_FUSE", "1") != "0"     # A/B knob
 _XSTATS = os.environ.get("VTACO_UNET_DGRAD_XSTATS", "1") != "0"      # A/B knob: GroupNorm-backward sums from the data-gradient conv's epilogue
+_FIN_FUSE = os.environ.get("VTACO_UNET_FIN_BWD", "1") != "0"        # A/B knob: the final 1x1x1 conv's backward + the last layer's mask in one pass
 _WGRAD_SPARSE = os.environ.get("VTACO_UNET_WGRAD_SPARSE", "1") != "0"   # A/B knob: the first layer's weight gradient without the blocks whose input is zero
 
 
@@ -192,6 +193,25 @@ class _GcrFn(torch.autograd.Function):
         if m_low:
             low_link.ready, low_link.gmax = True, res[5]
         return dskip, dlow, dgamma, dbeta, dw, None, None, None, None, None, None, None, None, None
+
+
+class _FinConvFn(torch.autograd.Function):
+    """The final 1x1x1 conv (32 -> 32) behind the last 'gcr' layer under autograd: forward = the matmul, backward = ONE pass
+    (ops.conv1x1_bwd_masked) that leaves the last layer's MASKED output gradient with its maximum (handed over through ``link``,
+    as a reader's GroupNorm backward does for the inner layers), dW and db."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias, link):
+        ctx.save_for_backward(y, weight)
+        ctx.link = link
+        return F.linear(y, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, weight = ctx.saved_tensors
+        g, gmax, dw, db = ops.conv1x1_bwd_masked(dout, y, weight, want_dw=ctx.needs_input_grad[1], want_db=ctx.needs_input_grad[2])
+        ctx.link.ready, ctx.link.gmax = True, gmax
+        return g, dw, db, None
 
 
 class _MaxPoolFn(torch.autograd.Function):
@@ -494,11 +514,17 @@ class UNet3D(nn.Module):
         for k, (dec, (skip, skip_part)) in enumerate(zip(self.decoders, skips[-2::-1])):
             l12 = link()
             x, part = gcr(dec.basic_module.SingleConv1, skip, skip_part, low=x, low_part=part, out_link=l12, low_link=low_link)
-            low_link = link() if k + 1 < n_dec else None
+            # (the last layer's output has one reader too: the final conv, whose backward masks)
+            fin = (k + 1 == n_dec and _FIN_FUSE and _MASK_FUSE and self.train_precision == "f16x3" and self.final_conv.bias is not None
+                   and tuple(self.final_conv.weight.shape[:2]) == (32, 32) and x.shape[-1] == 32)
+            low_link = link() if (k + 1 < n_dec or fin) else None
             x, part = gcr(dec.basic_module.SingleConv2, x, part, x_link=l12, out_link=low_link)
         w = self.final_conv.weight.reshape(self.final_conv.out_channels, -1)
-        # 2 M voxels x 32 channels: the weight gradient is a 32 x 32 GEMM with K = 2 M (hipBLASLt: one 2.6 ms kernel) -> split-K
-        x = _TallLinear.apply(x, w, self.final_conv.bias) if x.numel() // x.shape[-1] >= 4096 else F.linear(x, w, self.final_conv.bias)
+        if n_dec and fin:
+            x = _FinConvFn.apply(x, w, self.final_conv.bias, low_link)
+        else:
+            # 2 M voxels x 32 channels: the weight gradient is a 32 x 32 GEMM with K = 2 M (hipBLASLt: one 2.6 ms kernel) -> split-K
+            x = _TallLinear.apply(x, w, self.final_conv.bias) if x.numel() // x.shape[-1] >= 4096 else F.linear(x, w, self.final_conv.bias)
         if self.testing and self.final_activation is not None:
             x = self.final_activation(x) if isinstance(self.final_activation, nn.Sigmoid) else torch.softmax(x, dim=-1)
         return x

@@ -1475,6 +1475,27 @@ def relu_mask(dy, y, want_absmax=False):
     return g
 
 
+def conv1x1_bwd_masked(dout, y, w, want_dw=True, want_db=True):
+    """Backward of a 32 -> 32 pointwise conv out = y W^T + b whose input y is the ReLU output of the layer in front of it
+    (vt_conv1x1_bwd_masked): returns (g, gmax, dw, db) with g = (y > 0) * (dout W) -- that layer's masked output gradient -- its
+    max |g| as a device scalar, dw [32,32] and db [32] (None where not wanted)."""
+    lib = _lib.load()
+    if w.shape != (32, 32) or y.shape[-1] != 32 or dout.shape != y.shape:
+        raise VtError(f"conv1x1_bwd_masked: built for 32 -> 32 channels over equal-shaped dout / y, got {tuple(w.shape)}, {tuple(dout.shape)}, {tuple(y.shape)}")
+    dout, y, w = _c(dout), _c(y), _c(w)
+    n = y.numel() // 32
+    g = torch.empty_like(y)
+    gmax = torch.empty(1, dtype=torch.float32, device=y.device)
+    dw = torch.empty((32, 32), dtype=torch.float32, device=y.device) if want_dw else None
+    db = torch.empty(32, dtype=torch.float32, device=y.device) if want_db else None
+    nbytes = lib.vt_conv1x1_bwd_workspace_bytes()
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=y.device)
+    check(lib.vt_conv1x1_bwd_masked(dev_ptr(dout, "dout"), dev_ptr(y, "y"), dev_ptr(w, "w"), n, dev_ptr(g, "g"), dev_ptr(gmax, "absmax"),
+                                    dev_ptr(dw, "dw"), dev_ptr(db, "db"), ctypes.c_void_p(ws.data_ptr()), nbytes, stream_ptr()),
+          "vt_conv1x1_bwd_masked")
+    return g, gmax, dw, db
+
+
 def conv3d_wgrad(x, low, ss, g, precision="f32", g_absmax=None):
     """dW [Cout,Cin,3,3,3] of the 3x3x3 conv over xn = [x | upsample(low)] * scale + shift (vt_conv3d_wgrad).
     ``precision="f16x3"``: vt_conv3d_wgrad_f16x3 where it covers the shape (split-half operands on the f16 matrix core;
