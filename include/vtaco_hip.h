@@ -686,6 +686,11 @@ int vt_conv1x1_pack_f16x3(const float *w, int Cout, int Cin, float *packed /* 10
 int vt_conv3d_gcr_f16x3_final(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                               const float *scale_shift, const float *packed_w_f16x3, int Cout,
                               const float *final_packed_f16x3, const float *final_b, float *out, void *stream);
+/* the same launch, and relu(conv(...)) itself to `y_keep` [B,D,H,W,32]: the training forward keeps the last layer's output for its     */
+/* backward and for vt_conv1x1_bwd_masked (reference: the same two modules under autograd, src/conv_onet/training.py:757-894)            */
+int vt_conv3d_gcr_f16x3_final_keep(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                                   const float *scale_shift, const float *packed_w_f16x3, int Cout,
+                                   const float *final_packed_f16x3, const float *final_b, float *out, float *y_keep, void *stream);
 size_t vt_unet3d_workspace_bytes(int B, int R, const vt_unet3d_params *params_host);
 int vt_unet3d_fwd(const float *x_cl, int B, int R, const vt_unet3d_params *params_host,
                   void *workspace, size_t workspace_bytes, float *out, void *stream);

@@ -210,6 +210,7 @@ SIGNATURES = {
     "vt_conv3d_final_fusable": (_I, [_I, _I, _I, _I, _I, _I]),
     "vt_conv1x1_pack_f16x3": (_I, [_VP, _I, _I, _VP, _VP]),
     "vt_conv3d_gcr_f16x3_final": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP]),
+    "vt_conv3d_gcr_f16x3_final_keep": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "vt_conv3d_stat_blocks_bf16x3": (_I, [_I, _I, _I, _I, _I, _I]),
     "vt_conv3d_gcr_bf16x3": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _VP]),
     "vt_conv3d_ksplit_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),

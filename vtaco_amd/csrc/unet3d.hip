@@ -1050,6 +1050,7 @@ struct HbArgs {
     // between the decoder's layers -- and six MFMAs against fin_w (vt_conv1x1_pack_f16x3) + fin_b give what is stored
     const float *fin_w = nullptr;
     const float *fin_b = nullptr;
+    float *fin_y = nullptr;     // or null: relu(conv) itself goes here as well (the training forward keeps it for the backward)
     // or null.  [B][D/8][H/8][W/8] bytes: 1 = no voxel of that 8^3 block's halo (as far as this layer reads) differs from zero before
     // the GroupNorm, i.e. the normalised input there is the per-channel shift.  The specialised-wave kernel then skips the block's taps:
     // its output is sum over the in-volume taps of T[tap][cout] = sum_cin W[cout][cin][tap] shift[cin] (vt_voxel_tile_flags makes the
@@ -1773,6 +1774,7 @@ conv3d_gcr_hw_kernel(HbArgs ha) {
                     for (int r = 0; r < 16; ++r) o[r] = ha.fin_b ? ha.fin_b[chan_of(r, kg)] : 0.0f;
                     o = dense32s<2>(o, ha.fin_w, xs, lane);
                     store_acc16(orow, o, kg);
+                    if (ha.fin_y) store_acc16(ha.fin_y + vox * a.Cout, v, kg);
                     continue;
                 }
                 store_acc16(orow + co_blk * 32, v, kg);
@@ -2171,6 +2173,7 @@ conv3d_gcr_hx_kernel(HbArgs ha) {
                     for (int r = 0; r < 16; ++r) o[r] = ha.fin_b ? ha.fin_b[chan_of(r, kg)] : 0.0f;
                     o = dense32s<2>(o, ha.fin_w, xs, lane);
                     store_acc16(orow, o, kg);
+                    if (ha.fin_y) store_acc16(ha.fin_y + (orow - a.out), v, kg);
                     continue;
                 }
                 store_acc16(orow + co_blk * 32, v, kg);
@@ -2769,7 +2772,7 @@ static int conv_h_launch(const float *skip, int C1, const float *low, int C2, in
                          const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
                          float *out_part, const float *in_absmax, const float *fin_w, const float *fin_b, void *stream,
                          const GnIn &stat_in = GnIn{}, const GnOut &stat_out = GnOut{}, const unsigned char *tile_skip = nullptr,
-                         const ClsLink &cls = ClsLink{}, const float *stat_x = nullptr);
+                         const ClsLink &cls = ClsLink{}, const float *stat_x = nullptr, float *fin_y = nullptr);
 // would conv_h_launch take skip flags on this plain layer?
 static bool conv_h_skip_accepts(int B, int D, int H, int W, int Cin, int Cout);
 static int conv_h_wgs_of(int B, int D, int H, int W, int Cin, int Cout);
@@ -2818,6 +2821,17 @@ int vt_conv3d_gcr_f16x3_final(const float *skip, int C1, const float *low, int C
     return conv_h_launch(skip, C1, low, C2, B, D, H, W, scale_shift, packed_w_f16x3, Cout, 1, out, nullptr, nullptr, final_packed_f16x3, final_b, stream);
 }
 
+// the same launch, and y = relu(conv(...)) itself to `y_keep` (the training forward: the layer's backward and the final conv's read it)
+int vt_conv3d_gcr_f16x3_final_keep(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                                   const float *scale_shift, const float *packed_w_f16x3, int Cout,
+                                   const float *final_packed_f16x3, const float *final_b, float *out, float *y_keep, void *stream) {
+    if (!final_packed_f16x3 || !y_keep) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr_f16x3_final_keep: null argument");
+    if (Cout != 32 || !conv_h_specialised(conv_h_tz(B, D, H, W, C1 + (low ? C2 : 0), Cout)))
+        return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_gcr_f16x3_final_keep: needs Cout = 32 and a shape of the specialised-wave kernel");
+    return conv_h_launch(skip, C1, low, C2, B, D, H, W, scale_shift, packed_w_f16x3, Cout, 1, out, nullptr, nullptr, final_packed_f16x3, final_b, stream,
+                         GnIn{}, GnOut{}, nullptr, ClsLink{}, nullptr, y_keep);
+}
+
 // w [32][32] (out, in) -> the A-operand fragments of dense32s<2>: [part: hi, lo][k-step 0, 1][64 lanes][8 halves], lane = (out row,
 // k-group), element e of k-step s = input channel chan_of(8 s + e, k-group) -- the channel that register 8 s + e of the 3x3x3
 // layer's accumulator holds in that half of the wave
@@ -2846,12 +2860,13 @@ int vt_conv1x1_pack_f16x3(const float *w, int Cout, int Cin, float *packed, void
 static int conv_h_launch(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                          const float *scale_shift, const float *packed_w_f16x3, int Cout, int relu, float *out,
                          float *out_part, const float *in_absmax, const float *fin_w, const float *fin_b, void *stream,
-                         const GnIn &stat_in, const GnOut &stat_out, const unsigned char *tile_skip, const ClsLink &cls, const float *stat_x) {
+                         const GnIn &stat_in, const GnOut &stat_out, const unsigned char *tile_skip, const ClsLink &cls, const float *stat_x,
+                         float *fin_y) {
     HbArgs ha;
     ha.stat_x = stat_x;
     ha.c.stat_in = stat_in; ha.c.stat_out = stat_out;
     ha.in_absmax = in_absmax;
-    ha.fin_w = fin_w; ha.fin_b = fin_b;
+    ha.fin_w = fin_w; ha.fin_b = fin_b; ha.fin_y = fin_w ? fin_y : nullptr;
     ConvArgs &a = ha.c;
     a.s = Src{skip, low, C1, low ? C2 : 0, D, H, W};
     if (!src_ok(a.s, B) || !packed_w_f16x3 || !out) return vt_fail(VT_ERR_INVALID, "vt_conv3d_gcr_f16x3: bad argument");

@@ -97,6 +97,7 @@ class _MaskLink:
 
 _MASK_FUSE = os.environ.get("VTACO_UNET_MASK_FUSE", "1") != "0"     # A/B knob
 _XSTATS = os.environ.get("VTACO_UNET_DGRAD_XSTATS", "1") != "0"      # A/B knob: GroupNorm-backward sums from the data-gradient conv's epilogue
+_FIN_FWD = os.environ.get("VTACO_UNET_FIN_FWD", "1") != "0"         # A/B knob: the final conv's training forward in the last layer's epilogue
 _FIN_FUSE = os.environ.get("VTACO_UNET_FIN_BWD", "1") != "0"        # A/B knob: the final 1x1x1 conv's backward + the last layer's mask in one pass
 _WGRAD_SPARSE = os.environ.get("VTACO_UNET_WGRAD_SPARSE", "1") != "0"   # A/B knob: the first layer's weight gradient without the blocks whose input is zero
 
@@ -110,7 +111,7 @@ class _GcrFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, low, gamma, beta, weight, x_part, low_part, groups, eps, precision, tile_flags=None, out_link=None,
-                x_link=None, low_link=None):
+                x_link=None, low_link=None, fin=None):
         B, D, H, W, C1 = x.shape
         C2 = low.shape[-1] if low is not None else 0
         Cout = weight.shape[0]
@@ -122,7 +123,12 @@ class _GcrFn(torch.autograd.Function):
         # inside the half range, error at f32 rounding level)
         half = ops.conv3d_pack(weight, "f16x3") if precision == "f16x3" else None
         ctx.flags = None
-        if tile_flags is not None and half is not None and low is None and ops.conv3d_skip_covers(x, Cout):
+        if fin is not None and half is not None and low is None and Cout == 32 and ops.final_fusable(x, Cout):
+            # the last layer: the final 1x1x1 conv rides in its epilogue (fin = (weight [32,32], bias, stash)); y is kept as well, no
+            # statistics (nothing normalises it)
+            y, fin[2].out = ops.conv3d_gcr_final_keep(x, ss, half, ops.conv1x1_pack_f16x3(fin[0].detach()), fin[1].detach())
+            part = x_part.new_empty(0)
+        elif tile_flags is not None and half is not None and low is None and ops.conv3d_skip_covers(x, Cout):
             # the network's first layer on a mean grid: the blocks no point comes near are filled from the border-class constants
             y, (part, _) = ops.conv3d_gcr_skip(x, ss, half, Cout, tile_flags)
             ctx.flags = tile_flags                                          # (the weight gradient leaves the same blocks out)
@@ -192,7 +198,12 @@ class _GcrFn(torch.autograd.Function):
             x_link.ready, x_link.gmax = True, res[4]
         if m_low:
             low_link.ready, low_link.gmax = True, res[5]
-        return dskip, dlow, dgamma, dbeta, dw, None, None, None, None, None, None, None, None, None
+        return dskip, dlow, dgamma, dbeta, dw, None, None, None, None, None, None, None, None, None, None
+
+
+class _FinStash:
+    """The final conv's output when the last layer's launch computed it in its epilogue (handed from _GcrFn to _FinConvFn)."""
+    out = None
 
 
 class _FinConvFn(torch.autograd.Function):
@@ -201,17 +212,18 @@ class _FinConvFn(torch.autograd.Function):
     as a reader's GroupNorm backward does for the inner layers), dW and db."""
 
     @staticmethod
-    def forward(ctx, y, weight, bias, link):
+    def forward(ctx, y, weight, bias, link, stash):
         ctx.save_for_backward(y, weight)
         ctx.link = link
-        return F.linear(y, weight, bias)
+        out, stash.out = stash.out, None                              # the last layer's launch already left it (its epilogue)
+        return out if out is not None else F.linear(y, weight, bias)
 
     @staticmethod
     def backward(ctx, dout):
         y, weight = ctx.saved_tensors
         g, gmax, dw, db = ops.conv1x1_bwd_masked(dout, y, weight, want_dw=ctx.needs_input_grad[1], want_db=ctx.needs_input_grad[2])
         ctx.link.ready, ctx.link.gmax = True, gmax
-        return g, dw, db, None
+        return g, dw, db, None, None
 
 
 class _MaxPoolFn(torch.autograd.Function):
@@ -478,10 +490,10 @@ class UNet3D(nn.Module):
         def stats(t):
             return ops.channel_stats(t.detach())[0]
 
-        def gcr(single, t, part, low=None, low_part=None, flags=None, out_link=None, x_link=None, low_link=None):
+        def gcr(single, t, part, low=None, low_part=None, flags=None, out_link=None, x_link=None, low_link=None, fin=None):
             gn, conv = single.groupnorm, single.conv
             return _GcrFn.apply(t, low, gn.weight, gn.bias, conv.weight, part, low_part, gn.num_groups, gn.eps, self.train_precision, flags,
-                                out_link, x_link, low_link)
+                                out_link, x_link, low_link, fin)
 
         def link():
             return _MaskLink() if _MASK_FUSE else None
@@ -518,10 +530,13 @@ class UNet3D(nn.Module):
             fin = (k + 1 == n_dec and _FIN_FUSE and _MASK_FUSE and self.train_precision == "f16x3" and self.final_conv.bias is not None
                    and tuple(self.final_conv.weight.shape[:2]) == (32, 32) and x.shape[-1] == 32)
             low_link = link() if (k + 1 < n_dec or fin) else None
-            x, part = gcr(dec.basic_module.SingleConv2, x, part, x_link=l12, out_link=low_link)
+            stash = _FinStash() if fin else None
+            w = self.final_conv.weight.reshape(self.final_conv.out_channels, -1)
+            x, part = gcr(dec.basic_module.SingleConv2, x, part, x_link=l12, out_link=low_link,
+                          fin=(w, self.final_conv.bias, stash) if fin and _FIN_FWD else None)
         w = self.final_conv.weight.reshape(self.final_conv.out_channels, -1)
         if n_dec and fin:
-            x = _FinConvFn.apply(x, w, self.final_conv.bias, low_link)
+            x = _FinConvFn.apply(x, w, self.final_conv.bias, low_link, stash)
         else:
             # 2 M voxels x 32 channels: the weight gradient is a 32 x 32 GEMM with K = 2 M (hipBLASLt: one 2.6 ms kernel) -> split-K
             x = _TallLinear.apply(x, w, self.final_conv.bias) if x.numel() // x.shape[-1] >= 4096 else F.linear(x, w, self.final_conv.bias)

@@ -1327,6 +1327,19 @@ def conv3d_gcr_final(x, ss, packed_w_f16x3, final_packed, final_bias):
     return out
 
 
+def conv3d_gcr_final_keep(x, ss, packed_w_f16x3, final_packed, final_bias):
+    """As conv3d_gcr_final, returning (y, out): y = relu(conv3x3x3(x * scale + shift)) is stored too
+    (vt_conv3d_gcr_f16x3_final_keep: the training forward of the last layer + final conv)."""
+    B, D, H, W, C1 = x.shape
+    y = torch.empty((B, D, H, W, 32), dtype=torch.float32, device=x.device)
+    out = torch.empty((B, D, H, W, 32), dtype=torch.float32, device=x.device)
+    check(_lib.load().vt_conv3d_gcr_f16x3_final_keep(dev_ptr(x, "x"), C1, None, 0, B, D, H, W, dev_ptr(ss, "scale_shift"),
+                                                     dev_ptr(packed_w_f16x3, "packed_w"), 32, dev_ptr(final_packed, "final_packed"),
+                                                     dev_ptr(_c(final_bias), "final_bias"), dev_ptr(out, "out"), dev_ptr(y, "y_keep"),
+                                                     stream_ptr()), "vt_conv3d_gcr_f16x3_final_keep")
+    return y, out
+
+
 def conv3d_skip_covers(x, Cout):
     """Does the persistent split-f16 kernel (the one that takes block flags) run a plain layer of this shape?"""
     B, D, H, W, C = x.shape
