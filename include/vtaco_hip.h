@@ -762,6 +762,15 @@ size_t vt_conv3d_wgrad_f16x3_workspace_bytes(int B, int D, int H, int W, int Cin
 int vt_conv3d_wgrad_f16x3(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
                           const float *scale_shift, const float *g, int Cout, const float *g_absmax,
                           void *workspace, size_t workspace_bytes, float *dw, void *stream);
+/* The same dW for a decoder-entry layer [skip | nearest-upsample(low)] (reference: src/encoder/unet3d.py:283-293 under autograd):     */
+/* the skip channels as vt_conv3d_wgrad_f16x3; the upsampled channels per output parity class -- tap t of voxel 2 u + p reads the     */
+/* low-resolution voxel u + ((p + t) >> 1), so each class is a 2 x 2 x 2-tap weight gradient over the low-resolution grid (64          */
+/* products of N / 8 voxels instead of 27 of N), summed into the 27 taps by the reduction in a fixed order.  Sides in multiples of     */
+/* 16 (D: 4), channels of 32 (workspace_bytes returns 0 otherwise: use vt_conv3d_wgrad_f16x3).                                          */
+size_t vt_conv3d_wgrad_f16x3_up_workspace_bytes(int B, int D, int H, int W, int C1, int C2, int Cout);
+int vt_conv3d_wgrad_f16x3_up(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                             const float *scale_shift, const float *g, int Cout, const float *g_absmax,
+                             void *workspace, size_t workspace_bytes, float *dw, void *stream);
 /* The same dW for a layer whose input x [B,D,H,W,C] is EXACTLY zero over most of the volume -- the UNet3D's first layer on a scene's */
 /* mean grid (reference: src/encoder/pointnet.py:102-114 leaves >= 98.8 % of the grid zero; its gradient, src/conv_onet/training.py   */
 /* :757-894).  xn = x * scale + shift inside the volume, 0 outside, so dW = sum_v g[v] (x * scale)[v + tap] + shift * (sum of g over   */

@@ -227,8 +227,10 @@ def test_wgrad_f16x3_matches_f32_kernel():
     (power-of-two rescale from g_absmax); error at f32 accumulation-order level; bit-reproducible."""
     from vtaco_amd import ops
     g = torch.Generator().manual_seed(21)
+    # (concatenated inputs with sides in multiples of 16 take vt_conv3d_wgrad_f16x3_up: the upsampled channels per output parity class)
     for B, R, C1, C2, Cout, gs in ((1, 8, 32, 0, 32, 1.0), (2, 16, 32, 0, 64, 1e-6), (1, 16, 32, 64, 32, 1e-6), (2, 8, 64, 128, 64, 1e-3),
-                                   (1, 32, 32, 0, 32, 1e-6), (1, 64, 32, 0, 32, 1e-7)):
+                                   (1, 32, 32, 0, 32, 1e-6), (1, 64, 32, 0, 32, 1e-7), (2, 32, 32, 64, 32, 1e-6), (1, 16, 64, 128, 64, 1e-4),
+                                   (1, 64, 32, 64, 32, 1e-6)):
         x = torch.randn(B, R, R, R, C1, generator=g).to(DEV)
         low = torch.randn(B, R // 2, R // 2, R // 2, C2, generator=g).to(DEV) if C2 else None
         gamma = (1 + 0.2 * torch.randn(C1 + C2, generator=g)).to(DEV)

@@ -187,6 +187,8 @@ SIGNATURES = {
     "vt_conv3d_wgrad_f16x3": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _SZ, _VP, _VP]),
     "vt_conv1x1_bwd_workspace_bytes": (_SZ, []),
     "vt_conv1x1_bwd_masked": (_I, [_VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "vt_conv3d_wgrad_f16x3_up_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I, _I]),
+    "vt_conv3d_wgrad_f16x3_up": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _SZ, _VP, _VP]),
     "vt_conv3d_wgrad_f16x3_sparse_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "vt_conv3d_wgrad_f16x3_sparse": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _VP, _SZ, _VP, _VP]),
     "vt_conv3d_xstats_blocks": (_I, [_I, _I, _I, _I, _I, _I]),

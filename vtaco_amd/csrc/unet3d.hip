@@ -3714,6 +3714,7 @@ static_assert(2 * WH_LDS <= 160 * 1024, "two workgroups per CU");
 struct WgradHArgs {
     WgradArgs w;
     const float *g_absmax;      // device scalar max |g| (or null: no rescale)
+    int ss_cin;                 // channels per scene of scale_shift's rows when they are more than this launch's (0: its own Cin)
     const int *list;            // null: every tile.  Else [0] = n, [1 .. n] = the tiles to visit, ascending (wgrad_tile_list_kernel):
                                 // the staged input is then x * scale WITHOUT the shift (zero wherever x is), and the shift's share of dW
                                 // is the rank-one term the reduce kernel adds (vt_conv3d_wgrad_f16x3_sparse)
@@ -3836,7 +3837,7 @@ __device__ __forceinline__ void wgrad_h_wave(const WgradHArgs &ha, char *whl) {
         const int x0 = tx * 8, y0 = ty * 8, z0 = tz * WH_TZ;
         sc = f32x4{1.f, 1.f, 1.f, 1.f}; sh = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.c.scale_shift) {
-            const float *ss = a.c.scale_shift + ((size_t)b * Cin + chq) * 2;
+            const float *ss = a.c.scale_shift + ((size_t)b * (ha.ss_cin ? ha.ss_cin : Cin) + chq) * 2;
             sc = f32x4{ss[0], ss[2], ss[4], ss[6]};
             if (!LIST) sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
         }
@@ -3947,6 +3948,185 @@ conv3d_wgrad_h_kernel(WgradHArgs ha) {
     else if (wave == 1) wgrad_h_wave<1, LIST>(ha, whl);
     else if (wave == 2) wgrad_h_wave<2, LIST>(ha, whl);
     else wgrad_h_wave<3, LIST>(ha, whl);
+}
+
+// ---- weight gradient of a decoder-entry layer's UPSAMPLED channels, per output parity --------------------------------------
+// xn[v + t] of a nearest-upsampled channel is xl[(v + t) >> 1] (xl = the normalised low-resolution field, zero outside), so with
+// v = 2 u + p (p in {0,1}^3) the tap t reads xl[u + d], d = (p + t) >> 1 per axis: d in {-1, 0} for p = 0, {0, +1} for p = 1.
+//     dW[t] = sum_p C_p[(p + t) >> 1],   C_p[d] = sum_u g[2 u + p] (x) xl[u + d]
+// -- per parity class a 2 x 2 x 2-tap weight gradient over the LOW-resolution grid: 64 products of N / 8 voxels instead of 27 of N
+// (0.30 of the MFMAs).  The kernel is conv3d_wgrad_h_kernel on the coarse grid: blockIdx.z = the parity class, the output
+// gradient's tile gathered from the voxels of that class (x stride two), the halo of xl staged as there; wave w takes the rows
+// d_z = p_z - 1 + (w >> 1), d_y = p_y - 1 + (w & 1) and both d_x.  partial[chunk][class][pair][w * 2 + i][co][ci];
+// conv3d_wgrad_reduce_parity_kernel adds chunks and classes in order.
+template <int W>
+__device__ __forceinline__ void wgrad_hp_wave(const WgradHArgs &ha, char *whl) {
+    char *xh = whl, *xl = whl + WH_XPLANE, *gh = whl + 2 * WH_XPLANE, *gl = gh + WH_GPLANE;
+    const WgradArgs &a = ha.w;
+    const Src &s = a.c.s;
+    const int lane = threadIdx.x & 63;
+    const int Cin = s.C1 + s.C2, ncib = s.C2 / 32, nco = a.c.Cout / 32;
+    const int cob = blockIdx.y / ncib, cib = blockIdx.y % ncib;
+    const int par = blockIdx.z, pz = par >> 2, py = (par >> 1) & 1, px = par & 1;
+    const float pre = pow2_scale_for(ha.g_absmax);
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const int q = threadIdx.x & 7, chq = cib * 32 + q * 4;                 // channel quad among the low channels
+    const int D2 = s.D >> 1, H2 = s.H >> 1, W2 = s.W >> 1;
+    const int tiles_per_scene = a.c.tiles_x * a.c.tiles_y * a.c.tiles_z;   // coarse tiles
+    f32x4 px0[WH_XITERS], px1[WH_XITERS], pg0[WH_GITERS], pg1[WH_GITERS], sc, sh;
+    unsigned inmask = 0;
+    auto fetch = [&](int tile) {
+        const int b = tile / tiles_per_scene;
+        int t = tile - b * tiles_per_scene;
+        const int tx = t % a.c.tiles_x; t /= a.c.tiles_x;
+        const int ty = t % a.c.tiles_y, tz = t / a.c.tiles_y;
+        const int x0 = tx * 8, y0 = ty * 8, z0 = tz * WH_TZ;               // coarse
+        {
+            const float *ss = a.c.scale_shift + ((size_t)b * Cin + s.C1 + chq) * 2;
+            sc = f32x4{ss[0], ss[2], ss[4], ss[6]}; sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
+        }
+        inmask = 0;
+#pragma unroll
+        for (int it = 0; it < WH_XITERS; ++it) {
+            const int id = min((int)threadIdx.x + it * WH_THREADS, WH_XITEMS - 1);
+            const int rp = id >> 3, p = rp % 5, row = rp / 5, yy = row % 10, zz = row / 10;
+            const int gx = x0 - 1 + 2 * p, gy = y0 - 1 + yy, gz = z0 - 1 + zz;
+            const bool rowin = (unsigned)gy < (unsigned)H2 && (unsigned)gz < (unsigned)D2;
+            if (rowin && gx >= 0) inmask |= 1u << (2 * it);
+            if (rowin && gx + 1 < W2) inmask |= 2u << (2 * it);
+            const int cz = min(max(gz, 0), D2 - 1), cy = min(max(gy, 0), H2 - 1), cx0 = max(gx, 0), cx1 = min(gx + 1, W2 - 1);
+            const unsigned voff0 = (unsigned)(((b * D2 + cz) * H2 + cy) * W2 + cx0) * (unsigned)s.C2 + (unsigned)chq;
+            const unsigned voff1 = voff0 + (unsigned)(cx1 - cx0) * (unsigned)s.C2;
+            px0[it] = *reinterpret_cast<const f32x4 *>(s.low + voff0);
+            px1[it] = *reinterpret_cast<const f32x4 *>(s.low + voff1);
+        }
+#pragma unroll
+        for (int it = 0; it < WH_GITERS; ++it) {
+            const int id = threadIdx.x + it * WH_THREADS;
+            const int rp = id >> 3, p = rp & 3, row = rp >> 2, y = row & 7, z = row >> 3;
+            // the class's voxels: fine coordinate 2 * coarse + parity
+            const unsigned goff = (unsigned)(((b * s.D + 2 * (z0 + z) + pz) * s.H + 2 * (y0 + y) + py) * s.W + 2 * (x0 + 2 * p) + px) * (unsigned)a.c.Cout
+                                  + (unsigned)(cob * 32 + q * 4);
+            pg0[it] = *reinterpret_cast<const f32x4 *>(a.g + goff);
+            pg1[it] = *reinterpret_cast<const f32x4 *>(a.g + goff + 2u * (unsigned)a.c.Cout);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int it = 0; it < WH_XITERS; ++it) {
+            const int id = threadIdx.x + it * WH_THREADS;
+            if (id >= WH_XITEMS) continue;
+            const int rp = id >> 3, p = rp % 5, row = rp / 5;
+            const bool in0 = inmask >> (2 * it) & 1u, in1 = inmask >> (2 * it + 1) & 1u;
+            const int off = (q * 4) * WH_XCH + row * WH_ROWB + p * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned hi, lo;
+                split_pair_h(in0 ? fmaf(px0[it][c], sc[c], sh[c]) : 0.0f, in1 ? fmaf(px1[it][c], sc[c], sh[c]) : 0.0f, hi, lo);
+                *reinterpret_cast<unsigned *>(xh + off + c * WH_XCH) = hi;
+                *reinterpret_cast<unsigned *>(xl + off + c * WH_XCH) = lo;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < WH_GITERS; ++it) {
+            const int id = threadIdx.x + it * WH_THREADS;
+            const int rp = id >> 3, p = rp & 3, row = rp >> 2;
+            const int off = (q * 4) * WH_GCH + row * 16 + p * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned hi, lo;
+                split_pair_h(pg0[it][c] * pre, pg1[it][c] * pre, hi, lo);
+                *reinterpret_cast<unsigned *>(gh + off + c * WH_GCH) = hi;
+                *reinterpret_cast<unsigned *>(gl + off + c * WH_GCH) = lo;
+            }
+        }
+    };
+    const int dz = pz - 1 + (W >> 1), dy = py - 1 + (W & 1);
+    const int ch = lane & 31, kg = lane >> 5;
+    auto ksteps = [&]() {
+#pragma unroll 1
+        for (int ks = 0; ks < WH_TZ * 4; ++ks) {
+            const int z = ks >> 2, y = (ks & 3) * 2 + kg;
+            const int goff = ch * WH_GCH + (z * 8 + y) * 16;
+            const f16x8 ah = *reinterpret_cast<const f16x8 *>(gh + goff), al = *reinterpret_cast<const f16x8 *>(gl + goff);
+            const int xoff = ch * WH_XCH + ((z + dz + 1) * 10 + (y + dy + 1)) * WH_ROWB;
+            // the row's ten voxels as five dwords (hi and lo planes); windows: d_x = -1 dwords 0-3, d_x = 0 the byte-aligned middle,
+            // d_x = +1 dwords 1-4
+            const u32x2 a0 = *reinterpret_cast<const u32x2 *>(xh + xoff), a1 = *reinterpret_cast<const u32x2 *>(xh + xoff + 8);
+            const u32x2 b0 = *reinterpret_cast<const u32x2 *>(xl + xoff), b1 = *reinterpret_cast<const u32x2 *>(xl + xoff + 8);
+            const unsigned a4 = *reinterpret_cast<const unsigned *>(xh + xoff + 16), b4 = *reinterpret_cast<const unsigned *>(xl + xoff + 16);
+            const u32x4 mh = u32x4{__builtin_amdgcn_alignbyte(a0.y, a0.x, 2), __builtin_amdgcn_alignbyte(a1.x, a0.y, 2),
+                                   __builtin_amdgcn_alignbyte(a1.y, a1.x, 2), __builtin_amdgcn_alignbyte(a4, a1.y, 2)};
+            const u32x4 ml = u32x4{__builtin_amdgcn_alignbyte(b0.y, b0.x, 2), __builtin_amdgcn_alignbyte(b1.x, b0.y, 2),
+                                   __builtin_amdgcn_alignbyte(b1.y, b1.x, 2), __builtin_amdgcn_alignbyte(b4, b1.y, 2)};
+            const u32x4 eh = px ? u32x4{a0.y, a1.x, a1.y, a4} : u32x4{a0.x, a0.y, a1.x, a1.y};       // the class's other window
+            const u32x4 el = px ? u32x4{b0.y, b1.x, b1.y, b4} : u32x4{b0.x, b0.y, b1.x, b1.y};
+            // accumulator 0: d_x = p_x - 1, accumulator 1: d_x = p_x
+            const f16x8 w0h = __builtin_bit_cast(f16x8, px ? mh : eh), w0l = __builtin_bit_cast(f16x8, px ? ml : el);
+            const f16x8 w1h = __builtin_bit_cast(f16x8, px ? eh : mh), w1l = __builtin_bit_cast(f16x8, px ? el : ml);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w0h, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w1h, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0l, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1l, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0h, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1h, acc[1], 0, 0, 0);
+        }
+    };
+    if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+        ksteps();
+    }
+    // partial[chunk][class][pair][W * 2 + i][co][ci]: lane (ci, half kk) register r = co chan_of(r, kk)
+    float *dst = a.partial + ((((size_t)blockIdx.x * 8 + par) * (nco * ncib) + blockIdx.y) * 8 + W * 2) * 1024;
+    const int i = lane & 31, kk = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(size_t)t * 1024 + chan_of(r, kk) * 32 + i] = acc[t][r];
+}
+
+__global__ void __launch_bounds__(WH_THREADS, VT_WH_WPS)
+conv3d_wgrad_hp_kernel(WgradHArgs ha) {
+    extern __shared__ __attribute__((aligned(16))) char whl[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == 0) wgrad_hp_wave<0>(ha, whl);
+    else if (wave == 1) wgrad_hp_wave<1>(ha, whl);
+    else if (wave == 2) wgrad_hp_wave<2>(ha, whl);
+    else wgrad_hp_wave<3>(ha, whl);
+}
+
+// dW[co][C1 + ci][tap] = (sum over chunks and parity classes, in that order, of the class's product for d = (p + t) >> 1) / scale:
+// one thread per (co, ci, tap) of a (cout block, low cin block) pair
+__global__ void __launch_bounds__(256)
+conv3d_wgrad_reduce_parity_kernel(const float *partial, int chunks, int Cout, int C1, int C2, const float *g_absmax, float *dw) {
+    const int nco = Cout / 32, ncib = C2 / 32, npairs = nco * ncib;
+    const size_t total = (size_t)Cout * C2 * 27;
+    const float post = 1.0f / pow2_scale_for(g_absmax);
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int ci = (int)(e & 31), co = (int)((e >> 5) & 31);
+        size_t r = e >> 10;
+        const int tap = (int)(r % 27); r /= 27;
+        const int pair = (int)r, cob = pair / ncib, cib = pair % ncib;
+        const int tz = tap / 9 - 1, ty = (tap / 3) % 3 - 1, tx = tap % 3 - 1;
+        float sum = 0.0f;
+        for (int c = 0; c < chunks; ++c)
+#pragma unroll
+            for (int par = 0; par < 8; ++par) {
+                const int pz = par >> 2, py = (par >> 1) & 1, px = par & 1;
+                // row index per axis: d - (p - 1) with d = (p + t) >> 1 (arithmetic)
+                const int rz = ((pz + tz) >> 1) - pz + 1, ry = ((py + ty) >> 1) - py + 1, rx = ((px + tx) >> 1) - px + 1;
+                sum += partial[((((size_t)c * 8 + par) * npairs + pair) * 8 + (rz * 2 + ry) * 2 + rx) * 1024 + co * 32 + ci];
+            }
+        dw[((size_t)(cob * 32 + co) * (C1 + C2) + C1 + cib * 32 + ci) * 27 + tap] = sum * post;
+    }
 }
 
 // ---- weight gradient of a layer whose input is mostly EXACT zeros (the network's first layer on a scene's mean grid) -------------
@@ -4081,7 +4261,7 @@ wgrad_gsum_final_kernel(const float *P, int D, int Cout, float *S) {
 // above leaves out of its staged input
 __global__ void __launch_bounds__(256)
 conv3d_wgrad_reduce_scaled_kernel(const float *partial, int chunks, int Cout, int Cin, const float *g_absmax, float *dw,
-                                  const float *rank_s = nullptr, const float *scale_shift = nullptr, int B = 0) {
+                                  const float *rank_s = nullptr, const float *scale_shift = nullptr, int B = 0, int cin_stride = 0) {
     __shared__ float quarter[4][64];
     const int nco = Cout / 32, ncib = Cin / 32;
     const size_t total = (size_t)Cout * Cin * 27, per_chunk = (size_t)nco * ncib * 27 * 1024;
@@ -4112,7 +4292,7 @@ conv3d_wgrad_reduce_scaled_kernel(const float *partial, int chunks, int Cout, in
             if (rank_s)
                 for (int b = 0; b < B; ++b)
                     v = fmaf(scale_shift[((size_t)b * Cin + cib * 32 + ci) * 2 + 1], rank_s[((size_t)b * 27 + tap) * Cout + cob * 32 + co], v);
-            dw[((size_t)(cob * 32 + co) * Cin + cib * 32 + ci) * 27 + tap] = v;
+            dw[((size_t)(cob * 32 + co) * (cin_stride ? cin_stride : Cin) + cib * 32 + ci) * 27 + tap] = v;      // (cin_stride: the first Cin of a wider dW)
         }
         __syncthreads();
     }
@@ -4535,7 +4715,7 @@ int vt_conv3d_wgrad_f16x3(const float *skip, int C1, const float *low, int C2, i
     a.g = g; a.partial = (float *)workspace;
     a.ntiles = B * a.c.tiles_x * a.c.tiles_y * a.c.tiles_z;
     ha.g_absmax = g_absmax;
-    ha.list = nullptr;
+    ha.list = nullptr; ha.ss_cin = 0;
     const int pairs = (Cin / 32) * (Cout / 32), chunks = wgrad_h_chunks(B, D, H, W, pairs);
     bool attr = false;        // (vt_max_dyn_lds keeps the per-device record)
     if (!attr) {
@@ -4549,6 +4729,77 @@ int vt_conv3d_wgrad_f16x3(const float *skip, int C1, const float *low, int C2, i
     hipLaunchKernelGGL(conv3d_wgrad_reduce_scaled_kernel, dim3((unsigned)(total / 64 < 4096 ? total / 64 : 4096)), dim3(256), 0, st,
                        (const float *)workspace, chunks, Cout, Cin, g_absmax, dw);
     return vt_check(hipGetLastError(), "vt_conv3d_wgrad_f16x3");
+}
+
+// the weight gradient of a decoder-entry layer [skip | upsample(low)]: the skip channels on conv3d_wgrad_h_kernel, the upsampled ones
+// per output parity class on conv3d_wgrad_hp_kernel (workspace = [skip partials][parity partials])
+static int wgrad_hp_chunks(int B, int D, int H, int W, int pairs_l) {
+    const int ntiles = B * (W / 16) * (H / 16) * (D / (2 * WH_TZ));
+    int chunks = 512 / (pairs_l * 8);
+    if (chunks < 1) chunks = 1;
+    if (chunks > ntiles) chunks = ntiles;
+    return chunks;
+}
+
+static size_t wgrad_up_layout(int B, int D, int H, int W, int C1, int C2, int Cout, size_t *par_off) {
+    if (C1 <= 0 || C2 <= 0 || (C1 & 31) || (C2 & 31) || Cout <= 0 || (Cout & 31) || (D % (2 * WH_TZ)) || (H & 15) || (W & 15)) return 0;
+    const size_t dense = vt_conv3d_wgrad_f16x3_workspace_bytes(B, D, H, W, C1, Cout);
+    if (!dense || (size_t)B * D * H * W * (C1 + C2 > Cout ? C1 + C2 : Cout) >= ((size_t)1 << 32)) return 0;
+    const int pairs_l = (C2 / 32) * (Cout / 32);
+    const size_t off = (dense + 255) / 256 * 256;
+    if (par_off) *par_off = off;
+    return off + (size_t)wgrad_hp_chunks(B, D, H, W, pairs_l) * 8 * pairs_l * 8 * 1024 * sizeof(float);
+}
+
+size_t vt_conv3d_wgrad_f16x3_up_workspace_bytes(int B, int D, int H, int W, int C1, int C2, int Cout) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    return wgrad_up_layout(B, D, H, W, C1, C2, Cout, nullptr);
+}
+
+int vt_conv3d_wgrad_f16x3_up(const float *skip, int C1, const float *low, int C2, int B, int D, int H, int W,
+                             const float *scale_shift, const float *g, int Cout, const float *g_absmax,
+                             void *workspace, size_t workspace_bytes, float *dw, void *stream) {
+    WgradHArgs ha;
+    WgradArgs &a = ha.w;
+    a.c.s = Src{skip, low, C1, C2, D, H, W};
+    if (!low || !src_ok(a.c.s, B) || !g || !workspace || !dw || !scale_shift) return vt_fail(VT_ERR_INVALID, "vt_conv3d_wgrad_f16x3_up: bad argument");
+    size_t par_off;
+    const size_t need = wgrad_up_layout(B, D, H, W, C1, C2, Cout, &par_off);
+    if (!need) return vt_fail(VT_ERR_UNSUPPORTED, "vt_conv3d_wgrad_f16x3_up: shape not covered (sides in multiples of 16, channels of 32); use vt_conv3d_wgrad_f16x3");
+    if (workspace_bytes < need) return vt_fail(VT_ERR_WORKSPACE, "vt_conv3d_wgrad_f16x3_up: workspace too small");
+    hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_wgrad_h_kernel<false>), (int)WH_LDS);
+    if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_wgrad_hp_kernel), (int)WH_LDS);
+    if (e != hipSuccess) return vt_check(e, "vt_conv3d_wgrad_f16x3_up: hipFuncSetAttribute");
+    hipStream_t st = (hipStream_t)stream;
+    a.c.scale_shift = scale_shift; a.c.wp = nullptr; a.c.out = nullptr; a.c.part = nullptr; a.c.Cout = Cout; a.c.relu = 0;
+    a.c.TX = 8; a.c.TY = 8; a.c.TZ = WH_TZ;
+    a.g = g;
+    ha.g_absmax = g_absmax; ha.list = nullptr;
+    {   // the skip channels: the dense kernel over [skip] alone, its scale / shift rows taken from the wider table
+        a.c.s = Src{skip, nullptr, C1, 0, D, H, W};
+        a.c.tiles_x = W / 8; a.c.tiles_y = H / 8; a.c.tiles_z = D / WH_TZ;
+        a.ntiles = B * a.c.tiles_x * a.c.tiles_y * a.c.tiles_z;
+        a.partial = (float *)workspace;
+        ha.ss_cin = C1 + C2;
+        const int pairs = (C1 / 32) * (Cout / 32), chunks = wgrad_h_chunks(B, D, H, W, pairs);
+        hipLaunchKernelGGL(conv3d_wgrad_h_kernel<false>, dim3((unsigned)chunks, (unsigned)pairs), dim3(WH_THREADS), WH_LDS, st, ha);
+        const size_t total = (size_t)Cout * C1 * 27;
+        hipLaunchKernelGGL(conv3d_wgrad_reduce_scaled_kernel, dim3((unsigned)(total / 64 < 4096 ? total / 64 : 4096)), dim3(256), 0, st,
+                           (const float *)workspace, chunks, Cout, C1, g_absmax, dw, (const float *)nullptr, (const float *)nullptr, 0, C1 + C2);
+    }
+    {   // the upsampled channels, per parity class on the coarse grid
+        a.c.s = Src{skip, low, C1, C2, D, H, W};
+        a.c.tiles_x = W / 16; a.c.tiles_y = H / 16; a.c.tiles_z = D / (2 * WH_TZ);
+        a.ntiles = B * a.c.tiles_x * a.c.tiles_y * a.c.tiles_z;
+        a.partial = reinterpret_cast<float *>((char *)workspace + par_off);
+        ha.ss_cin = 0;
+        const int pairs_l = (C2 / 32) * (Cout / 32), chunks = wgrad_hp_chunks(B, D, H, W, pairs_l);
+        hipLaunchKernelGGL(conv3d_wgrad_hp_kernel, dim3((unsigned)chunks, (unsigned)pairs_l, 8u), dim3(WH_THREADS), WH_LDS, st, ha);
+        const size_t total = (size_t)Cout * C2 * 27;
+        hipLaunchKernelGGL(conv3d_wgrad_reduce_parity_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, st,
+                           (const float *)a.partial, chunks, Cout, C1, C2, g_absmax, dw);
+    }
+    return vt_check(hipGetLastError(), "vt_conv3d_wgrad_f16x3_up");
 }
 
 // the same weight gradient for an input that is exactly zero over most of the volume (see wgrad_tile_list_kernel): workspace =
@@ -4591,7 +4842,7 @@ int vt_conv3d_wgrad_f16x3_sparse(const float *x, int C, int B, int D, int H, int
     ha.g_absmax = g_absmax;
     int *list = reinterpret_cast<int *>((char *)workspace + list_off);
     float *P = reinterpret_cast<float *>((char *)workspace + p_off), *S = reinterpret_cast<float *>((char *)workspace + s_off);
-    ha.list = list;
+    ha.list = list; ha.ss_cin = 0;
     const int pairs = (C / 32) * (Cout / 32), chunks = wgrad_h_chunks(B, D, H, W, pairs);
     const hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&conv3d_wgrad_h_kernel<true>), (int)WH_LDS);
     if (e != hipSuccess) return vt_check(e, "vt_conv3d_wgrad_f16x3_sparse: hipFuncSetAttribute");

@@ -1509,6 +1509,9 @@ def conv1x1_bwd_masked(dout, y, w, want_dw=True, want_db=True):
     return g, gmax, dw, db
 
 
+_WGRAD_UP = os.environ.get("VTACO_UNET_WGRAD_UP", "1") != "0"       # A/B knob: decoder-entry weight gradients per parity class
+
+
 def conv3d_wgrad(x, low, ss, g, precision="f32", g_absmax=None):
     """dW [Cout,Cin,3,3,3] of the 3x3x3 conv over xn = [x | upsample(low)] * scale + shift (vt_conv3d_wgrad).
     ``precision="f16x3"``: vt_conv3d_wgrad_f16x3 where it covers the shape (split-half operands on the f16 matrix core;
@@ -1517,6 +1520,16 @@ def conv3d_wgrad(x, low, ss, g, precision="f32", g_absmax=None):
     B, D, H, W, C1 = x.shape
     C2 = low.shape[-1] if low is not None else 0
     Cout = g.shape[-1]
+    ubytes = (lib.vt_conv3d_wgrad_f16x3_up_workspace_bytes(B, D, H, W, C1, C2, Cout)
+              if precision == "f16x3" and low is not None and _WGRAD_UP else 0)
+    if ubytes:
+        # a decoder entry: the upsampled channels per output parity class (2 x 2 x 2 taps over the low-resolution grid)
+        ws = torch.empty(ubytes // 4, dtype=torch.float32, device=x.device)
+        dw = torch.empty((Cout, C1 + C2, 3, 3, 3), dtype=torch.float32, device=x.device)
+        check(lib.vt_conv3d_wgrad_f16x3_up(dev_ptr(x, "x"), C1, dev_ptr(low, "low"), C2, B, D, H, W, dev_ptr(ss, "scale_shift"),
+                                           dev_ptr(g, "g"), Cout, dev_ptr(g_absmax, "g_absmax"), ctypes.c_void_p(ws.data_ptr()), ubytes,
+                                           dev_ptr(dw, "dw"), stream_ptr()), "vt_conv3d_wgrad_f16x3_up")
+        return dw
     hbytes = lib.vt_conv3d_wgrad_f16x3_workspace_bytes(B, D, H, W, C1 + C2, Cout) if precision == "f16x3" else 0
     if hbytes:
         ws = torch.empty(hbytes // 4, dtype=torch.float32, device=x.device)
