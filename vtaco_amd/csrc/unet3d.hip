@@ -3955,7 +3955,7 @@ conv3d_wgrad_h_kernel(WgradHArgs ha) {
 // v = 2 u + p (p in {0,1}^3) the tap t reads xl[u + d], d = (p + t) >> 1 per axis: d in {-1, 0} for p = 0, {0, +1} for p = 1.
 //     dW[t] = sum_p C_p[(p + t) >> 1],   C_p[d] = sum_u g[2 u + p] (x) xl[u + d]
 // -- per parity class a 2 x 2 x 2-tap weight gradient over the LOW-resolution grid: 64 products of N / 8 voxels instead of 27 of N
-// (0.30 of the MFMAs).  The kernel is conv3d_wgrad_h_kernel on the coarse grid: blockIdx.z = the parity class, the output
+// (0.30 of the MFMAs).  The kernel is conv3d_wgrad_h_kernel on the coarse grid: blockIdx.z = (p_z, p_y), both p_x in turn, the output
 // gradient's tile gathered from the voxels of that class (x stride two), the halo of xl staged as there; wave w takes the rows
 // d_z = p_z - 1 + (w >> 1), d_y = p_y - 1 + (w & 1) and both d_x.  partial[chunk][class][pair][w * 2 + i][co][ci];
 // conv3d_wgrad_reduce_parity_kernel adds chunks and classes in order.
@@ -3967,11 +3967,12 @@ __device__ __forceinline__ void wgrad_hp_wave(const WgradHArgs &ha, char *whl) {
     const int lane = threadIdx.x & 63;
     const int Cin = s.C1 + s.C2, ncib = s.C2 / 32, nco = a.c.Cout / 32;
     const int cob = blockIdx.y / ncib, cib = blockIdx.y % ncib;
-    const int par = blockIdx.z, pz = par >> 2, py = (par >> 1) & 1, px = par & 1;
+    // a workgroup takes the two classes (p_z, p_y, 0) and (p_z, p_y, 1): they read the same halo rows of xl, staged once per tile
+    const int pz = blockIdx.z >> 1, py = blockIdx.z & 1;
     const float pre = pow2_scale_for(ha.g_absmax);
-    f32x16 acc[2];
+    f32x16 acc[4];                                                          // [p_x][d_x - (p_x - 1)]
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     const int q = threadIdx.x & 7, chq = cib * 32 + q * 4;                 // channel quad among the low channels
@@ -3979,12 +3980,16 @@ __device__ __forceinline__ void wgrad_hp_wave(const WgradHArgs &ha, char *whl) {
     const int tiles_per_scene = a.c.tiles_x * a.c.tiles_y * a.c.tiles_z;   // coarse tiles
     f32x4 px0[WH_XITERS], px1[WH_XITERS], pg0[WH_GITERS], pg1[WH_GITERS], sc, sh;
     unsigned inmask = 0;
-    auto fetch = [&](int tile) {
-        const int b = tile / tiles_per_scene;
+    auto origin = [&](int tile, int &b, int &x0, int &y0, int &z0) {
+        b = tile / tiles_per_scene;
         int t = tile - b * tiles_per_scene;
         const int tx = t % a.c.tiles_x; t /= a.c.tiles_x;
         const int ty = t % a.c.tiles_y, tz = t / a.c.tiles_y;
-        const int x0 = tx * 8, y0 = ty * 8, z0 = tz * WH_TZ;               // coarse
+        x0 = tx * 8; y0 = ty * 8; z0 = tz * WH_TZ;                          // coarse
+    };
+    auto fetch_x = [&](int tile) {
+        int b, x0, y0, z0;
+        origin(tile, b, x0, y0, z0);
         {
             const float *ss = a.c.scale_shift + ((size_t)b * Cin + s.C1 + chq) * 2;
             sc = f32x4{ss[0], ss[2], ss[4], ss[6]}; sh = f32x4{ss[1], ss[3], ss[5], ss[7]};
@@ -4004,6 +4009,10 @@ __device__ __forceinline__ void wgrad_hp_wave(const WgradHArgs &ha, char *whl) {
             px0[it] = *reinterpret_cast<const f32x4 *>(s.low + voff0);
             px1[it] = *reinterpret_cast<const f32x4 *>(s.low + voff1);
         }
+    };
+    auto fetch_g = [&](int tile, int px) {
+        int b, x0, y0, z0;
+        origin(tile, b, x0, y0, z0);
 #pragma unroll
         for (int it = 0; it < WH_GITERS; ++it) {
             const int id = threadIdx.x + it * WH_THREADS;
@@ -4015,7 +4024,7 @@ __device__ __forceinline__ void wgrad_hp_wave(const WgradHArgs &ha, char *whl) {
             pg1[it] = *reinterpret_cast<const f32x4 *>(a.g + goff + 2u * (unsigned)a.c.Cout);
         }
     };
-    auto commit = [&]() {
+    auto commit_x = [&]() {
 #pragma unroll
         for (int it = 0; it < WH_XITERS; ++it) {
             const int id = threadIdx.x + it * WH_THREADS;
@@ -4031,6 +4040,8 @@ __device__ __forceinline__ void wgrad_hp_wave(const WgradHArgs &ha, char *whl) {
                 *reinterpret_cast<unsigned *>(xl + off + c * WH_XCH) = lo;
             }
         }
+    };
+    auto commit_g = [&]() {
 #pragma unroll
         for (int it = 0; it < WH_GITERS; ++it) {
             const int id = threadIdx.x + it * WH_THREADS;
@@ -4047,7 +4058,8 @@ __device__ __forceinline__ void wgrad_hp_wave(const WgradHArgs &ha, char *whl) {
     };
     const int dz = pz - 1 + (W >> 1), dy = py - 1 + (W & 1);
     const int ch = lane & 31, kg = lane >> 5;
-    auto ksteps = [&]() {
+    auto ksteps = [&](auto pxc, f32x16 &c0, f32x16 &c1) {
+        constexpr int PX = decltype(pxc)::value;
 #pragma unroll 1
         for (int ks = 0; ks < WH_TZ * 4; ++ks) {
             const int z = ks >> 2, y = (ks & 3) * 2 + kg;
@@ -4063,34 +4075,44 @@ __device__ __forceinline__ void wgrad_hp_wave(const WgradHArgs &ha, char *whl) {
                                    __builtin_amdgcn_alignbyte(a1.y, a1.x, 2), __builtin_amdgcn_alignbyte(a4, a1.y, 2)};
             const u32x4 ml = u32x4{__builtin_amdgcn_alignbyte(b0.y, b0.x, 2), __builtin_amdgcn_alignbyte(b1.x, b0.y, 2),
                                    __builtin_amdgcn_alignbyte(b1.y, b1.x, 2), __builtin_amdgcn_alignbyte(b4, b1.y, 2)};
-            const u32x4 eh = px ? u32x4{a0.y, a1.x, a1.y, a4} : u32x4{a0.x, a0.y, a1.x, a1.y};       // the class's other window
-            const u32x4 el = px ? u32x4{b0.y, b1.x, b1.y, b4} : u32x4{b0.x, b0.y, b1.x, b1.y};
-            // accumulator 0: d_x = p_x - 1, accumulator 1: d_x = p_x
-            const f16x8 w0h = __builtin_bit_cast(f16x8, px ? mh : eh), w0l = __builtin_bit_cast(f16x8, px ? ml : el);
-            const f16x8 w1h = __builtin_bit_cast(f16x8, px ? eh : mh), w1l = __builtin_bit_cast(f16x8, px ? el : ml);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w0h, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w1h, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0l, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1l, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0h, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1h, acc[1], 0, 0, 0);
+            const u32x4 eh = PX ? u32x4{a0.y, a1.x, a1.y, a4} : u32x4{a0.x, a0.y, a1.x, a1.y};       // the class's other window
+            const u32x4 el = PX ? u32x4{b0.y, b1.x, b1.y, b4} : u32x4{b0.x, b0.y, b1.x, b1.y};
+            // c0: d_x = p_x - 1, c1: d_x = p_x
+            const f16x8 w0h = __builtin_bit_cast(f16x8, PX ? mh : eh), w0l = __builtin_bit_cast(f16x8, PX ? ml : el);
+            const f16x8 w1h = __builtin_bit_cast(f16x8, PX ? eh : mh), w1l = __builtin_bit_cast(f16x8, PX ? el : ml);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w0h, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w1h, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0l, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1l, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0h, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1h, c1, 0, 0, 0);
         }
     };
-    if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
+    if ((int)blockIdx.x < a.ntiles) { fetch_x(blockIdx.x); fetch_g(blockIdx.x, 0); }
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        __syncthreads();                                                   // the previous k-steps are done with the planes
+        commit_x();
+        commit_g();
         __syncthreads();
-        commit();
+        fetch_g(tile, 1);
+        ksteps(std::integral_constant<int, 0>{}, acc[0], acc[1]);
         __syncthreads();
-        if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
-        ksteps();
+        commit_g();
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.ntiles) { fetch_x(tile + gridDim.x); fetch_g(tile + gridDim.x, 0); }
+        ksteps(std::integral_constant<int, 1>{}, acc[2], acc[3]);
     }
     // partial[chunk][class][pair][W * 2 + i][co][ci]: lane (ci, half kk) register r = co chan_of(r, kk)
-    float *dst = a.partial + ((((size_t)blockIdx.x * 8 + par) * (nco * ncib) + blockIdx.y) * 8 + W * 2) * 1024;
     const int i = lane & 31, kk = lane >> 5;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int px = 0; px < 2; ++px) {
+        const int par = (int)blockIdx.z * 2 + px;
+        float *dst = a.partial + ((((size_t)blockIdx.x * 8 + par) * (nco * ncib) + blockIdx.y) * 8 + W * 2) * 1024;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[(size_t)t * 1024 + chan_of(r, kk) * 32 + i] = acc[t][r];
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(size_t)t * 1024 + chan_of(r, kk) * 32 + i] = acc[px * 2 + t][r];
+    }
 }
 
 __global__ void __launch_bounds__(WH_THREADS, VT_WH_WPS)
@@ -4735,7 +4757,7 @@ int vt_conv3d_wgrad_f16x3(const float *skip, int C1, const float *low, int C2, i
 // per output parity class on conv3d_wgrad_hp_kernel (workspace = [skip partials][parity partials])
 static int wgrad_hp_chunks(int B, int D, int H, int W, int pairs_l) {
     const int ntiles = B * (W / 16) * (H / 16) * (D / (2 * WH_TZ));
-    int chunks = 512 / (pairs_l * 8);
+    int chunks = 512 / (pairs_l * 4);                              // a workgroup takes two of the eight classes
     if (chunks < 1) chunks = 1;
     if (chunks > ntiles) chunks = ntiles;
     return chunks;
@@ -4794,7 +4816,7 @@ int vt_conv3d_wgrad_f16x3_up(const float *skip, int C1, const float *low, int C2
         a.partial = reinterpret_cast<float *>((char *)workspace + par_off);
         ha.ss_cin = 0;
         const int pairs_l = (C2 / 32) * (Cout / 32), chunks = wgrad_hp_chunks(B, D, H, W, pairs_l);
-        hipLaunchKernelGGL(conv3d_wgrad_hp_kernel, dim3((unsigned)chunks, (unsigned)pairs_l, 8u), dim3(WH_THREADS), WH_LDS, st, ha);
+        hipLaunchKernelGGL(conv3d_wgrad_hp_kernel, dim3((unsigned)chunks, (unsigned)pairs_l, 4u), dim3(WH_THREADS), WH_LDS, st, ha);
         const size_t total = (size_t)Cout * C2 * 27;
         hipLaunchKernelGGL(conv3d_wgrad_reduce_parity_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, st,
                            (const float *)a.partial, chunks, Cout, C1, C2, g_absmax, dw);
