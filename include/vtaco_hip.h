@@ -828,7 +828,7 @@ int vt_maxpool3d_cl_bwd_fork(const float *y, const float *dskip, const float *dp
 /*   sums the per-plane results).  vt_plane_scatter_mean_*: plane [B,C,R,R].          */
 /* MANO layer: replaces ManoLayer.forward (src/encoder/manolayer.py:160-364) for the  */
 /*   shipped configuration (axis-angle root + joints, use_pca False, hands_mean added, */
-/*   model betas, no translation, right hand).  vt_mano_pack lays the model out once:  */
+/*   model betas, no translation; right hand, or left with vt_mano_pack_side).  vt_mano_pack lays the model out once: */
 /*   v_template [778,3], shapedirs [778,3,10] + betas [10] (both may be NULL: betas 0), */
 /*   posedirs [778,3,135], j_regressor [16,778] dense, weights [778,16], hands_mean [45] */
 /*   -> blob[VT_MANO_BLOB_FLOATS].  vt_mano_fwd: pose [B,48] = root axis-angle + 45 joint */
@@ -844,6 +844,10 @@ int vt_plane_scatter_mean_bwd(const float *grad_plane, const int *idx, const int
                               int B, int T, int C, int R, float *grad_feat, void *stream);
 int vt_mano_pack(const float *v_template, const float *shapedirs, const float *betas, const float *posedirs,
                  const float *j_regressor, const float *weights, const float *hands_mean, float *blob, void *stream);
+/* the same with the hand's side: left != 0 marks a MANO_LEFT model, whose middle-finger tip is vertex 445 instead of 444            */
+/* (manolayer.py:327-330); the side travels in the blob, vt_mano_fwd / vt_mano_bwd read it there                                      */
+int vt_mano_pack_side(const float *v_template, const float *shapedirs, const float *betas, const float *posedirs,
+                      const float *j_regressor, const float *weights, const float *hands_mean, int left, float *blob, void *stream);
 int vt_mano_fwd(const float *pose, int B, const float *blob, int center_idx, float *verts, float *joints, void *stream);
 /* Backward of vt_mano_fwd (PyTorch autograd through manolayer.py:186-347 under loss_mano / loss_pc, training.py:59-60):   */
 /* dpose [B,48] from dverts [B,778,3] and djoints [B,21,3]; one workgroup per hand, the forward's intermediates recomputed,  */

@@ -560,13 +560,14 @@ def rodrigues(axisang):
 
 MANO_PARENTS = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14]        # three joints per finger off the wrist
 MANO_TIPS_RIGHT = [745, 317, 444, 556, 673]
+MANO_TIPS_LEFT = [745, 317, 445, 556, 673]            # manolayer.py:327-330: the left hand's middle-finger tip vertex
 MANO_JOINT_ORDER = [0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20]
 
 
-def mano_forward(model, pose, center_idx=9):
+def mano_forward(model, pose, center_idx=9, side="right"):
     """``ManoLayer.forward`` (src/encoder/manolayer.py:160-364) for the shipped configuration
     (axis-angle root + joints, use_pca False, flat_hand_mean False, betas = the model's zeros,
-    th_trans = 0, right hand).  ``model``: dict of f32 tensors v_template [778,3], shapedirs [778,3,10],
+    th_trans = 0; ``side`` picks the tip vertices, manolayer.py:327-330).  ``model``: dict of f32 tensors v_template [778,3], shapedirs [778,3,10],
     posedirs [778,3,135], J_regressor [16,778], weights [778,16], hands_mean [45], betas [10].
     pose [B,48] -> (verts [B,778,3], joints [B,21,3]) centred on joint ``center_idx``."""
     B = pose.shape[0]
@@ -593,7 +594,7 @@ def mano_forward(model, pose, center_idx=9):
     T = torch.einsum("vj,bjrc->bvrc", model["weights"], A)                                      # [B,778,4,4]
     vh = torch.cat([v_posed, torch.ones(B, v_posed.shape[1], 1, dtype=pose.dtype)], dim=2)
     verts = torch.einsum("bvrc,bvc->bvr", T, vh)[:, :, :3]
-    jtr = torch.cat([G[:, :, :3, 3], verts[:, MANO_TIPS_RIGHT]], dim=1)[:, MANO_JOINT_ORDER]
+    jtr = torch.cat([G[:, :, :3, 3], verts[:, MANO_TIPS_RIGHT if side == "right" else MANO_TIPS_LEFT]], dim=1)[:, MANO_JOINT_ORDER]
     centre = jtr[:, center_idx:center_idx + 1] if center_idx is not None else torch.zeros(B, 1, 3, dtype=pose.dtype)
     return verts - centre, jtr - centre
 

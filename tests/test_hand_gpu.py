@@ -122,6 +122,36 @@ def test_mano_layer_kernel(center_idx, tmp_path):
     assert maxdiff(pj.grad, pr2.grad.float()) <= 2e-5 * float(pr2.grad.abs().max())
 
 
+@pytest.mark.parametrize("center_idx", [9, 12])
+def test_mano_layer_left_hand(center_idx, tmp_path):
+    """side='left' (manolayer.py:112-118, 327-330: MANO_LEFT.pkl, middle-finger tip = vertex 445) on the kernels: forward and backward
+    against the oracle with the left tips, centred on a chain joint and on the tip that differs (joint 12 of the output order)."""
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd.encoder.manolayer import ManoLayer
+    asset = synth_mano.make_asset(3)
+    synth_mano.write_pkl(asset, str(tmp_path), side="left")
+    dev = torch.device("cuda:0")
+    layer = ManoLayer(**dict(MANO_KW, mano_root=str(tmp_path), center_idx=center_idx, side="left")).to(dev)
+    model = synth_mano.as_model(asset)
+    pose = torch.randn(9, 48, generator=torch.Generator().manual_seed(12)) * 0.8
+    with torch.no_grad():
+        v, j = layer(pose.to(dev))
+    rv, rj = orc.mano_forward(model, pose, center_idx, side="left")
+    assert maxdiff(v, rv) <= 2e-6 and maxdiff(j, rj) <= 2e-6
+    rv_r, rj_r = orc.mano_forward(model, pose, center_idx, side="right")
+    assert maxdiff(rj, rj_r) > 1e-4                                  # the two tip tables do differ on this model
+    gen = torch.Generator().manual_seed(13)
+    wv, wj = torch.randn(9, 778, 3, generator=gen), torch.randn(9, 21, 3, generator=gen) * 5.0
+    pg = pose.clone().to(dev).requires_grad_(True)
+    vt, jt = layer(pg)
+    ((vt * wv.to(dev)).sum() + (jt * wj.to(dev)).sum()).backward()
+    pr = pose.clone().double().requires_grad_(True)
+    model64 = {k: (t.double() if torch.is_tensor(t) and t.is_floating_point() else t) for k, t in model.items()}
+    r64 = orc.mano_forward(model64, pr, center_idx, side="left")
+    ((r64[0] * wv.double()).sum() + (r64[1] * wj.double()).sum()).backward()
+    assert maxdiff(pg.grad, pr.grad.float()) <= 2e-5 * float(pr.grad.abs().max())
+
+
 def test_pca_pose_space_and_refused_arguments(tmp_path):
     from oracle import vtaco_oracle as orc
     from vtaco_amd._lib import VtError

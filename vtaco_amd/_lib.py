@@ -168,6 +168,7 @@ SIGNATURES = {
     "vt_plane_scatter_mean_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "vt_plane_scatter_mean_bwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "vt_mano_pack": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "vt_mano_pack_side": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP]),
     "vt_mano_fwd": (_I, [_VP, _I, _VP, _I, _VP, _VP, _VP]),
     "vt_mano_bwd": (_I, [_VP, _I, _VP, _I, _VP, _VP, _VP, _VP]),
     "vt_conv3d_packed_floats": (_SZ, [_I, _I]),

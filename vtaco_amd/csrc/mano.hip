@@ -25,12 +25,15 @@ constexpr int THREADS = 256;
 
 __constant__ int PARENT[NJ] = {-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14};
 __constant__ int TIPS[5] = {745, 317, 444, 556, 673};                                  // right hand (manolayer.py:328)
+// the left hand's middle-finger tip is vertex 445 (manolayer.py:330): the blob's unused mean slot 47 carries the side (0 right, 1 left)
+constexpr int OFF_SIDE = 47;
+__device__ __forceinline__ int tip_vertex(const float *blob, int i) { return TIPS[i] + ((i == 2 && blob[OFF_SIDE] != 0.0f) ? 1 : 0); }
 // output joint order (manolayer.py:339): entries < 16 index the chain joints, 16..20 the five tips
 __constant__ int JORDER[21] = {0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20};
 
 __global__ void __launch_bounds__(THREADS)
 mano_pack_kernel(const float *v_template, const float *shapedirs, const float *betas, const float *posedirs,
-                 const float *j_regressor, const float *weights, const float *hands_mean, float *blob) {
+                 const float *j_regressor, const float *weights, const float *hands_mean, float *blob, int left) {
     __shared__ float vs[NCP];
     const int tid = threadIdx.x;
     if (blockIdx.x == 0) {
@@ -49,7 +52,7 @@ mano_pack_kernel(const float *v_template, const float *shapedirs, const float *b
             float s = 0.0f;
             for (int v = 0; v < NV; ++v) s += j_regressor[(size_t)j * NV + v] * vs[3 * v + c];
             blob[OFF_J + tid] = s;
-            blob[OFF_MEAN + tid] = tid < 45 ? hands_mean[tid] : 0.0f;
+            blob[OFF_MEAN + tid] = tid < 45 ? hands_mean[tid] : (tid == OFF_SIDE && left ? 1.0f : 0.0f);
         }
         for (int e = tid; e < NV * NJ; e += THREADS) blob[OFF_W + e] = weights[e];
     }
@@ -185,7 +188,7 @@ mano_fwd_kernel(const float *pose, const float *blob, int center_idx, float *ver
     __shared__ float ctr_s[3];
     const int tid = threadIdx.x, b = blockIdx.x / MANO_SLICES, sl = blockIdx.x - b * MANO_SLICES;
     const int v0 = sl * MANO_VS, nv = min(MANO_VS, NV - v0);
-    const int csrc = center_idx >= 0 ? JORDER[center_idx] : -1, ctip = csrc >= NJ ? TIPS[csrc - NJ] : -1;     // the centre, if it is a tip vertex
+    const int csrc = center_idx >= 0 ? JORDER[center_idx] : -1, ctip = csrc >= NJ ? tip_vertex(blob, csrc - NJ) : -1;     // the centre, if it is a tip vertex
     mano_chain(pose + (size_t)b * 48, blob, rot, pm, Gc, G, nullptr);
     mano_blend(blob, pm, vp - 3 * v0, 3 * v0, 3 * (v0 + nv));
     if (ctip >= 0) mano_blend(blob, pm, vp + 3 * nv - 3 * ctip, 3 * ctip, 3 * ctip + 3);
@@ -219,7 +222,7 @@ mano_fwd_kernel(const float *pose, const float *blob, int center_idx, float *ver
         const int i = tid / 3, r = tid - 3 * i, src = JORDER[i];
         if (src < NJ) { if (sl == 0) joints[(size_t)b * 63 + tid] = Gc[src][4 * r + 3] - ctr[r]; }
         else {
-            const int tv = TIPS[src - NJ];
+            const int tv = tip_vertex(blob, src - NJ);
             if (tv >= v0 && tv < v0 + nv) joints[(size_t)b * 63 + tid] = vp[3 * (tv - v0) + r] - ctr[r];
         }
     }
@@ -278,7 +281,7 @@ mano_bwd_kernel(const float *pose, const float *blob, int center_idx, const floa
             const int src = JORDER[i];
             for (int r = 0; r < 3; ++r) {
                 if (src < NJ) dtg[src][r] += dj[i][r];
-                else dout[3 * TIPS[src - NJ] + r] += dj[i][r];
+                else dout[3 * tip_vertex(blob, src - NJ) + r] += dj[i][r];
             }
         }
     }
@@ -394,14 +397,19 @@ mano_bwd_kernel(const float *pose, const float *blob, int center_idx, const floa
 
 extern "C" {
 
-int vt_mano_pack(const float *v_template, const float *shapedirs, const float *betas, const float *posedirs,
-                 const float *j_regressor, const float *weights, const float *hands_mean, float *blob, void *stream) {
+int vt_mano_pack_side(const float *v_template, const float *shapedirs, const float *betas, const float *posedirs,
+                      const float *j_regressor, const float *weights, const float *hands_mean, int left, float *blob, void *stream) {
     if (!v_template || !posedirs || !j_regressor || !weights || !hands_mean || !blob)
         return vt_fail(VT_ERR_INVALID, "vt_mano_pack: null argument");
     if (betas && !shapedirs) return vt_fail(VT_ERR_INVALID, "vt_mano_pack: betas without shapedirs");
     hipLaunchKernelGGL(mano_pack_kernel, dim3(256), dim3(THREADS), 0, (hipStream_t)stream,
-                       v_template, shapedirs, betas, posedirs, j_regressor, weights, hands_mean, blob);
+                       v_template, shapedirs, betas, posedirs, j_regressor, weights, hands_mean, blob, left ? 1 : 0);
     return vt_check(hipGetLastError(), "vt_mano_pack");
+}
+
+int vt_mano_pack(const float *v_template, const float *shapedirs, const float *betas, const float *posedirs,
+                 const float *j_regressor, const float *weights, const float *hands_mean, float *blob, void *stream) {
+    return vt_mano_pack_side(v_template, shapedirs, betas, posedirs, j_regressor, weights, hands_mean, 0, blob, stream);
 }
 
 int vt_mano_fwd(const float *pose, int B, const float *blob, int center_idx, float *verts, float *joints, void *stream) {

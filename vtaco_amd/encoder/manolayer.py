@@ -159,7 +159,7 @@ class ManoLayer(nn.Module):
     def _packed(self):
         if self._blob is None or self._blob.device != self.th_posedirs.device:
             self._blob = ops.mano_pack(self.th_v_template[0], self.th_shapedirs, self.th_betas[0], self.th_posedirs,
-                                       self.th_J_regressor, self.th_weights, self.th_hands_mean[0])
+                                       self.th_J_regressor, self.th_weights, self.th_hands_mean[0], left=self.side == "left")
         return self._blob
 
     def _axis_angles(self, th_pose_coeffs):
@@ -206,9 +206,7 @@ class ManoLayer(nn.Module):
         if not th_pose_coeffs.is_cuda:
             raise VtError(f"ManoLayer: inputs must live on a HIP device (got {th_pose_coeffs.device})")
         pose48 = self._axis_angles(th_pose_coeffs.float())
-        if self.side != "right":
-            verts, jtr = self.forward_torch(pose48)                  # the kernels' tip table is the right hand's
-        elif torch.is_grad_enabled() and pose48.requires_grad:
+        if torch.is_grad_enabled() and pose48.requires_grad:
             if os.environ.get("VTACO_MANO_BACKWARD", "hip") == "host":
                 verts, jtr = self.forward_torch(pose48)              # A/B knob: host-PyTorch autograd
             else:

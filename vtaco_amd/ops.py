@@ -720,8 +720,8 @@ def plane_scatter_mean_bwd(grad_plane, pi, C):
 MANO_BLOB_FLOATS = 330240
 
 
-def mano_pack(v_template, shapedirs, betas, posedirs, j_regressor, weights, hands_mean):
-    """Model arrays (f32, on the device) -> the blob vt_mano_fwd reads (vt_mano_pack)."""
+def mano_pack(v_template, shapedirs, betas, posedirs, j_regressor, weights, hands_mean, left=False):
+    """Model arrays (f32, on the device) -> the blob vt_mano_fwd reads (vt_mano_pack_side; ``left``: a MANO_LEFT model)."""
     dev = v_template.device
     want = {"v_template": (v_template, (778, 3)), "posedirs": (posedirs, (778, 3, 135)),
             "j_regressor": (j_regressor, (16, 778)), "weights": (weights, (778, 16)), "hands_mean": (hands_mean, (45,))}
@@ -733,11 +733,11 @@ def mano_pack(v_template, shapedirs, betas, posedirs, j_regressor, weights, hand
             raise _lib.VtError(f"mano_pack: {name} has shape {tuple(t.shape)}, expected {shape}")
         arrs[name] = _c(t.float())
     blob = torch.empty(MANO_BLOB_FLOATS, dtype=torch.float32, device=dev)
-    check(_lib.load().vt_mano_pack(dev_ptr(arrs["v_template"], "v_template"), dev_ptr(arrs.get("shapedirs"), "shapedirs"),
-                                   dev_ptr(arrs.get("betas"), "betas"), dev_ptr(arrs["posedirs"], "posedirs"),
-                                   dev_ptr(arrs["j_regressor"], "j_regressor"), dev_ptr(arrs["weights"], "weights"),
-                                   dev_ptr(arrs["hands_mean"], "hands_mean"), dev_ptr(blob, "blob"), stream_ptr()),
-          "vt_mano_pack")
+    check(_lib.load().vt_mano_pack_side(dev_ptr(arrs["v_template"], "v_template"), dev_ptr(arrs.get("shapedirs"), "shapedirs"),
+                                        dev_ptr(arrs.get("betas"), "betas"), dev_ptr(arrs["posedirs"], "posedirs"),
+                                        dev_ptr(arrs["j_regressor"], "j_regressor"), dev_ptr(arrs["weights"], "weights"),
+                                        dev_ptr(arrs["hands_mean"], "hands_mean"), int(bool(left)), dev_ptr(blob, "blob"), stream_ptr()),
+          "vt_mano_pack_side")
     return blob
 
 
