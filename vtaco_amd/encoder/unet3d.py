@@ -247,10 +247,13 @@ class _PoolForkFn(torch.autograd.Function):
     def forward(ctx, y, link):
         ctx.save_for_backward(y)
         ctx.link = link
-        return y.view_as(y), ops.maxpool3d_cl(y)
+        # (the pooled tensor's GroupNorm partial sums from the same pass: what channel_stats(pooled) would leave, bit for bit)
+        pooled, (part, _) = ops.maxpool3d_cl_stats(y)
+        ctx.mark_non_differentiable(part)
+        return y.view_as(y), pooled, part
 
     @staticmethod
-    def backward(ctx, dskip, dpooled):
+    def backward(ctx, dskip, dpooled, _dpart):
         (y,) = ctx.saved_tensors
         if dskip is None or dpooled is None:        # one branch unused: the plain forms
             dx = ops.maxpool3d_cl_bwd(y, dpooled) if dpooled is not None else dskip
@@ -508,7 +511,9 @@ class UNet3D(nn.Module):
         for i, enc in enumerate(self.encoders):
             if i > 0:
                 x = pooled if pooled is not None else _MaxPoolFn.apply(x)
-            if i > 0 or part is None:
+            if pooled is not None:
+                part = pooled_part
+            elif i > 0 or part is None:
                 part = stats(x)
             l12 = link()
             x, part = gcr(enc.basic_module.SingleConv1, x, part, flags=tile_flags if i == 0 else None, out_link=l12)
@@ -520,7 +525,7 @@ class UNet3D(nn.Module):
             low_link = out_link if last else None
             pooled = None
             if not last and _MASK_FUSE:
-                x, pooled = _PoolForkFn.apply(x, out_link)
+                x, pooled, pooled_part = _PoolForkFn.apply(x, out_link)
             skips.append((x, part))
         n_dec = len(self.decoders)
         for k, (dec, (skip, skip_part)) in enumerate(zip(self.decoders, skips[-2::-1])):
