@@ -393,3 +393,30 @@ def test_wide_decoder_precision_routing_and_encoder_skip_switch(monkeypatch):
     assert not encoder_dict['pointnet_local_pool'](**kw).skip_empty
     for R in (12, 4, 136):                                         # not a multiple of 8 / below a block / beyond the flags' LDS table
         assert ops.voxel_tile_flags(SimpleNamespace(R=R, B=1, T=1, idx=None)) is None
+
+
+def test_tactile_resnet_over_all_scenes_at_once_equals_the_per_scene_loop():
+    """TactileResNet.forward_scenes (one pass over S x F images, every BatchNorm with the statistics of each scene's images alone) against
+    the reference's loop over the scenes (models/__init__.py:115-136): outputs, parameter gradients and the running statistics after
+    the S sequential updates; eval mode too."""
+    import copy
+    from vtaco_amd.layers import Resnet18
+    torch.manual_seed(5)
+    net = Resnet18(8).train()
+    ref = copy.deepcopy(net)
+    imgs = torch.rand(3, 2, 3, 64, 48)
+    a = net.forward_scenes(imgs)
+    b = torch.cat([ref(imgs[s]).reshape(1, 2, -1) for s in range(3)])
+    assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+    w = torch.randn(a.shape, generator=torch.Generator().manual_seed(6))
+    (a * w).sum().backward()
+    (b * w).sum().backward()
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert float((p.grad - q.grad).abs().max()) <= 2e-5 * max(1e-6, float(q.grad.abs().max()))
+    for (n1, p), (_, q) in zip(net.named_buffers(), ref.named_buffers()):
+        assert float((p.float() - q.float()).abs().max()) <= 2e-6 * max(1.0, float(q.float().abs().max())), n1
+    net.eval(); ref.eval()
+    with torch.no_grad():
+        e = net.forward_scenes(imgs)
+        f = torch.cat([ref(imgs[s]).reshape(1, 2, -1) for s in range(3)])
+    assert float((e - f).abs().max()) <= 2e-6 * max(1.0, float(f.abs().max()))

@@ -1,6 +1,8 @@
 """Model container (drop-in for reference src/conv_onet/models/__init__.py:15-197)."""
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import distributions as dist
 from torch import nn
@@ -9,6 +11,9 @@ from . import decoder
 
 # same registry names as the reference (models/__init__.py:7-12); the crop / PointConv
 # baselines are out of scope
+# A/B knob: "0" keeps the reference's per-scene loop over the tactile feature encoder (one pass over all scenes' images otherwise)
+_SCENE_BATCH = os.environ.get("VTACO_TACTILE_SCENE_BATCH", "1") != "0"
+
 decoder_dict = {
     'simple_local': decoder.LocalDecoder,
     'attention_local': decoder.AttentionDecoder,
@@ -51,6 +56,8 @@ class ConvolutionalOccupancyNetwork(nn.Module):
         if self.encoder_img is None:
             return torch.empty(imgs.size(0), 0)
         B, Fn = imgs.shape[:2]
+        if B > 1 and _SCENE_BATCH and hasattr(self.encoder_img, "forward_scenes"):
+            return self.encoder_img.forward_scenes(imgs)             # the same values from one pass over the B * Fn images
         return torch.cat([self.encoder_img(imgs[b]).reshape(1, Fn, -1) for b in range(B)], dim=0)
 
     def encode_t2d(self, inputs, imgs):

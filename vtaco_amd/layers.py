@@ -137,6 +137,33 @@ class TactileUNet(nn.Module):
         return torch.sigmoid(self.conv_final(x)) * 1
 
 
+def _bn_scenes(bn, x, scenes):
+    """``bn(x)`` for a batch of ``scenes`` groups of images ordered image-major (image f of scene b at row f * scenes + b), with the
+    statistics of every scene's images alone -- what the reference's per-scene calls compute (models/__init__.py:115-136: train-mode
+    BatchNorm sees the five images of ONE scene) -- from one pass: in that order [F * S, C, H, W] is [F, S * C, H, W], a batch of F
+    images with S * C channels.  The running statistics move as the S calls in scene order would move them."""
+    if scenes <= 1 or not bn.training:
+        return bn(x)                                                  # (eval mode: the running statistics, whatever the order)
+    N, C, H, W = x.shape
+    xv = x.contiguous().view(N // scenes, scenes * C, H, W)
+    w = bn.weight.repeat(scenes) if bn.weight is not None else None
+    b = bn.bias.repeat(scenes) if bn.bias is not None else None
+    if bn.track_running_stats and bn.running_mean is not None:
+        mean, var = x.new_zeros(scenes * C), x.new_ones(scenes * C)
+        y = F.batch_norm(xv, mean, var, w, b, True, 1.0, bn.eps)      # momentum 1: the buffers receive the batch statistics themselves
+        with torch.no_grad():
+            bn.num_batches_tracked += scenes
+            if bn.momentum is None:
+                raise NotImplementedError("_bn_scenes: cumulative-average BatchNorm (momentum=None) is not on this path")
+            m = float(bn.momentum)
+            coef = torch.tensor([m * (1.0 - m) ** (scenes - 1 - k) for k in range(scenes)], dtype=x.dtype, device=x.device)
+            bn.running_mean.mul_((1.0 - m) ** scenes).add_((coef[:, None] * mean.view(scenes, C)).sum(0))
+            bn.running_var.mul_((1.0 - m) ** scenes).add_((coef[:, None] * var.view(scenes, C)).sum(0))
+    else:
+        y = F.batch_norm(xv, None, None, w, b, True, 0.0, bn.eps)
+    return y.view(N, C, H, W)
+
+
 class _ResidualPair(nn.Module):
     """Two 3x3 conv + BatchNorm stages with an identity (or 1x1-projected) skip: the basic ResNet block
     (reference ``BasicBlock``, src/layers.py:52-82; parameter names conv1/bn1/conv2/bn2/downsample)."""
@@ -150,9 +177,14 @@ class _ResidualPair(nn.Module):
         self.bn2 = nn.BatchNorm2d(out_channel)
         self.downsample = downsample
 
-    def forward(self, x):
-        skip = x if self.downsample is None else self.downsample(x)
-        y = self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))
+    def forward(self, x, scenes=1):
+        if self.downsample is None:
+            skip = x
+        elif scenes > 1:
+            skip = _bn_scenes(self.downsample[1], self.downsample[0](x), scenes)
+        else:
+            skip = self.downsample(x)
+        y = _bn_scenes(self.bn2, self.conv2(F.relu(_bn_scenes(self.bn1, self.conv1(x), scenes))), scenes)
         return F.relu(y + skip)
 
 
@@ -188,10 +220,21 @@ class TactileResNet(nn.Module):
         blocks += [_ResidualPair(channel, channel) for _ in range(1, count)]
         return nn.Sequential(*blocks)
 
-    def forward(self, x):
-        x = self.maxpool(F.relu(self.bn1(self.conv1(x))))
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+    def forward(self, x, scenes=1):
+        x = self.maxpool(F.relu(_bn_scenes(self.bn1, self.conv1(x), scenes)))
+        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for block in stage:
+                x = block(x, scenes)
         return self.fc(self.linear(torch.flatten(self.avgpool(x), 1)))
+
+    def forward_scenes(self, imgs):
+        """imgs [S, F, 3, H, W] -> [S, F, num_classes]: the reference's loop ``cat([self(imgs[s]) for s])`` (models/__init__.py:115-136)
+        as ONE pass over the S * F images -- the convolutions at batch S * F (MIOpen at batch five runs at a third of that rate), every
+        BatchNorm with the statistics of each scene's images alone (_bn_scenes), so values, gradients and running statistics are the
+        loop's."""
+        S, Fn = imgs.shape[:2]
+        x = imgs.transpose(0, 1).reshape(Fn * S, *imgs.shape[2:])       # image-major
+        return self.forward(x, scenes=S).view(Fn, S, -1).transpose(0, 1)
 
 
 def Resnet18(num_classes=32):
