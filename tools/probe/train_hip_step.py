@@ -1,5 +1,5 @@
 """One steady-state step of the part of config 4's training step that runs on this repository's kernels (tools/train_hip_prof.py's
-trainer) under torch.profiler: kernels by device time, and the wall time of the step."""
+trainer) under torch.profiler: kernels by device time, and the wall time of the step.  ``full``: the whole config-4 step (with_img, encode_t2d)."""
 import sys, time
 import numpy as np
 import torch
@@ -9,7 +9,7 @@ from vtaco_amd.bench_util import build_train_case
 from vtaco_amd.conv_onet.training import Trainer
 dev = torch.device('cuda:0')
 model, trainer, batch, vf = build_train_case(dev, 0, scenes=8, pretrained_t2d=True, grad_sync=False)
-vis = Trainer(model, trainer.optimizer, device=dev, input_type="pointcloud", threshold=0.5, num_sample=2048, with_img=False, encode_t2d=False)
+vis = trainer if len(sys.argv) > 1 and sys.argv[1] == "full" else Trainer(model, trainer.optimizer, device=dev, input_type="pointcloud", threshold=0.5, num_sample=2048, with_img=False, encode_t2d=False)
 np.random.seed(0)
 for _ in range(4):
     vis.train_step(batch, vf)

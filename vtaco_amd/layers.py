@@ -156,7 +156,12 @@ def _bn_scenes(bn, x, scenes):
             if bn.momentum is None:
                 raise NotImplementedError("_bn_scenes: cumulative-average BatchNorm (momentum=None) is not on this path")
             m = float(bn.momentum)
-            coef = torch.tensor([m * (1.0 - m) ** (scenes - 1 - k) for k in range(scenes)], dtype=x.dtype, device=x.device)
+            # (kept on the module: a tensor made from host values would be a copy inside a stream capture)
+            key = (scenes, m, x.dtype, x.device)
+            cache = bn.__dict__.setdefault("_scene_coef", {})
+            coef = cache.get(key)
+            if coef is None:
+                coef = cache[key] = torch.tensor([m * (1.0 - m) ** (scenes - 1 - k) for k in range(scenes)], dtype=x.dtype, device=x.device)
             bn.running_mean.mul_((1.0 - m) ** scenes).add_((coef[:, None] * mean.view(scenes, C)).sum(0))
             bn.running_var.mul_((1.0 - m) ** scenes).add_((coef[:, None] * var.view(scenes, C)).sum(0))
     else:
