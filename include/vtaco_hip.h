@@ -484,6 +484,16 @@ int vt_mc_read_counts_end(int token, int *nverts_host, int *nfaces_host, double 
 /* vt_mc_read_counts_end takes, which then polls the slot for that sequence number instead of waiting for an event.                 */
 int vt_mc_count_notify(const float *vol, int n0, int n1, int n2, double level, int auto_level,
                        void *workspace, size_t workspace_bytes, void *stream, int *token);
+/* The same for a scene whose launches are CAPTURED in a hipGraph (a kernel argument -- vt_mc_count_notify's sequence number -- would  */
+/* be frozen into the graph): vt_mc_echo_slot makes a page-locked slot (outside the capture; it lives as long as the graph),            */
+/* vt_mc_count_echo is vt_mc_count whose scan kernel reads the number to echo from that slot, vt_mc_echo_arm sets a fresh number        */
+/* before every replay and vt_mc_echo_wait spins until the slot's header carries it, then returns the counts.  One replay in flight     */
+/* per slot.  (No copy command and no event between the scan and the emit kernels: 19 us of a 0.9 ms scene.)                             */
+int vt_mc_echo_slot(int *token);
+int vt_mc_count_echo(const float *vol, int n0, int n1, int n2, double level, int auto_level,
+                     void *workspace, size_t workspace_bytes, void *stream, int token);
+int vt_mc_echo_arm(int token);
+int vt_mc_echo_wait(int token, void *stream, int *nverts_host, int *nfaces_host, double *level_host);
 int vt_mc_emit(const float *vol, int n0, int n1, int n2, void *workspace,
                float *verts, int max_verts, int *faces, int max_faces,
                int rescale, float shift, float scale, void *stream);

@@ -21,6 +21,10 @@ import torch
 from .. import ops
 from .._lib import VtError
 
+# A/B knob: "0" reads a captured scene's marching-cubes counts through a copy + event behind the graph instead of the page-locked slot
+# the scan kernel writes (ops.mc_count_echo)
+_MC_ECHO = os.environ.get("VTACO_MC_ECHO", "1") != "0"
+
 Mesh = namedtuple("Mesh", ["vertices", "faces"])
 _tensor_version = operator.attrgetter("_version")
 
@@ -286,12 +290,25 @@ class Generator3D(object):
 
     def _scene_graph(self, shape, nx):
         """Encode + dense decode + marching-cubes classification of one (input shape, lattice size) as one graph."""
+        key = (tuple(shape), nx, self.decode_precision)
+        hit = getattr(self, "_graphs", {}).get(key)
+        # the counts of a replay arrive in a page-locked slot the scan kernel writes (no copy command between it and the emit kernels);
+        # the slot is made before the capture and belongs to this graph
+        if hit is not None and "echo" in hit:
+            echo = hit["echo"]
+        else:
+            try:
+                echo = ops.mc_echo_slot() if _MC_ECHO else None
+            except VtError:                                           # every slot taken (64 captured shapes): the copy + event form
+                echo = None
+
         def run(static_in):
             c = self.model.encode_inputs(static_in)
             vol = self.eval_lattice(c, nx).reshape(nx, nx, nx)
-            return vol, ops.mc_count(vol)
-        g = self._captured((tuple(shape), nx, self.decode_precision), [shape], run)
+            return vol, (ops.mc_count_echo(vol, None, echo) if echo is not None else ops.mc_count(vol))
+        g = self._captured(key, [shape], run)
         g["vol"], g["ws"] = g["out"]
+        g["echo"] = echo
         return g
 
     def _graphs_allowed(self):
@@ -342,8 +359,10 @@ class Generator3D(object):
         nx = self.resolution0 * 4
         g = self._scene_graph(inputs.shape, nx)
         g["in"][0].copy_(inputs.to(self.device), non_blocking=True)
+        if g.get("echo") is not None:
+            ops.mc_echo_arm(g["echo"])                               # the number this replay's scan kernel writes behind the counts
         g["graph"].replay()
-        verts, faces, _ = ops.mc_emit(g["vol"], g["ws"], rescale=(nx / 2, (1 + self.padding) / nx))
+        verts, faces, _ = ops.mc_emit(g["vol"], g["ws"], rescale=(nx / 2, (1 + self.padding) / nx), echo=g.get("echo"))
         return Mesh(verts, faces)
 
     @_range_guarded(collective=True)

@@ -470,12 +470,15 @@ mc_classify_kernel(const float *vol, McDims d, McWs ws, double level_in, int aut
 // walking its own 64 strided entries took 134 us there.)
 constexpr int SC_BATCH = 16;
 
-__global__ void __launch_bounds__(1024) mc_scan_kernel(McWs ws, unsigned nblk, McHeader *host_hdr, int host_seq) {
+__global__ void __launch_bounds__(1024) mc_scan_kernel(McWs ws, unsigned nblk, McHeader *host_hdr, int host_seq, const int *seq_src) {
     __shared__ uint2 wtot[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned rows = ((nblk + 1023) / 1024), seg = rows * 64;            // rows per wave, entries per wave
     const unsigned lo = (unsigned)w * seg;
     unsigned a = 0, b = 0;
+    // seq_src (captured scenes, vt_mc_count_echo): the number to write behind the counts is read from a page-locked word the host set
+    // before the replay -- a kernel argument would be frozen into the graph.  Requested here, used at the end of the kernel.
+    if (seq_src && threadIdx.x == 0) host_seq = __hip_atomic_load(seq_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (unsigned r0 = 0; r0 < rows; r0 += SC_BATCH) {
         uint2 v[SC_BATCH];
 #pragma unroll
@@ -735,7 +738,7 @@ size_t vt_mc_workspace_bytes(int n0, int n1, int n2) {
 }
 
 static int mc_count_impl(const float *vol, int n0, int n1, int n2, double level, int auto_level,
-                         void *workspace, size_t workspace_bytes, void *stream, McHeader *host_hdr, int host_seq) {
+                         void *workspace, size_t workspace_bytes, void *stream, McHeader *host_hdr, int host_seq, const int *seq_src = nullptr) {
     if (!vol || !workspace) return vt_fail(VT_ERR_INVALID, "vt_mc_count: null argument");
     McDims d; size_t off[8], total; unsigned nblk;
     if (!mc_layout(n0, n1, n2, d, off, total, nblk))
@@ -754,7 +757,7 @@ static int mc_count_impl(const float *vol, int n0, int n1, int n2, double level,
     }
     hipLaunchKernelGGL(mc_classify_kernel, dim3((nblk + CLS_CHUNKS - 1) / CLS_CHUNKS), dim3(CELLS_PER_BLOCK), 0, s,
                        vol, d, ws, level, auto_level, nblk, (int)g);
-    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, s, ws, nblk, host_hdr, host_seq);
+    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, s, ws, nblk, host_hdr, host_seq, seq_src);
     return vt_check(hipGetLastError(), "vt_mc_count");
 }
 
@@ -881,6 +884,71 @@ int vt_mc_read_counts_end(int token, int *nverts_host, int *nfaces_host, double 
         mc_slots[token].busy = false;                       // the token is spent either way
     }
     return e == hipSuccess ? 0 : vt_check(e, "vt_mc_read_counts_end");
+}
+
+// ---- the counts of a CAPTURED scene without a copy between the scan and the emit kernels ---------------------------------------
+// vt_mc_count_notify's sequence number is a kernel argument: frozen at capture.  Here the host owns a page-locked word per slot
+// (`want`), sets it to a fresh number before every replay (vt_mc_echo_arm), the scan kernel of the replay reads it and writes it
+// behind the counts into the slot's header, and vt_mc_echo_wait spins until the header carries that number.  The slot is made OUTSIDE
+// the capture (page-locked allocation) and lives as long as the graph; one replay in flight per slot.
+namespace {
+constexpr int MC_ECHO_SLOTS = 64;
+struct McEcho { McHeader *host; int *want; int nonce; bool made; };
+McEcho mc_echo[MC_ECHO_SLOTS];
+int mc_echo_made = 0;
+}  // namespace
+
+int vt_mc_echo_slot(int *token) {
+    if (!token) return vt_fail(VT_ERR_INVALID, "vt_mc_echo_slot: null argument");
+    std::lock_guard<std::mutex> lock(mc_slots_mutex);
+    if (mc_echo_made >= MC_ECHO_SLOTS) return vt_fail(VT_ERR_INVALID, "vt_mc_echo_slot: all 64 slots are taken (one per captured scene shape)");
+    McEcho &sl = mc_echo[mc_echo_made];
+    char *mem = nullptr;
+    const hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&mem), sizeof(McHeader) + 64, hipHostMallocDefault);
+    if (e != hipSuccess) return vt_check(e, "vt_mc_echo_slot: page-locked slot");
+    memset(mem, 0, sizeof(McHeader) + 64);
+    sl.host = reinterpret_cast<McHeader *>(mem);
+    sl.want = reinterpret_cast<int *>(mem + sizeof(McHeader));
+    sl.nonce = 0; sl.made = true;
+    *token = mc_echo_made++;
+    return 0;
+}
+
+int vt_mc_count_echo(const float *vol, int n0, int n1, int n2, double level, int auto_level,
+                     void *workspace, size_t workspace_bytes, void *stream, int token) {
+    if (token < 0 || token >= mc_echo_made) return vt_fail(VT_ERR_INVALID, "vt_mc_count_echo: bad token");
+    return mc_count_impl(vol, n0, n1, n2, level, auto_level, workspace, workspace_bytes, stream, mc_echo[token].host, 0, mc_echo[token].want);
+}
+
+int vt_mc_echo_arm(int token) {
+    if (token < 0 || token >= mc_echo_made) return vt_fail(VT_ERR_INVALID, "vt_mc_echo_arm: bad token");
+    McEcho &sl = mc_echo[token];
+    sl.nonce = sl.nonce == 0x7fffffff ? 1 : sl.nonce + 1;           // never 0: a fresh slot reads 0
+    __atomic_store_n(sl.want, sl.nonce, __ATOMIC_RELEASE);
+    return 0;
+}
+
+int vt_mc_echo_wait(int token, void *stream, int *nverts_host, int *nfaces_host, double *level_host) {
+    if (token < 0 || token >= mc_echo_made || !nverts_host || !nfaces_host) return vt_fail(VT_ERR_INVALID, "vt_mc_echo_wait: bad token or null argument");
+    McEcho &sl = mc_echo[token];
+    volatile int *seq = &sl.host->reserved[0];
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    hipError_t e = hipSuccess;
+    while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != sl.nonce) {
+        if ((++spins & 0xfffu) == 0) {
+            if (hipPeekAtLastError() != hipSuccess) { e = hipGetLastError(); break; }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                e = hipStreamSynchronize((hipStream_t)stream);          // a long backlog (or a paused process): wait for the stream itself
+                if (e == hipSuccess && __atomic_load_n(seq, __ATOMIC_ACQUIRE) != sl.nonce) e = hipErrorUnknown;
+                break;
+            }
+        }
+    }
+    if (e != hipSuccess) return vt_check(e, "vt_mc_echo_wait");
+    *nverts_host = sl.host->nverts; *nfaces_host = sl.host->nfaces;
+    if (level_host) *level_host = sl.host->level;
+    return 0;
 }
 
 int vt_mc_emit(const float *vol, int n0, int n1, int n2, void *workspace,

@@ -369,10 +369,35 @@ def mc_count_notify(vol, level=None):
     return ws, tok.value
 
 
+def mc_echo_slot():
+    """A page-locked slot for the counts of a CAPTURED scene (vt_mc_echo_slot): make it outside the capture, hand it to
+    ``mc_count_echo`` inside, ``mc_echo_arm`` it before every replay and pass it to ``mc_emit(echo=...)``."""
+    tok = ctypes.c_int()
+    check(_lib.load().vt_mc_echo_slot(ctypes.byref(tok)), "vt_mc_echo_slot")
+    return tok.value
+
+
+def mc_count_echo(vol, level, slot):
+    """``mc_count`` for graph capture whose scan kernel echoes the slot's current number behind the counts into the slot's page-locked
+    header (vt_mc_count_echo): the replayed scene needs no copy command between the count and the emit kernels."""
+    if vol.dim() != 3 or not vol.is_contiguous():
+        raise VtError("marching_cubes: volume must be a contiguous [n0,n1,n2] tensor")
+    ws, nbytes = _mc_workspace(vol)
+    n0, n1, n2 = vol.shape
+    check(_lib.load().vt_mc_count_echo(dev_ptr(vol, "vol"), n0, n1, n2, 0.0 if level is None else float(level), int(level is None),
+                                       ctypes.c_void_p(ws.data_ptr()), nbytes, stream_ptr(), int(slot)), "vt_mc_count_echo")
+    return ws
+
+
+def mc_echo_arm(slot):
+    """A fresh number into the slot (vt_mc_echo_arm): before every replay of the graph that holds ``mc_count_echo``."""
+    check(_lib.load().vt_mc_echo_arm(int(slot)), "vt_mc_echo_arm")
+
+
 _mc_guess = {}          # volume shape -> (vertex, face) capacity that covered the last extraction there
 
 
-def mc_emit(vol, ws, rescale=None, capacity=None, token=None):
+def mc_emit(vol, ws, rescale=None, capacity=None, token=None, echo=None):
     """Phase 2 (vt_mc_emit + vt_mc_read_counts).  With ``capacity=(V,F)`` nothing is read back
     (no stream sync; the counts stay in the workspace).  Otherwise the outputs are sized by the
     counts, which costs one host read: after the first extraction of a shape the emit kernels are
@@ -380,7 +405,7 @@ def mc_emit(vol, ws, rescale=None, capacity=None, token=None):
     the read is the only synchronisation of the call; if the surface outgrew the guess the emit is
     repeated at the exact size (the kernels never write past their capacity)."""
     lib = _lib.load()
-    if capacity is not None and token is not None:
+    if capacity is not None and (token is not None or echo is not None):
         raise VtError("mc_emit: a token (mc_count_notify) is handed back by reading the counts; with capacity= nothing is read -- "
                       "use mc_count for fixed-capacity extraction")
     n0, n1, n2 = vol.shape
@@ -404,13 +429,16 @@ def mc_emit(vol, ws, rescale=None, capacity=None, token=None):
     # the copy of the counts is queued FIRST (it needs the classify / scan launches only) and waited for by its own event, so
     # the speculative emit kernels run under that wait instead of in front of the copy
     tok = ctypes.c_int(-1 if token is None else token)
-    if token is None:
+    if token is None and echo is None:
         check(lib.vt_mc_read_counts_begin(wp, st, ctypes.byref(tok)), "vt_mc_read_counts_begin")
     nv, nf, lvl = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
     try:
         spec = emit(*guess) if guess is not None else None
     finally:                             # the token is handed back whatever the emit did (sixteen exist)
-        rc = lib.vt_mc_read_counts_end(tok.value, ctypes.byref(nv), ctypes.byref(nf), ctypes.byref(lvl))
+        if echo is not None:             # (a captured scene's slot, armed before the replay: the scan kernel echoes its number)
+            rc = lib.vt_mc_echo_wait(int(echo), st, ctypes.byref(nv), ctypes.byref(nf), ctypes.byref(lvl))
+        else:
+            rc = lib.vt_mc_read_counts_end(tok.value, ctypes.byref(nv), ctypes.byref(nf), ctypes.byref(lvl))
     check(rc, "vt_mc_read_counts_end")
     if nv.value == 0:
         raise RuntimeError("No surface found at the given iso value.")
