@@ -467,7 +467,9 @@ def train_step_section(dev, fx, rank, world, dist, steps=8, scenes=8):
            "points_per_scene": 2048, "parameters": n_param, "allreduce_bytes": 4 * sync.numel, "first_step_s": first_s,
            "t2d_pretrained": True,
            "workload": "Trainer(with_img, encode_t2d).train_step: shipped VTacO model (get_model) with the pretrained (frozen) t2d net, "
-                       "contact clouds from depth images, winding-number targets, Adam 1e-4; synthetic batch"}
+                       "contact clouds from depth images, winding-number targets, Adam 1e-4; synthetic batch; the tactile Resnet18 "
+                       "(host PyTorch / MIOpen) runs once over all scenes' images with every BatchNorm on each scene's statistics alone "
+                       "(= the reference's per-scene loop; VTACO_TACTILE_SCENE_BATCH=0 runs the loop)"}
     if world > 1:
         res["buckets"] = dict(sync.stats)
         # the all-reduce alone: the same buckets, nothing to overlap with
