@@ -3,7 +3,8 @@ Marching cubes against the C oracle on random shapes / fields / levels, the deco
 random (B, N, R) and lattices, the voxeliser against the oracle on random clouds, the fusion pipeline on ragged N, the
 UNet3D forward (both conv precisions) on small volumes, its first layer with the empty blocks skipped, its first two layers
 likewise inside vt_unet3d_fwd_skip at 64^3, LocalDecoder at random widths beyond 32 / 32 (exact and split-f16 kernels), the hand branch (plane ids / scatter, the PointNet MLP kernels,
-the MANO layer on random synthetic assets), the winding-number kernel on random triangle soups.  Prints a summary; exits 1 on a mismatch."""
+the MANO layer on random synthetic assets), the winding-number kernel on random triangle soups, the round-5 weight-gradient forms
+(per-parity, sparse first layer) and the final conv's fused backward.  Prints a summary; exits 1 on a mismatch."""
 import os
 import sys
 import time
@@ -342,7 +343,66 @@ def one_winding():
         fails.append(("winding", V, Fn, N, float(np.abs(got - ref).max())))
 
 
-counts.update({"fusion": 0, "unet3d": 0, "hand": 0, "winding": 0, "skip": 0, "skip2": 0, "wide": 0})
+def one_wgrad():
+    """The round-5 weight-gradient forms against the exact-f32 kernel on random shapes: a decoder-entry layer (upsampled channels per
+    output parity class), a first layer on a grid that is zero away from a cloud (listed tiles + the shift's rank-one share), and the
+    final 1x1x1 conv's fused backward against autograd in f64."""
+    g = torch.Generator().manual_seed(int(rng.randint(1 << 30)))
+    kind = int(rng.randint(3))
+    if kind == 0:
+        B, R = int(rng.randint(1, 3)), int(rng.choice([16, 32]))
+        C1, C2, Cout = 32 * int(rng.randint(1, 3)), 32 * int(rng.randint(1, 3)), 32 * int(rng.randint(1, 3))
+        x = torch.randn(B, R, R, R, C1, generator=g).to(DEV)
+        low = torch.randn(B, R // 2, R // 2, R // 2, C2, generator=g).to(DEV)
+        gamma, beta = (1 + 0.2 * torch.randn(C1 + C2, generator=g)).to(DEV), (0.2 * torch.randn(C1 + C2, generator=g)).to(DEV)
+        ss = ops.gn_scale_shift(ops.channel_stats(x), ops.channel_stats(low), C1, C2, B, R ** 3, gamma, beta, 8, 1e-5, DEV)
+        gs = float(10.0 ** rng.uniform(-7, 0))
+        gr = (torch.randn(B, R, R, R, Cout, generator=g) * gs).to(DEV)
+        ref = ops.conv3d_wgrad(x, low, ss, gr)
+        got = ops.conv3d_wgrad(x, low, ss, gr, precision="f16x3", g_absmax=gr.abs().max().reshape(1))
+        err, scale = float((got - ref).abs().max()), float(ref.abs().max())
+        if not err <= 2e-7 * (B * R ** 3) ** 0.5 * scale:
+            fails.append(("wgrad_up", B, R, C1, C2, Cout, err, scale))
+    elif kind == 1:
+        B, R, C, Cout = int(rng.randint(1, 3)), int(rng.choice([16, 32])), 32, 32 * int(rng.randint(1, 3))
+        n_pts = int(rng.randint(1, 200))
+        lo = float(rng.uniform(0, 0.6)); hi = float(rng.uniform(lo + 0.1, 1.0))
+        xyz = (torch.rand(B, n_pts, 3, generator=g) * (hi - lo) + lo).clamp(0, 0.999)
+        v = (xyz * R).long()
+        idx = (v[..., 0] + R * (v[..., 1] + R * v[..., 2]))
+        x = torch.zeros(B, R ** 3, C)
+        for b in range(B):
+            x[b, idx[b]] = torch.randn(n_pts, C, generator=g)
+        from types import SimpleNamespace
+        x = x.reshape(B, R, R, R, C).to(DEV)
+        flags = ops.voxel_tile_flags(SimpleNamespace(idx=idx.int().to(DEV).contiguous(), B=B, T=n_pts, R=R))
+        gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV), (0.3 * torch.randn(C, generator=g)).to(DEV)
+        ss = ops.gn_scale_shift(ops.channel_stats(x), None, C, 0, B, R ** 3, gamma, beta, 8, 1e-5, DEV)
+        gr = (torch.randn(B, R, R, R, Cout, generator=g) * float(10.0 ** rng.uniform(-6, 0))).to(DEV)
+        gmax = gr.abs().max().reshape(1)
+        ref = ops.conv3d_wgrad(x, None, ss, gr)
+        got = ops.conv3d_wgrad_sparse(x, ss, gr, flags, g_absmax=gmax)
+        err, scale = float((got - ref).abs().max()), float(ref.abs().max())
+        if got is None or not err <= 2e-5 * scale:
+            fails.append(("wgrad_sparse", B, R, Cout, n_pts, err, scale))
+    else:
+        n = int(rng.randint(1, 70000))
+        pre = torch.randn(n, 32, generator=g).to(DEV)
+        w = (torch.randn(32, 32, generator=g) * 0.2).to(DEV)
+        dout = (torch.randn(n, 32, generator=g) * float(10.0 ** rng.uniform(-7, 0))).to(DEV)
+        y = torch.relu(pre)
+        gg, gmax, dw, db = ops.conv1x1_bwd_masked(dout, y, w)
+        p64, w64 = pre.double().requires_grad_(True), w.double().requires_grad_(True)
+        b64 = torch.zeros(32, dtype=torch.float64, device=DEV, requires_grad=True)
+        torch.nn.functional.linear(torch.relu(p64), w64, b64).backward(dout.double())
+        e1 = float((gg.double() - p64.grad).abs().max()) / max(1e-30, float(p64.grad.abs().max()))
+        e2 = float((dw.double() - w64.grad).abs().max()) / max(1e-30, float(w64.grad.abs().max()))
+        e3 = float((db.double() - b64.grad).abs().max()) / max(1e-30, float(b64.grad.abs().max()))
+        if not (e1 <= 2e-6 and e2 <= 2e-5 and e3 <= 2e-5 and float(gmax) == float(gg.abs().max())):
+            fails.append(("conv1x1_bwd", n, e1, e2, e3))
+
+
+counts.update({"fusion": 0, "unet3d": 0, "hand": 0, "winding": 0, "skip": 0, "skip2": 0, "wide": 0, "wgrad": 0})
 t0 = time.time()
 it = 0
 while time.time() - t0 < budget and len(fails) < 5:
@@ -356,6 +416,7 @@ while time.time() - t0 < budget and len(fails) < 5:
         jobs.append(("wide", one_wide))
     if it % 8 == 0:
         jobs.append(("skip2", one_skip2))
+        jobs.append(("wgrad", one_wgrad))
     if it % 40 == 0:
         jobs.append(("unet3d", one_unet))
     for name, fn in jobs:
