@@ -270,6 +270,8 @@ int vt_decode_bwd_wide(int B, int R, int C, const float *pts, int64_t N, const f
 /*   contact points; fingers in ascending order, later ones overwrite).                              */
 /*   anchors [F,K,3], count [F] (valid anchors per finger), success [F] (u8); ids [B,N] u8, 255=none. */
 /* vt_decode_fwd_ids = vt_decode_fwd with c_img[b,n,:] = finger_feats[ids[b,n]] (0 where 255).        */
+/* In every *_ids entry an id >= n_fingers (F) reads as 255 does -- a zero feature -- never as a row  */
+/* past the table (the host gather this replaces, table[row], raised on such an index).              */
 int vt_tactile_assign(const float *pts, int B, int64_t N, int lattice_nx, float lattice_box, int64_t lattice_first,
                       const float *anchors, const int *count, const unsigned char *success, int F, int K,
                       int mode, double radius, unsigned char *ids, void *stream);

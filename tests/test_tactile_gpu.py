@@ -71,6 +71,46 @@ def test_decode_by_finger_id_equals_dense_c_img():
     assert torch.equal(by_id, ref)
 
 
+def test_finger_id_outside_the_table_reads_as_no_feature():
+    """An id >= n_fingers (a table with fewer rows than the ids were assigned against) must never index past the table: every
+    by-id kernel (shipped decoder in all four arithmetics, the wide decoder exact and split-f16, the fuser) treats it like 255 --
+    the result equals the one with those ids rewritten to 255, bit for bit.  (The host gather this replaces raised instead; the
+    table here is the LAST allocation of a fresh segment so that a read past it would at least fetch other bytes.)"""
+    from vtaco_amd import ops
+    from vtaco_amd.conv_onet.models import decoder_dict
+    from vtaco_amd.transformer_fusion import TransformerFusion
+    a, sd = load_golden("g1_decode.npz")
+    dec = decoder_dict['simple_local'](dim=3, c_dim=32, hidden_size=32, with_contact=True)
+    dec.load_state_dict(sd, strict=True)
+    dec.to(DEV)
+    g = torch.Generator().manual_seed(7)
+    nx = 32
+    grid = torch.from_numpy(a["grid"]).to(DEV)
+    ids = torch.full((1, nx ** 3), 255, dtype=torch.uint8)
+    pick = torch.rand(nx ** 3, generator=g) < 0.1
+    ids[0, pick] = torch.randint(0, 9, (int(pick.sum()),), generator=g).to(torch.uint8)      # ids 3..8 are outside a 3-row table
+    clean = torch.where(ids >= 3, torch.full_like(ids, 255), ids)
+    assert int(((ids >= 3) & (ids != 255)).sum()) > 50
+    feats = torch.randn(3, 32, generator=g).to(DEV)
+    with torch.no_grad():
+        for prec in ops.PRECISIONS:
+            got = dec.decode_lattice_ids(grid, nx, ids.to(DEV), feats, precision=prec)
+            ref = dec.decode_lattice_ids(grid, nx, clean.to(DEV), feats, precision=prec)
+            assert torch.equal(got, ref), prec
+        torch.manual_seed(5)
+        wdec = decoder_dict['simple_local'](dim=3, c_dim=32, hidden_size=64, n_blocks=3).to(DEV).eval()
+        for prec in ("f32", "f16x3"):
+            got = wdec.decode_lattice_ids(grid, nx, ids.to(DEV), feats, precision=prec)
+            ref = wdec.decode_lattice_ids(grid, nx, clean.to(DEV), feats, precision=prec)
+            assert torch.equal(got, ref), ("wide", prec)
+        torch.manual_seed(3)
+        fuser = TransformerFusion(use_xyz=True, input_size=2048, d_model=32, num_layers=1, key_feature_dim=64, with_pos_embed=False,
+                                  encoder_pos_embed_input_dim=3, decoder_pos_embed_input_dim=3).to(DEV).eval()
+        c = torch.randn(4, 512, 32, generator=g).to(DEV)
+        fid, fclean = ids[0, :2048].reshape(4, 512).to(DEV), clean[0, :2048].reshape(4, 512).to(DEV)
+        assert torch.equal(fuser.forward_ids(fid, feats, c), fuser.forward_ids(fclean, feats, c))
+
+
 def test_generator_tactile_mesh_equals_dense_c_img_all_path():
     """Generator3D.generate_obj_mesh_tactile (finger ids + feature table) produces the mesh of the reference-style path
     that materialises c_img_all [1, nx^3, C] from the oracle's assignment rule and decodes with forward_img."""

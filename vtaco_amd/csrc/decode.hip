@@ -48,11 +48,11 @@ __device__ __forceinline__ void mlp_and_heads(const DecodeArgs &a, const float *
         if (a.cimg_ids) {
             // tactile feature by finger id: most tiles touch no finger and skip the 16 MFMAs
             const unsigned id = a.cimg_ids[g];
-            if (__ballot(id != 255u) != 0ull) {
+            if (__ballot(id < a.cimg_nf) != 0ull) {
                 f32x16 ci;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) ci[s] = 0.0f;
-                if (id != 255u) ci = load_frag16(a.cimg_table + (size_t)id * 32 + 16 * h);
+                if (id < a.cimg_nf) ci = load_frag16(a.cimg_table + (size_t)id * 32 + 16 * h);
                 if constexpr (P != 0) net = dense32s<P>(net, L + VT_OFF_WPI, split16<false, P>(ci), lane);
                 else net = dense32<false>(net, L + VT_OFF_WPI, ci, lane);
             }
@@ -640,11 +640,11 @@ decode_fwd_staged2_kernel(DecodeArgs a) {
         if (a.cimg_ids) {
             // tactile feature by finger id: most double bricks touch no finger and skip the layer
             const unsigned idA = a.cimg_ids[gA], idB = a.cimg_ids[gB];
-            if (__ballot(idA != 255u || idB != 255u) != 0ull) {
+            if (__ballot(idA < a.cimg_nf || idB < a.cimg_nf) != 0ull) {
 #pragma unroll
                 for (int s = 0; s < 16; ++s) { ciA[s] = 0.0f; ciB[s] = 0.0f; }
-                if (idA != 255u) ciA = load_frag16(a.cimg_table + (size_t)idA * 32 + 16 * h);
-                if (idB != 255u) ciB = load_frag16(a.cimg_table + (size_t)idB * 32 + 16 * h);
+                if (idA < a.cimg_nf) ciA = load_frag16(a.cimg_table + (size_t)idA * 32 + 16 * h);
+                if (idB < a.cimg_nf) ciB = load_frag16(a.cimg_table + (size_t)idB * 32 + 16 * h);
                 has_img = true;
             }
         } else if (a.c_img) {
@@ -1163,7 +1163,7 @@ int vt_st3_sample_lattice(const float *grid_cl, int B, int R, int C, int64_t N, 
     if (off) return 0;
     DecodeArgs a;
     a.status = nullptr; a.clk = nullptr; a.claim = 1;
-    a.c_direct = nullptr; a.grid = grid_cl; a.pts = nullptr; a.brick = 1; a.cimg_ids = nullptr; a.cimg_table = nullptr; a.c_img = nullptr;
+    a.c_direct = nullptr; a.grid = grid_cl; a.pts = nullptr; a.brick = 1; a.cimg_ids = nullptr; a.cimg_table = nullptr; a.cimg_nf = 0; a.c_img = nullptr;
     a.blob = nullptr; a.out = feat; a.out2 = nullptr; a.save = nullptr;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)first;
     a.R = R; a.nx = nx; a.box = box; a.divisor = (float)(1.0 + padding + 10e-4);
@@ -1176,7 +1176,7 @@ int vt_st3_sample_lattice(const float *grid_cl, int B, int R, int C, int64_t N, 
 template <int P>
 static int decode_launch(const float *grid_cl, const float *c_direct, int B, int R, int C, const float *pts, int64_t N,
                          int lattice_nx, float lattice_box, int64_t lattice_first,
-                         const float *c_img, const unsigned char *cimg_ids, const float *cimg_table,
+                         const float *c_img, const unsigned char *cimg_ids, const float *cimg_table, int cimg_nf,
                          const float *blob, double padding,
                          float *out, float *out2, float *save, void *stream) {
     if ((!grid_cl && !c_direct) || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: null argument");
@@ -1197,7 +1197,7 @@ static int decode_launch(const float *grid_cl, const float *c_direct, int B, int
     static const int claim_tiles = !(getenv("VTACO_DECODE_CLAIM") && atoi(getenv("VTACO_DECODE_CLAIM")) == 0);
     a.claim = claim_tiles && P != 0;                       // (same box, claims / fixed shares: f16x3 163.2 / 167.2 us, f16f8 149.5 / 155.0,
                                                            // bf16x3 186.0 / 190.1 -- and exact f32 502.9 / 496.3: its waves are matrix-bound, not issue-bound)
-    a.c_direct = c_direct; a.grid = grid_cl; a.pts = pts; a.brick = 0; a.cimg_ids = cimg_ids; a.cimg_table = cimg_table; a.c_img = c_img; a.blob = blob; a.out = out; a.out2 = out2; a.save = save;
+    a.c_direct = c_direct; a.grid = grid_cl; a.pts = pts; a.brick = 0; a.cimg_ids = cimg_ids; a.cimg_table = cimg_table; a.cimg_nf = cimg_ids ? (uint32_t)(cimg_nf < 255 ? cimg_nf : 255) : 0u; a.c_img = c_img; a.blob = blob; a.out = out; a.out2 = out2; a.save = save;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box;
     a.divisor = (float)(1.0 + padding + 10e-4);   // src/common.py:302, rounded to f32 as torch does
@@ -1306,7 +1306,7 @@ int vt_decode_fwd_f16f8(const float *grid_cl, int B, int R, int C, int64_t N, in
     a.status = vt_decode_status_dev();
     a.clk = nullptr;
     a.claim = !(getenv("VTACO_DECODE_CLAIM") && atoi(getenv("VTACO_DECODE_CLAIM")) == 0);
-    a.c_direct = nullptr; a.grid = grid_cl; a.pts = nullptr; a.brick = 1; a.cimg_ids = finger_ids; a.cimg_table = finger_ids ? finger_feats : nullptr;
+    a.c_direct = nullptr; a.grid = grid_cl; a.pts = nullptr; a.brick = 1; a.cimg_ids = finger_ids; a.cimg_table = finger_ids ? finger_feats : nullptr; a.cimg_nf = finger_ids ? (uint32_t)(F < 255 ? F : 255) : 0u;
     a.c_img = c_img; a.blob = blob_f16f8; a.out = out; a.out2 = nullptr; a.save = nullptr;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box; a.divisor = (float)(1.0 + padding + 10e-4);
@@ -1321,7 +1321,7 @@ int vt_decode_fwd_f16x3(const float *grid_cl, int B, int R, int C, const float *
     if (c_img && finger_ids) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_f16x3: give c_img or finger ids, not both");
     if (finger_ids && (!finger_feats || F <= 0)) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_f16x3: finger ids without a feature table");
     return decode_launch<2>(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img,
-                            finger_ids, finger_ids ? finger_feats : nullptr, blob_f16x3, padding, out, out2, nullptr, stream);
+                            finger_ids, finger_ids ? finger_feats : nullptr, F, blob_f16x3, padding, out, out2, nullptr, stream);
 }
 
 // vt_decode_mlp_fwd with split-f16 layers (inference: the MLP behind the TransformerFusion of AttentionDecoder.forward_img)
@@ -1329,7 +1329,7 @@ int vt_decode_mlp_fwd_f16x3(const float *c, int B, int C, const float *pts, int6
                             int lattice_nx, float lattice_box, int64_t lattice_first,
                             const float *blob_f16x3, float *out, void *stream) {
     if (!c) return vt_fail(VT_ERR_INVALID, "vt_decode_mlp_fwd_f16x3: null features");
-    return decode_launch<2>(nullptr, c, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, nullptr, nullptr, blob_f16x3, 0.1,
+    return decode_launch<2>(nullptr, c, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, nullptr, nullptr, 0, blob_f16x3, 0.1,
                             out, nullptr, nullptr, stream);
 }
 #else
@@ -1338,7 +1338,7 @@ int vt_decode_fwd(const float *grid_cl, int B, int R, int C, const float *pts, i
                   const float *c_img, const float *blob, double padding,
                   float *out, float *out2, float *save, void *stream) {
     if (!grid_cl) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd: null grid");
-    return decode_launch<0>(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img, nullptr, nullptr,
+    return decode_launch<0>(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img, nullptr, nullptr, 0,
                             blob, padding, out, out2, save, stream);
 }
 
@@ -1347,7 +1347,7 @@ int vt_decode_fwd_ids(const float *grid_cl, int B, int R, int C, const float *pt
                       const unsigned char *finger_ids, const float *finger_feats, int F,
                       const float *blob, double padding, float *out, void *stream) {
     if (!grid_cl || !finger_ids || !finger_feats || F <= 0) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_ids: null argument");
-    return decode_launch<0>(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, finger_ids, finger_feats,
+    return decode_launch<0>(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, finger_ids, finger_feats, F,
                             blob, padding, out, nullptr, nullptr, stream);
 }
 
@@ -1359,14 +1359,14 @@ int vt_decode_fwd_bf16x3(const float *grid_cl, int B, int R, int C, const float 
     if (c_img && finger_ids) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_bf16x3: give c_img or finger ids, not both");
     if (finger_ids && (!finger_feats || F <= 0)) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_bf16x3: finger ids without a feature table");
     return decode_launch<1>(grid_cl, nullptr, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, c_img,
-                            finger_ids, finger_ids ? finger_feats : nullptr, blob_bf16x3, padding, out, out2, nullptr, stream);
+                            finger_ids, finger_ids ? finger_feats : nullptr, F, blob_bf16x3, padding, out, out2, nullptr, stream);
 }
 
 int vt_decode_mlp_fwd(const float *c, int B, int C, const float *pts, int64_t N,
                       int lattice_nx, float lattice_box, int64_t lattice_first,
                       const float *blob, float *out, void *stream) {
     if (!c) return vt_fail(VT_ERR_INVALID, "vt_decode_mlp_fwd: null features");
-    return decode_launch<0>(nullptr, c, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, nullptr, nullptr, blob, 0.1,
+    return decode_launch<0>(nullptr, c, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, nullptr, nullptr, 0, blob, 0.1,
                             out, nullptr, nullptr, stream);
 }
 
@@ -1374,7 +1374,7 @@ int vt_decode_mlp_fwd_train(const float *c, int B, int C, const float *pts, int6
                             int lattice_nx, float lattice_box, int64_t lattice_first,
                             const float *blob, float *out, float *save, void *stream) {
     if (!c || !save) return vt_fail(VT_ERR_INVALID, "vt_decode_mlp_fwd_train: null argument");
-    return decode_launch<0>(nullptr, c, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, nullptr, nullptr, blob, 0.1,
+    return decode_launch<0>(nullptr, c, B, 2, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, nullptr, nullptr, 0, blob, 0.1,
                             out, nullptr, save, stream);
 }
 
@@ -1394,7 +1394,7 @@ int vt_sample_grid(const float *grid_cl, int B, int R, int C, const float *pts, 
     }
     DecodeArgs a;
     a.status = nullptr; a.clk = nullptr; a.claim = 0;
-    a.c_direct = nullptr; a.brick = 0; a.cimg_ids = nullptr; a.cimg_table = nullptr; a.grid = grid_cl; a.pts = pts; a.c_img = nullptr; a.blob = nullptr; a.out = nullptr; a.out2 = nullptr; a.save = nullptr;
+    a.c_direct = nullptr; a.brick = 0; a.cimg_ids = nullptr; a.cimg_table = nullptr; a.cimg_nf = 0; a.grid = grid_cl; a.pts = pts; a.c_img = nullptr; a.blob = nullptr; a.out = nullptr; a.out2 = nullptr; a.save = nullptr;
     a.N = (uint32_t)N; a.total = (uint32_t)((int64_t)B * N); a.lattice_first = (uint32_t)lattice_first;
     a.R = R; a.nx = lattice_nx; a.box = lattice_box; a.divisor = (float)(1.0 + padding + 10e-4);
     int64_t blocks = (((int64_t)a.total + 31) / 32 + 3) / 4;

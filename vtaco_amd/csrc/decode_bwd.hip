@@ -368,7 +368,7 @@ bool fill_decode_args(DecodeArgs &d, int B, int R, int C, const float *pts, int6
     if (C != 32) { rc = vt_fail(VT_ERR_UNSUPPORTED, "c_dim must be 32"); return false; }
     if ((int64_t)B * N >= (int64_t)1 << 31) { rc = vt_fail(VT_ERR_UNSUPPORTED, "B*N must be < 2^31"); return false; }
     if (!pts && nx < 2) { rc = vt_fail(VT_ERR_INVALID, "lattice mode needs nx >= 2"); return false; }
-    d.c_direct = nullptr; d.brick = 0; d.cimg_ids = nullptr; d.cimg_table = nullptr; d.grid = nullptr; d.pts = pts; d.c_img = nullptr; d.blob = nullptr; d.out = nullptr; d.out2 = nullptr; d.save = nullptr;
+    d.c_direct = nullptr; d.brick = 0; d.cimg_ids = nullptr; d.cimg_table = nullptr; d.cimg_nf = 0; d.grid = nullptr; d.pts = pts; d.c_img = nullptr; d.blob = nullptr; d.out = nullptr; d.out2 = nullptr; d.save = nullptr;
     d.N = (uint32_t)N; d.total = (uint32_t)((int64_t)B * N); d.lattice_first = (uint32_t)first;
     d.R = R; d.nx = nx; d.box = box; d.divisor = (float)(1.0 + padding + 10e-4);
     return true;

@@ -269,6 +269,7 @@ struct DecodeArgs {
     const float *c_direct;  // [B,N,32] conditioning features given directly (no grid gather), or null
     const unsigned char *cimg_ids;   // [B,N] finger id per point (255 = none) with cimg_table, instead of c_img
     const float *cimg_table;         // [F][32] tactile feature per finger
+    uint32_t cimg_nf;                // F: an id >= F (255 included) reads as "no feature" -- never as a row past the table
     int brick;           // lattice mode with tiles = 2x4x4 bricks (slab aligned to x-plane pairs, nx % 4 == 0)
     uint32_t N;          // points per batch element
     uint32_t total;      // B*N   (< 2^31, checked by the entry point)

@@ -415,11 +415,11 @@ decode_fwd_staged3_kernel(DecodeArgs a) {
             bool has_img = true;
             if (a.cimg_ids) {
                 const unsigned idA = a.cimg_ids[gA], idB = a.cimg_ids[gB];
-                has_img = __ballot(idA != 255u || idB != 255u) != 0ull;  // most double bricks touch no finger
+                has_img = __ballot(idA < a.cimg_nf || idB < a.cimg_nf) != 0ull;  // most double bricks touch no finger
 #pragma unroll
                 for (int s = 0; s < 16; ++s) { ciA[s] = 0.0f; ciB[s] = 0.0f; }
-                if (has_img && idA != 255u) ciA = load_frag16(a.cimg_table + (size_t)idA * 32 + 16 * h);
-                if (has_img && idB != 255u) ciB = load_frag16(a.cimg_table + (size_t)idB * 32 + 16 * h);
+                if (has_img && idA < a.cimg_nf) ciA = load_frag16(a.cimg_table + (size_t)idA * 32 + 16 * h);
+                if (has_img && idB < a.cimg_nf) ciB = load_frag16(a.cimg_table + (size_t)idB * 32 + 16 * h);
             } else {
                 ciA = load_frag16(a.c_img + (size_t)gA * 32 + 16 * h);
                 ciB = load_frag16(a.c_img + (size_t)gB * 32 + 16 * h);

@@ -104,7 +104,7 @@ __device__ __forceinline__ float actvn(float x, int leaky) { return x > 0.0f ? x
 __device__ __forceinline__ float wide_cimg(const DecodeArgs &d, uint32_t g, int k3, int C) {
     if (d.cimg_ids) {
         const unsigned id = d.cimg_ids[g];
-        return id == 255u ? 0.0f : d.cimg_table[(size_t)id * C + k3];
+        return id >= d.cimg_nf ? 0.0f : d.cimg_table[(size_t)id * C + k3];
     }
     return d.c_img[(size_t)g * C + k3];
 }
@@ -718,7 +718,7 @@ static int wide_fwd_impl(const float *grid_cl, int B, int R, int C, const float 
                          int lattice_nx, float lattice_box, int64_t lattice_first,
                          const float *c_img, const float *blob, int hidden, int n_blocks, int flags, double padding,
                          float *out, float *out2, float *save, void *stream,
-                         const unsigned char *finger_ids = nullptr, const float *finger_feats = nullptr, const float *c_direct = nullptr) {
+                         const unsigned char *finger_ids = nullptr, const float *finger_feats = nullptr, const float *c_direct = nullptr, int n_fingers = 0) {
     if ((!grid_cl && !c_direct) || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide: null argument");
     if (c_img && finger_ids) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide: give c_img or finger ids, not both");
     const int p_in = (c_img || finger_ids) ? 3 + C : 3;
@@ -732,7 +732,7 @@ static int wide_fwd_impl(const float *grid_cl, int B, int R, int C, const float 
     }
     WideArgs a{};
     a.d.grid = grid_cl; a.d.pts = pts; a.d.c_img = c_img; a.d.out = out; a.d.out2 = out2;
-    a.d.cimg_ids = finger_ids; a.d.cimg_table = finger_ids ? finger_feats : nullptr; a.d.c_direct = c_direct;
+    a.d.cimg_ids = finger_ids; a.d.cimg_table = finger_ids ? finger_feats : nullptr; a.d.cimg_nf = finger_ids ? (uint32_t)n_fingers : 0u; a.d.c_direct = c_direct;
     a.d.N = (uint32_t)N; a.d.total = (uint32_t)((uint64_t)B * (uint64_t)N); a.d.lattice_first = (uint32_t)lattice_first;
     a.d.R = R; a.d.nx = lattice_nx; a.d.box = lattice_box; a.d.divisor = (float)(1.0 + padding + 10e-4);
     a.blob = blob; a.H = hidden; a.C = C; a.nb = n_blocks; a.p_in = p_in; a.Kp = (p_in + 7) / 8 * 8; a.leaky = (flags & VT_WIDE_LEAKY) ? 1 : 0; a.nearest = (flags & VT_WIDE_NEAREST) ? 1 : 0;
@@ -774,7 +774,7 @@ int vt_decode_fwd_wide_ids(const float *grid_cl, int B, int R, int C, const floa
                            float *out, float *out2, void *stream) {
     if (!finger_ids || !finger_feats || n_fingers <= 0 || n_fingers > 255) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_ids: bad finger table");
     return wide_fwd_impl(grid_cl, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, blob, hidden, n_blocks, flags, padding,
-                         out, out2, nullptr, stream, finger_ids, finger_feats);
+                         out, out2, nullptr, stream, finger_ids, finger_feats, nullptr, n_fingers);
 }
 
 // ---- split-f16 form of the same forward (inference) ----
@@ -826,7 +826,7 @@ static int wideh_fwd_impl(const float *grid_cl, int B, int R, int C, const float
                           int lattice_nx, float lattice_box, int64_t lattice_first,
                           const float *c_img, const unsigned char *finger_ids, const float *finger_feats,
                           const float *blob, int hidden, int n_blocks, int flags, double padding,
-                          float *out, float *out2, void *stream, const float *c_direct = nullptr, void *ws = nullptr, size_t ws_bytes = 0) {
+                          float *out, float *out2, void *stream, const float *c_direct = nullptr, void *ws = nullptr, size_t ws_bytes = 0, int n_fingers = 0) {
     if ((!grid_cl && !c_direct) || !blob || !out) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3: null argument");
     if (c_img && finger_ids) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3: give c_img or finger ids, not both");
     const int p_in = (c_img || finger_ids) ? 3 + C : 3;
@@ -838,7 +838,7 @@ static int wideh_fwd_impl(const float *grid_cl, int B, int R, int C, const float
         return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3: lattice range outside nx^3");
     WideHArgs a{};
     a.d.grid = grid_cl; a.d.pts = pts; a.d.c_img = c_img; a.d.out = out; a.d.out2 = out2;
-    a.d.cimg_ids = finger_ids; a.d.cimg_table = finger_ids ? finger_feats : nullptr; a.d.c_direct = c_direct;
+    a.d.cimg_ids = finger_ids; a.d.cimg_table = finger_ids ? finger_feats : nullptr; a.d.cimg_nf = finger_ids ? (uint32_t)n_fingers : 0u; a.d.c_direct = c_direct;
     a.d.N = (uint32_t)N; a.d.total = (uint32_t)((uint64_t)B * (uint64_t)N); a.d.lattice_first = (uint32_t)lattice_first;
     a.d.R = R; a.d.nx = lattice_nx; a.d.box = lattice_box; a.d.divisor = (float)(1.0 + padding + 10e-4);
     a.blob = blob; a.H = hidden; a.C = C; a.nb = n_blocks; a.p_in = p_in; a.Kp = (p_in + 15) / 16 * 16;
@@ -934,7 +934,7 @@ int vt_decode_fwd_wide_f16x3_ids(const float *grid_cl, int B, int R, int C, cons
                                  float *out, float *out2, void *stream) {
     if (!finger_ids || !finger_feats || n_fingers <= 0 || n_fingers > 255) return vt_fail(VT_ERR_INVALID, "vt_decode_fwd_wide_f16x3_ids: bad finger table");
     return wideh_fwd_impl(grid_cl, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, nullptr, finger_ids, finger_feats, blob, hidden,
-                          n_blocks, flags, padding, out, out2, stream);
+                          n_blocks, flags, padding, out, out2, stream, nullptr, nullptr, 0, n_fingers);
 }
 
 // the conditioned MLP alone on features given per point (AttentionDecoder.forward_img behind its fuser, decoder.py:259-271): c [B][N][C]

@@ -1099,7 +1099,7 @@ int vt_fusion_fwd_ids(const unsigned char *finger_ids, const float *finger_feats
     hipLaunchKernelGGL(fusion_pack_kernel, dim3(6), dim3(1024), 0, s, us, w.blob_s);
     hipLaunchKernelGGL(fusion_pack_kernel, dim3(6), dim3(1024), 0, s, ux, w.blob_x);
     XIds xi;
-    xi.ids = finger_ids; xi.table = finger_feats; xi.chunk = chunk_index; xi.N = N;
+    xi.ids = finger_ids; xi.table = finger_feats; xi.chunk = chunk_index; xi.N = N; xi.F = (unsigned)n_fingers;
     run_unit(c, c, us, w.blob_s, w, w.M, B, N, s);                 // encoder: memory from the grid features
     run_unit(nullptr, nullptr, us, w.blob_s, w, w.T, B, N, s, nullptr, DropCfg{0, 0, 1.0f, 0}, xi);   // decoder self-attention on the rows by id
     run_unit(w.T, w.M, ux, w.blob_x, w, out, B, N, s);             // decoder cross-attention

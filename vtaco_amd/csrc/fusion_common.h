@@ -15,7 +15,7 @@ struct FusionUnitDev {
 
 // The tactile rows of the decoder's self-attention unit given by finger id instead of a dense [B][N][32] tensor (vt_fusion_fwd_ids:
 // what the reference gathers on the host, generation.py:159-255): point n of batch element b reads table[ids[row(b)][n]], a zero
-// row where the id is 255; row(b) = chunk[b] (the chunks a generator picked out of a lattice) or b.
+// row where the id is 255 or not a row of the table; row(b) = chunk[b] (the chunks a generator picked out of a lattice) or b.
 __device__ const float vt_fusion_zero_row[32] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
                                                  0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 struct XIds {
@@ -23,10 +23,11 @@ struct XIds {
     const float *table = nullptr;           // [F][32]
     const int *chunk = nullptr;
     int N = 0;
+    unsigned F = 0;                         // rows of the table: an id >= F (255 included) reads the zero row
     __device__ __forceinline__ const float *row(size_t p) const {
         const size_t b = p / (size_t)N, n = p - b * (size_t)N;
         const unsigned id = ids[(chunk ? (size_t)chunk[b] : b) * (size_t)N + n];
-        return id == 255u ? vt_fusion_zero_row : table + (size_t)id * 32;
+        return id >= F ? vt_fusion_zero_row : table + (size_t)id * 32;
     }
 };
 

@@ -84,7 +84,7 @@ extern "C" int vt_tactile_assign(const float *pts, int B, int64_t N, int lattice
     if (lds > 64 * 1024) return vt_fail(VT_ERR_UNSUPPORTED, "vt_tactile_assign: anchor set does not fit 64 KiB of LDS");
     AssignArgs a;
     a.d.c_direct = nullptr; a.d.brick = 0; a.d.grid = nullptr; a.d.pts = pts; a.d.c_img = nullptr; a.d.blob = nullptr;
-    a.d.out = nullptr; a.d.out2 = nullptr; a.d.save = nullptr; a.d.cimg_ids = nullptr; a.d.cimg_table = nullptr;
+    a.d.out = nullptr; a.d.out2 = nullptr; a.d.save = nullptr; a.d.cimg_ids = nullptr; a.d.cimg_table = nullptr; a.d.cimg_nf = 0;
     a.d.N = (uint32_t)N; a.d.total = (uint32_t)((int64_t)B * N); a.d.lattice_first = (uint32_t)lattice_first;
     a.d.R = 2; a.d.nx = lattice_nx; a.d.box = lattice_box; a.d.divisor = 1.0f;
     a.anchors = anchors; a.count = count; a.success = success; a.F = F; a.K = K; a.mode = mode; a.radius = radius; a.ids = ids;

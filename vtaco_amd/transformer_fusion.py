@@ -9,7 +9,7 @@ mode: the reference's dropout layers are identity there); under autograd it is `
 ``vt_fusion_fwd_train`` (the same pipeline with TransNonlinear's two train-mode dropouts, masks a
 function of a per-call seed drawn from torch's generator) and ``vt_fusion_bwd`` (gradients of
 c_img, c and all twenty parameter tensors; the shared self-attention's are the sum of its two uses).
-``forward_torch`` keeps the same arithmetic as host-PyTorch ops for reference.
+There is no host-operator form of the fuser in this package (the oracle under ``oracle/`` is the checker).
 """
 from __future__ import annotations
 
@@ -17,8 +17,6 @@ import math
 
 import torch
 from torch import nn
-
-from torch.nn import functional as F
 
 from . import ops
 from ._lib import VtError
@@ -54,18 +52,6 @@ class MultiheadAttention(nn.Module):
         self.Nh = n_head
         self.head = nn.ModuleList([RelationUnit(feature_dim, key_feature_dim)])
         self.extra_nonlinear = nn.ModuleList([TransNonlinear(feature_dim, key_feature_dim)])
-
-    def forward_torch(self, q, k, v):
-        """RelationUnit + TransNonlinear as differentiable torch ops on [B,N,C] tensors
-        (TransformerFusion.py:92-113, 21-25); dropout is active in training mode only."""
-        h, e = self.head[0], self.extra_nonlinear[0]
-        wk = F.normalize(h.WK(k), p=2, dim=-1)
-        wq = F.normalize(h.WQ(q), p=2, dim=-1)
-        aff = F.softmax(torch.bmm(wq, wk.transpose(1, 2)), dim=-1)
-        aff = aff / (1e-9 + aff.sum(dim=1, keepdim=True))                    # the reference's column re-normalisation
-        r = F.relu(h.trans_conv(q - torch.bmm(aff, h.WV(v))))
-        y = e.linear2(F.dropout(F.relu(e.linear1(r)), e.p_drop, self.training))
-        return e.norm2(r + F.dropout(y, e.p_drop, self.training))
 
     def unit_tensors(self):
         h, e = self.head[0], self.extra_nonlinear[0]
@@ -124,21 +110,6 @@ class TransformerFusion(nn.Module):
         self.decoder = _Stack(_Layer(shared, MultiheadAttention(feature_dim=d_model, n_head=1,
                                                                 key_feature_dim=key_feature_dim)))
 
-    @staticmethod
-    def _inorm_relu(x):
-        m = x.mean(dim=1, keepdim=True)
-        return F.relu((x - m) / torch.sqrt(x.var(dim=1, unbiased=False, keepdim=True) + 1e-5))
-
-    def forward_torch(self, search_feature, template_feature):
-        """The same fusion as differentiable host-PyTorch ops (training: the HIP pipeline has no backward).
-        InstanceNorm1d over the N points, no affine (TransformerFusion.py:144-145, 209-218)."""
-        layer = self.decoder.layers[0]
-        sa, ca = layer.self_attn, layer.cross_attn
-        c, ci = template_feature, search_feature
-        mem = self._inorm_relu(c + sa.forward_torch(c, c, c))
-        tgt = self._inorm_relu(ci + sa.forward_torch(ci, ci, ci))
-        return self._inorm_relu(tgt + ca.forward_torch(tgt, mem, mem))
-
     def forward(self, search_feature, search_coord, template_feature, template_coord):
         """fuse(search=c_img [B,N,C], template=c [B,N,C]) -> [B,N,C]  (TransformerFusion.py:311-333)."""
         layer = self.decoder.layers[0]
@@ -162,7 +133,7 @@ class TransformerFusion(nn.Module):
             feats = finger_feats.float()
             table = torch.cat([feats, feats.new_zeros(1, feats.shape[1])])
             rows = finger_ids if chunk_index is None else finger_ids[chunk_index.long()]
-            gathered = table[torch.where(rows == 255, torch.full_like(rows, feats.shape[0]), rows).long()]
+            gathered = table[torch.where(rows >= feats.shape[0], torch.full_like(rows, feats.shape[0]), rows).long()]   # 255 or past the table: zero row
             return ops.fusion_fwd(gathered, template_feature, layer.self_attn.unit_tensors(), layer.cross_attn.unit_tensors())
         return ops.fusion_fwd_ids(finger_ids, finger_feats, template_feature, layer.self_attn.unit_tensors(),
                                   layer.cross_attn.unit_tensors(), chunk_index=chunk_index)
