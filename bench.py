@@ -514,6 +514,233 @@ def train_step_section(dev, fx, rank, world, dist, steps=8, scenes=8):
     return res
 
 
+def _median_ms(fn, n=7, warm=2):
+    import torch
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    return sorted(ts)[len(ts) // 2]
+
+
+def _route_stages(gen, model, data, nx, n=7):
+    """generate_obj_mesh_wnf(with_img) end to end (median wall ms, device idle on both sides) and its stages timed one by one the
+    same way: shape encoder (a graph replay), the branch's setup (hand encoder / Resnet18 replays + the host-side anchors), finger ids
+    + decode of the lattice, marching cubes."""
+    import torch
+    res = {"end_to_end_ms": _median_ms(lambda: gen.generate_obj_mesh_wnf(data), n)}
+    inputs = data["inputs"].to(gen.device)
+    box = {}
+
+    def enc():
+        box["c"] = gen._replay("encode_inputs", [inputs], model.encode_inputs)
+
+    def setup():
+        box["setup"] = gen._tactile_setup(data)
+
+    def lattice():
+        with torch.no_grad():
+            box["vals"] = gen._eval_lattice_tactile(box["c"], nx, box["setup"])
+
+    def mc():
+        box["mesh"] = gen.extract_mesh(box["vals"].reshape(nx, nx, nx))
+    res["stage_ms"] = {"encode_pointnet_unet3d": _median_ms(enc, n), "tactile_setup": _median_ms(setup, n),
+                       "finger_ids_and_decode": _median_ms(lattice, n), "marching_cubes": _median_ms(mc, n)}
+    res["verts"], res["faces"] = int(box["mesh"].vertices.shape[0]), int(box["mesh"].faces.shape[0])
+    return res, box
+
+
+def _kernel_ms(fn, name_part):
+    """(average device ms per launch, launches) of the kernels whose name contains ``name_part`` during one call of fn (torch.profiler
+    = roctracer on this image; rocprofv3 of tools/pmc_fusion.sh gives the same table offline: profiles/r06_fusion_kernel_stats.csv)."""
+    import torch
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        fn()
+        torch.cuda.synchronize()
+    ev = [e for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CUDA and name_part in e.key]
+    n = sum(e.count for e in ev)
+    return (sum(e.device_time_total for e in ev) / 1e3 / n, n) if n else (None, 0)
+
+
+def config3_section(dev, precision, nx=128):
+    """BASELINE config 3 -- full VTacO at 128^3 on one GPU, four numbers:
+    (a) the tactile-concat decode of the lattice (LocalDecoder.forward_img, the SHIPPED VTacO decoder): dense c_img and by finger id;
+    (b) AttentionDecoder.forward_img over the lattice in chunks of 2048 points, EVERY chunk through the three attention units, with a
+        roofline object for the pass (HIP events) and one for its dominant kernel, fusion_attend_kernel (192 N^2 FLOP per chunk:
+        2 N^2 64 for the scores + 2 N^2 32 for A V'; SURVEY.md 8d's 576 N per point is three of these);
+    (c) Generator3D(with_img, encode_t2d).generate_obj_mesh_wnf -- the reference's entry point (generation.py:202-257, 268-273) --
+        end to end on the shipped VTacO model with either decoder, with stage times; beside it the t2d net's forward, which the
+        reference runs and whose result it discards (:212-217, 226: the dataset's depth overwrites the predicted one);
+    (d) the oracle on the host cores for the stages it has (a bounded sample: 4 chunks of the attention decoder, the assignment
+        rule on 1/64 of the lattice)."""
+    import numpy as np
+    import torch
+    from vtaco_amd import ops
+    from vtaco_amd.bench_util import build_tactile_scene
+    from vtaco_amd.conv_onet.generation import Generator3D
+    res = {}
+    npts = nx ** 3
+    # ---- (c) first: it builds the models the other parts reuse ----
+    routes = {}
+    keep = {}
+    for decoder in ("simple_local", "attention_local"):
+        model, data, origin = build_tactile_scene(dev, "vtaco", decoder)
+        gen = Generator3D(model, device=dev, resolution0=nx // 4, padding=0.1, with_img=True, encode_t2d=True,
+                          points_batch_size=2048 if decoder == "attention_local" else 100000, decode_precision=precision,
+                          depth_origin=origin)
+        np.random.seed(11)
+        r, box = _route_stages(gen, model, data, nx)
+        ids = ops.tactile_assign(box["setup"]["anchors"].to(dev), box["setup"]["success"].to(dev), "within", 0.015,
+                                 lattice=(nx, 1.1, 0, npts), count=box["setup"]["count"].to(dev))
+        r["lattice_points_with_a_tactile_feature"] = int((ids != 255).sum())
+        if decoder == "attention_local":
+            r["chunks"] = npts // 2048
+            r["chunks_with_a_tactile_feature"] = int((ids.reshape(-1, 2048) != 255).any(dim=1).sum())
+            r["note"] = "chunks no finger touches skip the fuser (fuse(0, c) = 0 exactly: Generator3D._eval_lattice_fused); (b) is the pass without that shortcut"
+        routes[decoder] = r
+        keep[decoder] = (model, gen, data, box, ids)
+    model, gen, data, box, ids = keep["simple_local"]
+    imgs, inputs = data["inputs.img"].to(dev), data["inputs"].to(dev)
+    with torch.no_grad():
+        t2d_ms = _median_ms(lambda: model.encode_t2d(inputs, imgs), 5, 2)
+    res["generate_obj_mesh_wnf_t2d"] = dict(routes, encode_t2d_forward_ms=t2d_ms,
+                                            encode_t2d_note="tactile U-Net (5 images of 320 x 240, host PyTorch / MIOpen by north_star) + digit-pose "
+                                                            "encoder: the reference runs it in this branch and discards both results; "
+                                                            "this generator does not run it (same mesh)")
+    # ---- (a) tactile concat over the lattice ----
+    dec, grid = model.decoder, box["c"]["grid"]
+    feats = box["setup"]["feats"].to(dev).float()
+    dense = torch.zeros(1, npts, 32, device=dev)
+    hit = ids[0] != 255
+    dense[0, hit] = feats[ids[0][hit].long()]
+    out = torch.empty((1, npts), dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        t_dense = _median_ms(lambda: dec.decode_lattice(grid, nx, c_img=dense, out=out, precision=precision), 20, 5)
+        t_ids = _median_ms(lambda: dec.decode_lattice_ids(grid, nx, ids, feats, out=out, precision=precision), 20, 5)
+    res["tactile_concat_decode"] = {
+        "dense_c_img_ms": t_dense, "by_finger_id_ms": t_ids, "points_per_s_by_id": npts / (t_ids * 1e-3), "precision": precision,
+        "tflops_dense": FLOP_PER_POINT_IMG * npts / (t_dense * 1e-3) / 1e12,
+        "note": "LocalDecoder.forward_img over the 128^3 lattice: dense = [1, nx^3, 32] f32 c_img_all (268 MB read per pass), by id = one byte "
+                "per point + the [5, 32] table (tiles no finger touches skip fc_p_img's c_img columns)"}
+    del dense
+    # ---- (b) the attention decoder, every chunk through the fuser ----
+    amodel, agen, adata, abox, aids = keep["attention_local"]
+    adec, agrid = amodel.decoder, abox["c"]["grid"]
+    afeats = abox["setup"]["feats"].to(dev).float()
+    N, chunks = 2048, npts // 2048
+    agen.skip_untouched_chunks = False
+    setup = abox["setup"]
+    with torch.no_grad():
+        run = lambda: agen._eval_lattice_fused(abox["c"], nx, aids, afeats)
+        t_pass = _median_ms(run, 5, 2)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(3):
+            run()
+        ev[1].record()
+        torch.cuda.synchronize()
+        t_pass_ev = ev[0].elapsed_time(ev[1]) / 3
+        att_ms, att_n = _kernel_ms(run, "fusion_attend_kernel")
+        exp_ms, exp_n = _kernel_ms(run, "fusion_expsum")
+    agen.skip_untouched_chunks = True
+    flop_pt = 30976 + 576 * N + 61440
+    tf = flop_pt * npts / (t_pass_ev * 1e-3) / 1e12
+    att = None
+    if att_ms:
+        chunks_per_launch = 3 * chunks / att_n                       # three attention units per chunk
+        att_tf = 192.0 * N * N * chunks_per_launch / (att_ms * 1e-3) / 1e12
+        att = {"bound": "mfma", "achieved": att_tf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": att_tf / PEAK_BF16_MFMA_TFLOPS,
+               "traffic": None, "kernel": "fusion_attend_kernel", "kernel_ms": att_ms, "launches_per_pass": att_n,
+               "chunks_per_launch": chunks_per_launch, "flop_per_chunk": 192 * N * N,
+               "note": "algorithmic 192 N^2 FLOP per chunk and unit (scores once + A V' once) over the kernel's average device time "
+                       "(torch.profiler, live); the kernel recomputes the score tile with split operands (3 half products or f16 + fp8 "
+                       "corrections), so the matrix pipe executes ~2.3x this; counters: profiles/r06_fusion_pmc_summary.csv"}
+    res["attention_decoder_dense"] = {
+        "ms_per_lattice": t_pass, "ms_per_lattice_hip_events": t_pass_ev, "points_per_s": npts / (t_pass * 1e-3), "chunk_points": N, "chunks": chunks,
+        "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_MFMA_TFLOPS,
+                     "traffic": None, "flop_per_point": flop_pt,
+                     "note": "SURVEY.md 8d: 30 976 + 576 N + 61 440 FLOP per point at N = 2048, over the HIP-event time of the whole pass "
+                             "(grid sample, three attention units, conditioned MLP)"},
+        "attend_kernel_roofline": att,
+        "expsum_kernels": {"avg_ms": exp_ms, "launches_per_pass": exp_n}}
+    # ---- (d) the oracle on the host cores, bounded samples ----
+    try:
+        from oracle import vtaco_oracle as orc
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        cpu = {"cores": torch.get_num_threads(), "kind": "port"}
+        sd = {k: v.detach().cpu() for k, v in adec.state_dict().items()}
+        gcpu = agrid.detach().cpu().contiguous()
+        pts = 1.1 * orc.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3)
+        k = 4
+        ci = torch.zeros(1, N, 32)
+        t0 = time.perf_counter()
+        for j in range(k):
+            orc.attention_decoder_forward_img(sd, pts[j * N:(j + 1) * N].unsqueeze(0), gcpu, ci)
+        dt = time.perf_counter() - t0
+        cpu["attention_decoder_ms_per_lattice_scaled"] = 1e3 * dt * chunks / k
+        cpu["attention_decoder_sample"] = f"{k} of {chunks} chunks of {N} points, oracle.attention_decoder_forward_img (torch CPU f32)"
+        anchors, count = setup["anchors"].double().numpy(), setup["count"].numpy()
+        sub = pts[:npts // 64].numpy()
+        t0 = time.perf_counter()
+        orc.tactile_assign_within(sub, anchors, count, setup["success"].numpy())
+        cpu["tactile_assign_ms_per_lattice_scaled"] = 1e3 * (time.perf_counter() - t0) * 64
+        cpu["tactile_assign_sample"] = "1/64 of the lattice, oracle.tactile_assign_within (numpy cdist rule, one thread)"
+        res["cpu_baseline"] = cpu
+    except Exception as e:                                                 # noqa: BLE001
+        res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return res
+
+
+def config5_section(dev, precision, nx=256):
+    """BASELINE config 5 on ONE GPU -- the VTacOH route of generate_obj_mesh_wnf at 256^3, end to end (generation.py:161-200, 257,
+    268-273): shape encoder -> hand encoder (plane PointNet + 2-D U-Net + MANO layer) -> fingertips -> Resnet18 tactile features ->
+    vt_tactile_assign (nearest fingertip within 0.05) -> decode by finger id -> marching cubes.  (The sharded form of the same work
+    is `sharded_scene`; the reference walks 168 chunks of 100 000 points through a dense [1, 256^3, 32] c_img_all = 2.1 GB.)"""
+    import numpy as np
+    import torch
+    from vtaco_amd import ops
+    from vtaco_amd.bench_util import build_tactile_scene
+    from vtaco_amd.conv_onet.generation import Generator3D
+    model, data, _ = build_tactile_scene(dev, "vtacoh", "simple_local")
+    gen = Generator3D(model, device=dev, resolution0=nx // 4, padding=0.1, with_img=True, encode_t2d=False, decode_precision=precision)
+    res, box = _route_stages(gen, model, data, nx)
+    setup, inputs, imgs = box["setup"], data["inputs"].to(dev), data["inputs.img"].to(dev)
+    with torch.no_grad():
+        ids = ops.tactile_assign(setup["anchors"].to(dev), setup["success"].to(dev), "nearest", 0.05, lattice=(nx, 1.1, 0, nx ** 3),
+                                 count=setup["count"].to(dev))
+        feats, out = setup["feats"].to(dev).float(), torch.empty((1, nx ** 3), dtype=torch.float32, device=dev)
+        grid = box["c"]["grid"]
+        res["setup_stage_ms"] = {
+            "hand_encoder_unet_mano": _median_ms(lambda: gen._replay("encode_hand_inputs", [inputs], model.encode_hand_inputs)),
+            "resnet18_tactile_features": _median_ms(lambda: gen._replay("encode_img", [data["inputs.img"]], model.encode_img_inputs)),
+            "note": "graph replays; the rest of tactile_setup is the host side (fingertips into the object frame: 5 x 3 numbers, numpy)"}
+        res["lattice_stage_ms"] = {
+            "vt_tactile_assign": _median_ms(lambda: ops.tactile_assign(setup["anchors"].to(dev), setup["success"].to(dev), "nearest", 0.05,
+                                                                       lattice=(nx, 1.1, 0, nx ** 3), count=setup["count"].to(dev))),
+            "decode_by_finger_id": _median_ms(lambda: model.decoder.decode_lattice_ids(grid, nx, ids, feats, out=out, precision=precision))}
+    res["lattice_points_with_a_tactile_feature"] = int((ids != 255).sum())
+    res["points_per_s_end_to_end"] = nx ** 3 / (res["end_to_end_ms"] * 1e-3)
+    res["nx"], res["precision"] = nx, precision
+    try:
+        from oracle import vtaco_oracle as orc
+        pts = (1.1 * orc.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3))[:nx ** 3 // 64].numpy()
+        tips = setup["anchors"][:, 0].double().numpy()
+        t0 = time.perf_counter()
+        orc.tactile_assign_nearest(pts, tips, setup["success"].numpy(), radius=0.05)
+        res["cpu_baseline"] = {"tactile_assign_ms_per_lattice_scaled": 1e3 * (time.perf_counter() - t0) * 64, "cores": 1, "kind": "port",
+                               "sample": "1/64 of the 256^3 lattice, oracle.tactile_assign_nearest (numpy cdist rule); decode / encode / marching cubes: "
+                                         "the headline's cpu_baseline.stages_ms at 128^3"}
+    except Exception as e:                                                 # noqa: BLE001
+        res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return res
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 
 def main():
@@ -531,6 +758,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-only", action="store_true", help="only the decode metric (perf experiments)")
     ap.add_argument("--no-train", action="store_true", help="skip the config-4 training-step section")
+    ap.add_argument("--no-configs35", action="store_true", help="skip the config-3 (full VTacO, 128^3) and config-5 (VTacOH route, 256^3) sections")
     ap.add_argument("--train-scenes", type=int, default=8, help="scenes per GPU of the training-step section (config 4: 8)")
     ap.add_argument("--train-steps", type=int, default=8, help="timed steps of the training-step section")
     ap.add_argument("--sharded-sizes", default="128,256", help="lattice sizes of the sharded-scene section (config 5: 128,256)")
@@ -710,6 +938,16 @@ def main():
             tr = None if args.no_train else train_step_section(dev, fx, rank, world, dist, steps=args.train_steps, scenes=args.train_scenes)
             if rank == 0 and tr is not None:
                 res["train_step"] = tr
+            if world == 1 and not args.no_configs35:
+                # BASELINE configs 3 and 5 on one GPU (each in its own try: one failing must not lose the other)
+                for key, fn in (("config3", config3_section), ("config5", config5_section)):
+                    try:
+                        t0 = time.perf_counter()
+                        res[key] = fn(dev, args.precision)
+                        res[key]["section_s"] = time.perf_counter() - t0
+                    except Exception as e:                                   # noqa: BLE001 -- reported in the line
+                        res[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+                    torch.cuda.empty_cache()
         except Exception as e:                                           # noqa: BLE001 -- reported in the line
             if rank == 0:
                 res["extras_error"] = f"{type(e).__name__}: {e}"[:400]

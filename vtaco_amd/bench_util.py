@@ -177,3 +177,64 @@ def build_train_case(device, rank=0, scenes=8, num_sample=2048, n_points=8192, g
         # page-locked host tensors, as a DataLoader(pin_memory=True) hands them over (50 MB of images and depths per step)
         batch = {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in batch.items()}
     return model, trainer, batch, {"ico": {"v": verts, "f": faces}}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs 3 and 5: ONE synthetic scene for Generator3D's tactile routes (generate_obj_mesh_wnf with_img):
+# VTacO / t2d (contact clouds from the depth images, generation.py:202-257) and VTacOH (fingertips from the hand encoder's
+# MANO joints, generation.py:161-200).  Shapes of configs/VTacO/VTacO_YCB.yaml / VTacOH_YCB.yaml and SURVEY.md Appendix B.
+# ---------------------------------------------------------------------------------------------------------------------
+
+def build_tactile_scene(device, variant="vtaco", decoder="simple_local", seed=0):
+    """(model, data, depth_origin): the shipped VTacO (``variant="vtaco"``: encoder_t2d present) or VTacOH model section built by
+    ``get_model`` on a synthetic MANO-format asset, with ``decoder`` 'simple_local' (tactile concat, what the shipped configs use) or
+    'attention_local' (TransformerFusion, BASELINE config 3's decoder; c_dim = hidden = 32), and one scene's sample dictionary with
+    the keys the reference generator reads (generation.py:123-143).  The wrist of the VTacOH sample is placed so that the predicted
+    fingertips lie on the object (the synthetic pose is arbitrary); the VTacO sample's sensors look at the sphere from 0.32."""
+    import tempfile
+
+    import numpy as np
+
+    from . import synth_mano
+    from .common import fingertips_in_object_frame
+    from .conv_onet import config as cfgmod
+    root = tempfile.mkdtemp(prefix="vt_mano_")
+    synth_mano.write_pkl(synth_mano.make_asset(0), root)
+    cfg = vtaco_cfg(root)
+    m = cfg["model"]
+    m["decoder"] = decoder
+    if variant == "vtacoh":
+        m["encoder_t2d"] = False
+        m.pop("encoder_t2d_kwargs")
+    torch.manual_seed(0)
+    model = cfgmod.get_model(cfg, device=device).eval()
+    randomise_fc1(model.decoder, 1)
+    randomise_fc1(model.encoder, 2)
+    H, W = 320, 240
+    depth_origin = np.full(H * W, 0.02, dtype=np.float64)
+    g = torch.Generator().manual_seed(7000 + seed)
+    cloud = sphere_cloud(seed)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    depth = torch.full((1, 5, H * W), 0.02)
+    touch = torch.tensor([[1, 1, 0, 1, 1]], dtype=torch.uint8)
+    for t in range(5):
+        if touch[0, t]:
+            cy, cx = int(torch.randint(60, H - 60, (1,), generator=g)), int(torch.randint(60, W - 60, (1,), generator=g))
+            disc = ((yy - cy) ** 2 + (xx - cx) ** 2) < 12 ** 2
+            depth[0, t][disc.reshape(-1)] = 0.02 - 0.002 * torch.rand(int(disc.sum()), generator=g) - 0.0005
+    d = torch.randn(1, 5, 3, generator=g)
+    data = {"inputs": cloud, "inputs.pc_ply": cloud.clone(), "inputs.img": torch.rand(1, 5, 3, H, W, generator=g) / 255.0,
+            "inputs.depth": depth, "inputs.touch_success": touch,
+            "points.cam_pos": (0.32 * d / d.norm(dim=-1, keepdim=True)).double(),
+            "points.cam_rot": (torch.rand(1, 5, 3, generator=g) * 2 - 1).double(),
+            "points.mano": torch.zeros(1, 51), "points.wrist": torch.zeros(1, 3)}
+    if variant == "vtacoh":
+        with torch.no_grad():
+            joints = model.encode_hand_inputs(cloud.to(device))["mano_joints"].float().cpu().numpy()
+        pc = cloud.numpy()
+        scale = 2 * np.max(np.sqrt(np.sum((pc[0] - pc[0].mean(0)) ** 2, axis=1)))
+        tips0 = fingertips_in_object_frame(joints, np.zeros((1, 3)), data["points.wrist"].numpy(), pc)
+        # the tips' centroid goes onto the cloud the encoder sees (the sphere of radius 0.3)
+        target = np.array([0.3, 0.0, 0.0])
+        data["points.mano"][0, :3] = torch.from_numpy((target - tips0[0].mean(0)) * scale).float()
+    return model, data, depth_origin
