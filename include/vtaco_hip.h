@@ -868,6 +868,63 @@ int vt_mano_bwd(const float *pose, int B, const float *blob, int center_idx, con
                 float *dpose, void *stream);
 
 /* ------------------------------------------------------------------------- */
+/* The hand encoder's 2-D U-Net over its feature planes.    */
+/* Replaces: UNet.forward (src/encoder/unet.py:220-233: DownConv :52-79,         */
+/*   UpConv :82-120, conv_final) as LocalPoolPointnet builds and calls it         */
+/*   (src/encoder/pointnet.py:49-50, 96-99): UNet(c_dim, in_channels=c_dim,        */
+/*   depth, start_filts, merge_mode 'concat', up_mode 'transpose') on the planes   */
+/*   [B, c_dim, R, R] of a scene -- here on n_img images at once (the net has no   */
+/*   cross-image operation): x [n_img][in_channels][H][W] -> out [n_img][classes]  */
+/*   [H][W], both NCHW like the reference's tensors.                               */
+/* One launch per layer of ONE kernel template (implicit GEMM on the f32 matrix     */
+/*   core: a workgroup per 32 pixels x 32 output channels, K split over its waves); */
+/*   bias + ReLU in the epilogue, the 2x2 max-pool and the skip concat in the next  */
+/*   layer's loader (no pass of their own).  Weights in nn.Conv2d /                 */
+/*   nn.ConvTranspose2d layout; vt_plane_unet_pack lays them out in fragment order */
+/*   (blob of vt_plane_unet_blob_bytes; repack after every weight update).         */
+/* Covered (vt_plane_unet_supported): depth 2..5; in_channels, start_filts and     */
+/*   num_classes multiples of 32; H, W powers of two with at least 4 x 4 pixels at */
+/*   the bottom level.  After the call the workspace holds every layer's           */
+/*   channels-last activations: vt_plane_unet_bwd reads them (the training forward */
+/*   is this same call).                                                           */
+/* ------------------------------------------------------------------------- */
+#define VT_PLANE_UNET_MAX_DEPTH 5
+typedef struct vt_plane_unet_params {
+    int32_t depth, in_channels, start_filts, num_classes;
+    const float *down_w[VT_PLANE_UNET_MAX_DEPTH][2];   /* down_convs.{l}.conv{1,2}.weight [Cout][Cin][3][3] */
+    const float *down_b[VT_PLANE_UNET_MAX_DEPTH][2];
+    const float *up_tw[VT_PLANE_UNET_MAX_DEPTH];        /* up_convs.{u}.upconv.weight [Cin][Cout][2][2]      */
+    const float *up_tb[VT_PLANE_UNET_MAX_DEPTH];
+    const float *up_w[VT_PLANE_UNET_MAX_DEPTH][2];      /* up_convs.{u}.conv{1,2}.weight                     */
+    const float *up_b[VT_PLANE_UNET_MAX_DEPTH][2];
+    const float *final_w, *final_b;                     /* conv_final [classes][start_filts][1][1]           */
+} vt_plane_unet_params;
+int vt_plane_unet_supported(int depth, int in_channels, int start_filts, int num_classes, int H, int W);
+size_t vt_plane_unet_blob_bytes(int depth, int in_channels, int start_filts, int num_classes);
+size_t vt_plane_unet_workspace_bytes(int depth, int in_channels, int start_filts, int num_classes, int n_img, int H, int W);
+int vt_plane_unet_pack(const vt_plane_unet_params *params_host, float *blob, size_t blob_bytes, void *stream);
+int vt_plane_unet_fwd(const float *x, int n_img, int H, int W, const vt_plane_unet_params *dims_host, const float *blob,
+                      void *workspace, size_t workspace_bytes, float *out, void *stream);
+/* Backward of vt_plane_unet_fwd (PyTorch autograd through UNet.forward under the hand encoder's losses, loss_mano / loss_pc,   */
+/* src/conv_onet/training.py:59-60, 79-96): from dout [n_img][classes][H][W], the input x, the packed weights and the forward's   */
+/* workspace (its activations) -> dx [n_img][in_channels][H][W] and the gradient of every weight and bias in the parameter's own   */
+/* layout (vt_plane_unet_grads: the pointers of vt_plane_unet_params, written, not accumulated).  Per layer, in reverse: one       */
+/* data-gradient launch of the forward's kernel template (mirrored taps, transposed weights: the second half of the blob) whose     */
+/* loader assembles the layer's output gradient from what its consumers left -- the skip concat's and the pooled path's sum, the     */
+/* max-pool's routing to the window's first maximum, the ReLU mask -- and one weight-gradient launch (pixels as K, partial sums per   */
+/* pixel slice); one finalize launch sums the slices.  Every sum in a fixed order: bit-reproducible.                                   */
+typedef struct vt_plane_unet_grads {
+    float *down_w[VT_PLANE_UNET_MAX_DEPTH][2], *down_b[VT_PLANE_UNET_MAX_DEPTH][2];
+    float *up_tw[VT_PLANE_UNET_MAX_DEPTH], *up_tb[VT_PLANE_UNET_MAX_DEPTH];
+    float *up_w[VT_PLANE_UNET_MAX_DEPTH][2], *up_b[VT_PLANE_UNET_MAX_DEPTH][2];
+    float *final_w, *final_b;
+} vt_plane_unet_grads;
+size_t vt_plane_unet_bwd_workspace_bytes(int depth, int in_channels, int start_filts, int num_classes, int n_img, int H, int W);
+int vt_plane_unet_bwd(const float *x, int n_img, int H, int W, const vt_plane_unet_params *dims_host, const float *blob,
+                      const void *fwd_workspace, const float *dout, void *workspace, size_t workspace_bytes,
+                      const vt_plane_unet_grads *grads_host, float *dx, void *stream);
+
+/* ------------------------------------------------------------------------- */
 /* PointNet per-point MLP (inference).  Replaces the nn.Linear / ResnetBlockFC   */
 /* calls of LocalPoolPointnet.forward (src/encoder/pointnet.py:154-162;           */
 /* src/layers.py:8-50): rows are points, weights in nn.Linear layout [out][in].   */

@@ -203,5 +203,5 @@ if "hand" in SECTIONS:
             t_m = timed(lambda: henc.mano_layer(pose), 100, 10)
             print(json.dumps({"workload": f"MANO layer (vt_mano_fwd), {Bh} hands", "ms": t_m * 1e3, "hands_per_s": Bh / t_m,
                               "gflops": 0.95e-3 * Bh / t_m}))
-    print(json.dumps({"workload": "hand encoder: 3000 pts -> 3 planes @32^2 -> U-Net (depth 4, 32 filters, MIOpen) -> MANO",
+    print(json.dumps({"workload": "hand encoder: 3000 pts -> 3 planes @32^2 -> U-Net (depth 4, 32 filters, vt_plane_unet_fwd: 18 launches) -> MANO",
                       "ms": t_enc * 1e3, "plane_build_x3_ms": t_idx * 1e3, "pool_max_x3_ms": t_pool * 1e3}))

@@ -74,6 +74,26 @@ class UnetParams(ctypes.Structure):
                 ("final_packed_f16x3", ctypes.c_void_p)]
 
 
+VT_PLANE_UNET_MAX_DEPTH = 5
+
+
+class PlaneUnetParams(ctypes.Structure):
+    """Mirror of ``vt_plane_unet_params``."""
+    _fields_ = [("depth", ctypes.c_int32), ("in_channels", ctypes.c_int32), ("start_filts", ctypes.c_int32), ("num_classes", ctypes.c_int32),
+                ("down_w", (ctypes.c_void_p * 2) * VT_PLANE_UNET_MAX_DEPTH), ("down_b", (ctypes.c_void_p * 2) * VT_PLANE_UNET_MAX_DEPTH),
+                ("up_tw", ctypes.c_void_p * VT_PLANE_UNET_MAX_DEPTH), ("up_tb", ctypes.c_void_p * VT_PLANE_UNET_MAX_DEPTH),
+                ("up_w", (ctypes.c_void_p * 2) * VT_PLANE_UNET_MAX_DEPTH), ("up_b", (ctypes.c_void_p * 2) * VT_PLANE_UNET_MAX_DEPTH),
+                ("final_w", ctypes.c_void_p), ("final_b", ctypes.c_void_p)]
+
+
+class PlaneUnetGrads(ctypes.Structure):
+    """Mirror of ``vt_plane_unet_grads``."""
+    _fields_ = [("down_w", (ctypes.c_void_p * 2) * VT_PLANE_UNET_MAX_DEPTH), ("down_b", (ctypes.c_void_p * 2) * VT_PLANE_UNET_MAX_DEPTH),
+                ("up_tw", ctypes.c_void_p * VT_PLANE_UNET_MAX_DEPTH), ("up_tb", ctypes.c_void_p * VT_PLANE_UNET_MAX_DEPTH),
+                ("up_w", (ctypes.c_void_p * 2) * VT_PLANE_UNET_MAX_DEPTH), ("up_b", (ctypes.c_void_p * 2) * VT_PLANE_UNET_MAX_DEPTH),
+                ("final_w", ctypes.c_void_p), ("final_b", ctypes.c_void_p)]
+
+
 # name -> (restype, argtypes); kept in step with include/vtaco_hip.h (tests/test_abi.py
 # parses the header and checks that every declared symbol is exported and listed here)
 _VP, _I, _I64, _F, _D, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_size_t
@@ -171,6 +191,13 @@ SIGNATURES = {
     "vt_plane_build": (_I, [_VP, _I, _I, _I, _D, _I, _VP, _VP, _VP, _VP, _VP]),
     "vt_plane_scatter_mean_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "vt_plane_scatter_mean_bwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
+    "vt_plane_unet_supported": (_I, [_I, _I, _I, _I, _I, _I]),
+    "vt_plane_unet_blob_bytes": (_SZ, [_I, _I, _I, _I]),
+    "vt_plane_unet_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I, _I]),
+    "vt_plane_unet_pack": (_I, [ctypes.POINTER(PlaneUnetParams), _VP, _SZ, _VP]),
+    "vt_plane_unet_fwd": (_I, [_VP, _I, _I, _I, ctypes.POINTER(PlaneUnetParams), _VP, _VP, _SZ, _VP, _VP]),
+    "vt_plane_unet_bwd_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I, _I]),
+    "vt_plane_unet_bwd": (_I, [_VP, _I, _I, _I, ctypes.POINTER(PlaneUnetParams), _VP, _VP, _VP, _VP, _SZ, ctypes.POINTER(PlaneUnetGrads), _VP, _VP]),
     "vt_mano_pack": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vt_mano_pack_side": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP]),
     "vt_mano_fwd": (_I, [_VP, _I, _VP, _I, _VP, _VP, _VP]),

@@ -1,16 +1,47 @@
 """2-D U-Net over the hand encoder's 32x32 (or 64x64) feature planes (drop-in for reference
 src/encoder/unet.py:52-233; built by LocalPoolPointnet when ``unet: True``, pointnet.py:49-50).
 
-Host PyTorch-ROCm (MIOpen) convolutions: three 32^2 planes per scene are 0.3 GFLOP, three orders of
-magnitude below the UNet3D next to it, so this stays plumbing like the tactile U-Net.
+On a HIP device the shipped shapes (concat merge, transposed-conv upsampling, channel counts multiples of 32, power-of-two
+planes: ``ops.plane_unet_supported``) run as ONE persistent launch, ``vt_plane_unet_fwd`` (csrc/plane_unet.hip: every conv a phase
+of the kernel, bias / ReLU / max-pool / concat in the consuming phase's loader); other configurations (``up_mode='upsample'``,
+``merge_mode='add'``, odd channel counts) keep the nn.Conv2d modules below (host PyTorch-ROCm / MIOpen).
 Parameter names follow the reference checkpoint: ``down_convs.{i}.conv{1,2}``,
 ``up_convs.{i}.{upconv,conv1,conv2}``, ``conv_final``.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
+
+from .. import ops
+
+# A/B knob: "0" keeps the nn.Conv2d modules (MIOpen) on every shape
+_HIP_UNET = os.environ.get("VTACO_PLANE_UNET", "1") != "0"
+# A/B knob: "host" trains through the nn.Conv2d modules' autograd (MIOpen) while inference stays on the HIP kernel
+_HIP_UNET_TRAIN = os.environ.get("VTACO_PLANE_UNET_TRAIN", "hip") != "host"
+
+
+class _PlaneUNetFn(torch.autograd.Function):
+    """UNet.forward under autograd on the HIP kernels: vt_plane_unet_fwd with its workspace kept, vt_plane_unet_bwd.  ``params`` = the
+    net's parameters in ``named_parameters()`` order (so autograd hands the gradients back to them)."""
+
+    @staticmethod
+    def forward(ctx, x, net, *params):
+        blob = net._blob()
+        ws = ops.plane_unet_workspace(net, x.shape[0], x.shape[2], x.shape[3], fresh=True)
+        out = ops.plane_unet_fwd(x, net, blob, ws)
+        ctx.net, ctx.blob, ctx.ws = net, blob, ws
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, = ctx.saved_tensors
+        dx, grads = ops.plane_unet_bwd(x, ctx.net, ctx.blob, ctx.ws, dout)
+        return (dx, None) + tuple(grads[name] for name, _ in ctx.net.named_parameters())
 
 
 class DownConv(nn.Module):
@@ -80,7 +111,29 @@ class UNet(nn.Module):
                 nn.init.xavier_normal_(m.weight)
                 nn.init.constant_(m.bias, 0)
 
+    def hip_supported(self, x):
+        return (_HIP_UNET and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and self.up_mode == "transpose"
+                and self.merge_mode == "concat" and ops.plane_unet_supported(self, x.shape[2], x.shape[3]))
+
+    def _blob(self):
+        """The packed weights, repacked when a parameter changed (storage or version)."""
+        stamp = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        hit = getattr(self, "_blob_cache", None)
+        if hit is None or hit[0] != stamp:
+            hit = self._blob_cache = (stamp, ops.plane_unet_pack(self))
+        return hit[1]
+
     def forward(self, x):
+        if self.hip_supported(x):
+            if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+                if _HIP_UNET_TRAIN:
+                    return _PlaneUNetFn.apply(x, self, *self.parameters())
+                return self.forward_modules(x)
+            return ops.plane_unet_fwd(x, self, self._blob())
+        return self.forward_modules(x)
+
+    def forward_modules(self, x):
+        """The nn.Conv2d modules one by one (host PyTorch-ROCm / MIOpen): shapes the HIP kernel does not cover."""
         skips = []
         for down in self.down_convs:
             x, skip = down(x)

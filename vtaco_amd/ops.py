@@ -1807,3 +1807,124 @@ def decode_fwd_ids(grid, blob, ids, feats, pts=None, lattice=None, padding=0.1, 
                                         dev_ptr(feats, "feats"), feats.shape[0], dev_ptr(blob, "blob"), float(padding),
                                         dev_ptr(out, "out"), stream_ptr()), "vt_decode_fwd_ids")
     return out
+
+
+# ---- the hand encoder's 2-D U-Net as one persistent launch (plane_unet.hip) --------------------------------------------
+
+def plane_unet_params(net):
+    """(PlaneUnetParams, tensors it points to) of an ``encoder.unet.UNet`` (depth, channel counts, nn.Conv2d / nn.ConvTranspose2d
+    weights in their own layout)."""
+    prm = _lib.PlaneUnetParams()
+    prm.depth, prm.in_channels, prm.start_filts, prm.num_classes = net.depth, net.in_channels, net.start_filts, net.num_classes
+    keep = []
+
+    def ptr(t, name):
+        t = t.detach()
+        if not t.is_contiguous():
+            t = t.contiguous()
+        keep.append(t)
+        return dev_ptr(t, name).value
+    for l, d in enumerate(net.down_convs):
+        for k, conv in enumerate((d.conv1, d.conv2)):
+            prm.down_w[l][k], prm.down_b[l][k] = ptr(conv.weight, "down conv weight"), ptr(conv.bias, "down conv bias")
+    for u, up in enumerate(net.up_convs):
+        prm.up_tw[u], prm.up_tb[u] = ptr(up.upconv.weight, "upconv weight"), ptr(up.upconv.bias, "upconv bias")
+        for k, conv in enumerate((up.conv1, up.conv2)):
+            prm.up_w[u][k], prm.up_b[u][k] = ptr(conv.weight, "up conv weight"), ptr(conv.bias, "up conv bias")
+    prm.final_w, prm.final_b = ptr(net.conv_final.weight, "conv_final.weight"), ptr(net.conv_final.bias, "conv_final.bias")
+    return prm, keep
+
+
+def plane_unet_supported(net, H, W):
+    return bool(_lib.load().vt_plane_unet_supported(net.depth, net.in_channels, net.start_filts, net.num_classes, int(H), int(W)))
+
+
+def plane_unet_pack(net):
+    """The net's weights in fragment order + its biases: the blob vt_plane_unet_fwd reads (vt_plane_unet_pack)."""
+    lib = _lib.load()
+    n = lib.vt_plane_unet_blob_bytes(net.depth, net.in_channels, net.start_filts, net.num_classes)
+    if n == 0:
+        raise VtError("plane U-Net shape not built: depth 2..5, in_channels / start_filts / num_classes multiples of 32")
+    prm, keep = plane_unet_params(net)
+    blob = torch.empty(n // 4, dtype=torch.float32, device=keep[0].device)
+    check(lib.vt_plane_unet_pack(ctypes.byref(prm), dev_ptr(blob, "blob"), n, stream_ptr()), "vt_plane_unet_pack")
+    return blob
+
+
+_plane_unet_ws = {}    # (device, dims, images, H, W) -> workspace (every phase's activations)
+
+
+def plane_unet_workspace(net, n_img, H, W, fresh=False):
+    """Workspace of vt_plane_unet_fwd (every phase's channels-last activations).  Inference calls share one per shape (torch's current
+    stream orders them); ``fresh`` makes a new one (the training forward keeps it for the backward)."""
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    key = (dev.index, net.depth, net.in_channels, net.start_filts, net.num_classes, int(n_img), int(H), int(W))
+    if not fresh and key in _plane_unet_ws:
+        ws = _plane_unet_ws[key]
+        keep_for_graph(ws)
+        return ws
+    n = lib.vt_plane_unet_workspace_bytes(net.depth, net.in_channels, net.start_filts, net.num_classes, int(n_img), int(H), int(W))
+    if n == 0:
+        raise VtError("plane U-Net shape not built (vt_plane_unet_supported)")
+    ws = torch.empty(n, dtype=torch.uint8, device=dev)
+    if not fresh:
+        if len(_plane_unet_ws) >= 8:
+            _plane_unet_ws.pop(next(iter(_plane_unet_ws)))
+        _plane_unet_ws[key] = ws
+    keep_for_graph(ws)
+    return ws
+
+
+def plane_unet_fwd(x, net, blob, ws=None):
+    """UNet.forward on the HIP kernel: x [n_img, in_channels, H, W] -> [n_img, num_classes, H, W] (vt_plane_unet_fwd)."""
+    x = _c(x)
+    n_img, C, H, W = x.shape
+    if C != net.in_channels:
+        raise VtError(f"plane_unet_fwd: input has {C} channels, the net takes {net.in_channels}")
+    if ws is None:
+        ws = plane_unet_workspace(net, n_img, H, W)
+    prm = _lib.PlaneUnetParams()
+    prm.depth, prm.in_channels, prm.start_filts, prm.num_classes = net.depth, net.in_channels, net.start_filts, net.num_classes
+    out = torch.empty((n_img, net.num_classes, H, W), dtype=torch.float32, device=x.device)
+    keep_for_graph(blob)
+    check(_lib.load().vt_plane_unet_fwd(dev_ptr(x, "x"), n_img, H, W, ctypes.byref(prm), dev_ptr(blob, "blob"),
+                                        ctypes.c_void_p(ws.data_ptr()), ws.numel(), dev_ptr(out, "out"), stream_ptr()), "vt_plane_unet_fwd")
+    return out
+
+
+def plane_unet_bwd(x, net, blob, fwd_ws, dout):
+    """Backward of plane_unet_fwd (vt_plane_unet_bwd): (dx, {parameter name: gradient}) from dout, the input, the packed weights and the
+    workspace the forward filled.  Gradients are written, not accumulated."""
+    lib = _lib.load()
+    x, dout = _c(x), _c(dout)
+    n_img, C, H, W = x.shape
+    n = lib.vt_plane_unet_bwd_workspace_bytes(net.depth, net.in_channels, net.start_filts, net.num_classes, n_img, H, W)
+    if n == 0:
+        raise VtError("plane U-Net shape not built (vt_plane_unet_supported)")
+    ws = torch.empty(n, dtype=torch.uint8, device=x.device)
+    prm = _lib.PlaneUnetParams()
+    prm.depth, prm.in_channels, prm.start_filts, prm.num_classes = net.depth, net.in_channels, net.start_filts, net.num_classes
+    g = _lib.PlaneUnetGrads()
+    grads = {}
+
+    def buf(name, like):
+        t = torch.empty(like.shape, dtype=torch.float32, device=x.device)
+        grads[name] = t
+        return dev_ptr(t, name).value
+    for l, d in enumerate(net.down_convs):
+        for k, cname in enumerate(("conv1", "conv2")):
+            conv = getattr(d, cname)
+            g.down_w[l][k], g.down_b[l][k] = buf(f"down_convs.{l}.{cname}.weight", conv.weight), buf(f"down_convs.{l}.{cname}.bias", conv.bias)
+    for u, up in enumerate(net.up_convs):
+        g.up_tw[u], g.up_tb[u] = buf(f"up_convs.{u}.upconv.weight", up.upconv.weight), buf(f"up_convs.{u}.upconv.bias", up.upconv.bias)
+        for k, cname in enumerate(("conv1", "conv2")):
+            conv = getattr(up, cname)
+            g.up_w[u][k], g.up_b[u][k] = buf(f"up_convs.{u}.{cname}.weight", conv.weight), buf(f"up_convs.{u}.{cname}.bias", conv.bias)
+    g.final_w, g.final_b = buf("conv_final.weight", net.conv_final.weight), buf("conv_final.bias", net.conv_final.bias)
+    dx = torch.empty_like(x)
+    check(lib.vt_plane_unet_bwd(dev_ptr(x, "x"), n_img, H, W, ctypes.byref(prm), dev_ptr(blob, "blob"), ctypes.c_void_p(fwd_ws.data_ptr()),
+                                dev_ptr(dout, "dout"), ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.byref(g), dev_ptr(dx, "dx"),
+                                stream_ptr()), "vt_plane_unet_bwd")
+    return dx, grads
+
