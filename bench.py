@@ -685,10 +685,10 @@ def config3_section(dev, precision, nx=128):
         dt = time.perf_counter() - t0
         cpu["attention_decoder_ms_per_lattice_scaled"] = 1e3 * dt * chunks / k
         cpu["attention_decoder_sample"] = f"{k} of {chunks} chunks of {N} points, oracle.attention_decoder_forward_img (torch CPU f32)"
-        anchors, count = setup["anchors"].double().numpy(), setup["count"].numpy()
+        anchors, count = setup["anchors"].double().cpu().numpy(), setup["count"].cpu().numpy()
         sub = pts[:npts // 64].numpy()
         t0 = time.perf_counter()
-        orc.tactile_assign_within(sub, anchors, count, setup["success"].numpy())
+        orc.tactile_assign_within(sub, anchors, count, setup["success"].cpu().numpy())
         cpu["tactile_assign_ms_per_lattice_scaled"] = 1e3 * (time.perf_counter() - t0) * 64
         cpu["tactile_assign_sample"] = "1/64 of the lattice, oracle.tactile_assign_within (numpy cdist rule, one thread)"
         res["cpu_baseline"] = cpu
@@ -730,9 +730,9 @@ def config5_section(dev, precision, nx=256):
     try:
         from oracle import vtaco_oracle as orc
         pts = (1.1 * orc.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (nx,) * 3))[:nx ** 3 // 64].numpy()
-        tips = setup["anchors"][:, 0].double().numpy()
+        tips = setup["anchors"][:, 0].double().cpu().numpy()
         t0 = time.perf_counter()
-        orc.tactile_assign_nearest(pts, tips, setup["success"].numpy(), radius=0.05)
+        orc.tactile_assign_nearest(pts, tips, setup["success"].cpu().numpy(), radius=0.05)
         res["cpu_baseline"] = {"tactile_assign_ms_per_lattice_scaled": 1e3 * (time.perf_counter() - t0) * 64, "cores": 1, "kind": "port",
                                "sample": "1/64 of the 256^3 lattice, oracle.tactile_assign_nearest (numpy cdist rule); decode / encode / marching cubes: "
                                          "the headline's cpu_baseline.stages_ms at 128^3"}

@@ -988,6 +988,29 @@ int vt_resblock_wgrad(const float *x1, int C1, const float *x2, int C2, int64_t 
 /*   verts [V,3] f32, faces [F,3] i32, pts [N,3] f32 -> out [N] f32.                    */
 /* ------------------------------------------------------------------------- */
 int vt_winding_number(const float *verts, int V, const int32_t *faces, int F, const float *pts, int64_t N, float *out, void *stream);
+/* The same for a batch of scenes in ONE launch (the reference loops over the batch, training.py:723, 862): scenes = device array of  */
+/* B records {const float *verts; const int32_t *faces; int32 V; int32 F} (24 bytes each, the meshes anywhere in device memory), */
+/* pts [B][N][3], out [B][N].                                                                                                     */
+int vt_winding_number_scenes(const void *scenes, int B, const float *pts, int64_t N, float *out, void *stream);
+
+/* Contact clouds of the tactile sensors from their depth images (SURVEY.md section 8f "next" row 2: the training side).          */
+/* Replaces: the per-scene, per-sensor numpy passes of src/conv_onet/training.py:817-853 and generation.py:224-244               */
+/*   (np.where(abs(depth - depth_origin) > 1e-4), depth_2_camera_pointcloud, np.random.randint, pc_cam_to_world, norm_pc_1).        */
+/* vt_contact_scan: depth [n_images][n_pixels] f32, depth_origin [n_pixels] f64 (the sensor's flat reading), touch_success          */
+/*   [n_images] u8 or NULL -> index [n_images][n_pixels] i32 (the touched pixels in ascending order = np.where's) and count         */
+/*   [n_images]; the comparison in float64 as numpy's.  The host reads the counts, draws np.random.randint(count, size=128) where a  */
+/*   count exceeds 128 (the draws stay on the host: a seeded run consumes numpy's generator as the reference does) and inverts the   */
+/*   4 x 4 camera poses.                                                                                                             */
+/* vt_contact_points: per image kept[i] points (all `count` in order when sel is NULL, else index[sel[i][j]]), pose [n_images][16]  */
+/*   f64 = {inverse pose's 3x3 row-major, translation 3, cloud centroid 3, cloud scale 1}: pinhole unprojection (f = height /        */
+/*   (2 tan(fov / 2)), principal point at the centre, axes (z, -x, -y)), world = M cam + t, (world - centroid) / scale in float64,    */
+/*   written as float32 rows row0[i] .. row0[i] + kept[i] of scene i / 5 in p_sample [B][S][3] (finger [B][S] i64 gets i % 5; may be  */
+/*   NULL).  n_images = 5 B.                                                                                                          */
+int vt_contact_scan(const float *depth, const double *depth_origin, const unsigned char *touch_success, int n_images, int n_pixels,
+                    double threshold, int *index, int *count, void *stream);
+int vt_contact_points(const float *depth, const int *index, const int *sel, const int *kept, const int *row0, const double *pose,
+                      int n_images, int n_pixels, int width, int height, double fov_deg, int max_points, int S,
+                      float *p_sample, long long *finger, void *stream);
 
 #ifdef __cplusplus
 }

@@ -445,3 +445,63 @@ def test_trainer_train_tactile_step():
     assert len(first) == 3 and last[0] < first[0]
     model.encoder_hand = None
     assert len(Trainer(model, torch.optim.Adam(model.parameters(), lr=1e-3), device=dev, train_tactile=True).train_step(data)) == 2
+
+
+def test_contact_clouds_on_the_device_equal_the_host_rule():
+    """vt_contact_scan + vt_contact_points against ``contact_clouds_from_depth`` (the reference's numpy rule, pinned by g12 / g13):
+    the touched pixels (count and order), the same ``randint`` draws under the same seed, the points to float32 rounding -- on the
+    g12 fixture's real depth images and on synthetic ones with more than 128 touched pixels and an untouched sensor."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from vtaco_amd import ops
+    from vtaco_amd.common import contact_clouds_from_depth, contact_clouds_on_device
+    z = np.load(os.path.join(GOLDEN, "g12_t2d.npz"))
+    H, W = 320, 240
+    g = torch.Generator().manual_seed(3)
+    cases = [(z["depths"][None].astype(np.float32), z["depth_origin"].astype(np.float64), z["cam_pos"].astype(np.float64),
+              z["cam_rot"].astype(np.float64), z["pc_ply"].astype(np.float32), np.asarray(z["touch"]).reshape(1, 5))]
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    depth = torch.full((3, 5, H * W), 0.02)
+    for b in range(3):
+        for t in range(5):
+            r = (4, 9, 15, 30, 2)[(b + t) % 5]
+            disc = ((yy - 60 - 40 * t) ** 2 + (xx - 50 - 30 * b) ** 2) < r * r
+            depth[b, t][disc.reshape(-1)] = 0.02 - 0.002 * torch.rand(int(disc.sum()), generator=g) - 0.0005
+    d = torch.randn(3, 5, 3, generator=g)
+    touch = np.array([[1, 1, 0, 1, 1], [1, 0, 1, 1, 1], [1, 1, 1, 1, 0]], dtype=np.uint8)
+    cases.append((depth.numpy(), np.full(H * W, 0.02), (0.32 * d / d.norm(dim=-1, keepdim=True)).double().numpy(),
+                  (torch.rand(3, 5, 3, generator=g) * 2 - 1).double().numpy(), (torch.randn(3, 500, 3, generator=g) * 0.2).numpy(), touch))
+    for depths, origin, cam_pos, cam_rot, pc_ply, touch in cases:
+        B, S, N = depths.shape[0], 1024, 4000
+        p_host = torch.rand(B, N, 3, generator=g).numpy()
+        state = np.random.get_state()
+        try:
+            np.random.seed(21)
+            ref = np.zeros((B, S, 3), dtype=np.float32)
+            ref_f = np.full((B, S), -1, dtype=np.int64)
+            for b in range(B):
+                anchors, count = contact_clouds_from_depth(depths[b], origin, cam_pos[b], cam_rot[b], pc_ply[b], touch[b])
+                k = 0
+                for t in range(5):
+                    if touch[b][t]:
+                        n = int(count[t])
+                        ref[b, k:k + n], ref_f[b, k:k + n] = anchors[t, :n].astype(np.float32), t
+                        k += n
+                ref[b, k:] = p_host[b][np.random.randint(N, size=S - k)]
+            np.random.seed(21)
+            buf = np.zeros((B, S, 3), dtype=np.float32)
+            got, got_f = contact_clouds_on_device(torch.from_numpy(depths).to(DEV), torch.from_numpy(origin).to(DEV), cam_pos, cam_rot, pc_ply,
+                                                  touch, buf, p_host, S)
+            after = np.random.randint(1 << 30)                           # ... and both consumed the generator equally
+            np.random.seed(21)
+            for b in range(B):
+                contact_clouds_from_depth(depths[b], origin, cam_pos[b], cam_rot[b], pc_ply[b], touch[b])
+                np.random.randint(N, size=S - int((ref_f[b] >= 0).sum()))
+            assert after == np.random.randint(1 << 30)
+        finally:
+            np.random.set_state(state)
+        assert np.array_equal(got_f, ref_f) and int((ref_f >= 0).sum()) > 20
+        err = np.abs(got.cpu().numpy() - ref)
+        assert float(err.max()) <= 1e-6 * max(1.0, float(np.abs(ref).max())), float(err.max())
+        assert float((err > 0).mean()) < 0.01                               # float64 arithmetic in the same order: equal but for rare ties

@@ -179,6 +179,9 @@ SIGNATURES = {
     "vt_voxel_scatter_mean_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "vt_voxel_scatter_mean_bwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "vt_winding_number": (_I, [_VP, _I, _VP, _I, _VP, _I64, _VP, _VP]),
+    "vt_winding_number_scenes": (_I, [_VP, _I, _VP, _I64, _VP, _VP]),
+    "vt_contact_scan": (_I, [_VP, _VP, _VP, _I, _I, _D, _VP, _VP, _VP]),
+    "vt_contact_points": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _D, _I, _I, _VP, _VP, _VP]),
     "vt_linear_rows": (_I, [_VP, _VP, _VP, _I64, _I, _I, _VP, _VP]),
     "vt_resblock_fc": (_I, [_VP, _I, _VP, _I, _I64, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
     "vt_pointnet_mlp_stat_blocks": (_I, [_I, _I]),

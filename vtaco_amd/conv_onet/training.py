@@ -17,6 +17,8 @@ at model level (``model.decode_img(p, c, c_img)``) or as finger ids (``vt_tactil
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 from torch.nn import functional as F
@@ -24,6 +26,10 @@ from torch.nn import functional as F
 from .._lib import VtError
 from ..common import fingertips_in_object_frame
 from ..eval import compute_iou
+
+
+# A/B knob: "host" keeps the contact clouds of the VTacO step on the host (numpy, the reference's loop); default: the pixel work on the device
+_DEVICE_CLOUDS = os.environ.get("VTACO_CONTACT_CLOUDS", "device") != "host"
 
 
 class Trainer:
@@ -143,18 +149,36 @@ class Trainer:
             self.depth_origin = src
         return np.asarray(src, dtype=np.float64).reshape(-1)
 
+    def _device_mesh(self, vf_dict, name):
+        """(verts f32 [V,3], faces i32 [F,3]) of ``vf_dict[name]`` on the device, uploaded once per mesh object (the dataset's
+        meshes do not change during a run; an entry whose arrays were replaced is uploaded again)."""
+        cache = self.__dict__.setdefault("_mesh_cache", {})
+        m = vf_dict[name]
+        hit = cache.get(name)
+        if hit is None or hit[0] is not m['v'] or hit[1] is not m['f']:
+            v = torch.as_tensor(np.ascontiguousarray(m['v'])).float().to(self.device).contiguous()
+            f = torch.as_tensor(np.ascontiguousarray(np.asarray(m['f']).astype(np.int32))).to(self.device).contiguous()
+            if len(cache) >= 4096:
+                cache.pop(next(iter(cache)))
+            hit = cache[name] = (m['v'], m['f'], v, f)
+        return hit[2], hit[3]
+
     def _t2d_samples(self, data, vf_dict, normalise_depth):
         """Query points, finger per row and winding-number targets of a VTacO step (training.py:809-866 / 672-733), plus the t2d
         net's outputs and the depth images as the calling variant uses them."""
         from .. import ops
         from ..common import contact_clouds_from_depth
         dev = self.device
-        p = data.get('points').to(dev)
+        p = data.get('points')                                        # only its shape and a host view are used here
         B, N = p.shape[:2]
         S = self.num_sample
         inputs = data.get('inputs').to(dev)
         imgs = data.get('inputs.img').to(dev)
-        depths = data.get('inputs.depth').to(dev).float()
+        # the depth images stay where the loader left them (host) for the contact clouds: what the device needs of them is the
+        # depth loss's target, which only a t2d net under training has -- 12 MB up and down per step otherwise
+        depths_src = data.get('inputs.depth')
+        need_dev = normalise_depth or not self.pretrained_t2d
+        depths = depths_src.to(dev, non_blocking=True).float() if need_dev else None
         if normalise_depth:
             depths = (depths - depths.min()) / (depths.max() - depths.min())
         cam_pos = data.get('points.cam_pos').reshape(B, 5, 3)
@@ -166,30 +190,38 @@ class Trainer:
         else:
             pred_depth, c_hand_d = self.model.encode_t2d(inputs, imgs)
         origin = self._depth_origin()
-        p_host = p.detach().float().cpu().numpy()
+        p_host = data.get('points').detach().float().cpu().numpy()      # (a host tensor as the loader hands it over: no copy)
         pc_ply = data.get('inputs.pc_ply').float().cpu().numpy()
         touch = data.get('inputs.touch_success').cpu().numpy()
-        depths_host = depths.detach().cpu().numpy()
         p_sample = np.zeros((B, S, 3), dtype=np.float32)
-        finger = np.full((B, S), -1, dtype=np.int64)
-        for b in range(B):
-            anchors, count = contact_clouds_from_depth(depths_host[b], origin, cam_pos[b].cpu().numpy(), cam_rot[b].cpu().numpy(),
-                                                       pc_ply[b], touch[b])
-            k = 0
-            for t in range(5):
-                n = int(count[t])
-                if touch[b][t]:
-                    if k + n > S:
-                        raise VtError(f"Trainer: {k + n} contact points do not fit num_sample = {S}")
-                    p_sample[b, k:k + n] = anchors[t, :n].astype(np.float32)
-                    finger[b, k:k + n] = t
-                    k += n
-            p_sample[b, k:] = p_host[b][np.random.randint(N, size=S - k)]
-        p_sample_t = torch.from_numpy(p_sample).to(dev)
+        if _DEVICE_CLOUDS:
+            # threshold + np.where + unprojection + pose of the 5 B depth images on the device (vt_contact_scan / vt_contact_points);
+            # the randint draws and the 4 x 4 pose inverses stay on the host, in the reference's order
+            from ..common import contact_clouds_on_device
+            dd = depths if depths is not None else depths_src.to(dev, non_blocking=True).float()
+            if getattr(self, "_origin_dev", None) is None or self._origin_dev[0] is not self.depth_origin:
+                self._origin_dev = (self.depth_origin, torch.from_numpy(origin).to(dev))
+            p_sample_t, finger = contact_clouds_on_device(dd, self._origin_dev[1], cam_pos.cpu().numpy(), cam_rot.cpu().numpy(), pc_ply, touch,
+                                                          p_sample, p_host, S)
+        else:
+            depths_host = (depths if normalise_depth else depths_src).detach().float().cpu().numpy()
+            finger = np.full((B, S), -1, dtype=np.int64)
+            for b in range(B):
+                anchors, count = contact_clouds_from_depth(depths_host[b], origin, cam_pos[b].cpu().numpy(), cam_rot[b].cpu().numpy(),
+                                                           pc_ply[b], touch[b])
+                k = 0
+                for t in range(5):
+                    n = int(count[t])
+                    if touch[b][t]:
+                        if k + n > S:
+                            raise VtError(f"Trainer: {k + n} contact points do not fit num_sample = {S}")
+                        p_sample[b, k:k + n] = anchors[t, :n].astype(np.float32)
+                        finger[b, k:k + n] = t
+                        k += n
+                p_sample[b, k:] = p_host[b][np.random.randint(N, size=S - k)]
+            p_sample_t = torch.from_numpy(p_sample).to(dev)
         names = data.get('points.name')
-        occ_new = torch.stack([ops.winding_number(torch.as_tensor(vf_dict[names[b]]['v']).to(dev),
-                                                  torch.as_tensor(np.asarray(vf_dict[names[b]]['f']).astype(np.int32)).to(dev),
-                                                  p_sample_t[b]) for b in range(B)])
+        occ_new = ops.winding_number_scenes([self._device_mesh(vf_dict, names[b]) for b in range(B)], p_sample_t)    # one launch
         cam_info = torch.cat((cam_pos.reshape(B, -1), cam_rot.reshape(B, -1)), dim=1).to(dev).float()
         return {'inputs': inputs, 'imgs': imgs, 'p_sample': p_sample_t, 'finger': torch.from_numpy(finger).to(dev), 'occ': occ_new,
                 'pred_depth': pred_depth, 'digit': c_hand_d['mano_param'], 'depths': depths, 'cam_info': cam_info}
@@ -218,7 +250,7 @@ class Trainer:
         c = self.model.encode_inputs(s['inputs'])
         logits = self.model.decode_img(s['p_sample'], c, c_img_all).logits
         d = s['depths']
-        return self._t2d_losses(data, s, logits, (d - d.min()) / (d.max() - d.min()))
+        return self._t2d_losses(data, s, logits, None if self.pretrained_t2d else (d - d.min()) / (d.max() - d.min()))
 
     def compute_loss_t2d(self, data, vf_dict):
         """The VTacO step without tactile features (training.py:628-755): the same sample assembly decoded by the plain decoder.

@@ -15,9 +15,17 @@ constexpr int WN_THREADS = 256;
 constexpr int WN_SUB = 16;                       // lanes per query point: each takes every 16th face of a tile
 constexpr int WN_POINTS = WN_THREADS / WN_SUB;   // 16 points per workgroup (a training step has ~16 k points: 1024 workgroups)
 
+// one scene's mesh in a batch (vt_winding_number_scenes): device pointers and counts
+struct WnScene { const float *verts; const int32_t *faces; int V, F; };
+
 __global__ void __launch_bounds__(WN_THREADS)
-winding_kernel(const float *verts, int V, const int32_t *faces, int F, const float *pts, int64_t N, float *out) {
+winding_kernel(const float *verts, int V, const int32_t *faces, int F, const float *pts, int64_t N, float *out, const WnScene *scenes) {
     __shared__ float tri[WN_THREADS][9];
+    if (scenes) {                                 // blockIdx.y = scene: its own mesh, its N points
+        const WnScene sc = scenes[blockIdx.y];
+        verts = sc.verts; V = sc.V; faces = sc.faces; F = sc.F;
+        pts += (size_t)blockIdx.y * N * 3; out += (size_t)blockIdx.y * N;
+    }
     const int sub = threadIdx.x % WN_SUB;
     const int64_t n = (int64_t)blockIdx.x * WN_POINTS + threadIdx.x / WN_SUB;
     double px = 0, py = 0, pz = 0;
@@ -61,8 +69,16 @@ int vt_winding_number(const float *verts, int V, const int32_t *faces, int F, co
     if (N == 0) return 0;
     if (!verts || !faces || !pts || !out || V <= 0 || F < 0 || N < 0) return vt_fail(VT_ERR_INVALID, "vt_winding_number: bad argument");
     hipLaunchKernelGGL(winding_kernel, dim3((unsigned)((N + WN_POINTS - 1) / WN_POINTS)), dim3(WN_THREADS), 0, (hipStream_t)stream,
-                       verts, V, faces, F, pts, N, out);
+                       verts, V, faces, F, pts, N, out, (const WnScene *)nullptr);
     return vt_check(hipGetLastError(), "vt_winding_number");
+}
+
+int vt_winding_number_scenes(const void *scenes, int B, const float *pts, int64_t N, float *out, void *stream) {
+    if (B == 0 || N == 0) return 0;
+    if (!scenes || !pts || !out || B < 0 || N < 0) return vt_fail(VT_ERR_INVALID, "vt_winding_number_scenes: bad argument");
+    hipLaunchKernelGGL(winding_kernel, dim3((unsigned)((N + WN_POINTS - 1) / WN_POINTS), (unsigned)B), dim3(WN_THREADS), 0, (hipStream_t)stream,
+                       (const float *)nullptr, 0, (const int32_t *)nullptr, 0, pts, N, out, reinterpret_cast<const WnScene *>(scenes));
+    return vt_check(hipGetLastError(), "vt_winding_number_scenes");
 }
 
 }  // extern "C"

@@ -606,6 +606,53 @@ def winding_number(verts, faces, pts):
     return out
 
 
+def contact_scan(depth, origin, touch, threshold=1e-4):
+    """(index [n_images, n_pixels] i32, count [n_images] i32): per depth image the pixels whose reading departs from the sensor's
+    flat one by more than ``threshold``, ascending (np.where's order); images whose ``touch`` byte is 0 count 0 (vt_contact_scan).
+    depth [n_images, n_pixels] f32, origin [n_pixels] f64, touch [n_images] u8 or None."""
+    depth = _c(depth)
+    n_img, n_pix = depth.shape
+    index = torch.empty((n_img, n_pix), dtype=I32, device=depth.device)
+    count = torch.empty((n_img,), dtype=I32, device=depth.device)
+    check(_lib.load().vt_contact_scan(dev_ptr(depth, "depth"), dev_ptr(origin, "depth_origin", torch.float64),
+                                      dev_ptr(touch, "touch_success", torch.uint8) if touch is not None else None, n_img, n_pix,
+                                      float(threshold), dev_ptr(index, "index", I32), dev_ptr(count, "count", I32), stream_ptr()), "vt_contact_scan")
+    return index, count
+
+
+def contact_points(depth, index, sel, kept, row0, pose, width, height, fov, max_points, p_sample, finger=None):
+    """Writes the contact rows of ``p_sample`` [B, S, 3] in place (vt_contact_points): per image ``kept`` pixels (``index[sel]``),
+    unprojected, posed and normalised in float64 (``pose`` [n_images, 16] f64: inverse pose 3 x 3, translation, cloud centroid, scale)."""
+    depth = _c(depth)
+    n_img, n_pix = depth.shape
+    check(_lib.load().vt_contact_points(dev_ptr(depth, "depth"), dev_ptr(index, "index", I32), dev_ptr(sel, "sel", I32) if sel is not None else None,
+                                        dev_ptr(kept, "kept", I32), dev_ptr(row0, "row0", I32), dev_ptr(pose, "pose", torch.float64),
+                                        n_img, n_pix, int(width), int(height), float(fov), int(max_points), p_sample.shape[1],
+                                        dev_ptr(p_sample, "p_sample"), dev_ptr(finger, "finger", torch.int64) if finger is not None else None,
+                                        stream_ptr()), "vt_contact_points")
+    return p_sample
+
+
+def winding_number_scenes(meshes, pts):
+    """w(q) for a batch of scenes in one launch (vt_winding_number_scenes): ``meshes`` = [(verts [V,3] f32, faces [F,3] i32)] device
+    tensors per scene, pts [B, N, 3] -> [B, N].  The 24-byte records go up in one small copy."""
+    import struct
+    pts = _c(pts.float())
+    B, N = pts.shape[:2]
+    if len(meshes) != B:
+        raise VtError(f"winding_number_scenes: {len(meshes)} meshes for {B} scenes")
+    rec = bytearray()
+    for v, f in meshes:
+        if v.dtype != torch.float32 or f.dtype != I32 or not v.is_contiguous() or not f.is_contiguous() or not v.is_cuda or not f.is_cuda:
+            raise VtError("winding_number_scenes: meshes must be contiguous device tensors (verts f32 [V,3], faces i32 [F,3])")
+        rec += struct.pack("<QQii", v.data_ptr(), f.data_ptr(), v.shape[0], f.shape[0])
+    table = torch.frombuffer(rec, dtype=torch.uint8).to(pts.device, non_blocking=True)
+    out = torch.empty((B, N), dtype=torch.float32, device=pts.device)
+    check(_lib.load().vt_winding_number_scenes(ctypes.c_void_p(table.data_ptr()), B, dev_ptr(pts, "pts"), N, dev_ptr(out, "out"), stream_ptr()),
+          "vt_winding_number_scenes")
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # PointNet per-point MLP, inference (vt_linear_rows, vt_resblock_fc)
 # --------------------------------------------------------------------------------------
