@@ -176,3 +176,35 @@ def test_oracle_at_the_shipped_shape_of_config2():
         p = c2.lattice_points(z[name]).unsqueeze(0)
         key = "logits" if name == "sample" else "logits_near"
         assert maxdiff(orc.local_decoder_forward(dsd, p, grid)[0], z[key]) <= 1e-5
+
+
+def test_oracle_plane_unet_matches_the_reference_module_golden():
+    """g19 (the real reference src/encoder/unet.py, shipped hand-encoder shape): the oracle's unet2d_forward and torch autograd through
+    it reproduce the reference's output, input gradient and parameter-gradient samples -- the oracle the GPU kernels are checked against
+    on other shapes (tests/test_plane_unet_gpu.py)."""
+    import os
+    import numpy as np
+    import torch
+    from conftest import GOLDEN
+    from vtaco_amd.encoder.unet import UNet
+    z = np.load(os.path.join(GOLDEN, "g19_plane_unet.npz"))
+    torch.manual_seed(int(z["seeds"][0]))
+    net = UNet(32, in_channels=32, depth=4, start_filts=32, merge_mode="concat")
+    g = torch.Generator().manual_seed(int(z["seeds"][1]))
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if name.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    for name in sd:
+        assert float(sd[name].detach().double().sum()) == z[f"psum.{name}"][0], name
+    x = torch.from_numpy(z["x"]).requires_grad_(True)
+    out = orc.unet2d_forward(sd, x)
+    (out * torch.from_numpy(z["w"])).sum().backward()
+    assert float((out.detach() - torch.from_numpy(z["out"])).abs().max()) <= 1e-5 * float(np.abs(z["out"]).max())
+    assert float((x.grad - torch.from_numpy(z["dx"])).abs().max()) <= 1e-5 * float(np.abs(z["dx"]).max())
+    for name in sd:
+        gr = sd[name].grad.double().reshape(-1)
+        idx = torch.randint(0, gr.numel(), (64,), generator=torch.Generator().manual_seed(int(z["seeds"][3]) + sum(map(ord, name))))
+        ref = torch.from_numpy(z[f"gsample.{name}"]).double()
+        assert float((gr[idx] - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1e-6) + 1e-9, name

@@ -155,3 +155,45 @@ def test_plane_unet_backward_routes_pool_ties_to_the_first_maximum():
         ref = sd[name].grad
         assert float((p.grad.cpu() - ref).abs().max()) <= 3e-5 * max(1e-6, float(ref.abs().max())), name
     assert float(net.down_convs[0].conv2.bias.grad.abs().max()) > 0      # the tied windows did carry gradient
+
+
+def _g19_net():
+    """vtaco_amd's UNet with the parameters the reference module drew for g19 (same seeds; every tensor's sums re-checked)."""
+    from conftest import GOLDEN
+    from vtaco_amd.encoder.unet import UNet
+    z = np.load(os.path.join(GOLDEN, "g19_plane_unet.npz"))
+    seed, bias_seed = int(z["seeds"][0]), int(z["seeds"][1])
+    torch.manual_seed(seed)
+    net = UNet(32, in_channels=32, depth=4, start_filts=32, merge_mode="concat")
+    g = torch.Generator().manual_seed(bias_seed)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if name.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    for name, p in net.named_parameters():
+        ref = z[f"psum.{name}"]
+        assert float(p.detach().double().sum()) == ref[0] and float(p.detach().double().abs().sum()) == ref[1], name
+    return net, z
+
+
+def test_plane_unet_against_the_reference_module_golden():
+    """g19: the REAL reference src/encoder/unet.py at the shipped shape (depth 4, 32 filters, three 32 x 32 planes), forward and
+    backward: output, dL/dx, and every parameter gradient's 64 sampled entries + sum against vt_plane_unet_fwd / _bwd."""
+    net, z = _g19_net()
+    net = net.to(DEV)
+    x = torch.from_numpy(z["x"]).to(DEV).requires_grad_(True)
+    out = net(x)
+    (out * torch.from_numpy(z["w"]).to(DEV)).sum().backward()
+    scale = float(np.abs(z["out"]).max())
+    assert float((out.detach().cpu() - torch.from_numpy(z["out"])).abs().max()) <= 2e-5 * scale
+    dscale = float(np.abs(z["dx"]).max())
+    assert float((x.grad.cpu() - torch.from_numpy(z["dx"])).abs().max()) <= 3e-5 * dscale
+    sample_seed = int(z["seeds"][3])
+    for name, p in net.named_parameters():
+        gr = p.grad.double().reshape(-1).cpu()
+        idx = torch.randint(0, gr.numel(), (64,), generator=torch.Generator().manual_seed(sample_seed + sum(map(ord, name))))
+        ref = torch.from_numpy(z[f"gsample.{name}"]).double()
+        gs = z[f"gsum.{name}"]
+        tol = 3e-5 * max(1e-6, float(gs[1]) / gr.numel() * 8)         # relative to the gradient's typical entry
+        assert float((gr[idx] - ref).abs().max()) <= max(tol, 3e-5 * float(ref.abs().max())), name
+        assert abs(float(gr.sum()) - gs[0]) <= 3e-5 * gs[1] + 1e-9, name
