@@ -492,6 +492,9 @@ int vt_mc_count_notify(const float *vol, int n0, int n1, int n2, double level, i
 /* before every replay and vt_mc_echo_wait spins until the slot's header carries it, then returns the counts.  One replay in flight     */
 /* per slot.  (No copy command and no event between the scan and the emit kernels: 19 us of a 0.9 ms scene.)                             */
 int vt_mc_echo_slot(int *token);
+/* vt_mc_echo_release hands a slot back once the graph that echoes into it has been destroyed (no replay in flight): the next   */
+/* vt_mc_echo_slot reuses its page-locked block.                                                                                */
+int vt_mc_echo_release(int token);
 int vt_mc_count_echo(const float *vol, int n0, int n1, int n2, double level, int auto_level,
                      void *workspace, size_t workspace_bytes, void *stream, int token);
 int vt_mc_echo_arm(int token);

@@ -147,3 +147,27 @@ def test_counts_by_notification_equal_the_copied_counts():
         assert (nv2.value, nf2.value, lvl2.value) == (nv.value, nf.value, lvl.value)
         v, f, l3 = ops.marching_cubes(vol, level)                    # notify + speculative emit
         assert l3 == lvl.value and torch.equal(f, ref_f) and torch.equal(v, ref_v)
+
+
+def test_echo_slots_are_reused_after_release():
+    """The 64 page-locked echo slots of a process are a pool: a released slot (its graph is gone) is what the next request gets, so a
+    long run that re-captures scenes (LRU eviction, a generator per validation pass) never exhausts them."""
+    from vtaco_amd import ops
+    from vtaco_amd._lib import VtError
+    held = []
+    try:
+        while True:
+            held.append(ops.mc_echo_slot())
+    except VtError:
+        pass
+    assert 1 <= len(held) <= 64
+    victim = held.pop(len(held) // 2)
+    ops.mc_echo_release(victim)
+    assert ops.mc_echo_slot() == victim                    # the freed block, not a 65th
+    held.append(victim)
+    with pytest.raises(VtError):
+        ops.mc_echo_slot()
+    for t in held:
+        ops.mc_echo_release(t)
+    with pytest.raises(VtError):
+        ops.mc_echo_release(held[0])                        # already free

@@ -164,6 +164,7 @@ SIGNATURES = {
     "vt_mc_read_counts": (_I, [_VP, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_D), _VP]),
     "vt_mc_count_notify": (_I, [_VP, _I, _I, _I, _D, _I, _VP, _SZ, _VP, ctypes.POINTER(ctypes.c_int)]),
     "vt_mc_echo_slot": (_I, [ctypes.POINTER(ctypes.c_int)]),
+    "vt_mc_echo_release": (_I, [_I]),
     "vt_mc_count_echo": (_I, [_VP, _I, _I, _I, _D, _I, _VP, _SZ, _VP, _I]),
     "vt_mc_echo_arm": (_I, [_I]),
     "vt_mc_echo_wait": (_I, [_I, _VP, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_D)]),

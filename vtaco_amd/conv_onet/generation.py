@@ -264,9 +264,9 @@ class Generator3D(object):
             if len(self._graphs) > 1:
                 self._graphs[key] = self._graphs.pop(key)   # most recently used last
             return hit
-        self._graphs.pop(key, None)                      # stale: drop the old graph (and its keep-alive list) first
+        self._drop_graph(key)                            # stale: drop the old graph (and its keep-alive list) first
         while len(self._graphs) >= self.MAX_SCENE_GRAPHS:   # every graph pins its workspaces (~0.5 GB at 128^3): keep a few shapes
-            self._graphs.pop(next(iter(self._graphs)))
+            self._drop_graph(next(iter(self._graphs)))
         static = [torch.zeros(shape, dtype=torch.float32, device=self.device) for shape in shapes]
         with ops.graph_keepalive() as keep:
             side = torch.cuda.Stream()
@@ -288,6 +288,22 @@ class Generator3D(object):
         self._graphs[key] = {"graph": graph, "in": static, "out": out, "keep": list(keep), "stamps": stamps}
         return self._graphs[key]
 
+    def _drop_graph(self, key):
+        """Forget a captured graph; its marching-cubes echo slot (a page-locked block, 64 per process) goes back to the pool once the
+        device has drained the graph's last replay."""
+        hit = self._graphs.pop(key, None)
+        if hit is not None and hit.get("echo") is not None:
+            torch.cuda.synchronize()
+            hit.pop("graph", None)
+            ops.mc_echo_release(hit["echo"])
+
+    def __del__(self):
+        try:
+            for key in list(getattr(self, "_graphs", {})):
+                self._drop_graph(key)
+        except Exception:                                 # noqa: BLE001 -- interpreter shutdown: the library may be gone
+            pass
+
     def _scene_graph(self, shape, nx):
         """Encode + dense decode + marching-cubes classification of one (input shape, lattice size) as one graph."""
         key = (tuple(shape), nx, self.decode_precision)
@@ -295,7 +311,7 @@ class Generator3D(object):
         # the counts of a replay arrive in a page-locked slot the scan kernel writes (no copy command between it and the emit kernels);
         # the slot is made before the capture and belongs to this graph
         if hit is not None and "echo" in hit:
-            echo = hit["echo"]
+            echo = hit.pop("echo")                        # (a stale entry is re-captured below: its slot moves to the new graph)
         else:
             try:
                 echo = ops.mc_echo_slot() if _MC_ECHO else None

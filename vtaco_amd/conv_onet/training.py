@@ -304,6 +304,11 @@ class Trainer:
         self._train_calls = getattr(self, "_train_calls", 0) + 1
         if mods is None or mods[0] is not self.model or self._train_calls % 256 == 1:
             mods = self._train_mods = list(self.model.modules())
+            # a module whose class overrides train() (a frozen sub-net that keeps its BatchNorm in eval mode, ...) must see the call
+            self._train_plain = any(type(m).train is not torch.nn.Module.train for m in mods)
+        if self._train_plain:
+            self.model.train()
+            return
         for m in mods:
             m.__dict__["training"] = True
 

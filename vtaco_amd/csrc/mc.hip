@@ -893,7 +893,7 @@ int vt_mc_read_counts_end(int token, int *nverts_host, int *nfaces_host, double 
 // the capture (page-locked allocation) and lives as long as the graph; one replay in flight per slot.
 namespace {
 constexpr int MC_ECHO_SLOTS = 64;
-struct McEcho { McHeader *host; int *want; int nonce; bool made; };
+struct McEcho { McHeader *host; int *want; int nonce; bool made; bool free_; };
 McEcho mc_echo[MC_ECHO_SLOTS];
 int mc_echo_made = 0;
 }  // namespace
@@ -901,6 +901,14 @@ int mc_echo_made = 0;
 int vt_mc_echo_slot(int *token) {
     if (!token) return vt_fail(VT_ERR_INVALID, "vt_mc_echo_slot: null argument");
     std::lock_guard<std::mutex> lock(mc_slots_mutex);
+    for (int i = 0; i < mc_echo_made; ++i)
+        if (mc_echo[i].free_) {                                     // a released slot (its graph is gone): the page-locked block is reused
+            McEcho &sl = mc_echo[i];
+            memset(sl.host, 0, sizeof(McHeader) + 64);
+            sl.nonce = 0; sl.free_ = false;
+            *token = i;
+            return 0;
+        }
     if (mc_echo_made >= MC_ECHO_SLOTS) return vt_fail(VT_ERR_INVALID, "vt_mc_echo_slot: all 64 slots are taken (one per captured scene shape)");
     McEcho &sl = mc_echo[mc_echo_made];
     char *mem = nullptr;
@@ -909,8 +917,15 @@ int vt_mc_echo_slot(int *token) {
     memset(mem, 0, sizeof(McHeader) + 64);
     sl.host = reinterpret_cast<McHeader *>(mem);
     sl.want = reinterpret_cast<int *>(mem + sizeof(McHeader));
-    sl.nonce = 0; sl.made = true;
+    sl.nonce = 0; sl.made = true; sl.free_ = false;
     *token = mc_echo_made++;
+    return 0;
+}
+
+int vt_mc_echo_release(int token) {
+    std::lock_guard<std::mutex> lock(mc_slots_mutex);
+    if (token < 0 || token >= mc_echo_made || mc_echo[token].free_) return vt_fail(VT_ERR_INVALID, "vt_mc_echo_release: bad token");
+    mc_echo[token].free_ = true;
     return 0;
 }
 
