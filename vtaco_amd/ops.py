@@ -288,16 +288,11 @@ def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want
                   name + "_ids")
             return (out, out2) if want_contact else out
         wsb = lib.vt_decode_wide_f16x3_workspace_bytes(B * N, int(hidden), C, int(nb), 0 if c_img is None else 1) if precision == "wide_f16x3" else 0
-        if wsb and (B == 1 or not want_contact):          # (a batch with the contact head keeps the streaming kernel below)
+        if wsb:
             # 64 / 32 / <= 5: the register-resident pipeline on the grid's samples, which a pre-pass leaves in a workspace.  The call
-            # runs in slices of WIDE_SLICE points (the workspace is 128 bytes per point: 67 MB per slice instead of 268 MB for a
-            # 128^3 lattice and 2.1 GB for 256^3; a slice's samples are still in the Infinity Cache when the pipeline reads them),
+            # runs scene by scene in slices of WIDE_SLICE points (the workspace is 128 bytes per point: 67 MB per slice instead of 268 MB
+            # for a 128^3 lattice and 2.1 GB for 256^3; a slice's samples are still in the Infinity Cache when the pipeline reads them),
             # one workspace per (device, stream) -- two streams decoding at once do not share it -- released when a smaller call comes
-            if B > 1:
-                for b in range(B):
-                    decode_fwd(grid[b:b + 1], blob, None if pts is None else pts[b:b + 1], None if c_img is None else c_img[b:b + 1], padding,
-                               lattice, want_contact, out[b:b + 1], None, precision, wide)
-                return out
             step = min(N, WIDE_SLICE)
             wsb = lib.vt_decode_wide_f16x3_workspace_bytes(step, int(hidden), C, int(nb), 0 if c_img is None else 1)
             key = (grid.device, stream_ptr().value)
@@ -305,14 +300,18 @@ def decode_fwd(grid, blob, pts=None, c_img=None, padding=0.1, lattice=None, want
             if ws is None or ws.numel() < wsb or ws.numel() > 4 * wsb:
                 ws = _wide_ws[key] = torch.empty(wsb, dtype=torch.uint8, device=grid.device)
             keep_for_graph(ws)
-            for lo in range(0, N, step):
-                n = min(step, N - lo)
-                check(lib.vt_decode_fwd_wide_f16x3_ws(gptr, 1, D, C, dev_ptr(pts[:, lo:lo + n] if pts is not None else None, "pts"), n, nx, box,
-                                                      first + lo if pts is None else 0, dev_ptr(c_img[:, lo:lo + n] if c_img is not None else None, "c_img"),
-                                                      dev_ptr(blob, "blob"), int(hidden), int(nb), flags, float(padding),
-                                                      dev_ptr(out[:, lo:lo + n], "out"), dev_ptr(out2[:, lo:lo + n] if out2 is not None else None, "out2"),
-                                                      ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream_ptr()),
-                      "vt_decode_fwd_wide_f16x3_ws")
+            cl = keep.permute(0, 2, 3, 4, 1)                           # [B, R, R, R, C] contiguous: scene b starts at cl[b]
+            for b in range(B):
+                for lo in range(0, N, step):
+                    n = min(step, N - lo)
+                    sl = (slice(b, b + 1), slice(lo, lo + n))
+                    check(lib.vt_decode_fwd_wide_f16x3_ws(dev_ptr(cl[b], "grid"), 1, D, C, dev_ptr(pts[sl] if pts is not None else None, "pts"), n,
+                                                          nx, box, first + lo if pts is None else 0,
+                                                          dev_ptr(c_img[sl] if c_img is not None else None, "c_img"), dev_ptr(blob, "blob"),
+                                                          int(hidden), int(nb), flags, float(padding), dev_ptr(out[sl], "out"),
+                                                          dev_ptr(out2[sl] if out2 is not None else None, "out2"),
+                                                          ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream_ptr()),
+                          "vt_decode_fwd_wide_f16x3_ws")
             return (out, out2) if want_contact else out
         check(getattr(lib, name)(gptr, B, D, C, dev_ptr(pts, "pts"), N, nx, box, first, dev_ptr(c_img, "c_img"),
                                  dev_ptr(blob, "blob"), int(hidden), int(nb), flags, float(padding),
