@@ -187,7 +187,7 @@ def stage_times(scene, dec, grid, nx, out, dev, precision):
     return res
 
 
-PMC_SUMMARY = os.path.join("profiles", "r05_pmc_summary.csv")
+PMC_SUMMARY = os.path.join("profiles", "r06_pmc_summary.csv")
 EXTRAS_LIMIT_S = 420            # the sections after the headline (sharded scene, training step, CPU baseline) take well under a minute
 DECODE_SOURCES = ("decode.hip", "decode_f16.hip", "decode_common.h", "decode_st3.h", "decode_st3_f16x3.inc", "decode_st3_f16f8.inc",
                   "vt_common.h", "Makefile")
