@@ -410,6 +410,15 @@ int vt_fusion_bwd(const float *d_out, const float *c_img, const float *c, int B,
                   float p_drop, unsigned long long seed, const void *saved, size_t saved_bytes, void *workspace,
                   size_t workspace_bytes, float *d_c_img, float *d_c, const vt_fusion_grads *grads_host, void *stream);
 int vt_fusion_dropout_mask(float p_drop, unsigned long long seed, int call, int which, int points, float *mask, void *stream);
+/* d_model 64 / 96 / 128 under autograd (the reference trains AttentionDecoder at its defaults c_dim 128 / hidden 256 like any module,   */
+/* decoder.py:176-207): vt_fusion_fwd_train / vt_fusion_bwd take those widths too (tensors [B][N][d_model], the unit's shapes with 32 ->   */
+/* d_model), with `saved` of vt_fusion_saved_bytes_wide, workspaces of vt_fusion_workspace_bytes_wide / vt_fusion_bwd_workspace_bytes_wide.  */
+/* The backward's three N x N passes are linear in their payload and run once per 32-channel slice of it (per-key / per-query scalars    */
+/* enter with the first slice); the per-point parts are one-wave-per-point kernels with the weights in LDS; the weight gradients are        */
+/* vt_rows_wgrad products.  Dropout masks of these widths: vt_fusion_dropout_mask_wide (which 1: [points][d_model]).                        */
+size_t vt_fusion_saved_bytes_wide(int B, int N, int d_model);
+size_t vt_fusion_bwd_workspace_bytes_wide(int B, int N, int d_model);
+int vt_fusion_dropout_mask_wide(float p_drop, unsigned long long seed, int call, int which, int points, int d_model, float *mask, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* Backward of vt_decode_fwd (training).                                        */

@@ -120,6 +120,9 @@ SIGNATURES = {
     "vt_fusion_bwd": (_I, [_VP, _VP, _VP, _I, _I, ctypes.POINTER(FusionParams), _F, ctypes.c_ulonglong, _VP, _SZ, _VP, _SZ, _VP, _VP,
                            ctypes.POINTER(FusionGrads), _VP]),
     "vt_fusion_dropout_mask": (_I, [_F, ctypes.c_ulonglong, _I, _I, _I, _VP, _VP]),
+    "vt_fusion_saved_bytes_wide": (_SZ, [_I, _I, _I]),
+    "vt_fusion_bwd_workspace_bytes_wide": (_SZ, [_I, _I, _I]),
+    "vt_fusion_dropout_mask_wide": (_I, [_F, ctypes.c_ulonglong, _I, _I, _I, _I, _VP, _VP]),
     "vt_decoder_blob_t_bytes": (_SZ, [_I, _I, _I]),
     "vt_decoder_pack_bf16x3": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
     "vt_decode_fwd_bf16x3": (_I, [_VP, _I, _I, _I, _VP, _I64, _I, _F, _I64, _VP, _VP, _VP, _I, _VP, _D, _VP, _VP, _VP]),

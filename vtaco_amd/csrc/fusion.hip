@@ -733,7 +733,7 @@ static int proj_tiles(int P) {
 // one attention unit: Xq against Xk -> out = relu(IN(Xq + MHA(Xq, Xk, Xk))).  ``Osave`` != null: training forward (w.l / w.s /
 // w.V / w.Z then point into the caller's saved state instead of the scratch workspace, and the dropouts of ``dc`` are applied)
 void run_unit(const float *Xq, const float *Xk, const FusionUnitDev &u, const float *blob, const FusionWs &w,
-              float *out, int B, int N, hipStream_t s, float *Osave = nullptr, DropCfg dc = DropCfg{0, 0, 1.0f, 0}, XIds xi = XIds{}) {
+              float *out, int B, int N, hipStream_t s, float *Osave = nullptr, DropCfg dc = DropCfg{0, 0, 1.0f, 0, 6}, XIds xi = XIds{}) {
     const int P = B * N, Npad = (N + 31) / 32 * 32;
     const int ntile = (N + 31) / 32;
     const int nrb = (N + FROWS - 1) / FROWS;
@@ -919,7 +919,7 @@ struct FusionwEpi { const float *wt, *w1, *w2, *b1, *b2, *lnw, *lnb; };     // p
 // C / 32 waves, 32 points per tile; wave ob owns the output rows 32 ob .. 32 ob + 31, waves 0 and 1 the 64 hidden rows of linear1
 template <int C>
 __global__ void __launch_bounds__(C * 2)
-fusionw_epilogue_kernel(const float *X, const float *O, FusionwEpi e, float *Z, int total) {
+fusionw_epilogue_kernel(const float *X, const float *O, FusionwEpi e, float *Z, int total, DropCfg dc) {
     constexpr int NW = C / 32;
     __shared__ float bufD[C * FW_PITCH], bufR[C * FW_PITCH], bufH[64 * FW_PITCH], red[2][NW][32];
     const int tid = threadIdx.x, lane = tid & 63, ob = tid >> 6, j = lane & 31, kg = lane >> 5;
@@ -943,15 +943,20 @@ fusionw_epilogue_kernel(const float *X, const float *O, FusionwEpi e, float *Z, 
 #pragma unroll
             for (int i = 0; i < 16; ++i) hd[i] = e.b1[32 * ob + chan_of(i, kg)];
             hd = relu16(fusionw_gemm(hd, e.w1, ob, C, bufR, lane));
+            const uint32_t pd = (uint32_t)min(tile * 32 + j, total - 1);           // TransNonlinear's dropout on relu(linear1), train mode
 #pragma unroll
-            for (int i = 0; i < 16; ++i) bufH[(32 * ob + chan_of(i, kg)) * FW_PITCH + j] = hd[i];
+            for (int i = 0; i < 16; ++i) bufH[(32 * ob + chan_of(i, kg)) * FW_PITCH + j] = hd[i] * drop_mask(dc, 0, pd, (uint32_t)(32 * ob + chan_of(i, kg)));
         }
         __syncthreads();
         f32x16 t;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t[i] = e.b2[32 * ob + chan_of(i, kg)];
         t = fusionw_gemm(t, e.w2, ob, 64, bufH, lane);
-        t = t + r;
+        {
+            const uint32_t pd = (uint32_t)min(tile * 32 + j, total - 1);           // ... and dropout2 on linear2's output
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t[i] = fmaf(t[i], drop_mask(dc, 1, pd, (uint32_t)(32 * ob + chan_of(i, kg))), r[i]);
+        }
         // LayerNorm over the C channels of a point: this wave's 32 (16 registers x 2 lane halves), then the waves' sums through LDS
         float m = 0.0f;
 #pragma unroll
@@ -1006,7 +1011,8 @@ size_t fusionw_layout(int B, int N, int C, FusionwWs *ws, char *base) {
 }
 
 template <int C>
-void run_unit_wide(const float *Xq, const float *Xk, const FusionUnitDev &u, const float *pk, const FusionwWs &w, float *out, int B, int N, hipStream_t s) {
+void run_unit_wide(const float *Xq, const float *Xk, const FusionUnitDev &u, const float *pk, const FusionwWs &w, float *out, int B, int N, hipStream_t s,
+                   DropCfg dc = DropCfg{0, 0, 1.0f, 0, 8}) {
     const int P = B * N, ntile = (N + 31) / 32, nrb = (N + FROWS - 1) / FROWS;
     const dim3 pg((P + 128 * PROJ_TILES - 1) / (128 * PROJ_TILES)), tg((unsigned)nrb * (unsigned)B);
     const size_t plds = (size_t)(4 + C / 32) * (C / 2) * 64 * sizeof(float);
@@ -1019,12 +1025,12 @@ void run_unit_wide(const float *Xq, const float *Xk, const FusionUnitDev &u, con
     for (int sl = 0; sl < C / 32; ++sl) {                            // the attention output, one 32-channel slice of V' at a time
         hipLaunchKernelGGL(fusion_scalev_kernel, dim3((unsigned)g), dim3(256), 0, s, w.V, w.s, w.VT, N, ntile, tot, C, 32 * sl);
         hipLaunchKernelGGL((fusion_attend_kernel<false, true, false>), tg, dim3(FT), 0, s, w.Qd, w.Kd, w.VT, w.l, Xq, w.blob, w.Z, N, ntile,
-                           w.O + 32 * sl, DropCfg{0, 0, 1.0f, 0}, nrb, B, XIds{}, C);
+                           w.O + 32 * sl, DropCfg{0, 0, 1.0f, 0, 6}, nrb, B, XIds{}, C);
     }
     FusionwEpi e{pk, pk + (size_t)C * C, pk + (size_t)C * C + 64 * (size_t)C, u.l1b, u.l2b, u.lnw, u.lnb};
     int eg = (P + 31) / 32;
     if (eg > vt_num_cus() * 4) eg = vt_num_cus() * 4;
-    hipLaunchKernelGGL(fusionw_epilogue_kernel<C>, dim3(eg), dim3(C * 2), 0, s, Xq, w.O, e, w.Z, P);
+    hipLaunchKernelGGL(fusionw_epilogue_kernel<C>, dim3(eg), dim3(C * 2), 0, s, Xq, w.O, e, w.Z, P, dc);
     hipLaunchKernelGGL(fusion_inorm_relu_kernel, dim3(B, C / 32), dim3(1024), 0, s, w.Z, out, N, C);
 }
 
@@ -1047,6 +1053,36 @@ int fusion_fwd_wide(const float *c_img, const float *c, int B, int N, const vt_f
     run_unit_wide<C>(c_img, c_img, us, w.pk[0], w, w.T, B, N, s);      // decoder self-attention (SAME weights)
     run_unit_wide<C>(w.T, w.M, ux, w.pk[1], w, out, B, N, s);          // decoder cross-attention
     return vt_check(hipGetLastError(), "vt_fusion_fwd");
+}
+
+// the training forward at d_model C > 32: the same launches with TransNonlinear's dropouts and with the O(N) state the backward needs
+// (1 / l, s, V, O, Z per attention call; the two inner results) written into the caller's saved buffer instead of the scratch workspace
+template <int C>
+int fusion_fwd_train_wide(const float *c_img, const float *c, int B, int N, const vt_fusion_params *p, float p_drop, unsigned long long seed,
+                          void *workspace, size_t workspace_bytes, void *saved, size_t saved_bytes, float *out, hipStream_t s) {
+    FusionwWs w;
+    FusionSaved sv;
+    if (workspace_bytes < fusionw_layout(B, N, C, &w, (char *)workspace)) return vt_fail(VT_ERR_WORKSPACE, "vt_fusion_fwd_train: workspace too small");
+    if (saved_bytes < fusion_saved_layout(B, N, &sv, (char *)saved, C)) return vt_fail(VT_ERR_WORKSPACE, "vt_fusion_fwd_train: saved-state buffer too small");
+    hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&fusionw_proj_kernel<C>), 160 * 1024);
+    if (e != hipSuccess) return vt_check(e, "vt_fusion_fwd_train: hipFuncSetAttribute");
+    const FusionUnitDev us = unit_of(p->self_attn), ux = unit_of(p->cross_attn);
+    hipLaunchKernelGGL(fusion_pack_kernel, dim3(6), dim3(1024), 0, s, us, w.blob);
+    for (int k = 0; k < 2; ++k) {
+        const FusionUnitDev &u = k ? ux : us;
+        hipLaunchKernelGGL(fusionw_pack_kernel, dim3(64), dim3(256), 0, s, u.Wt, C, C, w.pk[k]);
+        hipLaunchKernelGGL(fusionw_pack_kernel, dim3(32), dim3(256), 0, s, u.l1w, 64, C, w.pk[k] + (size_t)C * C);
+        hipLaunchKernelGGL(fusionw_pack_kernel, dim3(32), dim3(256), 0, s, u.l2w, C, 64, w.pk[k] + (size_t)C * C + 64 * (size_t)C);
+    }
+    auto call = [&](int k, const float *Xq, const float *Xk, const FusionUnitDev &u, const float *pk, float *dst) {
+        FusionwWs wk = w;
+        wk.l = sv.linv[k]; wk.s = sv.s[k]; wk.V = sv.V[k]; wk.O = sv.O[k]; wk.Z = sv.Z[k];
+        run_unit_wide<C>(Xq, Xk, u, pk, wk, dst, B, N, s, drop_cfg(p_drop, seed, (uint32_t)k, 8));
+    };
+    call(0, c, c, us, w.pk[0], sv.M);
+    call(1, c_img, c_img, us, w.pk[0], sv.T);
+    call(2, sv.T, sv.M, ux, w.pk[1], out);
+    return vt_check(hipGetLastError(), "vt_fusion_fwd_train");
 }
 
 }  // namespace
@@ -1101,7 +1137,7 @@ int vt_fusion_fwd_ids(const unsigned char *finger_ids, const float *finger_feats
     XIds xi;
     xi.ids = finger_ids; xi.table = finger_feats; xi.chunk = chunk_index; xi.N = N; xi.F = (unsigned)n_fingers;
     run_unit(c, c, us, w.blob_s, w, w.M, B, N, s);                 // encoder: memory from the grid features
-    run_unit(nullptr, nullptr, us, w.blob_s, w, w.T, B, N, s, nullptr, DropCfg{0, 0, 1.0f, 0}, xi);   // decoder self-attention on the rows by id
+    run_unit(nullptr, nullptr, us, w.blob_s, w, w.T, B, N, s, nullptr, DropCfg{0, 0, 1.0f, 0, 6}, xi);   // decoder self-attention on the rows by id
     run_unit(w.T, w.M, ux, w.blob_x, w, out, B, N, s);             // decoder cross-attention
     return vt_check(hipGetLastError(), "vt_fusion_fwd_ids");
 }
@@ -1111,13 +1147,21 @@ size_t vt_fusion_saved_bytes(int B, int N) {
     return fusion_saved_layout(B, N, nullptr, nullptr);
 }
 
+size_t vt_fusion_saved_bytes_wide(int B, int N, int d_model) {
+    if (B <= 0 || N <= 0 || d_model <= 0 || (d_model & 31) || d_model > FW_MAX) return 0;
+    return fusion_saved_layout(B, N, nullptr, nullptr, d_model);
+}
+
 int vt_fusion_fwd_train(const float *c_img, const float *c, int B, int N, const vt_fusion_params *p, float p_drop,
                         unsigned long long seed, void *workspace, size_t workspace_bytes, void *saved, size_t saved_bytes,
                         float *out, void *stream) {
     if (!c_img || !c || !p || !workspace || !saved || !out) return vt_fail(VT_ERR_INVALID, "vt_fusion_fwd_train: null argument");
     if (B <= 0 || N <= 0) return vt_fail(VT_ERR_INVALID, "vt_fusion_fwd_train: bad size");
     if (!(p_drop >= 0.0f && p_drop < 1.0f)) return vt_fail(VT_ERR_INVALID, "vt_fusion_fwd_train: p_drop must be in [0, 1)");
-    if (p->d_model != 32 || p->key_dim != 64) return vt_fail(VT_ERR_UNSUPPORTED, "vt_fusion_fwd_train: d_model=32, key_feature_dim=64 only");
+    if (p->key_dim == 64 && p->d_model == 64) return fusion_fwd_train_wide<64>(c_img, c, B, N, p, p_drop, seed, workspace, workspace_bytes, saved, saved_bytes, out, (hipStream_t)stream);
+    if (p->key_dim == 64 && p->d_model == 96) return fusion_fwd_train_wide<96>(c_img, c, B, N, p, p_drop, seed, workspace, workspace_bytes, saved, saved_bytes, out, (hipStream_t)stream);
+    if (p->key_dim == 64 && p->d_model == 128) return fusion_fwd_train_wide<128>(c_img, c, B, N, p, p_drop, seed, workspace, workspace_bytes, saved, saved_bytes, out, (hipStream_t)stream);
+    if (p->d_model != 32 || p->key_dim != 64) return vt_fail(VT_ERR_UNSUPPORTED, "vt_fusion_fwd_train: d_model in {32, 64, 96, 128} with key_feature_dim = 64");
     FusionWs w;
     FusionSaved sv;
     if (workspace_bytes < fusion_layout(B, N, &w, (char *)workspace)) return vt_fail(VT_ERR_WORKSPACE, "vt_fusion_fwd_train: workspace too small");

@@ -61,11 +61,13 @@ struct DropCfg {
     uint32_t thresh;        // keep iff hash >= thresh; 0 = no dropout
     float scale;            // 1 / (1 - p)
     uint32_t call;
+    uint32_t shift;         // the point's place in the hashed word: 6 at d_model 32 (channels < 64), 8 at the wider models (< 256)
 };
-__host__ __device__ inline DropCfg drop_cfg(float p, unsigned long long seed, uint32_t call) {
+__host__ __device__ inline DropCfg drop_cfg(float p, unsigned long long seed, uint32_t call, uint32_t shift = 6) {
     DropCfg d;
     d.seed = seed;
     d.call = call;
+    d.shift = shift;
     if (!(p > 0.0f)) { d.thresh = 0; d.scale = 1.0f; return d; }
     const double t = (double)p * 4294967296.0;
     d.thresh = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
@@ -74,7 +76,7 @@ __host__ __device__ inline DropCfg drop_cfg(float p, unsigned long long seed, ui
 }
 __device__ __forceinline__ float drop_mask(const DropCfg &d, uint32_t which, uint32_t point, uint32_t channel) {
     if (d.thresh == 0) return 1.0f;
-    unsigned long long z = d.seed + 0x9E3779B97F4A7C15ull * (((unsigned long long)(d.call * 2 + which) << 40) + ((unsigned long long)point << 6) + channel + 1);
+    unsigned long long z = d.seed + 0x9E3779B97F4A7C15ull * (((unsigned long long)(d.call * 2 + which) << 40) + ((unsigned long long)point << d.shift) + channel + 1);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z ^= z >> 31;
@@ -93,13 +95,13 @@ __device__ __forceinline__ f32x16 drop16(const f32x16 &v, const DropCfg &d, uint
 struct FusionSaved {
     float *linv[3], *s[3], *V[3], *O[3], *Z[3], *M, *T;
 };
-inline size_t fusion_saved_layout(int B, int N, FusionSaved *sv, char *base) {
+inline size_t fusion_saved_layout(int B, int N, FusionSaved *sv, char *base, int C = 32) {
     const size_t P = (size_t)B * N;
     size_t off = 0;
     auto take = [&](size_t floats) { float *p = base ? (float *)(base + off) : nullptr; off += (floats * 4 + 255) / 256 * 256; return p; };
     FusionSaved t;
-    for (int c = 0; c < 3; ++c) { t.linv[c] = take(P); t.s[c] = take(P); t.V[c] = take(P * 32); t.O[c] = take(P * 32); t.Z[c] = take(P * 32); }
-    t.M = take(P * 32); t.T = take(P * 32);
+    for (int c = 0; c < 3; ++c) { t.linv[c] = take(P); t.s[c] = take(P); t.V[c] = take(P * C); t.O[c] = take(P * C); t.Z[c] = take(P * C); }
+    t.M = take(P * C); t.T = take(P * C);
     if (sv) *sv = t;
     return off;
 }

@@ -1285,7 +1285,9 @@ def fusion_fwd_train(c_img, c, self_attn, cross_attn, p_drop=0.0, seed=0):
         raise VtError(f"fusion: c_img {tuple(c_img.shape)} and c {tuple(c.shape)} must match")
     keep = []
     prm = _fusion_params(self_attn, cross_attn, C, keep)
-    nbytes, sbytes = lib.vt_fusion_workspace_bytes(B, N), lib.vt_fusion_saved_bytes(B, N)
+    nbytes, sbytes = lib.vt_fusion_workspace_bytes_wide(B, N, C), lib.vt_fusion_saved_bytes_wide(B, N, C)
+    if not nbytes or not sbytes:
+        raise VtError(f"fusion_fwd_train: d_model {C} is not built (32, 64, 96, 128)")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=c.device)
     saved = torch.empty(sbytes, dtype=torch.uint8, device=c.device)
     out = torch.empty((B, N, C), dtype=torch.float32, device=c.device)
@@ -1311,7 +1313,9 @@ def fusion_bwd(d_out, c_img, c, self_attn, cross_attn, saved, p_drop=0.0, seed=0
             setattr(unit, name, dev_ptr(g[name], "grad " + name).value)
         outs.append(g)
     d_c_img, d_c = torch.empty_like(c), torch.empty_like(c)
-    nbytes = lib.vt_fusion_bwd_workspace_bytes(B, N)
+    nbytes = lib.vt_fusion_bwd_workspace_bytes_wide(B, N, C)
+    if not nbytes:
+        raise VtError(f"fusion_bwd: d_model {C} is not built (32, 64, 96, 128)")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=c.device)
     check(lib.vt_fusion_bwd(dev_ptr(d_out, "d_out"), dev_ptr(c_img, "c_img"), dev_ptr(c, "c"), B, N, ctypes.byref(prm), float(p_drop),
                             int(seed), ctypes.c_void_p(saved.data_ptr()), saved.numel(), ctypes.c_void_p(ws.data_ptr()), nbytes,
@@ -1319,11 +1323,15 @@ def fusion_bwd(d_out, c_img, c, self_attn, cross_attn, saved, p_drop=0.0, seed=0
     return d_c_img, d_c, outs[0], outs[1]
 
 
-def fusion_dropout_mask(p_drop, seed, call, which, points, device):
-    """The dropout factors (0 or 1/(1-p)) the fusion kernels apply: [points, 64] for which=0, [points, 32] for which=1."""
-    out = torch.empty((points, 64 if which == 0 else 32), dtype=torch.float32, device=device)
-    check(_lib.load().vt_fusion_dropout_mask(float(p_drop), int(seed), int(call), int(which), int(points), dev_ptr(out, "mask"),
-                                            stream_ptr()), "vt_fusion_dropout_mask")
+def fusion_dropout_mask(p_drop, seed, call, which, points, device, d_model=32):
+    """The dropout factors (0 or 1/(1-p)) the fusion kernels apply: [points, 64] for which=0, [points, d_model] for which=1."""
+    out = torch.empty((points, 64 if which == 0 else d_model), dtype=torch.float32, device=device)
+    if d_model == 32:
+        check(_lib.load().vt_fusion_dropout_mask(float(p_drop), int(seed), int(call), int(which), int(points), dev_ptr(out, "mask"),
+                                                stream_ptr()), "vt_fusion_dropout_mask")
+    else:
+        check(_lib.load().vt_fusion_dropout_mask_wide(float(p_drop), int(seed), int(call), int(which), int(points), int(d_model),
+                                                     dev_ptr(out, "mask"), stream_ptr()), "vt_fusion_dropout_mask_wide")
     return out
 
 
