@@ -262,6 +262,14 @@ int vt_decoder_pack_wide_t(const vt_decoder_params *params_host, float *blob_t, 
 int vt_decode_bwd_wide(int B, int R, int C, const float *pts, int64_t N, const float *blob_wide_t, int hidden, int n_blocks, int flags,
                        double padding, const float *grad_out, const float *grad_out2, const float *save, float *gws,
                        float *grad_grid_cl, float *grad_c_img, void *stream);
+/* The conditioned MLP alone under autograd at these widths (AttentionDecoder.forward_img behind its fuser, decoder.py:259-271 with  */
+/* c_dim 64 / 96 / 128): vt_decode_mlp_fwd_wide on query points that also fills `save` (same layout; its c slot is left unwritten --   */
+/* the caller holds c), and the data pass that returns d c per point [B][N][C] instead of a grid scatter.  gws and the weight          */
+/* gradients as vt_decode_bwd_wide's, with fc_c_i <- (dN_i, the caller's c).  vt_sample_grid_bwd[_sorted] take any c_dim % 32 == 0.    */
+int vt_decode_mlp_fwd_wide_train(const float *c, int B, int C, const float *pts, int64_t N, const float *blob_wide, int hidden, int n_blocks,
+                                 int flags, float *out, float *out2, float *save, void *stream);
+int vt_decode_mlp_bwd_wide(int B, int C, const float *pts, int64_t N, const float *blob_wide_t, int hidden, int n_blocks, int flags,
+                           const float *grad_out, const float *grad_out2, const float *save, float *gws, float *grad_c, void *stream);
 
 /* Tactile feature assignment and decode by finger id (SURVEY.md section 8f "next" row 2).        */
 /* Replaces: the scipy cdist + np.where glue that fills the dense c_img_all [1,N,32] at            */

@@ -242,13 +242,13 @@ def transformer_fusion(sd, c_img, c, masks=None):
     return _inorm_relu(tgt + _mha1(sd, ca, tgt, mem, mem, masks[2]))
 
 
-def attention_decoder_forward_img(sd, p, grid, c_img, padding=0.1):
-    """``AttentionDecoder.forward_img`` (decoder.py:237-271)."""
+def attention_decoder_forward_img(sd, p, grid, c_img, padding=0.1, leaky=False):
+    """``AttentionDecoder.forward_img`` (decoder.py:237-271; ``leaky``: decoder.py:210-213 -- the head's activation only)."""
     c = trilinear_sample(grid, p, padding)
     fsd = {k[len("fuser."):]: v for k, v in sd.items() if k.startswith("fuser.")}
     c = transformer_fusion(fsd, c_img, c)
     net = decoder_mlp(sd, _lin(sd, "fc_p", p.to(sd["fc_p.weight"].dtype)), c)
-    return _lin(sd, "fc_out", F.relu(net)).squeeze(-1)
+    return _lin(sd, "fc_out", _head_actvn(net, leaky)).squeeze(-1)
 
 
 # --------------------------------------------------------------------------

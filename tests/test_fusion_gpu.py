@@ -289,9 +289,131 @@ def test_attention_decoder_beyond_the_shipped_widths_against_the_reference_fixtu
     # the oracle (width-generic restatement) agrees with the fixture as well: it is the checker of the shapes in between
     o = orc.attention_decoder_forward_img(sdc, T(arrs["p"]), T(arrs["grid"].astype("float32")), T(arrs["c_img"].astype("float32")))
     assert float((o - T(arrs["logits_img"])).abs().max()) <= 2e-5
-    grid.requires_grad_(True)
-    with pytest.raises(Exception, match="training is built at the shipped shape"):
-        dec.forward_img(p, {"grid": grid}, c_img)
+
+
+@pytest.mark.parametrize("tag", ["D", "E"])
+def test_attention_decoder_beyond_the_shipped_widths_trains_like_the_reference(tag):
+    """The same two decoders under autograd against the REAL reference's own gradients (g20, make_attn_wide_goldens.py): d grid,
+    d c_img and every parameter's gradient (64 sampled entries + its sum) of L = sum(logits * w) through vt_sample_grid[_bwd] at
+    c_dim 64 / 128, vt_fusion_fwd_train / vt_fusion_bwd at d_model 64 / 128 and vt_decode_mlp_fwd_wide_train / vt_decode_mlp_bwd_wide /
+    vt_rows_wgrad; the framework's linear / grid_sample operators made to raise (nothing falls back)."""
+    import os
+    import numpy as np
+    import torch.nn.functional as F
+    from conftest import GOLDEN, load_golden
+    from test_oracle_golden import _g20_check_param_grads
+    from vtaco_amd.conv_onet.models.decoder import AttentionDecoder
+    a, sd = load_golden("g17_attention_wide.npz")
+    z = dict(np.load(os.path.join(GOLDEN, "g20_attention_wide_grads.npz")))
+    arrs = {k[2:]: v for k, v in a.items() if k.startswith(tag + ".")}
+    sdc = {k[2:]: v.float() for k, v in sd.items() if k.startswith(tag + ".")}
+    c_dim, hidden, nb, B, N = (int(x) for x in arrs["shape"])
+    dec = AttentionDecoder(dim=3, c_dim=c_dim, hidden_size=hidden, n_blocks=nb, padding=0.1)
+    dec.load_state_dict(sdc)
+    dec = dec.to(DEV).eval()
+    T = torch.from_numpy
+    grid = T(arrs["grid"].astype("float32")).to(DEV).requires_grad_(True)
+    c_img = T(arrs["c_img"].astype("float32")).to(DEV).requires_grad_(True)
+    p, w = T(arrs["p"]).to(DEV), T(z[f"{tag}.w"]).to(DEV)
+    saved = F.linear, F.grid_sample
+
+    def boom(*a, **k):
+        raise AssertionError("a framework operator ran under the HIP decoder")
+    F.linear = F.grid_sample = boom
+    try:
+        out = dec.forward_img(p, {"grid": grid}, c_img)
+        (out * w).sum().backward()
+    finally:
+        F.linear, F.grid_sample = saved
+    ref = T(arrs["logits_img"])
+    assert float((out.detach().cpu() - ref).abs().max()) <= 5e-5 * max(1.0, float(ref.abs().max()))
+    # The reference ran on the CPU: a ReLU of the MLP or of the fuser at ~0 may take the other branch on a point here, which moves
+    # that point's row of d c_img (seen in the fuser's own test: one row in ~2000), and d grid and every parameter's gradient a little.  At most two rows beyond the tolerance; the parameters to 2e-4, or 2e-2 when a row did flip.
+    rows_bad = 0
+    for got, key in ((c_img.grad, "d_c_img"), (grid.grad, "d_grid")):
+        refg = T(z[f"{tag}.{key}"])
+        err = (got.cpu() - refg).abs()
+        tol = 1e-4 * float(refg.abs().max())
+        if key == "d_c_img":
+            rows_bad = int((err.reshape(B * N, -1).max(dim=1).values > tol).sum())
+            assert rows_bad <= 2, (tag, key, rows_bad, float(err.max()), tol)
+        else:
+            # (a flipped row reaches every corner of the grid a little: its key / value rows enter every point's attention)
+            assert rows_bad > 0 or float(err.max()) <= tol, (tag, key, float(err.max()), tol)
+        assert float((got.cpu() - refg).norm()) <= (1e-4 if rows_bad == 0 else 2e-2) * float(refg.norm()), (tag, key)
+    _g20_check_param_grads(z, tag, {n: prm.grad for n, prm in dec.named_parameters()}, 2e-4 if rows_bad == 0 else 2e-2)
+    # a second backward accumulates through autograd as usual
+    g1 = {n: prm.grad.clone() for n, prm in dec.named_parameters() if prm.grad is not None}
+    (dec.forward_img(p, {"grid": grid}, c_img) * w).sum().backward()
+    for n, prm in dec.named_parameters():
+        if prm.grad is not None:
+            assert float((prm.grad - 2 * g1[n]).abs().max()) <= 1e-5 * max(1e-6, float(g1[n].abs().max())), n
+
+
+@pytest.mark.parametrize("c_dim,hidden,nb,B,N,leaky", [(32, 64, 3, 2, 200, False), (96, 128, 3, 1, 256, True), (128, 32, 1, 2, 65, False)])
+def test_attention_decoder_wide_backward_vs_oracle_autograd(c_dim, hidden, nb, B, N, leaky):
+    """The widths between the fixtures (a 32-wide fuser in front of a 64-wide MLP; 96 / 128 with leaky_relu in front of the head; a
+    128-wide fuser in front of a 32-wide one-block MLP on ragged chunks) against torch-CPU autograd through the oracle, eval mode;
+    then train mode: the dropout of the fuser is drawn from a seed, so the same seed gives the same bits and another seed other ones."""
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd.conv_onet.models.decoder import AttentionDecoder
+    torch.manual_seed(40 + c_dim + hidden)
+    dec = AttentionDecoder(dim=3, c_dim=c_dim, hidden_size=hidden, n_blocks=nb, padding=0.1, leaky=leaky).eval()
+    g = torch.Generator().manual_seed(41)
+    with torch.no_grad():
+        for n, prm in dec.named_parameters():
+            if n.endswith(".bias") or n.endswith("norm2.weight"):
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.1)
+    R = 6
+    grid = torch.randn(B, c_dim, R, R, R, generator=g)
+    p = (torch.rand(B, N, 3, generator=g) - 0.5) * 1.2
+    c_img = torch.randn(B, N, c_dim, generator=g) * (torch.rand(B, N, 1, generator=g) < 0.3)
+    w = torch.randn(B, N, generator=g)
+    sdr = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in dec.state_dict().items()}
+    gr, cr = grid.clone().requires_grad_(), c_img.clone().requires_grad_()
+    ref = orc.attention_decoder_forward_img(sdr, p, gr, cr, leaky=leaky)
+    (ref * w).sum().backward()
+    dec = dec.to(DEV)
+    gd, cd = grid.to(DEV).requires_grad_(), c_img.to(DEV).requires_grad_()
+    out = dec.forward_img(p.to(DEV), {"grid": gd}, cd)
+    (out * w.to(DEV)).sum().backward()
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) <= 5e-5 * max(1.0, float(ref.detach().abs().max()))
+    rows_bad = 0
+    for got, refg, key in ((cd.grad, cr.grad, "d c_img"), (gd.grad, gr.grad, "d grid")):
+        err = (got.cpu() - refg).abs()
+        tol = 1e-4 * float(refg.abs().max())
+        if key == "d c_img":
+            rows_bad = int((err.reshape(B * N, -1).max(dim=1).values > tol).sum())
+            assert rows_bad <= 2, (key, rows_bad, float(err.max()), tol)
+        assert float((got.cpu() - refg).norm()) <= (1e-4 if rows_bad == 0 else 2e-2) * float(refg.norm()), (key, float(err.max()), tol)
+    ptol = 2e-4 if rows_bad == 0 else 2e-2
+    shared = "fuser.decoder.layers.0.self_attn."
+    for n, prm in dec.named_parameters():
+        refp = sdr[n].grad
+        if n.startswith("fuser.encoder.layers.0.self_attn."):       # the shared unit: both uses
+            other = sdr[n.replace("fuser.encoder.", "fuser.decoder.")].grad
+            refp = refp + other if other is not None else refp
+        if refp is None:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, n
+            continue
+        if n.endswith("norm2.bias"):                                # zero in exact arithmetic (InstanceNorm follows): noise on both sides
+            continue
+        scale = max(1e-6, float(refp.abs().max()))
+        assert float((prm.grad.cpu() - refp).abs().max()) <= ptol * scale, (n, float((prm.grad.cpu() - refp).abs().max()), scale)
+    assert not any(n.startswith(shared) for n, _ in dec.named_parameters())
+    # train mode
+    dec.train()
+    outs = []
+    for seed in (7, 7, 8):
+        torch.manual_seed(seed)
+        for prm in dec.parameters():
+            prm.grad = None
+        o = dec.forward_img(p.to(DEV), {"grid": gd}, cd)
+        (o * w.to(DEV)).sum().backward()
+        outs.append((o.detach().clone(), dec.fc_p.weight.grad.clone()))
+        assert bool(torch.isfinite(o).all()) and all(bool(torch.isfinite(q.grad).all()) for q in dec.parameters() if q.grad is not None)
+    assert torch.equal(outs[0][0], outs[1][0]) and not torch.equal(outs[0][0], outs[2][0])
+    assert float((outs[0][1] - outs[1][1]).abs().max()) <= 1e-5 * float(outs[0][1].abs().max())      # (atomics in the grid scatter only)
 
 
 def test_wide_fusion_against_the_oracle_on_a_whole_chunk():

@@ -208,3 +208,61 @@ def test_oracle_plane_unet_matches_the_reference_module_golden():
         idx = torch.randint(0, gr.numel(), (64,), generator=torch.Generator().manual_seed(int(z["seeds"][3]) + sum(map(ord, name))))
         ref = torch.from_numpy(z[f"gsample.{name}"]).double()
         assert float((gr[idx] - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1e-6) + 1e-9, name
+
+
+G20_SAMPLE_SEED = 2000
+
+
+def _g20_check_param_grads(z, tag, grads, tol, sample_seed=G20_SAMPLE_SEED):
+    """Per parameter: the 64 sampled entries and the sum of its gradient against g20 (a parameter absent from g20 is one the reference
+    left without gradient on this path)."""
+    seen = 0
+    for name, gr in grads.items():
+        key = f"{tag}.gsum.{name}"
+        if key not in z:
+            assert gr is None or float(gr.abs().max()) == 0.0, name
+            continue
+        seen += 1
+        gr = gr.double().reshape(-1).cpu()
+        if name.endswith("norm2.bias"):
+            # a per-channel constant in front of InstanceNorm (TransformerFusion.py:259-262, 299-304): its gradient is zero in exact
+            # arithmetic and rounding noise in the reference (1e-6 of norm2.weight's) -- noise here as well, nothing to compare digit by digit
+            wsum = z[key.replace("norm2.bias", "norm2.weight")][1]
+            assert float(gr.abs().sum()) <= 1e-4 * wsum and z[key][1] <= 1e-4 * wsum, (tag, name)
+            continue
+        idx = torch.randint(0, gr.numel(), (64,), generator=torch.Generator().manual_seed(sample_seed + sum(map(ord, name))))
+        ref = T(z[f"{tag}.gsample.{name}"]).double()
+        gs = z[key]
+        typical = max(1e-12, float(gs[1]) / gr.numel())
+        assert float((gr[idx] - ref).abs().max()) <= tol * max(8 * typical, float(ref.abs().max())), (tag, name)
+        assert abs(float(gr.sum()) - gs[0]) <= tol * gs[1] + 1e-9, (tag, name)
+    assert seen == sum(1 for k in z if k.startswith(f"{tag}.gsum."))
+
+
+@pytest.mark.parametrize("tag", ["D", "E"])
+def test_oracle_attention_decoder_autograd_matches_the_reference_gradients(tag):
+    """g20 (the REAL reference's autograd through AttentionDecoder.forward_img at c_dim 128 / hidden 256 / 5 blocks and 64 / 64 / 2,
+    make_attn_wide_goldens.py): torch autograd through the oracle's restatement gives the same d grid, d c_img and parameter
+    gradients -- what makes it the checker of the HIP backward at the widths in between (tests/test_fusion_gpu.py)."""
+    import os
+    from conftest import GOLDEN
+    a, sd = load_golden("g17_attention_wide.npz")
+    z = dict(np.load(os.path.join(GOLDEN, "g20_attention_wide_grads.npz")))
+    arrs = {k[2:]: v for k, v in a.items() if k.startswith(tag + ".")}
+    sdc = {k[2:]: v.float().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items() if k.startswith(tag + ".")}
+    grid = T(arrs["grid"].astype("float32")).requires_grad_(True)
+    c_img = T(arrs["c_img"].astype("float32")).requires_grad_(True)
+    out = orc.attention_decoder_forward_img(sdc, T(arrs["p"]), grid, c_img)
+    (out * T(z[f"{tag}.w"])).sum().backward()
+    for got, key in ((grid.grad, "d_grid"), (c_img.grad, "d_c_img")):
+        ref = T(z[f"{tag}.{key}"])
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (tag, key)
+    # the fuser's self-attention unit is ONE module used by its encoder and its decoder layer (TransformerFusion.py:282-296): the
+    # reference's named_parameters lists it once, under the encoder's name, with the sum of both uses' gradients
+    grads = {k: v.grad for k, v in sdc.items() if v.dtype.is_floating_point and "running" not in k}
+    for k in [k for k in grads if k.startswith("fuser.decoder.layers.0.self_attn.")]:
+        g = grads.pop(k)
+        enc = k.replace("fuser.decoder.", "fuser.encoder.")
+        if g is not None:
+            grads[enc] = g if grads[enc] is None else grads[enc] + g
+    _g20_check_param_grads(z, tag, grads, 2e-5)

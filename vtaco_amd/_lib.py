@@ -150,6 +150,8 @@ SIGNATURES = {
     "vt_decoder_wide_blob_t_bytes": (_SZ, [_I, _I, _I]),
     "vt_decoder_pack_wide_t": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),
     "vt_decode_bwd_wide": (_I, [_I, _I, _I, _VP, _I64, _VP, _I, _I, _I, _D, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "vt_decode_mlp_fwd_wide_train": (_I, [_VP, _I, _I, _VP, _I64, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
+    "vt_decode_mlp_bwd_wide": (_I, [_I, _I, _VP, _I64, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vt_decode_f16f8_covers": (_I, [_I, _I, _I, _F, _I64, _I64, _D]),
     "vt_decode_fwd_f16f8": (_I, [_VP, _I, _I, _I, _I64, _I, _F, _I64, _VP, _VP, _VP, _I, _VP, _D, _VP, _VP]),
     "vt_decoder_pack_t": (_I, [ctypes.POINTER(DecoderParams), _VP, _SZ, _VP]),

@@ -141,6 +141,26 @@ class _DecodeMlpFn(torch.autograd.Function):
         return (None, None, grad_c, *grads)
 
 
+class _DecodeMlpWideFn(torch.autograd.Function):
+    """_DecodeMlpFn at the widths beyond 32 / 32 (vt_decode_mlp_fwd_wide_train; backward vt_decode_mlp_bwd_wide + vt_rows_wgrad per
+    layer): gradients to the given features and to every decoder parameter (fc_p form)."""
+
+    @staticmethod
+    def forward(ctx, dec, p, c, *params):
+        out, save = ops.decode_mlp_fwd_wide_train(c, dec._blob(), p, dec.hidden_size, dec.n_blocks, dec.leaky)
+        ctx.dec, ctx.save, ctx.p, ctx.c = dec, save, p.detach(), c.detach()
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        dec = ctx.dec
+        blob_t = ops.pack_decoder_wide_t(dec.fc_p.weight, [l.weight for l in dec.fc_c], [(b.fc_0.weight, b.fc_1.weight) for b in dec.blocks],
+                                         dec.fc_out.weight, None)
+        grad_c, g = ops.decode_mlp_bwd_wide(blob_t, grad_out, ctx.save, ctx.p, ctx.c, dec.hidden_size, dec.n_blocks, dec.leaky)
+        grads = [g[key] if idx is None else g[key][idx] for key, idx in dec._param_order(False)]
+        return (None, None, grad_c, *grads)
+
+
 class LocalDecoder(nn.Module):
     """Decoder conditioned on a local 3-D feature grid.
 
@@ -351,15 +371,13 @@ class AttentionDecoder(LocalDecoder):
 
     def forward_img(self, p, c_plane, c_img, **kwargs):
         grid = self._grid_of(c_plane)
-        if self._wants_grad(grid, c_img) and self._wide:
-            raise VtError("AttentionDecoder: training is built at the shipped shape (hidden_size = c_dim = 32); the wider shapes run "
-                          "inference (torch.no_grad)")
         if self._wants_grad(grid, c_img):
             # under autograd every stage is HIP, forward and backward: vt_sample_grid[_bwd], vt_fusion_fwd_train / vt_fusion_bwd
-            # (train-mode dropout replayed from a seed), vt_decode_mlp_fwd_train / vt_decode_mlp_bwd / vt_decode_wgrad
+            # (train-mode dropout replayed from a seed), vt_decode_mlp_fwd_train / vt_decode_mlp_bwd / vt_decode_wgrad -- at the
+            # widths beyond 32 / 32 vt_decode_mlp_fwd_wide_train / vt_decode_mlp_bwd_wide / vt_rows_wgrad
             c = _SampleGridFn.apply(grid, p, self.padding)
             c = self.fuser.forward_train(c_img, c)
-            return _DecodeMlpFn.apply(self, p, c, *self._params(False))
+            return (_DecodeMlpWideFn if self._wide else _DecodeMlpFn).apply(self, p, c, *self._params(False))
         c = ops.sample_grid(grid, p, self.padding)
         c = self.fuser(c_img, 1, c, 1)
         return self._mlp_fwd(c, p)

@@ -172,10 +172,11 @@ decode_bwd_data_kernel(BwdArgs a) {
     }
 }
 
-// backward of vt_sample_grid alone: scatter d feat [total][32] to the 8 corners of every point
+// backward of vt_sample_grid alone: scatter d feat [total][C] to the 8 corners of every point (blockIdx.y = the 32-channel slice)
 __global__ void __launch_bounds__(256)
-sample_grid_bwd_kernel(DecodeArgs d, const float *grad_feat, float *grad_grid) {
+sample_grid_bwd_kernel(DecodeArgs d, const float *grad_feat, float *grad_grid, int C) {
     const int lane = threadIdx.x & 63, pl = lane & 31, h = lane >> 5;
+    grad_feat += 32 * blockIdx.y; grad_grid += 32 * blockIdx.y;
     const uint32_t ntiles = (d.total + 31u) >> 5;
     const int R = d.R;
     for (uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += gridDim.x * 4) {
@@ -185,14 +186,14 @@ sample_grid_bwd_kernel(DecodeArgs d, const float *grad_feat, float *grad_grid) {
         float px, py, pz;
         point_of(d, g, n, px, py, pz);
         const Tri t = tri_setup(px, py, pz, d.divisor, R);
-        const f32x16 dc = load_frag16(grad_feat + (size_t)g * 32 + 16 * h);
-        float *gb = grad_grid + (size_t)b * R * R * R * 32 + 16 * h;
+        const f32x16 dc = load_frag16(grad_feat + (size_t)g * C + 16 * h);
+        float *gb = grad_grid + (size_t)b * R * R * R * C + 16 * h;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int zz = (k & 4) ? t.z1 : t.z0, yy = (k & 2) ? t.y1 : t.y0, xx = (k & 1) ? t.x1 : t.x0;
             const float w = (((k & 1) ? t.wx1 : t.wx0) * ((k & 2) ? t.wy1 : t.wy0)) * ((k & 4) ? t.wz1 : t.wz0);
             if (w != 0.0f) {
-                float *dst = gb + (((size_t)zz * R + yy) * R + xx) * 32;
+                float *dst = gb + (((size_t)zz * R + yy) * R + xx) * C;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) atomicAdd(dst + s, w * dc[s]);
             }
@@ -209,8 +210,8 @@ sample_grid_bwd_kernel(DecodeArgs d, const float *grad_feat, float *grad_grid) {
 // 16 384 points against 0.1 ms for everything else it does).  A point whose own cell differs from its bin's (the two
 // normalisations round differently on a cell boundary) falls back to its own 8 x 32 atomics: same sum either way.
 __global__ void __launch_bounds__(256)
-sample_grid_bwd_sorted_kernel(DecodeArgs d, const float *grad_feat, const int *order, const int *seg_lo, const int *seg_hi, float *grad_grid) {
-    const int lane = threadIdx.x & 63, ch = lane & 31, half = lane >> 5;
+sample_grid_bwd_sorted_kernel(DecodeArgs d, const float *grad_feat, const int *order, const int *seg_lo, const int *seg_hi, float *grad_grid, int C) {
+    const int lane = threadIdx.x & 63, ch = (lane & 31) + 32 * blockIdx.y, half = lane >> 5;         // blockIdx.y = the 32-channel slice
     const int R = d.R;
     for (uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6); g < d.total; g += gridDim.x * 4) {
         const uint32_t b = g / d.N, t = g - b * d.N;
@@ -223,12 +224,12 @@ sample_grid_bwd_sorted_kernel(DecodeArgs d, const float *grad_feat, const int *o
         float acc[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] = 0.0f;
-        float *gb = grad_grid + (size_t)b * R * R * R * 32 + ch;
+        float *gb = grad_grid + (size_t)b * R * R * R * C + ch;
         for (int j = lo + half; j < hi; j += 2) {
             const uint32_t n = (uint32_t)ord[j], gn = b * d.N + n;
             point_of(d, gn, n, px, py, pz);
             const Tri tr = tri_setup(px, py, pz, d.divisor, R);
-            const float v = grad_feat[(size_t)gn * 32 + ch];
+            const float v = grad_feat[(size_t)gn * C + ch];
             const bool same = tr.x0 == head.x0 && tr.y0 == head.y0 && tr.z0 == head.z0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -236,7 +237,7 @@ sample_grid_bwd_sorted_kernel(DecodeArgs d, const float *grad_feat, const int *o
                 if (same) acc[k] = fmaf(w, v, acc[k]);
                 else if (w != 0.0f) {
                     const int zz = (k & 4) ? tr.z1 : tr.z0, yy = (k & 2) ? tr.y1 : tr.y0, xx = (k & 1) ? tr.x1 : tr.x0;
-                    atomicAdd(gb + (((size_t)zz * R + yy) * R + xx) * 32, w * v);
+                    atomicAdd(gb + (((size_t)zz * R + yy) * R + xx) * C, w * v);
                 }
             }
         }
@@ -247,7 +248,7 @@ sample_grid_bwd_sorted_kernel(DecodeArgs d, const float *grad_feat, const int *o
             for (int k = 0; k < 8; ++k) {
                 if (acc[k] == 0.0f) continue;
                 const int zz = (k & 4) ? head.z1 : head.z0, yy = (k & 2) ? head.y1 : head.y0, xx = (k & 1) ? head.x1 : head.x0;
-                atomicAdd(gb + (((size_t)zz * R + yy) * R + xx) * 32, acc[k]);
+                atomicAdd(gb + (((size_t)zz * R + yy) * R + xx) * C, acc[k]);
             }
         }
     }
@@ -362,10 +363,10 @@ decode_wgrad_reduce_kernel(ReduceArgs a) {
 }
 
 bool fill_decode_args(DecodeArgs &d, int B, int R, int C, const float *pts, int64_t N, int nx, float box,
-                      int64_t first, double padding, const char *who, int &rc) {
+                      int64_t first, double padding, const char *who, int &rc, bool any_width = false) {
     rc = 0;
     if (B <= 0 || R < 2 || N <= 0) { rc = vt_fail(VT_ERR_INVALID, who); return false; }
-    if (C != 32) { rc = vt_fail(VT_ERR_UNSUPPORTED, "c_dim must be 32"); return false; }
+    if (any_width ? (C <= 0 || (C & 31)) : C != 32) { rc = vt_fail(VT_ERR_UNSUPPORTED, any_width ? "c_dim must be a multiple of 32" : "c_dim must be 32"); return false; }
     if ((int64_t)B * N >= (int64_t)1 << 31) { rc = vt_fail(VT_ERR_UNSUPPORTED, "B*N must be < 2^31"); return false; }
     if (!pts && nx < 2) { rc = vt_fail(VT_ERR_INVALID, "lattice mode needs nx >= 2"); return false; }
     d.c_direct = nullptr; d.brick = 0; d.cimg_ids = nullptr; d.cimg_table = nullptr; d.cimg_nf = 0; d.grid = nullptr; d.pts = pts; d.c_img = nullptr; d.blob = nullptr; d.out = nullptr; d.out2 = nullptr; d.save = nullptr;
@@ -467,11 +468,11 @@ int vt_sample_grid_bwd(int B, int R, int C, const float *pts, int64_t N,
     if (!grad_feat || !grad_grid_cl) return vt_fail(VT_ERR_INVALID, "vt_sample_grid_bwd: null argument");
     DecodeArgs d;
     int rc;
-    if (!fill_decode_args(d, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, padding, "vt_sample_grid_bwd: bad size", rc)) return rc;
+    if (!fill_decode_args(d, B, R, C, pts, N, lattice_nx, lattice_box, lattice_first, padding, "vt_sample_grid_bwd: bad size", rc, true)) return rc;
     int64_t blocks = (((int64_t)d.total + 31) / 32 + 3) / 4;
     const int64_t cap = 8 * vt_num_cus();
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(sample_grid_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d, grad_feat, grad_grid_cl);
+    hipLaunchKernelGGL(sample_grid_bwd_kernel, dim3((unsigned)blocks, (unsigned)(C / 32)), dim3(256), 0, (hipStream_t)stream, d, grad_feat, grad_grid_cl, C);
     return vt_check(hipGetLastError(), "vt_sample_grid_bwd");
 }
 
@@ -480,11 +481,11 @@ int vt_sample_grid_bwd_sorted(int B, int R, int C, const float *pts, int64_t N, 
     if (!grad_feat || !grad_grid_cl || !pts || !order || !seg_lo || !seg_hi) return vt_fail(VT_ERR_INVALID, "vt_sample_grid_bwd_sorted: null argument");
     DecodeArgs d;
     int rc;
-    if (!fill_decode_args(d, B, R, C, pts, N, 0, 0.0f, 0, padding, "vt_sample_grid_bwd_sorted: bad size", rc)) return rc;
+    if (!fill_decode_args(d, B, R, C, pts, N, 0, 0.0f, 0, padding, "vt_sample_grid_bwd_sorted: bad size", rc, true)) return rc;
     int64_t blocks = ((int64_t)d.total + 3) / 4;
     const int64_t cap = 32 * vt_num_cus();
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(sample_grid_bwd_sorted_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d, grad_feat, order, seg_lo, seg_hi, grad_grid_cl);
+    hipLaunchKernelGGL(sample_grid_bwd_sorted_kernel, dim3((unsigned)blocks, (unsigned)(C / 32)), dim3(256), 0, (hipStream_t)stream, d, grad_feat, order, seg_lo, seg_hi, grad_grid_cl, C);
     return vt_check(hipGetLastError(), "vt_sample_grid_bwd_sorted");
 }
 

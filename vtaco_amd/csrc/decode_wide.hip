@@ -279,6 +279,7 @@ struct WideBwdArgs {
     const float *blob_t, *save, *grad_out, *grad_out2;
     float *gws, *grad_grid, *grad_cimg;
     int H, C, nb, leaky, nearest;
+    float *grad_c;              // d c per point [total][C] instead of the scatter (the MLP on given features)
 };
 
 template <int WIDE_WAVES>
@@ -345,7 +346,7 @@ decode_wide_bwd_kernel(WideBwdArgs a) {
                 if (live) store_acc16(a.gws + gw.dn + ((size_t)blk * d.total + gj) * H + 32 * ob, dn, kg);
             }
             __syncthreads();                                          // bufG = dN_i complete; every read of bufH done
-            if (ob < nc && a.grad_grid) dc = wide_gemm(dc, wb + lay.w_1 + lay.w_0, ob, H, bufG, lane);     // Wc_i^T dN_i
+            if (ob < nc && (a.grad_grid || a.grad_c)) dc = wide_gemm(dc, wb + lay.w_1 + lay.w_0, ob, H, bufG, lane);     // Wc_i^T dN_i
         }
         // ---- the front: d c_img = Wp[:, 3:]^T dN_0 (bufG still holds dN_0) ----
         if (ob < nc && a.grad_cimg) {
@@ -355,6 +356,7 @@ decode_wide_bwd_kernel(WideBwdArgs a) {
             const f32x16 dci = wide_gemm(z, a.blob_t + lay.w_pc, ob, H, bufG, lane);
             if (live) store_acc16(a.grad_cimg + (size_t)gj * C + 32 * ob, dci, kg);
         }
+        if (a.grad_c && ob < nc && live) store_acc16(a.grad_c + (size_t)gj * C + 32 * ob, dc, kg);
         // ---- d c -> the grid gradient ----
         if (a.grad_grid) {
             if (ob < nc) {
@@ -1009,9 +1011,11 @@ int vt_decoder_pack_wide_t(const vt_decoder_params *p, float *blob_t, size_t blo
     return vt_check(hipGetLastError(), "vt_decoder_pack_wide_t");
 }
 
-int vt_decode_bwd_wide(int B, int R, int C, const float *pts, int64_t N, const float *blob_t, int hidden, int n_blocks, int flags,
-                       double padding, const float *grad_out, const float *grad_out2, const float *save, float *gws,
-                       float *grad_grid_cl, float *grad_c_img, void *stream) {
+}  // extern "C"
+
+static int wide_bwd_impl(int B, int R, int C, const float *pts, int64_t N, const float *blob_t, int hidden, int n_blocks, int flags,
+                         double padding, const float *grad_out, const float *grad_out2, const float *save, float *gws,
+                         float *grad_grid_cl, float *grad_c_img, float *grad_c, void *stream) {
     if (!pts || !blob_t || !grad_out || !save || !gws) return vt_fail(VT_ERR_INVALID, "vt_decode_bwd_wide: null argument");
     if (!wide_shape_ok(hidden, C, n_blocks, 3))
         return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_bwd_wide: hidden and c_dim must be multiples of 32 up to 256");
@@ -1021,7 +1025,7 @@ int vt_decode_bwd_wide(int B, int R, int C, const float *pts, int64_t N, const f
     a.d.pts = pts; a.d.N = (uint32_t)N; a.d.total = (uint32_t)((uint64_t)B * (uint64_t)N); a.d.R = R;
     a.d.divisor = (float)(1.0 + padding + 10e-4);
     a.blob_t = blob_t; a.save = save; a.grad_out = grad_out; a.grad_out2 = grad_out2; a.gws = gws;
-    a.grad_grid = grad_grid_cl; a.grad_cimg = grad_c_img;
+    a.grad_grid = grad_grid_cl; a.grad_cimg = grad_c_img; a.grad_c = grad_c;
     a.H = hidden; a.C = C; a.nb = n_blocks; a.leaky = (flags & VT_WIDE_LEAKY) ? 1 : 0; a.nearest = (flags & VT_WIDE_NEAREST) ? 1 : 0;
     const int widest = hidden > C ? hidden : C;
     const int waves = widest <= 128 ? 4 : 8;
@@ -1039,6 +1043,31 @@ int vt_decode_bwd_wide(int B, int R, int C, const float *pts, int64_t N, const f
     if (waves == 4) hipLaunchKernelGGL(decode_wide_bwd_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(decode_wide_bwd_kernel<8>, grid, dim3(512), lds, (hipStream_t)stream, a);
     return vt_check(hipGetLastError(), "vt_decode_bwd_wide");
+}
+
+extern "C" {
+
+int vt_decode_bwd_wide(int B, int R, int C, const float *pts, int64_t N, const float *blob_t, int hidden, int n_blocks, int flags,
+                       double padding, const float *grad_out, const float *grad_out2, const float *save, float *gws,
+                       float *grad_grid_cl, float *grad_c_img, void *stream) {
+    return wide_bwd_impl(B, R, C, pts, N, blob_t, hidden, n_blocks, flags, padding, grad_out, grad_out2, save, gws, grad_grid_cl, grad_c_img,
+                         nullptr, stream);
+}
+
+// the conditioned MLP on given features under autograd (AttentionDecoder.forward_img behind its fuser at the widths beyond 32 / 32):
+// the forward of vt_decode_mlp_fwd_wide that keeps every layer's input (the c slot of ``save`` stays unwritten: the caller holds c),
+// and the data pass that returns d c per point [B][N][C] instead of scattering it to a grid
+int vt_decode_mlp_fwd_wide_train(const float *c, int B, int C, const float *pts, int64_t N, const float *blob, int hidden, int n_blocks,
+                                 int flags, float *out, float *out2, float *save, void *stream) {
+    if (!c || !pts || !save) return vt_fail(VT_ERR_INVALID, "vt_decode_mlp_fwd_wide_train: null argument");
+    return wide_fwd_impl(nullptr, B, 2, C, pts, N, 0, 0.0f, 0, nullptr, blob, hidden, n_blocks, flags, 0.1, out, out2, save, stream,
+                         nullptr, nullptr, c);
+}
+
+int vt_decode_mlp_bwd_wide(int B, int C, const float *pts, int64_t N, const float *blob_t, int hidden, int n_blocks, int flags,
+                           const float *grad_out, const float *grad_out2, const float *save, float *gws, float *grad_c, void *stream) {
+    if (!grad_c) return vt_fail(VT_ERR_INVALID, "vt_decode_mlp_bwd_wide: null argument");
+    return wide_bwd_impl(B, 2, C, pts, N, blob_t, hidden, n_blocks, flags, 0.1, grad_out, grad_out2, save, gws, nullptr, nullptr, grad_c, stream);
 }
 
 }  // extern "C"

@@ -1046,6 +1046,40 @@ def pack_decoder_wide_t(fc_p_w, fc_c, blocks, fc_out_w, fc_out2_w=None):
     return out
 
 
+def _wide_zero_grads(H, C, nb, p_in, dev, contact):
+    z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+    g = {"fc_p.weight": z(H, p_in), "fc_p.bias": z(H), "fc_c.weight": [z(H, C) for _ in range(nb)], "fc_c.bias": [z(H) for _ in range(nb)],
+         "fc_0.weight": [z(H, H) for _ in range(nb)], "fc_0.bias": [z(H) for _ in range(nb)],
+         "fc_1.weight": [z(H, H) for _ in range(nb)], "fc_1.bias": [z(H) for _ in range(nb)],
+         "fc_out.weight": z(1, H), "fc_out.bias": z(1)}
+    if contact:
+        g["fc_out_contact.weight"], g["fc_out_contact.bias"] = z(1, H), z(1)
+    return g
+
+
+def _wide_wgrads(save, gws, P, H, C, nb, pts, c_rows, c_img, grad_out, g2):
+    """The decoder's parameter gradients from the rows the data pass leaves (vt_rows_wgrad per layer; layouts: decode_wide.hip
+    wide_save_layout / wide_gws_layout).  ``c_rows`` [P, C]: the conditioning features (the save's c slot, or the caller's)."""
+    sv_blk = save[P * C:P * C + 2 * nb * P * H].view(nb, 2, P, H)
+    sv_af = save[P * C + 2 * nb * P * H:].view(P, H)
+    dn = gws[:(nb + 1) * P * H].view(nb + 1, P, H)
+    dh = gws[(nb + 1) * P * H:].view(nb, P, H)
+    g = {}
+    x2 = _c(c_img.float()).view(P, C) if c_img is not None else None
+    g["fc_p.weight"], g["fc_p.bias"] = rows_wgrad(dn[0], pts.view(P, 3), x2)
+    wc, bc, w0, b0, w1, b1 = [], [], [], [], [], []
+    for i in range(nb):
+        a, b = rows_wgrad(dn[i], c_rows); wc.append(a); bc.append(b)
+        a, b = rows_wgrad(dh[i], sv_blk[i, 0]); w0.append(a); b0.append(b)
+        a, b = rows_wgrad(dn[i + 1], sv_blk[i, 1]); w1.append(a); b1.append(b)
+    g["fc_c.weight"], g["fc_c.bias"] = wc, bc
+    g["fc_0.weight"], g["fc_0.bias"], g["fc_1.weight"], g["fc_1.bias"] = w0, b0, w1, b1
+    g["fc_out.weight"], g["fc_out.bias"] = rows_wgrad(grad_out.view(P, 1), sv_af)
+    if g2 is not None:
+        g["fc_out_contact.weight"], g["fc_out_contact.bias"] = rows_wgrad(g2.view(P, 1), sv_af)
+    return g
+
+
 def decode_bwd_wide(grid_shape, blob_t, grad_out, save, pts, hidden, nb, leaky, nearest, padding=0.1, c_img=None,
                     want_grid_grad=True, grad_out2=None):
     """vt_decode_bwd_wide + the weight gradients (vt_rows_wgrad over the saved layer inputs and the output gradients the data pass
@@ -1063,40 +1097,50 @@ def decode_bwd_wide(grid_shape, blob_t, grad_out, save, pts, hidden, nb, leaky, 
     ggrid = torch.zeros((B, R, R, R, C), dtype=torch.float32, device=dev) if want_grid_grad else None
     gimg = torch.empty((B, N, C), dtype=torch.float32, device=dev) if c_img is not None else None
     if P == 0:                                                      # an empty query set: every gradient is zero, no launch
-        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-        p_in = 3 + C if c_img is not None else 3
-        g = {"fc_p.weight": z(H, p_in), "fc_p.bias": z(H), "fc_c.weight": [z(H, C) for _ in range(nb)], "fc_c.bias": [z(H) for _ in range(nb)],
-             "fc_0.weight": [z(H, H) for _ in range(nb)], "fc_0.bias": [z(H) for _ in range(nb)],
-             "fc_1.weight": [z(H, H) for _ in range(nb)], "fc_1.bias": [z(H) for _ in range(nb)],
-             "fc_out.weight": z(1, H), "fc_out.bias": z(1)}
-        if g2 is not None:
-            g["fc_out_contact.weight"], g["fc_out_contact.bias"] = z(1, H), z(1)
+        g = _wide_zero_grads(H, C, nb, 3 + C if c_img is not None else 3, dev, g2 is not None)
         return (ggrid.permute(0, 4, 1, 2, 3) if ggrid is not None else None), gimg, g
     gws = torch.empty(lib.vt_decode_wide_gws_floats(P, H, C, int(nb)), dtype=torch.float32, device=dev)
     check(lib.vt_decode_bwd_wide(B, R, C, dev_ptr(pts, "pts"), N, dev_ptr(blob_t, "blob_t"), H, int(nb), _wide_flags(leaky, nearest),
                                  float(padding), dev_ptr(grad_out, "grad_out"), dev_ptr(g2, "grad_out2"), dev_ptr(save, "save"),
                                  dev_ptr(gws, "gws"), dev_ptr(ggrid, "grad_grid"), dev_ptr(gimg, "grad_c_img"), stream_ptr()),
           "vt_decode_bwd_wide")
-    # the slots of the two buffers as [P, width] views (layouts: decode_wide.hip wide_save_layout / wide_gws_layout)
-    sv_c = save[:P * C].view(P, C)
-    sv_blk = save[P * C:P * C + 2 * nb * P * H].view(nb, 2, P, H)
-    sv_af = save[P * C + 2 * nb * P * H:].view(P, H)
-    dn = gws[:(nb + 1) * P * H].view(nb + 1, P, H)
-    dh = gws[(nb + 1) * P * H:].view(nb, P, H)
-    g = {}
-    x2 = _c(c_img.float()).view(P, C) if c_img is not None else None
-    g["fc_p.weight"], g["fc_p.bias"] = rows_wgrad(dn[0], pts.view(P, 3), x2)
-    wc, bc, w0, b0, w1, b1 = [], [], [], [], [], []
-    for i in range(nb):
-        a, b = rows_wgrad(dn[i], sv_c); wc.append(a); bc.append(b)
-        a, b = rows_wgrad(dh[i], sv_blk[i, 0]); w0.append(a); b0.append(b)
-        a, b = rows_wgrad(dn[i + 1], sv_blk[i, 1]); w1.append(a); b1.append(b)
-    g["fc_c.weight"], g["fc_c.bias"] = wc, bc
-    g["fc_0.weight"], g["fc_0.bias"], g["fc_1.weight"], g["fc_1.bias"] = w0, b0, w1, b1
-    g["fc_out.weight"], g["fc_out.bias"] = rows_wgrad(grad_out.view(P, 1), sv_af)
-    if g2 is not None:
-        g["fc_out_contact.weight"], g["fc_out_contact.bias"] = rows_wgrad(g2.view(P, 1), sv_af)
+    g = _wide_wgrads(save, gws, P, H, C, int(nb), pts, save[:P * C].view(P, C), c_img, grad_out, g2)
     return (ggrid.permute(0, 4, 1, 2, 3) if ggrid is not None else None), gimg, g
+
+
+def decode_mlp_fwd_wide_train(c, blob, pts, hidden, nb, leaky):
+    """vt_decode_mlp_fwd_wide_train: the conditioned MLP on given features c [B,N,C] at the wide shapes, keeping every layer's input."""
+    lib = _lib.load()
+    c = _c(c.detach().float())
+    pts = _c(pts.detach().float())
+    B, N, C = c.shape
+    if lib.vt_decode_wide_save_floats(1, int(hidden), C, int(nb)) == 0:
+        raise VtError(f"decoder shape hidden={hidden}, c_dim={C}, n_blocks={nb} is not built (multiples of 32 up to 256)")
+    out = torch.empty((B, N), dtype=torch.float32, device=c.device)
+    save = torch.empty(lib.vt_decode_wide_save_floats(B * N, int(hidden), C, int(nb)) if B * N else 0, dtype=torch.float32, device=c.device)
+    if B * N:
+        check(lib.vt_decode_mlp_fwd_wide_train(dev_ptr(c, "c"), B, C, dev_ptr(pts, "pts"), N, dev_ptr(blob, "blob"), int(hidden), int(nb),
+                                               _wide_flags(leaky, False), dev_ptr(out, "out"), None, dev_ptr(save, "save"), stream_ptr()),
+              "vt_decode_mlp_fwd_wide_train")
+    return out, save
+
+
+def decode_mlp_bwd_wide(blob_t, grad_out, save, pts, c, hidden, nb, leaky):
+    """vt_decode_mlp_bwd_wide + the weight gradients: (grad_c [B,N,C], dict of parameter gradients keyed like split_decoder_grads)."""
+    lib = _lib.load()
+    grad_out = _c(grad_out.float())
+    pts = _c(pts.float())
+    c = _c(c.float())
+    B, N, C = c.shape
+    H, P, dev = int(hidden), B * N, grad_out.device
+    grad_c = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+    if P == 0:
+        return grad_c, _wide_zero_grads(H, C, nb, 3, dev, False)
+    gws = torch.empty(lib.vt_decode_wide_gws_floats(P, H, C, int(nb)), dtype=torch.float32, device=dev)
+    check(lib.vt_decode_mlp_bwd_wide(B, C, dev_ptr(pts, "pts"), N, dev_ptr(blob_t, "blob_t"), H, int(nb), _wide_flags(leaky, False),
+                                     dev_ptr(grad_out, "grad_out"), None, dev_ptr(save, "save"), dev_ptr(gws, "gws"),
+                                     dev_ptr(grad_c, "grad_c"), stream_ptr()), "vt_decode_mlp_bwd_wide")
+    return grad_c, _wide_wgrads(save, gws, P, H, C, int(nb), pts, c.view(P, C), None, grad_out, None)
 
 
 # --------------------------------------------------------------------------------------
