@@ -36,6 +36,9 @@ def fill():
 
 def one():
     if bwd:
+        for prm in net.parameters():        # as after optimizer.zero_grad(): the gradients are written, not accumulated
+            prm.grad = None
+        x.grad = None
         y = net(x)
         y.sum().backward()
     else:

@@ -22,7 +22,9 @@ print(f"{1e2 * (time.perf_counter() - t0):.2f} ms per step")
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     vis.train_step(batch, vf)
     torch.cuda.synchronize()
-ev = [e for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CUDA]
+# (kineto mirrors user annotations such as "Optimizer.step#Adam.step" onto the device timeline as ranges over their kernels: not launches)
+ev = [e for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CUDA and not getattr(e, "is_user_annotation", False)
+      and not e.key.startswith("Optimizer.")]
 ev.sort(key=lambda e: -e.device_time_total)
 print(f"device time of the step's kernels: {sum(e.device_time_total for e in ev) / 1e3:.2f} ms over {sum(e.count for e in ev)} launches")
 for e in ev[:45]:

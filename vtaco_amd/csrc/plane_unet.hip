@@ -23,6 +23,7 @@
 // (tools/probe/barrier_probe.hip) against 1.45 us for a kernel boundary -- so the phases are launches.
 //
 // The training forward is the same launch sequence with the activations kept (the workspace) for vt_plane_unet_bwd.
+#include <algorithm>
 #include "vt_common.h"
 #include "decode_common.h"
 
@@ -492,18 +493,29 @@ inline long long pu_dz_offset(const PuDims &d, int j) {
     return off;
 }
 struct PuWgPlan { int px_per_slice, n_slices, ntaps; long long part_floats, db_floats; };
+// A phase's weight gradient costs tiles x pixels x taps MFMA pairs.  All phases share one launch, so the slices are cut for EQUAL work
+// per workgroup -- the whole net's cost over ~3 workgroups per slot of the chip (2 per CU) -- instead of a fixed pixel count: fewer,
+// longer walks where the weights are small (the partial sums a slice writes are ntaps x Cout x Cin floats whatever its length: 101 MB
+// per backward of 24 planes with 128-pixel slices, half of it now), at least 64 pixels each.
+inline long long pu_wg_cost(const PuDims &d, int j) {
+    const PuShape s = pu_shape(d, j);
+    const long long P = (long long)d.n_img * (d.H >> s.level_in) * (d.W >> s.level_in);
+    return (long long)(s.Cout / 32) * (s.Cin / 32) * P * (s.mode == 1 ? 4 : s.ntaps);
+}
 inline PuWgPlan pu_wg_plan(const PuDims &d, int j) {
     const PuShape s = pu_shape(d, j);
     PuWgPlan w;
     const long long P = (long long)d.n_img * (d.H >> s.level_in) * (d.W >> s.level_in);
-    const int tiles = (s.Cout / 32) * (s.Cin / 32);
-    long long slices = (P + 127) / 128, cap = 256 / tiles;
-    if (cap < 1) cap = 1;
-    if (slices > cap) slices = cap;
+    w.ntaps = s.mode == 1 ? 4 : s.ntaps;
+    long long total = 0;
+    for (int k = 0; k < pu_n_phases(d); ++k) total += pu_wg_cost(d, k);
+    long long share = total / 1536;                                  // pixel-taps per workgroup
+    if (share < 64 * 9) share = 64 * 9;
+    long long slices = (P * w.ntaps + share / 2) / share, most = (P + 63) / 64;
+    if (slices > most) slices = most;
     if (slices < 1) slices = 1;
     w.px_per_slice = (int)(((P + slices - 1) / slices + 7) / 8 * 8);
     w.n_slices = (int)((P + w.px_per_slice - 1) / w.px_per_slice);
-    w.ntaps = s.mode == 1 ? 4 : s.ntaps;
     w.part_floats = (long long)w.n_slices * w.ntaps * s.Cout * s.Cin;
     w.db_floats = (long long)w.n_slices * s.Cout;
     return w;
@@ -597,12 +609,10 @@ __device__ __forceinline__ float pu_read1(const PuSrc &s, int img, int y, int x,
 }
 
 template <int MODE, int VK>      // MODE 0: 3x3 conv (9 taps); 1: transposed conv 2x2 stride 2 (4 parities); 2: 1x1 head
-__global__ void __launch_bounds__(256, 2) plane_unet_wgrad_kernel(PuWg w) {
+__device__ __forceinline__ void pu_wgrad_body(const PuWg &w, const int block, float *red, float *dbs) {
     constexpr int NT = MODE == 0 ? 9 : MODE == 1 ? 4 : 1;
-    __shared__ float red[3 * 16 * 64];
-    __shared__ float dbs[4 * 64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, lc = lane & 31;
-    const int cib = blockIdx.x % w.n_cib, cob = (blockIdx.x / w.n_cib) % w.n_cob, slice = blockIdx.x / (w.n_cib * w.n_cob);
+    const int cib = block % w.n_cib, cob = (block / w.n_cib) % w.n_cob, slice = block / (w.n_cib * w.n_cob);
     const int P = w.n_img * w.H * w.W;
     const int s0 = slice * w.px_per_slice + wave * (w.px_per_slice / 4);
     int s1 = s0 + w.px_per_slice / 4;
@@ -698,6 +708,28 @@ __global__ void __launch_bounds__(256, 2) plane_unet_wgrad_kernel(PuWg w) {
             for (int k = 0; k < 4; ++k) sum += dbs[k * 64 + threadIdx.x] + dbs[k * 64 + 32 + threadIdx.x];
             w.dbpart[(size_t)slice * w.Cout + cob * 32 + threadIdx.x] = sum;
         }
+    }
+}
+
+// Every phase's weight gradient in ONE launch behind the data-gradient chain (their inputs -- the forward activations, the dZ side
+// outputs, the consumers' dX -- all survive to the end of the chain): a phase alone offers <= 256 workgroups of a serial walk over its
+// slice, i.e. half the chip's slots at best for ~15 us each, nineteen times; together they are ~4000 workgroups, the longest first.
+enum { PU_W_CONV = 0, PU_W_CONV_POOL, PU_W_CONV_NCHW, PU_W_CONVT, PU_W_HEAD };
+struct PuWgAll { int n; int first[PU_MAX_PHASES + 1]; unsigned char kind[PU_MAX_PHASES + 1]; PuWg w[PU_MAX_PHASES]; };
+
+__global__ void __launch_bounds__(256, 2) plane_unet_wgrad_kernel(PuWgAll all) {
+    __shared__ float red[3 * 16 * 64];
+    __shared__ float dbs[4 * 64];
+    int k = 0;
+    while (k + 1 < all.n && (int)blockIdx.x >= all.first[k + 1]) ++k;
+    const PuWg &w = all.w[k];
+    const int block = (int)blockIdx.x - all.first[k];
+    switch (all.kind[k]) {
+    case PU_W_CONV: pu_wgrad_body<0, PU_L_PLAIN>(w, block, red, dbs); break;
+    case PU_W_CONV_POOL: pu_wgrad_body<0, PU_L_POOL>(w, block, red, dbs); break;
+    case PU_W_CONV_NCHW: pu_wgrad_body<0, PU_L_NCHW>(w, block, red, dbs); break;
+    case PU_W_CONVT: pu_wgrad_body<1, PU_L_PLAIN>(w, block, red, dbs); break;
+    default: pu_wgrad_body<2, PU_L_PLAIN>(w, block, red, dbs); break;
     }
 }
 
@@ -819,6 +851,9 @@ int vt_plane_unet_bwd(const float *x, int n_img, int H, int W, const vt_plane_un
     const int n = pu_n_phases(d), D = d.depth;
     PuFinAll fin{};
     fin.n = n;
+    PuWg wg[PU_MAX_PHASES];
+    int wg_kind[PU_MAX_PHASES], wg_blocks[PU_MAX_PHASES];
+    long long wg_cost[PU_MAX_PHASES];
     for (int j = n - 1; j >= 0; --j) {
         const PuShape sh = pu_shape(d, j);
         const PuBwd bw = pu_bwd_of(a, j);
@@ -834,12 +869,10 @@ int vt_plane_unet_bwd(const float *x, int n_img, int H, int W, const vt_plane_un
         w.part = part; w.dbpart = part + plan.part_floats;
         w.Cin = sh.Cin; w.Cout = sh.Cout; w.W = fp.W; w.H = fp.H; w.n_img = n_img; w.px_per_slice = plan.px_per_slice;
         w.n_cob = sh.Cout / 32; w.n_cib = sh.Cin / 32;
-        const dim3 grid((unsigned)(plan.n_slices * w.n_cob * w.n_cib));
-        if (sh.mode == 1) hipLaunchKernelGGL((plane_unet_wgrad_kernel<1, PU_L_PLAIN>), grid, dim3(256), 0, s, w);
-        else if (sh.ntaps == 1) hipLaunchKernelGGL((plane_unet_wgrad_kernel<2, PU_L_PLAIN>), grid, dim3(256), 0, s, w);
-        else if (fp.a.nchw) hipLaunchKernelGGL((plane_unet_wgrad_kernel<0, PU_L_NCHW>), grid, dim3(256), 0, s, w);
-        else if (fp.a.pool) hipLaunchKernelGGL((plane_unet_wgrad_kernel<0, PU_L_POOL>), grid, dim3(256), 0, s, w);
-        else hipLaunchKernelGGL((plane_unet_wgrad_kernel<0, PU_L_PLAIN>), grid, dim3(256), 0, s, w);
+        wg[j] = w;
+        wg_blocks[j] = plan.n_slices * w.n_cob * w.n_cib;
+        wg_kind[j] = sh.mode == 1 ? PU_W_CONVT : sh.ntaps == 1 ? PU_W_HEAD : fp.a.nchw ? PU_W_CONV_NCHW : fp.a.pool ? PU_W_CONV_POOL : PU_W_CONV;
+        wg_cost[j] = (long long)plan.px_per_slice * plan.ntaps * (fp.a.pool ? 2 : 1);      // a workgroup's walk: the longest go first
         PuFin &f = fin.f[j];
         f.part = w.part; f.dbpart = w.dbpart; f.Cin = sh.Cin; f.Cout = sh.Cout; f.mode = sh.mode; f.ntaps = plan.ntaps; f.n_slices = plan.n_slices;
         if (j < 2 * D) { f.dw = grads->down_w[j >> 1][j & 1]; f.db = grads->down_b[j >> 1][j & 1]; }
@@ -849,6 +882,20 @@ int vt_plane_unet_bwd(const float *x, int n_img, int H, int W, const vt_plane_un
             f.db = k == 0 ? grads->up_tb[u] : grads->up_b[u][k - 1];
         } else { f.dw = grads->final_w; f.db = grads->final_b; }
         if (!f.dw || !f.db) return vt_fail(VT_ERR_INVALID, "vt_plane_unet_bwd: null gradient buffer");
+    }
+    {
+        PuWgAll all{};
+        all.n = n;
+        int idx[PU_MAX_PHASES];
+        for (int j = 0; j < n; ++j) idx[j] = j;
+        std::stable_sort(idx, idx + n, [&](int x, int y) { return wg_cost[x] > wg_cost[y]; });
+        int total = 0;
+        for (int k = 0; k < n; ++k) {
+            all.first[k] = total; all.w[k] = wg[idx[k]]; all.kind[k] = (unsigned char)wg_kind[idx[k]];
+            total += wg_blocks[idx[k]];
+        }
+        all.first[n] = total;
+        hipLaunchKernelGGL(plane_unet_wgrad_kernel, dim3((unsigned)total), dim3(256), 0, s, all);
     }
     hipLaunchKernelGGL(plane_unet_wgrad_finalize_kernel, dim3(256, n), dim3(256), 0, s, fin);
     return vt_check(hipGetLastError(), "vt_plane_unet_bwd");
