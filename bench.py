@@ -193,15 +193,42 @@ DECODE_SOURCES = ("decode.hip", "decode_f16.hip", "decode_common.h", "decode_st3
                   "vt_common.h", "Makefile")
 
 
-def decode_source_hash():
-    """sha256 over the sources the decode kernels are built from (tools/src_hash.py prints the same): the committed counter
-    summary carries it in its first line, and counters collected on other sources are not reported."""
+WIDE_SOURCES = ("decode_wide.hip", "decode_wide_pipe.inc", "decode_common.h", "vt_common.h", "Makefile")
+PMC_WIDE_SUMMARY = os.path.join("profiles", "r06_pmc_wide_summary.csv")
+
+
+def source_hash(names):
     import hashlib
     h = hashlib.sha256()
-    for name in DECODE_SOURCES:
+    for name in names:
         with open(os.path.join(ROOT, "vtaco_amd", "csrc", name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
+
+
+def decode_source_hash():
+    """sha256 over the sources the decode kernels are built from (tools/src_hash.py prints the same): the committed counter
+    summary carries it in its first line, and counters collected on other sources are not reported."""
+    return source_hash(DECODE_SOURCES)
+
+
+def pmc_wide_table():
+    """{kernel key: {counter: mean per launch}} of the general-shape decoder's kernels (tools/pmc_wide.sh), or {} when the committed
+    summary was collected on other sources than this tree's (its first line carries their hash)."""
+    tab, stamp = {}, None
+    try:
+        for line in open(os.path.join(ROOT, PMC_WIDE_SUMMARY)).read().splitlines():
+            if line.startswith("#"):
+                if "wide_sources=" in line:
+                    stamp = line.split("wide_sources=", 1)[1].strip()
+                continue
+            if line.startswith("kernel,"):
+                continue
+            k, c, n, mean = line.split(",")
+            tab.setdefault(k, {})[c] = float(mean)
+    except Exception:
+        return {}
+    return tab if stamp == source_hash(WIDE_SOURCES) else {}
 
 
 _pmc_cache = {}

@@ -62,11 +62,25 @@ if "wide" in SECTIONS:
             for prec, kernel, peak in (("f32", "vt_decode_fwd_wide, exact f32", 157.3), ("f16x3", "vt_decode_fwd_wide_f16x3, split f16", 2500.0)):
                 t = timed(lambda: wdec.decode_lattice(wgrid, nx, precision=prec), 5, 1)
                 err = float((wdec.decode_lattice(wgrid, nx, precision=prec) - exact).abs().max())
+                roof = {"bound": "mfma", "achieved": flop * nx ** 3 / t / 1e12, "peak": peak, "unit": "TFLOP/s",
+                        "frac": flop * nx ** 3 / t / 1e12 / peak, "traffic": None}
+                # counters of tools/pmc_wide.sh (profiles/r06_pmc_wide_summary.csv; dropped when collected on other sources): HBM-side bytes
+                # per launch ((2 x FETCH_SIZE + WRITE_SIZE) KB, the guide's gfx950 correction), matrix pipe busy, L2 requests
+                import bench as _bench
+                pmc = _bench.pmc_wide_table().get(f"wide_{prec}_{hidden}", {})
+                if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                    roof["traffic"] = (2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+                    roof["algorithmic_bytes"] = 4.0 * (wgrid.numel() + nx ** 3)
+                if "GRBM_GUI_ACTIVE" in pmc and "SQ_VALU_MFMA_BUSY_CYCLES" in pmc:
+                    simd_cycles = 1024.0 * pmc["GRBM_GUI_ACTIVE"] / 8.0
+                    roof["pmc"] = {"matrix_pipe_busy": pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,
+                                   "valu_issue": 4.0 * pmc.get("SQ_INSTS_VALU", 0.0) / simd_cycles,
+                                   "l2_requests": pmc.get("TCC_REQ_sum"), "l2_hit_rate": (pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
+                                                                                        if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc else None),
+                                   "source": _bench.PMC_WIDE_SUMMARY}
                 print(json.dumps({"workload": f"LocalDecoder hidden {hidden} / c_dim {cd} / 5 blocks, 128^3 lattice ({kernel})",
                                   "ms": t * 1e3, "points_per_s": nx ** 3 / t, "tflops": flop * nx ** 3 / t / 1e12,
-                                  "max_abs_vs_exact_f32": err, "logit_absmax": float(exact.abs().max()),
-                                  "roofline": {"bound": "mfma", "achieved": flop * nx ** 3 / t / 1e12, "peak": peak, "unit": "TFLOP/s",
-                                               "frac": flop * nx ** 3 / t / 1e12 / peak, "traffic": None}}))
+                                  "max_abs_vs_exact_f32": err, "logit_absmax": float(exact.abs().max()), "roofline": roof}))
 
 # --- fusion: attention decoder, chunks of 2048 points as a batch of 1024 "scenes" sharing one grid
 torch.manual_seed(0)

@@ -1,8 +1,8 @@
 # Round-6 evidence on the GPU box (every file goes into profiles/ only through tools/keep_evidence.py: empty files and tracebacks are
-# refused).  Usage (GPU box): bash tools/probe/r06_collect.sh [decode|conv|fusion|train|rest ...]   (default: all)
+# refused).  Usage (GPU box): bash tools/probe/r06_collect.sh [decode|conv|fusion|wide|train|rest ...]   (default: all)
 cd /root/repo; mkdir -p gpurun_out/r06
 K="python3 tools/keep_evidence.py"
-WANT=${*:-decode conv fusion train rest}
+WANT=${*:-decode conv fusion wide train rest}
 has(){ case " $WANT " in *" $1 "*) return 0;; esac; return 1; }
 if has decode; then
   TAG=r06 bash tools/collect_profiles.sh > gpurun_out/r06_collect.log 2>&1; echo "collect rc=$?"; tail -3 gpurun_out/r06_collect.log
@@ -23,6 +23,11 @@ if has fusion; then
   TAG=r06 bash tools/pmc_fusion.sh > gpurun_out/r06_pmc_fusion.log 2>&1; echo "pmc_fusion rc=$?"
   $K gpurun_out/prof_fusion_r06/pmc_summary.csv gpurun_out/r06/r06_fusion_pmc_summary.csv --must-contain fusion_attend
   $K "$(find gpurun_out/prof_fusion_r06/stats -name '*kernel_stats.csv' | head -1)" gpurun_out/r06/r06_fusion_kernel_stats.csv --must-contain fusion_attend
+fi
+if has wide; then
+  TAG=r06 bash tools/pmc_wide.sh > gpurun_out/r06_pmc_wide.log 2>&1; echo "pmc_wide rc=$?"
+  $K gpurun_out/prof_wide_r06/pmc_summary.csv gpurun_out/r06/r06_pmc_wide_summary.csv --must-contain wide_sources= --must-contain FETCH_SIZE
+  $K "$(find gpurun_out/prof_wide_r06/stats -name '*kernel_stats.csv' | head -1)" gpurun_out/r06/r06_wide_kernel_stats.csv --must-contain decode_wide
 fi
 if has train; then
   (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_train_r06 -o train -- python3 /root/repo/tools/train_hip_prof.py 10 > /root/repo/gpurun_out/r06_train_hip.txt 2>&1; find /root/repo/gpurun_out/prof_train_r06 -name "*kernel_trace*" -delete)

@@ -5,4 +5,7 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-print(bench.decode_source_hash())
+if len(sys.argv) > 1 and sys.argv[1] == "wide":     # the general-shape decoder's sources (tools/pmc_wide.sh)
+    print(bench.source_hash(bench.WIDE_SOURCES))
+else:
+    print(bench.decode_source_hash())

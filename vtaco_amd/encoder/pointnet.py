@@ -187,9 +187,9 @@ class LocalPoolPointnet(nn.Module):
                 raise VtError("LocalPoolPointnet: out_mano=True is defined for the three planes or the grid only")
             if out_dim > 30 and manolayer_kwargs is None:
                 raise VtError("LocalPoolPointnet: out_dim > 30 runs the MANO layer (pointnet.py:194-201): pass manolayer_kwargs")
-        # channels_last_3d parameters: MIOpen's f32 conv3d is ~14x faster in that layout on gfx950
-        # (26 vs 382 ms fwd+bwd for two 64^3 scenes), and it is the layout the HIP kernels use
-        self.unet3d = UNet3D(**unet3d_kwargs).to(memory_format=torch.channels_last_3d) if unet3d else None
+        # (parameters in the default layout: the HIP kernels read [Cout,Cin,3,3,3] as it is -- channels_last_3d weights, which MIOpen's
+        # f32 conv3d wanted when the modules ran the net, cost three re-layout copies per layer and step on the packing kernels' way)
+        self.unet3d = UNet3D(**unet3d_kwargs) if unet3d else None
         self.reso_plane, self.reso_grid = plane_resolution, grid_resolution
         self.plane_type, self.padding = plane_type, padding
         # inference: the UNet3D's first layer skips the 8^3 blocks of the mean grid that no point comes near (ops.voxel_tile_flags)
