@@ -7,10 +7,10 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o 
 find $O/stats -name '*kernel_trace*' -delete 2>/dev/null
 echo "# wide_sources=$(python3 $R/tools/src_hash.py wide)" > $O/pmc_summary.csv
 echo "kernel,counter,launches,mean_per_launch" >> $O/pmc_summary.csv
-# keys: the exact-f32 kernel at 256 / 128 (8 waves) and 64 / 32 (4 waves), the split-f16 streaming kernel (256 / 128), the 64 / 32
+# keys (patterns match the MANGLED names the counter database holds): the exact-f32 kernel at 256 / 128 (8 waves) and 64 / 32 (4 waves), the split-f16 streaming kernel (256 / 128), the 64 / 32
 # register-resident pipeline and its sampling pre-pass
 pmc(){ tag=$1; shift; d=$O/pmc_$tag; timeout 600 rocprofv3 --pmc "$@" --kernel-trace -d $d -o p -- python3 $R/tools/bench_extra.py wide > /dev/null 2>&1; echo "pmc $tag rc=$?"
-  for kv in "wide_f32_256=decode_wide_kernel<8>" "wide_f32_64=decode_wide_kernel<4>" "wide_f16x3_256=decode_wide_h_kernel" "wide_f16x3_64=decode_wide_p_kernel" "wide_sample=wide_sample_kernel"; do
+  for kv in "wide_f32_256=decode_wide_kernelILi8E" "wide_f32_64=decode_wide_kernelILi4E" "wide_f16x3_256=decode_wide_h_kernel" "wide_f16x3_64=decode_wide_p_kernel" "wide_sample=wide_sample_kernel"; do
     python3 $R/tools/pmc_summary.py ${kv%%=*}=$d --kernel "${kv#*=}" | tail -n +2 >> $O/pmc_summary.csv; done
   rm -rf $d; }
 pmc sq GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES

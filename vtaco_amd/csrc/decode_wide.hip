@@ -415,7 +415,8 @@ struct WideHArgs {
     const float *blob;
     int H, C, nb, Kp, p_in, leaky, nearest;
     unsigned *status;
-    int npair;                  // pairs of 32-point groups per workgroup tile (the launcher sizes it: spare waves, LDS)
+    int npair;                  // sets of NG 32-point groups per workgroup tile (the launcher sizes it: spare waves, LDS)
+    int heads_on_c;             // the heads' partial sums share the c planes' LDS (the planes fill it)
 };
 __host__ __device__ inline int wideh_pitch(int ch) { return ch * 2 + 16; }             // bytes per point row of a half plane: 16 lanes x 16 bytes tile the 64 banks
 
@@ -425,35 +426,52 @@ __device__ __forceinline__ void wideh_split2(float a, float b, unsigned &hi, uns
     lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)hp[0], b - (float)hp[1]));
 }
 
-// acc_g += W[rows 32 ob ..][K] . X_g[K][32 points], g = 0, 1; wf: the layer's fragments [ob][K / 16][hi, lo][64 lanes][8 halves].
+// acc_g += W[rows 32 ob ..][K] . X_g[K][32 points], g = 0 .. NG - 1; wf: the layer's fragments [ob][K / 16][hi, lo][64 lanes][8 halves].
 // The fragments come from L2 (a round trip is ~10 k-steps of MFMAs): WIDEH_AHEAD k-steps of them are kept in flight in registers.
 // (hidden <= 128 runs four-wave workgroups, several per CU: there the plain loop with its 122 registers hides the latency by occupancy)
-template <int WIDEH_AHEAD>
-__device__ __forceinline__ void wideh_gemm(f32x16 &acc0, f32x16 &acc1, const float *wf, int ob, int K, const char *xh, const char *xl, int pitch, int lane) {
+// NG = 32-point groups that share every fragment: the stream out of the L2s (865 M requests per 128^3 at 256 / 128 with NG = 2:
+// profiles/r06_pmc_wide_summary.csv) shrinks by 2 / NG per point.
+template <int WIDEH_AHEAD, int NG>
+__device__ __forceinline__ void wideh_gemm(f32x16 (&acc)[NG], const float *wf, int ob, int K, const char *xh, const char *xl, int pitch, int lane) {
     const int nks = K / 16;
     const u32x4 *w = reinterpret_cast<const u32x4 *>(wf) + (size_t)ob * nks * 128 + lane;
     const int j = lane & 31, kg = lane >> 5;
-    const char *r0h = xh + j * pitch + kg * 16, *r0l = xl + j * pitch + kg * 16;
-    const char *r1h = r0h + 32 * pitch, *r1l = r0l + 32 * pitch;
+    const char *rh = xh + j * pitch + kg * 16, *rl = xl + j * pitch + kg * 16;
+    auto products = [&](const f16x8 &wh, const f16x8 &wl, const f16x8 (&bh)[NG], const f16x8 (&bl)[NG]) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh[g], acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl[g], acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh[g], acc[g], 0, 0, 0);
+    };
+    auto loadb = [&](f16x8 (&bh)[NG], f16x8 (&bl)[NG], int ks) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            bh[g] = *reinterpret_cast<const f16x8 *>(rh + g * 32 * pitch + ks * 32);
+            bl[g] = *reinterpret_cast<const f16x8 *>(rl + g * 32 * pitch + ks * 32);
+        }
+    };
     if constexpr (WIDEH_AHEAD <= 1) {
 #pragma unroll 2
         for (int ks = 0; ks < nks; ++ks) {
+            f16x8 bh[NG], bl[NG];
             const f16x8 wh = __builtin_bit_cast(f16x8, w[(size_t)ks * 128]), wl = __builtin_bit_cast(f16x8, w[(size_t)ks * 128 + 64]);
-            const f16x8 b0h = *reinterpret_cast<const f16x8 *>(r0h + ks * 32), b0l = *reinterpret_cast<const f16x8 *>(r0l + ks * 32);
-            const f16x8 b1h = *reinterpret_cast<const f16x8 *>(r1h + ks * 32), b1l = *reinterpret_cast<const f16x8 *>(r1l + ks * 32);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b0h, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b1h, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b0l, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b1l, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b0h, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b1h, acc1, 0, 0, 0);
+            loadb(bh, bl, ks);
+            products(wh, wl, bh, bl);
         }
         return;
     }
+    // eight-wave workgroups (one per CU, 256 registers per lane): the weight fragments WIDEH_AHEAD k-steps ahead, the activation operands one
+    // k-step ahead (two register sets; with three groups one set -- the SIMD's other wave covers the LDS read), and nothing else in flight:
+    // the scheduler is fenced per k-step, or it hoists every LDS read of the unrolled steps in front of the first MFMA and spills
     u32x4 wq[WIDEH_AHEAD][2];
 #pragma unroll
     for (int i = 0; i < WIDEH_AHEAD; ++i)
         if (i < nks) { wq[i][0] = w[(size_t)i * 128]; wq[i][1] = w[(size_t)i * 128 + 64]; }
+    constexpr int NB = NG >= 3 ? 1 : 2;
+    f16x8 bh[NB][NG], bl[NB][NG];
+    if (NB == 2) loadb(bh[0], bl[0], 0);
     for (int base = 0; base < nks; base += WIDEH_AHEAD) {
 #pragma unroll
         for (int i = 0; i < WIDEH_AHEAD; ++i) {
@@ -461,14 +479,10 @@ __device__ __forceinline__ void wideh_gemm(f32x16 &acc0, f32x16 &acc1, const flo
             if (ks >= nks) break;
             const f16x8 wh = __builtin_bit_cast(f16x8, wq[i][0]), wl = __builtin_bit_cast(f16x8, wq[i][1]);
             if (ks + WIDEH_AHEAD < nks) { wq[i][0] = w[(size_t)(ks + WIDEH_AHEAD) * 128]; wq[i][1] = w[(size_t)(ks + WIDEH_AHEAD) * 128 + 64]; }
-            const f16x8 b0h = *reinterpret_cast<const f16x8 *>(r0h + ks * 32), b0l = *reinterpret_cast<const f16x8 *>(r0l + ks * 32);
-            const f16x8 b1h = *reinterpret_cast<const f16x8 *>(r1h + ks * 32), b1l = *reinterpret_cast<const f16x8 *>(r1l + ks * 32);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b0h, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b1h, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b0l, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b1l, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b0h, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b1h, acc1, 0, 0, 0);
+            if (NB == 2) { if (ks + 1 < nks) loadb(bh[(i + 1) & 1], bl[(i + 1) & 1], ks + 1); }
+            else loadb(bh[0], bl[0], ks);
+            products(wh, wl, bh[NB == 2 ? (i & 1) : 0], bl[NB == 2 ? (i & 1) : 0]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -488,10 +502,11 @@ __device__ __forceinline__ void wideh_store(char *ah, char *al, int pitch, int p
     }
 }
 
-template <int WIDE_WAVES>
+// NG: 32-point groups per wave (a "set" of GP = 32 NG points shares every fragment); AH: weight k-steps in flight per wave
+template <int WIDE_WAVES, int NG, int AH>
 __global__ void __launch_bounds__(WIDE_WAVES * 64)
 decode_wide_h_kernel(WideHArgs a) {
-    constexpr int WIDE_THREADS = WIDE_WAVES * 64, AH = WIDE_WAVES >= 8 ? 4 : 1;         // weight k-steps in flight per wave
+    constexpr int WIDE_THREADS = WIDE_WAVES * 64, GP = 32 * NG;
     extern __shared__ __attribute__((aligned(16))) char whs[];      // c hi | c lo [64][pitch(C)] ; act hi | act lo [64][pitch(max(H, Kp))] ; heads
     const DecodeArgs &d = a.d;
     const int H = a.H, C = a.C, nh = H / 32, Kp = a.Kp;
@@ -499,9 +514,11 @@ decode_wide_h_kernel(WideHArgs a) {
     // narrow layers leave waves over (hidden 64: two 32-row blocks for four waves): the spare waves take further PAIRS of 32-point
     // groups instead of idling -- wave w owns rows 32 (w % nh) of pair w / nh, the tile grows to `npair` pairs' worth of points, and a
     // weight fragment streamed from L2 serves `npair` times the points (the second wave's load of it hits L1)
-    const int npair = a.npair, PTS = WH_PTS * npair;
+    const int npair = a.npair, PTS = GP * npair;
     char *ch_ = whs, *cl_ = ch_ + PTS * pc, *ah = cl_ + PTS * pc, *al = ah + PTS * pa;
-    float *heads = reinterpret_cast<float *>(al + PTS * pa);       // [waves][2 lane halves][2 heads][64 points of the wave's pair]
+    // [waves][2 lane halves][2 heads][GP points of the wave's set]; where the planes leave no room for it, on top of the c planes (last
+    // read by the last block's fc_c product, four barriers before the heads are written; rewritten behind the tile's last barrier)
+    float *heads = a.heads_on_c ? reinterpret_cast<float *>(ch_) : reinterpret_cast<float *>(al + PTS * pa);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kg = lane >> 5;
     const WideLayout lay = wide_layout(H, C, a.nb, Kp);
     const float *bias = a.blob + lay.bias;
@@ -558,13 +575,15 @@ decode_wide_h_kernel(WideHArgs a) {
         __syncthreads();
         const int ob = wave % nh, pr = wave / nh;                   // nh <= WIDE_WAVES; waves beyond nh * npair only keep the barriers
         const bool on = pr < npair;
-        // this wave's pair of point groups: rows 64 pr .. 64 pr + 63 of the planes
-        char *const chp = ch_ + pr * WH_PTS * pc, *const clp = cl_ + pr * WH_PTS * pc, *const ahp = ah + pr * WH_PTS * pa, *const alp = al + pr * WH_PTS * pa;
+        // this wave's set of point groups: rows GP pr .. GP pr + GP - 1 of the planes
+        char *const chp = ch_ + pr * GP * pc, *const clp = cl_ + pr * GP * pc, *const ahp = ah + pr * GP * pa, *const alp = al + pr * GP * pa;
         // ---- fc_p (decoder.py:139 / 81) ----
-        f32x16 net0, net1;
+        f32x16 net[NG];
         if (on) {
-            net0 = bias16(bias, ob, kg); net1 = net0;
-            wideh_gemm<AH>(net0, net1, a.blob + lay.w_p, ob, Kp, ahp, alp, pa, lane);
+            net[0] = bias16(bias, ob, kg);
+#pragma unroll
+            for (int g = 1; g < NG; ++g) net[g] = net[0];
+            wideh_gemm<AH, NG>(net, a.blob + lay.w_p, ob, Kp, ahp, alp, pa, lane);
         }
         // ---- n_blocks x (fc_c add, ResnetBlockFC: layers.py:41-50; its activations are ReLU) ----
         for (int blk = 0; blk < a.nb; ++blk) {
@@ -573,56 +592,67 @@ decode_wide_h_kernel(WideHArgs a) {
             if (on) {
                 const f32x16 bc = bias16(bb, ob, kg);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { net0[i] += bc[i]; net1[i] += bc[i]; }
-                wideh_gemm<AH>(net0, net1, wb, ob, C, chp, clp, pc, lane);
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) net[g][i] += bc[i];
+                wideh_gemm<AH, NG>(net, wb, ob, C, chp, clp, pc, lane);
             }
             __syncthreads();                                        // the readers of the activation buffer (fc_p / the last fc_1) are done
             if (on) {
-                wideh_store(ahp, alp, pa, j, ob, kg, net0, rmax);
-                wideh_store(ahp, alp, pa, j + 32, ob, kg, net1, rmax);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) wideh_store(ahp, alp, pa, j + 32 * g, ob, kg, net[g], rmax);
             }
             __syncthreads();
-            f32x16 hid0, hid1;
+            f32x16 hid[NG];
             if (on) {
-                hid0 = bias16(bb + H, ob, kg); hid1 = hid0;
-                wideh_gemm<AH>(hid0, hid1, wb + lay.w_c, ob, H, ahp, alp, pa, lane);
+                hid[0] = bias16(bb + H, ob, kg);
+#pragma unroll
+                for (int g = 1; g < NG; ++g) hid[g] = hid[0];
+                wideh_gemm<AH, NG>(hid, wb + lay.w_c, ob, H, ahp, alp, pa, lane);
             }
             __syncthreads();                                        // fc_0's readers are done
             if (on) {
-                wideh_store(ahp, alp, pa, j, ob, kg, hid0, rmax);
-                wideh_store(ahp, alp, pa, j + 32, ob, kg, hid1, rmax);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) wideh_store(ahp, alp, pa, j + 32 * g, ob, kg, hid[g], rmax);
             }
             __syncthreads();
             if (on) {
                 const f32x16 b1 = bias16(bb + 2 * H, ob, kg);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { net0[i] += b1[i]; net1[i] += b1[i]; }
-                wideh_gemm<AH>(net0, net1, wb + lay.w_c + lay.w_0, ob, H, ahp, alp, pa, lane);
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) net[g][i] += b1[i];
+                wideh_gemm<AH, NG>(net, wb + lay.w_c + lay.w_0, ob, H, ahp, alp, pa, lane);
             }
         }
         // ---- fc_out / fc_out_contact on actvn(net) (decoder.py:157-158, 128-131): f32 dot products, as in the exact kernel ----
         const float *ow = bias + (size_t)H * (1 + 3 * a.nb), *ow2 = ow + H + 1;
-        float o1[2] = {0.0f, 0.0f}, o2[2] = {0.0f, 0.0f};
+        float o1[NG], o2[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { o1[g] = 0.0f; o2[g] = 0.0f; }
         if (on) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = 32 * ob + chan_of(i, kg);
-                const float v0 = actvn(net0[i], a.leaky), v1 = actvn(net1[i], a.leaky);
-                o1[0] = fmaf(ow[row], v0, o1[0]); o2[0] = fmaf(ow2[row], v0, o2[0]);
-                o1[1] = fmaf(ow[row], v1, o1[1]); o2[1] = fmaf(ow2[row], v1, o2[1]);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const float v = actvn(net[g][i], a.leaky);
+                    o1[g] = fmaf(ow[row], v, o1[g]); o2[g] = fmaf(ow2[row], v, o2[g]);
+                }
             }
         }
+        if (a.heads_on_c) __syncthreads();                          // (the c planes' last readers are four barriers back already; kept explicit)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            heads[((wave * 2 + kg) * 2 + 0) * WH_PTS + j + 32 * g] = o1[g];
-            heads[((wave * 2 + kg) * 2 + 1) * WH_PTS + j + 32 * g] = o2[g];
+        for (int g = 0; g < NG; ++g) {
+            heads[((wave * 2 + kg) * 2 + 0) * GP + j + 32 * g] = o1[g];
+            heads[((wave * 2 + kg) * 2 + 1) * GP + j + 32 * g] = o2[g];
         }
         __syncthreads();
         for (int e = tid; e < 2 * PTS; e += WIDE_THREADS) {
-            const int pt = e % PTS, which = e / PTS, pp = pt / WH_PTS, q = pt % WH_PTS;
+            const int pt = e % PTS, which = e / PTS, pp = pt / GP, q = pt % GP;
             float o = which ? ow2[H] : ow[H];
-            for (int w = 2 * pp * nh; w < 2 * (pp + 1) * nh; ++w)     // the waves of this point's pair and their lane halves, in a fixed order
-                o += heads[(w * 2 + which) * WH_PTS + q];
+            for (int w = 2 * pp * nh; w < 2 * (pp + 1) * nh; ++w)     // the waves of this point's set and their lane halves, in a fixed order
+                o += heads[(w * 2 + which) * GP + q];
             const uint32_t g = tile * PTS + pt;
             float *dst = which ? d.out2 : d.out;
             if (g < d.total && dst) dst[g] = o;
@@ -852,9 +882,18 @@ static int wideh_fwd_impl(const float *grid_cl, int B, int R, int C, const float
     if (wide_pipe_shape(hidden, C, n_blocks, p_in) &&
         (c_direct ? ((size_t)c_direct & 15) == 0 : (ws && ((size_t)ws & 15) == 0 && ws_bytes >= (size_t)a.d.total * C * sizeof(float)))) {
         if (!c_direct) {
-            const unsigned long long items = (unsigned long long)a.d.total * (C / 4);
-            const unsigned long long want = (items + 255) / 256, cap = (unsigned long long)vt_num_cus() * 32ull;
-            hipLaunchKernelGGL(wide_sample_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, (hipStream_t)stream, a.d, a.nearest, C, (float *)ws);
+            // a lattice slab of whole x-plane pairs: the LDS-staged gather of the shipped-shape kernels (vt_st3_sample_lattice: footprints by
+            // LDS-DMA, the same corner and FMA order, 30 us per 2^19 points against 43 for the plain gather); anything else the plain gather
+            int covered = 0;
+            if (!pts && !a.nearest) {
+                const int src = vt_st3_sample_lattice(grid_cl, B, R, C, N, lattice_nx, lattice_box, lattice_first, padding, (float *)ws, stream, &covered);
+                if (src) return src;
+            }
+            if (!covered) {
+                const unsigned long long items = (unsigned long long)a.d.total * (C / 4);
+                const unsigned long long want = (items + 255) / 256, cap = (unsigned long long)vt_num_cus() * 32ull;
+                hipLaunchKernelGGL(wide_sample_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, (hipStream_t)stream, a.d, a.nearest, C, (float *)ws);
+            }
             a.d.c_direct = (const float *)ws;
         }
         const size_t lds = wp_lds_bytes(n_blocks);
@@ -887,24 +926,31 @@ static int wideh_fwd_impl(const float *grid_cl, int B, int R, int C, const float
     const int wid = hidden > a.Kp ? hidden : a.Kp;
     // pairs of point groups per tile: what the spare waves can take, as far as the planes fit the LDS
     int npair = wideh_pairs(waves, hidden / 32);
-    auto lds_of = [&](int np) { return (size_t)2 * WH_PTS * np * wideh_pitch(C) + (size_t)2 * WH_PTS * np * wideh_pitch(wid) + (size_t)waves * 2 * 2 * WH_PTS * sizeof(float); };
-    while (npair > 1 && lds_of(npair) > 150 * 1024) --npair;
+    // groups per wave: three where the eight-wave workgroup's planes still fit the LDS (256 / 128: 150 KB with the heads' partial sums on
+    // top of the c planes) -- a fragment out of the L2s then serves 96 points instead of 64; two elsewhere (VTACO_WIDE_NG3=0: two everywhere)
+    auto planes_of = [&](int gp, int np) { return (size_t)2 * gp * np * wideh_pitch(C) + (size_t)2 * gp * np * wideh_pitch(wid); };
+    auto heads_of = [&](int gp) { return (size_t)waves * 2 * 2 * gp * sizeof(float); };
+    static const bool ng3_off = getenv("VTACO_WIDE_NG3") != nullptr && atoi(getenv("VTACO_WIDE_NG3")) == 0;
+    const bool ng3 = waves == 8 && npair == 1 && !ng3_off && planes_of(96, 1) <= 160 * 1024 && heads_of(96) <= (size_t)2 * 96 * wideh_pitch(C);
+    const int gp = ng3 ? 96 : WH_PTS;
+    while (npair > 1 && planes_of(gp, npair) + heads_of(gp) > 150 * 1024) --npair;
     a.npair = npair;
-    const int tile_pts = WH_PTS * npair;
-    const size_t lds = lds_of(npair);
+    a.heads_on_c = ng3 && planes_of(gp, npair) + heads_of(gp) > 160 * 1024;
+    const int tile_pts = gp * npair;
+    const size_t lds = planes_of(gp, npair) + (a.heads_on_c ? 0 : heads_of(gp));
     if (lds > 160 * 1024) return vt_fail(VT_ERR_UNSUPPORTED, "vt_decode_fwd_wide_f16x3: the activation planes of this shape do not fit the LDS");
-    bool attr = false;        // (vt_max_dyn_lds keeps the per-device record)
-    if (!attr) {
-        hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_wide_h_kernel<4>), 160 * 1024);
-        if (e == hipSuccess) e = vt_max_dyn_lds(reinterpret_cast<const void *>(&decode_wide_h_kernel<8>), 160 * 1024);
-        if (e != hipSuccess) return vt_check(e, "vt_decode_fwd_wide_f16x3: hipFuncSetAttribute");
-        attr = true;
-    }
     const uint32_t ntiles = (a.d.total + tile_pts - 1) / tile_pts;
     const uint32_t cap = (uint32_t)vt_num_cus() * 4u;
     const dim3 grid(ntiles < cap ? ntiles : cap);
-    if (waves == 4) hipLaunchKernelGGL(decode_wide_h_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(decode_wide_h_kernel<8>, grid, dim3(512), lds, (hipStream_t)stream, a);
+    auto go = [&](auto kern, int threads) -> int {
+        const hipError_t e = vt_max_dyn_lds(reinterpret_cast<const void *>(kern), 160 * 1024);
+        if (e != hipSuccess) return vt_check(e, "vt_decode_fwd_wide_f16x3: hipFuncSetAttribute");
+        hipLaunchKernelGGL(kern, grid, dim3(threads), lds, (hipStream_t)stream, a);
+        return 0;
+    };
+    // (fragment k-steps in flight: 2 .. 8 measured within 3 % of each other at 256 / 128; 4 keeps both forms off the stack)
+    const int lrc = waves == 4 ? go(&decode_wide_h_kernel<4, 2, 1>, 256) : ng3 ? go(&decode_wide_h_kernel<8, 3, 4>, 512) : go(&decode_wide_h_kernel<8, 2, 4>, 512);
+    if (lrc) return lrc;
     return vt_check(hipGetLastError(), "vt_decode_fwd_wide_f16x3");
 }
 
