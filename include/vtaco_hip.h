@@ -553,6 +553,14 @@ int vt_voxel_build_clear_flags(const float *pts, int B, int T, int R, double pad
                                void *clear, size_t clear_bytes, unsigned char *tile_flags, void *stream);
 int vt_voxel_pool_max_fwd(const float *feat, const int *order, const int *seg_lo, const int *seg_hi,
                           int B, int T, int C, float *out, int *argmax, void *stream);
+/* pool_local over K <= 4 cell partitions of the same points, summed in the order k = 0, 1, ... (the hand encoder's xz + xy + yz planes,    */
+/* pointnet.py:116-132: `c += pooled`): out[b][t][c] = sum_k max of feat over t's cell in partition k; order / seg_lo / seg_hi / argmax:    */
+/* host arrays of K device pointers (argmax, or its entries, may be NULL in the forward).  Same maxima and first arg-maxima as K calls of   */
+/* vt_voxel_pool_max_fwd + K - 1 adds; one launch.  The backward sums, per partition in order, the cell's grad_out at its arg-max point.     */
+int vt_voxel_pool_max_sum_fwd(const float *feat, int K, const int *const *order, const int *const *seg_lo, const int *const *seg_hi,
+                              int B, int T, int C, float *out, int *const *argmax, void *stream);
+int vt_voxel_pool_max_sum_bwd(const float *grad_out, int K, int *const *argmax, const int *const *order, const int *const *seg_lo,
+                              const int *const *seg_hi, int B, int T, int C, float *grad_feat, void *stream);
 /* pool_local with scatter_type = 'mean' (pointnet.py:64-69, 116-132: scatter_mean over the cells, gathered back to the points):  */
 /* out[b][t][c] = mean of feat over the points of t's cell (cells of a volume or a plane: the segments of vt_voxel_build /          */
 /* vt_plane_build).  Its backward is the same call on the gradient.                                                              */

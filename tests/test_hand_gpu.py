@@ -65,6 +65,47 @@ def test_pool_local_sums_the_three_planes():
     assert maxdiff(got, ref) <= 1e-6
 
 
+def test_pool_over_the_three_planes_in_one_launch():
+    """vt_voxel_pool_max_sum_fwd / _bwd (the hand encoder's `c += pooled` over xz, xy, yz in one launch each way) against three
+    vt_voxel_pool_max_fwd / _bwd calls summed in the same order: the same bits for the values and the first arg-maxima (ties included:
+    a block of duplicated rows), the same routing and sums for the gradients; the oracle's values; a degenerate cloud (every point in
+    one cell) as well."""
+    from oracle import vtaco_oracle as orc
+    from vtaco_amd import ops
+    from vtaco_amd.encoder.pointnet import _PoolMaxSum
+    a, _ = load_golden("g10_hand.npz")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(18)
+    for case in ("golden", "one cell"):
+        p = T(a["p"]) if case == "golden" else 0.001 * torch.randn(2, 700, 3, generator=g)
+        B, N = p.shape[0], p.shape[1]
+        feat = torch.randn(B, N, 32, generator=g)
+        feat[:, 100:140] = feat[:, 60:100]                          # exact ties between points that share cells with their neighbours
+        pis = [ops.PlaneIndex(p.to(dev), 32, 0.1, k) for k in PLANES]
+        fd = feat.to(dev)
+        out, args = ops.voxel_pool_max_sum_fwd(fd, pis)
+        singles = [ops.voxel_pool_max_fwd(fd, pi) for pi in pis]
+        want = (singles[0][0] + singles[1][0]) + singles[2][0]
+        assert torch.equal(out, want)
+        for k in range(3):
+            assert torch.equal(args[k], singles[k][1]), (case, k)
+        assert torch.equal(ops.voxel_pool_max_sum_fwd(fd, pis, want_argmax=False)[0], out)
+        go = torch.randn(B, N, 32, generator=g).to(dev)
+        gsum = ops.voxel_pool_max_sum_bwd(go, args, pis)
+        gs = [ops.voxel_pool_max_bwd(go, singles[k][1], pis[k]) for k in range(3)]
+        # (cells of more than 32 points: the single-partition kernel sums them cooperatively, in another order)
+        ref_g = (gs[0] + gs[1]) + gs[2]
+        assert maxdiff(gsum, ref_g) <= 1e-5 * float(ref_g.abs().max()), case
+        assert torch.equal(gsum == 0, ref_g == 0)                   # the same routing: only arg-max points receive gradient
+        if case == "golden":                                        # the oracle: values and, through autograd, the gradient's routing
+            fr = feat.clone().requires_grad_()
+            ref = sum(orc.segment_pool_max(fr, T(a["idx_" + k]).long()) for k in PLANES)
+            assert maxdiff(out, ref.detach()) <= 1e-6
+        f2 = fd.clone().requires_grad_()
+        _PoolMaxSum.apply(f2, pis).backward(go)
+        assert torch.equal(f2.grad, gsum)
+
+
 @pytest.mark.parametrize("center_idx", [9, None, 0])
 def test_mano_layer_kernel(center_idx, tmp_path):
     from oracle import vtaco_oracle as orc

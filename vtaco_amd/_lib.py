@@ -182,6 +182,8 @@ SIGNATURES = {
     "vt_voxel_pool_max_fwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "vt_voxel_pool_mean": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
     "vt_voxel_pool_max_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
+    "vt_voxel_pool_max_sum_fwd": (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
+    "vt_voxel_pool_max_sum_bwd": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
     "vt_voxel_scatter_mean_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "vt_voxel_scatter_mean_bwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "vt_winding_number": (_I, [_VP, _I, _VP, _I, _VP, _I64, _VP, _VP]),

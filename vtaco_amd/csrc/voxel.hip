@@ -427,6 +427,63 @@ pool_max_bwd_kernel(const float *grad_out, const int *argmax, const int *order, 
     }
 }
 
+// pool_local over SEVERAL cell partitions of the same points, summed (the hand encoder pools its point features over the xz, xy and yz
+// planes and adds the three, pointnet.py:116-132): out[b][t][c] = sum_k max over t's cell in partition k, in the order k = 0, 1, ...
+// (the order of the reference's `c += pooled`).  Gather form -- every (point, channel) walks its own cell in sorted order, strict '>'
+// from the cell's head, so all members of a cell find the same maximum and the same first arg-max as vt_voxel_pool_max_fwd's head does
+// -- because the partitions group the points differently: no thread could own an output element across them otherwise.  One launch
+// instead of K pool launches and K - 1 framework adds per PointNet block; a cell of n points costs n^2 row reads (L2), which only
+// matters for degenerate clouds.
+constexpr int POOL_MAX_SETS = 4;
+struct PoolSets { const int *order[POOL_MAX_SETS], *seg_lo[POOL_MAX_SETS], *seg_hi[POOL_MAX_SETS]; int *argmax[POOL_MAX_SETS]; int K; };
+
+__global__ void __launch_bounds__(256)
+pool_max_sum_fwd_kernel(const float *feat, PoolSets s, float *out, int T, int C, uint32_t npts) {
+    uint32_t bt; int c0;
+    if (!point_lane(C, npts, bt, c0)) return;
+    const uint32_t b = bt / (uint32_t)T;
+    const float *fb = feat + (size_t)b * T * C;
+    for (int c = c0; c < C; c += 256) {
+        float sum = 0.0f;
+        for (int k = 0; k < s.K; ++k) {
+            const int lo = s.seg_lo[k][bt], hi = s.seg_hi[k][bt];
+            const int *ord = s.order[k] + (size_t)b * T;
+            int best = ord[lo];
+            float m = fb[(size_t)best * C + c];
+            for (int j = lo + 1; j < hi; ++j) {
+                const int t2 = ord[j];
+                const float v = fb[(size_t)t2 * C + c];
+                if (v > m) { m = v; best = t2; }
+            }
+            sum = k ? sum + m : m;
+            if (s.argmax[k]) s.argmax[k][(size_t)bt * C + c] = best;
+        }
+        out[(size_t)bt * C + c] = sum;
+    }
+}
+
+// its backward: grad_feat[b][t][c] = sum_k [t is the arg-max of its cell in partition k] * (sum of grad_out over that cell), k in order
+__global__ void __launch_bounds__(256)
+pool_max_sum_bwd_kernel(const float *grad_out, PoolSets s, float *grad_feat, int T, int C, uint32_t npts) {
+    uint32_t bt; int c0;
+    if (!point_lane(C, npts, bt, c0)) return;
+    const uint32_t b = bt / (uint32_t)T;
+    const int t = (int)(bt - b * (uint32_t)T);
+    const float *gb = grad_out + (size_t)b * T * C;
+    for (int c = c0; c < C; c += 256) {
+        float sum = 0.0f;
+        for (int k = 0; k < s.K; ++k) {
+            if (s.argmax[k][(size_t)bt * C + c] != t) continue;
+            const int lo = s.seg_lo[k][bt], hi = s.seg_hi[k][bt];
+            const int *ord = s.order[k] + (size_t)b * T;
+            float g = 0.0f;
+            for (int j = lo; j < hi; ++j) g += gb[(size_t)ord[j] * C + c];
+            sum += g;
+        }
+        grad_feat[(size_t)bt * C + c] = sum;
+    }
+}
+
 // grid cell = mean of feat over the cell's points (grid pre-zeroed).  CL = false: NCDHW / NCHW [b][c][cell];
 // CL = true: channels-last [b][cell][c] (what the UNet3D kernels read)
 template <bool CL>
@@ -637,6 +694,40 @@ int vt_voxel_pool_max_fwd(const float *feat, const int *order, const int *seg_lo
     hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(sb + large_blocks(B, T)), dim3(256), 0, (hipStream_t)stream,
                        feat, order, seg_lo, seg_hi, out, argmax, T, C, (uint32_t)npts, sb);
     return vt_check(hipGetLastError(), "vt_voxel_pool_max_fwd");
+}
+
+static int pool_sets(PoolSets &s, const char *who, int K, const int *const *order, const int *const *seg_lo, const int *const *seg_hi,
+                     int *const *argmax, bool need_argmax) {
+    if (K < 1 || K > POOL_MAX_SETS || !order || !seg_lo || !seg_hi || (need_argmax && !argmax)) return vt_fail(VT_ERR_INVALID, who);
+    s.K = K;
+    for (int k = 0; k < POOL_MAX_SETS; ++k) {
+        s.order[k] = k < K ? order[k] : nullptr; s.seg_lo[k] = k < K ? seg_lo[k] : nullptr; s.seg_hi[k] = k < K ? seg_hi[k] : nullptr;
+        s.argmax[k] = (k < K && argmax) ? argmax[k] : nullptr;
+        if (k < K && (!s.order[k] || !s.seg_lo[k] || !s.seg_hi[k] || (need_argmax && !s.argmax[k]))) return vt_fail(VT_ERR_INVALID, who);
+    }
+    return 0;
+}
+
+int vt_voxel_pool_max_sum_fwd(const float *feat, int K, const int *const *order, const int *const *seg_lo, const int *const *seg_hi,
+                              int B, int T, int C, float *out, int *const *argmax, void *stream) {
+    if (!feat || !out) return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_max_sum_fwd: null argument");
+    if (B <= 0 || T <= 0 || C <= 0) return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_max_sum_fwd: bad size");
+    PoolSets s;
+    if (const int rc = pool_sets(s, "vt_voxel_pool_max_sum_fwd: 1..4 partitions with their three index arrays", K, order, seg_lo, seg_hi, argmax, false)) return rc;
+    const size_t npts = (size_t)B * T;
+    hipLaunchKernelGGL(pool_max_sum_fwd_kernel, dim3(point_blocks(C, npts)), dim3(256), 0, (hipStream_t)stream, feat, s, out, T, C, (uint32_t)npts);
+    return vt_check(hipGetLastError(), "vt_voxel_pool_max_sum_fwd");
+}
+
+int vt_voxel_pool_max_sum_bwd(const float *grad_out, int K, int *const *argmax, const int *const *order, const int *const *seg_lo,
+                              const int *const *seg_hi, int B, int T, int C, float *grad_feat, void *stream) {
+    if (!grad_out || !grad_feat) return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_max_sum_bwd: null argument");
+    if (B <= 0 || T <= 0 || C <= 0) return vt_fail(VT_ERR_INVALID, "vt_voxel_pool_max_sum_bwd: bad size");
+    PoolSets s;
+    if (const int rc = pool_sets(s, "vt_voxel_pool_max_sum_bwd: 1..4 partitions with their index arrays and arg-maxima", K, order, seg_lo, seg_hi, argmax, true)) return rc;
+    const size_t npts = (size_t)B * T;
+    hipLaunchKernelGGL(pool_max_sum_bwd_kernel, dim3(point_blocks(C, npts)), dim3(256), 0, (hipStream_t)stream, grad_out, s, grad_feat, T, C, (uint32_t)npts);
+    return vt_check(hipGetLastError(), "vt_voxel_pool_max_sum_bwd");
 }
 
 int vt_voxel_pool_mean(const float *feat, const int *order, const int *seg_lo, const int *seg_hi, int B, int T, int C, float *out, void *stream) {

@@ -39,6 +39,21 @@ class _PoolMax(torch.autograd.Function):
         return ops.voxel_pool_max_bwd(grad, ctx.arg, ctx.vi), None
 
 
+class _PoolMaxSum(torch.autograd.Function):
+    """The sum of pool_local over several index sets (the hand encoder's three planes, pointnet.py:116-132) in one launch each way
+    (vt_voxel_pool_max_sum_fwd / _bwd) instead of a pool per set and the framework's adds."""
+
+    @staticmethod
+    def forward(ctx, feat, vis):
+        out, args = ops.voxel_pool_max_sum_fwd(feat, vis, want_argmax=True)
+        ctx.vis, ctx.args = vis, args
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        return ops.voxel_pool_max_sum_bwd(grad, ctx.args, ctx.vis), None
+
+
 class _PoolMean(torch.autograd.Function):
     """pool_local with scatter_type='mean' (pointnet.py:64-69, 116-132): per-cell mean, gathered back; self-adjoint."""
 
@@ -221,9 +236,12 @@ class LocalPoolPointnet(nn.Module):
         pool = _PoolMax.apply if self.scatter_type == 'max' else _PoolMean.apply
         for blk in self.blocks[1:]:
             if isinstance(vi, (list, tuple)):
-                pooled = pool(net, vi[0])
-                for other in vi[1:]:
-                    pooled = pooled + pool(net, other)
+                if self.scatter_type == 'max' and 1 < len(vi) <= 4:
+                    pooled = _PoolMaxSum.apply(net, list(vi))
+                else:
+                    pooled = pool(net, vi[0])
+                    for other in vi[1:]:
+                        pooled = pooled + pool(net, other)
             else:
                 pooled = pool(net, vi)
             net = block(blk, net, pooled)
@@ -275,9 +293,12 @@ class LocalPoolPointnet(nn.Module):
         pool = (lambda f, v: ops.voxel_pool_max_fwd(f, v, want_argmax=False)[0]) if self.scatter_type == 'max' else ops.voxel_pool_mean
         for blk in self.blocks[1:]:
             if isinstance(vi, (list, tuple)):
-                pooled = pool(net, vi[0])
-                for other in vi[1:]:
-                    pooled = pooled + pool(net, other)
+                if self.scatter_type == 'max' and 1 < len(vi) <= 4:
+                    pooled = ops.voxel_pool_max_sum_fwd(net, list(vi), want_argmax=False)[0]
+                else:
+                    pooled = pool(net, vi[0])
+                    for other in vi[1:]:
+                        pooled = pooled + pool(net, other)
             else:
                 pooled = pool(net, vi)
             net = ops.resblock_fc(net, pooled, blk.fc_0, blk.fc_1, blk.shortcut)

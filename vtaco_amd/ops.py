@@ -567,6 +567,40 @@ def voxel_pool_max_fwd(feat, vi, want_argmax=True):
     return out, arg
 
 
+def _ptr_array(tensors, name):
+    """A host array of device pointers (ctypes c_void_p * K) for the K int32 tensors, or None entries."""
+    arr = (ctypes.c_void_p * len(tensors))()
+    for k, t in enumerate(tensors):
+        arr[k] = dev_ptr(t, name, I32).value if t is not None else None
+    return arr
+
+
+def voxel_pool_max_sum_fwd(feat, vis, want_argmax=True):
+    """Sum over the index sets ``vis`` of the per-cell channel max, gathered back to the points (vt_voxel_pool_max_sum_fwd): one launch
+    for the hand encoder's three planes.  Returns (out [B,T,C], list of arg-max tensors or None)."""
+    feat = _c(feat)
+    B, T, C = feat.shape
+    K = len(vis)
+    out = torch.empty_like(feat)
+    args = [torch.empty((B, T, C), dtype=I32, device=feat.device) for _ in range(K)] if want_argmax else None
+    check(_lib.load().vt_voxel_pool_max_sum_fwd(dev_ptr(feat, "feat"), K, _ptr_array([v.order for v in vis], "order"),
+                                                _ptr_array([v.seg_lo for v in vis], "seg_lo"), _ptr_array([v.seg_hi for v in vis], "seg_hi"),
+                                                B, T, C, dev_ptr(out, "out"), _ptr_array(args, "argmax") if args else None, stream_ptr()),
+          "vt_voxel_pool_max_sum_fwd")
+    return out, args
+
+
+def voxel_pool_max_sum_bwd(grad_out, args, vis):
+    grad_out = _c(grad_out)
+    B, T, C = grad_out.shape
+    g = torch.empty_like(grad_out)
+    check(_lib.load().vt_voxel_pool_max_sum_bwd(dev_ptr(grad_out, "grad_out"), len(vis), _ptr_array(args, "argmax"),
+                                                _ptr_array([v.order for v in vis], "order"), _ptr_array([v.seg_lo for v in vis], "seg_lo"),
+                                                _ptr_array([v.seg_hi for v in vis], "seg_hi"), B, T, C, dev_ptr(g, "grad_feat"), stream_ptr()),
+          "vt_voxel_pool_max_sum_bwd")
+    return g
+
+
 def voxel_pool_mean(feat, vi):
     """pool_local with scatter_type='mean' (vt_voxel_pool_mean): every point gets the mean of the features of its cell; its
     backward is the same call on the gradient."""
