@@ -877,6 +877,10 @@ int vt_maxpool3d_cl_bwd_fork(const float *y, const float *dskip, const float *dp
 #define VT_MANO_BLOB_FLOATS 330240
 int vt_plane_build(const float *pts, int B, int T, int R, double padding, int plane,
                    int *idx, int *order, int *seg_lo, int *seg_hi, void *stream);
+/* The planes of a scene side by side in ONE launch: `planes` = n_planes ids (0 xz, 1 xy, 2 yz); idx / order / seg_lo / seg_hi are       */
+/* [n_planes][B][T], slice k = what vt_plane_build(plane = planes[k]) writes (the hand encoder builds all three per forward).            */
+int vt_plane_build_multi(const float *pts, int B, int T, int R, double padding, int n_planes, const int *planes,
+                         int *idx, int *order, int *seg_lo, int *seg_hi, void *stream);
 int vt_plane_scatter_mean_fwd(const float *feat, const int *idx, const int *order,
                               const int *seg_lo, const int *seg_hi,
                               int B, int T, int C, int R, float *plane, void *stream);

@@ -65,6 +65,34 @@ def test_pool_local_sums_the_three_planes():
     assert maxdiff(got, ref) <= 1e-6
 
 
+def test_plane_indices_in_one_launch_equal_the_single_builds():
+    """vt_plane_build_multi (the three planes' sorts side by side) writes what three vt_plane_build calls write: ids, sorted order, segment
+    bounds -- on the golden cloud, a ragged one, one with every point in one cell (a 700-point segment) and through the large-cloud path."""
+    import os
+    from vtaco_amd import ops
+    a, _ = load_golden("g10_hand.npz")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    clouds = [T(a["p"]), 0.5 * (torch.rand(3, 1237, 3, generator=g) - 0.5), 0.001 * torch.randn(2, 700, 3, generator=g),
+              0.6 * (torch.rand(1, 9000, 3, generator=g) - 0.5)]
+    for p in clouds:
+        p = p.to(dev)
+        for planes in (("xz", "xy", "yz"), ("yz", "xz"), ("xy",)):
+            many = ops.plane_indices(p, 32, 0.1, planes)
+            for pi, k in zip(many, planes):
+                one = ops.PlaneIndex(p, 32, 0.1, k)
+                for f in ("idx", "order", "seg_lo", "seg_hi"):
+                    assert torch.equal(getattr(pi, f), getattr(one, f)), (tuple(p.shape), planes, k, f)
+                # the bounds are those of the sorted ids: [lo, hi) is the maximal run of the point's cell
+                ids = torch.gather(one.idx, 1, one.order.long())
+                lo = torch.gather(one.seg_lo, 1, one.order.long()).long()
+                hi = torch.gather(one.seg_hi, 1, one.order.long()).long()
+                pos = torch.arange(p.shape[1], device=dev).expand_as(ids)
+                assert bool(((lo <= pos) & (pos < hi)).all()) and bool((torch.gather(ids, 1, lo) == ids).all()) and bool((torch.gather(ids, 1, hi - 1) == ids).all())
+                assert bool(((lo == 0) | (torch.gather(ids, 1, (lo - 1).clamp(min=0)) != ids)).all())
+                assert bool(((hi == p.shape[1]) | (torch.gather(ids, 1, hi.clamp(max=p.shape[1] - 1)) != ids)).all())
+
+
 def test_pool_over_the_three_planes_in_one_launch():
     """vt_voxel_pool_max_sum_fwd / _bwd (the hand encoder's `c += pooled` over xz, xy, yz in one launch each way) against three
     vt_voxel_pool_max_fwd / _bwd calls summed in the same order: the same bits for the values and the first arg-maxima (ties included:

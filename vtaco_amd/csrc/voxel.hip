@@ -46,9 +46,19 @@ constexpr int FLAG_MAX_TILES = 4096;                               // 8^3 blocks
 // in its 12^3 halo either (vt_voxel_tile_flags)
 __global__ void __launch_bounds__(SORT_THREADS)
 voxel_build_kernel(const float *pts, int T, int nbits, int R, float divisor, float clamp_hi, int a0, int a1, int a2,
-                   int *idx, int *order, int *seg_lo, int *seg_hi, int B, uint4 *fill, size_t fill16, unsigned char *tile_flags) {
+                   int *idx, int *order, int *seg_lo, int *seg_hi, int B, uint4 *fill, size_t fill16, unsigned char *tile_flags, int planes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
     __shared__ unsigned char tflag[FLAG_MAX_TILES], tflag2[FLAG_MAX_TILES];
+    // `planes` (vt_plane_build_multi): n | id_0 << 4 | id_1 << 6 | ...; workgroup pl * (B / n) + scene sorts the scene's points by the
+    // cells of plane id_pl into the pl-th [B / n][T] slice of the outputs -- the planes of a scene side by side instead of one after the other
+    int b = blockIdx.x;
+    if (planes && (int)blockIdx.x < B) {
+        const int scenes = B / (planes & 15), pl = blockIdx.x / scenes, plane = (planes >> (4 + 2 * pl)) & 3;
+        b = blockIdx.x - pl * scenes;
+        a0 = plane == 2 ? 1 : 0; a1 = plane == 1 ? 1 : 2;
+        const size_t off = (size_t)pl * scenes * T;
+        idx += off; order += off; seg_lo += off; seg_hi += off;
+    }
     if ((int)blockIdx.x >= B) {
         // the workgroups behind the B sorting ones clear a buffer of the caller's (the grid the scatter-mean fills next): the sort keeps
         // one CU per scene busy for ~18 us, the other CUs stream 33 MB of zeros in that time instead of in a launch of their own
@@ -61,7 +71,7 @@ voxel_build_kernel(const float *pts, int T, int nbits, int R, float divisor, flo
     unsigned short *perm_b = perm_a + MAX_T;                                         // [MAX_T]
     unsigned short *table = perm_b + MAX_T;                                          // [RADIX][nchunk]
     __shared__ unsigned wave_tot[SORT_THREADS / 64];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *p = pts + (size_t)b * T * 3;
     const int nround = (T + SORT_THREADS - 1) / SORT_THREADS, nchunk = nround * (SORT_THREADS / 64);
     const int nt1 = R >> 3;
@@ -137,20 +147,58 @@ voxel_build_kernel(const float *pts, int T, int nbits, int R, float divisor, flo
         __syncthreads();
         unsigned short *sw = perm_a; perm_a = perm_b; perm_b = sw;
     }
-    // segment bounds: every point learns [lo,hi) of its cell in sorted order
-    for (int j = tid; j < T; j += SORT_THREADS) {
-        const int t = perm_a[j];
-        const unsigned id = ids[t];
-        order[(size_t)b * T + j] = t;
-        const bool first = (j == 0) || (ids[perm_a[j - 1]] != id);
-        if (first) {
-            int e = j + 1;
-            while (e < T && ids[perm_a[e]] == id) ++e;
-            for (int q = j; q < e; ++q) {
-                const int tq = perm_a[q];
-                seg_lo[(size_t)b * T + tq] = j;
-                seg_hi[(size_t)b * T + tq] = e;
+    // segment bounds: every point learns [lo, hi) of its cell in sorted order.  A volume's cells hold one to three points: the cell's
+    // head walks it and writes its members' bounds (17.7 us per sort; the scan below: 20.0).
+    if (a2 >= 0) {
+        for (int j = tid; j < T; j += SORT_THREADS) {
+            const int t = perm_a[j];
+            const unsigned id = ids[t];
+            order[(size_t)b * T + j] = t;
+            const bool first = (j == 0) || (ids[perm_a[j - 1]] != id);
+            if (first) {
+                int e = j + 1;
+                while (e < T && ids[perm_a[e]] == id) ++e;
+                for (int q = j; q < e; ++q) {
+                    const int tq = perm_a[q];
+                    seg_lo[(size_t)b * T + tq] = j;
+                    seg_hi[(size_t)b * T + tq] = e;
+                }
             }
+        }
+        return;
+    }
+    // A plane's cells hold tens of points, and that walk cost ~10 us of 25: there the bounds in parallel -- lo = the last head at or before
+    // a position (a max-scan over contiguous ranges, the carry through one wave scan), a cell's end = the next head's position, left by
+    // that head at the previous cell's lo.  perm_b and the count table are free after the last pass.
+    {
+        unsigned short *lo_arr = perm_b, *end_arr = table;
+        const int per = (T + SORT_THREADS - 1) / SORT_THREADS;
+        const int j0 = min(tid * per, T), j1 = min(j0 + per, T);
+        int run = 0;
+        for (int j = j0; j < j1; ++j) {
+            if (j == 0 || ids[perm_a[j - 1]] != ids[perm_a[j]]) run = j;
+            lo_arr[j] = (unsigned short)run;                        // (0 in front of the range's first head: the carry fills it in)
+        }
+        int incl = run;
+        for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl = max(incl, up); }
+        __syncthreads();                                            // (wave_tot's readers of the last pass are done)
+        if (lane == 63) wave_tot[wave] = (unsigned)incl;
+        __syncthreads();
+        int carry = __shfl_up(incl, 1);
+        if (lane == 0) carry = 0;
+        for (int w = 0; w < wave; ++w) carry = max(carry, (int)wave_tot[w]);
+        for (int j = j0; j < j1; ++j) lo_arr[j] = (unsigned short)max(carry, (int)lo_arr[j]);
+        __syncthreads();
+        for (int j = j0; j < j1; ++j) {
+            if (j > 0 && lo_arr[j] == j) end_arr[lo_arr[j - 1]] = (unsigned short)j;
+            if (j == T - 1) end_arr[lo_arr[j]] = (unsigned short)T;
+        }
+        __syncthreads();
+        for (int j = tid; j < T; j += SORT_THREADS) {
+            const int t = perm_a[j], lo = lo_arr[j];
+            order[(size_t)b * T + j] = t;
+            seg_lo[(size_t)b * T + t] = lo;
+            seg_hi[(size_t)b * T + t] = end_arr[lo];
         }
     }
 }
@@ -579,7 +627,7 @@ tile_flags_kernel(const int *idx, int T, int R, unsigned char *flags) {
 
 int build_launch(const char *who, const float *pts, int B, int T, int R, float divisor, float clamp_hi,
                  int a0, int a1, int a2, int *idx, int *order, int *seg_lo, int *seg_hi, void *stream,
-                 void *fill = nullptr, size_t fill_bytes = 0, unsigned char *tile_flags = nullptr) {
+                 void *fill = nullptr, size_t fill_bytes = 0, unsigned char *tile_flags = nullptr, int planes = 0) {
     char msg[96];
     auto fail = [&](int code, const char *what) { snprintf(msg, sizeof msg, "%s: %s", who, what); return vt_fail(code, msg); };
     if (!pts || !idx || !order || !seg_lo || !seg_hi) return fail(VT_ERR_INVALID, "null argument");
@@ -592,6 +640,17 @@ int build_launch(const char *who, const float *pts, int B, int T, int R, float d
     static const bool force_global = getenv("VTACO_VOXEL_GLOBAL_SORT") != nullptr;     // tests: the large-cloud path on small clouds
     if (fill_bytes && (!fill || (fill_bytes & 15) || ((size_t)fill & 15))) return fail(VT_ERR_INVALID, "the buffer to clear must be 16-byte aligned and sized");
     if (tile_flags && (a2 < 0 || R < 8 || (R & 7) || R > 128)) return fail(VT_ERR_UNSUPPORTED, "block flags: a volume whose resolution is a multiple of 8, at most 128");
+    if (planes && (T > MAX_T || (force_global && T >= 64))) {       // large clouds: plane after plane through the global-memory sort
+        const int n = planes & 15, scenes = B / n;
+        for (int pl = 0; pl < n; ++pl) {
+            const int plane = (planes >> (4 + 2 * pl)) & 3;
+            const size_t off = (size_t)pl * scenes * T;
+            const int rc = build_launch(who, pts, scenes, T, R, divisor, clamp_hi, plane == 2 ? 1 : 0, plane == 1 ? 1 : 2, -1,
+                                        idx + off, order + off, seg_lo + off, seg_hi + off, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     if (T > MAX_T || (force_global && T >= 64)) {
         hipStream_t s = (hipStream_t)stream;
         if (fill_bytes) { const int frc = vt_fill32(fill, 0u, fill_bytes, s); if (frc) return frc; }
@@ -619,7 +678,7 @@ int build_launch(const char *who, const float *pts, int B, int T, int R, float d
     size_t fb = (fill16 + SORT_THREADS * 16 - 1) / (SORT_THREADS * 16);                 // >= 16 stores per thread, at most two rounds of the chip
     if (fb > (size_t)vt_num_cus() * 2) fb = (size_t)vt_num_cus() * 2;
     hipLaunchKernelGGL(voxel_build_kernel, dim3((unsigned)(B + fb)), dim3(SORT_THREADS), SORT_LDS, (hipStream_t)stream,
-                       pts, T, nbits, R, divisor, clamp_hi, a0, a1, a2, idx, order, seg_lo, seg_hi, B, (uint4 *)fill, fill16, tile_flags);
+                       pts, T, nbits, R, divisor, clamp_hi, a0, a1, a2, idx, order, seg_lo, seg_hi, B, (uint4 *)fill, fill16, tile_flags, planes);
     return vt_check(hipGetLastError(), who);
 }
 
@@ -659,6 +718,19 @@ int vt_plane_build(const float *pts, int B, int T, int R, double padding, int pl
     const int a0 = plane == 2 ? 1 : 0, a1 = plane == 1 ? 1 : 2;
     return build_launch("vt_plane_build", pts, B, T, R, (float)(1.0 + padding + 10e-6), (float)(1.0 - 10e-6), a0, a1, -1,
                         idx, order, seg_lo, seg_hi, stream);
+}
+
+int vt_plane_build_multi(const float *pts, int B, int T, int R, double padding, int n_planes, const int *planes,
+                         int *idx, int *order, int *seg_lo, int *seg_hi, void *stream) {
+    if (n_planes < 1 || n_planes > 3 || !planes) return vt_fail(VT_ERR_INVALID, "vt_plane_build_multi: one to three planes");
+    int code = n_planes;
+    for (int k = 0; k < n_planes; ++k) {
+        if (planes[k] < 0 || planes[k] > 2) return vt_fail(VT_ERR_INVALID, "vt_plane_build_multi: plane must be 0 (xz), 1 (xy) or 2 (yz)");
+        code |= planes[k] << (4 + 2 * k);
+    }
+    if ((unsigned long long)B * n_planes > 0x7fffffffull / (unsigned long long)(T > 0 ? T : 1)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_plane_build_multi: more than 2^31 points per call");
+    return build_launch("vt_plane_build_multi", pts, B * n_planes, T, R, (float)(1.0 + padding + 10e-6), (float)(1.0 - 10e-6), 0, 2, -1,
+                        idx, order, seg_lo, seg_hi, stream, nullptr, 0, nullptr, code);
 }
 
 int vt_plane_scatter_mean_fwd(const float *feat, const int *idx, const int *order, const int *seg_lo, const int *seg_hi,

@@ -322,7 +322,7 @@ class LocalPoolPointnet(nn.Module):
         return {'mano_verts': verts, 'mano_joints': joints, 'mano_faces': self.mano_layer.th_faces}
 
     def forward_planes(self, p):
-        pis = [ops.PlaneIndex(p, self.reso_plane, self.padding, k) for k in self.planes]
+        pis = ops.plane_indices(p, self.reso_plane, self.padding, self.planes)      # the planes' sorts in one launch
         feat = self.point_features(p.float(), pis)
         planes = [_ScatterMeanPlane.apply(feat, pi) for pi in pis]
         if self.unet is not None:

@@ -825,6 +825,32 @@ class PlaneIndex(VoxelIndex):
                                          stream_ptr()), "vt_plane_build")
 
 
+def plane_indices(pts, reso, padding=0.1, planes=("xz", "xy", "yz")):
+    """[PlaneIndex(pts, reso, padding, k) for k in planes] from ONE launch (vt_plane_build_multi): the planes' sorts run side by side."""
+    for k in planes:
+        if k not in PLANES:
+            raise _lib.VtError(f"PlaneIndex: unknown plane {k!r} (one of {sorted(PLANES)})")
+    if not 1 <= len(planes) <= 3:
+        return [PlaneIndex(pts, reso, padding, k) for k in planes]
+    pts = pts.detach().float()
+    if not pts.is_contiguous():
+        pts = pts.contiguous()
+    B, T, _ = pts.shape
+    n = len(planes)
+    buf = torch.empty((4, n, B, T), dtype=I32, device=pts.device)
+    ids = (ctypes.c_int * n)(*[PLANES[k] for k in planes])
+    check(_lib.load().vt_plane_build_multi(dev_ptr(pts, "pts"), B, T, reso, float(padding), n, ids, dev_ptr(buf[0], "idx", I32),
+                                           dev_ptr(buf[1], "order", I32), dev_ptr(buf[2], "seg_lo", I32), dev_ptr(buf[3], "seg_hi", I32),
+                                           stream_ptr()), "vt_plane_build_multi")
+    out = []
+    for i, k in enumerate(planes):
+        pi = PlaneIndex.__new__(PlaneIndex)
+        pi.B, pi.T, pi.R, pi.plane, pi.tile_flags = B, T, reso, k, None
+        pi.idx, pi.order, pi.seg_lo, pi.seg_hi = buf[0, i], buf[1, i], buf[2, i], buf[3, i]
+        out.append(pi)
+    return out
+
+
 def plane_scatter_mean_fwd(feat, pi):
     feat = _c(feat)
     B, T, C = feat.shape
