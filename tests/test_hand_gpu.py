@@ -93,6 +93,30 @@ def test_plane_indices_in_one_launch_equal_the_single_builds():
                 assert bool(((hi == p.shape[1]) | (torch.gather(ids, 1, hi.clamp(max=p.shape[1] - 1)) != ids)).all())
 
 
+def test_multi_plane_entries_refuse_bad_arguments():
+    """The C ABI's checks of the round-6 plane entries: unknown plane ids, more partitions than the kernels take, null tables."""
+    import ctypes
+    from vtaco_amd import _lib, ops
+    from vtaco_amd._lib import VtError
+    dev = torch.device("cuda:0")
+    p = torch.rand(1, 64, 3, device=dev) - 0.5
+    with pytest.raises(VtError):
+        ops.plane_indices(p, 32, 0.1, ("xz", "zx"))
+    lib = _lib.load()
+    buf = torch.empty((4, 1, 64), dtype=torch.int32, device=dev)
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    bad = (ctypes.c_int * 2)(0, 3)
+    assert lib.vt_plane_build_multi(ptr(p), 1, 64, 32, 0.1, 2, bad, ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), None) != 0
+    assert lib.vt_plane_build_multi(ptr(p), 1, 64, 32, 0.1, 4, bad, ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), None) != 0
+    feat = torch.randn(1, 64, 32, device=dev)
+    pis = ops.plane_indices(p, 32, 0.1, ("xz", "xy", "yz"))
+    with pytest.raises(VtError):
+        ops.voxel_pool_max_sum_fwd(feat, pis + pis[:2])              # five partitions
+    out = torch.empty_like(feat)
+    assert lib.vt_voxel_pool_max_sum_fwd(ptr(feat), 3, None, None, None, 1, 64, 32, ptr(out), None, None) != 0
+    torch.cuda.synchronize()
+
+
 def test_pool_over_the_three_planes_in_one_launch():
     """vt_voxel_pool_max_sum_fwd / _bwd (the hand encoder's `c += pooled` over xz, xy, yz in one launch each way) against three
     vt_voxel_pool_max_fwd / _bwd calls summed in the same order: the same bits for the values and the first arg-maxima (ties included:
