@@ -38,6 +38,7 @@ if has train; then
   $K gpurun_out/r06_train_full_step.txt gpurun_out/r06/r06_train_full_step.txt --must-contain "ms per step"
 fi
 if has rest; then
+  bash tools/probe/scene_graph_tl.sh > /dev/null 2>&1; $K gpurun_out/scene_graph_tl.txt gpurun_out/r06/r06_scene_graph_timeline.txt --must-contain span
   bash tools/probe/plane_unet_tl.sh 3 > /dev/null 2>&1; $K gpurun_out/plane_unet_tl_3.txt gpurun_out/r06/r06_plane_unet_timeline.txt --must-contain "kernel time"
   bash tools/probe/plane_unet_tl.sh 24 bwd > /dev/null 2>&1; $K gpurun_out/plane_unet_tl_24bwd.txt gpurun_out/r06/r06_plane_unet_train_timeline.txt --must-contain "kernel time"
   tools/probe/barrier_probe > gpurun_out/r06_barrier_probe.txt 2>&1; $K gpurun_out/r06_barrier_probe.txt gpurun_out/r06/r06_barrier_probe.txt --must-contain "per barrier"
