@@ -881,6 +881,13 @@ int vt_plane_build(const float *pts, int B, int T, int R, double padding, int pl
 /* [n_planes][B][T], slice k = what vt_plane_build(plane = planes[k]) writes (the hand encoder builds all three per forward).            */
 int vt_plane_build_multi(const float *pts, int B, int T, int R, double padding, int n_planes, const int *planes,
                          int *idx, int *order, int *seg_lo, int *seg_hi, void *stream);
+/* generate_plane_features (pointnet.py:85-95) for those planes in one launch each way: planes / grad_planes [n_planes][B][C][R*R] (the      */
+/* layout of torch.cat over the planes' [B,C,R,R] tensors: what the hand encoder hands its U-Net), index arrays as above; the backward sums */
+/* the planes' shares per point in plane order.                                                                                              */
+int vt_plane_scatter_mean_multi_fwd(const float *feat, int n_planes, const int *idx, const int *order, const int *seg_lo, const int *seg_hi,
+                                    int B, int T, int C, int R, float *planes, void *stream);
+int vt_plane_scatter_mean_multi_bwd(const float *grad_planes, int n_planes, const int *idx, const int *seg_lo, const int *seg_hi,
+                                    int B, int T, int C, int R, float *grad_feat, void *stream);
 int vt_plane_scatter_mean_fwd(const float *feat, const int *idx, const int *order,
                               const int *seg_lo, const int *seg_hi,
                               int B, int T, int C, int R, float *plane, void *stream);

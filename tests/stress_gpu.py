@@ -299,6 +299,26 @@ def one_hand():
         fails.append(("plane pool_max", plane, B, T, R))
     if float((ops.plane_scatter_mean_fwd(feat.to(DEV), pi).cpu() - orc.scatter_mean_plane(feat, idx, R)).abs().max()) > 1e-5:
         fails.append(("plane scatter_mean", plane, B, T, R))
+    # the three planes in one launch (round 6): ids / order / bounds as the single builds, the summed pool and its backward against the oracle
+    planes3 = tuple(rng.permutation(["xz", "xy", "yz"])[:int(rng.randint(1, 4))])
+    many = ops.plane_indices(p.to(DEV), R, 0.1, planes3)
+    for pk, k in zip(many, planes3):
+        one = ops.PlaneIndex(p.to(DEV), R, 0.1, k)
+        if not all(torch.equal(getattr(pk, f), getattr(one, f)) for f in ("idx", "order", "seg_lo", "seg_hi")):
+            fails.append(("plane_indices", planes3, k, B, T, R))
+            return
+    if len(many) > 1:
+        fr = feat.clone().requires_grad_()
+        ref = sum(orc.segment_pool_max(fr, orc.plane_index(p, R, 0.1, k)) for k in planes3)
+        go = torch.randn(B, T, 32, generator=g)
+        ref.backward(go)
+        out, args = ops.voxel_pool_max_sum_fwd(feat.to(DEV), many)
+        if float((out.cpu() - ref.detach()).abs().max()) > 1e-6 * max(1.0, float(ref.detach().abs().max())):
+            fails.append(("pool_max_sum fwd", planes3, B, T, R))
+        gsum = ops.voxel_pool_max_sum_bwd(go.to(DEV), args, many).cpu()
+        # (ties between points of a cell: torch's scatter-based oracle may route to another of the equal maxima; random features have none)
+        if float((gsum - fr.grad).abs().max()) > 1e-5 * max(1.0, float(fr.grad.abs().max())):
+            fails.append(("pool_max_sum bwd", planes3, B, T, R, float((gsum - fr.grad).abs().max())))
     # PointNet MLP kernels against the nn.Module
     C1, C2 = int(rng.choice([8, 32, 64])), int(rng.choice([0, 32]))
     H, O = int(rng.choice([16, 32, 48])), int(rng.choice([16, 32, C1 + C2]))

@@ -93,6 +93,34 @@ def test_plane_indices_in_one_launch_equal_the_single_builds():
                 assert bool(((hi == p.shape[1]) | (torch.gather(ids, 1, hi.clamp(max=p.shape[1] - 1)) != ids)).all())
 
 
+def test_plane_scatter_means_in_one_launch():
+    """vt_plane_scatter_mean_multi_fwd / _bwd against the per-plane calls: the stacked planes are torch.cat of the three, the gradient
+    their sum in plane order -- the same bits; through the autograd Function as the hand encoder calls it."""
+    from vtaco_amd import ops
+    from vtaco_amd.encoder.pointnet import _ScatterMeanPlanes
+    a, _ = load_golden("g10_hand.npz")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(21)
+    for p in (T(a["p"]), 0.001 * torch.randn(2, 700, 3, generator=g), 0.5 * (torch.rand(3, 1237, 3, generator=g) - 0.5)):
+        p = p.to(dev)
+        B, N = p.shape[0], p.shape[1]
+        feat = torch.randn(B, N, 32, generator=g).to(dev)
+        for planes in (("xz", "xy", "yz"), ("yz", "xz")):
+            pis = ops.plane_indices(p, 32, 0.1, planes)
+            singles = [ops.PlaneIndex(p, 32, 0.1, k) for k in planes]
+            want = torch.cat([ops.plane_scatter_mean_fwd(feat, pi) for pi in singles], dim=0)
+            got = ops.plane_scatter_mean_multi_fwd(feat, pis)
+            assert torch.equal(got, want), (tuple(p.shape), planes)
+            go = torch.randn(want.shape, generator=g).to(dev)
+            gs = [ops.plane_scatter_mean_bwd(go[i * B:(i + 1) * B], pi, 32) for i, pi in enumerate(singles)]
+            ref_g = gs[0] + gs[1] if len(gs) == 2 else (gs[0] + gs[1]) + gs[2]
+            assert torch.equal(ops.plane_scatter_mean_multi_bwd(go, pis, 32), ref_g), (tuple(p.shape), planes)
+            f2 = feat.clone().requires_grad_()
+            _ScatterMeanPlanes.apply(f2, pis).backward(go)
+            assert torch.equal(f2.grad, ref_g)
+    assert ops._plane_group(singles) is None                        # separately built indices do not share a buffer: the per-plane path
+
+
 def test_multi_plane_entries_refuse_bad_arguments():
     """The C ABI's checks of the round-6 plane entries: unknown plane ids, more partitions than the kernels take, null tables."""
     import ctypes

@@ -201,6 +201,8 @@ SIGNATURES = {
     "vt_resblock_wgrad": (_I, [_VP, _I, _VP, _I, _I64, _VP, _VP, _VP, _I, _I, _VP, _SZ, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vt_plane_build": (_I, [_VP, _I, _I, _I, _D, _I, _VP, _VP, _VP, _VP, _VP]),
     "vt_plane_build_multi": (_I, [_VP, _I, _I, _I, _D, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "vt_plane_scatter_mean_multi_fwd": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
+    "vt_plane_scatter_mean_multi_bwd": (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "vt_plane_scatter_mean_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "vt_plane_scatter_mean_bwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "vt_plane_unet_supported": (_I, [_I, _I, _I, _I, _I, _I]),

@@ -716,6 +716,7 @@ __device__ __forceinline__ void pu_wgrad_body(const PuWg &w, const int block, fl
 // slice, i.e. half the chip's slots at best for ~15 us each, nineteen times; together they are ~4000 workgroups, the longest first.
 enum { PU_W_CONV = 0, PU_W_CONV_POOL, PU_W_CONV_NCHW, PU_W_CONVT, PU_W_HEAD };
 struct PuWgAll { int n; int first[PU_MAX_PHASES + 1]; unsigned char kind[PU_MAX_PHASES + 1]; PuWg w[PU_MAX_PHASES]; };
+static_assert(sizeof(PuWgAll) <= 4096, "the phase table travels as a kernel argument: 4 KB at most");
 
 __global__ void __launch_bounds__(256, 2) plane_unet_wgrad_kernel(PuWgAll all) {
     __shared__ float red[3 * 16 * 64];

@@ -537,7 +537,8 @@ pool_max_sum_bwd_kernel(const float *grad_out, PoolSets s, float *grad_feat, int
 template <bool CL>
 __global__ void __launch_bounds__(256)
 scatter_mean_fwd_kernel(const float *feat, const int *idx, const int *order, const int *seg_lo, const int *seg_hi,
-                        float *grid, int T, int C, size_t V, uint32_t npts, uint32_t small_blocks) {   // V = cells per channel
+                        float *grid, int T, int C, size_t V, uint32_t npts, uint32_t small_blocks, uint32_t feat_scenes = 0) {   // V = cells per channel
+    // feat_scenes: the index arrays hold several partitions of the SAME feat_scenes scenes one after the other (vt_plane_scatter_mean_multi_fwd)
     auto cell = [&](uint32_t b, int c, int id) -> size_t {
         return CL ? ((size_t)b * V + (size_t)id) * C + c : ((size_t)b * C + c) * V + (size_t)id;
     };
@@ -549,7 +550,7 @@ scatter_mean_fwd_kernel(const float *feat, const int *idx, const int *order, con
         const int lo = seg_lo[bt], hi = seg_hi[bt];
         const int *ord = order + (size_t)b * T;
         if (hi - lo > SEG_SMALL || ord[lo] != t) return;       // the cell's first point writes
-        const float *fb = feat + (size_t)b * T * C;
+        const float *fb = feat + (size_t)(feat_scenes ? b % feat_scenes : b) * T * C;
         for (int c = c0; c < C; c += 256) {
             float s = 0.0f;
             for (int j = lo; j < hi; ++j) s += fb[(size_t)ord[j] * C + c];
@@ -564,7 +565,7 @@ scatter_mean_fwd_kernel(const float *feat, const int *idx, const int *order, con
     const int *ord = order + (size_t)b * T;
     const int id = idx[(size_t)b * T + ord[lo]];
     for (int c = c0; c < C; c += 256) {
-        const float tot = block_segment_sum(feat + (size_t)b * T * C, ord, lo, hi, C, c, cl, G, grp, c0, red);
+        const float tot = block_segment_sum(feat + (size_t)(feat_scenes ? b % feat_scenes : b) * T * C, ord, lo, hi, C, c, cl, G, grp, c0, red);
         if (grp == 0) grid[cell(b, c, id)] = tot / (float)(hi - lo);
     }
 }
@@ -580,6 +581,24 @@ scatter_mean_bwd_kernel(const float *grad_grid, const int *idx, const int *seg_l
     for (int c = c0; c < C; c += 256) {
         const size_t g = CL ? ((size_t)b * V + (size_t)idx[bt]) * C + c : ((size_t)b * C + c) * V + (size_t)idx[bt];
         grad_feat[(size_t)bt * C + c] = grad_grid[g] * inv;
+    }
+}
+
+// the backward of n partitions' scatter-means of the same features: grad_feat[b][t][c] = sum_k grad_plane_k[b][c][cell_k(t)] / count_k, k in order
+__global__ void __launch_bounds__(256)
+scatter_mean_multi_bwd_kernel(const float *grad_planes, const int *idx, const int *seg_lo, const int *seg_hi, float *grad_feat,
+                              int T, int C, size_t V, uint32_t npts, int n) {
+    uint32_t bt; int c0;
+    if (!point_lane(C, npts, bt, c0)) return;
+    const uint32_t b = bt / (uint32_t)T, scenes = npts / (uint32_t)T;
+    for (int c = c0; c < C; c += 256) {
+        float sum = 0.0f;
+        for (int k = 0; k < n; ++k) {
+            const size_t kt = (size_t)k * npts + bt;
+            const float g = grad_planes[(((size_t)k * scenes + b) * C + c) * V + (size_t)idx[kt]] * (1.0f / (float)(seg_hi[kt] - seg_lo[kt]));
+            sum = k ? sum + g : g;
+        }
+        grad_feat[(size_t)bt * C + c] = sum;
     }
 }
 
@@ -745,6 +764,30 @@ int vt_plane_scatter_mean_fwd(const float *feat, const int *idx, const int *orde
     hipLaunchKernelGGL(scatter_mean_fwd_kernel<false>, dim3(sb + large_blocks(B, T)), dim3(256), 0, (hipStream_t)stream,
                        feat, idx, order, seg_lo, seg_hi, plane, T, C, V, (uint32_t)((size_t)B * T), sb);
     return vt_check(hipGetLastError(), "vt_plane_scatter_mean_fwd");
+}
+
+// n partitions of the same scenes (index arrays [n][B][T] as vt_plane_build_multi leaves them) in one launch each way: planes [n][B][C][R^2]
+int vt_plane_scatter_mean_multi_fwd(const float *feat, int n, const int *idx, const int *order, const int *seg_lo, const int *seg_hi,
+                                    int B, int T, int C, int R, float *planes, void *stream) {
+    if (!feat || !idx || !order || !seg_lo || !seg_hi || !planes) return vt_fail(VT_ERR_INVALID, "vt_plane_scatter_mean_multi_fwd: null argument");
+    if (n < 1 || n > 3 || B <= 0 || T <= 0 || C <= 0 || R < 1) return vt_fail(VT_ERR_INVALID, "vt_plane_scatter_mean_multi_fwd: bad size");
+    if ((unsigned long long)n * B * T > 0x7fffffffull) return vt_fail(VT_ERR_UNSUPPORTED, "vt_plane_scatter_mean_multi_fwd: more than 2^31 points per call");
+    const size_t V = (size_t)R * R;
+    const int frc = vt_fill32(planes, 0u, (size_t)n * B * C * V * sizeof(float), (hipStream_t)stream);
+    if (frc) return frc;
+    const unsigned sb = point_blocks(C, (size_t)n * B * T);
+    hipLaunchKernelGGL(scatter_mean_fwd_kernel<false>, dim3(sb + large_blocks(n * B, T)), dim3(256), 0, (hipStream_t)stream,
+                       feat, idx, order, seg_lo, seg_hi, planes, T, C, V, (uint32_t)((size_t)n * B * T), sb, (uint32_t)B);
+    return vt_check(hipGetLastError(), "vt_plane_scatter_mean_multi_fwd");
+}
+
+int vt_plane_scatter_mean_multi_bwd(const float *grad_planes, int n, const int *idx, const int *seg_lo, const int *seg_hi,
+                                    int B, int T, int C, int R, float *grad_feat, void *stream) {
+    if (!grad_planes || !idx || !seg_lo || !seg_hi || !grad_feat) return vt_fail(VT_ERR_INVALID, "vt_plane_scatter_mean_multi_bwd: null argument");
+    if (n < 1 || n > 3 || B <= 0 || T <= 0 || C <= 0 || R < 1) return vt_fail(VT_ERR_INVALID, "vt_plane_scatter_mean_multi_bwd: bad size");
+    hipLaunchKernelGGL(scatter_mean_multi_bwd_kernel, dim3(point_blocks(C, (size_t)B * T)), dim3(256), 0, (hipStream_t)stream,
+                       grad_planes, idx, seg_lo, seg_hi, grad_feat, T, C, (size_t)R * R, (uint32_t)((size_t)B * T), n);
+    return vt_check(hipGetLastError(), "vt_plane_scatter_mean_multi_bwd");
 }
 
 int vt_plane_scatter_mean_bwd(const float *grad_plane, const int *idx, const int *seg_lo, const int *seg_hi,

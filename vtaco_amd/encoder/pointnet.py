@@ -157,6 +157,20 @@ class _ScatterMeanPlane(torch.autograd.Function):
         return ops.plane_scatter_mean_bwd(grad, ctx.pi, ctx.C), None
 
 
+class _ScatterMeanPlanes(torch.autograd.Function):
+    """_ScatterMeanPlane for the planes of one ops.plane_indices call in one launch each way: [B,T,C] -> [n * B, C, R, R], the planes one
+    after the other (what torch.cat of the per-plane tensors gives, and what the U-Net takes)."""
+
+    @staticmethod
+    def forward(ctx, feat, pis):
+        ctx.pis, ctx.C = pis, feat.shape[2]
+        return ops.plane_scatter_mean_multi_fwd(feat, pis)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return ops.plane_scatter_mean_multi_bwd(grad, ctx.pis, ctx.C), None
+
+
 class LocalPoolPointnet(nn.Module):
     """Args as the reference (pointnet.py:32-35).  Built: scatter_type 'max' (the configs') and 'mean' with plane_type 'grid'
     (object encoder) or any of 'xz','xy','yz' (hand encoder; 'grid' and planes are not mixed)."""
@@ -324,12 +338,15 @@ class LocalPoolPointnet(nn.Module):
     def forward_planes(self, p):
         pis = ops.plane_indices(p, self.reso_plane, self.padding, self.planes)      # the planes' sorts in one launch
         feat = self.point_features(p.float(), pis)
-        planes = [_ScatterMeanPlane.apply(feat, pi) for pi in pis]
+        if len(pis) > 1 and ops._plane_group(pis) is not None:
+            stacked = _ScatterMeanPlanes.apply(feat, pis)           # the planes' scatter-means in one launch, already stacked
+        else:
+            stacked = torch.cat([_ScatterMeanPlane.apply(feat, pi) for pi in pis], dim=0)
         if self.unet is not None:
             # one U-Net pass over the planes stacked on the batch axis: the net has no cross-sample op
             # (no normalisation layers), so this equals the reference's per-plane calls with a third of the launches
-            planes = self.unet(torch.cat(planes, dim=0)).split(p.shape[0], dim=0)
-        return dict(zip(self.planes, planes))
+            stacked = self.unet(stacked)
+        return dict(zip(self.planes, stacked.split(p.shape[0], dim=0)))
 
     def forward(self, p):
         if not p.is_cuda:

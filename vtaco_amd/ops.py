@@ -847,8 +847,42 @@ def plane_indices(pts, reso, padding=0.1, planes=("xz", "xy", "yz")):
         pi = PlaneIndex.__new__(PlaneIndex)
         pi.B, pi.T, pi.R, pi.plane, pi.tile_flags = B, T, reso, k, None
         pi.idx, pi.order, pi.seg_lo, pi.seg_hi = buf[0, i], buf[1, i], buf[2, i], buf[3, i]
+        pi.group = (buf, i, n)                                      # the planes' arrays side by side: the *_multi entries take them whole
         out.append(pi)
     return out
+
+
+def _plane_group(pis):
+    """The shared [4, n, B, T] index buffer of ``pis`` if they are exactly the planes of one plane_indices call, in order; else None."""
+    g = getattr(pis[0], "group", None)
+    if g is None or g[2] != len(pis) or any(getattr(p, "group", (None,))[0] is not g[0] or p.group[1] != i for i, p in enumerate(pis)):
+        return None
+    return g[0]
+
+
+def plane_scatter_mean_multi_fwd(feat, pis):
+    """generate_plane_features for the planes of one plane_indices call in one launch (vt_plane_scatter_mean_multi_fwd): [n * B, C, R, R],
+    the planes one after the other (= torch.cat of the per-plane tensors)."""
+    buf = _plane_group(pis)
+    feat = _c(feat)
+    B, T, C = feat.shape
+    n, R = len(pis), pis[0].R
+    planes = torch.empty((n * B, C, R, R), dtype=torch.float32, device=feat.device)
+    check(_lib.load().vt_plane_scatter_mean_multi_fwd(dev_ptr(feat, "feat"), n, dev_ptr(buf[0], "idx", I32), dev_ptr(buf[1], "order", I32),
+                                                      dev_ptr(buf[2], "seg_lo", I32), dev_ptr(buf[3], "seg_hi", I32), B, T, C, R,
+                                                      dev_ptr(planes, "planes"), stream_ptr()), "vt_plane_scatter_mean_multi_fwd")
+    return planes
+
+
+def plane_scatter_mean_multi_bwd(grad_planes, pis, C):
+    buf = _plane_group(pis)
+    grad_planes = _c(grad_planes)
+    B, T, n, R = pis[0].B, pis[0].T, len(pis), pis[0].R
+    g = torch.empty((B, T, C), dtype=torch.float32, device=grad_planes.device)
+    check(_lib.load().vt_plane_scatter_mean_multi_bwd(dev_ptr(grad_planes, "grad_planes"), n, dev_ptr(buf[0], "idx", I32),
+                                                      dev_ptr(buf[2], "seg_lo", I32), dev_ptr(buf[3], "seg_hi", I32), B, T, C, R,
+                                                      dev_ptr(g, "grad_feat"), stream_ptr()), "vt_plane_scatter_mean_multi_bwd")
+    return g
 
 
 def plane_scatter_mean_fwd(feat, pi):
