@@ -118,7 +118,7 @@ def test_plane_scatter_means_in_one_launch():
             f2 = feat.clone().requires_grad_()
             _ScatterMeanPlanes.apply(f2, pis).backward(go)
             assert torch.equal(f2.grad, ref_g)
-    assert ops._plane_group(singles) is None                        # separately built indices do not share a buffer: the per-plane path
+    assert ops.plane_group(singles) is None                        # separately built indices do not share a buffer: the per-plane path
 
 
 def test_multi_plane_entries_refuse_bad_arguments():

@@ -338,7 +338,7 @@ class LocalPoolPointnet(nn.Module):
     def forward_planes(self, p):
         pis = ops.plane_indices(p, self.reso_plane, self.padding, self.planes)      # the planes' sorts in one launch
         feat = self.point_features(p.float(), pis)
-        if len(pis) > 1 and ops._plane_group(pis) is not None:
+        if len(pis) > 1 and ops.plane_group(pis) is not None:
             stacked = _ScatterMeanPlanes.apply(feat, pis)           # the planes' scatter-means in one launch, already stacked
         else:
             stacked = torch.cat([_ScatterMeanPlane.apply(feat, pi) for pi in pis], dim=0)

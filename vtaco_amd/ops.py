@@ -852,7 +852,7 @@ def plane_indices(pts, reso, padding=0.1, planes=("xz", "xy", "yz")):
     return out
 
 
-def _plane_group(pis):
+def plane_group(pis):
     """The shared [4, n, B, T] index buffer of ``pis`` if they are exactly the planes of one plane_indices call, in order; else None."""
     g = getattr(pis[0], "group", None)
     if g is None or g[2] != len(pis) or any(getattr(p, "group", (None,))[0] is not g[0] or p.group[1] != i for i, p in enumerate(pis)):
@@ -863,7 +863,7 @@ def _plane_group(pis):
 def plane_scatter_mean_multi_fwd(feat, pis):
     """generate_plane_features for the planes of one plane_indices call in one launch (vt_plane_scatter_mean_multi_fwd): [n * B, C, R, R],
     the planes one after the other (= torch.cat of the per-plane tensors)."""
-    buf = _plane_group(pis)
+    buf = plane_group(pis)
     feat = _c(feat)
     B, T, C = feat.shape
     n, R = len(pis), pis[0].R
@@ -875,7 +875,7 @@ def plane_scatter_mean_multi_fwd(feat, pis):
 
 
 def plane_scatter_mean_multi_bwd(grad_planes, pis, C):
-    buf = _plane_group(pis)
+    buf = plane_group(pis)
     grad_planes = _c(grad_planes)
     B, T, n, R = pis[0].B, pis[0].T, len(pis), pis[0].R
     g = torch.empty((B, T, C), dtype=torch.float32, device=grad_planes.device)
