@@ -578,6 +578,9 @@ def _route_stages(gen, model, data, nx, n=7):
         box["mesh"] = gen.extract_mesh(box["vals"].reshape(nx, nx, nx))
     res["stage_ms"] = {"encode_pointnet_unet3d": _median_ms(enc, n), "tactile_setup": _median_ms(setup, n),
                        "finger_ids_and_decode": _median_ms(lattice, n), "marching_cubes": _median_ms(mc, n)}
+    res["stage_note"] = ("stages timed ONE BY ONE; end_to_end_ms is the entry point itself, which replays the scene's independent encoders "
+                         "(shape, tactile features, hand) on three HIP streams at once (Generator3D._generate_tactile): it is less than the "
+                         "stages' sum")
     res["verts"], res["faces"] = int(box["mesh"].vertices.shape[0]), int(box["mesh"].faces.shape[0])
     return res, box
 

@@ -200,3 +200,43 @@ def test_chunks_without_tactile_features_skip_the_fuser_bit_for_bit():
             feat = torch.randn(3, n, 32, generator=g).to(DEV)
             z = adec.fuser(torch.zeros(3, n, 32, device=DEV), 1, feat, 1)
             assert float(z.abs().max()) == 0.0, n
+
+
+@pytest.mark.parametrize("variant", ["vtaco", "vtacoh"])
+def test_tactile_routes_with_overlapped_encoders_equal_the_sequential_ones(variant):
+    """generate_obj_mesh_wnf(with_img) replays the scene's independent encoders (shape, tactile features, hand) on three HIP streams at
+    once (Generator3D._generate_tactile); the mesh must be the one the sequential route (VTACO_SCENE_OVERLAP=0) gives, call after
+    call -- eager first calls, the capturing call and graph replays all included -- on the shipped model sections."""
+    import os
+    import numpy as np
+    from vtaco_amd.bench_util import build_tactile_scene
+    from vtaco_amd.conv_onet.generation import Generator3D
+    model, data, depth_origin = build_tactile_scene(torch.device(DEV), variant=variant)
+    kw = dict(device=torch.device(DEV), resolution0=16, padding=0.1, with_img=True, encode_t2d=variant == "vtaco", depth_origin=depth_origin)
+
+    def run(gen, n):
+        out = []
+        for _ in range(n):
+            np.random.seed(11)                                      # the t2d rule draws from numpy's global generator
+            m = gen.generate_obj_mesh_wnf(data)
+            out.append((m.vertices.clone(), m.faces.clone()))
+        return out
+    saved = os.environ.get("VTACO_SCENE_OVERLAP")
+    try:
+        os.environ["VTACO_SCENE_OVERLAP"] = "0"
+        ref = run(Generator3D(model, **kw), 2)
+        os.environ["VTACO_SCENE_OVERLAP"] = "1"
+        gen = Generator3D(model, **kw)
+        got = run(gen, 8)
+        assert getattr(gen, "_sides", None) is not None             # the side streams were used
+    finally:
+        if saved is None:
+            os.environ.pop("VTACO_SCENE_OVERLAP", None)
+        else:
+            os.environ["VTACO_SCENE_OVERLAP"] = saved
+    # (the tactile features come from MIOpen's Resnet18, whose sums move in the last bits from call to call -- sequential route included,
+    # tools/probe/overlap_diag.py -- so the vertices are compared to 1e-5; the faces and the vertex count exactly)
+    assert ref[0][0].shape[0] > 0
+    for v, f in ref[1:] + got:
+        assert v.shape == ref[0][0].shape and torch.equal(f, ref[0][1])
+        assert float((v - ref[0][0]).abs().max()) <= 1e-5

@@ -602,25 +602,52 @@ class Generator3D(object):
             self.depth_origin = src
         return np.asarray(src.cpu() if torch.is_tensor(src) else src, dtype=np.float64).reshape(-1)
 
-    def _tactile_setup(self, data):
-        """Finger features, anchors and assignment rule of the configured tactile branch (VTacO t2d or VTacOH)."""
-        return self._setup_vtaco_t2d(data) if self.encode_t2d else self._setup_vtacoh(data)
+    def _tactile_setup(self, data, sides=None):
+        """Finger features, anchors and assignment rule of the configured tactile branch (VTacO t2d or VTacOH).  ``sides``: two HIP
+        streams that take the branch's encoders (see _generate_tactile); None: everything on the current stream."""
+        return self._setup_vtaco_t2d(data, sides) if self.encode_t2d else self._setup_vtacoh(data, sides)
+
+    def _side_streams(self):
+        """Two side streams per generator for the tactile branch's encoders, or None where graphs / overlap are off
+        (VTACO_SCENE_OVERLAP=0: the three encoders one after the other on the caller's stream)."""
+        if os.environ.get("VTACO_SCENE_OVERLAP", "1") == "0" or not self._graphs_allowed():
+            return None
+        if getattr(self, "_sides", None) is None:
+            # (plain priority: with high-priority side streams the VTacOH route measured 3.59 against 3.71 ms, the t2d route 4.7 against
+            # 2.25 -- the shape encoder's convs then wait behind ~60 small launches)
+            prio = int(os.environ.get("VTACO_SCENE_SIDE_PRIORITY", "0"))
+            self._sides = (torch.cuda.Stream(device=self.device, priority=prio), torch.cuda.Stream(device=self.device, priority=prio))
+        return self._sides
 
     def _generate_tactile(self, data):
-        """generate_obj_mesh_tactile with the branch's own setup, the device work queued first: the shape encoder is replayed before
-        the setup's host side (contact clouds in numpy, 0.5 ms) starts, so that runs under the 0.7 ms of the encode."""
+        """generate_obj_mesh_tactile with the branch's own setup.  The scene's encoders do not depend on each other -- the shape
+        encoder (0.6 ms, the whole chip for its 64^3 convs), the tactile feature encoder (Resnet18 on five images: 1.2-1.3 ms of
+        launch-bound kernels on a few CUs) and, in the VTacOH branch, the hand encoder (0.44 ms) -- so their graphs are replayed on
+        three HIP streams at once and joined in front of the decode: 2.3 ms of encoders one after the other become the longest one.
+        The setup's host side (contact clouds in numpy, the fingertips' frame change) runs under them."""
         self._eval_mode()
         nx = self.resolution0 * 4
         inputs = data.get('inputs').to(self.device)
         if inputs.shape[0] != 1:
             raise VtError(f"generate_obj_mesh_wnf: one scene at a time (got a batch of {inputs.shape[0]})")
-        c = self._replay("encode_inputs", [inputs], self.model.encode_inputs)
-        setup = self._tactile_setup(data)
+        sides = self._side_streams()
+        if sides is not None:
+            cur = torch.cuda.current_stream(self.device)
+            for side in sides:                                      # (the side streams see everything queued so far: the inputs' uploads,
+                side.wait_stream(cur)                               #  the previous scene's reads of the graphs' static outputs)
+            pending = self._tactile_setup(data, sides)              # queues the tactile encoders; returns the host part still to do
+            c = self._replay("encode_inputs", [inputs], self.model.encode_inputs)
+            setup = pending()
+            for side in sides:
+                cur.wait_stream(side)
+        else:
+            c = self._replay("encode_inputs", [inputs], self.model.encode_inputs)
+            setup = self._tactile_setup(data)
         with torch.no_grad():
             values = self._eval_lattice_tactile(c, nx, setup)
         return self.extract_mesh(values.reshape(nx, nx, nx))
 
-    def _setup_vtaco_t2d(self, data):
+    def _setup_vtaco_t2d(self, data, sides=None):
         """The VTacO branch of generate_obj_mesh_wnf (generation.py:202-257): per finger whose touch succeeded, the contact cloud
         unprojected from the sample's depth image (as the reference: the dataset's depth, not the predicted one, and the dataset's
         camera poses), at most 128 points; every lattice point within 0.015 of a contact point takes that finger's tactile feature
@@ -634,18 +661,31 @@ class Generator3D(object):
             raise VtError(f"generate_obj_mesh_wnf: one scene at a time (got a batch of {inputs.shape[0]})")
         self._eval_mode()
         # [1,5,C]; the feature encoder (Resnet18 in eval mode: ~60 launch-bound MIOpen / ATen kernels) replayed as a graph
-        c_img = self._replay("encode_img", [data.get('inputs.img')], self.model.encode_img_inputs).clone()
+        c_img = self._replay_on(sides[0] if sides else None, "encode_img", [data.get('inputs.img')], self.model.encode_img_inputs)
         # (one scene's five images stay on the host: 0.5 ms of numpy that runs under the shape encoder's replay; the device kernels of
         # the training step -- vt_contact_scan / vt_contact_points, 40 images per step -- need the counts back on the host in between,
         # which would wait for that replay: measured 1.78 against 1.26 ms for this setup)
-        anchors, count = contact_clouds_from_depth(
-            data.get('inputs.depth')[0].float().cpu().numpy(), self._depth_origin(),
-            data.get('points.cam_pos').reshape(1, 5, 3)[0].cpu().numpy(), data.get('points.cam_rot').reshape(1, 5, 3)[0].cpu().numpy(),
-            data.get('inputs.pc_ply')[0].float().cpu().numpy(), data.get('inputs.touch_success')[0].cpu().numpy())
-        return {'feats': c_img[0], 'anchors': torch.from_numpy(anchors).float(), 'success': torch.from_numpy((count > 0).astype('uint8')),
-                'mode': 'within', 'radius': 0.015, 'count': torch.from_numpy(count).int()}
+        def host_part():
+            anchors, count = contact_clouds_from_depth(
+                data.get('inputs.depth')[0].float().cpu().numpy(), self._depth_origin(),
+                data.get('points.cam_pos').reshape(1, 5, 3)[0].cpu().numpy(), data.get('points.cam_rot').reshape(1, 5, 3)[0].cpu().numpy(),
+                data.get('inputs.pc_ply')[0].float().cpu().numpy(), data.get('inputs.touch_success')[0].cpu().numpy())
+            return {'feats': c_img[0], 'anchors': torch.from_numpy(anchors).float(), 'success': torch.from_numpy((count > 0).astype('uint8')),
+                    'mode': 'within', 'radius': 0.015, 'count': torch.from_numpy(count).int()}
+        return host_part if sides else host_part()
 
-    def _setup_vtacoh(self, data):
+    def _replay_on(self, stream, kind, tensors, run):
+        """A clone of ``_replay(kind, tensors, run)``'s result, queued on ``stream`` (None: the current one).  The clone is marked as
+        used by the caller's stream, which reads it behind its ``wait_stream``."""
+        if stream is None:
+            return self._replay(kind, tensors, run).clone()
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(stream):
+            out = self._replay(kind, tensors, run).clone()
+        out.record_stream(cur)
+        return out
+
+    def _setup_vtacoh(self, data, sides=None):
         """The VTacOH branch of generate_obj_mesh_wnf (generation.py:161-200): fingertips from the hand encoder's MANO joints
         in the object's frame (ground-truth wrist position and wrist Euler angles from the sample), every lattice point
         within 0.05 of its nearest fingertip takes that finger's tactile feature if its touch succeeded -- by finger id
@@ -658,13 +698,21 @@ class Generator3D(object):
         if inputs.shape[0] != 1:
             raise VtError(f"generate_obj_mesh_wnf: one scene at a time (got a batch of {inputs.shape[0]})")
         self._eval_mode()
-        c_hand = self._replay("encode_hand_inputs", [inputs], self.model.encode_hand_inputs)   # plane PointNet + 2-D U-Net + MANO as one graph
-        with torch.no_grad():
+        # the tactile features first (the longest of the scene's encoders), then the hand encoder: plane PointNet + 2-D U-Net + MANO as one graph
+        c_img = self._replay_on(sides[0] if sides else None, "encode_img", [data.get('inputs.img')], self.model.encode_img_inputs)    # [1,5,C]
+        hand_stream = sides[1] if sides else torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(hand_stream):
+            c_hand = self._replay("encode_hand_inputs", [inputs], self.model.encode_hand_inputs)
             if 'mano_joints' not in c_hand:
                 raise VtError("generate_obj_mesh_wnf(with_img): the hand encoder has no MANO layer (out_dim <= 30)")
-        c_img = self._replay("encode_img", [data.get('inputs.img')], self.model.encode_img_inputs).clone()    # [1,5,C]
-        tips = fingertips_in_object_frame(c_hand['mano_joints'].float().cpu().numpy(), data.get('points.mano').cpu().numpy()[:, :3],
-                                          data.get('points.wrist').cpu().numpy(), data.get('inputs.pc_ply').float().cpu().numpy())
-        anchors = torch.from_numpy(tips[0]).float().unsqueeze(1)                                   # [5,1,3]
-        return {'feats': c_img[0], 'anchors': anchors, 'success': data.get('inputs.touch_success')[0].to(torch.uint8),
-                'mode': 'nearest', 'radius': 0.05, 'count': torch.ones(5, dtype=torch.int32)}
+            joints_dev = c_hand['mano_joints'].float()
+
+        def host_part():
+            with torch.cuda.stream(hand_stream):                    # (the copy back waits for the hand encoder's stream only)
+                joints = joints_dev.cpu().numpy()
+            tips = fingertips_in_object_frame(joints, data.get('points.mano').cpu().numpy()[:, :3],
+                                              data.get('points.wrist').cpu().numpy(), data.get('inputs.pc_ply').float().cpu().numpy())
+            anchors = torch.from_numpy(tips[0]).float().unsqueeze(1)                               # [5,1,3]
+            return {'feats': c_img[0], 'anchors': anchors, 'success': data.get('inputs.touch_success')[0].to(torch.uint8),
+                    'mode': 'nearest', 'radius': 0.05, 'count': torch.ones(5, dtype=torch.int32)}
+        return host_part if sides else host_part()
