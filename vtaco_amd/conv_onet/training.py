@@ -226,6 +226,17 @@ class Trainer:
         return {'inputs': inputs, 'imgs': imgs, 'p_sample': p_sample_t, 'finger': torch.from_numpy(finger).to(dev), 'occ': occ_new,
                 'pred_depth': pred_depth, 'digit': c_hand_d['mano_param'], 'depths': depths, 'cam_info': cam_info}
 
+    def _side_stream(self):
+        """A side stream for the tactile feature encoder of the VTacO step, or None: VTACO_TRAIN_OVERLAP=0, a CPU device, or gradient
+        synchronisation in use (GradAllReduce's buckets mix both encoders' parameters and are launched from whichever hook fires last:
+        the multi-process path keeps the single stream it was verified on)."""
+        import os
+        if (os.environ.get("VTACO_TRAIN_OVERLAP", "1") == "0" or self.grad_sync is not None or torch.device(self.device).type != "cuda"):
+            return None
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
     def _t2d_losses(self, data, s, logits, depth_target):
         dev = self.device
         c_hand = self.model.encode_hand_inputs(s['inputs'])
@@ -244,10 +255,26 @@ class Trainer:
         scene's mesh ``vf_dict[name]`` -- vt_winding_number, the exact sum where the reference calls libigl's fast
         approximation.  With ``pretrained_t2d=False`` the depth and digit-pose losses of the t2d net are added (:887-891)."""
         s = self._t2d_samples(data, vf_dict, normalise_depth=False)
-        c_img = self.model.encode_img_inputs(s['imgs'])                                     # [B,5,C]
-        feat = torch.gather(c_img, 1, s['finger'].clamp(min=0).unsqueeze(-1).expand(-1, -1, c_img.shape[2]))
-        c_img_all = torch.where((s['finger'] >= 0).unsqueeze(-1), feat, torch.ones_like(feat))   # ones where there is no touch
-        c = self.model.encode_inputs(s['inputs'])
+
+        def tactile():
+            c_img = self.model.encode_img_inputs(s['imgs'])                                 # [B,5,C]
+            feat = torch.gather(c_img, 1, s['finger'].clamp(min=0).unsqueeze(-1).expand(-1, -1, c_img.shape[2]))
+            return torch.where((s['finger'] >= 0).unsqueeze(-1), feat, torch.ones_like(feat))    # ones where there is no touch
+        side = self._side_stream()
+        if side is not None:
+            # the tactile feature encoder (Resnet18 over the step's 5 B images: the framework's / MIOpen's kernels) and the shape encoder
+            # (this repository's kernels) do not depend on each other: the first on a side stream, forward AND backward (autograd runs a
+            # node's backward on its forward's stream and orders the streams where gradients cross), joined in front of the decoder
+            cur = torch.cuda.current_stream(self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                c_img_all = tactile()
+            c = self.model.encode_inputs(s['inputs'])
+            cur.wait_stream(side)
+            c_img_all.record_stream(cur)
+        else:
+            c_img_all = tactile()
+            c = self.model.encode_inputs(s['inputs'])
         logits = self.model.decode_img(s['p_sample'], c, c_img_all).logits
         d = s['depths']
         return self._t2d_losses(data, s, logits, None if self.pretrained_t2d else (d - d.min()) / (d.max() - d.min()))
