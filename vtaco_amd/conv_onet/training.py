@@ -55,16 +55,41 @@ class Trainer:
         p = data.get('points').to(self.device)
         occ = data.get('points.occ').to(self.device)
         inputs = data.get('inputs').to(self.device)
+        hand = self._hand_branch(inputs, data) if getattr(self.model, 'encoder_hand', None) is not None else None
         c = self.model.encode_inputs(inputs)
         logits = self.model.decode(p, c).logits
         loss = F.l1_loss(logits, occ)
-        if getattr(self.model, 'encoder_hand', None) is None:
+        if hand is None:
             zero = logits.new_zeros(())
             return loss, zero, zero
-        c_hand = self.model.encode_hand_inputs(inputs)
-        loss_mano = F.mse_loss(c_hand['mano_param'], data.get('points.mano').to(self.device).float())
-        loss_pc = F.mse_loss(c_hand['mano_verts'], data.get('points.pc_hand').to(self.device).float())
+        loss_mano, loss_pc = hand()
         return loss + loss_mano + loss_pc, loss_mano, loss_pc
+
+    def _hand_branch(self, inputs, data):
+        """The hand branch of a step -- plane PointNet, 2-D U-Net, MANO layer, loss_mano and loss_pc (training.py:476-489) -- queued NOW;
+        returns the function that hands over (loss_mano, loss_pc).  In a single process it runs on a side stream: ~120 small launches
+        forward and backward that do not depend on the shape branch and hide under its convolutions (autograd runs a node's backward on
+        its forward's stream)."""
+        dev = self.device
+
+        def run():
+            c_hand = self.model.encode_hand_inputs(inputs)
+            return (F.mse_loss(c_hand['mano_param'], data.get('points.mano').to(dev).float()),
+                    F.mse_loss(c_hand['mano_verts'], data.get('points.pc_hand').to(dev).float()))
+        side = self._side_stream(1)
+        if side is None:
+            return run
+        cur = torch.cuda.current_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            losses = run()
+
+        def join():
+            cur.wait_stream(side)
+            for t in losses:
+                t.record_stream(cur)
+            return losses
+        return join
 
     # -- VTacOH: tactile features concatenated to the points near a fingertip (training.py:502-626) -------------------
     def fingertips(self, mano_joints, mano_gt, wrist_euler, pc_ply):
@@ -226,22 +251,19 @@ class Trainer:
         return {'inputs': inputs, 'imgs': imgs, 'p_sample': p_sample_t, 'finger': torch.from_numpy(finger).to(dev), 'occ': occ_new,
                 'pred_depth': pred_depth, 'digit': c_hand_d['mano_param'], 'depths': depths, 'cam_info': cam_info}
 
-    def _side_stream(self):
-        """A side stream for the tactile feature encoder of the VTacO step, or None: VTACO_TRAIN_OVERLAP=0, a CPU device, or gradient
-        synchronisation in use (GradAllReduce's buckets mix both encoders' parameters and are launched from whichever hook fires last:
-        the multi-process path keeps the single stream it was verified on)."""
+    def _side_stream(self, which=0):
+        """Side stream 0 (the tactile feature encoder of the VTacO step) or 1 (the hand branch), or None: VTACO_TRAIN_OVERLAP=0, a CPU
+        device, or gradient synchronisation in use (GradAllReduce's buckets mix the encoders' parameters and are launched from
+        whichever hook fires last: the multi-process path keeps the single stream it was verified on)."""
         import os
         if (os.environ.get("VTACO_TRAIN_OVERLAP", "1") == "0" or self.grad_sync is not None or torch.device(self.device).type != "cuda"):
             return None
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        return self._side
+        if getattr(self, "_sides", None) is None:
+            self._sides = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+        return self._sides[which]
 
-    def _t2d_losses(self, data, s, logits, depth_target):
-        dev = self.device
-        c_hand = self.model.encode_hand_inputs(s['inputs'])
-        loss_mano = F.mse_loss(c_hand['mano_param'], data.get('points.mano').to(dev).float())
-        loss_pc = F.mse_loss(c_hand['mano_verts'], data.get('points.pc_hand').to(dev).float())
+    def _t2d_losses(self, data, s, logits, depth_target, hand=None):
+        loss_mano, loss_pc = (hand or self._hand_branch(s['inputs'], data))()
         loss = F.l1_loss(logits, s['occ']) + loss_mano + loss_pc
         if not self.pretrained_t2d:
             loss = loss + F.l1_loss(s['pred_depth'], depth_target) + F.mse_loss(s['digit'], s['cam_info'])
@@ -255,6 +277,7 @@ class Trainer:
         scene's mesh ``vf_dict[name]`` -- vt_winding_number, the exact sum where the reference calls libigl's fast
         approximation.  With ``pretrained_t2d=False`` the depth and digit-pose losses of the t2d net are added (:887-891)."""
         s = self._t2d_samples(data, vf_dict, normalise_depth=False)
+        hand = self._hand_branch(s['inputs'], data)
 
         def tactile():
             c_img = self.model.encode_img_inputs(s['imgs'])                                 # [B,5,C]
@@ -277,16 +300,17 @@ class Trainer:
             c = self.model.encode_inputs(s['inputs'])
         logits = self.model.decode_img(s['p_sample'], c, c_img_all).logits
         d = s['depths']
-        return self._t2d_losses(data, s, logits, None if self.pretrained_t2d else (d - d.min()) / (d.max() - d.min()))
+        return self._t2d_losses(data, s, logits, None if self.pretrained_t2d else (d - d.min()) / (d.max() - d.min()), hand)
 
     def compute_loss_t2d(self, data, vf_dict):
         """The VTacO step without tactile features (training.py:628-755): the same sample assembly decoded by the plain decoder.
         As in the reference this variant normalises the depth images to [0, 1] BEFORE looking for contact pixels (:643-644), so
         nearly every pixel counts as touched -- reproduced as is."""
         s = self._t2d_samples(data, vf_dict, normalise_depth=True)
+        hand = self._hand_branch(s['inputs'], data)
         c = self.model.encode_inputs(s['inputs'])
         logits = self.model.decode(s['p_sample'], c).logits
-        return self._t2d_losses(data, s, logits, s['depths'])
+        return self._t2d_losses(data, s, logits, s['depths'], hand)
 
     def compute_loss_contact(self, data):
         """(loss, loss_mano, loss_pc, loss_contact) with the decoder's contact head (training.py:896-948): L1 on the occupancy
