@@ -253,10 +253,11 @@ class Trainer:
 
     def _side_stream(self, which=0):
         """Side stream 0 (the tactile feature encoder of the VTacO step) or 1 (the hand branch), or None: VTACO_TRAIN_OVERLAP=0, a CPU
-        device, or gradient synchronisation in use (GradAllReduce's buckets mix the encoders' parameters and are launched from
+        device, or gradient synchronisation over more than one process (GradAllReduce's buckets mix the encoders' parameters and are launched from
         whichever hook fires last: the multi-process path keeps the single stream it was verified on)."""
         import os
-        if (os.environ.get("VTACO_TRAIN_OVERLAP", "1") == "0" or self.grad_sync is not None or torch.device(self.device).type != "cuda"):
+        syncing = self.grad_sync is not None and getattr(self.grad_sync, "_active", lambda: True)()    # (a sync object without peers is idle)
+        if os.environ.get("VTACO_TRAIN_OVERLAP", "1") == "0" or syncing or torch.device(self.device).type != "cuda":
             return None
         if getattr(self, "_sides", None) is None:
             self._sides = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
